@@ -1,0 +1,115 @@
+/*
+ * tc2li_hip.h -- C ABI of the MI355X (gfx950) implementation of TC2LI-SLAM's per-frame front end and
+ * local bundle adjustment.  Plain pointers and sizes only; every entry point names the reference call
+ * site it replaces (paths relative to the reference tree, SF/ = slam_framework/).
+ *
+ * Conventions
+ *   - return value: >= 0 success (often a count), < 0 a tc2li_status error.  tc2li_last_error() gives text.
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device memory on the current device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - there is no CPU fallback: every compute entry point fails with TC2LI_ERR_NO_DEVICE without a GPU.
+ */
+#ifndef TC2LI_HIP_H
+#define TC2LI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tc2li_status {
+    TC2LI_OK = 0,
+    TC2LI_ERR_INVALID = -2,    /* bad argument */
+    TC2LI_ERR_NO_DEVICE = -3,  /* no HIP device / HIP runtime failure at init */
+    TC2LI_ERR_HIP = -4,        /* a HIP call failed; see tc2li_last_error() */
+    TC2LI_ERR_CAPACITY = -5,   /* caller-provided buffer too small */
+    TC2LI_ERR_EMPTY = -1       /* empty image: the reference returns -1 (SF/src/ORBextractor.cc:1063-1064) */
+} tc2li_status;
+
+const char* tc2li_last_error(void);
+/* ABI version, bumped on any signature change. */
+int tc2li_abi_version(void);
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+int tc2li_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ORB extractor -- replaces TC2LI_SLAM::ORBextractor (SF/include/ORBextractor.h:46-121,
+ * SF/src/ORBextractor.cc:383-443 ctor, :1060-1141 operator()).  One handle per extractor object; the
+ * reference runs the left and right extractor concurrently from two threads (SF/src/Frame.cc:139-142),
+ * so handles are independent and re-entrant per handle.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Subset of cv::KeyPoint the reference reads (pt, size, angle, response, octave). */
+typedef struct tc2li_keypoint {
+    float x, y;      /* level-0 pixel coordinates (SF/src/ORBextractor.cc:1122-1124) */
+    float size;      /* 31 * scale[octave], truncated (:851,:861) */
+    float angle;     /* degrees, cv::fastAtan2 of the intensity centroid (:50-77) */
+    float response;  /* FAST score */
+    int32_t octave;
+} tc2li_keypoint;
+
+/* ORBextractor ctor arguments (SF/src/ORBextractor.cc:383-384; values from config/.../KITTI00-02.yaml:60-73). */
+typedef struct tc2li_orb_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+} tc2li_orb_params;
+
+typedef struct tc2li_orb tc2li_orb;
+
+/* Creates an extractor able to process up to `max_images` images of at most max_width x max_height per call. */
+int tc2li_orb_create(const tc2li_orb_params* params, int max_width, int max_height, int max_images, tc2li_orb** out);
+void tc2li_orb_destroy(tc2li_orb* orb);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea)  (SF/src/ORBextractor.cc:1060).
+ * One host image in; keypoints and N x 32 descriptor bytes out in the reference's order (level-major, mono
+ * indices ascending from the front, lapping-area keys descending from the back).  *n_keypoints receives N.
+ * Returns monoIndex like the reference, TC2LI_ERR_EMPTY (-1) for an empty image. */
+int tc2li_orb_extract(tc2li_orb* orb, const uint8_t* image, int width, int height, int stride,
+                      const int32_t lapping_area[2], tc2li_keypoint* keypoints, uint8_t* descriptors, int capacity,
+                      int32_t* n_keypoints);
+
+/* Batched form for images already resident in device memory: image i starts at dev_images + i*image_pitch_bytes,
+ * rows are `stride` bytes apart.  Results go to host arrays laid out [n_images][capacity].  mono_index may be NULL.
+ * The device images must stay valid until the handle's pyramids are no longer needed (level 0 is read in place). */
+int tc2li_orb_extract_batch(tc2li_orb* orb, const uint8_t* dev_images, int n_images, int width, int height, int stride,
+                            size_t image_pitch_bytes, const int32_t lapping_area[2], tc2li_keypoint* keypoints,
+                            uint8_t* descriptors, int capacity, int32_t* n_keypoints, int32_t* mono_index, void* stream);
+
+/* Accessors the reference reads off the extractor: GetLevels/GetScaleFactors/... (SF/include/ORBextractor.h:70-90)
+ * and mvImagePyramid (:92; used by Frame::ComputeStereoMatches, SF/src/Frame.cc:848,938,953). */
+int tc2li_orb_levels(const tc2li_orb* orb);
+int tc2li_orb_scale_factors(const tc2li_orb* orb, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+int tc2li_orb_features_per_level(const tc2li_orb* orb, int32_t* per_level);
+int tc2li_orb_level_size(const tc2li_orb* orb, int level, int* width, int* height);
+/* Copies pyramid level `level` of image `image_index` of the last call to host, tightly packed width*height. */
+int tc2li_orb_download_level(tc2li_orb* orb, int image_index, int level, uint8_t* dst);
+/* Same for the 7x7 Gaussian-blurred level the descriptors were sampled from (SF/src/ORBextractor.cc:1105-1106). */
+int tc2li_orb_download_blurred(tc2li_orb* orb, int image_index, int level, uint8_t* dst);
+/* FAST candidates of the last call before the quadtree (diagnostic; x, y in level pixels, response): returns count. */
+int tc2li_orb_download_candidates(tc2li_orb* orb, int image_index, int level, float* xyr, int capacity);
+
+/* Times of the last batch call in milliseconds.  Device stages are measured with HIP events on the stream each
+ * kernel is launched on: [0] pyramid (nlevels-1 resize launches), [1] FAST cells kernel, [2] candidate compaction
+ * kernel, [3] blur (nlevels launches), [4] orientation+descriptor kernel; host wall clock: [5] quadtree stage,
+ * [6] call entry to quadtree start (device stage 1 + candidate download), [7] whole call.
+ * With profiling enabled every kernel is issued on the caller's stream (no overlap of blur with FAST), so that
+ * [0]..[4] are clean per-stage durations. */
+int tc2li_orb_set_profiling(tc2li_orb* orb, int enabled);
+int tc2li_orb_last_timings(const tc2li_orb* orb, float ms[8]);
+
+/* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
+ * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
+ * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in
+ * the reference's output order and returns their number. */
+int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
+                                   float* out_xyr, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TC2LI_HIP_H */

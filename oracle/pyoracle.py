@@ -1,0 +1,144 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes access to the CPU oracle (oracle/liboracle.so).
+
+Allowed importers: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product package
+(tc2li-slam_amd/) must never import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.oracle_orb_create.restype = C.c_void_p
+        L.oracle_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.oracle_orb_destroy.argtypes = [C.c_void_p]
+        L.oracle_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.oracle_orb_extract_pair.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_orb_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_orb_blurred_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_orb_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_orb_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_orb_distribute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int]
+        L.oracle_fast_atan2.restype = C.c_float
+        L.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.oracle_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4")])
+
+
+def _kps_from_floats(a):
+    out = np.zeros(len(a), KP_DTYPE)
+    for i, name in enumerate(["x", "y", "size", "angle", "response"]):
+        out[name] = a[:, i]
+    out["octave"] = a[:, 5].astype(np.int32)
+    return out
+
+
+class OrbOracle:
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7):
+        self.nlevels = nlevels
+        self.cap = nfeatures + 4 * nlevels
+        self._h = C.c_void_p(lib().oracle_orb_create(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_orb_destroy(self._h)
+            self._h = None
+
+    def extract(self, image, lapping_area=(0, 0)):
+        image = np.ascontiguousarray(image, np.uint8)
+        if image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        k = np.zeros((self.cap, 6), np.float32)
+        d = np.zeros((self.cap, 32), np.uint8)
+        mono = C.c_int(0)
+        n = lib().oracle_orb_extract(self._h, image.ctypes.data, image.shape[1], image.shape[0], image.strides[0],
+                                     lapping_area[0], lapping_area[1], k.ctypes.data, d.ctypes.data, self.cap, C.byref(mono))
+        assert n >= 0, n
+        return mono.value, _kps_from_floats(k[:n]), d[:n].copy()
+
+    def level(self, level):
+        w, h = C.c_int(), C.c_int()
+        lib().oracle_orb_level_size(self._h, level, C.byref(w), C.byref(h))
+        out = np.empty((h.value, w.value), np.uint8)
+        lib().oracle_orb_level_copy(self._h, level, out.ctypes.data)
+        return out
+
+    def blurred(self, level):
+        w, h = C.c_int(), C.c_int()
+        lib().oracle_orb_level_size(self._h, level, C.byref(w), C.byref(h))
+        out = np.empty((h.value, w.value), np.uint8)
+        lib().oracle_orb_blurred_copy(self._h, level, out.ctypes.data)
+        return out
+
+    def candidates(self, level):
+        n = lib().oracle_orb_candidates(self._h, level, None, 0)
+        out = np.empty((max(n, 1), 3), np.float32)
+        n = lib().oracle_orb_candidates(self._h, level, out.ctypes.data, len(out))
+        return out[:n]
+
+    def tables(self):
+        s = np.empty(self.nlevels, np.float32)
+        p = np.empty(self.nlevels, np.int32)
+        u = np.empty(16, np.int32)
+        lib().oracle_orb_tables(self._h, s.ctypes.data, p.ctypes.data, u.ctypes.data)
+        return s, p, u
+
+    def distribute(self, xyr, min_x, max_x, min_y, max_y, n_target):
+        xyr = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+        out = np.empty((max(len(xyr), 1), 3), np.float32)
+        n = lib().oracle_orb_distribute(self._h, xyr.ctypes.data, len(xyr), min_x, max_x, min_y, max_y, n_target,
+                                        out.ctypes.data, len(out))
+        assert n >= 0
+        return out[:n].copy()
+
+
+def fast9_16(img, threshold, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((img.size, 3), np.float32)
+    n = lib().oracle_fast9_16(img.ctypes.data, img.strides[0], img.shape[1], img.shape[0], threshold, int(nms),
+                              out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def resize_linear(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().oracle_resize_linear(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data, dw, dh)
+    return out
+
+
+def gaussian_blur7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().oracle_gaussian_blur7(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data)
+    return out
+
+
+def fast_atan2(y, x):
+    return lib().oracle_fast_atan2(float(y), float(x))

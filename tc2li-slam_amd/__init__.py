@@ -1,0 +1,20 @@
+"""tc2li-slam_amd -- host-side mirror (ctypes) of the gfx950 C-ABI library ``libtc2li_hip.so``.
+
+The directory name carries a hyphen (it is fixed by the project layout), so import it through
+``tc2li_loader.load()`` at the repository root, which registers it as module ``tc2li_slam_amd``.
+
+Only plumbing lives here: every computation happens inside the shared library (hand-written HIP kernels plus
+the C++ host stages); there is no Python or CPU fallback -- without the built library, or without a GPU, the
+compute entry points raise.
+"""
+from .capi import (  # noqa: F401
+    LIB_PATH,
+    Tc2liError,
+    OrbParams,
+    OrbExtractor,
+    abi_version,
+    device_count,
+    distribute_quadtree_host,
+    exported_symbols,
+    lib,
+)

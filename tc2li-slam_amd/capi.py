@@ -1,0 +1,204 @@
+"""ctypes binding of include/tc2li_hip.h and thin classes that mirror the reference's C++ interface
+(``ORBextractor`` -> :class:`OrbExtractor`).  Mirrors names, argument meaning and error behaviour of
+SF/include/ORBextractor.h:46-121 so that the parity tests read like tests of the reference class."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtc2li_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tc2li_hip.h")
+
+_lib = None
+
+
+class Tc2liError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("tc2li error %d: %s" % (code, text))
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4")])
+
+
+def lib():
+    """Loads libtc2li_hip.so (built in-tree by ``__graft_entry__.build()``); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Tc2liError(-3, "native library %s not built (run __graft_entry__.build()); there is no fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.tc2li_last_error.restype = C.c_char_p
+    L.tc2li_orb_create.argtypes = [C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tc2li_orb_destroy.argtypes = [C.c_void_p]
+    L.tc2li_orb_destroy.restype = None
+    L.tc2li_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_void_p,
+                                    C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+    L.tc2li_orb_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                          C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
+    L.tc2li_orb_levels.argtypes = [C.c_void_p]
+    L.tc2li_orb_scale_factors.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    L.tc2li_orb_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+    L.tc2li_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.tc2li_orb_download_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.tc2li_orb_download_blurred.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.tc2li_orb_download_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.tc2li_orb_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+    L.tc2li_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.tc2li_host_distribute_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise Tc2liError(rc, lib().tc2li_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def abi_version():
+    return lib().tc2li_abi_version()
+
+
+def device_count():
+    return lib().tc2li_device_count()
+
+
+def exported_symbols():
+    """Names of the functions include/tc2li_hip.h declares (used by the CPU-side ABI test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tc2li_[a-z0-9_]+)\s*\(", text)))
+
+
+def distribute_quadtree_host(xyr, min_x, max_x, min_y, max_y, n_target):
+    xyr = np.ascontiguousarray(xyr, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((max(len(xyr), 1), 3), np.float32)
+    n = _check(lib().tc2li_host_distribute_quadtree(xyr.ctypes.data, len(xyr), min_x, max_x, min_y, max_y, n_target,
+                                                    out.ctypes.data, len(out)))
+    return out[:n].copy()
+
+
+class OrbExtractor:
+    """Mirror of ``TC2LI_SLAM::ORBextractor`` (SF/include/ORBextractor.h:46).
+
+    ``extract(image)`` is ``operator()``: returns ``(monoIndex, keypoints, descriptors)``; an empty image gives
+    ``(-1, [], [])`` like the reference (SF/src/ORBextractor.cc:1063-1064).
+    """
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7,
+                 max_width=1242, max_height=376, max_images=2):
+        self._h = C.c_void_p()
+        self.params = OrbParams(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast)
+        self.capacity = nfeatures + 4 * nlevels
+        self.max_images = max_images
+        _check(lib().tc2li_orb_create(C.byref(self.params), max_width, max_height, max_images, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().tc2li_orb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- accessors (ORBextractor.h:70-90) ----
+    def GetLevels(self):
+        return lib().tc2li_orb_levels(self._h)
+
+    def _scales(self):
+        n = self.GetLevels()
+        arrs = [np.empty(n, np.float32) for _ in range(4)]
+        _check(lib().tc2li_orb_scale_factors(self._h, *[a.ctypes.data for a in arrs]))
+        return arrs
+
+    def GetScaleFactors(self):
+        return self._scales()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._scales()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._scales()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._scales()[3]
+
+    def features_per_level(self):
+        a = np.empty(self.GetLevels(), np.int32)
+        _check(lib().tc2li_orb_features_per_level(self._h, a.ctypes.data))
+        return a
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().tc2li_orb_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    # ---- operator() ----
+    def extract(self, image, lapping_area=(0, 0)):
+        image = np.asarray(image)
+        kps = np.zeros(self.capacity, KEYPOINT_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int32(0)
+        lap = (C.c_int32 * 2)(*lapping_area)
+        if image.size == 0:
+            rc = lib().tc2li_orb_extract(self._h, None, 0, 0, 0, lap, kps.ctypes.data, desc.ctypes.data, self.capacity,
+                                         C.byref(n))
+            return rc, kps[:0], desc[:0]
+        assert image.dtype == np.uint8 and image.ndim == 2
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        rc = lib().tc2li_orb_extract(self._h, image.ctypes.data, image.shape[1], image.shape[0], image.strides[0], lap,
+                                     kps.ctypes.data, desc.ctypes.data, self.capacity, C.byref(n))
+        _check(rc)
+        return rc, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_dev(self, dev_ptr, n_images, width, height, stride, image_pitch, stream=0, lapping_area=(0, 0),
+                          out=None):
+        """Images resident in device memory (``dev_ptr`` = integer device address). Returns per-image arrays."""
+        if out is None:
+            out = (np.zeros((n_images, self.capacity), KEYPOINT_DTYPE), np.zeros((n_images, self.capacity, 32), np.uint8),
+                   np.zeros(n_images, np.int32), np.zeros(n_images, np.int32))
+        kps, desc, counts, mono = out
+        lap = (C.c_int32 * 2)(*lapping_area)
+        _check(lib().tc2li_orb_extract_batch(self._h, C.c_void_p(dev_ptr), n_images, width, height, stride, image_pitch,
+                                             lap, kps.ctypes.data, desc.ctypes.data, self.capacity, counts.ctypes.data,
+                                             mono.ctypes.data, C.c_void_p(stream)))
+        return kps, desc, counts, mono
+
+    # ---- mvImagePyramid and diagnostics ----
+    def pyramid_level(self, image_index, level):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        _check(lib().tc2li_orb_download_level(self._h, image_index, level, out.ctypes.data))
+        return out
+
+    def blurred_level(self, image_index, level):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        _check(lib().tc2li_orb_download_blurred(self._h, image_index, level, out.ctypes.data))
+        return out
+
+    def candidates(self, image_index, level):
+        n = _check(lib().tc2li_orb_download_candidates(self._h, image_index, level, None, 0))
+        out = np.empty((max(n, 1), 3), np.float32)
+        n = _check(lib().tc2li_orb_download_candidates(self._h, image_index, level, out.ctypes.data, len(out)))
+        return out[:n]
+
+    def set_profiling(self, enabled):
+        _check(lib().tc2li_orb_set_profiling(self._h, int(enabled)))
+
+    def last_timings(self):
+        t = np.zeros(8, np.float32)
+        _check(lib().tc2li_orb_last_timings(self._h, t.ctypes.data))
+        return t

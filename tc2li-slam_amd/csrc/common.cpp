@@ -1,0 +1,111 @@
+#include "common.hpp"
+
+#include <cstdlib>
+
+namespace tc2li {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+bool device_ready() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+
+WorkerPool::WorkerPool(int nthreads) {
+    for (int i = 0; i < nthreads - 1; ++i) workers_.emplace_back([this] { loop(); });
+}
+
+WorkerPool::~WorkerPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+        ++generation_;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+}
+
+void WorkerPool::loop() {
+    int seen = 0;
+    for (;;) {
+        const std::function<void(int)>* fn;
+        int n;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (stop_) return;
+            fn = fn_;
+            n = n_;
+            if (!fn) continue;  // woke after that generation had already been drained
+            ++active_;
+        }
+        for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            --active_;
+        }
+        done_cv_.notify_all();
+    }
+}
+
+void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    if (workers_.empty() || n == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        fn_ = &fn;
+        n_ = n;
+        next_.store(0);
+        ++generation_;
+    }
+    cv_.notify_all();
+    for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
+    // wait until every worker that picked this generation up has drained
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return active_ == 0 && next_.load() >= n; });
+    // workers that have not woken yet will find next_ >= n and do nothing with a still-valid n_
+    fn_ = nullptr;
+}
+
+WorkerPool& global_pool() {
+    static WorkerPool* pool = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        if (const char* s = getenv("TC2LI_HOST_THREADS")) n = atoi(s);
+        if (n < 1) n = 1;
+        if (n > 32) n = 32;
+        return new WorkerPool(n);
+    }();
+    return *pool;
+}
+
+}  // namespace tc2li
+
+extern "C" {
+const char* tc2li_last_error(void) { return tc2li::g_last_error.c_str(); }
+int tc2li_abi_version(void) { return 1; }
+int tc2li_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+}

@@ -1,0 +1,98 @@
+// Host-side helpers shared by the C-ABI translation units: error reporting, HIP call checking, a small
+// persistent worker pool for the sequential per-(image, level) host stages, RAII device/pinned buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tc2li_hip.h"
+
+namespace tc2li {
+
+void set_error(const char* fmt, ...);
+bool device_ready();  // true when a HIP device is usable; sets the error text otherwise
+
+#define TC2LI_HIP_CHECK(call)                                                                       \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            ::tc2li::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return TC2LI_ERR_HIP;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count + count / 4); }
+    hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+template <typename T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinnedBuf() {}
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    ~PinnedBuf() { release(); }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t ensure(size_t count) { return count <= n ? hipSuccess : alloc(count + count / 4); }
+};
+
+// Runs fn(i) for i in [0, n) on a fixed set of worker threads (the caller participates).
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads);
+    ~WorkerPool();
+    void parallel_for(int n, const std::function<void(int)>& fn);
+    int size() const { return (int)workers_.size() + 1; }
+
+private:
+    void loop();
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, generation_ = 0, active_ = 0;
+    bool stop_ = false;
+};
+
+WorkerPool& global_pool();
+
+}  // namespace tc2li

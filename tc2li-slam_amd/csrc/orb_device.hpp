@@ -1,0 +1,47 @@
+// Structures shared between the host orchestration and the gfx950 ORB kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tc2li {
+
+constexpr int kMaxLevels = 12;
+constexpr int kEdgeThreshold = 19;            // SF/src/ORBextractor.cc:47
+constexpr int kMinBorder = kEdgeThreshold - 3;  // minBorderX/Y, :763-764
+constexpr int kFastTilePitch = 80;            // >= widest cell window (wCell + 6 < 76)
+constexpr int kFastTileH = 76;
+constexpr int kMaxCellsPerLevel = 2048;
+
+// One pyramid level of a batch: image i starts at img + i*img_stride, rows are pitch bytes apart.
+struct LevelDesc {
+    const uint8_t* img;
+    size_t img_stride;
+    int pitch, w, h, pad_;
+};
+struct LevelTable { LevelDesc lv[kMaxLevels]; };
+
+// One FAST cell window of a level (identical for every image of the batch): SF/src/ORBextractor.cc:776-797.
+struct FastCell {
+    int16_t level, x0, y0, w, h, pad_;  // window origin/size in level pixels
+    int32_t slab_off, slab_cap;         // slot of this cell's candidates in the per-image slab
+};
+
+// A keypoint handed to the orientation/descriptor kernel: level pixel coordinates.
+struct DevKeypoint {
+    uint32_t packed;     // y << 20 | x << 8 | score
+    uint32_t img_level;  // image << 8 | level
+};
+
+void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
+                   const short* ibeta, int nimg, hipStream_t st);
+void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
+                 size_t slab_img_stride, int* cell_counts, int nimg, hipStream_t st);
+void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
+                    const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
+                    int* level_counts, int nlevels, int nimg, hipStream_t st);
+void launch_blur(const LevelDesc& src, const LevelDesc& dst, int nimg, hipStream_t st);
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const DevKeypoint* kps, int nkp,
+                            float* angles, uint8_t* desc, hipStream_t st);
+hipError_t upload_umax(const int* umax16);
+
+}  // namespace tc2li

@@ -1,0 +1,562 @@
+// Host orchestration of the gfx950 ORB extractor behind the C ABI of include/tc2li_hip.h.
+// Mirrors TC2LI_SLAM::ORBextractor (SF/src/ORBextractor.cc): ctor tables (:383-443), ComputePyramid (:1143),
+// ComputeKeyPointsOctTree (:755) and operator() (:1060).  The only stage kept on the host is the quadtree
+// distribution (:529-753), which is sequential and order-defining; it runs on the worker pool, one task per
+// (image, level), while the GPU blurs the levels on a second stream.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+#include "orb_device.hpp"
+#include "quadtree.hpp"
+
+using namespace tc2li;
+
+namespace {
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
+inline int cvCeilD(double v) { int i = (int)v; return i + (i < v); }
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct LevelGeom {
+    int w = 0, h = 0, pitch = 0;
+    size_t img_stride = 0;
+    int cell_begin = 0, cell_end = 0;
+    int dense_off = 0;  // offset of this level's region inside the per-image slab
+    int min_bx = 0, max_bx = 0, min_by = 0, max_by = 0;
+};
+
+}  // namespace
+
+struct tc2li_orb {
+    tc2li_orb_params prm{};
+    int max_w = 0, max_h = 0, max_images = 0;
+    // ctor tables (SF/src/ORBextractor.cc:388-442)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> features_per_level;
+    int umax[16];
+
+    // geometry of the current image size
+    int cur_w = 0, cur_h = 0;
+    std::vector<LevelGeom> geom;
+    std::vector<FastCell> cells;
+    int slab_per_image = 0;
+    int kp_cap_per_image = 0;
+
+    // device memory
+    DevBuf<uint8_t> d_level0;               // used by the host-image entry point
+    std::vector<DevBuf<uint8_t>> d_levels;  // [1..nlevels)
+    std::vector<DevBuf<uint8_t>> d_blur;    // [0..nlevels)
+    std::vector<DevBuf<int>> d_xofs, d_yofs;
+    std::vector<DevBuf<short>> d_ialpha, d_ibeta;
+    DevBuf<FastCell> d_cells;
+    DevBuf<int> d_level_cell_begin, d_level_dense_off, d_cell_counts, d_level_counts;
+    DevBuf<uint32_t> d_slab, d_dense;
+    DevBuf<DevKeypoint> d_kps;
+    DevBuf<float> d_angles;
+    DevBuf<uint8_t> d_desc;
+    // pinned host mirrors
+    PinnedBuf<int> h_level_counts;
+    PinnedBuf<uint32_t> h_dense;
+    PinnedBuf<DevKeypoint> h_kps;
+    PinnedBuf<float> h_angles;
+    PinnedBuf<uint8_t> h_desc;
+
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev[12] = {};
+    bool profiling = false;  // serialise all kernels on the caller's stream so that per-kernel event times are clean
+    LevelTable raw_tab{}, blur_tab{};
+    int last_nimg = 0;
+    std::vector<int> last_level_counts;  // [nimg][nlevels] candidates
+    std::vector<size_t> last_level_off;  // offsets into h_dense
+    float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<QuadtreeScratch> scratch;
+
+    ~tc2li_orb() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+    }
+};
+
+namespace {
+
+// cv::resize INTER_LINEAR coefficient tables (OpenCV imgproc resize(): 11-bit fixed point)
+void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<int>& xofs, std::vector<short>& ialpha,
+                         std::vector<int>& yofs, std::vector<short>& ibeta) {
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    auto sat = [](float v) { int r = cvRoundF(v); return (short)std::min(32767, std::max(-32768, r)); };
+    xofs.resize(dw); ialpha.resize(2 * dw); yofs.resize(dh); ibeta.resize(2 * dh);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cvFloorD(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat((1.f - fx) * 2048);
+        ialpha[2 * dx + 1] = sat(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cvFloorD(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[2 * dy] = sat((1.f - fy) * 2048);
+        ibeta[2 * dy + 1] = sat(fy * 2048);
+    }
+}
+
+int setup_geometry(tc2li_orb* o, int w, int h) {
+    if (o->cur_w == w && o->cur_h == h) return TC2LI_OK;
+    const int L = o->prm.nlevels, M = o->max_images;
+    o->geom.assign(L, LevelGeom());
+    o->cells.clear();
+    std::vector<int> level_cell_begin(L + 1, 0), level_dense_off(L, 0);
+    int slab = 0;
+    for (int l = 0; l < L; ++l) {
+        LevelGeom& g = o->geom[l];
+        g.w = cvRoundF((float)w * o->inv_scale[l]);   // SF/src/ORBextractor.cc:1148
+        g.h = cvRoundF((float)h * o->inv_scale[l]);
+        g.pitch = align_up(g.w, 64);
+        g.img_stride = (size_t)align_up(g.pitch * g.h, 256);
+        // cell grid, SF/src/ORBextractor.cc:763-797
+        g.min_bx = g.min_by = kMinBorder;
+        g.max_bx = g.w - kEdgeThreshold + 3;
+        g.max_by = g.h - kEdgeThreshold + 3;
+        g.cell_begin = (int)o->cells.size();
+        g.dense_off = slab;
+        const float width = (float)(g.max_bx - g.min_bx), height = (float)(g.max_by - g.min_by);
+        const int nCols = (int)(width / 35.f), nRows = (int)(height / 35.f);
+        if (nCols > 0 && nRows > 0 && g.w > 2 * kEdgeThreshold && g.h > 2 * kEdgeThreshold) {
+            const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+            for (int i = 0; i < nRows; ++i) {
+                const float iniY = (float)(g.min_by + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= g.max_by - 3) continue;
+                if (maxY > g.max_by) maxY = (float)g.max_by;
+                for (int j = 0; j < nCols; ++j) {
+                    const float iniX = (float)(g.min_bx + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= g.max_bx - 6) continue;
+                    if (maxX > g.max_bx) maxX = (float)g.max_bx;
+                    FastCell c{};
+                    c.level = (int16_t)l;
+                    c.x0 = (int16_t)iniX; c.y0 = (int16_t)iniY;
+                    c.w = (int16_t)((int)maxX - (int)iniX); c.h = (int16_t)((int)maxY - (int)iniY);
+                    if (c.w > kFastTilePitch || c.h > kFastTileH) {
+                        set_error("FAST cell window %dx%d exceeds the kernel tile", c.w, c.h);
+                        return TC2LI_ERR_INVALID;
+                    }
+                    const int ew = std::max(c.w - 6, 0), eh = std::max(c.h - 6, 0);
+                    c.slab_off = slab;
+                    c.slab_cap = ((ew + 1) / 2) * ((eh + 1) / 2);  // 3x3 strict maxima: at most one per 2x2 block
+                    slab += c.slab_cap;
+                    o->cells.push_back(c);
+                }
+            }
+        }
+        g.cell_end = (int)o->cells.size();
+        if (g.cell_end - g.cell_begin >= kMaxCellsPerLevel) {
+            set_error("too many FAST cells on level %d", l);
+            return TC2LI_ERR_INVALID;
+        }
+        level_cell_begin[l] = g.cell_begin;
+        level_dense_off[l] = g.dense_off;
+        if (g.w >= 4096 + kMinBorder || g.h >= 4096 + kMinBorder) {
+            set_error("image too large for the 12-bit candidate packing");
+            return TC2LI_ERR_INVALID;
+        }
+    }
+    level_cell_begin[L] = (int)o->cells.size();
+    o->slab_per_image = align_up(std::max(slab, 1), 64);
+    o->kp_cap_per_image = o->prm.nfeatures + 4 * L;
+    for (int l = 0; l < L; ++l) o->kp_cap_per_image += 0;
+
+    // device allocations
+    TC2LI_HIP_CHECK(o->d_level0.alloc((size_t)M * o->geom[0].img_stride));
+    for (int l = 0; l < L; ++l) {
+        if (l > 0) TC2LI_HIP_CHECK(o->d_levels[l].alloc((size_t)M * o->geom[l].img_stride));
+        TC2LI_HIP_CHECK(o->d_blur[l].alloc((size_t)M * o->geom[l].img_stride));
+        if (l > 0) {
+            std::vector<int> xofs, yofs;
+            std::vector<short> ia, ib;
+            build_resize_tables(o->geom[l - 1].w, o->geom[l - 1].h, o->geom[l].w, o->geom[l].h, xofs, ia, yofs, ib);
+            TC2LI_HIP_CHECK(o->d_xofs[l].upload(xofs));
+            TC2LI_HIP_CHECK(o->d_yofs[l].upload(yofs));
+            TC2LI_HIP_CHECK(o->d_ialpha[l].upload(ia));
+            TC2LI_HIP_CHECK(o->d_ibeta[l].upload(ib));
+        }
+    }
+    TC2LI_HIP_CHECK(o->d_cells.upload(o->cells));
+    TC2LI_HIP_CHECK(o->d_level_cell_begin.upload(level_cell_begin));
+    TC2LI_HIP_CHECK(o->d_level_dense_off.upload(level_dense_off));
+    TC2LI_HIP_CHECK(o->d_cell_counts.alloc((size_t)M * std::max<size_t>(o->cells.size(), 1)));
+    TC2LI_HIP_CHECK(o->d_level_counts.alloc((size_t)M * L));
+    TC2LI_HIP_CHECK(o->d_slab.alloc((size_t)M * o->slab_per_image));
+    TC2LI_HIP_CHECK(o->d_dense.alloc((size_t)M * o->slab_per_image));
+    TC2LI_HIP_CHECK(o->d_kps.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->d_angles.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->d_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
+    TC2LI_HIP_CHECK(o->h_level_counts.alloc((size_t)M * L));
+    TC2LI_HIP_CHECK(o->h_kps.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->h_angles.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->h_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
+    o->cur_w = w;
+    o->cur_h = h;
+    return TC2LI_OK;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return -1.f; }
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, int max_images, tc2li_orb** out) {
+    if (!p || !out || max_width <= 0 || max_height <= 0 || max_images <= 0 || p->nlevels < 1 ||
+        p->nlevels > kMaxLevels || p->nfeatures < 1 || !(p->scale_factor > 1.f)) {
+        set_error("tc2li_orb_create: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    std::unique_ptr<tc2li_orb> o(new tc2li_orb());
+    o->prm = *p;
+    o->max_w = max_width; o->max_h = max_height; o->max_images = max_images;
+    const int L = p->nlevels;
+    // SF/src/ORBextractor.cc:388-419; the member scaleFactor is a double holding the float argument
+    const double scaleFactor = (double)p->scale_factor;
+    o->scale.resize(L); o->sigma2.resize(L); o->inv_scale.resize(L); o->inv_sigma2.resize(L);
+    o->scale[0] = 1.0f; o->sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        o->scale[i] = (float)(o->scale[i - 1] * scaleFactor);
+        o->sigma2[i] = o->scale[i] * o->scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        o->inv_scale[i] = 1.0f / o->scale[i];
+        o->inv_sigma2[i] = 1.0f / o->sigma2[i];
+    }
+    o->features_per_level.resize(L);
+    const float factor = (float)(1.0f / scaleFactor);
+    float desired = p->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        o->features_per_level[l] = cvRoundF(desired);
+        sum += o->features_per_level[l];
+        desired *= factor;
+    }
+    o->features_per_level[L - 1] = std::max(p->nfeatures - sum, 0);
+    // umax, :427-442
+    {
+        const int HP = 15;
+        int v, v0, vmax = cvFloorD(HP * sqrt(2.f) / 2 + 1), vmin = cvCeilD(HP * sqrt(2.f) / 2);
+        const double hp2 = HP * HP;
+        for (v = 0; v <= vmax; ++v) o->umax[v] = cvRoundD(sqrt(hp2 - v * v));
+        for (v = HP, v0 = 0; v >= vmin; --v) {
+            while (o->umax[v0] == o->umax[v0 + 1]) ++v0;
+            o->umax[v] = v0;
+            ++v0;
+        }
+    }
+    TC2LI_HIP_CHECK(upload_umax(o->umax));
+    o->d_levels.resize(L); o->d_blur.resize(L);
+    o->d_xofs.resize(L); o->d_yofs.resize(L); o->d_ialpha.resize(L); o->d_ibeta.resize(L);
+    TC2LI_HIP_CHECK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
+    for (auto& e : o->ev) TC2LI_HIP_CHECK(hipEventCreate(&e));
+    int rc = setup_geometry(o.get(), max_width, max_height);
+    if (rc != TC2LI_OK) return rc;
+    *out = o.release();
+    return TC2LI_OK;
+}
+
+void tc2li_orb_destroy(tc2li_orb* orb) { delete orb; }
+
+int tc2li_orb_levels(const tc2li_orb* o) { return o ? o->prm.nlevels : TC2LI_ERR_INVALID; }
+
+int tc2li_orb_scale_factors(const tc2li_orb* o, float* s, float* is, float* s2, float* is2) {
+    if (!o) return TC2LI_ERR_INVALID;
+    const size_t n = o->scale.size() * sizeof(float);
+    if (s) memcpy(s, o->scale.data(), n);
+    if (is) memcpy(is, o->inv_scale.data(), n);
+    if (s2) memcpy(s2, o->sigma2.data(), n);
+    if (is2) memcpy(is2, o->inv_sigma2.data(), n);
+    return o->prm.nlevels;
+}
+
+int tc2li_orb_features_per_level(const tc2li_orb* o, int32_t* per_level) {
+    if (!o || !per_level) return TC2LI_ERR_INVALID;
+    memcpy(per_level, o->features_per_level.data(), o->features_per_level.size() * sizeof(int32_t));
+    return o->prm.nlevels;
+}
+
+int tc2li_orb_level_size(const tc2li_orb* o, int level, int* w, int* h) {
+    if (!o || level < 0 || level >= o->prm.nlevels) return TC2LI_ERR_INVALID;
+    if (w) *w = o->geom[level].w;
+    if (h) *h = o->geom[level].h;
+    return TC2LI_OK;
+}
+
+int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_images, int width, int height, int stride,
+                            size_t image_pitch_bytes, const int32_t lapping_area[2], tc2li_keypoint* keypoints,
+                            uint8_t* descriptors, int capacity, int32_t* n_keypoints, int32_t* mono_index,
+                            void* stream_) {
+    if (!o || !keypoints || !descriptors || !n_keypoints || !lapping_area || capacity < 0 || n_images < 0) {
+        set_error("tc2li_orb_extract_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_images == 0) return 0;
+    if (width <= 0 || height <= 0 || !dev_images) {
+        for (int i = 0; i < n_images; ++i) { n_keypoints[i] = 0; if (mono_index) mono_index[i] = -1; }
+        return TC2LI_ERR_EMPTY;  // SF/src/ORBextractor.cc:1063-1064
+    }
+    if (n_images > o->max_images || width > o->max_w || height > o->max_h || stride < width) {
+        set_error("tc2li_orb_extract_batch: %d images of %dx%d (stride %d) exceed the handle (%d of %dx%d)", n_images,
+                  width, height, stride, o->max_images, o->max_w, o->max_h);
+        return TC2LI_ERR_INVALID;
+    }
+    int rc = setup_geometry(o, width, height);
+    if (rc != TC2LI_OK) return rc;
+    hipStream_t st = (hipStream_t)stream_;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const int L = o->prm.nlevels, M = n_images;
+    const int ncells = (int)o->cells.size();
+
+    LevelTable& raw = o->raw_tab;
+    LevelTable& blur = o->blur_tab;
+    for (int l = 0; l < L; ++l) {
+        const LevelGeom& g = o->geom[l];
+        raw.lv[l] = LevelDesc{l == 0 ? dev_images : o->d_levels[l].p, l == 0 ? image_pitch_bytes : g.img_stride,
+                              l == 0 ? stride : g.pitch, g.w, g.h, 0};
+        blur.lv[l] = LevelDesc{o->d_blur[l].p, g.img_stride, g.pitch, g.w, g.h, 0};
+    }
+    o->last_nimg = M;
+
+    // ---- stage 1: pyramid, FAST, compaction (main stream); blur (side stream, or main stream when profiling) ---
+    hipStream_t blur_st = o->profiling ? st : o->side_stream;
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[0], st));
+    for (int l = 1; l < L; ++l)
+        launch_resize(raw.lv[l - 1], raw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, M, st);
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[1], st));
+    if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, o->ev[1], 0));
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[4], blur_st));
+    for (int l = 0; l < L; ++l) launch_blur(raw.lv[l], blur.lv[l], M, blur_st);
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[5], blur_st));
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[8], st));
+    if (ncells > 0) {
+        launch_fast(raw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p,
+                    (size_t)o->slab_per_image, o->d_cell_counts.p, M, st);
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
+        launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p, ncells, o->d_slab.p,
+                       (size_t)o->slab_per_image, o->d_dense.p, o->d_level_dense_off.p, o->d_level_counts.p, L, M, st);
+    } else {
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
+        TC2LI_HIP_CHECK(hipMemsetAsync(o->d_level_counts.p, 0, (size_t)M * L * sizeof(int), st));
+    }
+    TC2LI_HIP_CHECK(hipEventRecord(o->ev[2], st));
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_level_counts.p, o->d_level_counts.p, (size_t)M * L * sizeof(int),
+                                   hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+
+    // candidates of every (image, level) to the host
+    o->last_level_counts.assign(o->h_level_counts.p, o->h_level_counts.p + (size_t)M * L);
+    o->last_level_off.assign((size_t)M * L + 1, 0);
+    size_t total = 0;
+    for (int i = 0; i < M * L; ++i) { o->last_level_off[i] = total; total += (size_t)o->last_level_counts[i]; }
+    o->last_level_off[(size_t)M * L] = total;
+    TC2LI_HIP_CHECK(o->h_dense.ensure(std::max<size_t>(total, 1)));
+    for (int i = 0; i < M; ++i)
+        for (int l = 0; l < L; ++l) {
+            const int n = o->last_level_counts[i * L + l];
+            if (n > 0)
+                TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_dense.p + o->last_level_off[i * L + l],
+                                               o->d_dense.p + (size_t)i * o->slab_per_image + o->geom[l].dense_off,
+                                               (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        }
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+
+    // ---- stage 2 (host): quadtree distribution per (image, level) ------------------------------------------
+    const auto t0 = std::chrono::steady_clock::now();
+    WorkerPool& pool = global_pool();
+    if ((int)o->scratch.size() < M * L) o->scratch.resize((size_t)M * L);
+    std::vector<std::vector<int32_t>> picked((size_t)M * L);
+    pool.parallel_for(M * L, [&](int task) {
+        const int l = task % L;
+        const LevelGeom& g = o->geom[l];
+        picked[task].clear();
+        distribute_quadtree(o->h_dense.p + o->last_level_off[task], o->last_level_counts[task], g.min_bx, g.max_bx,
+                            g.min_by, g.max_by, o->features_per_level[l], o->scratch[task], picked[task]);
+    });
+    std::vector<int> img_kp_off(M + 1, 0);
+    for (int i = 0; i < M; ++i) {
+        int n = 0;
+        for (int l = 0; l < L; ++l) n += (int)picked[i * L + l].size();
+        if (n > o->kp_cap_per_image) { set_error("keypoint capacity exceeded"); return TC2LI_ERR_CAPACITY; }
+        img_kp_off[i + 1] = img_kp_off[i] + n;
+    }
+    const int nkp_total = img_kp_off[M];
+    for (int i = 0; i < M; ++i) {
+        DevKeypoint* dst = o->h_kps.p + img_kp_off[i];
+        for (int l = 0; l < L; ++l) {
+            const uint32_t* cand = o->h_dense.p + o->last_level_off[i * L + l];
+            for (int32_t k : picked[i * L + l]) {
+                const uint32_t c = cand[k];
+                const uint32_t x = ((c >> 8) & 0xfff) + kMinBorder, y = (c >> 20) + kMinBorder;  // :856-857
+                *dst++ = DevKeypoint{(y << 20) | (x << 8) | (c & 0xff), ((uint32_t)i << 8) | (uint32_t)l};
+            }
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+
+    // ---- stage 3: orientation + descriptors ---------------------------------------------------------------
+    if (nkp_total > 0) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(o->d_kps.p, o->h_kps.p, (size_t)nkp_total * sizeof(DevKeypoint),
+                                       hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
+        launch_orient_describe(raw, blur, o->d_kps.p, nkp_total, o->d_angles.p, o->d_desc.p, st);
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_angles.p, o->d_angles.p, (size_t)nkp_total * sizeof(float),
+                                       hipMemcpyDeviceToHost, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_desc.p, o->d_desc.p, (size_t)nkp_total * 32, hipMemcpyDeviceToHost, st));
+    } else {
+        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
+        TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
+    }
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+
+    // ---- assemble in the reference's output order (SF/src/ORBextractor.cc:1093-1137) -----------------------
+    int status = TC2LI_OK;
+    for (int i = 0; i < M; ++i) {
+        const int n = img_kp_off[i + 1] - img_kp_off[i];
+        n_keypoints[i] = n;
+        if (n > capacity) { status = TC2LI_ERR_CAPACITY; if (mono_index) mono_index[i] = -1; continue; }
+        tc2li_keypoint* kout = keypoints + (size_t)i * capacity;
+        uint8_t* dout = descriptors + (size_t)i * capacity * 32;
+        int mono = 0, stereo = n - 1;
+        for (int k = 0; k < n; ++k) {
+            const int g = img_kp_off[i] + k;
+            const DevKeypoint& dk = o->h_kps.p[g];
+            const int l = dk.img_level & 0xff;
+            tc2li_keypoint kp;
+            kp.x = (float)((dk.packed >> 8) & 0xfff);
+            kp.y = (float)(dk.packed >> 20);
+            kp.response = (float)(dk.packed & 0xff);
+            kp.octave = l;
+            kp.size = (float)(int)(31 * o->scale[l]);  // scaledPatchSize, :851
+            kp.angle = o->h_angles.p[g];
+            if (l != 0) { kp.x *= o->scale[l]; kp.y *= o->scale[l]; }
+            int dsti;
+            if (kp.x >= lapping_area[0] && kp.x <= lapping_area[1]) dsti = stereo--;
+            else dsti = mono++;
+            kout[dsti] = kp;
+            memcpy(dout + (size_t)dsti * 32, o->h_desc.p + (size_t)g * 32, 32);
+        }
+        if (mono_index) mono_index[i] = mono;
+    }
+    o->timings[0] = elapsed(o->ev[0], o->ev[1]);
+    o->timings[1] = elapsed(o->ev[8], o->ev[3]);
+    o->timings[2] = elapsed(o->ev[3], o->ev[2]);
+    o->timings[3] = elapsed(o->ev[4], o->ev[5]);
+    o->timings[4] = elapsed(o->ev[6], o->ev[7]);
+    o->timings[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    o->timings[6] = std::chrono::duration<float, std::milli>(t0 - t_begin).count();
+    o->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (status != TC2LI_OK) { set_error("keypoint capacity %d too small", capacity); return status; }
+    return n_images;
+}
+
+int tc2li_orb_extract(tc2li_orb* o, const uint8_t* image, int width, int height, int stride,
+                      const int32_t lapping_area[2], tc2li_keypoint* keypoints, uint8_t* descriptors, int capacity,
+                      int32_t* n_keypoints) {
+    if (!o || !n_keypoints) { set_error("tc2li_orb_extract: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (!image || width <= 0 || height <= 0) { *n_keypoints = 0; return TC2LI_ERR_EMPTY; }
+    if (width > o->max_w || height > o->max_h || stride < width) {
+        set_error("tc2li_orb_extract: image %dx%d exceeds the handle", width, height);
+        return TC2LI_ERR_INVALID;
+    }
+    int rc = setup_geometry(o, width, height);
+    if (rc != TC2LI_OK) return rc;
+    const LevelGeom& g = o->geom[0];
+    TC2LI_HIP_CHECK(hipMemcpy2D(o->d_level0.p, g.pitch, image, stride, width, height, hipMemcpyHostToDevice));
+    int32_t mono = -1;
+    rc = tc2li_orb_extract_batch(o, o->d_level0.p, 1, width, height, g.pitch, g.img_stride, lapping_area, keypoints,
+                                 descriptors, capacity, n_keypoints, &mono, nullptr);
+    if (rc < 0) return rc;
+    return mono;
+}
+
+static int download_plane(const LevelDesc& d, int image_index, uint8_t* dst) {
+    TC2LI_HIP_CHECK(hipMemcpy2D(dst, d.w, d.img + (size_t)image_index * d.img_stride, d.pitch, d.w, d.h,
+                                hipMemcpyDeviceToHost));
+    return TC2LI_OK;
+}
+
+int tc2li_orb_download_level(tc2li_orb* o, int image_index, int level, uint8_t* dst) {
+    if (!o || !dst || level < 0 || level >= o->prm.nlevels || image_index < 0 || image_index >= o->last_nimg)
+        return TC2LI_ERR_INVALID;
+    return download_plane(o->raw_tab.lv[level], image_index, dst);
+}
+
+int tc2li_orb_download_blurred(tc2li_orb* o, int image_index, int level, uint8_t* dst) {
+    if (!o || !dst || level < 0 || level >= o->prm.nlevels || image_index < 0 || image_index >= o->last_nimg)
+        return TC2LI_ERR_INVALID;
+    return download_plane(o->blur_tab.lv[level], image_index, dst);
+}
+
+int tc2li_orb_download_candidates(tc2li_orb* o, int image_index, int level, float* xyr, int capacity) {
+    if (!o || level < 0 || level >= o->prm.nlevels || image_index < 0 || image_index >= o->last_nimg)
+        return TC2LI_ERR_INVALID;
+    const int L = o->prm.nlevels;
+    const int n = o->last_level_counts[image_index * L + level];
+    if (!xyr) return n;
+    if (n > capacity) return TC2LI_ERR_CAPACITY;
+    const uint32_t* c = o->h_dense.p + o->last_level_off[image_index * L + level];
+    for (int k = 0; k < n; ++k) {
+        xyr[3 * k] = (float)(((c[k] >> 8) & 0xfff) + kMinBorder);
+        xyr[3 * k + 1] = (float)((c[k] >> 20) + kMinBorder);
+        xyr[3 * k + 2] = (float)(c[k] & 0xff);
+    }
+    return n;
+}
+
+int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
+                                   float* out_xyr, int capacity) {
+    if (!xyr || !out_xyr || n < 0) return TC2LI_ERR_INVALID;
+    std::vector<uint32_t> cand(n);
+    for (int i = 0; i < n; ++i) {
+        const int x = (int)xyr[3 * i], y = (int)xyr[3 * i + 1], r = (int)xyr[3 * i + 2];
+        if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return TC2LI_ERR_INVALID;
+        cand[i] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)r;
+    }
+    QuadtreeScratch scratch;
+    std::vector<int32_t> picked;
+    distribute_quadtree(cand.data(), n, min_x, max_x, min_y, max_y, n_target, scratch, picked);
+    if ((int)picked.size() > capacity) return TC2LI_ERR_CAPACITY;
+    for (size_t k = 0; k < picked.size(); ++k) memcpy(out_xyr + 3 * k, xyr + 3 * picked[k], 3 * sizeof(float));
+    return (int)picked.size();
+}
+
+int tc2li_orb_set_profiling(tc2li_orb* o, int enabled) {
+    if (!o) return TC2LI_ERR_INVALID;
+    o->profiling = enabled != 0;
+    return TC2LI_OK;
+}
+
+int tc2li_orb_last_timings(const tc2li_orb* o, float ms[8]) {
+    if (!o || !ms) return TC2LI_ERR_INVALID;
+    memcpy(ms, o->timings, sizeof(o->timings));
+    return TC2LI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,389 @@
+// gfx950 kernels of the ORB extractor (replaces the internals of SF/src/ORBextractor.cc).
+// All arithmetic is integer or explicitly rounded float, so the output is bit-identical to the CPU path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "det_math.hpp"
+#include "orb_device.hpp"
+
+namespace tc2li {
+
+// ------------------------------------------------------------------------------------------------------
+// Pyramid level from the previous one: cv::resize(INTER_LINEAR) on 8-bit (SF/src/ORBextractor.cc:1156).
+// Tables (xofs/ialpha/yofs/ibeta) are built on the host with the library's float/double recipe.  One thread
+// produces 4 horizontally adjacent destination pixels and stores them as one dword.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict__ src, int src_pitch, size_t src_img_stride,
+                                                       int sw, int sh, uint8_t* __restrict__ dst, int dst_pitch,
+                                                       size_t dst_img_stride, int dw, int dh,
+                                                       const int* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                       const int* __restrict__ yofs, const short* __restrict__ ibeta) {
+    const int img = blockIdx.z;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy >= dh || dx0 >= dw) return;
+    const uint8_t* S = src + (size_t)img * src_img_stride;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
+    const uint8_t* R0 = S + (size_t)sy0 * src_pitch;
+    const uint8_t* R1 = S + (size_t)sy1 * src_pitch;
+    const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = dx0 + k;
+        if (dx < dw) {
+            const int sx = xofs[dx];
+            const int sx1 = sx + 1 < sw ? sx + 1 : sx;  // weight of the clamped tap is 0
+            const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+            const int r0 = R0[sx] * a0 + R0[sx1] * a1;
+            const int r1 = R1[sx] * a0 + R1[sx1] * a1;
+            const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+    }
+    uint8_t* D = dst + (size_t)img * dst_img_stride + (size_t)dy * dst_pitch + dx0;
+    if (dx0 + 3 < dw) {
+        *reinterpret_cast<uint32_t*>(D) = packed;  // dst_pitch and dx0 are multiples of 4
+    } else {
+        for (int k = 0; k < 4 && dx0 + k < dw; ++k) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// FAST-9/16 per 35-px cell with the reference's threshold fallback (SF/src/ORBextractor.cc:776-846):
+// one workgroup per (cell, image).  The cell window (cell + 6 px) is staged in LDS; S = the largest arc
+// contrast is computed once (a pixel is a corner at threshold t iff S > t, its cv::FAST score is S-1), then
+// 3x3 strict non-max suppression is evaluated for iniTh and, if that leaves the cell empty, for minTh.
+// Survivors are emitted in row-major order through wave ballots, which is the order cv::FAST returns them in.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool has_arc9(uint32_t m16) {
+    uint32_t x = m16 | (m16 << 16);
+    uint32_t r = x & (x >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= x >> 8;
+    return (r & 0xffffu) != 0;
+}
+
+template <bool DARK>
+__device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
+    // max over the 16 arcs of 9 contiguous circle pixels of min(v - p) (DARK) or min(p - v)
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = DARK ? v - p[k] : p[k] - v;
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+    int best = -256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) best = max(best, min(m8[k], d[(k + 8) & 15]));
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
+                                                    int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
+                                                    int* __restrict__ cell_counts, int ncells) {
+    __shared__ uint8_t tile[kFastTileH * kFastTilePitch];
+    __shared__ uint8_t score[kFastTileH * kFastTilePitch];
+    __shared__ int s_wave[4];
+    __shared__ int s_cnt_ini;
+
+    const int tid = threadIdx.x, img = blockIdx.y;
+    const FastCell c = cells[blockIdx.x];
+    const LevelDesc L = levels.lv[c.level];
+    const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
+    const int w = c.w, h = c.h;
+
+    for (int i = tid; i < h * kFastTilePitch; i += 256) {
+        const int y = i / kFastTilePitch, x = i - y * kFastTilePitch;
+        tile[i] = x < w ? src[(size_t)y * L.pitch + x] : 0;
+        score[i] = 0;
+    }
+    if (tid == 0) s_cnt_ini = 0;
+    __syncthreads();
+
+    const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
+    for (int i = tid; i < npix; i += 256) {
+        const int ey = i / ew, ex = i - ey * ew;
+        const uint8_t* t = tile + (ey + 3) * kFastTilePitch + (ex + 3);
+        const int v = t[0];
+        int p[16];
+        p[0] = t[3 * kFastTilePitch];          p[1] = t[3 * kFastTilePitch + 1];   p[2] = t[2 * kFastTilePitch + 2];
+        p[3] = t[kFastTilePitch + 3];          p[4] = t[3];                        p[5] = t[-kFastTilePitch + 3];
+        p[6] = t[-2 * kFastTilePitch + 2];     p[7] = t[-3 * kFastTilePitch + 1];  p[8] = t[-3 * kFastTilePitch];
+        p[9] = t[-3 * kFastTilePitch - 1];     p[10] = t[-2 * kFastTilePitch - 2]; p[11] = t[-kFastTilePitch - 3];
+        p[12] = t[-3];                         p[13] = t[kFastTilePitch - 3];      p[14] = t[2 * kFastTilePitch - 2];
+        p[15] = t[3 * kFastTilePitch - 1];
+        uint32_t mb = 0, md = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            mb |= (uint32_t)(p[k] > v + min_th) << k;
+            md |= (uint32_t)(p[k] < v - min_th) << k;
+        }
+        int S = 0;
+        if (has_arc9(mb) || has_arc9(md)) S = max(arc_contrast<true>(p, v), arc_contrast<false>(p, v));
+        score[(ey + 3) * kFastTilePitch + (ex + 3)] = (uint8_t)S;
+    }
+    __syncthreads();
+
+    // non-max suppression flags for both thresholds (bit0: iniTh, bit1: minTh); tile[] is reused for flags
+    int my_ini = 0;
+    for (int i = tid; i < npix; i += 256) {
+        const int ey = i / ew, ex = i - ey * ew;
+        const uint8_t* s = score + (ey + 3) * kFastTilePitch + (ex + 3);
+        const int S = s[0];
+        int flags = 0;
+        if (S > min_th) {
+            int nb[8] = {s[-kFastTilePitch - 1], s[-kFastTilePitch], s[-kFastTilePitch + 1], s[-1],
+                         s[1], s[kFastTilePitch - 1], s[kFastTilePitch], s[kFastTilePitch + 1]};
+            bool keep_ini = S > ini_th, keep_min = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int n_ini = nb[k] > ini_th ? nb[k] - 1 : 0;
+                const int n_min = nb[k] > min_th ? nb[k] - 1 : 0;
+                keep_ini = keep_ini && (S - 1 > n_ini);
+                keep_min = keep_min && (S - 1 > n_min);
+            }
+            flags = (keep_ini ? 1 : 0) | (keep_min ? 2 : 0);
+            my_ini += keep_ini ? 1 : 0;
+        }
+        tile[i] = (uint8_t)flags;  // npix <= tile size
+    }
+    if (my_ini) atomicAdd(&s_cnt_ini, my_ini);
+    __syncthreads();
+    const int sel = s_cnt_ini > 0 ? 1 : 2;
+
+    uint32_t* out = slab + (size_t)img * slab_img_stride + c.slab_off;
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int start = 0; start < npix; start += 256) {
+        const int i = start + tid;
+        const bool f = i < npix && (tile[i] & sel);
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int k = 0; k < wave; ++k) off += s_wave[k];
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (f) {
+            const int ey = i / ew, ex = i - ey * ew;
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const uint32_t sc = score[(ey + 3) * kFastTilePitch + (ex + 3)] - 1;
+            // candidate coordinates in the border-free frame of the level (SF/src/ORBextractor.cc:833-838)
+            const uint32_t cx = (uint32_t)(c.x0 + ex + 3 - kMinBorder), cy = (uint32_t)(c.y0 + ey + 3 - kMinBorder);
+            if (pos < c.slab_cap) out[pos] = (cy << 20) | (cx << 8) | sc;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) cell_counts[(size_t)img * ncells + blockIdx.x] = base;
+}
+
+// Ordered concatenation of the per-cell candidate lists of one (image, level) into a dense list: cell-major order,
+// the order vToDistributeKeys is filled in (SF/src/ORBextractor.cc:829-842).
+__global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restrict__ cells, const int* __restrict__ level_cell_begin,
+                                                       const int* __restrict__ cell_counts, int ncells,
+                                                       const uint32_t* __restrict__ slab, size_t slab_img_stride,
+                                                       uint32_t* __restrict__ dense, const int* __restrict__ level_dense_off,
+                                                       int* __restrict__ level_counts, int nlevels) {
+    __shared__ int s_off[kMaxCellsPerLevel + 1];
+    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int cb = level_cell_begin[level], ce = level_cell_begin[level + 1], n = ce - cb;
+    const int* cnt = cell_counts + (size_t)img * ncells + cb;
+    // exclusive scan of the n (<= kMaxCellsPerLevel) cell counts: 8 per thread, wave scan, cross-wave fix-up
+    __shared__ int s_wsum[4];
+    {
+        int v[8], run = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid * 8 + k;
+            v[k] = run;
+            run += idx < n ? cnt[idx] : 0;
+        }
+        int incl = run;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int k = 0; k < wave; ++k) wbase += s_wsum[k];
+        const int excl = wbase + incl - run;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = tid * 8 + k;
+            if (idx <= n) s_off[idx] = excl + v[k];
+        }
+        if (tid == 0) level_counts[img * nlevels + level] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    }
+    __syncthreads();
+    const uint32_t* in = slab + (size_t)img * slab_img_stride;
+    uint32_t* out = dense + (size_t)img * slab_img_stride + level_dense_off[level];
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = wave; k < n; k += 4) {
+        const int m = s_off[k + 1] - s_off[k];
+        const uint32_t* ci = in + cells[cb + k].slab_off;
+        for (int t = lane; t < m; t += 64) out[s_off[k] + t] = ci[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 7x7 sigma=2 Gaussian on 8-bit, REFLECT_101, OpenCV's fixed-point separable path
+// (SF/src/ORBextractor.cc:1105-1106): taps {18,34,48,56,48,34,18}/256, 8.8 horizontal, 16.16 vertical,
+// round to nearest.  64x16 output tile per workgroup, halo staged in LDS, dword stores.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kBlurTW = 64, kBlurTH = 16;
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, int pitch, size_t img_stride, int w, int h,
+                                               uint8_t* __restrict__ dst, int dpitch, size_t dimg_stride) {
+    __shared__ uint8_t in[(kBlurTH + 6) * (kBlurTW + 8)];
+    __shared__ uint16_t hz[(kBlurTH + 6) * kBlurTW];
+    const int tid = threadIdx.x, img = blockIdx.z;
+    const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
+    const uint8_t* S = src + (size_t)img * img_stride;
+    constexpr int IW = kBlurTW + 6, IP = kBlurTW + 8;
+    for (int i = tid; i < (kBlurTH + 6) * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        int sy = y0 + r - 3, sx = x0 + c - 3;
+        // REFLECT_101; tiles beyond the image only need valid addresses
+        sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
+        sx = sx < 0 ? -sx : (sx >= w ? 2 * w - 2 - sx : sx);
+        sy = min(max(sy, 0), h - 1);
+        sx = min(max(sx, 0), w - 1);
+        in[r * IP + c] = S[(size_t)sy * pitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int r = i / kBlurTW, c = i - r * kBlurTW;
+        const uint8_t* p = in + r * IP + c;
+        hz[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    }
+    __syncthreads();
+    // 64x16 outputs = 256 threads x 4 horizontally adjacent pixels
+    const int ty = tid >> 4, tx = (tid & 15) * 4;
+    const int oy = y0 + ty, ox = x0 + tx;
+    if (oy >= h || ox >= w) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint16_t* q = hz + ty * kBlurTW + tx + k;
+        const uint32_t acc = 18u * (q[0] + q[6 * kBlurTW]) + 34u * (q[kBlurTW] + q[5 * kBlurTW]) +
+                             48u * (q[2 * kBlurTW] + q[4 * kBlurTW]) + 56u * q[3 * kBlurTW];
+        packed |= ((acc + 32768u) >> 16) << (8 * k);
+    }
+    uint8_t* D = dst + (size_t)img * dimg_stride + (size_t)oy * dpitch + ox;
+    if (ox + 3 < w) *reinterpret_cast<uint32_t*>(D) = packed;
+    else for (int k = 0; k < 4 && ox + k < w; ++k) D[k] = (uint8_t)(packed >> (8 * k));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Orientation (IC_Angle, SF/src/ORBextractor.cc:50-77) on the un-blurred level and the rotated-BRIEF descriptor
+// (computeOrbDescriptor, :81-120) on the blurred level: half a wavefront (32 lanes) per keypoint.  Lane u-16
+// sums one column of the radius-15 disc; lane i then produces descriptor byte i (8 pattern pairs).
+// ------------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int c_umax[16];
+
+__global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, const DevKeypoint* __restrict__ kps,
+                                                         int nkp, float* __restrict__ angles, uint8_t* __restrict__ desc) {
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    if (g >= nkp) return;
+    const DevKeypoint kp = kps[g];
+    const int level = kp.img_level & 0xff, img = kp.img_level >> 8;
+    const int x = (kp.packed >> 8) & 0xfff, y = kp.packed >> 20;
+    {
+        const LevelDesc L = raw.lv[level];
+        const uint8_t* center = L.img + (size_t)img * L.img_stride + (size_t)y * L.pitch + x;
+        const int u = lane - 16;  // lanes 1..31 cover u = -15..15
+        int m10 = 0, m01 = 0;
+        if (lane >= 1) {
+            const int au = u < 0 ? -u : u;
+            int col = 0, vsum = 0;
+            for (int v = -15; v <= 15; ++v) {
+                const int av = v < 0 ? -v : v;
+                if (au <= c_umax[av]) {
+                    const int val = center[v * L.pitch + u];
+                    col += val;
+                    vsum += v * val;
+                }
+            }
+            m10 = u * col;
+            m01 = vsum;
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            m10 += __shfl_xor(m10, o, 32);
+            m01 += __shfl_xor(m01, o, 32);
+        }
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        if (lane == 0) angles[g] = angle;
+        constexpr float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
+        float a, b;
+        det_sincosf(__fmul_rn(angle, factorPI), &b, &a);
+        const LevelDesc B = blurred.lv[level];
+        const uint8_t* bc = B.img + (size_t)img * B.img_stride + (size_t)y * B.pitch + x;
+        const int8_t* pat = c_pattern + lane * 32;
+        int val = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int t[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float px = (float)pat[4 * k + 2 * j], py = (float)pat[4 * k + 2 * j + 1];
+                const int ry = cv_round(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
+                const int rx = cv_round(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
+                t[j] = bc[ry * B.pitch + rx];
+            }
+            val |= (t[0] < t[1]) << k;
+        }
+        desc[(size_t)g * 32 + lane] = (uint8_t)val;
+    }
+}
+
+// ---- launch wrappers (host side of this translation unit) ----------------------------------------------
+void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
+                   const short* ibeta, int nimg, hipStream_t st) {
+    dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nimg);
+    hipLaunchKernelGGL(k_resize_linear, grid, dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta);
+}
+
+void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
+                 size_t slab_img_stride, int* cell_counts, int nimg, hipStream_t st) {
+    hipLaunchKernelGGL(k_fast_cells, dim3(ncells, nimg), dim3(256), 0, st, levels, cells, ini_th, min_th, slab,
+                       slab_img_stride, cell_counts, ncells);
+}
+
+void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
+                    const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
+                    int* level_counts, int nlevels, int nimg, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact_cells, dim3(nlevels, nimg), dim3(256), 0, st, cells, level_cell_begin, cell_counts,
+                       ncells, slab, slab_img_stride, dense, level_dense_off, level_counts, nlevels);
+}
+
+void launch_blur(const LevelDesc& src, const LevelDesc& dst, int nimg, hipStream_t st) {
+    dim3 grid((src.w + kBlurTW - 1) / kBlurTW, (src.h + kBlurTH - 1) / kBlurTH, nimg);
+    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride);
+}
+
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const DevKeypoint* kps, int nkp,
+                            float* angles, uint8_t* desc, hipStream_t st) {
+    if (nkp <= 0) return;
+    hipLaunchKernelGGL(k_orient_describe, dim3((nkp + 7) / 8), dim3(256), 0, st, raw, blurred, kps, nkp, angles, desc);
+}
+
+hipError_t upload_umax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }
+
+}  // namespace tc2li

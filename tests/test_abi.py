@@ -1,0 +1,68 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol the header declares, refuses to compute
+without a GPU (no silent fallback), and its host-only stage (quadtree) equals the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_header_symbols(pkg):
+    L = pkg.lib()
+    syms = pkg.exported_symbols()
+    assert "tc2li_orb_extract" in syms and "tc2li_orb_extract_batch" in syms and len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+    assert pkg.abi_version() >= 1
+
+
+def test_no_cpu_fallback(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.Tc2liError) as e:
+        pkg.OrbExtractor()
+    assert e.value.code == -3  # TC2LI_ERR_NO_DEVICE
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_does_not_reference_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg_dir = os.path.join(root, "tc2li-slam_amd")
+    for dp, _, files in os.walk(pkg_dir):
+        if os.sep + "build" in dp or os.sep + "lib" in dp:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dp, f), errors="replace").read()
+                assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text, os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("seed,n,w,h,target", [(0, 5000, 1210, 343, 434), (1, 300, 315, 73, 122), (2, 40, 500, 200, 100),
+                                               (3, 1, 400, 300, 50), (4, 0, 400, 300, 50), (5, 2500, 640, 640, 700),
+                                               (6, 900, 980, 260, 1)])
+def test_host_quadtree_equals_oracle(pkg, oracle, seed, n, w, h, target):
+    rng = np.random.default_rng(seed)
+    # distinct integer pixel positions in cv::FAST emission order is not required by the tree; use row-major order
+    pos = rng.choice(w * h, size=n, replace=False) if n else np.zeros(0, np.int64)
+    pos.sort()
+    xyr = np.stack([pos % w, pos // w, rng.integers(7, 120, n)], 1).astype(np.float32).reshape(-1, 3)
+    o = oracle.OrbOracle()
+    want = o.distribute(xyr, 16, 16 + w, 16, 16 + h, target)
+    got = pkg.distribute_quadtree_host(xyr, 16, 16 + w, 16, 16 + h, target)
+    assert np.array_equal(got, want)
+    if n:
+        assert len(got) >= min(n, 1)
+
+
+def test_host_quadtree_on_real_candidates(pkg, oracle, synthetic):
+    left, _ = synthetic.stereo_pair(7, 800, 300)
+    o = oracle.OrbOracle()
+    o.extract(left)
+    per_level = o.tables()[1]
+    for lvl in range(8):
+        c = o.candidates(lvl).copy()
+        lh, lw = o.level(lvl).shape
+        c[:, :2] -= 16
+        want = o.distribute(c, 16, lw - 16, 16, lh - 16, int(per_level[lvl]))
+        got = pkg.distribute_quadtree_host(c, 16, lw - 16, 16, lh - 16, int(per_level[lvl]))
+        assert np.array_equal(got, want), lvl

@@ -1,0 +1,150 @@
+"""GPU parity tests of the HIP ORB extractor against the CPU oracle: bit-exact pyramids, blurred levels, FAST
+candidates, keypoints and descriptors (the bar of BASELINE.json: 'bit-exact for ORB descriptors/keypoint
+indices').  Everything goes through the C ABI (tc2li_orb_*)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave")
+
+
+def assert_same_features(got, want):
+    gm, gk, gd = got
+    wm, wk, wd = want
+    assert gm == wm
+    assert len(gk) == len(wk)
+    for f in FIELDS:
+        assert np.array_equal(gk[f], wk[f]), f
+    assert np.array_equal(gd, wd)
+
+
+@pytest.fixture(scope="module")
+def ext(pkg):
+    assert pkg.device_count() >= 1, "GPU tests need a device; the library has no fallback"
+    e = pkg.OrbExtractor(max_width=1242, max_height=376, max_images=4)
+    yield e
+    e.close()
+
+
+def test_full_size_stages_bit_exact(ext, oracle, synthetic):
+    left, right = synthetic.stereo_pair(0)
+    o = oracle.OrbOracle()
+    for img in (left, right):
+        want = o.extract(img)
+        got = ext.extract(img)
+        for lvl in range(8):
+            assert ext.level_size(lvl) == o.level(lvl).shape[::-1]
+            assert np.array_equal(ext.pyramid_level(0, lvl), o.level(lvl)), "pyramid level %d" % lvl
+            assert np.array_equal(ext.blurred_level(0, lvl), o.blurred(lvl)), "blurred level %d" % lvl
+            assert np.array_equal(ext.candidates(0, lvl), o.candidates(lvl)), "FAST candidates level %d" % lvl
+        assert_same_features(got, want)
+        assert len(got[1]) >= 2000
+
+
+def test_tables_match(ext, oracle):
+    s, per_level, _ = oracle.OrbOracle().tables()
+    assert np.array_equal(ext.GetScaleFactors(), s)
+    assert np.array_equal(ext.features_per_level(), per_level)
+    assert np.array_equal(ext.GetInverseScaleFactors(), (np.float32(1) / s).astype(np.float32))
+    assert ext.GetLevels() == 8
+
+
+@pytest.mark.parametrize("seed,w,h", [(1, 1241, 376), (2, 1226, 370), (3, 640, 480), (4, 333, 257), (5, 250, 150)])
+def test_other_sizes(pkg, oracle, synthetic, seed, w, h):
+    left, _ = synthetic.stereo_pair(seed, w, h)
+    e = pkg.OrbExtractor(nfeatures=1200, ini_th_fast=12, max_width=w, max_height=h, max_images=1)
+    o = oracle.OrbOracle(nfeatures=1200, ini_th_fast=12)
+    assert_same_features(e.extract(left), o.extract(left))
+    e.close()
+
+
+def test_strided_input_and_handle_reuse(ext, oracle, synthetic):
+    left, right = synthetic.stereo_pair(6)
+    wide = np.zeros((375, 1300), np.uint8)
+    wide[:, :1242] = right
+    view = wide[:, :1242]  # row stride 1300
+    o = oracle.OrbOracle()
+    assert_same_features(ext.extract(view), o.extract(right))
+    # smaller image through the same handle, then the large one again
+    small = np.ascontiguousarray(left[40:340, 100:900])
+    assert_same_features(ext.extract(small), o.extract(small))
+    assert_same_features(ext.extract(left), o.extract(left))
+
+
+def test_edge_cases(ext, oracle):
+    # empty image: -1 like the reference (ORBextractor.cc:1063-1064)
+    mono, k, d = ext.extract(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0
+    # flat image: no corners, zero keypoints, monoIndex 0
+    flat = np.full((375, 1242), 77, np.uint8)
+    mono, k, d = ext.extract(flat)
+    assert mono == 0 and len(k) == 0
+    # low-contrast texture: cells fall back to minThFAST (ORBextractor.cc:816-820)
+    rng = np.random.default_rng(3)
+    low = (100 + rng.integers(0, 14, (375, 1242))).astype(np.uint8)
+    low[::9, ::11] += 16
+    o = oracle.OrbOracle()
+    want = o.extract(low)
+    assert_same_features(ext.extract(low), want)
+    # saturated checkerboard: plateaus of equal scores, everything suppressed or tie-broken identically
+    yy, xx = np.mgrid[0:375, 0:1242]
+    chk = (((yy // 6) + (xx // 6)) % 2 * 255).astype(np.uint8)
+    assert_same_features(ext.extract(chk), o.extract(chk))
+    # pure noise: maximal candidate load
+    noise = rng.integers(0, 256, (375, 1242)).astype(np.uint8)
+    assert_same_features(ext.extract(noise), o.extract(noise))
+
+
+def test_lapping_area(ext, oracle, synthetic):
+    left, _ = synthetic.stereo_pair(8)
+    o = oracle.OrbOracle()
+    want = o.extract(left, (400, 800))
+    got = ext.extract(left, (400, 800))
+    assert want[0] < len(want[1])
+    assert_same_features(got, want)
+
+
+@pytest.mark.parametrize("name", ["orb_a", "orb_b"])
+def test_golden_vectors(pkg, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    nf, ini, mn = [int(v) for v in g["params"]]
+    img = g["image"]
+    e = pkg.OrbExtractor(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn, max_width=img.shape[1], max_height=img.shape[0],
+                         max_images=1)
+    mono, kps, desc = e.extract(img)
+    assert mono == int(g["mono"])
+    kp = g["keypoints"]
+    for i, f in enumerate(FIELDS[:5]):
+        assert np.array_equal(kps[f], kp[:, i]), f
+    assert np.array_equal(kps["octave"], kp[:, 5].astype(np.int32))
+    assert np.array_equal(desc, g["descriptors"])
+    assert np.array_equal(e.pyramid_level(0, 7), g["level7"])
+    assert np.array_equal(e.blurred_level(0, 3), g["blurred3"])
+    e.close()
+
+
+def test_batch_device_resident(pkg, oracle, synthetic):
+    """Batched entry point on images resident in HBM (torch is only the allocator here)."""
+    import torch
+    frames = synthetic.stereo_batch(3, seed=20)  # [3, 2, H, W]
+    n = frames.shape[0] * 2
+    h, w = frames.shape[2:]
+    dev = torch.from_numpy(frames.reshape(n, h, w)).cuda()
+    e = pkg.OrbExtractor(max_width=w, max_height=h, max_images=n)
+    kps, desc, counts, mono = e.extract_batch_dev(dev.data_ptr(), n, w, h, w, w * h,
+                                                  stream=torch.cuda.current_stream().cuda_stream)
+    o = oracle.OrbOracle()
+    for i in range(n):
+        wm, wk, wd = o.extract(frames.reshape(n, h, w)[i])
+        assert counts[i] == len(wk) and mono[i] == wm
+        for f in FIELDS:
+            assert np.array_equal(kps[i, :counts[i]][f], wk[f]), (i, f)
+        assert np.array_equal(desc[i, :counts[i]], wd)
+    # size-independent properties at full size: descriptors of a repeated image are identical; order is level-major
+    assert np.all(np.diff(kps[0, :counts[0]]["octave"]) >= 0)
+    t = e.last_timings()
+    assert np.all(t >= 0)
+    e.close()
