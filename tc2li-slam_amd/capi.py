@@ -34,6 +34,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing torch first makes the
+    # dynamic loader satisfy our DT_NEEDED libamdhip64.so.7 with that already-loaded copy, so device pointers and
+    # streams can be shared with torch.  Without torch the system runtime under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
     if not os.path.exists(LIB_PATH):
         raise Tc2liError(-3, "native library %s not built (run __graft_entry__.build()); there is no fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
