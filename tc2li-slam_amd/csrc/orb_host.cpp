@@ -4,6 +4,7 @@
 // distribution (:529-753), which is sequential and order-defining; it runs on the worker pool, one task per
 // (image, level), while the GPU blurs the levels on a second stream.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -55,12 +56,10 @@ struct tc2li_orb {
     std::vector<DevBuf<int>> d_xofs, d_yofs;
     std::vector<DevBuf<short>> d_ialpha, d_ibeta;
     DevBuf<FastCell> d_cells;
-    DevBuf<int> d_level_cell_begin, d_level_dense_off, d_cell_counts, d_level_counts;
-    DevBuf<uint32_t> d_slab, d_dense;
-    DevBuf<DevKeypoint> d_kps;
-    DevBuf<float> d_angles;
-    DevBuf<uint8_t> d_desc;
-    // pinned host mirrors
+    DevBuf<int> d_level_cell_begin, d_level_dense_off, d_cell_counts;
+    DevBuf<uint32_t> d_slab;
+    // pinned, device-mapped host buffers: the compaction kernel writes candidates and counts straight into them and
+    // the descriptor kernel reads keypoints from / writes angles and descriptors to them (no staging copies)
     PinnedBuf<int> h_level_counts;
     PinnedBuf<uint32_t> h_dense;
     PinnedBuf<DevKeypoint> h_kps;
@@ -196,12 +195,8 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     TC2LI_HIP_CHECK(o->d_level_cell_begin.upload(level_cell_begin));
     TC2LI_HIP_CHECK(o->d_level_dense_off.upload(level_dense_off));
     TC2LI_HIP_CHECK(o->d_cell_counts.alloc((size_t)M * std::max<size_t>(o->cells.size(), 1)));
-    TC2LI_HIP_CHECK(o->d_level_counts.alloc((size_t)M * L));
     TC2LI_HIP_CHECK(o->d_slab.alloc((size_t)M * o->slab_per_image));
-    TC2LI_HIP_CHECK(o->d_dense.alloc((size_t)M * o->slab_per_image));
-    TC2LI_HIP_CHECK(o->d_kps.alloc((size_t)M * o->kp_cap_per_image));
-    TC2LI_HIP_CHECK(o->d_angles.alloc((size_t)M * o->kp_cap_per_image));
-    TC2LI_HIP_CHECK(o->d_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
+    TC2LI_HIP_CHECK(o->h_dense.alloc((size_t)M * o->slab_per_image));
     TC2LI_HIP_CHECK(o->h_level_counts.alloc((size_t)M * L));
     TC2LI_HIP_CHECK(o->h_kps.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->h_angles.alloc((size_t)M * o->kp_cap_per_image));
@@ -355,33 +350,21 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
                     (size_t)o->slab_per_image, o->d_cell_counts.p, M, st);
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
         launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p, ncells, o->d_slab.p,
-                       (size_t)o->slab_per_image, o->d_dense.p, o->d_level_dense_off.p, o->d_level_counts.p, L, M, st);
+                       (size_t)o->slab_per_image, o->h_dense.p, o->d_level_dense_off.p, o->h_level_counts.p, L, M, st);
     } else {
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
-        TC2LI_HIP_CHECK(hipMemsetAsync(o->d_level_counts.p, 0, (size_t)M * L * sizeof(int), st));
+        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        memset(o->h_level_counts.p, 0, (size_t)M * L * sizeof(int));
     }
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[2], st));
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_level_counts.p, o->d_level_counts.p, (size_t)M * L * sizeof(int),
-                                   hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
 
-    // candidates of every (image, level) to the host
+    // candidates of every (image, level) are now visible in the pinned buffer
     o->last_level_counts.assign(o->h_level_counts.p, o->h_level_counts.p + (size_t)M * L);
     o->last_level_off.assign((size_t)M * L + 1, 0);
-    size_t total = 0;
-    for (int i = 0; i < M * L; ++i) { o->last_level_off[i] = total; total += (size_t)o->last_level_counts[i]; }
-    o->last_level_off[(size_t)M * L] = total;
-    TC2LI_HIP_CHECK(o->h_dense.ensure(std::max<size_t>(total, 1)));
     for (int i = 0; i < M; ++i)
-        for (int l = 0; l < L; ++l) {
-            const int n = o->last_level_counts[i * L + l];
-            if (n > 0)
-                TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_dense.p + o->last_level_off[i * L + l],
-                                               o->d_dense.p + (size_t)i * o->slab_per_image + o->geom[l].dense_off,
-                                               (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        }
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        for (int l = 0; l < L; ++l) o->last_level_off[i * L + l] = (size_t)i * o->slab_per_image + o->geom[l].dense_off;
 
     // ---- stage 2 (host): quadtree distribution per (image, level) ------------------------------------------
     const auto t0 = std::chrono::steady_clock::now();
@@ -418,16 +401,11 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
 
     // ---- stage 3: orientation + descriptors ---------------------------------------------------------------
     if (nkp_total > 0) {
-        TC2LI_HIP_CHECK(hipMemcpyAsync(o->d_kps.p, o->h_kps.p, (size_t)nkp_total * sizeof(DevKeypoint),
-                                       hipMemcpyHostToDevice, st));
         TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
-        launch_orient_describe(raw, blur, o->d_kps.p, nkp_total, o->d_angles.p, o->d_desc.p, st);
+        launch_orient_describe(raw, blur, o->h_kps.p, nkp_total, o->h_angles.p, o->h_desc.p, st);
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
         TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_angles.p, o->d_angles.p, (size_t)nkp_total * sizeof(float),
-                                       hipMemcpyDeviceToHost, st));
-        TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_desc.p, o->d_desc.p, (size_t)nkp_total * 32, hipMemcpyDeviceToHost, st));
     } else {
         TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
@@ -436,11 +414,11 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
 
     // ---- assemble in the reference's output order (SF/src/ORBextractor.cc:1093-1137) -----------------------
-    int status = TC2LI_OK;
-    for (int i = 0; i < M; ++i) {
+    std::atomic<int> status{TC2LI_OK};
+    pool.parallel_for(M, [&](int i) {
         const int n = img_kp_off[i + 1] - img_kp_off[i];
         n_keypoints[i] = n;
-        if (n > capacity) { status = TC2LI_ERR_CAPACITY; if (mono_index) mono_index[i] = -1; continue; }
+        if (n > capacity) { status = TC2LI_ERR_CAPACITY; if (mono_index) mono_index[i] = -1; return; }
         tc2li_keypoint* kout = keypoints + (size_t)i * capacity;
         uint8_t* dout = descriptors + (size_t)i * capacity * 32;
         int mono = 0, stereo = n - 1;
@@ -463,7 +441,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
             memcpy(dout + (size_t)dsti * 32, o->h_desc.p + (size_t)g * 32, 32);
         }
         if (mono_index) mono_index[i] = mono;
-    }
+    });
     o->timings[0] = elapsed(o->ev[0], o->ev[1]);
     o->timings[1] = elapsed(o->ev[8], o->ev[3]);
     o->timings[2] = elapsed(o->ev[3], o->ev[2]);
@@ -472,7 +450,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     o->timings[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
     o->timings[6] = std::chrono::duration<float, std::milli>(t0 - t_begin).count();
     o->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (status != TC2LI_OK) { set_error("keypoint capacity %d too small", capacity); return status; }
+    if (status.load() != TC2LI_OK) { set_error("keypoint capacity %d too small", capacity); return status.load(); }
     return n_images;
 }
 
