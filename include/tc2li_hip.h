@@ -102,6 +102,24 @@ int tc2li_orb_download_candidates(tc2li_orb* orb, int image_index, int level, fl
 int tc2li_orb_set_profiling(tc2li_orb* orb, int enabled);
 int tc2li_orb_last_timings(const tc2li_orb* orb, float ms[8]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Stereo matching -- replaces Frame::ComputeStereoMatches (SF/src/Frame.cc:841-1011; called from the stereo
+ * Frame constructor, :160).  bf = mbf, b = mb (= mbf / fx, :197).  Outputs are mvuRight / mvDepth: -1 where a left
+ * keypoint has no accepted match.  best_sad (may be NULL) receives the SAD of the sub-pixel stage before the
+ * final 1.5*1.4*median cut (-1 = none).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Single frame, reference-style: the two extractor handles hold the pyramids of the left / right image of their
+ * last tc2li_orb_extract call (mvImagePyramid), keypoints and descriptors come back from the caller. */
+int tc2li_stereo_match(tc2li_orb* left, tc2li_orb* right, const tc2li_keypoint* keys_left, const uint8_t* desc_left,
+                       int n_left, const tc2li_keypoint* keys_right, const uint8_t* desc_right, int n_right, float bf, float b,
+                       float* u_right, float* depth, int32_t* best_sad);
+
+/* Batched: frame f = images 2f (left) and 2f+1 (right) of the handle's last tc2li_orb_extract_batch call (lapping
+ * area {0,0}); features are taken from device memory where that call left them.  Outputs are [n_frames][capacity]. */
+int tc2li_stereo_match_batch(tc2li_orb* orb, int n_frames, float bf, float b, float* u_right, float* depth,
+                             int32_t* best_sad, int capacity, void* stream);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

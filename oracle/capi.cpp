@@ -4,6 +4,7 @@
 #include <thread>
 
 #include "orb.hpp"
+#include "stereo.hpp"
 
 using namespace oracle;
 
@@ -95,6 +96,39 @@ int oracle_orb_distribute(void* h, const float* xyr, int n, int minX, int maxX, 
     if ((int)r.size() > cap) return -1;
     for (size_t i = 0; i < r.size(); ++i) { out[3 * i] = r[i].x; out[3 * i + 1] = r[i].y; out[3 * i + 2] = r[i].response; }
     return (int)r.size();
+}
+
+static std::vector<KeyPoint> kps_from(const float* k, int n) {
+    std::vector<KeyPoint> v(n);
+    for (int i = 0; i < n; ++i) {
+        v[i].x = k[6 * i]; v[i].y = k[6 * i + 1]; v[i].size = k[6 * i + 2]; v[i].angle = k[6 * i + 3];
+        v[i].response = k[6 * i + 4]; v[i].octave = (int)k[6 * i + 5];
+    }
+    return v;
+}
+
+// Frame::ComputeStereoMatches on the pyramids the two oracle extractors hold from their last extract() call.
+void oracle_stereo_match(void* hl, void* hr, const float* kl, const uint8_t* dl, int nl, const float* kr, const uint8_t* dr,
+                         int nr, float mbf, float mb, float* u_right, float* depth, int* best_sad) {
+    auto keysL = kps_from(kl, nl), keysR = kps_from(kr, nr);
+    std::vector<uint8_t> descL(dl, dl + (size_t)nl * 32), descR(dr, dr + (size_t)nr * 32);
+    StereoResult r = ComputeStereoMatches(*(ORBextractor*)hl, *(ORBextractor*)hr, keysL, descL, keysR, descR, mbf, mb);
+    for (int i = 0; i < nl; ++i) { u_right[i] = r.uRight[i]; depth[i] = r.depth[i]; if (best_sad) best_sad[i] = r.bestDist[i]; }
+}
+
+int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+// Feature grid: returns the flattened GetFeaturesInArea result for one query.
+int oracle_features_in_area(const float* k, int n, int cols, int rows, float x, float y, float r, int minLevel, int maxLevel,
+                            int* out, int cap) {
+    auto keys = kps_from(k, n);
+    FeatureGrid g;
+    g.init(cols, rows);
+    g.assign(keys);
+    auto v = g.GetFeaturesInArea(keys, x, y, r, minLevel, maxLevel);
+    if ((int)v.size() > cap) return -1;
+    for (size_t i = 0; i < v.size(); ++i) out[i] = (int)v[i];
+    return (int)v.size();
 }
 
 // single-function probes for unit tests

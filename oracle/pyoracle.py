@@ -43,6 +43,12 @@ def lib():
         L.oracle_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.oracle_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.oracle_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_stereo_match.restype = None
+        L.oracle_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -142,3 +148,35 @@ def gaussian_blur7(img):
 
 def fast_atan2(y, x):
     return lib().oracle_fast_atan2(float(y), float(x))
+
+
+def _kps_to_floats(kps):
+    a = np.zeros((len(kps), 6), np.float32)
+    for i, name in enumerate(["x", "y", "size", "angle", "response"]):
+        a[:, i] = kps[name]
+    a[:, 5] = kps["octave"]
+    return a
+
+
+def stereo_match(ora_left, ora_right, kps_l, desc_l, kps_r, desc_r, mbf, mb):
+    """Frame::ComputeStereoMatches on the pyramids of two OrbOracle objects -> (uRight, depth, bestSAD)."""
+    kl, kr = _kps_to_floats(kps_l), _kps_to_floats(kps_r)
+    dl, dr = np.ascontiguousarray(desc_l, np.uint8), np.ascontiguousarray(desc_r, np.uint8)
+    u = np.empty(len(kl), np.float32)
+    d = np.empty(len(kl), np.float32)
+    s = np.empty(len(kl), np.int32)
+    lib().oracle_stereo_match(ora_left._h, ora_right._h, kl.ctypes.data, dl.ctypes.data, len(kl), kr.ctypes.data,
+                              dr.ctypes.data, len(kr), mbf, mb, u.ctypes.data, d.ctypes.data, s.ctypes.data)
+    return u, d, s
+
+
+def descriptor_distance(a, b):
+    a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_descriptor_distance(a.ctypes.data, b.ctypes.data)
+
+
+def features_in_area(kps, cols, rows, x, y, r, min_level=-1, max_level=-1):
+    k = _kps_to_floats(kps)
+    out = np.empty(max(len(k), 1), np.int32)
+    n = lib().oracle_features_in_area(k.ctypes.data, len(k), cols, rows, x, y, r, min_level, max_level, out.ctypes.data, len(out))
+    return out[:n].copy()

@@ -13,6 +13,8 @@ from .capi import (  # noqa: F401
     OrbParams,
     OrbExtractor,
     abi_version,
+    compute_stereo_matches,
+    stereo_match_batch,
     device_count,
     distribute_quadtree_host,
     exported_symbols,

@@ -64,6 +64,10 @@ def lib():
     L.tc2li_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.tc2li_host_distribute_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_int]
+    L.tc2li_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_stereo_match_batch.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -209,3 +213,29 @@ class OrbExtractor:
         t = np.zeros(8, np.float32)
         _check(lib().tc2li_orb_last_timings(self._h, t.ctypes.data))
         return t
+
+
+def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, bf, b):
+    """``Frame::ComputeStereoMatches`` (SF/src/Frame.cc:841): returns (mvuRight, mvDepth, bestSAD)."""
+    kps_l = np.ascontiguousarray(kps_l, KEYPOINT_DTYPE)
+    kps_r = np.ascontiguousarray(kps_r, KEYPOINT_DTYPE)
+    desc_l = np.ascontiguousarray(desc_l, np.uint8)
+    desc_r = np.ascontiguousarray(desc_r, np.uint8)
+    n = len(kps_l)
+    u = np.full(max(n, 1), -1, np.float32)
+    d = np.full(max(n, 1), -1, np.float32)
+    s = np.full(max(n, 1), -1, np.int32)
+    _check(lib().tc2li_stereo_match(ext_left._h, ext_right._h, kps_l.ctypes.data, desc_l.ctypes.data, n, kps_r.ctypes.data,
+                                    desc_r.ctypes.data, len(kps_r), bf, b, u.ctypes.data, d.ctypes.data, s.ctypes.data))
+    return u[:n], d[:n], s[:n]
+
+
+def stereo_match_batch(ext, n_frames, bf, b, stream=0, out=None):
+    """Batched stereo matching on the device-resident features of the preceding ``extract_batch_dev`` call."""
+    if out is None:
+        out = (np.full((n_frames, ext.capacity), -1, np.float32), np.full((n_frames, ext.capacity), -1, np.float32),
+               np.full((n_frames, ext.capacity), -1, np.int32))
+    u, d, s = out
+    _check(lib().tc2li_stereo_match_batch(ext._h, n_frames, bf, b, u.ctypes.data, d.ctypes.data, s.ctypes.data, ext.capacity,
+                                          C.c_void_p(stream)))
+    return u, d, s

@@ -40,8 +40,33 @@ void launch_compact(const FastCell* cells, const int* level_cell_begin, const in
                     const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
                     int* level_counts, int nlevels, int nimg, hipStream_t st);
 void launch_blur(const LevelDesc& src, const LevelDesc& dst, int nimg, hipStream_t st);
-void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const DevKeypoint* kps, int nkp,
-                            float* angles, uint8_t* desc, hipStream_t st);
+struct MatchKey;
+struct ScaleTable;
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
+                            int nkp, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st);
 hipError_t upload_umax(const int* umax16);
+
+}  // namespace tc2li
+
+namespace tc2li {
+
+// Keypoint as the matchers see it: level-0 pixel coordinates and octave (cv::KeyPoint pt/octave).
+struct MatchKey {
+    float x, y;
+    int32_t octave;
+};
+
+struct ScaleTable { float scale[kMaxLevels], inv_scale[kMaxLevels]; };
+
+// One stereo frame for k_stereo_match: key/descriptor ranges and pyramid image indices.
+struct StereoFrame {
+    int32_t left_off, n_left, right_off, n_right;  // ranges in the key/descriptor arrays
+    int32_t left_img, right_img;                   // image index inside the left / right level table
+    int32_t out_off, pad_;
+};
+
+void launch_stereo_match(const LevelTable& left, const LevelTable& right, const ScaleTable& sc, const StereoFrame* frames,
+                         int nframes, int max_left, const MatchKey* keys, const uint8_t* desc, float mbf, float max_d,
+                         float* u_right, float* depth, int* best_sad, hipStream_t st);
 
 }  // namespace tc2li

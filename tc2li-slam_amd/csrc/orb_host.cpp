@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "orb_device.hpp"
 #include "quadtree.hpp"
+#include "orb_handle.hpp"
 
 using namespace tc2li;
 
@@ -24,63 +25,7 @@ inline int cvFloorD(double v) { int i = (int)v; return i - (i > v); }
 inline int cvCeilD(double v) { int i = (int)v; return i + (i < v); }
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-struct LevelGeom {
-    int w = 0, h = 0, pitch = 0;
-    size_t img_stride = 0;
-    int cell_begin = 0, cell_end = 0;
-    int dense_off = 0;  // offset of this level's region inside the per-image slab
-    int min_bx = 0, max_bx = 0, min_by = 0, max_by = 0;
-};
-
 }  // namespace
-
-struct tc2li_orb {
-    tc2li_orb_params prm{};
-    int max_w = 0, max_h = 0, max_images = 0;
-    // ctor tables (SF/src/ORBextractor.cc:388-442)
-    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
-    std::vector<int> features_per_level;
-    int umax[16];
-
-    // geometry of the current image size
-    int cur_w = 0, cur_h = 0;
-    std::vector<LevelGeom> geom;
-    std::vector<FastCell> cells;
-    int slab_per_image = 0;
-    int kp_cap_per_image = 0;
-
-    // device memory
-    DevBuf<uint8_t> d_level0;               // used by the host-image entry point
-    std::vector<DevBuf<uint8_t>> d_levels;  // [1..nlevels)
-    std::vector<DevBuf<uint8_t>> d_blur;    // [0..nlevels)
-    std::vector<DevBuf<int>> d_xofs, d_yofs;
-    std::vector<DevBuf<short>> d_ialpha, d_ibeta;
-    DevBuf<FastCell> d_cells;
-    DevBuf<int> d_level_cell_begin, d_level_dense_off, d_cell_counts;
-    DevBuf<uint32_t> d_slab;
-    // pinned, device-mapped host buffers: the compaction kernel writes candidates and counts straight into them and
-    // the descriptor kernel reads keypoints from / writes angles and descriptors to them (no staging copies)
-    PinnedBuf<int> h_level_counts;
-    PinnedBuf<uint32_t> h_dense;
-    PinnedBuf<DevKeypoint> h_kps;
-    PinnedBuf<float> h_angles;
-    PinnedBuf<uint8_t> h_desc;
-
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev[12] = {};
-    bool profiling = false;  // serialise all kernels on the caller's stream so that per-kernel event times are clean
-    LevelTable raw_tab{}, blur_tab{};
-    int last_nimg = 0;
-    std::vector<int> last_level_counts;  // [nimg][nlevels] candidates
-    std::vector<size_t> last_level_off;  // offsets into h_dense
-    float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<QuadtreeScratch> scratch;
-
-    ~tc2li_orb() {
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (side_stream) (void)hipStreamDestroy(side_stream);
-    }
-};
 
 namespace {
 
@@ -197,6 +142,8 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     TC2LI_HIP_CHECK(o->d_cell_counts.alloc((size_t)M * std::max<size_t>(o->cells.size(), 1)));
     TC2LI_HIP_CHECK(o->d_slab.alloc((size_t)M * o->slab_per_image));
     TC2LI_HIP_CHECK(o->h_dense.alloc((size_t)M * o->slab_per_image));
+    TC2LI_HIP_CHECK(o->d_mkeys.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->d_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
     TC2LI_HIP_CHECK(o->h_level_counts.alloc((size_t)M * L));
     TC2LI_HIP_CHECK(o->h_kps.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->h_angles.alloc((size_t)M * o->kp_cap_per_image));
@@ -262,6 +209,7 @@ int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, i
         }
     }
     TC2LI_HIP_CHECK(upload_umax(o->umax));
+    for (int i = 0; i < L; ++i) { o->scale_tab.scale[i] = o->scale[i]; o->scale_tab.inv_scale[i] = o->inv_scale[i]; }
     o->d_levels.resize(L); o->d_blur.resize(L);
     o->d_xofs.resize(L); o->d_yofs.resize(L); o->d_ialpha.resize(L); o->d_ibeta.resize(L);
     TC2LI_HIP_CHECK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
@@ -272,7 +220,11 @@ int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, i
     return TC2LI_OK;
 }
 
-void tc2li_orb_destroy(tc2li_orb* orb) { delete orb; }
+void tc2li_orb_destroy(tc2li_orb* orb) {
+    if (!orb) return;
+    tc2li::stereo_release_workspace(orb);
+    delete orb;
+}
 
 int tc2li_orb_levels(const tc2li_orb* o) { return o ? o->prm.nlevels : TC2LI_ERR_INVALID; }
 
@@ -386,6 +338,8 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         img_kp_off[i + 1] = img_kp_off[i] + n;
     }
     const int nkp_total = img_kp_off[M];
+    o->last_kp_off = img_kp_off;
+    o->last_plain_order = true;
     for (int i = 0; i < M; ++i) {
         DevKeypoint* dst = o->h_kps.p + img_kp_off[i];
         for (int l = 0; l < L; ++l) {
@@ -403,7 +357,8 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     if (nkp_total > 0) {
         TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
-        launch_orient_describe(raw, blur, o->h_kps.p, nkp_total, o->h_angles.p, o->h_desc.p, st);
+        launch_orient_describe(raw, blur, o->scale_tab, o->h_kps.p, nkp_total, o->h_angles.p, o->h_desc.p, o->d_mkeys.p,
+                               o->d_desc.p, st);
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
         TC2LI_HIP_CHECK(hipGetLastError());
     } else {
@@ -435,7 +390,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
             kp.angle = o->h_angles.p[g];
             if (l != 0) { kp.x *= o->scale[l]; kp.y *= o->scale[l]; }
             int dsti;
-            if (kp.x >= lapping_area[0] && kp.x <= lapping_area[1]) dsti = stereo--;
+            if (kp.x >= lapping_area[0] && kp.x <= lapping_area[1]) { dsti = stereo--; o->last_plain_order = false; }
             else dsti = mono++;
             kout[dsti] = kp;
             memcpy(dout + (size_t)dsti * 32, o->h_desc.p + (size_t)g * 32, 32);

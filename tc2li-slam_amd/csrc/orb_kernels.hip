@@ -294,8 +294,10 @@ __constant__ int8_t c_pattern[256 * 4] = {
 };
 __constant__ int c_umax[16];
 
-__global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, const DevKeypoint* __restrict__ kps,
-                                                         int nkp, float* __restrict__ angles, uint8_t* __restrict__ desc) {
+__global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, ScaleTable sc,
+                                                         const DevKeypoint* __restrict__ kps, int nkp,
+                                                         float* __restrict__ angles, uint8_t* __restrict__ desc,
+                                                         MatchKey* __restrict__ mkeys, uint8_t* __restrict__ desc_dev) {
     const int g = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31;
     if (g >= nkp) return;
@@ -327,7 +329,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
             m01 += __shfl_xor(m01, o, 32);
         }
         const float angle = fast_atan2_deg((float)m01, (float)m10);
-        if (lane == 0) angles[g] = angle;
+        if (lane == 0) {
+            angles[g] = angle;
+            // level-0 coordinates as the reference scales them (SF/src/ORBextractor.cc:1122-1124)
+            mkeys[g] = MatchKey{__fmul_rn((float)x, sc.scale[level]), __fmul_rn((float)y, sc.scale[level]), level};
+        }
         constexpr float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
         float a, b;
         det_sincosf(__fmul_rn(angle, factorPI), &b, &a);
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
             val |= (t[0] < t[1]) << k;
         }
         desc[(size_t)g * 32 + lane] = (uint8_t)val;
+        desc_dev[(size_t)g * 32 + lane] = (uint8_t)val;
     }
 }
 
@@ -378,10 +385,11 @@ void launch_blur(const LevelDesc& src, const LevelDesc& dst, int nimg, hipStream
                        const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride);
 }
 
-void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const DevKeypoint* kps, int nkp,
-                            float* angles, uint8_t* desc, hipStream_t st) {
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
+                            int nkp, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st) {
     if (nkp <= 0) return;
-    hipLaunchKernelGGL(k_orient_describe, dim3((nkp + 7) / 8), dim3(256), 0, st, raw, blurred, kps, nkp, angles, desc);
+    hipLaunchKernelGGL(k_orient_describe, dim3((nkp + 7) / 8), dim3(256), 0, st, raw, blurred, sc, kps, nkp, angles, desc,
+                       mkeys, desc_dev);
 }
 
 hipError_t upload_umax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }

@@ -1,0 +1,143 @@
+// Stereo matching of Frame::ComputeStereoMatches (SF/src/Frame.cc:841-1011) on gfx950: one wavefront per left
+// keypoint.  The wave scans all right keypoints of the frame (row band / octave / disparity gates from compact key
+// records staged in LDS), takes the best Hamming distance with a wave-wide min on (distance, index), then slides
+// the 11x11 SAD window over +-5 px on the keypoint's pyramid level and fits the parabola.  Integer work is exact;
+// the float tail uses explicitly rounded operations so that uRight/depth equal the CPU results bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "det_math.hpp"
+#include "orb_device.hpp"
+
+namespace tc2li {
+
+constexpr int kStereoMaxRight = 4096;  // right keypoints per frame that fit the LDS records
+constexpr int kLeftPerBlock = 32;
+
+struct RightRec {
+    float x;
+    int16_t minr, maxr;
+    int32_t octave;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTable right, ScaleTable sc,
+                                                      const StereoFrame* __restrict__ frames, const MatchKey* __restrict__ keys,
+                                                      const uint8_t* __restrict__ desc, float mbf, float max_d,
+                                                      float* __restrict__ u_right, float* __restrict__ depth,
+                                                      int* __restrict__ best_sad) {
+    __shared__ RightRec recs[kStereoMaxRight];
+    const StereoFrame fr = frames[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * kLeftPerBlock;
+    if (first >= fr.n_left) return;
+    const MatchKey* kr = keys + fr.right_off;
+    for (int i = tid; i < fr.n_right; i += 256) {
+        const MatchKey k = kr[i];
+        const float r = __fmul_rn(2.0f, sc.scale[k.octave]);
+        RightRec rc;
+        rc.x = k.x;
+        rc.maxr = (int16_t)(int)ceilf(__fadd_rn(k.y, r));
+        rc.minr = (int16_t)(int)floorf(__fsub_rn(k.y, r));
+        rc.octave = k.octave;
+        recs[i] = rc;
+    }
+    __syncthreads();
+
+    const uint32_t* dR = reinterpret_cast<const uint32_t*>(desc + (size_t)fr.right_off * 32);
+    for (int li = first + wave; li < min(first + kLeftPerBlock, fr.n_left); li += 4) {
+        const MatchKey kl = keys[fr.left_off + li];
+        const uint32_t* dLp = reinterpret_cast<const uint32_t*>(desc + (size_t)(fr.left_off + li) * 32);
+        uint32_t dl[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dl[k] = dLp[k];
+        const int row = (int)kl.y;
+        const float minU = __fsub_rn(kl.x, max_d), maxU = kl.x;
+        uint32_t best = (100u << 16) | 0xffffu;  // TH_HIGH; ties resolve to the smallest right index
+        for (int i = lane; i < fr.n_right; i += 64) {
+            const RightRec rc = recs[i];
+            const bool ok = row >= rc.minr && row <= rc.maxr && rc.octave >= kl.octave - 1 && rc.octave <= kl.octave + 1 &&
+                            rc.x >= minU && rc.x <= maxU;
+            if (ok) {
+                const uint32_t* p = dR + (size_t)i * 8;
+                int dist = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dist += __popc(dl[k] ^ p[k]);
+                const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)i;
+                best = min(best, key);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+        const int bestDist = (int)(best >> 16), bestIdx = (int)(best & 0xffff);
+        float out_u = -1.0f, out_d = -1.0f;
+        int out_sad = -1;
+        if (bestDist < 75 && !(maxU < 0)) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
+            const float uR0 = recs[bestIdx].x;
+            const float sf = sc.inv_scale[kl.octave];
+            const float scaleduL = roundf(__fmul_rn(kl.x, sf));
+            const float scaledvL = roundf(__fmul_rn(kl.y, sf));
+            const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+            const LevelDesc PL = left.lv[kl.octave], PR = right.lv[kl.octave];
+            const float iniu = scaleduR0, endu = __fadd_rn(scaleduR0, 11.0f);  // scaleduR0+L-w, scaleduR0+L+w+1
+            if (!(iniu < 0 || endu >= (float)PR.w)) {
+                const uint8_t* il = PL.img + (size_t)fr.left_img * PL.img_stride + (size_t)((int)scaledvL - 5) * PL.pitch +
+                                    ((int)scaleduL - 5);
+                const uint8_t* ir = PR.img + (size_t)fr.right_img * PR.img_stride + (size_t)((int)scaledvL - 5) * PR.pitch +
+                                    ((int)scaleduR0 - 5);
+                // lane owns window pixels `lane` and `lane + 64` (121 in total)
+                const int p0 = lane, p1 = lane + 64;
+                const int y0 = p0 / 11, x0 = p0 - y0 * 11, y1 = p1 / 11, x1 = p1 - y1 * 11;
+                const bool has1 = p1 < 121;
+                const int a0 = il[y0 * PL.pitch + x0];
+                const int a1 = has1 ? il[y1 * PL.pitch + x1] : 0;
+                int bestS = 0x7fffffff, bestInc = 0, sads[11];
+#pragma unroll
+                for (int inc = -5; inc <= 5; ++inc) {
+                    int s = abs(a0 - (int)ir[y0 * PR.pitch + x0 + inc]);
+                    if (has1) s += abs(a1 - (int)ir[y1 * PR.pitch + x1 + inc]);
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+                    sads[inc + 5] = s;
+                    if (s < bestS) { bestS = s; bestInc = inc; }
+                }
+                if (bestInc != -5 && bestInc != 5) {
+                    float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                    for (int k = 1; k < 10; ++k)
+                        if (k == bestInc + 5) { d1 = (float)sads[k - 1]; d2 = (float)sads[k]; d3 = (float)sads[k + 1]; }
+                    const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+                    const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = __fmul_rn(sc.scale[kl.octave], __fadd_rn(__fadd_rn(scaleduR0, (float)bestInc), deltaR));
+                        float disparity = __fsub_rn(kl.x, bestuR);
+                        if (disparity >= 0 && disparity < max_d) {
+                            if (disparity <= 0) {
+                                disparity = (float)0.01;
+                                bestuR = (float)__dsub_rn((double)kl.x, 0.01);
+                            }
+                            out_d = __fdiv_rn(mbf, disparity);
+                            out_u = bestuR;
+                            out_sad = bestS;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == 0) {
+            u_right[fr.out_off + li] = out_u;
+            depth[fr.out_off + li] = out_d;
+            best_sad[fr.out_off + li] = out_sad;
+        }
+    }
+}
+
+void launch_stereo_match(const LevelTable& left, const LevelTable& right, const ScaleTable& sc, const StereoFrame* frames,
+                         int nframes, int max_left, const MatchKey* keys, const uint8_t* desc, float mbf, float max_d,
+                         float* u_right, float* depth, int* best_sad, hipStream_t st) {
+    if (nframes <= 0 || max_left <= 0) return;
+    dim3 grid((max_left + kLeftPerBlock - 1) / kLeftPerBlock, nframes);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
+                       depth, best_sad);
+}
+
+}  // namespace tc2li
