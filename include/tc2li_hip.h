@@ -120,6 +120,74 @@ int tc2li_stereo_match(tc2li_orb* left, tc2li_orb* right, const tc2li_keypoint* 
 int tc2li_stereo_match_batch(tc2li_orb* orb, int n_frames, float bf, float b, float* u_right, float* depth,
                              int32_t* best_sad, int capacity, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * LiDAR front end, camera-LiDAR branch -- replaces the internals of
+ *   Preprocess::process / velodyne_handler      SF/include/lidar_front_end/preprocess.cpp:63-167 (non-feature branch)
+ *   pcl::VoxelGrid<PointXYZINormal>::filter      call sites LidarFrontEnd.cpp:712-714, 913-915
+ *   ikdtree.Build / Add_Points / Nearest_Search  SF/include/ikd-Tree/ikd_Tree.cpp:409-461 (a hash grid here, same 5-NN)
+ *   feature_extraction / EstiPlane               LidarFrontEnd.cpp:964-1073, with pointBodyToWorld :130-139
+ * Point layouts are PCL's: velodyne_ros::Point (32 B, preprocess.h:62-70) and pcl::PointXYZINormal (48 B).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_velodyne_point {
+    float x, y, z, pad0;
+    float intensity, time;
+    uint16_t ring, pad1;
+    float pad2;
+} tc2li_velodyne_point;
+
+typedef struct tc2li_point { /* pcl::PointXYZINormal */
+    float x, y, z, pad0;
+    float normal_x, normal_y, normal_z, pad1;
+    float intensity, curvature, pad2, pad3;
+} tc2li_point;
+
+/* The parts of state_ikfom that pointBodyToWorld reads (LidarFrontEnd.cpp:130-139); matrices row-major. */
+typedef struct tc2li_lidar_state {
+    double rot[9], pos[3], offset_R_L_I[9], offset_T_L_I[3];
+} tc2li_lidar_state;
+
+typedef struct tc2li_lidar tc2li_lidar;         /* stage workspace for up to max_scans scans per call */
+typedef struct tc2li_lidar_map tc2li_lidar_map; /* the incremental map (the reference's global `ikdtree`) */
+
+int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out);
+void tc2li_lidar_destroy(tc2li_lidar* lidar);
+
+/* Preprocess::process for a Velodyne cloud with feature_enabled = false: keeps point i when i % point_filter_num == 0
+ * and |p|^2 > blind^2; curvature = time * time_unit_scale (ms).  Returns the number of points written. */
+int tc2li_lidar_preprocess(tc2li_lidar* lidar, const tc2li_velodyne_point* raw, int n, int point_filter_num, double blind,
+                           float time_unit_scale, tc2li_point* out, int capacity);
+
+/* downSizeFilterSurf.setInputCloud(in); downSizeFilterSurf.filter(out) with leaf size `leaf` on all three axes:
+ * one centroid (of every field) per occupied voxel, in ascending voxel-index order. */
+int tc2li_lidar_voxel_filter(tc2li_lidar* lidar, const tc2li_point* in, int n, float leaf, tc2li_point* out, int capacity);
+
+int tc2li_lidar_map_create(tc2li_lidar_map** out);
+void tc2li_lidar_map_destroy(tc2li_lidar_map* map);
+/* ikdtree.Build(points) (LidarFrontEnd.cpp:918-931): replaces the map content.  Returns the map size. */
+int tc2li_lidar_map_build(tc2li_lidar_map* map, const tc2li_point* world_points, int n);
+/* ikdtree.Add_Points(points, false): appends without down-sampling.  Returns the map size. */
+int tc2li_lidar_map_add(tc2li_lidar_map* map, const tc2li_point* world_points, int n);
+int tc2li_lidar_map_size(const tc2li_lidar_map* map);
+
+/* feature_extraction() (LidarFrontEnd.cpp:999-1073) for one down-sampled scan.  Per input point i (arrays of n, any
+ * may be NULL): feats_down_world[i], point_selected[i], normvec[i] (plane normal, intensity = pd2), the up-to-5
+ * Nearest_Points[i] ([n][5], ascending distance) with their squared distances and count.  laser_cloud_ori /
+ * corr_normvect receive the compacted selection; the return value is effct_feat_num. */
+int tc2li_lidar_feature_extraction(tc2li_lidar* lidar, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n,
+                                   const tc2li_lidar_state* state, tc2li_point* feats_down_world, uint8_t* point_selected,
+                                   tc2li_point* normvec, tc2li_point* nearest_points, float* nearest_sqdist, int32_t* n_nearest,
+                                   tc2li_point* laser_cloud_ori, tc2li_point* corr_normvect, int capacity);
+
+/* Whole front end for a batch of raw scans resident in device memory (scan s = dev_raw[raw_offsets[s] .. raw_offsets[s+1])):
+ * preprocess -> voxel filter -> feature extraction against maps[s] with states[s]; stages chain on the device.
+ * Per-scan counts come back in the three int arrays; the compacted selections in [n_scans][capacity] host arrays
+ * (either may be NULL). */
+int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
+                               int point_filter_num, double blind, float time_unit_scale, float leaf,
+                               tc2li_lidar_map* const* maps, const tc2li_lidar_state* states, int32_t* n_preprocessed,
+                               int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
+                               tc2li_point* corr_normvect, int capacity, void* stream);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

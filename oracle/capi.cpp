@@ -5,6 +5,7 @@
 
 #include "orb.hpp"
 #include "stereo.hpp"
+#include "lidar.hpp"
 
 using namespace oracle;
 
@@ -129,6 +130,76 @@ int oracle_features_in_area(const float* k, int n, int cols, int rows, float x, 
     if ((int)v.size() > cap) return -1;
     for (size_t i = 0; i < v.size(); ++i) out[i] = (int)v[i];
     return (int)v.size();
+}
+
+// ---- LiDAR -----------------------------------------------------------------------------------------------------
+int oracle_lidar_preprocess(const VelodynePoint* raw, int n, int point_filter_num, double blind, float time_unit_scale,
+                            PointXYZINormal* out, int cap) {
+    PointVector v = preprocess_velodyne(raw, n, point_filter_num, blind, time_unit_scale);
+    if ((int)v.size() > cap) return -1;
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(PointXYZINormal));
+    return (int)v.size();
+}
+
+int oracle_lidar_voxel_grid(const PointXYZINormal* in, int n, float leaf, PointXYZINormal* out, int cap) {
+    PointVector v = voxel_grid_filter(PointVector(in, in + n), leaf);
+    if ((int)v.size() > cap) return -1;
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(PointXYZINormal));
+    return (int)v.size();
+}
+
+void* oracle_kdtree_build(const PointXYZINormal* pts, int n) {
+    KdTree* t = new KdTree();
+    t->Build(PointVector(pts, pts + n));
+    return t;
+}
+void oracle_kdtree_add(void* h, const PointXYZINormal* pts, int n) {
+    for (int i = 0; i < n; ++i) ((KdTree*)h)->Add_Point(pts[i]);
+}
+void oracle_kdtree_destroy(void* h) { delete (KdTree*)h; }
+int oracle_kdtree_size(void* h) { return (int)((KdTree*)h)->size(); }
+
+// k nearest of each query: near [nq][k] points, sqdist [nq][k], found [nq]
+void oracle_kdtree_knn(void* h, const PointXYZINormal* q, int nq, int k, PointXYZINormal* near, float* sqdist, int* found) {
+    const KdTree* t = (KdTree*)h;
+    PointVector pn;
+    std::vector<float> d;
+    for (int i = 0; i < nq; ++i) {
+        t->Nearest_Search(q[i], k, pn, d);
+        found[i] = (int)pn.size();
+        for (size_t j = 0; j < pn.size(); ++j) { near[(size_t)i * k + j] = pn[j]; sqdist[(size_t)i * k + j] = d[j]; }
+    }
+}
+
+int oracle_esti_plane(const PointXYZINormal* five, float threshold, float* pabcd) {
+    return EstiPlane(pabcd, PointVector(five, five + 5), threshold) ? 1 : 0;
+}
+
+// feature_extraction(): state = rot[9], pos[3], offset_R[9], offset_T[3] (row-major doubles).  Outputs per input point:
+// world point, selected flag, normal+pd2 (normvec), 5 neighbours; plus the compacted laserCloudOri / corr_normvect.
+int oracle_lidar_feature_extraction(void* tree, const PointXYZINormal* body, int n, const double* state24,
+                                    PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec,
+                                    PointXYZINormal* nearest5, int* nfound, PointXYZINormal* cloud_ori,
+                                    PointXYZINormal* corr_norm) {
+    LidarState st;
+    std::memcpy(st.rot, state24, 9 * sizeof(double));
+    std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
+    std::memcpy(st.offset_R_L_I, state24 + 12, 9 * sizeof(double));
+    std::memcpy(st.offset_T_L_I, state24 + 21, 3 * sizeof(double));
+    FeatureExtraction fe = feature_extraction(PointVector(body, body + n), st, *(KdTree*)tree);
+    for (int i = 0; i < n; ++i) {
+        if (world) world[i] = fe.feats_down_world[i];
+        if (selected) selected[i] = fe.point_selected_surf[i];
+        if (normvec) normvec[i] = fe.normvec[i];
+        if (nfound) nfound[i] = (int)fe.Nearest_Points[i].size();
+        if (nearest5)
+            for (size_t j = 0; j < fe.Nearest_Points[i].size() && j < 5; ++j) nearest5[(size_t)i * 5 + j] = fe.Nearest_Points[i][j];
+    }
+    for (int i = 0; i < fe.effct_feat_num; ++i) {
+        if (cloud_ori) cloud_ori[i] = fe.laserCloudOri[i];
+        if (corr_norm) corr_norm[i] = fe.corr_normvect[i];
+    }
+    return fe.effct_feat_num;
 }
 
 // single-function probes for unit tests

@@ -1,0 +1,409 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle, never linked into or called from the product path.
+// See lidar.hpp for the reference locations each function follows.
+#include "lidar.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cstring>
+
+namespace oracle {
+
+// preprocess.cpp:145-166
+PointVector preprocess_velodyne(const VelodynePoint* raw, int plsize, int point_filter_num, double blind,
+                                float time_unit_scale) {
+    PointVector pl_surf;
+    if (plsize == 0) return pl_surf;
+    pl_surf.reserve(plsize);
+    for (int i = 0; i < plsize; i++) {
+        PointXYZINormal added_pt;
+        std::memset(&added_pt, 0, sizeof(added_pt));
+        added_pt.pad0 = 1.0f;  // PCL_ADD_POINT4D initialises data[3] to 1
+        added_pt.x = raw[i].x;
+        added_pt.y = raw[i].y;
+        added_pt.z = raw[i].z;
+        added_pt.intensity = raw[i].intensity;
+        added_pt.curvature = raw[i].time * time_unit_scale;
+        if (i % point_filter_num == 0) {
+            if (added_pt.x * added_pt.x + added_pt.y * added_pt.y + added_pt.z * added_pt.z > (blind * blind))
+                pl_surf.push_back(added_pt);
+        }
+    }
+    return pl_surf;
+}
+
+// pcl::VoxelGrid<PointT>::applyFilter (PCL 1.12 filters/impl/voxel_grid.hpp), all fields averaged.
+PointVector voxel_grid_filter(const PointVector& in, float leaf) {
+    PointVector out;
+    if (in.empty()) return out;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (const auto& p : in) {
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        mn[0] = std::min(mn[0], p.x); mn[1] = std::min(mn[1], p.y); mn[2] = std::min(mn[2], p.z);
+        mx[0] = std::max(mx[0], p.x); mx[1] = std::max(mx[1], p.y); mx[2] = std::max(mx[2], p.z);
+    }
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+                  dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT_MAX) return in;  // "leaf size too small": the filter hands the input back
+    int min_b[3], max_b[3], div_b[3], mul[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)std::floor(mn[a] * inv);
+        max_b[a] = (int)std::floor(mx[a] * inv);
+        div_b[a] = max_b[a] - min_b[a] + 1;
+    }
+    mul[0] = 1; mul[1] = div_b[0]; mul[2] = div_b[0] * div_b[1];
+    std::vector<std::pair<int, int>> index;  // (voxel, point)
+    index.reserve(in.size());
+    for (int i = 0; i < (int)in.size(); ++i) {
+        const auto& p = in[i];
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+        const int i0 = (int)(std::floor(p.x * inv) - (float)min_b[0]);
+        const int i1 = (int)(std::floor(p.y * inv) - (float)min_b[1]);
+        const int i2 = (int)(std::floor(p.z * inv) - (float)min_b[2]);
+        index.emplace_back(i0 * mul[0] + i1 * mul[1] + i2 * mul[2], i);
+    }
+    std::sort(index.begin(), index.end());  // by voxel, then by point index (the order the sums are taken in)
+    size_t first = 0;
+    while (first < index.size()) {
+        size_t last = first + 1;
+        while (last < index.size() && index[last].first == index[first].first) ++last;
+        // CentroidPoint: per-field running sums, divided by the count; the normal is re-normalised if non-zero
+        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t k = first; k < last; ++k) {
+            const auto& p = in[index[k].second];
+            s[0] += p.x; s[1] += p.y; s[2] += p.z;
+            s[3] += p.normal_x; s[4] += p.normal_y; s[5] += p.normal_z;
+            s[6] += p.intensity; s[7] += p.curvature;
+        }
+        const float n = (float)(last - first);
+        PointXYZINormal o;
+        std::memset(&o, 0, sizeof(o));
+        o.pad0 = 1.0f;
+        o.x = s[0] / n; o.y = s[1] / n; o.z = s[2] / n;
+        float nx = s[3], ny = s[4], nz = s[5];
+        const float nn = nx * nx + ny * ny + nz * nz;
+        if (nn > 0) { const float r = std::sqrt(nn); nx /= r; ny /= r; nz /= r; }
+        o.normal_x = nx; o.normal_y = ny; o.normal_z = nz;
+        o.intensity = s[6] / n;
+        o.curvature = s[7] / n;
+        out.push_back(o);
+        first = last;
+    }
+    return out;
+}
+
+// LidarFrontEnd.cpp:130-139
+PointXYZINormal pointBodyToWorld(const PointXYZINormal& pi, const LidarState& s) {
+    const double b[3] = {pi.x, pi.y, pi.z};
+    double t[3], g[3];
+    for (int r = 0; r < 3; ++r)
+        t[r] = (s.offset_R_L_I[3 * r] * b[0] + s.offset_R_L_I[3 * r + 1] * b[1] + s.offset_R_L_I[3 * r + 2] * b[2]) + s.offset_T_L_I[r];
+    for (int r = 0; r < 3; ++r) g[r] = (s.rot[3 * r] * t[0] + s.rot[3 * r + 1] * t[1] + s.rot[3 * r + 2] * t[2]) + s.pos[r];
+    PointXYZINormal po;
+    std::memset(&po, 0, sizeof(po));
+    po.pad0 = 1.0f;
+    po.x = (float)g[0]; po.y = (float)g[1]; po.z = (float)g[2];
+    po.intensity = pi.intensity;
+    return po;
+}
+
+// ---- k-d tree ------------------------------------------------------------------------------------------------
+static inline float coord(const PointXYZINormal& p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); }
+
+// ikd_Tree.cpp:1750-1755
+static inline float calc_dist(const PointXYZINormal& a, const PointXYZINormal& b) {
+    return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y) + (a.z - b.z) * (a.z - b.z);
+}
+
+void KdTree::update(int n) {
+    Node& nd = nodes[n];
+    for (int a = 0; a < 3; ++a) nd.lo[a] = nd.hi[a] = coord(nd.p, a);
+    for (int c : {nd.left, nd.right})
+        if (c >= 0)
+            for (int a = 0; a < 3; ++a) { nd.lo[a] = std::min(nd.lo[a], nodes[c].lo[a]); nd.hi[a] = std::max(nd.hi[a], nodes[c].hi[a]); }
+}
+
+// ikd_Tree.cpp:690-744
+int KdTree::build(PointVector& s, int l, int r) {
+    if (l > r) return -1;
+    const int mid = (l + r) >> 1;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = l; i <= r; ++i)
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], coord(s[i], a)); mx[a] = std::max(mx[a], coord(s[i], a)); }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    std::nth_element(s.begin() + l, s.begin() + mid, s.begin() + r + 1,
+                     [axis](const PointXYZINormal& a, const PointXYZINormal& b) { return coord(a, axis) < coord(b, axis); });
+    const int id = (int)nodes.size();
+    nodes.emplace_back();
+    nodes[id].p = s[mid];
+    nodes[id].axis = axis;
+    const int lc = build(s, l, mid - 1);
+    const int rc = build(s, mid + 1, r);
+    nodes[id].left = lc;
+    nodes[id].right = rc;
+    update(id);
+    return id;
+}
+
+void KdTree::Build(PointVector pts) {
+    nodes.clear();
+    nodes.reserve(pts.size());
+    root = pts.empty() ? -1 : build(pts, 0, (int)pts.size() - 1);
+}
+
+// ikd_Tree.cpp:1007-1070 without re-balancing
+void KdTree::Add_Point(const PointXYZINormal& p) {
+    const int id = (int)nodes.size();
+    nodes.emplace_back();
+    nodes[id].p = p;
+    if (root < 0) { nodes[id].axis = 0; root = id; update(id); return; }
+    std::vector<int> path;
+    int cur = root;
+    for (;;) {
+        path.push_back(cur);
+        const int ax = nodes[cur].axis;
+        int& child = coord(p, ax) < coord(nodes[cur].p, ax) ? nodes[cur].left : nodes[cur].right;
+        if (child < 0) { child = id; nodes[id].axis = (ax + 1) % 3; break; }
+        cur = child;
+    }
+    update(id);
+    for (int i = (int)path.size() - 1; i >= 0; --i) update(path[i]);
+}
+
+// MANUAL_HEAP + PointType_CMP, ikd_Tree.h:93-201
+struct KdTree::Heap {
+    std::vector<HeapItem> h;
+    int n = 0;
+    explicit Heap(int cap) : h(cap) {}
+    static bool less(const HeapItem& a, const HeapItem& b) {
+        if (std::fabs(a.dist - b.dist) < 1e-10) return a.p.x < b.p.x;
+        return a.dist < b.dist;
+    }
+    void pop() {
+        if (!n) return;
+        h[0] = h[n - 1];
+        --n;
+        int i = 0, l = 1;
+        HeapItem tmp = h[0];
+        while (l < n) {
+            if (l + 1 < n && less(h[l], h[l + 1])) l++;
+            if (less(tmp, h[l])) { h[i] = h[l]; i = l; l = 2 * i + 1; } else break;
+        }
+        h[i] = tmp;
+    }
+    void push(const HeapItem& it) {
+        if (n >= (int)h.size()) return;
+        int i = n, a = (i - 1) / 2;
+        h[n] = it;
+        HeapItem tmp = it;
+        while (i > 0) {
+            if (less(h[a], tmp)) { h[i] = h[a]; i = a; a = (i - 1) / 2; } else break;
+        }
+        h[i] = tmp;
+        ++n;
+    }
+};
+
+// ikd_Tree.cpp:1757-1776
+float KdTree::box_dist(int n, const PointXYZINormal& q) const {
+    if (n < 0) return INFINITY;
+    const Node& nd = nodes[n];
+    float d = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float c = coord(q, a);
+        if (c < nd.lo[a]) d += (c - nd.lo[a]) * (c - nd.lo[a]);
+        if (c > nd.hi[a]) d += (c - nd.hi[a]) * (c - nd.hi[a]);
+    }
+    return d;
+}
+
+// ikd_Tree.cpp:1074-1256 (max_dist = INFINITY, no deleted points, single thread)
+void KdTree::search(int n, int k, const PointXYZINormal& q, Heap& hp) const {
+    if (n < 0) return;
+    const Node& nd = nodes[n];
+    const float dist = calc_dist(q, nd.p);
+    if (hp.n < k || dist < hp.h[0].dist) {
+        if (hp.n >= k) hp.pop();
+        hp.push(HeapItem{nd.p, dist});
+    }
+    const float dl = box_dist(nd.left, q), dr = box_dist(nd.right, q);
+    if (hp.n < k || (dl < hp.h[0].dist && dr < hp.h[0].dist)) {
+        if (dl <= dr) {
+            search(nd.left, k, q, hp);
+            if (hp.n < k || dr < hp.h[0].dist) search(nd.right, k, q, hp);
+        } else {
+            search(nd.right, k, q, hp);
+            if (hp.n < k || dl < hp.h[0].dist) search(nd.left, k, q, hp);
+        }
+    } else {
+        if (dl < hp.h[0].dist) search(nd.left, k, q, hp);
+        if (dr < hp.h[0].dist) search(nd.right, k, q, hp);
+    }
+}
+
+// ikd_Tree.cpp:426-461
+void KdTree::Nearest_Search(const PointXYZINormal& q, int k, PointVector& near, std::vector<float>& sqdist) const {
+    Heap hp(2 * k);
+    search(root, k, q, hp);
+    const int found = std::min(k, hp.n);
+    near.assign(found, PointXYZINormal());
+    sqdist.assign(found, 0.f);
+    for (int i = found - 1; i >= 0; --i) { near[i] = hp.h[0].p; sqdist[i] = hp.h[0].dist; hp.pop(); }
+}
+
+// ---- plane fit ----------------------------------------------------------------------------------------------
+// Least-squares solution of the 5x3 system A x = b by Householder QR with column pivoting (the method behind
+// Eigen's colPivHouseholderQr().solve()), single precision, sums taken in index order.
+static void qr_solve_5x3(float A[5][3], float b[5], float x[3]) {
+    const int R = 5, C = 3;
+    float normU[3], normD[3];
+    for (int j = 0; j < C; ++j) {
+        float s = 0;
+        for (int i = 0; i < R; ++i) s += A[i][j] * A[i][j];
+        normU[j] = normD[j] = std::sqrt(s);
+    }
+    float maxn = std::max(normU[0], std::max(normU[1], normU[2]));
+    const float thr_helper = (maxn * FLT_EPSILON) * (maxn * FLT_EPSILON) / (float)R;
+    const float downdate_thr = std::sqrt(FLT_EPSILON);
+    int perm[3] = {0, 1, 2};
+    int nonzero = C;
+    float tau[3] = {0, 0, 0};
+    for (int k = 0; k < C; ++k) {
+        int big = k;
+        for (int j = k + 1; j < C; ++j) if (normU[j] > normU[big]) big = j;
+        const float big_sq = normU[big] * normU[big];
+        if (nonzero == C && big_sq < thr_helper * (float)(R - k)) nonzero = k;
+        if (big != k) {
+            for (int i = 0; i < R; ++i) std::swap(A[i][k], A[i][big]);
+            std::swap(normU[k], normU[big]);
+            std::swap(normD[k], normD[big]);
+            std::swap(perm[k], perm[big]);
+        }
+        // Householder vector of column k below the diagonal
+        float tail = 0;
+        for (int i = k + 1; i < R; ++i) tail += A[i][k] * A[i][k];
+        const float c0 = A[k][k];
+        float beta;
+        if (tail <= FLT_MIN) {
+            tau[k] = 0;
+            beta = c0;
+            for (int i = k + 1; i < R; ++i) A[i][k] = 0;
+        } else {
+            beta = std::sqrt(c0 * c0 + tail);
+            if (c0 >= 0) beta = -beta;
+            for (int i = k + 1; i < R; ++i) A[i][k] = A[i][k] / (c0 - beta);
+            tau[k] = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        // apply H_k = I - tau v v^T (v = [1, essential]) to the remaining columns and to b
+        if (tau[k] != 0) {
+            for (int j = k + 1; j < C; ++j) {
+                float t = 0;
+                for (int i = k + 1; i < R; ++i) t += A[i][k] * A[i][j];
+                t += A[k][j];
+                A[k][j] -= tau[k] * t;
+                for (int i = k + 1; i < R; ++i) A[i][j] -= tau[k] * A[i][k] * t;
+            }
+        }
+        for (int j = k + 1; j < C; ++j) {
+            if (normU[j] != 0) {
+                float temp = std::fabs(A[k][j]) / normU[j];
+                temp = (1.0f + temp) * (1.0f - temp);
+                temp = temp < 0 ? 0 : temp;
+                const float r = normU[j] / normD[j];
+                const float temp2 = temp * (r * r);
+                if (temp2 <= downdate_thr) {
+                    float s = 0;
+                    for (int i = k + 1; i < R; ++i) s += A[i][j] * A[i][j];
+                    normD[j] = std::sqrt(s);
+                    normU[j] = normD[j];
+                } else {
+                    normU[j] *= std::sqrt(temp);
+                }
+            }
+        }
+    }
+    // c = Q^T b
+    for (int k = 0; k < nonzero; ++k) {
+        if (tau[k] == 0) continue;
+        float t = 0;
+        for (int i = k + 1; i < R; ++i) t += A[i][k] * b[i];
+        t += b[k];
+        b[k] -= tau[k] * t;
+        for (int i = k + 1; i < R; ++i) b[i] -= tau[k] * A[i][k] * t;
+    }
+    // back substitution on the leading nonzero x nonzero block of R
+    float c[3] = {0, 0, 0};
+    for (int i = nonzero - 1; i >= 0; --i) {
+        float s = b[i];
+        for (int j = i + 1; j < nonzero; ++j) s -= A[i][j] * c[j];
+        c[i] = s / A[i][i];
+    }
+    x[0] = x[1] = x[2] = 0;
+    for (int i = 0; i < nonzero; ++i) x[perm[i]] = c[i];
+}
+
+// LidarFrontEnd.cpp:964-997
+bool EstiPlane(float pca_result[4], const PointVector& point, float threshold) {
+    float A[5][3], b[5], nv[3];
+    for (int j = 0; j < 5; j++) {
+        A[j][0] = point[j].x; A[j][1] = point[j].y; A[j][2] = point[j].z;
+        b[j] = -1.0f;
+    }
+    qr_solve_5x3(A, b, nv);
+    const float n = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    pca_result[0] = nv[0] / n;
+    pca_result[1] = nv[1] / n;
+    pca_result[2] = nv[2] / n;
+    pca_result[3] = (float)(1.0 / n);
+    for (int j = 0; j < 5; j++)
+        if (std::fabs(pca_result[0] * point[j].x + pca_result[1] * point[j].y + pca_result[2] * point[j].z + pca_result[3]) > threshold)
+            return false;
+    return true;
+}
+
+// LidarFrontEnd.cpp:999-1073
+FeatureExtraction feature_extraction(const PointVector& feats_down_body, const LidarState& st, const KdTree& tree) {
+    const int N = (int)feats_down_body.size();
+    FeatureExtraction fe;
+    fe.feats_down_world.resize(N);
+    fe.Nearest_Points.resize(N);
+    fe.point_selected_surf.assign(N, 0);
+    PointXYZINormal blank;
+    std::memset(&blank, 0, sizeof(blank));
+    blank.pad0 = 1.0f;  // pcl points are constructed with data[3] = 1
+    fe.normvec.assign(N, blank);
+    for (int i = 0; i < N; i++) {
+        const PointXYZINormal& point_body = feats_down_body[i];
+        PointXYZINormal& point_world = fe.feats_down_world[i];
+        const double pb[3] = {point_body.x, point_body.y, point_body.z};
+        point_world = pointBodyToWorld(point_body, st);
+        std::vector<float> pointSearchSqDis(5);
+        auto& points_near = fe.Nearest_Points[i];
+        tree.Nearest_Search(point_world, 5, points_near, pointSearchSqDis);
+        bool sel = points_near.size() < 5 ? false : (pointSearchSqDis[4] > 5 ? false : true);
+        if (!sel) continue;
+        float pabcd[4];
+        if (EstiPlane(pabcd, points_near, 0.1f)) {
+            const float pd2 = pabcd[0] * point_world.x + pabcd[1] * point_world.y + pabcd[2] * point_world.z + pabcd[3];
+            const double pnorm = std::sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
+            const float s = (float)(1 - 0.9 * std::fabs(pd2) / std::sqrt(pnorm));
+            if (s > 0.9) {
+                fe.point_selected_surf[i] = 1;
+                fe.normvec[i].x = pabcd[0]; fe.normvec[i].y = pabcd[1]; fe.normvec[i].z = pabcd[2];
+                fe.normvec[i].intensity = pd2;
+            }
+        }
+    }
+    for (int i = 0; i < N; i++)
+        if (fe.point_selected_surf[i]) {
+            fe.laserCloudOri.push_back(feats_down_body[i]);
+            fe.corr_normvect.push_back(fe.normvec[i]);
+            fe.effct_feat_num++;
+        }
+    return fe;
+}
+
+}  // namespace oracle

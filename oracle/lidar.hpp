@@ -1,0 +1,81 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle, never linked into or called from the product path.
+//
+// Restatement of the LiDAR front end on the camera-LiDAR path:
+//   Preprocess::velodyne_handler, non-feature branch      SF/include/lidar_front_end/preprocess.cpp:145-166
+//   pcl::VoxelGrid<PointXYZINormal>::filter call sites     LidarFrontEnd.cpp:712-714, 913-915 (PCL 1.12, NOT in tree)
+//   pointBodyToWorld                                       LidarFrontEnd.cpp:130-139
+//   KD_TREE::Build / BuildTree / Nearest_Search / Search   SF/include/ikd-Tree/ikd_Tree.cpp:409-423,690-744,426-461,1074-1256
+//   EstiPlane (Eigen colPivHouseholderQr, NOT in tree)     LidarFrontEnd.cpp:964-997
+//   feature_extraction                                     LidarFrontEnd.cpp:999-1073
+// PARITY UNPINNED: no reference tests/vectors exist for these; PCL and Eigen are un-vendored dependencies
+// (CMakeLists.txt:72-73) whose published algorithms are restated here with sequential float summation order.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace oracle {
+
+struct VelodynePoint {  // velodyne_ros::Point, preprocess.h:62-70 (32 bytes)
+    float x, y, z, pad0;
+    float intensity, time;
+    uint16_t ring, pad1;
+    float pad2;
+};
+static_assert(sizeof(VelodynePoint) == 32, "layout");
+
+struct PointXYZINormal {  // pcl::PointXYZINormal (48 bytes)
+    float x, y, z, pad0;
+    float normal_x, normal_y, normal_z, pad1;
+    float intensity, curvature, pad2, pad3;
+};
+static_assert(sizeof(PointXYZINormal) == 48, "layout");
+
+using PointVector = std::vector<PointXYZINormal>;
+
+// preprocess.cpp:63-86 (time unit scale) and :145-166
+PointVector preprocess_velodyne(const VelodynePoint* raw, int n, int point_filter_num, double blind, float time_unit_scale);
+
+// pcl::VoxelGrid::applyFilter with downsample_all_data = true, min_points_per_voxel = 0
+PointVector voxel_grid_filter(const PointVector& in, float leaf);
+
+struct LidarState {  // the parts of state_ikfom that pointBodyToWorld reads (row-major 3x3)
+    double rot[9], pos[3], offset_R_L_I[9], offset_T_L_I[3];
+};
+PointXYZINormal pointBodyToWorld(const PointXYZINormal& pi, const LidarState& s);
+
+// Static k-d tree with ikd-Tree's build rule and search procedure (no re-balancing, no deletions).
+class KdTree {
+public:
+    void Build(PointVector pts);                                   // ikd_Tree.cpp:409-423, 690-744
+    void Add_Point(const PointXYZINormal& p);                      // Add_by_point without downsampling, :1263-1312
+    void Nearest_Search(const PointXYZINormal& q, int k, PointVector& near, std::vector<float>& sqdist) const;  // :426-461
+    size_t size() const { return nodes.size(); }
+    const PointXYZINormal& point(size_t i) const { return nodes[i].p; }
+
+private:
+    struct Node { PointXYZINormal p; int left = -1, right = -1, axis = 0; float lo[3], hi[3]; };
+    std::vector<Node> nodes;
+    int root = -1;
+    int build(PointVector& s, int l, int r);
+    void update(int n);
+    struct HeapItem { PointXYZINormal p; float dist; };
+    struct Heap;
+    void search(int n, int k, const PointXYZINormal& q, Heap& h) const;
+    float box_dist(int n, const PointXYZINormal& q) const;
+};
+
+// EstiPlane<float>: solve A n = -1 (5x3) by column-pivoted Householder QR, normalise, test |n.p + d| <= threshold
+bool EstiPlane(float pca_result[4], const PointVector& pts, float threshold);
+
+struct FeatureExtraction {
+    PointVector feats_down_world;            // every down-sampled point in the world frame
+    std::vector<PointVector> Nearest_Points;  // per point: neighbours in ascending distance
+    std::vector<uint8_t> point_selected_surf;
+    PointVector normvec;                      // per point: plane normal, intensity = pd2 (valid where selected)
+    PointVector laserCloudOri, corr_normvect; // compacted selection (body-frame points / normals)
+    int effct_feat_num = 0;
+};
+FeatureExtraction feature_extraction(const PointVector& feats_down_body, const LidarState& st, const KdTree& tree);
+
+}  // namespace oracle

@@ -49,6 +49,19 @@ def lib():
         L.oracle_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                               C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oracle_lidar_preprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_void_p, C.c_int]
+        L.oracle_lidar_voxel_grid.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        L.oracle_kdtree_build.restype = C.c_void_p
+        L.oracle_kdtree_build.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_kdtree_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.oracle_kdtree_add.restype = None
+        L.oracle_kdtree_destroy.argtypes = [C.c_void_p]
+        L.oracle_kdtree_destroy.restype = None
+        L.oracle_kdtree_size.argtypes = [C.c_void_p]
+        L.oracle_kdtree_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_kdtree_knn.restype = None
+        L.oracle_esti_plane.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_lidar_feature_extraction.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
         _lib = L
     return _lib
 
@@ -180,3 +193,82 @@ def features_in_area(kps, cols, rows, x, y, r, min_level=-1, max_level=-1):
     out = np.empty(max(len(k), 1), np.int32)
     n = lib().oracle_features_in_area(k.ctypes.data, len(k), cols, rows, x, y, r, min_level, max_level, out.ctypes.data, len(out))
     return out[:n].copy()
+
+
+# ---- LiDAR ------------------------------------------------------------------------------------------------------
+VELODYNE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                           ("time", "<f4"), ("ring", "<u2"), ("pad1", "<u2"), ("pad2", "<f4")])
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("normal_x", "<f4"),
+                        ("normal_y", "<f4"), ("normal_z", "<f4"), ("pad1", "<f4"), ("intensity", "<f4"),
+                        ("curvature", "<f4"), ("pad2", "<f4"), ("pad3", "<f4")])
+
+
+def lidar_preprocess(raw, point_filter_num=2, blind=2.0, time_unit_scale=1e-3):
+    raw = np.ascontiguousarray(raw, VELODYNE_DTYPE)
+    out = np.zeros(max(len(raw), 1), POINT_DTYPE)
+    n = lib().oracle_lidar_preprocess(raw.ctypes.data, len(raw), point_filter_num, blind, time_unit_scale,
+                                      out.ctypes.data, len(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+def voxel_grid(points, leaf=0.5):
+    points = np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(max(len(points), 1), POINT_DTYPE)
+    n = lib().oracle_lidar_voxel_grid(points.ctypes.data, len(points), leaf, out.ctypes.data, len(out))
+    assert n >= 0
+    return out[:n].copy()
+
+
+class KdTree:
+    def __init__(self, points):
+        points = np.ascontiguousarray(points, POINT_DTYPE)
+        self._h = C.c_void_p(lib().oracle_kdtree_build(points.ctypes.data, len(points)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_kdtree_destroy(self._h)
+            self._h = None
+
+    def add(self, points):
+        points = np.ascontiguousarray(points, POINT_DTYPE)
+        lib().oracle_kdtree_add(self._h, points.ctypes.data, len(points))
+
+    def size(self):
+        return lib().oracle_kdtree_size(self._h)
+
+    def knn(self, queries, k=5):
+        q = np.ascontiguousarray(queries, POINT_DTYPE)
+        near = np.zeros((len(q), k), POINT_DTYPE)
+        d = np.zeros((len(q), k), np.float32)
+        found = np.zeros(len(q), np.int32)
+        lib().oracle_kdtree_knn(self._h, q.ctypes.data, len(q), k, near.ctypes.data, d.ctypes.data, found.ctypes.data)
+        return near, d, found
+
+
+def esti_plane(five, threshold=0.1):
+    five = np.ascontiguousarray(five, POINT_DTYPE)
+    out = np.zeros(4, np.float32)
+    ok = lib().oracle_esti_plane(five.ctypes.data, threshold, out.ctypes.data)
+    return bool(ok), out
+
+
+def pack_state(rot, pos, off_r, off_t):
+    return np.ascontiguousarray(np.concatenate([np.ravel(rot), np.ravel(pos), np.ravel(off_r), np.ravel(off_t)]), np.float64)
+
+
+def feature_extraction(tree, body, state24):
+    body = np.ascontiguousarray(body, POINT_DTYPE)
+    n = len(body)
+    world = np.zeros(n, POINT_DTYPE)
+    sel = np.zeros(n, np.uint8)
+    normvec = np.zeros(n, POINT_DTYPE)
+    near = np.zeros((n, 5), POINT_DTYPE)
+    nfound = np.zeros(n, np.int32)
+    ori = np.zeros(n, POINT_DTYPE)
+    corr = np.zeros(n, POINT_DTYPE)
+    m = lib().oracle_lidar_feature_extraction(tree._h, body.ctypes.data, n, state24.ctypes.data, world.ctypes.data,
+                                              sel.ctypes.data, normvec.ctypes.data, near.ctypes.data, nfound.ctypes.data,
+                                              ori.ctypes.data, corr.ctypes.data)
+    return dict(world=world, selected=sel, normvec=normvec, nearest=near, nfound=nfound, cloud_ori=ori[:m], corr_normvect=corr[:m],
+                effct_feat_num=m)

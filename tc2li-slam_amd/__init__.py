@@ -13,6 +13,11 @@ from .capi import (  # noqa: F401
     OrbParams,
     OrbExtractor,
     abi_version,
+    LidarFrontEnd,
+    LidarMap,
+    pack_lidar_state,
+    POINT_DTYPE,
+    VELODYNE_DTYPE,
     compute_stereo_matches,
     stereo_match_batch,
     device_count,

@@ -68,6 +68,21 @@ def lib():
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_stereo_match_batch.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p]
+    L.tc2li_lidar_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tc2li_lidar_destroy.argtypes = [C.c_void_p]
+    L.tc2li_lidar_destroy.restype = None
+    L.tc2li_lidar_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_void_p, C.c_int]
+    L.tc2li_lidar_voxel_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    L.tc2li_lidar_map_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.tc2li_lidar_map_destroy.argtypes = [C.c_void_p]
+    L.tc2li_lidar_map_destroy.restype = None
+    L.tc2li_lidar_map_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tc2li_lidar_map_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tc2li_lidar_map_size.argtypes = [C.c_void_p]
+    L.tc2li_lidar_feature_extraction.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 8 + [C.c_int]
+    L.tc2li_lidar_frontend_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -239,3 +254,112 @@ def stereo_match_batch(ext, n_frames, bf, b, stream=0, out=None):
     _check(lib().tc2li_stereo_match_batch(ext._h, n_frames, bf, b, u.ctypes.data, d.ctypes.data, s.ctypes.data, ext.capacity,
                                           C.c_void_p(stream)))
     return u, d, s
+
+
+# ---- LiDAR front end ---------------------------------------------------------------------------------------------
+VELODYNE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                           ("time", "<f4"), ("ring", "<u2"), ("pad1", "<u2"), ("pad2", "<f4")])
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("normal_x", "<f4"),
+                        ("normal_y", "<f4"), ("normal_z", "<f4"), ("pad1", "<f4"), ("intensity", "<f4"),
+                        ("curvature", "<f4"), ("pad2", "<f4"), ("pad3", "<f4")])
+
+
+def pack_lidar_state(rot, pos, offset_r=None, offset_t=None):
+    """tc2li_lidar_state as 24 float64 (rot row-major, pos, offset_R_L_I row-major, offset_T_L_I)."""
+    offset_r = np.eye(3) if offset_r is None else offset_r
+    offset_t = np.zeros(3) if offset_t is None else offset_t
+    return np.ascontiguousarray(np.concatenate([np.ravel(rot), np.ravel(pos), np.ravel(offset_r), np.ravel(offset_t)]), np.float64)
+
+
+class LidarMap:
+    """The incremental LiDAR map (global ``ikdtree`` of LidarFrontEnd.cpp:96): Build / Add_Points / size."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().tc2li_lidar_map_create(C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().tc2li_lidar_map_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def Build(self, points):
+        points = np.ascontiguousarray(points, POINT_DTYPE)
+        return _check(lib().tc2li_lidar_map_build(self._h, points.ctypes.data, len(points)))
+
+    def Add_Points(self, points):
+        points = np.ascontiguousarray(points, POINT_DTYPE)
+        return _check(lib().tc2li_lidar_map_add(self._h, points.ctypes.data, len(points)))
+
+    def size(self):
+        return _check(lib().tc2li_lidar_map_size(self._h))
+
+
+class LidarFrontEnd:
+    """Stage functions of the camera-LiDAR front end (Preprocess::process, VoxelGrid::filter, feature_extraction)."""
+
+    def __init__(self, max_points_per_scan=140000, max_scans=1):
+        self._h = C.c_void_p()
+        self.cap = max_points_per_scan
+        self.max_scans = max_scans
+        _check(lib().tc2li_lidar_create(max_points_per_scan, max_scans, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().tc2li_lidar_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def process(self, raw, point_filter_num=2, blind=2.0, time_unit_scale=1e-3):
+        raw = np.ascontiguousarray(raw, VELODYNE_DTYPE)
+        out = np.zeros(max(len(raw), 1), POINT_DTYPE)
+        n = _check(lib().tc2li_lidar_preprocess(self._h, raw.ctypes.data, len(raw), point_filter_num, blind, time_unit_scale,
+                                                out.ctypes.data, len(out)))
+        return out[:n].copy()
+
+    def voxel_filter(self, points, leaf=0.5):
+        points = np.ascontiguousarray(points, POINT_DTYPE)
+        out = np.zeros(max(len(points), 1), POINT_DTYPE)
+        n = _check(lib().tc2li_lidar_voxel_filter(self._h, points.ctypes.data, len(points), leaf, out.ctypes.data, len(out)))
+        return out[:n].copy()
+
+    def feature_extraction(self, lidar_map, feats_down_body, state24):
+        body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
+        n = len(body)
+        m1 = max(n, 1)
+        world = np.zeros(m1, POINT_DTYPE)
+        sel = np.zeros(m1, np.uint8)
+        normvec = np.zeros(m1, POINT_DTYPE)
+        near = np.zeros((m1, 5), POINT_DTYPE)
+        dist = np.zeros((m1, 5), np.float32)
+        nfound = np.zeros(m1, np.int32)
+        ori = np.zeros(m1, POINT_DTYPE)
+        corr = np.zeros(m1, POINT_DTYPE)
+        state24 = np.ascontiguousarray(state24, np.float64)
+        m = _check(lib().tc2li_lidar_feature_extraction(self._h, lidar_map._h, body.ctypes.data, n, state24.ctypes.data,
+                                                        world.ctypes.data, sel.ctypes.data, normvec.ctypes.data, near.ctypes.data,
+                                                        dist.ctypes.data, nfound.ctypes.data, ori.ctypes.data, corr.ctypes.data, m1))
+        return dict(world=world[:n], selected=sel[:n], normvec=normvec[:n], nearest=near[:n], sqdist=dist[:n], nfound=nfound[:n],
+                    cloud_ori=ori[:m], corr_normvect=corr[:m], effct_feat_num=m)
+
+    def frontend_batch(self, dev_raw_ptr, raw_offsets, maps, states, point_filter_num=2, blind=2.0, time_unit_scale=1e-3,
+                       leaf=0.5, stream=0, want_points=True, capacity=None):
+        n_scans = len(raw_offsets) - 1
+        raw_offsets = np.ascontiguousarray(raw_offsets, np.int32)
+        states = np.ascontiguousarray(states, np.float64).reshape(n_scans, 24)
+        handles = (C.c_void_p * n_scans)(*[m._h for m in maps])
+        counts = np.zeros((3, n_scans), np.int32)
+        capacity = capacity or self.cap
+        ori = corr = None
+        if want_points:
+            ori = np.zeros((n_scans, capacity), POINT_DTYPE)
+            corr = np.zeros((n_scans, capacity), POINT_DTYPE)
+        _check(lib().tc2li_lidar_frontend_batch(self._h, n_scans, C.c_void_p(dev_raw_ptr), raw_offsets.ctypes.data,
+                                                point_filter_num, blind, time_unit_scale, leaf, handles, states.ctypes.data,
+                                                counts[0].ctypes.data, counts[1].ctypes.data, counts[2].ctypes.data,
+                                                ori.ctypes.data if want_points else None,
+                                                corr.ctypes.data if want_points else None, capacity, C.c_void_p(stream)))
+        return counts, ori, corr

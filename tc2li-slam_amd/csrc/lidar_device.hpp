@@ -1,0 +1,85 @@
+// Structures shared by the host orchestration and the gfx950 kernels of the LiDAR front end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tc2li {
+
+struct VelodynePoint {  // velodyne_ros::Point (SF/include/lidar_front_end/preprocess.h:62-70), 32 bytes
+    float x, y, z, pad0;
+    float intensity, time;
+    uint16_t ring, pad1;
+    float pad2;
+};
+struct PointXYZINormal {  // pcl::PointXYZINormal, 48 bytes
+    float x, y, z, pad0;
+    float normal_x, normal_y, normal_z, pad1;
+    float intensity, curvature, pad2, pad3;
+};
+static_assert(sizeof(VelodynePoint) == 32 && sizeof(PointXYZINormal) == 48, "PCL layouts");
+
+constexpr int kSegBlock = 1024;  // points per block of the segmented (per-scan) passes
+
+// A block of a segmented pass: which scan it belongs to and where it starts inside that scan's slot.
+struct SegBlock { int32_t scan, start; };
+
+// Per-scan slots: every per-point array reserves `cap` entries starting at `base` for a scan; how many are in use
+// at each stage lives in device counters so that stages chain without host synchronisation.
+struct ScanSlot { int32_t base, cap, first_block, n_blocks; };
+
+struct VoxelParams {  // pcl::VoxelGrid::applyFilter bookkeeping for one scan
+    int32_t min_b[3], mul[3];
+    int32_t passthrough;  // index space overflow: the filter returns its input unchanged
+    int32_t table_base, table_mask;
+};
+
+struct LidarStateDev { double rot[9], pos[3], off_r[9], off_t[3]; };
+
+struct PreprocessParams { int32_t point_filter_num; float time_unit_scale; double blind_sq; };
+
+// Uniform hash grid over the map (replaces the ikd-Tree as the spatial index; same 5 nearest neighbours).
+struct MapGrid {
+    const PointXYZINormal* points;  // the map points in insertion order (what Nearest_Search returns copies of)
+    const float4* pts;          // cell-sorted xyz + original index (as int bits in w)
+    const int32_t* bucket_start;  // [n_buckets + 1]
+    int32_t n_buckets_mask, n_points;
+    float inv_cell, cell;
+};
+
+void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
+                      int nblocks, PreprocessParams prm, int* block_counts, hipStream_t st);
+void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st);
+void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
+                        int nblocks, PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st);
+
+void launch_voxel_bbox(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                       int* bbox_enc, hipStream_t st);
+void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* slots, int nscans, float leaf, VoxelParams* vp,
+                         hipStream_t st);
+void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, hipStream_t st);
+void launch_fill_int(int* p, size_t n, int v, hipStream_t st);
+void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys, const int* table_counts,
+                       int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status, hipStream_t st);
+void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                       float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* vox_member_off,
+                       int* vox_fill, int* members, hipStream_t st);
+void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                           const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
+                           PointXYZINormal* out, int* out_count, hipStream_t st);
+
+void launch_map_count(const PointXYZINormal* pts, int n, float inv_cell, int mask, int* bucket_counts, hipStream_t st);
+void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st);
+void launch_map_scatter(const PointXYZINormal* pts, int n, float inv_cell, int mask, const int* bucket_start, int* bucket_fill,
+                        float4* sorted, hipStream_t st);
+void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
+                      const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
+                      PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,
+                      int* nfound, hipStream_t st);
+void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                      int* block_counts, hipStream_t st);
+void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                        const int* block_offsets, const PointXYZINormal* body, const PointXYZINormal* normvec,
+                        PointXYZINormal* cloud_ori, PointXYZINormal* corr_norm, hipStream_t st);
+
+}  // namespace tc2li

@@ -1,0 +1,336 @@
+// Host orchestration of the gfx950 LiDAR front end behind tc2li_lidar_* (include/tc2li_hip.h).  Mirrors the
+// camera-LiDAR branch of SF/include/lidar_front_end: Preprocess::process -> pcl::VoxelGrid -> feature_extraction
+// against the incremental map (LidarFrontEnd.cpp:233-261, 886-962, 999-1073).  Every stage works on a batch of
+// scans laid out in fixed per-scan slots; the per-scan point counts produced by one stage are consumed by the next
+// one from device memory.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "common.hpp"
+#include "lidar_device.hpp"
+
+using namespace tc2li;
+
+static_assert(sizeof(tc2li_velodyne_point) == sizeof(VelodynePoint), "ABI layout");
+static_assert(sizeof(tc2li_point) == sizeof(PointXYZINormal), "ABI layout");
+static_assert(sizeof(tc2li_lidar_state) == sizeof(LidarStateDev), "ABI layout");
+
+struct tc2li_lidar_map {
+    DevBuf<PointXYZINormal> d_points;
+    DevBuf<float4> d_sorted;
+    DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill;
+    int n = 0, n_buckets = 0;
+    float cell = 1.0f;
+    MapGrid grid{};
+};
+
+struct tc2li_lidar {
+    int max_scans = 0, cap = 0;  // scans per call, points per scan slot
+    size_t total = 0;
+    int table_size = 0;          // hash-table entries per scan (power of two)
+    DevBuf<VelodynePoint> d_raw;
+    DevBuf<PointXYZINormal> d_pre, d_down, d_world, d_normvec, d_cloud_ori, d_corr;
+    DevBuf<uint8_t> d_selected;
+    DevBuf<int> d_nearest_idx, d_nfound;
+    DevBuf<float> d_nearest_d;
+    DevBuf<int> d_raw_count, d_pre_count, d_down_count, d_sel_count, d_block_counts, d_block_offsets;
+    DevBuf<ScanSlot> d_slots;
+    DevBuf<SegBlock> d_blocks;
+    DevBuf<int> d_bbox, d_table_keys, d_table_counts, d_table_rank, d_vox_keys, d_member_off, d_vox_fill, d_members, d_n_vox,
+        d_status;
+    DevBuf<VoxelParams> d_vp;
+    DevBuf<LidarStateDev> d_states;
+    DevBuf<MapGrid> d_grids;
+    PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
+    std::vector<ScanSlot> slots;
+    std::vector<SegBlock> blocks;
+    int n_scans = 0;
+};
+
+namespace {
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// Builds the slot/block tables for `n_scans` scans with the given upper bounds of points per scan.
+int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st) {
+    L->slots.resize(n_scans);
+    L->blocks.clear();
+    for (int s = 0; s < n_scans; ++s) {
+        if (upper[s] > L->cap) { set_error("scan %d has %d points, slot capacity is %d", s, upper[s], L->cap); return TC2LI_ERR_CAPACITY; }
+        ScanSlot& sl = L->slots[s];
+        sl.base = s * L->cap; sl.cap = L->cap; sl.first_block = (int)L->blocks.size();
+        sl.n_blocks = (upper[s] + kSegBlock - 1) / kSegBlock;
+        for (int b = 0; b < sl.n_blocks; ++b) L->blocks.push_back(SegBlock{s, b * kSegBlock});
+    }
+    L->n_scans = n_scans;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_slots.p, L->slots.data(), n_scans * sizeof(ScanSlot), hipMemcpyHostToDevice, st));
+    if (!L->blocks.empty())
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks.p, L->blocks.data(), L->blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+    return TC2LI_OK;
+}
+
+// b1
+int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_num, double blind, float time_unit_scale, hipStream_t st) {
+    PreprocessParams prm{point_filter_num, time_unit_scale, blind * blind};
+    const int nb = (int)L->blocks.size();
+    launch_pre_count(d_raw, L->d_raw_count.p, L->d_slots.p, L->d_blocks.p, nb, prm, L->d_block_counts.p, st);
+    launch_seg_scan(L->d_slots.p, L->n_scans, L->d_block_counts.p, L->d_block_offsets.p, L->d_pre_count.p, st);
+    launch_pre_scatter(d_raw, L->d_raw_count.p, L->d_slots.p, L->d_blocks.p, nb, prm, L->d_block_offsets.p, L->d_pre.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    return TC2LI_OK;
+}
+
+// b3: in = (pts, count) per slot -> d_down / d_down_count
+int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count, float leaf, hipStream_t st) {
+    const int S = L->n_scans, nb = (int)L->blocks.size();
+    std::vector<VoxelParams> vp(S);
+    for (int s = 0; s < S; ++s) { memset(&vp[s], 0, sizeof(VoxelParams)); vp[s].table_base = s * L->table_size; vp[s].table_mask = L->table_size - 1; }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_vp.p, vp.data(), S * sizeof(VoxelParams), hipMemcpyHostToDevice, st));
+    std::vector<int> bbox_init(6 * S);
+    for (int s = 0; s < S; ++s) for (int a = 0; a < 3; ++a) { bbox_init[6 * s + a] = 0x7fffffff; bbox_init[6 * s + 3 + a] = (int)0x80000000; }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_bbox.p, bbox_init.data(), bbox_init.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    launch_fill_int(L->d_table_keys.p, (size_t)S * L->table_size, -1, st);
+    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_vox_fill.p, 0, (size_t)S * L->cap * sizeof(int), st));
+    launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
+    launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
+    launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, st);
+    launch_voxel_sort(L->d_slots.p, S, L->d_vp.p, d_in_count, L->d_table_keys.p, L->d_table_counts.p, L->d_table_rank.p, L->d_vox_keys.p,
+                      L->d_member_off.p, L->d_n_vox.p, L->d_status.p, st);
+    launch_voxel_fill(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_rank.p,
+                      L->d_member_off.p, L->d_vox_fill.p, L->d_members.p, st);
+    launch_voxel_centroid(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_vp.p, L->d_n_vox.p, L->d_member_off.p, L->d_vox_fill.p,
+                          L->d_members.p, L->d_down.p, L->d_down_count.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    return TC2LI_OK;
+}
+
+// b4-b6
+int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_body_count, tc2li_lidar_map* const* maps,
+                 const tc2li_lidar_state* states, hipStream_t st) {
+    const int S = L->n_scans, nb = (int)L->blocks.size();
+    std::vector<MapGrid> grids(S);
+    for (int s = 0; s < S; ++s) grids[s] = maps[s]->grid;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_grids.p, grids.data(), S * sizeof(MapGrid), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
+    launch_knn_plane(L->d_grids.p, d_body, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
+                     L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, st);
+    launch_sel_count(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_counts.p, st);
+    launch_seg_scan(L->d_slots.p, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
+    launch_sel_scatter(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_offsets.p, d_body, L->d_normvec.p,
+                       L->d_cloud_ori.p, L->d_corr.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    return TC2LI_OK;
+}
+
+int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) {
+    const int nb = std::min(1 << 22, std::max(1024, next_pow2(2 * std::max(m->n, 1))));
+    if (nb != m->n_buckets) {
+        TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nb));
+        TC2LI_HIP_CHECK(m->d_bucket_fill.alloc(nb));
+        TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nb + 1));
+        m->n_buckets = nb;
+    }
+    TC2LI_HIP_CHECK(m->d_sorted.ensure(std::max(m->n, 1)));
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, nb * sizeof(int), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_fill.p, 0, nb * sizeof(int), st));
+    const float inv_cell = 1.0f / m->cell;
+    launch_map_count(m->d_points.p, m->n, inv_cell, nb - 1, m->d_bucket_counts.p, st);
+    launch_map_scan(m->d_bucket_counts.p, nb, m->d_bucket_start.p, st);
+    launch_map_scatter(m->d_points.p, m->n, inv_cell, nb - 1, m->d_bucket_start.p, m->d_bucket_fill.p, m->d_sorted.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    m->grid = MapGrid{m->d_points.p, m->d_sorted.p, m->d_bucket_start.p, nb - 1, m->n, inv_cell, m->cell};
+    return TC2LI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out) {
+    if (!out || max_points_per_scan <= 0 || max_scans <= 0) { set_error("tc2li_lidar_create: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    std::unique_ptr<tc2li_lidar> L(new tc2li_lidar());
+    L->max_scans = max_scans;
+    L->cap = (max_points_per_scan + kSegBlock - 1) / kSegBlock * kSegBlock;
+    L->total = (size_t)L->cap * max_scans;
+    L->table_size = next_pow2(2 * L->cap);
+    const size_t T = L->total, S = max_scans, NB = T / kSegBlock;
+    TC2LI_HIP_CHECK(L->d_raw.alloc(T));
+    TC2LI_HIP_CHECK(L->d_pre.alloc(T)); TC2LI_HIP_CHECK(L->d_down.alloc(T)); TC2LI_HIP_CHECK(L->d_world.alloc(T));
+    TC2LI_HIP_CHECK(L->d_normvec.alloc(T)); TC2LI_HIP_CHECK(L->d_cloud_ori.alloc(T)); TC2LI_HIP_CHECK(L->d_corr.alloc(T));
+    TC2LI_HIP_CHECK(L->d_selected.alloc(T)); TC2LI_HIP_CHECK(L->d_nearest_idx.alloc(T * 5)); TC2LI_HIP_CHECK(L->d_nearest_d.alloc(T * 5));
+    TC2LI_HIP_CHECK(L->d_nfound.alloc(T));
+    TC2LI_HIP_CHECK(L->d_raw_count.alloc(S)); TC2LI_HIP_CHECK(L->d_pre_count.alloc(S)); TC2LI_HIP_CHECK(L->d_down_count.alloc(S));
+    TC2LI_HIP_CHECK(L->d_sel_count.alloc(S)); TC2LI_HIP_CHECK(L->d_block_counts.alloc(NB)); TC2LI_HIP_CHECK(L->d_block_offsets.alloc(NB));
+    TC2LI_HIP_CHECK(L->d_slots.alloc(S)); TC2LI_HIP_CHECK(L->d_blocks.alloc(NB));
+    TC2LI_HIP_CHECK(L->d_bbox.alloc(6 * S)); TC2LI_HIP_CHECK(L->d_vp.alloc(S));
+    TC2LI_HIP_CHECK(L->d_table_keys.alloc(S * L->table_size)); TC2LI_HIP_CHECK(L->d_table_counts.alloc(S * L->table_size));
+    TC2LI_HIP_CHECK(L->d_table_rank.alloc(S * L->table_size));
+    TC2LI_HIP_CHECK(L->d_vox_keys.alloc(T)); TC2LI_HIP_CHECK(L->d_member_off.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_fill.alloc(T));
+    TC2LI_HIP_CHECK(L->d_members.alloc(T)); TC2LI_HIP_CHECK(L->d_n_vox.alloc(S)); TC2LI_HIP_CHECK(L->d_status.alloc(1));
+    TC2LI_HIP_CHECK(L->d_states.alloc(S)); TC2LI_HIP_CHECK(L->d_grids.alloc(S));
+    TC2LI_HIP_CHECK(L->h_counts.alloc(4 * S + 1));
+    TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int)));
+    *out = L.release();
+    return TC2LI_OK;
+}
+
+void tc2li_lidar_destroy(tc2li_lidar* L) { delete L; }
+
+int tc2li_lidar_preprocess(tc2li_lidar* L, const tc2li_velodyne_point* raw, int n, int point_filter_num, double blind,
+                           float time_unit_scale, tc2li_point* out, int capacity) {
+    if (!L || n < 0 || (n > 0 && !raw) || point_filter_num < 1 || !out) { set_error("tc2li_lidar_preprocess: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n == 0) return 0;  // preprocess.cpp:97 `if (plsize == 0) return;`
+    int rc = setup_segments(L, 1, &n, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_raw.p, raw, (size_t)n * sizeof(VelodynePoint), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_raw_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
+    rc = run_preprocess(L, L->d_raw.p, point_filter_num, blind, time_unit_scale, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    int m = 0;
+    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_pre_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
+    if (m) TC2LI_HIP_CHECK(hipMemcpy(out, L->d_pre.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    return m;
+}
+
+int tc2li_lidar_voxel_filter(tc2li_lidar* L, const tc2li_point* in, int n, float leaf, tc2li_point* out, int capacity) {
+    if (!L || n < 0 || (n > 0 && !in) || !(leaf > 0) || !out) { set_error("tc2li_lidar_voxel_filter: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n == 0) return 0;
+    int rc = setup_segments(L, 1, &n, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre.p, in, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
+    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    int m = 0, status = 0;
+    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_down_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    TC2LI_HIP_CHECK(hipMemcpy(&status, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
+    if (m) TC2LI_HIP_CHECK(hipMemcpy(out, L->d_down.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    return m;
+}
+
+int tc2li_lidar_map_create(tc2li_lidar_map** out) {
+    if (!out) return TC2LI_ERR_INVALID;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    tc2li_lidar_map* m = new tc2li_lidar_map();
+    int rc = rebuild_grid(m, nullptr);
+    if (rc != TC2LI_OK) { delete m; return rc; }
+    *out = m;
+    return TC2LI_OK;
+}
+void tc2li_lidar_map_destroy(tc2li_lidar_map* m) { delete m; }
+int tc2li_lidar_map_size(const tc2li_lidar_map* m) { return m ? m->n : TC2LI_ERR_INVALID; }
+
+static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool reset) {
+    if (!m || n < 0 || (n > 0 && !pts)) { set_error("tc2li_lidar_map: invalid argument"); return TC2LI_ERR_INVALID; }
+    const int old = reset ? 0 : m->n;
+    if ((size_t)old + n > m->d_points.n) {
+        DevBuf<PointXYZINormal> bigger;
+        TC2LI_HIP_CHECK(bigger.alloc(((size_t)old + n) * 3 / 2 + 1024));
+        if (old) TC2LI_HIP_CHECK(hipMemcpy(bigger.p, m->d_points.p, (size_t)old * sizeof(PointXYZINormal), hipMemcpyDeviceToDevice));
+        std::swap(bigger.p, m->d_points.p);
+        std::swap(bigger.n, m->d_points.n);
+    }
+    if (n) TC2LI_HIP_CHECK(hipMemcpy(m->d_points.p + old, pts, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    m->n = old + n;
+    int rc = rebuild_grid(m, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return m->n;
+}
+int tc2li_lidar_map_build(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, true); }
+int tc2li_lidar_map_add(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, false); }
+
+int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n,
+                                   const tc2li_lidar_state* state, tc2li_point* feats_down_world, uint8_t* point_selected,
+                                   tc2li_point* normvec, tc2li_point* nearest_points, float* nearest_sqdist, int32_t* n_nearest,
+                                   tc2li_point* laser_cloud_ori, tc2li_point* corr_normvect, int capacity) {
+    if (!L || !map || n < 0 || (n > 0 && !feats_down_body) || !state) { set_error("tc2li_lidar_feature_extraction: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n == 0) return 0;
+    int rc = setup_segments(L, 1, &n, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
+    rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, state, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    int m = 0;
+    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (feats_down_world) TC2LI_HIP_CHECK(hipMemcpy(feats_down_world, L->d_world.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (point_selected) TC2LI_HIP_CHECK(hipMemcpy(point_selected, L->d_selected.p, (size_t)n, hipMemcpyDeviceToHost));
+    if (normvec) TC2LI_HIP_CHECK(hipMemcpy(normvec, L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (n_nearest) TC2LI_HIP_CHECK(hipMemcpy(n_nearest, L->d_nfound.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (nearest_sqdist) TC2LI_HIP_CHECK(hipMemcpy(nearest_sqdist, L->d_nearest_d.p, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    if (nearest_points) {
+        std::vector<int> idx((size_t)n * 5);
+        std::vector<PointXYZINormal> mp(map->n);
+        TC2LI_HIP_CHECK(hipMemcpy(idx.data(), L->d_nearest_idx.p, idx.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (map->n) TC2LI_HIP_CHECK(hipMemcpy(mp.data(), map->d_points.p, (size_t)map->n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < idx.size(); ++k)
+            if (idx[k] >= 0) memcpy(&nearest_points[k], &mp[idx[k]], sizeof(PointXYZINormal));
+            else memset(&nearest_points[k], 0, sizeof(PointXYZINormal));
+    }
+    if (m > capacity && (laser_cloud_ori || corr_normvect)) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
+    if (laser_cloud_ori && m) TC2LI_HIP_CHECK(hipMemcpy(laser_cloud_ori, L->d_cloud_ori.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (corr_normvect && m) TC2LI_HIP_CHECK(hipMemcpy(corr_normvect, L->d_corr.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    return m;
+}
+
+int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
+                               int point_filter_num, double blind, float time_unit_scale, float leaf,
+                               tc2li_lidar_map* const* maps, const tc2li_lidar_state* states, int32_t* n_preprocessed,
+                               int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
+                               tc2li_point* corr_normvect, int capacity, void* stream_) {
+    if (!L || n_scans < 0 || n_scans > (L ? L->max_scans : 0) || !dev_raw || !raw_offsets || !maps || !states || point_filter_num < 1 ||
+        !(leaf > 0)) {
+        set_error("tc2li_lidar_frontend_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_scans == 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    std::vector<int> upper(n_scans);
+    for (int s = 0; s < n_scans; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
+    int rc = setup_segments(L, n_scans, upper.data(), st);
+    if (rc != TC2LI_OK) return rc;
+    // raw scans are packed back to back by the caller; copy each into its slot (device to device) so that every later
+    // pass can use the fixed slot layout
+    for (int s = 0; s < n_scans; ++s)
+        if (upper[s])
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw.p + (size_t)s * L->cap, (const VelodynePoint*)dev_raw + raw_offsets[s],
+                                           (size_t)upper[s] * sizeof(VelodynePoint), hipMemcpyDeviceToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), n_scans * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = run_preprocess(L, L->d_raw.p, point_filter_num, blind, time_unit_scale, st);
+    if (rc != TC2LI_OK) return rc;
+    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, st);
+    if (rc != TC2LI_OK) return rc;
+    rc = run_features(L, L->d_down.p, L->d_down_count.p, maps, states, st);
+    if (rc != TC2LI_OK) return rc;
+    int* hc = L->h_counts.p;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc + n_scans, L->d_down_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 2 * n_scans, L->d_sel_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * n_scans, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    for (int s = 0; s < n_scans; ++s) {
+        if (n_preprocessed) n_preprocessed[s] = hc[s];
+        if (n_downsampled) n_downsampled[s] = hc[n_scans + s];
+        if (n_selected) n_selected[s] = hc[2 * n_scans + s];
+        const int m = hc[2 * n_scans + s];
+        if ((laser_cloud_ori || corr_normvect) && m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
+        if (laser_cloud_ori && m)
+            TC2LI_HIP_CHECK(hipMemcpyAsync(laser_cloud_ori + (size_t)s * capacity, L->d_cloud_ori.p + (size_t)s * L->cap,
+                                           (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
+        if (corr_normvect && m)
+            TC2LI_HIP_CHECK(hipMemcpyAsync(corr_normvect + (size_t)s * capacity, L->d_corr.p + (size_t)s * L->cap,
+                                           (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
+    }
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    return n_scans;
+}
+
+}  // extern "C"

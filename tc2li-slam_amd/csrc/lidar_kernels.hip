@@ -1,0 +1,722 @@
+// gfx950 kernels of the LiDAR front end on the camera-LiDAR path:
+// preprocess (stride decimation + blind cut, ordered compaction), PCL-style voxel-grid centroid filter, uniform
+// hash-grid map with exact 5-nearest-neighbour search, 5-point plane fit with the reference's gates, ordered
+// compaction of the selected points.  All passes are segmented over the scans of a batch; per-scan counts stay in
+// device memory so that the stages chain without host synchronisation.  Float work uses individually rounded IEEE
+// operations (the library is built with -ffp-contract=off), sums are taken in the CPU order: results are bit-equal
+// to the CPU path.
+#include <hip/hip_runtime.h>
+// Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
+// `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
+// the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "lidar_device.hpp"
+
+namespace tc2li {
+
+// ---- helpers ------------------------------------------------------------------------------------------------------
+// Exclusive prefix of a per-thread flag over a 1024-thread block (16 wavefronts); returns the block total in `total`.
+__device__ __forceinline__ int block_flag_scan(bool f, int* s_wave, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kSegBlock / 64; ++k) {
+        const int c = s_wave[k];
+        off += k < wave ? c : 0;
+        tot += c;
+    }
+    total = tot;
+    __syncthreads();
+    return off + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__global__ void k_fill_int(int* p, size_t n, int v) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_int(int* p, size_t n, int v, hipStream_t st) {
+    if (n == 0) return;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_fill_int, dim3(grid), dim3(256), 0, st, p, n, v);
+}
+
+// ---- b1: Preprocess::velodyne_handler, non-feature branch (preprocess.cpp:145-166) ---------------------------------
+__device__ __forceinline__ bool pre_keep(const VelodynePoint& p, int i, const PreprocessParams& prm) {
+    if (i % prm.point_filter_num != 0) return false;
+    const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
+    return (double)r2 > prm.blind_sq;
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_pre_count(const VelodynePoint* __restrict__ raw, const int* __restrict__ raw_count,
+                                                         const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                         PreprocessParams prm, int* __restrict__ block_counts) {
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int i = b.start + threadIdx.x;
+    bool f = false;
+    if (i < raw_count[b.scan]) f = pre_keep(raw[sl.base + i], i, prm);
+    const int c = __syncthreads_count(f);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
+}
+
+// Exclusive scan of the block counts of each scan (one workgroup per scan).
+__global__ __launch_bounds__(256) void k_seg_scan(const ScanSlot* __restrict__ slots, const int* __restrict__ block_counts,
+                                                  int* __restrict__ block_offsets, int* __restrict__ totals) {
+    __shared__ int s_part[256];
+    const ScanSlot sl = slots[blockIdx.x];
+    const int nb = sl.n_blocks, per = (nb + 255) / 256, tid = threadIdx.x;
+    const int lo = tid * per, hi = min(lo + per, nb);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += block_counts[sl.first_block + k];
+    s_part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele over 256 partials
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int k = lo; k < hi; ++k) {
+        block_offsets[sl.first_block + k] = run;
+        run += block_counts[sl.first_block + k];
+    }
+    if (tid == 255) totals[blockIdx.x] = s_part[255];
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_pre_scatter(const VelodynePoint* __restrict__ raw, const int* __restrict__ raw_count,
+                                                           const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                           PreprocessParams prm, const int* __restrict__ block_offsets,
+                                                           PointXYZINormal* __restrict__ out) {
+    __shared__ int s_wave[kSegBlock / 64];
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int i = b.start + threadIdx.x;
+    bool f = false;
+    VelodynePoint p;
+    if (i < raw_count[b.scan]) { p = raw[sl.base + i]; f = pre_keep(p, i, prm); }
+    int total;
+    const int pos = block_flag_scan(f, s_wave, total);
+    if (f) {
+        PointXYZINormal o;
+        o.x = p.x; o.y = p.y; o.z = p.z; o.pad0 = 1.0f;
+        o.normal_x = 0; o.normal_y = 0; o.normal_z = 0; o.pad1 = 0;
+        o.intensity = p.intensity;
+        o.curvature = p.time * prm.time_unit_scale;  // milliseconds (preprocess.cpp:157)
+        o.pad2 = 0; o.pad3 = 0;
+        out[sl.base + block_offsets[blockIdx.x] + pos] = o;
+    }
+}
+
+// ---- b3: pcl::VoxelGrid<PointXYZINormal>::filter (LidarFrontEnd.cpp:712-714, 913-915) -------------------------------
+__device__ __forceinline__ int enc_float(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float dec_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__device__ __forceinline__ bool finite3(const PointXYZINormal& p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+
+__global__ __launch_bounds__(kSegBlock) void k_voxel_bbox(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                          const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                          int* __restrict__ bbox_enc) {
+    __shared__ int s_min[3], s_max[3];
+    const SegBlock b = blocks[blockIdx.x];
+    if (b.start >= count[b.scan]) return;
+    const ScanSlot sl = slots[b.scan];
+    if (threadIdx.x < 3) { s_min[threadIdx.x] = 0x7fffffff; s_max[threadIdx.x] = (int)0x80000000; }
+    __syncthreads();
+    const int i = b.start + threadIdx.x;
+    if (i < count[b.scan]) {
+        const PointXYZINormal p = pts[sl.base + i];
+        if (finite3(p)) {
+            atomicMin(&s_min[0], enc_float(p.x)); atomicMax(&s_max[0], enc_float(p.x));
+            atomicMin(&s_min[1], enc_float(p.y)); atomicMax(&s_max[1], enc_float(p.y));
+            atomicMin(&s_min[2], enc_float(p.z)); atomicMax(&s_max[2], enc_float(p.z));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        atomicMin(&bbox_enc[b.scan * 6 + threadIdx.x], s_min[threadIdx.x]);
+        atomicMax(&bbox_enc[b.scan * 6 + 3 + threadIdx.x], s_max[threadIdx.x]);
+    }
+}
+
+__global__ void k_voxel_params(const int* __restrict__ bbox_enc, const int* __restrict__ count, int nscans, float leaf,
+                               VoxelParams* __restrict__ vp) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nscans) return;
+    VoxelParams v = vp[s];  // table_base / table_mask were filled by the host
+    const float inv = 1.0f / leaf;
+    int div_b[3];
+    long long cells = 1;
+    bool any = count[s] > 0 && bbox_enc[s * 6] != 0x7fffffff;
+    for (int a = 0; a < 3; ++a) {
+        const float mn = any ? dec_float(bbox_enc[s * 6 + a]) : 0.f, mx = any ? dec_float(bbox_enc[s * 6 + 3 + a]) : 0.f;
+        cells *= (long long)((mx - mn) * inv) + 1;
+        v.min_b[a] = (int)floorf(mn * inv);
+        div_b[a] = (int)floorf(mx * inv) - v.min_b[a] + 1;
+    }
+    v.passthrough = cells > 2147483647ll ? 1 : 0;
+    v.mul[0] = 1; v.mul[1] = div_b[0]; v.mul[2] = div_b[0] * div_b[1];
+    vp[s] = v;
+}
+
+__device__ __forceinline__ int voxel_index(const PointXYZINormal& p, float inv, const VoxelParams& v) {
+    const int i0 = (int)(floorf(p.x * inv) - (float)v.min_b[0]);
+    const int i1 = (int)(floorf(p.y * inv) - (float)v.min_b[1]);
+    const int i2 = (int)(floorf(p.z * inv) - (float)v.min_b[2]);
+    return i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2];
+}
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                            const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                            float leaf, const VoxelParams* __restrict__ vp,
+                                                            int* __restrict__ table_keys, int* __restrict__ table_counts) {
+    const SegBlock b = blocks[blockIdx.x];
+    const int i = b.start + threadIdx.x;
+    if (i >= count[b.scan]) return;
+    const VoxelParams v = vp[b.scan];
+    if (v.passthrough) return;
+    const PointXYZINormal p = pts[slots[b.scan].base + i];
+    if (!finite3(p)) return;
+    const int idx = voxel_index(p, 1.0f / leaf, v);
+    uint32_t h = hash_u32((uint32_t)idx) & (uint32_t)v.table_mask;
+    for (;;) {
+        const int prev = atomicCAS(&table_keys[v.table_base + h], -1, idx);
+        if (prev == -1 || prev == idx) { atomicAdd(&table_counts[v.table_base + h], 1); break; }
+        h = (h + 1) & (uint32_t)v.table_mask;
+    }
+}
+
+__device__ __forceinline__ int table_find(const int* __restrict__ table_keys, const VoxelParams& v, int idx) {
+    uint32_t h = hash_u32((uint32_t)idx) & (uint32_t)v.table_mask;
+    while (table_keys[v.table_base + h] != idx) h = (h + 1) & (uint32_t)v.table_mask;
+    return v.table_base + (int)h;
+}
+
+// One workgroup per scan: gather the occupied voxel keys, bitonic-sort them ascending in LDS (PCL emits voxels in
+// ascending index order), publish rank and member offsets.
+constexpr int kMaxVoxelsPerScan = 32768;
+__global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict__ slots, const VoxelParams* __restrict__ vp,
+                                                     const int* __restrict__ count, const int* __restrict__ table_keys,
+                                                     const int* __restrict__ table_counts, int* __restrict__ table_rank,
+                                                     int* __restrict__ vox_keys, int* __restrict__ vox_member_off,
+                                                     int* __restrict__ n_vox, int* __restrict__ status) {
+    extern __shared__ int s_keys[];  // kMaxVoxelsPerScan
+    __shared__ int s_n;
+    __shared__ int s_part[1024];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const ScanSlot sl = slots[s];
+    const VoxelParams v = vp[s];
+    if (v.passthrough) { if (tid == 0) n_vox[s] = count[s]; return; }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int tsize = v.table_mask + 1;
+    for (int k = tid; k < tsize; k += 1024) {
+        const int key = table_keys[v.table_base + k];
+        if (key != -1) {
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < kMaxVoxelsPerScan) s_keys[pos] = key;
+        }
+    }
+    __syncthreads();
+    int n = s_n;
+    if (n > kMaxVoxelsPerScan) { if (tid == 0) { atomicExch(status, 1); n_vox[s] = 0; } return; }
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int k = n + tid; k < np2; k += 1024) s_keys[k] = 0x7fffffff;
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int k = tid; k < (np2 >> 1); k += 1024) {
+                const int lo = (k / stride) * (stride << 1) + (k % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const int a = s_keys[lo], b = s_keys[hi];
+                if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // rank -> table, member counts -> exclusive offsets (scan in global memory, this block only)
+    const int per = (n + 1023) / 1024, lo = tid * per, hi = min(lo + per, n);
+    int sum = 0;
+    for (int r = lo; r < hi; ++r) {
+        const int key = s_keys[r];
+        const int slot = table_find(table_keys, v, key);
+        table_rank[slot] = r;
+        vox_keys[sl.base + r] = key;
+        sum += table_counts[slot];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int r = lo; r < hi; ++r) {
+        vox_member_off[sl.base + r] = run;
+        run += table_counts[table_find(table_keys, v, s_keys[r])];
+    }
+    if (tid == 0) n_vox[s] = n;
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                          const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                          float leaf, const VoxelParams* __restrict__ vp,
+                                                          const int* __restrict__ table_keys, const int* __restrict__ table_rank,
+                                                          const int* __restrict__ vox_member_off, int* __restrict__ vox_fill,
+                                                          int* __restrict__ members) {
+    const SegBlock b = blocks[blockIdx.x];
+    const int i = b.start + threadIdx.x;
+    if (i >= count[b.scan]) return;
+    const VoxelParams v = vp[b.scan];
+    if (v.passthrough) return;
+    const ScanSlot sl = slots[b.scan];
+    const PointXYZINormal p = pts[sl.base + i];
+    if (!finite3(p)) return;
+    const int r = table_rank[table_find(table_keys, v, voxel_index(p, 1.0f / leaf, v))];
+    const int pos = atomicAdd(&vox_fill[sl.base + r], 1);
+    members[sl.base + vox_member_off[sl.base + r] + pos] = i;
+}
+
+// One thread per voxel: order its members by point index (the order PCL's sorted index vector yields), sum every
+// field sequentially in float, divide by the count (pcl::CentroidPoint with all fields).
+__global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                        const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                        const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
+                                                        const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
+                                                        int* __restrict__ members, PointXYZINormal* __restrict__ out,
+                                                        int* __restrict__ out_count) {
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int nv = n_vox[b.scan];
+    if (b.start == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
+    for (int r = b.start + threadIdx.x; r < min(b.start + kSegBlock, nv); r += 256) {
+        if (vp[b.scan].passthrough) { out[sl.base + r] = pts[sl.base + r]; continue; }
+        int* m = members + sl.base + vox_member_off[sl.base + r];
+        const int n = vox_fill[sl.base + r];
+        for (int a = 1; a < n; ++a) {  // insertion sort, n is small
+            const int key = m[a];
+            int c = a - 1;
+            while (c >= 0 && m[c] > key) { m[c + 1] = m[c]; --c; }
+            m[c + 1] = key;
+        }
+        float sx = 0, sy = 0, sz = 0, snx = 0, sny = 0, snz = 0, si = 0, sc = 0;
+        for (int a = 0; a < n; ++a) {
+            const PointXYZINormal p = pts[sl.base + m[a]];
+            sx += p.x; sy += p.y; sz += p.z;
+            snx += p.normal_x; sny += p.normal_y; snz += p.normal_z;
+            si += p.intensity; sc += p.curvature;
+        }
+        const float fn = (float)n;
+        PointXYZINormal o;
+        o.x = sx / fn; o.y = sy / fn; o.z = sz / fn; o.pad0 = 1.0f;
+        const float nn = snx * snx + sny * sny + snz * snz;
+        if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
+        o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
+        o.intensity = si / fn; o.curvature = sc / fn; o.pad2 = 0; o.pad3 = 0;
+        out[sl.base + r] = o;
+    }
+}
+
+// ---- b5: map spatial index (replaces ikd-Tree Build/Add as a uniform hash grid) -----------------------------------
+__device__ __forceinline__ uint32_t cell_hash(int cx, int cy, int cz) {
+    return hash_u32((uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u);
+}
+
+__global__ void k_map_count(const PointXYZINormal* __restrict__ pts, int n, float inv_cell, int mask, int* __restrict__ bucket_counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PointXYZINormal p = pts[i];
+    const uint32_t h = cell_hash((int)floorf(p.x * inv_cell), (int)floorf(p.y * inv_cell), (int)floorf(p.z * inv_cell)) & (uint32_t)mask;
+    atomicAdd(&bucket_counts[h], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_map_scan(const int* __restrict__ bucket_counts, int n_buckets, int* __restrict__ bucket_start) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, per = (n_buckets + 1023) / 1024, lo = tid * per, hi = min(lo + per, n_buckets);
+    int sum = 0;
+    for (int k = lo; k < hi; ++k) sum += bucket_counts[k];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int k = lo; k < hi; ++k) { bucket_start[k] = run; run += bucket_counts[k]; }
+    if (tid == 1023) bucket_start[n_buckets] = s_part[1023];
+}
+
+__global__ void k_map_scatter(const PointXYZINormal* __restrict__ pts, int n, float inv_cell, int mask,
+                              const int* __restrict__ bucket_start, int* __restrict__ bucket_fill, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PointXYZINormal p = pts[i];
+    const uint32_t h = cell_hash((int)floorf(p.x * inv_cell), (int)floorf(p.y * inv_cell), (int)floorf(p.z * inv_cell)) & (uint32_t)mask;
+    const int pos = bucket_start[h] + atomicAdd(&bucket_fill[h], 1);
+    sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ---- b4 + b5 + b6: pointBodyToWorld, 5-NN, EstiPlane and the gates of feature_extraction --------------------------
+struct Cand { float d, x; int idx; };
+// ikd-Tree's PointType_CMP (ikd_Tree.h:93-109): distance, then x when the distances coincide
+__device__ __forceinline__ bool cand_less(const Cand& a, const Cand& b) {
+    if ((double)fabsf(a.d - b.d) < 1e-10) return a.x < b.x;
+    return a.d < b.d;
+}
+__device__ __forceinline__ void top5_insert(Cand (&best)[5], int& nb, const Cand& c) {
+    if (nb == 5 && !cand_less(c, best[4])) return;
+    int pos = nb < 5 ? nb : 4;
+    while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
+    best[pos] = c;
+    if (nb < 5) ++nb;
+}
+
+// Least squares of the 5x3 system by Householder QR with column pivoting (what colPivHouseholderQr().solve() does),
+// same operation order as the CPU statement.
+__device__ void qr_solve_5x3(float (&A)[5][3], float (&b)[5], float (&x)[3]) {
+    constexpr int R = 5, C = 3;
+    constexpr float kEps = 1.1920928955078125e-07f, kMin = 1.17549435082228750797e-38f;
+    float normU[3], normD[3];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        float s = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) s += A[i][j] * A[i][j];
+        normU[j] = normD[j] = sqrtf(s);
+    }
+    const float maxn = fmaxf(normU[0], fmaxf(normU[1], normU[2]));
+    const float thr_helper = __fdiv_rn((maxn * kEps) * (maxn * kEps), (float)R);
+    const float downdate_thr = sqrtf(kEps);
+    int perm[3] = {0, 1, 2};
+    int nonzero = C;
+    float tau[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        int big = k;
+#pragma unroll
+        for (int j = k + 1; j < C; ++j) if (normU[j] > normU[big]) big = j;
+        const float big_sq = normU[big] * normU[big];
+        if (nonzero == C && big_sq < thr_helper * (float)(R - k)) nonzero = k;
+        if (big != k) {
+#pragma unroll
+            for (int j = k + 1; j < C; ++j)
+                if (j == big) {
+#pragma unroll
+                    for (int i = 0; i < R; ++i) { const float t = A[i][k]; A[i][k] = A[i][j]; A[i][j] = t; }
+                    float t = normU[k]; normU[k] = normU[j]; normU[j] = t;
+                    t = normD[k]; normD[k] = normD[j]; normD[j] = t;
+                    const int ti = perm[k]; perm[k] = perm[j]; perm[j] = ti;
+                }
+        }
+        float tail = 0;
+#pragma unroll
+        for (int i = k + 1; i < R; ++i) tail += A[i][k] * A[i][k];
+        const float c0 = A[k][k];
+        float beta;
+        if (tail <= kMin) {
+            tau[k] = 0;
+            beta = c0;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) A[i][k] = 0;
+        } else {
+            beta = sqrtf(c0 * c0 + tail);
+            if (c0 >= 0) beta = -beta;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) A[i][k] = __fdiv_rn(A[i][k], c0 - beta);
+            tau[k] = __fdiv_rn(beta - c0, beta);
+        }
+        A[k][k] = beta;
+        if (tau[k] != 0) {
+#pragma unroll
+            for (int j = k + 1; j < C; ++j) {
+                float t = 0;
+#pragma unroll
+                for (int i = k + 1; i < R; ++i) t += A[i][k] * A[i][j];
+                t += A[k][j];
+                A[k][j] -= tau[k] * t;
+#pragma unroll
+                for (int i = k + 1; i < R; ++i) A[i][j] -= tau[k] * A[i][k] * t;
+            }
+        }
+#pragma unroll
+        for (int j = k + 1; j < C; ++j) {
+            if (normU[j] != 0) {
+                float temp = __fdiv_rn(fabsf(A[k][j]), normU[j]);
+                temp = (1.0f + temp) * (1.0f - temp);
+                temp = temp < 0 ? 0 : temp;
+                const float r = __fdiv_rn(normU[j], normD[j]);
+                const float temp2 = temp * (r * r);
+                if (temp2 <= downdate_thr) {
+                    float s = 0;
+#pragma unroll
+                    for (int i = k + 1; i < R; ++i) s += A[i][j] * A[i][j];
+                    normD[j] = sqrtf(s);
+                    normU[j] = normD[j];
+                } else {
+                    normU[j] *= sqrtf(temp);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        if (k < nonzero && tau[k] != 0) {
+            float t = 0;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) t += A[i][k] * b[i];
+            t += b[k];
+            b[k] -= tau[k] * t;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) b[i] -= tau[k] * A[i][k] * t;
+        }
+    }
+    float c[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = C - 1; i >= 0; --i) {
+        if (i < nonzero) {
+            float s = b[i];
+#pragma unroll
+            for (int j = i + 1; j < C; ++j) if (j < nonzero) s -= A[i][j] * c[j];
+            c[i] = __fdiv_rn(s, A[i][i]);
+        }
+    }
+    x[0] = x[1] = x[2] = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i)
+        if (i < nonzero) {
+#pragma unroll
+            for (int j = 0; j < C; ++j) if (perm[i] == j) x[j] = c[i];
+        }
+}
+
+constexpr int kMaxRing = 6;
+
+__global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ grids,
+                                                   const PointXYZINormal* __restrict__ body, const int* __restrict__ count,
+                                                   const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                   const LidarStateDev* __restrict__ states, PointXYZINormal* __restrict__ world,
+                                                   uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
+                                                   int* __restrict__ nearest_idx, float* __restrict__ nearest_d,
+                                                   int* __restrict__ nfound) {
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int n = count[b.scan];
+    const MapGrid grid = grids[b.scan];
+    const PointXYZINormal* __restrict__ map_pts = grid.points;
+    for (int i = b.start + threadIdx.x; i < min(b.start + kSegBlock, n); i += 256) {
+        const PointXYZINormal pb = body[sl.base + i];
+        const LidarStateDev& st = states[b.scan];
+        // pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
+        const double bx = pb.x, by = pb.y, bz = pb.z;
+        double t[3], g[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) t[r] = (st.off_r[3 * r] * bx + st.off_r[3 * r + 1] * by + st.off_r[3 * r + 2] * bz) + st.off_t[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g[r] = (st.rot[3 * r] * t[0] + st.rot[3 * r + 1] * t[1] + st.rot[3 * r + 2] * t[2]) + st.pos[r];
+        PointXYZINormal pw;
+        pw.x = (float)g[0]; pw.y = (float)g[1]; pw.z = (float)g[2]; pw.pad0 = 1.0f;
+        pw.normal_x = 0; pw.normal_y = 0; pw.normal_z = 0; pw.pad1 = 0;
+        pw.intensity = pb.intensity; pw.curvature = 0; pw.pad2 = 0; pw.pad3 = 0;
+        world[sl.base + i] = pw;
+
+        // exact 5 nearest map points: grow a cube of grid cells until the 5th distance is inside the searched cube
+        Cand best[5];
+        int nb = 0;
+        const int cx = (int)floorf(pw.x * grid.inv_cell), cy = (int)floorf(pw.y * grid.inv_cell), cz = (int)floorf(pw.z * grid.inv_cell);
+        bool done = grid.n_points == 0;
+        for (int ring = 0; ring <= kMaxRing && !done; ++ring) {
+            for (int dz = -ring; dz <= ring; ++dz)
+                for (int dy = -ring; dy <= ring; ++dy)
+                    for (int dx = -ring; dx <= ring; ++dx) {
+                        if (max(abs(dx), max(abs(dy), abs(dz))) != ring) continue;
+                        const int qx = cx + dx, qy = cy + dy, qz = cz + dz;
+                        const uint32_t h = cell_hash(qx, qy, qz) & (uint32_t)grid.n_buckets_mask;
+                        for (int k = grid.bucket_start[h]; k < grid.bucket_start[h + 1]; ++k) {
+                            const float4 m = grid.pts[k];
+                            if ((int)floorf(m.x * grid.inv_cell) != qx || (int)floorf(m.y * grid.inv_cell) != qy ||
+                                (int)floorf(m.z * grid.inv_cell) != qz)
+                                continue;
+                            Cand c;
+                            c.d = (pw.x - m.x) * (pw.x - m.x) + (pw.y - m.y) * (pw.y - m.y) + (pw.z - m.z) * (pw.z - m.z);
+                            c.x = m.x;
+                            c.idx = __float_as_int(m.w);
+                            top5_insert(best, nb, c);
+                        }
+                    }
+            if (nb == 5) {
+                // every unsearched point is at least `edge` away from the query
+                const float lo = (float)ring * grid.cell, hi = (float)(ring + 1) * grid.cell;
+                const float fx = pw.x - (float)cx * grid.cell, fy = pw.y - (float)cy * grid.cell, fz = pw.z - (float)cz * grid.cell;
+                float edge = fminf(fminf(fx + lo, hi - fx), fminf(fminf(fy + lo, hi - fy), fminf(fz + lo, hi - fz)));
+                edge = fmaxf(edge, 0.f);
+                if (best[4].d < edge * edge * 0.999f) done = true;
+            }
+        }
+        if (!done) {  // rare: isolated query -> exhaustive scan keeps the result exact
+            nb = 0;
+            for (int k = 0; k < grid.n_points; ++k) {
+                const float4 m = grid.pts[k];
+                Cand c;
+                c.d = (pw.x - m.x) * (pw.x - m.x) + (pw.y - m.y) * (pw.y - m.y) + (pw.z - m.z) * (pw.z - m.z);
+                c.x = m.x;
+                c.idx = __float_as_int(m.w);
+                top5_insert(best, nb, c);
+            }
+        }
+        nfound[sl.base + i] = nb;
+        for (int k = 0; k < 5; ++k) {
+            nearest_idx[(size_t)(sl.base + i) * 5 + k] = k < nb ? best[k].idx : -1;
+            nearest_d[(size_t)(sl.base + i) * 5 + k] = k < nb ? best[k].d : 0.f;
+        }
+
+        // feature_extraction gates (LidarFrontEnd.cpp:1032-1055)
+        uint8_t sel = 0;
+        PointXYZINormal nv;
+        nv.x = 0; nv.y = 0; nv.z = 0; nv.pad0 = 1.0f; nv.normal_x = 0; nv.normal_y = 0; nv.normal_z = 0; nv.pad1 = 0;
+        nv.intensity = 0; nv.curvature = 0; nv.pad2 = 0; nv.pad3 = 0;
+        if (nb == 5 && !(best[4].d > 5.f)) {
+            float A[5][3], rhs[5], sol[3], px[5], py[5], pz[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const PointXYZINormal m = map_pts[best[j].idx];
+                px[j] = m.x; py[j] = m.y; pz[j] = m.z;
+                A[j][0] = m.x; A[j][1] = m.y; A[j][2] = m.z;
+                rhs[j] = -1.0f;
+            }
+            qr_solve_5x3(A, rhs, sol);
+            const float nrm = sqrtf(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+            const float pa = __fdiv_rn(sol[0], nrm), pbn = __fdiv_rn(sol[1], nrm), pc = __fdiv_rn(sol[2], nrm);
+            const float pd = (float)(1.0 / (double)nrm);
+            bool plane = true;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (fabsf(pa * px[j] + pbn * py[j] + pc * pz[j] + pd) > 0.1f) plane = false;
+            if (plane) {
+                const float pd2 = pa * pw.x + pbn * pw.y + pc * pw.z + pd;
+                const double pnorm = sqrt(bx * bx + by * by + bz * bz);
+                const float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(pnorm));
+                if ((double)s > 0.9) {
+                    sel = 1;
+                    nv.x = pa; nv.y = pbn; nv.z = pc; nv.intensity = pd2;
+                }
+            }
+        }
+        selected[sl.base + i] = sel;
+        normvec[sl.base + i] = nv;
+    }
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_sel_count(const uint8_t* __restrict__ selected, const int* __restrict__ count,
+                                                         const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                         int* __restrict__ block_counts) {
+    const SegBlock b = blocks[blockIdx.x];
+    const int i = b.start + threadIdx.x;
+    const bool f = i < count[b.scan] && selected[slots[b.scan].base + i];
+    const int c = __syncthreads_count(f);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
+}
+
+__global__ __launch_bounds__(kSegBlock) void k_sel_scatter(const uint8_t* __restrict__ selected, const int* __restrict__ count,
+                                                           const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                           const int* __restrict__ block_offsets, const PointXYZINormal* __restrict__ body,
+                                                           const PointXYZINormal* __restrict__ normvec,
+                                                           PointXYZINormal* __restrict__ cloud_ori, PointXYZINormal* __restrict__ corr_norm) {
+    __shared__ int s_wave[kSegBlock / 64];
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int i = b.start + threadIdx.x;
+    const bool f = i < count[b.scan] && selected[sl.base + i];
+    int total;
+    const int pos = block_flag_scan(f, s_wave, total);
+    if (f) {
+        const int o = sl.base + block_offsets[blockIdx.x] + pos;
+        cloud_ori[o] = body[sl.base + i];
+        corr_norm[o] = normvec[sl.base + i];
+    }
+}
+
+// ---- launch wrappers ----------------------------------------------------------------------------------------------
+void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                      PreprocessParams prm, int* block_counts, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
+}
+void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st) {
+    if (nscans) hipLaunchKernelGGL(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);
+}
+void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                        PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_pre_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_offsets, out);
+}
+void launch_voxel_bbox(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                       int* bbox_enc, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_bbox, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, bbox_enc);
+}
+void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* slots, int nscans, float leaf, VoxelParams* vp,
+                         hipStream_t st) {
+    (void)slots;
+    if (nscans) hipLaunchKernelGGL(k_voxel_params, dim3((nscans + 63) / 64), dim3(64), 0, st, bbox_enc, count, nscans, leaf, vp);
+}
+void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts);
+}
+void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
+                       const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
+                       hipStream_t st) {
+    if (!nscans) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_voxel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxVoxelsPerScan * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
+                       table_rank, vox_keys, vox_member_off, n_vox, status);
+}
+void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                       float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* vox_member_off,
+                       int* vox_fill, int* members, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_rank, vox_member_off, vox_fill, members);
+}
+void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                           const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
+                           PointXYZINormal* out, int* out_count, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
+}
+void launch_map_count(const PointXYZINormal* pts, int n, float inv_cell, int mask, int* bucket_counts, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, inv_cell, mask, bucket_counts);
+}
+void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st) {
+    hipLaunchKernelGGL(k_map_scan, dim3(1), dim3(1024), 0, st, bucket_counts, n_buckets, bucket_start);
+}
+void launch_map_scatter(const PointXYZINormal* pts, int n, float inv_cell, int mask, const int* bucket_start, int* bucket_fill,
+                        float4* sorted, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, inv_cell, mask, bucket_start, bucket_fill, sorted);
+}
+void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
+                      const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
+                      uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d, int* nfound, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_knn_plane, dim3(nblocks), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected, normvec, nearest_idx, nearest_d, nfound);
+}
+void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                      int* block_counts, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_sel_count, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_counts);
+}
+void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                        const int* block_offsets, const PointXYZINormal* body, const PointXYZINormal* normvec,
+                        PointXYZINormal* cloud_ori, PointXYZINormal* corr_norm, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_sel_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_offsets, body, normvec, cloud_ori, corr_norm);
+}
+
+}  // namespace tc2li

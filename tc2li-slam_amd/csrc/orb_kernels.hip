@@ -1,6 +1,10 @@
 // gfx950 kernels of the ORB extractor (replaces the internals of SF/src/ORBextractor.cc).
 // All arithmetic is integer or explicitly rounded float, so the output is bit-identical to the CPU path.
 #include <hip/hip_runtime.h>
+// Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
+// `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
+// the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
+#pragma clang fp contract(off)
 #include <stdint.h>
 
 #include "det_math.hpp"

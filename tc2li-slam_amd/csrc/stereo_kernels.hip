@@ -4,6 +4,10 @@
 // the 11x11 SAD window over +-5 px on the keypoint's pyramid level and fits the parabola.  Integer work is exact;
 // the float tail uses explicitly rounded operations so that uRight/depth equal the CPU results bit for bit.
 #include <hip/hip_runtime.h>
+// Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
+// `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
+// the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
+#pragma clang fp contract(off)
 #include <stdint.h>
 
 #include "det_math.hpp"

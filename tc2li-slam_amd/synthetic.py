@@ -120,3 +120,73 @@ def stereo_batch(n_frames, seed=0, width=WIDTH, height=HEIGHT):
     for f in range(n_frames):
         out[f, 0], out[f, 1] = stereo_pair(seed + f, width, height)
     return out
+
+
+# ---- 64-beam scans ---------------------------------------------------------------------
+# LiDAR axes: x forward, y left, z up; the sensor sits at the left camera centre.  With camera axes x right,
+# y down, z forward:  p_cam = R_CL p_lidar,  R_CL = [[0,-1,0],[0,0,-1],[1,0,0]].
+N_BEAMS, N_AZIMUTH = 64, 2048
+R_CAM_FROM_LIDAR = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])
+VELODYNE_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                           ("time", "<f4"), ("ring", "<u2"), ("pad1", "<u2"), ("pad2", "<f4")])
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("normal_x", "<f4"),
+                        ("normal_y", "<f4"), ("normal_z", "<f4"), ("pad1", "<f4"), ("intensity", "<f4"),
+                        ("curvature", "<f4"), ("pad2", "<f4"), ("pad3", "<f4")])
+assert VELODYNE_DTYPE.itemsize == 32 and POINT_DTYPE.itemsize == 48
+
+
+def sensor_pose(frame, speed=10.0, rate=10.0):
+    """World-from-LiDAR pose of frame `frame`: 10 m/s forward with a slow yaw sinusoid.  Returns (R 3x3, t 3)."""
+    t = frame / rate
+    yaw = 0.05 * np.sin(0.1 * 2 * np.pi * t)
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    return R, np.array([speed * t, 0.3 * np.sin(0.2 * t), 0.0])
+
+
+def lidar_scan(scene, frame=0, max_range=100.0, noise=0.02):
+    """One HDL-64E-like sweep of `scene` from sensor_pose(frame): structured array of velodyne_ros::Point (32 B),
+    azimuth-major firing order, no-return rays dropped; `time` in microseconds over the 0.1 s sweep."""
+    R, t = sensor_pose(frame)
+    elev = np.deg2rad(np.linspace(2.0, -24.8, N_BEAMS))
+    azim = np.linspace(0.0, 2 * np.pi, N_AZIMUTH, endpoint=False)
+    az, el = np.meshgrid(azim, elev, indexing="ij")  # [azimuth, beam]
+    d_l = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], -1).reshape(-1, 3)
+    d_w = d_l @ R.T  # world frame = LiDAR frame of frame 0 (x forward, y left, z up)
+    best = np.full(len(d_w), np.inf)
+    # ground z = -CAM_HEIGHT
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = (-CAM_HEIGHT - t[2]) / d_w[:, 2]
+        tg = np.where((d_w[:, 2] < 0) & (tg > 0), tg, np.inf)
+        best = np.minimum(best, tg)
+        # boxes: fronto-parallel faces; camera (x right, y down, z fwd) -> world x = z_cam, y = -x_cam, z = -y_cam
+        for x0, x1, y0, y1, zb in scene.boxes:
+            tb = (zb - t[0]) / d_w[:, 0]
+            hy = t[1] + tb * d_w[:, 1]
+            hz = t[2] + tb * d_w[:, 2]
+            ok = (tb > 0) & (-hy >= x0) & (-hy <= x1) & (-hz >= y0) & (-hz <= y1)
+            best = np.minimum(best, np.where(ok, tb, np.inf))
+        # side walls y = +-15 m, 6 m high (a street canyon), so that there are vertical planes all along the way
+        for wy in (-15.0, 15.0):
+            tw = (wy - t[1]) / d_w[:, 1]
+            hz = t[2] + tw * d_w[:, 2]
+            ok = (tw > 0) & (hz >= -CAM_HEIGHT) & (hz <= 6.0)
+            best = np.minimum(best, np.where(ok, tw, np.inf))
+    rng = np.random.default_rng([SEED0 + scene.seed, 77, frame])
+    rngd = best + rng.normal(0.0, noise, best.shape)
+    keep = np.isfinite(best) & (best <= max_range)
+    pts = d_l * rngd[:, None]
+    out = np.zeros(int(keep.sum()), VELODYNE_DTYPE)
+    out["x"], out["y"], out["z"] = pts[keep, 0], pts[keep, 1], pts[keep, 2]
+    out["intensity"] = (rng.random(len(best))[keep] * 100).astype(np.float32)
+    idx = np.nonzero(keep)[0]
+    out["time"] = ((idx // N_BEAMS) / N_AZIMUTH * 1.0e5).astype(np.float32)
+    out["ring"] = (idx % N_BEAMS).astype(np.uint16)
+    return out
+
+
+def lidar_state(frame):
+    """state_point of LidarFrontEnd.cpp (rot, pos of the body in the LiDAR world frame; identity LiDAR-IMU offset)
+    as four float64 arrays: rot[9] (row-major), pos[3], offset_R_L_I[9], offset_T_L_I[3]."""
+    R, t = sensor_pose(frame)
+    return R.reshape(-1).copy(), t.copy(), np.eye(3).reshape(-1).copy(), np.zeros(3)
