@@ -202,6 +202,39 @@ int oracle_lidar_feature_extraction(void* tree, const PointXYZINormal* body, int
     return fe.effct_feat_num;
 }
 
+// One frame of the front end with the reference's threading: left/right ORB on two threads (SF/src/Frame.cc:139-142)
+// followed by stereo matching on the tracking thread, while the LiDAR thread (src/examples/camera_lidar.cc:84) runs
+// preprocess -> voxel filter -> feature_extraction.  Returns the number of stereo matches; *n_sel gets effct_feat_num.
+int oracle_frontend_frame(void* hl, void* hr, const uint8_t* il, const uint8_t* ir, int w, int hgt, float mbf, float mb,
+                          const VelodynePoint* raw, int n_raw, void* tree, const double* state24, int* n_sel) {
+    int sel = 0;
+    std::thread lidar([&] {
+        PointVector pre = preprocess_velodyne(raw, n_raw, 2, 2.0, 1e-3f);
+        PointVector down = voxel_grid_filter(pre, 0.5f);
+        LidarState st;
+        std::memcpy(st.rot, state24, 9 * sizeof(double));
+        std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
+        std::memcpy(st.offset_R_L_I, state24 + 12, 9 * sizeof(double));
+        std::memcpy(st.offset_T_L_I, state24 + 21, 3 * sizeof(double));
+        sel = feature_extraction(down, st, *(KdTree*)tree).effct_feat_num;
+    });
+    ORBextractor* el = (ORBextractor*)hl;
+    ORBextractor* er = (ORBextractor*)hr;
+    std::vector<KeyPoint> kl, kr;
+    std::vector<uint8_t> dl, dr;
+    const int lap[2] = {0, 0};
+    std::thread tl([&] { el->extract(Img::view(il, w, hgt, w), kl, dl, lap); });
+    std::thread tr([&] { er->extract(Img::view(ir, w, hgt, w), kr, dr, lap); });
+    tl.join();
+    tr.join();
+    StereoResult r = ComputeStereoMatches(*el, *er, kl, dl, kr, dr, mbf, mb);
+    int matches = 0;
+    for (float d : r.depth) matches += d > 0;
+    lidar.join();
+    if (n_sel) *n_sel = sel;
+    return matches;
+}
+
 // single-function probes for unit tests
 float oracle_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 int oracle_fast9_16(const uint8_t* img, int stride, int w, int h, int th, int nms, float* xyr, int cap) {

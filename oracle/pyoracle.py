@@ -62,6 +62,8 @@ def lib():
         L.oracle_kdtree_knn.restype = None
         L.oracle_esti_plane.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         L.oracle_lidar_feature_extraction.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
+        L.oracle_frontend_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 

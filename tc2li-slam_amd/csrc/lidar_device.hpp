@@ -37,12 +37,14 @@ struct LidarStateDev { double rot[9], pos[3], off_r[9], off_t[3]; };
 
 struct PreprocessParams { int32_t point_filter_num; float time_unit_scale; double blind_sq; };
 
-// Uniform hash grid over the map (replaces the ikd-Tree as the spatial index; same 5 nearest neighbours).
+// Dense uniform grid over the map's bounding box (replaces the ikd-Tree as the spatial index; same 5 nearest
+// neighbours).  Cell (ix, iy, iz) relative to (x0, y0, z0) has linear index (iz * ny + iy) * nx + ix.
 struct MapGrid {
     const PointXYZINormal* points;  // the map points in insertion order (what Nearest_Search returns copies of)
-    const float4* pts;          // cell-sorted xyz + original index (as int bits in w)
-    const int32_t* bucket_start;  // [n_buckets + 1]
-    int32_t n_buckets_mask, n_points;
+    const float4* pts;              // cell-sorted xyz + original index (as int bits in w)
+    const int32_t* bucket_start;    // [nx * ny * nz + 1]
+    int32_t x0, y0, z0, nx, ny, nz;
+    int32_t n_points;
     float inv_cell, cell;
 };
 
@@ -68,10 +70,9 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
                            const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
-void launch_map_count(const PointXYZINormal* pts, int n, float inv_cell, int mask, int* bucket_counts, hipStream_t st);
+void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st);
 void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st);
-void launch_map_scatter(const PointXYZINormal* pts, int n, float inv_cell, int mask, const int* bucket_start, int* bucket_fill,
-                        float4* sorted, hipStream_t st);
+void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted, hipStream_t st);
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,

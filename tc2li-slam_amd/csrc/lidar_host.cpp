@@ -4,6 +4,7 @@
 // scans laid out in fixed per-scan slots; the per-scan point counts produced by one stage are consumed by the next
 // one from device memory.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 
@@ -20,8 +21,9 @@ struct tc2li_lidar_map {
     DevBuf<PointXYZINormal> d_points;
     DevBuf<float4> d_sorted;
     DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill;
-    int n = 0, n_buckets = 0;
+    int n = 0, n_cells = 0;
     float cell = 1.0f;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounding box of the points
     MapGrid grid{};
 };
 
@@ -125,22 +127,42 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
 }
 
 int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) {
-    const int nb = std::min(1 << 22, std::max(1024, next_pow2(2 * std::max(m->n, 1))));
-    if (nb != m->n_buckets) {
-        TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nb));
-        TC2LI_HIP_CHECK(m->d_bucket_fill.alloc(nb));
-        TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nb + 1));
-        m->n_buckets = nb;
+    // cell size: 1 m unless the bounding box would need more than 4M cells
+    MapGrid g{};
+    float cell = 1.0f;
+    for (;;) {
+        const float inv = 1.0f / cell;
+        long long cells = 1;
+        int o[3], d[3];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = m->n ? (int)std::floor(m->lo[a] * inv) : 0;
+            d[a] = m->n ? (int)std::floor(m->hi[a] * inv) - o[a] + 1 : 1;
+            cells *= d[a];
+        }
+        if (cells <= (4ll << 20)) {
+            g.x0 = o[0]; g.y0 = o[1]; g.z0 = o[2]; g.nx = d[0]; g.ny = d[1]; g.nz = d[2];
+            g.inv_cell = inv; g.cell = cell;
+            break;
+        }
+        cell *= 1.5f;
+    }
+    m->cell = cell;
+    const int nc = g.nx * g.ny * g.nz;
+    if (nc > m->n_cells) {
+        TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nc + nc / 2));
+        TC2LI_HIP_CHECK(m->d_bucket_fill.alloc(nc + nc / 2));
+        TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nc + nc / 2 + 1));
+        m->n_cells = nc + nc / 2;
     }
     TC2LI_HIP_CHECK(m->d_sorted.ensure(std::max(m->n, 1)));
-    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, nb * sizeof(int), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_fill.p, 0, nb * sizeof(int), st));
-    const float inv_cell = 1.0f / m->cell;
-    launch_map_count(m->d_points.p, m->n, inv_cell, nb - 1, m->d_bucket_counts.p, st);
-    launch_map_scan(m->d_bucket_counts.p, nb, m->d_bucket_start.p, st);
-    launch_map_scatter(m->d_points.p, m->n, inv_cell, nb - 1, m->d_bucket_start.p, m->d_bucket_fill.p, m->d_sorted.p, st);
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, nc * sizeof(int), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_fill.p, 0, nc * sizeof(int), st));
+    g.points = m->d_points.p; g.pts = m->d_sorted.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
+    launch_map_count(g, m->n, m->d_bucket_counts.p, st);
+    launch_map_scan(m->d_bucket_counts.p, nc, m->d_bucket_start.p, st);
+    launch_map_scatter(g, m->n, m->d_bucket_fill.p, m->d_sorted.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
-    m->grid = MapGrid{m->d_points.p, m->d_sorted.p, m->d_bucket_start.p, nb - 1, m->n, inv_cell, m->cell};
+    m->grid = g;
     return TC2LI_OK;
 }
 
@@ -237,6 +259,15 @@ static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool re
         std::swap(bigger.n, m->d_points.n);
     }
     if (n) TC2LI_HIP_CHECK(hipMemcpy(m->d_points.p + old, pts, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {pts[i].x, pts[i].y, pts[i].z};
+        if (!std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) { set_error("non-finite map point"); return TC2LI_ERR_INVALID; }
+        for (int a = 0; a < 3; ++a) {
+            if (old + i == 0) { m->lo[a] = m->hi[a] = c[a]; }
+            m->lo[a] = std::min(m->lo[a], c[a]);
+            m->hi[a] = std::max(m->hi[a], c[a]);
+        }
+    }
     m->n = old + n;
     int rc = rebuild_grid(m, nullptr);
     if (rc != TC2LI_OK) return rc;

@@ -35,6 +35,15 @@ __device__ __forceinline__ int block_flag_scan(bool f, int* s_wave, int& total) 
     return off + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
+// Orders the LDS accesses of the lanes of ONE wavefront (waves of a block run different trip counts in the kernels
+// below, so a block barrier cannot be used): release + acquire fence at workgroup scope drains lgkmcnt and stops the
+// compiler from moving LDS accesses across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __global__ void k_fill_int(int* p, size_t n, int v) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -287,62 +296,102 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const PointXYZINormal*
     members[sl.base + vox_member_off[sl.base + r] + pos] = i;
 }
 
-// One thread per voxel: order its members by point index (the order PCL's sorted index vector yields), sum every
-// field sequentially in float, divide by the count (pcl::CentroidPoint with all fields).
+// One wavefront per voxel.  The members are ranked by point index (the order PCL's sorted index vector yields:
+// rank = number of members with a smaller index, counted by all lanes in parallel), staged 64 at a time in LDS in
+// that order, and lanes 0..7 each accumulate one field sequentially in float -- the exact summation order of
+// pcl::CentroidPoint -- before dividing by the count.
 __global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                         const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                         const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
                                                         const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
                                                         int* __restrict__ members, PointXYZINormal* __restrict__ out,
                                                         int* __restrict__ out_count) {
+    constexpr int kLdsMembers = 1024;
+    __shared__ float s_stage[4][64][8];
+    __shared__ int s_mem[4][kLdsMembers], s_sorted[4][kLdsMembers];
     const SegBlock b = blocks[blockIdx.x];
     const ScanSlot sl = slots[b.scan];
     const int nv = n_vox[b.scan];
-    if (b.start == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
-    for (int r = b.start + threadIdx.x; r < min(b.start + kSegBlock, nv); r += 256) {
-        if (vp[b.scan].passthrough) { out[sl.base + r] = pts[sl.base + r]; continue; }
-        int* m = members + sl.base + vox_member_off[sl.base + r];
-        const int n = vox_fill[sl.base + r];
-        for (int a = 1; a < n; ++a) {  // insertion sort, n is small
-            const int key = m[a];
-            int c = a - 1;
-            while (c >= 0 && m[c] > key) { m[c + 1] = m[c]; --c; }
-            m[c + 1] = key;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (b.start == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
+    const bool pass = vp[b.scan].passthrough != 0;
+    // neighbouring voxels differ a lot in population (dense near the sensor): interleave them over blocks and waves
+    for (int r = b.start + (int)blockIdx.y + 16 * wave; r < min(b.start + kSegBlock, nv); r += 64) {
+        if (pass) {
+            if (lane == 0) out[sl.base + r] = pts[sl.base + r];
+            continue;
         }
-        float sx = 0, sy = 0, sz = 0, snx = 0, sny = 0, snz = 0, si = 0, sc = 0;
-        for (int a = 0; a < n; ++a) {
-            const PointXYZINormal p = pts[sl.base + m[a]];
-            sx += p.x; sy += p.y; sz += p.z;
-            snx += p.normal_x; sny += p.normal_y; snz += p.normal_z;
-            si += p.intensity; sc += p.curvature;
+        const int* m = members + sl.base + vox_member_off[sl.base + r];
+        const int n = vox_fill[sl.base + r];
+        float acc = 0.f;  // lanes 0..7: x, y, z, normal_x, normal_y, normal_z, intensity, curvature
+        const bool in_lds = n <= kLdsMembers;
+        if (in_lds) {
+            for (int i = lane; i < n; i += 64) s_mem[wave][i] = m[i];
+            wave_lds_sync();
+            for (int i = lane; i < n; i += 64) {
+                const int mine = s_mem[wave][i];
+                int rank = 0;
+                for (int k = 0; k < n; ++k) rank += s_mem[wave][k] < mine ? 1 : 0;
+                s_sorted[wave][rank] = mine;
+            }
+            wave_lds_sync();
+        }
+        for (int base = 0; base < n; base += 64) {
+            if (!in_lds) {
+                // very large voxel: rank against global memory, one 64-member window at a time
+                for (int i = lane; i < n; i += 64) {
+                    const int mine = m[i];
+                    int rank = 0;
+                    for (int k = 0; k < n; ++k) rank += m[k] < mine ? 1 : 0;
+                    if (rank >= base && rank < base + 64) s_sorted[wave][rank - base] = mine;
+                }
+                wave_lds_sync();
+            }
+            const int cnt = min(64, n - base);
+            if (lane < cnt) {
+                const PointXYZINormal p = pts[sl.base + s_sorted[wave][in_lds ? base + lane : lane]];
+                float* d = s_stage[wave][lane];
+                d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.normal_x; d[4] = p.normal_y; d[5] = p.normal_z;
+                d[6] = p.intensity; d[7] = p.curvature;
+            }
+            wave_lds_sync();
+            if (lane < 8)
+                for (int k = 0; k < cnt; ++k) acc += s_stage[wave][k][lane];
+            wave_lds_sync();
         }
         const float fn = (float)n;
-        PointXYZINormal o;
-        o.x = sx / fn; o.y = sy / fn; o.z = sz / fn; o.pad0 = 1.0f;
-        const float nn = snx * snx + sny * sny + snz * snz;
-        if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
-        o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
-        o.intensity = si / fn; o.curvature = sc / fn; o.pad2 = 0; o.pad3 = 0;
-        out[sl.base + r] = o;
+        const float sx = __shfl(acc, 0, 64), sy = __shfl(acc, 1, 64), sz = __shfl(acc, 2, 64);
+        float snx = __shfl(acc, 3, 64), sny = __shfl(acc, 4, 64), snz = __shfl(acc, 5, 64);
+        const float si = __shfl(acc, 6, 64), sc = __shfl(acc, 7, 64);
+        if (lane == 0) {
+            PointXYZINormal o;
+            o.x = sx / fn; o.y = sy / fn; o.z = sz / fn; o.pad0 = 1.0f;
+            const float nn = snx * snx + sny * sny + snz * snz;
+            if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
+            o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
+            o.intensity = si / fn; o.curvature = sc / fn; o.pad2 = 0; o.pad3 = 0;
+            out[sl.base + r] = o;
+        }
     }
 }
 
-// ---- b5: map spatial index (replaces ikd-Tree Build/Add as a uniform hash grid) -----------------------------------
-__device__ __forceinline__ uint32_t cell_hash(int cx, int cy, int cz) {
-    return hash_u32((uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u);
+// ---- b5: map spatial index (replaces the ikd-Tree as a dense uniform grid over the map's bounding box) ------------
+// Cells are ordered x-fastest, so the points of a run of cells along x are one contiguous range of the sorted array.
+__device__ __forceinline__ int map_cell(const MapGrid& g, float x, float y, float z) {
+    const int cx = (int)floorf(x * g.inv_cell) - g.x0, cy = (int)floorf(y * g.inv_cell) - g.y0, cz = (int)floorf(z * g.inv_cell) - g.z0;
+    return (cz * g.ny + cy) * g.nx + cx;
 }
 
-__global__ void k_map_count(const PointXYZINormal* __restrict__ pts, int n, float inv_cell, int mask, int* __restrict__ bucket_counts) {
+__global__ void k_map_count(MapGrid g, int n, int* __restrict__ cell_counts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PointXYZINormal p = pts[i];
-    const uint32_t h = cell_hash((int)floorf(p.x * inv_cell), (int)floorf(p.y * inv_cell), (int)floorf(p.z * inv_cell)) & (uint32_t)mask;
-    atomicAdd(&bucket_counts[h], 1);
+    const PointXYZINormal p = g.points[i];
+    atomicAdd(&cell_counts[map_cell(g, p.x, p.y, p.z)], 1);
 }
 
 __global__ __launch_bounds__(1024) void k_map_scan(const int* __restrict__ bucket_counts, int n_buckets, int* __restrict__ bucket_start) {
     __shared__ int s_part[1024];
-    const int tid = threadIdx.x, per = (n_buckets + 1023) / 1024, lo = tid * per, hi = min(lo + per, n_buckets);
+    const int tid = threadIdx.x, per = (n_buckets + 1023) / 1024, lo = min(tid * per, n_buckets), hi = min(lo + per, n_buckets);
     int sum = 0;
     for (int k = lo; k < hi; ++k) sum += bucket_counts[k];
     s_part[tid] = sum;
@@ -358,13 +407,12 @@ __global__ __launch_bounds__(1024) void k_map_scan(const int* __restrict__ bucke
     if (tid == 1023) bucket_start[n_buckets] = s_part[1023];
 }
 
-__global__ void k_map_scatter(const PointXYZINormal* __restrict__ pts, int n, float inv_cell, int mask,
-                              const int* __restrict__ bucket_start, int* __restrict__ bucket_fill, float4* __restrict__ sorted) {
+__global__ void k_map_scatter(MapGrid g, int n, int* __restrict__ cell_fill, float4* __restrict__ sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PointXYZINormal p = pts[i];
-    const uint32_t h = cell_hash((int)floorf(p.x * inv_cell), (int)floorf(p.y * inv_cell), (int)floorf(p.z * inv_cell)) & (uint32_t)mask;
-    const int pos = bucket_start[h] + atomicAdd(&bucket_fill[h], 1);
+    const PointXYZINormal p = g.points[i];
+    const int c = map_cell(g, p.x, p.y, p.z);
+    const int pos = g.bucket_start[c] + atomicAdd(&cell_fill[c], 1);
     sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
 }
 
@@ -501,7 +549,7 @@ __device__ void qr_solve_5x3(float (&A)[5][3], float (&b)[5], float (&x)[3]) {
         }
 }
 
-constexpr int kMaxRing = 6;
+constexpr int kMaxRing = 32;  // rings 1, 2, 4, ... cells; beyond that an exhaustive scan
 
 __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ grids,
                                                    const PointXYZINormal* __restrict__ body, const int* __restrict__ count,
@@ -515,7 +563,9 @@ __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ g
     const int n = count[b.scan];
     const MapGrid grid = grids[b.scan];
     const PointXYZINormal* __restrict__ map_pts = grid.points;
-    for (int i = b.start + threadIdx.x; i < min(b.start + kSegBlock, n); i += 256) {
+    {
+        const int i = b.start + blockIdx.y * 256 + threadIdx.x;
+        if (i >= n) return;
         const PointXYZINormal pb = body[sl.base + i];
         const LidarStateDev& st = states[b.scan];
         // pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
@@ -531,23 +581,21 @@ __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ g
         pw.intensity = pb.intensity; pw.curvature = 0; pw.pad2 = 0; pw.pad3 = 0;
         world[sl.base + i] = pw;
 
-        // exact 5 nearest map points: grow a cube of grid cells until the 5th distance is inside the searched cube
+        // exact 5 nearest map points: search the cube of cells [c - ring, c + ring]^3 (as runs along x), growing the
+        // ring until the 5th distance lies inside the part of space the cube certainly covers
         Cand best[5];
         int nb = 0;
         const int cx = (int)floorf(pw.x * grid.inv_cell), cy = (int)floorf(pw.y * grid.inv_cell), cz = (int)floorf(pw.z * grid.inv_cell);
         bool done = grid.n_points == 0;
-        for (int ring = 0; ring <= kMaxRing && !done; ++ring) {
-            for (int dz = -ring; dz <= ring; ++dz)
-                for (int dy = -ring; dy <= ring; ++dy)
-                    for (int dx = -ring; dx <= ring; ++dx) {
-                        if (max(abs(dx), max(abs(dy), abs(dz))) != ring) continue;
-                        const int qx = cx + dx, qy = cy + dy, qz = cz + dz;
-                        const uint32_t h = cell_hash(qx, qy, qz) & (uint32_t)grid.n_buckets_mask;
-                        for (int k = grid.bucket_start[h]; k < grid.bucket_start[h + 1]; ++k) {
+        for (int ring = 1; ring <= kMaxRing && !done; ring *= 2) {
+            nb = 0;
+            const int xa = max(cx - ring - grid.x0, 0), xb = min(cx + ring - grid.x0, grid.nx - 1);
+            if (xa <= xb)
+                for (int qz = max(cz - ring - grid.z0, 0); qz <= min(cz + ring - grid.z0, grid.nz - 1); ++qz)
+                    for (int qy = max(cy - ring - grid.y0, 0); qy <= min(cy + ring - grid.y0, grid.ny - 1); ++qy) {
+                        const int row = (qz * grid.ny + qy) * grid.nx;
+                        for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
                             const float4 m = grid.pts[k];
-                            if ((int)floorf(m.x * grid.inv_cell) != qx || (int)floorf(m.y * grid.inv_cell) != qy ||
-                                (int)floorf(m.z * grid.inv_cell) != qz)
-                                continue;
                             Cand c;
                             c.d = (pw.x - m.x) * (pw.x - m.x) + (pw.y - m.y) * (pw.y - m.y) + (pw.z - m.z) * (pw.z - m.z);
                             c.x = m.x;
@@ -556,7 +604,7 @@ __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ g
                         }
                     }
             if (nb == 5) {
-                // every unsearched point is at least `edge` away from the query
+                // every point outside the cube is at least `edge` away from the query
                 const float lo = (float)ring * grid.cell, hi = (float)(ring + 1) * grid.cell;
                 const float fx = pw.x - (float)cx * grid.cell, fy = pw.y - (float)cy * grid.cell, fz = pw.z - (float)cz * grid.cell;
                 float edge = fminf(fminf(fx + lo, hi - fx), fminf(fminf(fy + lo, hi - fy), fminf(fz + lo, hi - fz)));
@@ -692,22 +740,21 @@ void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanS
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
                            PointXYZINormal* out, int* out_count, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
+    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 64), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
 }
-void launch_map_count(const PointXYZINormal* pts, int n, float inv_cell, int mask, int* bucket_counts, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, inv_cell, mask, bucket_counts);
+void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_counts);
 }
 void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st) {
     hipLaunchKernelGGL(k_map_scan, dim3(1), dim3(1024), 0, st, bucket_counts, n_buckets, bucket_start);
 }
-void launch_map_scatter(const PointXYZINormal* pts, int n, float inv_cell, int mask, const int* bucket_start, int* bucket_fill,
-                        float4* sorted, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, inv_cell, mask, bucket_start, bucket_fill, sorted);
+void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_fill, sorted);
 }
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
                       uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d, int* nfound, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_knn_plane, dim3(nblocks), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected, normvec, nearest_idx, nearest_d, nfound);
+    if (nblocks) hipLaunchKernelGGL(k_knn_plane, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected, normvec, nearest_idx, nearest_d, nfound);
 }
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st) {
