@@ -188,6 +188,31 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
                                int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
                                tc2li_point* corr_normvect, int capacity, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optimisation back end.  Poses are Tcw as 7 doubles (qx, qy, qz, qw, tx, ty, tz) -- g2o::SE3Quat of
+ * VertexSE3Expmap (Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:60-77); map points 3 doubles.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_camera { double fx, fy, cx, cy, bf; } tc2li_camera;
+
+/* One projection edge: EdgeStereoSE3ProjectXYZ[OnlyPose] when u_right >= 0, else the monocular
+ * EdgeSE3ProjectXYZ[OnlyPose]; information = inv_sigma2 * I (mvInvLevelSigma2[octave]). */
+typedef struct tc2li_ba_edge {
+    int32_t point, pose; /* indices into the point / pose arrays of the call */
+    double u, v, u_right, inv_sigma2;
+} tc2li_ba_edge;
+
+/* Optimizer::PoseOptimization(Frame*) (SF/src/Optimizer.cc:816; callers Tracking.cc:2628,2796,2858): motion-only
+ * optimisation of one frame pose against its n map-point correspondences (Xw[3*edges[i].point], edges[i].pose
+ * ignored), 4 rounds x optimize(10) with Huber sqrt(5.991)/sqrt(7.815) and chi2 gates 5.991/7.815.  pose7 is updated
+ * (rounded through float like Frame::SetPose), outlier[i] = mvbOutlier; returns nInitialCorrespondences - nBad. */
+int tc2li_pose_optimization(double pose7[7], const double* Xw, const tc2li_ba_edge* edges, int n, const tc2li_camera* cam,
+                            uint8_t* outlier);
+/* Many frames in one launch (one workgroup per frame): frame f owns edges/Xw/outlier [edge_offsets[f], edge_offsets[f+1]),
+ * its edges' `point` index is relative to that range. */
+int tc2li_pose_optimization_batch(int n_frames, double* poses7, const int32_t* edge_offsets, const double* Xw,
+                                  const tc2li_ba_edge* edges, const tc2li_camera* cam, uint8_t* outlier, int32_t* n_inliers,
+                                  void* stream);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

@@ -6,6 +6,7 @@
 #include "orb.hpp"
 #include "stereo.hpp"
 #include "lidar.hpp"
+#include "ba.hpp"
 
 using namespace oracle;
 
@@ -234,6 +235,58 @@ int oracle_frontend_frame(void* hl, void* hr, const uint8_t* il, const uint8_t* 
     if (n_sel) *n_sel = sel;
     return matches;
 }
+
+// ---- optimisation back end ---------------------------------------------------------------------------------------
+// poses as 7 doubles (qx, qy, qz, qw, tx, ty, tz); edges as 6 doubles (point, pose, u, v, uR, invSigma2); cam = fx fy cx cy bf
+static std::vector<BAEdge> edges_from(const double* e, int n) {
+    std::vector<BAEdge> v(n);
+    for (int i = 0; i < n; ++i) {
+        v[i].point = (int)e[6 * i]; v[i].pose = (int)e[6 * i + 1];
+        v[i].obs[0] = e[6 * i + 2]; v[i].obs[1] = e[6 * i + 3]; v[i].obs[2] = e[6 * i + 4]; v[i].info = e[6 * i + 5];
+    }
+    return v;
+}
+static SE3Quat pose_from(const double* p) { SE3Quat T; std::memcpy(T.q, p, 4 * sizeof(double)); std::memcpy(T.t, p + 4, 3 * sizeof(double)); return T; }
+static void pose_to(const SE3Quat& T, double* p) { std::memcpy(p, T.q, 4 * sizeof(double)); std::memcpy(p + 4, T.t, 3 * sizeof(double)); }
+
+int oracle_pose_optimization(double* pose7, const double* Xw, const double* edges6, int n, const double* cam5, uint8_t* outlier,
+                             double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap, int* trace_n) {
+    SE3Quat T = pose_from(pose7);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    std::vector<uint8_t> out;
+    LMTrace tr;
+    int inl = PoseOptimization(T, std::vector<double>(Xw, Xw + 3 * (size_t)n), edges_from(edges6, n), cam, out, &tr);
+    pose_to(T, pose7);
+    for (int i = 0; i < n && i < (int)out.size(); ++i) outlier[i] = out[i];
+    const int m = std::min((int)tr.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = tr.chi2[i]; if (trace_lambda) trace_lambda[i] = tr.lambda[i]; if (trace_trials) trace_trials[i] = tr.trials[i]; }
+    if (trace_n) *trace_n = (int)tr.chi2.size();
+    return inl;
+}
+
+int oracle_local_ba(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points, const double* edges6, int n_edges,
+                    const double* cam5, int iterations, double lambda_init, double* chi2_out, uint8_t* depth_pos,
+                    double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap) {
+    std::vector<SE3Quat> poses(n_poses);
+    for (int i = 0; i < n_poses; ++i) poses[i] = pose_from(poses7 + 7 * i);
+    std::vector<double> pts(points3, points3 + 3 * (size_t)n_points);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    BAResult r = LocalBundleAdjustment(poses, std::vector<uint8_t>(fixed, fixed + n_poses), pts, edges_from(edges6, n_edges), cam,
+                                       iterations, lambda_init, nullptr);
+    for (int i = 0; i < n_poses; ++i) pose_to(poses[i], poses7 + 7 * i);
+    std::memcpy(points3, pts.data(), pts.size() * sizeof(double));
+    for (int e = 0; e < n_edges; ++e) { if (chi2_out) chi2_out[e] = r.chi2[e]; if (depth_pos) depth_pos[e] = r.depth_pos[e]; }
+    const int m = std::min((int)r.trace.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
+    return r.iterations;
+}
+
+// error + analytic Jacobians of one binary projection edge (dim returned)
+int oracle_edge_linearize(const double* pose7, const double* X, const double* edge6, const double* cam5, double* err, double* A, double* B) {
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    return edge_linearize(pose_from(pose7), X, edges_from(edge6, 1)[0], cam, err, A, B);
+}
+void oracle_se3_exp_mul(const double* update6, const double* pose7, double* out7) { pose_to(se3_mul(se3_exp(update6), pose_from(pose7)), out7); }
 
 // single-function probes for unit tests
 float oracle_fast_atan2(float y, float x) { return fastAtan2(y, x); }

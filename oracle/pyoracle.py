@@ -64,6 +64,12 @@ def lib():
         L.oracle_lidar_feature_extraction.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_void_p] * 7
         L.oracle_frontend_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.oracle_pose_optimization.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        L.oracle_local_ba.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_double] + [C.c_void_p] * 5 + [C.c_int]
+        L.oracle_edge_linearize.argtypes = [C.c_void_p] * 7
+        L.oracle_se3_exp_mul.argtypes = [C.c_void_p] * 3
+        L.oracle_se3_exp_mul.restype = None
         _lib = L
     return _lib
 
@@ -274,3 +280,51 @@ def feature_extraction(tree, body, state24):
                                               ori.ctypes.data, corr.ctypes.data)
     return dict(world=world, selected=sel, normvec=normvec, nearest=near, nfound=nfound, cloud_ori=ori[:m], corr_normvect=corr[:m],
                 effct_feat_num=m)
+
+
+# ---- optimisation back end ----------------------------------------------------------------------------------------
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def pose_optimization(pose7, Xw, edges6, cam5):
+    """Optimizer::PoseOptimization -> (pose7, outlier mask, inliers, trace dict)."""
+    pose = _f64(pose7).copy()
+    Xw, edges6, cam5 = _f64(Xw), _f64(edges6), _f64(cam5)
+    n = len(edges6)
+    out = np.zeros(max(n, 1), np.uint8)
+    tc, tl, tt, tn = np.zeros(64), np.zeros(64), np.zeros(64, np.int32), C.c_int(0)
+    inl = lib().oracle_pose_optimization(pose.ctypes.data, Xw.ctypes.data, edges6.ctypes.data, n, cam5.ctypes.data, out.ctypes.data,
+                                         tc.ctypes.data, tl.ctypes.data, tt.ctypes.data, 64, C.byref(tn))
+    k = min(tn.value, 64)
+    return pose, out[:n], inl, dict(chi2=tc[:k], lam=tl[:k], trials=tt[:k])
+
+
+def local_ba(poses7, fixed, points3, edges6, cam5, iterations=10, lambda_init=0.0):
+    """Visual local BA -> (poses7, points3, chi2 per edge, depth-positive flags, iterations, trace)."""
+    poses, pts = _f64(poses7).copy(), _f64(points3).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges6, cam5 = _f64(edges6), _f64(cam5)
+    E = len(edges6)
+    chi2 = np.zeros(max(E, 1))
+    dpos = np.zeros(max(E, 1), np.uint8)
+    tc, tl, tt = np.zeros(32), np.zeros(32), np.zeros(32, np.int32)
+    it = lib().oracle_local_ba(poses.ctypes.data, fixed.ctypes.data, len(poses), pts.ctypes.data, len(pts), edges6.ctypes.data, E,
+                               cam5.ctypes.data, iterations, lambda_init, chi2.ctypes.data, dpos.ctypes.data, tc.ctypes.data,
+                               tl.ctypes.data, tt.ctypes.data, 32)
+    return poses, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it])
+
+
+def edge_linearize(pose7, X, edge6, cam5):
+    err, A, B = np.zeros(3), np.zeros(9), np.zeros(18)
+    pose7, X, edge6, cam5 = _f64(pose7), _f64(X), _f64(edge6), _f64(cam5)
+    dim = lib().oracle_edge_linearize(pose7.ctypes.data, X.ctypes.data, edge6.ctypes.data, cam5.ctypes.data, err.ctypes.data,
+                                      A.ctypes.data, B.ctypes.data)
+    return err[:dim], A.reshape(3, 3)[:dim], B.reshape(3, 6)[:dim]
+
+
+def se3_exp_mul(update6, pose7):
+    out = np.zeros(7)
+    update6, pose7 = _f64(update6), _f64(pose7)
+    lib().oracle_se3_exp_mul(update6.ctypes.data, pose7.ctypes.data, out.ctypes.data)
+    return out

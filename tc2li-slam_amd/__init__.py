@@ -13,6 +13,10 @@ from .capi import (  # noqa: F401
     OrbParams,
     OrbExtractor,
     abi_version,
+    BA_EDGE_DTYPE,
+    pack_ba_edges,
+    pose_optimization,
+    pose_optimization_batch,
     LidarFrontEnd,
     LidarMap,
     pack_lidar_state,

@@ -83,6 +83,8 @@ def lib():
     L.tc2li_lidar_frontend_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_void_p]
+    L.tc2li_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.tc2li_pose_optimization_batch.argtypes = [C.c_int] + [C.c_void_p] * 8
     _lib = L
     return L
 
@@ -363,3 +365,42 @@ class LidarFrontEnd:
                                                 ori.ctypes.data if want_points else None,
                                                 corr.ctypes.data if want_points else None, capacity, C.c_void_p(stream)))
         return counts, ori, corr
+
+
+# ---- optimisation back end ----------------------------------------------------------------------------------------
+BA_EDGE_DTYPE = np.dtype([("point", "<i4"), ("pose", "<i4"), ("u", "<f8"), ("v", "<f8"), ("u_right", "<f8"), ("inv_sigma2", "<f8")])
+
+
+def pack_ba_edges(edges6):
+    """[E, 6] float array (point, pose, u, v, uR, invSigma2) -> structured tc2li_ba_edge array."""
+    e = np.asarray(edges6, np.float64).reshape(-1, 6)
+    out = np.zeros(len(e), BA_EDGE_DTYPE)
+    out["point"], out["pose"] = e[:, 0].astype(np.int32), e[:, 1].astype(np.int32)
+    out["u"], out["v"], out["u_right"], out["inv_sigma2"] = e[:, 2], e[:, 3], e[:, 4], e[:, 5]
+    return out
+
+
+def pose_optimization(pose7, Xw, edges, cam5):
+    """``Optimizer::PoseOptimization`` -> (pose7, outlier mask, inliers)."""
+    pose = np.ascontiguousarray(pose7, np.float64).copy()
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    out = np.zeros(max(len(edges), 1), np.uint8)
+    inl = _check(lib().tc2li_pose_optimization(pose.ctypes.data, Xw.ctypes.data, edges.ctypes.data, len(edges), cam5.ctypes.data,
+                                               out.ctypes.data))
+    return pose, out[:len(edges)], inl
+
+
+def pose_optimization_batch(poses7, edge_offsets, Xw, edges, cam5, stream=0):
+    poses = np.ascontiguousarray(poses7, np.float64).copy()
+    offs = np.ascontiguousarray(edge_offsets, np.int32)
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    n = len(offs) - 1
+    out = np.zeros(max(len(edges), 1), np.uint8)
+    inl = np.zeros(n, np.int32)
+    _check(lib().tc2li_pose_optimization_batch(n, poses.ctypes.data, offs.ctypes.data, Xw.ctypes.data, edges.ctypes.data,
+                                               cam5.ctypes.data, out.ctypes.data, inl.ctypes.data, C.c_void_p(stream)))
+    return poses, out[:len(edges)], inl

@@ -1,0 +1,238 @@
+// Optimizer::PoseOptimization (SF/src/Optimizer.cc:816-1116) as ONE persistent workgroup per frame: the four
+// outlier-classification rounds, each a g2o Levenberg-Marquardt run of up to 10 iterations (optimization_algorithm_
+// levenberg.cpp:61-169) on a single 6-dof vertex, execute inside the kernel -- no host round trip per iteration.
+// Edges are spread over the 256 threads; the 6x6 normal equations and the robust chi2 are reduced through LDS in a
+// fixed order (deterministic), thread 0 does the 6x6 LDL^T and the accept/reject logic and broadcasts the decision.
+#include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "ba_math.hpp"
+#include "pose_opt_device.hpp"
+
+namespace tc2li {
+
+constexpr int kPoThreads = 256;
+constexpr int kRed = 28;  // 21 upper-triangular H entries + 6 b entries + chi
+
+__device__ __forceinline__ void block_reduce(double (&v)[kRed], double* s_red /*[4][kRed]*/, double* s_out /*[kRed]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kRed; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0) s_red[wave * kRed + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kRed) s_out[threadIdx.x] = (s_red[threadIdx.x] + s_red[kRed + threadIdx.x]) + (s_red[2 * kRed + threadIdx.x] + s_red[3 * kRed + threadIdx.x]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
+                                                                 const BaEdge* __restrict__ edges, CameraD cam,
+                                                                 double* __restrict__ poses7, uint8_t* __restrict__ outlier,
+                                                                 double* __restrict__ chi2_scratch, int* __restrict__ inliers) {
+    __shared__ double s_red[4 * kRed], s_sum[kRed];
+    __shared__ Se3 s_pose, s_trial;
+    __shared__ int s_flag[4];  // [0] continue trial loop, [1] accepted, [2] iteration result ok, [3] solve ok
+    const PoseProblem pr = probs[blockIdx.x];
+    const int tid = threadIdx.x, N = pr.n;
+    const BaEdge* E = edges + pr.edge_off;
+    const double* X = Xw + 3 * (size_t)pr.edge_off;
+    uint8_t* out = outlier + pr.edge_off;
+    double* chi2 = chi2_scratch + pr.edge_off;
+    double* pose_io = poses7 + 7 * (size_t)blockIdx.x;
+
+    for (int i = tid; i < N; i += kPoThreads) out[i] = 0;
+    if (N < 3) {  // nInitialCorrespondences < 3 (Optimizer.cc:999-1000)
+        if (tid == 0) inliers[blockIdx.x] = 0;
+        return;
+    }
+    Se3 initial;
+    for (int k = 0; k < 4; ++k) initial.q[k] = pose_io[k];
+    for (int k = 0; k < 3; ++k) initial.t[k] = pose_io[4 + k];
+    const double d_mono = (double)sqrtf(5.991f), d_stereo = (double)sqrtf(7.815f);
+    const float dsqr_mono = (float)(d_mono * d_mono), dsqr_stereo = (float)(d_stereo * d_stereo);
+    __syncthreads();
+
+    int n_bad_total = 0;
+    bool robust = true;
+    for (int round = 0; round < 4; ++round) {
+        if (tid == 0) s_pose = initial;  // every round restarts from the frame pose (Optimizer.cc:1012-1013)
+        __syncthreads();
+        double lambda = 0, ni = 2;  // thread 0 only
+        int n_bad_lm = 0;
+        bool ok = true;
+        for (int it = 0; it < 10 && ok; ++it) {
+            // computeActiveErrors + buildSystem over the level-0 edges
+            const Se3 T = s_pose;
+            double acc[kRed];
+#pragma unroll
+            for (int k = 0; k < kRed; ++k) acc[k] = 0;
+            for (int i = tid; i < N; i += kPoThreads) {
+                if (out[i]) continue;  // level 1
+                const BaEdge e = E[i];
+                double p[3], err[3], B[18];
+                se3_map(T, X + 3 * i, p);
+                const bool stereo = e.ur >= 0;
+                const int dim = edge_error(p, e, cam, err);
+                double c2 = 0;
+                for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
+                chi2[i] = c2;
+                double rho0 = c2, rho1 = 1.0;
+                if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
+                pose_jacobian(p, stereo, true, cam, B);
+                const double w = rho1 * e.info;
+                int h = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int c = r; c < 6; ++c) {
+                        double s = 0;
+                        for (int d = 0; d < dim; ++d) s += B[6 * d + r] * w * B[6 * d + c];
+                        acc[h++] += s;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double s = 0;
+                    for (int d = 0; d < dim; ++d) s += B[6 * d + r] * (e.info * err[d]);
+                    acc[21 + r] -= rho1 * s;
+                }
+                acc[27] += rho0;
+            }
+            block_reduce(acc, s_red, s_sum);
+            double H[36], b[6], currentChi = s_sum[27];
+            {
+                int h = 0;
+                for (int r = 0; r < 6; ++r)
+                    for (int c = r; c < 6; ++c) { H[6 * r + c] = s_sum[h]; H[6 * c + r] = s_sum[h]; ++h; }
+                for (int r = 0; r < 6; ++r) b[r] = s_sum[21 + r];
+            }
+            const double iniChi = currentChi;
+            if (tid == 0 && it == 0) {  // computeLambdaInit: tau * max diagonal
+                double mx = 0;
+                for (int r = 0; r < 6; ++r) mx = fmax(fabs(H[7 * r]), mx);
+                lambda = 1e-5 * mx;
+                ni = 2;
+                n_bad_lm = 0;
+            }
+            double rho = 0;
+            int qmax = 0;
+            for (;;) {
+                double x[6] = {0, 0, 0, 0, 0, 0};
+                if (tid == 0) {
+                    double Hl[36];
+                    for (int k = 0; k < 36; ++k) Hl[k] = H[k];
+                    for (int r = 0; r < 6; ++r) Hl[7 * r] += lambda;
+                    const bool ok2 = ldlt_solve_small(Hl, 6, b, x, true);
+                    s_flag[3] = ok2 ? 1 : 0;
+                    s_trial = se3_exp_mul(x, s_pose);
+                }
+                __syncthreads();
+                const Se3 Tt = s_trial;
+                double a2[kRed];
+#pragma unroll
+                for (int k = 0; k < kRed; ++k) a2[k] = 0;
+                for (int i = tid; i < N; i += kPoThreads) {
+                    if (out[i]) continue;
+                    const BaEdge e = E[i];
+                    double p[3], err[3];
+                    se3_map(Tt, X + 3 * i, p);
+                    const bool stereo = e.ur >= 0;
+                    const int dim = edge_error(p, e, cam, err);
+                    double c2 = 0;
+                    for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
+                    chi2[i] = c2;
+                    double rho0 = c2, rho1 = 1.0;
+                    if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
+                    a2[27] += rho0;
+                }
+                block_reduce(a2, s_red, s_sum);
+                if (tid == 0) {
+                    double tempChi = s_sum[27];
+                    if (!s_flag[3]) tempChi = 1.7976931348623157e308;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+                    for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    const bool finite = tempChi - tempChi == 0.0;
+                    if (rho > 0 && finite) {
+                        double alpha = 1. - pow((2 * rho - 1), 3.0);
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha);
+                        ni = 2;
+                        currentChi = tempChi;
+                        s_pose = s_trial;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                    }
+                    qmax++;
+                    s_flag[0] = (rho < 0 && qmax < 10) ? 1 : 0;
+                }
+                __syncthreads();
+                if (!s_flag[0]) break;
+            }
+            if (tid == 0) {
+                int res_ok = 1;
+                if (qmax == 10 || rho == 0) res_ok = 0;
+                else {
+                    if ((iniChi - currentChi) * 1e3 < iniChi) n_bad_lm++; else n_bad_lm = 0;
+                    if (n_bad_lm >= 3) res_ok = 0;
+                }
+                s_flag[2] = res_ok;
+            }
+            __syncthreads();
+            ok = s_flag[2] != 0;
+            __syncthreads();
+        }
+        // classification (Optimizer.cc:1018-1102): outliers get their error recomputed at the final pose, inliers keep
+        // the chi2 the optimiser left behind
+        const Se3 T = s_pose;
+        int bad = 0;
+        for (int i = tid; i < N; i += kPoThreads) {
+            const BaEdge e = E[i];
+            if (out[i]) {
+                double p[3], err[3];
+                se3_map(T, X + 3 * i, p);
+                const int dim = edge_error(p, e, cam, err);
+                double c2 = 0;
+                for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
+                chi2[i] = c2;
+            }
+            const float c = (float)chi2[i];
+            const float th = e.ur >= 0 ? 7.815f : 5.991f;
+            if (c > th) { out[i] = 1; bad++; } else out[i] = 0;
+        }
+        __syncthreads();
+        {
+            // block-wide sum of `bad`
+            double a3[kRed];
+#pragma unroll
+            for (int k = 0; k < kRed; ++k) a3[k] = 0;
+            a3[0] = (double)bad;
+            block_reduce(a3, s_red, s_sum);
+            n_bad_total = (int)s_sum[0];
+        }
+        if (round == 2) robust = false;
+        if (N < 10) break;  // optimizer.edges().size() < 10
+    }
+    if (tid == 0) {
+        // Frame::SetPose(Sophus::SE3<float>): the result is stored in float
+        for (int k = 0; k < 4; ++k) pose_io[k] = (double)(float)s_pose.q[k];
+        for (int k = 0; k < 3; ++k) pose_io[4 + k] = (double)(float)s_pose.t[k];
+        inliers[blockIdx.x] = N - n_bad_total;
+    }
+}
+
+void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double* Xw, const BaEdge* edges, const CameraD& cam,
+                              double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, hipStream_t st) {
+    if (nprobs > 0)
+        hipLaunchKernelGGL(k_pose_optimization, dim3(nprobs), dim3(kPoThreads), 0, st, probs, Xw, edges, cam, poses7, outlier,
+                           chi2_scratch, inliers);
+}
+
+}  // namespace tc2li

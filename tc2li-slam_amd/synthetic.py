@@ -190,3 +190,83 @@ def lidar_state(frame):
     as four float64 arrays: rot[9] (row-major), pos[3], offset_R_L_I[9], offset_T_L_I[3]."""
     R, t = sensor_pose(frame)
     return R.reshape(-1).copy(), t.copy(), np.eye(3).reshape(-1).copy(), np.zeros(3)
+
+
+# ---- bundle-adjustment windows (SURVEY.md section 8d) -------------------------------------------------------------
+def _quat_from_rot(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    x = (R[2, 1] - R[1, 2]) / (4 * w); y = (R[0, 2] - R[2, 0]) / (4 * w); z = (R[1, 0] - R[0, 1]) / (4 * w)
+    return np.array([x, y, z, w])
+
+
+def _rot_from_rvec(r):
+    th = np.linalg.norm(r)
+    if th < 1e-12:
+        return np.eye(3)
+    k = r / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def ba_window(seed=0, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.5, 0.05), point_noise=0.01, outlier_frac=0.05,
+              mono_frac=0.1, pixel_sigma=1.0):
+    """Synthetic local-BA window: keyframes on a forward trajectory (camera frame: x right, y down, z forward), points
+    in front of them, stereo observations with pixel noise scaled by the pyramid level, a few gross outliers and
+    monocular observations.  Returns a dict of flat arrays in the layout the C ABI takes:
+    poses [K,7] (qx,qy,qz,qw,tx,ty,tz = Tcw), fixed [K], points [P,3], edges [E,6] (point, pose, u, v, uR, invSigma2),
+    cam (fx, fy, cx, cy, bf), plus the noise-free truth."""
+    rng = np.random.default_rng([SEED0, 0xBA, seed])
+    K = n_opt + n_fix
+    # fixed keyframes first in time (older), optimisable ones last; ids ascending = vertex order in g2o
+    Rs, ts = [], []
+    for k in range(K):
+        yaw = 0.03 * np.sin(0.4 * k)
+        Rwc = _rot_from_rvec(np.array([0.0, yaw, 0.0]))
+        twc = np.array([0.3 * np.sin(0.2 * k), 0.02 * np.cos(0.3 * k), 1.0 * k])
+        Rcw = Rwc.T
+        Rs.append(Rcw); ts.append(-Rcw @ twc)
+    # points: in a corridor ahead of the trajectory
+    z = rng.uniform(2.0, K + 40.0, n_points)
+    pts = np.stack([rng.uniform(-12, 12, n_points), rng.uniform(-3, 1.65, n_points), z], 1)
+    scale = 1.2 ** np.arange(8)
+    edges, truth_uv = [], []
+    for p in range(n_points):
+        for k in range(K):
+            pc = Rs[k] @ pts[p] + ts[k]
+            if pc[2] < 1.0 or pc[2] > 45.0:
+                continue
+            u = FX * pc[0] / pc[2] + CX
+            v = FY * pc[1] / pc[2] + CY
+            if not (20 < u < WIDTH - 20 and 20 < v < HEIGHT - 20):
+                continue
+            if rng.random() > 0.55:  # not every keyframe that could see a point has matched it
+                continue
+            lvl = int(min(7, max(0, np.floor(np.log(max(pc[2], 1.0) / 6.0) / np.log(1.2) + 3))))
+            s = pixel_sigma * scale[lvl]
+            uo, vo = u + rng.normal(0, s), v + rng.normal(0, s)
+            ur = uo - BF / pc[2] + rng.normal(0, s)
+            if rng.random() < outlier_frac:
+                uo += rng.choice([-1, 1]) * rng.uniform(8, 20); vo += rng.choice([-1, 1]) * rng.uniform(8, 20)
+            if rng.random() < mono_frac:
+                ur = -1.0
+            edges.append((p, k, np.float32(uo), np.float32(vo), np.float32(ur), np.float32(1.0) / np.float32(scale[lvl] ** 2)))
+    edges = np.array(edges, np.float64)
+    # keep points with at least 2 observations (as local mapping would)
+    cnt = np.bincount(edges[:, 0].astype(int), minlength=n_points)
+    keep = cnt >= 2
+    remap = -np.ones(n_points, int); remap[keep] = np.arange(keep.sum())
+    edges = edges[keep[edges[:, 0].astype(int)]]
+    edges[:, 0] = remap[edges[:, 0].astype(int)]
+    pts_true = pts[keep]
+    poses_true = np.array([np.concatenate([_quat_from_rot(Rs[k]), ts[k]]) for k in range(K)])
+    fixed = np.zeros(K, np.uint8); fixed[:n_fix] = 1
+    poses = poses_true.copy()
+    for k in range(n_fix, K):
+        dR = _rot_from_rvec(rng.normal(0, np.deg2rad(pose_noise[0]), 3))
+        Rn = dR @ Rs[k]
+        poses[k] = np.concatenate([_quat_from_rot(Rn), ts[k] + rng.normal(0, pose_noise[1], 3)])
+    # estimates live in float on the map (Sophus::SE3f / Eigen::Vector3f): round through float32
+    poses = poses.astype(np.float32).astype(np.float64)
+    pts_noisy = (pts_true * (1 + rng.normal(0, point_noise, (len(pts_true), 1)))).astype(np.float32).astype(np.float64)
+    cam = np.array([np.float32(FX), np.float32(FY), np.float32(CX), np.float32(CY), np.float32(BF)], np.float64)
+    return dict(poses=poses, fixed=fixed, points=pts_noisy, edges=edges, cam=cam, poses_true=poses_true, points_true=pts_true)
