@@ -213,6 +213,26 @@ int tc2li_pose_optimization_batch(int n_frames, double* poses7, const int32_t* e
                                   const tc2li_ba_edge* edges, const tc2li_camera* cam, uint8_t* outlier, int32_t* n_inliers,
                                   void* stream);
 
+/* Statistics of one bundle adjustment (all optional). */
+typedef struct tc2li_ba_stats {
+    int32_t iterations, trials, n_free_poses, pad_;
+    double initial_chi2, final_chi2, final_lambda;
+} tc2li_ba_stats;
+
+/* The optimisation of Optimizer::LocalBundleAdjustment / OptimizerWithLidar::LocalLVBundleAdjustment (visual edges;
+ * SF/src/Optimizer.cc:1118, SF/src/OptimizerWithLidar.cc:60; callers LocalMapping.cc:170,173): the host shim gathers
+ * local / fixed keyframes and map points exactly as the reference does (OptimizerWithLidar.cc:63-130) and passes them
+ * flattened -- poses in vertex-id order with their fixed flags, points, one edge per observation.  Runs
+ * optimizer.optimize(iterations) with Huber sqrt(5.991) / sqrt(7.815); lambda_init <= 0 selects tau * max diagonal,
+ * the inertial-map branch passes 100 (OptimizerWithLidar.cc:141-142).  stop_flag is *pbStopFlag, polled between
+ * Levenberg trials like g2o's forceStopFlag.  Outputs: poses and points updated in place (double; the shim casts to
+ * float, :468-484), per-edge chi2 as the optimiser left it and isDepthPositive() for the outlier rules (:402-449).
+ * Returns the number of iterations performed. */
+int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                  const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                  double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                  uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

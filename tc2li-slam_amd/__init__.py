@@ -13,6 +13,7 @@ from .capi import (  # noqa: F401
     OrbParams,
     OrbExtractor,
     abi_version,
+    local_bundle_adjustment,
     BA_EDGE_DTYPE,
     pack_ba_edges,
     pose_optimization,

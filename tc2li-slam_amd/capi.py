@@ -85,6 +85,8 @@ def lib():
                                              C.c_int, C.c_void_p]
     L.tc2li_pose_optimization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_pose_optimization_batch.argtypes = [C.c_int] + [C.c_void_p] * 8
+    L.tc2li_local_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -404,3 +406,25 @@ def pose_optimization_batch(poses7, edge_offsets, Xw, edges, cam5, stream=0):
     _check(lib().tc2li_pose_optimization_batch(n, poses.ctypes.data, offs.ctypes.data, Xw.ctypes.data, edges.ctypes.data,
                                                cam5.ctypes.data, out.ctypes.data, inl.ctypes.data, C.c_void_p(stream)))
     return poses, out[:len(edges)], inl
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("n_free_poses", C.c_int32), ("pad_", C.c_int32),
+                ("initial_chi2", C.c_double), ("final_chi2", C.c_double), ("final_lambda", C.c_double)]
+
+
+def local_bundle_adjustment(poses7, fixed, points3, edges, cam5, iterations=10, lambda_init=0.0, stop_flag=None, stream=0):
+    """The optimisation of ``Optimizer::LocalBundleAdjustment`` -> (poses7, points3, chi2, depth_positive, stats)."""
+    poses = np.ascontiguousarray(poses7, np.float64).copy()
+    pts = np.ascontiguousarray(points3, np.float64).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    chi2 = np.zeros(max(len(edges), 1))
+    dpos = np.zeros(max(len(edges), 1), np.uint8)
+    stats = BaStats()
+    stop_ptr = stop_flag.ctypes.data if stop_flag is not None else None
+    _check(lib().tc2li_local_bundle_adjustment(poses.ctypes.data, fixed.ctypes.data, len(poses), pts.ctypes.data, len(pts),
+                                               edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
+                                               chi2.ctypes.data, dpos.ctypes.data, C.byref(stats), C.c_void_p(stream)))
+    return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats

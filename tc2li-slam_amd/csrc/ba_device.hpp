@@ -1,0 +1,38 @@
+// Shared between the host orchestration and the bundle-adjustment kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ba_math.hpp"
+
+namespace tc2li {
+
+// One local-BA problem resident on the device.  Free (non-fixed) poses are numbered 0..n_free-1 through pose_var;
+// pt_* is a CSR of the edges of each landmark, pv_* a CSR of the edges of each free pose (n_free_edges in total).
+struct BaProblemDev {
+    int32_t n_edges, n_points, n_poses, n_free, n_free_edges, np_pad;
+    CameraD cam;
+    double delta_mono, delta_stereo;
+    float dsqr_mono, dsqr_stereo;
+    Se3 *poses, *poses_trial;
+    double *points, *points_trial;
+    const BaEdge* edges;
+    const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges;
+    double *chi2, *rho0;
+    double *contrib_l, *contrib_p, *W;   // per edge: 9, 27, 18 doubles
+    double *Hll, *bl, *diag_l;           // per landmark: 6, 3, 1
+    double *Hpp, *diag_p;                // per free pose: 27 (21 packed upper + 6 b), 1
+    double *Dinv, *db;                   // per landmark: 9, 3
+    double *coef_e, *coef;               // per edge 6, per free pose 6
+    double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands
+    double *S_part;                      // [n_slices][np_pad * np_pad]
+    double *scale_l;                     // per landmark
+};
+
+void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, hipStream_t st);
+// S_out [np*np], bs_out [2*np]: b_s followed by b_p
+void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
+void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st);
+void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st);
+
+}  // namespace tc2li

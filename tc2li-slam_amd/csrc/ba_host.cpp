@@ -1,10 +1,13 @@
 // Host side of the optimisation entry points (include/tc2li_hip.h): tc2li_pose_optimization[_batch] replaces
 // Optimizer::PoseOptimization (SF/src/Optimizer.cc:816-1116).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <mutex>
 
 #include "common.hpp"
+#include "ba_device.hpp"
 #include "pose_opt_device.hpp"
 
 using namespace tc2li;
@@ -76,6 +79,182 @@ int tc2li_pose_optimization(double pose7[7], const double* Xw, const tc2li_ba_ed
     int rc = tc2li_pose_optimization_batch(1, pose7, offs, Xw, edges, cam, outlier, &inl, nullptr);
     if (rc < 0) return rc;
     return inl;
+}
+
+// OptimizerWithLidar::LocalLVBundleAdjustment / Optimizer::LocalBundleAdjustment, visual part: the optimisation between
+// "Setup optimizer" and "Check inlier observations" (SF/src/OptimizerWithLidar.cc:132-400).  The Levenberg-Marquardt
+// control flow of g2o (optimization_algorithm_levenberg.cpp:61-169) runs here on the host; every numerical step is a
+// kernel of ba_kernels.hip; the reduced camera system (6 x free poses) is factorised on the host (LDL^T), as g2o's
+// LinearSolverEigen does.
+int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                  const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                  double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                  uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
+    if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
+        set_error("tc2li_local_bundle_adjustment: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    // ---- structure: free-pose numbering, CSR by landmark and by free pose ----
+    std::vector<int> pose_var(n_poses, -1);
+    int n_free = 0;
+    std::vector<uint8_t> used(n_poses, 0);
+    for (int e = 0; e < n_edges; ++e) {
+        if (edges[e].pose < 0 || edges[e].pose >= n_poses || edges[e].point < 0 || edges[e].point >= n_points) {
+            set_error("edge %d references pose %d / point %d out of range", e, edges[e].pose, edges[e].point);
+            return TC2LI_ERR_INVALID;
+        }
+        used[edges[e].pose] = 1;
+    }
+    for (int k = 0; k < n_poses; ++k) if (!fixed[k] && used[k]) pose_var[k] = n_free++;
+    std::vector<int> pt_off(n_points + 1, 0), pt_edges(n_edges), pv_off(n_free + 1, 0);
+    for (int e = 0; e < n_edges; ++e) { pt_off[edges[e].point + 1]++; if (pose_var[edges[e].pose] >= 0) pv_off[pose_var[edges[e].pose] + 1]++; }
+    for (int l = 0; l < n_points; ++l) {
+        if (pt_off[l + 1] == 0) { set_error("point %d has no edge", l); return TC2LI_ERR_INVALID; }
+        pt_off[l + 1] += pt_off[l];
+    }
+    for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
+    const int n_free_edges = pv_off[n_free];
+    std::vector<int> pv_edges(std::max(n_free_edges, 1));
+    {
+        std::vector<int> fl(pt_off.begin(), pt_off.end() - 1), fp(pv_off.begin(), pv_off.end() - 1);
+        for (int e = 0; e < n_edges; ++e) {
+            pt_edges[fl[edges[e].point]++] = e;
+            const int i = pose_var[edges[e].pose];
+            if (i >= 0) pv_edges[fp[i]++] = e;
+        }
+    }
+    const int np = 6 * n_free, np_pad = std::max(16, (np + 15) / 16 * 16);
+    const int k_total = 3 * n_points;
+    const int n_slices = std::max(1, std::min(64, k_total / 256));
+    const int k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
+
+    // ---- device memory ----
+    DevBuf<Se3> d_poses, d_poses_trial;
+    DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
+        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_l;
+    DevBuf<BaEdge> d_edges;
+    DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
+    DevBuf<uint8_t> d_depth;
+    PinnedBuf<double> h_S, h_bs, h_xp, h_scal;
+    const size_t E = n_edges, P = n_points;
+    TC2LI_HIP_CHECK(d_poses.alloc(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.alloc(n_poses));
+    TC2LI_HIP_CHECK(d_points.alloc(3 * P)); TC2LI_HIP_CHECK(d_points_trial.alloc(3 * P));
+    TC2LI_HIP_CHECK(d_chi2.alloc(E)); TC2LI_HIP_CHECK(d_rho0.alloc(E)); TC2LI_HIP_CHECK(d_cl.alloc(9 * E)); TC2LI_HIP_CHECK(d_cp.alloc(27 * E));
+    TC2LI_HIP_CHECK(d_W.alloc(18 * E)); TC2LI_HIP_CHECK(d_Hll.alloc(6 * P)); TC2LI_HIP_CHECK(d_bl.alloc(3 * P)); TC2LI_HIP_CHECK(d_diag_l.alloc(P));
+    TC2LI_HIP_CHECK(d_Hpp.alloc(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.alloc(std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_Dinv.alloc(9 * P)); TC2LI_HIP_CHECK(d_db.alloc(3 * P)); TC2LI_HIP_CHECK(d_coef_e.alloc(6 * E));
+    TC2LI_HIP_CHECK(d_coef.alloc(6 * (size_t)std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_AT.alloc((size_t)(k_per_slice * n_slices + 4) * np_pad)); TC2LI_HIP_CHECK(d_BT.alloc((size_t)(k_per_slice * n_slices + 4) * np_pad));
+    TC2LI_HIP_CHECK(d_Spart.alloc((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_l.alloc(P));
+    TC2LI_HIP_CHECK(d_edges.alloc(E)); TC2LI_HIP_CHECK(d_pose_var.alloc(n_poses)); TC2LI_HIP_CHECK(d_pt_off.alloc(P + 1));
+    TC2LI_HIP_CHECK(d_pt_edges.alloc(E)); TC2LI_HIP_CHECK(d_pv_off.alloc(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.alloc(pv_edges.size()));
+    TC2LI_HIP_CHECK(d_depth.alloc(E));
+    TC2LI_HIP_CHECK(h_S.alloc((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.alloc(2 * (size_t)std::max(np, 1)));
+    TC2LI_HIP_CHECK(h_xp.alloc(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.alloc(8));
+    std::vector<Se3> poses(n_poses);
+    for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_points.p, points3, 3 * P * sizeof(double), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_edges.p, edges, E * sizeof(BaEdge), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_var.p, pose_var.data(), n_poses * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_off.p, pt_off.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_edges.p, pt_edges.data(), E * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_off.p, pv_off.data(), (n_free + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_edges.p, pv_edges.data(), pv_edges.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, d_AT.n * sizeof(double), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, d_BT.n * sizeof(double), st));
+
+    BaProblemDev pb{};
+    pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
+    memcpy(&pb.cam, cam, sizeof(CameraD));
+    const float dm = sqrtf(5.991f), ds = sqrtf(7.815f);  // thHuberMono / thHuberStereo are floats (OptimizerWithLidar.cc:219-220)
+    pb.delta_mono = dm; pb.delta_stereo = ds;
+    pb.dsqr_mono = (float)((double)dm * (double)dm); pb.dsqr_stereo = (float)((double)ds * (double)ds);
+    pb.poses = d_poses.p; pb.poses_trial = d_poses_trial.p; pb.points = d_points.p; pb.points_trial = d_points_trial.p;
+    pb.edges = d_edges.p; pb.pose_var = d_pose_var.p; pb.pt_off = d_pt_off.p; pb.pt_edges = d_pt_edges.p; pb.pv_off = d_pv_off.p; pb.pv_edges = d_pv_edges.p;
+    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
+    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
+    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_l = d_scale_l.p;
+
+    auto stopped = [&] { return stop_flag && *stop_flag; };
+    double lambda = -1, ni = 2;
+    int n_bad = 0, done = 0, trials_total = 0;
+    bool ok = true;
+    std::vector<double> Swork((size_t)std::max(np * np, 1)), x(std::max(np, 1));
+    for (int it = 0; it < iterations && !stopped() && ok; ++it) {
+        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        double currentChi = h_scal.p[0], tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) {
+            if (stats) stats->initial_chi2 = currentChi;
+            lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(h_scal.p[1], h_scal.p[2]);
+            ni = 2;
+            n_bad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            bool ok2 = true;
+            ba_launch_schur(pb, lambda, n_slices, k_per_slice, h_S.p, h_bs.p, st);
+            TC2LI_HIP_CHECK(hipGetLastError());
+            if (np > 0) {
+                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                memcpy(Swork.data(), h_S.p, (size_t)np * np * sizeof(double));
+                ok2 = ldlt_solve_small(Swork.data(), np, h_bs.p, x.data(), false);
+                memcpy(h_xp.p, x.data(), np * sizeof(double));
+            }
+            double scale = 0;
+            // pose part of computeScale(): b_p is what the finish kernel left in h_bs[np .. 2 np)
+            for (int j = 0; j < np; ++j) scale += x[j] * (lambda * x[j] + h_bs.p[np + j]);
+            if (ok2) {
+                ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
+                TC2LI_HIP_CHECK(hipGetLastError());
+                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                tempChi = h_scal.p[4];
+                scale += h_scal.p[3];
+            } else {
+                tempChi = std::numeric_limits<double>::max();
+            }
+            rho = currentChi - tempChi;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                std::swap(pb.poses, pb.poses_trial);
+                std::swap(pb.points, pb.points_trial);
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+            qmax++;
+            trials_total++;
+        } while (rho < 0 && qmax < 10 && !stopped());
+        ++done;
+        if (stats) { stats->final_chi2 = currentChi; stats->final_lambda = lambda; }
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
+        if (n_bad >= 3) ok = false;
+    }
+    if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; }
+    // ---- results ----
+    ba_launch_depth(pb, d_depth.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(poses.data(), pb.poses, n_poses * sizeof(Se3), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(points3, pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (edge_chi2) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_chi2, d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (edge_depth_positive) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_depth_positive, d_depth.p, E, hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < n_poses; ++k) { memcpy(poses7 + 7 * k, poses[k].q, 4 * sizeof(double)); memcpy(poses7 + 7 * k + 4, poses[k].t, 3 * sizeof(double)); }
+    return done;
 }
 
 }  // extern "C"

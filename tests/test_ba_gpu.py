@@ -58,3 +58,48 @@ def test_pose_optimization_batch(pkg, oracle, synthetic):
         assert inl[i] == want_inl
         assert np.array_equal(out[offs[i]:offs[i + 1]], want_out)
         assert np.allclose(poses[i], want_pose, rtol=POSE_RTOL, atol=1e-7)
+
+
+def rel_pose_err(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("seed,n_opt,n_fix,n_pts,lam", [(0, 12, 20, 3000, 0.0), (1, 4, 2, 120, 0.0), (2, 8, 10, 800, 100.0),
+                                                          (6, 20, 12, 2000, 0.0)])
+def test_local_bundle_adjustment(pkg, oracle, synthetic, seed, n_opt, n_fix, n_pts, lam):
+    w = synthetic.ba_window(seed, n_opt=n_opt, n_fix=n_fix, n_points=n_pts)
+    want = oracle.local_ba(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], iterations=10, lambda_init=lam)
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], pkg.pack_ba_edges(w["edges"]),
+                                                              w["cam"], iterations=10, lambda_init=lam)
+    assert stats.iterations == want[4]
+    assert stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.final_chi2 - want[5]["chi2"][-1]) <= 1e-6 * want[5]["chi2"][-1]
+    # optimised SE3 poses within 1e-4 relative (BASELINE.json); points likewise
+    for k in range(len(poses)):
+        assert rel_pose_err(poses[k], want[0][k]) < POSE_RTOL
+    assert np.array_equal(poses[w["fixed"] > 0], w["poses"][w["fixed"] > 0])
+    assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6)
+    # same outlier set under the reference's rules (OptimizerWithLidar.cc:406-449)
+    stereo = w["edges"][:, 4] >= 0
+    th = np.where(stereo, 7.815, 5.991)
+    assert np.array_equal((chi2 > th) | (dpos == 0), (want[2] > th) | (want[3] == 0))
+    assert np.allclose(chi2, want[2], rtol=1e-5, atol=1e-7)
+
+
+def test_local_ba_stop_flag_and_structure(pkg, oracle, synthetic):
+    w = synthetic.ba_window(3, n_opt=5, n_fix=4, n_points=300)
+    e = pkg.pack_ba_edges(w["edges"])
+    # *pbStopFlag set before the optimisation: nothing moves (OptimizerWithLidar.cc:387-391)
+    stop = np.ones(1, np.uint8)
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], stop_flag=stop)
+    assert stats.iterations == 0 and np.array_equal(poses, w["poses"]) and np.array_equal(pts, w["points"])
+    # every pose fixed: only the landmarks move
+    allfix = np.ones_like(w["fixed"])
+    want = oracle.local_ba(w["poses"], allfix, w["points"], w["edges"], w["cam"], iterations=5)
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], allfix, w["points"], e, w["cam"], iterations=5)
+    assert np.array_equal(poses, w["poses"]) and stats.n_free_poses == 0
+    assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6)
+    # malformed input is refused
+    bad = e.copy(); bad["pose"][0] = 10 ** 6
+    with pytest.raises(pkg.Tc2liError):
+        pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], bad, w["cam"])
