@@ -27,6 +27,18 @@ struct PoseOptWorkspace {
 };
 PoseOptWorkspace& po_ws() { static PoseOptWorkspace w; return w; }
 
+struct BaWorkspace {
+    DevBuf<Se3> d_poses, d_poses_trial;
+    DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
+        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_l;
+    DevBuf<BaEdge> d_edges;
+    DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
+    DevBuf<uint8_t> d_depth;
+    PinnedBuf<double> h_S, h_bs, h_xp, h_scal;
+    std::mutex mu;
+};
+BaWorkspace& ba_ws() { static BaWorkspace w; return w; }
+
 }  // namespace
 
 extern "C" {
@@ -131,29 +143,34 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     const int n_slices = std::max(1, std::min(64, k_total / 256));
     const int k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
 
-    // ---- device memory ----
-    DevBuf<Se3> d_poses, d_poses_trial;
-    DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
-        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_l;
-    DevBuf<BaEdge> d_edges;
-    DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
-    DevBuf<uint8_t> d_depth;
-    PinnedBuf<double> h_S, h_bs, h_xp, h_scal;
+    // ---- device memory: a process-wide workspace that only grows (hipMalloc per call would dominate the run time) ----
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    auto &d_poses = ws.d_poses, &d_poses_trial = ws.d_poses_trial;
+    auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
+         &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
+         &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
+         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_l = ws.d_scale_l;
+    auto& d_edges = ws.d_edges;
+    auto &d_pose_var = ws.d_pose_var, &d_pt_off = ws.d_pt_off, &d_pt_edges = ws.d_pt_edges, &d_pv_off = ws.d_pv_off, &d_pv_edges = ws.d_pv_edges;
+    auto& d_depth = ws.d_depth;
+    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
     const size_t E = n_edges, P = n_points;
-    TC2LI_HIP_CHECK(d_poses.alloc(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.alloc(n_poses));
-    TC2LI_HIP_CHECK(d_points.alloc(3 * P)); TC2LI_HIP_CHECK(d_points_trial.alloc(3 * P));
-    TC2LI_HIP_CHECK(d_chi2.alloc(E)); TC2LI_HIP_CHECK(d_rho0.alloc(E)); TC2LI_HIP_CHECK(d_cl.alloc(9 * E)); TC2LI_HIP_CHECK(d_cp.alloc(27 * E));
-    TC2LI_HIP_CHECK(d_W.alloc(18 * E)); TC2LI_HIP_CHECK(d_Hll.alloc(6 * P)); TC2LI_HIP_CHECK(d_bl.alloc(3 * P)); TC2LI_HIP_CHECK(d_diag_l.alloc(P));
-    TC2LI_HIP_CHECK(d_Hpp.alloc(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.alloc(std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_Dinv.alloc(9 * P)); TC2LI_HIP_CHECK(d_db.alloc(3 * P)); TC2LI_HIP_CHECK(d_coef_e.alloc(6 * E));
-    TC2LI_HIP_CHECK(d_coef.alloc(6 * (size_t)std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_AT.alloc((size_t)(k_per_slice * n_slices + 4) * np_pad)); TC2LI_HIP_CHECK(d_BT.alloc((size_t)(k_per_slice * n_slices + 4) * np_pad));
-    TC2LI_HIP_CHECK(d_Spart.alloc((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_l.alloc(P));
-    TC2LI_HIP_CHECK(d_edges.alloc(E)); TC2LI_HIP_CHECK(d_pose_var.alloc(n_poses)); TC2LI_HIP_CHECK(d_pt_off.alloc(P + 1));
-    TC2LI_HIP_CHECK(d_pt_edges.alloc(E)); TC2LI_HIP_CHECK(d_pv_off.alloc(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.alloc(pv_edges.size()));
-    TC2LI_HIP_CHECK(d_depth.alloc(E));
-    TC2LI_HIP_CHECK(h_S.alloc((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.alloc(2 * (size_t)std::max(np, 1)));
-    TC2LI_HIP_CHECK(h_xp.alloc(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.alloc(8));
+    const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
+    TC2LI_HIP_CHECK(d_poses.ensure(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
+    TC2LI_HIP_CHECK(d_points.ensure(3 * P)); TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
+    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(9 * E)); TC2LI_HIP_CHECK(d_cp.ensure(27 * E));
+    TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
+    TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
+    TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_AT.ensure(at_elems)); TC2LI_HIP_CHECK(d_BT.ensure(at_elems));
+    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_l.ensure(P));
+    TC2LI_HIP_CHECK(d_edges.ensure(E)); TC2LI_HIP_CHECK(d_pose_var.ensure(n_poses)); TC2LI_HIP_CHECK(d_pt_off.ensure(P + 1));
+    TC2LI_HIP_CHECK(d_pt_edges.ensure(E)); TC2LI_HIP_CHECK(d_pv_off.ensure(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.ensure(pv_edges.size()));
+    TC2LI_HIP_CHECK(d_depth.ensure(E));
+    TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
+    TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
     std::vector<Se3> poses(n_poses);
     for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
@@ -164,8 +181,8 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_edges.p, pt_edges.data(), E * sizeof(int), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_off.p, pv_off.data(), (n_free + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_edges.p, pv_edges.data(), pv_edges.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, d_AT.n * sizeof(double), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, d_BT.n * sizeof(double), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, at_elems * sizeof(double), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, at_elems * sizeof(double), st));
 
     BaProblemDev pb{};
     pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
