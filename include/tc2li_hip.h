@@ -189,6 +189,61 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
                                tc2li_point* corr_normvect, int capacity, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Projection-guided matching of the tracking thread -- replaces the two overloads of ORBmatcher::SearchByProjection
+ * that Tracking uses: (Frame&, const Frame& LastFrame, th, bMono) SF/src/ORBmatcher.cc:1685 (TrackWithMotionModel,
+ * Tracking.cc:2771,2780) and (Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) :52 (SearchLocalPoints,
+ * Tracking.cc:3282).  Map-point pointers stay on the host: each source point becomes one query.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_proj_query {
+    float u, v;                 /* projection in the current frame */
+    float radius;               /* window half size handed to Frame::GetFeaturesInArea */
+    float u_right;              /* predicted right coordinate (stereo consistency check) */
+    int32_t min_level, max_level; /* GetFeaturesInArea level arguments */
+    float angle;                /* keypoint angle in the source frame (rotation histogram) */
+    int16_t valid;              /* 0: the source point produces no search */
+    int16_t has_observations;   /* pMP->Observations() > 0: a match blocks the keypoint for later points */
+    uint8_t descriptor[32];     /* pMP->GetDescriptor() */
+} tc2li_proj_query;
+
+typedef struct tc2li_frame_view {  /* the parts of the current Frame the matcher reads */
+    const tc2li_keypoint* keys;    /* mvKeysUn */
+    const uint8_t* descriptors;    /* mDescriptors, n x 32 */
+    const float* u_right;          /* mvuRight */
+    const uint8_t* occupied;       /* mvpMapPoints[i] && Observations() > 0 before the call (may be NULL) */
+    int32_t n;
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY */
+} tc2li_frame_view;
+
+typedef struct tc2li_map_point {  /* what Frame::isInFrustum / PredictScale read off a MapPoint */
+    float pos[3], normal[3];
+    float min_distance, max_distance; /* Get{Min,Max}DistanceInvariance() */
+    float max_distance_raw;           /* mfMaxDistance */
+    uint8_t descriptor[32];
+} tc2li_map_point;
+
+/* The matching loops.  mode 0: best Hamming distance <= TH_HIGH (last-frame overload); mode 1: best / second best with
+ * nn_ratio when both lie on one level (local-map overload).  check_orientation applies the 30-bin rotation histogram.
+ * match_of_query[q] = matched keypoint or -1; query_of_keypoint[i] (may be NULL) = the query now held by keypoint i.
+ * Returns nmatches like the reference. */
+int tc2li_search_by_projection(const tc2li_frame_view* frame, const tc2li_proj_query* queries, int n_queries, int mode,
+                               float nn_ratio, int check_orientation, int32_t* match_of_query, int32_t* query_of_keypoint);
+
+/* Query construction of the last-frame overload (ORBmatcher.cc:1696-1739).  Poses are Sophus::SE3f as 7 floats
+ * (qx, qy, qz, qw, tx, ty, tz); cam4 = fx, fy, cx, cy; b = mb, bf = mbf.  One query per last-frame keypoint i
+ * (has_point[i] = LastFrame.mvpMapPoints[i] != NULL, outlier[i] = mvbOutlier[i], Xw = world positions).  Returns the
+ * number of valid queries. */
+int tc2li_project_last_frame(const float pose_cur7[7], const float pose_last7[7], const float cam4[4], float b, float bf,
+                             const float* scale_factors, int n_levels, int cols, int rows, int n, const uint8_t* has_point,
+                             const uint8_t* outlier, const float* Xw, const tc2li_keypoint* last_keys, const uint8_t* mp_descriptors,
+                             float th, int mono, tc2li_proj_query* queries);
+
+/* Frame::isInFrustum(pMP, viewing_cos_limit) (SF/src/Frame.cc:542-603) + MapPoint::PredictScale + the window of the
+ * local-map overload (ORBmatcher.cc:62-81) for n local map points. */
+int tc2li_project_local_map(const float pose7[7], const float cam4[4], float bf, const float* scale_factors, int n_levels,
+                            float log_scale_factor, int cols, int rows, int n, const tc2li_map_point* points, float th,
+                            int far_points, float th_far_points, float viewing_cos_limit, tc2li_proj_query* queries);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimisation back end.  Poses are Tcw as 7 doubles (qx, qy, qz, qw, tx, ty, tz) -- g2o::SE3Quat of
  * VertexSE3Expmap (Thirdparty/g2o/g2o/types/types_six_dof_expmap.h:60-77); map points 3 doubles.
  * ---------------------------------------------------------------------------------------------- */

@@ -7,6 +7,7 @@
 #include "stereo.hpp"
 #include "lidar.hpp"
 #include "ba.hpp"
+#include "matcher.hpp"
 
 using namespace oracle;
 
@@ -287,6 +288,81 @@ int oracle_edge_linearize(const double* pose7, const double* X, const double* ed
     return edge_linearize(pose_from(pose7), X, edges_from(edge6, 1)[0], cam, err, A, B);
 }
 void oracle_se3_exp_mul(const double* update6, const double* pose7, double* out7) { pose_to(se3_mul(se3_exp(update6), pose_from(pose7)), out7); }
+
+// ---- projection matching -------------------------------------------------------------------------------------------
+struct QueryPOD {  // same 64-byte layout as tc2li_proj_query
+    float u, v, radius, u_right;
+    int32_t min_level, max_level;
+    float angle;
+    int16_t valid, has_observations;
+    uint8_t desc[32];
+};
+static_assert(sizeof(QueryPOD) == 64, "layout");
+static std::vector<ProjQuery> queries_from(const QueryPOD* q, int n) {
+    std::vector<ProjQuery> v(n);
+    for (int i = 0; i < n; ++i) {
+        v[i].u = q[i].u; v[i].v = q[i].v; v[i].radius = q[i].radius; v[i].u_right = q[i].u_right; v[i].min_level = q[i].min_level;
+        v[i].max_level = q[i].max_level; v[i].angle = q[i].angle; v[i].valid = q[i].valid; v[i].has_observations = q[i].has_observations;
+        std::memcpy(v[i].desc, q[i].desc, 32);
+    }
+    return v;
+}
+static void queries_to(const std::vector<ProjQuery>& v, QueryPOD* q) {
+    for (size_t i = 0; i < v.size(); ++i) {
+        std::memset(&q[i], 0, sizeof(QueryPOD));
+        q[i].u = v[i].u; q[i].v = v[i].v; q[i].radius = v[i].radius; q[i].u_right = v[i].u_right; q[i].min_level = v[i].min_level;
+        q[i].max_level = v[i].max_level; q[i].angle = v[i].angle; q[i].valid = (int16_t)v[i].valid; q[i].has_observations = (int16_t)v[i].has_observations;
+        std::memcpy(q[i].desc, v[i].desc, 32);
+    }
+}
+
+// frame: keys as 6 floats each, desc, uRight, occupied; returns nmatches after the optional rotation filter
+int oracle_search_by_projection(const float* keys6, const uint8_t* desc, const float* uright, const uint8_t* occupied, int n, int cols,
+                                int rows, const QueryPOD* queries, int m, int mode, float nnratio, int check_orientation, int* match_of_query) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    if (occupied) F.occupied.assign(occupied, occupied + n); else F.occupied.assign(n, 0);
+    F.cols = cols; F.rows = rows;
+    std::vector<ProjQuery> qs = queries_from(queries, m);
+    std::vector<int> match;
+    int nm = match_queries(F, qs, mode == 0 ? MATCH_BEST : MATCH_RATIO, nnratio, match);
+    if (check_orientation) nm -= rotation_filter(F, qs, match);
+    for (int q = 0; q < m; ++q) match_of_query[q] = match[q];
+    return nm;
+}
+
+void oracle_project_last_frame(const float* pose_cur7, const float* pose_last7, const float* cam4, float mb, float mbf, const float* scales,
+                               int nlevels, int cols, int rows, int n, const uint8_t* has_point, const uint8_t* outlier, const float* Xw,
+                               const float* last_keys6, const uint8_t* mp_desc, float th, int mono, QueryPOD* out) {
+    SE3f Tcw, Tlw;
+    std::memcpy(Tcw.q, pose_cur7, 16); std::memcpy(Tcw.t, pose_cur7 + 4, 12);
+    std::memcpy(Tlw.q, pose_last7, 16); std::memcpy(Tlw.t, pose_last7 + 4, 12);
+    CamF cam{cam4[0], cam4[1], cam4[2], cam4[3]};
+    auto qs = build_queries_last_frame(Tcw, Tlw, cam, mb, mbf, std::vector<float>(scales, scales + nlevels), cols, rows,
+                                       std::vector<uint8_t>(has_point, has_point + n), std::vector<uint8_t>(outlier, outlier + n),
+                                       std::vector<float>(Xw, Xw + 3 * (size_t)n), kps_from(last_keys6, n),
+                                       std::vector<uint8_t>(mp_desc, mp_desc + (size_t)n * 32), th, mono != 0);
+    queries_to(qs, out);
+}
+
+struct MapPointPOD { float pos[3], normal[3], min_distance, max_distance, max_distance_raw; uint8_t desc[32]; };  // tc2li_map_point
+void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, const float* scales, int nlevels, float log_scale, int cols,
+                              int rows, int n, const MapPointPOD* pts, float th, int far_points, float th_far, float cos_limit, QueryPOD* out) {
+    SE3f Tcw;
+    std::memcpy(Tcw.q, pose7, 16); std::memcpy(Tcw.t, pose7 + 4, 12);
+    CamF cam{cam4[0], cam4[1], cam4[2], cam4[3]};
+    std::vector<MapPointView> mps(n);
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(mps[i].pos, pts[i].pos, 12); std::memcpy(mps[i].normal, pts[i].normal, 12);
+        mps[i].min_dist = pts[i].min_distance; mps[i].max_dist = pts[i].max_distance; mps[i].mfMaxDistance = pts[i].max_distance_raw;
+        std::memcpy(mps[i].desc, pts[i].desc, 32);
+    }
+    auto qs = build_queries_local_map(Tcw, cam, mbf, std::vector<float>(scales, scales + nlevels), log_scale, cols, rows, mps, th,
+                                      far_points != 0, th_far, cos_limit);
+    queries_to(qs, out);
+}
 
 // single-function probes for unit tests
 float oracle_fast_atan2(float y, float x) { return fastAtan2(y, x); }

@@ -70,6 +70,12 @@ def lib():
         L.oracle_edge_linearize.argtypes = [C.c_void_p] * 7
         L.oracle_se3_exp_mul.argtypes = [C.c_void_p] * 3
         L.oracle_se3_exp_mul.restype = None
+        L.oracle_search_by_projection.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.oracle_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
+        L.oracle_project_last_frame.restype = None
+        L.oracle_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_project_local_map.restype = None
         _lib = L
     return _lib
 
@@ -328,3 +334,46 @@ def se3_exp_mul(update6, pose7):
     update6, pose7 = _f64(update6), _f64(pose7)
     lib().oracle_se3_exp_mul(update6.ctypes.data, pose7.ctypes.data, out.ctypes.data)
     return out
+
+
+# ---- projection matching ------------------------------------------------------------------------------------------
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("angle", "<f4"), ("valid", "<i2"), ("has_observations", "<i2"), ("descriptor", "u1", (32,))])
+MAP_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"),
+                            ("max_distance_raw", "<f4"), ("descriptor", "u1", (32,))])
+assert QUERY_DTYPE.itemsize == 64 and MAP_POINT_DTYPE.itemsize == 68
+
+
+def search_by_projection(keys, desc, u_right, occupied, cols, rows, queries, mode, nn_ratio=0.9, check_orientation=False):
+    k6 = _kps_to_floats(keys)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(u_right, np.float32)
+    occ = np.ascontiguousarray(occupied if occupied is not None else np.zeros(len(k6), np.uint8), np.uint8)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    match = np.full(max(len(queries), 1), -1, np.int32)
+    n = lib().oracle_search_by_projection(k6.ctypes.data, desc.ctypes.data, ur.ctypes.data, occ.ctypes.data, len(k6), cols, rows,
+                                          queries.ctypes.data, len(queries), mode, nn_ratio, int(check_orientation), match.ctypes.data)
+    return n, match[:len(queries)]
+
+
+def project_last_frame(pose_cur7, pose_last7, cam4, mb, mbf, scales, cols, rows, has_point, outlier, Xw, last_keys, mp_desc, th, mono=False):
+    pc, pl, cam4 = [np.ascontiguousarray(a, np.float32) for a in (pose_cur7, pose_last7, cam4)]
+    scales = np.ascontiguousarray(scales, np.float32)
+    hp, ol = np.ascontiguousarray(has_point, np.uint8), np.ascontiguousarray(outlier, np.uint8)
+    Xw = np.ascontiguousarray(Xw, np.float32)
+    k6 = _kps_to_floats(last_keys)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    out = np.zeros(max(len(k6), 1), QUERY_DTYPE)
+    lib().oracle_project_last_frame(pc.ctypes.data, pl.ctypes.data, cam4.ctypes.data, mb, mbf, scales.ctypes.data, len(scales), cols, rows,
+                                    len(k6), hp.ctypes.data, ol.ctypes.data, Xw.ctypes.data, k6.ctypes.data, mp_desc.ctypes.data, th,
+                                    int(mono), out.ctypes.data)
+    return out[:len(k6)]
+
+
+def project_local_map(pose7, cam4, mbf, scales, log_scale, cols, rows, points, th, far_points=False, th_far=0.0, cos_limit=0.5):
+    pose7, cam4, scales = [np.ascontiguousarray(a, np.float32) for a in (pose7, cam4, scales)]
+    points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    out = np.zeros(max(len(points), 1), QUERY_DTYPE)
+    lib().oracle_project_local_map(pose7.ctypes.data, cam4.ctypes.data, mbf, scales.ctypes.data, len(scales), log_scale, cols, rows,
+                                   len(points), points.ctypes.data, th, int(far_points), th_far, cos_limit, out.ctypes.data)
+    return out[:len(points)]

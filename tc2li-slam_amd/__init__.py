@@ -13,6 +13,11 @@ from .capi import (  # noqa: F401
     OrbParams,
     OrbExtractor,
     abi_version,
+    search_by_projection,
+    project_last_frame,
+    project_local_map,
+    QUERY_DTYPE,
+    MAP_POINT_DTYPE,
     local_bundle_adjustment,
     BA_EDGE_DTYPE,
     pack_ba_edges,

@@ -87,6 +87,10 @@ def lib():
     L.tc2li_pose_optimization_batch.argtypes = [C.c_int] + [C.c_void_p] * 8
     L.tc2li_local_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
+    L.tc2li_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
     _lib = L
     return L
 
@@ -428,3 +432,54 @@ def local_bundle_adjustment(poses7, fixed, points3, edges, cam5, iterations=10, 
                                                edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
                                                chi2.ctypes.data, dpos.ctypes.data, C.byref(stats), C.c_void_p(stream)))
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats
+
+
+# ---- projection matching (ORBmatcher::SearchByProjection) ----------------------------------------------------------
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("radius", "<f4"), ("u_right", "<f4"), ("min_level", "<i4"), ("max_level", "<i4"),
+                        ("angle", "<f4"), ("valid", "<i2"), ("has_observations", "<i2"), ("descriptor", "u1", (32,))])
+MAP_POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_distance", "<f4"), ("max_distance", "<f4"),
+                            ("max_distance_raw", "<f4"), ("descriptor", "u1", (32,))])
+
+
+class FrameView(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p), ("occupied", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+def search_by_projection(keys, desc, u_right, occupied, cols, rows, queries, mode, nn_ratio=0.9, check_orientation=False):
+    """The matching loops of both tracking overloads -> (nmatches, match_of_query, query_of_keypoint)."""
+    keys = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(u_right, np.float32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    fv = FrameView(keys.ctypes.data, desc.ctypes.data, ur.ctypes.data, None if occ is None else occ.ctypes.data, len(keys), 0.0,
+                   float(cols), 0.0, float(rows))
+    match = np.full(max(len(queries), 1), -1, np.int32)
+    qok = np.full(max(len(keys), 1), -1, np.int32)
+    n = _check(lib().tc2li_search_by_projection(C.byref(fv), queries.ctypes.data, len(queries), mode, nn_ratio, int(check_orientation),
+                                                match.ctypes.data, qok.ctypes.data))
+    return n, match[:len(queries)], qok[:len(keys)]
+
+
+def project_last_frame(pose_cur7, pose_last7, cam4, b, bf, scales, cols, rows, has_point, outlier, Xw, last_keys, mp_desc, th, mono=False):
+    pc, pl, cam4 = [np.ascontiguousarray(a, np.float32) for a in (pose_cur7, pose_last7, cam4)]
+    scales = np.ascontiguousarray(scales, np.float32)
+    hp, ol = np.ascontiguousarray(has_point, np.uint8), np.ascontiguousarray(outlier, np.uint8)
+    Xw = np.ascontiguousarray(Xw, np.float32)
+    last_keys = np.ascontiguousarray(last_keys, KEYPOINT_DTYPE)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    out = np.zeros(max(len(last_keys), 1), QUERY_DTYPE)
+    _check(lib().tc2li_project_last_frame(pc.ctypes.data, pl.ctypes.data, cam4.ctypes.data, b, bf, scales.ctypes.data, len(scales), cols,
+                                          rows, len(last_keys), hp.ctypes.data, ol.ctypes.data, Xw.ctypes.data, last_keys.ctypes.data,
+                                          mp_desc.ctypes.data, th, int(mono), out.ctypes.data))
+    return out[:len(last_keys)]
+
+
+def project_local_map(pose7, cam4, bf, scales, log_scale, cols, rows, points, th, far_points=False, th_far=0.0, cos_limit=0.5):
+    pose7, cam4, scales = [np.ascontiguousarray(a, np.float32) for a in (pose7, cam4, scales)]
+    points = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    out = np.zeros(max(len(points), 1), QUERY_DTYPE)
+    _check(lib().tc2li_project_local_map(pose7.ctypes.data, cam4.ctypes.data, bf, scales.ctypes.data, len(scales), log_scale, cols, rows,
+                                         len(points), points.ctypes.data, th, int(far_points), th_far, cos_limit, out.ctypes.data))
+    return out[:len(points)]
