@@ -226,6 +226,8 @@ struct Problem {
     Camera cam;
     Huber huber_mono{(float)std::sqrt(5.991)}, huber_stereo{(float)std::sqrt(7.815)};
     const bool* stop = nullptr;
+    EdgeLidar* lidar = nullptr;      // EdgeLidarSE3 over the window vertices lidar_pose
+    std::vector<int> lidar_pose;
     // per-edge state kept between calls, like g2o's _error
     std::vector<double> err;   // 3 per edge
     std::vector<double> chi2;  // per edge
@@ -252,9 +254,23 @@ struct Problem {
         for (int i = 0; i < dim; ++i) s += err[3 * e + i] * (*edges)[e].info * err[3 * e + i];
         chi2[e] = s;
     }
-    void compute_active_errors() { for (int e : active) compute_error(e); }
+    void lidar_vertex_matrices(std::vector<double>& R, std::vector<double>& t) const {
+        R.resize(9 * lidar_pose.size()); t.resize(3 * lidar_pose.size());
+        for (size_t i = 0; i < lidar_pose.size(); ++i) {
+            quat_to_matrix((*poses)[lidar_pose[i]].q, &R[9 * i]);
+            std::memcpy(&t[3 * i], (*poses)[lidar_pose[i]].t, 3 * sizeof(double));
+        }
+    }
+    void compute_active_errors() {
+        for (int e : active) compute_error(e);
+        if (lidar) {
+            std::vector<double> R, t;
+            lidar_vertex_matrices(R, t);
+            lidar->computeError(R.data(), t.data(), (int)lidar_pose.size());
+        }
+    }
     double active_robust_chi2() const {
-        double chi = 0;
+        double chi = lidar ? lidar->chi2() : 0.0;
         for (int e : active) {
             if (robust[e]) { double rho[3]; huber(e).robustify(chi2[e], rho); chi += rho[0]; }
             else chi += chi2[e];
@@ -269,6 +285,7 @@ struct Problem {
         pose_var.assign(poses->size(), -1);
         std::vector<uint8_t> used_pose(poses->size(), 0), used_point(points ? points->size() / 3 : 0, 0);
         for (int e : active) { used_pose[(*edges)[e].pose] = 1; if (points) used_point[(*edges)[e].point] = 1; }
+        for (int k : lidar_pose) used_pose[k] = 1;
         n_pose_vars = 0;
         for (size_t i = 0; i < poses->size(); ++i) if (used_pose[i] && !fixed[i]) pose_var[i] = n_pose_vars++;
         point_var.assign(used_point.size(), -1);
@@ -350,6 +367,33 @@ int Problem::optimize(int iterations) {
                         for (int i = 0; i < dim; ++i) h += B[6 * i + r] * w * B[6 * i + c];
                         Hpp[(size_t)(6 * pv + r) * np + 6 * pv + c] += h;
                     }
+                }
+            }
+        }
+        if (lidar) {
+            // EdgeLidarSE3::linearizeOplus + computeQuadraticFormLidarRes (G2oTypesWithLidar.h:148-236), quirks included:
+            // the 6x6 blocks are read at ELEMENT offsets (i, i) / (i, j) of the 6W x 6W Hessian, and b -= info * J^T
+            std::vector<double> R, t;
+            lidar_vertex_matrices(R, t);
+            const int W = (int)lidar_pose.size(), n = 6 * W;
+            lidar->linearizeOplus(R.data(), t.data(), W);
+            const double info = lidar->information;
+            for (int i = 0; i < W; ++i) {
+                const int vi = pose_var[lidar_pose[i]];
+                if (vi < 0) continue;
+                for (int r = 0; r < 6; ++r) {
+                    b[6 * vi + r] -= info * lidar->JacT[6 * i + r];
+                    for (int c = 0; c < 6; ++c) Hpp[(size_t)(6 * vi + r) * np + 6 * vi + c] += lidar->Hessian[(size_t)(i + r) * n + i + c] * info;
+                }
+                for (int j = i + 1; j < W; ++j) {
+                    const int vj = pose_var[lidar_pose[j]];
+                    if (vj < 0) continue;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) {
+                            const double h = lidar->Hessian[(size_t)(i + r) * n + j + c] * info;
+                            Hpp[(size_t)(6 * vi + r) * np + 6 * vj + c] += h;
+                            Hpp[(size_t)(6 * vj + c) * np + 6 * vi + r] += h;
+                        }
                 }
             }
         }
@@ -515,13 +559,14 @@ int PoseOptimization(SE3Quat& pose, const std::vector<double>& Xw, const std::ve
 
 BAResult LocalBundleAdjustment(std::vector<SE3Quat>& poses, const std::vector<uint8_t>& fixed, std::vector<double>& points,
                                const std::vector<BAEdge>& edges, const Camera& cam, int iterations, double lambda_init,
-                               const bool* stop) {
+                               const bool* stop, EdgeLidar* lidar, const std::vector<int>* lidar_pose) {
     BAResult res;
     const int E = (int)edges.size();
     Problem P;
     P.poses = &poses; P.fixed = fixed; P.points = &points; P.Xw = nullptr; P.edges = &edges; P.cam = cam;
     P.level.assign(E, 0); P.robust.assign(E, 1); P.err.assign(3 * E, 0); P.chi2.assign(E, 0);
     P.user_lambda = lambda_init; P.stop = stop; P.trace = &res.trace;
+    if (lidar && lidar_pose) { P.lidar = lidar; P.lidar_pose = *lidar_pose; }
     P.initialize(0);
     res.iterations = (stop && *stop) ? 0 : P.optimize(iterations);
     res.chi2 = P.chi2;  // e->chi2() as the optimiser left it (OptimizerWithLidar.cc:406-449)

@@ -16,6 +16,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "balm.hpp"
+
 namespace oracle {
 
 struct SE3Quat {
@@ -52,9 +54,11 @@ struct BAResult {
 // The optimisation of LocalBundleAdjustment: poses (with fixed flags) in vertex-id order, points, edges; Huber
 // kernels sqrt(5.991) / sqrt(7.815); optimize(iterations) with lambda_init <= 0 meaning tau * max diagonal.
 // `stop` is polled like g2o's forceStopFlag.  Poses and points are updated in place (double precision).
+// lidar (optional): the BALM edge of LocalLVBundleAdjustment (OptimizerWithLidar.cc:226-260) over the window poses
+// `lidar_pose` (indices into `poses`, in window order), already built (AddFromKeyFrame + BuildVoxHess), information = wLBA.
 BAResult LocalBundleAdjustment(std::vector<SE3Quat>& poses, const std::vector<uint8_t>& fixed, std::vector<double>& points,
                                const std::vector<BAEdge>& edges, const Camera& cam, int iterations, double lambda_init,
-                               const bool* stop = nullptr);
+                               const bool* stop = nullptr, EdgeLidar* lidar = nullptr, const std::vector<int>* lidar_pose = nullptr);
 
 // helpers exposed for unit tests
 SE3Quat se3_exp(const double update[6]);

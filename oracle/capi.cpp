@@ -282,6 +282,101 @@ int oracle_local_ba(double* poses7, const uint8_t* fixed, int n_poses, double* p
     return r.iterations;
 }
 
+// Local BA with the BALM edge: window = the first n_win entries of win_pose (pose indices, window order), clouds packed
+// back to back (cloud_off[n_win + 1], xyz floats in the LiDAR frame), Tcl as 7 floats, information = wLBA.
+int oracle_local_ba_lidar(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points, const double* edges6,
+                          int n_edges, const double* cam5, int iterations, double lambda_init, const int* win_pose, int n_win,
+                          const float* clouds, const int* cloud_off, const float* Tcl7, double wLBA, double* chi2_out,
+                          uint8_t* depth_pos, double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap,
+                          int* n_planes, double* lidar_out /* [2 + 6W + 36W^2]: residual, chi2, JacT, Hessian at the end */) {
+    std::vector<SE3Quat> poses(n_poses);
+    for (int i = 0; i < n_poses; ++i) poses[i] = pose_from(poses7 + 7 * i);
+    std::vector<double> pts(points3, points3 + 3 * (size_t)n_points);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    SE3fQ Tcl;
+    std::memcpy(Tcl.q, Tcl7, 16); std::memcpy(Tcl.t, Tcl7 + 4, 12);
+    LidarCovisRes lio(Tcl);
+    lio.win_size_ = n_win;
+    std::vector<int> lp(win_pose, win_pose + n_win);
+    for (int i = 0; i < n_win; ++i) {
+        SE3fQ Tcw;  // KeyFrame::GetPose() is a Sophus::SE3f
+        for (int k = 0; k < 4; ++k) Tcw.q[k] = (float)poses[lp[i]].q[k];
+        for (int k = 0; k < 3; ++k) Tcw.t[k] = (float)poses[lp[i]].t[k];
+        lio.AddFromKeyFrame(Tcw, std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+    }
+    lio.BuildVoxHess();
+    if (n_planes) *n_planes = (int)lio.planes().size();
+    EdgeLidar edge;
+    edge.lio = &lio;
+    edge.information = wLBA;
+    BAResult r = LocalBundleAdjustment(poses, std::vector<uint8_t>(fixed, fixed + n_poses), pts, edges_from(edges6, n_edges), cam,
+                                       iterations, lambda_init, nullptr, &edge, &lp);
+    for (int i = 0; i < n_poses; ++i) pose_to(poses[i], poses7 + 7 * i);
+    std::memcpy(points3, pts.data(), pts.size() * sizeof(double));
+    for (int e = 0; e < n_edges; ++e) { if (chi2_out) chi2_out[e] = r.chi2[e]; if (depth_pos) depth_pos[e] = r.depth_pos[e]; }
+    const int m = std::min((int)r.trace.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
+    if (lidar_out) {
+        lidar_out[0] = edge.error; lidar_out[1] = edge.chi2();
+        for (size_t k = 0; k < edge.JacT.size(); ++k) lidar_out[2 + k] = edge.JacT[k];
+        for (size_t k = 0; k < edge.Hessian.size(); ++k) lidar_out[2 + edge.JacT.size() + k] = edge.Hessian[k];
+    }
+    return r.iterations;
+}
+
+// BALM residual and raw (LiDAR-pose) Jacobian / Hessian of BALM2::divide_thread for given window poses Twl (R 9 + p 3 doubles each)
+// on planes built from `n_win` clouds at those poses: used to check the analytic derivatives against finite differences.
+int oracle_balm_evaluate(const double* Twl12, int n_win, const float* clouds, const int* cloud_off, double* residual, double* JacT,
+                         double* Hess, const double* eval_Twl12, int n_eval, double* eval_residual) {
+    // poses are given directly as Twl; build with Tcl = identity and Tcw = Twl^-1 (float round trip as in the reference)
+    SE3fQ Tcl;
+    LidarCovisRes lio(Tcl);
+    lio.win_size_ = n_win;
+    std::vector<double> Rcw(9 * n_win), tcw(3 * n_win);
+    for (int i = 0; i < n_win; ++i) {
+        const double* R = Twl12 + 12 * i;
+        const double* p = R + 9;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rcw[9 * i + 3 * r + c] = R[3 * c + r];
+        for (int r = 0; r < 3; ++r) tcw[3 * i + r] = -(Rcw[9 * i + 3 * r] * p[0] + Rcw[9 * i + 3 * r + 1] * p[1] + Rcw[9 * i + 3 * r + 2] * p[2]);
+        SE3Quat q;
+        // Tcw as SE3f
+        SE3fQ Tcw;
+        float Rf[9];
+        for (int k = 0; k < 9; ++k) Rf[k] = (float)Rcw[9 * i + k];
+        // quaternion via the double helper of ba.cpp is not visible here: use UpdatePose after AddFromKeyFrame instead
+        (void)q; (void)Rf;
+        double tr = Rcw[9 * i] + Rcw[9 * i + 4] + Rcw[9 * i + 8];
+        double qw = std::sqrt(std::max(0.0, 1 + tr)) / 2;
+        Tcw.q[3] = (float)qw;
+        Tcw.q[0] = (float)((Rcw[9 * i + 7] - Rcw[9 * i + 5]) / (4 * qw));
+        Tcw.q[1] = (float)((Rcw[9 * i + 2] - Rcw[9 * i + 6]) / (4 * qw));
+        Tcw.q[2] = (float)((Rcw[9 * i + 3] - Rcw[9 * i + 1]) / (4 * qw));
+        for (int k = 0; k < 3; ++k) Tcw.t[k] = (float)tcw[3 * i + k];
+        lio.AddFromKeyFrame(Tcw, std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+    }
+    lio.BuildVoxHess();
+    for (int i = 0; i < n_win; ++i) lio.UpdatePose(i, &Rcw[9 * i], &tcw[3 * i]);
+    if (residual) *residual = lio.ComputeError();
+    if (JacT && Hess) {
+        std::vector<double> H, J;
+        lio.divide_thread(H, J);
+        std::memcpy(JacT, J.data(), J.size() * sizeof(double));
+        std::memcpy(Hess, H.data(), H.size() * sizeof(double));
+    }
+    for (int e = 0; e < n_eval; ++e) {  // residual of the same planes at other window poses
+        for (int i = 0; i < n_win; ++i) {
+            const double* R = eval_Twl12 + 12 * ((size_t)e * n_win + i);
+            const double* p = R + 9;
+            double Rc[9], tc[3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rc[3 * r + c] = R[3 * c + r];
+            for (int r = 0; r < 3; ++r) tc[r] = -(Rc[3 * r] * p[0] + Rc[3 * r + 1] * p[1] + Rc[3 * r + 2] * p[2]);
+            lio.UpdatePose(i, Rc, tc);
+        }
+        eval_residual[e] = lio.ComputeError();
+    }
+    return (int)lio.planes().size();
+}
+
 // error + analytic Jacobians of one binary projection edge (dim returned)
 int oracle_edge_linearize(const double* pose7, const double* X, const double* edge6, const double* cam5, double* err, double* A, double* B) {
     Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};

@@ -76,6 +76,9 @@ def lib():
         L.oracle_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.oracle_project_local_map.restype = None
+        L.oracle_local_ba_lidar.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_balm_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -377,3 +380,42 @@ def project_local_map(pose7, cam4, mbf, scales, log_scale, cols, rows, points, t
     lib().oracle_project_local_map(pose7.ctypes.data, cam4.ctypes.data, mbf, scales.ctypes.data, len(scales), log_scale, cols, rows,
                                    len(points), points.ctypes.data, th, int(far_points), th_far, cos_limit, out.ctypes.data)
     return out[:len(points)]
+
+
+def local_ba_lidar(poses7, fixed, points3, edges6, cam5, win_pose, clouds, Tcl7, wLBA, iterations=10, lambda_init=0.0):
+    """LocalLVBundleAdjustment's optimisation: visual edges + the BALM edge over the window keyframes `win_pose`.
+    clouds: list of [n_i, 3] float32 arrays (LiDAR frame).  Returns (poses, points, chi2, depth_pos, iterations, trace, n_planes, lidar)."""
+    poses, pts = _f64(poses7).copy(), _f64(points3).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges6, cam5 = _f64(edges6), _f64(cam5)
+    win = np.ascontiguousarray(win_pose, np.int32)
+    W = len(win)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    Tcl7 = np.ascontiguousarray(Tcl7, np.float32)
+    E = len(edges6)
+    chi2, dpos = np.zeros(max(E, 1)), np.zeros(max(E, 1), np.uint8)
+    tc, tl, tt = np.zeros(32), np.zeros(32), np.zeros(32, np.int32)
+    npl = C.c_int(0)
+    lid = np.zeros(2 + 6 * W + 36 * W * W)
+    it = lib().oracle_local_ba_lidar(poses.ctypes.data, fixed.ctypes.data, len(poses), pts.ctypes.data, len(pts), edges6.ctypes.data, E,
+                                     cam5.ctypes.data, iterations, lambda_init, win.ctypes.data, W, cl.ctypes.data, off.ctypes.data,
+                                     Tcl7.ctypes.data, wLBA, chi2.ctypes.data, dpos.ctypes.data, tc.ctypes.data, tl.ctypes.data,
+                                     tt.ctypes.data, 32, C.byref(npl), lid.ctypes.data)
+    lidar = dict(residual=lid[0], chi2=lid[1], JacT=lid[2:2 + 6 * W].copy(), Hessian=lid[2 + 6 * W:].reshape(6 * W, 6 * W).copy())
+    return poses, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it]), npl.value, lidar
+
+
+def balm_evaluate(Twl, clouds, eval_Twl=None):
+    """Planes from `clouds` at LiDAR poses Twl [W, 12] (R row-major, p) -> (n_planes, residual, JacT, Hess, residuals at eval_Twl)."""
+    Twl = _f64(Twl)
+    W = len(Twl)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    res = C.c_double(0)
+    J, H = np.zeros(6 * W), np.zeros((6 * W, 6 * W))
+    ev = _f64(eval_Twl if eval_Twl is not None else np.zeros((0, W, 12)))
+    er = np.zeros(max(len(ev), 1))
+    n = lib().oracle_balm_evaluate(Twl.ctypes.data, W, cl.ctypes.data, off.ctypes.data, C.addressof(res), J.ctypes.data, H.ctypes.data,
+                                   ev.ctypes.data, len(ev), er.ctypes.data)
+    return n, res.value, J, H, er[:len(ev)]

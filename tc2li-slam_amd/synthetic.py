@@ -270,3 +270,37 @@ def ba_window(seed=0, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.5, 0.05),
     pts_noisy = (pts_true * (1 + rng.normal(0, point_noise, (len(pts_true), 1)))).astype(np.float32).astype(np.float64)
     cam = np.array([np.float32(FX), np.float32(FY), np.float32(CX), np.float32(CY), np.float32(BF)], np.float64)
     return dict(poses=poses, fixed=fixed, points=pts_noisy, edges=edges, cam=cam, poses_true=poses_true, points_true=pts_true)
+
+
+# ---- LiDAR clouds for the BALM term of the local BA -----------------------------------------------------------------
+# KITTI-00 camera <- LiDAR extrinsic used by the synthetic windows: LiDAR axes x forward / y left / z up, camera axes
+# x right / y down / z forward, LiDAR 0.27 m behind and 0.08 m above the camera.
+TCL7 = np.array([0.5, -0.5, 0.5, 0.5, 0.0, -0.08, -0.27], np.float32)  # (qx, qy, qz, qw, tx, ty, tz) of Tcl
+
+
+def _quat_R(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def ba_window_clouds(w, win_pose, n_points=3000, noise=0.02, seed=0):
+    """Surface clouds (LiDAR frame, float32 [n, 3]) for the keyframes `win_pose` of a ba_window(): samples of the ground
+    plane y = CAM_HEIGHT and of two walls x = -7 / x = +9 (camera-world axes) around each TRUE keyframe pose."""
+    rng = np.random.default_rng([SEED0, 0xC10D, seed])
+    Rcl, tcl = _quat_R(TCL7[:4]), TCL7[4:].astype(np.float64)
+    clouds = []
+    for k in win_pose:
+        q, t = w["poses_true"][k][:4], w["poses_true"][k][4:]
+        Rcw = _quat_R(q)
+        cz = -(Rcw.T @ t)  # camera centre in the world
+        m = n_points // 3
+        g = np.stack([rng.uniform(-4, 4, m) + cz[0], np.full(m, CAM_HEIGHT), rng.uniform(2, 12, m) + cz[2]], 1)
+        wl = np.stack([np.full(m, -7.0), rng.uniform(-1.5, CAM_HEIGHT, m), rng.uniform(2, 12, m) + cz[2]], 1)
+        wr = np.stack([np.full(n_points - 2 * m, 9.0), rng.uniform(-1.5, CAM_HEIGHT, n_points - 2 * m), rng.uniform(2, 12, n_points - 2 * m) + cz[2]], 1)
+        Xw = np.concatenate([g, wl, wr]) + rng.normal(0, noise, (n_points, 3))
+        Xc = Xw @ Rcw.T + t
+        Xl = (Xc - tcl) @ Rcl  # Tlc * Xc
+        clouds.append(Xl.astype(np.float32))
+    return clouds
