@@ -288,6 +288,50 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                   double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                                   uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
 
+/* The LiDAR co-visibility window of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): the first
+ * min(6, .) local keyframes with a non-empty surface cloud, in list order.  Replaces LidarCovisRes::AddFromKeyFrame /
+ * BuildVoxHess (SF/src/LidarRes.cc:32-80) and the EdgeLidarSE3 they feed (SF/include/G2oTypesWithLidar.h:88-236). */
+typedef struct tc2li_lidar_window {
+    int32_t n_keyframes;          /* win_size_, 1 .. 20 */
+    int32_t pad_;
+    const int32_t* pose_index;    /* [n_keyframes] rows of poses7, the order of eBalm->setVertex(i, .) */
+    const float* cloud_xyz;       /* GetSurfacePcl() of the keyframes back to back, x y z per point, LiDAR frame */
+    const int32_t* cloud_offsets; /* [n_keyframes + 1], in points; every keyframe must have points */
+    float Tcl[7];                 /* mLidarParam->mTcl as qx qy qz qw tx ty tz */
+    float pad2_;
+    double weight;                /* mLidarParam->mWeightLocalBA (the edge's information) */
+} tc2li_lidar_window;
+
+typedef struct tc2li_lidar_ba_stats {
+    int32_t n_planes, hessian_evaluations;
+    double residual, chi2;        /* the edge's last error and chi2 */
+} tc2li_lidar_ba_stats;
+
+/* OptimizerWithLidar::LocalLVBundleAdjustment with the LiDAR edge (SF/src/OptimizerWithLidar.cc:60-487): the arguments of
+ * tc2li_local_bundle_adjustment plus the window.  The planes are extracted at the input poses; the optimiser then
+ * minimises the visual cost + weight * (sum over planes of N * lambda_min)^2 as the reference's edge does, including
+ * its bookkeeping (the Hessian is kept while the LiDAR cost grows, 6x6 blocks read at element offsets).  lidar == NULL
+ * is the visual-only optimisation.  Returns the number of iterations performed. */
+int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                     const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                     double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                     uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar,
+                                     tc2li_lidar_ba_stats* lidar_stats, void* stream);
+
+/* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
+ * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =
+ * LidarCovisRes::ComputeJandHSE3 (SF/src/LidarRes.cc:136-186, with respect to the camera se3 increments).  JacT and
+ * Hessian may be NULL.  Returns the number of planes. */
+int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* lidar, double* residual,
+                                double* JacT, double* Hessian, void* stream);
+
+/* Host-only stage of the LiDAR term, exposed so that it can be checked without a GPU: the planes of the window
+ * (cut_voxel + recut + tras_opt, SF/src/bavoxel.cc:42-91, SF/include/bavoxel.h:492-602,723-740).  clusters receives, per
+ * plane and window keyframe, 10 doubles: P00 P01 P02 P11 P12 P22 (sum x x^T), v (sum x), N in the keyframe's LiDAR
+ * frame; coe the plane weights.  Returns the number of planes (which may exceed `capacity`; only that many are written). */
+int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar_window* lidar, double* clusters, double* coe,
+                            int capacity);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

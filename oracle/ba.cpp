@@ -38,6 +38,7 @@ static void quat_to_matrix(const double q[4], double R[9]) {
     R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
+void quat_to_matrix_public(const double q[4], double R[9]) { quat_to_matrix(q, R); }
 static void matrix_to_quat(const double R[9], double q[4]) {  // Eigen::Quaterniond(Matrix3d)
     double t = R[0] + R[4] + R[8];
     if (t > 0) {

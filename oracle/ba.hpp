@@ -64,6 +64,7 @@ BAResult LocalBundleAdjustment(std::vector<SE3Quat>& poses, const std::vector<ui
 SE3Quat se3_exp(const double update[6]);
 SE3Quat se3_mul(const SE3Quat& a, const SE3Quat& b);
 void se3_map(const SE3Quat& T, const double X[3], double out[3]);
+void quat_to_matrix_public(const double q[4], double R[9]);  // Eigen::Quaterniond::toRotationMatrix
 // error (2 or 3 rows), Jacobians wrt point (A: dim x 3) and pose (B: dim x 6) of the binary projection edge
 int edge_linearize(const SE3Quat& T, const double X[3], const BAEdge& e, const Camera& cam, double err[3], double A[9], double B[18]);
 

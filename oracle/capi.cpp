@@ -324,6 +324,69 @@ int oracle_local_ba_lidar(double* poses7, const uint8_t* fixed, int n_poses, dou
     return r.iterations;
 }
 
+// The LiDAR edge alone: planes from the window at poses7, then ComputeError and ComputeJandHSE3 at the same poses
+// (the quantities tc2li_lidar_window_evaluate returns).
+int oracle_lidar_window_evaluate(const double* poses7, int n_poses, const int* win_pose, int n_win, const float* clouds,
+                                 const int* cloud_off, const float* Tcl7, double* residual, double* JacT, double* Hess) {
+    (void)n_poses;
+    SE3fQ Tcl;
+    std::memcpy(Tcl.q, Tcl7, 16); std::memcpy(Tcl.t, Tcl7 + 4, 12);
+    LidarCovisRes lio(Tcl);
+    lio.win_size_ = n_win;
+    std::vector<double> R(9 * n_win), t(3 * n_win);
+    for (int i = 0; i < n_win; ++i) {
+        const SE3Quat T = pose_from(poses7 + 7 * win_pose[i]);
+        SE3fQ Tcw;
+        for (int k = 0; k < 4; ++k) Tcw.q[k] = (float)T.q[k];
+        for (int k = 0; k < 3; ++k) Tcw.t[k] = (float)T.t[k];
+        lio.AddFromKeyFrame(Tcw, std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+        double Rt[9];
+        oracle::quat_to_matrix_public(T.q, Rt);
+        std::memcpy(&R[9 * i], Rt, sizeof(Rt));
+        std::memcpy(&t[3 * i], T.t, 3 * sizeof(double));
+    }
+    lio.BuildVoxHess();
+    EdgeLidar edge;
+    edge.lio = &lio;
+    edge.computeError(R.data(), t.data(), n_win);
+    if (residual) *residual = edge.error;
+    if (JacT && Hess) {
+        edge.is_calc_hess = true;
+        edge.linearizeOplus(R.data(), t.data(), n_win);
+        std::memcpy(JacT, edge.JacT.data(), edge.JacT.size() * sizeof(double));
+        std::memcpy(Hess, edge.Hessian.data(), edge.Hessian.size() * sizeof(double));
+    }
+    return (int)lio.planes().size();
+}
+
+// The planes of the window (VOX_HESS after BuildVoxHess): per plane and keyframe P (9), v (3), N -> 13 doubles; coe per plane.
+int oracle_lidar_planes(const double* poses7, const int* win_pose, int n_win, const float* clouds, const int* cloud_off,
+                        const float* Tcl7, double* clusters13, double* coe, int capacity) {
+    SE3fQ Tcl;
+    std::memcpy(Tcl.q, Tcl7, 16); std::memcpy(Tcl.t, Tcl7 + 4, 12);
+    LidarCovisRes lio(Tcl);
+    lio.win_size_ = n_win;
+    for (int i = 0; i < n_win; ++i) {
+        const SE3Quat T = pose_from(poses7 + 7 * win_pose[i]);
+        SE3fQ Tcw;
+        for (int k = 0; k < 4; ++k) Tcw.q[k] = (float)T.q[k];
+        for (int k = 0; k < 3; ++k) Tcw.t[k] = (float)T.t[k];
+        lio.AddFromKeyFrame(Tcw, std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+    }
+    lio.BuildVoxHess();
+    const int n = (int)lio.planes().size();
+    for (int a = 0; a < std::min(n, capacity); ++a) {
+        const PlaneVoxel& pv = lio.planes()[a];
+        coe[a] = pv.coe;
+        for (int i = 0; i < n_win; ++i) {
+            double* o = clusters13 + 13 * ((size_t)a * n_win + i);
+            std::memcpy(o, pv.sig_orig[i].P.m, 9 * sizeof(double));
+            o[9] = pv.sig_orig[i].v.x; o[10] = pv.sig_orig[i].v.y; o[11] = pv.sig_orig[i].v.z; o[12] = pv.sig_orig[i].N;
+        }
+    }
+    return n;
+}
+
 // BALM residual and raw (LiDAR-pose) Jacobian / Hessian of BALM2::divide_thread for given window poses Twl (R 9 + p 3 doubles each)
 // on planes built from `n_win` clouds at those poses: used to check the analytic derivatives against finite differences.
 int oracle_balm_evaluate(const double* Twl12, int n_win, const float* clouds, const int* cloud_off, double* residual, double* JacT,

@@ -79,6 +79,8 @@ def lib():
         L.oracle_local_ba_lidar.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_balm_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p]
+        L.oracle_lidar_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        L.oracle_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
         _lib = L
     return _lib
 
@@ -404,6 +406,35 @@ def local_ba_lidar(poses7, fixed, points3, edges6, cam5, win_pose, clouds, Tcl7,
                                      tt.ctypes.data, 32, C.byref(npl), lid.ctypes.data)
     lidar = dict(residual=lid[0], chi2=lid[1], JacT=lid[2:2 + 6 * W].copy(), Hessian=lid[2 + 6 * W:].reshape(6 * W, 6 * W).copy())
     return poses, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it]), npl.value, lidar
+
+
+def lidar_planes(poses7, win_pose, clouds, Tcl7, capacity=20000):
+    """Planes of the window -> (clusters [n, W, 13] = P (9) v (3) N, coe [n])."""
+    poses = _f64(poses7)
+    win = np.ascontiguousarray(win_pose, np.int32)
+    W = len(win)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    Tcl7 = np.ascontiguousarray(Tcl7, np.float32)
+    out, coe = np.zeros((capacity, W, 13)), np.zeros(capacity)
+    n = lib().oracle_lidar_planes(poses.ctypes.data, win.ctypes.data, W, cl.ctypes.data, off.ctypes.data, Tcl7.ctypes.data,
+                                  out.ctypes.data, coe.ctypes.data, capacity)
+    return out[:n].copy(), coe[:n].copy()
+
+
+def lidar_window_evaluate(poses7, win_pose, clouds, Tcl7):
+    """The LiDAR edge alone at poses7 -> (n_planes, residual, JacT [6W], Hessian [6W, 6W]) in the camera se3 parameterisation."""
+    poses = _f64(poses7)
+    win = np.ascontiguousarray(win_pose, np.int32)
+    W = len(win)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    Tcl7 = np.ascontiguousarray(Tcl7, np.float32)
+    res = C.c_double(0)
+    J, H = np.zeros(6 * W), np.zeros((6 * W, 6 * W))
+    n = lib().oracle_lidar_window_evaluate(poses.ctypes.data, len(poses), win.ctypes.data, W, cl.ctypes.data, off.ctypes.data,
+                                           Tcl7.ctypes.data, C.addressof(res), J.ctypes.data, H.ctypes.data)
+    return n, res.value, J, H
 
 
 def balm_evaluate(Twl, clouds, eval_Twl=None):

@@ -87,6 +87,10 @@ def lib():
     L.tc2li_pose_optimization_batch.argtypes = [C.c_int] + [C.c_void_p] * 8
     L.tc2li_local_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_local_lv_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                   C.c_int, C.c_double] + [C.c_void_p] * 7
+    L.tc2li_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
     L.tc2li_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -432,6 +436,70 @@ def local_bundle_adjustment(poses7, fixed, points3, edges, cam5, iterations=10, 
                                                edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
                                                chi2.ctypes.data, dpos.ctypes.data, C.byref(stats), C.c_void_p(stream)))
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats
+
+
+class LidarWindow(C.Structure):
+    """tc2li_lidar_window: the co-visibility window of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260)."""
+    _fields_ = [("n_keyframes", C.c_int32), ("pad_", C.c_int32), ("pose_index", C.c_void_p), ("cloud_xyz", C.c_void_p),
+                ("cloud_offsets", C.c_void_p), ("Tcl", C.c_float * 7), ("pad2_", C.c_float), ("weight", C.c_double)]
+
+
+class LidarBaStats(C.Structure):
+    _fields_ = [("n_planes", C.c_int32), ("hessian_evaluations", C.c_int32), ("residual", C.c_double), ("chi2", C.c_double)]
+
+
+def _pack_lidar_window(win_pose, clouds, Tcl7, weight):
+    win = np.ascontiguousarray(win_pose, np.int32)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float32).reshape(-1, 3) for c in clouds]), np.float32)
+    w = LidarWindow(len(win), 0, win.ctypes.data, cl.ctypes.data, off.ctypes.data, (C.c_float * 7)(*[float(x) for x in Tcl7]), 0.0,
+                    float(weight))
+    return w, (win, off, cl)  # keep the arrays alive
+
+
+def local_lv_bundle_adjustment(poses7, fixed, points3, edges, cam5, win_pose, clouds, Tcl7, weight, iterations=10, lambda_init=0.0,
+                               stop_flag=None, stream=0):
+    """``OptimizerWithLidar::LocalLVBundleAdjustment`` with the LiDAR edge over the keyframes ``win_pose`` (rows of
+    poses7) and their surface clouds -> (poses7, points3, chi2, depth_positive, stats, lidar_stats)."""
+    poses = np.ascontiguousarray(poses7, np.float64).copy()
+    pts = np.ascontiguousarray(points3, np.float64).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    chi2 = np.zeros(max(len(edges), 1))
+    dpos = np.zeros(max(len(edges), 1), np.uint8)
+    stats, lstats = BaStats(), LidarBaStats()
+    stop_ptr = stop_flag.ctypes.data if stop_flag is not None else None
+    w, keep = _pack_lidar_window(win_pose, clouds, Tcl7, weight)
+    _check(lib().tc2li_local_lv_bundle_adjustment(poses.ctypes.data, fixed.ctypes.data, len(poses), pts.ctypes.data, len(pts),
+                                                  edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
+                                                  chi2.ctypes.data, dpos.ctypes.data, C.addressof(stats), C.addressof(w),
+                                                  C.addressof(lstats), C.c_void_p(stream)))
+    del keep
+    return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
+
+
+def lidar_planes_host(poses7, win_pose, clouds, Tcl7, capacity=20000):
+    """Host-only plane extraction of the LiDAR window -> (clusters [n, W, 10] = P00 P01 P02 P11 P12 P22 v N, coe [n])."""
+    poses = np.ascontiguousarray(poses7, np.float64)
+    w, keep = _pack_lidar_window(win_pose, clouds, Tcl7, 1.0)
+    out, coe = np.zeros((capacity, w.n_keyframes, 10)), np.zeros(capacity)
+    n = _check(lib().tc2li_host_lidar_planes(poses.ctypes.data, len(poses), C.addressof(w), out.ctypes.data, coe.ctypes.data, capacity))
+    del keep
+    return out[:n].copy(), coe[:n].copy()
+
+
+def lidar_window_evaluate(poses7, win_pose, clouds, Tcl7, derivatives=True):
+    """The LiDAR edge alone -> (n_planes, residual, JacT [6W], Hessian [6W, 6W]) (ComputeError / ComputeJandHSE3)."""
+    poses = np.ascontiguousarray(poses7, np.float64)
+    w, keep = _pack_lidar_window(win_pose, clouds, Tcl7, 1.0)
+    W = w.n_keyframes
+    res = C.c_double(0)
+    J, H = np.zeros(6 * W), np.zeros((6 * W, 6 * W))
+    n = _check(lib().tc2li_lidar_window_evaluate(poses.ctypes.data, len(poses), C.addressof(w), C.addressof(res),
+                                                 J.ctypes.data if derivatives else None, H.ctypes.data if derivatives else None, None))
+    del keep
+    return n, res.value, J, H
 
 
 # ---- projection matching (ORBmatcher::SearchByProjection) ----------------------------------------------------------

@@ -8,6 +8,7 @@
 
 #include "common.hpp"
 #include "ba_device.hpp"
+#include "balm_host.hpp"
 #include "pose_opt_device.hpp"
 
 using namespace tc2li;
@@ -34,7 +35,8 @@ struct BaWorkspace {
     DevBuf<BaEdge> d_edges;
     DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
     DevBuf<uint8_t> d_depth;
-    PinnedBuf<double> h_S, h_bs, h_xp, h_scal;
+    PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp;
+    BalmTerm lidar;
     std::mutex mu;
 };
 BaWorkspace& ba_ws() { static BaWorkspace w; return w; }
@@ -98,10 +100,11 @@ int tc2li_pose_optimization(double pose7[7], const double* Xw, const tc2li_ba_ed
 // control flow of g2o (optimization_algorithm_levenberg.cpp:61-169) runs here on the host; every numerical step is a
 // kernel of ba_kernels.hip; the reduced camera system (6 x free poses) is factorised on the host (LDL^T), as g2o's
 // LinearSolverEigen does.
-int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
-                                  const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
-                                  double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
-                                  uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
+int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                     const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                     double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                     uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
+                                     tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
     if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
         set_error("tc2li_local_bundle_adjustment: invalid argument");
         return TC2LI_ERR_INVALID;
@@ -109,6 +112,7 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream_;
     if (stats) memset(stats, 0, sizeof(*stats));
+    if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
     // ---- structure: free-pose numbering, CSR by landmark and by free pose ----
     std::vector<int> pose_var(n_poses, -1);
     int n_free = 0;
@@ -119,6 +123,14 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
             return TC2LI_ERR_INVALID;
         }
         used[edges[e].pose] = 1;
+    }
+    if (lidar_window) {
+        if (lidar_window->n_keyframes < 1 || !lidar_window->pose_index) { set_error("lidar window: invalid argument"); return TC2LI_ERR_INVALID; }
+        for (int i = 0; i < lidar_window->n_keyframes; ++i) {
+            const int k = lidar_window->pose_index[i];
+            if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
+            used[k] = 1;
+        }
     }
     for (int k = 0; k < n_poses; ++k) if (!fixed[k] && used[k]) pose_var[k] = n_free++;
     std::vector<int> pt_off(n_points + 1, 0), pt_edges(n_edges), pv_off(n_free + 1, 0);
@@ -146,6 +158,12 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     // ---- device memory: a process-wide workspace that only grows (hipMalloc per call would dominate the run time) ----
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
+    BalmTerm* lidar = nullptr;
+    if (lidar_window) {
+        const int rc = ws.lidar.build(poses7, n_poses, lidar_window, st);
+        if (rc < 0) return rc;
+        lidar = &ws.lidar;
+    }
     auto &d_poses = ws.d_poses, &d_poses_trial = ws.d_poses_trial;
     auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
@@ -201,15 +219,41 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     int n_bad = 0, done = 0, trials_total = 0;
     bool ok = true;
     std::vector<double> Swork((size_t)std::max(np * np, 1)), x(std::max(np, 1));
+    std::vector<double> Hl, bl_;  // dense pose-pose contribution of the LiDAR edge
+    if (lidar) { Hl.assign((size_t)np * np, 0.0); bl_.assign(np, 0.0); }
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, st);
         TC2LI_HIP_CHECK(hipGetLastError());
+        const bool need_diag = lidar && it == 0 && !(lambda_init > 0) && n_free > 0;
+        if (need_diag) {
+            TC2LI_HIP_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
+            TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
         TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-        double currentChi = h_scal.p[0], tempChi = currentChi;
+        double currentChi = h_scal.p[0];
+        double max_pose_diag = h_scal.p[2];
+        if (lidar) {
+            // computeActiveErrors + linearizeOplus + constructQuadraticForm of the LiDAR edge
+            int rc = lidar->compute_error(pb.poses, st);
+            if (rc < 0) return rc;
+            currentChi = lidar->chi2() + currentChi;
+            rc = lidar->linearize(pb.poses, st);
+            if (rc < 0) return rc;
+            std::fill(Hl.begin(), Hl.end(), 0.0);
+            std::fill(bl_.begin(), bl_.end(), 0.0);
+            lidar->add_quadratic_form(pose_var.data(), np, Hl.data(), bl_.data());
+            if (need_diag) {
+                static const int dpos[6] = {0, 6, 11, 15, 18, 20};  // diagonal of the packed upper triangle
+                max_pose_diag = 0;
+                for (int j = 0; j < np; ++j)
+                    max_pose_diag = std::max(max_pose_diag, std::fabs(ws.h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + Hl[(size_t)j * np + j]));
+            }
+        }
+        double tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
             if (stats) stats->initial_chi2 = currentChi;
-            lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(h_scal.p[1], h_scal.p[2]);
+            lambda = lambda_init > 0 ? lambda_init : 1e-5 * std::max(h_scal.p[1], max_pose_diag);
             ni = 2;
             n_bad = 0;
         }
@@ -222,6 +266,10 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
             if (np > 0) {
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
                 memcpy(Swork.data(), h_S.p, (size_t)np * np * sizeof(double));
+                if (lidar) {
+                    for (size_t k = 0; k < (size_t)np * np; ++k) Swork[k] += Hl[k];
+                    for (int j = 0; j < np; ++j) { h_bs.p[j] += bl_[j]; h_bs.p[np + j] += bl_[j]; }
+                }
                 ok2 = ldlt_solve_small(Swork.data(), np, h_bs.p, x.data(), false);
                 memcpy(h_xp.p, x.data(), np * sizeof(double));
             }
@@ -234,6 +282,11 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
                 tempChi = h_scal.p[4];
                 scale += h_scal.p[3];
+                if (lidar) {
+                    const int rc = lidar->compute_error(pb.poses_trial, st);
+                    if (rc < 0) return rc;
+                    tempChi = lidar->chi2() + tempChi;
+                }
             } else {
                 tempChi = std::numeric_limits<double>::max();
             }
@@ -262,6 +315,10 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
         if (n_bad >= 3) ok = false;
     }
     if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; }
+    if (lidar && lidar_stats) {
+        lidar_stats->n_planes = lidar->n_planes; lidar_stats->hessian_evaluations = lidar->hessian_evaluations;
+        lidar_stats->residual = lidar->error; lidar_stats->chi2 = lidar->chi2();
+    }
     // ---- results ----
     ba_launch_depth(pb, d_depth.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
@@ -272,6 +329,41 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
     for (int k = 0; k < n_poses; ++k) { memcpy(poses7 + 7 * k, poses[k].q, 4 * sizeof(double)); memcpy(poses7 + 7 * k + 4, poses[k].t, 3 * sizeof(double)); }
     return done;
+}
+
+int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                  const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                  double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                  uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream) {
+    return tc2li_local_lv_bundle_adjustment(poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, iterations, lambda_init,
+                                            stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, stream);
+}
+
+int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* residual, double* JacT,
+                                double* Hessian, void* stream_) {
+    if (!poses7 || n_poses <= 0 || !win) { set_error("tc2li_lidar_window_evaluate: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    int rc = ws.lidar.build(poses7, n_poses, win, st);
+    if (rc < 0) return rc;
+    std::vector<Se3> poses(n_poses);
+    for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
+    TC2LI_HIP_CHECK(ws.d_poses.ensure(n_poses));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
+    rc = ws.lidar.compute_error(ws.d_poses.p, st);
+    if (rc < 0) return rc;
+    if (residual) *residual = ws.lidar.error;
+    if (JacT && Hessian) {
+        ws.lidar.is_calc_hess = true;
+        rc = ws.lidar.linearize(ws.d_poses.p, st);
+        if (rc < 0) return rc;
+        const int n = 6 * ws.lidar.W;
+        memcpy(JacT, ws.lidar.JacT.data(), n * sizeof(double));
+        memcpy(Hessian, ws.lidar.Hessian.data(), (size_t)n * n * sizeof(double));
+    }
+    return ws.lidar.n_planes;
 }
 
 }  // extern "C"

@@ -313,8 +313,8 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     hipLaunchKernelGGL(k_ba_schur_points, dim3(blocks(pb.n_points)), dim3(256), 0, st, pb, lambda);
-    if (pb.n_free_edges) {
-        hipLaunchKernelGGL(k_ba_schur_edges, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
+    if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
+        if (pb.n_free_edges) hipLaunchKernelGGL(k_ba_schur_edges, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
         hipLaunchKernelGGL(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
         const int tiles = pb.np_pad / 16;
         hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points,

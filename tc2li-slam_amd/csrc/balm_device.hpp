@@ -1,0 +1,36 @@
+// Shared between the host orchestration and the kernels of the LiDAR plane term (balm_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "balm_math.hpp"
+
+namespace tc2li {
+
+constexpr int kMaxLidarWindow = 20;  // LidarCovisRes::win_size_ default (SF/include/LidarRes.h); the local BA uses <= 6
+
+// The plane list of one window resident on the device (VOX_HESS: plvec_voxels / coeffs, SF/include/bavoxel.h:48-78).
+struct BalmDev {
+    int32_t W, n_planes, n_chunks, planes_per_chunk;
+    const PlaneCluster* clusters;  // [n_planes][W]
+    const double* coe;             // [n_planes]
+    const int32_t* pose_index;     // [W] rows of the pose array
+    SE3f Tcl;
+    LidarPose* twl;                // [W]
+    double* plane_res;             // [n_planes]
+    double* part;                  // [n_chunks][balm_part_stride(W)]
+    double* out;                   // [1 + 6W + (6W)^2]: residual, JacT, Hessian (row-major)
+};
+
+inline int balm_items(int W) { return W * (W + 1) / 2 * 36; }
+inline int balm_part_stride(int W) { return balm_items(W) + 6 * W + 1; }
+inline int balm_out_size(int W) { return 1 + 6 * W + 36 * W * W; }
+
+// twl[i] = LiDAR pose of window slot i from the vertex estimates `poses` (LidarCovisRes::UpdatePose)
+void balm_launch_poses(const BalmDev& b, const Se3* poses, hipStream_t st);
+// out[0] = sum over planes of coe * lambda_min at the poses in b.twl (VOX_HESS::evaluate_only_residual)
+void balm_launch_residual(const BalmDev& b, hipStream_t st);
+// out = residual, JacT and Hessian with respect to the LiDAR poses (BALM2::divide_thread / VOX_HESS::acc_evaluate2)
+void balm_launch_hessian(const BalmDev& b, hipStream_t st);
+
+}  // namespace tc2li

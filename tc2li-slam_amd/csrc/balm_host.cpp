@@ -1,0 +1,424 @@
+// See balm_host.hpp.  Host stages of the LiDAR plane term: plane extraction (once per local BA), the change of variables
+// of the 6W x 6W system (once per linearisation) and the edge state machine.
+#include "balm_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace tc2li {
+
+namespace {
+
+constexpr int kLayerLimit = 2, kMinPoints = 15;                       // SF/include/bavoxel.h:35-41
+constexpr float kPlaneRatio[3] = {1.0f / 36, 1.0f / 25, 1.0f / 25};  // eigen_value_array
+constexpr double kVoxelSize = 1.0;
+
+struct VoxelKey {
+    int64_t x, y, z;
+    bool operator==(const VoxelKey& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct VoxelKeyHash {
+    size_t operator()(const VoxelKey& k) const {
+        uint64_t h = (uint64_t)k.x * 0x9E3779B97F4A7C15ull;
+        h ^= (uint64_t)k.y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+        h ^= (uint64_t)k.z * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+        return (size_t)h;
+    }
+};
+
+struct WindowPoint { double local[3], world[3]; int32_t slot; };
+
+struct Moments {  // running sums in insertion order: PointCluster::push
+    double P[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+    int n = 0;
+    void push(const double* x) {
+        ++n;
+        P[0] += x[0] * x[0]; P[1] += x[0] * x[1]; P[2] += x[0] * x[2]; P[3] += x[1] * x[1]; P[4] += x[1] * x[2]; P[5] += x[2] * x[2];
+        v[0] += x[0]; v[1] += x[1]; v[2] += x[2];
+    }
+};
+
+struct Cell { int begin, end, layer; float center[3], quarter; };
+
+}  // namespace
+
+void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const int32_t* off, std::vector<PlaneCluster>& clusters,
+                       std::vector<double>& coe) {
+    clusters.clear();
+    coe.clear();
+    const int total = off[W];
+    std::vector<WindowPoint> pts(total);
+    // ---- points into the frame of the first keyframe's LiDAR, root voxel of every point ----
+    double R0t[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R0t[3 * r + c] = twl[0].R[3 * c + r];
+    std::unordered_map<VoxelKey, int, VoxelKeyHash> root_of;
+    root_of.reserve((size_t)total / 4 + 16);
+    std::vector<VoxelKey> root_key;
+    std::vector<int> root_id(total), root_count;
+    for (int i = 0; i < W; ++i) {
+        double d[3], p[3], R[9];
+        for (int k = 0; k < 3; ++k) d[k] = twl[i].p[k] - twl[0].p[k];
+        m3_vec(R0t, d, p);
+        m3_mul(R0t, twl[i].R, R);
+        for (int j = off[i]; j < off[i + 1]; ++j) {
+            WindowPoint& q = pts[j];
+            q.slot = i;
+            for (int k = 0; k < 3; ++k) q.local[k] = (double)cloud[3 * (size_t)j + k];
+            double Rx[3];
+            m3_vec(R, q.local, Rx);
+            VoxelKey key;
+            int64_t* kk = &key.x;
+            for (int k = 0; k < 3; ++k) {
+                q.world[k] = Rx[k] + p[k];
+                float loc = (float)(q.world[k] / kVoxelSize);
+                if (loc < 0) loc -= 1.0f;
+                kk[k] = (int64_t)loc;
+            }
+            auto it = root_of.find(key);
+            int id;
+            if (it == root_of.end()) {
+                id = (int)root_key.size();
+                root_of.emplace(key, id);
+                root_key.push_back(key);
+                root_count.push_back(0);
+            } else {
+                id = it->second;
+            }
+            root_id[j] = id;
+            root_count[id]++;
+        }
+    }
+    // ---- counting sort by root voxel; inside a voxel the points stay in (keyframe, scan) order ----
+    const int n_roots = (int)root_key.size();
+    std::vector<int> start(n_roots + 1, 0);
+    for (int r = 0; r < n_roots; ++r) start[r + 1] = start[r] + root_count[r];
+    std::vector<int> order(total), scratch(total);
+    {
+        std::vector<int> cur(start.begin(), start.end() - 1);
+        for (int j = 0; j < total; ++j) order[cur[root_id[j]]++] = j;
+    }
+    // ---- every root voxel: plane test, split into octants while not planar ----
+    std::vector<Moments> local(W), world(W);
+    std::vector<Cell> stack;
+    for (int r = 0; r < n_roots; ++r) {
+        Cell root;
+        root.begin = start[r]; root.end = start[r + 1]; root.layer = 0;
+        const int64_t* kk = &root_key[r].x;
+        for (int k = 0; k < 3; ++k) root.center[k] = (float)((0.5 + (double)kk[k]) * kVoxelSize);
+        root.quarter = (float)(kVoxelSize / 4.0);
+        stack.clear();
+        stack.push_back(root);
+        while (!stack.empty()) {
+            const Cell cell = stack.back();
+            stack.pop_back();
+            const int count = cell.end - cell.begin;
+            if (count <= kMinPoints) continue;
+            for (int i = 0; i < W; ++i) { local[i] = Moments(); world[i] = Moments(); }
+            for (int a = cell.begin; a < cell.end; ++a) {
+                const WindowPoint& q = pts[order[a]];
+                local[q.slot].push(q.local);
+                world[q.slot].push(q.world);
+            }
+            // covariance of all points of the cell in the common frame
+            double P[6] = {0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+            int n = 0;
+            for (int i = 0; i < W; ++i) {
+                for (int k = 0; k < 6; ++k) P[k] += world[i].P[k];
+                for (int k = 0; k < 3; ++k) v[k] += world[i].v[k];
+                n += world[i].n;
+            }
+            const double inv = 1.0 / n;
+            const double c[3] = {inv * v[0], inv * v[1], inv * v[2]};
+            double Ps[9], C[9], lambda[3], U[9];
+            sym_unpack(P, Ps);
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = inv * Ps[3 * a + b] - c[a] * c[b];
+            eig_sym3(C, lambda, U);
+            if (lambda[0] / lambda[1] < (double)kPlaneRatio[cell.layer]) {
+                int seen = 0;
+                for (int i = 0; i < W; ++i) seen += local[i].n != 0;
+                if (seen < 2) continue;  // VOX_HESS::push_voxel: a plane must be seen from two keyframes
+                double weight = 0;
+                for (int i = 0; i < W; ++i) {
+                    PlaneCluster pc;
+                    memcpy(pc.P, local[i].P, sizeof(pc.P));
+                    memcpy(pc.v, local[i].v, sizeof(pc.v));
+                    pc.n = (double)local[i].n;
+                    weight += (double)local[i].n;
+                    clusters.push_back(pc);
+                }
+                coe.push_back(weight);
+                continue;
+            }
+            if (cell.layer == kLayerLimit) continue;
+            // stable split into the 8 octants around the cell centre
+            int cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            auto octant = [&](const WindowPoint& q) {
+                return 4 * (q.world[0] > cell.center[0]) + 2 * (q.world[1] > cell.center[1]) + (q.world[2] > cell.center[2]);
+            };
+            for (int a = cell.begin; a < cell.end; ++a) cnt[octant(pts[order[a]]) + 1]++;
+            for (int o = 0; o < 8; ++o) cnt[o + 1] += cnt[o];
+            int cur[8];
+            for (int o = 0; o < 8; ++o) cur[o] = cell.begin + cnt[o];
+            for (int a = cell.begin; a < cell.end; ++a) { const int j = order[a]; scratch[cur[octant(pts[j])]++] = j; }
+            std::copy(scratch.begin() + cell.begin, scratch.begin() + cell.end, order.begin() + cell.begin);
+            for (int o = 7; o >= 0; --o) {  // pushed in reverse so that octant 0 is visited first
+                if (cnt[o + 1] == cnt[o]) continue;
+                Cell child;
+                child.begin = cell.begin + cnt[o]; child.end = cell.begin + cnt[o + 1]; child.layer = cell.layer + 1;
+                const int bit[3] = {(o >> 2) & 1, (o >> 1) & 1, o & 1};
+                for (int k = 0; k < 3; ++k) child.center[k] = cell.center[k] + (2 * bit[k] - 1) * cell.quarter;
+                child.quarter = cell.quarter / 2;
+                stack.push_back(child);
+            }
+        }
+    }
+}
+
+// ---- LiDAR-pose derivatives -> camera se3 derivatives ---------------------------------------------------------------
+static void so3_log_f(const double* Rd, double out[3]) {  // Sophus::SO3f(R.cast<float>()).log()
+    float R[9], q[4];
+    for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
+    matrix_to_quat_f(R, q);
+    const float sq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], w = q[3];
+    float two_atan;
+    const float eps = 1e-10f;
+    if (sq < eps * eps) {
+        two_atan = 2.0f / w - (2.0f / 3.0f) * sq / (w * w * w);
+    } else {
+        const float n = sqrtf(sq);
+        if (fabsf(w) < eps) two_atan = (w > 0 ? 3.14159265358979323846f : -3.14159265358979323846f) / n;
+        else two_atan = 2.0f * atanf(n / w) / n;
+    }
+    for (int k = 0; k < 3; ++k) out[k] = (double)(two_atan * q[k]);
+}
+
+static void inverse_right_jacobian_so3(const double v[3], double J[9]) {  // SF/src/G2oTypes.cc:823-839
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+    for (int k = 0; k < 9; ++k) J[k] = k % 4 == 0 ? 1.0 : 0.0;
+    if (d < 1e-5) return;
+    double Wm[9], W2[9];
+    m3_hat(v, Wm);
+    m3_mul(Wm, Wm, W2);
+    const double k2 = 1.0 / d2 - (1.0 + cos(d)) / (2.0 * d * sin(d));
+    for (int k = 0; k < 9; ++k) J[k] = J[k] + 0.5 * Wm[k] + k2 * W2[k];
+}
+
+void balm_to_camera_se3(const LidarPose* twl, int W, const SE3f& Tcl, double* JacT, double* H) {
+    const int n = 6 * W;
+    // Tlc = Tcl^-1 in float, widened
+    const float qi[4] = {-Tcl.q[0], -Tcl.q[1], -Tcl.q[2], Tcl.q[3]};
+    const float nt[3] = {Tcl.t[0] * -1.f, Tcl.t[1] * -1.f, Tcl.t[2] * -1.f};
+    float tlc_f[3];
+    quat_rotate_f(qi, nt, tlc_f);
+    double Rlc[9];
+    quat_to_matrix_f(qi, Rlc);
+    const double tlc[3] = {(double)tlc_f[0], (double)tlc_f[1], (double)tlc_f[2]};
+    const double tcl[3] = {(double)Tcl.t[0], (double)Tcl.t[1], (double)Tcl.t[2]};
+    for (int i = 0; i < W; ++i) {
+        const double* Rwl = twl[i].R;
+        double Rwc[9], Rcw[9], twc[3], tcw[3], tmp[3];
+        m3_mul(Rwl, Rlc, Rwc);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rcw[3 * r + c] = Rwc[3 * c + r];
+        m3_vec(Rwl, tlc, tmp);
+        for (int k = 0; k < 3; ++k) twc[k] = tmp[k] + twl[i].p[k];
+        m3_vec(Rcw, twc, tmp);
+        for (int k = 0; k < 3; ++k) tcw[k] = -1.0 * tmp[k];
+        const double* Jw = JacT + 6 * i;
+        const double* Jt = JacT + 6 * i + 3;
+        double rwl[3], Jr[9], JrRlc[9], A[9] /* (Jr^-1 Rlc)^T */, dt[3], dth[9], RwcH[9], B[9] /* (Rwc [tcl - tcw]x)^T */;
+        so3_log_f(Rwl, rwl);
+        inverse_right_jacobian_so3(rwl, Jr);
+        m3_mul(Jr, Rlc, JrRlc);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlc[3 * c + r];
+        for (int k = 0; k < 3; ++k) dt[k] = tcl[k] - tcw[k];
+        m3_hat(dt, dth);
+        m3_mul(Rwc, dth, RwcH);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwcH[3 * c + r];
+        double AJw[3], BJt[3], Jw2[3], Jt2[3], tcwh[9], tcwhT[9], t1[3], t2[3];
+        m3_vec(A, Jw, AJw);
+        m3_vec(B, Jt, BJt);
+        for (int k = 0; k < 3; ++k) Jw2[k] = -1.0 * AJw[k] + BJt[k];
+        m3_vec(Rcw, Jt, tmp);
+        for (int k = 0; k < 3; ++k) Jt2[k] = -1.0 * tmp[k];
+        m3_hat(tcw, tcwh);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tcwhT[3 * r + c] = tcwh[3 * c + r];
+        m3_vec(Rcw, Jw2, t1);
+        m3_vec(tcwhT, Jt2, t2);
+        // D_i^T (6 x 6): rows = camera increment (rotation, translation), columns = LiDAR-pose increment
+        double DT[36] = {0}, D[36], m1[9], m2[9], m3[9];
+        m3_mul(Rcw, A, m1);
+        m3_mul(Rcw, B, m2);
+        m3_mul(tcwhT, Rcw, m3);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                DT[6 * r + c] = -1.0 * m1[3 * r + c];
+                DT[6 * r + 3 + c] = m2[3 * r + c] + m3[3 * r + c];
+                DT[6 * (3 + r) + 3 + c] = -1.0 * Rcw[3 * r + c];
+            }
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[6 * r + c] = DT[6 * c + r];
+        for (int k = 0; k < 3; ++k) { JacT[6 * i + k] = t1[k] - t2[k]; JacT[6 * i + 3 + k] = Jt2[k]; }
+        // row block i <- D_i^T * row block i, then column block i <- column block i * D_i, block by block
+        for (int j = 0; j < W; ++j) {
+            double blk[36], o[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * i + r) * n + 6 * j + c];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DT[6 * r + k] * blk[6 * k + c]; o[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * i + r) * n + 6 * j + c] = o[6 * r + c];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * j + r) * n + 6 * i + c];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += blk[6 * r + k] * D[6 * k + c]; o[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * j + r) * n + 6 * i + c] = o[6 * r + c];
+        }
+    }
+}
+
+// ---- the edge ---------------------------------------------------------------------------------------------------------
+int BalmTerm::window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl) {
+    const int W = win->n_keyframes;
+    if (W < 1 || W > kMaxLidarWindow || !win->pose_index || !win->cloud_xyz || !win->cloud_offsets) {
+        set_error("lidar window: n_keyframes must be in [1, %d] and the arrays non-null", kMaxLidarWindow);
+        return TC2LI_ERR_INVALID;
+    }
+    if (win->cloud_offsets[0] != 0) { set_error("lidar window: cloud_offsets[0] must be 0"); return TC2LI_ERR_INVALID; }
+    SE3f Tcl;
+    memcpy(Tcl.q, win->Tcl, 4 * sizeof(float));
+    memcpy(Tcl.t, win->Tcl + 4, 3 * sizeof(float));
+    twl.resize(W);
+    for (int i = 0; i < W; ++i) {
+        const int k = win->pose_index[i];
+        if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
+        if (win->cloud_offsets[i + 1] <= win->cloud_offsets[i]) { set_error("lidar window: keyframe %d has no points", i); return TC2LI_ERR_INVALID; }
+        SE3f Tcw;  // KeyFrame::GetPose() is a Sophus::SE3f
+        for (int c = 0; c < 4; ++c) Tcw.q[c] = (float)poses7[7 * k + c];
+        for (int c = 0; c < 3; ++c) Tcw.t[c] = (float)poses7[7 * k + 4 + c];
+        twl[i] = lidar_pose_from(Tcw, Tcl);
+    }
+    return 0;
+}
+
+int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st) {
+    std::vector<LidarPose> twl;
+    const int rcw = window_poses(poses7, n_poses, win, twl);
+    if (rcw < 0) return rcw;
+    W = win->n_keyframes;
+    memcpy(Tcl.q, win->Tcl, 4 * sizeof(float));
+    memcpy(Tcl.t, win->Tcl + 4, 3 * sizeof(float));
+    information = win->weight;
+    error = 0; r1 = 1000; r2 = 1000; is_calc_hess = true; hessian_evaluations = 0;
+    JacT.assign(6 * (size_t)W, 0.0);
+    Hessian.assign(36 * (size_t)W * W, 0.0);
+    pose_index.assign(win->pose_index, win->pose_index + W);
+    std::vector<PlaneCluster> clusters;
+    std::vector<double> coe;
+    balm_build_planes(twl.data(), W, win->cloud_xyz, win->cloud_offsets, clusters, coe);
+    n_planes = (int)coe.size();
+    dev = BalmDev{};
+    dev.W = W; dev.n_planes = n_planes;
+    dev.n_chunks = std::max(1, std::min(n_planes, 1024));
+    dev.planes_per_chunk = n_planes ? (n_planes + dev.n_chunks - 1) / dev.n_chunks : 0;
+    dev.n_chunks = n_planes ? (n_planes + dev.planes_per_chunk - 1) / dev.planes_per_chunk : 1;
+    dev.Tcl = Tcl;
+    TC2LI_HIP_CHECK(d_clusters.ensure(std::max(clusters.size(), (size_t)1)));
+    TC2LI_HIP_CHECK(d_coe.ensure(std::max(n_planes, 1)));
+    TC2LI_HIP_CHECK(d_plane_res.ensure(std::max(n_planes, 1)));
+    TC2LI_HIP_CHECK(d_part.ensure((size_t)dev.n_chunks * balm_part_stride(W)));
+    TC2LI_HIP_CHECK(d_pose_index.ensure(W));
+    TC2LI_HIP_CHECK(d_twl.ensure(W));
+    TC2LI_HIP_CHECK(h_out.ensure(balm_out_size(W)));
+    TC2LI_HIP_CHECK(h_twl.ensure(W));
+    if (n_planes) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_clusters.p, clusters.data(), clusters.size() * sizeof(PlaneCluster), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, coe.data(), coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors go out of scope
+    dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
+    dev.plane_res = d_plane_res.p; dev.part = d_part.p; dev.out = h_out.p;
+    return 0;
+}
+
+int BalmTerm::compute_error(const Se3* d_poses, hipStream_t st) {
+    double r = 0;
+    if (n_planes) {
+        balm_launch_poses(dev, d_poses, st);
+        balm_launch_residual(dev, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        r = h_out.p[0];
+    }
+    error = r;
+    r1 = r2;
+    r2 = r;
+    is_calc_hess = !(r1 - r2 < 0);  // the Hessian is kept while the cost grows (G2oTypesWithLidar.h:130-139)
+    return 0;
+}
+
+int BalmTerm::linearize(const Se3* d_poses, hipStream_t st) {
+    if (!is_calc_hess) return 0;
+    ++hessian_evaluations;
+    if (!n_planes) {
+        std::fill(JacT.begin(), JacT.end(), 0.0);
+        std::fill(Hessian.begin(), Hessian.end(), 0.0);
+        return 0;
+    }
+    balm_launch_poses(dev, d_poses, st);
+    balm_launch_hessian(dev, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(h_twl.p, d_twl.p, W * sizeof(LidarPose), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    const int n = 6 * W;
+    memcpy(JacT.data(), h_out.p + 1, n * sizeof(double));
+    memcpy(Hessian.data(), h_out.p + 1 + n, (size_t)n * n * sizeof(double));
+    balm_to_camera_se3(h_twl.p, W, Tcl, JacT.data(), Hessian.data());
+    return 0;
+}
+
+void BalmTerm::add_quadratic_form(const int* pose_var, int np, double* Hpp, double* b) const {
+    // The reference reads the 6x6 blocks at ELEMENT offsets (i, i) / (i, j) of the 6W x 6W Hessian and subtracts
+    // information * J^T from b (G2oTypesWithLidar.h:168-236); kept as is so that the optimiser takes the same steps.
+    const int n = 6 * W;
+    for (int i = 0; i < W; ++i) {
+        const int vi = pose_var[pose_index[i]];
+        if (vi < 0) continue;
+        for (int r = 0; r < 6; ++r) {
+            b[6 * vi + r] -= information * JacT[6 * i + r];
+            for (int c = 0; c < 6; ++c) Hpp[(size_t)(6 * vi + r) * np + 6 * vi + c] += Hessian[(size_t)(i + r) * n + i + c] * information;
+        }
+        for (int j = i + 1; j < W; ++j) {
+            const int vj = pose_var[pose_index[j]];
+            if (vj < 0) continue;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    const double h = Hessian[(size_t)(i + r) * n + j + c] * information;
+                    Hpp[(size_t)(6 * vi + r) * np + 6 * vj + c] += h;
+                    Hpp[(size_t)(6 * vj + c) * np + 6 * vi + r] += h;
+                }
+        }
+    }
+}
+
+}  // namespace tc2li
+
+extern "C" int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* clusters, double* coe,
+                                       int capacity) {
+    using namespace tc2li;
+    if (!poses7 || n_poses <= 0 || !win || capacity < 0 || (capacity > 0 && (!clusters || !coe))) {
+        set_error("tc2li_host_lidar_planes: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    std::vector<LidarPose> twl;
+    const int rc = BalmTerm::window_poses(poses7, n_poses, win, twl);
+    if (rc < 0) return rc;
+    std::vector<PlaneCluster> cl;
+    std::vector<double> w;
+    balm_build_planes(twl.data(), win->n_keyframes, win->cloud_xyz, win->cloud_offsets, cl, w);
+    const int n = (int)w.size(), m = std::min(n, capacity);
+    static_assert(sizeof(PlaneCluster) == 10 * sizeof(double), "cluster layout");
+    if (m > 0) {
+        memcpy(clusters, cl.data(), (size_t)m * win->n_keyframes * sizeof(PlaneCluster));
+        memcpy(coe, w.data(), (size_t)m * sizeof(double));
+    }
+    return n;
+}

@@ -1,0 +1,54 @@
+// Host side of the LiDAR plane term of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): plane extraction
+// from the window's surface clouds and the EdgeLidarSE3 state that the Levenberg-Marquardt loop of ba_host.cpp drives.
+#pragma once
+#include <vector>
+
+#include "../../include/tc2li_hip.h"
+#include "balm_device.hpp"
+#include "common.hpp"
+
+namespace tc2li {
+
+// Adaptive voxelisation of the window clouds (cut_voxel + OCTO_TREE_NODE::recut / tras_opt, SF/src/bavoxel.cc:42-91,
+// SF/include/bavoxel.h:492-602,723-740): points are binned into 1 m voxels in the frame of the first keyframe's LiDAR;
+// a voxel whose points are planar (lambda_min / lambda_mid below 1/36, 1/25 in deeper layers) becomes one plane, a
+// non-planar one is split into octants up to two times.  Returns the per-keyframe clusters [n_planes][W] and coe.
+void balm_build_planes(const LidarPose* twl, int W, const float* cloud_xyz, const int32_t* cloud_offsets,
+                       std::vector<PlaneCluster>& clusters, std::vector<double>& coe);
+
+// Jacobian / Hessian with respect to the LiDAR poses (R <- R Exp(dtheta), p <- p + dp) -> with respect to the left
+// se3 increment of the camera poses Tcw that g2o::VertexSE3Expmap applies (LidarCovisRes::ComputeJandHSE3,
+// SF/src/LidarRes.cc:136-186).  In place; H is (6W)^2 row-major.
+void balm_to_camera_se3(const LidarPose* twl, int W, const SE3f& Tcl, double* JacT, double* H);
+
+struct BalmTerm {
+    int W = 0, n_planes = 0;
+    double information = 1;
+    SE3f Tcl{};
+    std::vector<int32_t> pose_index;
+    // EdgeLidarSE3 state (SF/include/G2oTypesWithLidar.h:88-236)
+    double error = 0, r1 = 1000, r2 = 1000;
+    bool is_calc_hess = true;
+    int hessian_evaluations = 0;
+    std::vector<double> JacT, Hessian;  // camera-se3 forms of the last evaluation
+
+    BalmDev dev{};
+    DevBuf<PlaneCluster> d_clusters;
+    DevBuf<double> d_coe, d_plane_res, d_part;
+    DevBuf<int32_t> d_pose_index;
+    DevBuf<LidarPose> d_twl;
+    PinnedBuf<double> h_out;
+    PinnedBuf<LidarPose> h_twl;
+
+    // argument checks + LiDAR poses of the window keyframes at `poses7`
+    static int window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl);
+    // planes of the window at the poses `poses7` (Tcw per keyframe, rows pose_index of the array)
+    int build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st);
+    int compute_error(const Se3* d_poses, hipStream_t st);  // EdgeLidarSE3::computeError
+    int linearize(const Se3* d_poses, hipStream_t st);      // EdgeLidarSE3::linearizeOplus
+    double chi2() const { return error * information * error; }
+    // EdgeLidarSE3::computeQuadraticFormLidarRes: add to the dense pose-pose system (free pose numbering pose_var)
+    void add_quadratic_form(const int* pose_var, int np, double* Hpp, double* b) const;
+};
+
+}  // namespace tc2li

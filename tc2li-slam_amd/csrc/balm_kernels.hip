@@ -1,0 +1,250 @@
+// LiDAR plane term of the local bundle adjustment on gfx950: the cost sum_planes N * lambda_min(cov of the plane's points
+// over the window) and its first / second derivatives with respect to the window's LiDAR poses.
+//   VOX_HESS::evaluate_only_residual   SF/include/bavoxel.h:276-315   -> k_balm_residual
+//   VOX_HESS::acc_evaluate2            SF/include/bavoxel.h:80-196    -> k_balm_hessian
+//   BALM2::divide_thread               SF/include/bavoxel.h:778-817   -> chunks of planes + k_balm_combine (fixed order)
+//   LidarCovisRes::UpdatePose          SF/src/LidarRes.cc:221-235     -> k_balm_poses
+// Layout: one workgroup owns a contiguous chunk of planes; every thread owns up to 8 entries of the upper block triangle
+// of the (6W)^2 Hessian in registers (entry = (block pair, row, column)), so no atomics and a fixed summation order.
+#include <hip/hip_runtime.h>
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "balm_device.hpp"
+
+namespace tc2li {
+
+constexpr int kHessThreads = 1024, kItemsPerThread = 8;
+static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsPerThread, "window too large for the item ownership");
+
+__global__ void k_balm_poses(BalmDev b, const Se3* __restrict__ poses) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.W) return;
+    b.twl[i] = lidar_pose_from(se3f_from_vertex(poses[b.pose_index[i]]), b.Tcl);
+}
+
+// merged window cluster of one plane -> covariance -> eigen decomposition
+__device__ __forceinline__ void plane_eigen(const ClusterW* cw, int W, double& NN, double vbar[3], double lambda[3], double U[9]) {
+    double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
+    double n = 0;
+    for (int i = 0; i < W; ++i) {
+        if (cw[i].n == 0) continue;
+        for (int k = 0; k < 9; ++k) P[k] += cw[i].P[k];
+        for (int k = 0; k < 3; ++k) v[k] += cw[i].v[k];
+        n += cw[i].n;
+    }
+    NN = n;
+    const double inv = 1.0 / n;
+    for (int k = 0; k < 3; ++k) vbar[k] = inv * v[k];
+    double C[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vbar[r] * vbar[c];
+    eig_sym3(C, lambda, U);
+}
+
+__global__ __launch_bounds__(64) void k_balm_residual(BalmDev b) {
+    const int a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= b.n_planes) return;
+    double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0}, n = 0;
+    for (int i = 0; i < b.W; ++i) {
+        const PlaneCluster s = b.clusters[(size_t)a * b.W + i];
+        if (s.n == 0) continue;
+        ClusterW t;
+        cluster_transform(s, b.twl[i], t);
+        for (int k = 0; k < 9; ++k) P[k] += t.P[k];
+        for (int k = 0; k < 3; ++k) v[k] += t.v[k];
+        n += t.n;
+    }
+    const double inv = 1.0 / n;
+    double vb[3], C[9], lambda[3], U[9];
+    for (int k = 0; k < 3; ++k) vb[k] = inv * v[k];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vb[r] * vb[c];
+    eig_sym3(C, lambda, U);
+    b.plane_res[a] = b.coe[a] * lambda[0];
+}
+
+// out[0] = in[0] + in[1] + ... in a fixed tree order
+__global__ __launch_bounds__(1024) void k_balm_sum(const double* __restrict__ in, int n, double* __restrict__ out) {
+    __shared__ double s[1024];
+    double a = 0;
+    for (int k = threadIdx.x; k < n; k += 1024) a += in[k];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 512; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b) {
+    __shared__ ClusterW s_cw[kMaxLidarWindow];
+    __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
+    __shared__ double s_w[kMaxLidarWindow][3], s_E[kMaxLidarWindow][9], s_k1[kMaxLidarWindow], s_k2[kMaxLidarWindow], s_n[kMaxLidarWindow];
+    __shared__ double s_uk[3], s_ukuk[9], s_umum[9], s_vbar[3], s_NN, s_l0;
+    __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
+    const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
+    if (tid == 0) {
+        int p = 0;
+        for (int i = 0; i < W; ++i)
+            for (int j = i; j < W; ++j) { s_pi[p] = (uint8_t)i; s_pj[p] = (uint8_t)j; ++p; }
+    }
+    double acc[kItemsPerThread], jac[6] = {0, 0, 0, 0, 0, 0}, res = 0;
+#pragma unroll
+    for (int k = 0; k < kItemsPerThread; ++k) acc[k] = 0;
+    const int a0 = blockIdx.x * b.planes_per_chunk, a1 = min(a0 + b.planes_per_chunk, b.n_planes);
+    for (int a = a0; a < a1; ++a) {
+        const double coe = b.coe[a];
+        PlaneCluster mine;
+        mine.n = 0;
+        if (tid < W) {
+            mine = b.clusters[(size_t)a * W + tid];
+            s_n[tid] = mine.n;
+            if (mine.n != 0) cluster_transform(mine, b.twl[tid], s_cw[tid]);
+            else s_cw[tid].n = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double NN, vbar[3], lambda[3], U[9];
+            plane_eigen(s_cw, W, NN, vbar, lambda, U);
+            const double u0[3] = {U[0], U[3], U[6]};
+            for (int k = 0; k < 3; ++k) { s_uk[k] = u0[k]; s_vbar[k] = vbar[k]; }
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    s_ukuk[3 * r + c] = u0[r] * u0[c];
+                    double m = 0;
+                    for (int e = 1; e < 3; ++e) m = m + (2.0 / (lambda[0] - lambda[e])) * (U[3 * r + e] * U[3 * c + e]);
+                    s_umum[3 * r + c] = m;
+                }
+            s_NN = NN;
+            s_l0 = lambda[0];
+        }
+        __syncthreads();
+        const double NN = s_NN;
+        if (tid == 0) res += coe * s_l0;
+        if (tid < W && mine.n != 0) {
+            const LidarPose T = b.twl[tid];
+            const double ni = mine.n;
+            double Pi[9], uk[3] = {s_uk[0], s_uk[1], s_uk[2]};
+            sym_unpack(mine.P, Pi);
+            const double* vi = mine.v;
+            double vihat[9], RiTuk[3], RiTukhat[9], PiRiTuk[3], w[3], tv[3];
+            m3_hat(vi, vihat);
+            m3_tvec(T.R, uk, RiTuk);
+            m3_hat(RiTuk, RiTukhat);
+            m3_vec(Pi, RiTuk, PiRiTuk);
+            m3_vec(vihat, RiTuk, w);
+            for (int k = 0; k < 3; ++k) tv[k] = T.p[k] - s_vbar[k];
+            const double ukt = uk[0] * tv[0] + uk[1] * tv[1] + uk[2] * tv[2];
+            double combo1[9], h[9], combo2[3], Rv[3];
+            m3_hat(PiRiTuk, h);
+            for (int k = 0; k < 9; ++k) combo1[k] = h[k] + ukt * vihat[k];
+            m3_vec(T.R, vi, Rv);
+            for (int k = 0; k < 3; ++k) combo2[k] = Rv[k] + ni * tv[k];
+            double RP[9], lhs[9], left[9], Rc[9];
+            m3_mul(T.R, Pi, RP);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) RP[3 * r + c] = RP[3 * r + c] + tv[r] * vi[c];
+            m3_mul(RP, RiTukhat, lhs);
+            m3_mul(T.R, combo1, Rc);
+            for (int k = 0; k < 9; ++k) left[k] = lhs[k] - Rc[k];
+            const double c2u = combo2[0] * uk[0] + combo2[1] * uk[1] + combo2[2] * uk[2];
+            double A[18];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    A[6 * r + c] = left[3 * r + c] / NN;
+                    A[6 * r + 3 + c] = (combo2[r] * uk[c] + (r == c ? c2u : 0.0)) / NN;
+                }
+            double jjt[6];
+            for (int c = 0; c < 6; ++c) {
+                jjt[c] = A[c] * uk[0] + A[6 + c] * uk[1] + A[12 + c] * uk[2];
+                jac[c] += coe * jjt[c];
+            }
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    s_A[tid][6 * r + c] = A[6 * r + c];
+                    s_MB[tid][6 * r + c] = s_umum[3 * r] * A[c] + s_umum[3 * r + 1] * A[6 + c] + s_umum[3 * r + 2] * A[12 + c];
+                }
+            // extra terms of the diagonal block: rotation-rotation part
+            double d1[9], d2[9], RhP[9], jh[9];
+            m3_mul(RiTukhat, Pi, RhP);
+            for (int k = 0; k < 9; ++k) d1[k] = combo1[k] - RhP[k];
+            m3_mul(d1, RiTukhat, d2);
+            m3_hat(jjt, jh);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    s_E[tid][3 * r + c] = (2.0 / NN) * d2[3 * r + c] + (-2.0 / NN / NN) * (w[r] * w[c]) + (-0.5) * jh[3 * r + c];
+            for (int k = 0; k < 3; ++k) s_w[tid][k] = w[k];
+            s_k1[tid] = 2.0 / NN * (1.0 - ni / NN);
+            s_k2[tid] = 2.0 / NN * (ni - ni * ni / NN);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItemsPerThread; ++k) {
+            const int item = k * kHessThreads + tid;
+            if (item >= n_items) continue;
+            const int pair = item / 36, rc = item % 36, r = rc / 6, c = rc % 6;
+            const int i = s_pi[pair], j = s_pj[pair];
+            const double ni = s_n[i], nj = s_n[j];
+            if (ni == 0 || nj == 0) continue;
+            double val = s_A[i][r] * s_MB[j][c] + s_A[i][6 + r] * s_MB[j][6 + c] + s_A[i][12 + r] * s_MB[j][12 + c];
+            if (i == j) {
+                if (r < 3 && c < 3) val += s_E[i][3 * r + c];
+                else if (r < 3) val += s_k1[i] * (s_w[i][r] * s_uk[c - 3]);
+                else if (c < 3) val += s_k1[i] * (s_w[i][c] * s_uk[r - 3]);
+                else val += s_k2[i] * s_ukuk[3 * (r - 3) + (c - 3)];
+            } else {
+                if (r < 3 && c < 3) val += (-2.0 / NN / NN) * (s_w[i][r] * s_w[j][c]);
+                else if (r < 3) val += (-2.0 * nj / NN / NN) * (s_w[i][r] * s_uk[c - 3]);
+                else if (c < 3) val += (-2.0 * ni / NN / NN) * (s_uk[r - 3] * s_w[j][c]);
+                else val += (-2.0 * ni * nj / NN / NN) * s_ukuk[3 * (r - 3) + (c - 3)];
+            }
+            acc[k] += coe * val;
+        }
+        __syncthreads();
+    }
+    double* part = b.part + (size_t)blockIdx.x * (n_items + 6 * W + 1);
+#pragma unroll
+    for (int k = 0; k < kItemsPerThread; ++k) {
+        const int item = k * kHessThreads + tid;
+        if (item < n_items) part[item] = acc[k];
+    }
+    if (tid < W)
+        for (int c = 0; c < 6; ++c) part[n_items + 6 * tid + c] = jac[c];
+    if (tid == 0) part[n_items + 6 * W] = res;
+}
+
+// chunk partials -> out (residual, JacT, full Hessian with the lower block triangle mirrored), chunks added in order
+__global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
+    const int W = b.W, n = 6 * W, n_items = W * (W + 1) / 2 * 36, stride = n_items + n + 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= stride) return;
+    double s = 0;
+    for (int k = 0; k < b.n_chunks; ++k) s += b.part[(size_t)k * stride + idx];
+    if (idx == n_items + n) { b.out[0] = s; return; }
+    if (idx >= n_items) { b.out[1 + (idx - n_items)] = s; return; }
+    const int pair = idx / 36, rc = idx % 36, r = rc / 6, c = rc % 6;
+    int i = 0, rem = pair;  // pair -> (i, j >= i)
+    while (rem >= W - i) { rem -= W - i; ++i; }
+    const int j = i + rem;
+    double* H = b.out + 1 + n;
+    H[(size_t)(6 * i + r) * n + 6 * j + c] = s;
+    if (i != j) H[(size_t)(6 * j + c) * n + 6 * i + r] = s;
+}
+
+void balm_launch_poses(const BalmDev& b, const Se3* poses, hipStream_t st) {
+    hipLaunchKernelGGL(k_balm_poses, dim3(1), dim3(64), 0, st, b, poses);
+}
+
+void balm_launch_residual(const BalmDev& b, hipStream_t st) {
+    hipLaunchKernelGGL(k_balm_residual, dim3((b.n_planes + 63) / 64), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(k_balm_sum, dim3(1), dim3(1024), 0, st, b.plane_res, b.n_planes, b.out);
+}
+
+void balm_launch_hessian(const BalmDev& b, hipStream_t st) {
+    hipLaunchKernelGGL(k_balm_hessian, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b);
+    hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 255) / 256), dim3(256), 0, st, b);
+}
+
+}  // namespace tc2li

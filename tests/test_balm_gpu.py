@@ -1,0 +1,86 @@
+"""GPU parity of the LiDAR plane term with the oracle: the edge alone (residual, Jacobian,
+Hessian in the camera se3 parameterisation) and LocalLVBundleAdjustment with the edge in the Levenberg-Marquardt loop.
+Bar (BASELINE.json): optimised SE3 poses within 1e-4 relative; the optimiser must also take the same trials."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_RTOL = 1e-4
+
+
+def rel_pose_err(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("seed,W,n_pts", [(0, 4, 2400), (1, 6, 3000), (2, 2, 1500), (3, 12, 1200), (4, 20, 800)])
+def test_lidar_edge_alone(pkg, oracle, synthetic, seed, W, n_pts):
+    n_opt = max(6, W)
+    w = synthetic.ba_window(seed, n_opt=n_opt, n_fix=4, n_points=200, pose_noise=(0.1, 0.01))
+    last = len(w["poses"]) - 1
+    win = list(range(last, last - W, -1))
+    clouds = synthetic.ba_window_clouds(w, win, n_points=n_pts)
+    n0, r0, J0, H0 = oracle.lidar_window_evaluate(w["poses"], win, clouds, synthetic.TCL7)
+    n1, r1, J1, H1 = pkg.capi.lidar_window_evaluate(w["poses"], win, clouds, synthetic.TCL7)
+    assert n1 == n0 and n0 > 10
+    assert abs(r1 - r0) <= 1e-10 * abs(r0)
+    assert np.allclose(J1, J0, rtol=1e-8, atol=1e-9 * np.abs(J0).max())
+    assert np.allclose(H1, H0, rtol=1e-8, atol=1e-9 * np.abs(H0).max())
+    # residual only (derivatives not requested)
+    n2, r2, _, _ = pkg.capi.lidar_window_evaluate(w["poses"], win, clouds, synthetic.TCL7, derivatives=False)
+    assert n2 == n0 and r2 == r1
+
+
+@pytest.mark.parametrize("seed,weight,lam,W", [(0, 0.01, 0.0, 6), (0, 1.0, 0.0, 6), (1, 100.0, 0.0, 6), (2, 1.0, 100.0, 4), (3, 10.0, 0.0, 3)])
+def test_local_lv_bundle_adjustment(pkg, oracle, synthetic, seed, weight, lam, W):
+    w = synthetic.ba_window(seed, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
+    last = len(w["poses"]) - 1
+    win = list(range(last, last - W, -1))
+    clouds = synthetic.ba_window_clouds(w, win, n_points=3000)
+    want = oracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], win, clouds, synthetic.TCL7, weight,
+                                 iterations=10, lambda_init=lam)
+    poses, pts, chi2, dpos, stats, ls = pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], pkg.pack_ba_edges(w["edges"]),
+                                                                           w["cam"], win, clouds, synthetic.TCL7, weight, iterations=10,
+                                                                           lambda_init=lam)
+    assert ls.n_planes == want[6] and ls.n_planes > 10
+    assert stats.iterations == want[4]
+    assert stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.final_chi2 - want[5]["chi2"][-1]) <= 1e-6 * want[5]["chi2"][-1]
+    assert abs(ls.residual - want[7]["residual"]) <= 1e-6 * abs(want[7]["residual"])
+    for k in range(len(poses)):
+        assert rel_pose_err(poses[k], want[0][k]) < POSE_RTOL
+    assert np.array_equal(poses[w["fixed"] > 0], w["poses"][w["fixed"] > 0])
+    assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6)
+    assert np.array_equal(dpos, want[3])
+    assert np.allclose(chi2, want[2], rtol=1e-4, atol=1e-6)
+    # the edge really takes part: the result differs from the visual-only optimisation
+    base = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], pkg.pack_ba_edges(w["edges"]), w["cam"], iterations=10, lambda_init=lam)
+    assert np.abs(base[0] - poses).max() > 1e-8
+
+
+def test_lidar_window_with_a_keyframe_outside_the_visual_graph(pkg, oracle, synthetic):
+    """A window keyframe without any visual edge still becomes a variable (its vertex is connected through the LiDAR edge)."""
+    w = synthetic.ba_window(5, n_opt=6, n_fix=6, n_points=800, pose_noise=(0.1, 0.01))
+    last = len(w["poses"]) - 1
+    win = [last, last - 1, last - 2]
+    clouds = synthetic.ba_window_clouds(w, win, n_points=2400)
+    edges = w["edges"][w["edges"][:, 1] != last - 1]
+    seen = np.zeros(len(w["points"]), bool); seen[edges[:, 0].astype(int)] = True
+    remap = np.cumsum(seen) - 1
+    edges = edges.copy(); edges[:, 0] = remap[edges[:, 0].astype(int)]
+    points = w["points"][seen]
+    want = oracle.local_ba_lidar(w["poses"], w["fixed"], points, edges, w["cam"], win, clouds, synthetic.TCL7, 1.0)
+    got = pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], points, pkg.pack_ba_edges(edges), w["cam"], win, clouds, synthetic.TCL7, 1.0)
+    assert got[4].iterations == want[4] and got[4].trials == int(want[5]["trials"].sum())
+    for k in range(len(got[0])):
+        assert rel_pose_err(got[0][k], want[0][k]) < POSE_RTOL
+    assert np.abs(got[0][last - 1] - w["poses"][last - 1]).max() > 1e-9  # moved by the LiDAR edge alone
+
+
+def test_lidar_window_argument_errors(pkg, synthetic):
+    w = synthetic.ba_window(0, n_opt=3, n_fix=3, n_points=100)
+    clouds = synthetic.ba_window_clouds(w, [5, 4], n_points=200)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.lidar_window_evaluate(w["poses"], [5, 77], clouds, synthetic.TCL7)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.lidar_window_evaluate(w["poses"], list(range(6)) * 4, clouds * 12, synthetic.TCL7)  # 24 keyframes > 20

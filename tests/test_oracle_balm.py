@@ -88,3 +88,37 @@ def test_lidar_edge_in_the_lm_loop(oracle, synthetic):
     # window of 2 keyframes is below the reference's threshold (> 2, OptimizerWithLidar.cc:236) but the edge itself works
     r2 = oracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], win[:3], clouds[:3], synthetic.TCL7, 0.01)
     assert r2[4] >= 1
+
+
+def _canon(P6v3n, coe):
+    """Order-independent view of a plane list: sort planes by a key built from their content."""
+    key = np.round(np.concatenate([coe[:, None], P6v3n[:, :, 6:9].sum(1)], 1), 6)
+    order = np.lexsort(key.T[::-1])
+    return P6v3n[order], coe[order]
+
+
+def test_host_plane_extraction_matches_the_oracle(pkg, oracle, synthetic):
+    """tc2li_host_lidar_planes (the product's host stage; no GPU needed) against cut_voxel / recut / tras_opt of the oracle:
+    same planes, bit-identical cluster sums (the visiting order of planes is unspecified in the reference: unordered_map)."""
+    for seed, n_pts, noise in [(0, 2400, (0.1, 0.01)), (3, 1500, (0.02, 0.002))]:
+        w = synthetic.ba_window(seed, n_opt=6, n_fix=6, n_points=300, pose_noise=noise)
+        win = [11, 10, 9, 8, 7]
+        clouds = synthetic.ba_window_clouds(w, win, n_points=n_pts)
+        oc, ocoe = oracle.lidar_planes(w["poses"], win, clouds, synthetic.TCL7)
+        pc, pcoe = pkg.capi.lidar_planes_host(w["poses"], win, clouds, synthetic.TCL7)
+        assert len(ocoe) == len(pcoe) and len(ocoe) > 20
+        o10 = np.concatenate([oc[:, :, [0, 1, 2, 4, 5, 8]], oc[:, :, 9:13]], 2)
+        assert np.array_equal(oc[:, :, [1, 2, 5]], oc[:, :, [3, 6, 7]])  # P is symmetric
+        a, ac = _canon(o10, ocoe)
+        b, bc = _canon(pc, pcoe)
+        assert np.array_equal(ac, bc)
+        assert np.array_equal(a, b)
+
+
+def test_host_plane_extraction_rejects_bad_windows(pkg, synthetic):
+    w = synthetic.ba_window(0, n_opt=3, n_fix=3, n_points=100)
+    clouds = synthetic.ba_window_clouds(w, [5, 4], n_points=200)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.lidar_planes_host(w["poses"], [5, 99], clouds, synthetic.TCL7)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.lidar_planes_host(w["poses"], [5, 4], [clouds[0], np.zeros((0, 3), np.float32)], synthetic.TCL7)
