@@ -288,6 +288,35 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                   double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                                   uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834), data path only, for a batch of independent frames
+ * whose features are device-resident: SearchByProjection(cur, last, th) with ORBmatcher(0.9, true), the 2*th retry
+ * when fewer than 20 matches, Optimizer::PoseOptimization, outlier bookkeeping.  Frame f is images 2f / 2f+1 of the
+ * handle's last tc2li_orb_extract_batch call; keypoints ([2*n_frames][capacity]) and u_right ([n_frames][capacity])
+ * are the host arrays that call and tc2li_stereo_match_batch returned.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_last_frame {      /* what the matcher reads of mLastFrame */
+    int32_t n;
+    int32_t pad_;
+    const uint8_t* has_point;          /* mvpMapPoints[i] != NULL */
+    const uint8_t* outlier;            /* mvbOutlier[i] */
+    const float* Xw;                   /* pMP->GetWorldPos(), 3 per keypoint */
+    const tc2li_keypoint* keys;        /* mvKeysUn (octave, angle are read) */
+    const uint8_t* descriptors;        /* pMP->GetDescriptor(), 32 B per keypoint */
+    float pose7[7];                    /* LastFrame.GetPose() */
+    float pad2_;
+} tc2li_last_frame;
+
+/* pose_pred7 [n_frames][7] = mVelocity * mLastFrame.GetPose() (Sophus::SE3f).  Outputs: poses7 [n_frames][7] (double:
+ * the optimised pose rounded through float as Frame::SetPose does, or the prediction when tracking failed),
+ * map_point_of_keypoint [n_frames][capacity] = index of the last-frame point now held by keypoint i (mvpMapPoints[i])
+ * or -1, outliers already discarded; n_matches[f] = matches after the search stage; n_inliers[f] = the value
+ * PoseOptimization returned, -1 when fewer than 20 matches were found (Tracking.cc:2785-2793). */
+int tc2li_track_motion_model_batch(tc2li_orb* orb, int n_frames, const tc2li_keypoint* keypoints, const float* u_right,
+                                   int capacity, const tc2li_last_frame* last, const float* pose_pred7,
+                                   const tc2li_camera* cam, float b, float th, double* poses7,
+                                   int32_t* map_point_of_keypoint, int32_t* n_matches, int32_t* n_inliers, void* stream);
+
 /* The LiDAR co-visibility window of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): the first
  * min(6, .) local keyframes with a non-empty surface cloud, in list order.  Replaces LidarCovisRes::AddFromKeyFrame /
  * BuildVoxHess (SF/src/LidarRes.cc:32-80) and the EdgeLidarSE3 they feed (SF/include/G2oTypesWithLidar.h:88-236). */

@@ -505,6 +505,65 @@ void oracle_project_last_frame(const float* pose_cur7, const float* pose_last7, 
     queries_to(qs, out);
 }
 
+// Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834), data path of one frame: SearchByProjection(th) with
+// ORBmatcher(0.9, true), the 2*th retry below 20 matches, PoseOptimization, outliers discarded.  Returns the value of
+// PoseOptimization, -1 when the search found fewer than 20 matches.
+int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
+                              const float* inv_sigma2, int nlevels, const float* pose_pred7, const float* pose_last7, const double* cam5,
+                              float mb, float th, int n_last, const uint8_t* has_point, const uint8_t* outlier_last, const float* Xw,
+                              const float* last_keys6, const uint8_t* mp_desc, double* pose_out7, int* map_point_of_keypoint,
+                              int* n_matches) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    F.occupied.assign(n, 0);
+    F.cols = cols; F.rows = rows;
+    SE3f Tcw, Tlw;
+    std::memcpy(Tcw.q, pose_pred7, 16); std::memcpy(Tcw.t, pose_pred7 + 4, 12);
+    std::memcpy(Tlw.q, pose_last7, 16); std::memcpy(Tlw.t, pose_last7 + 4, 12);
+    CamF camf{(float)cam5[0], (float)cam5[1], (float)cam5[2], (float)cam5[3]};
+    const std::vector<float> sc(scales, scales + nlevels);
+    const std::vector<uint8_t> hp(has_point, has_point + n_last), ol(outlier_last, outlier_last + n_last);
+    const std::vector<float> X(Xw, Xw + 3 * (size_t)n_last);
+    const std::vector<KeyPoint> lk = kps_from(last_keys6, n_last);
+    const std::vector<uint8_t> md(mp_desc, mp_desc + (size_t)n_last * 32);
+    std::vector<int> match;
+    int nm = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        auto qs = build_queries_last_frame(Tcw, Tlw, camf, mb, (float)cam5[4], sc, cols, rows, hp, ol, X, lk, md, attempt == 0 ? th : 2 * th, false);
+        nm = match_queries(F, qs, MATCH_BEST, 0.9f, match);
+        nm -= rotation_filter(F, qs, match);
+        if (nm >= 20) break;
+    }
+    *n_matches = nm;
+    for (int i = 0; i < n; ++i) map_point_of_keypoint[i] = -1;
+    for (int q = 0; q < n_last; ++q) if (match[q] >= 0) map_point_of_keypoint[match[q]] = q;
+    for (int c = 0; c < 7; ++c) pose_out7[c] = (double)pose_pred7[c];
+    if (nm < 20) return -1;
+    std::vector<double> Xd;
+    std::vector<BAEdge> edges;
+    std::vector<int> kp_of_edge;
+    for (int i = 0; i < n; ++i) {
+        const int q = map_point_of_keypoint[i];
+        if (q < 0) continue;
+        BAEdge e;
+        e.point = (int)edges.size(); e.pose = 0;
+        e.obs[0] = F.keys[i].x; e.obs[1] = F.keys[i].y; e.obs[2] = uright[i];
+        e.info = inv_sigma2[F.keys[i].octave];
+        edges.push_back(e);
+        for (int c = 0; c < 3; ++c) Xd.push_back((double)Xw[3 * (size_t)q + c]);
+        kp_of_edge.push_back(i);
+    }
+    SE3Quat T = pose_from(pose_out7);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    std::vector<uint8_t> out;
+    const int inl = PoseOptimization(T, Xd, edges, cam, out);
+    pose_to(T, pose_out7);
+    for (size_t e = 0; e < edges.size() && e < out.size(); ++e) if (out[e]) map_point_of_keypoint[kp_of_edge[e]] = -1;
+    return inl;
+}
+
 struct MapPointPOD { float pos[3], normal[3], min_distance, max_distance, max_distance_raw; uint8_t desc[32]; };  // tc2li_map_point
 void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, const float* scales, int nlevels, float log_scale, int cols,
                               int rows, int n, const MapPointPOD* pts, float th, int far_points, float th_far, float cos_limit, QueryPOD* out) {

@@ -361,6 +361,30 @@ def search_by_projection(keys, desc, u_right, occupied, cols, rows, queries, mod
     return n, match[:len(queries)]
 
 
+def track_motion_model(keys, desc, u_right, cols, rows, scales, inv_sigma2, pose_pred7, pose_last7, cam5, mb, th, has_point, outlier,
+                       Xw, last_keys, mp_desc):
+    """Tracking::TrackWithMotionModel data path of one frame -> (pose7, map_point_of_keypoint, n_matches, n_inliers)."""
+    k6 = _kps_to_floats(keys)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(u_right, np.float32)
+    scales, inv_sigma2 = np.ascontiguousarray(scales, np.float32), np.ascontiguousarray(inv_sigma2, np.float32)
+    pp, pl = np.ascontiguousarray(pose_pred7, np.float32), np.ascontiguousarray(pose_last7, np.float32)
+    cam5 = _f64(cam5)
+    hp, ol = np.ascontiguousarray(has_point, np.uint8), np.ascontiguousarray(outlier, np.uint8)
+    Xw = np.ascontiguousarray(Xw, np.float32)
+    l6 = _kps_to_floats(last_keys)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    pose = np.zeros(7)
+    mp = np.full(max(len(k6), 1), -1, np.int32)
+    nm = C.c_int(0)
+    f = lib().oracle_track_motion_model
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 8
+    inl = f(k6.ctypes.data, desc.ctypes.data, ur.ctypes.data, len(k6), cols, rows, scales.ctypes.data, inv_sigma2.ctypes.data, len(scales),
+            pp.ctypes.data, pl.ctypes.data, cam5.ctypes.data, mb, th, len(l6), hp.ctypes.data, ol.ctypes.data, Xw.ctypes.data, l6.ctypes.data,
+            mp_desc.ctypes.data, pose.ctypes.data, mp.ctypes.data, C.addressof(nm))
+    return pose, mp[:len(k6)], nm.value, inl
+
+
 def project_last_frame(pose_cur7, pose_last7, cam4, mb, mbf, scales, cols, rows, has_point, outlier, Xw, last_keys, mp_desc, th, mono=False):
     pc, pl, cam4 = [np.ascontiguousarray(a, np.float32) for a in (pose_cur7, pose_last7, cam4)]
     scales = np.ascontiguousarray(scales, np.float32)

@@ -90,6 +90,8 @@ def lib():
     L.tc2li_local_lv_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                    C.c_int, C.c_double] + [C.c_void_p] * 7
     L.tc2li_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.tc2li_track_motion_model_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_float, C.c_float] + [C.c_void_p] * 5
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -436,6 +438,45 @@ def local_bundle_adjustment(poses7, fixed, points3, edges, cam5, iterations=10, 
                                                edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
                                                chi2.ctypes.data, dpos.ctypes.data, C.byref(stats), C.c_void_p(stream)))
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats
+
+
+class LastFrame(C.Structure):
+    """tc2li_last_frame: what SearchByProjection(F, LastFrame) reads of mLastFrame."""
+    _fields_ = [("n", C.c_int32), ("pad_", C.c_int32), ("has_point", C.c_void_p), ("outlier", C.c_void_p), ("Xw", C.c_void_p),
+                ("keys", C.c_void_p), ("descriptors", C.c_void_p), ("pose7", C.c_float * 7), ("pad2_", C.c_float)]
+
+
+def pack_last_frames(items):
+    """items: list of dicts with has_point, outlier, Xw, keys, descriptors, pose7 -> (ctypes array, keep-alive list)."""
+    arr = (LastFrame * len(items))()
+    keep = []
+    for i, it in enumerate(items):
+        hp = np.ascontiguousarray(it["has_point"], np.uint8); ol = np.ascontiguousarray(it["outlier"], np.uint8)
+        Xw = np.ascontiguousarray(it["Xw"], np.float32); keys = np.ascontiguousarray(it["keys"], KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(it["descriptors"], np.uint8)
+        keep.append((hp, ol, Xw, keys, desc))
+        arr[i] = LastFrame(len(keys), 0, hp.ctypes.data, ol.ctypes.data, Xw.ctypes.data, keys.ctypes.data, desc.ctypes.data,
+                           (C.c_float * 7)(*[float(x) for x in it["pose7"]]), 0.0)
+    return arr, keep
+
+
+def track_motion_model_batch(ext, n_frames, keypoints, u_right, last_frames, pose_pred7, cam5, b, th=7.0, stream=0, out=None):
+    """``Tracking::TrackWithMotionModel`` data path for the frames of the preceding ``extract_batch_dev`` /
+    ``stereo_match_batch`` calls -> (poses7 [F, 7], map_point_of_keypoint [F, capacity], n_matches [F], n_inliers [F]).
+    last_frames: result of ``pack_last_frames``."""
+    keypoints = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
+    u_right = np.ascontiguousarray(u_right, np.float32)
+    pp = np.ascontiguousarray(pose_pred7, np.float32)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    cap = keypoints.shape[1]
+    if out is None:
+        out = (np.zeros((n_frames, 7)), np.full((n_frames, cap), -1, np.int32), np.zeros(n_frames, np.int32), np.zeros(n_frames, np.int32))
+    poses, mp, nm, inl = out
+    arr = last_frames[0] if isinstance(last_frames, tuple) else last_frames
+    _check(lib().tc2li_track_motion_model_batch(ext._h, n_frames, keypoints.ctypes.data, u_right.ctypes.data, cap, C.addressof(arr),
+                                                pp.ctypes.data, cam5.ctypes.data, b, th, poses.ctypes.data, mp.ctypes.data,
+                                                nm.ctypes.data, inl.ctypes.data, C.c_void_p(stream)))
+    return poses, mp, nm, inl
 
 
 class LidarWindow(C.Structure):

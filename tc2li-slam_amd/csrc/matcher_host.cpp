@@ -10,6 +10,8 @@
 
 #include "common.hpp"
 #include "matcher_device.hpp"
+#include "matcher_host.hpp"
+#include "orb_handle.hpp"
 
 using namespace tc2li;
 
@@ -24,6 +26,9 @@ struct MatcherWorkspace {
     DevBuf<float> d_ur;
     DevBuf<MatchQuery> d_queries;
     DevBuf<int32_t> d_match, d_prev, d_rounds;
+    PinnedBuf<float> h_ur;
+    PinnedBuf<MatchFrameDev> h_frames;
+    PinnedBuf<int32_t> h_match;
     std::mutex mu;
 };
 MatcherWorkspace& mws() { static MatcherWorkspace w; return w; }
@@ -54,7 +59,81 @@ void three_maxima(const int* count, int L, int& ind1, int& ind2, int& ind3) {
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
+// Rotation consistency of the last-frame overload (SF/src/ORBmatcher.cc:1783-1799, 1858-1881): matches outside the three
+// dominant 30-bin rotation bins are removed; returns how many.
+int rotation_filter(const tc2li_proj_query* queries, int M, const tc2li_keypoint* keys, int32_t* match_of_query) {
+    const int L = 30;
+    const float factor = 1.0f / L;
+    std::vector<int> bin_of(M, -1);
+    int count[30] = {0};
+    for (int q = 0; q < M; ++q) {
+        if (match_of_query[q] < 0) continue;
+        float rot = queries[q].angle - keys[match_of_query[q]].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == L) bin = 0;
+        bin_of[q] = bin;
+        count[bin]++;
+    }
+    int ind1 = -1, ind2 = -1, ind3 = -1, removed = 0;
+    three_maxima(count, L, ind1, ind2, ind3);
+    for (int q = 0; q < M; ++q)
+        if (bin_of[q] >= 0 && bin_of[q] != ind1 && bin_of[q] != ind2 && bin_of[q] != ind3) { match_of_query[q] = -1; removed++; }
+    return removed;
+}
+
 }  // namespace
+
+namespace tc2li {
+
+// Batched search on the device-resident features of the extractor handle (see matcher_host.hpp).
+int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_frames, const tc2li_proj_query* queries, int mode,
+                        float nn_ratio, bool check_orientation, int32_t* match_of_query, int32_t* n_matches, hipStream_t st) {
+    MatcherWorkspace& w = mws();
+    std::lock_guard<std::mutex> lk(w.mu);
+    int total_q = 0, total_k = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frames[f].n_keys > kMaxMatchKeys) { set_error("frame has %d keypoints, the matcher supports %d", frames[f].n_keys, kMaxMatchKeys); return TC2LI_ERR_CAPACITY; }
+        total_q = std::max(total_q, frames[f].q_off + frames[f].n_q);
+        total_k += frames[f].n_keys;
+    }
+    for (int f = 0; f < n_frames; ++f) n_matches[f] = 0;
+    if (total_q == 0) return 0;
+    TC2LI_HIP_CHECK(w.d_frames.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_ur.ensure(std::max(total_k, 1)));
+    TC2LI_HIP_CHECK(w.d_queries.ensure(total_q)); TC2LI_HIP_CHECK(w.d_match.ensure(total_q)); TC2LI_HIP_CHECK(w.d_prev.ensure(total_q));
+    TC2LI_HIP_CHECK(w.d_rounds.ensure(n_frames));
+    TC2LI_HIP_CHECK(w.h_ur.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.h_frames.ensure(n_frames));
+    TC2LI_HIP_CHECK(w.h_match.ensure(total_q));
+    int koff = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        const BatchSearchFrame& fr = frames[f];
+        memcpy(w.h_ur.p + koff, fr.u_right_host, fr.n_keys * sizeof(float));
+        w.h_frames.p[f] = MatchFrameDev{o->d_mkeys.p + fr.key_off, o->d_desc.p + (size_t)fr.key_off * 32, w.d_ur.p + koff, nullptr,
+                                        w.d_queries.p + fr.q_off, fr.n_keys, fr.n_q, fr.q_off, 0, 0.0f, (float)o->cur_w, 0.0f, (float)o->cur_h};
+        koff += fr.n_keys;
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_ur.p, w.h_ur.p, std::max(total_k, 1) * sizeof(float), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_queries.p, queries, (size_t)total_q * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
+    launch_match_by_projection(w.d_frames.p, n_frames, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    global_pool().parallel_for(n_frames, [&](int f) {
+        const BatchSearchFrame& fr = frames[f];
+        int32_t* m = match_of_query + fr.q_off;
+        memcpy(m, w.h_match.p + fr.q_off, fr.n_q * sizeof(int32_t));
+        int nm = 0;
+        if (fr.n_keys == 0) for (int q = 0; q < fr.n_q; ++q) m[q] = -1;
+        for (int q = 0; q < fr.n_q; ++q) nm += m[q] >= 0;
+        if (check_orientation) nm -= rotation_filter(queries + fr.q_off, fr.n_q, fr.keys_host, m);
+        n_matches[f] = nm;
+    });
+    return 0;
+}
+
+}  // namespace tc2li
 
 extern "C" {
 
@@ -92,25 +171,7 @@ int tc2li_search_by_projection(const tc2li_frame_view* frame, const tc2li_proj_q
     TC2LI_HIP_CHECK(hipMemcpy(match_of_query, w.d_match.p, M * sizeof(int32_t), hipMemcpyDeviceToHost));
     int nmatches = 0;
     for (int q = 0; q < M; ++q) nmatches += match_of_query[q] >= 0;
-    if (check_orientation) {  // SF/src/ORBmatcher.cc:1783-1799, 1858-1881
-        const int L = 30;
-        const float factor = 1.0f / L;
-        std::vector<int> bin_of(M, -1);
-        int count[30] = {0};
-        for (int q = 0; q < M; ++q) {
-            if (match_of_query[q] < 0) continue;
-            float rot = queries[q].angle - frame->keys[match_of_query[q]].angle;
-            if (rot < 0.0) rot += 360.0f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == L) bin = 0;
-            bin_of[q] = bin;
-            count[bin]++;
-        }
-        int ind1 = -1, ind2 = -1, ind3 = -1;
-        three_maxima(count, L, ind1, ind2, ind3);
-        for (int q = 0; q < M; ++q)
-            if (bin_of[q] >= 0 && bin_of[q] != ind1 && bin_of[q] != ind2 && bin_of[q] != ind3) { match_of_query[q] = -1; nmatches--; }
-    }
+    if (check_orientation) nmatches -= rotation_filter(queries, M, frame->keys, match_of_query);
     if (query_of_keypoint)
         for (int q = 0; q < M; ++q) if (match_of_query[q] >= 0) query_of_keypoint[match_of_query[q]] = q;
     return nmatches;
