@@ -187,6 +187,9 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
                                tc2li_lidar_map* const* maps, const tc2li_lidar_state* states, int32_t* n_preprocessed,
                                int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
                                tc2li_point* corr_normvect, int capacity, void* stream);
+/* Device time of the stages of the last tc2li_lidar_frontend_batch call, from HIP events on its stream: ms[0]
+ * preprocess, [1] voxel hashing/sorting, [2] voxel centroids, [3] 5-NN + plane fit, [4] selection, [5] total. */
+int tc2li_lidar_last_timings(tc2li_lidar* lidar, float ms[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * Projection-guided matching of the tracking thread -- replaces the two overloads of ORBmatcher::SearchByProjection
@@ -346,6 +349,22 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
                                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                                      uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar,
                                      tc2li_lidar_ba_stats* lidar_stats, void* stream);
+
+/* Many independent windows (multi-sequence operation, BASELINE configs[4]): every problem is what one
+ * tc2li_local_lv_bundle_adjustment call takes; up to max_concurrency of them are in flight at a time, each on its own
+ * HIP stream with its own device workspace, so that the small kernels of different windows overlap on the GPU.
+ * results[i] receives the return value of problem i.  Returns the number of problems that succeeded. */
+typedef struct tc2li_ba_problem {
+    double* poses7; const uint8_t* fixed; double* points3; const tc2li_ba_edge* edges;
+    int32_t n_poses, n_points, n_edges, iterations;
+    double lambda_init;
+    const volatile uint8_t* stop_flag;
+    double* edge_chi2; uint8_t* edge_depth_positive;
+    tc2li_ba_stats* stats;
+    const tc2li_lidar_window* lidar; tc2li_lidar_ba_stats* lidar_stats;
+} tc2li_ba_problem;
+int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam,
+                                        int max_concurrency, int32_t* results);
 
 /* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
  * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =

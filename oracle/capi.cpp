@@ -508,17 +508,11 @@ void oracle_project_last_frame(const float* pose_cur7, const float* pose_last7, 
 // Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834), data path of one frame: SearchByProjection(th) with
 // ORBmatcher(0.9, true), the 2*th retry below 20 matches, PoseOptimization, outliers discarded.  Returns the value of
 // PoseOptimization, -1 when the search found fewer than 20 matches.
-int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
-                              const float* inv_sigma2, int nlevels, const float* pose_pred7, const float* pose_last7, const double* cam5,
-                              float mb, float th, int n_last, const uint8_t* has_point, const uint8_t* outlier_last, const float* Xw,
-                              const float* last_keys6, const uint8_t* mp_desc, double* pose_out7, int* map_point_of_keypoint,
-                              int* n_matches) {
-    FrameView F;
-    F.keys = kps_from(keys6, n);
-    F.desc.assign(desc, desc + (size_t)n * 32);
-    F.uRight.assign(uright, uright + n);
-    F.occupied.assign(n, 0);
-    F.cols = cols; F.rows = rows;
+static int track_core(const FrameView& F, const float* scales, const float* inv_sigma2, int nlevels, const float* pose_pred7,
+                      const float* pose_last7, const double* cam5, float mb, float th, int n_last, const uint8_t* has_point,
+                      const uint8_t* outlier_last, const float* Xw, const std::vector<KeyPoint>& lk, const uint8_t* mp_desc,
+                      double* pose_out7, int* map_point_of_keypoint, int* n_matches) {
+    const int n = (int)F.keys.size(), cols = F.cols, rows = F.rows;
     SE3f Tcw, Tlw;
     std::memcpy(Tcw.q, pose_pred7, 16); std::memcpy(Tcw.t, pose_pred7 + 4, 12);
     std::memcpy(Tlw.q, pose_last7, 16); std::memcpy(Tlw.t, pose_last7 + 4, 12);
@@ -526,7 +520,6 @@ int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const flo
     const std::vector<float> sc(scales, scales + nlevels);
     const std::vector<uint8_t> hp(has_point, has_point + n_last), ol(outlier_last, outlier_last + n_last);
     const std::vector<float> X(Xw, Xw + 3 * (size_t)n_last);
-    const std::vector<KeyPoint> lk = kps_from(last_keys6, n_last);
     const std::vector<uint8_t> md(mp_desc, mp_desc + (size_t)n_last * 32);
     std::vector<int> match;
     int nm = 0;
@@ -549,7 +542,7 @@ int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const flo
         if (q < 0) continue;
         BAEdge e;
         e.point = (int)edges.size(); e.pose = 0;
-        e.obs[0] = F.keys[i].x; e.obs[1] = F.keys[i].y; e.obs[2] = uright[i];
+        e.obs[0] = F.keys[i].x; e.obs[1] = F.keys[i].y; e.obs[2] = F.uRight[i];
         e.info = inv_sigma2[F.keys[i].octave];
         edges.push_back(e);
         for (int c = 0; c < 3; ++c) Xd.push_back((double)Xw[3 * (size_t)q + c]);
@@ -561,6 +554,61 @@ int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const flo
     const int inl = PoseOptimization(T, Xd, edges, cam, out);
     pose_to(T, pose_out7);
     for (size_t e = 0; e < edges.size() && e < out.size(); ++e) if (out[e]) map_point_of_keypoint[kp_of_edge[e]] = -1;
+    return inl;
+}
+
+int oracle_track_motion_model(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
+                              const float* inv_sigma2, int nlevels, const float* pose_pred7, const float* pose_last7, const double* cam5,
+                              float mb, float th, int n_last, const uint8_t* has_point, const uint8_t* outlier_last, const float* Xw,
+                              const float* last_keys6, const uint8_t* mp_desc, double* pose_out7, int* map_point_of_keypoint,
+                              int* n_matches) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    F.occupied.assign(n, 0);
+    F.cols = cols; F.rows = rows;
+    return track_core(F, scales, inv_sigma2, nlevels, pose_pred7, pose_last7, cam5, mb, th, n_last, has_point, outlier_last, Xw,
+                      kps_from(last_keys6, n_last), mp_desc, pose_out7, map_point_of_keypoint, n_matches);
+}
+
+// One frame of the tracking loop with the reference's threading: oracle_frontend_frame (left / right ORB on two threads,
+// stereo matching, the LiDAR front end on its own thread) followed on the tracking thread by TrackWithMotionModel's data
+// path against the given last frame.  Returns PoseOptimization's inlier count (-1: lost).
+int oracle_loop_frame(void* hl, void* hr, const uint8_t* il, const uint8_t* ir, int w, int hgt, float mbf, float mb,
+                      const VelodynePoint* raw, int n_raw, void* tree, const double* state24, const float* pose_pred7,
+                      const float* pose_last7, const double* cam5, float th, int n_last, const uint8_t* has_point,
+                      const uint8_t* outlier_last, const float* Xw, const float* last_keys6, const uint8_t* mp_desc, double* pose_out7,
+                      int* n_sel, int* n_matches) {
+    int sel = 0;
+    std::thread lidar([&] {
+        PointVector pre = preprocess_velodyne(raw, n_raw, 2, 2.0, 1e-3f);
+        PointVector down = voxel_grid_filter(pre, 0.5f);
+        LidarState st;
+        std::memcpy(st.rot, state24, 9 * sizeof(double));
+        std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
+        std::memcpy(st.offset_R_L_I, state24 + 12, 9 * sizeof(double));
+        std::memcpy(st.offset_T_L_I, state24 + 21, 3 * sizeof(double));
+        sel = feature_extraction(down, st, *(KdTree*)tree).effct_feat_num;
+    });
+    ORBextractor* el = (ORBextractor*)hl;
+    ORBextractor* er = (ORBextractor*)hr;
+    std::vector<KeyPoint> kl, kr;
+    std::vector<uint8_t> dl, dr;
+    const int lap[2] = {0, 0};
+    std::thread tl([&] { el->extract(Img::view(il, w, hgt, w), kl, dl, lap); });
+    std::thread tr([&] { er->extract(Img::view(ir, w, hgt, w), kr, dr, lap); });
+    tl.join();
+    tr.join();
+    StereoResult r = ComputeStereoMatches(*el, *er, kl, dl, kr, dr, mbf, mb);
+    FrameView F;
+    F.keys = kl; F.desc = dl; F.uRight = r.uRight; F.occupied.assign(kl.size(), 0); F.cols = w; F.rows = hgt;
+    std::vector<int> mp(kl.size() + 1);
+    const int inl = track_core(F, el->mvScaleFactor.data(), el->mvInvLevelSigma2.data(), (int)el->mvScaleFactor.size(), pose_pred7,
+                               pose_last7, cam5, mb, th, n_last, has_point, outlier_last, Xw, kps_from(last_keys6, n_last), mp_desc,
+                               pose_out7, mp.data(), n_matches);
+    lidar.join();
+    if (n_sel) *n_sel = sel;
     return inl;
 }
 

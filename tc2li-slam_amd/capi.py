@@ -92,6 +92,8 @@ def lib():
     L.tc2li_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.tc2li_track_motion_model_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
+    L.tc2li_local_bundle_adjustment_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_lidar_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -325,6 +327,12 @@ class LidarFrontEnd:
             lib().tc2li_lidar_destroy(self._h)
             self._h = C.c_void_p()
 
+    def last_timings(self):
+        """Device ms of the last frontend_batch: preprocess, voxel hashing, voxel centroids, 5-NN + plane fit, selection, total."""
+        t = np.zeros(8, np.float32)
+        _check(lib().tc2li_lidar_last_timings(self._h, t.ctypes.data))
+        return t[:6]
+
     __del__ = close
 
     def process(self, raw, point_filter_num=2, blind=2.0, time_unit_scale=1e-3):
@@ -518,6 +526,57 @@ def local_lv_bundle_adjustment(poses7, fixed, points3, edges, cam5, win_pose, cl
                                                   C.addressof(lstats), C.c_void_p(stream)))
     del keep
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
+
+
+class BaProblem(C.Structure):
+    """tc2li_ba_problem"""
+    _fields_ = [("poses7", C.c_void_p), ("fixed", C.c_void_p), ("points3", C.c_void_p), ("edges", C.c_void_p), ("n_poses", C.c_int32),
+                ("n_points", C.c_int32), ("n_edges", C.c_int32), ("iterations", C.c_int32), ("lambda_init", C.c_double),
+                ("stop_flag", C.c_void_p), ("edge_chi2", C.c_void_p), ("edge_depth_positive", C.c_void_p), ("stats", C.c_void_p),
+                ("lidar", C.c_void_p), ("lidar_stats", C.c_void_p)]
+
+
+class BaBatch:
+    """A set of independent local-BA windows prepared once (arrays pinned down for the C side) and optimised together by
+    ``tc2li_local_bundle_adjustment_batch``.  windows: dicts with poses, fixed, points, edges (BA_EDGE_DTYPE) and optionally
+    win_pose, clouds, Tcl7, weight; iterations / lambda_init per window optional."""
+
+    def __init__(self, windows, cam5):
+        self.n = len(windows)
+        self.cam5 = np.ascontiguousarray(cam5, np.float64)
+        self.arr = (BaProblem * self.n)()
+        self.init = []
+        self.keep = []
+        self.stats = (BaStats * self.n)()
+        self.lstats = (LidarBaStats * self.n)()
+        self.results = np.zeros(self.n, np.int32)
+        for i, w in enumerate(windows):
+            poses0 = np.ascontiguousarray(w["poses"], np.float64); pts0 = np.ascontiguousarray(w["points"], np.float64)
+            poses, pts = poses0.copy(), pts0.copy()
+            fixed = np.ascontiguousarray(w["fixed"], np.uint8)
+            edges = np.ascontiguousarray(w["edges"], BA_EDGE_DTYPE)
+            chi2, dpos = np.zeros(max(len(edges), 1)), np.zeros(max(len(edges), 1), np.uint8)
+            lw = None
+            if w.get("win_pose") is not None:
+                lw = _pack_lidar_window(w["win_pose"], w["clouds"], w["Tcl7"], w.get("weight", 1.0))
+            self.init.append((poses0, pts0))
+            self.keep.append((poses, pts, fixed, edges, chi2, dpos, lw))
+            self.arr[i] = BaProblem(poses.ctypes.data, fixed.ctypes.data, pts.ctypes.data, edges.ctypes.data, len(poses), len(pts), len(edges),
+                                    int(w.get("iterations", 10)), float(w.get("lambda_init", 0.0)), None, chi2.ctypes.data, dpos.ctypes.data,
+                                    C.addressof(self.stats) + i * C.sizeof(BaStats), C.addressof(lw[0]) if lw else None,
+                                    C.addressof(self.lstats) + i * C.sizeof(LidarBaStats))
+
+    def run(self, max_concurrency=8):
+        """Resets every window to its initial estimate and optimises all of them -> number of successful windows."""
+        for (p0, x0), k in zip(self.init, self.keep):
+            k[0][...] = p0
+            k[1][...] = x0
+        return _check(lib().tc2li_local_bundle_adjustment_batch(C.addressof(self.arr), self.n, self.cam5.ctypes.data, max_concurrency,
+                                                                self.results.ctypes.data))
+
+    def result(self, i):
+        k = self.keep[i]
+        return k[0], k[1], k[4][:len(k[3])], k[5][:len(k[3])], self.stats[i], self.lstats[i]
 
 
 def lidar_planes_host(poses7, win_pose, clouds, Tcl7, capacity=20000):

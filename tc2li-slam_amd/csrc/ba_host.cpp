@@ -1,6 +1,7 @@
 // Host side of the optimisation entry points (include/tc2li_hip.h): tc2li_pose_optimization[_batch] replaces
 // Optimizer::PoseOptimization (SF/src/Optimizer.cc:816-1116).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -39,7 +40,9 @@ struct BaWorkspace {
     BalmTerm lidar;
     std::mutex mu;
 };
-BaWorkspace& ba_ws() { static BaWorkspace w; return w; }
+// one workspace per host thread: windows optimised from different threads (tc2li_local_bundle_adjustment_batch) do not
+// share device buffers
+BaWorkspace& ba_ws() { static thread_local BaWorkspace w; return w; }
 
 }  // namespace
 
@@ -337,6 +340,33 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                   uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream) {
     return tc2li_local_lv_bundle_adjustment(poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, iterations, lambda_init,
                                             stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, stream);
+}
+
+int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int max_concurrency,
+                                        int32_t* results) {
+    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam) { set_error("tc2li_local_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n_problems == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
+    static WorkerPool* pool = new WorkerPool(16);  // persistent: its threads keep their streams and workspaces
+    struct ThreadStream {
+        hipStream_t s = nullptr;
+        ~ThreadStream() { if (s) (void)hipStreamDestroy(s); }
+    };
+    std::atomic<int> next{0};
+    pool->parallel_for(workers, [&](int) {
+        static thread_local ThreadStream ts;
+        if (!ts.s && hipStreamCreateWithFlags(&ts.s, hipStreamNonBlocking) != hipSuccess) ts.s = nullptr;
+        for (int i; (i = next.fetch_add(1)) < n_problems;) {
+            const tc2li_ba_problem& p = problems[i];
+            results[i] = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
+                                                          p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive,
+                                                          p.stats, p.lidar, p.lidar_stats, ts.s);
+        }
+    });
+    int ok = 0;
+    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
+    return ok;
 }
 
 int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* residual, double* JacT,

@@ -71,6 +71,7 @@ void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
         for (int i = 0; i < n; ++i) fn(i);
         return;
     }
+    std::lock_guard<std::mutex> call(call_mu_);
     {
         std::lock_guard<std::mutex> lk(mu_);
         fn_ = &fn;

@@ -85,7 +85,7 @@ public:
 private:
     void loop();
     std::vector<std::thread> workers_;
-    std::mutex mu_;
+    std::mutex mu_, call_mu_;  // call_mu_ serialises concurrent parallel_for callers
     std::condition_variable cv_, done_cv_;
     const std::function<void(int)>* fn_ = nullptr;
     std::atomic<int> next_{0};

@@ -25,7 +25,8 @@ struct SegBlock { int32_t scan, start; };
 
 // Per-scan slots: every per-point array reserves `cap` entries starting at `base` for a scan; how many are in use
 // at each stage lives in device counters so that stages chain without host synchronisation.
-struct ScanSlot { int32_t base, cap, first_block, n_blocks; };
+// raw_base: where the scan's raw points start in the caller's array (packed scans are read in place).
+struct ScanSlot { int32_t base, cap, first_block, n_blocks, raw_base, pad_[3]; };
 
 struct VoxelParams {  // pcl::VoxelGrid::applyFilter bookkeeping for one scan
     int32_t min_b[3], mul[3];

@@ -48,6 +48,12 @@ struct tc2li_lidar {
     std::vector<ScanSlot> slots;
     std::vector<SegBlock> blocks;
     int n_scans = 0;
+    // stage boundaries of the last tc2li_lidar_frontend_batch call: start, after preprocess, before / after the centroid
+    // kernel, after the kNN + plane kernel, end
+    hipEvent_t ev[6] = {};
+    bool timed = false;
+    void record(int k, hipStream_t st) { if (ev[k] || hipEventCreate(&ev[k]) == hipSuccess) (void)hipEventRecord(ev[k], st); }
+    ~tc2li_lidar() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 };
 
 namespace {
@@ -55,13 +61,15 @@ namespace {
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // Builds the slot/block tables for `n_scans` scans with the given upper bounds of points per scan.
-int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st) {
+int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st, const int32_t* raw_offsets = nullptr) {
     L->slots.resize(n_scans);
     L->blocks.clear();
     for (int s = 0; s < n_scans; ++s) {
         if (upper[s] > L->cap) { set_error("scan %d has %d points, slot capacity is %d", s, upper[s], L->cap); return TC2LI_ERR_CAPACITY; }
         ScanSlot& sl = L->slots[s];
         sl.base = s * L->cap; sl.cap = L->cap; sl.first_block = (int)L->blocks.size();
+        sl.raw_base = raw_offsets ? raw_offsets[s] : sl.base;
+        sl.pad_[0] = sl.pad_[1] = sl.pad_[2] = 0;
         sl.n_blocks = (upper[s] + kSegBlock - 1) / kSegBlock;
         for (int b = 0; b < sl.n_blocks; ++b) L->blocks.push_back(SegBlock{s, b * kSegBlock});
     }
@@ -102,6 +110,7 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
                       L->d_member_off.p, L->d_n_vox.p, L->d_status.p, st);
     launch_voxel_fill(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_rank.p,
                       L->d_member_off.p, L->d_vox_fill.p, L->d_members.p, st);
+    L->record(2, st);
     launch_voxel_centroid(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_vp.p, L->d_n_vox.p, L->d_member_off.p, L->d_vox_fill.p,
                           L->d_members.p, L->d_down.p, L->d_down_count.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
@@ -118,6 +127,7 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
     launch_knn_plane(L->d_grids.p, d_body, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
                      L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, st);
+    L->record(4, st);
     launch_sel_count(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_counts.p, st);
     launch_seg_scan(L->d_slots.p, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
     launch_sel_scatter(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_offsets.p, d_body, L->d_normvec.p,
@@ -200,6 +210,15 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
 }
 
 void tc2li_lidar_destroy(tc2li_lidar* L) { delete L; }
+
+int tc2li_lidar_last_timings(tc2li_lidar* L, float ms[8]) {
+    if (!L || !ms) { set_error("tc2li_lidar_last_timings: invalid argument"); return TC2LI_ERR_INVALID; }
+    for (int k = 0; k < 8; ++k) ms[k] = 0;
+    if (!L->timed) return TC2LI_OK;
+    for (int k = 0; k < 5; ++k) if (hipEventElapsedTime(&ms[k], L->ev[k], L->ev[k + 1]) != hipSuccess) ms[k] = 0;
+    if (hipEventElapsedTime(&ms[5], L->ev[0], L->ev[5]) != hipSuccess) ms[5] = 0;
+    return TC2LI_OK;
+}
 
 int tc2li_lidar_preprocess(tc2li_lidar* L, const tc2li_velodyne_point* raw, int n, int point_filter_num, double blind,
                            float time_unit_scale, tc2li_point* out, int capacity) {
@@ -325,21 +344,21 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     hipStream_t st = (hipStream_t)stream_;
     std::vector<int> upper(n_scans);
     for (int s = 0; s < n_scans; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
-    int rc = setup_segments(L, n_scans, upper.data(), st);
+    // raw scans are packed back to back by the caller and read in place (ScanSlot::raw_base)
+    int rc = setup_segments(L, n_scans, upper.data(), st, raw_offsets);
     if (rc != TC2LI_OK) return rc;
-    // raw scans are packed back to back by the caller; copy each into its slot (device to device) so that every later
-    // pass can use the fixed slot layout
-    for (int s = 0; s < n_scans; ++s)
-        if (upper[s])
-            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw.p + (size_t)s * L->cap, (const VelodynePoint*)dev_raw + raw_offsets[s],
-                                           (size_t)upper[s] * sizeof(VelodynePoint), hipMemcpyDeviceToDevice, st));
+    L->record(0, st);
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), n_scans * sizeof(int), hipMemcpyHostToDevice, st));
-    rc = run_preprocess(L, L->d_raw.p, point_filter_num, blind, time_unit_scale, st);
+    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
     if (rc != TC2LI_OK) return rc;
+    L->record(1, st);
     rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, st);
     if (rc != TC2LI_OK) return rc;
+    L->record(3, st);
     rc = run_features(L, L->d_down.p, L->d_down_count.p, maps, states, st);
     if (rc != TC2LI_OK) return rc;
+    L->record(5, st);
+    L->timed = true;
     int* hc = L->h_counts.p;
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + n_scans, L->d_down_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_count(const VelodynePoint* __
     const ScanSlot sl = slots[b.scan];
     const int i = b.start + threadIdx.x;
     bool f = false;
-    if (i < raw_count[b.scan]) f = pre_keep(raw[sl.base + i], i, prm);
+    if (i < raw_count[b.scan]) f = pre_keep(raw[sl.raw_base + i], i, prm);
     const int c = __syncthreads_count(f);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
 }
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_scatter(const VelodynePoint* 
     const int i = b.start + threadIdx.x;
     bool f = false;
     VelodynePoint p;
-    if (i < raw_count[b.scan]) { p = raw[sl.base + i]; f = pre_keep(p, i, prm); }
+    if (i < raw_count[b.scan]) { p = raw[sl.raw_base + i]; f = pre_keep(p, i, prm); }
     int total;
     const int pos = block_flag_scan(f, s_wave, total);
     if (f) {
@@ -296,82 +296,122 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const PointXYZINormal*
     members[sl.base + vox_member_off[sl.base + r] + pos] = i;
 }
 
-// One wavefront per voxel.  The members are ranked by point index (the order PCL's sorted index vector yields:
-// rank = number of members with a smaller index, counted by all lanes in parallel), staged 64 at a time in LDS in
-// that order, and lanes 0..7 each accumulate one field sequentially in float -- the exact summation order of
-// pcl::CentroidPoint -- before dividing by the count.
-__global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
-                                                        const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
-                                                        const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
-                                                        const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
-                                                        int* __restrict__ members, PointXYZINormal* __restrict__ out,
-                                                        int* __restrict__ out_count) {
-    constexpr int kLdsMembers = 1024;
-    __shared__ float s_stage[4][64][8];
-    __shared__ int s_mem[4][kLdsMembers], s_sorted[4][kLdsMembers];
+// One workgroup per 256 consecutive voxels of a scan (their member lists are one contiguous range of `members`).
+// PCL sums a voxel's points in the order of its sorted index vector, i.e. by ascending point index: the range is staged
+// in LDS, every member finds its rank inside its voxel (count of smaller indices, all threads busy whatever the voxel
+// populations are), and then one thread per voxel adds the fields sequentially in float in that order -- the exact
+// summation order of pcl::CentroidPoint -- before dividing by the count.  Ranges longer than the LDS stage are
+// processed in sub-batches of whole voxels; a single voxel larger than the stage is ranked against global memory.
+constexpr int kCentroidThreads = 256, kCentroidStage = 4096;
+
+__device__ __forceinline__ void centroid_store(const float a[8], int n, PointXYZINormal* __restrict__ dst) {
+    const float fn = (float)n;
+    PointXYZINormal o;
+    o.x = a[0] / fn; o.y = a[1] / fn; o.z = a[2] / fn; o.pad0 = 1.0f;
+    float snx = a[3], sny = a[4], snz = a[5];
+    const float nn = snx * snx + sny * sny + snz * snz;
+    if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
+    o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
+    o.intensity = a[6] / fn; o.curvature = a[7] / fn; o.pad2 = 0; o.pad3 = 0;
+    *dst = o;
+}
+
+__global__ __launch_bounds__(kCentroidThreads) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                                     const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                                     const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
+                                                                     const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
+                                                                     int* __restrict__ members, PointXYZINormal* __restrict__ out,
+                                                                     int* __restrict__ out_count) {
+    __shared__ int s_off[kCentroidThreads + 1];
+    __shared__ int s_raw[kCentroidStage], s_sorted[kCentroidStage];
+    __shared__ int s_v1;
+    __shared__ float s_acc[8];
     const SegBlock b = blocks[blockIdx.x];
     const ScanSlot sl = slots[b.scan];
     const int nv = n_vox[b.scan];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (b.start == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
-    const bool pass = vp[b.scan].passthrough != 0;
-    // neighbouring voxels differ a lot in population (dense near the sensor): interleave them over blocks and waves
-    for (int r = b.start + (int)blockIdx.y + 16 * wave; r < min(b.start + kSegBlock, nv); r += 64) {
-        if (pass) {
-            if (lane == 0) out[sl.base + r] = pts[sl.base + r];
-            continue;
+    const int tid = threadIdx.x;
+    if (b.start == 0 && blockIdx.y == 0 && tid == 0) out_count[b.scan] = nv;
+    const int r0 = b.start + (int)blockIdx.y * kCentroidThreads, r1 = min(r0 + kCentroidThreads, min(b.start + kSegBlock, nv));
+    if (r0 >= r1) return;
+    if (vp[b.scan].passthrough != 0) {
+        if (r0 + tid < r1) out[sl.base + r0 + tid] = pts[sl.base + r0 + tid];
+        return;
+    }
+    const int nvb = r1 - r0;
+    if (tid < nvb) s_off[tid] = vox_member_off[sl.base + r0 + tid];
+    if (tid == 0) s_off[nvb] = vox_member_off[sl.base + r1 - 1] + vox_fill[sl.base + r1 - 1];
+    __syncthreads();
+    const int* mem = members + sl.base;
+    const PointXYZINormal* P = pts + sl.base;
+    int v0 = 0;
+    while (v0 < nvb) {
+        if (tid == 0) {  // the longest run of whole voxels that fits the stage (at least one voxel)
+            int v1 = v0 + 1;
+            while (v1 < nvb && s_off[v1 + 1] - s_off[v0] <= kCentroidStage) ++v1;
+            s_v1 = v1;
         }
-        const int* m = members + sl.base + vox_member_off[sl.base + r];
-        const int n = vox_fill[sl.base + r];
-        float acc = 0.f;  // lanes 0..7: x, y, z, normal_x, normal_y, normal_z, intensity, curvature
-        const bool in_lds = n <= kLdsMembers;
-        if (in_lds) {
-            for (int i = lane; i < n; i += 64) s_mem[wave][i] = m[i];
-            wave_lds_sync();
-            for (int i = lane; i < n; i += 64) {
-                const int mine = s_mem[wave][i];
-                int rank = 0;
-                for (int k = 0; k < n; ++k) rank += s_mem[wave][k] < mine ? 1 : 0;
-                s_sorted[wave][rank] = mine;
-            }
-            wave_lds_sync();
-        }
-        for (int base = 0; base < n; base += 64) {
-            if (!in_lds) {
-                // very large voxel: rank against global memory, one 64-member window at a time
-                for (int i = lane; i < n; i += 64) {
-                    const int mine = m[i];
-                    int rank = 0;
-                    for (int k = 0; k < n; ++k) rank += m[k] < mine ? 1 : 0;
-                    if (rank >= base && rank < base + 64) s_sorted[wave][rank - base] = mine;
+        __syncthreads();
+        const int v1 = s_v1, m0 = s_off[v0], len = s_off[v1] - m0;
+        if (len <= kCentroidStage) {
+            for (int e = tid; e < len; e += kCentroidThreads) s_raw[e] = mem[m0 + e];
+            __syncthreads();
+            for (int e = tid; e < len; e += kCentroidThreads) {
+                int lo = v0, hi = v1;  // voxel of member e: s_off[lo] - m0 <= e < s_off[lo + 1] - m0
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_off[mid] - m0 <= e) lo = mid; else hi = mid;
                 }
-                wave_lds_sync();
+                const int ss = s_off[lo] - m0, se = s_off[lo + 1] - m0, mine = s_raw[e];
+                int rank = 0;
+                for (int k = ss; k < se; ++k) rank += s_raw[k] < mine ? 1 : 0;
+                s_sorted[ss + rank] = mine;
             }
-            const int cnt = min(64, n - base);
-            if (lane < cnt) {
-                const PointXYZINormal p = pts[sl.base + s_sorted[wave][in_lds ? base + lane : lane]];
-                float* d = s_stage[wave][lane];
-                d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.normal_x; d[4] = p.normal_y; d[5] = p.normal_z;
-                d[6] = p.intensity; d[7] = p.curvature;
+            __syncthreads();
+            const int v = v0 + tid;
+            if (v < v1) {
+                const int ss = s_off[v] - m0, n = s_off[v + 1] - s_off[v];
+                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < n; ++k) {
+                    const PointXYZINormal p = P[s_sorted[ss + k]];
+                    a[0] += p.x; a[1] += p.y; a[2] += p.z; a[3] += p.normal_x; a[4] += p.normal_y; a[5] += p.normal_z;
+                    a[6] += p.intensity; a[7] += p.curvature;
+                }
+                centroid_store(a, n, out + sl.base + r0 + v);
             }
-            wave_lds_sync();
-            if (lane < 8)
-                for (int k = 0; k < cnt; ++k) acc += s_stage[wave][k][lane];
-            wave_lds_sync();
+            __syncthreads();
+        } else {
+            // one voxel larger than the stage: rank against global memory, one stage-sized window of ranks at a time
+            const int n = len;
+            if (tid < 8) s_acc[tid] = 0.f;
+            for (int base = 0; base < n; base += kCentroidStage) {
+                for (int e = tid; e < n; e += kCentroidThreads) {
+                    const int mine = mem[m0 + e];
+                    int rank = 0;
+                    for (int k = 0; k < n; ++k) rank += mem[m0 + k] < mine ? 1 : 0;
+                    if (rank >= base && rank < base + kCentroidStage) s_sorted[rank - base] = mine;
+                }
+                __syncthreads();
+                const int cnt = min(kCentroidStage, n - base);
+                if (tid < 8) {
+                    float acc = s_acc[tid];
+                    for (int k = 0; k < cnt; ++k) {
+                        const PointXYZINormal& p = P[s_sorted[k]];
+                        const float f = tid == 0 ? p.x : tid == 1 ? p.y : tid == 2 ? p.z : tid == 3 ? p.normal_x : tid == 4 ? p.normal_y
+                                      : tid == 5 ? p.normal_z : tid == 6 ? p.intensity : p.curvature;
+                        acc += f;
+                    }
+                    s_acc[tid] = acc;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                float a[8];
+                for (int k = 0; k < 8; ++k) a[k] = s_acc[k];
+                centroid_store(a, n, out + sl.base + r0 + v0);
+            }
+            __syncthreads();
         }
-        const float fn = (float)n;
-        const float sx = __shfl(acc, 0, 64), sy = __shfl(acc, 1, 64), sz = __shfl(acc, 2, 64);
-        float snx = __shfl(acc, 3, 64), sny = __shfl(acc, 4, 64), snz = __shfl(acc, 5, 64);
-        const float si = __shfl(acc, 6, 64), sc = __shfl(acc, 7, 64);
-        if (lane == 0) {
-            PointXYZINormal o;
-            o.x = sx / fn; o.y = sy / fn; o.z = sz / fn; o.pad0 = 1.0f;
-            const float nn = snx * snx + sny * sny + snz * snz;
-            if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
-            o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
-            o.intensity = si / fn; o.curvature = sc / fn; o.pad2 = 0; o.pad3 = 0;
-            out[sl.base + r] = o;
-        }
+        v0 = v1;
     }
 }
 
@@ -740,7 +780,7 @@ void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanS
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
                            PointXYZINormal* out, int* out_count, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 64), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
+    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / kCentroidThreads), dim3(kCentroidThreads), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
 }
 void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_counts);

@@ -84,3 +84,31 @@ def test_lidar_window_argument_errors(pkg, synthetic):
         pkg.capi.lidar_window_evaluate(w["poses"], [5, 77], clouds, synthetic.TCL7)
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.lidar_window_evaluate(w["poses"], list(range(6)) * 4, clouds * 12, synthetic.TCL7)  # 24 keyframes > 20
+
+
+def test_local_bundle_adjustment_batch(pkg, synthetic):
+    """Windows optimised concurrently (own stream + workspace per host thread) give exactly the single-call results."""
+    windows, singles = [], []
+    for seed in range(7):
+        w = synthetic.ba_window(seed, n_opt=6 + seed, n_fix=8, n_points=600 + 200 * seed, pose_noise=(0.1, 0.01))
+        e = pkg.pack_ba_edges(w["edges"])
+        d = dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=e)
+        if seed % 2 == 0:
+            last = len(w["poses"]) - 1
+            win = list(range(last, last - 4, -1))
+            d.update(win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=2000), Tcl7=synthetic.TCL7, weight=1.0)
+            singles.append(pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], win, d["clouds"], synthetic.TCL7, 1.0))
+        else:
+            singles.append(pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"]))
+        windows.append(d)
+        cam = w["cam"]
+    batch = pkg.capi.BaBatch(windows, cam)
+    for conc in (1, 4, 8):
+        assert batch.run(max_concurrency=conc) == len(windows)
+        for i, s in enumerate(singles):
+            r = batch.result(i)
+            assert batch.results[i] == s[4].iterations
+            assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2]) and np.array_equal(r[3], s[3])
+            assert r[4].trials == s[4].trials
+            if i % 2 == 0:
+                assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual

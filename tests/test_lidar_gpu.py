@@ -50,6 +50,11 @@ def test_voxel_filter(fe, oracle, scans, leaf):
     dense = pts[:3000].copy()
     dense["x"] = dense["x"] * np.float32(0.01); dense["y"] *= np.float32(0.01); dense["z"] *= np.float32(0.01)
     assert same_points(fe.voxel_filter(dense, leaf), oracle.voxel_grid(dense, leaf))
+    # one voxel with more members than the LDS stage of the centroid kernel (4096), next to ordinary ones
+    huge = pts[:12000].copy()
+    for name in ("x", "y", "z"):
+        huge[name][:9000] = huge[name][:9000] * np.float32(0.002) + np.float32(0.1)
+    assert same_points(fe.voxel_filter(huge, leaf), oracle.voxel_grid(huge, leaf))
 
 
 def test_feature_extraction(pkg, fe, oracle, synthetic, scans):
