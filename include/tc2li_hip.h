@@ -292,6 +292,36 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                   uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * IMU pre-integration (camera-LiDAR-inertial configuration) -- replaces IMU::Preintegrated (SF/src/ImuTypes.cc:152-316),
+ * the sample interpolation of Tracking::PreintegrateIMU (SF/src/Tracking.cc:1710-1822) and Tracking::PredictStateIMU
+ * (:1825-1875).  Host-only (about ten float samples per frame); the result feeds the inertial edges of the local BA.
+ * Matrices are row-major floats.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_imu_sample { double t; float a[3], w[3]; } tc2li_imu_sample;              /* IMU::Point */
+typedef struct tc2li_imu_bias { float bax, bay, baz, bwx, bwy, bwz; } tc2li_imu_bias;          /* IMU::Bias */
+typedef struct tc2li_preintegrated {                                                           /* IMU::Preintegrated */
+    float dT;
+    int32_t n_measurements;
+    float dR[9], dV[3], dP[3], JRg[9], JVg[9], JVa[9], JPg[9], JPa[9], avgA[3], avgW[3];
+    float C[225];                  /* 15 x 15 covariance: rotation, velocity, position, gyro walk, acc walk */
+    float noise[6], noise_walk[6]; /* diagonals of Nga / NgaWalk (IMU::Calib::Set, ImuTypes.cc:403-416) */
+    tc2li_imu_bias bias;           /* the bias the integration was made with */
+} tc2li_preintegrated;
+
+/* Preintegrated(bias, calib): ng, na, ngw, naw as passed to IMU::Calib::Set. */
+int tc2li_imu_preintegrated_init(tc2li_preintegrated* p, const tc2li_imu_bias* bias, float ng, float na, float ngw, float naw);
+/* Preintegrated::IntegrateNewMeasurement */
+int tc2li_imu_integrate(tc2li_preintegrated* p, const float acc[3], const float ang_vel[3], float dt);
+/* The loop of Tracking::PreintegrateIMU over mvImuFromLastFrame (samples between the two frame stamps, one before and
+ * one after included); returns the number of integration steps. */
+int tc2li_imu_preintegrate(tc2li_preintegrated* p, const tc2li_imu_sample* samples, int n_samples, double t_prev, double t_cur);
+/* GetDeltaRotation / GetDeltaVelocity / GetDeltaPosition at another bias (outputs may be NULL) */
+int tc2li_imu_delta(const tc2li_preintegrated* p, const tc2li_imu_bias* bias, float dR[9], float dV[3], float dP[3]);
+/* Tracking::PredictStateIMU: (Rwb1, twb1, Vwb1) of the last keyframe / frame -> the current frame's IMU state */
+int tc2li_imu_predict_state(const tc2li_preintegrated* p, const tc2li_imu_bias* bias, const float Rwb1[9], const float twb1[3],
+                            const float Vwb1[3], float Rwb2[9], float twb2[3], float Vwb2[3]);
+
+/* ------------------------------------------------------------------------------------------------
  * Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834), data path only, for a batch of independent frames
  * whose features are device-resident: SearchByProjection(cur, last, th) with ORBmatcher(0.9, true), the 2*th retry
  * when fewer than 20 matches, Optimizer::PoseOptimization, outlier bookkeeping.  Frame f is images 2f / 2f+1 of the

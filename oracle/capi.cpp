@@ -7,6 +7,7 @@
 #include "stereo.hpp"
 #include "lidar.hpp"
 #include "ba.hpp"
+#include "imu.hpp"
 #include "matcher.hpp"
 
 using namespace oracle;
@@ -650,5 +651,37 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
     gaussianBlur7(s, d);
     std::memcpy(dst, d.store.data(), (size_t)w * h);
 }
+
+// ---- IMU pre-integration -------------------------------------------------------------------------------------------------
+// out: dT, dR 9, dV 3, dP 3, JRg 9, JVg 9, JVa 9, JPg 9, JPa 9, avgA 3, avgW 3, C 225 (= 292 floats); samples as (t, a, w) with t double
+struct ImuSamplePOD { double t; float a[3], w[3]; };
+int oracle_imu_preintegrate(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, float ng, float na,
+                            float ngw, float naw, float* out292) {
+    ImuBias b{bias6[0], bias6[1], bias6[2], bias6[3], bias6[4], bias6[5]};
+    Preintegrated p(b, ng, na, ngw, naw);
+    std::vector<ImuSample> v(n);
+    for (int i = 0; i < n; ++i) { v[i].t = samples[i].t; std::memcpy(v[i].a, samples[i].a, 12); std::memcpy(v[i].w, samples[i].w, 12); }
+    const int steps = PreintegrateIMU(v, t_prev, t_cur, p);
+    float* o = out292;
+    *o++ = p.dT;
+    auto put = [&](const float* src, int k) { std::memcpy(o, src, k * sizeof(float)); o += k; };
+    put(p.dR, 9); put(p.dV, 3); put(p.dP, 3); put(p.JRg, 9); put(p.JVg, 9); put(p.JVa, 9); put(p.JPg, 9); put(p.JPa, 9); put(p.avgA, 3);
+    put(p.avgW, 3); put(p.C, 225);
+    return steps;
+}
+// state prediction from the pre-integration of the given samples at another bias: out = Rwb2 9, twb2 3, Vwb2 3, dR 9, dV 3, dP 3
+int oracle_imu_predict(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, const float* bias_eval6,
+                       float ng, float na, float ngw, float naw, const float* Rwb1, const float* twb1, const float* Vwb1, float* out30) {
+    ImuBias b{bias6[0], bias6[1], bias6[2], bias6[3], bias6[4], bias6[5]};
+    ImuBias be{bias_eval6[0], bias_eval6[1], bias_eval6[2], bias_eval6[3], bias_eval6[4], bias_eval6[5]};
+    Preintegrated p(b, ng, na, ngw, naw);
+    std::vector<ImuSample> v(n);
+    for (int i = 0; i < n; ++i) { v[i].t = samples[i].t; std::memcpy(v[i].a, samples[i].a, 12); std::memcpy(v[i].w, samples[i].w, 12); }
+    const int steps = PreintegrateIMU(v, t_prev, t_cur, p);
+    PredictStateIMU(p, be, Rwb1, twb1, Vwb1, out30, out30 + 9, out30 + 12);
+    p.GetDeltaRotation(be, out30 + 15); p.GetDeltaVelocity(be, out30 + 24); p.GetDeltaPosition(be, out30 + 27);
+    return steps;
+}
+void oracle_normalize_rotation(const float* R, float* out) { NormalizeRotation(R, out); }
 
 }  // extern "C"

@@ -474,3 +474,44 @@ def balm_evaluate(Twl, clouds, eval_Twl=None):
     n = lib().oracle_balm_evaluate(Twl.ctypes.data, W, cl.ctypes.data, off.ctypes.data, C.addressof(res), J.ctypes.data, H.ctypes.data,
                                    ev.ctypes.data, len(ev), er.ctypes.data)
     return n, res.value, J, H, er[:len(ev)]
+
+
+# ---- IMU pre-integration ---------------------------------------------------------------------------------------------------
+IMU_SAMPLE_DTYPE = np.dtype([("t", "<f8"), ("a", "<f4", (3,)), ("w", "<f4", (3,))])
+
+
+def imu_preintegrate(samples, t_prev, t_cur, bias6, ng, na, ngw, naw):
+    """Tracking::PreintegrateIMU into a fresh IMU::Preintegrated -> (steps, dict of its fields)."""
+    s = np.ascontiguousarray(samples, IMU_SAMPLE_DTYPE)
+    b = np.ascontiguousarray(bias6, np.float32)
+    out = np.zeros(292, np.float32)
+    f = lib().oracle_imu_preintegrate
+    f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    steps = f(s.ctypes.data, len(s), t_prev, t_cur, b.ctypes.data, ng, na, ngw, naw, out.ctypes.data)
+    names = [("dR", 9), ("dV", 3), ("dP", 3), ("JRg", 9), ("JVg", 9), ("JVa", 9), ("JPg", 9), ("JPa", 9), ("avgA", 3), ("avgW", 3), ("C", 225)]
+    d, o = dict(dT=float(out[0])), 1
+    for name, k in names:
+        d[name] = out[o:o + k].copy().reshape((3, 3) if k == 9 else (15, 15) if k == 225 else (3,))
+        o += k
+    return steps, d
+
+
+def imu_predict(samples, t_prev, t_cur, bias6, bias_eval6, ng, na, ngw, naw, Rwb1, twb1, Vwb1):
+    """PredictStateIMU on the pre-integration of `samples`, deltas evaluated at bias_eval6 -> (Rwb2, twb2, Vwb2, dR, dV, dP)."""
+    s = np.ascontiguousarray(samples, IMU_SAMPLE_DTYPE)
+    b, be = np.ascontiguousarray(bias6, np.float32), np.ascontiguousarray(bias_eval6, np.float32)
+    R1, t1, v1 = [np.ascontiguousarray(a, np.float32) for a in (Rwb1, twb1, Vwb1)]
+    out = np.zeros(30, np.float32)
+    f = lib().oracle_imu_predict
+    f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4
+    f(s.ctypes.data, len(s), t_prev, t_cur, b.ctypes.data, be.ctypes.data, ng, na, ngw, naw, R1.ctypes.data, t1.ctypes.data, v1.ctypes.data,
+      out.ctypes.data)
+    return out[:9].reshape(3, 3), out[9:12], out[12:15], out[15:24].reshape(3, 3), out[24:27], out[27:30]
+
+
+def normalize_rotation(R):
+    R = np.ascontiguousarray(R, np.float32)
+    out = np.zeros(9, np.float32)
+    lib().oracle_normalize_rotation.argtypes = [C.c_void_p, C.c_void_p]
+    lib().oracle_normalize_rotation(R.ctypes.data, out.ctypes.data)
+    return out.reshape(3, 3)

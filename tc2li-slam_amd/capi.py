@@ -94,6 +94,11 @@ def lib():
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
     L.tc2li_local_bundle_adjustment_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_lidar_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+    L.tc2li_imu_preintegrated_init.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.tc2li_imu_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+    L.tc2li_imu_preintegrate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    L.tc2li_imu_delta.argtypes = [C.c_void_p] * 5
+    L.tc2li_imu_predict_state.argtypes = [C.c_void_p] * 8
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -446,6 +451,60 @@ def local_bundle_adjustment(poses7, fixed, points3, edges, cam5, iterations=10, 
                                                edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
                                                chi2.ctypes.data, dpos.ctypes.data, C.byref(stats), C.c_void_p(stream)))
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats
+
+
+# ---- IMU pre-integration (IMU::Preintegrated, Tracking::PreintegrateIMU / PredictStateIMU) -----------------------------
+IMU_SAMPLE_DTYPE = np.dtype([("t", "<f8"), ("a", "<f4", (3,)), ("w", "<f4", (3,))])
+
+
+class ImuBias(C.Structure):
+    _fields_ = [("bax", C.c_float), ("bay", C.c_float), ("baz", C.c_float), ("bwx", C.c_float), ("bwy", C.c_float), ("bwz", C.c_float)]
+
+
+class PreintegratedPOD(C.Structure):
+    _fields_ = [("dT", C.c_float), ("n_measurements", C.c_int32), ("dR", C.c_float * 9), ("dV", C.c_float * 3), ("dP", C.c_float * 3),
+                ("JRg", C.c_float * 9), ("JVg", C.c_float * 9), ("JVa", C.c_float * 9), ("JPg", C.c_float * 9), ("JPa", C.c_float * 9),
+                ("avgA", C.c_float * 3), ("avgW", C.c_float * 3), ("C", C.c_float * 225), ("noise", C.c_float * 6),
+                ("noise_walk", C.c_float * 6), ("bias", ImuBias)]
+
+
+class Preintegrated:
+    """Mirror of ``IMU::Preintegrated`` (SF/include/ImuTypes.h:141-235)."""
+
+    def __init__(self, bias6, ng, na, ngw, naw):
+        self.p = PreintegratedPOD()
+        b = ImuBias(*[float(x) for x in bias6])
+        _check(lib().tc2li_imu_preintegrated_init(C.addressof(self.p), C.addressof(b), ng, na, ngw, naw))
+
+    def IntegrateNewMeasurement(self, acc, ang_vel, dt):
+        a, w = np.ascontiguousarray(acc, np.float32), np.ascontiguousarray(ang_vel, np.float32)
+        _check(lib().tc2li_imu_integrate(C.addressof(self.p), a.ctypes.data, w.ctypes.data, float(dt)))
+
+    def preintegrate(self, samples, t_prev, t_cur):
+        """The loop of Tracking::PreintegrateIMU over mvImuFromLastFrame -> number of integration steps."""
+        s = np.ascontiguousarray(samples, IMU_SAMPLE_DTYPE)
+        return _check(lib().tc2li_imu_preintegrate(C.addressof(self.p), s.ctypes.data, len(s), float(t_prev), float(t_cur)))
+
+    def delta(self, bias6):
+        """GetDeltaRotation / GetDeltaVelocity / GetDeltaPosition at another bias."""
+        b = ImuBias(*[float(x) for x in bias6])
+        dR, dV, dP = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        _check(lib().tc2li_imu_delta(C.addressof(self.p), C.addressof(b), dR.ctypes.data, dV.ctypes.data, dP.ctypes.data))
+        return dR.reshape(3, 3), dV, dP
+
+    def predict_state(self, bias6, Rwb1, twb1, Vwb1):
+        """Tracking::PredictStateIMU -> (Rwb2, twb2, Vwb2)."""
+        b = ImuBias(*[float(x) for x in bias6])
+        R1, t1, v1 = [np.ascontiguousarray(a, np.float32) for a in (Rwb1, twb1, Vwb1)]
+        R2, t2, v2 = np.zeros(9, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        _check(lib().tc2li_imu_predict_state(C.addressof(self.p), C.addressof(b), R1.ctypes.data, t1.ctypes.data, v1.ctypes.data,
+                                             R2.ctypes.data, t2.ctypes.data, v2.ctypes.data))
+        return R2.reshape(3, 3), t2, v2
+
+    def fields(self):
+        g = lambda name, shape: np.array(getattr(self.p, name), np.float32).reshape(shape)
+        return dict(dT=self.p.dT, dR=g("dR", (3, 3)), dV=g("dV", 3), dP=g("dP", 3), JRg=g("JRg", (3, 3)), JVg=g("JVg", (3, 3)),
+                    JVa=g("JVa", (3, 3)), JPg=g("JPg", (3, 3)), JPa=g("JPa", (3, 3)), avgA=g("avgA", 3), avgW=g("avgW", 3), C=g("C", (15, 15)))
 
 
 class LastFrame(C.Structure):

@@ -304,3 +304,27 @@ def ba_window_clouds(w, win_pose, n_points=3000, noise=0.02, seed=0):
         Xl = (Xc - tcl) @ Rcl  # Tlc * Xc
         clouds.append(Xl.astype(np.float32))
     return clouds
+
+
+IMU_SAMPLE_DTYPE = np.dtype([("t", "<f8"), ("a", "<f4", (3,)), ("w", "<f4", (3,))])
+# config/Camera-Inertial-Lidar/KITTI04-12.yaml:50-54 (NoiseGyro, NoiseAcc, GyroWalk, AccWalk, Frequency 100 Hz): Calib::Set gets
+# ng = NoiseGyro * sqrt(f), na = NoiseAcc * sqrt(f), ngw = GyroWalk / sqrt(f), naw = AccWalk / sqrt(f) (SF/src/Tracking.cc ParseIMUParamFile)
+IMU_NOISE = (1.6968e-04 * 10.0, 2.0e-03 * 10.0, 1.9393e-05 / 10.0, 3.0e-03 / 10.0)
+
+
+def imu_samples(t0, t1, rate=100.0, seed=0, noise=True, omega=(0.02, -0.1, 0.05), acc_body=(0.3, 0.1, 9.7), jitter=0.0):
+    """IMU samples covering [t0, t1] with one sample before t0 and one after t1 (what mvImuFromLastFrame holds): a smooth
+    angular velocity / specific force signal plus white noise."""
+    rng = np.random.default_rng([SEED0, 0x1A0, seed])
+    k0, k1 = int(np.floor(t0 * rate)) - (0 if jitter else 0), int(np.ceil(t1 * rate)) + 1
+    t = np.arange(k0, k1 + 1) / rate + (rng.uniform(-jitter, jitter, k1 - k0 + 1) / rate if jitter else 0.0)
+    out = np.zeros(len(t), IMU_SAMPLE_DTYPE)
+    out["t"] = t
+    ph = 2 * np.pi * 0.7 * t
+    w = np.stack([omega[0] + 0.05 * np.sin(ph), omega[1] + 0.03 * np.cos(1.3 * ph), omega[2] + 0.04 * np.sin(0.6 * ph)], 1)
+    a = np.stack([acc_body[0] + 0.5 * np.sin(1.1 * ph), acc_body[1] + 0.3 * np.cos(ph), acc_body[2] + 0.2 * np.sin(0.4 * ph)], 1)
+    if noise:
+        w += rng.normal(0, IMU_NOISE[0], w.shape)
+        a += rng.normal(0, IMU_NOISE[1], a.shape)
+    out["w"], out["a"] = w.astype(np.float32), a.astype(np.float32)
+    return out
