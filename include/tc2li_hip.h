@@ -187,6 +187,32 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
                                tc2li_lidar_map* const* maps, const tc2li_lidar_state* states, int32_t* n_preprocessed,
                                int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
                                tc2li_point* corr_normvect, int capacity, void* stream);
+/* ---- camera-LiDAR-inertial branch: motion compensation of the scan (ImuProcess::UndistortPcl,
+ * SF/include/lidar_front_end/IMU_Processing.cpp:160-277) ---- */
+typedef struct tc2li_imu_pose6d {   /* Pose6D saved at every IMU sample during the forward propagation */
+    double offset_time;             /* seconds since the scan start */
+    double acc[3], gyr[3];          /* world-frame acceleration / bias-free angular velocity of the interval ending here */
+    double vel[3], pos[3], rot[9];  /* IMU state at the sample */
+} tc2li_imu_pose6d;
+typedef struct tc2li_imu_state {    /* the parts of state_ikfom the propagation reads / writes (rotations row-major) */
+    double pos[3], rot[9], vel[3], bg[3], ba[3], grav[3], offset_R_L_I[9], offset_T_L_I[3];
+} tc2li_imu_state;
+typedef struct tc2li_imu_meas { double t, acc[3], gyr[3]; } tc2li_imu_meas;   /* sensor_msgs::Imu fields used */
+
+/* Forward propagation of UndistortPcl (:176-233), state part of esekf::predict (covariance: see the ESKF entry):
+ * v_imu = last scan's tail sample followed by this scan's samples; acc_scale = G_m_s2 / mean_acc.norm();
+ * acc_s_last / angvel_last from the previous call.  Writes the poses (capacity >= n_imu) and the scan-end state into
+ * *state; returns the number of poses.  Host-only. */
+int tc2li_lidar_imu_propagate(tc2li_imu_state* state, const tc2li_imu_meas* v_imu, int n_imu, double pcl_beg_time,
+                              double pcl_end_time, double last_lidar_end_time, double acc_scale, double acc_s_last[3],
+                              double angvel_last[3], tc2li_imu_pose6d* poses, int capacity);
+
+/* The point part (:170-172, 236-276): sorts the scan by time offset (curvature, ms) in the order std::sort(time_list)
+ * produces and moves every point into the scan-end frame; in place on the host array.  end_state = imu_state after the
+ * last predict (rot, pos, offset_R_L_I, offset_T_L_I are read). */
+int tc2li_lidar_undistort(tc2li_lidar* lidar, tc2li_point* points, int n, const tc2li_imu_pose6d* imu_poses, int n_poses,
+                          const tc2li_lidar_state* end_state);
+
 /* Device time of the stages of the last tc2li_lidar_frontend_batch call, from HIP events on its stream: ms[0]
  * preprocess, [1] voxel hashing/sorting, [2] voxel centroids, [3] 5-NN + plane fit, [4] selection, [5] total. */
 int tc2li_lidar_last_timings(tc2li_lidar* lidar, float ms[8]);

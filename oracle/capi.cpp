@@ -652,6 +652,34 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
     std::memcpy(dst, d.store.data(), (size_t)w * h);
 }
 
+// ---- LiDAR motion compensation ---------------------------------------------------------------------------------------------
+// poses: 22 doubles each (offset_time, acc, gyr, vel, pos, rot); state24 like the other LiDAR entries
+void oracle_undistort(PointXYZINormal* pts, int n, const double* poses22, int n_poses, const double* state24) {
+    PointVector v(pts, pts + n);
+    std::vector<Pose6D> P(n_poses);
+    for (int i = 0; i < n_poses; ++i) std::memcpy(&P[i], poses22 + 22 * i, sizeof(Pose6D));
+    LidarState st;
+    std::memcpy(st.rot, state24, 9 * sizeof(double));
+    std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
+    std::memcpy(st.offset_R_L_I, state24 + 12, 9 * sizeof(double));
+    std::memcpy(st.offset_T_L_I, state24 + 21, 3 * sizeof(double));
+    UndistortPcl(v, P, st);
+    std::memcpy(pts, v.data(), (size_t)n * sizeof(PointXYZINormal));
+}
+// state42: pos 3, rot 9, vel 3, bg 3, ba 3, grav 3, offset_R 9, offset_T 3 (in/out); imu7: t, acc, gyr; last6: acc_s_last, angvel_last
+int oracle_imu_propagate(double* state36, const double* imu7, int n_imu, double beg, double end, double last_end, double acc_scale,
+                         const double* last6, double* poses22, int capacity) {
+    static_assert(sizeof(ImuState) == 36 * sizeof(double), "layout");
+    ImuState st;
+    std::memcpy(&st, state36, sizeof(st));
+    std::vector<ImuMeas> v(n_imu);
+    for (int i = 0; i < n_imu; ++i) std::memcpy(&v[i], imu7 + 7 * i, sizeof(ImuMeas));
+    std::vector<Pose6D> P = ForwardPropagate(st, v, beg, end, last_end, acc_scale, last6, last6 + 3);
+    std::memcpy(state36, &st, sizeof(st));
+    for (int i = 0; i < (int)P.size() && i < capacity; ++i) std::memcpy(poses22 + 22 * i, &P[i], sizeof(Pose6D));
+    return (int)P.size();
+}
+
 // ---- IMU pre-integration -------------------------------------------------------------------------------------------------
 // out: dT, dR 9, dV 3, dP 3, JRg 9, JVg 9, JVa 9, JPg 9, JPa 9, avgA 3, avgW 3, C 225 (= 292 floats); samples as (t, a, w) with t double
 struct ImuSamplePOD { double t; float a[3], w[3]; };

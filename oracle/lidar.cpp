@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <climits>
+#include <cmath>
 #include <cstring>
 
 namespace oracle {
@@ -404,6 +405,98 @@ FeatureExtraction feature_extraction(const PointVector& feats_down_body, const L
             fe.effct_feat_num++;
         }
     return fe;
+}
+
+// ---- b2: ImuProcess::UndistortPcl -------------------------------------------------------------------------------------
+namespace {
+void so3_Exp(const double w[3], double dt, double R[9]) {  // so3_math.h:63-85
+    const double n = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (n > 0.0000001) {
+        const double a[3] = {w[0] / n, w[1] / n, w[2] / n};
+        const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+        const double ang = n * dt, s = std::sin(ang), c1 = 1.0 - std::cos(ang);
+        double cK[9], cKK[9];
+        for (int k = 0; k < 9; ++k) cK[k] = c1 * K[k];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cKK[3 * r + c] = cK[3 * r] * K[c] + cK[3 * r + 1] * K[3 + c] + cK[3 * r + 2] * K[6 + c];
+        for (int k = 0; k < 9; ++k) R[k] = (I[k] + s * K[k]) + cKK[k];
+    } else {
+        for (int k = 0; k < 9; ++k) R[k] = I[k];
+    }
+}
+void mat3(const double* a, const double* b, double* o) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c]; }
+void matv(const double* a, const double* v, double* o) { for (int r = 0; r < 3; ++r) o[r] = a[3 * r] * v[0] + a[3 * r + 1] * v[1] + a[3 * r + 2] * v[2]; }
+void mattv(const double* a, const double* v, double* o) { for (int r = 0; r < 3; ++r) o[r] = a[r] * v[0] + a[3 + r] * v[1] + a[6 + r] * v[2]; }
+bool time_list(const PointXYZINormal& x, const PointXYZINormal& y) { return x.curvature < y.curvature; }
+}  // namespace
+
+void UndistortPcl(PointVector& pcl, const std::vector<Pose6D>& IMUpose, const LidarState& end) {
+    std::sort(pcl.begin(), pcl.end(), time_list);
+    if (pcl.empty() || IMUpose.empty()) return;
+    auto it_pcl = pcl.end() - 1;
+    for (auto it_kp = IMUpose.end() - 1; it_kp != IMUpose.begin(); it_kp--) {
+        auto head = it_kp - 1;
+        auto tail = it_kp;
+        for (; it_pcl->curvature / double(1000) > head->offset_time; it_pcl--) {
+            const double dt = it_pcl->curvature / double(1000) - head->offset_time;
+            double E[9], R_i[9];
+            so3_Exp(tail->gyr, dt, E);
+            mat3(head->rot, E, R_i);
+            const double P_i[3] = {it_pcl->x, it_pcl->y, it_pcl->z};
+            double T_ei[3], a[3], b[3], c[3], d[3];
+            for (int k = 0; k < 3; ++k) T_ei[k] = ((head->pos[k] + head->vel[k] * dt) + ((0.5 * tail->acc[k]) * dt) * dt) - end.pos[k];
+            matv(end.offset_R_L_I, P_i, a);
+            for (int k = 0; k < 3; ++k) a[k] += end.offset_T_L_I[k];
+            matv(R_i, a, b);
+            for (int k = 0; k < 3; ++k) b[k] += T_ei[k];
+            mattv(end.rot, b, c);
+            for (int k = 0; k < 3; ++k) c[k] -= end.offset_T_L_I[k];
+            mattv(end.offset_R_L_I, c, d);
+            it_pcl->x = (float)d[0]; it_pcl->y = (float)d[1]; it_pcl->z = (float)d[2];
+            if (it_pcl == pcl.begin()) break;
+        }
+    }
+}
+
+std::vector<Pose6D> ForwardPropagate(ImuState& st, const std::vector<ImuMeas>& v_imu, double pcl_beg_time, double pcl_end_time,
+                                     double last_lidar_end_time, double acc_scale, const double acc_s_last[3], const double angvel_last[3]) {
+    std::vector<Pose6D> out;
+    auto save = [&](double t, const double* acc, const double* gyr) {
+        Pose6D p;
+        p.offset_time = t;
+        std::memcpy(p.acc, acc, 24); std::memcpy(p.gyr, gyr, 24); std::memcpy(p.vel, st.vel, 24); std::memcpy(p.pos, st.pos, 24); std::memcpy(p.rot, st.rot, 72);
+        out.push_back(p);
+    };
+    save(0.0, acc_s_last, angvel_last);
+    auto predict = [&](double dt, const double* acc, const double* gyr) {  // state part of esekf::predict
+        double w[3], am[3], Ra[3], E[9], Rn[9];
+        for (int k = 0; k < 3; ++k) { w[k] = gyr[k] - st.bg[k]; am[k] = acc[k] - st.ba[k]; }
+        matv(st.rot, am, Ra);
+        for (int k = 0; k < 3; ++k) st.pos[k] += st.vel[k] * dt;
+        const double wdt[3] = {w[0] * dt, w[1] * dt, w[2] * dt};
+        so3_Exp(wdt, 1.0, E);
+        mat3(st.rot, E, Rn);
+        for (int k = 0; k < 3; ++k) st.vel[k] += (Ra[k] + st.grav[k]) * dt;
+        std::memcpy(st.rot, Rn, sizeof(Rn));
+    };
+    double acc_avr[3] = {0, 0, 0}, angvel_avr[3] = {0, 0, 0};
+    for (size_t i = 0; i + 1 < v_imu.size(); ++i) {
+        const ImuMeas& head = v_imu[i];
+        const ImuMeas& tail = v_imu[i + 1];
+        if (tail.t < last_lidar_end_time) continue;
+        for (int k = 0; k < 3; ++k) { angvel_avr[k] = 0.5 * (head.gyr[k] + tail.gyr[k]); acc_avr[k] = 0.5 * (head.acc[k] + tail.acc[k]) * acc_scale; }
+        const double dt = head.t < last_lidar_end_time ? tail.t - last_lidar_end_time : tail.t - head.t;
+        predict(dt, acc_avr, angvel_avr);
+        double gl[3], al[3], am[3];
+        for (int k = 0; k < 3; ++k) { gl[k] = angvel_avr[k] - st.bg[k]; am[k] = acc_avr[k] - st.ba[k]; }
+        matv(st.rot, am, al);
+        for (int k = 0; k < 3; ++k) al[k] += st.grav[k];
+        save(tail.t - pcl_beg_time, al, gl);
+    }
+    const double imu_end_time = v_imu.back().t;
+    const double note = pcl_end_time > imu_end_time ? 1.0 : -1.0;
+    predict(note * (pcl_end_time - imu_end_time), acc_avr, angvel_avr);
+    return out;
 }
 
 }  // namespace oracle

@@ -44,6 +44,20 @@ struct LidarState {  // the parts of state_ikfom that pointBodyToWorld reads (ro
 };
 PointXYZINormal pointBodyToWorld(const PointXYZINormal& pi, const LidarState& s);
 
+// ImuProcess::UndistortPcl, the point part (SF/include/lidar_front_end/IMU_Processing.cpp:170-172, 236-276): points sorted
+// by curvature (time offset in ms) with std::sort(time_list), then every point compensated into the scan-end frame from
+// the IMU poses saved during the forward propagation (Pose6D: offset_time, acc, gyr, vel, pos, rot).  `end` is imu_state
+// after the last predict.  Includes the reference's handling of the first point (re-compensated once per earlier segment).
+struct Pose6D { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
+void UndistortPcl(PointVector& pcl, const std::vector<Pose6D>& IMUpose, const LidarState& end);
+// The forward propagation that produces IMUpose (IMU_Processing.cpp:176-233), state part of esekf::predict only
+// (x <- x boxplus f(x, u) dt: pos += vel dt, rot = rot Exp((w - bg) dt), vel += (rot (a - ba) + grav) dt; use-ikfom.hpp get_f,
+// esekfom.hpp:281-...).  imu: (t, acc, gyr) samples v_imu (the previous tail sample first); returns the end state in `st`.
+struct ImuState { double pos[3], rot[9], vel[3], bg[3], ba[3], grav[3], offset_R_L_I[9], offset_T_L_I[3]; };
+struct ImuMeas { double t, acc[3], gyr[3]; };
+std::vector<Pose6D> ForwardPropagate(ImuState& st, const std::vector<ImuMeas>& v_imu, double pcl_beg_time, double pcl_end_time,
+                                     double last_lidar_end_time, double acc_scale, const double acc_s_last[3], const double angvel_last[3]);
+
 // Static k-d tree with ikd-Tree's build rule and search procedure (no re-balancing, no deletions).
 class KdTree {
 public:

@@ -515,3 +515,25 @@ def normalize_rotation(R):
     lib().oracle_normalize_rotation.argtypes = [C.c_void_p, C.c_void_p]
     lib().oracle_normalize_rotation(R.ctypes.data, out.ctypes.data)
     return out.reshape(3, 3)
+
+
+# ---- LiDAR motion compensation (ImuProcess::UndistortPcl) -----------------------------------------------------------------
+def undistort(points, poses22, state24):
+    pts = np.ascontiguousarray(points, POINT_DTYPE).copy()
+    poses = _f64(poses22).reshape(-1, 22)
+    st = _f64(state24)
+    f = lib().oracle_undistort
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    f(pts.ctypes.data, len(pts), poses.ctypes.data, len(poses), st.ctypes.data)
+    return pts
+
+
+def imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
+    """Forward propagation of UndistortPcl -> (end state [36], poses [K, 22])."""
+    st = _f64(state36).copy()
+    imu = _f64(imu7).reshape(-1, 7)
+    poses = np.zeros((len(imu) + 2, 22))
+    f = lib().oracle_imu_propagate
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    k = f(st.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, _f64(last6).ctypes.data, poses.ctypes.data, len(poses))
+    return st, poses[:k]

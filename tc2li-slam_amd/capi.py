@@ -99,6 +99,9 @@ def lib():
     L.tc2li_imu_preintegrate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
     L.tc2li_imu_delta.argtypes = [C.c_void_p] * 5
     L.tc2li_imu_predict_state.argtypes = [C.c_void_p] * 8
+    L.tc2li_lidar_undistort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_lidar_imu_propagate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -353,6 +356,14 @@ class LidarFrontEnd:
         n = _check(lib().tc2li_lidar_voxel_filter(self._h, points.ctypes.data, len(points), leaf, out.ctypes.data, len(out)))
         return out[:n].copy()
 
+    def undistort(self, points, imu_poses22, end_state24):
+        """ImuProcess::UndistortPcl, the point part: time sort + compensation into the scan-end frame."""
+        pts = np.ascontiguousarray(points, POINT_DTYPE).copy()
+        poses = np.ascontiguousarray(imu_poses22, np.float64).reshape(-1, 22)
+        st = np.ascontiguousarray(end_state24, np.float64)
+        _check(lib().tc2li_lidar_undistort(self._h, pts.ctypes.data, len(pts), poses.ctypes.data, len(poses), st.ctypes.data))
+        return pts
+
     def feature_extraction(self, lidar_map, feats_down_body, state24):
         body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
         n = len(body)
@@ -505,6 +516,17 @@ class Preintegrated:
         g = lambda name, shape: np.array(getattr(self.p, name), np.float32).reshape(shape)
         return dict(dT=self.p.dT, dR=g("dR", (3, 3)), dV=g("dV", 3), dP=g("dP", 3), JRg=g("JRg", (3, 3)), JVg=g("JVg", (3, 3)),
                     JVa=g("JVa", (3, 3)), JPg=g("JPg", (3, 3)), JPa=g("JPa", (3, 3)), avgA=g("avgA", 3), avgW=g("avgW", 3), C=g("C", (15, 15)))
+
+
+def lidar_imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
+    """Forward propagation of UndistortPcl (host) -> (end state [36], poses [K, 22], updated last6)."""
+    st = np.ascontiguousarray(state36, np.float64).copy()
+    imu = np.ascontiguousarray(imu7, np.float64).reshape(-1, 7)
+    last = np.ascontiguousarray(last6, np.float64).copy()
+    poses = np.zeros((len(imu) + 2, 22))
+    k = _check(lib().tc2li_lidar_imu_propagate(st.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, last.ctypes.data,
+                                               last.ctypes.data + 24, poses.ctypes.data, len(poses)))
+    return st, poses[:k], last
 
 
 class LastFrame(C.Structure):

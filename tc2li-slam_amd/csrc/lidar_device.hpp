@@ -71,6 +71,12 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
                            const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
+struct Pose6DDev { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
+constexpr int kMaxImuPoses = 64;
+// points[i] = in[perm[i]] compensated into the scan-end frame (ImuProcess::UndistortPcl)
+void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const Pose6DDev* poses, int n_poses, const LidarStateDev* end,
+                      PointXYZINormal* out, hipStream_t st);
+
 void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st);
 void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st);
 void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted, hipStream_t st);

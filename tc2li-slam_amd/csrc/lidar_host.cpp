@@ -44,6 +44,8 @@ struct tc2li_lidar {
     DevBuf<VoxelParams> d_vp;
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
+    DevBuf<int> d_perm;
+    DevBuf<Pose6DDev> d_imu_poses;
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
     std::vector<ScanSlot> slots;
     std::vector<SegBlock> blocks;
@@ -253,6 +255,92 @@ int tc2li_lidar_voxel_filter(tc2li_lidar* L, const tc2li_point* in, int n, float
     if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
     if (m) TC2LI_HIP_CHECK(hipMemcpy(out, L->d_down.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
     return m;
+}
+
+int tc2li_lidar_undistort(tc2li_lidar* L, tc2li_point* points, int n, const tc2li_imu_pose6d* imu_poses, int n_poses,
+                          const tc2li_lidar_state* end_state) {
+    if (!L || n < 0 || (n > 0 && !points) || n_poses < 0 || (n_poses > 0 && !imu_poses) || !end_state) {
+        set_error("tc2li_lidar_undistort: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_poses > kMaxImuPoses) { set_error("more than %d IMU poses in one scan", kMaxImuPoses); return TC2LI_ERR_CAPACITY; }
+    if (n > L->cap) { set_error("scan has %d points, slot capacity is %d", n, L->cap); return TC2LI_ERR_CAPACITY; }
+    if (n == 0) return 0;
+    // sort(pcl_out.points.begin(), pcl_out.points.end(), time_list): std::sort is not stable, and the order it leaves equal
+    // time stamps in is part of the reference's result (the voxel filter sums in point order).  Its moves depend only on the
+    // comparison outcomes, so sorting (time, index) records with the same comparator yields the same permutation.
+    struct Rec { float t; int idx; };
+    std::vector<Rec> rec(n);
+    const PointXYZINormal* P = reinterpret_cast<const PointXYZINormal*>(points);
+    for (int i = 0; i < n; ++i) rec[i] = Rec{P[i].curvature, i};
+    std::sort(rec.begin(), rec.end(), [](const Rec& x, const Rec& y) { return x.t < y.t; });
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = rec[i].idx;
+    static_assert(sizeof(tc2li_imu_pose6d) == sizeof(Pose6DDev), "ABI layout");
+    TC2LI_HIP_CHECK(L->d_perm.ensure(n));
+    TC2LI_HIP_CHECK(L->d_imu_poses.ensure(std::max(n_poses, 1)));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_perm.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    if (n_poses) TC2LI_HIP_CHECK(hipMemcpy(L->d_imu_poses.p, imu_poses, (size_t)n_poses * sizeof(Pose6DDev), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_states.p, end_state, sizeof(LidarStateDev), hipMemcpyHostToDevice));
+    launch_undistort(L->d_pre.p, L->d_perm.p, n, L->d_imu_poses.p, n_poses, L->d_states.p, L->d_down.p, nullptr);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpy(points, L->d_down.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    return n;
+}
+
+// Forward propagation at the IMU samples of one scan, state part (host; a dozen samples).
+int tc2li_lidar_imu_propagate(tc2li_imu_state* st, const tc2li_imu_meas* v, int n_imu, double pcl_beg_time, double pcl_end_time,
+                              double last_lidar_end_time, double acc_scale, double acc_s_last[3], double angvel_last[3],
+                              tc2li_imu_pose6d* poses, int capacity) {
+    if (!st || n_imu < 1 || !v || !acc_s_last || !angvel_last || !poses || capacity < 1) { set_error("tc2li_lidar_imu_propagate: invalid argument"); return TC2LI_ERR_INVALID; }
+    int np = 0;
+    auto save = [&](double t) {
+        tc2li_imu_pose6d& p = poses[np++];
+        p.offset_time = t;
+        memcpy(p.acc, acc_s_last, 24); memcpy(p.gyr, angvel_last, 24); memcpy(p.vel, st->vel, 24); memcpy(p.pos, st->pos, 24); memcpy(p.rot, st->rot, 72);
+    };
+    auto rotv = [](const double* R, const double* x, double* o) { for (int r = 0; r < 3; ++r) o[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2]; };
+    auto predict = [&](double dt, const double* acc, const double* gyr) {  // x <- x [+] f(x, u) dt  (use-ikfom.hpp get_f)
+        double am[3], Ra[3], th[3];
+        for (int k = 0; k < 3; ++k) { th[k] = (gyr[k] - st->bg[k]) * dt; am[k] = acc[k] - st->ba[k]; }
+        rotv(st->rot, am, Ra);
+        for (int k = 0; k < 3; ++k) st->pos[k] += st->vel[k] * dt;
+        const double n = std::sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+        if (n > 0.0000001) {
+            const double a[3] = {th[0] / n, th[1] / n, th[2] / n};
+            const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+            const double s = std::sin(n), c1 = 1.0 - std::cos(n);
+            double E[9], Rn[9];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    const double kk = (c1 * K[3 * r]) * K[c] + (c1 * K[3 * r + 1]) * K[3 + c] + (c1 * K[3 * r + 2]) * K[6 + c];
+                    E[3 * r + c] = ((r == c ? 1.0 : 0.0) + s * K[3 * r + c]) + kk;
+                }
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Rn[3 * r + c] = st->rot[3 * r] * E[c] + st->rot[3 * r + 1] * E[3 + c] + st->rot[3 * r + 2] * E[6 + c];
+            memcpy(st->rot, Rn, sizeof(Rn));
+        }
+        for (int k = 0; k < 3; ++k) st->vel[k] += (Ra[k] + st->grav[k]) * dt;
+    };
+    save(0.0);
+    double acc_avr[3] = {0, 0, 0}, w_avr[3] = {0, 0, 0};
+    for (int i = 0; i + 1 < n_imu; ++i) {
+        const tc2li_imu_meas& head = v[i];
+        const tc2li_imu_meas& tail = v[i + 1];
+        if (tail.t < last_lidar_end_time) continue;
+        for (int k = 0; k < 3; ++k) { w_avr[k] = 0.5 * (head.gyr[k] + tail.gyr[k]); acc_avr[k] = 0.5 * (head.acc[k] + tail.acc[k]) * acc_scale; }
+        predict(head.t < last_lidar_end_time ? tail.t - last_lidar_end_time : tail.t - head.t, acc_avr, w_avr);
+        double am[3];
+        for (int k = 0; k < 3; ++k) { angvel_last[k] = w_avr[k] - st->bg[k]; am[k] = acc_avr[k] - st->ba[k]; }
+        rotv(st->rot, am, acc_s_last);
+        for (int k = 0; k < 3; ++k) acc_s_last[k] += st->grav[k];
+        if (np >= capacity) { set_error("pose capacity %d too small", capacity); return TC2LI_ERR_CAPACITY; }
+        save(tail.t - pcl_beg_time);
+    }
+    const double imu_end = v[n_imu - 1].t;
+    predict((pcl_end_time > imu_end ? 1.0 : -1.0) * (pcl_end_time - imu_end), acc_avr, w_avr);
+    return np;
 }
 
 int tc2li_lidar_map_create(tc2li_lidar_map** out) {

@@ -415,6 +415,70 @@ __global__ __launch_bounds__(kCentroidThreads) void k_voxel_centroid(const Point
     }
 }
 
+// ---- b2: ImuProcess::UndistortPcl, backward propagation (IMU_Processing.cpp:236-276) --------------------------------
+// Points are in time order.  A point with time t belongs to the interval whose head pose is the last one earlier than t;
+// it is rotated / translated with the constant-rate model of that interval into the scan-end frame, all in double like the
+// reference (V3D / M3D), then rounded to float.  The first point of the sorted scan is compensated once per interval from
+// its own down to the first (the reference's loop re-enters it after the break at pcl_out.points.begin()).
+__device__ __forceinline__ void undistort_once(const Pose6DDev& head, const Pose6DDev& tail, double dt, const LidarStateDev& e, double P[3]) {
+    const double* w = tail.gyr;
+    const double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (n > 0.0000001) {  // so3_math.h Exp(ang_vel, dt)
+        const double a[3] = {w[0] / n, w[1] / n, w[2] / n};
+        const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+        const double ang = n * dt, s = sin(ang), c1 = 1.0 - cos(ang);
+        double cK[9];
+        for (int k = 0; k < 9; ++k) cK[k] = c1 * K[k];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                const double kk = cK[3 * r] * K[c] + cK[3 * r + 1] * K[3 + c] + cK[3 * r + 2] * K[6 + c];
+                E[3 * r + c] = (E[3 * r + c] + s * K[3 * r + c]) + kk;
+            }
+    }
+    double R_i[9], a[3], b[3], c[3];
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) R_i[3 * r + q] = head.rot[3 * r] * E[q] + head.rot[3 * r + 1] * E[3 + q] + head.rot[3 * r + 2] * E[6 + q];
+    for (int r = 0; r < 3; ++r) a[r] = (e.off_r[3 * r] * P[0] + e.off_r[3 * r + 1] * P[1] + e.off_r[3 * r + 2] * P[2]) + e.off_t[r];
+    for (int r = 0; r < 3; ++r) {
+        const double T_ei = ((head.pos[r] + head.vel[r] * dt) + ((0.5 * tail.acc[r]) * dt) * dt) - e.pos[r];
+        b[r] = (R_i[3 * r] * a[0] + R_i[3 * r + 1] * a[1] + R_i[3 * r + 2] * a[2]) + T_ei;
+    }
+    for (int r = 0; r < 3; ++r) c[r] = (e.rot[r] * b[0] + e.rot[3 + r] * b[1] + e.rot[6 + r] * b[2]) - e.off_t[r];
+    for (int r = 0; r < 3; ++r) P[r] = e.off_r[r] * c[0] + e.off_r[3 + r] * c[1] + e.off_r[6 + r] * c[2];
+}
+
+__global__ __launch_bounds__(256) void k_undistort(const PointXYZINormal* __restrict__ in, const int* __restrict__ perm, int n,
+                                                   const Pose6DDev* __restrict__ poses, int n_poses,
+                                                   const LidarStateDev* __restrict__ end, PointXYZINormal* __restrict__ out) {
+    __shared__ Pose6DDev s_pose[kMaxImuPoses];
+    __shared__ LidarStateDev s_end;
+    for (int k = threadIdx.x; k < n_poses * (int)(sizeof(Pose6DDev) / 8); k += 256) ((double*)s_pose)[k] = ((const double*)poses)[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(LidarStateDev) / 8); k += 256) ((double*)&s_end)[k] = ((const double*)end)[k];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    PointXYZINormal p = in[perm[i]];
+    const double t = (double)p.curvature / double(1000);
+    int k = 0;  // interval: head = pose k - 1, tail = pose k; 0 = not compensated
+    for (int j = 1; j < n_poses; ++j) if (t > s_pose[j - 1].offset_time) k = j;
+    if (k > 0) {
+        double P[3] = {(double)p.x, (double)p.y, (double)p.z};
+        const int k_last = i == 0 ? 1 : k;
+        for (int j = k; j >= k_last; --j) {
+            undistort_once(s_pose[j - 1], s_pose[j], t - s_pose[j - 1].offset_time, s_end, P);
+            P[0] = (double)(float)P[0]; P[1] = (double)(float)P[1]; P[2] = (double)(float)P[2];  // stored in the float point between passes
+        }
+        p.x = (float)P[0]; p.y = (float)P[1]; p.z = (float)P[2];
+    }
+    out[i] = p;
+}
+
+void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const Pose6DDev* poses, int n_poses, const LidarStateDev* end,
+                      PointXYZINormal* out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, n, poses, n_poses, end, out);
+}
+
 // ---- b5: map spatial index (replaces the ikd-Tree as a dense uniform grid over the map's bounding box) ------------
 // Cells are ordered x-fastest, so the points of a run of cells along x are one contiguous range of the sorted array.
 __device__ __forceinline__ int map_cell(const MapGrid& g, float x, float y, float z) {
