@@ -83,7 +83,7 @@ void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted,
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,
-                      int* nfound, hipStream_t st);
+                      int* nfound, int* hard_count, int2* hard_list, hipStream_t st);
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st);
 void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,

@@ -44,7 +44,8 @@ struct tc2li_lidar {
     DevBuf<VoxelParams> d_vp;
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
-    DevBuf<int> d_perm;
+    DevBuf<int> d_perm, d_hard_count;
+    DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
     std::vector<ScanSlot> slots;
@@ -128,7 +129,7 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_grids.p, grids.data(), S * sizeof(MapGrid), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
     launch_knn_plane(L->d_grids.p, d_body, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
-                     L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, st);
+                     L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, L->d_hard_count.p, L->d_hard_list.p, st);
     L->record(4, st);
     launch_sel_count(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_counts.p, st);
     launch_seg_scan(L->d_slots.p, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
@@ -205,6 +206,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     TC2LI_HIP_CHECK(L->d_vox_keys.alloc(T)); TC2LI_HIP_CHECK(L->d_member_off.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_fill.alloc(T));
     TC2LI_HIP_CHECK(L->d_members.alloc(T)); TC2LI_HIP_CHECK(L->d_n_vox.alloc(S)); TC2LI_HIP_CHECK(L->d_status.alloc(1));
     TC2LI_HIP_CHECK(L->d_states.alloc(S)); TC2LI_HIP_CHECK(L->d_grids.alloc(S));
+    TC2LI_HIP_CHECK(L->d_hard_count.alloc(1)); TC2LI_HIP_CHECK(L->d_hard_list.alloc(T));
     TC2LI_HIP_CHECK(L->h_counts.alloc(4 * S + 1));
     TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int)));
     *out = L.release();

@@ -521,20 +521,6 @@ __global__ void k_map_scatter(MapGrid g, int n, int* __restrict__ cell_fill, flo
 }
 
 // ---- b4 + b5 + b6: pointBodyToWorld, 5-NN, EstiPlane and the gates of feature_extraction --------------------------
-struct Cand { float d, x; int idx; };
-// ikd-Tree's PointType_CMP (ikd_Tree.h:93-109): distance, then x when the distances coincide
-__device__ __forceinline__ bool cand_less(const Cand& a, const Cand& b) {
-    if ((double)fabsf(a.d - b.d) < 1e-10) return a.x < b.x;
-    return a.d < b.d;
-}
-__device__ __forceinline__ void top5_insert(Cand (&best)[5], int& nb, const Cand& c) {
-    if (nb == 5 && !cand_less(c, best[4])) return;
-    int pos = nb < 5 ? nb : 4;
-    while (pos > 0 && cand_less(c, best[pos - 1])) { best[pos] = best[pos - 1]; --pos; }
-    best[pos] = c;
-    if (nb < 5) ++nb;
-}
-
 // Least squares of the 5x3 system by Householder QR with column pivoting (what colPivHouseholderQr().solve() does),
 // same operation order as the CPU statement.
 __device__ void qr_solve_5x3(float (&A)[5][3], float (&b)[5], float (&x)[3]) {
@@ -653,120 +639,272 @@ __device__ void qr_solve_5x3(float (&A)[5][3], float (&b)[5], float (&x)[3]) {
         }
 }
 
-constexpr int kMaxRing = 32;  // rings 1, 2, 4, ... cells; beyond that an exhaustive scan
+// Candidate with its position in the cell-sorted array: among candidates that compare equal under PointType_CMP the
+// sequential search keeps the one met first, and every scan below visits positions in ascending order.
+struct CandK { float d, x; int idx, k; };
+constexpr int kNoCand = 0x7fffffff;
+__device__ __forceinline__ bool candk_less(const CandK& a, const CandK& b) {
+    if (b.k == kNoCand) return a.k != kNoCand;
+    if (a.k == kNoCand) return false;
+    if ((double)fabsf(a.d - b.d) < 1e-10) { if (a.x != b.x) return a.x < b.x; return a.k < b.k; }
+    return a.d < b.d;
+}
+__device__ __forceinline__ CandK candk_empty() { CandK c; c.d = 0.f; c.x = 0.f; c.idx = -1; c.k = kNoCand; return c; }
+__device__ __forceinline__ CandK candk_sel(bool f, const CandK& a, const CandK& b) {
+    CandK o;
+    o.d = f ? a.d : b.d; o.x = f ? a.x : b.x; o.idx = f ? a.idx : b.idx; o.k = f ? a.k : b.k;
+    return o;
+}
+// The five best candidates, ascending; free slots hold the empty candidate (which compares greater than any other).
+// Named members and select-based updates: the list must live in registers (an indexed array ends up in scratch memory
+// and made this search memory-latency bound on its own bookkeeping).
+struct Top5 {
+    CandK b0, b1, b2, b3, b4;
+    __device__ __forceinline__ void clear() { b0 = b1 = b2 = b3 = b4 = candk_empty(); }
+    __device__ __forceinline__ int count() const {
+        return (b0.k != kNoCand) + (b1.k != kNoCand) + (b2.k != kNoCand) + (b3.k != kNoCand) + (b4.k != kNoCand);
+    }
+    __device__ __forceinline__ void insert(const CandK& c) {
+        if (!candk_less(c, b4)) return;
+        const bool l3 = candk_less(c, b3), l2 = candk_less(c, b2), l1 = candk_less(c, b1), l0 = candk_less(c, b0);
+        b4 = candk_sel(l3, b3, c);
+        b3 = candk_sel(l3, candk_sel(l2, b2, c), b3);
+        b2 = candk_sel(l2, candk_sel(l1, b1, c), b2);
+        b1 = candk_sel(l1, candk_sel(l0, b0, c), b1);
+        b0 = candk_sel(l0, c, b0);
+    }
+    __device__ __forceinline__ void pop() { b0 = b1; b1 = b2; b2 = b3; b3 = b4; b4 = candk_empty(); }
+};
+__device__ __forceinline__ CandK candk_shfl_xor(const CandK& c, int m) {
+    CandK o;
+    o.d = __shfl_xor(c.d, m, 64); o.x = __shfl_xor(c.x, m, 64); o.idx = __shfl_xor(c.idx, m, 64); o.k = __shfl_xor(c.k, m, 64);
+    return o;
+}
+__device__ __forceinline__ CandK candk_shfl(const CandK& c, int src) {
+    CandK o;
+    o.d = __shfl(c.d, src, 64); o.x = __shfl(c.x, src, 64); o.idx = __shfl(c.idx, src, 64); o.k = __shfl(c.k, src, 64);
+    return o;
+}
+// Smallest head among the GROUP lanes that share a query (GROUP = 4: quad, 64: wavefront); the lane that owns it pops.
+template <int GROUP>
+__device__ __forceinline__ CandK merge_step(Top5& t) {
+    const int lane = threadIdx.x & 63, leader = lane & ~(GROUP - 1);
+    const CandK head = t.b0;
+    CandK w = head;
+#pragma unroll
+    for (int m = 1; m < GROUP; m <<= 1) {
+        const CandK o = candk_shfl_xor(w, m);
+        w = candk_sel(candk_less(o, w), o, w);
+    }
+    w = candk_shfl(w, leader);  // one opinion per group even where the tolerance compare is not transitive
+    if (head.k != kNoCand && head.k == w.k) t.pop();
+    return w;
+}
+// Merges the sorted lists of the group; afterwards every lane of the group holds the same five best candidates.
+template <int GROUP>
+__device__ __forceinline__ void merge_top5(Top5& t) {
+    Top5 o;
+    o.b0 = merge_step<GROUP>(t); o.b1 = merge_step<GROUP>(t); o.b2 = merge_step<GROUP>(t); o.b3 = merge_step<GROUP>(t);
+    o.b4 = merge_step<GROUP>(t);
+    t = o;
+}
 
+__device__ __forceinline__ void scan_run(const float4* __restrict__ pts, int s, int e, float qx, float qy, float qz, Top5& t) {
+    for (int k = s; k < e; k += 2) {
+        const float4 m0 = pts[k];
+        const float4 m1 = pts[min(k + 1, e - 1)];  // issued together with m0: half the dependent-load stalls
+        CandK c;
+        c.d = (qx - m0.x) * (qx - m0.x) + (qy - m0.y) * (qy - m0.y) + (qz - m0.z) * (qz - m0.z);
+        c.x = m0.x; c.idx = __float_as_int(m0.w); c.k = k;
+        t.insert(c);
+        if (k + 1 < e) {
+            c.d = (qx - m1.x) * (qx - m1.x) + (qy - m1.y) * (qy - m1.y) + (qz - m1.z) * (qz - m1.z);
+            c.x = m1.x; c.idx = __float_as_int(m1.w); c.k = k + 1;
+            t.insert(c);
+        }
+    }
+}
+
+// The cube of cells [c - RING, c + RING]^3 as (2 RING + 1)^2 runs along x, the runs dealt round-robin to the GROUP lanes
+// of the query; the bucket bounds of all of a lane's runs are fetched before the first point is read.
+template <int RING, int GROUP>
+__device__ __forceinline__ void scan_cube(const MapGrid& g, int cx, int cy, int cz, float qx, float qy, float qz, int l, Top5& t) {
+    constexpr int W = 2 * RING + 1, NR = W * W, PER = (NR + GROUP - 1) / GROUP;
+    t.clear();
+    const int xa = max(cx - RING - g.x0, 0), xb = min(cx + RING - g.x0, g.nx - 1);
+    int rs[PER], re[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int r = l + GROUP * j;
+        const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
+        const bool ok = r < NR && xa <= xb && iz >= 0 && iz < g.nz && iy >= 0 && iy < g.ny;
+        const int row = (iz * g.ny + iy) * g.nx;
+        rs[j] = ok ? g.bucket_start[row + xa] : 0;
+        re[j] = ok ? g.bucket_start[row + xb + 1] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) scan_run(g.pts, rs[j], re[j], qx, qy, qz, t);
+    merge_top5<GROUP>(t);
+}
+
+__device__ __forceinline__ bool knn_complete(const MapGrid& g, int ring, int cx, int cy, int cz, float qx, float qy, float qz, const Top5& t) {
+    if (t.b4.k == kNoCand) return false;
+    // every point outside the cube is at least `edge` away from the query
+    const float lo = (float)ring * g.cell, hi = (float)(ring + 1) * g.cell;
+    const float fx = qx - (float)cx * g.cell, fy = qy - (float)cy * g.cell, fz = qz - (float)cz * g.cell;
+    float edge = fminf(fminf(fx + lo, hi - fx), fminf(fminf(fy + lo, hi - fy), fminf(fz + lo, hi - fz)));
+    edge = fmaxf(edge, 0.f);
+    return t.b4.d < edge * edge * 0.999f;
+}
+
+// feature_extraction gates (LidarFrontEnd.cpp:1032-1055) and the result records of one query
+__device__ __forceinline__ void knn_finish(const MapGrid& grid, const Top5& t, const PointXYZINormal& pw, double bx, double by,
+                                           double bz, bool write, int o, uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
+                                           int* __restrict__ nearest_idx, float* __restrict__ nearest_d, int* __restrict__ nfound) {
+    const PointXYZINormal* __restrict__ map_pts = grid.points;
+    const int nb = t.count();
+    uint8_t sel = 0;
+    PointXYZINormal nv;
+    nv.x = 0; nv.y = 0; nv.z = 0; nv.pad0 = 1.0f; nv.normal_x = 0; nv.normal_y = 0; nv.normal_z = 0; nv.pad1 = 0;
+    nv.intensity = 0; nv.curvature = 0; nv.pad2 = 0; nv.pad3 = 0;
+    if (nb == 5 && !(t.b4.d > 5.f)) {
+        float A[5][3], rhs[5], sol[3], px[5], py[5], pz[5];
+        const int ids[5] = {t.b0.idx, t.b1.idx, t.b2.idx, t.b3.idx, t.b4.idx};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const PointXYZINormal m = map_pts[ids[j]];
+            px[j] = m.x; py[j] = m.y; pz[j] = m.z;
+            A[j][0] = m.x; A[j][1] = m.y; A[j][2] = m.z;
+            rhs[j] = -1.0f;
+        }
+        qr_solve_5x3(A, rhs, sol);
+        const float nrm = sqrtf(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+        const float pa = __fdiv_rn(sol[0], nrm), pbn = __fdiv_rn(sol[1], nrm), pc = __fdiv_rn(sol[2], nrm);
+        const float pd = (float)(1.0 / (double)nrm);
+        bool plane = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (fabsf(pa * px[j] + pbn * py[j] + pc * pz[j] + pd) > 0.1f) plane = false;
+        if (plane) {
+            const float pd2 = pa * pw.x + pbn * pw.y + pc * pw.z + pd;
+            const double pnorm = sqrt(bx * bx + by * by + bz * bz);
+            const float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(pnorm));
+            if ((double)s > 0.9) {
+                sel = 1;
+                nv.x = pa; nv.y = pbn; nv.z = pc; nv.intensity = pd2;
+            }
+        }
+    }
+    if (!write) return;
+    nfound[o] = nb;
+    int* ni = nearest_idx + (size_t)o * 5;
+    float* nd = nearest_d + (size_t)o * 5;
+    ni[0] = t.b0.idx; ni[1] = t.b1.idx; ni[2] = t.b2.idx; ni[3] = t.b3.idx; ni[4] = t.b4.idx;  // idx of an empty slot is -1, its d is 0
+    nd[0] = t.b0.d; nd[1] = t.b1.d; nd[2] = t.b2.d; nd[3] = t.b3.d; nd[4] = t.b4.d;
+    selected[o] = sel;
+    normvec[o] = nv;
+}
+
+// pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
+__device__ __forceinline__ PointXYZINormal body_to_world(const PointXYZINormal& pb, const LidarStateDev& st) {
+    const double bx = pb.x, by = pb.y, bz = pb.z;
+    double t[3], g[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) t[r] = (st.off_r[3 * r] * bx + st.off_r[3 * r + 1] * by + st.off_r[3 * r + 2] * bz) + st.off_t[r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g[r] = (st.rot[3 * r] * t[0] + st.rot[3 * r + 1] * t[1] + st.rot[3 * r + 2] * t[2]) + st.pos[r];
+    PointXYZINormal pw;
+    pw.x = (float)g[0]; pw.y = (float)g[1]; pw.z = (float)g[2]; pw.pad0 = 1.0f;
+    pw.normal_x = 0; pw.normal_y = 0; pw.normal_z = 0; pw.pad1 = 0;
+    pw.intensity = pb.intensity; pw.curvature = 0; pw.pad2 = 0; pw.pad3 = 0;
+    return pw;
+}
+
+// Pass 1: four lanes per query search the 3^3 and, if needed, the 5^3 cube of map cells (the exact 5 nearest map points
+// of almost every query of a scan that overlaps the map lie there); queries that need a wider search are queued.
 __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ grids,
                                                    const PointXYZINormal* __restrict__ body, const int* __restrict__ count,
                                                    const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                    const LidarStateDev* __restrict__ states, PointXYZINormal* __restrict__ world,
                                                    uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
                                                    int* __restrict__ nearest_idx, float* __restrict__ nearest_d,
-                                                   int* __restrict__ nfound) {
+                                                   int* __restrict__ nfound, int* __restrict__ hard_count, int2* __restrict__ hard_list) {
     const SegBlock b = blocks[blockIdx.x];
     const ScanSlot sl = slots[b.scan];
     const int n = count[b.scan];
+    const int i = b.start + blockIdx.y * 64 + (threadIdx.x >> 2), l = threadIdx.x & 3;
+    if (i >= n) return;  // whole quads leave together
     const MapGrid grid = grids[b.scan];
-    const PointXYZINormal* __restrict__ map_pts = grid.points;
-    {
-        const int i = b.start + blockIdx.y * 256 + threadIdx.x;
-        if (i >= n) return;
-        const PointXYZINormal pb = body[sl.base + i];
-        const LidarStateDev& st = states[b.scan];
-        // pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
-        const double bx = pb.x, by = pb.y, bz = pb.z;
-        double t[3], g[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) t[r] = (st.off_r[3 * r] * bx + st.off_r[3 * r + 1] * by + st.off_r[3 * r + 2] * bz) + st.off_t[r];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) g[r] = (st.rot[3 * r] * t[0] + st.rot[3 * r + 1] * t[1] + st.rot[3 * r + 2] * t[2]) + st.pos[r];
-        PointXYZINormal pw;
-        pw.x = (float)g[0]; pw.y = (float)g[1]; pw.z = (float)g[2]; pw.pad0 = 1.0f;
-        pw.normal_x = 0; pw.normal_y = 0; pw.normal_z = 0; pw.pad1 = 0;
-        pw.intensity = pb.intensity; pw.curvature = 0; pw.pad2 = 0; pw.pad3 = 0;
-        world[sl.base + i] = pw;
+    const PointXYZINormal pb = body[sl.base + i];
+    const PointXYZINormal pw = body_to_world(pb, states[b.scan]);
+    if (l == 0) world[sl.base + i] = pw;
+    Top5 t;
+    t.clear();
+    const int cx = (int)floorf(pw.x * grid.inv_cell), cy = (int)floorf(pw.y * grid.inv_cell), cz = (int)floorf(pw.z * grid.inv_cell);
+    bool done = grid.n_points == 0;
+    if (!done) {
+        scan_cube<1, 4>(grid, cx, cy, cz, pw.x, pw.y, pw.z, l, t);
+        done = knn_complete(grid, 1, cx, cy, cz, pw.x, pw.y, pw.z, t);
+    }
+    if (!done) {
+        scan_cube<2, 4>(grid, cx, cy, cz, pw.x, pw.y, pw.z, l, t);
+        done = knn_complete(grid, 2, cx, cy, cz, pw.x, pw.y, pw.z, t);
+    }
+    if (!done) {
+        if (l == 0) hard_list[atomicAdd(hard_count, 1)] = make_int2(b.scan, i);
+        return;
+    }
+    knn_finish(grid, t, pw, (double)pb.x, (double)pb.y, (double)pb.z, l == 0, sl.base + i, selected, normvec, nearest_idx, nearest_d, nfound);
+}
 
-        // exact 5 nearest map points: search the cube of cells [c - ring, c + ring]^3 (as runs along x), growing the
-        // ring until the 5th distance lies inside the part of space the cube certainly covers
-        Cand best[5];
-        int nb = 0;
+// Pass 2: one wavefront per queued query; wider cubes (runs dealt to the 64 lanes), finally the whole map.
+template <int RING>
+__device__ __forceinline__ bool hard_ring(const MapGrid& g, int cx, int cy, int cz, float qx, float qy, float qz, int lane, Top5& t) {
+    constexpr int W = 2 * RING + 1;
+    t.clear();
+    const int xa = max(cx - RING - g.x0, 0), xb = min(cx + RING - g.x0, g.nx - 1);
+    if (xa <= xb)
+        for (int r = lane; r < W * W; r += 64) {
+            const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
+            if (iz < 0 || iz >= g.nz || iy < 0 || iy >= g.ny) continue;
+            const int row = (iz * g.ny + iy) * g.nx;
+            scan_run(g.pts, g.bucket_start[row + xa], g.bucket_start[row + xb + 1], qx, qy, qz, t);
+        }
+    merge_top5<64>(t);
+    return knn_complete(g, RING, cx, cy, cz, qx, qy, qz, t);
+}
+
+__global__ __launch_bounds__(256) void k_knn_hard(const MapGrid* __restrict__ grids, const PointXYZINormal* __restrict__ body,
+                                                  const ScanSlot* __restrict__ slots, const LidarStateDev* __restrict__ states,
+                                                  uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
+                                                  int* __restrict__ nearest_idx, float* __restrict__ nearest_d, int* __restrict__ nfound,
+                                                  const int* __restrict__ hard_count, const int2* __restrict__ hard_list) {
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+    const int total = *hard_count;
+    for (int h = wave; h < total; h += n_waves) {
+        const int2 q = hard_list[h];
+        const ScanSlot sl = slots[q.x];
+        const MapGrid grid = grids[q.x];
+        const PointXYZINormal pb = body[sl.base + q.y];
+        const PointXYZINormal pw = body_to_world(pb, states[q.x]);
         const int cx = (int)floorf(pw.x * grid.inv_cell), cy = (int)floorf(pw.y * grid.inv_cell), cz = (int)floorf(pw.z * grid.inv_cell);
-        bool done = grid.n_points == 0;
-        for (int ring = 1; ring <= kMaxRing && !done; ring *= 2) {
-            nb = 0;
-            const int xa = max(cx - ring - grid.x0, 0), xb = min(cx + ring - grid.x0, grid.nx - 1);
-            if (xa <= xb)
-                for (int qz = max(cz - ring - grid.z0, 0); qz <= min(cz + ring - grid.z0, grid.nz - 1); ++qz)
-                    for (int qy = max(cy - ring - grid.y0, 0); qy <= min(cy + ring - grid.y0, grid.ny - 1); ++qy) {
-                        const int row = (qz * grid.ny + qy) * grid.nx;
-                        for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
-                            const float4 m = grid.pts[k];
-                            Cand c;
-                            c.d = (pw.x - m.x) * (pw.x - m.x) + (pw.y - m.y) * (pw.y - m.y) + (pw.z - m.z) * (pw.z - m.z);
-                            c.x = m.x;
-                            c.idx = __float_as_int(m.w);
-                            top5_insert(best, nb, c);
-                        }
-                    }
-            if (nb == 5) {
-                // every point outside the cube is at least `edge` away from the query
-                const float lo = (float)ring * grid.cell, hi = (float)(ring + 1) * grid.cell;
-                const float fx = pw.x - (float)cx * grid.cell, fy = pw.y - (float)cy * grid.cell, fz = pw.z - (float)cz * grid.cell;
-                float edge = fminf(fminf(fx + lo, hi - fx), fminf(fminf(fy + lo, hi - fy), fminf(fz + lo, hi - fz)));
-                edge = fmaxf(edge, 0.f);
-                if (best[4].d < edge * edge * 0.999f) done = true;
-            }
+        Top5 t;
+        t.clear();
+        // a cube is worth visiting only while it has fewer runs than a third of the map has points
+        const int np3 = grid.n_points / 3;
+        bool done = false;
+        if (!done && 9 * 9 < np3) done = hard_ring<4>(grid, cx, cy, cz, pw.x, pw.y, pw.z, lane, t);
+        if (!done && 17 * 17 < np3) done = hard_ring<8>(grid, cx, cy, cz, pw.x, pw.y, pw.z, lane, t);
+        if (!done && 33 * 33 < np3) done = hard_ring<16>(grid, cx, cy, cz, pw.x, pw.y, pw.z, lane, t);
+        if (!done && 65 * 65 < np3) done = hard_ring<32>(grid, cx, cy, cz, pw.x, pw.y, pw.z, lane, t);
+        if (!done) {  // isolated query: the whole map keeps the result exact
+            t.clear();
+            const int per = (grid.n_points + 63) / 64;
+            scan_run(grid.pts, min(lane * per, grid.n_points), min((lane + 1) * per, grid.n_points), pw.x, pw.y, pw.z, t);
+            merge_top5<64>(t);
         }
-        if (!done) {  // rare: isolated query -> exhaustive scan keeps the result exact
-            nb = 0;
-            for (int k = 0; k < grid.n_points; ++k) {
-                const float4 m = grid.pts[k];
-                Cand c;
-                c.d = (pw.x - m.x) * (pw.x - m.x) + (pw.y - m.y) * (pw.y - m.y) + (pw.z - m.z) * (pw.z - m.z);
-                c.x = m.x;
-                c.idx = __float_as_int(m.w);
-                top5_insert(best, nb, c);
-            }
-        }
-        nfound[sl.base + i] = nb;
-        for (int k = 0; k < 5; ++k) {
-            nearest_idx[(size_t)(sl.base + i) * 5 + k] = k < nb ? best[k].idx : -1;
-            nearest_d[(size_t)(sl.base + i) * 5 + k] = k < nb ? best[k].d : 0.f;
-        }
-
-        // feature_extraction gates (LidarFrontEnd.cpp:1032-1055)
-        uint8_t sel = 0;
-        PointXYZINormal nv;
-        nv.x = 0; nv.y = 0; nv.z = 0; nv.pad0 = 1.0f; nv.normal_x = 0; nv.normal_y = 0; nv.normal_z = 0; nv.pad1 = 0;
-        nv.intensity = 0; nv.curvature = 0; nv.pad2 = 0; nv.pad3 = 0;
-        if (nb == 5 && !(best[4].d > 5.f)) {
-            float A[5][3], rhs[5], sol[3], px[5], py[5], pz[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const PointXYZINormal m = map_pts[best[j].idx];
-                px[j] = m.x; py[j] = m.y; pz[j] = m.z;
-                A[j][0] = m.x; A[j][1] = m.y; A[j][2] = m.z;
-                rhs[j] = -1.0f;
-            }
-            qr_solve_5x3(A, rhs, sol);
-            const float nrm = sqrtf(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
-            const float pa = __fdiv_rn(sol[0], nrm), pbn = __fdiv_rn(sol[1], nrm), pc = __fdiv_rn(sol[2], nrm);
-            const float pd = (float)(1.0 / (double)nrm);
-            bool plane = true;
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-                if (fabsf(pa * px[j] + pbn * py[j] + pc * pz[j] + pd) > 0.1f) plane = false;
-            if (plane) {
-                const float pd2 = pa * pw.x + pbn * pw.y + pc * pw.z + pd;
-                const double pnorm = sqrt(bx * bx + by * by + bz * bz);
-                const float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(pnorm));
-                if ((double)s > 0.9) {
-                    sel = 1;
-                    nv.x = pa; nv.y = pbn; nv.z = pc; nv.intensity = pd2;
-                }
-            }
-        }
-        selected[sl.base + i] = sel;
-        normvec[sl.base + i] = nv;
+        knn_finish(grid, t, pw, (double)pb.x, (double)pb.y, (double)pb.z, lane == 0, sl.base + q.y, selected, normvec, nearest_idx, nearest_d,
+                   nfound);
     }
 }
 
@@ -857,8 +995,14 @@ void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted,
 }
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
-                      uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d, int* nfound, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_knn_plane, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected, normvec, nearest_idx, nearest_d, nfound);
+                      uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d, int* nfound, int* hard_count,
+                      int2* hard_list, hipStream_t st) {
+    if (!nblocks) return;
+    (void)hipMemsetAsync(hard_count, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_knn_plane, dim3(nblocks, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
+                       normvec, nearest_idx, nearest_d, nfound, hard_count, hard_list);
+    hipLaunchKernelGGL(k_knn_hard, dim3(512), dim3(256), 0, st, grids, body, slots, states, selected, normvec, nearest_idx, nearest_d, nfound,
+                       hard_count, hard_list);
 }
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st) {
