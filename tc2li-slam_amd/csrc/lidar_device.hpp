@@ -68,7 +68,8 @@ void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanS
                        float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* vox_member_off,
                        int* vox_fill, int* members, hipStream_t st);
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                           const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
+                           float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* n_vox,
+                           const int* vox_member_off, const int* vox_fill, const int* members, void* recs /* 32 B per point */,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
 struct Pose6DDev { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };

@@ -45,6 +45,7 @@ struct tc2li_lidar {
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
     DevBuf<int> d_perm, d_hard_count;
+    DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
@@ -114,8 +115,8 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     launch_voxel_fill(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_rank.p,
                       L->d_member_off.p, L->d_vox_fill.p, L->d_members.p, st);
     L->record(2, st);
-    launch_voxel_centroid(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_vp.p, L->d_n_vox.p, L->d_member_off.p, L->d_vox_fill.p,
-                          L->d_members.p, L->d_down.p, L->d_down_count.p, st);
+    launch_voxel_centroid(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_rank.p, L->d_n_vox.p,
+                          L->d_member_off.p, L->d_vox_fill.p, L->d_members.p, L->d_recs.p, L->d_down.p, L->d_down_count.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     return TC2LI_OK;
 }
@@ -206,7 +207,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     TC2LI_HIP_CHECK(L->d_vox_keys.alloc(T)); TC2LI_HIP_CHECK(L->d_member_off.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_fill.alloc(T));
     TC2LI_HIP_CHECK(L->d_members.alloc(T)); TC2LI_HIP_CHECK(L->d_n_vox.alloc(S)); TC2LI_HIP_CHECK(L->d_status.alloc(1));
     TC2LI_HIP_CHECK(L->d_states.alloc(S)); TC2LI_HIP_CHECK(L->d_grids.alloc(S));
-    TC2LI_HIP_CHECK(L->d_hard_count.alloc(1)); TC2LI_HIP_CHECK(L->d_hard_list.alloc(T));
+    TC2LI_HIP_CHECK(L->d_hard_count.alloc(1)); TC2LI_HIP_CHECK(L->d_hard_list.alloc(T)); TC2LI_HIP_CHECK(L->d_recs.alloc(2 * T));
     TC2LI_HIP_CHECK(L->h_counts.alloc(4 * S + 1));
     TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int)));
     *out = L.release();

@@ -296,123 +296,81 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const PointXYZINormal*
     members[sl.base + vox_member_off[sl.base + r] + pos] = i;
 }
 
-// One workgroup per 256 consecutive voxels of a scan (their member lists are one contiguous range of `members`).
-// PCL sums a voxel's points in the order of its sorted index vector, i.e. by ascending point index: the range is staged
-// in LDS, every member finds its rank inside its voxel (count of smaller indices, all threads busy whatever the voxel
-// populations are), and then one thread per voxel adds the fields sequentially in float in that order -- the exact
-// summation order of pcl::CentroidPoint -- before dividing by the count.  Ranges longer than the LDS stage are
-// processed in sub-batches of whole voxels; a single voxel larger than the stage is ranked against global memory.
-constexpr int kCentroidThreads = 256, kCentroidStage = 4096;
+// PCL sums a voxel's points in the order of its sorted index vector, i.e. by ascending point index, in float.
+// k_voxel_rank: one thread per POINT finds its rank inside its voxel (count of member indices below its own; the members
+// were filled in atomic order) and writes the point's fields to that position of a record array -- the quadratic part
+// of the work is spread evenly over the whole grid whatever the voxel populations are (dense voxels near the sensor are
+// neighbours in voxel order: a block-per-voxel-range layout left a few workgroups with most of the work).
+// k_voxel_centroid: one thread per voxel adds its now contiguous records sequentially -- the exact summation order of
+// pcl::CentroidPoint -- and divides by the count.
+struct CentroidRec { float4 lo, hi; };  // x y z normal_x | normal_y normal_z intensity curvature
 
-__device__ __forceinline__ void centroid_store(const float a[8], int n, PointXYZINormal* __restrict__ dst) {
-    const float fn = (float)n;
-    PointXYZINormal o;
-    o.x = a[0] / fn; o.y = a[1] / fn; o.z = a[2] / fn; o.pad0 = 1.0f;
-    float snx = a[3], sny = a[4], snz = a[5];
-    const float nn = snx * snx + sny * sny + snz * snz;
-    if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
-    o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
-    o.intensity = a[6] / fn; o.curvature = a[7] / fn; o.pad2 = 0; o.pad3 = 0;
-    *dst = o;
+__global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                    const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks, float leaf,
+                                                    const VoxelParams* __restrict__ vp, const int* __restrict__ table_keys,
+                                                    const int* __restrict__ table_rank, const int* __restrict__ vox_member_off,
+                                                    const int* __restrict__ vox_fill, const int* __restrict__ members,
+                                                    CentroidRec* __restrict__ recs) {
+    const SegBlock b = blocks[blockIdx.x];
+    const int i = b.start + (int)blockIdx.y * 256 + threadIdx.x;
+    if (i >= count[b.scan]) return;
+    const VoxelParams v = vp[b.scan];
+    if (v.passthrough) return;
+    const ScanSlot sl = slots[b.scan];
+    const PointXYZINormal p = pts[sl.base + i];
+    if (!finite3(p)) return;
+    const int r = table_rank[table_find(table_keys, v, voxel_index(p, 1.0f / leaf, v))];
+    const int off = vox_member_off[sl.base + r], n = vox_fill[sl.base + r];
+    const int* m = members + sl.base + off;
+    int rank = 0, k = 0;
+    for (; k + 4 <= n; k += 4) {  // four independent loads in flight
+        const int a0 = m[k], a1 = m[k + 1], a2 = m[k + 2], a3 = m[k + 3];
+        rank += (a0 < i) + (a1 < i) + (a2 < i) + (a3 < i);
+    }
+    for (; k < n; ++k) rank += m[k] < i;
+    CentroidRec rec;
+    rec.lo = make_float4(p.x, p.y, p.z, p.normal_x);
+    rec.hi = make_float4(p.normal_y, p.normal_z, p.intensity, p.curvature);
+    recs[sl.base + off + rank] = rec;
 }
 
-__global__ __launch_bounds__(kCentroidThreads) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
-                                                                     const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
-                                                                     const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
-                                                                     const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
-                                                                     int* __restrict__ members, PointXYZINormal* __restrict__ out,
-                                                                     int* __restrict__ out_count) {
-    __shared__ int s_off[kCentroidThreads + 1];
-    __shared__ int s_raw[kCentroidStage], s_sorted[kCentroidStage];
-    __shared__ int s_v1;
-    __shared__ float s_acc[8];
+__global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                        const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                        const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
+                                                        const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
+                                                        const CentroidRec* __restrict__ recs, PointXYZINormal* __restrict__ out,
+                                                        int* __restrict__ out_count) {
     const SegBlock b = blocks[blockIdx.x];
     const ScanSlot sl = slots[b.scan];
     const int nv = n_vox[b.scan];
-    const int tid = threadIdx.x;
-    if (b.start == 0 && blockIdx.y == 0 && tid == 0) out_count[b.scan] = nv;
-    const int r0 = b.start + (int)blockIdx.y * kCentroidThreads, r1 = min(r0 + kCentroidThreads, min(b.start + kSegBlock, nv));
-    if (r0 >= r1) return;
-    if (vp[b.scan].passthrough != 0) {
-        if (r0 + tid < r1) out[sl.base + r0 + tid] = pts[sl.base + r0 + tid];
-        return;
+    if (b.start == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
+    const int r = b.start + (int)blockIdx.y * 256 + threadIdx.x;
+    if (r >= nv) return;
+    if (vp[b.scan].passthrough != 0) { out[sl.base + r] = pts[sl.base + r]; return; }
+    const int n = vox_fill[sl.base + r];
+    const CentroidRec* __restrict__ q = recs + sl.base + vox_member_off[sl.base + r];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {  // loads of four records issued together, additions strictly in order
+        const CentroidRec r0 = q[k], r1 = q[k + 1], r2 = q[k + 2], r3 = q[k + 3];
+        a0 += r0.lo.x; a1 += r0.lo.y; a2 += r0.lo.z; a3 += r0.lo.w; a4 += r0.hi.x; a5 += r0.hi.y; a6 += r0.hi.z; a7 += r0.hi.w;
+        a0 += r1.lo.x; a1 += r1.lo.y; a2 += r1.lo.z; a3 += r1.lo.w; a4 += r1.hi.x; a5 += r1.hi.y; a6 += r1.hi.z; a7 += r1.hi.w;
+        a0 += r2.lo.x; a1 += r2.lo.y; a2 += r2.lo.z; a3 += r2.lo.w; a4 += r2.hi.x; a5 += r2.hi.y; a6 += r2.hi.z; a7 += r2.hi.w;
+        a0 += r3.lo.x; a1 += r3.lo.y; a2 += r3.lo.z; a3 += r3.lo.w; a4 += r3.hi.x; a5 += r3.hi.y; a6 += r3.hi.z; a7 += r3.hi.w;
     }
-    const int nvb = r1 - r0;
-    if (tid < nvb) s_off[tid] = vox_member_off[sl.base + r0 + tid];
-    if (tid == 0) s_off[nvb] = vox_member_off[sl.base + r1 - 1] + vox_fill[sl.base + r1 - 1];
-    __syncthreads();
-    const int* mem = members + sl.base;
-    const PointXYZINormal* P = pts + sl.base;
-    int v0 = 0;
-    while (v0 < nvb) {
-        if (tid == 0) {  // the longest run of whole voxels that fits the stage (at least one voxel)
-            int v1 = v0 + 1;
-            while (v1 < nvb && s_off[v1 + 1] - s_off[v0] <= kCentroidStage) ++v1;
-            s_v1 = v1;
-        }
-        __syncthreads();
-        const int v1 = s_v1, m0 = s_off[v0], len = s_off[v1] - m0;
-        if (len <= kCentroidStage) {
-            for (int e = tid; e < len; e += kCentroidThreads) s_raw[e] = mem[m0 + e];
-            __syncthreads();
-            for (int e = tid; e < len; e += kCentroidThreads) {
-                int lo = v0, hi = v1;  // voxel of member e: s_off[lo] - m0 <= e < s_off[lo + 1] - m0
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_off[mid] - m0 <= e) lo = mid; else hi = mid;
-                }
-                const int ss = s_off[lo] - m0, se = s_off[lo + 1] - m0, mine = s_raw[e];
-                int rank = 0;
-                for (int k = ss; k < se; ++k) rank += s_raw[k] < mine ? 1 : 0;
-                s_sorted[ss + rank] = mine;
-            }
-            __syncthreads();
-            const int v = v0 + tid;
-            if (v < v1) {
-                const int ss = s_off[v] - m0, n = s_off[v + 1] - s_off[v];
-                float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int k = 0; k < n; ++k) {
-                    const PointXYZINormal p = P[s_sorted[ss + k]];
-                    a[0] += p.x; a[1] += p.y; a[2] += p.z; a[3] += p.normal_x; a[4] += p.normal_y; a[5] += p.normal_z;
-                    a[6] += p.intensity; a[7] += p.curvature;
-                }
-                centroid_store(a, n, out + sl.base + r0 + v);
-            }
-            __syncthreads();
-        } else {
-            // one voxel larger than the stage: rank against global memory, one stage-sized window of ranks at a time
-            const int n = len;
-            if (tid < 8) s_acc[tid] = 0.f;
-            for (int base = 0; base < n; base += kCentroidStage) {
-                for (int e = tid; e < n; e += kCentroidThreads) {
-                    const int mine = mem[m0 + e];
-                    int rank = 0;
-                    for (int k = 0; k < n; ++k) rank += mem[m0 + k] < mine ? 1 : 0;
-                    if (rank >= base && rank < base + kCentroidStage) s_sorted[rank - base] = mine;
-                }
-                __syncthreads();
-                const int cnt = min(kCentroidStage, n - base);
-                if (tid < 8) {
-                    float acc = s_acc[tid];
-                    for (int k = 0; k < cnt; ++k) {
-                        const PointXYZINormal& p = P[s_sorted[k]];
-                        const float f = tid == 0 ? p.x : tid == 1 ? p.y : tid == 2 ? p.z : tid == 3 ? p.normal_x : tid == 4 ? p.normal_y
-                                      : tid == 5 ? p.normal_z : tid == 6 ? p.intensity : p.curvature;
-                        acc += f;
-                    }
-                    s_acc[tid] = acc;
-                }
-                __syncthreads();
-            }
-            if (tid == 0) {
-                float a[8];
-                for (int k = 0; k < 8; ++k) a[k] = s_acc[k];
-                centroid_store(a, n, out + sl.base + r0 + v0);
-            }
-            __syncthreads();
-        }
-        v0 = v1;
+    for (; k < n; ++k) {
+        const CentroidRec r0 = q[k];
+        a0 += r0.lo.x; a1 += r0.lo.y; a2 += r0.lo.z; a3 += r0.lo.w; a4 += r0.hi.x; a5 += r0.hi.y; a6 += r0.hi.z; a7 += r0.hi.w;
     }
+    const float fn = (float)n;
+    PointXYZINormal o;
+    o.x = a0 / fn; o.y = a1 / fn; o.z = a2 / fn; o.pad0 = 1.0f;
+    float snx = a3, sny = a4, snz = a5;
+    const float nn = snx * snx + sny * sny + snz * snz;
+    if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
+    o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
+    o.intensity = a6 / fn; o.curvature = a7 / fn; o.pad2 = 0; o.pad3 = 0;
+    out[sl.base + r] = o;
 }
 
 // ---- b2: ImuProcess::UndistortPcl, backward propagation (IMU_Processing.cpp:236-276) --------------------------------
@@ -980,9 +938,14 @@ void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanS
     if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_rank, vox_member_off, vox_fill, members);
 }
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                           const VoxelParams* vp, const int* n_vox, const int* vox_member_off, const int* vox_fill, int* members,
-                           PointXYZINormal* out, int* out_count, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / kCentroidThreads), dim3(kCentroidThreads), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off, vox_fill, members, out, out_count);
+                           float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* n_vox,
+                           const int* vox_member_off, const int* vox_fill, const int* members, void* recs, PointXYZINormal* out,
+                           int* out_count, hipStream_t st) {
+    if (!nblocks) return;
+    hipLaunchKernelGGL(k_voxel_rank, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_rank,
+                       vox_member_off, vox_fill, members, (CentroidRec*)recs);
+    hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
+                       vox_fill, (const CentroidRec*)recs, out, out_count);
 }
 void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_counts);
