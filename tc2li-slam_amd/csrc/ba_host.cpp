@@ -2,6 +2,7 @@
 // Optimizer::PoseOptimization (SF/src/Optimizer.cc:816-1116).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -217,6 +218,10 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
     pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_l = d_scale_l.p;
 
+    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     auto stopped = [&] { return stop_flag && *stop_flag; };
     double lambda = -1, ni = 2;
     int n_bad = 0, done = 0, trials_total = 0;
@@ -224,7 +229,9 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     std::vector<double> Swork((size_t)std::max(np * np, 1)), x(std::max(np, 1));
     std::vector<double> Hl, bl_;  // dense pose-pose contribution of the LiDAR edge
     if (lidar) { Hl.assign((size_t)np * np, 0.0); bl_.assign(np, 0.0); }
+    tm[0] = now() - t_begin;
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
+        double t0 = now();
         ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         const bool need_diag = lidar && it == 0 && !(lambda_init > 0) && n_free > 0;
@@ -232,16 +239,20 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
             TC2LI_HIP_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
             TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
         }
+        if (lidar) {  // computeActiveErrors + linearizeOplus of the LiDAR edge ride on the same synchronisation
+            lidar->enqueue_error(pb.poses, st);
+            const int rc = lidar->enqueue_linearization(pb.poses, st);
+            if (rc < 0) return rc;
+        }
+        TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        tm[1] += now() - t0; t0 = now();
         double currentChi = h_scal.p[0];
         double max_pose_diag = h_scal.p[2];
         if (lidar) {
-            // computeActiveErrors + linearizeOplus + constructQuadraticForm of the LiDAR edge
-            int rc = lidar->compute_error(pb.poses, st);
-            if (rc < 0) return rc;
+            lidar->finish_error();
             currentChi = lidar->chi2() + currentChi;
-            rc = lidar->linearize(pb.poses, st);
-            if (rc < 0) return rc;
+            lidar->finish_linearization();  // constructQuadraticForm uses the stored Jacobian / Hessian when the cost grew
             std::fill(Hl.begin(), Hl.end(), 0.0);
             std::fill(bl_.begin(), bl_.end(), 0.0);
             lidar->add_quadratic_form(pose_var.data(), np, Hl.data(), bl_.data());
@@ -252,6 +263,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
                     max_pose_diag = std::max(max_pose_diag, std::fabs(ws.h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + Hl[(size_t)j * np + j]));
             }
         }
+        tm[2] += now() - t0;
         double tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
@@ -264,10 +276,12 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
         int qmax = 0;
         do {
             bool ok2 = true;
+            t0 = now();
             ba_launch_schur(pb, lambda, n_slices, k_per_slice, h_S.p, h_bs.p, st);
             TC2LI_HIP_CHECK(hipGetLastError());
             if (np > 0) {
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                tm[3] += now() - t0; t0 = now();
                 memcpy(Swork.data(), h_S.p, (size_t)np * np * sizeof(double));
                 if (lidar) {
                     for (size_t k = 0; k < (size_t)np * np; ++k) Swork[k] += Hl[k];
@@ -275,20 +289,23 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
                 }
                 ok2 = ldlt_solve_small(Swork.data(), np, h_bs.p, x.data(), false);
                 memcpy(h_xp.p, x.data(), np * sizeof(double));
+                tm[4] += now() - t0; t0 = now();
             }
             double scale = 0;
             // pose part of computeScale(): b_p is what the finish kernel left in h_bs[np .. 2 np)
             for (int j = 0; j < np; ++j) scale += x[j] * (lambda * x[j] + h_bs.p[np + j]);
             if (ok2) {
                 ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
+                if (lidar) lidar->enqueue_error(pb.poses_trial, st);
                 TC2LI_HIP_CHECK(hipGetLastError());
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
                 tempChi = h_scal.p[4];
                 scale += h_scal.p[3];
+                tm[5] += now() - t0; t0 = now();
                 if (lidar) {
-                    const int rc = lidar->compute_error(pb.poses_trial, st);
-                    if (rc < 0) return rc;
+                    lidar->finish_error();
                     tempChi = lidar->chi2() + tempChi;
+                    tm[6] += now() - t0;
                 }
             } else {
                 tempChi = std::numeric_limits<double>::max();
@@ -331,6 +348,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     if (edge_depth_positive) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_depth_positive, d_depth.p, E, hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
     for (int k = 0; k < n_poses; ++k) { memcpy(poses7 + 7 * k, poses[k].q, 4 * sizeof(double)); memcpy(poses7 + 7 * k + 4, poses[k].t, 3 * sizeof(double)); }
+    if (kTiming) fprintf(stderr, "BA timing ms: setup %.3f linearize %.3f lidar-lin %.3f schur %.3f solve %.3f trial %.3f lidar-err %.3f total %.3f\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], now() - t_begin);
     return done;
 }
 

@@ -19,12 +19,12 @@ struct BalmDev {
     LidarPose* twl;                // [W]
     double* plane_res;             // [n_planes]
     double* part;                  // [n_chunks][balm_part_stride(W)]
-    double* out;                   // [1 + 6W + (6W)^2]: residual, JacT, Hessian (row-major)
+    double* out;                   // [2 + 6W + (6W)^2]: residual (residual kernels), JacT, Hessian (row-major), residual (Hessian kernels)
 };
 
 inline int balm_items(int W) { return W * (W + 1) / 2 * 36; }
 inline int balm_part_stride(int W) { return balm_items(W) + 6 * W + 1; }
-inline int balm_out_size(int W) { return 1 + 6 * W + 36 * W * W; }
+inline int balm_out_size(int W) { return 2 + 6 * W + 36 * W * W; }
 
 // twl[i] = LiDAR pose of window slot i from the vertex estimates `poses` (LidarCovisRes::UpdatePose)
 void balm_launch_poses(const BalmDev& b, const Se3* poses, hipStream_t st);

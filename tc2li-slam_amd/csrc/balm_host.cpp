@@ -339,39 +339,57 @@ int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window*
     return 0;
 }
 
-int BalmTerm::compute_error(const Se3* d_poses, hipStream_t st) {
-    double r = 0;
-    if (n_planes) {
-        balm_launch_poses(dev, d_poses, st);
-        balm_launch_residual(dev, st);
-        TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-        r = h_out.p[0];
-    }
+void BalmTerm::enqueue_error(const Se3* d_poses, hipStream_t st) {
+    if (!n_planes) return;
+    balm_launch_poses(dev, d_poses, st);
+    balm_launch_residual(dev, st);
+}
+
+void BalmTerm::finish_error() {
+    const double r = n_planes ? h_out.p[0] : 0.0;
     error = r;
     r1 = r2;
     r2 = r;
     is_calc_hess = !(r1 - r2 < 0);  // the Hessian is kept while the cost grows (G2oTypesWithLidar.h:130-139)
+}
+
+int BalmTerm::enqueue_linearization(const Se3* d_poses, hipStream_t st) {
+    if (!n_planes) return 0;
+    balm_launch_poses(dev, d_poses, st);
+    balm_launch_hessian(dev, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(h_twl.p, d_twl.p, W * sizeof(LidarPose), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+void BalmTerm::finish_linearization() {
+    if (!is_calc_hess) return;
+    ++hessian_evaluations;
+    if (!n_planes) {
+        std::fill(JacT.begin(), JacT.end(), 0.0);
+        std::fill(Hessian.begin(), Hessian.end(), 0.0);
+        return;
+    }
+    const int n = 6 * W;
+    memcpy(JacT.data(), h_out.p + 1, n * sizeof(double));
+    memcpy(Hessian.data(), h_out.p + 1 + n, (size_t)n * n * sizeof(double));
+    balm_to_camera_se3(h_twl.p, W, Tcl, JacT.data(), Hessian.data());
+}
+
+int BalmTerm::compute_error(const Se3* d_poses, hipStream_t st) {
+    enqueue_error(d_poses, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    finish_error();
     return 0;
 }
 
 int BalmTerm::linearize(const Se3* d_poses, hipStream_t st) {
     if (!is_calc_hess) return 0;
-    ++hessian_evaluations;
-    if (!n_planes) {
-        std::fill(JacT.begin(), JacT.end(), 0.0);
-        std::fill(Hessian.begin(), Hessian.end(), 0.0);
-        return 0;
-    }
-    balm_launch_poses(dev, d_poses, st);
-    balm_launch_hessian(dev, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(h_twl.p, d_twl.p, W * sizeof(LidarPose), hipMemcpyDeviceToHost, st));
+    const int rc = enqueue_linearization(d_poses, st);
+    if (rc < 0) return rc;
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-    const int n = 6 * W;
-    memcpy(JacT.data(), h_out.p + 1, n * sizeof(double));
-    memcpy(Hessian.data(), h_out.p + 1 + n, (size_t)n * n * sizeof(double));
-    balm_to_camera_se3(h_twl.p, W, Tcl, JacT.data(), Hessian.data());
+    finish_linearization();
     return 0;
 }
 

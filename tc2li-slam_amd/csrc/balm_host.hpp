@@ -46,6 +46,13 @@ struct BalmTerm {
     int build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st);
     int compute_error(const Se3* d_poses, hipStream_t st);  // EdgeLidarSE3::computeError
     int linearize(const Se3* d_poses, hipStream_t st);      // EdgeLidarSE3::linearizeOplus
+    // The same two steps split into "enqueue the kernels" and "use the numbers after the caller's synchronisation", so
+    // that the optimiser's loop synchronises once per phase.  enqueue_linearization always evaluates the Hessian (whether
+    // the edge will take it is only known once the residual is back).
+    void enqueue_error(const Se3* d_poses, hipStream_t st);
+    void finish_error();
+    int enqueue_linearization(const Se3* d_poses, hipStream_t st);
+    void finish_linearization();
     double chi2() const { return error * information * error; }
     // EdgeLidarSE3::computeQuadraticFormLidarRes: add to the dense pose-pose system (free pose numbering pose_var)
     void add_quadratic_form(const int* pose_var, int np, double* Hpp, double* b) const;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
     if (idx >= stride) return;
     double s = 0;
     for (int k = 0; k < b.n_chunks; ++k) s += b.part[(size_t)k * stride + idx];
-    if (idx == n_items + n) { b.out[0] = s; return; }
+    if (idx == n_items + n) { b.out[1 + n + n * n] = s; return; }  // out[0] belongs to the residual-only kernels
     if (idx >= n_items) { b.out[1 + (idx - n_items)] = s; return; }
     const int pair = idx / 36, rc = idx % 36, r = rc / 6, c = rc % 6;
     int i = 0, rem = pair;  // pair -> (i, j >= i)
