@@ -187,6 +187,25 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
                                tc2li_lidar_map* const* maps, const tc2li_lidar_state* states, int32_t* n_preprocessed,
                                int32_t* n_downsampled, int32_t* n_selected, tc2li_point* laser_cloud_ori,
                                tc2li_point* corr_normvect, int capacity, void* stream);
+/* ---- persistent map maintenance on the device (the map never returns to the host) ----
+ * map_incremental (SF/include/lidar_front_end/LidarFrontEnd.cpp:387-435) for scan slot `scan` of the handle's last
+ * feature extraction (tc2li_lidar_feature_extraction: slot 0; tc2li_lidar_frontend_batch: the scan's index) against the
+ * SAME map, unchanged since: world coordinates at `state` (UpdateLidarPose may have moved it), the insertion rule
+ * (one point per filter_size_map_min voxel, the one nearest the voxel centre), then
+ * ikdtree.Add_Points(PointToAdd, true) / Add_Points(PointNoNeedDownsample, false) (ikd_Tree.cpp:478-584).
+ * ekf_inited = flg_EKF_inited.  Returns the new map size; the list sizes go to n_to_add / n_no_need (may be NULL). */
+int tc2li_lidar_map_incremental(tc2li_lidar* lidar, int scan, tc2li_lidar_map* map, const tc2li_lidar_state* state, int ekf_inited,
+                                double filter_size_map_min, int32_t* n_to_add, int32_t* n_no_need, void* stream);
+/* ikdtree.Delete_Point_Boxes (ikd_Tree.cpp:643): removes the points inside the boxes [min, max) given as
+ * min x y z, max x y z per box; returns how many were removed. */
+int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* map, const float* boxes6, int n_boxes, void* stream);
+/* Copies the map points to the host (diagnostics / tests); returns the map size. */
+int tc2li_lidar_map_download(const tc2li_lidar_map* map, tc2li_point* out, int capacity);
+/* lasermap_fov_segment (LidarFrontEnd.cpp:183-231), host logic: keeps the local-map cube around the sensor and returns
+ * the number of boxes (<= 3, written to boxes6) whose points must be deleted. */
+typedef struct tc2li_local_map_box { float vertex_min[3], vertex_max[3]; int32_t initialized; } tc2li_local_map_box;
+int tc2li_lidar_fov_segment(tc2li_local_map_box* local_map, const double pos_lid[3], double cube_len, double det_range, float boxes6[18]);
+
 /* ---- camera-LiDAR-inertial branch: motion compensation of the scan (ImuProcess::UndistortPcl,
  * SF/include/lidar_front_end/IMU_Processing.cpp:160-277) ---- */
 typedef struct tc2li_imu_pose6d {   /* Pose6D saved at every IMU sample during the forward propagation */

@@ -652,6 +652,55 @@ void oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
     std::memcpy(dst, d.store.data(), (size_t)w * h);
 }
 
+// ---- persistent map maintenance ----------------------------------------------------------------------------------------------
+// One map_incremental step on a map given as a point list: feature extraction of the down-sampled scan at state_extract
+// (a k-d tree built from the map), the two insertion lists at state_update, Add_Points twice.  Returns the new map size;
+// lists: n_to_add / n_no_need.
+int oracle_map_incremental(const PointXYZINormal* map_pts, int n_map, const PointXYZINormal* feats_down_body, int n_down,
+                           const double* state_extract24, const double* state_update24, int ekf_inited, double filter_size_map_min,
+                           PointXYZINormal* map_out, int capacity, int* n_to_add, int* n_no_need) {
+    auto state_from = [](const double* s24) {
+        LidarState st;
+        std::memcpy(st.rot, s24, 9 * sizeof(double)); std::memcpy(st.pos, s24 + 9, 3 * sizeof(double));
+        std::memcpy(st.offset_R_L_I, s24 + 12, 9 * sizeof(double)); std::memcpy(st.offset_T_L_I, s24 + 21, 3 * sizeof(double));
+        return st;
+    };
+    KdTree tree;
+    tree.Build(PointVector(map_pts, map_pts + n_map));
+    const PointVector down(feats_down_body, feats_down_body + n_down);
+    const FeatureExtraction fe = feature_extraction(down, state_from(state_extract24), tree);
+    const MapIncrement inc = map_incremental_lists(down, state_from(state_update24), fe.Nearest_Points, ekf_inited != 0, filter_size_map_min);
+    MapPoints mp;
+    mp.pts.assign(map_pts, map_pts + n_map);
+    mp.Add_Points(inc.PointToAdd, true, (float)filter_size_map_min);
+    mp.Add_Points(inc.PointNoNeedDownsample, false, (float)filter_size_map_min);
+    if (n_to_add) *n_to_add = (int)inc.PointToAdd.size();
+    if (n_no_need) *n_no_need = (int)inc.PointNoNeedDownsample.size();
+    const int k = std::min((int)mp.pts.size(), capacity);
+    std::memcpy(map_out, mp.pts.data(), (size_t)k * sizeof(PointXYZINormal));
+    return (int)mp.pts.size();
+}
+int oracle_map_delete_boxes(const PointXYZINormal* map_pts, int n_map, const float* boxes6, int n_boxes, PointXYZINormal* map_out) {
+    MapPoints mp;
+    mp.pts.assign(map_pts, map_pts + n_map);
+    std::vector<BoxPointType> boxes(n_boxes);
+    for (int b = 0; b < n_boxes; ++b) { std::memcpy(boxes[b].vertex_min, boxes6 + 6 * b, 12); std::memcpy(boxes[b].vertex_max, boxes6 + 6 * b + 3, 12); }
+    mp.Delete_Point_Boxes(boxes);
+    std::memcpy(map_out, mp.pts.data(), mp.pts.size() * sizeof(PointXYZINormal));
+    return (int)mp.pts.size();
+}
+// lm7: vertex_min 3, vertex_max 3, initialized (as floats, in/out); returns the number of boxes written to boxes6
+int oracle_fov_segment(float* lm7, const double* pos, double cube_len, double det_range, float* boxes6) {
+    LocalMapBox lm;
+    std::memcpy(lm.box.vertex_min, lm7, 12); std::memcpy(lm.box.vertex_max, lm7 + 3, 12);
+    lm.initialized = lm7[6] != 0;
+    const std::vector<BoxPointType> b = lasermap_fov_segment(lm, pos, cube_len, det_range);
+    std::memcpy(lm7, lm.box.vertex_min, 12); std::memcpy(lm7 + 3, lm.box.vertex_max, 12);
+    lm7[6] = lm.initialized ? 1.f : 0.f;
+    for (size_t i = 0; i < b.size(); ++i) { std::memcpy(boxes6 + 6 * i, b[i].vertex_min, 12); std::memcpy(boxes6 + 6 * i + 3, b[i].vertex_max, 12); }
+    return (int)b.size();
+}
+
 // ---- LiDAR motion compensation ---------------------------------------------------------------------------------------------
 // poses: 22 doubles each (offset_time, acc, gyr, vel, pos, rot); state24 like the other LiDAR entries
 void oracle_undistort(PointXYZINormal* pts, int n, const double* poses22, int n_poses, const double* state24) {

@@ -499,4 +499,130 @@ std::vector<Pose6D> ForwardPropagate(ImuState& st, const std::vector<ImuMeas>& v
     return out;
 }
 
+// ---- map maintenance ---------------------------------------------------------------------------------------------------
+namespace {
+inline bool same_point(const PointXYZINormal& a, const PointXYZINormal& b) {  // ikd_Tree.cpp: EPSS 1e-6
+    return std::fabs(a.x - b.x) < 1e-6f && std::fabs(a.y - b.y) < 1e-6f && std::fabs(a.z - b.z) < 1e-6f;
+}
+inline bool in_box(const PointXYZINormal& p, const BoxPointType& b) {
+    return b.vertex_min[0] <= p.x && b.vertex_max[0] > p.x && b.vertex_min[1] <= p.y && b.vertex_max[1] > p.y && b.vertex_min[2] <= p.z && b.vertex_max[2] > p.z;
+}
+}  // namespace
+
+int MapPoints::Add_Points(const PointVector& PointToAdd, bool downsample_on, float downsample_size) {
+    int tmp_counter = 0;
+    for (size_t i = 0; i < PointToAdd.size(); i++) {
+        if (!downsample_on) { pts.push_back(PointToAdd[i]); continue; }
+        BoxPointType Box;
+        const float c[3] = {PointToAdd[i].x, PointToAdd[i].y, PointToAdd[i].z};
+        PointXYZINormal mid = PointToAdd[i];
+        float m[3];
+        for (int k = 0; k < 3; ++k) {
+            Box.vertex_min[k] = (float)(std::floor(c[k] / downsample_size) * downsample_size);
+            Box.vertex_max[k] = Box.vertex_min[k] + downsample_size;
+            m[k] = (float)(Box.vertex_min[k] + (Box.vertex_max[k] - Box.vertex_min[k]) / 2.0);
+        }
+        mid.x = m[0]; mid.y = m[1]; mid.z = m[2];
+        std::vector<size_t> storage;
+        for (size_t k = 0; k < pts.size(); ++k) if (in_box(pts[k], Box)) storage.push_back(k);
+        float min_dist = calc_dist(PointToAdd[i], mid);
+        PointXYZINormal result = PointToAdd[i];
+        for (size_t k : storage) {
+            const float d = calc_dist(pts[k], mid);
+            if (d < min_dist) { min_dist = d; result = pts[k]; }
+        }
+        if (storage.size() > 1 || same_point(PointToAdd[i], result)) {
+            if (!storage.empty()) {
+                PointVector kept;
+                kept.reserve(pts.size());
+                for (size_t k = 0; k < pts.size(); ++k) if (!in_box(pts[k], Box)) kept.push_back(pts[k]);
+                pts.swap(kept);
+            }
+            pts.push_back(result);
+            tmp_counter++;
+        }
+    }
+    return tmp_counter;
+}
+
+int MapPoints::Delete_Point_Boxes(const std::vector<BoxPointType>& boxes) {
+    int deleted = 0;
+    for (const BoxPointType& b : boxes) {
+        PointVector kept;
+        kept.reserve(pts.size());
+        for (const PointXYZINormal& p : pts) { if (in_box(p, b)) ++deleted; else kept.push_back(p); }
+        pts.swap(kept);
+    }
+    return deleted;
+}
+
+MapIncrement map_incremental_lists(const PointVector& feats_down_body, const LidarState& st, const std::vector<PointVector>& Nearest_Points,
+                                   bool flg_EKF_inited, double filter_size_map_min) {
+    MapIncrement out;
+    const int NUM_MATCH_POINTS = 5;
+    for (size_t i = 0; i < feats_down_body.size(); i++) {
+        const PointXYZINormal pw = pointBodyToWorld(feats_down_body[i], st);
+        if (!Nearest_Points[i].empty() && flg_EKF_inited) {
+            const PointVector& points_near = Nearest_Points[i];
+            bool need_add = true;
+            PointXYZINormal mid_point = pw;
+            mid_point.x = (float)(std::floor(pw.x / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+            mid_point.y = (float)(std::floor(pw.y / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+            mid_point.z = (float)(std::floor(pw.z / filter_size_map_min) * filter_size_map_min + 0.5 * filter_size_map_min);
+            const float dist = calc_dist(pw, mid_point);
+            if (std::fabs(points_near[0].x - mid_point.x) > 0.5 * filter_size_map_min && std::fabs(points_near[0].y - mid_point.y) > 0.5 * filter_size_map_min &&
+                std::fabs(points_near[0].z - mid_point.z) > 0.5 * filter_size_map_min) {
+                out.PointNoNeedDownsample.push_back(pw);
+                continue;
+            }
+            for (int readd_i = 0; readd_i < NUM_MATCH_POINTS; readd_i++) {
+                if ((int)points_near.size() < NUM_MATCH_POINTS) break;
+                if (calc_dist(points_near[readd_i], mid_point) < dist) { need_add = false; break; }
+            }
+            if (need_add) out.PointToAdd.push_back(pw);
+        } else {
+            out.PointToAdd.push_back(pw);
+        }
+    }
+    return out;
+}
+
+std::vector<BoxPointType> lasermap_fov_segment(LocalMapBox& lm, const double pos_LiD[3], double cube_len, double DET_RANGE, float MOV_THRESHOLD) {
+    std::vector<BoxPointType> cub_needrm;
+    if (!lm.initialized) {
+        for (int i = 0; i < 3; i++) {
+            lm.box.vertex_min[i] = (float)(pos_LiD[i] - cube_len / 2.0);
+            lm.box.vertex_max[i] = (float)(pos_LiD[i] + cube_len / 2.0);
+        }
+        lm.initialized = true;
+        return cub_needrm;
+    }
+    float dist_to_map_edge[3][2];
+    bool need_move = false;
+    for (int i = 0; i < 3; i++) {
+        dist_to_map_edge[i][0] = (float)std::fabs(pos_LiD[i] - lm.box.vertex_min[i]);
+        dist_to_map_edge[i][1] = (float)std::fabs(pos_LiD[i] - lm.box.vertex_max[i]);
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * DET_RANGE || dist_to_map_edge[i][1] <= MOV_THRESHOLD * DET_RANGE) need_move = true;
+    }
+    if (!need_move) return cub_needrm;
+    BoxPointType New = lm.box, tmp;
+    const float mov_dist = (float)std::max((cube_len - 2.0 * MOV_THRESHOLD * DET_RANGE) * 0.5 * 0.9, double(DET_RANGE * (MOV_THRESHOLD - 1)));
+    for (int i = 0; i < 3; i++) {
+        tmp = lm.box;
+        if (dist_to_map_edge[i][0] <= MOV_THRESHOLD * DET_RANGE) {
+            New.vertex_max[i] -= mov_dist;
+            New.vertex_min[i] -= mov_dist;
+            tmp.vertex_min[i] = lm.box.vertex_max[i] - mov_dist;
+            cub_needrm.push_back(tmp);
+        } else if (dist_to_map_edge[i][1] <= MOV_THRESHOLD * DET_RANGE) {
+            New.vertex_max[i] += mov_dist;
+            New.vertex_min[i] += mov_dist;
+            tmp.vertex_max[i] = lm.box.vertex_min[i] + mov_dist;
+            cub_needrm.push_back(tmp);
+        }
+    }
+    lm.box = New;
+    return cub_needrm;
+}
+
 }  // namespace oracle

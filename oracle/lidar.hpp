@@ -92,4 +92,25 @@ struct FeatureExtraction {
 };
 FeatureExtraction feature_extraction(const PointVector& feats_down_body, const LidarState& st, const KdTree& tree);
 
+// ---- persistent map maintenance ---------------------------------------------------------
+//   map_incremental            SF/include/lidar_front_end/LidarFrontEnd.cpp:387-435
+//   lasermap_fov_segment       LidarFrontEnd.cpp:183-231
+//   KD_TREE::Add_Points        SF/include/ikd-Tree/ikd_Tree.cpp:478-584 (down-sampling branch :493-530)
+//   KD_TREE::Delete_Point_Boxes / Delete_by_range / Search_by_range   ikd_Tree.cpp:643, 776-860, 1259-1306 (box = [min, max))
+// The map is kept as the multiset of its points: what a query returns does not depend on the shape of the tree (exact ties of
+// the distance to a voxel centre between stored points, which the tree's traversal order would decide, are not modelled).
+struct BoxPointType { float vertex_min[3], vertex_max[3]; };
+struct MapPoints {
+    PointVector pts;
+    int Add_Points(const PointVector& to_add, bool downsample_on, float downsample_size);   // returns tmp_counter
+    int Delete_Point_Boxes(const std::vector<BoxPointType>& boxes);                        // returns the number of deleted points
+};
+struct MapIncrement { PointVector PointToAdd, PointNoNeedDownsample; };
+// feats_down_body + the neighbours found by feature_extraction -> the two insertion lists (world frame at state st)
+MapIncrement map_incremental_lists(const PointVector& feats_down_body, const LidarState& st, const std::vector<PointVector>& Nearest_Points,
+                                   bool flg_EKF_inited, double filter_size_map_min);
+struct LocalMapBox { BoxPointType box; bool initialized = false; };
+// lasermap_fov_segment: moves the local-map cube when the sensor comes near its border; returns the boxes to delete
+std::vector<BoxPointType> lasermap_fov_segment(LocalMapBox& lm, const double pos_lid[3], double cube_len, double det_range, float mov_threshold = 1.5f);
+
 }  // namespace oracle

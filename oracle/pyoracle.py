@@ -537,3 +537,37 @@ def imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
     k = f(st.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, _f64(last6).ctypes.data, poses.ctypes.data, len(poses))
     return st, poses[:k]
+
+
+# ---- persistent map maintenance -------------------------------------------------------------------------------------------
+def map_incremental(map_points, feats_down_body, state_extract24, state_update24, ekf_inited=True, filter_size_map_min=0.5):
+    """feature_extraction at state_extract + map_incremental at state_update -> (new map points, n_to_add, n_no_need)."""
+    mp = np.ascontiguousarray(map_points, POINT_DTYPE)
+    down = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
+    s0, s1 = _f64(state_extract24), _f64(state_update24)
+    out = np.zeros(len(mp) + len(down) + 1, POINT_DTYPE)
+    na, nn = C.c_int(0), C.c_int(0)
+    f = lib().oracle_map_incremental
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    n = f(mp.ctypes.data, len(mp), down.ctypes.data, len(down), s0.ctypes.data, s1.ctypes.data, int(ekf_inited), filter_size_map_min,
+          out.ctypes.data, len(out), C.addressof(na), C.addressof(nn))
+    return out[:n].copy(), na.value, nn.value
+
+
+def map_delete_boxes(map_points, boxes6):
+    mp = np.ascontiguousarray(map_points, POINT_DTYPE)
+    b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+    out = np.zeros(max(len(mp), 1), POINT_DTYPE)
+    f = lib().oracle_map_delete_boxes
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    n = f(mp.ctypes.data, len(mp), b.ctypes.data, len(b), out.ctypes.data)
+    return out[:n].copy()
+
+
+def fov_segment(lm7, pos, cube_len, det_range):
+    lm = np.ascontiguousarray(lm7, np.float32).copy()
+    boxes = np.zeros((3, 6), np.float32)
+    f = lib().oracle_fov_segment
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    n = f(lm.ctypes.data, _f64(pos).ctypes.data, cube_len, det_range, boxes.ctypes.data)
+    return lm, boxes[:n].copy()

@@ -102,6 +102,10 @@ def lib():
     L.tc2li_lidar_undistort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_lidar_imu_propagate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int]
+    L.tc2li_lidar_map_incremental.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_lidar_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_lidar_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.tc2li_lidar_fov_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -319,6 +323,38 @@ class LidarMap:
 
     def size(self):
         return _check(lib().tc2li_lidar_map_size(self._h))
+
+    def points(self):
+        n = self.size()
+        out = np.zeros(max(n, 1), POINT_DTYPE)
+        _check(lib().tc2li_lidar_map_download(self._h, out.ctypes.data, len(out)))
+        return out[:n].copy()
+
+    def Delete_Point_Boxes(self, boxes6, stream=0):
+        """boxes6: [n, 6] = min x y z, max x y z; returns the number of removed points."""
+        b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+        return _check(lib().tc2li_lidar_map_delete_boxes(self._h, b.ctypes.data, len(b), C.c_void_p(stream)))
+
+    def map_incremental(self, front_end, scan, state24, ekf_inited=True, filter_size_map_min=0.5, stream=0):
+        """``map_incremental()`` for scan slot ``scan`` of ``front_end``'s last feature extraction against this map ->
+        (map size, n_to_add, n_no_need)."""
+        st = np.ascontiguousarray(state24, np.float64)
+        na, nn = C.c_int32(0), C.c_int32(0)
+        n = _check(lib().tc2li_lidar_map_incremental(front_end._h, scan, self._h, st.ctypes.data, int(ekf_inited), filter_size_map_min,
+                                                     C.addressof(na), C.addressof(nn), C.c_void_p(stream)))
+        return n, na.value, nn.value
+
+
+class LocalMapBox(C.Structure):
+    _fields_ = [("vertex_min", C.c_float * 3), ("vertex_max", C.c_float * 3), ("initialized", C.c_int32)]
+
+
+def lidar_fov_segment(local_map, pos_lid, cube_len=200.0, det_range=100.0):
+    """``lasermap_fov_segment`` (host): updates ``local_map`` (a LocalMapBox) and returns the boxes [k, 6] to delete."""
+    pos = np.ascontiguousarray(pos_lid, np.float64)
+    boxes = np.zeros((3, 6), np.float32)
+    k = _check(lib().tc2li_lidar_fov_segment(C.addressof(local_map), pos.ctypes.data, cube_len, det_range, boxes.ctypes.data))
+    return boxes[:k].copy()
 
 
 class LidarFrontEnd:

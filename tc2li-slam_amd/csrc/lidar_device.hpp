@@ -72,6 +72,21 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
                            const int* vox_member_off, const int* vox_fill, const int* members, void* recs /* 32 B per point */,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
+// ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes) ----
+struct MapIncRec { unsigned long long key; int idx; int pad; };
+constexpr int kMapIncMax = 8192;
+void launch_mapinc_classify(const PointXYZINormal* body, int n, const LidarStateDev& st, const MapGrid& grid, const int* nearest_idx,
+                            const int* nfound, int ekf_inited, double fs, PointXYZINormal* world, uint8_t* cls, hipStream_t st_);
+void launch_mapinc_group(const PointXYZINormal* world, const uint8_t* cls, int n, float ds, MapIncRec* recs, int* group_start,
+                         int* noneed_list, int* counts, hipStream_t st);
+void launch_mapinc_apply(const PointXYZINormal* world, const MapIncRec* recs, const int* group_start, const int* counts, int n_groups,
+                         const MapGrid& grid, float ds, uint8_t* deleted, PointXYZINormal* appended, uint8_t* has_append, hipStream_t st);
+void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st);
+// out = kept points (order preserved) + appended representatives + no-need points; totals: [0] kept [1] appended; bbox_enc: 6 encoded floats
+void launch_map_compact(const PointXYZINormal* pts, const uint8_t* deleted, int n, int* block_counts, const PointXYZINormal* appended,
+                        const uint8_t* has_append, const PointXYZINormal* world, const int* noneed_list, const int* inc_counts, int* totals,
+                        PointXYZINormal* out, int* bbox_enc, hipStream_t st);
+
 struct Pose6DDev { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
 constexpr int kMaxImuPoses = 64;
 // points[i] = in[perm[i]] compensated into the scan-end frame (ImuProcess::UndistortPcl)

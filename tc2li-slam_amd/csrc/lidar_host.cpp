@@ -18,7 +18,11 @@ static_assert(sizeof(tc2li_point) == sizeof(PointXYZINormal), "ABI layout");
 static_assert(sizeof(tc2li_lidar_state) == sizeof(LidarStateDev), "ABI layout");
 
 struct tc2li_lidar_map {
-    DevBuf<PointXYZINormal> d_points;
+    DevBuf<PointXYZINormal> d_points, d_points_alt;
+    DevBuf<uint8_t> d_deleted;
+    DevBuf<int> d_keep_counts, d_totals, d_bbox;
+    DevBuf<float> d_boxes;
+    PinnedBuf<int> h_io;  // totals (2) + encoded bounding box (6)
     DevBuf<float4> d_sorted;
     DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill;
     int n = 0, n_cells = 0;
@@ -44,7 +48,12 @@ struct tc2li_lidar {
     DevBuf<VoxelParams> d_vp;
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
-    DevBuf<int> d_perm, d_hard_count;
+    DevBuf<int> d_perm, d_hard_count, d_group_start, d_noneed, d_inc_counts;
+    DevBuf<uint8_t> d_cls, d_has_append;
+    DevBuf<MapIncRec> d_inc_recs;
+    DevBuf<PointXYZINormal> d_appended;
+    PinnedBuf<int> h_inc;
+    std::vector<int> last_down;  // per slot: down-sampled points of the last feature extraction
     DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
@@ -387,6 +396,145 @@ static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool re
 int tc2li_lidar_map_build(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, true); }
 int tc2li_lidar_map_add(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, false); }
 
+namespace {
+inline float dec_enc(int i) { const int v = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &v, 4); return f; }
+
+// Removes the points flagged in m->d_deleted, appends the increment lists (if any) and rebuilds the grid.
+int map_compact_and_rebuild(tc2li_lidar_map* m, tc2li_lidar* L, int scan_base, int n_groups, int n_noneed, hipStream_t st) {
+    const int n = m->n, nb = (n + 1023) / 1024;
+    TC2LI_HIP_CHECK(m->d_keep_counts.ensure(std::max(nb, 1)));
+    TC2LI_HIP_CHECK(m->d_totals.ensure(2));
+    TC2LI_HIP_CHECK(m->d_bbox.ensure(6));
+    TC2LI_HIP_CHECK(m->h_io.ensure(8));
+    TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)n + n_groups + n_noneed + 1));
+    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    launch_map_compact(m->d_points.p, m->d_deleted.p, n, m->d_keep_counts.p, L ? L->d_appended.p : nullptr, L ? L->d_has_append.p : nullptr,
+                       L ? L->d_world.p + scan_base : nullptr, L ? L->d_noneed.p : nullptr, L ? L->d_inc_counts.p : nullptr, m->d_totals.p,
+                       m->d_points_alt.p, m->d_bbox.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p, m->d_totals.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p + 2, m->d_bbox.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    const int kept = m->h_io.p[0], appended = L ? m->h_io.p[1] : 0;
+    const int added = appended + (L ? n_noneed : 0);
+    if (added > 0)
+        for (int a = 0; a < 3; ++a) {
+            const float lo = dec_enc(m->h_io.p[2 + a]), hi = dec_enc(m->h_io.p[5 + a]);
+            if (kept == 0) { m->lo[a] = lo; m->hi[a] = hi; }  // otherwise the old box stays a (possibly loose) superset
+            m->lo[a] = std::min(m->lo[a], lo);
+            m->hi[a] = std::max(m->hi[a], hi);
+        }
+    std::swap(m->d_points.p, m->d_points_alt.p);
+    std::swap(m->d_points.n, m->d_points_alt.n);
+    m->n = kept + added;
+    const int rc = rebuild_grid(m, st);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    return kept;
+}
+}  // namespace
+
+int tc2li_lidar_map_incremental(tc2li_lidar* L, int scan, tc2li_lidar_map* m, const tc2li_lidar_state* state, int ekf_inited,
+                                double filter_size_map_min, int32_t* n_to_add, int32_t* n_no_need, void* stream_) {
+    if (!L || !m || !state || scan < 0 || scan >= (int)L->last_down.size() || !(filter_size_map_min > 0)) {
+        set_error("tc2li_lidar_map_incremental: invalid argument (the scan slot must come from the last feature extraction)");
+        return TC2LI_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    const int n = L->last_down[scan];
+    const size_t base = (size_t)scan * L->cap;
+    if (n_to_add) *n_to_add = 0;
+    if (n_no_need) *n_no_need = 0;
+    if (n == 0) return m->n;
+    TC2LI_HIP_CHECK(L->d_cls.ensure(L->cap)); TC2LI_HIP_CHECK(L->d_inc_recs.ensure(kMapIncMax)); TC2LI_HIP_CHECK(L->d_group_start.ensure(kMapIncMax + 1));
+    TC2LI_HIP_CHECK(L->d_noneed.ensure(L->cap)); TC2LI_HIP_CHECK(L->d_inc_counts.ensure(4)); TC2LI_HIP_CHECK(L->d_appended.ensure(kMapIncMax));
+    TC2LI_HIP_CHECK(L->d_has_append.ensure(kMapIncMax)); TC2LI_HIP_CHECK(L->h_inc.ensure(4));
+    TC2LI_HIP_CHECK(m->d_deleted.ensure(std::max(m->n, 1)));
+    LidarStateDev sd;
+    memcpy(&sd, state, sizeof(sd));
+    const float ds = (float)filter_size_map_min;  // ikdtree.set_downsample_param(filter_size_map_min): float downsample_size
+    launch_mapinc_classify(L->d_down.p + base, n, sd, m->grid, L->d_nearest_idx.p + base * 5, L->d_nfound.p + base, ekf_inited, filter_size_map_min,
+                           L->d_world.p + base, L->d_cls.p, st);
+    launch_mapinc_group(L->d_world.p + base, L->d_cls.p, n, ds, L->d_inc_recs.p, L->d_group_start.p, L->d_noneed.p, L->d_inc_counts.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_inc.p, L->d_inc_counts.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (m->n) TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    const int n_add = L->h_inc.p[0], n_groups = L->h_inc.p[1], n_noneed = L->h_inc.p[2];
+    if (L->h_inc.p[3]) { set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax); return TC2LI_ERR_CAPACITY; }
+    launch_mapinc_apply(L->d_world.p + base, L->d_inc_recs.p, L->d_group_start.p, L->d_inc_counts.p, n_groups, m->grid, ds, m->d_deleted.p,
+                        L->d_appended.p, L->d_has_append.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    const int rc = map_compact_and_rebuild(m, L, (int)base, n_groups, n_noneed, st);
+    if (rc < 0) return rc;
+    if (n_to_add) *n_to_add = n_add;
+    if (n_no_need) *n_no_need = n_noneed;
+    return m->n;
+}
+
+int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_boxes, void* stream_) {
+    if (!m || n_boxes < 0 || (n_boxes > 0 && !boxes6)) { set_error("tc2li_lidar_map_delete_boxes: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n_boxes == 0 || m->n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    TC2LI_HIP_CHECK(m->d_deleted.ensure(m->n));
+    TC2LI_HIP_CHECK(m->d_boxes.ensure(6 * (size_t)n_boxes));
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_boxes.p, boxes6, 6 * (size_t)n_boxes * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_map_mark_boxes(m->d_points.p, m->n, m->d_boxes.p, n_boxes, m->d_deleted.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    const int before = m->n;
+    const int kept = map_compact_and_rebuild(m, nullptr, 0, 0, 0, st);
+    if (kept < 0) return kept;
+    return before - kept;
+}
+
+int tc2li_lidar_map_download(const tc2li_lidar_map* m, tc2li_point* out, int capacity) {
+    if (!m || (capacity > 0 && !out)) { set_error("tc2li_lidar_map_download: invalid argument"); return TC2LI_ERR_INVALID; }
+    const int k = std::min(m->n, capacity);
+    if (k > 0) TC2LI_HIP_CHECK(hipMemcpy(out, m->d_points.p, (size_t)k * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    return m->n;
+}
+
+// lasermap_fov_segment (LidarFrontEnd.cpp:183-231): host logic; returns the boxes to pass to tc2li_lidar_map_delete_boxes
+int tc2li_lidar_fov_segment(tc2li_local_map_box* lm, const double pos_lid[3], double cube_len, double det_range, float boxes6[18]) {
+    if (!lm || !pos_lid || !boxes6) { set_error("tc2li_lidar_fov_segment: invalid argument"); return TC2LI_ERR_INVALID; }
+    const float MOV_THRESHOLD = 1.5f;
+    if (!lm->initialized) {
+        for (int i = 0; i < 3; i++) { lm->vertex_min[i] = (float)(pos_lid[i] - cube_len / 2.0); lm->vertex_max[i] = (float)(pos_lid[i] + cube_len / 2.0); }
+        lm->initialized = 1;
+        return 0;
+    }
+    float edge[3][2];
+    bool need_move = false;
+    const double thr = (double)MOV_THRESHOLD * det_range;
+    for (int i = 0; i < 3; i++) {
+        edge[i][0] = (float)std::fabs(pos_lid[i] - lm->vertex_min[i]);
+        edge[i][1] = (float)std::fabs(pos_lid[i] - lm->vertex_max[i]);
+        if (edge[i][0] <= thr || edge[i][1] <= thr) need_move = true;
+    }
+    if (!need_move) return 0;
+    float nmin[3], nmax[3];
+    memcpy(nmin, lm->vertex_min, 12); memcpy(nmax, lm->vertex_max, 12);
+    const float mov_dist = (float)std::max((cube_len - 2.0 * MOV_THRESHOLD * det_range) * 0.5 * 0.9, double((float)det_range * (MOV_THRESHOLD - 1)));
+    int nb = 0;
+    for (int i = 0; i < 3; i++) {
+        float* b = boxes6 + 6 * nb;
+        memcpy(b, lm->vertex_min, 12); memcpy(b + 3, lm->vertex_max, 12);
+        if (edge[i][0] <= thr) {
+            nmax[i] -= mov_dist; nmin[i] -= mov_dist;
+            b[i] = lm->vertex_max[i] - mov_dist;
+            ++nb;
+        } else if (edge[i][1] <= thr) {
+            nmax[i] += mov_dist; nmin[i] += mov_dist;
+            b[3 + i] = lm->vertex_min[i] + mov_dist;
+            ++nb;
+        }
+    }
+    memcpy(lm->vertex_min, nmin, 12); memcpy(lm->vertex_max, nmax, 12);
+    return nb;
+}
+
 int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n,
                                    const tc2li_lidar_state* state, tc2li_point* feats_down_world, uint8_t* point_selected,
                                    tc2li_point* normvec, tc2li_point* nearest_points, float* nearest_sqdist, int32_t* n_nearest,
@@ -399,6 +547,7 @@ int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const t
     TC2LI_HIP_CHECK(hipMemcpy(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
     rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, state, nullptr);
     if (rc != TC2LI_OK) return rc;
+    L->last_down.assign(1, n);
     int m = 0;
     TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost));
     if (feats_down_world) TC2LI_HIP_CHECK(hipMemcpy(feats_down_world, L->d_world.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
@@ -457,6 +606,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * n_scans, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
     if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    L->last_down.assign(hc + n_scans, hc + 2 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
         if (n_preprocessed) n_preprocessed[s] = hc[s];
         if (n_downsampled) n_downsampled[s] = hc[n_scans + s];
