@@ -68,24 +68,18 @@ def main():
     ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
-    import torch.distributed as dist
     import __graft_entry__ as ge
     ge.build_native()
     import tc2li_loader
     pkg = tc2li_loader.load()
-    from tc2li_slam_amd import synthetic
+    from tc2li_slam_amd import synthetic, dist_util
+    rank, local_rank, world = dist_util.rank_info()
 
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dist = dist_util.init("nccl", rank, world, device=torch.device("cuda", local_rank))  # None when world == 1
 
     W, H = synthetic.WIDTH, synthetic.HEIGHT
     F, U = args.frames, min(args.unique, args.frames)
@@ -194,9 +188,7 @@ def main():
             fb.result()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        dist_util.barrier(dist, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         step()
@@ -205,11 +197,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0, device="cuda")
     stage_ms = ext.last_timings().astype(float)
     nkp = float(np.mean(orb_out[2]))
     n_match = float(np.mean((st_out[1] > 0).sum(1)))
@@ -310,7 +298,7 @@ def main():
         total_frames = F * args.steps * world
         line = {
             "metric": "frames/sec (ORB+LiDAR front-end + local BA) on KITTI-00, 1/2/4/8 GPU; ATE vs ref",
-            "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(dist_util.job_throughput(F, args.steps, world, elapsed), 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (ORB, matching), f32 (LiDAR), f64 (optimisation)", "data": "synthetic",
             "config": {"workload": ("configs[1]: KITTI-00 camera-LiDAR front end on 1xMI355X per rank" if args.front_end_only else
@@ -337,7 +325,7 @@ def main():
                                "knn_plane": round(lidar_ms[3], 4), "select": round(lidar_ms[4], 4), "total": round(lidar_ms[5], 4)},
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 
