@@ -26,10 +26,12 @@ struct BaProblemDev {
     double *coef_e, *coef;               // per edge 6, per free pose 6
     double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands
     double *S_part;                      // [n_slices][np_pad * np_pad]
-    double *scale_l;                     // per landmark
+    double *scale_part;                  // per 4 landmarks: partial sums of the gain-ratio scale
+    double *chi_part;                    // per 256 edges: partial sums of the robust cost
 };
 
-void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, hipStream_t st);
+// chi_out[0] = robust cost; maxdiag_out[0..1] = largest |diagonal| of the landmark / pose blocks when want_maxdiag
+void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st);
 // S_out [np*np], bs_out [2*np]: b_s followed by b_p
 void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st);

@@ -33,7 +33,7 @@ PoseOptWorkspace& po_ws() { static PoseOptWorkspace w; return w; }
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;
     DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
-        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_l;
+        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_part, d_chi_part;
     DevBuf<BaEdge> d_edges;
     DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
     DevBuf<uint8_t> d_depth;
@@ -156,7 +156,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     }
     const int np = 6 * n_free, np_pad = std::max(16, (np + 15) / 16 * 16);
     const int k_total = 3 * n_points;
-    const int n_slices = std::max(1, std::min(64, k_total / 256));
+    const int n_slices = std::max(1, std::min(64, k_total / 64));
     const int k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
 
     // ---- device memory: a process-wide workspace that only grows (hipMalloc per call would dominate the run time) ----
@@ -172,7 +172,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
          &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
-         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_l = ws.d_scale_l;
+         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
     auto& d_edges = ws.d_edges;
     auto &d_pose_var = ws.d_pose_var, &d_pt_off = ws.d_pt_off, &d_pt_edges = ws.d_pt_edges, &d_pv_off = ws.d_pv_off, &d_pv_edges = ws.d_pv_edges;
     auto& d_depth = ws.d_depth;
@@ -187,7 +187,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
     TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
     TC2LI_HIP_CHECK(d_AT.ensure(at_elems)); TC2LI_HIP_CHECK(d_BT.ensure(at_elems));
-    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_l.ensure(P));
+    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 4 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
     TC2LI_HIP_CHECK(d_edges.ensure(E)); TC2LI_HIP_CHECK(d_pose_var.ensure(n_poses)); TC2LI_HIP_CHECK(d_pt_off.ensure(P + 1));
     TC2LI_HIP_CHECK(d_pt_edges.ensure(E)); TC2LI_HIP_CHECK(d_pv_off.ensure(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.ensure(pv_edges.size()));
     TC2LI_HIP_CHECK(d_depth.ensure(E));
@@ -216,7 +216,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     pb.edges = d_edges.p; pb.pose_var = d_pose_var.p; pb.pt_off = d_pt_off.p; pb.pt_edges = d_pt_edges.p; pb.pv_off = d_pv_off.p; pb.pv_edges = d_pv_edges.p;
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
-    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_l = d_scale_l.p;
+    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -232,7 +232,7 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     tm[0] = now() - t_begin;
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         double t0 = now();
-        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, st);
+        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
         TC2LI_HIP_CHECK(hipGetLastError());
         const bool need_diag = lidar && it == 0 && !(lambda_init > 0) && n_free > 0;
         if (need_diag) {

@@ -2,15 +2,16 @@
 // OptimizerWithLidar::LocalLVBundleAdjustment, SF/src/Optimizer.cc:1118, SF/src/OptimizerWithLidar.cc:60), i.e. the
 // numerical work of g2o's BlockSolver_6_3 with Schur complement (Thirdparty/g2o/g2o/core/block_solver.hpp:353-607):
 //   k_ba_linearize      one thread per edge: error, Huber weight, Jacobians, the edge's blocks of J^T W J and J^T W r
-//   k_ba_reduce_points  one thread per landmark: Hll, b_l from its edges (CSR, fixed order)
-//   k_ba_reduce_poses   one workgroup per free pose: Hpp, b_p from its edges (LDS tree, fixed order)
-//   k_ba_schur_points   (Hll + lambda I)^-1 and D^-1 b_l per landmark
-//   k_ba_schur_edges    per edge W D^-1 and W (6x3) scattered into the two k-major GEMM operands; W D^-1 b_l
+//   k_ba_reduce_all     by workgroup role: Hll, b_l per landmark (CSR, fixed order) | Hpp, b_p per free pose (LDS tree) | robust cost
+//   k_ba_maxdiag        largest diagonal entries for computeLambdaInit (first iteration only)
+//   k_ba_schur_prepare  by role: (Hll + lambda I)^-1, D^-1 b_l per landmark | per edge W D^-1 and W into the k-major GEMM operands
+//   k_ba_reduce_coef    W D^-1 b_l summed per free pose
 //   k_ba_schur_gemm     S_part = sum_k (W D^-1)[:,k] W[:,k]^T with v_mfma_f64_16x16x4_f64, split over k
 //   k_ba_schur_finish   S = Hpp + lambda I - sum S_part, b_s = b_p - coefficients
-//   k_ba_backsub        x_l = D^-1 (b_l - W^T x_p), trial points, the landmark part of the gain-ratio scale
-//   k_ba_update_poses   trial poses exp(x_p) * T
+//   k_ba_trial_update   by role: x_l = D^-1 (b_l - W^T x_p), trial points, landmark part of the gain-ratio scale | trial poses exp(x_p) * T
 //   k_ba_errors         robust chi2 at the trial estimate
+//   k_ba_trial_reduce   scale and cost sums
+// Launches that only depend on the same earlier results share one grid (a dependent launch costs ~10 us on its own).
 // All arithmetic is double precision; reductions run in a fixed order, so results are reproducible run to run.
 #include <hip/hip_runtime.h>
 #pragma clang fp contract(off)
@@ -30,67 +31,98 @@ __device__ __forceinline__ void edge_state(const Se3* __restrict__ poses, const 
     for (int d = 0; d < dim; ++d) chi2 += err[d] * e.info * err[d];
 }
 
-__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= pb.n_edges) return;
-    const BaEdge ed = pb.edges[e];
-    double p[3], err[3], c2;
-    int dim;
-    edge_state(pb.poses, pb.points, ed, pb.cam, p, err, dim, c2);
-    const bool stereo = ed.ur >= 0;
-    double rho0, rho1;
-    huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
-    pb.chi2[e] = c2;
-    pb.rho0[e] = rho0;
-    double R[9], A[9], B[18];
-    quat_to_matrix(pb.poses[ed.pose].q, R);
-    point_jacobian(p, R, stereo, pb.cam, A);
-    pose_jacobian(p, stereo, false, pb.cam, B);
-    const double w = rho1 * ed.info;
-    double wr[3];  // omega_r = -rho' * Omega * e
-    for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
-    // landmark block: A^T W A (upper 6) and A^T omega_r
-    double* cl = pb.contrib_l + 9 * (size_t)e;
-    {
-        int h = 0;
-        for (int r = 0; r < 3; ++r)
-            for (int c = r; c < 3; ++c) {
-                double s = 0;
-                for (int d = 0; d < dim; ++d) s += A[3 * d + r] * w * A[3 * d + c];
-                cl[h++] = s;
-            }
-        for (int r = 0; r < 3; ++r) {
-            double s = 0;
-            for (int d = 0; d < dim; ++d) s += A[3 * d + r] * wr[d];
-            cl[6 + r] = s;
-        }
+// sum of v over the workgroup's 256 threads in a fixed order -> out[0]
+__device__ __forceinline__ void block_sum_256(double v, double* s, double* __restrict__ out) {
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
     }
-    if (pb.pose_var[ed.pose] >= 0) {
-        double* cp = pb.contrib_p + 27 * (size_t)e;
-        int h = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) {
-                double s = 0;
-                for (int d = 0; d < dim; ++d) s += B[6 * d + r] * w * B[6 * d + c];
-                cp[h++] = s;
-            }
-        for (int r = 0; r < 6; ++r) {
-            double s = 0;
-            for (int d = 0; d < dim; ++d) s += B[6 * d + r] * wr[d];
-            cp[21 + r] = s;
-        }
-        double* W = pb.W + 18 * (size_t)e;  // Hpl block: B^T W A (6 x 3)
-        for (int r = 0; r < 6; ++r)
-            for (int c = 0; c < 3; ++c) {
-                double s = 0;
-                for (int d = 0; d < dim; ++d) s += B[6 * d + r] * w * A[3 * d + c];
-                W[3 * r + c] = s;
-            }
-    }
+    if (threadIdx.x == 0) out[0] = s[0];
 }
 
-__global__ __launch_bounds__(256) void k_ba_reduce_points(BaProblemDev pb) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
+    __shared__ double s_sum[256];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    double rho0 = 0;
+    if (e < pb.n_edges) {
+        const BaEdge ed = pb.edges[e];
+        double p[3], err[3], c2;
+        int dim;
+        edge_state(pb.poses, pb.points, ed, pb.cam, p, err, dim, c2);
+        const bool stereo = ed.ur >= 0;
+        double rho1;
+        huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
+        pb.chi2[e] = c2;
+        pb.rho0[e] = rho0;
+        double R[9], A[9], B[18];
+        quat_to_matrix(pb.poses[ed.pose].q, R);
+        point_jacobian(p, R, stereo, pb.cam, A);
+        pose_jacobian(p, stereo, false, pb.cam, B);
+        const double w = rho1 * ed.info;
+        double wr[3];  // omega_r = -rho' * Omega * e
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
+        // The row sums run over all three rows with compile-time indices (everything stays in registers); the third row of
+        // A and B is zero for a monocular edge, so its terms add exact zeros.
+        // landmark block: A^T W A (upper 6) and A^T omega_r
+        double* cl = pb.contrib_l + 9 * (size_t)e;
+        {
+            int h = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = r; c < 3; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += A[3 * d + r] * w * A[3 * d + c];
+                    cl[h++] = s;
+                }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double s = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) s += A[3 * d + r] * wr[d];
+                cl[6 + r] = s;
+            }
+        }
+        if (pb.pose_var[ed.pose] >= 0) {
+            double* cp = pb.contrib_p + 27 * (size_t)e;
+            int h = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * B[6 * d + c];
+                    cp[h++] = s;
+                }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double s = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) s += B[6 * d + r] * wr[d];
+                cp[21 + r] = s;
+            }
+            double* W = pb.W + 18 * (size_t)e;  // Hpl block: B^T W A (6 x 3)
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * A[3 * d + c];
+                    W[3 * r + c] = s;
+                }
+        }
+    }
+    block_sum_256(rho0, s_sum, pb.chi_part + blockIdx.x);  // the robust cost is summed per workgroup here, finished in the next launch
+}
+
+__device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int block) {
+    const int l = block * 256 + threadIdx.x;
     if (l >= pb.n_points) return;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
@@ -123,9 +155,7 @@ __device__ __forceinline__ void block_sum_items(const double* __restrict__ items
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_ba_reduce_poses(BaProblemDev pb) {
-    __shared__ double s_part[256 * 27];
-    const int i = blockIdx.x;  // free pose
+__device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i /* free pose */, double* s_part) {
     block_sum_items<27>(pb.contrib_p, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.Hpp + 27 * (size_t)i);
     if (threadIdx.x == 0) {
         const double* h = pb.Hpp + 27 * (size_t)i;
@@ -134,48 +164,74 @@ __global__ __launch_bounds__(256) void k_ba_reduce_poses(BaProblemDev pb) {
     }
 }
 
-// out[0] = sum(in[0..n)) (or max when MAX) in a fixed order, one workgroup of 1024 threads.
+// out[0] = in[0] + in[1] + ... (or the maximum) by one 256-thread workgroup, fixed order
 template <bool MAX>
-__global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ in, int n, double* __restrict__ out) {
-    __shared__ double s[1024];
+__device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, int n, double* s, double* out) {
     double a = 0;
-    for (int k = threadIdx.x; k < n; k += 1024) a = MAX ? fmax(a, in[k]) : a + in[k];
+    for (int k = threadIdx.x; k < n; k += 256) a = MAX ? fmax(a, in[k]) : a + in[k];
     s[threadIdx.x] = a;
     __syncthreads();
-    for (int st = 512; st >= 1; st >>= 1) {
+    for (int st = 128; st >= 1; st >>= 1) {
         if ((int)threadIdx.x < st) s[threadIdx.x] = MAX ? fmax(s[threadIdx.x], s[threadIdx.x + st]) : s[threadIdx.x] + s[threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = s[0];
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_ba_schur_points(BaProblemDev pb, double lambda) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= pb.n_points) return;
+// One launch after k_ba_linearize: workgroups [0, nbp) sum the landmark blocks, [nbp, nbp + n_free) the pose blocks, the
+// last one the robust cost (the three jobs only read what the linearisation wrote).
+__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, int nbp, double* __restrict__ chi_out) {
+    __shared__ double s_part[256 * 27];
+    const int b = blockIdx.x;
+    if (b < nbp) reduce_points_body(pb, b);
+    else if (b < nbp + pb.n_free) reduce_poses_body(pb, b - nbp, s_part);
+    else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s_part, chi_out);
+}
+
+// computeLambdaInit needs the largest diagonal entries: [0] landmarks, [1] poses (first iteration only)
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaProblemDev pb, double* __restrict__ out) {
+    __shared__ double s[256];
+    if (blockIdx.x == 0) block_reduce_256<true>(pb.diag_l, pb.n_points, s, out);
+    else block_reduce_256<true>(pb.diag_p, pb.n_free, s, out + 1);
+}
+
+// (Hll + lambda I)^-1 and its product with b_l for landmark l
+__device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double lambda, double Di[9], double db[3]) {
     const double* h = pb.Hll + 6 * (size_t)l;
     // D = Hll + lambda I (symmetric: h = [00 01 02 11 12 22]); inverse by cofactors like Eigen's fixed 3x3 inverse
     const double d00 = h[0] + lambda, d01 = h[1], d02 = h[2], d11 = h[3] + lambda, d12 = h[4], d22 = h[5] + lambda;
     const double c00 = d11 * d22 - d12 * d12, c01 = d12 * d02 - d01 * d22, c02 = d01 * d12 - d11 * d02;
     const double det = d00 * c00 + d01 * c01 + d02 * c02, id = 1.0 / det;
-    double Di[9];
     Di[0] = c00 * id; Di[1] = (d02 * d12 - d01 * d22) * id; Di[2] = (d01 * d12 - d02 * d11) * id;
     Di[3] = c01 * id; Di[4] = (d00 * d22 - d02 * d02) * id; Di[5] = (d02 * d01 - d00 * d12) * id;
     Di[6] = c02 * id; Di[7] = (d01 * d02 - d00 * d12) * id; Di[8] = (d00 * d11 - d01 * d01) * id;
-    double* o = pb.Dinv + 9 * (size_t)l;
-    for (int i = 0; i < 9; ++i) o[i] = Di[i];
     const double* b = pb.bl + 3 * (size_t)l;
-    for (int r = 0; r < 3; ++r) pb.db[3 * (size_t)l + r] = Di[3 * r] * b[0] + Di[3 * r + 1] * b[1] + Di[3 * r + 2] * b[2];
+    for (int r = 0; r < 3; ++r) db[r] = Di[3 * r] * b[0] + Di[3 * r + 1] * b[1] + Di[3 * r + 2] * b[2];
 }
 
-__global__ __launch_bounds__(256) void k_ba_schur_edges(BaProblemDev pb) {
-    const int k = blockIdx.x * 256 + threadIdx.x;  // index into the list of edges with a free pose
+// One launch: workgroups [0, nbp) store D^-1 and D^-1 b_l per landmark (for the back substitution), the others handle
+// the edges with a free pose: W D^-1 and W (6x3) scattered into the two k-major GEMM operands, W D^-1 b_l.  An edge
+// recomputes its landmark's 3x3 inverse (same arithmetic, same value) instead of waiting for the landmark pass.
+__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int nbp, double lambda) {
+    if ((int)blockIdx.x < nbp) {
+        const int l = blockIdx.x * 256 + threadIdx.x;
+        if (l >= pb.n_points) return;
+        double Di[9], db[3];
+        point_dinv(pb, l, lambda, Di, db);
+        double* o = pb.Dinv + 9 * (size_t)l;
+        for (int i = 0; i < 9; ++i) o[i] = Di[i];
+        for (int r = 0; r < 3; ++r) pb.db[3 * (size_t)l + r] = db[r];
+        return;
+    }
+    const int k = ((int)blockIdx.x - nbp) * 256 + threadIdx.x;  // index into the list of edges with a free pose
     if (k >= pb.n_free_edges) return;
     const int e = pb.pv_edges[k];
     const BaEdge ed = pb.edges[e];
     const int i = pb.pose_var[ed.pose], l = ed.point;
     const double* W = pb.W + 18 * (size_t)e;
-    const double* Di = pb.Dinv + 9 * (size_t)l;
-    const double* db = pb.db + 3 * (size_t)l;
+    double Di[9], db[3];
+    point_dinv(pb, l, lambda, Di, db);
     double* ce = pb.coef_e + 6 * (size_t)e;
     for (int r = 0; r < 6; ++r) {
         ce[r] = W[3 * r] * db[0] + W[3 * r + 1] * db[1] + W[3 * r + 2] * db[2];
@@ -205,12 +261,26 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__
     const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
     v4d acc = {0, 0, 0, 0};
     const int i = lane % 16, kk = lane / 16;
-    for (int k = k0; k < k1; k += 4) {
+    const double* pa = AT + 16 * ti + i;
+    const double* pb_ = BT + 16 * tj + i;
+    int k = k0;
+    for (; k + 16 <= k1; k += 16) {  // four k-steps of operands in flight before the first MFMA: the loop is bound by load latency
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t kr = (size_t)(k + 4 * u + kk) * np_pad;
+            a[u] = pa[kr];
+            b[u] = pb_[kr];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < k1; k += 4) {
         const int kr = k + kk;
         double a = 0, b = 0;
         if (kr < k1) {
-            a = AT[(size_t)kr * np_pad + 16 * ti + i];
-            b = BT[(size_t)kr * np_pad + 16 * tj + i];
+            a = pa[(size_t)kr * np_pad];
+            b = pb_[(size_t)kr * np_pad];
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
     }
@@ -231,7 +301,17 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double
             if (r == c) s += lambda;
         }
         double sub = 0;
-        for (int k = 0; k < n_slices; ++k) sub += pb.S_part[(size_t)k * pb.np_pad * pb.np_pad + (size_t)r * pb.np_pad + c];
+        const double* sp = pb.S_part + (size_t)r * pb.np_pad + c;
+        const size_t step = (size_t)pb.np_pad * pb.np_pad;
+        int k = 0;
+        for (; k + 8 <= n_slices; k += 8) {  // eight partials in flight, added in slice order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(k + u) * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sub += v[u];
+        }
+        for (; k < n_slices; ++k) sub += sp[(size_t)k * step];
         S_out[idx] = s - sub;
     }
     if (idx < np) {
@@ -241,33 +321,38 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double
     }
 }
 
-__global__ __launch_bounds__(256) void k_ba_backsub(BaProblemDev pb, const double* __restrict__ xp, double lambda) {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= pb.n_points) return;
-    double cl[3] = {pb.bl[3 * (size_t)l], pb.bl[3 * (size_t)l + 1], pb.bl[3 * (size_t)l + 2]};
-    for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
-        const int e = pb.pt_edges[k];
-        const int i = pb.pose_var[pb.edges[e].pose];
-        if (i < 0) continue;
-        const double* W = pb.W + 18 * (size_t)e;
-        for (int c = 0; c < 3; ++c) {
-            double s = 0;
-            for (int r = 0; r < 6; ++r) s += W[3 * r + c] * xp[6 * i + r];
-            cl[c] -= s;
+// x_l = D^-1 (b_l - W^T x_p) for four landmarks per workgroup: the three rows of W^T of a landmark are rows 3l..3l+2 of
+// the k-major GEMM operand BT (zeros where the landmark has no edge to a pose), 16 lanes per row, fixed shuffle order.
+__device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, const double* __restrict__ xp, double lambda, double* s_sum) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = block * 4 + wave;
+    const int row = lane >> 4, sub = lane & 15, np = 6 * pb.n_free;
+    double sc = 0;
+    if (l < pb.n_points) {
+        double dot = 0;
+        if (row < 3) {
+            const double* w = pb.BT + (size_t)(3 * l + row) * pb.np_pad;
+            for (int j = sub; j < np; j += 16) dot += w[j] * xp[j];
+        }
+        for (int o = 8; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        const double d0 = __shfl(dot, 0, 64), d1 = __shfl(dot, 16, 64), d2 = __shfl(dot, 32, 64);
+        if (lane == 0) {
+            const double cl[3] = {pb.bl[3 * (size_t)l] - d0, pb.bl[3 * (size_t)l + 1] - d1, pb.bl[3 * (size_t)l + 2] - d2};
+            const double* Di = pb.Dinv + 9 * (size_t)l;
+            for (int r = 0; r < 3; ++r) {
+                const double x = Di[3 * r] * cl[0] + Di[3 * r + 1] * cl[1] + Di[3 * r + 2] * cl[2];
+                pb.points_trial[3 * (size_t)l + r] = pb.points[3 * (size_t)l + r] + x;
+                sc += x * (lambda * x + pb.bl[3 * (size_t)l + r]);
+            }
         }
     }
-    const double* Di = pb.Dinv + 9 * (size_t)l;
-    double sc = 0;
-    for (int r = 0; r < 3; ++r) {
-        const double x = Di[3 * r] * cl[0] + Di[3 * r + 1] * cl[1] + Di[3 * r + 2] * cl[2];
-        pb.points_trial[3 * (size_t)l + r] = pb.points[3 * (size_t)l + r] + x;
-        sc += x * (lambda * x + pb.bl[3 * (size_t)l + r]);
-    }
-    pb.scale_l[l] = sc;
+    block_sum_256(sc, s_sum, pb.scale_part + block);  // landmark part of computeScale, per workgroup
 }
 
-__global__ void k_ba_update_poses(BaProblemDev pb, const double* __restrict__ xp) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// One launch: workgroups [0, nbp) back-substitute the landmarks, the rest move the poses (exp(x_p) * T)
+__global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nbp, const double* __restrict__ xp, double lambda) {
+    __shared__ double s_sum[256];
+    if ((int)blockIdx.x < nbp) { backsub_body(pb, blockIdx.x, xp, lambda, s_sum); return; }
+    const int k = ((int)blockIdx.x - nbp) * 256 + threadIdx.x;
     if (k >= pb.n_poses) return;
     const int i = pb.pose_var[k];
     if (i < 0) { pb.poses_trial[k] = pb.poses[k]; return; }
@@ -276,18 +361,29 @@ __global__ void k_ba_update_poses(BaProblemDev pb, const double* __restrict__ xp
     pb.poses_trial[k] = se3_exp_mul(u, pb.poses[k]);
 }
 
+// [0] landmark part of the gain-ratio scale, [1] robust cost of the trial estimate
+__global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double* __restrict__ scale_out, double* __restrict__ chi_out) {
+    __shared__ double s[256];
+    if (blockIdx.x == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + 3) / 4, s, scale_out);
+    else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
+}
+
 __global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb, const Se3* __restrict__ poses, const double* __restrict__ points) {
+    __shared__ double s_sum[256];
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= pb.n_edges) return;
-    const BaEdge ed = pb.edges[e];
-    double p[3], err[3], c2;
-    int dim;
-    edge_state(poses, points, ed, pb.cam, p, err, dim, c2);
-    const bool stereo = ed.ur >= 0;
-    double rho0, rho1;
-    huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
-    pb.chi2[e] = c2;
-    pb.rho0[e] = rho0;
+    double rho0 = 0;
+    if (e < pb.n_edges) {
+        const BaEdge ed = pb.edges[e];
+        double p[3], err[3], c2;
+        int dim;
+        edge_state(poses, points, ed, pb.cam, p, err, dim, c2);
+        const bool stereo = ed.ur >= 0;
+        double rho1;
+        huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
+        pb.chi2[e] = c2;
+        pb.rho0[e] = rho0;
+    }
+    block_sum_256(rho0, s_sum, pb.chi_part + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __restrict__ depth_pos) {
@@ -302,19 +398,17 @@ __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __re
 // ---- launch wrappers ----------------------------------------------------------------------------------------------
 static inline int blocks(int n) { return (n + 255) / 256; }
 
-void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, hipStream_t st) {
+void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st) {
+    const int nbp = blocks(pb.n_points);
     hipLaunchKernelGGL(k_ba_linearize, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
-    hipLaunchKernelGGL(k_ba_reduce_points, dim3(blocks(pb.n_points)), dim3(256), 0, st, pb);
-    if (pb.n_free) hipLaunchKernelGGL(k_ba_reduce_poses, dim3(pb.n_free), dim3(256), 0, st, pb);
-    hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, st, pb.rho0, pb.n_edges, chi_out);
-    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(1024), 0, st, pb.diag_l, pb.n_points, maxdiag_out);
-    hipLaunchKernelGGL(k_reduce<true>, dim3(1), dim3(1024), 0, st, pb.diag_p, pb.n_free, maxdiag_out + 1);
+    hipLaunchKernelGGL(k_ba_reduce_all, dim3(nbp + pb.n_free + 1), dim3(256), 0, st, pb, nbp, chi_out);
+    if (want_maxdiag) hipLaunchKernelGGL(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_ba_schur_points, dim3(blocks(pb.n_points)), dim3(256), 0, st, pb, lambda);
+    const int nbp = blocks(pb.n_points);
+    hipLaunchKernelGGL(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_free_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
     if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
-        if (pb.n_free_edges) hipLaunchKernelGGL(k_ba_schur_edges, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
         hipLaunchKernelGGL(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
         const int tiles = pb.np_pad / 16;
         hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points,
@@ -325,11 +419,10 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_
 }
 
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_ba_backsub, dim3(blocks(pb.n_points)), dim3(256), 0, st, pb, xp, lambda);
-    hipLaunchKernelGGL(k_ba_update_poses, dim3((pb.n_poses + 63) / 64), dim3(64), 0, st, pb, xp);
+    const int nbp = (pb.n_points + 3) / 4;  // four landmarks per workgroup
+    hipLaunchKernelGGL(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
     hipLaunchKernelGGL(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, pb.poses_trial, pb.points_trial);
-    hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, st, pb.scale_l, pb.n_points, scale_out);
-    hipLaunchKernelGGL(k_reduce<false>, dim3(1), dim3(1024), 0, st, pb.rho0, pb.n_edges, chi_out);
+    hipLaunchKernelGGL(k_ba_trial_reduce, dim3(2), dim3(256), 0, st, pb, scale_out, chi_out);
 }
 
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st) {

@@ -19,18 +19,18 @@ struct BalmDev {
     LidarPose* twl;                // [W]
     double* plane_res;             // [n_planes]
     double* part;                  // [n_chunks][balm_part_stride(W)]
-    double* out;                   // [2 + 6W + (6W)^2]: residual (residual kernels), JacT, Hessian (row-major), residual (Hessian kernels)
+    double* out;                   // [2 + 6W + (6W)^2 + 12W]: residual (residual kernels), JacT, Hessian (row-major), residual (Hessian
+                                   // kernels), the LiDAR poses the derivatives were taken at
 };
 
 inline int balm_items(int W) { return W * (W + 1) / 2 * 36; }
 inline int balm_part_stride(int W) { return balm_items(W) + 6 * W + 1; }
-inline int balm_out_size(int W) { return 2 + 6 * W + 36 * W * W; }
+inline int balm_out_size(int W) { return 2 + 6 * W + 36 * W * W + 12 * W; }
 
-// twl[i] = LiDAR pose of window slot i from the vertex estimates `poses` (LidarCovisRes::UpdatePose)
-void balm_launch_poses(const BalmDev& b, const Se3* poses, hipStream_t st);
-// out[0] = sum over planes of coe * lambda_min at the poses in b.twl (VOX_HESS::evaluate_only_residual)
-void balm_launch_residual(const BalmDev& b, hipStream_t st);
-// out = residual, JacT and Hessian with respect to the LiDAR poses (BALM2::divide_thread / VOX_HESS::acc_evaluate2)
-void balm_launch_hessian(const BalmDev& b, hipStream_t st);
+// out[0] = sum over planes of coe * lambda_min at the window poses derived from the vertex estimates `poses`
+// (LidarCovisRes::UpdatePose + VOX_HESS::evaluate_only_residual)
+void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st);
+// out = JacT, Hessian with respect to the LiDAR poses (BALM2::divide_thread / VOX_HESS::acc_evaluate2) and those poses
+void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st);
 
 }  // namespace tc2li

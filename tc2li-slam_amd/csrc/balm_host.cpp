@@ -341,8 +341,7 @@ int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window*
 
 void BalmTerm::enqueue_error(const Se3* d_poses, hipStream_t st) {
     if (!n_planes) return;
-    balm_launch_poses(dev, d_poses, st);
-    balm_launch_residual(dev, st);
+    balm_launch_residual(dev, d_poses, st);
 }
 
 void BalmTerm::finish_error() {
@@ -355,10 +354,8 @@ void BalmTerm::finish_error() {
 
 int BalmTerm::enqueue_linearization(const Se3* d_poses, hipStream_t st) {
     if (!n_planes) return 0;
-    balm_launch_poses(dev, d_poses, st);
-    balm_launch_hessian(dev, st);
+    balm_launch_hessian(dev, d_poses, st);
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(h_twl.p, d_twl.p, W * sizeof(LidarPose), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -373,7 +370,7 @@ void BalmTerm::finish_linearization() {
     const int n = 6 * W;
     memcpy(JacT.data(), h_out.p + 1, n * sizeof(double));
     memcpy(Hessian.data(), h_out.p + 1 + n, (size_t)n * n * sizeof(double));
-    balm_to_camera_se3(h_twl.p, W, Tcl, JacT.data(), Hessian.data());
+    balm_to_camera_se3(reinterpret_cast<const LidarPose*>(h_out.p + 2 + n + (size_t)n * n), W, Tcl, JacT.data(), Hessian.data());
 }
 
 int BalmTerm::compute_error(const Se3* d_poses, hipStream_t st) {

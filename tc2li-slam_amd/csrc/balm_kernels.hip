@@ -3,7 +3,7 @@
 //   VOX_HESS::evaluate_only_residual   SF/include/bavoxel.h:276-315   -> k_balm_residual
 //   VOX_HESS::acc_evaluate2            SF/include/bavoxel.h:80-196    -> k_balm_hessian
 //   BALM2::divide_thread               SF/include/bavoxel.h:778-817   -> chunks of planes + k_balm_combine (fixed order)
-//   LidarCovisRes::UpdatePose          SF/src/LidarRes.cc:221-235     -> k_balm_poses
+//   LidarCovisRes::UpdatePose          SF/src/LidarRes.cc:221-235     -> window_poses (inside every kernel)
 // Layout: one workgroup owns a contiguous chunk of planes; every thread owns up to 8 entries of the upper block triangle
 // of the (6W)^2 Hessian in registers (entry = (block pair, row, column)), so no atomics and a fixed summation order.
 #include <hip/hip_runtime.h>
@@ -17,10 +17,10 @@ namespace tc2li {
 constexpr int kHessThreads = 1024, kItemsPerThread = 8;
 static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsPerThread, "window too large for the item ownership");
 
-__global__ void k_balm_poses(BalmDev b, const Se3* __restrict__ poses) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.W) return;
-    b.twl[i] = lidar_pose_from(se3f_from_vertex(poses[b.pose_index[i]]), b.Tcl);
+// LiDAR poses of the window slots from the vertex estimates (LidarCovisRes::UpdatePose), into LDS of the calling workgroup
+__device__ __forceinline__ void window_poses(const BalmDev& b, const Se3* __restrict__ poses, LidarPose* s_twl) {
+    if ((int)threadIdx.x < b.W) s_twl[threadIdx.x] = lidar_pose_from(se3f_from_vertex(poses[b.pose_index[threadIdx.x]]), b.Tcl);
+    __syncthreads();
 }
 
 // merged window cluster of one plane -> covariance -> eigen decomposition
@@ -42,15 +42,13 @@ __device__ __forceinline__ void plane_eigen(const ClusterW* cw, int W, double& N
     eig_sym3(C, lambda, U);
 }
 
-__global__ __launch_bounds__(64) void k_balm_residual(BalmDev b) {
-    const int a = blockIdx.x * 64 + threadIdx.x;
-    if (a >= b.n_planes) return;
+__device__ __forceinline__ double plane_residual(const BalmDev& b, const LidarPose* twl, int a) {
     double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0}, n = 0;
     for (int i = 0; i < b.W; ++i) {
         const PlaneCluster s = b.clusters[(size_t)a * b.W + i];
         if (s.n == 0) continue;
         ClusterW t;
-        cluster_transform(s, b.twl[i], t);
+        cluster_transform(s, twl[i], t);
         for (int k = 0; k < 9; ++k) P[k] += t.P[k];
         for (int k = 0; k < 3; ++k) v[k] += t.v[k];
         n += t.n;
@@ -61,30 +59,53 @@ __global__ __launch_bounds__(64) void k_balm_residual(BalmDev b) {
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vb[r] * vb[c];
     eig_sym3(C, lambda, U);
-    b.plane_res[a] = b.coe[a] * lambda[0];
+    return b.coe[a] * lambda[0];
 }
 
-// out[0] = in[0] + in[1] + ... in a fixed tree order
-__global__ __launch_bounds__(1024) void k_balm_sum(const double* __restrict__ in, int n, double* __restrict__ out) {
-    __shared__ double s[1024];
+// out[0] = in[0] + in[1] + ... in a fixed order (256 threads: strided partial sums, then a tree)
+__device__ __forceinline__ void sum_fixed_256(const double* __restrict__ in, int n, double* s, double* __restrict__ out) {
     double a = 0;
-    for (int k = threadIdx.x; k < n; k += 1024) a += in[k];
+    for (int k = threadIdx.x; k < n; k += 256) a += in[k];
     s[threadIdx.x] = a;
     __syncthreads();
-    for (int st = 512; st >= 1; st >>= 1) {
+    for (int st = 128; st >= 1; st >>= 1) {
         if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b) {
+// VOX_HESS::evaluate_only_residual in one launch when the planes fit one workgroup's loop: poses, per-plane terms, sum
+__global__ __launch_bounds__(256) void k_balm_residual_total(BalmDev b, const Se3* __restrict__ poses) {
+    __shared__ LidarPose s_twl[kMaxLidarWindow];
+    __shared__ double s[256];
+    window_poses(b, poses, s_twl);
+    for (int a = threadIdx.x; a < b.n_planes; a += 256) b.plane_res[a] = plane_residual(b, s_twl, a);
+    __syncthreads();
+    sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
+}
+// many planes: one thread per plane over the whole grid, then the same fixed-order sum
+__global__ __launch_bounds__(256) void k_balm_residual_planes(BalmDev b, const Se3* __restrict__ poses) {
+    __shared__ LidarPose s_twl[kMaxLidarWindow];
+    window_poses(b, poses, s_twl);
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < b.n_planes) b.plane_res[a] = plane_residual(b, s_twl, a);
+}
+__global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
+    __shared__ double s[256];
+    sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
+}
+
+__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) {
+    __shared__ LidarPose s_twl[kMaxLidarWindow];
     __shared__ ClusterW s_cw[kMaxLidarWindow];
     __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
     __shared__ double s_w[kMaxLidarWindow][3], s_E[kMaxLidarWindow][9], s_k1[kMaxLidarWindow], s_k2[kMaxLidarWindow], s_n[kMaxLidarWindow];
     __shared__ double s_uk[3], s_ukuk[9], s_umum[9], s_vbar[3], s_NN, s_l0;
     __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
+    window_poses(b, poses, s_twl);
+    if (blockIdx.x == 0 && tid < W) b.twl[tid] = s_twl[tid];  // for the change of variables on the host
     if (tid == 0) {
         int p = 0;
         for (int i = 0; i < W; ++i)
@@ -101,7 +122,7 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b) {
         if (tid < W) {
             mine = b.clusters[(size_t)a * W + tid];
             s_n[tid] = mine.n;
-            if (mine.n != 0) cluster_transform(mine, b.twl[tid], s_cw[tid]);
+            if (mine.n != 0) cluster_transform(mine, s_twl[tid], s_cw[tid]);
             else s_cw[tid].n = 0;
         }
         __syncthreads();
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b) {
         const double NN = s_NN;
         if (tid == 0) res += coe * s_l0;
         if (tid < W && mine.n != 0) {
-            const LidarPose T = b.twl[tid];
+            const LidarPose T = s_twl[tid];
             const double ni = mine.n;
             double Pi[9], uk[3] = {s_uk[0], s_uk[1], s_uk[2]};
             sym_unpack(mine.P, Pi);
@@ -215,13 +236,18 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b) {
     if (tid == 0) part[n_items + 6 * W] = res;
 }
 
-// chunk partials -> out (residual, JacT, full Hessian with the lower block triangle mirrored), chunks added in order
+// chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one
+// wavefront per output value, its lanes add the chunks in a fixed order (strided partial sums, then shuffles).
 __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
     const int W = b.W, n = 6 * W, n_items = W * (W + 1) / 2 * 36, stride = n_items + n + 1;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, idx = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 12 * W) b.out[2 + n + n * n + t] = reinterpret_cast<const double*>(b.twl)[t];  // the poses the derivatives refer to
     if (idx >= stride) return;
     double s = 0;
-    for (int k = 0; k < b.n_chunks; ++k) s += b.part[(size_t)k * stride + idx];
+    for (int k = lane; k < b.n_chunks; k += 64) s += b.part[(size_t)k * stride + idx];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane != 0) return;
     if (idx == n_items + n) { b.out[1 + n + n * n] = s; return; }  // out[0] belongs to the residual-only kernels
     if (idx >= n_items) { b.out[1 + (idx - n_items)] = s; return; }
     const int pair = idx / 36, rc = idx % 36, r = rc / 6, c = rc % 6;
@@ -233,18 +259,18 @@ __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
     if (i != j) H[(size_t)(6 * j + c) * n + 6 * i + r] = s;
 }
 
-void balm_launch_poses(const BalmDev& b, const Se3* poses, hipStream_t st) {
-    hipLaunchKernelGGL(k_balm_poses, dim3(1), dim3(64), 0, st, b, poses);
+void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
+    if (b.n_planes <= 2048) {
+        hipLaunchKernelGGL(k_balm_residual_total, dim3(1), dim3(256), 0, st, b, poses);
+    } else {
+        hipLaunchKernelGGL(k_balm_residual_planes, dim3((b.n_planes + 255) / 256), dim3(256), 0, st, b, poses);
+        hipLaunchKernelGGL(k_balm_sum, dim3(1), dim3(256), 0, st, b);
+    }
 }
 
-void balm_launch_residual(const BalmDev& b, hipStream_t st) {
-    hipLaunchKernelGGL(k_balm_residual, dim3((b.n_planes + 63) / 64), dim3(64), 0, st, b);
-    hipLaunchKernelGGL(k_balm_sum, dim3(1), dim3(1024), 0, st, b.plane_res, b.n_planes, b.out);
-}
-
-void balm_launch_hessian(const BalmDev& b, hipStream_t st) {
-    hipLaunchKernelGGL(k_balm_hessian, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b);
-    hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 255) / 256), dim3(256), 0, st, b);
+void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
+    hipLaunchKernelGGL(k_balm_hessian, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
 }
 
 }  // namespace tc2li
