@@ -4,6 +4,8 @@
 // the pose-only optimisation kernel; this file only sequences them and does the per-frame bookkeeping the reference
 // does between them (edge construction of Optimizer::PoseOptimization :858-990, outlier discarding :2798-2822).
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -30,6 +32,9 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream_;
+    static const bool kTiming = getenv("TC2LI_TRACK_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm[6] = {0, 0, 0, 0, 0, 0}, t0 = now();
     const int L = o->prm.nlevels;
     const float cam4[4] = {(float)cam->fx, (float)cam->fy, (float)cam->cx, (float)cam->cy};
     const float bf = (float)cam->bf;
@@ -61,8 +66,10 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     };
     global_pool().parallel_for(n_frames, [&](int f) { build_queries(f, th); });
     for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
+    tm[0] = now() - t0; t0 = now();
     int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 0, 0.9f, true, match.data(), n_matches, st);
     if (r < 0) return r;
+    tm[1] = now() - t0; t0 = now();
     // fewer than 20 matches: wider window (Tracking.cc:2774-2783)
     std::vector<int> retry;
     for (int f = 0; f < n_frames; ++f) if (n_matches[f] < 20) retry.push_back(f);
@@ -105,14 +112,17 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
             ++e;
         }
     });
+    tm[2] = now() - t0; t0 = now();
     std::vector<int32_t> inl(n_frames, 0);
     r = tc2li_pose_optimization_batch(n_frames, poses7, edge_off.data(), Xw.data(), edges.data(), cam, outlier.data(), inl.data(), stream_);
     if (r < 0) return r;
+    tm[3] = now() - t0; t0 = now();
     for (int f = 0; f < n_frames; ++f) {
         if (n_matches[f] < 20) { n_inliers[f] = -1; for (int c = 0; c < 7; ++c) poses7[7 * f + c] = (double)pose_pred7[7 * f + c]; continue; }
         n_inliers[f] = inl[f];
         int32_t* mp = map_point_of_keypoint + (size_t)f * capacity;
         for (int e = edge_off[f]; e < edge_off[f + 1]; ++e) if (outlier[e]) mp[edge_kp[e]] = -1;  // Tracking.cc:2804-2818
     }
+    if (kTiming) fprintf(stderr, "track timing ms: queries %.3f search %.3f edges %.3f pose-opt %.3f finish %.3f\n", tm[0], tm[1], tm[2], tm[3], now() - t0);
     return n_frames;
 }
