@@ -247,8 +247,18 @@ def main():
     dom = max(single, key=lambda k: kern_ms[k])  # the kernel with the largest device time per step
     bytes_per_launch = alg[dom] * units[dom] / launches[dom]
     achieved = bytes_per_launch / (kern_ms[dom] / launches[dom] * 1e-3) / 1e9
+    # HBM traffic of that kernel from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE per launch, see
+    # tools/summarize_profile.py); the counters cannot be read inside this process, so the committed summary is used
+    traffic = None
+    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        pmc = json.load(open(f))
+        hit = [v for k, v in pmc.items() if k.split("::")[-1] == names[dom]]
+        if hit and hit[0].get("hbm_bytes_per_launch"):
+            traffic = {"bytes_per_launch": int(hit[0]["hbm_bytes_per_launch"]), "source": os.path.basename(f),
+                       "note": "measured at the batch size of that profile run"}
+            break
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None, "avg_launch_ms": round(kern_ms[dom] / launches[dom], 5),
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(kern_ms[dom] / launches[dom], 5),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "all_kernels_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                 "all_kernels_GBps": {k: round(alg[k] * units[k] / (kern_ms[k] * 1e-3) / 1e9, 2) for k in kern_ms if kern_ms[k] > 0}}

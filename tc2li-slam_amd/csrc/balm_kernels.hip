@@ -4,7 +4,7 @@
 //   VOX_HESS::acc_evaluate2            SF/include/bavoxel.h:80-196    -> k_balm_hessian
 //   BALM2::divide_thread               SF/include/bavoxel.h:778-817   -> chunks of planes + k_balm_combine (fixed order)
 //   LidarCovisRes::UpdatePose          SF/src/LidarRes.cc:221-235     -> window_poses (inside every kernel)
-// Layout: one workgroup owns a contiguous chunk of planes; every thread owns up to 8 entries of the upper block triangle
+// Layout: one workgroup owns a contiguous chunk of planes; every thread owns a few entries of the upper block triangle
 // of the (6W)^2 Hessian in registers (entry = (block pair, row, column)), so no atomics and a fixed summation order.
 #include <hip/hip_runtime.h>
 #pragma clang fp contract(off)
@@ -14,8 +14,12 @@
 
 namespace tc2li {
 
-constexpr int kHessThreads = 1024, kItemsPerThread = 8;
-static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsPerThread, "window too large for the item ownership");
+// 256 threads per workgroup: the per-slot algebra needs well over 128 registers (1024-thread workgroups cap a thread at
+// 128 and spilled 512 B per lane to scratch: 67 MB of scratch writes per launch in the first profile).
+constexpr int kHessThreads = 256;
+constexpr int kItemsSmall = 4, kItemsLarge = 30;  // Hessian entries owned per thread: windows of <= 7 / <= 20 keyframes
+static_assert(7 * 8 / 2 * 36 <= kHessThreads * kItemsSmall, "small window does not fit");
+static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsLarge, "window too large for the item ownership");
 
 // LiDAR poses of the window slots from the vertex estimates (LidarCovisRes::UpdatePose), into LDS of the calling workgroup
 __device__ __forceinline__ void window_poses(const BalmDev& b, const Se3* __restrict__ poses, LidarPose* s_twl) {
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
     sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
 }
 
+template <int kItemsPerThread>
 __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
     __shared__ ClusterW s_cw[kMaxLidarWindow];
@@ -269,7 +274,8 @@ void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
 }
 
 void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
-    hipLaunchKernelGGL(k_balm_hessian, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    if (b.W <= 7) hipLaunchKernelGGL(k_balm_hessian<kItemsSmall>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    else hipLaunchKernelGGL(k_balm_hessian<kItemsLarge>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
     hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
 }
 

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace + stats of the default bench command, then the HBM counters of the same
+# command in two separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no trace domains next to --pmc).
+# Usage (from the repo root, through gpurun): bash tools/profile_round.sh r01
+set -e
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ARGS="bench.py --no-cpu-baseline --steps 8 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ARGS > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $ARGS > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $ARGS > $OUT/bench_write.log 2>&1
+python tools/summarize_profile.py $OUT $TAG
