@@ -90,14 +90,16 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
 #pragma unroll
                     for (int c = r; c < 6; ++c) {
                         double s = 0;
-                        for (int d = 0; d < dim; ++d) s += B[6 * d + r] * w * B[6 * d + c];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * B[6 * d + c];  // rows beyond dim are zero
                         acc[h++] += s;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 6; ++r) {
                     double s = 0;
-                    for (int d = 0; d < dim; ++d) s += B[6 * d + r] * (e.info * err[d]);
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * (e.info * err[d]);  // err[2] = 0 for a monocular edge
                     acc[21 + r] -= rho1 * s;
                 }
                 acc[27] += rho0;
