@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
                                                     int* __restrict__ cell_counts, int ncells) {
     __shared__ uint8_t tile[kFastTileH * kFastTilePitch];
     __shared__ uint8_t score[kFastTileH * kFastTilePitch];
+    __shared__ uint16_t s_list[kFastTileH * kFastTilePitch];  // tile offset | polarity << 14 of the pixels passing the segment test
     __shared__ int s_wave[4];
-    __shared__ int s_cnt_ini;
+    __shared__ int s_cnt_ini, s_nlist;
 
     const int tid = threadIdx.x, img = blockIdx.y;
     const FastCell c = cells[blockIdx.x];
@@ -109,10 +110,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         tile[i] = x < w ? src[(size_t)y * L.pitch + x] : 0;
         score[i] = 0;
     }
-    if (tid == 0) s_cnt_ini = 0;
+    if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; }
     __syncthreads();
 
     const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
+    // Pass 1, every pixel: the cheap segment test at the lower threshold (two 16-bit masks, "9 contiguous" by shifts).
+    // Only a few percent of the pixels pass, but almost every wavefront holds one, so the exact contrast is not computed
+    // here: the survivors are appended to a list (any order: each writes its own score cell).
     for (int i = tid; i < npix; i += 256) {
         const int ey = i / ew, ex = i - ey * ew;
         const uint8_t* t = tile + (ey + 3) * kFastTilePitch + (ex + 3);
@@ -130,9 +134,29 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
             mb |= (uint32_t)(p[k] > v + min_th) << k;
             md |= (uint32_t)(p[k] < v - min_th) << k;
         }
+        const uint32_t pol = (has_arc9(md) ? 1u : 0u) | (has_arc9(mb) ? 2u : 0u);  // bit 0: darker arc, bit 1: brighter arc
+        if (pol) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(((ey + 3) * kFastTilePitch + (ex + 3)) | (pol << 14));
+    }
+    __syncthreads();
+    // Pass 2, survivors only, packed densely over the lanes: S = the largest arc contrast of the polarity that has an arc
+    // (the other polarity cannot exceed the threshold, so it cannot be the maximum).
+    const int nlist = s_nlist;
+    for (int k = tid; k < nlist; k += 256) {
+        const uint32_t e = s_list[k];
+        const int at = e & 0x3fff;
+        const uint8_t* t = tile + at;
+        const int v = t[0];
+        int p[16];
+        p[0] = t[3 * kFastTilePitch];          p[1] = t[3 * kFastTilePitch + 1];   p[2] = t[2 * kFastTilePitch + 2];
+        p[3] = t[kFastTilePitch + 3];          p[4] = t[3];                        p[5] = t[-kFastTilePitch + 3];
+        p[6] = t[-2 * kFastTilePitch + 2];     p[7] = t[-3 * kFastTilePitch + 1];  p[8] = t[-3 * kFastTilePitch];
+        p[9] = t[-3 * kFastTilePitch - 1];     p[10] = t[-2 * kFastTilePitch - 2]; p[11] = t[-kFastTilePitch - 3];
+        p[12] = t[-3];                         p[13] = t[kFastTilePitch - 3];      p[14] = t[2 * kFastTilePitch - 2];
+        p[15] = t[3 * kFastTilePitch - 1];
         int S = 0;
-        if (has_arc9(mb) || has_arc9(md)) S = max(arc_contrast<true>(p, v), arc_contrast<false>(p, v));
-        score[(ey + 3) * kFastTilePitch + (ex + 3)] = (uint8_t)S;
+        if (e & 0x4000) S = arc_contrast<true>(p, v);
+        if (e & 0x8000) S = max(S, arc_contrast<false>(p, v));
+        score[at] = (uint8_t)S;
     }
     __syncthreads();
 
