@@ -71,6 +71,14 @@ __device__ __forceinline__ bool has_arc9(uint32_t m16) {
     return (r & 0xffffu) != 0;
 }
 
+// i / n for 0 <= i < 2^16, 1 <= n < 256: the float quotient is off by less than one unit, one correction step makes it exact
+__device__ __forceinline__ int row_of(int i, int n, float inv_n) {
+    int q = (int)((float)i * inv_n);
+    q -= q * n > i ? 1 : 0;
+    q += (q + 1) * n <= i ? 1 : 0;
+    return q;
+}
+
 template <bool DARK>
 __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
     // max over the 16 arcs of 9 contiguous circle pixels of min(v - p) (DARK) or min(p - v)
@@ -105,20 +113,36 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
     const int w = c.w, h = c.h;
 
-    for (int i = tid; i < h * kFastTilePitch; i += 256) {
-        const int y = i / kFastTilePitch, x = i - y * kFastTilePitch;
-        tile[i] = x < w ? src[(size_t)y * L.pitch + x] : 0;
-        score[i] = 0;
+    // window rows as aligned dwords (a row of the window starts at any byte address: level 0 is the caller's image)
+    {
+        constexpr int kDw = kFastTilePitch / 4 + 1;  // dwords that can cover one row of the window
+        uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
+        for (int i = tid; i < h * kDw; i += 256) {
+            const int y = i / kDw, j = i - y * kDw;
+            const uint8_t* row = src + (size_t)y * L.pitch;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(row) & 3);
+            if (4 * j - mis < w) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(row - mis + 4 * j);
+                uint8_t* d = tile + y * kFastTilePitch;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int x = 4 * j + b - mis;
+                    if (x >= 0 && x < w) d[x] = (uint8_t)(v >> (8 * b));
+                }
+            }
+        }
+        for (int i = tid; i < h * (kFastTilePitch / 4); i += 256) score32[i] = 0;
     }
     if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; }
     __syncthreads();
 
     const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
+    const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
     // Pass 1, every pixel: the cheap segment test at the lower threshold (two 16-bit masks, "9 contiguous" by shifts).
     // Only a few percent of the pixels pass, but almost every wavefront holds one, so the exact contrast is not computed
     // here: the survivors are appended to a list (any order: each writes its own score cell).
     for (int i = tid; i < npix; i += 256) {
-        const int ey = i / ew, ex = i - ey * ew;
+        const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
         const uint8_t* t = tile + (ey + 3) * kFastTilePitch + (ex + 3);
         const int v = t[0];
         int p[16];
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     // non-max suppression flags for both thresholds (bit0: iniTh, bit1: minTh); tile[] is reused for flags
     int my_ini = 0;
     for (int i = tid; i < npix; i += 256) {
-        const int ey = i / ew, ex = i - ey * ew;
+        const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
         const uint8_t* s = score + (ey + 3) * kFastTilePitch + (ex + 3);
         const int S = s[0];
         int flags = 0;
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         for (int k = 0; k < wave; ++k) off += s_wave[k];
         const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         if (f) {
-            const int ey = i / ew, ex = i - ey * ew;
+            const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
             const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
             const uint32_t sc = score[(ey + 3) * kFastTilePitch + (ex + 3)] - 1;
             // candidate coordinates in the border-free frame of the level (SF/src/ORBextractor.cc:833-838)
