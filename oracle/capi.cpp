@@ -8,6 +8,7 @@
 #include "lidar.hpp"
 #include "ba.hpp"
 #include "imu.hpp"
+#include "inertial_ba.hpp"
 #include "matcher.hpp"
 
 using namespace oracle;
@@ -760,5 +761,78 @@ int oracle_imu_predict(const ImuSamplePOD* samples, int n, double t_prev, double
     return steps;
 }
 void oracle_normalize_rotation(const float* R, float* out) { NormalizeRotation(R, out); }
+
+// ---- visual-inertial local BA -----------------------------------------------------------------------------------------------
+// kf33: Rcw 9, tcw 3, Rwb 9, twb 3, v 3, bg 3, ba 3 per keyframe (in/out); calib24: Rcb 9, tcb 3, Rbc 9, tbc 3;
+// links: link4 = kf1, kf2, robust, info_scale (doubles); pre = per link the 292 floats of oracle_imu_preintegrate + 6 bias floats
+static InertialKeyFrame kf_from(const double* s, uint8_t fixed, uint8_t has_imu) {
+    InertialKeyFrame k;
+    std::memcpy(k.Rcw, s, 72); std::memcpy(k.tcw, s + 9, 24); std::memcpy(k.Rwb, s + 12, 72); std::memcpy(k.twb, s + 21, 24);
+    std::memcpy(k.v, s + 24, 24); std::memcpy(k.bg, s + 27, 24); std::memcpy(k.ba, s + 30, 24);
+    k.fixed = fixed; k.has_imu = has_imu;
+    return k;
+}
+static void kf_to(const InertialKeyFrame& k, double* s) {
+    std::memcpy(s, k.Rcw, 72); std::memcpy(s + 9, k.tcw, 24); std::memcpy(s + 12, k.Rwb, 72); std::memcpy(s + 21, k.twb, 24);
+    std::memcpy(s + 24, k.v, 24); std::memcpy(s + 27, k.bg, 24); std::memcpy(s + 30, k.ba, 24);
+}
+static Preintegrated preint_from(const float* f298) {
+    ImuBias b{f298[292], f298[293], f298[294], f298[295], f298[296], f298[297]};
+    Preintegrated p(b, 0, 0, 0, 0);
+    const float* o = f298;
+    p.dT = *o++;
+    auto get = [&](float* dst, int k) { std::memcpy(dst, o, k * sizeof(float)); o += k; };
+    get(p.dR, 9); get(p.dV, 3); get(p.dP, 3); get(p.JRg, 9); get(p.JVg, 9); get(p.JVa, 9); get(p.JPg, 9); get(p.JPa, 9); get(p.avgA, 3);
+    get(p.avgW, 3); get(p.C, 225);
+    return p;
+}
+static ImuCalibD calib_from(const double* c) {
+    ImuCalibD k;
+    std::memcpy(k.Rcb, c, 72); std::memcpy(k.tcb, c + 9, 24); std::memcpy(k.Rbc, c + 12, 72); std::memcpy(k.tbc, c + 21, 24);
+    return k;
+}
+int oracle_local_inertial_ba(double* kf33, const uint8_t* fixed, const uint8_t* has_imu, int n_kf, const double* calib24, double* points3,
+                             int n_points, const double* edges6, int n_edges, const double* link4, const float* pre298, int n_links,
+                             const double* cam5, int iterations, double lambda_init, double* chi2_out, uint8_t* depth_pos, double* err2,
+                             double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap) {
+    std::vector<InertialKeyFrame> kfs(n_kf);
+    for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, fixed[k], has_imu[k]);
+    std::vector<Preintegrated> pre;
+    pre.reserve(n_links);
+    std::vector<InertialLink> links(n_links);
+    for (int l = 0; l < n_links; ++l) pre.push_back(preint_from(pre298 + 298 * (size_t)l));
+    for (int l = 0; l < n_links; ++l) {
+        links[l].kf1 = (int)link4[4 * l]; links[l].kf2 = (int)link4[4 * l + 1]; links[l].robust = link4[4 * l + 2] != 0; links[l].info_scale = link4[4 * l + 3];
+        links[l].pint = &pre[l];
+    }
+    std::vector<double> pts(points3, points3 + 3 * (size_t)n_points);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    InertialBAResult r = LocalInertialBA(kfs, calib_from(calib24), pts, edges_from(edges6, n_edges), links, cam, iterations, lambda_init);
+    for (int k = 0; k < n_kf; ++k) kf_to(kfs[k], kf33 + 33 * k);
+    std::memcpy(points3, pts.data(), pts.size() * sizeof(double));
+    for (int e = 0; e < n_edges; ++e) { if (chi2_out) chi2_out[e] = r.chi2[e]; if (depth_pos) depth_pos[e] = r.depth_pos[e]; }
+    if (err2) { err2[0] = r.err; err2[1] = r.err_end; }
+    const int m = std::min((int)r.trace.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
+    return r.iterations;
+}
+// one inertial edge: error (9) and Jacobians (9 x 24) at the two keyframe states
+void oracle_inertial_edge(const double* kf33_1, const double* kf33_2, const float* pre298, double* err9, double* J216) {
+    const InertialKeyFrame k1 = kf_from(kf33_1, 0, 1), k2 = kf_from(kf33_2, 0, 1);
+    const Preintegrated p = preint_from(pre298);
+    inertial_edge(k1, k2, p, err9, J216);
+}
+// one visual edge in the ImuCamPose parameterisation: returns dim
+int oracle_inertial_visual_edge(const double* kf33, const double* calib24, const double* X, const double* edge6, const double* cam5, double* err3,
+                                double* A9, double* B18) {
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    return inertial_visual_edge(kf_from(kf33, 0, 1), calib_from(calib24), X, edges_from(edge6, 1)[0], cam, err3, A9, B18);
+}
+// ImuCamPose::Update applied to a keyframe state (its counter in/out)
+void oracle_imu_pose_update(double* kf33, int* its, const double* calib24, const double* u6) {
+    InertialKeyFrame k = kf_from(kf33, 0, 1);
+    imu_pose_update(k, *its, calib_from(calib24), u6);
+    kf_to(k, kf33);
+}
 
 }  // extern "C"

@@ -1,0 +1,497 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle, never linked into or called from the product path.  See inertial_ba.hpp.
+#include "inertial_ba.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace oracle {
+
+namespace {
+
+// ---- 3x3 algebra (row-major) ---------------------------------------------------------------------------------------------
+void mul(const double* a, const double* b, double* o) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c]; }
+void mulv(const double* a, const double* v, double* o) { for (int r = 0; r < 3; ++r) o[r] = a[3 * r] * v[0] + a[3 * r + 1] * v[1] + a[3 * r + 2] * v[2]; }
+void tr(const double* a, double* o) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[3 * r + c] = a[3 * c + r]; }
+void hat(const double* v, double* o) { o[0] = 0; o[1] = -v[2]; o[2] = v[1]; o[3] = v[2]; o[4] = 0; o[5] = -v[0]; o[6] = -v[1]; o[7] = v[0]; o[8] = 0; }
+bool inv3(const double* a, double* o) {
+    const double c0 = a[4] * a[8] - a[5] * a[7], c1 = a[5] * a[6] - a[3] * a[8], c2 = a[3] * a[7] - a[4] * a[6];
+    const double det = a[0] * c0 + a[1] * c1 + a[2] * c2;
+    if (det == 0) return false;
+    const double id = 1.0 / det;
+    o[0] = c0 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    o[3] = c1 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    o[6] = c2 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    return true;
+}
+void normalize_rotation(double* R) {  // U V^T of the SVD = orthogonal polar factor (Newton iteration)
+    for (int it = 0; it < 50; ++it) {
+        double Xi[9], XiT[9], N[9], diff = 0;
+        if (!inv3(R, Xi)) return;
+        tr(Xi, XiT);
+        for (int k = 0; k < 9; ++k) { N[k] = 0.5 * (R[k] + XiT[k]); diff = std::fmax(diff, std::fabs(N[k] - R[k])); }
+        std::memcpy(R, N, sizeof(N));
+        if (diff < 1e-16) break;
+    }
+}
+void right_jacobian(const double v[3], double J[9]) {
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = std::sqrt(d2);
+    double W[9], W2[9];
+    hat(v, W); mul(W, W, W2);
+    for (int k = 0; k < 9; ++k) J[k] = k % 4 == 0 ? 1.0 : 0.0;
+    if (d < 1e-5) return;
+    for (int k = 0; k < 9; ++k) J[k] = J[k] - W[k] * (1.0 - std::cos(d)) / d2 + W2[k] * (d - std::sin(d)) / (d2 * d);
+}
+void inv_right_jacobian(const double v[3], double J[9]) {
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = std::sqrt(d2);
+    double W[9], W2[9];
+    hat(v, W); mul(W, W, W2);
+    for (int k = 0; k < 9; ++k) J[k] = k % 4 == 0 ? 1.0 : 0.0;
+    if (d < 1e-5) return;
+    for (int k = 0; k < 9; ++k) J[k] = J[k] + W[k] / 2 + W2[k] * (1.0 / d2 - (1.0 + std::cos(d)) / (2.0 * d * std::sin(d)));
+}
+
+// ---- dense helpers --------------------------------------------------------------------------------------------------------
+bool invert(std::vector<double> A, int n, std::vector<double>& inv) {  // Gauss-Jordan with partial pivoting
+    inv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int p = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)p * n + c])) p = r;
+        if (A[(size_t)p * n + c] == 0.0) return false;
+        if (p != c) for (int k = 0; k < n; ++k) { std::swap(A[(size_t)p * n + k], A[(size_t)c * n + k]); std::swap(inv[(size_t)p * n + k], inv[(size_t)c * n + k]); }
+        const double d = 1.0 / A[(size_t)c * n + c];
+        for (int k = 0; k < n; ++k) { A[(size_t)c * n + k] *= d; inv[(size_t)c * n + k] *= d; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = A[(size_t)r * n + c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < n; ++k) { A[(size_t)r * n + k] -= f * A[(size_t)c * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k]; }
+        }
+    }
+    return true;
+}
+void eig_sym(std::vector<double> A, int n, std::vector<double>& w, std::vector<double>& V) {  // cyclic Jacobi
+    V.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) (i == j ? dg : off) += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        if (off <= 1e-30 * dg || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) { const double x = A[(size_t)k * n + p], y = A[(size_t)k * n + q]; A[(size_t)k * n + p] = c * x - s * y; A[(size_t)k * n + q] = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = A[(size_t)p * n + k], y = A[(size_t)q * n + k]; A[(size_t)p * n + k] = c * x - s * y; A[(size_t)q * n + k] = s * x + c * y; }
+                for (int k = 0; k < n; ++k) { const double x = V[(size_t)k * n + p], y = V[(size_t)k * n + q]; V[(size_t)k * n + p] = c * x - s * y; V[(size_t)k * n + q] = s * x + c * y; }
+            }
+    }
+    w.resize(n);
+    for (int i = 0; i < n; ++i) w[i] = A[(size_t)i * n + i];
+}
+bool ldlt(std::vector<double>& H, int n, const double* b, double* x) {
+    std::vector<double> D(n);
+    for (int j = 0; j < n; ++j) {
+        double d = H[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= H[(size_t)j * n + k] * H[(size_t)j * n + k] * D[k];
+        if (!std::isfinite(d) || d == 0.0) return false;
+        D[j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = H[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= H[(size_t)i * n + k] * H[(size_t)j * n + k] * D[k];
+            H[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= H[(size_t)i * n + k] * x[k]; x[i] = s; }
+    for (int i = 0; i < n; ++i) x[i] /= D[i];
+    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < n; ++k) s -= H[(size_t)k * n + i] * x[k]; x[i] = s; }
+    return true;
+}
+struct HuberD {
+    double delta; float dsqr;
+    explicit HuberD(float d) : delta(d), dsqr((float)((double)d * (double)d)) {}
+    void rho(double e, double& r0, double& r1) const {
+        if (e <= dsqr) { r0 = e; r1 = 1.0; } else { const double s = std::sqrt(e); r0 = 2 * s * delta - dsqr; r1 = delta / s; }
+    }
+};
+
+}  // namespace
+
+void ExpSO3(const double w[3], double R[9]) {
+    const double d2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], d = std::sqrt(d2);
+    double W[9], W2[9];
+    hat(w, W); mul(W, W, W2);
+    for (int k = 0; k < 9; ++k) {
+        const double I = k % 4 == 0 ? 1.0 : 0.0;
+        R[k] = d < 1e-5 ? I + W[k] + 0.5 * W2[k] : I + W[k] * std::sin(d) / d + W2[k] * (1.0 - std::cos(d)) / d2;
+    }
+    normalize_rotation(R);
+}
+void LogSO3(const double R[9], double w[3]) {
+    const double trc = R[0] + R[4] + R[8];
+    w[0] = (R[7] - R[5]) / 2; w[1] = (R[2] - R[6]) / 2; w[2] = (R[3] - R[1]) / 2;
+    const double costheta = (trc - 1.0) * 0.5f;
+    if (costheta > 1 || costheta < -1) return;
+    const double theta = std::acos(costheta), s = std::sin(theta);
+    if (std::fabs(s) < 1e-5) return;
+    for (int k = 0; k < 3; ++k) w[k] = theta * w[k] / s;
+}
+
+void imu_pose_update(InertialKeyFrame& kf, int& its, const ImuCalibD& cal, const double u[6]) {  // ImuCamPose::Update
+    double Rut[3], E[9], Rn[9];
+    mulv(kf.Rwb, u + 3, Rut);
+    for (int k = 0; k < 3; ++k) kf.twb[k] += Rut[k];
+    ExpSO3(u, E);
+    mul(kf.Rwb, E, Rn);
+    std::memcpy(kf.Rwb, Rn, sizeof(Rn));
+    its++;
+    if (its >= 3) { normalize_rotation(kf.Rwb); its = 0; }
+    double Rbw[9], tbw[3], t[3];
+    tr(kf.Rwb, Rbw);
+    mulv(Rbw, kf.twb, t);
+    for (int k = 0; k < 3; ++k) tbw[k] = -t[k];
+    mul(cal.Rcb, Rbw, kf.Rcw);
+    mulv(cal.Rcb, tbw, t);
+    for (int k = 0; k < 3; ++k) kf.tcw[k] = t[k] + cal.tcb[k];
+}
+
+int inertial_visual_edge(const InertialKeyFrame& kf, const ImuCalibD& cal, const double X[3], const BAEdge& e, const Camera& cam, double err[3],
+                         double A[9], double B[18]) {
+    double Xc[3], Xb[3];
+    mulv(kf.Rcw, X, Xc);
+    for (int k = 0; k < 3; ++k) Xc[k] += kf.tcw[k];
+    mulv(cal.Rbc, Xc, Xb);
+    for (int k = 0; k < 3; ++k) Xb[k] += cal.tbc[k];
+    const bool stereo = e.obs[2] >= 0;
+    const int dim = stereo ? 3 : 2;
+    const double fx = (double)(float)cam.fx, fy = (double)(float)cam.fy, cx = (double)(float)cam.cx, cy = (double)(float)cam.cy;  // mvParameters are floats
+    const double u = fx * Xc[0] / Xc[2] + cx, v = fy * Xc[1] / Xc[2] + cy;
+    err[0] = e.obs[0] - u; err[1] = e.obs[1] - v; err[2] = 0;
+    if (stereo) { const double invZ = 1 / Xc[2]; err[2] = e.obs[2] - (u - cam.bf * invZ); }
+    double pj[9] = {fx / Xc[2], 0.0, -fx * Xc[0] / (Xc[2] * Xc[2]), 0.0, fy / Xc[2], -fy * Xc[1] / (Xc[2] * Xc[2]), 0, 0, 0};
+    if (stereo) { pj[6] = pj[0]; pj[7] = pj[1]; pj[8] = pj[2] + cam.bf * (1.0 / (Xc[2] * Xc[2])); }
+    std::memset(A, 0, 9 * sizeof(double));
+    std::memset(B, 0, 18 * sizeof(double));
+    for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < 3; ++c) A[3 * r + c] = -(pj[3 * r] * kf.Rcw[c] + pj[3 * r + 1] * kf.Rcw[3 + c] + pj[3 * r + 2] * kf.Rcw[6 + c]);
+    const double x = Xb[0], y = Xb[1], z = Xb[2];
+    const double S[18] = {0.0, z, -y, 1.0, 0.0, 0.0, -z, 0.0, x, 0.0, 1.0, 0.0, y, -x, 0.0, 0.0, 0.0, 1.0};
+    double PR[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) PR[3 * r + c] = pj[3 * r] * cal.Rcb[c] + pj[3 * r + 1] * cal.Rcb[3 + c] + pj[3 * r + 2] * cal.Rcb[6 + c];
+    for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < 6; ++c) B[6 * r + c] = PR[3 * r] * S[c] + PR[3 * r + 1] * S[6 + c] + PR[3 * r + 2] * S[12 + c];
+    return dim;
+}
+
+void inertial_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const Preintegrated& pint, double err[9], double J[9 * 24]) {
+    ImuBias b1;
+    b1.bax = (float)k1.ba[0]; b1.bay = (float)k1.ba[1]; b1.baz = (float)k1.ba[2];
+    b1.bwx = (float)k1.bg[0]; b1.bwy = (float)k1.bg[1]; b1.bwz = (float)k1.bg[2];
+    float dRf[9], dVf[3], dPf[3];
+    pint.GetDeltaRotation(b1, dRf); pint.GetDeltaVelocity(b1, dVf); pint.GetDeltaPosition(b1, dPf);
+    double dR[9], dV[3], dP[3];
+    for (int k = 0; k < 9; ++k) dR[k] = dRf[k];
+    for (int k = 0; k < 3; ++k) { dV[k] = dVf[k]; dP[k] = dPf[k]; }
+    const double dt = pint.dT;
+    const double g[3] = {0, 0, -(double)9.81f};
+    double Rbw1[9], dRt[9], t1[9], eR[9], er[3];
+    tr(k1.Rwb, Rbw1); tr(dR, dRt);
+    mul(dRt, Rbw1, t1); mul(t1, k2.Rwb, eR);
+    LogSO3(eR, er);
+    double dv[3], dp[3], rv[3], rp[3];
+    for (int k = 0; k < 3; ++k) { dv[k] = k2.v[k] - k1.v[k] - g[k] * dt; dp[k] = k2.twb[k] - k1.twb[k] - k1.v[k] * dt - g[k] * dt * dt / 2; }
+    mulv(Rbw1, dv, rv); mulv(Rbw1, dp, rp);
+    for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = rv[k] - dV[k]; err[6 + k] = rp[k] - dP[k]; }
+    if (!J) return;
+    std::memset(J, 0, 9 * 24 * sizeof(double));
+    auto put = [&](int r0, int c0, const double* m, double s) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) J[24 * (r0 + r) + c0 + c] = s * m[3 * r + c]; };
+    double invJr[9], Rwb2t[9], m1[9], m2[9], hv[9], hp[9], I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    inv_right_jacobian(er, invJr);
+    tr(k2.Rwb, Rwb2t);
+    mul(invJr, Rwb2t, m1); mul(m1, k1.Rwb, m2);
+    put(0, 0, m2, -1.0);                                  // pose 1: rotation
+    double dp2[3];
+    for (int k = 0; k < 3; ++k) dp2[k] = k2.twb[k] - k1.twb[k] - k1.v[k] * dt - 0.5 * g[k] * dt * dt;
+    mulv(Rbw1, dp2, rp);
+    hat(rv, hv); hat(rp, hp);
+    put(3, 0, hv, 1.0); put(6, 0, hp, 1.0);
+    put(6, 3, I, -1.0);                                   // pose 1: translation
+    put(3, 6, Rbw1, -1.0); put(6, 6, Rbw1, -dt);          // velocity 1
+    // gyro bias 1: -invJr * eR^T * RightJacobian(JRg * dbg) * JRg, -JVg, -JPg
+    double JRg[9], JVg[9], JPg[9], JVa[9], JPa[9];
+    for (int k = 0; k < 9; ++k) { JRg[k] = pint.JRg[k]; JVg[k] = pint.JVg[k]; JPg[k] = pint.JPg[k]; JVa[k] = pint.JVa[k]; JPa[k] = pint.JPa[k]; }
+    const double dbg[3] = {(double)(b1.bwx - pint.b.bwx), (double)(b1.bwy - pint.b.bwy), (double)(b1.bwz - pint.b.bwz)};  // GetDeltaBias is float
+    double Jd[3], RJ[9], eRt[9], a1[9], a2[9], a3[9];
+    mulv(JRg, dbg, Jd);
+    right_jacobian(Jd, RJ);
+    tr(eR, eRt);
+    mul(invJr, eRt, a1); mul(a1, RJ, a2); mul(a2, JRg, a3);
+    put(0, 9, a3, -1.0); put(3, 9, JVg, -1.0); put(6, 9, JPg, -1.0);
+    put(3, 12, JVa, -1.0); put(6, 12, JPa, -1.0);         // accelerometer bias 1
+    put(0, 15, invJr, 1.0);                               // pose 2: rotation
+    double R12[9];
+    mul(Rbw1, k2.Rwb, R12);
+    put(6, 18, R12, 1.0);                                 // pose 2: translation
+    put(3, 21, Rbw1, 1.0);                                // velocity 2
+}
+
+InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCalibD& cal, std::vector<double>& points,
+                                 const std::vector<BAEdge>& edges, const std::vector<InertialLink>& links, const Camera& cam,
+                                 int iterations, double lambda_init) {
+    const int K = (int)kfs.size(), P = (int)points.size() / 3, E = (int)edges.size(), Lk = (int)links.size();
+    InertialBAResult res;
+    res.chi2.assign(E, 0.0); res.depth_pos.assign(E, 0);
+    std::vector<int> pose_var(K, -1), imu_var(K, -1), its(K, 0);
+    int n_pose = 0, n_imu = 0;
+    for (int k = 0; k < K; ++k) if (!kfs[k].fixed) pose_var[k] = n_pose++;
+    for (int k = 0; k < K; ++k) if (!kfs[k].fixed && kfs[k].has_imu) imu_var[k] = n_imu++;
+    const int np = 6 * n_pose, n = np + 9 * n_imu;
+    // edge informations
+    std::vector<std::vector<double>> infoI(Lk), infoG(Lk), infoA(Lk);
+    for (int l = 0; l < Lk; ++l) {
+        const Preintegrated& p = *links[l].pint;
+        std::vector<double> C9(81), inv, w, V;
+        for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[9 * r + c] = p.C[15 * r + c];
+        invert(C9, 9, inv);
+        for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double m = (inv[9 * r + c] + inv[9 * c + r]) / 2; inv[9 * r + c] = inv[9 * c + r] = m; }
+        eig_sym(inv, 9, w, V);
+        for (double& x : w) if (x < 1e-12) x = 0;
+        infoI[l].assign(81, 0.0);
+        for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += V[9 * r + k] * w[k] * V[9 * c + k]; infoI[l][9 * r + c] = s * links[l].info_scale; }
+        std::vector<double> G(9), A(9);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { G[3 * r + c] = p.C[15 * (9 + r) + 9 + c]; A[3 * r + c] = p.C[15 * (12 + r) + 12 + c]; }
+        invert(G, 3, infoG[l]); invert(A, 3, infoA[l]);
+    }
+    const HuberD hub_mono((float)std::sqrt(5.991)), hub_stereo((float)std::sqrt(7.815)), hub_imu((float)std::sqrt(16.92));
+
+    std::vector<double> err_v(3 * (size_t)E), err_i(9 * (size_t)Lk);
+    std::vector<double> chi_i(Lk), chi_g(Lk), chi_a(Lk);
+    auto compute_errors = [&]() {
+        for (int e = 0; e < E; ++e) {
+            double A[9], B[18];
+            const int dim = inertial_visual_edge(kfs[edges[e].pose], cal, &points[3 * edges[e].point], edges[e], cam, &err_v[3 * e], A, B);
+            double s = 0;
+            for (int d = 0; d < dim; ++d) s += err_v[3 * e + d] * edges[e].info * err_v[3 * e + d];
+            res.chi2[e] = s;
+        }
+        for (int l = 0; l < Lk; ++l) {
+            inertial_edge(kfs[links[l].kf1], kfs[links[l].kf2], *links[l].pint, &err_i[9 * l], nullptr);
+            double s = 0;
+            for (int r = 0; r < 9; ++r) { double t = 0; for (int c = 0; c < 9; ++c) t += infoI[l][9 * r + c] * err_i[9 * l + c]; s += err_i[9 * l + r] * t; }
+            chi_i[l] = s;
+            double sg = 0, sa = 0;
+            for (int r = 0; r < 3; ++r) {
+                double tg = 0, ta = 0;
+                for (int c = 0; c < 3; ++c) {
+                    tg += infoG[l][3 * r + c] * (kfs[links[l].kf2].bg[c] - kfs[links[l].kf1].bg[c]);
+                    ta += infoA[l][3 * r + c] * (kfs[links[l].kf2].ba[c] - kfs[links[l].kf1].ba[c]);
+                }
+                sg += (kfs[links[l].kf2].bg[r] - kfs[links[l].kf1].bg[r]) * tg;
+                sa += (kfs[links[l].kf2].ba[r] - kfs[links[l].kf1].ba[r]) * ta;
+            }
+            chi_g[l] = sg; chi_a[l] = sa;
+        }
+    };
+    auto robust_chi2 = [&]() {
+        double chi = 0;
+        for (int l = 0; l < Lk; ++l) {
+            double r0 = chi_i[l], r1;
+            if (links[l].robust) hub_imu.rho(chi_i[l], r0, r1);
+            chi += r0 + chi_g[l] + chi_a[l];
+        }
+        for (int e = 0; e < E; ++e) {
+            double r0, r1;
+            (edges[e].obs[2] >= 0 ? hub_stereo : hub_mono).rho(res.chi2[e], r0, r1);
+            chi += r0;
+        }
+        return chi;
+    };
+    compute_errors();
+    res.err = robust_chi2();
+
+    std::vector<double> H((size_t)n * n), b(n), Hll(9 * (size_t)P), bl(3 * (size_t)P), Hpl(18 * (size_t)E), S, bs(n), x(n), xl(3 * (size_t)P), Dinv(9 * (size_t)P);
+    double lambda = lambda_init, ni = 2;
+    int n_bad = 0;
+    bool ok = true;
+    for (int it = 0; it < iterations && ok; ++it) {
+        compute_errors();
+        double currentChi = robust_chi2(), tempChi = currentChi;
+        const double iniChi = currentChi;
+        std::fill(H.begin(), H.end(), 0.0); std::fill(b.begin(), b.end(), 0.0); std::fill(Hll.begin(), Hll.end(), 0.0);
+        std::fill(bl.begin(), bl.end(), 0.0); std::fill(Hpl.begin(), Hpl.end(), 0.0);
+        for (int e = 0; e < E; ++e) {
+            const BAEdge& ed = edges[e];
+            double er[3], A[9], B[18];
+            const int dim = inertial_visual_edge(kfs[ed.pose], cal, &points[3 * ed.point], ed, cam, er, A, B);
+            double r0, r1;
+            (ed.obs[2] >= 0 ? hub_stereo : hub_mono).rho(res.chi2[e], r0, r1);
+            const double w = r1 * ed.info;
+            const int pv = pose_var[ed.pose], l = ed.point;
+            for (int r = 0; r < 3; ++r) {
+                double s = 0;
+                for (int d = 0; d < dim; ++d) s += A[3 * d + r] * (-ed.info * er[d] * r1);
+                bl[3 * l + r] += s;
+                for (int c = 0; c < 3; ++c) { double h = 0; for (int d = 0; d < dim; ++d) h += A[3 * d + r] * w * A[3 * d + c]; Hll[9 * l + 3 * r + c] += h; }
+            }
+            if (pv >= 0) {
+                for (int r = 0; r < 6; ++r) {
+                    double s = 0;
+                    for (int d = 0; d < dim; ++d) s += B[6 * d + r] * (-ed.info * er[d] * r1);
+                    b[6 * pv + r] += s;
+                    for (int c = 0; c < 6; ++c) { double h = 0; for (int d = 0; d < dim; ++d) h += B[6 * d + r] * w * B[6 * d + c]; H[(size_t)(6 * pv + r) * n + 6 * pv + c] += h; }
+                    for (int c = 0; c < 3; ++c) { double h = 0; for (int d = 0; d < dim; ++d) h += B[6 * d + r] * w * A[3 * d + c]; Hpl[18 * (size_t)e + 3 * r + c] += h; }
+                }
+            }
+        }
+        for (int l = 0; l < Lk; ++l) {
+            const InertialLink& lk = links[l];
+            double er[9], J[9 * 24];
+            inertial_edge(kfs[lk.kf1], kfs[lk.kf2], *lk.pint, er, J);
+            double r0, r1 = 1.0;
+            if (lk.robust) hub_imu.rho(chi_i[l], r0, r1);
+            // vertex blocks of the edge: offset in the state vector (-1: fixed), column offset in J, size
+            const int off[6] = {pose_var[lk.kf1] >= 0 ? 6 * pose_var[lk.kf1] : -1, imu_var[lk.kf1] >= 0 ? np + 9 * imu_var[lk.kf1] : -1,
+                                imu_var[lk.kf1] >= 0 ? np + 9 * imu_var[lk.kf1] + 3 : -1, imu_var[lk.kf1] >= 0 ? np + 9 * imu_var[lk.kf1] + 6 : -1,
+                                pose_var[lk.kf2] >= 0 ? 6 * pose_var[lk.kf2] : -1, imu_var[lk.kf2] >= 0 ? np + 9 * imu_var[lk.kf2] : -1};
+            const int col[6] = {0, 6, 9, 12, 15, 21}, sz[6] = {6, 3, 3, 3, 6, 3};
+            double OJ[9 * 24], Oe[9];  // (w Omega) J and (w Omega) e
+            for (int r = 0; r < 9; ++r) {
+                double s = 0;
+                for (int k = 0; k < 9; ++k) s += r1 * infoI[l][9 * r + k] * er[k];
+                Oe[r] = s;
+                for (int c = 0; c < 24; ++c) { double t = 0; for (int k = 0; k < 9; ++k) t += r1 * infoI[l][9 * r + k] * J[24 * k + c]; OJ[24 * r + c] = t; }
+            }
+            for (int a = 0; a < 6; ++a) {
+                if (off[a] < 0) continue;
+                for (int r = 0; r < sz[a]; ++r) {
+                    double s = 0;
+                    for (int k = 0; k < 9; ++k) s += J[24 * k + col[a] + r] * Oe[k];
+                    b[off[a] + r] -= s;
+                    for (int bb = 0; bb < 6; ++bb) {
+                        if (off[bb] < 0) continue;
+                        for (int c = 0; c < sz[bb]; ++c) { double h = 0; for (int k = 0; k < 9; ++k) h += J[24 * k + col[a] + r] * OJ[24 * k + col[bb] + c]; H[(size_t)(off[a] + r) * n + off[bb] + c] += h; }
+                    }
+                }
+            }
+            // random walks of the two biases
+            for (int which = 0; which < 2; ++which) {
+                const std::vector<double>& Om = which == 0 ? infoG[l] : infoA[l];
+                const int o1 = imu_var[lk.kf1] >= 0 ? np + 9 * imu_var[lk.kf1] + 3 + 3 * which : -1, o2 = imu_var[lk.kf2] >= 0 ? np + 9 * imu_var[lk.kf2] + 3 + 3 * which : -1;
+                double e3[3], Oe3[3];
+                for (int k = 0; k < 3; ++k) e3[k] = which == 0 ? kfs[lk.kf2].bg[k] - kfs[lk.kf1].bg[k] : kfs[lk.kf2].ba[k] - kfs[lk.kf1].ba[k];
+                for (int r = 0; r < 3; ++r) Oe3[r] = Om[3 * r] * e3[0] + Om[3 * r + 1] * e3[1] + Om[3 * r + 2] * e3[2];
+                for (int r = 0; r < 3; ++r) {
+                    if (o1 >= 0) b[o1 + r] += Oe3[r];   // J1 = -I: b += -J1^T Omega e
+                    if (o2 >= 0) b[o2 + r] -= Oe3[r];
+                    for (int c = 0; c < 3; ++c) {
+                        if (o1 >= 0) H[(size_t)(o1 + r) * n + o1 + c] += Om[3 * r + c];
+                        if (o2 >= 0) H[(size_t)(o2 + r) * n + o2 + c] += Om[3 * r + c];
+                        if (o1 >= 0 && o2 >= 0) { H[(size_t)(o1 + r) * n + o2 + c] -= Om[3 * r + c]; H[(size_t)(o2 + r) * n + o1 + c] -= Om[3 * r + c]; }
+                    }
+                }
+            }
+        }
+        if (it == 0 && !(lambda_init > 0)) {
+            double mx = 0;
+            for (int i = 0; i < n; ++i) mx = std::max(mx, std::fabs(H[(size_t)i * n + i]));
+            for (int l = 0; l < P; ++l) for (int j = 0; j < 3; ++j) mx = std::max(mx, std::fabs(Hll[9 * (size_t)l + 4 * j]));
+            lambda = 1e-5 * mx;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const std::vector<InertialKeyFrame> backup_kf = kfs;
+            const std::vector<int> backup_its = its;
+            const std::vector<double> backup_pts = points;
+            S = H;
+            for (int i = 0; i < n; ++i) S[(size_t)i * n + i] += lambda;
+            std::vector<double> coeff(n, 0.0);
+            for (int l = 0; l < P; ++l) {
+                double D[9];
+                std::memcpy(D, &Hll[9 * (size_t)l], sizeof(D));
+                D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                inv3(D, &Dinv[9 * (size_t)l]);
+            }
+            std::vector<std::vector<int>> by_point(P);
+            for (int e = 0; e < E; ++e) if (pose_var[edges[e].pose] >= 0) by_point[edges[e].point].push_back(e);
+            for (int l = 0; l < P; ++l) {
+                const double* Di = &Dinv[9 * (size_t)l];
+                double db[3];
+                mulv(Di, &bl[3 * l], db);
+                for (int e1 : by_point[l]) {
+                    const int i1 = pose_var[edges[e1].pose];
+                    const double* Bi = &Hpl[18 * (size_t)e1];
+                    double BD[18];
+                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[3 * r + c] = Bi[3 * r] * Di[c] + Bi[3 * r + 1] * Di[3 + c] + Bi[3 * r + 2] * Di[6 + c];
+                    for (int r = 0; r < 6; ++r) coeff[6 * i1 + r] += Bi[3 * r] * db[0] + Bi[3 * r + 1] * db[1] + Bi[3 * r + 2] * db[2];
+                    for (int e2 : by_point[l]) {
+                        const int i2 = pose_var[edges[e2].pose];
+                        const double* Bj = &Hpl[18 * (size_t)e2];
+                        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
+                            S[(size_t)(6 * i1 + r) * n + 6 * i2 + c] -= BD[3 * r] * Bj[3 * c] + BD[3 * r + 1] * Bj[3 * c + 1] + BD[3 * r + 2] * Bj[3 * c + 2];
+                    }
+                }
+            }
+            for (int i = 0; i < n; ++i) bs[i] = b[i] - coeff[i];
+            const bool ok2 = n == 0 ? true : ldlt(S, n, bs.data(), x.data());
+            if (ok2) {
+                std::vector<double> cl(bl);
+                for (int e = 0; e < E; ++e) {
+                    const int pv = pose_var[edges[e].pose];
+                    if (pv < 0) continue;
+                    const double* Bi = &Hpl[18 * (size_t)e];
+                    for (int c = 0; c < 3; ++c) { double s = 0; for (int r = 0; r < 6; ++r) s += Bi[3 * r + c] * x[6 * pv + r]; cl[3 * edges[e].point + c] -= s; }
+                }
+                for (int l = 0; l < P; ++l) mulv(&Dinv[9 * (size_t)l], &cl[3 * l], &xl[3 * l]);
+            }
+            for (int k = 0; k < K; ++k) {
+                if (pose_var[k] >= 0) imu_pose_update(kfs[k], its[k], cal, &x[6 * pose_var[k]]);
+                if (imu_var[k] >= 0) {
+                    const double* u = &x[np + 9 * imu_var[k]];
+                    for (int c = 0; c < 3; ++c) { kfs[k].v[c] += u[c]; kfs[k].bg[c] += u[3 + c]; kfs[k].ba[c] += u[6 + c]; }
+                }
+            }
+            for (int i = 0; i < 3 * P; ++i) points[i] += xl[i];
+            compute_errors();
+            tempChi = robust_chi2();
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            double scale = 0;
+            for (int j = 0; j < n; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+            for (int j = 0; j < 3 * P; ++j) scale += xl[j] * (lambda * xl[j] + bl[j]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                kfs = backup_kf; its = backup_its; points = backup_pts;
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        ++res.iterations;
+        res.trace.chi2.push_back(currentChi); res.trace.lambda.push_back(lambda); res.trace.trials.push_back(qmax);
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
+        if (n_bad >= 3) ok = false;
+    }
+    res.err_end = robust_chi2();  // activeRobustChi2 with the errors of the last computeActiveErrors
+    for (int e = 0; e < E; ++e) {
+        const InertialKeyFrame& kf = kfs[edges[e].pose];
+        const double* X = &points[3 * edges[e].point];
+        res.depth_pos[e] = (kf.Rcw[6] * X[0] + kf.Rcw[7] * X[1] + kf.Rcw[8] * X[2] + kf.tcw[2]) > 0.0;
+    }
+    return res;
+}
+
+}  // namespace oracle

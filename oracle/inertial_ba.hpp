@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle, never linked into or called from the product path.
+//
+// Restatement of the visual-inertial local bundle adjustment:
+//   Optimizer::LocalInertialBA (graph, Levenberg-Marquardt settings)          SF/src/Optimizer.cc:1512-2085
+//   ImuCamPose (ctor from a keyframe, Project, ProjectStereo, Update)         SF/src/G2oTypes.cc:35-83, 178-232
+//   VertexPose / VertexVelocity / VertexGyroBias / VertexAccBias              SF/include/G2oTypes.h:139-255
+//   EdgeMono / EdgeStereo (error, Jacobians in the body-frame parameterisation)  SF/include/G2oTypes.h:378-460, SF/src/G2oTypes.cc:358-436
+//   EdgeInertial (information with eigenvalue clamp, error, Jacobians)        SF/src/G2oTypes.cc:499-601
+//   EdgeGyroRW / EdgeAccRW                                                   SF/include/G2oTypes.h:645-714
+//   ExpSO3, LogSO3, RightJacobianSO3, InverseRightJacobianSO3, NormalizeRotation   SF/src/G2oTypes.cc:783-865, SF/include/G2oTypes.h:76-81
+//   g2o: BaseMultiEdge::constructQuadraticForm / computeQuadraticForm         Thirdparty/g2o/g2o/core/base_multi_edge.hpp:60-222
+//        (robustInformation = rho'[1] * information, core/base_edge.h:96-102), LM and Schur as in ba.hpp
+// Eigen pieces not in tree are replaced: JacobiSVD (NormalizeRotation) by the polar factor via Newton iteration,
+// SelfAdjointEigenSolver<9x9> by cyclic Jacobi rotations, the 9x9 / 3x3 inverses by Gauss-Jordan with partial pivoting.
+// PARITY UNPINNED: the reference has no tests or vectors for these.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "ba.hpp"
+#include "imu.hpp"
+
+namespace oracle {
+
+struct ImuCalibD { double Rcb[9], tcb[3], Rbc[9], tbc[3]; };  // mImuCalib.mTcb / mTbc widened from float
+struct InertialKeyFrame {
+    double Rcw[9], tcw[3];  // camera pose (Sophus::SE3f widened)
+    double Rwb[9], twb[3];  // GetImuRotation / GetImuPosition
+    double v[3], bg[3], ba[3];
+    uint8_t fixed = 0, has_imu = 1;
+};
+struct InertialLink {  // EdgeInertial + EdgeGyroRW + EdgeAccRW between keyframe kf1 (earlier) and kf2
+    int kf1 = 0, kf2 = 0;
+    const Preintegrated* pint = nullptr;  // pKF2->mpImuPreintegrated after SetNewBias(pKF1->GetImuBias())
+    bool robust = false;                   // Huber sqrt(16.92) (the link to the fixed keyframe, or bRecInit)
+    double info_scale = 1.0;               // 1e-2 for the oldest link
+};
+struct InertialBAResult {
+    std::vector<double> chi2;        // per visual edge
+    std::vector<uint8_t> depth_pos;  // per visual edge
+    double err = 0, err_end = 0;     // activeRobustChi2 before / after optimize()
+    int iterations = 0;
+    LMTrace trace;
+};
+
+// Keyframes in vertex-id order; points, edges as in LocalBundleAdjustment (edge.pose indexes kfs).  Updates kfs (poses,
+// velocities, biases) and points in place.
+InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCalibD& calib, std::vector<double>& points,
+                                 const std::vector<BAEdge>& edges, const std::vector<InertialLink>& links, const Camera& cam,
+                                 int iterations, double lambda_init);
+
+// exposed for unit tests
+void ExpSO3(const double w[3], double R[9]);
+void LogSO3(const double R[9], double w[3]);
+// EdgeInertial: 9-vector error and the six Jacobian blocks (9 x {6,3,3,3,6,3}, row-major, concatenated: 9 x 24)
+void inertial_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const Preintegrated& pint, double err[9], double J[9 * 24]);
+// visual edge in the ImuCamPose parameterisation: error (2 or 3), d/d point (dim x 3), d/d pose increment (dim x 6)
+int inertial_visual_edge(const InertialKeyFrame& kf, const ImuCalibD& calib, const double X[3], const BAEdge& e, const Camera& cam, double err[3],
+                         double A[9], double B[18]);
+void imu_pose_update(InertialKeyFrame& kf, int& its, const ImuCalibD& calib, const double u[6]);
+
+}  // namespace oracle

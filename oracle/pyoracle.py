@@ -571,3 +571,58 @@ def fov_segment(lm7, pos, cube_len, det_range):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
     n = f(lm.ctypes.data, _f64(pos).ctypes.data, cube_len, det_range, boxes.ctypes.data)
     return lm, boxes[:n].copy()
+
+
+# ---- visual-inertial local BA ----------------------------------------------------------------------------------------------
+def pack_preintegrated(fields, bias6):
+    """dict of IMU::Preintegrated fields (as imu_preintegrate returns) + its bias -> 298 floats for the inertial entry points."""
+    out = [np.float32([fields["dT"]])]
+    for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa", "avgA", "avgW", "C"):
+        out.append(np.asarray(fields[name], np.float32).ravel())
+    out.append(np.asarray(bias6, np.float32))
+    return np.concatenate(out)
+
+
+def local_inertial_ba(kf33, fixed, has_imu, calib24, points3, edges6, link4, pre298, cam5, iterations=10, lambda_init=1.0):
+    """Optimizer::LocalInertialBA's optimisation -> (kf33, points, chi2, depth_pos, iterations, trace, (err, err_end))."""
+    kf, pts = _f64(kf33).copy(), _f64(points3).copy()
+    fixed, has_imu = np.ascontiguousarray(fixed, np.uint8), np.ascontiguousarray(has_imu, np.uint8)
+    calib24, edges6, link4, cam5 = _f64(calib24), _f64(edges6), _f64(link4).reshape(-1, 4), _f64(cam5)
+    pre = np.ascontiguousarray(pre298, np.float32).reshape(-1, 298)
+    E = len(edges6)
+    chi2, dpos, err2 = np.zeros(max(E, 1)), np.zeros(max(E, 1), np.uint8), np.zeros(2)
+    tc, tl, tt = np.zeros(32), np.zeros(32), np.zeros(32, np.int32)
+    f = lib().oracle_local_inertial_ba
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                  C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 6 + [C.c_int]
+    it = f(kf.ctypes.data, fixed.ctypes.data, has_imu.ctypes.data, len(kf), calib24.ctypes.data, pts.ctypes.data, len(pts), edges6.ctypes.data, E,
+           link4.ctypes.data, pre.ctypes.data, len(link4), cam5.ctypes.data, iterations, lambda_init, chi2.ctypes.data, dpos.ctypes.data,
+           err2.ctypes.data, tc.ctypes.data, tl.ctypes.data, tt.ctypes.data, 32)
+    return kf, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it]), (err2[0], err2[1])
+
+
+def inertial_edge(kf33_1, kf33_2, pre298):
+    a, b, p = _f64(kf33_1), _f64(kf33_2), np.ascontiguousarray(pre298, np.float32)
+    err, J = np.zeros(9), np.zeros((9, 24))
+    f = lib().oracle_inertial_edge
+    f.argtypes = [C.c_void_p] * 5
+    f(a.ctypes.data, b.ctypes.data, p.ctypes.data, err.ctypes.data, J.ctypes.data)
+    return err, J
+
+
+def inertial_visual_edge(kf33, calib24, X, edge6, cam5):
+    kf, cal, X, e, cam = _f64(kf33), _f64(calib24), _f64(X), _f64(edge6), _f64(cam5)
+    err, A, B = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 6))
+    f = lib().oracle_inertial_visual_edge
+    f.argtypes = [C.c_void_p] * 8
+    dim = f(kf.ctypes.data, cal.ctypes.data, X.ctypes.data, e.ctypes.data, cam.ctypes.data, err.ctypes.data, A.ctypes.data, B.ctypes.data)
+    return dim, err, A, B
+
+
+def imu_pose_update(kf33, its, calib24, u6):
+    kf = _f64(kf33).copy()
+    it = C.c_int(its)
+    f = lib().oracle_imu_pose_update
+    f.argtypes = [C.c_void_p] * 4
+    f(kf.ctypes.data, C.addressof(it), _f64(calib24).ctypes.data, _f64(u6).ctypes.data)
+    return kf, it.value

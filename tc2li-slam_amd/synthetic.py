@@ -328,3 +328,111 @@ def imu_samples(t0, t1, rate=100.0, seed=0, noise=True, omega=(0.02, -0.1, 0.05)
         a += rng.normal(0, IMU_NOISE[1], a.shape)
     out["w"], out["a"] = w.astype(np.float32), a.astype(np.float32)
     return out
+
+
+# ---- visual-inertial local BA windows -------------------------------------------------------------------------------------
+# body frame: x forward, y left, z up (world gravity = (0, 0, -9.81)); camera: z forward, x right, y down
+RBC = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+TBC = np.array([0.3, 0.05, 0.1])
+
+
+def _traj(t):
+    """Analytic body trajectory -> (p, R) at time t (scalar)."""
+    from scipy.spatial.transform import Rotation
+    p = np.array([8.0 * t + 0.5 * np.sin(0.8 * t), 1.5 * np.sin(0.5 * t), 0.2 * np.sin(0.7 * t)])
+    R = Rotation.from_euler("zyx", [0.25 * np.sin(0.4 * t), 0.05 * np.sin(0.9 * t), 0.04 * np.cos(0.6 * t)]).as_matrix()
+    return p, R
+
+
+def inertial_window(seed=0, n_opt=8, n_points=600, kf_dt=0.4, rate=200.0, pose_noise=(0.3, 0.03), vel_noise=0.05, pixel_noise=0.5,
+                    outlier_frac=0.02):
+    """A LocalInertialBA problem: 1 fixed keyframe + n_opt optimisable ones (vertex-id order = time order), pre-integrated
+    IMU between consecutive keyframes (from noisy samples of the analytic trajectory), stereo observations of random points.
+    Returns a dict: kf33 [K, 33] (noisy estimate), kf33_true, fixed, has_imu, calib24, points, points_true, edges [E, 6],
+    link4 [L, 4], samples (per link: IMU_SAMPLE_DTYPE array, t1, t2), bias6 (used for the integration), cam."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng([SEED0, 0x1BA, seed])
+    K = n_opt + 1
+    times = 2.0 + kf_dt * np.arange(K)
+    h = 1e-4
+    Rcb, tcb = RBC.T, -RBC.T @ TBC
+    calib24 = np.concatenate([Rcb.ravel(), tcb, RBC.ravel(), TBC])
+    bg_true, ba_true = np.array([0.002, -0.001, 0.0015]), np.array([0.03, -0.02, 0.01])
+
+    def state(t):
+        p, R = _traj(t)
+        v = (_traj(t + h)[0] - _traj(t - h)[0]) / (2 * h)
+        Rcw = Rcb @ R.T
+        tcw = Rcb @ (-R.T @ p) + tcb
+        return p, R, v, Rcw, tcw
+
+    def pack(p, R, v, Rcw, tcw, bg, ba):
+        return np.concatenate([Rcw.ravel(), tcw, R.ravel(), p, v, bg, ba])
+
+    kf_true = np.stack([pack(*state(t), bg_true, ba_true) for t in times])
+    kf = kf_true.copy()
+    for k in range(1, K):  # keyframe 0 is the fixed one: exact
+        p, R, v, _, _ = state(times[k])
+        Rn = R @ Rotation.from_rotvec(rng.normal(0, np.deg2rad(pose_noise[0]), 3)).as_matrix()
+        pn = p + rng.normal(0, pose_noise[1], 3)
+        Rcw = Rcb @ Rn.T
+        tcw = Rcb @ (-Rn.T @ pn) + tcb
+        kf[k] = pack(pn, Rn, v + rng.normal(0, vel_noise, 3), Rcw, tcw, bg_true + rng.normal(0, 2e-4, 3), ba_true + rng.normal(0, 3e-3, 3))
+    # the map keeps floats
+    kf = kf.astype(np.float32).astype(np.float64)
+    kf_true32 = kf_true.astype(np.float32).astype(np.float64)
+    kf[0] = kf_true32[0]
+    # IMU samples between consecutive keyframes
+    g = np.array([0.0, 0.0, -9.81])
+    samples, link4 = [], []
+    for k in range(1, K):
+        t1, t2 = times[k - 1], times[k]
+        ts = np.arange(np.floor(t1 * rate) - 0, np.ceil(t2 * rate) + 1) / rate
+        ts = ts[(ts >= t1 - 1.0 / rate - 1e-9) & (ts <= t2 + 1.0 / rate + 1e-9)]
+        out = np.zeros(len(ts), IMU_SAMPLE_DTYPE)
+        for i, t in enumerate(ts):
+            p0, R0 = _traj(t)
+            acc_w = (_traj(t + h)[0] - 2 * p0 + _traj(t - h)[0]) / (h * h)
+            Rm, Rp = _traj(t - h)[1], _traj(t + h)[1]
+            W = R0.T @ (Rp - Rm) / (2 * h)
+            w_b = np.array([W[2, 1], W[0, 2], W[1, 0]])
+            out["t"][i] = t
+            out["a"][i] = R0.T @ (acc_w - g) + ba_true + rng.normal(0, IMU_NOISE[1] * 0.1, 3)
+            out["w"][i] = w_b + bg_true + rng.normal(0, IMU_NOISE[0] * 0.1, 3)
+        samples.append((out, t1, t2))
+        link4.append([k - 1, k, 1.0 if k == 1 else 0.0, 1e-2 if k == 1 else 1.0])  # the link to the fixed keyframe is robust and down-weighted
+    # points in front of the trajectory and their stereo observations
+    cam = np.array([FX, FY, CX, CY, BF], np.float64)
+    cam = np.float32(cam).astype(np.float64)
+    pts_true = np.stack([rng.uniform(10, 8.0 * times[-1] + 40, n_points), rng.uniform(-12, 12, n_points), rng.uniform(-1.5, 4, n_points)], 1)
+    edges = []
+    used = np.zeros(n_points, bool)
+    for k in range(K):
+        _, _, _, Rcw, tcw = state(times[k])
+        Xc = pts_true @ Rcw.T + tcw
+        z = Xc[:, 2]
+        u = cam[0] * Xc[:, 0] / z + cam[2]
+        v = cam[1] * Xc[:, 1] / z + cam[3]
+        vis = (z > 2) & (z < 60) & (u > 20) & (u < WIDTH - 20) & (v > 20) & (v < HEIGHT - 20)
+        for i in np.nonzero(vis)[0]:
+            octave = int(min(7, max(0, np.log(z[i] / 6.0) / np.log(1.2))))
+            s2 = 1.2 ** (2 * octave)
+            du, dv = rng.normal(0, pixel_noise * np.sqrt(s2), 2)
+            if rng.random() < outlier_frac:
+                du += rng.choice([-1, 1]) * rng.uniform(8, 20)
+            ur = u[i] + du - cam[4] / z[i] + rng.normal(0, 0.3)
+            mono = z[i] > 45
+            edges.append([i, k, np.float32(u[i] + du), np.float32(v[i] + dv), -1.0 if mono else np.float32(ur), 1.0 / s2])
+            used[i] = True
+    edges = np.array(edges, np.float64)
+    nobs = np.bincount(edges[:, 0].astype(int), minlength=n_points)
+    keep = nobs >= 2
+    remap = np.cumsum(keep) - 1
+    edges = edges[keep[edges[:, 0].astype(int)]]
+    edges[:, 0] = remap[edges[:, 0].astype(int)]
+    pts_true = pts_true[keep]
+    pts = (pts_true + rng.normal(0, 0.05, pts_true.shape) * (1 + np.linalg.norm(pts_true - _traj(times[K // 2])[0], axis=1, keepdims=True) / 20)).astype(np.float32).astype(np.float64)
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1
+    return dict(kf33=kf, kf33_true=kf_true32, fixed=fixed, has_imu=np.ones(K, np.uint8), calib24=calib24, points=pts, points_true=pts_true,
+                edges=edges, link4=np.array(link4), samples=samples, bias6=np.concatenate([ba_true, bg_true]).astype(np.float32), cam=cam,
+                times=times)
