@@ -441,6 +441,40 @@ typedef struct tc2li_ba_problem {
 int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam,
                                         int max_concurrency, int32_t* results);
 
+/* ------------------------------------------------------------------------------------------------
+ * Visual-inertial local bundle adjustment -- the optimisation of Optimizer::LocalInertialBA (SF/src/Optimizer.cc:1512-2085;
+ * caller LocalMapping.cc:158,161): vertices VertexPose (ImuCamPose, body-frame update), VertexVelocity, VertexGyroBias,
+ * VertexAccBias per keyframe and marginalised points; edges EdgeMono / EdgeStereo (Huber), EdgeInertial (+ Huber
+ * sqrt(16.92) where `robust`), EdgeGyroRW, EdgeAccRW (SF/include/G2oTypes.h, SF/src/G2oTypes.cc).  The host shim gathers
+ * the temporal window, the fixed keyframes and the points exactly as :1520-1640 does and passes them flattened, keyframes in
+ * vertex-id order.  Projection edges run on the GPU, the few inertial edges on the host (row c6), the reduced system
+ * (6 + 9 unknowns per optimisable keyframe) is solved on the host like g2o's LinearSolverEigen.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_inertial_keyframe {  /* ImuCamPose(KeyFrame*) + velocity + biases, widened from the map's floats */
+    double Rcw[9], tcw[3];                /* GetRotation(), GetTranslation() */
+    double Rwb[9], twb[3];                /* GetImuRotation(), GetImuPosition() */
+    double velocity[3], gyro_bias[3], acc_bias[3];
+} tc2li_inertial_keyframe;
+typedef struct tc2li_imu_calib { double Rcb[9], tcb[3], Rbc[9], tbc[3]; } tc2li_imu_calib;  /* mImuCalib.mTcb / mTbc */
+typedef struct tc2li_inertial_link {      /* EdgeInertial + EdgeGyroRW + EdgeAccRW between keyframe kf1 (= kf2->mPrevKF) and kf2 */
+    int32_t kf1, kf2;
+    int32_t robust;                       /* i == N-1 || bRecInit (Optimizer.cc:1757-1766) */
+    int32_t pad_;
+    double info_scale;                    /* 1e-2 for the link to the keyframe before the window, else 1 */
+    const tc2li_preintegrated* preintegrated; /* kf2->mpImuPreintegrated after SetNewBias(kf1->GetImuBias()) */
+} tc2li_inertial_link;
+
+/* fixed[k]: the keyframe's pose, velocity and biases are constants; has_imu[k] = pKFi->bImu.  iterations / lambda_init:
+ * 10 and 1e0, or 4 and 1e-2 for bLarge (:1516-1523, 1637-1650).  stats->initial_chi2 / final_chi2 are activeRobustChi2()
+ * before and after optimize() (err / err_end of :1968-1971).  Keyframes and points are updated in place; edge_chi2 /
+ * edge_depth_positive as in tc2li_local_bundle_adjustment.  Returns the number of iterations performed. */
+int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const uint8_t* fixed, const uint8_t* has_imu,
+                                           int n_keyframes, const tc2li_imu_calib* calib, double* points3, int n_points,
+                                           const tc2li_ba_edge* edges, int n_edges, const tc2li_inertial_link* links,
+                                           int n_links, const tc2li_camera* cam, int iterations, double lambda_init,
+                                           const volatile uint8_t* stop_flag, double* edge_chi2,
+                                           uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
+
 /* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
  * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =
  * LidarCovisRes::ComputeJandHSE3 (SF/src/LidarRes.cc:136-186, with respect to the camera se3 increments).  JacT and

@@ -106,6 +106,8 @@ def lib():
     L.tc2li_lidar_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_lidar_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_lidar_fov_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    L.tc2li_local_inertial_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 5
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
@@ -563,6 +565,37 @@ def lidar_imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     k = _check(lib().tc2li_lidar_imu_propagate(st.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, last.ctypes.data,
                                                last.ctypes.data + 24, poses.ctypes.data, len(poses)))
     return st, poses[:k], last
+
+
+class InertialLink(C.Structure):
+    """tc2li_inertial_link"""
+    _fields_ = [("kf1", C.c_int32), ("kf2", C.c_int32), ("robust", C.c_int32), ("pad_", C.c_int32), ("info_scale", C.c_double),
+                ("preintegrated", C.c_void_p)]
+
+
+def local_inertial_bundle_adjustment(kf33, fixed, has_imu, calib24, points3, edges, link4, preintegrated, cam5, iterations=10, lambda_init=1.0,
+                                     stop_flag=None, stream=0):
+    """The optimisation of ``Optimizer::LocalInertialBA``.  kf33: [K, 33] = Rcw 9, tcw 3, Rwb 9, twb 3, velocity 3, gyro bias 3,
+    acc bias 3 per keyframe; link4: [L, 4] = kf1, kf2, robust, info_scale; preintegrated: list of ``Preintegrated`` (one per
+    link) -> (kf33, points3, chi2, depth_positive, stats)."""
+    kf = np.ascontiguousarray(kf33, np.float64).copy()
+    pts = np.ascontiguousarray(points3, np.float64).copy()
+    fixed, has_imu = np.ascontiguousarray(fixed, np.uint8), np.ascontiguousarray(has_imu, np.uint8)
+    calib24, cam5 = np.ascontiguousarray(calib24, np.float64), np.ascontiguousarray(cam5, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    link4 = np.ascontiguousarray(link4, np.float64).reshape(-1, 4)
+    links = (InertialLink * max(len(link4), 1))()
+    for l, row in enumerate(link4):
+        links[l] = InertialLink(int(row[0]), int(row[1]), int(row[2] != 0), 0, float(row[3]), C.addressof(preintegrated[l].p))
+    chi2 = np.zeros(max(len(edges), 1))
+    dpos = np.zeros(max(len(edges), 1), np.uint8)
+    stats = BaStats()
+    stop_ptr = stop_flag.ctypes.data if stop_flag is not None else None
+    _check(lib().tc2li_local_inertial_bundle_adjustment(kf.ctypes.data, fixed.ctypes.data, has_imu.ctypes.data, len(kf), calib24.ctypes.data,
+                                                        pts.ctypes.data, len(pts), edges.ctypes.data, len(edges), C.addressof(links), len(link4),
+                                                        cam5.ctypes.data, iterations, lambda_init, stop_ptr, chi2.ctypes.data, dpos.ctypes.data,
+                                                        C.addressof(stats), C.c_void_p(stream)))
+    return kf, pts, chi2[:len(edges)], dpos[:len(edges)], stats
 
 
 class LastFrame(C.Structure):

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "ba_math.hpp"
+#include "inertial_math.hpp"
 
 namespace tc2li {
 
@@ -15,6 +16,10 @@ struct BaProblemDev {
     double delta_mono, delta_stereo;
     float dsqr_mono, dsqr_stereo;
     Se3 *poses, *poses_trial;
+    // visual-inertial mode (Optimizer::LocalInertialBA): keyframe poses as ImuCamPose instead of SE3Quat
+    int32_t inertial, pad_;
+    ImuPose *iposes, *iposes_trial;
+    ImuCalib calib;
     double *points, *points_trial;
     const BaEdge* edges;
     const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges;

@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "ba_device.hpp"
 #include "balm_host.hpp"
+#include "inertial_host.hpp"
 #include "pose_opt_device.hpp"
 
 using namespace tc2li;
@@ -38,12 +39,118 @@ struct BaWorkspace {
     DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
     DevBuf<uint8_t> d_depth;
     PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp;
+    DevBuf<ImuPose> d_iposes, d_iposes_trial;
+    PinnedBuf<ImuPose> h_iposes;
     BalmTerm lidar;
     std::mutex mu;
 };
 // one workspace per host thread: windows optimised from different threads (tc2li_local_bundle_adjustment_batch) do not
 // share device buffers
 BaWorkspace& ba_ws() { static thread_local BaWorkspace w; return w; }
+
+// Structure and device state of the projection-edge part of a local BA (shared by the visual / LiDAR and the inertial
+// entry points): free-pose numbering, CSR of the edges by landmark and by free pose, workspace sizing, uploads, and the
+// BaProblemDev handed to the kernels.  poses7 == NULL: the caller uploads ImuPose states itself (inertial mode).
+struct VisualProblem {
+    BaProblemDev pb{};
+    std::vector<int> pose_var;
+    std::vector<Se3> poses;
+    int n_free = 0, np = 0, n_slices = 1, k_per_slice = 4;
+
+    int setup(BaWorkspace& ws, const double* poses7, const uint8_t* fixed, int n_poses, const double* points3, int n_points,
+              const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, const uint8_t* extra_used, hipStream_t st) {
+    // ---- structure: free-pose numbering, CSR by landmark and by free pose ----
+    pose_var.assign(n_poses, -1);
+    n_free = 0;
+    std::vector<uint8_t> used(n_poses, 0);
+    for (int e = 0; e < n_edges; ++e) {
+        if (edges[e].pose < 0 || edges[e].pose >= n_poses || edges[e].point < 0 || edges[e].point >= n_points) {
+            set_error("edge %d references pose %d / point %d out of range", e, edges[e].pose, edges[e].point);
+            return TC2LI_ERR_INVALID;
+        }
+        used[edges[e].pose] = 1;
+    }
+    for (int k = 0; k < n_poses; ++k) if (extra_used && extra_used[k]) used[k] = 1;
+    for (int k = 0; k < n_poses; ++k) if (!fixed[k] && used[k]) pose_var[k] = n_free++;
+    std::vector<int> pt_off(n_points + 1, 0), pt_edges(n_edges), pv_off(n_free + 1, 0);
+    for (int e = 0; e < n_edges; ++e) { pt_off[edges[e].point + 1]++; if (pose_var[edges[e].pose] >= 0) pv_off[pose_var[edges[e].pose] + 1]++; }
+    for (int l = 0; l < n_points; ++l) {
+        if (pt_off[l + 1] == 0) { set_error("point %d has no edge", l); return TC2LI_ERR_INVALID; }
+        pt_off[l + 1] += pt_off[l];
+    }
+    for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
+    const int n_free_edges = pv_off[n_free];
+    std::vector<int> pv_edges(std::max(n_free_edges, 1));
+    {
+        std::vector<int> fl(pt_off.begin(), pt_off.end() - 1), fp(pv_off.begin(), pv_off.end() - 1);
+        for (int e = 0; e < n_edges; ++e) {
+            pt_edges[fl[edges[e].point]++] = e;
+            const int i = pose_var[edges[e].pose];
+            if (i >= 0) pv_edges[fp[i]++] = e;
+        }
+    }
+    np = 6 * n_free;
+    const int np_pad = std::max(16, (np + 15) / 16 * 16);
+    const int k_total = 3 * n_points;
+    n_slices = std::max(1, std::min(64, k_total / 64));
+    k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
+
+    // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
+    auto &d_poses = ws.d_poses, &d_poses_trial = ws.d_poses_trial;
+    auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
+         &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
+         &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
+         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
+    auto& d_edges = ws.d_edges;
+    auto &d_pose_var = ws.d_pose_var, &d_pt_off = ws.d_pt_off, &d_pt_edges = ws.d_pt_edges, &d_pv_off = ws.d_pv_off, &d_pv_edges = ws.d_pv_edges;
+    auto& d_depth = ws.d_depth;
+    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
+    const size_t E = n_edges, P = n_points;
+    const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
+    TC2LI_HIP_CHECK(d_poses.ensure(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
+    TC2LI_HIP_CHECK(d_points.ensure(3 * P)); TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
+    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(9 * E)); TC2LI_HIP_CHECK(d_cp.ensure(27 * E));
+    TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
+    TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
+    TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
+    TC2LI_HIP_CHECK(d_AT.ensure(at_elems)); TC2LI_HIP_CHECK(d_BT.ensure(at_elems));
+    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 4 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
+    TC2LI_HIP_CHECK(d_edges.ensure(E)); TC2LI_HIP_CHECK(d_pose_var.ensure(n_poses)); TC2LI_HIP_CHECK(d_pt_off.ensure(P + 1));
+    TC2LI_HIP_CHECK(d_pt_edges.ensure(E)); TC2LI_HIP_CHECK(d_pv_off.ensure(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.ensure(pv_edges.size()));
+    TC2LI_HIP_CHECK(d_depth.ensure(E));
+    TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
+    TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
+    if (poses7) {
+        poses.resize(n_poses);
+        for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_points.p, points3, 3 * P * sizeof(double), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_edges.p, edges, E * sizeof(BaEdge), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_var.p, pose_var.data(), n_poses * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_off.p, pt_off.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_edges.p, pt_edges.data(), E * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_off.p, pv_off.data(), (n_free + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_edges.p, pv_edges.data(), pv_edges.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, at_elems * sizeof(double), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, at_elems * sizeof(double), st));
+
+    pb = BaProblemDev{};
+    pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
+    memcpy(&pb.cam, cam, sizeof(CameraD));
+    const float dm = sqrtf(5.991f), ds = sqrtf(7.815f);  // thHuberMono / thHuberStereo are floats (OptimizerWithLidar.cc:219-220)
+    pb.delta_mono = dm; pb.delta_stereo = ds;
+    pb.dsqr_mono = (float)((double)dm * (double)dm); pb.dsqr_stereo = (float)((double)ds * (double)ds);
+    pb.poses = d_poses.p; pb.poses_trial = d_poses_trial.p; pb.points = d_points.p; pb.points_trial = d_points_trial.p;
+    pb.edges = d_edges.p; pb.pose_var = d_pose_var.p; pb.pt_off = d_pt_off.p; pb.pt_edges = d_pt_edges.p; pb.pv_off = d_pv_off.p; pb.pv_edges = d_pv_edges.p;
+    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
+    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
+    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
+
+        return TC2LI_OK;
+    }
+};
 
 }  // namespace
 
@@ -117,49 +224,16 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     hipStream_t st = (hipStream_t)stream_;
     if (stats) memset(stats, 0, sizeof(*stats));
     if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
-    // ---- structure: free-pose numbering, CSR by landmark and by free pose ----
-    std::vector<int> pose_var(n_poses, -1);
-    int n_free = 0;
-    std::vector<uint8_t> used(n_poses, 0);
-    for (int e = 0; e < n_edges; ++e) {
-        if (edges[e].pose < 0 || edges[e].pose >= n_poses || edges[e].point < 0 || edges[e].point >= n_points) {
-            set_error("edge %d references pose %d / point %d out of range", e, edges[e].pose, edges[e].point);
-            return TC2LI_ERR_INVALID;
-        }
-        used[edges[e].pose] = 1;
-    }
+    std::vector<uint8_t> extra_used;
     if (lidar_window) {
         if (lidar_window->n_keyframes < 1 || !lidar_window->pose_index) { set_error("lidar window: invalid argument"); return TC2LI_ERR_INVALID; }
+        extra_used.assign(n_poses, 0);
         for (int i = 0; i < lidar_window->n_keyframes; ++i) {
             const int k = lidar_window->pose_index[i];
             if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
-            used[k] = 1;
+            extra_used[k] = 1;
         }
     }
-    for (int k = 0; k < n_poses; ++k) if (!fixed[k] && used[k]) pose_var[k] = n_free++;
-    std::vector<int> pt_off(n_points + 1, 0), pt_edges(n_edges), pv_off(n_free + 1, 0);
-    for (int e = 0; e < n_edges; ++e) { pt_off[edges[e].point + 1]++; if (pose_var[edges[e].pose] >= 0) pv_off[pose_var[edges[e].pose] + 1]++; }
-    for (int l = 0; l < n_points; ++l) {
-        if (pt_off[l + 1] == 0) { set_error("point %d has no edge", l); return TC2LI_ERR_INVALID; }
-        pt_off[l + 1] += pt_off[l];
-    }
-    for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
-    const int n_free_edges = pv_off[n_free];
-    std::vector<int> pv_edges(std::max(n_free_edges, 1));
-    {
-        std::vector<int> fl(pt_off.begin(), pt_off.end() - 1), fp(pv_off.begin(), pv_off.end() - 1);
-        for (int e = 0; e < n_edges; ++e) {
-            pt_edges[fl[edges[e].point]++] = e;
-            const int i = pose_var[edges[e].pose];
-            if (i >= 0) pv_edges[fp[i]++] = e;
-        }
-    }
-    const int np = 6 * n_free, np_pad = std::max(16, (np + 15) / 16 * 16);
-    const int k_total = 3 * n_points;
-    const int n_slices = std::max(1, std::min(64, k_total / 64));
-    const int k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
-
-    // ---- device memory: a process-wide workspace that only grows (hipMalloc per call would dominate the run time) ----
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
     BalmTerm* lidar = nullptr;
@@ -168,55 +242,19 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
         if (rc < 0) return rc;
         lidar = &ws.lidar;
     }
-    auto &d_poses = ws.d_poses, &d_poses_trial = ws.d_poses_trial;
-    auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
-         &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
-         &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
-         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
-    auto& d_edges = ws.d_edges;
-    auto &d_pose_var = ws.d_pose_var, &d_pt_off = ws.d_pt_off, &d_pt_edges = ws.d_pt_edges, &d_pv_off = ws.d_pv_off, &d_pv_edges = ws.d_pv_edges;
-    auto& d_depth = ws.d_depth;
+    VisualProblem vp;
+    {
+        const int rc = vp.setup(ws, poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, extra_used.empty() ? nullptr : extra_used.data(), st);
+        if (rc < 0) return rc;
+    }
+    BaProblemDev& pb = vp.pb;
+    const std::vector<int>& pose_var = vp.pose_var;
+    std::vector<Se3>& poses = vp.poses;
+    const int n_free = vp.n_free, np = vp.np, n_slices = vp.n_slices, k_per_slice = vp.k_per_slice;
     auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
+    auto &d_Hpp = ws.d_Hpp, &d_chi2 = ws.d_chi2;
+    auto& d_depth = ws.d_depth;
     const size_t E = n_edges, P = n_points;
-    const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
-    TC2LI_HIP_CHECK(d_poses.ensure(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
-    TC2LI_HIP_CHECK(d_points.ensure(3 * P)); TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
-    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(9 * E)); TC2LI_HIP_CHECK(d_cp.ensure(27 * E));
-    TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
-    TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
-    TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_AT.ensure(at_elems)); TC2LI_HIP_CHECK(d_BT.ensure(at_elems));
-    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 4 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
-    TC2LI_HIP_CHECK(d_edges.ensure(E)); TC2LI_HIP_CHECK(d_pose_var.ensure(n_poses)); TC2LI_HIP_CHECK(d_pt_off.ensure(P + 1));
-    TC2LI_HIP_CHECK(d_pt_edges.ensure(E)); TC2LI_HIP_CHECK(d_pv_off.ensure(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.ensure(pv_edges.size()));
-    TC2LI_HIP_CHECK(d_depth.ensure(E));
-    TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
-    TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
-    std::vector<Se3> poses(n_poses);
-    for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_points.p, points3, 3 * P * sizeof(double), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_edges.p, edges, E * sizeof(BaEdge), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_var.p, pose_var.data(), n_poses * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_off.p, pt_off.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_edges.p, pt_edges.data(), E * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_off.p, pv_off.data(), (n_free + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_edges.p, pv_edges.data(), pv_edges.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, at_elems * sizeof(double), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, at_elems * sizeof(double), st));
-
-    BaProblemDev pb{};
-    pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
-    memcpy(&pb.cam, cam, sizeof(CameraD));
-    const float dm = sqrtf(5.991f), ds = sqrtf(7.815f);  // thHuberMono / thHuberStereo are floats (OptimizerWithLidar.cc:219-220)
-    pb.delta_mono = dm; pb.delta_stereo = ds;
-    pb.dsqr_mono = (float)((double)dm * (double)dm); pb.dsqr_stereo = (float)((double)ds * (double)ds);
-    pb.poses = d_poses.p; pb.poses_trial = d_poses_trial.p; pb.points = d_points.p; pb.points_trial = d_points_trial.p;
-    pb.edges = d_edges.p; pb.pose_var = d_pose_var.p; pb.pt_off = d_pt_off.p; pb.pt_edges = d_pt_edges.p; pb.pv_off = d_pv_off.p; pb.pv_edges = d_pv_edges.p;
-    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
-    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
-    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -358,6 +396,230 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                   uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream) {
     return tc2li_local_lv_bundle_adjustment(poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, iterations, lambda_init,
                                             stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, stream);
+}
+
+static_assert(sizeof(tc2li_imu_calib) == sizeof(ImuCalib), "ABI layout");
+
+int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
+                                           const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges,
+                                           int n_edges, const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam,
+                                           int iterations, double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                           uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
+    if (!kfs || !fixed || !has_imu || !calib || !points3 || !edges || !cam || n_kfs <= 0 || n_points <= 0 || n_edges <= 0 || n_links < 0 ||
+        (n_links > 0 && !links) || iterations < 0) {
+        set_error("tc2li_local_inertial_bundle_adjustment: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    // ---- inertial edges ----
+    std::vector<InertialLinkHost> L(n_links);
+    std::vector<uint8_t> extra_used(n_kfs, 0);
+    for (int l = 0; l < n_links; ++l) {
+        const tc2li_inertial_link& in = links[l];
+        if (in.kf1 < 0 || in.kf1 >= n_kfs || in.kf2 < 0 || in.kf2 >= n_kfs || !in.preintegrated) { set_error("inertial link %d: invalid keyframe index or null pre-integration", l); return TC2LI_ERR_INVALID; }
+        if (!has_imu[in.kf1] || !has_imu[in.kf2]) { set_error("inertial link %d joins a keyframe without IMU state", l); return TC2LI_ERR_INVALID; }
+        L[l].kf1 = in.kf1; L[l].kf2 = in.kf2; L[l].robust = in.robust != 0; L[l].pre = in.preintegrated;
+        if (!L[l].prepare(in.info_scale)) { set_error("inertial link %d: the pre-integration covariance is not positive definite", l); return TC2LI_ERR_INVALID; }
+        extra_used[in.kf1] = extra_used[in.kf2] = 1;
+    }
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    VisualProblem vp;
+    {
+        const int rc = vp.setup(ws, nullptr, fixed, n_kfs, points3, n_points, edges, n_edges, cam, extra_used.data(), st);
+        if (rc < 0) return rc;
+    }
+    BaProblemDev& pb = vp.pb;
+    const std::vector<int>& pose_var = vp.pose_var;
+    const int n_free = vp.n_free, np = vp.np;
+    std::vector<int> imu_var(n_kfs, -1);
+    int n_imu = 0;
+    for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && extra_used[k]) imu_var[k] = n_imu++;
+    const int n = np + 9 * n_imu;
+    // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
+    std::vector<ImuPose> hp(n_kfs), hp_trial(n_kfs);
+    std::vector<ImuVertexState> sv(n_kfs), sv_trial(n_kfs);
+    for (int k = 0; k < n_kfs; ++k) {
+        memcpy(hp[k].Rcw, kfs[k].Rcw, 72); memcpy(hp[k].tcw, kfs[k].tcw, 24); memcpy(hp[k].Rwb, kfs[k].Rwb, 72); memcpy(hp[k].twb, kfs[k].twb, 24);
+        hp[k].its = 0; hp[k].pad_ = 0;
+        memcpy(sv[k].v, kfs[k].velocity, 24); memcpy(sv[k].bg, kfs[k].gyro_bias, 24); memcpy(sv[k].ba, kfs[k].acc_bias, 24);
+    }
+    TC2LI_HIP_CHECK(ws.d_iposes.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.d_iposes_trial.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.h_iposes.ensure(n_kfs));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_iposes.p, hp.data(), n_kfs * sizeof(ImuPose), hipMemcpyHostToDevice, st));
+    pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
+    memcpy(&pb.calib, calib, sizeof(ImuCalib));
+    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
+    const size_t E = n_edges, P = n_points;
+
+    const float d_imu_f = sqrtf(16.92f);
+    const double d_imu = d_imu_f;
+    const float dsqr_imu = (float)((double)d_imu_f * (double)d_imu_f);
+    // robust cost of the inertial part at a state; optionally the dense normal equations of the inertial edges
+    std::vector<double> Hi((size_t)n * n), bi(n);
+    auto inertial_cost = [&](const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
+        double chi = 0;
+        if (linearize) { std::fill(Hi.begin(), Hi.end(), 0.0); std::fill(bi.begin(), bi.end(), 0.0); }
+        for (const InertialLinkHost& lk_ : L) {
+            double er[9], J[9 * 24];
+            lk_.evaluate(Pz[lk_.kf1], Sz[lk_.kf1], Pz[lk_.kf2], Sz[lk_.kf2], er, linearize ? J : nullptr);
+            double Oe[9], c2 = 0;
+            for (int r = 0; r < 9; ++r) { double s = 0; for (int k = 0; k < 9; ++k) s += lk_.info[9 * r + k] * er[k]; Oe[r] = s; c2 += er[r] * s; }
+            double rho0 = c2, rho1 = 1.0;
+            if (lk_.robust) huber(c2, d_imu, dsqr_imu, rho0, rho1);
+            chi += rho0;
+            double eg[3], ea[3], Og[3], Oa[3];
+            for (int k = 0; k < 3; ++k) { eg[k] = Sz[lk_.kf2].bg[k] - Sz[lk_.kf1].bg[k]; ea[k] = Sz[lk_.kf2].ba[k] - Sz[lk_.kf1].ba[k]; }
+            for (int r = 0; r < 3; ++r) {
+                Og[r] = lk_.infoG[3 * r] * eg[0] + lk_.infoG[3 * r + 1] * eg[1] + lk_.infoG[3 * r + 2] * eg[2];
+                Oa[r] = lk_.infoA[3 * r] * ea[0] + lk_.infoA[3 * r + 1] * ea[1] + lk_.infoA[3 * r + 2] * ea[2];
+                chi += eg[r] * Og[r] + ea[r] * Oa[r];
+            }
+            if (!linearize) continue;
+            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2], p1 = pose_var[lk_.kf1], p2 = pose_var[lk_.kf2];
+            const int off[6] = {p1 >= 0 ? 6 * p1 : -1, i1 >= 0 ? np + 9 * i1 : -1, i1 >= 0 ? np + 9 * i1 + 3 : -1, i1 >= 0 ? np + 9 * i1 + 6 : -1,
+                                p2 >= 0 ? 6 * p2 : -1, i2 >= 0 ? np + 9 * i2 : -1};
+            const int col[6] = {0, 6, 9, 12, 15, 21}, sz[6] = {6, 3, 3, 3, 6, 3};
+            double OJ[9 * 24];  // (rho' Omega) J
+            for (int r = 0; r < 9; ++r)
+                for (int c = 0; c < 24; ++c) { double t = 0; for (int k = 0; k < 9; ++k) t += rho1 * lk_.info[9 * r + k] * J[24 * k + c]; OJ[24 * r + c] = t; }
+            for (int a = 0; a < 6; ++a) {
+                if (off[a] < 0) continue;
+                for (int r = 0; r < sz[a]; ++r) {
+                    double s = 0;
+                    for (int k = 0; k < 9; ++k) s += J[24 * k + col[a] + r] * (rho1 * Oe[k]);
+                    bi[off[a] + r] -= s;
+                    for (int b2 = 0; b2 < 6; ++b2) {
+                        if (off[b2] < 0) continue;
+                        for (int c = 0; c < sz[b2]; ++c) {
+                            double h = 0;
+                            for (int k = 0; k < 9; ++k) h += J[24 * k + col[a] + r] * OJ[24 * k + col[b2] + c];
+                            Hi[(size_t)(off[a] + r) * n + off[b2] + c] += h;
+                        }
+                    }
+                }
+            }
+            for (int which = 0; which < 2; ++which) {  // EdgeGyroRW / EdgeAccRW: J = (-I, I)
+                const double* Om = which == 0 ? lk_.infoG : lk_.infoA;
+                const double* Oe3 = which == 0 ? Og : Oa;
+                const int o1 = i1 >= 0 ? np + 9 * i1 + 3 + 3 * which : -1, o2 = i2 >= 0 ? np + 9 * i2 + 3 + 3 * which : -1;
+                for (int r = 0; r < 3; ++r) {
+                    if (o1 >= 0) bi[o1 + r] += Oe3[r];
+                    if (o2 >= 0) bi[o2 + r] -= Oe3[r];
+                    for (int c = 0; c < 3; ++c) {
+                        if (o1 >= 0) Hi[(size_t)(o1 + r) * n + o1 + c] += Om[3 * r + c];
+                        if (o2 >= 0) Hi[(size_t)(o2 + r) * n + o2 + c] += Om[3 * r + c];
+                        if (o1 >= 0 && o2 >= 0) { Hi[(size_t)(o1 + r) * n + o2 + c] -= Om[3 * r + c]; Hi[(size_t)(o2 + r) * n + o1 + c] -= Om[3 * r + c]; }
+                    }
+                }
+            }
+        }
+        return chi;
+    };
+
+    auto stopped = [&] { return stop_flag && *stop_flag; };
+    double lambda = lambda_init, ni = 2, last_chi = 0;
+    int n_bad = 0, done = 0, trials_total = 0;
+    bool ok = true;
+    std::vector<double> M((size_t)std::max(n * n, 1)), rhs(std::max(n, 1)), bfull(std::max(n, 1)), x(std::max(n, 1), 0.0);
+    for (int it = 0; it < iterations && !stopped() && ok; ++it) {
+        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        const double chi_imu = inertial_cost(hp, sv, true);  // overlaps with the kernels
+        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        double currentChi = chi_imu + h_scal.p[0], tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) {
+            if (stats) stats->initial_chi2 = currentChi;
+            last_chi = currentChi;
+            if (!(lambda_init > 0)) {  // computeLambdaInit over the whole diagonal (not used by the reference's settings)
+                double mx = std::max(h_scal.p[1], h_scal.p[2]);
+                for (int j = np; j < n; ++j) mx = std::max(mx, std::fabs(Hi[(size_t)j * n + j]));
+                lambda = 1e-5 * mx;
+            }
+            ni = 2;
+            n_bad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            ba_launch_schur(pb, lambda, vp.n_slices, vp.k_per_slice, h_S.p, h_bs.p, st);
+            TC2LI_HIP_CHECK(hipGetLastError());
+            TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+            // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c < n; ++c) {
+                    double v = Hi[(size_t)r * n + c];
+                    if (r < np && c < np) v += h_S.p[(size_t)r * np + c];
+                    else if (r == c) v += lambda;
+                    M[(size_t)r * n + c] = v;
+                }
+            for (int j = 0; j < n; ++j) {
+                bfull[j] = bi[j] + (j < np ? h_bs.p[np + j] : 0.0);
+                rhs[j] = bi[j] + (j < np ? h_bs.p[j] : 0.0);
+            }
+            const bool ok2 = n == 0 ? true : ldlt_solve_small(M.data(), n, rhs.data(), x.data(), false);
+            double scale = 0;
+            for (int j = 0; j < n; ++j) scale += x[j] * (lambda * x[j] + bfull[j]);
+            if (ok2) {
+                if (np) memcpy(h_xp.p, x.data(), np * sizeof(double));
+                ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
+                TC2LI_HIP_CHECK(hipGetLastError());
+                TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_iposes.p, pb.iposes_trial, n_kfs * sizeof(ImuPose), hipMemcpyDeviceToHost, st));
+                sv_trial = sv;
+                for (int k = 0; k < n_kfs; ++k)
+                    if (imu_var[k] >= 0) {
+                        const double* u = &x[np + 9 * imu_var[k]];
+                        for (int c = 0; c < 3; ++c) { sv_trial[k].v[c] += u[c]; sv_trial[k].bg[c] += u[3 + c]; sv_trial[k].ba[c] += u[6 + c]; }
+                    }
+                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                memcpy(hp_trial.data(), ws.h_iposes.p, n_kfs * sizeof(ImuPose));
+                tempChi = inertial_cost(hp_trial, sv_trial, false) + h_scal.p[4];
+                scale += h_scal.p[3];
+                last_chi = tempChi;
+            } else {
+                tempChi = std::numeric_limits<double>::max();
+            }
+            rho = currentChi - tempChi;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                std::swap(pb.iposes, pb.iposes_trial);
+                std::swap(pb.points, pb.points_trial);
+                hp.swap(hp_trial);
+                sv.swap(sv_trial);
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+            qmax++;
+            trials_total++;
+        } while (rho < 0 && qmax < 10 && !stopped());
+        ++done;
+        if (stats) stats->final_lambda = lambda;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
+        if (n_bad >= 3) ok = false;
+    }
+    if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; stats->final_chi2 = last_chi; }
+    // ---- results ----
+    ba_launch_depth(pb, ws.d_depth.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(points3, pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (edge_chi2) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_chi2, ws.d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (edge_depth_positive) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_depth_positive, ws.d_depth.p, E, hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < n_kfs; ++k) {
+        memcpy(kfs[k].Rcw, hp[k].Rcw, 72); memcpy(kfs[k].tcw, hp[k].tcw, 24); memcpy(kfs[k].Rwb, hp[k].Rwb, 72); memcpy(kfs[k].twb, hp[k].twb, 24);
+        memcpy(kfs[k].velocity, sv[k].v, 24); memcpy(kfs[k].gyro_bias, sv[k].bg, 24); memcpy(kfs[k].acc_bias, sv[k].ba, 24);
+    }
+    return done;
 }
 
 int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int max_concurrency,

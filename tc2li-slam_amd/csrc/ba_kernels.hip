@@ -23,10 +23,15 @@ namespace tc2li {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void edge_state(const Se3* __restrict__ poses, const double* __restrict__ points, const BaEdge& e,
-                                           const CameraD& cam, double p[3], double err[3], int& dim, double& chi2) {
-    se3_map(poses[e.pose], points + 3 * (size_t)e.point, p);
-    dim = edge_error(p, e, cam, err);
+// error of one projection edge at the given estimate: g2o's SE3 vertices (local BA) or ImuCamPose vertices (inertial BA)
+__device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, const BaEdge& e, double p[3], double err[3], int& dim, double& chi2) {
+    const double* X = (trial ? pb.points_trial : pb.points) + 3 * (size_t)e.point;
+    if (pb.inertial) {
+        dim = imu_edge_error((trial ? pb.iposes_trial : pb.iposes)[e.pose], X, e, pb.cam, p, err);
+    } else {
+        se3_map((trial ? pb.poses_trial : pb.poses)[e.pose], X, p);
+        dim = edge_error(p, e, pb.cam, err);
+    }
     chi2 = 0;
     for (int d = 0; d < dim; ++d) chi2 += err[d] * e.info * err[d];
 }
@@ -50,16 +55,21 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
         const BaEdge ed = pb.edges[e];
         double p[3], err[3], c2;
         int dim;
-        edge_state(pb.poses, pb.points, ed, pb.cam, p, err, dim, c2);
+        edge_state(pb, false, ed, p, err, dim, c2);
         const bool stereo = ed.ur >= 0;
         double rho1;
         huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
         pb.chi2[e] = c2;
         pb.rho0[e] = rho0;
-        double R[9], A[9], B[18];
-        quat_to_matrix(pb.poses[ed.pose].q, R);
-        point_jacobian(p, R, stereo, pb.cam, A);
-        pose_jacobian(p, stereo, false, pb.cam, B);
+        double A[9], B[18];
+        if (pb.inertial) {
+            imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
+        } else {
+            double R[9];
+            quat_to_matrix(pb.poses[ed.pose].q, R);
+            point_jacobian(p, R, stereo, pb.cam, A);
+            pose_jacobian(p, stereo, false, pb.cam, B);
+        }
         const double w = rho1 * ed.info;
         double wr[3];  // omega_r = -rho' * Omega * e
 #pragma unroll
@@ -355,6 +365,16 @@ __global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nb
     const int k = ((int)blockIdx.x - nbp) * 256 + threadIdx.x;
     if (k >= pb.n_poses) return;
     const int i = pb.pose_var[k];
+    if (pb.inertial) {
+        ImuPose T = pb.iposes[k];
+        if (i >= 0) {
+            double u[6];
+            for (int r = 0; r < 6; ++r) u[r] = xp[6 * i + r];
+            imu_pose_update(T, pb.calib, u);
+        }
+        pb.iposes_trial[k] = T;
+        return;
+    }
     if (i < 0) { pb.poses_trial[k] = pb.poses[k]; return; }
     double u[6];
     for (int r = 0; r < 6; ++r) u[r] = xp[6 * i + r];
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double
     else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
 }
 
-__global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb, const Se3* __restrict__ poses, const double* __restrict__ points) {
+__global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) {
     __shared__ double s_sum[256];
     const int e = blockIdx.x * 256 + threadIdx.x;
     double rho0 = 0;
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb, const Se3* _
         const BaEdge ed = pb.edges[e];
         double p[3], err[3], c2;
         int dim;
-        edge_state(poses, points, ed, pb.cam, p, err, dim, c2);
+        edge_state(pb, true, ed, p, err, dim, c2);
         const bool stereo = ed.ur >= 0;
         double rho1;
         huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
@@ -390,8 +410,14 @@ __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __re
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= pb.n_edges) return;
     const BaEdge ed = pb.edges[e];
+    const double* X = pb.points + 3 * (size_t)ed.point;
+    if (pb.inertial) {  // ImuCamPose::isDepthPositive
+        const ImuPose& T = pb.iposes[ed.pose];
+        depth_pos[e] = (T.Rcw[6] * X[0] + T.Rcw[7] * X[1] + T.Rcw[8] * X[2] + T.tcw[2]) > 0.0;
+        return;
+    }
     double p[3];
-    se3_map(pb.poses[ed.pose], pb.points + 3 * (size_t)ed.point, p);
+    se3_map(pb.poses[ed.pose], X, p);
     depth_pos[e] = p[2] > 0.0;
 }
 
@@ -421,7 +447,7 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
     const int nbp = (pb.n_points + 3) / 4;  // four landmarks per workgroup
     hipLaunchKernelGGL(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
-    hipLaunchKernelGGL(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, pb.poses_trial, pb.points_trial);
+    hipLaunchKernelGGL(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
     hipLaunchKernelGGL(k_ba_trial_reduce, dim3(2), dim3(256), 0, st, pb, scale_out, chi_out);
 }
 

@@ -1,0 +1,70 @@
+"""GPU parity of the visual-inertial local BA with the oracle: same Levenberg-Marquardt
+trials, optimised keyframe states within 1e-4 relative (BASELINE.json's bar for SE3 poses), per-edge chi2, outlier flags.
+Both sides get the same pre-integrations (the product's, row a11), so that this test isolates the optimisation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def problem(pkg, oracle, synthetic, seed, **kw):
+    w = synthetic.inertial_window(seed, **kw)
+    pre, pre298 = [], []
+    for s, t1, t2 in w["samples"]:
+        p = pkg.capi.Preintegrated(w["bias6"], *synthetic.IMU_NOISE)
+        p.preintegrate(s, t1, t2)
+        pre.append(p)
+        pre298.append(oracle.pack_preintegrated(p.fields(), w["bias6"]))
+    w["pre"], w["pre298"] = pre, np.stack(pre298)
+    return w
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("seed,n_opt,n_pts,iters,lam", [(0, 6, 400, 10, 1.0), (1, 10, 900, 10, 1.0), (2, 8, 600, 4, 1e-2), (3, 3, 200, 10, 1.0)])
+def test_local_inertial_ba(pkg, oracle, synthetic, seed, n_opt, n_pts, iters, lam):
+    w = problem(pkg, oracle, synthetic, seed, n_opt=n_opt, n_points=n_pts)
+    want = oracle.local_inertial_ba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], w["pre298"], w["cam"],
+                                    iterations=iters, lambda_init=lam)
+    kf, pts, chi2, dpos, stats = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"],
+                                                                          pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"],
+                                                                          iterations=iters, lambda_init=lam)
+    assert stats.iterations == want[4]
+    assert stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.initial_chi2 - want[6][0]) <= 1e-6 * want[6][0]
+    assert abs(stats.final_chi2 - want[6][1]) <= 1e-6 * want[6][1]
+    for k in range(len(kf)):
+        assert rel(kf[k, :24], want[0][k, :24]) < RTOL          # camera and body pose
+        assert np.allclose(kf[k, 24:], want[0][k, 24:], rtol=RTOL, atol=1e-6)  # velocity, biases
+    assert np.array_equal(kf[0], w["kf33"][0])                  # the fixed keyframe
+    assert np.allclose(pts, want[1], rtol=RTOL, atol=1e-5)
+    assert np.array_equal(dpos, want[3])
+    # the two sides evaluate the bias-corrected pre-integration in float / double (row a11): the optimum moves by ~1e-6, the
+    # reprojection errors of single edges by ~1e-4 px
+    assert np.allclose(chi2, want[2], rtol=5e-3, atol=1e-3)
+    assert np.array_equal(chi2 > 7.815, want[2] > 7.815) or np.sum((chi2 > 7.815) != (want[2] > 7.815)) <= 1
+    # it really optimises
+    assert stats.final_chi2 < 0.3 * stats.initial_chi2
+    err0 = np.linalg.norm(w["kf33"][:, 21:24] - w["kf33_true"][:, 21:24], axis=1).mean()
+    err1 = np.linalg.norm(kf[:, 21:24] - w["kf33_true"][:, 21:24], axis=1).mean()
+    assert err1 < 0.6 * err0
+
+
+def test_inertial_ba_argument_errors(pkg, oracle, synthetic):
+    w = problem(pkg, oracle, synthetic, 0, n_opt=3, n_points=150)
+    bad = w["link4"].copy(); bad[0, 1] = 99
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]), bad,
+                                                  w["pre"], w["cam"])
+    no_imu = w["has_imu"].copy(); no_imu[2] = 0
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], no_imu, w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]), w["link4"],
+                                                  w["pre"], w["cam"])
+    # without inertial links it is a visual BA in the ImuCamPose parameterisation
+    r = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]),
+                                                  np.zeros((0, 4)), [], w["cam"])
+    assert r[4].iterations >= 1 and r[4].final_chi2 < r[4].initial_chi2
