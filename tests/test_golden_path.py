@@ -1,0 +1,173 @@
+"""The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py):
+ - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
+ - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
+Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
+import os
+
+import numpy as np
+import pytest
+
+RTOL = 1e-4
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def kp_floats(k):
+    return np.stack([k[f].astype(np.float32) for f in ("x", "y", "size", "angle", "response")] + [k["octave"].astype(np.float32)], 1)
+
+
+def points(pkg_or_oracle, xyz, intensity=None, curvature=None):
+    a = np.zeros(len(xyz), pkg_or_oracle.POINT_DTYPE)
+    a["x"], a["y"], a["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if intensity is not None:
+        a["intensity"] = intensity
+    if curvature is not None:
+        a["curvature"] = curvature
+    return a
+
+
+def split(flat, off):
+    return [np.ascontiguousarray(flat[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def inertial_samples(g):
+    s, off, t12 = g["samples"], g["sample_off"], g["t12"]
+    return [(np.ascontiguousarray(s[off[i]:off[i + 1]]), float(t12[i, 0]), float(t12[i, 1])) for i in range(len(t12))]
+
+
+# ---- the oracle against the vectors (CPU) --------------------------------------------------------------------------------
+def test_oracle_stereo_golden(oracle, golden_dir):
+    g = load(golden_dir, "stereo_a")
+    ol, orr = oracle.OrbOracle(nfeatures=int(g["nfeatures"])), oracle.OrbOracle(nfeatures=int(g["nfeatures"]))
+    _, kl, dl = ol.extract(g["left"])
+    _, kr, dr = orr.extract(g["right"])
+    assert np.array_equal(kp_floats(kl), g["kps_left"]) and np.array_equal(dl, g["desc_left"])
+    assert np.array_equal(kp_floats(kr), g["kps_right"]) and np.array_equal(dr, g["desc_right"])
+    u, d, s = oracle.stereo_match(ol, orr, kl, dl, kr, dr, float(g["bf"]), float(g["b"]))
+    assert np.array_equal(u, g["u_right"]) and np.array_equal(d, g["depth"]) and np.array_equal(s, g["sad"])
+
+
+def test_oracle_lidar_golden(oracle, golden_dir):
+    g = load(golden_dir, "lidar_a")
+    tree = oracle.KdTree(points(oracle, g["map_xyz"]))
+    fx = oracle.feature_extraction(tree, points(oracle, g["body_xyz"], g["body_intensity"], g["body_curvature"]), g["state24"])
+    assert np.array_equal(fx["selected"], g["selected"]) and fx["effct_feat_num"] == int(g["effct_feat_num"])
+    assert np.array_equal(np.stack([fx["world"][f] for f in "xyz"], 1), g["world_xyz"])
+    assert np.array_equal(np.stack([fx["normvec"][f] for f in ("x", "y", "z", "intensity")], 1), g["normvec"])
+    assert np.array_equal(np.stack([fx["corr_normvect"][f] for f in ("x", "y", "z", "intensity")], 1), g["corr_normvect"])
+
+
+def test_oracle_ba_golden(oracle, golden_dir):
+    g = load(golden_dir, "ba_a")
+    r = oracle.local_ba(g["poses"], g["fixed"], g["points"], g["edges"], g["cam"], iterations=10, lambda_init=0.0)
+    assert r[4] == int(g["v_iterations"]) and np.array_equal(r[5]["trials"], g["v_trace_trials"])
+    assert np.allclose(r[0], g["v_poses"], rtol=0, atol=1e-10) and np.allclose(r[1], g["v_points"], rtol=0, atol=1e-9)
+    assert np.allclose(r[5]["chi2"], g["v_trace_chi2"], rtol=1e-9) and np.allclose(r[5]["lam"], g["v_trace_lambda"], rtol=1e-9)
+    assert np.array_equal(r[3], g["v_depth_pos"])
+    clouds = split(g["clouds"], g["cloud_off"])
+    lv = oracle.local_ba_lidar(g["poses"], g["fixed"], g["points"], g["edges"], g["cam"], g["win"], clouds, g["Tcl7"], 1.0)
+    assert lv[4] == int(g["lv_iterations"]) and lv[6] == int(g["lv_n_planes"]) and np.array_equal(lv[5]["trials"], g["lv_trace_trials"])
+    assert np.allclose(lv[0], g["lv_poses"], rtol=0, atol=1e-10)
+    assert np.allclose(lv[5]["chi2"], g["lv_trace_chi2"], rtol=1e-9) and np.allclose(lv[5]["lam"], g["lv_trace_lambda"], rtol=1e-9)
+    lw = oracle.lidar_window_evaluate(g["poses"], g["win"], clouds, g["Tcl7"])
+    assert lw[0] == int(g["lw_n_planes"]) and np.isclose(lw[1], float(g["lw_residual"]), rtol=1e-12)
+    assert np.allclose(lw[2], g["lw_JacT"], rtol=1e-10, atol=1e-12) and np.allclose(lw[3], g["lw_Hessian"], rtol=1e-10, atol=1e-12)
+
+
+def test_oracle_balm_golden(oracle, golden_dir):
+    g = load(golden_dir, "balm_a")
+    n, res, J, H, _ = oracle.balm_evaluate(g["Twl"], split(g["clouds"], g["cloud_off"]))
+    assert n == int(g["n_planes"]) and n > 10
+    assert np.isclose(res, float(g["residual"]), rtol=1e-12)
+    assert np.allclose(J, g["JacT"], rtol=1e-10, atol=1e-12) and np.allclose(H, g["Hessian"], rtol=1e-10, atol=1e-12)
+
+
+def test_oracle_inertial_golden(oracle, golden_dir):
+    g = load(golden_dir, "inertial_a")
+    pre = []
+    for s, t1, t2 in inertial_samples(g):
+        _, f = oracle.imu_preintegrate(s, t1, t2, g["bias6"], *g["noise"])
+        pre.append(oracle.pack_preintegrated(f, g["bias6"]))
+    assert np.array_equal(np.stack(pre), g["pre298"])
+    r = oracle.local_inertial_ba(g["kf33"], g["fixed"], g["has_imu"], g["calib24"], g["points"], g["edges"], g["link4"], g["pre298"], g["cam"])
+    assert r[4] == int(g["out_iterations"]) and np.array_equal(r[5]["trials"], g["out_trace_trials"])
+    assert np.allclose(r[0], g["out_kf33"], rtol=0, atol=1e-9) and np.allclose(r[1], g["out_points"], rtol=0, atol=1e-9)
+    assert np.allclose(r[6], g["out_err"], rtol=1e-9)
+
+
+# ---- the product against the vectors (GPU, through the C ABI, no oracle) ---------------------------------------------------
+@pytest.mark.gpu
+def test_product_stereo_golden(pkg, golden_dir):
+    g = load(golden_dir, "stereo_a")
+    h, w = g["left"].shape
+    el = pkg.OrbExtractor(nfeatures=int(g["nfeatures"]), max_width=w, max_height=h, max_images=1)
+    er = pkg.OrbExtractor(nfeatures=int(g["nfeatures"]), max_width=w, max_height=h, max_images=1)
+    _, kl, dl = el.extract(g["left"])
+    _, kr, dr = er.extract(g["right"])
+    assert np.array_equal(kp_floats(kl), g["kps_left"]) and np.array_equal(dl, g["desc_left"])
+    assert np.array_equal(kp_floats(kr), g["kps_right"]) and np.array_equal(dr, g["desc_right"])
+    u, d, s = pkg.compute_stereo_matches(el, er, kl, dl, kr, dr, float(g["bf"]), float(g["b"]))
+    assert np.array_equal(u, g["u_right"]) and np.array_equal(d, g["depth"]) and np.array_equal(s, g["sad"])
+
+
+@pytest.mark.gpu
+def test_product_lidar_golden(pkg, golden_dir):
+    g = load(golden_dir, "lidar_a")
+    fe = pkg.LidarFrontEnd(max_points_per_scan=8192, max_scans=1)
+    m = pkg.LidarMap()
+    m.Build(points(pkg, g["map_xyz"]))
+    fx = fe.feature_extraction(m, points(pkg, g["body_xyz"], g["body_intensity"], g["body_curvature"]), g["state24"])
+    assert np.array_equal(fx["selected"], g["selected"]) and fx["effct_feat_num"] == int(g["effct_feat_num"])
+    assert np.array_equal(np.stack([fx["world"][f] for f in "xyz"], 1), g["world_xyz"])
+    sel = g["selected"].astype(bool)
+    got = np.stack([fx["normvec"][f] for f in ("x", "y", "z", "intensity")], 1)
+    assert np.array_equal(got[sel], g["normvec"][sel])
+    assert np.array_equal(np.stack([fx["corr_normvect"][f] for f in ("x", "y", "z", "intensity")], 1), g["corr_normvect"])
+
+
+@pytest.mark.gpu
+def test_product_ba_golden(pkg, golden_dir):
+    g = load(golden_dir, "ba_a")
+    edges = pkg.pack_ba_edges(g["edges"])
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(g["poses"], g["fixed"], g["points"], edges, g["cam"])
+    assert stats.iterations == int(g["v_iterations"]) and stats.trials == int(g["v_trace_trials"].sum())
+    assert rel(poses, g["v_poses"]) < RTOL and np.allclose(pts, g["v_points"], rtol=RTOL, atol=1e-5)
+    assert np.array_equal(dpos, g["v_depth_pos"]) and np.allclose(chi2, g["v_chi2"], rtol=1e-3, atol=1e-4)
+    clouds = split(g["clouds"], g["cloud_off"])
+    n, res, J, H = pkg.capi.lidar_window_evaluate(g["poses"], g["win"], clouds, g["Tcl7"])
+    assert n == int(g["lw_n_planes"]) and np.isclose(res, float(g["lw_residual"]), rtol=1e-9)
+    scale = np.abs(g["lw_Hessian"]).max()
+    assert np.abs(J - g["lw_JacT"]).max() <= 1e-9 * np.abs(g["lw_JacT"]).max() and np.abs(H - g["lw_Hessian"]).max() <= 1e-9 * scale
+    poses, pts, chi2, dpos, stats, ls = pkg.capi.local_lv_bundle_adjustment(g["poses"], g["fixed"], g["points"], edges, g["cam"], g["win"], clouds,
+                                                                           g["Tcl7"], 1.0)
+    assert stats.iterations == int(g["lv_iterations"]) and stats.trials == int(g["lv_trace_trials"].sum()) and ls.n_planes == int(g["lv_n_planes"])
+    assert rel(poses, g["lv_poses"]) < RTOL and np.allclose(pts, g["lv_points"], rtol=RTOL, atol=1e-5)
+    assert np.array_equal(dpos, g["lv_depth_pos"])
+
+
+@pytest.mark.gpu
+def test_product_inertial_golden(pkg, golden_dir):
+    g = load(golden_dir, "inertial_a")
+    pre = []
+    for i, (s, t1, t2) in enumerate(inertial_samples(g)):
+        p = pkg.capi.Preintegrated(g["bias6"], *[float(x) for x in g["noise"]])
+        p.preintegrate(s, t1, t2)
+        f = p.fields()
+        # row a11 is float arithmetic on both sides; the polar factor of NormalizeRotation differs in the last bits
+        assert np.allclose(f["dR"].ravel(), g["pre298"][i, 1:10], atol=2e-6) and np.allclose(f["dP"], g["pre298"][i, 13:16], rtol=1e-4, atol=1e-6)
+        pre.append(p)
+    kf, pts, chi2, dpos, stats = pkg.capi.local_inertial_bundle_adjustment(g["kf33"], g["fixed"], g["has_imu"], g["calib24"], g["points"],
+                                                                          pkg.pack_ba_edges(g["edges"]), g["link4"], pre, g["cam"])
+    assert stats.iterations == int(g["out_iterations"]) and stats.trials == int(g["out_trace_trials"].sum())
+    for k in range(len(kf)):
+        assert rel(kf[k, :24], g["out_kf33"][k, :24]) < RTOL
+        assert np.allclose(kf[k, 24:], g["out_kf33"][k, 24:], rtol=RTOL, atol=1e-5)
+    assert np.allclose(pts, g["out_points"], rtol=RTOL, atol=1e-4)
+    assert np.array_equal(dpos, g["out_depth_pos"])
+    assert abs(stats.final_chi2 - g["out_err"][1]) <= 1e-3 * g["out_err"][1]
