@@ -475,6 +475,19 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* keyframes, c
                                            const volatile uint8_t* stop_flag, double* edge_chi2,
                                            uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream);
 
+/* OptimizerWithLidar::LocalLVIBA (SF/src/OptimizerWithLidar.cc:489-1100): the visual-inertial local BA plus the LiDAR edge
+ * on the body-frame pose vertices (EdgeLidar, SF/src/G2oTypesWithLidar.cc:33-140; LidarCovisRes::ComputeJandH,
+ * SF/src/LidarRes.cc:89-128).  lidar->pose_index are rows of `keyframes` -- the reference takes the first min(N, 6) optimisable
+ * keyframes when N > 5 (:704-724); Tbl = mLidarParam->mTbl as qx qy qz qw tx ty tz.  The edge's error is sqrt(sum over planes of
+ * N * lambda_min), its information lidar->weight.  lidar == NULL is tc2li_local_inertial_bundle_adjustment. */
+int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const uint8_t* fixed, const uint8_t* has_imu,
+                                      int n_keyframes, const tc2li_imu_calib* calib, double* points3, int n_points,
+                                      const tc2li_ba_edge* edges, int n_edges, const tc2li_inertial_link* links, int n_links,
+                                      const tc2li_camera* cam, int iterations, double lambda_init,
+                                      const volatile uint8_t* stop_flag, double* edge_chi2, uint8_t* edge_depth_positive,
+                                      tc2li_ba_stats* stats, const tc2li_lidar_window* lidar, const float* Tbl,
+                                      tc2li_lidar_ba_stats* lidar_stats, void* stream);
+
 /* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
  * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =
  * LidarCovisRes::ComputeJandHSE3 (SF/src/LidarRes.cc:136-186, with respect to the camera se3 increments).  JacT and

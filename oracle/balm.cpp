@@ -275,14 +275,18 @@ void LidarCovisRes::BuildVoxHess() {  // LidarRes.cc:64-80
     }
 }
 
+SE3fQ se3f_from_rt(const double R[9], const double t[3]) {
+    float Rf[9];
+    SE3fQ T;
+    for (int k = 0; k < 9; ++k) Rf[k] = (float)R[k];
+    mat_to_quat_f(Rf, T.q);
+    for (int k = 0; k < 3; ++k) T.t[k] = (float)t[k];
+    return T;
+}
+
 void LidarCovisRes::UpdatePose(int i, const double Rcw[9], const double tcw[3]) {  // LidarRes.cc:221-235
     if (i >= win_size_) return;
-    float Rf[9];
-    SE3fQ Tcw;
-    for (int k = 0; k < 9; ++k) Rf[k] = (float)Rcw[k];
-    mat_to_quat_f(Rf, Tcw.q);
-    for (int k = 0; k < 3; ++k) Tcw.t[k] = (float)tcw[k];
-    mPoseBuf[i] = twl_from(Tcw, mTcl);
+    mPoseBuf[i] = twl_from(se3f_from_rt(Rcw, tcw), mTcl);
 }
 
 double LidarCovisRes::ComputeError() const {  // evaluate_only_residual, bavoxel.h:276-315
@@ -460,11 +464,49 @@ void LidarCovisRes::ComputeJandHSE3(std::vector<double>& JacT, std::vector<doubl
     }
 }
 
-// ---- EdgeLidarSE3 ---------------------------------------------------------------------------------------------------
+void LidarCovisRes::ComputeJandH(std::vector<double>& JacT, std::vector<double>& Hess) const {  // LidarRes.cc:89-128
+    const int W = win_size_, n = 6 * W;
+    divide_thread(Hess, JacT);
+    // mTlb = mTbl.inverse() (Sophus::SE3f), its rotation cast to double; tbl = mTbl.translation()
+    const float qi[4] = {-mTbl.q[0], -mTbl.q[1], -mTbl.q[2], mTbl.q[3]};
+    float Rf[9];
+    quat_to_mat_f(qi, Rf);
+    M3 Rlb;
+    for (int i = 0; i < 9; ++i) Rlb.m[i] = (double)Rf[i];
+    const V3 tbl{(double)mTbl.t[0], (double)mTbl.t[1], (double)mTbl.t[2]};
+    for (int i = 0; i < W; ++i) {
+        const M3 Rwbi = mPoseBuf[i].R * Rlb;
+        const V3 JacwT{JacT[6 * i], JacT[6 * i + 1], JacT[6 * i + 2]}, JactT{JacT[6 * i + 3], JacT[6 * i + 4], JacT[6 * i + 5]};
+        const V3 rwl = so3f_log(mPoseBuf[i].R);
+        const M3 inverseJr_Rlb_T = T(InverseRightJacobianSO3(rwl) * Rlb);
+        const M3 Rwb_tbl_skew_T = T(Rwbi * hat(tbl));
+        const V3 jw = inverseJr_Rlb_T * JacwT - Rwb_tbl_skew_T * JactT;
+        const V3 jt = T(Rwbi) * JactT;
+        for (int c = 0; c < 3; ++c) { JacT[6 * i + c] = jw[c]; JacT[6 * i + 3 + c] = jt[c]; }
+        double DiT[36] = {0}, Di[36];
+        auto set33 = [&](int r0, int c0, const M3& m, double s) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) DiT[6 * (r0 + r) + c0 + c] += s * m(r, c); };
+        set33(0, 0, inverseJr_Rlb_T, 1.0);
+        set33(0, 3, Rwb_tbl_skew_T, -1.0);
+        set33(3, 3, T(Rwbi), 1.0);
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Di[6 * r + c] = DiT[6 * c + r];
+        for (int j = 0; j < W; ++j) {
+            double Hij[36], out[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hij[6 * r + c] = Hess[(size_t)(6 * i + r) * n + 6 * j + c];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DiT[6 * r + k] * Hij[6 * k + c]; out[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hess[(size_t)(6 * i + r) * n + 6 * j + c] = out[6 * r + c];
+            double Hji[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hji[6 * r + c] = Hess[(size_t)(6 * j + r) * n + 6 * i + c];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += Hji[6 * r + k] * Di[6 * k + c]; out[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hess[(size_t)(6 * j + r) * n + 6 * i + c] = out[6 * r + c];
+        }
+    }
+}
+
+// ---- EdgeLidarSE3 / EdgeLidar -----------------------------------------------------------------------------------------
 void EdgeLidar::computeError(const double* R, const double* t, int W) {  // G2oTypesWithLidar.h:124-140
     for (int i = 0; i < W; ++i) lio->UpdatePose(i, R + 9 * i, t + 3 * i);
     const double r = lio->ComputeError();
-    error = r;
+    error = body ? std::sqrt(r) : r;  // G2oTypesWithLidar.cc:41-42 / G2oTypesWithLidar.h:131
     r1 = r2;
     r2 = r;
     is_calc_hess = !(r1 - r2 < 0);
@@ -472,7 +514,7 @@ void EdgeLidar::computeError(const double* R, const double* t, int W) {  // G2oT
 
 void EdgeLidar::linearizeOplus(const double* R, const double* t, int W) {  // :148-166
     for (int i = 0; i < W; ++i) lio->UpdatePose(i, R + 9 * i, t + 3 * i);
-    if (is_calc_hess) lio->ComputeJandHSE3(JacT, Hessian);
+    if (is_calc_hess) { if (body) lio->ComputeJandH(JacT, Hessian); else lio->ComputeJandHSE3(JacT, Hessian); }
 }
 
 }  // namespace oracle

@@ -10,6 +10,9 @@
 //                                                         SF/src/LidarRes.cc:32-75, 136-186, 221-235
 //   EdgeLidarSE3::{computeError, linearizeOplus, constructQuadraticForm, computeQuadraticFormLidarRes}
 //                                                         SF/include/G2oTypesWithLidar.h:118-236
+//   LidarCovisRes::ComputeJandH (body-frame increment of VertexPose)  SF/src/LidarRes.cc:89-128
+//   EdgeLidar::{computeError, linearizeOplus, computeQuadraticFormLidarRes} (the edge of LocalLVIBA)
+//                                                         SF/src/G2oTypesWithLidar.cc:33-140
 //   InverseRightJacobianSO3                               SF/src/G2oTypes.cc:823-839
 // The reference quirks listed in SURVEY.md section 7 are reproduced on purpose (Hessian.block<6,6>(i,i) with element
 // offsets, b -= info * A^T without the residual, Hessian reuse while the cost grows, float SE3 round trip in UpdatePose).
@@ -46,9 +49,13 @@ struct PlaneVoxel {            // one entry of VOX_HESS: plvec_voxels[a] (per wi
 
 struct SE3fQ { float q[4] = {0, 0, 0, 1}; float t[3] = {0, 0, 0}; };  // Sophus::SE3f
 
+// Sophus::SE3f(R.cast<float>(), t.cast<float>())
+SE3fQ se3f_from_rt(const double R[9], const double t[3]);
+
 class LidarCovisRes {
 public:
     explicit LidarCovisRes(const SE3fQ& Tcl) : mTcl(Tcl) {}
+    LidarCovisRes(const SE3fQ& Tcl, const SE3fQ& Tbl) : mTcl(Tcl), mTbl(Tbl) {}
     int win_size_ = 20;
     // pose = Tcw of the keyframe (Sophus::SE3f), cloud = its surface cloud in the LiDAR frame (x, y, z per point)
     void AddFromKeyFrame(const SE3fQ& Tcw, const std::vector<float>& cloud_xyz);
@@ -56,6 +63,7 @@ public:
     void UpdatePose(int i, const double Rcw[9], const double tcw[3]);
     double ComputeError() const;
     void ComputeJandHSE3(std::vector<double>& JacT, std::vector<double>& Hess) const;  // 6W and (6W)^2 row-major
+    void ComputeJandH(std::vector<double>& JacT, std::vector<double>& Hess) const;     // w.r.t. ImuCamPose::Update's increment
     const std::vector<PlaneVoxel>& planes() const { return mVoxHess; }
     const std::vector<IMUST>& poses() const { return mPoseBuf; }
     double divide_thread(std::vector<double>& Hess, std::vector<double>& JacT) const;
@@ -67,15 +75,17 @@ private:
     std::vector<PlaneVoxel> mVoxHess;
     std::vector<IMUST> mPoseBuf;
     IMUST mPose0;
-    SE3fQ mTcl;
+    SE3fQ mTcl, mTbl;
     int mCurrPosId = 0;
     void acc_evaluate2(int head, int end, std::vector<double>& Hess, std::vector<double>& JacT, double& residual) const;
 };
 
-// The edge state machine of EdgeLidarSE3 (G2oTypesWithLidar.h:88-236) over W window vertices.
+// The edge state machine of EdgeLidarSE3 (G2oTypesWithLidar.h:88-236) over W window vertices; body = true is EdgeLidar on
+// VertexPose (G2oTypesWithLidar.cc:33-75): error = sqrt(r), derivatives from ComputeJandH.
 struct EdgeLidar {
     LidarCovisRes* lio = nullptr;
     double information = 1;
+    bool body = false;
     std::vector<double> JacT, Hessian;
     double error = 0, r1 = 1000, r2 = 1000;
     bool is_calc_hess = true;

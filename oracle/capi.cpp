@@ -816,6 +816,83 @@ int oracle_local_inertial_ba(double* kf33, const uint8_t* fixed, const uint8_t* 
     for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
     return r.iterations;
 }
+// OptimizerWithLidar::LocalLVIBA: the same with EdgeLidar over the keyframes win_kf (rows of kf33)
+int oracle_local_lviba(double* kf33, const uint8_t* fixed, const uint8_t* has_imu, int n_kf, const double* calib24, double* points3,
+                       int n_points, const double* edges6, int n_edges, const double* link4, const float* pre298, int n_links,
+                       const double* cam5, int iterations, double lambda_init, const int* win_kf, int n_win, const float* clouds,
+                       const int* cloud_off, const float* Tcl7, const float* Tbl7, double weight, double* chi2_out, uint8_t* depth_pos,
+                       double* err2, double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap, int* n_planes,
+                       double* lidar_out /* [2 + 6W + 36W^2]: error, chi2, JacT, Hessian at the end */) {
+    std::vector<InertialKeyFrame> kfs(n_kf);
+    for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, fixed[k], has_imu[k]);
+    std::vector<Preintegrated> pre;
+    pre.reserve(n_links);
+    std::vector<InertialLink> links(n_links);
+    for (int l = 0; l < n_links; ++l) pre.push_back(preint_from(pre298 + 298 * (size_t)l));
+    for (int l = 0; l < n_links; ++l) {
+        links[l].kf1 = (int)link4[4 * l]; links[l].kf2 = (int)link4[4 * l + 1]; links[l].robust = link4[4 * l + 2] != 0; links[l].info_scale = link4[4 * l + 3];
+        links[l].pint = &pre[l];
+    }
+    std::vector<double> pts(points3, points3 + 3 * (size_t)n_points);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    SE3fQ Tcl, Tbl;
+    std::memcpy(Tcl.q, Tcl7, 16); std::memcpy(Tcl.t, Tcl7 + 4, 12);
+    std::memcpy(Tbl.q, Tbl7, 16); std::memcpy(Tbl.t, Tbl7 + 4, 12);
+    LidarCovisRes lio(Tcl, Tbl);
+    lio.win_size_ = n_win;
+    std::vector<int> lk(win_kf, win_kf + n_win);
+    for (int i = 0; i < n_win; ++i)
+        lio.AddFromKeyFrame(se3f_from_rt(kfs[lk[i]].Rcw, kfs[lk[i]].tcw), std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+    lio.BuildVoxHess();
+    if (n_planes) *n_planes = (int)lio.planes().size();
+    EdgeLidar edge;
+    edge.lio = &lio;
+    edge.information = weight;
+    edge.body = true;
+    InertialBAResult r = LocalInertialBA(kfs, calib_from(calib24), pts, edges_from(edges6, n_edges), links, cam, iterations, lambda_init, &edge, &lk);
+    for (int k = 0; k < n_kf; ++k) kf_to(kfs[k], kf33 + 33 * k);
+    std::memcpy(points3, pts.data(), pts.size() * sizeof(double));
+    for (int e = 0; e < n_edges; ++e) { if (chi2_out) chi2_out[e] = r.chi2[e]; if (depth_pos) depth_pos[e] = r.depth_pos[e]; }
+    if (err2) { err2[0] = r.err; err2[1] = r.err_end; }
+    const int m = std::min((int)r.trace.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
+    if (lidar_out) {
+        lidar_out[0] = edge.error; lidar_out[1] = edge.chi2();
+        for (size_t k = 0; k < edge.JacT.size(); ++k) lidar_out[2 + k] = edge.JacT[k];
+        for (size_t k = 0; k < edge.Hessian.size(); ++k) lidar_out[2 + edge.JacT.size() + k] = edge.Hessian[k];
+    }
+    return r.iterations;
+}
+// EdgeLidar (body variant) alone: planes from the window at the keyframe states kf33_build, then the edge's error (sqrt r) and
+// ComputeJandH at kf33_eval
+int oracle_lidar_window_evaluate_body(const double* kf33_build, const double* kf33_eval, const int* win_kf, int n_win, const float* clouds,
+                                      const int* cloud_off, const float* Tcl7, const float* Tbl7, double* error, double* JacT, double* Hess) {
+    SE3fQ Tcl, Tbl;
+    std::memcpy(Tcl.q, Tcl7, 16); std::memcpy(Tcl.t, Tcl7 + 4, 12);
+    std::memcpy(Tbl.q, Tbl7, 16); std::memcpy(Tbl.t, Tbl7 + 4, 12);
+    LidarCovisRes lio(Tcl, Tbl);
+    lio.win_size_ = n_win;
+    std::vector<double> R(9 * n_win), t(3 * n_win);
+    for (int i = 0; i < n_win; ++i) {
+        const double* b = kf33_build + 33 * win_kf[i];
+        lio.AddFromKeyFrame(se3f_from_rt(b, b + 9), std::vector<float>(clouds + 3 * (size_t)cloud_off[i], clouds + 3 * (size_t)cloud_off[i + 1]));
+        std::memcpy(&R[9 * i], kf33_eval + 33 * win_kf[i], 72);
+        std::memcpy(&t[3 * i], kf33_eval + 33 * win_kf[i] + 9, 24);
+    }
+    lio.BuildVoxHess();
+    EdgeLidar edge;
+    edge.lio = &lio;
+    edge.body = true;
+    edge.computeError(R.data(), t.data(), n_win);
+    if (error) *error = edge.error;
+    if (JacT && Hess) {
+        edge.is_calc_hess = true;
+        edge.linearizeOplus(R.data(), t.data(), n_win);
+        std::memcpy(JacT, edge.JacT.data(), edge.JacT.size() * sizeof(double));
+        std::memcpy(Hess, edge.Hessian.data(), edge.Hessian.size() * sizeof(double));
+    }
+    return (int)lio.planes().size();
+}
 // one inertial edge: error (9) and Jacobians (9 x 24) at the two keyframe states
 void oracle_inertial_edge(const double* kf33_1, const double* kf33_2, const float* pre298, double* err9, double* J216) {
     const InertialKeyFrame k1 = kf_from(kf33_1, 0, 1), k2 = kf_from(kf33_2, 0, 1);

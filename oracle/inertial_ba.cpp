@@ -242,7 +242,7 @@ void inertial_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const
 
 InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCalibD& cal, std::vector<double>& points,
                                  const std::vector<BAEdge>& edges, const std::vector<InertialLink>& links, const Camera& cam,
-                                 int iterations, double lambda_init) {
+                                 int iterations, double lambda_init, EdgeLidar* lidar, const std::vector<int>* lidar_kf) {
     const int K = (int)kfs.size(), P = (int)points.size() / 3, E = (int)edges.size(), Lk = (int)links.size();
     InertialBAResult res;
     res.chi2.assign(E, 0.0); res.depth_pos.assign(E, 0);
@@ -271,7 +271,13 @@ InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCa
 
     std::vector<double> err_v(3 * (size_t)E), err_i(9 * (size_t)Lk);
     std::vector<double> chi_i(Lk), chi_g(Lk), chi_a(Lk);
+    const int Wl = lidar && lidar_kf ? (int)lidar_kf->size() : 0;
+    std::vector<double> lR(9 * (size_t)Wl), lt(3 * (size_t)Wl);
+    auto lidar_vertices = [&]() {  // VPi->estimate().Rcw[0] / tcw[0]
+        for (int i = 0; i < Wl; ++i) { std::memcpy(&lR[9 * i], kfs[(*lidar_kf)[i]].Rcw, 72); std::memcpy(&lt[3 * i], kfs[(*lidar_kf)[i]].tcw, 24); }
+    };
     auto compute_errors = [&]() {
+        if (Wl) { lidar_vertices(); lidar->computeError(lR.data(), lt.data(), Wl); }
         for (int e = 0; e < E; ++e) {
             double A[9], B[18];
             const int dim = inertial_visual_edge(kfs[edges[e].pose], cal, &points[3 * edges[e].point], edges[e], cam, &err_v[3 * e], A, B);
@@ -298,7 +304,7 @@ InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCa
         }
     };
     auto robust_chi2 = [&]() {
-        double chi = 0;
+        double chi = Wl ? lidar->chi2() : 0.0;
         for (int l = 0; l < Lk; ++l) {
             double r0 = chi_i[l], r1;
             if (links[l].robust) hub_imu.rho(chi_i[l], r0, r1);
@@ -393,6 +399,36 @@ InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCa
                         if (o2 >= 0) H[(size_t)(o2 + r) * n + o2 + c] += Om[3 * r + c];
                         if (o1 >= 0 && o2 >= 0) { H[(size_t)(o1 + r) * n + o2 + c] -= Om[3 * r + c]; H[(size_t)(o2 + r) * n + o1 + c] -= Om[3 * r + c]; }
                     }
+                }
+            }
+        }
+        if (Wl) {
+            // EdgeLidar::linearizeOplus + computeQuadraticFormLidarRes (G2oTypesWithLidar.cc:55-140), quirks as in ba.cpp: the
+            // 6x6 blocks are read at element offsets (i, i) / (i, j), b takes -info * JacT without the residual
+            lidar_vertices();
+            lidar->linearizeOplus(lR.data(), lt.data(), Wl);
+            const int nl = 6 * Wl;
+            const double info = lidar->information;
+            for (int i = 0; i < Wl; ++i) {
+                const int vi = pose_var[(*lidar_kf)[i]];
+                if (vi < 0) continue;
+                for (int r = 0; r < 6; ++r) {
+                    b[6 * vi + r] -= info * lidar->JacT[6 * i + r];
+                    for (int c = 0; c < 6; ++c) H[(size_t)(6 * vi + r) * n + 6 * vi + c] += lidar->Hessian[(size_t)(i + r) * nl + i + c] * info;
+                }
+                for (int j = i + 1; j < Wl; ++j) {
+                    const int vj = pose_var[(*lidar_kf)[j]];
+                    if (vj < 0) continue;
+                    // the upper block (smaller variable index first) receives Hessian.block(i, j), or block(j, i) when the
+                    // helper is transposed; the matrix is kept symmetric here
+                    const bool transposed = vi > vj;
+                    for (int r = 0; r < 6; ++r)
+                        for (int c = 0; c < 6; ++c) {
+                            const double h = (transposed ? lidar->Hessian[(size_t)(j + r) * nl + i + c] : lidar->Hessian[(size_t)(i + r) * nl + j + c]) * info;
+                            const int ur = transposed ? 6 * vj + r : 6 * vi + r, uc = transposed ? 6 * vi + c : 6 * vj + c;
+                            H[(size_t)ur * n + uc] += h;
+                            H[(size_t)uc * n + ur] += h;
+                        }
                 }
             }
         }

@@ -8,6 +8,8 @@
 //   EdgeInertial (information with eigenvalue clamp, error, Jacobians)        SF/src/G2oTypes.cc:499-601
 //   EdgeGyroRW / EdgeAccRW                                                   SF/include/G2oTypes.h:645-714
 //   ExpSO3, LogSO3, RightJacobianSO3, InverseRightJacobianSO3, NormalizeRotation   SF/src/G2oTypes.cc:783-865, SF/include/G2oTypes.h:76-81
+//   OptimizerWithLidar::LocalLVIBA: the same graph plus EdgeLidar over the first min(N, 6) optimisable keyframes when N > 5
+//                                                                            SF/src/OptimizerWithLidar.cc:489-1100 (edge: 697-725)
 //   g2o: BaseMultiEdge::constructQuadraticForm / computeQuadraticForm         Thirdparty/g2o/g2o/core/base_multi_edge.hpp:60-222
 //        (robustInformation = rho'[1] * information, core/base_edge.h:96-102), LM and Schur as in ba.hpp
 // Eigen pieces not in tree are replaced: JacobiSVD (NormalizeRotation) by the polar factor via Newton iteration,
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "ba.hpp"
+#include "balm.hpp"
 #include "imu.hpp"
 
 namespace oracle {
@@ -44,10 +47,11 @@ struct InertialBAResult {
 };
 
 // Keyframes in vertex-id order; points, edges as in LocalBundleAdjustment (edge.pose indexes kfs).  Updates kfs (poses,
-// velocities, biases) and points in place.
+// velocities, biases) and points in place.  lidar (optional): the EdgeLidar of LocalLVIBA (body = true, already built:
+// AddFromKeyFrame + BuildVoxHess, information = mWeightLocalBA) over the keyframes lidar_kf in vertex order.
 InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCalibD& calib, std::vector<double>& points,
                                  const std::vector<BAEdge>& edges, const std::vector<InertialLink>& links, const Camera& cam,
-                                 int iterations, double lambda_init);
+                                 int iterations, double lambda_init, EdgeLidar* lidar = nullptr, const std::vector<int>* lidar_kf = nullptr);
 
 // exposed for unit tests
 void ExpSO3(const double w[3], double R[9]);

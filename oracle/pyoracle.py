@@ -601,6 +601,53 @@ def local_inertial_ba(kf33, fixed, has_imu, calib24, points3, edges6, link4, pre
     return kf, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it]), (err2[0], err2[1])
 
 
+def local_lviba(kf33, fixed, has_imu, calib24, points3, edges6, link4, pre298, cam5, win_kf, clouds, Tcl7, Tbl7, weight, iterations=10,
+                lambda_init=1.0):
+    """OptimizerWithLidar::LocalLVIBA's optimisation: local_inertial_ba plus the EdgeLidar over keyframes `win_kf`
+    -> (kf33, points, chi2, depth_pos, iterations, trace, (err, err_end), n_planes, lidar)."""
+    kf, pts = _f64(kf33).copy(), _f64(points3).copy()
+    fixed, has_imu = np.ascontiguousarray(fixed, np.uint8), np.ascontiguousarray(has_imu, np.uint8)
+    calib24, edges6, link4, cam5 = _f64(calib24), _f64(edges6), _f64(link4).reshape(-1, 4), _f64(cam5)
+    pre = np.ascontiguousarray(pre298, np.float32).reshape(-1, 298)
+    win = np.ascontiguousarray(win_kf, np.int32)
+    W = len(win)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    Tcl7, Tbl7 = np.ascontiguousarray(Tcl7, np.float32), np.ascontiguousarray(Tbl7, np.float32)
+    E = len(edges6)
+    chi2, dpos, err2 = np.zeros(max(E, 1)), np.zeros(max(E, 1), np.uint8), np.zeros(2)
+    tc, tl, tt = np.zeros(32), np.zeros(32), np.zeros(32, np.int32)
+    npl = C.c_int(0)
+    lid = np.zeros(2 + 6 * W + 36 * W * W)
+    f = lib().oracle_local_lviba
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                  C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double] + \
+                 [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]
+    it = f(kf.ctypes.data, fixed.ctypes.data, has_imu.ctypes.data, len(kf), calib24.ctypes.data, pts.ctypes.data, len(pts), edges6.ctypes.data, E,
+           link4.ctypes.data, pre.ctypes.data, len(link4), cam5.ctypes.data, iterations, lambda_init, win.ctypes.data, W, cl.ctypes.data,
+           off.ctypes.data, Tcl7.ctypes.data, Tbl7.ctypes.data, weight, chi2.ctypes.data, dpos.ctypes.data, err2.ctypes.data, tc.ctypes.data,
+           tl.ctypes.data, tt.ctypes.data, 32, C.addressof(npl), lid.ctypes.data)
+    lidar = dict(error=lid[0], chi2=lid[1], JacT=lid[2:2 + 6 * W].copy(), Hessian=lid[2 + 6 * W:].reshape(6 * W, 6 * W).copy())
+    return kf, pts, chi2[:E], dpos[:E], it, dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it]), (err2[0], err2[1]), npl.value, lidar
+
+
+def lidar_window_evaluate_body(kf33_build, kf33_eval, win_kf, clouds, Tcl7, Tbl7, derivatives=True):
+    """EdgeLidar of LocalLVIBA alone: planes at kf33_build, then (n_planes, error = sqrt(r), JacT, Hessian) at kf33_eval."""
+    kb, ke = _f64(kf33_build), _f64(kf33_eval)
+    win = np.ascontiguousarray(win_kf, np.int32)
+    W = len(win)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    cl = np.ascontiguousarray(np.concatenate(clouds), np.float32)
+    Tcl7, Tbl7 = np.ascontiguousarray(Tcl7, np.float32), np.ascontiguousarray(Tbl7, np.float32)
+    err = C.c_double(0)
+    J, H = np.zeros(6 * W), np.zeros((6 * W, 6 * W))
+    f = lib().oracle_lidar_window_evaluate_body
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    n = f(kb.ctypes.data, ke.ctypes.data, win.ctypes.data, W, cl.ctypes.data, off.ctypes.data, Tcl7.ctypes.data, Tbl7.ctypes.data, C.addressof(err),
+          J.ctypes.data if derivatives else None, H.ctypes.data if derivatives else None)
+    return n, err.value, J, H
+
+
 def inertial_edge(kf33_1, kf33_2, pre298):
     a, b, p = _f64(kf33_1), _f64(kf33_2), np.ascontiguousarray(pre298, np.float32)
     err, J = np.zeros(9), np.zeros((9, 24))

@@ -739,6 +739,35 @@ def lidar_planes_host(poses7, win_pose, clouds, Tcl7, capacity=20000):
     return out[:n].copy(), coe[:n].copy()
 
 
+def local_lvi_bundle_adjustment(kf33, fixed, has_imu, calib24, points3, edges, link4, preintegrated, cam5, win_kf, clouds, Tcl7, Tbl7, weight,
+                                iterations=10, lambda_init=1.0, stop_flag=None, stream=0):
+    """``OptimizerWithLidar::LocalLVIBA``: local_inertial_bundle_adjustment plus the LiDAR edge over the keyframes ``win_kf``
+    (rows of kf33) -> (kf33, points3, chi2, depth_positive, stats, lidar_stats)."""
+    kf = np.ascontiguousarray(kf33, np.float64).copy()
+    pts = np.ascontiguousarray(points3, np.float64).copy()
+    fixed, has_imu = np.ascontiguousarray(fixed, np.uint8), np.ascontiguousarray(has_imu, np.uint8)
+    calib24, cam5 = np.ascontiguousarray(calib24, np.float64), np.ascontiguousarray(cam5, np.float64)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    link4 = np.ascontiguousarray(link4, np.float64).reshape(-1, 4)
+    links = (InertialLink * max(len(link4), 1))()
+    for l, row in enumerate(link4):
+        links[l] = InertialLink(int(row[0]), int(row[1]), int(row[2] != 0), 0, float(row[3]), C.addressof(preintegrated[l].p))
+    chi2 = np.zeros(max(len(edges), 1))
+    dpos = np.zeros(max(len(edges), 1), np.uint8)
+    stats, lstats = BaStats(), LidarBaStats()
+    stop_ptr = stop_flag.ctypes.data if stop_flag is not None else None
+    w, keep = _pack_lidar_window(win_kf, clouds, Tcl7, weight)
+    tbl = np.ascontiguousarray(Tbl7, np.float32)
+    f = lib().tc2li_local_lvi_bundle_adjustment
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                  C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(kf.ctypes.data, fixed.ctypes.data, has_imu.ctypes.data, len(kf), calib24.ctypes.data, pts.ctypes.data, len(pts), edges.ctypes.data,
+             len(edges), C.addressof(links), len(link4), cam5.ctypes.data, iterations, lambda_init, stop_ptr, chi2.ctypes.data, dpos.ctypes.data,
+             C.addressof(stats), C.addressof(w), tbl.ctypes.data, C.addressof(lstats), C.c_void_p(stream)))
+    del keep
+    return kf, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
+
+
 def lidar_window_evaluate(poses7, win_pose, clouds, Tcl7, derivatives=True):
     """The LiDAR edge alone -> (n_planes, residual, JacT [6W], Hessian [6W, 6W]) (ComputeError / ComputeJandHSE3)."""
     poses = np.ascontiguousarray(poses7, np.float64)

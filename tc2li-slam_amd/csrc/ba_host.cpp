@@ -4,6 +4,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -405,11 +406,22 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
                                            int n_edges, const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam,
                                            int iterations, double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                                            uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
+    return tc2li_local_lvi_bundle_adjustment(kfs, fixed, has_imu, n_kfs, calib, points3, n_points, edges, n_edges, links, n_links, cam, iterations,
+                                             lambda_init, stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, nullptr, stream_);
+}
+
+int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
+                                      const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges, int n_edges,
+                                      const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam, int iterations,
+                                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2, uint8_t* edge_depth_positive,
+                                      tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window, const float* Tbl7,
+                                      tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
     if (!kfs || !fixed || !has_imu || !calib || !points3 || !edges || !cam || n_kfs <= 0 || n_points <= 0 || n_edges <= 0 || n_links < 0 ||
-        (n_links > 0 && !links) || iterations < 0) {
+        (n_links > 0 && !links) || iterations < 0 || (lidar_window && !Tbl7)) {
         set_error("tc2li_local_inertial_bundle_adjustment: invalid argument");
         return TC2LI_ERR_INVALID;
     }
+    if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream_;
     if (stats) memset(stats, 0, sizeof(*stats));
@@ -424,8 +436,18 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
         if (!L[l].prepare(in.info_scale)) { set_error("inertial link %d: the pre-integration covariance is not positive definite", l); return TC2LI_ERR_INVALID; }
         extra_used[in.kf1] = extra_used[in.kf2] = 1;
     }
+    std::vector<uint8_t> imu_used = extra_used;  // keyframes whose velocity / bias vertices an inertial edge touches
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
+    static_assert(offsetof(tc2li_inertial_keyframe, Rcw) == 0 && offsetof(tc2li_inertial_keyframe, tcw) == 72, "Rcw, tcw first");
+    static_assert(offsetof(ImuPose, Rcw) == 0 && offsetof(ImuPose, tcw) == 72, "Rcw, tcw first");
+    BalmTerm* lidar = nullptr;
+    if (lidar_window) {
+        const int rc = ws.lidar.build_body(kfs, sizeof(tc2li_inertial_keyframe), n_kfs, lidar_window, Tbl7, sizeof(ImuPose), st);
+        if (rc < 0) return rc;
+        lidar = &ws.lidar;
+        for (int i = 0; i < lidar_window->n_keyframes; ++i) extra_used[lidar_window->pose_index[i]] = 1;
+    }
     VisualProblem vp;
     {
         const int rc = vp.setup(ws, nullptr, fixed, n_kfs, points3, n_points, edges, n_edges, cam, extra_used.data(), st);
@@ -436,7 +458,7 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
     const int n_free = vp.n_free, np = vp.np;
     std::vector<int> imu_var(n_kfs, -1);
     int n_imu = 0;
-    for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && extra_used[k]) imu_var[k] = n_imu++;
+    for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && imu_used[k]) imu_var[k] = n_imu++;
     const int n = np + 9 * n_imu;
     // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
     std::vector<ImuPose> hp(n_kfs), hp_trial(n_kfs);
@@ -526,8 +548,20 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
         TC2LI_HIP_CHECK(hipGetLastError());
-        const double chi_imu = inertial_cost(hp, sv, true);  // overlaps with the kernels
+        if (lidar) {  // computeActiveErrors + linearizeOplus of the LiDAR edge ride on the same synchronisation
+            lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes), st);
+            const int rc = lidar->enqueue_linearization(reinterpret_cast<const Se3*>(pb.iposes), st);
+            if (rc < 0) return rc;
+        }
+        double chi_imu = inertial_cost(hp, sv, true);  // overlaps with the kernels
         TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        if (lidar) {
+            if (it == 0) lidar->finish_error();  // the computeActiveErrors() before optimize() (OptimizerWithLidar.cc:978)
+            lidar->finish_error();
+            chi_imu += lidar->chi2();
+            lidar->finish_linearization();  // constructQuadraticForm uses the stored Jacobian / Hessian when the cost grew
+            lidar->add_quadratic_form(pose_var.data(), n, Hi.data(), bi.data());
+        }
         double currentChi = chi_imu + h_scal.p[0], tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
@@ -567,6 +601,7 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
                 ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
                 TC2LI_HIP_CHECK(hipGetLastError());
                 TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_iposes.p, pb.iposes_trial, n_kfs * sizeof(ImuPose), hipMemcpyDeviceToHost, st));
+                if (lidar) lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes_trial), st);
                 sv_trial = sv;
                 for (int k = 0; k < n_kfs; ++k)
                     if (imu_var[k] >= 0) {
@@ -576,6 +611,7 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
                 memcpy(hp_trial.data(), ws.h_iposes.p, n_kfs * sizeof(ImuPose));
                 tempChi = inertial_cost(hp_trial, sv_trial, false) + h_scal.p[4];
+                if (lidar) { lidar->finish_error(); tempChi += lidar->chi2(); }
                 scale += h_scal.p[3];
                 last_chi = tempChi;
             } else {
@@ -608,6 +644,10 @@ int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const u
         if (n_bad >= 3) ok = false;
     }
     if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; stats->final_chi2 = last_chi; }
+    if (lidar && lidar_stats) {
+        lidar_stats->n_planes = lidar->n_planes; lidar_stats->hessian_evaluations = lidar->hessian_evaluations;
+        lidar_stats->residual = lidar->error; lidar_stats->chi2 = lidar->chi2();
+    }
     // ---- results ----
     ba_launch_depth(pb, ws.d_depth.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());

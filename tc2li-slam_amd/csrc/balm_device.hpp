@@ -12,6 +12,7 @@ constexpr int kMaxLidarWindow = 20;  // LidarCovisRes::win_size_ default (SF/inc
 // The plane list of one window resident on the device (VOX_HESS: plvec_voxels / coeffs, SF/include/bavoxel.h:48-78).
 struct BalmDev {
     int32_t W, n_planes, n_chunks, planes_per_chunk;
+    int32_t imu_pose_bytes, pad_;  // 0: the vertex array holds Se3; otherwise ImuPose records of this size (Rcw[9], tcw[3] first)
     const PlaneCluster* clusters;  // [n_planes][W]
     const double* coe;             // [n_planes]
     const int32_t* pose_index;     // [W] rows of the pose array

@@ -274,22 +274,78 @@ void balm_to_camera_se3(const LidarPose* twl, int W, const SE3f& Tcl, double* Ja
     }
 }
 
+void balm_to_body(const LidarPose* twl, int W, const SE3f& Tbl, double* JacT, double* H) {
+    const int n = 6 * W;
+    const float qi[4] = {-Tbl.q[0], -Tbl.q[1], -Tbl.q[2], Tbl.q[3]};  // mTlb = mTbl.inverse()
+    double Rlb[9];
+    quat_to_matrix_f(qi, Rlb);
+    const double tbl[3] = {(double)Tbl.t[0], (double)Tbl.t[1], (double)Tbl.t[2]};
+    for (int i = 0; i < W; ++i) {
+        const double* Rwl = twl[i].R;
+        double Rwb[9], RwbT[9], rwl[3], Jr[9], JrRlb[9], A[9] /* (Jr^-1 Rlb)^T */, th[9], RwbH[9], B[9] /* (Rwb [tbl]x)^T */;
+        m3_mul(Rwl, Rlb, Rwb);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RwbT[3 * r + c] = Rwb[3 * c + r];
+        so3_log_f(Rwl, rwl);
+        inverse_right_jacobian_so3(rwl, Jr);
+        m3_mul(Jr, Rlb, JrRlb);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlb[3 * c + r];
+        m3_hat(tbl, th);
+        m3_mul(Rwb, th, RwbH);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwbH[3 * c + r];
+        const double Jw[3] = {JacT[6 * i], JacT[6 * i + 1], JacT[6 * i + 2]}, Jt[3] = {JacT[6 * i + 3], JacT[6 * i + 4], JacT[6 * i + 5]};
+        double AJw[3], BJt[3], RJt[3];
+        m3_vec(A, Jw, AJw);
+        m3_vec(B, Jt, BJt);
+        m3_vec(RwbT, Jt, RJt);
+        for (int k = 0; k < 3; ++k) { JacT[6 * i + k] = AJw[k] - BJt[k]; JacT[6 * i + 3 + k] = RJt[k]; }
+        double DT[36] = {0}, D[36];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                DT[6 * r + c] = A[3 * r + c];
+                DT[6 * r + 3 + c] = -1.0 * B[3 * r + c];
+                DT[6 * (3 + r) + 3 + c] = RwbT[3 * r + c];
+            }
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[6 * r + c] = DT[6 * c + r];
+        for (int j = 0; j < W; ++j) {
+            double blk[36], o[36];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * i + r) * n + 6 * j + c];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DT[6 * r + k] * blk[6 * k + c]; o[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * i + r) * n + 6 * j + c] = o[6 * r + c];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * j + r) * n + 6 * i + c];
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += blk[6 * r + k] * D[6 * k + c]; o[6 * r + c] = s; }
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * j + r) * n + 6 * i + c] = o[6 * r + c];
+        }
+    }
+}
+
 // ---- the edge ---------------------------------------------------------------------------------------------------------
-int BalmTerm::window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl) {
+int BalmTerm::check_window(const tc2li_lidar_window* win, int n_poses) {
     const int W = win->n_keyframes;
     if (W < 1 || W > kMaxLidarWindow || !win->pose_index || !win->cloud_xyz || !win->cloud_offsets) {
         set_error("lidar window: n_keyframes must be in [1, %d] and the arrays non-null", kMaxLidarWindow);
         return TC2LI_ERR_INVALID;
     }
     if (win->cloud_offsets[0] != 0) { set_error("lidar window: cloud_offsets[0] must be 0"); return TC2LI_ERR_INVALID; }
+    for (int i = 0; i < W; ++i) {
+        const int k = win->pose_index[i];
+        if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
+        if (win->cloud_offsets[i + 1] <= win->cloud_offsets[i]) { set_error("lidar window: keyframe %d has no points", i); return TC2LI_ERR_INVALID; }
+    }
+    return 0;
+}
+
+int BalmTerm::window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl) {
+    const int rc = check_window(win, n_poses);
+    if (rc < 0) return rc;
+    const int W = win->n_keyframes;
     SE3f Tcl;
     memcpy(Tcl.q, win->Tcl, 4 * sizeof(float));
     memcpy(Tcl.t, win->Tcl + 4, 3 * sizeof(float));
     twl.resize(W);
     for (int i = 0; i < W; ++i) {
         const int k = win->pose_index[i];
-        if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
-        if (win->cloud_offsets[i + 1] <= win->cloud_offsets[i]) { set_error("lidar window: keyframe %d has no points", i); return TC2LI_ERR_INVALID; }
         SE3f Tcw;  // KeyFrame::GetPose() is a Sophus::SE3f
         for (int c = 0; c < 4; ++c) Tcw.q[c] = (float)poses7[7 * k + c];
         for (int c = 0; c < 3; ++c) Tcw.t[c] = (float)poses7[7 * k + 4 + c];
@@ -302,6 +358,31 @@ int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window*
     std::vector<LidarPose> twl;
     const int rcw = window_poses(poses7, n_poses, win, twl);
     if (rcw < 0) return rcw;
+    body = false;
+    return upload(twl, win, st);
+}
+
+int BalmTerm::build_body(const void* kfs, size_t kf_bytes, int n_kfs, const tc2li_lidar_window* win, const float* Tbl7, size_t imu_pose_bytes,
+                         hipStream_t st) {
+    const int rc = check_window(win, n_kfs);
+    if (rc < 0) return rc;
+    SE3f tcl;
+    memcpy(tcl.q, win->Tcl, 4 * sizeof(float));
+    memcpy(tcl.t, win->Tcl + 4, 3 * sizeof(float));
+    std::vector<LidarPose> twl(win->n_keyframes);
+    for (int i = 0; i < win->n_keyframes; ++i) {  // pKF->GetPoseInverse() * mTcl (SF/src/LidarRes.cc:44)
+        const double* rt = reinterpret_cast<const double*>(static_cast<const char*>(kfs) + (size_t)win->pose_index[i] * kf_bytes);
+        twl[i] = lidar_pose_from(se3f_from_rt(rt, rt + 9), tcl);
+    }
+    body = true;
+    memcpy(Tbl.q, Tbl7, 4 * sizeof(float));
+    memcpy(Tbl.t, Tbl7 + 4, 3 * sizeof(float));
+    const int r = upload(twl, win, st);
+    dev.imu_pose_bytes = (int32_t)imu_pose_bytes;
+    return r;
+}
+
+int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st) {
     W = win->n_keyframes;
     memcpy(Tcl.q, win->Tcl, 4 * sizeof(float));
     memcpy(Tcl.t, win->Tcl + 4, 3 * sizeof(float));
@@ -346,7 +427,7 @@ void BalmTerm::enqueue_error(const Se3* d_poses, hipStream_t st) {
 
 void BalmTerm::finish_error() {
     const double r = n_planes ? h_out.p[0] : 0.0;
-    error = r;
+    error = body ? std::sqrt(r) : r;  // G2oTypesWithLidar.cc:41-42 / G2oTypesWithLidar.h:131
     r1 = r2;
     r2 = r;
     is_calc_hess = !(r1 - r2 < 0);  // the Hessian is kept while the cost grows (G2oTypesWithLidar.h:130-139)
@@ -370,7 +451,9 @@ void BalmTerm::finish_linearization() {
     const int n = 6 * W;
     memcpy(JacT.data(), h_out.p + 1, n * sizeof(double));
     memcpy(Hessian.data(), h_out.p + 1 + n, (size_t)n * n * sizeof(double));
-    balm_to_camera_se3(reinterpret_cast<const LidarPose*>(h_out.p + 2 + n + (size_t)n * n), W, Tcl, JacT.data(), Hessian.data());
+    const LidarPose* at = reinterpret_cast<const LidarPose*>(h_out.p + 2 + n + (size_t)n * n);
+    if (body) balm_to_body(at, W, Tbl, JacT.data(), Hessian.data());
+    else balm_to_camera_se3(at, W, Tcl, JacT.data(), Hessian.data());
 }
 
 int BalmTerm::compute_error(const Se3* d_poses, hipStream_t st) {
@@ -390,7 +473,7 @@ int BalmTerm::linearize(const Se3* d_poses, hipStream_t st) {
     return 0;
 }
 
-void BalmTerm::add_quadratic_form(const int* pose_var, int np, double* Hpp, double* b) const {
+void BalmTerm::add_quadratic_form(const int* pose_var, int np /* row stride of Hpp */, double* Hpp, double* b) const {
     // The reference reads the 6x6 blocks at ELEMENT offsets (i, i) / (i, j) of the 6W x 6W Hessian and subtracts
     // information * J^T from b (G2oTypesWithLidar.h:168-236); kept as is so that the optimiser takes the same steps.
     const int n = 6 * W;

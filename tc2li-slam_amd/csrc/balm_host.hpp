@@ -21,10 +21,17 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud_xyz, cons
 // SF/src/LidarRes.cc:136-186).  In place; H is (6W)^2 row-major.
 void balm_to_camera_se3(const LidarPose* twl, int W, const SE3f& Tcl, double* JacT, double* H);
 
+// The same for the body-frame increment of VertexPose (ImuCamPose::Update): LidarCovisRes::ComputeJandH, SF/src/LidarRes.cc:89-128.
+void balm_to_body(const LidarPose* twl, int W, const SE3f& Tbl, double* JacT, double* H);
+
 struct BalmTerm {
     int W = 0, n_planes = 0;
     double information = 1;
     SE3f Tcl{};
+    // EdgeLidar on VertexPose (LocalLVIBA, SF/src/G2oTypesWithLidar.cc:33-75): the vertex array holds ImuPose records, the edge's
+    // error is sqrt(r) and the derivatives go through ComputeJandH
+    bool body = false;
+    SE3f Tbl{};
     std::vector<int32_t> pose_index;
     // EdgeLidarSE3 state (SF/include/G2oTypesWithLidar.h:88-236)
     double error = 0, r1 = 1000, r2 = 1000;
@@ -44,6 +51,9 @@ struct BalmTerm {
     static int window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl);
     // planes of the window at the poses `poses7` (Tcw per keyframe, rows pose_index of the array)
     int build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st);
+    // the same from keyframe records whose first 12 doubles are Rcw (row-major), tcw (tc2li_inertial_keyframe); body mode
+    int build_body(const void* kfs, size_t kf_bytes, int n_kfs, const tc2li_lidar_window* win, const float* Tbl7, size_t imu_pose_bytes,
+                   hipStream_t st);
     int compute_error(const Se3* d_poses, hipStream_t st);  // EdgeLidarSE3::computeError
     int linearize(const Se3* d_poses, hipStream_t st);      // EdgeLidarSE3::linearizeOplus
     // The same two steps split into "enqueue the kernels" and "use the numbers after the caller's synchronisation", so
@@ -55,7 +65,11 @@ struct BalmTerm {
     void finish_linearization();
     double chi2() const { return error * information * error; }
     // EdgeLidarSE3::computeQuadraticFormLidarRes: add to the dense pose-pose system (free pose numbering pose_var)
-    void add_quadratic_form(const int* pose_var, int np, double* Hpp, double* b) const;
+    void add_quadratic_form(const int* pose_var, int ld, double* Hpp, double* b) const;
+
+private:
+    int upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st);
+    static int check_window(const tc2li_lidar_window* win, int n_poses);
 };
 
 }  // namespace tc2li

@@ -23,7 +23,15 @@ static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads *
 
 // LiDAR poses of the window slots from the vertex estimates (LidarCovisRes::UpdatePose), into LDS of the calling workgroup
 __device__ __forceinline__ void window_poses(const BalmDev& b, const Se3* __restrict__ poses, LidarPose* s_twl) {
-    if ((int)threadIdx.x < b.W) s_twl[threadIdx.x] = lidar_pose_from(se3f_from_vertex(poses[b.pose_index[threadIdx.x]]), b.Tcl);
+    if ((int)threadIdx.x < b.W) {
+        const int k = b.pose_index[threadIdx.x];
+        if (b.imu_pose_bytes) {  // EdgeLidar on VertexPose (LocalLVIBA): Rcw / tcw of the ImuCamPose
+            const double* rt = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (size_t)k * b.imu_pose_bytes);
+            s_twl[threadIdx.x] = lidar_pose_from(se3f_from_rt(rt, rt + 9), b.Tcl);
+        } else {
+            s_twl[threadIdx.x] = lidar_pose_from(se3f_from_vertex(poses[k]), b.Tcl);
+        }
+    }
     __syncthreads();
 }
 

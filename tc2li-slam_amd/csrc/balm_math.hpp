@@ -83,6 +83,15 @@ __host__ __device__ inline SE3f se3f_from_vertex(const Se3& T) {
     for (int k = 0; k < 3; ++k) o.t[k] = (float)T.t[k];
     return o;
 }
+// VertexPose's estimate().Rcw[0] / tcw[0] (doubles) as the Sophus::SE3f of the same UpdatePose (SF/src/G2oTypesWithLidar.cc:35-39)
+__host__ __device__ inline SE3f se3f_from_rt(const double* Rcw, const double* tcw) {
+    float Rf[9];
+    for (int k = 0; k < 9; ++k) Rf[k] = (float)Rcw[k];
+    SE3f o;
+    matrix_to_quat_f(Rf, o.q);
+    for (int k = 0; k < 3; ++k) o.t[k] = (float)tcw[k];
+    return o;
+}
 
 // ---- 3x3 helpers (row-major) ------------------------------------------------------------------------------------------
 __host__ __device__ inline void m3_mul(const double* a, const double* b, double* o) {

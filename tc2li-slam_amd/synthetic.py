@@ -436,3 +436,30 @@ def inertial_window(seed=0, n_opt=8, n_points=600, kf_dt=0.4, rate=200.0, pose_n
     return dict(kf33=kf, kf33_true=kf_true32, fixed=fixed, has_imu=np.ones(K, np.uint8), calib24=calib24, points=pts, points_true=pts_true,
                 edges=edges, link4=np.array(link4), samples=samples, bias6=np.concatenate([ba_true, bg_true]).astype(np.float32), cam=cam,
                 times=times)
+
+
+def tbl7():
+    """mLidarParam->mTbl = Tbc * Tcl of the synthetic rig as (qx, qy, qz, qw, tx, ty, tz) float32."""
+    from scipy.spatial.transform import Rotation
+    Rcl, tcl = _quat_R(TCL7[:4]), TCL7[4:].astype(np.float64)
+    R, t = RBC @ Rcl, RBC @ tcl + TBC
+    return np.concatenate([Rotation.from_matrix(R).as_quat(), t]).astype(np.float32)
+
+
+def inertial_window_clouds(w, win_kf, n_points=2400, noise=0.02, seed=0):
+    """Surface clouds (LiDAR frame, float32 [n, 3]) for the keyframes `win_kf` of an inertial_window(): samples of the ground
+    z = -1.7 and of two walls y = -8 / y = +9 (world axes: x forward, z up) ahead of each TRUE keyframe pose."""
+    rng = np.random.default_rng([SEED0, 0xC11D, seed])
+    Rcl, tcl = _quat_R(TCL7[:4]), TCL7[4:].astype(np.float64)
+    clouds = []
+    for k in win_kf:
+        Rcw, tcw, twb = w["kf33_true"][k][:9].reshape(3, 3), w["kf33_true"][k][9:12], w["kf33_true"][k][21:24]
+        m = n_points // 3
+        r = n_points - 2 * m
+        g = np.stack([rng.uniform(2, 12, m) + twb[0], rng.uniform(-4, 4, m) + twb[1], np.full(m, -1.7)], 1)
+        wl = np.stack([rng.uniform(2, 12, m) + twb[0], np.full(m, -8.0), rng.uniform(-1.7, 1.5, m)], 1)
+        wr = np.stack([rng.uniform(2, 12, r) + twb[0], np.full(r, 9.0), rng.uniform(-1.7, 1.5, r)], 1)
+        Xw = np.concatenate([g, wl, wr]) + rng.normal(0, noise, (n_points, 3))
+        Xc = Xw @ Rcw.T + tcw
+        clouds.append(((Xc - tcl) @ Rcl).astype(np.float32))
+    return clouds

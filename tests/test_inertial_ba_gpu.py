@@ -54,6 +54,47 @@ def test_local_inertial_ba(pkg, oracle, synthetic, seed, n_opt, n_pts, iters, la
     assert err1 < 0.6 * err0
 
 
+@pytest.mark.parametrize("seed,n_opt,weight", [(0, 6, 1.0), (1, 8, 100.0), (2, 7, 10.0)])
+def test_local_lviba(pkg, oracle, synthetic, seed, n_opt, weight):
+    """OptimizerWithLidar::LocalLVIBA: the inertial BA plus EdgeLidar on the first 6 optimisable keyframes (most recent first)."""
+    w = problem(pkg, oracle, synthetic, seed, n_opt=n_opt, n_points=400)
+    K = len(w["kf33"])
+    win = list(range(K - 1, K - 7, -1))
+    clouds = synthetic.inertial_window_clouds(w, win, n_points=2400, seed=seed)
+    tbl = synthetic.tbl7()
+    want = oracle.local_lviba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], w["pre298"], w["cam"], win,
+                              clouds, synthetic.TCL7, tbl, weight)
+    kf, pts, chi2, dpos, stats, ls = pkg.capi.local_lvi_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"],
+                                                                         pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"], win, clouds,
+                                                                         synthetic.TCL7, tbl, weight)
+    assert ls.n_planes == want[7] and ls.n_planes > 50
+    assert stats.iterations == want[4]
+    assert stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.initial_chi2 - want[6][0]) <= 1e-6 * want[6][0]
+    assert abs(stats.final_chi2 - want[6][1]) <= 1e-5 * want[6][1]
+    # the poses pass through float in UpdatePose: the residual moves in steps of ~1e-6 relative
+    assert abs(ls.residual - want[8]["error"]) <= 1e-4 * want[8]["error"]
+    for k in range(len(kf)):
+        assert rel(kf[k, :24], want[0][k, :24]) < RTOL
+        assert np.allclose(kf[k, 24:], want[0][k, 24:], rtol=RTOL, atol=1e-5)
+    assert np.allclose(pts, want[1], rtol=RTOL, atol=1e-4)
+    assert np.array_equal(dpos, want[3])
+    # the edge changes the result (it is really in the system)
+    plain = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]),
+                                                      w["link4"], w["pre"], w["cam"])
+    assert np.abs(plain[0][:, 21:24] - kf[:, 21:24]).max() > 1e-5
+
+
+def test_lviba_argument_errors(pkg, oracle, synthetic):
+    w = problem(pkg, oracle, synthetic, 0, n_opt=6, n_points=200)
+    clouds = synthetic.inertial_window_clouds(w, [6, 5], n_points=300)
+    args = (w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"])
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.local_lvi_bundle_adjustment(*args, [6, 99], clouds, synthetic.TCL7, synthetic.tbl7(), 1.0)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.local_lvi_bundle_adjustment(*args, [6, 5], [clouds[0], clouds[1][:0]], synthetic.TCL7, synthetic.tbl7(), 1.0)
+
+
 def test_inertial_ba_argument_errors(pkg, oracle, synthetic):
     w = problem(pkg, oracle, synthetic, 0, n_opt=3, n_points=150)
     bad = w["link4"].copy(); bad[0, 1] = 99

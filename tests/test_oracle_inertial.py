@@ -108,3 +108,67 @@ def test_local_inertial_ba_reduces_the_error(oracle, window):
     # the large-window settings of the reference (4 iterations, lambda 1e-2) also run
     r2 = oracle.local_inertial_ba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], w["pre298"], w["cam"], 4, 1e-2)
     assert r2[4] >= 1 and r2[6][1] < r2[6][0]
+
+
+def test_lviba_lidar_edge_derivatives(oracle, synthetic):
+    """EdgeLidar of LocalLVIBA (LidarCovisRes::ComputeJandH, SF/src/LidarRes.cc:89-128): the translation rows are the gradient of
+    r with respect to ImuCamPose::Update's increment; the rotation rows carry the reference's extra InverseRightJacobianSO3
+    factor -- removing it (J_w' = Rlb^T A^-T ...) gives the finite-difference gradient, which pins the restatement."""
+    w = synthetic.inertial_window(0, n_opt=6, n_points=300)
+    K = len(w["kf33"])
+    win = list(range(K - 1, K - 7, -1))
+    clouds = synthetic.inertial_window_clouds(w, win, n_points=2400)
+    tbl = synthetic.tbl7()
+    n, err, J, H = oracle.lidar_window_evaluate_body(w["kf33"], w["kf33"], win, clouds, synthetic.TCL7, tbl)
+    assert n > 50 and err > 0
+    assert np.allclose(H, H.T, rtol=1e-9, atol=1e-9 * np.abs(H).max())
+
+    def hat(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+    from scipy.spatial.transform import Rotation
+    Rcl = synthetic._quat_R(synthetic.TCL7[:4])
+    Rlb = synthetic._quat_R(tbl[:4]).T
+    t_bl = tbl[4:].astype(np.float64)
+    for i, k in enumerate(win[:3]):
+        g = np.zeros(6)
+        for c in range(6):
+            h = 2e-3 if c < 3 else 2e-2
+            r = []
+            for sgn in (1, -1):
+                u = np.zeros(6); u[c] = sgn * h
+                kf = w["kf33"].copy()
+                kf[k], _ = oracle.imu_pose_update(kf[k], 0, w["calib24"], u)
+                e = oracle.lidar_window_evaluate_body(w["kf33"], kf, win, clouds, synthetic.TCL7, tbl, derivatives=False)[1]
+                r.append(e * e)
+            g[c] = (r[0] - r[1]) / (2 * h)
+        jw, jt = J[6 * i:6 * i + 3], J[6 * i + 3:6 * i + 6]
+        assert np.allclose(jt, g[3:], rtol=2e-2, atol=2e-2 * np.abs(g).max())
+        Rwl = w["kf33"][k][:9].reshape(3, 3).T @ Rcl
+        rwl = Rotation.from_matrix(Rwl).as_rotvec()
+        th = np.linalg.norm(rwl)
+        Wm = hat(rwl)
+        Jrinv = np.eye(3) + 0.5 * Wm + (1 / th ** 2 - (1 + np.cos(th)) / (2 * th * np.sin(th))) * Wm @ Wm
+        Rwb = Rwl @ Rlb
+        A, B = (Jrinv @ Rlb).T, (Rwb @ hat(t_bl)).T
+        Jt = Rwb @ jt
+        Jw = np.linalg.solve(A, jw + B @ Jt)
+        assert np.allclose(Rlb.T @ Jw - B @ Jt, g[:3], rtol=2e-2, atol=2e-2 * np.abs(g).max())
+
+
+def test_lviba_runs_and_reports(oracle, synthetic):
+    w = synthetic.inertial_window(1, n_opt=7, n_points=300)
+    K = len(w["kf33"])
+    win = list(range(K - 1, K - 7, -1))
+    clouds = synthetic.inertial_window_clouds(w, win, n_points=1800)
+    pre = []
+    for s, t1, t2 in w["samples"]:
+        _, f = oracle.imu_preintegrate(s, t1, t2, w["bias6"], *synthetic.IMU_NOISE)
+        pre.append(oracle.pack_preintegrated(f, w["bias6"]))
+    r = oracle.local_lviba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], np.stack(pre), w["cam"], win, clouds,
+                           synthetic.TCL7, synthetic.tbl7(), 1.0)
+    assert r[4] >= 3 and r[7] > 50 and r[6][1] < 0.01 * r[6][0]
+    err0 = np.linalg.norm(w["kf33"][:, 21:24] - w["kf33_true"][:, 21:24], axis=1).mean()
+    err1 = np.linalg.norm(r[0][:, 21:24] - w["kf33_true"][:, 21:24], axis=1).mean()
+    assert err1 < 0.5 * err0
+    assert np.array_equal(r[0][0], w["kf33"][0])
