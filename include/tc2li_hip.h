@@ -226,6 +226,35 @@ int tc2li_lidar_imu_propagate(tc2li_imu_state* state, const tc2li_imu_meas* v_im
                               double pcl_end_time, double last_lidar_end_time, double acc_scale, double acc_s_last[3],
                               double angvel_last[3], tc2li_imu_pose6d* poses, int capacity);
 
+/* The same forward propagation with the covariance (esekf::predict, SF/include/IKFoM_toolkit/esekfom/esekfom.hpp:281-392 with
+ * get_f / df_dx / df_dw of SF/src/use-ikfom.cpp:45-91): P is the 23 x 23 row-major error-state covariance in the order pos, rot,
+ * offset_R_L_I, offset_T_L_I, vel, bg, ba, grav (2); cov12 = cov_gyr, cov_acc, cov_bias_gyr, cov_bias_acc, the diagonal of Q
+ * (IMU_Processing.cpp:215-218).  Host-only: 23 x 23 products per IMU sample. */
+int tc2li_lidar_imu_propagate_cov(tc2li_imu_state* state, double* P, const double cov12[12], const tc2li_imu_meas* v_imu, int n_imu,
+                                  double pcl_beg_time, double pcl_end_time, double last_lidar_end_time, double acc_scale,
+                                  double acc_s_last[3], double angvel_last[3], tc2li_imu_pose6d* poses, int capacity);
+/* One esekf::predict step with a full 12 x 12 process noise Q (ng, na, nbg, nba). */
+int tc2li_eskf_predict(tc2li_imu_state* state, double* P, const double* Q, const double acc[3], const double gyr[3], double dt);
+
+/* esekf::update_iterated_dyn_share_modified (esekfom.hpp:1621-1932) with h_share_model (LidarFrontEnd.cpp:485-602) as the
+ * measurement model, as called at LidarFrontEnd.cpp:749: R = LASER_POINT_COV, maximum_iter = NUM_MAX_ITERATIONS, limit23 = epsi.
+ * Every iteration evaluates the point-to-plane residuals of feats_down_body against `map` at the current state (the neighbour
+ * search only when the previous iteration converged, as the reference does), reduces the 12 active columns of H to H^T H and
+ * H^T h on the device, and solves the 23-dof update on the host.  State and P (23 x 23) are updated in place.  Afterwards the
+ * handle holds Nearest_Points / the selection of the last evaluation for tc2li_lidar_map_incremental.  Returns effct_feat_num
+ * of the last evaluation. */
+typedef struct tc2li_eskf_stats {
+    int32_t calls;            /* h_share_model evaluations */
+    int32_t effct_feat_num;   /* selected points of the last one */
+    int32_t searches;         /* evaluations that ran the neighbour search */
+    int32_t converged;        /* iterations whose step stayed below limit23 */
+    int32_t finished;         /* the covariance update ran (:1823-1928) */
+    int32_t pad_;
+    double res_mean_last;
+} tc2li_eskf_stats;
+int tc2li_lidar_eskf_update(tc2li_lidar* lidar, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n, tc2li_imu_state* state,
+                            double* P, double R, int maximum_iter, const double* limit23, int extrinsic_est_en, tc2li_eskf_stats* stats);
+
 /* The point part (:170-172, 236-276): sorts the scan by time offset (curvature, ms) in the order std::sort(time_list)
  * produces and moves every point into the scan-end frame; in place on the host array.  end_state = imu_state after the
  * last predict (rot, pos, offset_R_L_I, offset_T_L_I are read). */

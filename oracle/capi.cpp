@@ -6,6 +6,7 @@
 #include "orb.hpp"
 #include "stereo.hpp"
 #include "lidar.hpp"
+#include "eskf.hpp"
 #include "ba.hpp"
 #include "imu.hpp"
 #include "inertial_ba.hpp"
@@ -725,6 +726,49 @@ int oracle_imu_propagate(double* state36, const double* imu7, int n_imu, double 
     std::vector<ImuMeas> v(n_imu);
     for (int i = 0; i < n_imu; ++i) std::memcpy(&v[i], imu7 + 7 * i, sizeof(ImuMeas));
     std::vector<Pose6D> P = ForwardPropagate(st, v, beg, end, last_end, acc_scale, last6, last6 + 3);
+    std::memcpy(state36, &st, sizeof(st));
+    for (int i = 0; i < (int)P.size() && i < capacity; ++i) std::memcpy(poses22 + 22 * i, &P[i], sizeof(Pose6D));
+    return (int)P.size();
+}
+
+// ---- iterated ESKF of the LiDAR-inertial front end (row b7) ------------------------------------------------------------------
+void oracle_eskf_predict(double* state36, double* P529, const double* Q144, const double* acc, const double* gyr, double dt) {
+    ImuState st;
+    std::memcpy(&st, state36, sizeof(st));
+    eskf_predict(st, P529, Q144, acc, gyr, dt);
+    std::memcpy(state36, &st, sizeof(st));
+}
+void oracle_eskf_boxplus(double* state36, const double* d23) {
+    ImuState st;
+    std::memcpy(&st, state36, sizeof(st));
+    eskf_boxplus(st, d23);
+    std::memcpy(state36, &st, sizeof(st));
+}
+void oracle_eskf_boxminus(const double* a36, const double* b36, double* d23) {
+    ImuState a, b;
+    std::memcpy(&a, a36, sizeof(a)); std::memcpy(&b, b36, sizeof(b));
+    eskf_boxminus(a, b, d23);
+}
+void oracle_s2(const double* g, const double* delta2, double* Bx6, double* Nx6, double* Mx6) {
+    s2_Bx(g, Bx6); s2_Nx_yy(g, Nx6); s2_Mx(g, delta2, Mx6);
+}
+// out6: calls, effct_feat_num, searches, converged, finished, res_mean_last
+void oracle_eskf_update(double* state36, double* P529, void* tree, const PointXYZINormal* body, int n, double R, int max_iter, const double* limit23,
+                        int extrinsic_est_en, double* out6) {
+    ImuState st;
+    std::memcpy(&st, state36, sizeof(st));
+    PointVector b(body, body + n);
+    const EskfUpdate u = eskf_update(st, P529, *static_cast<KdTree*>(tree), b, R, max_iter, limit23, extrinsic_est_en != 0);
+    std::memcpy(state36, &st, sizeof(st));
+    out6[0] = u.calls; out6[1] = u.effct_feat_num; out6[2] = u.searches; out6[3] = u.converged; out6[4] = u.finished; out6[5] = u.res_mean_last;
+}
+int oracle_imu_propagate_cov(double* state36, double* P529, const double* cov12, const double* imu7, int n_imu, double beg, double end, double last_end,
+                             double acc_scale, const double* last6, double* poses22, int capacity) {
+    ImuState st;
+    std::memcpy(&st, state36, sizeof(st));
+    std::vector<ImuMeas> v(n_imu);
+    for (int i = 0; i < n_imu; ++i) std::memcpy(&v[i], imu7 + 7 * i, sizeof(ImuMeas));
+    std::vector<Pose6D> P = ForwardPropagateCov(st, P529, cov12, v, beg, end, last_end, acc_scale, last6, last6 + 3);
     std::memcpy(state36, &st, sizeof(st));
     for (int i = 0; i < (int)P.size() && i < capacity; ++i) std::memcpy(poses22 + 22 * i, &P[i], sizeof(Pose6D));
     return (int)P.size();

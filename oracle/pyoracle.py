@@ -539,6 +539,67 @@ def imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     return st, poses[:k]
 
 
+# ---- iterated ESKF (row b7) --------------------------------------------------------------------------------------------------
+# state36: pos 3, rot 9, vel 3, bg 3, ba 3, grav 3, offset_R_L_I 9, offset_T_L_I 3; error state (23): pos, rot, offset_R, offset_T, vel,
+# bg, ba, grav (2)
+def eskf_predict(state36, P, Q, acc, gyr, dt):
+    st, P = _f64(state36).copy(), _f64(P).copy()
+    f = lib().oracle_eskf_predict
+    f.argtypes = [C.c_void_p] * 5 + [C.c_double]
+    f(st.ctypes.data, P.ctypes.data, _f64(Q).ctypes.data, _f64(acc).ctypes.data, _f64(gyr).ctypes.data, dt)
+    return st, P
+
+
+def eskf_boxplus(state36, d23):
+    st = _f64(state36).copy()
+    f = lib().oracle_eskf_boxplus
+    f.argtypes = [C.c_void_p] * 2
+    f(st.ctypes.data, _f64(d23).ctypes.data)
+    return st
+
+
+def eskf_boxminus(a36, b36):
+    d = np.zeros(23)
+    f = lib().oracle_eskf_boxminus
+    f.argtypes = [C.c_void_p] * 3
+    f(_f64(a36).ctypes.data, _f64(b36).ctypes.data, d.ctypes.data)
+    return d
+
+
+def s2_matrices(g, delta2=(0.0, 0.0)):
+    Bx, Nx, Mx = np.zeros((3, 2)), np.zeros((2, 3)), np.zeros((3, 2))
+    f = lib().oracle_s2
+    f.argtypes = [C.c_void_p] * 5
+    f(_f64(g).ctypes.data, _f64(delta2).ctypes.data, Bx.ctypes.data, Nx.ctypes.data, Mx.ctypes.data)
+    return Bx, Nx, Mx
+
+
+def eskf_update(state36, P, tree, feats_down_body, R=0.001, max_iter=4, limit=None, extrinsic_est_en=False):
+    """esekf::update_iterated_dyn_share_modified with h_share_model -> (state36, P, dict(calls, effct_feat_num, searches, converged,
+    finished, res_mean_last))."""
+    st, P = _f64(state36).copy(), _f64(P).copy()
+    body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
+    limit = _f64(np.full(23, 0.001) if limit is None else limit)
+    out = np.zeros(6)
+    f = lib().oracle_eskf_update
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    f(st.ctypes.data, P.ctypes.data, tree._h, body.ctypes.data, len(body), R, max_iter, limit.ctypes.data, int(extrinsic_est_en), out.ctypes.data)
+    return st, P, dict(calls=int(out[0]), effct_feat_num=int(out[1]), searches=int(out[2]), converged=int(out[3]), finished=bool(out[4]),
+                       res_mean_last=out[5])
+
+
+def imu_propagate_cov(state36, P, cov12, imu7, beg, end, last_end, acc_scale, last6):
+    """Forward propagation of UndistortPcl with the covariance -> (end state [36], P, poses [K, 22])."""
+    st, P = _f64(state36).copy(), _f64(P).copy()
+    imu = _f64(imu7).reshape(-1, 7)
+    poses = np.zeros((len(imu) + 2, 22))
+    f = lib().oracle_imu_propagate_cov
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    k = f(st.ctypes.data, P.ctypes.data, _f64(cov12).ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, _f64(last6).ctypes.data,
+          poses.ctypes.data, len(poses))
+    return st, P, poses[:k]
+
+
 # ---- persistent map maintenance -------------------------------------------------------------------------------------------
 def map_incremental(map_points, feats_down_body, state_extract24, state_update24, ekf_inited=True, filter_size_map_min=0.5):
     """feature_extraction at state_extract + map_incremental at state_update -> (new map points, n_to_add, n_no_need)."""

@@ -402,6 +402,20 @@ class LidarFrontEnd:
         _check(lib().tc2li_lidar_undistort(self._h, pts.ctypes.data, len(pts), poses.ctypes.data, len(poses), st.ctypes.data))
         return pts
 
+    def eskf_update(self, lidar_map, feats_down_body, state36, P, R=0.001, max_iter=4, limit=None, extrinsic_est_en=False):
+        """``esekf::update_iterated_dyn_share_modified`` with ``h_share_model`` -> (state36, P [23, 23], EskfStats).  state36: pos 3,
+        rot 9, vel 3, bg 3, ba 3, grav 3, offset_R_L_I 9, offset_T_L_I 3."""
+        body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
+        st = np.ascontiguousarray(state36, np.float64).copy()
+        Pm = np.ascontiguousarray(P, np.float64).reshape(23, 23).copy()
+        lim = np.ascontiguousarray(np.full(23, 0.001) if limit is None else limit, np.float64)
+        stats = EskfStats()
+        f = lib().tc2li_lidar_eskf_update
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _check(f(self._h, lidar_map._h, body.ctypes.data, len(body), st.ctypes.data, Pm.ctypes.data, R, max_iter, lim.ctypes.data,
+                 int(extrinsic_est_en), C.addressof(stats)))
+        return st, Pm, stats
+
     def feature_extraction(self, lidar_map, feats_down_body, state24):
         body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
         n = len(body)
@@ -565,6 +579,40 @@ def lidar_imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     k = _check(lib().tc2li_lidar_imu_propagate(st.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, last.ctypes.data,
                                                last.ctypes.data + 24, poses.ctypes.data, len(poses)))
     return st, poses[:k], last
+
+
+class EskfStats(C.Structure):
+    """tc2li_eskf_stats"""
+    _fields_ = [("calls", C.c_int32), ("effct_feat_num", C.c_int32), ("searches", C.c_int32), ("converged", C.c_int32), ("finished", C.c_int32),
+                ("pad_", C.c_int32), ("res_mean_last", C.c_double)]
+
+
+def eskf_predict(state36, P, Q, acc, gyr, dt):
+    """One ``esekf::predict`` step (host) -> (state36, P)."""
+    st = np.ascontiguousarray(state36, np.float64).copy()
+    Pm = np.ascontiguousarray(P, np.float64).reshape(23, 23).copy()
+    Qm = np.ascontiguousarray(Q, np.float64).reshape(12, 12)
+    a, g = np.ascontiguousarray(acc, np.float64), np.ascontiguousarray(gyr, np.float64)
+    f = lib().tc2li_eskf_predict
+    f.argtypes = [C.c_void_p] * 5 + [C.c_double]
+    _check(f(st.ctypes.data, Pm.ctypes.data, Qm.ctypes.data, a.ctypes.data, g.ctypes.data, dt))
+    return st, Pm
+
+
+def lidar_imu_propagate_cov(state36, P, cov12, imu7, beg, end, last_end, acc_scale, last6):
+    """Forward propagation of UndistortPcl with the covariance (host) -> (end state [36], P, poses [K, 22], updated last6)."""
+    st = np.ascontiguousarray(state36, np.float64).copy()
+    Pm = np.ascontiguousarray(P, np.float64).reshape(23, 23).copy()
+    cov = np.ascontiguousarray(cov12, np.float64)
+    imu = np.ascontiguousarray(imu7, np.float64).reshape(-1, 7)
+    last = np.ascontiguousarray(last6, np.float64).copy()
+    poses = np.zeros((len(imu) + 2, 22))
+    f = lib().tc2li_lidar_imu_propagate_cov
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_int]
+    k = _check(f(st.ctypes.data, Pm.ctypes.data, cov.ctypes.data, imu.ctypes.data, len(imu), beg, end, last_end, acc_scale, last.ctypes.data,
+                 last.ctypes.data + 24, poses.ctypes.data, len(poses)))
+    return st, Pm, poses[:k], last
 
 
 class InertialLink(C.Structure):

@@ -100,6 +100,13 @@ void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const i
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,
                       int* nfound, int* hard_count, int2* hard_list, hipStream_t st);
+// iterated ESKF (row b7): re-evaluation of the kept neighbours at a new state; normal equations of the measurement rows ->
+// out[158] = H^T H (12 x 12), H^T h (12), sum |pd2|, number of rows (partial: [(n + 255) / 256][158])
+constexpr int kEskfOutSize = 144 + 12 + 2;
+void launch_eskf_refit(const MapGrid& grid, const PointXYZINormal* body, int n, const LidarStateDev* state, const int* nearest_idx,
+                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, hipStream_t st);
+void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev* state, const uint8_t* selected, const PointXYZINormal* normvec,
+                        int extrinsic_est_en, double* partial, double* out, hipStream_t st);
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st);
 void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,

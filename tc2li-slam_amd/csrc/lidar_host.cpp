@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include "eskf_math.hpp"
 #include "lidar_device.hpp"
 
 using namespace tc2li;
@@ -57,6 +58,8 @@ struct tc2li_lidar {
     DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
+    DevBuf<double> d_eskf_partial;  // [(cap + 255) / 256][kEskfOutSize]
+    PinnedBuf<double> h_eskf_out;   // [kEskfOutSize], written by k_eskf_reduce
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
     std::vector<ScanSlot> slots;
     std::vector<SegBlock> blocks;
@@ -301,10 +304,10 @@ int tc2li_lidar_undistort(tc2li_lidar* L, tc2li_point* points, int n, const tc2l
     return n;
 }
 
-// Forward propagation at the IMU samples of one scan, state part (host; a dozen samples).
-int tc2li_lidar_imu_propagate(tc2li_imu_state* st, const tc2li_imu_meas* v, int n_imu, double pcl_beg_time, double pcl_end_time,
-                              double last_lidar_end_time, double acc_scale, double acc_s_last[3], double angvel_last[3],
-                              tc2li_imu_pose6d* poses, int capacity) {
+// Forward propagation at the IMU samples of one scan (host; a dozen samples): the state, and with P / Q the covariance as well.
+static int imu_propagate_impl(tc2li_imu_state* st, eskf::Cov* P, const eskf::Mat<eskf::kW, eskf::kW>* Q, const tc2li_imu_meas* v, int n_imu,
+                              double pcl_beg_time, double pcl_end_time, double last_lidar_end_time, double acc_scale, double acc_s_last[3],
+                              double angvel_last[3], tc2li_imu_pose6d* poses, int capacity) {
     if (!st || n_imu < 1 || !v || !acc_s_last || !angvel_last || !poses || capacity < 1) { set_error("tc2li_lidar_imu_propagate: invalid argument"); return TC2LI_ERR_INVALID; }
     int np = 0;
     auto save = [&](double t) {
@@ -314,6 +317,7 @@ int tc2li_lidar_imu_propagate(tc2li_imu_state* st, const tc2li_imu_meas* v, int 
     };
     auto rotv = [](const double* R, const double* x, double* o) { for (int r = 0; r < 3; ++r) o[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2]; };
     auto predict = [&](double dt, const double* acc, const double* gyr) {  // x <- x [+] f(x, u) dt  (use-ikfom.hpp get_f)
+        if (P) { eskf::predict(*st, *P, *Q, acc, gyr, dt); return; }
         double am[3], Ra[3], th[3];
         for (int k = 0; k < 3; ++k) { th[k] = (gyr[k] - st->bg[k]) * dt; am[k] = acc[k] - st->ba[k]; }
         rotv(st->rot, am, Ra);
@@ -353,6 +357,202 @@ int tc2li_lidar_imu_propagate(tc2li_imu_state* st, const tc2li_imu_meas* v, int 
     const double imu_end = v[n_imu - 1].t;
     predict((pcl_end_time > imu_end ? 1.0 : -1.0) * (pcl_end_time - imu_end), acc_avr, w_avr);
     return np;
+}
+
+int tc2li_lidar_imu_propagate(tc2li_imu_state* st, const tc2li_imu_meas* v, int n_imu, double pcl_beg_time, double pcl_end_time,
+                              double last_lidar_end_time, double acc_scale, double acc_s_last[3], double angvel_last[3],
+                              tc2li_imu_pose6d* poses, int capacity) {
+    return imu_propagate_impl(st, nullptr, nullptr, v, n_imu, pcl_beg_time, pcl_end_time, last_lidar_end_time, acc_scale, acc_s_last, angvel_last,
+                              poses, capacity);
+}
+
+int tc2li_lidar_imu_propagate_cov(tc2li_imu_state* st, double* P529, const double cov12[12], const tc2li_imu_meas* v, int n_imu,
+                                  double pcl_beg_time, double pcl_end_time, double last_lidar_end_time, double acc_scale,
+                                  double acc_s_last[3], double angvel_last[3], tc2li_imu_pose6d* poses, int capacity) {
+    if (!P529 || !cov12) { set_error("tc2li_lidar_imu_propagate_cov: invalid argument"); return TC2LI_ERR_INVALID; }
+    eskf::Cov P;
+    memcpy(P.a, P529, sizeof(P.a));
+    eskf::Mat<eskf::kW, eskf::kW> Q = eskf::Mat<eskf::kW, eskf::kW>::zero();
+    for (int k = 0; k < eskf::kW; ++k) Q(k, k) = cov12[k];  // cov_gyr, cov_acc, cov_bias_gyr, cov_bias_acc (IMU_Processing.cpp:215-218)
+    const int r = imu_propagate_impl(st, &P, &Q, v, n_imu, pcl_beg_time, pcl_end_time, last_lidar_end_time, acc_scale, acc_s_last, angvel_last, poses,
+                                     capacity);
+    if (r >= 0) memcpy(P529, P.a, sizeof(P.a));
+    return r;
+}
+
+int tc2li_eskf_predict(tc2li_imu_state* st, double* P529, const double* Q144, const double acc[3], const double gyr[3], double dt) {
+    if (!st || !P529 || !Q144 || !acc || !gyr) { set_error("tc2li_eskf_predict: invalid argument"); return TC2LI_ERR_INVALID; }
+    eskf::Cov P;
+    eskf::Mat<eskf::kW, eskf::kW> Q;
+    memcpy(P.a, P529, sizeof(P.a));
+    memcpy(Q.a, Q144, sizeof(Q.a));
+    eskf::predict(*st, P, Q, acc, gyr, dt);
+    memcpy(P529, P.a, sizeof(P.a));
+    return TC2LI_OK;
+}
+
+// esekf::update_iterated_dyn_share_modified with h_share_model as the measurement model (esekfom.hpp:1621-1932,
+// LidarFrontEnd.cpp:485-602): neighbour search / plane fit / selection and the normal equations of the measurement rows on the
+// device, the 23 x 23 algebra of the iteration on the host.
+int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n, tc2li_imu_state* x, double* P529,
+                            double R, int maximum_iter, const double* limit23, int extrinsic_est_en, tc2li_eskf_stats* stats) {
+    using namespace eskf;
+    if (!L || !map || n < 0 || (n > 0 && !feats_down_body) || !x || !P529 || !(R > 0) || maximum_iter < 0 || !limit23) {
+        set_error("tc2li_lidar_eskf_update: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    if (n == 0) return 0;
+    int rc = setup_segments(L, 1, &n, nullptr);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(hipMemcpy(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(L->d_eskf_partial.ensure((size_t)((n + 255) / 256) * kEskfOutSize));
+    TC2LI_HIP_CHECK(L->h_eskf_out.ensure(kEskfOutSize));
+    L->last_down.assign(1, n);
+    const PointXYZINormal* body = reinterpret_cast<const PointXYZINormal*>(feats_down_body);
+
+    const tc2li_imu_state x_propagated = *x;
+    Cov P_propagated;
+    memcpy(P_propagated.a, P529, sizeof(P_propagated.a));
+    Cov P = P_propagated, K_x = Cov::zero();
+    double K_h[kN] = {0}, dx_new[kN] = {0};
+    bool converge = true;
+    int t = 0, calls = 0, searches = 0, effct = 0;
+    double res_mean = 0;
+    const int so3_idx[2] = {3, 6};
+    for (int i = -1; i < maximum_iter; i++) {
+        // ---- h_share_model at the current state ----
+        tc2li_lidar_state ls;
+        memcpy(ls.rot, x->rot, 72); memcpy(ls.pos, x->pos, 24); memcpy(ls.offset_R_L_I, x->offset_R_L_I, 72); memcpy(ls.offset_T_L_I, x->offset_T_L_I, 24);
+        if (converge) {
+            rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, &ls, nullptr);
+            if (rc != TC2LI_OK) return rc;
+            ++searches;
+        } else {
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, &ls, sizeof(LidarStateDev), hipMemcpyHostToDevice, nullptr));
+            launch_eskf_refit(map->grid, L->d_down.p, n, L->d_states.p, L->d_nearest_idx.p, L->d_world.p, L->d_selected.p, L->d_normvec.p, nullptr);
+        }
+        launch_eskf_normal(L->d_down.p, n, L->d_states.p, L->d_selected.p, L->d_normvec.p, extrinsic_est_en, L->d_eskf_partial.p, L->h_eskf_out.p, nullptr);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+        ++calls;
+        const double* o = L->h_eskf_out.p;
+        const int M = (int)o[157];
+        effct = M;
+        if (M < 1) continue;  // ekfom_data.valid = false
+        res_mean = o[156] / M;
+        // ---- the iteration (esekfom.hpp:1653-1800) ----
+        double dx[kN];
+        boxminus(*x, x_propagated, dx);
+        for (int k = 0; k < kN; ++k) dx_new[k] = dx[k];
+        P = P_propagated;
+        for (int s : so3_idx) {
+            const M3 At = transpose(A_matrix(dx + s));
+            double v[3];
+            for (int r = 0; r < 3; ++r) v[r] = At(r, 0) * dx_new[s] + At(r, 1) * dx_new[s + 1] + At(r, 2) * dx_new[s + 2];
+            for (int r = 0; r < 3; ++r) dx_new[s + r] = v[r];
+            rows_apply<3>(P, s, At);
+            cols_apply<3>(P, s, At);
+        }
+        {
+            const Mat<2, 2> T = mul(s2_Nx_yy(x->grav), s2_Mx(x_propagated.grav, dx + 21));
+            const double v0 = T(0, 0) * dx_new[21] + T(0, 1) * dx_new[22], v1 = T(1, 0) * dx_new[21] + T(1, 1) * dx_new[22];
+            dx_new[21] = v0; dx_new[22] = v1;
+            rows_apply<2>(P, 21, T);
+            cols_apply<2>(P, 21, T);
+        }
+        K_x = Cov::zero();
+        if (kN > M) {
+            // fewer rows than states: K = P Hc^T (Hc P Hc^T / R + I)^-1 / R on the explicit rows (at most 22 of them)
+            std::vector<uint8_t> sel(n);
+            std::vector<PointXYZINormal> nv(n);
+            TC2LI_HIP_CHECK(hipMemcpy(sel.data(), L->d_selected.p, n, hipMemcpyDeviceToHost));
+            TC2LI_HIP_CHECK(hipMemcpy(nv.data(), L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+            std::vector<double> H((size_t)M * 12, 0.0), h(M), PHt((size_t)kN * M), S((size_t)M * M), Si((size_t)M * M), K((size_t)kN * M);
+            const M3 Rw = m3_from(x->rot), Ro = m3_from(x->offset_R_L_I);
+            int k = 0;
+            for (int p = 0; p < n && k < M; ++p) {
+                if (!sel[p]) continue;
+                const double pbe[3] = {body[p].x, body[p].y, body[p].z}, nr[3] = {nv[p].x, nv[p].y, nv[p].z};
+                double pt[3], C[3], D[3];
+                for (int r = 0; r < 3; ++r) pt[r] = (Ro(r, 0) * pbe[0] + Ro(r, 1) * pbe[1] + Ro(r, 2) * pbe[2]) + x->offset_T_L_I[r];
+                for (int r = 0; r < 3; ++r) C[r] = Rw(0, r) * nr[0] + Rw(1, r) * nr[1] + Rw(2, r) * nr[2];
+                for (int r = 0; r < 3; ++r) D[r] = Ro(0, r) * C[0] + Ro(1, r) * C[1] + Ro(2, r) * C[2];
+                double* row = &H[(size_t)k * 12];
+                row[0] = nr[0]; row[1] = nr[1]; row[2] = nr[2];
+                row[3] = pt[1] * C[2] - pt[2] * C[1]; row[4] = pt[2] * C[0] - pt[0] * C[2]; row[5] = pt[0] * C[1] - pt[1] * C[0];
+                if (extrinsic_est_en) {
+                    row[6] = pbe[1] * D[2] - pbe[2] * D[1]; row[7] = pbe[2] * D[0] - pbe[0] * D[2]; row[8] = pbe[0] * D[1] - pbe[1] * D[0];
+                    row[9] = C[0]; row[10] = C[1]; row[11] = C[2];
+                }
+                h[k] = -(double)nv[p].intensity;
+                ++k;
+            }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < 12; ++q) s += P(r, q) * H[(size_t)c * 12 + q]; PHt[(size_t)r * M + c] = s; }
+            for (int r = 0; r < M; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < 12; ++q) s += H[(size_t)r * 12 + q] * PHt[(size_t)q * M + c]; S[(size_t)r * M + c] = s / R + (r == c ? 1.0 : 0.0); }
+            if (!lu_inverse(S.data(), M, Si.data())) { set_error("tc2li_lidar_eskf_update: singular innovation matrix"); return TC2LI_ERR_INVALID; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < M; ++q) s += PHt[(size_t)r * M + q] * Si[(size_t)q * M + c]; K[(size_t)r * M + c] = s / R; }
+            for (int r = 0; r < kN; ++r) { double s = 0; for (int q = 0; q < M; ++q) s += K[(size_t)r * M + q] * h[q]; K_h[r] = s; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s = 0; for (int q = 0; q < M; ++q) s += K[(size_t)r * M + q] * H[(size_t)q * 12 + c]; K_x(r, c) = s; }
+        } else {
+            Cov PR, P_temp, P_inv;
+            for (int k = 0; k < kN * kN; ++k) PR.a[k] = P.a[k] / R;
+            if (!lu_inverse(PR.a, kN, P_temp.a)) { set_error("tc2li_lidar_eskf_update: singular covariance"); return TC2LI_ERR_INVALID; }
+            for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c) P_temp(r, c) += o[12 * r + c];
+            if (!lu_inverse(P_temp.a, kN, P_inv.a)) { set_error("tc2li_lidar_eskf_update: singular information matrix"); return TC2LI_ERR_INVALID; }
+            for (int r = 0; r < kN; ++r) { double s = 0; for (int k = 0; k < 12; ++k) s += P_inv(r, k) * o[144 + k]; K_h[r] = s; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s = 0; for (int k = 0; k < 12; ++k) s += P_inv(r, k) * o[12 * k + c]; K_x(r, c) = s; }
+        }
+        double dx_[kN];
+        for (int r = 0; r < kN; ++r) {
+            double s = K_h[r];
+            for (int c = 0; c < kN; ++c) s += (K_x(r, c) - (r == c ? 1.0 : 0.0)) * dx_new[c];
+            dx_[r] = s;
+        }
+        boxplus(*x, dx_);
+        converge = true;
+        for (int k = 0; k < kN; ++k) if (std::fabs(dx_[k]) > limit23[k]) { converge = false; break; }
+        if (converge) t++;
+        if (!t && i == maximum_iter - 2) converge = true;
+        if (t > 1 || i == maximum_iter - 1) {
+            Cov Lm = P;
+            for (int s : so3_idx) {
+                const M3 At = transpose(A_matrix(dx_ + s));
+                for (int c = 0; c < kN; ++c)
+                    for (int r = 0; r < 3; ++r) Lm(s + r, c) = At(r, 0) * P(s, c) + At(r, 1) * P(s + 1, c) + At(r, 2) * P(s + 2, c);
+                for (int c = 0; c < 12; ++c) {
+                    const double k3[3] = {K_x(s, c), K_x(s + 1, c), K_x(s + 2, c)};
+                    for (int r = 0; r < 3; ++r) K_x(s + r, c) = At(r, 0) * k3[0] + At(r, 1) * k3[1] + At(r, 2) * k3[2];
+                }
+                cols_apply<3>(Lm, s, At);
+                cols_apply<3>(P, s, At);
+            }
+            {
+                const Mat<2, 2> T = mul(s2_Nx_yy(x->grav), s2_Mx(x_propagated.grav, dx_ + 21));
+                for (int c = 0; c < kN; ++c)
+                    for (int r = 0; r < 2; ++r) Lm(21 + r, c) = T(r, 0) * P(21, c) + T(r, 1) * P(22, c);
+                for (int c = 0; c < 12; ++c) {
+                    const double k2[2] = {K_x(21, c), K_x(22, c)};
+                    for (int r = 0; r < 2; ++r) K_x(21 + r, c) = T(r, 0) * k2[0] + T(r, 1) * k2[1];
+                }
+                cols_apply<2>(Lm, 21, T);
+                cols_apply<2>(P, 21, T);
+            }
+            for (int r = 0; r < kN; ++r)
+                for (int c = 0; c < kN; ++c) {
+                    double s = 0;
+                    for (int k = 0; k < 12; ++k) s += K_x(r, k) * P(k, c);
+                    P529[r * kN + c] = Lm(r, c) - s;
+                }
+            if (stats) { stats->calls = calls; stats->effct_feat_num = effct; stats->searches = searches; stats->converged = t; stats->finished = 1; stats->res_mean_last = res_mean; }
+            return effct;
+        }
+    }
+    memcpy(P529, P.a, sizeof(P.a));
+    if (stats) { stats->calls = calls; stats->effct_feat_num = effct; stats->searches = searches; stats->converged = t; stats->finished = 0; stats->res_mean_last = res_mean; }
+    return effct;
 }
 
 int tc2li_lidar_map_create(tc2li_lidar_map** out) {

@@ -715,43 +715,49 @@ __device__ __forceinline__ bool knn_complete(const MapGrid& g, int ring, int cx,
     return t.b4.d < edge * edge * 0.999f;
 }
 
+// esti_plane + the residual gate of feature_extraction / h_share_model (LidarFrontEnd.cpp:453-482, 1040-1055, 529-545) for one
+// query and its five neighbours: returns the selection flag and fills nv (normal, intensity = pd2)
+__device__ __forceinline__ uint8_t plane_gate(const PointXYZINormal* __restrict__ map_pts, const int (&ids)[5], const PointXYZINormal& pw,
+                                              double bx, double by, double bz, PointXYZINormal& nv) {
+    nv.x = 0; nv.y = 0; nv.z = 0; nv.pad0 = 1.0f; nv.normal_x = 0; nv.normal_y = 0; nv.normal_z = 0; nv.pad1 = 0;
+    nv.intensity = 0; nv.curvature = 0; nv.pad2 = 0; nv.pad3 = 0;
+    float A[5][3], rhs[5], sol[3], px[5], py[5], pz[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const PointXYZINormal m = map_pts[ids[j]];
+        px[j] = m.x; py[j] = m.y; pz[j] = m.z;
+        A[j][0] = m.x; A[j][1] = m.y; A[j][2] = m.z;
+        rhs[j] = -1.0f;
+    }
+    qr_solve_5x3(A, rhs, sol);
+    const float nrm = sqrtf(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    const float pa = __fdiv_rn(sol[0], nrm), pbn = __fdiv_rn(sol[1], nrm), pc = __fdiv_rn(sol[2], nrm);
+    const float pd = (float)(1.0 / (double)nrm);
+    bool plane = true;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        if (fabsf(pa * px[j] + pbn * py[j] + pc * pz[j] + pd) > 0.1f) plane = false;
+    if (!plane) return 0;
+    const float pd2 = pa * pw.x + pbn * pw.y + pc * pw.z + pd;
+    const double pnorm = sqrt(bx * bx + by * by + bz * bz);
+    const float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(pnorm));
+    if (!((double)s > 0.9)) return 0;
+    nv.x = pa; nv.y = pbn; nv.z = pc; nv.intensity = pd2;
+    return 1;
+}
+
 // feature_extraction gates (LidarFrontEnd.cpp:1032-1055) and the result records of one query
 __device__ __forceinline__ void knn_finish(const MapGrid& grid, const Top5& t, const PointXYZINormal& pw, double bx, double by,
                                            double bz, bool write, int o, uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
                                            int* __restrict__ nearest_idx, float* __restrict__ nearest_d, int* __restrict__ nfound) {
-    const PointXYZINormal* __restrict__ map_pts = grid.points;
     const int nb = t.count();
     uint8_t sel = 0;
     PointXYZINormal nv;
     nv.x = 0; nv.y = 0; nv.z = 0; nv.pad0 = 1.0f; nv.normal_x = 0; nv.normal_y = 0; nv.normal_z = 0; nv.pad1 = 0;
     nv.intensity = 0; nv.curvature = 0; nv.pad2 = 0; nv.pad3 = 0;
     if (nb == 5 && !(t.b4.d > 5.f)) {
-        float A[5][3], rhs[5], sol[3], px[5], py[5], pz[5];
         const int ids[5] = {t.b0.idx, t.b1.idx, t.b2.idx, t.b3.idx, t.b4.idx};
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const PointXYZINormal m = map_pts[ids[j]];
-            px[j] = m.x; py[j] = m.y; pz[j] = m.z;
-            A[j][0] = m.x; A[j][1] = m.y; A[j][2] = m.z;
-            rhs[j] = -1.0f;
-        }
-        qr_solve_5x3(A, rhs, sol);
-        const float nrm = sqrtf(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
-        const float pa = __fdiv_rn(sol[0], nrm), pbn = __fdiv_rn(sol[1], nrm), pc = __fdiv_rn(sol[2], nrm);
-        const float pd = (float)(1.0 / (double)nrm);
-        bool plane = true;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-            if (fabsf(pa * px[j] + pbn * py[j] + pc * pz[j] + pd) > 0.1f) plane = false;
-        if (plane) {
-            const float pd2 = pa * pw.x + pbn * pw.y + pc * pw.z + pd;
-            const double pnorm = sqrt(bx * bx + by * by + bz * bz);
-            const float s = (float)(1 - 0.9 * (double)fabsf(pd2) / sqrt(pnorm));
-            if ((double)s > 0.9) {
-                sel = 1;
-                nv.x = pa; nv.y = pbn; nv.z = pc; nv.intensity = pd2;
-            }
-        }
+        sel = plane_gate(grid.points, ids, pw, bx, by, bz, nv);
     }
     if (!write) return;
     nfound[o] = nb;
@@ -1141,6 +1147,97 @@ __global__ __launch_bounds__(256) void k_map_append(const PointXYZINormal* __res
     }
 }
 
+// ---- iterated ESKF (esekf::update_iterated_dyn_share_modified with h_share_model, row b7) -----------------------------------
+// An iteration that does not follow a converged one keeps the neighbours and the selection of the previous iteration and only
+// re-evaluates the plane residual at the new state (LidarFrontEnd.cpp:519-545).
+__global__ __launch_bounds__(256) void k_eskf_refit(const MapGrid grid, const PointXYZINormal* __restrict__ body, int n, const LidarStateDev* __restrict__ state,
+                                                    const int* __restrict__ nearest_idx, PointXYZINormal* __restrict__ world,
+                                                    uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const PointXYZINormal pb = body[i];
+    const PointXYZINormal pw = body_to_world(pb, *state);
+    world[i] = pw;
+    if (!selected[i]) return;
+    const int* ni = nearest_idx + (size_t)i * 5;
+    const int ids[5] = {ni[0], ni[1], ni[2], ni[3], ni[4]};
+    PointXYZINormal nv;
+    const uint8_t sel = plane_gate(grid.points, ids, pw, (double)pb.x, (double)pb.y, (double)pb.z, nv);
+    selected[i] = sel;
+    if (sel) normvec[i] = nv;
+}
+
+// Rows of the measurement Jacobian (LidarFrontEnd.cpp:566-600) and their normal equations: per workgroup the partial sums of
+// H^T H (144), H^T h (12), sum |pd2| and the number of rows; summed over the workgroups in index order by k_eskf_reduce.
+constexpr int kEskfOut = 144 + 12 + 2;
+__global__ __launch_bounds__(256) void k_eskf_normal(const PointXYZINormal* __restrict__ body, int n, const LidarStateDev* __restrict__ state,
+                                                     const uint8_t* __restrict__ selected, const PointXYZINormal* __restrict__ normvec,
+                                                     int extrinsic_est_en, double* __restrict__ partial) {
+    __shared__ double s_row[256][13];
+    __shared__ float s_abs[256];
+    __shared__ int s_cnt[256];
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    double row[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) row[k] = 0.0;
+    float ares = 0.f;
+    int cnt = 0;
+    if (i < n && selected[i]) {
+        const LidarStateDev st = *state;
+        const PointXYZINormal pb = body[i];
+        const PointXYZINormal nv = normvec[i];
+        const double pbe[3] = {(double)pb.x, (double)pb.y, (double)pb.z}, nrm[3] = {(double)nv.x, (double)nv.y, (double)nv.z};
+        double pt[3], C[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) pt[r] = (st.off_r[3 * r] * pbe[0] + st.off_r[3 * r + 1] * pbe[1] + st.off_r[3 * r + 2] * pbe[2]) + st.off_t[r];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) C[r] = st.rot[r] * nrm[0] + st.rot[3 + r] * nrm[1] + st.rot[6 + r] * nrm[2];  // rot^T n
+        row[0] = nrm[0]; row[1] = nrm[1]; row[2] = nrm[2];
+        row[3] = pt[1] * C[2] - pt[2] * C[1];  // hat(point_this) * C
+        row[4] = pt[2] * C[0] - pt[0] * C[2];
+        row[5] = pt[0] * C[1] - pt[1] * C[0];
+        if (extrinsic_est_en) {
+            double D[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) D[r] = st.off_r[r] * C[0] + st.off_r[3 + r] * C[1] + st.off_r[6 + r] * C[2];  // offset_R^T C
+            row[6] = pbe[1] * D[2] - pbe[2] * D[1];
+            row[7] = pbe[2] * D[0] - pbe[0] * D[2];
+            row[8] = pbe[0] * D[1] - pbe[1] * D[0];
+            row[9] = C[0]; row[10] = C[1]; row[11] = C[2];
+        }
+        row[12] = -(double)nv.intensity;
+        ares = fabsf(nv.intensity);
+        cnt = 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 13; ++k) s_row[tid][k] = row[k];
+    s_abs[tid] = ares;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    if (tid < kEskfOut) {
+        double acc = 0.0;
+        if (tid < 144) {
+            const int r = tid / 12, c = tid % 12;
+            for (int k = 0; k < 256; ++k) acc += s_row[k][r] * s_row[k][c];
+        } else if (tid < 156) {
+            const int r = tid - 144;
+            for (int k = 0; k < 256; ++k) acc += s_row[k][r] * s_row[k][12];
+        } else if (tid == 156) {
+            for (int k = 0; k < 256; ++k) acc += (double)s_abs[k];
+        } else {
+            for (int k = 0; k < 256; ++k) acc += (double)s_cnt[k];
+        }
+        partial[(size_t)blockIdx.x * kEskfOut + tid] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_eskf_reduce(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    const int tid = threadIdx.x;
+    if (tid >= kEskfOut) return;
+    double acc = 0.0;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * kEskfOut + tid];
+    out[tid] = acc;
+}
+
 __global__ __launch_bounds__(kSegBlock) void k_sel_count(const uint8_t* __restrict__ selected, const int* __restrict__ count,
                                                          const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                          int* __restrict__ block_counts) {
@@ -1250,6 +1347,17 @@ void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlo
                         const int* block_offsets, const PointXYZINormal* body, const PointXYZINormal* normvec,
                         PointXYZINormal* cloud_ori, PointXYZINormal* corr_norm, hipStream_t st) {
     if (nblocks) hipLaunchKernelGGL(k_sel_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_offsets, body, normvec, cloud_ori, corr_norm);
+}
+
+void launch_eskf_refit(const MapGrid& grid, const PointXYZINormal* body, int n, const LidarStateDev* state, const int* nearest_idx,
+                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_eskf_refit, dim3((n + 255) / 256), dim3(256), 0, st, grid, body, n, state, nearest_idx, world, selected, normvec);
+}
+void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev* state, const uint8_t* selected, const PointXYZINormal* normvec,
+                        int extrinsic_est_en, double* partial, double* out, hipStream_t st) {
+    const int nb = (n + 255) / 256;
+    if (nb) hipLaunchKernelGGL(k_eskf_normal, dim3(nb), dim3(256), 0, st, body, n, state, selected, normvec, extrinsic_est_en, partial);
+    hipLaunchKernelGGL(k_eskf_reduce, dim3(1), dim3(256), 0, st, partial, nb, out);
 }
 
 void launch_mapinc_classify(const PointXYZINormal* body, int n, const LidarStateDev& st, const MapGrid& grid, const int* nearest_idx,
