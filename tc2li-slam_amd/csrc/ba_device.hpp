@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "ba_math.hpp"
+#include "balm_device.hpp"
 #include "inertial_math.hpp"
 
 namespace tc2li {
@@ -41,5 +42,27 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
 void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st);
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st);
+
+// ---- lock-step batch (tc2li_local_bundle_adjustment_batch): one launch per phase for all windows ----
+// A slot describes one window for the batched kernels; the table lives in device memory and is rewritten by the host before a
+// phase whenever a window's state (accepted / trial buffers, lambda, step) changed.
+struct BaBatchSlot {
+    BaProblemDev pb;
+    double lambda;
+    int32_t n_slices, k_per_slice, want_maxdiag, has_lidar;
+    double *chi_out, *maxdiag_out, *S_out, *bs_out, *scale_out, *chi_trial_out;
+    const double* xp;
+    uint8_t* depth_out;
+    BalmDev balm;
+};
+struct BaBatchExtent { int max_edges, max_points, max_poses, max_free, max_free_edges, max_np_pad, max_slices, max_planes, max_chunks, max_W; };
+void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
+void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+// the LiDAR term of the listed windows (all with W <= 7 and at most 2048 planes): residual at the accepted or the trial poses,
+// Jacobian / Hessian at the accepted poses
+void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st);
+void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st);
 
 }  // namespace tc2li

@@ -662,6 +662,309 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
     return done;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ---- lock-step batch -----------------------------------------------------------------------------------------------------
+// All windows advance through the phases of the Levenberg-Marquardt loop together: one launch per kernel and one stream
+// synchronisation per phase for the whole batch (a window alone is bound by launch and synchronisation latency: its kernels take
+// 5-20 us each).  The arithmetic of a window is the one of tc2li_local_lv_bundle_adjustment (same kernel bodies, same host
+// steps), so the results are identical to optimising the windows one by one.
+struct LockstepWindow {
+    const tc2li_ba_problem* p = nullptr;
+    BaWorkspace* ws = nullptr;
+    VisualProblem vp;
+    BalmTerm* lidar = nullptr;
+    std::vector<uint8_t> extra_used;
+    std::vector<double> Swork, x, Hl, bl_;
+    double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, max_pose_diag = 0;
+    int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
+    bool ok = true, ok2 = true, need_diag = false, want_maxdiag = false;
+    bool stopped() const { return p->stop_flag && *p->stop_flag; }
+    bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
+};
+
+struct LockstepContext {
+    std::mutex mu;
+    std::vector<std::unique_ptr<BaWorkspace>> ws;
+    DevBuf<BaBatchSlot> d_slots;
+    DevBuf<int> d_lists;
+    PinnedBuf<BaBatchSlot> h_slots;
+    PinnedBuf<int> h_lists;
+    hipStream_t st = nullptr;
+};
+LockstepContext& lockstep_ctx() { static LockstepContext c; return c; }
+
+// returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
+bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results) {
+    LockstepContext& C = lockstep_ctx();
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (int i = 0; i < n; ++i)
+        if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
+    if (!C.st && hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
+    hipStream_t st = C.st;
+    while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
+    if (C.d_slots.ensure(n) != hipSuccess || C.d_lists.ensure(4 * (size_t)n) != hipSuccess || C.h_slots.ensure(n) != hipSuccess ||
+        C.h_lists.ensure(4 * (size_t)n) != hipSuccess) return false;
+    std::vector<LockstepWindow> W(n);
+    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = now();
+    const double t_begin = t0;
+    // ---- setup: argument checks, plane extraction (host), uploads ----
+    pool.parallel_for(n, [&](int i) {
+        LockstepWindow& w = W[i];
+        const tc2li_ba_problem& p = problems[i];
+        w.p = &p; w.ws = C.ws[i].get();
+        if (!p.poses7 || !p.fixed || !p.points3 || !p.edges || p.n_poses <= 0 || p.n_points <= 0 || p.n_edges <= 0 || p.iterations < 0) {
+            set_error("tc2li_local_bundle_adjustment: invalid argument");
+            w.rc = TC2LI_ERR_INVALID;
+            return;
+        }
+        if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
+        if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
+        if (p.lidar) {
+            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) { set_error("lidar window: invalid argument"); w.rc = TC2LI_ERR_INVALID; return; }
+            w.extra_used.assign(p.n_poses, 0);
+            for (int k = 0; k < p.lidar->n_keyframes; ++k) {
+                const int q = p.lidar->pose_index[k];
+                if (q < 0 || q >= p.n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", k, q); w.rc = TC2LI_ERR_INVALID; return; }
+                w.extra_used[q] = 1;
+            }
+            w.rc = w.ws->lidar.build(p.poses7, p.n_poses, p.lidar, st);
+            if (w.rc < 0) return;
+            w.lidar = &w.ws->lidar;
+        }
+        w.rc = w.vp.setup(*w.ws, p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
+                          w.extra_used.empty() ? nullptr : w.extra_used.data(), st);
+        if (w.rc < 0) return;
+        const int np = w.vp.np;
+        w.Swork.assign((size_t)std::max(np * np, 1), 0.0);
+        w.x.assign(std::max(np, 1), 0.0);
+        if (w.lidar) { w.Hl.assign((size_t)np * np, 0.0); w.bl_.assign(np, 0.0); }
+    });
+    for (int i = 0; i < n; ++i)
+        if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) {  // outside the batched LiDAR kernels: per-window path for this batch
+            (void)hipStreamSynchronize(st);
+            return false;
+        }
+    tm[0] = now() - t0;
+    BaBatchExtent X{};
+    for (int i = 0; i < n; ++i) {
+        if (W[i].rc < 0) continue;
+        const BaProblemDev& pb = W[i].vp.pb;
+        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
+        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges);
+        X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
+        if (W[i].lidar) {
+            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
+            X.max_W = std::max(X.max_W, W[i].lidar->W);
+        }
+    }
+    auto fill_slot = [&](int i) {
+        LockstepWindow& w = W[i];
+        BaBatchSlot& s = C.h_slots.p[i];
+        s.pb = w.vp.pb;
+        s.lambda = w.lambda;
+        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.want_maxdiag = w.want_maxdiag; s.has_lidar = w.lidar != nullptr;
+        double* sc = w.ws->h_scal.p;
+        s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
+        s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
+        if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
+    };
+    bool failed = false;
+    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_lists[0..), list b at d_lists[n..)
+        for (size_t k = 0; k < a.size(); ++k) C.h_lists.p[k] = a[k];
+        for (size_t k = 0; k < b.size(); ++k) C.h_lists.p[n + k] = b[k];
+        if (hipMemcpyAsync(C.d_slots.p, C.h_slots.p, n * sizeof(BaBatchSlot), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(C.d_lists.p, C.h_lists.p, 2 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+    };
+    auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
+
+    for (;;) {
+        std::vector<int> active, with_lidar;
+        for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
+        if (active.empty() || failed) break;
+        // ---- phase A: linearisation at the accepted estimate ----
+        t0 = now();
+        bool any_maxdiag = false;
+        for (int i : active) {
+            LockstepWindow& w = W[i];
+            w.want_maxdiag = w.it == 0 && !(w.p->lambda_init > 0);
+            w.need_diag = w.lidar && w.want_maxdiag && w.vp.n_free > 0;
+            any_maxdiag |= w.want_maxdiag;
+            if (w.lidar) with_lidar.push_back(i);
+            fill_slot(i);
+        }
+        upload(active, with_lidar);
+        ba_batch_launch_linearize(C.d_slots.p, C.d_lists.p, (int)active.size(), X, any_maxdiag, st);
+        for (int i : active) {
+            LockstepWindow& w = W[i];
+            if (!w.need_diag) continue;
+            if (w.ws->h_Hpp.ensure(27 * (size_t)w.vp.n_free) != hipSuccess ||
+                hipMemcpyAsync(w.ws->h_Hpp.p, w.ws->d_Hpp.p, 27 * (size_t)w.vp.n_free * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+        }
+        balm_batch_launch_residual(C.d_slots.p, C.d_lists.p + n, (int)with_lidar.size(), false, st);
+        balm_batch_launch_hessian(C.d_slots.p, C.d_lists.p + n, (int)with_lidar.size(), X, st);
+        sync();
+        if (failed) break;
+        tm[1] += now() - t0; t0 = now();
+        pool.parallel_for((int)active.size(), [&](int k) {
+            LockstepWindow& w = W[active[k]];
+            const int np = w.vp.np;
+            const double* sc = w.ws->h_scal.p;
+            w.currentChi = sc[0];
+            w.max_pose_diag = sc[2];
+            if (w.lidar) {
+                w.lidar->finish_error();
+                w.currentChi = w.lidar->chi2() + w.currentChi;
+                w.lidar->finish_linearization();
+                std::fill(w.Hl.begin(), w.Hl.end(), 0.0);
+                std::fill(w.bl_.begin(), w.bl_.end(), 0.0);
+                w.lidar->add_quadratic_form(w.vp.pose_var.data(), np, w.Hl.data(), w.bl_.data());
+                if (w.need_diag) {
+                    static const int dpos[6] = {0, 6, 11, 15, 18, 20};
+                    w.max_pose_diag = 0;
+                    for (int j = 0; j < np; ++j)
+                        w.max_pose_diag = std::max(w.max_pose_diag, std::fabs(w.ws->h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + w.Hl[(size_t)j * np + j]));
+                }
+            }
+            w.tempChi = w.currentChi;
+            w.iniChi = w.currentChi;
+            if (w.it == 0) {
+                if (w.p->stats) w.p->stats->initial_chi2 = w.currentChi;
+                w.lambda = w.p->lambda_init > 0 ? w.p->lambda_init : 1e-5 * std::max(sc[1], w.max_pose_diag);
+                w.ni = 2;
+                w.n_bad = 0;
+            }
+            w.rho = 0;
+            w.qmax = 0;
+        });
+        // ---- trials ----
+        tm[2] += now() - t0;
+        std::vector<int> trial = active;
+        while (!trial.empty() && !failed) {
+            // phase B: reduced camera system at the window's lambda
+            t0 = now();
+            for (int i : trial) fill_slot(i);
+            upload(trial, {});
+            ba_batch_launch_schur(C.d_slots.p, C.d_lists.p, (int)trial.size(), X, st);
+            sync();
+            if (failed) break;
+            tm[3] += now() - t0; t0 = now();
+            pool.parallel_for((int)trial.size(), [&](int k) {
+                LockstepWindow& w = W[trial[k]];
+                const int np = w.vp.np;
+                BaWorkspace& ws = *w.ws;
+                w.ok2 = true;
+                if (np > 0) {
+                    memcpy(w.Swork.data(), ws.h_S.p, (size_t)np * np * sizeof(double));
+                    if (w.lidar) {
+                        for (size_t q = 0; q < (size_t)np * np; ++q) w.Swork[q] += w.Hl[q];
+                        for (int j = 0; j < np; ++j) { ws.h_bs.p[j] += w.bl_[j]; ws.h_bs.p[np + j] += w.bl_[j]; }
+                    }
+                    w.ok2 = ldlt_solve_small(w.Swork.data(), np, ws.h_bs.p, w.x.data(), false);
+                    memcpy(ws.h_xp.p, w.x.data(), np * sizeof(double));
+                }
+                w.scale = 0;
+                for (int j = 0; j < np; ++j) w.scale += w.x[j] * (w.lambda * w.x[j] + ws.h_bs.p[np + j]);
+            });
+            // phase C: the trial estimate and its cost
+            tm[4] += now() - t0; t0 = now();
+            std::vector<int> step, step_lidar;
+            for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
+            if (!step.empty()) {
+                upload(step, step_lidar);  // slots unchanged since phase B
+                ba_batch_launch_trial(C.d_slots.p, C.d_lists.p, (int)step.size(), X, st);
+                balm_batch_launch_residual(C.d_slots.p, C.d_lists.p + n, (int)step_lidar.size(), true, st);
+                sync();
+                if (failed) break;
+            }
+            tm[5] += now() - t0; t0 = now();
+            std::vector<int> again;
+            for (int i : trial) {
+                LockstepWindow& w = W[i];
+                if (w.ok2) {
+                    const double* sc = w.ws->h_scal.p;
+                    w.tempChi = sc[4];
+                    w.scale += sc[3];
+                    if (w.lidar) { w.lidar->finish_error(); w.tempChi = w.lidar->chi2() + w.tempChi; }
+                } else {
+                    w.tempChi = std::numeric_limits<double>::max();
+                }
+                w.rho = w.currentChi - w.tempChi;
+                w.scale += 1e-3;
+                w.rho /= w.scale;
+                if (w.rho > 0 && std::isfinite(w.tempChi)) {
+                    double alpha = 1. - std::pow((2 * w.rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    w.lambda *= std::max(1. / 3., alpha);
+                    w.ni = 2;
+                    w.currentChi = w.tempChi;
+                    std::swap(w.vp.pb.poses, w.vp.pb.poses_trial);
+                    std::swap(w.vp.pb.points, w.vp.pb.points_trial);
+                } else {
+                    w.lambda *= w.ni;
+                    w.ni *= 2;
+                }
+                w.qmax++;
+                w.trials_total++;
+                if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
+            }
+            trial.swap(again);
+        }
+        for (int i : active) {
+            LockstepWindow& w = W[i];
+            ++w.done;
+            ++w.it;
+            if (w.p->stats) { w.p->stats->final_chi2 = w.currentChi; w.p->stats->final_lambda = w.lambda; }
+            if (w.qmax == 10 || w.rho == 0) { w.ok = false; continue; }
+            if ((w.iniChi - w.currentChi) * 1e3 < w.iniChi) w.n_bad++; else w.n_bad = 0;
+            if (w.n_bad >= 3) w.ok = false;
+        }
+    }
+    // ---- results ----
+    t0 = now();
+    std::vector<int> all;
+    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
+    if (!failed && !all.empty()) {
+        upload(all, {});
+        ba_batch_launch_depth(C.d_slots.p, C.d_lists.p, (int)all.size(), X, st);
+        for (int i : all) {
+            LockstepWindow& w = W[i];
+            const tc2li_ba_problem& p = *w.p;
+            const BaProblemDev& pb = w.vp.pb;
+            const size_t E = p.n_edges, P = p.n_points;
+            if (hipMemcpyAsync(w.vp.poses.data(), pb.poses, p.n_poses * sizeof(Se3), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(p.points3, pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            if (p.edge_chi2 && hipMemcpyAsync(p.edge_chi2, w.ws->d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            if (p.edge_depth_positive && hipMemcpyAsync(p.edge_depth_positive, w.ws->d_depth.p, E, hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+        }
+        sync();
+    }
+    for (int i = 0; i < n; ++i) {
+        LockstepWindow& w = W[i];
+        if (w.rc < 0) { results[i] = w.rc; continue; }
+        if (failed) { set_error("tc2li_local_bundle_adjustment_batch: HIP error in the lock-step loop: %s", hipGetErrorString(hipGetLastError())); results[i] = TC2LI_ERR_HIP; continue; }
+        const tc2li_ba_problem& p = *w.p;
+        for (int k = 0; k < p.n_poses; ++k) { memcpy(p.poses7 + 7 * k, w.vp.poses[k].q, 4 * sizeof(double)); memcpy(p.poses7 + 7 * k + 4, w.vp.poses[k].t, 3 * sizeof(double)); }
+        if (p.stats) { p.stats->iterations = w.done; p.stats->trials = w.trials_total; p.stats->n_free_poses = w.vp.n_free; }
+        if (w.lidar && p.lidar_stats) {
+            p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = w.lidar->hessian_evaluations;
+            p.lidar_stats->residual = w.lidar->error; p.lidar_stats->chi2 = w.lidar->chi2();
+        }
+        results[i] = w.done;
+    }
+    if (kTiming) fprintf(stderr, "BA lock-step timing ms (%d windows): setup %.3f linearize %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f results %.3f total %.3f\n",
+                         n, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], now() - t0, now() - t_begin);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
 int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int max_concurrency,
                                         int32_t* results) {
     if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam) { set_error("tc2li_local_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
@@ -669,6 +972,12 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
     static WorkerPool* pool = new WorkerPool(16);  // persistent: its threads keep their streams and workspaces
+    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;  // A/B switch for measurements
+    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep && ba_batch_lockstep(problems, n_problems, cam, *pool, results)) {
+        int ok_ = 0;
+        for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
+        return ok_;
+    }
     struct ThreadStream {
         hipStream_t s = nullptr;
         ~ThreadStream() { if (s) (void)hipStreamDestroy(s); }

@@ -47,9 +47,9 @@ __device__ __forceinline__ void block_sum_256(double v, double* s, double* __res
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
+__device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int bx) {
     __shared__ double s_sum[256];
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx * 256 + threadIdx.x;
     double rho0 = 0;
     if (e < pb.n_edges) {
         const BaEdge ed = pb.edges[e];
@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
                 }
         }
     }
-    block_sum_256(rho0, s_sum, pb.chi_part + blockIdx.x);  // the robust cost is summed per workgroup here, finished in the next launch
+    block_sum_256(rho0, s_sum, pb.chi_part + bx);  // the robust cost is summed per workgroup here, finished in the next launch
 }
+__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) { d_ba_linearize(pb, blockIdx.x); }
 
 __device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int block) {
     const int l = block * 256 + threadIdx.x;
@@ -191,20 +192,22 @@ __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, 
 
 // One launch after k_ba_linearize: workgroups [0, nbp) sum the landmark blocks, [nbp, nbp + n_free) the pose blocks, the
 // last one the robust cost (the three jobs only read what the linearisation wrote).
-__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, int nbp, double* __restrict__ chi_out) {
+__device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, int nbp, double* __restrict__ chi_out) {
     __shared__ double s_part[256 * 27];
-    const int b = blockIdx.x;
+    const int b = bx;
     if (b < nbp) reduce_points_body(pb, b);
     else if (b < nbp + pb.n_free) reduce_poses_body(pb, b - nbp, s_part);
     else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s_part, chi_out);
 }
+__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, int nbp, double* __restrict__ chi_out) { d_ba_reduce_all(pb, blockIdx.x, nbp, chi_out); }
 
 // computeLambdaInit needs the largest diagonal entries: [0] landmarks, [1] poses (first iteration only)
-__global__ __launch_bounds__(256) void k_ba_maxdiag(BaProblemDev pb, double* __restrict__ out) {
+__device__ __forceinline__ void d_ba_maxdiag(const BaProblemDev& pb, const int bx, double* __restrict__ out) {
     __shared__ double s[256];
-    if (blockIdx.x == 0) block_reduce_256<true>(pb.diag_l, pb.n_points, s, out);
+    if (bx == 0) block_reduce_256<true>(pb.diag_l, pb.n_points, s, out);
     else block_reduce_256<true>(pb.diag_p, pb.n_free, s, out + 1);
 }
+__global__ __launch_bounds__(256) void k_ba_maxdiag(BaProblemDev pb, double* __restrict__ out) { d_ba_maxdiag(pb, blockIdx.x, out); }
 
 // (Hll + lambda I)^-1 and its product with b_l for landmark l
 __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double lambda, double Di[9], double db[3]) {
@@ -223,9 +226,9 @@ __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double
 // One launch: workgroups [0, nbp) store D^-1 and D^-1 b_l per landmark (for the back substitution), the others handle
 // the edges with a free pose: W D^-1 and W (6x3) scattered into the two k-major GEMM operands, W D^-1 b_l.  An edge
 // recomputes its landmark's 3x3 inverse (same arithmetic, same value) instead of waiting for the landmark pass.
-__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int nbp, double lambda) {
-    if ((int)blockIdx.x < nbp) {
-        const int l = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const int bx, int nbp, double lambda) {
+    if (bx < nbp) {
+        const int l = bx * 256 + threadIdx.x;
         if (l >= pb.n_points) return;
         double Di[9], db[3];
         point_dinv(pb, l, lambda, Di, db);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int n
         for (int r = 0; r < 3; ++r) pb.db[3 * (size_t)l + r] = db[r];
         return;
     }
-    const int k = ((int)blockIdx.x - nbp) * 256 + threadIdx.x;  // index into the list of edges with a free pose
+    const int k = (bx - nbp) * 256 + threadIdx.x;  // index into the list of edges with a free pose
     if (k >= pb.n_free_edges) return;
     const int e = pb.pv_edges[k];
     const BaEdge ed = pb.edges[e];
@@ -253,21 +256,23 @@ __global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int n
         }
     }
 }
+__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int nbp, double lambda) { d_ba_schur_prepare(pb, blockIdx.x, nbp, lambda); }
 
-__global__ __launch_bounds__(256) void k_ba_reduce_coef(BaProblemDev pb) {
+__device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const int bx) {
     __shared__ double s_part[256 * 6];
-    const int i = blockIdx.x;
+    const int i = bx;
     block_sum_items<6>(pb.coef_e, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.coef + 6 * (size_t)i);
 }
+__global__ __launch_bounds__(256) void k_ba_reduce_coef(BaProblemDev pb) { d_ba_reduce_coef(pb, blockIdx.x); }
 
 // S_part[slice] (np_pad x np_pad, row-major) = sum over the slice's k of AT[k][:]^T BT[k][:]; one wavefront per
 // 16x16 tile and k-slice.  Fragment layout of v_mfma_f64_16x16x4_f64 (checked on gfx950, tools/dbg/mfma_f64_test.hip):
 // A: lane -> A[i = lane % 16][k = lane / 16]; B: lane -> B[k = lane / 16][j = lane % 16];
 // D: lane, r -> D[i = lane / 16 + 4 r][j = lane % 16].
-__global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__ AT, const double* __restrict__ BT, int np_pad,
-                                                      int k_total, int k_per_slice, double* __restrict__ S_part) {
+__device__ __forceinline__ void d_ba_schur_gemm(const int bx, const int by, const double* __restrict__ AT, const double* __restrict__ BT, int np_pad,
+                                                int k_total, int k_per_slice, double* __restrict__ S_part) {
     const int lane = threadIdx.x, tiles = np_pad / 16;
-    const int ti = blockIdx.x / tiles, tj = blockIdx.x % tiles, slice = blockIdx.y;
+    const int ti = bx / tiles, tj = bx % tiles, slice = by;
     const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
     v4d acc = {0, 0, 0, 0};
     const int i = lane % 16, kk = lane / 16;
@@ -297,10 +302,14 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__
     double* out = S_part + (size_t)slice * np_pad * np_pad;
     for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + kk + 4 * r) * np_pad + 16 * tj + i] = acc[r];
 }
+__global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__ AT, const double* __restrict__ BT, int np_pad,
+                                                      int k_total, int k_per_slice, double* __restrict__ S_part) {
+    d_ba_schur_gemm(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
+}
 
-__global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double lambda, int n_slices, double* __restrict__ S_out,
+__device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) {
-    const int np = 6 * pb.n_free, idx = blockIdx.x * 256 + threadIdx.x;
+    const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
     if (idx < np * np) {
         const int r = idx / np, c = idx % np;
         double s = 0;
@@ -330,6 +339,8 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double
         bs_out[np + idx] = bp;
     }
 }
+__global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double lambda, int n_slices, double* __restrict__ S_out,
+                                                         double* __restrict__ bs_out) { d_ba_schur_finish(pb, blockIdx.x, lambda, n_slices, S_out, bs_out); }
 
 // x_l = D^-1 (b_l - W^T x_p) for four landmarks per workgroup: the three rows of W^T of a landmark are rows 3l..3l+2 of
 // the k-major GEMM operand BT (zeros where the landmark has no edge to a pose), 16 lanes per row, fixed shuffle order.
@@ -359,10 +370,10 @@ __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, 
 }
 
 // One launch: workgroups [0, nbp) back-substitute the landmarks, the rest move the poses (exp(x_p) * T)
-__global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nbp, const double* __restrict__ xp, double lambda) {
+__device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const int bx, int nbp, const double* __restrict__ xp, double lambda) {
     __shared__ double s_sum[256];
-    if ((int)blockIdx.x < nbp) { backsub_body(pb, blockIdx.x, xp, lambda, s_sum); return; }
-    const int k = ((int)blockIdx.x - nbp) * 256 + threadIdx.x;
+    if (bx < nbp) { backsub_body(pb, bx, xp, lambda, s_sum); return; }
+    const int k = (bx - nbp) * 256 + threadIdx.x;
     if (k >= pb.n_poses) return;
     const int i = pb.pose_var[k];
     if (pb.inertial) {
@@ -380,17 +391,19 @@ __global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nb
     for (int r = 0; r < 6; ++r) u[r] = xp[6 * i + r];
     pb.poses_trial[k] = se3_exp_mul(u, pb.poses[k]);
 }
+__global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nbp, const double* __restrict__ xp, double lambda) { d_ba_trial_update(pb, blockIdx.x, nbp, xp, lambda); }
 
 // [0] landmark part of the gain-ratio scale, [1] robust cost of the trial estimate
-__global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double* __restrict__ scale_out, double* __restrict__ chi_out) {
+__device__ __forceinline__ void d_ba_trial_reduce(const BaProblemDev& pb, const int bx, double* __restrict__ scale_out, double* __restrict__ chi_out) {
     __shared__ double s[256];
-    if (blockIdx.x == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + 3) / 4, s, scale_out);
+    if (bx == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + 3) / 4, s, scale_out);
     else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
 }
+__global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double* __restrict__ scale_out, double* __restrict__ chi_out) { d_ba_trial_reduce(pb, blockIdx.x, scale_out, chi_out); }
 
-__global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) {
+__device__ __forceinline__ void d_ba_errors(const BaProblemDev& pb, const int bx) {
     __shared__ double s_sum[256];
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = bx * 256 + threadIdx.x;
     double rho0 = 0;
     if (e < pb.n_edges) {
         const BaEdge ed = pb.edges[e];
@@ -403,11 +416,12 @@ __global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) {
         pb.chi2[e] = c2;
         pb.rho0[e] = rho0;
     }
-    block_sum_256(rho0, s_sum, pb.chi_part + blockIdx.x);
+    block_sum_256(rho0, s_sum, pb.chi_part + bx);
 }
+__global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) { d_ba_errors(pb, blockIdx.x); }
 
-__global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __restrict__ depth_pos) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void d_ba_depth(const BaProblemDev& pb, const int bx, uint8_t* __restrict__ depth_pos) {
+    const int e = bx * 256 + threadIdx.x;
     if (e >= pb.n_edges) return;
     const BaEdge ed = pb.edges[e];
     const double* X = pb.points + 3 * (size_t)ed.point;
@@ -420,6 +434,73 @@ __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __re
     se3_map(pb.poses[ed.pose], X, p);
     depth_pos[e] = p[2] > 0.0;
 }
+__global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __restrict__ depth_pos) { d_ba_depth(pb, blockIdx.x, depth_pos); }
+
+
+// ---- lock-step batch: the same bodies, the window taken from a slot table (blockIdx.y / z = position in the active list) ----
+static inline __device__ int blocks256(int n) { return (n + 255) / 256; }
+#define TC2LI_SLOT(axis) const BaBatchSlot& sl = slots[active[blockIdx.axis]]; const BaProblemDev pb = sl.pb  /* a private copy: no reloads after stores */
+
+__global__ __launch_bounds__(256) void k_ba_linearize_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    d_ba_linearize(pb, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    const int nbp = blocks256(pb.n_points);
+    if ((int)blockIdx.x >= nbp + pb.n_free + 1) return;
+    d_ba_reduce_all(pb, blockIdx.x, nbp, sl.chi_out);
+}
+__global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if (!sl.want_maxdiag) return;
+    d_ba_maxdiag(pb, blockIdx.x, sl.maxdiag_out);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    const int nbp = blocks256(pb.n_points);
+    if ((int)blockIdx.x >= nbp + (pb.n_free_edges ? blocks256(pb.n_free_edges) : 0)) return;
+    d_ba_schur_prepare(pb, blockIdx.x, nbp, sl.lambda);
+}
+__global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= pb.n_free) return;
+    d_ba_reduce_coef(pb, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(z);
+    const int tiles = pb.np_pad / 16;
+    if (!pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
+    d_ba_schur_gemm(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    const int np = 6 * pb.n_free;
+    if (!pb.n_free || (int)blockIdx.x >= blocks256(np * np)) return;
+    d_ba_schur_finish(pb, blockIdx.x, sl.lambda, sl.n_slices, sl.S_out, sl.bs_out);
+}
+__global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    const int nbp = (pb.n_points + 3) / 4;
+    if ((int)blockIdx.x >= nbp + blocks256(pb.n_poses)) return;
+    d_ba_trial_update(pb, blockIdx.x, nbp, sl.xp, sl.lambda);
+}
+__global__ __launch_bounds__(256) void k_ba_errors_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    d_ba_errors(pb, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_ba_trial_reduce_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    d_ba_trial_reduce(pb, blockIdx.x, sl.scale_out, sl.chi_trial_out);
+}
+__global__ __launch_bounds__(256) void k_ba_depth_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    d_ba_depth(pb, blockIdx.x, sl.depth_out);
+}
+#undef TC2LI_SLOT
 
 // ---- launch wrappers ----------------------------------------------------------------------------------------------
 static inline int blocks(int n) { return (n + 255) / 256; }
@@ -453,6 +534,31 @@ void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, do
 
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st) {
     hipLaunchKernelGGL(k_ba_depth, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, depth_pos);
+}
+
+void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
+    if (!n_active) return;
+    hipLaunchKernelGGL(k_ba_linearize_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_reduce_all_b, dim3(blocks(x.max_points) + x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
+    if (any_maxdiag) hipLaunchKernelGGL(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+}
+void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+    if (!n_active) return;
+    hipLaunchKernelGGL(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + blocks(x.max_free_edges), n_active), dim3(256), 0, st, slots, active);
+    if (!x.max_free) return;
+    hipLaunchKernelGGL(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
+    const int tiles = x.max_np_pad / 16;
+    hipLaunchKernelGGL(k_ba_schur_gemm_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
+}
+void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+    if (!n_active) return;
+    hipLaunchKernelGGL(k_ba_trial_update_b, dim3((x.max_points + 3) / 4 + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+}
+void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+    if (n_active) hipLaunchKernelGGL(k_ba_depth_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
 }
 
 }  // namespace tc2li

@@ -26,6 +26,7 @@ struct BalmDev {
 
 inline int balm_items(int W) { return W * (W + 1) / 2 * 36; }
 inline int balm_part_stride(int W) { return balm_items(W) + 6 * W + 1; }
+__device__ inline int balm_part_stride_dev(int W) { return W * (W + 1) / 2 * 36 + 6 * W + 1; }
 inline int balm_out_size(int W) { return 2 + 6 * W + 36 * W * W + 12 * W; }
 
 // out[0] = sum over planes of coe * lambda_min at the window poses derived from the vertex estimates `poses`

@@ -10,6 +10,7 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include "ba_device.hpp"
 #include "balm_device.hpp"
 
 namespace tc2li {
@@ -88,7 +89,7 @@ __device__ __forceinline__ void sum_fixed_256(const double* __restrict__ in, int
 }
 
 // VOX_HESS::evaluate_only_residual in one launch when the planes fit one workgroup's loop: poses, per-plane terms, sum
-__global__ __launch_bounds__(256) void k_balm_residual_total(BalmDev b, const Se3* __restrict__ poses) {
+__device__ __forceinline__ void d_balm_residual_total(const BalmDev& b, const Se3* __restrict__ poses) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
     __shared__ double s[256];
     window_poses(b, poses, s_twl);
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void k_balm_residual_total(BalmDev b, const Se
     __syncthreads();
     sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
 }
+__global__ __launch_bounds__(256) void k_balm_residual_total(BalmDev b, const Se3* __restrict__ poses) { d_balm_residual_total(b, poses); }
 // many planes: one thread per plane over the whole grid, then the same fixed-order sum
 __global__ __launch_bounds__(256) void k_balm_residual_planes(BalmDev b, const Se3* __restrict__ poses) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
 }
 
 template <int kItemsPerThread>
-__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) {
+__device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
     __shared__ ClusterW s_cw[kMaxLidarWindow];
     __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const 
     __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
     window_poses(b, poses, s_twl);
-    if (blockIdx.x == 0 && tid < W) b.twl[tid] = s_twl[tid];  // for the change of variables on the host
+    if (bx == 0 && tid < W) b.twl[tid] = s_twl[tid];  // for the change of variables on the host
     if (tid == 0) {
         int p = 0;
         for (int i = 0; i < W; ++i)
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const 
     double acc[kItemsPerThread], jac[6] = {0, 0, 0, 0, 0, 0}, res = 0;
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) acc[k] = 0;
-    const int a0 = blockIdx.x * b.planes_per_chunk, a1 = min(a0 + b.planes_per_chunk, b.n_planes);
+    const int a0 = bx * b.planes_per_chunk, a1 = min(a0 + b.planes_per_chunk, b.n_planes);
     for (int a = a0; a < a1; ++a) {
         const double coe = b.coe[a];
         PlaneCluster mine;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const 
         }
         __syncthreads();
     }
-    double* part = b.part + (size_t)blockIdx.x * (n_items + 6 * W + 1);
+    double* part = b.part + (size_t)bx * (n_items + 6 * W + 1);
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) {
         const int item = k * kHessThreads + tid;
@@ -248,13 +250,15 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const 
         for (int c = 0; c < 6; ++c) part[n_items + 6 * tid + c] = jac[c];
     if (tid == 0) part[n_items + 6 * W] = res;
 }
+template <int kItemsPerThread>
+__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) { d_balm_hessian<kItemsPerThread>(b, poses, blockIdx.x); }
 
 // chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one
 // wavefront per output value, its lanes add the chunks in a fixed order (strided partial sums, then shuffles).
-__global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
+__device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) {
     const int W = b.W, n = 6 * W, n_items = W * (W + 1) / 2 * 36, stride = n_items + n + 1;
-    const int lane = threadIdx.x & 63, idx = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, idx = (bx * 256 + threadIdx.x) >> 6;
+    const int t = bx * 256 + threadIdx.x;
     if (t < 12 * W) b.out[2 + n + n * n + t] = reinterpret_cast<const double*>(b.twl)[t];  // the poses the derivatives refer to
     if (idx >= stride) return;
     double s = 0;
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) {
     H[(size_t)(6 * i + r) * n + 6 * j + c] = s;
     if (i != j) H[(size_t)(6 * j + c) * n + 6 * i + r] = s;
 }
+__global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) { d_balm_combine(b, blockIdx.x); }
 
 void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
     if (b.n_planes <= 2048) {
@@ -285,6 +290,37 @@ void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
     if (b.W <= 7) hipLaunchKernelGGL(k_balm_hessian<kItemsSmall>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
     else hipLaunchKernelGGL(k_balm_hessian<kItemsLarge>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
     hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
+}
+
+// ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
+__device__ __forceinline__ const Se3* slot_poses(const BaBatchSlot& sl, bool trial) {
+    if (sl.pb.inertial) return reinterpret_cast<const Se3*>(trial ? sl.pb.iposes_trial : sl.pb.iposes);
+    return trial ? sl.pb.poses_trial : sl.pb.poses;
+}
+__global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list, int trial) {
+    const BaBatchSlot& sl = slots[list[blockIdx.x]];
+    const BalmDev b = sl.balm;
+    d_balm_residual_total(b, slot_poses(sl, trial != 0));
+}
+__global__ __launch_bounds__(kHessThreads) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+    const BaBatchSlot& sl = slots[list[blockIdx.y]];
+    const BalmDev b = sl.balm;
+    if ((int)blockIdx.x >= b.n_chunks) return;
+    d_balm_hessian<kItemsSmall>(b, slot_poses(sl, false), blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+    const BaBatchSlot& sl = slots[list[blockIdx.y]];
+    const BalmDev b = sl.balm;
+    if ((int)blockIdx.x >= (balm_part_stride_dev(b.W) + 3) / 4) return;
+    d_balm_combine(b, blockIdx.x);
+}
+void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, slots, list, trial ? 1 : 0);
+}
+void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreads), 0, st, slots, list);
+    hipLaunchKernelGGL(k_balm_combine_b, dim3((balm_part_stride(x.max_W) + 3) / 4, n), dim3(256), 0, st, slots, list);
 }
 
 }  // namespace tc2li
