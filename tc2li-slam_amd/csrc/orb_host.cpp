@@ -294,7 +294,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[1], st));
     if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, o->ev[1], 0));
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[4], blur_st));
-    for (int l = 0; l < L; ++l) launch_blur(raw.lv[l], blur.lv[l], M, blur_st);
+    launch_blur_all(raw, blur, L, M, blur_st);
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[5], blur_st));
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[8], st));
     if (ncells > 0) {

@@ -12,6 +12,13 @@
 
 namespace tc2li {
 
+// Pointers that arrive inside by-value tables (LevelTable) are generic to the compiler: loads through them become flat_load.
+// They are device-global by construction; saying so gives global_load (no LDS aperture check, vmcnt only).
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+    return (const __attribute__((address_space(1))) T*)p;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Pyramid level from the previous one: cv::resize(INTER_LINEAR) on 8-bit (SF/src/ORBextractor.cc:1156).
 // Tables (xofs/ialpha/yofs/ibeta) are built on the host with the library's float/double recipe.  One thread
@@ -291,49 +298,143 @@ __global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restric
 // ------------------------------------------------------------------------------------------------------
 // 7x7 sigma=2 Gaussian on 8-bit, REFLECT_101, OpenCV's fixed-point separable path
 // (SF/src/ORBextractor.cc:1105-1106): taps {18,34,48,56,48,34,18}/256, 8.8 horizontal, 16.16 vertical,
-// round to nearest.  64x16 output tile per workgroup, halo staged in LDS, dword stores.
+// round to nearest.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 16;
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, int pitch, size_t img_stride, int w, int h,
-                                               uint8_t* __restrict__ dst, int dpitch, size_t dimg_stride) {
-    __shared__ uint8_t in[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ uint16_t hz[(kBlurTH + 6) * kBlurTW];
-    const int tid = threadIdx.x, img = blockIdx.z;
-    const int x0 = blockIdx.x * kBlurTW, y0 = blockIdx.y * kBlurTH;
-    const uint8_t* S = src + (size_t)img * img_stride;
-    constexpr int IW = kBlurTW + 6, IP = kBlurTW + 8;
-    for (int i = tid; i < (kBlurTH + 6) * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        int sy = y0 + r - 3, sx = x0 + c - 3;
-        // REFLECT_101; tiles beyond the image only need valid addresses
-        sy = sy < 0 ? -sy : (sy >= h ? 2 * h - 2 - sy : sy);
-        sx = sx < 0 ? -sx : (sx >= w ? 2 * w - 2 - sx : sx);
-        sy = min(max(sy, 0), h - 1);
-        sx = min(max(sx, 0), w - 1);
-        in[r * IP + c] = S[(size_t)sy * pitch + sx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i / kBlurTW, c = i - r * kBlurTW;
-        const uint8_t* p = in + r * IP + c;
-        hz[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
-    }
-    __syncthreads();
-    // 64x16 outputs = 256 threads x 4 horizontally adjacent pixels
-    const int ty = tid >> 4, tx = (tid & 15) * 4;
-    const int oy = y0 + ty, ox = x0 + tx;
-    if (oy >= h || ox >= w) return;
-    uint32_t packed = 0;
+// Every level in one launch, streaming: a wavefront owns a strip of 256 columns x 32 rows; a lane loads one aligned dword per
+// row (rows of a caller image may start at any byte: the four pixels are cut out of two neighbouring dwords with
+// v_alignbit), takes its neighbours' pixels by wave shuffle, filters horizontally into four 8.8 values and keeps the last
+// seven rows of them in registers for the vertical pass: every pixel is read once from HBM (plus a 6-row halo per 32 rows)
+// and no LDS is used.  The few lanes at the left / right image border gather their pixels one by one with REFLECT_101.
+constexpr int kStripW = 256, kStripRows = 32, kStripWaves = 4;
+struct BlurWork { int32_t first_block[kMaxLevels + 1]; int32_t nsx[kMaxLevels], ncy[kMaxLevels]; int32_t nlevels, nimg; };
+
+__device__ __forceinline__ int reflect101(int v, int n) {
+    v = v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v);
+    return min(max(v, 0), n - 1);
+}
+// the dword of pixels [x, x + 4) of a row with REFLECT_101 applied per pixel (border lanes only)
+__device__ __forceinline__ uint32_t gather4(const uint8_t* __restrict__ row, int x, int w) {
+    uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint16_t* q = hz + ty * kBlurTW + tx + k;
-        const uint32_t acc = 18u * (q[0] + q[6 * kBlurTW]) + 34u * (q[kBlurTW] + q[5 * kBlurTW]) +
-                             48u * (q[2 * kBlurTW] + q[4 * kBlurTW]) + 56u * q[3 * kBlurTW];
-        packed |= ((acc + 32768u) >> 16) << (8 * k);
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)row[reflect101(x + k, w)] << (8 * k);
+    return v;
+}
+__device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t mid, uint32_t hi, int k /* -4 .. 7, compile time */) {
+    return k < 0 ? (lo >> (8 * (k + 4))) & 0xffu : (k < 4 ? (mid >> (8 * k)) & 0xffu : (hi >> (8 * (k - 4))) & 0xffu);
+}
+
+__global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable src, LevelTable dst, BlurWork wk) {
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; ++l) if (l < wk.nlevels && (int)blockIdx.x >= wk.first_block[l]) level = l;
+    const LevelDesc S = src.lv[level], D = dst.lv[level];
+    int b = blockIdx.x - wk.first_block[level];
+    const int per_img = wk.nsx[level] * wk.ncy[level];
+    const int img = b / per_img;
+    b -= img * per_img;
+    const int cy = b / wk.nsx[level], sx = b - cy * wk.nsx[level];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y0 = (cy * kStripWaves + wave) * kStripRows;
+    if (y0 >= S.h) return;
+    const int w = S.w, h = S.h;
+    const int x = sx * kStripW + 4 * lane;
+    const uint8_t* base = S.img + (size_t)img * S.img_stride;
+    uint8_t* out = const_cast<uint8_t*>(D.img) + (size_t)img * D.img_stride;
+    const bool inside = x < w;                        // the lane owns at least one pixel
+    const int y1 = min(y0 + kStripRows, h);
+    // Border lanes: the lane at x = 0 mirrors its left neighbour dword out of its own pixels, the last lane of the row mirrors
+    // the bytes past the row end out of its own and its left neighbour's pixels (REFLECT_101), both with one v_perm_b32 whose
+    // selector is fixed for the whole strip.  Byte numbering of v_perm(S0, S1): S1 = bytes 0..3, S0 = bytes 4..7.
+    const int nvalid = w - x;                          // pixels the lane owns when it is the last one: 1..4
+    const bool is_first = x == 0, is_last = inside && nvalid <= 4;
+    uint32_t sel_cur = 0x07060504u, sel_hi = 0;        // over (S0 = cur, S1 = lo)
+    if (is_last) {
+        sel_cur = 0; sel_hi = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int sc = i < nvalid ? 4 + i : 4 + 2 * nvalid - 2 - i;  // cur byte i
+            const int sh_ = 4 + 2 * nvalid - 6 - i;                        // hi byte i (only needed while it maps into lo / cur)
+            sel_cur |= (uint32_t)max(sc, 0) << (8 * i);
+            sel_hi |= (uint32_t)max(sh_, 0) << (8 * i);
+        }
     }
-    uint8_t* D = dst + (size_t)img * dimg_stride + (size_t)oy * dpitch + ox;
-    if (ox + 3 < w) *reinterpret_cast<uint32_t*>(D) = packed;
-    else for (int k = 0; k < 4 && ox + k < w; ++k) D[k] = (uint8_t)(packed >> (8 * k));
+    // rows whose dword loads could leave the buffer (they read up to 3 bytes before and 7 bytes after the row): the first row
+    // of the first image and the last row of the last image take the byte-wise path
+    const bool tiny = w < 16;
+    auto load4 = [](const uint8_t* p) -> uint32_t {  // four bytes at any address from the two aligned dwords around it
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+        const auto* q = as_global(reinterpret_cast<const uint32_t*>(p - mis));
+        const uint32_t d0 = q[0], d1 = mis ? q[1] : 0u;
+        return __builtin_amdgcn_alignbit(d1, d0, 8u * mis);
+    };
+    // V[j][k] = (hz of row j-1, hz of row j) of pixel k as two u16: the vertical pass is three v_dot2_u32_u16 on the pairs
+    // (r-6, r-5), (r-4, r-3), (r-2, r-1) plus the tap of row r.  Six rows of pairs live in registers; the loop is unrolled by
+    // six so that their roles rotate at compile time instead of moving registers.
+    uint32_t V[6][4], prev[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) V[j][k] = 0;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
+        return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+    };
+    constexpr uint32_t TA = 18u | (34u << 8) | (48u << 16) | (56u << 24), TB = 48u | (34u << 8) | (18u << 16);
+    constexpr uint32_t C01 = 18u | (34u << 16), C23 = 48u | (56u << 16), C45 = 48u | (34u << 16);
+    const int r_end = y1 + 3;
+    const bool own_next = inside && (lane == 63 || x + 4 >= w);  // the dword after the lane's own is not a neighbour's
+    for (int r0 = y0 - 3; r0 < r_end; r0 += 6) {
+#pragma unroll
+        for (int ph = 0; ph < 6; ++ph) {
+            const int r = r0 + ph;
+            if (r < r_end) {
+                const int ry = reflect101(r, h);
+                const uint8_t* row = base + (size_t)ry * S.pitch;
+                uint32_t cur = 0, lo, hi;
+                const bool guarded = tiny || (img == 0 && ry == 0) || (img == wk.nimg - 1 && ry == h - 1);
+                if (!guarded) {
+                    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(row + x) & 3);  // the same for every lane of the row
+                    const auto* q = as_global(reinterpret_cast<const uint32_t*>(row + x - mis));
+                    const uint32_t sh = 8u * mis;
+                    const uint32_t m = inside ? q[0] : 0u;
+                    uint32_t next = __shfl_down(m, 1, 64);
+                    if (own_next && sh) next = q[1];
+                    cur = __builtin_amdgcn_alignbit(next, m, sh);
+                    lo = __shfl_up(cur, 1, 64);
+                    if (lane == 0 && x > 0) lo = load4(row + x - 4);
+                    cur = __builtin_amdgcn_perm(cur, lo, sel_cur);           // identity except in the last lane
+                    hi = __shfl_down(cur, 1, 64);
+                    if (lane == 63 && x + 4 < w) hi = load4(row + x + 4);    // never the last lane of the row
+                    if (is_last) hi = __builtin_amdgcn_perm(cur, lo, sel_hi);
+                    if (is_first) lo = __builtin_amdgcn_perm(hi, cur, 0x01020304u);  // pixels -4..-1 = pixels 4, 3, 2, 1
+                } else {
+                    if (inside) { cur = gather4(row, x, w); lo = gather4(row, x - 4, w); hi = gather4(row, x + 4, w); }
+                    else { lo = 0; hi = 0; }
+                }
+                // horizontal: pixel k needs bytes k-3 .. k+3 around its own: two 4-byte windows, two v_dot4_u32_u8
+                uint32_t hz[4];
+                hz[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 1), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 1), TB, 0u, false), false);
+                hz[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 2), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 2), TB, 0u, false), false);
+                hz[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 3), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 3), TB, 0u, false), false);
+                hz[3] = __builtin_amdgcn_udot4(cur, TA, __builtin_amdgcn_udot4(hi, TB, 0u, false), false);
+                // slot (ph) receives the pair (row r-1, row r); the pairs of rows (r-6, r-5), (r-4, r-3), (r-2, r-1) are in the
+                // slots written 5, 3 and 1 rows ago
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t acc = dot2(V[(ph + 1) % 6][k], C01, dot2(V[(ph + 3) % 6][k], C23, dot2(V[(ph + 5) % 6][k], C45, 18u * hz[k] + 32768u)));
+                    packed |= (acc >> 16) << (8 * k);
+                    V[ph][k] = prev[k] | (hz[k] << 16);
+                    prev[k] = hz[k];
+                }
+                const int oy = r - 3;
+                if (oy >= y0 && inside) {
+                    uint8_t* o = out + (size_t)oy * D.pitch + x;
+                    if (x + 4 <= w) *reinterpret_cast<uint32_t*>(o) = packed;
+                    else for (int k = 0; k < 4 && x + k < w; ++k) o[k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -431,10 +532,19 @@ void launch_compact(const FastCell* cells, const int* level_cell_begin, const in
                        ncells, slab, slab_img_stride, dense, level_dense_off, level_counts, nlevels);
 }
 
-void launch_blur(const LevelDesc& src, const LevelDesc& dst, int nimg, hipStream_t st) {
-    dim3 grid((src.w + kBlurTW - 1) / kBlurTW, (src.h + kBlurTH - 1) / kBlurTH, nimg);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
-                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride);
+void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, hipStream_t st) {
+    BlurWork wk{};
+    wk.nlevels = nlevels; wk.nimg = nimg;
+    int total = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const LevelDesc& L = src.lv[l];
+        wk.first_block[l] = total;
+        wk.nsx[l] = (L.w + kStripW - 1) / kStripW;
+        wk.ncy[l] = (L.h + kStripRows * kStripWaves - 1) / (kStripRows * kStripWaves);
+        total += wk.nsx[l] * wk.ncy[l] * nimg;
+    }
+    for (int l = nlevels; l <= kMaxLevels; ++l) wk.first_block[l] = total;
+    if (total) hipLaunchKernelGGL(k_blur7_strips, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
 }
 
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
