@@ -42,6 +42,7 @@ struct BaWorkspace {
     PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp;
     DevBuf<ImuPose> d_iposes, d_iposes_trial;
     PinnedBuf<ImuPose> h_iposes;
+    PinnedBuf<uint8_t> h_result;  // lock-step batch: poses, points, per-edge chi2 and depth flags on their way to the caller
     BalmTerm lidar;
     std::mutex mu;
 };
@@ -713,37 +714,47 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = now();
     const double t_begin = t0;
     // ---- setup: argument checks, plane extraction (host), uploads ----
-    pool.parallel_for(n, [&](int i) {
+    std::vector<int> rc_lidar(n, 0);
+    pool.parallel_for(2 * n, [&](int task) {  // two tasks per window: the visual structure + uploads, the LiDAR plane extraction
+        const int i = task >> 1;
         LockstepWindow& w = W[i];
         const tc2li_ba_problem& p = problems[i];
-        w.p = &p; w.ws = C.ws[i].get();
-        if (!p.poses7 || !p.fixed || !p.points3 || !p.edges || p.n_poses <= 0 || p.n_points <= 0 || p.n_edges <= 0 || p.iterations < 0) {
-            set_error("tc2li_local_bundle_adjustment: invalid argument");
-            w.rc = TC2LI_ERR_INVALID;
+        const bool args_ok = p.poses7 && p.fixed && p.points3 && p.edges && p.n_poses > 0 && p.n_points > 0 && p.n_edges > 0 && p.iterations >= 0;
+        bool lidar_ok = true;
+        if (args_ok && p.lidar) {
+            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) lidar_ok = false;
+            else for (int k = 0; k < p.lidar->n_keyframes; ++k) if (p.lidar->pose_index[k] < 0 || p.lidar->pose_index[k] >= p.n_poses) lidar_ok = false;
+        }
+        if (task & 1) {
+            if (!args_ok || !lidar_ok || !p.lidar) return;
+            const double tb = now();
+            rc_lidar[i] = C.ws[i]->lidar.build(p.poses7, p.n_poses, p.lidar, st);
+            if (kTiming && i == 0) fprintf(stderr, "  window 0: lidar build %.3f ms\n", now() - tb);
             return;
         }
+        w.p = &p; w.ws = C.ws[i].get();
+        if (!args_ok) { set_error("tc2li_local_bundle_adjustment: invalid argument"); w.rc = TC2LI_ERR_INVALID; return; }
+        if (!lidar_ok) { set_error("lidar window: invalid argument or pose_index out of range"); w.rc = TC2LI_ERR_INVALID; return; }
         if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
         if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
         if (p.lidar) {
-            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) { set_error("lidar window: invalid argument"); w.rc = TC2LI_ERR_INVALID; return; }
             w.extra_used.assign(p.n_poses, 0);
-            for (int k = 0; k < p.lidar->n_keyframes; ++k) {
-                const int q = p.lidar->pose_index[k];
-                if (q < 0 || q >= p.n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", k, q); w.rc = TC2LI_ERR_INVALID; return; }
-                w.extra_used[q] = 1;
-            }
-            w.rc = w.ws->lidar.build(p.poses7, p.n_poses, p.lidar, st);
-            if (w.rc < 0) return;
-            w.lidar = &w.ws->lidar;
+            for (int k = 0; k < p.lidar->n_keyframes; ++k) w.extra_used[p.lidar->pose_index[k]] = 1;
         }
+        const double ts = now();
         w.rc = w.vp.setup(*w.ws, p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
                           w.extra_used.empty() ? nullptr : w.extra_used.data(), st);
+        if (kTiming && i == 0) fprintf(stderr, "  window 0: visual setup %.3f ms\n", now() - ts);
         if (w.rc < 0) return;
         const int np = w.vp.np;
         w.Swork.assign((size_t)std::max(np * np, 1), 0.0);
         w.x.assign(std::max(np, 1), 0.0);
-        if (w.lidar) { w.Hl.assign((size_t)np * np, 0.0); w.bl_.assign(np, 0.0); }
+        if (p.lidar) { w.Hl.assign((size_t)np * np, 0.0); w.bl_.assign(np, 0.0); }
     });
+    for (int i = 0; i < n; ++i) {
+        if (W[i].rc < 0 || !problems[i].lidar) continue;
+        if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
+    }
     for (int i = 0; i < n; ++i)
         if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) {  // outside the batched LiDAR kernels: per-window path for this batch
             (void)hipStreamSynchronize(st);
@@ -931,17 +942,33 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     if (!failed && !all.empty()) {
         upload(all, {});
         ba_batch_launch_depth(C.d_slots.p, C.d_lists.p, (int)all.size(), X, st);
-        for (int i : all) {
+        for (int i : all) {  // device -> pinned staging (asynchronous), then the copies into the caller's arrays run in parallel
             LockstepWindow& w = W[i];
             const tc2li_ba_problem& p = *w.p;
             const BaProblemDev& pb = w.vp.pb;
             const size_t E = p.n_edges, P = p.n_points;
-            if (hipMemcpyAsync(w.vp.poses.data(), pb.poses, p.n_poses * sizeof(Se3), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(p.points3, pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
-            if (p.edge_chi2 && hipMemcpyAsync(p.edge_chi2, w.ws->d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
-            if (p.edge_depth_positive && hipMemcpyAsync(p.edge_depth_positive, w.ws->d_depth.p, E, hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            const size_t bytes = p.n_poses * sizeof(Se3) + 3 * P * sizeof(double) + E * sizeof(double) + E;
+            if (w.ws->h_result.ensure(bytes) != hipSuccess) { failed = true; break; }
+            uint8_t* h = w.ws->h_result.p;
+            if (hipMemcpyAsync(h, pb.poses, p.n_poses * sizeof(Se3), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
+            if (p.edge_chi2 && hipMemcpyAsync(hc, w.ws->d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            if (p.edge_depth_positive && hipMemcpyAsync(hc + E * sizeof(double), w.ws->d_depth.p, E, hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
         }
         sync();
+        if (!failed)
+            pool.parallel_for((int)all.size(), [&](int k) {
+                LockstepWindow& w = W[all[k]];
+                const tc2li_ba_problem& p = *w.p;
+                const size_t E = p.n_edges, P = p.n_points;
+                const uint8_t* h = w.ws->h_result.p;
+                memcpy(w.vp.poses.data(), h, p.n_poses * sizeof(Se3));
+                memcpy(p.points3, h + p.n_poses * sizeof(Se3), 3 * P * sizeof(double));
+                const uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
+                if (p.edge_chi2) memcpy(p.edge_chi2, hc, E * sizeof(double));
+                if (p.edge_depth_positive) memcpy(p.edge_depth_positive, hc + E * sizeof(double), E);
+            });
     }
     for (int i = 0; i < n; ++i) {
         LockstepWindow& w = W[i];

@@ -237,11 +237,14 @@ __device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const
         for (int r = 0; r < 3; ++r) pb.db[3 * (size_t)l + r] = db[r];
         return;
     }
-    const int k = (bx - nbp) * 256 + threadIdx.x;  // index into the list of edges with a free pose
-    if (k >= pb.n_free_edges) return;
-    const int e = pb.pv_edges[k];
+    // edges in landmark-major order (the CSR by landmark): neighbouring threads write neighbouring segments of the same three
+    // rows of the GEMM operands; edges of fixed poses drop out
+    const int k = (bx - nbp) * 256 + threadIdx.x;
+    if (k >= pb.n_edges) return;
+    const int e = pb.pt_edges[k];
     const BaEdge ed = pb.edges[e];
     const int i = pb.pose_var[ed.pose], l = ed.point;
+    if (i < 0) return;
     const double* W = pb.W + 18 * (size_t)e;
     double Di[9], db[3];
     point_dinv(pb, l, lambda, Di, db);
@@ -307,6 +310,57 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__
     d_ba_schur_gemm(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
 }
 
+// The same product with one wavefront per (strip of 32 rows, k-slice): two row tiles times all column tiles (at most CT) in
+// registers, so a k-slice of W D^-1 is read once and the slice of W once per strip instead of once per 16x16 tile.  Every tile
+// still accumulates its k-steps in ascending order: the partial sums are bit-identical to k_ba_schur_gemm's.
+template <int CT>
+__device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int slice, const double* __restrict__ AT, const double* __restrict__ BT,
+                                                      int np_pad, int k_total, int k_per_slice, double* __restrict__ S_part) {
+    const int lane = threadIdx.x, tiles = np_pad / 16;
+    const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
+    const int i = lane % 16, kk = lane / 16;
+    const int t0 = 2 * strip;
+    const bool row1 = t0 + 1 < tiles;
+    v4d acc[2][CT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < CT; ++t) acc[a][t] = v4d{0, 0, 0, 0};
+    const double* pa0 = AT + 16 * t0 + i;
+    const double* pa1 = AT + 16 * (row1 ? t0 + 1 : t0) + i;
+    const double* pbase = BT + i;
+    for (int k = k0; k < k1; k += 4) {
+        const int kr = k + kk;
+        const bool in = kr < k1;
+        const size_t ro = (size_t)kr * np_pad;
+        const double a0 = in ? pa0[ro] : 0.0, a1 = (in && row1) ? pa1[ro] : 0.0;
+        double b[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) b[t] = (in && t < tiles) ? pbase[ro + 16 * t] : 0.0;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[t], acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[t], acc[1][t], 0, 0, 0);
+        }
+    }
+    double* out = S_part + (size_t)slice * np_pad * np_pad;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a == 1 && !row1) break;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            if (t >= tiles) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(16 * (t0 + a) + kk + 4 * r) * np_pad + 16 * t + i] = acc[a][t][r];
+        }
+    }
+}
+template <int CT>
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_strip(const double* __restrict__ AT, const double* __restrict__ BT, int np_pad, int k_total,
+                                                            int k_per_slice, double* __restrict__ S_part) {
+    d_ba_schur_gemm_strip<CT>(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
+}
+
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
@@ -342,21 +396,29 @@ __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const 
 __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) { d_ba_schur_finish(pb, blockIdx.x, lambda, n_slices, S_out, bs_out); }
 
-// x_l = D^-1 (b_l - W^T x_p) for four landmarks per workgroup: the three rows of W^T of a landmark are rows 3l..3l+2 of
-// the k-major GEMM operand BT (zeros where the landmark has no edge to a pose), 16 lanes per row, fixed shuffle order.
+// x_l = D^-1 (b_l - W^T x_p) for sixteen landmarks per workgroup: 16 lanes per landmark, each lane owns the columns j, j + 16, ...
+// of the landmark's three rows of W^T (rows 3l..3l+2 of the k-major GEMM operand BT, zeros where the landmark has no edge to a
+// pose); the 16 partial dot products are added in a fixed shuffle order.
+constexpr int kBacksubPerBlock = 16;
 __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, const double* __restrict__ xp, double lambda, double* s_sum) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l = block * 4 + wave;
-    const int row = lane >> 4, sub = lane & 15, np = 6 * pb.n_free;
+    const int group = threadIdx.x >> 4, sub = threadIdx.x & 15, l = block * kBacksubPerBlock + group;
+    const int np = 6 * pb.n_free;
     double sc = 0;
     if (l < pb.n_points) {
-        double dot = 0;
-        if (row < 3) {
-            const double* w = pb.BT + (size_t)(3 * l + row) * pb.np_pad;
-            for (int j = sub; j < np; j += 16) dot += w[j] * xp[j];
+        double d0 = 0, d1 = 0, d2 = 0;
+        const double* w = pb.BT + (size_t)(3 * l) * pb.np_pad;
+        for (int j = sub; j < np; j += 16) {
+            const double x = xp[j];
+            d0 += w[j] * x;
+            d1 += w[pb.np_pad + j] * x;
+            d2 += w[2 * pb.np_pad + j] * x;
         }
-        for (int o = 8; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        const double d0 = __shfl(dot, 0, 64), d1 = __shfl(dot, 16, 64), d2 = __shfl(dot, 32, 64);
-        if (lane == 0) {
+        for (int o = 8; o >= 1; o >>= 1) {
+            d0 += __shfl_xor(d0, o, 64);
+            d1 += __shfl_xor(d1, o, 64);
+            d2 += __shfl_xor(d2, o, 64);
+        }
+        if (sub == 0) {
             const double cl[3] = {pb.bl[3 * (size_t)l] - d0, pb.bl[3 * (size_t)l + 1] - d1, pb.bl[3 * (size_t)l + 2] - d2};
             const double* Di = pb.Dinv + 9 * (size_t)l;
             for (int r = 0; r < 3; ++r) {
@@ -396,7 +458,7 @@ __global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nb
 // [0] landmark part of the gain-ratio scale, [1] robust cost of the trial estimate
 __device__ __forceinline__ void d_ba_trial_reduce(const BaProblemDev& pb, const int bx, double* __restrict__ scale_out, double* __restrict__ chi_out) {
     __shared__ double s[256];
-    if (bx == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + 3) / 4, s, scale_out);
+    if (bx == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock, s, scale_out);
     else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
 }
 __global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double* __restrict__ scale_out, double* __restrict__ chi_out) { d_ba_trial_reduce(pb, blockIdx.x, scale_out, chi_out); }
@@ -460,7 +522,7 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restr
 __global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
     const int nbp = blocks256(pb.n_points);
-    if ((int)blockIdx.x >= nbp + (pb.n_free_edges ? blocks256(pb.n_free_edges) : 0)) return;
+    if ((int)blockIdx.x >= nbp + (pb.n_free_edges ? blocks256(pb.n_edges) : 0)) return;
     d_ba_schur_prepare(pb, blockIdx.x, nbp, sl.lambda);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
@@ -468,11 +530,18 @@ __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaBatchSlot* __r
     if ((int)blockIdx.x >= pb.n_free) return;
     d_ba_reduce_coef(pb, blockIdx.x);
 }
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(z);
     const int tiles = pb.np_pad / 16;
     if (!pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
     d_ba_schur_gemm(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
+}
+template <int CT>
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(z);
+    const int tiles = pb.np_pad / 16;
+    if (!pb.n_free || 2 * (int)blockIdx.x >= tiles || (int)blockIdx.y >= sl.n_slices) return;
+    d_ba_schur_gemm_strip<CT>(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -482,7 +551,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __
 }
 __global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
-    const int nbp = (pb.n_points + 3) / 4;
+    const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
     if ((int)blockIdx.x >= nbp + blocks256(pb.n_poses)) return;
     d_ba_trial_update(pb, blockIdx.x, nbp, sl.xp, sl.lambda);
 }
@@ -514,19 +583,20 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     const int nbp = blocks(pb.n_points);
-    hipLaunchKernelGGL(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_free_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
+    hipLaunchKernelGGL(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
     if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
         hipLaunchKernelGGL(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
-        const int tiles = pb.np_pad / 16;
-        hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points,
-                           k_per_slice, pb.S_part);
+        const int tiles = pb.np_pad / 16, strips = (tiles + 1) / 2;
+        if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_strip<5>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         const int np = 6 * pb.n_free;
         hipLaunchKernelGGL(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda, n_slices, S_out, bs_out);
     }
 }
 
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
-    const int nbp = (pb.n_points + 3) / 4;  // four landmarks per workgroup
+    const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
     hipLaunchKernelGGL(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
     hipLaunchKernelGGL(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
     hipLaunchKernelGGL(k_ba_trial_reduce, dim3(2), dim3(256), 0, st, pb, scale_out, chi_out);
@@ -544,16 +614,18 @@ void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int 
 }
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
-    hipLaunchKernelGGL(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + blocks(x.max_free_edges), n_active), dim3(256), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + (x.max_free_edges ? blocks(x.max_edges) : 0), n_active), dim3(256), 0, st, slots, active);
     if (!x.max_free) return;
     hipLaunchKernelGGL(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
-    const int tiles = x.max_np_pad / 16;
-    hipLaunchKernelGGL(k_ba_schur_gemm_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
+    if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_b<5>, dim3(strips, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_b<8>, dim3(strips, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    else hipLaunchKernelGGL(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
     hipLaunchKernelGGL(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
-    hipLaunchKernelGGL(k_ba_trial_update_b, dim3((x.max_points + 3) / 4 + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
+    hipLaunchKernelGGL(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
     hipLaunchKernelGGL(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
     hipLaunchKernelGGL(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
 }
