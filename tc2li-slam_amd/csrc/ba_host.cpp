@@ -703,7 +703,13 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     std::lock_guard<std::mutex> lk(C.mu);
     for (int i = 0; i < n; ++i)
         if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
-    if (!C.st && hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
+    if (!C.st) {
+        // the loop is a chain of ~140 short dependent launches: on a GPU shared with the front-end kernels they go first
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
+            hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
+    }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
     if (C.d_slots.ensure(n) != hipSuccess || C.d_lists.ensure(4 * (size_t)n) != hipSuccess || C.h_slots.ensure(n) != hipSuccess ||
@@ -784,6 +790,13 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
     };
+    // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
+    // (a pool dispatch costs more than it saves, and far more on a busy host)
+    static const int kSerialBelow = getenv("TC2LI_BA_PHASE_SERIAL") ? atoi(getenv("TC2LI_BA_PHASE_SERIAL")) : 0;
+    auto phase_for = [&](int cnt, const std::function<void(int)>& fn) {
+        if (cnt <= kSerialBelow) { for (int k = 0; k < cnt; ++k) fn(k); }
+        else pool.parallel_for(cnt, fn);
+    };
     bool failed = false;
     auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_lists[0..), list b at d_lists[n..)
         for (size_t k = 0; k < a.size(); ++k) C.h_lists.p[k] = a[k];
@@ -821,7 +834,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         sync();
         if (failed) break;
         tm[1] += now() - t0; t0 = now();
-        pool.parallel_for((int)active.size(), [&](int k) {
+        phase_for((int)active.size(), [&](int k) {
             LockstepWindow& w = W[active[k]];
             const int np = w.vp.np;
             const double* sc = w.ws->h_scal.p;
@@ -864,7 +877,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             sync();
             if (failed) break;
             tm[3] += now() - t0; t0 = now();
-            pool.parallel_for((int)trial.size(), [&](int k) {
+            phase_for((int)trial.size(), [&](int k) {
                 LockstepWindow& w = W[trial[k]];
                 const int np = w.vp.np;
                 BaWorkspace& ws = *w.ws;
