@@ -50,6 +50,7 @@ def algorithmic_bytes(w, h, nkp, lidar_counts):
         "lidar_voxel_hash": 3 * pre * 48 + pre * 4,       # bbox, insert, fill passes over the points + member list
         "lidar_voxel_centroid": pre * (48 + 4) + down * 48,
         "lidar_knn_plane": down * (48 + 48 + 48 + 5 * 8 + 27 * 16),  # point in, world + normvec out, neighbours, 27-cell gather
+        "lidar_knn_hard": down * 0.02 * (48 + 48 + 48 + 5 * 8 + 125 * 16),  # the ~2 % of the queries that need the wider cubes
         "lidar_select": down * 1 + sel * 4 * 48,
     }
 
@@ -66,6 +67,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
+    ap.add_argument("--stages", default="orb,track,lidar,ba", help="diagnostics: run only these stage threads in the timed loop")
     args = ap.parse_args()
 
     import torch
@@ -174,6 +176,7 @@ def main():
     trk_outs = [None, None]
     lidar_counts = None
     thread_ms = {}
+    orb_times, lidar_times = [], []  # HIP-event stage durations of every call (the timed region is what run_steps did last)
 
     def run_steps(n_steps):
         nonlocal lidar_counts
@@ -195,6 +198,7 @@ def main():
             for _ in range(n_steps):
                 k = free.get()
                 orb_outs[k] = exts[k].extract_batch_dev(dev_img.data_ptr(), n_img, W, H, W, W * H, stream=stream, out=orb_outs[k])
+                orb_times.append(exts[k].last_timings().astype(float))
                 ready.put(k)
 
         def track_thread():
@@ -211,6 +215,7 @@ def main():
             nonlocal lidar_counts
             for _ in range(n_steps):
                 lidar_counts = lidar.frontend_batch(dev_raw.data_ptr(), raw_offs, maps, states, stream=lidar_stream.cuda_stream, want_points=False)[0]
+                lidar_times.append(lidar.last_timings().astype(float))
 
         def ba_thread():
             for _ in range(n_steps):
@@ -218,6 +223,13 @@ def main():
                     raise RuntimeError("a local BA window failed")
 
         fns = [orb_thread, track_thread, lidar_thread] + ([ba_thread] if ba_batch else [])
+        want = set(args.stages.split(","))
+        if "track" in want:
+            want.add("orb")  # tracking consumes what the extraction produces
+        fns = [f for f in fns if f.__name__.split("_")[0] in want]
+        if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
+            for _ in range(n_steps):
+                free.put(0)
 
         def timed(fn):
             def wrapped():
@@ -240,9 +252,11 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     barrier()
+    orb_times.clear(); lidar_times.clear()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
+    loop_orb_ms, loop_lidar_ms = np.mean(orb_times, 0), np.mean(lidar_times, 0)
     elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0, device="cuda")
     stage_ms = ext.last_timings().astype(float)
     orb_out, st_out, trk_out = orb_outs[0], st_outs[0], trk_outs[0]
@@ -270,7 +284,9 @@ def main():
         ba_batch.run(1)
         wall["local_lv_ba_batch, 1 window at a time"] = time.perf_counter() - t_a
 
-    # ---- roofline of the dominant kernel: per-kernel HIP-event durations on the stream each kernel group runs on ----
+    # ---- roofline of the dominant kernel: HIP-event durations of every launch of the timed region (the stages run
+    # concurrently there, as in the rocprofv3 trace of the same command), on the stream each kernel is launched on; the same
+    # kernels measured alone afterwards are reported next to them ----
     ext.set_profiling(True)
     prof = []
     for _ in range(3):
@@ -283,15 +299,20 @@ def main():
         lidar.frontend_batch(dev_raw.data_ptr(), raw_offs, maps, states, stream=stream, want_points=False)
         lprof.append(lidar.last_timings().astype(float))
     lprof = np.mean(lprof, 0)
+
+    def stage_table(o, l):
+        return {"pyramid": o[0], "fast": o[1], "blur": o[3], "orient_describe": o[4], "lidar_preprocess": l[0], "lidar_voxel_hash": l[1],
+                "lidar_voxel_centroid": l[2], "lidar_knn_plane": l[6], "lidar_knn_hard": l[7], "lidar_select": l[4]}
+    isolated_ms = stage_table(prof, lprof)
     alg = algorithmic_bytes(W, H, nkp, lid_mean)
-    kern_ms = {"pyramid": prof[0], "fast": prof[1], "blur": prof[3], "orient_describe": prof[4], "lidar_preprocess": lprof[0],
-               "lidar_voxel_hash": lprof[1], "lidar_voxel_centroid": lprof[2], "lidar_knn_plane": lprof[3], "lidar_select": lprof[4]}
+    kern_ms = stage_table(loop_orb_ms, loop_lidar_ms)
     units = {k: (F if k.startswith("lidar") else n_img) for k in kern_ms}
     launches = {"pyramid": 7, "fast": 1, "blur": 1, "orient_describe": 1, "lidar_preprocess": 3, "lidar_voxel_hash": 8, "lidar_voxel_centroid": 1,
-                "lidar_knn_plane": 1, "lidar_select": 3}
+                "lidar_knn_plane": 1, "lidar_knn_hard": 1, "lidar_select": 3}
     names = {"fast": "k_fast_cells", "blur": "k_blur7_strips", "pyramid": "k_resize_linear", "orient_describe": "k_orient_describe",
              "lidar_preprocess": "k_pre_count+k_seg_scan+k_pre_scatter", "lidar_voxel_hash": "k_voxel_bbox..k_voxel_fill",
-             "lidar_voxel_centroid": "k_voxel_centroid", "lidar_knn_plane": "k_knn_plane", "lidar_select": "k_sel_count+k_seg_scan+k_sel_scatter"}
+             "lidar_voxel_centroid": "k_voxel_centroid", "lidar_knn_plane": "k_knn_plane", "lidar_knn_hard": "k_knn_hard",
+             "lidar_select": "k_sel_count+k_seg_scan+k_sel_scatter"}
     single = [k for k in kern_ms if launches[k] == 1 or k in ("pyramid", "blur")]  # groups made of one kernel (x launches)
     dom = max(single, key=lambda k: kern_ms[k])  # the kernel with the largest device time per step
     bytes_per_launch = alg[dom] * units[dom] / launches[dom]
@@ -310,6 +331,7 @@ def main():
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(kern_ms[dom] / launches[dom], 5),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "all_kernels_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+                "all_kernels_ms_measured_alone": {k: round(v, 4) for k, v in isolated_ms.items()},
                 "all_kernels_GBps": {k: round(alg[k] * units[k] / (kern_ms[k] * 1e-3) / 1e9, 2) for k in kern_ms if kern_ms[k] > 0}}
 
     # ---- CPU baseline: the oracle (a port) with the reference's threading -----------------------------------------

@@ -262,7 +262,8 @@ int tc2li_lidar_undistort(tc2li_lidar* lidar, tc2li_point* points, int n, const 
                           const tc2li_lidar_state* end_state);
 
 /* Device time of the stages of the last tc2li_lidar_frontend_batch call, from HIP events on its stream: ms[0]
- * preprocess, [1] voxel hashing/sorting, [2] voxel centroids, [3] 5-NN + plane fit, [4] selection, [5] total. */
+ * preprocess, [1] voxel hashing/sorting, [2] voxel centroids, [3] 5-NN + plane fit, [4] selection, [5] total, [6] / [7] the two
+ * kernels of stage [3] (k_knn_plane, k_knn_hard). */
 int tc2li_lidar_last_timings(tc2li_lidar* lidar, float ms[8]);
 
 /* ------------------------------------------------------------------------------------------------

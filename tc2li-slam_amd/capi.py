@@ -374,10 +374,11 @@ class LidarFrontEnd:
             self._h = C.c_void_p()
 
     def last_timings(self):
-        """Device ms of the last frontend_batch: preprocess, voxel hashing, voxel centroids, 5-NN + plane fit, selection, total."""
+        """Device ms of the last frontend_batch: preprocess, voxel hashing, voxel centroids, 5-NN + plane fit, selection, total,
+        then the 5-NN stage split into k_knn_plane and k_knn_hard."""
         t = np.zeros(8, np.float32)
         _check(lib().tc2li_lidar_last_timings(self._h, t.ctypes.data))
-        return t[:6]
+        return t
 
     __del__ = close
 

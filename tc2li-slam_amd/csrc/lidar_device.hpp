@@ -99,7 +99,7 @@ void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted,
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,
-                      int* nfound, int* hard_count, int2* hard_list, hipStream_t st);
+                      int* nfound, int* hard_count, int2* hard_list, hipStream_t st, hipEvent_t after_first = nullptr);
 // iterated ESKF (row b7): re-evaluation of the kept neighbours at a new state; normal equations of the measurement rows ->
 // out[158] = H^T H (12 x 12), H^T h (12), sum |pd2|, number of rows (partial: [(n + 255) / 256][158])
 constexpr int kEskfOutSize = 144 + 12 + 2;

@@ -66,7 +66,7 @@ struct tc2li_lidar {
     int n_scans = 0;
     // stage boundaries of the last tc2li_lidar_frontend_batch call: start, after preprocess, before / after the centroid
     // kernel, after the kNN + plane kernel, end
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[7] = {};  // [6]: between the two kernels of the neighbour search
     bool timed = false;
     void record(int k, hipStream_t st) { if (ev[k] || hipEventCreate(&ev[k]) == hipSuccess) (void)hipEventRecord(ev[k], st); }
     ~tc2li_lidar() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
@@ -142,7 +142,8 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_grids.p, grids.data(), S * sizeof(MapGrid), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
     launch_knn_plane(L->d_grids.p, d_body, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
-                     L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, L->d_hard_count.p, L->d_hard_list.p, st);
+                     L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, L->d_hard_count.p, L->d_hard_list.p, st,
+                     (L->ev[6] || hipEventCreate(&L->ev[6]) == hipSuccess) ? L->ev[6] : nullptr);
     L->record(4, st);
     launch_sel_count(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_counts.p, st);
     launch_seg_scan(L->d_slots.p, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
@@ -234,6 +235,9 @@ int tc2li_lidar_last_timings(tc2li_lidar* L, float ms[8]) {
     if (!L->timed) return TC2LI_OK;
     for (int k = 0; k < 5; ++k) if (hipEventElapsedTime(&ms[k], L->ev[k], L->ev[k + 1]) != hipSuccess) ms[k] = 0;
     if (hipEventElapsedTime(&ms[5], L->ev[0], L->ev[5]) != hipSuccess) ms[5] = 0;
+    // the neighbour search split into its two kernels: k_knn_plane, k_knn_hard
+    if (!L->ev[6] || hipEventElapsedTime(&ms[6], L->ev[3], L->ev[6]) != hipSuccess) ms[6] = 0;
+    if (!L->ev[6] || hipEventElapsedTime(&ms[7], L->ev[6], L->ev[4]) != hipSuccess) ms[7] = 0;
     return TC2LI_OK;
 }
 

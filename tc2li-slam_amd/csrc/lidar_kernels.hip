@@ -1331,11 +1331,12 @@ void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted,
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
                       uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d, int* nfound, int* hard_count,
-                      int2* hard_list, hipStream_t st) {
+                      int2* hard_list, hipStream_t st, hipEvent_t after_first) {
     if (!nblocks) return;
     (void)hipMemsetAsync(hard_count, 0, sizeof(int), st);
     hipLaunchKernelGGL(k_knn_plane, dim3(nblocks, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
                        normvec, nearest_idx, nearest_d, nfound, hard_count, hard_list);
+    if (after_first) (void)hipEventRecord(after_first, st);
     hipLaunchKernelGGL(k_knn_hard, dim3(512), dim3(256), 0, st, grids, body, slots, states, selected, normvec, nearest_idx, nearest_d, nfound,
                        hard_count, hard_list);
 }

@@ -28,6 +28,20 @@ struct MatchFrameDev {
     float min_x, max_x, min_y, max_y;
 };
 
+// the three-launch form (grid, candidate lists, rounds over the lists); the tables live in the caller's workspace.  When
+// pool_top[1] comes back non-zero the candidate pool was too small and launch_match_by_projection has to be used instead.
+struct MatchLists {
+    int32_t* cell_start;   // [nframes][kCells + 1]
+    uint16_t* items;       // [total keys], frame f at key_base[f]
+    const int32_t* key_base;  // [nframes]
+    int32_t* cand_off;     // [total queries]
+    int32_t* cand_cnt;     // [total queries], bit 30 = has_observations
+    uint32_t* pool;
+    int32_t* pool_top;     // [0] = entries used, [1] = overflow flag
+    int32_t pool_cap, pad_;
+};
+void launch_match_lists(const MatchFrameDev* frames, int nframes, const int32_t* query_frame, int total_q, const MatchLists& L, int mode,
+                        float nn_ratio, int32_t* match_of_query, int32_t* prev_claim, int32_t* rounds_out, hipStream_t st);
 void launch_match_by_projection(const MatchFrameDev* frames, int nframes, int mode, float nn_ratio, int32_t* match_of_query,
                                 int32_t* prev_claim, int32_t* rounds_out, hipStream_t st);
 

@@ -29,6 +29,11 @@ struct MatcherWorkspace {
     PinnedBuf<float> h_ur;
     PinnedBuf<MatchFrameDev> h_frames;
     PinnedBuf<int32_t> h_match;
+    // candidate-list form of the batched search
+    DevBuf<int32_t> d_cell_start, d_key_base, d_cand_off, d_cand_cnt, d_pool_top, d_query_frame;
+    DevBuf<uint16_t> d_items;
+    DevBuf<uint32_t> d_pool;
+    PinnedBuf<int32_t> h_query_frame, h_key_base, h_pool_top;
     std::mutex mu;
 };
 MatcherWorkspace& mws() { static MatcherWorkspace w; return w; }
@@ -116,10 +121,34 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_queries.p, queries, (size_t)total_q * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
-    launch_match_by_projection(w.d_frames.p, n_frames, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
+    // candidate lists once, then the rounds over the lists (matcher_kernels.hip); the pool holds 32 candidates per query on average
+    constexpr int kCellsPlus1 = 64 * 48 + 1;
+    const int pool_cap = 32 * total_q;
+    TC2LI_HIP_CHECK(w.d_cell_start.ensure((size_t)n_frames * kCellsPlus1)); TC2LI_HIP_CHECK(w.d_key_base.ensure(n_frames));
+    TC2LI_HIP_CHECK(w.d_cand_off.ensure(total_q)); TC2LI_HIP_CHECK(w.d_cand_cnt.ensure(total_q)); TC2LI_HIP_CHECK(w.d_pool_top.ensure(2));
+    TC2LI_HIP_CHECK(w.d_query_frame.ensure(total_q)); TC2LI_HIP_CHECK(w.d_items.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.d_pool.ensure(pool_cap));
+    TC2LI_HIP_CHECK(w.h_query_frame.ensure(total_q)); TC2LI_HIP_CHECK(w.h_key_base.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_pool_top.ensure(2));
+    for (int q = 0; q < total_q; ++q) w.h_query_frame.p[q] = -1;
+    for (int f = 0, kb = 0; f < n_frames; ++f) {
+        w.h_key_base.p[f] = kb;
+        kb += frames[f].n_keys;
+        for (int q = 0; q < frames[f].n_q; ++q) w.h_query_frame.p[frames[f].q_off + q] = f;
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_query_frame.p, w.h_query_frame.p, (size_t)total_q * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_key_base.p, w.h_key_base.p, n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MatchLists lists{w.d_cell_start.p, w.d_items.p, w.d_key_base.p, w.d_cand_off.p, w.d_cand_cnt.p, w.d_pool.p, w.d_pool_top.p, pool_cap, 0};
+    launch_match_lists(w.d_frames.p, n_frames, w.d_query_frame.p, total_q, lists, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_pool_top.p, w.d_pool_top.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    if (w.h_pool_top.p[1]) {  // candidate pool exhausted (very dense windows): the one-kernel form computes the same result
+        TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
+        launch_match_by_projection(w.d_frames.p, n_frames, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    }
     global_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];
         int32_t* m = match_of_query + fr.q_off;

@@ -2,6 +2,7 @@
 # Round profile on the GPU box: kernel trace + stats of the default bench command, then the HBM counters of the same
 # command in two separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no trace domains next to --pmc).
 # Usage (from the repo root, through gpurun): bash tools/profile_round.sh r01
+# The summaries land in gpurun_out/profiles_<tag>/ (gpurun only brings gpurun_out/ back): copy them into profiles/ afterwards.
 set -e
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
@@ -12,3 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $ARGS > $OUT/bench_write.log 2>&1
 python tools/summarize_profile.py $OUT $TAG
+mkdir -p gpurun_out/profiles_$TAG
+cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+# keep the merge small: the raw traces stay on the box
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
