@@ -256,6 +256,11 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
+    if set(args.stages.split(",")) != {"orb", "track", "lidar", "ba"}:  # diagnostics: which stages slow each other down
+        if rank == 0:
+            print(json.dumps({"diagnostic_stages": args.stages, "ms_per_step": round(1e3 * (time.perf_counter() - t0) / args.steps, 3),
+                              "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()}}))
+        return
     loop_orb_ms, loop_lidar_ms = np.mean(orb_times, 0), np.mean(lidar_times, 0)
     elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0, device="cuda")
     stage_ms = ext.last_timings().astype(float)
