@@ -108,57 +108,62 @@ __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
 __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
                                                     int* __restrict__ cell_counts, int ncells) {
-    __shared__ uint8_t tile[kFastTileH * kFastTilePitch];
+    // The window rows are staged as the aligned dwords they come in: pixel (x, y) of the window is byte
+    // y * kTileP + x + mis(y) of the tile, mis(y) = byte offset of row y inside its first dword (rows of the caller's image
+    // start at any byte address).
+    constexpr int kTileP = kFastTilePitch + 4;
+    __shared__ uint32_t tile32[kFastTileH * kTileP / 4];
     __shared__ uint8_t score[kFastTileH * kFastTilePitch];
-    __shared__ uint16_t s_list[kFastTileH * kFastTilePitch];  // tile offset | polarity << 14 of the pixels passing the segment test
-    __shared__ int s_wave[4];
-    __shared__ int s_cnt_ini, s_nlist;
+    __shared__ uint16_t s_list[kFastTileH * kFastTilePitch];  // window offset | polarity << 14 of the pixels passing the segment test
+    __shared__ uint8_t s_flag[kFastTileH * kFastTilePitch];   // per list entry: bit 0 kept at iniTh, bit 1 kept at minTh
+    constexpr int kMaxKept = ((kFastTilePitch - 6 + 1) / 2) * ((kFastTileH - 6 + 1) / 2);  // >= any cell's slab_cap
+    __shared__ uint16_t s_kept[kMaxKept];
+    __shared__ int s_cnt_ini, s_nlist, s_nkept;
+    const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
 
     const int tid = threadIdx.x, img = blockIdx.y;
     const FastCell c = cells[blockIdx.x];
     const LevelDesc L = levels.lv[c.level];
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
     const int w = c.w, h = c.h;
-
-    // window rows as aligned dwords (a row of the window starts at any byte address: level 0 is the caller's image)
+    const uint32_t mis0 = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3), pm = (uint32_t)L.pitch & 3u;
+    auto mis = [&](int y) { return (int)((mis0 + (uint32_t)y * pm) & 3u); };
     {
-        constexpr int kDw = kFastTilePitch / 4 + 1;  // dwords that can cover one row of the window
-        uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
+        constexpr int kDw = kTileP / 4;  // dwords per tile row
         for (int i = tid; i < h * kDw; i += 256) {
             const int y = i / kDw, j = i - y * kDw;
             const uint8_t* row = src + (size_t)y * L.pitch;
-            const int mis = (int)(reinterpret_cast<uintptr_t>(row) & 3);
-            if (4 * j - mis < w) {
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(row - mis + 4 * j);
-                uint8_t* d = tile + y * kFastTilePitch;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int x = 4 * j + b - mis;
-                    if (x >= 0 && x < w) d[x] = (uint8_t)(v >> (8 * b));
-                }
-            }
+            const int m = mis(y);
+            if (4 * j - m < w) tile32[i] = *as_global(reinterpret_cast<const uint32_t*>(row - m + 4 * j));
         }
+        uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
         for (int i = tid; i < h * (kFastTilePitch / 4); i += 256) score32[i] = 0;
     }
-    if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; }
+    if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; s_nkept = 0; }
     __syncthreads();
 
     const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
     const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
+    // the 16 circle pixels and the centre of window position (cx, cy)
+    auto circle = [&](int cx, int cy, int (&p)[16]) -> int {
+        const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
+        const uint8_t* r1 = tile + (cy - 2) * kTileP + mis(cy - 2) + cx;
+        const uint8_t* r2 = tile + (cy - 1) * kTileP + mis(cy - 1) + cx;
+        const uint8_t* r3 = tile + cy * kTileP + mis(cy) + cx;
+        const uint8_t* r4 = tile + (cy + 1) * kTileP + mis(cy + 1) + cx;
+        const uint8_t* r5 = tile + (cy + 2) * kTileP + mis(cy + 2) + cx;
+        const uint8_t* r6 = tile + (cy + 3) * kTileP + mis(cy + 3) + cx;
+        p[0] = r6[0];  p[1] = r6[1];  p[2] = r5[2];  p[3] = r4[3];  p[4] = r3[3];  p[5] = r2[3];  p[6] = r1[2];  p[7] = r0[1];
+        p[8] = r0[0];  p[9] = r0[-1]; p[10] = r1[-2]; p[11] = r2[-3]; p[12] = r3[-3]; p[13] = r4[-3]; p[14] = r5[-2]; p[15] = r6[-1];
+        return r3[0];
+    };
     // Pass 1, every pixel: the cheap segment test at the lower threshold (two 16-bit masks, "9 contiguous" by shifts).
     // Only a few percent of the pixels pass, but almost every wavefront holds one, so the exact contrast is not computed
     // here: the survivors are appended to a list (any order: each writes its own score cell).
     for (int i = tid; i < npix; i += 256) {
         const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
-        const uint8_t* t = tile + (ey + 3) * kFastTilePitch + (ex + 3);
-        const int v = t[0];
         int p[16];
-        p[0] = t[3 * kFastTilePitch];          p[1] = t[3 * kFastTilePitch + 1];   p[2] = t[2 * kFastTilePitch + 2];
-        p[3] = t[kFastTilePitch + 3];          p[4] = t[3];                        p[5] = t[-kFastTilePitch + 3];
-        p[6] = t[-2 * kFastTilePitch + 2];     p[7] = t[-3 * kFastTilePitch + 1];  p[8] = t[-3 * kFastTilePitch];
-        p[9] = t[-3 * kFastTilePitch - 1];     p[10] = t[-2 * kFastTilePitch - 2]; p[11] = t[-kFastTilePitch - 3];
-        p[12] = t[-3];                         p[13] = t[kFastTilePitch - 3];      p[14] = t[2 * kFastTilePitch - 2];
-        p[15] = t[3 * kFastTilePitch - 1];
+        const int v = circle(ex + 3, ey + 3, p);
         uint32_t mb = 0, md = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -174,74 +179,59 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     const int nlist = s_nlist;
     for (int k = tid; k < nlist; k += 256) {
         const uint32_t e = s_list[k];
-        const int at = e & 0x3fff;
-        const uint8_t* t = tile + at;
-        const int v = t[0];
+        const int at = e & 0x3fff, cy = at / kFastTilePitch, cx = at - cy * kFastTilePitch;
         int p[16];
-        p[0] = t[3 * kFastTilePitch];          p[1] = t[3 * kFastTilePitch + 1];   p[2] = t[2 * kFastTilePitch + 2];
-        p[3] = t[kFastTilePitch + 3];          p[4] = t[3];                        p[5] = t[-kFastTilePitch + 3];
-        p[6] = t[-2 * kFastTilePitch + 2];     p[7] = t[-3 * kFastTilePitch + 1];  p[8] = t[-3 * kFastTilePitch];
-        p[9] = t[-3 * kFastTilePitch - 1];     p[10] = t[-2 * kFastTilePitch - 2]; p[11] = t[-kFastTilePitch - 3];
-        p[12] = t[-3];                         p[13] = t[kFastTilePitch - 3];      p[14] = t[2 * kFastTilePitch - 2];
-        p[15] = t[3 * kFastTilePitch - 1];
+        const int v = circle(cx, cy, p);
         int S = 0;
         if (e & 0x4000) S = arc_contrast<true>(p, v);
         if (e & 0x8000) S = max(S, arc_contrast<false>(p, v));
         score[at] = (uint8_t)S;
     }
     __syncthreads();
-
-    // non-max suppression flags for both thresholds (bit0: iniTh, bit1: minTh); tile[] is reused for flags
+    // Pass 3, survivors only: 3x3 strict non-max suppression for both thresholds (every survivor has S > minTh; a neighbour
+    // counts with its score only where it is a corner at the threshold in question, cv::FAST's score buffer semantics)
     int my_ini = 0;
-    for (int i = tid; i < npix; i += 256) {
-        const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
-        const uint8_t* s = score + (ey + 3) * kFastTilePitch + (ex + 3);
-        const int S = s[0];
-        int flags = 0;
-        if (S > min_th) {
-            int nb[8] = {s[-kFastTilePitch - 1], s[-kFastTilePitch], s[-kFastTilePitch + 1], s[-1],
-                         s[1], s[kFastTilePitch - 1], s[kFastTilePitch], s[kFastTilePitch + 1]};
-            bool keep_ini = S > ini_th, keep_min = true;
+    for (int k = tid; k < nlist; k += 256) {
+        const int at = s_list[k] & 0x3fff;
+        const uint8_t* sc = score + at;
+        const int S = sc[0];
+        const int nb[8] = {sc[-kFastTilePitch - 1], sc[-kFastTilePitch], sc[-kFastTilePitch + 1], sc[-1],
+                           sc[1], sc[kFastTilePitch - 1], sc[kFastTilePitch], sc[kFastTilePitch + 1]};
+        bool keep_ini = S > ini_th, keep_min = true;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int n_ini = nb[k] > ini_th ? nb[k] - 1 : 0;
-                const int n_min = nb[k] > min_th ? nb[k] - 1 : 0;
-                keep_ini = keep_ini && (S - 1 > n_ini);
-                keep_min = keep_min && (S - 1 > n_min);
-            }
-            flags = (keep_ini ? 1 : 0) | (keep_min ? 2 : 0);
-            my_ini += keep_ini ? 1 : 0;
+        for (int j = 0; j < 8; ++j) {
+            const int n_ini = nb[j] > ini_th ? nb[j] - 1 : 0;
+            const int n_min = nb[j] > min_th ? nb[j] - 1 : 0;
+            keep_ini = keep_ini && (S - 1 > n_ini);
+            keep_min = keep_min && (S - 1 > n_min);
         }
-        tile[i] = (uint8_t)flags;  // npix <= tile size
+        s_flag[k] = (uint8_t)((keep_ini ? 1 : 0) | (keep_min ? 2 : 0));
+        my_ini += keep_ini ? 1 : 0;
     }
     if (my_ini) atomicAdd(&s_cnt_ini, my_ini);
     __syncthreads();
     const int sel = s_cnt_ini > 0 ? 1 : 2;
-
-    uint32_t* out = slab + (size_t)img * slab_img_stride + c.slab_off;
-    const int lane = tid & 63, wave = tid >> 6;
-    int base = 0;
-    for (int start = 0; start < npix; start += 256) {
-        const int i = start + tid;
-        const bool f = i < npix && (tile[i] & sel);
-        const unsigned long long bal = __ballot(f);
-        if (lane == 0) s_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int k = 0; k < wave; ++k) off += s_wave[k];
-        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        if (f) {
-            const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
-            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-            const uint32_t sc = score[(ey + 3) * kFastTilePitch + (ex + 3)] - 1;
-            // candidate coordinates in the border-free frame of the level (SF/src/ORBextractor.cc:833-838)
-            const uint32_t cx = (uint32_t)(c.x0 + ex + 3 - kMinBorder), cy = (uint32_t)(c.y0 + ey + 3 - kMinBorder);
-            if (pos < c.slab_cap) out[pos] = (cy << 20) | (cx << 8) | sc;
+    // Emission in row-major order (the order cv::FAST returns the keypoints in): the kept survivors are gathered (a few tens
+    // per cell; strict 3x3 maxima: at most one per 2x2 block), the rank of each among them is its output slot.
+    for (int k = tid; k < nlist; k += 256)
+        if (s_flag[k] & sel) {
+            const int slot = atomicAdd(&s_nkept, 1);
+            if (slot < kMaxKept) s_kept[slot] = (uint16_t)(s_list[k] & 0x3fff);
         }
-        base += total;
-        __syncthreads();
+    __syncthreads();
+    const int nkept = s_nkept, nk = min(nkept, kMaxKept);
+    uint32_t* out = slab + (size_t)img * slab_img_stride + c.slab_off;
+    for (int k = tid; k < nk; k += 256) {
+        const int at = s_kept[k];
+        int rank = 0;
+        for (int j = 0; j < nk; ++j) rank += (int)s_kept[j] < at ? 1 : 0;
+        const int cy = at / kFastTilePitch, cx = at - cy * kFastTilePitch;
+        const uint32_t scv = (uint32_t)score[at] - 1;
+        // candidate coordinates in the border-free frame of the level (SF/src/ORBextractor.cc:833-838)
+        const uint32_t px = (uint32_t)(c.x0 + cx - kMinBorder), py = (uint32_t)(c.y0 + cy - kMinBorder);
+        if (rank < c.slab_cap) out[rank] = (py << 20) | (px << 8) | scv;
     }
-    if (tid == 0) cell_counts[(size_t)img * ncells + blockIdx.x] = base;
+    if (tid == 0) cell_counts[(size_t)img * ncells + blockIdx.x] = s_nkept;
 }
 
 // Ordered concatenation of the per-cell candidate lists of one (image, level) into a dense list: cell-major order,

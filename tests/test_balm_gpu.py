@@ -130,3 +130,21 @@ def test_local_bundle_adjustment_batch(pkg, synthetic):
                 assert np.array_equal(r[2], s[2]), (conc, i)
             if len(s) > 5:
                 assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual
+
+
+def test_batch_with_a_large_window(pkg, synthetic):
+    """More than 21 free poses (9 column tiles of the reduced system): the batch takes the per-tile Schur product; still identical
+    to the single calls."""
+    windows, singles = [], []
+    for seed, n_opt in [(31, 24), (32, 6), (33, 14)]:
+        w = synthetic.ba_window(seed, n_opt=n_opt, n_fix=5, n_points=900, pose_noise=(0.1, 0.01))
+        e = pkg.pack_ba_edges(w["edges"])
+        windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=e))
+        singles.append(pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"]))
+        cam = w["cam"]
+    batch = pkg.capi.BaBatch(windows, cam)
+    assert batch.run(max_concurrency=8) == len(windows)
+    for i, s in enumerate(singles):
+        r = batch.result(i)
+        assert r[4].trials == s[4].trials and batch.results[i] == s[4].iterations
+        assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2])
