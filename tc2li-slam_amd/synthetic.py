@@ -69,8 +69,8 @@ class Scene:
         self.boxes = np.stack([x - w / 2, x + w / 2, CAM_HEIGHT - h, np.full(n_boxes, CAM_HEIGHT), z], 1)
         self.salts = rng.integers(1, 1 << 20, n_boxes + 1)
 
-    def render(self, cam_x=0.0, width=WIDTH, height=HEIGHT, noise_seed=0):
-        """8-bit image and depth (z) map seen from a camera translated by cam_x along +x."""
+    def render(self, cam_x=0.0, width=WIDTH, height=HEIGHT, noise_seed=0, cam_z=0.0):
+        """8-bit image and depth (z) map seen from a camera translated by cam_x along +x and by cam_z along +z (forward)."""
         uu, vv = np.meshgrid(np.arange(width, dtype=np.float32), np.arange(height, dtype=np.float32))
         dx, dy = (uu - np.float32(CX)) / np.float32(FX), (vv - np.float32(CY)) / np.float32(FY)  # ray (dx, dy, 1)
         depth = np.full((height, width), 1e6, np.float32)
@@ -79,11 +79,14 @@ class Scene:
         if r0 < height:
             zg = (np.float32(CAM_HEIGHT) / dy[r0:]).astype(np.float32)
             X = (np.float32(cam_x) + dx[r0:] * zg).astype(np.float32)
-            img[r0:] = _texture(X, zg, int(self.salts[-1]), 2.0)
+            img[r0:] = _texture(X, (zg + np.float32(cam_z)).astype(np.float32), int(self.salts[-1]), 2.0)
             depth[r0:] = zg
         order = np.argsort(-self.boxes[:, 4], kind="stable")  # far to near: nearer boxes overwrite
         for k in order:
             x0, x1, y0, y1, zb = self.boxes[k]
+            zb = zb - cam_z  # depth of the box in front of the moved camera
+            if zb < 0.5:
+                continue
             c0 = int(np.floor(CX + FX * (x0 - cam_x) / zb)) - 1
             c1 = int(np.ceil(CX + FX * (x1 - cam_x) / zb)) + 2
             q0 = int(np.floor(CY + FY * y0 / zb)) - 1
