@@ -518,6 +518,20 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const 
                                       tc2li_ba_stats* stats, const tc2li_lidar_window* lidar, const float* Tbl,
                                       tc2li_lidar_ba_stats* lidar_stats, void* stream);
 
+/* Per-map-point refresh of local mapping after a local BA / after creating or fusing points (LocalMapping.cc, Optimizer.cc:1506,
+ * OptimizerWithLidar.cc:484 `pMP->UpdateNormalAndDepth()`; `ComputeDistinctiveDescriptors` in CreateNewMapPoints / Fuse):
+ * MapPoint::ComputeDistinctiveDescriptors (SF/src/MapPoint.cc:338-412) and MapPoint::UpdateNormalAndDepth (:444-503) for a flat
+ * list of points.  Observations of point p are [obs_offsets[p], obs_offsets[p + 1]) in the iteration order of mObservations
+ * (left, then right index of every keyframe that is not bad): obs_descriptors [total][32], obs_centres [total][3] = the
+ * observing camera's centre.  positions / ref_centres (mpRefKF->GetCameraCenter()) [n][3], ref_level_scale[p] =
+ * mvScaleFactors[octave of the reference observation], last_level_scale = mvScaleFactors[nLevels - 1].
+ * Out: best_obs[p] = the observation whose descriptor becomes mDescriptor (-1: no observations, outputs untouched),
+ * normals [n][3] = mNormalVector, min_distance / max_distance = mfMinDistance / mfMaxDistance.  At most 112 observations
+ * per point (TC2LI_ERR_CAPACITY beyond).  Returns n_points. */
+int tc2li_map_points_refresh(int n_points, const int32_t* obs_offsets, const uint8_t* obs_descriptors, const float* obs_centres,
+                             const float* positions, const float* ref_centres, const float* ref_level_scale, float last_level_scale,
+                             int32_t* best_obs, float* normals, float* min_distance, float* max_distance, void* stream);
+
 /* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
  * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =
  * LidarCovisRes::ComputeJandHSE3 (SF/src/LidarRes.cc:136-186, with respect to the camera se3 increments).  JacT and

@@ -7,6 +7,7 @@
 #include "stereo.hpp"
 #include "lidar.hpp"
 #include "eskf.hpp"
+#include "mappoint.hpp"
 #include "ba.hpp"
 #include "imu.hpp"
 #include "inertial_ba.hpp"
@@ -772,6 +773,19 @@ int oracle_imu_propagate_cov(double* state36, double* P529, const double* cov12,
     std::memcpy(state36, &st, sizeof(st));
     for (int i = 0; i < (int)P.size() && i < capacity; ++i) std::memcpy(poses22 + 22 * i, &P[i], sizeof(Pose6D));
     return (int)P.size();
+}
+
+// ---- map-point refresh (section 8f item 3) ---------------------------------------------------------------------------------
+void oracle_map_points_refresh(int n_points, const int32_t* obs_off, const uint8_t* desc, const float* centres, const float* positions,
+                               const float* ref_centres, const float* level_scale, float last_scale, int32_t* best_obs, float* normals,
+                               float* min_dist, float* max_dist) {
+    for (int p = 0; p < n_points; ++p) {
+        const int b = obs_off[p], n = obs_off[p + 1] - b;
+        if (n <= 0) { best_obs[p] = -1; continue; }  // the reference returns early and leaves the point as it is
+        best_obs[p] = ComputeDistinctiveDescriptor(desc + 32 * (size_t)b, n);
+        UpdateNormalAndDepth(centres + 3 * (size_t)b, n, positions + 3 * p, ref_centres + 3 * p, level_scale[p], last_scale, normals + 3 * p,
+                             min_dist + p, max_dist + p);
+    }
 }
 
 // ---- IMU pre-integration -------------------------------------------------------------------------------------------------

@@ -600,6 +600,23 @@ def imu_propagate_cov(state36, P, cov12, imu7, beg, end, last_end, acc_scale, la
     return st, P, poses[:k]
 
 
+# ---- map-point refresh -------------------------------------------------------------------------------------------------------
+def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale):
+    """MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth for a flat list of points -> (best_obs, normals, min_d, max_d)."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    n = len(off) - 1
+    d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+    c = np.ascontiguousarray(centres, np.float32).reshape(-1, 3)
+    pos, ref = np.ascontiguousarray(positions, np.float32).reshape(-1, 3), np.ascontiguousarray(ref_centres, np.float32).reshape(-1, 3)
+    ls = np.ascontiguousarray(level_scale, np.float32)
+    best, normals, mn, mx = np.full(n, -1, np.int32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    f = lib().oracle_map_points_refresh
+    f.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 4
+    f(n, off.ctypes.data, d.ctypes.data, c.ctypes.data, pos.ctypes.data, ref.ctypes.data, ls.ctypes.data, float(last_scale), best.ctypes.data,
+      normals.ctypes.data, mn.ctypes.data, mx.ctypes.data)
+    return best, normals, mn, mx
+
+
 # ---- persistent map maintenance -------------------------------------------------------------------------------------------
 def map_incremental(map_points, feats_down_body, state_extract24, state_update24, ekf_inited=True, filter_size_map_min=0.5):
     """feature_extraction at state_extract + map_incremental at state_update -> (new map points, n_to_add, n_no_need)."""

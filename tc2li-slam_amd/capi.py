@@ -582,6 +582,23 @@ def lidar_imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     return st, poses[:k], last
 
 
+def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale, stream=0):
+    """``MapPoint::ComputeDistinctiveDescriptors`` + ``UpdateNormalAndDepth`` for a flat list of points ->
+    (best_obs, normals [n, 3], min_distance, max_distance)."""
+    off = np.ascontiguousarray(obs_off, np.int32)
+    n = len(off) - 1
+    d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+    c = np.ascontiguousarray(centres, np.float32).reshape(-1, 3)
+    pos, ref = np.ascontiguousarray(positions, np.float32).reshape(-1, 3), np.ascontiguousarray(ref_centres, np.float32).reshape(-1, 3)
+    ls = np.ascontiguousarray(level_scale, np.float32)
+    best, normals, mn, mx = np.full(max(n, 1), -1, np.int32), np.zeros((max(n, 1), 3), np.float32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    f = lib().tc2li_map_points_refresh
+    f.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 5
+    _check(f(n, off.ctypes.data, d.ctypes.data if len(d) else None, c.ctypes.data if len(c) else None, pos.ctypes.data, ref.ctypes.data, ls.ctypes.data,
+             float(last_scale), best.ctypes.data, normals.ctypes.data, mn.ctypes.data, mx.ctypes.data, C.c_void_p(stream)))
+    return best[:n], normals[:n], mn[:n], mx[:n]
+
+
 class EskfStats(C.Structure):
     """tc2li_eskf_stats"""
     _fields_ = [("calls", C.c_int32), ("effct_feat_num", C.c_int32), ("searches", C.c_int32), ("converged", C.c_int32), ("finished", C.c_int32),
