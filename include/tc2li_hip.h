@@ -518,6 +518,48 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const 
                                       tc2li_ba_stats* stats, const tc2li_lidar_window* lidar, const float* Tbl,
                                       tc2li_lidar_ba_stats* lidar_stats, void* stream);
 
+/* ---- local mapping: new map points ----
+ * What ORBmatcher::SearchForTriangulation (SF/src/ORBmatcher.cc:916) and the pair loop of LocalMapping::CreateNewMapPoints
+ * (SF/src/LocalMapping.cc:402-726) read of a keyframe (pinhole camera, no second camera model). */
+typedef struct tc2li_keyframe_view {
+    int32_t n, n_nodes;            /* keypoints; entries of mFeatVec */
+    const tc2li_keypoint* keys;    /* mvKeysUn */
+    const uint8_t* descriptors;    /* mDescriptors, [n][32] */
+    const float* u_right;          /* mvuRight */
+    const float* depth;            /* mvDepth */
+    const uint8_t* has_point;      /* GetMapPoint(i) != NULL */
+    const int32_t* fv_node;        /* mFeatVec: node ids, ascending */
+    const int32_t* fv_offset;      /* [n_nodes + 1] */
+    const int32_t* fv_index;       /* the feature indices of every node, in insertion order */
+    float pose7[7];                /* GetPose(): qx qy qz qw tx ty tz of Tcw */
+    float pad_;
+} tc2li_keyframe_view;
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse): match12[i] = matched keypoint of kf2 or
+ * -1 for every keypoint of kf1 (vMatchedPairs = the pairs with match12[i] >= 0, i ascending).  level_sigma2 = mvLevelSigma2,
+ * scale_factors = mvScaleFactors.  Returns nmatches. */
+int tc2li_search_for_triangulation(const tc2li_keyframe_view* kf1, const tc2li_keyframe_view* kf2, const tc2li_camera* cam,
+                                   const float* scale_factors, const float* level_sigma2, int n_levels, int only_stereo,
+                                   int coarse, int check_orientation, int32_t* match12, void* stream);
+
+typedef struct tc2li_new_map_point {
+    int32_t idx1, neighbour, idx2; /* keypoint of the current keyframe, index into `neighbours`, keypoint there */
+    int32_t stereo;                /* the point came from UnprojectStereo (bPointStereo) */
+    float x3D[3];
+    float pad_;
+} tc2li_new_map_point;
+
+/* The geometric loop of LocalMapping::CreateNewMapPoints over the neighbours the caller chose (vpNeighKFs, in order): search,
+ * parallax gates, triangulation or stereo un-projection, depth / reprojection / scale gates; a keypoint that received a point
+ * from an earlier neighbour is skipped for the later ones.  mb = pKF->mb, cam->bf = mbf, scale_factor = mfScaleFactor, inertial =
+ * mbInertial, far_points / th_far_points = mbFarPoints / mThFarPoints, coarse = bCoarse.  The points come in creation order;
+ * the caller creates the MapPoint objects, adds the observations and refreshes them (tc2li_map_points_refresh).  Triangulated
+ * coordinates agree with the reference to float rounding (Eigen's JacobiSVD is not reproduced bit for bit).  Returns the count. */
+int tc2li_create_new_map_points(const tc2li_keyframe_view* current, const tc2li_keyframe_view* neighbours, int n_neighbours,
+                                const tc2li_camera* cam, float mb, const float* scale_factors, const float* level_sigma2,
+                                int n_levels, float scale_factor, int inertial, int far_points, float th_far_points, int coarse,
+                                tc2li_new_map_point* points, int capacity, void* stream);
+
 /* Per-map-point refresh of local mapping after a local BA / after creating or fusing points (LocalMapping.cc, Optimizer.cc:1506,
  * OptimizerWithLidar.cc:484 `pMP->UpdateNormalAndDepth()`; `ComputeDistinctiveDescriptors` in CreateNewMapPoints / Fuse):
  * MapPoint::ComputeDistinctiveDescriptors (SF/src/MapPoint.cc:338-412) and MapPoint::UpdateNormalAndDepth (:444-503) for a flat

@@ -8,6 +8,7 @@
 #include "lidar.hpp"
 #include "eskf.hpp"
 #include "mappoint.hpp"
+#include "mapping.hpp"
 #include "ba.hpp"
 #include "imu.hpp"
 #include "inertial_ba.hpp"
@@ -786,6 +787,61 @@ void oracle_map_points_refresh(int n_points, const int32_t* obs_off, const uint8
         UpdateNormalAndDepth(centres + 3 * (size_t)b, n, positions + 3 * p, ref_centres + 3 * p, level_scale[p], last_scale, normals + 3 * p,
                              min_dist + p, max_dist + p);
     }
+}
+
+// ---- CreateNewMapPoints core (section 8f item 1) ---------------------------------------------------------------------------
+struct KeyFrameViewPOD {  // the same layout as tc2li_keyframe_view
+    int32_t n, n_nodes;
+    const float* keys;  // tc2li_keypoint: x, y, size, angle, response (floats), octave (int32)
+    const uint8_t* desc;
+    const float *u_right, *depth;
+    const uint8_t* has_point;
+    const int32_t *fv_node, *fv_off, *fv_idx;
+    float pose7[7];
+    float pad_;
+};
+static KeyFrameView view_from(const KeyFrameViewPOD& p, std::vector<KeyPoint>& keys) {
+    keys.resize(p.n);
+    for (int i = 0; i < p.n; ++i) {
+        const float* k = p.keys + 6 * (size_t)i;
+        int32_t oct;
+        std::memcpy(&oct, k + 5, 4);
+        keys[i] = KeyPoint{k[0], k[1], k[2], k[3], k[4], oct};
+    }
+    KeyFrameView v;
+    v.n = p.n; v.keys = keys.data(); v.desc = p.desc; v.u_right = p.u_right; v.depth = p.depth; v.has_point = p.has_point;
+    v.n_nodes = p.n_nodes; v.fv_node = p.fv_node; v.fv_off = p.fv_off; v.fv_idx = p.fv_idx;
+    std::memcpy(v.Tcw.q, p.pose7, 16); std::memcpy(v.Tcw.t, p.pose7 + 4, 12);
+    return v;
+}
+int oracle_search_for_triangulation(const KeyFrameViewPOD* kf1, const KeyFrameViewPOD* kf2, const float* cam4, const float* scale_factors,
+                                    const float* level_sigma2, int n_levels, int only_stereo, int coarse, int check_orientation, int32_t* match12) {
+    std::vector<KeyPoint> k1, k2;
+    const KeyFrameView a = view_from(*kf1, k1), b = view_from(*kf2, k2);
+    std::vector<int> m;
+    const int n = SearchForTriangulation(a, b, CamF{cam4[0], cam4[1], cam4[2], cam4[3]}, std::vector<float>(scale_factors, scale_factors + n_levels),
+                                         std::vector<float>(level_sigma2, level_sigma2 + n_levels), only_stereo != 0, coarse != 0, check_orientation != 0, m);
+    for (int i = 0; i < a.n; ++i) match12[i] = m[i];
+    return n;
+}
+// out: per point idx1, neighbour, idx2, stereo (int32 x 4) and x3D (float x 3)
+int oracle_create_new_map_points(const KeyFrameViewPOD* cur, const KeyFrameViewPOD* neigh, int n_neigh, const float* cam4, float mb, float mbf,
+                                 const float* scale_factors, const float* level_sigma2, int n_levels, float scale_factor, int inertial,
+                                 int far_points, float th_far, int coarse, int32_t* out_idx4, float* out_x3, int capacity) {
+    std::vector<KeyPoint> kc;
+    std::vector<std::vector<KeyPoint>> kn(n_neigh);
+    const KeyFrameView c = view_from(*cur, kc);
+    std::vector<KeyFrameView> nb(n_neigh);
+    for (int j = 0; j < n_neigh; ++j) nb[j] = view_from(neigh[j], kn[j]);
+    MappingParams prm{mb, mbf, scale_factor, inertial != 0, far_points != 0, th_far};
+    const std::vector<NewMapPoint> pts = CreateNewMapPoints(c, nb, CamF{cam4[0], cam4[1], cam4[2], cam4[3]},
+                                                            std::vector<float>(scale_factors, scale_factors + n_levels),
+                                                            std::vector<float>(level_sigma2, level_sigma2 + n_levels), prm, coarse != 0);
+    for (size_t k = 0; k < pts.size() && (int)k < capacity; ++k) {
+        out_idx4[4 * k] = pts[k].idx1; out_idx4[4 * k + 1] = pts[k].neighbour; out_idx4[4 * k + 2] = pts[k].idx2; out_idx4[4 * k + 3] = pts[k].stereo;
+        std::memcpy(out_x3 + 3 * k, pts[k].x3D, 12);
+    }
+    return (int)pts.size();
 }
 
 // ---- IMU pre-integration -------------------------------------------------------------------------------------------------

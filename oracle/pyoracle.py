@@ -600,6 +600,61 @@ def imu_propagate_cov(state36, P, cov12, imu7, beg, end, last_end, acc_scale, la
     return st, P, poses[:k]
 
 
+# ---- CreateNewMapPoints core ---------------------------------------------------------------------------------------------------
+_KP24 = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4")])  # tc2li_keypoint
+
+
+class _KfView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("n_nodes", C.c_int32), ("keys", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p), ("depth", C.c_void_p),
+                ("has_point", C.c_void_p), ("fv_node", C.c_void_p), ("fv_off", C.c_void_p), ("fv_idx", C.c_void_p), ("pose7", C.c_float * 7),
+                ("pad_", C.c_float)]
+
+
+def _pack_views(items):
+    arr = (_KfView * max(len(items), 1))()
+    keep = []
+    for i, it in enumerate(items):
+        k = np.ascontiguousarray(it["keys"], _KP24)
+        d = np.ascontiguousarray(it["descriptors"], np.uint8).reshape(-1, 32)
+        ur, z, hp = np.ascontiguousarray(it["u_right"], np.float32), np.ascontiguousarray(it["depth"], np.float32), np.ascontiguousarray(it["has_point"], np.uint8)
+        fn, fo, fi = [np.ascontiguousarray(it[f], np.int32) for f in ("fv_node", "fv_offset", "fv_index")]
+        keep.append((k, d, ur, z, hp, fn, fo, fi))
+        arr[i].n, arr[i].n_nodes = len(k), len(fn)
+        arr[i].keys, arr[i].desc, arr[i].u_right, arr[i].depth, arr[i].has_point = k.ctypes.data, d.ctypes.data, ur.ctypes.data, z.ctypes.data, hp.ctypes.data
+        arr[i].fv_node, arr[i].fv_off, arr[i].fv_idx = fn.ctypes.data, fo.ctypes.data, fi.ctypes.data
+        arr[i].pose7 = (C.c_float * 7)(*[float(v) for v in it["pose7"]])
+    return arr, keep
+
+
+def search_for_triangulation(kf1, kf2, cam4, scale_factors, level_sigma2, only_stereo=False, coarse=False, check_orientation=False):
+    arr, keep = _pack_views([kf1, kf2])
+    cam4 = np.ascontiguousarray(cam4, np.float32)
+    sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    match = np.full(max(arr[0].n, 1), -1, np.int32)
+    f = lib().oracle_search_for_triangulation
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]
+    n = f(C.addressof(arr), C.addressof(arr) + C.sizeof(_KfView), cam4.ctypes.data, sf.ctypes.data, sg.ctypes.data, len(sf), int(only_stereo), int(coarse),
+          int(check_orientation), match.ctypes.data)
+    del keep
+    return n, match[:arr[0].n]
+
+
+def create_new_map_points(cur, neighbours, cam4, mb, mbf, scale_factors, level_sigma2, scale_factor=1.2, inertial=False, far_points=False,
+                          th_far_points=0.0, coarse=False):
+    arr, keep = _pack_views([cur] + list(neighbours))
+    cam4 = np.ascontiguousarray(cam4, np.float32)
+    sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    cap = max(arr[0].n, 1)
+    idx, x3 = np.zeros((cap, 4), np.int32), np.zeros((cap, 3), np.float32)
+    f = lib().oracle_create_new_map_points
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float,
+                  C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n = f(C.addressof(arr), C.addressof(arr) + C.sizeof(_KfView), len(neighbours), cam4.ctypes.data, mb, mbf, sf.ctypes.data, sg.ctypes.data, len(sf),
+          scale_factor, int(inertial), int(far_points), th_far_points, int(coarse), idx.ctypes.data, x3.ctypes.data, cap)
+    del keep
+    return idx[:n].copy(), x3[:n].copy()
+
+
 # ---- map-point refresh -------------------------------------------------------------------------------------------------------
 def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale):
     """MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth for a flat list of points -> (best_obs, normals, min_d, max_d)."""

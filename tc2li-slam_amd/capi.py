@@ -582,6 +582,71 @@ def lidar_imu_propagate(state36, imu7, beg, end, last_end, acc_scale, last6):
     return st, poses[:k], last
 
 
+class KeyframeView(C.Structure):
+    """tc2li_keyframe_view"""
+    _fields_ = [("n", C.c_int32), ("n_nodes", C.c_int32), ("keys", C.c_void_p), ("descriptors", C.c_void_p), ("u_right", C.c_void_p),
+                ("depth", C.c_void_p), ("has_point", C.c_void_p), ("fv_node", C.c_void_p), ("fv_offset", C.c_void_p), ("fv_index", C.c_void_p),
+                ("pose7", C.c_float * 7), ("pad_", C.c_float)]
+
+
+class NewMapPoint(C.Structure):
+    """tc2li_new_map_point"""
+    _fields_ = [("idx1", C.c_int32), ("neighbour", C.c_int32), ("idx2", C.c_int32), ("stereo", C.c_int32), ("x3D", C.c_float * 3), ("pad_", C.c_float)]
+
+
+def pack_keyframe_views(items):
+    """items: dicts with keys (KEYPOINT_DTYPE), descriptors, u_right, depth, has_point, fv_node, fv_offset, fv_index, pose7 ->
+    (ctypes array of tc2li_keyframe_view, keep-alive list)."""
+    arr = (KeyframeView * max(len(items), 1))()
+    keep = []
+    for i, it in enumerate(items):
+        k = np.ascontiguousarray(it["keys"], KEYPOINT_DTYPE)
+        d = np.ascontiguousarray(it["descriptors"], np.uint8).reshape(-1, 32)
+        ur, z = np.ascontiguousarray(it["u_right"], np.float32), np.ascontiguousarray(it["depth"], np.float32)
+        hp = np.ascontiguousarray(it["has_point"], np.uint8)
+        fn, fo, fi = [np.ascontiguousarray(it[f], np.int32) for f in ("fv_node", "fv_offset", "fv_index")]
+        keep.append((k, d, ur, z, hp, fn, fo, fi))
+        arr[i].n, arr[i].n_nodes = len(k), len(fn)
+        arr[i].keys, arr[i].descriptors, arr[i].u_right, arr[i].depth, arr[i].has_point = (k.ctypes.data, d.ctypes.data, ur.ctypes.data, z.ctypes.data,
+                                                                                          hp.ctypes.data)
+        arr[i].fv_node, arr[i].fv_offset, arr[i].fv_index = fn.ctypes.data, fo.ctypes.data, fi.ctypes.data
+        arr[i].pose7 = (C.c_float * 7)(*[float(v) for v in it["pose7"]])
+    return arr, keep
+
+
+def search_for_triangulation(kf1, kf2, cam5, scale_factors, level_sigma2, only_stereo=False, coarse=False, check_orientation=False, stream=0):
+    """``ORBmatcher::SearchForTriangulation`` -> (nmatches, match12 [n1])."""
+    arr, keep = pack_keyframe_views([kf1, kf2])
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    match = np.full(max(arr[0].n, 1), -1, np.int32)
+    f = lib().tc2li_search_for_triangulation
+    f.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+    n = _check(f(C.addressof(arr), C.addressof(arr) + C.sizeof(KeyframeView), cam5.ctypes.data, sf.ctypes.data, sg.ctypes.data, len(sf), int(only_stereo),
+                 int(coarse), int(check_orientation), match.ctypes.data, C.c_void_p(stream)))
+    del keep
+    return n, match[:arr[0].n]
+
+
+def create_new_map_points(cur, neighbours, cam5, mb, scale_factors, level_sigma2, scale_factor=1.2, inertial=False, far_points=False,
+                          th_far_points=0.0, coarse=False, stream=0):
+    """The geometric loop of ``LocalMapping::CreateNewMapPoints`` -> (idx [k, 4] = idx1, neighbour, idx2, stereo; x3D [k, 3])."""
+    arr, keep = pack_keyframe_views([cur] + list(neighbours))
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    cap = max(arr[0].n, 1)
+    pts = (NewMapPoint * cap)()
+    f = lib().tc2li_create_new_map_points
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float,
+                  C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    n = _check(f(C.addressof(arr), C.addressof(arr) + C.sizeof(KeyframeView), len(neighbours), cam5.ctypes.data, mb, sf.ctypes.data, sg.ctypes.data,
+                 len(sf), scale_factor, int(inertial), int(far_points), th_far_points, int(coarse), C.addressof(pts), cap, C.c_void_p(stream)))
+    del keep
+    idx = np.array([[pts[k].idx1, pts[k].neighbour, pts[k].idx2, pts[k].stereo] for k in range(n)], np.int32).reshape(-1, 4)
+    x3D = np.array([list(pts[k].x3D) for k in range(n)], np.float32).reshape(-1, 3)
+    return idx, x3D
+
+
 def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale, stream=0):
     """``MapPoint::ComputeDistinctiveDescriptors`` + ``UpdateNormalAndDepth`` for a flat list of points ->
     (best_obs, normals [n, 3], min_distance, max_distance)."""
