@@ -560,6 +560,17 @@ int tc2li_create_new_map_points(const tc2li_keyframe_view* current, const tc2li_
                                 int n_levels, float scale_factor, int inertial, int far_points, float th_far_points, int coarse,
                                 tc2li_new_map_point* points, int capacity, void* stream);
 
+/* ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false), the search (SF/src/ORBmatcher.cc:1157-1330; called from
+ * LocalMapping::SearchInNeighbors :728-837): for every map point the keypoint of the keyframe it is fused with -- projection and
+ * gates (depth, image, distance range, viewing direction), MapPoint::PredictScale, the keypoints inside th * scale on the
+ * keyframe's feature grid, level and reprojection gates (7.8 / 5.99 on mvInvLevelSigma2), least descriptor distance <= TH_LOW --
+ * or -1.  valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF).  A point's result depends on no other point; the caller
+ * walks the results in list order and does Replace / AddObservation on its objects (re-checking isBad / IsInKeyFrame there).
+ * best_dist may be NULL.  Returns how many points found a keypoint. */
+int tc2li_fuse_search(const tc2li_frame_view* keyframe, const float pose7[7], const float cam4[4], float bf, const float* scale_factors,
+                      const float* inv_level_sigma2, int n_levels, float log_scale_factor, const tc2li_map_point* points,
+                      const uint8_t* valid, int n_points, float th, int32_t* best_idx, int32_t* best_dist, void* stream);
+
 /* Per-map-point refresh of local mapping after a local BA / after creating or fusing points (LocalMapping.cc, Optimizer.cc:1506,
  * OptimizerWithLidar.cc:484 `pMP->UpdateNormalAndDepth()`; `ComputeDistinctiveDescriptors` in CreateNewMapPoints / Fuse):
  * MapPoint::ComputeDistinctiveDescriptors (SF/src/MapPoint.cc:338-412) and MapPoint::UpdateNormalAndDepth (:444-503) for a flat

@@ -634,6 +634,31 @@ void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, 
     queries_to(qs, out);
 }
 
+// ORBmatcher::Fuse, search part: best keypoint (or -1) and best distance per map point; returns how many would be fused
+int oracle_fuse_search(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* pose7, const float* cam4,
+                       float bf, const float* scales, const float* inv_sigma2, int nlevels, float log_scale, const MapPointPOD* pts,
+                       const uint8_t* valid, int m, float th, int32_t* best_idx, int32_t* best_dist) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    F.occupied.assign(n, 0);
+    F.cols = cols; F.rows = rows;
+    SE3f Tcw;
+    std::memcpy(Tcw.q, pose7, 16); std::memcpy(Tcw.t, pose7 + 4, 12);
+    std::vector<MapPointView> mps(m);
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(mps[i].pos, pts[i].pos, 12); std::memcpy(mps[i].normal, pts[i].normal, 12);
+        mps[i].min_dist = pts[i].min_distance; mps[i].max_dist = pts[i].max_distance; mps[i].mfMaxDistance = pts[i].max_distance_raw;
+        std::memcpy(mps[i].desc, pts[i].desc, 32);
+    }
+    std::vector<int> bi, bd;
+    const int nf = FuseSearch(F, Tcw, CamF{cam4[0], cam4[1], cam4[2], cam4[3]}, bf, std::vector<float>(scales, scales + nlevels),
+                              std::vector<float>(inv_sigma2, inv_sigma2 + nlevels), log_scale, mps, std::vector<uint8_t>(valid, valid + m), th, bi, bd);
+    for (int i = 0; i < m; ++i) { best_idx[i] = bi[i]; best_dist[i] = bd[i]; }
+    return nf;
+}
+
 // single-function probes for unit tests
 float oracle_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 int oracle_fast9_16(const uint8_t* img, int stride, int w, int h, int th, int nms, float* xyr, int cap) {

@@ -197,6 +197,64 @@ int SearchForTriangulation(const KeyFrameView& kf1, const KeyFrameView& kf2, con
     return nmatches;
 }
 
+int FuseSearch(const FrameView& kf, const SE3f& Tcw, const CamF& cam, float bf, const std::vector<float>& sf, const std::vector<float>& inv_sigma2,
+               float log_scale_factor, const std::vector<MapPointView>& points, const std::vector<uint8_t>& valid, float th,
+               std::vector<int>& best_idx, std::vector<int>& best_dist) {
+    FeatureGrid grid;
+    grid.init(kf.cols, kf.rows);
+    grid.assign(kf.keys);
+    const SE3f Twc = se3_inverse(Tcw);
+    const float* Ow = Twc.t;
+    const int nlevels = (int)sf.size();
+    const int n = (int)points.size();
+    best_idx.assign(n, -1);
+    best_dist.assign(n, 256);
+    int nFused = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!valid[i]) continue;
+        const MapPointView& M = points[i];
+        float p3Dc[3];
+        quat_rot_f(Tcw.q, M.pos, p3Dc);
+        for (int c = 0; c < 3; ++c) p3Dc[c] += Tcw.t[c];
+        if (p3Dc[2] < 0.0f) continue;
+        const float invz = 1 / p3Dc[2];
+        const float u = cam.fx * p3Dc[0] / p3Dc[2] + cam.cx, v = cam.fy * p3Dc[1] / p3Dc[2] + cam.cy;
+        if (!(u >= grid.mnMinX && u < grid.mnMaxX && v >= grid.mnMinY && v < grid.mnMaxY)) continue;  // IsInImage
+        const float ur = u - bf * invz;
+        const float PO[3] = {M.pos[0] - Ow[0], M.pos[1] - Ow[1], M.pos[2] - Ow[2]};
+        const float dist3D = std::sqrt((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+        if (dist3D < M.min_dist || dist3D > M.max_dist) continue;
+        const float dotn = (PO[0] * M.normal[0] + PO[1] * M.normal[1]) + PO[2] * M.normal[2];
+        if ((double)dotn < 0.5 * (double)dist3D) continue;
+        const float ratio = M.mfMaxDistance / dist3D;  // MapPoint::PredictScale (MapPoint.cc:540-555)
+        int level = (int)std::ceil(std::log(ratio) / log_scale_factor);
+        if (level < 0) level = 0; else if (level >= nlevels) level = nlevels - 1;
+        const float radius = th * sf[level];
+        const std::vector<size_t> cand = grid.GetFeaturesInArea(kf.keys, u, v, radius, -1, -1);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t idx : cand) {
+            const KeyPoint& kp = kf.keys[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < level - 1 || kpLevel > level) continue;
+            if (kf.uRight[idx] >= 0) {
+                const float ex = u - kp.x, ey = v - kp.y, er = ur - kf.uRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if ((double)(e2 * inv_sigma2[kpLevel]) > 7.8) continue;
+            } else {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if ((double)(e2 * inv_sigma2[kpLevel]) > 5.99) continue;
+            }
+            const int dist = descriptor_distance(M.desc, kf.desc.data() + 32 * idx);
+            if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+        }
+        best_dist[i] = bestDist;
+        if (bestDist <= kThLow) { best_idx[i] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
 std::vector<NewMapPoint> CreateNewMapPoints(const KeyFrameView& cur, const std::vector<KeyFrameView>& neigh, const CamF& cam,
                                             const std::vector<float>& sf, const std::vector<float>& sigma2, const MappingParams& prm,
                                             bool coarse) {

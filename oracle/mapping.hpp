@@ -45,6 +45,14 @@ int SearchForTriangulation(const KeyFrameView& kf1, const KeyFrameView& kf2, con
 struct NewMapPoint { int idx1, neighbour, idx2, stereo; float x3D[3]; };
 struct MappingParams { float mb, mbf, scale_factor; bool inertial, far_points; float th_far_points; };
 // the loop over the neighbours of the current keyframe (already chosen by the caller), points in creation order
+// ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight = false), the search part (SF/src/ORBmatcher.cc:1157-1330): per map point the keypoint
+// of the keyframe it would be fused into (best descriptor distance <= TH_LOW among the keypoints inside the projection window that
+// pass the level and reprojection gates) or -1.  valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF).  Replace / AddObservation
+// stay with the caller (they act on the object graph, in list order).
+int FuseSearch(const FrameView& kf, const SE3f& Tcw, const CamF& cam, float bf, const std::vector<float>& scale_factors,
+               const std::vector<float>& inv_level_sigma2, float log_scale_factor, const std::vector<MapPointView>& points,
+               const std::vector<uint8_t>& valid, float th, std::vector<int>& best_idx, std::vector<int>& best_dist);
+
 std::vector<NewMapPoint> CreateNewMapPoints(const KeyFrameView& cur, const std::vector<KeyFrameView>& neighbours, const CamF& cam,
                                             const std::vector<float>& scale_factors, const std::vector<float>& level_sigma2,
                                             const MappingParams& prm, bool coarse);

@@ -655,6 +655,25 @@ def create_new_map_points(cur, neighbours, cam4, mb, mbf, scale_factors, level_s
     return idx[:n].copy(), x3[:n].copy()
 
 
+def fuse_search(keys, desc, u_right, cols, rows, pose7, cam4, bf, scale_factors, inv_level_sigma2, log_scale_factor, points, valid, th=3.0):
+    """ORBmatcher::Fuse, search part -> (n_fused, best_idx [m], best_dist [m]); points: MAP_POINT_DTYPE."""
+    k6 = _kps_to_floats(keys)
+    d = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(u_right, np.float32)
+    pts = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    val = np.ascontiguousarray(valid, np.uint8)
+    sf, isg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(inv_level_sigma2, np.float32)
+    m = len(pts)
+    bi, bd = np.full(max(m, 1), -1, np.int32), np.zeros(max(m, 1), np.int32)
+    f = lib().oracle_fuse_search
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    nf = f(k6.ctypes.data, d.ctypes.data, ur.ctypes.data, len(k6), cols, rows, np.ascontiguousarray(pose7, np.float32).ctypes.data,
+           np.ascontiguousarray(cam4, np.float32).ctypes.data, bf, sf.ctypes.data, isg.ctypes.data, len(sf), log_scale_factor, pts.ctypes.data, val.ctypes.data, m,
+           th, bi.ctypes.data, bd.ctypes.data)
+    return nf, bi[:m], bd[:m]
+
+
 # ---- map-point refresh -------------------------------------------------------------------------------------------------------
 def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale):
     """MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth for a flat list of points -> (best_obs, normals, min_d, max_d)."""

@@ -647,6 +647,26 @@ def create_new_map_points(cur, neighbours, cam5, mb, scale_factors, level_sigma2
     return idx, x3D
 
 
+def fuse_search(keys, desc, u_right, cols, rows, pose7, cam4, bf, scale_factors, inv_level_sigma2, log_scale_factor, points, valid, th=3.0, stream=0):
+    """``ORBmatcher::Fuse``, the search part -> (n_fused, best_idx [m], best_dist [m]); points: MAP_POINT_DTYPE."""
+    k = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    d = np.ascontiguousarray(desc, np.uint8)
+    ur = np.ascontiguousarray(u_right, np.float32)
+    fv = FrameView(k.ctypes.data, d.ctypes.data, ur.ctypes.data, None, len(k), 0.0, float(cols), 0.0, float(rows))
+    pts = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    val = np.ascontiguousarray(valid, np.uint8)
+    sf, isg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(inv_level_sigma2, np.float32)
+    p7, c4 = np.ascontiguousarray(pose7, np.float32), np.ascontiguousarray(cam4, np.float32)
+    m = len(pts)
+    bi, bd = np.full(max(m, 1), -1, np.int32), np.zeros(max(m, 1), np.int32)
+    f = lib().tc2li_fuse_search
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    nf = _check(f(C.addressof(fv), p7.ctypes.data, c4.ctypes.data, bf, sf.ctypes.data, isg.ctypes.data, len(sf), log_scale_factor, pts.ctypes.data,
+                  val.ctypes.data, m, th, bi.ctypes.data, bd.ctypes.data, C.c_void_p(stream)))
+    return nf, bi[:m], bd[:m]
+
+
 def map_points_refresh(obs_off, descriptors, centres, positions, ref_centres, level_scale, last_scale, stream=0):
     """``MapPoint::ComputeDistinctiveDescriptors`` + ``UpdateNormalAndDepth`` for a flat list of points ->
     (best_obs, normals [n, 3], min_distance, max_distance)."""

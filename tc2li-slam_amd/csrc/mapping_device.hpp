@@ -28,6 +28,22 @@ struct MappingDev {
     uint8_t* ok;                // [n_neigh][cur.n]: 1 = a point passes every gate, bit 1 = stereo point
     float* x3D;                 // [n_neigh][cur.n][3]
 };
+struct FuseDev {  // ORBmatcher::Fuse, search part
+    const float* keys;            // tc2li_keypoint records
+    const uint8_t* desc;
+    const float* u_right;
+    const int32_t* cell_start;    // 64 x 48 grid of the keyframe (k_match_grid): [kCells + 1]
+    const uint16_t* items;
+    int32_t n_keys, n_points, n_levels, pad_;
+    float q[4], t[3], Ow[3];
+    float fx, fy, cx, cy, bf, th, log_scale_factor;
+    float min_x, max_x, min_y, max_y;
+    const float *scale_factors, *inv_level_sigma2;
+    const uint8_t* points;        // tc2li_map_point records (68 bytes)
+    const uint8_t* valid;
+    int32_t *best_idx, *best_dist;
+};
+void launch_fuse_search(const FuseDev& f, hipStream_t st);
 void launch_tri_search(const MappingDev& m, int max_entries, hipStream_t st);
 void launch_tri_points(const MappingDev& m, hipStream_t st);
 

@@ -10,6 +10,7 @@
 
 #include "common.hpp"
 #include "mapping_device.hpp"
+#include "matcher_device.hpp"
 
 using namespace tc2li;
 
@@ -73,6 +74,17 @@ struct KfBuffers {
     DevBuf<uint8_t> desc, has_point;
     DevBuf<int32_t> fv_node, fv_off, fv_idx;
 };
+struct FuseWorkspace {
+    DevBuf<float> keys, u_right, scale, inv_sigma;
+    DevBuf<uint8_t> desc, points, valid;
+    DevBuf<MatchKey> mkeys;
+    DevBuf<MatchFrameDev> frame;
+    DevBuf<int32_t> cell_start, key_base, best_idx, best_dist;
+    DevBuf<uint16_t> items;
+    std::mutex mu;
+};
+FuseWorkspace& fws() { static FuseWorkspace w; return w; }
+
 struct Workspace {
     std::vector<std::unique_ptr<KfBuffers>> kf;  // [0] = current keyframe, [1 + j] = neighbour j
     DevBuf<KfDev> d_neigh;
@@ -303,4 +315,66 @@ extern "C" int tc2li_create_new_map_points(const tc2li_keyframe_view* cur, const
         }
     if (count > capacity) { set_error("tc2li_create_new_map_points: %d points, capacity %d", count, capacity); return TC2LI_ERR_CAPACITY; }
     return count;
+}
+
+static_assert(sizeof(tc2li_map_point) == 68, "ABI layout");
+
+extern "C" int tc2li_fuse_search(const tc2li_frame_view* kf, const float pose7[7], const float cam4[4], float bf, const float* scale_factors,
+                                 const float* inv_level_sigma2, int n_levels, float log_scale_factor, const tc2li_map_point* points,
+                                 const uint8_t* valid, int n_points, float th, int32_t* best_idx, int32_t* best_dist, void* stream_) {
+    if (!kf || !pose7 || !cam4 || !scale_factors || !inv_level_sigma2 || n_levels < 1 || n_points < 0 || (n_points > 0 && (!points || !valid || !best_idx)) ||
+        kf->n < 0 || !(kf->max_x > kf->min_x) || !(kf->max_y > kf->min_y) || !(log_scale_factor > 0)) {
+        set_error("tc2li_fuse_search: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_points == 0) return 0;
+    for (int i = 0; i < n_points; ++i) { best_idx[i] = -1; if (best_dist) best_dist[i] = 256; }
+    if (kf->n == 0) return 0;
+    if (!kf->keys || !kf->descriptors || !kf->u_right) { set_error("tc2li_fuse_search: null keyframe arrays"); return TC2LI_ERR_INVALID; }
+    if (kf->n > kMaxMatchKeys) { set_error("keyframe has %d keypoints, the feature grid supports %d", kf->n, kMaxMatchKeys); return TC2LI_ERR_CAPACITY; }
+    for (int i = 0; i < kf->n; ++i) if (kf->keys[i].octave < 0 || kf->keys[i].octave >= n_levels) { set_error("tc2li_fuse_search: keypoint octave out of range"); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    FuseWorkspace& w = fws();
+    std::lock_guard<std::mutex> lk(w.mu);
+    const int N = kf->n;
+    std::vector<MatchKey> mk(N);
+    for (int i = 0; i < N; ++i) mk[i] = MatchKey{kf->keys[i].x, kf->keys[i].y, kf->keys[i].octave};
+    TC2LI_HIP_CHECK(w.keys.ensure(6 * (size_t)N)); TC2LI_HIP_CHECK(w.u_right.ensure(N)); TC2LI_HIP_CHECK(w.desc.ensure(32 * (size_t)N)); TC2LI_HIP_CHECK(w.mkeys.ensure(N));
+    TC2LI_HIP_CHECK(w.scale.ensure(n_levels)); TC2LI_HIP_CHECK(w.inv_sigma.ensure(n_levels)); TC2LI_HIP_CHECK(w.points.ensure(68 * (size_t)n_points));
+    TC2LI_HIP_CHECK(w.valid.ensure(n_points)); TC2LI_HIP_CHECK(w.frame.ensure(1)); TC2LI_HIP_CHECK(w.cell_start.ensure(64 * 48 + 1)); TC2LI_HIP_CHECK(w.key_base.ensure(1));
+    TC2LI_HIP_CHECK(w.items.ensure(N)); TC2LI_HIP_CHECK(w.best_idx.ensure(n_points)); TC2LI_HIP_CHECK(w.best_dist.ensure(n_points));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.keys.p, kf->keys, (size_t)N * sizeof(tc2li_keypoint), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.mkeys.p, mk.data(), N * sizeof(MatchKey), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.u_right.p, kf->u_right, N * sizeof(float), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.desc.p, kf->descriptors, 32 * (size_t)N, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.scale.p, scale_factors, n_levels * sizeof(float), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.inv_sigma.p, inv_level_sigma2, n_levels * sizeof(float), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.points.p, points, 68 * (size_t)n_points, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.valid.p, valid, n_points, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(w.key_base.p, 0, sizeof(int32_t), st));
+    const MatchFrameDev fd{w.mkeys.p, w.desc.p, w.u_right.p, nullptr, nullptr, N, 0, 0, 0, kf->min_x, kf->max_x, kf->min_y, kf->max_y};
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.frame.p, &fd, sizeof(fd), hipMemcpyHostToDevice, st));
+    MatchLists L{};
+    L.cell_start = w.cell_start.p; L.items = w.items.p; L.key_base = w.key_base.p;
+    launch_match_grid(w.frame.p, 1, L, st);
+    FuseDev f{};
+    f.keys = w.keys.p; f.desc = w.desc.p; f.u_right = w.u_right.p; f.cell_start = w.cell_start.p; f.items = w.items.p;
+    f.n_keys = N; f.n_points = n_points; f.n_levels = n_levels;
+    memcpy(f.q, pose7, 16); memcpy(f.t, pose7 + 4, 12);
+    Q7 T; memcpy(T.q, pose7, 16); memcpy(T.t, pose7 + 4, 12);
+    const Q7 Tw = inv7(T);
+    memcpy(f.Ow, Tw.t, 12);
+    f.fx = cam4[0]; f.fy = cam4[1]; f.cx = cam4[2]; f.cy = cam4[3]; f.bf = bf; f.th = th; f.log_scale_factor = log_scale_factor;
+    f.min_x = kf->min_x; f.max_x = kf->max_x; f.min_y = kf->min_y; f.max_y = kf->max_y;
+    f.scale_factors = w.scale.p; f.inv_level_sigma2 = w.inv_sigma.p; f.points = w.points.p; f.valid = w.valid.p;
+    f.best_idx = w.best_idx.p; f.best_dist = w.best_dist.p;
+    launch_fuse_search(f, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(best_idx, w.best_idx.p, n_points * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (best_dist) TC2LI_HIP_CHECK(hipMemcpyAsync(best_dist, w.best_dist.p, n_points * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    int nfused = 0;
+    for (int i = 0; i < n_points; ++i) nfused += best_idx[i] >= 0;
+    return nfused;
 }

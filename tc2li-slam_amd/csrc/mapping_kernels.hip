@@ -215,6 +215,90 @@ __global__ __launch_bounds__(128) void k_tri_points(MappingDev m) {
     m.x3D[3 * slot] = x3D[0]; m.x3D[3 * slot + 1] = x3D[1]; m.x3D[3 * slot + 2] = x3D[2];
 }
 
+// ORBmatcher::Fuse, the search of one map point (SF/src/ORBmatcher.cc:1185-1300): projection and gates, predicted level, the
+// keypoints of the window on the keyframe's feature grid, level / reprojection gates, best descriptor distance
+__device__ __forceinline__ void q_rot_dev(const float q[4], const float v[3], float out[3]) {  // Eigen _transformVector
+    float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    out[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    out[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    out[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+constexpr int kFuseGridCols = 64, kFuseGridRows = 48;
+__global__ __launch_bounds__(128) void k_fuse_search(FuseDev f) {
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= f.n_points) return;
+    int best_idx = -1, best_dist = 256;
+    const float* P = reinterpret_cast<const float*>(f.points + 68 * (size_t)i);  // pos 3, normal 3, min, max, max_raw, descriptor
+    if (f.valid[i]) {
+        const float pos[3] = {P[0], P[1], P[2]};
+        float pc[3];
+        q_rot_dev(f.q, pos, pc);
+        pc[0] += f.t[0]; pc[1] += f.t[1]; pc[2] += f.t[2];
+        bool go = !(pc[2] < 0.0f);
+        float u = 0, v = 0, ur = 0, dist3D = 0;
+        if (go) {
+            const float invz = 1 / pc[2];
+            u = f.fx * pc[0] / pc[2] + f.cx; v = f.fy * pc[1] / pc[2] + f.cy;
+            go = u >= f.min_x && u < f.max_x && v >= f.min_y && v < f.max_y;
+            ur = u - f.bf * invz;
+        }
+        if (go) {
+            const float PO[3] = {pos[0] - f.Ow[0], pos[1] - f.Ow[1], pos[2] - f.Ow[2]};
+            dist3D = sqrtf((PO[0] * PO[0] + PO[1] * PO[1]) + PO[2] * PO[2]);
+            go = !(dist3D < P[6] || dist3D > P[7]);
+            const float dotn = (PO[0] * P[3] + PO[1] * P[4]) + PO[2] * P[5];
+            go = go && !((double)dotn < 0.5 * (double)dist3D);
+        }
+        if (go) {
+            const float ratio = P[8] / dist3D;
+            int level = (int)ceilf((float)log((double)ratio) / f.log_scale_factor);  // logf of the reference, evaluated through double
+            level = level < 0 ? 0 : (level >= f.n_levels ? f.n_levels - 1 : level);
+            const float r = f.th * f.scale_factors[level];
+            const float invW = (float)kFuseGridCols / (f.max_x - f.min_x), invH = (float)kFuseGridRows / (f.max_y - f.min_y);
+            const int minCX = max(0, (int)floorf((u - f.min_x - r) * invW)), maxCX = min(kFuseGridCols - 1, (int)ceilf((u - f.min_x + r) * invW));
+            const int minCY = max(0, (int)floorf((v - f.min_y - r) * invH)), maxCY = min(kFuseGridRows - 1, (int)ceilf((v - f.min_y + r) * invH));
+            if (!(minCX >= kFuseGridCols || maxCX < 0 || minCY >= kFuseGridRows || maxCY < 0)) {
+                const uint32_t* qd = reinterpret_cast<const uint32_t*>(P + 9);
+                uint32_t q[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) q[w] = qd[w];
+                for (int ix = minCX; ix <= maxCX; ++ix)
+                    for (int iy = minCY; iy <= maxCY; ++iy) {
+                        const int c = ix * kFuseGridRows + iy;
+                        for (int k = f.cell_start[c]; k < f.cell_start[c + 1]; ++k) {
+                            const int idx = f.items[k];
+                            const Kp kp = load_kp(f.keys, idx);
+                            if (!(fabsf(kp.x - u) < r && fabsf(kp.y - v) < r)) continue;
+                            if (kp.octave < level - 1 || kp.octave > level) continue;
+                            const float kur = f.u_right[idx];
+                            const float ex = u - kp.x, ey = v - kp.y;
+                            if (kur >= 0) {
+                                const float er = ur - kur;
+                                const float e2 = ex * ex + ey * ey + er * er;
+                                if ((double)(e2 * f.inv_level_sigma2[kp.octave]) > 7.8) continue;
+                            } else {
+                                const float e2 = ex * ex + ey * ey;
+                                if ((double)(e2 * f.inv_level_sigma2[kp.octave]) > 5.99) continue;
+                            }
+                            const uint32_t* kd = reinterpret_cast<const uint32_t*>(f.desc) + 8 * (size_t)idx;
+                            int dist = 0;
+#pragma unroll
+                            for (int w = 0; w < 8; ++w) dist += __popc(q[w] ^ kd[w]);
+                            if (dist < best_dist) { best_dist = dist; best_idx = idx; }
+                        }
+                    }
+            }
+        }
+    }
+    f.best_dist[i] = best_dist;
+    f.best_idx[i] = best_dist <= 50 ? best_idx : -1;  // TH_LOW
+}
+
+void launch_fuse_search(const FuseDev& f, hipStream_t st) {
+    if (f.n_points > 0) hipLaunchKernelGGL(k_fuse_search, dim3((f.n_points + 127) / 128), dim3(128), 0, st, f);
+}
+
 void launch_tri_search(const MappingDev& m, int max_entries, hipStream_t st) {
     if (m.n_neigh > 0 && max_entries > 0) hipLaunchKernelGGL(k_tri_search, dim3((max_entries + 255) / 256, m.n_neigh), dim3(256), 0, st, m);
 }

@@ -40,6 +40,8 @@ struct MatchLists {
     int32_t* pool_top;     // [0] = entries used, [1] = overflow flag
     int32_t pool_cap, pad_;
 };
+// only the feature grids (cell_start, items) of the frames: used by the fuse search as well
+void launch_match_grid(const MatchFrameDev* frames, int nframes, const MatchLists& L, hipStream_t st);
 void launch_match_lists(const MatchFrameDev* frames, int nframes, const int32_t* query_frame, int total_q, const MatchLists& L, int mode,
                         float nn_ratio, int32_t* match_of_query, int32_t* prev_claim, int32_t* rounds_out, hipStream_t st);
 void launch_match_by_projection(const MatchFrameDev* frames, int nframes, int mode, float nn_ratio, int32_t* match_of_query,

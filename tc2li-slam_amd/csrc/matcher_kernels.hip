@@ -349,6 +349,10 @@ __global__ __launch_bounds__(kThreads) void k_match_resolve(const MatchFrameDev*
     if (tid == 0) rounds_out[blockIdx.x] = round;
 }
 
+void launch_match_grid(const MatchFrameDev* frames, int nframes, const MatchLists& L, hipStream_t st) {
+    if (nframes > 0) hipLaunchKernelGGL(k_match_grid, dim3(nframes), dim3(kThreads), 0, st, frames, L);
+}
+
 void launch_match_lists(const MatchFrameDev* frames, int nframes, const int32_t* query_frame, int total_q, const MatchLists& L, int mode,
                         float nn_ratio, int32_t* match_of_query, int32_t* prev_claim, int32_t* rounds_out, hipStream_t st) {
     if (nframes <= 0) return;

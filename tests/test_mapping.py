@@ -154,3 +154,62 @@ def test_product_matches_the_oracle(pkg, oracle, synthetic, keyframes):
     bad = dict(cur); bad["fv_index"] = cur["fv_index"].copy(); bad["fv_index"][0] = 10 ** 6
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.search_for_triangulation(bad, keyframes[1], cam5, sf, sg)
+
+
+# ---- ORBmatcher::Fuse, the search -----------------------------------------------------------------------------------------------
+def fuse_problem(oracle, keyframes, synthetic, src=2, dst=0, seed=0):
+    """Map points = the stereo points of keyframe `src`; they are fused into keyframe `dst`."""
+    cam4, mbf, mb = cam_of(synthetic)
+    sf, sg = tables()
+    rng = np.random.default_rng(seed)
+    A, B = keyframes[src], keyframes[dst]
+    sel = np.nonzero(A["depth"] > 0)[0]
+    z = A["depth"][sel]
+    Xc = np.stack([(A["keys"]["x"][sel] - cam4[2]) * z / cam4[0], (A["keys"]["y"][sel] - cam4[3]) * z / cam4[1], z], 1).astype(np.float32)
+    Xw = (Xc + A["centre"].astype(np.float32)).astype(np.float32)
+    pts = np.zeros(len(sel), oracle.MAP_POINT_DTYPE)
+    pts["pos"] = Xw
+    v = Xw - A["centre"].astype(np.float32)
+    dist = np.linalg.norm(v, axis=1).astype(np.float32)
+    pts["normal"] = v / dist[:, None]
+    raw = (dist * sf[A["keys"]["octave"][sel]]).astype(np.float32)
+    pts["max_distance_raw"] = raw
+    pts["max_distance"] = np.float32(1.2) * raw
+    pts["min_distance"] = np.float32(0.8) * (raw / sf[-1])
+    pts["descriptor"] = A["descriptors"][sel]
+    valid = (rng.random(len(sel)) < 0.85).astype(np.uint8)
+    return B, pts, valid, cam4, mbf, sf, (np.float32(1) / sg).astype(np.float32), float(np.log(np.float32(1.2)))
+
+
+def test_oracle_fuse_search(oracle, synthetic, keyframes):
+    B, pts, valid, cam4, mbf, sf, isg, logsf = fuse_problem(oracle, keyframes, synthetic)
+    nf, bi, bd = oracle.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, logsf, pts, valid, th=3.0)
+    assert nf == (bi >= 0).sum() and nf > 100
+    assert not (bi[valid == 0] >= 0).any()
+    hit = np.nonzero(bi >= 0)[0]
+    assert np.all(bd[hit] <= 50)
+    # the fused keypoint lies where the point projects
+    Xc = pts["pos"][hit] - B["centre"].astype(np.float32)
+    u = cam4[0] * Xc[:, 0] / Xc[:, 2] + cam4[2]
+    v = cam4[1] * Xc[:, 1] / Xc[:, 2] + cam4[3]
+    err = np.hypot(u - B["keys"]["x"][bi[hit]], v - B["keys"]["y"][bi[hit]])
+    assert np.median(err) < 1.5 and np.all(err < 3.0 * sf[B["keys"]["octave"][bi[hit]]] * np.sqrt(2) + 1e-3)
+    # a wider window cannot lose candidates that pass the gates; behind the camera nothing is fused
+    nf2, bi2, _ = oracle.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, logsf, pts, valid, th=6.0)
+    assert nf2 >= nf
+    back = B["pose7"].copy(); back[6] -= 500.0
+    assert oracle.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, back, cam4, mbf, sf, isg, logsf, pts, valid)[0] == 0
+
+
+@pytest.mark.gpu
+def test_product_fuse_search(pkg, oracle, synthetic, keyframes):
+    for src, dst, th in [(2, 0, 3.0), (0, 3, 3.0), (1, 4, 6.0)]:
+        B, pts, valid, cam4, mbf, sf, isg, logsf = fuse_problem(oracle, keyframes, synthetic, src, dst, seed=src)
+        want = oracle.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, logsf, pts, valid, th=th)
+        got = pkg.capi.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, logsf, pts, valid, th=th)
+        assert got[0] == want[0] and want[0] > 50
+        assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    got = pkg.capi.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, logsf, pts[:0], valid[:0])
+    assert got[0] == 0
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.fuse_search(B["keys"], B["descriptors"], B["u_right"], W, H, B["pose7"], cam4, mbf, sf, isg, 0.0, pts, valid)
