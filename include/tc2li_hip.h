@@ -425,6 +425,22 @@ int tc2li_track_motion_model_batch(tc2li_orb* orb, int n_frames, const tc2li_key
                                    const tc2li_camera* cam, float b, float th, double* poses7,
                                    int32_t* map_point_of_keypoint, int32_t* n_matches, int32_t* n_inliers, void* stream);
 
+/* The data path of Tracking::TrackLocalMap (SF/src/Tracking.cc:3119-3230) after TrackWithMotionModel, for the same batch of
+ * frames: SearchLocalPoints (:3232-3294: Frame::isInFrustum(pMP, 0.5) + ORBmatcher(0.8).SearchByProjection(F, mvpLocalMapPoints,
+ * th, mbFarPoints, mThFarPoints)), Optimizer::PoseOptimization over every map point the frame holds, mnMatchesInliers.
+ * poses7 [n_frames][7] (float) = the frames' current poses; held [n_frames][capacity]: 0 = keypoint i holds no map point, 1 = holds
+ * one with Observations() > 0 (it blocks the search), 2 = holds one without observations; held_Xw [n_frames][capacity][3] its
+ * world position.  local_points + local_offsets [n_frames + 1]: per frame the local map points still to be matched (not bad,
+ * mnLastFrameSeen != this frame).  th as chosen at :3262-3281.  Out: poses7_out (double), local_of_keypoint [n_frames][capacity] =
+ * index (within the frame's list) of the local point now held by keypoint i or -1, outlier [n_frames][capacity] = mvbOutlier
+ * of every held point, n_matches[f] = SearchByProjection's result, n_inliers[f] = mnMatchesInliers.  The caller applies the
+ * sensor-specific clean-up (:3198-3199) and the thresholds of :3205-3229. */
+int tc2li_track_local_map_batch(tc2li_orb* orb, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
+                                int32_t* n_inliers, void* stream);
+
 /* The LiDAR co-visibility window of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): the first
  * min(6, .) local keyframes with a non-empty surface cloud, in list order.  Replaces LidarCovisRes::AddFromKeyFrame /
  * BuildVoxHess (SF/src/LidarRes.cc:32-80) and the EdgeLidarSE3 they feed (SF/include/G2oTypesWithLidar.h:88-236). */

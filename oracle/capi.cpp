@@ -634,6 +634,66 @@ void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, 
     queries_to(qs, out);
 }
 
+// Tracking::TrackLocalMap's data path for one frame (SearchLocalPoints -> PoseOptimization -> mnMatchesInliers); returns mnMatchesInliers
+int oracle_track_local_map(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
+                           const float* inv_sigma2, int nlevels, float log_scale, const float* pose7, const double* cam5, const uint8_t* held,
+                           const float* held_Xw, const MapPointPOD* pts, int m, float th, int far_points, float th_far, double* pose_out7,
+                           int* local_of_keypoint, uint8_t* outlier, int* n_matches) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    F.occupied.resize(n);
+    for (int i = 0; i < n; ++i) F.occupied[i] = held[i] == 1;
+    F.cols = cols; F.rows = rows;
+    SE3f Tcw;
+    std::memcpy(Tcw.q, pose7, 16); std::memcpy(Tcw.t, pose7 + 4, 12);
+    CamF camf{(float)cam5[0], (float)cam5[1], (float)cam5[2], (float)cam5[3]};
+    std::vector<MapPointView> mps(m);
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(mps[i].pos, pts[i].pos, 12); std::memcpy(mps[i].normal, pts[i].normal, 12);
+        mps[i].min_dist = pts[i].min_distance; mps[i].max_dist = pts[i].max_distance; mps[i].mfMaxDistance = pts[i].max_distance_raw;
+        std::memcpy(mps[i].desc, pts[i].desc, 32);
+    }
+    std::vector<int> match(m, -1);
+    int nm = 0;
+    if (m > 0) {
+        auto qs = build_queries_local_map(Tcw, camf, (float)cam5[4], std::vector<float>(scales, scales + nlevels), log_scale, cols, rows, mps, th,
+                                          far_points != 0, th_far, 0.5f);
+        nm = match_queries(F, qs, MATCH_RATIO, 0.8f, match);
+    }
+    *n_matches = nm;
+    for (int i = 0; i < n; ++i) { local_of_keypoint[i] = -1; outlier[i] = 0; }
+    for (int q = 0; q < m; ++q) if (match[q] >= 0) local_of_keypoint[match[q]] = q;
+    std::vector<double> Xd;
+    std::vector<BAEdge> edges;
+    std::vector<int> kp_of_edge;
+    for (int i = 0; i < n; ++i) {
+        if (!(held[i] != 0 || local_of_keypoint[i] >= 0)) continue;
+        BAEdge e;
+        e.point = (int)edges.size(); e.pose = 0;
+        e.obs[0] = F.keys[i].x; e.obs[1] = F.keys[i].y; e.obs[2] = F.uRight[i];
+        e.info = inv_sigma2[F.keys[i].octave];
+        edges.push_back(e);
+        const float* X = local_of_keypoint[i] >= 0 ? pts[local_of_keypoint[i]].pos : held_Xw + 3 * (size_t)i;
+        for (int c = 0; c < 3; ++c) Xd.push_back((double)X[c]);
+        kp_of_edge.push_back(i);
+    }
+    for (int c = 0; c < 7; ++c) pose_out7[c] = (double)pose7[c];
+    SE3Quat T = pose_from(pose_out7);
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    std::vector<uint8_t> out;
+    PoseOptimization(T, Xd, edges, cam, out);
+    pose_to(T, pose_out7);
+    int good = 0;
+    for (size_t e = 0; e < edges.size() && e < out.size(); ++e) {
+        const int i = kp_of_edge[e];
+        outlier[i] = out[e];
+        if (!out[e] && (local_of_keypoint[i] >= 0 || held[i] == 1)) ++good;
+    }
+    return good;
+}
+
 // ORBmatcher::Fuse, search part: best keypoint (or -1) and best distance per map point; returns how many would be fused
 int oracle_fuse_search(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* pose7, const float* cam4,
                        float bf, const float* scales, const float* inv_sigma2, int nlevels, float log_scale, const MapPointPOD* pts,

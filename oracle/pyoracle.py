@@ -655,6 +655,25 @@ def create_new_map_points(cur, neighbours, cam4, mb, mbf, scale_factors, level_s
     return idx[:n].copy(), x3[:n].copy()
 
 
+def track_local_map(keys, desc, u_right, cols, rows, scales, inv_sigma2, log_scale, pose7, cam5, held, held_Xw, points, th=1.0, far_points=False,
+                    th_far=0.0):
+    """Tracking::TrackLocalMap's data path for one frame -> (pose7 double, local_of_keypoint, outlier, n_matches, n_inliers)."""
+    k6 = _kps_to_floats(keys)
+    n = len(k6)
+    d, ur = np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(u_right, np.float32)
+    sc, isg = np.ascontiguousarray(scales, np.float32), np.ascontiguousarray(inv_sigma2, np.float32)
+    pts = np.ascontiguousarray(points, MAP_POINT_DTYPE)
+    h, hx = np.ascontiguousarray(held, np.uint8), np.ascontiguousarray(held_Xw, np.float32)
+    pose_out, lk, ol, nm = np.zeros(7), np.full(max(n, 1), -1, np.int32), np.zeros(max(n, 1), np.uint8), C.c_int(0)
+    f = lib().oracle_track_local_map
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    inl = f(k6.ctypes.data, d.ctypes.data, ur.ctypes.data, n, cols, rows, sc.ctypes.data, isg.ctypes.data, len(sc), log_scale,
+            np.ascontiguousarray(pose7, np.float32).ctypes.data, _f64(cam5).ctypes.data, h.ctypes.data, hx.ctypes.data, pts.ctypes.data, len(pts), th,
+            int(far_points), th_far, pose_out.ctypes.data, lk.ctypes.data, ol.ctypes.data, C.addressof(nm))
+    return pose_out, lk[:n], ol[:n], nm.value, inl
+
+
 def fuse_search(keys, desc, u_right, cols, rows, pose7, cam4, bf, scale_factors, inv_level_sigma2, log_scale_factor, points, valid, th=3.0):
     """ORBmatcher::Fuse, search part -> (n_fused, best_idx [m], best_dist [m]); points: MAP_POINT_DTYPE."""
     k6 = _kps_to_floats(keys)

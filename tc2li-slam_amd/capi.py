@@ -647,6 +647,30 @@ def create_new_map_points(cur, neighbours, cam5, mb, scale_factors, level_sigma2
     return idx, x3D
 
 
+def track_local_map_batch(ext, n_frames, keypoints, u_right, poses7, held, held_Xw, local_points, local_offsets, cam5, th=1.0, far_points=False,
+                          th_far=0.0, stream=0):
+    """``tc2li_track_local_map_batch`` on the features of the last ``extract_batch_dev`` call ->
+    (poses7 double [F, 7], local_of_keypoint [F, cap], outlier [F, cap], n_matches [F], n_inliers [F])."""
+    kps = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
+    cap = kps.shape[1]
+    ur = np.ascontiguousarray(u_right, np.float32)
+    p7 = np.ascontiguousarray(poses7, np.float32).reshape(n_frames, 7)
+    h = np.ascontiguousarray(held, np.uint8).reshape(n_frames, cap)
+    hx = np.ascontiguousarray(held_Xw, np.float32).reshape(n_frames, cap, 3)
+    pts = np.ascontiguousarray(local_points, MAP_POINT_DTYPE)
+    off = np.ascontiguousarray(local_offsets, np.int32)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    out_p, lk, ol = np.zeros((n_frames, 7)), np.full((n_frames, cap), -1, np.int32), np.zeros((n_frames, cap), np.uint8)
+    nm, inl = np.zeros(n_frames, np.int32), np.zeros(n_frames, np.int32)
+    f = lib().tc2li_track_local_map_batch
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                  C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(ext._h, n_frames, kps.ctypes.data, ur.ctypes.data, cap, p7.ctypes.data, h.ctypes.data, hx.ctypes.data, pts.ctypes.data if len(pts) else None,
+             off.ctypes.data, cam5.ctypes.data, th, int(far_points), th_far, out_p.ctypes.data, lk.ctypes.data, ol.ctypes.data, nm.ctypes.data,
+             inl.ctypes.data, C.c_void_p(stream)))
+    return out_p, lk, ol, nm, inl
+
+
 def fuse_search(keys, desc, u_right, cols, rows, pose7, cam4, bf, scale_factors, inv_level_sigma2, log_scale_factor, points, valid, th=3.0, stream=0):
     """``ORBmatcher::Fuse``, the search part -> (n_fused, best_idx [m], best_dist [m]); points: MAP_POINT_DTYPE."""
     k = np.ascontiguousarray(keys, KEYPOINT_DTYPE)

@@ -109,15 +109,24 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
     TC2LI_HIP_CHECK(w.d_rounds.ensure(n_frames));
     TC2LI_HIP_CHECK(w.h_ur.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.h_frames.ensure(n_frames));
     TC2LI_HIP_CHECK(w.h_match.ensure(total_q));
+    bool any_occ = false;
+    for (int f = 0; f < n_frames; ++f) any_occ |= frames[f].occupied_host != nullptr;
+    std::vector<uint8_t> occ;
+    if (any_occ) {
+        occ.assign(std::max(total_k, 1), 0);
+        TC2LI_HIP_CHECK(w.d_occ.ensure(std::max(total_k, 1)));
+    }
     int koff = 0;
     for (int f = 0; f < n_frames; ++f) {
         const BatchSearchFrame& fr = frames[f];
         memcpy(w.h_ur.p + koff, fr.u_right_host, fr.n_keys * sizeof(float));
-        w.h_frames.p[f] = MatchFrameDev{o->d_mkeys.p + fr.key_off, o->d_desc.p + (size_t)fr.key_off * 32, w.d_ur.p + koff, nullptr,
+        if (fr.occupied_host) memcpy(occ.data() + koff, fr.occupied_host, fr.n_keys);
+        w.h_frames.p[f] = MatchFrameDev{o->d_mkeys.p + fr.key_off, o->d_desc.p + (size_t)fr.key_off * 32, w.d_ur.p + koff, any_occ ? w.d_occ.p + koff : nullptr,
                                         w.d_queries.p + fr.q_off, fr.n_keys, fr.n_q, fr.q_off, 0, 0.0f, (float)o->cur_w, 0.0f, (float)o->cur_h};
         koff += fr.n_keys;
     }
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_ur.p, w.h_ur.p, std::max(total_k, 1) * sizeof(float), hipMemcpyHostToDevice, st));
+    if (any_occ) TC2LI_HIP_CHECK(hipMemcpy(w.d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice));  // pageable source: synchronous copy
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_queries.p, queries, (size_t)total_q * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));

@@ -11,6 +11,7 @@ struct BatchSearchFrame {
     const tc2li_keypoint* keys_host;   // the same keypoints on the host (angles for the rotation histogram)
     const float* u_right_host;         // mvuRight
     int q_off, n_q;                    // range of the frame's queries
+    const uint8_t* occupied_host = nullptr;  // mvpMapPoints[i] && Observations() > 0 before the search (NULL: none)
 };
 
 // ORBmatcher::SearchByProjection loop bodies for many frames in one launch; match_of_query is indexed like `queries`.

@@ -126,3 +126,120 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     if (kTiming) fprintf(stderr, "track timing ms: queries %.3f search %.3f edges %.3f pose-opt %.3f finish %.3f\n", tm[0], tm[1], tm[2], tm[3], now() - t0);
     return n_frames;
 }
+
+// The data path of Tracking::TrackLocalMap (SF/src/Tracking.cc:3119-3230) for a batch of independent frames: SearchLocalPoints
+// (:3232-3294: isInFrustum + SearchByProjection(F, mvpLocalMapPoints, th, far points) with ORBmatcher(0.8)) on the device-resident
+// features, then Optimizer::PoseOptimization over every map point the frame holds, and mnMatchesInliers.
+extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                           const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                           const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                           double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
+                                           int32_t* n_inliers, void* stream_) {
+    if (!o || n_frames < 0 || capacity < 0 || !keypoints || !u_right || !poses7 || !held || !held_Xw || !local_offsets || !cam || !poses7_out ||
+        !local_of_keypoint || !outlier || !n_matches || !n_inliers) {
+        set_error("tc2li_track_local_map_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_frames == 0) return 0;
+    if (2 * n_frames > o->last_nimg || !o->last_plain_order) {
+        set_error("tc2li_track_local_map_batch: needs the features of a preceding tc2li_orb_extract_batch call with lapping area {0,0} and "
+                  "2*n_frames images");
+        return TC2LI_ERR_INVALID;
+    }
+    if (local_offsets[0] != 0) { set_error("tc2li_track_local_map_batch: local_offsets[0] must be 0"); return TC2LI_ERR_INVALID; }
+    const int total_q = local_offsets[n_frames];
+    if (total_q < 0 || (total_q > 0 && !local_points)) { set_error("tc2li_track_local_map_batch: invalid local points"); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    const int L = o->prm.nlevels;
+    const float cam4[4] = {(float)cam->fx, (float)cam->fy, (float)cam->cx, (float)cam->cy};
+    const float bf = (float)cam->bf;
+    const float log_scale = std::log(o->prm.scale_factor);  // mfLogScaleFactor = log(mfScaleFactor) (SF/src/Frame.cc:96)
+    std::vector<BatchSearchFrame> frames(n_frames);
+    std::vector<std::vector<uint8_t>> occ(n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        BatchSearchFrame& fr = frames[f];
+        fr.key_off = o->last_kp_off[2 * f];
+        fr.n_keys = o->last_kp_off[2 * f + 1] - fr.key_off;
+        if (fr.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, fr.n_keys); return TC2LI_ERR_CAPACITY; }
+        if (local_offsets[f + 1] < local_offsets[f]) { set_error("tc2li_track_local_map_batch: local_offsets must not decrease"); return TC2LI_ERR_INVALID; }
+        fr.keys_host = keypoints + (size_t)(2 * f) * capacity;
+        fr.u_right_host = u_right + (size_t)f * capacity;
+        fr.q_off = local_offsets[f];
+        fr.n_q = local_offsets[f + 1] - local_offsets[f];
+        occ[f].resize(std::max(fr.n_keys, 1));
+        const uint8_t* h = held + (size_t)f * capacity;
+        for (int i = 0; i < fr.n_keys; ++i) occ[f][i] = h[i] == 1;  // held with Observations() > 0 (ORBmatcher.cc:100-102)
+        fr.occupied_host = occ[f].data();
+    }
+    std::vector<tc2li_proj_query> queries(std::max(total_q, 1));
+    std::vector<int32_t> match(std::max(total_q, 1), -1);
+    std::vector<int> rc(n_frames, 0);
+    global_pool().parallel_for(n_frames, [&](int f) {
+        if (frames[f].n_q > 0)
+            rc[f] = tc2li_project_local_map(poses7 + 7 * f, cam4, bf, o->scale.data(), L, log_scale, o->cur_w, o->cur_h, frames[f].n_q,
+                                            local_points + frames[f].q_off, th, far_points, th_far_points, 0.5f, queries.data() + frames[f].q_off);
+    });
+    for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
+    int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 1, 0.8f, false, match.data(), n_matches, st);
+    if (r < 0) return r;
+    // ---- Optimizer::PoseOptimization over every map point the frame now holds, in keypoint order ----
+    std::vector<int32_t> edge_off(n_frames + 1, 0);
+    global_pool().parallel_for(n_frames, [&](int f) {
+        const BatchSearchFrame& fr = frames[f];
+        int32_t* lk = local_of_keypoint + (size_t)f * capacity;
+        for (int i = 0; i < capacity; ++i) lk[i] = -1;
+        const int32_t* m = match.data() + fr.q_off;
+        for (int q = 0; q < fr.n_q; ++q) if (m[q] >= 0) lk[m[q]] = q;  // F.mvpMapPoints[bestIdx] = pMP
+    });
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* h = held + (size_t)f * capacity;
+        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
+        int ne = 0;
+        for (int i = 0; i < frames[f].n_keys; ++i) ne += (h[i] != 0 || lk[i] >= 0) ? 1 : 0;
+        edge_off[f + 1] = edge_off[f] + ne;
+    }
+    const int total_e = edge_off[n_frames];
+    std::vector<double> Xw(3 * (size_t)std::max(total_e, 1));
+    std::vector<tc2li_ba_edge> edges(std::max(total_e, 1));
+    std::vector<int32_t> edge_kp(std::max(total_e, 1));
+    std::vector<uint8_t> out(std::max(total_e, 1), 0);
+    global_pool().parallel_for(n_frames, [&](int f) {
+        const BatchSearchFrame& fr = frames[f];
+        const uint8_t* h = held + (size_t)f * capacity;
+        const float* hx = held_Xw + 3 * (size_t)f * capacity;
+        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
+        for (int c = 0; c < 7; ++c) poses7_out[7 * f + c] = (double)poses7[7 * f + c];
+        int e = edge_off[f];
+        for (int i = 0; i < fr.n_keys; ++i) {
+            if (!(h[i] != 0 || lk[i] >= 0)) continue;
+            const tc2li_keypoint& kp = fr.keys_host[i];
+            tc2li_ba_edge& ed = edges[e];
+            ed.point = e - edge_off[f]; ed.pose = 0;
+            ed.u = kp.x; ed.v = kp.y; ed.u_right = fr.u_right_host[i];
+            ed.inv_sigma2 = o->inv_sigma2[kp.octave];
+            const float* X = lk[i] >= 0 ? local_points[fr.q_off + lk[i]].pos : hx + 3 * (size_t)i;
+            for (int c = 0; c < 3; ++c) Xw[3 * (size_t)e + c] = (double)X[c];
+            edge_kp[e] = i;
+            ++e;
+        }
+    });
+    std::vector<int32_t> inl(n_frames, 0);
+    r = tc2li_pose_optimization_batch(n_frames, poses7_out, edge_off.data(), Xw.data(), edges.data(), cam, out.data(), inl.data(), stream_);
+    if (r < 0) return r;
+    for (int f = 0; f < n_frames; ++f) {
+        uint8_t* ol = outlier + (size_t)f * capacity;
+        memset(ol, 0, capacity);
+        const uint8_t* h = held + (size_t)f * capacity;
+        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
+        int good = 0;
+        for (int e = edge_off[f]; e < edge_off[f + 1]; ++e) {
+            const int i = edge_kp[e];
+            ol[i] = out[e];
+            // mnMatchesInliers: not an outlier and Observations() > 0 (held == 2: a point without observations; local points have them)
+            if (!out[e] && (lk[i] >= 0 || h[i] == 1)) ++good;
+        }
+        n_inliers[f] = good;
+    }
+    return n_frames;
+}

@@ -90,3 +90,78 @@ def test_track_motion_model_argument_errors(pkg, synthetic):
         pkg.capi.track_motion_model_batch(sc["ext"], 2, np.tile(sc["kps"], (2, 1)), np.tile(sc["u_right"], (2, 1)),
                                           pkg.capi.pack_last_frames(sc["lasts"] * 2), np.tile(sc["preds"], (2, 1)), cam5, sc["b"])
     del packed
+
+
+# ---- Tracking::TrackLocalMap --------------------------------------------------------------------------------------------------
+def local_map_scenario(pkg, oracle, synthetic, seeds):
+    sc = scenario(pkg, synthetic, seeds)
+    F = len(seeds)
+    cap = sc["kps"].shape[1]
+    fx, fy, cx, cy = [np.float32(v) for v in (synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY)]
+    sf = sc["ext"].GetScaleFactors()
+    held, held_Xw, pts_all, offs, poses = np.zeros((F, cap), np.uint8), np.zeros((F, cap, 3), np.float32), [], [0], []
+    _, depth, _ = pkg.stereo_match_batch(sc["ext"], F, sc["bf"], sc["b"])
+    for f in range(F):
+        rng = np.random.default_rng(500 + f)
+        n = int(sc["counts"][2 * f])
+        k, d, z = sc["kps"][2 * f, :n], sc["desc"][2 * f, :n], depth[f, :n]
+        ok = z > 0
+        zz = np.where(ok, z, 1).astype(np.float32)
+        X = np.stack([(k["x"] - cx) * zz / fx, (k["y"] - cy) * zz / fy, zz], 1).astype(np.float32)
+        roll = rng.random(n)
+        h = np.where(ok & (roll < 0.3), 1, np.where(ok & (roll < 0.35), 2, 0)).astype(np.uint8)
+        held[f, :n], held_Xw[f, :n] = h, X
+        loc = np.nonzero(ok & (h == 0) & (roll < 0.9))[0]
+        loc = loc[rng.permutation(len(loc))]
+        pts = np.zeros(len(loc), pkg.MAP_POINT_DTYPE)
+        pts["pos"] = X[loc] + rng.normal(0, 0.01, (len(loc), 3)).astype(np.float32)
+        dist = np.linalg.norm(X[loc], axis=1).astype(np.float32)
+        pts["normal"] = X[loc] / dist[:, None]
+        raw = (dist * sf[k["octave"][loc]]).astype(np.float32)
+        pts["max_distance_raw"], pts["max_distance"], pts["min_distance"] = raw, np.float32(1.2) * raw, np.float32(0.8) * (raw / sf[-1])
+        md = d[loc].copy()
+        for i in range(len(loc)):
+            for bit in rng.choice(256, size=int(rng.integers(0, 25)), replace=False):
+                md[i, bit // 8] ^= np.uint8(1 << (bit % 8))
+        pts["descriptor"] = md
+        pts_all.append(pts)
+        offs.append(offs[-1] + len(pts))
+        ang = 0.0015
+        poses.append(np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), 0.01, -0.005, -0.03], np.float32))
+    sc.update(held=held, held_Xw=held_Xw, local=np.concatenate(pts_all), local_off=np.array(offs, np.int32), poses=np.stack(poses))
+    return sc
+
+
+@pytest.mark.parametrize("th,far", [(1.0, False), (6.0, False), (2.0, True)])
+def test_track_local_map_batch(pkg, oracle, synthetic, th, far):
+    sc = local_map_scenario(pkg, oracle, synthetic, [10, 11, 12, 13])
+    F = len(sc["poses"])
+    cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, sc["bf"]]).astype(np.float64)
+    got = pkg.capi.track_local_map_batch(sc["ext"], F, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"], sc["local_off"], cam5,
+                                         th=th, far_points=far, th_far=30.0)
+    scales, inv_sigma2 = sc["ext"].GetScaleFactors(), sc["ext"].GetInverseScaleSigmaSquares()
+    log_scale = float(np.log(np.float32(1.2)))
+    for f in range(F):
+        n = int(sc["counts"][2 * f])
+        pts = sc["local"][sc["local_off"][f]:sc["local_off"][f + 1]]
+        want = oracle.track_local_map(sc["kps"][2 * f, :n], sc["desc"][2 * f, :n], sc["u_right"][f, :n], sc["w"], sc["h"], scales, inv_sigma2, log_scale,
+                                      sc["poses"][f], cam5, sc["held"][f, :n], sc["held_Xw"][f, :n], pts, th=th, far_points=far, th_far=30.0)
+        assert got[3][f] == want[3] and want[3] > 100
+        assert np.array_equal(got[1][f, :n], want[1]) and np.all(got[1][f, n:] == -1)
+        assert np.array_equal(got[2][f, :n], want[2])
+        assert got[4][f] == want[4] and want[4] > 200
+        assert np.allclose(got[0][f], want[0], rtol=1e-4, atol=1e-6)
+        # a keypoint that holds a point with observations keeps it
+        assert np.all(got[1][f, :n][sc["held"][f, :n] == 1] == -1)
+
+
+def test_track_local_map_edge_cases(pkg, oracle, synthetic):
+    sc = local_map_scenario(pkg, oracle, synthetic, [14, 15])
+    cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, sc["bf"]]).astype(np.float64)
+    # no local points at all: the pose is optimised over the held points only
+    got = pkg.capi.track_local_map_batch(sc["ext"], 2, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"][:0],
+                                         np.zeros(3, np.int32), cam5)
+    assert np.all(got[3] == 0) and np.all(got[1] == -1) and np.all(got[4] > 50)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.track_local_map_batch(sc["ext"], 2, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"],
+                                       np.array([1, 5, 9], np.int32), cam5)
