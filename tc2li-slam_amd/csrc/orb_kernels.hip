@@ -347,6 +347,14 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
             sel_hi |= (uint32_t)max(sh_, 0) << (8 * i);
         }
     }
+    // lane 63 of a strip whose right neighbour dword [x + 4, x + 8) crosses the row end (the last lane sits in the next strip):
+    // byte i of that dword is pixel x + 4 + i, mirrored to 2 (w - 1) - (x + 4 + i) when it lies beyond the row; over
+    // (S0 = the loaded dword, S1 = cur) the source index is 4 + i for a real pixel and 2 (w - x) - 6 - i for a mirrored one
+    uint32_t sel_hi63 = 0x07060504u;
+    if (lane == 63 && x + 4 < w && x + 8 > w) {
+        sel_hi63 = 0;
+        for (int i = 0; i < 4; ++i) sel_hi63 |= (uint32_t)(x + 4 + i < w ? 4 + i : 2 * (w - x) - 6 - i) << (8 * i);
+    }
     // rows whose dword loads could leave the buffer (they read up to 3 bytes before and 7 bytes after the row): the first row
     // of the first image and the last row of the last image take the byte-wise path
     const bool tiny = w < 16;
@@ -393,7 +401,10 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
                     if (lane == 0 && x > 0) lo = load4(row + x - 4);
                     cur = __builtin_amdgcn_perm(cur, lo, sel_cur);           // identity except in the last lane
                     hi = __shfl_down(cur, 1, 64);
-                    if (lane == 63 && x + 4 < w) hi = load4(row + x + 4);    // never the last lane of the row
+                    if (lane == 63 && x + 4 < w) {                           // never the last lane of the row
+                        hi = load4(row + x + 4);
+                        if (x + 8 > w) hi = __builtin_amdgcn_perm(hi, cur, sel_hi63);  // the row ends inside that dword: mirror the rest
+                    }
                     if (is_last) hi = __builtin_amdgcn_perm(cur, lo, sel_hi);
                     if (is_first) lo = __builtin_amdgcn_perm(hi, cur, 0x01020304u);  // pixels -4..-1 = pixels 4, 3, 2, 1
                 } else {

@@ -148,3 +148,17 @@ def test_batch_device_resident(pkg, oracle, synthetic):
     t = e.last_timings()
     assert np.all(t >= 0)
     e.close()
+
+
+@pytest.mark.parametrize("width", [253, 256, 257, 258, 259, 260, 261, 263, 511, 512, 513, 515, 770])
+def test_blur_row_ends(pkg, oracle, synthetic, width):
+    """The streaming blur owns 256-column strips: every position of the row end relative to a strip / dword boundary, on the
+    caller's image (any pitch) and on the pyramid levels."""
+    left = synthetic.stereo_pair(3, 1242, 375)[0]
+    img = np.ascontiguousarray(left[60:300, 100:100 + width])  # 240 rows: the smallest level still has a row of FAST cells
+    ext = pkg.OrbExtractor(nfeatures=300, max_width=width, max_height=240, max_images=1)
+    ora = oracle.OrbOracle(nfeatures=300)
+    ext.extract(img)
+    ora.extract(img)
+    for level in range(8):
+        assert np.array_equal(ext.blurred_level(0, level), ora.blurred(level)), (width, level)
