@@ -5,6 +5,7 @@
 // the rotation-histogram filter (:1858-1881, ComputeThreeMaxima :2021-2062) is applied to the result on the host.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -132,7 +133,8 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
     TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
     // candidate lists once, then the rounds over the lists (matcher_kernels.hip); the pool holds 32 candidates per query on average
     constexpr int kCellsPlus1 = 64 * 48 + 1;
-    const int pool_cap = 32 * total_q;
+    const char* per_query = getenv("TC2LI_MATCH_POOL_PER_QUERY");  // tests shrink the pool to reach the overflow path
+    const int pool_cap = std::max(1, per_query ? atoi(per_query) : 32) * total_q;
     TC2LI_HIP_CHECK(w.d_cell_start.ensure((size_t)n_frames * kCellsPlus1)); TC2LI_HIP_CHECK(w.d_key_base.ensure(n_frames));
     TC2LI_HIP_CHECK(w.d_cand_off.ensure(total_q)); TC2LI_HIP_CHECK(w.d_cand_cnt.ensure(total_q)); TC2LI_HIP_CHECK(w.d_pool_top.ensure(2));
     TC2LI_HIP_CHECK(w.d_query_frame.ensure(total_q)); TC2LI_HIP_CHECK(w.d_items.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.d_pool.ensure(pool_cap));

@@ -165,3 +165,12 @@ def test_track_local_map_edge_cases(pkg, oracle, synthetic):
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.track_local_map_batch(sc["ext"], 2, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"],
                                        np.array([1, 5, 9], np.int32), cam5)
+
+
+def test_matcher_pool_overflow_takes_the_one_kernel_path(pkg, oracle, synthetic, monkeypatch):
+    """With a candidate pool of one entry per query the list form overflows and the batch falls back to the one-kernel matcher:
+    the results must not change."""
+    sc = scenario(pkg, synthetic, [20, 21])
+    ref = check(pkg, oracle, synthetic, sc)
+    monkeypatch.setenv("TC2LI_MATCH_POOL_PER_QUERY", "1")
+    assert check(pkg, oracle, synthetic, sc) == ref
