@@ -60,6 +60,7 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     const int L = o->prm.nlevels, M = o->max_images;
     o->geom.assign(L, LevelGeom());
     o->cells.clear();
+    o->max_cell_w = o->max_cell_h = 0;
     std::vector<int> level_cell_begin(L + 1, 0), level_dense_off(L, 0);
     int slab = 0;
     for (int l = 0; l < L; ++l) {
@@ -96,6 +97,7 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
                         set_error("FAST cell window %dx%d exceeds the kernel tile", c.w, c.h);
                         return TC2LI_ERR_INVALID;
                     }
+                    o->max_cell_w = std::max(o->max_cell_w, (int)c.w); o->max_cell_h = std::max(o->max_cell_h, (int)c.h);
                     const int ew = std::max(c.w - 6, 0), eh = std::max(c.h - 6, 0);
                     c.slab_off = slab;
                     c.slab_cap = ((ew + 1) / 2) * ((eh + 1) / 2);  // 3x3 strict maxima: at most one per 2x2 block
@@ -299,7 +301,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     TC2LI_HIP_CHECK(hipEventRecord(o->ev[8], st));
     if (ncells > 0) {
         launch_fast(raw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p,
-                    (size_t)o->slab_per_image, o->d_cell_counts.p, M, st);
+                    (size_t)o->slab_per_image, o->d_cell_counts.p, M, o->max_cell_w, o->max_cell_h, st);
         TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
         launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p, ncells, o->d_slab.p,
                        (size_t)o->slab_per_image, o->h_dense.p, o->d_level_dense_off.p, o->h_level_counts.p, L, M, st);

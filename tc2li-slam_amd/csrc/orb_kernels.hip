@@ -105,24 +105,33 @@ __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
     return best;
 }
 
+// TH x TW: the largest cell window the instantiation holds (LDS is sized by it: the small variant fits 8 workgroups per CU)
+template <int TH, int TW>
 __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
-                                                    int* __restrict__ cell_counts, int ncells) {
+                                                    int* __restrict__ cell_counts, int ncells, int nimg) {
     // The window rows are staged as the aligned dwords they come in: pixel (x, y) of the window is byte
     // y * kTileP + x + mis(y) of the tile, mis(y) = byte offset of row y inside its first dword (rows of the caller's image
     // start at any byte address).
-    constexpr int kTileP = kFastTilePitch + 4;
-    __shared__ uint32_t tile32[kFastTileH * kTileP / 4];
-    __shared__ uint8_t score[kFastTileH * kFastTilePitch];
-    __shared__ uint16_t s_list[kFastTileH * kFastTilePitch];  // window offset | polarity << 14 of the pixels passing the segment test
-    __shared__ uint8_t s_flag[kFastTileH * kFastTilePitch];   // per list entry: bit 0 kept at iniTh, bit 1 kept at minTh
-    constexpr int kMaxKept = ((kFastTilePitch - 6 + 1) / 2) * ((kFastTileH - 6 + 1) / 2);  // >= any cell's slab_cap
+    constexpr int kTileP = TW + 4;
+    __shared__ uint32_t tile32[TH * kTileP / 4];
+    __shared__ uint8_t score[TH * TW];
+    __shared__ uint16_t s_list[TH * TW];  // window offset | polarity << 14 of the pixels passing the segment test
+    __shared__ uint8_t s_flag[TH * TW];   // per list entry: bit 0 kept at iniTh, bit 1 kept at minTh
+    constexpr int kMaxKept = ((TW - 6 + 1) / 2) * ((TH - 6 + 1) / 2);  // >= any cell's slab_cap
     __shared__ uint16_t s_kept[kMaxKept];
     __shared__ int s_cnt_ini, s_nlist, s_nkept;
     const uint8_t* tile = reinterpret_cast<const uint8_t*>(tile32);
 
-    const int tid = threadIdx.x, img = blockIdx.y;
-    const FastCell c = cells[blockIdx.x];
+    // Workgroups go to the 8 XCDs round-robin by their linear index, and each XCD has its own L2.  Neighbouring cell windows
+    // share cache lines (a 42-byte window row is a third of a line, windows overlap by 6 px), so XCD k takes the k-th contiguous
+    // eighth of the (image, cell) list instead of every 8th cell: without this every line was fetched by ~4 XCDs (389 MB of HBM
+    // reads per launch for 96 MB of pixels in the first PMC profile).
+    const int total = ncells * nimg, per_xcd = (total + 7) / 8;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int tid = threadIdx.x, img = logical / ncells, cell = logical - img * ncells;
+    const FastCell c = cells[cell];
     const LevelDesc L = levels.lv[c.level];
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
     const int w = c.w, h = c.h;
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
             if (4 * j - m < w) tile32[i] = *as_global(reinterpret_cast<const uint32_t*>(row - m + 4 * j));
         }
         uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
-        for (int i = tid; i < h * (kFastTilePitch / 4); i += 256) score32[i] = 0;
+        for (int i = tid; i < h * (TW / 4); i += 256) score32[i] = 0;
     }
     if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; s_nkept = 0; }
     __syncthreads();
@@ -157,21 +166,49 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         p[8] = r0[0];  p[9] = r0[-1]; p[10] = r1[-2]; p[11] = r2[-3]; p[12] = r3[-3]; p[13] = r4[-3]; p[14] = r5[-2]; p[15] = r6[-1];
         return r3[0];
     };
-    // Pass 1, every pixel: the cheap segment test at the lower threshold (two 16-bit masks, "9 contiguous" by shifts).
-    // Only a few percent of the pixels pass, but almost every wavefront holds one, so the exact contrast is not computed
-    // here: the survivors are appended to a list (any order: each writes its own score cell).
+    // Pass 0, every pixel: a necessary condition of the segment test on the four compass pixels -- nine contiguous circle pixels
+    // always contain pixel 0 or 8 and pixel 4 or 12, so a brighter (darker) arc needs (p0 | p8) & (p4 | p12) brighter (darker).
+    // Most pixels of an image stop here after five LDS bytes; the others are appended to a list (any order).
     for (int i = tid; i < npix; i += 256) {
         const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
-        int p[16];
-        const int v = circle(ex + 3, ey + 3, p);
-        uint32_t mb = 0, md = 0;
+        const int cx = ex + 3, cy = ey + 3;
+        const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
+        const uint8_t* r3 = tile + cy * kTileP + mis(cy) + cx;
+        const uint8_t* r6 = tile + (cy + 3) * kTileP + mis(cy + 3) + cx;
+        const int v = r3[0], hi_t = v + min_th, lo_t = v - min_th;
+        const int p0 = r6[0], p8 = r0[0], p4 = r3[3], p12 = r3[-3];
+        const bool bright = (p0 > hi_t || p8 > hi_t) && (p4 > hi_t || p12 > hi_t);
+        const bool dark = (p0 < lo_t || p8 < lo_t) && (p4 < lo_t || p12 < lo_t);
+        if (bright || dark) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(cy * TW + cx);
+    }
+    __syncthreads();
+    // Pass 1, the pixels that passed, packed densely over the lanes: the segment test proper (two 16-bit masks, "9 contiguous"
+    // by shifts); the list is compacted in place -- a round reads its 256 entries before any of them is overwritten, and what a
+    // round appends lies below the entries of the later rounds.
+    {
+        const int npre = s_nlist;
+        __syncthreads();
+        if (tid == 0) s_nlist = 0;
+        __syncthreads();
+        for (int base = 0; base < npre; base += 256) {
+            const int k = base + tid;
+            uint32_t entry = 0;
+            if (k < npre) {
+                const int at = s_list[k], cy = at / TW, cx = at - cy * TW;
+                int p[16];
+                const int v = circle(cx, cy, p);
+                uint32_t mb = 0, md = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            mb |= (uint32_t)(p[k] > v + min_th) << k;
-            md |= (uint32_t)(p[k] < v - min_th) << k;
+                for (int j = 0; j < 16; ++j) {
+                    mb |= (uint32_t)(p[j] > v + min_th) << j;
+                    md |= (uint32_t)(p[j] < v - min_th) << j;
+                }
+                const uint32_t pol = (has_arc9(md) ? 1u : 0u) | (has_arc9(mb) ? 2u : 0u);  // bit 0: darker arc, bit 1: brighter arc
+                if (pol) entry = (uint32_t)at | (pol << 14);
+            }
+            __syncthreads();  // every entry of this round has been read
+            if (entry) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)entry;
         }
-        const uint32_t pol = (has_arc9(md) ? 1u : 0u) | (has_arc9(mb) ? 2u : 0u);  // bit 0: darker arc, bit 1: brighter arc
-        if (pol) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(((ey + 3) * kFastTilePitch + (ex + 3)) | (pol << 14));
     }
     __syncthreads();
     // Pass 2, survivors only, packed densely over the lanes: S = the largest arc contrast of the polarity that has an arc
@@ -179,7 +216,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     const int nlist = s_nlist;
     for (int k = tid; k < nlist; k += 256) {
         const uint32_t e = s_list[k];
-        const int at = e & 0x3fff, cy = at / kFastTilePitch, cx = at - cy * kFastTilePitch;
+        const int at = e & 0x3fff, cy = at / TW, cx = at - cy * TW;
         int p[16];
         const int v = circle(cx, cy, p);
         int S = 0;
@@ -195,8 +232,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         const int at = s_list[k] & 0x3fff;
         const uint8_t* sc = score + at;
         const int S = sc[0];
-        const int nb[8] = {sc[-kFastTilePitch - 1], sc[-kFastTilePitch], sc[-kFastTilePitch + 1], sc[-1],
-                           sc[1], sc[kFastTilePitch - 1], sc[kFastTilePitch], sc[kFastTilePitch + 1]};
+        const int nb[8] = {sc[-TW - 1], sc[-TW], sc[-TW + 1], sc[-1],
+                           sc[1], sc[TW - 1], sc[TW], sc[TW + 1]};
         bool keep_ini = S > ini_th, keep_min = true;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -225,13 +262,13 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         const int at = s_kept[k];
         int rank = 0;
         for (int j = 0; j < nk; ++j) rank += (int)s_kept[j] < at ? 1 : 0;
-        const int cy = at / kFastTilePitch, cx = at - cy * kFastTilePitch;
+        const int cy = at / TW, cx = at - cy * TW;
         const uint32_t scv = (uint32_t)score[at] - 1;
         // candidate coordinates in the border-free frame of the level (SF/src/ORBextractor.cc:833-838)
         const uint32_t px = (uint32_t)(c.x0 + cx - kMinBorder), py = (uint32_t)(c.y0 + cy - kMinBorder);
         if (rank < c.slab_cap) out[rank] = (py << 20) | (px << 8) | scv;
     }
-    if (tid == 0) cell_counts[(size_t)img * ncells + blockIdx.x] = s_nkept;
+    if (tid == 0) cell_counts[(size_t)img * ncells + cell] = s_nkept;
 }
 
 // Ordered concatenation of the per-cell candidate lists of one (image, level) into a dense list: cell-major order,
@@ -521,9 +558,14 @@ void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, 
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
-                 size_t slab_img_stride, int* cell_counts, int nimg, hipStream_t st) {
-    hipLaunchKernelGGL(k_fast_cells, dim3(ncells, nimg), dim3(256), 0, st, levels, cells, ini_th, min_th, slab,
-                       slab_img_stride, cell_counts, ncells);
+                 size_t slab_img_stride, int* cell_counts, int nimg, int max_cell_w, int max_cell_h, hipStream_t st) {
+    // cell windows are 35-px cells + 6: 48 x 48 covers every image of at least ~330 px per side; the full-size variant is for tiny levels
+    const int blocks = ((ncells * nimg + 7) / 8) * 8;
+    if (max_cell_w <= 48 && max_cell_h <= 48)
+        hipLaunchKernelGGL((k_fast_cells<48, 48>), dim3(blocks), dim3(256), 0, st, levels, cells, ini_th, min_th, slab, slab_img_stride, cell_counts, ncells, nimg);
+    else
+        hipLaunchKernelGGL((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(blocks), dim3(256), 0, st, levels, cells, ini_th, min_th, slab, slab_img_stride,
+                           cell_counts, ncells, nimg);
 }
 
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
