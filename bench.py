@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
+    ap.add_argument("--split-ba", action="store_true", help="after the timed loop: ONE LV-BA window split over all ranks (landmark partition + "
+                    "RCCL all-reduce of the shared-pose blocks, tc2li_local_lv_bundle_adjustment_sharded) next to the same window on one GPU; "
+                    "reported as \"sharded_window\", not part of `value`")
     ap.add_argument("--stages", default="orb,track,lidar,ba", help="diagnostics: run only these stage threads in the timed loop")
     args = ap.parse_args()
 
@@ -380,6 +383,37 @@ def main():
                          "thread; local mapping (LV-BA, single-threaded g2o semantics) on a 4th" % (done, tcpu, len(ba_futs)),
                "host_cpus": os.cpu_count()}
 
+    # ---- optional: one window over all ranks (BASELINE configs[4]); every rank passes the same window ----
+    sharded_window = None
+    if args.split_ba:
+        w = synthetic.ba_window(4242, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
+        last = len(w["poses"]) - 1
+        win = list(range(last, last - 6, -1))
+        clouds = synthetic.ba_window_clouds(w, win, n_points=3000)
+        e = pkg.pack_ba_edges(w["edges"])
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(pkg.capi.RcclComm.unique_id()), dtype=torch.uint8))
+        if dist is not None:
+            dist.broadcast(uid, 0)
+        comm = pkg.capi.RcclComm(uid.cpu().numpy().tobytes(), rank, world)
+        shard = comm.shard()
+        t_sh, t_one = [], []
+        for _ in range(4):
+            barrier()
+            t_a = time.perf_counter()
+            got = pkg.capi.local_lv_bundle_adjustment_sharded(shard, w["poses"], w["fixed"], w["points"], e, w["cam"], win_pose=win, clouds=clouds,
+                                                              Tcl7=synthetic.TCL7, weight=1.0)
+            t_sh.append(time.perf_counter() - t_a)
+            t_a = time.perf_counter()
+            one = pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], win, clouds, synthetic.TCL7, 1.0)
+            t_one.append(time.perf_counter() - t_a)
+        comm.close()
+        sharded_window = {"ranks": world, "ms_per_window": round(1e3 * min(t_sh[1:]), 3), "single_gpu_ms_per_window": round(1e3 * min(t_one[1:]), 3),
+                          "iterations/trials": [int(got[4].iterations), int(got[4].trials)], "allreduces_per_window": 2 * int(got[4].trials) + int(got[4].iterations) + 3,
+                          "max_pose_difference_vs_single_gpu": float(np.abs(got[0] - one[0]).max()),
+                          "note": "landmarks l % ranks; per LM trial one sum of [S | b_schur | b_p] and one of [scale, chi2, stop]"}
+
     if rank == 0:
         total_frames = F * args.steps * world
         line = {
@@ -404,7 +438,7 @@ def main():
                        "scan_points_raw/preprocessed/downsampled/selected": lid_mean, "map_points": int(lmap.size()),
                        "ba": None if not ba_batch else {"iterations": int(ba_batch.stats[0].iterations), "trials": int(ba_batch.stats[0].trials),
                                                         "planes": int(ba_batch.lstats[0].n_planes), "edges": int(len(ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()}, "stage_wall_ms_per_step": {k: round(1e3 * v, 3) for k, v in wall.items()},
             "orb_stage_ms_last_step": {"pyramid": round(stage_ms[0], 4), "fast": round(stage_ms[1], 4),
                                        "compact": round(stage_ms[2], 4), "blur": round(stage_ms[3], 4),

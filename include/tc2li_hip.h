@@ -25,6 +25,7 @@ typedef enum tc2li_status {
     TC2LI_ERR_NO_DEVICE = -3,  /* no HIP device / HIP runtime failure at init */
     TC2LI_ERR_HIP = -4,        /* a HIP call failed; see tc2li_last_error() */
     TC2LI_ERR_CAPACITY = -5,   /* caller-provided buffer too small */
+    TC2LI_ERR_COMM = -6,       /* the all-reduce of a sharded window failed (or librccl could not be loaded) */
     TC2LI_ERR_EMPTY = -1       /* empty image: the reference returns -1 (SF/src/ORBextractor.cc:1063-1064) */
 } tc2li_status;
 
@@ -486,6 +487,47 @@ typedef struct tc2li_ba_problem {
 } tc2li_ba_problem;
 int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam,
                                         int max_concurrency, int32_t* results);
+
+/* One window split over the GPUs of a node (BASELINE configs[4]): the landmarks -- and with them the stereo / mono
+ * edges, W, Hll and the back-substitution -- are partitioned over the ranks (landmark l belongs to rank l % world); every rank
+ * keeps all keyframe poses.  What the ranks exchange are the shared-pose blocks only: per LM trial ONE sum of
+ * [S | b_schur | b_p] (the rank's part of the reduced camera system: its Hpp, minus its landmarks' W Hll^-1 W^T), and one sum
+ * of [scale, chi2] after the trial update; once per call the max / sum that g2o's initial lambda needs, and at the end one
+ * sum that hands every rank all points, per-edge chi2 and depth flags.  The LM control flow, the LDL^T of the reduced system
+ * and the LiDAR edge are replicated (they are deterministic, so every rank takes the same decisions).
+ * The reference has no counterpart: its g2o solver is single-threaded (SF/Thirdparty/g2o/config.h:4); this entry is the
+ * "RCCL all-reduce of the shared-pose Hessian" BASELINE.json names.  EVERY rank passes the SAME arguments (the whole window)
+ * and every rank receives the whole result.  The sums run in rank order inside the collective, so the result agrees with the
+ * single-GPU entry to rounding, not bit for bit.
+ *
+ * allreduce(ctx, device_buf, count, op, stream): in-place all-reduce of `count` doubles in device memory, enqueued on (or
+ * ordered after the work already on) `stream`; returns 0 on success.  tc2li_rccl_allreduce below is such a function over an
+ * RCCL communicator; a host may pass its own (torch.distributed, MPI). */
+enum { TC2LI_REDUCE_SUM = 0, TC2LI_REDUCE_MAX = 1 };
+typedef int (*tc2li_allreduce_fn)(void* ctx, double* device_buf, size_t count, int op, void* stream);
+typedef struct tc2li_ba_shard {
+    int32_t rank, world;
+    tc2li_allreduce_fn allreduce;
+    void* ctx;
+} tc2li_ba_shard;
+int tc2li_local_lv_bundle_adjustment_sharded(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                             const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                             double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                             uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar,
+                                             tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, void* stream);
+/* The rank's share of a window: landmark_owned[l] = 1 where l % world == rank, edge_owned[e] likewise for the edge's landmark.
+ * Host logic only (no device needed).  Returns the number of owned edges. */
+int tc2li_ba_shard_select(const tc2li_ba_edge* edges, int n_edges, int n_points, int rank, int world, uint8_t* landmark_owned,
+                          uint8_t* edge_owned);
+
+/* RCCL glue for the sharded window (one process per GPU; librccl is loaded on first use, the library has no link-time
+ * dependency on it).  unique_id: 128 bytes made by rank 0 with tc2li_rccl_unique_id and handed to the other ranks by the
+ * launcher (bench.py broadcasts it over torch.distributed).  tc2li_rccl_allreduce has the tc2li_allreduce_fn signature with
+ * ctx = the communicator. */
+int tc2li_rccl_unique_id(void* unique_id_128);
+int tc2li_rccl_comm_create(const void* unique_id_128, int rank, int world, void** comm);
+int tc2li_rccl_comm_destroy(void* comm);
+int tc2li_rccl_allreduce(void* comm, double* device_buf, size_t count, int op, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Visual-inertial local bundle adjustment -- the optimisation of Optimizer::LocalInertialBA (SF/src/Optimizer.cc:1512-2085;

@@ -89,6 +89,13 @@ def lib():
                                                 C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_local_lv_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                    C.c_int, C.c_double] + [C.c_void_p] * 7
+    L.tc2li_local_lv_bundle_adjustment_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                           C.c_int, C.c_double] + [C.c_void_p] * 8
+    L.tc2li_ba_shard_select.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.tc2li_rccl_unique_id.argtypes = [C.c_void_p]
+    L.tc2li_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.tc2li_rccl_comm_destroy.argtypes = [C.c_void_p]
+    L.tc2li_rccl_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     L.tc2li_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.tc2li_track_motion_model_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
@@ -849,6 +856,106 @@ def local_lv_bundle_adjustment(poses7, fixed, points3, edges, cam5, win_pose, cl
                                                   edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
                                                   chi2.ctypes.data, dpos.ctypes.data, C.addressof(stats), C.addressof(w),
                                                   C.addressof(lstats), C.c_void_p(stream)))
+    del keep
+    return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
+
+
+REDUCE_SUM, REDUCE_MAX = 0, 1
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class BaShard(C.Structure):
+    """tc2li_ba_shard"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("allreduce", C.c_void_p), ("ctx", C.c_void_p)]
+
+
+class RcclComm:
+    """An RCCL communicator made by the library (``tc2li_rccl_comm_create``): rank 0 calls ``RcclComm.unique_id()`` and hands
+    the 128 bytes to the other ranks (bench.py broadcasts them over torch.distributed)."""
+
+    def __init__(self, unique_id, rank, world):
+        uid = np.ascontiguousarray(np.frombuffer(bytes(unique_id), np.uint8))
+        assert uid.size == 128
+        self.rank, self.world = rank, world
+        self.h = C.c_void_p()
+        _check(lib().tc2li_rccl_comm_create(uid.ctypes.data, rank, world, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(128, np.uint8)
+        _check(lib().tc2li_rccl_unique_id(uid.ctypes.data))
+        return uid.tobytes()
+
+    def shard(self):
+        """tc2li_ba_shard whose all-reduce is ``tc2li_rccl_allreduce`` on this communicator (no Python on the data path)."""
+        fn = C.cast(lib().tc2li_rccl_allreduce, C.c_void_p).value
+        return BaShard(self.rank, self.world, fn, self.h.value)
+
+    def close(self):
+        if self.h:
+            lib().tc2li_rccl_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def torch_allreduce_shard(rank, world, group=None):
+    """tc2li_ba_shard whose all-reduce is ``torch.distributed.all_reduce`` (any backend that takes device tensors) -> (shard,
+    keep-alive).  The library hands the callback a device pointer; the tensor that aliases it goes through
+    ``__cuda_array_interface__``."""
+    import torch
+    import torch.distributed as dist
+
+    class _Alias:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+    def cb(ctx, ptr, count, op, stream):
+        try:
+            ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()
+            rop = dist.ReduceOp.SUM if op == REDUCE_SUM else dist.ReduceOp.MAX
+            with torch.cuda.stream(ext):
+                t = torch.as_tensor(_Alias(ptr, count), device="cuda")
+                if dist.get_backend(group) == "gloo":  # host collective: stage through host memory, in stream order
+                    h = t.cpu()
+                    dist.all_reduce(h, op=rop, group=group)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, op=rop, group=group)
+            return 0
+        except Exception as e:  # the C side turns a non-zero return into TC2LI_ERR_COMM
+            print("all-reduce callback failed:", repr(e))
+            return 1
+
+    fn = ALLREDUCE_FN(cb)
+    return BaShard(rank, world, C.cast(fn, C.c_void_p).value, None), fn
+
+
+def ba_shard_select(edges, n_points, rank, world):
+    """``tc2li_ba_shard_select`` -> (landmark_owned, edge_owned) masks of the rank."""
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    lo, eo = np.zeros(max(n_points, 1), np.uint8), np.zeros(max(len(edges), 1), np.uint8)
+    _check(lib().tc2li_ba_shard_select(edges.ctypes.data, len(edges), n_points, rank, world, lo.ctypes.data, eo.ctypes.data))
+    return lo[:n_points].astype(bool), eo[:len(edges)].astype(bool)
+
+
+def local_lv_bundle_adjustment_sharded(shard, poses7, fixed, points3, edges, cam5, win_pose=None, clouds=None, Tcl7=None, weight=1.0,
+                                       iterations=10, lambda_init=0.0, stop_flag=None, stream=0):
+    """One window split over the ranks of ``shard`` (landmark partition + all-reduce of the shared-pose blocks); every rank
+    passes the whole window and receives the whole result -> (poses7, points3, chi2, depth_positive, stats, lidar_stats)."""
+    poses = np.ascontiguousarray(poses7, np.float64).copy()
+    pts = np.ascontiguousarray(points3, np.float64).copy()
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, BA_EDGE_DTYPE)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    chi2 = np.zeros(max(len(edges), 1))
+    dpos = np.zeros(max(len(edges), 1), np.uint8)
+    stats, lstats = BaStats(), LidarBaStats()
+    stop_ptr = stop_flag.ctypes.data if stop_flag is not None else None
+    w, keep = (None, None) if win_pose is None else _pack_lidar_window(win_pose, clouds, Tcl7, weight)
+    _check(lib().tc2li_local_lv_bundle_adjustment_sharded(poses.ctypes.data, fixed.ctypes.data, len(poses), pts.ctypes.data, len(pts),
+                                                          edges.ctypes.data, len(edges), cam5.ctypes.data, iterations, lambda_init, stop_ptr,
+                                                          chi2.ctypes.data, dpos.ctypes.data, C.addressof(stats),
+                                                          C.addressof(w) if w is not None else None, C.addressof(lstats),
+                                                          C.addressof(shard), C.c_void_p(stream)))
     del keep
     return poses, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
 

@@ -39,7 +39,8 @@ struct BaProblemDev {
 // chi_out[0] = robust cost; maxdiag_out[0..1] = largest |diagonal| of the landmark / pose blocks when want_maxdiag
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st);
 // S_out [np*np], bs_out [2*np]: b_s followed by b_p
-void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
+// lambda_pose: what the finish kernel adds to the diagonal of S (lambda; 0 on the ranks > 0 of a sharded window, whose parts are summed)
+void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st);
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st);
 

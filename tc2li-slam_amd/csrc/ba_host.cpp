@@ -35,7 +35,7 @@ PoseOptWorkspace& po_ws() { static PoseOptWorkspace w; return w; }
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;
     DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
-        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_part, d_chi_part;
+        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_part, d_chi_part, d_red;
     DevBuf<BaEdge> d_edges;
     DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
     DevBuf<uint8_t> d_depth;
@@ -213,11 +213,16 @@ int tc2li_pose_optimization(double pose7[7], const double* Xw, const tc2li_ba_ed
 // control flow of g2o (optimization_algorithm_levenberg.cpp:61-169) runs here on the host; every numerical step is a
 // kernel of ba_kernels.hip; the reduced camera system (6 x free poses) is factorised on the host (LDL^T), as g2o's
 // LinearSolverEigen does.
-int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
-                                     const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
-                                     double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
-                                     uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
-                                     tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
+//
+// shard != NULL: this rank holds the landmarks (points3, edges) it owns of a window split over several GPUs
+// (tc2li_local_lv_bundle_adjustment_sharded below); used_all marks the poses any rank's edges touch, so that the free-pose
+// numbering is the same everywhere.  The kernels then write their sums to device memory, the ranks' parts are added by the
+// caller's all-reduce, and only the sum comes to the host.
+static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                      const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                      uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
+                      tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, const uint8_t* used_all, void* stream_) {
     if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
         set_error("tc2li_local_bundle_adjustment: invalid argument");
         return TC2LI_ERR_INVALID;
@@ -230,11 +235,14 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     if (lidar_window) {
         if (lidar_window->n_keyframes < 1 || !lidar_window->pose_index) { set_error("lidar window: invalid argument"); return TC2LI_ERR_INVALID; }
         extra_used.assign(n_poses, 0);
+        if (used_all) extra_used.assign(used_all, used_all + n_poses);
         for (int i = 0; i < lidar_window->n_keyframes; ++i) {
             const int k = lidar_window->pose_index[i];
             if (k < 0 || k >= n_poses) { set_error("lidar window: pose_index[%d] = %d out of range", i, k); return TC2LI_ERR_INVALID; }
             extra_used[k] = 1;
         }
+    } else if (used_all) {
+        extra_used.assign(used_all, used_all + n_poses);
     }
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
@@ -262,7 +270,21 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    auto stopped = [&] { return stop_flag && *stop_flag; };
+    // sharded window: the sums land in d_red, are all-reduced there and then copied to where the single-GPU path has them;
+    // the stop flag is agreed on with the [scale, chi2] sum of every trial, so that all ranks leave the loops together
+    const bool sharded = shard != nullptr;
+    bool stop_agreed = false;
+    double* d_red = nullptr;
+    if (sharded) {
+        TC2LI_HIP_CHECK(ws.d_red.ensure((size_t)np * np + 2 * (size_t)np + 27 * (size_t)std::max(n_free, 1) + 8));
+        d_red = ws.d_red.p;
+    }
+    auto reduce = [&](double* dev, size_t count, int op) {
+        const int rc = shard->allreduce(shard->ctx, dev, count, op, st);
+        if (rc != 0) { set_error("sharded bundle adjustment: the all-reduce callback returned %d", rc); return (int)TC2LI_ERR_COMM; }
+        return 0;
+    };
+    auto stopped = [&] { return sharded ? stop_agreed : (stop_flag && *stop_flag); };
     double lambda = -1, ni = 2;
     int n_bad = 0, done = 0, trials_total = 0;
     bool ok = true;
@@ -272,11 +294,24 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     tm[0] = now() - t_begin;
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         double t0 = now();
-        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
+        const bool want_maxdiag = it == 0 && !(lambda_init > 0);
+        ba_launch_linearize(pb, sharded ? d_red : h_scal.p, sharded ? d_red + 1 : h_scal.p + 1, want_maxdiag, st);
         TC2LI_HIP_CHECK(hipGetLastError());
-        const bool need_diag = lidar && it == 0 && !(lambda_init > 0) && n_free > 0;
-        if (need_diag) {
-            TC2LI_HIP_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
+        const bool need_diag = (lidar || sharded) && want_maxdiag && n_free > 0;
+        if (need_diag) TC2LI_HIP_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
+        if (sharded) {
+            if (int rc = reduce(d_red, 1, TC2LI_REDUCE_SUM)) return rc;  // chi2 of all edges
+            if (want_maxdiag) {
+                if (int rc = reduce(d_red + 1, 1, TC2LI_REDUCE_MAX)) return rc;  // largest landmark diagonal of any rank
+                if (need_diag) {  // the pose diagonal is a sum over the ranks' edges before it is a maximum
+                    double* d_hpp_sum = d_red + 8;
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(d_hpp_sum, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    if (int rc = reduce(d_hpp_sum, 27 * (size_t)n_free, TC2LI_REDUCE_SUM)) return rc;
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_hpp_sum, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
+                }
+            }
+            TC2LI_HIP_CHECK(hipMemcpyAsync(h_scal.p, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        } else if (need_diag) {
             TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
         }
         if (lidar) {  // computeActiveErrors + linearizeOplus of the LiDAR edge ride on the same synchronisation
@@ -296,12 +331,12 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
             std::fill(Hl.begin(), Hl.end(), 0.0);
             std::fill(bl_.begin(), bl_.end(), 0.0);
             lidar->add_quadratic_form(pose_var.data(), np, Hl.data(), bl_.data());
-            if (need_diag) {
-                static const int dpos[6] = {0, 6, 11, 15, 18, 20};  // diagonal of the packed upper triangle
-                max_pose_diag = 0;
-                for (int j = 0; j < np; ++j)
-                    max_pose_diag = std::max(max_pose_diag, std::fabs(ws.h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + Hl[(size_t)j * np + j]));
-            }
+        }
+        if (need_diag) {
+            static const int dpos[6] = {0, 6, 11, 15, 18, 20};  // diagonal of the packed upper triangle
+            max_pose_diag = 0;
+            for (int j = 0; j < np; ++j)
+                max_pose_diag = std::max(max_pose_diag, std::fabs(ws.h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + (lidar ? Hl[(size_t)j * np + j] : 0.0)));
         }
         tm[2] += now() - t0;
         double tempChi = currentChi;
@@ -317,9 +352,17 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
         do {
             bool ok2 = true;
             t0 = now();
-            ba_launch_schur(pb, lambda, n_slices, k_per_slice, h_S.p, h_bs.p, st);
+            // a rank's part of the reduced camera system: its edges' Hpp and b_p, minus its landmarks' W Hll^-1 W^T and
+            // W Hll^-1 b_l; lambda goes onto the diagonal once (rank 0)
+            ba_launch_schur(pb, lambda, sharded && shard->rank != 0 ? 0.0 : lambda, n_slices, k_per_slice, sharded ? d_red : h_S.p,
+                            sharded ? d_red + (size_t)np * np : h_bs.p, st);
             TC2LI_HIP_CHECK(hipGetLastError());
             if (np > 0) {
+                if (sharded) {
+                    if (int rc = reduce(d_red, (size_t)np * np + 2 * (size_t)np, TC2LI_REDUCE_SUM)) return rc;
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_S.p, d_red, (size_t)np * np * sizeof(double), hipMemcpyDeviceToHost, st));
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_bs.p, d_red + (size_t)np * np, 2 * (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
+                }
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
                 tm[3] += now() - t0; t0 = now();
                 memcpy(Swork.data(), h_S.p, (size_t)np * np * sizeof(double));
@@ -335,10 +378,17 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
             // pose part of computeScale(): b_p is what the finish kernel left in h_bs[np .. 2 np)
             for (int j = 0; j < np; ++j) scale += x[j] * (lambda * x[j] + h_bs.p[np + j]);
             if (ok2) {
-                ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
+                ba_launch_trial(pb, h_xp.p, lambda, sharded ? d_red : h_scal.p + 3, sharded ? d_red + 1 : h_scal.p + 4, st);
+                if (sharded) {
+                    h_scal.p[7] = stop_flag && *stop_flag ? 1.0 : 0.0;
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(d_red + 2, h_scal.p + 7, sizeof(double), hipMemcpyHostToDevice, st));
+                    if (int rc = reduce(d_red, 3, TC2LI_REDUCE_SUM)) return rc;
+                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_scal.p + 3, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+                }
                 if (lidar) lidar->enqueue_error(pb.poses_trial, st);
                 TC2LI_HIP_CHECK(hipGetLastError());
                 TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                if (sharded) stop_agreed = h_scal.p[5] > 0;
                 tempChi = h_scal.p[4];
                 scale += h_scal.p[3];
                 tm[5] += now() - t0; t0 = now();
@@ -390,6 +440,96 @@ int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n
     for (int k = 0; k < n_poses; ++k) { memcpy(poses7 + 7 * k, poses[k].q, 4 * sizeof(double)); memcpy(poses7 + 7 * k + 4, poses[k].t, 3 * sizeof(double)); }
     if (kTiming) fprintf(stderr, "BA timing ms: setup %.3f linearize %.3f lidar-lin %.3f schur %.3f solve %.3f trial %.3f lidar-err %.3f total %.3f\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], now() - t_begin);
     return done;
+}
+
+int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                     const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                     double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                     uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
+                                     tc2li_lidar_ba_stats* lidar_stats, void* stream) {
+    return lv_ba_impl(poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, iterations, lambda_init, stop_flag, edge_chi2,
+                      edge_depth_positive, stats, lidar_window, lidar_stats, nullptr, nullptr, stream);
+}
+
+int tc2li_ba_shard_select(const tc2li_ba_edge* edges, int n_edges, int n_points, int rank, int world, uint8_t* landmark_owned,
+                          uint8_t* edge_owned) {
+    if (n_edges < 0 || n_points < 0 || world < 1 || rank < 0 || rank >= world || (n_edges > 0 && !edges)) {
+        set_error("tc2li_ba_shard_select: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (landmark_owned) for (int l = 0; l < n_points; ++l) landmark_owned[l] = l % world == rank;
+    int owned = 0;
+    for (int e = 0; e < n_edges; ++e) {
+        if (edges[e].point < 0 || edges[e].point >= n_points) { set_error("edge %d references point %d out of range", e, edges[e].point); return TC2LI_ERR_INVALID; }
+        const bool mine = edges[e].point % world == rank;
+        if (edge_owned) edge_owned[e] = mine;
+        owned += mine;
+    }
+    return owned;
+}
+
+int tc2li_local_lv_bundle_adjustment_sharded(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
+                                             const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
+                                             double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                             uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
+                                             tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, void* stream_) {
+    if (!shard || !shard->allreduce || shard->world < 1 || shard->rank < 0 || shard->rank >= shard->world) {
+        set_error("tc2li_local_lv_bundle_adjustment_sharded: invalid shard description");
+        return TC2LI_ERR_INVALID;
+    }
+    if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
+        set_error("tc2li_local_lv_bundle_adjustment_sharded: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    // Everything that can be rejected is rejected here, on the whole window, which every rank sees: a rank that left on its own
+    // would leave the others waiting in the collective.
+    if (n_points < shard->world) { set_error("a window of %d points cannot be split over %d ranks", n_points, shard->world); return TC2LI_ERR_INVALID; }
+    std::vector<uint8_t> used_all(n_poses, 0), has_edge(n_points, 0);
+    for (int e = 0; e < n_edges; ++e) {
+        if (edges[e].pose < 0 || edges[e].pose >= n_poses || edges[e].point < 0 || edges[e].point >= n_points) {
+            set_error("edge %d references pose %d / point %d out of range", e, edges[e].pose, edges[e].point);
+            return TC2LI_ERR_INVALID;
+        }
+        used_all[edges[e].pose] = 1;
+        has_edge[edges[e].point] = 1;
+    }
+    for (int l = 0; l < n_points; ++l) if (!has_edge[l]) { set_error("point %d has no edge", l); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    const int rank = shard->rank, world = shard->world;
+    // ---- this rank's landmarks and their edges, renumbered ----
+    std::vector<int> local_of(n_points, -1), global_point, global_edge;
+    for (int l = rank; l < n_points; l += world) { local_of[l] = (int)global_point.size(); global_point.push_back(l); }
+    std::vector<double> pts(3 * global_point.size());
+    for (size_t i = 0; i < global_point.size(); ++i) memcpy(&pts[3 * i], points3 + 3 * (size_t)global_point[i], 3 * sizeof(double));
+    std::vector<tc2li_ba_edge> mine;
+    for (int e = 0; e < n_edges; ++e) {
+        if (local_of[edges[e].point] < 0) continue;
+        mine.push_back(edges[e]);
+        mine.back().point = local_of[edges[e].point];
+        global_edge.push_back(e);
+    }
+    std::vector<double> chi2(mine.size());
+    std::vector<uint8_t> depth(mine.size());
+    const int rc = lv_ba_impl(poses7, fixed, n_poses, pts.data(), (int)global_point.size(), mine.data(), (int)mine.size(), cam, iterations,
+                              lambda_init, stop_flag, chi2.data(), depth.data(), stats, lidar_window, lidar_stats, shard, used_all.data(), stream_);
+    if (rc < 0) return rc;
+    // ---- every rank receives the whole result: one sum of [points | chi2 | depth flags], zeros where another rank owns the entry ----
+    const size_t P = n_points, E = n_edges, total = 3 * P + 2 * E;
+    std::vector<double> all(total, 0.0);
+    for (size_t i = 0; i < global_point.size(); ++i) memcpy(&all[3 * (size_t)global_point[i]], &pts[3 * i], 3 * sizeof(double));
+    for (size_t i = 0; i < global_edge.size(); ++i) { all[3 * P + global_edge[i]] = chi2[i]; all[3 * P + E + global_edge[i]] = depth[i]; }
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    TC2LI_HIP_CHECK(ws.d_red.ensure(total));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_red.p, all.data(), total * sizeof(double), hipMemcpyHostToDevice, st));
+    if (shard->allreduce(shard->ctx, ws.d_red.p, total, TC2LI_REDUCE_SUM, st) != 0) { set_error("sharded bundle adjustment: the final all-reduce failed"); return TC2LI_ERR_COMM; }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(all.data(), ws.d_red.p, total * sizeof(double), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(points3, all.data(), 3 * P * sizeof(double));
+    if (edge_chi2) memcpy(edge_chi2, &all[3 * P], E * sizeof(double));
+    if (edge_depth_positive) for (size_t e = 0; e < E; ++e) edge_depth_positive[e] = all[3 * P + E + e] != 0;
+    return rc;
 }
 
 int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
@@ -579,7 +719,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
         double rho = 0;
         int qmax = 0;
         do {
-            ba_launch_schur(pb, lambda, vp.n_slices, vp.k_per_slice, h_S.p, h_bs.p, st);
+            ba_launch_schur(pb, lambda, lambda, vp.n_slices, vp.k_per_slice, h_S.p, h_bs.p, st);
             TC2LI_HIP_CHECK(hipGetLastError());
             TC2LI_HIP_CHECK(hipStreamSynchronize(st));
             // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]

@@ -581,7 +581,7 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
     if (want_maxdiag) hipLaunchKernelGGL(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
-void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
+void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     const int nbp = blocks(pb.n_points);
     hipLaunchKernelGGL(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
     if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
@@ -591,7 +591,7 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, int n_slices, int k_
         else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         const int np = 6 * pb.n_free;
-        hipLaunchKernelGGL(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda, n_slices, S_out, bs_out);
+        hipLaunchKernelGGL(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
     }
 }
 

@@ -51,3 +51,40 @@ def test_single_rank_needs_no_process_group():
     assert dist_util.init("gloo", 0, 1) is None
     assert dist_util.max_elapsed(None, 1.5) == 1.5
     assert dist_util.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def _select_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tc2li_loader
+    pkg = tc2li_loader.load()
+    from tc2li_slam_amd import synthetic
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = synthetic.ba_window(2, n_opt=4, n_fix=4, n_points=301)
+    e = pkg.pack_ba_edges(w["edges"])
+    lo, eo = pkg.capi.ba_shard_select(e, len(w["points"]), rank, world)
+    # what the sharded window's collectives do with the ranks' parts, on host tensors: the ownership masks sum to all-ones
+    t = torch.from_numpy(np.concatenate([lo, eo]).astype(np.float64))
+    dist.all_reduce(t)
+    out[rank] = (int(lo.sum()), int(eo.sum()), bool((t == 1).all()), bool(lo[rank::world].all()), bool(np.array_equal(eo, lo[e["point"]])),
+                 len(w["points"]), len(e))
+    dist.destroy_process_group()
+
+
+def test_landmark_partition_of_a_sharded_window_over_gloo():
+    """tc2li_ba_shard_select (host logic of tc2li_local_lv_bundle_adjustment_sharded): every landmark and edge has exactly one owner."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29950 + os.getpid() % 40
+    mp.spawn(_select_worker, args=(world, port, out), nprocs=world, join=True)
+    n_points, n_edges = out[0][5], out[0][6]
+    assert n_points > 100 and out[0][0] + out[1][0] == n_points and out[0][0] == (n_points + 1) // 2
+    assert out[0][1] + out[1][1] == n_edges
+    assert out[0][2] and out[1][2] and out[0][3] and out[1][3] and out[0][4] and out[1][4]
+    assert out[0][1] > 0 and out[1][1] > 0
