@@ -643,6 +643,44 @@ int tc2li_map_points_refresh(int n_points, const int32_t* obs_offsets, const uin
                              const float* positions, const float* ref_centres, const float* ref_level_scale, float last_level_scale,
                              int32_t* best_obs, float* normals, float* min_distance, float* max_distance, void* stream);
 
+/* Local-map bookkeeping that feeds SearchLocalPoints: Tracking::UpdateLocalKeyFrames + Tracking::UpdateLocalPoints
+ * (SF/src/Tracking.cc:3326-3476, :3296-3323; caller Tracking::UpdateLocalMap :3286) on a device-resident mirror of the graph
+ * pieces they read.  Keyframes and map points are indices into the mirror.  The reference keys its containers by object
+ * address (std::map<KeyFrame*, int> keyframeCounter, std::set<KeyFrame*> children, std::map<KeyFrame*, ...> observations), so
+ * its iteration order is the allocator's; here index order stands in for address order and the caller lists children /
+ * observations in the order its containers iterate.
+ *   covis        mvpOrderedConnectedKeyFrames per keyframe (GetBestCovisibilityKeyFrames(10) takes the first 10)
+ *   children     GetChilds();  parent / prev_kf: GetParent() / mPrevKF, -1 = none
+ *   matches      GetMapPointMatches(): the map point of every keypoint slot, -1 = none
+ *   obs_kf       the keyframes of GetObservations() per map point */
+typedef struct tc2li_map_graph {
+    int32_t n_keyframes, n_points;
+    const uint8_t* kf_bad;                               /* [n_keyframes] KeyFrame::isBad() */
+    const int32_t *covis_offsets, *covis;                /* CSR over keyframes */
+    const int32_t *child_offsets, *children;
+    const int32_t *parent, *prev_kf;                     /* [n_keyframes] */
+    const int32_t *match_offsets, *matches;
+    const uint8_t* point_bad;                            /* [n_points] MapPoint::isBad() */
+    const int32_t *obs_offsets, *obs_kf;                 /* CSR over map points */
+} tc2li_map_graph;
+typedef struct tc2li_local_map tc2li_local_map;
+int tc2li_local_map_create(tc2li_local_map** out);
+void tc2li_local_map_destroy(tc2li_local_map* map);
+/* Uploads (replaces) the mirror; call when keyframes / points / observations changed.  The arrays are copied. */
+int tc2li_local_map_set_graph(tc2li_local_map* map, const tc2li_map_graph* graph, void* stream);
+/* One UpdateLocalMap.  frame_points = mCurrentFrame.mvpMapPoints (mLastFrame's once the IMU is initialised, :3350), -1 = none;
+ * temporal_last_kf = mCurrentFrame.mpLastKeyFrame for IMU_STEREO_LIDAR (the temporal block :3453-3469), -1 otherwise.
+ * Out: mvpLocalKeyFrames in the reference's order (voted keyframes by index, then the neighbour / child / parent extensions with
+ * the reference's early exits, then up to 20 temporal keyframes), reference_kf = pKFmax (-1: none), mvpLocalMapPoints in the
+ * reference's order (local keyframes walked backwards, slots forwards, first occurrence kept, bad points skipped), and
+ * frame_point_cleared[i] = 1 where the reference sets the frame's point to NULL because it is bad.  The local point list also
+ * stays on the device (tc2li_local_map_device_points).  Returns the number of local points; TC2LI_ERR_CAPACITY when a list does not fit. */
+int tc2li_local_map_update(tc2li_local_map* map, const int32_t* frame_points, int n_frame_points, int temporal_last_kf,
+                           int32_t* local_keyframes, int keyframe_capacity, int32_t* n_local_keyframes, int32_t* reference_kf,
+                           int32_t* local_points, int point_capacity, int32_t* n_local_points, uint8_t* frame_point_cleared,
+                           void* stream);
+const int32_t* tc2li_local_map_device_points(const tc2li_local_map* map);
+
 /* The LiDAR term alone at the poses poses7 (Tcw of the window keyframes are rows lidar->pose_index): planes from the
  * window, then *residual = LidarCovisRes::ComputeError() and JacT [6W] / Hessian [(6W)^2, row-major] =
  * LidarCovisRes::ComputeJandHSE3 (SF/src/LidarRes.cc:136-186, with respect to the camera se3 increments).  JacT and

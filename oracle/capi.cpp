@@ -7,6 +7,7 @@
 #include "stereo.hpp"
 #include "lidar.hpp"
 #include "eskf.hpp"
+#include "localmap.hpp"
 #include "mappoint.hpp"
 #include "mapping.hpp"
 #include "ba.hpp"
@@ -1112,3 +1113,22 @@ void oracle_imu_pose_update(double* kf33, int* its, const double* calib24, const
 }
 
 }  // extern "C"
+
+// ---- UpdateLocalKeyFrames / UpdateLocalPoints (section 8f item 3) ----------------------------------------------------------
+extern "C" int oracle_update_local_map(int n_keyframes, int n_points, const uint8_t* kf_bad, const int32_t* covis_off, const int32_t* covis,
+                                       const int32_t* child_off, const int32_t* children, const int32_t* parent, const int32_t* prev_kf,
+                                       const int32_t* match_off, const int32_t* matches, const uint8_t* point_bad, const int32_t* obs_off,
+                                       const int32_t* obs_kf, const int32_t* frame_points, int n_frame_points, int temporal_last_kf,
+                                       int32_t* local_kfs, int32_t* n_local_kfs, int32_t* reference_kf, int32_t* local_points,
+                                       int32_t* n_local_points, uint8_t* frame_cleared) {
+    oracle::MapGraph g;
+    g.n_keyframes = n_keyframes; g.n_points = n_points; g.kf_bad = kf_bad; g.covis_off = covis_off; g.covis = covis; g.child_off = child_off;
+    g.children = children; g.parent = parent; g.prev_kf = prev_kf; g.match_off = match_off; g.matches = matches; g.point_bad = point_bad;
+    g.obs_off = obs_off; g.obs_kf = obs_kf;
+    const oracle::LocalMap m = oracle::UpdateLocalMap(g, frame_points, n_frame_points, temporal_last_kf);
+    for (size_t i = 0; i < m.keyframes.size(); ++i) local_kfs[i] = m.keyframes[i];
+    for (size_t i = 0; i < m.points.size(); ++i) local_points[i] = m.points[i];
+    for (int i = 0; i < n_frame_points; ++i) frame_cleared[i] = m.frame_cleared[i];
+    *n_local_kfs = (int)m.keyframes.size(); *n_local_points = (int)m.points.size(); *reference_kf = m.reference_kf;
+    return 0;
+}

@@ -844,3 +844,24 @@ def imu_pose_update(kf33, its, calib24, u6):
     f.argtypes = [C.c_void_p] * 4
     f(kf.ctypes.data, C.addressof(it), _f64(calib24).ctypes.data, _f64(u6).ctypes.data)
     return kf, it.value
+
+
+# ---- local-map bookkeeping (UpdateLocalKeyFrames / UpdateLocalPoints) -----------------------------------------------------------
+def update_local_map(graph, frame_points, temporal_last_kf=-1):
+    """graph: dict of flat arrays (kf_bad, covis_off, covis, child_off, children, parent, prev_kf, match_off, matches, point_bad,
+    obs_off, obs_kf) -> (local keyframes, reference keyframe, local points, frame points cleared)."""
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    g = {k: (u8(v) if k in ("kf_bad", "point_bad") else i32(v)) for k, v in graph.items()}
+    fp = i32(frame_points)
+    nk, npnt = len(g["kf_bad"]), len(g["point_bad"])
+    kfs, pts = np.zeros(nk + 1, np.int32), np.zeros(npnt + 1, np.int32)
+    cleared = np.zeros(max(len(fp), 1), np.uint8)
+    n_k, n_p, ref = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
+    f = lib().oracle_update_local_map
+    f.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_int] + [C.c_void_p] * 6
+    f(nk, npnt, g["kf_bad"].ctypes.data, g["covis_off"].ctypes.data, g["covis"].ctypes.data, g["child_off"].ctypes.data, g["children"].ctypes.data,
+      g["parent"].ctypes.data, g["prev_kf"].ctypes.data, g["match_off"].ctypes.data, g["matches"].ctypes.data, g["point_bad"].ctypes.data,
+      g["obs_off"].ctypes.data, g["obs_kf"].ctypes.data, fp.ctypes.data, len(fp), int(temporal_last_kf), kfs.ctypes.data, C.addressof(n_k),
+      C.addressof(ref), pts.ctypes.data, C.addressof(n_p), cleared.ctypes.data)
+    return kfs[:n_k.value].copy(), ref.value, pts[:n_p.value].copy(), cleared[:len(fp)].astype(bool)

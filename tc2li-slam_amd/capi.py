@@ -96,6 +96,14 @@ def lib():
     L.tc2li_rccl_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.tc2li_rccl_comm_destroy.argtypes = [C.c_void_p]
     L.tc2li_rccl_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.tc2li_local_map_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.tc2li_local_map_destroy.argtypes = [C.c_void_p]
+    L.tc2li_local_map_destroy.restype = None
+    L.tc2li_local_map_set_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_local_map_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    L.tc2li_local_map_device_points.argtypes = [C.c_void_p]
+    L.tc2li_local_map_device_points.restype = C.c_void_p
     L.tc2li_lidar_window_evaluate.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.tc2li_track_motion_model_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
@@ -1112,3 +1120,53 @@ def project_local_map(pose7, cam4, bf, scales, log_scale, cols, rows, points, th
     _check(lib().tc2li_project_local_map(pose7.ctypes.data, cam4.ctypes.data, bf, scales.ctypes.data, len(scales), log_scale, cols, rows,
                                          len(points), points.ctypes.data, th, int(far_points), th_far, cos_limit, out.ctypes.data))
     return out[:len(points)]
+
+
+# ---- local-map bookkeeping (Tracking::UpdateLocalKeyFrames / UpdateLocalPoints) ---------------------------------------------
+class MapGraph(C.Structure):
+    """tc2li_map_graph"""
+    _fields_ = [("n_keyframes", C.c_int32), ("n_points", C.c_int32), ("kf_bad", C.c_void_p), ("covis_offsets", C.c_void_p), ("covis", C.c_void_p),
+                ("child_offsets", C.c_void_p), ("children", C.c_void_p), ("parent", C.c_void_p), ("prev_kf", C.c_void_p),
+                ("match_offsets", C.c_void_p), ("matches", C.c_void_p), ("point_bad", C.c_void_p), ("obs_offsets", C.c_void_p), ("obs_kf", C.c_void_p)]
+
+
+class LocalMap:
+    """Device-resident mirror of the keyframe graph (``tc2li_local_map``) and ``Tracking::UpdateLocalMap`` on it.  graph: dict of flat
+    arrays kf_bad, covis_off, covis, child_off, children, parent, prev_kf, match_off, matches, point_bad, obs_off, obs_kf."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib().tc2li_local_map_create(C.byref(self.h)))
+        self.n_keyframes = self.n_points = 0
+
+    def set_graph(self, graph, stream=0):
+        g = {k: np.ascontiguousarray(v, np.uint8 if k in ("kf_bad", "point_bad") else np.int32) for k, v in graph.items()}
+        ptr = lambda k: g[k].ctypes.data if g[k].size else None
+        mg = MapGraph(len(g["kf_bad"]), len(g["point_bad"]), ptr("kf_bad"), ptr("covis_off"), ptr("covis"), ptr("child_off"), ptr("children"),
+                      ptr("parent"), ptr("prev_kf"), ptr("match_off"), ptr("matches"), ptr("point_bad"), ptr("obs_off"), ptr("obs_kf"))
+        _check(lib().tc2li_local_map_set_graph(self.h, C.addressof(mg), C.c_void_p(stream)))
+        self.n_keyframes, self.n_points = mg.n_keyframes, mg.n_points
+
+    def update(self, frame_points, temporal_last_kf=-1, stream=0, keyframe_capacity=None, point_capacity=None):
+        """-> (local keyframes, reference keyframe, local points, frame points cleared)"""
+        fp = np.ascontiguousarray(frame_points, np.int32)
+        kc = self.n_keyframes if keyframe_capacity is None else keyframe_capacity
+        pc = self.n_points if point_capacity is None else point_capacity
+        kfs, pts = np.zeros(max(kc, 1), np.int32), np.zeros(max(pc, 1), np.int32)
+        cleared = np.zeros(max(len(fp), 1), np.uint8)
+        n_k, n_p, ref = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
+        _check(lib().tc2li_local_map_update(self.h, fp.ctypes.data if len(fp) else None, len(fp), int(temporal_last_kf), kfs.ctypes.data, kc,
+                                            C.addressof(n_k), C.addressof(ref), pts.ctypes.data, pc, C.addressof(n_p),
+                                            cleared.ctypes.data if len(fp) else None, C.c_void_p(stream)))
+        return kfs[:n_k.value].copy(), ref.value, pts[:n_p.value].copy(), cleared[:len(fp)].astype(bool)
+
+    def close(self):
+        if self.h:
+            lib().tc2li_local_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -835,11 +835,12 @@ struct LockstepContext {
     PinnedBuf<int> h_lists;
     hipStream_t st = nullptr;
 };
-LockstepContext& lockstep_ctx() { static LockstepContext c; return c; }
+constexpr int kMaxLockstepGroups = 4;
+LockstepContext& lockstep_ctx(int group) { static LockstepContext c[kMaxLockstepGroups]; return c[group]; }
 
 // returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
-bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results) {
-    LockstepContext& C = lockstep_ctx();
+bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
+    LockstepContext& C = lockstep_ctx(group);
     std::lock_guard<std::mutex> lk(C.mu);
     for (int i = 0; i < n; ++i)
         if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
@@ -1153,10 +1154,30 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
     static WorkerPool* pool = new WorkerPool(16);  // persistent: its threads keep their streams and workspaces
     static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;  // A/B switch for measurements
-    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep && ba_batch_lockstep(problems, n_problems, cam, *pool, results)) {
-        int ok_ = 0;
-        for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
-        return ok_;
+    // The lock-step loop is a chain of dependent launches with a host step after every phase: while the host works the stream is
+    // empty.  Several groups of windows, each a lock-step batch of its own on its own stream and host thread, fill each other's gaps.
+    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 2));
+    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
+        const int groups = std::min(kGroups, n_problems / 2);
+        bool done = false;
+        if (groups <= 1) {
+            done = ba_batch_lockstep(problems, n_problems, cam, *pool, results);
+        } else {
+            static WorkerPool* group_pools[kMaxLockstepGroups] = {nullptr, nullptr, nullptr, nullptr};
+            static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
+            for (int g = 0; g < groups; ++g) if (!group_pools[g]) group_pools[g] = new WorkerPool(8);
+            std::atomic<int> fell_back{0};
+            top->parallel_for(groups, [&](int g) {
+                const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
+                if (!ba_batch_lockstep(problems + b, e - b, cam, *group_pools[g], results + b, g)) fell_back++;
+            });
+            done = fell_back.load() == 0;
+        }
+        if (done) {
+            int ok_ = 0;
+            for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
+            return ok_;
+        }
     }
     struct ThreadStream {
         hipStream_t s = nullptr;
