@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=32, help="frames (stereo pair + scan) per step per GPU")
+    ap.add_argument("--frames", type=int, default=64, help="frames (stereo pair + scan) per step per GPU")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames rendered (tiled to --frames)")
     ap.add_argument("--kf-interval", type=int, default=4, help="a keyframe (one local BA window) every k-th frame")
     ap.add_argument("--ba-concurrency", type=int, default=8, help="local-BA windows in flight (streams) per GPU")

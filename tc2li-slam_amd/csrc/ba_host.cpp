@@ -33,11 +33,13 @@ struct PoseOptWorkspace {
 PoseOptWorkspace& po_ws() { static PoseOptWorkspace w; return w; }
 
 struct BaWorkspace {
-    DevBuf<Se3> d_poses, d_poses_trial;
-    DevBuf<double> d_points, d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
-        d_coef_e, d_coef, d_AT, d_BT, d_Spart, d_scale_part, d_chi_part, d_red;
-    DevBuf<BaEdge> d_edges;
-    DevBuf<int> d_pose_var, d_pt_off, d_pt_edges, d_pv_off, d_pv_edges;
+    DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
+    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
+        d_coef_e, d_coef, d_AT, d_Spart, d_scale_part, d_chi_part, d_red;
+    // the window as the caller hands it over -- poses, points, edges and the index arrays -- goes up in ONE copy: a stream operation
+    // costs about as much as one of the loop's kernels, and a batch has one such set per window
+    DevBuf<uint8_t> d_in;
+    PinnedBuf<uint8_t> h_in;
     DevBuf<uint8_t> d_depth;
     PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp;
     DevBuf<ImuPose> d_iposes, d_iposes_trial;
@@ -98,45 +100,52 @@ struct VisualProblem {
     k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
 
     // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
-    auto &d_poses = ws.d_poses, &d_poses_trial = ws.d_poses_trial;
-    auto &d_points = ws.d_points, &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
+    auto& d_poses_trial = ws.d_poses_trial;
+    auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
          &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
-         &d_BT = ws.d_BT, &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
-    auto& d_edges = ws.d_edges;
-    auto &d_pose_var = ws.d_pose_var, &d_pt_off = ws.d_pt_off, &d_pt_edges = ws.d_pt_edges, &d_pv_off = ws.d_pv_off, &d_pv_edges = ws.d_pv_edges;
+         &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
     auto& d_depth = ws.d_depth;
     auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
     const size_t E = n_edges, P = n_points;
     const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
-    TC2LI_HIP_CHECK(d_poses.ensure(n_poses)); TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
-    TC2LI_HIP_CHECK(d_points.ensure(3 * P)); TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
+    TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
+    TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
     TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(9 * E)); TC2LI_HIP_CHECK(d_cp.ensure(27 * E));
     TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
     TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
     TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
     TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_AT.ensure(at_elems)); TC2LI_HIP_CHECK(d_BT.ensure(at_elems));
+    TC2LI_HIP_CHECK(d_AT.ensure(2 * at_elems));  // A^T and B^T operands back to back: one fill
     TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 4 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
-    TC2LI_HIP_CHECK(d_edges.ensure(E)); TC2LI_HIP_CHECK(d_pose_var.ensure(n_poses)); TC2LI_HIP_CHECK(d_pt_off.ensure(P + 1));
-    TC2LI_HIP_CHECK(d_pt_edges.ensure(E)); TC2LI_HIP_CHECK(d_pv_off.ensure(n_free + 1)); TC2LI_HIP_CHECK(d_pv_edges.ensure(pv_edges.size()));
     TC2LI_HIP_CHECK(d_depth.ensure(E));
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
+    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges], every part 16-byte aligned ----
+    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
+                 o_pose_var = align16(o_edges + E * sizeof(BaEdge)), o_pt_off = align16(o_pose_var + n_poses * sizeof(int)),
+                 o_pt_edges = align16(o_pt_off + (P + 1) * sizeof(int)), o_pv_off = align16(o_pt_edges + E * sizeof(int)),
+                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), in_bytes = align16(o_pv_edges + pv_edges.size() * sizeof(int));
+    TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
+    uint8_t* const h = ws.h_in.p;
     if (poses7) {
         poses.resize(n_poses);
         for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
-        TC2LI_HIP_CHECK(hipMemcpyAsync(d_poses.p, poses.data(), n_poses * sizeof(Se3), hipMemcpyHostToDevice, st));
+        memcpy(h + o_poses, poses.data(), n_poses * sizeof(Se3));
     }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_points.p, points3, 3 * P * sizeof(double), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_edges.p, edges, E * sizeof(BaEdge), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_var.p, pose_var.data(), n_poses * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_off.p, pt_off.data(), (P + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pt_edges.p, pt_edges.data(), E * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_off.p, pv_off.data(), (n_free + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pv_edges.p, pv_edges.data(), pv_edges.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, at_elems * sizeof(double), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_BT.p, 0, at_elems * sizeof(double), st));
+    memcpy(h + o_points, points3, 3 * P * sizeof(double));
+    memcpy(h + o_edges, edges, E * sizeof(BaEdge));
+    memcpy(h + o_pose_var, pose_var.data(), n_poses * sizeof(int));
+    memcpy(h + o_pt_off, pt_off.data(), (P + 1) * sizeof(int));
+    memcpy(h + o_pt_edges, pt_edges.data(), E * sizeof(int));
+    memcpy(h + o_pv_off, pv_off.data(), (n_free + 1) * sizeof(int));
+    memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));
+    // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
+    const size_t first = poses7 ? 0 : o_points;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_in.p + first, h + first, in_bytes - first, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, 2 * at_elems * sizeof(double), st));
+    uint8_t* const d = ws.d_in.p;
 
     pb = BaProblemDev{};
     pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
@@ -144,11 +153,12 @@ struct VisualProblem {
     const float dm = sqrtf(5.991f), ds = sqrtf(7.815f);  // thHuberMono / thHuberStereo are floats (OptimizerWithLidar.cc:219-220)
     pb.delta_mono = dm; pb.delta_stereo = ds;
     pb.dsqr_mono = (float)((double)dm * (double)dm); pb.dsqr_stereo = (float)((double)ds * (double)ds);
-    pb.poses = d_poses.p; pb.poses_trial = d_poses_trial.p; pb.points = d_points.p; pb.points_trial = d_points_trial.p;
-    pb.edges = d_edges.p; pb.pose_var = d_pose_var.p; pb.pt_off = d_pt_off.p; pb.pt_edges = d_pt_edges.p; pb.pv_off = d_pv_off.p; pb.pv_edges = d_pv_edges.p;
+    pb.poses = (Se3*)(d + o_poses); pb.poses_trial = d_poses_trial.p; pb.points = (double*)(d + o_points); pb.points_trial = d_points_trial.p;
+    pb.edges = (const BaEdge*)(d + o_edges); pb.pose_var = (const int*)(d + o_pose_var); pb.pt_off = (const int*)(d + o_pt_off);
+    pb.pt_edges = (const int*)(d + o_pt_edges); pb.pv_off = (const int*)(d + o_pv_off); pb.pv_edges = (const int*)(d + o_pv_edges);
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
-    pb.AT = d_AT.p; pb.BT = d_BT.p; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
+    pb.AT = d_AT.p; pb.BT = d_AT.p + at_elems; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
         return TC2LI_OK;
     }
@@ -829,10 +839,9 @@ struct LockstepWindow {
 struct LockstepContext {
     std::mutex mu;
     std::vector<std::unique_ptr<BaWorkspace>> ws;
-    DevBuf<BaBatchSlot> d_slots;
-    DevBuf<int> d_lists;
-    PinnedBuf<BaBatchSlot> h_slots;
-    PinnedBuf<int> h_lists;
+    // slot table and, behind it, the two index lists of a phase: one host buffer, one device buffer, one copy per phase
+    DevBuf<uint8_t> d_table;
+    PinnedBuf<uint8_t> h_table;
     hipStream_t st = nullptr;
 };
 constexpr int kMaxLockstepGroups = 4;
@@ -853,8 +862,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    if (C.d_slots.ensure(n) != hipSuccess || C.d_lists.ensure(4 * (size_t)n) != hipSuccess || C.h_slots.ensure(n) != hipSuccess ||
-        C.h_lists.ensure(4 * (size_t)n) != hipSuccess) return false;
+    const size_t table_bytes = n * sizeof(BaBatchSlot) + 2 * (size_t)n * sizeof(int);
+    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(table_bytes) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
+    int* const h_lists = (int*)(C.h_table.p + n * sizeof(BaBatchSlot));
+    const BaBatchSlot* const d_slots = (const BaBatchSlot*)C.d_table.p;
+    const int* const d_lists = (const int*)(C.d_table.p + n * sizeof(BaBatchSlot));
     std::vector<LockstepWindow> W(n);
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -922,7 +935,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     }
     auto fill_slot = [&](int i) {
         LockstepWindow& w = W[i];
-        BaBatchSlot& s = C.h_slots.p[i];
+        BaBatchSlot& s = h_slots[i];
         s.pb = w.vp.pb;
         s.lambda = w.lambda;
         s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.want_maxdiag = w.want_maxdiag; s.has_lidar = w.lidar != nullptr;
@@ -940,10 +953,9 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     };
     bool failed = false;
     auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_lists[0..), list b at d_lists[n..)
-        for (size_t k = 0; k < a.size(); ++k) C.h_lists.p[k] = a[k];
-        for (size_t k = 0; k < b.size(); ++k) C.h_lists.p[n + k] = b[k];
-        if (hipMemcpyAsync(C.d_slots.p, C.h_slots.p, n * sizeof(BaBatchSlot), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(C.d_lists.p, C.h_lists.p, 2 * (size_t)n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = a[k];
+        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = b[k];
+        if (hipMemcpyAsync(C.d_table.p, C.h_table.p, table_bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
     };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
@@ -963,15 +975,16 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             fill_slot(i);
         }
         upload(active, with_lidar);
-        ba_batch_launch_linearize(C.d_slots.p, C.d_lists.p, (int)active.size(), X, any_maxdiag, st);
+        ba_batch_launch_linearize(d_slots, d_lists, (int)active.size(), X, any_maxdiag, st);
         for (int i : active) {
             LockstepWindow& w = W[i];
             if (!w.need_diag) continue;
             if (w.ws->h_Hpp.ensure(27 * (size_t)w.vp.n_free) != hipSuccess ||
                 hipMemcpyAsync(w.ws->h_Hpp.p, w.ws->d_Hpp.p, 27 * (size_t)w.vp.n_free * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
         }
-        balm_batch_launch_residual(C.d_slots.p, C.d_lists.p + n, (int)with_lidar.size(), false, st);
-        balm_batch_launch_hessian(C.d_slots.p, C.d_lists.p + n, (int)with_lidar.size(), X, st);
+        // (running the LiDAR kernels on a second stream beside the visual ones was measured: no gain, the chain is not the limit there)
+        balm_batch_launch_residual(d_slots, d_lists + n, (int)with_lidar.size(), false, st);
+        balm_batch_launch_hessian(d_slots, d_lists + n, (int)with_lidar.size(), X, st);
         sync();
         if (failed) break;
         tm[1] += now() - t0; t0 = now();
@@ -1014,7 +1027,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             t0 = now();
             for (int i : trial) fill_slot(i);
             upload(trial, {});
-            ba_batch_launch_schur(C.d_slots.p, C.d_lists.p, (int)trial.size(), X, st);
+            ba_batch_launch_schur(d_slots, d_lists, (int)trial.size(), X, st);
             sync();
             if (failed) break;
             tm[3] += now() - t0; t0 = now();
@@ -1041,8 +1054,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
                 upload(step, step_lidar);  // slots unchanged since phase B
-                ba_batch_launch_trial(C.d_slots.p, C.d_lists.p, (int)step.size(), X, st);
-                balm_batch_launch_residual(C.d_slots.p, C.d_lists.p + n, (int)step_lidar.size(), true, st);
+                ba_batch_launch_trial(d_slots, d_lists, (int)step.size(), X, st);
+                balm_batch_launch_residual(d_slots, d_lists + n, (int)step_lidar.size(), true, st);
                 sync();
                 if (failed) break;
             }
@@ -1095,7 +1108,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
     if (!failed && !all.empty()) {
         upload(all, {});
-        ba_batch_launch_depth(C.d_slots.p, C.d_lists.p, (int)all.size(), X, st);
+        ba_batch_launch_depth(d_slots, d_lists, (int)all.size(), X, st);
         for (int i : all) {  // device -> pinned staging (asynchronous), then the copies into the caller's arrays run in parallel
             LockstepWindow& w = W[i];
             const tc2li_ba_problem& p = *w.p;
