@@ -276,6 +276,7 @@ __device__ __forceinline__ void d_ba_schur_gemm(const int bx, const int by, cons
                                                 int k_total, int k_per_slice, double* __restrict__ S_part) {
     const int lane = threadIdx.x, tiles = np_pad / 16;
     const int ti = bx / tiles, tj = bx % tiles, slice = by;
+    if (ti < tj) return;  // the LDL^T reads the lower triangle only (ldlt_solve_small)
     const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
     v4d acc = {0, 0, 0, 0};
     const int i = lane % 16, kk = lane / 16;
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__
 
 // The same product with one wavefront per (strip of 32 rows, k-slice): two row tiles times all column tiles (at most CT) in
 // registers, so a k-slice of W D^-1 is read once and the slice of W once per strip instead of once per 16x16 tile.  Every tile
-// still accumulates its k-steps in ascending order: the partial sums are bit-identical to k_ba_schur_gemm's.
+// still accumulates its k-steps in ascending order: the partial sums are bit-identical to k_ba_schur_gemm's.  Only the tiles on
+// and below the diagonal are formed (column tile <= row tile): the solver reads nothing else, and it is 15 of 25 tiles at 12 poses.
 template <int CT>
 __device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int slice, const double* __restrict__ AT, const double* __restrict__ BT,
                                                       int np_pad, int k_total, int k_per_slice, double* __restrict__ S_part) {
@@ -336,10 +338,11 @@ __device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int
         const double a0 = in ? pa0[ro] : 0.0, a1 = (in && row1) ? pa1[ro] : 0.0;
         double b[CT];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) b[t] = (in && t < tiles) ? pbase[ro + 16 * t] : 0.0;
+        for (int t = 0; t < CT; ++t) b[t] = (in && t < tiles && t <= t0 + 1) ? pbase[ro + 16 * t] : 0.0;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[t], acc[0][t], 0, 0, 0);
+            if (t > t0 + 1) break;  // uniform over the wavefront
+            if (t <= t0) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[t], acc[0][t], 0, 0, 0);
             acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[t], acc[1][t], 0, 0, 0);
         }
     }
@@ -349,7 +352,7 @@ __device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int
         if (a == 1 && !row1) break;
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            if (t >= tiles) break;
+            if (t >= tiles || t > t0 + a) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(size_t)(16 * (t0 + a) + kk + 4 * r) * np_pad + 16 * t + i] = acc[a][t][r];
         }
@@ -373,19 +376,23 @@ __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const 
             s = pb.Hpp[27 * (size_t)(r / 6) + packed];
             if (r == c) s += lambda;
         }
-        double sub = 0;
-        const double* sp = pb.S_part + (size_t)r * pb.np_pad + c;
-        const size_t step = (size_t)pb.np_pad * pb.np_pad;
-        int k = 0;
-        for (; k + 8 <= n_slices; k += 8) {  // eight partials in flight, added in slice order
-            double v[8];
+        if (r / 16 < c / 16) {  // tiles above the diagonal are not formed (and not read by the solver)
+            S_out[idx] = 0;
+        } else {
+            double sub = 0;
+            const double* sp = pb.S_part + (size_t)r * pb.np_pad + c;
+            const size_t step = (size_t)pb.np_pad * pb.np_pad;
+            int k = 0;
+            for (; k + 8 <= n_slices; k += 8) {  // eight partials in flight, added in slice order
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(k + u) * step];
+                for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(k + u) * step];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) sub += v[u];
+                for (int u = 0; u < 8; ++u) sub += v[u];
+            }
+            for (; k < n_slices; ++k) sub += sp[(size_t)k * step];
+            S_out[idx] = s - sub;
         }
-        for (; k < n_slices; ++k) sub += sp[(size_t)k * step];
-        S_out[idx] = s - sub;
     }
     if (idx < np) {
         const double bp = pb.Hpp[27 * (size_t)(idx / 6) + 21 + idx % 6];
