@@ -137,13 +137,27 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_bbox(const PointXYZINormal*
     if (threadIdx.x < 3) { s_min[threadIdx.x] = 0x7fffffff; s_max[threadIdx.x] = (int)0x80000000; }
     __syncthreads();
     const int i = b.start + threadIdx.x;
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     if (i < count[b.scan]) {
         const PointXYZINormal p = pts[sl.base + i];
         if (finite3(p)) {
-            atomicMin(&s_min[0], enc_float(p.x)); atomicMax(&s_max[0], enc_float(p.x));
-            atomicMin(&s_min[1], enc_float(p.y)); atomicMax(&s_max[1], enc_float(p.y));
-            atomicMin(&s_min[2], enc_float(p.z)); atomicMax(&s_max[2], enc_float(p.z));
+            mn[0] = mx[0] = enc_float(p.x);
+            mn[1] = mx[1] = enc_float(p.y);
+            mn[2] = mx[2] = enc_float(p.z);
         }
+    }
+    // one LDS atomic per wavefront and axis instead of one per point (they all hit the same six words)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&s_min[a], mn[a]); atomicMax(&s_max[a], mx[a]); }
     }
     __syncthreads();
     if (threadIdx.x < 3) {
