@@ -1,0 +1,15 @@
+#!/bin/bash
+# Kernel statistics of one stage of the bench loop alone (diagnostic): bash tools/profile_stage.sh ba   (through gpurun)
+STAGE=${1:-ba}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_stage
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stage -o st -- python bench.py --no-cpu-baseline --steps 10 --warmup 2 --stages $STAGE > gpurun_out/prof_stage.log 2>&1
+python - <<PY
+import csv,glob
+f=glob.glob("gpurun_out/prof_stage/**/*kernel_stats.csv", recursive=True)[0]
+rows=list(csv.DictReader(open(f)))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms", round(tot/1e6,2))
+for r in rows[:${2:-16}]: print(r["Name"][:60].ljust(60), r["Calls"].rjust(6), round(float(r["AverageNs"])/1e3,1), r["Percentage"])
+PY
+rm -rf gpurun_out/prof_stage
