@@ -245,17 +245,36 @@ __device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const
     const BaEdge ed = pb.edges[e];
     const int i = pb.pose_var[ed.pose], l = ed.point;
     if (i < 0) return;
-    const double* W = pb.W + 18 * (size_t)e;
+    // everything is read first and written last, in 16-byte pieces: the arrays may alias as far as the compiler knows, and
+    // interleaved scalar stores keep it from merging anything (36 eight-byte stores per edge otherwise)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double W[18];
+    {
+        const d2* w2 = reinterpret_cast<const d2*>(pb.W + 18 * (size_t)e);  // 144 bytes per edge: 16-byte aligned
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const d2 v = w2[q]; W[2 * q] = v.x; W[2 * q + 1] = v.y; }
+    }
     double Di[9], db[3];
     point_dinv(pb, l, lambda, Di, db);
-    double* ce = pb.coef_e + 6 * (size_t)e;
+    double ce[6], y[3][6];
+#pragma unroll
     for (int r = 0; r < 6; ++r) {
         ce[r] = W[3 * r] * db[0] + W[3 * r + 1] * db[1] + W[3 * r + 2] * db[2];
-        for (int c = 0; c < 3; ++c) {
-            const double y = W[3 * r] * Di[c] + W[3 * r + 1] * Di[3 + c] + W[3 * r + 2] * Di[6 + c];
-            const size_t at = (size_t)(3 * l + c) * pb.np_pad + 6 * i + r;
-            pb.AT[at] = y;          // (W D^-1)^T, k-major
-            pb.BT[at] = W[3 * r + c];  // W^T, k-major
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c][r] = W[3 * r] * Di[c] + W[3 * r + 1] * Di[3 + c] + W[3 * r + 2] * Di[6 + c];
+    }
+    d2* co = reinterpret_cast<d2*>(pb.coef_e + 6 * (size_t)e);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) co[q] = d2{ce[2 * q], ce[2 * q + 1]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t at = (size_t)(3 * l + c) * pb.np_pad + 6 * i;  // np_pad is a multiple of 16, 6 i even: 16-byte aligned
+        d2* a = reinterpret_cast<d2*>(pb.AT + at);  // (W D^-1)^T, k-major
+        d2* b = reinterpret_cast<d2*>(pb.BT + at);  // W^T, k-major
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a[q] = d2{y[c][2 * q], y[c][2 * q + 1]};
+            b[q] = d2{W[3 * (2 * q) + c], W[3 * (2 * q + 1) + c]};
         }
     }
 }
