@@ -11,6 +11,9 @@ namespace tc2li {
 
 // One local-BA problem resident on the device.  Free (non-fixed) poses are numbered 0..n_free-1 through pose_var;
 // pt_* is a CSR of the edges of each landmark, pv_* a CSR of the edges of each free pose (n_free_edges in total).
+// Per-edge records of the linearisation are padded to whole 16-byte pieces (9 -> 10 and 27 -> 28 doubles) so that they are written
+// and read as double2: the kernels' many pointers may alias as far as the compiler knows, and scalar stores stay scalar.
+constexpr int kContribL = 10, kContribP = 28;
 struct BaProblemDev {
     int32_t n_edges, n_points, n_poses, n_free, n_free_edges, np_pad;
     CameraD cam;

@@ -111,7 +111,7 @@ struct VisualProblem {
     const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
     TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
     TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
-    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(9 * E)); TC2LI_HIP_CHECK(d_cp.ensure(27 * E));
+    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(kContribL * E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * E));
     TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
     TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
     TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));

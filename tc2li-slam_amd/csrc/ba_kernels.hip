@@ -22,6 +22,21 @@
 namespace tc2li {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// N doubles (N even) from / to a 16-byte aligned address as double2
+template <int N>
+__device__ __forceinline__ void store_d2(double* __restrict__ dst, const double* v) {
+    v2d* o = reinterpret_cast<v2d*>(dst);
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) o[q] = v2d{v[2 * q], v[2 * q + 1]};
+}
+template <int N>
+__device__ __forceinline__ void load_d2(const double* __restrict__ src, double* v) {
+    const v2d* i = reinterpret_cast<const v2d*>(src);
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) { const v2d t = i[q]; v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+}
 
 // error of one projection edge at the given estimate: g2o's SE3 vertices (local BA) or ImuCamPose vertices (inertial BA)
 __device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, const BaEdge& e, double p[3], double err[3], int& dim, double& chi2) {
@@ -77,7 +92,8 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
         // The row sums run over all three rows with compile-time indices (everything stays in registers); the third row of
         // A and B is zero for a monocular edge, so its terms add exact zeros.
         // landmark block: A^T W A (upper 6) and A^T omega_r
-        double* cl = pb.contrib_l + 9 * (size_t)e;
+        double cl[kContribL];
+        cl[9] = 0;
         {
             int h = 0;
 #pragma unroll
@@ -97,8 +113,10 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
                 cl[6 + r] = s;
             }
         }
+        store_d2<kContribL>(pb.contrib_l + kContribL * (size_t)e, cl);
         if (pb.pose_var[ed.pose] >= 0) {
-            double* cp = pb.contrib_p + 27 * (size_t)e;
+            double cp[kContribP];
+            cp[27] = 0;
             int h = 0;
 #pragma unroll
             for (int r = 0; r < 6; ++r)
@@ -116,7 +134,7 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
                 for (int d = 0; d < 3; ++d) s += B[6 * d + r] * wr[d];
                 cp[21 + r] = s;
             }
-            double* W = pb.W + 18 * (size_t)e;  // Hpl block: B^T W A (6 x 3)
+            double W[18];  // Hpl block: B^T W A (6 x 3)
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -126,6 +144,8 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
                     for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * A[3 * d + c];
                     W[3 * r + c] = s;
                 }
+            store_d2<kContribP>(pb.contrib_p + kContribP * (size_t)e, cp);
+            store_d2<18>(pb.W + 18 * (size_t)e, W);
         }
     }
     block_sum_256(rho0, s_sum, pb.chi_part + bx);  // the robust cost is summed per workgroup here, finished in the next launch
@@ -137,7 +157,9 @@ __device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int b
     if (l >= pb.n_points) return;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
-        const double* c = pb.contrib_l + 9 * (size_t)pb.pt_edges[k];
+        double c[kContribL];
+        load_d2<kContribL>(pb.contrib_l + kContribL * (size_t)pb.pt_edges[k], c);
+#pragma unroll
         for (int i = 0; i < 9; ++i) acc[i] += c[i];
     }
     for (int i = 0; i < 6; ++i) pb.Hll[6 * (size_t)l + i] = acc[i];
@@ -146,13 +168,15 @@ __device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int b
 }
 
 // Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.
-template <int WIDTH>
+template <int WIDTH, int STRIDE = WIDTH>
 __device__ __forceinline__ void block_sum_items(const double* __restrict__ items, const int* __restrict__ index, int begin, int end,
                                                 double* s_part /*[256][WIDTH]*/, double* out) {
     double acc[WIDTH];
     for (int i = 0; i < WIDTH; ++i) acc[i] = 0;
     for (int k = begin + (int)threadIdx.x; k < end; k += 256) {
-        const double* c = items + WIDTH * (size_t)(index ? index[k] : k);
+        double c[STRIDE];
+        load_d2<STRIDE>(items + STRIDE * (size_t)(index ? index[k] : k), c);  // STRIDE is even: records are 16-byte aligned
+#pragma unroll
         for (int i = 0; i < WIDTH; ++i) acc[i] += c[i];
     }
     for (int i = 0; i < WIDTH; ++i) s_part[threadIdx.x * WIDTH + i] = acc[i];
@@ -167,7 +191,7 @@ __device__ __forceinline__ void block_sum_items(const double* __restrict__ items
 }
 
 __device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i /* free pose */, double* s_part) {
-    block_sum_items<27>(pb.contrib_p, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.Hpp + 27 * (size_t)i);
+    block_sum_items<27, kContribP>(pb.contrib_p, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.Hpp + 27 * (size_t)i);
     if (threadIdx.x == 0) {
         const double* h = pb.Hpp + 27 * (size_t)i;
         // diagonal entries of the packed upper triangle: 0, 6, 11, 15, 18, 20
@@ -350,19 +374,30 @@ __device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int
     const double* pa0 = AT + 16 * t0 + i;
     const double* pa1 = AT + 16 * (row1 ? t0 + 1 : t0) + i;
     const double* pbase = BT + i;
-    for (int k = k0; k < k1; k += 4) {
-        const int kr = k + kk;
-        const bool in = kr < k1;
-        const size_t ro = (size_t)kr * np_pad;
-        const double a0 = in ? pa0[ro] : 0.0, a1 = (in && row1) ? pa1[ro] : 0.0;
-        double b[CT];
+    // kU k-steps of operands are requested before the first MFMA of the group consumes them: the loop is bound by load latency,
+    // not by the matrix unit.  The MFMAs of a tile still run in ascending k.
+    constexpr int kU = CT <= 5 ? 8 : 4;
+    for (int k = k0; k < k1; k += 4 * kU) {
+        double a0[kU], a1[kU], b[kU][CT];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) b[t] = (in && t < tiles && t <= t0 + 1) ? pbase[ro + 16 * t] : 0.0;
+        for (int u = 0; u < kU; ++u) {
+            const int kr = k + 4 * u + kk;
+            const bool in = kr < k1;
+            const size_t ro = (size_t)kr * np_pad;
+            a0[u] = in ? pa0[ro] : 0.0;
+            a1[u] = (in && row1) ? pa1[ro] : 0.0;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            if (t > t0 + 1) break;  // uniform over the wavefront
-            if (t <= t0) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[t], acc[0][t], 0, 0, 0);
-            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[t], acc[1][t], 0, 0, 0);
+            for (int t = 0; t < CT; ++t) b[u][t] = (in && t < tiles && t <= t0 + 1) ? pbase[ro + 16 * t] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            if (k + 4 * u >= k1) break;  // uniform: steps past the slice would only add zeros
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                if (t > t0 + 1) break;  // uniform over the wavefront
+                if (t <= t0) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u][t], acc[1][t], 0, 0, 0);
+            }
         }
     }
     double* out = S_part + (size_t)slice * np_pad * np_pad;

@@ -7,6 +7,7 @@
 
 namespace tc2li {
 
+constexpr int kBalmEig = 16;
 constexpr int kMaxLidarWindow = 20;  // LidarCovisRes::win_size_ default (SF/include/LidarRes.h); the local BA uses <= 6
 
 // The plane list of one window resident on the device (VOX_HESS: plvec_voxels / coeffs, SF/include/bavoxel.h:48-78).
@@ -19,6 +20,7 @@ struct BalmDev {
     SE3f Tcl;
     LidarPose* twl;                // [W]
     double* plane_res;             // [n_planes]
+    double* eig;                   // [n_planes][kBalmEig]: NN, vbar[3], lambda[3], U[9] of the merged plane at the poses of the last residual pass
     double* part;                  // [n_chunks][balm_part_stride(W)]
     double* out;                   // [2 + 6W + (6W)^2 + 12W]: residual (residual kernels), JacT, Hessian (row-major), residual (Hessian
                                    // kernels), the LiDAR poses the derivatives were taken at

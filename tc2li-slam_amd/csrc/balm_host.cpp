@@ -404,6 +404,8 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     TC2LI_HIP_CHECK(d_clusters.ensure(std::max(clusters.size(), (size_t)1)));
     TC2LI_HIP_CHECK(d_coe.ensure(std::max(n_planes, 1)));
     TC2LI_HIP_CHECK(d_plane_res.ensure(std::max(n_planes, 1)));
+    TC2LI_HIP_CHECK(d_eig.ensure((size_t)kBalmEig * std::max(n_planes, 1)));
+    eig_at = nullptr;
     TC2LI_HIP_CHECK(d_part.ensure((size_t)dev.n_chunks * balm_part_stride(W)));
     TC2LI_HIP_CHECK(d_pose_index.ensure(W));
     TC2LI_HIP_CHECK(d_twl.ensure(W));
@@ -416,13 +418,14 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors go out of scope
     dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
-    dev.plane_res = d_plane_res.p; dev.part = d_part.p; dev.out = h_out.p;
+    dev.plane_res = d_plane_res.p; dev.eig = d_eig.p; dev.part = d_part.p; dev.out = h_out.p;
     return 0;
 }
 
 void BalmTerm::enqueue_error(const Se3* d_poses, hipStream_t st) {
     if (!n_planes) return;
     balm_launch_residual(dev, d_poses, st);
+    eig_at = d_poses;
 }
 
 void BalmTerm::finish_error() {
@@ -435,6 +438,9 @@ void BalmTerm::finish_error() {
 
 int BalmTerm::enqueue_linearization(const Se3* d_poses, hipStream_t st) {
     if (!n_planes) return 0;
+    // the Hessian kernel starts from the eigen decompositions of a residual pass at the same poses: the optimisers run one right
+    // before (computeActiveErrors, then linearizeOplus); any other caller gets it here
+    if (eig_at != d_poses) { balm_launch_residual(dev, d_poses, st); eig_at = d_poses; }
     balm_launch_hessian(dev, d_poses, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     return 0;

@@ -36,25 +36,7 @@ __device__ __forceinline__ void window_poses(const BalmDev& b, const Se3* __rest
     __syncthreads();
 }
 
-// merged window cluster of one plane -> covariance -> eigen decomposition
-__device__ __forceinline__ void plane_eigen(const ClusterW* cw, int W, double& NN, double vbar[3], double lambda[3], double U[9]) {
-    double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0};
-    double n = 0;
-    for (int i = 0; i < W; ++i) {
-        if (cw[i].n == 0) continue;
-        for (int k = 0; k < 9; ++k) P[k] += cw[i].P[k];
-        for (int k = 0; k < 3; ++k) v[k] += cw[i].v[k];
-        n += cw[i].n;
-    }
-    NN = n;
-    const double inv = 1.0 / n;
-    for (int k = 0; k < 3; ++k) vbar[k] = inv * v[k];
-    double C[9];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vbar[r] * vbar[c];
-    eig_sym3(C, lambda, U);
-}
-
+// merged window cluster of one plane -> covariance -> eigen decomposition -> its term of the residual
 __device__ __forceinline__ double plane_residual(const BalmDev& b, const LidarPose* twl, int a) {
     double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0}, n = 0;
     for (int i = 0; i < b.W; ++i) {
@@ -72,6 +54,11 @@ __device__ __forceinline__ double plane_residual(const BalmDev& b, const LidarPo
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vb[r] * vb[c];
     eig_sym3(C, lambda, U);
+    // the Hessian pass that follows at the same poses starts from this decomposition instead of repeating it in one lane
+    double* eo = b.eig + (size_t)kBalmEig * a;
+    eo[0] = n;
+    for (int k = 0; k < 3; ++k) { eo[1 + k] = vb[k]; eo[4 + k] = lambda[k]; }
+    for (int k = 0; k < 9; ++k) eo[7 + k] = U[k];
     return b.coe[a] * lambda[0];
 }
 
@@ -113,7 +100,6 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
 template <int kItemsPerThread>
 __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
-    __shared__ ClusterW s_cw[kMaxLidarWindow];
     __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
     __shared__ double s_w[kMaxLidarWindow][3], s_E[kMaxLidarWindow][9], s_k1[kMaxLidarWindow], s_k2[kMaxLidarWindow], s_n[kMaxLidarWindow];
     __shared__ double s_uk[3], s_ukuk[9], s_umum[9], s_vbar[3], s_NN, s_l0;
@@ -137,13 +123,14 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
         if (tid < W) {
             mine = b.clusters[(size_t)a * W + tid];
             s_n[tid] = mine.n;
-            if (mine.n != 0) cluster_transform(mine, s_twl[tid], s_cw[tid]);
-            else s_cw[tid].n = 0;
         }
-        __syncthreads();
         if (tid == 0) {
-            double NN, vbar[3], lambda[3], U[9];
-            plane_eigen(s_cw, W, NN, vbar, lambda, U);
+            // merged cluster -> covariance -> eigen decomposition: taken from the residual pass at these poses (plane_residual; the
+            // host launches it right before, see BalmTerm::enqueue_linearization), there is no second copy of that arithmetic
+            const double* ei = b.eig + (size_t)kBalmEig * a;
+            const double NN = ei[0];
+            const double vbar[3] = {ei[1], ei[2], ei[3]}, lambda[3] = {ei[4], ei[5], ei[6]};
+            const double* U = ei + 7;
             const double u0[3] = {U[0], U[3], U[6]};
             for (int k = 0; k < 3; ++k) { s_uk[k] = u0[k]; s_vbar[k] = vbar[k]; }
             for (int r = 0; r < 3; ++r)
