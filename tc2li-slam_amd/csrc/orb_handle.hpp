@@ -58,7 +58,9 @@ struct tc2li_orb {
     tc2li::ScaleTable scale_tab{};
 
     hipStream_t side_stream = nullptr;
-    hipEvent_t ev[12] = {};
+    // per chunk of a batch call (tc2li_orb_extract_batch pipelines chunks of images): 0/1 pyramid, 8/3 FAST, 3/2 compaction, 4/5 blur, 6/7 descriptors
+    static constexpr int kMaxChunks = 4, kEvPerChunk = 9;
+    hipEvent_t ev[kMaxChunks * kEvPerChunk] = {};
     bool profiling = false;  // serialise all kernels on the caller's stream so that per-kernel event times are clean
     tc2li::LevelTable raw_tab{}, blur_tab{};
     int last_nimg = 0;

@@ -288,86 +288,106 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     }
     o->last_nimg = M;
 
-    // ---- stage 1: pyramid, FAST, compaction (main stream); blur (side stream, or main stream when profiling) ---
+    // The call is a pipeline over chunks of images: stage 1 (pyramid, FAST, compaction on the main stream; blur on the side stream)
+    // of every chunk is queued at once; the host then takes the chunks in order -- quadtree distribution (stage 2) as soon as the
+    // chunk's candidates are in the pinned buffer, then its orientation + descriptor launch (stage 3) -- so that the GPU works on
+    // the later chunks and on the descriptors while the host distributes.  With profiling on there is one chunk and every kernel
+    // is on the caller's stream, which gives clean per-stage durations.
+    static const int kChunkEnv = getenv("TC2LI_ORB_CHUNKS") ? atoi(getenv("TC2LI_ORB_CHUNKS")) : 0;
+    const int want_chunks = kChunkEnv > 0 ? kChunkEnv : (M >= 64 ? 4 : (M >= 16 ? 2 : 1));
+    const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     hipStream_t blur_st = o->profiling ? st : o->side_stream;
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[0], st));
-    for (int l = 1; l < L; ++l)
-        launch_resize(raw.lv[l - 1], raw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, M, st);
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[1], st));
-    if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, o->ev[1], 0));
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[4], blur_st));
-    launch_blur_all(raw, blur, L, M, blur_st);
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[5], blur_st));
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[8], st));
-    if (ncells > 0) {
-        launch_fast(raw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p,
-                    (size_t)o->slab_per_image, o->d_cell_counts.p, M, o->max_cell_w, o->max_cell_h, st);
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
-        launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p, ncells, o->d_slab.p,
-                       (size_t)o->slab_per_image, o->h_dense.p, o->d_level_dense_off.p, o->h_level_counts.p, L, M, st);
-    } else {
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[3], st));
-        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-        memset(o->h_level_counts.p, 0, (size_t)M * L * sizeof(int));
+    auto EV = [&](int chunk, int k) { return o->ev[chunk * tc2li_orb::kEvPerChunk + k]; };
+    auto chunk_begin = [&](int c) { return (int)((long)M * c / n_chunks); };
+    for (int c = 0; c < n_chunks; ++c) {
+        const int i0 = chunk_begin(c), m = chunk_begin(c + 1) - i0;
+        LevelTable craw = raw, cblur = blur;  // this chunk's images
+        for (int l = 0; l < L; ++l) {
+            craw.lv[l].img = raw.lv[l].img + (size_t)i0 * raw.lv[l].img_stride;
+            cblur.lv[l].img = blur.lv[l].img + (size_t)i0 * blur.lv[l].img_stride;
+        }
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 0), st));
+        for (int l = 1; l < L; ++l)
+            launch_resize(craw.lv[l - 1], craw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, m, st);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 1), st));
+        if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, EV(c, 1), 0));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 4), blur_st));
+        launch_blur_all(craw, cblur, L, m, blur_st);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 5), blur_st));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 8), st));
+        if (ncells > 0) {
+            launch_fast(craw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p + (size_t)i0 * o->slab_per_image,
+                        (size_t)o->slab_per_image, o->d_cell_counts.p + (size_t)i0 * ncells, m, o->max_cell_w, o->max_cell_h, st);
+            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
+            launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p + (size_t)i0 * ncells, ncells,
+                           o->d_slab.p + (size_t)i0 * o->slab_per_image, (size_t)o->slab_per_image,
+                           o->h_dense.p + (size_t)i0 * o->slab_per_image, o->d_level_dense_off.p, o->h_level_counts.p + (size_t)i0 * L, L, m, st);
+        } else {
+            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
+        }
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 2), st));
     }
-    TC2LI_HIP_CHECK(hipEventRecord(o->ev[2], st));
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
 
-    // candidates of every (image, level) are now visible in the pinned buffer
-    o->last_level_counts.assign(o->h_level_counts.p, o->h_level_counts.p + (size_t)M * L);
+    o->last_level_counts.assign((size_t)M * L, 0);
     o->last_level_off.assign((size_t)M * L + 1, 0);
     for (int i = 0; i < M; ++i)
         for (int l = 0; l < L; ++l) o->last_level_off[i * L + l] = (size_t)i * o->slab_per_image + o->geom[l].dense_off;
 
-    // ---- stage 2 (host): quadtree distribution per (image, level) ------------------------------------------
-    const auto t0 = std::chrono::steady_clock::now();
     WorkerPool& pool = global_pool();
     if ((int)o->scratch.size() < M * L) o->scratch.resize((size_t)M * L);
     std::vector<std::vector<int32_t>> picked((size_t)M * L);
-    pool.parallel_for(M * L, [&](int task) {
-        const int l = task % L;
-        const LevelGeom& g = o->geom[l];
-        picked[task].clear();
-        distribute_quadtree(o->h_dense.p + o->last_level_off[task], o->last_level_counts[task], g.min_bx, g.max_bx,
-                            g.min_by, g.max_by, o->features_per_level[l], o->scratch[task], picked[task]);
-    });
     std::vector<int> img_kp_off(M + 1, 0);
-    for (int i = 0; i < M; ++i) {
-        int n = 0;
-        for (int l = 0; l < L; ++l) n += (int)picked[i * L + l].size();
-        if (n > o->kp_cap_per_image) { set_error("keypoint capacity exceeded"); return TC2LI_ERR_CAPACITY; }
-        img_kp_off[i + 1] = img_kp_off[i] + n;
-    }
-    const int nkp_total = img_kp_off[M];
-    o->last_kp_off = img_kp_off;
-    o->last_plain_order = true;
-    for (int i = 0; i < M; ++i) {
-        DevKeypoint* dst = o->h_kps.p + img_kp_off[i];
-        for (int l = 0; l < L; ++l) {
-            const uint32_t* cand = o->h_dense.p + o->last_level_off[i * L + l];
-            for (int32_t k : picked[i * L + l]) {
-                const uint32_t c = cand[k];
-                const uint32_t x = ((c >> 8) & 0xfff) + kMinBorder, y = (c >> 20) + kMinBorder;  // :856-857
-                *dst++ = DevKeypoint{(y << 20) | (x << 8) | (c & 0xff), ((uint32_t)i << 8) | (uint32_t)l};
+    float host_ms = 0;
+    auto fail_after_sync = [&](int code) { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(blur_st); return code; };
+    std::chrono::steady_clock::time_point t_first_chunk{};
+    for (int c = 0; c < n_chunks; ++c) {
+        const int i0 = chunk_begin(c), i1 = chunk_begin(c + 1), m = i1 - i0;
+        // candidates of the chunk's (image, level) lists are visible in the pinned buffer once its compaction has run
+        TC2LI_HIP_CHECK(hipEventSynchronize(EV(c, 2)));
+        if (c == 0) t_first_chunk = std::chrono::steady_clock::now();
+        if (ncells > 0) memcpy(o->last_level_counts.data() + (size_t)i0 * L, o->h_level_counts.p + (size_t)i0 * L, (size_t)m * L * sizeof(int));
+        // ---- stage 2 (host): quadtree distribution per (image, level) ----
+        const auto t0 = std::chrono::steady_clock::now();
+        pool.parallel_for(m * L, [&](int t) {
+            const int task = i0 * L + t, l = task % L;
+            const LevelGeom& g = o->geom[l];
+            picked[task].clear();
+            distribute_quadtree(o->h_dense.p + o->last_level_off[task], o->last_level_counts[task], g.min_bx, g.max_bx,
+                                g.min_by, g.max_by, o->features_per_level[l], o->scratch[task], picked[task]);
+        });
+        for (int i = i0; i < i1; ++i) {
+            int n = 0;
+            for (int l = 0; l < L; ++l) n += (int)picked[i * L + l].size();
+            if (n > o->kp_cap_per_image) { set_error("keypoint capacity exceeded"); return fail_after_sync(TC2LI_ERR_CAPACITY); }
+            img_kp_off[i + 1] = img_kp_off[i] + n;
+        }
+        for (int i = i0; i < i1; ++i) {
+            DevKeypoint* dst = o->h_kps.p + img_kp_off[i];
+            for (int l = 0; l < L; ++l) {
+                const uint32_t* cand = o->h_dense.p + o->last_level_off[i * L + l];
+                for (int32_t k : picked[i * L + l]) {
+                    const uint32_t cc = cand[k];
+                    const uint32_t x = ((cc >> 8) & 0xfff) + kMinBorder, y = (cc >> 20) + kMinBorder;  // :856-857
+                    *dst++ = DevKeypoint{(y << 20) | (x << 8) | (cc & 0xff), ((uint32_t)i << 8) | (uint32_t)l};
+                }
             }
         }
-    }
-    const auto t1 = std::chrono::steady_clock::now();
-
-    // ---- stage 3: orientation + descriptors ---------------------------------------------------------------
-    if (nkp_total > 0) {
-        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
-        launch_orient_describe(raw, blur, o->scale_tab, o->h_kps.p, nkp_total, o->h_angles.p, o->h_desc.p, o->d_mkeys.p,
-                               o->d_desc.p, st);
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
+        host_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        // ---- stage 3: orientation + descriptors of the chunk's keypoints (they index the whole batch's level tables) ----
+        const int k0 = img_kp_off[i0], nk = img_kp_off[i1] - k0;
+        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, EV(c, 5), 0));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 6), st));
+        if (nk > 0)
+            launch_orient_describe(raw, blur, o->scale_tab, o->h_kps.p + k0, nk, o->h_angles.p + k0, o->h_desc.p + (size_t)32 * k0, o->d_mkeys.p + k0,
+                                   o->d_desc.p + (size_t)32 * k0, st);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 7), st));
         TC2LI_HIP_CHECK(hipGetLastError());
-    } else {
-        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, o->ev[5], 0));
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[6], st));
-        TC2LI_HIP_CHECK(hipEventRecord(o->ev[7], st));
     }
+    const int nkp_total = img_kp_off[M];
+    (void)nkp_total;
+    o->last_kp_off = img_kp_off;
+    o->last_plain_order = true;
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
 
     // ---- assemble in the reference's output order (SF/src/ORBextractor.cc:1093-1137) -----------------------
@@ -399,13 +419,16 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         }
         if (mono_index) mono_index[i] = mono;
     });
-    o->timings[0] = elapsed(o->ev[0], o->ev[1]);
-    o->timings[1] = elapsed(o->ev[8], o->ev[3]);
-    o->timings[2] = elapsed(o->ev[3], o->ev[2]);
-    o->timings[3] = elapsed(o->ev[4], o->ev[5]);
-    o->timings[4] = elapsed(o->ev[6], o->ev[7]);
-    o->timings[5] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    o->timings[6] = std::chrono::duration<float, std::milli>(t0 - t_begin).count();
+    for (int k = 0; k < 5; ++k) o->timings[k] = 0;
+    for (int c = 0; c < n_chunks; ++c) {  // device stages: the chunks' durations added up
+        o->timings[0] += elapsed(EV(c, 0), EV(c, 1));
+        o->timings[1] += elapsed(EV(c, 8), EV(c, 3));
+        o->timings[2] += elapsed(EV(c, 3), EV(c, 2));
+        o->timings[3] += elapsed(EV(c, 4), EV(c, 5));
+        o->timings[4] += elapsed(EV(c, 6), EV(c, 7));
+    }
+    o->timings[5] = host_ms;
+    o->timings[6] = std::chrono::duration<float, std::milli>(t_first_chunk - t_begin).count();
     o->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (status.load() != TC2LI_OK) { set_error("keypoint capacity %d too small", capacity); return status.load(); }
     return n_images;
