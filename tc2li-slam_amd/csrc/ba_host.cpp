@@ -204,7 +204,7 @@ int tc2li_pose_optimization_batch(int n_frames, double* poses7, const int32_t* e
     TC2LI_HIP_CHECK(hipMemcpyAsync(poses7, w.d_poses.p, (size_t)7 * n_frames * sizeof(double), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(n_inliers, w.d_inliers.p, n_frames * sizeof(int), hipMemcpyDeviceToHost, st));
     if (total) TC2LI_HIP_CHECK(hipMemcpyAsync(outlier, w.d_outlier.p, total, hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     return n_frames;
 }
 
@@ -1169,7 +1169,7 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;  // A/B switch for measurements
     // The lock-step loop is a chain of dependent launches with a host step after every phase: while the host works the stream is
     // empty.  Several groups of windows, each a lock-step batch of its own on its own stream and host thread, fill each other's gaps.
-    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 2));
+    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
     if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
         const int groups = std::min(kGroups, n_problems / 2);
         bool done = false;

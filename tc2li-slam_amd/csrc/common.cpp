@@ -27,6 +27,23 @@ bool device_ready() {
     return true;
 }
 
+hipError_t stream_wait_blocking(hipStream_t st) {
+    struct Ev {
+        hipEvent_t e = nullptr;
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    };
+    static thread_local Ev ev;
+    static const bool spin = getenv("TC2LI_SPIN_WAIT") != nullptr;  // A/B switch for measurements
+    if (spin) return hipStreamSynchronize(st);
+    if (!ev.e) {
+        hipError_t e = hipEventCreateWithFlags(&ev.e, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) { ev.e = nullptr; return hipStreamSynchronize(st); }
+    }
+    hipError_t e = hipEventRecord(ev.e, st);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ev.e);
+}
+
 WorkerPool::WorkerPool(int nthreads) {
     for (int i = 0; i < nthreads - 1; ++i) workers_.emplace_back([this] { loop(); });
 }

@@ -18,7 +18,12 @@
 namespace tc2li {
 
 void set_error(const char* fmt, ...);
-bool device_ready();  // true when a HIP device is usable; sets the error text otherwise
+bool device_ready();
+// hipStreamSynchronize for waits that last milliseconds (the front-end stages): the calling thread sleeps on an event made with
+// hipEventBlockingSync instead of spinning on the queue -- several host threads wait on the GPU at once and a spinning thread costs
+// a whole core (the GPU boxes give a process 16).  The short waits of the bundle-adjustment loop keep spinning: a wake-up costs
+// more than one of its kernels.
+hipError_t stream_wait_blocking(hipStream_t st);  // true when a HIP device is usable; sets the error text otherwise
 
 #define TC2LI_HIP_CHECK(call)                                                                       \
     do {                                                                                            \

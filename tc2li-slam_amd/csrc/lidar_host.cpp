@@ -619,7 +619,7 @@ int map_compact_and_rebuild(tc2li_lidar_map* m, tc2li_lidar* L, int scan_base, i
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p, m->d_totals.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p + 2, m->d_bbox.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     const int kept = m->h_io.p[0], appended = L ? m->h_io.p[1] : 0;
     const int added = appended + (L ? n_noneed : 0);
     if (added > 0)
@@ -634,7 +634,7 @@ int map_compact_and_rebuild(tc2li_lidar_map* m, tc2li_lidar* L, int scan_base, i
     m->n = kept + added;
     const int rc = rebuild_grid(m, st);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     return kept;
 }
 }  // namespace
@@ -664,7 +664,7 @@ int tc2li_lidar_map_incremental(tc2li_lidar* L, int scan, tc2li_lidar_map* m, co
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_inc.p, L->d_inc_counts.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     if (m->n) TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     const int n_add = L->h_inc.p[0], n_groups = L->h_inc.p[1], n_noneed = L->h_inc.p[2];
     if (L->h_inc.p[3]) { set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax); return TC2LI_ERR_CAPACITY; }
     launch_mapinc_apply(L->d_world.p + base, L->d_inc_recs.p, L->d_group_start.p, L->d_inc_counts.p, n_groups, m->grid, ds, m->d_deleted.p,
@@ -808,7 +808,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + n_scans, L->d_down_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 2 * n_scans, L->d_sel_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * n_scans, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     L->last_down.assign(hc + n_scans, hc + 2 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
@@ -824,7 +824,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
             TC2LI_HIP_CHECK(hipMemcpyAsync(corr_normvect + (size_t)s * capacity, L->d_corr.p + (size_t)s * L->cap,
                                            (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
     }
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     return n_scans;
 }
 

@@ -152,13 +152,13 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_pool_top.p, w.d_pool_top.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     if (w.h_pool_top.p[1]) {  // candidate pool exhausted (very dense windows): the one-kernel form computes the same result
         TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
         launch_match_by_projection(w.d_frames.p, n_frames, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
     }
     global_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];

@@ -215,7 +215,7 @@ int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, i
     o->d_levels.resize(L); o->d_blur.resize(L);
     o->d_xofs.resize(L); o->d_yofs.resize(L); o->d_ialpha.resize(L); o->d_ibeta.resize(L);
     TC2LI_HIP_CHECK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
-    for (auto& e : o->ev) TC2LI_HIP_CHECK(hipEventCreate(&e));
+    for (auto& e : o->ev) TC2LI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync));  // timed, and waited on without spinning
     int rc = setup_geometry(o.get(), max_width, max_height);
     if (rc != TC2LI_OK) return rc;
     *out = o.release();
@@ -339,7 +339,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     std::vector<std::vector<int32_t>> picked((size_t)M * L);
     std::vector<int> img_kp_off(M + 1, 0);
     float host_ms = 0;
-    auto fail_after_sync = [&](int code) { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(blur_st); return code; };
+    auto fail_after_sync = [&](int code) { (void)stream_wait_blocking(st); (void)hipStreamSynchronize(blur_st); return code; };
     std::chrono::steady_clock::time_point t_first_chunk{};
     for (int c = 0; c < n_chunks; ++c) {
         const int i0 = chunk_begin(c), i1 = chunk_begin(c + 1), m = i1 - i0;
@@ -388,7 +388,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     (void)nkp_total;
     o->last_kp_off = img_kp_off;
     o->last_plain_order = true;
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
 
     // ---- assemble in the reference's output order (SF/src/ORBextractor.cc:1093-1137) -----------------------
     std::atomic<int> status{TC2LI_OK};

@@ -91,7 +91,7 @@ int tc2li_stereo_match_batch(tc2li_orb* o, int n_frames, float bf, float b, floa
     launch_stereo_match(o->raw_tab, o->raw_tab, o->scale_tab, ws->d_frames.p, n_frames, max_left, o->d_mkeys.p, o->d_desc.p,
                         bf, max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     global_pool().parallel_for(n_frames, [&](int f) {
         const StereoFrame& fr = frames[f];
         float* u = u_right + (size_t)f * capacity;
