@@ -265,6 +265,7 @@ def main():
                               "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()}}))
         return
     loop_orb_ms, loop_lidar_ms = np.mean(orb_times, 0), np.mean(lidar_times, 0)
+    loop_chunks = ext.last_chunks()
     elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0, device="cuda")
     stage_ms = ext.last_timings().astype(float)
     orb_out, st_out, trk_out = orb_outs[0], st_outs[0], trk_outs[0]
@@ -315,13 +316,16 @@ def main():
     alg = algorithmic_bytes(W, H, nkp, lid_mean)
     kern_ms = stage_table(loop_orb_ms, loop_lidar_ms)
     units = {k: (F if k.startswith("lidar") else n_img) for k in kern_ms}
-    launches = {"pyramid": 7, "fast": 1, "blur": 1, "orient_describe": 1, "lidar_preprocess": 3, "lidar_voxel_hash": 8, "lidar_voxel_centroid": 1,
+    # the ORB call pipelines chunks of images: each of its device stages is launched once per chunk, the event durations are the
+    # chunks' sums (the profiling passes above run unchunked, so `measured alone` is one launch per stage)
+    ch = max(1, loop_chunks)
+    launches = {"pyramid": 7 * ch, "fast": ch, "blur": ch, "orient_describe": ch, "lidar_preprocess": 3, "lidar_voxel_hash": 8, "lidar_voxel_centroid": 1,
                 "lidar_knn_plane": 1, "lidar_knn_hard": 1, "lidar_select": 3}
     names = {"fast": "k_fast_cells", "blur": "k_blur7_strips", "pyramid": "k_resize_linear", "orient_describe": "k_orient_describe",
              "lidar_preprocess": "k_pre_count+k_seg_scan+k_pre_scatter", "lidar_voxel_hash": "k_voxel_bbox..k_voxel_fill",
              "lidar_voxel_centroid": "k_voxel_centroid", "lidar_knn_plane": "k_knn_plane", "lidar_knn_hard": "k_knn_hard",
              "lidar_select": "k_sel_count+k_seg_scan+k_sel_scatter"}
-    single = [k for k in kern_ms if launches[k] == 1 or k in ("pyramid", "blur")]  # groups made of one kernel (x launches)
+    single = [k for k in kern_ms if k in ("pyramid", "fast", "blur", "orient_describe") or launches[k] == 1]  # groups made of one kernel (x launches)
     dom = max(single, key=lambda k: kern_ms[k])  # the kernel with the largest device time per step
     bytes_per_launch = alg[dom] * units[dom] / launches[dom]
     achieved = bytes_per_launch / (kern_ms[dom] / launches[dom] * 1e-3) / 1e9
@@ -330,14 +334,14 @@ def main():
     traffic = None
     for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         pmc = json.load(open(f))
-        hit = [v for k, v in pmc.items() if k.split("::")[-1] == names[dom]]
+        hit = [v for k, v in pmc.items() if k.split("::")[-1].split("<")[0] == names[dom]]
         if hit and hit[0].get("hbm_bytes_per_launch"):
             traffic = {"bytes_per_launch": int(hit[0]["hbm_bytes_per_launch"]), "source": os.path.basename(f),
-                       "note": "measured at the batch size of that profile run"}
+                       "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch, from the rocprofv3 --pmc passes of this same command"}
             break
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(kern_ms[dom] / launches[dom], 5),
-                "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "launches_per_step": launches[dom],
                 "all_kernels_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                 "all_kernels_ms_measured_alone": {k: round(v, 4) for k, v in isolated_ms.items()},
                 "all_kernels_GBps": {k: round(alg[k] * units[k] / (kern_ms[k] * 1e-3) / 1e9, 2) for k in kern_ms if kern_ms[k] > 0}}

@@ -102,6 +102,9 @@ int tc2li_orb_download_candidates(tc2li_orb* orb, int image_index, int level, fl
  * [0]..[4] are clean per-stage durations. */
 int tc2li_orb_set_profiling(tc2li_orb* orb, int enabled);
 int tc2li_orb_last_timings(const tc2li_orb* orb, float ms[8]);
+/* A batch call is pipelined over chunks of images (the host quadtree of one chunk runs while the device works on the others): every
+ * device stage is launched once per chunk, and [0]..[4] above are the sums over the chunks.  Returns the chunk count of the last call. */
+int tc2li_orb_last_chunks(const tc2li_orb* orb);
 
 /* ------------------------------------------------------------------------------------------------
  * Stereo matching -- replaces Frame::ComputeStereoMatches (SF/src/Frame.cc:841-1011; called from the stereo

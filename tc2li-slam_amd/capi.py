@@ -61,6 +61,7 @@ def lib():
     L.tc2li_orb_download_blurred.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.tc2li_orb_download_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.tc2li_orb_last_timings.argtypes = [C.c_void_p, C.c_void_p]
+    L.tc2li_orb_last_chunks.argtypes = [C.c_void_p]
     L.tc2li_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.tc2li_host_distribute_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_int]
@@ -273,6 +274,10 @@ class OrbExtractor:
         t = np.zeros(8, np.float32)
         _check(lib().tc2li_orb_last_timings(self._h, t.ctypes.data))
         return t
+
+    def last_chunks(self):
+        """Chunks of images the last batch call was pipelined over (every device stage is launched once per chunk)."""
+        return _check(lib().tc2li_orb_last_chunks(self._h))
 
 
 def compute_stereo_matches(ext_left, ext_right, kps_l, desc_l, kps_r, desc_r, bf, b):

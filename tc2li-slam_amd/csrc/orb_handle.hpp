@@ -61,6 +61,7 @@ struct tc2li_orb {
     // per chunk of a batch call (tc2li_orb_extract_batch pipelines chunks of images): 0/1 pyramid, 8/3 FAST, 3/2 compaction, 4/5 blur, 6/7 descriptors
     static constexpr int kMaxChunks = 4, kEvPerChunk = 9;
     hipEvent_t ev[kMaxChunks * kEvPerChunk] = {};
+    int last_chunks = 1;
     bool profiling = false;  // serialise all kernels on the caller's stream so that per-kernel event times are clean
     tc2li::LevelTable raw_tab{}, blur_tab{};
     int last_nimg = 0;

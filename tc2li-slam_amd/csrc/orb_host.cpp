@@ -240,6 +240,8 @@ int tc2li_orb_scale_factors(const tc2li_orb* o, float* s, float* is, float* s2, 
     return o->prm.nlevels;
 }
 
+int tc2li_orb_last_chunks(const tc2li_orb* o) { return o ? o->last_chunks : TC2LI_ERR_INVALID; }
+
 int tc2li_orb_features_per_level(const tc2li_orb* o, int32_t* per_level) {
     if (!o || !per_level) return TC2LI_ERR_INVALID;
     memcpy(per_level, o->features_per_level.data(), o->features_per_level.size() * sizeof(int32_t));
@@ -296,6 +298,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     static const int kChunkEnv = getenv("TC2LI_ORB_CHUNKS") ? atoi(getenv("TC2LI_ORB_CHUNKS")) : 0;
     const int want_chunks = kChunkEnv > 0 ? kChunkEnv : (M >= 64 ? 4 : (M >= 16 ? 2 : 1));
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
+    o->last_chunks = n_chunks;
     hipStream_t blur_st = o->profiling ? st : o->side_stream;
     auto EV = [&](int chunk, int k) { return o->ev[chunk * tc2li_orb::kEvPerChunk + k]; };
     auto chunk_begin = [&](int c) { return (int)((long)M * c / n_chunks); };
