@@ -325,7 +325,10 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
         }
         if (lidar) {  // computeActiveErrors + linearizeOplus of the LiDAR edge ride on the same synchronisation
-            lidar->enqueue_error(pb.poses, st);
+            // after the first iteration the accepted estimate IS the last trial (a rejected last trial ends the loop): its residual
+            // and plane decompositions are already there, computing them again would give the same bits
+            if (it == 0) lidar->enqueue_error(pb.poses, st);
+            else lidar->eig_at = pb.poses;
             const int rc = lidar->enqueue_linearization(pb.poses, st);
             if (rc < 0) return rc;
         }
@@ -983,7 +986,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                 hipMemcpyAsync(w.ws->h_Hpp.p, w.ws->d_Hpp.p, 27 * (size_t)w.vp.n_free * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
         }
         // (running the LiDAR kernels on a second stream beside the visual ones was measured: no gain, the chain is not the limit there)
-        balm_batch_launch_residual(d_slots, d_lists + n, (int)with_lidar.size(), false, st);
+        // the residual pass at the accepted estimate: only before the first iteration -- later the accepted estimate is the last
+        // trial, whose residual and plane decompositions are still in place (same bits)
+        bool first_pass = false;
+        for (int i : with_lidar) first_pass |= W[i].it == 0;
+        if (first_pass) balm_batch_launch_residual(d_slots, d_lists + n, (int)with_lidar.size(), false, st);
         balm_batch_launch_hessian(d_slots, d_lists + n, (int)with_lidar.size(), X, st);
         sync();
         if (failed) break;
