@@ -197,24 +197,55 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     return x;
 }
 
+// Neighbouring returns of a scan mostly fall into the same voxel: lanes that continue their left neighbour's voxel (a "run")
+// leave the table work to the run's first lane -- one CAS probe and one counter atomic per run instead of per point -- and take
+// its slot by shuffle.  pt_slot keeps every point's table slot for the later passes (-1: point not filtered).
+struct RunInfo { bool head; int head_lane, length; };
+__device__ __forceinline__ RunInfo wave_runs(int key) {
+    const int lane = threadIdx.x & 63;
+    const int left = __shfl_up(key, 1, 64);
+    RunInfo r;
+    r.head = lane == 0 || left != key;
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    r.head_lane = 63 - __clzll(heads & upto);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    r.length = above ? __ffsll((long long)above) : 64 - lane;  // for a head: lanes up to the next head
+    return r;
+}
+
 __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                             const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                             float leaf, const VoxelParams* __restrict__ vp,
-                                                            int* __restrict__ table_keys, int* __restrict__ table_counts) {
+                                                            int* __restrict__ table_keys, int* __restrict__ table_counts,
+                                                            int* __restrict__ pt_slot) {
     const SegBlock b = blocks[blockIdx.x];
-    const int i = b.start + threadIdx.x;
-    if (i >= count[b.scan]) return;
+    const int i = b.start + threadIdx.x, n = count[b.scan];
+    if (b.start >= n) return;  // whole workgroup
     const VoxelParams v = vp[b.scan];
     if (v.passthrough) return;
-    const PointXYZINormal p = pts[slots[b.scan].base + i];
-    if (!finite3(p)) return;
-    const int idx = voxel_index(p, 1.0f / leaf, v);
-    uint32_t h = hash_u32((uint32_t)idx) & (uint32_t)v.table_mask;
-    for (;;) {
-        const int prev = atomicCAS(&table_keys[v.table_base + h], -1, idx);
-        if (prev == -1 || prev == idx) { atomicAdd(&table_counts[v.table_base + h], 1); break; }
-        h = (h + 1) & (uint32_t)v.table_mask;
+    const int base = slots[b.scan].base;
+    bool valid = i < n;
+    int idx = -1 - (int)(threadIdx.x & 63);  // lanes without a point: keys no neighbour shares
+    if (valid) {
+        const PointXYZINormal p = pts[base + i];
+        valid = finite3(p);
+        if (valid) idx = voxel_index(p, 1.0f / leaf, v);
     }
+    const RunInfo run = wave_runs(idx);
+    int slot = -1;
+    if (run.head && valid) {
+        uint32_t h = hash_u32((uint32_t)idx) & (uint32_t)v.table_mask;
+        for (;;) {
+            const int prev = atomicCAS(&table_keys[v.table_base + h], -1, idx);
+            if (prev == -1 || prev == idx) break;
+            h = (h + 1) & (uint32_t)v.table_mask;
+        }
+        slot = v.table_base + (int)h;
+        atomicAdd(&table_counts[slot], run.length);
+    }
+    slot = __shfl(slot, run.head_lane, 64);
+    if (i < n) pt_slot[base + i] = valid ? slot : -1;
 }
 
 __device__ __forceinline__ int table_find(const int* __restrict__ table_keys, const VoxelParams& v, int idx) {
@@ -291,23 +322,26 @@ __global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict_
     if (tid == 0) n_vox[s] = n;
 }
 
-__global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
-                                                          const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
-                                                          float leaf, const VoxelParams* __restrict__ vp,
-                                                          const int* __restrict__ table_keys, const int* __restrict__ table_rank,
+__global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const int* __restrict__ count, const ScanSlot* __restrict__ slots,
+                                                          const SegBlock* __restrict__ blocks, const VoxelParams* __restrict__ vp,
+                                                          const int* __restrict__ pt_slot, const int* __restrict__ table_rank,
                                                           const int* __restrict__ vox_member_off, int* __restrict__ vox_fill,
                                                           int* __restrict__ members) {
     const SegBlock b = blocks[blockIdx.x];
-    const int i = b.start + threadIdx.x;
-    if (i >= count[b.scan]) return;
-    const VoxelParams v = vp[b.scan];
-    if (v.passthrough) return;
+    const int i = b.start + threadIdx.x, n = count[b.scan];
+    if (b.start >= n) return;
+    if (vp[b.scan].passthrough) return;
     const ScanSlot sl = slots[b.scan];
-    const PointXYZINormal p = pts[sl.base + i];
-    if (!finite3(p)) return;
-    const int r = table_rank[table_find(table_keys, v, voxel_index(p, 1.0f / leaf, v))];
-    const int pos = atomicAdd(&vox_fill[sl.base + r], 1);
-    members[sl.base + vox_member_off[sl.base + r] + pos] = i;
+    const int slot = i < n ? pt_slot[sl.base + i] : -1;
+    const RunInfo run = wave_runs(slot >= 0 ? slot : -1 - (int)(threadIdx.x & 63));
+    int r = 0, first = 0;
+    if (run.head && slot >= 0) {  // one position atomic per run; its lanes take consecutive places
+        r = table_rank[slot];
+        first = atomicAdd(&vox_fill[sl.base + r], run.length);
+    }
+    r = __shfl(r, run.head_lane, 64);
+    first = __shfl(first, run.head_lane, 64);
+    if (slot >= 0) members[sl.base + vox_member_off[sl.base + r] + first + ((int)(threadIdx.x & 63) - run.head_lane)] = i;
 }
 
 // PCL sums a voxel's points in the order of its sorted index vector, i.e. by ascending point index, in float.
@@ -321,7 +355,7 @@ struct CentroidRec { float4 lo, hi; };  // x y z normal_x | normal_y normal_z in
 
 __global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                     const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks, float leaf,
-                                                    const VoxelParams* __restrict__ vp, const int* __restrict__ table_keys,
+                                                    const VoxelParams* __restrict__ vp, const int* __restrict__ pt_slot,
                                                     const int* __restrict__ table_rank, const int* __restrict__ vox_member_off,
                                                     const int* __restrict__ vox_fill, const int* __restrict__ members,
                                                     CentroidRec* __restrict__ recs) {
@@ -331,9 +365,10 @@ __global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __res
     const VoxelParams v = vp[b.scan];
     if (v.passthrough) return;
     const ScanSlot sl = slots[b.scan];
+    const int slot = pt_slot[sl.base + i];
+    if (slot < 0) return;
     const PointXYZINormal p = pts[sl.base + i];
-    if (!finite3(p)) return;
-    const int r = table_rank[table_find(table_keys, v, voxel_index(p, 1.0f / leaf, v))];
+    const int r = table_rank[slot];
     const int off = vox_member_off[sl.base + r], n = vox_fill[sl.base + r];
     const int* m = members + sl.base + off;
     int rank = 0, k = 0;
@@ -1303,8 +1338,8 @@ void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* 
     if (nscans) hipLaunchKernelGGL(k_voxel_params, dim3((nscans + 63) / 64), dim3(64), 0, st, bbox_enc, count, nscans, leaf, vp);
 }
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts);
+                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
@@ -1318,17 +1353,16 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
     hipLaunchKernelGGL(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
                        table_rank, vox_keys, vox_member_off, n_vox, status);
 }
-void launch_voxel_fill(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                       float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* vox_member_off,
-                       int* vox_fill, int* members, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_rank, vox_member_off, vox_fill, members);
+void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
+                       const int* table_rank, const int* vox_member_off, int* vox_fill, int* members, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3(nblocks), dim3(kSegBlock), 0, st, count, slots, blocks, vp, pt_slot, table_rank, vox_member_off, vox_fill, members);
 }
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                           float leaf, const VoxelParams* vp, const int* table_keys, const int* table_rank, const int* n_vox,
+                           float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
                            const int* vox_member_off, const int* vox_fill, const int* members, void* recs, PointXYZINormal* out,
                            int* out_count, hipStream_t st) {
     if (!nblocks) return;
-    hipLaunchKernelGGL(k_voxel_rank, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_rank,
+    hipLaunchKernelGGL(k_voxel_rank, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
                        vox_member_off, vox_fill, members, (CentroidRec*)recs);
     hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
                        vox_fill, (const CentroidRec*)recs, out, out_count);
