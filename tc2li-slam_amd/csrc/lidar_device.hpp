@@ -60,7 +60,7 @@ void launch_voxel_bbox(const PointXYZINormal* pts, const int* count, const ScanS
 void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* slots, int nscans, float leaf, VoxelParams* vp,
                          hipStream_t st);
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, hipStream_t st);
+                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st);
 void launch_fill_int(int* p, size_t n, int v, hipStream_t st);
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys, const int* table_counts,
                        int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status, hipStream_t st);

@@ -119,9 +119,10 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     launch_fill_int(L->d_table_keys.p, (size_t)S * L->table_size, -1, st);
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_vox_fill.p, 0, (size_t)S * L->cap * sizeof(int), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_n_vox.p, 0, (size_t)S * sizeof(int), st));
     launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
     launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
-    launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, L->d_pt_slot.p, st);
+    launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, L->d_pt_slot.p, L->d_n_vox.p, L->d_vox_keys.p, st);
     launch_voxel_sort(L->d_slots.p, S, L->d_vp.p, d_in_count, L->d_table_keys.p, L->d_table_counts.p, L->d_table_rank.p, L->d_vox_keys.p,
                       L->d_member_off.p, L->d_n_vox.p, L->d_status.p, st);
     launch_voxel_fill(d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_vp.p, L->d_pt_slot.p, L->d_table_rank.p, L->d_member_off.p, L->d_vox_fill.p,

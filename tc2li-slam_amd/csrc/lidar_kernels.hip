@@ -200,6 +200,7 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // Neighbouring returns of a scan mostly fall into the same voxel: lanes that continue their left neighbour's voxel (a "run")
 // leave the table work to the run's first lane -- one CAS probe and one counter atomic per run instead of per point -- and take
 // its slot by shuffle.  pt_slot keeps every point's table slot for the later passes (-1: point not filtered).
+constexpr int kMaxVoxelsPerScan = 32768;  // voxels of one scan the LDS sort holds
 struct RunInfo { bool head; int head_lane, length; };
 __device__ __forceinline__ RunInfo wave_runs(int key) {
     const int lane = threadIdx.x & 63;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
                                                             const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                             float leaf, const VoxelParams* __restrict__ vp,
                                                             int* __restrict__ table_keys, int* __restrict__ table_counts,
-                                                            int* __restrict__ pt_slot) {
+                                                            int* __restrict__ pt_slot, int* __restrict__ n_vox, int* __restrict__ vox_keys) {
     const SegBlock b = blocks[blockIdx.x];
     const int i = b.start + threadIdx.x, n = count[b.scan];
     if (b.start >= n) return;  // whole workgroup
@@ -232,13 +233,17 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
         valid = finite3(p);
         if (valid) idx = voxel_index(p, 1.0f / leaf, v);
     }
+    __shared__ int s_new[kSegBlock], s_n_new, s_first;
+    if (threadIdx.x == 0) s_n_new = 0;
+    __syncthreads();
     const RunInfo run = wave_runs(idx);
     int slot = -1;
     if (run.head && valid) {
         uint32_t h = hash_u32((uint32_t)idx) & (uint32_t)v.table_mask;
         for (;;) {
             const int prev = atomicCAS(&table_keys[v.table_base + h], -1, idx);
-            if (prev == -1 || prev == idx) break;
+            if (prev == -1) { s_new[atomicAdd(&s_n_new, 1)] = idx; break; }  // a voxel nobody had seen: listed below
+            if (prev == idx) break;
             h = (h + 1) & (uint32_t)v.table_mask;
         }
         slot = v.table_base + (int)h;
@@ -246,6 +251,15 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
     }
     slot = __shfl(slot, run.head_lane, 64);
     if (i < n) pt_slot[base + i] = valid ? slot : -1;
+    // the keys of the scan's voxels in arrival order: the sort reads this list, not the 2 x capacity table; one global atomic per workgroup
+    __syncthreads();
+    const int n_new = s_n_new;
+    if (threadIdx.x == 0 && n_new > 0) s_first = atomicAdd(&n_vox[b.scan], n_new);
+    __syncthreads();
+    if ((int)threadIdx.x < n_new) {
+        const int pos = s_first + (int)threadIdx.x;
+        if (pos < kMaxVoxelsPerScan) vox_keys[base + pos] = s_new[threadIdx.x];
+    }
 }
 
 __device__ __forceinline__ int table_find(const int* __restrict__ table_keys, const VoxelParams& v, int idx) {
@@ -256,7 +270,6 @@ __device__ __forceinline__ int table_find(const int* __restrict__ table_keys, co
 
 // One workgroup per scan: gather the occupied voxel keys, bitonic-sort them ascending in LDS (PCL emits voxels in
 // ascending index order), publish rank and member offsets.
-constexpr int kMaxVoxelsPerScan = 32768;
 __global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict__ slots, const VoxelParams* __restrict__ vp,
                                                      const int* __restrict__ count, const int* __restrict__ table_keys,
                                                      const int* __restrict__ table_counts, int* __restrict__ table_rank,
@@ -269,19 +282,12 @@ __global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict_
     const ScanSlot sl = slots[s];
     const VoxelParams v = vp[s];
     if (v.passthrough) { if (tid == 0) n_vox[s] = count[s]; return; }
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    const int tsize = v.table_mask + 1;
-    for (int k = tid; k < tsize; k += 1024) {
-        const int key = table_keys[v.table_base + k];
-        if (key != -1) {
-            const int pos = atomicAdd(&s_n, 1);
-            if (pos < kMaxVoxelsPerScan) s_keys[pos] = key;
-        }
-    }
+    if (tid == 0) s_n = n_vox[s];  // the insert pass counted the scan's voxels and listed their keys (in arrival order)
     __syncthreads();
     int n = s_n;
     if (n > kMaxVoxelsPerScan) { if (tid == 0) { atomicExch(status, 1); n_vox[s] = 0; } return; }
+    for (int k = tid; k < n; k += 1024) s_keys[k] = vox_keys[sl.base + k];
+    __syncthreads();
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     for (int k = n + tid; k < np2; k += 1024) s_keys[k] = 0x7fffffff;
@@ -1338,8 +1344,8 @@ void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* 
     if (nscans) hipLaunchKernelGGL(k_voxel_params, dim3((nscans + 63) / 64), dim3(64), 0, st, bbox_enc, count, nscans, leaf, vp);
 }
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
-                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot);
+                         float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st) {
+    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
