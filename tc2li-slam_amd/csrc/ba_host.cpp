@@ -862,6 +862,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
             hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
+        if (getenv("TC2LI_BA_TIMING")) {
+            int pr = 0;
+            (void)hipStreamGetPriority(C.st, &pr);
+            fprintf(stderr, "BA lock-step stream: priority %d (device range least %d .. greatest %d)\n", pr, lo, hi);
+        }
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
