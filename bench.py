@@ -236,6 +236,7 @@ def main():
 
         def timed(fn):
             def wrapped():
+                torch.cuda.set_device(local_rank)  # HIP's current device is per thread; a new thread starts on device 0
                 t = time.perf_counter()
                 fn()
                 thread_ms[fn.__name__] = 1e3 * (time.perf_counter() - t) / max(n_steps, 1)

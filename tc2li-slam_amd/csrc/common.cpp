@@ -59,7 +59,7 @@ WorkerPool::~WorkerPool() {
 }
 
 void WorkerPool::loop() {
-    int seen = 0;
+    int seen = 0, dev = -1, my_dev = -1;
     for (;;) {
         const std::function<void(int)>* fn;
         int n;
@@ -72,7 +72,10 @@ void WorkerPool::loop() {
             n = n_;
             if (!fn) continue;  // woke after that generation had already been drained
             ++active_;
+            dev = device_;
         }
+        // the work runs on the caller's GPU (one process may see several; a worker thread would otherwise launch on device 0)
+        if (dev >= 0 && dev != my_dev && hipSetDevice(dev) == hipSuccess) my_dev = dev;
         for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -94,6 +97,9 @@ void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
         fn_ = &fn;
         n_ = n;
         next_.store(0);
+        int d = -1;
+        device_ = hipGetDevice(&d) == hipSuccess ? d : -1;
+        if (device_ < 0) (void)hipGetLastError();  // no device: host-only work
         ++generation_;
     }
     cv_.notify_all();

@@ -95,6 +95,7 @@ private:
     const std::function<void(int)>* fn_ = nullptr;
     std::atomic<int> next_{0};
     int n_ = 0, generation_ = 0, active_ = 0;
+    int device_ = -1;  // HIP device of the thread that called parallel_for: the current device is per thread, and a new thread starts on device 0
     bool stop_ = false;
 };
 
