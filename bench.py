@@ -349,7 +349,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port) with the reference's threading -----------------------------------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed at N = 1 only
         from oracle import pyoracle
         pyoracle.build()
         L = pyoracle.lib()
