@@ -12,8 +12,10 @@ ARGS="bench.py --no-cpu-baseline --steps 8 --warmup 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $ARGS > $OUT/bench_write.log 2>&1
+# matrix-unit occupancy of the Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $ARGS > $OUT/bench_mfma.log 2>&1
 python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma

@@ -44,3 +44,22 @@ json.dump(res, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1, sort_k
 top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
 for k, v in top:
     print("%-40s launches %5d  fetch %12.0f B  write %12.0f B per launch" % (k[:40], v["launches"], v["fetch_bytes_per_launch"] or 0, v["write_bytes_per_launch"] or 0))
+
+
+# ---- matrix-unit occupancy (the Schur GEMM is the only MFMA user): SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed over the SIMDs that
+# ran the kernel; SQ_BUSY_CYCLES is the time the SQ had any wave of the dispatch, per shader engine / XCD instance as rocprofv3 sums it
+mf = counter_per_kernel("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+busy = counter_per_kernel("pmc_mfma", "SQ_BUSY_CYCLES")
+wave = counter_per_kernel("pmc_mfma", "SQ_WAVE_CYCLES")
+mres = {}
+for k, (n, v) in mf.items():
+    if v <= 0:
+        continue
+    b, w = busy.get(k, [0, 0.0]), wave.get(k, [0, 0.0])
+    mres[k] = {"launches": n, "mfma_busy_cycles_per_launch": v / n, "sq_busy_cycles_per_launch": b[1] / b[0] if b[0] else None,
+               "sq_wave_cycles_per_launch": w[1] / w[0] if w[0] else None}
+if mres:
+    json.dump(mres, open("profiles/%s_pmc_mfma.json" % tag, "w"), indent=1, sort_keys=True)
+    for k, v in mres.items():
+        print("MFMA %-40s launches %5d  mfma busy %12.0f  sq busy %12.0f  wave cycles %12.0f per launch" %
+              (k[:40], v["launches"], v["mfma_busy_cycles_per_launch"], v["sq_busy_cycles_per_launch"] or 0, v["sq_wave_cycles_per_launch"] or 0))
