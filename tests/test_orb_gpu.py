@@ -162,3 +162,45 @@ def test_blur_row_ends(pkg, oracle, synthetic, width):
     ora.extract(img)
     for level in range(8):
         assert np.array_equal(ext.blurred_level(0, level), ora.blurred(level)), (width, level)
+
+
+@pytest.mark.parametrize("n_images", [17, 66])
+def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_images):
+    """tc2li_orb_extract_batch pipelines chunks of images (2 chunks from 16 images, 4 from 64): every image's features, its
+    diagnostics and the stereo matcher's view of the batch are those of the unchunked path."""
+    import torch
+    w, h = 640, 300
+    base_l, base_r = synthetic.stereo_pair(9, 1242, 375)
+    imgs = np.empty((n_images, h, w), np.uint8)
+    for i in range(n_images):  # different windows of the scene, every image distinct
+        src = base_l if i % 2 == 0 else base_r
+        x0, y0 = (37 * i) % (1242 - w), (11 * i) % (375 - h)
+        imgs[i] = src[y0:y0 + h, x0:x0 + w]
+    e = pkg.OrbExtractor(max_width=w, max_height=h, max_images=n_images)
+    single = pkg.OrbExtractor(max_width=w, max_height=h, max_images=1)
+    dev = torch.from_numpy(imgs).cuda()
+    kps, desc, counts, mono = e.extract_batch_dev(dev.data_ptr(), n_images, w, h, w, w * h)
+    assert e.last_chunks() == (2 if n_images < 64 else 4)
+    o = oracle.OrbOracle()
+    for i in range(n_images):
+        m, k, d = single.extract(imgs[i])
+        n = int(counts[i])
+        assert n == len(k) and int(mono[i]) == m, i
+        for f in FIELDS:
+            assert np.array_equal(kps[i, :n][f], k[f]), (i, f)
+        assert np.array_equal(desc[i, :n], d), i
+    for i in (0, n_images // 2, n_images - 1):  # chunk boundaries against the oracle, with the per-image diagnostics
+        want = o.extract(imgs[i])
+        assert int(counts[i]) == len(want[1]) and np.array_equal(desc[i, :len(want[1])], want[2])
+        assert np.array_equal(e.candidates(i, 0), o.candidates(0)) and np.array_equal(e.blurred_level(i, 3), o.blurred(3))
+    # the device-resident features feed the batched stereo matcher: frames (0,1), (2,3), ...
+    nf = n_images // 2
+    bf, b = float(np.float32(synthetic.BF)), float(np.float32(synthetic.BF) / np.float32(synthetic.FX))
+    u_right, depth, _ = pkg.stereo_match_batch(e, nf, bf, b)
+    for f in (0, nf - 1):
+        ol, orr = oracle.OrbOracle(), oracle.OrbOracle()
+        _, kl, dl = ol.extract(imgs[2 * f])
+        _, kr, dr = orr.extract(imgs[2 * f + 1])
+        wu, wd, _ = oracle.stereo_match(ol, orr, kl, dl, kr, dr, bf, b)
+        assert np.array_equal(u_right[f, :len(kl)], wu) and np.array_equal(depth[f, :len(kl)], wd)
+    e.close(); single.close()
