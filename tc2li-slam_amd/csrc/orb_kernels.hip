@@ -135,6 +135,7 @@ __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
 }
 
 // TH x TW: the largest cell window the instantiation holds (LDS is sized by it: the small variant fits 8 workgroups per CU)
+__constant__ int c_fast_stop = 99;  // TEMP diagnostics
 template <int TH, int TW>
 __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
@@ -168,17 +169,29 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     auto mis = [&](int y) { return (int)((mis0 + (uint32_t)y * pm) & 3u); };
     {
         constexpr int kDw = kTileP / 4;  // dwords per tile row
-        for (int i = tid; i < h * kDw; i += 256) {
+        constexpr int kRounds = (TH * kDw + 255) / 256;
+        // every load of the workgroup is requested before the first one is waited for (a dependent loop would pay the global
+        // latency once per round: the staging was a quarter of the kernel)
+        uint32_t v[kRounds];
+        bool ok[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int i = tid + 256 * r;
             const int y = i / kDw, j = i - y * kDw;
-            const uint8_t* row = src + (size_t)y * L.pitch;
             const int m = mis(y);
-            if (4 * j - m < w) tile32[i] = *as_global(reinterpret_cast<const uint32_t*>(row - m + 4 * j));
+            ok[r] = i < h * kDw && 4 * j - m < w;
+            v[r] = 0;
+            if (ok[r]) v[r] = *as_global(reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch - m + 4 * j));
         }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r)
+            if (ok[r]) tile32[tid + 256 * r] = v[r];
         uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
         for (int i = tid; i < h * (TW / 4); i += 256) score32[i] = 0;
     }
     if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; s_nkept = 0; }
     __syncthreads();
+    if (c_fast_stop == 0) return;
 
     const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
     const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         if (bright || dark) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(cy * TW + cx);
     }
     __syncthreads();
+    if (c_fast_stop == 1) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 1, the pixels that passed, packed densely over the lanes: the segment test proper (two 16-bit masks, "9 contiguous"
     // by shifts); the list is compacted in place -- a round reads its 256 entries before any of them is overwritten, and what a
     // round appends lies below the entries of the later rounds.
@@ -240,6 +254,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         }
     }
     __syncthreads();
+    if (c_fast_stop == 2) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 2, survivors only, packed densely over the lanes: S = the largest arc contrast of the polarity that has an arc
     // (the other polarity cannot exceed the threshold, so it cannot be the maximum).
     const int nlist = s_nlist;
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         score[at] = (uint8_t)S;
     }
     __syncthreads();
+    if (c_fast_stop == 3) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 3, survivors only: 3x3 strict non-max suppression for both thresholds (every survivor has S > minTh; a neighbour
     // counts with its score only where it is a corner at the threshold in question, cv::FAST's score buffer semantics)
     int my_ini = 0;
@@ -590,6 +606,7 @@ void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, in
                  size_t slab_img_stride, int* cell_counts, int nimg, int max_cell_w, int max_cell_h, hipStream_t st) {
     // cell windows are 35-px cells + 6: 48 x 48 covers every image of at least ~330 px per side; the full-size variant is for tiny levels
     const int blocks = ((ncells * nimg + 7) / 8) * 8;
+    { static bool once = false; if (!once && getenv("TC2LI_FAST_STOP")) { int v = atoi(getenv("TC2LI_FAST_STOP")); (void)hipMemcpyToSymbol(HIP_SYMBOL(c_fast_stop), &v, sizeof(int)); } once = true; }
     if (max_cell_w <= 48 && max_cell_h <= 48)
         hipLaunchKernelGGL((k_fast_cells<48, 48>), dim3(blocks), dim3(256), 0, st, levels, cells, ini_th, min_th, slab, slab_img_stride, cell_counts, ncells, nimg);
     else
