@@ -335,9 +335,11 @@ def main():
     traffic = None
     for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         pmc = json.load(open(f))
-        hit = [v for k, v in pmc.items() if k.split("::")[-1].split("<")[0] == names[dom]]
-        if hit and hit[0].get("hbm_bytes_per_launch"):
-            traffic = {"bytes_per_launch": int(hit[0]["hbm_bytes_per_launch"]), "source": os.path.basename(f),
+        # template instantiations of one kernel (FAST: the 48 x 48 and the full-size window variant, launched back to back per chunk)
+        # count as one launch of the stage
+        hit = [v for k, v in pmc.items() if k.split("::")[-1].split("<")[0] == names[dom] and v.get("hbm_bytes_per_launch")]
+        if hit:
+            traffic = {"bytes_per_launch": int(sum(v["hbm_bytes_per_launch"] for v in hit)), "source": os.path.basename(f),
                        "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch, from the rocprofv3 --pmc passes of this same command"}
             break
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",

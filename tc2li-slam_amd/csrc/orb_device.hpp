@@ -35,7 +35,8 @@ struct DevKeypoint {
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st);
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
-                 size_t slab_img_stride, int* cell_counts, int nimg, int max_cell_w, int max_cell_h, hipStream_t st);
+                 size_t slab_img_stride, int* cell_counts, int nimg, const int* small_ids, int n_small, const int* large_ids, int n_large,
+                 hipStream_t st);
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
                     const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
                     int* level_counts, int nlevels, int nimg, hipStream_t st);

@@ -21,7 +21,9 @@ struct LevelGeom {
 struct tc2li_orb {
     tc2li_orb_params prm{};
     int max_w = 0, max_h = 0, max_images = 0;
-    int max_cell_w = 0, max_cell_h = 0;  // largest FAST cell window of the current geometry (selects the kernel variant)
+    int max_cell_w = 0, max_cell_h = 0;  // largest FAST cell window of the current geometry
+    tc2li::DevBuf<int> d_cell_ids;       // cells whose window fits 48 x 48, then the others (one kernel variant each)
+    int n_small_cells = 0, n_large_cells = 0;
     // ctor tables (SF/src/ORBextractor.cc:388-442)
     std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
     std::vector<int> features_per_level;

@@ -119,6 +119,14 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
         }
     }
     level_cell_begin[L] = (int)o->cells.size();
+    {
+        std::vector<int> ids, large;
+        for (int k = 0; k < (int)o->cells.size(); ++k) (o->cells[k].w <= 48 && o->cells[k].h <= 48 ? ids : large).push_back(k);
+        o->n_small_cells = (int)ids.size(); o->n_large_cells = (int)large.size();
+        ids.insert(ids.end(), large.begin(), large.end());
+        if (ids.empty()) ids.push_back(0);
+        TC2LI_HIP_CHECK(o->d_cell_ids.upload(ids));
+    }
     o->slab_per_image = align_up(std::max(slab, 1), 64);
     o->kp_cap_per_image = o->prm.nfeatures + 4 * L;
     for (int l = 0; l < L; ++l) o->kp_cap_per_image += 0;
@@ -320,7 +328,8 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 8), st));
         if (ncells > 0) {
             launch_fast(craw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p + (size_t)i0 * o->slab_per_image,
-                        (size_t)o->slab_per_image, o->d_cell_counts.p + (size_t)i0 * ncells, m, o->max_cell_w, o->max_cell_h, st);
+                        (size_t)o->slab_per_image, o->d_cell_counts.p + (size_t)i0 * ncells, m, o->d_cell_ids.p, o->n_small_cells,
+                        o->d_cell_ids.p + o->n_small_cells, o->n_large_cells, st);
             TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
             launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p + (size_t)i0 * ncells, ncells,
                            o->d_slab.p + (size_t)i0 * o->slab_per_image, (size_t)o->slab_per_image,

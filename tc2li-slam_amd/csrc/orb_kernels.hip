@@ -135,11 +135,12 @@ __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
 }
 
 // TH x TW: the largest cell window the instantiation holds (LDS is sized by it: the small variant fits 8 workgroups per CU)
-__constant__ int c_fast_stop = 99;  // TEMP diagnostics
+constexpr int kFastThreads = 256;  // threads per cell (128 was tried: the all-pixel passes dominate, 1.13 ms against 0.89 ms)
 template <int TH, int TW>
-__global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
+__global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
-                                                    int* __restrict__ cell_counts, int ncells, int nimg) {
+                                                    int* __restrict__ cell_counts, int ncells, int nimg,
+                                                    const int* __restrict__ cell_ids, int n_ids) {
     // The window rows are staged as the aligned dwords they come in: pixel (x, y) of the window is byte
     // y * kTileP + x + mis(y) of the tile, mis(y) = byte offset of row y inside its first dword (rows of the caller's image
     // start at any byte address).
@@ -157,10 +158,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     // share cache lines (a 42-byte window row is a third of a line, windows overlap by 6 px), so XCD k takes the k-th contiguous
     // eighth of the (image, cell) list instead of every 8th cell: without this every line was fetched by ~4 XCDs (389 MB of HBM
     // reads per launch for 96 MB of pixels in the first PMC profile).
-    const int total = ncells * nimg, per_xcd = (total + 7) / 8;
+    // cell_ids: the cells this launch covers (the windows that fit the instantiation's tile), n_ids of the ncells of an image
+    const int total = n_ids * nimg, per_xcd = (total + 7) / 8;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= total) return;
-    const int tid = threadIdx.x, img = logical / ncells, cell = logical - img * ncells;
+    const int tid = threadIdx.x, img = logical / n_ids, cell = cell_ids[logical - img * n_ids];
     const FastCell c = cells[cell];
     const LevelDesc L = levels.lv[c.level];
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
@@ -169,14 +171,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     auto mis = [&](int y) { return (int)((mis0 + (uint32_t)y * pm) & 3u); };
     {
         constexpr int kDw = kTileP / 4;  // dwords per tile row
-        constexpr int kRounds = (TH * kDw + 255) / 256;
+        constexpr int kRounds = (TH * kDw + kFastThreads - 1) / kFastThreads;
         // every load of the workgroup is requested before the first one is waited for (a dependent loop would pay the global
         // latency once per round: the staging was a quarter of the kernel)
         uint32_t v[kRounds];
         bool ok[kRounds];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
-            const int i = tid + 256 * r;
+            const int i = tid + kFastThreads * r;
             const int y = i / kDw, j = i - y * kDw;
             const int m = mis(y);
             ok[r] = i < h * kDw && 4 * j - m < w;
@@ -185,13 +187,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         }
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
-            if (ok[r]) tile32[tid + 256 * r] = v[r];
+            if (ok[r]) tile32[tid + kFastThreads * r] = v[r];
         uint32_t* score32 = reinterpret_cast<uint32_t*>(score);
-        for (int i = tid; i < h * (TW / 4); i += 256) score32[i] = 0;
+        for (int i = tid; i < h * (TW / 4); i += kFastThreads) score32[i] = 0;
     }
     if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; s_nkept = 0; }
     __syncthreads();
-    if (c_fast_stop == 0) return;
 
     const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
     const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     // Pass 0, every pixel: a necessary condition of the segment test on the four compass pixels -- nine contiguous circle pixels
     // always contain pixel 0 or 8 and pixel 4 or 12, so a brighter (darker) arc needs (p0 | p8) & (p4 | p12) brighter (darker).
     // Most pixels of an image stop here after five LDS bytes; the others are appended to a list (any order).
-    for (int i = tid; i < npix; i += 256) {
+    for (int i = tid; i < npix; i += kFastThreads) {
         const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
         const int cx = ex + 3, cy = ey + 3;
         const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
@@ -224,16 +225,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         if (bright || dark) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(cy * TW + cx);
     }
     __syncthreads();
-    if (c_fast_stop == 1) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 1, the pixels that passed, packed densely over the lanes: the segment test proper (two 16-bit masks, "9 contiguous"
-    // by shifts); the list is compacted in place -- a round reads its 256 entries before any of them is overwritten, and what a
+    // by shifts); the list is compacted in place -- a round reads its kFastThreads entries before any of them is overwritten, and what a
     // round appends lies below the entries of the later rounds.
     {
         const int npre = s_nlist;
         __syncthreads();
         if (tid == 0) s_nlist = 0;
         __syncthreads();
-        for (int base = 0; base < npre; base += 256) {
+        for (int base = 0; base < npre; base += kFastThreads) {
             const int k = base + tid;
             uint32_t entry = 0;
             if (k < npre) {
@@ -254,11 +254,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         }
     }
     __syncthreads();
-    if (c_fast_stop == 2) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 2, survivors only, packed densely over the lanes: S = the largest arc contrast of the polarity that has an arc
     // (the other polarity cannot exceed the threshold, so it cannot be the maximum).
     const int nlist = s_nlist;
-    for (int k = tid; k < nlist; k += 256) {
+    for (int k = tid; k < nlist; k += kFastThreads) {
         const uint32_t e = s_list[k];
         const int at = e & 0x3fff, cy = at / TW, cx = at - cy * TW;
         int p[16];
@@ -269,11 +268,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
         score[at] = (uint8_t)S;
     }
     __syncthreads();
-    if (c_fast_stop == 3) { if (tid == 0) cell_counts[(size_t)img * ncells + cell] = 0; return; }
     // Pass 3, survivors only: 3x3 strict non-max suppression for both thresholds (every survivor has S > minTh; a neighbour
     // counts with its score only where it is a corner at the threshold in question, cv::FAST's score buffer semantics)
     int my_ini = 0;
-    for (int k = tid; k < nlist; k += 256) {
+    for (int k = tid; k < nlist; k += kFastThreads) {
         const int at = s_list[k] & 0x3fff;
         const uint8_t* sc = score + at;
         const int S = sc[0];
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     const int sel = s_cnt_ini > 0 ? 1 : 2;
     // Emission in row-major order (the order cv::FAST returns the keypoints in): the kept survivors are gathered (a few tens
     // per cell; strict 3x3 maxima: at most one per 2x2 block), the rank of each among them is its output slot.
-    for (int k = tid; k < nlist; k += 256)
+    for (int k = tid; k < nlist; k += kFastThreads)
         if (s_flag[k] & sel) {
             const int slot = atomicAdd(&s_nkept, 1);
             if (slot < kMaxKept) s_kept[slot] = (uint16_t)(s_list[k] & 0x3fff);
@@ -303,7 +301,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(LevelTable levels, const Fas
     __syncthreads();
     const int nkept = s_nkept, nk = min(nkept, kMaxKept);
     uint32_t* out = slab + (size_t)img * slab_img_stride + c.slab_off;
-    for (int k = tid; k < nk; k += 256) {
+    for (int k = tid; k < nk; k += kFastThreads) {
         const int at = s_kept[k];
         int rank = 0;
         for (int j = 0; j < nk; ++j) rank += (int)s_kept[j] < at ? 1 : 0;
@@ -603,15 +601,16 @@ void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, 
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
-                 size_t slab_img_stride, int* cell_counts, int nimg, int max_cell_w, int max_cell_h, hipStream_t st) {
-    // cell windows are 35-px cells + 6: 48 x 48 covers every image of at least ~330 px per side; the full-size variant is for tiny levels
-    const int blocks = ((ncells * nimg + 7) / 8) * 8;
-    { static bool once = false; if (!once && getenv("TC2LI_FAST_STOP")) { int v = atoi(getenv("TC2LI_FAST_STOP")); (void)hipMemcpyToSymbol(HIP_SYMBOL(c_fast_stop), &v, sizeof(int)); } once = true; }
-    if (max_cell_w <= 48 && max_cell_h <= 48)
-        hipLaunchKernelGGL((k_fast_cells<48, 48>), dim3(blocks), dim3(256), 0, st, levels, cells, ini_th, min_th, slab, slab_img_stride, cell_counts, ncells, nimg);
-    else
-        hipLaunchKernelGGL((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(blocks), dim3(256), 0, st, levels, cells, ini_th, min_th, slab, slab_img_stride,
-                           cell_counts, ncells, nimg);
+                 size_t slab_img_stride, int* cell_counts, int nimg, const int* small_ids, int n_small, const int* large_ids, int n_large,
+                 hipStream_t st) {
+    // cell windows are 35-px cells + 6: 48 x 48 holds all but the levels whose height leaves one or two tall rows of cells; those go
+    // through the full-size variant (a third of the LDS-limited occupancy), each window class in its own launch
+    if (n_small > 0)
+        hipLaunchKernelGGL((k_fast_cells<48, 48>), dim3(((n_small * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th, min_th, slab,
+                           slab_img_stride, cell_counts, ncells, nimg, small_ids, n_small);
+    if (n_large > 0)
+        hipLaunchKernelGGL((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(((n_large * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th,
+                           min_th, slab, slab_img_stride, cell_counts, ncells, nimg, large_ids, n_large);
 }
 
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
