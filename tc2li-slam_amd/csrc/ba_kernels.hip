@@ -167,26 +167,59 @@ __device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int b
     pb.diag_l[l] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
 }
 
-// Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.
+// Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.  The tree is the one a 256-entry
+// LDS array would be folded with (t += t + 128, t += t + 64, ... , t += t + 1), so the bits do not depend on how it is carried out:
+// the two folds that cross wavefronts go through LDS in chunks of kSumChunk values (128 x kSumChunk doubles instead of 256 x WIDTH:
+// a 55 KB workgroup had to wait for half a CU's LDS on a busy GPU), the six inside wavefront 0 are shuffles.
+constexpr int kSumChunk = 9;
 template <int WIDTH, int STRIDE = WIDTH>
 __device__ __forceinline__ void block_sum_items(const double* __restrict__ items, const int* __restrict__ index, int begin, int end,
-                                                double* s_part /*[256][WIDTH]*/, double* out) {
+                                                double* s_part /*[128][min(WIDTH, kSumChunk)]*/, double* out) {
+    constexpr int CH = WIDTH < kSumChunk ? WIDTH : kSumChunk;
+    const int tid = threadIdx.x;
     double acc[WIDTH];
+#pragma unroll
     for (int i = 0; i < WIDTH; ++i) acc[i] = 0;
-    for (int k = begin + (int)threadIdx.x; k < end; k += 256) {
+    for (int k = begin + tid; k < end; k += 256) {
         double c[STRIDE];
         load_d2<STRIDE>(items + STRIDE * (size_t)(index ? index[k] : k), c);  // STRIDE is even: records are 16-byte aligned
 #pragma unroll
         for (int i = 0; i < WIDTH; ++i) acc[i] += c[i];
     }
-    for (int i = 0; i < WIDTH; ++i) s_part[threadIdx.x * WIDTH + i] = acc[i];
-    __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int i = 0; i < WIDTH; ++i) s_part[threadIdx.x * WIDTH + i] += s_part[(threadIdx.x + s) * WIDTH + i];
+#pragma unroll
+    for (int c0 = 0; c0 < WIDTH; c0 += CH) {
         __syncthreads();
+        if (tid >= 128) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) if (c0 + i < WIDTH) s_part[(tid - 128) * CH + i] = acc[c0 + i];
+        }
+        __syncthreads();
+        if (tid < 128) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) if (c0 + i < WIDTH) acc[c0 + i] += s_part[tid * CH + i];
+        }
+        __syncthreads();
+        if (tid >= 64 && tid < 128) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) if (c0 + i < WIDTH) s_part[(tid - 64) * CH + i] = acc[c0 + i];
+        }
+        __syncthreads();
+        if (tid < 64) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) if (c0 + i < WIDTH) acc[c0 + i] += s_part[tid * CH + i];
+        }
     }
-    if (threadIdx.x < WIDTH) out[threadIdx.x] = s_part[threadIdx.x];
+    if (tid < 64) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+#pragma unroll
+            for (int i = 0; i < WIDTH; ++i) acc[i] += __shfl_down(acc[i], sft, 64);  // lanes >= sft compute values nobody reads
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < WIDTH; ++i) out[i] = acc[i];
+        }
+    }
     __syncthreads();
 }
 
@@ -217,7 +250,7 @@ __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, 
 // One launch after k_ba_linearize: workgroups [0, nbp) sum the landmark blocks, [nbp, nbp + n_free) the pose blocks, the
 // last one the robust cost (the three jobs only read what the linearisation wrote).
 __device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, int nbp, double* __restrict__ chi_out) {
-    __shared__ double s_part[256 * 27];
+    __shared__ double s_part[128 * kSumChunk];  // block_sum_items' two cross-wavefront folds (also >= the 256 of block_reduce_256)
     const int b = bx;
     if (b < nbp) reduce_points_body(pb, b);
     else if (b < nbp + pb.n_free) reduce_poses_body(pb, b - nbp, s_part);
@@ -305,7 +338,7 @@ __device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const
 __global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int nbp, double lambda) { d_ba_schur_prepare(pb, blockIdx.x, nbp, lambda); }
 
 __device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const int bx) {
-    __shared__ double s_part[256 * 6];
+    __shared__ double s_part[128 * 6];
     const int i = bx;
     block_sum_items<6>(pb.coef_e, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.coef + 6 * (size_t)i);
 }
