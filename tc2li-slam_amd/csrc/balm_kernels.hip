@@ -18,8 +18,12 @@ namespace tc2li {
 // 256 threads per workgroup: the per-slot algebra needs well over 128 registers (1024-thread workgroups cap a thread at
 // 128 and spilled 512 B per lane to scratch: 67 MB of scratch writes per launch in the first profile).
 constexpr int kHessThreads = 256;
-constexpr int kItemsSmall = 4, kItemsLarge = 30;  // Hessian entries owned per thread: windows of <= 7 / <= 20 keyframes
-static_assert(7 * 8 / 2 * 36 <= kHessThreads * kItemsSmall, "small window does not fit");
+// Hessian entries owned per thread: windows of <= 7 / <= 20 keyframes.  The small-window form is ONE wavefront per plane: the kernel
+// needs ~200 VGPRs, and a 256-thread workgroup of it has to find that room on all four SIMDs of a CU at once -- on a GPU shared with
+// the front end its launches waited (72 us on average in the loop against 35 us alone); a single wavefront fits wherever one SIMD has room.
+constexpr int kHessThreadsSmall = 64;
+constexpr int kItemsSmall = 16, kItemsLarge = 30;
+static_assert(7 * 8 / 2 * 36 <= kHessThreadsSmall * kItemsSmall, "small window does not fit");
 static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsLarge, "window too large for the item ownership");
 
 // LiDAR poses of the window slots from the vertex estimates (LidarCovisRes::UpdatePose), into LDS of the calling workgroup
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
     sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
 }
 
-template <int kItemsPerThread>
+template <int kItemsPerThread, int NT>
 __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx) {
     __shared__ LidarPose s_twl[kMaxLidarWindow];
     __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
@@ -205,7 +209,7 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < kItemsPerThread; ++k) {
-            const int item = k * kHessThreads + tid;
+            const int item = k * NT + tid;
             if (item >= n_items) continue;
             const int pair = item / 36, rc = item % 36, r = rc / 6, c = rc % 6;
             const int i = s_pi[pair], j = s_pj[pair];
@@ -230,15 +234,15 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
     double* part = b.part + (size_t)bx * (n_items + 6 * W + 1);
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) {
-        const int item = k * kHessThreads + tid;
+        const int item = k * NT + tid;
         if (item < n_items) part[item] = acc[k];
     }
     if (tid < W)
         for (int c = 0; c < 6; ++c) part[n_items + 6 * tid + c] = jac[c];
     if (tid == 0) part[n_items + 6 * W] = res;
 }
-template <int kItemsPerThread>
-__global__ __launch_bounds__(kHessThreads) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) { d_balm_hessian<kItemsPerThread>(b, poses, blockIdx.x); }
+template <int kItemsPerThread, int NT>
+__global__ __launch_bounds__(NT) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) { d_balm_hessian<kItemsPerThread, NT>(b, poses, blockIdx.x); }
 
 // chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one
 // wavefront per output value, its lanes add the chunks in a fixed order (strided partial sums, then shuffles).
@@ -274,8 +278,8 @@ void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
 }
 
 void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
-    if (b.W <= 7) hipLaunchKernelGGL(k_balm_hessian<kItemsSmall>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
-    else hipLaunchKernelGGL(k_balm_hessian<kItemsLarge>, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    if (b.W <= 7) hipLaunchKernelGGL((k_balm_hessian<kItemsSmall, kHessThreadsSmall>), dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
+    else hipLaunchKernelGGL((k_balm_hessian<kItemsLarge, kHessThreads>), dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
     hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
 }
 
@@ -289,11 +293,11 @@ __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaBatchSlot
     const BalmDev b = sl.balm;
     d_balm_residual_total(b, slot_poses(sl, trial != 0));
 }
-__global__ __launch_bounds__(kHessThreads) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+__global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
     const BaBatchSlot& sl = slots[list[blockIdx.y]];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= b.n_chunks) return;
-    d_balm_hessian<kItemsSmall>(b, slot_poses(sl, false), blockIdx.x);
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall>(b, slot_poses(sl, false), blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
     const BaBatchSlot& sl = slots[list[blockIdx.y]];
@@ -306,7 +310,7 @@ void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n
 }
 void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreads), 0, st, slots, list);
+    hipLaunchKernelGGL(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, slots, list);
     hipLaunchKernelGGL(k_balm_combine_b, dim3((balm_part_stride(x.max_W) + 3) / 4, n), dim3(256), 0, st, slots, list);
 }
 
