@@ -391,8 +391,12 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     JacT.assign(6 * (size_t)W, 0.0);
     Hessian.assign(36 * (size_t)W * W, 0.0);
     pose_index.assign(win->pose_index, win->pose_index + W);
-    std::vector<PlaneCluster> clusters;
-    std::vector<double> coe;
+    // members: the asynchronous uploads below read them, and a synchronisation here would make every window of a lock-step group
+    // wait for everything the other windows have queued on the shared stream (their operand fills, their uploads)
+    std::vector<PlaneCluster>& clusters = h_clusters;
+    std::vector<double>& coe = h_coe;
+    clusters.clear();
+    coe.clear();
     balm_build_planes(twl.data(), W, win->cloud_xyz, win->cloud_offsets, clusters, coe);
     n_planes = (int)coe.size();
     dev = BalmDev{};
@@ -416,7 +420,6 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
         TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, coe.data(), coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
     }
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors go out of scope
     dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
     dev.plane_res = d_plane_res.p; dev.eig = d_eig.p; dev.part = d_part.p; dev.out = h_out.p;
     return 0;

@@ -41,6 +41,8 @@ struct BalmTerm {
 
     BalmDev dev{};
     DevBuf<PlaneCluster> d_clusters;
+    std::vector<PlaneCluster> h_clusters;  // the planes of the last build (kept alive for the asynchronous upload)
+    std::vector<double> h_coe;
     DevBuf<double> d_coe, d_plane_res, d_part, d_eig;
     const void* eig_at = nullptr;  // the pose array of the last residual pass: the Hessian pass reuses its eigen decompositions
     DevBuf<int32_t> d_pose_index;
