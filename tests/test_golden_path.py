@@ -1,4 +1,5 @@
-"""The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py):
+"""The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
+local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -171,3 +172,33 @@ def test_product_inertial_golden(pkg, golden_dir):
     assert np.allclose(pts, g["out_points"], rtol=RTOL, atol=1e-4)
     assert np.array_equal(dpos, g["out_depth_pos"])
     assert abs(stats.final_chi2 - g["out_err"][1]) <= 1e-3 * g["out_err"][1]
+
+
+# ---- local-map bookkeeping (tools/make_golden_localmap.py) -------------------------------------------------------------------
+GRAPH_KEYS = ("kf_bad", "covis_off", "covis", "child_off", "children", "parent", "prev_kf", "match_off", "matches", "point_bad", "obs_off", "obs_kf")
+
+
+def _localmap_cases(g):
+    graph = {k: g[k] for k in GRAPH_KEYS}
+    return graph, [(g["frame_points_%d" % i], int(g["temporal_%d" % i]), g["local_kfs_%d" % i], int(g["reference_%d" % i]),
+                    g["local_points_%d" % i], g["cleared_%d" % i]) for i in range(int(g["n_cases"]))]
+
+
+def test_oracle_localmap_golden(oracle, golden_dir):
+    graph, cases = _localmap_cases(load(golden_dir, "localmap_a"))
+    assert len(cases) == 3
+    for fp, temporal, kfs, ref, pts, cleared in cases:
+        got = oracle.update_local_map(graph, fp, temporal)
+        assert np.array_equal(got[0], kfs) and got[1] == ref and np.array_equal(got[2], pts) and np.array_equal(got[3], cleared)
+        assert len(kfs) > 5 and len(pts) > 100
+
+
+@pytest.mark.gpu
+def test_product_localmap_golden(pkg, golden_dir):
+    graph, cases = _localmap_cases(load(golden_dir, "localmap_a"))
+    lm = pkg.capi.LocalMap()
+    lm.set_graph(graph)
+    for fp, temporal, kfs, ref, pts, cleared in cases:
+        got = lm.update(fp, temporal)
+        assert np.array_equal(got[0], kfs) and got[1] == ref and np.array_equal(got[2], pts) and np.array_equal(got[3], cleared)
+    lm.close()
