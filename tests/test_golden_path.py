@@ -1,5 +1,5 @@
 """The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
-local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py):
+local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) and the ESKF update (eskf_a.npz, tools/make_golden_eskf.py):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -202,3 +202,35 @@ def test_product_localmap_golden(pkg, golden_dir):
         got = lm.update(fp, temporal)
         assert np.array_equal(got[0], kfs) and got[1] == ref and np.array_equal(got[2], pts) and np.array_equal(got[3], cleared)
     lm.close()
+
+
+# ---- LiDAR-inertial ESKF update, row b7 (tools/make_golden_eskf.py) -----------------------------------------------------------
+def _eskf_cases(g):
+    return [(g["x_%d" % i], g["P_%d" % i], bool(g["ext_%d" % i]), g["out_x_%d" % i], g["out_P_%d" % i], g["out_info_%d" % i], float(g["out_res_%d" % i]))
+            for i in range(int(g["n_cases"]))]
+
+
+def test_oracle_eskf_golden(oracle, golden_dir):
+    g = load(golden_dir, "eskf_a")
+    tree = oracle.KdTree(g["map_points"])
+    for xe, P, ext, want_x, want_P, info, res in _eskf_cases(g):
+        xs, Ps, got = oracle.eskf_update(xe, P, tree, g["body"], max_iter=4, extrinsic_est_en=ext)
+        assert [got["calls"], got["searches"], got["converged"], int(got["finished"]), got["effct_feat_num"]] == info.tolist()
+        assert np.allclose(xs, want_x, rtol=1e-12, atol=1e-12) and np.allclose(np.asarray(Ps).reshape(23, 23), want_P, rtol=1e-10, atol=1e-14)
+        assert abs(got["res_mean_last"] - res) <= 1e-12 * res
+
+
+@pytest.mark.gpu
+def test_product_eskf_golden(pkg, golden_dir):
+    g = load(golden_dir, "eskf_a")
+    body = g["body"]
+    fe = pkg.LidarFrontEnd(max_points_per_scan=max(len(body), 256), max_scans=1)
+    m = pkg.LidarMap(); m.Build(g["map_points"])
+    for xe, P, ext, want_x, want_P, info, res in _eskf_cases(g):
+        x, Pn, st = fe.eskf_update(m, body, xe, P, max_iter=4, extrinsic_est_en=ext)
+        assert [st.calls, st.searches, st.converged, int(bool(st.finished)), st.effct_feat_num] == info.tolist()
+        assert abs(st.res_mean_last - res) <= 1e-5 * res
+        assert np.abs(x[:3] - want_x[:3]).max() / max(1.0, np.abs(want_x[:3]).max()) < RTOL
+        assert np.abs(x[3:12] - want_x[3:12]).max() < 1e-6 and np.abs(x[24:33] - want_x[24:33]).max() < 1e-6  # rotations
+        assert np.allclose(x[12:24], want_x[12:24], rtol=RTOL, atol=1e-6) and np.allclose(x[33:], want_x[33:], rtol=RTOL, atol=1e-6)
+        assert np.abs(Pn - want_P).max() <= 1e-6 * np.abs(want_P).max()
