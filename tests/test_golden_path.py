@@ -1,5 +1,5 @@
 """The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
-local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) and the ESKF update (eskf_a.npz, tools/make_golden_eskf.py):
+local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) and the tracking path (tracking_a.npz, tools/make_golden_tracking.py):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -234,3 +234,47 @@ def test_product_eskf_golden(pkg, golden_dir):
         assert np.abs(x[3:12] - want_x[3:12]).max() < 1e-6 and np.abs(x[24:33] - want_x[24:33]).max() < 1e-6  # rotations
         assert np.allclose(x[12:24], want_x[12:24], rtol=RTOL, atol=1e-6) and np.allclose(x[33:], want_x[33:], rtol=RTOL, atol=1e-6)
         assert np.abs(Pn - want_P).max() <= 1e-6 * np.abs(want_P).max()
+
+
+# ---- tracking data path, rows a9 + a10 composed (tools/make_golden_tracking.py) -------------------------------------------------
+def _keys_from_floats(dtype, a):
+    k = np.zeros(len(a), dtype)
+    for i, f in enumerate(("x", "y", "size", "angle", "response")):
+        k[f] = a[:, i]
+    k["octave"] = a[:, 5].astype(np.int32)
+    return k
+
+
+def test_oracle_tracking_golden(oracle, golden_dir):
+    g = load(golden_dir, "tracking_a")
+    h, w = g["left"].shape
+    n = int(g["nfeatures"])
+    ol, orr = oracle.OrbOracle(nfeatures=n), oracle.OrbOracle(nfeatures=n)
+    _, kl, dl = ol.extract(g["left"])
+    _, kr, dr = orr.extract(g["right"])
+    u, d, _ = oracle.stereo_match(ol, orr, kl, dl, kr, dr, float(g["bf"]), float(g["b"]))
+    lk = _keys_from_floats(kl.dtype, g["last_keys"])
+    r = oracle.track_motion_model(kl, dl, u, w, h, g["scales"], g["inv_sigma2"], g["pred7"], g["last_pose7"], g["cam5"], float(g["b"]), float(g["th"]),
+                                  g["last_has_point"], g["last_outlier"], g["last_Xw"], lk, g["last_desc"])
+    assert int(r[2]) == int(g["out_n_matches"]) and int(r[3]) == int(g["out_n_inliers"]) and int(r[3]) > 200
+    assert np.array_equal(np.asarray(r[1], np.int32), g["out_matches"]) and np.allclose(r[0], g["out_pose7"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_product_tracking_golden(pkg, golden_dir):
+    import torch
+    g = load(golden_dir, "tracking_a")
+    h, w = g["left"].shape
+    ext = pkg.OrbExtractor(nfeatures=int(g["nfeatures"]), max_width=w, max_height=h, max_images=2)
+    dev = torch.from_numpy(np.stack([g["left"], g["right"]])).cuda()
+    kps, desc, counts, _ = ext.extract_batch_dev(dev.data_ptr(), 2, w, h, w, w * h)
+    u_right, depth, _ = pkg.stereo_match_batch(ext, 1, float(g["bf"]), float(g["b"]))
+    last = dict(has_point=g["last_has_point"], outlier=g["last_outlier"], Xw=g["last_Xw"], keys=_keys_from_floats(kps.dtype, g["last_keys"]),
+                descriptors=g["last_desc"], pose7=g["last_pose7"])
+    poses, mp, nm, inl = pkg.capi.track_motion_model_batch(ext, 1, kps, u_right, pkg.capi.pack_last_frames([last]), g["pred7"][None], g["cam5"],
+                                                            float(g["b"]), float(g["th"]))
+    n = int(counts[0])
+    assert n == len(g["out_matches"]) and int(nm[0]) == int(g["out_n_matches"]) and int(inl[0]) == int(g["out_n_inliers"])
+    assert np.array_equal(mp[0, :n], g["out_matches"])
+    assert np.allclose(poses[0], g["out_pose7"], rtol=RTOL, atol=1e-6)
+    ext.close()
