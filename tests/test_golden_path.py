@@ -1,5 +1,6 @@
 """The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
-local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) and the tracking path (tracking_a.npz, tools/make_golden_tracking.py):
+local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) the tracking path (tracking_a.npz, tools/make_golden_tracking.py) and the scan motion compensation (undistort_a.npz,
+tools/make_golden_undistort.py):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -278,3 +279,31 @@ def test_product_tracking_golden(pkg, golden_dir):
     assert np.array_equal(mp[0, :n], g["out_matches"])
     assert np.allclose(poses[0], g["out_pose7"], rtol=RTOL, atol=1e-6)
     ext.close()
+
+
+# ---- scan motion compensation, row b2 (tools/make_golden_undistort.py) ----------------------------------------------------------
+def _lidar_state24(st36):
+    return np.concatenate([st36[3:12], st36[0:3], st36[24:33], st36[33:36]])
+
+
+def test_oracle_undistort_golden(oracle, golden_dir):
+    g = load(golden_dir, "undistort_a")
+    t = g["t"]
+    st, poses = oracle.imu_propagate(g["state0"], g["imu"], t[0], t[1], t[2], t[3], g["last6"])
+    assert np.allclose(st, g["out_state"], rtol=1e-13, atol=1e-13) and np.allclose(poses, g["out_poses"], rtol=1e-13, atol=1e-13)
+    out = oracle.undistort(g["points"], poses, _lidar_state24(st))
+    assert out.tobytes() == g["out_points"].tobytes() and len(out) > 5000
+
+
+@pytest.mark.gpu
+def test_product_undistort_golden(pkg, golden_dir):
+    g = load(golden_dir, "undistort_a")
+    t = g["t"]
+    st, poses, _ = pkg.capi.lidar_imu_propagate(g["state0"], g["imu"], t[0], t[1], t[2], t[3], g["last6"])
+    assert np.allclose(st, g["out_state"], rtol=1e-12, atol=1e-12) and np.allclose(poses, g["out_poses"], rtol=1e-12, atol=1e-12)
+    fe = pkg.LidarFrontEnd(max_points_per_scan=len(g["points"]) + 256, max_scans=1)
+    got, want = fe.undistort(g["points"], g["out_poses"], _lidar_state24(g["out_state"])), g["out_points"]
+    for name in ("intensity", "curvature", "normal_x"):  # identical order: the other fields travel with the point
+        assert np.array_equal(got[name], want[name]), name
+    xyz_g, xyz_w = np.stack([got["x"], got["y"], got["z"]], 1), np.stack([want["x"], want["y"], want["z"]], 1)
+    assert np.all(np.abs(xyz_g - xyz_w) <= np.spacing(np.abs(xyz_w).astype(np.float32)))  # double results rounded to float: one ulp at most
