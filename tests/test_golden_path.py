@@ -1,6 +1,6 @@
 """The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
-local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) the tracking path (tracking_a.npz, tools/make_golden_tracking.py) and the scan motion compensation (undistort_a.npz,
-tools/make_golden_undistort.py):
+local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) the tracking path (tracking_a.npz, tools/make_golden_tracking.py) the scan motion compensation (undistort_a.npz,
+tools/make_golden_undistort.py) and the LiDAR preprocessing + voxel filter (lidar_pre_a.npz, tools/make_golden_lidar_pre.py):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -307,3 +307,22 @@ def test_product_undistort_golden(pkg, golden_dir):
         assert np.array_equal(got[name], want[name]), name
     xyz_g, xyz_w = np.stack([got["x"], got["y"], got["z"]], 1), np.stack([want["x"], want["y"], want["z"]], 1)
     assert np.all(np.abs(xyz_g - xyz_w) <= np.spacing(np.abs(xyz_w).astype(np.float32)))  # double results rounded to float: one ulp at most
+
+
+# ---- LiDAR preprocessing + voxel filter, rows b1 + b3 (tools/make_golden_lidar_pre.py) -------------------------------------------
+def test_oracle_lidar_pre_golden(oracle, golden_dir):
+    g = load(golden_dir, "lidar_pre_a")
+    pre = oracle.lidar_preprocess(g["raw"], int(g["point_filter_num"]), float(g["blind"]), float(g["time_unit_scale"]))
+    assert pre.tobytes() == g["out_pre"].tobytes() and len(pre) > 5000
+    down = oracle.voxel_grid(pre, float(g["leaf"]))
+    assert down.tobytes() == g["out_down"].tobytes() and 1000 < len(down) < len(pre)
+
+
+@pytest.mark.gpu
+def test_product_lidar_pre_golden(pkg, golden_dir):
+    g = load(golden_dir, "lidar_pre_a")
+    fe = pkg.LidarFrontEnd(max_points_per_scan=len(g["raw"]) + 256, max_scans=1)
+    pre = fe.process(g["raw"], int(g["point_filter_num"]), float(g["blind"]), float(g["time_unit_scale"]))
+    assert pre.tobytes() == g["out_pre"].tobytes()
+    down = fe.voxel_filter(g["out_pre"], float(g["leaf"]))
+    assert down.tobytes() == g["out_down"].tobytes()
