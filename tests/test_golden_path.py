@@ -1,6 +1,7 @@
 """The committed golden vectors of SURVEY.md section 8c items (2)-(5) (tests/golden/*.npz, made by tools/make_golden_path.py) and of the
 local-map bookkeeping (localmap_a.npz, tools/make_golden_localmap.py) the ESKF update (eskf_a.npz, tools/make_golden_eskf.py) the tracking path (tracking_a.npz, tools/make_golden_tracking.py) the scan motion compensation (undistort_a.npz,
-tools/make_golden_undistort.py) and the LiDAR preprocessing + voxel filter (lidar_pre_a.npz, tools/make_golden_lidar_pre.py):
+tools/make_golden_undistort.py) the LiDAR preprocessing + voxel filter (lidar_pre_a.npz, tools/make_golden_lidar_pre.py), the map-point refresh (mappoint_a.npz) and
+LocalMapping's geometric steps (mapping_a.npz):
  - without a GPU the oracle must reproduce them (this pins the checker against silent drift);
  - on the GPU the product, called through the C ABI, is compared with the stored vectors alone -- the oracle is not involved.
 Integer / byte / selection results bit for bit; optimised states within 1e-4 relative (BASELINE.json's bar)."""
@@ -326,3 +327,68 @@ def test_product_lidar_pre_golden(pkg, golden_dir):
     assert pre.tobytes() == g["out_pre"].tobytes()
     down = fe.voxel_filter(g["out_pre"], float(g["leaf"]))
     assert down.tobytes() == g["out_down"].tobytes()
+
+
+# ---- map-point refresh, section 8f item 3 (tools/make_golden_mappoint.py) ----------------------------------------------------------
+def _mappoint_args(g):
+    return g["obs_off"], g["descriptors"], g["centres"], g["positions"], g["ref_centres"], g["level_scale"], float(g["last_scale"])
+
+
+def _check_mappoint(got, g):
+    assert np.array_equal(got[0], g["out_best"])
+    has = g["out_best"] >= 0
+    assert has.sum() > 150
+    for a, name in zip(got[1:], ("out_normals", "out_min", "out_max")):
+        assert np.array_equal(a[has], g[name][has]), name  # float arithmetic in the reference's order: bit for bit
+
+
+def test_oracle_mappoint_golden(oracle, golden_dir):
+    g = load(golden_dir, "mappoint_a")
+    _check_mappoint(oracle.map_points_refresh(*_mappoint_args(g)), g)
+
+
+@pytest.mark.gpu
+def test_product_mappoint_golden(pkg, golden_dir):
+    g = load(golden_dir, "mappoint_a")
+    _check_mappoint(pkg.capi.map_points_refresh(*_mappoint_args(g)), g)
+
+
+# ---- LocalMapping's geometric steps, section 8f item 1 (tools/make_golden_mapping.py) ----------------------------------------------
+def _mapping_keyframes(g, key_dtype):
+    kfs = []
+    for i in range(int(g["n_kf"])):
+        kfs.append(dict(keys=_keys_from_floats(key_dtype, g["keys_%d" % i]), descriptors=g["desc_%d" % i], u_right=g["u_right_%d" % i],
+                        depth=g["depth_%d" % i], has_point=g["has_point_%d" % i], fv_node=g["fv_node_%d" % i], fv_offset=g["fv_offset_%d" % i],
+                        fv_index=g["fv_index_%d" % i], pose7=g["pose7_%d" % i], centre=g["centre_%d" % i]))
+    return kfs
+
+
+def _check_mapping(tri, new, fuse, g):
+    assert tri[0] == int(g["out_tri_n"]) and np.array_equal(tri[1], g["out_tri_matches"]) and tri[0] > 20
+    assert np.array_equal(new[0], g["out_new_idx"]) and len(new[0]) > 20
+    stereo = g["out_new_idx"][:, 3] == 1
+    assert np.array_equal(new[1][stereo], g["out_new_x3"][stereo])                        # un-projections: bit for bit
+    assert np.allclose(new[1][~stereo], g["out_new_x3"][~stereo], rtol=RTOL, atol=1e-5)   # triangulations: float rounding of the eigenvector
+    assert fuse[0] == int(g["out_fuse_n"]) and np.array_equal(fuse[1], g["out_fuse_idx"]) and np.array_equal(fuse[2], g["out_fuse_dist"])
+
+
+def test_oracle_mapping_golden(oracle, golden_dir):
+    g = load(golden_dir, "mapping_a")
+    kfs = _mapping_keyframes(g, oracle.OrbOracle(nfeatures=10).extract(np.zeros((64, 64), np.uint8))[1].dtype)
+    cam4, mb, mbf, sf, sg = g["cam4"], float(g["mb"]), float(g["mbf"]), g["sf"], g["sg"]
+    B = kfs[0]
+    _check_mapping(oracle.search_for_triangulation(kfs[0], kfs[2], cam4, sf, sg), oracle.create_new_map_points(kfs[0], kfs[1:], cam4, mb, mbf, sf, sg),
+                   oracle.fuse_search(B["keys"], B["descriptors"], B["u_right"], int(g["width"]), int(g["height"]), B["pose7"], cam4, mbf, sf, g["fuse_isg"],
+                                      float(g["fuse_logsf"]), g["fuse_points"], g["fuse_valid"], th=3.0), g)
+
+
+@pytest.mark.gpu
+def test_product_mapping_golden(pkg, golden_dir):
+    g = load(golden_dir, "mapping_a")
+    kfs = _mapping_keyframes(g, pkg.capi.KEYPOINT_DTYPE)
+    cam4, mb, mbf, sf, sg = g["cam4"], float(g["mb"]), float(g["mbf"]), g["sf"], g["sg"]
+    cam5 = np.float32([cam4[0], cam4[1], cam4[2], cam4[3], mbf]).astype(np.float64)
+    B = kfs[0]
+    _check_mapping(pkg.capi.search_for_triangulation(kfs[0], kfs[2], cam5, sf, sg), pkg.capi.create_new_map_points(kfs[0], kfs[1:], cam5, mb, sf, sg),
+                   pkg.capi.fuse_search(B["keys"], B["descriptors"], B["u_right"], int(g["width"]), int(g["height"]), B["pose7"], cam4, mbf, sf, g["fuse_isg"],
+                                        float(g["fuse_logsf"]), g["fuse_points"], g["fuse_valid"], th=3.0), g)
