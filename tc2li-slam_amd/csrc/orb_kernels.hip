@@ -28,10 +28,16 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
                                                        int sw, int sh, uint8_t* __restrict__ dst, int dst_pitch,
                                                        size_t dst_img_stride, int dw, int dh,
                                                        const int* __restrict__ xofs, const short* __restrict__ ialpha,
-                                                       const int* __restrict__ yofs, const short* __restrict__ ibeta) {
-    const int img = blockIdx.z;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+                                                       const int* __restrict__ yofs, const short* __restrict__ ibeta, int gx, int gy, int nimg) {
+    // One-dimensional launch, XCD-aware: workgroups go to the 8 XCDs round-robin by their linear index and each XCD has its own L2;
+    // blocks that are neighbours in (x, y) read the same source rows, so XCD k takes the k-th contiguous eighth of the
+    // (image, row block, column block) list instead of every 8th block.
+    const int per_xcd = (gx * gy * nimg + 7) / 8;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= gx * gy * nimg) return;
+    const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
+    const int dy = by * 4 + (threadIdx.x >> 6);
+    const int dx0 = (bx * 64 + (threadIdx.x & 63)) * 4;
     if (dy >= dh || dx0 >= dw) return;
     const uint8_t* S = src + (size_t)img * src_img_stride;
     int sy0 = yofs[dy], sy1 = sy0 + 1;
@@ -595,9 +601,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
 // ---- launch wrappers (host side of this translation unit) ----------------------------------------------
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st) {
-    dim3 grid((dst.w + 255) / 256, (dst.h + 3) / 4, nimg);
-    hipLaunchKernelGGL(k_resize_linear, grid, dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
-                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta);
+    const int gx = (dst.w + 255) / 256, gy = (dst.h + 3) / 4;
+    hipLaunchKernelGGL(k_resize_linear, dim3(((gx * gy * nimg + 7) / 8) * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
