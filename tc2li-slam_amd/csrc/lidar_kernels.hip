@@ -192,6 +192,13 @@ __device__ __forceinline__ int voxel_index(const PointXYZINormal& p, float inv, 
     const int i2 = (int)(floorf(p.z * inv) - (float)v.min_b[2]);
     return i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2];
 }
+// Launch-order -> work-list index so that XCD k (workgroups reach the XCDs round-robin by linear index; grid.x is rounded up to a
+// multiple of 8) takes the k-th contiguous eighth of the list: the blocks of a scan, and with them its hash table, member lists and map
+// grid, meet in one L2 instead of eight.  -1: padding block.
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+    const int per = (n + 7) >> 3, l = (bid & 7) * per + (bid >> 3);
+    return l < n ? l : -1;
+}
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -219,8 +226,10 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
                                                             const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                             float leaf, const VoxelParams* __restrict__ vp,
                                                             int* __restrict__ table_keys, int* __restrict__ table_counts,
-                                                            int* __restrict__ pt_slot, int* __restrict__ n_vox, int* __restrict__ vox_keys) {
-    const SegBlock b = blocks[blockIdx.x];
+                                                            int* __restrict__ pt_slot, int* __restrict__ n_vox, int* __restrict__ vox_keys, int nblocks) {
+    const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
+    if (bi < 0) return;
+    const SegBlock b = blocks[bi];
     const int i = b.start + threadIdx.x, n = count[b.scan];
     if (b.start >= n) return;  // whole workgroup
     const VoxelParams v = vp[b.scan];
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const int* __restrict_
                                                           const SegBlock* __restrict__ blocks, const VoxelParams* __restrict__ vp,
                                                           const int* __restrict__ pt_slot, const int* __restrict__ table_rank,
                                                           const int* __restrict__ vox_member_off, int* __restrict__ vox_fill,
-                                                          int* __restrict__ members) {
+                                                          int* __restrict__ members, int nblocks) {
+    if ((int)blockIdx.x >= nblocks) return;  // launch order kept: the XCD-contiguous order doubled this kernel's time (its position atomics)
     const SegBlock b = blocks[blockIdx.x];
     const int i = b.start + threadIdx.x, n = count[b.scan];
     if (b.start >= n) return;
@@ -364,8 +374,10 @@ __global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __res
                                                     const VoxelParams* __restrict__ vp, const int* __restrict__ pt_slot,
                                                     const int* __restrict__ table_rank, const int* __restrict__ vox_member_off,
                                                     const int* __restrict__ vox_fill, const int* __restrict__ members,
-                                                    CentroidRec* __restrict__ recs) {
-    const SegBlock b = blocks[blockIdx.x];
+                                                    CentroidRec* __restrict__ recs, int nblocks) {
+    const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
+    if (bi < 0) return;
+    const SegBlock b = blocks[bi];
     const int i = b.start + (int)blockIdx.y * 256 + threadIdx.x;
     if (i >= count[b.scan]) return;
     const VoxelParams v = vp[b.scan];
@@ -847,8 +859,10 @@ __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ g
                                                    const LidarStateDev* __restrict__ states, PointXYZINormal* __restrict__ world,
                                                    uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
                                                    int* __restrict__ nearest_idx, float* __restrict__ nearest_d,
-                                                   int* __restrict__ nfound, int* __restrict__ hard_count, int2* __restrict__ hard_list) {
-    const SegBlock b = blocks[blockIdx.x];
+                                                   int* __restrict__ nfound, int* __restrict__ hard_count, int2* __restrict__ hard_list, int nblocks) {
+    const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
+    if (bi < 0) return;
+    const SegBlock b = blocks[bi];
     const ScanSlot sl = slots[b.scan];
     const int n = count[b.scan];
     const int i = b.start + blockIdx.y * 64 + (threadIdx.x >> 2), l = threadIdx.x & 3;
@@ -1345,7 +1359,7 @@ void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* 
 }
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                          float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys);
+    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
@@ -1361,15 +1375,15 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
 }
 void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
                        const int* table_rank, const int* vox_member_off, int* vox_fill, int* members, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3(nblocks), dim3(kSegBlock), 0, st, count, slots, blocks, vp, pt_slot, table_rank, vox_member_off, vox_fill, members);
+    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, count, slots, blocks, vp, pt_slot, table_rank, vox_member_off, vox_fill, members, nblocks);
 }
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
                            const int* vox_member_off, const int* vox_fill, const int* members, void* recs, PointXYZINormal* out,
                            int* out_count, hipStream_t st) {
     if (!nblocks) return;
-    hipLaunchKernelGGL(k_voxel_rank, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
-                       vox_member_off, vox_fill, members, (CentroidRec*)recs);
+    hipLaunchKernelGGL(k_voxel_rank, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
+                       vox_member_off, vox_fill, members, (CentroidRec*)recs, nblocks);
     hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
                        vox_fill, (const CentroidRec*)recs, out, out_count);
 }
@@ -1388,8 +1402,8 @@ void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const i
                       int2* hard_list, hipStream_t st, hipEvent_t after_first) {
     if (!nblocks) return;
     (void)hipMemsetAsync(hard_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_knn_plane, dim3(nblocks, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
-                       normvec, nearest_idx, nearest_d, nfound, hard_count, hard_list);
+    hipLaunchKernelGGL(k_knn_plane, dim3((nblocks + 7) / 8 * 8, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
+                       normvec, nearest_idx, nearest_d, nfound, hard_count, hard_list, nblocks);
     if (after_first) (void)hipEventRecord(after_first, st);
     hipLaunchKernelGGL(k_knn_hard, dim3(512), dim3(256), 0, st, grids, body, slots, states, selected, normvec, nearest_idx, nearest_d, nfound,
                        hard_count, hard_list);
