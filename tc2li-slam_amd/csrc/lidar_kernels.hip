@@ -406,8 +406,10 @@ __global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* _
                                                         const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
                                                         const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
                                                         const CentroidRec* __restrict__ recs, PointXYZINormal* __restrict__ out,
-                                                        int* __restrict__ out_count) {
-    const SegBlock b = blocks[blockIdx.x];
+                                                        int* __restrict__ out_count, int nblocks) {
+    const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
+    if (bi < 0) return;
+    const SegBlock b = blocks[bi];
     const ScanSlot sl = slots[b.scan];
     const int nv = n_vox[b.scan];
     if (b.start == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
@@ -1384,8 +1386,8 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
     if (!nblocks) return;
     hipLaunchKernelGGL(k_voxel_rank, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
                        vox_member_off, vox_fill, members, (CentroidRec*)recs, nblocks);
-    hipLaunchKernelGGL(k_voxel_centroid, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
-                       vox_fill, (const CentroidRec*)recs, out, out_count);
+    hipLaunchKernelGGL(k_voxel_centroid, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
+                       vox_fill, (const CentroidRec*)recs, out, out_count, nblocks);
 }
 void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_counts);

@@ -28,11 +28,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
                                                       const StereoFrame* __restrict__ frames, const MatchKey* __restrict__ keys,
                                                       const uint8_t* __restrict__ desc, float mbf, float max_d,
                                                       float* __restrict__ u_right, float* __restrict__ depth,
-                                                      int* __restrict__ best_sad) {
+                                                      int* __restrict__ best_sad, int gx, int nframes) {
     __shared__ RightRec recs[kStereoMaxRight];
-    const StereoFrame fr = frames[blockIdx.y];
+    // One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each XCD has its own
+    // L2): XCD k takes the k-th eighth of the (frame, key block) list, so a frame's pyramid rows and right-image records are
+    // fetched into one L2.
+    const int total = gx * nframes, per_xcd = (total + 7) / 8;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int frame = logical / gx, bx = logical - frame * gx;
+    const StereoFrame fr = frames[frame];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int first = blockIdx.x * kLeftPerBlock;
+    const int first = bx * kLeftPerBlock;
     if (first >= fr.n_left) return;
     const MatchKey* kr = keys + fr.right_off;
     for (int i = tid; i < fr.n_right; i += 256) {
@@ -139,9 +146,9 @@ void launch_stereo_match(const LevelTable& left, const LevelTable& right, const 
                          int nframes, int max_left, const MatchKey* keys, const uint8_t* desc, float mbf, float max_d,
                          float* u_right, float* depth, int* best_sad, hipStream_t st) {
     if (nframes <= 0 || max_left <= 0) return;
-    dim3 grid((max_left + kLeftPerBlock - 1) / kLeftPerBlock, nframes);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
-                       depth, best_sad);
+    const int gx = (max_left + kLeftPerBlock - 1) / kLeftPerBlock;
+    hipLaunchKernelGGL(k_stereo_match, dim3((gx * nframes + 7) / 8 * 8), dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
+                       depth, best_sad, gx, nframes);
 }
 
 }  // namespace tc2li
