@@ -630,12 +630,20 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaBatchSlot*
     if (!pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
     d_ba_schur_gemm(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
+// One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each with its own L2): the
+// strips of one k-slice read the same rows of W^T, so consecutive entries of the (window, slice, strip) list stay on one XCD.
 template <int CT>
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
-    TC2LI_SLOT(z);
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active, int strips, int max_slices,
+                                                        int n_active) {
+    const int total = strips * max_slices * n_active, per_xcd = (total + 7) / 8;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int window = logical / (strips * max_slices), rem = logical - window * (strips * max_slices), slice = rem / strips, strip = rem - slice * strips;
+    const BaBatchSlot& sl = slots[active[window]];
+    const BaProblemDev pb = sl.pb;
     const int tiles = pb.np_pad / 16;
-    if (!pb.n_free || 2 * (int)blockIdx.x >= tiles || (int)blockIdx.y >= sl.n_slices) return;
-    d_ba_schur_gemm_strip<CT>(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
+    if (!pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
+    d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -712,8 +720,9 @@ void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_ac
     if (!x.max_free) return;
     hipLaunchKernelGGL(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
     const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
-    if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_b<5>, dim3(strips, x.max_slices, n_active), dim3(64), 0, st, slots, active);
-    else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_b<8>, dim3(strips, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
+    if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
+    else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
     else hipLaunchKernelGGL(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
     hipLaunchKernelGGL(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
 }
