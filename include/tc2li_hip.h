@@ -165,6 +165,18 @@ int tc2li_lidar_preprocess(tc2li_lidar* lidar, const tc2li_velodyne_point* raw, 
  * one centroid (of every field) per occupied voxel, in ascending voxel-index order. */
 int tc2li_lidar_voxel_filter(tc2li_lidar* lidar, const tc2li_point* in, int n, float leaf, tc2li_point* out, int capacity);
 
+/* LiDAR map handle -- thread contract.  In the reference the global `ikdtree` is touched from two threads: the LiDAR thread
+ * (feature_extraction / h_share_model, LidarFrontEnd.cpp:942,749) and the tracking thread (UpdateMap -> map_incremental,
+ * Tracking.cc:1602-1603, under `finishMutex`).  A tc2li_lidar_map may be used from any number of host threads: every entry
+ * point that reads or changes a map (build / add / size / download / feature_extraction / frontend_batch / eskf_update /
+ * map_incremental / delete_boxes) holds the handle's internal lock from its first access until its device work on the map
+ * has completed (each of them synchronises its stream before it returns), so calls on one handle serialise inside the
+ * library; a batch call locks the distinct maps of its batch in address order.  What the lock cannot give is the reference's
+ * sequencing: tc2li_lidar_map_incremental replays the neighbours found by the handle's LAST feature extraction against the
+ * same map, so the caller must not let another thread change that map in between (the reference's finishMutex does this).
+ * A tc2li_lidar workspace itself is NOT shareable between threads (one per calling thread, like the ORB extractor handle).
+ * tc2li_lidar_map_destroy must not race with any other call on the handle.
+ * Entry points without a `stream` argument run on a private non-blocking stream of the calling thread (never the NULL stream). */
 int tc2li_lidar_map_create(tc2li_lidar_map** out);
 void tc2li_lidar_map_destroy(tc2li_lidar_map* map);
 /* ikdtree.Build(points) (LidarFrontEnd.cpp:918-931): replaces the map content.  Returns the map size. */

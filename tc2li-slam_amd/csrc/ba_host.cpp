@@ -41,7 +41,7 @@ struct BaWorkspace {
     DevBuf<uint8_t> d_in;
     PinnedBuf<uint8_t> h_in;
     DevBuf<uint8_t> d_depth;
-    PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp;
+    PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp, h_stat;
     DevBuf<ImuPose> d_iposes, d_iposes_trial;
     PinnedBuf<ImuPose> h_iposes;
     PinnedBuf<uint8_t> h_result;  // lock-step batch: poses, points, per-edge chi2 and depth flags on their way to the caller
@@ -232,13 +232,85 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
                       const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
                       double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                       uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
-                      tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, const uint8_t* used_all, void* stream_) {
+                      tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, const uint8_t* used_all, void* stream_,
+                      bool* peers_told = nullptr) {
     if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
         set_error("tc2li_local_bundle_adjustment: invalid argument");
         return TC2LI_ERR_INVALID;
     }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream_;
+    // ---- sharded window: a failure is agreed on, no rank leaves alone -------------------------------------------------------
+    // Every all-reduce carries one more element, the status word (0 = fine, 1 = this rank failed), and every rank reads it at
+    // the synchronisation that follows: a peer's failure makes all ranks return TC2LI_ERR_COMM from the same collective.  A rank
+    // that fails between two collectives (a HIP error, VisualProblem::setup, BalmTerm::build, an allocation) does not return at
+    // once: it first joins the collective the others are heading for (`next`: same buffer size and operation -- the control
+    // flow is replicated, so the failing rank knows it) with its status word set, then returns its own error.  What this cannot
+    // cover: a failing all-reduce callback (the communicator itself is broken) and a device so broken that the poisoned
+    // collective cannot be enqueued -- the launcher's watchdog has to end those.
+    const bool sharded = shard != nullptr;
+    struct Collective { double* dev = nullptr; size_t count = 0; int op = TC2LI_REDUCE_SUM; } next;
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    double* h_stat = nullptr;  // [0..4): status words read back since the last synchronisation; [6] = 0.0, [7] = 1.0 (sources)
+    int n_stat = 0;
+    double* d_red = nullptr;
+    auto reduce = [&](double* dev, size_t count, int op, bool failed = false) -> int {
+        if (hipMemcpyAsync(dev + count, h_stat + (failed ? 7 : 6), sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("sharded bundle adjustment: the status word could not be written");
+            return (int)TC2LI_ERR_HIP;
+        }
+        const int rc = shard->allreduce(shard->ctx, dev, count + 1, op, st);
+        if (rc != 0) { set_error("sharded bundle adjustment: the all-reduce callback returned %d", rc); return (int)TC2LI_ERR_COMM; }
+        if (!failed && hipMemcpyAsync(h_stat + n_stat++, dev + count, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("sharded bundle adjustment: the status word could not be read");
+            return (int)TC2LI_ERR_HIP;
+        }
+        return 0;
+    };
+    auto peer_failed = [&] {  // after a synchronisation
+        bool bad = false;
+        for (int i = 0; i < n_stat; ++i) bad |= h_stat[i] > 0;
+        n_stat = 0;
+        if (bad) set_error("sharded bundle adjustment: another rank failed; all ranks leave the window");
+        return bad;
+    };
+    auto leave = [&](int rc) {  // a local failure: tell the peers through their next collective, then return the error
+        if (sharded && next.dev && h_stat) {
+            const std::string why = tc2li_last_error();
+            if (reduce(next.dev, next.count, next.op, true) == 0 && hipStreamSynchronize(st) == hipSuccess) { if (peers_told) *peers_told = true; }
+            (void)hipGetLastError();
+            set_error("%s", why.c_str());
+        }
+        return rc;
+    };
+#define TC2LI_SH_CHECK(call)                                                                                         \
+    do {                                                                                                             \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess) {                                                                                      \
+            ::tc2li::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);             \
+            return leave(TC2LI_ERR_HIP);                                                                             \
+        }                                                                                                            \
+    } while (0)
+    if (sharded) {
+        // the reduction buffer before anything that can fail: sized for the largest reduced system this window can have
+        const size_t np_max = 6 * (size_t)n_poses;
+        TC2LI_HIP_CHECK(ws.d_red.ensure(np_max * np_max + 2 * np_max + 27 * (size_t)n_poses + 16));
+        TC2LI_HIP_CHECK(ws.h_stat.ensure(8));
+        d_red = ws.d_red.p;
+        h_stat = ws.h_stat.p;
+        h_stat[6] = 0.0; h_stat[7] = 1.0;
+        if (iterations > 0) next = Collective{d_red, 1, TC2LI_REDUCE_SUM};  // else: the wrapper's result sum comes first
+        if (const char* inj = getenv("TC2LI_TEST_SHARD_FAIL")) {  // tests: "<rank>:setup" makes that rank fail before its first collective
+            int r = -1; char where[16] = {0};
+            if (sscanf(inj, "%d:%15s", &r, where) == 2 && r == shard->rank && !strcmp(where, "setup")) {
+                set_error("injected failure (TC2LI_TEST_SHARD_FAIL=%s)", inj);
+                return leave(TC2LI_ERR_INVALID);
+            }
+        }
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
     std::vector<uint8_t> extra_used;
@@ -254,18 +326,16 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     } else if (used_all) {
         extra_used.assign(used_all, used_all + n_poses);
     }
-    BaWorkspace& ws = ba_ws();
-    std::lock_guard<std::mutex> lk(ws.mu);
     BalmTerm* lidar = nullptr;
     if (lidar_window) {
         const int rc = ws.lidar.build(poses7, n_poses, lidar_window, st);
-        if (rc < 0) return rc;
+        if (rc < 0) return leave(rc);
         lidar = &ws.lidar;
     }
     VisualProblem vp;
     {
         const int rc = vp.setup(ws, poses7, fixed, n_poses, points3, n_points, edges, n_edges, cam, extra_used.empty() ? nullptr : extra_used.data(), st);
-        if (rc < 0) return rc;
+        if (rc < 0) return leave(rc);
     }
     BaProblemDev& pb = vp.pb;
     const std::vector<int>& pose_var = vp.pose_var;
@@ -282,18 +352,8 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     const double t_begin = now();
     // sharded window: the sums land in d_red, are all-reduced there and then copied to where the single-GPU path has them;
     // the stop flag is agreed on with the [scale, chi2] sum of every trial, so that all ranks leave the loops together
-    const bool sharded = shard != nullptr;
     bool stop_agreed = false;
-    double* d_red = nullptr;
-    if (sharded) {
-        TC2LI_HIP_CHECK(ws.d_red.ensure((size_t)np * np + 2 * (size_t)np + 27 * (size_t)std::max(n_free, 1) + 8));
-        d_red = ws.d_red.p;
-    }
-    auto reduce = [&](double* dev, size_t count, int op) {
-        const int rc = shard->allreduce(shard->ctx, dev, count, op, st);
-        if (rc != 0) { set_error("sharded bundle adjustment: the all-reduce callback returned %d", rc); return (int)TC2LI_ERR_COMM; }
-        return 0;
-    };
+    const Collective kTrialSystem{d_red, (size_t)np * np + 2 * (size_t)np, TC2LI_REDUCE_SUM}, kTrialScalars{d_red, 3, TC2LI_REDUCE_SUM};
     auto stopped = [&] { return sharded ? stop_agreed : (stop_flag && *stop_flag); };
     double lambda = -1, ni = 2;
     int n_bad = 0, done = 0, trials_total = 0;
@@ -305,22 +365,40 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         double t0 = now();
         const bool want_maxdiag = it == 0 && !(lambda_init > 0);
-        ba_launch_linearize(pb, sharded ? d_red : h_scal.p, sharded ? d_red + 1 : h_scal.p + 1, want_maxdiag, st);
-        TC2LI_HIP_CHECK(hipGetLastError());
+        if (sharded) next = Collective{d_red, 1, TC2LI_REDUCE_SUM};
+        // sharded layout of d_red in this phase: [0] chi2, [1] its status word, [4] largest landmark diagonal ([5]: status word, over
+        // the pose maximum k_ba_maxdiag leaves there -- the pose diagonal is summed over the ranks below), [8 ..) packed Hpp
+        ba_launch_linearize(pb, sharded ? d_red : h_scal.p, sharded ? d_red + 4 : h_scal.p + 1, want_maxdiag, st);
+        TC2LI_SH_CHECK(hipGetLastError());
         const bool need_diag = (lidar || sharded) && want_maxdiag && n_free > 0;
-        if (need_diag) TC2LI_HIP_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
+        if (need_diag) TC2LI_SH_CHECK(ws.h_Hpp.ensure(27 * (size_t)n_free));
         if (sharded) {
             if (int rc = reduce(d_red, 1, TC2LI_REDUCE_SUM)) return rc;  // chi2 of all edges
+            next = np > 0 ? kTrialSystem : kTrialScalars;
+            // a failed rank joins ONE collective: before another one follows without a decision in between (first iteration only),
+            // the status word of the one just made is read
+            auto agreed = [&]() -> int {
+                if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); set_error("sharded bundle adjustment: synchronisation failed"); return (int)TC2LI_ERR_HIP; }
+                return peer_failed() ? (int)TC2LI_ERR_COMM : 0;
+            };
             if (want_maxdiag) {
-                if (int rc = reduce(d_red + 1, 1, TC2LI_REDUCE_MAX)) return rc;  // largest landmark diagonal of any rank
+                next = Collective{d_red + 4, 1, TC2LI_REDUCE_MAX};
+                if (int rc = agreed()) return rc;
+                if (int rc = reduce(d_red + 4, 1, TC2LI_REDUCE_MAX)) return rc;  // largest landmark diagonal of any rank
+                next = np > 0 ? kTrialSystem : kTrialScalars;
                 if (need_diag) {  // the pose diagonal is a sum over the ranks' edges before it is a maximum
                     double* d_hpp_sum = d_red + 8;
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(d_hpp_sum, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    next = Collective{d_hpp_sum, 27 * (size_t)n_free, TC2LI_REDUCE_SUM};
+                    if (int rc = agreed()) return rc;
+                    TC2LI_SH_CHECK(hipMemcpyAsync(d_hpp_sum, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToDevice, st));
                     if (int rc = reduce(d_hpp_sum, 27 * (size_t)n_free, TC2LI_REDUCE_SUM)) return rc;
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_hpp_sum, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
+                    next = np > 0 ? kTrialSystem : kTrialScalars;
+                    TC2LI_SH_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_hpp_sum, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
                 }
             }
-            TC2LI_HIP_CHECK(hipMemcpyAsync(h_scal.p, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+            TC2LI_SH_CHECK(hipMemcpyAsync(h_scal.p, d_red, sizeof(double), hipMemcpyDeviceToHost, st));
+            TC2LI_SH_CHECK(hipMemcpyAsync(h_scal.p + 1, d_red + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+            h_scal.p[2] = 0;  // the pose maximum comes from the summed Hpp (need_diag) or there is no free pose
         } else if (need_diag) {
             TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_Hpp.p, d_Hpp.p, 27 * (size_t)n_free * sizeof(double), hipMemcpyDeviceToHost, st));
         }
@@ -330,10 +408,11 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             if (it == 0) lidar->enqueue_error(pb.poses, st);
             else lidar->eig_at = pb.poses;
             const int rc = lidar->enqueue_linearization(pb.poses, st);
-            if (rc < 0) return rc;
+            if (rc < 0) return leave(rc);
         }
-        TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+        TC2LI_SH_CHECK(hipGetLastError());
+        TC2LI_SH_CHECK(hipStreamSynchronize(st));
+        if (sharded && peer_failed()) return (int)TC2LI_ERR_COMM;
         tm[1] += now() - t0; t0 = now();
         double currentChi = h_scal.p[0];
         double max_pose_diag = h_scal.p[2];
@@ -369,14 +448,16 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             // W Hll^-1 b_l; lambda goes onto the diagonal once (rank 0)
             ba_launch_schur(pb, lambda, sharded && shard->rank != 0 ? 0.0 : lambda, n_slices, k_per_slice, sharded ? d_red : h_S.p,
                             sharded ? d_red + (size_t)np * np : h_bs.p, st);
-            TC2LI_HIP_CHECK(hipGetLastError());
+            TC2LI_SH_CHECK(hipGetLastError());
             if (np > 0) {
                 if (sharded) {
                     if (int rc = reduce(d_red, (size_t)np * np + 2 * (size_t)np, TC2LI_REDUCE_SUM)) return rc;
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_S.p, d_red, (size_t)np * np * sizeof(double), hipMemcpyDeviceToHost, st));
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_bs.p, d_red + (size_t)np * np, 2 * (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
+                    next = kTrialScalars;  // what follows when the reduced system can be solved (a rank that fails before it knows cannot tell)
+                    TC2LI_SH_CHECK(hipMemcpyAsync(h_S.p, d_red, (size_t)np * np * sizeof(double), hipMemcpyDeviceToHost, st));
+                    TC2LI_SH_CHECK(hipMemcpyAsync(h_bs.p, d_red + (size_t)np * np, 2 * (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
                 }
-                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                TC2LI_SH_CHECK(hipStreamSynchronize(st));
+                if (sharded && peer_failed()) return (int)TC2LI_ERR_COMM;
                 tm[3] += now() - t0; t0 = now();
                 memcpy(Swork.data(), h_S.p, (size_t)np * np * sizeof(double));
                 if (lidar) {
@@ -393,14 +474,17 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             if (ok2) {
                 ba_launch_trial(pb, h_xp.p, lambda, sharded ? d_red : h_scal.p + 3, sharded ? d_red + 1 : h_scal.p + 4, st);
                 if (sharded) {
+                    next = kTrialScalars;
                     h_scal.p[7] = stop_flag && *stop_flag ? 1.0 : 0.0;
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(d_red + 2, h_scal.p + 7, sizeof(double), hipMemcpyHostToDevice, st));
+                    TC2LI_SH_CHECK(hipMemcpyAsync(d_red + 2, h_scal.p + 7, sizeof(double), hipMemcpyHostToDevice, st));
                     if (int rc = reduce(d_red, 3, TC2LI_REDUCE_SUM)) return rc;
-                    TC2LI_HIP_CHECK(hipMemcpyAsync(h_scal.p + 3, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+                    next = Collective{};  // trial again, next iteration or the result sum: decided by values this rank has not read yet
+                    TC2LI_SH_CHECK(hipMemcpyAsync(h_scal.p + 3, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
                 }
                 if (lidar) lidar->enqueue_error(pb.poses_trial, st);
-                TC2LI_HIP_CHECK(hipGetLastError());
-                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                TC2LI_SH_CHECK(hipGetLastError());
+                TC2LI_SH_CHECK(hipStreamSynchronize(st));
+                if (sharded && peer_failed()) return (int)TC2LI_ERR_COMM;
                 if (sharded) stop_agreed = h_scal.p[5] > 0;
                 tempChi = h_scal.p[4];
                 scale += h_scal.p[3];
@@ -413,6 +497,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             } else {
                 tempChi = std::numeric_limits<double>::max();
             }
+            if (sharded) next = np > 0 ? kTrialSystem : kTrialScalars;  // another trial (corrected below when the loops end)
             rho = currentChi - tempChi;
             scale += 1e-3;
             rho /= scale;
@@ -437,6 +522,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
         if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
         if (n_bad >= 3) ok = false;
     }
+    next = Collective{};  // the wrapper's result sum is the next collective: it tells the peers itself
     if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; }
     if (lidar && lidar_stats) {
         lidar_stats->n_planes = lidar->n_planes; lidar_stats->hessian_evaluations = lidar->hessian_evaluations;
@@ -453,6 +539,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     for (int k = 0; k < n_poses; ++k) { memcpy(poses7 + 7 * k, poses[k].q, 4 * sizeof(double)); memcpy(poses7 + 7 * k + 4, poses[k].t, 3 * sizeof(double)); }
     if (kTiming) fprintf(stderr, "BA timing ms: setup %.3f linearize %.3f lidar-lin %.3f schur %.3f solve %.3f trial %.3f lidar-err %.3f total %.3f\n", tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], now() - t_begin);
     return done;
+#undef TC2LI_SH_CHECK
 }
 
 int tc2li_local_lv_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
@@ -524,21 +611,32 @@ int tc2li_local_lv_bundle_adjustment_sharded(double* poses7, const uint8_t* fixe
     }
     std::vector<double> chi2(mine.size());
     std::vector<uint8_t> depth(mine.size());
-    const int rc = lv_ba_impl(poses7, fixed, n_poses, pts.data(), (int)global_point.size(), mine.data(), (int)mine.size(), cam, iterations,
-                              lambda_init, stop_flag, chi2.data(), depth.data(), stats, lidar_window, lidar_stats, shard, used_all.data(), stream_);
-    if (rc < 0) return rc;
-    // ---- every rank receives the whole result: one sum of [points | chi2 | depth flags], zeros where another rank owns the entry ----
+    bool peers_told = false;
+    int rc = lv_ba_impl(poses7, fixed, n_poses, pts.data(), (int)global_point.size(), mine.data(), (int)mine.size(), cam, iterations,
+                        lambda_init, stop_flag, chi2.data(), depth.data(), stats, lidar_window, lidar_stats, shard, used_all.data(), stream_, &peers_told);
+    if (rc == TC2LI_ERR_COMM || (rc < 0 && peers_told)) return rc;  // agreed on inside the loops: every rank is leaving
+    // ---- every rank receives the whole result: one sum of [points | chi2 | depth flags | status word], zeros where another rank owns the
+    // entry.  A rank that failed locally after its last collective joins this sum with its status word set (and zeros), so that the others
+    // return TC2LI_ERR_COMM instead of waiting for it. ----
     const size_t P = n_points, E = n_edges, total = 3 * P + 2 * E;
-    std::vector<double> all(total, 0.0);
-    for (size_t i = 0; i < global_point.size(); ++i) memcpy(&all[3 * (size_t)global_point[i]], &pts[3 * i], 3 * sizeof(double));
-    for (size_t i = 0; i < global_edge.size(); ++i) { all[3 * P + global_edge[i]] = chi2[i]; all[3 * P + E + global_edge[i]] = depth[i]; }
+    std::vector<double> all(total + 1, 0.0);
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
-    TC2LI_HIP_CHECK(ws.d_red.ensure(total));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_red.p, all.data(), total * sizeof(double), hipMemcpyHostToDevice, st));
-    if (shard->allreduce(shard->ctx, ws.d_red.p, total, TC2LI_REDUCE_SUM, st) != 0) { set_error("sharded bundle adjustment: the final all-reduce failed"); return TC2LI_ERR_COMM; }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(all.data(), ws.d_red.p, total * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (rc >= 0 && ws.d_red.ensure(total + 1) != hipSuccess) { set_error("sharded bundle adjustment: no memory for the result sum"); rc = TC2LI_ERR_HIP; }
+    if (rc >= 0) {
+        for (size_t i = 0; i < global_point.size(); ++i) memcpy(&all[3 * (size_t)global_point[i]], &pts[3 * i], 3 * sizeof(double));
+        for (size_t i = 0; i < global_edge.size(); ++i) { all[3 * P + global_edge[i]] = chi2[i]; all[3 * P + E + global_edge[i]] = depth[i]; }
+    } else {
+        all[total] = 1.0;
+        if (ws.d_red.n < total + 1) return rc;  // nothing to send from: the peers cannot be told
+    }
+    const std::string why = rc < 0 ? tc2li_last_error() : "";
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_red.p, all.data(), (total + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    if (shard->allreduce(shard->ctx, ws.d_red.p, total + 1, TC2LI_REDUCE_SUM, st) != 0) { set_error("sharded bundle adjustment: the final all-reduce failed"); return TC2LI_ERR_COMM; }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(all.data(), ws.d_red.p, (total + 1) * sizeof(double), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    if (rc < 0) { set_error("%s", why.c_str()); return rc; }
+    if (all[total] > 0) { set_error("sharded bundle adjustment: another rank failed; all ranks leave the window"); return TC2LI_ERR_COMM; }
     memcpy(points3, all.data(), 3 * P * sizeof(double));
     if (edge_chi2) memcpy(edge_chi2, &all[3 * P], E * sizeof(double));
     if (edge_depth_positive) for (size_t e = 0; e < E; ++e) edge_depth_positive[e] = all[3 * P + E + e] != 0;

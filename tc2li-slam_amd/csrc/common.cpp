@@ -44,6 +44,30 @@ hipError_t stream_wait_blocking(hipStream_t st) {
     return hipEventSynchronize(ev.e);
 }
 
+hipStream_t private_stream() {
+    constexpr int kMaxDev = 16;
+    struct Streams {
+        hipStream_t s[kMaxDev] = {};  // never destroyed: a thread may end after the HIP runtime has been torn down
+    };
+    static thread_local Streams ts;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
+    if (!ts.s[d] && hipStreamCreateWithFlags(&ts.s[d], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ts.s[d] = nullptr; }
+    return ts.s[d];
+}
+
+hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
+hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 WorkerPool::WorkerPool(int nthreads) {
     for (int i = 0; i < nthreads - 1; ++i) workers_.emplace_back([this] { loop(); });
 }

@@ -23,7 +23,14 @@ bool device_ready();
 // hipEventBlockingSync instead of spinning on the queue -- several host threads wait on the GPU at once and a spinning thread costs
 // a whole core (the GPU boxes give a process 16).  The short waits of the bundle-adjustment loop keep spinning: a wake-up costs
 // more than one of its kernels.
-hipError_t stream_wait_blocking(hipStream_t st);  // true when a HIP device is usable; sets the error text otherwise
+hipError_t stream_wait_blocking(hipStream_t st);
+// The stream of the entry points that take none (single-scan / single-frame calls): one non-blocking stream per host thread and
+// device, so such a call never touches the NULL stream -- work on the NULL stream serialises against every blocking stream of the
+// process (the other stage threads of the caller).  nullptr (= the NULL stream) only when the stream cannot be created.
+hipStream_t private_stream();
+// hipMemcpy on a stream of our own: asynchronous copy + wait for that stream only.
+hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st);
 
 #define TC2LI_HIP_CHECK(call)                                                                       \
     do {                                                                                            \

@@ -30,7 +30,27 @@ struct tc2li_lidar_map {
     float cell = 1.0f;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounding box of the points
     MapGrid grid{};
+    // Thread contract (include/tc2li_hip.h, "LiDAR map handle"): every entry point that reads or changes the map holds this lock from
+    // its first access until its device work on the map has completed, so calls from the tracking thread (UpdateMap -> map_incremental,
+    // Tracking.cc:1602-1603) and the LiDAR thread (feature_extraction) on one handle serialise inside the library.
+    mutable std::mutex mu;
 };
+
+namespace {
+// Locks the distinct maps of a batch in address order (two batches that share maps cannot deadlock).
+struct MapLocks {
+    std::vector<std::mutex*> mus;
+    MapLocks(tc2li_lidar_map* const* maps, int n) {
+        for (int i = 0; i < n; ++i) if (maps[i]) mus.push_back(&maps[i]->mu);
+        std::sort(mus.begin(), mus.end());
+        mus.erase(std::unique(mus.begin(), mus.end()), mus.end());
+        for (auto* m : mus) m->lock();
+    }
+    ~MapLocks() { for (auto it = mus.rbegin(); it != mus.rend(); ++it) (*it)->unlock(); }
+    MapLocks(const MapLocks&) = delete;
+    MapLocks& operator=(const MapLocks&) = delete;
+};
+}  // namespace
 
 struct tc2li_lidar {
     int max_scans = 0, cap = 0;  // scans per call, points per scan slot
@@ -202,6 +222,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     if (!out || max_points_per_scan <= 0 || max_scans <= 0) { set_error("tc2li_lidar_create: invalid argument"); return TC2LI_ERR_INVALID; }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     std::unique_ptr<tc2li_lidar> L(new tc2li_lidar());
+    hipStream_t ps = private_stream();
     L->max_scans = max_scans;
     L->cap = (max_points_per_scan + kSegBlock - 1) / kSegBlock * kSegBlock;
     L->total = (size_t)L->cap * max_scans;
@@ -223,7 +244,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     TC2LI_HIP_CHECK(L->d_states.alloc(S)); TC2LI_HIP_CHECK(L->d_grids.alloc(S));
     TC2LI_HIP_CHECK(L->d_hard_count.alloc(1)); TC2LI_HIP_CHECK(L->d_hard_list.alloc(T)); TC2LI_HIP_CHECK(L->d_recs.alloc(2 * T));
     TC2LI_HIP_CHECK(L->h_counts.alloc(4 * S + 1));
-    TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int)));
+    TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), ps));
     *out = L.release();
     return TC2LI_OK;
 }
@@ -246,34 +267,36 @@ int tc2li_lidar_preprocess(tc2li_lidar* L, const tc2li_velodyne_point* raw, int 
                            float time_unit_scale, tc2li_point* out, int capacity) {
     if (!L || n < 0 || (n > 0 && !raw) || point_filter_num < 1 || !out) { set_error("tc2li_lidar_preprocess: invalid argument"); return TC2LI_ERR_INVALID; }
     if (n == 0) return 0;  // preprocess.cpp:97 `if (plsize == 0) return;`
-    int rc = setup_segments(L, 1, &n, nullptr);
+    hipStream_t ps = private_stream();
+    int rc = setup_segments(L, 1, &n, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_raw.p, raw, (size_t)n * sizeof(VelodynePoint), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_raw_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
-    rc = run_preprocess(L, L->d_raw.p, point_filter_num, blind, time_unit_scale, nullptr);
+    TC2LI_HIP_CHECK(copy_sync(L->d_raw.p, raw, (size_t)n * sizeof(VelodynePoint), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_raw_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
+    rc = run_preprocess(L, L->d_raw.p, point_filter_num, blind, time_unit_scale, ps);
     if (rc != TC2LI_OK) return rc;
     int m = 0;
-    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_pre_count.p, sizeof(int), hipMemcpyDeviceToHost));
+    TC2LI_HIP_CHECK(copy_sync(&m, L->d_pre_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));
     if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
-    if (m) TC2LI_HIP_CHECK(hipMemcpy(out, L->d_pre.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (m) TC2LI_HIP_CHECK(copy_sync(out, L->d_pre.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     return m;
 }
 
 int tc2li_lidar_voxel_filter(tc2li_lidar* L, const tc2li_point* in, int n, float leaf, tc2li_point* out, int capacity) {
     if (!L || n < 0 || (n > 0 && !in) || !(leaf > 0) || !out) { set_error("tc2li_lidar_voxel_filter: invalid argument"); return TC2LI_ERR_INVALID; }
     if (n == 0) return 0;
-    int rc = setup_segments(L, 1, &n, nullptr);
+    hipStream_t ps = private_stream();
+    int rc = setup_segments(L, 1, &n, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre.p, in, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
-    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, nullptr);
+    TC2LI_HIP_CHECK(copy_sync(L->d_pre.p, in, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
+    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, ps);
     if (rc != TC2LI_OK) return rc;
     int m = 0, status = 0;
-    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_down_count.p, sizeof(int), hipMemcpyDeviceToHost));
-    TC2LI_HIP_CHECK(hipMemcpy(&status, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (status) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    TC2LI_HIP_CHECK(copy_sync(&m, L->d_down_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    TC2LI_HIP_CHECK(copy_sync(&status, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    if (status) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), ps)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
-    if (m) TC2LI_HIP_CHECK(hipMemcpy(out, L->d_down.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (m) TC2LI_HIP_CHECK(copy_sync(out, L->d_down.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     return m;
 }
 
@@ -297,15 +320,16 @@ int tc2li_lidar_undistort(tc2li_lidar* L, tc2li_point* points, int n, const tc2l
     std::vector<int> perm(n);
     for (int i = 0; i < n; ++i) perm[i] = rec[i].idx;
     static_assert(sizeof(tc2li_imu_pose6d) == sizeof(Pose6DDev), "ABI layout");
+    hipStream_t ps = private_stream();
     TC2LI_HIP_CHECK(L->d_perm.ensure(n));
     TC2LI_HIP_CHECK(L->d_imu_poses.ensure(std::max(n_poses, 1)));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_perm.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    if (n_poses) TC2LI_HIP_CHECK(hipMemcpy(L->d_imu_poses.p, imu_poses, (size_t)n_poses * sizeof(Pose6DDev), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_states.p, end_state, sizeof(LidarStateDev), hipMemcpyHostToDevice));
-    launch_undistort(L->d_pre.p, L->d_perm.p, n, L->d_imu_poses.p, n_poses, L->d_states.p, L->d_down.p, nullptr);
+    TC2LI_HIP_CHECK(copy_sync(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_perm.p, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ps));
+    if (n_poses) TC2LI_HIP_CHECK(copy_sync(L->d_imu_poses.p, imu_poses, (size_t)n_poses * sizeof(Pose6DDev), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_states.p, end_state, sizeof(LidarStateDev), hipMemcpyHostToDevice, ps));
+    launch_undistort(L->d_pre.p, L->d_perm.p, n, L->d_imu_poses.p, n_poses, L->d_states.p, L->d_down.p, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpy(points, L->d_down.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    TC2LI_HIP_CHECK(copy_sync(points, L->d_down.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     return n;
 }
 
@@ -409,10 +433,12 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     if (n == 0) return 0;
-    int rc = setup_segments(L, 1, &n, nullptr);
+    hipStream_t ps = private_stream();
+    std::lock_guard<std::mutex> lock(map->mu);
+    int rc = setup_segments(L, 1, &n, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(copy_sync(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
     TC2LI_HIP_CHECK(L->d_eskf_partial.ensure((size_t)((n + 255) / 256) * kEskfOutSize));
     TC2LI_HIP_CHECK(L->h_eskf_out.ensure(kEskfOutSize));
     L->last_down.assign(1, n);
@@ -432,16 +458,16 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
         tc2li_lidar_state ls;
         memcpy(ls.rot, x->rot, 72); memcpy(ls.pos, x->pos, 24); memcpy(ls.offset_R_L_I, x->offset_R_L_I, 72); memcpy(ls.offset_T_L_I, x->offset_T_L_I, 24);
         if (converge) {
-            rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, &ls, nullptr);
+            rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, &ls, ps);
             if (rc != TC2LI_OK) return rc;
             ++searches;
         } else {
-            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, &ls, sizeof(LidarStateDev), hipMemcpyHostToDevice, nullptr));
-            launch_eskf_refit(map->grid, L->d_down.p, n, L->d_states.p, L->d_nearest_idx.p, L->d_world.p, L->d_selected.p, L->d_normvec.p, nullptr);
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, &ls, sizeof(LidarStateDev), hipMemcpyHostToDevice, ps));
+            launch_eskf_refit(map->grid, L->d_down.p, n, L->d_states.p, L->d_nearest_idx.p, L->d_world.p, L->d_selected.p, L->d_normvec.p, ps);
         }
-        launch_eskf_normal(L->d_down.p, n, L->d_states.p, L->d_selected.p, L->d_normvec.p, extrinsic_est_en, L->d_eskf_partial.p, L->h_eskf_out.p, nullptr);
+        launch_eskf_normal(L->d_down.p, n, L->d_states.p, L->d_selected.p, L->d_normvec.p, extrinsic_est_en, L->d_eskf_partial.p, L->h_eskf_out.p, ps);
         TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+        TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
         ++calls;
         const double* o = L->h_eskf_out.p;
         const int M = (int)o[157];
@@ -473,8 +499,8 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
             // fewer rows than states: K = P Hc^T (Hc P Hc^T / R + I)^-1 / R on the explicit rows (at most 22 of them)
             std::vector<uint8_t> sel(n);
             std::vector<PointXYZINormal> nv(n);
-            TC2LI_HIP_CHECK(hipMemcpy(sel.data(), L->d_selected.p, n, hipMemcpyDeviceToHost));
-            TC2LI_HIP_CHECK(hipMemcpy(nv.data(), L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+            TC2LI_HIP_CHECK(copy_sync(sel.data(), L->d_selected.p, n, hipMemcpyDeviceToHost, ps));
+            TC2LI_HIP_CHECK(copy_sync(nv.data(), L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
             std::vector<double> H((size_t)M * 12, 0.0), h(M), PHt((size_t)kN * M), S((size_t)M * M), Si((size_t)M * M), K((size_t)kN * M);
             const M3 Rw = m3_from(x->rot), Ro = m3_from(x->offset_R_L_I);
             int k = 0;
@@ -564,25 +590,32 @@ int tc2li_lidar_map_create(tc2li_lidar_map** out) {
     if (!out) return TC2LI_ERR_INVALID;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     tc2li_lidar_map* m = new tc2li_lidar_map();
-    int rc = rebuild_grid(m, nullptr);
+    hipStream_t ps = private_stream();
+    int rc = rebuild_grid(m, ps);
     if (rc != TC2LI_OK) { delete m; return rc; }
     *out = m;
     return TC2LI_OK;
 }
 void tc2li_lidar_map_destroy(tc2li_lidar_map* m) { delete m; }
-int tc2li_lidar_map_size(const tc2li_lidar_map* m) { return m ? m->n : TC2LI_ERR_INVALID; }
+int tc2li_lidar_map_size(const tc2li_lidar_map* m) {
+    if (!m) return TC2LI_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(m->mu);
+    return m->n;
+}
 
 static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool reset) {
     if (!m || n < 0 || (n > 0 && !pts)) { set_error("tc2li_lidar_map: invalid argument"); return TC2LI_ERR_INVALID; }
+    hipStream_t ps = private_stream();
+    std::lock_guard<std::mutex> lock(m->mu);
     const int old = reset ? 0 : m->n;
     if ((size_t)old + n > m->d_points.n) {
         DevBuf<PointXYZINormal> bigger;
         TC2LI_HIP_CHECK(bigger.alloc(((size_t)old + n) * 3 / 2 + 1024));
-        if (old) TC2LI_HIP_CHECK(hipMemcpy(bigger.p, m->d_points.p, (size_t)old * sizeof(PointXYZINormal), hipMemcpyDeviceToDevice));
+        if (old) TC2LI_HIP_CHECK(copy_sync(bigger.p, m->d_points.p, (size_t)old * sizeof(PointXYZINormal), hipMemcpyDeviceToDevice, ps));
         std::swap(bigger.p, m->d_points.p);
         std::swap(bigger.n, m->d_points.n);
     }
-    if (n) TC2LI_HIP_CHECK(hipMemcpy(m->d_points.p + old, pts, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
+    if (n) TC2LI_HIP_CHECK(copy_sync(m->d_points.p + old, pts, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
     for (int i = 0; i < n; ++i) {
         const float c[3] = {pts[i].x, pts[i].y, pts[i].z};
         if (!std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) { set_error("non-finite map point"); return TC2LI_ERR_INVALID; }
@@ -593,9 +626,9 @@ static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool re
         }
     }
     m->n = old + n;
-    int rc = rebuild_grid(m, nullptr);
+    int rc = rebuild_grid(m, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
     return m->n;
 }
 int tc2li_lidar_map_build(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, true); }
@@ -647,6 +680,7 @@ int tc2li_lidar_map_incremental(tc2li_lidar* L, int scan, tc2li_lidar_map* m, co
         return TC2LI_ERR_INVALID;
     }
     hipStream_t st = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lock(m->mu);
     const int n = L->last_down[scan];
     const size_t base = (size_t)scan * L->cap;
     if (n_to_add) *n_to_add = 0;
@@ -680,8 +714,9 @@ int tc2li_lidar_map_incremental(tc2li_lidar* L, int scan, tc2li_lidar_map* m, co
 
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_boxes, void* stream_) {
     if (!m || n_boxes < 0 || (n_boxes > 0 && !boxes6)) { set_error("tc2li_lidar_map_delete_boxes: invalid argument"); return TC2LI_ERR_INVALID; }
-    if (n_boxes == 0 || m->n == 0) return 0;
     hipStream_t st = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (n_boxes == 0 || m->n == 0) return 0;
     TC2LI_HIP_CHECK(m->d_deleted.ensure(m->n));
     TC2LI_HIP_CHECK(m->d_boxes.ensure(6 * (size_t)n_boxes));
     TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
@@ -696,8 +731,10 @@ int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_
 
 int tc2li_lidar_map_download(const tc2li_lidar_map* m, tc2li_point* out, int capacity) {
     if (!m || (capacity > 0 && !out)) { set_error("tc2li_lidar_map_download: invalid argument"); return TC2LI_ERR_INVALID; }
+    hipStream_t ps = private_stream();
+    std::lock_guard<std::mutex> lock(m->mu);
     const int k = std::min(m->n, capacity);
-    if (k > 0) TC2LI_HIP_CHECK(hipMemcpy(out, m->d_points.p, (size_t)k * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (k > 0) TC2LI_HIP_CHECK(copy_sync(out, m->d_points.p, (size_t)k * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     return m->n;
 }
 
@@ -746,32 +783,34 @@ int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const t
                                    tc2li_point* laser_cloud_ori, tc2li_point* corr_normvect, int capacity) {
     if (!L || !map || n < 0 || (n > 0 && !feats_down_body) || !state) { set_error("tc2li_lidar_feature_extraction: invalid argument"); return TC2LI_ERR_INVALID; }
     if (n == 0) return 0;
-    int rc = setup_segments(L, 1, &n, nullptr);
+    hipStream_t ps = private_stream();
+    std::lock_guard<std::mutex> lock(map->mu);
+    int rc = setup_segments(L, 1, &n, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice));
-    rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, state, nullptr);
+    TC2LI_HIP_CHECK(copy_sync(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
+    rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, state, ps);
     if (rc != TC2LI_OK) return rc;
     L->last_down.assign(1, n);
     int m = 0;
-    TC2LI_HIP_CHECK(hipMemcpy(&m, L->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (feats_down_world) TC2LI_HIP_CHECK(hipMemcpy(feats_down_world, L->d_world.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
-    if (point_selected) TC2LI_HIP_CHECK(hipMemcpy(point_selected, L->d_selected.p, (size_t)n, hipMemcpyDeviceToHost));
-    if (normvec) TC2LI_HIP_CHECK(hipMemcpy(normvec, L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
-    if (n_nearest) TC2LI_HIP_CHECK(hipMemcpy(n_nearest, L->d_nfound.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    if (nearest_sqdist) TC2LI_HIP_CHECK(hipMemcpy(nearest_sqdist, L->d_nearest_d.p, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost));
+    TC2LI_HIP_CHECK(copy_sync(&m, L->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    if (feats_down_world) TC2LI_HIP_CHECK(copy_sync(feats_down_world, L->d_world.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
+    if (point_selected) TC2LI_HIP_CHECK(copy_sync(point_selected, L->d_selected.p, (size_t)n, hipMemcpyDeviceToHost, ps));
+    if (normvec) TC2LI_HIP_CHECK(copy_sync(normvec, L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
+    if (n_nearest) TC2LI_HIP_CHECK(copy_sync(n_nearest, L->d_nfound.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ps));
+    if (nearest_sqdist) TC2LI_HIP_CHECK(copy_sync(nearest_sqdist, L->d_nearest_d.p, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, ps));
     if (nearest_points) {
         std::vector<int> idx((size_t)n * 5);
         std::vector<PointXYZINormal> mp(map->n);
-        TC2LI_HIP_CHECK(hipMemcpy(idx.data(), L->d_nearest_idx.p, idx.size() * sizeof(int), hipMemcpyDeviceToHost));
-        if (map->n) TC2LI_HIP_CHECK(hipMemcpy(mp.data(), map->d_points.p, (size_t)map->n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+        TC2LI_HIP_CHECK(copy_sync(idx.data(), L->d_nearest_idx.p, idx.size() * sizeof(int), hipMemcpyDeviceToHost, ps));
+        if (map->n) TC2LI_HIP_CHECK(copy_sync(mp.data(), map->d_points.p, (size_t)map->n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
         for (size_t k = 0; k < idx.size(); ++k)
             if (idx[k] >= 0) memcpy(&nearest_points[k], &mp[idx[k]], sizeof(PointXYZINormal));
             else memset(&nearest_points[k], 0, sizeof(PointXYZINormal));
     }
     if (m > capacity && (laser_cloud_ori || corr_normvect)) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
-    if (laser_cloud_ori && m) TC2LI_HIP_CHECK(hipMemcpy(laser_cloud_ori, L->d_cloud_ori.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
-    if (corr_normvect && m) TC2LI_HIP_CHECK(hipMemcpy(corr_normvect, L->d_corr.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost));
+    if (laser_cloud_ori && m) TC2LI_HIP_CHECK(copy_sync(laser_cloud_ori, L->d_cloud_ori.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
+    if (corr_normvect && m) TC2LI_HIP_CHECK(copy_sync(corr_normvect, L->d_corr.p, (size_t)m * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     return m;
 }
 
@@ -787,6 +826,8 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     }
     if (n_scans == 0) return 0;
     hipStream_t st = (hipStream_t)stream_;
+    for (int s = 0; s < n_scans; ++s) if (!maps[s]) { set_error("tc2li_lidar_frontend_batch: map %d is NULL", s); return TC2LI_ERR_INVALID; }
+    MapLocks locks(maps, n_scans);
     std::vector<int> upper(n_scans);
     for (int s = 0; s < n_scans; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
     // raw scans are packed back to back by the caller and read in place (ScanSlot::raw_base)
@@ -810,7 +851,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 2 * n_scans, L->d_sel_count.p, n_scans * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * n_scans, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(hipMemset(L->d_status.p, 0, sizeof(int))); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), st)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     L->last_down.assign(hc + n_scans, hc + 2 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
         if (n_preprocessed) n_preprocessed[s] = hc[s];

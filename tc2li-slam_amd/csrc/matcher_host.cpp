@@ -127,7 +127,7 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
         koff += fr.n_keys;
     }
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_ur.p, w.h_ur.p, std::max(total_k, 1) * sizeof(float), hipMemcpyHostToDevice, st));
-    if (any_occ) TC2LI_HIP_CHECK(hipMemcpy(w.d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice));  // pageable source: synchronous copy
+    if (any_occ) TC2LI_HIP_CHECK(copy_sync(w.d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice, st));  // pageable source: synchronous copy
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_queries.p, queries, (size_t)total_q * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
@@ -193,22 +193,23 @@ int tc2li_search_by_projection(const tc2li_frame_view* frame, const tc2li_proj_q
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     MatcherWorkspace& w = mws();
     std::lock_guard<std::mutex> lk(w.mu);
+    hipStream_t ps = private_stream();
     std::vector<MatchKey> keys(N);
     for (int i = 0; i < N; ++i) keys[i] = MatchKey{frame->keys[i].x, frame->keys[i].y, frame->keys[i].octave};
     TC2LI_HIP_CHECK(w.d_frames.ensure(1)); TC2LI_HIP_CHECK(w.d_keys.ensure(N)); TC2LI_HIP_CHECK(w.d_desc.ensure((size_t)N * 32));
     TC2LI_HIP_CHECK(w.d_occ.ensure(N)); TC2LI_HIP_CHECK(w.d_ur.ensure(N)); TC2LI_HIP_CHECK(w.d_queries.ensure(M));
     TC2LI_HIP_CHECK(w.d_match.ensure(M)); TC2LI_HIP_CHECK(w.d_prev.ensure(M)); TC2LI_HIP_CHECK(w.d_rounds.ensure(1));
-    TC2LI_HIP_CHECK(hipMemcpy(w.d_keys.p, keys.data(), N * sizeof(MatchKey), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(w.d_desc.p, frame->descriptors, (size_t)N * 32, hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(w.d_ur.p, frame->u_right, N * sizeof(float), hipMemcpyHostToDevice));
-    if (frame->occupied) TC2LI_HIP_CHECK(hipMemcpy(w.d_occ.p, frame->occupied, N, hipMemcpyHostToDevice));
-    else TC2LI_HIP_CHECK(hipMemset(w.d_occ.p, 0, N));
-    TC2LI_HIP_CHECK(hipMemcpy(w.d_queries.p, queries, (size_t)M * sizeof(MatchQuery), hipMemcpyHostToDevice));
+    TC2LI_HIP_CHECK(copy_sync(w.d_keys.p, keys.data(), N * sizeof(MatchKey), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(w.d_desc.p, frame->descriptors, (size_t)N * 32, hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(w.d_ur.p, frame->u_right, N * sizeof(float), hipMemcpyHostToDevice, ps));
+    if (frame->occupied) TC2LI_HIP_CHECK(copy_sync(w.d_occ.p, frame->occupied, N, hipMemcpyHostToDevice, ps));
+    else TC2LI_HIP_CHECK(memset_sync(w.d_occ.p, 0, N, ps));
+    TC2LI_HIP_CHECK(copy_sync(w.d_queries.p, queries, (size_t)M * sizeof(MatchQuery), hipMemcpyHostToDevice, ps));
     MatchFrameDev fd{w.d_keys.p, w.d_desc.p, w.d_ur.p, w.d_occ.p, w.d_queries.p, N, M, 0, 0, frame->min_x, frame->max_x, frame->min_y, frame->max_y};
-    TC2LI_HIP_CHECK(hipMemcpy(w.d_frames.p, &fd, sizeof(fd), hipMemcpyHostToDevice));
-    launch_match_by_projection(w.d_frames.p, 1, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, nullptr);
+    TC2LI_HIP_CHECK(copy_sync(w.d_frames.p, &fd, sizeof(fd), hipMemcpyHostToDevice, ps));
+    launch_match_by_projection(w.d_frames.p, 1, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpy(match_of_query, w.d_match.p, M * sizeof(int32_t), hipMemcpyDeviceToHost));
+    TC2LI_HIP_CHECK(copy_sync(match_of_query, w.d_match.p, M * sizeof(int32_t), hipMemcpyDeviceToHost, ps));
     int nmatches = 0;
     for (int q = 0; q < M; ++q) nmatches += match_of_query[q] >= 0;
     if (check_orientation) nmatches -= rotation_filter(queries, M, frame->keys, match_of_query);

@@ -458,10 +458,12 @@ int tc2li_orb_extract(tc2li_orb* o, const uint8_t* image, int width, int height,
     int rc = setup_geometry(o, width, height);
     if (rc != TC2LI_OK) return rc;
     const LevelGeom& g = o->geom[0];
-    TC2LI_HIP_CHECK(hipMemcpy2D(o->d_level0.p, g.pitch, image, stride, width, height, hipMemcpyHostToDevice));
+    hipStream_t ps = private_stream();  // not the NULL stream: it would serialise against every blocking stream of the process
+    TC2LI_HIP_CHECK(hipMemcpy2DAsync(o->d_level0.p, g.pitch, image, stride, width, height, hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
     int32_t mono = -1;
     rc = tc2li_orb_extract_batch(o, o->d_level0.p, 1, width, height, g.pitch, g.img_stride, lapping_area, keypoints,
-                                 descriptors, capacity, n_keypoints, &mono, nullptr);
+                                 descriptors, capacity, n_keypoints, &mono, ps);
     if (rc < 0) return rc;
     return mono;
 }

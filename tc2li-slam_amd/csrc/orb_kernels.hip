@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
 // one workgroup per (cell, image).  The cell window (cell + 6 px) is staged in LDS; S = the largest arc
 // contrast is computed once (a pixel is a corner at threshold t iff S > t, its cv::FAST score is S-1), then
 // 3x3 strict non-max suppression is evaluated for iniTh and, if that leaves the cell empty, for minTh.
-// Survivors are emitted in row-major order through wave ballots, which is the order cv::FAST returns them in.
+// Survivors go into an LDS list through a counter atomic and are then ranked by counting the survivors that precede them in
+// row-major order (the order cv::FAST returns them in), so the emitted list is ordered without a ballot pass (a ballot
+// compaction was tried: 1.05 ms against 0.64 ms per 128 images).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool has_arc9(uint32_t m16) {
     uint32_t x = m16 | (m16 << 16);

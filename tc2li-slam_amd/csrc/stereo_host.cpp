@@ -138,15 +138,16 @@ int tc2li_stereo_match(tc2li_orb* left, tc2li_orb* right, const tc2li_keypoint* 
     TC2LI_HIP_CHECK(ws->h_d.ensure(n_left));
     TC2LI_HIP_CHECK(ws->h_sad.ensure(n_left));
     StereoFrame fr{0, n_left, n_left, n_right, 0, 0, 0, 0};
-    TC2LI_HIP_CHECK(hipMemcpy(ws->d_keys.p, keys.data(), n * sizeof(MatchKey), hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(ws->d_desc.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice));
-    if (n_right) TC2LI_HIP_CHECK(hipMemcpy(ws->d_desc.p + (size_t)n_left * 32, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice));
-    TC2LI_HIP_CHECK(hipMemcpy(ws->d_frames.p, &fr, sizeof(fr), hipMemcpyHostToDevice));
+    hipStream_t ps = private_stream();
+    TC2LI_HIP_CHECK(copy_sync(ws->d_keys.p, keys.data(), n * sizeof(MatchKey), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(ws->d_desc.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice, ps));
+    if (n_right) TC2LI_HIP_CHECK(copy_sync(ws->d_desc.p + (size_t)n_left * 32, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(ws->d_frames.p, &fr, sizeof(fr), hipMemcpyHostToDevice, ps));
     const float max_d = bf / b;
     launch_stereo_match(left->raw_tab, right->raw_tab, left->scale_tab, ws->d_frames.p, 1, n_left, ws->d_keys.p, ws->d_desc.p, bf,
-                        max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, nullptr);
+                        max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+    TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
     memcpy(u_right, ws->h_u.p, n_left * sizeof(float));
     memcpy(depth, ws->h_d.p, n_left * sizeof(float));
     if (best_sad) memcpy(best_sad, ws->h_sad.p, n_left * sizeof(int));

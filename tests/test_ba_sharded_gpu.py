@@ -114,3 +114,42 @@ def test_shard_argument_errors(pkg, synthetic):
     many = pkg.capi.BaShard(0, len(w["points"]) + 1, shard.allreduce, None)  # more ranks than landmarks
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.local_lv_bundle_adjustment_sharded(many, w["poses"], w["fixed"], w["points"], e, w["cam"])
+
+
+def _rank_failing(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TC2LI_TEST_SHARD_FAIL"] = "1:setup"  # rank 1 fails before its first collective (read by every rank, acted on by rank 1)
+    import torch
+    import torch.distributed as dist
+    import tc2li_loader
+    pkg = tc2li_loader.load()
+    from tc2li_slam_amd import synthetic
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, kw = _window(synthetic, 3, False)
+        e = pkg.pack_ba_edges(w["edges"])
+        shard, keep = pkg.capi.torch_allreduce_shard(rank, world)
+        try:
+            pkg.capi.local_lv_bundle_adjustment_sharded(shard, w["poses"], w["fixed"], w["points"], e, w["cam"], **kw)
+            out[rank] = "returned"
+        except pkg.capi.Tc2liError as err:
+            out[rank] = str(err)
+        del keep
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_takes_the_others_with_it(pkg):
+    """a rank that fails between two collectives must not leave the others blocked in the next all-reduce.  Rank 1 fails
+    in its set-up; it joins rank 0's first collective with the status word set, rank 0 reads it and returns TC2LI_ERR_COMM."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29800 + os.getpid() % 90
+    mp.spawn(_rank_failing, args=(2, port, out), nprocs=2, join=True)
+    assert "injected failure" in out[1], out[1]
+    assert "another rank failed" in out[0], out[0]
