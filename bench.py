@@ -1,33 +1,120 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the TC2LI-SLAM per-frame loop on MI355X (BASELINE.json metric: ORB+LiDAR front end + local BA).
 
-A step = one pass of the hot path over one batch of `--frames` synthetic KITTI-sized frames that are already resident in
-HBM (F independent sequences advancing one frame each):
-  camera / tracking thread : stereo ORB (2 x 1242x375) -> stereo matching -> TrackWithMotionModel (projection matching
-                             against the last frame + pose-only optimisation)
-  LiDAR thread             : preprocess -> voxel filter -> 5-NN + plane-fit feature extraction (one 64-beam scan per frame)
-  local-mapping thread     : every `--kf-interval`-th frame inserts a keyframe -> LocalLVBundleAdjustment (visual edges
-                             + the LiDAR plane edge), F / kf_interval windows per step
-which is the reference's thread structure (tracking, LiDAR front end, local mapping).  N > 1: one process per GPU;
-torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time -- sequences are
-independent units, so the path shards with no data-path collective ("weak": every rank processes its own frames).
+A step = one pass of the hot path over one batch of synthetic KITTI-sized frames that are already resident in HBM: every sequence of
+the batch advances one frame through the reference's threads:
+  camera / tracking thread : stereo ORB (2 x 1242x375) -> stereo matching -> TrackWithMotionModel (projection matching against the
+                             last frame + pose-only optimisation) -> TrackLocalMap (SearchLocalPoints + pose-only optimisation)
+  LiDAR thread             : lasermap_fov_segment -> preprocess -> voxel filter -> 5-NN + plane-fit feature extraction against the
+                             sequence's own map (1e5 - 1e6 points) -> map_incremental (the map grows in place on the device)
+  local-mapping thread     : every `--kf-interval`-th frame inserts a keyframe -> LocalLVBundleAdjustment (visual edges + the LiDAR
+                             plane edge)
+N > 1: one process per GPU (`python bench.py --gpus N` spawns the N ranks itself when it is not already running under
+torch.distributed.run); sequences are independent units, so the path shards with no data-path collective.  `--scaling strong`
+(default): a fixed global list of `--sequences` sequences is dealt over the ranks (dist_util.shard_units); `--scaling weak`: every
+rank owns `--frames` sequences.  torch.distributed (RCCL) carries the barrier around the timed region, the MAX of the elapsed times
+and the count of ranks.
 
-Prints ONE JSON line on rank 0; DESIGN.md section "Measurement" explains how roofline / cpu_baseline are derived.
+Prints ONE JSON line on rank 0; DESIGN.md section "Measurement" explains how roofline / cpu_baseline / the extra lines are derived.
 """
 import argparse
 import ctypes as C
 from concurrent.futures import ThreadPoolExecutor
 import json
 import os
+import queue
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+METRIC = "frames/sec (ORB+LiDAR front-end + local BA) on KITTI-00, 1/2/4/8 GPU; ATE vs ref"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--sequences", type=int, default=512, help="strong scaling: sequences of the whole job, dealt over the ranks")
+    ap.add_argument("--frames", type=int, default=64, help="weak scaling: sequences (one frame each per step) per GPU")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames rendered (tiled over the sequences)")
+    ap.add_argument("--kf-interval", type=int, default=4, help="a keyframe (one local BA window) every k-th frame")
+    ap.add_argument("--ba-concurrency", type=int, default=8, help="local-BA windows in flight (streams) per GPU")
+    ap.add_argument("--map-length", type=float, default=1000.0, help="metres of street in every sequence's LiDAR map (~190 points per metre)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU-oracle baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-lines", action="store_true", help="skip the single-sequence and the roofline passes (diagnostic runs)")
+    ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
+    ap.add_argument("--split-ba", action="store_true", help="after the timed loop: ONE LV-BA window split over all ranks (landmark partition + "
+                    "RCCL all-reduce of the shared-pose blocks, tc2li_local_lv_bundle_adjustment_sharded) next to the same window on one GPU; "
+                    "reported as \"sharded_window\", not part of `value`")
+    ap.add_argument("--stages", default="orb,track,lidar,ba", help="diagnostics: run only these stage threads in the timed loop")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--rehearse", action="store_true", help="no GPU work: the rank plumbing only (spawn, rendezvous, sharding, timing protocol, "
+                    "JSON line) -- what the world-2 gloo test on CPU drives")
+    ap.add_argument("--no-build", action="store_true", help="fail instead of building when the library is missing or stale (profiling runs: "
+                    "no child process may start under rocprofv3)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# rank plumbing
+# ---------------------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (this parent never touches
+    the GPU -- a process that has initialised HIP must not fork or exec), rendezvous on 127.0.0.1, pass rank 0's line through."""
+    n = args.gpus
+    if not args.rehearse:
+        import torch
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+        if have < n:
+            sys.stderr.write("bench.py --gpus %d: this node has %d GPU(s); refusing to run fewer ranks than asked for\n" % (n, have))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def rehearse(args, rank, world, dist, dist_util):
+    """The multi-rank protocol without device work: every rank 'processes' its share of the global list by sleeping."""
+    units = dist_util.shard_units(args.sequences, rank, world) if args.scaling == "strong" else list(range(args.frames))
+    dist_util.barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-4 * len(units))
+    dist_util.barrier(dist)
+    elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0)
+    seen = dist_util.count_ranks(dist)
+    total = dist_util.sum_int(dist, len(units))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(total * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "none (rehearsal)", "data": "none", "rehearsal": True,
+                          "ranks_seen": seen, "config": {"workload": "rank plumbing only", "sequences_total": total,
+                                                         "sequences_of_rank0": len(units)}}))
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------------------------------------------------
 def level_dims(w, h, nlevels=8, scale=1.2):
     dims, s = [], np.float32(1.0)
     for _ in range(nlevels):
@@ -37,212 +124,273 @@ def level_dims(w, h, nlevels=8, scale=1.2):
     return dims
 
 
-def algorithmic_bytes(w, h, nkp, lidar_counts):
-    """Compulsory HBM bytes per image (ORB kernels) / per scan (LiDAR kernels) of each kernel group."""
-    px = [a * b for a, b in level_dims(w, h)]
-    raw, pre, down, sel = lidar_counts
-    return {
-        "pyramid": sum(px[:-1]) + sum(px[1:]),           # read levels 0..6, write levels 1..7
-        "fast": sum(px) + 4 * 15000,                      # read every level once, write the candidate list
-        "blur": 2 * sum(px),                              # read + write every level
-        "orient_describe": nkp * (709 + 512 + 64 + 16),  # patch gathers + descriptor/angle/key out
-        "lidar_preprocess": 2 * raw * 32 + pre * 48,      # count pass + scatter pass read the raw scan, one write
-        "lidar_voxel_hash": 3 * pre * 48 + pre * 4,       # bbox, insert, fill passes over the points + member list
-        "lidar_voxel_centroid": pre * (48 + 4) + down * 48,
-        "lidar_knn_plane": down * (48 + 48 + 48 + 5 * 8 + 27 * 16),  # point in, world + normvec out, neighbours, 27-cell gather
-        "lidar_knn_hard": down * 0.02 * (48 + 48 + 48 + 5 * 8 + 125 * 16),  # the ~2 % of the queries that need the wider cubes
-        "lidar_select": down * 1 + sel * 4 * 48,
-    }
+class Workload:
+    """The synthetic inputs of `unique` distinct sequences: stereo pair, 64-beam scan, the street's accumulated
+    LiDAR map, the last frame TrackWithMotionModel projects from and the local map TrackLocalMap searches; sequence s uses set s % unique."""
+
+    def __init__(self, pkg, synthetic, unique, map_length, with_ba):
+        self.pkg, self.synthetic, self.U = pkg, synthetic, unique
+        W, H = synthetic.WIDTH, synthetic.HEIGHT
+        self.W, self.H = W, H
+        self.bf = np.float32(synthetic.BF)
+        self.b = np.float32(self.bf / np.float32(synthetic.FX))
+        self.cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, self.bf]).astype(np.float64)
+        self.images = np.empty((unique, 2, H, W), np.uint8)
+        self.scans, self.states, self.maps = [], [], []
+        for u in range(unique):
+            sc = synthetic.Scene(u)
+            self.images[u, 0], _ = sc.render(0.0, W, H, noise_seed=1)
+            self.images[u, 1], _ = sc.render(synthetic.BASELINE, W, H, noise_seed=2)
+            self.scans.append(synthetic.lidar_scan(sc, u + 1))
+            self.states.append(pkg.pack_lidar_state(*synthetic.lidar_state(u + 1)[:2]))
+            self.maps.append(synthetic.lidar_map(sc, x_from=-0.7 * map_length, x_to=0.3 * map_length))
+        self.ba_windows = []
+        if with_ba:
+            for k in range(4):
+                w = synthetic.ba_window(k, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
+                last = len(w["poses"]) - 1
+                win = list(range(last, last - 6, -1))
+                self.ba_windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=w["edges"],
+                                            win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=3000), Tcl7=synthetic.TCL7, weight=1.0,
+                                            cam=w["cam"]))
+        ang = 0.002
+        self.pose_pred = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), 0.02, -0.01, -0.08], np.float32)
+        self.last = None   # per unique: the last frame of TrackWithMotionModel
+        self.local = None  # per unique: (held, held_Xw, local map points)
+
+    def build_tracking_inputs(self, ext, stream):
+        """One extraction + stereo matching of the unique frames gives the 3-D points the tracking inputs are made of: the 'last frame' of
+        every sequence = the frame's own stereo points seen from the previous pose (descriptors drifted, 3 % outliers); the local map =
+        the frame's stereo points that the motion-model step does not hold, plus as many again that project outside the image or carry
+        foreign descriptors (what UpdateLocalMap hands to SearchLocalPoints: a few thousand points, about half of them in the frustum)."""
+        pkg, U, W, H = self.pkg, self.U, self.W, self.H
+        import torch
+        dev = torch.from_numpy(self.images.reshape(2 * U, H, W)).cuda()
+        orb = ext.extract_batch_dev(dev.data_ptr(), 2 * U, W, H, W, W * H, stream=stream)
+        st = pkg.stereo_match_batch(ext, U, float(self.bf), float(self.b), stream=stream)
+        fx, fy, cx, cy = [np.float32(v) for v in self.cam5[:4]]
+        sf = ext.GetScaleFactors()
+        self.last, lasts = [], []
+        for u in range(U):
+            rng = np.random.default_rng(7000 + u)
+            n = int(orb[2][2 * u])
+            kl, dl, z = orb[0][2 * u, :n].copy(), orb[1][2 * u, :n].copy(), st[1][u, :n].copy()
+            order = rng.permutation(n)
+            lk = kl[order]
+            lk["angle"] = (lk["angle"] + rng.normal(0, 3, n).astype(np.float32)) % np.float32(360)
+            zz = np.where(z[order] > 0, z[order], 1).astype(np.float32)
+            Xw = np.stack([(lk["x"] - cx) * zz / fx, (lk["y"] - cy) * zz / fy, zz], 1).astype(np.float32)
+            md = dl[order]
+            flips = rng.integers(0, 256, (n, 12))
+            for k in range(12):  # descriptor drift between consecutive frames
+                rows = rng.random(n) < 0.7
+                md[rows, flips[rows, k] // 8] ^= (np.uint8(1) << (flips[rows, k] % 8).astype(np.uint8))
+            self.last.append(dict(has_point=(z[order] > 0).astype(np.uint8), outlier=(rng.random(n) < 0.03).astype(np.uint8), Xw=Xw, keys=lk,
+                                  descriptors=md, pose7=np.array([0, 0, 0, 1, 0, 0, 0], np.float32)))
+        # what the motion-model step leaves on the frame decides which keypoints hold a point when TrackLocalMap starts
+        packed = pkg.capi.pack_last_frames(self.last)
+        trk = pkg.capi.track_motion_model_batch(ext, U, orb[0], st[0], packed, np.tile(self.pose_pred, (U, 1)), self.cam5, float(self.b), 7.0,
+                                                stream=stream)
+        self.local = []
+        cap = orb[0].shape[1]
+        for u in range(U):
+            rng = np.random.default_rng(9000 + u)
+            n = int(orb[2][2 * u])
+            k, d, z = orb[0][2 * u, :n], orb[1][2 * u, :n], st[1][u, :n]
+            ok = z > 0
+            zz = np.where(ok, z, 1).astype(np.float32)
+            X = np.stack([(k["x"] - cx) * zz / fx, (k["y"] - cy) * zz / fy, zz], 1).astype(np.float32)
+            mp = trk[1][u, :n]
+            held = np.where(mp >= 0, 1, 0).astype(np.uint8)
+            held_Xw = np.zeros((cap, 3), np.float32)
+            held_Xw[:n][mp >= 0] = self.last[u]["Xw"][mp[mp >= 0]]
+            loc = np.nonzero(ok & (held == 0))[0]
+            loc = loc[rng.permutation(len(loc))]
+            n_extra = len(loc) + 1500
+            pts = np.zeros(len(loc) + n_extra, pkg.MAP_POINT_DTYPE)
+            P = X[loc] + rng.normal(0, 0.01, (len(loc), 3)).astype(np.float32)
+            ze = rng.uniform(3.0, 70.0, n_extra).astype(np.float32)  # the rest of the local map: around and beyond the frustum
+            E = np.stack([rng.uniform(-1.6, 1.6, n_extra).astype(np.float32) * ze, rng.uniform(-0.5, 0.4, n_extra).astype(np.float32) * ze, ze], 1)
+            pts["pos"] = np.concatenate([P, E]).astype(np.float32)
+            dist = np.linalg.norm(pts["pos"], axis=1).astype(np.float32)
+            pts["normal"] = pts["pos"] / dist[:, None]
+            octave = np.concatenate([k["octave"][loc], rng.integers(0, 8, n_extra)])
+            raw = (dist * sf[octave]).astype(np.float32)
+            pts["max_distance_raw"], pts["max_distance"], pts["min_distance"] = raw, np.float32(1.2) * raw, np.float32(0.8) * (raw / sf[-1])
+            md = np.concatenate([d[loc], rng.integers(0, 256, (n_extra, 32)).astype(np.uint8)])
+            flips = rng.integers(0, 256, (len(loc), 12))
+            for j in range(12):
+                rows = np.nonzero(rng.random(len(loc)) < 0.7)[0]
+                md[rows, flips[rows, j] // 8] ^= (np.uint8(1) << (flips[rows, j] % 8).astype(np.uint8))
+            pts["descriptor"] = md
+            pts = pts[rng.permutation(len(pts))]
+            hfull = np.zeros(cap, np.uint8)
+            hfull[:n] = held
+            self.local.append((hfull, held_Xw, pts))
+        self.keypoints_per_image = float(np.mean(orb[2]))
+        self.stereo_matches = float(np.mean((st[1] > 0).sum(1)))
+        return orb
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames (stereo pair + scan) per step per GPU")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames rendered (tiled to --frames)")
-    ap.add_argument("--kf-interval", type=int, default=4, help="a keyframe (one local BA window) every k-th frame")
-    ap.add_argument("--ba-concurrency", type=int, default=8, help="local-BA windows in flight (streams) per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
-    ap.add_argument("--split-ba", action="store_true", help="after the timed loop: ONE LV-BA window split over all ranks (landmark partition + "
-                    "RCCL all-reduce of the shared-pose blocks, tc2li_local_lv_bundle_adjustment_sharded) next to the same window on one GPU; "
-                    "reported as \"sharded_window\", not part of `value`")
-    ap.add_argument("--stages", default="orb,track,lidar,ba", help="diagnostics: run only these stage threads in the timed loop")
-    args = ap.parse_args()
+class Loop:
+    """Handles and stage threads for F sequences (sequence ids `seq_ids`; sequence s runs on input set s % U)."""
 
-    import torch
-    import __graft_entry__ as ge
-    ge.build_native()
-    import tc2li_loader
-    pkg = tc2li_loader.load()
-    from tc2li_slam_amd import synthetic, dist_util
-    rank, local_rank, world = dist_util.rank_info()
+    def __init__(self, wl, seq_ids, args, local_rank, template_orb_out=None):
+        import torch
+        self.torch, self.wl, self.args, self.local_rank = torch, wl, args, local_rank
+        pkg, U, W, H = wl.pkg, wl.U, wl.W, wl.H
+        self.pkg = pkg
+        self.F = F = len(seq_ids)
+        self.tile = tile = [s % U for s in seq_ids]
+        self.n_img = 2 * F
+        self.dev_img = torch.from_numpy(wl.images[tile].reshape(2 * F, H, W)).cuda()
+        raw = np.concatenate([wl.scans[t] for t in tile])
+        self.raw_offs = np.concatenate([[0], np.cumsum([len(wl.scans[t]) for t in tile])]).astype(np.int32)
+        self.dev_raw = torch.from_numpy(raw.view(np.uint8)).cuda()
+        self.states = np.stack([wl.states[t] for t in tile])
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.lidar_stream = torch.cuda.Stream()
+        self.track_stream = torch.cuda.Stream()
+        self.exts = [pkg.OrbExtractor(max_width=W, max_height=H, max_images=self.n_img) for _ in range(2)]  # extraction of batch k+1 overlaps tracking of batch k
+        self.lidar = pkg.LidarFrontEnd(max_points_per_scan=int(max(len(s) for s in wl.scans)), max_scans=F)
+        self.maps = []
+        for t in tile:  # every sequence owns its map: map_incremental changes it
+            m = pkg.LidarMap()
+            m.Build(wl.maps[t])
+            self.maps.append(m)
+        self.map_points0 = int(np.mean([m.size() for m in self.maps]))
+        self.boxes = [pkg.capi.LocalMapBox() for _ in range(F)]
+        self.scan_ids = np.arange(F, dtype=np.int32)
+        # tracking inputs
+        self.last_frames = pkg.capi.pack_last_frames([wl.last[t] for t in tile])
+        self.pose_pred = np.tile(wl.pose_pred, (F, 1))
+        self.held = np.stack([wl.local[t][0] for t in tile])
+        self.held_Xw = np.stack([wl.local[t][1] for t in tile])
+        self.local_pts = np.concatenate([wl.local[t][2] for t in tile])
+        self.local_off = np.concatenate([[0], np.cumsum([len(wl.local[t][2]) for t in tile])]).astype(np.int32)
+        # local mapping: F / kf_interval windows per step (a fraction of a window per step when F < kf_interval)
+        self.ba_rate = 0.0 if (args.front_end_only or not wl.ba_windows) else F / args.kf_interval
+        n_ba = int(np.ceil(self.ba_rate)) if self.ba_rate else 0
+        self.n_ba = n_ba
+        self.ba_batch = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n_ba)], wl.ba_windows[0]["cam"]) if n_ba else None
+        self.ba_due = 0.0
+        self.orb_outs = [None, None]
+        self.st_outs = [None, None]
+        self.trk_outs = [None, None]
+        self.tlm_out = None
+        self.lidar_counts = None
+        self.map_adds = [0, 0]
+        self.thread_ms = {}
+        self.orb_times, self.lidar_times = [], []
+        self.ba_windows_done = 0
 
-    if not torch.cuda.is_available() or pkg.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = dist_util.init("nccl", rank, world, device=torch.device("cuda", local_rank))  # None when world == 1
+    # -- stages ------------------------------------------------------------------------------------------------------------
+    def extract(self, k, stream):
+        W, H = self.wl.W, self.wl.H
+        self.orb_outs[k] = self.exts[k].extract_batch_dev(self.dev_img.data_ptr(), self.n_img, W, H, W, W * H, stream=stream, out=self.orb_outs[k])
 
-    W, H = synthetic.WIDTH, synthetic.HEIGHT
-    F, U = args.frames, min(args.unique, args.frames)
-    bf = np.float32(synthetic.BF)
-    b = np.float32(bf / np.float32(synthetic.FX))
-    cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, bf]).astype(np.float64)
+    def track(self, k, stream):
+        wl, pkg, F = self.wl, self.pkg, self.F
+        self.st_outs[k] = pkg.stereo_match_batch(self.exts[k], F, float(wl.bf), float(wl.b), stream=stream, out=self.st_outs[k])
+        self.trk_outs[k] = pkg.capi.track_motion_model_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.last_frames, self.pose_pred, wl.cam5,
+                                                             float(wl.b), 7.0, stream=stream, out=self.trk_outs[k])
+        # TrackLocalMap from the pose the motion-model step left on the frame (Tracking.cc:2038 -> :2218)
+        self.tlm_out = pkg.capi.track_local_map_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.trk_outs[k][0].astype(np.float32),
+                                                      self.held, self.held_Xw, self.local_pts, self.local_off, wl.cam5, th=1.0, stream=stream)
 
-    # ---- synthetic workload: U distinct frames (scene seed per rank), tiled to F --------------------------------
-    scene = synthetic.Scene(1000 * rank)
-    uniq_img = np.empty((U, 2, H, W), np.uint8)
-    scans = []
-    for f in range(U):
-        sc = synthetic.Scene(1000 * rank + f)
-        uniq_img[f, 0], _ = sc.render(0.0, W, H, noise_seed=1)
-        uniq_img[f, 1], _ = sc.render(synthetic.BASELINE, W, H, noise_seed=2)
-        scans.append(synthetic.lidar_scan(scene, f + 1))
-    tile = [f % U for f in range(F)]
-    frames = uniq_img[tile]
-    n_img = 2 * F
-    dev_img = torch.from_numpy(frames.reshape(n_img, H, W)).cuda()
-    raw = np.concatenate([scans[t] for t in tile])
-    raw_offs = np.concatenate([[0], np.cumsum([len(scans[t]) for t in tile])]).astype(np.int32)
-    dev_raw = torch.from_numpy(raw.view(np.uint8)).cuda()
-    states = np.stack([pkg.pack_lidar_state(*synthetic.lidar_state(t + 1)[:2]) for t in tile])
-    stream = torch.cuda.current_stream().cuda_stream
+    def lidar_step(self):
+        pkg, F = self.pkg, self.F
+        # lasermap_fov_segment (host logic) + the box deletions it asks for, per sequence
+        for s in range(F):
+            boxes = pkg.capi.lidar_fov_segment(self.boxes[s], self.states[s][9:12], cube_len=1000.0, det_range=100.0)
+            if len(boxes):
+                self.maps[s].Delete_Point_Boxes(boxes, stream=self.lidar_stream.cuda_stream)
+        self.lidar_counts = self.lidar.frontend_batch(self.dev_raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
+                                                      want_points=False)[0]
+        self.lidar_times.append(self.lidar.last_timings().astype(float))
+        # UpdateMap -> map_incremental (Tracking.cc:1602-1603) for every sequence's map: one batched call
+        na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, self.states, stream=self.lidar_stream.cuda_stream)
+        self.map_adds = [int(na.sum()), int(nn.sum())]
 
-    ext = pkg.OrbExtractor(max_width=W, max_height=H, max_images=n_img)
-    ext2 = pkg.OrbExtractor(max_width=W, max_height=H, max_images=n_img)  # second feature buffer: extraction of batch k+1 overlaps tracking of batch k
-    lidar = pkg.LidarFrontEnd(max_points_per_scan=int(max(len(s) for s in scans)), max_scans=F)
-    # resident map: the world-frame down-sampled scan of frame 0 (what ikdtree.Build gets, LidarFrontEnd.cpp:918-931)
-    boot = pkg.LidarMap()
-    scan0 = synthetic.lidar_scan(scene, 0)
-    down0 = lidar.voxel_filter(lidar.process(scan0))
-    boot.Build(down0[:8])
-    world0 = lidar.feature_extraction(boot, down0, pkg.pack_lidar_state(*synthetic.lidar_state(0)[:2]))["world"]
-    lmap = pkg.LidarMap()
-    lmap.Build(world0)
-    maps = [lmap] * F
+    def ba_step(self):
+        self.ba_due += self.ba_rate
+        k = int(self.ba_due + 1e-9)
+        if k < 1:
+            return
+        self.ba_due -= k
+        if self.ba_batch.run(self.args.ba_concurrency) != self.n_ba:
+            raise RuntimeError("a local BA window failed")
+        self.ba_windows_done += self.n_ba
 
-    # ---- tracking inputs: the "last frame" of every sequence = the frame's own stereo points seen from the previous pose
-    orb_out = ext.extract_batch_dev(dev_img.data_ptr(), n_img, W, H, W, W * H, stream=stream)
-    st_out = pkg.stereo_match_batch(ext, F, float(bf), float(b), stream=stream)
-    fx, fy, cx, cy = [np.float32(v) for v in cam5[:4]]
-    uniq_last = []
-    for u in range(U):
-        rng = np.random.default_rng(7000 + 1000 * rank + u)
-        f = tile.index(u)
-        n = int(orb_out[2][2 * f])
-        kl, dl, z = orb_out[0][2 * f, :n].copy(), orb_out[1][2 * f, :n].copy(), st_out[1][f, :n].copy()
-        order = rng.permutation(n)
-        lk = kl[order]
-        lk["angle"] = (lk["angle"] + rng.normal(0, 3, n).astype(np.float32)) % np.float32(360)
-        zz = np.where(z[order] > 0, z[order], 1).astype(np.float32)
-        Xw = np.stack([(lk["x"] - cx) * zz / fx, (lk["y"] - cy) * zz / fy, zz], 1).astype(np.float32)
-        md = dl[order]
-        flips = rng.integers(0, 256, (n, 12))
-        for k in range(12):  # descriptor drift between consecutive frames
-            sel_rows = rng.random(n) < 0.7
-            md[sel_rows, flips[sel_rows, k] // 8] ^= (np.uint8(1) << (flips[sel_rows, k] % 8).astype(np.uint8))
-        uniq_last.append(dict(has_point=(z[order] > 0).astype(np.uint8), outlier=(rng.random(n) < 0.03).astype(np.uint8), Xw=Xw, keys=lk,
-                              descriptors=md, pose7=np.array([0, 0, 0, 1, 0, 0, 0], np.float32)))
-    last_frames = pkg.capi.pack_last_frames([uniq_last[t] for t in tile])
-    ang = 0.002
-    pose_pred = np.tile(np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), 0.02, -0.01, -0.08], np.float32), (F, 1))
-    trk_out = None
-
-    # ---- local mapping: one LV-BA window per keyframe (SURVEY.md section 8d: 12 + 20 keyframes, ~3000 points, 6 clouds)
-    n_ba = 0 if args.front_end_only else max(1, F // args.kf_interval)
-    ba_batch = None
-    ba_windows = []
-    if n_ba:
-        for k in range(min(4, n_ba)):
-            w = synthetic.ba_window(100 * rank + k, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
-            last = len(w["poses"]) - 1
-            win = list(range(last, last - 6, -1))
-            ba_windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=w["edges"],
-                                   win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=3000), Tcl7=synthetic.TCL7, weight=1.0,
-                                   cam=w["cam"]))
-        ba_batch = pkg.capi.BaBatch([ba_windows[k % len(ba_windows)] for k in range(n_ba)], ba_windows[0]["cam"])
-
-    # Camera path, LiDAR path and local mapping are independent threads in the reference (src/examples/camera_lidar.cc:84,
-    # System.cc: tracking / local mapping threads, queues in between); here each stage runs its steps on its own host thread and
-    # HIP stream: ORB extraction -> (stereo matching + TrackWithMotionModel) as a two-deep pipeline over two feature buffers,
-    # the LiDAR front end, and local mapping.  A run of K steps = every stage has processed K batches.
-    import queue
-    import threading
-    lidar_stream = torch.cuda.Stream()
-    track_stream = torch.cuda.Stream()
-    exts = [ext, ext2]
-    orb_outs = [orb_out, tuple(np.zeros_like(a) for a in orb_out)]
-    st_outs = [st_out, None]
-    trk_outs = [None, None]
-    lidar_counts = None
-    thread_ms = {}
-    orb_times, lidar_times = [], []  # HIP-event stage durations of every call (the timed region is what run_steps did last)
-
-    def run_steps(n_steps):
-        nonlocal lidar_counts
-        free = queue.Queue()
-        ready = queue.Queue()
+    # -- the loop ------------------------------------------------------------------------------------------------------------
+    def run(self, n_steps, stages=("orb", "track", "lidar", "ba")):
+        """Every stage thread processes n_steps batches; ORB extraction and tracking form a two-deep pipeline over two feature buffers.
+        A failure in any stage stops all of them (no thread is left blocked on a queue) and is re-raised."""
+        torch = self.torch
+        free, ready = queue.Queue(), queue.Queue()
         free.put(0); free.put(1)
+        failed = threading.Event()
         errors = []
 
-        def guard(fn):
-            def wrapped():
+        def get(q):
+            while not failed.is_set():
                 try:
-                    fn()
-                except BaseException as e:  # noqa: BLE001
-                    errors.append(e)
-                    ready.put(None)
-            return wrapped
+                    return q.get(timeout=0.2)
+                except queue.Empty:
+                    continue
+            return None
 
         def orb_thread():
             for _ in range(n_steps):
-                k = free.get()
-                orb_outs[k] = exts[k].extract_batch_dev(dev_img.data_ptr(), n_img, W, H, W, W * H, stream=stream, out=orb_outs[k])
-                orb_times.append(exts[k].last_timings().astype(float))
+                k = get(free)
+                if k is None:
+                    return
+                self.extract(k, self.stream)
+                self.orb_times.append(self.exts[k].last_timings().astype(float))
                 ready.put(k)
 
         def track_thread():
             for _ in range(n_steps):
-                k = ready.get()
+                k = get(ready)
                 if k is None:
                     return
-                st_outs[k] = pkg.stereo_match_batch(exts[k], F, float(bf), float(b), stream=track_stream.cuda_stream, out=st_outs[k])
-                trk_outs[k] = pkg.capi.track_motion_model_batch(exts[k], F, orb_outs[k][0], st_outs[k][0], last_frames, pose_pred, cam5, float(b), 7.0,
-                                                                stream=track_stream.cuda_stream, out=trk_outs[k])
+                self.track(k, self.track_stream.cuda_stream)
                 free.put(k)
 
         def lidar_thread():
-            nonlocal lidar_counts
             for _ in range(n_steps):
-                lidar_counts = lidar.frontend_batch(dev_raw.data_ptr(), raw_offs, maps, states, stream=lidar_stream.cuda_stream, want_points=False)[0]
-                lidar_times.append(lidar.last_timings().astype(float))
+                if failed.is_set():
+                    return
+                self.lidar_step()
 
         def ba_thread():
             for _ in range(n_steps):
-                if ba_batch.run(args.ba_concurrency) != n_ba:
-                    raise RuntimeError("a local BA window failed")
+                if failed.is_set():
+                    return
+                self.ba_step()
 
-        fns = [orb_thread, track_thread, lidar_thread] + ([ba_thread] if ba_batch else [])
-        want = set(args.stages.split(","))
+        want = set(stages)
         if "track" in want:
             want.add("orb")  # tracking consumes what the extraction produces
-        fns = [f for f in fns if f.__name__.split("_")[0] in want]
+        fns = [f for f in (orb_thread, track_thread, lidar_thread, ba_thread) if f.__name__.split("_")[0] in want]
+        if not self.ba_batch:
+            fns = [f for f in fns if f is not ba_thread]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
             for _ in range(n_steps):
                 free.put(0)
 
-        def timed(fn):
+        def wrap(fn):
             def wrapped():
-                torch.cuda.set_device(local_rank)  # HIP's current device is per thread; a new thread starts on device 0
-                t = time.perf_counter()
-                fn()
-                thread_ms[fn.__name__] = 1e3 * (time.perf_counter() - t) / max(n_steps, 1)
+                try:
+                    torch.cuda.set_device(self.local_rank)  # HIP's current device is per thread; a new thread starts on device 0
+                    t = time.perf_counter()
+                    fn()
+                    self.thread_ms[fn.__name__] = 1e3 * (time.perf_counter() - t) / max(n_steps, 1)
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+                    failed.set()
             return wrapped
-        fns = [timed(fn) for fn in fns]
-        threads = [threading.Thread(target=guard(fn)) for fn in fns]
+        threads = [threading.Thread(target=wrap(fn), daemon=True) for fn in fns]
         for t in threads:
             t.start()
         for t in threads:
@@ -250,145 +398,320 @@ def main():
         if errors:
             raise errors[0]
 
+    def close(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# roofline: algorithmic bytes (or FLOPs) of one step per kernel (SURVEY.md section 8d figures x the units a step processes)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def algorithmic_work(wl, loop, nkp, lid, ba):
+    """{kernel name: (bytes or flops per STEP of `loop`, 'B' | 'FLOP')}.  lid = mean (raw, preprocessed, down-sampled, selected) points per scan;
+    ba = dict(edges, points, free, planes, win, windows, linearisations, trials) per step."""
+    px = [a * b for a, b in level_dims(wl.W, wl.H)]
+    n_img, F = loop.n_img, loop.F
+    raw, pre, down, sel = lid
+    mp = loop.map_points0
+    w = {
+        "k_resize_linear": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # read levels 0..6, write levels 1..7
+        "k_fast_cells": (n_img * (sum(px) + 4 * 15000), "B"),                          # every level once + the candidate list
+        "k_blur7_strips": (n_img * 2 * sum(px), "B"),
+        "k_orient_describe": (n_img * nkp * (709 + 512 + 64 + 16), "B"),                # patch gathers + descriptor / angle / key out
+        "k_compact_cells": (n_img * 120e3, "B"),
+        "k_stereo_match": (F * nkp * 40 * 64, "B"),                                     # ~40 candidate pairs per left key, 64 B per pair
+        "k_pre_count": (F * raw * 32, "B"), "k_pre_scatter": (F * (raw * 32 + pre * 48), "B"),   # SURVEY 8d counts the raw scan once: 7.3 MB per scan in all
+        "k_voxel_bbox": (F * pre * 48, "B"), "k_voxel_insert": (F * pre * 48, "B"), "k_voxel_fill": (F * pre * 8, "B"),
+        "k_voxel_rank": (F * pre * (48 + 32), "B"), "k_voxel_centroid": (F * (pre * 32 + down * 48), "B"),
+        "k_knn_plane": (F * down * (48 + 48 + 48 + 5 * 8 + 27 * 16), "B"),
+        "k_knn_hard": (F * down * 0.02 * (48 + 48 + 48 + 5 * 8 + 125 * 16), "B"),
+        "k_sel_scatter": (F * (down + sel * 4 * 48), "B"),
+        "k_map_keep_scatter": (F * mp * 96, "B"), "k_map_count": (F * mp * 52, "B"), "k_map_scatter": (F * mp * (48 + 16 + 8), "B"),
+        "k_map_keep_count": (F * mp, "B"),
+    }
+    if ba:
+        E, P, lin, tr, nw = ba["edges"], ba["points"], ba["linearisations"], ba["trials"], ba["windows"]
+        w.update({
+            "k_ba_linearize_b": (nw * lin * E * 700, "B"),                 # ~0.7 kB per edge per linearisation (SURVEY 8d)
+            "k_ba_reduce_all_b": (nw * lin * E * (36 + 9 + 9) * 8, "B"),
+            "k_ba_schur_prepare_b": (nw * tr * E * (18 + 36) * 8, "B"),
+            "k_ba_reduce_coef_b": (nw * tr * E * 36 * 8, "B"),
+            "k_ba_trial_update_b": (nw * tr * (E * 18 * 8 + P * 15 * 8), "B"),
+            "k_ba_errors_b": (nw * tr * E * 112, "B"),
+            # S -= (W D^-1) W^T as a dense product: 2 * (6 K)^2 / 2 * 3 P FLOP per trial over the lower tiles
+            "k_ba_schur_gemm_b": (nw * tr * 2.0 * (6 * ba["free"]) ** 2 / 2 * 3 * P, "FLOP"),
+            "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
+            "k_balm_residual_total_b": (nw * (lin + tr) * ba["planes"] * ba["win"] * 80, "B"),
+        })
+    return w
+
+
+def base_name(name):
+    return name.split("<")[0]
+
+
+def roofline_from_profile(report, work, peaks, n_steps):
+    """The kernel with the largest total device time of the profiled pass and what it achieves against its bound."""
+    by_kernel = {}
+    for name, (calls, ms) in report.items():
+        b = base_name(name)
+        c0, m0 = by_kernel.get(b, (0, 0.0))
+        by_kernel[b] = (c0 + calls, m0 + ms)
+    total_ms = sum(m for _, m in by_kernel.values())
+    ranked = sorted(by_kernel.items(), key=lambda kv: -kv[1][1])
+    table = {}
+    for name, (calls, ms) in ranked[:24]:
+        row = {"launches_per_step": round(calls / n_steps, 2), "ms_per_step": round(ms / n_steps, 4), "avg_launch_us": round(1e3 * ms / max(calls, 1), 2),
+               "share_of_kernel_time": round(ms / max(total_ms, 1e-9), 4)}
+        if name in work:
+            amount, unit = work[name]
+            rate = amount * n_steps / (ms * 1e-3)
+            if unit == "B":
+                row.update({"achieved_GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / 8000.0, 5)})
+            else:
+                row.update({"achieved_TFLOPs": round(rate / 1e12, 3), "frac_mfma_f64_measured": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5)})
+        table[name] = row
+    dom, (calls, ms) = ranked[0]
+    # copy / fill engines' blit kernels are not ours: the dominant kernel is the first one the library launches
+    for name, (c, m) in ranked:
+        if name.startswith("k_"):
+            dom, calls, ms = name, c, m
+            break
+    out = {"kernel": dom, "launches_per_step": round(calls / n_steps, 2), "avg_launch_ms": round(ms / max(calls, 1), 6),
+           "share_of_kernel_time": round(ms / max(total_ms, 1e-9), 4)}
+    if dom in work:
+        amount, unit = work[dom]
+        per_launch = amount * n_steps / max(calls, 1)
+        rate = per_launch / (ms / max(calls, 1) * 1e-3)
+        if unit == "B":
+            out.update({"bound": "hbm", "achieved": round(rate / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(rate / 1e9 / 8000.0, 5),
+                        "algorithmic_bytes_per_launch": int(per_launch)})
+        else:
+            out.update({"bound": "mfma", "achieved": round(rate / 1e12, 3), "peak": round(peaks["mfma_f64_tflops"], 2), "unit": "TFLOP/s",
+                        "frac": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5), "algorithmic_flops_per_launch": int(per_launch),
+                        "peak_source": "measured: back-to-back v_mfma_f64_16x16x4_f64 (tc2li_diag_peaks)"})
+    else:
+        out.update({"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None})
+    return out, table, total_ms / n_steps
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/profile_round.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
+    --pmc passes; the counters cannot be read inside this process).  None when no summary names the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        pmc = json.load(open(f))
+        hit = [v for k, v in pmc.items() if base_name(k.split("::")[-1]) == kernel and v.get("hbm_bytes_per_launch")]
+        if hit:
+            n = sum(v["launches"] for v in hit)
+            return {"bytes_per_launch": int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / max(n, 1)), "source": "profiles/" + os.path.basename(f),
+                    "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of the bench command at the commit that file was "
+                            "made at -- an earlier run, not this one"}
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle; rank 0 at N = 1 only)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, args, n_seq_gpu, with_ba):
+    from oracle import pyoracle
+    pyoracle.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    W, H = wl.W, wl.H
+    lasts = [dict(pose7=l["pose7"], has_point=l["has_point"], outlier=l["outlier"], Xw=l["Xw"], keys6=pyoracle._kps_to_floats(l["keys"]),
+                  descriptors=l["descriptors"]) for l in wl.last]
+
+    def make_seq(t):
+        return pyoracle.Sequence(wl.maps[t])
+
+    def frame(seq, t):
+        n = len(wl.last[t]["keys"])  # noqa: F841
+        held, held_Xw, pts = wl.local[t]
+        return seq.frame(wl.images[t, 0], wl.images[t, 1], float(wl.bf), float(wl.b), wl.scans[t], wl.states[t], wl.pose_pred, lasts[t], wl.cam5, 7.0,
+                         held, held_Xw, pts, th_local=1.0)
+
+    def cpu_ba(k):
+        w = wl.ba_windows[k % len(wl.ba_windows)]
+        return pyoracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges6"], w["cam"], w["win_pose"], w["clouds"], w["Tcl7"], 1.0)[4]
+
+    def run_sequences(n_seq, n_workers, budget):
+        """n_seq sequences advanced frame by frame by n_workers concurrent tracking threads (each frame call spawns the reference's ORB and LiDAR
+        threads itself); one local-mapping thread per sequence slot runs the LV-BA of every kf_interval-th frame."""
+        seqs = [make_seq(s % wl.U) for s in range(n_seq)]
+        ba_pool = ThreadPoolExecutor(max_workers=n_workers)
+        ba_futs, done = [], [0] * n_seq
+        stop = threading.Event()
+        t0 = time.perf_counter()
+
+        def worker(j):
+            while not stop.is_set():
+                for s in range(j, n_seq, n_workers):
+                    frame(seqs[s], s % wl.U)
+                    done[s] += 1
+                    if with_ba and done[s] % args.kf_interval == 0:
+                        ba_futs.append(ba_pool.submit(cpu_ba, done[s] // args.kf_interval + s))
+                if time.perf_counter() - t0 > budget and min(done[j::n_workers]) >= 2:
+                    return
+        ts = [threading.Thread(target=worker, args=(j,)) for j in range(n_workers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for f in ba_futs:
+            f.result()  # the loop is not finished before local mapping has caught up
+        dt = time.perf_counter() - t0
+        return sum(done), dt, len(ba_futs), seqs[0].map_size()
+
+    frames1, dt1, nba1, msize = run_sequences(1, 1, args.cpu_seconds)
+    n_many = max(2, min(n_seq_gpu, 2 * cores))
+    framesN, dtN, nbaN, _ = run_sequences(n_many, min(n_many, cores), args.cpu_seconds)
+    return {"value": round(framesN / dtN, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d sequences advanced concurrently on the %d host cores this process may use (of %d on the box), %d frames in %.1f s with %d local "
+                      "LV-BA windows; every frame with the reference's own threads (left / right ORB on 2 threads, LiDAR front end on a 3rd, tracking on "
+                      "the caller, local mapping on a 4th); the GPU line advances %d sequences per step -- the CPU rate does not depend on how many "
+                      "sequences wait beyond the cores, so the sample stops at 2 x cores" % (n_many, cores, os.cpu_count(), framesN, dtN, nbaN, n_seq_gpu),
+            "single_sequence": {"value": round(frames1 / dt1, 3), "unit": "frames/s", "cores": 4 if with_ba else 3,
+                                "sample": "1 sequence, %d frames in %.1f s (%d local LV-BA windows), the reference's 4 threads" % (frames1, dt1, nba1)},
+            "map_points": msize, "host_cpus": os.cpu_count()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+
+    import tc2li_loader
+    pkg = tc2li_loader.load()
+    from tc2li_slam_amd import synthetic, dist_util
+    rank, local_rank, world = dist_util.rank_info()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
+    if args.rehearse:
+        dist = dist_util.init("gloo", rank, world)
+        rc = rehearse(args, rank, world, dist, dist_util)
+        if dist is not None:
+            dist.destroy_process_group()
+        return rc
+
+    import torch
+    import __graft_entry__ as ge
+    if args.no_build or os.environ.get("TC2LI_NO_BUILD"):
+        if not ge.native_is_fresh():
+            raise SystemExit("bench.py --no-build: %s is missing or older than its sources; run `python __graft_entry__.py` first" % ge.LIB)
+    elif rank == 0:
+        ge.build_native()
+    if not torch.cuda.is_available() or pkg.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (the node shows %d)" % (rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dist = dist_util.init(args.backend, rank, world, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+
+    if args.scaling == "strong":
+        seq_ids = dist_util.shard_units(args.sequences, rank, world)
+        total_sequences = args.sequences
+    else:
+        seq_ids = list(range(rank * args.frames, (rank + 1) * args.frames))
+        total_sequences = args.frames * world
+    if not seq_ids:
+        raise SystemExit("bench.py: rank %d owns no sequence (%d sequences over %d ranks)" % (rank, args.sequences, world))
+    U = min(args.unique, max(len(seq_ids), 1) if args.scaling == "weak" else args.unique)
+    wl = Workload(pkg, synthetic, U, args.map_length, with_ba=not args.front_end_only)
+    stream = torch.cuda.current_stream().cuda_stream
+    ext0 = pkg.OrbExtractor(max_width=wl.W, max_height=wl.H, max_images=2 * U)
+    wl.build_tracking_inputs(ext0, stream)
+    ext0.close()
+    loop = Loop(wl, seq_ids, args, local_rank)
+    F = loop.F
+
     def barrier():
         dist_util.barrier(dist, torch.cuda.synchronize)
 
+    stages = tuple(args.stages.split(","))
     if args.warmup:
-        run_steps(args.warmup)
+        loop.run(args.warmup, stages)
     barrier()
-    orb_times.clear(); lidar_times.clear()
+    loop.orb_times.clear(); loop.lidar_times.clear()
+    ba0 = loop.ba_windows_done
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    loop.run(args.steps, stages)
     barrier()
-    if set(args.stages.split(",")) != {"orb", "track", "lidar", "ba"}:  # diagnostics: which stages slow each other down
+    local_elapsed = time.perf_counter() - t0
+    elapsed = dist_util.max_elapsed(dist, local_elapsed, device="cuda" if args.backend == "nccl" else "cpu")
+    ranks_seen = dist_util.count_ranks(dist, device="cuda" if args.backend == "nccl" else "cpu")
+    if set(stages) != {"orb", "track", "lidar", "ba"}:  # diagnostics: which stages slow each other down
         if rank == 0:
-            print(json.dumps({"diagnostic_stages": args.stages, "ms_per_step": round(1e3 * (time.perf_counter() - t0) / args.steps, 3),
-                              "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()}}))
-        return
-    loop_orb_ms, loop_lidar_ms = np.mean(orb_times, 0), np.mean(lidar_times, 0)
-    loop_chunks = ext.last_chunks()
-    elapsed = dist_util.max_elapsed(dist, time.perf_counter() - t0, device="cuda")
-    stage_ms = ext.last_timings().astype(float)
-    orb_out, st_out, trk_out = orb_outs[0], st_outs[0], trk_outs[0]
-    if st_out is None:
-        st_out = pkg.stereo_match_batch(ext, F, float(bf), float(b), stream=stream)
+            print(json.dumps({"diagnostic_stages": args.stages, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "frames_per_step": F,
+                              "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in loop.thread_ms.items()}}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+    thread_ms = dict(loop.thread_ms)
+    ba_windows_timed = loop.ba_windows_done - ba0
+    orb_out, st_out, trk_out, tlm_out = loop.orb_outs[0], loop.st_outs[0], loop.trk_outs[0], loop.tlm_out
     nkp = float(np.mean(orb_out[2]))
-    n_match = float(np.mean((st_out[1] > 0).sum(1)))
-    lid_mean = [int(np.mean(np.diff(raw_offs)))] + [int(v) for v in np.mean(lidar_counts, 1)]
+    lid_mean = [int(np.mean(np.diff(loop.raw_offs)))] + [int(v) for v in np.mean(loop.lidar_counts, 1)]
+    map_points_end = int(np.mean([m.size() for m in loop.maps]))
 
-    # stage wall times of one more step, every stage alone (host clock, each stage synchronises at its end)
+    # ---- stage wall times of one more step, every stage alone (host clock, each stage synchronises at its end) ----
     wall = {}
-    t_a = time.perf_counter()
-    ext.extract_batch_dev(dev_img.data_ptr(), n_img, W, H, W, W * H, stream=stream, out=orb_out)
-    wall["orb_extract_batch"] = time.perf_counter() - t_a; t_a = time.perf_counter()
-    pkg.stereo_match_batch(ext, F, float(bf), float(b), stream=stream, out=st_out)
-    wall["stereo_match_batch"] = time.perf_counter() - t_a; t_a = time.perf_counter()
-    pkg.capi.track_motion_model_batch(ext, F, orb_out[0], st_out[0], last_frames, pose_pred, cam5, float(b), 7.0, stream=stream, out=trk_out)
-    wall["track_motion_model_batch"] = time.perf_counter() - t_a; t_a = time.perf_counter()
-    lidar.frontend_batch(dev_raw.data_ptr(), raw_offs, maps, states, stream=stream, want_points=False)
-    wall["lidar_frontend_batch"] = time.perf_counter() - t_a; t_a = time.perf_counter()
-    lidar_ms = lidar.last_timings().astype(float)
-    if ba_batch:
-        ba_batch.run(args.ba_concurrency)
-        wall["local_lv_ba_batch(%d windows)" % n_ba] = time.perf_counter() - t_a; t_a = time.perf_counter()
-        ba_batch.run(1)
-        wall["local_lv_ba_batch, 1 window at a time"] = time.perf_counter() - t_a
+    if rank == 0 and not args.no_extra_lines:
+        t_a = time.perf_counter(); loop.extract(0, stream); wall["orb_extract_batch"] = time.perf_counter() - t_a
+        t_a = time.perf_counter(); loop.track(0, stream); wall["stereo + TrackWithMotionModel + TrackLocalMap"] = time.perf_counter() - t_a
+        t_a = time.perf_counter(); loop.lidar_step(); wall["lidar_frontend_batch + map_incremental"] = time.perf_counter() - t_a
+        if loop.ba_batch:
+            t_a = time.perf_counter(); loop.ba_batch.run(args.ba_concurrency); wall["local_lv_ba_batch(%d windows)" % loop.n_ba] = time.perf_counter() - t_a
 
-    # ---- roofline of the dominant kernel: HIP-event durations of every launch of the timed region (the stages run
-    # concurrently there, as in the rocprofv3 trace of the same command), on the stream each kernel is launched on; the same
-    # kernels measured alone afterwards are reported next to them ----
-    ext.set_profiling(True)
-    prof = []
-    for _ in range(3):
-        ext.extract_batch_dev(dev_img.data_ptr(), n_img, W, H, W, W * H, stream=stream, out=orb_out)
-        prof.append(ext.last_timings().astype(float))
-    ext.set_profiling(False)
-    prof = np.mean(prof, 0)
-    lprof = []
-    for _ in range(3):
-        lidar.frontend_batch(dev_raw.data_ptr(), raw_offs, maps, states, stream=stream, want_points=False)
-        lprof.append(lidar.last_timings().astype(float))
-    lprof = np.mean(lprof, 0)
+    # ---- roofline: a second pass of the same loop with an event pair around every kernel launch (the first, timed pass is
+    # un-instrumented: `value` comes from it); the dominant kernel = the one with the largest total device time over ALL kernels ----
+    roofline, kernel_table, kernel_ms_per_step, peaks = None, None, None, None
+    if rank == 0 and not args.no_extra_lines:
+        pk = pkg.capi.diag_peaks()
+        peaks = {"mfma_f64_tflops": round(pk[0], 2), "fma_f64_tflops": round(pk[1], 2), "hbm_copy_GBps": round(pk[2], 1),
+                 "note": "measured on this GPU by tc2li_diag_peaks: back-to-back v_mfma_f64_16x16x4_f64, f64 vector FMA, 1 GiB float4 copy (read + write)"}
+        n_prof = max(4, min(args.steps, 10))
+        pkg.capi.profile_enable(True)
+        ba1 = loop.ba_windows_done
+        loop.run(n_prof, stages)
+        torch.cuda.synchronize()
+        pkg.capi.profile_enable(False)
+        report = pkg.capi.profile_report()
+        ba = None
+        if loop.ba_batch:
+            s0, ls0 = loop.ba_batch.stats[0], loop.ba_batch.lstats[0]
+            w0 = wl.ba_windows[0]
+            ba = {"edges": len(w0["edges"]), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(ls0.n_planes), "win": 6,
+                  "windows": (loop.ba_windows_done - ba1) / n_prof, "linearisations": int(s0.iterations), "trials": int(s0.trials)}
+        roofline, kernel_table, kernel_ms_per_step = roofline_from_profile(report, algorithmic_work(wl, loop, nkp, lid_mean, ba), peaks, n_prof)
+        roofline["traffic"] = pmc_traffic(roofline["kernel"])
+        roofline["measured_in"] = ("a second pass of %d steps of the same concurrent loop with a HIP event pair around every kernel launch, on the stream "
+                                   "the kernel is launched on (tc2li_profile_*); tools/profile_round.sh commits the rocprofv3 --kernel-trace --stats "
+                                   "summary of this command under profiles/" % n_prof)
+        roofline["all_kernels"] = kernel_table
+        roofline["kernel_ms_per_step_all_streams"] = round(kernel_ms_per_step, 3)
+        roofline["peaks_measured"] = peaks
 
-    def stage_table(o, l):
-        return {"pyramid": o[0], "fast": o[1], "blur": o[3], "orient_describe": o[4], "lidar_preprocess": l[0], "lidar_voxel_hash": l[1],
-                "lidar_voxel_centroid": l[2], "lidar_knn_plane": l[6], "lidar_knn_hard": l[7], "lidar_select": l[4]}
-    isolated_ms = stage_table(prof, lprof)
-    alg = algorithmic_bytes(W, H, nkp, lid_mean)
-    kern_ms = stage_table(loop_orb_ms, loop_lidar_ms)
-    units = {k: (F if k.startswith("lidar") else n_img) for k in kern_ms}
-    # the ORB call pipelines chunks of images: each of its device stages is launched once per chunk, the event durations are the
-    # chunks' sums (the profiling passes above run unchunked, so `measured alone` is one launch per stage)
-    ch = max(1, loop_chunks)
-    launches = {"pyramid": 7 * ch, "fast": ch, "blur": ch, "orient_describe": ch, "lidar_preprocess": 3, "lidar_voxel_hash": 8, "lidar_voxel_centroid": 1,
-                "lidar_knn_plane": 1, "lidar_knn_hard": 1, "lidar_select": 3}
-    names = {"fast": "k_fast_cells", "blur": "k_blur7_strips", "pyramid": "k_resize_linear", "orient_describe": "k_orient_describe",
-             "lidar_preprocess": "k_pre_count+k_seg_scan+k_pre_scatter", "lidar_voxel_hash": "k_voxel_bbox..k_voxel_fill",
-             "lidar_voxel_centroid": "k_voxel_centroid", "lidar_knn_plane": "k_knn_plane", "lidar_knn_hard": "k_knn_hard",
-             "lidar_select": "k_sel_count+k_seg_scan+k_sel_scatter"}
-    single = [k for k in kern_ms if k in ("pyramid", "fast", "blur", "orient_describe") or launches[k] == 1]  # groups made of one kernel (x launches)
-    dom = max(single, key=lambda k: kern_ms[k])  # the kernel with the largest device time per step
-    bytes_per_launch = alg[dom] * units[dom] / launches[dom]
-    achieved = bytes_per_launch / (kern_ms[dom] / launches[dom] * 1e-3) / 1e9
-    # HBM traffic of that kernel from the PMC passes of tools/profile_round.sh (FETCH_SIZE x2 + WRITE_SIZE per launch, see
-    # tools/summarize_profile.py); the counters cannot be read inside this process, so the committed summary is used
-    traffic = None
-    for f in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        pmc = json.load(open(f))
-        # template instantiations of one kernel (FAST: the 48 x 48 and the full-size window variant, launched back to back per chunk)
-        # count as one launch of the stage
-        hit = [v for k, v in pmc.items() if k.split("::")[-1].split("<")[0] == names[dom] and v.get("hbm_bytes_per_launch")]
-        if hit:
-            traffic = {"bytes_per_launch": int(sum(v["hbm_bytes_per_launch"] for v in hit)), "source": os.path.basename(f),
-                       "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch, from the rocprofv3 --pmc passes of this same command"}
-            break
-    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "avg_launch_ms": round(kern_ms[dom] / launches[dom], 5),
-                "algorithmic_bytes_per_launch": int(bytes_per_launch), "launches_per_step": launches[dom],
-                "all_kernels_ms": {k: round(v, 4) for k, v in kern_ms.items()},
-                "all_kernels_ms_measured_alone": {k: round(v, 4) for k, v in isolated_ms.items()},
-                "all_kernels_GBps": {k: round(alg[k] * units[k] / (kern_ms[k] * 1e-3) / 1e9, 2) for k in kern_ms if kern_ms[k] > 0}}
+    # ---- the same loop for ONE sequence (F = 1): what a single KITTI-00 run sees ----
+    single = None
+    if rank == 0 and not args.no_extra_lines:
+        one = Loop(wl, [0], args, local_rank)
+        one.run(8, stages)
+        torch.cuda.synchronize()
+        n1 = 48
+        t1 = time.perf_counter()
+        one.run(n1, stages)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        single = {"value": round(n1 / dt1, 2), "unit": "frames/s", "ms_per_frame": round(1e3 * dt1 / n1, 3), "frames": n1,
+                  "ba_windows": one.ba_windows_done, "workload": "the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame" % args.kf_interval,
+                  "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one.thread_ms.items()}}
+        one.close()
 
-    # ---- CPU baseline: the oracle (a port) with the reference's threading -----------------------------------------
+    # ---- CPU baseline: the oracle (a port) with the reference's threading ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed at N = 1 only
-        from oracle import pyoracle
-        pyoracle.build()
-        L = pyoracle.lib()
-        L.oracle_loop_frame.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +
-                                        [C.c_float, C.c_int] + [C.c_void_p] * 8)
-        ol, orr = pyoracle.OrbOracle(), pyoracle.OrbOracle()
-        tree = pyoracle.KdTree(world0)
-        nsel, nmat = C.c_int(0), C.c_int(0)
-        pose_out = np.zeros(7)
-        lasts6 = [pyoracle._kps_to_floats(u["keys"]) for u in uniq_last]
-        ba_pool = ThreadPoolExecutor(max_workers=1)  # the local-mapping thread
-        ba_futs = []
-
-        def cpu_ba(k):
-            w = ba_windows[k % len(ba_windows)]
-            return pyoracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges6"], w["cam"], w["win_pose"], w["clouds"], w["Tcl7"], 1.0)[4]
-
-        done, tcpu0 = 0, time.perf_counter()
-        while done < 4 or (time.perf_counter() - tcpu0 < args.cpu_seconds and done < 600):
-            t = tile[done % F]
-            u = uniq_last[t]
-            L.oracle_loop_frame(ol._h, orr._h, uniq_img[t, 0].ctypes.data, uniq_img[t, 1].ctypes.data, W, H, float(bf), float(b),
-                                scans[t].ctypes.data, len(scans[t]), tree._h, states[done % F].ctypes.data, pose_pred[0].ctypes.data,
-                                u["pose7"].ctypes.data, cam5.ctypes.data, 7.0, len(u["keys"]), u["has_point"].ctypes.data,
-                                u["outlier"].ctypes.data, u["Xw"].ctypes.data, lasts6[t].ctypes.data, u["descriptors"].ctypes.data,
-                                pose_out.ctypes.data, C.byref(nsel), C.byref(nmat))
-            done += 1
-            if n_ba and done % args.kf_interval == 0:
-                ba_futs.append(ba_pool.submit(cpu_ba, done // args.kf_interval))
-        for fut in ba_futs:
-            fut.result()  # the loop is not finished before local mapping has caught up
-        tcpu = time.perf_counter() - tcpu0
-        cpu = {"value": round(done / tcpu, 3), "unit": "frames/s", "cores": 4 if n_ba else 3, "kind": "port",
-               "sample": "%d synthetic frames of the same workload in %.1f s (%d local LV-BA windows); threads as in the reference: left/right "
-                         "ORB on 2 threads, then stereo match + TrackWithMotionModel on the tracking thread; LiDAR front end on a 3rd "
-                         "thread; local mapping (LV-BA, single-threaded g2o semantics) on a 4th" % (done, tcpu, len(ba_futs)),
-               "host_cpus": os.cpu_count()}
+        cpu = cpu_baseline(wl, args, F, with_ba=bool(loop.ba_batch))
 
     # ---- optional: one window over all ranks (BASELINE configs[4]); every rank passes the same window ----
     sharded_window = None
@@ -413,51 +736,55 @@ def main():
                                                               Tcl7=synthetic.TCL7, weight=1.0)
             t_sh.append(time.perf_counter() - t_a)
             t_a = time.perf_counter()
-            one = pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], win, clouds, synthetic.TCL7, 1.0)
+            one_gpu = pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], win, clouds, synthetic.TCL7, 1.0)
             t_one.append(time.perf_counter() - t_a)
         comm.close()
         sharded_window = {"ranks": world, "ms_per_window": round(1e3 * min(t_sh[1:]), 3), "single_gpu_ms_per_window": round(1e3 * min(t_one[1:]), 3),
                           "iterations/trials": [int(got[4].iterations), int(got[4].trials)], "allreduces_per_window": 2 * int(got[4].trials) + int(got[4].iterations) + 3,
-                          "max_pose_difference_vs_single_gpu": float(np.abs(got[0] - one[0]).max()),
-                          "note": "landmarks l % ranks; per LM trial one sum of [S | b_schur | b_p] and one of [scale, chi2, stop]"}
+                          "max_pose_difference_vs_single_gpu": float(np.abs(got[0] - one_gpu[0]).max()),
+                          "note": "landmarks l % ranks; per LM trial one sum of [S | b_schur | b_p | status] and one of [scale, chi2, stop, status]"}
 
     if rank == 0:
-        total_frames = F * args.steps * world
+        pool_threads = int(os.environ.get("TC2LI_HOST_THREADS", min(32, os.cpu_count() or 1)))
         line = {
-            "metric": "frames/sec (ORB+LiDAR front-end + local BA) on KITTI-00, 1/2/4/8 GPU; ATE vs ref",
-            "value": round(dist_util.job_throughput(F, args.steps, world, elapsed), 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (ORB, matching), f32 (LiDAR), f64 (optimisation)", "data": "synthetic",
-            "config": {"stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel | LiDAR front end | local mapping, each on its own host "
-                                        "thread and HIP stream as in the reference (tracking / LiDAR / local-mapping threads); a step = every stage "
-                                        "has processed one batch",
-                       "workload": ("configs[1]: KITTI-00 camera-LiDAR front end on 1xMI355X per rank" if args.front_end_only else
-                                    "configs[1]+[2]: KITTI camera-LiDAR loop on 1xMI355X per rank: front end + HIP local LV-BA every %d-th frame"
-                                    % args.kf_interval) +
-                                   " -- stereo ORB (2 x 1242x375, 2000 features, 8 levels, FAST 20/7), stereo matching, "
-                                   "TrackWithMotionModel (projection matching + pose optimisation), LiDAR preprocess / voxel 0.5 m / 5-NN "
-                                   "plane features (64-beam scan, ~130k returns)" +
-                                   ("" if args.front_end_only else ", LocalLVBundleAdjustment (12 free + 20 fixed keyframes, ~2500 points, "
-                                                                   "~26k stereo edges, LiDAR plane edge over 6 keyframes x 3000 points)"),
-                       "frames_per_step_per_gpu": F, "images_per_step_per_gpu": n_img, "ba_windows_per_step_per_gpu": n_ba,
-                       "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(n_match, 1),
-                       "tracked_matches/inliers_per_frame": [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
-                       "scan_points_raw/preprocessed/downsampled/selected": lid_mean, "map_points": int(lmap.size()),
-                       "ba": None if not ba_batch else {"iterations": int(ba_batch.stats[0].iterations), "trials": int(ba_batch.stats[0].trials),
-                                                        "planes": int(ba_batch.lstats[0].n_planes), "edges": int(len(ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu, **({"sharded_window": sharded_window} if sharded_window else {}),
-            "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()}, "stage_wall_ms_per_step": {k: round(1e3 * v, 3) for k, v in wall.items()},
-            "orb_stage_ms_last_step": {"pyramid": round(stage_ms[0], 4), "fast": round(stage_ms[1], 4),
-                                       "compact": round(stage_ms[2], 4), "blur": round(stage_ms[3], 4),
-                                       "orient_describe": round(stage_ms[4], 4), "host_quadtree": round(stage_ms[5], 4),
-                                       "host_until_quadtree": round(stage_ms[6], 4), "call_total": round(stage_ms[7], 4)},
-            "lidar_stage_ms": {"preprocess": round(lidar_ms[0], 4), "voxel_hash": round(lidar_ms[1], 4), "voxel_centroid": round(lidar_ms[2], 4),
-                               "knn_plane": round(lidar_ms[3], 4), "select": round(lidar_ms[4], 4), "total": round(lidar_ms[5], 4)},
+            "metric": METRIC, "value": round(total_sequences * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u8 (ORB, matching), f32 (LiDAR), f64 (optimisation)", "data": "synthetic", "ranks_seen": ranks_seen,
+            "config": {
+                "workload": ("configs[1]: KITTI-00 camera-LiDAR front end" if args.front_end_only else
+                             "configs[1]+[2]: KITTI camera-LiDAR loop, front end + HIP local LV-BA every %d-th frame" % args.kf_interval) +
+                            ", %d batched sequences in all (%s scaling: %s), one frame of every sequence per step -- stereo ORB (2 x 1242x375, 2000 "
+                            "features, 8 levels, FAST 20/7), stereo matching, TrackWithMotionModel + TrackLocalMap (projection matching + pose "
+                            "optimisation, twice), LiDAR fov_segment / preprocess / voxel 0.5 m / 5-NN plane features against the sequence's own "
+                            "map / map_incremental (64-beam scan, ~130k returns)" % (
+                                total_sequences, args.scaling, "the list is dealt over the ranks" if args.scaling == "strong" else "%d per rank" % args.frames) +
+                            ("" if args.front_end_only else ", LocalLVBundleAdjustment (12 free + 20 fixed keyframes, ~2500 points, ~26k stereo "
+                                                            "edges, LiDAR plane edge over 6 keyframes x 3000 points)"),
+                "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel + TrackLocalMap | LiDAR front end + map maintenance | local "
+                                 "mapping, each on its own host thread and HIP stream as in the reference; a step = every stage has processed one batch",
+                "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
+                "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": {
+                    "stage_threads": 4, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
+                    "cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()},
+                "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),
+                "motion_model_matches/inliers_per_frame": [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
+                "local_map_points/matches/inliers_per_frame": [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1),
+                                                               round(float(np.mean(tlm_out[4])), 1)],
+                "scan_points_raw/preprocessed/downsampled/selected": lid_mean,
+                "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
+                "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_batch.stats[0].iterations), "trials": int(loop.ba_batch.stats[0].trials),
+                                                      "planes": int(loop.ba_batch.lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
+            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, **({"sharded_window": sharded_window} if sharded_window else {}),
+            "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
+            "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
         }
         print(json.dumps(line))
+        sys.stdout.flush()
+    loop.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -212,6 +212,13 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velo
  * ekf_inited = flg_EKF_inited.  Returns the new map size; the list sizes go to n_to_add / n_no_need (may be NULL). */
 int tc2li_lidar_map_incremental(tc2li_lidar* lidar, int scan, tc2li_lidar_map* map, const tc2li_lidar_state* state, int ekf_inited,
                                 double filter_size_map_min, int32_t* n_to_add, int32_t* n_no_need, void* stream);
+/* The same for n (scan slot, map) pairs of the handle's last tc2li_lidar_frontend_batch in one call -- what the tracking threads of n
+ * sequences do at SyncWithLidar (Tracking.cc:1602-1603), with one kernel launch per phase for all maps instead of a dozen per map.
+ * scans[i] = scan slot, maps[i] = its map (every map at most once), states[i] = the state map_incremental reads.  The list sizes and
+ * the new map sizes go to the three int arrays (any may be NULL).  Returns n.  On TC2LI_ERR_CAPACITY no map has been changed. */
+int tc2li_lidar_map_incremental_batch(tc2li_lidar* lidar, int n, const int32_t* scans, tc2li_lidar_map* const* maps,
+                                      const tc2li_lidar_state* states, int ekf_inited, double filter_size_map_min, int32_t* n_to_add,
+                                      int32_t* n_no_need, int32_t* map_sizes, void* stream);
 /* ikdtree.Delete_Point_Boxes (ikd_Tree.cpp:643): removes the points inside the boxes [min, max) given as
  * min x y z, max x y z per box; returns how many were removed. */
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* map, const float* boxes6, int n_boxes, void* stream);
@@ -716,6 +723,19 @@ int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar
  * the reference's output order and returns their number. */
 int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
                                    float* out_xyr, int capacity);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement (bench.py; not on the hot path).
+ * tc2li_profile_enable(1): every kernel launch of the library is bracketed by two HIP events on the stream it is launched on.
+ * tc2li_profile_report: call when the streams are idle; writes "name<TAB>launches<TAB>total_ms<NL>" per kernel (sorted by total
+ * time) into text, forgets the recorded launches and returns the bytes the whole report needs.
+ * tc2li_diag_peaks: what this GPU reaches on back-to-back v_mfma_f64_16x16x4_f64 (TFLOP/s), on f64 vector FMAs (TFLOP/s) and on a
+ * 1 GiB float4 copy (GB/s, read + write) -- the peaks the roofline of bench.py is priced against next to the datasheet's 8 TB/s.
+ * Any pointer may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int tc2li_profile_enable(int on);
+int tc2li_profile_report(char* text, int capacity);
+int tc2li_diag_peaks(double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbps);
 
 #ifdef __cplusplus
 }

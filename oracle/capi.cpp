@@ -165,6 +165,28 @@ void oracle_kdtree_add(void* h, const PointXYZINormal* pts, int n) {
     for (int i = 0; i < n; ++i) ((KdTree*)h)->Add_Point(pts[i]);
 }
 void oracle_kdtree_destroy(void* h) { delete (KdTree*)h; }
+// the incremental operations on the tree, and the same on the plain point list (MapPoints) that pins them in the tests
+int oracle_kdtree_add_points(void* h, const PointXYZINormal* pts, int n, int downsample_on, float downsample_size) {
+    return ((KdTree*)h)->Add_Points(PointVector(pts, pts + n), downsample_on != 0, downsample_size);
+}
+int oracle_kdtree_delete_boxes(void* h, const float* boxes6, int n_boxes) {
+    std::vector<BoxPointType> boxes(n_boxes);
+    for (int b = 0; b < n_boxes; ++b) { std::memcpy(boxes[b].vertex_min, boxes6 + 6 * b, 12); std::memcpy(boxes[b].vertex_max, boxes6 + 6 * b + 3, 12); }
+    return ((KdTree*)h)->Delete_Point_Boxes(boxes);
+}
+int oracle_kdtree_valid_points(void* h, PointXYZINormal* out, int capacity) {
+    const PointVector v = ((KdTree*)h)->valid_points();
+    std::memcpy(out, v.data(), std::min((size_t)capacity, v.size()) * sizeof(PointXYZINormal));
+    return (int)v.size();
+}
+int oracle_mappoints_add(const PointXYZINormal* map_pts, int n_map, const PointXYZINormal* pts, int n, int downsample_on, float downsample_size,
+                         PointXYZINormal* out, int capacity) {
+    MapPoints mp;
+    mp.pts.assign(map_pts, map_pts + n_map);
+    mp.Add_Points(PointVector(pts, pts + n), downsample_on != 0, downsample_size);
+    std::memcpy(out, mp.pts.data(), std::min((size_t)capacity, mp.pts.size()) * sizeof(PointXYZINormal));
+    return (int)mp.pts.size();
+}
 int oracle_kdtree_size(void* h) { return (int)((KdTree*)h)->size(); }
 
 // k nearest of each query: near [nq][k] points, sqdist [nq][k], found [nq]
@@ -636,17 +658,13 @@ void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, 
 }
 
 // Tracking::TrackLocalMap's data path for one frame (SearchLocalPoints -> PoseOptimization -> mnMatchesInliers); returns mnMatchesInliers
-int oracle_track_local_map(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
-                           const float* inv_sigma2, int nlevels, float log_scale, const float* pose7, const double* cam5, const uint8_t* held,
-                           const float* held_Xw, const MapPointPOD* pts, int m, float th, int far_points, float th_far, double* pose_out7,
-                           int* local_of_keypoint, uint8_t* outlier, int* n_matches) {
-    FrameView F;
-    F.keys = kps_from(keys6, n);
-    F.desc.assign(desc, desc + (size_t)n * 32);
-    F.uRight.assign(uright, uright + n);
+}  // extern "C"
+static int track_local_core(FrameView& F, const float* scales, const float* inv_sigma2, int nlevels, float log_scale, const float* pose7,
+                            const double* cam5, const uint8_t* held, const float* held_Xw, const MapPointPOD* pts, int m, float th, int far_points,
+                            float th_far, double* pose_out7, int* local_of_keypoint, uint8_t* outlier, int* n_matches) {
+    const int n = (int)F.keys.size(), cols = F.cols, rows = F.rows;
     F.occupied.resize(n);
     for (int i = 0; i < n; ++i) F.occupied[i] = held[i] == 1;
-    F.cols = cols; F.rows = rows;
     SE3f Tcw;
     std::memcpy(Tcw.q, pose7, 16); std::memcpy(Tcw.t, pose7 + 4, 12);
     CamF camf{(float)cam5[0], (float)cam5[1], (float)cam5[2], (float)cam5[3]};
@@ -693,6 +711,99 @@ int oracle_track_local_map(const float* keys6, const uint8_t* desc, const float*
         if (!out[e] && (local_of_keypoint[i] >= 0 || held[i] == 1)) ++good;
     }
     return good;
+}
+extern "C" {
+int oracle_track_local_map(const float* keys6, const uint8_t* desc, const float* uright, int n, int cols, int rows, const float* scales,
+                           const float* inv_sigma2, int nlevels, float log_scale, const float* pose7, const double* cam5, const uint8_t* held,
+                           const float* held_Xw, const MapPointPOD* pts, int m, float th, int far_points, float th_far, double* pose_out7,
+                           int* local_of_keypoint, uint8_t* outlier, int* n_matches) {
+    FrameView F;
+    F.keys = kps_from(keys6, n);
+    F.desc.assign(desc, desc + (size_t)n * 32);
+    F.uRight.assign(uright, uright + n);
+    F.cols = cols; F.rows = rows;
+    return track_local_core(F, scales, inv_sigma2, nlevels, log_scale, pose7, cam5, held, held_Xw, pts, m, th, far_points, th_far, pose_out7,
+                            local_of_keypoint, outlier, n_matches);
+}
+
+// ---- one sequence of the per-frame loop, as the CPU baseline of bench.py runs it -----------------------------------------------------
+// State that persists from frame to frame in the reference: the two ORB extractors (Tracking.cc mpORBextractorLeft/Right), the ikd-Tree map
+// and the local-map cube (LidarFrontEnd.cpp globals `ikdtree`, `LocalMap_Points`).
+struct OracleSequence {
+    ORBextractor el, er;
+    KdTree map;
+    LocalMapBox box;
+    OracleSequence(int nfeatures, float scale, int nlevels, int ini, int mn) : el(nfeatures, scale, nlevels, ini, mn), er(nfeatures, scale, nlevels, ini, mn) {}
+};
+void* oracle_sequence_create(int nfeatures, float scale, int nlevels, int ini_th, int min_th, const PointXYZINormal* map_pts, int n_map) {
+    OracleSequence* s = new OracleSequence(nfeatures, scale, nlevels, ini_th, min_th);
+    s->map.Build(PointVector(map_pts, map_pts + n_map));
+    return s;
+}
+void oracle_sequence_destroy(void* h) { delete (OracleSequence*)h; }
+int oracle_sequence_map_size(void* h) { return (int)((OracleSequence*)h)->map.valid_size(); }
+
+// One frame with the reference's threads: the LiDAR thread runs Preprocess::process, lasermap_fov_segment (+ the box
+// deletions), the voxel filter and feature_extraction (LidarFrontEnd.cpp:886-962); the tracking thread builds the Frame (left / right ORB
+// on two threads, ComputeStereoMatches), then TrackWithMotionModel and TrackLocalMap (Tracking.cc:2038,2218), then, at SyncWithLidar,
+// UpdateMap -> map_incremental on the shared tree (Tracking.cc:1602-1603).  `local` = the frame's local map points as UpdateLocalMap
+// left them; held / held_Xw = the map points the frame's keypoints hold after TrackWithMotionModel (precomputed by the caller: they are
+// object state in the reference).  out4: inliers of the motion-model step, mnMatchesInliers, selected LiDAR features, map size.
+int oracle_sequence_frame(void* h, const uint8_t* il, const uint8_t* ir, int w, int hgt, float mbf, float mb, const VelodynePoint* raw, int n_raw,
+                          const double* state24, const float* pose_pred7, const float* pose_last7, const double* cam5, float th, int n_last,
+                          const uint8_t* has_point, const uint8_t* outlier_last, const float* Xw, const float* last_keys6, const uint8_t* mp_desc,
+                          int n_held, const uint8_t* held, const float* held_Xw, const MapPointPOD* local, int n_local, float th_local,
+                          double cube_len, double det_range, double* pose_out7, int* out4) {
+    OracleSequence* S = (OracleSequence*)h;
+    LidarState st;
+    std::memcpy(st.rot, state24, 9 * sizeof(double)); std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
+    std::memcpy(st.offset_R_L_I, state24 + 12, 9 * sizeof(double)); std::memcpy(st.offset_T_L_I, state24 + 21, 3 * sizeof(double));
+    PointVector down;
+    FeatureExtraction fe;
+    std::thread lidar([&] {
+        PointVector pre = preprocess_velodyne(raw, n_raw, 2, 2.0, 1e-3f);
+        double pos_lid[3];  // pos_lid = state.pos + state.rot * offset_T_L_I (LidarFrontEnd.cpp:706 / :905)
+        for (int r = 0; r < 3; ++r) pos_lid[r] = st.pos[r] + st.rot[3 * r] * st.offset_T_L_I[0] + st.rot[3 * r + 1] * st.offset_T_L_I[1] + st.rot[3 * r + 2] * st.offset_T_L_I[2];
+        const std::vector<BoxPointType> rm = lasermap_fov_segment(S->box, pos_lid, cube_len, det_range);
+        if (!rm.empty()) S->map.Delete_Point_Boxes(rm);
+        down = voxel_grid_filter(pre, 0.5f);
+        fe = feature_extraction(down, st, S->map);
+    });
+    std::vector<KeyPoint> kl, kr;
+    std::vector<uint8_t> dl, dr;
+    const int lap[2] = {0, 0};
+    std::thread tl([&] { S->el.extract(Img::view(il, w, hgt, w), kl, dl, lap); });
+    std::thread tr([&] { S->er.extract(Img::view(ir, w, hgt, w), kr, dr, lap); });
+    tl.join();
+    tr.join();
+    StereoResult r = ComputeStereoMatches(S->el, S->er, kl, dl, kr, dr, mbf, mb);
+    FrameView F;
+    F.keys = kl; F.desc = dl; F.uRight = r.uRight; F.occupied.assign(kl.size(), 0); F.cols = w; F.rows = hgt;
+    const int n = (int)kl.size();
+    std::vector<int> mp(n + 1), lk(n + 1);
+    int nm = 0, nm2 = 0;
+    double pose_mm[7];
+    out4[0] = track_core(F, S->el.mvScaleFactor.data(), S->el.mvInvLevelSigma2.data(), (int)S->el.mvScaleFactor.size(), pose_pred7, pose_last7, cam5, mb,
+                         th, n_last, has_point, outlier_last, Xw, kps_from(last_keys6, n_last), mp_desc, pose_mm, mp.data(), &nm);
+    // TrackLocalMap starts from the pose TrackWithMotionModel left (float on the Frame)
+    float pose_f[7];
+    for (int c = 0; c < 7; ++c) pose_f[c] = (float)pose_mm[c];
+    std::vector<uint8_t> held_n(n, 0), outl(n + 1);
+    std::vector<float> heldX(3 * (size_t)n, 0.f);
+    const int nh = std::min(n, n_held);
+    std::memcpy(held_n.data(), held, nh);
+    std::memcpy(heldX.data(), held_Xw, 3 * (size_t)nh * sizeof(float));
+    const float log_scale = std::log(S->el.mvScaleFactor[1]);
+    out4[1] = track_local_core(F, S->el.mvScaleFactor.data(), S->el.mvInvLevelSigma2.data(), (int)S->el.mvScaleFactor.size(), log_scale, pose_f, cam5,
+                               held_n.data(), heldX.data(), local, n_local, th_local, 0, 0.f, pose_out7, lk.data(), outl.data(), &nm2);
+    lidar.join();
+    out4[2] = fe.effct_feat_num;
+    // UpdateMap (LidarFrontEnd.cpp:1075-1079) -> map_incremental (:387-435)
+    const MapIncrement inc = map_incremental_lists(down, st, fe.Nearest_Points, true, 0.5);
+    S->map.Add_Points(inc.PointToAdd, true, 0.5f);
+    S->map.Add_Points(inc.PointNoNeedDownsample, false, 0.5f);
+    out4[3] = (int)S->map.valid_size();
+    return out4[1];
 }
 
 // ORBmatcher::Fuse, search part: best keypoint (or -1) and best distance per map point; returns how many would be fused

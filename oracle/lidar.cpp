@@ -225,7 +225,7 @@ void KdTree::search(int n, int k, const PointXYZINormal& q, Heap& hp) const {
     if (n < 0) return;
     const Node& nd = nodes[n];
     const float dist = calc_dist(q, nd.p);
-    if (hp.n < k || dist < hp.h[0].dist) {
+    if (!nd.deleted && (hp.n < k || dist < hp.h[0].dist)) {  // ikd_Tree.cpp:1085 `if (!root->point_deleted)`
         if (hp.n >= k) hp.pop();
         hp.push(HeapItem{nd.p, dist});
     }
@@ -508,6 +508,74 @@ inline bool in_box(const PointXYZINormal& p, const BoxPointType& b) {
     return b.vertex_min[0] <= p.x && b.vertex_max[0] > p.x && b.vertex_min[1] <= p.y && b.vertex_max[1] > p.y && b.vertex_min[2] <= p.z && b.vertex_max[2] > p.z;
 }
 }  // namespace
+
+// ---- the same operations on the tree (ikd-Tree keeps deleted points as flagged nodes until a rebuild) --------------------
+// One walk serves Search_by_range (storage != NULL) and Delete_by_range (n_del != NULL): prune on the node box, test the node's
+// point against [min, max), descend.  The node boxes are those of all points ever inserted below (a superset of the live ones).
+void KdTree::range_search(int n, const BoxPointType& box, PointVector* storage, int* n_del) {
+    if (n < 0) return;
+    Node& nd = nodes[n];
+    for (int a = 0; a < 3; ++a) if (box.vertex_max[a] <= nd.lo[a] || box.vertex_min[a] > nd.hi[a]) return;
+    if (!nd.deleted && in_box(nd.p, box)) {
+        if (storage) storage->push_back(nd.p);
+        if (n_del) { nd.deleted = true; ++n_deleted; ++*n_del; }
+    }
+    range_search(nd.left, box, storage, n_del);
+    range_search(nd.right, box, storage, n_del);
+}
+void KdTree::Search_by_range(const BoxPointType& box, PointVector& storage) const {
+    const_cast<KdTree*>(this)->range_search(root, box, &storage, nullptr);
+}
+int KdTree::Delete_by_range(const BoxPointType& box) {
+    int n = 0;
+    range_search(root, box, nullptr, &n);
+    return n;
+}
+int KdTree::Delete_Point_Boxes(const std::vector<BoxPointType>& boxes) {
+    int n = 0;
+    for (const BoxPointType& b : boxes) n += Delete_by_range(b);
+    return n;
+}
+PointVector KdTree::valid_points() const {
+    PointVector out;
+    out.reserve(valid_size());
+    for (const Node& nd : nodes) if (!nd.deleted) out.push_back(nd.p);
+    return out;
+}
+// ikd_Tree.cpp:478-584 with Rebuild_Ptr == nullptr (no background rebuild): per point the voxel box, the stored points inside it,
+// the one nearest the voxel centre (the new point when it is nearer), and -- when the box held more than one point or the new
+// point wins -- delete the box and insert the winner.
+int KdTree::Add_Points(const PointVector& PointToAdd, bool downsample_on, float downsample_size) {
+    int tmp_counter = 0;
+    PointVector Downsample_Storage;
+    for (size_t i = 0; i < PointToAdd.size(); i++) {
+        if (!downsample_on) { Add_Point(PointToAdd[i]); continue; }
+        BoxPointType Box;
+        const float c[3] = {PointToAdd[i].x, PointToAdd[i].y, PointToAdd[i].z};
+        PointXYZINormal mid = PointToAdd[i];
+        float m[3];
+        for (int k = 0; k < 3; ++k) {
+            Box.vertex_min[k] = (float)(std::floor(c[k] / downsample_size) * downsample_size);
+            Box.vertex_max[k] = Box.vertex_min[k] + downsample_size;
+            m[k] = (float)(Box.vertex_min[k] + (Box.vertex_max[k] - Box.vertex_min[k]) / 2.0);
+        }
+        mid.x = m[0]; mid.y = m[1]; mid.z = m[2];
+        Downsample_Storage.clear();
+        Search_by_range(Box, Downsample_Storage);
+        float min_dist = calc_dist(PointToAdd[i], mid);
+        PointXYZINormal result = PointToAdd[i];
+        for (const PointXYZINormal& q : Downsample_Storage) {
+            const float d = calc_dist(q, mid);
+            if (d < min_dist) { min_dist = d; result = q; }
+        }
+        if (Downsample_Storage.size() > 1 || same_point(PointToAdd[i], result)) {
+            if (!Downsample_Storage.empty()) Delete_by_range(Box);
+            Add_Point(result);
+            tmp_counter++;
+        }
+    }
+    return tmp_counter;
+}
 
 int MapPoints::Add_Points(const PointVector& PointToAdd, bool downsample_on, float downsample_size) {
     int tmp_counter = 0;

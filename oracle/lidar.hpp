@@ -58,17 +58,29 @@ struct ImuMeas { double t, acc[3], gyr[3]; };
 std::vector<Pose6D> ForwardPropagate(ImuState& st, const std::vector<ImuMeas>& v_imu, double pcl_beg_time, double pcl_end_time,
                                      double last_lidar_end_time, double acc_scale, const double acc_s_last[3], const double angvel_last[3]);
 
-// Static k-d tree with ikd-Tree's build rule and search procedure (no re-balancing, no deletions).
+struct BoxPointType { float vertex_min[3], vertex_max[3]; };
+
+// k-d tree with ikd-Tree's build rule, search procedure and lazy deletion (point_deleted flags; no re-balancing, so the shape
+// differs from a tree the reference has rebuilt -- the search is exact, its result does not depend on the shape).
 class KdTree {
 public:
     void Build(PointVector pts);                                   // ikd_Tree.cpp:409-423, 690-744
     void Add_Point(const PointXYZINormal& p);                      // Add_by_point without downsampling, :1263-1312
     void Nearest_Search(const PointXYZINormal& q, int k, PointVector& near, std::vector<float>& sqdist) const;  // :426-461
-    size_t size() const { return nodes.size(); }
+    size_t size() const { return nodes.size(); }                   // nodes, deleted ones included
     const PointXYZINormal& point(size_t i) const { return nodes[i].p; }
+    // ---- the incremental operations of the map thread (what keeps the CPU baseline's map a tree instead of a list) ----
+    void Search_by_range(const BoxPointType& box, PointVector& storage) const;             // ikd_Tree.cpp:1259-1306, box = [min, max)
+    int Delete_by_range(const BoxPointType& box);                                          // :779-860 (flags only)
+    int Add_Points(const PointVector& to_add, bool downsample_on, float downsample_size);  // :478-584
+    int Delete_Point_Boxes(const std::vector<BoxPointType>& boxes);                        // :643-668
+    size_t valid_size() const { return nodes.size() - n_deleted; }
+    PointVector valid_points() const;                                                      // insertion order
 
 private:
-    struct Node { PointXYZINormal p; int left = -1, right = -1, axis = 0; float lo[3], hi[3]; };
+    struct Node { PointXYZINormal p; int left = -1, right = -1, axis = 0; float lo[3], hi[3]; bool deleted = false; };
+    size_t n_deleted = 0;
+    void range_search(int n, const BoxPointType& box, PointVector* storage, int* n_del);
     std::vector<Node> nodes;
     int root = -1;
     int build(PointVector& s, int l, int r);
@@ -99,7 +111,6 @@ FeatureExtraction feature_extraction(const PointVector& feats_down_body, const L
 //   KD_TREE::Delete_Point_Boxes / Delete_by_range / Search_by_range   ikd_Tree.cpp:643, 776-860, 1259-1306 (box = [min, max))
 // The map is kept as the multiset of its points: what a query returns does not depend on the shape of the tree (exact ties of
 // the distance to a voxel centre between stored points, which the tree's traversal order would decide, are not modelled).
-struct BoxPointType { float vertex_min[3], vertex_max[3]; };
 struct MapPoints {
     PointVector pts;
     int Add_Points(const PointVector& to_add, bool downsample_on, float downsample_size);   // returns tmp_counter

@@ -265,6 +265,80 @@ class KdTree:
         return near, d, found
 
 
+def kdtree_add_points(tree, points, downsample=True, size=0.5):
+    """``KD_TREE::Add_Points`` on the tree (lazy deletion); returns tmp_counter."""
+    p = np.ascontiguousarray(points, POINT_DTYPE)
+    f = lib().oracle_kdtree_add_points
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    return f(tree._h, p.ctypes.data, len(p), int(downsample), size)
+
+
+def kdtree_delete_boxes(tree, boxes6):
+    b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)
+    f = lib().oracle_kdtree_delete_boxes
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    return f(tree._h, b.ctypes.data, len(b))
+
+
+def kdtree_valid_points(tree):
+    out = np.zeros(tree.size() + 1, POINT_DTYPE)
+    f = lib().oracle_kdtree_valid_points
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    n = f(tree._h, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+def mappoints_add(map_points, points, downsample=True, size=0.5):
+    """``KD_TREE::Add_Points`` on the plain point list (the O(map) statement the tree version is held against)."""
+    mp, p = np.ascontiguousarray(map_points, POINT_DTYPE), np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(len(mp) + len(p) + 1, POINT_DTYPE)
+    f = lib().oracle_mappoints_add
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    n = f(mp.ctypes.data, len(mp), p.ctypes.data, len(p), int(downsample), size, out.ctypes.data, len(out))
+    return out[:n].copy()
+
+
+class Sequence:
+    """One sequence of the per-frame loop on the CPU (bench.py cpu_baseline): ORB extractors, ikd-Tree-like map and local-map cube persist."""
+
+    def __init__(self, map_points, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7):
+        mp = np.ascontiguousarray(map_points, POINT_DTYPE)
+        f = lib().oracle_sequence_create
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        self._h = C.c_void_p(f(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, mp.ctypes.data, len(mp)))
+        self._frame = lib().oracle_sequence_frame
+        self._frame.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int] +
+                                [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oracle_sequence_destroy.argtypes = [C.c_void_p]
+            lib().oracle_sequence_destroy(self._h)
+            self._h = None
+
+    def map_size(self):
+        lib().oracle_sequence_map_size.argtypes = [C.c_void_p]
+        return lib().oracle_sequence_map_size(self._h)
+
+    def frame(self, left, right, bf, b, scan, state24, pose_pred7, last, cam5, th, held, held_Xw, local_points, th_local=1.0, cube_len=1000.0,
+              det_range=100.0):
+        """last: dict with pose7, has_point, outlier, Xw, keys6 (floats), descriptors.  -> (pose7 double, [inliers of the motion-model step,
+        mnMatchesInliers, selected LiDAR features, map size])."""
+        h, w = left.shape
+        st = _f64(state24)
+        pp = np.ascontiguousarray(pose_pred7, np.float32); pl = np.ascontiguousarray(last["pose7"], np.float32)
+        cam = _f64(cam5)
+        held = np.ascontiguousarray(held, np.uint8); hx = np.ascontiguousarray(held_Xw, np.float32)
+        lp = np.ascontiguousarray(local_points)
+        pose, out4 = np.zeros(7), np.zeros(4, np.int32)
+        self._frame(self._h, left.ctypes.data, right.ctypes.data, w, h, bf, b, scan.ctypes.data, len(scan), st.ctypes.data, pp.ctypes.data, pl.ctypes.data,
+                    cam.ctypes.data, th, len(last["keys6"]), last["has_point"].ctypes.data, last["outlier"].ctypes.data, last["Xw"].ctypes.data,
+                    last["keys6"].ctypes.data, last["descriptors"].ctypes.data, len(held), held.ctypes.data, hx.ctypes.data,
+                    lp.ctypes.data if len(lp) else None, len(lp), th_local, cube_len, det_range, pose.ctypes.data, out4.ctypes.data)
+        return pose, out4
+
+
 def esti_plane(five, threshold=0.1):
     five = np.ascontiguousarray(five, POINT_DTYPE)
     out = np.zeros(4, np.float32)

@@ -154,6 +154,34 @@ def exported_symbols():
     return sorted(set(re.findall(r"\b(tc2li_[a-z0-9_]+)\s*\(", text)))
 
 
+def profile_enable(on=True):
+    _check(lib().tc2li_profile_enable(int(bool(on))))
+
+
+def profile_report():
+    """{kernel name: (launches, total ms)} of the launches since the last report (call with idle streams)."""
+    f = lib().tc2li_profile_report
+    f.argtypes = [C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(1 << 18)
+    f(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split("\t")
+        name = name.strip("() ").replace(" ", "")
+        c0, m0 = out.get(name, (0, 0.0))
+        out[name] = (c0 + int(calls), m0 + float(ms))
+    return out
+
+
+def diag_peaks():
+    """(f64 MFMA TFLOP/s, f64 vector FMA TFLOP/s, HBM copy GB/s) measured on the current device."""
+    a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+    f = lib().tc2li_diag_peaks
+    f.argtypes = [C.c_void_p] * 3
+    _check(f(C.addressof(a), C.addressof(b), C.addressof(c)))
+    return a.value, b.value, c.value
+
+
 def distribute_quadtree_host(xyr, min_x, max_x, min_y, max_y, n_target):
     xyr = np.ascontiguousarray(xyr, dtype=np.float32).reshape(-1, 3)
     out = np.empty((max(len(xyr), 1), 3), np.float32)
@@ -365,6 +393,20 @@ class LidarMap:
         n = _check(lib().tc2li_lidar_map_incremental(front_end._h, scan, self._h, st.ctypes.data, int(ekf_inited), filter_size_map_min,
                                                      C.addressof(na), C.addressof(nn), C.c_void_p(stream)))
         return n, na.value, nn.value
+
+
+def map_incremental_batch(front_end, scans, maps, states24, ekf_inited=True, filter_size_map_min=0.5, stream=0):
+    """``tc2li_lidar_map_incremental_batch`` -> (n_to_add [n], n_no_need [n], map sizes [n])."""
+    n = len(maps)
+    sc = np.ascontiguousarray(scans, np.int32)
+    st = np.ascontiguousarray(states24, np.float64).reshape(n, 24)
+    handles = (C.c_void_p * n)(*[m._h for m in maps])
+    na, nn, sz = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    f = lib().tc2li_lidar_map_incremental_batch
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(front_end._h, n, sc.ctypes.data, handles, st.ctypes.data, int(ekf_inited), filter_size_map_min, na.ctypes.data, nn.ctypes.data,
+             sz.ctypes.data, C.c_void_p(stream)))
+    return na, nn, sz
 
 
 class LocalMapBox(C.Structure):

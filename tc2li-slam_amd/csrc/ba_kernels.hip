@@ -14,6 +14,8 @@
 // Launches that only depend on the same earlier results share one grid (a dependent launch costs ~10 us on its own).
 // All arithmetic is double precision; reductions run in a fixed order, so results are reproducible run to run.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -678,62 +680,62 @@ static inline int blocks(int n) { return (n + 255) / 256; }
 
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st) {
     const int nbp = blocks(pb.n_points);
-    hipLaunchKernelGGL(k_ba_linearize, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
-    hipLaunchKernelGGL(k_ba_reduce_all, dim3(nbp + pb.n_free + 1), dim3(256), 0, st, pb, nbp, chi_out);
-    if (want_maxdiag) hipLaunchKernelGGL(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
+    TC2LI_LAUNCH(k_ba_linearize, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
+    TC2LI_LAUNCH(k_ba_reduce_all, dim3(nbp + pb.n_free + 1), dim3(256), 0, st, pb, nbp, chi_out);
+    if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     const int nbp = blocks(pb.n_points);
-    hipLaunchKernelGGL(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
+    TC2LI_LAUNCH(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
     if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
-        hipLaunchKernelGGL(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
+        TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
         const int tiles = pb.np_pad / 16, strips = (tiles + 1) / 2;
-        if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_strip<5>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
-        else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
-        else hipLaunchKernelGGL(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_strip<5>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        else TC2LI_LAUNCH(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         const int np = 6 * pb.n_free;
-        hipLaunchKernelGGL(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
+        TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
     }
 }
 
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
     const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
-    hipLaunchKernelGGL(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
-    hipLaunchKernelGGL(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
-    hipLaunchKernelGGL(k_ba_trial_reduce, dim3(2), dim3(256), 0, st, pb, scale_out, chi_out);
+    TC2LI_LAUNCH(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
+    TC2LI_LAUNCH(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
+    TC2LI_LAUNCH(k_ba_trial_reduce, dim3(2), dim3(256), 0, st, pb, scale_out, chi_out);
 }
 
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st) {
-    hipLaunchKernelGGL(k_ba_depth, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, depth_pos);
+    TC2LI_LAUNCH(k_ba_depth, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, depth_pos);
 }
 
 void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    hipLaunchKernelGGL(k_ba_linearize_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
-    hipLaunchKernelGGL(k_ba_reduce_all_b, dim3(blocks(x.max_points) + x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
-    if (any_maxdiag) hipLaunchKernelGGL(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_linearize_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(blocks(x.max_points) + x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
+    if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
-    hipLaunchKernelGGL(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + (x.max_free_edges ? blocks(x.max_edges) : 0), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + (x.max_free_edges ? blocks(x.max_edges) : 0), n_active), dim3(256), 0, st, slots, active);
     if (!x.max_free) return;
-    hipLaunchKernelGGL(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
     const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
     const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
-    if (tiles <= 5) hipLaunchKernelGGL(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-    else if (tiles <= 8) hipLaunchKernelGGL(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-    else hipLaunchKernelGGL(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
-    hipLaunchKernelGGL(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
+    if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
+    else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
+    else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
-    hipLaunchKernelGGL(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
-    hipLaunchKernelGGL(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
-    hipLaunchKernelGGL(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
-    if (n_active) hipLaunchKernelGGL(k_ba_depth_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+    if (n_active) TC2LI_LAUNCH(k_ba_depth_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
 }
 
 }  // namespace tc2li

@@ -7,6 +7,8 @@
 // Layout: one workgroup owns a contiguous chunk of planes; every thread owns a few entries of the upper block triangle
 // of the (6W)^2 Hessian in registers (entry = (block pair, row, column)), so no atomics and a fixed summation order.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -270,17 +272,17 @@ __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) { d_balm_combin
 
 void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
     if (b.n_planes <= 2048) {
-        hipLaunchKernelGGL(k_balm_residual_total, dim3(1), dim3(256), 0, st, b, poses);
+        TC2LI_LAUNCH(k_balm_residual_total, dim3(1), dim3(256), 0, st, b, poses);
     } else {
-        hipLaunchKernelGGL(k_balm_residual_planes, dim3((b.n_planes + 255) / 256), dim3(256), 0, st, b, poses);
-        hipLaunchKernelGGL(k_balm_sum, dim3(1), dim3(256), 0, st, b);
+        TC2LI_LAUNCH(k_balm_residual_planes, dim3((b.n_planes + 255) / 256), dim3(256), 0, st, b, poses);
+        TC2LI_LAUNCH(k_balm_sum, dim3(1), dim3(256), 0, st, b);
     }
 }
 
 void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
-    if (b.W <= 7) hipLaunchKernelGGL((k_balm_hessian<kItemsSmall, kHessThreadsSmall>), dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
-    else hipLaunchKernelGGL((k_balm_hessian<kItemsLarge, kHessThreads>), dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
-    hipLaunchKernelGGL(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
+    if (b.W <= 7) TC2LI_LAUNCH((k_balm_hessian<kItemsSmall, kHessThreadsSmall>), dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
+    else TC2LI_LAUNCH((k_balm_hessian<kItemsLarge, kHessThreads>), dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    TC2LI_LAUNCH(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
 }
 
 // ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
@@ -306,12 +308,12 @@ __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __res
     d_balm_combine(b, blockIdx.x);
 }
 void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, slots, list, trial ? 1 : 0);
+    if (n) TC2LI_LAUNCH(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, slots, list, trial ? 1 : 0);
 }
 void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st) {
     if (!n) return;
-    hipLaunchKernelGGL(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, slots, list);
-    hipLaunchKernelGGL(k_balm_combine_b, dim3((balm_part_stride(x.max_W) + 3) / 4, n), dim3(256), 0, st, slots, list);
+    TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, slots, list);
+    TC2LI_LAUNCH(k_balm_combine_b, dim3((balm_part_stride(x.max_W) + 3) / 4, n), dim3(256), 0, st, slots, list);
 }
 
 }  // namespace tc2li

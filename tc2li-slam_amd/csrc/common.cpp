@@ -1,6 +1,8 @@
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace tc2li {
 
@@ -67,6 +69,35 @@ hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st) {
     hipError_t e = hipMemsetAsync(dst, value, bytes, st);
     return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
+
+namespace prof {
+std::atomic<int> g_enabled{0};
+namespace {
+struct Rec { const char* name; hipEvent_t a, b; };
+std::mutex g_mu;
+std::vector<Rec> g_recs;                              // launches since the last report
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;  // event pairs to reuse
+constexpr size_t kMaxRecs = 1u << 20;
+}  // namespace
+void Scope::begin(const char* name) {
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_recs.size() >= kMaxRecs) return;
+        if (!g_free.empty()) { ev = g_free.back(); g_free.pop_back(); }
+    }
+    if (!ev.first && (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(ev.first, st) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    slot = (int)g_recs.size();
+    g_recs.push_back(Rec{name, ev.first, ev.second});
+}
+void Scope::end() {
+    hipEvent_t b;
+    { std::lock_guard<std::mutex> lk(g_mu); b = g_recs[slot].b; }
+    if (hipEventRecord(b, st) != hipSuccess) (void)hipGetLastError();
+}
+}  // namespace prof
 
 WorkerPool::WorkerPool(int nthreads) {
     for (int i = 0; i < nthreads - 1; ++i) workers_.emplace_back([this] { loop(); });
@@ -149,6 +180,33 @@ WorkerPool& global_pool() {
 }  // namespace tc2li
 
 extern "C" {
+int tc2li_profile_enable(int on) {
+    tc2li::prof::g_enabled.store(on ? 1 : 0);
+    return TC2LI_OK;
+}
+// text: one line per kernel, "name<TAB>launches<TAB>total_ms<NL>", sorted by total time; returns the number of bytes the whole report needs
+int tc2li_profile_report(char* text, int capacity) {
+    using namespace tc2li::prof;
+    std::vector<Rec> recs;
+    { std::lock_guard<std::mutex> lk(g_mu); recs.swap(g_recs); }
+    struct Acc { std::string name; long calls = 0; double ms = 0; };
+    std::vector<Acc> acc;
+    for (const Rec& r : recs) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); ms = 0; }
+        size_t k = 0;
+        while (k < acc.size() && acc[k].name != r.name) ++k;
+        if (k == acc.size()) { acc.emplace_back(); acc[k].name = r.name; }
+        acc[k].calls++; acc[k].ms += ms;
+    }
+    { std::lock_guard<std::mutex> lk(g_mu); for (const Rec& r : recs) g_free.emplace_back(r.a, r.b); }
+    std::sort(acc.begin(), acc.end(), [](const Acc& x, const Acc& y) { return x.ms > y.ms; });
+    std::string out;
+    char line[512];
+    for (const Acc& a : acc) { snprintf(line, sizeof(line), "%s\t%ld\t%.6f\n", a.name.c_str(), a.calls, a.ms); out += line; }
+    if (text && capacity > 0) { const size_t n = std::min((size_t)capacity - 1, out.size()); memcpy(text, out.data(), n); text[n] = 0; }
+    return (int)out.size() + 1;
+}
 const char* tc2li_last_error(void) { return tc2li::g_last_error.c_str(); }
 int tc2li_abi_version(void) { return 1; }
 int tc2li_device_count(void) {

@@ -15,6 +15,8 @@
 
 #include "../../include/tc2li_hip.h"
 
+#include "launch.hpp"
+
 namespace tc2li {
 
 void set_error(const char* fmt, ...);

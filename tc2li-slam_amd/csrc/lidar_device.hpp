@@ -71,20 +71,48 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
                            const int* vox_member_off, const int* vox_fill, const int* members, void* recs /* 32 B per point */,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
-// ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes) ----
+// ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes), batched over maps ----
 struct MapIncRec { unsigned long long key; int idx; int pad; };
 constexpr int kMapIncMax = 8192;
-void launch_mapinc_classify(const PointXYZINormal* body, int n, const LidarStateDev& st, const MapGrid& grid, const int* nearest_idx,
-                            const int* nfound, int ekf_inited, double fs, PointXYZINormal* world, uint8_t* cls, hipStream_t st_);
-void launch_mapinc_group(const PointXYZINormal* world, const uint8_t* cls, int n, float ds, MapIncRec* recs, int* group_start,
-                         int* noneed_list, int* counts, hipStream_t st);
-void launch_mapinc_apply(const PointXYZINormal* world, const MapIncRec* recs, const int* group_start, const int* counts, int n_groups,
-                         const MapGrid& grid, float ds, uint8_t* deleted, PointXYZINormal* appended, uint8_t* has_append, hipStream_t st);
+constexpr int kMapIncOut = 12;  // per task: [0] n_add [1] n_groups [2] n_noneed [3] overflow [4] kept [5] appended [6..11] bbox of the added points
+// One (scan, map) pair of a batched map_incremental / compaction (map_kernels.hip).  has_inc = 0: compaction only (box deletion).
+struct MapIncTask {
+    // scan side: slots of the tc2li_lidar workspace
+    const PointXYZINormal* body;   // [n] down-sampled points of the scan
+    const int* nearest_idx;        // [n][5]
+    const int* nfound;             // [n]
+    PointXYZINormal* world;        // [n]
+    uint8_t* cls;                  // [n]
+    MapIncRec* recs;               // [kMapIncMax]
+    int* group_start;              // [kMapIncMax + 1]
+    int* noneed;                   // [n]
+    PointXYZINormal* appended;     // [kMapIncMax]
+    uint8_t* has_append;           // [kMapIncMax]
+    int* out;                      // [kMapIncOut]
+    // map side
+    MapGrid grid;                  // the map before the update (grid.points = the points in insertion order)
+    uint8_t* deleted;              // [n_map], all zero between calls
+    int* keep_counts;              // [keep_blocks]
+    PointXYZINormal* dst;          // the map's other point buffer: kept + appended + no-need points
+    LidarStateDev st;
+    double fs;                     // filter_size_map_min
+    float ds;                      // ikdtree downsample_size
+    int n, n_map, keep_blocks, ekf_inited, has_inc;
+};
+// Counting sort of one map's points into its dense grid.
+struct MapGridTask {
+    MapGrid g;         // geometry + points of the map (g.pts / g.bucket_start = what the build writes)
+    int* counts;       // [n_cells]
+    int* fill;         // [n_cells]
+    int* start;        // [n_cells + 1]
+    float4* sorted;    // [n_points]
+    int* tile_sums;    // [ceil(n_cells / 4096)]
+    int n_cells;
+};
+void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
 void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st);
-// out = kept points (order preserved) + appended representatives + no-need points; totals: [0] kept [1] appended; bbox_enc: 6 encoded floats
-void launch_map_compact(const PointXYZINormal* pts, const uint8_t* deleted, int n, int* block_counts, const PointXYZINormal* appended,
-                        const uint8_t* has_append, const PointXYZINormal* world, const int* noneed_list, const int* inc_counts, int* totals,
-                        PointXYZINormal* out, int* bbox_enc, hipStream_t st);
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
+void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st);
 
 struct Pose6DDev { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
 constexpr int kMaxImuPoses = 64;
@@ -92,9 +120,6 @@ constexpr int kMaxImuPoses = 64;
 void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const Pose6DDev* poses, int n_poses, const LidarStateDev* end,
                       PointXYZINormal* out, hipStream_t st);
 
-void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st);
-void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st);
-void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted, hipStream_t st);
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,

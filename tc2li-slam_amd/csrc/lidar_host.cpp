@@ -20,12 +20,14 @@ static_assert(sizeof(tc2li_lidar_state) == sizeof(LidarStateDev), "ABI layout");
 
 struct tc2li_lidar_map {
     DevBuf<PointXYZINormal> d_points, d_points_alt;
-    DevBuf<uint8_t> d_deleted;
-    DevBuf<int> d_keep_counts, d_totals, d_bbox;
+    DevBuf<uint8_t> d_deleted;  // all zero between calls (k_map_keep_scatter clears what the marking kernels set)
+    DevBuf<int> d_keep_counts, d_out;  // d_out [kMapIncOut]: a compaction without a scan (box deletion)
     DevBuf<float> d_boxes;
-    PinnedBuf<int> h_io;  // totals (2) + encoded bounding box (6)
+    PinnedBuf<int> h_out;
     DevBuf<float4> d_sorted;
-    DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill;
+    DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill, d_tile_sums;
+    DevBuf<MapIncTask> d_inc_task;    // batches of one map: Build / Add_Points / Delete_Point_Boxes
+    DevBuf<MapGridTask> d_grid_task;
     int n = 0, n_cells = 0;
     float cell = 1.0f;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounding box of the points
@@ -69,11 +71,15 @@ struct tc2li_lidar {
     DevBuf<VoxelParams> d_vp;
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
-    DevBuf<int> d_perm, d_hard_count, d_group_start, d_noneed, d_inc_counts;
+    DevBuf<int> d_perm, d_hard_count;
+    // map_incremental, one slot per scan of the batch (allocated on first use)
+    DevBuf<int> d_group_start, d_noneed, d_mapinc_out;
     DevBuf<uint8_t> d_cls, d_has_append;
     DevBuf<MapIncRec> d_inc_recs;
     DevBuf<PointXYZINormal> d_appended;
-    PinnedBuf<int> h_inc;
+    DevBuf<MapIncTask> d_inc_tasks;
+    DevBuf<MapGridTask> d_grid_tasks;
+    PinnedBuf<int> h_mapinc_out;
     std::vector<int> last_down;  // per slot: down-sampled points of the last feature extraction
     DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
@@ -140,6 +146,7 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_vox_fill.p, 0, (size_t)S * L->cap * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_n_vox.p, 0, (size_t)S * sizeof(int), st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_down_count.p, 0, (size_t)S * sizeof(int), st));  // an empty scan has no block that would write its count
     launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
     launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
     launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, L->d_pt_slot.p, L->d_n_vox.p, L->d_vox_keys.p, st);
@@ -174,8 +181,10 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
     return TC2LI_OK;
 }
 
-int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) {
-    // cell size: 1 m unless the bounding box would need more than 4M cells
+inline float dec_enc(int i) { const int v = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &v, 4); return f; }
+
+// Geometry of the dense grid over the map's bounding box: 1 m cells unless that would need more than 4M of them.
+MapGrid grid_geometry(const tc2li_lidar_map* m, float* cell_out) {
     MapGrid g{};
     float cell = 1.0f;
     for (;;) {
@@ -194,24 +203,73 @@ int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) {
         }
         cell *= 1.5f;
     }
+    *cell_out = cell;
+    return g;
+}
+
+// Sizes the map's grid arrays for its current points and fills the build task (no launch).
+int grid_prepare(tc2li_lidar_map* m, MapGridTask* t) {
+    float cell;
+    MapGrid g = grid_geometry(m, &cell);
     m->cell = cell;
     const int nc = g.nx * g.ny * g.nz;
     if (nc > m->n_cells) {
         TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nc + nc / 2));
         TC2LI_HIP_CHECK(m->d_bucket_fill.alloc(nc + nc / 2));
         TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nc + nc / 2 + 1));
+        TC2LI_HIP_CHECK(m->d_tile_sums.alloc((size_t)(nc + nc / 2) / 4096 + 2));
         m->n_cells = nc + nc / 2;
     }
     TC2LI_HIP_CHECK(m->d_sorted.ensure(std::max(m->n, 1)));
-    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, nc * sizeof(int), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_fill.p, 0, nc * sizeof(int), st));
     g.points = m->d_points.p; g.pts = m->d_sorted.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
-    launch_map_count(g, m->n, m->d_bucket_counts.p, st);
-    launch_map_scan(m->d_bucket_counts.p, nc, m->d_bucket_start.p, st);
-    launch_map_scatter(g, m->n, m->d_bucket_fill.p, m->d_sorted.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    m->grid = g;
+    t->g = g; t->counts = m->d_bucket_counts.p; t->fill = m->d_bucket_fill.p; t->start = m->d_bucket_start.p; t->sorted = m->d_sorted.p;
+    t->tile_sums = m->d_tile_sums.p; t->n_cells = nc;
     return TC2LI_OK;
+}
+
+// (Re)builds the grids of a set of maps with one launch per phase; tasks go up through d_tasks.  No synchronisation.
+int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>& d_tasks, hipStream_t st) {
+    if (n_maps <= 0) return TC2LI_OK;
+    std::vector<MapGridTask> tasks(n_maps);
+    int max_points = 0, max_cells = 0;
+    for (int i = 0; i < n_maps; ++i) {
+        const int rc = grid_prepare(maps[i], &tasks[i]);
+        if (rc != TC2LI_OK) return rc;
+        max_points = std::max(max_points, maps[i]->n);
+        max_cells = std::max(max_cells, tasks[i].n_cells);
+    }
+    TC2LI_HIP_CHECK(d_tasks.ensure(n_maps));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_tasks.p, tasks.data(), n_maps * sizeof(MapGridTask), hipMemcpyHostToDevice, st));
+    launch_map_grid_build(d_tasks.p, n_maps, max_points, max_cells, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < n_maps; ++i) maps[i]->grid = tasks[i].g;
+    return TC2LI_OK;
+}
+int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) { return rebuild_grids(&m, 1, m->d_grid_task, st); }
+
+// The flags must be zero outside a call: a grown buffer starts zeroed.
+int ensure_deleted(tc2li_lidar_map* m, int n, hipStream_t st) {
+    if ((size_t)n <= m->d_deleted.n) return TC2LI_OK;
+    TC2LI_HIP_CHECK(m->d_deleted.alloc((size_t)n + n / 2 + 1024));
+    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->d_deleted.n, st));
+    return TC2LI_OK;
+}
+
+// After the compaction kernels of a batch have finished (results of task i at out + kMapIncOut * i on the host): the maps take over
+// their new point lists.
+void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
+    const int kept = out[4], appended = has_inc ? out[5] : 0, noneed = has_inc ? out[2] : 0;
+    const int added = appended + noneed;
+    if (added > 0)
+        for (int a = 0; a < 3; ++a) {
+            const float lo = dec_enc(out[6 + a]), hi = dec_enc(out[9 + a]);
+            if (kept == 0) { m->lo[a] = lo; m->hi[a] = hi; }  // otherwise the old box stays a (possibly loose) superset
+            m->lo[a] = std::min(m->lo[a], lo);
+            m->hi[a] = std::max(m->hi[a], hi);
+        }
+    std::swap(m->d_points.p, m->d_points_alt.p);
+    std::swap(m->d_points.n, m->d_points_alt.n);
+    m->n = kept + added;
 }
 
 }  // namespace
@@ -635,81 +693,109 @@ int tc2li_lidar_map_build(tc2li_lidar_map* m, const tc2li_point* pts, int n) { r
 int tc2li_lidar_map_add(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, false); }
 
 namespace {
-inline float dec_enc(int i) { const int v = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &v, 4); return f; }
-
-// Removes the points flagged in m->d_deleted, appends the increment lists (if any) and rebuilds the grid.
-int map_compact_and_rebuild(tc2li_lidar_map* m, tc2li_lidar* L, int scan_base, int n_groups, int n_noneed, hipStream_t st) {
-    const int n = m->n, nb = (n + 1023) / 1024;
-    TC2LI_HIP_CHECK(m->d_keep_counts.ensure(std::max(nb, 1)));
-    TC2LI_HIP_CHECK(m->d_totals.ensure(2));
-    TC2LI_HIP_CHECK(m->d_bbox.ensure(6));
-    TC2LI_HIP_CHECK(m->h_io.ensure(8));
-    TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)n + n_groups + n_noneed + 1));
-    const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-    launch_map_compact(m->d_points.p, m->d_deleted.p, n, m->d_keep_counts.p, L ? L->d_appended.p : nullptr, L ? L->d_has_append.p : nullptr,
-                       L ? L->d_world.p + scan_base : nullptr, L ? L->d_noneed.p : nullptr, L ? L->d_inc_counts.p : nullptr, m->d_totals.p,
-                       m->d_points_alt.p, m->d_bbox.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p, m->d_totals.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_io.p + 2, m->d_bbox.p, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    const int kept = m->h_io.p[0], appended = L ? m->h_io.p[1] : 0;
-    const int added = appended + (L ? n_noneed : 0);
-    if (added > 0)
-        for (int a = 0; a < 3; ++a) {
-            const float lo = dec_enc(m->h_io.p[2 + a]), hi = dec_enc(m->h_io.p[5 + a]);
-            if (kept == 0) { m->lo[a] = lo; m->hi[a] = hi; }  // otherwise the old box stays a (possibly loose) superset
-            m->lo[a] = std::min(m->lo[a], lo);
-            m->hi[a] = std::max(m->hi[a], hi);
+// map_incremental for a batch of (scan slot, map) pairs: one launch per phase for all of them, one synchronisation between the
+// compaction and the grid rebuild (the host sizes the new grids) and one at the end.
+int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2li_lidar_map* const* maps, const tc2li_lidar_state* states,
+                         int ekf_inited, double fs, int32_t* n_to_add, int32_t* n_no_need, int32_t* map_sizes, hipStream_t st) {
+    for (int i = 0; i < n_tasks; ++i) {
+        if (!maps[i] || scans[i] < 0 || scans[i] >= (int)L->last_down.size()) {
+            set_error("tc2li_lidar_map_incremental: invalid argument (the scan slots must come from the last feature extraction)");
+            return TC2LI_ERR_INVALID;
         }
-    std::swap(m->d_points.p, m->d_points_alt.p);
-    std::swap(m->d_points.n, m->d_points_alt.n);
-    m->n = kept + added;
-    const int rc = rebuild_grid(m, st);
-    if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    return kept;
+        if (n_to_add) n_to_add[i] = 0;
+        if (n_no_need) n_no_need[i] = 0;
+    }
+    {
+        std::vector<const tc2li_lidar_map*> seen(maps, maps + n_tasks);
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { set_error("tc2li_lidar_map_incremental_batch: a map appears twice in one batch"); return TC2LI_ERR_INVALID; }
+    }
+    MapLocks locks(maps, n_tasks);
+    const size_t S = L->max_scans, T = L->total;
+    if (L->d_inc_tasks.n < S) {
+        TC2LI_HIP_CHECK(L->d_cls.alloc(T)); TC2LI_HIP_CHECK(L->d_noneed.alloc(T));
+        TC2LI_HIP_CHECK(L->d_inc_recs.alloc(S * kMapIncMax)); TC2LI_HIP_CHECK(L->d_group_start.alloc(S * (kMapIncMax + 1)));
+        TC2LI_HIP_CHECK(L->d_appended.alloc(S * kMapIncMax)); TC2LI_HIP_CHECK(L->d_has_append.alloc(S * kMapIncMax));
+        TC2LI_HIP_CHECK(L->d_mapinc_out.alloc(S * kMapIncOut)); TC2LI_HIP_CHECK(L->h_mapinc_out.alloc(S * kMapIncOut));
+        TC2LI_HIP_CHECK(L->d_grid_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_inc_tasks.alloc(S));
+    }
+    std::vector<MapIncTask> tasks;
+    std::vector<int> which;  // task -> index in the caller's arrays
+    tasks.reserve(n_tasks);
+    int max_points = 0, max_map = 0;
+    const float ds = (float)fs;  // ikdtree.set_downsample_param(filter_size_map_min): float downsample_size
+    for (int i = 0; i < n_tasks; ++i) {
+        tc2li_lidar_map* m = maps[i];
+        const int scan = scans[i], n = L->last_down[scan];
+        if (n == 0) continue;  // nothing to insert: the map stays as it is
+        const size_t base = (size_t)scan * L->cap;
+        int rc = ensure_deleted(m, std::max(m->n, 1), st);
+        if (rc != TC2LI_OK) return rc;
+        const int kb = (m->n + 1023) / 1024;
+        TC2LI_HIP_CHECK(m->d_keep_counts.ensure(std::max(kb, 1)));
+        TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + std::min(n, kMapIncMax) + n + 1));
+        MapIncTask t{};
+        t.body = L->d_down.p + base; t.nearest_idx = L->d_nearest_idx.p + base * 5; t.nfound = L->d_nfound.p + base;
+        t.world = L->d_world.p + base; t.cls = L->d_cls.p + base; t.noneed = L->d_noneed.p + base;
+        t.recs = L->d_inc_recs.p + (size_t)scan * kMapIncMax; t.group_start = L->d_group_start.p + (size_t)scan * (kMapIncMax + 1);
+        t.appended = L->d_appended.p + (size_t)scan * kMapIncMax; t.has_append = L->d_has_append.p + (size_t)scan * kMapIncMax;
+        t.out = L->d_mapinc_out.p + (size_t)tasks.size() * kMapIncOut;
+        t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
+        memcpy(&t.st, &states[i], sizeof(LidarStateDev));
+        t.fs = fs; t.ds = ds; t.n = n; t.n_map = m->n; t.keep_blocks = kb; t.ekf_inited = ekf_inited; t.has_inc = 1;
+        tasks.push_back(t);
+        which.push_back(i);
+        max_points = std::max(max_points, n);
+        max_map = std::max(max_map, m->n);
+    }
+    const int nt = (int)tasks.size();
+    if (nt) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
+        launch_mapinc_lists(L->d_inc_tasks.p, nt, max_points, st);
+        launch_map_compact(L->d_inc_tasks.p, nt, max_map, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        for (int k = 0; k < nt; ++k)
+            if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {  // nothing has been committed: every map is as it was
+                set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax);
+                return TC2LI_ERR_CAPACITY;
+            }
+        std::vector<tc2li_lidar_map*> changed(nt);
+        for (int k = 0; k < nt; ++k) {
+            const int* o = L->h_mapinc_out.p + k * kMapIncOut;
+            commit_compaction(maps[which[k]], o, true);
+            changed[k] = maps[which[k]];
+            if (n_to_add) n_to_add[which[k]] = o[0];
+            if (n_no_need) n_no_need[which[k]] = o[2];
+        }
+        const int rc = rebuild_grids(changed.data(), nt, L->d_grid_tasks, st);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    }
+    if (map_sizes) for (int i = 0; i < n_tasks; ++i) map_sizes[i] = maps[i]->n;
+    return n_tasks;
 }
 }  // namespace
 
 int tc2li_lidar_map_incremental(tc2li_lidar* L, int scan, tc2li_lidar_map* m, const tc2li_lidar_state* state, int ekf_inited,
                                 double filter_size_map_min, int32_t* n_to_add, int32_t* n_no_need, void* stream_) {
-    if (!L || !m || !state || scan < 0 || scan >= (int)L->last_down.size() || !(filter_size_map_min > 0)) {
-        set_error("tc2li_lidar_map_incremental: invalid argument (the scan slot must come from the last feature extraction)");
+    if (!L || !m || !state || !(filter_size_map_min > 0)) { set_error("tc2li_lidar_map_incremental: invalid argument"); return TC2LI_ERR_INVALID; }
+    const int32_t sc = scan;
+    int32_t size = 0;
+    const int rc = map_incremental_impl(L, 1, &sc, &m, state, ekf_inited, filter_size_map_min, n_to_add, n_no_need, &size, (hipStream_t)stream_);
+    return rc < 0 ? rc : size;
+}
+
+int tc2li_lidar_map_incremental_batch(tc2li_lidar* L, int n, const int32_t* scans, tc2li_lidar_map* const* maps, const tc2li_lidar_state* states,
+                                      int ekf_inited, double filter_size_map_min, int32_t* n_to_add, int32_t* n_no_need, int32_t* map_sizes,
+                                      void* stream_) {
+    if (!L || n < 0 || (n > 0 && (!scans || !maps || !states)) || n > (L ? L->max_scans : 0) || !(filter_size_map_min > 0)) {
+        set_error("tc2li_lidar_map_incremental_batch: invalid argument");
         return TC2LI_ERR_INVALID;
     }
-    hipStream_t st = (hipStream_t)stream_;
-    std::lock_guard<std::mutex> lock(m->mu);
-    const int n = L->last_down[scan];
-    const size_t base = (size_t)scan * L->cap;
-    if (n_to_add) *n_to_add = 0;
-    if (n_no_need) *n_no_need = 0;
-    if (n == 0) return m->n;
-    TC2LI_HIP_CHECK(L->d_cls.ensure(L->cap)); TC2LI_HIP_CHECK(L->d_inc_recs.ensure(kMapIncMax)); TC2LI_HIP_CHECK(L->d_group_start.ensure(kMapIncMax + 1));
-    TC2LI_HIP_CHECK(L->d_noneed.ensure(L->cap)); TC2LI_HIP_CHECK(L->d_inc_counts.ensure(4)); TC2LI_HIP_CHECK(L->d_appended.ensure(kMapIncMax));
-    TC2LI_HIP_CHECK(L->d_has_append.ensure(kMapIncMax)); TC2LI_HIP_CHECK(L->h_inc.ensure(4));
-    TC2LI_HIP_CHECK(m->d_deleted.ensure(std::max(m->n, 1)));
-    LidarStateDev sd;
-    memcpy(&sd, state, sizeof(sd));
-    const float ds = (float)filter_size_map_min;  // ikdtree.set_downsample_param(filter_size_map_min): float downsample_size
-    launch_mapinc_classify(L->d_down.p + base, n, sd, m->grid, L->d_nearest_idx.p + base * 5, L->d_nfound.p + base, ekf_inited, filter_size_map_min,
-                           L->d_world.p + base, L->d_cls.p, st);
-    launch_mapinc_group(L->d_world.p + base, L->d_cls.p, n, ds, L->d_inc_recs.p, L->d_group_start.p, L->d_noneed.p, L->d_inc_counts.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_inc.p, L->d_inc_counts.p, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (m->n) TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    const int n_add = L->h_inc.p[0], n_groups = L->h_inc.p[1], n_noneed = L->h_inc.p[2];
-    if (L->h_inc.p[3]) { set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax); return TC2LI_ERR_CAPACITY; }
-    launch_mapinc_apply(L->d_world.p + base, L->d_inc_recs.p, L->d_group_start.p, L->d_inc_counts.p, n_groups, m->grid, ds, m->d_deleted.p,
-                        L->d_appended.p, L->d_has_append.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    const int rc = map_compact_and_rebuild(m, L, (int)base, n_groups, n_noneed, st);
-    if (rc < 0) return rc;
-    if (n_to_add) *n_to_add = n_add;
-    if (n_no_need) *n_no_need = n_noneed;
-    return m->n;
+    if (n == 0) return 0;
+    return map_incremental_impl(L, n, scans, maps, states, ekf_inited, filter_size_map_min, n_to_add, n_no_need, map_sizes, (hipStream_t)stream_);
 }
 
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_boxes, void* stream_) {
@@ -717,16 +803,28 @@ int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_
     hipStream_t st = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lock(m->mu);
     if (n_boxes == 0 || m->n == 0) return 0;
-    TC2LI_HIP_CHECK(m->d_deleted.ensure(m->n));
+    int rc = ensure_deleted(m, m->n, st);
+    if (rc != TC2LI_OK) return rc;
+    const int kb = (m->n + 1023) / 1024;
     TC2LI_HIP_CHECK(m->d_boxes.ensure(6 * (size_t)n_boxes));
-    TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->n, st));
+    TC2LI_HIP_CHECK(m->d_keep_counts.ensure(kb)); TC2LI_HIP_CHECK(m->d_out.ensure(kMapIncOut)); TC2LI_HIP_CHECK(m->h_out.ensure(kMapIncOut));
+    TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + 1)); TC2LI_HIP_CHECK(m->d_inc_task.ensure(1));
     TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_boxes.p, boxes6, 6 * (size_t)n_boxes * sizeof(float), hipMemcpyHostToDevice, st));
     launch_map_mark_boxes(m->d_points.p, m->n, m->d_boxes.p, n_boxes, m->d_deleted.p, st);
+    MapIncTask t{};
+    t.out = m->d_out.p; t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
+    t.n_map = m->n; t.keep_blocks = kb; t.has_inc = 0;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_inc_task.p, &t, sizeof(t), hipMemcpyHostToDevice, st));
+    launch_map_compact(m->d_inc_task.p, 1, m->n, st);
     TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_out.p, m->d_out.p, kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
     const int before = m->n;
-    const int kept = map_compact_and_rebuild(m, nullptr, 0, 0, 0, st);
-    if (kept < 0) return kept;
-    return before - kept;
+    commit_compaction(m, m->h_out.p, false);
+    rc = rebuild_grid(m, st);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    return before - m->n;
 }
 
 int tc2li_lidar_map_download(const tc2li_lidar_map* m, tc2li_point* out, int capacity) {

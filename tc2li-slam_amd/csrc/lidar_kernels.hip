@@ -6,6 +6,8 @@
 // operations (the library is built with -ffp-contract=off), sums are taken in the CPU order: results are bit-equal
 // to the CPU path.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 // Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
 // `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
 // the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
@@ -13,28 +15,11 @@
 #include <stdint.h>
 
 #include "lidar_device.hpp"
+#include "lidar_device_fn.hpp"
 
 namespace tc2li {
 
 // ---- helpers ------------------------------------------------------------------------------------------------------
-// Exclusive prefix of a per-thread flag over a 1024-thread block (16 wavefronts); returns the block total in `total`.
-__device__ __forceinline__ int block_flag_scan(bool f, int* s_wave, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(f);
-    if (lane == 0) s_wave[wave] = __popcll(bal);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < kSegBlock / 64; ++k) {
-        const int c = s_wave[k];
-        off += k < wave ? c : 0;
-        tot += c;
-    }
-    total = tot;
-    __syncthreads();
-    return off + __popcll(bal & ((1ull << lane) - 1ull));
-}
-
 // Orders the LDS accesses of the lanes of ONE wavefront (waves of a block run different trip counts in the kernels
 // below, so a block barrier cannot be used): release + acquire fence at workgroup scope drains lgkmcnt and stops the
 // compiler from moving LDS accesses across this point.
@@ -50,7 +35,7 @@ __global__ void k_fill_int(int* p, size_t n, int v) {
 void launch_fill_int(int* p, size_t n, int v, hipStream_t st) {
     if (n == 0) return;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_fill_int, dim3(grid), dim3(256), 0, st, p, n, v);
+    TC2LI_LAUNCH(k_fill_int, dim3(grid), dim3(256), 0, st, p, n, v);
 }
 
 // ---- b1: Preprocess::velodyne_handler, non-feature branch (preprocess.cpp:145-166) ---------------------------------
@@ -123,8 +108,6 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_scatter(const VelodynePoint* 
 }
 
 // ---- b3: pcl::VoxelGrid<PointXYZINormal>::filter (LidarFrontEnd.cpp:712-714, 913-915) -------------------------------
-__device__ __forceinline__ int enc_float(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
-__device__ __forceinline__ float dec_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 __device__ __forceinline__ bool finite3(const PointXYZINormal& p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
 
 __global__ __launch_bounds__(kSegBlock) void k_voxel_bbox(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
@@ -503,50 +486,11 @@ __global__ __launch_bounds__(256) void k_undistort(const PointXYZINormal* __rest
 
 void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const Pose6DDev* poses, int n_poses, const LidarStateDev* end,
                       PointXYZINormal* out, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, n, poses, n_poses, end, out);
+    if (n) TC2LI_LAUNCH(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, n, poses, n_poses, end, out);
 }
 
 // ---- b5: map spatial index (replaces the ikd-Tree as a dense uniform grid over the map's bounding box) ------------
 // Cells are ordered x-fastest, so the points of a run of cells along x are one contiguous range of the sorted array.
-__device__ __forceinline__ int map_cell(const MapGrid& g, float x, float y, float z) {
-    const int cx = (int)floorf(x * g.inv_cell) - g.x0, cy = (int)floorf(y * g.inv_cell) - g.y0, cz = (int)floorf(z * g.inv_cell) - g.z0;
-    return (cz * g.ny + cy) * g.nx + cx;
-}
-
-__global__ void k_map_count(MapGrid g, int n, int* __restrict__ cell_counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PointXYZINormal p = g.points[i];
-    atomicAdd(&cell_counts[map_cell(g, p.x, p.y, p.z)], 1);
-}
-
-__global__ __launch_bounds__(1024) void k_map_scan(const int* __restrict__ bucket_counts, int n_buckets, int* __restrict__ bucket_start) {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x, per = (n_buckets + 1023) / 1024, lo = min(tid * per, n_buckets), hi = min(lo + per, n_buckets);
-    int sum = 0;
-    for (int k = lo; k < hi; ++k) sum += bucket_counts[k];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int t = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += t;
-        __syncthreads();
-    }
-    int run = s_part[tid] - sum;
-    for (int k = lo; k < hi; ++k) { bucket_start[k] = run; run += bucket_counts[k]; }
-    if (tid == 1023) bucket_start[n_buckets] = s_part[1023];
-}
-
-__global__ void k_map_scatter(MapGrid g, int n, int* __restrict__ cell_fill, float4* __restrict__ sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const PointXYZINormal p = g.points[i];
-    const int c = map_cell(g, p.x, p.y, p.z);
-    const int pos = g.bucket_start[c] + atomicAdd(&cell_fill[c], 1);
-    sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
-}
-
 // ---- b4 + b5 + b6: pointBodyToWorld, 5-NN, EstiPlane and the gates of feature_extraction --------------------------
 // Least squares of the 5x3 system by Householder QR with column pivoting (what colPivHouseholderQr().solve() does),
 // same operation order as the CPU statement.
@@ -838,21 +782,6 @@ __device__ __forceinline__ void knn_finish(const MapGrid& grid, const Top5& t, c
     normvec[o] = nv;
 }
 
-// pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
-__device__ __forceinline__ PointXYZINormal body_to_world(const PointXYZINormal& pb, const LidarStateDev& st) {
-    const double bx = pb.x, by = pb.y, bz = pb.z;
-    double t[3], g[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) t[r] = (st.off_r[3 * r] * bx + st.off_r[3 * r + 1] * by + st.off_r[3 * r + 2] * bz) + st.off_t[r];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) g[r] = (st.rot[3 * r] * t[0] + st.rot[3 * r + 1] * t[1] + st.rot[3 * r + 2] * t[2]) + st.pos[r];
-    PointXYZINormal pw;
-    pw.x = (float)g[0]; pw.y = (float)g[1]; pw.z = (float)g[2]; pw.pad0 = 1.0f;
-    pw.normal_x = 0; pw.normal_y = 0; pw.normal_z = 0; pw.pad1 = 0;
-    pw.intensity = pb.intensity; pw.curvature = 0; pw.pad2 = 0; pw.pad3 = 0;
-    return pw;
-}
-
 // Pass 1: four lanes per query search the 3^3 and, if needed, the 5^3 cube of map cells (the exact 5 nearest map points
 // of almost every query of a scan that overlaps the map lie there); queries that need a wider search are queued.
 __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ grids,
@@ -940,281 +869,6 @@ __global__ __launch_bounds__(256) void k_knn_hard(const MapGrid* __restrict__ gr
         }
         knn_finish(grid, t, pw, (double)pb.x, (double)pb.y, (double)pb.z, lane == 0, sl.base + q.y, selected, normvec, nearest_idx, nearest_d,
                    nfound);
-    }
-}
-
-// ---- persistent map maintenance: map_incremental (LidarFrontEnd.cpp:387-435), KD_TREE::Add_Points with down-sampling
-// (ikd_Tree.cpp:478-584) and Delete_Point_Boxes (:643) on the flat map + dense grid ---------------------------------------
-__device__ __forceinline__ float calc_dist3(float ax, float ay, float az, float bx, float by, float bz) {
-    return (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
-}
-
-// One thread per down-sampled scan point: world coordinates at the (possibly updated) state and the insertion class
-// 0 = not added, 1 = PointToAdd (down-sampled insertion), 2 = PointNoNeedDownsample.
-__global__ __launch_bounds__(256) void k_mapinc_classify(const PointXYZINormal* __restrict__ body, int n, LidarStateDev st, MapGrid grid,
-                                                         const int* __restrict__ nearest_idx, const int* __restrict__ nfound,
-                                                         int ekf_inited, double fs, PointXYZINormal* __restrict__ world,
-                                                         uint8_t* __restrict__ cls) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const PointXYZINormal pw = body_to_world(body[i], st);
-    world[i] = pw;
-    uint8_t c = 1;
-    const int nf = nfound[i];
-    if (nf > 0 && ekf_inited) {
-        const float mx = (float)(floor((double)pw.x / fs) * fs + 0.5 * fs), my = (float)(floor((double)pw.y / fs) * fs + 0.5 * fs),
-                    mz = (float)(floor((double)pw.z / fs) * fs + 0.5 * fs);
-        const float dist = calc_dist3(pw.x, pw.y, pw.z, mx, my, mz);
-        const PointXYZINormal n0 = grid.points[nearest_idx[(size_t)i * 5]];
-        if ((double)fabsf(n0.x - mx) > 0.5 * fs && (double)fabsf(n0.y - my) > 0.5 * fs && (double)fabsf(n0.z - mz) > 0.5 * fs) {
-            c = 2;
-        } else if (nf >= 5) {
-            for (int r = 0; r < 5; ++r) {
-                const PointXYZINormal q = grid.points[nearest_idx[(size_t)i * 5 + r]];
-                if (calc_dist3(q.x, q.y, q.z, mx, my, mz) < dist) { c = 0; break; }
-            }
-        }
-    }
-    cls[i] = c;
-}
-
-
-// One workgroup: the PointToAdd list in scan order, sorted by (map voxel, scan order) so that every voxel's candidates
-// are consecutive and keep their order; group starts are flagged.  The PointNoNeedDownsample list is compacted in order.
-__global__ __launch_bounds__(1024) void k_mapinc_group(const PointXYZINormal* __restrict__ world, const uint8_t* __restrict__ cls, int n,
-                                                       float ds, MapIncRec* __restrict__ recs, int* __restrict__ group_start,
-                                                       int* __restrict__ noneed_list, int* __restrict__ counts /* [0] n_add [1] n_groups [2] n_noneed [3] overflow */) {
-    extern __shared__ unsigned long long s_key[];  // kMapIncMax keys, then kMapIncMax indices
-    int* s_idx = reinterpret_cast<int*>(s_key + kMapIncMax);
-    __shared__ int s_wave[16], s_base[3];
-    const int tid = threadIdx.x;
-    if (tid < 3) s_base[tid] = 0;
-    __syncthreads();
-    // ordered compaction of both lists, 1024 points at a time
-    for (int b0 = 0; b0 < n; b0 += 1024) {
-        const int i = b0 + tid;
-        const uint8_t c = i < n ? cls[i] : 0;
-        int total;
-        int pos = block_flag_scan(c == 1, s_wave, total);
-        if (c == 1) {
-            const int o = s_base[0] + pos;
-            if (o < kMapIncMax) {
-                const PointXYZINormal p = world[i];
-                const long long ix = (long long)floorf(p.x / ds), iy = (long long)floorf(p.y / ds), iz = (long long)floorf(p.z / ds);
-                s_key[o] = ((unsigned long long)((ix + (1 << 20)) & 0x1fffff) << 42) | ((unsigned long long)((iy + (1 << 20)) & 0x1fffff) << 21) |
-                           (unsigned long long)((iz + (1 << 20)) & 0x1fffff);
-                s_idx[o] = i;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_base[0] += total;
-        __syncthreads();
-        pos = block_flag_scan(c == 2, s_wave, total);
-        if (c == 2) noneed_list[s_base[2] + pos] = i;
-        __syncthreads();
-        if (tid == 0) s_base[2] += total;
-        __syncthreads();
-    }
-    const int m = min(s_base[0], kMapIncMax);
-    int P = 1;
-    while (P < m) P <<= 1;
-    for (int k = m + tid; k < P; k += 1024) { s_key[k] = ~0ull; s_idx[k] = 0x7fffffff; }
-    __syncthreads();
-    for (int size = 2; size <= P; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (P >> 1); t += 1024) {
-                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long ka = s_key[lo], kb = s_key[hi];
-                const int ia = s_idx[lo], ib = s_idx[hi];
-                const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
-                if (a_gt_b == up) { s_key[lo] = kb; s_key[hi] = ka; s_idx[lo] = ib; s_idx[hi] = ia; }
-            }
-            __syncthreads();
-        }
-    // group starts (ordered compaction of the flags)
-    if (tid == 0) s_base[1] = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < m; b0 += 1024) {
-        const int k = b0 + tid;
-        const bool start = k < m && (k == 0 || s_key[k] != s_key[k - 1]);
-        if (k < m) { recs[k].key = s_key[k]; recs[k].idx = s_idx[k]; recs[k].pad = 0; }
-        int total;
-        const int pos = block_flag_scan(start, s_wave, total);
-        if (start) group_start[s_base[1] + pos] = k;
-        __syncthreads();
-        if (tid == 0) s_base[1] += total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        group_start[s_base[1]] = m;
-        counts[0] = m; counts[1] = s_base[1]; counts[2] = s_base[2]; counts[3] = s_base[0] > kMapIncMax ? 1 : 0;
-    }
-}
-
-// One thread per map voxel that receives candidates: the sequence of KD_TREE::Add_Points(downsample_on) calls for that
-// voxel.  The voxel's content is either the stored points E (untouched so far) or a single point c; a candidate p replaces
-// the content by the point closest to the voxel centre among content + p whenever the content has more than one point or
-// p itself is that closest point.
-__global__ __launch_bounds__(128) void k_mapinc_apply(const PointXYZINormal* __restrict__ world, const MapIncRec* __restrict__ recs,
-                                                      const int* __restrict__ group_start, const int* __restrict__ counts, MapGrid grid,
-                                                      float ds, uint8_t* __restrict__ deleted, PointXYZINormal* __restrict__ appended,
-                                                      uint8_t* __restrict__ has_append) {
-    const int g = blockIdx.x * 128 + threadIdx.x;
-    if (g >= counts[1]) return;
-    const int k0 = group_start[g], k1 = group_start[g + 1];
-    const PointXYZINormal first = world[recs[k0].idx];
-    float bmin[3], bmax[3], mid[3];
-    const float c[3] = {first.x, first.y, first.z};
-    for (int a = 0; a < 3; ++a) {
-        bmin[a] = (float)(floor((double)(c[a] / ds)) * (double)ds);
-        bmax[a] = bmin[a] + ds;
-        mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
-    }
-    // stored points inside [bmin, bmax): count and the one closest to the centre
-    int s = 0;
-    float e_dist = 0.f;
-    PointXYZINormal e_best = first;
-    auto for_each_stored = [&](auto&& fn) {
-        if (grid.n_points == 0) return;
-        const int xa = max((int)floorf(bmin[0] * grid.inv_cell) - grid.x0, 0), xb = min((int)floorf(bmax[0] * grid.inv_cell) - grid.x0, grid.nx - 1);
-        const int ya = max((int)floorf(bmin[1] * grid.inv_cell) - grid.y0, 0), yb = min((int)floorf(bmax[1] * grid.inv_cell) - grid.y0, grid.ny - 1);
-        const int za = max((int)floorf(bmin[2] * grid.inv_cell) - grid.z0, 0), zb = min((int)floorf(bmax[2] * grid.inv_cell) - grid.z0, grid.nz - 1);
-        if (xa > xb) return;
-        for (int qz = za; qz <= zb; ++qz)
-            for (int qy = ya; qy <= yb; ++qy) {
-                const int row = (qz * grid.ny + qy) * grid.nx;
-                for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
-                    const float4 m = grid.pts[k];
-                    if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w));
-                }
-            }
-    };
-    for_each_stored([&](int idx) {
-        const PointXYZINormal q = grid.points[idx];
-        const float d = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
-        if (s == 0 || d < e_dist) { e_dist = d; e_best = q; }
-        ++s;
-    });
-    bool intact = true;
-    PointXYZINormal cur = first;  // the single point of a replaced content
-    float cur_dist = 0.f;
-    for (int k = k0; k < k1; ++k) {
-        const PointXYZINormal p = world[recs[k].idx];
-        const float dp = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
-        const int size = intact ? s : 1;
-        const float stored_dist = intact ? e_dist : cur_dist;
-        const bool stored_wins = size > 0 && stored_dist < dp;
-        const PointXYZINormal best = stored_wins ? (intact ? e_best : cur) : p;
-        const bool same = fabsf(p.x - best.x) < 1e-6f && fabsf(p.y - best.y) < 1e-6f && fabsf(p.z - best.z) < 1e-6f;
-        if (size > 1 || same) {  // Delete_by_range(box) + Add_by_point(best)
-            cur_dist = stored_wins ? stored_dist : dp;
-            cur = best;
-            intact = false;
-        }
-    }
-    if (!intact) {
-        for_each_stored([&](int idx) { deleted[idx] = 1; });
-        appended[g] = cur;
-        has_append[g] = 1;
-    } else {
-        has_append[g] = 0;
-    }
-}
-
-// deleted[i] = 1 for every map point inside one of the boxes [min, max) (KD_TREE::Delete_Point_Boxes)
-__global__ __launch_bounds__(256) void k_map_mark_boxes(const PointXYZINormal* __restrict__ pts, int n, const float* __restrict__ boxes, int n_boxes,
-                                                        uint8_t* __restrict__ deleted) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const PointXYZINormal p = pts[i];
-    uint8_t d = deleted[i];
-    for (int b = 0; b < n_boxes; ++b) {
-        const float* q = boxes + 6 * b;
-        if (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z) d = 1;
-    }
-    deleted[i] = d;
-}
-
-// Ordered compaction of the map after deletions: per-block kept counts, their scan (single workgroup), scatter; then the
-// appended voxel representatives (group order) and the PointNoNeedDownsample points (scan order) follow.
-__global__ __launch_bounds__(1024) void k_map_keep_count(const uint8_t* __restrict__ deleted, int n, int* __restrict__ block_counts) {
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const int c = __syncthreads_count(i < n && !deleted[i]);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
-}
-__global__ __launch_bounds__(1024) void k_map_keep_scan(int* __restrict__ block_counts, int nblocks, const uint8_t* __restrict__ has_append,
-                                                        const int* __restrict__ inc_counts, int* __restrict__ totals /* [0] kept [1] appended */) {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x, per = (nblocks + 1023) / 1024;
-    const int lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
-    int sum = 0;
-    for (int k = lo; k < hi; ++k) sum += block_counts[k];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - sum;
-    for (int k = lo; k < hi; ++k) { const int c = block_counts[k]; block_counts[k] = run; run += c; }
-    if (tid == 1023) totals[0] = s_part[1023];
-    if (tid == 0) {
-        int a = 0;
-        const int ng = inc_counts ? inc_counts[1] : 0;
-        for (int g = 0; g < ng; ++g) a += has_append[g];
-        totals[1] = a;
-    }
-}
-__global__ __launch_bounds__(1024) void k_map_keep_scatter(const PointXYZINormal* __restrict__ pts, const uint8_t* __restrict__ deleted, int n,
-                                                           const int* __restrict__ block_offsets, PointXYZINormal* __restrict__ out) {
-    __shared__ int s_wave[16];
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const bool keep = i < n && !deleted[i];
-    int total;
-    const int pos = block_flag_scan(keep, s_wave, total);
-    if (keep) out[block_offsets[blockIdx.x] + pos] = pts[i];
-}
-// out[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added (encoded floats)
-__global__ __launch_bounds__(256) void k_map_append(const PointXYZINormal* __restrict__ appended, const uint8_t* __restrict__ has_append,
-                                                    const PointXYZINormal* __restrict__ world, const int* __restrict__ noneed_list,
-                                                    const int* __restrict__ inc_counts, const int* __restrict__ totals,
-                                                    PointXYZINormal* __restrict__ out, int* __restrict__ bbox_enc) {
-    // single workgroup: the lists are short
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    const int tid = threadIdx.x, ng = inc_counts[1], nn = inc_counts[2], kept = totals[0];
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < ng; b0 += 256) {
-        const int g = b0 + tid;
-        const bool f = g < ng && has_append[g];
-        const unsigned long long bal = __ballot(f);
-        const int lane = tid & 63, wave = tid >> 6;
-        if (lane == 0) s_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = 0, tot = 0;
-        for (int k = 0; k < 4; ++k) { off += k < wave ? s_wave[k] : 0; tot += s_wave[k]; }
-        if (f) {
-            const PointXYZINormal p = appended[g];
-            out[kept + s_base + off + __popcll(bal & ((1ull << lane) - 1ull))] = p;
-            atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
-            atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
-            atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
-        }
-        __syncthreads();
-        if (tid == 0) s_base += tot;
-        __syncthreads();
-    }
-    const int base = kept + totals[1];
-    for (int k = tid; k < nn; k += 256) {
-        const PointXYZINormal p = world[noneed_list[k]];
-        out[base + k] = p;
-        atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
-        atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
-        atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
     }
 }
 
@@ -1341,27 +995,27 @@ __global__ __launch_bounds__(kSegBlock) void k_sel_scatter(const uint8_t* __rest
 // ---- launch wrappers ----------------------------------------------------------------------------------------------
 void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       PreprocessParams prm, int* block_counts, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
+    if (nblocks) TC2LI_LAUNCH(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
 }
 void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st) {
-    if (nscans) hipLaunchKernelGGL(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);
+    if (nscans) TC2LI_LAUNCH(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);
 }
 void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                         PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_pre_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_offsets, out);
+    if (nblocks) TC2LI_LAUNCH(k_pre_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_offsets, out);
 }
 void launch_voxel_bbox(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                        int* bbox_enc, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_bbox, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, bbox_enc);
+    if (nblocks) TC2LI_LAUNCH(k_voxel_bbox, dim3(nblocks), dim3(kSegBlock), 0, st, pts, count, slots, blocks, bbox_enc);
 }
 void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* slots, int nscans, float leaf, VoxelParams* vp,
                          hipStream_t st) {
     (void)slots;
-    if (nscans) hipLaunchKernelGGL(k_voxel_params, dim3((nscans + 63) / 64), dim3(64), 0, st, bbox_enc, count, nscans, leaf, vp);
+    if (nscans) TC2LI_LAUNCH(k_voxel_params, dim3((nscans + 63) / 64), dim3(64), 0, st, bbox_enc, count, nscans, leaf, vp);
 }
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                          float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_insert, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
+    if (nblocks) TC2LI_LAUNCH(k_voxel_insert, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
@@ -1372,31 +1026,22 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
         (void)hipFuncSetAttribute((const void*)k_voxel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxVoxelsPerScan * 4);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
+    TC2LI_LAUNCH(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
                        table_rank, vox_keys, vox_member_off, n_vox, status);
 }
 void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
                        const int* table_rank, const int* vox_member_off, int* vox_fill, int* members, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_voxel_fill, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, count, slots, blocks, vp, pt_slot, table_rank, vox_member_off, vox_fill, members, nblocks);
+    if (nblocks) TC2LI_LAUNCH(k_voxel_fill, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, count, slots, blocks, vp, pt_slot, table_rank, vox_member_off, vox_fill, members, nblocks);
 }
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
                            const int* vox_member_off, const int* vox_fill, const int* members, void* recs, PointXYZINormal* out,
                            int* out_count, hipStream_t st) {
     if (!nblocks) return;
-    hipLaunchKernelGGL(k_voxel_rank, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
+    TC2LI_LAUNCH(k_voxel_rank, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
                        vox_member_off, vox_fill, members, (CentroidRec*)recs, nblocks);
-    hipLaunchKernelGGL(k_voxel_centroid, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
+    TC2LI_LAUNCH(k_voxel_centroid, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
                        vox_fill, (const CentroidRec*)recs, out, out_count, nblocks);
-}
-void launch_map_count(const MapGrid& g, int n, int* cell_counts, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_map_count, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_counts);
-}
-void launch_map_scan(int* bucket_counts, int n_buckets, int* bucket_start, hipStream_t st) {
-    hipLaunchKernelGGL(k_map_scan, dim3(1), dim3(1024), 0, st, bucket_counts, n_buckets, bucket_start);
-}
-void launch_map_scatter(const MapGrid& g, int n, int* cell_fill, float4* sorted, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_map_scatter, dim3((n + 255) / 256), dim3(256), 0, st, g, n, cell_fill, sorted);
 }
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
@@ -1404,59 +1049,32 @@ void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const i
                       int2* hard_list, hipStream_t st, hipEvent_t after_first) {
     if (!nblocks) return;
     (void)hipMemsetAsync(hard_count, 0, sizeof(int), st);
-    hipLaunchKernelGGL(k_knn_plane, dim3((nblocks + 7) / 8 * 8, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
+    TC2LI_LAUNCH(k_knn_plane, dim3((nblocks + 7) / 8 * 8, kSegBlock / 64), dim3(256), 0, st, grids, body, count, slots, blocks, states, world, selected,
                        normvec, nearest_idx, nearest_d, nfound, hard_count, hard_list, nblocks);
     if (after_first) (void)hipEventRecord(after_first, st);
-    hipLaunchKernelGGL(k_knn_hard, dim3(512), dim3(256), 0, st, grids, body, slots, states, selected, normvec, nearest_idx, nearest_d, nfound,
+    TC2LI_LAUNCH(k_knn_hard, dim3(512), dim3(256), 0, st, grids, body, slots, states, selected, normvec, nearest_idx, nearest_d, nfound,
                        hard_count, hard_list);
 }
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_sel_count, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_counts);
+    if (nblocks) TC2LI_LAUNCH(k_sel_count, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_counts);
 }
 void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                         const int* block_offsets, const PointXYZINormal* body, const PointXYZINormal* normvec,
                         PointXYZINormal* cloud_ori, PointXYZINormal* corr_norm, hipStream_t st) {
-    if (nblocks) hipLaunchKernelGGL(k_sel_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_offsets, body, normvec, cloud_ori, corr_norm);
+    if (nblocks) TC2LI_LAUNCH(k_sel_scatter, dim3(nblocks), dim3(kSegBlock), 0, st, selected, count, slots, blocks, block_offsets, body, normvec, cloud_ori, corr_norm);
 }
 
 void launch_eskf_refit(const MapGrid& grid, const PointXYZINormal* body, int n, const LidarStateDev* state, const int* nearest_idx,
                        PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_eskf_refit, dim3((n + 255) / 256), dim3(256), 0, st, grid, body, n, state, nearest_idx, world, selected, normvec);
+    if (n) TC2LI_LAUNCH(k_eskf_refit, dim3((n + 255) / 256), dim3(256), 0, st, grid, body, n, state, nearest_idx, world, selected, normvec);
 }
 void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev* state, const uint8_t* selected, const PointXYZINormal* normvec,
                         int extrinsic_est_en, double* partial, double* out, hipStream_t st) {
     const int nb = (n + 255) / 256;
-    if (nb) hipLaunchKernelGGL(k_eskf_normal, dim3(nb), dim3(256), 0, st, body, n, state, selected, normvec, extrinsic_est_en, partial);
-    hipLaunchKernelGGL(k_eskf_reduce, dim3(1), dim3(256), 0, st, partial, nb, out);
+    if (nb) TC2LI_LAUNCH(k_eskf_normal, dim3(nb), dim3(256), 0, st, body, n, state, selected, normvec, extrinsic_est_en, partial);
+    TC2LI_LAUNCH(k_eskf_reduce, dim3(1), dim3(256), 0, st, partial, nb, out);
 }
 
-void launch_mapinc_classify(const PointXYZINormal* body, int n, const LidarStateDev& st, const MapGrid& grid, const int* nearest_idx,
-                            const int* nfound, int ekf_inited, double fs, PointXYZINormal* world, uint8_t* cls, hipStream_t st_) {
-    if (n) hipLaunchKernelGGL(k_mapinc_classify, dim3((n + 255) / 256), dim3(256), 0, st_, body, n, st, grid, nearest_idx, nfound, ekf_inited, fs, world, cls);
-}
-void launch_mapinc_group(const PointXYZINormal* world, const uint8_t* cls, int n, float ds, MapIncRec* recs, int* group_start,
-                         int* noneed_list, int* counts, hipStream_t st) {
-    static bool attr_set = false;
-    const int lds = kMapIncMax * 12;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_mapinc_group, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
-    hipLaunchKernelGGL(k_mapinc_group, dim3(1), dim3(1024), lds, st, world, cls, n, ds, recs, group_start, noneed_list, counts);
-}
-void launch_mapinc_apply(const PointXYZINormal* world, const MapIncRec* recs, const int* group_start, const int* counts, int n_groups,
-                         const MapGrid& grid, float ds, uint8_t* deleted, PointXYZINormal* appended, uint8_t* has_append, hipStream_t st) {
-    if (n_groups) hipLaunchKernelGGL(k_mapinc_apply, dim3((n_groups + 127) / 128), dim3(128), 0, st, world, recs, group_start, counts, grid, ds, deleted, appended, has_append);
-}
-void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st) {
-    if (n && n_boxes) hipLaunchKernelGGL(k_map_mark_boxes, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, boxes, n_boxes, deleted);
-}
-void launch_map_compact(const PointXYZINormal* pts, const uint8_t* deleted, int n, int* block_counts, const PointXYZINormal* appended,
-                        const uint8_t* has_append, const PointXYZINormal* world, const int* noneed_list, const int* inc_counts, int* totals,
-                        PointXYZINormal* out, int* bbox_enc, hipStream_t st) {
-    const int nb = (n + 1023) / 1024;
-    if (nb) hipLaunchKernelGGL(k_map_keep_count, dim3(nb), dim3(1024), 0, st, deleted, n, block_counts);
-    hipLaunchKernelGGL(k_map_keep_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, has_append, inc_counts, totals);
-    if (nb) hipLaunchKernelGGL(k_map_keep_scatter, dim3(nb), dim3(1024), 0, st, pts, deleted, n, block_counts, out);
-    if (inc_counts) hipLaunchKernelGGL(k_map_append, dim3(1), dim3(256), 0, st, appended, has_append, world, noneed_list, inc_counts, totals, out, bbox_enc);
-}
 
 }  // namespace tc2li

@@ -7,6 +7,8 @@
 //   k_lm_first      one thread per match slot of the local keyframes: the first position at which a point occurs (atomicMin)
 //   k_lm_count / k_lm_scatter   ordered compaction of the first occurrences = mvpLocalMapPoints in the reference's order
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #include <stdint.h>
 
 #include "localmap_device.hpp"
@@ -169,16 +171,16 @@ __global__ __launch_bounds__(256) void k_lm_scatter(LocalMapDev m, int n_local, 
 }
 
 void launch_local_map_votes(const LocalMapDev& m, const int32_t* frame_points, int n, uint8_t* cleared, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(k_lm_votes, dim3((n + 255) / 256), dim3(256), 0, st, m, frame_points, n, cleared);
+    if (n > 0) TC2LI_LAUNCH(k_lm_votes, dim3((n + 255) / 256), dim3(256), 0, st, m, frame_points, n, cleared);
 }
 void launch_local_map_keyframes(const LocalMapDev& m, int temporal_last_kf, hipStream_t st) {
-    hipLaunchKernelGGL(k_lm_keyframes, dim3(1), dim3(1024), 0, st, m, temporal_last_kf);
+    TC2LI_LAUNCH(k_lm_keyframes, dim3(1), dim3(1024), 0, st, m, temporal_last_kf);
 }
 void launch_local_map_points(const LocalMapDev& m, int n_local, int total, hipStream_t st) {
     const int blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(k_lm_first, dim3(blocks), dim3(256), 0, st, m, n_local, total);
-    hipLaunchKernelGGL(k_lm_count, dim3(blocks), dim3(256), 0, st, m, n_local, total);
-    hipLaunchKernelGGL(k_lm_scatter, dim3(blocks), dim3(256), 0, st, m, n_local, total);
+    TC2LI_LAUNCH(k_lm_first, dim3(blocks), dim3(256), 0, st, m, n_local, total);
+    TC2LI_LAUNCH(k_lm_count, dim3(blocks), dim3(256), 0, st, m, n_local, total);
+    TC2LI_LAUNCH(k_lm_scatter, dim3(blocks), dim3(256), 0, st, m, n_local, total);
 }
 
 }  // namespace tc2li

@@ -1,0 +1,420 @@
+// gfx950 kernels of the persistent LiDAR map: map_incremental
+// (SF/include/lidar_front_end/LidarFrontEnd.cpp:387-435), KD_TREE::Add_Points with down-sampling (ikd_Tree.cpp:478-584),
+// Delete_Point_Boxes (:643) and the (re)build of the dense grid that stands in for the ikd-Tree.
+// Every kernel works on a BATCH of maps: task = blockIdx.y names one (scan, map) pair whose pointers and sizes sit in a
+// device-resident task record, so the maps of all sequences of a step are maintained by one launch per phase instead of a dozen
+// launches and three host synchronisations per map (the single-map entry points are batches of one).
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "lidar_device.hpp"
+#include "lidar_device_fn.hpp"
+
+namespace tc2li {
+
+// ---- map_incremental: insertion class of every down-sampled scan point -----------------------------------------------------------
+// 0 = not added, 1 = PointToAdd (down-sampled insertion), 2 = PointNoNeedDownsample; world coordinates at the (possibly updated) state.
+__global__ __launch_bounds__(256) void k_mapinc_classify(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.n) return;
+    const double fs = T.fs;
+    const PointXYZINormal pw = body_to_world(T.body[i], T.st);
+    T.world[i] = pw;
+    uint8_t c = 1;
+    const int nf = T.nfound[i];
+    if (nf > 0 && T.ekf_inited) {
+        const float mx = (float)(floor((double)pw.x / fs) * fs + 0.5 * fs), my = (float)(floor((double)pw.y / fs) * fs + 0.5 * fs),
+                    mz = (float)(floor((double)pw.z / fs) * fs + 0.5 * fs);
+        const float dist = calc_dist3(pw.x, pw.y, pw.z, mx, my, mz);
+        const PointXYZINormal n0 = T.grid.points[T.nearest_idx[(size_t)i * 5]];
+        if ((double)fabsf(n0.x - mx) > 0.5 * fs && (double)fabsf(n0.y - my) > 0.5 * fs && (double)fabsf(n0.z - mz) > 0.5 * fs) {
+            c = 2;
+        } else if (nf >= 5) {
+            for (int r = 0; r < 5; ++r) {
+                const PointXYZINormal q = T.grid.points[T.nearest_idx[(size_t)i * 5 + r]];
+                if (calc_dist3(q.x, q.y, q.z, mx, my, mz) < dist) { c = 0; break; }
+            }
+        }
+    }
+    T.cls[i] = c;
+}
+
+// One workgroup per task: the PointToAdd list in scan order, sorted by (map voxel, scan order) so that every voxel's candidates
+// are consecutive and keep their order; group starts are flagged.  The PointNoNeedDownsample list is compacted in order.
+// counts: [0] n_add [1] n_groups [2] n_noneed [3] overflow
+__global__ __launch_bounds__(1024) void k_mapinc_group(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.x];
+    extern __shared__ unsigned long long s_key[];  // kMapIncMax keys, then kMapIncMax indices
+    int* s_idx = reinterpret_cast<int*>(s_key + kMapIncMax);
+    __shared__ int s_wave[16], s_base[3];
+    const int tid = threadIdx.x, n = T.n;
+    const float ds = T.ds;
+    if (tid < 3) s_base[tid] = 0;
+    __syncthreads();
+    // ordered compaction of both lists, 1024 points at a time
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        const int i = b0 + tid;
+        const uint8_t c = i < n ? T.cls[i] : 0;
+        int total;
+        int pos = block_flag_scan(c == 1, s_wave, total);
+        if (c == 1) {
+            const int o = s_base[0] + pos;
+            if (o < kMapIncMax) {
+                const PointXYZINormal p = T.world[i];
+                const long long ix = (long long)floorf(p.x / ds), iy = (long long)floorf(p.y / ds), iz = (long long)floorf(p.z / ds);
+                s_key[o] = ((unsigned long long)((ix + (1 << 20)) & 0x1fffff) << 42) | ((unsigned long long)((iy + (1 << 20)) & 0x1fffff) << 21) |
+                           (unsigned long long)((iz + (1 << 20)) & 0x1fffff);
+                s_idx[o] = i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_base[0] += total;
+        __syncthreads();
+        pos = block_flag_scan(c == 2, s_wave, total);
+        if (c == 2) T.noneed[s_base[2] + pos] = i;
+        __syncthreads();
+        if (tid == 0) s_base[2] += total;
+        __syncthreads();
+    }
+    const int m = min(s_base[0], kMapIncMax);
+    int P = 1;
+    while (P < m) P <<= 1;
+    for (int k = m + tid; k < P; k += 1024) { s_key[k] = ~0ull; s_idx[k] = 0x7fffffff; }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long ka = s_key[lo], kb = s_key[hi];
+                const int ia = s_idx[lo], ib = s_idx[hi];
+                const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+                if (a_gt_b == up) { s_key[lo] = kb; s_key[hi] = ka; s_idx[lo] = ib; s_idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    // group starts (ordered compaction of the flags)
+    if (tid == 0) s_base[1] = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < m; b0 += 1024) {
+        const int k = b0 + tid;
+        const bool start = k < m && (k == 0 || s_key[k] != s_key[k - 1]);
+        if (k < m) { T.recs[k].key = s_key[k]; T.recs[k].idx = s_idx[k]; T.recs[k].pad = 0; }
+        int total;
+        const int pos = block_flag_scan(start, s_wave, total);
+        if (start) T.group_start[s_base[1] + pos] = k;
+        __syncthreads();
+        if (tid == 0) s_base[1] += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        T.group_start[s_base[1]] = m;
+        T.out[0] = m; T.out[1] = s_base[1]; T.out[2] = s_base[2]; T.out[3] = s_base[0] > kMapIncMax ? 1 : 0;
+    }
+}
+
+// One thread per map voxel that receives candidates: the sequence of KD_TREE::Add_Points(downsample_on) calls for that
+// voxel.  The voxel's content is either the stored points E (untouched so far) or a single point c; a candidate p replaces
+// the content by the point closest to the voxel centre among content + p whenever the content has more than one point or
+// p itself is that closest point.
+__global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
+    const int g = blockIdx.x * 128 + threadIdx.x;
+    if (g >= T.out[1]) return;
+    const MapGrid& grid = T.grid;
+    const float ds = T.ds;
+    const int k0 = T.group_start[g], k1 = T.group_start[g + 1];
+    const PointXYZINormal first = T.world[T.recs[k0].idx];
+    float bmin[3], bmax[3], mid[3];
+    const float c[3] = {first.x, first.y, first.z};
+    for (int a = 0; a < 3; ++a) {
+        bmin[a] = (float)(floor((double)(c[a] / ds)) * (double)ds);
+        bmax[a] = bmin[a] + ds;
+        mid[a] = (float)((double)bmin[a] + (double)(bmax[a] - bmin[a]) / 2.0);
+    }
+    // stored points inside [bmin, bmax): count and the one closest to the centre
+    int s = 0;
+    float e_dist = 0.f;
+    PointXYZINormal e_best = first;
+    auto for_each_stored = [&](auto&& fn) {
+        if (grid.n_points == 0) return;
+        const int xa = max((int)floorf(bmin[0] * grid.inv_cell) - grid.x0, 0), xb = min((int)floorf(bmax[0] * grid.inv_cell) - grid.x0, grid.nx - 1);
+        const int ya = max((int)floorf(bmin[1] * grid.inv_cell) - grid.y0, 0), yb = min((int)floorf(bmax[1] * grid.inv_cell) - grid.y0, grid.ny - 1);
+        const int za = max((int)floorf(bmin[2] * grid.inv_cell) - grid.z0, 0), zb = min((int)floorf(bmax[2] * grid.inv_cell) - grid.z0, grid.nz - 1);
+        if (xa > xb) return;
+        for (int qz = za; qz <= zb; ++qz)
+            for (int qy = ya; qy <= yb; ++qy) {
+                const int row = (qz * grid.ny + qy) * grid.nx;
+                for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
+                    const float4 m = grid.pts[k];
+                    if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w));
+                }
+            }
+    };
+    for_each_stored([&](int idx) {
+        const PointXYZINormal q = grid.points[idx];
+        const float d = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
+        if (s == 0 || d < e_dist) { e_dist = d; e_best = q; }
+        ++s;
+    });
+    bool intact = true;
+    PointXYZINormal cur = first;  // the single point of a replaced content
+    float cur_dist = 0.f;
+    for (int k = k0; k < k1; ++k) {
+        const PointXYZINormal p = T.world[T.recs[k].idx];
+        const float dp = calc_dist3(p.x, p.y, p.z, mid[0], mid[1], mid[2]);
+        const int size = intact ? s : 1;
+        const float stored_dist = intact ? e_dist : cur_dist;
+        const bool stored_wins = size > 0 && stored_dist < dp;
+        const PointXYZINormal best = stored_wins ? (intact ? e_best : cur) : p;
+        const bool same = fabsf(p.x - best.x) < 1e-6f && fabsf(p.y - best.y) < 1e-6f && fabsf(p.z - best.z) < 1e-6f;
+        if (size > 1 || same) {  // Delete_by_range(box) + Add_by_point(best)
+            cur_dist = stored_wins ? stored_dist : dp;
+            cur = best;
+            intact = false;
+        }
+    }
+    if (!intact) {
+        for_each_stored([&](int idx) { T.deleted[idx] = 1; });
+        T.appended[g] = cur;
+        T.has_append[g] = 1;
+    } else {
+        T.has_append[g] = 0;
+    }
+}
+
+// deleted[i] = 1 for every map point inside one of the boxes [min, max) (KD_TREE::Delete_Point_Boxes)
+__global__ __launch_bounds__(256) void k_map_mark_boxes(const PointXYZINormal* __restrict__ pts, int n, const float* __restrict__ boxes, int n_boxes,
+                                                        uint8_t* __restrict__ deleted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const PointXYZINormal p = pts[i];
+    uint8_t d = deleted[i];
+    for (int b = 0; b < n_boxes; ++b) {
+        const float* q = boxes + 6 * b;
+        if (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z) d = 1;
+    }
+    deleted[i] = d;
+}
+
+// ---- ordered compaction of the map after deletions: per-block kept counts, their scan (one workgroup per map), scatter; then the
+// appended voxel representatives (group order) and the PointNoNeedDownsample points (scan order) follow -----------------------------
+__global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
+    if ((int)blockIdx.x >= T.keep_blocks) return;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int c = __syncthreads_count(i < T.n_map && !T.deleted[i]);
+    if (threadIdx.x == 0) T.keep_counts[blockIdx.x] = c;
+}
+// out: [4] kept [5] appended [6..11] bounding box of what is added (encoded floats), initialised here
+__global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.x];
+    __shared__ int s_part[1024];
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, nblocks = T.keep_blocks;
+    // chunks of 1024 block counts, coalesced; the running offset carried from chunk to chunk
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int k = b0 + tid;
+        const int v = k < nblocks ? T.keep_counts[k] : 0;
+        s_part[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int u = tid >= o ? s_part[tid - o] : 0;
+            __syncthreads();
+            s_part[tid] += u;
+            __syncthreads();
+        }
+        if (k < nblocks) T.keep_counts[k] = carry + s_part[tid] - v;
+        carry += s_part[1023];
+        __syncthreads();
+    }
+    // appended representatives: has_append over the groups
+    int a = 0;
+    const int ng = T.has_inc ? T.out[1] : 0;
+    for (int g = tid; g < ng; g += 1024) a += T.has_append[g];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) tot += s_wave[k];
+        T.out[4] = carry;
+        T.out[5] = tot;
+        for (int k = 0; k < 3; ++k) { T.out[6 + k] = 0x7fffffff; T.out[9 + k] = (int)0x80000000; }
+    }
+}
+__global__ __launch_bounds__(1024) void k_map_keep_scatter(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
+    if ((int)blockIdx.x >= T.keep_blocks) return;
+    __shared__ int s_wave[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const bool in = i < T.n_map;
+    const bool keep = in && !T.deleted[i];
+    if (in) T.deleted[i] = 0;  // the flags are all zero again when the call ends (they belong to the old numbering)
+    int total;
+    const int pos = block_flag_scan(keep, s_wave, total);
+    if (keep) T.dst[T.keep_counts[blockIdx.x] + pos] = T.grid.points[i];
+}
+// dst[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added
+__global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.x];
+    if (!T.has_inc) return;
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, ng = T.out[1], nn = T.out[2], kept = T.out[4];
+    int* bbox_enc = T.out + 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < ng; b0 += 256) {
+        const int g = b0 + tid;
+        const bool f = g < ng && T.has_append[g];
+        const unsigned long long bal = __ballot(f);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int k = 0; k < 4; ++k) { off += k < wave ? s_wave[k] : 0; tot += s_wave[k]; }
+        if (f) {
+            const PointXYZINormal p = T.appended[g];
+            T.dst[kept + s_base + off + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+            atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
+            atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
+            atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    const int base = kept + T.out[5];
+    for (int k = tid; k < nn; k += 256) {
+        const PointXYZINormal p = T.world[T.noneed[k]];
+        T.dst[base + k] = p;
+        atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
+        atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
+        atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
+    }
+}
+
+// ---- dense grid (re)build: counting sort of the map points into 1 m cells -----------------------------------------------------------
+constexpr int kScanTile = 4096;  // cells per tile of the two-level prefix sum (1024 threads x 4)
+__global__ __launch_bounds__(256) void k_map_zero(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < T.n_cells; i += gridDim.x * 256) { T.counts[i] = 0; T.fill[i] = 0; }
+}
+__global__ __launch_bounds__(256) void k_map_count(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.g.n_points) return;
+    const PointXYZINormal p = T.g.points[i];
+    atomicAdd(&T.counts[map_cell(T.g, p.x, p.y, p.z)], 1);
+}
+// level 1: sums of tiles of 4096 consecutive cells (coalesced int4 loads)
+__global__ __launch_bounds__(1024) void k_map_scan_tiles(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    const int tile = blockIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
+    if (tile >= n_tiles) return;
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, base = tile * kScanTile + 4 * tid;
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += base + k < T.n_cells ? T.counts[base + k] : 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) tot += s_wave[k];
+        T.tile_sums[tile] = tot;
+    }
+}
+// level 2: exclusive scan of the tile sums (<= 1024 tiles = 4 M cells), one workgroup per map
+__global__ __launch_bounds__(1024) void k_map_scan_tops(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.x];
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
+    const int v = tid < n_tiles ? T.tile_sums[tid] : 0;
+    s_part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int u = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += u;
+        __syncthreads();
+    }
+    if (tid < n_tiles) T.tile_sums[tid] = s_part[tid] - v;
+    if (tid == 1023) T.start[T.n_cells] = s_part[1023];
+}
+// level 3: exclusive scan inside every tile + the tile's offset
+__global__ __launch_bounds__(1024) void k_map_scan_cells(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    const int tile = blockIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
+    if (tile >= n_tiles) return;
+    __shared__ int s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = tile * kScanTile + 4 * tid;
+    int c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = base + k < T.n_cells ? T.counts[base + k] : 0; sum += c[k]; }
+    int incl = sum;  // inclusive scan over the wavefront
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int off = T.tile_sums[tile];
+    for (int k = 0; k < wave; ++k) off += s_wave[k];
+    int run = off + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < T.n_cells) T.start[base + k] = run;
+        run += c[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.g.n_points) return;
+    const PointXYZINormal p = T.g.points[i];
+    const int c = map_cell(T.g, p.x, p.y, p.z);
+    const int pos = T.start[c] + atomicAdd(&T.fill[c], 1);
+    T.sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------------
+void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st) {
+    if (!n_tasks || !max_points) return;
+    TC2LI_LAUNCH(k_mapinc_classify, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
+    const size_t lds = (size_t)kMapIncMax * (sizeof(unsigned long long) + sizeof(int));
+    static bool attr = false;  // 96 KB of dynamic LDS: above the default limit of a kernel
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mapinc_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    TC2LI_LAUNCH(k_mapinc_group, dim3(n_tasks), dim3(1024), lds, st, tasks);
+    TC2LI_LAUNCH(k_mapinc_apply, dim3(kMapIncMax / 128, n_tasks), dim3(128), 0, st, tasks);
+}
+void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st) {
+    if (n && n_boxes) TC2LI_LAUNCH(k_map_mark_boxes, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, boxes, n_boxes, deleted);
+}
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
+    if (!n_tasks) return;
+    const int nb = (max_map_points + 1023) / 1024;
+    if (nb) TC2LI_LAUNCH(k_map_keep_count, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
+    if (nb) TC2LI_LAUNCH(k_map_keep_scatter, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);
+}
+void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st) {
+    if (!n_tasks) return;
+    const int tiles = (max_cells + kScanTile - 1) / kScanTile;
+    TC2LI_LAUNCH(k_map_zero, dim3(std::min((max_cells + 255) / 256, 512), n_tasks), dim3(256), 0, st, tasks);
+    if (max_points) TC2LI_LAUNCH(k_map_count, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_scan_tiles, dim3(tiles, n_tasks), dim3(1024), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_scan_tops, dim3(n_tasks), dim3(1024), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_scan_cells, dim3(tiles, n_tasks), dim3(1024), 0, st, tasks);
+    if (max_points) TC2LI_LAUNCH(k_map_scatter, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
+}
+
+}  // namespace tc2li

@@ -6,6 +6,8 @@
 // The reference lets a keypoint that received a point from an earlier neighbour drop out of the later neighbours; a pair's result
 // does not depend on any other pair, so every (neighbour, keypoint) is evaluated here and the host keeps the first success.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -296,14 +298,14 @@ __global__ __launch_bounds__(128) void k_fuse_search(FuseDev f) {
 }
 
 void launch_fuse_search(const FuseDev& f, hipStream_t st) {
-    if (f.n_points > 0) hipLaunchKernelGGL(k_fuse_search, dim3((f.n_points + 127) / 128), dim3(128), 0, st, f);
+    if (f.n_points > 0) TC2LI_LAUNCH(k_fuse_search, dim3((f.n_points + 127) / 128), dim3(128), 0, st, f);
 }
 
 void launch_tri_search(const MappingDev& m, int max_entries, hipStream_t st) {
-    if (m.n_neigh > 0 && max_entries > 0) hipLaunchKernelGGL(k_tri_search, dim3((max_entries + 255) / 256, m.n_neigh), dim3(256), 0, st, m);
+    if (m.n_neigh > 0 && max_entries > 0) TC2LI_LAUNCH(k_tri_search, dim3((max_entries + 255) / 256, m.n_neigh), dim3(256), 0, st, m);
 }
 void launch_tri_points(const MappingDev& m, hipStream_t st) {
-    if (m.n_neigh > 0 && m.cur.n > 0) hipLaunchKernelGGL(k_tri_points, dim3((m.cur.n + 127) / 128, m.n_neigh), dim3(128), 0, st, m);
+    if (m.n_neigh > 0 && m.cur.n > 0) TC2LI_LAUNCH(k_tri_points, dim3((m.cur.n + 127) / 128, m.n_neigh), dim3(128), 0, st, m);
 }
 
 }  // namespace tc2li

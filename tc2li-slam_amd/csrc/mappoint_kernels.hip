@@ -6,6 +6,8 @@
 // value range 0..256 (the smallest v with at least k + 1 entries <= v); the first row with the least median wins, as in the
 // reference's loop.  The mean viewing direction is accumulated by one lane in observation order (float, like the reference).
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(64) void k_map_points_refresh(MapPointRefresh a) {
 }
 
 void launch_map_points_refresh(const MapPointRefresh& a, int n_points, hipStream_t st) {
-    if (n_points > 0) hipLaunchKernelGGL(k_map_points_refresh, dim3(n_points), dim3(64), 0, st, a);
+    if (n_points > 0) TC2LI_LAUNCH(k_map_points_refresh, dim3(n_points), dim3(64), 0, st, a);
 }
 
 }  // namespace tc2li

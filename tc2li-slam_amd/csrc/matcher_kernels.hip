@@ -9,6 +9,8 @@
 // answer depends only on the answers of queries < q, so after round k the first k queries are final and the
 // iteration stops at the first round that changes nothing (unique fixed point = the sequential result).
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -350,22 +352,22 @@ __global__ __launch_bounds__(kThreads) void k_match_resolve(const MatchFrameDev*
 }
 
 void launch_match_grid(const MatchFrameDev* frames, int nframes, const MatchLists& L, hipStream_t st) {
-    if (nframes > 0) hipLaunchKernelGGL(k_match_grid, dim3(nframes), dim3(kThreads), 0, st, frames, L);
+    if (nframes > 0) TC2LI_LAUNCH(k_match_grid, dim3(nframes), dim3(kThreads), 0, st, frames, L);
 }
 
 void launch_match_lists(const MatchFrameDev* frames, int nframes, const int32_t* query_frame, int total_q, const MatchLists& L, int mode,
                         float nn_ratio, int32_t* match_of_query, int32_t* prev_claim, int32_t* rounds_out, hipStream_t st) {
     if (nframes <= 0) return;
     (void)hipMemsetAsync(L.pool_top, 0, 2 * sizeof(int32_t), st);
-    hipLaunchKernelGGL(k_match_grid, dim3(nframes), dim3(kThreads), 0, st, frames, L);
-    hipLaunchKernelGGL(k_match_candidates, dim3((total_q + 255) / 256), dim3(256), 0, st, frames, nframes, query_frame, total_q, L);
-    hipLaunchKernelGGL(k_match_resolve, dim3(nframes), dim3(kThreads), 0, st, frames, mode, nn_ratio, L, match_of_query, prev_claim, rounds_out);
+    TC2LI_LAUNCH(k_match_grid, dim3(nframes), dim3(kThreads), 0, st, frames, L);
+    TC2LI_LAUNCH(k_match_candidates, dim3((total_q + 255) / 256), dim3(256), 0, st, frames, nframes, query_frame, total_q, L);
+    TC2LI_LAUNCH(k_match_resolve, dim3(nframes), dim3(kThreads), 0, st, frames, mode, nn_ratio, L, match_of_query, prev_claim, rounds_out);
 }
 
 void launch_match_by_projection(const MatchFrameDev* frames, int nframes, int mode, float nn_ratio, int32_t* match_of_query,
                                 int32_t* prev_claim, int32_t* rounds_out, hipStream_t st) {
     if (nframes > 0)
-        hipLaunchKernelGGL(k_match_by_projection, dim3(nframes), dim3(kThreads), 0, st, frames, mode, nn_ratio, match_of_query, prev_claim,
+        TC2LI_LAUNCH(k_match_by_projection, dim3(nframes), dim3(kThreads), 0, st, frames, mode, nn_ratio, match_of_query, prev_claim,
                            rounds_out);
 }
 

@@ -1,6 +1,8 @@
 // gfx950 kernels of the ORB extractor (replaces the internals of SF/src/ORBextractor.cc).
 // All arithmetic is integer or explicitly rounded float, so the output is bit-identical to the CPU path.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 // Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
 // `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
 // the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st) {
     const int gx = (dst.w + 255) / 256, gy = (dst.h + 3) / 4;
-    hipLaunchKernelGGL(k_resize_linear, dim3(((gx * gy * nimg + 7) / 8) * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+    TC2LI_LAUNCH(k_resize_linear, dim3(((gx * gy * nimg + 7) / 8) * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
                        const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
 }
 
@@ -621,17 +623,17 @@ void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, in
     // cell windows are 35-px cells + 6: 48 x 48 holds all but the levels whose height leaves one or two tall rows of cells; those go
     // through the full-size variant (a third of the LDS-limited occupancy), each window class in its own launch
     if (n_small > 0)
-        hipLaunchKernelGGL((k_fast_cells<48, 48>), dim3(((n_small * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th, min_th, slab,
+        TC2LI_LAUNCH((k_fast_cells<48, 48>), dim3(((n_small * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th, min_th, slab,
                            slab_img_stride, cell_counts, ncells, nimg, small_ids, n_small);
     if (n_large > 0)
-        hipLaunchKernelGGL((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(((n_large * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th,
+        TC2LI_LAUNCH((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(((n_large * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th,
                            min_th, slab, slab_img_stride, cell_counts, ncells, nimg, large_ids, n_large);
 }
 
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
                     const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
                     int* level_counts, int nlevels, int nimg, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact_cells, dim3(nlevels, nimg), dim3(256), 0, st, cells, level_cell_begin, cell_counts,
+    TC2LI_LAUNCH(k_compact_cells, dim3(nlevels, nimg), dim3(256), 0, st, cells, level_cell_begin, cell_counts,
                        ncells, slab, slab_img_stride, dense, level_dense_off, level_counts, nlevels);
 }
 
@@ -647,13 +649,13 @@ void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, 
         total += wk.nsx[l] * wk.ncy[l] * nimg;
     }
     for (int l = nlevels; l <= kMaxLevels; ++l) wk.first_block[l] = total;
-    if (total) hipLaunchKernelGGL(k_blur7_strips, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
+    if (total) TC2LI_LAUNCH(k_blur7_strips, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
 }
 
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
                             int nkp, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st) {
     if (nkp <= 0) return;
-    hipLaunchKernelGGL(k_orient_describe, dim3((((nkp + 7) / 8 + 7) / 8) * 8), dim3(256), 0, st, raw, blurred, sc, kps, nkp, angles, desc,
+    TC2LI_LAUNCH(k_orient_describe, dim3((((nkp + 7) / 8 + 7) / 8) * 8), dim3(256), 0, st, raw, blurred, sc, kps, nkp, angles, desc,
                        mkeys, desc_dev);
 }
 

@@ -4,6 +4,8 @@
 // Edges are spread over the 256 threads; the 6x6 normal equations and the robust chi2 are reduced through LDS in a
 // fixed order (deterministic), thread 0 does the 6x6 LDL^T and the accept/reject logic and broadcasts the decision.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
 
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
 void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double* Xw, const BaEdge* edges, const CameraD& cam,
                               double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, hipStream_t st) {
     if (nprobs > 0)
-        hipLaunchKernelGGL(k_pose_optimization, dim3(nprobs), dim3(kPoThreads), 0, st, probs, Xw, edges, cam, poses7, outlier,
+        TC2LI_LAUNCH(k_pose_optimization, dim3(nprobs), dim3(kPoThreads), 0, st, probs, Xw, edges, cam, poses7, outlier,
                            chi2_scratch, inliers);
 }
 

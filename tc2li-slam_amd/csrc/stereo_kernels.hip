@@ -4,6 +4,8 @@
 // the 11x11 SAD window over +-5 px on the keypoint's pyramid level and fits the parabola.  Integer work is exact;
 // the float tail uses explicitly rounded operations so that uRight/depth equal the CPU results bit for bit.
 #include <hip/hip_runtime.h>
+
+#include "launch.hpp"
 // Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
 // `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
 // the approximate native square root -- use sqrtf(), which hipcc rounds correctly by default).
@@ -147,7 +149,7 @@ void launch_stereo_match(const LevelTable& left, const LevelTable& right, const 
                          float* u_right, float* depth, int* best_sad, hipStream_t st) {
     if (nframes <= 0 || max_left <= 0) return;
     const int gx = (max_left + kLeftPerBlock - 1) / kLeftPerBlock;
-    hipLaunchKernelGGL(k_stereo_match, dim3((gx * nframes + 7) / 8 * 8), dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
+    TC2LI_LAUNCH(k_stereo_match, dim3((gx * nframes + 7) / 8 * 8), dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
                        depth, best_sad, gx, nframes);
 }
 

@@ -42,6 +42,21 @@ def max_elapsed(dist, elapsed, device="cpu"):
     return float(t.item())
 
 
+def sum_int(dist, value, device="cpu"):
+    """SUM over ranks of an integer (units owned, ranks present)."""
+    if dist is None:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], device=device, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def count_ranks(dist, device="cpu"):
+    """How many ranks took part in the collective (what the bench line reports as ranks_seen)."""
+    return sum_int(dist, 1, device)
+
+
 def job_throughput(units_per_rank_per_step, steps, world, elapsed_max):
     """Whole-job units/s: every rank processed units_per_rank_per_step * steps units in at most elapsed_max seconds."""
     return units_per_rank_per_step * steps * world / elapsed_max

@@ -188,6 +188,39 @@ def lidar_scan(scene, frame=0, max_range=100.0, noise=0.02):
     return out
 
 
+def lidar_map(scene, x_from=-700.0, x_to=300.0, voxel=0.5, seed=0):
+    """The accumulated LiDAR map of a drive along the street of `scene`, as map_incremental leaves it: one point per `voxel`-sized cell
+    (LidarFrontEnd.cpp:387-435 keeps the point nearest the cell centre) on the ground, the two side walls and the box faces between
+    x_from and x_to in the LiDAR world frame (x forward, y left, z up), each jittered inside its cell plus the range noise.  The reference
+    holds 10^5 - 10^6 such points; 1000 m of street gives about 1.9 * 10^5."""
+    rng = np.random.default_rng([SEED0 + scene.seed, 991, seed])
+    parts = []
+
+    def lattice(a0, a1, b0, b1):
+        a = np.arange(np.floor(a0 / voxel), np.ceil(a1 / voxel)) * voxel
+        b = np.arange(np.floor(b0 / voxel), np.ceil(b1 / voxel)) * voxel
+        A, B = np.meshgrid(a, b, indexing="ij")
+        A = A.reshape(-1) + rng.uniform(0.05, voxel - 0.05, A.size)
+        B = B.reshape(-1) + rng.uniform(0.05, voxel - 0.05, B.size)
+        return A, B
+
+    gx, gy = lattice(x_from, x_to, -15.0, 15.0)  # ground z = -CAM_HEIGHT
+    parts.append(np.stack([gx, gy, np.full(gx.size, -CAM_HEIGHT) + rng.normal(0, 0.02, gx.size)], 1))
+    for wy in (-15.0, 15.0):                      # side walls, 6 m high
+        wx, wz = lattice(x_from, x_to, -CAM_HEIGHT, 6.0)
+        parts.append(np.stack([wx, np.full(wx.size, wy) + rng.normal(0, 0.02, wx.size), wz], 1))
+    for x0, x1, y0, y1, zb in scene.boxes:        # box faces: plane x = zb, y in [-x1, -x0], z in [-y1, -y0]
+        if not (x_from <= zb <= x_to):
+            continue
+        by, bz = lattice(-x1, -x0, -y1, -y0)
+        parts.append(np.stack([np.full(by.size, zb) + rng.normal(0, 0.02, by.size), by, bz], 1))
+    xyz = np.concatenate(parts).astype(np.float32)
+    out = np.zeros(len(xyz), POINT_DTYPE)
+    out["x"], out["y"], out["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    out["pad0"] = 1.0
+    return out[rng.permutation(len(out))]
+
+
 def lidar_state(frame):
     """state_point of LidarFrontEnd.cpp (rot, pos of the body in the LiDAR world frame; identity LiDAR-IMU offset)
     as four float64 arrays: rot[9] (row-major), pos[3], offset_R_L_I[9], offset_T_L_I[3]."""

@@ -88,3 +88,48 @@ def test_landmark_partition_of_a_sharded_window_over_gloo():
     assert out[0][1] + out[1][1] == n_edges
     assert out[0][2] and out[1][2] and out[0][3] and out[1][3] and out[0][4] and out[1][4]
     assert out[0][1] > 0 and out[1][1] > 0
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_spawns_its_ranks_world_2_gloo():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two ranks itself (fresh child processes, rendezvous on 127.0.0.1);
+    --rehearse runs the rank protocol without device work: the line must say 2 GPUs / 2 ranks seen, and the strong-scaling list of 11
+    sequences must be dealt completely (6 + 5)."""
+    import json
+    r = _bench("--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--sequences", "11")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["sequences_total"] == 11 and line["config"]["sequences_of_rank0"] == 6
+    assert line["steps"] == 3 and line["value"] > 0
+
+
+def test_bench_weak_scaling_line_under_torchrun_env():
+    """The driver's launch: RANK / WORLD_SIZE already set by torch.distributed.run -> no spawning, world 1 here."""
+    import json
+    r = _bench("--gpus", "1", "--rehearse", "--scaling", "weak", "--frames", "7", "--steps", "2",
+               env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode == 0, r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["config"]["sequences_total"] == 7
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """On a node with fewer GPUs than --gpus the bench fails loudly instead of printing n_gpus: 1."""
+    r = _bench("--gpus", "2", "--steps", "1", env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_bench_world_size_must_match_gpus():
+    r = _bench("--gpus", "1", "--rehearse", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -86,3 +86,79 @@ def test_delete_point_boxes_and_fov_segment(pkg, oracle, setup):
         lm7, want_boxes = oracle.fov_segment(lm7, pos, 200.0, 100.0 / 3)
         assert np.array_equal(got, want_boxes)
         assert np.array_equal(np.array(lm.vertex_min), lm7[:3]) and np.array_equal(np.array(lm.vertex_max), lm7[3:6])
+
+
+def test_map_incremental_batch_equals_one_map_at_a_time(pkg, oracle, synthetic):
+    """tc2li_lidar_map_incremental_batch (one launch per phase for all maps) leaves every map exactly as the per-map call and as the
+    oracle do; the batch holds maps of different sizes, a scan slot that is not part of the batch and an empty scan."""
+    S = 4
+    fe = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=S)
+    one = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=1)
+    import torch
+    scene = synthetic.Scene(2)
+    raws = [synthetic.lidar_scan(scene, f) for f in range(1, S + 1)]
+    raws[2] = raws[2][:0]  # an empty scan: its map must stay untouched
+    states = np.stack([pkg.pack_lidar_state(*synthetic.lidar_state(f)[:2]) for f in range(1, S + 1)])
+    street = synthetic.lidar_map(scene, x_from=-60.0, x_to=90.0)
+    inits = [street, street[: len(street) // 3], street[::2], street[5::7]]
+    maps = [pkg.LidarMap() for _ in range(S)]
+    for m, p in zip(maps, inits):
+        m.Build(p)
+    raw = np.concatenate(raws)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int32)
+    dev = torch.from_numpy(raw.view(np.uint8)).cuda()
+    counts, _, _ = fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    upd = states.copy(); upd[:, 9:12] += [0.02, -0.01, 0.005]
+    sel = [0, 2, 3]  # slot 1 is left out of the batch
+    na, nn, sz = pkg.capi.map_incremental_batch(fe, sel, [maps[s] for s in sel], upd[sel])
+    for k, s in enumerate(sel):
+        down = oracle.voxel_grid(oracle.lidar_preprocess(raws[s])) if len(raws[s]) else np.zeros(0, oracle.POINT_DTYPE)
+        assert counts[1][s] == len(down)
+        if len(down) == 0:
+            assert (na[k], nn[k], sz[k]) == (0, 0, len(inits[s])) and np.array_equal(canon(maps[s].points()), canon(inits[s]))
+            continue
+        want, wa, wn = oracle.map_incremental(inits[s], down, states[s], upd[s])
+        assert (na[k], nn[k], sz[k]) == (wa, wn, len(want)) and wa > 50
+        assert np.array_equal(canon(maps[s].points()), canon(want))
+        # ... and the per-map entry point gives the same
+        m1 = pkg.LidarMap(); m1.Build(inits[s])
+        one.feature_extraction(m1, down, states[s])
+        n1, a1, b1 = m1.map_incremental(one, 0, upd[s])
+        assert (n1, a1, b1) == (sz[k], na[k], nn[k]) and np.array_equal(canon(m1.points()), canon(maps[s].points()))
+    assert np.array_equal(canon(maps[1].points()), canon(inits[1]))
+    # a second frame against the grown maps: the rebuilt grids answer like fresh ones
+    counts2, _, _ = fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    fresh = [pkg.LidarMap() for _ in range(S)]
+    for f, m in zip(fresh, maps):
+        f.Build(m.points())
+    counts3, _, _ = fe.frontend_batch(dev.data_ptr(), offs, fresh, states, want_points=False)
+    assert np.array_equal(counts2, counts3)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.map_incremental_batch(fe, [0, 1], [maps[0], maps[0]], upd[:2])  # a map twice in one batch
+
+
+def test_reference_sized_map(pkg, oracle, synthetic):
+    """the reference's map holds 10^5 - 10^6 points.  Feature extraction and map_incremental against the
+    ~1.9 * 10^5-point street map bench.py uses: identical neighbours, selection and inserted points as the oracle's k-d tree."""
+    scene = synthetic.Scene(1)
+    street = synthetic.lidar_map(scene)
+    assert len(street) > 150000
+    fe = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=1)
+    m = pkg.LidarMap(); m.Build(street)
+    tree = oracle.KdTree(street)
+    ref = street
+    for f in (3, 4):
+        down = oracle.voxel_grid(oracle.lidar_preprocess(synthetic.lidar_scan(scene, f)))
+        st = pkg.pack_lidar_state(*synthetic.lidar_state(f)[:2])
+        got = fe.feature_extraction(m, down, st)
+        want = oracle.feature_extraction(tree, down, st)
+        assert np.array_equal(got["selected"], want["selected"]) and got["selected"].sum() > 2000
+        assert np.array_equal(got["nfound"], want["nfound"])
+        assert np.array_equal(got["nearest"], want["nearest"])
+        assert np.array_equal(got["normvec"][got["selected"] > 0], want["normvec"][want["selected"] > 0])
+        n, na, nn = m.map_incremental(fe, 0, st)
+        ref2, wa, wn = oracle.map_incremental(ref, down, st, st)
+        assert (n, na, nn) == (len(ref2), wa, wn)
+        assert np.array_equal(canon(m.points()), canon(ref2))
+        ref = ref2
+        tree = oracle.KdTree(ref)

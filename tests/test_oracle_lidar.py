@@ -126,3 +126,46 @@ def test_feature_extraction(oracle, synthetic, scans):
     assert np.all(fe["nfound"] == 5)
     # the ground dominates: many normals are close to +-z
     assert (np.abs(nv["z"]) > 0.95).mean() > 0.3
+
+
+def test_tree_map_operations_equal_the_point_list(oracle, synthetic):
+    """The CPU baseline keeps its map in the k-d tree (Add_Points with down-sampling and box deletion as lazily flagged nodes, the way
+    ikd-Tree does it, ikd_Tree.cpp:478-584,779-860) -- the same operations on the plain point list are the statement the GPU map
+    maintenance is tested against, so the two must leave the same multiset of points."""
+    rng = np.random.default_rng(5)
+    base = np.zeros(4000, oracle.POINT_DTYPE)
+    base["x"], base["y"], base["z"] = rng.uniform(-10, 10, 4000), rng.uniform(-10, 10, 4000), rng.uniform(-1, 1, 4000)
+    tree = oracle.KdTree(base)
+    lst = base.copy()
+    for step in range(4):
+        add = np.zeros(1500, oracle.POINT_DTYPE)
+        add["x"], add["y"], add["z"] = rng.uniform(-12, 12, 1500), rng.uniform(-12, 12, 1500), rng.uniform(-1, 1, 1500)
+        add["intensity"] = step
+        oracle.kdtree_add_points(tree, add, downsample=True, size=0.5)
+        lst = oracle.mappoints_add(lst, add, downsample=True, size=0.5)
+        plain = add[:100].copy(); plain["x"] += 30
+        oracle.kdtree_add_points(tree, plain, downsample=False)
+        lst = oracle.mappoints_add(lst, plain, downsample=False)
+        box = np.array([[-3 + step, -3, -1, 0 + step, 2, 1]], np.float32)
+        n_del = oracle.kdtree_delete_boxes(tree, box)
+        lst2 = oracle.map_delete_boxes(lst, box)
+        assert n_del == len(lst) - len(lst2) and n_del > 0
+        lst = lst2
+        got = oracle.kdtree_valid_points(tree)
+        assert len(got) == len(lst)
+        key = lambda a: np.lexsort((a["intensity"], a["z"], a["y"], a["x"]))
+        assert np.array_equal(got[key(got)], lst[key(lst)])
+    # the search skips the flagged points: same neighbours as a tree built from the surviving points
+    q = np.zeros(300, oracle.POINT_DTYPE)
+    q["x"], q["y"], q["z"] = rng.uniform(-12, 12, 300), rng.uniform(-12, 12, 300), rng.uniform(-1, 1, 300)
+    fresh = oracle.KdTree(lst)
+    a, b = tree.knn(q), fresh.knn(q)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_synthetic_street_map_is_reference_sized(synthetic):
+    m = synthetic.lidar_map(synthetic.Scene(0))
+    assert 1e5 < len(m) < 1e6
+    # one point per 0.5 m cell
+    cells = np.floor(np.stack([m["x"], m["y"], m["z"]], 1) / 0.5).astype(np.int64)
+    assert len(np.unique(cells, axis=0)) > 0.97 * len(m)

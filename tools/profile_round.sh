@@ -1,19 +1,23 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel trace + stats of the default bench command, then the HBM counters of the same
 # command in two separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no trace domains next to --pmc).
-# Usage (from the repo root, through gpurun): bash tools/profile_round.sh r01
+# Usage (from the repo root, through gpurun): bash tools/profile_round.sh r02 [extra bench flags]
 # The summaries land in gpurun_out/profiles_<tag>/ (gpurun only brings gpurun_out/ back): copy them into profiles/ afterwards.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="bench.py --no-cpu-baseline --steps 8 --warmup 2"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $ARGS > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $ARGS > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python $ARGS > $OUT/bench_write.log 2>&1
+# Build BEFORE any rocprofv3 line: under the profiler's preload a child process (make -> sh -> hipcc) would be an exec from a process
+# that has initialised the GPU.  bench.py --no-build then fails instead of building, and the command after `--` stays one interpreter.
+python __graft_entry__.py
+ARGS="bench.py --no-build --no-cpu-baseline --steps 8 --warmup 2 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_write.log 2>&1
 # matrix-unit occupancy of the Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python $ARGS > $OUT/bench_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_mfma.log 2>&1
 python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
