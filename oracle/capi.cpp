@@ -1127,6 +1127,36 @@ int oracle_local_inertial_ba(double* kf33, const uint8_t* fixed, const uint8_t* 
     for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
     return r.iterations;
 }
+// Optimizer::PoseInertialOptimizationLastKeyFrame (last_frame = 0) / LastFrame (1).  cur33 / other33: one kf33 record each (in/out);
+// prior246: ConstraintPoseImu of the previous frame = Rwb 9, twb 3, vwb 3, bg 3, ba 3, H 225 (NULL for the keyframe form);
+// edges6[e] = (index into Xw, unused, u, v, uR, invSigma2); prior_out246: the frame's new mpcpi; stats3: n_initial, n_bad, n_inliers.
+// Returns nInitialCorrespondences - nBad.
+int oracle_pose_inertial(double* cur33, double* other33, int last_frame, const double* prior246, const double* calib24, const float* pre298,
+                         const float* pre_rw298, const double* Xw, const double* edges6, int n_edges, const uint8_t* close, const double* cam5,
+                         int rec_init, uint8_t* outlier, double* prior_out246, int* stats3) {
+    InertialKeyFrame cur = kf_from(cur33, 0, 1), other = kf_from(other33, last_frame ? 0 : 1, 1);
+    PoseImuPrior prior;
+    if (prior246) {
+        std::memcpy(prior.Rwb, prior246, 72); std::memcpy(prior.twb, prior246 + 9, 24); std::memcpy(prior.vwb, prior246 + 12, 24);
+        std::memcpy(prior.bg, prior246 + 15, 24); std::memcpy(prior.ba, prior246 + 18, 24); std::memcpy(prior.H, prior246 + 21, 225 * sizeof(double));
+    }
+    const Preintegrated pint = preint_from(pre298), pint_rw = preint_from(pre_rw298);
+    int max_pt = -1;
+    const std::vector<BAEdge> edges = edges_from(edges6, n_edges);
+    for (const BAEdge& e : edges) max_pt = std::max(max_pt, e.point);
+    const std::vector<double> X(Xw, Xw + 3 * (size_t)(max_pt + 1));
+    Camera cam{cam5[0], cam5[1], cam5[2], cam5[3], cam5[4]};
+    const PoseInertialResult r = PoseInertialOptimization(cur, other, last_frame != 0, prior246 ? &prior : nullptr, calib_from(calib24), pint, pint_rw, X, edges,
+                                                          std::vector<uint8_t>(close, close + n_edges), cam, rec_init != 0);
+    kf_to(cur, cur33); kf_to(other, other33);
+    for (int e = 0; e < n_edges; ++e) outlier[e] = r.outlier[e];
+    if (prior_out246) {
+        std::memcpy(prior_out246, r.prior.Rwb, 72); std::memcpy(prior_out246 + 9, r.prior.twb, 24); std::memcpy(prior_out246 + 12, r.prior.vwb, 24);
+        std::memcpy(prior_out246 + 15, r.prior.bg, 24); std::memcpy(prior_out246 + 18, r.prior.ba, 24); std::memcpy(prior_out246 + 21, r.prior.H, 225 * sizeof(double));
+    }
+    if (stats3) { stats3[0] = r.n_initial; stats3[1] = r.n_bad; stats3[2] = r.n_inliers; }
+    return r.n_initial - r.n_bad;
+}
 // OptimizerWithLidar::LocalLVIBA: the same with EdgeLidar over the keyframes win_kf (rows of kf33)
 int oracle_local_lviba(double* kf33, const uint8_t* fixed, const uint8_t* has_imu, int n_kf, const double* calib24, double* points3,
                        int n_points, const double* edges6, int n_edges, const double* link4, const float* pre298, int n_links,

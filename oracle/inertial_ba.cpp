@@ -530,4 +530,296 @@ InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCa
     return res;
 }
 
+
+// ---- PoseInertialOptimizationLastKeyFrame / LastFrame -----------------------------------------------------------------------------------
+namespace {
+// EdgeInertial ctor (G2oTypes.cc:499-515): inverse of C(0:9, 0:9), symmetrised, eigenvalues below 1e-12 cleared
+void edge_inertial_information(const Preintegrated& p, std::vector<double>& info) {
+    std::vector<double> C9(81), inv, w, V;
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C9[9 * r + c] = p.C[15 * r + c];
+    invert(C9, 9, inv);
+    for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) { const double m = (inv[9 * r + c] + inv[9 * c + r]) / 2; inv[9 * r + c] = inv[9 * c + r] = m; }
+    eig_sym(inv, 9, w, V);
+    for (double& x : w) if (x < 1e-12) x = 0;
+    info.assign(81, 0.0);
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) { double s = 0; for (int k = 0; k < 9; ++k) s += V[9 * r + k] * w[k] * V[9 * c + k]; info[9 * r + c] = s; }
+}
+// ConstraintPoseImu ctor (G2oTypes.h:721-732)
+void constraint_clamp(double H[225]) {
+    std::vector<double> A(H, H + 225), w, V;
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) A[15 * r + c] = (H[15 * r + c] + H[15 * r + c]) / 2;  // "(H + H) / 2", as written
+    eig_sym(A, 15, w, V);
+    for (double& x : w) if (x < 1e-12) x = 0;
+    for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) { double s = 0; for (int k = 0; k < 15; ++k) s += V[15 * r + k] * w[k] * V[15 * c + k]; H[15 * r + c] = s; }
+}
+}  // namespace
+
+PoseInertialResult PoseInertialOptimization(InertialKeyFrame& cur, InertialKeyFrame& other, bool last_frame, const PoseImuPrior* prior_prev,
+                                            const ImuCalibD& cal, const Preintegrated& pint, const Preintegrated& pint_rw,
+                                            const std::vector<double>& Xw, const std::vector<BAEdge>& edges, const std::vector<uint8_t>& close,
+                                            const Camera& cam, bool bRecInit) {
+    const int E = (int)edges.size();
+    PoseInertialResult res;
+    res.outlier.assign(E, 0);
+    res.n_initial = E;
+    // unknowns: the frame's pose 6, velocity 3, gyro bias 3, accelerometer bias 3 (vertex ids 0..3), then the previous frame's (ids 4..7)
+    const int n = last_frame ? 30 : 15;
+    std::vector<double> infoI, infoG, infoA;
+    edge_inertial_information(pint, infoI);
+    {
+        std::vector<double> G(9), A(9);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { G[3 * r + c] = pint_rw.C[15 * (9 + r) + 9 + c]; A[3 * r + c] = pint_rw.C[15 * (12 + r) + 12 + c]; }
+        invert(G, 3, infoG); invert(A, 3, infoA);
+    }
+    const HuberD hub_mono((float)std::sqrt(5.991)), hub_stereo((float)std::sqrt(7.815)), hub_prior(5.0f);
+    std::vector<uint8_t> level(E, 0), robust(E, 1);
+    std::vector<double> err(3 * (size_t)E), chi2(E, 0.0);
+    int its_cur = 0, its_other = 0;
+    auto visual_error = [&](int e, double* A, double* B) {
+        const int dim = inertial_visual_edge(cur, cal, &Xw[3 * edges[e].point], edges[e], cam, &err[3 * e], A, B);
+        double s = 0;
+        for (int d = 0; d < dim; ++d) s += err[3 * e + d] * edges[e].info * err[3 * e + d];
+        chi2[e] = s;
+        return dim;
+    };
+    // EdgePriorPoseImu (G2oTypes.cc:738-767): error 15, Jacobian 15 x 15 (block diagonal), information = prior H
+    auto prior_edge = [&](double e15[15], double J[225]) {
+        double Rt[9], dR[9], er[3], dt[3], et[3];
+        tr(prior_prev->Rwb, Rt);
+        mul(Rt, other.Rwb, dR);
+        LogSO3(dR, er);
+        for (int k = 0; k < 3; ++k) dt[k] = other.twb[k] - prior_prev->twb[k];
+        mulv(Rt, dt, et);
+        for (int k = 0; k < 3; ++k) { e15[k] = er[k]; e15[3 + k] = et[k]; e15[6 + k] = other.v[k] - prior_prev->vwb[k]; e15[9 + k] = other.bg[k] - prior_prev->bg[k]; e15[12 + k] = other.ba[k] - prior_prev->ba[k]; }
+        if (!J) return;
+        std::memset(J, 0, 225 * sizeof(double));
+        double iJr[9];
+        inv_right_jacobian(er, iJr);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { J[15 * r + c] = iJr[3 * r + c]; J[15 * (3 + r) + 3 + c] = dR[3 * r + c]; }
+        for (int k = 6; k < 15; ++k) J[15 * k + k] = 1.0;
+    };
+    std::vector<double> H((size_t)n * n), b(n), x(n, 0.0);
+    const float chi2Mono_kf[4] = {12, 7.5, 5.991, 5.991}, chi2Mono_f[4] = {5.991, 5.991, 5.991, 5.991}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    const int n_graph_edges = E + 3 + (last_frame ? 1 : 0);
+    int nBad = 0, nInliers = 0;
+    for (int round = 0; round < 4; ++round) {
+        bool ok = true;
+        for (int it = 0; it < 10 && ok; ++it) {
+            std::fill(H.begin(), H.end(), 0.0);
+            std::fill(b.begin(), b.end(), 0.0);
+            // visual edges of level 0 -> pose block of the frame
+            for (int e = 0; e < E; ++e) {
+                if (level[e]) continue;
+                double A[9], B[18];
+                const int dim = visual_error(e, A, B);
+                double r0 = chi2[e], r1 = 1.0;
+                if (robust[e]) (dim == 3 ? hub_stereo : hub_mono).rho(chi2[e], r0, r1);
+                const double w = edges[e].info;
+                for (int i = 0; i < 6; ++i) {
+                    double g = 0;
+                    for (int d = 0; d < dim; ++d) g += B[6 * d + i] * w * err[3 * e + d];
+                    b[i] -= r1 * g;
+                    for (int j = 0; j < 6; ++j) {
+                        double h = 0;
+                        for (int d = 0; d < dim; ++d) h += B[6 * d + i] * (r1 * w) * B[6 * d + j];
+                        H[(size_t)i * n + j] += h;
+                    }
+                }
+            }
+            // EdgeInertial: vertices (other P, V, G, A | cur P, V); columns of J: P1 6 | V1 3 | G1 3 | A1 3 | P2 6 | V2 3
+            {
+                double e9[9], J[9 * 24];
+                inertial_edge(other, cur, pint, e9, J);
+                int col[24];
+                for (int k = 0; k < 15; ++k) col[k] = last_frame ? 15 + k : -1;  // the other state: free only in the last-frame form
+                for (int k = 0; k < 9; ++k) col[15 + k] = k;                     // the frame's pose and velocity
+                double Oe[9];
+                for (int r = 0; r < 9; ++r) { double s = 0; for (int c = 0; c < 9; ++c) s += infoI[9 * r + c] * e9[c]; Oe[r] = s; }
+                for (int i = 0; i < 24; ++i) {
+                    if (col[i] < 0) continue;
+                    double g = 0;
+                    for (int r = 0; r < 9; ++r) g += J[24 * r + i] * Oe[r];
+                    b[col[i]] -= g;
+                    for (int j = 0; j < 24; ++j) {
+                        if (col[j] < 0) continue;
+                        double h = 0;
+                        for (int r = 0; r < 9; ++r) { double t = 0; for (int c = 0; c < 9; ++c) t += infoI[9 * r + c] * J[24 * c + j]; h += J[24 * r + i] * t; }
+                        H[(size_t)col[i] * n + col[j]] += h;
+                    }
+                }
+            }
+            // EdgeGyroRW / EdgeAccRW: error = cur - other, Jacobians -I (other) and +I (cur)
+            for (int which = 0; which < 2; ++which) {
+                const std::vector<double>& info = which ? infoA : infoG;
+                const double* c2 = which ? cur.ba : cur.bg;
+                const double* c1 = which ? other.ba : other.bg;
+                const int ic = which ? 12 : 9, io = last_frame ? 15 + ic : -1;
+                double e3[3], Oe[3];
+                for (int k = 0; k < 3; ++k) e3[k] = c2[k] - c1[k];
+                for (int r = 0; r < 3; ++r) Oe[r] = info[3 * r] * e3[0] + info[3 * r + 1] * e3[1] + info[3 * r + 2] * e3[2];
+                for (int r = 0; r < 3; ++r) {
+                    b[ic + r] -= Oe[r];
+                    if (io >= 0) b[io + r] += Oe[r];
+                    for (int c = 0; c < 3; ++c) {
+                        H[(size_t)(ic + r) * n + ic + c] += info[3 * r + c];
+                        if (io >= 0) {
+                            H[(size_t)(io + r) * n + io + c] += info[3 * r + c];
+                            H[(size_t)(ic + r) * n + io + c] -= info[3 * r + c];
+                            H[(size_t)(io + r) * n + ic + c] -= info[3 * r + c];
+                        }
+                    }
+                }
+            }
+            // EdgePriorPoseImu on the previous frame (Huber 5)
+            if (last_frame) {
+                double e15[15], J[225], Oe[15];
+                prior_edge(e15, J);
+                double c = 0;
+                for (int r = 0; r < 15; ++r) { double s = 0; for (int k = 0; k < 15; ++k) s += prior_prev->H[15 * r + k] * e15[k]; Oe[r] = s; c += e15[r] * s; }
+                double r0, r1;
+                hub_prior.rho(c, r0, r1);
+                for (int i = 0; i < 15; ++i) {
+                    double g = 0;
+                    for (int r = 0; r < 15; ++r) g += J[15 * r + i] * Oe[r];
+                    b[15 + i] -= r1 * g;
+                    for (int j = 0; j < 15; ++j) {
+                        double h = 0;
+                        for (int r = 0; r < 15; ++r) { double t = 0; for (int k = 0; k < 15; ++k) t += prior_prev->H[15 * r + k] * J[15 * k + j]; h += J[15 * r + i] * t; }
+                        H[(size_t)(15 + i) * n + 15 + j] += r1 * h;
+                    }
+                }
+            }
+            // LinearSolverDense: LDLT, usable only when no pivot is negative (Eigen::LDLT::isPositive)
+            std::vector<double> Hw = H;
+            std::vector<double> xn(n);
+            bool pos = ldlt(Hw, n, b.data(), xn.data());
+            if (pos) {  // the sign of D: recompute the pivots (ldlt() leaves the unit lower factor in Hw, D is not kept)
+                std::vector<double> D(n);
+                for (int j = 0; j < n && pos; ++j) {
+                    double d = H[(size_t)j * n + j];
+                    for (int k = 0; k < j; ++k) d -= Hw[(size_t)j * n + k] * Hw[(size_t)j * n + k] * D[k];
+                    D[j] = d;
+                    if (d < 0) pos = false;
+                }
+            }
+            if (pos) x = xn; else { ok = false; res.solver_failed = true; }
+            // SparseOptimizer::update: the increment is applied whether or not the solve succeeded (GaussNewton::solve :84-91)
+            imu_pose_update(cur, its_cur, cal, &x[0]);
+            for (int k = 0; k < 3; ++k) { cur.v[k] += x[6 + k]; cur.bg[k] += x[9 + k]; cur.ba[k] += x[12 + k]; }
+            if (last_frame) {
+                imu_pose_update(other, its_other, cal, &x[15]);
+                for (int k = 0; k < 3; ++k) { other.v[k] += x[21 + k]; other.bg[k] += x[24 + k]; other.ba[k] += x[27 + k]; }
+            }
+        }
+        // Classification.  e->chi2() reads the error stored by the LAST computeActiveErrors(), which Gauss-Newton runs at the start of
+        // an iteration: for the edges that were active that is the estimate BEFORE the round's last update; only the edges that were
+        // outliers are recomputed, at the final estimate (:2680-2683, :3097-3100).
+        nBad = 0; nInliers = 0;
+        const float* chiM = last_frame ? chi2Mono_f : chi2Mono_kf;
+        const float chi2close = 1.5f * chiM[round];
+        for (int e = 0; e < E; ++e) {
+            const bool stereo = edges[e].obs[2] >= 0;
+            if (res.outlier[e]) { double A[9], B[18]; visual_error(e, A, B); }
+            const float c = (float)chi2[e];
+            bool bad;
+            if (stereo) {
+                bad = c > chi2Stereo[round];
+            } else {
+                double Xc[3];
+                mulv(cur.Rcw, &Xw[3 * edges[e].point], Xc);
+                const bool depth_pos = Xc[2] + cur.tcw[2] > 0.0;
+                bad = (c > chiM[round] && !close[e]) || (close[e] && c > chi2close) || !depth_pos;
+            }
+            res.outlier[e] = bad;
+            level[e] = bad;
+            if (bad) ++nBad; else ++nInliers;
+            if (round == 2) robust[e] = 0;
+        }
+        if (n_graph_edges < 10) break;
+    }
+    // "If not too much tracks, recover not too bad points" (:2738-2765, :3160-3188)
+    if (nInliers < 30 && !bRecInit) {
+        nBad = 0;
+        for (int pass = 0; pass < 2; ++pass)  // monocular edges first, then the stereo ones (the order only matters for nBad's sum)
+            for (int e = 0; e < E; ++e) {
+                const bool stereo = edges[e].obs[2] >= 0;
+                if (stereo != (pass == 1)) continue;
+                double A[9], B[18];
+                visual_error(e, A, B);
+                if ((float)chi2[e] < (stereo ? 24.f : 18.f)) res.outlier[e] = 0; else ++nBad;
+            }
+    }
+    res.n_bad = nBad;
+    res.n_inliers = nInliers;
+    // ---- the new prior: Hessian at the final estimate (GetHessian* call linearizeOplus(), no robust weights) ----
+    double e9[9], J[9 * 24];
+    inertial_edge(other, cur, pint, e9, J);
+    auto JtOJ = [&](const double* Jm, int rows, int cols, const double* Om, std::vector<double>& out) {  // out[cols x cols] = J^T Omega J
+        out.assign((size_t)cols * cols, 0.0);
+        for (int i = 0; i < cols; ++i)
+            for (int j = 0; j < cols; ++j) {
+                double h = 0;
+                for (int r = 0; r < rows; ++r) { double t = 0; for (int c = 0; c < rows; ++c) t += Om[rows * r + c] * Jm[cols * c + j]; h += Jm[cols * r + i] * t; }
+                out[(size_t)i * cols + j] = h;
+            }
+    };
+    std::vector<double> Hv(36, 0.0);  // inlier visual edges: sum of B^T Omega B
+    for (int e = 0; e < E; ++e) {
+        if (res.outlier[e]) continue;
+        double A[9], B[18], ebuf[3];
+        const int dim = inertial_visual_edge(cur, cal, &Xw[3 * edges[e].point], edges[e], cam, ebuf, A, B);
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) { double h = 0; for (int d = 0; d < dim; ++d) h += B[6 * d + i] * edges[e].info * B[6 * d + j]; Hv[6 * i + j] += h; }
+    }
+    double Hn[225];
+    std::memset(Hn, 0, sizeof(Hn));
+    if (!last_frame) {
+        // H(0:9, 0:9) += ei->GetHessian2() (pose and velocity of the frame), H(9:12) += InfoG, H(12:15) += InfoA, pose block += visual
+        double J2[9 * 9];
+        for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) J2[9 * r + c] = J[24 * r + 15 + c];
+        std::vector<double> H2;
+        JtOJ(J2, 9, 9, infoI.data(), H2);
+        for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) Hn[15 * r + c] += H2[9 * r + c];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Hn[15 * (9 + r) + 9 + c] += infoG[3 * r + c]; Hn[15 * (12 + r) + 12 + c] += infoA[3 * r + c]; }
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) Hn[15 * r + c] += Hv[6 * r + c];
+    } else {
+        // 30 x 30: [previous frame P V G A | frame P V G A] (:3200-3262), then Marginalize(H, 0, 14)
+        std::vector<double> H30(900, 0.0), H24;
+        JtOJ(J, 9, 24, infoI.data(), H24);
+        for (int r = 0; r < 24; ++r) for (int c = 0; c < 24; ++c) H30[30 * r + c] += H24[24 * r + c];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                const double g = infoG[3 * r + c], a = infoA[3 * r + c];  // J = [-I, I]: blocks +, -, -, +
+                H30[30 * (9 + r) + 9 + c] += g; H30[30 * (9 + r) + 24 + c] -= g; H30[30 * (24 + r) + 9 + c] -= g; H30[30 * (24 + r) + 24 + c] += g;
+                H30[30 * (12 + r) + 12 + c] += a; H30[30 * (12 + r) + 27 + c] -= a; H30[30 * (27 + r) + 12 + c] -= a; H30[30 * (27 + r) + 27 + c] += a;
+            }
+        double e15[15], Jp[225];
+        prior_edge(e15, Jp);
+        std::vector<double> Hp;
+        JtOJ(Jp, 15, 15, prior_prev->H, Hp);
+        for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) H30[30 * r + c] += Hp[15 * r + c];
+        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H30[30 * (15 + r) + 15 + c] += Hv[6 * r + c];
+        // Marginalize(H, 0, 14): c* = c - cb pinv(b) bc with b = H(0:15, 0:15); pinv through the SVD, singular values <= 1e-6 dropped.
+        // b is symmetric: its SVD is the eigen decomposition (singular value = |eigenvalue|, U = V sign).
+        std::vector<double> Bm(225), w, V;
+        for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) Bm[15 * r + c] = H30[30 * r + c];
+        eig_sym(Bm, 15, w, V);
+        std::vector<double> pinv(225, 0.0);
+        for (int k = 0; k < 15; ++k) {
+            if (!(std::fabs(w[k]) > 1e-6)) continue;
+            const double iw = 1.0 / w[k];
+            for (int r = 0; r < 15; ++r) for (int c = 0; c < 15; ++c) pinv[15 * r + c] += V[15 * r + k] * iw * V[15 * c + k];
+        }
+        for (int r = 0; r < 15; ++r)
+            for (int c = 0; c < 15; ++c) {
+                double s = 0;
+                for (int i = 0; i < 15; ++i) { double t = 0; for (int j = 0; j < 15; ++j) t += pinv[15 * i + j] * H30[30 * j + 15 + c]; s += H30[30 * (15 + r) + i] * t; }
+                Hn[15 * r + c] = H30[30 * (15 + r) + 15 + c] - s;
+            }
+    }
+    constraint_clamp(Hn);
+    std::memcpy(res.prior.Rwb, cur.Rwb, 72); std::memcpy(res.prior.twb, cur.twb, 24); std::memcpy(res.prior.vwb, cur.v, 24);
+    std::memcpy(res.prior.bg, cur.bg, 24); std::memcpy(res.prior.ba, cur.ba, 24); std::memcpy(res.prior.H, Hn, sizeof(Hn));
+    return res;
+}
+
 }  // namespace oracle

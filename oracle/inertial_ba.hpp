@@ -53,6 +53,32 @@ InertialBAResult LocalInertialBA(std::vector<InertialKeyFrame>& kfs, const ImuCa
                                  const std::vector<BAEdge>& edges, const std::vector<InertialLink>& links, const Camera& cam,
                                  int iterations, double lambda_init, EdgeLidar* lidar = nullptr, const std::vector<int>* lidar_kf = nullptr);
 
+// ---- Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame (SF/src/Optimizer.cc:2469-2852, 2854-3270) ---------------------------
+// The per-frame optimiser of Tracking::TrackLocalMap once the IMU is initialised (Tracking.cc:2872/2877): Gauss-Newton with a dense
+// LDLT (g2o OptimizationAlgorithmGaussNewton + LinearSolverDense, core/optimization_algorithm_gauss_newton.cpp:49-93,
+// solvers/linear_solver_dense.h:65-113), vertices pose / velocity / gyro bias / accelerometer bias of the frame (and of the previous
+// frame when last_frame), unary EdgeMonoOnlyPose / EdgeStereoOnlyPose (G2oTypes.h:400-503, G2oTypes.cc:384-463) with Huber
+// sqrt(5.991) / sqrt(7.815), EdgeInertial + EdgeGyroRW + EdgeAccRW to the other state, EdgePriorPoseImu (G2oTypes.cc:727-767, Huber 5)
+// on the previous frame; 4 rounds x 10 iterations with the inlier tests {12, 7.5, 5.991, 5.991} (last keyframe) or 5.991 (last frame)
+// for monocular edges (x 1.5 for points closer than 10 m) and {15.6, 9.8, 7.815, 7.815} for stereo edges, chi2 compared as float;
+// the recovery pass (:2738-2765, :3160-3188); the Hessian of the new prior (15 x 15: GetHessian2 blocks, or the 30 x 30 system
+// marginalised over the previous frame, Optimizer::Marginalize :2087-2166) through ConstraintPoseImu's eigenvalue clamp
+// (G2oTypes.h:716-740).  JacobiSVD of the (symmetric) marginalised block = its eigen decomposition (cyclic Jacobi).
+struct PoseImuPrior { double Rwb[9], twb[3], vwb[3], bg[3], ba[3], H[225]; };  // ConstraintPoseImu (mpcpi)
+struct PoseInertialResult {
+    int n_initial = 0, n_bad = 0, n_inliers = 0;   // returns n_initial - n_bad
+    std::vector<uint8_t> outlier;                   // mvbOutlier per edge
+    PoseImuPrior prior;                             // pFrame->mpcpi
+    bool solver_failed = false;
+};
+// cur: the frame (updated in place); other: the last keyframe (fixed) or, when last_frame, the previous frame (free, updated too).
+// pint: the pre-integration of EdgeInertial (mpImuPreintegrated / mpImuPreintegratedFrame); pint_rw: the one whose bias-walk covariance
+// gives the random-walk informations (always pFrame->mpImuPreintegrated, :2645/:3049).  edges[e].point indexes Xw; close[e] = mTrackDepth < 10.
+PoseInertialResult PoseInertialOptimization(InertialKeyFrame& cur, InertialKeyFrame& other, bool last_frame, const PoseImuPrior* prior_prev,
+                                            const ImuCalibD& calib, const Preintegrated& pint, const Preintegrated& pint_rw,
+                                            const std::vector<double>& Xw, const std::vector<BAEdge>& edges, const std::vector<uint8_t>& close,
+                                            const Camera& cam, bool bRecInit);
+
 // exposed for unit tests
 void ExpSO3(const double w[3], double R[9]);
 void LogSO3(const double R[9], double w[3]);

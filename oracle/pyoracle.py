@@ -828,6 +828,23 @@ def pack_preintegrated(fields, bias6):
     return np.concatenate(out)
 
 
+def pose_inertial(cur33, other33, last_frame, prior246, calib24, pre298, pre_rw298, Xw, edges6, close, cam5, rec_init=False):
+    """Optimizer::PoseInertialOptimizationLastKeyFrame (last_frame False) / LastFrame (True)
+    -> (cur33, other33, outlier [E], prior246 of the frame, return value, (n_initial, n_bad, n_inliers))."""
+    cur, oth = _f64(cur33).copy(), _f64(other33).copy()
+    e6, X = _f64(edges6).reshape(-1, 6), _f64(Xw).reshape(-1, 3)
+    cl = np.ascontiguousarray(close, np.uint8)
+    pre, prw = np.ascontiguousarray(pre298, np.float32), np.ascontiguousarray(pre_rw298, np.float32)
+    pr = _f64(prior246) if prior246 is not None else None
+    out, outlier, st = np.zeros(246), np.zeros(len(e6), np.uint8), np.zeros(3, np.int32)
+    f = lib().oracle_pose_inertial
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rv = f(cur.ctypes.data, oth.ctypes.data, int(last_frame), pr.ctypes.data if pr is not None else None, _f64(calib24).ctypes.data, pre.ctypes.data,
+           prw.ctypes.data, X.ctypes.data, e6.ctypes.data, len(e6), cl.ctypes.data, _f64(cam5).ctypes.data, int(rec_init), outlier.ctypes.data,
+           out.ctypes.data, st.ctypes.data)
+    return cur, oth, outlier, out, rv, tuple(int(v) for v in st)
+
+
 def local_inertial_ba(kf33, fixed, has_imu, calib24, points3, edges6, link4, pre298, cam5, iterations=10, lambda_init=1.0):
     """Optimizer::LocalInertialBA's optimisation -> (kf33, points, chi2, depth_pos, iterations, trace, (err, err_end))."""
     kf, pts = _f64(kf33).copy(), _f64(points3).copy()

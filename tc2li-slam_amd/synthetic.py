@@ -474,6 +474,47 @@ def inertial_window(seed=0, n_opt=8, n_points=600, kf_dt=0.4, rate=200.0, pose_n
                 times=times)
 
 
+def pose_inertial_problem(seed=0, n_points=500, frame_dt=0.1, last_frame=False, outlier_frac=0.04, mono_frac=0.15):
+    """One Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame problem: the frame (noisy state, kf33 layout), the other state (last
+    keyframe: exact, fixed; previous frame: slightly off, free, with a prior mpcpi), the IMU samples between them, the map points the
+    frame holds (fixed), their observations, the close flags (mTrackDepth < 10) and the camera.
+    -> dict(cur33, other33, cur33_true, prior246 | None, calib24, samples, t1, t2, bias6, Xw, edges [E, 6], close, cam)."""
+    from scipy.spatial.transform import Rotation
+    w = inertial_window(1000 + seed, n_opt=1, n_points=n_points, kf_dt=frame_dt, pose_noise=(0.4, 0.05), vel_noise=0.08, outlier_frac=0.0)
+    rng = np.random.default_rng([SEED0, 0x9014, seed])
+    e = w["edges"][w["edges"][:, 1] == 1].copy()
+    ids, inv = np.unique(e[:, 0].astype(int), return_inverse=True)
+    e[:, 0], e[:, 1] = inv, 0
+    Xw = (w["points_true"][ids] + rng.normal(0, 0.02, (len(ids), 3))).astype(np.float32).astype(np.float64)
+    bad = rng.random(len(e)) < outlier_frac
+    e[bad, 2] += rng.choice([-1, 1], bad.sum()) * rng.uniform(8, 25, bad.sum())
+    e[bad, 3] += rng.choice([-1, 1], bad.sum()) * rng.uniform(8, 25, bad.sum())
+    mono = rng.random(len(e)) < mono_frac
+    e[mono, 4] = -1.0
+    Rcw, tcw = w["kf33_true"][1][:9].reshape(3, 3), w["kf33_true"][1][9:12]
+    depth = (Xw[e[:, 0].astype(int)] @ Rcw.T + tcw)[:, 2]
+    close = (depth < 10.0).astype(np.uint8)
+    other = w["kf33_true"][0].copy()
+    prior = None
+    if last_frame:
+        # the previous frame is an estimate too (and moves a little); its prior = that estimate with a plausible information matrix
+        Rcb, tcb = w["calib24"][:9].reshape(3, 3), w["calib24"][9:12]
+        R = other[12:21].reshape(3, 3) @ Rotation.from_rotvec(rng.normal(0, np.deg2rad(0.05), 3)).as_matrix()
+        p = other[21:24] + rng.normal(0, 0.01, 3)
+        other[12:21], other[21:24] = R.ravel(), p
+        other[:9], other[9:12] = (Rcb @ R.T).ravel(), Rcb @ (-R.T @ p) + tcb
+        other[24:27] += rng.normal(0, 0.02, 3)
+        other = other.astype(np.float32).astype(np.float64)
+        A = rng.normal(0, 1, (15, 15))
+        d = np.concatenate([np.full(3, 3e4), np.full(3, 3e3), np.full(3, 4e2), np.full(3, 1e6), np.full(3, 1e4)])
+        H = np.diag(d) + 0.02 * np.sqrt(np.outer(d, d)) * (A + A.T) / 2
+        H = (H + H.T) / 2
+        prior = np.concatenate([other[12:21], other[21:24], other[24:27], other[27:30], other[30:33], H.ravel()])
+    s, t1, t2 = w["samples"][0]
+    return dict(cur33=w["kf33"][1].copy(), other33=other, cur33_true=w["kf33_true"][1].copy(), prior246=prior, calib24=w["calib24"], samples=s, t1=t1, t2=t2,
+                bias6=w["bias6"], Xw=Xw, edges=e, close=close, cam=w["cam"], gross=bad)
+
+
 def tbl7():
     """mLidarParam->mTbl = Tbc * Tcl of the synthetic rig as (qx, qy, qz, qw, tx, ty, tz) float32."""
     from scipy.spatial.transform import Rotation

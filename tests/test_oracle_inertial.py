@@ -172,3 +172,51 @@ def test_lviba_runs_and_reports(oracle, synthetic):
     err1 = np.linalg.norm(r[0][:, 21:24] - w["kf33_true"][:, 21:24], axis=1).mean()
     assert err1 < 0.5 * err0
     assert np.array_equal(r[0][0], w["kf33"][0])
+
+
+# ---- Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame (row a10') ----------------------------------------------------------
+def _pose_inertial_problem(oracle, synthetic, seed, last_frame, **kw):
+    w = synthetic.pose_inertial_problem(seed, last_frame=last_frame, **kw)
+    f = oracle.imu_preintegrate(w["samples"], w["t1"], w["t2"], w["bias6"], *synthetic.IMU_NOISE)
+    w["pre298"] = oracle.pack_preintegrated(f[1] if isinstance(f, tuple) else f, w["bias6"])
+    return w
+
+
+@pytest.mark.parametrize("last_frame", [False, True])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_pose_inertial_optimisation(oracle, synthetic, seed, last_frame):
+    w = _pose_inertial_problem(oracle, synthetic, seed, last_frame)
+    cur, oth, outlier, prior, rv, (n0, nbad, ninl) = oracle.pose_inertial(w["cur33"], w["other33"], last_frame, w["prior246"], w["calib24"], w["pre298"],
+                                                                          w["pre298"], w["Xw"], w["edges"], w["close"], w["cam"])
+    E = len(w["edges"])
+    assert n0 == E and rv == n0 - nbad and ninl + nbad == E and ninl > 0.8 * E
+    # the gross outliers are found, few good edges are lost
+    assert outlier[w["gross"]].mean() > 0.9 and outlier[~w["gross"]].mean() < 0.08
+    # the pose moves towards the truth
+    err0 = np.linalg.norm(w["cur33"][21:24] - w["cur33_true"][21:24])
+    err1 = np.linalg.norm(cur[21:24] - w["cur33_true"][21:24])
+    assert err1 < 0.4 * err0 and err1 < 0.03
+    R0, R1, Rt = (x[12:21].reshape(3, 3) for x in (w["cur33"], cur, w["cur33_true"]))
+    ang = lambda R: np.degrees(np.arccos(np.clip((np.trace(R @ Rt.T) - 1) / 2, -1, 1)))
+    assert ang(R1) < 0.3 * ang(R0)
+    # camera pose consistent with the body pose (ImuCamPose::Update)
+    Rcb, tcb = w["calib24"][:9].reshape(3, 3), w["calib24"][9:12]
+    assert np.allclose(cur[:9].reshape(3, 3), Rcb @ R1.T, atol=1e-12) and np.allclose(cur[9:12], Rcb @ (-R1.T @ cur[21:24]) + tcb, atol=1e-10)
+    # the other state: fixed for the keyframe form, moved by the previous-frame form
+    assert np.array_equal(oth, w["other33"]) != last_frame
+    # the new prior: the frame's state and a symmetric positive semi-definite information matrix
+    H = prior[21:].reshape(15, 15)
+    assert np.array_equal(prior[:9], cur[12:21]) and np.array_equal(prior[9:12], cur[21:24]) and np.array_equal(prior[12:15], cur[24:27])
+    assert np.allclose(H, H.T, rtol=1e-9, atol=1e-6 * np.abs(H).max())
+    assert np.linalg.eigvalsh((H + H.T) / 2).min() > -1e-6 * np.abs(H).max() and np.linalg.eigvalsh((H + H.T) / 2).max() > 1.0
+    # pose block: at least the sum of the inlier edges' J^T W J (a few thousand per pixel^-2 unit)
+    assert H[0, 0] > 100 and H[3, 3] > 100
+
+
+def test_pose_inertial_recovery_pass(oracle, synthetic):
+    """Fewer than 30 inliers and !bRecInit: every edge is re-tested against 18 / 24 (Optimizer.cc:2738-2765); with bRecInit it is not."""
+    w = _pose_inertial_problem(oracle, synthetic, 3, False, n_points=30, outlier_frac=0.3)
+    a = oracle.pose_inertial(w["cur33"], w["other33"], False, None, w["calib24"], w["pre298"], w["pre298"], w["Xw"], w["edges"], w["close"], w["cam"], rec_init=False)
+    b = oracle.pose_inertial(w["cur33"], w["other33"], False, None, w["calib24"], w["pre298"], w["pre298"], w["Xw"], w["edges"], w["close"], w["cam"], rec_init=True)
+    assert a[5][2] < 30 and np.allclose(a[0], b[0])      # same optimisation
+    assert a[2].sum() <= b[2].sum() and a[4] >= b[4]      # the recovery can only clear flags
