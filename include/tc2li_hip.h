@@ -725,6 +725,41 @@ int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x
                                    float* out_xyr, int capacity);
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer::PoseInertialOptimizationLastKeyFrame (SF/src/Optimizer.cc:2469-2852) and PoseInertialOptimizationLastFrame
+ * (:2854-3270) -- the per-frame optimiser of Tracking::TrackLocalMap once the IMU is initialised (Tracking.cc:2872 / 2877) -- for a
+ * batch of independent frames: pose, velocity and biases of the frame (and, in the last-frame form, of the previous frame) against the
+ * map points the frame holds (EdgeMonoOnlyPose / EdgeStereoOnlyPose, Huber sqrt(5.991) / sqrt(7.815)), EdgeInertial + EdgeGyroRW +
+ * EdgeAccRW to the other state and, in the last-frame form, EdgePriorPoseImu (Huber 5) on the previous frame's mpcpi; Gauss-Newton with
+ * a dense LDL^T, 4 rounds x 10 iterations, the inlier tests {12, 7.5, 5.991, 5.991} (keyframe form) or 5.991 (last-frame form) for
+ * monocular edges (x 1.5 for points with mTrackDepth < 10) and {15.6, 9.8, 7.815, 7.815} for stereo edges, the recovery pass when fewer
+ * than 30 inliers remain and !bRecInit; then the frame's new prior: state + Hessian (the last-frame form marginalises the previous
+ * frame out of the 30 x 30 system, Optimizer::Marginalize :2087-2166; eigenvalues below 1e-12 cleared as ConstraintPoseImu does).
+ * The whole optimisation of every frame runs inside one kernel launch (one workgroup per frame).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tc2li_pose_imu_prior {      /* ConstraintPoseImu (SF/include/G2oTypes.h:716-740): pFrame->mpcpi */
+    double Rwb[9], twb[3], vwb[3], bg[3], ba[3];
+    double H[225];                         /* 15 x 15: rotation, translation, velocity, gyro bias, accelerometer bias */
+} tc2li_pose_imu_prior;
+typedef struct tc2li_pose_inertial_problem {
+    tc2li_inertial_keyframe frame;         /* in / out: VertexPose(pFrame), VertexVelocity, VertexGyroBias, VertexAccBias */
+    tc2li_inertial_keyframe other;         /* mpLastKeyFrame (constant) or, with last_frame, mpPrevFrame (in / out) */
+    const tc2li_pose_imu_prior* prior;     /* pFp->mpcpi; last_frame only */
+    const tc2li_preintegrated* preintegrated;     /* EdgeInertial: mpImuPreintegrated (keyframe form) / mpImuPreintegratedFrame */
+    const tc2li_preintegrated* preintegrated_rw;  /* the bias-walk covariance of InfoG / InfoA: always pFrame->mpImuPreintegrated (:2645, :3049) */
+    const double* Xw;                      /* [n_edges][3]: pMP->GetWorldPos() widened */
+    const tc2li_ba_edge* edges;            /* u, v, u_right (< 0: monocular), inv_sigma2; point / pose are not read */
+    const uint8_t* close_point;            /* [n_edges]: mTrackDepth < 10 */
+    uint8_t* outlier;                      /* out [n_edges]: mvbOutlier */
+    tc2li_pose_imu_prior* prior_out;       /* out (may be NULL): the frame's new mpcpi */
+    int32_t n_edges, last_frame, rec_init;
+    int32_t n_initial, n_bad, n_inliers, solver_failed;  /* out */
+    int32_t pad_;
+} tc2li_pose_inertial_problem;
+/* results[f] (may be NULL) = nInitialCorrespondences - nBad, the value the reference returns.  Returns n_frames. */
+int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_problem* problems, int n_frames, const tc2li_imu_calib* calib,
+                                           const tc2li_camera* cam, int32_t* results, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement (bench.py; not on the hot path).
  * tc2li_profile_enable(1): every kernel launch of the library is bracketed by two HIP events on the stream it is launched on.
  * tc2li_profile_report: call when the streams are idle; writes "name<TAB>launches<TAB>total_ms<NL>" per kernel (sorted by total

@@ -835,6 +835,56 @@ def local_inertial_bundle_adjustment(kf33, fixed, has_imu, calib24, points3, edg
     return kf, pts, chi2[:len(edges)], dpos[:len(edges)], stats
 
 
+class PoseImuPrior(C.Structure):
+    """tc2li_pose_imu_prior"""
+    _fields_ = [("Rwb", C.c_double * 9), ("twb", C.c_double * 3), ("vwb", C.c_double * 3), ("bg", C.c_double * 3), ("ba", C.c_double * 3),
+                ("H", C.c_double * 225)]
+
+
+class PoseInertialProblem(C.Structure):
+    """tc2li_pose_inertial_problem"""
+    _fields_ = [("frame", C.c_double * 33), ("other", C.c_double * 33), ("prior", C.c_void_p), ("preintegrated", C.c_void_p),
+                ("preintegrated_rw", C.c_void_p), ("Xw", C.c_void_p), ("edges", C.c_void_p), ("close_point", C.c_void_p), ("outlier", C.c_void_p),
+                ("prior_out", C.c_void_p), ("n_edges", C.c_int32), ("last_frame", C.c_int32), ("rec_init", C.c_int32), ("n_initial", C.c_int32),
+                ("n_bad", C.c_int32), ("n_inliers", C.c_int32), ("solver_failed", C.c_int32), ("pad_", C.c_int32)]
+
+
+def pose_inertial_optimization_batch(problems, calib24, cam5, stream=0):
+    """``tc2li_pose_inertial_optimization_batch``.  problems: dicts with cur33, other33 (kf33 layout), last_frame, prior246 (or None),
+    pre / pre_rw (``Preintegrated``), Xw [E, 3], edges (BA_EDGE_DTYPE), close [E], rec_init
+    -> per frame (cur33, other33, outlier, prior246, return value, (n_initial, n_bad, n_inliers), solver_failed)."""
+    n = len(problems)
+    arr = (PoseInertialProblem * max(n, 1))()
+    keep = []
+    for f, pr in enumerate(problems):
+        Xw = np.ascontiguousarray(pr["Xw"], np.float64).reshape(-1, 3)
+        e = np.ascontiguousarray(pr["edges"], BA_EDGE_DTYPE)
+        cl = np.ascontiguousarray(pr["close"], np.uint8)
+        out = np.zeros(max(len(e), 1), np.uint8)
+        prior_in, prior_out = PoseImuPrior(), PoseImuPrior()
+        if pr.get("prior246") is not None:
+            C.memmove(C.addressof(prior_in), np.ascontiguousarray(pr["prior246"], np.float64).ctypes.data, 246 * 8)
+        keep.append((Xw, e, cl, out, prior_in, prior_out))
+        a = arr[f]
+        C.memmove(a.frame, np.ascontiguousarray(pr["cur33"], np.float64).ctypes.data, 33 * 8)
+        C.memmove(a.other, np.ascontiguousarray(pr["other33"], np.float64).ctypes.data, 33 * 8)
+        a.prior = C.addressof(prior_in) if pr.get("prior246") is not None else None
+        a.preintegrated, a.preintegrated_rw = C.addressof(pr["pre"].p), C.addressof(pr.get("pre_rw", pr["pre"]).p)
+        a.Xw, a.edges, a.close_point, a.outlier, a.prior_out = Xw.ctypes.data, e.ctypes.data, cl.ctypes.data, out.ctypes.data, C.addressof(prior_out)
+        a.n_edges, a.last_frame, a.rec_init = len(e), int(bool(pr.get("last_frame"))), int(bool(pr.get("rec_init")))
+    res = np.zeros(max(n, 1), np.int32)
+    f_ = lib().tc2li_pose_inertial_optimization_batch
+    f_.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f_(C.addressof(arr), n, np.ascontiguousarray(calib24, np.float64).ctypes.data, np.ascontiguousarray(cam5, np.float64).ctypes.data, res.ctypes.data,
+              C.c_void_p(stream)))
+    outs = []
+    for f in range(n):
+        a, (Xw, e, cl, out, prior_in, prior_out) = arr[f], keep[f]
+        outs.append((np.array(a.frame), np.array(a.other), out[:len(e)].copy(), np.frombuffer(bytes(prior_out), np.float64).copy(), int(res[f]),
+                     (a.n_initial, a.n_bad, a.n_inliers), bool(a.solver_failed)))
+    return outs
+
+
 class LastFrame(C.Structure):
     """tc2li_last_frame: what SearchByProjection(F, LastFrame) reads of mLastFrame."""
     _fields_ = [("n", C.c_int32), ("pad_", C.c_int32), ("has_point", C.c_void_p), ("outlier", C.c_void_p), ("Xw", C.c_void_p),

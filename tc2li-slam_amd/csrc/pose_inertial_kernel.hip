@@ -1,0 +1,331 @@
+// Optimizer::PoseInertialOptimizationLastKeyFrame / LastFrame (SF/src/Optimizer.cc:2469-2852, 2854-3270) as ONE workgroup per frame:
+// the four classification rounds of ten Gauss-Newton iterations each (g2o OptimizationAlgorithmGaussNewton + LinearSolverDense,
+// core/optimization_algorithm_gauss_newton.cpp:49-93, solvers/linear_solver_dense.h:65-113) run inside the kernel.  Per iteration the
+// unary visual edges (EdgeMonoOnlyPose / EdgeStereoOnlyPose, G2oTypes.cc:384-463) are spread over the 256 threads and their 6 x 6
+// normal equations reduced through LDS in a fixed order; the inertial edge, the two random-walk edges and (previous-frame form) the
+// prior edge are evaluated by single lanes and expanded into the dense 15 / 30-unknown system by all threads; the LDL^T runs column
+// by column with one lane per row.  No host round trip until the frame is done; the Hessian of the new prior is assembled by the
+// host from the final states (pose_inertial_host.cpp).
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "ba_math.hpp"
+#include "pose_inertial_device.hpp"
+
+namespace tc2li {
+
+constexpr int kPiThreads = 256;
+constexpr int kPiRed = 28;  // 21 upper-triangular H entries + 6 b entries + one counter
+
+__device__ __forceinline__ void pi_block_reduce(double (&v)[kPiRed], double* s_red /*[4][kPiRed]*/, double* s_out /*[kPiRed]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kPiRed; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        if (lane == 0) s_red[wave * kPiRed + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPiRed) s_out[threadIdx.x] = (s_red[threadIdx.x] + s_red[kPiRed + threadIdx.x]) + (s_red[2 * kPiRed + threadIdx.x] + s_red[3 * kPiRed + threadIdx.x]);
+    __syncthreads();
+}
+
+// chi2 of one visual edge at pose T; B = d error / d pose increment when wanted
+__device__ __forceinline__ double pi_visual(const ImuPose& T, const ImuCalib& cal, const double* X, const BaEdge& e, const CameraD& cam, double err[3], double* B) {
+    double Xc[3], A[9];
+    const int dim = imu_edge_error(T, X, e, cam, Xc, err);
+    double c2 = 0;
+    for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
+    if (B) imu_edge_jacobians(T, cal, Xc, dim == 3, cam, A, B);
+    return c2;
+}
+
+__global__ __launch_bounds__(kPiThreads) void k_pose_inertial(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
+                                                            const uint8_t* __restrict__ close_flags, ImuCalib cal, CameraD cam, uint8_t* __restrict__ outlier,
+                                                            double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
+    __shared__ double s_red[4 * kPiRed], s_sum[kPiRed];
+    __shared__ double s_H[900], s_b[30], s_x[30], s_D[30], s_y[30];
+    __shared__ double s_J[216], s_T[216], s_e[9], s_Oe[9];        // inertial edge: J, Omega J, error, Omega error
+    __shared__ double s_pJ[225], s_pT[225], s_pe[15], s_pOe[15];  // prior edge
+    __shared__ double s_r1;                                        // Huber weight of the prior edge
+    __shared__ PiState s_cur, s_oth;
+    __shared__ int s_flag[2];  // [0] the factorisation found only positive pivots, [1] solver failed at least once
+    const PiProblem& pr = probs[blockIdx.x];
+    const int tid = threadIdx.x, N = pr.n_edges, last = pr.last_frame, n = last ? 30 : 15;
+    const BaEdge* E = edges + pr.edge_off;
+    const double* X = Xw + 3 * (size_t)pr.edge_off;
+    const uint8_t* cl = close_flags + pr.edge_off;
+    uint8_t* out = outlier + pr.edge_off;
+    double* chi2 = chi2_scratch + pr.edge_off;
+
+    for (int i = tid; i < N; i += kPiThreads) out[i] = 0;
+    if (tid == 0) { s_cur = pr.cur; s_oth = pr.other; s_flag[1] = 0; }
+    if (tid < 30) s_x[tid] = 0;
+    const double d_mono = (double)sqrtf(5.991f), d_stereo = (double)sqrtf(7.815f);
+    const float dsqr_mono = (float)(d_mono * d_mono), dsqr_stereo = (float)(d_stereo * d_stereo);
+    const float chi2Mono_kf[4] = {12.f, 7.5f, 5.991f, 5.991f}, chi2Stereo[4] = {15.6f, 9.8f, 7.815f, 7.815f};
+    __syncthreads();
+
+    bool robust = true;
+    int n_bad = 0, n_inl = 0;
+    const int n_graph_edges = N + 3 + (last ? 1 : 0);
+    for (int round = 0; round < 4; ++round) {
+        bool ok = true;
+        for (int it = 0; it < 10 && ok; ++it) {
+            // ---- computeActiveErrors + the visual part of buildSystem ----
+            const ImuPose T = s_cur.P;
+            double acc[kPiRed];
+#pragma unroll
+            for (int k = 0; k < kPiRed; ++k) acc[k] = 0;
+            for (int i = tid; i < N; i += kPiThreads) {
+                if (out[i]) continue;  // level 1
+                const BaEdge e = E[i];
+                double err[3], B[18];
+                const double c2 = pi_visual(T, cal, X + 3 * i, e, cam, err, B);
+                chi2[i] = c2;
+                const bool stereo = e.ur >= 0;
+                double rho0 = c2, rho1 = 1.0;
+                if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
+                const double w = rho1 * e.info;
+                int h = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int c = r; c < 6; ++c) {
+                        double s = 0;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * B[6 * d + c];  // rows beyond the edge's dimension are zero
+                        acc[h++] += s;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    double s = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * (e.info * err[d]);
+                    acc[21 + r] -= rho1 * s;
+                }
+            }
+            pi_block_reduce(acc, s_red, s_sum);
+            for (int k = tid; k < n * n; k += kPiThreads) s_H[k] = 0;
+            if (tid < n) s_b[tid] = 0;
+            __syncthreads();
+            if (tid < 36) {
+                const int r = tid / 6, c = tid % 6, lo = r < c ? r : c, hi = r < c ? c : r;
+                s_H[r * n + c] = s_sum[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+            }
+            if (tid < 6) s_b[tid] = s_sum[21 + tid];
+            // ---- the inertial edge (lane 0) and the prior edge (lane 64: another wavefront) ----
+            if (tid == 0) pi_inertial_edge(pr.pre, s_oth, s_cur, s_e, s_J);
+            if (tid == 64 && last) {
+                double Jr[9], Jt[9];
+                pi_prior_edge(pr.prior, s_oth, s_pe, Jr, Jt);
+                for (int k = 0; k < 225; ++k) s_pJ[k] = 0;
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { s_pJ[15 * r + c] = Jr[3 * r + c]; s_pJ[15 * (3 + r) + 3 + c] = Jt[3 * r + c]; }
+                for (int k = 6; k < 15; ++k) s_pJ[15 * k + k] = 1.0;
+            }
+            __syncthreads();
+            if (tid < 216) {  // T = Omega J
+                const int r = tid / 24, c = tid % 24;
+                double s = 0;
+                for (int k = 0; k < 9; ++k) s += pr.pre.info[9 * r + k] * s_J[24 * k + c];
+                s_T[tid] = s;
+            } else if (tid < 225) {
+                const int r = tid - 216;
+                double s = 0;
+                for (int k = 0; k < 9; ++k) s += pr.pre.info[9 * r + k] * s_e[k];
+                s_Oe[r] = s;
+            }
+            if (last && tid < 225) {  // prior: T2 = H_prior J
+                const int r = tid / 15, c = tid % 15;
+                double s = 0;
+                for (int k = 0; k < 15; ++k) s += pr.prior.H[15 * r + k] * s_pJ[15 * k + c];
+                s_pT[tid] = s;
+            }
+            if (last && tid >= 225 && tid < 240) {
+                const int r = tid - 225;
+                double s = 0;
+                for (int k = 0; k < 15; ++k) s += pr.prior.H[15 * r + k] * s_pe[k];
+                s_pOe[r] = s;
+            }
+            __syncthreads();
+            // inertial edge into the system: columns P1 V1 G1 A1 (the other state: unknowns 15.. only in the previous-frame form) | P2 V2
+            for (int k = tid; k < 576; k += kPiThreads) {
+                const int i = k / 24, j = k % 24;
+                const int ci = i < 15 ? (last ? 15 + i : -1) : i - 15, cj = j < 15 ? (last ? 15 + j : -1) : j - 15;
+                if (ci < 0 || cj < 0) continue;
+                double h = 0;
+                for (int r = 0; r < 9; ++r) h += s_J[24 * r + i] * s_T[24 * r + j];
+                s_H[ci * n + cj] += h;
+            }
+            if (tid < 24) {
+                const int ci = tid < 15 ? (last ? 15 + tid : -1) : tid - 15;
+                if (ci >= 0) {
+                    double g = 0;
+                    for (int r = 0; r < 9; ++r) g += s_J[24 * r + tid] * s_Oe[r];
+                    s_b[ci] -= g;
+                }
+            }
+            if (tid == 0 && last) {  // Huber weight of the prior edge (delta 5)
+                double c = 0;
+                for (int k = 0; k < 15; ++k) c += s_pe[k] * s_pOe[k];
+                double r0, r1;
+                huber(c, 5.0, 25.0f, r0, r1);
+                s_r1 = r1;
+            }
+            __syncthreads();
+            // EdgeGyroRW / EdgeAccRW: error = frame - other, Jacobians -I / +I
+            if (tid < 18) {
+                const int which = tid / 9, r = (tid % 9) / 3, c = tid % 3;
+                const double* info = which ? pr.pre.infoA : pr.pre.infoG;
+                const int ic = which ? 12 : 9, io = last ? 15 + ic : -1;
+                const double v = info[3 * r + c];
+                s_H[(ic + r) * n + ic + c] += v;
+                if (io >= 0) { s_H[(io + r) * n + io + c] += v; s_H[(ic + r) * n + io + c] -= v; s_H[(io + r) * n + ic + c] -= v; }
+                if (c == 0) {
+                    const double* c2 = which ? s_cur.ba : s_cur.bg;
+                    const double* c1 = which ? s_oth.ba : s_oth.bg;
+                    const double Oe = info[3 * r] * (c2[0] - c1[0]) + info[3 * r + 1] * (c2[1] - c1[1]) + info[3 * r + 2] * (c2[2] - c1[2]);
+                    s_b[ic + r] -= Oe;
+                    if (io >= 0) s_b[io + r] += Oe;
+                }
+            }
+            __syncthreads();
+            if (last) {
+                if (tid < 225) {
+                    const int i = tid / 15, j = tid % 15;
+                    double h = 0;
+                    for (int r = 0; r < 15; ++r) h += s_pJ[15 * r + i] * s_pT[15 * r + j];
+                    s_H[(15 + i) * n + 15 + j] += s_r1 * h;
+                } else if (tid < 240) {
+                    const int i = tid - 225;
+                    double g = 0;
+                    for (int r = 0; r < 15; ++r) g += s_pJ[15 * r + i] * s_pOe[r];
+                    s_b[15 + i] -= s_r1 * g;
+                }
+                __syncthreads();
+            }
+            // ---- LinearSolverDense: LDL^T, usable only when every pivot is positive ----
+            if (tid == 0) s_flag[0] = 1;
+            __syncthreads();
+            for (int j = 0; j < n; ++j) {
+                if (tid == 0) {
+                    double d = s_H[j * n + j];
+                    for (int k = 0; k < j; ++k) d -= s_H[j * n + k] * s_H[j * n + k] * s_D[k];
+                    s_D[j] = d;
+                    if (!(d > 0.0) || !(d - d == 0.0)) s_flag[0] = 0;
+                }
+                __syncthreads();
+                if (tid > j && tid < n) {
+                    double s = s_H[tid * n + j];
+                    for (int k = 0; k < j; ++k) s -= s_H[tid * n + k] * s_H[j * n + k] * s_D[k];
+                    s_H[tid * n + j] = s / s_D[j];
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                if (s_flag[0]) {
+                    for (int i = 0; i < n; ++i) { double s = s_b[i]; for (int k = 0; k < i; ++k) s -= s_H[i * n + k] * s_y[k]; s_y[i] = s; }
+                    for (int i = 0; i < n; ++i) s_y[i] /= s_D[i];
+                    for (int i = n - 1; i >= 0; --i) { double s = s_y[i]; for (int k = i + 1; k < n; ++k) s -= s_H[k * n + i] * s_y[k]; s_y[i] = s; }
+                    for (int i = 0; i < n; ++i) s_x[i] = s_y[i];
+                } else {
+                    s_flag[1] = 1;  // the increment of the previous iteration is applied once more and the round ends (GaussNewton::solve)
+                }
+                imu_pose_update(s_cur.P, cal, &s_x[0]);
+                for (int k = 0; k < 3; ++k) { s_cur.v[k] += s_x[6 + k]; s_cur.bg[k] += s_x[9 + k]; s_cur.ba[k] += s_x[12 + k]; }
+                if (last) {
+                    imu_pose_update(s_oth.P, cal, &s_x[15]);
+                    for (int k = 0; k < 3; ++k) { s_oth.v[k] += s_x[21 + k]; s_oth.bg[k] += s_x[24 + k]; s_oth.ba[k] += s_x[27 + k]; }
+                }
+            }
+            __syncthreads();
+            ok = s_flag[0] != 0;
+            __syncthreads();
+        }
+        // ---- classification: active edges keep the chi2 of the last computeActiveErrors (the estimate BEFORE the round's last update),
+        // outliers are recomputed at the final estimate (:2680-2683, :3097-3100) ----
+        const ImuPose T = s_cur.P;
+        const float chiM = last ? 5.991f : chi2Mono_kf[round];
+        const float chi2close = 1.5f * chiM;
+        double cnt[kPiRed];
+#pragma unroll
+        for (int k = 0; k < kPiRed; ++k) cnt[k] = 0;
+        for (int i = tid; i < N; i += kPiThreads) {
+            const BaEdge e = E[i];
+            if (out[i]) { double err[3]; chi2[i] = pi_visual(T, cal, X + 3 * i, e, cam, err, nullptr); }
+            const float c = (float)chi2[i];
+            bool bad;
+            if (e.ur >= 0) {
+                bad = c > chi2Stereo[round];
+            } else {
+                const double* Xp = X + 3 * i;
+                const bool depth_pos = (T.Rcw[6] * Xp[0] + T.Rcw[7] * Xp[1] + T.Rcw[8] * Xp[2]) + T.tcw[2] > 0.0;
+                bad = (c > chiM && !cl[i]) || (cl[i] && c > chi2close) || !depth_pos;
+            }
+            out[i] = bad ? 1 : 0;
+            cnt[bad ? 0 : 1] += 1.0;
+        }
+        pi_block_reduce(cnt, s_red, s_sum);
+        n_bad = (int)s_sum[0];
+        n_inl = (int)s_sum[1];
+        if (round == 2) robust = false;
+        if (n_graph_edges < 10) break;
+    }
+    // ---- "recover not too bad points" (:2738-2765, :3160-3188) ----
+    const ImuPose T = s_cur.P;
+    if (n_inl < 30 && !pr.rec_init) {
+        double cnt[kPiRed];
+#pragma unroll
+        for (int k = 0; k < kPiRed; ++k) cnt[k] = 0;
+        for (int i = tid; i < N; i += kPiThreads) {
+            const BaEdge e = E[i];
+            double err[3];
+            const double c2 = pi_visual(T, cal, X + 3 * i, e, cam, err, nullptr);
+            chi2[i] = c2;
+            if ((float)c2 < (e.ur >= 0 ? 24.f : 18.f)) out[i] = 0; else cnt[0] += 1.0;
+        }
+        pi_block_reduce(cnt, s_red, s_sum);
+        n_bad = (int)s_sum[0];
+    }
+    // ---- sum over the inlier edges of B^T Omega B at the final estimate (GetHessian(): no robust weight) ----
+    {
+        double acc[kPiRed];
+#pragma unroll
+        for (int k = 0; k < kPiRed; ++k) acc[k] = 0;
+        for (int i = tid; i < N; i += kPiThreads) {
+            if (out[i]) continue;
+            const BaEdge e = E[i];
+            double err[3], B[18];
+            pi_visual(T, cal, X + 3 * i, e, cam, err, B);
+            int h = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) {
+                    double s = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * e.info * B[6 * d + c];
+                    acc[h++] += s;
+                }
+        }
+        pi_block_reduce(acc, s_red, s_sum);
+    }
+    PiResult& R = results[blockIdx.x];
+    if (tid < 21) R.Hv[tid] = s_sum[tid];
+    if (tid == 0) {
+        R.cur = s_cur; R.other = s_oth;
+        R.n_bad = n_bad; R.n_inliers = n_inl; R.solver_failed = s_flag[1]; R.pad_ = 0;
+    }
+}
+
+void launch_pose_inertial(const PiProblem* probs, int n, const double* Xw, const BaEdge* edges, const uint8_t* close, const ImuCalib& cal,
+                          const CameraD& cam, uint8_t* outlier, double* chi2_scratch, PiResult* results, hipStream_t st) {
+    if (n > 0) TC2LI_LAUNCH(k_pose_inertial, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
+}
+
+}  // namespace tc2li

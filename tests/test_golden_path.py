@@ -238,6 +238,42 @@ def test_product_eskf_golden(pkg, golden_dir):
         assert np.abs(Pn - want_P).max() <= 1e-6 * np.abs(want_P).max()
 
 
+# ---- pose-inertial optimisation, row a10' (tools/make_golden_pose_inertial.py) ---------------------------------------------------
+def _pi_cases(g):
+    for i in range(int(g["n_cases"])):
+        yield (i, bool(i), g["cur33_%d" % i], g["other33_%d" % i], g["prior246_%d" % i] if i else None, g["pre298_%d" % i], g["Xw_%d" % i], g["edges_%d" % i],
+               g["close_%d" % i], g["out_cur_%d" % i], g["out_other_%d" % i], g["out_outlier_%d" % i], g["out_prior_%d" % i], g["out_counts_%d" % i])
+
+
+def test_oracle_pose_inertial_golden(oracle, golden_dir):
+    g = load(golden_dir, "pose_inertial_a")
+    for i, last, cur, oth, prior, pre, Xw, edges, close, wcur, woth, wout, wprior, wcounts in _pi_cases(g):
+        got = oracle.pose_inertial(cur, oth, last, prior, g["calib24"], pre, pre, Xw, edges, close, g["cam"])
+        assert np.allclose(got[0], wcur, rtol=1e-12, atol=1e-12) and np.allclose(got[1], woth, rtol=1e-12, atol=1e-12)
+        assert np.array_equal(got[2], wout) and [got[4], *got[5]] == wcounts.tolist()
+        assert np.allclose(got[3], wprior, rtol=1e-9, atol=1e-9 * np.abs(wprior).max())
+
+
+@pytest.mark.gpu
+def test_product_pose_inertial_golden(pkg, golden_dir):
+    g = load(golden_dir, "pose_inertial_a")
+    for i, last, cur, oth, prior, pre, Xw, edges, close, wcur, woth, wout, wprior, wcounts in _pi_cases(g):
+        p = pkg.capi.Preintegrated(pre[292:298], 0.0, 0.0, 0.0, 0.0)  # the stored pre-integration, field by field
+        P = p.p
+        P.dT = float(pre[0])
+        o = 1
+        for name, k in (("dR", 9), ("dV", 3), ("dP", 3), ("JRg", 9), ("JVg", 9), ("JVa", 9), ("JPg", 9), ("JPa", 9), ("avgA", 3), ("avgW", 3), ("C", 225)):
+            getattr(P, name)[:] = [float(v) for v in pre[o:o + k]]
+            o += k
+        got = pkg.capi.pose_inertial_optimization_batch([dict(cur33=cur, other33=oth, last_frame=last, prior246=prior, pre=p, Xw=Xw, edges=pkg.pack_ba_edges(edges),
+                                                              close=close)], g["calib24"], g["cam"])[0]
+        assert not got[6] and np.array_equal(got[2], wout) and [got[4], *got[5]] == wcounts.tolist()
+        assert np.abs(got[0][:24] - wcur[:24]).max() / max(1.0, np.abs(wcur[:24]).max()) < RTOL and np.allclose(got[0][24:], wcur[24:], rtol=RTOL, atol=1e-6)
+        assert np.abs(got[1][:24] - woth[:24]).max() / max(1.0, np.abs(woth[:24]).max()) < RTOL
+        H, wH = got[3][21:].reshape(15, 15), wprior[21:].reshape(15, 15)
+        assert np.abs(H - wH).max() <= 1e-4 * np.abs(wH).max()
+
+
 # ---- tracking data path, rows a9 + a10 composed (tools/make_golden_tracking.py) -------------------------------------------------
 def _keys_from_floats(dtype, a):
     k = np.zeros(len(a), dtype)
