@@ -219,6 +219,28 @@ int tc2li_lidar_map_incremental(tc2li_lidar* lidar, int scan, tc2li_lidar_map* m
 int tc2li_lidar_map_incremental_batch(tc2li_lidar* lidar, int n, const int32_t* scans, tc2li_lidar_map* const* maps,
                                       const tc2li_lidar_state* states, int ekf_inited, double filter_size_map_min, int32_t* n_to_add,
                                       int32_t* n_no_need, int32_t* map_sizes, void* stream);
+/* ---- pose plumbing between the camera thread and the LiDAR front end ----
+ * Poses are Sophus::SE3f as qx qy qz qw tx ty tz; the arithmetic is float, in Sophus' / Eigen's order.
+ * tc2li_lidar_update_pose = UpdateLidarPose (SF/include/lidar_front_end/LidarFrontEnd.cpp:786-800): Twc = Tcw_last^-1 * exp(t * log(velocity^-1)),
+ * the LiDAR pose in the front end's world frame (Rw2_w1 * Twc * Tcl) into state->rot / state->pos, pos_lid = pos + rot * offset_T_L_I (may be NULL).
+ * tc2li_se3_interpolate = InterpolateSE3 (SF/src/Tracking.cc:1552-1563): quaternion slerp + linear translation.
+ * tc2li_lidar_sync_transform = the transform Tracking::SyncWithLidar applies to a scan's feature cloud (:1600-1626):
+ *   Tlc * Tcw_frame * InterpolateSE3(Tcw_last^-1, Tcw_cur^-1, ratio) * Tcl, Tcw_frame = the frame the scan pairs with (current or last).
+ * tc2li_lidar_keyframe_transform = the one of Tracking::BuildLidarFeat4KeyFrame (:1537-1547): Tlc * Tcw_cur * (rel * Tcw_refkf)^-1 * Tcl.
+ * tc2li_transform_point_cloud = LidarFrontEndTools::transformPointCloud (SF/src/LidarTypes.cc:42-65) on host arrays; returns n.
+ * tc2li_lidar_transform_features_batch: the same for the selected feature clouds (laserCloudOri = mCurrFeatPoints) of scan slots `scans` of the
+ * handle's last tc2li_lidar_frontend_batch, read on the device where the front end left them, one launch for all scans:
+ * out [n][capacity] (host), n_points[i] = points written for scans[i] (may be NULL). */
+int tc2li_lidar_update_pose(const float Tcw_last7[7], const float velocity7[7], double time_from_last_frame, const float Tcl7[7],
+                            tc2li_lidar_state* state, double pos_lid[3]);
+int tc2li_se3_interpolate(const float a7[7], const float b7[7], float t, float out7[7]);
+int tc2li_lidar_sync_transform(const float Tcw_frame7[7], const float Tcw_last7[7], const float Tcw_cur7[7], float ratio, const float Tlc7[7],
+                               const float Tcl7[7], float out7[7]);
+int tc2li_lidar_keyframe_transform(const float Tcw_cur7[7], const float rel7[7], const float Tcw_refkf7[7], const float Tlc7[7],
+                                   const float Tcl7[7], float out7[7]);
+int tc2li_transform_point_cloud(const tc2li_point* in, int n, const float T7[7], tc2li_point* out, void* stream);
+int tc2li_lidar_transform_features_batch(tc2li_lidar* lidar, int n, const int32_t* scans, const float* T7, tc2li_point* out, int capacity,
+                                         int32_t* n_points, void* stream);
 /* ikdtree.Delete_Point_Boxes (ikd_Tree.cpp:643): removes the points inside the boxes [min, max) given as
  * min x y z, max x y z per box; returns how many were removed. */
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* map, const float* boxes6, int n_boxes, void* stream);

@@ -6,6 +6,7 @@
 #include "orb.hpp"
 #include "stereo.hpp"
 #include "lidar.hpp"
+#include "lidar_pose.hpp"
 #include "eskf.hpp"
 #include "localmap.hpp"
 #include "mappoint.hpp"
@@ -900,6 +901,34 @@ int oracle_fov_segment(float* lm7, const double* pos, double cube_len, double de
     lm7[6] = lm.initialized ? 1.f : 0.f;
     for (size_t i = 0; i < b.size(); ++i) { std::memcpy(boxes6 + 6 * i, b[i].vertex_min, 12); std::memcpy(boxes6 + 6 * i + 3, b[i].vertex_max, 12); }
     return (int)b.size();
+}
+
+// ---- pose plumbing between the camera thread and the LiDAR front end (row b4) ------------------------------------------------------
+static SE3F se3_from7(const float* p) { SE3F T; std::memcpy(T.q, p, 16); std::memcpy(T.t, p + 4, 12); return T; }
+static void se3_to7(const SE3F& T, float* p) { std::memcpy(p, T.q, 16); std::memcpy(p + 4, T.t, 12); }
+void oracle_se3f_ops(const float* a7, const float* b7, float t, float* inv7, float* mul7, float* log6, float* exp7_of_log, float* interp7) {
+    const SE3F A = se3_from7(a7), B = se3_from7(b7);
+    se3_to7(se3f_inverse(A), inv7);
+    se3_to7(se3f_mul(A, B), mul7);
+    se3f_log(A, log6);
+    se3_to7(se3f_exp(log6), exp7_of_log);
+    se3_to7(InterpolateSE3(A, B, t), interp7);
+}
+void oracle_update_lidar_pose(const float* Tcw_last7, const float* velocity7, double time_ratio, const float* Tcl7, double* state24, double* pos_lid3) {
+    LidarState st;
+    std::memcpy(st.rot, state24, 72); std::memcpy(st.pos, state24 + 9, 24); std::memcpy(st.offset_R_L_I, state24 + 12, 72); std::memcpy(st.offset_T_L_I, state24 + 21, 24);
+    UpdateLidarPose(se3_from7(Tcw_last7), se3_from7(velocity7), time_ratio, se3_from7(Tcl7), st, pos_lid3);
+    std::memcpy(state24, st.rot, 72); std::memcpy(state24 + 9, st.pos, 24);
+}
+void oracle_transform_point_cloud(const PointXYZINormal* in, int n, const float* T7, PointXYZINormal* out) {
+    const PointVector o = transformPointCloud(PointVector(in, in + n), se3_from7(T7));
+    std::memcpy(out, o.data(), (size_t)n * sizeof(PointXYZINormal));
+}
+void oracle_sync_transform(const float* Tcw_frame7, const float* Tcw_last7, const float* Tcw_cur7, float ratio, const float* Tlc7, const float* Tcl7, float* out7) {
+    se3_to7(sync_transform(se3_from7(Tcw_frame7), se3_from7(Tcw_last7), se3_from7(Tcw_cur7), ratio, se3_from7(Tlc7), se3_from7(Tcl7)), out7);
+}
+void oracle_keyframe_transform(const float* Tcw_cur7, const float* rel7, const float* Tcw_refkf7, const float* Tlc7, const float* Tcl7, float* out7) {
+    se3_to7(keyframe_transform(se3_from7(Tcw_cur7), se3_from7(rel7), se3_from7(Tcw_refkf7), se3_from7(Tlc7), se3_from7(Tcl7)), out7);
 }
 
 // ---- LiDAR motion compensation ---------------------------------------------------------------------------------------------

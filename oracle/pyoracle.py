@@ -339,6 +339,58 @@ class Sequence:
         return pose, out4
 
 
+# ---- pose plumbing between the camera thread and the LiDAR front end (row b4) ---------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def se3f_ops(a7, b7, t):
+    """Sophus::SE3f restated -> dict(inverse of a, a * b, log(a), exp(log(a)), InterpolateSE3(a, b, t))."""
+    inv, mul, lg, ex, itp = np.zeros(7, np.float32), np.zeros(7, np.float32), np.zeros(6, np.float32), np.zeros(7, np.float32), np.zeros(7, np.float32)
+    f = lib().oracle_se3f_ops
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 5
+    f.restype = None
+    f(_f32(a7).ctypes.data, _f32(b7).ctypes.data, t, inv.ctypes.data, mul.ctypes.data, lg.ctypes.data, ex.ctypes.data, itp.ctypes.data)
+    return dict(inverse=inv, mul=mul, log=lg, exp_log=ex, interpolate=itp)
+
+
+def update_lidar_pose(Tcw_last7, velocity7, time_ratio, Tcl7, state24):
+    st, pos = _f64(state24).copy(), np.zeros(3)
+    f = lib().oracle_update_lidar_pose
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(_f32(Tcw_last7).ctypes.data, _f32(velocity7).ctypes.data, time_ratio, _f32(Tcl7).ctypes.data, st.ctypes.data, pos.ctypes.data)
+    return st, pos
+
+
+def transform_point_cloud(points, T7):
+    p = np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(len(p), POINT_DTYPE)
+    f = lib().oracle_transform_point_cloud
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(p.ctypes.data, len(p), _f32(T7).ctypes.data, out.ctypes.data)
+    return out
+
+
+def sync_transform(Tcw_frame7, Tcw_last7, Tcw_cur7, ratio, Tlc7, Tcl7):
+    out = np.zeros(7, np.float32)
+    f = lib().oracle_sync_transform
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(_f32(Tcw_frame7).ctypes.data, _f32(Tcw_last7).ctypes.data, _f32(Tcw_cur7).ctypes.data, ratio, _f32(Tlc7).ctypes.data, _f32(Tcl7).ctypes.data, out.ctypes.data)
+    return out
+
+
+def keyframe_transform(Tcw_cur7, rel7, Tcw_refkf7, Tlc7, Tcl7):
+    out = np.zeros(7, np.float32)
+    f = lib().oracle_keyframe_transform
+    f.argtypes = [C.c_void_p] * 6
+    f.restype = None
+    f(_f32(Tcw_cur7).ctypes.data, _f32(rel7).ctypes.data, _f32(Tcw_refkf7).ctypes.data, _f32(Tlc7).ctypes.data, _f32(Tcl7).ctypes.data, out.ctypes.data)
+    return out
+
+
 def esti_plane(five, threshold=0.1):
     five = np.ascontiguousarray(five, POINT_DTYPE)
     out = np.zeros(4, np.float32)

@@ -409,6 +409,67 @@ def map_incremental_batch(front_end, scans, maps, states24, ekf_inited=True, fil
     return na, nn, sz
 
 
+# ---- pose plumbing between the camera thread and the LiDAR front end (row b4) ----
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def lidar_update_pose(Tcw_last7, velocity7, time_from_last_frame, Tcl7, state24):
+    """``UpdateLidarPose`` -> (state24 with rot / pos replaced, pos_lid)."""
+    st, pos = np.ascontiguousarray(state24, np.float64).copy(), np.zeros(3)
+    f = lib().tc2li_lidar_update_pose
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(_f32(Tcw_last7).ctypes.data, _f32(velocity7).ctypes.data, time_from_last_frame, _f32(Tcl7).ctypes.data, st.ctypes.data, pos.ctypes.data))
+    return st, pos
+
+
+def se3_interpolate(a7, b7, t):
+    out = np.zeros(7, np.float32)
+    f = lib().tc2li_se3_interpolate
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    _check(f(_f32(a7).ctypes.data, _f32(b7).ctypes.data, t, out.ctypes.data))
+    return out
+
+
+def lidar_sync_transform(Tcw_frame7, Tcw_last7, Tcw_cur7, ratio, Tlc7, Tcl7):
+    out = np.zeros(7, np.float32)
+    f = lib().tc2li_lidar_sync_transform
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(_f32(Tcw_frame7).ctypes.data, _f32(Tcw_last7).ctypes.data, _f32(Tcw_cur7).ctypes.data, ratio, _f32(Tlc7).ctypes.data, _f32(Tcl7).ctypes.data,
+             out.ctypes.data))
+    return out
+
+
+def lidar_keyframe_transform(Tcw_cur7, rel7, Tcw_refkf7, Tlc7, Tcl7):
+    out = np.zeros(7, np.float32)
+    f = lib().tc2li_lidar_keyframe_transform
+    f.argtypes = [C.c_void_p] * 6
+    _check(f(_f32(Tcw_cur7).ctypes.data, _f32(rel7).ctypes.data, _f32(Tcw_refkf7).ctypes.data, _f32(Tlc7).ctypes.data, _f32(Tcl7).ctypes.data, out.ctypes.data))
+    return out
+
+
+def transform_point_cloud(points, T7, stream=0):
+    p = np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(len(p), POINT_DTYPE)
+    f = lib().tc2li_transform_point_cloud
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(p.ctypes.data if len(p) else None, len(p), _f32(T7).ctypes.data, out.ctypes.data if len(p) else None, C.c_void_p(stream)))
+    return out
+
+
+def lidar_transform_features_batch(front_end, scans, T7, capacity=None, stream=0):
+    """The selected feature clouds of scan slots ``scans`` of the last ``frontend_batch``, each moved by T7[i] -> list of POINT_DTYPE arrays."""
+    sc = np.ascontiguousarray(scans, np.int32)
+    T = _f32(T7).reshape(len(sc), 7)
+    capacity = capacity or front_end.cap
+    out = np.zeros((len(sc), capacity), POINT_DTYPE)
+    npts = np.zeros(len(sc), np.int32)
+    f = lib().tc2li_lidar_transform_features_batch
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _check(f(front_end._h, len(sc), sc.ctypes.data, T.ctypes.data, out.ctypes.data, capacity, npts.ctypes.data, C.c_void_p(stream)))
+    return [out[i, :npts[i]].copy() for i in range(len(sc))]
+
+
 class LocalMapBox(C.Structure):
     _fields_ = [("vertex_min", C.c_float * 3), ("vertex_max", C.c_float * 3), ("initialized", C.c_int32)]
 

@@ -114,6 +114,12 @@ void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes
 void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st);
 
+// LidarFrontEndTools::transformPointCloud (SF/src/LidarTypes.cc:42-65) for one cloud: out[i] = (R in[i] + t, intensity kept, the rest as a
+// default-constructed point)
+struct TransformTask { const PointXYZINormal* in; PointXYZINormal* out; float R[9], t[3]; int32_t n, pad_; };
+void launch_transform_points(const TransformTask* tasks, int n_tasks, int max_points, hipStream_t st);
+void fill_transform_task(TransformTask& t, const float T7[7]);  // lidar_pose_host.cpp
+
 struct Pose6DDev { double offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]; };
 constexpr int kMaxImuPoses = 64;
 // points[i] = in[perm[i]] compensated into the scan-end frame (ImuProcess::UndistortPcl)

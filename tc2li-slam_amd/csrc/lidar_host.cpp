@@ -81,6 +81,9 @@ struct tc2li_lidar {
     DevBuf<MapGridTask> d_grid_tasks;
     PinnedBuf<int> h_mapinc_out;
     std::vector<int> last_down;  // per slot: down-sampled points of the last feature extraction
+    std::vector<int> last_sel;   // per slot: selected features (laserCloudOri) of the last tc2li_lidar_frontend_batch
+    DevBuf<TransformTask> d_xform_tasks;
+    DevBuf<PointXYZINormal> d_xform_out;
     DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
@@ -827,6 +830,38 @@ int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_
     return before - m->n;
 }
 
+// Tracking::SyncWithLidar / BuildLidarFeat4KeyFrame: the scans' feature clouds (mCurrFeatPoints = laserCloudOri of the front end, still on
+// the device) moved by one rigid transform each (LidarFrontEndTools::transformPointCloud), all scans in one launch
+int tc2li_lidar_transform_features_batch(tc2li_lidar* L, int n, const int32_t* scans, const float* T7, tc2li_point* out, int capacity, int32_t* n_points,
+                                         void* stream_) {
+    if (!L || n < 0 || (n > 0 && (!scans || !T7 || !out)) || capacity < 0) { set_error("tc2li_lidar_transform_features_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    std::vector<TransformTask> tasks(n);
+    TC2LI_HIP_CHECK(L->d_xform_tasks.ensure(n));
+    TC2LI_HIP_CHECK(L->d_xform_out.ensure((size_t)n * std::max(capacity, 1)));
+    int max_pts = 0;
+    for (int i = 0; i < n; ++i) {
+        if (scans[i] < 0 || scans[i] >= (int)L->last_sel.size()) { set_error("scan slot %d is not part of the last tc2li_lidar_frontend_batch", scans[i]); return TC2LI_ERR_INVALID; }
+        const int m = L->last_sel[scans[i]];
+        if (m > capacity) { set_error("output capacity %d < %d", capacity, m); return TC2LI_ERR_CAPACITY; }
+        TransformTask& t = tasks[i];
+        t.in = L->d_cloud_ori.p + (size_t)scans[i] * L->cap; t.out = L->d_xform_out.p + (size_t)i * capacity; t.n = m; t.pad_ = 0;
+        fill_transform_task(t, T7 + 7 * (size_t)i);
+        max_pts = std::max(max_pts, m);
+        if (n_points) n_points[i] = m;
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_xform_tasks.p, tasks.data(), n * sizeof(TransformTask), hipMemcpyHostToDevice, st));
+    launch_transform_points(L->d_xform_tasks.p, n, max_pts, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    for (int i = 0; i < n; ++i)
+        if (tasks[i].n)
+            TC2LI_HIP_CHECK(hipMemcpyAsync(out + (size_t)i * capacity, tasks[i].out, (size_t)tasks[i].n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    return n;
+}
+
 int tc2li_lidar_map_download(const tc2li_lidar_map* m, tc2li_point* out, int capacity) {
     if (!m || (capacity > 0 && !out)) { set_error("tc2li_lidar_map_download: invalid argument"); return TC2LI_ERR_INVALID; }
     hipStream_t ps = private_stream();
@@ -951,6 +986,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
     if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), st)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     L->last_down.assign(hc + n_scans, hc + 2 * n_scans);
+    L->last_sel.assign(hc + 2 * n_scans, hc + 3 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
         if (n_preprocessed) n_preprocessed[s] = hc[s];
         if (n_downsampled) n_downsampled[s] = hc[n_scans + s];

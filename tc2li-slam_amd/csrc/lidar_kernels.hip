@@ -1077,4 +1077,23 @@ void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev*
 }
 
 
+// ---- b4: LidarFrontEndTools::transformPointCloud for a batch of clouds (one 48-byte read and one 48-byte write per point) --------------
+__global__ __launch_bounds__(256) void k_transform_points(const TransformTask* __restrict__ tasks) {
+    const TransformTask& T = tasks[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T.n) return;
+    const PointXYZINormal p = T.in[i];
+    PointXYZINormal o;
+    o.x = (T.R[0] * p.x + T.R[1] * p.y + T.R[2] * p.z) + T.t[0];
+    o.y = (T.R[3] * p.x + T.R[4] * p.y + T.R[5] * p.z) + T.t[1];
+    o.z = (T.R[6] * p.x + T.R[7] * p.y + T.R[8] * p.z) + T.t[2];
+    o.pad0 = 1.0f;
+    o.normal_x = 0; o.normal_y = 0; o.normal_z = 0; o.pad1 = 0;
+    o.intensity = p.intensity; o.curvature = 0; o.pad2 = 0; o.pad3 = 0;
+    T.out[i] = o;
+}
+void launch_transform_points(const TransformTask* tasks, int n_tasks, int max_points, hipStream_t st) {
+    if (n_tasks > 0 && max_points > 0) TC2LI_LAUNCH(k_transform_points, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
+}
+
 }  // namespace tc2li
