@@ -251,7 +251,9 @@ class Loop:
         self.stream = torch.cuda.current_stream().cuda_stream
         self.lidar_stream = torch.cuda.Stream()
         self.track_stream = torch.cuda.Stream()
-        self.exts = [pkg.OrbExtractor(max_width=W, max_height=H, max_images=self.n_img) for _ in range(2)]  # extraction of batch k+1 overlaps tracking of batch k
+        # three feature buffers: extraction of batch k+2, motion-model tracking of batch k+1 and local-map tracking of batch k overlap
+        self.exts = [pkg.OrbExtractor(max_width=W, max_height=H, max_images=self.n_img) for _ in range(3)]
+        self.track2_stream = torch.cuda.Stream()
         self.lidar = pkg.LidarFrontEnd(max_points_per_scan=int(max(len(s) for s in wl.scans)), max_scans=F)
         self.maps = []
         for t in tile:  # every sequence owns its map: map_incremental changes it
@@ -274,10 +276,12 @@ class Loop:
         self.n_ba = n_ba
         self.ba_batch = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n_ba)], wl.ba_windows[0]["cam"]) if n_ba else None
         self.ba_due = 0.0
-        self.orb_outs = [None, None]
-        self.st_outs = [None, None]
-        self.trk_outs = [None, None]
+        self.orb_outs = [None, None, None]
+        self.st_outs = [None, None, None]
+        self.trk_outs = [None, None, None]
+        self.tlm_outs = [None, None, None]
         self.tlm_out = None
+        self.track_ms = [0.0, 0.0, 0.0]
         self.lidar_counts = None
         self.map_adds = [0, 0]
         self.thread_ms = {}
@@ -290,13 +294,24 @@ class Loop:
         self.orb_outs[k] = self.exts[k].extract_batch_dev(self.dev_img.data_ptr(), self.n_img, W, H, W, W * H, stream=stream, out=self.orb_outs[k])
 
     def track(self, k, stream):
+        """Stereo matching + TrackWithMotionModel of feature buffer k."""
         wl, pkg, F = self.wl, self.pkg, self.F
+        t0 = time.perf_counter()
         self.st_outs[k] = pkg.stereo_match_batch(self.exts[k], F, float(wl.bf), float(wl.b), stream=stream, out=self.st_outs[k])
+        t1 = time.perf_counter()
         self.trk_outs[k] = pkg.capi.track_motion_model_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.last_frames, self.pose_pred, wl.cam5,
                                                              float(wl.b), 7.0, stream=stream, out=self.trk_outs[k])
-        # TrackLocalMap from the pose the motion-model step left on the frame (Tracking.cc:2038 -> :2218)
-        self.tlm_out = pkg.capi.track_local_map_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.trk_outs[k][0].astype(np.float32),
-                                                      self.held, self.held_Xw, self.local_pts, self.local_off, wl.cam5, th=1.0, stream=stream)
+        self.track_ms[0], self.track_ms[1] = 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)
+
+    def track_local(self, k, stream):
+        """TrackLocalMap of feature buffer k, from the pose the motion-model step left on the frame (Tracking.cc:2038 -> :2218)."""
+        wl, pkg, F = self.wl, self.pkg, self.F
+        t0 = time.perf_counter()
+        self.tlm_outs[k] = pkg.capi.track_local_map_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.trk_outs[k][0].astype(np.float32),
+                                                          self.held, self.held_Xw, self.local_pts, self.local_off, wl.cam5, th=1.0, stream=stream,
+                                                          out=self.tlm_outs[k])
+        self.tlm_out = self.tlm_outs[k]
+        self.track_ms[2] = 1e3 * (time.perf_counter() - t0)
 
     def lidar_step(self):
         pkg, F = self.pkg, self.F
@@ -327,8 +342,9 @@ class Loop:
         """Every stage thread processes n_steps batches; ORB extraction and tracking form a two-deep pipeline over two feature buffers.
         A failure in any stage stops all of them (no thread is left blocked on a queue) and is re-raised."""
         torch = self.torch
-        free, ready = queue.Queue(), queue.Queue()
-        free.put(0); free.put(1)
+        free, ready, ready2 = queue.Queue(), queue.Queue(), queue.Queue()
+        for k in range(3):
+            free.put(k)
         failed = threading.Event()
         errors = []
 
@@ -349,12 +365,20 @@ class Loop:
                 self.orb_times.append(self.exts[k].last_timings().astype(float))
                 ready.put(k)
 
-        def track_thread():
+        def track_thread():   # the tracking thread, first half: stereo matching + TrackWithMotionModel
             for _ in range(n_steps):
                 k = get(ready)
                 if k is None:
                     return
                 self.track(k, self.track_stream.cuda_stream)
+                ready2.put(k)
+
+        def track2_thread():  # the tracking thread, second half: TrackLocalMap (a pipeline stage of its own when sequences are batched)
+            for _ in range(n_steps):
+                k = get(ready2)
+                if k is None:
+                    return
+                self.track_local(k, self.track2_stream.cuda_stream)
                 free.put(k)
 
         def lidar_thread():
@@ -372,7 +396,7 @@ class Loop:
         want = set(stages)
         if "track" in want:
             want.add("orb")  # tracking consumes what the extraction produces
-        fns = [f for f in (orb_thread, track_thread, lidar_thread, ba_thread) if f.__name__.split("_")[0] in want]
+        fns = [f for f in (orb_thread, track_thread, track2_thread, lidar_thread, ba_thread) if f.__name__.split("_")[0].rstrip("2") in want]
         if not self.ba_batch:
             fns = [f for f in fns if f is not ba_thread]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
@@ -400,6 +424,116 @@ class Loop:
 
     def close(self):
         pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# configs[3]: the camera-LiDAR-inertial loop (tc2li): IMU pre-integration, pose-inertial optimisation in TrackLocalMap, scan motion
+# compensation + iterated ESKF in the LiDAR thread, LocalLVIBA in local mapping
+# ---------------------------------------------------------------------------------------------------------------------------------
+class InertialLoop:
+    """F sequences of the inertial configuration.  Camera path: the batched calls of the main loop plus tc2li_pose_inertial_optimization_batch
+    (last-frame form) after the local-map search; LiDAR path per sequence: preprocess -> forward propagation with covariance (host) -> UndistortPcl ->
+    voxel filter -> iterated ESKF update against the sequence's map -> map_incremental; local mapping: one LocalLVIBA window (10 optimisable
+    keyframes + the fixed one, LiDAR edge over 6) every kf_interval-th frame.  The LiDAR / ESKF / LVIBA entry points take one scan or window per
+    call: each sequence has its own workspace and the sequences are dealt over host threads."""
+
+    def __init__(self, wl, F, args, local_rank):
+        import torch
+        from scipy.spatial.transform import Rotation
+        self.torch, self.wl, self.F, self.args, self.local_rank = torch, wl, F, args, local_rank
+        pkg, synthetic = wl.pkg, wl.synthetic
+        self.pkg = pkg
+        self.cam = Loop(wl, list(range(F)), argparse.Namespace(**dict(vars(args), front_end_only=True)), local_rank)  # camera path + maps
+        # pose-inertial problems (previous-frame form): the held map points of every frame
+        self.pi = []
+        for s in range(F):
+            w = synthetic.pose_inertial_problem(50 + s % wl.U, n_points=2000, last_frame=True)
+            pre = pkg.capi.Preintegrated(w["bias6"], *synthetic.IMU_NOISE)
+            self.pi.append(dict(w, pre=pre, edges=pkg.pack_ba_edges(w["edges"])))
+        self.calib24, self.cam5 = self.pi[0]["calib24"], self.pi[0]["cam"]
+        # LiDAR-inertial: per sequence a workspace, the raw scan, IMU samples over the sweep, the filter state and covariance
+        self.fe = [pkg.LidarFrontEnd(max_points_per_scan=int(max(len(x) for x in wl.scans)), max_scans=1) for _ in range(F)]
+        self.lidar_in = []
+        for s in range(F):
+            t = s % wl.U
+            R, p = synthetic.sensor_pose(t + 1)
+            rng = np.random.default_rng(300 + s)
+            beg, end = 10.0, 10.1
+            k0, k1 = int(np.floor((beg - 0.012) * 100)), int(np.ceil((end + 0.004) * 100))
+            ts = np.arange(k0, k1 + 1) / 100.0
+            imu = np.zeros((len(ts), 7))
+            imu[:, 0] = ts
+            imu[:, 1:4] = np.array([0.0, 0.0, 9.81]) + rng.normal(0, 0.02, (len(ts), 3))
+            imu[:, 4:7] = rng.normal(0, 0.002, (len(ts), 3))
+            x = np.concatenate([p + rng.normal(0, 0.02, 3), (R @ Rotation.from_rotvec(rng.normal(0, 0.002, 3)).as_matrix()).ravel(), [10.0, 0.0, 0.0], np.zeros(3),
+                                np.zeros(3), [0, 0, -9.81], np.eye(3).ravel(), np.zeros(3)])
+            A = rng.normal(0, 1, (23, 23))
+            P = A @ A.T * 1e-6 + np.diag([1e-3] * 3 + [1e-4] * 3 + [1e-5] * 6 + [1e-2] * 3 + [1e-5] * 6 + [1e-6] * 2)
+            self.lidar_in.append(dict(raw=wl.scans[t], imu=imu, x=x, P=P, beg=beg, end=end))
+        self.cov12 = np.array([0.1] * 3 + [0.1] * 3 + [1e-4] * 3 + [1e-4] * 3)
+        # local mapping: LVIBA windows
+        self.lviba = []
+        for k in range(min(4, max(1, F))):
+            w = synthetic.inertial_window(k, n_opt=10, n_points=900)
+            pre = []
+            for smp, t1, t2 in w["samples"]:
+                q = pkg.capi.Preintegrated(w["bias6"], *synthetic.IMU_NOISE)
+                q.preintegrate(smp, t1, t2)
+                pre.append(q)
+            K = len(w["kf33"])
+            win = list(range(K - 1, K - 7, -1))
+            self.lviba.append(dict(w, pre=pre, win=win, clouds=synthetic.inertial_window_clouds(w, win, n_points=2400, seed=k), packed=pkg.pack_ba_edges(w["edges"])))
+        self.tbl = synthetic.tbl7()
+        self.pool = ThreadPoolExecutor(max_workers=min(F, 8))
+        self.ba_pool = ThreadPoolExecutor(max_workers=2)
+        self.ba_futs = []
+        self.frames_done = 0
+        self.stats = {}
+
+    def _lidar_seq(self, s):
+        self.torch.cuda.set_device(self.local_rank)
+        pkg, fe, li, m = self.pkg, self.fe[s], self.lidar_in[s], self.cam.maps[s]
+        pts = fe.process(li["raw"])
+        x, P, poses, _ = pkg.capi.lidar_imu_propagate_cov(li["x"], li["P"], self.cov12, li["imu"], li["beg"], li["end"], li["beg"] - 0.001, 1.0, np.zeros(6))
+        st24 = np.concatenate([x[3:12], x[0:3], x[24:33], x[33:36]])
+        und = fe.undistort(pts, poses, st24)
+        down = fe.voxel_filter(und)
+        x2, P2, st = fe.eskf_update(m, down, x, P, max_iter=3)
+        st24 = np.concatenate([x2[3:12], x2[0:3], x2[24:33], x2[33:36]])
+        m.map_incremental(fe, 0, st24)
+        return len(pts), len(down), int(st.effct_feat_num), int(st.calls)
+
+    def _lviba(self, k):
+        self.torch.cuda.set_device(self.local_rank)
+        w = self.lviba[k % len(self.lviba)]
+        r = self.pkg.capi.local_lvi_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["packed"], w["link4"], w["pre"], w["cam"],
+                                                      w["win"], w["clouds"], self.wl.synthetic.TCL7, self.tbl, 1.0)
+        return int(r[4].iterations), int(r[5].n_planes)
+
+    def step(self):
+        pkg, F, cam = self.pkg, self.F, self.cam
+        lid = [self.pool.submit(self._lidar_seq, s) for s in range(F)]
+        # camera path: extraction, stereo, TrackWithMotionModel, local-map search (its visual-only PoseOptimization runs as well: extra work inside
+        # the timed region), IMU pre-integration between the frames, then the pose-inertial optimisation
+        cam.extract(0, cam.stream)
+        cam.track(0, cam.stream)
+        cam.track_local(0, cam.stream)
+        for pr in self.pi:
+            q = pkg.capi.Preintegrated(pr["bias6"], *self.wl.synthetic.IMU_NOISE)
+            q.preintegrate(pr["samples"], pr["t1"], pr["t2"])
+            pr["pre"] = q
+        res = pkg.capi.pose_inertial_optimization_batch(self.pi, self.calib24, self.cam5, stream=cam.stream)
+        self.frames_done += 1
+        if self.frames_done % self.args.kf_interval == 0:
+            self.ba_futs += [self.ba_pool.submit(self._lviba, self.frames_done + s) for s in range(F)]
+        lid = [f.result() for f in lid]
+        self.stats = {"scan_points_preprocessed/downsampled/eskf_features/h_share_model_calls": [int(np.mean([r[k] for r in lid])) for k in range(4)],
+                      "pose_inertial_edges/inliers": [int(np.mean([len(p["edges"]) for p in self.pi])), int(np.mean([r[5][2] for r in res]))]}
+
+    def finish(self):
+        out = [f.result() for f in self.ba_futs]
+        self.ba_futs = []
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -643,6 +777,7 @@ def main(argv=None):
     if set(stages) != {"orb", "track", "lidar", "ba"}:  # diagnostics: which stages slow each other down
         if rank == 0:
             print(json.dumps({"diagnostic_stages": args.stages, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "frames_per_step": F,
+                              "track_calls_ms_last_step": getattr(loop, "track_ms", None),
                               "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in loop.thread_ms.items()}}))
         if dist is not None:
             dist.destroy_process_group()
@@ -658,7 +793,8 @@ def main(argv=None):
     wall = {}
     if rank == 0 and not args.no_extra_lines:
         t_a = time.perf_counter(); loop.extract(0, stream); wall["orb_extract_batch"] = time.perf_counter() - t_a
-        t_a = time.perf_counter(); loop.track(0, stream); wall["stereo + TrackWithMotionModel + TrackLocalMap"] = time.perf_counter() - t_a
+        t_a = time.perf_counter(); loop.track(0, stream); wall["stereo + TrackWithMotionModel"] = time.perf_counter() - t_a
+        t_a = time.perf_counter(); loop.track_local(0, stream); wall["TrackLocalMap"] = time.perf_counter() - t_a
         t_a = time.perf_counter(); loop.lidar_step(); wall["lidar_frontend_batch + map_incremental"] = time.perf_counter() - t_a
         if loop.ba_batch:
             t_a = time.perf_counter(); loop.ba_batch.run(args.ba_concurrency); wall["local_lv_ba_batch(%d windows)" % loop.n_ba] = time.perf_counter() - t_a
@@ -707,6 +843,29 @@ def main(argv=None):
                   "ba_windows": one.ba_windows_done, "workload": "the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame" % args.kf_interval,
                   "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one.thread_ms.items()}}
         one.close()
+
+    # ---- configs[3]: the inertial configuration (IMU pre-integration, pose-inertial optimisation, UndistortPcl + ESKF, LocalLVIBA) ----
+    inertial = None
+    if rank == 0 and not args.no_extra_lines and not args.front_end_only:
+        Fi = 8
+        il = InertialLoop(wl, Fi, args, local_rank)
+        for _ in range(2):
+            il.step()
+        il.finish()
+        torch.cuda.synchronize()
+        n_i = 12
+        t1 = time.perf_counter()
+        for _ in range(n_i):
+            il.step()
+        ba_out = il.finish()
+        torch.cuda.synchronize()
+        dti = time.perf_counter() - t1
+        inertial = {"value": round(Fi * n_i / dti, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dti / n_i, 3), "sequences": Fi, "steps": n_i,
+                    "lviba_windows": len(ba_out), "lviba_iterations/planes": list(ba_out[0]) if ba_out else None,
+                    "workload": "configs[3], camera-LiDAR-inertial: stereo ORB + stereo matching + TrackWithMotionModel + local-map search + IMU "
+                                "pre-integration + PoseInertialOptimizationLastFrame (batched over the sequences); per sequence UndistortPcl + voxel filter + "
+                                "iterated ESKF update (h_share_model on the device) + map_incremental; LocalLVIBA (10 + 1 keyframes, LiDAR edge over 6) every "
+                                "%d-th frame" % args.kf_interval, **il.stats}
 
     # ---- CPU baseline: the oracle (a port) with the reference's threading ----
     cpu = None
@@ -760,11 +919,13 @@ def main(argv=None):
                                 total_sequences, args.scaling, "the list is dealt over the ranks" if args.scaling == "strong" else "%d per rank" % args.frames) +
                             ("" if args.front_end_only else ", LocalLVBundleAdjustment (12 free + 20 fixed keyframes, ~2500 points, ~26k stereo "
                                                             "edges, LiDAR plane edge over 6 keyframes x 3000 points)"),
-                "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel + TrackLocalMap | LiDAR front end + map maintenance | local "
-                                 "mapping, each on its own host thread and HIP stream as in the reference; a step = every stage has processed one batch",
+                "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel | TrackLocalMap | LiDAR front end + map maintenance | local "
+                                 "mapping, each on its own host thread and HIP stream (the reference's tracking / LiDAR / local-mapping threads; with batched "
+                                 "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
+                                 "processed one batch",
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": {
-                    "stage_threads": 4, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
+                    "stage_threads": 5, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
                     "cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()},
                 "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),
                 "motion_model_matches/inliers_per_frame": [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
@@ -774,9 +935,10 @@ def main(argv=None):
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
                 "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_batch.stats[0].iterations), "trials": int(loop.ba_batch.stats[0].trials),
                                                       "planes": int(loop.ba_batch.lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, **({"sharded_window": sharded_window} if sharded_window else {}),
+            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "inertial_config": inertial, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
             "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
+            "track_calls_ms_last_step": dict(zip(("stereo_match_batch", "track_motion_model_batch", "track_local_map_batch"), [round(v, 3) for v in loop.track_ms])),
         }
         print(json.dumps(line))
         sys.stdout.flush()

@@ -771,7 +771,7 @@ def create_new_map_points(cur, neighbours, cam5, mb, scale_factors, level_sigma2
 
 
 def track_local_map_batch(ext, n_frames, keypoints, u_right, poses7, held, held_Xw, local_points, local_offsets, cam5, th=1.0, far_points=False,
-                          th_far=0.0, stream=0):
+                          th_far=0.0, stream=0, out=None):
     """``tc2li_track_local_map_batch`` on the features of the last ``extract_batch_dev`` call ->
     (poses7 double [F, 7], local_of_keypoint [F, cap], outlier [F, cap], n_matches [F], n_inliers [F])."""
     kps = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
@@ -783,8 +783,10 @@ def track_local_map_batch(ext, n_frames, keypoints, u_right, poses7, held, held_
     pts = np.ascontiguousarray(local_points, MAP_POINT_DTYPE)
     off = np.ascontiguousarray(local_offsets, np.int32)
     cam5 = np.ascontiguousarray(cam5, np.float64)
-    out_p, lk, ol = np.zeros((n_frames, 7)), np.full((n_frames, cap), -1, np.int32), np.zeros((n_frames, cap), np.uint8)
-    nm, inl = np.zeros(n_frames, np.int32), np.zeros(n_frames, np.int32)
+    if out is None:
+        out = (np.zeros((n_frames, 7)), np.full((n_frames, cap), -1, np.int32), np.zeros((n_frames, cap), np.uint8), np.zeros(n_frames, np.int32),
+               np.zeros(n_frames, np.int32))
+    out_p, lk, ol, nm, inl = out
     f = lib().tc2li_track_local_map_batch
     f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                   C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

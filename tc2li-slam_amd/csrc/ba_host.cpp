@@ -30,7 +30,7 @@ struct PoseOptWorkspace {
     DevBuf<int> d_inliers;
     std::mutex mu;
 };
-PoseOptWorkspace& po_ws() { static PoseOptWorkspace w; return w; }
+PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
 
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in

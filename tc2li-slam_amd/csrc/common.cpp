@@ -177,6 +177,17 @@ WorkerPool& global_pool() {
     return *pool;
 }
 
+WorkerPool& tracking_pool() {
+    static WorkerPool* pool = [] {
+        int n = (int)std::thread::hardware_concurrency() / 2;
+        if (const char* s = getenv("TC2LI_TRACKING_THREADS")) n = atoi(s);
+        if (n < 1) n = 1;
+        if (n > 16) n = 16;
+        return new WorkerPool(n);
+    }();
+    return *pool;
+}
+
 }  // namespace tc2li
 
 extern "C" {

@@ -108,6 +108,10 @@ private:
     bool stop_ = false;
 };
 
-WorkerPool& global_pool();
+WorkerPool& global_pool();    // the ORB extractor's host stages (quadtree per image and level)
+// A second pool for the tracking thread's host steps (stereo / matcher / tracking entry points): WorkerPool::parallel_for serialises
+// its callers, so on one shared pool the milliseconds-long quadtree phase of the extraction thread would stall every short
+// parallel_for of the tracking thread that runs beside it.
+WorkerPool& tracking_pool();
 
 }  // namespace tc2li

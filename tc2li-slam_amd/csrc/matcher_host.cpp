@@ -37,7 +37,8 @@ struct MatcherWorkspace {
     PinnedBuf<int32_t> h_query_frame, h_key_base, h_pool_top;
     std::mutex mu;
 };
-MatcherWorkspace& mws() { static MatcherWorkspace w; return w; }
+// one workspace per host thread: two threads that search different batches side by side do not wait for each other
+MatcherWorkspace& mws() { static thread_local MatcherWorkspace w; return w; }
 
 inline void quat_rotate_f(const float q[4], const float v[3], float out[3]) {  // Eigen::Quaternionf::_transformVector
     float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
@@ -160,7 +161,7 @@ int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_fram
         TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
     }
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];
         int32_t* m = match_of_query + fr.q_off;
         memcpy(m, w.h_match.p + fr.q_off, fr.n_q * sizeof(int32_t));

@@ -92,7 +92,7 @@ int tc2li_stereo_match_batch(tc2li_orb* o, int n_frames, float bf, float b, floa
                         bf, max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         const StereoFrame& fr = frames[f];
         float* u = u_right + (size_t)f * capacity;
         float* d = depth + (size_t)f * capacity;

@@ -64,7 +64,7 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
         rc[f] = tc2li_project_last_frame(pose_pred7 + 7 * f, lf.pose7, cam4, b, bf, o->scale.data(), L, o->cur_w, o->cur_h, lf.n, lf.has_point,
                                          lf.outlier, lf.Xw, lf.keys, lf.descriptors, radius, 0, queries.data() + frames[f].q_off);
     };
-    global_pool().parallel_for(n_frames, [&](int f) { build_queries(f, th); });
+    tracking_pool().parallel_for(n_frames, [&](int f) { build_queries(f, th); });
     for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
     tm[0] = now() - t0; t0 = now();
     int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 0, 0.9f, true, match.data(), n_matches, st);
@@ -76,7 +76,7 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     if (!retry.empty()) {
         std::vector<BatchSearchFrame> again(retry.size());
         std::vector<int32_t> nm(retry.size());
-        global_pool().parallel_for((int)retry.size(), [&](int k) { build_queries(retry[k], 2 * th); });
+        tracking_pool().parallel_for((int)retry.size(), [&](int k) { build_queries(retry[k], 2 * th); });
         for (size_t k = 0; k < retry.size(); ++k) { if (rc[retry[k]] < 0) return rc[retry[k]]; again[k] = frames[retry[k]]; }
         r = search_batch_device(o, again.data(), (int)again.size(), queries.data(), 0, 0.9f, true, match.data(), nm.data(), st);
         if (r < 0) return r;
@@ -90,7 +90,7 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     std::vector<tc2li_ba_edge> edges(std::max(total_e, 1));
     std::vector<int32_t> edge_kp(std::max(total_e, 1));
     std::vector<uint8_t> outlier(std::max(total_e, 1), 0);
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];
         int32_t* mp = map_point_of_keypoint + (size_t)f * capacity;
         for (int i = 0; i < capacity; ++i) mp[i] = -1;
@@ -155,6 +155,9 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     const float cam4[4] = {(float)cam->fx, (float)cam->fy, (float)cam->cx, (float)cam->cy};
     const float bf = (float)cam->bf;
     const float log_scale = std::log(o->prm.scale_factor);  // mfLogScaleFactor = log(mfScaleFactor) (SF/src/Frame.cc:96)
+    static const bool kTiming = getenv("TC2LI_TRACK_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm[5] = {0, 0, 0, 0, 0}, t0 = now();
     std::vector<BatchSearchFrame> frames(n_frames);
     std::vector<std::vector<uint8_t>> occ(n_frames);
     for (int f = 0; f < n_frames; ++f) {
@@ -175,17 +178,19 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     std::vector<tc2li_proj_query> queries(std::max(total_q, 1));
     std::vector<int32_t> match(std::max(total_q, 1), -1);
     std::vector<int> rc(n_frames, 0);
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         if (frames[f].n_q > 0)
             rc[f] = tc2li_project_local_map(poses7 + 7 * f, cam4, bf, o->scale.data(), L, log_scale, o->cur_w, o->cur_h, frames[f].n_q,
                                             local_points + frames[f].q_off, th, far_points, th_far_points, 0.5f, queries.data() + frames[f].q_off);
     });
     for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
+    tm[0] = now() - t0; t0 = now();
     int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 1, 0.8f, false, match.data(), n_matches, st);
     if (r < 0) return r;
+    tm[1] = now() - t0; t0 = now();
     // ---- Optimizer::PoseOptimization over every map point the frame now holds, in keypoint order ----
     std::vector<int32_t> edge_off(n_frames + 1, 0);
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];
         int32_t* lk = local_of_keypoint + (size_t)f * capacity;
         for (int i = 0; i < capacity; ++i) lk[i] = -1;
@@ -204,7 +209,7 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     std::vector<tc2li_ba_edge> edges(std::max(total_e, 1));
     std::vector<int32_t> edge_kp(std::max(total_e, 1));
     std::vector<uint8_t> out(std::max(total_e, 1), 0);
-    global_pool().parallel_for(n_frames, [&](int f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         const BatchSearchFrame& fr = frames[f];
         const uint8_t* h = held + (size_t)f * capacity;
         const float* hx = held_Xw + 3 * (size_t)f * capacity;
@@ -225,8 +230,11 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
         }
     });
     std::vector<int32_t> inl(n_frames, 0);
+    tm[2] = now() - t0; t0 = now();
     r = tc2li_pose_optimization_batch(n_frames, poses7_out, edge_off.data(), Xw.data(), edges.data(), cam, out.data(), inl.data(), stream_);
     if (r < 0) return r;
+    tm[3] = now() - t0; t0 = now();
+    if (kTiming) fprintf(stderr, "track-local-map timing ms: queries %.3f search %.3f edges %.3f pose-opt %.3f\n", tm[0], tm[1], tm[2], tm[3]);
     for (int f = 0; f < n_frames; ++f) {
         uint8_t* ol = outlier + (size_t)f * capacity;
         memset(ol, 0, capacity);
