@@ -847,6 +847,8 @@ void oracle_resize_linear(const uint8_t* src, int sw, int sh, uint8_t* dst, int 
     resizeLinearU8(s, d);
     std::memcpy(dst, d.store.data(), (size_t)dw * dh);
 }
+void oracle_set_gauss_variant(int v) { gauss_variant() = v == 1 ? 1 : 0; }
+int oracle_get_gauss_variant() { return gauss_variant(); }
 void oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
     Img s = Img::view(src, w, h, w);
     Img d(w, h);

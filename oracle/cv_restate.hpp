@@ -139,8 +139,16 @@ static inline Img makeBorder101(const Img& src, int b) {
 // 8-bit images take OpenCV's fixed-point separable path: 8.8 kernel whose taps sum to 256
 // (error-diffused rounding of exp(-x^2/8)/sum -> {18,34,48,56,48,34,18}); the horizontal pass keeps
 // 8.8 values, the vertical pass 16.16, the result is rounded to nearest.
-static const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};
+// VARIANT (oracle_set_gauss_variant): which taps OpenCV 4.2 hands to that path cannot be checked here (no OpenCV in the container).
+//   0 (default) "error-diffused": {18,34,48,56,48,34,18}, sum 256 -- getGaussianKernelFixedPoint_ED, present in the later 3.4.x / 4.x releases;
+//   1 "rounded": {18,34,49,55,49,34,18}, sum 257 -- each tap of the bit-exact softdouble kernel rounded to 8.8 on its own, the earlier
+//     form of getFixedpointGaussianKernel; the result is saturated (the sum can reach 256).
+// Both have a golden file (tests/golden/orb_a.npz / orb_gauss_rounded.npz): the day a real OpenCV 4.2 is reachable, one
+// cv::GaussianBlur of the stored image decides, and TC2LI_GAUSS_TAPS=rounded switches the product.
+static const int kGaussTaps[2][7] = {{18, 34, 48, 56, 48, 34, 18}, {18, 34, 49, 55, 49, 34, 18}};
+inline int& gauss_variant() { static int v = 0; return v; }
 static inline void gaussianBlur7(const Img& src, Img& dst) {
+    const int* kGauss7 = kGaussTaps[gauss_variant()];
     const int w = src.w, h = src.h;
     std::vector<uint16_t> tmp((size_t)w * h);
     std::vector<uint8_t> prow((size_t)w + 6);
@@ -161,7 +169,8 @@ static inline void gaussianBlur7(const Img& src, Img& dst) {
         for (int x = 0; x < w; ++x) {
             const unsigned acc = kGauss7[0] * ((unsigned)R[0][x] + R[6][x]) + kGauss7[1] * ((unsigned)R[1][x] + R[5][x]) +
                                  kGauss7[2] * ((unsigned)R[2][x] + R[4][x]) + kGauss7[3] * (unsigned)R[3][x];
-            O[x] = (uint8_t)((acc + 32768u) >> 16);
+            const unsigned v = (acc + 32768u) >> 16;
+            O[x] = (uint8_t)(v > 255u ? 255u : v);
         }
     }
 }

@@ -171,6 +171,12 @@ def resize_linear(img, dw, dh):
     return out
 
 
+def set_gauss_variant(name):
+    """Which fixed-point taps the oracle's GaussianBlur(7 x 7, sigma 2) uses: "error-diffused" (default, sum 256) or "rounded" (sum 257)."""
+    lib().oracle_set_gauss_variant.argtypes = [C.c_int]
+    lib().oracle_set_gauss_variant({"error-diffused": 0, "rounded": 1}[name])
+
+
 def gaussian_blur7(img):
     img = np.ascontiguousarray(img, np.uint8)
     out = np.empty_like(img)

@@ -79,23 +79,18 @@ std::vector<Rec> g_recs;                              // launches since the last
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free;  // event pairs to reuse
 constexpr size_t kMaxRecs = 1u << 20;
 }  // namespace
-void Scope::begin(const char* name) {
+bool acquire(const char* name, hipEvent_t* start, hipEvent_t* stop) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (g_recs.size() >= kMaxRecs) return;
+        if (g_recs.size() >= kMaxRecs) return false;
         if (!g_free.empty()) { ev = g_free.back(); g_free.pop_back(); }
     }
-    if (!ev.first && (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)) { (void)hipGetLastError(); return; }
-    if (hipEventRecord(ev.first, st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (!ev.first && (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess)) { (void)hipGetLastError(); return false; }
     std::lock_guard<std::mutex> lk(g_mu);
-    slot = (int)g_recs.size();
     g_recs.push_back(Rec{name, ev.first, ev.second});
-}
-void Scope::end() {
-    hipEvent_t b;
-    { std::lock_guard<std::mutex> lk(g_mu); b = g_recs[slot].b; }
-    if (hipEventRecord(b, st) != hipSuccess) (void)hipGetLastError();
+    *start = ev.first; *stop = ev.second;
+    return true;
 }
 }  // namespace prof
 

@@ -1,28 +1,28 @@
-// Kernel launch macro of the library: hipLaunchKernelGGL plus the optional per-launch event pair of tc2li_profile_* (measurement).
+// Kernel launch macro of the library: hipLaunchKernelGGL, or -- while tc2li_profile_enable(1) -- hipExtLaunchKernelGGL with a start and a
+// stop event bound to the dispatch itself (measurement).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 
 namespace tc2li {
 // ---- per-launch timing (measurement only; include/tc2li_hip.h "tc2li_profile_*") ------------------------------------------------
-// While enabled, every kernel launch of the library is bracketed by two HIP events on the stream it is launched on; the report sums
-// the event spans per kernel name.  Off (the default) it costs one relaxed atomic load per launch.
+// While enabled, every kernel launch of the library carries two HIP events that the runtime stamps when the dispatch starts and when
+// it completes (hipExtLaunchKernel's startEvent / stopEvent): their distance is the kernel's own execution time -- what rocprofv3's
+// kernel trace reports -- not the span between two markers on a stream that waits its turn on a shared GPU.  The report sums the
+// durations per kernel name.  Off (the default) a launch costs one relaxed atomic load more.
 namespace prof {
 extern std::atomic<int> g_enabled;
-struct Scope {
-    int slot = -1;
-    hipStream_t st;
-    Scope(const char* name, hipStream_t stream) : st(stream) { if (g_enabled.load(std::memory_order_relaxed)) begin(name); }
-    ~Scope() { if (slot >= 0) end(); }
-    void begin(const char* name);
-    void end();
-};
+bool acquire(const char* name, hipEvent_t* start, hipEvent_t* stop);  // false: no events (limit reached, creation failed): launch plainly
 }  // namespace prof
-#define TC2LI_LAUNCH(kernel, grid, block, shmem, stream, ...)                    \
-    do {                                                                         \
-        ::tc2li::prof::Scope prof_scope_(#kernel, stream);                       \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);     \
+#define TC2LI_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                  \
+    do {                                                                                                                       \
+        hipEvent_t prof_a_ = nullptr, prof_b_ = nullptr;                                                                       \
+        if (::tc2li::prof::g_enabled.load(std::memory_order_relaxed) && ::tc2li::prof::acquire(#kernel, &prof_a_, &prof_b_))   \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, prof_a_, prof_b_, 0, __VA_ARGS__);                       \
+        else                                                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                               \
     } while (0)
 
 }  // namespace tc2li

@@ -40,7 +40,7 @@ void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, in
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
                     const uint32_t* slab, size_t slab_img_stride, uint32_t* dense, const int* level_dense_off,
                     int* level_counts, int nlevels, int nimg, hipStream_t st);
-void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, hipStream_t st);
+void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, bool rounded_taps, hipStream_t st);
 struct MatchKey;
 struct ScaleTable;
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,

@@ -21,6 +21,7 @@ struct LevelGeom {
 struct tc2li_orb {
     tc2li_orb_params prm{};
     int max_w = 0, max_h = 0, max_images = 0;
+    bool gauss_rounded_taps = false;  // TC2LI_GAUSS_TAPS=rounded at creation: the per-tap rounded 8.8 Gaussian (orb_kernels.hip, k_blur7_strips)
     int max_cell_w = 0, max_cell_h = 0;  // largest FAST cell window of the current geometry
     tc2li::DevBuf<int> d_cell_ids;       // cells whose window fits 48 x 48, then the others (one kernel variant each)
     int n_small_cells = 0, n_large_cells = 0;

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -182,6 +183,7 @@ int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, i
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     std::unique_ptr<tc2li_orb> o(new tc2li_orb());
     o->prm = *p;
+    if (const char* taps = getenv("TC2LI_GAUSS_TAPS")) o->gauss_rounded_taps = strcmp(taps, "rounded") == 0;
     o->max_w = max_width; o->max_h = max_height; o->max_images = max_images;
     const int L = p->nlevels;
     // SF/src/ORBextractor.cc:388-419; the member scaleFactor is a double holding the float argument
@@ -323,7 +325,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 1), st));
         if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, EV(c, 1), 0));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 4), blur_st));
-        launch_blur_all(craw, cblur, L, m, blur_st);
+        launch_blur_all(craw, cblur, L, m, o->gauss_rounded_taps, blur_st);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 5), blur_st));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 8), st));
         if (ncells > 0) {

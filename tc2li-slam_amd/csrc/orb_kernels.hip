@@ -403,6 +403,11 @@ __device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t mid, uint32_t 
     return k < 0 ? (lo >> (8 * (k + 4))) & 0xffu : (k < 4 ? (mid >> (8 * k)) & 0xffu : (hi >> (8 * (k - 4))) & 0xffu);
 }
 
+// ROUNDED selects the fixed-point taps of cv::GaussianBlur(7 x 7, sigma 2) on CV_8U (what getFixedpointGaussianKernel hands to the 8.8 path):
+//   false: {18, 34, 48, 56, 48, 34, 18}, sum 256 -- the error-diffused quantiser (getGaussianKernelFixedPoint_ED of the later 3.4 / 4.x releases);
+//   true:  {18, 34, 49, 55, 49, 34, 18}, sum 257 -- every tap rounded to nearest on its own (the earlier bit-exact path), result saturated.
+// Which of the two OpenCV 4.2 contains cannot be checked here (no OpenCV): DESIGN.md section 2; the default is the first.
+template <bool ROUNDED>
 __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable src, LevelTable dst, BlurWork wk) {
     // (an XCD-contiguous block order, which helps the cell and gather kernels, made this streaming kernel slower: 0.32 -> 0.38 ms)
     int level = 0;
@@ -467,8 +472,9 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
     auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
         return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
     };
-    constexpr uint32_t TA = 18u | (34u << 8) | (48u << 16) | (56u << 24), TB = 48u | (34u << 8) | (18u << 16);
-    constexpr uint32_t C01 = 18u | (34u << 16), C23 = 48u | (56u << 16), C45 = 48u | (34u << 16);
+    constexpr uint32_t T2 = ROUNDED ? 49u : 48u, T3 = ROUNDED ? 55u : 56u;
+    constexpr uint32_t TA = 18u | (34u << 8) | (T2 << 16) | (T3 << 24), TB = T2 | (34u << 8) | (18u << 16);
+    constexpr uint32_t C01 = 18u | (34u << 16), C23 = T2 | (T3 << 16), C45 = T2 | (34u << 16);
     const int r_end = y1 + 3;
     const bool own_next = inside && (lane == 63 || x + 4 >= w);  // the dword after the lane's own is not a neighbour's
     for (int r0 = y0 - 3; r0 < r_end; r0 += 6) {
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const uint32_t acc = dot2(V[(ph + 1) % 6][k], C01, dot2(V[(ph + 3) % 6][k], C23, dot2(V[(ph + 5) % 6][k], C45, 18u * hz[k] + 32768u)));
-                    packed |= (acc >> 16) << (8 * k);
+                    packed |= (ROUNDED ? min(acc >> 16, 255u) : (acc >> 16)) << (8 * k);  // taps summing to 257 can reach 256: saturate_cast
                     V[ph][k] = prev[k] | (hz[k] << 16);
                     prev[k] = hz[k];
                 }
@@ -637,7 +643,7 @@ void launch_compact(const FastCell* cells, const int* level_cell_begin, const in
                        ncells, slab, slab_img_stride, dense, level_dense_off, level_counts, nlevels);
 }
 
-void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, hipStream_t st) {
+void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, bool rounded_taps, hipStream_t st) {
     BlurWork wk{};
     wk.nlevels = nlevels; wk.nimg = nimg;
     int total = 0;
@@ -649,7 +655,8 @@ void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, 
         total += wk.nsx[l] * wk.ncy[l] * nimg;
     }
     for (int l = nlevels; l <= kMaxLevels; ++l) wk.first_block[l] = total;
-    if (total) TC2LI_LAUNCH(k_blur7_strips, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
+    if (total && rounded_taps) TC2LI_LAUNCH(k_blur7_strips<true>, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
+    else if (total) TC2LI_LAUNCH(k_blur7_strips<false>, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
 }
 
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,

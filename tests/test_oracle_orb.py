@@ -107,12 +107,17 @@ def test_ctor_tables(oracle):
     assert scale[0] == 1.0 and abs(scale[7] - 1.2 ** 7) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["orb_a", "orb_b"])
+@pytest.mark.parametrize("name", ["orb_a", "orb_b", "orb_gauss_rounded"])
 def test_oracle_matches_golden(oracle, golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     nf, ini, mn = [int(v) for v in g["params"]]
     o = oracle.OrbOracle(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
-    mono, kps, desc = o.extract(g["image"])
+    oracle.set_gauss_variant("rounded" if name == "orb_gauss_rounded" else "error-diffused")
+    try:
+        mono, kps, desc = o.extract(g["image"])
+        blurred3 = o.blurred(3)
+    finally:
+        oracle.set_gauss_variant("error-diffused")
     assert mono == int(g["mono"])
     kp = g["keypoints"]
     for i, f in enumerate(("x", "y", "size", "angle", "response")):
@@ -120,7 +125,7 @@ def test_oracle_matches_golden(oracle, golden_dir, name):
     assert np.array_equal(kps["octave"], kp[:, 5].astype(np.int32))
     assert np.array_equal(desc, g["descriptors"])
     assert np.array_equal(o.level(7), g["level7"])
-    assert np.array_equal(o.blurred(3), g["blurred3"])
+    assert np.array_equal(blurred3, g["blurred3"])
 
 
 def test_orb_structure(oracle, synthetic):
@@ -140,3 +145,55 @@ def test_orb_structure(oracle, synthetic):
     assert o.extract(np.zeros((0, 0), np.uint8))[0] == -1
     # a flat image has no corners at all
     assert len(o.extract(np.full((240, 320), 90, np.uint8))[1]) == 0
+
+
+def test_gaussian_variants(oracle, golden_dir):
+    """The two candidate 8.8 kernels of cv::GaussianBlur(7 x 7, sigma 2) on 8-bit images (which one OpenCV 4.2 uses cannot be checked here):
+    both follow from exp(-x^2 / 8) / sum scaled by 256 -- per-tap rounding gives {18, 34, 49, 55} (sum 257), spreading the rounding error
+    so that the sum stays 256 gives {18, 34, 48, 56}.  The second is (257 / 256)^2 brighter: up to two grey levels; keypoints do not depend on the blur."""
+    w = np.exp(-np.arange(-3, 4) ** 2 / 8.0)
+    w = 256 * w / w.sum()
+    assert np.rint(w).astype(int).tolist() == [18, 34, 49, 55, 49, 34, 18]
+    err, ed = 0.0, []
+    for v in w[:4]:  # error diffusion from the border towards the centre
+        q = np.floor(v + err + 0.5)
+        err += v - q
+        ed.append(int(q))
+    assert ed == [18, 34, 48, 56] and 2 * sum(ed[:3]) + ed[3] == 256
+    a, r = np.load(os.path.join(golden_dir, "orb_a.npz")), np.load(os.path.join(golden_dir, "orb_gauss_rounded.npz"))
+    assert np.array_equal(a["keypoints"], r["keypoints"]) and np.array_equal(a["level7"], r["level7"])
+    d = a["blurred3"].astype(int) - r["blurred3"].astype(int)
+    assert 1 <= np.abs(d).max() <= 2 and (d != 0).mean() > 0.05 and d.mean() < 0
+    bits = np.unpackbits(a["descriptors"] ^ r["descriptors"], axis=1).sum(1)
+    assert 0 < bits.mean() < 12  # a few of the 256 comparisons flip per descriptor
+    # float64 separable Gaussian on the same image: each variant stays within one grey level of it
+    img = a["image"].astype(np.float64)
+    for name in ("error-diffused", "rounded"):
+        oracle.set_gauss_variant(name)
+        try:
+            got = oracle.gaussian_blur7(a["image"]).astype(np.float64)
+        finally:
+            oracle.set_gauss_variant("error-diffused")
+        k = np.exp(-np.arange(-3, 4) ** 2 / 8.0); k /= k.sum()
+        pad = np.pad(img, 3, mode="reflect")
+        hz = sum(k[i] * pad[:, i:i + img.shape[1]] for i in range(7))
+        ref = sum(k[i] * hz[i:i + img.shape[0]] for i in range(7))
+        assert np.abs(got - ref).max() <= (1.0 if name == "error-diffused" else 2.6)
+
+
+def test_torch_crosscheck(oracle, golden_dir):
+    """The oracle's fixed-point restatements against PyTorch's float operators on the same inputs (tools/make_golden_torch_crosscheck.py):
+    resize within one grey level (11-bit weights, two roundings), blur within one grey level, fastAtan2 within 0.3 degrees."""
+    g = np.load(os.path.join(golden_dir, "torch_crosscheck.npz"))
+    img = g["image"]
+    for k in range(3):
+        w, h = [int(v) for v in g["resize_size_%d" % k]]
+        got = oracle.resize_linear(img, w, h).astype(np.float64)
+        ref = g["resize_%d" % k].astype(np.float64)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1.0 and np.abs(got - ref).mean() < 0.3
+    got = oracle.gaussian_blur7(img).astype(np.float64)
+    assert np.abs(got - g["blur"]).max() <= 1.0 and np.abs(got - g["blur"]).mean() < 0.3
+    a = np.array([oracle.fast_atan2(float(y), float(x)) for y, x in zip(g["atan_y"], g["atan_x"])])
+    d = np.abs(a - g["atan_deg"])
+    d = np.minimum(d, 360 - d)
+    assert d.max() < 0.3

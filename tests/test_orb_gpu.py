@@ -126,6 +126,27 @@ def test_golden_vectors(pkg, golden_dir, name):
     e.close()
 
 
+def test_gaussian_rounded_taps_switch(pkg, golden_dir, monkeypatch):
+    """TC2LI_GAUSS_TAPS=rounded at creation selects the per-tap rounded 8.8 Gaussian: the product then reproduces the oracle's second
+    golden file (descriptors and blurred level bit for bit); without it, the first."""
+    g = np.load(os.path.join(golden_dir, "orb_gauss_rounded.npz"))
+    nf, ini, mn = [int(v) for v in g["params"]]
+    img = g["image"]
+    monkeypatch.setenv("TC2LI_GAUSS_TAPS", "rounded")
+    e = pkg.OrbExtractor(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn, max_width=img.shape[1], max_height=img.shape[0], max_images=1)
+    monkeypatch.delenv("TC2LI_GAUSS_TAPS")
+    mono, kps, desc = e.extract(img)
+    assert mono == int(g["mono"]) and np.array_equal(desc, g["descriptors"]) and np.array_equal(e.blurred_level(0, 3), g["blurred3"])
+    e.close()
+    # a saturated image: with taps summing to 257 the result is clamped at 255
+    monkeypatch.setenv("TC2LI_GAUSS_TAPS", "rounded")
+    e = pkg.OrbExtractor(nfeatures=100, max_width=320, max_height=200, max_images=1)
+    monkeypatch.delenv("TC2LI_GAUSS_TAPS")
+    e.extract(np.full((200, 320), 255, np.uint8))
+    assert np.all(e.blurred_level(0, 0) == 255)
+    e.close()
+
+
 def test_batch_device_resident(pkg, oracle, synthetic):
     """Batched entry point on images resident in HBM (torch is only the allocator here)."""
     import torch

@@ -21,7 +21,9 @@ cases = [
     ("orb_a", 11, (100, 60, 400, 240), 500, 20, 7),
     ("orb_b", 12, (500, 100, 331, 201), 300, 12, 7),
 ]
+cases.append(("orb_gauss_rounded", 11, (100, 60, 400, 240), 500, 20, 7))  # orb_a under the alternative Gaussian taps (oracle/cv_restate.hpp)
 for name, seed, (x0, y0, w, h), nf, ini, mn in cases:
+    pyoracle.set_gauss_variant("rounded" if name == "orb_gauss_rounded" else "error-diffused")
     left, _ = synthetic.stereo_pair(seed)
     img = np.ascontiguousarray(left[y0:y0 + h, x0:x0 + w])
     o = pyoracle.OrbOracle(nfeatures=nf, ini_th_fast=ini, min_th_fast=mn)
@@ -32,3 +34,4 @@ for name, seed, (x0, y0, w, h), nf, ini, mn in cases:
                         mono=np.int32(mono), keypoints=kp_arr, descriptors=desc,
                         level7=o.level(7), blurred3=o.blurred(3))
     print(name, img.shape, mono, len(kps))
+pyoracle.set_gauss_variant("error-diffused")
