@@ -96,14 +96,15 @@ int tc2li_orb_download_candidates(tc2li_orb* orb, int image_index, int level, fl
 
 /* Times of the last batch call in milliseconds.  Device stages are measured with HIP events on the stream each
  * kernel is launched on: [0] pyramid (nlevels-1 resize launches), [1] FAST cells kernel, [2] candidate compaction
- * kernel, [3] blur (nlevels launches), [4] orientation+descriptor kernel; host wall clock: [5] quadtree stage,
- * [6] call entry to quadtree start (device stage 1 + candidate download), [7] whole call.
+ * kernel, [3] blur (nlevels launches), [4] orientation+descriptor kernel, [5] keypoint distribution (quadtree + gather kernels);
+ * host wall clock: [6] call entry until everything is queued, [7] whole call.
  * With profiling enabled every kernel is issued on the caller's stream (no overlap of blur with FAST), so that
  * [0]..[4] are clean per-stage durations. */
 int tc2li_orb_set_profiling(tc2li_orb* orb, int enabled);
 int tc2li_orb_last_timings(const tc2li_orb* orb, float ms[8]);
-/* A batch call is pipelined over chunks of images (the host quadtree of one chunk runs while the device works on the others): every
- * device stage is launched once per chunk, and [0]..[4] above are the sums over the chunks.  Returns the chunk count of the last call. */
+/* A batch call is queued in chunks of images (the blur of one chunk runs on a second stream beside the keypoint distribution of the
+ * chunk before): every device stage is launched once per chunk, and [0]..[5] above are the sums over the chunks.  Returns the chunk
+ * count of the last call. */
 int tc2li_orb_last_chunks(const tc2li_orb* orb);
 
 /* ------------------------------------------------------------------------------------------------
@@ -745,6 +746,11 @@ int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar
  * the reference's output order and returns their number. */
 int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
                                    float* out_xyr, int capacity);
+/* The same distribution as one job of the device kernel the extractor runs (k_quadtree, one workgroup of `threads` = 256 / 512 / 1024
+ * lanes; 0 = the extractor's choice): same arguments, same result.  The extractor itself calls the kernel on the device-resident
+ * candidates of a whole batch; this entry exists to check the kernel on arbitrary candidate sets. */
+int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target, float* out_xyr,
+                                     int capacity, int threads);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer::PoseInertialOptimizationLastKeyFrame (SF/src/Optimizer.cc:2469-2852) and PoseInertialOptimizationLastFrame

@@ -32,6 +32,7 @@ from .capi import (  # noqa: F401
     stereo_match_batch,
     device_count,
     distribute_quadtree_host,
+    distribute_quadtree_device,
     exported_symbols,
     lib,
 )

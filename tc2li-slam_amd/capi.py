@@ -65,6 +65,7 @@ def lib():
     L.tc2li_orb_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.tc2li_host_distribute_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_int]
+    L.tc2li_device_distribute_quadtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.tc2li_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_stereo_match_batch.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -187,6 +188,15 @@ def distribute_quadtree_host(xyr, min_x, max_x, min_y, max_y, n_target):
     out = np.empty((max(len(xyr), 1), 3), np.float32)
     n = _check(lib().tc2li_host_distribute_quadtree(xyr.ctypes.data, len(xyr), min_x, max_x, min_y, max_y, n_target,
                                                     out.ctypes.data, len(out)))
+    return out[:n].copy()
+
+
+def distribute_quadtree_device(xyr, min_x, max_x, min_y, max_y, n_target, threads=0):
+    """One job of the extractor's keypoint-distribution kernel (k_quadtree) on the given candidates."""
+    xyr = np.ascontiguousarray(xyr, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((max(len(xyr), n_target + 16, 1), 3), np.float32)
+    n = _check(lib().tc2li_device_distribute_quadtree(xyr.ctypes.data, len(xyr), min_x, max_x, min_y, max_y, n_target, out.ctypes.data, len(out),
+                                                      threads))
     return out[:n].copy()
 
 

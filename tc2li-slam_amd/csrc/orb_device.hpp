@@ -32,6 +32,22 @@ struct DevKeypoint {
     uint32_t img_level;  // image << 8 | level
 };
 
+// One (image, level) keypoint distribution for k_quadtree (ORBextractor::DistributeOctTree, SF/src/ORBextractor.cc:529-753).
+struct QuadJob {
+    int64_t cand_off;     // first candidate of the level's region in the dense candidate array
+    int64_t scratch_off;  // byte offset of the job's work space
+    int64_t out_off;      // first slot of the job's picks
+    int32_t count_idx;    // image * nlevels + level: index of the candidate count, and of the pick count
+    int32_t out_cap, max_keys, max_nodes;
+    int32_t min_x, max_x, min_y, max_y, n_target, pad_;
+};
+size_t quadtree_scratch_bytes(int max_keys, int max_nodes);
+void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
+                     int32_t* picked_count, int32_t* status, int threads, hipStream_t st);
+void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const int32_t* picked_count, const int32_t* level_counts, int first_image, int n_images,
+                            int nlevels, int kp_stride, DevKeypoint* kps, DevKeypoint* kps_host, int32_t* n_kp, int32_t* n_kp_host, int32_t* level_counts_host,
+                            int32_t* status, hipStream_t st);
+
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st);
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
@@ -43,8 +59,9 @@ void launch_compact(const FastCell* cells, const int* level_cell_begin, const in
 void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, int nimg, bool rounded_taps, hipStream_t st);
 struct MatchKey;
 struct ScaleTable;
-void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
-                            int nkp, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st);
+// Keypoint slots: image i owns [i * kp_stride, i * kp_stride + n_kp[i]) of kps and of every output array; images first_image .. + n_images.
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps, const int32_t* n_kp,
+                            int first_image, int n_images, int kp_stride, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st);
 hipError_t upload_umax(const int* umax16);
 
 }  // namespace tc2li

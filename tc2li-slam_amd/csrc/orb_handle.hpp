@@ -48,30 +48,35 @@ struct tc2li_orb {
     tc2li::DevBuf<uint32_t> d_slab;
     // pinned, device-mapped host buffers: the compaction kernel writes candidates and counts straight into them and
     // the descriptor kernel reads keypoints from / writes angles and descriptors to them (no staging copies)
-    tc2li::PinnedBuf<int> h_level_counts;
-    tc2li::PinnedBuf<uint32_t> h_dense;
+    // keypoint distribution on the device (k_quadtree): dense candidates per (image, level), one job each, its work space and picks;
+    // the keypoints of image i occupy kp_cap_per_image slots from i * kp_cap_per_image in d_kps and in every per-keypoint array
+    tc2li::DevBuf<uint32_t> d_dense, d_picked;
+    tc2li::DevBuf<int> d_level_counts, d_picked_count, d_nkp, d_status;
+    tc2li::DevBuf<tc2li::QuadJob> d_jobs;
+    tc2li::DevBuf<uint8_t> d_qscratch;
+    tc2li::DevBuf<tc2li::DevKeypoint> d_kps;
+    tc2li::PinnedBuf<int> h_level_counts, h_nkp, h_status;
     tc2li::PinnedBuf<tc2li::DevKeypoint> h_kps;
     tc2li::PinnedBuf<float> h_angles;
     tc2li::PinnedBuf<uint8_t> h_desc;
     // device-resident copy of the last call's features for the matchers (valid for lapping area {0,0})
     tc2li::DevBuf<tc2li::MatchKey> d_mkeys;
     tc2li::DevBuf<uint8_t> d_desc;
-    std::vector<int> last_kp_off;  // [nimg + 1] offsets of each image's keypoints in d_mkeys / d_desc
+    std::vector<int> last_kp_off, last_kp_cnt;  // [nimg] first slot and number of each image's keypoints in d_mkeys / d_desc
     bool last_plain_order = false;  // true when the device order equals the output order
     tc2li::ScaleTable scale_tab{};
 
     hipStream_t side_stream = nullptr;
     // per chunk of a batch call (tc2li_orb_extract_batch pipelines chunks of images): 0/1 pyramid, 8/3 FAST, 3/2 compaction, 4/5 blur, 6/7 descriptors
-    static constexpr int kMaxChunks = 4, kEvPerChunk = 9;
+    // 9/10 keypoint distribution
+    static constexpr int kMaxChunks = 4, kEvPerChunk = 11;
     hipEvent_t ev[kMaxChunks * kEvPerChunk] = {};
     int last_chunks = 1;
     bool profiling = false;  // serialise all kernels on the caller's stream so that per-kernel event times are clean
     tc2li::LevelTable raw_tab{}, blur_tab{};
     int last_nimg = 0;
     std::vector<int> last_level_counts;  // [nimg][nlevels] candidates
-    std::vector<size_t> last_level_off;  // offsets into h_dense
     float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<tc2li::QuadtreeScratch> scratch;
 
     ~tc2li_orb() {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);

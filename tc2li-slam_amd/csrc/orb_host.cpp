@@ -1,8 +1,8 @@
 // Host orchestration of the gfx950 ORB extractor behind the C ABI of include/tc2li_hip.h.
 // Mirrors TC2LI_SLAM::ORBextractor (SF/src/ORBextractor.cc): ctor tables (:383-443), ComputePyramid (:1143),
-// ComputeKeyPointsOctTree (:755) and operator() (:1060).  The only stage kept on the host is the quadtree
-// distribution (:529-753), which is sequential and order-defining; it runs on the worker pool, one task per
-// (image, level), while the GPU blurs the levels on a second stream.
+// ComputeKeyPointsOctTree (:755) and operator() (:1060).  Every stage is a kernel, the quadtree distribution (:529-753) included
+// (quadtree_kernels.hip: one workgroup per (image, level), the reference's list order reproduced); the host queues the whole call,
+// waits once and assembles the caller's arrays in the reference's output order.  The blur runs on a second stream.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -130,7 +130,36 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     }
     o->slab_per_image = align_up(std::max(slab, 1), 64);
     o->kp_cap_per_image = o->prm.nfeatures + 4 * L;
-    for (int l = 0; l < L; ++l) o->kp_cap_per_image += 0;
+    // one distribution job per (image, level): the work space is sized for the level's candidate capacity, the node arrays for the
+    // largest list the walk can reach (N + 3 after the closing division, or the 4 * nIni children of the first round)
+    std::vector<QuadJob> jobs((size_t)M * L);
+    size_t scratch_per_image = 0, picked_per_image = 0;
+    {
+        std::vector<size_t> scratch_off(L), picked_off(L);
+        std::vector<int> max_keys(L), max_nodes(L);
+        for (int l = 0; l < L; ++l) {
+            const LevelGeom& g = o->geom[l];
+            max_keys[l] = (l + 1 < L ? o->geom[l + 1].dense_off : slab) - g.dense_off;
+            if (max_keys[l] >= (1 << 21)) { set_error("level %d holds more FAST candidates than the distribution kernel packs", l); return TC2LI_ERR_INVALID; }
+            const int bw = g.max_bx - g.min_bx, bh = g.max_by - g.min_by;
+            const int n_ini = bh > 0 && bw > 0 ? (int)std::round(static_cast<float>(bw) / bh) : 0;
+            max_nodes[l] = std::max(o->features_per_level[l] + 3, 4 * std::max(n_ini, 1)) + 8;
+            scratch_off[l] = scratch_per_image; scratch_per_image += quadtree_scratch_bytes(max_keys[l], max_nodes[l]);
+            picked_off[l] = picked_per_image; picked_per_image += (size_t)max_nodes[l];
+        }
+        for (int i = 0; i < M; ++i)
+            for (int l = 0; l < L; ++l) {
+                const LevelGeom& g = o->geom[l];
+                QuadJob& j = jobs[(size_t)i * L + l];
+                j.cand_off = (int64_t)i * o->slab_per_image + g.dense_off;
+                j.scratch_off = (int64_t)((size_t)i * scratch_per_image + scratch_off[l]);
+                j.out_off = (int64_t)((size_t)i * picked_per_image + picked_off[l]);
+                j.count_idx = i * L + l;
+                j.out_cap = max_nodes[l]; j.max_keys = max_keys[l]; j.max_nodes = max_nodes[l];
+                j.min_x = g.min_bx; j.max_x = g.max_bx; j.min_y = g.min_by; j.max_y = g.max_by;
+                j.n_target = o->features_per_level[l]; j.pad_ = 0;
+            }
+    }
 
     // device allocations
     TC2LI_HIP_CHECK(o->d_level0.alloc((size_t)M * o->geom[0].img_stride));
@@ -152,7 +181,17 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     TC2LI_HIP_CHECK(o->d_level_dense_off.upload(level_dense_off));
     TC2LI_HIP_CHECK(o->d_cell_counts.alloc((size_t)M * std::max<size_t>(o->cells.size(), 1)));
     TC2LI_HIP_CHECK(o->d_slab.alloc((size_t)M * o->slab_per_image));
-    TC2LI_HIP_CHECK(o->h_dense.alloc((size_t)M * o->slab_per_image));
+    TC2LI_HIP_CHECK(o->d_dense.alloc((size_t)M * o->slab_per_image));
+    TC2LI_HIP_CHECK(o->d_jobs.upload(jobs));
+    TC2LI_HIP_CHECK(o->d_qscratch.alloc((size_t)M * scratch_per_image));
+    TC2LI_HIP_CHECK(o->d_picked.alloc((size_t)M * picked_per_image));
+    TC2LI_HIP_CHECK(o->d_picked_count.alloc((size_t)M * L));
+    TC2LI_HIP_CHECK(o->d_level_counts.alloc((size_t)M * L));
+    TC2LI_HIP_CHECK(o->d_kps.alloc((size_t)M * o->kp_cap_per_image));
+    TC2LI_HIP_CHECK(o->d_nkp.alloc((size_t)M));
+    TC2LI_HIP_CHECK(o->d_status.alloc(1));
+    TC2LI_HIP_CHECK(o->h_nkp.alloc((size_t)M));
+    TC2LI_HIP_CHECK(o->h_status.alloc(1));
     TC2LI_HIP_CHECK(o->d_mkeys.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->d_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
     TC2LI_HIP_CHECK(o->h_level_counts.alloc((size_t)M * L));
@@ -300,18 +339,21 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     }
     o->last_nimg = M;
 
-    // The call is a pipeline over chunks of images: stage 1 (pyramid, FAST, compaction on the main stream; blur on the side stream)
-    // of every chunk is queued at once; the host then takes the chunks in order -- quadtree distribution (stage 2) as soon as the
-    // chunk's candidates are in the pinned buffer, then its orientation + descriptor launch (stage 3) -- so that the GPU works on
-    // the later chunks and on the descriptors while the host distributes.  With profiling on there is one chunk and every kernel
-    // is on the caller's stream, which gives clean per-stage durations.
+    // The call is queued chunk by chunk (pyramid, FAST, compaction, keypoint distribution, then orientation + descriptors once the
+    // chunk's blur -- on the side stream -- is done), so that the tail of one chunk's distribution kernel (a few long level-0 jobs)
+    // overlaps the next chunk's blur; the host waits once, at the end.  With profiling on there is one chunk and every kernel is on
+    // the caller's stream, which gives clean per-stage durations.
     static const int kChunkEnv = getenv("TC2LI_ORB_CHUNKS") ? atoi(getenv("TC2LI_ORB_CHUNKS")) : 0;
+    static const int kQuadThreads = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 512;
     const int want_chunks = kChunkEnv > 0 ? kChunkEnv : (M >= 64 ? 4 : (M >= 16 ? 2 : 1));
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     o->last_chunks = n_chunks;
     hipStream_t blur_st = o->profiling ? st : o->side_stream;
     auto EV = [&](int chunk, int k) { return o->ev[chunk * tc2li_orb::kEvPerChunk + k]; };
     auto chunk_begin = [&](int c) { return (int)((long)M * c / n_chunks); };
+    const int kp_stride = o->kp_cap_per_image;
+    TC2LI_HIP_CHECK(hipMemsetAsync(o->d_status.p, 0, sizeof(int), st));
+    if (ncells == 0) TC2LI_HIP_CHECK(hipMemsetAsync(o->d_level_counts.p, 0, (size_t)M * L * sizeof(int), st));
     for (int c = 0; c < n_chunks; ++c) {
         const int i0 = chunk_begin(c), m = chunk_begin(c + 1) - i0;
         LevelTable craw = raw, cblur = blur;  // this chunk's images
@@ -335,79 +377,46 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
             TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
             launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p + (size_t)i0 * ncells, ncells,
                            o->d_slab.p + (size_t)i0 * o->slab_per_image, (size_t)o->slab_per_image,
-                           o->h_dense.p + (size_t)i0 * o->slab_per_image, o->d_level_dense_off.p, o->h_level_counts.p + (size_t)i0 * L, L, m, st);
+                           o->d_dense.p + (size_t)i0 * o->slab_per_image, o->d_level_dense_off.p, o->d_level_counts.p + (size_t)i0 * L, L, m, st);
         } else {
             TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
         }
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 2), st));
-    }
-    TC2LI_HIP_CHECK(hipGetLastError());
-
-    o->last_level_counts.assign((size_t)M * L, 0);
-    o->last_level_off.assign((size_t)M * L + 1, 0);
-    for (int i = 0; i < M; ++i)
-        for (int l = 0; l < L; ++l) o->last_level_off[i * L + l] = (size_t)i * o->slab_per_image + o->geom[l].dense_off;
-
-    WorkerPool& pool = global_pool();
-    if ((int)o->scratch.size() < M * L) o->scratch.resize((size_t)M * L);
-    std::vector<std::vector<int32_t>> picked((size_t)M * L);
-    std::vector<int> img_kp_off(M + 1, 0);
-    float host_ms = 0;
-    auto fail_after_sync = [&](int code) { (void)stream_wait_blocking(st); (void)hipStreamSynchronize(blur_st); return code; };
-    std::chrono::steady_clock::time_point t_first_chunk{};
-    for (int c = 0; c < n_chunks; ++c) {
-        const int i0 = chunk_begin(c), i1 = chunk_begin(c + 1), m = i1 - i0;
-        // candidates of the chunk's (image, level) lists are visible in the pinned buffer once its compaction has run
-        TC2LI_HIP_CHECK(hipEventSynchronize(EV(c, 2)));
-        if (c == 0) t_first_chunk = std::chrono::steady_clock::now();
-        if (ncells > 0) memcpy(o->last_level_counts.data() + (size_t)i0 * L, o->h_level_counts.p + (size_t)i0 * L, (size_t)m * L * sizeof(int));
-        // ---- stage 2 (host): quadtree distribution per (image, level) ----
-        const auto t0 = std::chrono::steady_clock::now();
-        pool.parallel_for(m * L, [&](int t) {
-            const int task = i0 * L + t, l = task % L;
-            const LevelGeom& g = o->geom[l];
-            picked[task].clear();
-            distribute_quadtree(o->h_dense.p + o->last_level_off[task], o->last_level_counts[task], g.min_bx, g.max_bx,
-                                g.min_by, g.max_by, o->features_per_level[l], o->scratch[task], picked[task]);
-        });
-        for (int i = i0; i < i1; ++i) {
-            int n = 0;
-            for (int l = 0; l < L; ++l) n += (int)picked[i * L + l].size();
-            if (n > o->kp_cap_per_image) { set_error("keypoint capacity exceeded"); return fail_after_sync(TC2LI_ERR_CAPACITY); }
-            img_kp_off[i + 1] = img_kp_off[i] + n;
-        }
-        for (int i = i0; i < i1; ++i) {
-            DevKeypoint* dst = o->h_kps.p + img_kp_off[i];
-            for (int l = 0; l < L; ++l) {
-                const uint32_t* cand = o->h_dense.p + o->last_level_off[i * L + l];
-                for (int32_t k : picked[i * L + l]) {
-                    const uint32_t cc = cand[k];
-                    const uint32_t x = ((cc >> 8) & 0xfff) + kMinBorder, y = (cc >> 20) + kMinBorder;  // :856-857
-                    *dst++ = DevKeypoint{(y << 20) | (x << 8) | (cc & 0xff), ((uint32_t)i << 8) | (uint32_t)l};
-                }
-            }
-        }
-        host_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        // ---- stage 3: orientation + descriptors of the chunk's keypoints (they index the whole batch's level tables) ----
-        const int k0 = img_kp_off[i0], nk = img_kp_off[i1] - k0;
+        // ---- stage 2: keypoint distribution per (image, level), and the per-image keypoint lists ----
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 9), st));
+        launch_quadtree(o->d_jobs.p, i0 * L, m * L, o->d_dense.p, o->d_level_counts.p, o->d_qscratch.p, o->d_picked.p, o->d_picked_count.p, o->d_status.p,
+                        kQuadThreads, st);
+        launch_quadtree_gather(o->d_jobs.p, o->d_picked.p, o->d_picked_count.p, o->d_level_counts.p, i0, m, L, kp_stride, o->d_kps.p, o->h_kps.p, o->d_nkp.p,
+                               o->h_nkp.p, o->h_level_counts.p, o->d_status.p, st);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 10), st));
+        // ---- stage 3: orientation + descriptors of the chunk's keypoints ----
         TC2LI_HIP_CHECK(hipStreamWaitEvent(st, EV(c, 5), 0));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 6), st));
-        if (nk > 0)
-            launch_orient_describe(raw, blur, o->scale_tab, o->h_kps.p + k0, nk, o->h_angles.p + k0, o->h_desc.p + (size_t)32 * k0, o->d_mkeys.p + k0,
-                                   o->d_desc.p + (size_t)32 * k0, st);
+        launch_orient_describe(raw, blur, o->scale_tab, o->d_kps.p, o->d_nkp.p, i0, m, kp_stride, o->h_angles.p, o->h_desc.p, o->d_mkeys.p, o->d_desc.p, st);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 7), st));
-        TC2LI_HIP_CHECK(hipGetLastError());
     }
-    const int nkp_total = img_kp_off[M];
-    (void)nkp_total;
-    o->last_kp_off = img_kp_off;
-    o->last_plain_order = true;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_status.p, o->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipGetLastError());
+    WorkerPool& pool = global_pool();
+    const auto t_queued = std::chrono::steady_clock::now();
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    if (o->h_status.p[0] != 0) {
+        static const char* const what[] = {"", "more candidates than the level's region holds", "more initial nodes than the node arrays hold",
+                                           "the node list outgrew its arrays", "more keypoints than the level's pick region holds", "keypoint capacity exceeded"};
+        set_error("keypoint distribution: %s", what[std::min(std::max(o->h_status.p[0], 0), 5)]);
+        return TC2LI_ERR_CAPACITY;
+    }
+    o->last_level_counts.assign(o->h_level_counts.p, o->h_level_counts.p + (size_t)M * L);
+    o->last_kp_off.resize(M); o->last_kp_cnt.resize(M);
+    for (int i = 0; i < M; ++i) { o->last_kp_off[i] = i * kp_stride; o->last_kp_cnt[i] = o->h_nkp.p[i]; }
+    o->last_plain_order = true;
+    const std::vector<int>& img_kp_off = o->last_kp_off;
+    const std::vector<int>& img_kp_cnt = o->last_kp_cnt;
 
     // ---- assemble in the reference's output order (SF/src/ORBextractor.cc:1093-1137) -----------------------
     std::atomic<int> status{TC2LI_OK};
     pool.parallel_for(M, [&](int i) {
-        const int n = img_kp_off[i + 1] - img_kp_off[i];
+        const int n = img_kp_cnt[i];
         n_keypoints[i] = n;
         if (n > capacity) { status = TC2LI_ERR_CAPACITY; if (mono_index) mono_index[i] = -1; return; }
         tc2li_keypoint* kout = keypoints + (size_t)i * capacity;
@@ -441,8 +450,9 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         o->timings[3] += elapsed(EV(c, 4), EV(c, 5));
         o->timings[4] += elapsed(EV(c, 6), EV(c, 7));
     }
-    o->timings[5] = host_ms;
-    o->timings[6] = std::chrono::duration<float, std::milli>(t_first_chunk - t_begin).count();
+    o->timings[5] = 0;
+    for (int c = 0; c < n_chunks; ++c) o->timings[5] += elapsed(EV(c, 9), EV(c, 10));
+    o->timings[6] = std::chrono::duration<float, std::milli>(t_queued - t_begin).count();
     o->timings[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (status.load() != TC2LI_OK) { set_error("keypoint capacity %d too small", capacity); return status.load(); }
     return n_images;
@@ -495,7 +505,9 @@ int tc2li_orb_download_candidates(tc2li_orb* o, int image_index, int level, floa
     const int n = o->last_level_counts[image_index * L + level];
     if (!xyr) return n;
     if (n > capacity) return TC2LI_ERR_CAPACITY;
-    const uint32_t* c = o->h_dense.p + o->last_level_off[image_index * L + level];
+    std::vector<uint32_t> c((size_t)std::max(n, 1));
+    TC2LI_HIP_CHECK(copy_sync(c.data(), o->d_dense.p + (size_t)image_index * o->slab_per_image + o->geom[level].dense_off, (size_t)n * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, private_stream()));
     for (int k = 0; k < n; ++k) {
         xyr[3 * k] = (float)(((c[k] >> 8) & 0xfff) + kMinBorder);
         xyr[3 * k + 1] = (float)((c[k] >> 20) + kMinBorder);
@@ -519,6 +531,53 @@ int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x
     if ((int)picked.size() > capacity) return TC2LI_ERR_CAPACITY;
     for (size_t k = 0; k < picked.size(); ++k) memcpy(out_xyr + 3 * k, xyr + 3 * picked[k], 3 * sizeof(float));
     return (int)picked.size();
+}
+
+int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target, float* out_xyr, int capacity,
+                                     int threads) {
+    if (!xyr || !out_xyr || n < 0 || n >= (1 << 21) || n_target < 0 || capacity < 0) return TC2LI_ERR_INVALID;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    std::vector<uint32_t> cand((size_t)std::max(n, 1));
+    for (int i = 0; i < n; ++i) {
+        const int x = (int)xyr[3 * i], y = (int)xyr[3 * i + 1], r = (int)xyr[3 * i + 2];
+        if (x < 0 || x > 4095 || y < 0 || y > 4095 || r < 0 || r > 255) return TC2LI_ERR_INVALID;
+        cand[i] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)r;
+    }
+    const int bw = max_x - min_x, bh = max_y - min_y;
+    const int n_ini = bh > 0 && bw > 0 ? (int)std::round(static_cast<float>(bw) / bh) : 0;
+    QuadJob job{};
+    job.max_keys = std::max(n, 1);
+    job.max_nodes = std::max(n_target + 3, 4 * std::max(n_ini, 1)) + 8;
+    job.out_cap = job.max_nodes;
+    job.min_x = min_x; job.max_x = max_x; job.min_y = min_y; job.max_y = max_y; job.n_target = n_target;
+    DevBuf<uint32_t> d_cand, d_picked;
+    DevBuf<int> d_counts;  // [0] candidates, [1] picks... the job's count_idx is 0 for both arrays
+    DevBuf<int> d_pick_count, d_status;
+    DevBuf<QuadJob> d_job;
+    DevBuf<uint8_t> d_scratch;
+    hipStream_t ps = private_stream();
+    TC2LI_HIP_CHECK(d_cand.upload(cand));
+    TC2LI_HIP_CHECK(d_counts.upload(std::vector<int>{n}));
+    TC2LI_HIP_CHECK(d_pick_count.upload(std::vector<int>{0}));
+    TC2LI_HIP_CHECK(d_status.upload(std::vector<int>{0}));
+    TC2LI_HIP_CHECK(d_job.upload(std::vector<QuadJob>{job}));
+    TC2LI_HIP_CHECK(d_scratch.alloc(quadtree_scratch_bytes(job.max_keys, job.max_nodes)));
+    TC2LI_HIP_CHECK(d_picked.alloc((size_t)job.out_cap));
+    launch_quadtree(d_job.p, 0, 1, d_cand.p, d_counts.p, d_scratch.p, d_picked.p, d_pick_count.p, d_status.p, threads > 0 ? threads : 512, ps);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    int count = 0, status = 0;
+    TC2LI_HIP_CHECK(copy_sync(&count, d_pick_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    TC2LI_HIP_CHECK(copy_sync(&status, d_status.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    if (status != 0) { set_error("keypoint distribution kernel: status %d", status); return TC2LI_ERR_CAPACITY; }
+    if (count > capacity) return TC2LI_ERR_CAPACITY;
+    std::vector<uint32_t> picked((size_t)std::max(count, 1));
+    TC2LI_HIP_CHECK(copy_sync(picked.data(), d_picked.p, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, ps));
+    for (int k = 0; k < count; ++k) {
+        out_xyr[3 * k] = (float)((picked[k] >> 8) & 0xfff);
+        out_xyr[3 * k + 1] = (float)(picked[k] >> 20);
+        out_xyr[3 * k + 2] = (float)(picked[k] & 0xff);
+    }
+    return count;
 }
 
 int tc2li_orb_set_profiling(tc2li_orb* o, int enabled) {

@@ -546,18 +546,22 @@ __constant__ int8_t c_pattern[256 * 4] = {
 __constant__ int c_umax[16];
 
 __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, ScaleTable sc,
-                                                         const DevKeypoint* __restrict__ kps, int nkp,
-                                                         float* __restrict__ angles, uint8_t* __restrict__ desc,
+                                                         const DevKeypoint* __restrict__ kps, const int32_t* __restrict__ n_kp, int first_image,
+                                                         int n_images, int kp_stride, float* __restrict__ angles, uint8_t* __restrict__ desc,
                                                          MatchKey* __restrict__ mkeys, uint8_t* __restrict__ desc_dev) {
     // XCD-contiguous block order (as in k_fast_cells): the keypoints come image by image and level by level, and XCD k works on the
     // k-th eighth of the list, so an image's levels are fetched into ONE L2 instead of all eight (307 MB of HBM reads per 64 k keypoints
     // before, against 90 MB of pyramid levels)
-    const int nblk = (nkp + 7) / 8, per_xcd = (nblk + 7) / 8;
+    // Keypoint slots: image i owns kp_stride of them and fills the first n_kp[i] (counts known on the device only: k_quadtree_gather)
+    const int nslot = n_images * kp_stride, nblk = (nslot + 7) / 8, per_xcd = (nblk + 7) / 8;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= nblk) return;
-    const int g = (logical * 256 + (int)threadIdx.x) >> 5;
+    const int slot = (logical * 256 + (int)threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31;
-    if (g >= nkp) return;
+    if (slot >= nslot) return;
+    const int slot_img = first_image + slot / kp_stride;
+    if (slot % kp_stride >= n_kp[slot_img]) return;
+    const int g = first_image * kp_stride + slot;
     const DevKeypoint kp = kps[g];
     const int level = kp.img_level & 0xff, img = kp.img_level >> 8;
     const int x = (kp.packed >> 8) & 0xfff, y = kp.packed >> 20;
@@ -659,11 +663,12 @@ void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, 
     else if (total) TC2LI_LAUNCH(k_blur7_strips<false>, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
 }
 
-void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps,
-                            int nkp, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st) {
-    if (nkp <= 0) return;
-    TC2LI_LAUNCH(k_orient_describe, dim3((((nkp + 7) / 8 + 7) / 8) * 8), dim3(256), 0, st, raw, blurred, sc, kps, nkp, angles, desc,
-                       mkeys, desc_dev);
+void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps, const int32_t* n_kp,
+                            int first_image, int n_images, int kp_stride, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st) {
+    const long nslot = (long)n_images * kp_stride;
+    if (nslot <= 0) return;
+    TC2LI_LAUNCH(k_orient_describe, dim3((unsigned)((((nslot + 7) / 8 + 7) / 8) * 8)), dim3(256), 0, st, raw, blurred, sc, kps, n_kp, first_image, n_images,
+                 kp_stride, angles, desc, mkeys, desc_dev);
 }
 
 hipError_t upload_umax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }

@@ -31,6 +31,18 @@ __device__ __forceinline__ void block_reduce(double (&v)[kRed], double* s_red /*
     __syncthreads();
 }
 
+// sum of ONE value over the block (the trial pass and the outlier count need nothing else: a 28-value reduction there is wasted latency)
+__device__ __forceinline__ double block_sum(double x, double* s_red, double* s_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (lane == 0) s_red[wave] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) s_out[0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    __syncthreads();
+    return s_out[0];
+}
+
 __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
                                                                  const BaEdge* __restrict__ edges, CameraD cam,
                                                                  double* __restrict__ poses7, uint8_t* __restrict__ outlier,
@@ -136,9 +148,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
                 }
                 __syncthreads();
                 const Se3 Tt = s_trial;
-                double a2[kRed];
-#pragma unroll
-                for (int k = 0; k < kRed; ++k) a2[k] = 0;
+                double chi_trial = 0;
                 for (int i = tid; i < N; i += kPoThreads) {
                     if (out[i]) continue;
                     const BaEdge e = E[i];
@@ -151,9 +161,9 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
                     chi2[i] = c2;
                     double rho0 = c2, rho1 = 1.0;
                     if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
-                    a2[27] += rho0;
+                    chi_trial += rho0;
                 }
-                block_reduce(a2, s_red, s_sum);
+                block_sum(chi_trial, s_red, s_sum + 27);
                 if (tid == 0) {
                     double tempChi = s_sum[27];
                     if (!s_flag[3]) tempChi = 1.7976931348623157e308;
@@ -213,13 +223,7 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
         }
         __syncthreads();
         {
-            // block-wide sum of `bad`
-            double a3[kRed];
-#pragma unroll
-            for (int k = 0; k < kRed; ++k) a3[k] = 0;
-            a3[0] = (double)bad;
-            block_reduce(a3, s_red, s_sum);
-            n_bad_total = (int)s_sum[0];
+            n_bad_total = (int)block_sum((double)bad, s_red, s_sum);
         }
         if (round == 2) robust = false;
         if (N < 10) break;  // optimizer.edges().size() < 10

@@ -1,0 +1,528 @@
+// ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753, ExtractorNode::DivideNode :454-510, compareNodes :512-527) on the
+// device: one workgroup per (image, pyramid level), all of them in one launch.  The reference walks a std::list of nodes and, per
+// node, partitions a std::vector of keypoints -- sequential code whose RESULT ORDER (the list order at the end) defines the keypoint
+// indices downstream.  Here every round of the walk is level-synchronous:
+//   * every key looks up its node and computes its quadrant; ONE prefix sum along the key array over the packed quadrant indicators
+//     (3 x 21 bits in a 64-bit word, the fourth quadrant is the remainder) gives both the populations of the children (difference of
+//     the prefix at the node's two ends) and the place of every key inside its child (difference to the prefix at the node's first
+//     key): keys keep their relative order, as the push_back loop of DivideNode does;
+//   * a prefix sum over the nodes in processing order gives every child its place in the new list -- children are pushed to the
+//     FRONT in the order UL, UR, BL, BR while the walk goes on, so the new list is [children of the last divided node, BR..UL | ... |
+//     children of the first divided node | the nodes that were not divided, in their old order].
+// The closing phase of the reference ("size + 3 * nToExpand > N": divide the largest nodes first until N nodes exist) is the same
+// round with the nodes to divide taken from the back of a list sorted by (population, UL.x).  That sort is std::sort in the reference:
+// not stable, so which of two nodes with equal population and equal UL.x comes first depends on libstdc++'s introsort -- restated
+// here move for move (median-of-three partition, depth limit 2 log2 n with the heap-sort fallback, final insertion sort with the
+// threshold 16), run by one lane on a few hundred records in LDS.
+// The candidate with the largest response of every final node is emitted in list order (:731-752).
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+#pragma clang fp contract(off)
+#include <stdint.h>
+
+#include "orb_device.hpp"
+
+namespace tc2li {
+
+namespace {
+
+struct QNode { int16_t ulx, uly, brx, bry; int32_t begin, count; };  // 16 bytes
+struct QRec { int32_t size, ulx, node; };                            // vSizeAndPointerToNode entry
+constexpr int kSortCap = 1536;                                        // records sorted in LDS (more: in global memory, slowly)
+constexpr unsigned long long kF21 = (1ull << 21) - 1;
+
+__device__ __forceinline__ int q_cx(uint32_t c) { return (int)((c >> 8) & 0xfff); }
+__device__ __forceinline__ int q_cy(uint32_t c) { return (int)(c >> 20); }
+__device__ __forceinline__ int q_cr(uint32_t c) { return (int)(c & 0xff); }
+__device__ __forceinline__ int q_quadrant(const QNode& p, uint32_t c) {
+    const int mx = p.ulx + (int)ceilf((float)(p.brx - p.ulx) / 2), my = p.uly + (int)ceilf((float)(p.bry - p.uly) / 2);
+    return (q_cx(c) < mx ? 0 : 1) + (q_cy(c) < my ? 0 : 2);
+}
+
+// ---- libstdc++ std::sort(first, last, comp) on QRec, comp = (size, ulx) ascending -------------------------------------------
+__device__ __forceinline__ bool rec_less(const QRec& a, const QRec& b) { return a.size != b.size ? a.size < b.size : a.ulx < b.ulx; }
+__device__ __forceinline__ void rec_swap(QRec* v, int a, int b) { const QRec t = v[a]; v[a] = v[b]; v[b] = t; }
+__device__ void std_push_heap(QRec* f, int hole, int top, QRec value) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && rec_less(f[parent], value)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
+    f[hole] = value;
+}
+__device__ void std_adjust_heap(QRec* f, int hole, int len, QRec value) {
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (rec_less(f[second], f[second - 1])) second--;
+        f[hole] = f[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        f[hole] = f[second - 1];
+        hole = second - 1;
+    }
+    std_push_heap(f, hole, top, value);
+}
+__device__ void std_heap_sort(QRec* f, int len) {  // __partial_sort(first, last, last): __make_heap + __sort_heap
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; --parent) {
+            const QRec v = f[parent];
+            std_adjust_heap(f, parent, len, v);
+            if (parent == 0) break;
+        }
+    }
+    for (int last = len; last > 1;) {
+        --last;
+        const QRec v = f[last];
+        f[last] = f[0];
+        std_adjust_heap(f, 0, last, v);
+    }
+}
+__device__ void std_unguarded_linear_insert(QRec* v, int last) {
+    const QRec val = v[last];
+    int next = last - 1;
+    while (rec_less(val, v[next])) { v[last] = v[next]; last = next; --next; }
+    v[last] = val;
+}
+__device__ void std_insertion_sort(QRec* v, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (rec_less(v[i], v[first])) {
+            const QRec val = v[i];
+            for (int k = i; k > first; --k) v[k] = v[k - 1];
+            v[first] = val;
+        } else {
+            std_unguarded_linear_insert(v, i);
+        }
+    }
+}
+// stack: 3 x 64 ints of LDS for the right-hand ranges of __introsort_loop (its recursion)
+__device__ void std_sort(QRec* v, int n, int* stack) {
+    if (n <= 0) return;
+    int depth0 = 0;
+    for (int t = n; t > 1; t >>= 1) ++depth0;
+    depth0 *= 2;
+    int sp = 0;
+    stack[0] = 0; stack[1] = n; stack[2] = depth0; ++sp;
+    while (sp > 0) {
+        --sp;
+        int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
+        while (last - first > 16) {
+            if (depth == 0) { std_heap_sort(v + first, last - first); break; }
+            --depth;
+            // __unguarded_partition_pivot: the median of (first + 1, mid, last - 1) goes to first
+            const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+            if (rec_less(v[a], v[b])) {
+                if (rec_less(v[b], v[c])) rec_swap(v, first, b);
+                else if (rec_less(v[a], v[c])) rec_swap(v, first, c);
+                else rec_swap(v, first, a);
+            } else if (rec_less(v[a], v[c])) rec_swap(v, first, a);
+            else if (rec_less(v[b], v[c])) rec_swap(v, first, c);
+            else rec_swap(v, first, b);
+            int lo = first + 1, hi = last;
+            for (;;) {
+                while (rec_less(v[lo], v[first])) ++lo;
+                --hi;
+                while (rec_less(v[first], v[hi])) --hi;
+                if (!(lo < hi)) break;
+                rec_swap(v, lo, hi);
+                ++lo;
+            }
+            // the reference recurses into [cut, last) and loops on [first, cut): disjoint ranges, any processing order gives the same array.
+            // The depth budget bounds the pending ranges to 2 log2 n < 64
+            stack[3 * sp] = lo; stack[3 * sp + 1] = last; stack[3 * sp + 2] = depth; ++sp;
+            last = lo;
+        }
+    }
+    if (n > 16) {  // __final_insertion_sort
+        std_insertion_sort(v, 0, 16);
+        for (int i = 16; i != n; ++i) std_unguarded_linear_insert(v, i);
+    } else {
+        std_insertion_sort(v, 0, n);
+    }
+}
+
+// Exclusive prefix sums over the block; every thread of the block calls them the same number of times.
+template <int T, typename V>
+__device__ __forceinline__ V block_excl_scan(V v, V* s_wave, V& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    V incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const V t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    V base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < T / 64; ++k) { const V w = s_wave[k]; base += k < wave ? w : (V)0; tot += w; }
+    total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+struct ScratchLayout {
+    size_t scanq, keys_a, keys_b, nodeof_a, nodeof_b, kq, nodes_a, nodes_b, cnt, cidx, procpos, order, newpos, rec_a, rec_b, total;
+    __host__ __device__ ScratchLayout(int K, int MN) {
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+        scanq = take((size_t)(K + 1) * 8);
+        keys_a = take((size_t)K * 4); keys_b = take((size_t)K * 4);
+        nodeof_a = take((size_t)K * 4); nodeof_b = take((size_t)K * 4);
+        kq = take((size_t)K);
+        nodes_a = take((size_t)MN * sizeof(QNode)); nodes_b = take((size_t)MN * sizeof(QNode));
+        cnt = take((size_t)MN * 16); cidx = take((size_t)MN * 16);
+        procpos = take((size_t)MN * 4); order = take((size_t)MN * 4); newpos = take((size_t)MN * 4);
+        rec_a = take((size_t)MN * sizeof(QRec)); rec_b = take((size_t)MN * sizeof(QRec));
+        total = o;
+    }
+};
+
+}  // namespace
+
+template <int T>
+__global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense, const int32_t* __restrict__ level_counts,
+                                               uint8_t* __restrict__ scratch, uint32_t* __restrict__ picked, int32_t* __restrict__ picked_count,
+                                               int32_t* __restrict__ status) {
+    const QuadJob J = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t* cand = dense + J.cand_off;
+    const int ncand = level_counts[J.count_idx];
+    uint32_t* out = picked + J.out_off;
+    int32_t* const out_count = picked_count + J.count_idx;
+    __shared__ int s_wave[T / 64];
+    __shared__ unsigned long long s_wave64[T / 64];
+    __shared__ int s_cut;
+    __shared__ int s_stack[3 * 64];
+    __shared__ QRec s_rec[kSortCap];
+    const int K = J.max_keys, MN = J.max_nodes, N = J.n_target;
+    if (ncand <= 0 || ncand > K) {
+        if (tid == 0) { *out_count = 0; if (ncand > K) atomicMax(status, 1); }
+        return;
+    }
+    const ScratchLayout lay(K, MN);
+    uint8_t* base = scratch + J.scratch_off;
+    unsigned long long* scanq = reinterpret_cast<unsigned long long*>(base + lay.scanq);
+    int32_t* keys = reinterpret_cast<int32_t*>(base + lay.keys_a);
+    int32_t* keys2 = reinterpret_cast<int32_t*>(base + lay.keys_b);
+    int32_t* nodeof = reinterpret_cast<int32_t*>(base + lay.nodeof_a);
+    int32_t* nodeof2 = reinterpret_cast<int32_t*>(base + lay.nodeof_b);
+    uint8_t* kq = base + lay.kq;
+    QNode* nodes = reinterpret_cast<QNode*>(base + lay.nodes_a);
+    QNode* nodes2 = reinterpret_cast<QNode*>(base + lay.nodes_b);
+    int32_t* cnt = reinterpret_cast<int32_t*>(base + lay.cnt);          // [MN][4] populations of the children of a divided node
+    int32_t* cidx = reinterpret_cast<int32_t*>(base + lay.cidx);        // [MN][4] place of the child in the new list
+    int32_t* procpos = reinterpret_cast<int32_t*>(base + lay.procpos);  // [MN] place of the node in this round's processing order, -1: not divided
+    int32_t* order = reinterpret_cast<int32_t*>(base + lay.order);      // [MN] the processing order
+    int32_t* newpos = reinterpret_cast<int32_t*>(base + lay.newpos);    // [MN] children pushed before this node's / new place of a node that stays
+    QRec* recs = reinterpret_cast<QRec*>(base + lay.rec_a);             // the multi-key children of the last round, in creation order
+    QRec* recs2 = reinterpret_cast<QRec*>(base + lay.rec_b);
+
+    // ---- initial nodes (:533-560): nIni columns, the keys dealt to them in candidate order; empty columns are erased ----
+    const int W = J.max_x - J.min_x, H = J.max_y - J.min_y;
+    const int n_ini = (int)roundf((float)W / (float)H);
+    if (n_ini <= 0 || n_ini > MN) {  // the reference would divide by zero for n_ini == 0
+        if (tid == 0) { *out_count = 0; if (n_ini > MN) atomicMax(status, 2); }
+        return;
+    }
+    const float hX = (float)W / (float)n_ini;
+    for (int k = tid; k < ncand; k += T) {
+        size_t b = (size_t)((float)q_cx(cand[k]) / hX);
+        if (b >= (size_t)n_ini) b = (size_t)n_ini - 1;  // unreachable for in-range candidates
+        nodeof2[k] = (int)b;
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < n_ini; s0 += 3) {  // three columns per pass
+        unsigned long long carry = 0;
+        for (int c0 = 0; c0 < ncand; c0 += T) {
+            const int k = c0 + tid;
+            const int sl = k < ncand ? nodeof2[k] - s0 : -1;
+            const bool mine = sl >= 0 && sl < 3;
+            unsigned long long tot;
+            const unsigned long long ex = carry + block_excl_scan<T>(mine ? 1ull << (21 * sl) : 0ull, s_wave64, tot);
+            if (mine) keys2[k] = (int)((ex >> (21 * sl)) & kF21);  // rank inside the column
+            carry += tot;
+        }
+        if (tid < 3 && s0 + tid < n_ini) cnt[s0 + tid] = (int)((carry >> (21 * tid)) & kF21);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, n = 0;
+        for (int i = 0; i < n_ini; ++i) {
+            const int c = cnt[i];
+            procpos[i] = c > 0 ? n : -1;  // column -> node
+            cidx[i] = acc;                // first key of the column
+            if (c > 0) nodes[n++] = QNode{(int16_t)(int)(hX * (float)i), 0, (int16_t)(int)(hX * (float)(i + 1)), (int16_t)H, acc, c};
+            acc += c;
+        }
+        s_cut = n;
+    }
+    __syncthreads();
+    for (int k = tid; k < ncand; k += T) {
+        const int sl = nodeof2[k], pos = cidx[sl] + keys2[k];
+        keys[pos] = k;
+        nodeof[pos] = procpos[sl];
+    }
+    int size = s_cut, phase = 0, n_rec = 0;
+    __syncthreads();
+
+    for (int guard = 0; guard < 100000 && phase != 2; ++guard) {
+        // ---- 1. the nodes to divide and their order: every multi-key node in list order, or (closing phase) the sorted records from the back ----
+        int n_proc;
+        if (phase == 0) {
+            int carry = 0;
+            for (int i0 = 0; i0 < size; i0 += T) {
+                const int i = i0 + tid;
+                const int f = i < size && nodes[i].count > 1 ? 1 : 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(f, s_wave, tot);
+                if (i < size) procpos[i] = f ? ex : -1;
+                if (f) order[ex] = i;
+                carry += tot;
+            }
+            n_proc = carry;
+        } else {
+            n_proc = n_rec;
+            for (int i = tid; i < size; i += T) procpos[i] = -1;
+            __syncthreads();
+            for (int j = tid; j < n_proc; j += T) { const int nd = recs[n_rec - 1 - j].node; order[j] = nd; procpos[nd] = j; }
+        }
+        __syncthreads();
+        // ---- 2. quadrant of every key of those nodes; prefix sums of the indicators along the key array ----
+        {
+            unsigned long long carry = 0;
+            for (int c0 = 0; c0 < ncand; c0 += T) {
+                const int k = c0 + tid;
+                unsigned long long v = 0;
+                if (k < ncand) {
+                    const int nd = nodeof[k];
+                    if (procpos[nd] >= 0) {
+                        const int q = q_quadrant(nodes[nd], cand[keys[k]]);
+                        kq[k] = (uint8_t)q;
+                        if (q < 3) v = 1ull << (21 * q);
+                    }
+                }
+                unsigned long long tot;
+                const unsigned long long ex = carry + block_excl_scan<T>(v, s_wave64, tot);
+                if (k < ncand) scanq[k] = ex;
+                carry += tot;
+            }
+            if (tid == 0) scanq[ncand] = carry;
+        }
+        __syncthreads();
+        // ---- 3. populations of the children ----
+        for (int j = tid; j < n_proc; j += T) {
+            const int nd = order[j];
+            const QNode p = nodes[nd];
+            const unsigned long long d = scanq[p.begin + p.count] - scanq[p.begin];
+            const int c0 = (int)(d & kF21), c1 = (int)((d >> 21) & kF21), c2 = (int)((d >> 42) & kF21);
+            cnt[4 * nd] = c0; cnt[4 * nd + 1] = c1; cnt[4 * nd + 2] = c2; cnt[4 * nd + 3] = p.count - c0 - c1 - c2;
+        }
+        if (tid == 0) s_cut = n_proc;
+        __syncthreads();
+        // ---- 4. closing phase: the walk stops as soon as the list holds N nodes (:700-701); a division adds children - 1 ----
+        if (phase == 1) {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int grow = 0;
+                if (j < n_proc) { for (int q = 0; q < 4; ++q) grow += cnt[4 * order[j] + q] > 0; grow -= 1; }
+                int tot;
+                const int ex = carry + block_excl_scan<T>(grow, s_wave, tot);
+                if (j < n_proc && size + ex + grow >= N) atomicMin(&s_cut, j + 1);
+                carry += tot;
+            }
+            __syncthreads();
+            const int m = s_cut;
+            for (int j = m + tid; j < n_proc; j += T) procpos[order[j]] = -1;  // not reached
+            n_proc = m;
+            __syncthreads();
+        }
+        // ---- 5. places in the new list ----
+        int n_children;
+        {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int ch = 0;
+                if (j < n_proc) for (int q = 0; q < 4; ++q) ch += cnt[4 * order[j] + q] > 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(ch, s_wave, tot);
+                if (j < n_proc) newpos[order[j]] = ex;
+                carry += tot;
+            }
+            n_children = carry;
+        }
+        int new_size;
+        {
+            int carry = 0;
+            for (int i0 = 0; i0 < size; i0 += T) {
+                const int i = i0 + tid;
+                const int f = i < size && procpos[i] < 0 ? 1 : 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(f, s_wave, tot);
+                if (f) newpos[i] = n_children + ex;
+                carry += tot;
+            }
+            new_size = n_children + carry;
+        }
+        if (new_size > MN) { if (tid == 0) { atomicMax(status, 3); *out_count = 0; } return; }
+        for (int i = tid; i < size; i += T) {
+            const QNode p = nodes[i];
+            if (procpos[i] < 0) { nodes2[newpos[i]] = p; continue; }
+            const int mx = p.ulx + (int)ceilf((float)(p.brx - p.ulx) / 2), my = p.uly + (int)ceilf((float)(p.bry - p.uly) / 2);
+            int pushed = newpos[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cnt[4 * i + q];
+                if (c == 0) { cidx[4 * i + q] = -1; continue; }
+                const int at = n_children - 1 - pushed;  // push_front: a later push lies nearer to the front
+                nodes2[at] = QNode{(int16_t)((q & 1) ? mx : p.ulx), (int16_t)((q & 2) ? my : p.uly), (int16_t)((q & 1) ? p.brx : mx),
+                                   (int16_t)((q & 2) ? p.bry : my), 0, c};
+                cidx[4 * i + q] = at;
+                ++pushed;
+            }
+        }
+        __syncthreads();
+        {  // first key of every new node
+            int carry = 0;
+            for (int i0 = 0; i0 < new_size; i0 += T) {
+                const int i = i0 + tid;
+                const int c = i < new_size ? nodes2[i].count : 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(c, s_wave, tot);
+                if (i < new_size) nodes2[i].begin = ex;
+                carry += tot;
+            }
+        }
+        __syncthreads();
+        // ---- 6. keys to their new nodes ----
+        for (int k = tid; k < ncand; k += T) {
+            const int nd = nodeof[k];
+            const QNode p = nodes[nd];
+            int nn, rank;
+            if (procpos[nd] < 0) {
+                nn = newpos[nd];
+                rank = k - p.begin;
+            } else {
+                const int q = kq[k];
+                const unsigned long long d = scanq[k] - scanq[p.begin];
+                const int r0 = (int)(d & kF21), r1 = (int)((d >> 21) & kF21), r2 = (int)((d >> 42) & kF21);
+                rank = q == 0 ? r0 : q == 1 ? r1 : q == 2 ? r2 : (k - p.begin) - r0 - r1 - r2;
+                nn = cidx[4 * nd + q];
+            }
+            const int pos = nodes2[nn].begin + rank;
+            keys2[pos] = keys[k];
+            nodeof2[pos] = nn;
+        }
+        // ---- 7. the multi-key children of this round, in creation order ----
+        int n_expand;
+        {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int m = 0;
+                if (j < n_proc) for (int q = 0; q < 4; ++q) m += cnt[4 * order[j] + q] > 1;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(m, s_wave, tot);
+                if (j < n_proc) {
+                    int at = ex;
+                    const int nd = order[j];
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cnt[4 * nd + q];
+                        if (c > 1) { const int nn = cidx[4 * nd + q]; recs2[at++] = QRec{c, (int)nodes2[nn].ulx, nn}; }
+                    }
+                }
+                carry += tot;
+            }
+            n_expand = carry;
+        }
+        __syncthreads();
+        // ---- 8. what comes next (:651-728) ----
+        int next_phase;
+        if (new_size >= N || new_size == size) next_phase = 2;
+        else if (phase == 1 || new_size + n_expand * 3 > N) next_phase = 1;
+        else next_phase = 0;
+        if (next_phase == 1) {  // sort(vPrevSizeAndPointerToNode.begin(), vPrevSizeAndPointerToNode.end(), compareNodes)
+            if (n_expand <= kSortCap) {
+                for (int j = tid; j < n_expand; j += T) s_rec[j] = recs2[j];
+                __syncthreads();
+                if (tid == 0) std_sort(s_rec, n_expand, s_stack);
+                __syncthreads();
+                for (int j = tid; j < n_expand; j += T) recs2[j] = s_rec[j];
+            } else if (tid == 0) {
+                std_sort(recs2, n_expand, s_stack);
+            }
+        }
+        { int32_t* t = keys; keys = keys2; keys2 = t; t = nodeof; nodeof = nodeof2; nodeof2 = t; }
+        { QNode* t = nodes; nodes = nodes2; nodes2 = t; }
+        { QRec* t = recs; recs = recs2; recs2 = t; }
+        size = new_size; phase = next_phase; n_rec = n_expand;
+        __syncthreads();
+    }
+    // ---- the best candidate of every node, in list order (:731-752) ----
+    if (size > J.out_cap) { if (tid == 0) { atomicMax(status, 4); *out_count = 0; } return; }
+    for (int i = tid; i < size; i += T) {
+        const QNode n = nodes[i];
+        int best = keys[n.begin], best_r = q_cr(cand[best]);
+        for (int k = 1; k < n.count; ++k) {
+            const int key = keys[n.begin + k];
+            const int r = q_cr(cand[key]);
+            if (r > best_r) { best = key; best_r = r; }
+        }
+        out[i] = cand[best];
+    }
+    if (tid == 0) *out_count = size;
+}
+
+// The keypoints of an image: its per-level lists behind each other (level order, :1093-1137), in level pixel coordinates with the
+// border added (:856-857).  One workgroup per image; the lists go to a device array (the descriptor kernel reads it) and to its pinned
+// host mirror (the assembly on the host reads it), the counts likewise.
+__global__ __launch_bounds__(256) void k_quadtree_gather(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ picked, const int32_t* __restrict__ picked_count,
+                                                        const int32_t* __restrict__ level_counts, int first_image, int nlevels, int kp_stride, int min_border,
+                                                        DevKeypoint* __restrict__ kps, DevKeypoint* __restrict__ kps_host, int32_t* __restrict__ n_kp,
+                                                        int32_t* __restrict__ n_kp_host, int32_t* __restrict__ level_counts_host, int32_t* __restrict__ status) {
+    const int img = first_image + (int)blockIdx.x, tid = threadIdx.x;
+    int off = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const int j = img * nlevels + l, n = picked_count[j];
+        const uint32_t* in = picked + jobs[j].out_off;
+        for (int k = tid; k < n; k += 256) {
+            if (off + k >= kp_stride) break;
+            const uint32_t cc = in[k];
+            const uint32_t x = ((cc >> 8) & 0xfff) + (uint32_t)min_border, y = (cc >> 20) + (uint32_t)min_border;
+            const DevKeypoint kp{(y << 20) | (x << 8) | (cc & 0xff), ((uint32_t)img << 8) | (uint32_t)l};
+            kps[(size_t)img * kp_stride + off + k] = kp;
+            kps_host[(size_t)img * kp_stride + off + k] = kp;
+        }
+        if (tid == 0) level_counts_host[j] = level_counts[j];
+        off += n;
+    }
+    if (tid == 0) {
+        if (off > kp_stride) { atomicMax(status, 5); off = kp_stride; }
+        n_kp[img] = off;
+        n_kp_host[img] = off;
+    }
+}
+
+void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
+                     int32_t* picked_count, int32_t* status, int threads, hipStream_t st) {
+    if (n_jobs <= 0) return;
+    const QuadJob* j0 = jobs + first_job;
+    if (threads >= 1024) TC2LI_LAUNCH(k_quadtree<1024>, dim3(n_jobs), dim3(1024), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+    else if (threads >= 512) TC2LI_LAUNCH(k_quadtree<512>, dim3(n_jobs), dim3(512), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+    else TC2LI_LAUNCH(k_quadtree<256>, dim3(n_jobs), dim3(256), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+}
+void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const int32_t* picked_count, const int32_t* level_counts, int first_image, int n_images,
+                            int nlevels, int kp_stride, DevKeypoint* kps, DevKeypoint* kps_host, int32_t* n_kp, int32_t* n_kp_host, int32_t* level_counts_host,
+                            int32_t* status, hipStream_t st) {
+    if (n_images > 0)
+        TC2LI_LAUNCH(k_quadtree_gather, dim3(n_images), dim3(256), 0, st, jobs, picked, picked_count, level_counts, first_image, nlevels, kp_stride, kMinBorder, kps,
+                     kps_host, n_kp, n_kp_host, level_counts_host, status);
+}
+
+size_t quadtree_scratch_bytes(int max_keys, int max_nodes) { return ScratchLayout(max_keys, max_nodes).total; }
+
+}  // namespace tc2li

@@ -74,8 +74,8 @@ int tc2li_stereo_match_batch(tc2li_orb* o, int n_frames, float bf, float b, floa
     for (int f = 0; f < n_frames; ++f) {
         StereoFrame& fr = frames[f];
         fr.left_img = 2 * f; fr.right_img = 2 * f + 1;
-        fr.left_off = o->last_kp_off[2 * f]; fr.n_left = o->last_kp_off[2 * f + 1] - fr.left_off;
-        fr.right_off = o->last_kp_off[2 * f + 1]; fr.n_right = o->last_kp_off[2 * f + 2] - fr.right_off;
+        fr.left_off = o->last_kp_off[2 * f]; fr.n_left = o->last_kp_cnt[2 * f];
+        fr.right_off = o->last_kp_off[2 * f + 1]; fr.n_right = o->last_kp_cnt[2 * f + 1];
         fr.out_off = out_total; fr.pad_ = 0;
         out_total += fr.n_left;
         max_left = std::max(max_left, fr.n_left);

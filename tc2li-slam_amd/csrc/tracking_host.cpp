@@ -44,7 +44,7 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     for (int f = 0; f < n_frames; ++f) {
         BatchSearchFrame& fr = frames[f];
         fr.key_off = o->last_kp_off[2 * f];
-        fr.n_keys = o->last_kp_off[2 * f + 1] - fr.key_off;
+        fr.n_keys = o->last_kp_cnt[2 * f];
         if (fr.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, fr.n_keys); return TC2LI_ERR_CAPACITY; }
         fr.keys_host = keypoints + (size_t)(2 * f) * capacity;
         fr.u_right_host = u_right + (size_t)f * capacity;
@@ -163,7 +163,7 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     for (int f = 0; f < n_frames; ++f) {
         BatchSearchFrame& fr = frames[f];
         fr.key_off = o->last_kp_off[2 * f];
-        fr.n_keys = o->last_kp_off[2 * f + 1] - fr.key_off;
+        fr.n_keys = o->last_kp_cnt[2 * f];
         if (fr.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, fr.n_keys); return TC2LI_ERR_CAPACITY; }
         if (local_offsets[f + 1] < local_offsets[f]) { set_error("tc2li_track_local_map_batch: local_offsets must not decrease"); return TC2LI_ERR_INVALID; }
         fr.keys_host = keypoints + (size_t)(2 * f) * capacity;
