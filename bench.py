@@ -316,10 +316,13 @@ class Loop:
     def lidar_step(self):
         pkg, F = self.pkg, self.F
         # lasermap_fov_segment (host logic) + the box deletions it asks for, per sequence
+        todo_maps, todo_boxes = [], []
         for s in range(F):
             boxes = pkg.capi.lidar_fov_segment(self.boxes[s], self.states[s][9:12], cube_len=1000.0, det_range=100.0)
             if len(boxes):
-                self.maps[s].Delete_Point_Boxes(boxes, stream=self.lidar_stream.cuda_stream)
+                todo_maps.append(self.maps[s]); todo_boxes.append(boxes)
+        if todo_maps:
+            pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
         self.lidar_counts = self.lidar.frontend_batch(self.dev_raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
                                                       want_points=False)[0]
         self.lidar_times.append(self.lidar.last_timings().astype(float))

@@ -245,6 +245,11 @@ int tc2li_lidar_transform_features_batch(tc2li_lidar* lidar, int n, const int32_
 /* ikdtree.Delete_Point_Boxes (ikd_Tree.cpp:643): removes the points inside the boxes [min, max) given as
  * min x y z, max x y z per box; returns how many were removed. */
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* map, const float* boxes6, int n_boxes, void* stream);
+/* The same for n_maps different maps in one go (one launch per phase; the per-sequence lasermap_fov_segment calls of a batch of
+ * sequences): map i gets the boxes box_offsets[i] .. box_offsets[i+1] of boxes6 (box_offsets[0] = 0).  n_removed [n_maps] (may be
+ * NULL) receives the per-map counts; returns their sum. */
+int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps, const float* boxes6, const int32_t* box_offsets,
+                                       int32_t* n_removed, void* stream);
 /* Copies the map points to the host (diagnostics / tests); returns the map size. */
 int tc2li_lidar_map_download(const tc2li_lidar_map* map, tc2li_point* out, int capacity);
 /* lasermap_fov_segment (LidarFrontEnd.cpp:183-231), host logic: keeps the local-map cube around the sensor and returns

@@ -121,6 +121,7 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_lidar_map_incremental.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_lidar_map_delete_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_lidar_map_delete_boxes_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_lidar_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_lidar_fov_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
     L.tc2li_local_inertial_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -403,6 +404,18 @@ class LidarMap:
         n = _check(lib().tc2li_lidar_map_incremental(front_end._h, scan, self._h, st.ctypes.data, int(ekf_inited), filter_size_map_min,
                                                      C.addressof(na), C.addressof(nn), C.c_void_p(stream)))
         return n, na.value, nn.value
+
+
+def delete_point_boxes_batch(maps, boxes_per_map, stream=0):
+    """``Delete_Point_Boxes`` on several maps at once: ``boxes_per_map[i]`` = [k_i, 6] boxes of map i -> removed points per map."""
+    n = len(maps)
+    offs = np.zeros(n + 1, np.int32)
+    offs[1:] = np.cumsum([len(np.asarray(b).reshape(-1, 6)) for b in boxes_per_map])
+    allb = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float32).reshape(-1, 6) for b in boxes_per_map] + [np.zeros((0, 6), np.float32)]), np.float32)
+    handles = (C.c_void_p * max(n, 1))(*[m._h for m in maps])
+    removed = np.zeros(max(n, 1), np.int32)
+    _check(lib().tc2li_lidar_map_delete_boxes_batch(n, handles, allb.ctypes.data, offs.ctypes.data, removed.ctypes.data, C.c_void_p(stream)))
+    return removed[:n]
 
 
 def map_incremental_batch(front_end, scans, maps, states24, ekf_inited=True, filter_size_map_min=0.5, stream=0):

@@ -98,6 +98,8 @@ struct MapIncTask {
     double fs;                     // filter_size_map_min
     float ds;                      // ikdtree downsample_size
     int n, n_map, keep_blocks, ekf_inited, has_inc;
+    const float* boxes;            // [n_boxes][6] (min, max) of KD_TREE::Delete_Point_Boxes; has_inc = 0 tasks only
+    int n_boxes, pad_;
 };
 // Counting sort of one map's points into its dense grid.
 struct MapGridTask {
@@ -110,7 +112,7 @@ struct MapGridTask {
     int n_cells;
 };
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
-void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st);
+void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st);
 

@@ -801,33 +801,94 @@ int tc2li_lidar_map_incremental_batch(tc2li_lidar* L, int n, const int32_t* scan
     return map_incremental_impl(L, n, scans, maps, states, ekf_inited, filter_size_map_min, n_to_add, n_no_need, map_sizes, (hipStream_t)stream_);
 }
 
+namespace {
+// Work space of a batch of box deletions (they have no tc2li_lidar handle to borrow one from): one per calling thread.
+struct DeleteBoxesWs {
+    DevBuf<MapIncTask> d_tasks;
+    DevBuf<MapGridTask> d_grid_tasks;
+    DevBuf<float> d_boxes;
+    DevBuf<int> d_out;
+    PinnedBuf<int> h_out;
+};
+DeleteBoxesWs& delete_boxes_ws() { thread_local DeleteBoxesWs ws; return ws; }
+}  // namespace
+
+int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps, const float* boxes6, const int32_t* box_offsets, int32_t* n_removed,
+                                       void* stream_) {
+    if (n_maps < 0 || (n_maps > 0 && (!maps || !box_offsets)) || (n_maps > 0 && box_offsets[0] != 0)) {
+        set_error("tc2li_lidar_map_delete_boxes_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_maps == 0) return 0;
+    for (int i = 0; i < n_maps; ++i)
+        if (!maps[i] || box_offsets[i + 1] < box_offsets[i]) { set_error("tc2li_lidar_map_delete_boxes_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    const int total_boxes = box_offsets[n_maps];
+    if (total_boxes > 0 && !boxes6) { set_error("tc2li_lidar_map_delete_boxes_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    {
+        std::vector<const tc2li_lidar_map*> seen(maps, maps + n_maps);
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { set_error("tc2li_lidar_map_delete_boxes_batch: a map appears twice in one batch"); return TC2LI_ERR_INVALID; }
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    MapLocks locks(maps, n_maps);
+    if (n_removed) for (int i = 0; i < n_maps; ++i) n_removed[i] = 0;
+    DeleteBoxesWs& ws = delete_boxes_ws();
+    std::vector<MapIncTask> tasks;
+    std::vector<int> which;
+    int max_map = 0;
+    TC2LI_HIP_CHECK(ws.d_boxes.ensure(6 * (size_t)std::max(total_boxes, 1)));
+    for (int i = 0; i < n_maps; ++i) {
+        tc2li_lidar_map* m = maps[i];
+        const int nb = box_offsets[i + 1] - box_offsets[i];
+        if (nb == 0 || m->n == 0) continue;
+        const int rc = ensure_deleted(m, m->n, st);
+        if (rc != TC2LI_OK) return rc;
+        const int kb = (m->n + 1023) / 1024;
+        TC2LI_HIP_CHECK(m->d_keep_counts.ensure(kb));
+        TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + 1));
+        MapIncTask t{};
+        t.grid = m->grid; t.grid.points = m->d_points.p;
+        t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
+        t.n_map = m->n; t.keep_blocks = kb; t.has_inc = 0;
+        t.boxes = ws.d_boxes.p + 6 * (size_t)box_offsets[i]; t.n_boxes = nb;
+        tasks.push_back(t);
+        which.push_back(i);
+        max_map = std::max(max_map, m->n);
+    }
+    const int nt = (int)tasks.size();
+    if (nt == 0) return 0;
+    TC2LI_HIP_CHECK(ws.d_tasks.ensure(nt)); TC2LI_HIP_CHECK(ws.d_out.ensure((size_t)nt * kMapIncOut)); TC2LI_HIP_CHECK(ws.h_out.ensure((size_t)nt * kMapIncOut));
+    for (int k = 0; k < nt; ++k) tasks[k].out = ws.d_out.p + (size_t)k * kMapIncOut;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_boxes.p, boxes6, 6 * (size_t)total_boxes * sizeof(float), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
+    launch_map_mark_boxes(ws.d_tasks.p, nt, max_map, st);
+    launch_map_compact(ws.d_tasks.p, nt, max_map, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_out.p, ws.d_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));  // the uploads above read the caller's and this function's host memory: done here too
+    std::vector<tc2li_lidar_map*> changed;
+    int removed_total = 0;
+    for (int k = 0; k < nt; ++k) {
+        tc2li_lidar_map* m = maps[which[k]];
+        const int before = m->n;
+        if (ws.h_out.p[k * kMapIncOut + 4] == before) continue;  // nothing inside the boxes: points, flags and grid stay as they are
+        commit_compaction(m, ws.h_out.p + k * kMapIncOut, false);
+        changed.push_back(m);
+        if (n_removed) n_removed[which[k]] = before - m->n;
+        removed_total += before - m->n;
+    }
+    if (!changed.empty()) {
+        const int rc = rebuild_grids(changed.data(), (int)changed.size(), ws.d_grid_tasks, st);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    }
+    return removed_total;
+}
+
 int tc2li_lidar_map_delete_boxes(tc2li_lidar_map* m, const float* boxes6, int n_boxes, void* stream_) {
     if (!m || n_boxes < 0 || (n_boxes > 0 && !boxes6)) { set_error("tc2li_lidar_map_delete_boxes: invalid argument"); return TC2LI_ERR_INVALID; }
-    hipStream_t st = (hipStream_t)stream_;
-    std::lock_guard<std::mutex> lock(m->mu);
-    if (n_boxes == 0 || m->n == 0) return 0;
-    int rc = ensure_deleted(m, m->n, st);
-    if (rc != TC2LI_OK) return rc;
-    const int kb = (m->n + 1023) / 1024;
-    TC2LI_HIP_CHECK(m->d_boxes.ensure(6 * (size_t)n_boxes));
-    TC2LI_HIP_CHECK(m->d_keep_counts.ensure(kb)); TC2LI_HIP_CHECK(m->d_out.ensure(kMapIncOut)); TC2LI_HIP_CHECK(m->h_out.ensure(kMapIncOut));
-    TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + 1)); TC2LI_HIP_CHECK(m->d_inc_task.ensure(1));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_boxes.p, boxes6, 6 * (size_t)n_boxes * sizeof(float), hipMemcpyHostToDevice, st));
-    launch_map_mark_boxes(m->d_points.p, m->n, m->d_boxes.p, n_boxes, m->d_deleted.p, st);
-    MapIncTask t{};
-    t.out = m->d_out.p; t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
-    t.n_map = m->n; t.keep_blocks = kb; t.has_inc = 0;
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->d_inc_task.p, &t, sizeof(t), hipMemcpyHostToDevice, st));
-    launch_map_compact(m->d_inc_task.p, 1, m->n, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(m->h_out.p, m->d_out.p, kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    const int before = m->n;
-    commit_compaction(m, m->h_out.p, false);
-    rc = rebuild_grid(m, st);
-    if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    return before - m->n;
+    const int32_t offsets[2] = {0, n_boxes};
+    return tc2li_lidar_map_delete_boxes_batch(1, &m, boxes6, offsets, nullptr, stream_);
 }
 
 // Tracking::SyncWithLidar / BuildLidarFeat4KeyFrame: the scans' feature clouds (mCurrFeatPoints = laserCloudOri of the front end, still on

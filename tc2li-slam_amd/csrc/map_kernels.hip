@@ -188,17 +188,17 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
 }
 
 // deleted[i] = 1 for every map point inside one of the boxes [min, max) (KD_TREE::Delete_Point_Boxes)
-__global__ __launch_bounds__(256) void k_map_mark_boxes(const PointXYZINormal* __restrict__ pts, int n, const float* __restrict__ boxes, int n_boxes,
-                                                        uint8_t* __restrict__ deleted) {
+__global__ __launch_bounds__(256) void k_map_mark_boxes(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const PointXYZINormal p = pts[i];
-    uint8_t d = deleted[i];
-    for (int b = 0; b < n_boxes; ++b) {
-        const float* q = boxes + 6 * b;
+    if (i >= T.n_map) return;
+    const PointXYZINormal p = T.grid.points[i];
+    uint8_t d = T.deleted[i];
+    for (int b = 0; b < T.n_boxes; ++b) {
+        const float* q = T.boxes + 6 * b;
         if (q[0] <= p.x && q[3] > p.x && q[1] <= p.y && q[4] > p.y && q[2] <= p.z && q[5] > p.z) d = 1;
     }
-    deleted[i] = d;
+    T.deleted[i] = d;
 }
 
 // ---- ordered compaction of the map after deletions: per-block kept counts, their scan (one workgroup per map), scatter; then the
@@ -395,8 +395,8 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
     TC2LI_LAUNCH(k_mapinc_group, dim3(n_tasks), dim3(1024), lds, st, tasks);
     TC2LI_LAUNCH(k_mapinc_apply, dim3(kMapIncMax / 128, n_tasks), dim3(128), 0, st, tasks);
 }
-void launch_map_mark_boxes(const PointXYZINormal* pts, int n, const float* boxes, int n_boxes, uint8_t* deleted, hipStream_t st) {
-    if (n && n_boxes) TC2LI_LAUNCH(k_map_mark_boxes, dim3((n + 255) / 256), dim3(256), 0, st, pts, n, boxes, n_boxes, deleted);
+void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
+    if (n_tasks && max_map_points) TC2LI_LAUNCH(k_map_mark_boxes, dim3((max_map_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
 }
 void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
     if (!n_tasks) return;

@@ -339,13 +339,15 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     }
     o->last_nimg = M;
 
-    // The call is queued chunk by chunk (pyramid, FAST, compaction, keypoint distribution, then orientation + descriptors once the
-    // chunk's blur -- on the side stream -- is done), so that the tail of one chunk's distribution kernel (a few long level-0 jobs)
-    // overlaps the next chunk's blur; the host waits once, at the end.  With profiling on there is one chunk and every kernel is on
+    // The whole call is queued at once (pyramid, FAST, compaction, keypoint distribution, then orientation + descriptors once the blur
+    // -- on the side stream -- is done) and the host waits once, at the end.  TC2LI_ORB_CHUNKS > 1 queues the images in that many
+    // chunks instead; measured on MI355X that is slower now that no host stage sits between the kernels (128 KITTI images: 2.4 ms in one
+    // chunk, 2.9 ms in two, 3.9 ms in four: every chunk pays the tail of its distribution kernel).  With profiling on every kernel is on
     // the caller's stream, which gives clean per-stage durations.
-    static const int kChunkEnv = getenv("TC2LI_ORB_CHUNKS") ? atoi(getenv("TC2LI_ORB_CHUNKS")) : 0;
-    static const int kQuadThreads = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 512;
-    const int want_chunks = kChunkEnv > 0 ? kChunkEnv : (M >= 64 ? 4 : (M >= 16 ? 2 : 1));
+    const char* chunk_env = getenv("TC2LI_ORB_CHUNKS");  // read per call: the tests switch it
+    const int kChunkEnv = chunk_env ? atoi(chunk_env) : 0;
+    static const int kQuadThreads = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 256;  // 256: 0.56 ms per 128 images, 512: 0.76, 1024: 1.21
+    const int want_chunks = kChunkEnv > 0 ? kChunkEnv : 1;
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     o->last_chunks = n_chunks;
     hipStream_t blur_st = o->profiling ? st : o->side_stream;
@@ -563,7 +565,7 @@ int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max
     TC2LI_HIP_CHECK(d_job.upload(std::vector<QuadJob>{job}));
     TC2LI_HIP_CHECK(d_scratch.alloc(quadtree_scratch_bytes(job.max_keys, job.max_nodes)));
     TC2LI_HIP_CHECK(d_picked.alloc((size_t)job.out_cap));
-    launch_quadtree(d_job.p, 0, 1, d_cand.p, d_counts.p, d_scratch.p, d_picked.p, d_pick_count.p, d_status.p, threads > 0 ? threads : 512, ps);
+    launch_quadtree(d_job.p, 0, 1, d_cand.p, d_counts.p, d_scratch.p, d_picked.p, d_pick_count.p, d_status.p, threads > 0 ? threads : 256, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
     int count = 0, status = 0;
     TC2LI_HIP_CHECK(copy_sync(&count, d_pick_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));

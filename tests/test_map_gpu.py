@@ -88,6 +88,38 @@ def test_delete_point_boxes_and_fov_segment(pkg, oracle, setup):
         assert np.array_equal(np.array(lm.vertex_min), lm7[:3]) and np.array_equal(np.array(lm.vertex_max), lm7[3:6])
 
 
+def test_delete_point_boxes_batch_equals_one_map_at_a_time(pkg, oracle, setup):
+    """tc2li_lidar_map_delete_boxes_batch: several maps, each with its own boxes (one without boxes, one whose boxes hit nothing, an empty
+    map), end as the per-map call and the oracle leave them -- point order included -- and stay searchable."""
+    fe, downs, states, world0 = setup
+    parts = [world0, world0[::2].copy(), world0[1::3].copy(), world0[:0].copy(), world0[::5].copy()]
+    boxes = [np.array([[-5, -50, -5, 5, 50, 5], [20, -10, -3, 40, 10, 10]], np.float32), np.zeros((0, 6), np.float32),
+             np.array([[1000, 1000, 1000, 1001, 1001, 1001]], np.float32), np.array([[-5, -50, -5, 5, 50, 5]], np.float32),
+             np.array([[-100, -100, -100, 100, 0, 100]], np.float32)]
+    maps = []
+    for p in parts:
+        m = pkg.LidarMap()
+        if len(p):
+            m.Build(p)
+        maps.append(m)
+    removed = pkg.capi.delete_point_boxes_batch(maps, boxes)
+    for i, (p, b) in enumerate(zip(parts, boxes)):
+        want = oracle.map_delete_boxes(p, b) if len(p) and len(b) else p
+        assert removed[i] == len(p) - len(want), i
+        got = maps[i].points()
+        assert np.array_equal(got, want), i  # compaction keeps the insertion order
+        if len(p):
+            single = pkg.LidarMap(); single.Build(p)
+            assert single.Delete_Point_Boxes(b) == removed[i]
+            assert np.array_equal(single.points(), got)
+    assert removed[0] > 100 and removed[2] == 0 and removed[4] > 0
+    fresh = pkg.LidarMap(); fresh.Build(maps[4].points())
+    a = fe.feature_extraction(maps[4], downs[1], states[1]); b = fe.feature_extraction(fresh, downs[1], states[1])
+    assert np.array_equal(a["selected"], b["selected"]) and np.array_equal(a["sqdist"], b["sqdist"])
+    with pytest.raises(Exception):
+        pkg.capi.delete_point_boxes_batch([maps[0], maps[0]], [boxes[0], boxes[0]])
+
+
 def test_map_incremental_batch_equals_one_map_at_a_time(pkg, oracle, synthetic):
     """tc2li_lidar_map_incremental_batch (one launch per phase for all maps) leaves every map exactly as the per-map call and as the
     oracle do; the batch holds maps of different sizes, a scan slot that is not part of the batch and an empty scan."""

@@ -185,10 +185,11 @@ def test_blur_row_ends(pkg, oracle, synthetic, width):
         assert np.array_equal(ext.blurred_level(0, level), ora.blurred(level)), (width, level)
 
 
-@pytest.mark.parametrize("n_images", [17, 66])
-def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_images):
-    """tc2li_orb_extract_batch pipelines chunks of images (2 chunks from 16 images, 4 from 64): every image's features, its
-    diagnostics and the stereo matcher's view of the batch are those of the unchunked path."""
+@pytest.mark.parametrize("n_images,chunks", [(17, 1), (17, 2), (66, 4)])
+def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_images, chunks, monkeypatch):
+    """tc2li_orb_extract_batch queues a batch at once, or (TC2LI_ORB_CHUNKS) in chunks of images: every image's features, its
+    diagnostics and the stereo matcher's view of the batch are those of single-image calls."""
+    monkeypatch.setenv("TC2LI_ORB_CHUNKS", str(chunks))
     import torch
     w, h = 640, 300
     base_l, base_r = synthetic.stereo_pair(9, 1242, 375)
@@ -201,7 +202,7 @@ def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_image
     single = pkg.OrbExtractor(max_width=w, max_height=h, max_images=1)
     dev = torch.from_numpy(imgs).cuda()
     kps, desc, counts, mono = e.extract_batch_dev(dev.data_ptr(), n_images, w, h, w, w * h)
-    assert e.last_chunks() == (2 if n_images < 64 else 4)
+    assert e.last_chunks() == chunks
     o = oracle.OrbOracle()
     for i in range(n_images):
         m, k, d = single.extract(imgs[i])
