@@ -810,7 +810,7 @@ struct DeleteBoxesWs {
     DevBuf<int> d_out;
     PinnedBuf<int> h_out;
 };
-DeleteBoxesWs& delete_boxes_ws() { thread_local DeleteBoxesWs ws; return ws; }
+DeleteBoxesWs* delete_boxes_ws() { thread_local DeleteBoxesWs ws; return &ws; }
 }  // namespace
 
 int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps, const float* boxes6, const int32_t* box_offsets, int32_t* n_removed,
@@ -832,7 +832,7 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
     hipStream_t st = (hipStream_t)stream_;
     MapLocks locks(maps, n_maps);
     if (n_removed) for (int i = 0; i < n_maps; ++i) n_removed[i] = 0;
-    DeleteBoxesWs& ws = delete_boxes_ws();
+    DeleteBoxesWs& ws = *delete_boxes_ws();
     std::vector<MapIncTask> tasks;
     std::vector<int> which;
     int max_map = 0;

@@ -11,7 +11,6 @@
 
 #include "common.hpp"
 #include "matcher_device.hpp"
-#include "matcher_host.hpp"
 #include "orb_handle.hpp"
 
 using namespace tc2li;
@@ -90,91 +89,6 @@ int rotation_filter(const tc2li_proj_query* queries, int M, const tc2li_keypoint
 }
 
 }  // namespace
-
-namespace tc2li {
-
-// Batched search on the device-resident features of the extractor handle (see matcher_host.hpp).
-int search_batch_device(tc2li_orb* o, const BatchSearchFrame* frames, int n_frames, const tc2li_proj_query* queries, int mode,
-                        float nn_ratio, bool check_orientation, int32_t* match_of_query, int32_t* n_matches, hipStream_t st) {
-    MatcherWorkspace& w = mws();
-    std::lock_guard<std::mutex> lk(w.mu);
-    int total_q = 0, total_k = 0;
-    for (int f = 0; f < n_frames; ++f) {
-        if (frames[f].n_keys > kMaxMatchKeys) { set_error("frame has %d keypoints, the matcher supports %d", frames[f].n_keys, kMaxMatchKeys); return TC2LI_ERR_CAPACITY; }
-        total_q = std::max(total_q, frames[f].q_off + frames[f].n_q);
-        total_k += frames[f].n_keys;
-    }
-    for (int f = 0; f < n_frames; ++f) n_matches[f] = 0;
-    if (total_q == 0) return 0;
-    TC2LI_HIP_CHECK(w.d_frames.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_ur.ensure(std::max(total_k, 1)));
-    TC2LI_HIP_CHECK(w.d_queries.ensure(total_q)); TC2LI_HIP_CHECK(w.d_match.ensure(total_q)); TC2LI_HIP_CHECK(w.d_prev.ensure(total_q));
-    TC2LI_HIP_CHECK(w.d_rounds.ensure(n_frames));
-    TC2LI_HIP_CHECK(w.h_ur.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.h_frames.ensure(n_frames));
-    TC2LI_HIP_CHECK(w.h_match.ensure(total_q));
-    bool any_occ = false;
-    for (int f = 0; f < n_frames; ++f) any_occ |= frames[f].occupied_host != nullptr;
-    std::vector<uint8_t> occ;
-    if (any_occ) {
-        occ.assign(std::max(total_k, 1), 0);
-        TC2LI_HIP_CHECK(w.d_occ.ensure(std::max(total_k, 1)));
-    }
-    int koff = 0;
-    for (int f = 0; f < n_frames; ++f) {
-        const BatchSearchFrame& fr = frames[f];
-        memcpy(w.h_ur.p + koff, fr.u_right_host, fr.n_keys * sizeof(float));
-        if (fr.occupied_host) memcpy(occ.data() + koff, fr.occupied_host, fr.n_keys);
-        w.h_frames.p[f] = MatchFrameDev{o->d_mkeys.p + fr.key_off, o->d_desc.p + (size_t)fr.key_off * 32, w.d_ur.p + koff, any_occ ? w.d_occ.p + koff : nullptr,
-                                        w.d_queries.p + fr.q_off, fr.n_keys, fr.n_q, fr.q_off, 0, 0.0f, (float)o->cur_w, 0.0f, (float)o->cur_h};
-        koff += fr.n_keys;
-    }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_ur.p, w.h_ur.p, std::max(total_k, 1) * sizeof(float), hipMemcpyHostToDevice, st));
-    if (any_occ) TC2LI_HIP_CHECK(copy_sync(w.d_occ.p, occ.data(), occ.size(), hipMemcpyHostToDevice, st));  // pageable source: synchronous copy
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_queries.p, queries, (size_t)total_q * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
-    // candidate lists once, then the rounds over the lists (matcher_kernels.hip); the pool holds 32 candidates per query on average
-    constexpr int kCellsPlus1 = 64 * 48 + 1;
-    const char* per_query = getenv("TC2LI_MATCH_POOL_PER_QUERY");  // tests shrink the pool to reach the overflow path
-    const int pool_cap = std::max(1, per_query ? atoi(per_query) : 32) * total_q;
-    TC2LI_HIP_CHECK(w.d_cell_start.ensure((size_t)n_frames * kCellsPlus1)); TC2LI_HIP_CHECK(w.d_key_base.ensure(n_frames));
-    TC2LI_HIP_CHECK(w.d_cand_off.ensure(total_q)); TC2LI_HIP_CHECK(w.d_cand_cnt.ensure(total_q)); TC2LI_HIP_CHECK(w.d_pool_top.ensure(2));
-    TC2LI_HIP_CHECK(w.d_query_frame.ensure(total_q)); TC2LI_HIP_CHECK(w.d_items.ensure(std::max(total_k, 1))); TC2LI_HIP_CHECK(w.d_pool.ensure(pool_cap));
-    TC2LI_HIP_CHECK(w.h_query_frame.ensure(total_q)); TC2LI_HIP_CHECK(w.h_key_base.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_pool_top.ensure(2));
-    for (int q = 0; q < total_q; ++q) w.h_query_frame.p[q] = -1;
-    for (int f = 0, kb = 0; f < n_frames; ++f) {
-        w.h_key_base.p[f] = kb;
-        kb += frames[f].n_keys;
-        for (int q = 0; q < frames[f].n_q; ++q) w.h_query_frame.p[frames[f].q_off + q] = f;
-    }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_query_frame.p, w.h_query_frame.p, (size_t)total_q * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_key_base.p, w.h_key_base.p, n_frames * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    MatchLists lists{w.d_cell_start.p, w.d_items.p, w.d_key_base.p, w.d_cand_off.p, w.d_cand_cnt.p, w.d_pool.p, w.d_pool_top.p, pool_cap, 0};
-    launch_match_lists(w.d_frames.p, n_frames, w.d_query_frame.p, total_q, lists, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_pool_top.p, w.d_pool_top.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    if (w.h_pool_top.p[1]) {  // candidate pool exhausted (very dense windows): the one-kernel form computes the same result
-        TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p, 0xff, (size_t)total_q * sizeof(int32_t), st));
-        launch_match_by_projection(w.d_frames.p, n_frames, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
-        TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_match.p, w.d_match.p, (size_t)total_q * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    }
-    tracking_pool().parallel_for(n_frames, [&](int f) {
-        const BatchSearchFrame& fr = frames[f];
-        int32_t* m = match_of_query + fr.q_off;
-        memcpy(m, w.h_match.p + fr.q_off, fr.n_q * sizeof(int32_t));
-        int nm = 0;
-        if (fr.n_keys == 0) for (int q = 0; q < fr.n_q; ++q) m[q] = -1;
-        for (int q = 0; q < fr.n_q; ++q) nm += m[q] >= 0;
-        if (check_orientation) nm -= rotation_filter(queries + fr.q_off, fr.n_q, fr.keys_host, m);
-        n_matches[f] = nm;
-    });
-    return 0;
-}
-
-}  // namespace tc2li
 
 extern "C" {
 

@@ -61,7 +61,8 @@ struct MatchKey;
 struct ScaleTable;
 // Keypoint slots: image i owns [i * kp_stride, i * kp_stride + n_kp[i]) of kps and of every output array; images first_image .. + n_images.
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps, const int32_t* n_kp,
-                            int first_image, int n_images, int kp_stride, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st);
+                            int first_image, int n_images, int kp_stride, float* angles, float* angles_dev, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev,
+                            hipStream_t st);
 hipError_t upload_umax(const int* umax16);
 
 }  // namespace tc2li

@@ -62,6 +62,7 @@ struct tc2li_orb {
     // device-resident copy of the last call's features for the matchers (valid for lapping area {0,0})
     tc2li::DevBuf<tc2li::MatchKey> d_mkeys;
     tc2li::DevBuf<uint8_t> d_desc;
+    tc2li::DevBuf<float> d_angles;  // keypoint angles (the matcher's rotation histogram)
     std::vector<int> last_kp_off, last_kp_cnt;  // [nimg] first slot and number of each image's keypoints in d_mkeys / d_desc
     bool last_plain_order = false;  // true when the device order equals the output order
     tc2li::ScaleTable scale_tab{};

@@ -194,6 +194,7 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
     TC2LI_HIP_CHECK(o->h_status.alloc(1));
     TC2LI_HIP_CHECK(o->d_mkeys.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->d_desc.alloc((size_t)M * o->kp_cap_per_image * 32));
+    TC2LI_HIP_CHECK(o->d_angles.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->h_level_counts.alloc((size_t)M * L));
     TC2LI_HIP_CHECK(o->h_kps.alloc((size_t)M * o->kp_cap_per_image));
     TC2LI_HIP_CHECK(o->h_angles.alloc((size_t)M * o->kp_cap_per_image));
@@ -394,7 +395,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         // ---- stage 3: orientation + descriptors of the chunk's keypoints ----
         TC2LI_HIP_CHECK(hipStreamWaitEvent(st, EV(c, 5), 0));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 6), st));
-        launch_orient_describe(raw, blur, o->scale_tab, o->d_kps.p, o->d_nkp.p, i0, m, kp_stride, o->h_angles.p, o->h_desc.p, o->d_mkeys.p, o->d_desc.p, st);
+        launch_orient_describe(raw, blur, o->scale_tab, o->d_kps.p, o->d_nkp.p, i0, m, kp_stride, o->h_angles.p, o->d_angles.p, o->h_desc.p, o->d_mkeys.p, o->d_desc.p, st);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 7), st));
     }
     TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_status.p, o->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));

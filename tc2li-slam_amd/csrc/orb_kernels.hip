@@ -547,7 +547,7 @@ __constant__ int c_umax[16];
 
 __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, ScaleTable sc,
                                                          const DevKeypoint* __restrict__ kps, const int32_t* __restrict__ n_kp, int first_image,
-                                                         int n_images, int kp_stride, float* __restrict__ angles, uint8_t* __restrict__ desc,
+                                                         int n_images, int kp_stride, float* __restrict__ angles, float* __restrict__ angles_dev, uint8_t* __restrict__ desc,
                                                          MatchKey* __restrict__ mkeys, uint8_t* __restrict__ desc_dev) {
     // XCD-contiguous block order (as in k_fast_cells): the keypoints come image by image and level by level, and XCD k works on the
     // k-th eighth of the list, so an image's levels are fetched into ONE L2 instead of all eight (307 MB of HBM reads per 64 k keypoints
@@ -592,6 +592,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         const float angle = fast_atan2_deg((float)m01, (float)m10);
         if (lane == 0) {
             angles[g] = angle;
+            angles_dev[g] = angle;
             // level-0 coordinates as the reference scales them (SF/src/ORBextractor.cc:1122-1124)
             mkeys[g] = MatchKey{__fmul_rn((float)x, sc.scale[level]), __fmul_rn((float)y, sc.scale[level]), level};
         }
@@ -664,11 +665,12 @@ void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, 
 }
 
 void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, const ScaleTable& sc, const DevKeypoint* kps, const int32_t* n_kp,
-                            int first_image, int n_images, int kp_stride, float* angles, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev, hipStream_t st) {
+                            int first_image, int n_images, int kp_stride, float* angles, float* angles_dev, uint8_t* desc, MatchKey* mkeys, uint8_t* desc_dev,
+                            hipStream_t st) {
     const long nslot = (long)n_images * kp_stride;
     if (nslot <= 0) return;
     TC2LI_LAUNCH(k_orient_describe, dim3((unsigned)((((nslot + 7) / 8 + 7) / 8) * 8)), dim3(256), 0, st, raw, blurred, sc, kps, n_kp, first_image, n_images,
-                 kp_stride, angles, desc, mkeys, desc_dev);
+                 kp_stride, angles, angles_dev, desc, mkeys, desc_dev);
 }
 
 hipError_t upload_umax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }

@@ -1,19 +1,142 @@
-// Host side of tc2li_track_motion_model_batch (include/tc2li_hip.h): the data path of Tracking::TrackWithMotionModel
-// (SF/src/Tracking.cc:2737-2834) for a batch of independent frames.  The stages are the library's own entry points:
-// query construction (tc2li_project_last_frame), the fixed-point greedy matcher on the device-resident features,
-// the pose-only optimisation kernel; this file only sequences them and does the per-frame bookkeeping the reference
-// does between them (edge construction of Optimizer::PoseOptimization :858-990, outlier discarding :2798-2822).
+// Host side of tc2li_track_motion_model_batch / tc2li_track_local_map_batch (include/tc2li_hip.h): the data path of
+// Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834) and Tracking::TrackLocalMap (:3119-3230) for a batch of independent
+// frames.  Everything per keypoint / per map point runs on the device (tracking_kernels.hip: query construction, rotation filter, edge
+// lists, outlier bookkeeping; matcher_kernels.hip: the search; pose_opt_kernel.hip: Optimizer::PoseOptimization).  The host packs the
+// callers' arrays into one pinned staging block per call (one upload), decides the few per-frame branches the reference takes between the
+// stages (fewer than 20 matches: search again with a wider window, Tracking.cc:2774-2783) and receives the per-frame results.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "common.hpp"
-#include "matcher_host.hpp"
+#include "matcher_device.hpp"
 #include "orb_handle.hpp"
+#include "pose_opt_device.hpp"
+#include "tracking_device.hpp"
 
 using namespace tc2li;
+
+namespace {
+
+constexpr int kCellsPlus1 = 64 * 48 + 1;  // the matcher's feature grid (matcher_kernels.hip)
+constexpr int kAmbiguousCap = 4096;
+
+struct TrackWs {
+    PinnedBuf<uint8_t> h_stage;
+    DevBuf<uint8_t> d_stage;
+    PinnedBuf<TrackFrameDev> h_frames;
+    DevBuf<TrackFrameDev> d_frames;
+    PinnedBuf<MatchFrameDev> h_mframes;
+    DevBuf<MatchFrameDev> d_mframes;
+    PinnedBuf<int32_t> h_pass, h_key_base, h_small, h_nmatch, h_amb;
+    DevBuf<int32_t> d_pass, d_key_base;
+    DevBuf<MatchQuery> d_queries, d_patch;
+    PinnedBuf<MatchQuery> h_patch;
+    DevBuf<int32_t> d_query_frame, d_match, d_prev, d_rounds, d_nmatch, d_amb;
+    DevBuf<int32_t> d_cell_start, d_cand_off, d_cand_cnt, d_pool_top;
+    DevBuf<uint16_t> d_items;
+    DevBuf<uint32_t> d_pool;
+    DevBuf<PoseProblem> d_probs;
+    DevBuf<BaEdge> d_edges;
+    DevBuf<double> d_Xw, d_poses, d_chi2;
+    DevBuf<uint8_t> d_outlier, d_occ, d_outlier_key;
+    DevBuf<int32_t> d_edge_kp, d_inliers, d_ninl, d_of_key;
+};
+// one work space per host thread: TrackWithMotionModel and TrackLocalMap of different batches run side by side
+TrackWs& tws() { static thread_local TrackWs w; return w; }
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline void quat_rotate_f(const float q[4], const float v[3], float out[3]) {  // Eigen::Quaternionf::_transformVector
+    float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    out[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    out[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    out[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+void fill_const(const tc2li_orb* o, const tc2li_camera* cam, float b, int capacity, TrackConst& C) {
+    memset(&C, 0, sizeof(C));
+    C.cam4[0] = (float)cam->fx; C.cam4[1] = (float)cam->fy; C.cam4[2] = (float)cam->cx; C.cam4[3] = (float)cam->cy;
+    C.b = b; C.bf = (float)cam->bf;
+    C.n_levels = o->prm.nlevels;
+    for (int l = 0; l < C.n_levels; ++l) { C.scale[l] = o->scale[l]; C.inv_sigma2[l] = o->inv_sigma2[l]; }
+    C.cols = o->cur_w; C.rows = o->cur_h; C.capacity = capacity;
+    C.log_scale = std::log(o->prm.scale_factor);  // mfLogScaleFactor = log(mfScaleFactor) (SF/src/Frame.cc:96)
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Pass {
+    TrackWs& w;
+    tc2li_orb* o;
+    int n_frames, total_q, capacity;
+    const float* d_ur;       // [n_frames][capacity]
+    const uint8_t* d_occ;    // [n_frames][capacity] or NULL
+    int mode;
+    float nn_ratio;
+    bool check_orientation;
+    hipStream_t st;
+    int pool_cap = 0;
+
+    int prepare() {
+        const char* per_query = getenv("TC2LI_MATCH_POOL_PER_QUERY");  // tests shrink the pool to reach the overflow path
+        pool_cap = std::max(1, per_query ? atoi(per_query) : 32) * std::max(total_q, 1);
+        TC2LI_HIP_CHECK(w.d_mframes.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_mframes.ensure(n_frames));
+        TC2LI_HIP_CHECK(w.d_pass.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_pass.ensure(n_frames));
+        TC2LI_HIP_CHECK(w.d_key_base.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_key_base.ensure(n_frames));
+        TC2LI_HIP_CHECK(w.d_prev.ensure(std::max(total_q, 1))); TC2LI_HIP_CHECK(w.d_rounds.ensure(n_frames));
+        TC2LI_HIP_CHECK(w.d_nmatch.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_nmatch.ensure(n_frames));
+        TC2LI_HIP_CHECK(w.d_cell_start.ensure((size_t)n_frames * kCellsPlus1));
+        TC2LI_HIP_CHECK(w.d_cand_off.ensure(std::max(total_q, 1))); TC2LI_HIP_CHECK(w.d_cand_cnt.ensure(std::max(total_q, 1)));
+        TC2LI_HIP_CHECK(w.d_pool_top.ensure(2)); TC2LI_HIP_CHECK(w.h_small.ensure(8));
+        TC2LI_HIP_CHECK(w.d_items.ensure((size_t)n_frames * std::max(capacity, 1))); TC2LI_HIP_CHECK(w.d_pool.ensure(pool_cap));
+        return TC2LI_OK;
+    }
+    // frames of the pass are in w.h_pass[0 .. n_pass); their TrackFrameDev (slot set) are on the device already
+    int queue(int n_pass, bool lists) {
+        for (int k = 0; k < n_pass; ++k) {
+            const int f = w.h_pass.p[k];
+            const TrackFrameDev& F = w.h_frames.p[f];
+            w.h_mframes.p[k] = MatchFrameDev{o->d_mkeys.p + F.key_off, o->d_desc.p + (size_t)F.key_off * 32, d_ur + (size_t)f * capacity,
+                                             d_occ ? d_occ + (size_t)f * capacity : nullptr, w.d_queries.p + F.q_off, F.n_keys, F.n_q, F.q_off, 0,
+                                             0.0f, (float)o->cur_w, 0.0f, (float)o->cur_h};
+            w.h_key_base.p[k] = f * capacity;
+        }
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_mframes.p, w.h_mframes.p, n_pass * sizeof(MatchFrameDev), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_key_base.p, w.h_key_base.p, n_pass * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_pass.p, w.h_pass.p, n_pass * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (lists) {
+            MatchLists L{w.d_cell_start.p, w.d_items.p, w.d_key_base.p, w.d_cand_off.p, w.d_cand_cnt.p, w.d_pool.p, w.d_pool_top.p, pool_cap, 0};
+            launch_match_lists(w.d_mframes.p, n_pass, w.d_query_frame.p, total_q, L, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
+            TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_small.p, w.d_pool_top.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        } else {  // the one-kernel form: same result, no candidate pool
+            launch_match_by_projection(w.d_mframes.p, n_pass, mode, nn_ratio, w.d_match.p, w.d_prev.p, w.d_rounds.p, st);
+            w.h_small.p[1] = 0;
+        }
+        launch_track_count(w.d_frames.p, w.d_pass.p, n_pass, w.d_queries.p, o->d_angles.p, check_orientation ? 1 : 0, w.d_match.p, w.d_nmatch.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_nmatch.p, w.d_nmatch.p, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        return TC2LI_OK;
+    }
+};
+
+// Resets the matches of the pass's frames (the query kernels do that when they rebuild the queries; the overflow path needs it alone).
+int reset_matches(TrackWs& w, int n_pass, hipStream_t st) {
+    for (int k = 0; k < n_pass; ++k) {
+        const TrackFrameDev& F = w.h_frames.p[w.h_pass.p[k]];
+        if (F.n_q) TC2LI_HIP_CHECK(hipMemsetAsync(w.d_match.p + F.q_off, 0xff, (size_t)F.n_q * sizeof(int32_t), st));
+    }
+    return TC2LI_OK;
+}
+
+}  // namespace
 
 extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right,
                                               int capacity, const tc2li_last_frame* last, const float* pose_pred7,
@@ -35,95 +158,134 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
     static const bool kTiming = getenv("TC2LI_TRACK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[6] = {0, 0, 0, 0, 0, 0}, t0 = now();
-    const int L = o->prm.nlevels;
-    const float cam4[4] = {(float)cam->fx, (float)cam->fy, (float)cam->cx, (float)cam->cy};
-    const float bf = (float)cam->bf;
+    TrackWs& w = tws();
+    TrackConst C;
+    fill_const(o, cam, b, capacity, C);
+    const int L = C.n_levels;
 
-    std::vector<BatchSearchFrame> frames(n_frames);
+    TC2LI_HIP_CHECK(w.h_frames.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_frames.ensure(n_frames));
     int total_q = 0;
     for (int f = 0; f < n_frames; ++f) {
-        BatchSearchFrame& fr = frames[f];
-        fr.key_off = o->last_kp_off[2 * f];
-        fr.n_keys = o->last_kp_cnt[2 * f];
-        if (fr.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, fr.n_keys); return TC2LI_ERR_CAPACITY; }
-        fr.keys_host = keypoints + (size_t)(2 * f) * capacity;
-        fr.u_right_host = u_right + (size_t)f * capacity;
+        TrackFrameDev& F = w.h_frames.p[f];
+        memset(&F, 0, sizeof(F));
+        F.key_off = o->last_kp_off[2 * f];
+        F.n_keys = o->last_kp_cnt[2 * f];
+        if (F.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, F.n_keys); return TC2LI_ERR_CAPACITY; }
+        if (F.n_keys > kMaxMatchKeys) { set_error("frame has %d keypoints, the matcher supports %d", F.n_keys, kMaxMatchKeys); return TC2LI_ERR_CAPACITY; }
         if (last[f].n < 0 || (last[f].n > 0 && (!last[f].has_point || !last[f].outlier || !last[f].Xw || !last[f].keys || !last[f].descriptors))) {
             set_error("tc2li_track_motion_model_batch: last frame %d has null arrays", f);
             return TC2LI_ERR_INVALID;
         }
-        fr.q_off = total_q;
-        fr.n_q = last[f].n;
+        F.q_off = total_q; F.n_q = last[f].n;
         total_q += last[f].n;
+        memcpy(F.pose7, pose_pred7 + 7 * (size_t)f, 7 * sizeof(float));
+        memcpy(F.last_pose7, last[f].pose7, 7 * sizeof(float));
+        F.th = th; F.slot = f;
+        // forward / backward (ORBmatcher.cc:1703-1708): tlc = Tlw * twc
+        float twc[3], tlc[3];
+        const float qi[4] = {-F.pose7[0], -F.pose7[1], -F.pose7[2], F.pose7[3]};
+        const float nt[3] = {F.pose7[4] * -1.f, F.pose7[5] * -1.f, F.pose7[6] * -1.f};
+        quat_rotate_f(qi, nt, twc);
+        quat_rotate_f(F.last_pose7, twc, tlc);
+        for (int c = 0; c < 3; ++c) tlc[c] += F.last_pose7[4 + c];
+        F.forward = tlc[2] > b; F.backward = -tlc[2] > b;
     }
-    std::vector<tc2li_proj_query> queries(std::max(total_q, 1));
-    std::vector<int32_t> match(std::max(total_q, 1), -1);
-    std::vector<int> rc(n_frames, 0);
-    auto build_queries = [&](int f, float radius) {
-        const tc2li_last_frame& lf = last[f];
-        rc[f] = tc2li_project_last_frame(pose_pred7 + 7 * f, lf.pose7, cam4, b, bf, o->scale.data(), L, o->cur_w, o->cur_h, lf.n, lf.has_point,
-                                         lf.outlier, lf.Xw, lf.keys, lf.descriptors, radius, 0, queries.data() + frames[f].q_off);
-    };
-    tracking_pool().parallel_for(n_frames, [&](int f) { build_queries(f, th); });
-    for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
-    tm[0] = now() - t0; t0 = now();
-    int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 0, 0.9f, true, match.data(), n_matches, st);
-    if (r < 0) return r;
-    tm[1] = now() - t0; t0 = now();
-    // fewer than 20 matches: wider window (Tracking.cc:2774-2783)
-    std::vector<int> retry;
-    for (int f = 0; f < n_frames; ++f) if (n_matches[f] < 20) retry.push_back(f);
-    if (!retry.empty()) {
-        std::vector<BatchSearchFrame> again(retry.size());
-        std::vector<int32_t> nm(retry.size());
-        tracking_pool().parallel_for((int)retry.size(), [&](int k) { build_queries(retry[k], 2 * th); });
-        for (size_t k = 0; k < retry.size(); ++k) { if (rc[retry[k]] < 0) return rc[retry[k]]; again[k] = frames[retry[k]]; }
-        r = search_batch_device(o, again.data(), (int)again.size(), queries.data(), 0, 0.9f, true, match.data(), nm.data(), st);
-        if (r < 0) return r;
-        for (size_t k = 0; k < retry.size(); ++k) n_matches[retry[k]] = nm[k];
-    }
-    // ---- Optimizer::PoseOptimization: one edge per keypoint that now holds a map point, in keypoint order ----
-    std::vector<int32_t> edge_off(n_frames + 1, 0);
-    for (int f = 0; f < n_frames; ++f) edge_off[f + 1] = edge_off[f] + (n_matches[f] >= 20 ? n_matches[f] : 0);
-    const int total_e = edge_off[n_frames];
-    std::vector<double> Xw(3 * (size_t)std::max(total_e, 1));
-    std::vector<tc2li_ba_edge> edges(std::max(total_e, 1));
-    std::vector<int32_t> edge_kp(std::max(total_e, 1));
-    std::vector<uint8_t> outlier(std::max(total_e, 1), 0);
+    // ---- one staging block: the last frames' points (structure of arrays) and mvuRight of the current frames ----
+    const size_t nq = (size_t)std::max(total_q, 1), nk = (size_t)n_frames * std::max(capacity, 1);
+    const size_t o_flags = 0, o_Xw = up256(o_flags + nq), o_ang = up256(o_Xw + 12 * nq), o_oct = up256(o_ang + 4 * nq), o_desc = up256(o_oct + 4 * nq),
+                 o_ur = up256(o_desc + 32 * nq), stage_bytes = up256(o_ur + 4 * nk);
+    TC2LI_HIP_CHECK(w.h_stage.ensure(stage_bytes)); TC2LI_HIP_CHECK(w.d_stage.ensure(stage_bytes));
+    std::vector<int> bad(n_frames, 0);
     tracking_pool().parallel_for(n_frames, [&](int f) {
-        const BatchSearchFrame& fr = frames[f];
-        int32_t* mp = map_point_of_keypoint + (size_t)f * capacity;
-        for (int i = 0; i < capacity; ++i) mp[i] = -1;
-        const int32_t* m = match.data() + fr.q_off;
-        for (int q = 0; q < fr.n_q; ++q) if (m[q] >= 0) mp[m[q]] = q;
-        for (int c = 0; c < 7; ++c) poses7[7 * f + c] = (double)pose_pred7[7 * f + c];
-        if (n_matches[f] < 20) return;
-        int e = edge_off[f];
-        for (int i = 0; i < fr.n_keys; ++i) {
-            const int q = mp[i];
-            if (q < 0) continue;
-            const tc2li_keypoint& kp = fr.keys_host[i];
-            tc2li_ba_edge& ed = edges[e];
-            ed.point = e - edge_off[f]; ed.pose = 0;
-            ed.u = kp.x; ed.v = kp.y; ed.u_right = fr.u_right_host[i];
-            ed.inv_sigma2 = o->inv_sigma2[kp.octave];
-            for (int c = 0; c < 3; ++c) Xw[3 * (size_t)e + c] = (double)last[f].Xw[3 * (size_t)q + c];
-            edge_kp[e] = i;
-            ++e;
+        const TrackFrameDev& F = w.h_frames.p[f];
+        const tc2li_last_frame& lf = last[f];
+        uint8_t* hs = w.h_stage.p;
+        uint8_t* fl = hs + o_flags + F.q_off;
+        float* ang = reinterpret_cast<float*>(hs + o_ang) + F.q_off;
+        int32_t* oct = reinterpret_cast<int32_t*>(hs + o_oct) + F.q_off;
+        for (int i = 0; i < lf.n; ++i) {
+            fl[i] = (uint8_t)((lf.has_point[i] ? 1 : 0) | (lf.outlier[i] ? 2 : 0));
+            ang[i] = lf.keys[i].angle;
+            oct[i] = lf.keys[i].octave;
+            if (fl[i] == 1 && (oct[i] < 0 || oct[i] >= L)) bad[f] = 1;
         }
+        if (lf.n) {
+            memcpy(hs + o_Xw + 12 * (size_t)F.q_off, lf.Xw, 12 * (size_t)lf.n);
+            memcpy(hs + o_desc + 32 * (size_t)F.q_off, lf.descriptors, 32 * (size_t)lf.n);
+        }
+        memcpy(hs + o_ur + 4 * (size_t)f * capacity, u_right + (size_t)f * capacity, 4 * (size_t)F.n_keys);
     });
-    tm[2] = now() - t0; t0 = now();
-    std::vector<int32_t> inl(n_frames, 0);
-    r = tc2li_pose_optimization_batch(n_frames, poses7, edge_off.data(), Xw.data(), edges.data(), cam, outlier.data(), inl.data(), stream_);
-    if (r < 0) return r;
-    tm[3] = now() - t0; t0 = now();
-    for (int f = 0; f < n_frames; ++f) {
-        if (n_matches[f] < 20) { n_inliers[f] = -1; for (int c = 0; c < 7; ++c) poses7[7 * f + c] = (double)pose_pred7[7 * f + c]; continue; }
-        n_inliers[f] = inl[f];
-        int32_t* mp = map_point_of_keypoint + (size_t)f * capacity;
-        for (int e = edge_off[f]; e < edge_off[f + 1]; ++e) if (outlier[e]) mp[edge_kp[e]] = -1;  // Tracking.cc:2804-2818
+    for (int f = 0; f < n_frames; ++f) if (bad[f]) { set_error("octave out of range"); return TC2LI_ERR_INVALID; }
+    tm[0] = now() - t0; t0 = now();
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_stage.p, w.h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(TrackFrameDev), hipMemcpyHostToDevice, st));
+    const uint8_t* ds = w.d_stage.p;
+    const LastFrameArrays A{ds + o_flags, reinterpret_cast<const float*>(ds + o_Xw), reinterpret_cast<const float*>(ds + o_ang),
+                            reinterpret_cast<const int32_t*>(ds + o_oct), ds + o_desc};
+    const float* d_ur = reinterpret_cast<const float*>(ds + o_ur);
+    TC2LI_HIP_CHECK(w.d_queries.ensure(nq)); TC2LI_HIP_CHECK(w.d_query_frame.ensure(nq)); TC2LI_HIP_CHECK(w.d_match.ensure(nq));
+    Pass pass{w, o, n_frames, total_q, capacity, d_ur, nullptr, 0, 0.9f, true, st};
+    int rc = pass.prepare();
+    if (rc != TC2LI_OK) return rc;
+    for (int f = 0; f < n_frames; ++f) w.h_pass.p[f] = f;
+    if (total_q > 0) {
+        launch_track_queries_last(w.d_frames.p, n_frames, C, A, total_q, w.d_queries.p, w.d_query_frame.p, w.d_match.p, st);
+        rc = pass.queue(n_frames, true);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        if (w.h_small.p[1]) {  // candidate pool exhausted (very dense windows)
+            rc = reset_matches(w, n_frames, st);
+            if (rc == TC2LI_OK) rc = pass.queue(n_frames, false);
+            if (rc != TC2LI_OK) return rc;
+            TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        }
+        memcpy(n_matches, w.h_nmatch.p, n_frames * sizeof(int32_t));
+    } else {
+        for (int f = 0; f < n_frames; ++f) n_matches[f] = 0;
+        TC2LI_HIP_CHECK(hipMemsetAsync(w.d_nmatch.p, 0, n_frames * sizeof(int32_t), st));
     }
-    if (kTiming) fprintf(stderr, "track timing ms: queries %.3f search %.3f edges %.3f pose-opt %.3f finish %.3f\n", tm[0], tm[1], tm[2], tm[3], now() - t0);
+    tm[1] = now() - t0; t0 = now();
+    // fewer than 20 matches: wider window (Tracking.cc:2774-2783), those frames only
+    int n_retry = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        TrackFrameDev& F = w.h_frames.p[f];
+        if (n_matches[f] < 20 && F.n_q > 0) { F.slot = n_retry; F.th = 2 * th; w.h_pass.p[n_retry++] = f; }
+        else F.slot = -1;
+    }
+    if (n_retry > 0) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(TrackFrameDev), hipMemcpyHostToDevice, st));
+        launch_track_queries_last(w.d_frames.p, n_frames, C, A, total_q, w.d_queries.p, w.d_query_frame.p, w.d_match.p, st);
+        rc = pass.queue(n_retry, true);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        if (w.h_small.p[1]) {
+            rc = reset_matches(w, n_retry, st);
+            if (rc == TC2LI_OK) rc = pass.queue(n_retry, false);
+            if (rc != TC2LI_OK) return rc;
+            TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        }
+        memcpy(n_matches, w.h_nmatch.p, n_frames * sizeof(int32_t));  // d_nmatch holds every frame: the pass rewrote its own
+    }
+    tm[2] = now() - t0; t0 = now();
+    // ---- Optimizer::PoseOptimization: one edge per keypoint that now holds a map point, in keypoint order ----
+    const size_t ne = (size_t)n_frames * std::max(capacity, 1);
+    TC2LI_HIP_CHECK(w.d_of_key.ensure(ne)); TC2LI_HIP_CHECK(w.d_probs.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_edges.ensure(ne)); TC2LI_HIP_CHECK(w.d_Xw.ensure(3 * ne));
+    TC2LI_HIP_CHECK(w.d_edge_kp.ensure(ne)); TC2LI_HIP_CHECK(w.d_poses.ensure(7 * (size_t)n_frames)); TC2LI_HIP_CHECK(w.d_outlier.ensure(ne));
+    TC2LI_HIP_CHECK(w.d_chi2.ensure(ne)); TC2LI_HIP_CHECK(w.d_inliers.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_ninl.ensure(n_frames));
+    launch_track_edges_last(w.d_frames.p, n_frames, C, o->d_mkeys.p, d_ur, w.d_match.p, w.d_nmatch.p, A.Xw, w.d_of_key.p, w.d_probs.p, w.d_edges.p, w.d_Xw.p,
+                            w.d_edge_kp.p, w.d_poses.p, st);
+    CameraD cd;
+    memcpy(&cd, cam, sizeof(cd));
+    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, st);
+    launch_track_finish_last(w.d_frames.p, n_frames, capacity, w.d_nmatch.p, w.d_probs.p, w.d_outlier.p, w.d_edge_kp.p, w.d_inliers.p, w.d_of_key.p, w.d_poses.p,
+                             w.d_ninl.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(map_point_of_keypoint, w.d_of_key.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(poses7, w.d_poses.p, 7 * (size_t)n_frames * sizeof(double), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(n_inliers, w.d_ninl.p, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    tm[3] = now() - t0;
+    if (kTiming) fprintf(stderr, "track timing ms: stage %.3f search %.3f retry %.3f edges+pose-opt+results %.3f\n", tm[0], tm[1], tm[2], tm[3]);
     return n_frames;
 }
 
@@ -150,104 +312,119 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     const int total_q = local_offsets[n_frames];
     if (total_q < 0 || (total_q > 0 && !local_points)) { set_error("tc2li_track_local_map_batch: invalid local points"); return TC2LI_ERR_INVALID; }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    static_assert(sizeof(tc2li_map_point) == sizeof(LocalPointDev), "ABI layout");
     hipStream_t st = (hipStream_t)stream_;
-    const int L = o->prm.nlevels;
-    const float cam4[4] = {(float)cam->fx, (float)cam->fy, (float)cam->cx, (float)cam->cy};
-    const float bf = (float)cam->bf;
-    const float log_scale = std::log(o->prm.scale_factor);  // mfLogScaleFactor = log(mfScaleFactor) (SF/src/Frame.cc:96)
     static const bool kTiming = getenv("TC2LI_TRACK_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[5] = {0, 0, 0, 0, 0}, t0 = now();
-    std::vector<BatchSearchFrame> frames(n_frames);
-    std::vector<std::vector<uint8_t>> occ(n_frames);
+    TrackWs& w = tws();
+    TrackConst C;
+    fill_const(o, cam, 0.f, capacity, C);
+    C.far_points = far_points; C.th_far = th_far_points; C.view_cos_limit = 0.5f;
+
+    TC2LI_HIP_CHECK(w.h_frames.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_frames.ensure(n_frames));
     for (int f = 0; f < n_frames; ++f) {
-        BatchSearchFrame& fr = frames[f];
-        fr.key_off = o->last_kp_off[2 * f];
-        fr.n_keys = o->last_kp_cnt[2 * f];
-        if (fr.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, fr.n_keys); return TC2LI_ERR_CAPACITY; }
+        TrackFrameDev& F = w.h_frames.p[f];
+        memset(&F, 0, sizeof(F));
+        F.key_off = o->last_kp_off[2 * f];
+        F.n_keys = o->last_kp_cnt[2 * f];
+        if (F.n_keys > capacity) { set_error("capacity %d < %d keypoints", capacity, F.n_keys); return TC2LI_ERR_CAPACITY; }
+        if (F.n_keys > kMaxMatchKeys) { set_error("frame has %d keypoints, the matcher supports %d", F.n_keys, kMaxMatchKeys); return TC2LI_ERR_CAPACITY; }
         if (local_offsets[f + 1] < local_offsets[f]) { set_error("tc2li_track_local_map_batch: local_offsets must not decrease"); return TC2LI_ERR_INVALID; }
-        fr.keys_host = keypoints + (size_t)(2 * f) * capacity;
-        fr.u_right_host = u_right + (size_t)f * capacity;
-        fr.q_off = local_offsets[f];
-        fr.n_q = local_offsets[f + 1] - local_offsets[f];
-        occ[f].resize(std::max(fr.n_keys, 1));
-        const uint8_t* h = held + (size_t)f * capacity;
-        for (int i = 0; i < fr.n_keys; ++i) occ[f][i] = h[i] == 1;  // held with Observations() > 0 (ORBmatcher.cc:100-102)
-        fr.occupied_host = occ[f].data();
+        F.q_off = local_offsets[f]; F.n_q = local_offsets[f + 1] - local_offsets[f];
+        memcpy(F.pose7, poses7 + 7 * (size_t)f, 7 * sizeof(float));
+        F.th = th; F.slot = f;
     }
-    std::vector<tc2li_proj_query> queries(std::max(total_q, 1));
-    std::vector<int32_t> match(std::max(total_q, 1), -1);
-    std::vector<int> rc(n_frames, 0);
-    tracking_pool().parallel_for(n_frames, [&](int f) {
-        if (frames[f].n_q > 0)
-            rc[f] = tc2li_project_local_map(poses7 + 7 * f, cam4, bf, o->scale.data(), L, log_scale, o->cur_w, o->cur_h, frames[f].n_q,
-                                            local_points + frames[f].q_off, th, far_points, th_far_points, 0.5f, queries.data() + frames[f].q_off);
-    });
-    for (int f = 0; f < n_frames; ++f) if (rc[f] < 0) return rc[f];
+    // ---- one staging block: the local points, mvuRight, the held flags and positions ----
+    const size_t nq = (size_t)std::max(total_q, 1), nk = (size_t)n_frames * std::max(capacity, 1);
+    const size_t o_pts = 0, o_ur = up256(o_pts + sizeof(LocalPointDev) * nq), o_held = up256(o_ur + 4 * nk), o_hx = up256(o_held + nk),
+                 stage_bytes = up256(o_hx + 12 * nk);
+    TC2LI_HIP_CHECK(w.h_stage.ensure(stage_bytes)); TC2LI_HIP_CHECK(w.d_stage.ensure(stage_bytes));
+    {
+        // the callers' arrays are contiguous: copied in 1 MiB pieces by the pool
+        struct Piece { uint8_t* dst; const uint8_t* src; size_t n; };
+        std::vector<Piece> pieces;
+        auto add = [&](size_t off, const void* src, size_t bytes) {
+            for (size_t at = 0; at < bytes; at += (size_t)1 << 20)
+                pieces.push_back(Piece{w.h_stage.p + off + at, static_cast<const uint8_t*>(src) + at, std::min((size_t)1 << 20, bytes - at)});
+        };
+        if (total_q) add(o_pts, local_points, sizeof(LocalPointDev) * (size_t)total_q);
+        add(o_ur, u_right, 4 * nk); add(o_held, held, nk); add(o_hx, held_Xw, 12 * nk);
+        tracking_pool().parallel_for((int)pieces.size(), [&](int k) { memcpy(pieces[k].dst, pieces[k].src, pieces[k].n); });
+    }
     tm[0] = now() - t0; t0 = now();
-    int r = search_batch_device(o, frames.data(), n_frames, queries.data(), 1, 0.8f, false, match.data(), n_matches, st);
-    if (r < 0) return r;
-    tm[1] = now() - t0; t0 = now();
-    // ---- Optimizer::PoseOptimization over every map point the frame now holds, in keypoint order ----
-    std::vector<int32_t> edge_off(n_frames + 1, 0);
-    tracking_pool().parallel_for(n_frames, [&](int f) {
-        const BatchSearchFrame& fr = frames[f];
-        int32_t* lk = local_of_keypoint + (size_t)f * capacity;
-        for (int i = 0; i < capacity; ++i) lk[i] = -1;
-        const int32_t* m = match.data() + fr.q_off;
-        for (int q = 0; q < fr.n_q; ++q) if (m[q] >= 0) lk[m[q]] = q;  // F.mvpMapPoints[bestIdx] = pMP
-    });
-    for (int f = 0; f < n_frames; ++f) {
-        const uint8_t* h = held + (size_t)f * capacity;
-        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
-        int ne = 0;
-        for (int i = 0; i < frames[f].n_keys; ++i) ne += (h[i] != 0 || lk[i] >= 0) ? 1 : 0;
-        edge_off[f + 1] = edge_off[f] + ne;
-    }
-    const int total_e = edge_off[n_frames];
-    std::vector<double> Xw(3 * (size_t)std::max(total_e, 1));
-    std::vector<tc2li_ba_edge> edges(std::max(total_e, 1));
-    std::vector<int32_t> edge_kp(std::max(total_e, 1));
-    std::vector<uint8_t> out(std::max(total_e, 1), 0);
-    tracking_pool().parallel_for(n_frames, [&](int f) {
-        const BatchSearchFrame& fr = frames[f];
-        const uint8_t* h = held + (size_t)f * capacity;
-        const float* hx = held_Xw + 3 * (size_t)f * capacity;
-        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
-        for (int c = 0; c < 7; ++c) poses7_out[7 * f + c] = (double)poses7[7 * f + c];
-        int e = edge_off[f];
-        for (int i = 0; i < fr.n_keys; ++i) {
-            if (!(h[i] != 0 || lk[i] >= 0)) continue;
-            const tc2li_keypoint& kp = fr.keys_host[i];
-            tc2li_ba_edge& ed = edges[e];
-            ed.point = e - edge_off[f]; ed.pose = 0;
-            ed.u = kp.x; ed.v = kp.y; ed.u_right = fr.u_right_host[i];
-            ed.inv_sigma2 = o->inv_sigma2[kp.octave];
-            const float* X = lk[i] >= 0 ? local_points[fr.q_off + lk[i]].pos : hx + 3 * (size_t)i;
-            for (int c = 0; c < 3; ++c) Xw[3 * (size_t)e + c] = (double)X[c];
-            edge_kp[e] = i;
-            ++e;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_stage.p, w.h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_frames.p, w.h_frames.p, n_frames * sizeof(TrackFrameDev), hipMemcpyHostToDevice, st));
+    const uint8_t* ds = w.d_stage.p;
+    const LocalPointDev* d_pts = reinterpret_cast<const LocalPointDev*>(ds + o_pts);
+    const float* d_ur = reinterpret_cast<const float*>(ds + o_ur);
+    const uint8_t* d_held = ds + o_held;
+    const float* d_hx = reinterpret_cast<const float*>(ds + o_hx);
+    TC2LI_HIP_CHECK(w.d_queries.ensure(nq)); TC2LI_HIP_CHECK(w.d_query_frame.ensure(nq)); TC2LI_HIP_CHECK(w.d_match.ensure(nq));
+    TC2LI_HIP_CHECK(w.d_occ.ensure(nk)); TC2LI_HIP_CHECK(w.d_amb.ensure(1 + kAmbiguousCap)); TC2LI_HIP_CHECK(w.h_amb.ensure(1 + kAmbiguousCap));
+    Pass pass{w, o, n_frames, total_q, capacity, d_ur, w.d_occ.p, 1, 0.8f, false, st};
+    int rc = pass.prepare();
+    if (rc != TC2LI_OK) return rc;
+    for (int f = 0; f < n_frames; ++f) w.h_pass.p[f] = f;
+    launch_track_occupied(d_held, nk, w.d_occ.p, st);
+    if (total_q > 0) {
+        TC2LI_HIP_CHECK(hipMemsetAsync(w.d_amb.p, 0, sizeof(int32_t), st));
+        launch_track_queries_local(w.d_frames.p, n_frames, C, d_pts, total_q, w.d_queries.p, w.d_query_frame.p, w.d_match.p, w.d_amb.p, kAmbiguousCap, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        // MapPoint::PredictScale near a level boundary: the host's logf decides (see k_track_queries_local).  Rare: one count comes back,
+        // the listed queries are rebuilt by the host restatement of the same arithmetic and patched in before the search starts.
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_amb.p, w.d_amb.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        const int n_amb = w.h_amb.p[0];
+        if (n_amb > kAmbiguousCap) { set_error("tc2li_track_local_map_batch: %d local points on a scale-level boundary (at most %d handled)", n_amb, kAmbiguousCap); return TC2LI_ERR_CAPACITY; }
+        if (n_amb > 0) {
+            TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_amb.p + 1, w.d_amb.p + 1, n_amb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            TC2LI_HIP_CHECK(stream_wait_blocking(st));
+            TC2LI_HIP_CHECK(w.h_patch.ensure(n_amb)); TC2LI_HIP_CHECK(w.d_patch.ensure(n_amb));
+            for (int k = 0; k < n_amb; ++k) {
+                const int g = w.h_amb.p[1 + k];
+                const int f = (int)(std::upper_bound(local_offsets, local_offsets + n_frames + 1, g) - local_offsets) - 1;
+                const int r = tc2li_project_local_map(poses7 + 7 * (size_t)f, C.cam4, C.bf, o->scale.data(), C.n_levels, C.log_scale, o->cur_w, o->cur_h, 1,
+                                                      local_points + g, th, far_points, th_far_points, 0.5f, reinterpret_cast<tc2li_proj_query*>(w.h_patch.p + k));
+                if (r < 0) return r;
+            }
+            TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_patch.p, w.h_patch.p, n_amb * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
+            launch_track_patch_queries(w.d_amb.p + 1, w.d_patch.p, n_amb, w.d_queries.p, st);
         }
-    });
-    std::vector<int32_t> inl(n_frames, 0);
+        tm[1] = now() - t0; t0 = now();
+        rc = pass.queue(n_frames, true);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        if (w.h_small.p[1]) {
+            rc = reset_matches(w, n_frames, st);
+            if (rc == TC2LI_OK) rc = pass.queue(n_frames, false);
+            if (rc != TC2LI_OK) return rc;
+            TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        }
+        memcpy(n_matches, w.h_nmatch.p, n_frames * sizeof(int32_t));
+    } else {
+        for (int f = 0; f < n_frames; ++f) n_matches[f] = 0;
+    }
     tm[2] = now() - t0; t0 = now();
-    r = tc2li_pose_optimization_batch(n_frames, poses7_out, edge_off.data(), Xw.data(), edges.data(), cam, out.data(), inl.data(), stream_);
-    if (r < 0) return r;
-    tm[3] = now() - t0; t0 = now();
-    if (kTiming) fprintf(stderr, "track-local-map timing ms: queries %.3f search %.3f edges %.3f pose-opt %.3f\n", tm[0], tm[1], tm[2], tm[3]);
-    for (int f = 0; f < n_frames; ++f) {
-        uint8_t* ol = outlier + (size_t)f * capacity;
-        memset(ol, 0, capacity);
-        const uint8_t* h = held + (size_t)f * capacity;
-        const int32_t* lk = local_of_keypoint + (size_t)f * capacity;
-        int good = 0;
-        for (int e = edge_off[f]; e < edge_off[f + 1]; ++e) {
-            const int i = edge_kp[e];
-            ol[i] = out[e];
-            // mnMatchesInliers: not an outlier and Observations() > 0 (held == 2: a point without observations; local points have them)
-            if (!out[e] && (lk[i] >= 0 || h[i] == 1)) ++good;
-        }
-        n_inliers[f] = good;
-    }
+    // ---- Optimizer::PoseOptimization over every map point the frame now holds, in keypoint order ----
+    const size_t ne = nk;
+    TC2LI_HIP_CHECK(w.d_of_key.ensure(ne)); TC2LI_HIP_CHECK(w.d_probs.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_edges.ensure(ne)); TC2LI_HIP_CHECK(w.d_Xw.ensure(3 * ne));
+    TC2LI_HIP_CHECK(w.d_edge_kp.ensure(ne)); TC2LI_HIP_CHECK(w.d_poses.ensure(7 * (size_t)n_frames)); TC2LI_HIP_CHECK(w.d_outlier.ensure(ne));
+    TC2LI_HIP_CHECK(w.d_chi2.ensure(ne)); TC2LI_HIP_CHECK(w.d_inliers.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_ninl.ensure(n_frames));
+    TC2LI_HIP_CHECK(w.d_outlier_key.ensure(ne));
+    launch_track_edges_local(w.d_frames.p, n_frames, C, o->d_mkeys.p, d_ur, w.d_match.p, d_held, d_hx, d_pts, w.d_of_key.p, w.d_probs.p, w.d_edges.p, w.d_Xw.p,
+                             w.d_edge_kp.p, w.d_poses.p, st);
+    CameraD cd;
+    memcpy(&cd, cam, sizeof(cd));
+    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, st);
+    launch_track_finish_local(w.d_frames.p, n_frames, capacity, w.d_probs.p, w.d_outlier.p, w.d_edge_kp.p, d_held, w.d_of_key.p, w.d_outlier_key.p, w.d_ninl.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(local_of_keypoint, w.d_of_key.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(outlier, w.d_outlier_key.p, ne, hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(poses7_out, w.d_poses.p, 7 * (size_t)n_frames * sizeof(double), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(n_inliers, w.d_ninl.p, n_frames * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    tm[3] = now() - t0;
+    if (kTiming) fprintf(stderr, "track-local-map timing ms: stage %.3f queries %.3f search %.3f edges+pose-opt+results %.3f\n", tm[0], tm[1], tm[2], tm[3]);
     return n_frames;
 }
