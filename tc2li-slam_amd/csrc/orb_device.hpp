@@ -86,6 +86,8 @@ struct StereoFrame {
 
 void launch_stereo_match(const LevelTable& left, const LevelTable& right, const ScaleTable& sc, const StereoFrame* frames,
                          int nframes, int max_left, const MatchKey* keys, const uint8_t* desc, float mbf, float max_d,
-                         float* u_right, float* depth, int* best_sad, hipStream_t st);
+                         float* u_right, float* depth, int* best_sad, int rows, int entry_cap, int32_t* row_start, uint16_t* entries, hipStream_t st);
+// candidates per frame the row lists of the stereo matcher can take: every right keypoint appears in the rows of its band
+int stereo_row_entry_cap(const ScaleTable& sc, int n_levels, int max_right);
 
 }  // namespace tc2li

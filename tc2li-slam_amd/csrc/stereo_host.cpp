@@ -17,6 +17,8 @@ struct StereoWorkspace {
     DevBuf<uint8_t> d_desc;
     PinnedBuf<float> h_u, h_d;
     PinnedBuf<int> h_sad;
+    DevBuf<int32_t> d_row_start;  // the matcher's row lists (k_stereo_rows)
+    DevBuf<uint16_t> d_entries;
 };
 
 // One workspace per left handle, kept in a side table so that the handle struct stays ORB-only.
@@ -88,8 +90,13 @@ int tc2li_stereo_match_batch(tc2li_orb* o, int n_frames, float bf, float b, floa
     TC2LI_HIP_CHECK(ws->h_sad.ensure(std::max(out_total, 1)));
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws->d_frames.p, frames.data(), n_frames * sizeof(StereoFrame), hipMemcpyHostToDevice, st));
     const float mb = b, max_d = bf / mb;  // minZ = mb, maxD = mbf / minZ (SF/src/Frame.cc:868-871)
+    int max_right = 0;
+    for (int f = 0; f < n_frames; ++f) max_right = std::max(max_right, frames[f].n_right);
+    const int rows = o->cur_h, entry_cap = stereo_row_entry_cap(o->scale_tab, o->prm.nlevels, std::max(max_right, 1));
+    TC2LI_HIP_CHECK(ws->d_row_start.ensure((size_t)n_frames * (rows + 1)));
+    TC2LI_HIP_CHECK(ws->d_entries.ensure((size_t)n_frames * entry_cap));
     launch_stereo_match(o->raw_tab, o->raw_tab, o->scale_tab, ws->d_frames.p, n_frames, max_left, o->d_mkeys.p, o->d_desc.p,
-                        bf, max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, st);
+                        bf, max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, rows, entry_cap, ws->d_row_start.p, ws->d_entries.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
     tracking_pool().parallel_for(n_frames, [&](int f) {
@@ -144,8 +151,11 @@ int tc2li_stereo_match(tc2li_orb* left, tc2li_orb* right, const tc2li_keypoint* 
     if (n_right) TC2LI_HIP_CHECK(copy_sync(ws->d_desc.p + (size_t)n_left * 32, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, ps));
     TC2LI_HIP_CHECK(copy_sync(ws->d_frames.p, &fr, sizeof(fr), hipMemcpyHostToDevice, ps));
     const float max_d = bf / b;
+    const int rows = left->cur_h, entry_cap = stereo_row_entry_cap(left->scale_tab, L, std::max(n_right, 1));
+    TC2LI_HIP_CHECK(ws->d_row_start.ensure((size_t)rows + 1));
+    TC2LI_HIP_CHECK(ws->d_entries.ensure((size_t)entry_cap));
     launch_stereo_match(left->raw_tab, right->raw_tab, left->scale_tab, ws->d_frames.p, 1, n_left, ws->d_keys.p, ws->d_desc.p, bf,
-                        max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, ps);
+                        max_d, ws->h_u.p, ws->h_d.p, ws->h_sad.p, rows, entry_cap, ws->d_row_start.p, ws->d_entries.p, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
     memcpy(u_right, ws->h_u.p, n_left * sizeof(float));

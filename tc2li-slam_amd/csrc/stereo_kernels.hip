@@ -12,6 +12,9 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include <algorithm>
+#include <cmath>
+
 #include "det_math.hpp"
 #include "orb_device.hpp"
 
@@ -19,6 +22,7 @@ namespace tc2li {
 
 constexpr int kStereoMaxRight = 4096;  // right keypoints per frame that fit the LDS records
 constexpr int kLeftPerBlock = 32;
+constexpr int kStereoMaxRows = 2048;  // image rows the row lists of k_stereo_rows cover
 
 struct RightRec {
     float x;
@@ -26,12 +30,69 @@ struct RightRec {
     int32_t octave;
 };
 
+// vRowIndices of Frame::ComputeStereoMatches (SF/src/Frame.cc:858-866): for every image row the right keypoints whose band
+// [floor(y - r), ceil(y + r)], r = 2 * scale[octave], covers it -- a counting sort per frame (one workgroup), lists in global memory.
+// A left keypoint then compares descriptors with the candidates of its row only (some tens) instead of gating all right keypoints.
+// The order inside a list is arbitrary: the match is the minimum over (distance, right index), which does not depend on it.
+__global__ __launch_bounds__(256) void k_stereo_rows(ScaleTable sc, const StereoFrame* __restrict__ frames, const MatchKey* __restrict__ keys, int rows,
+                                                     int entry_cap, int32_t* __restrict__ row_start, uint16_t* __restrict__ entries) {
+    __shared__ int s_cnt[kStereoMaxRows];
+    __shared__ int s_wave[4];
+    const StereoFrame fr = frames[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const MatchKey* kr = keys + fr.right_off;
+    int32_t* rs = row_start + (size_t)blockIdx.x * (rows + 1);
+    uint16_t* out = entries + (size_t)blockIdx.x * entry_cap;
+    for (int y = tid; y < rows; y += 256) s_cnt[y] = 0;
+    __syncthreads();
+    for (int i = tid; i < fr.n_right; i += 256) {
+        const MatchKey k = kr[i];
+        const float r = __fmul_rn(2.0f, sc.scale[k.octave]);
+        const int maxr = min(rows - 1, (int)ceilf(__fadd_rn(k.y, r))), minr = max(0, (int)floorf(__fsub_rn(k.y, r)));
+        for (int y = minr; y <= maxr; ++y) atomicAdd(&s_cnt[y], 1);
+    }
+    __syncthreads();
+    // exclusive prefix over the rows: 8 consecutive rows per lane and pass
+    int carry = 0;
+    for (int y0 = 0; y0 < rows; y0 += 2048) {
+        int c[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int y = y0 + tid * 8 + k; c[k] = y < rows ? s_cnt[y] : 0; sum += c[k]; }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int base = carry, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { base += k < wave ? s_wave[k] : 0; tot += s_wave[k]; }
+        int at = base + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int y = y0 + tid * 8 + k; if (y < rows) { rs[y] = at; s_cnt[y] = at; } at += c[k]; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) rs[rows] = carry;
+    for (int i = tid; i < fr.n_right; i += 256) {
+        const MatchKey k = kr[i];
+        const float r = __fmul_rn(2.0f, sc.scale[k.octave]);
+        const int maxr = min(rows - 1, (int)ceilf(__fadd_rn(k.y, r))), minr = max(0, (int)floorf(__fsub_rn(k.y, r)));
+        for (int y = minr; y <= maxr; ++y) {
+            const int pos = atomicAdd(&s_cnt[y], 1);
+            if (pos < entry_cap) out[pos] = (uint16_t)i;
+        }
+    }
+}
+
+// kRows: candidates from the row lists of k_stereo_rows; otherwise (images taller than kStereoMaxRows) every right keypoint is gated.
+template <bool kRows>
 __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTable right, ScaleTable sc,
                                                       const StereoFrame* __restrict__ frames, const MatchKey* __restrict__ keys,
                                                       const uint8_t* __restrict__ desc, float mbf, float max_d,
                                                       float* __restrict__ u_right, float* __restrict__ depth,
-                                                      int* __restrict__ best_sad, int gx, int nframes) {
-    __shared__ RightRec recs[kStereoMaxRight];
+                                                      int* __restrict__ best_sad, int gx, int nframes, int rows, int entry_cap,
+                                                      const int32_t* __restrict__ row_start, const uint16_t* __restrict__ entries) {
+    __shared__ RightRec recs[kRows ? 1 : kStereoMaxRight];
     // One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each XCD has its own
     // L2): XCD k takes the k-th eighth of the (frame, key block) list, so a frame's pyramid rows and right-image records are
     // fetched into one L2.
@@ -44,17 +105,21 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
     const int first = bx * kLeftPerBlock;
     if (first >= fr.n_left) return;
     const MatchKey* kr = keys + fr.right_off;
-    for (int i = tid; i < fr.n_right; i += 256) {
-        const MatchKey k = kr[i];
-        const float r = __fmul_rn(2.0f, sc.scale[k.octave]);
-        RightRec rc;
-        rc.x = k.x;
-        rc.maxr = (int16_t)(int)ceilf(__fadd_rn(k.y, r));
-        rc.minr = (int16_t)(int)floorf(__fsub_rn(k.y, r));
-        rc.octave = k.octave;
-        recs[i] = rc;
+    if (!kRows) {
+        for (int i = tid; i < fr.n_right; i += 256) {
+            const MatchKey k = kr[i];
+            const float r = __fmul_rn(2.0f, sc.scale[k.octave]);
+            RightRec rc;
+            rc.x = k.x;
+            rc.maxr = (int16_t)(int)ceilf(__fadd_rn(k.y, r));
+            rc.minr = (int16_t)(int)floorf(__fsub_rn(k.y, r));
+            rc.octave = k.octave;
+            recs[i] = rc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const int32_t* rs = kRows ? row_start + (size_t)frame * (rows + 1) : nullptr;
+    const uint16_t* ent = kRows ? entries + (size_t)frame * entry_cap : nullptr;
 
     const uint32_t* dR = reinterpret_cast<const uint32_t*>(desc + (size_t)fr.right_off * 32);
     for (int li = first + wave; li < min(first + kLeftPerBlock, fr.n_left); li += 4) {
@@ -66,17 +131,34 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
         const int row = (int)kl.y;
         const float minU = __fsub_rn(kl.x, max_d), maxU = kl.x;
         uint32_t best = (100u << 16) | 0xffffu;  // TH_HIGH; ties resolve to the smallest right index
-        for (int i = lane; i < fr.n_right; i += 64) {
-            const RightRec rc = recs[i];
-            const bool ok = row >= rc.minr && row <= rc.maxr && rc.octave >= kl.octave - 1 && rc.octave <= kl.octave + 1 &&
-                            rc.x >= minU && rc.x <= maxU;
-            if (ok) {
-                const uint32_t* p = dR + (size_t)i * 8;
-                int dist = 0;
+        if (kRows) {
+            if (row >= 0 && row < rows) {
+                const int c1 = rs[row + 1];
+                for (int c = rs[row] + lane; c < c1; c += 64) {
+                    const int i = ent[c];
+                    const MatchKey k = kr[i];
+                    if (k.octave >= kl.octave - 1 && k.octave <= kl.octave + 1 && k.x >= minU && k.x <= maxU) {
+                        const uint32_t* p = dR + (size_t)i * 8;
+                        int dist = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dist += __popc(dl[k] ^ p[k]);
-                const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)i;
-                best = min(best, key);
+                        for (int w = 0; w < 8; ++w) dist += __popc(dl[w] ^ p[w]);
+                        best = min(best, ((uint32_t)dist << 16) | (uint32_t)i);
+                    }
+                }
+            }
+        } else {
+            for (int i = lane; i < fr.n_right; i += 64) {
+                const RightRec rc = recs[i];
+                const bool ok = row >= rc.minr && row <= rc.maxr && rc.octave >= kl.octave - 1 && rc.octave <= kl.octave + 1 &&
+                                rc.x >= minU && rc.x <= maxU;
+                if (ok) {
+                    const uint32_t* p = dR + (size_t)i * 8;
+                    int dist = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dist += __popc(dl[k] ^ p[k]);
+                    const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)i;
+                    best = min(best, key);
+                }
             }
         }
 #pragma unroll
@@ -85,7 +167,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
         float out_u = -1.0f, out_d = -1.0f;
         int out_sad = -1;
         if (bestDist < 75 && !(maxU < 0)) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
-            const float uR0 = recs[bestIdx].x;
+            const float uR0 = kRows ? kr[bestIdx].x : recs[bestIdx].x;
             const float sf = sc.inv_scale[kl.octave];
             const float scaleduL = roundf(__fmul_rn(kl.x, sf));
             const float scaledvL = roundf(__fmul_rn(kl.y, sf));
@@ -144,13 +226,26 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
     }
 }
 
+int stereo_row_entry_cap(const ScaleTable& sc, int n_levels, int max_right) {
+    float smax = 1.f;
+    for (int l = 0; l < n_levels; ++l) smax = std::max(smax, sc.scale[l]);
+    return max_right * (2 * (int)ceilf(2.f * smax) + 3);
+}
+
 void launch_stereo_match(const LevelTable& left, const LevelTable& right, const ScaleTable& sc, const StereoFrame* frames,
                          int nframes, int max_left, const MatchKey* keys, const uint8_t* desc, float mbf, float max_d,
-                         float* u_right, float* depth, int* best_sad, hipStream_t st) {
+                         float* u_right, float* depth, int* best_sad, int rows, int entry_cap, int32_t* row_start, uint16_t* entries, hipStream_t st) {
     if (nframes <= 0 || max_left <= 0) return;
     const int gx = (max_left + kLeftPerBlock - 1) / kLeftPerBlock;
-    TC2LI_LAUNCH(k_stereo_match, dim3((gx * nframes + 7) / 8 * 8), dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right,
-                       depth, best_sad, gx, nframes);
+    const dim3 grid((gx * nframes + 7) / 8 * 8);
+    if (row_start && entries && rows > 0 && rows <= kStereoMaxRows) {
+        TC2LI_LAUNCH(k_stereo_rows, dim3(nframes), dim3(256), 0, st, sc, frames, keys, rows, entry_cap, row_start, entries);
+        TC2LI_LAUNCH(k_stereo_match<true>, grid, dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right, depth, best_sad, gx, nframes, rows,
+                     entry_cap, row_start, entries);
+    } else {
+        TC2LI_LAUNCH(k_stereo_match<false>, grid, dim3(256), 0, st, left, right, sc, frames, keys, desc, mbf, max_d, u_right, depth, best_sad, gx, nframes, 0, 0,
+                     nullptr, nullptr);
+    }
 }
 
 }  // namespace tc2li

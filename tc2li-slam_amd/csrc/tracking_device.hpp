@@ -49,11 +49,11 @@ static_assert(sizeof(LocalPointDev) == 68, "layout of tc2li_map_point");
 
 void launch_track_queries_last(const TrackFrameDev* frames, int n_frames, const TrackConst& C, const LastFrameArrays& A, int total_q, MatchQuery* queries,
                                int32_t* query_frame, int32_t* match, hipStream_t st);
-// ambiguous[0] = number of queries whose predicted level lies so close to a level boundary that the host's logf decides it; their
-// indices follow (at most ambiguous_cap)
+// amb_count[0] = number of queries whose predicted scale level the host's logf has to decide (k_track_queries_local); their indices,
+// ratios mfMaxDistance / dist and window factors follow in amb_ids / amb_ratio / amb_r (room for total_q each)
 void launch_track_queries_local(const TrackFrameDev* frames, int n_frames, const TrackConst& C, const LocalPointDev* points, int total_q, MatchQuery* queries,
-                                int32_t* query_frame, int32_t* match, int32_t* ambiguous, int ambiguous_cap, hipStream_t st);
-void launch_track_patch_queries(const int32_t* ids, const MatchQuery* src, int n, MatchQuery* queries, hipStream_t st);
+                                int32_t* query_frame, int32_t* match, int32_t* amb_count, int32_t* amb_ids, float* amb_ratio, float* amb_r, hipStream_t st);
+void launch_track_patch_levels(const int32_t* ids, const int32_t* levels, const float* r, int n, const TrackConst& C, MatchQuery* queries, hipStream_t st);
 void launch_track_occupied(const uint8_t* held, size_t n, uint8_t* occ, hipStream_t st);
 // per frame of the pass: rotation histogram filter (check_orientation) and the number of matches
 void launch_track_count(const TrackFrameDev* frames, const int32_t* pass_frames, int n_pass, const MatchQuery* queries, const float* key_angles,

@@ -22,7 +22,6 @@ using namespace tc2li;
 namespace {
 
 constexpr int kCellsPlus1 = 64 * 48 + 1;  // the matcher's feature grid (matcher_kernels.hip)
-constexpr int kAmbiguousCap = 4096;
 
 struct TrackWs {
     PinnedBuf<uint8_t> h_stage;
@@ -33,8 +32,11 @@ struct TrackWs {
     DevBuf<MatchFrameDev> d_mframes;
     PinnedBuf<int32_t> h_pass, h_key_base, h_small, h_nmatch, h_amb;
     DevBuf<int32_t> d_pass, d_key_base;
-    DevBuf<MatchQuery> d_queries, d_patch;
-    PinnedBuf<MatchQuery> h_patch;
+    DevBuf<MatchQuery> d_queries;
+    DevBuf<float> d_amb_ratio, d_amb_r;
+    PinnedBuf<float> h_amb_ratio;
+    DevBuf<int32_t> d_amb_ids, d_amb_level;
+    PinnedBuf<int32_t> h_amb_level;
     DevBuf<int32_t> d_query_frame, d_match, d_prev, d_rounds, d_nmatch, d_amb;
     DevBuf<int32_t> d_cell_start, d_cand_off, d_cand_cnt, d_pool_top;
     DevBuf<uint16_t> d_items;
@@ -361,7 +363,9 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     const uint8_t* d_held = ds + o_held;
     const float* d_hx = reinterpret_cast<const float*>(ds + o_hx);
     TC2LI_HIP_CHECK(w.d_queries.ensure(nq)); TC2LI_HIP_CHECK(w.d_query_frame.ensure(nq)); TC2LI_HIP_CHECK(w.d_match.ensure(nq));
-    TC2LI_HIP_CHECK(w.d_occ.ensure(nk)); TC2LI_HIP_CHECK(w.d_amb.ensure(1 + kAmbiguousCap)); TC2LI_HIP_CHECK(w.h_amb.ensure(1 + kAmbiguousCap));
+    TC2LI_HIP_CHECK(w.d_occ.ensure(nk)); TC2LI_HIP_CHECK(w.d_amb.ensure(1)); TC2LI_HIP_CHECK(w.h_amb.ensure(1));
+    TC2LI_HIP_CHECK(w.d_amb_ids.ensure(nq)); TC2LI_HIP_CHECK(w.d_amb_ratio.ensure(nq)); TC2LI_HIP_CHECK(w.d_amb_r.ensure(nq)); TC2LI_HIP_CHECK(w.d_amb_level.ensure(nq));
+    TC2LI_HIP_CHECK(w.h_amb_ratio.ensure(nq)); TC2LI_HIP_CHECK(w.h_amb_level.ensure(nq));
     Pass pass{w, o, n_frames, total_q, capacity, d_ur, w.d_occ.p, 1, 0.8f, false, st};
     int rc = pass.prepare();
     if (rc != TC2LI_OK) return rc;
@@ -369,27 +373,30 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     launch_track_occupied(d_held, nk, w.d_occ.p, st);
     if (total_q > 0) {
         TC2LI_HIP_CHECK(hipMemsetAsync(w.d_amb.p, 0, sizeof(int32_t), st));
-        launch_track_queries_local(w.d_frames.p, n_frames, C, d_pts, total_q, w.d_queries.p, w.d_query_frame.p, w.d_match.p, w.d_amb.p, kAmbiguousCap, st);
+        launch_track_queries_local(w.d_frames.p, n_frames, C, d_pts, total_q, w.d_queries.p, w.d_query_frame.p, w.d_match.p, w.d_amb.p, w.d_amb_ids.p, w.d_amb_ratio.p,
+                                   w.d_amb_r.p, st);
         TC2LI_HIP_CHECK(hipGetLastError());
-        // MapPoint::PredictScale near a level boundary: the host's logf decides (see k_track_queries_local).  Rare: one count comes back,
-        // the listed queries are rebuilt by the host restatement of the same arithmetic and patched in before the search starts.
+        // MapPoint::PredictScale on a level boundary: the host's logf decides (see k_track_queries_local).  One count comes back; the
+        // listed ratios get their level here and a patch kernel writes level and window before the search starts.
         TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_amb.p, w.d_amb.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
         const int n_amb = w.h_amb.p[0];
-        if (n_amb > kAmbiguousCap) { set_error("tc2li_track_local_map_batch: %d local points on a scale-level boundary (at most %d handled)", n_amb, kAmbiguousCap); return TC2LI_ERR_CAPACITY; }
         if (n_amb > 0) {
-            TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_amb.p + 1, w.d_amb.p + 1, n_amb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_amb_ratio.p, w.d_amb_ratio.p, n_amb * sizeof(float), hipMemcpyDeviceToHost, st));
             TC2LI_HIP_CHECK(stream_wait_blocking(st));
-            TC2LI_HIP_CHECK(w.h_patch.ensure(n_amb)); TC2LI_HIP_CHECK(w.d_patch.ensure(n_amb));
-            for (int k = 0; k < n_amb; ++k) {
-                const int g = w.h_amb.p[1 + k];
-                const int f = (int)(std::upper_bound(local_offsets, local_offsets + n_frames + 1, g) - local_offsets) - 1;
-                const int r = tc2li_project_local_map(poses7 + 7 * (size_t)f, C.cam4, C.bf, o->scale.data(), C.n_levels, C.log_scale, o->cur_w, o->cur_h, 1,
-                                                      local_points + g, th, far_points, th_far_points, 0.5f, reinterpret_cast<tc2li_proj_query*>(w.h_patch.p + k));
-                if (r < 0) return r;
-            }
-            TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_patch.p, w.h_patch.p, n_amb * sizeof(MatchQuery), hipMemcpyHostToDevice, st));
-            launch_track_patch_queries(w.d_amb.p + 1, w.d_patch.p, n_amb, w.d_queries.p, st);
+            const float ls = C.log_scale;
+            const int nl = C.n_levels;
+            const int chunk = 16384, n_chunks = (n_amb + chunk - 1) / chunk;
+            tracking_pool().parallel_for(n_chunks, [&](int c) {
+                const int k1 = std::min(n_amb, (c + 1) * chunk);
+                for (int k = c * chunk; k < k1; ++k) {
+                    int level = (int)ceilf(logf(w.h_amb_ratio.p[k]) / ls);  // as tc2li_project_local_map / MapPoint::PredictScale
+                    if (level < 0) level = 0; else if (level >= nl) level = nl - 1;
+                    w.h_amb_level.p[k] = level;
+                }
+            });
+            TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_amb_level.p, w.h_amb_level.p, n_amb * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            launch_track_patch_levels(w.d_amb_ids.p, w.d_amb_level.p, w.d_amb_r.p, n_amb, C, w.d_queries.p, st);
         }
         tm[1] = now() - t0; t0 = now();
         rc = pass.queue(n_frames, true);

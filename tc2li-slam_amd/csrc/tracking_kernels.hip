@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void k_track_queries_last(const TrackFrameDev*
 // ---- SearchLocalPoints: Frame::isInFrustum + PredictScale + the window of the local-map overload, one query per local point -----
 __global__ __launch_bounds__(256) void k_track_queries_local(const TrackFrameDev* __restrict__ frames, int n_frames, TrackConst C,
                                                              const LocalPointDev* __restrict__ points, int total_q, MatchQuery* __restrict__ queries,
-                                                             int32_t* __restrict__ query_frame, int32_t* __restrict__ match, int32_t* __restrict__ ambiguous,
-                                                             int ambiguous_cap) {
+                                                             int32_t* __restrict__ query_frame, int32_t* __restrict__ match, int32_t* __restrict__ amb_count,
+                                                             int32_t* __restrict__ amb_ids, float* __restrict__ amb_ratio, float* __restrict__ amb_r) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= total_q) return;
     const int f = frame_of_query(frames, n_frames, g);
@@ -161,20 +161,24 @@ __global__ __launch_bounds__(256) void k_track_queries_local(const TrackFrameDev
     if (view_cos < C.view_cos_limit) ok = false;
     if (C.far_points && pc_dist > C.th_far) ok = false;
     if (ok) {
-        // MapPoint::PredictScale: ceil(log(mfMaxDistance / dist) / mfLogScaleFactor).  logf here is the device library's; the
-        // reference's is the host libm's, and the two may differ in the last bit.  That only matters when the quotient lies within a few
-        // units in the last place of an integer: such queries are listed for the host, which recomputes them with its own logf
-        // (tracking_host.cpp) before the search starts.
+        // MapPoint::PredictScale: (int)ceil(logf(mfMaxDistance / dist) / mfLogScaleFactor) with the HOST libm's logf, whose last bit no
+        // device function reproduces.  The quotient is evaluated in double here: the host's float result lies within 1.4 units in the
+        // last place of it (logf: 0.82 ulp, the division: 0.5), so unless the double value is within 4 float ulps of an integer the
+        // ceiling is decided.  The others (a point seen from exactly the distance it was created at: ratio = 1.2^k) are listed with their
+        // ratio and window factor; the host takes logf of those and a patch kernel writes level and radius (tracking_host.cpp).
         const float ratio = max_distance_raw / dist;
-        const float quot = logf(ratio) / C.log_scale;
-        if (fabsf(quot - rintf(quot)) < 1e-3f) {
-            const int at = atomicAdd(ambiguous, 1);
-            if (at < ambiguous_cap) ambiguous[1 + at] = g;
-        }
-        int level = (int)ceilf(quot);
-        if (level < 0) level = 0; else if (level >= C.n_levels) level = C.n_levels - 1;
+        const double quot = log((double)ratio) / (double)C.log_scale;
         float r = view_cos > 0.998f ? 2.5f : 4.0f;
         if (F.th != 1.0f) r *= F.th;
+        int level = 0;
+        const double nearest = rint(quot);
+        if (!(fabs(quot) < 1e6) || fabs(quot - nearest) <= 4.8e-7 * fmax(1.0, fabs(quot))) {
+            const int at = atomicAdd(amb_count, 1);
+            amb_ids[at] = g; amb_ratio[at] = ratio; amb_r[at] = r;
+        } else {
+            level = (int)ceil(quot);
+            if (level < 0) level = 0; else if (level >= C.n_levels) level = C.n_levels - 1;
+        }
         Q.u = u; Q.v = v;
         Q.u_right = u - C.bf * invz;
         Q.radius = r * C.scale[level];
@@ -187,10 +191,15 @@ __global__ __launch_bounds__(256) void k_track_queries_local(const TrackFrameDev
     store_query(queries + g, Q);
 }
 
-__global__ __launch_bounds__(64) void k_track_patch_queries(const int32_t* __restrict__ ids, const MatchQuery* __restrict__ src, int n,
-                                                            MatchQuery* __restrict__ queries) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k < n) store_query(queries + ids[k], src[k]);
+// level (from the host's logf) and window of the listed queries
+__global__ __launch_bounds__(256) void k_track_patch_levels(const int32_t* __restrict__ ids, const int32_t* __restrict__ levels, const float* __restrict__ r, int n,
+                                                            TrackConst C, MatchQuery* __restrict__ queries) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    MatchQuery& Q = queries[ids[k]];
+    const int level = levels[k];
+    Q.radius = r[k] * C.scale[level];
+    Q.min_level = level - 1; Q.max_level = level;
 }
 
 // occupied[i] = held[i] == 1: the keypoint holds a map point with observations before the search (ORBmatcher.cc:100-102)
@@ -394,13 +403,13 @@ void launch_track_queries_last(const TrackFrameDev* frames, int n_frames, const 
     if (total_q > 0) TC2LI_LAUNCH(k_track_queries_last, dim3((total_q + 255) / 256), dim3(256), 0, st, frames, n_frames, C, A, total_q, queries, query_frame, match);
 }
 void launch_track_queries_local(const TrackFrameDev* frames, int n_frames, const TrackConst& C, const LocalPointDev* points, int total_q, MatchQuery* queries,
-                                int32_t* query_frame, int32_t* match, int32_t* ambiguous, int ambiguous_cap, hipStream_t st) {
+                                int32_t* query_frame, int32_t* match, int32_t* amb_count, int32_t* amb_ids, float* amb_ratio, float* amb_r, hipStream_t st) {
     if (total_q > 0)
-        TC2LI_LAUNCH(k_track_queries_local, dim3((total_q + 255) / 256), dim3(256), 0, st, frames, n_frames, C, points, total_q, queries, query_frame, match, ambiguous,
-                     ambiguous_cap);
+        TC2LI_LAUNCH(k_track_queries_local, dim3((total_q + 255) / 256), dim3(256), 0, st, frames, n_frames, C, points, total_q, queries, query_frame, match, amb_count,
+                     amb_ids, amb_ratio, amb_r);
 }
-void launch_track_patch_queries(const int32_t* ids, const MatchQuery* src, int n, MatchQuery* queries, hipStream_t st) {
-    if (n > 0) TC2LI_LAUNCH(k_track_patch_queries, dim3((n + 63) / 64), dim3(64), 0, st, ids, src, n, queries);
+void launch_track_patch_levels(const int32_t* ids, const int32_t* levels, const float* r, int n, const TrackConst& C, MatchQuery* queries, hipStream_t st) {
+    if (n > 0) TC2LI_LAUNCH(k_track_patch_levels, dim3((n + 255) / 256), dim3(256), 0, st, ids, levels, r, n, C, queries);
 }
 void launch_track_occupied(const uint8_t* held, size_t n, uint8_t* occ, hipStream_t st) {
     if (n > 0) TC2LI_LAUNCH(k_track_occupied, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, held, n, occ);
