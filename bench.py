@@ -549,6 +549,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
     n_img, F = loop.n_img, loop.F
     raw, pre, down, sel = lid
     mp = loop.map_points0
+    nloc = float(np.mean(np.diff(loop.local_off))) if getattr(loop, "local_off", None) is not None else 0.0
     w = {
         "k_resize_linear": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # read levels 0..6, write levels 1..7
         "k_fast_cells": (n_img * (sum(px) + 4 * 15000), "B"),                          # every level once + the candidate list
@@ -564,6 +565,17 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         "k_sel_scatter": (F * (down + sel * 4 * 48), "B"),
         "k_map_keep_scatter": (F * mp * 96, "B"), "k_map_count": (F * mp * 52, "B"), "k_map_scatter": (F * mp * (48 + 16 + 8), "B"),
         "k_map_keep_count": (F * mp, "B"),
+        # keypoint distribution: every candidate once (4 B) + the picks; the rounds of the walk re-read keys that stay in L2
+        "k_quadtree": (n_img * (4 * 15000 + 8 * nkp), "B"),
+        "k_stereo_rows": (F * nkp * (12 + 2 * 7), "B"),                                 # right keys in, ~7 row entries of 2 B each out
+        # tracking: TrackWithMotionModel + TrackLocalMap per frame -- queries (64 B out, source point in), candidate windows, edges
+        "k_track_queries_last": (F * nkp * (53 + 64), "B"), "k_track_queries_local": (F * nloc * (68 + 64), "B"),
+        "k_match_candidates": (F * (nkp + nloc) * (64 + 20 * (32 + 12 + 4)), "B"),      # the query + ~20 window candidates (descriptor, key, pool entry)
+        "k_match_resolve": (F * (nkp + nloc) * (8 + 20 * 4), "B"), "k_match_grid": (2 * F * nkp * (12 + 2), "B"),
+        "k_track_edges_last": (F * nkp * (4 + 12 + 4 + 12 + 40 + 24 + 4), "B"), "k_track_edges_local": (F * nkp * (4 + 12 + 4 + 12 + 40 + 24 + 4), "B"),
+        # Optimizer::PoseOptimization, two calls per frame: every correspondence read once (edge 40 B + point 24 B), outlier flag and chi2 out;
+        # the 4 x 10 Gauss-Newton passes over them are meant to stay on chip
+        "k_pose_optimization": (2 * F * nkp * 0.5 * (40 + 24 + 1 + 8), "B"),
     }
     if ba:
         E, P, lin, tr, nw = ba["edges"], ba["points"], ba["linearisations"], ba["trials"], ba["windows"]

@@ -5,6 +5,7 @@ intervals (device busy time), the time-weighted number of kernels in flight, and
 during which it was the ONLY kernel running."""
 import csv
 import gzip
+import os
 import sys
 from collections import defaultdict
 
@@ -19,6 +20,11 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tc2li::", "")))
     t_lo, t_hi = min(r[0] for r in rows), max(r[1] for r in rows)
     t0 = t_hi - int((t_hi - t_lo) * tail)
+    marker = os.environ.get("TIMELINE_MARKER", "k_quadtree<")  # once per step: the window starts at its 3rd launch (steady state)
+    marks = sorted(r[0] for r in rows if r[2].startswith(marker))
+    if len(marks) >= 4:
+        t0 = marks[2]
+        print("window: from the 3rd launch of %s (%d steps)" % (marker, len(marks) - 2))
     rows = [r for r in rows if r[0] >= t0]
     ev = []
     for i, (a, b, _) in enumerate(rows):
