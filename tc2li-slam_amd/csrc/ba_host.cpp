@@ -143,8 +143,8 @@ struct VisualProblem {
     memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_in.p + first, h + first, in_bytes - first, hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(d_AT.p, 0, 2 * at_elems * sizeof(double), st));
+    TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
+    TC2LI_HIP_CHECK(zero_or_defer(d_AT.p, 2 * at_elems * sizeof(double), st));
     uint8_t* const d = ws.d_in.p;
 
     pb = BaProblemDev{};
@@ -943,6 +943,7 @@ struct LockstepContext {
     // slot table and, behind it, the two index lists of a phase: one host buffer, one device buffer, one copy per phase
     DevBuf<uint8_t> d_table;
     PinnedBuf<uint8_t> h_table;
+    PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
     hipStream_t st = nullptr;
 };
 constexpr int kMaxLockstepGroups = 4;
@@ -981,7 +982,9 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     const double t_begin = t0;
     // ---- setup: argument checks, plane extraction (host), uploads ----
     std::vector<int> rc_lidar(n, 0);
+    std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);  // what the tasks would have queued as copies / fills of their own
     pool.parallel_for(2 * n, [&](int task) {  // two tasks per window: the visual structure + uploads, the LiDAR plane extraction
+        CopySink sink(&deferred[task]);
         const int i = task >> 1;
         LockstepWindow& w = W[i];
         const tc2li_ba_problem& p = problems[i];
@@ -1017,6 +1020,16 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         w.x.assign(std::max(np, 1), 0.0);
         if (p.lidar) { w.Hl.assign((size_t)np * np, 0.0); w.bl_.assign(np, 0.0); }
     });
+    {
+        size_t n_tasks = 0, max_bytes = 0;
+        for (const auto& d : deferred) n_tasks += d.size();
+        if (n_tasks) {
+            if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
+            size_t at = 0;
+            for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+            launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
+        }
+    }
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0 || !problems[i].lidar) continue;
         if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
@@ -1219,7 +1232,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     if (!failed && !all.empty()) {
         upload(all, {});
         ba_batch_launch_depth(d_slots, d_lists, (int)all.size(), X, st);
-        for (int i : all) {  // device -> pinned staging (asynchronous), then the copies into the caller's arrays run in parallel
+        // device -> pinned staging: one launch writes every window's results (the setup's copy list is done with: the stream has been
+        // synchronised many times since), then the copies into the caller's arrays run in parallel
+        size_t n_tasks = 0, max_bytes = 0;
+        if (C.h_tasks.ensure(4 * all.size()) != hipSuccess) failed = true;
+        for (int i : all) {
+            if (failed) break;
             LockstepWindow& w = W[i];
             const tc2li_ba_problem& p = *w.p;
             const BaProblemDev& pb = w.vp.pb;
@@ -1227,12 +1245,14 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             const size_t bytes = p.n_poses * sizeof(Se3) + 3 * P * sizeof(double) + E * sizeof(double) + E;
             if (w.ws->h_result.ensure(bytes) != hipSuccess) { failed = true; break; }
             uint8_t* h = w.ws->h_result.p;
-            if (hipMemcpyAsync(h, pb.poses, p.n_poses * sizeof(Se3), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
             uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
-            if (p.edge_chi2 && hipMemcpyAsync(hc, w.ws->d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
-            if (p.edge_depth_positive && hipMemcpyAsync(hc + E * sizeof(double), w.ws->d_depth.p, E, hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
+            auto add = [&](void* dst, const void* src, size_t nbytes) { C.h_tasks.p[n_tasks++] = CopyTask{dst, src, nbytes}; max_bytes = std::max(max_bytes, nbytes); };
+            add(h, pb.poses, p.n_poses * sizeof(Se3));
+            add(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double));
+            if (p.edge_chi2) add(hc, w.ws->d_chi2.p, E * sizeof(double));
+            if (p.edge_depth_positive) add(hc + E * sizeof(double), w.ws->d_depth.p, E);
         }
+        if (!failed) launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
         sync();
         if (!failed)
             pool.parallel_for((int)all.size(), [&](int k) {

@@ -415,11 +415,26 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     TC2LI_HIP_CHECK(d_twl.ensure(W));
     TC2LI_HIP_CHECK(h_out.ensure(balm_out_size(W)));
     TC2LI_HIP_CHECK(h_twl.ensure(W));
-    if (n_planes) {
-        TC2LI_HIP_CHECK(hipMemcpyAsync(d_clusters.p, clusters.data(), clusters.size() * sizeof(PlaneCluster), hipMemcpyHostToDevice, st));
-        TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, coe.data(), coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (copy_sink_active()) {
+        // a lock-step group gathers the uploads of all its windows into one launch that reads the sources in place: they must be pinned
+        const size_t cb = (clusters.size() * sizeof(PlaneCluster) + 15) & ~(size_t)15, qb = (coe.size() * sizeof(double) + 15) & ~(size_t)15;
+        TC2LI_HIP_CHECK(h_upload.ensure(cb + qb + W * sizeof(int32_t) + 16));
+        uint8_t* h = h_upload.p;
+        if (n_planes) {
+            memcpy(h, clusters.data(), clusters.size() * sizeof(PlaneCluster));
+            memcpy(h + cb, coe.data(), coe.size() * sizeof(double));
+            TC2LI_HIP_CHECK(upload_or_defer(d_clusters.p, h, clusters.size() * sizeof(PlaneCluster), st));
+            TC2LI_HIP_CHECK(upload_or_defer(d_coe.p, h + cb, coe.size() * sizeof(double), st));
+        }
+        memcpy(h + cb + qb, pose_index.data(), W * sizeof(int32_t));
+        TC2LI_HIP_CHECK(upload_or_defer(d_pose_index.p, h + cb + qb, W * sizeof(int32_t), st));
+    } else {
+        if (n_planes) {
+            TC2LI_HIP_CHECK(hipMemcpyAsync(d_clusters.p, clusters.data(), clusters.size() * sizeof(PlaneCluster), hipMemcpyHostToDevice, st));
+            TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, coe.data(), coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
     dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
     dev.plane_res = d_plane_res.p; dev.eig = d_eig.p; dev.part = d_part.p; dev.out = h_out.p;
     return 0;

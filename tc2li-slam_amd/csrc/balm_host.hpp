@@ -49,6 +49,7 @@ struct BalmTerm {
     DevBuf<LidarPose> d_twl;
     PinnedBuf<double> h_out;
     PinnedBuf<LidarPose> h_twl;
+    PinnedBuf<uint8_t> h_upload;  // clusters | coe | pose_index of the last build when the uploads are gathered (CopySink)
 
     // argument checks + LiDAR poses of the window keyframes at `poses7`
     static int window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl);

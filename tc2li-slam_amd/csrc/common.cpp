@@ -64,6 +64,21 @@ hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kin
     return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
+namespace { thread_local std::vector<CopyTask>* tl_copy_sink = nullptr; }
+CopySink::CopySink(std::vector<CopyTask>* list) : prev_(tl_copy_sink) { tl_copy_sink = list; }
+CopySink::~CopySink() { tl_copy_sink = prev_; }
+bool copy_sink_active() { return tl_copy_sink != nullptr; }
+hipError_t upload_or_defer(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (tl_copy_sink) { tl_copy_sink->push_back(CopyTask{dst, src, bytes}); return hipSuccess; }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+}
+hipError_t zero_or_defer(void* dst, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (tl_copy_sink) { tl_copy_sink->push_back(CopyTask{dst, nullptr, bytes}); return hipSuccess; }
+    return hipMemsetAsync(dst, 0, bytes, st);
+}
+
 hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(dst, value, bytes, st);

@@ -34,6 +34,23 @@ hipStream_t private_stream();
 hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
 hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st);
 
+// One copy (src: device memory or PINNED host memory) or zero fill (src == NULL) of a batch executed by a single launch (copy_kernels.hip).
+struct CopyTask { void* dst; const void* src; size_t bytes; };
+void launch_copy_tasks(const CopyTask* tasks /* pinned or device memory */, int n, size_t max_bytes, hipStream_t st);
+// While a CopySink is alive on a thread, upload_or_defer / zero_or_defer append to its list instead of queueing a copy of their own; the
+// owner of the list launches it once for the whole batch.  Sources handed to upload_or_defer must then be pinned and stay valid until
+// that launch has run.
+struct CopySink {
+    explicit CopySink(std::vector<CopyTask>* list);
+    ~CopySink();
+    CopySink(const CopySink&) = delete;
+    CopySink& operator=(const CopySink&) = delete;
+    std::vector<CopyTask>* prev_;
+};
+bool copy_sink_active();
+hipError_t upload_or_defer(void* dst, const void* src, size_t bytes, hipStream_t st);
+hipError_t zero_or_defer(void* dst, size_t bytes, hipStream_t st);
+
 #define TC2LI_HIP_CHECK(call)                                                                       \
     do {                                                                                            \
         hipError_t e_ = (call);                                                                     \

@@ -18,8 +18,11 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_write.log 2>&1
 # matrix-unit occupancy of the Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_mfma.log 2>&1
+# instruction mix and LDS behaviour of every kernel (the bound of k_fast_cells is stated from these): own passes, SQ counters only
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_insts -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_insts.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_lds.log 2>&1
 python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds

@@ -63,3 +63,30 @@ if mres:
     for k, v in mres.items():
         print("MFMA %-40s launches %5d  mfma busy %12.0f  sq busy %12.0f  wave cycles %12.0f per launch" %
               (k[:40], v["launches"], v["mfma_busy_cycles_per_launch"], v["sq_busy_cycles_per_launch"] or 0, v["sq_wave_cycles_per_launch"] or 0))
+
+
+# ---- instruction mix / LDS behaviour per kernel (SQ counters summed over the dispatch's waves), with the kernel's average duration
+# from the stats CSV beside it: VALU instructions per nanosecond against the chip's issue rate says whether a kernel is ALU-bound
+names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_WAIT_INST_ANY"]
+mix = {}
+for sub, group in (("pmc_insts", names[:4]), ("pmc_lds", names[4:])):
+    for c in group:
+        for k, (n, v) in counter_per_kernel(sub, c).items():
+            mix.setdefault(k, {})[c + "_per_launch"] = v / n if n else None
+            mix[k]["launches"] = n
+dur = {}
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        dur[r["Name"].split("(")[0]] = float(r["AverageNs"])
+for k, v in mix.items():
+    if k in dur:
+        v["avg_duration_ns_kernel_stats"] = dur[k]
+        if v.get("SQ_INSTS_VALU_per_launch"):
+            # 256 CUs x 4 SIMDs issue one VALU instruction per cycle each at 2.4 GHz: 2457.6 wave-instructions per ns
+            v["valu_issue_frac"] = v["SQ_INSTS_VALU_per_launch"] / dur[k] / 2457.6
+if mix:
+    json.dump(mix, open("profiles/%s_pmc_instruction_mix.json" % tag, "w"), indent=1, sort_keys=True)
+    for k, v in sorted(mix.items(), key=lambda kv: -(kv[1].get("SQ_INSTS_VALU_per_launch") or 0) * kv[1].get("launches", 0))[:10]:
+        print("MIX %-36s valu %12.0f lds %11.0f conflicts %11.0f per launch, valu issue frac %s" %
+              (k[:36], v.get("SQ_INSTS_VALU_per_launch") or 0, v.get("SQ_INSTS_LDS_per_launch") or 0, v.get("SQ_LDS_BANK_CONFLICT_per_launch") or 0,
+               ("%.3f" % v["valu_issue_frac"]) if "valu_issue_frac" in v else "-"))
