@@ -94,6 +94,7 @@ struct MapIncTask {
     uint8_t* deleted;              // [n_map], all zero between calls
     int* keep_counts;              // [keep_blocks]
     PointXYZINormal* dst;          // the map's other point buffer: kept + appended + no-need points
+    int* remap;                    // [n_map] new index of every old point, -1: deleted (the grid rebuild walks the OLD cell order with it)
     LidarStateDev st;
     double fs;                     // filter_size_map_min
     float ds;                      // ikdtree downsample_size
@@ -110,11 +111,16 @@ struct MapGridTask {
     float4* sorted;    // [n_points]
     int* tile_sums;    // [ceil(n_cells / 4096)]
     int n_cells;
+    // Points that were in the map before the last compaction are visited in the order of the OLD grid (cell-coherent: neighbouring lanes
+    // hit the same or neighbouring counters, one atomic per run of equal cells); what was added since, in insertion order.
+    const float4* old_sorted;  // [n_old] the old grid's cell-sorted copy (xyz + old index), NULL: no old grid (first build)
+    const int* remap;          // [n_old] old index -> new index, -1: deleted
+    int n_old, n_kept;         // g.points[0 .. n_kept) are the kept old points, [n_kept .. g.n_points) the added ones
 };
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
-void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st);
+void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work /* max over tasks of n_old + added */, int max_cells, hipStream_t st);
 
 // LidarFrontEndTools::transformPointCloud (SF/src/LidarTypes.cc:42-65) for one cloud: out[i] = (R in[i] + t, intensity kept, the rest as a
 // default-constructed point)

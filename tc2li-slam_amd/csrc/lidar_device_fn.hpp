@@ -25,6 +25,23 @@ __device__ __forceinline__ int block_flag_scan(bool f, int* s_wave, int& total) 
     return off + __popcll(bal & ((1ull << lane) - 1ull));
 }
 
+// Runs of equal keys along a wavefront: lanes that continue their left neighbour's key leave the shared-counter work to the run's
+// first lane (one atomic per run instead of per lane) and take its result by shuffle.  Lanes without work pass keys no neighbour shares.
+struct RunInfo { bool head; int head_lane, length; };
+__device__ __forceinline__ RunInfo wave_runs(int key) {
+    const int lane = threadIdx.x & 63;
+    const int left = __shfl_up(key, 1, 64);
+    RunInfo r;
+    r.head = lane == 0 || left != key;
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    r.head_lane = 63 - __clzll(heads & upto);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    r.length = above ? __ffsll((long long)above) : 64 - lane;  // for a head: lanes up to the next head
+    return r;
+}
+
+
 __device__ __forceinline__ int enc_float(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ __forceinline__ float dec_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 // Cells are ordered x-fastest, so the points of a run of cells along x are one contiguous range of the sorted array.

@@ -24,7 +24,10 @@ struct tc2li_lidar_map {
     DevBuf<int> d_keep_counts, d_out;  // d_out [kMapIncOut]: a compaction without a scan (box deletion)
     DevBuf<float> d_boxes;
     PinnedBuf<int> h_out;
-    DevBuf<float4> d_sorted;
+    DevBuf<float4> d_sorted, d_sorted_alt;  // the grid's cell-sorted copy; a rebuild after a compaction reads the old one while it writes the other
+    DevBuf<int> d_remap;                    // old index -> new index of the last compaction (-1: deleted)
+    bool have_remap = false;                // d_remap / d_sorted describe the map before the compaction that was just committed
+    int remap_n_old = 0, remap_n_kept = 0;
     DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill, d_tile_sums;
     DevBuf<MapIncTask> d_inc_task;    // batches of one map: Build / Add_Points / Delete_Point_Boxes
     DevBuf<MapGridTask> d_grid_task;
@@ -223,10 +226,17 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t) {
         TC2LI_HIP_CHECK(m->d_tile_sums.alloc((size_t)(nc + nc / 2) / 4096 + 2));
         m->n_cells = nc + nc / 2;
     }
-    TC2LI_HIP_CHECK(m->d_sorted.ensure(std::max(m->n, 1)));
-    g.points = m->d_points.p; g.pts = m->d_sorted.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
-    t->g = g; t->counts = m->d_bucket_counts.p; t->fill = m->d_bucket_fill.p; t->start = m->d_bucket_start.p; t->sorted = m->d_sorted.p;
+    // after a compaction the kept points are taken from the old grid's order (cell-coherent, see MapGridTask): the new order goes to the other buffer
+    const bool merge = m->have_remap && m->d_sorted.p && m->remap_n_old > 0;
+    DevBuf<float4>& target = merge ? m->d_sorted_alt : m->d_sorted;
+    TC2LI_HIP_CHECK(target.ensure(std::max(m->n, 1)));
+    g.points = m->d_points.p; g.pts = target.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
+    t->g = g; t->counts = m->d_bucket_counts.p; t->fill = m->d_bucket_fill.p; t->start = m->d_bucket_start.p; t->sorted = target.p;
     t->tile_sums = m->d_tile_sums.p; t->n_cells = nc;
+    t->old_sorted = merge ? m->d_sorted.p : nullptr; t->remap = merge ? m->d_remap.p : nullptr;
+    t->n_old = merge ? m->remap_n_old : 0; t->n_kept = merge ? m->remap_n_kept : 0;
+    if (merge) { std::swap(m->d_sorted.p, m->d_sorted_alt.p); std::swap(m->d_sorted.n, m->d_sorted_alt.n); }  // d_sorted = the new order from here on
+    m->have_remap = false;
     return TC2LI_OK;
 }
 
@@ -238,7 +248,7 @@ int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>&
     for (int i = 0; i < n_maps; ++i) {
         const int rc = grid_prepare(maps[i], &tasks[i]);
         if (rc != TC2LI_OK) return rc;
-        max_points = std::max(max_points, maps[i]->n);
+        max_points = std::max(max_points, tasks[i].n_old + (maps[i]->n - tasks[i].n_kept));
         max_cells = std::max(max_cells, tasks[i].n_cells);
     }
     TC2LI_HIP_CHECK(d_tasks.ensure(n_maps));
@@ -262,6 +272,8 @@ int ensure_deleted(tc2li_lidar_map* m, int n, hipStream_t st) {
 // their new point lists.
 void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
     const int kept = out[4], appended = has_inc ? out[5] : 0, noneed = has_inc ? out[2] : 0;
+    m->have_remap = m->d_remap.n >= (size_t)m->n && m->n > 0;  // the compaction wrote d_remap for the m->n points the map had
+    m->remap_n_old = m->n; m->remap_n_kept = kept;
     const int added = appended + noneed;
     if (added > 0)
         for (int a = 0; a < 3; ++a) {
@@ -737,13 +749,14 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         const int kb = (m->n + 1023) / 1024;
         TC2LI_HIP_CHECK(m->d_keep_counts.ensure(std::max(kb, 1)));
         TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + std::min(n, kMapIncMax) + n + 1));
+        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1)));
         MapIncTask t{};
         t.body = L->d_down.p + base; t.nearest_idx = L->d_nearest_idx.p + base * 5; t.nfound = L->d_nfound.p + base;
         t.world = L->d_world.p + base; t.cls = L->d_cls.p + base; t.noneed = L->d_noneed.p + base;
         t.recs = L->d_inc_recs.p + (size_t)scan * kMapIncMax; t.group_start = L->d_group_start.p + (size_t)scan * (kMapIncMax + 1);
         t.appended = L->d_appended.p + (size_t)scan * kMapIncMax; t.has_append = L->d_has_append.p + (size_t)scan * kMapIncMax;
         t.out = L->d_mapinc_out.p + (size_t)tasks.size() * kMapIncOut;
-        t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
+        t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p; t.remap = m->d_remap.p;
         memcpy(&t.st, &states[i], sizeof(LidarStateDev));
         t.fs = fs; t.ds = ds; t.n = n; t.n_map = m->n; t.keep_blocks = kb; t.ekf_inited = ekf_inited; t.has_inc = 1;
         tasks.push_back(t);
@@ -846,9 +859,10 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
         const int kb = (m->n + 1023) / 1024;
         TC2LI_HIP_CHECK(m->d_keep_counts.ensure(kb));
         TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + 1));
+        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1)));
         MapIncTask t{};
         t.grid = m->grid; t.grid.points = m->d_points.p;
-        t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p;
+        t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p; t.remap = m->d_remap.p;
         t.n_map = m->n; t.keep_blocks = kb; t.has_inc = 0;
         t.boxes = ws.d_boxes.p + 6 * (size_t)box_offsets[i]; t.n_boxes = nb;
         tasks.push_back(t);

@@ -191,20 +191,6 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // leave the table work to the run's first lane -- one CAS probe and one counter atomic per run instead of per point -- and take
 // its slot by shuffle.  pt_slot keeps every point's table slot for the later passes (-1: point not filtered).
 constexpr int kMaxVoxelsPerScan = 32768;  // voxels of one scan the LDS sort holds
-struct RunInfo { bool head; int head_lane, length; };
-__device__ __forceinline__ RunInfo wave_runs(int key) {
-    const int lane = threadIdx.x & 63;
-    const int left = __shfl_up(key, 1, 64);
-    RunInfo r;
-    r.head = lane == 0 || left != key;
-    const unsigned long long heads = __ballot(r.head);
-    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-    r.head_lane = 63 - __clzll(heads & upto);
-    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-    r.length = above ? __ffsll((long long)above) : 64 - lane;  // for a head: lanes up to the next head
-    return r;
-}
-
 __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                             const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                             float leaf, const VoxelParams* __restrict__ vp,

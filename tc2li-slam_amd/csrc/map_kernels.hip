@@ -259,6 +259,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_scatter(const MapIncTask* __r
     int total;
     const int pos = block_flag_scan(keep, s_wave, total);
     if (keep) T.dst[T.keep_counts[blockIdx.x] + pos] = T.grid.points[i];
+    if (in && T.remap) T.remap[i] = keep ? T.keep_counts[blockIdx.x] + pos : -1;
 }
 // dst[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added
 __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
@@ -306,12 +307,31 @@ __global__ __launch_bounds__(256) void k_map_zero(const MapGridTask* __restrict_
     const MapGridTask& T = tasks[blockIdx.y];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < T.n_cells; i += gridDim.x * 256) { T.counts[i] = 0; T.fill[i] = 0; }
 }
+// Work item u of a build: u < n_old: entry u of the old grid (skipped when its point was deleted); then the added points.
+// Returns the point's cell in the NEW geometry, or a negative key no neighbouring lane shares; xyzi = position and NEW index.
+__device__ __forceinline__ int map_build_item(const MapGridTask& T, int u, float4& xyzi) {
+    const int lane_key = -1 - (int)(threadIdx.x & 63);
+    if (u < T.n_old) {
+        const float4 e = T.old_sorted[u];
+        const int ni = T.remap[__float_as_int(e.w)];
+        if (ni < 0) return lane_key;
+        xyzi = make_float4(e.x, e.y, e.z, __int_as_float(ni));
+        return map_cell(T.g, e.x, e.y, e.z);
+    }
+    const int i = T.n_kept + (u - T.n_old);
+    if (i >= T.g.n_points) return lane_key;
+    const PointXYZINormal p = T.g.points[i];
+    xyzi = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    return map_cell(T.g, p.x, p.y, p.z);
+}
 __global__ __launch_bounds__(256) void k_map_count(const MapGridTask* __restrict__ tasks) {
     const MapGridTask& T = tasks[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T.g.n_points) return;
-    const PointXYZINormal p = T.g.points[i];
-    atomicAdd(&T.counts[map_cell(T.g, p.x, p.y, p.z)], 1);
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if ((int)(blockIdx.x * 256) >= T.n_old + (T.g.n_points - T.n_kept)) return;  // whole workgroup
+    float4 q;
+    const int c = map_build_item(T, u, q);
+    const RunInfo run = wave_runs(c);
+    if (run.head && c >= 0) atomicAdd(&T.counts[c], run.length);
 }
 // level 1: sums of tiles of 4096 consecutive cells (coalesced int4 loads)
 __global__ __launch_bounds__(1024) void k_map_scan_tiles(const MapGridTask* __restrict__ tasks) {
@@ -377,12 +397,15 @@ __global__ __launch_bounds__(1024) void k_map_scan_cells(const MapGridTask* __re
 }
 __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restrict__ tasks) {
     const MapGridTask& T = tasks[blockIdx.y];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T.g.n_points) return;
-    const PointXYZINormal p = T.g.points[i];
-    const int c = map_cell(T.g, p.x, p.y, p.z);
-    const int pos = T.start[c] + atomicAdd(&T.fill[c], 1);
-    T.sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if ((int)(blockIdx.x * 256) >= T.n_old + (T.g.n_points - T.n_kept)) return;  // whole workgroup
+    float4 q;
+    const int c = map_build_item(T, u, q);
+    const RunInfo run = wave_runs(c);
+    int first = 0;
+    if (run.head && c >= 0) first = T.start[c] + atomicAdd(&T.fill[c], run.length);  // the run's lanes take consecutive places
+    first = __shfl(first, run.head_lane, 64);
+    if (c >= 0) T.sorted[first + ((int)(threadIdx.x & 63) - run.head_lane)] = q;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
@@ -406,7 +429,8 @@ void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points
     if (nb) TC2LI_LAUNCH(k_map_keep_scatter, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
     TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);
 }
-void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_points, int max_cells, hipStream_t st) {
+void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, int max_cells, hipStream_t st) {
+    const int max_points = max_work;
     if (!n_tasks) return;
     const int tiles = (max_cells + kScanTile - 1) / kScanTile;
     TC2LI_LAUNCH(k_map_zero, dim3(std::min((max_cells + 255) / 256, 512), n_tasks), dim3(256), 0, st, tasks);
