@@ -74,7 +74,7 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
 // ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes), batched over maps ----
 struct MapIncRec { unsigned long long key; int idx; int pad; };
 constexpr int kMapIncMax = 8192;
-constexpr int kMapIncOut = 12;  // per task: [0] n_add [1] n_groups [2] n_noneed [3] overflow [4] kept [5] appended [6..11] bbox of the added points
+constexpr int kMapIncOut = 16;  // per task: [0] n_add [1] n_groups [2] n_noneed [3] overflow [4] kept K [5] appended [6..11] bbox of the added points [12] kept among the first K
 // One (scan, map) pair of a batched map_incremental / compaction (map_kernels.hip).  has_inc = 0: compaction only (box deletion).
 struct MapIncTask {
     // scan side: slots of the tc2li_lidar workspace
@@ -93,7 +93,9 @@ struct MapIncTask {
     MapGrid grid;                  // the map before the update (grid.points = the points in insertion order)
     uint8_t* deleted;              // [n_map], all zero between calls
     int* keep_counts;              // [keep_blocks]
-    PointXYZINormal* dst;          // the map's other point buffer: kept + appended + no-need points
+    PointXYZINormal* dst;          // the map's point buffer itself (compaction in place): [0, K) kept, then appended + no-need points
+    int* holes;                    // [n_map] deleted places below K, in index order | [n_map] kept points at or above K, in index order
+    int* batch_overflow;           // one word per batch: set when any task's insertion list overflowed -- then no map is touched
     int* remap;                    // [n_map] new index of every old point, -1: deleted (the grid rebuild walks the OLD cell order with it)
     LidarStateDev st;
     double fs;                     // filter_size_map_min

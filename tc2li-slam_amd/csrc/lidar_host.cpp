@@ -19,7 +19,8 @@ static_assert(sizeof(tc2li_point) == sizeof(PointXYZINormal), "ABI layout");
 static_assert(sizeof(tc2li_lidar_state) == sizeof(LidarStateDev), "ABI layout");
 
 struct tc2li_lidar_map {
-    DevBuf<PointXYZINormal> d_points, d_points_alt;
+    DevBuf<PointXYZINormal> d_points;
+    DevBuf<int> d_holes;  // [2 n] work lists of the in-place compaction
     DevBuf<uint8_t> d_deleted;  // all zero between calls (k_map_keep_scatter clears what the marking kernels set)
     DevBuf<int> d_keep_counts, d_out;  // d_out [kMapIncOut]: a compaction without a scan (box deletion)
     DevBuf<float> d_boxes;
@@ -76,7 +77,7 @@ struct tc2li_lidar {
     DevBuf<MapGrid> d_grids;
     DevBuf<int> d_perm, d_hard_count;
     // map_incremental, one slot per scan of the batch (allocated on first use)
-    DevBuf<int> d_group_start, d_noneed, d_mapinc_out;
+    DevBuf<int> d_group_start, d_noneed, d_mapinc_out, d_batch_overflow;
     DevBuf<uint8_t> d_cls, d_has_append;
     DevBuf<MapIncRec> d_inc_recs;
     DevBuf<PointXYZINormal> d_appended;
@@ -268,6 +269,18 @@ int ensure_deleted(tc2li_lidar_map* m, int n, hipStream_t st) {
     return TC2LI_OK;
 }
 
+// Room for `need` points, the present ones kept (the compaction works in place and appends behind the kept points).
+int ensure_point_capacity(tc2li_lidar_map* m, size_t need, hipStream_t st) {
+    if (need <= m->d_points.n) return TC2LI_OK;
+    DevBuf<PointXYZINormal> bigger;
+    TC2LI_HIP_CHECK(bigger.alloc(need + need / 2 + 1024));
+    if (m->n) TC2LI_HIP_CHECK(copy_sync(bigger.p, m->d_points.p, (size_t)m->n * sizeof(PointXYZINormal), hipMemcpyDeviceToDevice, st));
+    std::swap(bigger.p, m->d_points.p);
+    std::swap(bigger.n, m->d_points.n);
+    m->grid.points = m->d_points.p;
+    return TC2LI_OK;
+}
+
 // After the compaction kernels of a batch have finished (results of task i at out + kMapIncOut * i on the host): the maps take over
 // their new point lists.
 void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
@@ -282,8 +295,6 @@ void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
             m->lo[a] = std::min(m->lo[a], lo);
             m->hi[a] = std::max(m->hi[a], hi);
         }
-    std::swap(m->d_points.p, m->d_points_alt.p);
-    std::swap(m->d_points.n, m->d_points_alt.n);
     m->n = kept + added;
 }
 
@@ -732,7 +743,7 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         TC2LI_HIP_CHECK(L->d_inc_recs.alloc(S * kMapIncMax)); TC2LI_HIP_CHECK(L->d_group_start.alloc(S * (kMapIncMax + 1)));
         TC2LI_HIP_CHECK(L->d_appended.alloc(S * kMapIncMax)); TC2LI_HIP_CHECK(L->d_has_append.alloc(S * kMapIncMax));
         TC2LI_HIP_CHECK(L->d_mapinc_out.alloc(S * kMapIncOut)); TC2LI_HIP_CHECK(L->h_mapinc_out.alloc(S * kMapIncOut));
-        TC2LI_HIP_CHECK(L->d_grid_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_inc_tasks.alloc(S));
+        TC2LI_HIP_CHECK(L->d_grid_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_inc_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_batch_overflow.alloc(1));
     }
     std::vector<MapIncTask> tasks;
     std::vector<int> which;  // task -> index in the caller's arrays
@@ -748,15 +759,17 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         if (rc != TC2LI_OK) return rc;
         const int kb = (m->n + 1023) / 1024;
         TC2LI_HIP_CHECK(m->d_keep_counts.ensure(std::max(kb, 1)));
-        TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + std::min(n, kMapIncMax) + n + 1));
-        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1)));
+        rc = ensure_point_capacity(m, (size_t)m->n + std::min(n, kMapIncMax) + n + 1, st);
+        if (rc != TC2LI_OK) return rc;
+        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1))); TC2LI_HIP_CHECK(m->d_holes.ensure(2 * (size_t)std::max(m->n, 1)));
         MapIncTask t{};
         t.body = L->d_down.p + base; t.nearest_idx = L->d_nearest_idx.p + base * 5; t.nfound = L->d_nfound.p + base;
         t.world = L->d_world.p + base; t.cls = L->d_cls.p + base; t.noneed = L->d_noneed.p + base;
         t.recs = L->d_inc_recs.p + (size_t)scan * kMapIncMax; t.group_start = L->d_group_start.p + (size_t)scan * (kMapIncMax + 1);
         t.appended = L->d_appended.p + (size_t)scan * kMapIncMax; t.has_append = L->d_has_append.p + (size_t)scan * kMapIncMax;
         t.out = L->d_mapinc_out.p + (size_t)tasks.size() * kMapIncOut;
-        t.grid = m->grid; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p; t.remap = m->d_remap.p;
+        t.grid = m->grid; t.grid.points = m->d_points.p; t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points.p;
+        t.remap = m->d_remap.p; t.holes = m->d_holes.p; t.batch_overflow = L->d_batch_overflow.p;
         memcpy(&t.st, &states[i], sizeof(LidarStateDev));
         t.fs = fs; t.ds = ds; t.n = n; t.n_map = m->n; t.keep_blocks = kb; t.ekf_inited = ekf_inited; t.has_inc = 1;
         tasks.push_back(t);
@@ -767,13 +780,20 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
     const int nt = (int)tasks.size();
     if (nt) {
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemsetAsync(L->d_batch_overflow.p, 0, sizeof(int), st));
         launch_mapinc_lists(L->d_inc_tasks.p, nt, max_points, st);
         launch_map_compact(L->d_inc_tasks.p, nt, max_map, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
         for (int k = 0; k < nt; ++k)
-            if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {  // nothing has been committed: every map is as it was
+            if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {
+                // the compaction kernels saw the batch word and touched no map; the deletion marks of the lists are taken back
+                for (int q = 0; q < nt; ++q) {
+                    tc2li_lidar_map* m = maps[which[q]];
+                    if (m->d_deleted.p) TC2LI_HIP_CHECK(hipMemsetAsync(m->d_deleted.p, 0, m->d_deleted.n, st));
+                }
+                TC2LI_HIP_CHECK(stream_wait_blocking(st));
                 set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax);
                 return TC2LI_ERR_CAPACITY;
             }
@@ -820,7 +840,7 @@ struct DeleteBoxesWs {
     DevBuf<MapIncTask> d_tasks;
     DevBuf<MapGridTask> d_grid_tasks;
     DevBuf<float> d_boxes;
-    DevBuf<int> d_out;
+    DevBuf<int> d_out, d_overflow;  // d_overflow: the batch word of MapIncTask (always 0 here: a deletion has no insertion list)
     PinnedBuf<int> h_out;
 };
 DeleteBoxesWs* delete_boxes_ws() { thread_local DeleteBoxesWs ws; return &ws; }
@@ -850,6 +870,8 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
     std::vector<int> which;
     int max_map = 0;
     TC2LI_HIP_CHECK(ws.d_boxes.ensure(6 * (size_t)std::max(total_boxes, 1)));
+    TC2LI_HIP_CHECK(ws.d_overflow.ensure(1));
+    TC2LI_HIP_CHECK(hipMemsetAsync(ws.d_overflow.p, 0, sizeof(int), st));
     for (int i = 0; i < n_maps; ++i) {
         tc2li_lidar_map* m = maps[i];
         const int nb = box_offsets[i + 1] - box_offsets[i];
@@ -858,11 +880,11 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
         if (rc != TC2LI_OK) return rc;
         const int kb = (m->n + 1023) / 1024;
         TC2LI_HIP_CHECK(m->d_keep_counts.ensure(kb));
-        TC2LI_HIP_CHECK(m->d_points_alt.ensure((size_t)m->n + 1));
-        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1)));
+        TC2LI_HIP_CHECK(m->d_remap.ensure(std::max(m->n, 1))); TC2LI_HIP_CHECK(m->d_holes.ensure(2 * (size_t)std::max(m->n, 1)));
         MapIncTask t{};
         t.grid = m->grid; t.grid.points = m->d_points.p;
-        t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points_alt.p; t.remap = m->d_remap.p;
+        t.deleted = m->d_deleted.p; t.keep_counts = m->d_keep_counts.p; t.dst = m->d_points.p; t.remap = m->d_remap.p; t.holes = m->d_holes.p;
+        t.batch_overflow = ws.d_overflow.p;
         t.n_map = m->n; t.keep_blocks = kb; t.has_inc = 0;
         t.boxes = ws.d_boxes.p + 6 * (size_t)box_offsets[i]; t.n_boxes = nb;
         tasks.push_back(t);

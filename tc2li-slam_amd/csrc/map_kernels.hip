@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void k_mapinc_group(const MapIncTask* __restr
     if (tid == 0) {
         T.group_start[s_base[1]] = m;
         T.out[0] = m; T.out[1] = s_base[1]; T.out[2] = s_base[2]; T.out[3] = s_base[0] > kMapIncMax ? 1 : 0;
+        if (s_base[0] > kMapIncMax) atomicExch(T.batch_overflow, 1);
     }
 }
 
@@ -201,8 +202,11 @@ __global__ __launch_bounds__(256) void k_map_mark_boxes(const MapIncTask* __rest
     T.deleted[i] = d;
 }
 
-// ---- ordered compaction of the map after deletions: per-block kept counts, their scan (one workgroup per map), scatter; then the
-// appended voxel representatives (group order) and the PointNoNeedDownsample points (scan order) follow -----------------------------
+// ---- compaction of the map after deletions, in place: with K points kept, the deleted places below K are filled with the kept points
+// from K on (h-th hole <- h-th such point, both in index order: deterministic); only the moved points are copied, not the map.  The map
+// is a set (an ikd-Tree has no order), so the order of its flat array is ours to choose.  Per-block kept counts, their scan (one
+// workgroup per map), the hole / filler lists + the old -> new index map, the moves; then the appended voxel representatives (group
+// order) and the PointNoNeedDownsample points (scan order) follow from K on -------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __restrict__ tasks) {
     const MapIncTask& T = tasks[blockIdx.y];
     if ((int)blockIdx.x >= T.keep_blocks) return;
@@ -247,24 +251,45 @@ __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __rest
         T.out[5] = tot;
         for (int k = 0; k < 3; ++k) { T.out[6 + k] = 0x7fffffff; T.out[9 + k] = (int)0x80000000; }
     }
+    // kept points among the first K = carry places (the others are the holes to fill)
+    __syncthreads();
+    const int K = carry, bK = K / 1024;
+    const int i = bK * 1024 + tid;
+    const int c = __syncthreads_count(i < K && !T.deleted[i]);
+    if (tid == 0) T.out[12] = (bK < nblocks ? T.keep_counts[bK] : K) + c;
 }
-__global__ __launch_bounds__(1024) void k_map_keep_scatter(const MapIncTask* __restrict__ tasks) {
+__global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict__ tasks) {
     const MapIncTask& T = tasks[blockIdx.y];
     if ((int)blockIdx.x >= T.keep_blocks) return;
+    if (*T.batch_overflow) return;  // nothing is touched when the batch fails (the flags are reset by the host's next call)
     __shared__ int s_wave[16];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const bool in = i < T.n_map;
     const bool keep = in && !T.deleted[i];
     if (in) T.deleted[i] = 0;  // the flags are all zero again when the call ends (they belong to the old numbering)
     int total;
-    const int pos = block_flag_scan(keep, s_wave, total);
-    if (keep) T.dst[T.keep_counts[blockIdx.x] + pos] = T.grid.points[i];
-    if (in && T.remap) T.remap[i] = keep ? T.keep_counts[blockIdx.x] + pos : -1;
+    const int kp = T.keep_counts[blockIdx.x] + block_flag_scan(keep, s_wave, total);  // kept points before i
+    const int K = T.out[4], kpK = T.out[12];
+    if (!in) return;
+    T.remap[i] = keep ? i : -1;
+    if (!keep && i < K) T.holes[i - kp] = i;
+    if (keep && i >= K) T.holes[T.n_map + (kp - kpK)] = i;
+}
+__global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask& T = tasks[blockIdx.y];
+    if (*T.batch_overflow) return;
+    const int H = T.out[4] - T.out[12];
+    PointXYZINormal* pts = T.dst;
+    for (int h = blockIdx.x * 256 + threadIdx.x; h < H; h += gridDim.x * 256) {
+        const int dst = T.holes[h], src = T.holes[T.n_map + h];
+        pts[dst] = pts[src];
+        T.remap[src] = dst;
+    }
 }
 // dst[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added
 __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
     const MapIncTask& T = tasks[blockIdx.x];
-    if (!T.has_inc) return;
+    if (!T.has_inc || *T.batch_overflow) return;
     __shared__ int s_wave[4];
     __shared__ int s_base;
     const int tid = threadIdx.x, ng = T.out[1], nn = T.out[2], kept = T.out[4];
@@ -426,7 +451,8 @@ void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points
     const int nb = (max_map_points + 1023) / 1024;
     if (nb) TC2LI_LAUNCH(k_map_keep_count, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
     TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
-    if (nb) TC2LI_LAUNCH(k_map_keep_scatter, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
+    if (nb) TC2LI_LAUNCH(k_map_holes, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
+    if (nb) TC2LI_LAUNCH(k_map_fill, dim3(std::min(nb * 4, 64), n_tasks), dim3(256), 0, st, tasks);
     TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);
 }
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, int max_cells, hipStream_t st) {

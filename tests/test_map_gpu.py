@@ -107,11 +107,11 @@ def test_delete_point_boxes_batch_equals_one_map_at_a_time(pkg, oracle, setup):
         want = oracle.map_delete_boxes(p, b) if len(p) and len(b) else p
         assert removed[i] == len(p) - len(want), i
         got = maps[i].points()
-        assert np.array_equal(got, want), i  # compaction keeps the insertion order
+        assert np.array_equal(canon(got), canon(want)), i  # the map is a set: holes are filled from the tail, the order is the library's
         if len(p):
             single = pkg.LidarMap(); single.Build(p)
             assert single.Delete_Point_Boxes(b) == removed[i]
-            assert np.array_equal(single.points(), got)
+            assert np.array_equal(single.points(), got)  # and it is deterministic
     assert removed[0] > 100 and removed[2] == 0 and removed[4] > 0
     fresh = pkg.LidarMap(); fresh.Build(maps[4].points())
     a = fe.feature_extraction(maps[4], downs[1], states[1]); b = fe.feature_extraction(fresh, downs[1], states[1])
