@@ -65,6 +65,28 @@ def test_insertion_rule_inside_one_voxel(pkg, oracle, setup):
         assert np.array_equal(canon(m.points()), canon(want))
 
 
+def test_overflowing_insertion_list_changes_nothing(pkg, oracle, setup):
+    """More down-sampled points to insert than one call takes (8192): TC2LI_ERR_CAPACITY, the map as it was (the compaction kernels see
+    the batch's overflow word), and the next call on the same map works -- its deletion marks were taken back."""
+    fe, downs, states, world0 = setup
+    ident = pkg.pack_lidar_state(np.eye(3), np.zeros(3))
+    def P(xyz):
+        a = np.zeros(len(xyz), pkg.capi.POINT_DTYPE); a["x"], a["y"], a["z"] = np.array(xyz, np.float32).T; a["pad0"] = 1; return a
+    base = P([[10.26, 10.24, 10.25], [20.1, 20.1, 20.1], [30.05, 30.05, 30.05], [30.45, 30.4, 30.45], [30.3, 30.2, 30.2], [40.2, 40.2, 40.2]])
+    gx, gy = np.meshgrid(np.arange(100), np.arange(95))
+    many = P(np.stack([100.3 + gx.ravel(), 200.3 + gy.ravel(), np.full(gx.size, 3.3)], 1))  # 9500 points, one per empty 0.5 m voxel
+    m = pkg.LidarMap(); m.Build(base)
+    fe.feature_extraction(m, many, ident)
+    with pytest.raises(pkg.capi.Tc2liError) as err:
+        m.map_incremental(fe, 0, ident, ekf_inited=False)  # before the filter is initialised every point is a PointToAdd
+    assert err.value.code == -5 and m.size() == len(base) and np.array_equal(canon(m.points()), canon(base))
+    scan = P([[5.3, 5.3, 5.3], [10.1, 10.1, 10.1], [20.24, 20.26, 20.25], [30.26, 30.24, 30.26], [40.4, 40.45, 40.4], [40.27, 40.25, 40.26]])
+    fe.feature_extraction(m, scan, ident)
+    n, na, nn = m.map_incremental(fe, 0, ident, ekf_inited=True)
+    want, wa, wn = oracle.map_incremental(base, scan, ident, ident, ekf_inited=True)
+    assert (na, nn) == (wa, wn) and n == len(want) and np.array_equal(canon(m.points()), canon(want))
+
+
 def test_delete_point_boxes_and_fov_segment(pkg, oracle, setup):
     fe, downs, states, world0 = setup
     m = pkg.LidarMap(); m.Build(world0)
