@@ -291,22 +291,43 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
         }
         __syncthreads();
         // ---- 2. quadrant of every key of those nodes; prefix sums of the indicators along the key array ----
+        // four consecutive keys per lane: one block-wide scan (two barriers) per 4 T keys, vector loads / stores
         {
             unsigned long long carry = 0;
-            for (int c0 = 0; c0 < ncand; c0 += T) {
-                const int k = c0 + tid;
-                unsigned long long v = 0;
-                if (k < ncand) {
-                    const int nd = nodeof[k];
-                    if (procpos[nd] >= 0) {
-                        const int q = q_quadrant(nodes[nd], cand[keys[k]]);
-                        kq[k] = (uint8_t)q;
-                        if (q < 3) v = 1ull << (21 * q);
-                    }
+            for (int c0 = 0; c0 < ncand; c0 += 4 * T) {
+                const int k0 = c0 + 4 * tid;
+                int nd4[4] = {0, 0, 0, 0}, key4[4] = {0, 0, 0, 0};
+                const bool full = k0 + 3 < ncand;
+                if (full) {
+                    const int4 a = *reinterpret_cast<const int4*>(nodeof + k0), bkey = *reinterpret_cast<const int4*>(keys + k0);
+                    nd4[0] = a.x; nd4[1] = a.y; nd4[2] = a.z; nd4[3] = a.w;
+                    key4[0] = bkey.x; key4[1] = bkey.y; key4[2] = bkey.z; key4[3] = bkey.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k0 + j < ncand) { nd4[j] = nodeof[k0 + j]; key4[j] = keys[k0 + j]; }
                 }
+                unsigned long long v[4] = {0, 0, 0, 0};
+                uint32_t q4 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j < ncand && procpos[nd4[j]] >= 0) {
+                        const int q = q_quadrant(nodes[nd4[j]], cand[key4[j]]);
+                        q4 |= (uint32_t)q << (8 * j);
+                        if (q < 3) v[j] = 1ull << (21 * q);
+                    }
                 unsigned long long tot;
-                const unsigned long long ex = carry + block_excl_scan<T>(v, s_wave64, tot);
-                if (k < ncand) scanq[k] = ex;
+                unsigned long long run = carry + block_excl_scan<T>(v[0] + v[1] + v[2] + v[3], s_wave64, tot);
+                if (full) {
+                    *reinterpret_cast<uint32_t*>(kq + k0) = q4;
+                    ulonglong2 lo, hi;
+                    lo.x = run; lo.y = run + v[0]; hi.x = lo.y + v[1]; hi.y = hi.x + v[2];
+                    *reinterpret_cast<ulonglong2*>(scanq + k0) = lo;
+                    *reinterpret_cast<ulonglong2*>(scanq + k0 + 2) = hi;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j < ncand) { kq[k0 + j] = (uint8_t)(q4 >> (8 * j)); scanq[k0 + j] = run; run += v[j]; }
+                }
                 carry += tot;
             }
             if (tid == 0) scanq[ncand] = carry;
