@@ -148,3 +148,29 @@ def test_batch_with_a_large_window(pkg, synthetic):
         r = batch.result(i)
         assert r[4].trials == s[4].trials and batch.results[i] == s[4].iterations
         assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2])
+
+
+def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic):
+    """The windows bench.py times (12 free + 20 fixed keyframes, 3000 points, LiDAR edge over 6 keyframes x 3000 points), through the
+    lock-step batch entry, against the oracle directly: same iterations and LM trials, same planes, poses <= 1e-4 relative."""
+    windows, wants = [], []
+    for seed in (40, 41, 42, 43):
+        w = synthetic.ba_window(seed, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
+        last = len(w["poses"]) - 1
+        win = list(range(last, last - 6, -1))
+        clouds = synthetic.ba_window_clouds(w, win, n_points=3000)
+        wants.append((w, oracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], win, clouds, synthetic.TCL7, 1.0, iterations=10,
+                                               lambda_init=0.0)))
+        windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), win_pose=win, clouds=clouds,
+                            Tcl7=synthetic.TCL7, weight=1.0))
+        cam = w["cam"]
+    batch = pkg.capi.BaBatch(windows, cam)
+    assert batch.run(max_concurrency=8) == len(windows)
+    for i, (w, want) in enumerate(wants):
+        poses, pts, chi2, dpos, stats, ls = batch.result(i)
+        assert batch.results[i] == want[4] and stats.trials == int(want[5]["trials"].sum()), i
+        assert ls.n_planes == want[6] and abs(ls.residual - want[7]["residual"]) <= 1e-6 * abs(want[7]["residual"])
+        assert abs(stats.final_chi2 - want[5]["chi2"][-1]) <= 1e-6 * want[5]["chi2"][-1]
+        for k in range(len(poses)):
+            assert rel_pose_err(poses[k], want[0][k]) < POSE_RTOL, (i, k)
+        assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6) and np.array_equal(dpos, want[3])
