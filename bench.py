@@ -838,9 +838,10 @@ def main(argv=None):
                   "windows": (loop.ba_windows_done - ba1) / n_prof, "linearisations": int(s0.iterations), "trials": int(s0.trials)}
         roofline, kernel_table, kernel_ms_per_step = roofline_from_profile(report, algorithmic_work(wl, loop, nkp, lid_mean, ba), peaks, n_prof)
         roofline["traffic"] = pmc_traffic(roofline["kernel"])
-        roofline["measured_in"] = ("a second pass of %d steps of the same concurrent loop with a HIP event pair around every kernel launch, on the stream "
-                                   "the kernel is launched on (tc2li_profile_*); tools/profile_round.sh commits the rocprofv3 --kernel-trace --stats "
-                                   "summary of this command under profiles/" % n_prof)
+        roofline["measured_in"] = ("a second pass of %d steps of the same concurrent loop in which every kernel is launched with a start and a stop "
+                                   "event of its own dispatch (hipExtLaunchKernelGGL, on the stream the kernel is launched on; tc2li_profile_*): the "
+                                   "durations are those of kernels sharing the GPU with the other stage threads, as in the rocprofv3 --kernel-trace "
+                                   "--stats summary of this command that tools/profile_round.sh commits under profiles/" % n_prof)
         roofline["all_kernels"] = kernel_table
         roofline["kernel_ms_per_step_all_streams"] = round(kernel_ms_per_step, 3)
         roofline["peaks_measured"] = peaks
