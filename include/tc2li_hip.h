@@ -447,6 +447,24 @@ int tc2li_imu_delta(const tc2li_preintegrated* p, const tc2li_imu_bias* bias, fl
 int tc2li_imu_predict_state(const tc2li_preintegrated* p, const tc2li_imu_bias* bias, const float Rwb1[9], const float twb1[3],
                             const float Vwb1[3], float Rwb2[9], float twb2[3], float Vwb2[3]);
 
+/* IMU initialisation (host code by design: tens of keyframes, one 9-d edge per consecutive pair).
+ * tc2li_imu_init_gravity = the first estimate of LocalMapping::InitializeIMU (SF/src/LocalMapping.cc:1241-1270): keyframes in temporal
+ * order (Rwb [n][9] row-major, twb [n][3], float), pre[i] = keyframe i's pre-integration from keyframe i - 1 (pre[0] ignored, NULL
+ * entries skipped) -> the finite-difference velocities vel3 [n][3] and Rwg (gravity direction of the IMU world).  Returns the links used.
+ * tc2li_inertial_optimization = Optimizer::InertialOptimization(pMap, Rwg, scale, bg, ba, bMono, covInertial, bFixedVel, bGauss, priorG,
+ * priorA) (SF/src/Optimizer.cc:2169-2356): Levenberg-Marquardt (lambda 1e3 when prior_g != 0, `iterations` = 200 in the reference,
+ * g2o's stop rules) over the keyframe velocities (in / out, double), one gyro and one accelerometer bias (in: the first keyframe's; out:
+ * the estimate), the gravity direction Rwg (in / out) and, when mono, the scale (in / out); fixed_vel freezes velocities and biases.
+ * The pre-integrations are evaluated at the estimated biases through their bias Jacobians (SetNewBias + GetDelta*(b)).  What the
+ * reference does with the result on its objects (SetVelocity / SetNewBias / Reintegrate, ApplyScaledRotation) stays with the caller.
+ * Returns the iterations run. */
+typedef struct tc2li_inertial_init_stats { int32_t iterations, trials; double initial_chi2, final_chi2, final_lambda; } tc2li_inertial_init_stats;
+int tc2li_imu_init_gravity(int n_kfs, const float* Rwb9, const float* twb3, const tc2li_preintegrated* const* pre, float* vel3, float Rwg9[9]);
+int tc2li_inertial_optimization(int n_kfs, const double* Rwb9, const double* twb3, double* vel3, const tc2li_preintegrated* const* pre,
+                                double Rwg9[9], double* scale, double bg[3], double ba[3], int mono, int fixed_vel, float prior_g, float prior_a,
+                                int iterations, tc2li_inertial_init_stats* stats);
+
+
 /* ------------------------------------------------------------------------------------------------
  * Tracking::TrackWithMotionModel (SF/src/Tracking.cc:2737-2834), data path only, for a batch of independent frames
  * whose features are device-resident: SearchByProjection(cur, last, th) with ORBmatcher(0.9, true), the 2*th retry

@@ -1188,6 +1188,43 @@ int oracle_pose_inertial(double* cur33, double* other33, int last_frame, const d
     if (stats3) { stats3[0] = r.n_initial; stats3[1] = r.n_bad; stats3[2] = r.n_inliers; }
     return r.n_initial - r.n_bad;
 }
+// Optimizer::InertialOptimization (IMU initialisation): kf33 rows in temporal order (Rwb, twb, v read; v written), pre298[i] = row i's
+// pre-integration from row i - 1 (row 0 unused); state17 = Rwg 9 | scale | bg 3 | ba 3 | (pad).  Returns the iterations.
+int oracle_inertial_optimization(double* kf33, int n_kf, const float* pre298, double* state17, int mono, int fixed_vel, float priorG, float priorA, int its,
+                                 double* err2, int* trials, double* trace_chi2, double* trace_lambda, int* trace_trials, int trace_cap) {
+    std::vector<InertialKeyFrame> kfs(n_kf);
+    for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, 0, 1);
+    std::vector<Preintegrated> pre;
+    pre.reserve(n_kf);
+    for (int k = 0; k < n_kf; ++k) pre.push_back(preint_from(pre298 + 298 * (size_t)k));
+    std::vector<const Preintegrated*> pp(n_kf, nullptr);
+    for (int k = 1; k < n_kf; ++k) pp[k] = &pre[k];
+    double Rwg[9], scale = state17[9], bg[3], ba[3];
+    std::memcpy(Rwg, state17, 72); std::memcpy(bg, state17 + 10, 24); std::memcpy(ba, state17 + 13, 24);
+    const InertialInitResult r = InertialOptimization(kfs, pp, Rwg, scale, bg, ba, mono != 0, fixed_vel != 0, priorG, priorA, its);
+    for (int k = 0; k < n_kf; ++k) kf_to(kfs[k], kf33 + 33 * k);
+    std::memcpy(state17, Rwg, 72); state17[9] = scale; std::memcpy(state17 + 10, bg, 24); std::memcpy(state17 + 13, ba, 24);
+    if (err2) { err2[0] = r.err; err2[1] = r.err_end; }
+    if (trials) *trials = r.trials;
+    const int m = std::min((int)r.trace.chi2.size(), trace_cap);
+    for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
+    return r.iterations;
+}
+void oracle_initial_gravity_direction(const double* kf33, int n_kf, const float* pre298, float* vel, float* Rwg9) {
+    std::vector<InertialKeyFrame> kfs(n_kf);
+    for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, 0, 1);
+    std::vector<Preintegrated> pre;
+    pre.reserve(n_kf);
+    for (int k = 0; k < n_kf; ++k) pre.push_back(preint_from(pre298 + 298 * (size_t)k));
+    std::vector<const Preintegrated*> pp(n_kf, nullptr);
+    for (int k = 1; k < n_kf; ++k) pp[k] = &pre[k];
+    InitialGravityDirection(kfs, pp, vel, Rwg9);
+}
+void oracle_inertial_gs_edge(const double* kf33_1, const double* kf33_2, const double* bg, const double* ba, const double* Rwg, double s, const float* pre298,
+                             double* err9, double* J135) {
+    const Preintegrated p = preint_from(pre298);
+    inertial_gs_edge(kf_from(kf33_1, 0, 1), kf_from(kf33_2, 0, 1), bg, ba, Rwg, s, p, err9, J135);
+}
 // OptimizerWithLidar::LocalLVIBA: the same with EdgeLidar over the keyframes win_kf (rows of kf33)
 int oracle_local_lviba(double* kf33, const uint8_t* fixed, const uint8_t* has_imu, int n_kf, const double* calib24, double* points3,
                        int n_points, const double* edges6, int n_edges, const double* link4, const float* pre298, int n_links,

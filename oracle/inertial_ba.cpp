@@ -822,4 +822,239 @@ PoseInertialResult PoseInertialOptimization(InertialKeyFrame& cur, InertialKeyFr
     return res;
 }
 
+
+// ---- IMU initialisation: Optimizer::InertialOptimization (SF/src/Optimizer.cc:2169-2356, 2359-2466) --------------------------------------
+// EdgeInertialGS (SF/src/G2oTypes.cc:603-724): the inertial residual with the gravity direction Rwg and the scale s as variables; err (er, ev,
+// ep) and the Jacobian blocks of the non-fixed vertices, 9 x 15 row-major: V1 3 | gyro bias 3 | acc bias 3 | V2 3 | gravity direction 2 | scale 1
+// (the two VertexPose are fixed in both optimisations).
+void inertial_gs_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const double bg[3], const double ba[3], const double Rwg[9], double s,
+                      const Preintegrated& pint, double err[9], double* J) {
+    ImuBias b;
+    b.bax = (float)ba[0]; b.bay = (float)ba[1]; b.baz = (float)ba[2];
+    b.bwx = (float)bg[0]; b.bwy = (float)bg[1]; b.bwz = (float)bg[2];
+    float dRf[9], dVf[3], dPf[3];
+    pint.GetDeltaRotation(b, dRf); pint.GetDeltaVelocity(b, dVf); pint.GetDeltaPosition(b, dPf);
+    double dR[9], dV[3], dP[3];
+    for (int k = 0; k < 9; ++k) dR[k] = dRf[k];
+    for (int k = 0; k < 3; ++k) { dV[k] = dVf[k]; dP[k] = dPf[k]; }
+    const double dt = pint.dT, G = (double)9.81f;
+    const double gI[3] = {0, 0, -G};
+    double g[3];
+    mulv(Rwg, gI, g);
+    double Rbw1[9], dRt[9], t1[9], eR[9], er[3], dv[3], dp[3], rv[3], rp[3];
+    tr(k1.Rwb, Rbw1); tr(dR, dRt);
+    mul(dRt, Rbw1, t1); mul(t1, k2.Rwb, eR);
+    LogSO3(eR, er);
+    for (int k = 0; k < 3; ++k) {
+        dv[k] = s * (k2.v[k] - k1.v[k]) - g[k] * dt;
+        dp[k] = s * (k2.twb[k] - k1.twb[k] - k1.v[k] * dt) - g[k] * dt * dt / 2;
+    }
+    mulv(Rbw1, dv, rv); mulv(Rbw1, dp, rp);
+    for (int k = 0; k < 3; ++k) { err[k] = er[k]; err[3 + k] = rv[k] - dV[k]; err[6 + k] = rp[k] - dP[k]; }
+    if (!J) return;
+    std::memset(J, 0, 9 * 15 * sizeof(double));
+    auto put = [&](int r0, int c0, const double* m, double f) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) J[15 * (r0 + r) + c0 + c] = f * m[3 * r + c]; };
+    put(3, 0, Rbw1, -s); put(6, 0, Rbw1, -s * dt);                                 // velocity 1
+    double invJr[9], JRg[9], JVg[9], JPg[9], JVa[9], JPa[9], Jd[3], RJ[9], eRt[9], a1[9], a2[9], a3[9];
+    inv_right_jacobian(er, invJr);
+    for (int k = 0; k < 9; ++k) { JRg[k] = pint.JRg[k]; JVg[k] = pint.JVg[k]; JPg[k] = pint.JPg[k]; JVa[k] = pint.JVa[k]; JPa[k] = pint.JPa[k]; }
+    const double dbg[3] = {(double)(b.bwx - pint.b.bwx), (double)(b.bwy - pint.b.bwy), (double)(b.bwz - pint.b.bwz)};  // GetDeltaBias is float
+    mulv(JRg, dbg, Jd);
+    right_jacobian(Jd, RJ);
+    tr(eR, eRt);
+    mul(invJr, eRt, a1); mul(a1, RJ, a2); mul(a2, JRg, a3);
+    put(0, 3, a3, -1.0); put(3, 3, JVg, -1.0); put(6, 3, JPg, -1.0);               // gyro bias
+    put(3, 6, JVa, -1.0); put(6, 6, JPa, -1.0);                                    // accelerometer bias
+    put(3, 9, Rbw1, s);                                                            // velocity 2
+    // gravity direction: dGdTheta = Rwg * Gm, Gm = [0 -G; G 0; 0 0]
+    double dG[6];
+    for (int r = 0; r < 3; ++r) { dG[2 * r] = Rwg[3 * r + 1] * G; dG[2 * r + 1] = Rwg[3 * r] * -G; }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 2; ++c) {
+            double v = 0;
+            for (int k = 0; k < 3; ++k) v += Rbw1[3 * r + k] * dG[2 * k + c];
+            J[15 * (3 + r) + 12 + c] = -v * dt;
+            J[15 * (6 + r) + 12 + c] = -0.5 * v * dt * dt;
+        }
+    // scale
+    double d1[3], d2[3], s1[3], s2[3];
+    for (int k = 0; k < 3; ++k) { d1[k] = k2.v[k] - k1.v[k]; d2[k] = k2.twb[k] - k1.twb[k] - k1.v[k] * dt; }
+    mulv(Rbw1, d1, s1); mulv(Rbw1, d2, s2);
+    for (int r = 0; r < 3; ++r) { J[15 * (3 + r) + 14] = s1[r]; J[15 * (6 + r) + 14] = s2[r]; }
+}
+
+namespace {
+// the variables of the two optimisations and where their increments sit in the solution vector (-1: fixed)
+struct InitState {
+    std::vector<InertialKeyFrame> kfs;
+    double bg[3], ba[3], Rwg[9], s;
+};
+void gdir_update(double Rwg[9], double u0, double u1) {  // GDirection::Update: Rwg = Rwg * ExpSO3(u0, u1, 0)
+    const double w[3] = {u0, u1, 0.0};
+    double E[9], R[9];
+    ExpSO3(w, E);
+    mul(Rwg, E, R);
+    std::memcpy(Rwg, R, sizeof(R));
+}
+}  // namespace
+
+InertialInitResult InertialOptimization(std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, double Rwg[9], double& scale,
+                                        double bg[3], double ba[3], bool mono, bool fixed_vel, float priorG, float priorA, int its) {
+    const int N = (int)kfs.size();
+    InertialInitResult res;
+    // unknowns: velocities | gyro bias | acc bias | gravity direction | scale
+    const int o_v = 0, n_v = fixed_vel ? 0 : 3 * N, o_bg = fixed_vel ? -1 : n_v, o_ba = fixed_vel ? -1 : n_v + 3, o_g = fixed_vel ? 0 : n_v + 6,
+              o_s = mono ? o_g + 2 : -1, n = o_g + 2 + (mono ? 1 : 0);
+    std::vector<std::vector<double>> infos(N);
+    for (int i = 1; i < N; ++i) if (pints[i]) edge_inertial_information(*pints[i], infos[i]);
+    InitState st;
+    st.kfs = kfs; std::memcpy(st.bg, bg, 24); std::memcpy(st.ba, ba, 24); std::memcpy(st.Rwg, Rwg, 72); st.s = scale;
+    const double infoA = priorA, infoG = priorG;
+    auto chi2_of = [&](const InitState& x) {  // computeActiveErrors + activeRobustChi2 (no robust kernels here)
+        double chi = 0;
+        for (int i = 1; i < N; ++i) {
+            if (!pints[i]) continue;
+            double e[9];
+            inertial_gs_edge(x.kfs[i - 1], x.kfs[i], x.bg, x.ba, x.Rwg, x.s, *pints[i], e, nullptr);
+            for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) chi += e[r] * infos[i][9 * r + c] * e[c];
+        }
+        for (int k = 0; k < 3; ++k) chi += infoA * x.ba[k] * x.ba[k] + infoG * x.bg[k] * x.bg[k];  // EdgePriorAcc / EdgePriorGyro: e = 0 - b
+        return chi;
+    };
+    std::vector<double> H((size_t)n * n), b(n), x(n);
+    auto build = [&](const InitState& xs) {
+        std::fill(H.begin(), H.end(), 0.0); std::fill(b.begin(), b.end(), 0.0);
+        for (int i = 1; i < N; ++i) {
+            if (!pints[i]) continue;
+            double e[9], J[9 * 15];
+            inertial_gs_edge(xs.kfs[i - 1], xs.kfs[i], xs.bg, xs.ba, xs.Rwg, xs.s, *pints[i], e, J);
+            // column -> unknown
+            int col[15];
+            for (int k = 0; k < 3; ++k) {
+                col[k] = fixed_vel ? -1 : o_v + 3 * (i - 1) + k; col[3 + k] = o_bg < 0 ? -1 : o_bg + k; col[6 + k] = o_ba < 0 ? -1 : o_ba + k;
+                col[9 + k] = fixed_vel ? -1 : o_v + 3 * i + k;
+            }
+            col[12] = o_g; col[13] = o_g + 1; col[14] = o_s;
+            double OJ[9 * 15], Oe[9];
+            for (int r = 0; r < 9; ++r) {
+                for (int c = 0; c < 15; ++c) { double v = 0; for (int k = 0; k < 9; ++k) v += infos[i][9 * r + k] * J[15 * k + c]; OJ[15 * r + c] = v; }
+                double v = 0; for (int k = 0; k < 9; ++k) v += infos[i][9 * r + k] * e[k]; Oe[r] = v;
+            }
+            for (int a = 0; a < 15; ++a) {
+                if (col[a] < 0) continue;
+                double g = 0;
+                for (int r = 0; r < 9; ++r) g += J[15 * r + a] * Oe[r];
+                b[col[a]] -= g;
+                for (int c = 0; c < 15; ++c) {
+                    if (col[c] < 0) continue;
+                    double h = 0;
+                    for (int r = 0; r < 9; ++r) h += J[15 * r + a] * OJ[15 * r + c];
+                    H[(size_t)col[a] * n + col[c]] += h;
+                }
+            }
+        }
+        // the bias priors: error bprior - b with bprior = 0 and the Jacobian the reference declares, +I (SF/src/G2oTypes.cc:769-781)
+        if (o_ba >= 0) for (int k = 0; k < 3; ++k) { H[(size_t)(o_ba + k) * n + o_ba + k] += infoA; b[o_ba + k] -= infoA * (0.0 - xs.ba[k]); }
+        if (o_bg >= 0) for (int k = 0; k < 3; ++k) { H[(size_t)(o_bg + k) * n + o_bg + k] += infoG; b[o_bg + k] -= infoG * (0.0 - xs.bg[k]); }
+    };
+    auto apply = [&](InitState& xs, const std::vector<double>& u) {
+        if (!fixed_vel) {
+            for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) xs.kfs[i].v[k] += u[o_v + 3 * i + k];
+            for (int k = 0; k < 3; ++k) { xs.bg[k] += u[o_bg + k]; xs.ba[k] += u[o_ba + k]; }
+        }
+        gdir_update(xs.Rwg, u[o_g], u[o_g + 1]);
+        if (mono) xs.s *= std::exp(u[o_s]);
+    };
+    // OptimizationAlgorithmLevenberg::solve (core/optimization_algorithm_levenberg.cpp:61-169), dense system (all vertices in one block set:
+    // BlockSolverX without marginalised vertices; LinearSolverEigen = a Cholesky factorisation of it)
+    double lambda = 0, ni = 2;
+    int n_bad = 0;
+    res.err = chi2_of(st);
+    for (int it = 0; it < its; ++it) {
+        double currentChi = chi2_of(st), tempChi = currentChi;
+        const double iniChi = currentChi;
+        build(st);
+        if (it == 0) {
+            if (priorG != 0.f) lambda = 1e3;  // setUserLambdaInit(1e3)
+            else { double md = 0; for (int j = 0; j < n; ++j) md = std::fmax(md, std::fabs(H[(size_t)j * n + j])); lambda = 1e-5 * md; }
+            ni = 2; n_bad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            InitState backup = st;
+            std::vector<double> Hl = H;
+            for (int j = 0; j < n; ++j) Hl[(size_t)j * n + j] += lambda;
+            const bool ok2 = ldlt(Hl, n, b.data(), x.data());
+            apply(st, x);
+            tempChi = chi2_of(st);
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = currentChi - tempChi;
+            double sc = 0;
+            for (int j = 0; j < n; ++j) sc += x[j] * (lambda * x[j] + b[j]);
+            sc += 1e-3;
+            rho /= sc;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                st = backup;
+            }
+            qmax++;
+            res.trials++;
+        } while (rho < 0 && qmax < 10);
+        res.iterations++;
+        res.trace.chi2.push_back(currentChi); res.trace.lambda.push_back(lambda); res.trace.trials.push_back(qmax);
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
+        if (n_bad >= 3) break;
+    }
+    res.err_end = chi2_of(st);
+    kfs = st.kfs; std::memcpy(bg, st.bg, 24); std::memcpy(ba, st.ba, 24); std::memcpy(Rwg, st.Rwg, 72); scale = st.s;
+    return res;
+}
+
+namespace {
+void so3f_exp_matrix(const float v[3], float R[9]) {  // Sophus::SO3f::exp(v).matrix(), evaluated in double and rounded
+    const double w[3] = {v[0], v[1], v[2]};
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    double W[9], W2[9];
+    hat(w, W); mul(W, W, W2);
+    const double a = th < 1e-8 ? 1.0 - th2 / 6 : std::sin(th) / th, bq = th < 1e-8 ? 0.5 - th2 / 24 : (1 - std::cos(th)) / th2;
+    for (int k = 0; k < 9; ++k) R[k] = (float)((k % 4 == 0 ? 1.0 : 0.0) + a * W[k] + bq * W2[k]);
+}
+}  // namespace
+
+// LocalMapping::InitializeIMU, the first estimate (SF/src/LocalMapping.cc:1241-1270): dirG = -sum Rwb_prev * dV, the keyframe velocities
+// from the position differences, Rwg = exp(v * ang / |v|) with v = gI x dirG -- all in float (Eigen::Vector3f, Sophus::SO3f).
+void InitialGravityDirection(const std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, float vel[], float Rwg[9]) {
+    const int N = (int)kfs.size();
+    float dirG[3] = {0, 0, 0};
+    for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) vel[3 * i + k] = (float)kfs[i].v[k];
+    for (int i = 1; i < N; ++i) {
+        if (!pints[i]) continue;
+        float dV[3];
+        pints[i]->GetDeltaVelocity(pints[i]->b, dV);  // GetUpdatedDeltaVelocity at the bias of the integration: dV itself
+        float R[9], p1[3], p0[3];
+        for (int k = 0; k < 9; ++k) R[k] = (float)kfs[i - 1].Rwb[k];
+        for (int k = 0; k < 3; ++k) { p1[k] = (float)kfs[i].twb[k]; p0[k] = (float)kfs[i - 1].twb[k]; }
+        for (int r = 0; r < 3; ++r) dirG[r] -= (R[3 * r] * dV[0] + R[3 * r + 1] * dV[1]) + R[3 * r + 2] * dV[2];
+        for (int k = 0; k < 3; ++k) { const float v = (p1[k] - p0[k]) / pints[i]->dT; vel[3 * i + k] = v; vel[3 * (i - 1) + k] = v; }
+    }
+    const float nrm = std::sqrt((dirG[0] * dirG[0] + dirG[1] * dirG[1]) + dirG[2] * dirG[2]);
+    for (int k = 0; k < 3; ++k) dirG[k] = dirG[k] / nrm;
+    const float gI[3] = {0.0f, 0.0f, -1.0f};
+    const float v[3] = {gI[1] * dirG[2] - gI[2] * dirG[1], gI[2] * dirG[0] - gI[0] * dirG[2], gI[0] * dirG[1] - gI[1] * dirG[0]};
+    const float nv = std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const float cosg = (gI[0] * dirG[0] + gI[1] * dirG[1]) + gI[2] * dirG[2];
+    const float ang = std::acos(cosg);
+    const float vzg[3] = {v[0] * ang / nv, v[1] * ang / nv, v[2] * ang / nv};
+    so3f_exp_matrix(vzg, Rwg);
+}
+
 }  // namespace oracle

@@ -79,6 +79,20 @@ PoseInertialResult PoseInertialOptimization(InertialKeyFrame& cur, InertialKeyFr
                                             const std::vector<double>& Xw, const std::vector<BAEdge>& edges, const std::vector<uint8_t>& close,
                                             const Camera& cam, bool bRecInit);
 
+// ---- IMU initialisation: Optimizer::InertialOptimization, first overload (SF/src/Optimizer.cc:2169-2356) -----
+// Levenberg-Marquardt (user lambda 1e3 when priorG != 0, at most `its` = 200 iterations, g2o's stop rules) over the keyframe velocities,
+// one gyro and one accelerometer bias, the gravity direction (2 dof, VertexGDir) and -- monocular only -- the scale (VertexScale); the
+// keyframe poses are fixed; one EdgeInertialGS per consecutive pair + EdgePriorAcc / EdgePriorGyro (bprior = 0).  kfs in temporal order
+// (Rwb, twb, v used; v updated); pints[i] = kfs[i]'s pre-integration from kfs[i-1] (pints[0] unused; evaluated at the CURRENT biases
+// through the bias Jacobians, as SetNewBias + GetDelta*(b) do).
+struct InertialInitResult { int iterations = 0, trials = 0; double err = 0, err_end = 0; LMTrace trace; };
+InertialInitResult InertialOptimization(std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, double Rwg[9], double& scale,
+                                        double bg[3], double ba[3], bool mono, bool fixed_vel, float priorG, float priorA, int its = 200);
+// LocalMapping::InitializeIMU's first gravity direction and keyframe velocities (SF/src/LocalMapping.cc:1241-1270), float arithmetic
+void InitialGravityDirection(const std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, float vel[], float Rwg[9]);
+void inertial_gs_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const double bg[3], const double ba[3], const double Rwg[9], double s,
+                      const Preintegrated& pint, double err[9], double* J /* 9 x 15 or NULL */);
+
 // exposed for unit tests
 void ExpSO3(const double w[3], double R[9]);
 void LogSO3(const double R[9], double w[3]);

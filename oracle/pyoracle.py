@@ -903,6 +903,46 @@ def pose_inertial(cur33, other33, last_frame, prior246, calib24, pre298, pre_rw2
     return cur, oth, outlier, out, rv, tuple(int(v) for v in st)
 
 
+def inertial_optimization(kf33, pre298, Rwg, scale, bg, ba, mono=False, fixed_vel=False, priorG=1e2, priorA=1e6, its=200):
+    """Optimizer::InertialOptimization (IMU initialisation, first overload) -> (kf33 with the new velocities, Rwg, scale, bg, ba, iterations,
+    trials, (err, err_end), trace).  pre298[i]: keyframe i's pre-integration from keyframe i - 1 (row 0 is ignored)."""
+    kf = _f64(kf33).copy()
+    pre = np.ascontiguousarray(pre298, np.float32).reshape(-1, 298)
+    st = np.zeros(17)
+    st[:9], st[9], st[10:13], st[13:16] = _f64(Rwg).ravel(), scale, _f64(bg), _f64(ba)
+    err2, tr = np.zeros(2), C.c_int(0)
+    tc, tl, tt = np.zeros(256), np.zeros(256), np.zeros(256, np.int32)
+    f = lib().oracle_inertial_optimization
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_int]
+    it = f(kf.ctypes.data, len(kf), pre.ctypes.data, st.ctypes.data, int(mono), int(fixed_vel), priorG, priorA, its, err2.ctypes.data, C.addressof(tr),
+           tc.ctypes.data, tl.ctypes.data, tt.ctypes.data, 256)
+    return kf, st[:9].reshape(3, 3).copy(), float(st[9]), st[10:13].copy(), st[13:16].copy(), it, tr.value, (err2[0], err2[1]), dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it])
+
+
+def initial_gravity_direction(kf33, pre298):
+    """LocalMapping::InitializeIMU's first estimate -> (velocities [N, 3] float32, Rwg [3, 3] float32)."""
+    kf = _f64(kf33)
+    pre = np.ascontiguousarray(pre298, np.float32).reshape(-1, 298)
+    vel, R = np.zeros((len(kf), 3), np.float32), np.zeros(9, np.float32)
+    f = lib().oracle_initial_gravity_direction
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(kf.ctypes.data, len(kf), pre.ctypes.data, vel.ctypes.data, R.ctypes.data)
+    return vel, R.reshape(3, 3)
+
+
+def inertial_gs_edge(kf33_1, kf33_2, bg, ba, Rwg, s, pre298):
+    """EdgeInertialGS -> (error [9], Jacobian [9, 15]: V1 | bg | ba | V2 | gravity direction 2 | scale)."""
+    e, J = np.zeros(9), np.zeros(135)
+    f = lib().oracle_inertial_gs_edge
+    f.argtypes = [C.c_void_p] * 5 + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(_f64(kf33_1).ctypes.data, _f64(kf33_2).ctypes.data, _f64(bg).ctypes.data, _f64(ba).ctypes.data, _f64(Rwg).ctypes.data, float(s),
+      np.ascontiguousarray(pre298, np.float32).ctypes.data, e.ctypes.data, J.ctypes.data)
+    return e, J.reshape(9, 15)
+
+
 def local_inertial_ba(kf33, fixed, has_imu, calib24, points3, edges6, link4, pre298, cam5, iterations=10, lambda_init=1.0):
     """Optimizer::LocalInertialBA's optimisation -> (kf33, points, chi2, depth_pos, iterations, trace, (err, err_end))."""
     kf, pts = _f64(kf33).copy(), _f64(points3).copy()

@@ -671,6 +671,38 @@ class ImuBias(C.Structure):
     _fields_ = [("bax", C.c_float), ("bay", C.c_float), ("baz", C.c_float), ("bwx", C.c_float), ("bwy", C.c_float), ("bwz", C.c_float)]
 
 
+class InertialInitStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("initial_chi2", C.c_double), ("final_chi2", C.c_double), ("final_lambda", C.c_double)]
+
+
+def imu_init_gravity(Rwb, twb, pres):
+    """First estimate of ``LocalMapping::InitializeIMU``: keyframes in temporal order, ``pres[i]`` = Preintegrated of keyframe i from i - 1
+    (``pres[0]`` ignored) -> (velocities [N, 3] float32, Rwg [3, 3] float32)."""
+    R, t = np.ascontiguousarray(Rwb, np.float32).reshape(-1, 9), np.ascontiguousarray(twb, np.float32).reshape(-1, 3)
+    n = len(R)
+    ptrs = (C.c_void_p * n)(*[None if (i == 0 or pres[i] is None) else C.addressof(pres[i].p) for i in range(n)])
+    vel, Rwg = np.zeros((n, 3), np.float32), np.zeros(9, np.float32)
+    f = lib().tc2li_imu_init_gravity
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(n, R.ctypes.data, t.ctypes.data, ptrs, vel.ctypes.data, Rwg.ctypes.data))
+    return vel, Rwg.reshape(3, 3)
+
+
+def inertial_optimization(Rwb, twb, vel, pres, Rwg, scale, bg, ba, mono=False, fixed_vel=False, prior_g=1e2, prior_a=1e6, iterations=200):
+    """``Optimizer::InertialOptimization`` (IMU initialisation) -> (velocities [N, 3], Rwg, scale, bg, ba, InertialInitStats)."""
+    R, t = np.ascontiguousarray(Rwb, np.float64).reshape(-1, 9), np.ascontiguousarray(twb, np.float64).reshape(-1, 3)
+    n = len(R)
+    v = np.ascontiguousarray(vel, np.float64).reshape(n, 3).copy()
+    ptrs = (C.c_void_p * n)(*[None if (i == 0 or pres[i] is None) else C.addressof(pres[i].p) for i in range(n)])
+    Rg, g, a = np.ascontiguousarray(Rwg, np.float64).reshape(9).copy(), np.ascontiguousarray(bg, np.float64).copy(), np.ascontiguousarray(ba, np.float64).copy()
+    s, st = C.c_double(scale), InertialInitStats()
+    f = lib().tc2li_inertial_optimization
+    f.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    _check(f(n, R.ctypes.data, t.ctypes.data, v.ctypes.data, ptrs, Rg.ctypes.data, C.addressof(s), g.ctypes.data, a.ctypes.data, int(mono), int(fixed_vel),
+             prior_g, prior_a, iterations, C.addressof(st)))
+    return v, Rg.reshape(3, 3), s.value, g, a, st
+
+
 class PreintegratedPOD(C.Structure):
     _fields_ = [("dT", C.c_float), ("n_measurements", C.c_int32), ("dR", C.c_float * 9), ("dV", C.c_float * 3), ("dP", C.c_float * 3),
                 ("JRg", C.c_float * 9), ("JVg", C.c_float * 9), ("JVa", C.c_float * 9), ("JPg", C.c_float * 9), ("JPa", C.c_float * 9),

@@ -515,6 +515,26 @@ def pose_inertial_problem(seed=0, n_points=500, frame_dt=0.1, last_frame=False, 
                 bias6=w["bias6"], Xw=Xw, edges=e, close=close, cam=w["cam"], gross=bad)
 
 
+def imu_init_problem(seed=0, n_kf=12, kf_dt=0.4, tilt_deg=25.0, pos_noise=0.01):
+    """An IMU initialisation problem (LocalMapping::InitializeIMU): n_kf keyframes of the analytic trajectory seen in a visual world W that
+    is rotated against the gravity-aligned frame (the map before the IMU is initialised knows nothing of gravity), slightly noisy
+    positions, IMU samples between consecutive keyframes integrated at ZERO bias (the true biases are what the optimisation finds).
+    -> dict(Rwb [N, 3, 3], twb [N, 3] in W, samples (per link: array, t1, t2), Rwg_true (gravity in W = Rwg_true @ (0, 0, -9.81)),
+    vel_true [N, 3] in W, bg_true, ba_true)."""
+    from scipy.spatial.transform import Rotation
+    w = inertial_window(2000 + seed, n_opt=n_kf - 1, n_points=20, kf_dt=kf_dt)
+    rng = np.random.default_rng([SEED0, 0x1217, seed])
+    axis = rng.normal(0, 1, 3)
+    axis /= np.linalg.norm(axis)
+    Rwg = Rotation.from_rotvec(np.deg2rad(tilt_deg) * axis).as_matrix()
+    kt = w["kf33_true"]
+    Rwb = np.stack([Rwg @ k[12:21].reshape(3, 3) for k in kt])
+    twb = np.stack([Rwg @ k[21:24] for k in kt]) + rng.normal(0, pos_noise, (len(kt), 3))
+    vel = np.stack([Rwg @ k[24:27] for k in kt])
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    return dict(Rwb=f32(Rwb), twb=f32(twb), samples=w["samples"], Rwg_true=Rwg, vel_true=vel, bg_true=kt[0][27:30].copy(), ba_true=kt[0][30:33].copy())
+
+
 def tbl7():
     """mLidarParam->mTbl = Tbc * Tcl of the synthetic rig as (qx, qy, qz, qw, tx, ty, tz) float32."""
     from scipy.spatial.transform import Rotation

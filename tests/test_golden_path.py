@@ -274,6 +274,51 @@ def test_product_pose_inertial_golden(pkg, golden_dir):
         assert np.abs(H - wH).max() <= 1e-4 * np.abs(wH).max()
 
 
+# ---- IMU initialisation, section 8f item 4 (tools/make_golden_imu_init.py): host code on both sides, no GPU needed ------------------------
+def test_oracle_imu_init_golden(oracle, golden_dir):
+    g = load(golden_dir, "imu_init_a")
+    n = len(g["Rwb"])
+    kf = np.zeros((n, 33))
+    kf[:, 12:21], kf[:, 21:24] = g["Rwb"].reshape(n, 9), g["twb"]
+    vel0, Rwg0 = oracle.initial_gravity_direction(kf, g["pre298"])
+    assert np.array_equal(vel0, g["vel0"]) and np.array_equal(Rwg0, g["Rwg0"])
+    kf[:, 24:27] = vel0
+    for tag in ("ref", "mild"):
+        pg, pa = g["priors_" + tag]
+        o = oracle.inertial_optimization(kf, g["pre298"], Rwg0, 1.0, np.zeros(3), np.zeros(3), priorG=float(pg), priorA=float(pa))
+        assert [o[5], o[6]] == g["counts_" + tag].tolist()
+        assert np.allclose(o[0][:, 24:27], g["vel_" + tag], rtol=1e-12, atol=1e-12) and np.allclose(o[1], g["Rwg_" + tag], atol=1e-13)
+        assert np.allclose(o[3], g["bg_" + tag], rtol=1e-12, atol=1e-14) and np.allclose(o[4], g["ba_" + tag], rtol=1e-12, atol=1e-14)
+
+
+def test_product_imu_init_golden(pkg, golden_dir):
+    g = load(golden_dir, "imu_init_a")
+    pres = [None]
+    for pre in g["pre298"][1:]:
+        p = pkg.capi.Preintegrated(pre[292:298], 0.0, 0.0, 0.0, 0.0)  # the stored pre-integration, field by field
+        P = p.p
+        P.dT = float(pre[0])
+        o = 1
+        for name, k in (("dR", 9), ("dV", 3), ("dP", 3), ("JRg", 9), ("JVg", 9), ("JVa", 9), ("JPg", 9), ("JPa", 9), ("avgA", 3), ("avgW", 3), ("C", 225)):
+            getattr(P, name)[:] = [float(v) for v in pre[o:o + k]]
+            o += k
+        pres.append(p)
+    vel0, Rwg0 = pkg.capi.imu_init_gravity(g["Rwb"], g["twb"], pres)
+    assert np.allclose(vel0, g["vel0"], rtol=1e-6, atol=1e-6) and np.allclose(Rwg0, g["Rwg0"], atol=1e-6)
+    gdir = lambda R: np.asarray(R, np.float64) @ [0, 0, -1.0]
+    assert np.degrees(np.arccos(np.clip(gdir(Rwg0) @ gdir(g["Rwg_true"]), -1, 1))) < 3.0
+    for tag in ("ref", "mild"):
+        pg, pa = g["priors_" + tag]
+        v, R, s, bg, ba, st = pkg.capi.inertial_optimization(g["Rwb"], g["twb"], g["vel0"], pres, g["Rwg0"], 1.0, np.zeros(3), np.zeros(3), prior_g=float(pg),
+                                                           prior_a=float(pa))
+        assert abs(st.iterations - int(g["counts_" + tag][0])) <= 2 and abs(st.final_chi2 - g["err_" + tag][1]) <= 1e-5 * g["err_" + tag][1]
+        assert np.allclose(v, g["vel_" + tag], rtol=1e-4, atol=1e-4) and np.allclose(R, g["Rwg_" + tag], atol=1e-5) and s == 1.0
+        # with the reference's priors the accelerometer bias keeps creeping while trials at lambda ~ 1e8 are still accepted (the prior edge's
+        # gradient has the wrong sign, see tests/test_imu_init.py): how many are is decided by rounding, hence the absolute tolerance
+        assert np.allclose(bg, g["bg_" + tag], rtol=1e-4, atol=1e-6) and np.allclose(ba, g["ba_" + tag], rtol=1e-4, atol=5e-4 if tag == "ref" else 1e-4)
+        assert np.abs(bg - g["bg_true"]).max() < 1e-3 and np.degrees(np.arccos(np.clip(gdir(R) @ gdir(g["Rwg_true"]), -1, 1))) < 5.0
+
+
 # ---- tracking data path, rows a9 + a10 composed (tools/make_golden_tracking.py) -------------------------------------------------
 def _keys_from_floats(dtype, a):
     k = np.zeros(len(a), dtype)
