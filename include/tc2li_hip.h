@@ -460,6 +460,12 @@ int tc2li_imu_predict_state(const tc2li_preintegrated* p, const tc2li_imu_bias* 
  * Returns the iterations run. */
 typedef struct tc2li_inertial_init_stats { int32_t iterations, trials; double initial_chi2, final_chi2, final_lambda; } tc2li_inertial_init_stats;
 int tc2li_imu_init_gravity(int n_kfs, const float* Rwb9, const float* twb3, const tc2li_preintegrated* const* pre, float* vel3, float Rwg9[9]);
+/* Optimizer::InertialOptimization(pMap, Rwg, scale), the second overload (SF/src/Optimizer.cc:2359-2466; LocalMapping::ScaleRefinement):
+ * Gauss-Newton, `iterations` = 10 in the reference, gravity direction and scale only; the keyframes' velocities and biases ([n][3] each,
+ * edge i takes keyframe i - 1's biases) are fixed, every edge carries Huber(1).  chi2 (may be NULL) = activeRobustChi2 before / after.
+ * Returns the iterations run. */
+int tc2li_inertial_scale_refinement(int n_kfs, const double* Rwb9, const double* twb3, const double* vel3, const double* bg3, const double* ba3,
+                                    const tc2li_preintegrated* const* pre, double Rwg9[9], double* scale, int iterations, double chi2[2]);
 int tc2li_inertial_optimization(int n_kfs, const double* Rwb9, const double* twb3, double* vel3, const tc2li_preintegrated* const* pre,
                                 double Rwg9[9], double* scale, double bg[3], double ba[3], int mono, int fixed_vel, float prior_g, float prior_a,
                                 int iterations, tc2li_inertial_init_stats* stats);

@@ -1210,6 +1210,16 @@ int oracle_inertial_optimization(double* kf33, int n_kf, const float* pre298, do
     for (int i = 0; i < m; ++i) { if (trace_chi2) trace_chi2[i] = r.trace.chi2[i]; if (trace_lambda) trace_lambda[i] = r.trace.lambda[i]; if (trace_trials) trace_trials[i] = r.trace.trials[i]; }
     return r.iterations;
 }
+int oracle_inertial_scale_refinement(const double* kf33, int n_kf, const float* pre298, double* Rwg9, double* scale, int its, double* err2) {
+    std::vector<InertialKeyFrame> kfs(n_kf);
+    for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, 0, 1);
+    std::vector<Preintegrated> pre;
+    pre.reserve(n_kf);
+    for (int k = 0; k < n_kf; ++k) pre.push_back(preint_from(pre298 + 298 * (size_t)k));
+    std::vector<const Preintegrated*> pp(n_kf, nullptr);
+    for (int k = 1; k < n_kf; ++k) pp[k] = &pre[k];
+    return InertialScaleRefinement(kfs, pp, Rwg9, *scale, its, err2);
+}
 void oracle_initial_gravity_direction(const double* kf33, int n_kf, const float* pre298, float* vel, float* Rwg9) {
     std::vector<InertialKeyFrame> kfs(n_kf);
     for (int k = 0; k < n_kf; ++k) kfs[k] = kf_from(kf33 + 33 * k, 0, 1);

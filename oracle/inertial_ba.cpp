@@ -1019,6 +1019,60 @@ InertialInitResult InertialOptimization(std::vector<InertialKeyFrame>& kfs, cons
     return res;
 }
 
+// Optimizer::InertialOptimization(pMap, Rwg, scale) (SF/src/Optimizer.cc:2359-2466; LocalMapping::ScaleRefinement): Gauss-Newton
+// (core/optimization_algorithm_gauss_newton.cpp:49-93: build, solve, update -- no step control), 10 iterations, only the gravity direction
+// and the scale are variables; every EdgeInertialGS takes the biases of its earlier keyframe and carries a Huber kernel with delta 1
+// (robustInformation = rho'(chi2) * information, omega_r = -rho' * information * e; core/base_multi_edge.hpp).  Returns the iterations.
+int InertialScaleRefinement(const std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, double Rwg[9], double& scale, int its,
+                            double err2[2]) {
+    const int N = (int)kfs.size();
+    std::vector<std::vector<double>> infos(N);
+    for (int i = 1; i < N; ++i) if (pints[i]) edge_inertial_information(*pints[i], infos[i]);
+    const HuberD huber(1.f);
+    auto robust_chi2 = [&](const double R[9], double s) {
+        double tot = 0;
+        for (int i = 1; i < N; ++i) {
+            if (!pints[i]) continue;
+            double e[9], c = 0, r0, r1;
+            inertial_gs_edge(kfs[i - 1], kfs[i], kfs[i - 1].bg, kfs[i - 1].ba, R, s, *pints[i], e, nullptr);
+            for (int r = 0; r < 9; ++r) for (int q = 0; q < 9; ++q) c += e[r] * infos[i][9 * r + q] * e[q];
+            huber.rho(c, r0, r1);
+            tot += r0;
+        }
+        return tot;
+    };
+    if (err2) err2[0] = robust_chi2(Rwg, scale);
+    int done = 0;
+    for (int it = 0; it < its; ++it) {
+        std::vector<double> H(9, 0.0);
+        double b[3] = {0, 0, 0}, x[3];
+        for (int i = 1; i < N; ++i) {
+            if (!pints[i]) continue;
+            double e[9], J[135], c = 0, r0, r1;
+            inertial_gs_edge(kfs[i - 1], kfs[i], kfs[i - 1].bg, kfs[i - 1].ba, Rwg, scale, *pints[i], e, J);
+            double Oe[9];
+            for (int r = 0; r < 9; ++r) { double v = 0; for (int q = 0; q < 9; ++q) v += infos[i][9 * r + q] * e[q]; Oe[r] = v; c += e[r] * v; }
+            huber.rho(c, r0, r1);
+            for (int a = 0; a < 3; ++a) {
+                double g = 0;
+                for (int r = 0; r < 9; ++r) g += J[15 * r + 12 + a] * Oe[r];
+                b[a] -= r1 * g;
+                for (int q = 0; q < 3; ++q) {
+                    double h = 0;
+                    for (int r = 0; r < 9; ++r) { double oj = 0; for (int k = 0; k < 9; ++k) oj += infos[i][9 * r + k] * J[15 * k + 12 + q]; h += J[15 * r + 12 + a] * oj; }
+                    H[3 * a + q] += r1 * h;
+                }
+            }
+        }
+        if (!ldlt(H, 3, b, x)) break;
+        gdir_update(Rwg, x[0], x[1]);
+        scale *= std::exp(x[2]);
+        ++done;
+    }
+    if (err2) err2[1] = robust_chi2(Rwg, scale);
+    return done;
+}
+
 namespace {
 void so3f_exp_matrix(const float v[3], float R[9]) {  // Sophus::SO3f::exp(v).matrix(), evaluated in double and rounded
     const double w[3] = {v[0], v[1], v[2]};

@@ -88,6 +88,10 @@ PoseInertialResult PoseInertialOptimization(InertialKeyFrame& cur, InertialKeyFr
 struct InertialInitResult { int iterations = 0, trials = 0; double err = 0, err_end = 0; LMTrace trace; };
 InertialInitResult InertialOptimization(std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, double Rwg[9], double& scale,
                                         double bg[3], double ba[3], bool mono, bool fixed_vel, float priorG, float priorA, int its = 200);
+// Second overload, Optimizer::InertialOptimization(pMap, Rwg, scale) (SF/src/Optimizer.cc:2359-2466, LocalMapping::ScaleRefinement): Gauss-Newton,
+// `its` = 10, gravity direction and scale only, Huber(1) on every EdgeInertialGS, the keyframes' own velocities and biases fixed.
+int InertialScaleRefinement(const std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, double Rwg[9], double& scale, int its,
+                            double err2[2]);
 // LocalMapping::InitializeIMU's first gravity direction and keyframe velocities (SF/src/LocalMapping.cc:1241-1270), float arithmetic
 void InitialGravityDirection(const std::vector<InertialKeyFrame>& kfs, const std::vector<const Preintegrated*>& pints, float vel[], float Rwg[9]);
 void inertial_gs_edge(const InertialKeyFrame& k1, const InertialKeyFrame& k2, const double bg[3], const double ba[3], const double Rwg[9], double s,

@@ -920,6 +920,17 @@ def inertial_optimization(kf33, pre298, Rwg, scale, bg, ba, mono=False, fixed_ve
     return kf, st[:9].reshape(3, 3).copy(), float(st[9]), st[10:13].copy(), st[13:16].copy(), it, tr.value, (err2[0], err2[1]), dict(chi2=tc[:it], lam=tl[:it], trials=tt[:it])
 
 
+def inertial_scale_refinement(kf33, pre298, Rwg, scale, its=10):
+    """Optimizer::InertialOptimization(pMap, Rwg, scale) -> (Rwg, scale, iterations, (err, err_end)); kf33 rows carry v, bg, ba (fixed)."""
+    kf = _f64(kf33)
+    pre = np.ascontiguousarray(pre298, np.float32).reshape(-1, 298)
+    R, s, err2 = _f64(Rwg).reshape(9).copy(), C.c_double(scale), np.zeros(2)
+    f = lib().oracle_inertial_scale_refinement
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    it = f(kf.ctypes.data, len(kf), pre.ctypes.data, R.ctypes.data, C.addressof(s), its, err2.ctypes.data)
+    return R.reshape(3, 3), s.value, it, (err2[0], err2[1])
+
+
 def initial_gravity_direction(kf33, pre298):
     """LocalMapping::InitializeIMU's first estimate -> (velocities [N, 3] float32, Rwg [3, 3] float32)."""
     kf = _f64(kf33)

@@ -688,6 +688,19 @@ def imu_init_gravity(Rwb, twb, pres):
     return vel, Rwg.reshape(3, 3)
 
 
+def inertial_scale_refinement(Rwb, twb, vel, bg, ba, pres, Rwg, scale, iterations=10):
+    """``Optimizer::InertialOptimization(pMap, Rwg, scale)`` (ScaleRefinement) -> (Rwg, scale, iterations, (chi2 before, after))."""
+    R, t = np.ascontiguousarray(Rwb, np.float64).reshape(-1, 9), np.ascontiguousarray(twb, np.float64).reshape(-1, 3)
+    n = len(R)
+    v, g, a = [np.ascontiguousarray(x, np.float64).reshape(n, 3) for x in (vel, bg, ba)]
+    ptrs = (C.c_void_p * n)(*[None if (i == 0 or pres[i] is None) else C.addressof(pres[i].p) for i in range(n)])
+    Rg, s, chi = np.ascontiguousarray(Rwg, np.float64).reshape(9).copy(), C.c_double(scale), np.zeros(2)
+    f = lib().tc2li_inertial_scale_refinement
+    f.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p]
+    it = _check(f(n, R.ctypes.data, t.ctypes.data, v.ctypes.data, g.ctypes.data, a.ctypes.data, ptrs, Rg.ctypes.data, C.addressof(s), iterations, chi.ctypes.data))
+    return Rg.reshape(3, 3), s.value, it, (chi[0], chi[1])
+
+
 def inertial_optimization(Rwb, twb, vel, pres, Rwg, scale, bg, ba, mono=False, fixed_vel=False, prior_g=1e2, prior_a=1e6, iterations=200):
     """``Optimizer::InertialOptimization`` (IMU initialisation) -> (velocities [N, 3], Rwg, scale, bg, ba, InertialInitStats)."""
     R, t = np.ascontiguousarray(Rwb, np.float64).reshape(-1, 9), np.ascontiguousarray(twb, np.float64).reshape(-1, 3)

@@ -305,6 +305,77 @@ int tc2li_inertial_optimization(int n_kfs, const double* Rwb9, const double* twb
     return done;
 }
 
+int tc2li_inertial_scale_refinement(int n_kfs, const double* Rwb9, const double* twb3, const double* vel3, const double* bg3, const double* ba3,
+                                    const tc2li_preintegrated* const* pre, double Rwg9[9], double* scale, int iterations, double chi2[2]) {
+    if (n_kfs < 2 || !Rwb9 || !twb3 || !vel3 || !bg3 || !ba3 || !pre || !Rwg9 || !scale || iterations < 0) {
+        set_error("tc2li_inertial_scale_refinement: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    const int N = n_kfs;
+    std::vector<InertialLinkHost> links(N);
+    for (int i = 1; i < N; ++i) {
+        if (!pre[i]) continue;
+        links[i].pre = pre[i];
+        if (!links[i].prepare(1.0)) { set_error("tc2li_inertial_scale_refinement: covariance of link %d is not positive definite", i); return TC2LI_ERR_INVALID; }
+    }
+    InitVars x;
+    x.v.assign(vel3, vel3 + 3 * (size_t)N);
+    memcpy(x.Rwg, Rwg9, 72); x.s = *scale;
+    const float dsqr = 1.f;  // RobustKernelHuber, delta 1
+    auto huber = [&](double c, double& r0, double& r1) { if (c <= dsqr) { r0 = c; r1 = 1.0; } else { const double q = std::sqrt(c); r0 = 2 * q * 1.0 - dsqr; r1 = 1.0 / q; } };
+    auto edge = [&](int i, double e[9], double* J) {
+        memcpy(x.bg, bg3 + 3 * (size_t)(i - 1), 24); memcpy(x.ba, ba3 + 3 * (size_t)(i - 1), 24);  // the earlier keyframe's (fixed) biases
+        gs_edge(Rwb9 + 9 * (size_t)(i - 1), twb3 + 3 * (size_t)(i - 1), &x.v[3 * (size_t)(i - 1)], Rwb9 + 9 * (size_t)i, twb3 + 3 * (size_t)i, &x.v[3 * (size_t)i], x,
+                links[i].pre, e, J);
+    };
+    auto robust_chi2 = [&] {
+        double tot = 0;
+        for (int i = 1; i < N; ++i) {
+            if (!links[i].pre) continue;
+            double e[9], c = 0, r0, r1;
+            edge(i, e, nullptr);
+            for (int r = 0; r < 9; ++r) for (int q = 0; q < 9; ++q) c += e[r] * links[i].info[9 * r + q] * e[q];
+            huber(c, r0, r1);
+            tot += r0;
+        }
+        return tot;
+    };
+    if (chi2) chi2[0] = robust_chi2();
+    int done = 0;
+    for (int it = 0; it < iterations; ++it) {
+        double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, u[3];
+        for (int i = 1; i < N; ++i) {
+            if (!links[i].pre) continue;
+            double e[9], J[135], Oe[9], OJ[27], c = 0, r0, r1;
+            edge(i, e, J);
+            const double* O = links[i].info;
+            for (int r = 0; r < 9; ++r) {
+                double t = 0; for (int k = 0; k < 9; ++k) t += O[9 * r + k] * e[k];
+                Oe[r] = t; c += e[r] * t;
+                for (int q = 0; q < 3; ++q) { double w = 0; for (int k = 0; k < 9; ++k) w += O[9 * r + k] * J[15 * k + 12 + q]; OJ[3 * r + q] = w; }
+            }
+            huber(c, r0, r1);
+            for (int a = 0; a < 3; ++a) {
+                double g = 0;
+                for (int r = 0; r < 9; ++r) g += J[15 * r + 12 + a] * Oe[r];
+                b[a] -= r1 * g;
+                for (int q = 0; q < 3; ++q) { double h = 0; for (int r = 0; r < 9; ++r) h += J[15 * r + 12 + a] * OJ[3 * r + q]; H[3 * a + q] += r1 * h; }
+            }
+        }
+        if (!ldlt_solve_small(H, 3, b, u, false)) break;
+        const double w[3] = {u[0], u[1], 0.0};
+        double E[9], R[9];
+        exp_so3(w, E);
+        r3_mul(x.Rwg, E, R);
+        memcpy(x.Rwg, R, sizeof(R));
+        x.s *= std::exp(u[2]);
+        ++done;
+    }
+    if (chi2) chi2[1] = robust_chi2();
+    memcpy(Rwg9, x.Rwg, 72); *scale = x.s;
+    return done;
+}
+
 int tc2li_imu_init_gravity(int n_kfs, const float* Rwb9, const float* twb3, const tc2li_preintegrated* const* pre, float* vel3, float Rwg9[9]) {
     if (n_kfs < 2 || !Rwb9 || !twb3 || !pre || !vel3 || !Rwg9) { set_error("tc2li_imu_init_gravity: invalid argument"); return TC2LI_ERR_INVALID; }
     float dirG[3] = {0, 0, 0};

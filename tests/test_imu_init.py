@@ -115,6 +115,24 @@ def test_monocular_scale_and_fixed_velocities(pkg, oracle, synthetic):
     assert st2.iterations == it2 and np.allclose(R2, Rwg2, atol=1e-8) and np.array_equal(v2, kf[:, 24:27])
 
 
+def test_scale_refinement(pkg, oracle, synthetic):
+    """The second overload (LocalMapping::ScaleRefinement): Gauss-Newton on gravity direction + scale with Huber(1) edges."""
+    from scipy.spatial.transform import Rotation
+    w = problem(pkg, oracle, synthetic, 5, n_kf=16)
+    n = len(w["Rwb"])
+    kf = w["kf33"].copy()
+    kf[:, 24:27] = w["vel_true"]
+    kf[:, 27:30], kf[:, 30:33] = w["bg_true"], w["ba_true"]
+    R0 = w["Rwg_true"] @ Rotation.from_rotvec([0.04, -0.03, 0.2]).as_matrix()
+    Rw, sw, itw, errw = oracle.inertial_scale_refinement(kf, w["pre298"], R0, 1.0)
+    g_true = w["Rwg_true"] @ [0, 0, -1.0]
+    assert itw == 10 and errw[1] < errw[0] and angle_between(Rw @ [0, 0, -1.0], g_true) < angle_between(R0 @ [0, 0, -1.0], g_true)
+    R, s, it, err = pkg.capi.inertial_scale_refinement(w["Rwb"], w["twb"], w["vel_true"], np.tile(w["bg_true"], (n, 1)), np.tile(w["ba_true"], (n, 1)), w["pres"],
+                                                      R0, 1.0)
+    assert it == itw and np.allclose(R, Rw, atol=1e-6) and abs(s - sw) <= 1e-5 * sw
+    assert abs(err[0] - errw[0]) <= 1e-5 * errw[0] and abs(err[1] - errw[1]) <= 1e-4 * max(errw[1], 1e-9)
+
+
 def test_argument_errors(pkg, synthetic):
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.inertial_optimization(np.eye(3)[None], np.zeros((1, 3)), np.zeros((1, 3)), [None], np.eye(3), 1.0, np.zeros(3), np.zeros(3))
