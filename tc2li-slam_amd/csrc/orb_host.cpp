@@ -140,7 +140,7 @@ int setup_geometry(tc2li_orb* o, int w, int h) {
         for (int l = 0; l < L; ++l) {
             const LevelGeom& g = o->geom[l];
             max_keys[l] = (l + 1 < L ? o->geom[l + 1].dense_off : slab) - g.dense_off;
-            if (max_keys[l] >= (1 << 21)) { set_error("level %d holds more FAST candidates than the distribution kernel packs", l); return TC2LI_ERR_INVALID; }
+            if (max_keys[l] >= (1 << 20)) { set_error("level %d holds more FAST candidates than the distribution kernel packs", l); return TC2LI_ERR_INVALID; }
             const int bw = g.max_bx - g.min_bx, bh = g.max_by - g.min_by;
             const int n_ini = bh > 0 && bw > 0 ? (int)std::round(static_cast<float>(bw) / bh) : 0;
             max_nodes[l] = std::max(o->features_per_level[l] + 3, 4 * std::max(n_ini, 1)) + 8;
@@ -538,7 +538,7 @@ int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x
 
 int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target, float* out_xyr, int capacity,
                                      int threads) {
-    if (!xyr || !out_xyr || n < 0 || n >= (1 << 21) || n_target < 0 || capacity < 0) return TC2LI_ERR_INVALID;
+    if (!xyr || !out_xyr || n < 0 || n >= (1 << 20) || n_target < 0 || capacity < 0) return TC2LI_ERR_INVALID;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     std::vector<uint32_t> cand((size_t)std::max(n, 1));
     for (int i = 0; i < n; ++i) {

@@ -28,8 +28,9 @@ namespace tc2li {
 namespace {
 
 struct QNode { int16_t ulx, uly, brx, bry; int32_t begin, count; };  // 16 bytes
-struct QRec { int32_t size, ulx, node; };                            // vSizeAndPointerToNode entry
-constexpr int kSortCap = 1536;                                        // records sorted in LDS (more: in global memory, slowly)
+struct QRec { uint32_t key; int32_t node; };                        // vSizeAndPointerToNode entry: key = population << 12 | UL.x (compareNodes' order)
+constexpr int kSortCap = 1536;                                        // records sorted in LDS when they do not fit the register form
+constexpr int kSortRegLanes = 128;                                    // register form: 64 lanes x 2 records
 constexpr unsigned long long kF21 = (1ull << 21) - 1;
 
 __device__ __forceinline__ int q_cx(uint32_t c) { return (int)((c >> 8) & 0xfff); }
@@ -40,65 +41,96 @@ __device__ __forceinline__ int q_quadrant(const QNode& p, uint32_t c) {
     return (q_cx(c) < mx ? 0 : 1) + (q_cy(c) < my ? 0 : 2);
 }
 
-// ---- libstdc++ std::sort(first, last, comp) on QRec, comp = (size, ulx) ascending -------------------------------------------
-__device__ __forceinline__ bool rec_less(const QRec& a, const QRec& b) { return a.size != b.size ? a.size < b.size : a.ulx < b.ulx; }
-__device__ __forceinline__ void rec_swap(QRec* v, int a, int b) { const QRec t = v[a]; v[a] = v[b]; v[b] = t; }
-__device__ void std_push_heap(QRec* f, int hole, int top, QRec value) {
+// ---- libstdc++ std::sort(first, last, comp) on QRec, comp = (population, UL.x) ascending ----------------------------------------
+// The algorithm is scalar; what it costs is the latency of every dependent array access.  Two homes for the array:
+//   ArrMem: LDS (or global) memory, run by one lane -- ~100 cycles per access;
+//   ArrReg: up to 128 records, record i in lane i % 64 of register i / 64 of ONE wavefront whose lanes all execute the same scalar
+//           program: a read is a v_readlane with a scalar lane index, a write a compare-and-select on the lane id -- a few cycles.
+struct ArrMem {
+    QRec* p;
+    __device__ __forceinline__ QRec get(int i) const { return p[i]; }
+    __device__ __forceinline__ void set(int i, const QRec& r) const { p[i] = r; }
+};
+struct ArrReg {
+    uint32_t &k0, &k1;
+    int32_t &n0, &n1;
+    __device__ __forceinline__ QRec get(int i) const {
+        const int lane = __builtin_amdgcn_readfirstlane(i & 63);
+        const bool hi = __builtin_amdgcn_readfirstlane(i >> 6) != 0;
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)k0, lane), b = (uint32_t)__builtin_amdgcn_readlane((int)k1, lane);
+        const int32_t c = __builtin_amdgcn_readlane(n0, lane), d = __builtin_amdgcn_readlane(n1, lane);
+        return QRec{hi ? b : a, hi ? d : c};
+    }
+    __device__ __forceinline__ void set(int i, const QRec& q) const {
+        const int lane = __builtin_amdgcn_readfirstlane(i & 63);
+        const bool hi = __builtin_amdgcn_readfirstlane(i >> 6) != 0;
+        const bool me = (int)(threadIdx.x & 63) == lane;
+        k0 = me && !hi ? q.key : k0; k1 = me && hi ? q.key : k1;
+        n0 = me && !hi ? q.node : n0; n1 = me && hi ? q.node : n1;
+    }
+};
+__device__ __forceinline__ bool rec_less(const QRec& a, const QRec& b) { return a.key < b.key; }
+template <class A> __device__ __forceinline__ void rec_swap(const A& v, int a, int b) { const QRec t = v.get(a), u = v.get(b); v.set(a, u); v.set(b, t); }
+template <class A> __device__ void std_push_heap(const A& f, int o, int hole, int top, QRec value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && rec_less(f[parent], value)) { f[hole] = f[parent]; hole = parent; parent = (hole - 1) / 2; }
-    f[hole] = value;
+    while (hole > top && rec_less(f.get(o + parent), value)) { f.set(o + hole, f.get(o + parent)); hole = parent; parent = (hole - 1) / 2; }
+    f.set(o + hole, value);
 }
-__device__ void std_adjust_heap(QRec* f, int hole, int len, QRec value) {
+template <class A> __device__ void std_adjust_heap(const A& f, int o, int hole, int len, QRec value) {
     const int top = hole;
     int second = hole;
     while (second < (len - 1) / 2) {
         second = 2 * (second + 1);
-        if (rec_less(f[second], f[second - 1])) second--;
-        f[hole] = f[second];
+        if (rec_less(f.get(o + second), f.get(o + second - 1))) second--;
+        f.set(o + hole, f.get(o + second));
         hole = second;
     }
     if ((len & 1) == 0 && second == (len - 2) / 2) {
         second = 2 * (second + 1);
-        f[hole] = f[second - 1];
+        f.set(o + hole, f.get(o + second - 1));
         hole = second - 1;
     }
-    std_push_heap(f, hole, top, value);
+    std_push_heap(f, o, hole, top, value);
 }
-__device__ void std_heap_sort(QRec* f, int len) {  // __partial_sort(first, last, last): __make_heap + __sort_heap
+template <class A> __device__ void std_heap_sort(const A& f, int o, int len) {  // __partial_sort(first, last, last): __make_heap + __sort_heap
     if (len >= 2) {
         for (int parent = (len - 2) / 2;; --parent) {
-            const QRec v = f[parent];
-            std_adjust_heap(f, parent, len, v);
+            const QRec v = f.get(o + parent);
+            std_adjust_heap(f, o, parent, len, v);
             if (parent == 0) break;
         }
     }
     for (int last = len; last > 1;) {
         --last;
-        const QRec v = f[last];
-        f[last] = f[0];
-        std_adjust_heap(f, 0, last, v);
+        const QRec v = f.get(o + last);
+        f.set(o + last, f.get(o));
+        std_adjust_heap(f, o, 0, last, v);
     }
 }
-__device__ void std_unguarded_linear_insert(QRec* v, int last) {
-    const QRec val = v[last];
+template <class A> __device__ void std_unguarded_linear_insert(const A& v, int last) {
+    const QRec val = v.get(last);
     int next = last - 1;
-    while (rec_less(val, v[next])) { v[last] = v[next]; last = next; --next; }
-    v[last] = val;
+    for (;;) {
+        const QRec nx = v.get(next);
+        if (!rec_less(val, nx)) break;
+        v.set(last, nx); last = next; --next;
+    }
+    v.set(last, val);
 }
-__device__ void std_insertion_sort(QRec* v, int first, int last) {
+template <class A> __device__ void std_insertion_sort(const A& v, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
-        if (rec_less(v[i], v[first])) {
-            const QRec val = v[i];
-            for (int k = i; k > first; --k) v[k] = v[k - 1];
-            v[first] = val;
+        const QRec val = v.get(i);
+        if (rec_less(val, v.get(first))) {
+            for (int k = i; k > first; --k) v.set(k, v.get(k - 1));
+            v.set(first, val);
         } else {
             std_unguarded_linear_insert(v, i);
         }
     }
 }
 // stack: 3 x 64 ints of LDS for the right-hand ranges of __introsort_loop (its recursion)
-__device__ void std_sort(QRec* v, int n, int* stack) {
+template <class A> __device__ void std_sort(const A& v, int n, int* stack) {
     if (n <= 0) return;
     int depth0 = 0;
     for (int t = n; t > 1; t >>= 1) ++depth0;
@@ -109,22 +141,24 @@ __device__ void std_sort(QRec* v, int n, int* stack) {
         --sp;
         int first = stack[3 * sp], last = stack[3 * sp + 1], depth = stack[3 * sp + 2];
         while (last - first > 16) {
-            if (depth == 0) { std_heap_sort(v + first, last - first); break; }
+            if (depth == 0) { std_heap_sort(v, first, last - first); break; }
             --depth;
             // __unguarded_partition_pivot: the median of (first + 1, mid, last - 1) goes to first
             const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
-            if (rec_less(v[a], v[b])) {
-                if (rec_less(v[b], v[c])) rec_swap(v, first, b);
-                else if (rec_less(v[a], v[c])) rec_swap(v, first, c);
+            const QRec va = v.get(a), vb = v.get(b), vc = v.get(c);
+            if (rec_less(va, vb)) {
+                if (rec_less(vb, vc)) rec_swap(v, first, b);
+                else if (rec_less(va, vc)) rec_swap(v, first, c);
                 else rec_swap(v, first, a);
-            } else if (rec_less(v[a], v[c])) rec_swap(v, first, a);
-            else if (rec_less(v[b], v[c])) rec_swap(v, first, c);
+            } else if (rec_less(va, vc)) rec_swap(v, first, a);
+            else if (rec_less(vb, vc)) rec_swap(v, first, c);
             else rec_swap(v, first, b);
             int lo = first + 1, hi = last;
+            const QRec pivot = v.get(first);  // *first does not move during the partition
             for (;;) {
-                while (rec_less(v[lo], v[first])) ++lo;
+                while (rec_less(v.get(lo), pivot)) ++lo;
                 --hi;
-                while (rec_less(v[first], v[hi])) --hi;
+                while (rec_less(pivot, v.get(hi))) --hi;
                 if (!(lo < hi)) break;
                 rec_swap(v, lo, hi);
                 ++lo;
@@ -453,7 +487,7 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
                     const int nd = order[j];
                     for (int q = 0; q < 4; ++q) {
                         const int c = cnt[4 * nd + q];
-                        if (c > 1) { const int nn = cidx[4 * nd + q]; recs2[at++] = QRec{c, (int)nodes2[nn].ulx, nn}; }
+                        if (c > 1) { const int nn = cidx[4 * nd + q]; recs2[at++] = QRec{((uint32_t)c << 12) | (uint32_t)nodes2[nn].ulx, nn}; }
                     }
                 }
                 carry += tot;
@@ -467,14 +501,24 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
         else if (phase == 1 || new_size + n_expand * 3 > N) next_phase = 1;
         else next_phase = 0;
         if (next_phase == 1) {  // sort(vPrevSizeAndPointerToNode.begin(), vPrevSizeAndPointerToNode.end(), compareNodes)
-            if (n_expand <= kSortCap) {
+            if (n_expand <= kSortRegLanes) {
+                if (tid < 64) {  // wavefront 0, all lanes: the array lives in its registers
+                    const QRec pad{0xffffffffu, 0};
+                    const QRec q0 = tid < n_expand ? recs2[tid] : pad, q1 = 64 + tid < n_expand ? recs2[64 + tid] : pad;
+                    uint32_t k0 = q0.key, k1 = q1.key;
+                    int32_t n0 = q0.node, n1 = q1.node;
+                    std_sort(ArrReg{k0, k1, n0, n1}, n_expand, s_stack);
+                    if (tid < n_expand) recs2[tid] = QRec{k0, n0};
+                    if (64 + tid < n_expand) recs2[64 + tid] = QRec{k1, n1};
+                }
+            } else if (n_expand <= kSortCap) {
                 for (int j = tid; j < n_expand; j += T) s_rec[j] = recs2[j];
                 __syncthreads();
-                if (tid == 0) std_sort(s_rec, n_expand, s_stack);
+                if (tid == 0) std_sort(ArrMem{s_rec}, n_expand, s_stack);
                 __syncthreads();
                 for (int j = tid; j < n_expand; j += T) recs2[j] = s_rec[j];
             } else if (tid == 0) {
-                std_sort(recs2, n_expand, s_stack);
+                std_sort(ArrMem{recs2}, n_expand, s_stack);
             }
         }
         { int32_t* t = keys; keys = keys2; keys2 = t; t = nodeof; nodeof = nodeof2; nodeof2 = t; }
