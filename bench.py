@@ -277,6 +277,14 @@ class Loop:
         n_ba = int(np.ceil(self.ba_rate)) if self.ba_rate else 0
         self.n_ba = n_ba
         self.ba_batch = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n_ba)], wl.ba_windows[0]["cam"]) if n_ba else None
+        # Local mapping is asynchronous in the reference: it optimises whatever keyframes have arrived when it becomes free.  With few
+        # sequences per GPU a step's windows are a short, latency-bound batch (16 windows: 8.6 ms against 6.4 ms for the other stages), so
+        # the mapping thread takes the windows of two steps in one call, as soon as the tracking thread has finished both (a second,
+        # prebuilt batch of twice the windows; beyond 256 sequences a step's batch already fills the GPU and the thread runs free).
+        self.ba_batch2 = None
+        if n_ba >= 2 and F <= 256 and F % args.kf_interval == 0 and not os.environ.get("TC2LI_BENCH_BA_SINGLE_STEP"):
+            self.ba_batch2 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(2 * n_ba)], wl.ba_windows[0]["cam"])
+        self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
         self.st_outs = [None, None, None]
@@ -332,21 +340,24 @@ class Loop:
         na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, self.states, stream=self.lidar_stream.cuda_stream)
         self.map_adds = [int(na.sum()), int(nn.sum())]
 
-    def ba_step(self):
-        self.ba_due += self.ba_rate
+    def ba_step(self, m=1):
+        """The local-mapping work of m (1 or 2) steps."""
+        self.ba_due += m * self.ba_rate
         k = int(self.ba_due + 1e-9)
         if k < 1:
             return
         self.ba_due -= k
-        if self.ba_batch.run(self.args.ba_concurrency) != self.n_ba:
+        batch, n = (self.ba_batch2, 2 * self.n_ba) if m == 2 else (self.ba_batch, self.n_ba)
+        if batch.run(self.args.ba_concurrency) != n:
             raise RuntimeError("a local BA window failed")
-        self.ba_windows_done += self.n_ba
+        self.ba_windows_done += n
 
     # -- the loop ------------------------------------------------------------------------------------------------------------
     def run(self, n_steps, stages=("orb", "track", "lidar", "ba")):
         """Every stage thread processes n_steps batches; ORB extraction and tracking form a two-deep pipeline over two feature buffers.
         A failure in any stage stops all of them (no thread is left blocked on a queue) and is re-raised."""
         torch = self.torch
+        self.steps_tracked = 0
         free, ready, ready2 = queue.Queue(), queue.Queue(), queue.Queue()
         for k in range(3):
             free.put(k)
@@ -384,6 +395,7 @@ class Loop:
                 if k is None:
                     return
                 self.track_local(k, self.track2_stream.cuda_stream)
+                self.steps_tracked += 1
                 free.put(k)
 
         def lidar_thread():
@@ -393,10 +405,18 @@ class Loop:
                 self.lidar_step()
 
         def ba_thread():
-            for _ in range(n_steps):
-                if failed.is_set():
-                    return
-                self.ba_step()
+            done = 0  # steps whose windows have been optimised; a step's keyframes exist once the tracking thread has finished it
+            # (with a full GPU batch per step -- no second batch -- the thread runs free as before: nothing to gain from waiting)
+            follows_tracking = "track" in set(stages) and self.ba_batch2 is not None
+            while done < n_steps and not failed.is_set():
+                ready = (self.steps_tracked if follows_tracking else n_steps) - done
+                want = min(2, n_steps - done) if follows_tracking else 1  # two steps' keyframes per call while there are that many to come
+                if ready < want:
+                    time.sleep(0.0002)
+                    continue
+                m = want
+                self.ba_step(m)
+                done += m
 
         want = set(stages)
         if "track" in want:
@@ -940,7 +960,8 @@ def main(argv=None):
                 "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel | TrackLocalMap | LiDAR front end + map maintenance | local "
                                  "mapping, each on its own host thread and HIP stream (the reference's tracking / LiDAR / local-mapping threads; with batched "
                                  "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
-                                 "processed one batch",
+                                 "processed one batch" + ("; local mapping takes the keyframes of two tracked steps per call (it follows the tracking "
+                                                          "thread)" if loop.ba_batch2 is not None else "; the LiDAR stream has high priority"),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": {
                     "stage_threads": 5, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
