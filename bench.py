@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-lines", action="store_true", help="skip the single-sequence and the roofline passes (diagnostic runs)")
+    ap.add_argument("--with-roofline", action="store_true", help="with --no-extra-lines: still run the instrumented pass behind `roofline` (profile rounds)")
     ap.add_argument("--front-end-only", action="store_true", help="configs[1]: leave the local BA out of the step")
     ap.add_argument("--split-ba", action="store_true", help="after the timed loop: ONE LV-BA window split over all ranks (landmark partition + "
                     "RCCL all-reduce of the shared-pose blocks, tc2li_local_lv_bundle_adjustment_sharded) next to the same window on one GPU; "
@@ -839,7 +840,7 @@ def main(argv=None):
     # ---- roofline: a second pass of the same loop with an event pair around every kernel launch (the first, timed pass is
     # un-instrumented: `value` comes from it); the dominant kernel = the one with the largest total device time over ALL kernels ----
     roofline, kernel_table, kernel_ms_per_step, peaks = None, None, None, None
-    if rank == 0 and not args.no_extra_lines:
+    if rank == 0 and (not args.no_extra_lines or args.with_roofline):
         pk = pkg.capi.diag_peaks()
         peaks = {"mfma_f64_tflops": round(pk[0], 2), "fma_f64_tflops": round(pk[1], 2), "hbm_copy_GBps": round(pk[2], 1),
                  "note": "measured on this GPU by tc2li_diag_peaks: back-to-back v_mfma_f64_16x16x4_f64, f64 vector FMA, 1 GiB float4 copy (read + write)"}

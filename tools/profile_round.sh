@@ -13,7 +13,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # that has initialised the GPU.  bench.py --no-build then fails instead of building, and the command after `--` stays one interpreter.
 python __graft_entry__.py
 ARGS="bench.py --no-build --no-cpu-baseline --steps 8 --warmup 2 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS > $OUT/bench_trace.log 2>&1
+# --no-extra-lines: the process then runs the default workload only (warm-up, timed steps, the instrumented pass), so the CSV's per-kernel
+# averages are averages over the same loop the line's roofline is measured in
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS --no-extra-lines --with-roofline > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_write.log 2>&1
 # matrix-unit occupancy of the Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters)

@@ -90,3 +90,27 @@ if mix:
         print("MIX %-36s valu %12.0f lds %11.0f conflicts %11.0f per launch, valu issue frac %s" %
               (k[:36], v.get("SQ_INSTS_VALU_per_launch") or 0, v.get("SQ_INSTS_LDS_per_launch") or 0, v.get("SQ_LDS_BANK_CONFLICT_per_launch") or 0,
                ("%.3f" % v["valu_issue_frac"]) if "valu_issue_frac" in v else "-"))
+
+
+# ---- the line's roofline against the CSV of the same run: the dominant kernel's average duration as bench.py measured it (start / stop
+# events of every dispatch) next to rocprofv3's, and the roofline fraction recomputed from the CSV duration
+if line and stats:
+    try:
+        d = json.loads(line[-1])
+        r = d.get("roofline") or {}
+        name = r.get("kernel")
+        rows = [x for x in csv.DictReader(open(stats[0])) if x["Name"].split("(")[0].replace("void ", "").replace("tc2li::", "").split("<")[0] == name]
+        if name and rows:
+            calls = sum(int(x["Calls"]) for x in rows)
+            tot = sum(float(x["TotalDurationNs"]) for x in rows)
+            csv_ms = tot / calls / 1e6
+            per_launch = r.get("algorithmic_bytes_per_launch") or r.get("algorithmic_flops_per_launch")
+            chk = {"kernel": name, "bench_avg_launch_ms": r.get("avg_launch_ms"), "rocprof_csv_avg_launch_ms": round(csv_ms, 6), "rocprof_calls": calls,
+                   "bench_over_csv": round(r.get("avg_launch_ms", 0) / csv_ms, 4), "bench_frac": r.get("frac")}
+            if per_launch and r.get("peak"):
+                scale = 1e9 if r.get("unit") == "GB/s" else 1e12
+                chk["frac_from_csv_duration"] = round(per_launch / (csv_ms * 1e-3) / scale / r["peak"], 5)
+            json.dump(chk, open("profiles/%s_roofline_check.json" % tag, "w"), indent=1)
+            print("ROOFLINE CHECK", chk)
+    except Exception as e:  # noqa: BLE001
+        print("roofline check skipped:", e)
