@@ -219,6 +219,20 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
         p[8] = r0[0];  p[9] = r0[-1]; p[10] = r1[-2]; p[11] = r2[-3]; p[12] = r3[-3]; p[13] = r4[-3]; p[14] = r5[-2]; p[15] = r6[-1];
         return r3[0];
     };
+    // The reference runs cv::FAST(iniThFAST) on the cell and only if that finds nothing cv::FAST(minThFAST) (SF/src/ORBextractor.cc:799-812).
+    // Same here: the passes below run at iniThFAST first -- far fewer pixels get past the compass pre-test at 20 grey levels than at 7 -- and
+    // once more at minThFAST only for a cell without any corner (low-contrast regions, where few pixels survive either way).  The score of a
+    // pixel does not depend on the threshold; non-maximum suppression only sees neighbours that are corners at the threshold of the attempt
+    // (cv::FAST's score buffer): in the second attempt the survivors of the first are a subset, their scores are simply written again.
+    const int sel = 1;
+    int nlist = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const int th = attempt == 0 ? ini_th : min_th;
+    if (attempt == 1) {
+        __syncthreads();
+        if (tid == 0) { s_nlist = 0; s_cnt_ini = 0; }
+        __syncthreads();
+    }
     // Pass 0, every pixel: a necessary condition of the segment test on the four compass pixels -- nine contiguous circle pixels
     // always contain pixel 0 or 8 and pixel 4 or 12, so a brighter (darker) arc needs (p0 | p8) & (p4 | p12) brighter (darker).
     // Most pixels of an image stop here after five LDS bytes; the others are appended to a list (any order).
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
         const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
         const uint8_t* r3 = tile + cy * kTileP + mis(cy) + cx;
         const uint8_t* r6 = tile + (cy + 3) * kTileP + mis(cy + 3) + cx;
-        const int v = r3[0], hi_t = v + min_th, lo_t = v - min_th;
+        const int v = r3[0], hi_t = v + th, lo_t = v - th;
         const int p0 = r6[0], p8 = r0[0], p4 = r3[3], p12 = r3[-3];
         const bool bright = (p0 > hi_t || p8 > hi_t) && (p4 > hi_t || p12 > hi_t);
         const bool dark = (p0 < lo_t || p8 < lo_t) && (p4 < lo_t || p12 < lo_t);
@@ -253,8 +267,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
                 uint32_t mb = 0, md = 0;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    mb |= (uint32_t)(p[j] > v + min_th) << j;
-                    md |= (uint32_t)(p[j] < v - min_th) << j;
+                    mb |= (uint32_t)(p[j] > v + th) << j;
+                    md |= (uint32_t)(p[j] < v - th) << j;
                 }
                 const uint32_t pol = (has_arc9(md) ? 1u : 0u) | (has_arc9(mb) ? 2u : 0u);  // bit 0: darker arc, bit 1: brighter arc
                 if (pol) entry = (uint32_t)at | (pol << 14);
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     __syncthreads();
     // Pass 2, survivors only, packed densely over the lanes: S = the largest arc contrast of the polarity that has an arc
     // (the other polarity cannot exceed the threshold, so it cannot be the maximum).
-    const int nlist = s_nlist;
+    nlist = s_nlist;
     for (int k = tid; k < nlist; k += kFastThreads) {
         const uint32_t e = s_list[k];
         const int at = e & 0x3fff, cy = at / TW, cx = at - cy * TW;
@@ -278,29 +292,28 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
         score[at] = (uint8_t)S;
     }
     __syncthreads();
-    // Pass 3, survivors only: 3x3 strict non-max suppression for both thresholds (every survivor has S > minTh; a neighbour
-    // counts with its score only where it is a corner at the threshold in question, cv::FAST's score buffer semantics)
-    int my_ini = 0;
+    // Pass 3, survivors only: 3x3 strict non-max suppression at the attempt's threshold (every survivor has S > th; a neighbour
+    // counts with its score only where it is a corner at that threshold, cv::FAST's score buffer semantics)
+    int my_kept = 0;
     for (int k = tid; k < nlist; k += kFastThreads) {
         const int at = s_list[k] & 0x3fff;
         const uint8_t* sc = score + at;
         const int S = sc[0];
         const int nb[8] = {sc[-TW - 1], sc[-TW], sc[-TW + 1], sc[-1],
                            sc[1], sc[TW - 1], sc[TW], sc[TW + 1]};
-        bool keep_ini = S > ini_th, keep_min = true;
+        bool keep = true;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int n_ini = nb[j] > ini_th ? nb[j] - 1 : 0;
-            const int n_min = nb[j] > min_th ? nb[j] - 1 : 0;
-            keep_ini = keep_ini && (S - 1 > n_ini);
-            keep_min = keep_min && (S - 1 > n_min);
+            const int n_th = nb[j] > th ? nb[j] - 1 : 0;
+            keep = keep && (S - 1 > n_th);
         }
-        s_flag[k] = (uint8_t)((keep_ini ? 1 : 0) | (keep_min ? 2 : 0));
-        my_ini += keep_ini ? 1 : 0;
+        s_flag[k] = (uint8_t)(keep ? 1 : 0);
+        my_kept += keep ? 1 : 0;
     }
-    if (my_ini) atomicAdd(&s_cnt_ini, my_ini);
+    if (my_kept) atomicAdd(&s_cnt_ini, my_kept);
     __syncthreads();
-    const int sel = s_cnt_ini > 0 ? 1 : 2;
+    if (s_cnt_ini > 0) break;  // uniform: every lane reads the same count
+    }
     // Emission in row-major order (the order cv::FAST returns the keypoints in): the kept survivors are gathered (a few tens
     // per cell; strict 3x3 maxima: at most one per 2x2 block), the rank of each among them is its output slot.
     for (int k = tid; k < nlist; k += kFastThreads)
