@@ -27,15 +27,22 @@ struct BaProblemDev {
     double *points, *points_trial;
     const BaEdge* edges;
     const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges;
+    // the edges with a free pose, landmark-major (the order of pt_edges restricted to them): fl_off CSR by landmark, fl_pose the free
+    // pose of each, w_slot[e] the place of edge e among them (-1: fixed pose).  A landmark has at most one edge per pose.
+    // fl_lm: the landmark of each; slice_off / fl_place: the sparse Schur kernel's cut into slices (<= 256 such edges of <= 64 landmarks
+    // each) and the landmark's rank within its slice
+    const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off;
+    // sparse_schur: the Schur complement is formed from the landmark-major W blocks (k_ba_schur_sparse; np_pad / 16 <= 8 tile rows),
+    // one partial sum per slice; otherwise through the dense k-major operands AT / BT
+    int32_t sparse_schur, pad2_;
     double *chi2, *rho0;
-    double *contrib_l, *contrib_p, *W;   // per edge: 9, 27, 18 doubles
+    double *contrib_l, *contrib_p, *W;   // per edge: 9, 27 doubles; per edge with a free pose (at w_slot): 18
     double *Hll, *bl, *diag_l;           // per landmark: 6, 3, 1
     double *Hpp, *diag_p;                // per free pose: 27 (21 packed upper + 6 b), 1
-    double *Dinv, *db;                   // per landmark: 9, 3
     double *coef_e, *coef;               // per edge 6, per free pose 6
-    double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands
-    double *S_part;                      // [n_slices][np_pad * np_pad]
-    double *scale_part;                  // per 4 landmarks: partial sums of the gain-ratio scale
+    double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands (dense path only)
+    double *S_part;                      // [n_slices][np_pad * np_pad]; sparse path: row 6 n_free holds W D^-1 b_l
+    double *scale_part;                  // per 256 landmarks: partial sums of the gain-ratio scale
     double *chi_part;                    // per 256 edges: partial sums of the robust cost
 };
 
@@ -59,7 +66,11 @@ struct BaBatchSlot {
     uint8_t* depth_out;
     BalmDev balm;
 };
-struct BaBatchExtent { int max_edges, max_points, max_poses, max_free, max_free_edges, max_np_pad, max_slices, max_planes, max_chunks, max_W; };
+struct BaBatchExtent {
+    int max_edges, max_points, max_poses, max_free, max_free_edges, max_np_pad, max_slices, max_planes, max_chunks, max_W;
+    // max_np_pad / max_slices: over the windows on the dense Schur path; the sparse ones:
+    int any_dense, max_sparse_np_pad, max_sparse_slices;
+};
 void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);

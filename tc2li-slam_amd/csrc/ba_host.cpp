@@ -34,7 +34,7 @@ PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
 
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
-    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p, d_Dinv, d_db,
+    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
         d_coef_e, d_coef, d_AT, d_Spart, d_scale_part, d_chi_part, d_red;
     // the window as the caller hands it over -- poses, points, edges and the index arrays -- goes up in ONE copy: a stream operation
     // costs about as much as one of the loop's kernels, and a batch has one such set per window
@@ -93,40 +93,79 @@ struct VisualProblem {
             if (i >= 0) pv_edges[fp[i]++] = e;
         }
     }
+    // the edges with a free pose in landmark-major order: where the W blocks live (the Schur product and the back substitution walk
+    // them by landmark)
+    std::vector<int> fl_off(n_points + 1, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
+        w_slot(n_edges, -1), slice_off(1, 0);
+    {
+        // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
+        // the window alone, so that a window gives the same bits alone and in a batch
+        constexpr int kSliceEdges = 256, kSliceLandmarks = 64;
+        std::vector<int> seen(std::max(n_free, 1), -1);
+        int at = 0, slice_lms = 0;
+        for (int l = 0; l < n_points; ++l) {
+            const int begin = at;
+            for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
+                const int e = pt_edges[k], i = pose_var[edges[e].pose];
+                if (i < 0) continue;
+                // g2o would add the two edges' Hpl blocks; the operands here hold one block per (landmark, pose)
+                if (seen[i] == l) { set_error("point %d has two edges to pose %d", l, edges[e].pose); return TC2LI_ERR_INVALID; }
+                seen[i] = l;
+                w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; ++at;
+            }
+            fl_off[l + 1] = at;
+            if (at == begin) continue;
+            if (slice_lms == kSliceLandmarks || at - slice_off.back() > kSliceEdges) { slice_off.push_back(begin); slice_lms = 0; }
+            for (int k = begin; k < at; ++k) fl_place[k] = slice_lms;
+            ++slice_lms;
+        }
+        if (at > slice_off.back()) slice_off.push_back(at);
+    }
     np = 6 * n_free;
-    const int np_pad = std::max(16, (np + 15) / 16 * 16);
+    // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
+    const bool sparse = (np + 1 + 15) / 16 <= 8;
+    const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
     const int k_total = 3 * n_points;
-    n_slices = std::max(1, std::min(64, k_total / 64));
-    k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
+    if (sparse) {
+        n_slices = (int)slice_off.size() - 1;
+        k_per_slice = 0;
+    } else {
+        n_slices = std::max(1, std::min(64, k_total / 64));
+        k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
+    }
 
     // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
     auto& d_poses_trial = ws.d_poses_trial;
     auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
-         &d_diag_p = ws.d_diag_p, &d_Dinv = ws.d_Dinv, &d_db = ws.d_db, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
+         &d_diag_p = ws.d_diag_p, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
          &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
     auto& d_depth = ws.d_depth;
     auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
     const size_t E = n_edges, P = n_points;
-    const size_t at_elems = (size_t)(k_per_slice * n_slices + 4) * np_pad;
+    const size_t at_elems = sparse ? 0 : (size_t)(k_per_slice * n_slices + 4) * np_pad;
     TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
     TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
     TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(kContribL * E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * E));
-    TC2LI_HIP_CHECK(d_W.ensure(18 * E)); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
+    TC2LI_HIP_CHECK(d_W.ensure(18 * (size_t)std::max(n_free_edges, 1))); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
     TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_Dinv.ensure(9 * P)); TC2LI_HIP_CHECK(d_db.ensure(3 * P)); TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
+    if (!sparse) TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
     TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_AT.ensure(2 * at_elems));  // A^T and B^T operands back to back: one fill
-    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)n_slices * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 4 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
+    if (!sparse) TC2LI_HIP_CHECK(d_AT.ensure(2 * at_elems));  // A^T and B^T operands back to back: one fill
+    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)std::max(n_slices, 1) * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 256 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
     TC2LI_HIP_CHECK(d_depth.ensure(E));
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
-    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges], every part 16-byte aligned ----
+    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off], every
+    // part 16-byte aligned ----
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
                  o_pose_var = align16(o_edges + E * sizeof(BaEdge)), o_pt_off = align16(o_pose_var + n_poses * sizeof(int)),
                  o_pt_edges = align16(o_pt_off + (P + 1) * sizeof(int)), o_pv_off = align16(o_pt_edges + E * sizeof(int)),
-                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), in_bytes = align16(o_pv_edges + pv_edges.size() * sizeof(int));
+                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + pv_edges.size() * sizeof(int)),
+                 o_fl_pose = align16(o_fl_off + (P + 1) * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
+                 o_fl_lm = align16(o_w_slot + E * sizeof(int)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
+                 o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), in_bytes = align16(o_slice_off + slice_off.size() * sizeof(int));
     TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
     uint8_t* const h = ws.h_in.p;
     if (poses7) {
@@ -141,10 +180,16 @@ struct VisualProblem {
     memcpy(h + o_pt_edges, pt_edges.data(), E * sizeof(int));
     memcpy(h + o_pv_off, pv_off.data(), (n_free + 1) * sizeof(int));
     memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));
+    memcpy(h + o_fl_off, fl_off.data(), (P + 1) * sizeof(int));
+    memcpy(h + o_fl_pose, fl_pose.data(), fl_pose.size() * sizeof(int));
+    memcpy(h + o_w_slot, w_slot.data(), E * sizeof(int));
+    memcpy(h + o_fl_lm, fl_lm.data(), fl_lm.size() * sizeof(int));
+    memcpy(h + o_fl_place, fl_place.data(), fl_place.size() * sizeof(int));
+    memcpy(h + o_slice_off, slice_off.data(), slice_off.size() * sizeof(int));
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
     TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
-    TC2LI_HIP_CHECK(zero_or_defer(d_AT.p, 2 * at_elems * sizeof(double), st));
+    if (!sparse) TC2LI_HIP_CHECK(zero_or_defer(d_AT.p, 2 * at_elems * sizeof(double), st));
     uint8_t* const d = ws.d_in.p;
 
     pb = BaProblemDev{};
@@ -156,8 +201,11 @@ struct VisualProblem {
     pb.poses = (Se3*)(d + o_poses); pb.poses_trial = d_poses_trial.p; pb.points = (double*)(d + o_points); pb.points_trial = d_points_trial.p;
     pb.edges = (const BaEdge*)(d + o_edges); pb.pose_var = (const int*)(d + o_pose_var); pb.pt_off = (const int*)(d + o_pt_off);
     pb.pt_edges = (const int*)(d + o_pt_edges); pb.pv_off = (const int*)(d + o_pv_off); pb.pv_edges = (const int*)(d + o_pv_edges);
+    pb.fl_off = (const int*)(d + o_fl_off); pb.fl_pose = (const int*)(d + o_fl_pose); pb.w_slot = (const int*)(d + o_w_slot);
+    pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off);
+    pb.sparse_schur = sparse ? 1 : 0;
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
-    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.Dinv = d_Dinv.p; pb.db = d_db.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
+    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
     pb.AT = d_AT.p; pb.BT = d_AT.p + at_elems; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
         return TC2LI_OK;
@@ -1046,7 +1094,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         const BaProblemDev& pb = W[i].vp.pb;
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges);
-        X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
+        if (pb.sparse_schur) {
+            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
+        } else {
+            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
+        }
         if (W[i].lidar) {
             X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
             X.max_W = std::max(X.max_W, W[i].lidar->W);

@@ -147,7 +147,7 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
                     W[3 * r + c] = s;
                 }
             store_d2<kContribP>(pb.contrib_p + kContribP * (size_t)e, cp);
-            store_d2<18>(pb.W + 18 * (size_t)e, W);
+            store_d2<18>(pb.W + 18 * (size_t)pb.w_slot[e], W);
         }
     }
     block_sum_256(rho0, s_sum, pb.chi_part + bx);  // the robust cost is summed per workgroup here, finished in the next launch
@@ -282,23 +282,12 @@ __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double
     for (int r = 0; r < 3; ++r) db[r] = Di[3 * r] * b[0] + Di[3 * r + 1] * b[1] + Di[3 * r + 2] * b[2];
 }
 
-// One launch: workgroups [0, nbp) store D^-1 and D^-1 b_l per landmark (for the back substitution), the others handle
-// the edges with a free pose: W D^-1 and W (6x3) scattered into the two k-major GEMM operands, W D^-1 b_l.  An edge
-// recomputes its landmark's 3x3 inverse (same arithmetic, same value) instead of waiting for the landmark pass.
-__device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const int bx, int nbp, double lambda) {
-    if (bx < nbp) {
-        const int l = bx * 256 + threadIdx.x;
-        if (l >= pb.n_points) return;
-        double Di[9], db[3];
-        point_dinv(pb, l, lambda, Di, db);
-        double* o = pb.Dinv + 9 * (size_t)l;
-        for (int i = 0; i < 9; ++i) o[i] = Di[i];
-        for (int r = 0; r < 3; ++r) pb.db[3 * (size_t)l + r] = db[r];
-        return;
-    }
+// Dense path, per edge with a free pose: W D^-1 and W (6x3) scattered into the two k-major GEMM operands, W D^-1 b_l.  An edge
+// recomputes its landmark's 3x3 inverse (same arithmetic, same value as the back substitution's).
+__device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const int bx, double lambda) {
     // edges in landmark-major order (the CSR by landmark): neighbouring threads write neighbouring segments of the same three
     // rows of the GEMM operands; edges of fixed poses drop out
-    const int k = (bx - nbp) * 256 + threadIdx.x;
+    const int k = bx * 256 + threadIdx.x;
     if (k >= pb.n_edges) return;
     const int e = pb.pt_edges[k];
     const BaEdge ed = pb.edges[e];
@@ -309,7 +298,7 @@ __device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const
     typedef double d2 __attribute__((ext_vector_type(2)));
     double W[18];
     {
-        const d2* w2 = reinterpret_cast<const d2*>(pb.W + 18 * (size_t)e);  // 144 bytes per edge: 16-byte aligned
+        const d2* w2 = reinterpret_cast<const d2*>(pb.W + 18 * (size_t)pb.w_slot[e]);  // 144 bytes per edge: 16-byte aligned
 #pragma unroll
         for (int q = 0; q < 9; ++q) { const d2 v = w2[q]; W[2 * q] = v.x; W[2 * q + 1] = v.y; }
     }
@@ -337,7 +326,7 @@ __device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const
         }
     }
 }
-__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, int nbp, double lambda) { d_ba_schur_prepare(pb, blockIdx.x, nbp, lambda); }
+__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, double lambda) { d_ba_schur_prepare(pb, blockIdx.x, lambda); }
 
 __device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const int bx) {
     __shared__ double s_part[128 * 6];
@@ -453,6 +442,114 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_strip(const double* __rest
     d_ba_schur_gemm_strip<CT>(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
 }
 
+// ---- the Schur product from the landmark-major W blocks ----
+// One workgroup per slice of landmarks: at most 256 edges with a free pose (one per thread) of at most 64 landmarks, cut by the host
+// (slice_off; fl_place = the landmark's rank within its slice).  Every thread loads its 6x3 block W up front -- the only round trip to
+// memory -- and forms W D^-1; then, eight landmarks (24 operand rows, six MFMA k-steps) at a time, the threads of the chunk put their
+// blocks into two LDS operands [24][np_pad] that are zero elsewhere (and clear them again after the chunk's MFMAs).  Column 6 n_free
+// of the first operand takes D^-1 b_l, so that row 6 n_free of the product is sum_l W D^-1 b_l.  The dense operands of
+// k_ba_schur_prepare (2 x 3 n_points x np_pad doubles per window, written and read every iteration) never exist; HBM sees the W blocks
+// once.  The tiles on and below the diagonal are dealt to the four wavefronts round-robin; a tile accumulates its k-steps in ascending order, chunk after chunk, so the result does not depend on the launch.
+constexpr int kSchurChunk = 8, kSchurRows = 3 * kSchurChunk;
+__host__ __device__ inline int schur_ldw(int np_pad) { return np_pad % 32 == 16 ? np_pad : np_pad + 16; }  // rows r, r+1 on disjoint banks
+
+template <int TPW>  // tiles per wavefront: the tiles(tiles + 1) / 2 tiles on and below the diagonal are dealt round-robin
+__device__ __forceinline__ void d_ba_schur_sparse(const BaProblemDev& pb, const int slice, const double lambda, double* __restrict__ lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int np = 6 * pb.n_free, ld = pb.np_pad, tiles = ld / 16, ldw = schur_ldw(ld);
+    double* Yt = lds;                     // [24][ldw]: (W D^-1)^T, column np: D^-1 b_l
+    double* Wt = lds + kSchurRows * ldw;  // [24][ldw]: W^T
+    const int s0 = pb.slice_off[slice], s1 = pb.slice_off[slice + 1];
+    const int n_chunks = pb.fl_place[s1 - 1] / kSchurChunk + 1;  // the last edge belongs to the last landmark of the slice
+    const int s = s0 + tid;
+    double W[18], y[3][6], db[3];
+    int my_chunk = -1, at = 0;
+    bool first = false;
+    if (s < s1) {
+        const int l = pb.fl_lm[s], place = pb.fl_place[s];
+        load_d2<18>(pb.W + 18 * (size_t)s, W);
+        first = s == pb.fl_off[l];  // the landmark's first edge also carries D^-1 b_l
+        double Di[9];
+        point_dinv(pb, l, lambda, Di, db);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) y[c][r] = W[3 * r] * Di[c] + W[3 * r + 1] * Di[3 + c] + W[3 * r + 2] * Di[6 + c];
+        my_chunk = place / kSchurChunk;
+        at = 3 * (place % kSchurChunk) * ldw + 6 * pb.fl_pose[s];
+    }
+    for (int k = tid; k < 2 * kSchurRows * ldw; k += 256) lds[k] = 0.0;
+    int tile_a[TPW], tile_b[TPW];  // operand column offsets of this wavefront's tiles (-1: none), wavefront-uniform
+    {
+        const int n_tiles = tiles * (tiles + 1) / 2;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int n = wave + 4 * q;
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= n) ++ti;
+            tile_a[q] = n < n_tiles ? 16 * ti : -1;
+            tile_b[q] = 16 * (n - ti * (ti + 1) / 2);
+        }
+    }
+    v4d acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) acc[q] = v4d{0, 0, 0, 0};
+    const int i16 = lane & 15, kk = lane >> 4;
+    for (int q = 0; q < n_chunks; ++q) {
+        __syncthreads();  // the previous chunk's MFMAs have read the operands
+        if (q > 0 && my_chunk == q - 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    *reinterpret_cast<v2d*>(Yt + at + c * ldw + 2 * h) = v2d{0, 0};
+                    *reinterpret_cast<v2d*>(Wt + at + c * ldw + 2 * h) = v2d{0, 0};
+                }
+                if (first) Yt[at - at % ldw + c * ldw + np] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (my_chunk == q) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    *reinterpret_cast<v2d*>(Yt + at + c * ldw + 2 * h) = v2d{y[c][2 * h], y[c][2 * h + 1]};
+                    *reinterpret_cast<v2d*>(Wt + at + c * ldw + 2 * h) = v2d{W[3 * (2 * h) + c], W[3 * (2 * h + 1) + c]};
+                }
+                if (first) Yt[at - at % ldw + c * ldw + np] = db[c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < kSchurRows / 4; ++st) {
+            const int ro = (4 * st + kk) * ldw + i16;
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                if (tile_a[u] < 0) break;  // uniform over the wavefront
+                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[ro + tile_a[u]], Wt[ro + tile_b[u]], acc[u], 0, 0, 0);
+            }
+        }
+    }
+    double* out = pb.S_part + (size_t)slice * ld * ld;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        if (tile_a[q] < 0) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(tile_a[q] + kk + 4 * r) * ld + tile_b[q] + i16] = acc[q][r];
+    }
+}
+// 4 tiles per wavefront (np_pad <= 80): held to 168 registers, three wavefronts per SIMD (a dozen spilled values of the prologue) --
+// the other workgroups' MFMAs cover a workgroup's loads and barriers
+__global__ __launch_bounds__(256) void k_ba_schur_sparse4(BaProblemDev pb, double lambda) {
+    extern __shared__ double s_schur[];
+    d_ba_schur_sparse<4>(pb, blockIdx.x, lambda, s_schur);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, double lambda) {
+    extern __shared__ double s_schur[];
+    d_ba_schur_sparse<9>(pb, blockIdx.x, lambda, s_schur);
+}
+
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
@@ -485,43 +582,54 @@ __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const 
     }
     if (idx < np) {
         const double bp = pb.Hpp[27 * (size_t)(idx / 6) + 21 + idx % 6];
-        bs_out[idx] = bp - pb.coef[idx];
+        double coef = 0;
+        if (pb.sparse_schur) {  // row np of the product: sum_l W D^-1 b_l, slice after slice
+            const double* sp = pb.S_part + (size_t)np * pb.np_pad + idx;
+            const size_t step = (size_t)pb.np_pad * pb.np_pad;
+            for (int k = 0; k < n_slices; ++k) coef += sp[(size_t)k * step];
+        } else {
+            coef = pb.coef[idx];
+        }
+        bs_out[idx] = bp - coef;
         bs_out[np + idx] = bp;
     }
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) { d_ba_schur_finish(pb, blockIdx.x, lambda, n_slices, S_out, bs_out); }
 
-// x_l = D^-1 (b_l - W^T x_p) for sixteen landmarks per workgroup: 16 lanes per landmark, each lane owns the columns j, j + 16, ...
-// of the landmark's three rows of W^T (rows 3l..3l+2 of the k-major GEMM operand BT, zeros where the landmark has no edge to a
-// pose); the 16 partial dot products are added in a fixed shuffle order.
-constexpr int kBacksubPerBlock = 16;
-__device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, const double* __restrict__ xp, double lambda, double* s_sum) {
-    const int group = threadIdx.x >> 4, sub = threadIdx.x & 15, l = block * kBacksubPerBlock + group;
+// x_l = D^-1 (b_l - W^T x_p), one thread per landmark over its W blocks (landmark-major: a thread reads one contiguous run, the
+// workgroup one contiguous range); x_p comes from the host's pinned memory once per workgroup, not once per use.
+constexpr int kBacksubPerBlock = 256, kBacksubMaxNp = 512;
+__device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, const double* __restrict__ xp, double lambda, double* s_sum, double* s_x) {
+    const int l = block * kBacksubPerBlock + threadIdx.x;
     const int np = 6 * pb.n_free;
+    const bool staged = np <= kBacksubMaxNp;
+    if (staged) {
+        for (int j = threadIdx.x; j < np; j += 256) s_x[j] = xp[j];
+        __syncthreads();
+    }
     double sc = 0;
     if (l < pb.n_points) {
         double d0 = 0, d1 = 0, d2 = 0;
-        const double* w = pb.BT + (size_t)(3 * l) * pb.np_pad;
-        for (int j = sub; j < np; j += 16) {
-            const double x = xp[j];
-            d0 += w[j] * x;
-            d1 += w[pb.np_pad + j] * x;
-            d2 += w[2 * pb.np_pad + j] * x;
-        }
-        for (int o = 8; o >= 1; o >>= 1) {
-            d0 += __shfl_xor(d0, o, 64);
-            d1 += __shfl_xor(d1, o, 64);
-            d2 += __shfl_xor(d2, o, 64);
-        }
-        if (sub == 0) {
-            const double cl[3] = {pb.bl[3 * (size_t)l] - d0, pb.bl[3 * (size_t)l + 1] - d1, pb.bl[3 * (size_t)l + 2] - d2};
-            const double* Di = pb.Dinv + 9 * (size_t)l;
-            for (int r = 0; r < 3; ++r) {
-                const double x = Di[3 * r] * cl[0] + Di[3 * r + 1] * cl[1] + Di[3 * r + 2] * cl[2];
-                pb.points_trial[3 * (size_t)l + r] = pb.points[3 * (size_t)l + r] + x;
-                sc += x * (lambda * x + pb.bl[3 * (size_t)l + r]);
+        for (int k = pb.fl_off[l]; k < pb.fl_off[l + 1]; ++k) {
+            double W[18];
+            load_d2<18>(pb.W + 18 * (size_t)k, W);
+            const double* x = (staged ? s_x : xp) + 6 * pb.fl_pose[k];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double xr = x[r];
+                d0 += W[3 * r] * xr;
+                d1 += W[3 * r + 1] * xr;
+                d2 += W[3 * r + 2] * xr;
             }
+        }
+        const double cl[3] = {pb.bl[3 * (size_t)l] - d0, pb.bl[3 * (size_t)l + 1] - d1, pb.bl[3 * (size_t)l + 2] - d2};
+        double Di[9], db_[3];
+        point_dinv(pb, l, lambda, Di, db_);  // the arithmetic of the Schur product's D^-1: the same bits
+        for (int r = 0; r < 3; ++r) {
+            const double x = Di[3 * r] * cl[0] + Di[3 * r + 1] * cl[1] + Di[3 * r + 2] * cl[2];
+            pb.points_trial[3 * (size_t)l + r] = pb.points[3 * (size_t)l + r] + x;
+            sc += x * (lambda * x + pb.bl[3 * (size_t)l + r]);
         }
     }
     block_sum_256(sc, s_sum, pb.scale_part + block);  // landmark part of computeScale, per workgroup
@@ -529,8 +637,8 @@ __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, 
 
 // One launch: workgroups [0, nbp) back-substitute the landmarks, the rest move the poses (exp(x_p) * T)
 __device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const int bx, int nbp, const double* __restrict__ xp, double lambda) {
-    __shared__ double s_sum[256];
-    if (bx < nbp) { backsub_body(pb, bx, xp, lambda, s_sum); return; }
+    __shared__ double s_sum[256], s_x[kBacksubMaxNp];
+    if (bx < nbp) { backsub_body(pb, bx, xp, lambda, s_sum, s_x); return; }
     const int k = (bx - nbp) * 256 + threadIdx.x;
     if (k >= pb.n_poses) return;
     const int i = pb.pose_var[k];
@@ -617,19 +725,18 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restr
 }
 __global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
-    const int nbp = blocks256(pb.n_points);
-    if ((int)blockIdx.x >= nbp + (pb.n_free_edges ? blocks256(pb.n_edges) : 0)) return;
-    d_ba_schur_prepare(pb, blockIdx.x, nbp, sl.lambda);
+    if (pb.sparse_schur || !pb.n_free_edges || (int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    d_ba_schur_prepare(pb, blockIdx.x, sl.lambda);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= pb.n_free) return;
+    if (pb.sparse_schur || (int)blockIdx.x >= pb.n_free) return;
     d_ba_reduce_coef(pb, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(z);
     const int tiles = pb.np_pad / 16;
-    if (!pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
+    if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
     d_ba_schur_gemm(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
 // One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each with its own L2): the
@@ -644,8 +751,20 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __res
     const BaBatchSlot& sl = slots[active[window]];
     const BaProblemDev pb = sl.pb;
     const int tiles = pb.np_pad / 16;
-    if (!pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
+    if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    extern __shared__ double s_schur[];
+    TC2LI_SLOT(y);
+    if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_sparse<4>(pb, blockIdx.x, sl.lambda, s_schur);
+}
+__global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    extern __shared__ double s_schur[];
+    TC2LI_SLOT(y);
+    if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_sparse<9>(pb, blockIdx.x, sl.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -685,18 +804,25 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
+static inline size_t schur_lds_bytes(int np_pad) { return 2 * (size_t)kSchurRows * schur_ldw(np_pad) * sizeof(double); }
+
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
-    const int nbp = blocks(pb.n_points);
-    TC2LI_LAUNCH(k_ba_schur_prepare, dim3(nbp + (pb.n_free_edges ? blocks(pb.n_edges) : 0)), dim3(256), 0, st, pb, nbp, lambda);
-    if (pb.n_free) {  // a free pose may carry no visual edge when the LiDAR window brings it in
+    if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
+    const int np = 6 * pb.n_free;
+    if (pb.sparse_schur) {
+        if (n_slices) {
+            if (pb.np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
+            else TC2LI_LAUNCH(k_ba_schur_sparse9, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
+        }
+    } else {
+        if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, lambda);
         TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
         const int tiles = pb.np_pad / 16, strips = (tiles + 1) / 2;
         if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_strip<5>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
         else TC2LI_LAUNCH(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
-        const int np = 6 * pb.n_free;
-        TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
     }
+    TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
 }
 
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
@@ -717,15 +843,21 @@ void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int 
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
-    if (!n_active) return;
-    TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_points) + (x.max_free_edges ? blocks(x.max_edges) : 0), n_active), dim3(256), 0, st, slots, active);
-    if (!x.max_free) return;
-    TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
-    const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
-    const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
-    if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-    else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-    else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    if (!n_active || !x.max_free) return;
+    if (x.max_sparse_slices) {
+        const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
+        if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, slots, active);
+        else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, slots, active);
+    }
+    if (x.any_dense) {
+        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+        TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
+        const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
+        const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
+        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
+        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
+        else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+    }
     TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
