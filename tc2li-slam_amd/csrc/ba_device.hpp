@@ -13,9 +13,10 @@ namespace tc2li {
 // pt_* is a CSR of the edges of each landmark, pv_* a CSR of the edges of each free pose (n_free_edges in total).
 // Per-edge records of the linearisation are padded to whole 16-byte pieces (9 -> 10 and 27 -> 28 doubles) so that they are written
 // and read as double2: the kernels' many pointers may alias as far as the compiler knows, and scalar stores stay scalar.
-constexpr int kContribL = 10, kContribP = 28;
+constexpr int kContribP = 28;
 struct BaProblemDev {
     int32_t n_edges, n_points, n_poses, n_free, n_free_edges, np_pad;
+    int32_t n_groups, pad3_;  // workgroups of the linearisation: whole landmarks, at most 256 edges each (grp_k0 into pt_edges, grp_l0)
     CameraD cam;
     double delta_mono, delta_stereo;
     float dsqr_mono, dsqr_stereo;
@@ -26,24 +27,26 @@ struct BaProblemDev {
     ImuCalib calib;
     double *points, *points_trial;
     const BaEdge* edges;
-    const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges;
+    const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges, *grp_k0, *grp_l0;
     // the edges with a free pose, landmark-major (the order of pt_edges restricted to them): fl_off CSR by landmark, fl_pose the free
     // pose of each, w_slot[e] the place of edge e among them (-1: fixed pose).  A landmark has at most one edge per pose.
     // fl_lm: the landmark of each; slice_off / fl_place: the sparse Schur kernel's cut into slices (<= 256 such edges of <= 64 landmarks
     // each) and the landmark's rank within its slice
-    const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off;
+    const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each
     // sparse_schur: the Schur complement is formed from the landmark-major W blocks (k_ba_schur_sparse; np_pad / 16 <= 8 tile rows),
     // one partial sum per slice; otherwise through the dense k-major operands AT / BT
     int32_t sparse_schur, pad2_;
     double *chi2, *rho0;
-    double *contrib_l, *contrib_p, *W;   // per edge: 9, 27 doubles; per edge with a free pose (at w_slot): 18
+    double *cp_part, *W;                 // per (block of 256 free-pose edges, free pose): 27 (+1) doubles; per free-pose edge (at w_slot): 18
+    const int32_t* blk_off;              // per block: n_free + 1 offsets into its rows sorted by pose
+    const uint8_t* blk_rows;             // per block: 256 row numbers
     double *Hll, *bl, *diag_l;           // per landmark: 6, 3, 1
     double *Hpp, *diag_p;                // per free pose: 27 (21 packed upper + 6 b), 1
     double *coef_e, *coef;               // per edge 6, per free pose 6
     double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands (dense path only)
     double *S_part;                      // [n_slices][np_pad * np_pad]; sparse path: row 6 n_free holds W D^-1 b_l
     double *scale_part;                  // per 256 landmarks: partial sums of the gain-ratio scale
-    double *chi_part;                    // per 256 edges: partial sums of the robust cost
+    double *chi_part;                    // partial sums of the robust cost: per linearisation group / per 256 edges of a trial
 };
 
 // chi_out[0] = robust cost; maxdiag_out[0..1] = largest |diagonal| of the landmark / pose blocks when want_maxdiag
@@ -67,7 +70,7 @@ struct BaBatchSlot {
     BalmDev balm;
 };
 struct BaBatchExtent {
-    int max_edges, max_points, max_poses, max_free, max_free_edges, max_np_pad, max_slices, max_planes, max_chunks, max_W;
+    int max_edges, max_points, max_poses, max_free, max_free_edges, max_groups, max_np_pad, max_slices, max_planes, max_chunks, max_W;
     // max_np_pad / max_slices: over the windows on the dense Schur path; the sparse ones:
     int any_dense, max_sparse_np_pad, max_sparse_slices;
 };

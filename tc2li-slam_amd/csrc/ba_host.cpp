@@ -34,7 +34,7 @@ PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
 
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
-    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cl, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
+    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
         d_coef_e, d_coef, d_AT, d_Spart, d_scale_part, d_chi_part, d_red;
     // the window as the caller hands it over -- poses, points, edges and the index arrays -- goes up in ONE copy: a stream operation
     // costs about as much as one of the loop's kernels, and a batch has one such set per window
@@ -96,7 +96,7 @@ struct VisualProblem {
     // the edges with a free pose in landmark-major order: where the W blocks live (the Schur product and the back substitution walk
     // them by landmark)
     std::vector<int> fl_off(n_points + 1, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
-        w_slot(n_edges, -1), slice_off(1, 0);
+        fl_edge(std::max(n_free_edges, 1)), w_slot(n_edges, -1), slice_off(1, 0);
     {
         // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
         // the window alone, so that a window gives the same bits alone and in a batch
@@ -111,7 +111,7 @@ struct VisualProblem {
                 // g2o would add the two edges' Hpl blocks; the operands here hold one block per (landmark, pose)
                 if (seen[i] == l) { set_error("point %d has two edges to pose %d", l, edges[e].pose); return TC2LI_ERR_INVALID; }
                 seen[i] = l;
-                w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; ++at;
+                w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; fl_edge[at] = e; ++at;
             }
             fl_off[l + 1] = at;
             if (at == begin) continue;
@@ -121,6 +121,26 @@ struct VisualProblem {
         }
         if (at > slice_off.back()) slice_off.push_back(at);
     }
+    // blocks of 256 free-pose edges (the pose role of the linearisation): the block's rows sorted by pose, for the per-pose sums
+    const int n_blocks = (n_free_edges + 255) / 256;
+    std::vector<int> blk_off((size_t)std::max(n_blocks, 1) * (n_free + 1), 0);
+    std::vector<uint8_t> blk_rows((size_t)std::max(n_blocks, 1) * 256, 0);
+    for (int b = 0; b < n_blocks; ++b) {
+        int* off = blk_off.data() + (size_t)b * (n_free + 1);
+        const int s0 = 256 * b, s1 = std::min(n_free_edges, s0 + 256);
+        for (int s = s0; s < s1; ++s) off[fl_pose[s] + 1]++;
+        for (int i = 0; i < n_free; ++i) off[i + 1] += off[i];
+        std::vector<int> fill(off, off + n_free);
+        for (int s = s0; s < s1; ++s) blk_rows[(size_t)b * 256 + fill[fl_pose[s]]++] = (uint8_t)(s - s0);
+    }
+    // groups of the linearisation: whole landmarks, at most 256 edges (one per thread)
+    std::vector<int> grp_k0(1, 0), grp_l0(1, 0);
+    for (int l = 0; l < n_points; ++l) {
+        if (pt_off[l + 1] - pt_off[l] > 256) { set_error("point %d has more than 256 edges", l); return TC2LI_ERR_INVALID; }
+        if (pt_off[l + 1] - grp_k0.back() > 256) { grp_k0.push_back(pt_off[l]); grp_l0.push_back(l); }
+    }
+    grp_k0.push_back(n_edges); grp_l0.push_back(n_points);
+    const int n_groups = (int)grp_k0.size() - 1;
     np = 6 * n_free;
     // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
     const bool sparse = (np + 1 + 15) / 16 <= 8;
@@ -136,7 +156,7 @@ struct VisualProblem {
 
     // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
     auto& d_poses_trial = ws.d_poses_trial;
-    auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0, &d_cl = ws.d_cl,
+    auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
          &d_diag_p = ws.d_diag_p, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
          &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
@@ -146,17 +166,17 @@ struct VisualProblem {
     const size_t at_elems = sparse ? 0 : (size_t)(k_per_slice * n_slices + 4) * np_pad;
     TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
     TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
-    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cl.ensure(kContribL * E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * E));
+    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * (size_t)std::max(n_blocks * n_free, 1)));
     TC2LI_HIP_CHECK(d_W.ensure(18 * (size_t)std::max(n_free_edges, 1))); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
     TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
     if (!sparse) TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
     TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
     if (!sparse) TC2LI_HIP_CHECK(d_AT.ensure(2 * at_elems));  // A^T and B^T operands back to back: one fill
-    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)std::max(n_slices, 1) * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 256 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(E / 256 + 1));
+    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)std::max(n_slices, 1) * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 256 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(std::max(E / 256 + 1, (size_t)n_groups)));
     TC2LI_HIP_CHECK(d_depth.ensure(E));
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
-    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off], every
+    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows], every
     // part 16-byte aligned ----
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
@@ -165,7 +185,10 @@ struct VisualProblem {
                  o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + pv_edges.size() * sizeof(int)),
                  o_fl_pose = align16(o_fl_off + (P + 1) * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
                  o_fl_lm = align16(o_w_slot + E * sizeof(int)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
-                 o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), in_bytes = align16(o_slice_off + slice_off.size() * sizeof(int));
+                 o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
+                 o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
+                 o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
+                 in_bytes = align16(o_blk_rows + blk_rows.size());
     TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
     uint8_t* const h = ws.h_in.p;
     if (poses7) {
@@ -186,6 +209,11 @@ struct VisualProblem {
     memcpy(h + o_fl_lm, fl_lm.data(), fl_lm.size() * sizeof(int));
     memcpy(h + o_fl_place, fl_place.data(), fl_place.size() * sizeof(int));
     memcpy(h + o_slice_off, slice_off.data(), slice_off.size() * sizeof(int));
+    memcpy(h + o_fl_edge, fl_edge.data(), fl_edge.size() * sizeof(int));
+    memcpy(h + o_grp_k0, grp_k0.data(), grp_k0.size() * sizeof(int));
+    memcpy(h + o_grp_l0, grp_l0.data(), grp_l0.size() * sizeof(int));
+    memcpy(h + o_blk_off, blk_off.data(), blk_off.size() * sizeof(int));
+    memcpy(h + o_blk_rows, blk_rows.data(), blk_rows.size());
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
     TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
@@ -202,9 +230,11 @@ struct VisualProblem {
     pb.edges = (const BaEdge*)(d + o_edges); pb.pose_var = (const int*)(d + o_pose_var); pb.pt_off = (const int*)(d + o_pt_off);
     pb.pt_edges = (const int*)(d + o_pt_edges); pb.pv_off = (const int*)(d + o_pv_off); pb.pv_edges = (const int*)(d + o_pv_edges);
     pb.fl_off = (const int*)(d + o_fl_off); pb.fl_pose = (const int*)(d + o_fl_pose); pb.w_slot = (const int*)(d + o_w_slot);
-    pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off);
+    pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off); pb.fl_edge = (const int*)(d + o_fl_edge);
+    pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
+    pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
     pb.sparse_schur = sparse ? 1 : 0;
-    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.contrib_l = d_cl.p; pb.contrib_p = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
+    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
     pb.AT = d_AT.p; pb.BT = d_AT.p + at_elems; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
@@ -1093,7 +1123,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         if (W[i].rc < 0) continue;
         const BaProblemDev& pb = W[i].vp.pb;
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
-        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges);
+        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
         if (pb.sparse_schur) {
             X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
         } else {

@@ -64,20 +64,29 @@ __device__ __forceinline__ void block_sum_256(double v, double* s, double* __res
     if (threadIdx.x == 0) out[0] = s[0];
 }
 
-__device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int bx) {
-    __shared__ double s_sum[256];
-    const int e = bx * 256 + threadIdx.x;
-    double rho0 = 0;
-    if (e < pb.n_edges) {
+// Workgroups [0, nbe): every edge -- error, Huber weight, robust cost and the landmark block A^T W A, A^T omega_r.  Workgroups from
+// nbe on: the edges with a free pose in landmark-major order (fl_edge) -- the pose block B^T W B, B^T omega_r and W = B^T W A.  Two
+// roles instead of one thread doing both: four edges in ten have a free pose, and the pose part (most of the arithmetic and of the
+// bytes) ran with that share of its lanes; its W blocks now leave in slot order.  The error and the weight are simply formed again.
+__device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, const int bx) {
+    __shared__ double s_cp[256 * 9];
+    __shared__ uint8_t s_rows[256];
+    const int s = bx * 256 + threadIdx.x;
+    const bool valid = s < pb.n_free_edges;
+    // the per-pose sums below: the block's rows sorted by pose and this thread's range of them, requested with the edge's own loads
+    const int* off = pb.blk_off + (size_t)bx * (pb.n_free + 1);
+    s_rows[threadIdx.x] = pb.blk_rows[(size_t)bx * 256 + threadIdx.x];
+    int my_r0 = 0, my_r1 = 0;
+    if ((int)threadIdx.x < 9 * pb.n_free) { my_r0 = off[threadIdx.x / 9]; my_r1 = off[threadIdx.x / 9 + 1]; }
+    double cp[kContribP];
+    if (valid) {
+        const int e = pb.fl_edge[s];
         const BaEdge ed = pb.edges[e];
-        double p[3], err[3], c2;
+        double p[3], err[3], c2, rho0, rho1;
         int dim;
         edge_state(pb, false, ed, p, err, dim, c2);
         const bool stereo = ed.ur >= 0;
-        double rho1;
         huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
-        pb.chi2[e] = c2;
-        pb.rho0[e] = rho0;
         double A[9], B[18];
         if (pb.inertial) {
             imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
@@ -93,81 +102,124 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
         for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
         // The row sums run over all three rows with compile-time indices (everything stays in registers); the third row of
         // A and B is zero for a monocular edge, so its terms add exact zeros.
-        // landmark block: A^T W A (upper 6) and A^T omega_r
-        double cl[kContribL];
-        cl[9] = 0;
-        {
-            int h = 0;
+        cp[27] = 0;
+        int h = 0;
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = r; c < 3; ++c) {
-                    double s = 0;
+            for (int c = r; c < 6; ++c) {
+                double sum = 0;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) s += A[3 * d + r] * w * A[3 * d + c];
-                    cl[h++] = s;
-                }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                double s = 0;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) s += A[3 * d + r] * wr[d];
-                cl[6 + r] = s;
+                for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * B[6 * d + c];
+                cp[h++] = sum;
             }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double sum = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * wr[d];
+            cp[21 + r] = sum;
         }
-        store_d2<kContribL>(pb.contrib_l + kContribL * (size_t)e, cl);
-        if (pb.pose_var[ed.pose] >= 0) {
-            double cp[kContribP];
-            cp[27] = 0;
-            int h = 0;
+        double W[18];  // Hpl block: B^T W A (6 x 3)
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = r; c < 6; ++c) {
-                    double s = 0;
+            for (int c = 0; c < 3; ++c) {
+                double sum = 0;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * B[6 * d + c];
-                    cp[h++] = s;
-                }
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double s = 0;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) s += B[6 * d + r] * wr[d];
-                cp[21 + r] = s;
+                for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * A[3 * d + c];
+                W[3 * r + c] = sum;
             }
-            double W[18];  // Hpl block: B^T W A (6 x 3)
+        store_d2<18>(pb.W + 18 * (size_t)s, W);
+    }
+    // The pose blocks of the workgroup's 256 edges, added per pose in slot order (blk_rows: the block's rows sorted by pose, blk_off
+    // the poses' ranges; nine of the 27 values at a time through LDS): what leaves the kernel is one 27-vector per (block, pose)
+    // instead of one per edge (224 B written here and read back by the reduction).
+    const int nf = pb.n_free;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+    for (int c0 = 0; c0 < 27; c0 += 9) {
+        if (valid) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double s = 0;
+            for (int j = 0; j < 9; ++j) s_cp[9 * threadIdx.x + j] = cp[c0 + j];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 9 * nf; t += 256) {
+            const int i = t / 9, c = t - 9 * i;
+            const int r0 = t < 256 ? my_r0 : off[i], r1 = t < 256 ? my_r1 : off[i + 1];
+            double acc = 0;
+            for (int r = r0; r < r1; ++r) acc += s_cp[9 * s_rows[r] + c];
+            pb.cp_part[((size_t)bx * nf + i) * kContribP + c0 + c] = acc;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int g) {
+    __shared__ double s_sum[256];
+    __shared__ double s_cl[256 * 9];
+    const int k0 = pb.grp_k0[g], k1 = pb.grp_k0[g + 1], l0 = pb.grp_l0[g], l1 = pb.grp_l0[g + 1];
+    const int k = k0 + (int)threadIdx.x;
+    double rho0 = 0;
+    if (k < k1) {
+        const int e = pb.pt_edges[k];
+        const BaEdge ed = pb.edges[e];
+        double p[3], err[3], c2;
+        int dim;
+        edge_state(pb, false, ed, p, err, dim, c2);
+        const bool stereo = ed.ur >= 0;
+        double rho1;
+        huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
+        pb.chi2[e] = c2;
+        pb.rho0[e] = rho0;
+        double A[9];
+        if (pb.inertial) {
+            double B[18];
+            imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
+        } else {
+            double R[9];
+            quat_to_matrix(pb.poses[ed.pose].q, R);
+            point_jacobian(p, R, stereo, pb.cam, A);
+        }
+        const double w = rho1 * ed.info;
+        double wr[3];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) s += B[6 * d + r] * w * A[3 * d + c];
-                    W[3 * r + c] = s;
-                }
-            store_d2<kContribP>(pb.contrib_p + kContribP * (size_t)e, cp);
-            store_d2<18>(pb.W + 18 * (size_t)pb.w_slot[e], W);
+        for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
+        // landmark block: A^T W A (upper 6) and A^T omega_r; the row sums run over all three rows with compile-time indices (the third row
+        // of A is zero for a monocular edge, so its terms add exact zeros)
+        double* cl = s_cl + 9 * threadIdx.x;
+        int h = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = r; c < 3; ++c) {
+                double sum = 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) sum += A[3 * d + r] * w * A[3 * d + c];
+                cl[h++] = sum;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double sum = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sum += A[3 * d + r] * wr[d];
+            cl[6 + r] = sum;
         }
     }
-    block_sum_256(rho0, s_sum, pb.chi_part + bx);  // the robust cost is summed per workgroup here, finished in the next launch
+    __syncthreads();
+    const int l = l0 + (int)threadIdx.x;
+    if (l < l1) {
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = pb.pt_off[l] - k0; j < pb.pt_off[l + 1] - k0; ++j) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += s_cl[9 * j + i];
+        }
+        for (int i = 0; i < 6; ++i) pb.Hll[6 * (size_t)l + i] = acc[i];
+        for (int i = 0; i < 3; ++i) pb.bl[3 * (size_t)l + i] = acc[6 + i];
+        pb.diag_l[l] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+    block_sum_256(rho0, s_sum, pb.chi_part + g);  // the robust cost is summed per workgroup here, finished in the next launch
 }
 __global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) { d_ba_linearize(pb, blockIdx.x); }
-
-__device__ __forceinline__ void reduce_points_body(const BaProblemDev& pb, int block) {
-    const int l = block * 256 + threadIdx.x;
-    if (l >= pb.n_points) return;
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = pb.pt_off[l]; k < pb.pt_off[l + 1]; ++k) {
-        double c[kContribL];
-        load_d2<kContribL>(pb.contrib_l + kContribL * (size_t)pb.pt_edges[k], c);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) acc[i] += c[i];
-    }
-    for (int i = 0; i < 6; ++i) pb.Hll[6 * (size_t)l + i] = acc[i];
-    for (int i = 0; i < 3; ++i) pb.bl[3 * (size_t)l + i] = acc[6 + i];
-    pb.diag_l[l] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
-}
+__global__ __launch_bounds__(256) void k_ba_linearize_pose(BaProblemDev pb) { d_ba_linearize_pose(pb, blockIdx.x); }
 
 // Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.  The tree is the one a 256-entry
 // LDS array would be folded with (t += t + 128, t += t + 64, ... , t += t + 1), so the bits do not depend on how it is carried out:
@@ -225,8 +277,22 @@ __device__ __forceinline__ void block_sum_items(const double* __restrict__ items
     __syncthreads();
 }
 
+// Hpp, b_p of free pose i: the blocks' partial sums, eight interleaved series of blocks (lanes 32 q + c take the blocks q, q + 8, ...)
+// added in series order
 __device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i /* free pose */, double* s_part) {
-    block_sum_items<27, kContribP>(pb.contrib_p, pb.pv_edges, pb.pv_off[i], pb.pv_off[i + 1], s_part, pb.Hpp + 27 * (size_t)i);
+    const int q = threadIdx.x >> 5, c = threadIdx.x & 31, nb = (pb.n_free_edges + 255) / 256;
+    double acc = 0;
+    if (c < 27)
+        for (int b = q; b < nb; b += 8) acc += pb.cp_part[((size_t)b * pb.n_free + i) * kContribP + c];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double sum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += s_part[32 * u + threadIdx.x];
+        pb.Hpp[27 * (size_t)i + threadIdx.x] = sum;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const double* h = pb.Hpp + 27 * (size_t)i;
         // diagonal entries of the packed upper triangle: 0, 6, 11, 15, 18, 20
@@ -249,16 +315,13 @@ __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, 
     __syncthreads();
 }
 
-// One launch after k_ba_linearize: workgroups [0, nbp) sum the landmark blocks, [nbp, nbp + n_free) the pose blocks, the
-// last one the robust cost (the three jobs only read what the linearisation wrote).
-__device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, int nbp, double* __restrict__ chi_out) {
+// One launch after the linearisation: workgroups [0, n_free) sum the pose blocks, the last one the robust cost
+__device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, double* __restrict__ chi_out) {
     __shared__ double s_part[128 * kSumChunk];  // block_sum_items' two cross-wavefront folds (also >= the 256 of block_reduce_256)
-    const int b = bx;
-    if (b < nbp) reduce_points_body(pb, b);
-    else if (b < nbp + pb.n_free) reduce_poses_body(pb, b - nbp, s_part);
-    else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s_part, chi_out);
+    if (bx < pb.n_free) reduce_poses_body(pb, bx, s_part);
+    else block_reduce_256<false>(pb.chi_part, pb.n_groups, s_part, chi_out);
 }
-__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, int nbp, double* __restrict__ chi_out) { d_ba_reduce_all(pb, blockIdx.x, nbp, chi_out); }
+__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, double* __restrict__ chi_out) { d_ba_reduce_all(pb, blockIdx.x, chi_out); }
 
 // computeLambdaInit needs the largest diagonal entries: [0] landmarks, [1] poses (first iteration only)
 __device__ __forceinline__ void d_ba_maxdiag(const BaProblemDev& pb, const int bx, double* __restrict__ out) {
@@ -709,14 +772,18 @@ static inline __device__ int blocks256(int n) { return (n + 255) / 256; }
 
 __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    if ((int)blockIdx.x >= pb.n_groups) return;
     d_ba_linearize(pb, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void k_ba_linearize_pose_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= blocks256(pb.n_free_edges)) return;
+    d_ba_linearize_pose(pb, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
-    const int nbp = blocks256(pb.n_points);
-    if ((int)blockIdx.x >= nbp + pb.n_free + 1) return;
-    d_ba_reduce_all(pb, blockIdx.x, nbp, sl.chi_out);
+    if ((int)blockIdx.x >= pb.n_free + 1) return;
+    d_ba_reduce_all(pb, blockIdx.x, sl.chi_out);
 }
 __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -798,9 +865,9 @@ __global__ __launch_bounds__(256) void k_ba_depth_b(const BaBatchSlot* __restric
 static inline int blocks(int n) { return (n + 255) / 256; }
 
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st) {
-    const int nbp = blocks(pb.n_points);
-    TC2LI_LAUNCH(k_ba_linearize, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
-    TC2LI_LAUNCH(k_ba_reduce_all, dim3(nbp + pb.n_free + 1), dim3(256), 0, st, pb, nbp, chi_out);
+    TC2LI_LAUNCH(k_ba_linearize, dim3(pb.n_groups), dim3(256), 0, st, pb);
+    if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
+    TC2LI_LAUNCH(k_ba_reduce_all, dim3(pb.n_free + 1), dim3(256), 0, st, pb, chi_out);
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
@@ -838,8 +905,9 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    TC2LI_LAUNCH(k_ba_linearize_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
-    TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(blocks(x.max_points) + x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups, n_active), dim3(256), 0, st, slots, active);
+    if (x.max_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
 }
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {

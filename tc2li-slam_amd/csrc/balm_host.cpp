@@ -401,8 +401,10 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     n_planes = (int)coe.size();
     dev = BalmDev{};
     dev.W = W; dev.n_planes = n_planes;
-    dev.n_chunks = std::max(1, std::min(n_planes, 1024));
-    dev.planes_per_chunk = n_planes ? (n_planes + dev.n_chunks - 1) / dev.n_chunks : 0;
+    // a workgroup of the Hessian kernel takes whole batches of planes (8 for windows of <= 7 keyframes, else 4: balm_kernels.hip), at
+    // most 1024 workgroups; a function of the window alone (the partial sums' grouping decides the bits)
+    const int plane_batch = W <= 7 ? 8 : 4;
+    dev.planes_per_chunk = plane_batch * std::max(1, (n_planes + plane_batch * 1024 - 1) / (plane_batch * 1024));
     dev.n_chunks = n_planes ? (n_planes + dev.planes_per_chunk - 1) / dev.planes_per_chunk : 1;
     dev.Tcl = Tcl;
     TC2LI_HIP_CHECK(d_clusters.ensure(std::max(clusters.size(), (size_t)1)));

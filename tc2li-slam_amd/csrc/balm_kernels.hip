@@ -103,12 +103,16 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
     sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
 }
 
-template <int kItemsPerThread, int NT>
+// PB planes at a time: lane (p, i) = (tid / SL, tid % SL) does the per-slot algebra of plane p, slot i -- the long dependent chain of
+// the kernel, which one plane alone runs on W of the workgroup's lanes -- then every lane adds the PB planes' terms to the Hessian
+// entries it owns, in plane order (the sums are those of a plane-after-plane loop, bit for bit).  WC: slots the LDS tables hold.
+template <int kItemsPerThread, int NT, int PB, int SL, int WC>
 __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx) {
+    static_assert(PB * SL <= NT && WC <= SL, "lane layout");
     __shared__ LidarPose s_twl[kMaxLidarWindow];
-    __shared__ double s_A[kMaxLidarWindow][18], s_MB[kMaxLidarWindow][18];  // Auk (3 x 6) and umumT * Auk
-    __shared__ double s_w[kMaxLidarWindow][3], s_E[kMaxLidarWindow][9], s_k1[kMaxLidarWindow], s_k2[kMaxLidarWindow], s_n[kMaxLidarWindow];
-    __shared__ double s_uk[3], s_ukuk[9], s_umum[9], s_vbar[3], s_NN, s_l0;
+    __shared__ double s_A[PB][WC][18], s_MB[PB][WC][18];  // Auk (3 x 6) and umumT * Auk
+    __shared__ double s_w[PB][WC][3], s_E[PB][WC][9], s_k1[PB][WC], s_k2[PB][WC], s_n[PB][WC], s_cj[PB][WC][6];
+    __shared__ double s_uk[PB][3], s_ukuk[PB][9], s_umum[PB][9], s_vbar[PB][3], s_NN[PB], s_l0[PB], s_coe[PB];
     __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
     window_poses(b, poses, s_twl);
@@ -122,40 +126,43 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) acc[k] = 0;
     const int a0 = bx * b.planes_per_chunk, a1 = min(a0 + b.planes_per_chunk, b.n_planes);
-    for (int a = a0; a < a1; ++a) {
-        const double coe = b.coe[a];
+    const int lp = tid / SL, li = tid % SL;  // this lane's plane of the batch and slot
+    for (int ab = a0; ab < a1; ab += PB) {
+        const int a = ab + lp;
+        const bool slot_lane = lp < PB && li < W && a < a1;
         PlaneCluster mine;
         mine.n = 0;
-        if (tid < W) {
-            mine = b.clusters[(size_t)a * W + tid];
-            s_n[tid] = mine.n;
-        }
-        if (tid == 0) {
-            // merged cluster -> covariance -> eigen decomposition: taken from the residual pass at these poses (plane_residual; the
-            // host launches it right before, see BalmTerm::enqueue_linearization), there is no second copy of that arithmetic
-            const double* ei = b.eig + (size_t)kBalmEig * a;
-            const double NN = ei[0];
-            const double vbar[3] = {ei[1], ei[2], ei[3]}, lambda[3] = {ei[4], ei[5], ei[6]};
-            const double* U = ei + 7;
-            const double u0[3] = {U[0], U[3], U[6]};
-            for (int k = 0; k < 3; ++k) { s_uk[k] = u0[k]; s_vbar[k] = vbar[k]; }
-            for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) {
-                    s_ukuk[3 * r + c] = u0[r] * u0[c];
-                    double m = 0;
-                    for (int e = 1; e < 3; ++e) m = m + (2.0 / (lambda[0] - lambda[e])) * (U[3 * r + e] * U[3 * c + e]);
-                    s_umum[3 * r + c] = m;
-                }
-            s_NN = NN;
-            s_l0 = lambda[0];
+        if (slot_lane) mine = b.clusters[(size_t)a * W + li];
+        if (lp < PB && li < W) s_n[lp][li] = mine.n;  // zero for the planes past the chunk's end: their terms drop out below
+        if (lp < PB && li == 0) {
+            s_coe[lp] = 0;
+            if (a < a1) {
+                // merged cluster -> covariance -> eigen decomposition: taken from the residual pass at these poses (plane_residual; the
+                // host launches it right before, see BalmTerm::enqueue_linearization), there is no second copy of that arithmetic
+                const double* ei = b.eig + (size_t)kBalmEig * a;
+                const double NN = ei[0];
+                const double vbar[3] = {ei[1], ei[2], ei[3]}, lambda[3] = {ei[4], ei[5], ei[6]};
+                const double* U = ei + 7;
+                const double u0[3] = {U[0], U[3], U[6]};
+                for (int k = 0; k < 3; ++k) { s_uk[lp][k] = u0[k]; s_vbar[lp][k] = vbar[k]; }
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) {
+                        s_ukuk[lp][3 * r + c] = u0[r] * u0[c];
+                        double m = 0;
+                        for (int e = 1; e < 3; ++e) m = m + (2.0 / (lambda[0] - lambda[e])) * (U[3 * r + e] * U[3 * c + e]);
+                        s_umum[lp][3 * r + c] = m;
+                    }
+                s_NN[lp] = NN;
+                s_l0[lp] = lambda[0];
+                s_coe[lp] = b.coe[a];
+            }
         }
         __syncthreads();
-        const double NN = s_NN;
-        if (tid == 0) res += coe * s_l0;
-        if (tid < W && mine.n != 0) {
-            const LidarPose T = s_twl[tid];
+        if (slot_lane && mine.n != 0) {
+            const double NN = s_NN[lp], coe = s_coe[lp];
+            const LidarPose T = s_twl[li];
             const double ni = mine.n;
-            double Pi[9], uk[3] = {s_uk[0], s_uk[1], s_uk[2]};
+            double Pi[9], uk[3] = {s_uk[lp][0], s_uk[lp][1], s_uk[lp][2]};
             sym_unpack(mine.P, Pi);
             const double* vi = mine.v;
             double vihat[9], RiTuk[3], RiTukhat[9], PiRiTuk[3], w[3], tv[3];
@@ -164,7 +171,7 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
             m3_hat(RiTuk, RiTukhat);
             m3_vec(Pi, RiTuk, PiRiTuk);
             m3_vec(vihat, RiTuk, w);
-            for (int k = 0; k < 3; ++k) tv[k] = T.p[k] - s_vbar[k];
+            for (int k = 0; k < 3; ++k) tv[k] = T.p[k] - s_vbar[lp][k];
             const double ukt = uk[0] * tv[0] + uk[1] * tv[1] + uk[2] * tv[2];
             double combo1[9], h[9], combo2[3], Rv[3];
             m3_hat(PiRiTuk, h);
@@ -188,12 +195,12 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
             double jjt[6];
             for (int c = 0; c < 6; ++c) {
                 jjt[c] = A[c] * uk[0] + A[6 + c] * uk[1] + A[12 + c] * uk[2];
-                jac[c] += coe * jjt[c];
+                s_cj[lp][li][c] = coe * jjt[c];
             }
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 6; ++c) {
-                    s_A[tid][6 * r + c] = A[6 * r + c];
-                    s_MB[tid][6 * r + c] = s_umum[3 * r] * A[c] + s_umum[3 * r + 1] * A[6 + c] + s_umum[3 * r + 2] * A[12 + c];
+                    s_A[lp][li][6 * r + c] = A[6 * r + c];
+                    s_MB[lp][li][6 * r + c] = s_umum[lp][3 * r] * A[c] + s_umum[lp][3 * r + 1] * A[6 + c] + s_umum[lp][3 * r + 2] * A[12 + c];
                 }
             // extra terms of the diagonal block: rotation-rotation part
             double d1[9], d2[9], RhP[9], jh[9];
@@ -203,33 +210,43 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
             m3_hat(jjt, jh);
             for (int r = 0; r < 3; ++r)
                 for (int c = 0; c < 3; ++c)
-                    s_E[tid][3 * r + c] = (2.0 / NN) * d2[3 * r + c] + (-2.0 / NN / NN) * (w[r] * w[c]) + (-0.5) * jh[3 * r + c];
-            for (int k = 0; k < 3; ++k) s_w[tid][k] = w[k];
-            s_k1[tid] = 2.0 / NN * (1.0 - ni / NN);
-            s_k2[tid] = 2.0 / NN * (ni - ni * ni / NN);
+                    s_E[lp][li][3 * r + c] = (2.0 / NN) * d2[3 * r + c] + (-2.0 / NN / NN) * (w[r] * w[c]) + (-0.5) * jh[3 * r + c];
+            for (int k = 0; k < 3; ++k) s_w[lp][li][k] = w[k];
+            s_k1[lp][li] = 2.0 / NN * (1.0 - ni / NN);
+            s_k2[lp][li] = 2.0 / NN * (ni - ni * ni / NN);
         }
         __syncthreads();
+        const int np_ = min(PB, a1 - ab);
+        if (tid == 0)
+            for (int p = 0; p < np_; ++p) res += s_coe[p] * s_l0[p];
+        if (tid < W)
+            for (int p = 0; p < np_; ++p)
+                if (s_n[p][tid] != 0)
+                    for (int c = 0; c < 6; ++c) jac[c] += s_cj[p][tid][c];
 #pragma unroll
         for (int k = 0; k < kItemsPerThread; ++k) {
             const int item = k * NT + tid;
             if (item >= n_items) continue;
             const int pair = item / 36, rc = item % 36, r = rc / 6, c = rc % 6;
             const int i = s_pi[pair], j = s_pj[pair];
-            const double ni = s_n[i], nj = s_n[j];
-            if (ni == 0 || nj == 0) continue;
-            double val = s_A[i][r] * s_MB[j][c] + s_A[i][6 + r] * s_MB[j][6 + c] + s_A[i][12 + r] * s_MB[j][12 + c];
-            if (i == j) {
-                if (r < 3 && c < 3) val += s_E[i][3 * r + c];
-                else if (r < 3) val += s_k1[i] * (s_w[i][r] * s_uk[c - 3]);
-                else if (c < 3) val += s_k1[i] * (s_w[i][c] * s_uk[r - 3]);
-                else val += s_k2[i] * s_ukuk[3 * (r - 3) + (c - 3)];
-            } else {
-                if (r < 3 && c < 3) val += (-2.0 / NN / NN) * (s_w[i][r] * s_w[j][c]);
-                else if (r < 3) val += (-2.0 * nj / NN / NN) * (s_w[i][r] * s_uk[c - 3]);
-                else if (c < 3) val += (-2.0 * ni / NN / NN) * (s_uk[r - 3] * s_w[j][c]);
-                else val += (-2.0 * ni * nj / NN / NN) * s_ukuk[3 * (r - 3) + (c - 3)];
+            for (int p = 0; p < np_; ++p) {
+                const double ni = s_n[p][i], nj = s_n[p][j];
+                if (ni == 0 || nj == 0) continue;
+                const double NN = s_NN[p];
+                double val = s_A[p][i][r] * s_MB[p][j][c] + s_A[p][i][6 + r] * s_MB[p][j][6 + c] + s_A[p][i][12 + r] * s_MB[p][j][12 + c];
+                if (i == j) {
+                    if (r < 3 && c < 3) val += s_E[p][i][3 * r + c];
+                    else if (r < 3) val += s_k1[p][i] * (s_w[p][i][r] * s_uk[p][c - 3]);
+                    else if (c < 3) val += s_k1[p][i] * (s_w[p][i][c] * s_uk[p][r - 3]);
+                    else val += s_k2[p][i] * s_ukuk[p][3 * (r - 3) + (c - 3)];
+                } else {
+                    if (r < 3 && c < 3) val += (-2.0 / NN / NN) * (s_w[p][i][r] * s_w[p][j][c]);
+                    else if (r < 3) val += (-2.0 * nj / NN / NN) * (s_w[p][i][r] * s_uk[p][c - 3]);
+                    else if (c < 3) val += (-2.0 * ni / NN / NN) * (s_uk[p][r - 3] * s_w[p][j][c]);
+                    else val += (-2.0 * ni * nj / NN / NN) * s_ukuk[p][3 * (r - 3) + (c - 3)];
+                }
+                acc[k] += s_coe[p] * val;
             }
-            acc[k] += coe * val;
         }
         __syncthreads();
     }
@@ -243,8 +260,14 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
         for (int c = 0; c < 6; ++c) part[n_items + 6 * tid + c] = jac[c];
     if (tid == 0) part[n_items + 6 * W] = res;
 }
-template <int kItemsPerThread, int NT>
-__global__ __launch_bounds__(NT) void k_balm_hessian(BalmDev b, const Se3* __restrict__ poses) { d_balm_hessian<kItemsPerThread, NT>(b, poses, blockIdx.x); }
+// small windows: one wavefront, 8 planes x 8 slots; large ones: 256 threads, 4 planes x 32 slots
+constexpr int kHessPlanesSmall = 8, kHessPlanesLarge = 4;
+__global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_small(BalmDev b, const Se3* __restrict__ poses) {
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, poses, blockIdx.x);
+}
+__global__ __launch_bounds__(kHessThreads) void k_balm_hessian_large(BalmDev b, const Se3* __restrict__ poses) {
+    d_balm_hessian<kItemsLarge, kHessThreads, kHessPlanesLarge, 32, kMaxLidarWindow>(b, poses, blockIdx.x);
+}
 
 // chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one
 // wavefront per output value, its lanes add the chunks in a fixed order (strided partial sums, then shuffles).
@@ -280,8 +303,8 @@ void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
 }
 
 void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
-    if (b.W <= 7) TC2LI_LAUNCH((k_balm_hessian<kItemsSmall, kHessThreadsSmall>), dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
-    else TC2LI_LAUNCH((k_balm_hessian<kItemsLarge, kHessThreads>), dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
+    if (b.W <= 7) TC2LI_LAUNCH(k_balm_hessian_small, dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
+    else TC2LI_LAUNCH(k_balm_hessian_large, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
     TC2LI_LAUNCH(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
 }
 
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBa
     const BaBatchSlot& sl = slots[list[blockIdx.y]];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= b.n_chunks) return;
-    d_balm_hessian<kItemsSmall, kHessThreadsSmall>(b, slot_poses(sl, false), blockIdx.x);
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(sl, false), blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
     const BaBatchSlot& sl = slots[list[blockIdx.y]];
