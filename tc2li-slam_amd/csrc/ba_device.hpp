@@ -28,10 +28,9 @@ struct BaProblemDev {
     double *points, *points_trial;
     const BaEdge* edges;
     const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges, *grp_k0, *grp_l0;
-    // the edges with a free pose, landmark-major (the order of pt_edges restricted to them): fl_off CSR by landmark, fl_pose the free
-    // pose of each, w_slot[e] the place of edge e among them (-1: fixed pose).  A landmark has at most one edge per pose.
-    // fl_lm: the landmark of each; slice_off / fl_place: the sparse Schur kernel's cut into slices (<= 256 such edges of <= 64 landmarks
-    // each) and the landmark's rank within its slice
+    // the edges with a free pose, landmark-major ("slots"; the landmarks in the order of the poses they are seen from, ba_host.cpp):
+    // fl_off[2 l], fl_off[2 l + 1] = begin / end of landmark l's slots, fl_pose the free pose of each slot, w_slot[e] the slot of edge e
+    // (-1: fixed pose; dense path only).  A landmark has at most one edge per pose.
     const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each
     // sparse_schur: the Schur complement is formed from the landmark-major W blocks (k_ba_schur_sparse; np_pad / 16 <= 8 tile rows),
     // one partial sum per slice; otherwise through the dense k-major operands AT / BT

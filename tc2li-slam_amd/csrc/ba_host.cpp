@@ -95,7 +95,10 @@ struct VisualProblem {
     }
     // the edges with a free pose in landmark-major order: where the W blocks live (the Schur product and the back substitution walk
     // them by landmark)
-    std::vector<int> fl_off(n_points + 1, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
+    // fl_off: per landmark [begin, end) of its slots, the landmarks in index order.  (Tried: slots in the order of the poses a landmark
+    // is seen from, so that a chunk of the Schur kernel spans a narrow band of poses and the product's empty tiles can be skipped -- the
+    // windows' covisibility is not banded enough for that, and the linearisation lost its locality: 64 -> 98 us.)
+    std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
         fl_edge(std::max(n_free_edges, 1)), w_slot(n_edges, -1), slice_off(1, 0);
     {
         // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
@@ -113,7 +116,7 @@ struct VisualProblem {
                 seen[i] = l;
                 w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; fl_edge[at] = e; ++at;
             }
-            fl_off[l + 1] = at;
+            fl_off[2 * (size_t)l] = begin; fl_off[2 * (size_t)l + 1] = at;
             if (at == begin) continue;
             if (slice_lms == kSliceLandmarks || at - slice_off.back() > kSliceEdges) { slice_off.push_back(begin); slice_lms = 0; }
             for (int k = begin; k < at; ++k) fl_place[k] = slice_lms;
@@ -182,9 +185,9 @@ struct VisualProblem {
     const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
                  o_pose_var = align16(o_edges + E * sizeof(BaEdge)), o_pt_off = align16(o_pose_var + n_poses * sizeof(int)),
                  o_pt_edges = align16(o_pt_off + (P + 1) * sizeof(int)), o_pv_off = align16(o_pt_edges + E * sizeof(int)),
-                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + pv_edges.size() * sizeof(int)),
-                 o_fl_pose = align16(o_fl_off + (P + 1) * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
-                 o_fl_lm = align16(o_w_slot + E * sizeof(int)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
+                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + (sparse ? 0 : pv_edges.size()) * sizeof(int)),
+                 o_fl_pose = align16(o_fl_off + 2 * P * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
+                 o_fl_lm = align16(o_w_slot + (sparse ? 0 : E) * sizeof(int)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
                  o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
                  o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
                  o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
@@ -202,10 +205,10 @@ struct VisualProblem {
     memcpy(h + o_pt_off, pt_off.data(), (P + 1) * sizeof(int));
     memcpy(h + o_pt_edges, pt_edges.data(), E * sizeof(int));
     memcpy(h + o_pv_off, pv_off.data(), (n_free + 1) * sizeof(int));
-    memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));
-    memcpy(h + o_fl_off, fl_off.data(), (P + 1) * sizeof(int));
+    if (!sparse) memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));  // pv_edges, w_slot: the dense Schur path's
+    memcpy(h + o_fl_off, fl_off.data(), 2 * P * sizeof(int));
     memcpy(h + o_fl_pose, fl_pose.data(), fl_pose.size() * sizeof(int));
-    memcpy(h + o_w_slot, w_slot.data(), E * sizeof(int));
+    if (!sparse) memcpy(h + o_w_slot, w_slot.data(), E * sizeof(int));
     memcpy(h + o_fl_lm, fl_lm.data(), fl_lm.size() * sizeof(int));
     memcpy(h + o_fl_place, fl_place.data(), fl_place.size() * sizeof(int));
     memcpy(h + o_slice_off, slice_off.data(), slice_off.size() * sizeof(int));
@@ -1047,12 +1050,15 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    const size_t table_bytes = n * sizeof(BaBatchSlot) + 2 * (size_t)n * sizeof(int);
-    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(table_bytes) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
-    int* const h_lists = (int*)(C.h_table.p + n * sizeof(BaBatchSlot));
+    // the slot table: every window's slot on the host; before a phase the slots of the windows taking part are copied, in launch
+    // order, into the two device lists (A: the phase's windows, B: those of them with a LiDAR term) -- a kernel's workgroup finds its
+    // window at blockIdx without going through an index list first
+    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot);
+    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
+    BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
     const BaBatchSlot* const d_slots = (const BaBatchSlot*)C.d_table.p;
-    const int* const d_lists = (const int*)(C.d_table.p + n * sizeof(BaBatchSlot));
+    const BaBatchSlot* const d_slots_lidar = d_slots + n;
     std::vector<LockstepWindow> W(n);
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1153,10 +1159,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         else pool.parallel_for(cnt, fn);
     };
     bool failed = false;
-    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_lists[0..), list b at d_lists[n..)
-        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = a[k];
-        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = b[k];
-        if (hipMemcpyAsync(C.d_table.p, C.h_table.p, table_bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_slots[0..), list b at d_slots_lidar[0..)
+        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
+        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
+        const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
+        if (bytes && hipMemcpyAsync(C.d_table.p, C.h_table.p, bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
     };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
@@ -1176,7 +1183,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             fill_slot(i);
         }
         upload(active, with_lidar);
-        ba_batch_launch_linearize(d_slots, d_lists, (int)active.size(), X, any_maxdiag, st);
+        ba_batch_launch_linearize(d_slots, nullptr, (int)active.size(), X, any_maxdiag, st);
         for (int i : active) {
             LockstepWindow& w = W[i];
             if (!w.need_diag) continue;
@@ -1188,8 +1195,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         // trial, whose residual and plane decompositions are still in place (same bits)
         bool first_pass = false;
         for (int i : with_lidar) first_pass |= W[i].it == 0;
-        if (first_pass) balm_batch_launch_residual(d_slots, d_lists + n, (int)with_lidar.size(), false, st);
-        balm_batch_launch_hessian(d_slots, d_lists + n, (int)with_lidar.size(), X, st);
+        if (first_pass) balm_batch_launch_residual(d_slots_lidar, nullptr, (int)with_lidar.size(), false, st);
+        balm_batch_launch_hessian(d_slots_lidar, nullptr, (int)with_lidar.size(), X, st);
         sync();
         if (failed) break;
         tm[1] += now() - t0; t0 = now();
@@ -1232,7 +1239,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             t0 = now();
             for (int i : trial) fill_slot(i);
             upload(trial, {});
-            ba_batch_launch_schur(d_slots, d_lists, (int)trial.size(), X, st);
+            ba_batch_launch_schur(d_slots, nullptr, (int)trial.size(), X, st);
             sync();
             if (failed) break;
             tm[3] += now() - t0; t0 = now();
@@ -1259,8 +1266,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
                 upload(step, step_lidar);  // slots unchanged since phase B
-                ba_batch_launch_trial(d_slots, d_lists, (int)step.size(), X, st);
-                balm_batch_launch_residual(d_slots, d_lists + n, (int)step_lidar.size(), true, st);
+                ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
+                balm_batch_launch_residual(d_slots_lidar, nullptr, (int)step_lidar.size(), true, st);
                 sync();
                 if (failed) break;
             }
@@ -1313,7 +1320,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
     if (!failed && !all.empty()) {
         upload(all, {});
-        ba_batch_launch_depth(d_slots, d_lists, (int)all.size(), X, st);
+        ba_batch_launch_depth(d_slots, nullptr, (int)all.size(), X, st);
         // device -> pinned staging: one launch writes every window's results (the setup's copy list is done with: the stream has been
         // synchronised many times since), then the copies into the caller's arrays run in parallel
         size_t n_tasks = 0, max_bytes = 0;

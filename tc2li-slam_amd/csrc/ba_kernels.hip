@@ -508,20 +508,21 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_strip(const double* __rest
 // ---- the Schur product from the landmark-major W blocks ----
 // One workgroup per slice of landmarks: at most 256 edges with a free pose (one per thread) of at most 64 landmarks, cut by the host
 // (slice_off; fl_place = the landmark's rank within its slice).  Every thread loads its 6x3 block W up front -- the only round trip to
-// memory -- and forms W D^-1; then, eight landmarks (24 operand rows, six MFMA k-steps) at a time, the threads of the chunk put their
-// blocks into two LDS operands [24][np_pad] that are zero elsewhere (and clear them again after the chunk's MFMAs).  Column 6 n_free
+// memory -- and forms W D^-1; then, a chunk of 16 (8) landmarks = 48 (24) operand rows at a time, the threads of the chunk put their
+// blocks into two LDS operands [rows][np_pad] that are zero elsewhere (and clear them again after the chunk's MFMAs).  Column 6 n_free
 // of the first operand takes D^-1 b_l, so that row 6 n_free of the product is sum_l W D^-1 b_l.  The dense operands of
 // k_ba_schur_prepare (2 x 3 n_points x np_pad doubles per window, written and read every iteration) never exist; HBM sees the W blocks
 // once.  The tiles on and below the diagonal are dealt to the four wavefronts round-robin; a tile accumulates its k-steps in ascending order, chunk after chunk, so the result does not depend on the launch.
-constexpr int kSchurChunk = 8, kSchurRows = 3 * kSchurChunk;
+constexpr int kSchurChunkSmall = 16, kSchurChunkLarge = 8;  // landmarks per chunk at 4 / 9 tiles per wavefront (LDS: 2 x 3 x chunk x ldw doubles)
 __host__ __device__ inline int schur_ldw(int np_pad) { return np_pad % 32 == 16 ? np_pad : np_pad + 16; }  // rows r, r+1 on disjoint banks
 
-template <int TPW>  // tiles per wavefront: the tiles(tiles + 1) / 2 tiles on and below the diagonal are dealt round-robin
+template <int TPW, int kSchurChunk>  // TPW tiles per wavefront: the tiles(tiles + 1) / 2 tiles on and below the diagonal are dealt round-robin
 __device__ __forceinline__ void d_ba_schur_sparse(const BaProblemDev& pb, const int slice, const double lambda, double* __restrict__ lds) {
+    constexpr int kSchurRows = 3 * kSchurChunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int np = 6 * pb.n_free, ld = pb.np_pad, tiles = ld / 16, ldw = schur_ldw(ld);
-    double* Yt = lds;                     // [24][ldw]: (W D^-1)^T, column np: D^-1 b_l
-    double* Wt = lds + kSchurRows * ldw;  // [24][ldw]: W^T
+    double* Yt = lds;                     // [rows][ldw]: (W D^-1)^T, column np: D^-1 b_l
+    double* Wt = lds + kSchurRows * ldw;  // [rows][ldw]: W^T
     const int s0 = pb.slice_off[slice], s1 = pb.slice_off[slice + 1];
     const int n_chunks = pb.fl_place[s1 - 1] / kSchurChunk + 1;  // the last edge belongs to the last landmark of the slice
     const int s = s0 + tid;
@@ -531,7 +532,7 @@ __device__ __forceinline__ void d_ba_schur_sparse(const BaProblemDev& pb, const 
     if (s < s1) {
         const int l = pb.fl_lm[s], place = pb.fl_place[s];
         load_d2<18>(pb.W + 18 * (size_t)s, W);
-        first = s == pb.fl_off[l];  // the landmark's first edge also carries D^-1 b_l
+        first = s == pb.fl_off[2 * l];  // the landmark's first edge also carries D^-1 b_l
         double Di[9];
         point_dinv(pb, l, lambda, Di, db);
 #pragma unroll
@@ -606,17 +607,19 @@ __device__ __forceinline__ void d_ba_schur_sparse(const BaProblemDev& pb, const 
 // the other workgroups' MFMAs cover a workgroup's loads and barriers
 __global__ __launch_bounds__(256) void k_ba_schur_sparse4(BaProblemDev pb, double lambda) {
     extern __shared__ double s_schur[];
-    d_ba_schur_sparse<4>(pb, blockIdx.x, lambda, s_schur);
+    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, double lambda) {
     extern __shared__ double s_schur[];
-    d_ba_schur_sparse<9>(pb, blockIdx.x, lambda, s_schur);
+    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, lambda, s_schur);
 }
 
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
-    if (idx < np * np) {
+    // Only the lower triangle leaves (the LDL^T on the host reads nothing else, ldlt_solve_small): S_out is pinned host memory, every
+    // entry crosses PCIe.
+    if (idx < np * np && idx / np >= idx % np) {
         const int r = idx / np, c = idx % np;
         double s = 0;
         if (r / 6 == c / 6) {  // Hpp is block diagonal in the visual problem
@@ -625,23 +628,19 @@ __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const 
             s = pb.Hpp[27 * (size_t)(r / 6) + packed];
             if (r == c) s += lambda;
         }
-        if (r / 16 < c / 16) {  // tiles above the diagonal are not formed (and not read by the solver)
-            S_out[idx] = 0;
-        } else {
-            double sub = 0;
-            const double* sp = pb.S_part + (size_t)r * pb.np_pad + c;
-            const size_t step = (size_t)pb.np_pad * pb.np_pad;
-            int k = 0;
-            for (; k + 8 <= n_slices; k += 8) {  // eight partials in flight, added in slice order
-                double v[8];
+        double sub = 0;
+        const double* sp = pb.S_part + (size_t)r * pb.np_pad + c;
+        const size_t step = (size_t)pb.np_pad * pb.np_pad;
+        int k = 0;
+        for (; k + 8 <= n_slices; k += 8) {  // eight partials in flight, added in slice order
+            double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(k + u) * step];
+            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(k + u) * step];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sub += v[u];
-            }
-            for (; k < n_slices; ++k) sub += sp[(size_t)k * step];
-            S_out[idx] = s - sub;
+            for (int u = 0; u < 8; ++u) sub += v[u];
         }
+        for (; k < n_slices; ++k) sub += sp[(size_t)k * step];
+        S_out[idx] = s - sub;
     }
     if (idx < np) {
         const double bp = pb.Hpp[27 * (size_t)(idx / 6) + 21 + idx % 6];
@@ -674,7 +673,7 @@ __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, 
     double sc = 0;
     if (l < pb.n_points) {
         double d0 = 0, d1 = 0, d2 = 0;
-        for (int k = pb.fl_off[l]; k < pb.fl_off[l + 1]; ++k) {
+        for (int k = pb.fl_off[2 * l]; k < pb.fl_off[2 * l + 1]; ++k) {
             double W[18];
             load_d2<18>(pb.W + 18 * (size_t)k, W);
             const double* x = (staged ? s_x : xp) + 6 * pb.fl_pose[k];
@@ -768,7 +767,8 @@ __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __re
 
 // ---- lock-step batch: the same bodies, the window taken from a slot table (blockIdx.y / z = position in the active list) ----
 static inline __device__ int blocks256(int n) { return (n + 255) / 256; }
-#define TC2LI_SLOT(axis) const BaBatchSlot& sl = slots[active[blockIdx.axis]]; const BaProblemDev pb = sl.pb  /* a private copy: no reloads after stores */
+// active == NULL: the table is already in launch order (the host compacts it: one dependent load less at the head of every workgroup)
+#define TC2LI_SLOT(axis) const BaBatchSlot& sl = slots[active ? active[blockIdx.axis] : (int)blockIdx.axis]; const BaProblemDev pb = sl.pb  /* a private copy: no reloads after stores */
 
 __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __res
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= total) return;
     const int window = logical / (strips * max_slices), rem = logical - window * (strips * max_slices), slice = rem / strips, strip = rem - slice * strips;
-    const BaBatchSlot& sl = slots[active[window]];
+    const BaBatchSlot& sl = slots[active ? active[window] : window];
     const BaProblemDev pb = sl.pb;
     const int tiles = pb.np_pad / 16;
     if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
@@ -825,13 +825,13 @@ __global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaBatchSlot* _
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
     if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<4>(pb, blockIdx.x, sl.lambda, s_schur);
+    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, sl.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
     if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<9>(pb, blockIdx.x, sl.lambda, s_schur);
+    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, sl.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -871,7 +871,9 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
-static inline size_t schur_lds_bytes(int np_pad) { return 2 * (size_t)kSchurRows * schur_ldw(np_pad) * sizeof(double); }
+static inline size_t schur_lds_bytes(int np_pad) {
+    return 2 * 3 * (size_t)(np_pad / 16 <= 5 ? kSchurChunkSmall : kSchurChunkLarge) * schur_ldw(np_pad) * sizeof(double);
+}
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form

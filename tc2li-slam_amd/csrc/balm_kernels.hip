@@ -314,18 +314,18 @@ __device__ __forceinline__ const Se3* slot_poses(const BaBatchSlot& sl, bool tri
     return trial ? sl.pb.poses_trial : sl.pb.poses;
 }
 __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list, int trial) {
-    const BaBatchSlot& sl = slots[list[blockIdx.x]];
+    const BaBatchSlot& sl = slots[list ? list[blockIdx.x] : (int)blockIdx.x];
     const BalmDev b = sl.balm;
     d_balm_residual_total(b, slot_poses(sl, trial != 0));
 }
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
-    const BaBatchSlot& sl = slots[list[blockIdx.y]];
+    const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= b.n_chunks) return;
     d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(sl, false), blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
-    const BaBatchSlot& sl = slots[list[blockIdx.y]];
+    const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= (balm_part_stride_dev(b.W) + 3) / 4) return;
     d_balm_combine(b, blockIdx.x);
