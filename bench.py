@@ -626,15 +626,22 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
     }
     if ba:
         E, P, lin, tr, nw = ba["edges"], ba["points"], ba["linearisations"], ba["trials"], ba["windows"]
+        Ef, pairs, nf = ba["free_edges"], ba["pose_pairs"], ba["free"]    # edges with a free pose; sum over landmarks of f (f + 1) / 2
+        blocks, slices = -(-Ef // 256), max(-(-Ef // 256), -(-P // 64))   # 256-edge blocks of the pose role; slices of the Schur kernel
+        lower = 6 * nf * (6 * nf + 1) // 2
         w.update({
-            "k_ba_linearize_b": (nw * lin * E * 700, "B"),                 # ~0.7 kB per edge per linearisation
-            "k_ba_reduce_all_b": (nw * lin * E * (36 + 9 + 9) * 8, "B"),
-            "k_ba_schur_prepare_b": (nw * tr * E * (18 + 36) * 8, "B"),
-            "k_ba_reduce_coef_b": (nw * tr * E * 36 * 8, "B"),
-            "k_ba_trial_update_b": (nw * tr * (E * 18 * 8 + P * 15 * 8), "B"),
+            # all edges once: edge 40 B + its place in the landmark-major list 4 B in, chi2 / rho 16 B out; per landmark the point in, Hll / b_l out
+            "k_ba_linearize_b": (nw * lin * (E * 60 + P * (24 + 80)), "B"),
+            # free-pose edges: edge + slot in, W (144 B) out; one 27-vector per (block, pose) out
+            "k_ba_linearize_pose_b": (nw * lin * (Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),
+            "k_ba_reduce_all_b": (nw * lin * (blocks * nf * 224 + nf * 216), "B"),
+            # S -= W D^-1 W^T over the pose pairs a landmark is seen from: 6 x 3 x 6 multiply-adds per pair, W D^-1 and W D^-1 b per edge.
+            # (The kernel runs it as a zero-padded dense f64 MFMA product -- about nine times these FLOPs at this covisibility.)
+            "k_ba_schur_sparse4_b": (nw * tr * 2.0 * (pairs * 108 + Ef * (54 + 18)), "FLOP"),
+            "k_ba_schur_sparse9_b": (nw * tr * 2.0 * (pairs * 108 + Ef * (54 + 18)), "FLOP"),
+            "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
+            "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
-            # S -= (W D^-1) W^T as a dense product: 2 * (6 K)^2 / 2 * 3 P FLOP per trial over the lower tiles
-            "k_ba_schur_gemm_b": (nw * tr * 2.0 * (6 * ba["free"]) ** 2 / 2 * 3 * P, "FLOP"),
             "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
             "k_balm_residual_total_b": (nw * (lin + tr) * ba["planes"] * ba["win"] * 80, "B"),
         })
@@ -886,7 +893,10 @@ def main(argv=None):
         if loop.ba_batch:
             s0, ls0 = loop.ba_batch.stats[0], loop.ba_batch.lstats[0]
             w0 = wl.ba_windows[0]
+            free_edge = np.asarray(w0["fixed"])[np.asarray(w0["edges6"])[:, 1].astype(int)] == 0
+            f_l = np.bincount(np.asarray(w0["edges6"])[free_edge, 0].astype(int), minlength=len(w0["points"]))
             ba = {"edges": len(w0["edges"]), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(ls0.n_planes), "win": 6,
+                  "free_edges": int(free_edge.sum()), "pose_pairs": int((f_l * (f_l + 1) // 2).sum()),
                   "windows": (loop.ba_windows_done - ba1) / n_prof, "linearisations": int(s0.iterations), "trials": int(s0.trials)}
         roofline, kernel_table, kernel_ms_per_step = roofline_from_profile(report, algorithmic_work(wl, loop, nkp, lid_mean, ba), peaks, n_prof)
         roofline["traffic"] = pmc_traffic(roofline["kernel"])

@@ -12,6 +12,8 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ba_device.hpp"
 #include "balm_device.hpp"
 
@@ -113,6 +115,9 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
     __shared__ double s_A[PB][WC][18], s_MB[PB][WC][18];  // Auk (3 x 6) and umumT * Auk
     __shared__ double s_w[PB][WC][3], s_E[PB][WC][9], s_k1[PB][WC], s_k2[PB][WC], s_n[PB][WC], s_cj[PB][WC][6];
     __shared__ double s_uk[PB][3], s_ukuk[PB][9], s_umum[PB][9], s_vbar[PB][3], s_NN[PB], s_l0[PB], s_coe[PB];
+    // the off-diagonal blocks' factors -2 / NN / NN, -2 n_j / NN / NN and -2 n_i n_j / NN / NN: formed once per plane, slot and slot pair
+    // (two f64 divisions each) instead of once per Hessian entry
+    __shared__ double s_f0[PB], s_fn[PB][WC], s_fnn[PB][WC * (WC + 1) / 2];
     __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
     window_poses(b, poses, s_twl);
@@ -155,9 +160,15 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
                 s_NN[lp] = NN;
                 s_l0[lp] = lambda[0];
                 s_coe[lp] = b.coe[a];
+                s_f0[lp] = -2.0 / NN / NN;
             }
         }
         __syncthreads();
+        if (slot_lane) s_fn[lp][li] = -2.0 * mine.n / s_NN[lp] / s_NN[lp];
+        for (int t = tid; t < PB * (W * (W + 1) / 2); t += NT) {
+            const int p = t / (W * (W + 1) / 2), pair = t - p * (W * (W + 1) / 2);
+            if (ab + p < a1) s_fnn[p][pair] = -2.0 * s_n[p][s_pi[pair]] * s_n[p][s_pj[pair]] / s_NN[p] / s_NN[p];
+        }
         if (slot_lane && mine.n != 0) {
             const double NN = s_NN[lp], coe = s_coe[lp];
             const LidarPose T = s_twl[li];
@@ -232,7 +243,6 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
             for (int p = 0; p < np_; ++p) {
                 const double ni = s_n[p][i], nj = s_n[p][j];
                 if (ni == 0 || nj == 0) continue;
-                const double NN = s_NN[p];
                 double val = s_A[p][i][r] * s_MB[p][j][c] + s_A[p][i][6 + r] * s_MB[p][j][6 + c] + s_A[p][i][12 + r] * s_MB[p][j][12 + c];
                 if (i == j) {
                     if (r < 3 && c < 3) val += s_E[p][i][3 * r + c];
@@ -240,10 +250,10 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
                     else if (c < 3) val += s_k1[p][i] * (s_w[p][i][c] * s_uk[p][r - 3]);
                     else val += s_k2[p][i] * s_ukuk[p][3 * (r - 3) + (c - 3)];
                 } else {
-                    if (r < 3 && c < 3) val += (-2.0 / NN / NN) * (s_w[p][i][r] * s_w[p][j][c]);
-                    else if (r < 3) val += (-2.0 * nj / NN / NN) * (s_w[p][i][r] * s_uk[p][c - 3]);
-                    else if (c < 3) val += (-2.0 * ni / NN / NN) * (s_uk[p][r - 3] * s_w[p][j][c]);
-                    else val += (-2.0 * ni * nj / NN / NN) * s_ukuk[p][3 * (r - 3) + (c - 3)];
+                    if (r < 3 && c < 3) val += s_f0[p] * (s_w[p][i][r] * s_w[p][j][c]);
+                    else if (r < 3) val += s_fn[p][j] * (s_w[p][i][r] * s_uk[p][c - 3]);
+                    else if (c < 3) val += s_fn[p][i] * (s_uk[p][r - 3] * s_w[p][j][c]);
+                    else val += s_fnn[p][pair] * s_ukuk[p][3 * (r - 3) + (c - 3)];
                 }
                 acc[k] += s_coe[p] * val;
             }
@@ -269,18 +279,24 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian_large(BalmDev b, 
     d_balm_hessian<kItemsLarge, kHessThreads, kHessPlanesLarge, 32, kMaxLidarWindow>(b, poses, blockIdx.x);
 }
 
-// chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one
-// wavefront per output value, its lanes add the chunks in a fixed order (strided partial sums, then shuffles).
+// chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one thread per
+// output value adds the chunks in chunk order, eight loads in flight (neighbouring threads read neighbouring values of a chunk).
 __device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) {
     const int W = b.W, n = 6 * W, n_items = W * (W + 1) / 2 * 36, stride = n_items + n + 1;
-    const int lane = threadIdx.x & 63, idx = (bx * 256 + threadIdx.x) >> 6;
-    const int t = bx * 256 + threadIdx.x;
-    if (t < 12 * W) b.out[2 + n + n * n + t] = reinterpret_cast<const double*>(b.twl)[t];  // the poses the derivatives refer to
+    const int idx = bx * 256 + threadIdx.x;
+    if (idx < 12 * W) b.out[2 + n + n * n + idx] = reinterpret_cast<const double*>(b.twl)[idx];  // the poses the derivatives refer to
     if (idx >= stride) return;
     double s = 0;
-    for (int k = lane; k < b.n_chunks; k += 64) s += b.part[(size_t)k * stride + idx];
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane != 0) return;
+    const double* p = b.part + idx;
+    int k = 0;
+    for (; k + 8 <= b.n_chunks; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < b.n_chunks; ++k) s += p[(size_t)k * stride];
     if (idx == n_items + n) { b.out[1 + n + n * n] = s; return; }  // out[0] belongs to the residual-only kernels
     if (idx >= n_items) { b.out[1 + (idx - n_items)] = s; return; }
     const int pair = idx / 36, rc = idx % 36, r = rc / 6, c = rc % 6;
@@ -305,7 +321,7 @@ void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
 void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
     if (b.W <= 7) TC2LI_LAUNCH(k_balm_hessian_small, dim3(b.n_chunks), dim3(kHessThreadsSmall), 0, st, b, poses);
     else TC2LI_LAUNCH(k_balm_hessian_large, dim3(b.n_chunks), dim3(kHessThreads), 0, st, b, poses);
-    TC2LI_LAUNCH(k_balm_combine, dim3((balm_part_stride(b.W) + 3) / 4), dim3(256), 0, st, b);  // four outputs per workgroup
+    TC2LI_LAUNCH(k_balm_combine, dim3((std::max(balm_part_stride(b.W), 12 * b.W) + 255) / 256), dim3(256), 0, st, b);
 }
 
 // ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBa
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
     const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
     const BalmDev b = sl.balm;
-    if ((int)blockIdx.x >= (balm_part_stride_dev(b.W) + 3) / 4) return;
+    if ((int)blockIdx.x >= (max(balm_part_stride_dev(b.W), 12 * b.W) + 255) / 256) return;
     d_balm_combine(b, blockIdx.x);
 }
 void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st) {
@@ -336,7 +352,7 @@ void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n
 void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st) {
     if (!n) return;
     TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, slots, list);
-    TC2LI_LAUNCH(k_balm_combine_b, dim3((balm_part_stride(x.max_W) + 3) / 4, n), dim3(256), 0, st, slots, list);
+    TC2LI_LAUNCH(k_balm_combine_b, dim3((std::max(balm_part_stride(x.max_W), 12 * x.max_W) + 255) / 256, n), dim3(256), 0, st, slots, list);
 }
 
 }  // namespace tc2li
