@@ -2,6 +2,8 @@
 // All arithmetic is integer or explicitly rounded float, so the output is bit-identical to the CPU path.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "launch.hpp"
 // Bit-exactness with the CPU path needs every float operation rounded on its own: no FMA contraction (the HIP
 // `__fmul_rn`-style intrinsics are plain operators unless OCML_BASIC_ROUNDED_OPERATIONS is defined, and `__fsqrt_rn` is
@@ -568,19 +570,66 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
     // Keypoint slots: image i owns kp_stride of them and fills the first n_kp[i] (counts known on the device only: k_quadtree_gather)
     const int nslot = n_images * kp_stride, nblk = (nslot + 7) / 8, per_xcd = (nblk + 7) / 8;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (logical >= nblk) return;
+    if (logical >= nblk) return;  // whole workgroup
     const int slot = (logical * 256 + (int)threadIdx.x) >> 5;
-    const int lane = threadIdx.x & 31;
-    if (slot >= nslot) return;
-    const int slot_img = first_image + slot / kp_stride;
-    if (slot % kp_stride >= n_kp[slot_img]) return;
+    const int lane = threadIdx.x & 31, kpi = threadIdx.x >> 5;
+    // The two patches of a keypoint -- 31 x 31 of the level image (orientation), 37 x 37 of the blurred level (the rotated pattern
+    // reaches 18 px: its corner points are (+-13, +-13)) -- are staged in LDS as the aligned dwords their rows lie in, 9 + 12 coalesced
+    // dword loads per lane, instead of 31 + 16 byte gathers per lane from global memory (the 16 descriptor samples of a lane fall on ~16
+    // different cache lines).  Pixel (u, v) of a patch of half-size R is byte (v + R) * 4 * DW + u + R + mis(v + R), DW dwords per row,
+    // mis(r) = byte offset of row r inside its first dword.
+    constexpr int kRawR = 15, kRawDw = 9, kBlurR = 18, kBlurDw = 10;
+    __shared__ uint32_t s_raw[8][(2 * kRawR + 1) * kRawDw], s_blur[8][(2 * kBlurR + 1) * kBlurDw];
+    bool active = slot < nslot;
+    int slot_img = 0;
+    if (active) {
+        slot_img = first_image + slot / kp_stride;
+        active = slot % kp_stride < n_kp[slot_img];
+    }
     const int g = first_image * kp_stride + slot;
-    const DevKeypoint kp = kps[g];
+    DevKeypoint kp{};
+    if (active) kp = kps[g];
     const int level = kp.img_level & 0xff, img = kp.img_level >> 8;
     const int x = (kp.packed >> 8) & 0xfff, y = kp.packed >> 20;
+    uint32_t mis0[2] = {0, 0}, pm[2] = {0, 0};
+    auto stage = [&](const LevelDesc& D, auto r_tag, auto dw_tag, uint32_t* dst, int which) {
+        constexpr int R = decltype(r_tag)::value, DW = decltype(dw_tag)::value, N = (2 * R + 1) * DW, Q = (N + 31) / 32;
+        const uint8_t* corner = D.img + (size_t)img * D.img_stride + (size_t)(y - R) * D.pitch + (x - R);
+        const uint8_t* end = D.img + (size_t)(img + 1) * D.img_stride;  // nothing is read past the image's own buffer
+        mis0[which] = (uint32_t)(reinterpret_cast<uintptr_t>(corner) & 3);
+        pm[which] = (uint32_t)D.pitch & 3u;
+        uint32_t v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int t = lane + 32 * q, row = t / DW, j = t - DW * row;
+            v[q] = 0;
+            if (t < N) {
+                const uint8_t* rowp = corner + (size_t)row * D.pitch;
+                const uint8_t* a = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4 * j;
+                if (a + 4 <= end) v[q] = *reinterpret_cast<const uint32_t*>(a);
+                else for (int k = 0; k < 4; ++k) if (a + k < end) v[q] |= (uint32_t)a[k] << (8 * k);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) if (lane + 32 * q < N) dst[lane + 32 * q] = v[q];
+    };
+    if (active) {
+        stage(raw.lv[level], std::integral_constant<int, kRawR>{}, std::integral_constant<int, kRawDw>{}, s_raw[kpi], 0);
+        stage(blurred.lv[level], std::integral_constant<int, kBlurR>{}, std::integral_constant<int, kBlurDw>{}, s_blur[kpi], 1);
+    }
+    __syncthreads();
+    if (!active) return;
+    const uint8_t* praw = reinterpret_cast<const uint8_t*>(s_raw[kpi]);
+    const uint8_t* pblur = reinterpret_cast<const uint8_t*>(s_blur[kpi]);
+    auto raw_at = [&](int u, int v) -> int {
+        const int row = v + kRawR;
+        return praw[row * 4 * kRawDw + u + kRawR + (int)((mis0[0] + (uint32_t)row * pm[0]) & 3u)];
+    };
+    auto blur_at = [&](int u, int v) -> int {
+        const int row = v + kBlurR;
+        return pblur[row * 4 * kBlurDw + u + kBlurR + (int)((mis0[1] + (uint32_t)row * pm[1]) & 3u)];
+    };
     {
-        const LevelDesc L = raw.lv[level];
-        const uint8_t* center = L.img + (size_t)img * L.img_stride + (size_t)y * L.pitch + x;
         const int u = lane - 16;  // lanes 1..31 cover u = -15..15
         int m10 = 0, m01 = 0;
         if (lane >= 1) {
@@ -589,7 +638,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
             for (int v = -15; v <= 15; ++v) {
                 const int av = v < 0 ? -v : v;
                 if (au <= c_umax[av]) {
-                    const int val = center[v * L.pitch + u];
+                    const int val = raw_at(u, v);
                     col += val;
                     vsum += v * val;
                 }
@@ -612,8 +661,6 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         constexpr float factorPI = (float)(3.141592653589793238462643383279502884 / 180.f);
         float a, b;
         det_sincosf(__fmul_rn(angle, factorPI), &b, &a);
-        const LevelDesc B = blurred.lv[level];
-        const uint8_t* bc = B.img + (size_t)img * B.img_stride + (size_t)y * B.pitch + x;
         const int8_t* pat = c_pattern + lane * 32;
         int val = 0;
 #pragma unroll
@@ -624,7 +671,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
                 const float px = (float)pat[4 * k + 2 * j], py = (float)pat[4 * k + 2 * j + 1];
                 const int ry = cv_round(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
                 const int rx = cv_round(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
-                t[j] = bc[ry * B.pitch + rx];
+                t[j] = blur_at(rx, ry);
             }
             val |= (t[0] < t[1]) << k;
         }
