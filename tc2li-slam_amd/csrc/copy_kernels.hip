@@ -4,33 +4,60 @@
 // kernel moves the bytes: uploads read pinned host memory over the bus, results are written to it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.hpp"
 #include "launch.hpp"
 
 namespace tc2li {
 
-__global__ __launch_bounds__(256) void k_copy_tasks(const CopyTask* __restrict__ tasks) {
-    const CopyTask T = tasks[blockIdx.y];
-    const size_t stride = (size_t)gridDim.x * 256, first = (size_t)blockIdx.x * 256 + threadIdx.x;
-    uint8_t* dst = static_cast<uint8_t*>(T.dst);
-    const uint8_t* src = static_cast<const uint8_t*>(T.src);
-    const bool wide = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
-    if (wide) {
-        const size_t n16 = T.bytes / 16;
-        uint4* d = reinterpret_cast<uint4*>(dst);
-        const uint4* s = reinterpret_cast<const uint4*>(src);
-        if (src) for (size_t i = first; i < n16; i += stride) d[i] = s[i];
-        else for (size_t i = first; i < n16; i += stride) d[i] = uint4{0, 0, 0, 0};
-        for (size_t i = n16 * 16 + first; i < T.bytes; i += stride) dst[i] = src ? src[i] : (uint8_t)0;
-    } else {
-        for (size_t i = first; i < T.bytes; i += stride) dst[i] = src ? src[i] : (uint8_t)0;
+// A fixed, small grid: every workgroup takes its slice of every task.  (One workgroup per 16 KB of every task, as it was first written,
+// put ~1.5 million threads on the GPU for a batch of 43 windows: they filled every wavefront slot for the 1.4 ms the bus needs for the
+// 60 MB, and the kernels of the other streams waited for slots behind them.)  kCopyGroups x 256 threads x 4 x 16 B in flight is enough
+// to keep the bus busy.
+constexpr int kCopyGroups = 128, kCopyBatch = 256;
+__global__ __launch_bounds__(256) void k_copy_tasks(const CopyTask* __restrict__ tasks, int n) {
+    __shared__ CopyTask s_tasks[kCopyBatch];  // the descriptors live in pinned host memory: fetched once, not once per task and thread
+    const int tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+    for (int base = 0; base < n; base += kCopyBatch) {
+        const int m = min(kCopyBatch, n - base);
+        if (tid < m) s_tasks[tid] = tasks[base + tid];
+        __syncthreads();
+        for (int t = 0; t < m; ++t) {
+            const CopyTask T = s_tasks[t];
+            uint8_t* dst = static_cast<uint8_t*>(T.dst);
+            const uint8_t* src = static_cast<const uint8_t*>(T.src);
+            const bool wide = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+            if (wide) {
+                const size_t n16 = T.bytes / 16, per = (n16 + G - 1) / G, lo = (size_t)b * per, hi = min(n16, lo + per);
+                uint4* d = reinterpret_cast<uint4*>(dst);
+                const uint4* s = reinterpret_cast<const uint4*>(src);
+                if (src) {
+                    size_t i = lo + tid;
+                    for (; i + 768 < hi; i += 1024) {  // four loads in flight per thread
+                        const uint4 v0 = s[i], v1 = s[i + 256], v2 = s[i + 512], v3 = s[i + 768];
+                        d[i] = v0; d[i + 256] = v1; d[i + 512] = v2; d[i + 768] = v3;
+                    }
+                    for (; i < hi; i += 256) d[i] = s[i];
+                } else {
+                    for (size_t i = lo + tid; i < hi; i += 256) d[i] = uint4{0, 0, 0, 0};
+                }
+                if (b == 0) for (size_t i = n16 * 16 + tid; i < T.bytes; i += 256) dst[i] = src ? src[i] : (uint8_t)0;
+            } else {
+                const size_t per = (T.bytes + G - 1) / G, lo = (size_t)b * per, hi = min(T.bytes, lo + per);
+                for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src ? src[i] : (uint8_t)0;
+            }
+        }
+        __syncthreads();
     }
 }
 
 void launch_copy_tasks(const CopyTask* tasks, int n, size_t max_bytes, hipStream_t st) {
     if (n <= 0) return;
-    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(64, (max_bytes / 16 + 1023) / 1024));
-    TC2LI_LAUNCH(k_copy_tasks, dim3(gx, n), dim3(256), 0, st, tasks);
+    // small batches: no more workgroups than 4 KB slices of the largest task
+    static const int groups = getenv("TC2LI_COPY_GROUPS") ? atoi(getenv("TC2LI_COPY_GROUPS")) : kCopyGroups;
+    const unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>(groups, (max_bytes + 4095) / 4096));
+    TC2LI_LAUNCH(k_copy_tasks, dim3(g), dim3(256), 0, st, tasks, n);
 }
 
 }  // namespace tc2li
