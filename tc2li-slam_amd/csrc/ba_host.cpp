@@ -1027,7 +1027,7 @@ struct LockstepContext {
     PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
     hipStream_t st = nullptr;
 };
-constexpr int kMaxLockstepGroups = 4;
+constexpr int kMaxLockstepGroups = 8;
 LockstepContext& lockstep_ctx(int group) { static LockstepContext c[kMaxLockstepGroups]; return c[group]; }
 
 // returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
@@ -1197,6 +1197,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         for (int i : with_lidar) first_pass |= W[i].it == 0;
         if (first_pass) balm_batch_launch_residual(d_slots_lidar, nullptr, (int)with_lidar.size(), false, st);
         balm_batch_launch_hessian(d_slots_lidar, nullptr, (int)with_lidar.size(), X, st);
+        tm[6] += now() - t0;  // of the phase: the time to queue it
         sync();
         if (failed) break;
         tm[1] += now() - t0; t0 = now();
@@ -1369,8 +1370,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         }
         results[i] = w.done;
     }
-    if (kTiming) fprintf(stderr, "BA lock-step timing ms (%d windows): setup %.3f linearize %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f results %.3f total %.3f\n",
-                         n, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], now() - t0, now() - t_begin);
+    if (kTiming) fprintf(stderr, "BA lock-step timing ms (%d windows): setup %.3f linearize %.3f (queueing %.3f) host-lin %.3f schur %.3f solve %.3f trial %.3f results %.3f total %.3f\n",
+                         n, tm[0], tm[1], tm[6], tm[2], tm[3], tm[4], tm[5], now() - t0, now() - t_begin);
     return true;
 }
 
@@ -1395,7 +1396,7 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
         if (groups <= 1) {
             done = ba_batch_lockstep(problems, n_problems, cam, *pool, results);
         } else {
-            static WorkerPool* group_pools[kMaxLockstepGroups] = {nullptr, nullptr, nullptr, nullptr};
+            static WorkerPool* group_pools[kMaxLockstepGroups] = {};
             static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
             // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) is host work: 86 tasks of ~0.4 ms
             // for 43 windows, 4.5 ms of a 25 ms batch with 8 threads per group.  16 threads bring the batch alone from 28.5 to 26.1 ms, but in
