@@ -411,7 +411,9 @@ typedef struct tc2li_ba_stats {
  * the inertial-map branch passes 100 (OptimizerWithLidar.cc:141-142).  stop_flag is *pbStopFlag, polled between
  * Levenberg trials like g2o's forceStopFlag.  Outputs: poses and points updated in place (double; the shim casts to
  * float, :468-484), per-edge chi2 as the optimiser left it and isDepthPositive() for the outlier rules (:402-449).
- * Returns the number of iterations performed. */
+ * Returns the number of iterations performed.  Limits of the graph: every point has an edge; a point has at most one edge to a
+ * given optimisable keyframe (two observations of a point from one non-fixed vertex would share a Hessian block: TC2LI_ERR_INVALID)
+ * and at most 256 edges in all. */
 int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
                                   const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
                                   double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,

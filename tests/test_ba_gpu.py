@@ -103,3 +103,18 @@ def test_local_ba_stop_flag_and_structure(pkg, oracle, synthetic):
     bad = e.copy(); bad["pose"][0] = 10 ** 6
     with pytest.raises(pkg.Tc2liError):
         pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], bad, w["cam"])
+    # two edges between the same point and the same free keyframe: g2o would add their Hpl blocks, the W-block layout holds one per
+    # (landmark, pose) -- refused instead of silently dropping one
+    free_pose = int(np.flatnonzero(w["fixed"] == 0)[0])
+    k = int(np.flatnonzero(e["pose"] == free_pose)[0])
+    dup = np.concatenate([e, e[k:k + 1]])
+    with pytest.raises(pkg.Tc2liError):
+        pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], dup, w["cam"])
+    # the same pair on a FIXED keyframe only adds to the landmark's block: accepted
+    fixed_pose = int(np.flatnonzero(w["fixed"] > 0)[0])
+    k = int(np.flatnonzero(e["pose"] == fixed_pose)[0])
+    dup = np.concatenate([e, e[k:k + 1]])
+    w6 = np.concatenate([w["edges"], w["edges"][k:k + 1]])
+    want = oracle.local_ba(w["poses"], w["fixed"], w["points"], w6, w["cam"], iterations=5)
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], dup, w["cam"], iterations=5)
+    assert np.allclose(poses, want[0], rtol=POSE_RTOL, atol=1e-7)
