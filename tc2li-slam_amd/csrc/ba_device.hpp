@@ -64,6 +64,7 @@ struct BaBatchSlot {
     double lambda;
     int32_t n_slices, k_per_slice, want_maxdiag, has_lidar;
     double *chi_out, *maxdiag_out, *S_out, *bs_out, *scale_out, *chi_trial_out;
+    double* hpp_out;  // NULL, or where the host wants Hpp / b_p too (pinned)
     const double* xp;
     uint8_t* depth_out;
     BalmDev balm;

@@ -1149,6 +1149,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         double* sc = w.ws->h_scal.p;
         s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
         s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
+        s.hpp_out = w.need_diag ? w.ws->h_Hpp.p : nullptr;
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
     };
     // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
@@ -1180,16 +1181,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             w.need_diag = w.lidar && w.want_maxdiag && w.vp.n_free > 0;
             any_maxdiag |= w.want_maxdiag;
             if (w.lidar) with_lidar.push_back(i);
+            if (w.need_diag && w.ws->h_Hpp.ensure(27 * (size_t)w.vp.n_free) != hipSuccess) failed = true;  // the reduction writes it (slot.hpp_out)
             fill_slot(i);
         }
         upload(active, with_lidar);
         ba_batch_launch_linearize(d_slots, nullptr, (int)active.size(), X, any_maxdiag, st);
-        for (int i : active) {
-            LockstepWindow& w = W[i];
-            if (!w.need_diag) continue;
-            if (w.ws->h_Hpp.ensure(27 * (size_t)w.vp.n_free) != hipSuccess ||
-                hipMemcpyAsync(w.ws->h_Hpp.p, w.ws->d_Hpp.p, 27 * (size_t)w.vp.n_free * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) failed = true;
-        }
         // (running the LiDAR kernels on a second stream beside the visual ones was measured: no gain, the chain is not the limit there)
         // the residual pass at the accepted estimate: only before the first iteration -- later the accepted estimate is the last
         // trial, whose residual and plane decompositions are still in place (same bits)

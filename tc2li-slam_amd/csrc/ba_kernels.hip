@@ -279,7 +279,7 @@ __device__ __forceinline__ void block_sum_items(const double* __restrict__ items
 
 // Hpp, b_p of free pose i: the blocks' partial sums, eight interleaved series of blocks (lanes 32 q + c take the blocks q, q + 8, ...)
 // added in series order
-__device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i /* free pose */, double* s_part) {
+__device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i /* free pose */, double* s_part, double* __restrict__ hpp_out) {
     const int q = threadIdx.x >> 5, c = threadIdx.x & 31, nb = (pb.n_free_edges + 255) / 256;
     double acc = 0;
     if (c < 27)
@@ -291,6 +291,7 @@ __device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i 
 #pragma unroll
         for (int u = 0; u < 8; ++u) sum += s_part[32 * u + threadIdx.x];
         pb.Hpp[27 * (size_t)i + threadIdx.x] = sum;
+        if (hpp_out) hpp_out[27 * (size_t)i + threadIdx.x] = sum;  // the host's copy (pinned): computeLambdaInit with a LiDAR term reads the diagonal
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -316,12 +317,12 @@ __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, 
 }
 
 // One launch after the linearisation: workgroups [0, n_free) sum the pose blocks, the last one the robust cost
-__device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, double* __restrict__ chi_out) {
+__device__ __forceinline__ void d_ba_reduce_all(const BaProblemDev& pb, const int bx, double* __restrict__ chi_out, double* __restrict__ hpp_out) {
     __shared__ double s_part[128 * kSumChunk];  // block_sum_items' two cross-wavefront folds (also >= the 256 of block_reduce_256)
-    if (bx < pb.n_free) reduce_poses_body(pb, bx, s_part);
+    if (bx < pb.n_free) reduce_poses_body(pb, bx, s_part, hpp_out);
     else block_reduce_256<false>(pb.chi_part, pb.n_groups, s_part, chi_out);
 }
-__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, double* __restrict__ chi_out) { d_ba_reduce_all(pb, blockIdx.x, chi_out); }
+__global__ __launch_bounds__(256) void k_ba_reduce_all(BaProblemDev pb, double* __restrict__ chi_out) { d_ba_reduce_all(pb, blockIdx.x, chi_out, nullptr); }
 
 // computeLambdaInit needs the largest diagonal entries: [0] landmarks, [1] poses (first iteration only)
 __device__ __forceinline__ void d_ba_maxdiag(const BaProblemDev& pb, const int bx, double* __restrict__ out) {
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(256) void k_ba_linearize_pose_b(const BaBatchSlot* 
 __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
     if ((int)blockIdx.x >= pb.n_free + 1) return;
-    d_ba_reduce_all(pb, blockIdx.x, sl.chi_out);
+    d_ba_reduce_all(pb, blockIdx.x, sl.chi_out, sl.hpp_out);
 }
 __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
