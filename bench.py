@@ -635,10 +635,11 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # free-pose edges: edge + slot in, W (144 B) out; one 27-vector per (block, pose) out
             "k_ba_linearize_pose_b": (nw * lin * (Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),
             "k_ba_reduce_all_b": (nw * lin * (blocks * nf * 224 + nf * 216), "B"),
-            # S -= W D^-1 W^T over the pose pairs a landmark is seen from: 6 x 3 x 6 multiply-adds per pair, W D^-1 and W D^-1 b per edge.
-            # (The kernel runs it as a zero-padded dense f64 MFMA product -- about nine times these FLOPs at this covisibility.)
-            "k_ba_schur_sparse4_b": (nw * tr * 2.0 * (pairs * 108 + Ef * (54 + 18)), "FLOP"),
-            "k_ba_schur_sparse9_b": (nw * tr * 2.0 * (pairs * 108 + Ef * (54 + 18)), "FLOP"),
+            # S -= W D^-1 W^T: SURVEY 8d prices it per landmark with n (free-pose) observations at n (n + 1) / 2 x (6x3 . 3x3 + 6x3 . 3x6) =
+            # n (n + 1) / 2 x 324 FLOP.  (The kernel runs it as a zero-padded dense f64 MFMA product per chunk of landmarks: about nine times
+            # these FLOPs at this covisibility, 55 % of the measured matrix peak when it has the GPU to itself -- DESIGN.md section 4.)
+            "k_ba_schur_sparse4_b": (nw * tr * pairs * 324.0, "FLOP"),
+            "k_ba_schur_sparse9_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
             "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),

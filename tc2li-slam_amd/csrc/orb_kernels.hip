@@ -147,7 +147,12 @@ __device__ __forceinline__ int arc_contrast(const int (&p)[16], int v) {
 }
 
 // TH x TW: the largest cell window the instantiation holds (LDS is sized by it: the small variant fits 8 workgroups per CU)
-constexpr int kFastThreads = 256;  // threads per cell (128 was tried: the all-pixel passes dominate, 1.13 ms against 0.89 ms)
+// Threads per cell.  A cell's six phases are barrier-separated steps of about a microsecond, and the kernel issues VALU instructions 18 % of
+// the time (profiles/r02_pmc_instruction_mix.json): what counts is how many cells a CU has in flight.  128 threads per cell keep 15
+// workgroups resident (10.3 KB of LDS each) where 256 allow 8: 0.53 -> 0.43 ms per 128 images; 64: 0.52.  (Round 1 measured the
+// opposite, 1.13 against 0.89 ms, on the kernel that tested every pixel at the low threshold.)  Scoring inside the segment-test pass
+// (one barrier-separated step less, worse lane balance) was tried: 0.45 ms.
+constexpr int kFastThreads = 128;
 template <int TH, int TW>
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
@@ -159,8 +164,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     constexpr int kTileP = TW + 4;
     __shared__ uint32_t tile32[TH * kTileP / 4];
     __shared__ uint8_t score[TH * TW];
-    __shared__ uint16_t s_list[TH * TW];  // window offset | polarity << 14 of the pixels passing the segment test
-    __shared__ uint8_t s_flag[TH * TW];   // per list entry: bit 0 kept at iniTh, bit 1 kept at minTh
+    __shared__ uint16_t s_list[TH * TW];  // window offset | polarity << 14 of the pixels passing the segment test; after the NMS: offset | kept << 14
     constexpr int kMaxKept = ((TW - 6 + 1) / 2) * ((TH - 6 + 1) / 2);  // >= any cell's slab_cap
     __shared__ uint16_t s_kept[kMaxKept];
     __shared__ int s_cnt_ini, s_nlist, s_nkept;
@@ -226,7 +230,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     // once more at minThFAST only for a cell without any corner (low-contrast regions, where few pixels survive either way).  The score of a
     // pixel does not depend on the threshold; non-maximum suppression only sees neighbours that are corners at the threshold of the attempt
     // (cv::FAST's score buffer): in the second attempt the survivors of the first are a subset, their scores are simply written again.
-    const int sel = 1;
     int nlist = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
     const int th = attempt == 0 ? ini_th : min_th;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
             const int n_th = nb[j] > th ? nb[j] - 1 : 0;
             keep = keep && (S - 1 > n_th);
         }
-        s_flag[k] = (uint8_t)(keep ? 1 : 0);
+        s_list[k] = (uint16_t)(at | (keep ? 0x4000 : 0));  // the polarity bits have served (pass 2): bit 14 = kept
         my_kept += keep ? 1 : 0;
     }
     if (my_kept) atomicAdd(&s_cnt_ini, my_kept);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     // Emission in row-major order (the order cv::FAST returns the keypoints in): the kept survivors are gathered (a few tens
     // per cell; strict 3x3 maxima: at most one per 2x2 block), the rank of each among them is its output slot.
     for (int k = tid; k < nlist; k += kFastThreads)
-        if (s_flag[k] & sel) {
+        if (s_list[k] & 0x4000) {
             const int slot = atomicAdd(&s_nkept, 1);
             if (slot < kMaxKept) s_kept[slot] = (uint16_t)(s_list[k] & 0x3fff);
         }
