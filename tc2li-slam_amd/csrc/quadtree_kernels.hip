@@ -578,7 +578,8 @@ void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint3
     const QuadJob* j0 = jobs + first_job;
     if (threads >= 1024) TC2LI_LAUNCH(k_quadtree<1024>, dim3(n_jobs), dim3(1024), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
     else if (threads >= 512) TC2LI_LAUNCH(k_quadtree<512>, dim3(n_jobs), dim3(512), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
-    else TC2LI_LAUNCH(k_quadtree<256>, dim3(n_jobs), dim3(256), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+    else if (threads >= 256) TC2LI_LAUNCH(k_quadtree<256>, dim3(n_jobs), dim3(256), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+    else TC2LI_LAUNCH(k_quadtree<128>, dim3(n_jobs), dim3(128), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
 }
 void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const int32_t* picked_count, const int32_t* level_counts, int first_image, int n_images,
                             int nlevels, int kp_stride, DevKeypoint* kps, DevKeypoint* kps_host, int32_t* n_kp, int32_t* n_kp_host, int32_t* level_counts_host,
