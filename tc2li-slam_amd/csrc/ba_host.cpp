@@ -179,6 +179,7 @@ struct VisualProblem {
     TC2LI_HIP_CHECK(d_depth.ensure(E));
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
+    memset(h_S.p, 0, (size_t)std::max(np * np, 1) * sizeof(double));  // the finish kernel writes the lower triangle only; the rest stays defined
     // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows], every
     // part 16-byte aligned ----
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -527,6 +528,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             t0 = now();
             // a rank's part of the reduced camera system: its edges' Hpp and b_p, minus its landmarks' W Hll^-1 W^T and
             // W Hll^-1 b_l; lambda goes onto the diagonal once (rank 0)
+            if (sharded) TC2LI_SH_CHECK(hipMemsetAsync(d_red, 0, (size_t)np * np * sizeof(double), st));  // above the diagonal: summed, never read
             ba_launch_schur(pb, lambda, sharded && shard->rank != 0 ? 0.0 : lambda, n_slices, k_per_slice, sharded ? d_red : h_S.p,
                             sharded ? d_red + (size_t)np * np : h_bs.p, st);
             TC2LI_SH_CHECK(hipGetLastError());
