@@ -63,12 +63,14 @@ void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const Sca
                          float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st);
 void launch_fill_int(int* p, size_t n, int v, hipStream_t st);
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys, const int* table_counts,
-                       int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status, hipStream_t st);
+                       int* table_rank, int* vox_keys, int* vox_member_off, int* vox_fill /* cleared per voxel */, int* vox_count /* points per voxel */,
+                       int* n_vox, int* status, hipStream_t st);
 void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
-                       const int* table_rank, const int* vox_member_off, int* vox_fill, int* members, hipStream_t st);
+                       const int* table_rank, const int* vox_member_off, int* vox_fill /* runs per voxel */,
+                       int* members /* one word per run: first index | (length - 1) << 24 */, hipStream_t st);
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
-                           const int* vox_member_off, const int* vox_fill, const int* members, void* recs /* 32 B per point */,
+                           const int* vox_member_off, const int* vox_fill, const int* vox_count, const int* members, void* recs /* 32 B per point */,
                            PointXYZINormal* out, int* out_count, hipStream_t st);
 
 // ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes), batched over maps ----

@@ -70,8 +70,9 @@ struct tc2li_lidar {
     DevBuf<int> d_raw_count, d_pre_count, d_down_count, d_sel_count, d_block_counts, d_block_offsets;
     DevBuf<ScanSlot> d_slots;
     DevBuf<SegBlock> d_blocks;
-    DevBuf<int> d_bbox, d_table_keys, d_table_counts, d_table_rank, d_vox_keys, d_member_off, d_vox_fill, d_members, d_pt_slot, d_n_vox,
+    DevBuf<int> d_bbox, d_table_keys, d_table_counts, d_table_rank, d_vox_keys, d_member_off, d_members, d_pt_slot, d_n_vox,
         d_status;
+    DevBuf<int> d_vox_fill, d_vox_count;  // per voxel of a scan: runs (k_voxel_fill) and points (k_voxel_sort)
     DevBuf<VoxelParams> d_vp;
     DevBuf<LidarStateDev> d_states;
     DevBuf<MapGrid> d_grids;
@@ -151,19 +152,18 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_bbox.p, bbox_init.data(), bbox_init.size() * sizeof(int), hipMemcpyHostToDevice, st));
     launch_fill_int(L->d_table_keys.p, (size_t)S * L->table_size, -1, st);
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_vox_fill.p, 0, (size_t)S * L->cap * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_n_vox.p, 0, (size_t)S * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_down_count.p, 0, (size_t)S * sizeof(int), st));  // an empty scan has no block that would write its count
     launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
     launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
     launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, L->d_pt_slot.p, L->d_n_vox.p, L->d_vox_keys.p, st);
     launch_voxel_sort(L->d_slots.p, S, L->d_vp.p, d_in_count, L->d_table_keys.p, L->d_table_counts.p, L->d_table_rank.p, L->d_vox_keys.p,
-                      L->d_member_off.p, L->d_n_vox.p, L->d_status.p, st);
+                      L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, L->d_status.p, st);
     launch_voxel_fill(d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_vp.p, L->d_pt_slot.p, L->d_table_rank.p, L->d_member_off.p, L->d_vox_fill.p,
                       L->d_members.p, st);
     L->record(2, st);
     launch_voxel_centroid(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_pt_slot.p, L->d_table_rank.p, L->d_n_vox.p,
-                          L->d_member_off.p, L->d_vox_fill.p, L->d_members.p, L->d_recs.p, L->d_down.p, L->d_down_count.p, st);
+                          L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_members.p, L->d_recs.p, L->d_down.p, L->d_down_count.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     return TC2LI_OK;
 }
@@ -304,6 +304,8 @@ extern "C" {
 
 int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out) {
     if (!out || max_points_per_scan <= 0 || max_scans <= 0) { set_error("tc2li_lidar_create: invalid argument"); return TC2LI_ERR_INVALID; }
+    // the voxel filter's run records keep a point index in 24 bits (k_voxel_fill)
+    if (max_points_per_scan > (1 << 24) - 1024) { set_error("tc2li_lidar_create: at most %d points per scan", (1 << 24) - 1024); return TC2LI_ERR_INVALID; }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     std::unique_ptr<tc2li_lidar> L(new tc2li_lidar());
     hipStream_t ps = private_stream();
@@ -323,7 +325,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     TC2LI_HIP_CHECK(L->d_bbox.alloc(6 * S)); TC2LI_HIP_CHECK(L->d_vp.alloc(S));
     TC2LI_HIP_CHECK(L->d_table_keys.alloc(S * L->table_size)); TC2LI_HIP_CHECK(L->d_table_counts.alloc(S * L->table_size));
     TC2LI_HIP_CHECK(L->d_table_rank.alloc(S * L->table_size));
-    TC2LI_HIP_CHECK(L->d_vox_keys.alloc(T)); TC2LI_HIP_CHECK(L->d_member_off.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_fill.alloc(T));
+    TC2LI_HIP_CHECK(L->d_vox_keys.alloc(T)); TC2LI_HIP_CHECK(L->d_member_off.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_fill.alloc(T)); TC2LI_HIP_CHECK(L->d_vox_count.alloc(T));
     TC2LI_HIP_CHECK(L->d_members.alloc(T)); TC2LI_HIP_CHECK(L->d_pt_slot.alloc(T)); TC2LI_HIP_CHECK(L->d_n_vox.alloc(S)); TC2LI_HIP_CHECK(L->d_status.alloc(1));
     TC2LI_HIP_CHECK(L->d_states.alloc(S)); TC2LI_HIP_CHECK(L->d_grids.alloc(S));
     TC2LI_HIP_CHECK(L->d_hard_count.alloc(1)); TC2LI_HIP_CHECK(L->d_hard_list.alloc(T)); TC2LI_HIP_CHECK(L->d_recs.alloc(2 * T));

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict_
                                                      const int* __restrict__ count, const int* __restrict__ table_keys,
                                                      const int* __restrict__ table_counts, int* __restrict__ table_rank,
                                                      int* __restrict__ vox_keys, int* __restrict__ vox_member_off,
-                                                     int* __restrict__ n_vox, int* __restrict__ status) {
+                                                     int* __restrict__ vox_fill, int* __restrict__ vox_count, int* __restrict__ n_vox, int* __restrict__ status) {
     extern __shared__ int s_keys[];  // kMaxVoxelsPerScan
     __shared__ int s_n;
     __shared__ int s_part[1024];
@@ -301,11 +301,17 @@ __global__ __launch_bounds__(1024) void k_voxel_sort(const ScanSlot* __restrict_
     int run = s_part[tid] - sum;
     for (int r = lo; r < hi; ++r) {
         vox_member_off[sl.base + r] = run;
-        run += table_counts[table_find(table_keys, v, s_keys[r])];
+        vox_fill[sl.base + r] = 0;  // the fill pass counts the voxel's runs here: only the scan's voxels need clearing
+        const int cnt = table_counts[table_find(table_keys, v, s_keys[r])];
+        vox_count[sl.base + r] = cnt;
+        run += cnt;
     }
     if (tid == 0) n_vox[s] = n;
 }
 
+// A voxel's members are recorded as RUNS: lanes that continue their left neighbour's voxel are consecutive point indices, so one word
+// per run (first index | (length - 1) << 24) says everything the ranking pass needs, and only the run's first lane touches memory:
+// one counter atomic hands out the run's place.
 __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const int* __restrict__ count, const ScanSlot* __restrict__ slots,
                                                           const SegBlock* __restrict__ blocks, const VoxelParams* __restrict__ vp,
                                                           const int* __restrict__ pt_slot, const int* __restrict__ table_rank,
@@ -319,14 +325,11 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_fill(const int* __restrict_
     const ScanSlot sl = slots[b.scan];
     const int slot = i < n ? pt_slot[sl.base + i] : -1;
     const RunInfo run = wave_runs(slot >= 0 ? slot : -1 - (int)(threadIdx.x & 63));
-    int r = 0, first = 0;
-    if (run.head && slot >= 0) {  // one position atomic per run; its lanes take consecutive places
-        r = table_rank[slot];
-        first = atomicAdd(&vox_fill[sl.base + r], run.length);
+    if (run.head && slot >= 0) {
+        const int r = table_rank[slot];
+        const int k = atomicAdd(&vox_fill[sl.base + r], 1);
+        members[sl.base + vox_member_off[sl.base + r] + k] = i | ((run.length - 1) << 24);
     }
-    r = __shfl(r, run.head_lane, 64);
-    first = __shfl(first, run.head_lane, 64);
-    if (slot >= 0) members[sl.base + vox_member_off[sl.base + r] + first + ((int)(threadIdx.x & 63) - run.head_lane)] = i;
 }
 
 // PCL sums a voxel's points in the order of its sorted index vector, i.e. by ascending point index, in float.
@@ -356,14 +359,16 @@ __global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __res
     if (slot < 0) return;
     const PointXYZINormal p = pts[sl.base + i];
     const int r = table_rank[slot];
-    const int off = vox_member_off[sl.base + r], n = vox_fill[sl.base + r];
+    const int off = vox_member_off[sl.base + r], n = vox_fill[sl.base + r];  // runs of the voxel
     const int* m = members + sl.base + off;
+    // points of the voxel with a smaller index: of a run [s, s + L) that is clamp(i - s, 0, L)
     int rank = 0, k = 0;
     for (; k + 4 <= n; k += 4) {  // four independent loads in flight
         const int a0 = m[k], a1 = m[k + 1], a2 = m[k + 2], a3 = m[k + 3];
-        rank += (a0 < i) + (a1 < i) + (a2 < i) + (a3 < i);
+        rank += min(max(i - (a0 & 0xffffff), 0), (a0 >> 24) + 1) + min(max(i - (a1 & 0xffffff), 0), (a1 >> 24) + 1) +
+                min(max(i - (a2 & 0xffffff), 0), (a2 >> 24) + 1) + min(max(i - (a3 & 0xffffff), 0), (a3 >> 24) + 1);
     }
-    for (; k < n; ++k) rank += m[k] < i;
+    for (; k < n; ++k) { const int a = m[k]; rank += min(max(i - (a & 0xffffff), 0), (a >> 24) + 1); }
     CentroidRec rec;
     rec.lo = make_float4(p.x, p.y, p.z, p.normal_x);
     rec.hi = make_float4(p.normal_y, p.normal_z, p.intensity, p.curvature);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void k_voxel_rank(const PointXYZINormal* __res
 __global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                         const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                         const VoxelParams* __restrict__ vp, const int* __restrict__ n_vox,
-                                                        const int* __restrict__ vox_member_off, const int* __restrict__ vox_fill,
+                                                        const int* __restrict__ vox_member_off, const int* __restrict__ vox_count,
                                                         const CentroidRec* __restrict__ recs, PointXYZINormal* __restrict__ out,
                                                         int* __restrict__ out_count, int nblocks) {
     const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256) void k_voxel_centroid(const PointXYZINormal* _
     const int r = b.start + (int)blockIdx.y * 256 + threadIdx.x;
     if (r >= nv) return;
     if (vp[b.scan].passthrough != 0) { out[sl.base + r] = pts[sl.base + r]; return; }
-    const int n = vox_fill[sl.base + r];
+    const int n = vox_count[sl.base + r];
     const CentroidRec* __restrict__ q = recs + sl.base + vox_member_off[sl.base + r];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     int k = 0;
@@ -1004,8 +1009,8 @@ void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const Sca
     if (nblocks) TC2LI_LAUNCH(k_voxel_insert, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
-                       const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* n_vox, int* status,
-                       hipStream_t st) {
+                       const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* vox_fill, int* vox_count, int* n_vox,
+                       int* status, hipStream_t st) {
     if (!nscans) return;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1013,7 +1018,7 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
         attr_set = true;
     }
     TC2LI_LAUNCH(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
-                       table_rank, vox_keys, vox_member_off, n_vox, status);
+                       table_rank, vox_keys, vox_member_off, vox_fill, vox_count, n_vox, status);
 }
 void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
                        const int* table_rank, const int* vox_member_off, int* vox_fill, int* members, hipStream_t st) {
@@ -1021,13 +1026,13 @@ void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* 
 }
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
-                           const int* vox_member_off, const int* vox_fill, const int* members, void* recs, PointXYZINormal* out,
+                           const int* vox_member_off, const int* vox_fill, const int* vox_count, const int* members, void* recs, PointXYZINormal* out,
                            int* out_count, hipStream_t st) {
     if (!nblocks) return;
     TC2LI_LAUNCH(k_voxel_rank, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, leaf, vp, pt_slot, table_rank,
                        vox_member_off, vox_fill, members, (CentroidRec*)recs, nblocks);
     TC2LI_LAUNCH(k_voxel_centroid, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
-                       vox_fill, (const CentroidRec*)recs, out, out_count, nblocks);
+                       vox_count, (const CentroidRec*)recs, out, out_count, nblocks);
 }
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
