@@ -191,7 +191,9 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
 // leave the table work to the run's first lane -- one CAS probe and one counter atomic per run instead of per point -- and take
 // its slot by shuffle.  pt_slot keeps every point's table slot for the later passes (-1: point not filtered).
 constexpr int kMaxVoxelsPerScan = 32768;  // voxels of one scan the LDS sort holds
-__global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+constexpr int kInsertThreads = 256;  // a block of the list = kSegBlock points = kSegBlock / kInsertThreads workgroups (blockIdx.y): the barrier
+// below waits for the slowest probe chain of the workgroup, and 1024 lanes wait longer than 256
+__global__ __launch_bounds__(kInsertThreads) void k_voxel_insert(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                             const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                             float leaf, const VoxelParams* __restrict__ vp,
                                                             int* __restrict__ table_keys, int* __restrict__ table_counts,
@@ -199,8 +201,9 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
     const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
     if (bi < 0) return;
     const SegBlock b = blocks[bi];
-    const int i = b.start + threadIdx.x, n = count[b.scan];
-    if (b.start >= n) return;  // whole workgroup
+    const int first = b.start + (int)blockIdx.y * kInsertThreads;
+    const int i = first + (int)threadIdx.x, n = count[b.scan];
+    if (first >= n) return;  // whole workgroup
     const VoxelParams v = vp[b.scan];
     if (v.passthrough) return;
     const int base = slots[b.scan].base;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kSegBlock) void k_voxel_insert(const PointXYZINorma
         valid = finite3(p);
         if (valid) idx = voxel_index(p, 1.0f / leaf, v);
     }
-    __shared__ int s_new[kSegBlock], s_n_new, s_first;
+    __shared__ int s_new[kInsertThreads], s_n_new, s_first;
     if (threadIdx.x == 0) s_n_new = 0;
     __syncthreads();
     const RunInfo run = wave_runs(idx);
@@ -1006,7 +1009,7 @@ void launch_voxel_params(const int* bbox_enc, const int* count, const ScanSlot* 
 }
 void launch_voxel_insert(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                          float leaf, const VoxelParams* vp, int* table_keys, int* table_counts, int* pt_slot, int* n_vox, int* vox_keys, hipStream_t st) {
-    if (nblocks) TC2LI_LAUNCH(k_voxel_insert, dim3((nblocks + 7) / 8 * 8), dim3(kSegBlock), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
+    if (nblocks) TC2LI_LAUNCH(k_voxel_insert, dim3((nblocks + 7) / 8 * 8, kSegBlock / kInsertThreads), dim3(kInsertThreads), 0, st, pts, count, slots, blocks, leaf, vp, table_keys, table_counts, pt_slot, n_vox, vox_keys, nblocks);
 }
 void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp, const int* count, const int* table_keys,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* vox_fill, int* vox_count, int* n_vox,
