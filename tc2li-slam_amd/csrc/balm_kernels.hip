@@ -330,17 +330,20 @@ __device__ __forceinline__ const Se3* slot_poses(const BaBatchSlot& sl, bool tri
     return trial ? sl.pb.poses_trial : sl.pb.poses;
 }
 __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list, int trial) {
+    __builtin_amdgcn_s_setprio(3);
     const BaBatchSlot& sl = slots[list ? list[blockIdx.x] : (int)blockIdx.x];
     const BalmDev b = sl.balm;
     d_balm_residual_total(b, slot_poses(sl, trial != 0));
 }
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+    __builtin_amdgcn_s_setprio(3);
     const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= b.n_chunks) return;
     d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(sl, false), blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+    __builtin_amdgcn_s_setprio(3);
     const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= (max(balm_part_stride_dev(b.W), 12 * b.W) + 255) / 256) return;
