@@ -1396,10 +1396,11 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
         } else {
             static WorkerPool* group_pools[kMaxLockstepGroups] = {};
             static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
-            // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) is host work: 86 tasks of ~0.4 ms
-            // for 43 windows, 4.5 ms of a 25 ms batch with 8 threads per group.  16 threads bring the batch alone from 28.5 to 26.1 ms, but in
-            // the full loop the step does not move (the GPU is the limit there): 8 stays the default
-            static const int kGroupThreads = std::max(1, getenv("TC2LI_BA_GROUP_THREADS") ? atoi(getenv("TC2LI_BA_GROUP_THREADS")) : 8);
+            // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) and the per-window host steps
+            // between the phases (LiDAR quadratic form, 6K LDL^T) are host work: with 8 threads per group 4.9 + 1.9 + 0.5 ms of a group's 18.5 ms.
+            // While the GPU was the limit of the whole loop more threads changed nothing; since the BA kernels were rebuilt the mapping thread is
+            // the last one to finish a step, and 16 threads per group take the step from 41.8-42.9 to 40.7-40.8 ms (32: 41.0)
+            static const int kGroupThreads = std::max(1, getenv("TC2LI_BA_GROUP_THREADS") ? atoi(getenv("TC2LI_BA_GROUP_THREADS")) : 16);
             for (int g = 0; g < groups; ++g) if (!group_pools[g]) group_pools[g] = new WorkerPool(kGroupThreads);
             std::atomic<int> fell_back{0};
             top->parallel_for(groups, [&](int g) {
