@@ -65,6 +65,13 @@ struct BaBatchSlot {
     int32_t n_slices, k_per_slice, want_maxdiag, has_lidar;
     double *chi_out, *maxdiag_out, *S_out, *bs_out, *scale_out, *chi_trial_out;
     double* hpp_out;  // NULL, or where the host wants Hpp / b_p too (pinned)
+    // the reduced system solved on the device (k_ba_solve_b; S_out / bs_out are device buffers then): b_p for the host's gain-ratio scale,
+    // the LiDAR term's (6K)^2 Hessian and 6K gradient to add (NULL: none), the step for the trial kernels (= xp) and for the host, and
+    // whether the LDL^T went through
+    double* bp_host;
+    const double *Hl, *bl_lidar;
+    double *x_dev, *x_host;
+    int32_t* ok_host;
     const double* xp;
     uint8_t* depth_out;
     BalmDev balm;
@@ -76,6 +83,8 @@ struct BaBatchExtent {
 };
 void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+// x = (S + Hl)^-1 (b_s + bl) per window by dense LDL^T, one workgroup per window (windows of at most 21 free keyframes)
+void ba_batch_launch_solve(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
 void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
 // the LiDAR term of the listed windows (all with W <= 7 and at most 2048 planes): residual at the accepted or the trial poses,

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, doubl
 }
 
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
-                                                         double* __restrict__ bs_out) {
+                                                         double* __restrict__ bs_out, double* __restrict__ bp_host = nullptr) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
     // Only the lower triangle leaves (the LDL^T on the host reads nothing else, ldlt_solve_small): S_out is pinned host memory, every
     // entry crosses PCIe.
@@ -655,6 +655,7 @@ __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const 
         }
         bs_out[idx] = bp - coef;
         bs_out[np + idx] = bp;
+        if (bp_host) bp_host[idx] = bp;
     }
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double lambda, int n_slices, double* __restrict__ S_out,
@@ -840,7 +841,81 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __
     TC2LI_SLOT(y);
     const int np = 6 * pb.n_free;
     if (!pb.n_free || (int)blockIdx.x >= blocks256(np * np)) return;
-    d_ba_schur_finish(pb, blockIdx.x, sl.lambda, sl.n_slices, sl.S_out, sl.bs_out);
+    d_ba_schur_finish(pb, blockIdx.x, sl.lambda, sl.n_slices, sl.S_out, sl.bs_out, sl.bp_host);
+}
+// The reduced camera system of a window on the device: (S + Hl) x = b_s + bl by the dense LDL^T of ldlt_solve_small (ba_math.hpp), one
+// workgroup per window, lane i = row i.  Every element is formed by the same operations in the same order as on the host -- a row's
+// sums run over k ascending, one column after the other; the forward substitution subtracts column by column (k ascending per row); the
+// backward substitution is the host's row loop, one lane at a time -- so a window gives the same step here and in the one-window path.
+// The lower triangle lives packed in LDS (row i at i (i + 1) / 2).  A pivot that is zero or not finite: ok = 0 and a zero step (the
+// host treats the trial as failed).
+constexpr int kSolveThreads = 128;
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    extern __shared__ double s_solve[];
+    __shared__ int s_bad;
+    TC2LI_SLOT(x);
+    const int n = 6 * pb.n_free, tid = threadIdx.x;
+    if (n == 0 || !sl.x_dev) return;
+    double* L = s_solve;                    // packed lower triangle
+    double* dg = L + (size_t)n * (n + 1) / 2;  // pivots
+    double* xs = dg + n;                    // solution vector
+    if (tid == 0) s_bad = 0;
+    double* Li = L + (size_t)tid * (tid + 1) / 2;
+    double xi = 0;
+    if (tid < n) {
+        const double* Srow = sl.S_out + (size_t)tid * n;
+        if (sl.Hl) {
+            const double* Hrow = sl.Hl + (size_t)tid * n;
+            for (int k = 0; k <= tid; ++k) Li[k] = Srow[k] + Hrow[k];
+            xi = sl.bs_out[tid] + sl.bl_lidar[tid];
+        } else {
+            for (int k = 0; k <= tid; ++k) Li[k] = Srow[k];
+            xi = sl.bs_out[tid];
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double* Lj = L + (size_t)j * (j + 1) / 2;
+        double s = 0;
+        if (tid == j) {
+            double d = Lj[j];
+            for (int k = 0; k < j; ++k) d -= Lj[k] * Lj[k] * dg[k];
+            if (!(d == d) || d == 0.0 || d - d != 0.0) s_bad = 1;
+            dg[j] = d;
+            Li[j] = d;
+        } else if (tid > j && tid < n) {
+            s = Li[j];
+            for (int k = 0; k < j; ++k) s -= Li[k] * Lj[k] * dg[k];
+        }
+        __syncthreads();
+        if (tid > j && tid < n) Li[j] = s / dg[j];
+        __syncthreads();
+    }
+    // forward substitution, column by column
+    for (int k = 0; k < n; ++k) {
+        if (tid == k) xs[k] = xi;
+        __syncthreads();
+        if (tid > k && tid < n) xi -= Li[k] * xs[k];
+    }
+    __syncthreads();
+    if (tid < n) xs[tid] = xi / dg[tid];
+    __syncthreads();
+    // backward substitution: row i needs every later entry first, and adds them in ascending order like the host
+    for (int i = n - 1; i >= 0; --i) {
+        if (tid == i) {
+            double s = xs[i];
+            for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * (k + 1) / 2 + i] * xs[k];
+            xs[i] = s;
+        }
+        __syncthreads();
+    }
+    const bool bad = s_bad != 0;
+    if (tid < n) {
+        const double v = bad ? 0.0 : xs[tid];
+        sl.x_dev[tid] = v;
+        sl.x_host[tid] = v;
+    }
+    if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
 }
 __global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     TC2LI_SLOT(y);
@@ -932,6 +1007,17 @@ void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_ac
         else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
     }
     TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
+}
+void ba_batch_launch_solve(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+    if (!n_active || !x.max_free) return;
+    const int n = 6 * x.max_free;
+    const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {  // 21 free keyframes: 66 KB
+        (void)hipFuncSetAttribute((const void*)k_ba_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        attr_set = true;
+    }
+    TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, slots, active);
 }
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;

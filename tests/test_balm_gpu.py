@@ -130,6 +130,18 @@ def test_local_bundle_adjustment_batch(pkg, synthetic):
                 assert np.array_equal(r[2], s[2]), (conc, i)
             if len(s) > 5:
                 assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual
+    # the same batch with the reduced systems solved on the device (k_ba_solve_b, opt-in): the workgroup-per-window LDL^T repeats the host's
+    # operations in the host's order, so nothing changes -- trials, poses, points, per-edge chi2 bit for bit
+    import os
+    os.environ["TC2LI_BA_DEVICE_SOLVE"] = "1"
+    try:
+        assert batch.run(max_concurrency=8) == len(windows)
+    finally:
+        del os.environ["TC2LI_BA_DEVICE_SOLVE"]
+    for i, s in enumerate(singles):
+        r = batch.result(i)
+        assert batch.results[i] == s[4].iterations and r[4].trials == s[4].trials, i
+        assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[3], s[3]), i
 
 
 def test_batch_with_a_large_window(pkg, synthetic):
