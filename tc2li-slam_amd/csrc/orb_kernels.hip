@@ -618,16 +618,28 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         const uint8_t* end = D.img + (size_t)(img + 1) * D.img_stride;  // nothing is read past the image's own buffer
         mis0[which] = (uint32_t)(reinterpret_cast<uintptr_t>(corner) & 3);
         pm[which] = (uint32_t)D.pitch & 3u;
+        // every load is unconditional (a lane with nothing to fetch, or a dword that would cross the end of the image's buffer, reads the
+        // buffer's first dword instead: an address select), so all of them are in flight before the first is used; the dwords at the very
+        // end of the last image are then re-read byte by byte
+        const uint32_t* safe = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(D.img + (size_t)img * D.img_stride) & ~(uintptr_t)3);
         uint32_t v[Q];
+        bool tail[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int t = lane + 32 * q, row = t / DW, j = t - DW * row;
-            v[q] = 0;
-            if (t < N) {
+            const int t = min(lane + 32 * q, N - 1), row = t / DW, j = t - DW * row;
+            const uint8_t* rowp = corner + (size_t)row * D.pitch;
+            const uint8_t* a = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4 * j;
+            tail[q] = a + 4 > end;
+            v[q] = *as_global(tail[q] ? safe : reinterpret_cast<const uint32_t*>(a));
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (tail[q]) {
+                const int t = min(lane + 32 * q, N - 1), row = t / DW, j = t - DW * row;
                 const uint8_t* rowp = corner + (size_t)row * D.pitch;
                 const uint8_t* a = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4 * j;
-                if (a + 4 <= end) v[q] = *reinterpret_cast<const uint32_t*>(a);
-                else for (int k = 0; k < 4; ++k) if (a + k < end) v[q] |= (uint32_t)a[k] << (8 * k);
+                v[q] = 0;
+                for (int k = 0; k < 4; ++k) if (a + k < end) v[q] |= (uint32_t)a[k] << (8 * k);
             }
         }
 #pragma unroll

@@ -183,13 +183,22 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
                 const int p0 = lane, p1 = lane + 64;
                 const int y0 = p0 / 11, x0 = p0 - y0 * 11, y1 = p1 / 11, x1 = p1 - y1 * 11;
                 const bool has1 = p1 < 121;
-                const int a0 = il[y0 * PL.pitch + x0];
-                const int a1 = has1 ? il[y1 * PL.pitch + x1] : 0;
+                // all 24 bytes of the lane are requested before the first is used (a lane without a second pixel reads its first one
+                // again: an address select, so no load sits behind a branch -- with the load next to its use every one of the eleven
+                // window positions cost the wavefront a trip to memory)
+                const uint8_t* pl0 = il + y0 * PL.pitch + x0;
+                const uint8_t* pl1 = has1 ? il + y1 * PL.pitch + x1 : pl0;
+                const uint8_t* pr0 = ir + y0 * PR.pitch + x0;
+                const uint8_t* pr1 = has1 ? ir + y1 * PR.pitch + x1 : pr0;
+                const int a0 = *pl0, a1 = *pl1;
+                int rv0[11], rv1[11];
+#pragma unroll
+                for (int k = 0; k < 11; ++k) { rv0[k] = pr0[k - 5]; rv1[k] = pr1[k - 5]; }
                 int bestS = 0x7fffffff, bestInc = 0, sads[11];
 #pragma unroll
                 for (int inc = -5; inc <= 5; ++inc) {
-                    int s = abs(a0 - (int)ir[y0 * PR.pitch + x0 + inc]);
-                    if (has1) s += abs(a1 - (int)ir[y1 * PR.pitch + x1 + inc]);
+                    int s = abs(a0 - rv0[inc + 5]);
+                    if (has1) s += abs(a1 - rv1[inc + 5]);
 #pragma unroll
                     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
                     sads[inc + 5] = s;
