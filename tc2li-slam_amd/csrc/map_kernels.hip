@@ -287,6 +287,25 @@ __global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__
     }
 }
 // dst[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added
+// the bounding box of the points a wavefront holds (lanes without one pass have = false): shuffle minima / maxima, then six atomics per
+// wavefront instead of six per point on the map's six words
+__device__ __forceinline__ void wave_bbox(int* bbox_enc, const PointXYZINormal& p, bool have) {
+    int mn[3], mx[3];
+    mn[0] = have ? enc_float(p.x) : 0x7fffffff; mn[1] = have ? enc_float(p.y) : 0x7fffffff; mn[2] = have ? enc_float(p.z) : 0x7fffffff;
+    mx[0] = have ? enc_float(p.x) : (int)0x80000000; mx[1] = have ? enc_float(p.y) : (int)0x80000000; mx[2] = have ? enc_float(p.z) : (int)0x80000000;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    if ((threadIdx.x & 63) == 0 && mn[0] != 0x7fffffff) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&bbox_enc[a], mn[a]); atomicMax(&bbox_enc[3 + a], mx[a]); }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
     const MapIncTask& T = tasks[blockIdx.x];
     if (!T.has_inc || *T.batch_overflow) return;
@@ -305,24 +324,25 @@ __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict
         __syncthreads();
         int off = 0, tot = 0;
         for (int k = 0; k < 4; ++k) { off += k < wave ? s_wave[k] : 0; tot += s_wave[k]; }
+        PointXYZINormal p{};
         if (f) {
-            const PointXYZINormal p = T.appended[g];
+            p = T.appended[g];
             T.dst[kept + s_base + off + __popcll(bal & ((1ull << lane) - 1ull))] = p;
-            atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
-            atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
-            atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
         }
+        wave_bbox(bbox_enc, p, f);
         __syncthreads();
         if (tid == 0) s_base += tot;
         __syncthreads();
     }
     const int base = kept + T.out[5];
-    for (int k = tid; k < nn; k += 256) {
-        const PointXYZINormal p = T.world[T.noneed[k]];
-        T.dst[base + k] = p;
-        atomicMin(&bbox_enc[0], enc_float(p.x)); atomicMax(&bbox_enc[3], enc_float(p.x));
-        atomicMin(&bbox_enc[1], enc_float(p.y)); atomicMax(&bbox_enc[4], enc_float(p.y));
-        atomicMin(&bbox_enc[2], enc_float(p.z)); atomicMax(&bbox_enc[5], enc_float(p.z));
+    for (int k0 = 0; k0 < nn; k0 += 256) {  // whole wavefronts stay in the loop: the shuffles of wave_bbox need all lanes
+        const int k = k0 + tid;
+        PointXYZINormal p{};
+        if (k < nn) {
+            p = T.world[T.noneed[k]];
+            T.dst[base + k] = p;
+        }
+        wave_bbox(bbox_enc, p, k < nn);
     }
 }
 
