@@ -265,8 +265,9 @@ __global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict
     __shared__ int s_wave[16];
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const bool in = i < T.n_map;
-    const bool keep = in && !T.deleted[i];
-    if (in) T.deleted[i] = 0;  // the flags are all zero again when the call ends (they belong to the old numbering)
+    const bool was_deleted = in && T.deleted[i];
+    const bool keep = in && !was_deleted;
+    if (was_deleted) T.deleted[i] = 0;  // the flags are all zero again when the call ends (they belong to the old numbering); few are set
     int total;
     const int kp = T.keep_counts[blockIdx.x] + block_flag_scan(keep, s_wave, total);  // kept points before i
     const int K = T.out[4], kpK = T.out[12];
