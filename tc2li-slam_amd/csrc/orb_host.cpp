@@ -347,7 +347,10 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     // the caller's stream, which gives clean per-stage durations.
     const char* chunk_env = getenv("TC2LI_ORB_CHUNKS");  // read per call: the tests switch it
     const int kChunkEnv = chunk_env ? atoi(chunk_env) : 0;
-    static const int kQuadThreads = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 256;  // 256: 0.56 ms per 128 images, 512: 0.76, 1024: 1.21
+    // lanes per distribution job: a batch fills the GPU with jobs and 256 lanes per job are best (0.56 ms per 128 images; 512: 0.76, 1024:
+    // 1.21); a stereo pair alone is 16 jobs, each a long chain of rounds, and more lanes shorten a round (0.265 / 0.223 / 0.214 ms)
+    static const int kQuadThreadsEnv = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 0;
+    const int kQuadThreads = kQuadThreadsEnv > 0 ? kQuadThreadsEnv : (M <= 8 ? 1024 : (M <= 32 ? 512 : 256));
     const int want_chunks = kChunkEnv > 0 ? kChunkEnv : 1;
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     o->last_chunks = n_chunks;
