@@ -435,11 +435,12 @@ class Loop:
             follows_tracking = "track" in set(stages) and self.ba_batch2 is not None
             while done < n_steps and not failed.is_set():
                 ready = (self.steps_tracked if follows_tracking else n_steps) - done
-                want = min(2, n_steps - done) if follows_tracking else 1  # two steps' keyframes per call while there are that many to come
-                if ready < want:
+                # the keyframes of the steps tracked so far, at most two steps' per call: one step's when the thread has caught up (so that the
+                # run does not end on a double batch that could only start when the last frame had been tracked), two when it lags
+                if ready < 1:
                     time.sleep(0.0002)
                     continue
-                m = want
+                m = min(2, ready) if follows_tracking else 1
                 self.ba_step(m)
                 done += m
 
