@@ -9,6 +9,28 @@
 
 namespace tc2li {
 
+// ---- tasks of the block-by-block sparse Schur product (k_ba_schur_blocks, ba_kernels.hip) ----
+// A window's slices (<= 256 slots of <= 64 landmarks) are multiplied kSchurGroup at a time by one workgroup (a PART) of 256 threads,
+// thread = task: the 6x6 block (i, j) of free poses over one of R equal ranges of the slice's landmark ranks (diagonal blocks: tasks
+// Rd i + q; pairs i > j: tasks Rd nf + Ro (i (i - 1) / 2 + j) + q), then one coefficient-row task per free pose.  The diagonal block of
+// pose i gets a product from every slot of pose i, a pair block only from the landmarks both poses see; (Rd, Ro) is the finest cut
+// whose tasks fit the workgroup.
+constexpr int kSchurGroup = 4;
+constexpr int kSchurBlocksMaxFree = 21;  // every window of the sparse path (np_pad / 16 <= 8): 21 * 20 / 2 + 21 + 21 = 252 tasks
+__host__ __device__ inline int schur_tasks_for(int nf, int rd, int ro) { return rd * nf + ro * (nf * (nf - 1) / 2) + nf; }
+__host__ __device__ inline void schur_ranges(int nf, int& rd, int& ro) {
+    // measured at 12 free keyframes (43 windows, us per launch): (5,2) 65, (4,2) 71, (3,2) 70, (3,3) 76, (2,1) 78, (1,1) 84
+    const int pref[7][2] = {{5, 2}, {4, 2}, {3, 2}, {2, 2}, {3, 1}, {2, 1}, {1, 1}};
+    for (int k = 0; k < 7; ++k) { rd = pref[k][0]; ro = pref[k][1]; if (schur_tasks_for(nf, rd, ro) <= 256) return; }
+}
+__host__ __device__ inline int schur_task_count(int nf) { int rd = 1, ro = 1; schur_ranges(nf, rd, ro); return schur_tasks_for(nf, rd, ro); }
+// landmark ranks [64 q / R, 64 (q + 1) / R) as a bit mask
+__host__ __device__ inline unsigned long long schur_range_mask(int R, int q) {
+    const int lo = 64 * q / R, hi = 64 * (q + 1) / R;
+    const unsigned long long upto_hi = hi >= 64 ? ~0ull : (1ull << hi) - 1, upto_lo = (1ull << lo) - 1;
+    return upto_hi & ~upto_lo;
+}
+
 // One local-BA problem resident on the device.  Free (non-fixed) poses are numbered 0..n_free-1 through pose_var;
 // pt_* is a CSR of the edges of each landmark, pv_* a CSR of the edges of each free pose (n_free_edges in total).
 // Per-edge records of the linearisation are padded to whole 16-byte pieces (9 -> 10 and 27 -> 28 doubles) so that they are written
@@ -16,7 +38,8 @@ namespace tc2li {
 constexpr int kContribP = 28;
 struct BaProblemDev {
     int32_t n_edges, n_points, n_poses, n_free, n_free_edges, np_pad;
-    int32_t n_groups, pad3_;  // workgroups of the linearisation: whole landmarks, at most 256 edges each (grp_k0 into pt_edges, grp_l0)
+    int32_t n_groups;         // workgroups of the linearisation: whole landmarks, at most 256 edges each (grp_k0 into pt_edges, grp_l0)
+    int32_t n_schur_slices;   // slices of the sparse Schur product (slice_off has one more entry)
     CameraD cam;
     double delta_mono, delta_stereo;
     float dsqr_mono, dsqr_stereo;
@@ -34,7 +57,10 @@ struct BaProblemDev {
     const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each
     // sparse_schur: the Schur complement is formed from the landmark-major W blocks (k_ba_schur_sparse; np_pad / 16 <= 8 tile rows),
     // one partial sum per slice; otherwise through the dense k-major operands AT / BT
-    int32_t sparse_schur, pad2_;
+    // schur_blocks: the sparse product block by block on the f64 vector unit (k_ba_schur_blocks, one partial per kSchurGroup slices)
+    // instead of the zero-padded MFMA form (k_ba_schur_sparse4/9, one partial per slice; TC2LI_BA_SCHUR_MFMA=1)
+    int32_t sparse_schur, schur_blocks;
+    int32_t schur_rd, schur_ro;  // landmark ranges per diagonal / off-diagonal block task (schur_ranges)
     double *chi2, *rho0;
     double *cp_part, *W;                 // per (block of 256 free-pose edges, free pose): 27 (+1) doubles; per free-pose edge (at w_slot): 18
     const int32_t* blk_off;              // per block: n_free + 1 offsets into its rows sorted by pose
@@ -50,6 +76,9 @@ struct BaProblemDev {
 
 // chi_out[0] = robust cost; maxdiag_out[0..1] = largest |diagonal| of the landmark / pose blocks when want_maxdiag
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st);
+// number of partial sums the sparse Schur product of a window with `n_slices` slices leaves in S_part (what `n_slices` means to
+// ba_launch_schur / BaBatchSlot for such a window)
+int ba_schur_parts(int n_slices, bool blocks);
 // S_out [np*np], bs_out [2*np]: b_s followed by b_p
 // lambda_pose: what the finish kernel adds to the diagonal of S (lambda; 0 on the ranks > 0 of a sharded window, whose parts are summed)
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
@@ -80,6 +109,8 @@ struct BaBatchExtent {
     int max_edges, max_points, max_poses, max_free, max_free_edges, max_groups, max_np_pad, max_slices, max_planes, max_chunks, max_W;
     // max_np_pad / max_slices: over the windows on the dense Schur path; the sparse ones:
     int any_dense, max_sparse_np_pad, max_sparse_slices;
+    // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
+    int max_block_parts, max_block_free, min_block_free;
 };
 void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);

@@ -153,8 +153,12 @@ struct VisualProblem {
     const bool sparse = (np + 1 + 15) / 16 <= 8;
     const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
     const int k_total = 3 * n_points;
+    // TC2LI_BA_SCHUR_MFMA=1 (read per window): the zero-padded MFMA form of the sparse product instead of the block-by-block one (A/B measurements)
+    const char* mfma_env = getenv("TC2LI_BA_SCHUR_MFMA");
+    const bool blocks_form = sparse && n_free <= kSchurBlocksMaxFree && !(mfma_env && atoi(mfma_env) != 0);
+    const int n_schur_slices = (int)slice_off.size() - 1;
     if (sparse) {
-        n_slices = (int)slice_off.size() - 1;
+        n_slices = ba_schur_parts(n_schur_slices, blocks_form);  // partial sums in S_part
         k_per_slice = 0;
     } else {
         n_slices = std::max(1, std::min(64, k_total / 64));
@@ -241,7 +245,11 @@ struct VisualProblem {
     pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off); pb.fl_edge = (const int*)(d + o_fl_edge);
     pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
     pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
-    pb.sparse_schur = sparse ? 1 : 0;
+    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? 1 : 0; pb.n_schur_slices = sparse ? n_schur_slices : 0;
+    pb.schur_rd = pb.schur_ro = 1;
+    if (blocks_form) {
+        schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
+    }
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
     pb.AT = d_AT.p; pb.BT = d_AT.p + at_elems; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
@@ -1146,7 +1154,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         const BaProblemDev& pb = W[i].vp.pb;
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
-        if (pb.sparse_schur) {
+        if (pb.sparse_schur && pb.schur_blocks) {
+            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
+                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
+                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
+            }
+        } else if (pb.sparse_schur) {
             X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
         } else {
             X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);

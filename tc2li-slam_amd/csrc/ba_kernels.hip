@@ -615,6 +615,165 @@ __global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, doubl
     d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, lambda, s_schur);
 }
 
+// ---- the Schur product block by block on the f64 vector unit (default since round 3) ----
+// S_part = sum over landmarks l and pairs (i >= j) of free poses that see l of (W_il D_l^-1) W_jl^T, plus the row sum_l W_il D_l^-1 b_l:
+// exactly the 6x3 . 3x3 . 3x6 products g2o's BlockSolver forms (block_solver.hpp:381-432), and nothing else -- the MFMA form above
+// multiplies [48 x np_pad] operands that are nine tenths structural zeros.  One workgroup per PART = kSchurGroup consecutive slices
+// (<= 256 slots of <= 64 landmarks each).  Per slice: thread = slot loads its W block once (the next slice's loads are in flight while
+// this slice is multiplied: the slice loop is unrolled, so every wait counts exactly the loads it needs), forms Y = W D^-1 and puts
+// both into LDS; a 64-bit mask per free pose says which of the slice's landmarks it sees, a byte table which slot that is.  Then
+// thread = TASK (ba_device.hpp: schur_task_*): one 6x6 block (i, j) over one range of landmark ranks -- the diagonal blocks, which
+// every slot of pose i feeds, are cut into more ranges than the others, so that all tasks run loops of similar length -- or the
+// coefficient row of pose i; a task walks the landmarks of mask[i] & mask[j] in ascending order and keeps its 36 sums in registers
+// across the part's slices.  The order of every sum is a function of the window alone (slices and landmark ranks are cut by the
+// host from the window), so a window gives the same bits alone, in a lock-step batch and from launch to launch.  Output layout = the
+// MFMA form's: the lower triangle of [np_pad][np_pad] per part and the coefficient row np, so k_ba_schur_finish adds the parts as before.
+// Slot stride in LDS 38 doubles: 16-byte aligned blocks that spread over all banks (at 36 doubles every read of a wavefront met
+// 16-way conflicts).
+constexpr int kSchurOps = 38;  // doubles per slot in LDS: Y row-major [6][3] | W row-major [6][3] | 2 of padding
+__host__ __device__ inline size_t schur_blocks_lds_bytes(int nf) {
+    const size_t ops = 256 * kSchurOps * sizeof(double), outs = (size_t)256 * 36 * sizeof(double);
+    return (ops > outs ? ops : outs) + 64 * 3 * sizeof(double) + 2 * (size_t)nf * 8 + 64 * (size_t)nf;
+}
+
+struct SchurSlotA { int l, key; };                                 // landmark (-1: no slot) | place | pose << 8 | first-of-landmark << 16
+struct SchurSlotB { double W[18], H[6], b[3]; };                   // the slot's W block and its landmark's Hll, b_l
+__device__ __forceinline__ SchurSlotA schur_load_a(const BaProblemDev& pb, int slice, int s1_all) {
+    SchurSlotA a{-1, 0};
+    if (slice >= s1_all) return a;
+    const int s0 = pb.slice_off[slice], s = s0 + (int)threadIdx.x;
+    if (s >= pb.slice_off[slice + 1]) return a;
+    a.l = pb.fl_lm[s];
+    // a slice starts with a landmark's first slot (slices are whole landmarks)
+    const int first = threadIdx.x == 0 || pb.fl_lm[s - 1] != a.l;
+    a.key = pb.fl_place[s] | pb.fl_pose[s] << 8 | first << 16;
+    return a;
+}
+__device__ __forceinline__ void schur_load_b(const BaProblemDev& pb, int slice, const SchurSlotA& a, SchurSlotB& o) {
+    if (a.l < 0) return;
+    const int s = pb.slice_off[slice] + (int)threadIdx.x;
+    load_d2<18>(pb.W + 18 * (size_t)s, o.W);
+    load_d2<6>(pb.Hll + 6 * (size_t)a.l, o.H);
+    const double* b = pb.bl + 3 * (size_t)a.l;
+    o.b[0] = b[0]; o.b[1] = b[1]; o.b[2] = b[2];
+}
+
+__device__ __forceinline__ void d_ba_schur_blocks(const BaProblemDev& pb, const int part, const double lambda, double* __restrict__ lds) {
+    const int tid = threadIdx.x, NF = pb.n_free, np = 6 * NF, ld = pb.np_pad;
+    const int Rd = pb.schur_rd, Ro = pb.schur_ro;
+    const int nD = Rd * NF, nO = Ro * (NF * (NF - 1) / 2), nT = nD + nO + NF;
+    const size_t ops_doubles = max((size_t)256 * kSchurOps, (size_t)nT * 36);
+    double* const ops = lds;
+    double* const dbl = lds + ops_doubles;                                                   // [64][3]: D^-1 b_l by landmark rank
+    unsigned long long* const masks = reinterpret_cast<unsigned long long*>(dbl + 64 * 3);   // [2][NF]: landmarks of the slice a pose sees
+    unsigned char* const slot_of = reinterpret_cast<unsigned char*>(masks + 2 * NF);         // [64][NF]: the slot of (landmark rank, pose)
+    // ---- this thread's task ----
+    int t_i = 0, t_j = 0, t_kind = -1;  // 0: block, 1: coefficient row
+    unsigned long long t_sel = 0;
+    if (tid < nD) { t_i = t_j = tid / Rd; t_sel = schur_range_mask(Rd, tid - t_i * Rd); t_kind = 0; }
+    else if (tid < nD + nO) {
+        const int n = (tid - nD) / Ro;  // pair number i (i - 1) / 2 + j, i > j
+        int i = 1;
+        while (i * (i + 1) / 2 <= n) ++i;
+        t_i = i; t_j = n - i * (i - 1) / 2; t_sel = schur_range_mask(Ro, (tid - nD) - n * Ro); t_kind = 0;
+    } else if (tid < nT) { t_i = t_j = tid - nD - nO; t_sel = ~0ull; t_kind = 1; }
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    const int sl0 = part * kSchurGroup, sl1 = min(sl0 + kSchurGroup, pb.n_schur_slices);
+    // the index arrays of all the part's slices first (one round trip), then slice by slice the blocks
+    SchurSlotA a[kSchurGroup];
+#pragma unroll
+    for (int k = 0; k < kSchurGroup; ++k) a[k] = schur_load_a(pb, sl0 + k, sl1);
+    SchurSlotB b_cur, b_nxt;
+    schur_load_b(pb, sl0, a[0], b_cur);
+#pragma unroll
+    for (int k = 0; k < kSchurGroup; ++k) {
+        if (sl0 + k >= sl1) break;  // uniform
+        if (k + 1 < kSchurGroup) schur_load_b(pb, sl0 + k + 1, a[k + 1], b_nxt);  // in flight while this slice is multiplied
+        // two mask buffers in turn: this slice's is cleared while the tasks of the previous slice may still read theirs
+        unsigned long long* const mask = masks + (k & 1) * NF;
+        if (tid < NF) mask[tid] = 0ull;
+        double Y[18], db[3];
+        const bool have = a[k].l >= 0;
+        if (have) {
+            // (Hll + lambda I)^-1 and its product with b_l: the arithmetic of point_dinv (the back substitution forms the same inverse)
+            const double* h = b_cur.H;
+            const double d00 = h[0] + lambda, d01 = h[1], d02 = h[2], d11 = h[3] + lambda, d12 = h[4], d22 = h[5] + lambda;
+            const double c00 = d11 * d22 - d12 * d12, c01 = d12 * d02 - d01 * d22, c02 = d01 * d12 - d11 * d02;
+            const double det = d00 * c00 + d01 * c01 + d02 * c02, id = 1.0 / det;
+            double Di[9];
+            Di[0] = c00 * id; Di[1] = (d02 * d12 - d01 * d22) * id; Di[2] = (d01 * d12 - d02 * d11) * id;
+            Di[3] = c01 * id; Di[4] = (d00 * d22 - d02 * d02) * id; Di[5] = (d02 * d01 - d00 * d12) * id;
+            Di[6] = c02 * id; Di[7] = (d01 * d02 - d00 * d12) * id; Di[8] = (d00 * d11 - d01 * d01) * id;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) db[r] = Di[3 * r] * b_cur.b[0] + Di[3 * r + 1] * b_cur.b[1] + Di[3 * r + 2] * b_cur.b[2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Y[3 * r + c] = b_cur.W[3 * r] * Di[c] + b_cur.W[3 * r + 1] * Di[3 + c] + b_cur.W[3 * r + 2] * Di[6 + c];
+        }
+        __syncthreads();  // the masks are clear; the previous slice's tasks have read the operands and the slot table
+        if (have) {
+            const int place = a[k].key & 255, pose = (a[k].key >> 8) & 255;
+            store_d2<18>(ops + tid * kSchurOps, Y);
+            store_d2<18>(ops + tid * kSchurOps + 18, b_cur.W);
+            slot_of[place * NF + pose] = (unsigned char)tid;
+            atomicOr(&mask[pose], 1ull << place);
+            if (a[k].key >> 16) { dbl[3 * place] = db[0]; dbl[3 * place + 1] = db[1]; dbl[3 * place + 2] = db[2]; }
+        }
+        __syncthreads();
+        if (t_kind == 0) {
+            unsigned long long m = mask[t_i] & mask[t_j] & t_sel;
+            while (m) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                double y[18], w[18];
+                load_d2<18>(ops + (int)slot_of[p * NF + t_i] * kSchurOps, y);
+                load_d2<18>(ops + (int)slot_of[p * NF + t_j] * kSchurOps + 18, w);
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        acc[6 * r + c] = __builtin_fma(y[3 * r + 2], w[3 * c + 2], __builtin_fma(y[3 * r + 1], w[3 * c + 1], __builtin_fma(y[3 * r], w[3 * c], acc[6 * r + c])));
+            }
+        } else if (t_kind == 1) {
+            unsigned long long m = mask[t_i];
+            while (m) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                const double* Wa = ops + (int)slot_of[p * NF + t_i] * kSchurOps + 18;
+                const double d0 = dbl[3 * p], d1 = dbl[3 * p + 1], d2 = dbl[3 * p + 2];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[r] = __builtin_fma(Wa[3 * r + 2], d2, __builtin_fma(Wa[3 * r + 1], d1, __builtin_fma(Wa[3 * r], d0, acc[r])));
+            }
+        }
+        if (k + 1 < kSchurGroup) b_cur = b_nxt;
+    }
+    // ---- the part's sums: tasks -> LDS (by task number), then one thread per entry of the lower triangle / of the coefficient row adds
+    // the landmark ranges in order ----
+    __syncthreads();
+    if (t_kind >= 0) store_d2<36>(ops + (size_t)tid * 36, acc);
+    __syncthreads();
+    double* const out = pb.S_part + (size_t)part * ld * ld;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int r = wave; r < np; r += 4) {  // wavefront: row of the lower triangle, lane: column
+        const int bi = r / 6, e0 = 6 * (r - 6 * bi);
+        for (int c = lane; c <= r; c += 64) {
+            const int bj = c / 6, e = e0 + (c - 6 * bj);
+            const int t0 = bi == bj ? Rd * bi : nD + Ro * (bi * (bi - 1) / 2 + bj), R = bi == bj ? Rd : Ro;
+            double sum = ops[(size_t)t0 * 36 + e];
+            for (int q = 1; q < R; ++q) sum += ops[(size_t)(t0 + q) * 36 + e];
+            out[(size_t)r * ld + c] = sum;
+        }
+    }
+    if (tid < np) out[(size_t)np * ld + tid] = ops[(size_t)(nD + nO + tid / 6) * 36 + tid % 6];  // row np: sum_l W D^-1 b_l
+}
+__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks(BaProblemDev pb, double lambda) {  // two wavefronts per SIMD: 80 KB of LDS allow two workgroups per CU
+    extern __shared__ double s_schur[];
+    d_ba_schur_blocks(pb, blockIdx.x, lambda, s_schur);
+}
+
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out, double* __restrict__ bp_host = nullptr) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
@@ -825,16 +984,22 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __res
     if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
+__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+    extern __shared__ double s_schur[];
+    TC2LI_SLOT(y);
+    if (!pb.sparse_schur || !pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_blocks(pb, blockIdx.x, sl.lambda, s_schur);
+}
 __global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
     d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, sl.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
     d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, sl.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
@@ -953,10 +1118,26 @@ static inline size_t schur_lds_bytes(int np_pad) {
     return 2 * 3 * (size_t)(np_pad / 16 <= 5 ? kSchurChunkSmall : kSchurChunkLarge) * schur_ldw(np_pad) * sizeof(double);
 }
 
+int ba_schur_parts(int n_slices, bool blocks_form) { return blocks_form ? (n_slices + kSchurGroup - 1) / kSchurGroup : n_slices; }
+
+// the block-by-block kernels need more than the 64 KB of dynamic LDS a kernel gets by default
+static void schur_blocks_attr() {
+    static bool set = false;
+    if (set) return;
+    (void)hipFuncSetAttribute((const void*)k_ba_schur_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
+    (void)hipFuncSetAttribute((const void*)k_ba_schur_blocks_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
+    set = true;
+}
+
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
     const int np = 6 * pb.n_free;
-    if (pb.sparse_schur) {
+    if (pb.sparse_schur && pb.schur_blocks) {
+        if (n_slices) {
+            schur_blocks_attr();
+            TC2LI_LAUNCH(k_ba_schur_blocks, dim3(n_slices), dim3(256), schur_blocks_lds_bytes(pb.n_free), st, pb, lambda);
+        }
+    } else if (pb.sparse_schur) {
         if (n_slices) {
             if (pb.np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
             else TC2LI_LAUNCH(k_ba_schur_sparse9, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
@@ -992,6 +1173,10 @@ void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int 
 }
 void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
+    if (x.max_block_parts) {
+        schur_blocks_attr();
+        TC2LI_LAUNCH(k_ba_schur_blocks_b, dim3(x.max_block_parts, n_active), dim3(256), schur_blocks_lds_bytes(x.max_block_free), st, slots, active);
+    }
     if (x.max_sparse_slices) {
         const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
         if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, slots, active);
