@@ -312,6 +312,34 @@ int tc2li_lidar_eskf_update(tc2li_lidar* lidar, tc2li_lidar_map* map, const tc2l
 int tc2li_lidar_undistort(tc2li_lidar* lidar, tc2li_point* points, int n, const tc2li_imu_pose6d* imu_poses, int n_poses,
                           const tc2li_lidar_state* end_state);
 
+/* ---- the LiDAR thread of the camera-LiDAR-inertial configuration for a batch of sequences ----
+ * LidarInertialProcess (SF/include/lidar_front_end/LidarFrontEnd.cpp:615-785) for n_scans scans of n_scans sequences in one call:
+ * Preprocess::process of the raw scans (resident in device memory like tc2li_lidar_frontend_batch's), ImuProcess::Process = forward
+ * propagation with the covariance on the host (tc2li_lidar_imu_propagate_cov) + UndistortPcl on the device -- the time sort included: the
+ * permutation std::sort leaves is replayed on the device --, downSizeFilterSurf.filter, and kf.update_iterated_dyn_share_modified with
+ * h_share_model (:749) for all scans in lock step: per iteration one launch per phase over the scans still iterating, then every
+ * scan's 23-dof algebra on host threads.  Every scan's result is the one of the one-scan entry points called in that order
+ * (tc2li_lidar_preprocess, tc2li_lidar_imu_propagate_cov, tc2li_lidar_undistort, tc2li_lidar_voxel_filter, tc2li_lidar_eskf_update).
+ * Afterwards the handle holds every scan's down-sampled points and Nearest_Points for tc2li_lidar_map_incremental_batch (scan slot s). */
+typedef struct tc2li_lidar_inertial_scan {
+    const tc2li_imu_meas* imu;          /* v_imu: the last scan's tail sample followed by this scan's samples */
+    int32_t n_imu, pad_;
+    double pcl_beg_time, pcl_end_time, last_lidar_end_time, acc_scale;
+    double acc_s_last[3], angvel_last[3];   /* in / out, as tc2li_lidar_imu_propagate */
+    tc2li_imu_state state;              /* in: the filter state at the last scan end; out: after the iterated update */
+    double* P;                          /* [23 * 23] in / out */
+    tc2li_eskf_stats stats;             /* out */
+    int32_t n_preprocessed, n_downsampled;  /* out */
+} tc2li_lidar_inertial_scan;
+int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
+                                        int point_filter_num, double blind, float time_unit_scale, float leaf, tc2li_lidar_map* const* maps,
+                                        tc2li_lidar_inertial_scan* scans, const double cov12[12], double R, int maximum_iter,
+                                        const double* limit23, int extrinsic_est_en, void* stream);
+/* The time sort of UndistortPcl alone (tests / diagnostics): perm[i] = index of the point std::sort(points, time_list) leaves at place i,
+ * computed by the device kernel of the batch entry (one scan; depth_limit < 0: std::sort's own 2 floor(log2 n)).  Returns 1 when the
+ * recursion reached the depth limit (perm is then unspecified: the batch entry sorts such a scan on the host), else 0. */
+int tc2li_device_time_sort(tc2li_lidar* lidar, const tc2li_point* points, int n, int depth_limit, int32_t* perm);
+
 /* Device time of the stages of the last tc2li_lidar_frontend_batch call, from HIP events on its stream: ms[0]
  * preprocess, [1] voxel hashing/sorting, [2] voxel centroids, [3] 5-NN + plane fit, [4] selection, [5] total, [6] / [7] the two
  * kernels of stage [3] (k_knn_plane, k_knn_hard). */

@@ -131,6 +131,7 @@ def lib():
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
     L.tc2li_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.tc2li_device_time_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     _lib = L
     return L
 
@@ -563,6 +564,56 @@ class LidarFrontEnd:
                  int(extrinsic_est_en), C.addressof(stats)))
         return st, Pm, stats
 
+    def time_sort(self, points, depth_limit=-1):
+        """The permutation ``std::sort(points, time_list)`` leaves (UndistortPcl's time sort), computed by the device kernel of the
+        inertial batch -> (perm [n], reached_depth_limit)."""
+        pts = np.ascontiguousarray(points, POINT_DTYPE)
+        perm = np.zeros(max(len(pts), 1), np.int32)
+        fb = _check(lib().tc2li_device_time_sort(self._h, pts.ctypes.data, len(pts), int(depth_limit), perm.ctypes.data))
+        return perm[:len(pts)], bool(fb)
+
+    def inertial_frontend_batch(self, dev_raw_ptr, raw_offsets, maps, states36, Ps, imus, times, cov12, last6=None, point_filter_num=2, blind=2.0,
+                                time_unit_scale=1e-3, leaf=0.5, R=0.001, max_iter=3, limit=None, extrinsic_est_en=False, stream=0):
+        """``LidarInertialProcess`` for a batch of sequences (tc2li_lidar_inertial_frontend_batch).  states36 [S, 36] (pos 3, rot 9, vel 3, bg 3,
+        ba 3, grav 3, offset_R_L_I 9, offset_T_L_I 3), Ps [S, 23, 23], imus: list of [K, 7] sample arrays (t, acc, gyr), times [S, 4] =
+        pcl_beg_time, pcl_end_time, last_lidar_end_time, acc_scale, last6 [S, 6] = acc_s_last, angvel_last ->
+        (states36, Ps, list of EskfStats, n_preprocessed, n_downsampled, last6)."""
+        S = len(raw_offsets) - 1
+        raw_offsets = np.ascontiguousarray(raw_offsets, np.int32)
+        st = np.ascontiguousarray(states36, np.float64).reshape(S, 36).copy()
+        Pm = np.ascontiguousarray(Ps, np.float64).reshape(S, 529).copy()
+        times = np.ascontiguousarray(times, np.float64).reshape(S, 4)
+        last = np.zeros((S, 6)) if last6 is None else np.ascontiguousarray(last6, np.float64).reshape(S, 6).copy()
+        cov = np.ascontiguousarray(cov12, np.float64)
+        lim = np.ascontiguousarray(np.full(23, 0.001) if limit is None else limit, np.float64)
+        imus = [np.ascontiguousarray(x, np.float64).reshape(-1, 7) for x in imus]
+        scans = (LidarInertialScan * S)()
+        for s in range(S):
+            sc = scans[s]
+            sc.imu, sc.n_imu = imus[s].ctypes.data, len(imus[s])
+            sc.pcl_beg_time, sc.pcl_end_time, sc.last_lidar_end_time, sc.acc_scale = [float(v) for v in times[s]]
+            for k in range(3):
+                sc.acc_s_last[k], sc.angvel_last[k] = last[s, k], last[s, 3 + k]
+            C.memmove(C.addressof(sc.state), st[s].ctypes.data, 36 * 8)
+            sc.P = Pm[s].ctypes.data
+        handles = (C.c_void_p * S)(*[m._h for m in maps])
+        f = lib().tc2li_lidar_inertial_frontend_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        _check(f(self._h, S, C.c_void_p(dev_raw_ptr), raw_offsets.ctypes.data, point_filter_num, blind, time_unit_scale, leaf, handles, scans,
+                 cov.ctypes.data, R, max_iter, lim.ctypes.data, int(extrinsic_est_en), C.c_void_p(stream)))
+        stats, n_pre, n_down = [], np.zeros(S, np.int32), np.zeros(S, np.int32)
+        for s in range(S):
+            sc = scans[s]
+            C.memmove(st[s].ctypes.data, C.addressof(sc.state), 36 * 8)
+            e = EskfStats()
+            C.memmove(C.addressof(e), C.addressof(sc.stats), C.sizeof(EskfStats))
+            stats.append(e)
+            n_pre[s], n_down[s] = sc.n_preprocessed, sc.n_downsampled
+            for k in range(3):
+                last[s, k], last[s, 3 + k] = sc.acc_s_last[k], sc.angvel_last[k]
+        return st, Pm.reshape(S, 23, 23), stats, n_pre, n_down, last
+
     def feature_extraction(self, lidar_map, feats_down_body, state24):
         body = np.ascontiguousarray(feats_down_body, POINT_DTYPE)
         n = len(body)
@@ -905,6 +956,13 @@ class EskfStats(C.Structure):
     """tc2li_eskf_stats"""
     _fields_ = [("calls", C.c_int32), ("effct_feat_num", C.c_int32), ("searches", C.c_int32), ("converged", C.c_int32), ("finished", C.c_int32),
                 ("pad_", C.c_int32), ("res_mean_last", C.c_double)]
+
+
+class LidarInertialScan(C.Structure):
+    """tc2li_lidar_inertial_scan (state = tc2li_imu_state: pos 3, rot 9, vel 3, bg 3, ba 3, grav 3, offset_R_L_I 9, offset_T_L_I 3)"""
+    _fields_ = [("imu", C.c_void_p), ("n_imu", C.c_int32), ("pad_", C.c_int32), ("pcl_beg_time", C.c_double), ("pcl_end_time", C.c_double),
+                ("last_lidar_end_time", C.c_double), ("acc_scale", C.c_double), ("acc_s_last", C.c_double * 3), ("angvel_last", C.c_double * 3),
+                ("state", C.c_double * 36), ("P", C.c_void_p), ("stats", EskfStats), ("n_preprocessed", C.c_int32), ("n_downsampled", C.c_int32)]
 
 
 def eskf_predict(state36, P, Q, acc, gyr, dt):

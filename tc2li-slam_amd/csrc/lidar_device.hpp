@@ -138,6 +138,15 @@ constexpr int kMaxImuPoses = 64;
 void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const Pose6DDev* poses, int n_poses, const LidarStateDev* end,
                       PointXYZINormal* out, hipStream_t st);
 
+// the same for every scan of a batch, the time sort included (k_time_sort: std::sort's permutation replayed on the device):
+// key [total] floats, ints5 [5 total] / ints3 [3 total] ints, flag [total] bytes of work space in the scans' slots; fallback [n_scans] = 1
+// where the recursion reached std::sort's depth limit (the host sorts such a scan); depth_override >= 0 replaces that limit (tests)
+void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int n_scans, float* key, int* ints5, int* ints3, uint8_t* flag,
+                      size_t total, int* perm, int* fallback, int depth_override, hipStream_t st);
+void launch_undistort_batch(const PointXYZINormal* in, const int* perm, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                            const Pose6DDev* poses /* [n_scans][kMaxImuPoses] */, const int* n_poses, const LidarStateDev* ends, PointXYZINormal* out,
+                            hipStream_t st);
+
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states,
                       PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, int* nearest_idx, float* nearest_d,
@@ -149,6 +158,14 @@ void launch_eskf_refit(const MapGrid& grid, const PointXYZINormal* body, int n, 
                        PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, hipStream_t st);
 void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev* state, const uint8_t* selected, const PointXYZINormal* normvec,
                         int extrinsic_est_en, double* partial, double* out, hipStream_t st);
+// the batch forms: `blocks` lists the (scan, 1024-point block) pairs taking part, `scans` the scans whose sums are wanted;
+// partial [total / 256][kEskfOutSize], out [max_scans][kEskfOutSize] (pinned), a scan's result at its slot number
+void launch_eskf_refit_batch(const MapGrid* grids, const PointXYZINormal* body, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                             const LidarStateDev* states, const int* nearest_idx, PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec,
+                             hipStream_t st);
+void launch_eskf_normal_batch(const PointXYZINormal* body, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                              const LidarStateDev* states, const uint8_t* selected, const PointXYZINormal* normvec, int extrinsic_est_en, double* partial,
+                              const int* scans, int n_scans, double* out, hipStream_t st);
 void launch_sel_count(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       int* block_counts, hipStream_t st);
 void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,

@@ -92,6 +92,10 @@ struct tc2li_lidar {
     DevBuf<float4> d_recs;  // 2 per point: the voxel filter's records in summation order
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
+    // tc2li_lidar_inertial_frontend_batch: IMU poses per scan, the time sort's flags, block / scan lists of an iteration, pinned staging
+    DevBuf<int> d_n_poses, d_sort_fallback, d_scan_list;
+    DevBuf<SegBlock> d_blocks_a, d_blocks_b, d_blocks_c;
+    PinnedBuf<uint8_t> h_batch;
     DevBuf<double> d_eskf_partial;  // [(cap + 255) / 256][kEskfOutSize]
     PinnedBuf<double> h_eskf_out;   // [kEskfOutSize], written by k_eskf_reduce
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
@@ -506,59 +510,49 @@ int tc2li_eskf_predict(tc2li_imu_state* st, double* P529, const double* Q144, co
     return TC2LI_OK;
 }
 
-// esekf::update_iterated_dyn_share_modified with h_share_model as the measurement model (esekfom.hpp:1621-1932,
-// LidarFrontEnd.cpp:485-602): neighbour search / plane fit / selection and the normal equations of the measurement rows on the
-// device, the 23 x 23 algebra of the iteration on the host.
-int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n, tc2li_imu_state* x, double* P529,
-                            double R, int maximum_iter, const double* limit23, int extrinsic_est_en, tc2li_eskf_stats* stats) {
-    using namespace eskf;
-    if (!L || !map || n < 0 || (n > 0 && !feats_down_body) || !x || !P529 || !(R > 0) || maximum_iter < 0 || !limit23) {
-        set_error("tc2li_lidar_eskf_update: invalid argument");
-        return TC2LI_ERR_INVALID;
-    }
-    if (stats) memset(stats, 0, sizeof(*stats));
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    if (n == 0) return 0;
-    hipStream_t ps = private_stream();
-    std::lock_guard<std::mutex> lock(map->mu);
-    int rc = setup_segments(L, 1, &n, ps);
-    if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(copy_sync(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
-    TC2LI_HIP_CHECK(copy_sync(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
-    TC2LI_HIP_CHECK(L->d_eskf_partial.ensure((size_t)((n + 255) / 256) * kEskfOutSize));
-    TC2LI_HIP_CHECK(L->h_eskf_out.ensure(kEskfOutSize));
-    L->last_down.assign(1, n);
-    const PointXYZINormal* body = reinterpret_cast<const PointXYZINormal*>(feats_down_body);
+}  // extern "C"
 
-    const tc2li_imu_state x_propagated = *x;
-    Cov P_propagated;
-    memcpy(P_propagated.a, P529, sizeof(P_propagated.a));
-    Cov P = P_propagated, K_x = Cov::zero();
-    double K_h[kN] = {0}, dx_new[kN] = {0};
+namespace {
+// The host side of one iterated update (esekf::update_iterated_dyn_share_modified, esekfom.hpp:1621-1932): everything between two
+// evaluations of h_share_model.  One object per scan; the one-scan entry point and the batch drive it with the same calls, so a scan
+// gives the same state alone and in a batch.
+struct EskfRun {
+    tc2li_imu_state* x = nullptr;
+    double* P529 = nullptr;
+    tc2li_imu_state x_propagated;
+    eskf::Cov P_propagated, P, K_x;
+    double K_h[eskf::kN] = {0}, dx_new[eskf::kN] = {0};
     bool converge = true;
-    int t = 0, calls = 0, searches = 0, effct = 0;
+    int t = 0, calls = 0, searches = 0, effct = 0, finished = 0, rc = 0;
     double res_mean = 0;
-    const int so3_idx[2] = {3, 6};
-    for (int i = -1; i < maximum_iter; i++) {
-        // ---- h_share_model at the current state ----
+    bool done = false;
+
+    void begin(tc2li_imu_state* x_, double* P_) {
+        x = x_; P529 = P_;
+        x_propagated = *x;
+        memcpy(P_propagated.a, P529, sizeof(P_propagated.a));
+        P = P_propagated; K_x = eskf::Cov::zero();
+    }
+    tc2li_lidar_state lidar_state() const {
         tc2li_lidar_state ls;
         memcpy(ls.rot, x->rot, 72); memcpy(ls.pos, x->pos, 24); memcpy(ls.offset_R_L_I, x->offset_R_L_I, 72); memcpy(ls.offset_T_L_I, x->offset_T_L_I, 24);
-        if (converge) {
-            rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, &ls, ps);
-            if (rc != TC2LI_OK) return rc;
-            ++searches;
-        } else {
-            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, &ls, sizeof(LidarStateDev), hipMemcpyHostToDevice, ps));
-            launch_eskf_refit(map->grid, L->d_down.p, n, L->d_states.p, L->d_nearest_idx.p, L->d_world.p, L->d_selected.p, L->d_normvec.p, ps);
-        }
-        launch_eskf_normal(L->d_down.p, n, L->d_states.p, L->d_selected.p, L->d_normvec.p, extrinsic_est_en, L->d_eskf_partial.p, L->h_eskf_out.p, ps);
-        TC2LI_HIP_CHECK(hipGetLastError());
-        TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
+        return ls;
+    }
+    void write_stats(tc2li_eskf_stats* stats) const {
+        if (!stats) return;
+        stats->calls = calls; stats->effct_feat_num = effct; stats->searches = searches; stats->converged = t; stats->finished = finished; stats->res_mean_last = res_mean;
+    }
+    // After the evaluation of iteration i (i = -1 .. maximum_iter - 1): o = H^T H (144) | H^T h (12) | sum |pd2| | rows.  rows_of(sel, nv)
+    // fetches the scan's selection flags and normal vectors (only when there are fewer rows than states).  Sets `done` when the loop
+    // of the reference has ended (covariance update, or the last iteration); rc < 0 on a singular matrix.
+    template <class Fetch>
+    void step(int i, int maximum_iter, const double* o, int n, const PointXYZINormal* body, double R, const double* limit23, int extrinsic_est_en, Fetch&& rows_of) {
+        using namespace eskf;
+        const int so3_idx[2] = {3, 6};
         ++calls;
-        const double* o = L->h_eskf_out.p;
         const int M = (int)o[157];
         effct = M;
-        if (M < 1) continue;  // ekfom_data.valid = false
+        if (M >= 1) {
         res_mean = o[156] / M;
         // ---- the iteration (esekfom.hpp:1653-1800) ----
         double dx[kN];
@@ -585,8 +579,7 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
             // fewer rows than states: K = P Hc^T (Hc P Hc^T / R + I)^-1 / R on the explicit rows (at most 22 of them)
             std::vector<uint8_t> sel(n);
             std::vector<PointXYZINormal> nv(n);
-            TC2LI_HIP_CHECK(copy_sync(sel.data(), L->d_selected.p, n, hipMemcpyDeviceToHost, ps));
-            TC2LI_HIP_CHECK(copy_sync(nv.data(), L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
+            if (!rows_of(sel.data(), nv.data())) { rc = TC2LI_ERR_HIP; done = true; return; }
             std::vector<double> H((size_t)M * 12, 0.0), h(M), PHt((size_t)kN * M), S((size_t)M * M), Si((size_t)M * M), K((size_t)kN * M);
             const M3 Rw = m3_from(x->rot), Ro = m3_from(x->offset_R_L_I);
             int k = 0;
@@ -607,26 +600,26 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
                 h[k] = -(double)nv[p].intensity;
                 ++k;
             }
-            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < 12; ++q) s += P(r, q) * H[(size_t)c * 12 + q]; PHt[(size_t)r * M + c] = s; }
-            for (int r = 0; r < M; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < 12; ++q) s += H[(size_t)r * 12 + q] * PHt[(size_t)q * M + c]; S[(size_t)r * M + c] = s / R + (r == c ? 1.0 : 0.0); }
-            if (!lu_inverse(S.data(), M, Si.data())) { set_error("tc2li_lidar_eskf_update: singular innovation matrix"); return TC2LI_ERR_INVALID; }
-            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s = 0; for (int q = 0; q < M; ++q) s += PHt[(size_t)r * M + q] * Si[(size_t)q * M + c]; K[(size_t)r * M + c] = s / R; }
-            for (int r = 0; r < kN; ++r) { double s = 0; for (int q = 0; q < M; ++q) s += K[(size_t)r * M + q] * h[q]; K_h[r] = s; }
-            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s = 0; for (int q = 0; q < M; ++q) s += K[(size_t)r * M + q] * H[(size_t)q * 12 + c]; K_x(r, c) = s; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s_ = 0; for (int q = 0; q < 12; ++q) s_ += P(r, q) * H[(size_t)c * 12 + q]; PHt[(size_t)r * M + c] = s_; }
+            for (int r = 0; r < M; ++r) for (int c = 0; c < M; ++c) { double s_ = 0; for (int q = 0; q < 12; ++q) s_ += H[(size_t)r * 12 + q] * PHt[(size_t)q * M + c]; S[(size_t)r * M + c] = s_ / R + (r == c ? 1.0 : 0.0); }
+            if (!lu_inverse(S.data(), M, Si.data())) { set_error("tc2li_lidar_eskf_update: singular innovation matrix"); rc = TC2LI_ERR_INVALID; done = true; return; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < M; ++c) { double s_ = 0; for (int q = 0; q < M; ++q) s_ += PHt[(size_t)r * M + q] * Si[(size_t)q * M + c]; K[(size_t)r * M + c] = s_ / R; }
+            for (int r = 0; r < kN; ++r) { double s_ = 0; for (int q = 0; q < M; ++q) s_ += K[(size_t)r * M + q] * h[q]; K_h[r] = s_; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s_ = 0; for (int q = 0; q < M; ++q) s_ += K[(size_t)r * M + q] * H[(size_t)q * 12 + c]; K_x(r, c) = s_; }
         } else {
             Cov PR, P_temp, P_inv;
             for (int k = 0; k < kN * kN; ++k) PR.a[k] = P.a[k] / R;
-            if (!lu_inverse(PR.a, kN, P_temp.a)) { set_error("tc2li_lidar_eskf_update: singular covariance"); return TC2LI_ERR_INVALID; }
+            if (!lu_inverse(PR.a, kN, P_temp.a)) { set_error("tc2li_lidar_eskf_update: singular covariance"); rc = TC2LI_ERR_INVALID; done = true; return; }
             for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c) P_temp(r, c) += o[12 * r + c];
-            if (!lu_inverse(P_temp.a, kN, P_inv.a)) { set_error("tc2li_lidar_eskf_update: singular information matrix"); return TC2LI_ERR_INVALID; }
-            for (int r = 0; r < kN; ++r) { double s = 0; for (int k = 0; k < 12; ++k) s += P_inv(r, k) * o[144 + k]; K_h[r] = s; }
-            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s = 0; for (int k = 0; k < 12; ++k) s += P_inv(r, k) * o[12 * k + c]; K_x(r, c) = s; }
+            if (!lu_inverse(P_temp.a, kN, P_inv.a)) { set_error("tc2li_lidar_eskf_update: singular information matrix"); rc = TC2LI_ERR_INVALID; done = true; return; }
+            for (int r = 0; r < kN; ++r) { double s_ = 0; for (int k = 0; k < 12; ++k) s_ += P_inv(r, k) * o[144 + k]; K_h[r] = s_; }
+            for (int r = 0; r < kN; ++r) for (int c = 0; c < 12; ++c) { double s_ = 0; for (int k = 0; k < 12; ++k) s_ += P_inv(r, k) * o[12 * k + c]; K_x(r, c) = s_; }
         }
         double dx_[kN];
         for (int r = 0; r < kN; ++r) {
-            double s = K_h[r];
-            for (int c = 0; c < kN; ++c) s += (K_x(r, c) - (r == c ? 1.0 : 0.0)) * dx_new[c];
-            dx_[r] = s;
+            double s_ = K_h[r];
+            for (int c = 0; c < kN; ++c) s_ += (K_x(r, c) - (r == c ? 1.0 : 0.0)) * dx_new[c];
+            dx_[r] = s_;
         }
         boxplus(*x, dx_);
         converge = true;
@@ -659,17 +652,274 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
             }
             for (int r = 0; r < kN; ++r)
                 for (int c = 0; c < kN; ++c) {
-                    double s = 0;
-                    for (int k = 0; k < 12; ++k) s += K_x(r, k) * P(k, c);
-                    P529[r * kN + c] = Lm(r, c) - s;
+                    double s_ = 0;
+                    for (int k = 0; k < 12; ++k) s_ += K_x(r, k) * P(k, c);
+                    P529[r * kN + c] = Lm(r, c) - s_;
                 }
-            if (stats) { stats->calls = calls; stats->effct_feat_num = effct; stats->searches = searches; stats->converged = t; stats->finished = 1; stats->res_mean_last = res_mean; }
-            return effct;
+            finished = 1;
+            done = true;
+            return;
+        }
+        }  // M >= 1 (otherwise ekfom_data.valid = false: the iteration is skipped)
+        if (i == maximum_iter - 1) {  // the loop ends without the covariance update
+            memcpy(P529, P.a, sizeof(P.a));
+            done = true;
         }
     }
-    memcpy(P529, P.a, sizeof(P.a));
-    if (stats) { stats->calls = calls; stats->effct_feat_num = effct; stats->searches = searches; stats->converged = t; stats->finished = 0; stats->res_mean_last = res_mean; }
-    return effct;
+};
+}  // namespace
+
+extern "C" {
+
+// esekf::update_iterated_dyn_share_modified with h_share_model as the measurement model (esekfom.hpp:1621-1932,
+// LidarFrontEnd.cpp:485-602): neighbour search / plane fit / selection and the normal equations of the measurement rows on the
+// device, the 23 x 23 algebra of the iteration on the host (EskfRun).
+int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n, tc2li_imu_state* x, double* P529,
+                            double R, int maximum_iter, const double* limit23, int extrinsic_est_en, tc2li_eskf_stats* stats) {
+    if (!L || !map || n < 0 || (n > 0 && !feats_down_body) || !x || !P529 || !(R > 0) || maximum_iter < 0 || !limit23) {
+        set_error("tc2li_lidar_eskf_update: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    if (n == 0) return 0;
+    hipStream_t ps = private_stream();
+    std::lock_guard<std::mutex> lock(map->mu);
+    int rc = setup_segments(L, 1, &n, ps);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(copy_sync(L->d_down.p, feats_down_body, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_down_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(L->d_eskf_partial.ensure((size_t)((n + 255) / 256) * kEskfOutSize));
+    TC2LI_HIP_CHECK(L->h_eskf_out.ensure(kEskfOutSize));
+    L->last_down.assign(1, n);
+    const PointXYZINormal* body = reinterpret_cast<const PointXYZINormal*>(feats_down_body);
+    EskfRun run;
+    run.begin(x, P529);
+    for (int i = -1; i < maximum_iter && !run.done; i++) {
+        // ---- h_share_model at the current state ----
+        const tc2li_lidar_state ls = run.lidar_state();
+        if (run.converge) {
+            rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, &ls, ps);
+            if (rc != TC2LI_OK) return rc;
+            ++run.searches;
+        } else {
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, &ls, sizeof(LidarStateDev), hipMemcpyHostToDevice, ps));
+            launch_eskf_refit(map->grid, L->d_down.p, n, L->d_states.p, L->d_nearest_idx.p, L->d_world.p, L->d_selected.p, L->d_normvec.p, ps);
+        }
+        launch_eskf_normal(L->d_down.p, n, L->d_states.p, L->d_selected.p, L->d_normvec.p, extrinsic_est_en, L->d_eskf_partial.p, L->h_eskf_out.p, ps);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
+        run.step(i, maximum_iter, L->h_eskf_out.p, n, body, R, limit23, extrinsic_est_en, [&](uint8_t* sel, PointXYZINormal* nv) {
+            return copy_sync(sel, L->d_selected.p, n, hipMemcpyDeviceToHost, ps) == hipSuccess &&
+                   copy_sync(nv, L->d_normvec.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps) == hipSuccess;
+        });
+        if (run.rc < 0) return run.rc;
+    }
+    if (!run.done) memcpy(P529, run.P.a, sizeof(run.P.a));  // maximum_iter = 0: no evaluation
+    run.write_stats(stats);
+    return run.effct;
+}
+
+}  // extern "C"
+namespace {
+WorkerPool& lidar_pool() { static WorkerPool* p = new WorkerPool(16); return *p; }
+}  // namespace
+extern "C" {
+
+int tc2li_device_time_sort(tc2li_lidar* L, const tc2li_point* points, int n, int depth_limit, int32_t* perm) {
+    if (!L || n < 0 || (n > 0 && (!points || !perm))) { set_error("tc2li_device_time_sort: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n == 0) return 0;
+    hipStream_t ps = private_stream();
+    int rc = setup_segments(L, 1, &n, ps);
+    if (rc != TC2LI_OK) return rc;
+    const size_t T = L->total;
+    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(L->max_scans));
+    TC2LI_HIP_CHECK(copy_sync(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
+    TC2LI_HIP_CHECK(copy_sync(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
+    launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, 1, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, depth_limit, ps);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    int fb = 0;
+    TC2LI_HIP_CHECK(copy_sync(&fb, L->d_sort_fallback.p, sizeof(int), hipMemcpyDeviceToHost, ps));
+    TC2LI_HIP_CHECK(copy_sync(perm, L->d_perm.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ps));
+    return fb;
+}
+
+// LidarInertialProcess for a batch of sequences (LidarFrontEnd.cpp:615-785: sync_packages -> ImuProcess::Process (forward propagation,
+// UndistortPcl) -> VoxelGrid -> update_iterated_dyn_share_modified with h_share_model): one launch per phase for all scans, the scans'
+// iterated updates in lock step (an iteration's neighbour search for the scans whose last step converged, the re-evaluation of the kept
+// neighbours for the others, the normal equations of all of them; then the 23 x 23 algebra of every scan on the host pool).  Same
+// kernels bodies and host steps as the one-scan entry points: a scan gives the same state alone and in a batch.
+int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
+                                        int point_filter_num, double blind, float time_unit_scale, float leaf, tc2li_lidar_map* const* maps,
+                                        tc2li_lidar_inertial_scan* scans, const double cov12[12], double R, int maximum_iter, const double* limit23,
+                                        int extrinsic_est_en, void* stream_) {
+    using namespace eskf;
+    if (!L || n_scans < 0 || n_scans > (L ? L->max_scans : 0) || !dev_raw || !raw_offsets || !maps || !scans || !cov12 || point_filter_num < 1 ||
+        !(leaf > 0) || !(R > 0) || maximum_iter < 0 || !limit23) {
+        set_error("tc2li_lidar_inertial_frontend_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_scans == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    for (int s = 0; s < n_scans; ++s) {
+        if (!maps[s] || !scans[s].P || scans[s].n_imu < 1 || !scans[s].imu) { set_error("tc2li_lidar_inertial_frontend_batch: scan %d: NULL map / P / IMU samples", s); return TC2LI_ERR_INVALID; }
+        if (scans[s].n_imu + 1 > kMaxImuPoses) { set_error("more than %d IMU poses in one scan", kMaxImuPoses); return TC2LI_ERR_CAPACITY; }
+        memset(&scans[s].stats, 0, sizeof(scans[s].stats));
+        scans[s].n_preprocessed = scans[s].n_downsampled = 0;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    MapLocks locks(maps, n_scans);
+    const int S = n_scans;
+    const size_t T = L->total;
+    // ---- Preprocess::process of every raw scan (device; the host propagates meanwhile) ----
+    std::vector<int> upper(S);
+    for (int s = 0; s < S; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
+    int rc = setup_segments(L, S, upper.data(), st, raw_offsets);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
+    if (rc != TC2LI_OK) return rc;
+    // ---- work space of the batch (allocated on first use) ----
+    const size_t rows = T / 256;
+    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_imu_poses.ensure((size_t)L->max_scans * kMaxImuPoses));
+    TC2LI_HIP_CHECK(L->d_n_poses.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_scan_list.ensure(L->max_scans));
+    TC2LI_HIP_CHECK(L->d_blocks_a.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_b.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_c.ensure(T / kSegBlock));
+    TC2LI_HIP_CHECK(L->d_eskf_partial.ensure(rows * kEskfOutSize)); TC2LI_HIP_CHECK(L->h_eskf_out.ensure((size_t)L->max_scans * kEskfOutSize));
+    TC2LI_HIP_CHECK(L->h_batch.ensure((size_t)L->max_scans * (kMaxImuPoses * sizeof(Pose6DDev) + sizeof(LidarStateDev) + 4 * sizeof(int)) + 3 * (T / kSegBlock) * sizeof(SegBlock)));
+    // pinned staging: [poses S x 64][states S][n_poses S][fallback S][scan list S][block lists 3 x NB]
+    uint8_t* hb = L->h_batch.p;
+    Pose6DDev* h_poses = (Pose6DDev*)hb; hb += (size_t)L->max_scans * kMaxImuPoses * sizeof(Pose6DDev);
+    LidarStateDev* h_states = (LidarStateDev*)hb; hb += (size_t)L->max_scans * sizeof(LidarStateDev);
+    int* h_n_poses = (int*)hb; hb += (size_t)L->max_scans * sizeof(int);
+    int* h_fallback = (int*)hb; hb += (size_t)L->max_scans * sizeof(int);
+    int* h_scan_list = (int*)hb; hb += (size_t)L->max_scans * 2 * sizeof(int);
+    SegBlock* h_blocks_a = (SegBlock*)hb; SegBlock* h_blocks_b = h_blocks_a + T / kSegBlock; SegBlock* h_blocks_c = h_blocks_b + T / kSegBlock;
+    // ---- forward propagation of every sequence on the host (IMU_Processing.cpp:176-233; esekf::predict with the covariance) ----
+    Mat<kW, kW> Q = Mat<kW, kW>::zero();
+    for (int k = 0; k < kW; ++k) Q(k, k) = cov12[k];
+    std::vector<int> prc(S, 0);
+    lidar_pool().parallel_for(S, [&](int s) {
+        tc2li_lidar_inertial_scan& sc = scans[s];
+        Cov P;
+        memcpy(P.a, sc.P, sizeof(P.a));
+        static_assert(sizeof(tc2li_imu_pose6d) == sizeof(Pose6DDev), "ABI layout");
+        const int np = imu_propagate_impl(&sc.state, &P, &Q, sc.imu, sc.n_imu, sc.pcl_beg_time, sc.pcl_end_time, sc.last_lidar_end_time, sc.acc_scale,
+                                          sc.acc_s_last, sc.angvel_last, reinterpret_cast<tc2li_imu_pose6d*>(h_poses + (size_t)s * kMaxImuPoses), kMaxImuPoses);
+        prc[s] = np;
+        if (np < 0) return;
+        memcpy(sc.P, P.a, sizeof(P.a));
+        h_n_poses[s] = np;
+        memcpy(h_states[s].rot, sc.state.rot, 72); memcpy(h_states[s].pos, sc.state.pos, 24);
+        memcpy(h_states[s].off_r, sc.state.offset_R_L_I, 72); memcpy(h_states[s].off_t, sc.state.offset_T_L_I, 24);
+    });
+    for (int s = 0; s < S; ++s) if (prc[s] < 0) return prc[s];
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_imu_poses.p, h_poses, (size_t)S * kMaxImuPoses * sizeof(Pose6DDev), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_n_poses.p, h_n_poses, S * sizeof(int), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, h_states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
+    // ---- UndistortPcl: the time sort (std::sort's permutation, replayed on the device) and the compensation ----
+    const char* depth_env = getenv("TC2LI_TEST_SORT_DEPTH");  // tests: a small depth limit sends scans through the host fallback
+    launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, S, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, depth_env ? atoi(depth_env) : -1, st);
+    int* hc = L->h_counts.p;
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(h_fallback, L->d_sort_fallback.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    for (int s = 0; s < S; ++s) {
+        scans[s].n_preprocessed = hc[s];
+        if (!h_fallback[s]) continue;
+        // the recursion reached std::sort's depth limit (heap sort there): this scan is sorted on the host, like tc2li_lidar_undistort
+        const int n = hc[s];
+        std::vector<PointXYZINormal> pts(n);
+        TC2LI_HIP_CHECK(copy_sync(pts.data(), L->d_pre.p + (size_t)s * L->cap, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
+        struct Rec { float t; int idx; };
+        std::vector<Rec> rec(n);
+        for (int i = 0; i < n; ++i) rec[i] = Rec{pts[i].curvature, i};
+        std::sort(rec.begin(), rec.end(), [](const Rec& a, const Rec& b) { return a.t < b.t; });
+        std::vector<int> perm(n);
+        for (int i = 0; i < n; ++i) perm[i] = rec[i].idx;
+        TC2LI_HIP_CHECK(copy_sync(L->d_perm.p + (size_t)s * L->cap, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    // the compensated scans land in d_cloud_ori (free until a selection is compacted), the voxel filter reads them there
+    launch_undistort_batch(L->d_pre.p, L->d_perm.p, L->d_pre_count.p, L->d_slots.p, L->d_blocks.p, (int)L->blocks.size(), L->d_imu_poses.p, L->d_n_poses.p,
+                           L->d_states.p, L->d_cloud_ori.p, st);
+    rc = run_voxel(L, L->d_cloud_ori.p, L->d_pre_count.p, leaf, st);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc + S, L->d_down_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * S, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    if (hc[3 * S]) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), st)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
+    L->last_down.assign(hc + S, hc + 2 * S);
+    L->last_sel.assign(S, 0);
+    L->timed = false;
+    // ---- the iterated update, all scans in lock step ----
+    std::vector<MapGrid> grids(S);
+    for (int s = 0; s < S; ++s) grids[s] = maps[s]->grid;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_grids.p, grids.data(), S * sizeof(MapGrid), hipMemcpyHostToDevice, st));
+    std::vector<EskfRun> run(S);
+    std::vector<int> nd(S);
+    for (int s = 0; s < S; ++s) {
+        nd[s] = hc[S + s];
+        scans[s].n_downsampled = nd[s];
+        run[s].begin(&scans[s].state, scans[s].P);
+        if (nd[s] == 0) run[s].done = true;  // tc2li_lidar_eskf_update returns at once for an empty scan
+    }
+    std::vector<int> act, search, refit;
+    for (int i = -1; i < maximum_iter; ++i) {
+        act.clear(); search.clear(); refit.clear();
+        for (int s = 0; s < S; ++s) if (!run[s].done) { act.push_back(s); (run[s].converge ? search : refit).push_back(s); }
+        if (act.empty()) break;
+        int na = 0, nb = 0, nc = 0;
+        for (int s : act) {
+            const tc2li_lidar_state ls = run[s].lidar_state();
+            memcpy(&h_states[s], &ls, sizeof(LidarStateDev));
+            const int blocks_of = (nd[s] + kSegBlock - 1) / kSegBlock;
+            for (int b = 0; b < blocks_of; ++b) {
+                const SegBlock sb{s, b * kSegBlock};
+                h_blocks_c[nc++] = sb;
+                if (run[s].converge) h_blocks_a[na++] = sb; else h_blocks_b[nb++] = sb;
+            }
+        }
+        for (size_t k = 0; k < act.size(); ++k) h_scan_list[k] = act[k];
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, h_states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_scan_list.p, h_scan_list, act.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        if (na) TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks_a.p, h_blocks_a, na * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+        if (nb) TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks_b.p, h_blocks_b, nb * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks_c.p, h_blocks_c, nc * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+        if (na)
+            launch_knn_plane(L->d_grids.p, L->d_down.p, L->d_down_count.p, L->d_slots.p, L->d_blocks_a.p, na, L->d_states.p, L->d_world.p, L->d_selected.p,
+                             L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, L->d_hard_count.p, L->d_hard_list.p, st);
+        launch_eskf_refit_batch(L->d_grids.p, L->d_down.p, L->d_down_count.p, L->d_slots.p, L->d_blocks_b.p, nb, L->d_states.p, L->d_nearest_idx.p,
+                                L->d_world.p, L->d_selected.p, L->d_normvec.p, st);
+        launch_eskf_normal_batch(L->d_down.p, L->d_down_count.p, L->d_slots.p, L->d_blocks_c.p, nc, L->d_states.p, L->d_selected.p, L->d_normvec.p,
+                                 extrinsic_est_en, L->d_eskf_partial.p, L->d_scan_list.p, (int)act.size(), L->h_eskf_out.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        for (int s : search) ++run[s].searches;
+        lidar_pool().parallel_for((int)act.size(), [&](int k) {
+            const int s = act[k];
+            EskfRun& r = run[s];
+            const size_t base = (size_t)s * L->cap;
+            std::vector<PointXYZINormal> body;  // only fetched when there are fewer rows than states
+            const double* o = L->h_eskf_out.p + (size_t)s * kEskfOutSize;
+            if ((int)o[157] >= 1 && (int)o[157] < kN) {
+                body.resize(nd[s]);
+                if (copy_sync(body.data(), L->d_down.p + base, (size_t)nd[s] * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, private_stream()) != hipSuccess) { r.rc = TC2LI_ERR_HIP; r.done = true; return; }
+            }
+            r.step(i, maximum_iter, o, nd[s], body.data(), R, limit23, extrinsic_est_en, [&](uint8_t* sel, PointXYZINormal* nv) {
+                hipStream_t ps = private_stream();
+                return copy_sync(sel, L->d_selected.p + base, nd[s], hipMemcpyDeviceToHost, ps) == hipSuccess &&
+                       copy_sync(nv, L->d_normvec.p + base, (size_t)nd[s] * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps) == hipSuccess;
+            });
+        });
+        for (int s : act) if (run[s].rc < 0) return run[s].rc;
+    }
+    for (int s = 0; s < S; ++s) {
+        if (!run[s].done && nd[s] > 0) memcpy(scans[s].P, run[s].P.a, sizeof(run[s].P.a));  // maximum_iter = 0
+        run[s].write_stats(&scans[s].stats);
+    }
+    return n_scans;
 }
 
 int tc2li_lidar_map_create(tc2li_lidar_map** out) {

@@ -483,6 +483,206 @@ void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const P
     if (n) TC2LI_LAUNCH(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, n, poses, n_poses, end, out);
 }
 
+// ---- b2, batched: the time sort of ImuProcess::UndistortPcl (IMU_Processing.cpp:170-172) on the device ------------------------------
+// sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) is std::sort: not stable, and the order it leaves equal time stamps in
+// is part of the reference's result (the voxel filter sums in point order; the 64 beams of a spinning LiDAR share every time stamp).
+// libstdc++'s std::sort = introsort: while a range is longer than 16 -- median of (first + 1, middle, last - 1) swapped to `first`, an
+// unguarded Hoare partition of (first, last) around it, recursion into [cut, last), loop on [first, cut) -- with a depth limit of
+// 2 floor(log2 n) (then heap sort), and one insertion sort over everything at the end.  Which elements end where depends only on the
+// outcomes of the comparisons, so the moves can be replayed level by level, all ranges of a recursion depth at once:
+//   * the k-th swap of a partition exchanges the k-th element from the left that is not smaller than the pivot with the k-th from the
+//     right that is not larger, while the former lies left of the latter: two prefix counts along the array give every element its k,
+//     a scatter by k pairs them, and the cut is min(first unswapped left candidate, last swapped right candidate);
+//   * the closing insertion sort never moves an element past an equal one, and no element has to cross a range boundary (left of a cut
+//     everything is <= the pivot <= everything right of it): it is a stable sort inside every final range of at most 16 elements.
+// One workgroup of 1024 threads per scan; the arrays live in global memory (L2-resident: ~36 bytes per point).  A scan whose
+// recursion reaches the depth limit (std::sort would heap-sort the range) is flagged; the host sorts that scan itself.
+constexpr int kSortThreads = 1024, kSortWaves = kSortThreads / 64;
+struct TimeSortArrays { float* key; int *idx, *sf, *sl, *cl, *cr, *lp, *rp, *cut; uint8_t* flag; };
+
+__global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                            const ScanSlot* __restrict__ slots, TimeSortArrays A, int* __restrict__ perm,
+                                                            int* __restrict__ fallback, int depth_override) {
+    __shared__ int s_tot[2][kSortWaves], s_base[2][kSortWaves + 1], s_any;
+    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ScanSlot sl_ = slots[scan];
+    const int n = count[scan], B = sl_.base;
+    float* const key = A.key + B;
+    int *const idx = A.idx + B, *const sf = A.sf + B, *const sl = A.sl + B, *const cl = A.cl + B, *const cr = A.cr + B, *const lp = A.lp + B,
+        *const rp = A.rp + B, *const cut = A.cut + B;
+    uint8_t* const flag = A.flag + B;
+    if (tid == 0) fallback[scan] = 0;
+    if (n <= 0) return;
+    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; sf[x] = 0; sl[x] = n; }
+    int depth = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
+    // contiguous ranges of the wavefronts for the prefix counts: C elements each, a multiple of 64
+    const int C = ((n + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
+    bool any = n > 16;
+    __syncthreads();
+    while (any) {
+        if (depth == 0) { if (tid == 0) fallback[scan] = 1; break; }
+        --depth;
+        // ---- pivots: __move_median_to_first(first, first + 1, mid, last - 1) ----
+        for (int x = tid; x < n; x += kSortThreads) {
+            if (sf[x] != x) continue;
+            const int last = sl[x];
+            if (last - x <= 16) continue;
+            const int a = x + 1, b = x + (last - x) / 2, c = last - 1;
+            const float ka = key[a], kb = key[b], kc = key[c];
+            int m;
+            if (ka < kb) m = kb < kc ? b : (ka < kc ? c : a);
+            else m = ka < kc ? a : (kb < kc ? c : b);
+            const float kf = key[x], km = key[m];
+            const int jf = idx[x], jm = idx[m];
+            key[x] = km; idx[x] = jm; key[m] = kf; idx[m] = jf;
+        }
+        __syncthreads();
+        // ---- candidates of the partitions and their prefix counts along the array ----
+        {
+            int run_l = 0, run_r = 0;
+            const int x0 = wave * C, x1 = min(x0 + C, n);
+            for (int xb = x0; xb < x1; xb += 64) {
+                const int x = xb + lane;
+                bool fl = false, fr = false;
+                if (x < x1) {
+                    const int f = sf[x];
+                    if (sl[x] - f > 16 && x != f) {
+                        const float p = key[f], k = key[x];
+                        fl = !(k < p);
+                        fr = !(p < k);
+                    }
+                }
+                const unsigned long long bl = __ballot(fl), br = __ballot(fr), le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                if (x < x1) {
+                    cl[x] = run_l + __popcll(bl & le);
+                    cr[x] = run_r + __popcll(br & le);
+                    flag[x] = (uint8_t)((fl ? 1 : 0) | (fr ? 2 : 0));
+                }
+                run_l += __popcll(bl);
+                run_r += __popcll(br);
+            }
+            if (lane == 0) { s_tot[0][wave] = run_l; s_tot[1][wave] = run_r; }
+        }
+        __syncthreads();
+        if (tid < 2) {
+            int acc = 0;
+            for (int w = 0; w < kSortWaves; ++w) { s_base[tid][w] = acc; acc += s_tot[tid][w]; }
+            s_base[tid][kSortWaves] = acc;
+        }
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+#define TS_GL(x) (cl[x] + s_base[0][(x) / C])
+#define TS_GR(x) (cr[x] + s_base[1][(x) / C])
+        // ---- candidates by rank: lp[f + 1 + k] = k-th from the left, rp[f + 1 + k] = k-th from the right ----
+        for (int x = tid; x < n; x += kSortThreads) {
+            const int fg = flag[x];
+            if (!fg) continue;
+            const int f = sf[x], l = sl[x];
+            if (fg & 1) lp[f + 1 + (TS_GL(x) - TS_GL(f) - 1)] = x;
+            if (fg & 2) rp[f + 1 + (TS_GR(l - 1) - TS_GR(x))] = x;
+        }
+        __syncthreads();
+        // ---- the swaps and the cut ----
+        for (int x = tid; x < n; x += kSortThreads) {
+            const int f = sf[x], l = sl[x];
+            if (l - f <= 16 || x == f) continue;
+            const int k = x - (f + 1), nl = TS_GL(l - 1) - TS_GL(f), nr = TS_GR(l - 1) - TS_GR(f);
+            const int L = k < nl ? lp[x] : 0x7fffffff, R = k < nr ? rp[x] : -1;
+            if (L < R) {  // swap number k
+                const float k1 = key[L], k2 = key[R];
+                const int j1 = idx[L], j2 = idx[R];
+                key[L] = k2; idx[L] = j2; key[R] = k1; idx[R] = j1;
+            } else {
+                bool prev = k == 0;
+                int rprev = 0x7fffffff;
+                if (!prev) {
+                    const int Lp_ = k - 1 < nl ? lp[x - 1] : 0x7fffffff, Rp_ = k - 1 < nr ? rp[x - 1] : -1;
+                    prev = Lp_ < Rp_;
+                    rprev = Rp_;
+                }
+                if (prev) cut[f] = min(L, k >= 1 ? rprev : 0x7fffffff);  // the first k without a swap: __unguarded_partition returns here
+            }
+        }
+        __syncthreads();
+#undef TS_GL
+#undef TS_GR
+        // ---- the two ranges of every partition ----
+        bool mine = false;
+        for (int x = tid; x < n; x += kSortThreads) {
+            const int f = sf[x], l = sl[x];
+            if (l - f <= 16) continue;
+            const int c = cut[f];
+            int nf = f, nl_ = l;
+            if (x < c) nl_ = c; else nf = c;
+            sf[x] = nf; sl[x] = nl_;
+            mine |= nl_ - nf > 16;
+        }
+        if (mine) s_any = 1;
+        __syncthreads();
+        any = s_any != 0;
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- __final_insertion_sort: a stable sort inside every range ----
+    for (int x = tid; x < n; x += kSortThreads) {
+        const int f = sf[x], l = sl[x];
+        const float k = key[x];
+        int rank = 0;
+        if (l - f <= 16) {
+            for (int y = f; y < l; ++y) {
+                const float ky = key[y];
+                rank += (ky < k || (ky == k && y < x)) ? 1 : 0;
+            }
+            perm[B + f + rank] = idx[x];
+        } else {
+            perm[B + x] = idx[x];  // flagged for the host (depth limit)
+        }
+    }
+}
+
+// points[i] = in[perm[i]] compensated into the scan-end frame, every scan of a batch (ImuProcess::UndistortPcl, point part)
+__global__ __launch_bounds__(256) void k_undistort_batch(const PointXYZINormal* __restrict__ in, const int* __restrict__ perm, const int* __restrict__ count,
+                                                         const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                         const Pose6DDev* __restrict__ poses, const int* __restrict__ n_poses,
+                                                         const LidarStateDev* __restrict__ ends, PointXYZINormal* __restrict__ out) {
+    __shared__ Pose6DDev s_pose[kMaxImuPoses];
+    __shared__ LidarStateDev s_end;
+    const SegBlock b = blocks[blockIdx.x];
+    const ScanSlot sl = slots[b.scan];
+    const int n = count[b.scan], np_ = n_poses[b.scan];
+    const int i = b.start + blockIdx.y * 256 + threadIdx.x;
+    if (b.start + (int)blockIdx.y * 256 >= n) return;
+    for (int k = threadIdx.x; k < np_ * (int)(sizeof(Pose6DDev) / 8); k += 256) ((double*)s_pose)[k] = ((const double*)(poses + (size_t)b.scan * kMaxImuPoses))[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(LidarStateDev) / 8); k += 256) ((double*)&s_end)[k] = ((const double*)(ends + b.scan))[k];
+    __syncthreads();
+    if (i >= n) return;
+    PointXYZINormal p = in[sl.base + perm[sl.base + i]];
+    const double t = (double)p.curvature / double(1000);
+    int k = 0;  // interval: head = pose k - 1, tail = pose k; 0 = not compensated
+    for (int j = 1; j < np_; ++j) if (t > s_pose[j - 1].offset_time) k = j;
+    if (k > 0) {
+        double P[3] = {(double)p.x, (double)p.y, (double)p.z};
+        const int k_last = i == 0 ? 1 : k;
+        for (int j = k; j >= k_last; --j) {
+            undistort_once(s_pose[j - 1], s_pose[j], t - s_pose[j - 1].offset_time, s_end, P);
+            P[0] = (double)(float)P[0]; P[1] = (double)(float)P[1]; P[2] = (double)(float)P[2];  // stored in the float point between passes
+        }
+        p.x = (float)P[0]; p.y = (float)P[1]; p.z = (float)P[2];
+    }
+    out[sl.base + i] = p;
+}
+
+void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int n_scans, float* key, int* ints5, int* ints3, uint8_t* flag,
+                      size_t total, int* perm, int* fallback, int depth_override, hipStream_t st) {
+    if (!n_scans) return;
+    TimeSortArrays A{key, ints5, ints5 + total, ints5 + 2 * total, ints5 + 3 * total, ints5 + 4 * total, ints3, ints3 + total, ints3 + 2 * total, flag};
+    TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, depth_override);
+}
+void launch_undistort_batch(const PointXYZINormal* in, const int* perm, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                            const Pose6DDev* poses, const int* n_poses, const LidarStateDev* ends, PointXYZINormal* out, hipStream_t st) {
+    if (nblocks) TC2LI_LAUNCH(k_undistort_batch, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, in, perm, count, slots, blocks, poses, n_poses, ends, out);
+}
+
 // ---- b5: map spatial index (replaces the ikd-Tree as a dense uniform grid over the map's bounding box) ------------
 // Cells are ordered x-fastest, so the points of a run of cells along x are one contiguous range of the sorted array.
 // ---- b4 + b5 + b6: pointBodyToWorld, 5-NN, EstiPlane and the gates of feature_extraction --------------------------
@@ -889,13 +1089,10 @@ __global__ __launch_bounds__(256) void k_eskf_refit(const MapGrid grid, const Po
 // Rows of the measurement Jacobian (LidarFrontEnd.cpp:566-600) and their normal equations: per workgroup the partial sums of
 // H^T H (144), H^T h (12), sum |pd2| and the number of rows; summed over the workgroups in index order by k_eskf_reduce.
 constexpr int kEskfOut = 144 + 12 + 2;
-__global__ __launch_bounds__(256) void k_eskf_normal(const PointXYZINormal* __restrict__ body, int n, const LidarStateDev* __restrict__ state,
-                                                     const uint8_t* __restrict__ selected, const PointXYZINormal* __restrict__ normvec,
-                                                     int extrinsic_est_en, double* __restrict__ partial) {
-    __shared__ double s_row[256][13];
-    __shared__ float s_abs[256];
-    __shared__ int s_cnt[256];
-    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+__device__ __forceinline__ void eskf_normal_rows(const PointXYZINormal* __restrict__ body, int n, const LidarStateDev* __restrict__ state,
+                                                 const uint8_t* __restrict__ selected, const PointXYZINormal* __restrict__ normvec, int extrinsic_est_en,
+                                                 int i, double (*s_row)[13], float* s_abs, int* s_cnt, double* __restrict__ out) {
+    const int tid = threadIdx.x;
     double row[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) row[k] = 0.0;
@@ -946,8 +1143,17 @@ __global__ __launch_bounds__(256) void k_eskf_normal(const PointXYZINormal* __re
         } else {
             for (int k = 0; k < 256; ++k) acc += (double)s_cnt[k];
         }
-        partial[(size_t)blockIdx.x * kEskfOut + tid] = acc;
+        out[tid] = acc;
     }
+}
+__global__ __launch_bounds__(256) void k_eskf_normal(const PointXYZINormal* __restrict__ body, int n, const LidarStateDev* __restrict__ state,
+                                                     const uint8_t* __restrict__ selected, const PointXYZINormal* __restrict__ normvec,
+                                                     int extrinsic_est_en, double* __restrict__ partial) {
+    __shared__ double s_row[256][13];
+    __shared__ float s_abs[256];
+    __shared__ int s_cnt[256];
+    eskf_normal_rows(body, n, state, selected, normvec, extrinsic_est_en, blockIdx.x * 256 + threadIdx.x, s_row, s_abs, s_cnt,
+                     partial + (size_t)blockIdx.x * kEskfOut);
 }
 __global__ __launch_bounds__(256) void k_eskf_reduce(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
     const int tid = threadIdx.x;
@@ -955,6 +1161,53 @@ __global__ __launch_bounds__(256) void k_eskf_reduce(const double* __restrict__ 
     double acc = 0.0;
     for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * kEskfOut + tid];
     out[tid] = acc;
+}
+
+// ---- the same two kernels for the scans of a batch (tc2li_lidar_inertial_frontend_batch): a block list names the (scan, 1024-point
+// block) pairs taking part; partial sums of the normal equations at row (slot base + point) / 256, so that a scan's rows are summed in
+// the order of the one-scan kernels above (same bits) ----
+__global__ __launch_bounds__(256) void k_eskf_refit_b(const MapGrid* __restrict__ grids, const PointXYZINormal* __restrict__ body, const int* __restrict__ count,
+                                                      const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
+                                                      const LidarStateDev* __restrict__ states, const int* __restrict__ nearest_idx,
+                                                      PointXYZINormal* __restrict__ world, uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec) {
+    const SegBlock b = blocks[blockIdx.x];
+    const int i = b.start + blockIdx.y * 256 + threadIdx.x;
+    if (i >= count[b.scan]) return;
+    const size_t o = (size_t)slots[b.scan].base + i;
+    const PointXYZINormal pb = body[o];
+    const PointXYZINormal pw = body_to_world(pb, states[b.scan]);
+    world[o] = pw;
+    if (!selected[o]) return;
+    const int* ni = nearest_idx + o * 5;
+    const int ids[5] = {ni[0], ni[1], ni[2], ni[3], ni[4]};
+    PointXYZINormal nv;
+    const uint8_t sel = plane_gate(grids[b.scan].points, ids, pw, (double)pb.x, (double)pb.y, (double)pb.z, nv);
+    selected[o] = sel;
+    if (sel) normvec[o] = nv;
+}
+__global__ __launch_bounds__(256) void k_eskf_normal_b(const PointXYZINormal* __restrict__ body, const int* __restrict__ count, const ScanSlot* __restrict__ slots,
+                                                       const SegBlock* __restrict__ blocks, const LidarStateDev* __restrict__ states,
+                                                       const uint8_t* __restrict__ selected, const PointXYZINormal* __restrict__ normvec,
+                                                       int extrinsic_est_en, double* __restrict__ partial) {
+    __shared__ double s_row[256][13];
+    __shared__ float s_abs[256];
+    __shared__ int s_cnt[256];
+    const SegBlock b = blocks[blockIdx.x];
+    const int n = count[b.scan], i0 = b.start + blockIdx.y * 256;
+    if (i0 >= n) return;
+    const int base = slots[b.scan].base;
+    eskf_normal_rows(body + base, n, states + b.scan, selected + base, normvec + base, extrinsic_est_en, i0 + threadIdx.x, s_row, s_abs, s_cnt,
+                     partial + (size_t)((base + i0) / 256) * kEskfOut);
+}
+// one workgroup per listed scan: the scan's rows of `partial` in index order -> out[scan][kEskfOut] (pinned host memory)
+__global__ __launch_bounds__(256) void k_eskf_reduce_b(const double* __restrict__ partial, const int* __restrict__ count, const ScanSlot* __restrict__ slots,
+                                                       const int* __restrict__ scans, double* __restrict__ out) {
+    const int tid = threadIdx.x, scan = scans[blockIdx.x];
+    if (tid >= kEskfOut) return;
+    const int n = count[scan], r0 = slots[scan].base / 256, nb = (n + 255) / 256;
+    double acc = 0.0;
+    for (int b = 0; b < nb; ++b) acc += partial[(size_t)(r0 + b) * kEskfOut + tid];
+    out[(size_t)scan * kEskfOut + tid] = acc;
 }
 
 __global__ __launch_bounds__(kSegBlock) void k_sel_count(const uint8_t* __restrict__ selected, const int* __restrict__ count,
@@ -1062,6 +1315,17 @@ void launch_sel_scatter(const uint8_t* selected, const int* count, const ScanSlo
 void launch_eskf_refit(const MapGrid& grid, const PointXYZINormal* body, int n, const LidarStateDev* state, const int* nearest_idx,
                        PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec, hipStream_t st) {
     if (n) TC2LI_LAUNCH(k_eskf_refit, dim3((n + 255) / 256), dim3(256), 0, st, grid, body, n, state, nearest_idx, world, selected, normvec);
+}
+void launch_eskf_refit_batch(const MapGrid* grids, const PointXYZINormal* body, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                             const LidarStateDev* states, const int* nearest_idx, PointXYZINormal* world, uint8_t* selected, PointXYZINormal* normvec,
+                             hipStream_t st) {
+    if (nblocks) TC2LI_LAUNCH(k_eskf_refit_b, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, grids, body, count, slots, blocks, states, nearest_idx, world, selected, normvec);
+}
+void launch_eskf_normal_batch(const PointXYZINormal* body, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
+                              const LidarStateDev* states, const uint8_t* selected, const PointXYZINormal* normvec, int extrinsic_est_en, double* partial,
+                              const int* scans, int n_scans, double* out, hipStream_t st) {
+    if (nblocks) TC2LI_LAUNCH(k_eskf_normal_b, dim3(nblocks, kSegBlock / 256), dim3(256), 0, st, body, count, slots, blocks, states, selected, normvec, extrinsic_est_en, partial);
+    if (n_scans) TC2LI_LAUNCH(k_eskf_reduce_b, dim3(n_scans), dim3(256), 0, st, partial, count, slots, scans, out);
 }
 void launch_eskf_normal(const PointXYZINormal* body, int n, const LidarStateDev* state, const uint8_t* selected, const PointXYZINormal* normvec,
                         int extrinsic_est_en, double* partial, double* out, hipStream_t st) {
