@@ -680,6 +680,25 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const 
                                       tc2li_ba_stats* stats, const tc2li_lidar_window* lidar, const float* Tbl,
                                       tc2li_lidar_ba_stats* lidar_stats, void* stream);
 
+/* Many independent LocalLVIBA windows (the local-mapping threads of many sequences in the camera-LiDAR-inertial configuration): every
+ * problem is what one tc2li_local_lvi_bundle_adjustment call takes (same IMU calibration and camera for all).  With max_concurrency > 1
+ * the windows advance through the Levenberg-Marquardt phases in lock step like tc2li_local_bundle_adjustment_batch's -- one launch per
+ * kernel and one synchronisation per phase for all windows, the inertial edges and the dense reduced systems on host threads between
+ * the phases -- and every window's result is the one of the one-window call.  results[i] = iterations of window i or its error code;
+ * returns the number of windows that succeeded. */
+typedef struct tc2li_lvi_problem {
+    tc2li_inertial_keyframe* keyframes; const uint8_t* fixed; const uint8_t* has_imu;
+    double* points3; const tc2li_ba_edge* edges; const tc2li_inertial_link* links;
+    int32_t n_keyframes, n_points, n_edges, n_links, iterations, pad_;
+    double lambda_init;
+    const volatile uint8_t* stop_flag;
+    double* edge_chi2; uint8_t* edge_depth_positive;
+    tc2li_ba_stats* stats;
+    const tc2li_lidar_window* lidar; const float* Tbl; tc2li_lidar_ba_stats* lidar_stats;
+} tc2li_lvi_problem;
+int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib,
+                                            const tc2li_camera* cam, int max_concurrency, int32_t* results);
+
 /* ---- local mapping: new map points ----
  * What ORBmatcher::SearchForTriangulation (SF/src/ORBmatcher.cc:916) and the pair loop of LocalMapping::CreateNewMapPoints
  * (SF/src/LocalMapping.cc:402-726) read of a keyframe (pinhole camera, no second camera model). */

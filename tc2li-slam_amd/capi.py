@@ -1344,6 +1344,63 @@ def local_lvi_bundle_adjustment(kf33, fixed, has_imu, calib24, points3, edges, l
     return kf, pts, chi2[:len(edges)], dpos[:len(edges)], stats, lstats
 
 
+class LviProblem(C.Structure):
+    """tc2li_lvi_problem"""
+    _fields_ = [("keyframes", C.c_void_p), ("fixed", C.c_void_p), ("has_imu", C.c_void_p), ("points3", C.c_void_p), ("edges", C.c_void_p), ("links", C.c_void_p),
+                ("n_keyframes", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32), ("n_links", C.c_int32), ("iterations", C.c_int32), ("pad_", C.c_int32),
+                ("lambda_init", C.c_double), ("stop_flag", C.c_void_p), ("edge_chi2", C.c_void_p), ("edge_depth_positive", C.c_void_p), ("stats", C.c_void_p),
+                ("lidar", C.c_void_p), ("Tbl", C.c_void_p), ("lidar_stats", C.c_void_p)]
+
+
+class LviBatch:
+    """A set of independent ``LocalLVIBA`` windows prepared once and optimised together by ``tc2li_local_lvi_bundle_adjustment_batch``.
+    windows: dicts with kf33, fixed, has_imu, points, edges (BA_EDGE_DTYPE), link4, pre (list of Preintegrated) and optionally win_kf, clouds,
+    Tcl7, Tbl7, weight; iterations / lambda_init per window optional (10, 1.0)."""
+
+    def __init__(self, windows, calib24, cam5):
+        self.n = len(windows)
+        self.calib24, self.cam5 = np.ascontiguousarray(calib24, np.float64), np.ascontiguousarray(cam5, np.float64)
+        self.arr = (LviProblem * self.n)()
+        self.init, self.keep = [], []
+        self.stats = (BaStats * self.n)()
+        self.lstats = (LidarBaStats * self.n)()
+        self.results = np.zeros(self.n, np.int32)
+        for i, w in enumerate(windows):
+            kf0, pts0 = np.ascontiguousarray(w["kf33"], np.float64), np.ascontiguousarray(w["points"], np.float64)
+            kf, pts = kf0.copy(), pts0.copy()
+            fixed, has_imu = np.ascontiguousarray(w["fixed"], np.uint8), np.ascontiguousarray(w["has_imu"], np.uint8)
+            edges = np.ascontiguousarray(w["edges"], BA_EDGE_DTYPE)
+            link4 = np.ascontiguousarray(w["link4"], np.float64).reshape(-1, 4)
+            links = (InertialLink * max(len(link4), 1))()
+            for l, row in enumerate(link4):
+                links[l] = InertialLink(int(row[0]), int(row[1]), int(row[2] != 0), 0, float(row[3]), C.addressof(w["pre"][l].p))
+            chi2, dpos = np.zeros(max(len(edges), 1)), np.zeros(max(len(edges), 1), np.uint8)
+            lw, tbl = None, None
+            if w.get("win_kf") is not None:
+                lw = _pack_lidar_window(w["win_kf"], w["clouds"], w["Tcl7"], w.get("weight", 1.0))
+                tbl = np.ascontiguousarray(w["Tbl7"], np.float32)
+            self.init.append((kf0, pts0))
+            self.keep.append((kf, pts, fixed, has_imu, edges, links, chi2, dpos, lw, tbl, w["pre"]))
+            self.arr[i] = LviProblem(kf.ctypes.data, fixed.ctypes.data, has_imu.ctypes.data, pts.ctypes.data, edges.ctypes.data, C.addressof(links),
+                                     len(kf), len(pts), len(edges), len(link4), int(w.get("iterations", 10)), 0, float(w.get("lambda_init", 1.0)), None,
+                                     chi2.ctypes.data, dpos.ctypes.data, C.addressof(self.stats) + i * C.sizeof(BaStats),
+                                     C.addressof(lw[0]) if lw else None, tbl.ctypes.data if lw else None,
+                                     C.addressof(self.lstats) + i * C.sizeof(LidarBaStats))
+
+    def run(self, max_concurrency=8):
+        """Resets every window to its initial estimate and optimises all of them -> number of successful windows."""
+        for (k0, x0), k in zip(self.init, self.keep):
+            k[0][...] = k0
+            k[1][...] = x0
+        f = lib().tc2li_local_lvi_bundle_adjustment_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        return _check(f(C.addressof(self.arr), self.n, self.calib24.ctypes.data, self.cam5.ctypes.data, max_concurrency, self.results.ctypes.data))
+
+    def result(self, i):
+        k = self.keep[i]
+        return k[0], k[1], k[6][:len(k[4])], k[7][:len(k[4])], self.stats[i], self.lstats[i]
+
+
 def lidar_window_evaluate(poses7, win_pose, clouds, Tcl7, derivatives=True):
     """The LiDAR edge alone -> (n_planes, residual, JacT [6W], Hessian [6W, 6W]) (ComputeError / ComputeJandHSE3)."""
     poses = np.ascontiguousarray(poses7, np.float64)

@@ -43,7 +43,7 @@ struct BaWorkspace {
     DevBuf<uint8_t> d_depth;
     PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp, h_stat;
     DevBuf<ImuPose> d_iposes, d_iposes_trial;
-    PinnedBuf<ImuPose> h_iposes;
+    PinnedBuf<ImuPose> h_iposes, h_iposes_up;  // trial states on their way back; the initial states on their way up (lock-step batch)
     PinnedBuf<uint8_t> h_result;  // lock-step batch: poses, points, per-edge chi2 and depth flags on their way to the caller
     // lock-step batch with the reduced system solved on the device: S, [b_s | b_p], the step; the LiDAR term's Hessian | gradient on both sides
     DevBuf<double> d_S, d_bs, d_xp, d_Hl;
@@ -746,88 +746,49 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                             stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, stream);
 }
 
-static_assert(sizeof(tc2li_imu_calib) == sizeof(ImuCalib), "ABI layout");
+}  // extern "C"
 
-int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
-                                           const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges,
-                                           int n_edges, const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam,
-                                           int iterations, double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
-                                           uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
-    return tc2li_local_lvi_bundle_adjustment(kfs, fixed, has_imu, n_kfs, calib, points3, n_points, edges, n_edges, links, n_links, cam, iterations,
-                                             lambda_init, stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, nullptr, stream_);
-}
+namespace {
+// The inertial edges of a window (EdgeInertial + EdgeGyroRW + EdgeAccRW per link, SF/src/OptimizerWithLidar.cc:729-800) on the host:
+// their robust cost at a state and, when asked, their dense normal equations in the numbering [6 per free pose | 9 per free
+// keyframe with IMU state].  Shared by the one-window entry point and the lock-step batch.
+struct InertialTerm {
+    std::vector<InertialLinkHost> L;
+    std::vector<int> imu_var;
+    const std::vector<int>* pose_var = nullptr;
+    int np = 0, n = 0, n_imu = 0;
+    std::vector<double> Hi, bi;
+    double d_imu = 0;
+    float dsqr_imu = 0;
 
-int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
-                                      const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges, int n_edges,
-                                      const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam, int iterations,
-                                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2, uint8_t* edge_depth_positive,
-                                      tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window, const float* Tbl7,
-                                      tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
-    if (!kfs || !fixed || !has_imu || !calib || !points3 || !edges || !cam || n_kfs <= 0 || n_points <= 0 || n_edges <= 0 || n_links < 0 ||
-        (n_links > 0 && !links) || iterations < 0 || (lidar_window && !Tbl7)) {
-        set_error("tc2li_local_inertial_bundle_adjustment: invalid argument");
-        return TC2LI_ERR_INVALID;
+    // links -> L; extra_used / imu_used [n_kfs]: keyframes an inertial edge touches
+    int prepare(const tc2li_inertial_link* links, int n_links, const uint8_t* has_imu, int n_kfs, std::vector<uint8_t>& extra_used) {
+        L.resize(n_links);
+        extra_used.assign(n_kfs, 0);
+        for (int l = 0; l < n_links; ++l) {
+            const tc2li_inertial_link& in = links[l];
+            if (in.kf1 < 0 || in.kf1 >= n_kfs || in.kf2 < 0 || in.kf2 >= n_kfs || !in.preintegrated) { set_error("inertial link %d: invalid keyframe index or null pre-integration", l); return TC2LI_ERR_INVALID; }
+            if (!has_imu[in.kf1] || !has_imu[in.kf2]) { set_error("inertial link %d joins a keyframe without IMU state", l); return TC2LI_ERR_INVALID; }
+            L[l].kf1 = in.kf1; L[l].kf2 = in.kf2; L[l].robust = in.robust != 0; L[l].pre = in.preintegrated;
+            if (!L[l].prepare(in.info_scale)) { set_error("inertial link %d: the pre-integration covariance is not positive definite", l); return TC2LI_ERR_INVALID; }
+            extra_used[in.kf1] = extra_used[in.kf2] = 1;
+        }
+        const float d_imu_f = sqrtf(16.92f);
+        d_imu = d_imu_f;
+        dsqr_imu = (float)((double)d_imu_f * (double)d_imu_f);
+        return TC2LI_OK;
     }
-    if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    hipStream_t st = (hipStream_t)stream_;
-    if (stats) memset(stats, 0, sizeof(*stats));
-    // ---- inertial edges ----
-    std::vector<InertialLinkHost> L(n_links);
-    std::vector<uint8_t> extra_used(n_kfs, 0);
-    for (int l = 0; l < n_links; ++l) {
-        const tc2li_inertial_link& in = links[l];
-        if (in.kf1 < 0 || in.kf1 >= n_kfs || in.kf2 < 0 || in.kf2 >= n_kfs || !in.preintegrated) { set_error("inertial link %d: invalid keyframe index or null pre-integration", l); return TC2LI_ERR_INVALID; }
-        if (!has_imu[in.kf1] || !has_imu[in.kf2]) { set_error("inertial link %d joins a keyframe without IMU state", l); return TC2LI_ERR_INVALID; }
-        L[l].kf1 = in.kf1; L[l].kf2 = in.kf2; L[l].robust = in.robust != 0; L[l].pre = in.preintegrated;
-        if (!L[l].prepare(in.info_scale)) { set_error("inertial link %d: the pre-integration covariance is not positive definite", l); return TC2LI_ERR_INVALID; }
-        extra_used[in.kf1] = extra_used[in.kf2] = 1;
+    // imu_used: keyframes whose velocity / bias vertices an inertial edge touches (extra_used before the LiDAR window was added)
+    void number(const uint8_t* fixed, const uint8_t* has_imu, const std::vector<uint8_t>& imu_used, int n_kfs, const std::vector<int>& pose_var_, int np_) {
+        pose_var = &pose_var_; np = np_;
+        imu_var.assign(n_kfs, -1);
+        n_imu = 0;
+        for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && imu_used[k]) imu_var[k] = n_imu++;
+        n = np + 9 * n_imu;
+        Hi.assign((size_t)n * n, 0.0); bi.assign(n, 0.0);
     }
-    std::vector<uint8_t> imu_used = extra_used;  // keyframes whose velocity / bias vertices an inertial edge touches
-    BaWorkspace& ws = ba_ws();
-    std::lock_guard<std::mutex> lk(ws.mu);
-    static_assert(offsetof(tc2li_inertial_keyframe, Rcw) == 0 && offsetof(tc2li_inertial_keyframe, tcw) == 72, "Rcw, tcw first");
-    static_assert(offsetof(ImuPose, Rcw) == 0 && offsetof(ImuPose, tcw) == 72, "Rcw, tcw first");
-    BalmTerm* lidar = nullptr;
-    if (lidar_window) {
-        const int rc = ws.lidar.build_body(kfs, sizeof(tc2li_inertial_keyframe), n_kfs, lidar_window, Tbl7, sizeof(ImuPose), st);
-        if (rc < 0) return rc;
-        lidar = &ws.lidar;
-        for (int i = 0; i < lidar_window->n_keyframes; ++i) extra_used[lidar_window->pose_index[i]] = 1;
-    }
-    VisualProblem vp;
-    {
-        const int rc = vp.setup(ws, nullptr, fixed, n_kfs, points3, n_points, edges, n_edges, cam, extra_used.data(), st);
-        if (rc < 0) return rc;
-    }
-    BaProblemDev& pb = vp.pb;
-    const std::vector<int>& pose_var = vp.pose_var;
-    const int n_free = vp.n_free, np = vp.np;
-    std::vector<int> imu_var(n_kfs, -1);
-    int n_imu = 0;
-    for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && imu_used[k]) imu_var[k] = n_imu++;
-    const int n = np + 9 * n_imu;
-    // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
-    std::vector<ImuPose> hp(n_kfs), hp_trial(n_kfs);
-    std::vector<ImuVertexState> sv(n_kfs), sv_trial(n_kfs);
-    for (int k = 0; k < n_kfs; ++k) {
-        memcpy(hp[k].Rcw, kfs[k].Rcw, 72); memcpy(hp[k].tcw, kfs[k].tcw, 24); memcpy(hp[k].Rwb, kfs[k].Rwb, 72); memcpy(hp[k].twb, kfs[k].twb, 24);
-        hp[k].its = 0; hp[k].pad_ = 0;
-        memcpy(sv[k].v, kfs[k].velocity, 24); memcpy(sv[k].bg, kfs[k].gyro_bias, 24); memcpy(sv[k].ba, kfs[k].acc_bias, 24);
-    }
-    TC2LI_HIP_CHECK(ws.d_iposes.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.d_iposes_trial.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.h_iposes.ensure(n_kfs));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_iposes.p, hp.data(), n_kfs * sizeof(ImuPose), hipMemcpyHostToDevice, st));
-    pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
-    memcpy(&pb.calib, calib, sizeof(ImuCalib));
-    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
-    const size_t E = n_edges, P = n_points;
-
-    const float d_imu_f = sqrtf(16.92f);
-    const double d_imu = d_imu_f;
-    const float dsqr_imu = (float)((double)d_imu_f * (double)d_imu_f);
-    // robust cost of the inertial part at a state; optionally the dense normal equations of the inertial edges
-    std::vector<double> Hi((size_t)n * n), bi(n);
-    auto inertial_cost = [&](const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
+    double cost(const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
+        const std::vector<int>& pv = *pose_var;
         double chi = 0;
         if (linearize) { std::fill(Hi.begin(), Hi.end(), 0.0); std::fill(bi.begin(), bi.end(), 0.0); }
         for (const InertialLinkHost& lk_ : L) {
@@ -846,7 +807,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
                 chi += eg[r] * Og[r] + ea[r] * Oa[r];
             }
             if (!linearize) continue;
-            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2], p1 = pose_var[lk_.kf1], p2 = pose_var[lk_.kf2];
+            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2], p1 = pv[lk_.kf1], p2 = pv[lk_.kf2];
             const int off[6] = {p1 >= 0 ? 6 * p1 : -1, i1 >= 0 ? np + 9 * i1 : -1, i1 >= 0 ? np + 9 * i1 + 3 : -1, i1 >= 0 ? np + 9 * i1 + 6 : -1,
                                 p2 >= 0 ? 6 * p2 : -1, i2 >= 0 ? np + 9 * i2 : -1};
             const int col[6] = {0, 6, 9, 12, 15, 21}, sz[6] = {6, 3, 3, 3, 6, 3};
@@ -885,7 +846,85 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             }
         }
         return chi;
-    };
+    }
+};
+}  // namespace
+
+extern "C" {
+
+static_assert(sizeof(tc2li_imu_calib) == sizeof(ImuCalib), "ABI layout");
+
+int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
+                                           const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges,
+                                           int n_edges, const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam,
+                                           int iterations, double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
+                                           uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
+    return tc2li_local_lvi_bundle_adjustment(kfs, fixed, has_imu, n_kfs, calib, points3, n_points, edges, n_edges, links, n_links, cam, iterations,
+                                             lambda_init, stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, nullptr, stream_);
+}
+
+int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
+                                      const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges, int n_edges,
+                                      const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam, int iterations,
+                                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2, uint8_t* edge_depth_positive,
+                                      tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window, const float* Tbl7,
+                                      tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
+    if (!kfs || !fixed || !has_imu || !calib || !points3 || !edges || !cam || n_kfs <= 0 || n_points <= 0 || n_edges <= 0 || n_links < 0 ||
+        (n_links > 0 && !links) || iterations < 0 || (lidar_window && !Tbl7)) {
+        set_error("tc2li_local_inertial_bundle_adjustment: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream_;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    // ---- inertial edges ----
+    InertialTerm inertial;
+    std::vector<uint8_t> extra_used;
+    {
+        const int rc = inertial.prepare(links, n_links, has_imu, n_kfs, extra_used);
+        if (rc < 0) return rc;
+    }
+    std::vector<uint8_t> imu_used = extra_used;  // keyframes whose velocity / bias vertices an inertial edge touches
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    static_assert(offsetof(tc2li_inertial_keyframe, Rcw) == 0 && offsetof(tc2li_inertial_keyframe, tcw) == 72, "Rcw, tcw first");
+    static_assert(offsetof(ImuPose, Rcw) == 0 && offsetof(ImuPose, tcw) == 72, "Rcw, tcw first");
+    BalmTerm* lidar = nullptr;
+    if (lidar_window) {
+        const int rc = ws.lidar.build_body(kfs, sizeof(tc2li_inertial_keyframe), n_kfs, lidar_window, Tbl7, sizeof(ImuPose), st);
+        if (rc < 0) return rc;
+        lidar = &ws.lidar;
+        for (int i = 0; i < lidar_window->n_keyframes; ++i) extra_used[lidar_window->pose_index[i]] = 1;
+    }
+    VisualProblem vp;
+    {
+        const int rc = vp.setup(ws, nullptr, fixed, n_kfs, points3, n_points, edges, n_edges, cam, extra_used.data(), st);
+        if (rc < 0) return rc;
+    }
+    BaProblemDev& pb = vp.pb;
+    const std::vector<int>& pose_var = vp.pose_var;
+    const int n_free = vp.n_free, np = vp.np;
+    inertial.number(fixed, has_imu, imu_used, n_kfs, pose_var, np);
+    const std::vector<int>& imu_var = inertial.imu_var;
+    const int n = inertial.n;
+    // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
+    std::vector<ImuPose> hp(n_kfs), hp_trial(n_kfs);
+    std::vector<ImuVertexState> sv(n_kfs), sv_trial(n_kfs);
+    for (int k = 0; k < n_kfs; ++k) {
+        memcpy(hp[k].Rcw, kfs[k].Rcw, 72); memcpy(hp[k].tcw, kfs[k].tcw, 24); memcpy(hp[k].Rwb, kfs[k].Rwb, 72); memcpy(hp[k].twb, kfs[k].twb, 24);
+        hp[k].its = 0; hp[k].pad_ = 0;
+        memcpy(sv[k].v, kfs[k].velocity, 24); memcpy(sv[k].bg, kfs[k].gyro_bias, 24); memcpy(sv[k].ba, kfs[k].acc_bias, 24);
+    }
+    TC2LI_HIP_CHECK(ws.d_iposes.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.d_iposes_trial.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.h_iposes.ensure(n_kfs));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_iposes.p, hp.data(), n_kfs * sizeof(ImuPose), hipMemcpyHostToDevice, st));
+    pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
+    memcpy(&pb.calib, calib, sizeof(ImuCalib));
+    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
+    const size_t E = n_edges, P = n_points;
+
+    std::vector<double>&Hi = inertial.Hi, &bi = inertial.bi;
+    auto inertial_cost = [&](const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) { return inertial.cost(Pz, Sz, linearize); };
 
     auto stopped = [&] { return stop_flag && *stop_flag; };
     double lambda = lambda_init, ni = 2, last_chi = 0;
@@ -1454,6 +1493,369 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     return true;
 }
 
+// ---- lock-step batch of LocalLVIBA windows (tc2li_local_lvi_bundle_adjustment_batch) -------------------------------------------
+// The phases of ba_batch_lockstep with the host steps of tc2li_local_lvi_bundle_adjustment between them: the inertial edges'
+// normal equations (InertialTerm, overlapping the linearisation kernels), the dense reduced system [6 per free pose | 9 per free
+// keyframe with IMU state] = Schur complement of the landmarks + inertial + LiDAR blocks, its LDL^T, and the inertial cost of every
+// trial state (the trial ImuCamPose states come back through one copy launch per phase).  Same kernel bodies and host arithmetic
+// as the one-window entry point: a window gives the same result alone and in a batch.
+struct LviWindow {
+    const tc2li_lvi_problem* p = nullptr;
+    BaWorkspace* ws = nullptr;
+    VisualProblem vp;
+    BalmTerm* lidar = nullptr;
+    InertialTerm inertial;
+    std::vector<uint8_t> extra_used, imu_used;
+    std::vector<ImuPose> hp, hp_trial;
+    std::vector<ImuVertexState> sv, sv_trial;
+    std::vector<double> M, rhs, bfull, x;
+    double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, chi_imu = 0, last_chi = 0;
+    int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
+    bool ok = true, ok2 = true, want_maxdiag = false;
+    bool stopped() const { return p->stop_flag && *p->stop_flag; }
+    bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
+};
+LockstepContext& lvi_lockstep_ctx(int group) { static LockstepContext c[kMaxLockstepGroups]; return c[group]; }
+
+bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_imu_calib* calib, const tc2li_camera* cam, WorkerPool& pool, int32_t* results,
+                        int group = 0) {
+    LockstepContext& C = lvi_lockstep_ctx(group);
+    std::lock_guard<std::mutex> lk(C.mu);
+    for (int i = 0; i < n; ++i)
+        if (problems[i].lidar && problems[i].lidar->n_keyframes > 7) return false;
+    if (!C.st) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
+            hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
+    }
+    hipStream_t st = C.st;
+    while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
+    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot);
+    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
+    BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
+    const BaBatchSlot* const d_slots = (const BaBatchSlot*)C.d_table.p;
+    const BaBatchSlot* const d_slots_lidar = d_slots + n;
+    std::vector<LviWindow> W(n);
+    // ---- setup: argument checks, inertial links, plane extraction (host), uploads ----
+    std::vector<int> rc_lidar(n, 0);
+    std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);
+    pool.parallel_for(2 * n, [&](int task) {  // two tasks per window: structure + uploads, the LiDAR plane extraction
+        CopySink sink(&deferred[task]);
+        const int i = task >> 1;
+        LviWindow& w = W[i];
+        const tc2li_lvi_problem& p = problems[i];
+        const bool args_ok = p.keyframes && p.fixed && p.has_imu && p.points3 && p.edges && p.n_keyframes > 0 && p.n_points > 0 && p.n_edges > 0 &&
+                             p.n_links >= 0 && (p.n_links == 0 || p.links) && p.iterations >= 0 && (!p.lidar || p.Tbl);
+        bool lidar_ok = true;
+        if (args_ok && p.lidar) {
+            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) lidar_ok = false;
+            else for (int k = 0; k < p.lidar->n_keyframes; ++k) if (p.lidar->pose_index[k] < 0 || p.lidar->pose_index[k] >= p.n_keyframes) lidar_ok = false;
+        }
+        if (task & 1) {
+            if (!args_ok || !lidar_ok || !p.lidar) return;
+            rc_lidar[i] = C.ws[i]->lidar.build_body(p.keyframes, sizeof(tc2li_inertial_keyframe), p.n_keyframes, p.lidar, p.Tbl, sizeof(ImuPose), st);
+            return;
+        }
+        w.p = &p; w.ws = C.ws[i].get();
+        if (!args_ok) { set_error("tc2li_local_lvi_bundle_adjustment_batch: problem %d: invalid argument", i); w.rc = TC2LI_ERR_INVALID; return; }
+        if (!lidar_ok) { set_error("lidar window: invalid argument or pose_index out of range"); w.rc = TC2LI_ERR_INVALID; return; }
+        if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
+        if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
+        const int n_kfs = p.n_keyframes;
+        w.rc = w.inertial.prepare(p.links, p.n_links, p.has_imu, n_kfs, w.extra_used);
+        if (w.rc < 0) return;
+        w.imu_used = w.extra_used;
+        if (p.lidar) for (int k = 0; k < p.lidar->n_keyframes; ++k) w.extra_used[p.lidar->pose_index[k]] = 1;
+        w.rc = w.vp.setup(*w.ws, nullptr, p.fixed, n_kfs, p.points3, p.n_points, p.edges, p.n_edges, cam, w.extra_used.data(), st);
+        if (w.rc < 0) return;
+        w.inertial.number(p.fixed, p.has_imu, w.imu_used, n_kfs, w.vp.pose_var, w.vp.np);
+        BaWorkspace& ws = *w.ws;
+        w.hp.resize(n_kfs); w.hp_trial.resize(n_kfs); w.sv.resize(n_kfs); w.sv_trial.resize(n_kfs);
+        if (ws.d_iposes.ensure(n_kfs) != hipSuccess || ws.d_iposes_trial.ensure(n_kfs) != hipSuccess || ws.h_iposes.ensure(n_kfs) != hipSuccess ||
+            ws.h_iposes_up.ensure(n_kfs) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
+        for (int k = 0; k < n_kfs; ++k) {
+            const tc2li_inertial_keyframe& kf = p.keyframes[k];
+            memcpy(w.hp[k].Rcw, kf.Rcw, 72); memcpy(w.hp[k].tcw, kf.tcw, 24); memcpy(w.hp[k].Rwb, kf.Rwb, 72); memcpy(w.hp[k].twb, kf.twb, 24);
+            w.hp[k].its = 0; w.hp[k].pad_ = 0;
+            memcpy(w.sv[k].v, kf.velocity, 24); memcpy(w.sv[k].bg, kf.gyro_bias, 24); memcpy(w.sv[k].ba, kf.acc_bias, 24);
+        }
+        memcpy(ws.h_iposes_up.p, w.hp.data(), n_kfs * sizeof(ImuPose));
+        if (upload_or_defer(ws.d_iposes.p, ws.h_iposes_up.p, n_kfs * sizeof(ImuPose), st) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
+        BaProblemDev& pb = w.vp.pb;
+        pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
+        memcpy(&pb.calib, calib, sizeof(ImuCalib));
+        const int nn = w.inertial.n;
+        w.M.assign((size_t)std::max(nn * nn, 1), 0.0); w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
+    });
+    {
+        size_t n_tasks = 0, max_bytes = 0;
+        for (const auto& d : deferred) n_tasks += d.size();
+        if (n_tasks) {
+            if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
+            size_t at = 0;
+            for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+            launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (W[i].rc < 0 || !problems[i].lidar) continue;
+        if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
+    }
+    for (int i = 0; i < n; ++i)
+        if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) { (void)hipStreamSynchronize(st); return false; }
+    BaBatchExtent X{};
+    for (int i = 0; i < n; ++i) {
+        if (W[i].rc < 0) continue;
+        const BaProblemDev& pb = W[i].vp.pb;
+        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
+        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
+        if (pb.sparse_schur && pb.schur_blocks) {
+            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
+                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
+                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
+            }
+        } else if (pb.sparse_schur) {
+            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
+        } else {
+            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
+        }
+        if (W[i].lidar) {
+            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
+            X.max_W = std::max(X.max_W, W[i].lidar->W);
+        }
+    }
+    auto fill_slot = [&](int i) {
+        LviWindow& w = W[i];
+        BaBatchSlot& s = h_slots[i];
+        s.pb = w.vp.pb;
+        s.lambda = w.lambda;
+        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.want_maxdiag = w.want_maxdiag; s.has_lidar = w.lidar != nullptr;
+        double* sc = w.ws->h_scal.p;
+        s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
+        s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
+        s.hpp_out = nullptr; s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
+        if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
+    };
+    bool failed = false;
+    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {
+        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
+        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
+        const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
+        if (bytes && hipMemcpyAsync(C.d_table.p, C.h_table.p, bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+    };
+    auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
+
+    for (;;) {
+        std::vector<int> active, with_lidar;
+        for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
+        if (active.empty() || failed) break;
+        // ---- phase A: linearisation at the accepted estimate; the inertial edges on the host meanwhile ----
+        bool any_maxdiag = false;
+        for (int i : active) {
+            LviWindow& w = W[i];
+            w.want_maxdiag = w.it == 0 && !(w.p->lambda_init > 0);
+            any_maxdiag |= w.want_maxdiag;
+            if (w.lidar) with_lidar.push_back(i);
+            fill_slot(i);
+        }
+        upload(active, with_lidar);
+        ba_batch_launch_linearize(d_slots, nullptr, (int)active.size(), X, any_maxdiag, st);
+        // computeActiveErrors + linearizeOplus of the LiDAR edge: the residual at the accepted estimate and the Hessian, every iteration
+        // (the one-window path's enqueue_error + enqueue_linearization)
+        balm_batch_launch_residual(d_slots_lidar, nullptr, (int)with_lidar.size(), false, st);
+        balm_batch_launch_hessian(d_slots_lidar, nullptr, (int)with_lidar.size(), X, st);
+        pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
+        sync();
+        if (failed) break;
+        pool.parallel_for((int)active.size(), [&](int k) {
+            LviWindow& w = W[active[k]];
+            const double* sc = w.ws->h_scal.p;
+            const int np = w.vp.np, nn = w.inertial.n;
+            double chi_imu = w.chi_imu;
+            if (w.lidar) {
+                if (w.it == 0) w.lidar->finish_error();  // the computeActiveErrors() before optimize() (OptimizerWithLidar.cc:978)
+                w.lidar->finish_error();
+                chi_imu += w.lidar->chi2();
+                w.lidar->finish_linearization();
+                w.lidar->add_quadratic_form(w.vp.pose_var.data(), nn, w.inertial.Hi.data(), w.inertial.bi.data());
+            }
+            w.currentChi = chi_imu + sc[0];
+            w.tempChi = w.currentChi;
+            w.iniChi = w.currentChi;
+            if (w.it == 0) {
+                if (w.p->stats) w.p->stats->initial_chi2 = w.currentChi;
+                w.last_chi = w.currentChi;
+                w.lambda = w.p->lambda_init;
+                if (!(w.p->lambda_init > 0)) {  // computeLambdaInit over the whole diagonal (not used by the reference's settings)
+                    double mx = std::max(sc[1], sc[2]);
+                    for (int j = np; j < nn; ++j) mx = std::max(mx, std::fabs(w.inertial.Hi[(size_t)j * nn + j]));
+                    w.lambda = 1e-5 * mx;
+                }
+                w.ni = 2;
+                w.n_bad = 0;
+            }
+            w.rho = 0;
+            w.qmax = 0;
+        });
+        // ---- trials ----
+        std::vector<int> trial = active;
+        while (!trial.empty() && !failed) {
+            for (int i : trial) fill_slot(i);
+            upload(trial, {});
+            ba_batch_launch_schur(d_slots, nullptr, (int)trial.size(), X, st);
+            sync();
+            if (failed) break;
+            pool.parallel_for((int)trial.size(), [&](int k) {
+                LviWindow& w = W[trial[k]];
+                BaWorkspace& ws = *w.ws;
+                const int np = w.vp.np, nn = w.inertial.n;
+                const std::vector<double>&Hi = w.inertial.Hi, &bi = w.inertial.bi;
+                // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]
+                for (int r = 0; r < nn; ++r)
+                    for (int c = 0; c < nn; ++c) {
+                        double v = Hi[(size_t)r * nn + c];
+                        if (r < np && c < np) v += ws.h_S.p[(size_t)r * np + c];
+                        else if (r == c) v += w.lambda;
+                        w.M[(size_t)r * nn + c] = v;
+                    }
+                for (int j = 0; j < nn; ++j) {
+                    w.bfull[j] = bi[j] + (j < np ? ws.h_bs.p[np + j] : 0.0);
+                    w.rhs[j] = bi[j] + (j < np ? ws.h_bs.p[j] : 0.0);
+                }
+                w.ok2 = nn == 0 ? true : ldlt_solve_small(w.M.data(), nn, w.rhs.data(), w.x.data(), false);
+                w.scale = 0;
+                for (int j = 0; j < nn; ++j) w.scale += w.x[j] * (w.lambda * w.x[j] + w.bfull[j]);
+                if (w.ok2 && np) memcpy(ws.h_xp.p, w.x.data(), np * sizeof(double));
+            });
+            std::vector<int> step, step_lidar;
+            for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
+            if (!step.empty()) {
+                upload(step, step_lidar);
+                ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
+                if (C.h_tasks.ensure(step.size()) != hipSuccess) { failed = true; break; }
+                size_t max_bytes = 0;
+                for (size_t k = 0; k < step.size(); ++k) {  // the trial ImuCamPose states for the inertial cost
+                    LviWindow& w = W[step[k]];
+                    const size_t bytes = w.p->n_keyframes * sizeof(ImuPose);
+                    C.h_tasks.p[k] = CopyTask{w.ws->h_iposes.p, w.vp.pb.iposes_trial, bytes};
+                    max_bytes = std::max(max_bytes, bytes);
+                }
+                launch_copy_tasks(C.h_tasks.p, (int)step.size(), max_bytes, st);
+                balm_batch_launch_residual(d_slots_lidar, nullptr, (int)step_lidar.size(), true, st);
+                pool.parallel_for((int)step.size(), [&](int k) {  // velocity / bias part of the step, on the host
+                    LviWindow& w = W[step[k]];
+                    const int np = w.vp.np;
+                    w.sv_trial = w.sv;
+                    for (int q = 0; q < w.p->n_keyframes; ++q)
+                        if (w.inertial.imu_var[q] >= 0) {
+                            const double* u = &w.x[np + 9 * w.inertial.imu_var[q]];
+                            for (int c = 0; c < 3; ++c) { w.sv_trial[q].v[c] += u[c]; w.sv_trial[q].bg[c] += u[3 + c]; w.sv_trial[q].ba[c] += u[6 + c]; }
+                        }
+                });
+                sync();
+                if (failed) break;
+                pool.parallel_for((int)step.size(), [&](int k) {
+                    LviWindow& w = W[step[k]];
+                    memcpy(w.hp_trial.data(), w.ws->h_iposes.p, w.p->n_keyframes * sizeof(ImuPose));
+                    w.tempChi = w.inertial.cost(w.hp_trial, w.sv_trial, false) + w.ws->h_scal.p[4];
+                    if (w.lidar) { w.lidar->finish_error(); w.tempChi += w.lidar->chi2(); }
+                    w.scale += w.ws->h_scal.p[3];
+                    w.last_chi = w.tempChi;
+                });
+            }
+            std::vector<int> again;
+            for (int i : trial) {
+                LviWindow& w = W[i];
+                if (!w.ok2) w.tempChi = std::numeric_limits<double>::max();
+                w.rho = w.currentChi - w.tempChi;
+                w.scale += 1e-3;
+                w.rho /= w.scale;
+                if (w.rho > 0 && std::isfinite(w.tempChi)) {
+                    double alpha = 1. - std::pow((2 * w.rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    w.lambda *= std::max(1. / 3., alpha);
+                    w.ni = 2;
+                    w.currentChi = w.tempChi;
+                    std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);
+                    std::swap(w.vp.pb.points, w.vp.pb.points_trial);
+                    w.hp.swap(w.hp_trial);
+                    w.sv.swap(w.sv_trial);
+                } else {
+                    w.lambda *= w.ni;
+                    w.ni *= 2;
+                }
+                w.qmax++;
+                w.trials_total++;
+                if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
+            }
+            trial.swap(again);
+        }
+        for (int i : active) {
+            LviWindow& w = W[i];
+            ++w.done;
+            ++w.it;
+            if (w.p->stats) w.p->stats->final_lambda = w.lambda;
+            if (w.qmax == 10 || w.rho == 0) { w.ok = false; continue; }
+            if ((w.iniChi - w.currentChi) * 1e3 < w.iniChi) w.n_bad++; else w.n_bad = 0;
+            if (w.n_bad >= 3) w.ok = false;
+        }
+    }
+    // ---- results ----
+    std::vector<int> all;
+    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
+    if (!failed && !all.empty()) {
+        upload(all, {});
+        ba_batch_launch_depth(d_slots, nullptr, (int)all.size(), X, st);
+        size_t n_tasks = 0, max_bytes = 0;
+        if (C.h_tasks.ensure(3 * all.size()) != hipSuccess) failed = true;
+        for (int i : all) {
+            if (failed) break;
+            LviWindow& w = W[i];
+            const tc2li_lvi_problem& p = *w.p;
+            const size_t E = p.n_edges, P = p.n_points;
+            const size_t bytes = 3 * P * sizeof(double) + E * sizeof(double) + E;
+            if (w.ws->h_result.ensure(bytes) != hipSuccess) { failed = true; break; }
+            uint8_t* h = w.ws->h_result.p;
+            auto add = [&](void* dst, const void* src, size_t nbytes) { C.h_tasks.p[n_tasks++] = CopyTask{dst, src, nbytes}; max_bytes = std::max(max_bytes, nbytes); };
+            add(h, w.vp.pb.points, 3 * P * sizeof(double));
+            if (p.edge_chi2) add(h + 3 * P * sizeof(double), w.ws->d_chi2.p, E * sizeof(double));
+            if (p.edge_depth_positive) add(h + 3 * P * sizeof(double) + E * sizeof(double), w.ws->d_depth.p, E);
+        }
+        if (!failed) launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
+        sync();
+        if (!failed)
+            pool.parallel_for((int)all.size(), [&](int k) {
+                LviWindow& w = W[all[k]];
+                const tc2li_lvi_problem& p = *w.p;
+                const size_t E = p.n_edges, P = p.n_points;
+                const uint8_t* h = w.ws->h_result.p;
+                memcpy(p.points3, h, 3 * P * sizeof(double));
+                if (p.edge_chi2) memcpy(p.edge_chi2, h + 3 * P * sizeof(double), E * sizeof(double));
+                if (p.edge_depth_positive) memcpy(p.edge_depth_positive, h + 3 * P * sizeof(double) + E * sizeof(double), E);
+                for (int q = 0; q < p.n_keyframes; ++q) {
+                    tc2li_inertial_keyframe& kf = p.keyframes[q];
+                    memcpy(kf.Rcw, w.hp[q].Rcw, 72); memcpy(kf.tcw, w.hp[q].tcw, 24); memcpy(kf.Rwb, w.hp[q].Rwb, 72); memcpy(kf.twb, w.hp[q].twb, 24);
+                    memcpy(kf.velocity, w.sv[q].v, 24); memcpy(kf.gyro_bias, w.sv[q].bg, 24); memcpy(kf.acc_bias, w.sv[q].ba, 24);
+                }
+            });
+    }
+    for (int i = 0; i < n; ++i) {
+        LviWindow& w = W[i];
+        if (w.rc < 0) { results[i] = w.rc; continue; }
+        if (failed) { set_error("tc2li_local_lvi_bundle_adjustment_batch: HIP error in the lock-step loop: %s", hipGetErrorString(hipGetLastError())); results[i] = TC2LI_ERR_HIP; continue; }
+        const tc2li_lvi_problem& p = *w.p;
+        if (p.stats) { p.stats->iterations = w.done; p.stats->trials = w.trials_total; p.stats->n_free_poses = w.vp.n_free; p.stats->final_chi2 = w.last_chi; }
+        if (w.lidar && p.lidar_stats) {
+            p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = w.lidar->hessian_evaluations;
+            p.lidar_stats->residual = w.lidar->error; p.lidar_stats->chi2 = w.lidar->chi2();
+        }
+        results[i] = w.done;
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1511,6 +1913,50 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
                                                           p.stats, p.lidar, p.lidar_stats, ts.s);
         }
     });
+    int ok = 0;
+    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
+    return ok;
+}
+
+int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
+                                            int max_concurrency, int32_t* results) {
+    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam) { set_error("tc2li_local_lvi_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (n_problems == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
+    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
+    static const int kGroupThreads = std::max(1, getenv("TC2LI_BA_GROUP_THREADS") ? atoi(getenv("TC2LI_BA_GROUP_THREADS")) : 16);
+    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
+        static WorkerPool* group_pools[kMaxLockstepGroups] = {};
+        static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
+        static std::mutex pools_mu;
+        const int groups = std::max(1, std::min(kGroups, n_problems / 2));
+        {
+            std::lock_guard<std::mutex> lk(pools_mu);
+            for (int g = 0; g < groups; ++g) if (!group_pools[g]) group_pools[g] = new WorkerPool(kGroupThreads);
+        }
+        std::atomic<int> fell_back{0};
+        if (groups == 1) {
+            if (!lvi_batch_lockstep(problems, n_problems, calib, cam, *group_pools[0], results, 0)) fell_back++;
+        } else {
+            top->parallel_for(groups, [&](int g) {
+                const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
+                if (!lvi_batch_lockstep(problems + b, e - b, calib, cam, *group_pools[g], results + b, g)) fell_back++;
+            });
+        }
+        if (fell_back.load() == 0) {
+            int ok_ = 0;
+            for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
+            return ok_;
+        }
+    }
+    // one window after the other (a LiDAR window outside the batched kernels' range, or a batch of one)
+    for (int i = 0; i < n_problems; ++i) {
+        const tc2li_lvi_problem& p = problems[i];
+        results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
+                                                       p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,
+                                                       p.lidar, p.Tbl, p.lidar_stats, private_stream());
+    }
     int ok = 0;
     for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
     return ok;

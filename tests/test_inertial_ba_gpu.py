@@ -109,3 +109,78 @@ def test_inertial_ba_argument_errors(pkg, oracle, synthetic):
     r = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], pkg.pack_ba_edges(w["edges"]),
                                                   np.zeros((0, 4)), [], w["cam"])
     assert r[4].iterations >= 1 and r[4].final_chi2 < r[4].initial_chi2
+
+
+def _lvi_window(pkg, oracle, synthetic, seed, n_opt, n_pts, lidar=True, cloud_points=2400, **kw):
+    w = problem(pkg, oracle, synthetic, seed, n_opt=n_opt, n_points=n_pts)
+    K = len(w["kf33"])
+    d = dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), link4=w["link4"],
+             pre=w["pre"], **kw)
+    if lidar:
+        win = list(range(K - 1, K - 7, -1))
+        d.update(win_kf=win, clouds=synthetic.inertial_window_clouds(w, win, n_points=cloud_points, seed=seed), Tcl7=synthetic.TCL7, Tbl7=synthetic.tbl7(),
+                 weight=1.0 + seed)
+    return w, d
+
+
+def test_lviba_batch_equals_the_one_window_calls(pkg, oracle, synthetic):
+    """tc2li_local_lvi_bundle_adjustment_batch (lock step): every window's states, points, per-edge chi2 and counters are those of
+    tc2li_local_lvi_bundle_adjustment -- windows of different sizes, with and without the LiDAR edge, 4 and 10 iterations, lambda 1e-2 / 1."""
+    specs = [(0, 6, 400, True, {}), (1, 10, 900, True, {}), (2, 7, 500, False, {}), (3, 8, 600, True, dict(iterations=4, lambda_init=1e-2)),
+             (4, 10, 900, True, {}), (5, 3, 200, False, {})]
+    wins = [_lvi_window(pkg, oracle, synthetic, s, n, p, lidar=l, **kw) for s, n, p, l, kw in specs]
+    w0 = wins[0][0]
+    batch = pkg.capi.LviBatch([d for _, d in wins], w0["calib24"], w0["cam"])
+    for conc in (8, 1):  # lock step; one window after the other
+        assert batch.run(max_concurrency=conc) == len(wins)
+        for i, (w, d) in enumerate(wins):
+            it, lam = d.get("iterations", 10), d.get("lambda_init", 1.0)
+            if "win_kf" in d:
+                kf, pts, chi2, dpos, st, ls = pkg.capi.local_lvi_bundle_adjustment(d["kf33"], d["fixed"], d["has_imu"], w["calib24"], d["points"], d["edges"], d["link4"],
+                                                                                   d["pre"], w["cam"], d["win_kf"], d["clouds"], d["Tcl7"], d["Tbl7"], d["weight"],
+                                                                                   iterations=it, lambda_init=lam)
+            else:
+                kf, pts, chi2, dpos, st = pkg.capi.local_inertial_bundle_adjustment(d["kf33"], d["fixed"], d["has_imu"], w["calib24"], d["points"], d["edges"],
+                                                                                    d["link4"], d["pre"], w["cam"], iterations=it, lambda_init=lam)
+                ls = None
+            bkf, bpts, bchi2, bdpos, bst, bls = batch.result(i)
+            assert batch.results[i] == st.iterations == bst.iterations and bst.trials == st.trials and bst.n_free_poses == st.n_free_poses, i
+            assert bst.initial_chi2 == st.initial_chi2 and bst.final_chi2 == st.final_chi2 and bst.final_lambda == st.final_lambda, i
+            assert np.array_equal(bkf, kf) and np.array_equal(bpts, pts) and np.array_equal(bchi2, chi2) and np.array_equal(bdpos, dpos), i
+            if ls is not None:
+                assert (bls.n_planes, bls.hessian_evaluations, bls.residual, bls.chi2) == (ls.n_planes, ls.hessian_evaluations, ls.residual, ls.chi2), i
+            assert st.final_chi2 < st.initial_chi2
+
+
+def test_lviba_large_window_and_benched_cloud(pkg, oracle, synthetic):
+    """The 25-keyframe `bLarge` window of LocalInertialBA / LocalLVIBA (opt_it 4, lambda 1e-2: Optimizer.cc:1516-1523, OptimizerWithLidar.cc:493-500,
+    :618) against the oracle -- the reduced system has (6 + 9) * 25 unknowns and the dense Schur path is taken -- and an LVIBA window with the
+    LiDAR edge at the benched cloud size."""
+    w = problem(pkg, oracle, synthetic, 11, n_opt=25, n_points=1500)
+    K = len(w["kf33"])
+    win = list(range(K - 1, K - 7, -1))
+    clouds = synthetic.inertial_window_clouds(w, win, n_points=2400, seed=11)
+    tbl = synthetic.tbl7()
+    for lidar in (False, True):
+        if lidar:
+            want = oracle.local_lviba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], w["pre298"], w["cam"], win,
+                                      clouds, synthetic.TCL7, tbl, 1.0, iterations=4, lambda_init=1e-2)
+            kf, pts, chi2, dpos, stats, ls = pkg.capi.local_lvi_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"],
+                                                                                 pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"], win, clouds,
+                                                                                 synthetic.TCL7, tbl, 1.0, iterations=4, lambda_init=1e-2)
+            assert ls.n_planes == want[7] and ls.n_planes > 50
+        else:
+            want = oracle.local_inertial_ba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], w["pre298"], w["cam"],
+                                            iterations=4, lambda_init=1e-2)
+            kf, pts, chi2, dpos, stats = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"],
+                                                                                  pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"],
+                                                                                  iterations=4, lambda_init=1e-2)
+        assert stats.n_free_poses == 25 and stats.iterations == want[4] == 4
+        assert stats.trials == int(want[5]["trials"].sum())
+        assert abs(stats.initial_chi2 - want[6][0]) <= 1e-6 * want[6][0]
+        assert abs(stats.final_chi2 - want[6][1]) <= 1e-5 * want[6][1]
+        for k in range(len(kf)):
+            assert rel(kf[k, :24], want[0][k, :24]) < RTOL
+            assert np.allclose(kf[k, 24:], want[0][k, 24:], rtol=RTOL, atol=1e-5)
+        assert np.allclose(pts, want[1], rtol=RTOL, atol=1e-4)
+        assert stats.final_chi2 < stats.initial_chi2
