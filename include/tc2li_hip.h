@@ -471,6 +471,10 @@ int tc2li_imu_integrate(tc2li_preintegrated* p, const float acc[3], const float 
 /* The loop of Tracking::PreintegrateIMU over mvImuFromLastFrame (samples between the two frame stamps, one before and
  * one after included); returns the number of integration steps. */
 int tc2li_imu_preintegrate(tc2li_preintegrated* p, const tc2li_imu_sample* samples, int n_samples, double t_prev, double t_cur);
+/* The same for one frame of each of n_frames sequences (a batch of tracking threads): pre[f] is initialised at bias[f] with the calibration's
+ * noise values and integrates samples[sample_offsets[f] .. sample_offsets[f + 1]) between t_prev[f] and t_cur[f].  Returns n_frames. */
+int tc2li_imu_preintegrate_frames(int n_frames, tc2li_preintegrated* pre, const tc2li_imu_bias* bias, float ng, float na, float ngw, float naw,
+                                  const tc2li_imu_sample* samples, const int32_t* sample_offsets, const double* t_prev, const double* t_cur);
 /* GetDeltaRotation / GetDeltaVelocity / GetDeltaPosition at another bias (outputs may be NULL) */
 int tc2li_imu_delta(const tc2li_preintegrated* p, const tc2li_imu_bias* bias, float dR[9], float dV[3], float dP[3]);
 /* Tracking::PredictStateIMU: (Rwb1, twb1, Vwb1) of the last keyframe / frame -> the current frame's IMU state */

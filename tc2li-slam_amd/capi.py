@@ -1074,6 +1074,114 @@ def pose_inertial_optimization_batch(problems, calib24, cam5, stream=0):
     return outs
 
 
+class PoseInertialBatch:
+    """The IMU pre-integration between two frames and ``PoseInertialOptimizationLastFrame / LastKeyFrame`` for one frame of each of n sequences,
+    packed once: ``preintegrate()`` = tc2li_imu_preintegrate_frames, ``run()`` = tc2li_pose_inertial_optimization_batch from the initial states.
+    problems: dicts as for pose_inertial_optimization_batch plus samples (IMU_SAMPLE_DTYPE), t1, t2, bias6; noise4 = ng, na, ngw, naw."""
+
+    def __init__(self, problems, calib24, cam5, noise4):
+        n = self.n = len(problems)
+        self.calib24, self.cam5, self.noise4 = np.ascontiguousarray(calib24, np.float64), np.ascontiguousarray(cam5, np.float64), [float(v) for v in noise4]
+        self.arr = (PoseInertialProblem * n)()
+        self.pre = (PreintegratedPOD * n)()
+        self.bias = (ImuBias * n)()
+        self.samples = np.concatenate([np.ascontiguousarray(p["samples"], IMU_SAMPLE_DTYPE) for p in problems])
+        self.offsets = np.concatenate([[0], np.cumsum([len(p["samples"]) for p in problems])]).astype(np.int32)
+        self.t1, self.t2 = np.array([p["t1"] for p in problems], np.float64), np.array([p["t2"] for p in problems], np.float64)
+        self.keep, self.init = [], []
+        self.results = np.zeros(n, np.int32)
+        for f, pr in enumerate(problems):
+            Xw = np.ascontiguousarray(pr["Xw"], np.float64).reshape(-1, 3)
+            e = np.ascontiguousarray(pr["edges"], BA_EDGE_DTYPE)
+            cl = np.ascontiguousarray(pr["close"], np.uint8)
+            out = np.zeros(max(len(e), 1), np.uint8)
+            prior_in, prior_out = PoseImuPrior(), PoseImuPrior()
+            if pr.get("prior246") is not None:
+                C.memmove(C.addressof(prior_in), np.ascontiguousarray(pr["prior246"], np.float64).ctypes.data, 246 * 8)
+            self.bias[f] = ImuBias(*[float(x) for x in pr["bias6"]])
+            cur, oth = np.ascontiguousarray(pr["cur33"], np.float64).copy(), np.ascontiguousarray(pr["other33"], np.float64).copy()
+            self.keep.append((Xw, e, cl, out, prior_in, prior_out))
+            self.init.append((cur, oth))
+            a = self.arr[f]
+            a.prior = C.addressof(prior_in) if pr.get("prior246") is not None else None
+            a.preintegrated = a.preintegrated_rw = C.addressof(self.pre) + f * C.sizeof(PreintegratedPOD)
+            a.Xw, a.edges, a.close_point, a.outlier, a.prior_out = Xw.ctypes.data, e.ctypes.data, cl.ctypes.data, out.ctypes.data, C.addressof(prior_out)
+            a.n_edges, a.last_frame, a.rec_init = len(e), int(bool(pr.get("last_frame"))), int(bool(pr.get("rec_init")))
+        self.init33 = np.stack([np.concatenate(x) for x in self.init])  # [n, 66]
+
+    def preintegrate(self):
+        f = lib().tc2li_imu_preintegrate_frames
+        f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        return _check(f(self.n, C.addressof(self.pre), C.addressof(self.bias), *self.noise4, self.samples.ctypes.data, self.offsets.ctypes.data,
+                        self.t1.ctypes.data, self.t2.ctypes.data))
+
+    def run(self, stream=0):
+        """Resets every frame to its initial state and optimises all of them -> results [n] (initial correspondences - bad)."""
+        frame_off, stride = PoseInertialProblem.frame.offset, C.sizeof(PoseInertialProblem)
+        base = C.addressof(self.arr)
+        for f in range(self.n):
+            C.memmove(base + f * stride + frame_off, self.init33[f].ctypes.data, 66 * 8)  # frame | other are adjacent
+        f_ = lib().tc2li_pose_inertial_optimization_batch
+        f_.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _check(f_(base, self.n, self.calib24.ctypes.data, self.cam5.ctypes.data, self.results.ctypes.data, C.c_void_p(stream)))
+        return self.results
+
+    def inliers(self):
+        return np.array([self.arr[f].n_inliers for f in range(self.n)])
+
+
+class LidarInertialBatch:
+    """``tc2li_lidar_inertial_frontend_batch`` with its per-scan records packed once: ``run()`` starts every sequence from its initial filter
+    state and covariance again (a benchmark's repeated step).  Arguments as LidarFrontEnd.inertial_frontend_batch."""
+
+    def __init__(self, fe, raw_offsets, maps, states36, Ps, imus, times, cov12, R=0.001, max_iter=3, limit=None, extrinsic_est_en=False,
+                 point_filter_num=2, blind=2.0, time_unit_scale=1e-3, leaf=0.5):
+        S = self.S = len(raw_offsets) - 1
+        self.fe = fe
+        self.raw_offsets = np.ascontiguousarray(raw_offsets, np.int32)
+        self.st0 = np.ascontiguousarray(states36, np.float64).reshape(S, 36).copy()
+        self.P0 = np.ascontiguousarray(Ps, np.float64).reshape(S, 529).copy()
+        self.P = self.P0.copy()
+        self.cov, self.lim = np.ascontiguousarray(cov12, np.float64), np.ascontiguousarray(np.full(23, 0.001) if limit is None else limit, np.float64)
+        self.imus = [np.ascontiguousarray(x, np.float64).reshape(-1, 7) for x in imus]
+        times = np.ascontiguousarray(times, np.float64).reshape(S, 4)
+        self.scans = (LidarInertialScan * S)()
+        for s in range(S):
+            sc = self.scans[s]
+            sc.imu, sc.n_imu = self.imus[s].ctypes.data, len(self.imus[s])
+            sc.pcl_beg_time, sc.pcl_end_time, sc.last_lidar_end_time, sc.acc_scale = [float(v) for v in times[s]]
+            sc.P = self.P[s].ctypes.data
+        self.handles = (C.c_void_p * S)(*[m._h for m in maps])
+        self.args = (point_filter_num, blind, time_unit_scale, leaf)
+        self.tail = (R, max_iter, int(extrinsic_est_en))
+        self.state_off, self.stride = LidarInertialScan.state.offset, C.sizeof(LidarInertialScan)
+        self.last_off = LidarInertialScan.acc_s_last.offset
+        self.zero6 = np.zeros(6)
+
+    def run(self, dev_raw_ptr, stream=0):
+        base = C.addressof(self.scans)
+        self.P[...] = self.P0
+        for s in range(self.S):
+            C.memmove(base + s * self.stride + self.state_off, self.st0[s].ctypes.data, 36 * 8)
+            C.memmove(base + s * self.stride + self.last_off, self.zero6.ctypes.data, 48)
+        f = lib().tc2li_lidar_inertial_frontend_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        R, max_iter, ext = self.tail
+        return _check(f(self.fe._h, self.S, C.c_void_p(dev_raw_ptr), self.raw_offsets.ctypes.data, *self.args, self.handles, self.scans, self.cov.ctypes.data,
+                        R, max_iter, self.lim.ctypes.data, ext, C.c_void_p(stream)))
+
+    def states36(self):
+        out = np.zeros((self.S, 36))
+        base = C.addressof(self.scans)
+        for s in range(self.S):
+            C.memmove(out[s].ctypes.data, base + s * self.stride + self.state_off, 36 * 8)
+        return out
+
+    def stats(self):
+        return [(sc.stats.calls, sc.stats.searches, sc.stats.effct_feat_num, sc.n_preprocessed, sc.n_downsampled) for sc in self.scans]
+
+
 class LastFrame(C.Structure):
     """tc2li_last_frame: what SearchByProjection(F, LastFrame) reads of mLastFrame."""
     _fields_ = [("n", C.c_int32), ("pad_", C.c_int32), ("has_point", C.c_void_p), ("outlier", C.c_void_p), ("Xw", C.c_void_p),

@@ -2,6 +2,7 @@
 // prediction of the tracking thread -- IMU::Preintegrated (SF/src/ImuTypes.cc:152-316), Tracking::PreintegrateIMU
 // (SF/src/Tracking.cc:1710-1822) and Tracking::PredictStateIMU (:1825-1875).  About ten samples per frame in float:
 // SURVEY.md section 8a row a11 keeps it on the host; the result feeds the inertial edges of the local BA.
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -245,6 +246,24 @@ int tc2li_imu_predict_state(const tc2li_preintegrated* p, const tc2li_imu_bias* 
         Vwb2[k] = Vwb1[k] + t12 * Gz[k] + RdV[k];
     }
     return TC2LI_OK;
+}
+
+// Tracking::PreintegrateIMU for the frames of a batch of sequences: per frame a fresh Preintegrated at the frame's bias, then the loop
+// over its samples (tc2li_imu_preintegrated_init + tc2li_imu_preintegrate), the frames dealt over host threads.
+int tc2li_imu_preintegrate_frames(int n_frames, tc2li_preintegrated* pre, const tc2li_imu_bias* bias, float ng, float na, float ngw, float naw,
+                                  const tc2li_imu_sample* samples, const int32_t* sample_offsets, const double* t_prev, const double* t_cur) {
+    if (n_frames < 0 || (n_frames > 0 && (!pre || !bias || !samples || !sample_offsets || !t_prev || !t_cur))) {
+        set_error("tc2li_imu_preintegrate_frames: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    for (int f = 0; f < n_frames; ++f)
+        if (sample_offsets[f + 1] < sample_offsets[f]) { set_error("tc2li_imu_preintegrate_frames: sample offsets must be non-decreasing"); return TC2LI_ERR_INVALID; }
+    std::atomic<int> bad{0};
+    tracking_pool().parallel_for(n_frames, [&](int f) {
+        if (tc2li_imu_preintegrated_init(&pre[f], &bias[f], ng, na, ngw, naw) < 0 ||
+            tc2li_imu_preintegrate(&pre[f], samples + sample_offsets[f], sample_offsets[f + 1] - sample_offsets[f], t_prev[f], t_cur[f]) < 0) bad++;
+    });
+    return bad.load() ? TC2LI_ERR_INVALID : n_frames;
 }
 
 }  // extern "C"

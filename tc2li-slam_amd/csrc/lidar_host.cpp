@@ -93,7 +93,7 @@ struct tc2li_lidar {
     DevBuf<int2> d_hard_list;
     DevBuf<Pose6DDev> d_imu_poses;
     // tc2li_lidar_inertial_frontend_batch: IMU poses per scan, the time sort's flags, block / scan lists of an iteration, pinned staging
-    DevBuf<int> d_n_poses, d_sort_fallback, d_scan_list;
+    DevBuf<int> d_n_poses, d_sort_fallback /* [max_scans] flags | [max_scans] range counts */, d_sort_ranges, d_scan_list;
     DevBuf<SegBlock> d_blocks_a, d_blocks_b, d_blocks_c;
     PinnedBuf<uint8_t> h_batch;
     DevBuf<double> d_eskf_partial;  // [(cap + 255) / 256][kEskfOutSize]
@@ -733,11 +733,11 @@ int tc2li_device_time_sort(tc2li_lidar* L, const tc2li_point* points, int n, int
     int rc = setup_segments(L, 1, &n, ps);
     if (rc != TC2LI_OK) return rc;
     const size_t T = L->total;
-    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(L->max_scans));
+    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(2 * (size_t)L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_ranges.ensure(T));
     TC2LI_HIP_CHECK(copy_sync(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
     TC2LI_HIP_CHECK(copy_sync(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
     launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, 1, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
-                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, depth_limit, ps);
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_limit, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
     int fb = 0;
     TC2LI_HIP_CHECK(copy_sync(&fb, L->d_sort_fallback.p, sizeof(int), hipMemcpyDeviceToHost, ps));
@@ -783,7 +783,7 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     // ---- work space of the batch (allocated on first use) ----
     const size_t rows = T / 256;
     TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_imu_poses.ensure((size_t)L->max_scans * kMaxImuPoses));
-    TC2LI_HIP_CHECK(L->d_n_poses.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_scan_list.ensure(L->max_scans));
+    TC2LI_HIP_CHECK(L->d_n_poses.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(2 * (size_t)L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_ranges.ensure(T)); TC2LI_HIP_CHECK(L->d_scan_list.ensure(L->max_scans));
     TC2LI_HIP_CHECK(L->d_blocks_a.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_b.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_c.ensure(T / kSegBlock));
     TC2LI_HIP_CHECK(L->d_eskf_partial.ensure(rows * kEskfOutSize)); TC2LI_HIP_CHECK(L->h_eskf_out.ensure((size_t)L->max_scans * kEskfOutSize));
     TC2LI_HIP_CHECK(L->h_batch.ensure((size_t)L->max_scans * (kMaxImuPoses * sizeof(Pose6DDev) + sizeof(LidarStateDev) + 4 * sizeof(int)) + 3 * (T / kSegBlock) * sizeof(SegBlock)));
@@ -820,7 +820,7 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     // ---- UndistortPcl: the time sort (std::sort's permutation, replayed on the device) and the compensation ----
     const char* depth_env = getenv("TC2LI_TEST_SORT_DEPTH");  // tests: a small depth limit sends scans through the host fallback
     launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, S, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
-                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, depth_env ? atoi(depth_env) : -1, st);
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_env ? atoi(depth_env) : -1, st);
     int* hc = L->h_counts.p;
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));

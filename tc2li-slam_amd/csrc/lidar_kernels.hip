@@ -495,38 +495,35 @@ void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const P
 //     a scatter by k pairs them, and the cut is min(first unswapped left candidate, last swapped right candidate);
 //   * the closing insertion sort never moves an element past an equal one, and no element has to cross a range boundary (left of a cut
 //     everything is <= the pivot <= everything right of it): it is a stable sort inside every final range of at most 16 elements.
-// One workgroup of 1024 threads per scan; the arrays live in global memory (L2-resident: ~36 bytes per point).  A scan whose
-// recursion reaches the depth limit (std::sort would heap-sort the range) is flagged; the host sorts that scan itself.
-constexpr int kSortThreads = 1024, kSortWaves = kSortThreads / 64;
+// Two kernels.  k_time_sort: one workgroup of 1024 threads per scan replays the levels on arrays in global memory while a range is
+// longer than kSortLds elements (about five levels of a 65 k scan), then lists the ranges.  k_time_sort_lds: one workgroup of 256 threads
+// per listed range finishes it in LDS -- the same level loop on 16-bit range-local indices -- down to the stable sort of the final
+// ranges, and writes the permutation.  A range whose recursion reaches the depth limit (std::sort would heap-sort it) flags its scan;
+// the host sorts that scan itself.
+constexpr int kSortThreads = 1024, kSortLdsThreads = 256, kSortLds = 2048;
 struct TimeSortArrays { float* key; int *idx, *sf, *sl, *cl, *cr, *lp, *rp, *cut; uint8_t* flag; };
 
-__global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
-                                                            const ScanSlot* __restrict__ slots, TimeSortArrays A, int* __restrict__ perm,
-                                                            int* __restrict__ fallback, int depth_override) {
-    __shared__ int s_tot[2][kSortWaves], s_base[2][kSortWaves + 1], s_any;
-    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const ScanSlot sl_ = slots[scan];
-    const int n = count[scan], B = sl_.base;
-    float* const key = A.key + B;
-    int *const idx = A.idx + B, *const sf = A.sf + B, *const sl = A.sl + B, *const cl = A.cl + B, *const cr = A.cr + B, *const lp = A.lp + B,
-        *const rp = A.rp + B, *const cut = A.cut + B;
-    uint8_t* const flag = A.flag + B;
-    if (tid == 0) fallback[scan] = 0;
-    if (n <= 0) return;
-    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; sf[x] = 0; sl[x] = n; }
-    int depth = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
+// One pass over the recursion levels of the ranges of key[0 .. n) that are longer than `stop`: NT threads, arrays of index type T (global
+// ints or range-local shorts in LDS).  depth: levels left for the ranges of the first level; dep[first of a range] receives the levels
+// left for that range when `dep` is given.  Returns false when a range longer than `stop` remains at depth 0.
+template <int NT, typename T>
+__device__ __forceinline__ bool sort_levels(float* __restrict__ key, int* __restrict__ idx, T* __restrict__ sf, T* __restrict__ sl, T* __restrict__ cl,
+                                            T* __restrict__ cr, T* __restrict__ lp, T* __restrict__ rp, T* __restrict__ cut, uint8_t* __restrict__ flag,
+                                            int* __restrict__ dep, int n, int depth, int stop, int (*s_tot)[NT / 64], int (*s_base)[NT / 64 + 1], int* s_any) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // contiguous ranges of the wavefronts for the prefix counts: C elements each, a multiple of 64
-    const int C = ((n + kSortWaves - 1) / kSortWaves + 63) / 64 * 64;
-    bool any = n > 16;
+    const int C = ((n + NW - 1) / NW + 63) / 64 * 64;
+    bool any = n > stop;
     __syncthreads();
     while (any) {
-        if (depth == 0) { if (tid == 0) fallback[scan] = 1; break; }
+        if (depth == 0) return false;
         --depth;
         // ---- pivots: __move_median_to_first(first, first + 1, mid, last - 1) ----
-        for (int x = tid; x < n; x += kSortThreads) {
-            if (sf[x] != x) continue;
+        for (int x = tid; x < n; x += NT) {
+            if ((int)sf[x] != x) continue;
             const int last = sl[x];
-            if (last - x <= 16) continue;
+            if (last - x <= stop) continue;
             const int a = x + 1, b = x + (last - x) / 2, c = last - 1;
             const float ka = key[a], kb = key[b], kc = key[c];
             int m;
@@ -546,7 +543,7 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
                 bool fl = false, fr = false;
                 if (x < x1) {
                     const int f = sf[x];
-                    if (sl[x] - f > 16 && x != f) {
+                    if ((int)sl[x] - f > stop && x != f) {
                         const float p = key[f], k = key[x];
                         fl = !(k < p);
                         fr = !(p < k);
@@ -554,8 +551,8 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
                 }
                 const unsigned long long bl = __ballot(fl), br = __ballot(fr), le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
                 if (x < x1) {
-                    cl[x] = run_l + __popcll(bl & le);
-                    cr[x] = run_r + __popcll(br & le);
+                    cl[x] = (T)(run_l + __popcll(bl & le));
+                    cr[x] = (T)(run_r + __popcll(br & le));
                     flag[x] = (uint8_t)((fl ? 1 : 0) | (fr ? 2 : 0));
                 }
                 run_l += __popcll(bl);
@@ -566,28 +563,28 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
         __syncthreads();
         if (tid < 2) {
             int acc = 0;
-            for (int w = 0; w < kSortWaves; ++w) { s_base[tid][w] = acc; acc += s_tot[tid][w]; }
-            s_base[tid][kSortWaves] = acc;
+            for (int w = 0; w < NW; ++w) { s_base[tid][w] = acc; acc += s_tot[tid][w]; }
+            s_base[tid][NW] = acc;
         }
-        if (tid == 0) s_any = 0;
+        if (tid == 0) *s_any = 0;
         __syncthreads();
-#define TS_GL(x) (cl[x] + s_base[0][(x) / C])
-#define TS_GR(x) (cr[x] + s_base[1][(x) / C])
+#define TS_GL(x) ((int)cl[x] + s_base[0][(x) / C])
+#define TS_GR(x) ((int)cr[x] + s_base[1][(x) / C])
         // ---- candidates by rank: lp[f + 1 + k] = k-th from the left, rp[f + 1 + k] = k-th from the right ----
-        for (int x = tid; x < n; x += kSortThreads) {
+        for (int x = tid; x < n; x += NT) {
             const int fg = flag[x];
             if (!fg) continue;
             const int f = sf[x], l = sl[x];
-            if (fg & 1) lp[f + 1 + (TS_GL(x) - TS_GL(f) - 1)] = x;
-            if (fg & 2) rp[f + 1 + (TS_GR(l - 1) - TS_GR(x))] = x;
+            if (fg & 1) lp[f + 1 + (TS_GL(x) - TS_GL(f) - 1)] = (T)x;
+            if (fg & 2) rp[f + 1 + (TS_GR(l - 1) - TS_GR(x))] = (T)x;
         }
         __syncthreads();
         // ---- the swaps and the cut ----
-        for (int x = tid; x < n; x += kSortThreads) {
+        for (int x = tid; x < n; x += NT) {
             const int f = sf[x], l = sl[x];
-            if (l - f <= 16 || x == f) continue;
+            if (l - f <= stop || x == f) continue;
             const int k = x - (f + 1), nl = TS_GL(l - 1) - TS_GL(f), nr = TS_GR(l - 1) - TS_GR(f);
-            const int L = k < nl ? lp[x] : 0x7fffffff, R = k < nr ? rp[x] : -1;
+            const int L = k < nl ? (int)lp[x] : 0x7fffffff, R = k < nr ? (int)rp[x] : -1;
             if (L < R) {  // swap number k
                 const float k1 = key[L], k2 = key[R];
                 const int j1 = idx[L], j2 = idx[R];
@@ -596,11 +593,11 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
                 bool prev = k == 0;
                 int rprev = 0x7fffffff;
                 if (!prev) {
-                    const int Lp_ = k - 1 < nl ? lp[x - 1] : 0x7fffffff, Rp_ = k - 1 < nr ? rp[x - 1] : -1;
+                    const int Lp_ = k - 1 < nl ? (int)lp[x - 1] : 0x7fffffff, Rp_ = k - 1 < nr ? (int)rp[x - 1] : -1;
                     prev = Lp_ < Rp_;
                     rprev = Rp_;
                 }
-                if (prev) cut[f] = min(L, k >= 1 ? rprev : 0x7fffffff);  // the first k without a swap: __unguarded_partition returns here
+                if (prev) cut[f] = (T)min(L, k >= 1 ? rprev : 0x7fffffff);  // the first k without a swap: __unguarded_partition returns here
             }
         }
         __syncthreads();
@@ -608,35 +605,85 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
 #undef TS_GR
         // ---- the two ranges of every partition ----
         bool mine = false;
-        for (int x = tid; x < n; x += kSortThreads) {
+        for (int x = tid; x < n; x += NT) {
             const int f = sf[x], l = sl[x];
-            if (l - f <= 16) continue;
+            if (l - f <= stop) continue;
             const int c = cut[f];
             int nf = f, nl_ = l;
             if (x < c) nl_ = c; else nf = c;
-            sf[x] = nf; sl[x] = nl_;
-            mine |= nl_ - nf > 16;
+            sf[x] = (T)nf; sl[x] = (T)nl_;
+            if (dep && x == nf) dep[x] = depth;
+            mine |= nl_ - nf > stop;
         }
-        if (mine) s_any = 1;
+        if (mine) *s_any = 1;
         __syncthreads();
-        any = s_any != 0;
+        any = *s_any != 0;
         __syncthreads();
     }
-    __syncthreads();
-    // ---- __final_insertion_sort: a stable sort inside every range ----
-    for (int x = tid; x < n; x += kSortThreads) {
+    return true;
+}
+
+// __final_insertion_sort: a stable sort inside every range (of at most 16 elements); out[first of the range + rank] = idx
+template <int NT, typename T>
+__device__ __forceinline__ void sort_final(const float* __restrict__ key, const int* __restrict__ idx, const T* __restrict__ sf, const T* __restrict__ sl, int n,
+                                           int* __restrict__ out) {
+    for (int x = threadIdx.x; x < n; x += NT) {
         const int f = sf[x], l = sl[x];
         const float k = key[x];
         int rank = 0;
-        if (l - f <= 16) {
-            for (int y = f; y < l; ++y) {
-                const float ky = key[y];
-                rank += (ky < k || (ky == k && y < x)) ? 1 : 0;
-            }
-            perm[B + f + rank] = idx[x];
-        } else {
-            perm[B + x] = idx[x];  // flagged for the host (depth limit)
+        for (int y = f; y < l; ++y) {
+            const float ky = key[y];
+            rank += (ky < k || (ky == k && y < x)) ? 1 : 0;
         }
+        out[f + rank] = idx[x];
+    }
+}
+
+// ranges[scan slot base ..]: first index of every range the first kernel left for the second; n_ranges[scan]
+__global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
+                                                            const ScanSlot* __restrict__ slots, TimeSortArrays A, int* __restrict__ perm,
+                                                            int* __restrict__ fallback, int* __restrict__ ranges, int* __restrict__ n_ranges, int depth_override) {
+    __shared__ int s_tot[2][kSortThreads / 64], s_base[2][kSortThreads / 64 + 1], s_any, s_count;
+    const int scan = blockIdx.x, tid = threadIdx.x;
+    const ScanSlot sl_ = slots[scan];
+    const int n = count[scan], B = sl_.base;
+    if (tid == 0) { fallback[scan] = 0; n_ranges[scan] = 0; s_count = 0; }
+    if (n <= 0) return;
+    float* const key = A.key + B;
+    int *const idx = A.idx + B, *const sf = A.sf + B, *const sl = A.sl + B, *const dep = A.rp + B;  // rp[first of a range] is no candidate slot: free
+    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; sf[x] = 0; sl[x] = n; }
+    const int depth = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
+    if (tid == 0) dep[0] = depth;
+    const bool ok = sort_levels<kSortThreads, int>(key, idx, sf, sl, A.cl + B, A.cr + B, A.lp + B, A.rp + B, A.cut + B, A.flag + B, dep, n, depth, kSortLds,
+                                                   s_tot, s_base, &s_any);
+    if (!ok) { if (tid == 0) fallback[scan] = 1; return; }  // uniform
+    __syncthreads();
+    for (int x = tid; x < n; x += kSortThreads)
+        if (sf[x] == x) ranges[B + atomicAdd(&s_count, 1)] = x;
+    __syncthreads();
+    if (tid == 0) n_ranges[scan] = s_count;
+}
+
+__global__ __launch_bounds__(kSortLdsThreads) void k_time_sort_lds(const int* __restrict__ count, const ScanSlot* __restrict__ slots, TimeSortArrays A,
+                                                                   int* __restrict__ perm, int* __restrict__ fallback, const int* __restrict__ ranges,
+                                                                   const int* __restrict__ n_ranges) {
+    __shared__ float s_key[kSortLds];
+    __shared__ int s_idx[kSortLds];
+    __shared__ unsigned short s_sf[kSortLds], s_sl[kSortLds], s_cl[kSortLds], s_cr[kSortLds], s_lp[kSortLds + 1], s_rp[kSortLds + 1], s_cut[kSortLds];
+    __shared__ uint8_t s_flag[kSortLds];
+    __shared__ int s_tot[2][kSortLdsThreads / 64], s_base[2][kSortLdsThreads / 64 + 1], s_any;
+    const int scan = blockIdx.y, tid = threadIdx.x;
+    if (count[scan] <= 0 || fallback[scan]) return;
+    const int B = slots[scan].base, nr = n_ranges[scan];
+    for (int r = blockIdx.x; r < nr; r += gridDim.x) {
+        const int f = ranges[B + r], l = A.sl[B + f], m = l - f, depth = A.rp[B + f];
+        __syncthreads();  // the previous range's arrays are done with
+        for (int x = tid; x < m; x += kSortLdsThreads) { s_key[x] = A.key[B + f + x]; s_idx[x] = A.idx[B + f + x]; s_sf[x] = 0; s_sl[x] = (unsigned short)m; }
+        const bool ok = sort_levels<kSortLdsThreads, unsigned short>(s_key, s_idx, s_sf, s_sl, s_cl, s_cr, s_lp, s_rp, s_cut, s_flag, nullptr, m, depth, 16,
+                                                                     s_tot, s_base, &s_any);
+        if (!ok) { if (tid == 0) fallback[scan] = 1; continue; }  // uniform; the host sorts the scan
+        __syncthreads();
+        sort_final<kSortLdsThreads, unsigned short>(s_key, s_idx, s_sf, s_sl, m, perm + B + f);
     }
 }
 
@@ -673,10 +720,12 @@ __global__ __launch_bounds__(256) void k_undistort_batch(const PointXYZINormal* 
 }
 
 void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int n_scans, float* key, int* ints5, int* ints3, uint8_t* flag,
-                      size_t total, int* perm, int* fallback, int depth_override, hipStream_t st) {
+                      size_t total, int* perm, int* fallback, int* ranges, int* n_ranges, int depth_override, hipStream_t st) {
     if (!n_scans) return;
     TimeSortArrays A{key, ints5, ints5 + total, ints5 + 2 * total, ints5 + 3 * total, ints5 + 4 * total, ints3, ints3 + total, ints3 + 2 * total, flag};
-    TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, depth_override);
+    TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, ranges, n_ranges, depth_override);
+    // ranges per scan: a 65 k scan leaves some tens to a few hundred; the workgroups of a scan take them in turn
+    TC2LI_LAUNCH(k_time_sort_lds, dim3(n_scans >= 64 ? 64 : 256, n_scans), dim3(kSortLdsThreads), 0, st, count, slots, A, perm, fallback, ranges, n_ranges);
 }
 void launch_undistort_batch(const PointXYZINormal* in, const int* perm, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                             const Pose6DDev* poses, const int* n_poses, const LidarStateDev* ends, PointXYZINormal* out, hipStream_t st) {

@@ -5,6 +5,7 @@
 // new prior mpcpi: the GetHessian* blocks at the final estimate, Optimizer::Marginalize (:2087-2166) over the previous frame and
 // ConstraintPoseImu's eigenvalue clamp (G2oTypes.h:721-732) -- a 30 x 30 dense problem per frame.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -24,6 +25,7 @@ struct PiWorkspace {
     DevBuf<BaEdge> d_edges;
     DevBuf<uint8_t> d_close, d_outlier;
     PinnedBuf<PiResult> h_results;
+    PinnedBuf<uint8_t> h_stage;  // [Xw | edges | close flags] of all frames on their way up, then the outlier flags on their way back
     std::mutex mu;
 };
 PiWorkspace& pi_ws() { static thread_local PiWorkspace w; return w; }
@@ -125,7 +127,29 @@ extern "C" int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_proble
             set_error("tc2li_pose_inertial_optimization_batch: frame %d: invalid argument", f);
             return TC2LI_ERR_INVALID;
         }
+        probs[f].edge_off = (int32_t)total;
+        total += (size_t)p.n_edges;
+    }
+    PiWorkspace& w = pi_ws();
+    std::lock_guard<std::mutex> lk(w.mu);
+    const size_t T1 = std::max<size_t>(total, 1);
+    TC2LI_HIP_CHECK(w.d_probs.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_results.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_results.ensure(n_frames));
+    TC2LI_HIP_CHECK(w.d_Xw.ensure(3 * T1)); TC2LI_HIP_CHECK(w.d_chi2.ensure(T1));
+    TC2LI_HIP_CHECK(w.d_edges.ensure(T1)); TC2LI_HIP_CHECK(w.d_close.ensure(T1));
+    TC2LI_HIP_CHECK(w.d_outlier.ensure(T1));
+    static_assert(sizeof(BaEdge) == sizeof(tc2li_ba_edge), "ABI layout");
+    // the frames' arrays go up as three copies from one pinned block (a copy per frame and array costs more than the kernel at hundreds of
+    // frames); the per-frame host work -- information matrices of the inertial edge, later the marginalisation -- runs on the pool threads
+    const size_t o_edges = 3 * T1 * sizeof(double), o_close = o_edges + T1 * sizeof(BaEdge), stage_bytes = o_close + T1;
+    TC2LI_HIP_CHECK(w.h_stage.ensure(stage_bytes));
+    double* const h_Xw = reinterpret_cast<double*>(w.h_stage.p);
+    BaEdge* const h_edges = reinterpret_cast<BaEdge*>(w.h_stage.p + o_edges);
+    uint8_t* const h_close = w.h_stage.p + o_close;
+    std::atomic<int> bad_frame{-1};
+    tracking_pool().parallel_for(n_frames, [&](int f) {
+        const tc2li_pose_inertial_problem& p = problems[f];
         PiProblem& d = probs[f];
+        const int32_t edge_off = d.edge_off;
         memset(&d, 0, sizeof(d));
         state_from(p.frame, d.cur); state_from(p.other, d.other);
         const tc2li_preintegrated& q = *p.preintegrated;
@@ -135,29 +159,24 @@ extern "C" int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_proble
         d.pre.bias[0] = q.bias.bax; d.pre.bias[1] = q.bias.bay; d.pre.bias[2] = q.bias.baz; d.pre.bias[3] = q.bias.bwx; d.pre.bias[4] = q.bias.bwy; d.pre.bias[5] = q.bias.bwz;
         InertialLinkHost li, lw;  // the informations: EdgeInertial's from `preintegrated`, the random-walk ones from `preintegrated_rw` (:2645, :3049)
         li.pre = p.preintegrated; lw.pre = p.preintegrated_rw;
-        if (!li.prepare(1.0) || !lw.prepare(1.0)) { set_error("frame %d: the pre-integration covariance is not positive definite", f); return TC2LI_ERR_INVALID; }
+        if (!li.prepare(1.0) || !lw.prepare(1.0)) { bad_frame.store(f); return; }
         memcpy(d.pre.info, li.info, sizeof(li.info)); memcpy(d.pre.infoG, lw.infoG, sizeof(lw.infoG)); memcpy(d.pre.infoA, lw.infoA, sizeof(lw.infoA));
         if (p.last_frame) {
             memcpy(d.prior.Rwb, p.prior->Rwb, 72); memcpy(d.prior.twb, p.prior->twb, 24); memcpy(d.prior.vwb, p.prior->vwb, 24);
             memcpy(d.prior.bg, p.prior->bg, 24); memcpy(d.prior.ba, p.prior->ba, 24); memcpy(d.prior.H, p.prior->H, sizeof(d.prior.H));
         }
-        d.edge_off = (int32_t)total; d.n_edges = p.n_edges; d.last_frame = p.last_frame ? 1 : 0; d.rec_init = p.rec_init ? 1 : 0;
-        total += (size_t)p.n_edges;
-    }
-    PiWorkspace& w = pi_ws();
-    std::lock_guard<std::mutex> lk(w.mu);
-    TC2LI_HIP_CHECK(w.d_probs.ensure(n_frames)); TC2LI_HIP_CHECK(w.d_results.ensure(n_frames)); TC2LI_HIP_CHECK(w.h_results.ensure(n_frames));
-    TC2LI_HIP_CHECK(w.d_Xw.ensure(3 * std::max<size_t>(total, 1))); TC2LI_HIP_CHECK(w.d_chi2.ensure(std::max<size_t>(total, 1)));
-    TC2LI_HIP_CHECK(w.d_edges.ensure(std::max<size_t>(total, 1))); TC2LI_HIP_CHECK(w.d_close.ensure(std::max<size_t>(total, 1)));
-    TC2LI_HIP_CHECK(w.d_outlier.ensure(std::max<size_t>(total, 1)));
-    static_assert(sizeof(BaEdge) == sizeof(tc2li_ba_edge), "ABI layout");
-    for (int f = 0; f < n_frames; ++f) {
-        const tc2li_pose_inertial_problem& p = problems[f];
-        if (!p.n_edges) continue;
-        const size_t o = probs[f].edge_off;
-        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_Xw.p + 3 * o, p.Xw, 3 * (size_t)p.n_edges * sizeof(double), hipMemcpyHostToDevice, st));
-        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_edges.p + o, p.edges, (size_t)p.n_edges * sizeof(BaEdge), hipMemcpyHostToDevice, st));
-        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_close.p + o, p.close_point, (size_t)p.n_edges, hipMemcpyHostToDevice, st));
+        d.edge_off = edge_off; d.n_edges = p.n_edges; d.last_frame = p.last_frame ? 1 : 0; d.rec_init = p.rec_init ? 1 : 0;
+        if (p.n_edges) {
+            memcpy(h_Xw + 3 * (size_t)edge_off, p.Xw, 3 * (size_t)p.n_edges * sizeof(double));
+            memcpy(h_edges + edge_off, p.edges, (size_t)p.n_edges * sizeof(BaEdge));
+            memcpy(h_close + edge_off, p.close_point, (size_t)p.n_edges);
+        }
+    });
+    if (bad_frame.load() >= 0) { set_error("frame %d: the pre-integration covariance is not positive definite", bad_frame.load()); return TC2LI_ERR_INVALID; }
+    if (total) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_Xw.p, h_Xw, 3 * total * sizeof(double), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_edges.p, h_edges, total * sizeof(BaEdge), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_close.p, h_close, total, hipMemcpyHostToDevice, st));
     }
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.d_probs.p, probs.data(), n_frames * sizeof(PiProblem), hipMemcpyHostToDevice, st));
     ImuCalib cal;
@@ -168,22 +187,22 @@ extern "C" int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_proble
     launch_pose_inertial(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, w.d_close.p, cal, c, w.d_outlier.p, w.d_chi2.p, w.d_results.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(w.h_results.p, w.d_results.p, n_frames * sizeof(PiResult), hipMemcpyDeviceToHost, st));
-    for (int f = 0; f < n_frames; ++f)
-        if (problems[f].n_edges)
-            TC2LI_HIP_CHECK(hipMemcpyAsync(problems[f].outlier, w.d_outlier.p + probs[f].edge_off, (size_t)problems[f].n_edges, hipMemcpyDeviceToHost, st));
+    uint8_t* const h_outlier = w.h_stage.p;  // the uploads above have completed when this copy runs (same stream)
+    if (total) TC2LI_HIP_CHECK(hipMemcpyAsync(h_outlier, w.d_outlier.p, total, hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    for (int f = 0; f < n_frames; ++f) {
+    tracking_pool().parallel_for(n_frames, [&](int f) {
         tc2li_pose_inertial_problem& p = problems[f];
         const PiResult& R = w.h_results.p[f];
         state_to(R.cur, p.frame);
         if (p.last_frame) state_to(R.other, p.other);
         p.n_initial = p.n_edges; p.n_bad = R.n_bad; p.n_inliers = R.n_inliers; p.solver_failed = R.solver_failed;
+        if (p.n_edges) memcpy(p.outlier, h_outlier + probs[f].edge_off, (size_t)p.n_edges);
         if (p.prior_out) {
             tc2li_pose_imu_prior& o = *p.prior_out;
             memcpy(o.Rwb, R.cur.P.Rwb, 72); memcpy(o.twb, R.cur.P.twb, 24); memcpy(o.vwb, R.cur.v, 24); memcpy(o.bg, R.cur.bg, 24); memcpy(o.ba, R.cur.ba, 24);
             prior_hessian(probs[f], R, o.H);
         }
         if (results) results[f] = p.n_edges - R.n_bad;
-    }
+    });
     return n_frames;
 }
