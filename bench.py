@@ -68,10 +68,26 @@ def parse_args(argv=None):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # rank plumbing
 # ---------------------------------------------------------------------------------------------------------------------------------
+def under_profiler():
+    """rocprofv3 preloads its tool library into the profiled process, which initialises the GPU before main(): such a process must not
+    start children (spawned ranks, the single-sequence child, make for the oracle)."""
+    env = os.environ
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in env) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (this parent never touches
     the GPU -- a process that has initialised HIP must not fork or exec), rendezvous on 127.0.0.1, pass rank 0's line through."""
     n = args.gpus
+    if under_profiler():
+        sys.stderr.write("bench.py --gpus %d under a profiler: refusing to spawn rank processes from a profiled process; profile one rank "
+                         "(--gpus 1) or launch the ranks with torch.distributed.run under the profiler yourself\n" % n)
+        return 2
+    if not args.rehearse and not args.no_build and not os.environ.get("TC2LI_NO_BUILD"):
+        import __graft_entry__ as ge
+        ge.build_native()  # once, here: the ranks start together and must not load a library another rank is rewriting
+        if not args.no_cpu_baseline:
+            ge.build_oracle()
     if not args.rehearse:
         import torch
         have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
@@ -84,7 +100,7 @@ def spawn_ranks(args, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TC2LI_NO_BUILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -257,6 +273,37 @@ class Workload:
         return orb
 
 
+class StageWorker:
+    """A host thread that lives as long as its Loop and runs the stage functions handed to it: the library keeps work spaces and a private
+    stream per host thread (thread_local), so warm-up, timed and instrumented passes must run on the SAME threads -- fresh threads per pass
+    would allocate those work spaces again inside the timed region (and free them, synchronising the device, when the threads exit)."""
+
+    def __init__(self, name, local_rank, torch):
+        self.q = queue.Queue()
+        self.t = threading.Thread(target=self._main, args=(local_rank, torch), name=name, daemon=True)
+        self.t.start()
+
+    def _main(self, local_rank, torch):
+        torch.cuda.set_device(local_rank)  # HIP's current device is per thread; a new thread starts on device 0
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            fn, done = item
+            try:
+                fn()
+            finally:
+                done.set()
+
+    def submit(self, fn):
+        done = threading.Event()
+        self.q.put((fn, done))
+        return done
+
+    def stop(self):
+        self.q.put(None)
+
+
 class Loop:
     """Handles and stage threads for F sequences (sequence ids `seq_ids`; sequence s runs on input set s % U)."""
 
@@ -322,6 +369,7 @@ class Loop:
         self.thread_ms = {}
         self.orb_times, self.lidar_times = [], []
         self.ba_windows_done = 0
+        self.workers = {}
 
     # -- stages ------------------------------------------------------------------------------------------------------------
     def extract(self, k, stream):
@@ -457,7 +505,6 @@ class Loop:
         def wrap(fn):
             def wrapped():
                 try:
-                    torch.cuda.set_device(self.local_rank)  # HIP's current device is per thread; a new thread starts on device 0
                     t = time.perf_counter()
                     fn()
                     self.thread_ms[fn.__name__] = 1e3 * (time.perf_counter() - t) / max(n_steps, 1)
@@ -465,16 +512,21 @@ class Loop:
                     errors.append(e)
                     failed.set()
             return wrapped
-        threads = [threading.Thread(target=wrap(fn), daemon=True) for fn in fns]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        # the stage threads persist over the Loop's lifetime (one per stage function name)
+        done = []
+        for fn in fns:
+            if fn.__name__ not in self.workers:
+                self.workers[fn.__name__] = StageWorker(fn.__name__, self.local_rank, torch)
+            done.append(self.workers[fn.__name__].submit(wrap(fn)))
+        for d in done:
+            d.wait()
         if errors:
             raise errors[0]
 
     def close(self):
-        pass
+        for w in self.workers.values():
+            w.stop()
+        self.workers = {}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -831,8 +883,7 @@ def pmc_traffic(kernel):
 # CPU baseline (the oracle; rank 0 at N = 1 only)
 # ---------------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(wl, args, n_seq_gpu, with_ba):
-    from oracle import pyoracle
-    pyoracle.build()
+    from oracle import pyoracle  # built by main() before the GPU was touched
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     W, H = wl.W, wl.H
     lasts = [dict(pose7=l["pose7"], has_point=l["has_point"], outlier=l["outlier"], Xw=l["Xw"], keys6=pyoracle._kps_to_floats(l["keys"]),
@@ -918,13 +969,28 @@ def main(argv=None):
         if not ge.native_is_fresh():
             raise SystemExit("bench.py --no-build: %s is missing or older than its sources; run `python __graft_entry__.py` first" % ge.LIB)
     elif rank == 0:
+        if under_profiler() and not ge.native_is_fresh():
+            raise SystemExit("bench.py under a profiler with a stale library: build first (python __graft_entry__.py); a profiled process must not start make")
         ge.build_native()
+    else:
+        # under torch.distributed.run the ranks start together: only rank 0 builds, the others wait until the library is newer than its sources
+        t_wait = time.time()
+        while not ge.native_is_fresh():
+            if time.time() - t_wait > 900:
+                raise SystemExit("bench.py: rank %d waited 15 minutes for rank 0 to build %s" % (rank, ge.LIB))
+            time.sleep(0.5)
+    # the CPU oracle (the cpu_baseline leg's checker) is built before this process touches the GPU: a process that has initialised HIP does not
+    # start children
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:
+        if under_profiler():
+            raise SystemExit("bench.py under a profiler: pass --no-cpu-baseline (the CPU leg builds and runs the oracle; nothing to profile there)")
+        ge.build_oracle()
     # ---- the single-sequence line runs FIRST, in a child process of its own (this process has not touched the GPU yet: a process that has
     # may not start children): the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and the ten
     # streams of the five stage threads then queue behind each other -- with one sequence per step, where every kernel is tiny, that false
     # ordering is most of a frame's time (479 frames/s with 4 queues, 761 with 8; the batched lines lose 1-9 % with 8 and keep the default)
     single_child = None
-    if rank == 0 and not args.no_extra_lines and not args.rehearse and not os.environ.get("TC2LI_BENCH_SINGLE_INPROC"):
+    if rank == 0 and not args.no_extra_lines and not args.rehearse and not os.environ.get("TC2LI_BENCH_SINGLE_INPROC") and not under_profiler():
         single_child = single_sequence_child(args)
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -1089,6 +1155,7 @@ def main(argv=None):
                                         "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one_i.thread_ms.items()},
                                         "process": "in this process (4 hardware queues; the camera-LiDAR single-sequence line runs in a child with 8)"},
                     **stats_i}
+        one_i.close(); il.close()
         del one_i, il
 
     # ---- CPU baseline: the oracle (a port) with the reference's threading ----

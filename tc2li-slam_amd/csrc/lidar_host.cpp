@@ -33,6 +33,9 @@ struct tc2li_lidar_map {
     DevBuf<MapIncTask> d_inc_task;    // batches of one map: Build / Add_Points / Delete_Point_Boxes
     DevBuf<MapGridTask> d_grid_task;
     int n = 0, n_cells = 0;
+    // bumped whenever the points are renumbered or replaced (Build / Add_Points / compaction): tc2li_lidar_map_incremental replays neighbour
+    // INDICES found by an earlier feature extraction and refuses when the map has changed in between
+    uint64_t generation = 0;
     float cell = 1.0f;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};  // bounding box of the points
     MapGrid grid{};
@@ -86,6 +89,7 @@ struct tc2li_lidar {
     DevBuf<MapGridTask> d_grid_tasks;
     PinnedBuf<int> h_mapinc_out;
     std::vector<int> last_down;  // per slot: down-sampled points of the last feature extraction
+    std::vector<std::pair<const tc2li_lidar_map*, uint64_t>> last_map;  // per slot: the map searched and its generation then
     std::vector<int> last_sel;   // per slot: selected features (laserCloudOri) of the last tc2li_lidar_frontend_batch
     DevBuf<TransformTask> d_xform_tasks;
     DevBuf<PointXYZINormal> d_xform_out;
@@ -300,6 +304,7 @@ void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
             m->hi[a] = std::max(m->hi[a], hi);
         }
     m->n = kept + added;
+    ++m->generation;
 }
 
 }  // namespace
@@ -692,6 +697,7 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
     TC2LI_HIP_CHECK(L->d_eskf_partial.ensure((size_t)((n + 255) / 256) * kEskfOutSize));
     TC2LI_HIP_CHECK(L->h_eskf_out.ensure(kEskfOutSize));
     L->last_down.assign(1, n);
+    L->last_map.assign(1, {map, map->generation});
     const PointXYZINormal* body = reinterpret_cast<const PointXYZINormal*>(feats_down_body);
     EskfRun run;
     run.begin(x, P529);
@@ -851,6 +857,8 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
     if (hc[3 * S]) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), st)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     L->last_down.assign(hc + S, hc + 2 * S);
+    L->last_map.resize(S);
+    for (int s = 0; s < S; ++s) L->last_map[s] = {maps[s], maps[s]->generation};
     L->last_sel.assign(S, 0);
     L->timed = false;
     // ---- the iterated update, all scans in lock step ----
@@ -962,6 +970,7 @@ static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool re
         }
     }
     m->n = old + n;
+    ++m->generation;
     int rc = rebuild_grid(m, ps);
     if (rc != TC2LI_OK) return rc;
     TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
@@ -987,6 +996,18 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         std::vector<const tc2li_lidar_map*> seen(maps, maps + n_tasks);
         std::sort(seen.begin(), seen.end());
         if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { set_error("tc2li_lidar_map_incremental_batch: a map appears twice in one batch"); return TC2LI_ERR_INVALID; }
+        std::vector<int32_t> slots_seen(scans, scans + n_tasks);
+        std::sort(slots_seen.begin(), slots_seen.end());
+        if (std::adjacent_find(slots_seen.begin(), slots_seen.end()) != slots_seen.end()) { set_error("tc2li_lidar_map_incremental_batch: a scan slot appears twice in one batch"); return TC2LI_ERR_INVALID; }
+    }
+    // the neighbours of a scan slot are indices into the map its feature extraction searched: that map, unchanged since
+    for (int i = 0; i < n_tasks; ++i) {
+        const auto& lm = L->last_map[scans[i]];
+        if (lm.first != maps[i] || lm.second != maps[i]->generation) {
+            set_error("tc2li_lidar_map_incremental: map %d is not the map scan slot %d was matched against, or it has changed since (Build / Add_Points / "
+                      "map_incremental / Delete_Point_Boxes renumber the points the neighbour indices refer to)", i, scans[i]);
+            return TC2LI_ERR_INVALID;
+        }
     }
     MapLocks locks(maps, n_tasks);
     const size_t S = L->max_scans, T = L->total;
@@ -1274,6 +1295,7 @@ int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const t
     rc = run_features(L, L->d_down.p, L->d_down_count.p, &map, state, ps);
     if (rc != TC2LI_OK) return rc;
     L->last_down.assign(1, n);
+    L->last_map.assign(1, {map, map->generation});
     int m = 0;
     TC2LI_HIP_CHECK(copy_sync(&m, L->d_sel_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));
     if (feats_down_world) TC2LI_HIP_CHECK(copy_sync(feats_down_world, L->d_world.p, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
@@ -1335,6 +1357,8 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
     if (hc[3 * n_scans]) { TC2LI_HIP_CHECK(memset_sync(L->d_status.p, 0, sizeof(int), st)); set_error("more than 32768 occupied voxels in one scan"); return TC2LI_ERR_CAPACITY; }
     L->last_down.assign(hc + n_scans, hc + 2 * n_scans);
+    L->last_map.resize(n_scans);
+    for (int s = 0; s < n_scans; ++s) L->last_map[s] = {maps[s], maps[s]->generation};
     L->last_sel.assign(hc + 2 * n_scans, hc + 3 * n_scans);
     for (int s = 0; s < n_scans; ++s) {
         if (n_preprocessed) n_preprocessed[s] = hc[s];

@@ -216,3 +216,37 @@ def test_reference_sized_map(pkg, oracle, synthetic):
         assert np.array_equal(canon(m.points()), canon(ref2))
         ref = ref2
         tree = oracle.KdTree(ref)
+
+
+def test_map_incremental_refuses_stale_neighbour_indices(pkg, oracle, synthetic):
+    """map_incremental replays neighbour INDICES of the scan slot's feature extraction: the entry points refuse when the map is another one or has
+    been renumbered since (a second map_incremental, Delete_Point_Boxes, Build), and a scan slot twice in one batch."""
+    import torch
+    S = 2
+    fe = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=S)
+    scene = synthetic.Scene(3)
+    raws = [synthetic.lidar_scan(scene, f) for f in (1, 2)]
+    states = np.stack([pkg.pack_lidar_state(*synthetic.lidar_state(f)[:2]) for f in (1, 2)])
+    street = synthetic.lidar_map(scene, x_from=-40.0, x_to=60.0)
+    maps = [pkg.LidarMap(), pkg.LidarMap()]
+    for m in maps:
+        m.Build(street)
+    raw = np.concatenate(raws)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int32)
+    dev = torch.from_numpy(raw.view(np.uint8)).cuda()
+    fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.map_incremental_batch(fe, [0, 0], maps, states)          # a scan slot twice
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.map_incremental_batch(fe, [0, 1], maps[::-1], states)    # slot 0 was matched against maps[0], not maps[1]
+    size0 = maps[0].size()
+    na, nn, sz = pkg.capi.map_incremental_batch(fe, [0, 1], maps, states)
+    assert na[0] + nn[0] > 0 and sz[0] > size0
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.map_incremental_batch(fe, [0, 1], maps, states)          # the maps have been renumbered by the call above
+    fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    pkg.capi.delete_point_boxes_batch([maps[1]], [np.array([[-5, -5, -5, 5, 5, 5]], np.float32)])
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.map_incremental_batch(fe, [1], [maps[1]], states[1:])    # a box deletion in between
+    na, _, _ = pkg.capi.map_incremental_batch(fe, [0], [maps[0]], states[:1])  # slot 0's map is untouched: fine
+    assert na[0] >= 0
