@@ -327,7 +327,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
                       double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
                       uint8_t* edge_depth_positive, tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window,
                       tc2li_lidar_ba_stats* lidar_stats, const tc2li_ba_shard* shard, const uint8_t* used_all, void* stream_,
-                      bool* peers_told = nullptr) {
+                      int* shard_exit = nullptr) {
     if (!poses7 || !fixed || !points3 || !edges || !cam || n_poses <= 0 || n_points <= 0 || n_edges <= 0 || iterations < 0) {
         set_error("tc2li_local_bundle_adjustment: invalid argument");
         return TC2LI_ERR_INVALID;
@@ -344,12 +344,23 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     // collective cannot be enqueued -- the launcher's watchdog has to end those.
     const bool sharded = shard != nullptr;
     struct Collective { double* dev = nullptr; size_t count = 0; int op = TC2LI_REDUCE_SUM; } next;
+    // *shard_exit, for a sharded window that returns an error: kShardResultSumNext -- the peers' next collective is the wrapper's result sum
+    // (it joins that sum with its status word set); kShardPeersTold -- the peers were told through the collective they were heading for;
+    // kShardUnknown -- this rank cannot know what the peers enter next (or could not tell them): it must not enter any collective, the
+    // launcher's watchdog ends the job
+    enum { kShardResultSumNext = 0, kShardPeersTold = 1, kShardUnknown = 2 };
+    bool result_sum_next = false;
+    if (shard_exit) *shard_exit = kShardUnknown;
     BaWorkspace& ws = ba_ws();
     std::lock_guard<std::mutex> lk(ws.mu);
     double* h_stat = nullptr;  // [0..4): status words read back since the last synchronisation; [6] = 0.0, [7] = 1.0 (sources)
     int n_stat = 0;
     double* d_red = nullptr;
+    // One collective of the replicated control flow.  Its own failures leave this rank out of step with the peers (the status word did not go
+    // out, or the sum ran and its word could not be read: the peers are already past it): *shard_exit stays kShardUnknown.
     auto reduce = [&](double* dev, size_t count, int op, bool failed = false) -> int {
+        next = Collective{};
+        result_sum_next = false;
         if (hipMemcpyAsync(dev + count, h_stat + (failed ? 7 : 6), sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
             (void)hipGetLastError();
             set_error("sharded bundle adjustment: the status word could not be written");
@@ -374,9 +385,12 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     auto leave = [&](int rc) {  // a local failure: tell the peers through their next collective, then return the error
         if (sharded && next.dev && h_stat) {
             const std::string why = tc2li_last_error();
-            if (reduce(next.dev, next.count, next.op, true) == 0 && hipStreamSynchronize(st) == hipSuccess) { if (peers_told) *peers_told = true; }
+            const Collective c = next;
+            if (reduce(c.dev, c.count, c.op, true) == 0 && hipStreamSynchronize(st) == hipSuccess) { if (shard_exit) *shard_exit = kShardPeersTold; }
             (void)hipGetLastError();
             set_error("%s", why.c_str());
+        } else if (sharded && result_sum_next) {
+            if (shard_exit) *shard_exit = kShardResultSumNext;
         }
         return rc;
     };
@@ -396,7 +410,8 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
         d_red = ws.d_red.p;
         h_stat = ws.h_stat.p;
         h_stat[6] = 0.0; h_stat[7] = 1.0;
-        if (iterations > 0) next = Collective{d_red, 1, TC2LI_REDUCE_SUM};  // else: the wrapper's result sum comes first
+        if (iterations > 0) next = Collective{d_red, 1, TC2LI_REDUCE_SUM};
+        else result_sum_next = true;  // the wrapper's result sum comes first
         if (const char* inj = getenv("TC2LI_TEST_SHARD_FAIL")) {  // tests: "<rank>:setup" makes that rank fail before its first collective
             int r = -1; char where[16] = {0};
             if (sscanf(inj, "%d:%15s", &r, where) == 2 && r == shard->rank && !strcmp(where, "setup")) {
@@ -580,6 +595,14 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
                 TC2LI_SH_CHECK(hipGetLastError());
                 TC2LI_SH_CHECK(hipStreamSynchronize(st));
                 if (sharded && peer_failed()) return (int)TC2LI_ERR_COMM;
+                if (sharded)
+                    if (const char* inj = getenv("TC2LI_TEST_SHARD_FAIL")) {  // tests: "<rank>:trial" fails here, where the next collective is not known yet
+                        int r = -1; char where[16] = {0};
+                        if (sscanf(inj, "%d:%15s", &r, where) == 2 && r == shard->rank && !strcmp(where, "trial")) {
+                            set_error("injected failure (TC2LI_TEST_SHARD_FAIL=%s)", inj);
+                            return leave(TC2LI_ERR_INVALID);
+                        }
+                    }
                 if (sharded) stop_agreed = h_scal.p[5] > 0;
                 tempChi = h_scal.p[4];
                 scale += h_scal.p[3];
@@ -618,6 +641,8 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
         if (n_bad >= 3) ok = false;
     }
     next = Collective{};  // the wrapper's result sum is the next collective: it tells the peers itself
+    result_sum_next = true;
+    if (sharded && shard_exit) *shard_exit = kShardResultSumNext;  // also for the plain HIP checks of the result copies below
     if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; }
     if (lidar && lidar_stats) {
         lidar_stats->n_planes = lidar->n_planes; lidar_stats->hessian_evaluations = lidar->hessian_evaluations;
@@ -706,10 +731,13 @@ int tc2li_local_lv_bundle_adjustment_sharded(double* poses7, const uint8_t* fixe
     }
     std::vector<double> chi2(mine.size());
     std::vector<uint8_t> depth(mine.size());
-    bool peers_told = false;
+    int shard_exit = 2;
     int rc = lv_ba_impl(poses7, fixed, n_poses, pts.data(), (int)global_point.size(), mine.data(), (int)mine.size(), cam, iterations,
-                        lambda_init, stop_flag, chi2.data(), depth.data(), stats, lidar_window, lidar_stats, shard, used_all.data(), stream_, &peers_told);
-    if (rc == TC2LI_ERR_COMM || (rc < 0 && peers_told)) return rc;  // agreed on inside the loops: every rank is leaving
+                        lambda_init, stop_flag, chi2.data(), depth.data(), stats, lidar_window, lidar_stats, shard, used_all.data(), stream_, &shard_exit);
+    // a failed rank joins the result sum only when that sum IS the collective the peers enter next; told inside the loops: every rank is
+    // leaving; otherwise (the peers are in a collective of another size, or nothing is known) no collective is entered at all -- a sum of the
+    // wrong size would hang or corrupt the others, the launcher's watchdog ends the job instead
+    if (rc == TC2LI_ERR_COMM || (rc < 0 && shard_exit != 0)) return rc;
     // ---- every rank receives the whole result: one sum of [points | chi2 | depth flags | status word], zeros where another rank owns the
     // entry.  A rank that failed locally after its last collective joins this sum with its status word set (and zeros), so that the others
     // return TC2LI_ERR_COMM instead of waiting for it. ----

@@ -116,18 +116,19 @@ def test_shard_argument_errors(pkg, synthetic):
         pkg.capi.local_lv_bundle_adjustment_sharded(many, w["poses"], w["fixed"], w["points"], e, w["cam"])
 
 
-def _rank_failing(rank, world, port, out):
+def _rank_failing(rank, world, port, out, where="setup", timeout_s=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["TC2LI_TEST_SHARD_FAIL"] = "1:setup"  # rank 1 fails before its first collective (read by every rank, acted on by rank 1)
+    os.environ["TC2LI_TEST_SHARD_FAIL"] = "1:" + where  # rank 1 fails there (read by every rank, acted on by rank 1)
+    import datetime
     import torch
     import torch.distributed as dist
     import tc2li_loader
     pkg = tc2li_loader.load()
     from tc2li_slam_amd import synthetic
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, **({"timeout": datetime.timedelta(seconds=timeout_s)} if timeout_s else {}))
     try:
         w, kw = _window(synthetic, 3, False)
         e = pkg.pack_ba_edges(w["edges"])
@@ -153,3 +154,18 @@ def test_a_failing_rank_takes_the_others_with_it(pkg):
     mp.spawn(_rank_failing, args=(2, port, out), nprocs=2, join=True)
     assert "injected failure" in out[1], out[1]
     assert "another rank failed" in out[0], out[0]
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_failing_mid_trial_enters_no_collective(pkg):
+    """a rank that fails where it cannot know the peers' next collective (after a trial's scalar sum: another trial, the next
+    iteration or the result sum follows, decided by values it has not read) must not join any collective -- a sum of the wrong size would
+    hang or corrupt the others.  It returns its own error at once; the healthy rank stays in its next all-reduce until the communicator's
+    watchdog (here gloo's 8 s timeout) ends it, and returns TC2LI_ERR_COMM."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29700 + os.getpid() % 90
+    mp.spawn(_rank_failing, args=(2, port, out, "trial", 8), nprocs=2, join=True)
+    assert "injected failure" in out[1], out[1]
+    assert "all-reduce callback returned" in out[0] or "another rank failed" in out[0], out[0]
