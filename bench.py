@@ -864,18 +864,35 @@ def roofline_from_profile(report, work, peaks, n_steps):
     return out, table, total_ms / n_steps
 
 
+def source_hash():
+    """sha256 over the library's sources and this file: what tools/summarize_profile.py stamps into profiles/*_pmc_traffic.json, so that a
+    traffic figure is only quoted for the code it was measured on (the GPU box has no git history to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "tc2li-slam_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + ["../../include/tc2li_hip.h", "../../bench.py"]:
+        path = os.path.join(csrc, f)
+        if os.path.isfile(path) and not f.startswith("."):
+            h.update(f.encode()); h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (tools/profile_round.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
-    --pmc passes; the counters cannot be read inside this process).  None when no summary names the kernel."""
+    """HBM bytes per launch of `kernel` from a committed PMC summary (tools/profile_round.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc
+    passes of this bench command; the counters cannot be read inside this process) -- only from a summary made on THIS source tree
+    (`source_hash`); None otherwise."""
     import glob
+    here = source_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         pmc = json.load(open(f))
-        hit = [v for k, v in pmc.items() if base_name(k.split("::")[-1]) == kernel and v.get("hbm_bytes_per_launch")]
+        if pmc.get("_source_hash") != here:
+            continue
+        hit = [v for k, v in pmc.items() if not k.startswith("_") and base_name(k.split("::")[-1]) == kernel and v.get("hbm_bytes_per_launch")]
         if hit:
             n = sum(v["launches"] for v in hit)
             return {"bytes_per_launch": int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / max(n, 1)), "source": "profiles/" + os.path.basename(f),
-                    "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of the bench command at the commit that file was "
-                            "made at -- an earlier run, not this one"}
+                    "source_hash": here,
+                    "note": "FETCH_SIZE x 2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes of this bench command on the same sources"}
     return None
 
 
@@ -1061,7 +1078,12 @@ def main(argv=None):
     roofline, kernel_table, kernel_ms_per_step, peaks = None, None, None, None
     if rank == 0 and (not args.no_extra_lines or args.with_roofline):
         pk = pkg.capi.diag_peaks()
+        ck = pkg.capi.diag_clocks()
         peaks = {"mfma_f64_tflops": round(pk[0], 2), "fma_f64_tflops": round(pk[1], 2), "hbm_copy_GBps": round(pk[2], 1),
+                 "clock_ghz_in_mfma_loop": round(ck[0], 3), "clock_ghz_in_fma_loop": round(ck[1], 3),
+                 "mfma_f64_spec_tflops": 78.6,
+                 "mfma_note": "the matrix loop holds its clock (s_memtime against the 100 MHz counter): the gap to the 78.6 TFLOP/s of the data sheet is "
+                              "issue cadence (~105 cycles per v_mfma_f64_16x16x4_f64 and SIMD where 64 would give the data-sheet rate), not DVFS",
                  "note": "measured on this GPU by tc2li_diag_peaks: back-to-back v_mfma_f64_16x16x4_f64, f64 vector FMA, 1 GiB float4 copy (read + write)"}
         n_prof = max(4, min(args.steps, 10))
         pkg.capi.profile_enable(True)
@@ -1104,6 +1126,25 @@ def main(argv=None):
                   "ba_windows": one.ba_windows_done, "workload": "the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame" % args.kf_interval,
                   "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one.thread_ms.items()}}
         one.close()
+
+    # ---- sequences per GPU: what strong scaling over the fixed list turns into at 8 / 4 / 2 ranks, timed here on one GPU ----
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_extra_lines and set(stages) == {"orb", "track", "lidar", "ba"}:
+        sweep = {str(F): round(total_sequences * args.steps / elapsed, 1)}
+        for n_seq in (256, 128, 64):
+            if n_seq >= F:
+                continue
+            sub = Loop(wl, seq_ids[:n_seq], args, local_rank)
+            sub.run(3, stages)
+            torch.cuda.synchronize()
+            n_sw = 10
+            t1 = time.perf_counter()
+            sub.run(n_sw, stages)
+            torch.cuda.synchronize()
+            sweep[str(n_seq)] = round(n_seq * n_sw / (time.perf_counter() - t1), 1)
+            sub.close()
+            del sub
+        sweep["unit"] = "frames/s of the whole loop with that many sequences per step on this one GPU (3 warm-up + 10 timed steps each)"
 
     # ---- configs[3]: the inertial configuration (IMU pre-integration, pose-inertial optimisation, UndistortPcl + ESKF, LocalLVIBA), the same
     # sequences batched the same way, with its own roofline pass, single-sequence line and CPU leg ----
@@ -1227,11 +1268,19 @@ def main(argv=None):
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
                 "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_batch.stats[0].iterations), "trials": int(loop.ba_batch.stats[0].trials),
                                                       "planes": int(loop.ba_batch.lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "inertial_config": inertial, **({"sharded_window": sharded_window} if sharded_window else {}),
+            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "inertial_config": inertial, "sequences_per_gpu_sweep": sweep, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
             "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
             "track_calls_ms_last_step": dict(zip(("stereo_match_batch", "track_motion_model_batch", "track_local_map_batch"), [round(v, 3) for v in loop.track_ms])),
         }
+        # BASELINE.json's 1-GPU configs describe ONE sequence: that number and its CPU leg side by side, next to the batched `value`
+        if single is not None:
+            c1 = (cpu or {}).get("single_sequence")
+            line["config"]["baseline_config_value"] = {
+                "workload": "configs[1]+[2] as BASELINE.json states them: one KITTI-shaped sequence (F = 1), front end + local LV-BA every %d-th frame" % args.kf_interval,
+                "value": single["value"], "unit": "frames/s", "cpu_baseline": None if not c1 else c1["value"],
+                "vs_cpu": None if not c1 else round(single["value"] / c1["value"], 2),
+                "note": "`value` of this line is the same loop for %d sequences per step (multi-sequence operation, configs[4]'s workload on one GPU)" % total_sequences}
         print(json.dumps(line))
         sys.stdout.flush()
     loop.close()

@@ -881,6 +881,9 @@ int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_problem* problems
 int tc2li_profile_enable(int on);
 int tc2li_profile_report(char* text, int capacity);
 int tc2li_diag_peaks(double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbps);
+/* The shader clock (GHz) the chip holds inside the two arithmetic loops of tc2li_diag_peaks, from s_memtime against the constant 100 MHz
+ * counter: the data sheet's 78.6 TFLOP/s of f64 matrix / vector arithmetic assume 2.4 GHz. */
+int tc2li_diag_clocks(double* mfma_loop_ghz, double* fma_loop_ghz);
 
 #ifdef __cplusplus
 }

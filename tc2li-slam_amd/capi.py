@@ -157,6 +157,13 @@ def exported_symbols():
     return sorted(set(re.findall(r"\b(tc2li_[a-z0-9_]+)\s*\(", text)))
 
 
+def diag_clocks():
+    """(GHz inside the f64 MFMA loop, GHz inside the f64 FMA loop) of tc2li_diag_peaks' kernels."""
+    a, b = C.c_double(0), C.c_double(0)
+    _check(lib().tc2li_diag_clocks(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def profile_enable(on=True):
     _check(lib().tc2li_profile_enable(int(bool(on))))
 

@@ -25,6 +25,40 @@ __global__ __launch_bounds__(256) void k_diag_mfma_f64(int iters, double* __rest
     if (s == 12345.678) sink[0] = s;  // never true: keeps the loop alive
 }
 
+// The same loops with the shader clock (s_memtime) and the constant 100 MHz counter (s_memrealtime) read around them by one lane:
+// cycles per microsecond = the clock the chip holds under this load (the f64 matrix peak of the data sheet assumes 2.4 GHz).
+template <bool MFMA>
+__global__ __launch_bounds__(256) void k_diag_clock(int iters, long long* __restrict__ out, double* __restrict__ sink) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    double s = 0;
+    if (MFMA) {
+        const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+        v4d acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double x[8];
+        const double m = 1.0 + 1e-12 * threadIdx.x, c = 1e-9;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = 1.0 + i;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = fma(x[i], m, c);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += x[i];
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (s == 12345.678) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+
 // Plain f64 FMA on the vector pipe, 8 independent chains per lane (the rate the non-matrix BA kernels are bounded by).
 __global__ __launch_bounds__(256) void k_diag_fma_f64(int iters, double* __restrict__ sink) {
     double x[8];
@@ -48,6 +82,33 @@ __global__ __launch_bounds__(256) void k_diag_copy(const float4* __restrict__ sr
 }  // namespace tc2li
 
 using namespace tc2li;
+
+extern "C" int tc2li_diag_clocks(double* mfma_loop_ghz, double* fma_loop_ghz) {
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    hipStream_t st = private_stream();
+    DevBuf<double> sink;
+    DevBuf<long long> d_out;
+    TC2LI_HIP_CHECK(sink.alloc(8));
+    TC2LI_HIP_CHECK(d_out.alloc(2));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    TC2LI_HIP_CHECK(hipGetDevice(&dev));
+    TC2LI_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    long long h[2];
+    for (int which = 0; which < 2; ++which) {
+        double* dst = which == 0 ? mfma_loop_ghz : fma_loop_ghz;
+        if (!dst) continue;
+        for (int rep = 0; rep < 2; ++rep) {  // the second run: clocks settled under the load
+            if (which == 0) TC2LI_LAUNCH(k_diag_clock<true>, dim3(cus * 4), dim3(256), 0, st, 4096, d_out.p, sink.p);
+            else TC2LI_LAUNCH(k_diag_clock<false>, dim3(cus * 8), dim3(256), 0, st, 8192, d_out.p, sink.p);
+            TC2LI_HIP_CHECK(hipGetLastError());
+            TC2LI_HIP_CHECK(copy_sync(h, d_out.p, sizeof(h), hipMemcpyDeviceToHost, st));
+        }
+        *dst = h[1] > 0 ? (double)h[0] / ((double)h[1] * 10.0) : 0.0;  // shader cycles per nanosecond (s_memrealtime ticks are 10 ns)
+    }
+    return TC2LI_OK;
+}
 
 extern "C" int tc2li_diag_peaks(double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbps) {
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;

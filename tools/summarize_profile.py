@@ -40,7 +40,11 @@ for k in sorted(set(fetch) | set(write)):
               "write_bytes_per_launch": (1024.0 * w[1] / w[0]) if w[0] else None}
     fb, wb = res[k]["fetch_bytes_per_launch"], res[k]["write_bytes_per_launch"]
     res[k]["hbm_bytes_per_launch"] = (fb or 0.0) + (wb or 0.0)
+sys.path.insert(0, os.getcwd())
+import bench  # noqa: E402  (source_hash: the traffic figures are only quoted for the sources they were measured on)
+res["_source_hash"] = bench.source_hash()
 json.dump(res, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1, sort_keys=True)
+del res["_source_hash"]
 top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
 for k, v in top:
     print("%-40s launches %5d  fetch %12.0f B  write %12.0f B per launch" % (k[:40], v["launches"], v["fetch_bytes_per_launch"] or 0, v["write_bytes_per_launch"] or 0))
