@@ -293,7 +293,9 @@ int tc2li_pose_optimization_batch(int n_frames, double* poses7, const int32_t* e
     }
     CameraD c;
     memcpy(&c, cam, sizeof(c));
-    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, c, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, st);
+    int max_edges = 0;
+    for (int f = 0; f < n_frames; ++f) max_edges = std::max(max_edges, probs[f].n);
+    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, c, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, max_edges, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(poses7, w.d_poses.p, (size_t)7 * n_frames * sizeof(double), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(n_inliers, w.d_inliers.p, n_frames * sizeof(int), hipMemcpyDeviceToHost, st));

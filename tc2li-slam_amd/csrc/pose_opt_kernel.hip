@@ -43,24 +43,18 @@ __device__ __forceinline__ double block_sum(double x, double* s_red, double* s_o
     return s_out[0];
 }
 
-__global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
-                                                                 const BaEdge* __restrict__ edges, CameraD cam,
-                                                                 double* __restrict__ poses7, uint8_t* __restrict__ outlier,
-                                                                 double* __restrict__ chi2_scratch, int* __restrict__ inliers) {
+// E, X, chi2, out: the frame's N correspondences, their map points, one chi2 and one outlier flag per edge -- in global memory, or staged in
+// LDS by the caller (k_pose_optimization_lds)
+__device__ __forceinline__ void pose_optimization_body(const int N, const BaEdge* __restrict__ E, const double* __restrict__ X, double* __restrict__ chi2,
+                                                       uint8_t* __restrict__ out, const CameraD& cam, double* __restrict__ pose_io, int* __restrict__ inliers) {
     __shared__ double s_red[4 * kRed], s_sum[kRed];
     __shared__ Se3 s_pose, s_trial;
     __shared__ int s_flag[4];  // [0] continue trial loop, [1] accepted, [2] iteration result ok, [3] solve ok
-    const PoseProblem pr = probs[blockIdx.x];
-    const int tid = threadIdx.x, N = pr.n;
-    const BaEdge* E = edges + pr.edge_off;
-    const double* X = Xw + 3 * (size_t)pr.edge_off;
-    uint8_t* out = outlier + pr.edge_off;
-    double* chi2 = chi2_scratch + pr.edge_off;
-    double* pose_io = poses7 + 7 * (size_t)blockIdx.x;
+    const int tid = threadIdx.x;
 
     for (int i = tid; i < N; i += kPoThreads) out[i] = 0;
     if (N < 3) {  // nInitialCorrespondences < 3 (Optimizer.cc:999-1000)
-        if (tid == 0) inliers[blockIdx.x] = 0;
+        if (tid == 0) inliers[0] = 0;
         return;
     }
     Se3 initial;
@@ -232,15 +226,64 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
         // Frame::SetPose(Sophus::SE3<float>): the result is stored in float
         for (int k = 0; k < 4; ++k) pose_io[k] = (double)(float)s_pose.q[k];
         for (int k = 0; k < 3; ++k) pose_io[4 + k] = (double)(float)s_pose.t[k];
-        inliers[blockIdx.x] = N - n_bad_total;
+        inliers[0] = N - n_bad_total;
     }
 }
 
+__global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
+                                                                 const BaEdge* __restrict__ edges, CameraD cam,
+                                                                 double* __restrict__ poses7, uint8_t* __restrict__ outlier,
+                                                                 double* __restrict__ chi2_scratch, int* __restrict__ inliers) {
+    const PoseProblem pr = probs[blockIdx.x];
+    pose_optimization_body(pr.n, edges + pr.edge_off, Xw + 3 * (size_t)pr.edge_off, chi2_scratch + pr.edge_off, outlier + pr.edge_off, cam,
+                           poses7 + 7 * (size_t)blockIdx.x, inliers + blockIdx.x);
+}
+
+// The same with the frame's correspondences staged in LDS for the whole optimisation: HBM sees each edge and map point once and one outlier
+// flag per edge, instead of a re-read of edge, point and chi2 on each of the ~40 linearisations and trial evaluations (26 x the algorithmic
+// bytes in round 2's counters).  Same loops, same order of the sums: the same bits.  cap = edges the dynamic LDS block holds (>= every n).
+constexpr int kPoLdsPerEdge = sizeof(BaEdge) + 3 * sizeof(double) + sizeof(double) + 1;  // 73 B
+__global__ __launch_bounds__(kPoThreads) void k_pose_optimization_lds(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
+                                                                     const BaEdge* __restrict__ edges, CameraD cam,
+                                                                     double* __restrict__ poses7, uint8_t* __restrict__ outlier,
+                                                                     int* __restrict__ inliers, int cap) {
+    extern __shared__ double s_po[];
+    const PoseProblem pr = probs[blockIdx.x];
+    const int N = pr.n, tid = threadIdx.x;
+    double* const s_X = s_po;                                  // [cap][3]
+    double* const s_chi2 = s_X + 3 * (size_t)cap;              // [cap]
+    BaEdge* const s_E = reinterpret_cast<BaEdge*>(s_chi2 + cap);  // [cap] (40 B each: 8-byte aligned)
+    uint8_t* const s_out = reinterpret_cast<uint8_t*>(s_E + cap);
+    {
+        const double* gx = Xw + 3 * (size_t)pr.edge_off;
+        for (int k = tid; k < 3 * N; k += kPoThreads) s_X[k] = gx[k];
+        const double* ge = reinterpret_cast<const double*>(edges + pr.edge_off);
+        double* se = reinterpret_cast<double*>(s_E);
+        for (int k = tid; k < 5 * N; k += kPoThreads) se[k] = ge[k];
+    }
+    __syncthreads();
+    pose_optimization_body(N, s_E, s_X, s_chi2, s_out, cam, poses7 + 7 * (size_t)blockIdx.x, inliers + blockIdx.x);
+    __syncthreads();
+    uint8_t* out = outlier + pr.edge_off;
+    for (int i = tid; i < N; i += kPoThreads) out[i] = s_out[i];
+}
+
 void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double* Xw, const BaEdge* edges, const CameraD& cam,
-                              double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, hipStream_t st) {
-    if (nprobs > 0)
-        TC2LI_LAUNCH(k_pose_optimization, dim3(nprobs), dim3(kPoThreads), 0, st, probs, Xw, edges, cam, poses7, outlier,
-                           chi2_scratch, inliers);
+                              double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, int max_edges, hipStream_t st) {
+    if (nprobs <= 0) return;
+    // the correspondences of a frame in LDS when they fit: up to 1024 leave room for two workgroups per CU, up to 2048 for one
+    const int cap = max_edges <= 1024 ? 1024 : 2048;
+    if (max_edges <= 2048) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_pose_optimization_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * kPoLdsPerEdge + 64);
+            attr_set = true;
+        }
+        TC2LI_LAUNCH(k_pose_optimization_lds, dim3(nprobs), dim3(kPoThreads), (size_t)cap * kPoLdsPerEdge + 64, st, probs, Xw, edges, cam, poses7, outlier,
+                     inliers, cap);
+    } else {
+        TC2LI_LAUNCH(k_pose_optimization, dim3(nprobs), dim3(kPoThreads), 0, st, probs, Xw, edges, cam, poses7, outlier, chi2_scratch, inliers);
+    }
 }
 
 }  // namespace tc2li

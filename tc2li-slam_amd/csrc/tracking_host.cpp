@@ -278,7 +278,7 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
                             w.d_edge_kp.p, w.d_poses.p, st);
     CameraD cd;
     memcpy(&cd, cam, sizeof(cd));
-    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, st);
+    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, capacity, st);
     launch_track_finish_last(w.d_frames.p, n_frames, capacity, w.d_nmatch.p, w.d_probs.p, w.d_outlier.p, w.d_edge_kp.p, w.d_inliers.p, w.d_of_key.p, w.d_poses.p,
                              w.d_ninl.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
@@ -423,7 +423,7 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
                              w.d_edge_kp.p, w.d_poses.p, st);
     CameraD cd;
     memcpy(&cd, cam, sizeof(cd));
-    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, st);
+    launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, capacity, st);
     launch_track_finish_local(w.d_frames.p, n_frames, capacity, w.d_probs.p, w.d_outlier.p, w.d_edge_kp.p, d_held, w.d_of_key.p, w.d_outlier_key.p, w.d_ninl.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(local_of_keypoint, w.d_of_key.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, st));
