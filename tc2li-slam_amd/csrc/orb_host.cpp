@@ -350,7 +350,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     // lanes per distribution job: a batch fills the GPU with jobs and 256 lanes per job are best (0.56 ms per 128 images; 512: 0.76, 1024:
     // 1.21); a stereo pair alone is 16 jobs, each a long chain of rounds, and more lanes shorten a round (0.265 / 0.223 / 0.214 ms)
     static const int kQuadThreadsEnv = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 0;
-    const int kQuadThreads = kQuadThreadsEnv > 0 ? kQuadThreadsEnv : (M <= 8 ? 1024 : (M <= 32 ? 512 : 256));
+    const int kQuadThreads = kQuadThreadsEnv > 0 ? kQuadThreadsEnv : 0;  // 0: keys sorted by path in LDS (quadtree_kernels.hip); > 0: the global-memory form with that many lanes
     const int want_chunks = kChunkEnv > 0 ? kChunkEnv : 1;
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     o->last_chunks = n_chunks;
@@ -391,7 +391,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         // ---- stage 2: keypoint distribution per (image, level), and the per-image keypoint lists ----
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 9), st));
         launch_quadtree(o->d_jobs.p, i0 * L, m * L, o->d_dense.p, o->d_level_counts.p, o->d_qscratch.p, o->d_picked.p, o->d_picked_count.p, o->d_status.p,
-                        kQuadThreads, st);
+                        kQuadThreads, L, st);
         launch_quadtree_gather(o->d_jobs.p, o->d_picked.p, o->d_picked_count.p, o->d_level_counts.p, i0, m, L, kp_stride, o->d_kps.p, o->h_kps.p, o->d_nkp.p,
                                o->h_nkp.p, o->h_level_counts.p, o->d_status.p, st);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 10), st));
@@ -569,7 +569,7 @@ int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max
     TC2LI_HIP_CHECK(d_job.upload(std::vector<QuadJob>{job}));
     TC2LI_HIP_CHECK(d_scratch.alloc(quadtree_scratch_bytes(job.max_keys, job.max_nodes)));
     TC2LI_HIP_CHECK(d_picked.alloc((size_t)job.out_cap));
-    launch_quadtree(d_job.p, 0, 1, d_cand.p, d_counts.p, d_scratch.p, d_picked.p, d_pick_count.p, d_status.p, threads > 0 ? threads : 256, ps);
+    launch_quadtree(d_job.p, 0, 1, d_cand.p, d_counts.p, d_scratch.p, d_picked.p, d_pick_count.p, d_status.p, threads, 1, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
     int count = 0, status = 0;
     TC2LI_HIP_CHECK(copy_sync(&count, d_pick_count.p, sizeof(int), hipMemcpyDeviceToHost, ps));

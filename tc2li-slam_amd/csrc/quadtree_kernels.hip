@@ -21,6 +21,7 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include "intro_sort.hpp"
 #include "orb_device.hpp"
 
 namespace tc2li {
@@ -214,13 +215,62 @@ struct ScratchLayout {
     }
 };
 
+// ---- the sorted form's work space (k_quadtree_sorted below) ----
+constexpr int kPathDepth = 12;      // 12-bit coordinates: after 12 halvings a node is one pixel wide and high and every key goes to child 0
+constexpr int kQuadClasses = 3;       // LDS classes of the sorted form: a job runs in the first class it fits
+__host__ __device__ constexpr int quad_class_threads(int c) { return c == 0 ? 256 : c == 1 ? 512 : 1024; }
+__host__ __device__ constexpr size_t quad_class_lds(int c) { return (c == 0 ? 38 : c == 1 ? 76 : 156) * (size_t)1024; }  // dynamic LDS per workgroup: four, two, one per CU
+struct SNode { int16_t ulx, uly, brx, bry; int32_t begin, cd; };  // cd = population | depth << 24
+__device__ __forceinline__ int sn_count(const SNode& n) { return n.cd & 0xffffff; }
+__device__ __forceinline__ int sn_depth(const SNode& n) { return (int)((uint32_t)n.cd >> 24); }
+
+struct SortedLayout {
+    size_t codes, idx, codes_b, idx_b, counters, nodes_a, nodes_b, cnt, cidx, procpos, order, newpos, rec_a, rec_b, s_key, s_idx, s_u16, s_flag, total;
+    __host__ __device__ SortedLayout(int n, int MN, int T) {
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+        codes = take((size_t)n * 4); idx = take((size_t)n * 2);
+        const size_t b = o;
+        codes_b = take((size_t)n * 4); idx_b = take((size_t)n * 2); counters = take((size_t)16 * T * 2);
+        const size_t end_sort = o;
+        o = b;  // after the sort its second buffer and the counters are free
+        nodes_a = take((size_t)MN * sizeof(SNode)); nodes_b = take((size_t)MN * sizeof(SNode));
+        cnt = take((size_t)MN * 16); cidx = take((size_t)MN * 16);
+        procpos = take((size_t)MN * 4); order = take((size_t)MN * 4); newpos = take((size_t)MN * 4);
+        rec_a = take((size_t)MN * sizeof(QRec)); rec_b = take((size_t)MN * sizeof(QRec));
+        // the closing sort (intro_sort.hpp): keys, payload, seven 16-bit index arrays of MN + 2 entries, flags
+        s_key = take((size_t)MN * 4); s_idx = take((size_t)MN * 4); s_u16 = take((size_t)7 * (MN + 2) * 2); s_flag = take((size_t)MN);
+        total = o > end_sort ? o : end_sort;
+    }
+};
+// Jobs are stored (image, level) with `nlevels` levels per image, and the hardware deals consecutive workgroups to the eight XCDs in
+// turn: with eight levels every level's jobs -- the large level 0 ones, too -- would meet on ONE XCD (measured: the level-0 class ran
+// four rounds on 32 CUs while 224 idled).  Workgroup b takes image b % M, level b / M: neighbours are the same level of different images.
+__device__ __forceinline__ int quad_job_of_block(int b, int n_blocks, int nlevels) {
+    if (nlevels <= 1 || n_blocks % nlevels) return b;
+    const int M = n_blocks / nlevels;
+    return (b % M) * nlevels + b / M;
+}
+constexpr int kQuadMaxRun = 15;  // keys per lane in the sort (they stay in registers during a pass); the LDS classes hold fewer anyway
+// Does the job fit class c?  Never: more than 256 columns, key indices beyond 16 bits, more than kQuadMaxRun keys per lane
+__host__ __device__ inline bool quad_fits(int c, int ncand, int MN, int n_ini) {
+    const int T = quad_class_threads(c);
+    if (ncand > 65535 || n_ini > 256 || (((ncand + T - 1) / T) | 1) > kQuadMaxRun) return false;
+    return SortedLayout(ncand, MN, T).total <= quad_class_lds(c);
+}
+// the class a job runs in; kQuadClasses: none (k_quadtree takes it)
+__host__ __device__ inline int quad_class_of(int ncand, int MN, int n_ini) {
+    for (int c = 0; c < kQuadClasses; ++c) if (quad_fits(c, ncand, MN, n_ini)) return c;
+    return kQuadClasses;
+}
+
 }  // namespace
 
 template <int T>
 __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense, const int32_t* __restrict__ level_counts,
                                                uint8_t* __restrict__ scratch, uint32_t* __restrict__ picked, int32_t* __restrict__ picked_count,
-                                               int32_t* __restrict__ status) {
-    const QuadJob J = jobs[blockIdx.x];
+                                               int32_t* __restrict__ status, int after_sorted /* 0: all jobs; else only those the sorted form left */, int nlevels) {
+    const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
     const int tid = threadIdx.x;
     const uint32_t* cand = dense + J.cand_off;
     const int ncand = level_counts[J.count_idx];
@@ -232,6 +282,10 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
     __shared__ int s_stack[3 * 64];
     __shared__ QRec s_rec[kSortCap];
     const int K = J.max_keys, MN = J.max_nodes, N = J.n_target;
+    if (after_sorted) {  // the trivial outcomes and the jobs that fit were k_quadtree_sorted's
+        const int n_ini0 = (int)roundf((float)(J.max_x - J.min_x) / (float)(J.max_y - J.min_y));
+        if (ncand <= 0 || ncand > K || n_ini0 <= 0 || n_ini0 > MN || quad_class_of(ncand, MN, n_ini0) < kQuadClasses) return;
+    }
     if (ncand <= 0 || ncand > K) {
         if (tid == 0) { *out_count = 0; if (ncand > K) atomicMax(status, 1); }
         return;
@@ -542,6 +596,377 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
     if (tid == 0) *out_count = size;
 }
 
+// ---- the same walk over keys sorted ONCE by their path (the default since round 3) ----
+// The rectangle of a node is a function of its column and of the quadrants taken on the way down -- not of the data: DivideNode halves
+// with ceil() whatever the node holds.  So every candidate's whole path (column, then kPathDepth quadrant digits) is computed up
+// front and the keys are sorted by it once (LSD radix, 4 bits per pass; a lane keeps its run of <= 15 keys, its 16 digit counts and
+// its 16 running places in registers during a pass, LDS sees one counter matrix and the scatter).  From then on a node of ANY depth is
+// a contiguous range [begin, begin + count) of the sorted array, and a round of the walk touches nodes only: the populations of a
+// node's children are three binary searches for the digit boundaries inside its range (no pass over the keys, no key moves), the list
+// bookkeeping is the prefix sums of the form above.  The order of the keys INSIDE a node is not the reference's (candidate order) but
+// the order of their deeper digits; the only place the reference's order shows is "the first of the largest responses" at the end,
+// decided here by the key index.  Codes, indices and all node arrays live in LDS (the node arrays take the place of the sort's
+// second buffer).  The form above moved ~25 bytes per candidate and round through L2 / HBM (45x the algorithmic bytes on the PMC
+// counters, 0.47 ms per 128 KITTI images alone) and a third of a job's time was ONE lane replaying std::sort for the closing phase;
+// this one reads a candidate twice, replays the sort with the whole workgroup (intro_sort.hpp) and takes 0.26 ms in three launches
+// (LDS classes of 38 / 76 / 156 KB, i.e. 4 / 2 / 1 workgroups per CU: a job runs in the first class it fits; what fits none -- more
+// than ~12 k candidates, or more than ~1000 nodes -- is left to k_quadtree.  Same results: tests/test_quadtree_gpu.py runs both).
+template <int CLASS>
+__global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense,
+                                                                               const int32_t* __restrict__ level_counts, uint32_t* __restrict__ picked,
+                                                                               int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int nlevels) {
+    constexpr int T = quad_class_threads(CLASS);
+    extern __shared__ __align__(16) uint8_t s_quad[];
+    const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
+    const int tid = threadIdx.x;
+    const uint32_t* cand = dense + J.cand_off;
+    const int ncand = level_counts[J.count_idx];
+    uint32_t* out = picked + J.out_off;
+    int32_t* const out_count = picked_count + J.count_idx;
+    __shared__ int s_wave[T / 64];
+    __shared__ int s_cut;
+    __shared__ int s_stack[3 * 64];
+    __shared__ int s_tot[2][T / 64], s_base[2][T / 64 + 1], s_any;
+    const int K = J.max_keys, MN = J.max_nodes, N = J.n_target;
+    const int W = J.max_x - J.min_x, H = J.max_y - J.min_y;
+    const int n_ini = (int)roundf((float)W / (float)H);
+    if (ncand <= 0 || ncand > K || n_ini <= 0 || n_ini > MN) {  // the trivial outcomes belong to the first class
+        if (CLASS == 0 && tid == 0) {
+            *out_count = 0;
+            if (ncand > K) atomicMax(status, 1);
+            else if (ncand > 0 && n_ini > MN) atomicMax(status, 2);
+        }
+        return;
+    }
+    if (quad_class_of(ncand, MN, n_ini) != CLASS) return;  // another launch's job
+    const SortedLayout lay(ncand, MN, T);
+    uint32_t* const codes = reinterpret_cast<uint32_t*>(s_quad + lay.codes);
+    uint16_t* const idxs = reinterpret_cast<uint16_t*>(s_quad + lay.idx);
+    SNode* nodes = reinterpret_cast<SNode*>(s_quad + lay.nodes_a);
+    SNode* nodes2 = reinterpret_cast<SNode*>(s_quad + lay.nodes_b);
+    int32_t* const cnt = reinterpret_cast<int32_t*>(s_quad + lay.cnt);          // [MN][4] populations of the children of a divided node
+    int32_t* const cidx = reinterpret_cast<int32_t*>(s_quad + lay.cidx);        // [MN][4] place of the child in the new list
+    int32_t* const procpos = reinterpret_cast<int32_t*>(s_quad + lay.procpos);  // [MN] place of the node in this round's processing order, -1: not divided
+    int32_t* const order = reinterpret_cast<int32_t*>(s_quad + lay.order);      // [MN] the processing order
+    int32_t* const newpos = reinterpret_cast<int32_t*>(s_quad + lay.newpos);    // [MN] children pushed before this node's / new place of a node that stays
+    QRec* recs = reinterpret_cast<QRec*>(s_quad + lay.rec_a);                   // the multi-key children of the last round, in creation order
+    QRec* recs2 = reinterpret_cast<QRec*>(s_quad + lay.rec_b);
+
+    // ---- every key's path: column (:533-560), then the quadrants of DivideNode (:454-510) down to one pixel ----
+    const float hX = (float)W / (float)n_ini;
+    int col_bits = 0;
+    while ((1 << col_bits) < n_ini) ++col_bits;
+    const int passes = (2 * kPathDepth + col_bits + 3) / 4;
+    {
+        uint32_t* src_c = (passes & 1) ? reinterpret_cast<uint32_t*>(s_quad + lay.codes_b) : codes;
+        uint16_t* src_i = (passes & 1) ? reinterpret_cast<uint16_t*>(s_quad + lay.idx_b) : idxs;
+        uint32_t* dst_c = (passes & 1) ? codes : reinterpret_cast<uint32_t*>(s_quad + lay.codes_b);
+        uint16_t* dst_i = (passes & 1) ? idxs : reinterpret_cast<uint16_t*>(s_quad + lay.idx_b);
+        uint16_t* const ctr = reinterpret_cast<uint16_t*>(s_quad + lay.counters);  // [16][T]: digit-major, lane-minor = the order of a stable pass
+        for (int kb = tid; kb < ncand; kb += 4 * T) {  // four candidates per lane and trip: their loads are in flight together
+            uint32_t c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c4[u] = kb + u * T < ncand ? cand[kb + u * T] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = kb + u * T;
+                if (k >= ncand) continue;
+                const uint32_t c = c4[u];
+                const int x = q_cx(c), y = q_cy(c);
+                size_t b = (size_t)((float)x / hX);
+                if (b >= (size_t)n_ini) b = (size_t)n_ini - 1;  // unreachable for in-range candidates
+                int ulx = (int16_t)(int)(hX * (float)b), brx = (int16_t)(int)(hX * (float)(b + 1)), uly = 0, bry = (int16_t)H;
+                uint32_t code = (uint32_t)b;
+#pragma unroll
+                for (int d = 0; d < kPathDepth; ++d) {
+                    const int mx = ulx + ((brx - ulx + 1) >> 1), my = uly + ((bry - uly + 1) >> 1);  // ceil(w / 2) of DivideNode, w >= 0
+                    const bool right = !(x < mx), low = !(y < my);
+                    code = (code << 2) | (right ? 1u : 0u) | (low ? 2u : 0u);
+                    if (right) ulx = mx; else brx = mx;
+                    if (low) uly = my; else bry = my;
+                }
+                src_c[k] = code;
+                src_i[k] = (uint16_t)k;
+            }
+        }
+        __syncthreads();
+        const int seg = ((ncand + T - 1) / T) | 1;  // odd: the lanes' runs start in different banks
+        const int k0 = min(tid * seg, ncand), k1 = min(k0 + seg, ncand);
+        __syncthreads();
+        for (int p = 0; p < passes; ++p) {
+            const int sh = 4 * p;
+            const uint32_t* __restrict__ sc = src_c;
+            const uint16_t* __restrict__ si = src_i;
+            uint32_t* __restrict__ dc = dst_c;
+            uint16_t* __restrict__ di = dst_i;
+            // the lane's run of keys in registers for the whole pass; its digit counts likewise: 16 x 8 bits
+            uint32_t kc[kQuadMaxRun];
+            uint16_t ki[kQuadMaxRun];
+#pragma unroll
+            for (int j = 0; j < kQuadMaxRun; ++j) {
+                const bool in = k0 + j < k1;
+                kc[j] = in ? sc[k0 + j] : 0u;
+                ki[j] = in ? si[k0 + j] : (uint16_t)0;
+            }
+            unsigned long long c_lo = 0, c_hi = 0;
+#pragma unroll
+            for (int j = 0; j < kQuadMaxRun; ++j) {
+                const uint32_t d = (kc[j] >> sh) & 15;
+                const unsigned long long one = k0 + j < k1 ? 1ull << (8 * (d & 7)) : 0ull;
+                c_lo += d < 8 ? one : 0ull;
+                c_hi += d < 8 ? 0ull : one;
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) ctr[d * T + tid] = (uint16_t)(((d < 8 ? c_lo : c_hi) >> (8 * (d & 7))) & 255);
+            __syncthreads();
+            {
+                uint16_t* mine = ctr + 16 * tid;
+                int v[16], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { v[j] = mine[j]; sum += v[j]; }
+                int tot;
+                int run = block_excl_scan<T>(sum, s_wave, tot);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { mine[j] = (uint16_t)run; run += v[j]; }
+            }
+            __syncthreads();
+            // the lane's 16 running places, 16 bits each, in four registers
+            unsigned long long o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const unsigned long long v = (unsigned long long)ctr[d * T + tid] << (16 * (d & 3));
+                if (d < 4) o0 |= v; else if (d < 8) o1 |= v; else if (d < 12) o2 |= v; else o3 |= v;
+            }
+#pragma unroll
+            for (int j = 0; j < kQuadMaxRun; ++j) {
+                if (k0 + j >= k1) continue;
+                const uint32_t code = kc[j];
+                const uint32_t d = (code >> sh) & 15, w = d >> 2, s16 = 16 * (d & 3);
+                const unsigned long long reg = w == 0 ? o0 : w == 1 ? o1 : w == 2 ? o2 : o3;
+                const int pos = (int)((reg >> s16) & 0xffff);
+                const unsigned long long inc = 1ull << s16;
+                o0 += w == 0 ? inc : 0ull; o1 += w == 1 ? inc : 0ull; o2 += w == 2 ? inc : 0ull; o3 += w == 3 ? inc : 0ull;
+                dc[pos] = code;
+                di[pos] = ki[j];
+            }
+            __syncthreads();
+            { uint32_t* t = src_c; src_c = dst_c; dst_c = t; }
+            { uint16_t* t = src_i; src_i = dst_i; dst_i = t; }
+        }
+    }
+    // ---- initial nodes: the non-empty columns in order ----
+    for (int i = tid; i <= n_ini; i += T) {  // cidx[i]: first key of column i
+        const uint32_t want = (uint32_t)i << (2 * kPathDepth);
+        int lo = 0, hi = ncand;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (codes[mid] < want) lo = mid + 1; else hi = mid; }
+        cidx[i] = i == n_ini ? ncand : lo;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int i = 0; i < n_ini; ++i) {
+            const int c = cidx[i + 1] - cidx[i];
+            if (c > 0) nodes[n++] = SNode{(int16_t)(int)(hX * (float)i), 0, (int16_t)(int)(hX * (float)(i + 1)), (int16_t)H, cidx[i], c};
+        }
+        s_cut = n;
+    }
+    __syncthreads();
+    int size = s_cut, phase = 0, n_rec = 0;
+    __syncthreads();
+
+    for (int guard = 0; guard < 100000 && phase != 2; ++guard) {
+        // ---- 1. the nodes to divide and their order: every multi-key node in list order, or (closing phase) the sorted records from the back ----
+        int n_proc;
+        if (phase == 0) {
+            int carry = 0;
+            for (int i0 = 0; i0 < size; i0 += T) {
+                const int i = i0 + tid;
+                const int f = i < size && sn_count(nodes[i]) > 1 ? 1 : 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(f, s_wave, tot);
+                if (i < size) procpos[i] = f ? ex : -1;
+                if (f) order[ex] = i;
+                carry += tot;
+            }
+            n_proc = carry;
+        } else {
+            n_proc = n_rec;
+            for (int i = tid; i < size; i += T) procpos[i] = -1;
+            __syncthreads();
+            for (int j = tid; j < n_proc; j += T) { const int nd = recs[n_rec - 1 - j].node; order[j] = nd; procpos[nd] = j; }
+        }
+        __syncthreads();
+        // ---- 2. populations of the children: the boundaries of the next digit inside the node's range (four lanes per node) ----
+        for (int j0 = 0; j0 < n_proc; j0 += T / 4) {
+            const int j = j0 + (tid >> 2), q = tid & 3;
+            int bound = 0, nd = 0;
+            SNode p{};
+            if (j < n_proc) {
+                nd = order[j];
+                p = nodes[nd];
+                const int depth = sn_depth(p), count = sn_count(p);
+                if (q == 0) bound = p.begin;
+                else if (depth >= kPathDepth) bound = p.begin + count;  // one pixel: every key goes to the first child
+                else {
+                    const int sh = 2 * (kPathDepth - 1 - depth);
+                    const uint32_t want = ((codes[p.begin] >> (sh + 2)) << 2) | (uint32_t)q;
+                    int lo = p.begin, hi = p.begin + count;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((codes[mid] >> sh) < want) lo = mid + 1; else hi = mid; }
+                    bound = lo;
+                }
+            }
+            const int next = __shfl_down(bound, 1, 4);
+            if (j < n_proc) cnt[4 * nd + q] = (q == 3 ? p.begin + sn_count(p) : next) - bound;
+        }
+        if (tid == 0) s_cut = n_proc;
+        __syncthreads();
+        // ---- 3. closing phase: the walk stops as soon as the list holds N nodes (:700-701); a division adds children - 1 ----
+        if (phase == 1) {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int grow = 0;
+                if (j < n_proc) { for (int q = 0; q < 4; ++q) grow += cnt[4 * order[j] + q] > 0; grow -= 1; }
+                int tot;
+                const int ex = carry + block_excl_scan<T>(grow, s_wave, tot);
+                if (j < n_proc && size + ex + grow >= N) atomicMin(&s_cut, j + 1);
+                carry += tot;
+            }
+            __syncthreads();
+            const int m = s_cut;
+            for (int j = m + tid; j < n_proc; j += T) procpos[order[j]] = -1;  // not reached
+            n_proc = m;
+            __syncthreads();
+        }
+        // ---- 4. places in the new list ----
+        int n_children;
+        {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int ch = 0;
+                if (j < n_proc) for (int q = 0; q < 4; ++q) ch += cnt[4 * order[j] + q] > 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(ch, s_wave, tot);
+                if (j < n_proc) newpos[order[j]] = ex;
+                carry += tot;
+            }
+            n_children = carry;
+        }
+        int new_size;
+        {
+            int carry = 0;
+            for (int i0 = 0; i0 < size; i0 += T) {
+                const int i = i0 + tid;
+                const int f = i < size && procpos[i] < 0 ? 1 : 0;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(f, s_wave, tot);
+                if (f) newpos[i] = n_children + ex;
+                carry += tot;
+            }
+            new_size = n_children + carry;
+        }
+        if (new_size > MN) { if (tid == 0) { atomicMax(status, 3); *out_count = 0; } return; }
+        for (int i = tid; i < size; i += T) {
+            const SNode p = nodes[i];
+            if (procpos[i] < 0) { nodes2[newpos[i]] = p; continue; }
+            const int mx = p.ulx + (int)ceilf((float)(p.brx - p.ulx) / 2), my = p.uly + (int)ceilf((float)(p.bry - p.uly) / 2);
+            const int depth1 = min(sn_depth(p) + 1, 64);
+            int pushed = newpos[i], first = p.begin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cnt[4 * i + q];
+                if (c == 0) { cidx[4 * i + q] = -1; continue; }
+                const int at = n_children - 1 - pushed;  // push_front: a later push lies nearer to the front
+                nodes2[at] = SNode{(int16_t)((q & 1) ? mx : p.ulx), (int16_t)((q & 2) ? my : p.uly), (int16_t)((q & 1) ? p.brx : mx),
+                                   (int16_t)((q & 2) ? p.bry : my), first, c | depth1 << 24};
+                cidx[4 * i + q] = at;
+                first += c;
+                ++pushed;
+            }
+        }
+        __syncthreads();
+        // ---- 5. the multi-key children of this round, in creation order ----
+        int n_expand;
+        {
+            int carry = 0;
+            for (int j0 = 0; j0 < n_proc; j0 += T) {
+                const int j = j0 + tid;
+                int m = 0;
+                if (j < n_proc) for (int q = 0; q < 4; ++q) m += cnt[4 * order[j] + q] > 1;
+                int tot;
+                const int ex = carry + block_excl_scan<T>(m, s_wave, tot);
+                if (j < n_proc) {
+                    int at = ex;
+                    const int nd = order[j];
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = cnt[4 * nd + q];
+                        if (c > 1) { const int nn = cidx[4 * nd + q]; recs2[at++] = QRec{((uint32_t)c << 12) | (uint32_t)nodes2[nn].ulx, nn}; }
+                    }
+                }
+                carry += tot;
+            }
+            n_expand = carry;
+        }
+        __syncthreads();
+        // ---- 6. what comes next (:651-728) ----
+        int next_phase;
+        if (new_size >= N || new_size == size) next_phase = 2;
+        else if (phase == 1 || new_size + n_expand * 3 > N) next_phase = 1;
+        else next_phase = 0;
+        bool sorted_into_recs = false;
+        if (next_phase == 1) {  // sort(vPrevSizeAndPointerToNode.begin(), vPrevSizeAndPointerToNode.end(), compareNodes)
+            // std::sort's moves replayed by the whole workgroup (intro_sort.hpp); one lane doing them one by one took 120 us of a job's 190
+            uint32_t* const skey = reinterpret_cast<uint32_t*>(s_quad + lay.s_key);
+            int* const sidx = reinterpret_cast<int*>(s_quad + lay.s_idx);
+            unsigned short* const u16 = reinterpret_cast<unsigned short*>(s_quad + lay.s_u16);
+            unsigned short *const sf = u16, *const sl = u16 + (MN + 2), *const cl = u16 + 2 * (MN + 2), *const cr = u16 + 3 * (MN + 2),
+                                 *const lp = u16 + 4 * (MN + 2), *const rp = u16 + 5 * (MN + 2), *const cut = u16 + 6 * (MN + 2);
+            uint8_t* const flag = s_quad + lay.s_flag;
+            for (int j = tid; j < n_expand; j += T) { skey[j] = recs2[j].key; sidx[j] = j; sf[j] = 0; sl[j] = (unsigned short)n_expand; }
+            const int depth = n_expand > 1 ? 2 * (31 - __clz(n_expand)) : 0;
+            const bool ok = sort_levels<T, unsigned short, uint32_t>(skey, sidx, sf, sl, cl, cr, lp, rp, cut, flag, nullptr, n_expand, depth, 16, s_tot, s_base, &s_any);
+            __syncthreads();
+            if (ok) {
+                sort_final<T, unsigned short, uint32_t>(skey, sidx, sf, sl, n_expand, newpos);  // newpos is free here: the sorted order as record numbers
+                __syncthreads();
+                for (int j = tid; j < n_expand; j += T) recs[j] = recs2[newpos[j]];
+                sorted_into_recs = true;
+            } else if (tid == 0) {
+                std_sort(ArrMem{recs2}, n_expand, s_stack);  // the depth limit was reached (std::sort heap-sorts that range): one lane, move by move
+            }
+        }
+        { SNode* t = nodes; nodes = nodes2; nodes2 = t; }
+        if (!sorted_into_recs) { QRec* t = recs; recs = recs2; recs2 = t; }
+        size = new_size; phase = next_phase; n_rec = n_expand;
+        __syncthreads();
+    }
+    // ---- the best candidate of every node, in list order (:731-752): the node's keys stand in candidate order ----
+    if (size > J.out_cap) { if (tid == 0) { atomicMax(status, 4); *out_count = 0; } return; }
+    // the sorted order inside a node is the order of the deeper digits, so "the first of the largest responses" is decided by the key index
+    for (int kb = tid; kb < ncand; kb += 4 * T) {  // the paths have done their work: the candidates take their place
+        uint32_t c4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c4[u] = kb + u * T < ncand ? cand[idxs[kb + u * T]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (kb + u * T < ncand) codes[kb + u * T] = c4[u];
+    }
+    __syncthreads();
+    for (int i = tid; i < size; i += T) {
+        const SNode n = nodes[i];
+        const int count = sn_count(n);
+        uint32_t best = codes[n.begin];
+        int best_k = idxs[n.begin];
+        for (int k = 1; k < count; ++k) {
+            const uint32_t c = codes[n.begin + k];
+            const int key = idxs[n.begin + k];
+            if (q_cr(c) > q_cr(best) || (q_cr(c) == q_cr(best) && key < best_k)) { best = c; best_k = key; }
+        }
+        out[i] = best;
+    }
+    if (tid == 0) *out_count = size;
+}
+
 // The keypoints of an image: its per-level lists behind each other (level order, :1093-1137), in level pixel coordinates with the
 // border added (:856-857).  One workgroup per image; the lists go to a device array (the descriptor kernel reads it) and to its pinned
 // host mirror (the assembly on the host reads it), the counts likewise.
@@ -572,14 +997,30 @@ __global__ __launch_bounds__(256) void k_quadtree_gather(const QuadJob* __restri
     }
 }
 
+// threads == 0: the sorted form in three LDS classes (4 / 2 / 1 workgroups per CU; a job takes the first class it fits), then the
+// global-memory form for what is left; threads > 0: the global-memory form alone with that many lanes per job.
 void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
-                     int32_t* picked_count, int32_t* status, int threads, hipStream_t st) {
+                     int32_t* picked_count, int32_t* status, int threads, int nlevels, hipStream_t st) {
     if (n_jobs <= 0) return;
     const QuadJob* j0 = jobs + first_job;
-    if (threads >= 1024) TC2LI_LAUNCH(k_quadtree<1024>, dim3(n_jobs), dim3(1024), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
-    else if (threads >= 512) TC2LI_LAUNCH(k_quadtree<512>, dim3(n_jobs), dim3(512), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
-    else if (threads >= 256) TC2LI_LAUNCH(k_quadtree<256>, dim3(n_jobs), dim3(256), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
-    else TC2LI_LAUNCH(k_quadtree<128>, dim3(n_jobs), dim3(128), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status);
+    int after_sorted = 0;
+    if (threads <= 0) {
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_sorted<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_class_lds(1));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_sorted<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_class_lds(2));
+            return true;
+        }();
+        (void)attr;
+        TC2LI_LAUNCH(k_quadtree_sorted<0>, dim3(n_jobs), dim3(quad_class_threads(0)), quad_class_lds(0), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
+        TC2LI_LAUNCH(k_quadtree_sorted<1>, dim3(n_jobs), dim3(quad_class_threads(1)), quad_class_lds(1), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
+        TC2LI_LAUNCH(k_quadtree_sorted<2>, dim3(n_jobs), dim3(quad_class_threads(2)), quad_class_lds(2), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
+        after_sorted = 1;
+        threads = 256;
+    }
+    if (threads >= 1024) TC2LI_LAUNCH(k_quadtree<1024>, dim3(n_jobs), dim3(1024), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status, after_sorted, nlevels);
+    else if (threads >= 512) TC2LI_LAUNCH(k_quadtree<512>, dim3(n_jobs), dim3(512), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status, after_sorted, nlevels);
+    else if (threads >= 256) TC2LI_LAUNCH(k_quadtree<256>, dim3(n_jobs), dim3(256), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status, after_sorted, nlevels);
+    else TC2LI_LAUNCH(k_quadtree<128>, dim3(n_jobs), dim3(128), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status, after_sorted, nlevels);
 }
 void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const int32_t* picked_count, const int32_t* level_counts, int first_image, int n_images,
                             int nlevels, int kp_stride, DevKeypoint* kps, DevKeypoint* kps_host, int32_t* n_kp, int32_t* n_kp_host, int32_t* level_counts_host,
