@@ -829,7 +829,7 @@ int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar
 int tc2li_host_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target,
                                    float* out_xyr, int capacity);
 /* The same distribution as one job of the device kernels the extractor runs: `threads` = 0 is the extractor's choice (k_quadtree_sorted:
- * the keys sorted once by their path through the tree, everything in LDS; a job too large for LDS falls to k_quadtree), `threads` =
+ * the keys sorted once by their path through the tree, everything in LDS; a job too large for LDS falls to k_quadtree; `threads` = -1 - c starts with LDS class c), `threads` =
  * 256 / 512 / 1024 forces k_quadtree (work arrays in global memory) with that many lanes.  Same arguments, same result.  The extractor itself calls the kernel on the device-resident
  * candidates of a whole batch; this entry exists to check the kernel on arbitrary candidate sets. */
 int tc2li_device_distribute_quadtree(const float* xyr, int n, int min_x, int max_x, int min_y, int max_y, int n_target, float* out_xyr,

@@ -259,8 +259,8 @@ __host__ __device__ inline bool quad_fits(int c, int ncand, int MN, int n_ini) {
     return SortedLayout(ncand, MN, T).total <= quad_class_lds(c);
 }
 // the class a job runs in; kQuadClasses: none (k_quadtree takes it)
-__host__ __device__ inline int quad_class_of(int ncand, int MN, int n_ini) {
-    for (int c = 0; c < kQuadClasses; ++c) if (quad_fits(c, ncand, MN, n_ini)) return c;
+__host__ __device__ inline int quad_class_of(int ncand, int MN, int n_ini, int first_class) {
+    for (int c = first_class; c < kQuadClasses; ++c) if (quad_fits(c, ncand, MN, n_ini)) return c;
     return kQuadClasses;
 }
 
@@ -269,7 +269,7 @@ __host__ __device__ inline int quad_class_of(int ncand, int MN, int n_ini) {
 template <int T>
 __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense, const int32_t* __restrict__ level_counts,
                                                uint8_t* __restrict__ scratch, uint32_t* __restrict__ picked, int32_t* __restrict__ picked_count,
-                                               int32_t* __restrict__ status, int after_sorted /* 0: all jobs; else only those the sorted form left */, int nlevels) {
+                                               int32_t* __restrict__ status, int after_sorted /* 0: all jobs; else 1 + the first class that ran: only the jobs the sorted form left */, int nlevels) {
     const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
     const int tid = threadIdx.x;
     const uint32_t* cand = dense + J.cand_off;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
     const int K = J.max_keys, MN = J.max_nodes, N = J.n_target;
     if (after_sorted) {  // the trivial outcomes and the jobs that fit were k_quadtree_sorted's
         const int n_ini0 = (int)roundf((float)(J.max_x - J.min_x) / (float)(J.max_y - J.min_y));
-        if (ncand <= 0 || ncand > K || n_ini0 <= 0 || n_ini0 > MN || quad_class_of(ncand, MN, n_ini0) < kQuadClasses) return;
+        if (ncand <= 0 || ncand > K || n_ini0 <= 0 || n_ini0 > MN || quad_class_of(ncand, MN, n_ini0, after_sorted - 1) < kQuadClasses) return;
     }
     if (ncand <= 0 || ncand > K) {
         if (tid == 0) { *out_count = 0; if (ncand > K) atomicMax(status, 1); }
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
 template <int CLASS>
 __global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense,
                                                                                const int32_t* __restrict__ level_counts, uint32_t* __restrict__ picked,
-                                                                               int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int nlevels) {
+                                                                               int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int nlevels, int first_class) {
     constexpr int T = quad_class_threads(CLASS);
     extern __shared__ __align__(16) uint8_t s_quad[];
     const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
@@ -631,14 +631,14 @@ __global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(c
     const int W = J.max_x - J.min_x, H = J.max_y - J.min_y;
     const int n_ini = (int)roundf((float)W / (float)H);
     if (ncand <= 0 || ncand > K || n_ini <= 0 || n_ini > MN) {  // the trivial outcomes belong to the first class
-        if (CLASS == 0 && tid == 0) {
+        if (CLASS == first_class && tid == 0) {
             *out_count = 0;
             if (ncand > K) atomicMax(status, 1);
             else if (ncand > 0 && n_ini > MN) atomicMax(status, 2);
         }
         return;
     }
-    if (quad_class_of(ncand, MN, n_ini) != CLASS) return;  // another launch's job
+    if (quad_class_of(ncand, MN, n_ini, first_class) != CLASS) return;  // another launch's job
     const SortedLayout lay(ncand, MN, T);
     uint32_t* const codes = reinterpret_cast<uint32_t*>(s_quad + lay.codes);
     uint16_t* const idxs = reinterpret_cast<uint16_t*>(s_quad + lay.idx);
@@ -998,7 +998,8 @@ __global__ __launch_bounds__(256) void k_quadtree_gather(const QuadJob* __restri
 }
 
 // threads == 0: the sorted form in three LDS classes (4 / 2 / 1 workgroups per CU; a job takes the first class it fits), then the
-// global-memory form for what is left; threads > 0: the global-memory form alone with that many lanes per job.
+// global-memory form for what is left; threads = -1 - c: the same starting with class c; threads > 0: the global-memory form alone
+// with that many lanes per job.
 void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
                      int32_t* picked_count, int32_t* status, int threads, int nlevels, hipStream_t st) {
     if (n_jobs <= 0) return;
@@ -1011,10 +1012,14 @@ void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint3
             return true;
         }();
         (void)attr;
-        TC2LI_LAUNCH(k_quadtree_sorted<0>, dim3(n_jobs), dim3(quad_class_threads(0)), quad_class_lds(0), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
-        TC2LI_LAUNCH(k_quadtree_sorted<1>, dim3(n_jobs), dim3(quad_class_threads(1)), quad_class_lds(1), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
-        TC2LI_LAUNCH(k_quadtree_sorted<2>, dim3(n_jobs), dim3(quad_class_threads(2)), quad_class_lds(2), st, j0, dense, level_counts, picked, picked_count, status, nlevels);
-        after_sorted = 1;
+        // fewer jobs than CUs (a stereo pair is 16): every job in the widest class, one launch instead of three in a row
+        const int first_class = threads < 0 ? min(-threads - 1, kQuadClasses - 1) : (n_jobs <= 256 ? 2 : 0);  // threads < 0: the tests choose
+        if (first_class <= 0)
+            TC2LI_LAUNCH(k_quadtree_sorted<0>, dim3(n_jobs), dim3(quad_class_threads(0)), quad_class_lds(0), st, j0, dense, level_counts, picked, picked_count, status, nlevels, first_class);
+        if (first_class <= 1)
+            TC2LI_LAUNCH(k_quadtree_sorted<1>, dim3(n_jobs), dim3(quad_class_threads(1)), quad_class_lds(1), st, j0, dense, level_counts, picked, picked_count, status, nlevels, first_class);
+        TC2LI_LAUNCH(k_quadtree_sorted<2>, dim3(n_jobs), dim3(quad_class_threads(2)), quad_class_lds(2), st, j0, dense, level_counts, picked, picked_count, status, nlevels, first_class);
+        after_sorted = 1 + first_class;
         threads = 256;
     }
     if (threads >= 1024) TC2LI_LAUNCH(k_quadtree<1024>, dim3(n_jobs), dim3(1024), 0, st, j0, dense, level_counts, scratch, picked, picked_count, status, after_sorted, nlevels);

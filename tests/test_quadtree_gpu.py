@@ -14,7 +14,7 @@ def _candidates(seed, n, w, h, r_lo=7, r_hi=120):
     return np.stack([pos % w, pos // w, rng.integers(r_lo, r_hi, n)], 1).astype(np.float32).reshape(-1, 3)
 
 
-@pytest.mark.parametrize("threads", [0, 256, 512, 1024])  # 0: the sorted-path form in LDS (default), else the global-memory form
+@pytest.mark.parametrize("threads", [0, -1, -2, 256, 512, 1024])  # 0 / -1 - c: the sorted-path form in LDS (default / from class c on), else the global-memory form
 @pytest.mark.parametrize("seed,n,w,h,target", [(0, 5000, 1210, 343, 434), (1, 300, 315, 73, 122), (2, 40, 500, 200, 100), (3, 1, 400, 300, 50),
                                                (4, 0, 400, 300, 50), (5, 2500, 640, 640, 700), (6, 900, 980, 260, 1), (7, 20000, 1210, 343, 434),
                                                (8, 3, 1210, 343, 434), (9, 2000, 900, 100, 300), (10, 700, 1210, 343, 2000),
