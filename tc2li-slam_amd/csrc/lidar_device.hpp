@@ -68,6 +68,10 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
 void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const VoxelParams* vp, const int* pt_slot,
                        const int* table_rank, const int* vox_member_off, int* vox_fill /* runs per voxel */,
                        int* members /* one word per run: first index | (length - 1) << 24 */, hipStream_t st);
+// the sorted form of the voxel filter (after launch_voxel_bbox / launch_voxel_params): one workgroup per scan sorts (voxel, point), then the centroids
+void launch_voxel_sorted(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, const SegBlock* blocks, int nblocks, float leaf,
+                         const VoxelParams* vp, int* key_a, int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, void* recs,
+                         PointXYZINormal* out, int* out_count, hipStream_t st);
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
                            const int* vox_member_off, const int* vox_fill, const int* vox_count, const int* members, void* recs /* 32 B per point */,

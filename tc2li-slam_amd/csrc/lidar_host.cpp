@@ -158,12 +158,23 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     std::vector<int> bbox_init(6 * S);
     for (int s = 0; s < S; ++s) for (int a = 0; a < 3; ++a) { bbox_init[6 * s + a] = 0x7fffffff; bbox_init[6 * s + 3 + a] = (int)0x80000000; }
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_bbox.p, bbox_init.data(), bbox_init.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    launch_fill_int(L->d_table_keys.p, (size_t)S * L->table_size, -1, st);
-    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_n_vox.p, 0, (size_t)S * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_down_count.p, 0, (size_t)S * sizeof(int), st));  // an empty scan has no block that would write its count
     launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
     launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
+    // a batch of scans: one workgroup per scan sorts its (voxel, point) pairs (lidar_kernels.hip, "sorted form"); a few scans: the hash
+    // form, whose passes are spread over all points.  TC2LI_VOXEL_SORTED=0 / 1 forces one (the tests run both).
+    const char* env = getenv("TC2LI_VOXEL_SORTED");
+    const bool sorted = env ? atoi(env) != 0 : S >= 32;
+    if (sorted) {
+        L->record(2, st);
+        launch_voxel_sorted(d_in, d_in_count, L->d_slots.p, S, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_pt_slot.p, L->d_vox_keys.p, L->d_members.p,
+                            L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, L->d_recs.p, L->d_down.p, L->d_down_count.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        return TC2LI_OK;
+    }
+    launch_fill_int(L->d_table_keys.p, (size_t)S * L->table_size, -1, st);
+    TC2LI_HIP_CHECK(hipMemsetAsync(L->d_table_counts.p, 0, (size_t)S * L->table_size * sizeof(int), st));
     launch_voxel_insert(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_table_keys.p, L->d_table_counts.p, L->d_pt_slot.p, L->d_n_vox.p, L->d_vox_keys.p, st);
     launch_voxel_sort(L->d_slots.p, S, L->d_vp.p, d_in_count, L->d_table_keys.p, L->d_table_counts.p, L->d_table_rank.p, L->d_vox_keys.p,
                       L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, L->d_status.p, st);

@@ -36,8 +36,10 @@ def test_preprocess(fe, oracle, scans, pfn, blind):
     assert same_points(fe.process(raw[:1025], 2, 2.0), oracle.lidar_preprocess(raw[:1025], 2, 2.0))
 
 
+@pytest.mark.parametrize("form", ["hash", "sorted"])  # the two device forms of the filter (lidar_host.cpp run_voxel): few scans / batches
 @pytest.mark.parametrize("leaf", [0.5, 0.2, 1.5])
-def test_voxel_filter(fe, oracle, scans, leaf):
+def test_voxel_filter(fe, oracle, scans, leaf, form, monkeypatch):
+    monkeypatch.setenv("TC2LI_VOXEL_SORTED", "1" if form == "sorted" else "0")
     pts = oracle.lidar_preprocess(scans[1])
     got = fe.voxel_filter(pts, leaf)
     want = oracle.voxel_grid(pts, leaf)
@@ -55,6 +57,12 @@ def test_voxel_filter(fe, oracle, scans, leaf):
     for name in ("x", "y", "z"):
         huge[name][:9000] = huge[name][:9000] * np.float32(0.002) + np.float32(0.1)
     assert same_points(fe.voxel_filter(huge, leaf), oracle.voxel_grid(huge, leaf))
+    # points that are not finite are left out; coordinates on both sides of zero and a wide box (three or four key digits)
+    wide = pts[:20000].copy()
+    wide["x"][::7] *= np.float32(-3.0); wide["y"][::5] *= np.float32(4.0)
+    wide["x"][11::97] = np.float32(np.nan); wide["z"][5::131] = np.float32(np.inf)
+    assert same_points(fe.voxel_filter(wide, leaf), oracle.voxel_grid(wide, leaf))
+    assert len(fe.voxel_filter(pts[:0], leaf)) == 0
 
 
 def test_feature_extraction(pkg, fe, oracle, synthetic, scans):
