@@ -650,6 +650,10 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         "k_map_keep_count": (F * mp, "B"),
         # keypoint distribution: every candidate once (4 B) + the picks; the rounds of the walk re-read keys that stay in L2
         "k_quadtree": (n_img * (4 * 15000 + 8 * nkp), "B"),
+        "k_quadtree_sorted": (n_img * (4 * 15000 + 8 * nkp), "B"),                      # round 3: keys sorted once by their path, everything in LDS
+        # voxel filter, sorted form: xyz in, (voxel, point) out; the gather reads a point and writes its 32-byte record; the sums read the records
+        "k_voxel_sort_points": (F * pre * (16 + 8), "B"), "k_voxel_gather_sorted": (F * pre * (4 + 48 + 32), "B"),
+        "k_voxel_centroid_sorted": (F * (pre * 32 + down * 48), "B"),
         "k_stereo_rows": (F * nkp * (12 + 2 * 7), "B"),                                 # right keys in, ~7 row entries of 2 B each out
         # tracking: TrackWithMotionModel + TrackLocalMap per frame -- queries (64 B out, source point in), candidate windows, edges
         "k_track_queries_last": (F * nkp * (53 + 64), "B"), "k_track_queries_local": (F * nloc * (68 + 64), "B"),
@@ -683,6 +687,10 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
             "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
             "k_balm_residual_total_b": (nw * (lin + tr) * ba["planes"] * ba["win"] * 80, "B"),
+            # the windows' graphs over the bus and their results back, read + written once each (an estimate from the windows' sizes: edges 40 B,
+            # CSR / slot index arrays ~24 B per edge, points 24 B up and 25 B down, chi2 8 B per edge down, plane clusters 80 B per plane and
+            # keyframe).  A copy is priced against HBM like everything byte-bound; what bounds it is the host link (~55 GB/s), DESIGN.md section 4
+            "k_copy_tasks": (2 * nw * (E * (40 + 24 + 8) + P * 49 + ba["planes"] * ba["win"] * 80), "B"),
         })
     return w
 
@@ -709,7 +717,7 @@ def algorithmic_work_inertial(wl, il, nkp, windows_per_step):
     mp = il.map_points0
     w.update({
         # the time sort: every point's time stamp in, its place out (what a permutation needs); the compensation: point in and out + the place
-        "k_time_sort": (F * pre * 8, "B"), "k_undistort_batch": (F * pre * (48 + 4 + 48), "B"),
+        "k_time_sort": (F * pre * 8, "B"), "k_time_sort_lds": (F * pre * (8 + 4), "B"), "k_undistort_batch": (F * pre * (48 + 4 + 48), "B"),
         # the neighbour search runs once per converged iteration, the re-evaluation of the kept neighbours otherwise, the rows every time
         "k_knn_plane": (F * searches * down * (48 + 48 + 48 + 5 * 8 + 27 * 16), "B"),
         "k_knn_hard": (F * searches * down * 0.02 * (48 + 48 + 48 + 5 * 8 + 125 * 16), "B"),
