@@ -2,6 +2,8 @@
 // All arithmetic is integer or explicitly rounded float, so the output is bit-identical to the CPU path.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "launch.hpp"
@@ -98,6 +100,94 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
         *reinterpret_cast<uint32_t*>(D) = packed;  // dst_pitch and dx0 are multiples of 4
     } else {
         for (int k = 0; k < 4 && dx0 + k < dw; ++k) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+}
+
+// The same resize as column strips (round 3, default): the kernel above is bound by VALU issue (a wavefront instruction occupies its
+// SIMD for four cycles; ~26 lane-operations per destination pixel for the byte selection out of aligned dwords and the fixed-point
+// blend, twice per pixel because every destination row repeats the horizontal pass of both its source rows).  Here a lane keeps four
+// destination columns and walks kResizeRows destination rows down: the column tables (source offsets, alpha pairs) are loaded once, the
+// two source bytes of a tap pair come from ONE unaligned 16-bit load (no selection arithmetic), and the horizontal pass of a source row
+// that two consecutive destination rows share (scale < 2: every other row at 1.2) is computed once and kept in registers.  ~13
+// lane-operations per pixel.  Same integers as the kernel above: tests/test_orb_gpu.py compares every level with the oracle.
+constexpr int kResizeRows = 16;
+__device__ __forceinline__ uint32_t load_u16_unaligned(const uint8_t* p) {
+    uint16_t w;
+    __builtin_memcpy(&w, p, 2);
+    return w;
+}
+__global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict__ src, int src_pitch, size_t src_img_stride, int sw, int sh,
+                                                       uint8_t* __restrict__ dst, int dst_pitch, size_t dst_img_stride, int dw, int dh,
+                                                       const int* __restrict__ xofs, const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                                                       const short* __restrict__ ibeta, int gx, int gy, int nimg) {
+    // one wavefront = 256 columns x kResizeRows rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
+    const int n_units = gx * gy * nimg, per_xcd = (n_units + 7) / 8;
+    const int u = ((int)blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);  // the wavefront's unit inside its XCD's share
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + u;
+    if (u >= per_xcd || logical >= n_units) return;
+    const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
+    const int dx0 = (bx * 64 + (int)(threadIdx.x & 63)) * 4;
+    if (dx0 >= dw) return;
+    const uint8_t* S = src + (size_t)img * src_img_stride;
+    uint8_t* D = dst + (size_t)img * dst_img_stride + dx0;
+    const int dy_begin = by * kResizeRows, dy_end = min(dy_begin + kResizeRows, dh);
+    int sx[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = min(dx0 + k, dw - 1);
+        sx[k] = xofs[dx]; a0[k] = ialpha[2 * dx]; a1[k] = ialpha[2 * dx + 1];
+    }
+    const bool interior = dx0 + 3 < dw && sx[0] >= 0 && sx[3] + 1 < sw;  // every tap pair inside the row: two bytes from one load
+    // horizontal pass of source row `sy` for the lane's four columns, already shifted (r >> 4)
+    auto hpass = [&](int sy, int h[4]) {
+        const uint8_t* R = S + (size_t)sy * src_pitch;
+        if (interior) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = load_u16_unaligned(R + sx[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = ((int)(w[k] & 0xffu) * a0[k] + (int)(w[k] >> 8) * a1[k]) >> 4;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x0 = sx[k], x1 = x0 + 1 < sw ? x0 + 1 : x0;  // weight of the clamped tap is 0
+                h[k] = dx0 + k < dw ? ((int)R[x0] * a0[k] + (int)R[x1] * a1[k]) >> 4 : 0;
+            }
+        }
+    };
+    int have = -1, hc[4] = {0, 0, 0, 0};
+    for (int dy = dy_begin; dy < dy_end; ++dy) {
+        int sy0 = yofs[dy], sy1 = sy0 + 1;
+        sy0 = sy0 < 0 ? 0 : (sy0 >= sh ? sh - 1 : sy0);
+        sy1 = sy1 < 0 ? 0 : (sy1 >= sh ? sh - 1 : sy1);
+        const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+        int h0[4], h1[4];
+        if (sy0 == have) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h0[k] = hc[k];
+        } else {
+            hpass(sy0, h0);
+        }
+        if (sy1 == sy0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h1[k] = h0[k];
+        } else {
+            hpass(sy1, h1);
+        }
+        have = sy1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hc[k] = h1[k];
+            const int v = (((b0 * h0[k]) >> 16) + ((b1 * h1[k]) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        uint8_t* Drow = D + (size_t)dy * dst_pitch;
+        if (dx0 + 3 < dw) {
+            *reinterpret_cast<uint32_t*>(Drow) = packed;  // dst_pitch and dx0 are multiples of 4
+        } else {
+            for (int k = 0; k < 4 && dx0 + k < dw; ++k) Drow[k] = (uint8_t)(packed >> (8 * k));
+        }
     }
 }
 
@@ -715,9 +805,18 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
 // ---- launch wrappers (host side of this translation unit) ----------------------------------------------
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st) {
-    const int gx = (dst.w + 255) / 256, gy = (dst.h + 3) / 4;
-    TC2LI_LAUNCH(k_resize_linear, dim3(((gx * gy * nimg + 7) / 8) * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
-                       const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
+    static const bool pixel_form = getenv("TC2LI_RESIZE_PIXELS") && atoi(getenv("TC2LI_RESIZE_PIXELS")) != 0;  // the round-1 kernel: four pixels per thread
+    if (pixel_form) {
+        const int gx = (dst.w + 255) / 256, gy = (dst.h + 3) / 4;
+        TC2LI_LAUNCH(k_resize_linear, dim3(((gx * gy * nimg + 7) / 8) * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+                     const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
+        return;
+    }
+    // one wavefront per (256 columns, kResizeRows rows); four wavefronts per workgroup, the workgroup count a multiple of 8 (XCDs)
+    const int gx = (dst.w + 255) / 256, gy = (dst.h + kResizeRows - 1) / kResizeRows;
+    const int per_xcd = (gx * gy * nimg + 7) / 8, wg_per_xcd = (per_xcd + 3) / 4;
+    TC2LI_LAUNCH(k_resize_strips, dim3(wg_per_xcd * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
+                 const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
