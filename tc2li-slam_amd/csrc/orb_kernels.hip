@@ -684,12 +684,22 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
     const int slot = (logical * 256 + (int)threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31, kpi = threadIdx.x >> 5;
     // The two patches of a keypoint -- 31 x 31 of the level image (orientation), 37 x 37 of the blurred level (the rotated pattern
-    // reaches 18 px: its corner points are (+-13, +-13)) -- are staged in LDS as the aligned dwords their rows lie in, 9 + 12 coalesced
-    // dword loads per lane, instead of 31 + 16 byte gathers per lane from global memory (the 16 descriptor samples of a lane fall on ~16
-    // different cache lines).  Pixel (u, v) of a patch of half-size R is byte (v + R) * 4 * DW + u + R + mis(v + R), DW dwords per row,
-    // mis(r) = byte offset of row r inside its first dword.
+    // reaches 18 px: its corner points are (+-13, +-13)) -- are staged in LDS, 9 + 12 coalesced dword loads per lane, instead of 31 + 16
+    // byte gathers per lane from global memory (the 16 descriptor samples of a lane fall on ~16 different cache lines).  The dwords are
+    // read at the patch's own byte address (unaligned loads), so pixel (u, v) of a patch of half-size R is simply byte
+    // (v + R) * 4 * DW + u + R, DW dwords per row: the kernel is bound by VALU issue, and the per-access alignment term of the
+    // aligned-dword form (round 2) was a fifth of its instructions (1.92 -> ? ms per 1024 images).
     constexpr int kRawR = 15, kRawDw = 9, kBlurR = 18, kBlurDw = 10;
-    __shared__ uint32_t s_raw[8][(2 * kRawR + 1) * kRawDw], s_blur[8][(2 * kBlurR + 1) * kBlurDw];
+    __shared__ uint32_t s_raw[8][(2 * kRawR + 1) * kRawDw], s_blur[8][(2 * kBlurR + 1) * kBlurDw], s_icmask[kRawR + 1][kRawDw];
+    if ((int)threadIdx.x < (kRawR + 1) * kRawDw) {  // the circular patch of the orientation as byte masks per row |v| and dword
+        const int av = (int)threadIdx.x / kRawDw, j = (int)threadIdx.x - av * kRawDw, um = c_umax[av];
+        uint32_t m = 0;
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * j + k - kRawR;
+            if (u >= -um && u <= um) m |= 0xffu << (8 * k);
+        }
+        s_icmask[av][j] = m;
+    }
     bool active = slot < nslot;
     int slot_img = 0;
     if (active) {
@@ -701,72 +711,74 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
     if (active) kp = kps[g];
     const int level = kp.img_level & 0xff, img = kp.img_level >> 8;
     const int x = (kp.packed >> 8) & 0xfff, y = kp.packed >> 20;
-    uint32_t mis0[2] = {0, 0}, pm[2] = {0, 0};
-    auto stage = [&](const LevelDesc& D, auto r_tag, auto dw_tag, uint32_t* dst, int which) {
+    auto stage = [&](const LevelDesc& D, auto r_tag, auto dw_tag, uint32_t* dst) {
         constexpr int R = decltype(r_tag)::value, DW = decltype(dw_tag)::value, N = (2 * R + 1) * DW, Q = (N + 31) / 32;
-        const uint8_t* corner = D.img + (size_t)img * D.img_stride + (size_t)(y - R) * D.pitch + (x - R);
-        const uint8_t* end = D.img + (size_t)(img + 1) * D.img_stride;  // nothing is read past the image's own buffer
-        mis0[which] = (uint32_t)(reinterpret_cast<uintptr_t>(corner) & 3);
-        pm[which] = (uint32_t)D.pitch & 3u;
-        // every load is unconditional (a lane with nothing to fetch, or a dword that would cross the end of the image's buffer, reads the
-        // buffer's first dword instead: an address select), so all of them are in flight before the first is used; the dwords at the very
-        // end of the last image are then re-read byte by byte
-        const uint32_t* safe = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(D.img + (size_t)img * D.img_stride) & ~(uintptr_t)3);
+        const uint8_t* ibase = D.img + (size_t)img * D.img_stride;
+        const uint32_t off0 = (uint32_t)(y - R) * (uint32_t)D.pitch + (uint32_t)(x - R);  // the patch's first byte inside the image's buffer
+        // Would a dword of the patch cross the end of the image's buffer (only a patch in the last rows of an image whose pitch is its
+        // width can)?  Decided once per keypoint: the staging loop is a third of the kernel's instructions, and a 64-bit compare and
+        // select per load were half of the loop.
+        const bool near_end = (size_t)off0 + (size_t)(2 * R) * D.pitch + 4 * DW > D.img_stride;
         uint32_t v[Q];
-        bool tail[Q];
+        if (!near_end) {
+            // all loads first (dwords at byte addresses), 32-bit offsets, (row, j) of lane + 32 q stepped instead of divided
+            const int row0 = lane / DW;
+            int j = lane - DW * row0;
+            uint32_t off = off0 + (uint32_t)row0 * (uint32_t)D.pitch + 4u * (uint32_t)j;
+            const uint32_t step = (uint32_t)(32 / DW) * (uint32_t)D.pitch + 4u * (32 % DW), wrap = (uint32_t)D.pitch - 4u * DW;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int t = min(lane + 32 * q, N - 1), row = t / DW, j = t - DW * row;
-            const uint8_t* rowp = corner + (size_t)row * D.pitch;
-            const uint8_t* a = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4 * j;
-            tail[q] = a + 4 > end;
-            v[q] = *as_global(tail[q] ? safe : reinterpret_cast<const uint32_t*>(a));
-        }
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (tail[q]) {
+            for (int q = 0; q < Q; ++q) {
+                const bool in = lane + 32 * q < N;
+                uint32_t w;
+                __builtin_memcpy(&w, ibase + (in ? off : 0u), 4);
+                v[q] = w;
+                j += 32 % DW; off += step;
+                if (j >= DW) { j -= DW; off += wrap; }
+            }
+        } else {
+            const uint8_t* corner = ibase + off0;
+            const uint8_t* end = ibase + D.img_stride;  // nothing is read past the image's own buffer
+#pragma unroll 1
+            for (int q = 0; q < Q; ++q) {
                 const int t = min(lane + 32 * q, N - 1), row = t / DW, j = t - DW * row;
-                const uint8_t* rowp = corner + (size_t)row * D.pitch;
-                const uint8_t* a = rowp - (reinterpret_cast<uintptr_t>(rowp) & 3) + 4 * j;
-                v[q] = 0;
-                for (int k = 0; k < 4; ++k) if (a + k < end) v[q] |= (uint32_t)a[k] << (8 * k);
+                const uint8_t* a = corner + (size_t)row * D.pitch + 4 * j;
+                uint32_t w = 0;
+                if (a + 4 <= end) __builtin_memcpy(&w, a, 4);
+                else for (int k = 0; k < 4; ++k) if (a + k < end) w |= (uint32_t)a[k] << (8 * k);
+                v[q] = w;
             }
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) if (lane + 32 * q < N) dst[lane + 32 * q] = v[q];
     };
     if (active) {
-        stage(raw.lv[level], std::integral_constant<int, kRawR>{}, std::integral_constant<int, kRawDw>{}, s_raw[kpi], 0);
-        stage(blurred.lv[level], std::integral_constant<int, kBlurR>{}, std::integral_constant<int, kBlurDw>{}, s_blur[kpi], 1);
+        stage(raw.lv[level], std::integral_constant<int, kRawR>{}, std::integral_constant<int, kRawDw>{}, s_raw[kpi]);
+        stage(blurred.lv[level], std::integral_constant<int, kBlurR>{}, std::integral_constant<int, kBlurDw>{}, s_blur[kpi]);
     }
     __syncthreads();
     if (!active) return;
-    const uint8_t* praw = reinterpret_cast<const uint8_t*>(s_raw[kpi]);
     const uint8_t* pblur = reinterpret_cast<const uint8_t*>(s_blur[kpi]);
-    auto raw_at = [&](int u, int v) -> int {
-        const int row = v + kRawR;
-        return praw[row * 4 * kRawDw + u + kRawR + (int)((mis0[0] + (uint32_t)row * pm[0]) & 3u)];
-    };
-    auto blur_at = [&](int u, int v) -> int {
-        const int row = v + kBlurR;
-        return pblur[row * 4 * kBlurDw + u + kBlurR + (int)((mis0[1] + (uint32_t)row * pm[1]) & 3u)];
-    };
+    auto blur_at = [&](int u, int v) -> int { return pblur[(v + kBlurR) * 4 * kBlurDw + u + kBlurR]; };
     {
-        const int u = lane - 16;  // lanes 1..31 cover u = -15..15
+        // IC_Angle (:61-100): m10 = sum u I(u, v), m01 = sum v I(u, v) over the circular patch |u| <= umax[|v|].  Lane = row v: its 36
+        // staged bytes as nine dwords, the bytes outside the circle masked off (s_icmask[|v|], built once per workgroup), then per dword
+        // one v_dot4 with the byte weights u + 15 and one with ones -- integer sums, any order gives the reference's integers.  (A lane
+        // per column walking the 31 rows byte by byte was a quarter of the kernel's instructions.)
         int m10 = 0, m01 = 0;
-        if (lane >= 1) {
-            const int au = u < 0 ? -u : u;
-            int col = 0, vsum = 0;
-            for (int v = -15; v <= 15; ++v) {
-                const int av = v < 0 ? -v : v;
-                if (au <= c_umax[av]) {
-                    const int val = raw_at(u, v);
-                    col += val;
-                    vsum += v * val;
-                }
+        if (lane < 2 * kRawR + 1) {
+            const int v = lane - kRawR, av = v < 0 ? -v : v;
+            const uint32_t* rowp = s_raw[kpi] + lane * kRawDw;
+            const uint32_t* mk = s_icmask[av];
+            uint32_t wsum = 0, sum = 0;
+#pragma unroll
+            for (int j = 0; j < kRawDw; ++j) {
+                const uint32_t d = rowp[j] & mk[j];
+                const uint32_t wts = (uint32_t)(4 * j) * 0x01010101u + 0x03020100u;  // u + 15 of the dword's four bytes
+                wsum = __builtin_amdgcn_udot4(d, wts, wsum, false);
+                sum = __builtin_amdgcn_udot4(d, 0x01010101u, sum, false);
             }
-            m10 = u * col;
-            m01 = vsum;
+            m10 = (int)wsum - kRawR * (int)sum;
+            m01 = v * (int)sum;
         }
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) {
