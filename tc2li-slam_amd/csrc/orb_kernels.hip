@@ -248,9 +248,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
                                                     int* __restrict__ cell_counts, int ncells, int nimg,
                                                     const int* __restrict__ cell_ids, int n_ids) {
-    // The window rows are staged as the aligned dwords they come in: pixel (x, y) of the window is byte
-    // y * kTileP + x + mis(y) of the tile, mis(y) = byte offset of row y inside its first dword (rows of the caller's image
-    // start at any byte address).
+    // The window rows are staged as dwords read at the rows' own byte addresses (rows of the caller's image start anywhere): pixel
+    // (x, y) of the window is byte y * kTileP + x of the tile.  (Round 1 / 2 staged the ALIGNED dwords and carried a per-row
+    // misalignment term through every LDS address; the kernel is bound by VALU issue -- a wavefront instruction holds its SIMD for
+    // four cycles, 1.9 G of them per 1024 images are the kernel's 3.2 ms -- and that term was a sixth of the instructions.)
     constexpr int kTileP = TW + 4;
     __shared__ uint32_t tile32[TH * kTileP / 4];
     __shared__ uint8_t score[TH * TW];
@@ -273,8 +274,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     const LevelDesc L = levels.lv[c.level];
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
     const int w = c.w, h = c.h;
-    const uint32_t mis0 = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3), pm = (uint32_t)L.pitch & 3u;
-    auto mis = [&](int y) { return (int)((mis0 + (uint32_t)y * pm) & 3u); };
     {
         constexpr int kDw = kTileP / 4;  // dwords per tile row
         constexpr int kRounds = (TH * kDw + kFastThreads - 1) / kFastThreads;
@@ -286,10 +285,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
         for (int r = 0; r < kRounds; ++r) {
             const int i = tid + kFastThreads * r;
             const int y = i / kDw, j = i - y * kDw;
-            const int m = mis(y);
-            ok[r] = i < h * kDw && 4 * j - m < w;
+            ok[r] = i < h * kDw && 4 * j < w;
             v[r] = 0;
-            if (ok[r]) v[r] = *as_global(reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch - m + 4 * j));
+            if (ok[r]) { uint32_t t; __builtin_memcpy(&t, src + (size_t)y * L.pitch + 4 * j, 4); v[r] = t; }
         }
 #pragma unroll
         for (int r = 0; r < kRounds; ++r)
@@ -304,13 +302,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
     // the 16 circle pixels and the centre of window position (cx, cy)
     auto circle = [&](int cx, int cy, int (&p)[16]) -> int {
-        const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
-        const uint8_t* r1 = tile + (cy - 2) * kTileP + mis(cy - 2) + cx;
-        const uint8_t* r2 = tile + (cy - 1) * kTileP + mis(cy - 1) + cx;
-        const uint8_t* r3 = tile + cy * kTileP + mis(cy) + cx;
-        const uint8_t* r4 = tile + (cy + 1) * kTileP + mis(cy + 1) + cx;
-        const uint8_t* r5 = tile + (cy + 2) * kTileP + mis(cy + 2) + cx;
-        const uint8_t* r6 = tile + (cy + 3) * kTileP + mis(cy + 3) + cx;
+        const uint8_t* r3 = tile + cy * kTileP + cx;
+        const uint8_t *r0 = r3 - 3 * kTileP, *r1 = r3 - 2 * kTileP, *r2 = r3 - kTileP, *r4 = r3 + kTileP, *r5 = r3 + 2 * kTileP, *r6 = r3 + 3 * kTileP;
         p[0] = r6[0];  p[1] = r6[1];  p[2] = r5[2];  p[3] = r4[3];  p[4] = r3[3];  p[5] = r2[3];  p[6] = r1[2];  p[7] = r0[1];
         p[8] = r0[0];  p[9] = r0[-1]; p[10] = r1[-2]; p[11] = r2[-3]; p[12] = r3[-3]; p[13] = r4[-3]; p[14] = r5[-2]; p[15] = r6[-1];
         return r3[0];
@@ -331,12 +324,15 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     // Pass 0, every pixel: a necessary condition of the segment test on the four compass pixels -- nine contiguous circle pixels
     // always contain pixel 0 or 8 and pixel 4 or 12, so a brighter (darker) arc needs (p0 | p8) & (p4 | p12) brighter (darker).
     // Most pixels of an image stop here after five LDS bytes; the others are appended to a list (any order).
+    // (row, column) of pixel tid + 128 k stepped, not divided: 128 = q_step * ew + r_step
+    const int q_step = ew > 0 ? kFastThreads / ew : 0, r_step = kFastThreads - q_step * ew;
+    int ey = row_of(tid, ew > 0 ? ew : 1, inv_ew), ex = tid - ey * ew;
     for (int i = tid; i < npix; i += kFastThreads) {
-        const int ey = row_of(i, ew, inv_ew), ex = i - ey * ew;
         const int cx = ex + 3, cy = ey + 3;
-        const uint8_t* r0 = tile + (cy - 3) * kTileP + mis(cy - 3) + cx;
-        const uint8_t* r3 = tile + cy * kTileP + mis(cy) + cx;
-        const uint8_t* r6 = tile + (cy + 3) * kTileP + mis(cy + 3) + cx;
+        ex += r_step; ey += q_step;
+        if (ex >= ew) { ex -= ew; ++ey; }
+        const uint8_t* r3 = tile + cy * kTileP + cx;
+        const uint8_t *r0 = r3 - 3 * kTileP, *r6 = r3 + 3 * kTileP;
         const int v = r3[0], hi_t = v + th, lo_t = v - th;
         const int p0 = r6[0], p8 = r0[0], p4 = r3[3], p12 = r3[-3];
         const bool bright = (p0 > hi_t || p8 > hi_t) && (p4 > hi_t || p12 > hi_t);
