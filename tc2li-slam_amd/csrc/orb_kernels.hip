@@ -484,9 +484,9 @@ __global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restric
 // (SF/src/ORBextractor.cc:1105-1106): taps {18,34,48,56,48,34,18}/256, 8.8 horizontal, 16.16 vertical,
 // round to nearest.
 // ------------------------------------------------------------------------------------------------------
-// Every level in one launch, streaming: a wavefront owns a strip of 256 columns x 32 rows; a lane loads one aligned dword per
-// row (rows of a caller image may start at any byte: the four pixels are cut out of two neighbouring dwords with
-// v_alignbit), takes its neighbours' pixels by wave shuffle, filters horizontally into four 8.8 values and keeps the last
+// Every level in one launch, streaming: a wavefront owns a strip of 256 columns x 32 rows; a lane loads the dword of its four
+// pixels per row at its byte address (rows of a caller image may start at any byte; rounds 1-2 cut the pixels out of two aligned
+// dwords with v_alignbit -- the kernel is bound by VALU issue, so that went), takes its neighbours' pixels by wave shuffle, filters horizontally into four 8.8 values and keeps the last
 // seven rows of them in registers for the vertical pass: every pixel is read once from HBM (plus a 6-row halo per 32 rows)
 // and no LDS is used.  The few lanes at the left / right image border gather their pixels one by one with REFLECT_101.
 constexpr int kStripW = 256, kStripRows = 32, kStripWaves = 4;
@@ -574,16 +574,15 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
     constexpr uint32_t TA = 18u | (34u << 8) | (T2 << 16) | (T3 << 24), TB = T2 | (34u << 8) | (18u << 16);
     constexpr uint32_t C01 = 18u | (34u << 16), C23 = T2 | (T3 << 16), C45 = T2 | (34u << 16);
     const int r_end = y1 + 3;
-    const bool own_next = inside && (lane == 63 || x + 4 >= w);  // the dword after the lane's own is not a neighbour's
     for (int r0 = y0 - 3; r0 < r_end; r0 += 6) {
         // The six rows of a round are REQUESTED first and used afterwards: with the load next to its use every row cost the wavefront a
         // full trip to memory (one dword per lane in flight: 38 trips per strip, 0.31 ms per 128 images at 1.3 TB/s, 4 % VALU issue).
-        uint32_t ld_m[6], ld_l[6], ld_n1[6], ld_n2[6], ld_sh[6];  // raw dwords only (own, left, next, next but one): nothing here waits for a load
+        uint32_t ld_m[6], ld_l[6], ld_n1[6];  // raw dwords only (own, left of lane 0, right of lane 63), read at their byte addresses: nothing here waits for a load
         const uint8_t* ld_row[6];
         bool ld_guarded[6];
         // every load below is unconditional -- a lane that has nothing to fetch reads the image's first dword instead (an address
         // select, not a value select: nothing depends on a loaded register until the second loop)
-        const auto* safe = as_global(reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(base) & ~(uintptr_t)3));
+        auto load4 = [](const uint8_t* p) -> uint32_t { uint32_t t; __builtin_memcpy(&t, p, 4); return t; };
 #pragma unroll
         for (int ph = 0; ph < 6; ++ph) {
             const int r = r0 + ph;
@@ -591,17 +590,12 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
             const uint8_t* row = base + (size_t)ry * S.pitch;
             ld_row[ph] = row;
             ld_guarded[ph] = tiny || (img == 0 && ry == 0) || (img == wk.nimg - 1 && ry == h - 1);
-            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(row + x) & 3);  // the same for every lane of the row
-            const auto* q = as_global(reinterpret_cast<const uint32_t*>(row + x - mis));
-            ld_sh[ph] = 8u * mis;
             const bool live = r < r_end && !ld_guarded[ph];
-            // the four bytes left of lane 0 are cut out of the dword before the lane's own and its own; the lane whose right neighbour
-            // is not in the wavefront (lane 63, or the last lane of the row) takes the next dword and, for lane 63, the one after it
+            // the four bytes left of lane 0 and right of lane 63 are not a neighbour's: those lanes fetch them
             const bool want_l = live && lane == 0 && x > 0, want_hi = live && lane == 63 && x + 4 < w;
-            ld_m[ph] = *(live && inside ? q : safe);
-            ld_l[ph] = *(want_l ? q - 1 : safe);
-            ld_n1[ph] = *(want_hi || (live && own_next && mis) ? q + 1 : safe);
-            ld_n2[ph] = *(want_hi && mis ? q + 2 : safe);
+            ld_m[ph] = load4(live && inside ? row + x : base);
+            ld_l[ph] = load4(want_l ? row + x - 4 : base);
+            ld_n1[ph] = load4(want_hi ? row + x + 4 : base);
         }
 #pragma unroll
         for (int ph = 0; ph < 6; ++ph) {
@@ -610,17 +604,13 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
                 const uint8_t* row = ld_row[ph];
                 uint32_t cur = 0, lo, hi;
                 if (!ld_guarded[ph]) {
-                    const uint32_t sh = ld_sh[ph];
-                    const uint32_t m = inside ? ld_m[ph] : 0u;
-                    uint32_t next = __shfl_down(m, 1, 64);
-                    if (own_next && sh) next = ld_n1[ph];
-                    cur = __builtin_amdgcn_alignbit(next, m, sh);
+                    cur = inside ? ld_m[ph] : 0u;
                     lo = __shfl_up(cur, 1, 64);
-                    if (lane == 0 && x > 0) lo = __builtin_amdgcn_alignbit(m, ld_l[ph], sh);
+                    if (lane == 0 && x > 0) lo = ld_l[ph];
                     cur = __builtin_amdgcn_perm(cur, lo, sel_cur);           // identity except in the last lane
                     hi = __shfl_down(cur, 1, 64);
                     if (lane == 63 && x + 4 < w) {
-                        hi = __builtin_amdgcn_alignbit(ld_n2[ph], ld_n1[ph], sh);
+                        hi = ld_n1[ph];
                         if (x + 8 > w) hi = __builtin_amdgcn_perm(hi, cur, sel_hi63);  // the row ends inside that dword: mirror the rest
                     }
                     if (is_last) hi = __builtin_amdgcn_perm(cur, lo, sel_hi);
