@@ -86,8 +86,10 @@ for k, v in mix.items():
     if k in dur:
         v["avg_duration_ns_kernel_stats"] = dur[k]
         if v.get("SQ_INSTS_VALU_per_launch"):
-            # 256 CUs x 4 SIMDs issue one VALU instruction per cycle each at 2.4 GHz: 2457.6 wave-instructions per ns
-            v["valu_issue_frac"] = v["SQ_INSTS_VALU_per_launch"] / dur[k] / 2457.6
+            # 256 CUs x 4 SIMD-32s: a wave64 VALU instruction takes two cycles of its SIMD (MI355X_MICROARCH.md, wave scheduling), 2.4 GHz:
+            # 1228.8 wave-instructions per ns.  (Rounds 1-2 divided by 2457.6 -- one instruction per cycle -- and read the ORB kernels as
+            # "18 % VALU"; they sit at about half of the issue rate when alone, and their time scales with their instruction count.)
+            v["valu_issue_frac"] = v["SQ_INSTS_VALU_per_launch"] / dur[k] / 1228.8
 if mix:
     json.dump(mix, open("profiles/%s_pmc_instruction_mix.json" % tag, "w"), indent=1, sort_keys=True)
     for k, v in sorted(mix.items(), key=lambda kv: -(kv[1].get("SQ_INSTS_VALU_per_launch") or 0) * kv[1].get("launches", 0))[:10]:
