@@ -103,13 +103,15 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
     }
 }
 
-// The same resize as column strips (round 3, default): the kernel above is bound by VALU issue (a wavefront instruction occupies its
-// SIMD for four cycles; ~26 lane-operations per destination pixel for the byte selection out of aligned dwords and the fixed-point
-// blend, twice per pixel because every destination row repeats the horizontal pass of both its source rows).  Here a lane keeps four
+// The same resize as column strips (round 3, default): the kernel above is bound by instruction issue (a wavefront instruction takes
+// two cycles of its SIMD-32; 1.5e8 of them per launch are about half of the kernel's time when it runs alone, and its time follows
+// its instruction count): ~26 lane-operations per destination pixel for the byte selection out of aligned dwords and the fixed-point
+// blend, twice per pixel because every destination row repeats the horizontal pass of both its source rows.  Here a lane keeps four
 // destination columns and walks kResizeRows destination rows down: the column tables (source offsets, alpha pairs) are loaded once, the
 // two source bytes of a tap pair come from ONE unaligned 16-bit load (no selection arithmetic), and the horizontal pass of a source row
 // that two consecutive destination rows share (scale < 2: every other row at 1.2) is computed once and kept in registers.  ~13
-// lane-operations per pixel.  Same integers as the kernel above: tests/test_orb_gpu.py compares every level with the oracle.
+// lane-operations per pixel: 363 -> 196 us per launch of 1024 images.  Same integers as the kernel above: tests/test_orb_gpu.py
+// compares every level with the oracle.
 constexpr int kResizeRows = 16;
 __device__ __forceinline__ uint32_t load_u16_unaligned(const uint8_t* p) {
     uint16_t w;
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
                                                     const int* __restrict__ cell_ids, int n_ids) {
     // The window rows are staged as dwords read at the rows' own byte addresses (rows of the caller's image start anywhere): pixel
     // (x, y) of the window is byte y * kTileP + x of the tile.  (Round 1 / 2 staged the ALIGNED dwords and carried a per-row
-    // misalignment term through every LDS address; the kernel is bound by VALU issue -- a wavefront instruction holds its SIMD for
-    // four cycles, 1.9 G of them per 1024 images are the kernel's 3.2 ms -- and that term was a sixth of the instructions.)
+    // misalignment term through every LDS address; the kernel's time follows its instruction count -- 1.9 G wavefront VALU
+    // instructions per 1024 images at two cycles each are half of its 3.2 ms alone -- and that term was a sixth of them: 3.22 -> 2.66 ms.)
     constexpr int kTileP = TW + 4;
     __shared__ uint32_t tile32[TH * kTileP / 4];
     __shared__ uint8_t score[TH * TW];
