@@ -1,7 +1,8 @@
 // Many small copies / fills as ONE launch.  A lock-step group of local-BA windows used to queue ~9 hipMemcpyAsync / hipMemsetAsync calls
 // per window (input block, operand fill, plane clusters, results): ~1100 blit kernels of ~20 us per batch of 128 windows, all of them
 // links of the group's dependency chain.  Here the host only writes a task list (pinned memory, read by the kernel in place), and the
-// kernel moves the bytes: uploads read pinned host memory over the bus, results are written to it.
+// kernel moves the bytes: uploads read pinned host memory over the bus, results are written to it.  (Round 3: the few LARGE uploads
+// of the list are handed to hipMemcpyAsync after all, see launch_copy_tasks.)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -54,6 +55,28 @@ __global__ __launch_bounds__(256) void k_copy_tasks(const CopyTask* __restrict__
 
 void launch_copy_tasks(const CopyTask* tasks, int n, size_t max_bytes, hipStream_t st) {
     if (n <= 0) return;
+    // Copies of a megabyte or more (the windows' input blocks, 1.4 MB each) go to the runtime's copy path -- the SDMA engines -- instead
+    // of the kernel: the same bytes cross the bus, but no wavefront waits on them.  With all stages running the step went from 33.5
+    // to 30.0 ms (15.2 -> 17.0 k frames/s); with the threshold at 64 KB or 200 KB (results and plane clusters too: three times the
+    // calls) 31.0-31.9 ms.  The list lives in pinned memory, so the host takes those entries out of it.  TC2LI_COPY_ENGINE_BYTES
+    // sets the threshold, 0 leaves everything to the kernel.
+    static const long engine_bytes = getenv("TC2LI_COPY_ENGINE_BYTES") ? atol(getenv("TC2LI_COPY_ENGINE_BYTES")) : 1000000;
+    if (engine_bytes > 0) {
+        CopyTask* list = const_cast<CopyTask*>(tasks);
+        size_t left_max = 0;
+        int left = 0;
+        for (int i = 0; i < n; ++i) {
+            if (list[i].src && (long)list[i].bytes >= engine_bytes) {
+                (void)hipMemcpyAsync(list[i].dst, list[i].src, list[i].bytes, hipMemcpyDefault, st);
+                list[i].bytes = 0;
+            } else if (list[i].bytes) {
+                left_max = std::max(left_max, list[i].bytes);
+                ++left;
+            }
+        }
+        if (!left) return;
+        max_bytes = left_max;
+    }
     // small batches: no more workgroups than 4 KB slices of the largest task
     static const int groups = getenv("TC2LI_COPY_GROUPS") ? atoi(getenv("TC2LI_COPY_GROUPS")) : kCopyGroups;
     const unsigned g = (unsigned)std::max<size_t>(1, std::min<size_t>(groups, (max_bytes + 4095) / 4096));
