@@ -353,9 +353,13 @@ class Loop:
         # sequences per GPU a step's windows are a short, latency-bound batch (16 windows: 8.6 ms against 6.4 ms for the other stages), so
         # the mapping thread takes the windows of two steps in one call, as soon as the tracking thread has finished both (a second,
         # prebuilt batch of twice the windows; beyond 256 sequences a step's batch already fills the GPU and the thread runs free).
-        self.ba_batch2 = None
+        # With 64 sequences or fewer (what strong scaling over 512 leaves a GPU at 8 ranks) even two steps' windows are a latency-bound
+        # batch -- a call costs 4.6 ms for 16 windows, 6 ms for 32 -- so there the thread may take up to four steps' keyframes when it lags that far.
+        self.ba_batch2 = self.ba_batch4 = None
         if n_ba >= 2 and F <= 256 and F % args.kf_interval == 0 and not os.environ.get("TC2LI_BENCH_BA_SINGLE_STEP"):
             self.ba_batch2 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(2 * n_ba)], wl.ba_windows[0]["cam"])
+            if F <= 64:
+                self.ba_batch4 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(4 * n_ba)], wl.ba_windows[0]["cam"])
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
@@ -414,13 +418,13 @@ class Loop:
         self.map_adds = [int(na.sum()), int(nn.sum())]
 
     def ba_step(self, m=1):
-        """The local-mapping work of m (1 or 2) steps."""
+        """The local-mapping work of m (1, 2 or 4) steps."""
         self.ba_due += m * self.ba_rate
         k = int(self.ba_due + 1e-9)
         if k < 1:
             return
         self.ba_due -= k
-        batch, n = (self.ba_batch2, 2 * self.n_ba) if m == 2 else (self.ba_batch, self.n_ba)
+        batch, n = {1: (self.ba_batch, self.n_ba), 2: (self.ba_batch2, 2 * self.n_ba), 4: (self.ba_batch4, 4 * self.n_ba)}[m]
         if batch.run(self.args.ba_concurrency) != n:
             raise RuntimeError("a local BA window failed")
         self.ba_windows_done += n
@@ -488,7 +492,7 @@ class Loop:
                 if ready < 1:
                     time.sleep(0.0002)
                     continue
-                m = min(2, ready) if follows_tracking else 1
+                m = (4 if ready >= 4 and self.ba_batch4 is not None else min(2, ready)) if follows_tracking else 1
                 self.ba_step(m)
                 done += m
 
@@ -1262,8 +1266,8 @@ def main(argv=None):
                 "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel | TrackLocalMap | LiDAR front end + map maintenance | local "
                                  "mapping, each on its own host thread and HIP stream (the reference's tracking / LiDAR / local-mapping threads; with batched "
                                  "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
-                                 "processed one batch" + ("; local mapping takes the keyframes of two tracked steps per call (it follows the tracking "
-                                                          "thread)" if loop.ba_batch2 is not None else "; the LiDAR stream has high priority"),
+                                 "processed one batch" + ("; local mapping follows the tracking thread and takes the keyframes of the steps tracked since its last call, at most %d "
+                                                          "steps' per call" % (4 if loop.ba_batch4 is not None else 2) if loop.ba_batch2 is not None else "; the LiDAR stream has high priority"),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": {
                     "stage_threads": 5, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
