@@ -44,24 +44,46 @@ struct Cell { int begin, end, layer; float center[3], quarter; };
 
 }  // namespace
 
+// Work space of balm_build_planes, one per host thread: the function runs once per window on the pool threads of a lock-step group and was
+// three quarters of a group's setup time (0.6-1.1 ms of a window's 0.9-1.3): a node-based hash map with an allocation per root voxel, six
+// vectors sized per call, and the per-keyframe moments of BOTH frames for every cell visited.  Same arithmetic in the same order below.
+struct PlaneScratch {
+    std::vector<WindowPoint> pts;
+    std::vector<int> root_id, root_count, start, order, scratch, table;  // table: open addressing, root id + 1 per slot, 0 = empty
+    std::vector<VoxelKey> root_key;
+    std::vector<Moments> local, world;
+    std::vector<Cell> stack;
+};
+
 void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const int32_t* off, std::vector<PlaneCluster>& clusters,
                        std::vector<double>& coe) {
+    static thread_local PlaneScratch ws;
     clusters.clear();
     coe.clear();
     const int total = off[W];
-    std::vector<WindowPoint> pts(total);
+    std::vector<WindowPoint>& pts = ws.pts;
+    pts.resize(total);
     // ---- points into the frame of the first keyframe's LiDAR, root voxel of every point ----
     double R0t[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R0t[3 * r + c] = twl[0].R[3 * c + r];
-    std::unordered_map<VoxelKey, int, VoxelKeyHash> root_of;
-    root_of.reserve((size_t)total / 4 + 16);
-    std::vector<VoxelKey> root_key;
-    std::vector<int> root_id(total), root_count;
+    size_t cap = 64;
+    int cap_bits = 6;
+    while (cap < (size_t)total) { cap <<= 1; ++cap_bits; }  // every point its own voxel still leaves the table half empty
+    cap <<= 1; ++cap_bits;
+    std::vector<int>& table = ws.table;
+    table.assign(cap, 0);
+    std::vector<VoxelKey>& root_key = ws.root_key;
+    std::vector<int>&root_id = ws.root_id, &root_count = ws.root_count;
+    root_key.clear(); root_count.clear();
+    root_id.resize(total);
+    const VoxelKeyHash hasher;
     for (int i = 0; i < W; ++i) {
         double d[3], p[3], R[9];
         for (int k = 0; k < 3; ++k) d[k] = twl[i].p[k] - twl[0].p[k];
         m3_vec(R0t, d, p);
         m3_mul(R0t, twl[i].R, R);
+        VoxelKey last_key{0, 0, 0};
+        int last_id = -1;  // consecutive returns of a scan mostly fall into the same voxel
         for (int j = off[i]; j < off[i + 1]; ++j) {
             WindowPoint& q = pts[j];
             q.slot = i;
@@ -76,15 +98,25 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
                 if (loc < 0) loc -= 1.0f;
                 kk[k] = (int64_t)loc;
             }
-            auto it = root_of.find(key);
             int id;
-            if (it == root_of.end()) {
-                id = (int)root_key.size();
-                root_of.emplace(key, id);
-                root_key.push_back(key);
-                root_count.push_back(0);
+            if (last_id >= 0 && key == last_key) {
+                id = last_id;
             } else {
-                id = it->second;
+                // the slot from the HIGH bits of a multiplied hash: the low bits of the key mix follow the low bits of the coordinates
+                size_t h = (size_t)(((uint64_t)hasher(key) * 0x9E3779B97F4A7C15ull) >> (64 - cap_bits));
+                for (;;) {
+                    const int t = table[h];
+                    if (t == 0) {  // first appearance: ids in that order, as the insertion order of the reference's map walk
+                        id = (int)root_key.size();
+                        table[h] = id + 1;
+                        root_key.push_back(key);
+                        root_count.push_back(0);
+                        break;
+                    }
+                    if (root_key[t - 1] == key) { id = t - 1; break; }
+                    h = (h + 1) & (cap - 1);
+                }
+                last_key = key; last_id = id;
             }
             root_id[j] = id;
             root_count[id]++;
@@ -92,17 +124,21 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
     }
     // ---- counting sort by root voxel; inside a voxel the points stay in (keyframe, scan) order ----
     const int n_roots = (int)root_key.size();
-    std::vector<int> start(n_roots + 1, 0);
+    std::vector<int>&start = ws.start, &order = ws.order, &scratch = ws.scratch;
+    start.assign(n_roots + 1, 0);
     for (int r = 0; r < n_roots; ++r) start[r + 1] = start[r] + root_count[r];
-    std::vector<int> order(total), scratch(total);
+    order.resize(total); scratch.resize(total);
     {
-        std::vector<int> cur(start.begin(), start.end() - 1);
+        std::vector<int>& cur = ws.root_count;  // the counts have served: running places
+        for (int r = 0; r < n_roots; ++r) cur[r] = start[r];
         for (int j = 0; j < total; ++j) order[cur[root_id[j]]++] = j;
     }
     // ---- every root voxel: plane test, split into octants while not planar ----
-    std::vector<Moments> local(W), world(W);
-    std::vector<Cell> stack;
+    std::vector<Moments>&local = ws.local, &world = ws.world;
+    local.resize(W); world.resize(W);
+    std::vector<Cell>& stack = ws.stack;
     for (int r = 0; r < n_roots; ++r) {
+        if (start[r + 1] - start[r] <= kMinPoints) continue;  // (the walk below would pop the root and drop it)
         Cell root;
         root.begin = start[r]; root.end = start[r + 1]; root.layer = 0;
         const int64_t* kk = &root_key[r].x;
@@ -115,10 +151,10 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
             stack.pop_back();
             const int count = cell.end - cell.begin;
             if (count <= kMinPoints) continue;
-            for (int i = 0; i < W; ++i) { local[i] = Moments(); world[i] = Moments(); }
+            // the moments of the common frame decide; those of the keyframes' own frames are only formed for a cell that is a plane
+            for (int i = 0; i < W; ++i) world[i] = Moments();
             for (int a = cell.begin; a < cell.end; ++a) {
                 const WindowPoint& q = pts[order[a]];
-                local[q.slot].push(q.local);
                 world[q.slot].push(q.world);
             }
             // covariance of all points of the cell in the common frame
@@ -137,8 +173,13 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
             eig_sym3(C, lambda, U);
             if (lambda[0] / lambda[1] < (double)kPlaneRatio[cell.layer]) {
                 int seen = 0;
-                for (int i = 0; i < W; ++i) seen += local[i].n != 0;
+                for (int i = 0; i < W; ++i) seen += world[i].n != 0;
                 if (seen < 2) continue;  // VOX_HESS::push_voxel: a plane must be seen from two keyframes
+                for (int i = 0; i < W; ++i) local[i] = Moments();
+                for (int a = cell.begin; a < cell.end; ++a) {
+                    const WindowPoint& q = pts[order[a]];
+                    local[q.slot].push(q.local);
+                }
                 double weight = 0;
                 for (int i = 0; i < W; ++i) {
                     PlaneCluster pc;
@@ -176,7 +217,6 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
     }
 }
 
-// ---- LiDAR-pose derivatives -> camera se3 derivatives ---------------------------------------------------------------
 static void so3_log_f(const double* Rd, double out[3]) {  // Sophus::SO3f(R.cast<float>()).log()
     float R[9], q[4];
     for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
