@@ -1109,6 +1109,7 @@ struct LockstepContext {
     DevBuf<uint8_t> d_table;
     PinnedBuf<uint8_t> h_table;
     PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
+    PinnedBuf<CopyTask> h_table_task;  // the slot table's way up: one entry for k_copy_tasks (see `upload` in the lock-step loops)
     hipStream_t st = nullptr;
 };
 constexpr int kMaxLockstepGroups = 8;
@@ -1141,7 +1142,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
     BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
     BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
-    const BaBatchSlot* const d_slots = (const BaBatchSlot*)C.d_table.p;
+    static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
+    const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
     const BaBatchSlot* const d_slots_lidar = d_slots + n;
     std::vector<LockstepWindow> W(n);
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
@@ -1277,7 +1279,15 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
         for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
         const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
-        if (bytes && hipMemcpyAsync(C.d_table.p, C.h_table.p, bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+        // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
+        // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
+        // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
+        // TC2LI_BA_ZERO_COPY_SLOTS=1: the kernels read the pinned table themselves (same step time, every kernel slower).
+        if (bytes && !kZeroCopySlots) {
+            if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
+            C.h_table_task.p[0] = CopyTask{C.d_table.p, C.h_table.p, bytes};
+            launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
+        }
     };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
@@ -1565,7 +1575,8 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
     BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
     BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
-    const BaBatchSlot* const d_slots = (const BaBatchSlot*)C.d_table.p;
+    static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
+    const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
     const BaBatchSlot* const d_slots_lidar = d_slots + n;
     std::vector<LviWindow> W(n);
     // ---- setup: argument checks, inertial links, plane extraction (host), uploads ----
@@ -1673,7 +1684,15 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
         for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
         const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
-        if (bytes && hipMemcpyAsync(C.d_table.p, C.h_table.p, bytes, hipMemcpyHostToDevice, st) != hipSuccess) failed = true;
+        // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
+        // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
+        // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
+        // TC2LI_BA_ZERO_COPY_SLOTS=1: the kernels read the pinned table themselves (same step time, every kernel slower).
+        if (bytes && !kZeroCopySlots) {
+            if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
+            C.h_table_task.p[0] = CopyTask{C.d_table.p, C.h_table.p, bytes};
+            launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
+        }
     };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
