@@ -715,11 +715,11 @@ void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const P
 //   * the closing insertion sort never moves an element past an equal one, and no element has to cross a range boundary (left of a cut
 //     everything is <= the pivot <= everything right of it): it is a stable sort inside every final range of at most 16 elements.
 // Two kernels.  k_time_sort: one workgroup of 1024 threads per scan replays the levels on arrays in global memory while a range is
-// longer than kSortLds elements (about five levels of a 65 k scan), then lists the ranges.  k_time_sort_lds: one workgroup of 256 threads
+// longer than kSortLds elements (about five levels of a 65 k scan), then lists the ranges.  k_time_sort_lds: one workgroup of 512 threads (256: 4.95 ms per 512 scans, 512: 3.5, 1024: 3.7)
 // per listed range finishes it in LDS -- the same level loop on 16-bit range-local indices -- down to the stable sort of the final
 // ranges, and writes the permutation.  A range whose recursion reaches the depth limit (std::sort would heap-sort it) flags its scan;
 // the host sorts that scan itself.
-constexpr int kSortThreads = 1024, kSortLdsThreads = 256, kSortLds = 2048;
+constexpr int kSortThreads = 1024, kSortLdsThreads = 512, kSortLds = 2048;
 struct TimeSortArrays { float* key; int *idx, *sf, *sl, *cl, *cr, *lp, *rp, *cut; uint8_t* flag; };
 
 // ranges[scan slot base ..]: first index of every range the first kernel left for the second; n_ranges[scan]
