@@ -1302,4 +1302,11 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    rc = main()
+    # Leave without running the interpreter's finalisation: stage threads are daemon threads that may be inside a library call (GIL released);
+    # CPython 3.10 ends such a thread with pthread_exit when it wakes during finalisation, the forced unwinding runs into a noexcept frame of
+    # the library's worker code and the process aborts ("terminate called without an active exception") -- after the line has been printed,
+    # but with a non-zero exit code.  Seen once in a few dozen runs.
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc if isinstance(rc, int) else 0)
