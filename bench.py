@@ -133,6 +133,34 @@ def single_sequence_child(args):
         return None
 
 
+def sweep_children(args):
+    """The loop with 256 / 128 / 64 sequences per step, each in a fresh child process (what a rank of a 2- / 4- / 8-GPU strong-scaling run
+    is: a process of its own).  Measured as later legs of this process the same loops read a quarter less -- they inherit the streams and
+    hardware-queue assignment of every loop before them."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+                                                            "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env.update(TC2LI_NO_BUILD="1")
+    out = {}
+    for n_seq in (256, 128, 64):
+        if n_seq >= args.sequences:
+            continue
+        steps = max(10, min(40, 5120 // n_seq))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", str(n_seq), "--unique", str(args.unique), "--steps", str(steps), "--warmup", "8",
+               "--no-cpu-baseline", "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval), "--ba-concurrency", str(args.ba_concurrency),
+               "--map-length", str(args.map_length)]
+        if args.front_end_only:
+            cmd.append("--front-end-only")
+        try:
+            txt = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
+            out[str(n_seq)] = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])["value"]
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench.py: the %d-sequence child failed (%s)\n" % (n_seq, e))
+            return None
+    out["unit"] = ("frames/s of the whole loop with that many sequences per step on this one GPU, each in a child process of its own started before this "
+                   "process initialised the GPU (8 warm-up steps, then 20 / 40 / 40 timed steps)")
+    return out
+
+
 def rehearse(args, rank, world, dist, dist_util):
     """The multi-rank protocol without device work: every rank 'processes' its share of the global list by sleeping."""
     units = dist_util.shard_units(args.sequences, rank, world) if args.scaling == "strong" else list(range(args.frames))
@@ -1021,6 +1049,10 @@ def main(argv=None):
     single_child = None
     if rank == 0 and not args.no_extra_lines and not args.rehearse and not os.environ.get("TC2LI_BENCH_SINGLE_INPROC") and not under_profiler():
         single_child = single_sequence_child(args)
+    sweep_child = None
+    if (rank == 0 and world == 1 and not args.no_extra_lines and not args.rehearse and not args.front_end_only and not under_profiler()
+            and args.scaling == "strong" and set(args.stages.split(",")) == {"orb", "track", "lidar", "ba"}):
+        sweep_child = sweep_children(args)
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -1141,7 +1173,9 @@ def main(argv=None):
 
     # ---- sequences per GPU: what strong scaling over the fixed list turns into at 8 / 4 / 2 ranks, timed here on one GPU ----
     sweep = None
-    if rank == 0 and world == 1 and not args.no_extra_lines and set(stages) == {"orb", "track", "lidar", "ba"}:
+    if sweep_child is not None:
+        sweep = {str(F): round(total_sequences * args.steps / elapsed, 1), **sweep_child}
+    elif rank == 0 and world == 1 and not args.no_extra_lines and set(stages) == {"orb", "track", "lidar", "ba"}:
         sweep = {str(F): round(total_sequences * args.steps / elapsed, 1)}
         for n_seq in (256, 128, 64):
             if n_seq >= F:
