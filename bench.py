@@ -1343,4 +1343,6 @@ if __name__ == "__main__":
     # but with a non-zero exit code.  Seen once in a few dozen runs.
     sys.stdout.flush()
     sys.stderr.flush()
+    if under_profiler():  # the profiler writes its output from exit handlers
+        sys.exit(rc)
     os._exit(rc if isinstance(rc, int) else 0)
