@@ -912,7 +912,7 @@ def source_hash():
     csrc = os.path.join(ROOT, "tc2li-slam_amd", "csrc")
     for f in sorted(os.listdir(csrc)) + ["../../include/tc2li_hip.h", "../../bench.py"]:
         path = os.path.join(csrc, f)
-        if os.path.isfile(path) and not f.startswith("."):
+        if os.path.isfile(path) and not os.path.basename(f).startswith("."):
             h.update(f.encode()); h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
