@@ -121,8 +121,8 @@ __device__ __forceinline__ uint32_t load_u16_unaligned(const uint8_t* p) {
 __global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict__ src, int src_pitch, size_t src_img_stride, int sw, int sh,
                                                        uint8_t* __restrict__ dst, int dst_pitch, size_t dst_img_stride, int dw, int dh,
                                                        const int* __restrict__ xofs, const short* __restrict__ ialpha, const int* __restrict__ yofs,
-                                                       const short* __restrict__ ibeta, int gx, int gy, int nimg) {
-    // one wavefront = 256 columns x kResizeRows rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
+                                                       const short* __restrict__ ibeta, int gx, int gy, int nimg, int rows_per_wave) {
+    // one wavefront = 256 columns x rows_per_wave rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
     const int n_units = gx * gy * nimg, per_xcd = (n_units + 7) / 8;
     const int u = ((int)blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);  // the wavefront's unit inside its XCD's share
     const int logical = ((int)blockIdx.x & 7) * per_xcd + u;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict
     if (dx0 >= dw) return;
     const uint8_t* S = src + (size_t)img * src_img_stride;
     uint8_t* D = dst + (size_t)img * dst_img_stride + dx0;
-    const int dy_begin = by * kResizeRows, dy_end = min(dy_begin + kResizeRows, dh);
+    const int dy_begin = by * rows_per_wave, dy_end = min(dy_begin + rows_per_wave, dh);
     int sx[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -812,11 +812,14 @@ void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, 
                      const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
         return;
     }
-    // one wavefront per (256 columns, kResizeRows rows); four wavefronts per workgroup, the workgroup count a multiple of 8 (XCDs)
-    const int gx = (dst.w + 255) / 256, gy = (dst.h + kResizeRows - 1) / kResizeRows;
+    // one wavefront per (256 columns, `rows` rows); four wavefronts per workgroup, the workgroup count a multiple of 8 (XCDs).  A batch
+    // walks kResizeRows rows per wavefront (the shared source rows' horizontal pass is reused); a few images are a chain of seven
+    // latency-bound launches, where four rows per wavefront put four times the wavefronts on the GPU (a stereo pair: 16 -> ? us per launch)
+    const int rows = nimg >= 32 ? kResizeRows : 4;
+    const int gx = (dst.w + 255) / 256, gy = (dst.h + rows - 1) / rows;
     const int per_xcd = (gx * gy * nimg + 7) / 8, wg_per_xcd = (per_xcd + 3) / 4;
     TC2LI_LAUNCH(k_resize_strips, dim3(wg_per_xcd * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
-                 const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg);
+                 const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg, rows);
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
