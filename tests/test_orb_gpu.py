@@ -185,7 +185,7 @@ def test_blur_row_ends(pkg, oracle, synthetic, width):
         assert np.array_equal(ext.blurred_level(0, level), ora.blurred(level)), (width, level)
 
 
-@pytest.mark.parametrize("n_images,chunks", [(17, 1), (17, 2), (66, 4)])
+@pytest.mark.parametrize("n_images,chunks", [(17, 1), (17, 2), (66, 4), (40, 1)])  # (40, 1): a chunk of 32+ images takes the batch forms (resize: 16 rows per wavefront)
 def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_images, chunks, monkeypatch):
     """tc2li_orb_extract_batch queues a batch at once, or (TC2LI_ORB_CHUNKS) in chunks of images: every image's features, its
     diagnostics and the stereo matcher's view of the batch are those of single-image calls."""
