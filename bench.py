@@ -667,6 +667,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
     nloc = float(np.mean(np.diff(loop.local_off))) if getattr(loop, "local_off", None) is not None else 0.0
     w = {
         "k_resize_linear": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # read levels 0..6, write levels 1..7
+        "k_resize_strips": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # the same resize as column strips (round 3)
         "k_fast_cells": (n_img * (sum(px) + 4 * 15000), "B"),                          # every level once + the candidate list
         "k_blur7_strips": (n_img * 2 * sum(px), "B"),
         "k_orient_describe": (n_img * nkp * (709 + 512 + 64 + 16), "B"),                # patch gathers + descriptor / angle / key out
@@ -695,6 +696,8 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         # Optimizer::PoseOptimization, two calls per frame: every correspondence read once (edge 40 B + point 24 B), outlier flag and chi2 out;
         # the 4 x 10 Gauss-Newton passes over them are meant to stay on chip
         "k_pose_optimization": (2 * F * nkp * 0.5 * (40 + 24 + 1 + 8), "B"),
+        "k_pose_optimization_lds": (2 * F * nkp * 0.5 * (40 + 24 + 1 + 8), "B"),       # the same with the correspondences staged in LDS (round 3)
+        "k_map_holes": (F * mp * (1 + 4), "B"),                                          # compaction in place: every point's deleted flag in, its hole / mover rank out
     }
     if ba:
         E, P, lin, tr, nw = ba["edges"], ba["points"], ba["linearisations"], ba["trials"], ba["windows"]
