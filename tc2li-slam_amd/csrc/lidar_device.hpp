@@ -113,8 +113,7 @@ struct MapIncTask {
 // Counting sort of one map's points into its dense grid.
 struct MapGridTask {
     MapGrid g;         // geometry + points of the map (g.pts / g.bucket_start = what the build writes)
-    int* counts;       // [n_cells]
-    int* fill;         // [n_cells]
+    int* counts;       // [n_cells], zero outside a build
     int* start;        // [n_cells + 1]
     float4* sorted;    // [n_points]
     int* tile_sums;    // [ceil(n_cells / 4096)]

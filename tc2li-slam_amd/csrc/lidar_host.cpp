@@ -29,7 +29,7 @@ struct tc2li_lidar_map {
     DevBuf<int> d_remap;                    // old index -> new index of the last compaction (-1: deleted)
     bool have_remap = false;                // d_remap / d_sorted describe the map before the compaction that was just committed
     int remap_n_old = 0, remap_n_kept = 0;
-    DevBuf<int> d_bucket_counts, d_bucket_start, d_bucket_fill, d_tile_sums;
+    DevBuf<int> d_bucket_counts, d_bucket_start, d_tile_sums;
     DevBuf<MapIncTask> d_inc_task;    // batches of one map: Build / Add_Points / Delete_Point_Boxes
     DevBuf<MapGridTask> d_grid_task;
     int n = 0, n_cells = 0;
@@ -234,14 +234,14 @@ MapGrid grid_geometry(const tc2li_lidar_map* m, float* cell_out) {
 }
 
 // Sizes the map's grid arrays for its current points and fills the build task (no launch).
-int grid_prepare(tc2li_lidar_map* m, MapGridTask* t) {
+int grid_prepare(tc2li_lidar_map* m, MapGridTask* t, hipStream_t st) {
     float cell;
     MapGrid g = grid_geometry(m, &cell);
     m->cell = cell;
     const int nc = g.nx * g.ny * g.nz;
     if (nc > m->n_cells) {
         TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nc + nc / 2));
-        TC2LI_HIP_CHECK(m->d_bucket_fill.alloc(nc + nc / 2));
+        TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, ((size_t)nc + nc / 2) * sizeof(int), st));  // zero outside a build (map_kernels.hip)
         TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nc + nc / 2 + 1));
         TC2LI_HIP_CHECK(m->d_tile_sums.alloc((size_t)(nc + nc / 2) / 4096 + 2));
         m->n_cells = nc + nc / 2;
@@ -251,7 +251,7 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t) {
     DevBuf<float4>& target = merge ? m->d_sorted_alt : m->d_sorted;
     TC2LI_HIP_CHECK(target.ensure(std::max(m->n, 1)));
     g.points = m->d_points.p; g.pts = target.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
-    t->g = g; t->counts = m->d_bucket_counts.p; t->fill = m->d_bucket_fill.p; t->start = m->d_bucket_start.p; t->sorted = target.p;
+    t->g = g; t->counts = m->d_bucket_counts.p; t->start = m->d_bucket_start.p; t->sorted = target.p;
     t->tile_sums = m->d_tile_sums.p; t->n_cells = nc;
     t->old_sorted = merge ? m->d_sorted.p : nullptr; t->remap = merge ? m->d_remap.p : nullptr;
     t->n_old = merge ? m->remap_n_old : 0; t->n_kept = merge ? m->remap_n_kept : 0;
@@ -266,7 +266,7 @@ int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>&
     std::vector<MapGridTask> tasks(n_maps);
     int max_points = 0, max_cells = 0;
     for (int i = 0; i < n_maps; ++i) {
-        const int rc = grid_prepare(maps[i], &tasks[i]);
+        const int rc = grid_prepare(maps[i], &tasks[i], st);
         if (rc != TC2LI_OK) return rc;
         max_points = std::max(max_points, tasks[i].n_old + (maps[i]->n - tasks[i].n_kept));
         max_cells = std::max(max_cells, tasks[i].n_cells);

@@ -349,10 +349,9 @@ __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict
 
 // ---- dense grid (re)build: counting sort of the map points into 1 m cells -----------------------------------------------------------
 constexpr int kScanTile = 4096;  // cells per tile of the two-level prefix sum (1024 threads x 4)
-__global__ __launch_bounds__(256) void k_map_zero(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < T.n_cells; i += gridDim.x * 256) { T.counts[i] = 0; T.fill[i] = 0; }
-}
+// The cell counters are zero outside a build: allocated zeroed (lidar_host.cpp grid_prepare), raised by k_map_count, read by the scans,
+// and taken down again by k_map_scatter, which hands out a cell's places from the back (atomicSub).  Rounds 1-2 cleared them and a second
+// counter array per build (k_map_zero: 0.5 ms per step for 512 maps of ~0.9 M cells).
 // Work item u of a build: u < n_old: entry u of the old grid (skipped when its point was deleted); then the added points.
 // Returns the point's cell in the NEW geometry, or a negative key no neighbouring lane shares; xyzi = position and NEW index.
 __device__ __forceinline__ int map_build_item(const MapGridTask& T, int u, float4& xyzi) {
@@ -449,7 +448,8 @@ __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restri
     const int c = map_build_item(T, u, q);
     const RunInfo run = wave_runs(c);
     int first = 0;
-    if (run.head && c >= 0) first = T.start[c] + atomicAdd(&T.fill[c], run.length);  // the run's lanes take consecutive places
+    // the run's lanes take consecutive places; the cell's places go from the back, which leaves its counter at zero for the next build
+    if (run.head && c >= 0) first = T.start[c] + atomicSub(&T.counts[c], run.length) - run.length;
     first = __shfl(first, run.head_lane, 64);
     if (c >= 0) T.sorted[first + ((int)(threadIdx.x & 63) - run.head_lane)] = q;
 }
@@ -480,7 +480,6 @@ void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, 
     const int max_points = max_work;
     if (!n_tasks) return;
     const int tiles = (max_cells + kScanTile - 1) / kScanTile;
-    TC2LI_LAUNCH(k_map_zero, dim3(std::min((max_cells + 255) / 256, 512), n_tasks), dim3(256), 0, st, tasks);
     if (max_points) TC2LI_LAUNCH(k_map_count, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
     TC2LI_LAUNCH(k_map_scan_tiles, dim3(tiles, n_tasks), dim3(1024), 0, st, tasks);
     TC2LI_LAUNCH(k_map_scan_tops, dim3(n_tasks), dim3(1024), 0, st, tasks);
