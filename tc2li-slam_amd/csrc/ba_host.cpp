@@ -1138,10 +1138,15 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // the slot table: every window's slot on the host; before a phase the slots of the windows taking part are copied, in launch
     // order, into the two device lists (A: the phase's windows, B: those of them with a LiDAR term) -- a kernel's workgroup finds its
     // window at blockIdx without going through an index list first
-    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot);
-    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
+    // behind the two lists: the steps x_p of the windows of a trial phase (kXpStride doubles each), so that the trial kernels read them
+    // from device memory (they read the solver's pinned buffer before: a bus round trip at the start of every workgroup)
+    constexpr size_t kXpStride = 192;  // doubles: 6 x 32 free keyframes; a larger window keeps reading the pinned buffer
+    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
+    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes + (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)(C.h_table.p + table_bytes + xp_bytes);
     BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
+    double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
+    const double* const d_xp_area = (const double*)(C.d_table.p + table_bytes);
     static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
     const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
     const BaBatchSlot* const d_slots_lidar = d_slots + n;
@@ -1275,10 +1280,10 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         else pool.parallel_for(cnt, fn);
     };
     bool failed = false;
-    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {  // list a at d_slots[0..), list b at d_slots_lidar[0..)
+    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b, int n_xp = 0) {  // list a at d_slots[0..), list b at d_slots_lidar[0..); n_xp: steps behind them
         for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
         for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
-        const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
+        const size_t bytes = n_xp ? table_bytes + (size_t)n_xp * kXpStride * sizeof(double) : (b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes);
         // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
         // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
         // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
@@ -1423,7 +1428,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             std::vector<int> step, step_lidar;
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
-                upload(step, step_lidar);  // slots unchanged since phase B
+                int n_xp = 0;
+                if (!dev_solve && !kZeroCopySlots) {
+                    n_xp = (int)step.size();
+                    for (size_t k = 0; k < step.size(); ++k) {
+                        LockstepWindow& w = W[step[k]];
+                        if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
+                        memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
+                        h_slots[step[k]].xp = d_xp_area + k * kXpStride;
+                    }
+                }
+                upload(step, step_lidar, n_xp);  // slots unchanged since phase B but for the steps' place
                 ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
                 balm_batch_launch_residual(d_slots_lidar, nullptr, (int)step_lidar.size(), true, st);
                 sync();
@@ -1571,10 +1586,15 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot);
-    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(3 * (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p + 2 * (size_t)n;
+    // behind the two lists: the steps x_p of the windows of a trial phase (kXpStride doubles each), so that the trial kernels read them
+    // from device memory (they read the solver's pinned buffer before: a bus round trip at the start of every workgroup)
+    constexpr size_t kXpStride = 192;  // doubles: 6 x 32 free keyframes; a larger window keeps reading the pinned buffer
+    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
+    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes + (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)(C.h_table.p + table_bytes + xp_bytes);
     BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
+    double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
+    const double* const d_xp_area = (const double*)(C.d_table.p + table_bytes);
     static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
     const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
     const BaBatchSlot* const d_slots_lidar = d_slots + n;
@@ -1680,10 +1700,10 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
     };
     bool failed = false;
-    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b) {
+    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b, int n_xp = 0) {
         for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
         for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
-        const size_t bytes = b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes;
+        const size_t bytes = n_xp ? table_bytes + (size_t)n_xp * kXpStride * sizeof(double) : (b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes);
         // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
         // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
         // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
@@ -1781,7 +1801,17 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             std::vector<int> step, step_lidar;
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
-                upload(step, step_lidar);
+                int n_xp = 0;
+                if (!kZeroCopySlots) {
+                    n_xp = (int)step.size();
+                    for (size_t k = 0; k < step.size(); ++k) {
+                        LviWindow& w = W[step[k]];
+                        if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
+                        memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
+                        h_slots[step[k]].xp = d_xp_area + k * kXpStride;
+                    }
+                }
+                upload(step, step_lidar, n_xp);
                 ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
                 if (C.h_tasks.ensure(step.size()) != hipSuccess) { failed = true; break; }
                 size_t max_bytes = 0;
