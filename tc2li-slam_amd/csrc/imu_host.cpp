@@ -99,22 +99,26 @@ void integrate(tc2li_preintegrated& p, const float acceleration[3], const float 
     // position first (old velocity and rotation), then velocity (old rotation), rotation last
     for (int k = 0; k < 3; ++k) p.dP[k] = p.dP[k] + p.dV[k] * dt + 0.5f * Ra[k] * dt * dt;
     for (int k = 0; k < 3; ++k) p.dV[k] = p.dV[k] + Ra[k] * dt;
-    const M3f Wacc = hat(acc), RW = dR * Wacc;
+    // The reference's expressions in Eigen's order of evaluation (ImuTypes.cc:213-225): a scalar factor scales the matrix it stands next to,
+    // element by element, before the next product -- `-dR*dt*Wacc` is ((-dR) dt) Wacc, `0.5f*dR*dt*dt*Wacc*JRg` is ((((0.5 dR) dt) dt) Wacc) JRg.
+    // (Round 2 formed (dR Wacc) first and scaled afterwards: the same numbers to the last bit or two of a float.)
+    const M3f Wacc = hat(acc);
+    const M3f dRdt = dR * dt, dRdt2h = (dRdt * dt) * 0.5f;  // the factor 0.5 is exact wherever it is applied
+    const M3f RWdt = dRdt * Wacc, RWdt2h = dRdt2h * Wacc;
     float A[81] = {0}, B[54] = {0};
     for (int k = 0; k < 9; ++k) A[10 * k] = 1;
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
-            A[9 * (3 + r) + c] = -RW(r, c) * dt;
-            A[9 * (6 + r) + c] = -0.5f * RW(r, c) * dt * dt;
+            A[9 * (3 + r) + c] = -RWdt(r, c);
+            A[9 * (6 + r) + c] = -RWdt2h(r, c);
             A[9 * (6 + r) + 3 + c] = r == c ? dt : 0.0f;
-            B[6 * (3 + r) + 3 + c] = dR(r, c) * dt;
-            B[6 * (6 + r) + 3 + c] = 0.5f * dR(r, c) * dt * dt;
+            B[6 * (3 + r) + 3 + c] = dRdt(r, c);
+            B[6 * (6 + r) + 3 + c] = dRdt2h(r, c);
         }
-    const M3f RWJ = RW * JRg;
-    JPa = JPa + JVa * dt - dR * (0.5f * dt * dt);
-    JPg = JPg + JVg * dt - RWJ * (0.5f * dt * dt);
-    JVa = JVa - dR * dt;
-    JVg = JVg - RWJ * dt;
+    JPa = JPa + JVa * dt - dRdt2h;
+    JPg = JPg + JVg * dt - RWdt2h * JRg;
+    JVa = JVa - dRdt;
+    JVg = JVg - RWdt * JRg;
     // IntegratedRotation (ImuTypes.cc:95-116)
     const float v[3] = {accW[0] * dt, accW[1] * dt, accW[2] * dt};
     const float d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrtf(d2);
