@@ -34,6 +34,12 @@ const char* tc2li_last_error(void);
 int tc2li_abi_version(void);
 /* Number of visible HIP devices (0 without a GPU; never fails). */
 int tc2li_device_count(void);
+/* Hardware queues the HIP runtime maps this process's streams onto (the runtime's GPU_MAX_HW_QUEUES, 4 by default).  A process that runs
+ * ONE sequence -- the reference's own configuration: tracking, LiDAR and local-mapping threads with a stream each, every kernel tiny --
+ * should ask for 8 (streams that share a queue wait for each other: 479 against 761 frames/s); batched callers keep
+ * the default.  It only takes effect when called before the process's first HIP call (first thing in main, before any other tc2li_*
+ * entry and before anything else that touches the GPU); returns TC2LI_ERR_INVALID for n < 1 or n > 32.  No reference counterpart. */
+int tc2li_set_hardware_queues(int n);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor -- replaces TC2LI_SLAM::ORBextractor (SF/include/ORBextractor.h:46-121,

@@ -235,4 +235,11 @@ int tc2li_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+int tc2li_set_hardware_queues(int n) {
+    if (n < 1 || n > 32) { tc2li::set_error("tc2li_set_hardware_queues: %d queues", n); return TC2LI_ERR_INVALID; }
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", n);
+    setenv("GPU_MAX_HW_QUEUES", buf, 1);  // read by the HIP runtime when it initialises
+    return TC2LI_OK;
+}
 }
