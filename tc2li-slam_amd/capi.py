@@ -150,6 +150,11 @@ def device_count():
     return lib().tc2li_device_count()
 
 
+def set_hardware_queues(n):
+    """tc2li_set_hardware_queues: only effective before the process's first HIP call."""
+    _check(lib().tc2li_set_hardware_queues(int(n)))
+
+
 def exported_symbols():
     """Names of the functions include/tc2li_hip.h declares (used by the CPU-side ABI test)."""
     text = open(HEADER_PATH).read()

@@ -25,6 +25,22 @@ def test_no_cpu_fallback(pkg):
     assert "no HIP device" in str(e.value)
 
 
+def test_set_hardware_queues(pkg, monkeypatch):
+    """The one runtime knob that is an ABI call: it sets what the HIP runtime reads when it initialises, and refuses nonsense."""
+    import os
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")  # restored after the test
+    pkg.capi.set_hardware_queues(8)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") in ("8", "4")  # os.environ is Python's copy; the C environment is what counts:
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.getenv.restype = ctypes.c_char_p
+    assert libc.getenv(b"GPU_MAX_HW_QUEUES") == b"8"
+    for bad in (0, -1, 33):
+        with pytest.raises(pkg.capi.Tc2liError):
+            pkg.capi.set_hardware_queues(bad)
+    libc.setenv(b"GPU_MAX_HW_QUEUES", b"4", 1)
+
+
 def test_product_does_not_reference_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg_dir = os.path.join(root, "tc2li-slam_amd")
