@@ -301,6 +301,9 @@ class Workload:
         return orb
 
 
+_OPEN_LOOPS = set()  # every Loop with live stage threads: main() closes what an error path left open before the process ends
+
+
 class StageWorker:
     """A host thread that lives as long as its Loop and runs the stage functions handed to it: the library keeps work spaces and a private
     stream per host thread (thread_local), so warm-up, timed and instrumented passes must run on the SAME threads -- fresh threads per pass
@@ -308,7 +311,9 @@ class StageWorker:
 
     def __init__(self, name, local_rank, torch):
         self.q = queue.Queue()
-        self.t = threading.Thread(target=self._main, args=(local_rank, torch), name=name, daemon=True)
+        # not a daemon thread: Loop.close() joins it, so no stage thread is inside a library call (or inside the destructors of its
+        # thread-local work spaces: hipFree, device synchronisation) while later legs are timed or while the interpreter finalises
+        self.t = threading.Thread(target=self._main, args=(local_rank, torch), name=name)
         self.t.start()
 
     def _main(self, local_rank, torch):
@@ -329,7 +334,9 @@ class StageWorker:
         return done
 
     def stop(self):
+        """Ends the thread and waits for it: its thread-local work spaces in the library are released by its exit, here and now."""
         self.q.put(None)
+        self.t.join()
 
 
 class Loop:
@@ -402,6 +409,7 @@ class Loop:
         self.orb_times, self.lidar_times = [], []
         self.ba_windows_done = 0
         self.workers = {}
+        _OPEN_LOOPS.add(self)
 
     # -- stages ------------------------------------------------------------------------------------------------------------
     def extract(self, k, stream):
@@ -557,8 +565,11 @@ class Loop:
 
     def close(self):
         for w in self.workers.values():
-            w.stop()
+            w.q.put(None)
+        for w in self.workers.values():
+            w.t.join()
         self.workers = {}
+        _OPEN_LOOPS.discard(self)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -1338,14 +1349,26 @@ def main(argv=None):
     return 0
 
 
+def run_and_leave():
+    """main(), then an orderly end: every stage thread joined, the library's pools joined and its process-wide work spaces released
+    (tc2li_shutdown) while the HIP runtime is alive, then a plain sys.exit -- the same path under rocprofv3, whose output is written by
+    exit handlers."""
+    rc = 1
+    try:
+        rc = main()
+    finally:
+        for loop in list(_OPEN_LOOPS):
+            try:
+                loop.close()
+            except Exception:  # noqa: BLE001
+                pass
+        pkg = sys.modules.get("tc2li_slam_amd")
+        if pkg is not None and getattr(pkg, "capi", None) is not None and pkg.capi.lib_loaded():
+            pkg.capi.shutdown()
+        sys.stdout.flush()
+        sys.stderr.flush()
+    return rc
+
+
 if __name__ == "__main__":
-    rc = main()
-    # Leave without running the interpreter's finalisation: stage threads are daemon threads that may be inside a library call (GIL released);
-    # CPython 3.10 ends such a thread with pthread_exit when it wakes during finalisation, the forced unwinding runs into a noexcept frame of
-    # the library's worker code and the process aborts ("terminate called without an active exception") -- after the line has been printed,
-    # but with a non-zero exit code.  Seen once in a few dozen runs.
-    sys.stdout.flush()
-    sys.stderr.flush()
-    if under_profiler():  # the profiler writes its output from exit handlers
-        sys.exit(rc)
-    os._exit(rc if isinstance(rc, int) else 0)
+    sys.exit(run_and_leave())

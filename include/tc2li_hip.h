@@ -37,9 +37,29 @@ int tc2li_device_count(void);
 /* Hardware queues the HIP runtime maps this process's streams onto (the runtime's GPU_MAX_HW_QUEUES, 4 by default).  A process that runs
  * ONE sequence -- the reference's own configuration: tracking, LiDAR and local-mapping threads with a stream each, every kernel tiny --
  * should ask for 8 (streams that share a queue wait for each other: 479 against 761 frames/s); batched callers keep
- * the default.  It only takes effect when called before the process's first HIP call (first thing in main, before any other tc2li_*
- * entry and before anything else that touches the GPU); returns TC2LI_ERR_INVALID for n < 1 or n > 32.  No reference counterpart. */
+ * the default.  Returns TC2LI_ERR_INVALID for n < 1 or n > 32.  No reference counterpart.
+ * It only takes effect before the process's first HIP call: once this library has called into HIP (any entry that needs the device,
+ * tc2li_device_count included) it returns TC2LI_ERR_INVALID instead of silently doing nothing.  It sets an environment variable (setenv):
+ * call it before the process starts other threads. */
 int tc2li_set_hardware_queues(int n);
+/* Host threads this process may keep busy: the library sizes its worker pools from it (extractor pool a quarter, tracking pool, LiDAR pool
+ * and every lock-step BA group an eighth of what is left after the caller's own stage threads; caps 32 / 16 / 16 / 16 -- the sizes the pools
+ * were tuned at on a one-GPU box).  Default: the environment variable TC2LI_HOST_THREAD_BUDGET, else the cores the process may run on
+ * (sched_getaffinity).  A launcher with R ranks on a node passes cores / R so that the ranks' pools add up to the node.  Returns
+ * TC2LI_ERR_INVALID for threads < 1 or when a pool exists already (call it first, or after tc2li_shutdown).  No reference counterpart (the
+ * reference's four threads are fixed, SF/src/System.cc:184-224). */
+int tc2li_set_host_thread_budget(int threads);
+/* counts[0] = the budget in force, [1] extractor pool, [2] tracking pool, [3] LiDAR pool, [4] threads per lock-step BA group,
+ * [5] largest number of lock-step groups; capacity >= 6.  Returns 6. */
+int tc2li_host_threads(int32_t* counts, int capacity);
+/* Orderly end (or pause) of the library's own threads: joins every worker pool -- each worker's thread-local work spaces (device and pinned
+ * buffers, streams) are released by its exit -- releases the process-wide work spaces (lock-step BA contexts, mapping work spaces) and
+ * synchronises the device, all while the HIP runtime is alive.  The caller guarantees that no other thread is inside the library; its own
+ * threads that called the library should have ended (their thread-local work spaces go with them).  Handles stay valid and every entry
+ * keeps working afterwards (pools and work spaces are made again on demand).  Call it before main() returns: a process that leaves with
+ * library threads alive runs their teardown concurrently with the HIP runtime's (the reference's System::Shutdown, SF/src/System.cc:325-377,
+ * joins its threads for the same reason). */
+int tc2li_shutdown(void);
 
 /* ------------------------------------------------------------------------------------------------
  * ORB extractor -- replaces TC2LI_SLAM::ORBextractor (SF/include/ORBextractor.h:46-121,

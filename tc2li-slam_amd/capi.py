@@ -155,6 +155,28 @@ def set_hardware_queues(n):
     _check(lib().tc2li_set_hardware_queues(int(n)))
 
 
+def lib_loaded():
+    return _lib is not None
+
+
+def shutdown():
+    """tc2li_shutdown: joins the library's worker pools and releases its process-wide work spaces; no other thread may be inside the
+    library.  Handles stay valid, the next call that needs a pool makes it again."""
+    _check(lib().tc2li_shutdown())
+
+
+def set_host_thread_budget(threads):
+    """tc2li_set_host_thread_budget: host threads this process may keep busy (cores / ranks per node); before the pools exist."""
+    _check(lib().tc2li_set_host_thread_budget(int(threads)))
+
+
+def host_threads():
+    """{budget, extractor_pool, tracking_pool, lidar_pool, ba_group_pool, ba_groups_max}: the sizes the pools have (or will get)."""
+    out = (C.c_int32 * 6)()
+    _check(lib().tc2li_host_threads(out, 6))
+    return dict(zip(("budget", "extractor_pool", "tracking_pool", "lidar_pool", "ba_group_pool", "ba_groups_max"), [int(v) for v in out]))
+
+
 def exported_symbols():
     """Names of the functions include/tc2li_hip.h declares (used by the CPU-side ABI test)."""
     text = open(HEADER_PATH).read()

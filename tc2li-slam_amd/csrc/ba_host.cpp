@@ -1111,9 +1111,10 @@ struct LockstepContext {
     PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
     PinnedBuf<CopyTask> h_table_task;  // the slot table's way up: one entry for k_copy_tasks (see `upload` in the lock-step loops)
     hipStream_t st = nullptr;
+    ~LockstepContext() { if (st) (void)hipStreamDestroy(st); }
 };
-constexpr int kMaxLockstepGroups = 8;
-LockstepContext& lockstep_ctx(int group) { static LockstepContext c[kMaxLockstepGroups]; return c[group]; }
+struct LockstepContexts { LockstepContext c[kMaxLockstepGroups]; };
+LockstepContext& lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 0>().c[group]; }
 
 // returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
 bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
@@ -1570,7 +1571,7 @@ struct LviWindow {
     bool stopped() const { return p->stop_flag && *p->stop_flag; }
     bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
 };
-LockstepContext& lvi_lockstep_ctx(int group) { static LockstepContext c[kMaxLockstepGroups]; return c[group]; }
+LockstepContext& lvi_lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 1>().c[group]; }
 
 bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_imu_calib* calib, const tc2li_camera* cam, WorkerPool& pool, int32_t* results,
                         int group = 0) {
@@ -1945,47 +1946,44 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     if (n_problems == 0) return 0;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
-    static WorkerPool* pool = new WorkerPool(16);  // persistent: its threads keep their streams and workspaces
+    WorkerPool* pool = &named_pool(kPoolBaGroup0);  // persistent: its threads keep their streams and workspaces
     static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;  // A/B switch for measurements
     // The lock-step loop is a chain of dependent launches with a host step after every phase: while the host works the stream is
     // empty.  Several groups of windows, each a lock-step batch of its own on its own stream and host thread, fill each other's gaps.
     static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
+    // windows the lock-step groups could not take (a LiDAR window outside the batched kernels' range: a group that declines has written
+    // nothing but zeroed stats) go through the one-window path below -- those windows only, every other window keeps its lock-step result
+    std::vector<uint8_t> todo(n_problems, 1);
     if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
-        const int groups = std::min(kGroups, n_problems / 2);
-        bool done = false;
-        if (groups <= 1) {
-            done = ba_batch_lockstep(problems, n_problems, cam, *pool, results);
-        } else {
-            static WorkerPool* group_pools[kMaxLockstepGroups] = {};
-            static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
-            // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) and the per-window host steps
-            // between the phases (LiDAR quadratic form, 6K LDL^T) are host work: with 8 threads per group 4.9 + 1.9 + 0.5 ms of a group's 18.5 ms.
-            // While the GPU was the limit of the whole loop more threads changed nothing; since the BA kernels were rebuilt the mapping thread is
-            // the last one to finish a step, and 16 threads per group take the step from 41.8-42.9 to 40.7-40.8 ms (32: 41.0)
-            static const int kGroupThreads = std::max(1, getenv("TC2LI_BA_GROUP_THREADS") ? atoi(getenv("TC2LI_BA_GROUP_THREADS")) : 16);
-            for (int g = 0; g < groups; ++g) if (!group_pools[g]) group_pools[g] = new WorkerPool(kGroupThreads);
-            std::atomic<int> fell_back{0};
-            top->parallel_for(groups, [&](int g) {
-                const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
-                if (!ba_batch_lockstep(problems + b, e - b, cam, *group_pools[g], results + b, g)) fell_back++;
-            });
-            done = fell_back.load() == 0;
-        }
-        if (done) {
-            int ok_ = 0;
-            for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
-            return ok_;
-        }
+        const int groups = std::max(1, std::min(kGroups, n_problems / 2));
+        // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) and the per-window host steps
+        // between the phases (LiDAR quadratic form, 6K LDL^T) are host work on the group's own pool (common.cpp pool_threads: 16 threads per
+        // group on a one-GPU box -- 8 -> 16 took the step from 41.8-42.9 to 40.7-40.8 ms in round 2, 32: 41.0 -- fewer under a smaller budget)
+        auto run_group = [&](int g) {
+            const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
+            if (ba_batch_lockstep(problems + b, e - b, cam, named_pool(kPoolBaGroup0 + g), results + b, g))
+                std::fill(todo.begin() + b, todo.begin() + e, (uint8_t)0);
+        };
+        if (groups == 1) run_group(0);
+        else named_pool(kPoolBaTop).parallel_for(groups, run_group);
+    }
+    std::vector<int> rest;
+    for (int i = 0; i < n_problems; ++i) if (todo[i]) rest.push_back(i);
+    if (rest.empty()) {
+        int ok_ = 0;
+        for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
+        return ok_;
     }
     struct ThreadStream {
         hipStream_t s = nullptr;
         ~ThreadStream() { if (s) (void)hipStreamDestroy(s); }
     };
     std::atomic<int> next{0};
-    pool->parallel_for(workers, [&](int) {
+    pool->parallel_for(std::min(workers, (int)rest.size()), [&](int) {
         static thread_local ThreadStream ts;
         if (!ts.s && hipStreamCreateWithFlags(&ts.s, hipStreamNonBlocking) != hipSuccess) ts.s = nullptr;
-        for (int i; (i = next.fetch_add(1)) < n_problems;) {
+        for (int k; (k = next.fetch_add(1)) < (int)rest.size();) {
+            const int i = rest[k];
             const tc2li_ba_problem& p = problems[i];
             results[i] = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
                                                           p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive,
@@ -2004,33 +2002,21 @@ int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, i
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
     static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
-    static const int kGroupThreads = std::max(1, getenv("TC2LI_BA_GROUP_THREADS") ? atoi(getenv("TC2LI_BA_GROUP_THREADS")) : 16);
+    // as in tc2li_local_bundle_adjustment_batch: only the windows of a group that declined go through the one-window path
+    std::vector<uint8_t> todo(n_problems, 1);
     if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
-        static WorkerPool* group_pools[kMaxLockstepGroups] = {};
-        static WorkerPool* top = new WorkerPool(kMaxLockstepGroups);
-        static std::mutex pools_mu;
         const int groups = std::max(1, std::min(kGroups, n_problems / 2));
-        {
-            std::lock_guard<std::mutex> lk(pools_mu);
-            for (int g = 0; g < groups; ++g) if (!group_pools[g]) group_pools[g] = new WorkerPool(kGroupThreads);
-        }
-        std::atomic<int> fell_back{0};
-        if (groups == 1) {
-            if (!lvi_batch_lockstep(problems, n_problems, calib, cam, *group_pools[0], results, 0)) fell_back++;
-        } else {
-            top->parallel_for(groups, [&](int g) {
-                const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
-                if (!lvi_batch_lockstep(problems + b, e - b, calib, cam, *group_pools[g], results + b, g)) fell_back++;
-            });
-        }
-        if (fell_back.load() == 0) {
-            int ok_ = 0;
-            for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
-            return ok_;
-        }
+        auto run_group = [&](int g) {
+            const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
+            if (lvi_batch_lockstep(problems + b, e - b, calib, cam, named_pool(kPoolLviGroup0 + g), results + b, g))
+                std::fill(todo.begin() + b, todo.begin() + e, (uint8_t)0);
+        };
+        if (groups == 1) run_group(0);
+        else named_pool(kPoolLviTop).parallel_for(groups, run_group);
     }
     // one window after the other (a LiDAR window outside the batched kernels' range, or a batch of one)
     for (int i = 0; i < n_problems; ++i) {
+        if (!todo[i]) continue;
         const tc2li_lvi_problem& p = problems[i];
         results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
                                                        p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,

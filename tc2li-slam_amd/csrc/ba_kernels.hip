@@ -1121,12 +1121,9 @@ static inline size_t schur_lds_bytes(int np_pad) {
 int ba_schur_parts(int n_slices, bool blocks_form) { return blocks_form ? (n_slices + kSchurGroup - 1) / kSchurGroup : n_slices; }
 
 // the block-by-block kernels need more than the 64 KB of dynamic LDS a kernel gets by default
-static void schur_blocks_attr() {
-    static bool set = false;
-    if (set) return;
-    (void)hipFuncSetAttribute((const void*)k_ba_schur_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
-    (void)hipFuncSetAttribute((const void*)k_ba_schur_blocks_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
-    set = true;
+static void schur_blocks_attr() {  // a refusal shows as the launch's own error (the callers check hipGetLastError)
+    (void)ensure_dynamic_lds((const void*)k_ba_schur_blocks, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
+    (void)ensure_dynamic_lds((const void*)k_ba_schur_blocks_b, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
 }
 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
@@ -1197,11 +1194,7 @@ void ba_batch_launch_solve(const BaBatchSlot* slots, const int* active, int n_ac
     if (!n_active || !x.max_free) return;
     const int n = 6 * x.max_free;
     const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {  // 21 free keyframes: 66 KB
-        (void)hipFuncSetAttribute((const void*)k_ba_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-        attr_set = true;
-    }
+    (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 72 * 1024);  // 21 free keyframes: 66 KB
     TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, slots, active);
 }
 void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {

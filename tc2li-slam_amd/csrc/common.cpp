@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 namespace tc2li {
 
@@ -19,6 +22,7 @@ void set_error(const char* fmt, ...) {
 
 bool device_ready() {
     int n = 0;
+    note_hip_touched();
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
         set_error("no HIP device available (%s); this library has no CPU fallback",
@@ -83,6 +87,20 @@ hipError_t memset_sync(void* dst, int value, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(dst, value, bytes, st);
     return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
+bool ensure_dynamic_lds(const void* fn, int bytes) {
+    struct Entry { const void* fn; int dev, bytes; bool ok; };
+    static std::mutex mu;
+    static std::vector<Entry>* done = new std::vector<Entry>();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry& e : *done) if (e.fn == fn && e.dev == dev && e.bytes >= bytes) return e.ok;
+    const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (err != hipSuccess) { (void)hipGetLastError(); set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", bytes, dev, hipGetErrorString(err)); }
+    done->push_back(Entry{fn, dev, bytes, err == hipSuccess});
+    return err == hipSuccess;
 }
 
 namespace prof {
@@ -176,27 +194,72 @@ void WorkerPool::parallel_for(int n, const std::function<void(int)>& fn) {
     fn_ = nullptr;
 }
 
-WorkerPool& global_pool() {
-    static WorkerPool* pool = [] {
-        int n = (int)std::thread::hardware_concurrency();
-        if (const char* s = getenv("TC2LI_HOST_THREADS")) n = atoi(s);
-        if (n < 1) n = 1;
-        if (n > 32) n = 32;
-        return new WorkerPool(n);
-    }();
-    return *pool;
+// ---- the library's host threads --------------------------------------------------------------------------------------------
+// Every pool is created on first use and owned by this table, so that tc2li_shutdown can join the threads (whose thread-local work
+// spaces -- device and pinned buffers, streams -- are released by their destructors while the HIP runtime is still alive).
+namespace {
+std::mutex g_pools_mu;
+WorkerPool* g_pools[kPoolCount] = {};
+std::atomic<int> g_thread_budget{0};  // 0: not set -> derived from the cores this process may run on
+std::atomic<bool> g_hip_touched{false};
+std::mutex g_hooks_mu;
+std::vector<std::function<void()>>& hooks() { static auto* v = new std::vector<std::function<void()>>(); return *v; }
+
+int cores_of_this_process() {
+    int n = 0;
+#if defined(__linux__)
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+#endif
+    if (n < 1) n = (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : n;
+}
+}  // namespace
+
+void at_shutdown(std::function<void()> fn) {
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    hooks().push_back(std::move(fn));
 }
 
-WorkerPool& tracking_pool() {
-    static WorkerPool* pool = [] {
-        int n = (int)std::thread::hardware_concurrency() / 2;
-        if (const char* s = getenv("TC2LI_TRACKING_THREADS")) n = atoi(s);
-        if (n < 1) n = 1;
-        if (n > 16) n = 16;
-        return new WorkerPool(n);
-    }();
-    return *pool;
+void note_hip_touched() { g_hip_touched.store(true, std::memory_order_relaxed); }
+
+int host_thread_budget() {
+    int b = g_thread_budget.load();
+    if (b > 0) return b;
+    if (const char* s = getenv("TC2LI_HOST_THREAD_BUDGET")) { b = atoi(s); if (b > 0) return b; }
+    return cores_of_this_process();
 }
+
+// Threads of pool `id` under the budget B of this process: the stage threads of a caller like the reference (tracking, LiDAR, local
+// mapping: counted as 5) come off first; of the rest the extractor pool may take a quarter, the tracking pool, the LiDAR pool and each
+// lock-step BA group an eighth -- with B >= 133 every pool has the size it was tuned at on a one-GPU box (32 / 16 / 16 / 16 per group),
+// with 8 ranks on 256 cores (B = 32) they add up to 6 + 3 + 3 + 3 x 3 + 5 = 26 threads per rank.
+int pool_threads(int id) {
+    const int B = std::max(1, host_thread_budget() - 5);
+    auto share = [&](int cap, int den) { return std::max(1, std::min(cap, B / den)); };
+    if (id == kPoolGlobal) {
+        if (const char* s = getenv("TC2LI_HOST_THREADS")) return std::max(1, std::min(32, atoi(s)));
+        return share(32, 4);
+    }
+    if (id == kPoolTracking) {
+        if (const char* s = getenv("TC2LI_TRACKING_THREADS")) return std::max(1, std::min(16, atoi(s)));
+        return share(16, 8);
+    }
+    if (id == kPoolLidar) return share(16, 8);
+    if (id == kPoolBaTop || id == kPoolLviTop) return kMaxLockstepGroups;  // one thread per lock-step group: they wait on their streams
+    // lock-step BA groups: the setup of a group (graph structure, staging, plane extraction) and the per-window host steps between the phases
+    if (const char* s = getenv("TC2LI_BA_GROUP_THREADS")) return std::max(1, atoi(s));
+    return share(16, 8);
+}
+
+WorkerPool& named_pool(int id) {
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    if (!g_pools[id]) g_pools[id] = new WorkerPool(pool_threads(id));
+    return *g_pools[id];
+}
+
+WorkerPool& global_pool() { return named_pool(kPoolGlobal); }
+WorkerPool& tracking_pool() { return named_pool(kPoolTracking); }
 
 }  // namespace tc2li
 
@@ -232,14 +295,53 @@ const char* tc2li_last_error(void) { return tc2li::g_last_error.c_str(); }
 int tc2li_abi_version(void) { return 1; }
 int tc2li_device_count(void) {
     int n = 0;
+    tc2li::note_hip_touched();
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
 int tc2li_set_hardware_queues(int n) {
     if (n < 1 || n > 32) { tc2li::set_error("tc2li_set_hardware_queues: %d queues", n); return TC2LI_ERR_INVALID; }
+    if (tc2li::g_hip_touched.load()) {
+        tc2li::set_error("tc2li_set_hardware_queues: called after this library's first HIP call -- the runtime has read GPU_MAX_HW_QUEUES already");
+        return TC2LI_ERR_INVALID;
+    }
     char buf[16];
     snprintf(buf, sizeof(buf), "%d", n);
-    setenv("GPU_MAX_HW_QUEUES", buf, 1);  // read by the HIP runtime when it initialises
+    setenv("GPU_MAX_HW_QUEUES", buf, 1);  // read by the HIP runtime when it initialises; setenv: call it before the process has other threads
+    return TC2LI_OK;
+}
+int tc2li_set_host_thread_budget(int threads) {
+    if (threads < 1) { tc2li::set_error("tc2li_set_host_thread_budget: %d threads", threads); return TC2LI_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(tc2li::g_pools_mu);
+    for (int i = 0; i < tc2li::kPoolCount; ++i)
+        if (tc2li::g_pools[i]) { tc2li::set_error("tc2li_set_host_thread_budget: the library's worker pools exist already (call it first, or after tc2li_shutdown)"); return TC2LI_ERR_INVALID; }
+    tc2li::g_thread_budget.store(threads);
+    return TC2LI_OK;
+}
+int tc2li_host_threads(int32_t* counts, int capacity) {
+    const int ids[5] = {tc2li::kPoolGlobal, tc2li::kPoolTracking, tc2li::kPoolLidar, tc2li::kPoolBaGroup0, tc2li::kPoolBaTop};
+    if (!counts || capacity < 6) { tc2li::set_error("tc2li_host_threads: invalid argument"); return TC2LI_ERR_INVALID; }
+    counts[0] = tc2li::host_thread_budget();
+    for (int i = 0; i < 5; ++i) counts[1 + i] = tc2li::pool_threads(ids[i]);
+    return 6;
+}
+int tc2li_shutdown(void) {
+    // the caller guarantees that no other thread is inside the library; the pools' threads are idle then
+    tc2li::WorkerPool* pools[tc2li::kPoolCount];
+    {
+        std::lock_guard<std::mutex> lk(tc2li::g_pools_mu);
+        for (int i = 0; i < tc2li::kPoolCount; ++i) { pools[i] = tc2li::g_pools[i]; tc2li::g_pools[i] = nullptr; }
+    }
+    for (int i = 0; i < tc2li::kPoolCount; ++i) delete pools[i];  // joins: every worker's thread_local work spaces are freed by its own exit
+    {
+        std::vector<std::function<void()>> todo;
+        { std::lock_guard<std::mutex> lk(tc2li::g_hooks_mu); todo = tc2li::hooks(); }
+        for (auto& fn : todo) fn();  // the process-wide work spaces (lock-step BA contexts, mapping / map-point work spaces)
+    }
+    if (tc2li::g_hip_touched.load()) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) == hipSuccess && n > 0) (void)hipDeviceSynchronize(); else (void)hipGetLastError();
+    }
     return TC2LI_OK;
 }
 }

@@ -125,6 +125,41 @@ private:
     bool stop_ = false;
 };
 
+// The library's pools, created on first use and destroyed (threads joined) by tc2li_shutdown; sizes from the host-thread budget
+// (tc2li_set_host_thread_budget / TC2LI_HOST_THREAD_BUDGET / the cores this process may run on), common.cpp pool_threads().
+constexpr int kMaxLockstepGroups = 8;
+enum PoolId {
+    kPoolGlobal = 0,   // the ORB extractor's host stages
+    kPoolTracking,     // the tracking thread's host steps
+    kPoolLidar,        // per-scan host steps of the LiDAR batch calls
+    kPoolBaTop,        // one thread per lock-step group of tc2li_local_bundle_adjustment_batch
+    kPoolLviTop,       // the same for tc2li_local_lvi_bundle_adjustment_batch
+    kPoolBaGroup0,     // + g: host threads of lock-step group g (LV-BA)
+    kPoolLviGroup0 = kPoolBaGroup0 + kMaxLockstepGroups,
+    kPoolCount = kPoolLviGroup0 + kMaxLockstepGroups
+};
+WorkerPool& named_pool(int id);
+// fn runs inside tc2li_shutdown (after the pools' threads have been joined, while the HIP runtime is alive); hooks stay registered
+void at_shutdown(std::function<void()> fn);
+// The one process-wide instance of a work space T (Tag tells apart two of the same type): made on first use, destroyed by
+// tc2li_shutdown and made again by the next use; never destroyed at process exit, where its hipFree calls would run after the HIP
+// runtime's own teardown.
+template <typename T, int Tag = 0>
+T& shutdown_owned() {
+    static T* p = nullptr;
+    static std::mutex mu;
+    static bool registered = false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!registered) {
+        registered = true;
+        at_shutdown([] { std::lock_guard<std::mutex> lk2(mu); delete p; p = nullptr; });
+    }
+    if (!p) p = new T();
+    return *p;
+}
+int pool_threads(int id);
+int host_thread_budget();
+void note_hip_touched();  // tc2li_set_hardware_queues refuses once the library has called into HIP
 WorkerPool& global_pool();    // the ORB extractor's host stages (quadtree per image and level)
 // A second pool for the tracking thread's host steps (stereo / matcher / tracking entry points): WorkerPool::parallel_for serialises
 // its callers, so on one shared pool the milliseconds-long quadtree phase of the extraction thread would stall every short

@@ -16,6 +16,10 @@ namespace prof {
 extern std::atomic<int> g_enabled;
 bool acquire(const char* name, hipEvent_t* start, hipEvent_t* stop);  // false: no events (limit reached, creation failed): launch plainly
 }  // namespace prof
+// hipFuncAttributeMaxDynamicSharedMemorySize (a kernel gets 64 KB of dynamic LDS unless it asks for more) for kernel `fn` on the calling
+// thread's current device: set once per (kernel, device), thread-safe.  false: the runtime refused -- the caller takes its fall-back
+// kernel, or launches anyway and reports the launch error.
+bool ensure_dynamic_lds(const void* fn, int bytes);
 #define TC2LI_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                  \
     do {                                                                                                                       \
         hipEvent_t prof_a_ = nullptr, prof_b_ = nullptr;                                                                       \

@@ -739,7 +739,7 @@ int tc2li_lidar_eskf_update(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_po
 
 }  // extern "C"
 namespace {
-WorkerPool& lidar_pool() { static WorkerPool* p = new WorkerPool(16); return *p; }
+WorkerPool& lidar_pool() { return named_pool(kPoolLidar); }
 }  // namespace
 extern "C" {
 

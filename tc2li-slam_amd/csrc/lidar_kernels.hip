@@ -1400,11 +1400,7 @@ void launch_voxel_sort(const ScanSlot* slots, int nscans, const VoxelParams* vp,
                        const int* table_counts, int* table_rank, int* vox_keys, int* vox_member_off, int* vox_fill, int* vox_count, int* n_vox,
                        int* status, hipStream_t st) {
     if (!nscans) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_voxel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxVoxelsPerScan * 4);
-        attr_set = true;
-    }
+    (void)ensure_dynamic_lds((const void*)k_voxel_sort, kMaxVoxelsPerScan * 4);
     TC2LI_LAUNCH(k_voxel_sort, dim3(nscans), dim3(1024), kMaxVoxelsPerScan * 4, st, slots, vp, count, table_keys, table_counts,
                        table_rank, vox_keys, vox_member_off, vox_fill, vox_count, n_vox, status);
 }

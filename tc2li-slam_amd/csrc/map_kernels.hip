@@ -459,8 +459,7 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
     if (!n_tasks || !max_points) return;
     TC2LI_LAUNCH(k_mapinc_classify, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
     const size_t lds = (size_t)kMapIncMax * (sizeof(unsigned long long) + sizeof(int));
-    static bool attr = false;  // 96 KB of dynamic LDS: above the default limit of a kernel
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mapinc_group), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(k_mapinc_group), (int)lds);  // 96 KB of dynamic LDS: above the default limit of a kernel
     TC2LI_LAUNCH(k_mapinc_group, dim3(n_tasks), dim3(1024), lds, st, tasks);
     TC2LI_LAUNCH(k_mapinc_apply, dim3(kMapIncMax / 128, n_tasks), dim3(128), 0, st, tasks);
 }

@@ -83,7 +83,7 @@ struct FuseWorkspace {
     DevBuf<uint16_t> items;
     std::mutex mu;
 };
-FuseWorkspace& fws() { static FuseWorkspace w; return w; }
+FuseWorkspace& fws() { return shutdown_owned<FuseWorkspace>(); }
 
 struct Workspace {
     std::vector<std::unique_ptr<KfBuffers>> kf;  // [0] = current keyframe, [1 + j] = neighbour j
@@ -93,7 +93,7 @@ struct Workspace {
     DevBuf<uint8_t> d_ok;
     std::mutex mu;
 };
-Workspace& ws() { static Workspace w; return w; }
+Workspace& ws() { return shutdown_owned<Workspace>(); }
 
 int check_view(const tc2li_keyframe_view* v, const char* what) {
     if (!v || v->n < 0 || v->n_nodes < 0 || (v->n > 0 && (!v->keys || !v->descriptors || !v->u_right || !v->depth || !v->has_point)) ||

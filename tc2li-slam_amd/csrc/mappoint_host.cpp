@@ -15,7 +15,7 @@ struct Workspace {
     DevBuf<float> d_centres, d_pos, d_ref, d_scale, d_normals, d_min, d_max;
     std::mutex mu;
 };
-Workspace& ws() { static Workspace w; return w; }
+Workspace& ws() { return shutdown_owned<Workspace>(); }
 }  // namespace
 
 extern "C" int tc2li_map_points_refresh(int n_points, const int32_t* obs_offsets, const uint8_t* obs_descriptors, const float* obs_centres,

@@ -273,12 +273,7 @@ void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double
     if (nprobs <= 0) return;
     // the correspondences of a frame in LDS when they fit: up to 1024 leave room for two workgroups per CU, up to 2048 for one
     const int cap = max_edges <= 1024 ? 1024 : 2048;
-    if (max_edges <= 2048) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_pose_optimization_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 2048 * kPoLdsPerEdge + 64);
-            attr_set = true;
-        }
+    if (max_edges <= 2048 && ensure_dynamic_lds((const void*)k_pose_optimization_lds, 2048 * kPoLdsPerEdge + 64)) {
         TC2LI_LAUNCH(k_pose_optimization_lds, dim3(nprobs), dim3(kPoThreads), (size_t)cap * kPoLdsPerEdge + 64, st, probs, Xw, edges, cam, poses7, outlier,
                      inliers, cap);
     } else {

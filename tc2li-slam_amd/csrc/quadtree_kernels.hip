@@ -1005,13 +1005,10 @@ void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint3
     if (n_jobs <= 0) return;
     const QuadJob* j0 = jobs + first_job;
     int after_sorted = 0;
+    // the two wider classes need more dynamic LDS than a kernel gets by default; should the runtime refuse, every job takes the global-memory form
+    if (threads <= 0 && !(ensure_dynamic_lds(reinterpret_cast<const void*>(k_quadtree_sorted<1>), (int)quad_class_lds(1)) &&
+                          ensure_dynamic_lds(reinterpret_cast<const void*>(k_quadtree_sorted<2>), (int)quad_class_lds(2)))) threads = 256;
     if (threads <= 0) {
-        static const bool attr = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_sorted<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_class_lds(1));
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_sorted<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_class_lds(2));
-            return true;
-        }();
-        (void)attr;
         // fewer jobs than CUs (a stereo pair is 16): every job in the widest class, one launch instead of three in a row
         const int first_class = threads < 0 ? min(-threads - 1, kQuadClasses - 1) : (n_jobs <= 256 ? 2 : 0);  // threads < 0: the tests choose
         if (first_class <= 0)

@@ -162,6 +162,33 @@ def test_batch_with_a_large_window(pkg, synthetic):
         assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2])
 
 
+def test_mixed_batch_falls_back_per_group(pkg, synthetic):
+    """A batch of several lock-step groups in which ONE window lies outside the batched LiDAR kernels' range (8 keyframes in its LiDAR
+    window, more than the 7 the lock-step kernels take): only that window's group goes through the one-window path -- every window of
+    the batch, in the declined group and in the others, equals its one-window call bit for bit (the groups that had
+    succeeded were optimised a second time, from their optimised state)."""
+    windows, singles = [], []
+    for seed in range(9):
+        w = synthetic.ba_window(50 + seed, n_opt=8, n_fix=6, n_points=500, pose_noise=(0.1, 0.01))
+        e = pkg.pack_ba_edges(w["edges"])
+        last = len(w["poses"]) - 1
+        win = list(range(last, last - (8 if seed == 4 else 4), -1))
+        clouds = synthetic.ba_window_clouds(w, win, n_points=1200)
+        windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=e, win_pose=win, clouds=clouds, Tcl7=synthetic.TCL7, weight=1.0))
+        singles.append(pkg.capi.local_lv_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], win, clouds, synthetic.TCL7, 1.0))
+        cam = w["cam"]
+    assert all(s[4].iterations > 0 and s[4].final_chi2 < s[4].initial_chi2 for s in singles)
+    batch = pkg.capi.BaBatch(windows, cam)
+    for _ in range(2):  # the second call starts from the same inputs: BaBatch.run resets them
+        assert batch.run(max_concurrency=8) == len(windows)
+        for i, s in enumerate(singles):
+            r = batch.result(i)
+            assert batch.results[i] == s[4].iterations and r[4].trials == s[4].trials, i
+            assert r[4].initial_chi2 == s[4].initial_chi2 and r[4].final_chi2 == s[4].final_chi2, i
+            assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2]) and np.array_equal(r[3], s[3]), i
+            assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual, i
+
+
 def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic):
     """The windows bench.py times (12 free + 20 fixed keyframes, 3000 points, LiDAR edge over 6 keyframes x 3000 points), through the
     lock-step batch entry, against the oracle directly: same iterations and LM trials, same planes, poses <= 1e-4 relative."""
