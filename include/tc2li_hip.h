@@ -211,6 +211,15 @@ int tc2li_lidar_map_build(tc2li_lidar_map* map, const tc2li_point* world_points,
 /* ikdtree.Add_Points(points, false): appends without down-sampling.  Returns the map size. */
 int tc2li_lidar_map_add(tc2li_lidar_map* map, const tc2li_point* world_points, int n);
 int tc2li_lidar_map_size(const tc2li_lidar_map* map);
+/* Measurement / test hooks of the map's spatial index (no reference counterpart: ikd-Tree keeps its own counters, ikd_Tree.h:117-123).
+ * tc2li_lidar_map_stats: out[0] points, [1] places of the grid (entries + the rows' room), [2] grid builds so far, [3] in-place grid updates
+ * so far (map_incremental calls that merged their points into the existing rows, KD_TREE::Add_Points' own way, ikd_Tree.cpp:478-584),
+ * [4] tombstones (upper bound), [5] cells; capacity >= 6, returns 6.
+ * tc2li_lidar_map_grid_download: walks the grid on the host, checks it (every live entry stands in the cell its coordinates name and names
+ * an existing point, rows stay inside their room, unused room holds no live entry: TC2LI_ERR_INVALID with the finding otherwise) and
+ * returns the number of live entries, the first `capacity` of them as (cell, point index) in grid order. */
+int tc2li_lidar_map_stats(const tc2li_lidar_map* map, int32_t* out, int capacity);
+int tc2li_lidar_map_grid_download(const tc2li_lidar_map* map, int32_t* cells, int32_t* indices, int capacity);
 
 /* feature_extraction() (LidarFrontEnd.cpp:999-1073) for one down-sampled scan.  Per input point i (arrays of n, any
  * may be NULL): feats_down_world[i], point_selected[i], normvec[i] (plane normal, intensity = pd2), the up-to-5

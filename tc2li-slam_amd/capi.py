@@ -426,6 +426,25 @@ class LidarMap:
         _check(lib().tc2li_lidar_map_download(self._h, out.ctypes.data, len(out)))
         return out[:n].copy()
 
+    def stats(self):
+        """tc2li_lidar_map_stats -> dict(points, slots, grid_builds, grid_updates, tombstones, cells)."""
+        out = (C.c_int32 * 6)()
+        f = lib().tc2li_lidar_map_stats
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _check(f(self._h, out, 6))
+        return dict(zip(("points", "slots", "grid_builds", "grid_updates", "tombstones", "cells"), [int(v) for v in out]))
+
+    def grid(self):
+        """tc2li_lidar_map_grid_download: the grid walked and checked on the host -> (cells [n], point indices [n]) of its live entries."""
+        n = self.size()
+        cells, idx = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        f = lib().tc2li_lidar_map_grid_download
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        live = _check(f(self._h, cells.ctypes.data, idx.ctypes.data, len(cells)))
+        if live != n:
+            raise Tc2liError(-2, "the grid holds %d live entries for %d points" % (live, n))
+        return cells[:n].copy(), idx[:n].copy()
+
     def Delete_Point_Boxes(self, boxes6, stream=0):
         """boxes6: [n, 6] = min x y z, max x y z; returns the number of removed points."""
         b = np.ascontiguousarray(boxes6, np.float32).reshape(-1, 6)

@@ -29,9 +29,20 @@ struct tc2li_lidar_map {
     DevBuf<int> d_remap;                    // old index -> new index of the last compaction (-1: deleted)
     bool have_remap = false;                // d_remap / d_sorted describe the map before the compaction that was just committed
     int remap_n_old = 0, remap_n_kept = 0;
-    DevBuf<int> d_bucket_counts, d_bucket_start, d_tile_sums;
+    DevBuf<int> d_bucket_counts, d_bucket_start, d_tile_sums;  // d_bucket_start: the plain prefix over the cells (work array of a build)
+    DevBuf<int> d_row_start;          // the grid's row-wise starts (MapGrid::bucket_start)
     DevBuf<MapIncTask> d_inc_task;    // batches of one map: Build / Add_Points / Delete_Point_Boxes
     DevBuf<MapGridTask> d_grid_task;
+    // in-place insertion (k_map_ins_*): work arrays; grid_valid: `grid` describes the points as they are numbered now
+    DevBuf<unsigned long long> d_ins_keys;
+    DevBuf<int> d_ins_rows;
+    bool grid_valid = false;
+    bool counts_dirty = false;        // a build was queued and has not been seen to complete: the cell counters may not be zero (grid_prepare clears them)
+    // how the next build finds the points that were there before: 0 from the point list (all cells' counters contended), 1 in the old
+    // grid's order through d_remap (after a compaction), 2 in the old grid's order as it stands (its entries already carry the new indices)
+    int rebuild_mode = 0;
+    int tombstones = 0;               // entries of the grid that mark deleted points (an upper bound: a rewritten row drops its own)
+    int n_grid_builds = 0, n_grid_updates = 0;  // tc2li_lidar_map_stats
     int n = 0, n_cells = 0;
     // bumped whenever the points are renumbered or replaced (Build / Add_Points / compaction): tc2li_lidar_map_incremental replays neighbour
     // INDICES found by an earlier feature extraction and refuses when the map has changed in between
@@ -87,6 +98,9 @@ struct tc2li_lidar {
     DevBuf<PointXYZINormal> d_appended;
     DevBuf<MapIncTask> d_inc_tasks;
     DevBuf<MapGridTask> d_grid_tasks;
+    DevBuf<MapInsTask> d_ins_tasks;   // in-place grid insertion of a batch (k_map_ins_*): tasks, [2] result words per task
+    DevBuf<int> d_ins_out;
+    PinnedBuf<int> h_ins_out;
     PinnedBuf<int> h_mapinc_out;
     std::vector<int> last_down;  // per slot: down-sampled points of the last feature extraction
     std::vector<std::pair<const tc2li_lidar_map*, uint64_t>> last_map;  // per slot: the map searched and its generation then
@@ -210,25 +224,33 @@ int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_bod
 inline float dec_enc(int i) { const int v = i >= 0 ? i : i ^ 0x7fffffff; float f; memcpy(&f, &v, 4); return f; }
 
 // Geometry of the dense grid over the map's bounding box: 1 m cells unless that would need more than 4M of them.
+// A margin of cells around the box (8 along x and y, 2 along z, when that stays within the 4M): the points a moving sensor adds beyond
+// the present box find cells waiting, so the grid is updated in place for some scans before the box has to grow (a rebuild).
 MapGrid grid_geometry(const tc2li_lidar_map* m, float* cell_out) {
     MapGrid g{};
     float cell = 1.0f;
+    static const bool kNoMargin = getenv("TC2LI_MAP_NO_MARGIN") != nullptr;  // tests: the box as tight as rounds 1-3 had it
     for (;;) {
         const float inv = 1.0f / cell;
-        long long cells = 1;
+        long long cells = 1, cells_m = 1;
         int o[3], d[3];
+        const int margin[3] = {8, 8, 2};
         for (int a = 0; a < 3; ++a) {
             o[a] = m->n ? (int)std::floor(m->lo[a] * inv) : 0;
             d[a] = m->n ? (int)std::floor(m->hi[a] * inv) - o[a] + 1 : 1;
             cells *= d[a];
+            cells_m *= d[a] + 2 * margin[a];
         }
         if (cells <= (4ll << 20)) {
+            if (m->n && cells_m <= (4ll << 20) && !kNoMargin)
+                for (int a = 0; a < 3; ++a) { o[a] -= margin[a]; d[a] += 2 * margin[a]; }
             g.x0 = o[0]; g.y0 = o[1]; g.z0 = o[2]; g.nx = d[0]; g.ny = d[1]; g.nz = d[2];
             g.inv_cell = inv; g.cell = cell;
             break;
         }
         cell *= 1.5f;
     }
+    g.row_stride = g.nx + 1;
     *cell_out = cell;
     return g;
 }
@@ -238,44 +260,67 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t, hipStream_t st) {
     float cell;
     MapGrid g = grid_geometry(m, &cell);
     m->cell = cell;
-    const int nc = g.nx * g.ny * g.nz;
+    const int nc = g.nx * g.ny * g.nz, rows = g.ny * g.nz;
     if (nc > m->n_cells) {
         TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nc + nc / 2));
         TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, ((size_t)nc + nc / 2) * sizeof(int), st));  // zero outside a build (map_kernels.hip)
         TC2LI_HIP_CHECK(m->d_bucket_start.alloc((size_t)nc + nc / 2 + 1));
         TC2LI_HIP_CHECK(m->d_tile_sums.alloc((size_t)(nc + nc / 2) / 4096 + 2));
         m->n_cells = nc + nc / 2;
+        m->counts_dirty = false;
     }
-    // after a compaction the kept points are taken from the old grid's order (cell-coherent, see MapGridTask): the new order goes to the other buffer
-    const bool merge = m->have_remap && m->d_sorted.p && m->remap_n_old > 0;
-    DevBuf<float4>& target = merge ? m->d_sorted_alt : m->d_sorted;
-    TC2LI_HIP_CHECK(target.ensure(std::max(m->n, 1)));
-    g.points = m->d_points.p; g.pts = target.p; g.bucket_start = m->d_bucket_start.p; g.n_points = m->n;
-    t->g = g; t->counts = m->d_bucket_counts.p; t->start = m->d_bucket_start.p; t->sorted = target.p;
-    t->tile_sums = m->d_tile_sums.p; t->n_cells = nc;
-    t->old_sorted = merge ? m->d_sorted.p : nullptr; t->remap = merge ? m->d_remap.p : nullptr;
-    t->n_old = merge ? m->remap_n_old : 0; t->n_kept = merge ? m->remap_n_kept : 0;
-    if (merge) { std::swap(m->d_sorted.p, m->d_sorted_alt.p); std::swap(m->d_sorted.n, m->d_sorted_alt.n); }  // d_sorted = the new order from here on
+    if (m->counts_dirty) {  // a build that did not complete (a HIP error between its count and its scatter) leaves counters raised
+        TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, (size_t)m->n_cells * sizeof(int), st));
+        m->counts_dirty = false;
+    }
+    // a row gets room for as many entries again as it has, + row_slack
+    const int row_slack = (int)std::max(4ll, std::min(32ll, 4ll * m->n / std::max(rows, 1)));
+    const long long n_slots = 2ll * m->n + (long long)row_slack * rows;
+    if (n_slots > 0x7fffffffll - 1024 || (long long)rows * g.row_stride + 1 > 0x7fffffffll) { set_error("LiDAR map: %d points in %d rows do not fit the grid's 31-bit places", m->n, rows); return TC2LI_ERR_CAPACITY; }
+    TC2LI_HIP_CHECK(m->d_row_start.ensure((size_t)rows * g.row_stride + 1));
+    // the points that were in the map before are taken from the old grid's order (cell-coherent, see MapGridTask): the new grid goes to the other buffer
+    const bool from_old = m->rebuild_mode != 0 && m->grid_valid && m->d_sorted.p && m->grid.n_slots > 0;
+    DevBuf<float4>& target = from_old ? m->d_sorted_alt : m->d_sorted;
+    TC2LI_HIP_CHECK(target.ensure((size_t)std::max(n_slots, 1ll)));
+    TC2LI_HIP_CHECK(hipMemsetAsync(target.p, 0xff, (size_t)n_slots * sizeof(float4), st));  // all tombstones (index -1): the build fills in the entries
+    const int old_slots = m->grid.n_slots;
+    g.points = m->d_points.p; g.pts = target.p; g.bucket_start = m->d_row_start.p; g.n_points = m->n; g.n_slots = (int)n_slots;
+    t->g = g; t->counts = m->d_bucket_counts.p; t->start = m->d_bucket_start.p; t->row_start = m->d_row_start.p; t->sorted = target.p;
+    t->tile_sums = m->d_tile_sums.p; t->n_cells = nc; t->row_slack = row_slack;
+    t->old_sorted = from_old ? m->d_sorted.p : nullptr;
+    t->remap = from_old && m->rebuild_mode == 1 && m->have_remap ? m->d_remap.p : nullptr;
+    t->n_old = from_old ? old_slots : 0; t->n_kept = from_old ? m->remap_n_kept : 0;
+    if (from_old && m->rebuild_mode == 1 && !m->have_remap) { set_error("LiDAR map: compaction without its index map"); return TC2LI_ERR_INVALID; }
+    if (from_old) { std::swap(m->d_sorted.p, m->d_sorted_alt.p); std::swap(m->d_sorted.n, m->d_sorted_alt.n); }  // d_sorted = the new grid from here on
     m->have_remap = false;
+    m->rebuild_mode = 0;
     return TC2LI_OK;
 }
 
-// (Re)builds the grids of a set of maps with one launch per phase; tasks go up through d_tasks.  No synchronisation.
+// (Re)builds the grids of a set of maps with one launch per phase; tasks go up through d_tasks; waits for the stream (the maps' counters
+// are known to be zero again when it returns).
 int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>& d_tasks, hipStream_t st) {
     if (n_maps <= 0) return TC2LI_OK;
     std::vector<MapGridTask> tasks(n_maps);
-    int max_points = 0, max_cells = 0;
+    int max_points = 0, max_cells = 0, max_row_entries = 0;
     for (int i = 0; i < n_maps; ++i) {
+        maps[i]->grid_valid = maps[i]->grid_valid && maps[i]->rebuild_mode != 0;  // mode 0 does not read the old grid
         const int rc = grid_prepare(maps[i], &tasks[i], st);
-        if (rc != TC2LI_OK) return rc;
+        if (rc != TC2LI_OK) { maps[i]->grid_valid = false; return rc; }
         max_points = std::max(max_points, tasks[i].n_old + (maps[i]->n - tasks[i].n_kept));
         max_cells = std::max(max_cells, tasks[i].n_cells);
+        max_row_entries = std::max(max_row_entries, tasks[i].g.ny * tasks[i].g.nz * tasks[i].g.row_stride + 1);
     }
+    for (int i = 0; i < n_maps; ++i) { maps[i]->counts_dirty = true; maps[i]->grid_valid = false; }
     TC2LI_HIP_CHECK(d_tasks.ensure(n_maps));
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_tasks.p, tasks.data(), n_maps * sizeof(MapGridTask), hipMemcpyHostToDevice, st));
-    launch_map_grid_build(d_tasks.p, n_maps, max_points, max_cells, st);
+    launch_map_grid_build(d_tasks.p, n_maps, max_points, max_cells, max_row_entries, st);
     TC2LI_HIP_CHECK(hipGetLastError());
-    for (int i = 0; i < n_maps; ++i) maps[i]->grid = tasks[i].g;
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    for (int i = 0; i < n_maps; ++i) {
+        tc2li_lidar_map* m = maps[i];
+        m->grid = tasks[i].g; m->grid_valid = true; m->counts_dirty = false; m->tombstones = 0; ++m->n_grid_builds;
+    }
     return TC2LI_OK;
 }
 int rebuild_grid(tc2li_lidar_map* m, hipStream_t st) { return rebuild_grids(&m, 1, m->d_grid_task, st); }
@@ -306,6 +351,8 @@ void commit_compaction(tc2li_lidar_map* m, const int* out, bool has_inc) {
     const int kept = out[4], appended = has_inc ? out[5] : 0, noneed = has_inc ? out[2] : 0;
     m->have_remap = m->d_remap.n >= (size_t)m->n && m->n > 0;  // the compaction wrote d_remap for the m->n points the map had
     m->remap_n_old = m->n; m->remap_n_kept = kept;
+    m->rebuild_mode = m->have_remap ? 1 : 0;  // the callers that maintained the grid in place change it to 2 (or update the grid themselves)
+    m->tombstones += m->n - kept;
     const int added = appended + noneed;
     if (added > 0)
         for (int a = 0; a < 3; ++a) {
@@ -982,10 +1029,58 @@ static int map_append(tc2li_lidar_map* m, const tc2li_point* pts, int n, bool re
     }
     m->n = old + n;
     ++m->generation;
+    m->rebuild_mode = 0; m->have_remap = false;  // Build / Add_Points from the caller's list: the grid is made from the points
     int rc = rebuild_grid(m, ps);
     if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipStreamSynchronize(ps));
     return m->n;
+}
+int tc2li_lidar_map_stats(const tc2li_lidar_map* m, int32_t* out, int capacity) {
+    if (!m || !out || capacity < 6) { set_error("tc2li_lidar_map_stats: invalid argument"); return TC2LI_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    out[0] = m->n; out[1] = m->grid.n_slots; out[2] = m->n_grid_builds; out[3] = m->n_grid_updates; out[4] = m->tombstones;
+    out[5] = m->grid.nx * m->grid.ny * m->grid.nz;
+    return 6;
+}
+int tc2li_lidar_map_grid_download(const tc2li_lidar_map* m, int32_t* cells, int32_t* indices, int capacity) {
+    if (!m || capacity < 0 || (capacity > 0 && (!cells || !indices))) { set_error("tc2li_lidar_map_grid_download: invalid argument"); return TC2LI_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(m->mu);
+    if (!m->grid_valid) { set_error("tc2li_lidar_map_grid_download: the map has no valid grid"); return TC2LI_ERR_INVALID; }
+    const MapGrid& g = m->grid;
+    const int rows = g.ny * g.nz, stride = g.row_stride;
+    std::vector<float4> ent((size_t)std::max(g.n_slots, 1));
+    std::vector<int> rs((size_t)rows * stride + 1);
+    std::vector<PointXYZINormal> pts((size_t)std::max(m->n, 1));
+    hipStream_t ps = private_stream();
+    TC2LI_HIP_CHECK(copy_sync(ent.data(), g.pts, (size_t)g.n_slots * sizeof(float4), hipMemcpyDeviceToHost, ps));
+    TC2LI_HIP_CHECK(copy_sync(rs.data(), g.bucket_start, rs.size() * sizeof(int), hipMemcpyDeviceToHost, ps));
+    if (m->n) TC2LI_HIP_CHECK(copy_sync(pts.data(), m->d_points.p, (size_t)m->n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
+    auto idx_of = [](const float4& e) { int i; memcpy(&i, &e.w, 4); return i; };
+    int n_live = 0;
+    if (rs[(size_t)rows * stride] != g.n_slots) { set_error("grid: the last start is %d, not n_slots = %d", rs[(size_t)rows * stride], g.n_slots); return TC2LI_ERR_INVALID; }
+    for (int r = 0; r < rows; ++r) {
+        const int* cs = rs.data() + (size_t)r * stride;
+        const int limit = cs[stride];
+        if (cs[0] > cs[g.nx] || cs[g.nx] > limit) { set_error("grid: row %d spans [%d, %d) beyond its room up to %d", r, cs[0], cs[g.nx], limit); return TC2LI_ERR_INVALID; }
+        for (int ix = 0; ix < g.nx; ++ix) {
+            if (cs[ix] > cs[ix + 1]) { set_error("grid: row %d cell %d starts at %d behind the next cell's %d", r, ix, cs[ix], cs[ix + 1]); return TC2LI_ERR_INVALID; }
+            for (int k = cs[ix]; k < cs[ix + 1]; ++k) {
+                const int i = idx_of(ent[k]);
+                if (i < 0) continue;
+                if (i >= m->n) { set_error("grid: entry %d names point %d of %d", k, i, m->n); return TC2LI_ERR_INVALID; }
+                const PointXYZINormal& p = pts[i];
+                const int cx = (int)std::floor(p.x * g.inv_cell) - g.x0, cy = (int)std::floor(p.y * g.inv_cell) - g.y0, cz = (int)std::floor(p.z * g.inv_cell) - g.z0;
+                if (p.x != ent[k].x || p.y != ent[k].y || p.z != ent[k].z || (cz * g.ny + cy) * g.nx + cx != r * g.nx + ix) {
+                    set_error("grid: entry %d (point %d) stands in cell %d, its coordinates say %d", k, i, r * g.nx + ix, (cz * g.ny + cy) * g.nx + cx);
+                    return TC2LI_ERR_INVALID;
+                }
+                if (n_live < capacity) { cells[n_live] = r * g.nx + ix; indices[n_live] = i; }
+                ++n_live;
+            }
+        }
+        for (int k = cs[g.nx]; k < limit; ++k)
+            if (idx_of(ent[k]) >= 0) { set_error("grid: a live entry at %d in the unused room of row %d", k, r); return TC2LI_ERR_INVALID; }
+    }
+    return n_live;
 }
 int tc2li_lidar_map_build(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, true); }
 int tc2li_lidar_map_add(tc2li_lidar_map* m, const tc2li_point* pts, int n) { return map_append(m, pts, n, false); }
@@ -1011,7 +1106,9 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         std::sort(slots_seen.begin(), slots_seen.end());
         if (std::adjacent_find(slots_seen.begin(), slots_seen.end()) != slots_seen.end()) { set_error("tc2li_lidar_map_incremental_batch: a scan slot appears twice in one batch"); return TC2LI_ERR_INVALID; }
     }
-    // the neighbours of a scan slot are indices into the map its feature extraction searched: that map, unchanged since
+    MapLocks locks(maps, n_tasks);
+    // the neighbours of a scan slot are indices into the map its feature extraction searched: that map, unchanged since (read under the
+    // maps' locks: another thread's Build / Add_Points bumps the generation under them)
     for (int i = 0; i < n_tasks; ++i) {
         const auto& lm = L->last_map[scans[i]];
         if (lm.first != maps[i] || lm.second != maps[i]->generation) {
@@ -1020,7 +1117,6 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
             return TC2LI_ERR_INVALID;
         }
     }
-    MapLocks locks(maps, n_tasks);
     const size_t S = L->max_scans, T = L->total;
     if (L->d_inc_tasks.n < S) {
         TC2LI_HIP_CHECK(L->d_cls.alloc(T)); TC2LI_HIP_CHECK(L->d_noneed.alloc(T));
@@ -1028,7 +1124,11 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         TC2LI_HIP_CHECK(L->d_appended.alloc(S * kMapIncMax)); TC2LI_HIP_CHECK(L->d_has_append.alloc(S * kMapIncMax));
         TC2LI_HIP_CHECK(L->d_mapinc_out.alloc(S * kMapIncOut)); TC2LI_HIP_CHECK(L->h_mapinc_out.alloc(S * kMapIncOut));
         TC2LI_HIP_CHECK(L->d_grid_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_inc_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_batch_overflow.alloc(1));
+        TC2LI_HIP_CHECK(L->d_ins_tasks.alloc(S)); TC2LI_HIP_CHECK(L->d_ins_out.alloc(4 * S)); TC2LI_HIP_CHECK(L->h_ins_out.alloc(4 * S));
     }
+    // TC2LI_MAP_ALWAYS_REBUILD=1 (read per call; tests and A/B measurements): every changed grid is rebuilt, as in rounds 1-3
+    const char* always_env = getenv("TC2LI_MAP_ALWAYS_REBUILD");
+    const bool always_rebuild = always_env && atoi(always_env) != 0;
     std::vector<MapIncTask> tasks;
     std::vector<int> which;  // task -> index in the caller's arrays
     tasks.reserve(n_tasks);
@@ -1056,6 +1156,7 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         t.remap = m->d_remap.p; t.holes = m->d_holes.p; t.batch_overflow = L->d_batch_overflow.p;
         memcpy(&t.st, &states[i], sizeof(LidarStateDev));
         t.fs = fs; t.ds = ds; t.n = n; t.n_map = m->n; t.keep_blocks = kb; t.ekf_inited = ekf_inited; t.has_inc = 1;
+        t.fix_grid = m->grid_valid && m->grid.n_slots > 0 && !always_rebuild;
         tasks.push_back(t);
         which.push_back(i);
         max_points = std::max(max_points, n);
@@ -1081,17 +1182,50 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
                 set_error("more than %d points in the down-sampled insertion list of one scan", kMapIncMax);
                 return TC2LI_ERR_CAPACITY;
             }
-        std::vector<tc2li_lidar_map*> changed(nt);
+        // Every map takes over its new point list; its grid is then brought up to date IN PLACE where it was maintained through the
+        // compaction (tombstones for the deleted points, new indices for the moved ones: fix_grid) -- the added points are merged into the
+        // rows they fall into (k_map_ins_*) -- and rebuilt otherwise: no grid yet, more added points than the insertion takes, too many
+        // tombstones, or a row / the box without room (the insertion says so: out[1]).
+        std::vector<tc2li_lidar_map*> rebuild, inserted;
+        std::vector<MapInsTask> ins;
         for (int k = 0; k < nt; ++k) {
             const int* o = L->h_mapinc_out.p + k * kMapIncOut;
-            commit_compaction(maps[which[k]], o, true);
-            changed[k] = maps[which[k]];
+            tc2li_lidar_map* m = maps[which[k]];
+            const bool fixed = tasks[k].fix_grid != 0;
+            commit_compaction(m, o, true);
             if (n_to_add) n_to_add[which[k]] = o[0];
             if (n_no_need) n_no_need[which[k]] = o[2];
+            const int kept = o[4], added = o[5] + o[2];
+            if (fixed) { m->have_remap = false; m->rebuild_mode = 2; }  // the old grid's entries carry the new numbering already
+            if (!fixed || added > kMapInsMax || m->tombstones > std::max(1024, m->n / 8)) { rebuild.push_back(m); continue; }
+            m->grid.n_points = m->n;
+            if (added == 0) { m->rebuild_mode = 0; ++m->n_grid_updates; continue; }
+            TC2LI_HIP_CHECK(m->d_ins_keys.ensure(kMapInsMax)); TC2LI_HIP_CHECK(m->d_ins_rows.ensure(kMapInsMax + 1));
+            MapInsTask t{};
+            t.g = m->grid; t.g.points = m->d_points.p;
+            t.pts = const_cast<float4*>(m->grid.pts); t.row_start = const_cast<int*>(m->grid.bucket_start);
+            t.keys = m->d_ins_keys.p; t.row_list = m->d_ins_rows.p; t.out = L->d_ins_out.p + 4 * ins.size();
+            t.first = kept; t.count = added;
+            ins.push_back(t);
+            inserted.push_back(m);
         }
-        const int rc = rebuild_grids(changed.data(), nt, L->d_grid_tasks, st);
-        if (rc != TC2LI_OK) return rc;
-        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        if (!ins.empty()) {
+            const int ni = (int)ins.size();
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_ins_tasks.p, ins.data(), ni * sizeof(MapInsTask), hipMemcpyHostToDevice, st));
+            launch_map_insert(L->d_ins_tasks.p, ni, st);
+            TC2LI_HIP_CHECK(hipGetLastError());
+            TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_ins_out.p, L->d_ins_out.p, 4 * (size_t)ni * sizeof(int), hipMemcpyDeviceToHost, st));
+            TC2LI_HIP_CHECK(stream_wait_blocking(st));
+            for (int k = 0; k < ni; ++k) {
+                tc2li_lidar_map* m = inserted[k];
+                if (L->h_ins_out.p[4 * k + 1]) { m->rebuild_mode = 0; rebuild.push_back(m); }  // some rows may hold the new points already: from the point list
+                else { m->rebuild_mode = 0; ++m->n_grid_updates; m->tombstones = std::max(0, m->tombstones - L->h_ins_out.p[4 * k + 2]); }
+            }
+        }
+        if (!rebuild.empty()) {
+            const int rc = rebuild_grids(rebuild.data(), (int)rebuild.size(), L->d_grid_tasks, st);
+            if (rc != TC2LI_OK) return rc;
+        }
     }
     if (map_sizes) for (int i = 0; i < n_tasks; ++i) map_sizes[i] = maps[i]->n;
     return n_tasks;
@@ -1200,7 +1334,6 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
     if (!changed.empty()) {
         const int rc = rebuild_grids(changed.data(), (int)changed.size(), ws.d_grid_tasks, st);
         if (rc != TC2LI_OK) return rc;
-        TC2LI_HIP_CHECK(stream_wait_blocking(st));
     }
     return removed_total;
 }

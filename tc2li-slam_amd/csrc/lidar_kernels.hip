@@ -1013,11 +1013,11 @@ __device__ __forceinline__ void scan_run(const float4* __restrict__ pts, int s, 
         CandK c;
         c.d = (qx - m0.x) * (qx - m0.x) + (qy - m0.y) * (qy - m0.y) + (qz - m0.z) * (qz - m0.z);
         c.x = m0.x; c.idx = __float_as_int(m0.w); c.k = k;
-        t.insert(c);
+        if (c.idx >= 0) t.insert(c);  // < 0: a tombstone (deleted point, lidar_device.hpp MapGrid)
         if (k + 1 < e) {
             c.d = (qx - m1.x) * (qx - m1.x) + (qy - m1.y) * (qy - m1.y) + (qz - m1.z) * (qz - m1.z);
             c.x = m1.x; c.idx = __float_as_int(m1.w); c.k = k + 1;
-            t.insert(c);
+            if (c.idx >= 0) t.insert(c);
         }
     }
 }
@@ -1035,7 +1035,7 @@ __device__ __forceinline__ void scan_cube(const MapGrid& g, int cx, int cy, int 
         const int r = l + GROUP * j;
         const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
         const bool ok = r < NR && xa <= xb && iz >= 0 && iz < g.nz && iy >= 0 && iy < g.ny;
-        const int row = (iz * g.ny + iy) * g.nx;
+        const int row = (iz * g.ny + iy) * g.row_stride;
         rs[j] = ok ? g.bucket_start[row + xa] : 0;
         re[j] = ok ? g.bucket_start[row + xb + 1] : 0;
     }
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ bool hard_ring(const MapGrid& g, int cx, int cy, int 
         for (int r = lane; r < W * W; r += 64) {
             const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
             if (iz < 0 || iz >= g.nz || iy < 0 || iy >= g.ny) continue;
-            const int row = (iz * g.ny + iy) * g.nx;
+            const int row = (iz * g.ny + iy) * g.row_stride;
             scan_run(g.pts, g.bucket_start[row + xa], g.bucket_start[row + xb + 1], qx, qy, qz, t);
         }
     merge_top5<64>(t);
@@ -1189,8 +1189,8 @@ __global__ __launch_bounds__(256) void k_knn_hard(const MapGrid* __restrict__ gr
         if (!done && 65 * 65 < np3) done = hard_ring<32>(grid, cx, cy, cz, pw.x, pw.y, pw.z, lane, t);
         if (!done) {  // isolated query: the whole map keeps the result exact
             t.clear();
-            const int per = (grid.n_points + 63) / 64;
-            scan_run(grid.pts, min(lane * per, grid.n_points), min((lane + 1) * per, grid.n_points), pw.x, pw.y, pw.z, t);
+            const int per = (grid.n_slots + 63) / 64;  // every entry, the rows' unused room included (tombstones)
+            scan_run(grid.pts, min(lane * per, grid.n_slots), min((lane + 1) * per, grid.n_slots), pw.x, pw.y, pw.z, t);
             merge_top5<64>(t);
         }
         knn_finish(grid, t, pw, (double)pb.x, (double)pb.y, (double)pb.z, lane == 0, sl.base + q.y, selected, normvec, nearest_idx, nearest_d,

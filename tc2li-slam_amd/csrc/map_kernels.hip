@@ -126,6 +126,7 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
     const MapIncTask& T = tasks[blockIdx.y];
     const int g = blockIdx.x * 128 + threadIdx.x;
     if (g >= T.out[1]) return;
+    if (*T.batch_overflow) return;  // a failing batch marks nothing (k_mapinc_group has raised the word: no map is touched)
     const MapGrid& grid = T.grid;
     const float ds = T.ds;
     const int k0 = T.group_start[g], k1 = T.group_start[g + 1];
@@ -149,14 +150,15 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
         if (xa > xb) return;
         for (int qz = za; qz <= zb; ++qz)
             for (int qy = ya; qy <= yb; ++qy) {
-                const int row = (qz * grid.ny + qy) * grid.nx;
+                const int row = (qz * grid.ny + qy) * grid.row_stride;
                 for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
                     const float4 m = grid.pts[k];
-                    if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w));
+                    if (__float_as_int(m.w) < 0) continue;  // tombstone
+                    if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w), k);
                 }
             }
     };
-    for_each_stored([&](int idx) {
+    for_each_stored([&](int idx, int) {
         const PointXYZINormal q = grid.points[idx];
         const float d = calc_dist3(q.x, q.y, q.z, mid[0], mid[1], mid[2]);
         if (s == 0 || d < e_dist) { e_dist = d; e_best = q; }
@@ -180,7 +182,11 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
         }
     }
     if (!intact) {
-        for_each_stored([&](int idx) { T.deleted[idx] = 1; });
+        // Delete_by_range: the stored points of the voxel leave the map; with the grid maintained in place their entries become tombstones
+        // here (voxels are disjoint boxes: no other thread looks at these entries)
+        float4* const entries = const_cast<float4*>(grid.pts);
+        const int fix = T.fix_grid;
+        for_each_stored([&](int idx, int k) { T.deleted[idx] = 1; if (fix) entries[k].w = __int_as_float(-1); });
         T.appended[g] = cur;
         T.has_append[g] = 1;
     } else {
@@ -281,10 +287,19 @@ __global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__
     if (*T.batch_overflow) return;
     const int H = T.out[4] - T.out[12];
     PointXYZINormal* pts = T.dst;
+    const MapGrid& g = T.grid;
+    float4* const entries = const_cast<float4*>(g.pts);
     for (int h = blockIdx.x * 256 + threadIdx.x; h < H; h += gridDim.x * 256) {
         const int dst = T.holes[h], src = T.holes[T.n_map + h];
-        pts[dst] = pts[src];
+        const PointXYZINormal p = pts[src];
+        pts[dst] = p;
         T.remap[src] = dst;
+        if (T.fix_grid) {  // the moved point's grid entry carries its index: renumber it where it stands (its cell is a few entries)
+            const int c = map_cell(g, p.x, p.y, p.z), row = c / g.nx, ix = c - row * g.nx;
+            const int k0 = g.bucket_start[row * g.row_stride + ix], k1 = g.bucket_start[row * g.row_stride + ix + 1];
+            for (int k = k0; k < k1; ++k)
+                if (__float_as_int(entries[k].w) == src) { entries[k].w = __int_as_float(dst); break; }
+        }
     }
 }
 // dst[kept ...] <- appended representatives, then the no-need points; also the bounding box of what was added
@@ -358,7 +373,9 @@ __device__ __forceinline__ int map_build_item(const MapGridTask& T, int u, float
     const int lane_key = -1 - (int)(threadIdx.x & 63);
     if (u < T.n_old) {
         const float4 e = T.old_sorted[u];
-        const int ni = T.remap[__float_as_int(e.w)];
+        const int oi = __float_as_int(e.w);
+        if (oi < 0) return lane_key;  // tombstone / unused room of a row
+        const int ni = T.remap ? T.remap[oi] : oi;
         if (ni < 0) return lane_key;
         xyzi = make_float4(e.x, e.y, e.z, __int_as_float(ni));
         return map_cell(T.g, e.x, e.y, e.z);
@@ -449,12 +466,178 @@ __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restri
     const RunInfo run = wave_runs(c);
     int first = 0;
     // the run's lanes take consecutive places; the cell's places go from the back, which leaves its counter at zero for the next build
-    if (run.head && c >= 0) first = T.start[c] + atomicSub(&T.counts[c], run.length) - run.length;
+    if (run.head && c >= 0) {
+        const int row = c / T.g.nx;
+        first = T.row_start[row * T.g.row_stride + (c - row * T.g.nx)] + atomicSub(&T.counts[c], run.length) - run.length;
+    }
     first = __shfl(first, run.head_lane, 64);
     if (c >= 0) T.sorted[first + ((int)(threadIdx.x & 63) - run.head_lane)] = q;
 }
 
+// The row-wise starts from the plain exclusive prefix E over the cells: row r begins at 2 E[r nx] + row_slack r (room for as many entries
+// again + row_slack behind every row), cell ix of row r at E[r nx + ix] + E[r nx] + row_slack r; entry nx of a row = the end of its
+// entries, the last entry of the array (row = rows, ix = 0) = n_slots.
+__global__ __launch_bounds__(256) void k_map_row_starts(const MapGridTask* __restrict__ tasks) {
+    const MapGridTask& T = tasks[blockIdx.y];
+    const int stride = T.g.row_stride, rows = T.g.ny * T.g.nz;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx > rows * stride) return;
+    const int row = idx / stride, ix = idx - row * stride;
+    T.row_start[idx] = T.start[row * T.g.nx + ix] + T.start[row * T.g.nx] + T.row_slack * row;
+}
+
+// ---- in-place insertion (round 4): the added points of a step are merged into the rows they fall into, nothing else is touched -----
+// (KD_TREE::Add_Points inserts the points into the existing tree, ikd_Tree.cpp:478-584; rounds 1-3 rebuilt the whole grid instead:
+// 13 GB of traffic per step of 512 maps to add 40 MB of points.)
+// One workgroup per map: (cell, point) keys of the added points, sorted; the rows that receive points.
+__global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restrict__ tasks) {
+    const MapInsTask& T = tasks[blockIdx.x];
+    extern __shared__ unsigned long long s_keys[];  // kMapInsMax
+    __shared__ int s_wave[16], s_base, s_bad;
+    const int tid = threadIdx.x, n = T.count;
+    const MapGrid& g = T.g;
+    if (tid == 0) { s_base = 0; s_bad = n > kMapInsMax || g.n_slots <= 0; }
+    __syncthreads();
+    if (!s_bad) {
+        for (int i = tid; i < n; i += 1024) {
+            const PointXYZINormal p = g.points[T.first + i];
+            const int cx = (int)floorf(p.x * g.inv_cell) - g.x0, cy = (int)floorf(p.y * g.inv_cell) - g.y0, cz = (int)floorf(p.z * g.inv_cell) - g.z0;
+            if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || cz < 0 || cz >= g.nz) { s_bad = 1; s_keys[i] = ~0ull; }  // outside the grid's box
+            else s_keys[i] = (unsigned long long)(unsigned)((cz * g.ny + cy) * g.nx + cx) << 32 | (unsigned)(T.first + i);
+        }
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) { T.out[0] = 0; T.out[1] = 1; T.out[2] = 0; } return; }
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int k = n + tid; k < P; k += 1024) s_keys[k] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long ka = s_keys[lo], kb = s_keys[hi];
+                if ((ka > kb) == up) { s_keys[lo] = kb; s_keys[hi] = ka; }
+            }
+            __syncthreads();
+        }
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        const int k = b0 + tid;
+        bool start = false;
+        if (k < n) {
+            T.keys[k] = s_keys[k];
+            start = k == 0 || (int)(s_keys[k] >> 32) / g.nx != (int)(s_keys[k - 1] >> 32) / g.nx;
+        }
+        int total;
+        const int pos = block_flag_scan(start, s_wave, total);
+        if (start) T.row_list[s_base + pos] = k;
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) { T.row_list[s_base] = n; T.out[0] = s_base; T.out[1] = 0; T.out[2] = 0; }
+}
+// One workgroup per row that receives points (a map's rows dealt over blockIdx.x): the row's entries without their tombstones and the
+// new points, merged by cell (the old entries of a cell first, then the new ones by index), written back from the row's first place;
+// the row's nx + 1 starts follow.  A row without room, or with more entries than the merge holds, raises out[1]: the host rebuilds that
+// map's grid (rows written before stay valid or not -- the rebuild starts from the points).
+__global__ __launch_bounds__(256) void k_map_ins_rows(const MapInsTask* __restrict__ tasks) {
+    const MapInsTask& T = tasks[blockIdx.y];
+    __shared__ float4 s_ent[kMapRowMax];
+    __shared__ int s_rank[kMapRowMax + 1];
+    __shared__ int s_wave[4];
+    if (T.out[1]) return;
+    const MapGrid& g = T.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_rows = T.out[0], nx = g.nx;
+    for (int rr = blockIdx.x; rr < n_rows; rr += gridDim.x) {
+        const int k0 = T.row_list[rr], k1 = T.row_list[rr + 1], N = k1 - k0;
+        const int row = (int)(T.keys[k0] >> 32) / nx;
+        int* const cs = T.row_start + (size_t)row * g.row_stride;
+        const int b = cs[0], e = cs[nx], limit = cs[g.row_stride], M = e - b;
+        if (M + N > kMapRowMax) { if (tid == 0) atomicExch(&T.out[1], 1); continue; }  // uniform
+        for (int j = tid; j < M; j += 256) s_ent[j] = T.pts[b + j];
+        __syncthreads();
+        // s_rank[j] = live entries before j: a thread takes 8 consecutive entries, then a scan over the 256 threads
+        constexpr int PER = kMapRowMax / 256;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { const int j = tid * PER + q; cnt += j < M && __float_as_int(s_ent[j].w) >= 0; }
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int run = incl - cnt;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        const int V = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int j = tid * PER + q;
+            if (j <= M) s_rank[j] = run;
+            run += j < M && __float_as_int(s_ent[j].w) >= 0;
+        }
+        __syncthreads();
+        if (b + V + N > limit) { if (tid == 0) atomicExch(&T.out[1], 1); __syncthreads(); continue; }  // uniform: V is shared
+        // new entries with a cell below `cell` (the keys of the row are sorted)
+        auto new_below = [&](int cell) {
+            int lo = k0, hi = k1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(T.keys[mid] >> 32) < cell) lo = mid + 1; else hi = mid; }
+            return lo - k0;
+        };
+        // places of the new points (reads the row's old starts: before any of them is rewritten)
+        int dst_new[(kMapInsMax + 255) / 256 > 8 ? 8 : (kMapInsMax + 255) / 256];
+        constexpr int NEWPER = sizeof(dst_new) / sizeof(int);
+        bool spill = N > NEWPER * 256;  // more new points in one row than the registers hold: rebuilt (uniform)
+        if (spill) { if (tid == 0) atomicExch(&T.out[1], 1); __syncthreads(); continue; }
+#pragma unroll
+        for (int q = 0; q < NEWPER; ++q) {
+            const int i = tid + 256 * q;
+            dst_new[q] = 0;
+            if (i < N) {
+                const int ix = (int)(T.keys[k0 + i] >> 32) - row * nx;
+                dst_new[q] = b + i + s_rank[cs[ix + 1] - b];  // live old entries of the cells up to ix stand before it
+            }
+        }
+        if (tid == 0 && M > V) atomicAdd(&T.out[2], M - V);  // the tombstones this rewrite drops
+        // the row's new starts, computed from the old ones
+        const int n_cs = nx + 1;
+        __syncthreads();
+        for (int ix0 = 0; ix0 < n_cs; ix0 += 256) {
+            const int ix = ix0 + tid;
+            int v = 0;
+            if (ix < n_cs) v = ix == nx ? b + V + N : b + s_rank[cs[ix] - b] + new_below(row * nx + ix);
+            // every thread has read the old starts of this chunk and of its new points before anyone writes: the chunks are disjoint,
+            // and dst_new above is complete
+            if (ix < n_cs) cs[ix] = v;
+        }
+        // the entries
+        for (int j = tid; j < M; j += 256) {
+            const float4 en = s_ent[j];
+            if (__float_as_int(en.w) < 0) continue;
+            const int cell = row * nx + ((int)floorf(en.x * g.inv_cell) - g.x0);
+            T.pts[b + s_rank[j] + new_below(cell)] = en;
+        }
+#pragma unroll
+        for (int q = 0; q < NEWPER; ++q) {
+            const int i = tid + 256 * q;
+            if (i < N) {
+                const int idx = (int)(unsigned)(T.keys[k0 + i] & 0xffffffffull);
+                const PointXYZINormal p = g.points[idx];
+                T.pts[dst_new[q]] = make_float4(p.x, p.y, p.z, __int_as_float(idx));
+            }
+        }
+        for (int j = b + V + N + tid; j < e; j += 256) T.pts[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // a row that shrank: tombstones behind it
+        __syncthreads();
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------------------------
+void launch_map_insert(const MapInsTask* tasks, int n_tasks, hipStream_t st) {
+    if (!n_tasks) return;
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(k_map_ins_sort), kMapInsMax * (int)sizeof(unsigned long long));
+    TC2LI_LAUNCH(k_map_ins_sort, dim3(n_tasks), dim3(1024), kMapInsMax * sizeof(unsigned long long), st, tasks);
+    TC2LI_LAUNCH(k_map_ins_rows, dim3(64, n_tasks), dim3(256), 0, st, tasks);
+}
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st) {
     if (!n_tasks || !max_points) return;
     TC2LI_LAUNCH(k_mapinc_classify, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
@@ -475,7 +658,7 @@ void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points
     if (nb) TC2LI_LAUNCH(k_map_fill, dim3(std::min(nb * 4, 64), n_tasks), dim3(256), 0, st, tasks);
     TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);
 }
-void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, int max_cells, hipStream_t st) {
+void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, int max_cells, int max_row_entries, hipStream_t st) {
     const int max_points = max_work;
     if (!n_tasks) return;
     const int tiles = (max_cells + kScanTile - 1) / kScanTile;
@@ -483,6 +666,7 @@ void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work, 
     TC2LI_LAUNCH(k_map_scan_tiles, dim3(tiles, n_tasks), dim3(1024), 0, st, tasks);
     TC2LI_LAUNCH(k_map_scan_tops, dim3(n_tasks), dim3(1024), 0, st, tasks);
     TC2LI_LAUNCH(k_map_scan_cells, dim3(tiles, n_tasks), dim3(1024), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_row_starts, dim3((max_row_entries + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
     if (max_points) TC2LI_LAUNCH(k_map_scatter, dim3((max_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
 }
 

@@ -45,6 +45,77 @@ def test_map_incremental_sequence(pkg, oracle, setup, ekf, fs):
     assert m.size() > len(world0) or fs > 0.5  # a coarser voxel merges stored points
 
 
+def _grid_is_sound(m):
+    """The grid walked on the host (tc2li_lidar_map_grid_download checks every live entry against the cell its coordinates name, the rows'
+    room and the tombstones): every point of the map is there exactly once."""
+    cells, idx = m.grid()
+    assert np.array_equal(np.sort(idx), np.arange(m.size()))
+    return cells, idx
+
+
+def test_in_place_grid_update_equals_rebuild(pkg, oracle, setup, monkeypatch):
+    """VERDICT r3 item 3: map_incremental merges the added points into the rows of the existing grid (KD_TREE::Add_Points inserts into the
+    existing tree, ikd_Tree.cpp:478-584) instead of rebuilding it.  Two maps take the same twelve insertions, one in place, one with
+    TC2LI_MAP_ALWAYS_REBUILD=1 (rounds 1-3): after every step the point lists are equal element for element, both grids are sound cell
+    by cell, a search of either map gives the same neighbours / distances / planes, and both equal the oracle's map."""
+    fe, downs, states, world0 = setup
+    a, b = pkg.LidarMap(), pkg.LidarMap()
+    a.Build(world0); b.Build(world0)
+    builds0 = a.stats()["grid_builds"]
+    ref = world0.copy()
+    rng = np.random.default_rng(5)
+    for step in range(12):
+        f = 1 + step % 3
+        upd = states[f].copy(); upd[9:12] += rng.normal(0, 0.15, 3)  # the scans land a little elsewhere every time: new voxels, replaced points
+        monkeypatch.delenv("TC2LI_MAP_ALWAYS_REBUILD", raising=False)
+        ra = fe.feature_extraction(a, downs[f], states[f])
+        na = a.map_incremental(fe, 0, upd, ekf_inited=True, filter_size_map_min=0.5)
+        monkeypatch.setenv("TC2LI_MAP_ALWAYS_REBUILD", "1")
+        rb = fe.feature_extraction(b, downs[f], states[f])
+        nb = b.map_incremental(fe, 0, upd, ekf_inited=True, filter_size_map_min=0.5)
+        assert na == nb
+        for k in ("selected", "sqdist", "nearest", "normvec"):
+            if k in ra:
+                assert np.array_equal(ra[k], rb[k]), (step, k)
+        ref, wa, wn = oracle.map_incremental(ref, downs[f], states[f], upd, ekf_inited=True, filter_size_map_min=0.5)
+        pa, pb = a.points(), b.points()
+        assert np.array_equal(pa, pb) and np.array_equal(canon(pa), canon(ref)) and (na[1], na[2]) == (wa, wn), step
+        _grid_is_sound(a); _grid_is_sound(b)
+    sa, sb = a.stats(), b.stats()
+    assert sb["grid_builds"] == builds0 + 12 and sb["grid_updates"] == 0
+    assert sa["grid_updates"] >= 10 and sa["grid_builds"] + sa["grid_updates"] == builds0 + 12, sa  # a rebuild only where the grid said it had to
+
+
+def test_in_place_grid_update_falls_back_to_a_rebuild(pkg, oracle, setup):
+    """What the in-place insertion cannot take ends in a rebuild, with the oracle's map either way: a point outside the grid's box (beyond its
+    margin of 8 cells), a row that receives more points than it has room for, a row longer than the merge holds."""
+    fe, downs, states, world0 = setup
+    ident = pkg.pack_lidar_state(np.eye(3), np.zeros(3))
+    def P(xyz):
+        a = np.zeros(len(xyz), pkg.capi.POINT_DTYPE); a["x"], a["y"], a["z"] = np.array(xyz, np.float32).T; a["pad0"] = 1; return a
+    base = P([[10.26, 10.24, 10.25], [20.1, 20.1, 20.1], [30.05, 30.05, 30.05], [30.45, 30.4, 30.45], [30.3, 30.2, 30.2],
+              [40.2, 40.2, 40.2], [41, 41, 41], [42, 42, 42], [43, 43, 43], [44, 44, 44], [45, 45, 45]])
+    inside = P([[5.3, 5.3, 9.3], [10.1, 10.1, 10.1], [47.3, 46.2, 45.1]])  # within the box's margin (8 cells along x and y, 2 along z)
+    outside = P([[5.3, 5.3, 5.3], [-40.2, 10.1, 10.1]])
+    row = P(np.stack([np.linspace(10.3, 44.8, 70), np.full(70, 12.3), np.full(70, 12.3)], 1))          # 70 new voxels along one row of the grid
+    long_base = P(np.stack([0.05 + 0.1 * np.arange(2100), np.full(2100, 12.3), np.full(2100, 12.3)], 1))  # 2100 entries in one row of the grid
+    one = P([[50.26, 12.8, 12.8]])
+    for base, scan, in_place in ((base, inside, True), (base, outside, False), (base, row, False), (long_base, one, False)):
+        m = pkg.LidarMap(); m.Build(base)
+        builds0 = m.stats()["grid_builds"]
+        fe.feature_extraction(m, scan, ident)
+        n, na, nn = m.map_incremental(fe, 0, ident, ekf_inited=False)
+        want, wa, wn = oracle.map_incremental(base, scan, ident, ident, ekf_inited=False)
+        assert (na, nn) == (wa, wn) and n == len(want) and np.array_equal(canon(m.points()), canon(want))
+        _grid_is_sound(m)
+        st = m.stats()
+        assert (st["grid_updates"], st["grid_builds"] - builds0) == ((1, 0) if in_place else (0, 1)), (st, len(scan))
+        # and the map stays searchable: the same answers as a map built afresh from its points
+        fresh = pkg.LidarMap(); fresh.Build(m.points())
+        x, y = fe.feature_extraction(m, downs[1][:2000], ident), fe.feature_extraction(fresh, downs[1][:2000], ident)
+        assert np.array_equal(x["selected"], y["selected"]) and np.array_equal(x["sqdist"], y["sqdist"])
+
+
 def test_insertion_rule_inside_one_voxel(pkg, oracle, setup):
     """Hand-made cases: empty voxel, one stored point closer / farther than the candidate, several stored points, two
     candidates for one voxel (the second sees the first)."""
