@@ -40,20 +40,23 @@ struct PreprocessParams { int32_t point_filter_num; float time_unit_scale; doubl
 
 // Dense uniform grid over the map's bounding box (replaces the ikd-Tree as the spatial index; same 5 nearest
 // neighbours).  Cell (ix, iy, iz) relative to (x0, y0, z0) has linear index (iz * ny + iy) * nx + ix.
-// Layout since round 4 (in-place insertion, map_kernels.hip "k_map_ins_*"): the cell-sorted copy is cut into ROWS (the nx cells of one
-// (iy, iz)); a row's entries are contiguous and ordered by cell, rows follow each other with SLACK between them (a build leaves every row
-// room for as many entries again + row_slack), so points are added by rewriting the rows they fall into.  bucket_start has nx + 1
-// entries per row: [row * row_stride + ix] = first entry of cell ix, [row * row_stride + nx] = end of the row's entries; the next
-// row's first entry ([(row + 1) * row_stride]; n_slots behind the last row) is where the row's room ends.  An entry whose index (w) is
-// negative is a TOMBSTONE (a deleted point's place, or unused room): every reader skips it.
+// Layout since round 4 (in-place insertion, map_kernels.hip "k_map_ins_*"): the cell-sorted copy is cut into SEGMENTS of kMapSegCells
+// consecutive cells of one row (iy, iz) -- segment (row, sx) covers the cells ix = 16 sx .. 16 sx + 15 -- whose entries are contiguous
+// and ordered by cell; segments follow each other with SLACK between them (a build leaves every segment room for as many entries again
+// + seg_slack), so points are added by rewriting the few segments they fall into, whatever the shape of the map (a street's map has
+// rows of thousands of entries).  bucket_start has kMapSegStride = 17 entries per segment: [seg * 17 + j] = first entry of the
+// segment's cell j, [seg * 17 + 16] = end of the segment's entries; the next segment's first entry ([(seg + 1) * 17]; n_slots behind
+// the last segment) is where the segment's room ends.  A run of cells along x is one range per segment it touches.  An entry whose
+// index (w) is negative is a TOMBSTONE (a deleted point's place, or unused room): every reader skips it.
+constexpr int kMapSegCells = 16, kMapSegStride = kMapSegCells + 1;
 struct MapGrid {
     const PointXYZINormal* points;  // the map points in insertion order (what Nearest_Search returns copies of)
     const float4* pts;              // [n_slots] row-wise cell-sorted xyz + original index (as int bits in w; < 0: tombstone)
-    const int32_t* bucket_start;    // [ny * nz * row_stride + 1]
+    const int32_t* bucket_start;    // [ny * nz * nsx * kMapSegStride + 1]
     int32_t x0, y0, z0, nx, ny, nz;
     int32_t n_points;
     float inv_cell, cell;
-    int32_t row_stride, n_slots;    // nx + 1; entries of pts
+    int32_t nsx, n_slots;           // segments per row = ceil(nx / kMapSegCells); entries of pts
 };
 
 void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
@@ -123,10 +126,10 @@ struct MapGridTask {
     MapGrid g;         // geometry + points of the map (g.pts / g.bucket_start = what the build writes)
     int* counts;       // [n_cells], zero outside a build
     int* start;        // [n_cells + 1] exclusive prefix of the counts (work array of the build)
-    int* row_start;    // = g.bucket_start, writable: [rows * row_stride + 1]
+    int* row_start;    // = g.bucket_start, writable: [segments * kMapSegStride + 1]
     float4* sorted;    // = g.pts, writable: [g.n_slots], all tombstones when the build starts
     int* tile_sums;    // [ceil(n_cells / 4096)]
-    int n_cells, row_slack;
+    int n_cells, seg_slack;
     // Points that were in the map before the last compaction are visited in the order of the OLD grid (cell-coherent: neighbouring lanes
     // hit the same or neighbouring counters, one atomic per run of equal cells); what was added since, in insertion order.
     const float4* old_sorted;  // [n_old] the old grid's entries (xyz + old index; tombstones skipped), NULL: no old grid (first build)
@@ -135,13 +138,13 @@ struct MapGridTask {
 };
 // In-place insertion of the points [first, first + count) of a map into its grid (k_map_ins_sort + k_map_ins_rows).
 constexpr int kMapInsMax = 8192;   // added points per map and step the in-place path takes (more: the grid is rebuilt)
-constexpr int kMapRowMax = 2048;   // entries of one row (old + new) the row merge holds in LDS (more: rebuilt)
+constexpr int kMapRowMax = 512;    // entries of one segment (old + new) the merge holds in LDS (more: rebuilt): 16 cells x 32
 struct MapInsTask {
     MapGrid g;
     float4* pts;                   // = g.pts, writable
     int* row_start;                // = g.bucket_start, writable
-    unsigned long long* keys;      // [kMapInsMax] (cell << 32 | point index), sorted
-    int* row_list;                 // [kMapInsMax + 1] first key of every row that receives points
+    unsigned long long* keys;      // [kMapInsMax] ((segment * 16 + cell in the segment) << 32 | point index), sorted
+    int* row_list;                 // [kMapInsMax + 1] first key of every segment that receives points
     int* out;                      // [4]: [0] rows that receive points [1] 1: the grid could not take the points (outside the box, a row without room, ...) [2] tombstones the rewritten rows dropped
     int first, count;
 };
@@ -150,7 +153,7 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work /* max over tasks of n_old + added */, int max_cells,
-                           int max_row_entries /* max over tasks of rows * row_stride + 1 */, hipStream_t st);
+                           int max_row_entries /* max over tasks of segments * kMapSegStride + 1 */, hipStream_t st);
 
 // LidarFrontEndTools::transformPointCloud (SF/src/LidarTypes.cc:42-65) for one cloud: out[i] = (R in[i] + t, intensity kept, the rest as a
 // default-constructed point)

@@ -50,6 +50,11 @@ __device__ __forceinline__ int map_cell(const MapGrid& g, float x, float y, floa
     return (cz * g.ny + cy) * g.nx + cx;
 }
 
+// index into MapGrid::bucket_start of cell cx of row `row` (= iz * ny + iy); + 1 = the end of that cell's entries
+__device__ __forceinline__ int map_start_index(const MapGrid& g, int row, int cx) {
+    return (row * g.nsx + (cx >> 4)) * kMapSegStride + (cx & (kMapSegCells - 1));
+}
+
 // pointBodyToWorld (LidarFrontEnd.cpp:130-139): double arithmetic, float result
 __device__ __forceinline__ PointXYZINormal body_to_world(const PointXYZINormal& pb, const LidarStateDev& st) {
     const double bx = pb.x, by = pb.y, bz = pb.z;

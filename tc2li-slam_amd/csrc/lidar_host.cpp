@@ -250,7 +250,7 @@ MapGrid grid_geometry(const tc2li_lidar_map* m, float* cell_out) {
         }
         cell *= 1.5f;
     }
-    g.row_stride = g.nx + 1;
+    g.nsx = (g.nx + kMapSegCells - 1) / kMapSegCells;
     *cell_out = cell;
     return g;
 }
@@ -260,7 +260,8 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t, hipStream_t st) {
     float cell;
     MapGrid g = grid_geometry(m, &cell);
     m->cell = cell;
-    const int nc = g.nx * g.ny * g.nz, rows = g.ny * g.nz;
+    const int nc = g.nx * g.ny * g.nz;
+    const long long nseg = (long long)g.ny * g.nz * g.nsx;
     if (nc > m->n_cells) {
         TC2LI_HIP_CHECK(m->d_bucket_counts.alloc(nc + nc / 2));
         TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, ((size_t)nc + nc / 2) * sizeof(int), st));  // zero outside a build (map_kernels.hip)
@@ -273,11 +274,14 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t, hipStream_t st) {
         TC2LI_HIP_CHECK(hipMemsetAsync(m->d_bucket_counts.p, 0, (size_t)m->n_cells * sizeof(int), st));
         m->counts_dirty = false;
     }
-    // a row gets room for as many entries again as it has, + row_slack
-    const int row_slack = (int)std::max(4ll, std::min(32ll, 4ll * m->n / std::max(rows, 1)));
-    const long long n_slots = 2ll * m->n + (long long)row_slack * rows;
-    if (n_slots > 0x7fffffffll - 1024 || (long long)rows * g.row_stride + 1 > 0x7fffffffll) { set_error("LiDAR map: %d points in %d rows do not fit the grid's 31-bit places", m->n, rows); return TC2LI_ERR_CAPACITY; }
-    TC2LI_HIP_CHECK(m->d_row_start.ensure((size_t)rows * g.row_stride + 1));
+    // a segment gets room for as many entries again as it has, + seg_slack
+    const int seg_slack = (int)std::max(4ll, std::min(32ll, 4ll * m->n / std::max(nseg, 1ll)));
+    const long long n_slots = 2ll * m->n + (long long)seg_slack * nseg;
+    if (n_slots > 0x7fffffffll - 1024 || nseg * kMapSegStride + 1 > 0x7fffffffll || nseg >= (1ll << 27)) {
+        set_error("LiDAR map: %d points in %lld segments do not fit the grid's 31-bit places", m->n, nseg);
+        return TC2LI_ERR_CAPACITY;
+    }
+    TC2LI_HIP_CHECK(m->d_row_start.ensure((size_t)nseg * kMapSegStride + 1));
     // the points that were in the map before are taken from the old grid's order (cell-coherent, see MapGridTask): the new grid goes to the other buffer
     const bool from_old = m->rebuild_mode != 0 && m->grid_valid && m->d_sorted.p && m->grid.n_slots > 0;
     DevBuf<float4>& target = from_old ? m->d_sorted_alt : m->d_sorted;
@@ -286,7 +290,7 @@ int grid_prepare(tc2li_lidar_map* m, MapGridTask* t, hipStream_t st) {
     const int old_slots = m->grid.n_slots;
     g.points = m->d_points.p; g.pts = target.p; g.bucket_start = m->d_row_start.p; g.n_points = m->n; g.n_slots = (int)n_slots;
     t->g = g; t->counts = m->d_bucket_counts.p; t->start = m->d_bucket_start.p; t->row_start = m->d_row_start.p; t->sorted = target.p;
-    t->tile_sums = m->d_tile_sums.p; t->n_cells = nc; t->row_slack = row_slack;
+    t->tile_sums = m->d_tile_sums.p; t->n_cells = nc; t->seg_slack = seg_slack;
     t->old_sorted = from_old ? m->d_sorted.p : nullptr;
     t->remap = from_old && m->rebuild_mode == 1 && m->have_remap ? m->d_remap.p : nullptr;
     t->n_old = from_old ? old_slots : 0; t->n_kept = from_old ? m->remap_n_kept : 0;
@@ -309,14 +313,18 @@ int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>&
         if (rc != TC2LI_OK) { maps[i]->grid_valid = false; return rc; }
         max_points = std::max(max_points, tasks[i].n_old + (maps[i]->n - tasks[i].n_kept));
         max_cells = std::max(max_cells, tasks[i].n_cells);
-        max_row_entries = std::max(max_row_entries, tasks[i].g.ny * tasks[i].g.nz * tasks[i].g.row_stride + 1);
+        max_row_entries = std::max(max_row_entries, tasks[i].g.ny * tasks[i].g.nz * tasks[i].g.nsx * kMapSegStride + 1);
     }
     for (int i = 0; i < n_maps; ++i) { maps[i]->counts_dirty = true; maps[i]->grid_valid = false; }
+    static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
+    if (kDebug) fprintf(stderr, "rebuild_grids: %d maps, map 0: n %d n_old %d n_kept %d slots %d cells %d remap %p old %p\n", n_maps, maps[0]->n, tasks[0].n_old, tasks[0].n_kept,
+                        tasks[0].g.n_slots, tasks[0].n_cells, (const void*)tasks[0].remap, (const void*)tasks[0].old_sorted);
     TC2LI_HIP_CHECK(d_tasks.ensure(n_maps));
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_tasks.p, tasks.data(), n_maps * sizeof(MapGridTask), hipMemcpyHostToDevice, st));
     launch_map_grid_build(d_tasks.p, n_maps, max_points, max_cells, max_row_entries, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    if (kDebug) fprintf(stderr, "rebuild_grids: done\n");
     for (int i = 0; i < n_maps; ++i) {
         tc2li_lidar_map* m = maps[i];
         m->grid = tasks[i].g; m->grid_valid = true; m->counts_dirty = false; m->tombstones = 0; ++m->n_grid_builds;
@@ -1046,9 +1054,9 @@ int tc2li_lidar_map_grid_download(const tc2li_lidar_map* m, int32_t* cells, int3
     std::lock_guard<std::mutex> lock(m->mu);
     if (!m->grid_valid) { set_error("tc2li_lidar_map_grid_download: the map has no valid grid"); return TC2LI_ERR_INVALID; }
     const MapGrid& g = m->grid;
-    const int rows = g.ny * g.nz, stride = g.row_stride;
+    const int rows = g.ny * g.nz, nseg = rows * g.nsx, stride = kMapSegStride;
     std::vector<float4> ent((size_t)std::max(g.n_slots, 1));
-    std::vector<int> rs((size_t)rows * stride + 1);
+    std::vector<int> rs((size_t)nseg * stride + 1);
     std::vector<PointXYZINormal> pts((size_t)std::max(m->n, 1));
     hipStream_t ps = private_stream();
     TC2LI_HIP_CHECK(copy_sync(ent.data(), g.pts, (size_t)g.n_slots * sizeof(float4), hipMemcpyDeviceToHost, ps));
@@ -1056,14 +1064,16 @@ int tc2li_lidar_map_grid_download(const tc2li_lidar_map* m, int32_t* cells, int3
     if (m->n) TC2LI_HIP_CHECK(copy_sync(pts.data(), m->d_points.p, (size_t)m->n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, ps));
     auto idx_of = [](const float4& e) { int i; memcpy(&i, &e.w, 4); return i; };
     int n_live = 0;
-    if (rs[(size_t)rows * stride] != g.n_slots) { set_error("grid: the last start is %d, not n_slots = %d", rs[(size_t)rows * stride], g.n_slots); return TC2LI_ERR_INVALID; }
-    for (int r = 0; r < rows; ++r) {
-        const int* cs = rs.data() + (size_t)r * stride;
-        const int limit = cs[stride];
-        if (cs[0] > cs[g.nx] || cs[g.nx] > limit) { set_error("grid: row %d spans [%d, %d) beyond its room up to %d", r, cs[0], cs[g.nx], limit); return TC2LI_ERR_INVALID; }
-        for (int ix = 0; ix < g.nx; ++ix) {
-            if (cs[ix] > cs[ix + 1]) { set_error("grid: row %d cell %d starts at %d behind the next cell's %d", r, ix, cs[ix], cs[ix + 1]); return TC2LI_ERR_INVALID; }
-            for (int k = cs[ix]; k < cs[ix + 1]; ++k) {
+    if (rs[(size_t)nseg * stride] != g.n_slots) { set_error("grid: the last start is %d, not n_slots = %d", rs[(size_t)nseg * stride], g.n_slots); return TC2LI_ERR_INVALID; }
+    for (int q = 0; q < nseg; ++q) {
+        const int* cs = rs.data() + (size_t)q * stride;
+        const int limit = cs[stride], r = q / g.nsx, sx = q - r * g.nsx;
+        if (cs[0] > cs[kMapSegCells] || cs[kMapSegCells] > limit) { set_error("grid: segment %d spans [%d, %d) beyond its room up to %d", q, cs[0], cs[kMapSegCells], limit); return TC2LI_ERR_INVALID; }
+        for (int j = 0; j < kMapSegCells; ++j) {
+            const int ix = sx * kMapSegCells + j;
+            if (cs[j] > cs[j + 1]) { set_error("grid: segment %d cell %d starts at %d behind the next cell's %d", q, j, cs[j], cs[j + 1]); return TC2LI_ERR_INVALID; }
+            if (ix >= g.nx && cs[j] != cs[j + 1]) { set_error("grid: segment %d holds entries in cell %d beyond the row's %d cells", q, ix, g.nx); return TC2LI_ERR_INVALID; }
+            for (int k = cs[j]; k < cs[j + 1]; ++k) {
                 const int i = idx_of(ent[k]);
                 if (i < 0) continue;
                 if (i >= m->n) { set_error("grid: entry %d names point %d of %d", k, i, m->n); return TC2LI_ERR_INVALID; }
@@ -1077,8 +1087,8 @@ int tc2li_lidar_map_grid_download(const tc2li_lidar_map* m, int32_t* cells, int3
                 ++n_live;
             }
         }
-        for (int k = cs[g.nx]; k < limit; ++k)
-            if (idx_of(ent[k]) >= 0) { set_error("grid: a live entry at %d in the unused room of row %d", k, r); return TC2LI_ERR_INVALID; }
+        for (int k = cs[kMapSegCells]; k < limit; ++k)
+            if (idx_of(ent[k]) >= 0) { set_error("grid: a live entry at %d in the unused room of segment %d", k, q); return TC2LI_ERR_INVALID; }
     }
     return n_live;
 }
@@ -1171,6 +1181,7 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        if (getenv("TC2LI_MAP_DEBUG")) fprintf(stderr, "map_incremental: lists + compaction of %d maps done\n", nt);
         for (int k = 0; k < nt; ++k)
             if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {
                 // the compaction kernels saw the batch word and touched no map; the deletion marks of the lists are taken back
@@ -1192,14 +1203,21 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
             const int* o = L->h_mapinc_out.p + k * kMapIncOut;
             tc2li_lidar_map* m = maps[which[k]];
             const bool fixed = tasks[k].fix_grid != 0;
+            if (o[13]) fprintf(stderr, "tc2li: compaction of map %d found an inconsistent grid (code %d)\n", k, o[13]);
             commit_compaction(m, o, true);
             if (n_to_add) n_to_add[which[k]] = o[0];
             if (n_no_need) n_no_need[which[k]] = o[2];
             const int kept = o[4], added = o[5] + o[2];
             if (fixed) { m->have_remap = false; m->rebuild_mode = 2; }  // the old grid's entries carry the new numbering already
-            if (!fixed || added > kMapInsMax || m->tombstones > std::max(1024, m->n / 8)) { rebuild.push_back(m); continue; }
+            static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
+            if (kDebug && k == 0) fprintf(stderr, "map_incremental: map 0 fixed %d kept %d appended %d no-need %d tombstones %d of %d points\n", (int)fixed, kept, o[5], o[2], m->tombstones, m->n);
+            if (!fixed || added > kMapInsMax) { rebuild.push_back(m); continue; }
             m->grid.n_points = m->n;
-            if (added == 0) { m->rebuild_mode = 0; ++m->n_grid_updates; continue; }
+            if (added == 0) {
+                if (m->tombstones > std::max(1024, m->n / 8)) { m->remap_n_kept = m->n; rebuild.push_back(m); }  // mode 2: the old grid holds every point
+                else { m->rebuild_mode = 0; ++m->n_grid_updates; }
+                continue;
+            }
             TC2LI_HIP_CHECK(m->d_ins_keys.ensure(kMapInsMax)); TC2LI_HIP_CHECK(m->d_ins_rows.ensure(kMapInsMax + 1));
             MapInsTask t{};
             t.g = m->grid; t.g.points = m->d_points.p;
@@ -1214,12 +1232,23 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
             TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_ins_tasks.p, ins.data(), ni * sizeof(MapInsTask), hipMemcpyHostToDevice, st));
             launch_map_insert(L->d_ins_tasks.p, ni, st);
             TC2LI_HIP_CHECK(hipGetLastError());
+            if (getenv("TC2LI_MAP_DEBUG")) { TC2LI_HIP_CHECK(stream_wait_blocking(st)); fprintf(stderr, "  insertion of %d maps done\n", ni); }
             TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_ins_out.p, L->d_ins_out.p, 4 * (size_t)ni * sizeof(int), hipMemcpyDeviceToHost, st));
             TC2LI_HIP_CHECK(stream_wait_blocking(st));
             for (int k = 0; k < ni; ++k) {
                 tc2li_lidar_map* m = inserted[k];
+                static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
+                if (kDebug && k == 0) fprintf(stderr, "  insertion: rows %d overflow %d tombstones dropped %d\n", L->h_ins_out.p[4 * k], L->h_ins_out.p[4 * k + 1], L->h_ins_out.p[4 * k + 2]);
+                if (L->h_ins_out.p[4 * k + 3]) fprintf(stderr, "tc2li: in-place insertion of map %d found an inconsistent grid (code %d)\n", k, L->h_ins_out.p[4 * k + 3]);
                 if (L->h_ins_out.p[4 * k + 1]) { m->rebuild_mode = 0; rebuild.push_back(m); }  // some rows may hold the new points already: from the point list
-                else { m->rebuild_mode = 0; ++m->n_grid_updates; m->tombstones = std::max(0, m->tombstones - L->h_ins_out.p[4 * k + 2]); }
+                else {
+                    // the rewritten segments dropped their tombstones; what is left elsewhere is scanned by every search that passes: beyond an
+                    // eighth of the map the grid is rebuilt from its own order (mode 2: it holds every point under its new index)
+                    ++m->n_grid_updates;
+                    m->tombstones = std::max(0, m->tombstones - L->h_ins_out.p[4 * k + 2]);
+                    if (m->tombstones > std::max(1024, m->n / 8)) { m->rebuild_mode = 2; m->remap_n_kept = m->n; rebuild.push_back(m); }
+                    else m->rebuild_mode = 0;
+                }
             }
         }
         if (!rebuild.empty()) {

@@ -1027,20 +1027,29 @@ __device__ __forceinline__ void scan_run(const float4* __restrict__ pts, int s, 
 template <int RING, int GROUP>
 __device__ __forceinline__ void scan_cube(const MapGrid& g, int cx, int cy, int cz, float qx, float qy, float qz, int l, Top5& t) {
     constexpr int W = 2 * RING + 1, NR = W * W, PER = (NR + GROUP - 1) / GROUP;
+    static_assert(W <= kMapSegCells, "a run of the cube touches at most two segments");
     t.clear();
     const int xa = max(cx - RING - g.x0, 0), xb = min(cx + RING - g.x0, g.nx - 1);
-    int rs[PER], re[PER];
+    // the run's cells lie in one segment of the row, or in two: [xa, end of xa's segment] and [start of xb's segment, xb]
+    const bool two = (xa >> 4) != (xb >> 4);
+    const int xa_end = two ? (xa | (kMapSegCells - 1)) : xb, xb_begin = xb & ~(kMapSegCells - 1);
+    int rs[PER], re[PER], rs2[PER], re2[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int r = l + GROUP * j;
         const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
         const bool ok = r < NR && xa <= xb && iz >= 0 && iz < g.nz && iy >= 0 && iy < g.ny;
-        const int row = (iz * g.ny + iy) * g.row_stride;
-        rs[j] = ok ? g.bucket_start[row + xa] : 0;
-        re[j] = ok ? g.bucket_start[row + xb + 1] : 0;
+        const int row = iz * g.ny + iy;
+        rs[j] = ok ? g.bucket_start[map_start_index(g, row, xa)] : 0;
+        re[j] = ok ? g.bucket_start[map_start_index(g, row, xa_end) + 1] : 0;
+        rs2[j] = ok && two ? g.bucket_start[map_start_index(g, row, xb_begin)] : 0;
+        re2[j] = ok && two ? g.bucket_start[map_start_index(g, row, xb) + 1] : 0;
     }
 #pragma unroll
-    for (int j = 0; j < PER; ++j) scan_run(g.pts, rs[j], re[j], qx, qy, qz, t);
+    for (int j = 0; j < PER; ++j) {
+        scan_run(g.pts, rs[j], re[j], qx, qy, qz, t);
+        scan_run(g.pts, rs2[j], re2[j], qx, qy, qz, t);
+    }
     merge_top5<GROUP>(t);
 }
 
@@ -1157,8 +1166,11 @@ __device__ __forceinline__ bool hard_ring(const MapGrid& g, int cx, int cy, int 
         for (int r = lane; r < W * W; r += 64) {
             const int iz = cz - RING + r / W - g.z0, iy = cy - RING + r % W - g.y0;
             if (iz < 0 || iz >= g.nz || iy < 0 || iy >= g.ny) continue;
-            const int row = (iz * g.ny + iy) * g.row_stride;
-            scan_run(g.pts, g.bucket_start[row + xa], g.bucket_start[row + xb + 1], qx, qy, qz, t);
+            const int row = iz * g.ny + iy;
+            for (int x0 = xa; x0 <= xb; x0 = (x0 | (kMapSegCells - 1)) + 1) {  // segment by segment
+                const int x1 = min(x0 | (kMapSegCells - 1), xb);
+                scan_run(g.pts, g.bucket_start[map_start_index(g, row, x0)], g.bucket_start[map_start_index(g, row, x1) + 1], qx, qy, qz, t);
+            }
         }
     merge_top5<64>(t);
     return knn_complete(g, RING, cx, cy, cz, qx, qy, qz, t);

@@ -150,11 +150,14 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
         if (xa > xb) return;
         for (int qz = za; qz <= zb; ++qz)
             for (int qy = ya; qy <= yb; ++qy) {
-                const int row = (qz * grid.ny + qy) * grid.row_stride;
-                for (int k = grid.bucket_start[row + xa]; k < grid.bucket_start[row + xb + 1]; ++k) {
-                    const float4 m = grid.pts[k];
-                    if (__float_as_int(m.w) < 0) continue;  // tombstone
-                    if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w), k);
+                const int row = qz * grid.ny + qy;
+                for (int qx = xa; qx <= xb; ++qx) {  // cell by cell: a voxel's box touches one or two cells along x
+                    const int si = map_start_index(grid, row, qx);
+                    for (int k = grid.bucket_start[si]; k < grid.bucket_start[si + 1]; ++k) {
+                        const float4 m = grid.pts[k];
+                        if (__float_as_int(m.w) < 0) continue;  // tombstone
+                        if (bmin[0] <= m.x && bmax[0] > m.x && bmin[1] <= m.y && bmax[1] > m.y && bmin[2] <= m.z && bmax[2] > m.z) fn(__float_as_int(m.w), k);
+                    }
                 }
             }
     };
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __rest
         for (int k = 0; k < 16; ++k) tot += s_wave[k];
         T.out[4] = carry;
         T.out[5] = tot;
+        T.out[13] = 0;  // set by k_map_fill when it finds the grid inconsistent
         for (int k = 0; k < 3; ++k) { T.out[6 + k] = 0x7fffffff; T.out[9 + k] = (int)0x80000000; }
     }
     // kept points among the first K = carry places (the others are the holes to fill)
@@ -296,7 +300,10 @@ __global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__
         T.remap[src] = dst;
         if (T.fix_grid) {  // the moved point's grid entry carries its index: renumber it where it stands (its cell is a few entries)
             const int c = map_cell(g, p.x, p.y, p.z), row = c / g.nx, ix = c - row * g.nx;
-            const int k0 = g.bucket_start[row * g.row_stride + ix], k1 = g.bucket_start[row * g.row_stride + ix + 1];
+            if (c < 0 || row >= g.ny * g.nz) { atomicOr(&T.out[13], 1); continue; }
+            const int si = map_start_index(g, row, ix);
+            const int k0 = g.bucket_start[si], k1 = g.bucket_start[si + 1];
+            if (k0 < 0 || k1 < k0 || k1 > g.n_slots) { atomicOr(&T.out[13], 2); continue; }
             for (int k = k0; k < k1; ++k)
                 if (__float_as_int(entries[k].w) == src) { entries[k].w = __int_as_float(dst); break; }
         }
@@ -468,22 +475,26 @@ __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restri
     // the run's lanes take consecutive places; the cell's places go from the back, which leaves its counter at zero for the next build
     if (run.head && c >= 0) {
         const int row = c / T.g.nx;
-        first = T.row_start[row * T.g.row_stride + (c - row * T.g.nx)] + atomicSub(&T.counts[c], run.length) - run.length;
+        first = T.row_start[map_start_index(T.g, row, c - row * T.g.nx)] + atomicSub(&T.counts[c], run.length) - run.length;
     }
     first = __shfl(first, run.head_lane, 64);
     if (c >= 0) T.sorted[first + ((int)(threadIdx.x & 63) - run.head_lane)] = q;
 }
 
-// The row-wise starts from the plain exclusive prefix E over the cells: row r begins at 2 E[r nx] + row_slack r (room for as many entries
-// again + row_slack behind every row), cell ix of row r at E[r nx + ix] + E[r nx] + row_slack r; entry nx of a row = the end of its
-// entries, the last entry of the array (row = rows, ix = 0) = n_slots.
+// The segments' starts from the plain exclusive prefix E over the cells: the segment with first cell c0 and number q begins at
+// 2 E[c0] + seg_slack q (room for as many entries again + seg_slack behind every segment), its cell j at E[c0 + j] + E[c0] + seg_slack q
+// (cells beyond the row's last: the end of the segment's entries); entry 16 of a segment = the end of its entries, the last entry of
+// the array (segment = number of segments, j = 0) = n_slots.
 __global__ __launch_bounds__(256) void k_map_row_starts(const MapGridTask* __restrict__ tasks) {
     const MapGridTask& T = tasks[blockIdx.y];
-    const int stride = T.g.row_stride, rows = T.g.ny * T.g.nz;
+    const int nseg = T.g.ny * T.g.nz * T.g.nsx;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx > rows * stride) return;
-    const int row = idx / stride, ix = idx - row * stride;
-    T.row_start[idx] = T.start[row * T.g.nx + ix] + T.start[row * T.g.nx] + T.row_slack * row;
+    if (idx > nseg * kMapSegStride) return;
+    const int seg = idx / kMapSegStride, j = idx - seg * kMapSegStride;
+    const int row = seg / T.g.nsx, sx = seg - row * T.g.nsx;
+    const int c0 = row * T.g.nx + sx * kMapSegCells;                      // (row = rows, sx = 0: n_cells)
+    const int c = row * T.g.nx + min(sx * kMapSegCells + j, T.g.nx);      // past the row's last cell: the row's end
+    T.row_start[idx] = T.start[c] + T.start[c0] + T.seg_slack * seg;
 }
 
 // ---- in-place insertion (round 4): the added points of a step are merged into the rows they fall into, nothing else is touched -----
@@ -503,11 +514,11 @@ __global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restr
             const PointXYZINormal p = g.points[T.first + i];
             const int cx = (int)floorf(p.x * g.inv_cell) - g.x0, cy = (int)floorf(p.y * g.inv_cell) - g.y0, cz = (int)floorf(p.z * g.inv_cell) - g.z0;
             if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || cz < 0 || cz >= g.nz) { s_bad = 1; s_keys[i] = ~0ull; }  // outside the grid's box
-            else s_keys[i] = (unsigned long long)(unsigned)((cz * g.ny + cy) * g.nx + cx) << 32 | (unsigned)(T.first + i);
+            else s_keys[i] = (unsigned long long)(unsigned)((((cz * g.ny + cy) * g.nsx + (cx >> 4)) << 4) | (cx & 15)) << 32 | (unsigned)(T.first + i);
         }
     }
     __syncthreads();
-    if (s_bad) { if (tid == 0) { T.out[0] = 0; T.out[1] = 1; T.out[2] = 0; } return; }
+    if (s_bad) { if (tid == 0) { T.out[0] = 0; T.out[1] = 1; T.out[2] = 0; T.out[3] = 0; } return; }
     int P = 1;
     while (P < n) P <<= 1;
     for (int k = n + tid; k < P; k += 1024) s_keys[k] = ~0ull;
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restr
         bool start = false;
         if (k < n) {
             T.keys[k] = s_keys[k];
-            start = k == 0 || (int)(s_keys[k] >> 32) / g.nx != (int)(s_keys[k - 1] >> 32) / g.nx;
+            start = k == 0 || (int)(s_keys[k] >> 36) != (int)(s_keys[k - 1] >> 36);  // another segment
         }
         int total;
         const int pos = block_flag_scan(start, s_wave, total);
@@ -536,98 +547,78 @@ __global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restr
         if (tid == 0) s_base += total;
         __syncthreads();
     }
-    if (tid == 0) { T.row_list[s_base] = n; T.out[0] = s_base; T.out[1] = 0; T.out[2] = 0; }
+    if (tid == 0) { T.row_list[s_base] = n; T.out[0] = s_base; T.out[1] = 0; T.out[2] = 0; T.out[3] = 0; }
 }
-// One workgroup per row that receives points (a map's rows dealt over blockIdx.x): the row's entries without their tombstones and the
-// new points, merged by cell (the old entries of a cell first, then the new ones by index), written back from the row's first place;
-// the row's nx + 1 starts follow.  A row without room, or with more entries than the merge holds, raises out[1]: the host rebuilds that
-// map's grid (rows written before stay valid or not -- the rebuild starts from the points).
-__global__ __launch_bounds__(256) void k_map_ins_rows(const MapInsTask* __restrict__ tasks) {
+// One WAVEFRONT per segment that receives points (a map's segments dealt over blockIdx.x): the segment's entries without their tombstones
+// and the new points, merged by cell (the old entries of a cell first, then the new ones by index), written back from the segment's
+// first place; its 17 starts follow.  A segment without room, or with more entries than the merge holds, raises out[1]: the host rebuilds
+// that map's grid (segments written before stay valid or not -- the rebuild starts from the points).  A segment is some tens of entries:
+// a 256-thread workgroup per segment spent its time in barriers (1.6 ms per 512 maps; this form: see DESIGN.md).
+__global__ __launch_bounds__(64) void k_map_ins_rows(const MapInsTask* __restrict__ tasks) {
     const MapInsTask& T = tasks[blockIdx.y];
     __shared__ float4 s_ent[kMapRowMax];
     __shared__ int s_rank[kMapRowMax + 1];
-    __shared__ int s_wave[4];
-    if (T.out[1]) return;
+    __shared__ int s_cs[kMapSegStride + 1];
+    // (no early exit on out[1]: other workgroups raise it while this one runs; a map whose keys could not be made has no segments, out[0] = 0)
     const MapGrid& g = T.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_rows = T.out[0], nx = g.nx;
+    constexpr int nx = kMapSegCells;
+    const int lane = threadIdx.x, n_rows = T.out[0];
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int rr = blockIdx.x; rr < n_rows; rr += gridDim.x) {
+        __syncthreads();  // one wavefront: orders this iteration's LDS writes behind the last one's reads
         const int k0 = T.row_list[rr], k1 = T.row_list[rr + 1], N = k1 - k0;
-        const int row = (int)(T.keys[k0] >> 32) / nx;
-        int* const cs = T.row_start + (size_t)row * g.row_stride;
-        const int b = cs[0], e = cs[nx], limit = cs[g.row_stride], M = e - b;
-        if (M + N > kMapRowMax) { if (tid == 0) atomicExch(&T.out[1], 1); continue; }  // uniform
-        for (int j = tid; j < M; j += 256) s_ent[j] = T.pts[b + j];
+        const int seg = (int)(T.keys[k0] >> 36);
+        int* const cs = T.row_start + (size_t)seg * kMapSegStride;
+        if (lane <= kMapSegStride) s_cs[lane] = cs[lane];  // the segment's 17 starts + the next segment's first = where its room ends
         __syncthreads();
-        // s_rank[j] = live entries before j: a thread takes 8 consecutive entries, then a scan over the 256 threads
-        constexpr int PER = kMapRowMax / 256;
-        int cnt = 0;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) { const int j = tid * PER + q; cnt += j < M && __float_as_int(s_ent[j].w) >= 0; }
-        int incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int run = incl - cnt;
-        for (int w = 0; w < wave; ++w) run += s_wave[w];
-        const int V = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int j = tid * PER + q;
-            if (j <= M) s_rank[j] = run;
-            run += j < M && __float_as_int(s_ent[j].w) >= 0;
+        const int b = s_cs[0], e = s_cs[nx], limit = s_cs[kMapSegStride], M = e - b;
+        bool sane = b >= 0 && e >= b && limit >= e && limit <= g.n_slots && seg >= 0 && seg < g.ny * g.nz * g.nsx;
+        for (int j = 0; j < nx && sane; ++j) sane = s_cs[j] <= s_cs[j + 1];
+        if (!sane) {  // uniform; a grid that is not what the host says it is
+            if (lane == 0) { atomicExch(&T.out[1], 1); atomicOr(&T.out[3], 1); }
+            continue;
         }
+        if (M + N > kMapRowMax) { if (lane == 0) atomicExch(&T.out[1], 1); continue; }  // uniform
+        // the old entries into LDS; s_rank[j] = live entries before j
+        int V = 0;
+        for (int j0 = 0; j0 < M; j0 += 64) {
+            const int j = j0 + lane;
+            float4 en = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+            if (j < M) { en = T.pts[b + j]; s_ent[j] = en; }
+            const unsigned long long live = __ballot(__float_as_int(en.w) >= 0);
+            if (j < M) s_rank[j] = V + __popcll(live & below);
+            V += __popcll(live);
+        }
+        if (lane == 0) s_rank[M] = V;
         __syncthreads();
-        if (b + V + N > limit) { if (tid == 0) atomicExch(&T.out[1], 1); __syncthreads(); continue; }  // uniform: V is shared
-        // new entries with a cell below `cell` (the keys of the row are sorted)
+        if (b + V + N > limit) { if (lane == 0) atomicExch(&T.out[1], 1); continue; }  // uniform
+        if (lane == 0 && M > V) atomicAdd(&T.out[2], M - V);  // the tombstones this rewrite drops
+        // new entries with a cell below `cell` (the keys of the segment are sorted)
         auto new_below = [&](int cell) {
             int lo = k0, hi = k1;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)(T.keys[mid] >> 32) < cell) lo = mid + 1; else hi = mid; }
             return lo - k0;
         };
-        // places of the new points (reads the row's old starts: before any of them is rewritten)
-        int dst_new[(kMapInsMax + 255) / 256 > 8 ? 8 : (kMapInsMax + 255) / 256];
-        constexpr int NEWPER = sizeof(dst_new) / sizeof(int);
-        bool spill = N > NEWPER * 256;  // more new points in one row than the registers hold: rebuilt (uniform)
-        if (spill) { if (tid == 0) atomicExch(&T.out[1], 1); __syncthreads(); continue; }
-#pragma unroll
-        for (int q = 0; q < NEWPER; ++q) {
-            const int i = tid + 256 * q;
-            dst_new[q] = 0;
-            if (i < N) {
-                const int ix = (int)(T.keys[k0 + i] >> 32) - row * nx;
-                dst_new[q] = b + i + s_rank[cs[ix + 1] - b];  // live old entries of the cells up to ix stand before it
-            }
-        }
-        if (tid == 0 && M > V) atomicAdd(&T.out[2], M - V);  // the tombstones this rewrite drops
-        // the row's new starts, computed from the old ones
-        const int n_cs = nx + 1;
-        __syncthreads();
-        for (int ix0 = 0; ix0 < n_cs; ix0 += 256) {
-            const int ix = ix0 + tid;
-            int v = 0;
-            if (ix < n_cs) v = ix == nx ? b + V + N : b + s_rank[cs[ix] - b] + new_below(row * nx + ix);
-            // every thread has read the old starts of this chunk and of its new points before anyone writes: the chunks are disjoint,
-            // and dst_new above is complete
-            if (ix < n_cs) cs[ix] = v;
-        }
-        // the entries
-        for (int j = tid; j < M; j += 256) {
+        // the segment's new starts (from the old ones, which stay in s_cs)
+        if (lane <= nx) cs[lane] = lane == nx ? b + V + N : b + s_rank[s_cs[lane] - b] + new_below(seg * nx + lane);
+        // the old entries: live rank + the new points of the cells before theirs
+        for (int j = lane; j < M; j += 64) {
             const float4 en = s_ent[j];
             if (__float_as_int(en.w) < 0) continue;
-            const int cell = row * nx + ((int)floorf(en.x * g.inv_cell) - g.x0);
-            T.pts[b + s_rank[j] + new_below(cell)] = en;
+            const int cell = seg * nx + (((int)floorf(en.x * g.inv_cell) - g.x0) & (kMapSegCells - 1));
+            const int d = b + s_rank[j] + new_below(cell);
+            if (d < b || d >= limit) atomicOr(&T.out[3], 8); else T.pts[d] = en;
         }
-#pragma unroll
-        for (int q = 0; q < NEWPER; ++q) {
-            const int i = tid + 256 * q;
-            if (i < N) {
-                const int idx = (int)(unsigned)(T.keys[k0 + i] & 0xffffffffull);
-                const PointXYZINormal p = g.points[idx];
-                T.pts[dst_new[q]] = make_float4(p.x, p.y, p.z, __int_as_float(idx));
-            }
+        // the new points: behind the live old entries of the cells up to their own
+        for (int i = lane; i < N; i += 64) {
+            const unsigned long long key = T.keys[k0 + i];
+            const int ix = (int)(key >> 32) - seg * nx, idx = (int)(unsigned)(key & 0xffffffffull);
+            const int d = b + i + s_rank[s_cs[ix + 1] - b];
+            if (idx < 0 || idx >= g.n_points || d < b || d >= limit) { atomicOr(&T.out[3], 16); continue; }
+            const PointXYZINormal p = g.points[idx];
+            T.pts[d] = make_float4(p.x, p.y, p.z, __int_as_float(idx));
         }
-        for (int j = b + V + N + tid; j < e; j += 256) T.pts[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // a row that shrank: tombstones behind it
-        __syncthreads();
+        for (int j = b + V + N + lane; j < e; j += 64) T.pts[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));  // a segment that shrank: tombstones behind it
     }
 }
 
@@ -636,7 +627,7 @@ void launch_map_insert(const MapInsTask* tasks, int n_tasks, hipStream_t st) {
     if (!n_tasks) return;
     (void)ensure_dynamic_lds(reinterpret_cast<const void*>(k_map_ins_sort), kMapInsMax * (int)sizeof(unsigned long long));
     TC2LI_LAUNCH(k_map_ins_sort, dim3(n_tasks), dim3(1024), kMapInsMax * sizeof(unsigned long long), st, tasks);
-    TC2LI_LAUNCH(k_map_ins_rows, dim3(64, n_tasks), dim3(256), 0, st, tasks);
+    TC2LI_LAUNCH(k_map_ins_rows, dim3(256, n_tasks), dim3(64), 0, st, tasks);
 }
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st) {
     if (!n_tasks || !max_points) return;

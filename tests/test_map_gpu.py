@@ -83,12 +83,15 @@ def test_in_place_grid_update_equals_rebuild(pkg, oracle, setup, monkeypatch):
         _grid_is_sound(a); _grid_is_sound(b)
     sa, sb = a.stats(), b.stats()
     assert sb["grid_builds"] == builds0 + 12 and sb["grid_updates"] == 0
-    assert sa["grid_updates"] >= 10 and sa["grid_builds"] + sa["grid_updates"] == builds0 + 12, sa  # a rebuild only where the grid said it had to
+    # a rebuild only where the grid said it had to (a segment of this small, sparse map has room for 8 more points than it holds; the scans'
+    # first visits to new ground overflow some) -- or on top of an update, when the tombstones left elsewhere have piled up
+    assert sa["grid_updates"] >= 6 and sa["grid_builds"] + sa["grid_updates"] >= builds0 + 12, sa
 
 
 def test_in_place_grid_update_falls_back_to_a_rebuild(pkg, oracle, setup):
     """What the in-place insertion cannot take ends in a rebuild, with the oracle's map either way: a point outside the grid's box (beyond its
-    margin of 8 cells), a row that receives more points than it has room for, a row longer than the merge holds."""
+    margin of 8 cells), a segment (16 cells of a row) that receives more points than it has room for, a segment with more entries than the
+    merge holds."""
     fe, downs, states, world0 = setup
     ident = pkg.pack_lidar_state(np.eye(3), np.zeros(3))
     def P(xyz):
@@ -97,9 +100,9 @@ def test_in_place_grid_update_falls_back_to_a_rebuild(pkg, oracle, setup):
               [40.2, 40.2, 40.2], [41, 41, 41], [42, 42, 42], [43, 43, 43], [44, 44, 44], [45, 45, 45]])
     inside = P([[5.3, 5.3, 9.3], [10.1, 10.1, 10.1], [47.3, 46.2, 45.1]])  # within the box's margin (8 cells along x and y, 2 along z)
     outside = P([[5.3, 5.3, 5.3], [-40.2, 10.1, 10.1]])
-    row = P(np.stack([np.linspace(10.3, 44.8, 70), np.full(70, 12.3), np.full(70, 12.3)], 1))          # 70 new voxels along one row of the grid
-    long_base = P(np.stack([0.05 + 0.1 * np.arange(2100), np.full(2100, 12.3), np.full(2100, 12.3)], 1))  # 2100 entries in one row of the grid
-    one = P([[50.26, 12.8, 12.8]])
+    row = P(np.stack([np.linspace(10.3, 44.8, 70), np.full(70, 12.3), np.full(70, 12.3)], 1))          # 70 new voxels along one row of the grid: ~28 per segment, room for 4
+    long_base = P(np.stack([1.0 + 6.0 * np.arange(2100) / 2100.0, np.full(2100, 12.3), np.full(2100, 12.3)], 1))  # 2100 entries in one 16-cell segment
+    one = P([[3.26, 12.8, 12.8]])
     for base, scan, in_place in ((base, inside, True), (base, outside, False), (base, row, False), (long_base, one, False)):
         m = pkg.LidarMap(); m.Build(base)
         builds0 = m.stats()["grid_builds"]
