@@ -1075,13 +1075,13 @@ int oracle_create_new_map_points(const KeyFrameViewPOD* cur, const KeyFrameViewP
 // ---- IMU pre-integration -------------------------------------------------------------------------------------------------
 // out: dT, dR 9, dV 3, dP 3, JRg 9, JVg 9, JVa 9, JPg 9, JPa 9, avgA 3, avgW 3, C 225 (= 292 floats); samples as (t, a, w) with t double
 struct ImuSamplePOD { double t; float a[3], w[3]; };
-int oracle_imu_preintegrate(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, float ng, float na,
-                            float ngw, float naw, float* out292) {
+static int imu_preintegrate_impl(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, float ng, float na,
+                                 float ngw, float naw, float* out292, bool float_eval) {
     ImuBias b{bias6[0], bias6[1], bias6[2], bias6[3], bias6[4], bias6[5]};
     Preintegrated p(b, ng, na, ngw, naw);
     std::vector<ImuSample> v(n);
     for (int i = 0; i < n; ++i) { v[i].t = samples[i].t; std::memcpy(v[i].a, samples[i].a, 12); std::memcpy(v[i].w, samples[i].w, 12); }
-    const int steps = PreintegrateIMU(v, t_prev, t_cur, p);
+    const int steps = PreintegrateIMU(v, t_prev, t_cur, p, float_eval);
     float* o = out292;
     *o++ = p.dT;
     auto put = [&](const float* src, int k) { std::memcpy(o, src, k * sizeof(float)); o += k; };
@@ -1089,6 +1089,16 @@ int oracle_imu_preintegrate(const ImuSamplePOD* samples, int n, double t_prev, d
     put(p.avgW, 3); put(p.C, 225);
     return steps;
 }
+int oracle_imu_preintegrate(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, float ng, float na,
+                            float ngw, float naw, float* out292) {
+    return imu_preintegrate_impl(samples, n, t_prev, t_cur, bias6, ng, na, ngw, naw, out292, false);
+}
+// the float evaluation (IntegrateNewMeasurementFloat)
+int oracle_imu_preintegrate_f32(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, float ng, float na,
+                                float ngw, float naw, float* out292) {
+    return imu_preintegrate_impl(samples, n, t_prev, t_cur, bias6, ng, na, ngw, naw, out292, true);
+}
+void oracle_normalize_rotation_f32(const float* R, float* out) { NormalizeRotationFloat(R, out); }
 // state prediction from the pre-integration of the given samples at another bias: out = Rwb2 9, twb2 3, Vwb2 3, dR 9, dV 3, dP 3
 int oracle_imu_predict(const ImuSamplePOD* samples, int n, double t_prev, double t_cur, const float* bias6, const float* bias_eval6,
                        float ng, float na, float ngw, float naw, const float* Rwb1, const float* twb1, const float* Vwb1, float* out30) {

@@ -1,8 +1,10 @@
 // TEST INFRASTRUCTURE ONLY -- CPU oracle, never linked into or called from the product path.  See imu.hpp.
 #include "imu.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 namespace oracle {
 
@@ -65,6 +67,182 @@ void so3_exp(const double* v, double* R) {  // Sophus::SO3f::exp(v).matrix()
     for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0 ? 1.0 : 0.0) + a * W[k] + bq * W2[k];
 }
 }  // namespace
+
+// ---- float evaluation: the reference's expressions in float, in Eigen's order of evaluation ------------------
+// Every product / scaling below is one Eigen expression node evaluated left to right as the source text associates it
+// (`W*sin(d)/d` is (W * sin d) / d; `0.5f*dR*dt*dt*Wacc*JRg` is ((((0.5f dR) dt) dt) Wacc) JRg); a 3 x 3 product's coefficient is
+// (a0 b0 + a1 b1) + a2 b2.  Unknowable from here and fixed by choice: the summation order inside Eigen's 9 x 9 products (sequential
+// in k), and the SVD of NormalizeRotation, restated from Eigen's Jacobi/SVD sources (two-sided Jacobi sweeps; JacobiSVD.h, Jacobi.h
+// of Eigen 3.3) -- "parity unpinned" applies as everywhere in this oracle.
+namespace f32 {
+struct Mf { float m[9]; float& operator()(int r, int c) { return m[3 * r + c]; } float operator()(int r, int c) const { return m[3 * r + c]; } };
+Mf I3() { return Mf{{1, 0, 0, 0, 1, 0, 0, 0, 1}}; }
+Mf mulm(const Mf& a, const Mf& b) { Mf o; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o(r, c) = (a(r, 0) * b(0, c) + a(r, 1) * b(1, c)) + a(r, 2) * b(2, c); return o; }
+Mf scale(const Mf& a, float s) { Mf o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] * s; return o; }
+Mf div(const Mf& a, float s) { Mf o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] / s; return o; }
+Mf add(const Mf& a, const Mf& b) { Mf o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] + b.m[k]; return o; }
+Mf sub(const Mf& a, const Mf& b) { Mf o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] - b.m[k]; return o; }
+Mf neg(const Mf& a) { Mf o; for (int k = 0; k < 9; ++k) o.m[k] = -a.m[k]; return o; }
+Mf trm(const Mf& a) { Mf o; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o(r, c) = a(c, r); return o; }
+Mf hatm(const float v[3]) { return Mf{{0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}}; }
+void mulvf(const Mf& a, const float v[3], float o[3]) { for (int r = 0; r < 3; ++r) o[r] = (a(r, 0) * v[0] + a(r, 1) * v[1]) + a(r, 2) * v[2]; }
+
+// Eigen::JacobiRotation<float>
+struct Rot { float c, s; };
+Rot rot_mul(const Rot& a, const Rot& b) { return Rot{a.c * b.c - a.s * b.s, a.c * b.s + a.s * b.c}; }  // operator* for real scalars
+Rot rot_T(const Rot& a) { return Rot{a.c, -a.s}; }
+// makeJacobi(x, y, z): the rotation that diagonalises the symmetric 2 x 2 [[x, y], [y, z]]
+Rot make_jacobi(float x, float y, float z) {
+    const float deno = 2.0f * std::fabs(y);
+    if (deno < std::numeric_limits<float>::min()) return Rot{1.0f, 0.0f};
+    const float tau = (x - z) / deno, w = std::sqrt(tau * tau + 1.0f);
+    const float t = tau > 0.0f ? 1.0f / (tau + w) : 1.0f / (tau - w);
+    const float sign_t = t > 0.0f ? 1.0f : -1.0f;
+    const float n = 1.0f / std::sqrt(t * t + 1.0f);
+    return Rot{n, -sign_t * (y / std::fabs(y)) * std::fabs(t) * n};
+}
+// apply_rotation_in_the_plane on rows p, q (applyOnTheLeft) / columns p, q with j^T (applyOnTheRight)
+void rows(Mf& m, int p, int q, const Rot& j) {
+    if (j.c == 1.0f && j.s == 0.0f) return;
+    for (int i = 0; i < 3; ++i) { const float x = m(p, i), y = m(q, i); m(p, i) = j.c * x + j.s * y; m(q, i) = -j.s * x + j.c * y; }
+}
+void cols(Mf& m, int p, int q, const Rot& j_) {
+    const Rot j = rot_T(j_);
+    if (j.c == 1.0f && j.s == 0.0f) return;
+    for (int i = 0; i < 3; ++i) { const float x = m(i, p), y = m(i, q); m(i, p) = j.c * x + j.s * y; m(i, q) = -j.s * x + j.c * y; }
+}
+// JacobiSVD<Matrix3f>(R, ComputeFullU | ComputeFullV): U V^T
+Mf svd_uvT(const Mf& R) {
+    const float precision = 2.0f * std::numeric_limits<float>::epsilon(), tiny = std::numeric_limits<float>::min();
+    float scl = 0;
+    for (int k = 0; k < 9; ++k) scl = std::fmax(scl, std::fabs(R.m[k]));
+    if (scl == 0.0f) scl = 1.0f;
+    Mf W = div(R, scl), U = I3(), V = I3();
+    float max_diag = std::fmax(std::fabs(W(0, 0)), std::fmax(std::fabs(W(1, 1)), std::fabs(W(2, 2))));
+    for (bool finished = false; !finished;) {
+        finished = true;
+        for (int p = 1; p < 3; ++p)
+            for (int q = 0; q < p; ++q) {
+                const float threshold = std::fmax(tiny, precision * max_diag);
+                if (std::fabs(W(p, q)) > threshold || std::fabs(W(q, p)) > threshold) {
+                    finished = false;
+                    // real_2x2_jacobi_svd: a rotation that makes the 2 x 2 block symmetric, then the Jacobi rotation that diagonalises it
+                    float m00 = W(p, p), m01 = W(p, q), m10 = W(q, p), m11 = W(q, q);
+                    Rot rot1;
+                    const float t = m00 + m11, d = m10 - m01;
+                    if (std::fabs(d) < tiny) rot1 = Rot{1.0f, 0.0f};
+                    else { const float u = t / d, tmp = std::sqrt(1.0f + u * u); rot1 = Rot{u / tmp, 1.0f / tmp}; }
+                    if (!(rot1.c == 1.0f && rot1.s == 0.0f)) {  // m.applyOnTheLeft(0, 1, rot1)
+                        const float a0 = m00, a1 = m01, b0 = m10, b1 = m11;
+                        m00 = rot1.c * a0 + rot1.s * b0; m01 = rot1.c * a1 + rot1.s * b1;
+                        m10 = -rot1.s * a0 + rot1.c * b0; m11 = -rot1.s * a1 + rot1.c * b1;
+                    }
+                    const Rot j_right = make_jacobi(m00, m01, m11);
+                    const Rot j_left = rot_mul(rot1, rot_T(j_right));
+                    rows(W, p, q, j_left);
+                    cols(U, p, q, rot_T(j_left));
+                    cols(W, p, q, j_right);
+                    cols(V, p, q, j_right);
+                    max_diag = std::fmax(max_diag, std::fmax(std::fabs(W(p, p)), std::fabs(W(q, q))));
+                }
+            }
+    }
+    float sv[3];
+    for (int i = 0; i < 3; ++i) {
+        const float a = W(i, i);
+        sv[i] = std::fabs(a);
+        if (a < 0.0f) for (int r = 0; r < 3; ++r) U(r, i) = -U(r, i);
+    }
+    for (int i = 0; i < 3; ++i) {  // singular values in descending order, columns follow
+        int pos = i;
+        for (int k = i + 1; k < 3; ++k) if (sv[k] > sv[pos]) pos = k;
+        if (sv[pos] == 0.0f) break;
+        if (pos != i) {
+            std::swap(sv[i], sv[pos]);
+            for (int r = 0; r < 3; ++r) { std::swap(U(r, i), U(r, pos)); std::swap(V(r, i), V(r, pos)); }
+        }
+    }
+    return mulm(U, trm(V));
+}
+}  // namespace f32
+
+void NormalizeRotationFloat(const float R[9], float out[9]) {
+    f32::Mf m;
+    std::memcpy(m.m, R, 36);
+    const f32::Mf o = f32::svd_uvT(m);
+    std::memcpy(out, o.m, 36);
+}
+
+void Preintegrated::IntegrateNewMeasurementFloat(const float acceleration[3], const float angVel[3], float dt) {
+    using namespace f32;
+    ++n_measurements;
+    Mf R, jrg, jvg, jva, jpg, jpa;
+    std::memcpy(R.m, dR, 36); std::memcpy(jrg.m, JRg, 36); std::memcpy(jvg.m, JVg, 36); std::memcpy(jva.m, JVa, 36);
+    std::memcpy(jpg.m, JPg, 36); std::memcpy(jpa.m, JPa, 36);
+    const float acc[3] = {acceleration[0] - b.bax, acceleration[1] - b.bay, acceleration[2] - b.baz};
+    const float accW[3] = {angVel[0] - b.bwx, angVel[1] - b.bwy, angVel[2] - b.bwz};
+    float Ra[3];
+    mulvf(R, acc, Ra);                                              // dR*acc
+    for (int k = 0; k < 3; ++k) {                                  // (dT*avg + dR*acc*dt) / (dT + dt)
+        avgA[k] = (dT * avgA[k] + Ra[k] * dt) / (dT + dt);
+        avgW[k] = (dT * avgW[k] + accW[k] * dt) / (dT + dt);
+    }
+    const Mf hR = scale(R, 0.5f);                                  // 0.5f*dR
+    float hRa[3];
+    mulvf(hR, acc, hRa);                                            // 0.5f*dR*acc
+    for (int k = 0; k < 3; ++k) dP[k] = (dP[k] + dV[k] * dt) + (hRa[k] * dt) * dt;   // dP + dV*dt + 0.5f*dR*acc*dt*dt
+    for (int k = 0; k < 3; ++k) dV[k] = dV[k] + Ra[k] * dt;        // dV + dR*acc*dt
+    const Mf Wacc = hatm(acc);
+    float A[81] = {0}, B[54] = {0};
+    for (int k = 0; k < 9; ++k) A[10 * k] = 1;
+    const Mf A30 = mulm(scale(neg(R), dt), Wacc);                   // -dR*dt*Wacc
+    const Mf A60 = mulm(scale(scale(scale(R, -0.5f), dt), dt), Wacc);  // -0.5f*dR*dt*dt*Wacc
+    const Mf B33 = scale(R, dt);                                   // dR*dt
+    const Mf B63 = scale(scale(hR, dt), dt);                       // 0.5f*dR*dt*dt
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            A[9 * (3 + r) + c] = A30(r, c);
+            A[9 * (6 + r) + c] = A60(r, c);
+            A[9 * (6 + r) + 3 + c] = r == c ? dt : 0.0f;
+            B[6 * (3 + r) + 3 + c] = B33(r, c);
+            B[6 * (6 + r) + 3 + c] = B63(r, c);
+        }
+    jpa = sub(add(jpa, scale(jva, dt)), B63);                                      // JPa + JVa*dt - 0.5f*dR*dt*dt
+    jpg = sub(add(jpg, scale(jvg, dt)), mulm(mulm(B63, Wacc), jrg));                 // JPg + JVg*dt - 0.5f*dR*dt*dt*Wacc*JRg
+    jva = sub(jva, B33);                                                           // JVa - dR*dt
+    jvg = sub(jvg, mulm(mulm(B33, Wacc), jrg));                                      // JVg - dR*dt*Wacc*JRg
+    // IntegratedRotation dRi(angVel, b, dt)
+    const float x = (angVel[0] - b.bwx) * dt, y = (angVel[1] - b.bwy) * dt, z = (angVel[2] - b.bwz) * dt;
+    const float d2 = x * x + y * y + z * z, d = std::sqrt(d2);
+    const float v[3] = {x, y, z};
+    const Mf W = hatm(v);
+    Mf deltaR, rightJ;
+    if (d < 1e-4f) { deltaR = add(I3(), W); rightJ = I3(); }
+    else {
+        const Mf WW = mulm(W, W);
+        deltaR = add(add(I3(), div(scale(W, std::sin(d)), d)), div(scale(WW, 1.0f - std::cos(d)), d2));      // I + W*sin(d)/d + W*W*(1-cos(d))/d2
+        rightJ = add(sub(I3(), div(scale(W, 1.0f - std::cos(d)), d2)), div(scale(WW, d - std::sin(d)), d2 * d));  // I - W*(1-cos(d))/d2 + W*W*(d-sin(d))/(d2*d)
+    }
+    R = svd_uvT(mulm(R, deltaR));                                   // NormalizeRotation(dR*dRi.deltaR)
+    const Mf dRiT = trm(deltaR), rJdt = scale(rightJ, dt);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { A[9 * r + c] = dRiT(r, c); B[6 * r + c] = rJdt(r, c); }
+    float AC[81], Cn[81];
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) { float s = 0; for (int k = 0; k < 9; ++k) s += A[9 * r + k] * C[15 * k + c]; AC[9 * r + c] = s; }
+    for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 9; ++c) {
+            float s = 0, n = 0;
+            for (int k = 0; k < 9; ++k) s += AC[9 * r + k] * A[9 * c + k];
+            for (int k = 0; k < 6; ++k) n += B[6 * r + k] * Nga[k] * B[6 * c + k];
+            Cn[9 * r + c] = s + n;
+        }
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) C[15 * r + c] = Cn[9 * r + c];
+    for (int k = 0; k < 6; ++k) C[15 * (9 + k) + 9 + k] += NgaWalk[k];
+    jrg = sub(mulm(dRiT, jrg), rJdt);                               // dRi.deltaR.transpose()*JRg - dRi.rightJ*dt
+    std::memcpy(dR, R.m, 36); std::memcpy(JRg, jrg.m, 36); std::memcpy(JVg, jvg.m, 36); std::memcpy(JVa, jva.m, 36);
+    std::memcpy(JPg, jpg.m, 36); std::memcpy(JPa, jpa.m, 36);
+    dT += dt;
+}
 
 void NormalizeRotation(const float R[9], float out[9]) {
     double Rd[9], X[9];
@@ -179,7 +357,7 @@ void Preintegrated::GetDeltaPosition(const ImuBias& b_, float out[3]) const {
     }
 }
 
-int PreintegrateIMU(const std::vector<ImuSample>& m, double t_prev, double t_cur, Preintegrated& p) {
+int PreintegrateIMU(const std::vector<ImuSample>& m, double t_prev, double t_cur, Preintegrated& p, bool float_eval) {
     const int n = (int)m.size() - 1;
     if (n <= 0) return 0;
     for (int i = 0; i < n; i++) {
@@ -205,7 +383,8 @@ int PreintegrateIMU(const std::vector<ImuSample>& m, double t_prev, double t_cur
             for (int k = 0; k < 3; ++k) { acc[k] = m[i].a[k]; angVel[k] = m[i].w[k]; }
             tstep = (float)(t_cur - t_prev);
         }
-        p.IntegrateNewMeasurement(acc, angVel, tstep);
+        if (float_eval) p.IntegrateNewMeasurementFloat(acc, angVel, tstep);
+        else p.IntegrateNewMeasurement(acc, angVel, tstep);
     }
     return n;
 }

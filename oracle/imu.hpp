@@ -27,6 +27,9 @@ struct Preintegrated {
     int n_measurements = 0;
     Preintegrated(const ImuBias& b_, float ng, float na, float ngw, float naw);
     void IntegrateNewMeasurement(const float acc[3], const float angVel[3], float dt);
+    // the same update evaluated in FLOAT, expression by expression in Eigen's order (imu.cpp "float evaluation"): what the product's
+    // tc2li_imu_integrate is held to bit for bit; the double form above stays the accuracy check
+    void IntegrateNewMeasurementFloat(const float acc[3], const float angVel[3], float dt);
     void GetDeltaRotation(const ImuBias& b_, float out[9]) const;
     void GetDeltaVelocity(const ImuBias& b_, float out[3]) const;
     void GetDeltaPosition(const ImuBias& b_, float out[3]) const;
@@ -34,12 +37,13 @@ struct Preintegrated {
 
 // Tracking::PreintegrateIMU: integrates the samples between the previous and the current frame into p (and returns how many
 // integration steps were made).  samples = mvImuFromLastFrame (already selected by the queue logic, Tracking.cc:1731-1764).
-int PreintegrateIMU(const std::vector<ImuSample>& samples, double t_prev, double t_cur, Preintegrated& p);
+int PreintegrateIMU(const std::vector<ImuSample>& samples, double t_prev, double t_cur, Preintegrated& p, bool float_eval = false);
 
 // Tracking::PredictStateIMU (either branch): state 1 + pre-integration (evaluated at bias b) -> state 2
 void PredictStateIMU(const Preintegrated& p, const ImuBias& b, const float Rwb1[9], const float twb1[3], const float Vwb1[3],
                      float Rwb2[9], float twb2[3], float Vwb2[3]);
 
 void NormalizeRotation(const float R[9], float out[9]);
+void NormalizeRotationFloat(const float R[9], float out[9]);  // Eigen::JacobiSVD<Matrix3f> restated in float: U V^T
 
 }  // namespace oracle

@@ -612,12 +612,13 @@ def balm_evaluate(Twl, clouds, eval_Twl=None):
 IMU_SAMPLE_DTYPE = np.dtype([("t", "<f8"), ("a", "<f4", (3,)), ("w", "<f4", (3,))])
 
 
-def imu_preintegrate(samples, t_prev, t_cur, bias6, ng, na, ngw, naw):
-    """Tracking::PreintegrateIMU into a fresh IMU::Preintegrated -> (steps, dict of its fields)."""
+def imu_preintegrate(samples, t_prev, t_cur, bias6, ng, na, ngw, naw, float_eval=False):
+    """Tracking::PreintegrateIMU into a fresh IMU::Preintegrated -> (steps, dict of its fields).  float_eval: every update in float, in
+    Eigen's order of evaluation (the form the product is held to bit for bit) instead of in double."""
     s = np.ascontiguousarray(samples, IMU_SAMPLE_DTYPE)
     b = np.ascontiguousarray(bias6, np.float32)
     out = np.zeros(292, np.float32)
-    f = lib().oracle_imu_preintegrate
+    f = lib().oracle_imu_preintegrate_f32 if float_eval else lib().oracle_imu_preintegrate
     f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
     steps = f(s.ctypes.data, len(s), t_prev, t_cur, b.ctypes.data, ng, na, ngw, naw, out.ctypes.data)
     names = [("dR", 9), ("dV", 3), ("dP", 3), ("JRg", 9), ("JVg", 9), ("JVa", 9), ("JPg", 9), ("JPa", 9), ("avgA", 3), ("avgW", 3), ("C", 225)]
@@ -641,11 +642,12 @@ def imu_predict(samples, t_prev, t_cur, bias6, bias_eval6, ng, na, ngw, naw, Rwb
     return out[:9].reshape(3, 3), out[9:12], out[12:15], out[15:24].reshape(3, 3), out[24:27], out[27:30]
 
 
-def normalize_rotation(R):
+def normalize_rotation(R, float_eval=False):
     R = np.ascontiguousarray(R, np.float32)
     out = np.zeros(9, np.float32)
-    lib().oracle_normalize_rotation.argtypes = [C.c_void_p, C.c_void_p]
-    lib().oracle_normalize_rotation(R.ctypes.data, out.ctypes.data)
+    f = lib().oracle_normalize_rotation_f32 if float_eval else lib().oracle_normalize_rotation
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f(R.ctypes.data, out.ctypes.data)
     return out.reshape(3, 3)
 
 

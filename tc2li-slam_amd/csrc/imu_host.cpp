@@ -24,42 +24,100 @@ inline M3f operator*(const M3f& a, const M3f& b) {
     return o;
 }
 inline M3f operator*(const M3f& a, float s) { M3f o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] * s; return o; }
+inline M3f operator/(const M3f& a, float s) { M3f o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] / s; return o; }
 inline M3f operator+(const M3f& a, const M3f& b) { M3f o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] + b.m[k]; return o; }
 inline M3f operator-(const M3f& a, const M3f& b) { M3f o; for (int k = 0; k < 9; ++k) o.m[k] = a.m[k] - b.m[k]; return o; }
 inline M3f transpose(const M3f& a) { M3f o; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o(r, c) = a(c, r); return o; }
 inline M3f hat(const float v[3]) { return M3f{{0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}}; }
 inline void mulv(const M3f& a, const float v[3], float o[3]) { for (int r = 0; r < 3; ++r) o[r] = a(r, 0) * v[0] + a(r, 1) * v[1] + a(r, 2) * v[2]; }
 
-// IMU::NormalizeRotation: U V^T of the SVD of R (Eigen::JacobiSVD in the reference) -- here by one-sided Jacobi rotations
-// on the columns: R V = U S, so U V^T = (R V) S^-1 V^T.
-M3f normalize_rotation(const M3f& R) {
-    M3f A = R, V = ident();
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        float off = 0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                float app = 0, aqq = 0, apq = 0;
-                for (int k = 0; k < 3; ++k) { app += A(k, p) * A(k, p); aqq += A(k, q) * A(k, q); apq += A(k, p) * A(k, q); }
-                off = fmaxf(off, fabsf(apq) / sqrtf(fmaxf(app * aqq, 1e-30f)));
-                if (fabsf(apq) <= 1e-12f * sqrtf(app * aqq)) continue;
-                const float tau = (aqq - app) / (2.0f * apq);
-                const float t = (tau >= 0 ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(1.0f + tau * tau));
-                const float c = 1.0f / sqrtf(1.0f + t * t), s = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    const float x = A(k, p), y = A(k, q);
-                    A(k, p) = c * x - s * y; A(k, q) = s * x + c * y;
-                    const float vx = V(k, p), vy = V(k, q);
-                    V(k, p) = c * vx - s * vy; V(k, q) = s * vx + c * vy;
-                }
-            }
-        if (off < 1e-7f) break;
+// IMU::NormalizeRotation (ImuTypes.cc:41-44): U V^T of Eigen::JacobiSVD<Matrix3f>(R, ComputeFullU | ComputeFullV).  Eigen's algorithm
+// for a square real matrix, step for step (JacobiSVD.h compute(), real_2x2_jacobi_svd; Jacobi.h makeJacobi / apply_rotation_in_the_plane):
+// the matrix divided by its largest |entry|; sweeps over the pairs (p, q), q < p, until every off-diagonal pair is below
+// 2 eps x the largest diagonal entry met so far; a pair is diagonalised by a left rotation that symmetrises its 2 x 2 block times a
+// Jacobi rotation, U and V accumulate the rotations; negative diagonal entries flip their column of U; the singular values are
+// brought into descending order with their columns.  (Rounds 1-3 used one-sided Jacobi rotations: the same matrix to a few ulps.)
+struct JRot { float c, s; };
+inline JRot jrot_T(const JRot& j) { return JRot{j.c, -j.s}; }
+inline void rotate_rows(M3f& m, int p, int q, const JRot& j) {  // applyOnTheLeft(p, q, j)
+    if (j.c == 1.0f && j.s == 0.0f) return;
+    for (int i = 0; i < 3; ++i) {
+        const float x = m(p, i), y = m(q, i);
+        m(p, i) = j.c * x + j.s * y;
+        m(q, i) = -j.s * x + j.c * y;
     }
-    M3f U;
-    for (int c = 0; c < 3; ++c) {
-        float n = 0;
-        for (int k = 0; k < 3; ++k) n += A(k, c) * A(k, c);
-        n = sqrtf(n);
-        for (int k = 0; k < 3; ++k) U(k, c) = n > 0 ? A(k, c) / n : (k == c ? 1.0f : 0.0f);
+}
+inline void rotate_cols(M3f& m, int p, int q, const JRot& j_right) {  // applyOnTheRight(p, q, j): the plane rotation j^T on the columns
+    const JRot j = jrot_T(j_right);
+    if (j.c == 1.0f && j.s == 0.0f) return;
+    for (int i = 0; i < 3; ++i) {
+        const float x = m(i, p), y = m(i, q);
+        m(i, p) = j.c * x + j.s * y;
+        m(i, q) = -j.s * x + j.c * y;
+    }
+}
+M3f normalize_rotation(const M3f& R) {
+    const float eps2 = 2.0f * 1.1920929e-7f, tiny = 1.17549435e-38f;  // 2 * NumTraits<float>::epsilon(), numeric_limits<float>::min()
+    float scale = 0;
+    for (int k = 0; k < 9; ++k) scale = fmaxf(scale, fabsf(R.m[k]));
+    if (scale == 0.0f) scale = 1.0f;
+    M3f W, U = ident(), V = ident();
+    for (int k = 0; k < 9; ++k) W.m[k] = R.m[k] / scale;
+    float max_diag = fmaxf(fabsf(W(0, 0)), fmaxf(fabsf(W(1, 1)), fabsf(W(2, 2))));
+    bool finished = false;
+    while (!finished) {
+        finished = true;
+        for (int p = 1; p < 3; ++p)
+            for (int q = 0; q < p; ++q) {
+                const float threshold = fmaxf(tiny, eps2 * max_diag);
+                if (!(fabsf(W(p, q)) > threshold || fabsf(W(q, p)) > threshold)) continue;
+                finished = false;
+                float a = W(p, p), b = W(p, q), c = W(q, p), d = W(q, q);
+                JRot r1{1.0f, 0.0f};
+                const float t = a + d, df = c - b;
+                if (!(fabsf(df) < tiny)) {
+                    const float u = t / df, tmp = sqrtf(1.0f + u * u);
+                    r1.s = 1.0f / tmp;
+                    r1.c = u / tmp;
+                    const float a0 = a, b0 = b, c0 = c, d0 = d;
+                    a = r1.c * a0 + r1.s * c0; b = r1.c * b0 + r1.s * d0;
+                    c = -r1.s * a0 + r1.c * c0; d = -r1.s * b0 + r1.c * d0;
+                }
+                JRot jr{1.0f, 0.0f};  // makeJacobi(a, b, d)
+                const float deno = 2.0f * fabsf(b);
+                if (!(deno < tiny)) {
+                    const float tau = (a - d) / deno, w = sqrtf(tau * tau + 1.0f);
+                    const float tt = tau > 0.0f ? 1.0f / (tau + w) : 1.0f / (tau - w);
+                    const float sign_t = tt > 0.0f ? 1.0f : -1.0f, n = 1.0f / sqrtf(tt * tt + 1.0f);
+                    jr.s = -sign_t * (b / fabsf(b)) * fabsf(tt) * n;
+                    jr.c = n;
+                }
+                const JRot jrt = jrot_T(jr);
+                const JRot jl{r1.c * jrt.c - r1.s * jrt.s, r1.c * jrt.s + r1.s * jrt.c};  // rot1 * j_right^T
+                rotate_rows(W, p, q, jl);
+                rotate_cols(U, p, q, jrot_T(jl));
+                rotate_cols(W, p, q, jr);
+                rotate_cols(V, p, q, jr);
+                max_diag = fmaxf(max_diag, fmaxf(fabsf(W(p, p)), fabsf(W(q, q))));
+            }
+    }
+    float sv[3];
+    for (int i = 0; i < 3; ++i) {
+        const float a = W(i, i);
+        sv[i] = fabsf(a);
+        if (a < 0.0f) for (int r = 0; r < 3; ++r) U(r, i) = -U(r, i);
+    }
+    for (int i = 0; i < 3; ++i) {
+        int pos = i;
+        for (int k = i + 1; k < 3; ++k) if (sv[k] > sv[pos]) pos = k;
+        if (sv[pos] == 0.0f) break;
+        if (pos != i) {
+            const float ts = sv[i]; sv[i] = sv[pos]; sv[pos] = ts;
+            for (int r = 0; r < 3; ++r) {
+                const float tu = U(r, i); U(r, i) = U(r, pos); U(r, pos) = tu;
+                const float tv = V(r, i); V(r, i) = V(r, pos); V(r, pos) = tv;
+            }
+        }
     }
     return U * transpose(V);
 }
@@ -128,9 +186,11 @@ void integrate(tc2li_preintegrated& p, const float acceleration[3], const float 
         deltaR = ident() + W;
         rightJ = ident();
     } else {
+        // Eigen evaluates `W*sin(d)/d` as (W * sin d) / d and `W*W*(1.0f-cos(d))/d2` as ((W W) (1 - cos d)) / d2 (ImuTypes.cc:111-112): the
+        // scalar multiplies the matrix before the division (round 3 scaled by the quotient: the last bit of an entry could differ)
         const M3f W2 = W * W;
-        deltaR = ident() + W * (sinf(d) / d) + W2 * ((1.0f - cosf(d)) / d2);
-        rightJ = ident() - W * ((1.0f - cosf(d)) / d2) + W2 * ((d - sinf(d)) / (d2 * d));
+        deltaR = ident() + (W * sinf(d)) / d + (W2 * (1.0f - cosf(d))) / d2;
+        rightJ = ident() - (W * (1.0f - cosf(d))) / d2 + (W2 * (d - sinf(d))) / (d2 * d);
     }
     dR = normalize_rotation(dR * deltaR);
     const M3f dRiT = transpose(deltaR);

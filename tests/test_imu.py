@@ -40,6 +40,43 @@ def test_preintegration_matches_the_oracle(pkg, oracle, synthetic, noise, seed, 
     assert np.allclose(got["dR"] @ got["dR"].T, np.eye(3), atol=1e-6) and abs(np.linalg.det(got["dR"].astype(np.float64)) - 1) < 1e-6
 
 
+@pytest.mark.parametrize("seed,t0,t1,jitter", [(0, 1.003, 1.104, 0.0), (1, 2.5, 2.6, 0.0), (2, 0.101, 0.499, 0.3), (3, 5.0, 5.021, 0.0), (7, 3.0, 4.0, 0.5)])
+def test_preintegration_equals_the_float_oracle_bit_for_bit(pkg, oracle, synthetic, noise, seed, t0, t1, jitter):
+    """the oracle's FLOAT evaluation (IntegrateNewMeasurementFloat: the reference's Eigen expressions one node at a
+    time in the order the source associates them, ImuTypes.cc:186-244, NormalizeRotation as Eigen's two-sided Jacobi SVD) against
+    tc2li_imu_preintegrate: every field of IMU::Preintegrated, the covariance included, bit for bit -- the order of evaluation is now
+    tested, not only the value to 2e-5 (the double form above stays as the accuracy check)."""
+    s = synthetic.imu_samples(t0, t1, seed=seed, jitter=jitter)
+    bias = np.array([0.02, -0.01, 0.03, 0.001, -0.002, 0.0005], np.float32)
+    p = pkg.capi.Preintegrated(bias, *noise)
+    steps = p.preintegrate(s, t0, t1)
+    osteps, want = oracle.imu_preintegrate(s, t0, t1, bias, *noise, float_eval=True)
+    got = p.fields()
+    assert steps == osteps and np.float32(got["dT"]) == np.float32(want["dT"])
+    for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa", "avgA", "avgW", "C"):
+        assert np.array_equal(got[name], want[name]), (name, np.abs(got[name] - want[name]).max())
+    # and the float evaluation is the double one to float rounding
+    _, dbl = oracle.imu_preintegrate(s, t0, t1, bias, *noise)
+    for name in ("dR", "dV", "dP", "JRg", "JVg", "JVa", "JPg", "JPa"):
+        assert close(want[name], dbl[name]), name
+
+
+def test_normalize_rotation_float_is_a_rotation_close_to_the_polar_factor(oracle):
+    """The float SVD form of IMU::NormalizeRotation (restated from Eigen's JacobiSVD) against the double polar factor: orthogonal, det +1,
+    the same matrix to float rounding -- for near-rotations (what the pre-integration feeds it) and for scaled / skewed inputs."""
+    rng = np.random.default_rng(3)
+    for k in range(200):
+        R = Rotation.from_rotvec(rng.normal(0, 1.0, 3)).as_matrix()
+        if k % 2:
+            R = R + rng.normal(0, 1e-3 if k % 4 == 1 else 5e-2, (3, 3))
+        if k % 5 == 0:
+            R = R * rng.uniform(0.5, 20.0)
+        got = oracle.normalize_rotation(R.astype(np.float32), float_eval=True).astype(np.float64)
+        want = oracle.normalize_rotation(R.astype(np.float32)).astype(np.float64)
+        assert np.allclose(got @ got.T, np.eye(3), atol=5e-6) and abs(np.linalg.det(got) - 1) < 5e-6
+        assert np.allclose(got, want, atol=3e-6), (k, np.abs(got - want).max())
+
+
 def test_constant_signal_closed_form(pkg, noise):
     """Constant angular velocity about z and constant specific force: dR = Exp(w T); dV, dP against a fine numerical integral."""
     w = np.array([0, 0, 0.3], np.float32); a = np.array([1.0, 0.5, 9.0], np.float32)
