@@ -86,14 +86,15 @@ void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, do
 void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st);
 
 // ---- lock-step batch (tc2li_local_bundle_adjustment_batch): one launch per phase for all windows ----
-// A slot describes one window for the batched kernels; the table lives in device memory and is rewritten by the host before a
-// phase whenever a window's state (accepted / trial buffers, lambda, step) changed.
+// A slot describes one window for the batched kernels.  Since round 4 the table goes up ONCE per call, with the windows' input blocks
+// (rounds 2-3 rewrote it before every phase: 30 one-entry copy launches per call, in configs[3] the largest line of the kernel table);
+// what changes from phase to phase travels in the kernels' arguments (BaPhase).
 struct BaBatchSlot {
-    BaProblemDev pb;
-    double lambda;
-    int32_t n_slices, k_per_slice, want_maxdiag, has_lidar;
+    BaProblemDev pb;       // poses / points = the buffers the call starts from (BaPhase's parity bit swaps them with the trial buffers)
+    int32_t n_slices, k_per_slice, has_lidar, pad_;
     double *chi_out, *maxdiag_out, *S_out, *bs_out, *scale_out, *chi_trial_out;
-    double* hpp_out;  // NULL, or where the host wants Hpp / b_p too (pinned)
+    double* hpp_out;  // where the host wants Hpp / b_p when the phase asks for them (pinned; BaPhase flag)
+    ImuPose* iposes_host;  // inertial windows: the trial ImuCamPose states for the host's inertial cost (pinned; written by the trial kernel)
     // the reduced system solved on the device (k_ba_solve_b; S_out / bs_out are device buffers then): b_p for the host's gain-ratio scale,
     // the LiDAR term's (6K)^2 Hessian and 6K gradient to add (NULL: none), the step for the trial kernels (= xp) and for the host, and
     // whether the LDL^T went through
@@ -101,10 +102,24 @@ struct BaBatchSlot {
     const double *Hl, *bl_lidar;
     double *x_dev, *x_host;
     int32_t* ok_host;
-    const double* xp;
+    const double* xp;      // the step when the phase's staging area does not hold it (a window of more than kBaXpStride / 6 free poses; device solve)
     uint8_t* depth_out;
     BalmDev balm;
 };
+// The windows of one launch and their state in this phase, passed BY VALUE in the kernel arguments (HIP gives a kernel 4 KB of them):
+// workgroups of window position y = blockIdx.y (z for the tiled GEMM) work on table[win[y]].
+constexpr int kBaPhaseMax = 192;   // windows per launch; a longer phase list is launched in pieces
+constexpr int kBaXpStride = 192;   // doubles per window in the staging area of the steps x_p: 6 x 32 free keyframes
+struct BaPhase {
+    const BaBatchSlot* table;      // the call's table in device memory
+    const double* xp_area;         // steps of a trial phase, window position y at (first + y) * kBaXpStride; NULL: slot.xp
+    int32_t first, pad_;           // position of win[0] in the phase's list
+    uint16_t win[kBaPhaseMax];
+    uint8_t flags[kBaPhaseMax];    // kBaAcceptedInTrial: the accepted estimate lives in the trial buffers (an odd number of accepted steps);
+                                   // kBaWantMaxdiag: computeLambdaInit's diagonal maxima; kBaWantHpp: Hpp / b_p to slot.hpp_out
+    double lambda[kBaPhaseMax];
+};
+constexpr unsigned kBaAcceptedInTrial = 1, kBaWantMaxdiag = 2, kBaWantHpp = 4;
 struct BaBatchExtent {
     int max_edges, max_points, max_poses, max_free, max_free_edges, max_groups, max_np_pad, max_slices, max_planes, max_chunks, max_W;
     // max_np_pad / max_slices: over the windows on the dense Schur path; the sparse ones:
@@ -112,15 +127,16 @@ struct BaBatchExtent {
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
 };
-void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
-void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+// n_active <= kBaPhaseMax windows per call (the host cuts a longer list)
+void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);
+void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 // x = (S + Hl)^-1 (b_s + bl) per window by dense LDL^T, one workgroup per window (windows of at most 21 free keyframes)
-void ba_batch_launch_solve(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
-void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
-void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st);
+void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
+void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
+void ba_batch_launch_depth(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 // the LiDAR term of the listed windows (all with W <= 7 and at most 2048 planes): residual at the accepted or the trial poses,
 // Jacobian / Hessian at the accepted poses
-void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st);
-void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st);
+void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st);
+void balm_batch_launch_hessian(const BaPhase& ph, int n, const BaBatchExtent& x, hipStream_t st);
 
 }  // namespace tc2li

@@ -1097,10 +1097,35 @@ struct LockstepWindow {
     double *Hl = nullptr, *bl_ = nullptr;  // the LiDAR term's (6K)^2 Hessian and 6K gradient (pinned: ws->h_Hl)
     double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, max_pose_diag = 0;
     int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
+    int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot (an odd number of accepted steps)
     bool ok = true, ok2 = true, need_diag = false, want_maxdiag = false;
+    bool wants_hpp() const { return need_diag; }
     bool stopped() const { return p->stop_flag && *p->stop_flag; }
     bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
 };
+
+// The windows `list[c0 .. c1)` of a phase as kernel arguments (ba_device.hpp BaPhase): table index, parity / request bits, lambda.
+template <typename Win>
+BaPhase make_phase(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, size_t c0, size_t c1) {
+    BaPhase ph;
+    ph.table = d_table; ph.xp_area = d_xp_area; ph.first = (int32_t)c0; ph.pad_ = 0;
+    for (size_t k = c0; k < c1; ++k) {
+        const Win& w = W[list[k]];
+        ph.win[k - c0] = (uint16_t)list[k];
+        ph.flags[k - c0] = (uint8_t)((w.parity ? kBaAcceptedInTrial : 0u) | (w.want_maxdiag ? kBaWantMaxdiag : 0u) | (w.wants_hpp() ? kBaWantHpp : 0u));
+        ph.lambda[k - c0] = w.lambda;
+    }
+    return ph;
+}
+// fn(phase, windows in it) for every piece of at most kBaPhaseMax windows of `list`
+template <typename Win, typename Fn>
+void for_phase_pieces(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, Fn&& fn) {
+    for (size_t c0 = 0; c0 < list.size(); c0 += kBaPhaseMax) {
+        const size_t c1 = std::min(list.size(), c0 + (size_t)kBaPhaseMax);
+        const BaPhase ph = make_phase(d_table, d_xp_area, W, list, c0, c1);
+        fn(ph, (int)(c1 - c0));
+    }
+}
 
 struct LockstepContext {
     std::mutex mu;
@@ -1109,7 +1134,7 @@ struct LockstepContext {
     DevBuf<uint8_t> d_table;
     PinnedBuf<uint8_t> h_table;
     PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
-    PinnedBuf<CopyTask> h_table_task;  // the slot table's way up: one entry for k_copy_tasks (see `upload` in the lock-step loops)
+    PinnedBuf<CopyTask> h_table_task;  // the steps x_p of a trial phase on their way up: one entry for k_copy_tasks
     hipStream_t st = nullptr;
     ~LockstepContext() { if (st) (void)hipStreamDestroy(st); }
 };
@@ -1136,21 +1161,18 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    // the slot table: every window's slot on the host; before a phase the slots of the windows taking part are copied, in launch
-    // order, into the two device lists (A: the phase's windows, B: those of them with a LiDAR term) -- a kernel's workgroup finds its
-    // window at blockIdx without going through an index list first
-    // behind the two lists: the steps x_p of the windows of a trial phase (kXpStride doubles each), so that the trial kernels read them
-    // from device memory (they read the solver's pinned buffer before: a bus round trip at the start of every workgroup)
-    constexpr size_t kXpStride = 192;  // doubles: 6 x 32 free keyframes; a larger window keeps reading the pinned buffer
-    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
-    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes + (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)(C.h_table.p + table_bytes + xp_bytes);
-    BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
+    // the slot table: one slot per window, filled once after the setup and uploaded with the windows' input blocks; what a phase changes
+    // (which windows take part, lambda, which of a slot's two buffers holds the accepted estimate) travels in the kernels' arguments
+    // (BaPhase).  Behind the table: the steps x_p of the windows of a trial phase (kBaXpStride doubles each), so that the trial kernels
+    // read them from device memory (a window with more free keyframes than that keeps reading the solver's pinned buffer).
+    if (n > 65535) return false;  // BaPhase names a window by 16 bits
+    constexpr size_t kXpStride = kBaXpStride;
+    const size_t table_bytes = (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
+    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
     double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
-    const double* const d_xp_area = (const double*)(C.d_table.p + table_bytes);
-    static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
-    const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
-    const BaBatchSlot* const d_slots_lidar = d_slots + n;
+    const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
+    double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LockstepWindow> W(n);
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1200,21 +1222,13 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             w.rc = TC2LI_ERR_HIP; return;
         }
         if (p.lidar) {
+            // computeLambdaInit with a LiDAR term reads the diagonal of Hpp on the host (first iteration, no lambda given): where the reduction writes it
+            if (ws.h_Hpp.ensure(27 * (size_t)std::max(w.vp.n_free, 1)) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
             if (ws.d_Hl.ensure(nn + n1) != hipSuccess || ws.h_Hl.ensure(nn + n1) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
             w.Hl = ws.h_Hl.p; w.bl_ = ws.h_Hl.p + nn;
             std::fill(w.Hl, w.Hl + nn + n1, 0.0);
         }
     });
-    {
-        size_t n_tasks = 0, max_bytes = 0;
-        for (const auto& d : deferred) n_tasks += d.size();
-        if (n_tasks) {
-            if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
-            size_t at = 0;
-            for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-            launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-        }
-    }
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0 || !problems[i].lidar) continue;
         if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
@@ -1258,12 +1272,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         LockstepWindow& w = W[i];
         BaBatchSlot& s = h_slots[i];
         s.pb = w.vp.pb;
-        s.lambda = w.lambda;
-        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.want_maxdiag = w.want_maxdiag; s.has_lidar = w.lidar != nullptr;
+        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
         double* sc = w.ws->h_scal.p;
         s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
         s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
-        s.hpp_out = w.need_diag ? w.ws->h_Hpp.p : nullptr;
+        s.hpp_out = w.lidar ? w.ws->h_Hpp.p : nullptr;  // written when a phase asks for it (kBaWantHpp)
+        s.iposes_host = nullptr;
         s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
         if (dev_solve) {
             const size_t nn = (size_t)w.vp.np * w.vp.np;
@@ -1281,20 +1295,30 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         else pool.parallel_for(cnt, fn);
     };
     bool failed = false;
-    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b, int n_xp = 0) {  // list a at d_slots[0..), list b at d_slots_lidar[0..); n_xp: steps behind them
-        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
-        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
-        const size_t bytes = n_xp ? table_bytes + (size_t)n_xp * kXpStride * sizeof(double) : (b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes);
-        // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
-        // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
-        // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
-        // TC2LI_BA_ZERO_COPY_SLOTS=1: the kernels read the pinned table themselves (same step time, every kernel slower).
-        if (bytes && !kZeroCopySlots) {
-            if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
-            C.h_table_task.p[0] = CopyTask{C.d_table.p, C.h_table.p, bytes};
-            launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
+    // the table and everything the setup deferred (uploads, operand fills): one launch; the windows' megabyte input blocks go through the copy engines (launch_copy_tasks)
+    {
+        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) fill_slot(i); else h_slots[i] = BaBatchSlot{};
+        size_t n_tasks = 1, max_bytes = table_bytes;
+        for (const auto& d : deferred) n_tasks += d.size();
+        if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
+        size_t at = 0;
+        C.h_tasks.p[at++] = CopyTask{C.d_table.p, C.h_table.p, table_bytes};
+        for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+        launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
+    }
+    // the steps of a trial phase: window k of `step` at h_xp_area + k * kXpStride, up through a one-entry k_copy_tasks launch on the group's
+    // own stream (not hipMemcpyAsync: the runtime's copy path is where the other groups' 1.4 MB window blocks are queued)
+    auto stage_steps = [&](const std::vector<int>& step) {
+        for (size_t k = 0; k < step.size(); ++k) {
+            const LockstepWindow& w = W[step[k]];
+            if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
+            memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
         }
+        if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
+        C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
+        launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
     };
+    auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
     for (;;) {
@@ -1310,18 +1334,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             w.need_diag = w.lidar && w.want_maxdiag && w.vp.n_free > 0;
             any_maxdiag |= w.want_maxdiag;
             if (w.lidar) with_lidar.push_back(i);
-            if (w.need_diag && w.ws->h_Hpp.ensure(27 * (size_t)w.vp.n_free) != hipSuccess) failed = true;  // the reduction writes it (slot.hpp_out)
-            fill_slot(i);
         }
-        upload(active, with_lidar);
-        ba_batch_launch_linearize(d_slots, nullptr, (int)active.size(), X, any_maxdiag, st);
+        pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, any_maxdiag, st); });
         // (running the LiDAR kernels on a second stream beside the visual ones was measured: no gain, the chain is not the limit there)
         // the residual pass at the accepted estimate: only before the first iteration -- later the accepted estimate is the last
         // trial, whose residual and plane decompositions are still in place (same bits)
         bool first_pass = false;
         for (int i : with_lidar) first_pass |= W[i].it == 0;
-        if (first_pass) balm_batch_launch_residual(d_slots_lidar, nullptr, (int)with_lidar.size(), false, st);
-        balm_batch_launch_hessian(d_slots_lidar, nullptr, (int)with_lidar.size(), X, st);
+        pieces(with_lidar, nullptr, [&](const BaPhase& ph, int cnt) {
+            if (first_pass) balm_batch_launch_residual(ph, cnt, false, st);
+            balm_batch_launch_hessian(ph, cnt, X, st);
+        });
         tm[6] += now() - t0;  // of the phase: the time to queue it
         sync();
         if (failed) break;
@@ -1374,17 +1397,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         while (!trial.empty() && !failed) {
             // phase B: reduced camera system at the window's lambda
             t0 = now();
-            for (int i : trial) fill_slot(i);
             if (dev_solve) {
                 // phases B + C in one queue: Schur product, solve, trial estimate and its cost; the host sees the step, whether the
                 // factorisation went through, and the sums at the one synchronisation
                 std::vector<int> trial_lidar;
                 for (int i : trial) if (W[i].lidar) trial_lidar.push_back(i);
-                upload(trial, trial_lidar);
-                ba_batch_launch_schur(d_slots, nullptr, (int)trial.size(), X, st);
-                ba_batch_launch_solve(d_slots, nullptr, (int)trial.size(), X, st);
-                ba_batch_launch_trial(d_slots, nullptr, (int)trial.size(), X, st);
-                balm_batch_launch_residual(d_slots_lidar, nullptr, (int)trial_lidar.size(), true, st);
+                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) {
+                    ba_batch_launch_schur(ph, cnt, X, st);
+                    ba_batch_launch_solve(ph, cnt, X, st);
+                    ba_batch_launch_trial(ph, cnt, X, st);
+                });
+                pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
                 sync();
                 if (failed) break;
                 tm[3] += now() - t0; t0 = now();
@@ -1402,8 +1425,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                 }
                 tm[4] += now() - t0; t0 = now();
             } else {
-            upload(trial, {});
-            ba_batch_launch_schur(d_slots, nullptr, (int)trial.size(), X, st);
+            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
             sync();
             if (failed) break;
             tm[3] += now() - t0; t0 = now();
@@ -1429,19 +1451,9 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             std::vector<int> step, step_lidar;
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
-                int n_xp = 0;
-                if (!dev_solve && !kZeroCopySlots) {
-                    n_xp = (int)step.size();
-                    for (size_t k = 0; k < step.size(); ++k) {
-                        LockstepWindow& w = W[step[k]];
-                        if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
-                        memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
-                        h_slots[step[k]].xp = d_xp_area + k * kXpStride;
-                    }
-                }
-                upload(step, step_lidar, n_xp);  // slots unchanged since phase B but for the steps' place
-                ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
-                balm_batch_launch_residual(d_slots_lidar, nullptr, (int)step_lidar.size(), true, st);
+                stage_steps(step);
+                pieces(step, d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
+                pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
                 sync();
                 if (failed) break;
             }
@@ -1467,8 +1479,9 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                     w.lambda *= std::max(1. / 3., alpha);
                     w.ni = 2;
                     w.currentChi = w.tempChi;
-                    std::swap(w.vp.pb.poses, w.vp.pb.poses_trial);
+                    std::swap(w.vp.pb.poses, w.vp.pb.poses_trial);  // the host's record (the results are read through it); the device's view: parity
                     std::swap(w.vp.pb.points, w.vp.pb.points_trial);
+                    w.parity ^= 1;
                 } else {
                     w.lambda *= w.ni;
                     w.ni *= 2;
@@ -1492,10 +1505,9 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // ---- results ----
     t0 = now();
     std::vector<int> all;
-    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
+    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) all.push_back(i);
     if (!failed && !all.empty()) {
-        upload(all, {});
-        ba_batch_launch_depth(d_slots, nullptr, (int)all.size(), X, st);
+        pieces(all, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_depth(ph, cnt, X, st); });
         // device -> pinned staging: one launch writes every window's results (the setup's copy list is done with: the stream has been
         // synchronised many times since), then the copies into the caller's arrays run in parallel
         size_t n_tasks = 0, max_bytes = 0;
@@ -1567,7 +1579,9 @@ struct LviWindow {
     std::vector<double> M, rhs, bfull, x;
     double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, chi_imu = 0, last_chi = 0;
     int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
+    int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot
     bool ok = true, ok2 = true, want_maxdiag = false;
+    bool wants_hpp() const { return false; }
     bool stopped() const { return p->stop_flag && *p->stop_flag; }
     bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
 };
@@ -1587,18 +1601,15 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    // behind the two lists: the steps x_p of the windows of a trial phase (kXpStride doubles each), so that the trial kernels read them
-    // from device memory (they read the solver's pinned buffer before: a bus round trip at the start of every workgroup)
-    constexpr size_t kXpStride = 192;  // doubles: 6 x 32 free keyframes; a larger window keeps reading the pinned buffer
-    const size_t table_bytes = 2 * (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
-    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes + (size_t)n * sizeof(BaBatchSlot)) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)(C.h_table.p + table_bytes + xp_bytes);
-    BaBatchSlot* const h_lists = (BaBatchSlot*)C.h_table.p;
+    // the slot table and the steps' staging area, as in ba_batch_lockstep: the table goes up once, a phase's state in the kernels' arguments
+    if (n > 65535) return false;
+    constexpr size_t kXpStride = kBaXpStride;
+    const size_t table_bytes = (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
+    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes) != hipSuccess) return false;
+    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
     double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
-    const double* const d_xp_area = (const double*)(C.d_table.p + table_bytes);
-    static const bool kZeroCopySlots = getenv("TC2LI_BA_ZERO_COPY_SLOTS") && atoi(getenv("TC2LI_BA_ZERO_COPY_SLOTS")) != 0;  // experiment: kernels read the pinned table
-    const BaBatchSlot* const d_slots = kZeroCopySlots ? (const BaBatchSlot*)C.h_table.p : (const BaBatchSlot*)C.d_table.p;
-    const BaBatchSlot* const d_slots_lidar = d_slots + n;
+    const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
+    double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LviWindow> W(n);
     // ---- setup: argument checks, inertial links, plane extraction (host), uploads ----
     std::vector<int> rc_lidar(n, 0);
@@ -1651,16 +1662,6 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         const int nn = w.inertial.n;
         w.M.assign((size_t)std::max(nn * nn, 1), 0.0); w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
     });
-    {
-        size_t n_tasks = 0, max_bytes = 0;
-        for (const auto& d : deferred) n_tasks += d.size();
-        if (n_tasks) {
-            if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
-            size_t at = 0;
-            for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-            launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-        }
-    }
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0 || !problems[i].lidar) continue;
         if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
@@ -1692,29 +1693,36 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         LviWindow& w = W[i];
         BaBatchSlot& s = h_slots[i];
         s.pb = w.vp.pb;
-        s.lambda = w.lambda;
-        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.want_maxdiag = w.want_maxdiag; s.has_lidar = w.lidar != nullptr;
+        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
         double* sc = w.ws->h_scal.p;
         s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
         s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
         s.hpp_out = nullptr; s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
+        s.iposes_host = w.ws->h_iposes.p;  // the trial kernel leaves the trial ImuCamPose states there for the host's inertial cost
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
     };
     bool failed = false;
-    auto upload = [&](const std::vector<int>& a, const std::vector<int>& b, int n_xp = 0) {
-        for (size_t k = 0; k < a.size(); ++k) h_lists[k] = h_slots[a[k]];
-        for (size_t k = 0; k < b.size(); ++k) h_lists[n + k] = h_slots[b[k]];
-        const size_t bytes = n_xp ? table_bytes + (size_t)n_xp * kXpStride * sizeof(double) : (b.empty() ? a.size() * sizeof(BaBatchSlot) : table_bytes);
-        // The table goes up through a one-entry k_copy_tasks launch on the group's own stream, not through hipMemcpyAsync: the runtime's
-        // copy path is where the other groups' 1.4 MB window blocks are queued, and a phase's 30 KB table waited behind them -- the three
-        // groups of a call ran half serialised (a call took 31 ms for groups of 16.5 ms; 27.5 ms now, 16.0 -> 16.8 k frames/s).
-        // TC2LI_BA_ZERO_COPY_SLOTS=1: the kernels read the pinned table themselves (same step time, every kernel slower).
-        if (bytes && !kZeroCopySlots) {
-            if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
-            C.h_table_task.p[0] = CopyTask{C.d_table.p, C.h_table.p, bytes};
-            launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
+    {   // the table and everything the setup deferred: one launch
+        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) fill_slot(i); else h_slots[i] = BaBatchSlot{};
+        size_t n_tasks = 1, max_bytes = table_bytes;
+        for (const auto& d : deferred) n_tasks += d.size();
+        if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
+        size_t at = 0;
+        C.h_tasks.p[at++] = CopyTask{C.d_table.p, C.h_table.p, table_bytes};
+        for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+        launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
+    }
+    auto stage_steps = [&](const std::vector<int>& step) {
+        for (size_t k = 0; k < step.size(); ++k) {
+            const LviWindow& w = W[step[k]];
+            if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
+            memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
         }
+        if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
+        C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
+        launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
     };
+    auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
     for (;;) {
@@ -1728,14 +1736,14 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             w.want_maxdiag = w.it == 0 && !(w.p->lambda_init > 0);
             any_maxdiag |= w.want_maxdiag;
             if (w.lidar) with_lidar.push_back(i);
-            fill_slot(i);
         }
-        upload(active, with_lidar);
-        ba_batch_launch_linearize(d_slots, nullptr, (int)active.size(), X, any_maxdiag, st);
+        pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, any_maxdiag, st); });
         // computeActiveErrors + linearizeOplus of the LiDAR edge: the residual at the accepted estimate and the Hessian, every iteration
         // (the one-window path's enqueue_error + enqueue_linearization)
-        balm_batch_launch_residual(d_slots_lidar, nullptr, (int)with_lidar.size(), false, st);
-        balm_batch_launch_hessian(d_slots_lidar, nullptr, (int)with_lidar.size(), X, st);
+        pieces(with_lidar, nullptr, [&](const BaPhase& ph, int cnt) {
+            balm_batch_launch_residual(ph, cnt, false, st);
+            balm_batch_launch_hessian(ph, cnt, X, st);
+        });
         pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
         sync();
         if (failed) break;
@@ -1772,9 +1780,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         // ---- trials ----
         std::vector<int> trial = active;
         while (!trial.empty() && !failed) {
-            for (int i : trial) fill_slot(i);
-            upload(trial, {});
-            ba_batch_launch_schur(d_slots, nullptr, (int)trial.size(), X, st);
+            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
             sync();
             if (failed) break;
             pool.parallel_for((int)trial.size(), [&](int k) {
@@ -1802,28 +1808,10 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             std::vector<int> step, step_lidar;
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
-                int n_xp = 0;
-                if (!kZeroCopySlots) {
-                    n_xp = (int)step.size();
-                    for (size_t k = 0; k < step.size(); ++k) {
-                        LviWindow& w = W[step[k]];
-                        if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
-                        memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
-                        h_slots[step[k]].xp = d_xp_area + k * kXpStride;
-                    }
-                }
-                upload(step, step_lidar, n_xp);
-                ba_batch_launch_trial(d_slots, nullptr, (int)step.size(), X, st);
-                if (C.h_tasks.ensure(step.size()) != hipSuccess) { failed = true; break; }
-                size_t max_bytes = 0;
-                for (size_t k = 0; k < step.size(); ++k) {  // the trial ImuCamPose states for the inertial cost
-                    LviWindow& w = W[step[k]];
-                    const size_t bytes = w.p->n_keyframes * sizeof(ImuPose);
-                    C.h_tasks.p[k] = CopyTask{w.ws->h_iposes.p, w.vp.pb.iposes_trial, bytes};
-                    max_bytes = std::max(max_bytes, bytes);
-                }
-                launch_copy_tasks(C.h_tasks.p, (int)step.size(), max_bytes, st);
-                balm_batch_launch_residual(d_slots_lidar, nullptr, (int)step_lidar.size(), true, st);
+                stage_steps(step);
+                // (the trial ImuCamPose states come back through slot.iposes_host, written by the trial kernel: a copy launch per trial before)
+                pieces(step, d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
+                pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
                 pool.parallel_for((int)step.size(), [&](int k) {  // velocity / bias part of the step, on the host
                     LviWindow& w = W[step[k]];
                     const int np = w.vp.np;
@@ -1860,6 +1848,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                     w.currentChi = w.tempChi;
                     std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);
                     std::swap(w.vp.pb.points, w.vp.pb.points_trial);
+                    w.parity ^= 1;
                     w.hp.swap(w.hp_trial);
                     w.sv.swap(w.sv_trial);
                 } else {
@@ -1884,10 +1873,9 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     }
     // ---- results ----
     std::vector<int> all;
-    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { all.push_back(i); fill_slot(i); }
+    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) all.push_back(i);
     if (!failed && !all.empty()) {
-        upload(all, {});
-        ba_batch_launch_depth(d_slots, nullptr, (int)all.size(), X, st);
+        pieces(all, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_depth(ph, cnt, X, st); });
         size_t n_tasks = 0, max_bytes = 0;
         if (C.h_tasks.ensure(3 * all.size()) != hipSuccess) failed = true;
         for (int i : all) {

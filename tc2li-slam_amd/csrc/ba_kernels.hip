@@ -68,9 +68,11 @@ __device__ __forceinline__ void block_sum_256(double v, double* s, double* __res
 // nbe on: the edges with a free pose in landmark-major order (fl_edge) -- the pose block B^T W B, B^T omega_r and W = B^T W A.  Two
 // roles instead of one thread doing both: four edges in ten have a free pose, and the pose part (most of the arithmetic and of the
 // bytes) ran with that share of its lanes; its W blocks now leave in slot order.  The error and the weight are simply formed again.
-__device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, const int bx) {
-    __shared__ double s_cp[256 * 9];
-    __shared__ uint8_t s_rows[256];
+// LDS of the two roles of the linearisation, declared by the kernel (one launch runs both: the roles share it)
+struct LinearizeLds { double big[256 * 9]; double small[256]; };
+__device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, const int bx, LinearizeLds& lds) {
+    double* const s_cp = lds.big;
+    uint8_t* const s_rows = reinterpret_cast<uint8_t*>(lds.small);
     const int s = bx * 256 + threadIdx.x;
     const bool valid = s < pb.n_free_edges;
     // the per-pose sums below: the block's rows sorted by pose and this thread's range of them, requested with the edge's own loads
@@ -153,9 +155,9 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
         __syncthreads();
     }
 }
-__device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int g) {
-    __shared__ double s_sum[256];
-    __shared__ double s_cl[256 * 9];
+__device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int g, LinearizeLds& lds) {
+    double* const s_sum = lds.small;
+    double* const s_cl = lds.big;
     const int k0 = pb.grp_k0[g], k1 = pb.grp_k0[g + 1], l0 = pb.grp_l0[g], l1 = pb.grp_l0[g + 1];
     const int k = k0 + (int)threadIdx.x;
     double rho0 = 0;
@@ -218,8 +220,12 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
     }
     block_sum_256(rho0, s_sum, pb.chi_part + g);  // the robust cost is summed per workgroup here, finished in the next launch
 }
-__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) { d_ba_linearize(pb, blockIdx.x); }
-__global__ __launch_bounds__(256) void k_ba_linearize_pose(BaProblemDev pb) { d_ba_linearize_pose(pb, blockIdx.x); }
+// one launch, both roles: workgroups [0, n_groups) the landmark role, the rest the pose role (they do not depend on each other)
+__global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
+    __shared__ LinearizeLds lds;
+    if ((int)blockIdx.x < pb.n_groups) d_ba_linearize(pb, blockIdx.x, lds);
+    else d_ba_linearize_pose(pb, (int)blockIdx.x - pb.n_groups, lds);
+}
 
 // Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.  The tree is the one a 256-entry
 // LDS array would be folded with (t += t + 128, t += t + 64, ... , t += t + 1), so the bits do not depend on how it is carried out:
@@ -859,7 +865,8 @@ __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, 
 }
 
 // One launch: workgroups [0, nbp) back-substitute the landmarks, the rest move the poses (exp(x_p) * T)
-__device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const int bx, int nbp, const double* __restrict__ xp, double lambda) {
+__device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const int bx, int nbp, const double* __restrict__ xp, double lambda,
+                                                  ImuPose* __restrict__ iposes_host = nullptr) {
     __shared__ double s_sum[256], s_x[kBacksubMaxNp];
     if (bx < nbp) { backsub_body(pb, bx, xp, lambda, s_sum, s_x); return; }
     const int k = (bx - nbp) * 256 + threadIdx.x;
@@ -873,6 +880,7 @@ __device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const 
             imu_pose_update(T, pb.calib, u);
         }
         pb.iposes_trial[k] = T;
+        if (iposes_host) iposes_host[k] = T;  // the host's inertial cost of the trial state reads it there (a posted write; a copy launch per trial before)
         return;
     }
     if (i < 0) { pb.poses_trial[k] = pb.poses[k]; return; }
@@ -930,40 +938,60 @@ __global__ __launch_bounds__(256) void k_ba_depth(BaProblemDev pb, uint8_t* __re
 static inline __device__ int blocks256(int n) { return (n + 255) / 256; }
 // s_setprio 3: the lock-step kernels are links of a dependent chain with a host step after every phase, running beside the front end's
 // long kernels; their wavefronts go first in the SIMDs' issue arbitration (41.7 against 42.1 ms per step of the whole loop).
-// active == NULL: the table is already in launch order (the host compacts it: one dependent load less at the head of every workgroup)
-#define TC2LI_SLOT(axis) __builtin_amdgcn_s_setprio(3); const BaBatchSlot& sl = slots[active ? active[blockIdx.axis] : (int)blockIdx.axis]; const BaProblemDev pb = sl.pb  /* a private copy: no reloads after stores */
+// The window of a workgroup: the call's resident table entry of the phase's window number `pos`, with this phase's state applied to a
+// private copy of its problem record (no reloads after stores): the parity bit swaps the accepted and the trial buffers.
+struct BaSlotView {
+    const BaBatchSlot& sl;
+    BaProblemDev pb;
+    double lambda;
+    unsigned flags;
+    const double* xp;
+    __device__ __forceinline__ double* hpp_out() const { return (flags & kBaWantHpp) ? sl.hpp_out : nullptr; }
+};
+__device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
+    __builtin_amdgcn_s_setprio(3);
+    const BaBatchSlot& sl = ph.table[ph.win[pos]];
+    BaSlotView v{sl, sl.pb, ph.lambda[pos], ph.flags[pos], sl.xp};
+    if (v.flags & kBaAcceptedInTrial) {
+        Se3* const p = v.pb.poses; v.pb.poses = v.pb.poses_trial; v.pb.poses_trial = p;
+        ImuPose* const q = v.pb.iposes; v.pb.iposes = v.pb.iposes_trial; v.pb.iposes_trial = q;
+        double* const x = v.pb.points; v.pb.points = v.pb.points_trial; v.pb.points_trial = x;
+    }
+    if (ph.xp_area && 6 * v.pb.n_free <= kBaXpStride) v.xp = ph.xp_area + (size_t)(ph.first + pos) * kBaXpStride;
+    return v;
+}
+#define TC2LI_SLOT(axis) const BaSlotView view_ = ba_slot_view(ph, blockIdx.axis); const BaBatchSlot& sl = view_.sl; (void)sl; const BaProblemDev& pb = view_.pb
 
-__global__ __launch_bounds__(256) void k_ba_linearize_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+// workgroups [0, max_groups) of a window: the landmark role; [max_groups, ...): the pose role -- one launch (two before: the second
+// waited for the first to drain although neither reads what the other writes)
+__global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int max_groups) {
+    __shared__ LinearizeLds lds;
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= pb.n_groups) return;
-    d_ba_linearize(pb, blockIdx.x);
+    const int bx = blockIdx.x;
+    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize(pb, bx, lds); }
+    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose(pb, bx - max_groups, lds);
 }
-__global__ __launch_bounds__(256) void k_ba_linearize_pose_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
-    TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= blocks256(pb.n_free_edges)) return;
-    d_ba_linearize_pose(pb, blockIdx.x);
-}
-__global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if ((int)blockIdx.x >= pb.n_free + 1) return;
-    d_ba_reduce_all(pb, blockIdx.x, sl.chi_out, sl.hpp_out);
+    d_ba_reduce_all(pb, blockIdx.x, sl.chi_out, view_.hpp_out());
 }
-__global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaPhase ph) {
     TC2LI_SLOT(y);
-    if (!sl.want_maxdiag) return;
+    if (!(view_.flags & kBaWantMaxdiag)) return;
     d_ba_maxdiag(pb, blockIdx.x, sl.maxdiag_out);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if (pb.sparse_schur || !pb.n_free_edges || (int)blockIdx.x >= blocks256(pb.n_edges)) return;
-    d_ba_schur_prepare(pb, blockIdx.x, sl.lambda);
+    d_ba_schur_prepare(pb, blockIdx.x, view_.lambda);
 }
-__global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if (pb.sparse_schur || (int)blockIdx.x >= pb.n_free) return;
     d_ba_reduce_coef(pb, blockIdx.x);
 }
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaPhase ph) {
     TC2LI_SLOT(z);
     const int tiles = pb.np_pad / 16;
     if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
@@ -972,41 +1000,42 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaBatchSlot*
 // One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each with its own L2): the
 // strips of one k-slice read the same rows of W^T, so consecutive entries of the (window, slice, strip) list stay on one XCD.
 template <int CT>
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active, int strips, int max_slices,
+__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaPhase ph, int strips, int max_slices,
                                                         int n_active) {
     const int total = strips * max_slices * n_active, per_xcd = (total + 7) / 8;
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= total) return;
     const int window = logical / (strips * max_slices), rem = logical - window * (strips * max_slices), slice = rem / strips, strip = rem - slice * strips;
-    const BaBatchSlot& sl = slots[active ? active[window] : window];
-    const BaProblemDev pb = sl.pb;
+    const BaSlotView view_ = ba_slot_view(ph, window);
+    const BaBatchSlot& sl = view_.sl;
+    const BaProblemDev& pb = view_.pb;
     const int tiles = pb.np_pad / 16;
     if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
-__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
     if (!pb.sparse_schur || !pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_blocks(pb, blockIdx.x, sl.lambda, s_schur);
+    d_ba_schur_blocks(pb, blockIdx.x, view_.lambda, s_schur);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
     if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, sl.lambda, s_schur);
+    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, view_.lambda, s_schur);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
     if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, sl.lambda, s_schur);
+    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, view_.lambda, s_schur);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     const int np = 6 * pb.n_free;
     if (!pb.n_free || (int)blockIdx.x >= blocks256(np * np)) return;
-    d_ba_schur_finish(pb, blockIdx.x, sl.lambda, sl.n_slices, sl.S_out, sl.bs_out, sl.bp_host);
+    d_ba_schur_finish(pb, blockIdx.x, view_.lambda, sl.n_slices, sl.S_out, sl.bs_out, sl.bp_host);
 }
 // The reduced camera system of a window on the device: (S + Hl) x = b_s + bl by the dense LDL^T of ldlt_solve_small (ba_math.hpp), one
 // workgroup per window, lane i = row i.  Every element is formed by the same operations in the same order as on the host -- a row's
@@ -1015,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaBatchSlot* __
 // The lower triangle lives packed in LDS (row i at i (i + 1) / 2).  A pivot that is zero or not finite: ok = 0 and a zero step (the
 // host treats the trial as failed).
 constexpr int kSolveThreads = 128;
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) {
     extern __shared__ double s_solve[];
     __shared__ int s_bad;
     TC2LI_SLOT(x);
@@ -1082,22 +1111,22 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaBatchSlot*
     }
     if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
 }
-__global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
     if ((int)blockIdx.x >= nbp + blocks256(pb.n_poses)) return;
-    d_ba_trial_update(pb, blockIdx.x, nbp, sl.xp, sl.lambda);
+    d_ba_trial_update(pb, blockIdx.x, nbp, view_.xp, view_.lambda, sl.iposes_host);
 }
-__global__ __launch_bounds__(256) void k_ba_errors_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_errors_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
     d_ba_errors(pb, blockIdx.x);
 }
-__global__ __launch_bounds__(256) void k_ba_trial_reduce_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_trial_reduce_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     d_ba_trial_reduce(pb, blockIdx.x, sl.scale_out, sl.chi_trial_out);
 }
-__global__ __launch_bounds__(256) void k_ba_depth_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_ba_depth_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
     d_ba_depth(pb, blockIdx.x, sl.depth_out);
@@ -1108,8 +1137,7 @@ __global__ __launch_bounds__(256) void k_ba_depth_b(const BaBatchSlot* __restric
 static inline int blocks(int n) { return (n + 255) / 256; }
 
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st) {
-    TC2LI_LAUNCH(k_ba_linearize, dim3(pb.n_groups), dim3(256), 0, st, pb);
-    if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
+    TC2LI_LAUNCH(k_ba_linearize, dim3(pb.n_groups + blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
     TC2LI_LAUNCH(k_ba_reduce_all, dim3(pb.n_free + 1), dim3(256), 0, st, pb, chi_out);
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
@@ -1161,50 +1189,49 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
     TC2LI_LAUNCH(k_ba_depth, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, depth_pos);
 }
 
-void ba_batch_launch_linearize(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
+void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups, n_active), dim3(256), 0, st, slots, active);
-    if (x.max_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, slots, active);
-    TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, slots, active);
-    if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
+    if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }
-void ba_batch_launch_schur(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
     if (x.max_block_parts) {
         schur_blocks_attr();
-        TC2LI_LAUNCH(k_ba_schur_blocks_b, dim3(x.max_block_parts, n_active), dim3(256), schur_blocks_lds_bytes(x.max_block_free), st, slots, active);
+        TC2LI_LAUNCH(k_ba_schur_blocks_b, dim3(x.max_block_parts, n_active), dim3(256), schur_blocks_lds_bytes(x.max_block_free), st, ph);
     }
     if (x.max_sparse_slices) {
         const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
-        if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, slots, active);
-        else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, slots, active);
+        if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
+        else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
     }
     if (x.any_dense) {
-        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
-        TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, slots, active);
+        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
+        TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);
         const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
         const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
-        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, slots, active, strips, x.max_slices, n_active);
-        else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, slots, active);
+        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, ph, strips, x.max_slices, n_active);
+        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, ph, strips, x.max_slices, n_active);
+        else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, ph);
     }
-    TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, ph);
 }
-void ba_batch_launch_solve(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
     const int n = 6 * x.max_free;
     const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
     (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 72 * 1024);  // 21 free keyframes: 66 KB
-    TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, slots, active);
+    TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
 }
-void ba_batch_launch_trial(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
+void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
-    TC2LI_LAUNCH(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, slots, active);
-    TC2LI_LAUNCH(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
-    TC2LI_LAUNCH(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, slots, active);
+    TC2LI_LAUNCH(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, ph);
+    TC2LI_LAUNCH(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
+    TC2LI_LAUNCH(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }
-void ba_batch_launch_depth(const BaBatchSlot* slots, const int* active, int n_active, const BaBatchExtent& x, hipStream_t st) {
-    if (n_active) TC2LI_LAUNCH(k_ba_depth_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, slots, active);
+void ba_batch_launch_depth(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
+    if (n_active) TC2LI_LAUNCH(k_ba_depth_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
 }
 
 }  // namespace tc2li

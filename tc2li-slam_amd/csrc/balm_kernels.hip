@@ -325,37 +325,40 @@ void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
 }
 
 // ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
-__device__ __forceinline__ const Se3* slot_poses(const BaBatchSlot& sl, bool trial) {
-    if (sl.pb.inertial) return reinterpret_cast<const Se3*>(trial ? sl.pb.iposes_trial : sl.pb.iposes);
-    return trial ? sl.pb.poses_trial : sl.pb.poses;
+// the poses of the window at position `pos` of the phase: the accepted estimate or the trial one (the phase's parity bit says which of
+// the slot's two buffers holds the accepted estimate)
+__device__ __forceinline__ const Se3* slot_poses(const BaPhase& ph, int pos, const BaBatchSlot& sl, bool trial) {
+    const bool second = trial != ((ph.flags[pos] & kBaAcceptedInTrial) != 0);
+    if (sl.pb.inertial) return reinterpret_cast<const Se3*>(second ? sl.pb.iposes_trial : sl.pb.iposes);
+    return second ? sl.pb.poses_trial : sl.pb.poses;
 }
-__global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list, int trial) {
+__global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph, int trial) {
     __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = slots[list ? list[blockIdx.x] : (int)blockIdx.x];
+    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.x]];
     const BalmDev b = sl.balm;
-    d_balm_residual_total(b, slot_poses(sl, trial != 0));
+    d_balm_residual_total(b, slot_poses(ph, blockIdx.x, sl, trial != 0));
 }
-__global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+__global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPhase ph) {
     __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
+    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.y]];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= b.n_chunks) return;
-    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(sl, false), blockIdx.x);
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(ph, blockIdx.y, sl, false), blockIdx.x);
 }
-__global__ __launch_bounds__(256) void k_balm_combine_b(const BaBatchSlot* __restrict__ slots, const int* __restrict__ list) {
+__global__ __launch_bounds__(256) void k_balm_combine_b(const BaPhase ph) {
     __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = slots[list ? list[blockIdx.y] : (int)blockIdx.y];
+    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.y]];
     const BalmDev b = sl.balm;
     if ((int)blockIdx.x >= (max(balm_part_stride_dev(b.W), 12 * b.W) + 255) / 256) return;
     d_balm_combine(b, blockIdx.x);
 }
-void balm_batch_launch_residual(const BaBatchSlot* slots, const int* list, int n, bool trial, hipStream_t st) {
-    if (n) TC2LI_LAUNCH(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, slots, list, trial ? 1 : 0);
+void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st) {
+    if (n) TC2LI_LAUNCH(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, ph, trial ? 1 : 0);
 }
-void balm_batch_launch_hessian(const BaBatchSlot* slots, const int* list, int n, const BaBatchExtent& x, hipStream_t st) {
+void balm_batch_launch_hessian(const BaPhase& ph, int n, const BaBatchExtent& x, hipStream_t st) {
     if (!n) return;
-    TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, slots, list);
-    TC2LI_LAUNCH(k_balm_combine_b, dim3((std::max(balm_part_stride(x.max_W), 12 * x.max_W) + 255) / 256, n), dim3(256), 0, st, slots, list);
+    TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, ph);
+    TC2LI_LAUNCH(k_balm_combine_b, dim3((std::max(balm_part_stride(x.max_W), 12 * x.max_W) + 255) / 256, n), dim3(256), 0, st, ph);
 }
 
 }  // namespace tc2li
