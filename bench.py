@@ -60,6 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: the rank plumbing only (spawn, rendezvous, sharding, timing protocol, "
                     "JSON line) -- what the world-2 gloo test on CPU drives")
+    ap.add_argument("--host-fed", action="store_true", help="the timed loop takes every step's images and raw scans from pinned host memory (uploads inside the "
+                    "timed region, overlapped with the previous step): what a drop-in behind the reference's host-buffer entry points delivers")
+    ap.add_argument("--inertial-loop", action="store_true", help="the timed loop is the camera-LiDAR-inertial one (configs[3]) instead of the camera-LiDAR one: "
+                    "what the single-sequence child of the inertial line runs")
+    ap.add_argument("--mfma-only", action="store_true", help="only the matrix-unit line: a lock-step batch of 25-keyframe bLarge LocalLVIBA windows (the dense "
+                    "f64 MFMA Schur product); what the --pmc pass of the MFMA counters profiles")
     ap.add_argument("--no-build", action="store_true", help="fail instead of building when the library is missing or stale (profiling runs: "
                     "no child process may start under rocprofv3)")
     return ap.parse_args(argv)
@@ -99,7 +105,7 @@ def spawn_ranks(args, argv):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TC2LI_NO_BUILD="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -109,7 +115,7 @@ def spawn_ranks(args, argv):
     return rc
 
 
-def single_sequence_child(args):
+def single_sequence_child(args, extra=(), what="the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame"):
     """The F = 1 line measured by a fresh child process with GPU_MAX_HW_QUEUES=8 (see the call site); None when the child fails -- the
     caller then measures it in-process.  300 warm-up frames: a cold process (first allocations of every work space, GPU clocks) reads
     627 frames/s after 8 warm-up frames and 780-810 after 300 or 1000."""
@@ -120,12 +126,13 @@ def single_sequence_child(args):
            "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval), "--ba-concurrency", str(args.ba_concurrency)]
     if args.front_end_only:
         cmd.append("--front-end-only")
+    cmd += list(extra)
     try:
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
         line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         return {"value": line["value"], "unit": "frames/s", "ms_per_frame": line["ms_per_step"], "frames": line["steps"],
                 "ba_windows": int(round(line["config"]["ba_windows_per_step_per_gpu"] * line["steps"])),
-                "workload": "the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame" % args.kf_interval,
+                "workload": what % args.kf_interval,
                 "stage_thread_ms_per_frame": line.get("stage_thread_ms_per_step_concurrent"),
                 "process": "a child process of its own, before this one initialised the GPU", "env": {"GPU_MAX_HW_QUEUES": env["GPU_MAX_HW_QUEUES"]}}
     except Exception as e:  # noqa: BLE001
@@ -161,7 +168,29 @@ def sweep_children(args):
     return out
 
 
-def rehearse(args, rank, world, dist, dist_util):
+def apply_host_budget(pkg, local_rank):
+    """The host side of a rank: with R ranks on the node every rank keeps to its share of the cores this job may run on --
+    a contiguous block of the affinity list (ranks follow the GPUs; on the 8-GPU nodes neighbouring cores and neighbouring GPUs share a socket),
+    set with sched_setaffinity before any thread exists and before the first HIP call, so that the HIP runtime's and the library's threads
+    inherit it -- and tells the library its thread budget (tc2li_set_host_thread_budget: the pools of 8 ranks on 256 cores then add up to 26
+    threads per rank instead of ~130).  One rank: nothing is pinned, the budget is what the process may run on."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    mine = cores
+    if local_world > 1:
+        per = max(1, len(cores) // local_world)
+        mine = cores[(local_rank % local_world) * per:(local_rank % local_world + 1) * per] or cores
+        if hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, mine)
+    pkg.capi.set_host_thread_budget(len(mine))
+    h = pkg.capi.host_threads()
+    return {"ranks_on_node": local_world, "cores_of_this_rank": len(mine), "pinned": local_world > 1, "stage_threads": 5, "ba_lockstep_groups": 3,
+            "library_pools": {k: h[k] for k in ("extractor_pool", "tracking_pool", "lidar_pool", "ba_group_pool")},
+            "threads_of_this_rank": 5 + h["extractor_pool"] + h["tracking_pool"] + h["lidar_pool"] + 3 * h["ba_group_pool"],
+            "cpus_available": len(cores)}
+
+
+def rehearse(args, rank, world, dist, dist_util, host_budget=None):
     """The multi-rank protocol without device work: every rank 'processes' its share of the global list by sleeping."""
     units = dist_util.shard_units(args.sequences, rank, world) if args.scaling == "strong" else list(range(args.frames))
     dist_util.barrier(dist)
@@ -177,7 +206,8 @@ def rehearse(args, rank, world, dist, dist_util):
                           "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
                           "scaling": args.scaling, "vs_baseline": None, "dtype": "none (rehearsal)", "data": "none", "rehearsal": True,
                           "ranks_seen": seen, "config": {"workload": "rank plumbing only", "sequences_total": total,
-                                                         "sequences_of_rank0": len(units)}}))
+                                                         "sequences_of_rank0": len(units), "host_threads_gpu_path": host_budget,
+                                                         "affinity_of_rank0": sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}}))
     return 0
 
 
@@ -411,10 +441,33 @@ class Loop:
         self.workers = {}
         _OPEN_LOOPS.add(self)
 
+    # -- host-fed inputs --------------------------------------------------------------------------------
+    def enable_host_fed(self):
+        """What a drop-in sees: the reference's entry points take host buffers (cv::Mat images, Tracking.cc:1632; a ROS point-cloud message,
+        LidarFrontEnd.cpp:253).  From here on every step's images and raw scans start in PINNED HOST memory and go up through the copy engines
+        inside the timed region -- step k + 1's while step k is processed (two device buffers per input, a copy stream per input)."""
+        torch = self.torch
+        self.h_img, self.h_raw = self.dev_img.cpu().pin_memory(), self.dev_raw.cpu().pin_memory()
+        self.img_bufs, self.raw_bufs = [self.dev_img, torch.empty_like(self.dev_img)], [self.dev_raw, torch.empty_like(self.dev_raw)]
+        self.copy_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        self.host_fed = True
+        self.fed_bytes_per_step = int(self.h_img.numel() + self.h_raw.numel())
+
+    def _upload(self, which, buf):
+        """Queues the upload of the images (which = 0) or the scans (1) into device buffer `buf`; returns the event to wait for."""
+        torch = self.torch
+        st = self.copy_streams[which]
+        with torch.cuda.stream(st):
+            (self.img_bufs if which == 0 else self.raw_bufs)[buf].copy_(self.h_img if which == 0 else self.h_raw, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return ev
+
     # -- stages ------------------------------------------------------------------------------------------------------------
-    def extract(self, k, stream):
+    def extract(self, k, stream, img=None):
         W, H = self.wl.W, self.wl.H
-        self.orb_outs[k] = self.exts[k].extract_batch_dev(self.dev_img.data_ptr(), self.n_img, W, H, W, W * H, stream=stream, out=self.orb_outs[k])
+        img = self.dev_img if img is None else img
+        self.orb_outs[k] = self.exts[k].extract_batch_dev(img.data_ptr(), self.n_img, W, H, W, W * H, stream=stream, out=self.orb_outs[k])
 
     def track(self, k, stream):
         """Stereo matching + TrackWithMotionModel of feature buffer k."""
@@ -436,8 +489,9 @@ class Loop:
         self.tlm_out = self.tlm_outs[k]
         self.track_ms[2] = 1e3 * (time.perf_counter() - t0)
 
-    def lidar_step(self):
+    def lidar_step(self, raw=None):
         pkg, F = self.pkg, self.F
+        raw = self.dev_raw if raw is None else raw
         # lasermap_fov_segment (host logic) + the box deletions it asks for, per sequence
         todo_maps, todo_boxes = [], []
         for s in range(F):
@@ -446,7 +500,7 @@ class Loop:
                 todo_maps.append(self.maps[s]); todo_boxes.append(boxes)
         if todo_maps:
             pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
-        self.lidar_counts = self.lidar.frontend_batch(self.dev_raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
+        self.lidar_counts = self.lidar.frontend_batch(raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
                                                       want_points=False)[0]
         self.lidar_times.append(self.lidar.last_timings().astype(float))
         # UpdateMap -> map_incremental (Tracking.cc:1602-1603) for every sequence's map: one batched call
@@ -485,12 +539,21 @@ class Loop:
                     continue
             return None
 
+        fed = getattr(self, "host_fed", False)
+
         def orb_thread():
-            for _ in range(n_steps):
+            ev = self._upload(0, 0) if fed else None
+            for i in range(n_steps):
                 k = get(free)
                 if k is None:
                     return
-                self.extract(k, self.stream)
+                img = None
+                if fed:  # this step's images have been on their way since the step before; the next step's start now, into the other buffer
+                    ev.synchronize()
+                    img = self.img_bufs[i % 2]
+                    if i + 1 < n_steps:
+                        ev = self._upload(0, (i + 1) % 2)
+                self.extract(k, self.stream, img)
                 self.orb_times.append(self.exts[k].last_timings().astype(float))
                 ready.put(k)
 
@@ -512,10 +575,17 @@ class Loop:
                 free.put(k)
 
         def lidar_thread():
-            for _ in range(n_steps):
+            ev = self._upload(1, 0) if fed else None
+            for i in range(n_steps):
                 if failed.is_set():
                     return
-                self.lidar_step()
+                raw = None
+                if fed:
+                    ev.synchronize()
+                    raw = self.raw_bufs[i % 2]
+                    if i + 1 < n_steps:
+                        ev = self._upload(1, (i + 1) % 2)
+                self.lidar_step(raw) if raw is not None else self.lidar_step()
 
         def ba_thread():
             done = 0  # steps whose windows have been optimised; a step's keyframes exist once the tracking thread has finished it
@@ -724,7 +794,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # n (n + 1) / 2 x 324 FLOP.  (The kernel runs it as a zero-padded dense f64 MFMA product per chunk of landmarks: about nine times
             # these FLOPs at this covisibility, 55 % of the measured matrix peak when it has the GPU to itself -- DESIGN.md section 4.)
             # (since round 3 the default is k_ba_schur_blocks_b: exactly these products, on the f64 vector unit; the MFMA form is TC2LI_BA_SCHUR_MFMA=1)
-            "k_ba_schur_blocks_b": (nw * tr * pairs * 324.0, "FLOP"),
+            "k_ba_schur_blocks_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),
             "k_ba_schur_sparse4_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_sparse9_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
@@ -775,6 +845,68 @@ def algorithmic_work_inertial(wl, il, nkp, windows_per_step):
     for k in ("k_sel_scatter", "k_sel_count"):
         w.pop(k, None)
     return w
+
+
+def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
+    """the path that DOES use the matrix unit, benched.  The 25-keyframe `bLarge` LocalLVIBA window (Optimizer.cc:1516-1523,
+    OptimizerWithLidar.cc:493-500: opt_it 4, lambda 1e-2): 25 free keyframes put the reduced system beyond the block-by-block Schur kernel, so
+    S -= (W D^-1) W^T runs as the dense k-major f64 MFMA product (k_ba_schur_gemm*).  A lock-step batch of such windows, timed, then once more
+    with every launch timed (tc2li_profile_*): the GEMM's average launch against the measured f64 MFMA peak.  FLOPs = what the kernel executes
+    (tiles^2 x 16 x 16 x 2 per k step); the block-sparse product g2o forms needs about a ninth of them (`useful_frac`)."""
+    uniq = []
+    for k in range(4):
+        w = synthetic.inertial_window(100 + k, n_opt=25, n_points=1500)
+        pre = []
+        for smp, t1, t2 in w["samples"]:
+            q = pkg.capi.Preintegrated(w["bias6"], *synthetic.IMU_NOISE)
+            q.preintegrate(smp, t1, t2)
+            pre.append(q)
+        K = len(w["kf33"])
+        win = list(range(K - 1, K - 7, -1))
+        uniq.append(dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=np.asarray(w["edges"]),
+                         link4=w["link4"], pre=pre, win_kf=win, clouds=synthetic.inertial_window_clouds(w, win, n_points=2400, seed=100 + k), Tcl7=synthetic.TCL7,
+                         Tbl7=synthetic.tbl7(), weight=1.0, iterations=4, lambda_init=1e-2, calib24=w["calib24"], cam=w["cam"]))
+    batch = pkg.capi.LviBatch([uniq[k % 4] for k in range(n_windows)], uniq[0]["calib24"], uniq[0]["cam"])
+    if batch.run(8) != n_windows:
+        raise RuntimeError("a bLarge LocalLVIBA window failed")
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        batch.run(8)
+    dt = (time.perf_counter() - t0) / repeats
+    pkg.capi.profile_enable(True)
+    batch.run(8)
+    pkg.capi.profile_enable(False)
+    report = pkg.capi.profile_report()
+    s0 = batch.stats[0]
+    nf, P = int(s0.n_free_poses), len(uniq[0]["points"])
+    np_pad = max(16, (6 * nf + 15) // 16 * 16)
+    tiles, k_total = np_pad // 16, 3 * P
+    n_slices = max(1, min(64, k_total // 64))
+    k_per_slice = ((k_total + n_slices - 1) // n_slices + 3) // 4 * 4
+    e6, fixed = uniq[0]["edges6"], np.asarray(uniq[0]["fixed"])
+    free_edge = fixed[e6[:, 1].astype(int)] == 0
+    f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=P)
+    useful = float((f_l * (f_l + 1) // 2).sum()) * 324.0
+    gemm = {k: v for k, v in report.items() if base_name(k).startswith("k_ba_schur_gemm")}
+    out = {"workload": "%d bLarge LocalLVIBA windows in lock step (25 free keyframes + the fixed one, %d points, %d stereo edges, LiDAR edge over 6 keyframes x 2400 "
+                       "points, 4 iterations at lambda 1e-2): the dense Schur path" % (n_windows, P, len(e6)),
+           "windows_per_s": round(n_windows / dt, 1), "ms_per_batch": round(1e3 * dt, 3), "iterations/trials": [int(s0.iterations), int(s0.trials)],
+           "free_keyframes": nf, "reduced_system": "(6 + 9) x %d" % nf}
+    if gemm:
+        name = max(gemm, key=lambda k: gemm[k][1])
+        calls, ms = gemm[name]
+        third = n_windows // 3 if n_windows >= 6 else n_windows  # three lock-step groups: a launch covers a third of the windows
+        flop_window = tiles * tiles * 512.0 * k_per_slice * n_slices
+        per_launch = flop_window * n_windows * int(s0.trials) / max(calls, 1)
+        rate = per_launch / (ms / max(calls, 1) * 1e-3)
+        out["roofline"] = {"kernel": base_name(name), "bound": "mfma", "achieved": round(rate / 1e12, 3), "peak": round(peaks["mfma_f64_tflops"], 2), "unit": "TFLOP/s",
+                           "frac": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5), "frac_of_spec": round(rate / 1e12 / 78.6, 5),
+                           "launches": int(calls), "avg_launch_ms": round(ms / max(calls, 1), 6), "executed_flops_per_launch": int(per_launch),
+                           "useful_frac": round(useful / flop_window, 4), "windows_per_launch": third,
+                           "tiles": "%d x %d of 16 x 16, k = %d in %d slices" % (tiles, tiles, k_total, n_slices),
+                           "peak_source": "measured: back-to-back v_mfma_f64_16x16x4_f64 (tc2li_diag_peaks); data sheet 78.6 TFLOP/s (frac_of_spec)",
+                           "counters": "profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of this kernel (tools/profile_round.sh, its own --pmc pass of `bench.py --mfma-only`)"}
+    return out
 
 
 def cpu_baseline_inertial(wl, il, args, n_seq_gpu):
@@ -888,6 +1020,8 @@ def roofline_from_profile(report, work, peaks, n_steps):
             rate = amount * n_steps / (ms * 1e-3)
             if unit == "B":
                 row.update({"achieved_GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / 8000.0, 5)})
+            elif unit == "FLOP_VALU":
+                row.update({"achieved_TFLOPs": round(rate / 1e12, 3), "frac_valu_f64_measured": round(rate / 1e12 / max(peaks["fma_f64_tflops"], 1e-9), 5)})
             else:
                 row.update({"achieved_TFLOPs": round(rate / 1e12, 3), "frac_mfma_f64_measured": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5)})
         table[name] = row
@@ -906,6 +1040,13 @@ def roofline_from_profile(report, work, peaks, n_steps):
         if unit == "B":
             out.update({"bound": "hbm", "achieved": round(rate / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(rate / 1e9 / 8000.0, 5),
                         "algorithmic_bytes_per_launch": int(per_launch)})
+        elif unit == "FLOP_VALU":
+            # a kernel of the f64 VECTOR unit (k_ba_schur_blocks_b issues no matrix instruction): against the vector FMA rate this GPU reaches
+            # (tc2li_diag_peaks) and the data sheet's f64 vector figure -- the contract's vocabulary has "hbm" and "mfma" only, neither fits
+            out.update({"bound": "valu_f64", "achieved": round(rate / 1e12, 3), "peak": round(peaks["fma_f64_tflops"], 2), "unit": "TFLOP/s",
+                        "frac": round(rate / 1e12 / max(peaks["fma_f64_tflops"], 1e-9), 5), "algorithmic_flops_per_launch": int(per_launch),
+                        "peak_source": "measured: dependent-free f64 v_fma chains on every SIMD (tc2li_diag_peaks); data sheet 78.6 TFLOP/s f64 vector (frac_of_spec)",
+                        "frac_of_spec": round(rate / 1e12 / 78.6, 5)})
         else:
             out.update({"bound": "mfma", "achieved": round(rate / 1e12, 3), "peak": round(peaks["mfma_f64_tflops"], 2), "unit": "TFLOP/s",
                         "frac": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5), "algorithmic_flops_per_launch": int(per_launch),
@@ -930,13 +1071,13 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, pattern="*_pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from a committed PMC summary (tools/profile_round.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc
     passes of this bench command; the counters cannot be read inside this process) -- only from a summary made on THIS source tree
     (`source_hash`); None otherwise."""
     import glob
     here = source_hash()
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         pmc = json.load(open(f))
         if pmc.get("_source_hash") != here:
             continue
@@ -1026,9 +1167,10 @@ def main(argv=None):
     rank, local_rank, world = dist_util.rank_info()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
+    host_budget = apply_host_budget(pkg, local_rank)  # before the first HIP call and before this process has other threads
     if args.rehearse:
         dist = dist_util.init("gloo", rank, world)
-        rc = rehearse(args, rank, world, dist, dist_util)
+        rc = rehearse(args, rank, world, dist, dist_util, host_budget)
         if dist is not None:
             dist.destroy_process_group()
         return rc
@@ -1059,9 +1201,13 @@ def main(argv=None):
     # may not start children): the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and the ten
     # streams of the five stage threads then queue behind each other -- with one sequence per step, where every kernel is tiny, that false
     # ordering is most of a frame's time (479 frames/s with 4 queues, 761 with 8; the batched lines lose 1-9 % with 8 and keep the default)
-    single_child = None
+    single_child = single_fed_child = single_inertial_child = None
     if rank == 0 and not args.no_extra_lines and not args.rehearse and not os.environ.get("TC2LI_BENCH_SINGLE_INPROC") and not under_profiler():
         single_child = single_sequence_child(args)
+        # the same with every frame's images and scan taken from pinned host memory (what a drop-in delivers), and the inertial configuration
+        single_fed_child = single_sequence_child(args, ("--host-fed",))
+        if not args.front_end_only:
+            single_inertial_child = single_sequence_child(args, ("--inertial-loop",), "configs[3] with 1 sequence per step: one LocalLVIBA window every %d-th frame")
     sweep_child = None
     if (rank == 0 and world == 1 and not args.no_extra_lines and not args.rehearse and not args.front_end_only and not under_profiler()
             and args.scaling == "strong" and set(args.stages.split(",")) == {"orb", "track", "lidar", "ba"}):
@@ -1071,6 +1217,11 @@ def main(argv=None):
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d has no GPU (the node shows %d)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    if args.mfma_only:  # the matrix-unit line alone (what the MFMA counters' --pmc pass profiles)
+        pk = pkg.capi.diag_peaks()
+        print(json.dumps({"mfma_config": mfma_line(pkg, synthetic, {"mfma_f64_tflops": pk[0], "fma_f64_tflops": pk[1]})}))
+        sys.stdout.flush()
+        return 0
     dist = dist_util.init(args.backend, rank, world, device=torch.device("cuda", local_rank) if args.backend == "nccl" else None)
 
     if args.scaling == "strong":
@@ -1087,7 +1238,9 @@ def main(argv=None):
     ext0 = pkg.OrbExtractor(max_width=wl.W, max_height=wl.H, max_images=2 * U)
     wl.build_tracking_inputs(ext0, stream)
     ext0.close()
-    loop = Loop(wl, seq_ids, args, local_rank)
+    loop = InertialLoop(wl, seq_ids, args, local_rank) if args.inertial_loop else Loop(wl, seq_ids, args, local_rank)
+    if args.host_fed:
+        loop.enable_host_fed()
     F = loop.F
 
     def barrier():
@@ -1117,7 +1270,11 @@ def main(argv=None):
     ba_windows_timed = loop.ba_windows_done - ba0
     orb_out, st_out, trk_out, tlm_out = loop.orb_outs[0], loop.st_outs[0], loop.trk_outs[0], loop.tlm_out
     nkp = float(np.mean(orb_out[2]))
-    lid_mean = [int(np.mean(np.diff(loop.raw_offs)))] + [int(v) for v in np.mean(loop.lidar_counts, 1)]
+    if loop.lidar_counts is not None:
+        lid_mean = [int(np.mean(np.diff(loop.raw_offs)))] + [int(v) for v in np.mean(loop.lidar_counts, 1)]
+    else:  # the inertial loop (--inertial-loop): preprocessed, down-sampled, ESKF features from the LiDAR-inertial call's own counters
+        ls_ = np.array(loop.li.stats())
+        lid_mean = [int(np.mean(np.diff(loop.raw_offs))), int(ls_[:, 3].mean()), int(ls_[:, 4].mean()), int(ls_[:, 2].mean())]
     map_points_end = int(np.mean([m.size() for m in loop.maps]))
 
     # ---- stage wall times of one more step, every stage alone (host clock, each stage synchronises at its end) ----
@@ -1168,8 +1325,33 @@ def main(argv=None):
         roofline["kernel_ms_per_step_all_streams"] = round(kernel_ms_per_step, 3)
         roofline["peaks_measured"] = peaks
 
+    # ---- host-fed inputs: the same loop with every step's images and raw scans taken from pinned host memory (what a drop-in delivers) ----
+    host_fed = None
+    if rank == 0 and not args.no_extra_lines and not args.host_fed and set(stages) == {"orb", "track", "lidar", "ba"}:
+        loop.enable_host_fed()
+        loop.run(3, stages)
+        torch.cuda.synchronize()
+        n_hf = max(6, min(args.steps, 12))
+        t1 = time.perf_counter()
+        loop.run(n_hf, stages)
+        torch.cuda.synchronize()
+        dt_hf = time.perf_counter() - t1
+        gb = loop.fed_bytes_per_step / 1e9
+        host_fed = {"value": round(F * n_hf / dt_hf, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_hf / n_hf, 3), "sequences": F, "steps": n_hf,
+                    "GB_per_step": round(gb, 3), "link_GBps": round(gb * n_hf / dt_hf, 2),
+                    "link_spec_GBps": 63.0, "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in loop.thread_ms.items()},
+                    "workload": "the timed loop of `value` with the inputs of every step -- %d images and %d raw scans, %.2f GB -- starting in pinned host memory: "
+                                "uploads through the copy engines inside the timed region, step k + 1's under step k's processing (two device buffers per "
+                                "input); `link_GBps` = bytes uploaded / elapsed, i.e. what the loop drew from the host link (PCIe Gen5 x16: 63 GB/s by the "
+                                "data sheet)" % (loop.n_img, F, gb)}
+        loop.host_fed = False
+
     # ---- the same loop for ONE sequence (F = 1): what a single KITTI-00 run sees ----
     single = single_child
+    if single is not None and single_fed_child is not None:
+        # what a drop-in delivers for one sequence is the host-fed number: that is the one quoted; the HBM-resident one beside it
+        single = dict(single_fed_child, resident_value=single_child["value"], resident_ms_per_frame=single_child["ms_per_frame"],
+                      workload=single_fed_child["workload"] + "; every frame's two images and its scan (5.1 MB) start in pinned host memory (--host-fed)")
     if rank == 0 and not args.no_extra_lines and single is None:
         one = Loop(wl, [0], args, local_rank)
         one.run(8, stages)
@@ -1231,15 +1413,22 @@ def main(argv=None):
         rf_i, table_i, kms_i = roofline_from_profile(report_i, algorithmic_work_inertial(wl, il, nkp, (il.ba_windows_done - ba_i1) / n_pi), peaks, n_pi)
         rf_i["all_kernels"] = table_i
         rf_i["kernel_ms_per_step_all_streams"] = round(kms_i, 3)
-        rf_i["traffic"] = None
-        one_i = InertialLoop(wl, [seq_ids[0]], args, local_rank)
-        one_i.run(8, stages)
-        torch.cuda.synchronize()
-        n1 = 48
-        t1 = time.perf_counter()
-        one_i.run(n1, stages)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t1
+        rf_i["traffic"] = pmc_traffic(rf_i["kernel"], "*_pmc_traffic_inertial.json")
+        single_i = single_inertial_child
+        if single_i is None:  # no child (under a profiler, or it failed): in this process, after the batched loops
+            one_i = InertialLoop(wl, [seq_ids[0]], args, local_rank)
+            one_i.run(8, stages)
+            torch.cuda.synchronize()
+            n1 = 48
+            t1 = time.perf_counter()
+            one_i.run(n1, stages)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            single_i = {"value": round(n1 / dt1, 2), "unit": "frames/s", "ms_per_frame": round(1e3 * dt1 / n1, 3), "frames": n1,
+                        "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one_i.thread_ms.items()},
+                        "process": "in this process (4 hardware queues; the camera-LiDAR single-sequence line runs in a child with 8)"}
+            one_i.close()
+            del one_i
         cpu_i = None
         if world == 1 and not args.no_cpu_baseline:
             cpu_i = cpu_baseline_inertial(wl, il, args, F)
@@ -1251,12 +1440,15 @@ def main(argv=None):
                                 "in lock step, max 3 iterations) + map_incremental; LocalLVIBA in lock step (10 + 1 keyframes, ~900 points, LiDAR edge over "
                                 "6 keyframes x 2400 points) every %d-th frame" % (F, args.kf_interval),
                     "roofline": rf_i, "cpu_baseline": cpu_i,
-                    "single_sequence": {"value": round(n1 / dt1, 2), "unit": "frames/s", "ms_per_frame": round(1e3 * dt1 / n1, 3), "frames": n1,
-                                        "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one_i.thread_ms.items()},
-                                        "process": "in this process (4 hardware queues; the camera-LiDAR single-sequence line runs in a child with 8)"},
+                    "single_sequence": single_i,
                     **stats_i}
-        one_i.close(); il.close()
-        del one_i, il
+        il.close()
+        del il
+
+    # ---- the matrix unit where it is used: 25-keyframe bLarge LocalLVIBA windows (dense f64 MFMA Schur product) ----
+    mfma = None
+    if rank == 0 and not args.no_extra_lines and not args.front_end_only and peaks is not None:
+        mfma = mfma_line(pkg, synthetic, peaks)
 
     # ---- CPU baseline: the oracle (a port) with the reference's threading ----
     cpu = None
@@ -1295,7 +1487,6 @@ def main(argv=None):
                           "note": "landmarks l % ranks; per LM trial one sum of [S | b_schur | b_p | status] and one of [scale, chi2, stop, status]"}
 
     if rank == 0:
-        pool_threads = int(os.environ.get("TC2LI_HOST_THREADS", min(32, os.cpu_count() or 1)))
         line = {
             "metric": METRIC, "value": round(total_sequences * args.steps / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
@@ -1316,9 +1507,7 @@ def main(argv=None):
                                  "processed one batch" + ("; local mapping follows the tracking thread and takes the keyframes of the steps tracked since its last call, at most %d "
                                                           "steps' per call" % (4 if loop.ba_batch4 is not None else 2) if loop.ba_batch2 is not None else "; the LiDAR stream has high priority"),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
-                "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": {
-                    "stage_threads": 5, "ba_lockstep_group_threads": 3, "library_worker_pool": pool_threads,
-                    "cpus_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()},
+                "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": host_budget,
                 "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),
                 "motion_model_matches/inliers_per_frame": [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
                 "local_map_points/matches/inliers_per_frame": [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1),
@@ -1327,7 +1516,7 @@ def main(argv=None):
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
                 "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_batch.stats[0].iterations), "trials": int(loop.ba_batch.stats[0].trials),
                                                       "planes": int(loop.ba_batch.lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "inertial_config": inertial, "sequences_per_gpu_sweep": sweep, **({"sharded_window": sharded_window} if sharded_window else {}),
+            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "host_fed": host_fed, "inertial_config": inertial, "mfma_config": mfma, "sequences_per_gpu_sweep": sweep, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
             "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
             "track_calls_ms_last_step": dict(zip(("stereo_match_batch", "track_motion_model_batch", "track_local_map_batch"), [round(v, 3) for v in loop.track_ms])),

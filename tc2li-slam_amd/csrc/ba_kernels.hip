@@ -14,6 +14,7 @@
 // Launches that only depend on the same earlier results share one grid (a dependent launch costs ~10 us on its own).
 // All arithmetic is double precision; reductions run in a fixed order, so results are reproducible run to run.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "launch.hpp"
 #pragma clang fp contract(off)
@@ -971,6 +972,12 @@ __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int ma
     if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize(pb, bx, lds); }
     else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose(pb, bx - max_groups, lds);
 }
+// the pose role as a launch of its own (TC2LI_BA_SPLIT_LINEARIZE=1: A/B measurements against the one-launch form)
+__global__ __launch_bounds__(256) void k_ba_linearize_pose_b(const BaPhase ph) {
+    __shared__ LinearizeLds lds;
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x < blocks256(pb.n_free_edges)) d_ba_linearize_pose(pb, blockIdx.x, lds);
+}
 __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if ((int)blockIdx.x >= pb.n_free + 1) return;
@@ -1191,7 +1198,13 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    static const bool kSplit = getenv("TC2LI_BA_SPLIT_LINEARIZE") && atoi(getenv("TC2LI_BA_SPLIT_LINEARIZE")) != 0;
+    if (kSplit) {
+        TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups, n_active), dim3(256), 0, st, ph, x.max_groups);
+        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
+    } else {
+        TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    }
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }

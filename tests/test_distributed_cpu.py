@@ -112,6 +112,24 @@ def test_bench_spawns_its_ranks_world_2_gloo():
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong"
     assert line["config"]["sequences_total"] == 11 and line["config"]["sequences_of_rank0"] == 6
     assert line["steps"] == 3 and line["value"] > 0
+    # the host side of a rank: rank 0 keeps to its half of the cores this test may run on (pinned before any thread of
+    # its own exists) and the library sizes its pools from that share -- every pool at least one thread, none beyond the share
+    hb = line["config"]["host_threads_gpu_path"]
+    cores = len(os.sched_getaffinity(0))
+    assert hb["ranks_on_node"] == 2 and hb["pinned"] and hb["cores_of_this_rank"] == max(1, cores // 2)
+    assert len(line["config"]["affinity_of_rank0"]) == hb["cores_of_this_rank"]
+    assert all(1 <= v <= max(1, hb["cores_of_this_rank"]) for v in hb["library_pools"].values())
+
+
+def test_host_thread_budget_of_eight_ranks_fits_the_node():
+    """What apply_host_budget gives the library on the driver's 8-GPU node (256 cores): 32 cores per rank, pools that add up -- with the
+    five stage threads and three lock-step BA groups -- to at most those 32 (rounds 1-3: ~130 threads per rank whatever the rank count)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\nimport tc2li_loader\npkg = tc2li_loader.load()\npkg.capi.set_host_thread_budget(256 // 8)\n"
+            "h = pkg.capi.host_threads()\nprint(5 + h['extractor_pool'] + h['tracking_pool'] + h['lidar_pool'] + 3 * h['ba_group_pool'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout.split()[-1]) <= 32
 
 
 def test_bench_weak_scaling_line_under_torchrun_env():

@@ -18,13 +18,20 @@ ARGS="bench.py --no-build --no-cpu-baseline --steps 8 --warmup 2 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS --no-extra-lines --with-roofline > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_write.log 2>&1
-# matrix-unit occupancy of the Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_mfma.log 2>&1
+# matrix-unit occupancy of the dense Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters).
+# Round 4: the pass profiles `bench.py --mfma-only` -- the 25-keyframe bLarge LocalLVIBA batch, the workload that runs the MFMA kernel
+# (the default loop's Schur product is a vector-unit kernel since round 3 and issues no matrix instruction)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 bench.py --no-build --mfma-only > $OUT/bench_mfma.log 2>&1
+# HBM counters of the inertial loop (configs[3]): inertial_config.roofline.traffic
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_fetch_i.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_write_i.log 2>&1
 # instruction mix and LDS behaviour of every kernel (the bound of k_fast_cells is stated from these): own passes, SQ counters only
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_insts -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_insts.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_lds.log 2>&1
+# every pass must have left through a normal exit: no abort hidden behind the profiler's signal handler
+if grep -l "signal 6\|terminate called\|Memory access fault" $OUT/*.log; then echo "profile_round: a profiled process died (see the logs above)"; exit 1; fi
 python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds $OUT/pmc_fetch_i $OUT/pmc_write_i

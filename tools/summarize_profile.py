@@ -31,20 +31,31 @@ def counter_per_kernel(sub, name):
     return acc
 
 
-fetch, write = counter_per_kernel("pmc_fetch", "FETCH_SIZE"), counter_per_kernel("pmc_write", "WRITE_SIZE")
-res = {}
-for k in sorted(set(fetch) | set(write)):
-    f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
-    res[k] = {"launches": max(f[0], w[0]),
-              "fetch_bytes_per_launch": (2.0 * 1024.0 * f[1] / f[0]) if f[0] else None,   # gfx950 correction: x2
-              "write_bytes_per_launch": (1024.0 * w[1] / w[0]) if w[0] else None}
-    fb, wb = res[k]["fetch_bytes_per_launch"], res[k]["write_bytes_per_launch"]
-    res[k]["hbm_bytes_per_launch"] = (fb or 0.0) + (wb or 0.0)
 sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402  (source_hash: the traffic figures are only quoted for the sources they were measured on)
+
+
+def traffic(fetch_dir, write_dir):
+    fetch, write = counter_per_kernel(fetch_dir, "FETCH_SIZE"), counter_per_kernel(write_dir, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
+        res[k] = {"launches": max(f[0], w[0]),
+                  "fetch_bytes_per_launch": (2.0 * 1024.0 * f[1] / f[0]) if f[0] else None,   # gfx950 correction: x2
+                  "write_bytes_per_launch": (1024.0 * w[1] / w[0]) if w[0] else None}
+        fb, wb = res[k]["fetch_bytes_per_launch"], res[k]["write_bytes_per_launch"]
+        res[k]["hbm_bytes_per_launch"] = (fb or 0.0) + (wb or 0.0)
+    return res
+
+
+res = traffic("pmc_fetch", "pmc_write")
 res["_source_hash"] = bench.source_hash()
 json.dump(res, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1, sort_keys=True)
 del res["_source_hash"]
+res_i = traffic("pmc_fetch_i", "pmc_write_i")  # the inertial loop's own passes (configs[3])
+if res_i:
+    res_i["_source_hash"] = bench.source_hash()
+    json.dump(res_i, open("profiles/%s_pmc_traffic_inertial.json" % tag, "w"), indent=1, sort_keys=True)
 top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]
 for k, v in top:
     print("%-40s launches %5d  fetch %12.0f B  write %12.0f B per launch" % (k[:40], v["launches"], v["fetch_bytes_per_launch"] or 0, v["write_bytes_per_launch"] or 0))
