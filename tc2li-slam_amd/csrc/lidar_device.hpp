@@ -62,6 +62,10 @@ struct MapGrid {
 void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
                       int nblocks, PreprocessParams prm, int* block_counts, hipStream_t st);
 void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st);
+// the three launches above as one pass per scan (a workgroup per scan: batches of many scans); bbox_enc [6 per scan] = the bounding box of
+// the kept finite points as k_voxel_bbox leaves it
+void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
+                       int* out_count, int* bbox_enc, hipStream_t st);
 void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
                         int nblocks, PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st);
 

@@ -98,6 +98,7 @@ struct tc2li_lidar {
     DevBuf<PointXYZINormal> d_appended;
     DevBuf<MapIncTask> d_inc_tasks;
     DevBuf<MapGridTask> d_grid_tasks;
+    bool pre_bbox_valid = false;      // d_bbox holds the boxes of d_pre (k_pre_stream) -- until something else writes either
     DevBuf<MapInsTask> d_ins_tasks;   // in-place grid insertion of a batch (k_map_ins_*): tasks, [2] result words per task
     DevBuf<int> d_ins_out;
     PinnedBuf<int> h_ins_out;
@@ -136,6 +137,7 @@ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st, const int32_t* raw_offsets = nullptr) {
     L->slots.resize(n_scans);
     L->blocks.clear();
+    L->pre_bbox_valid = false;  // new scans in the slots: d_bbox describes nothing yet
     for (int s = 0; s < n_scans; ++s) {
         if (upper[s] > L->cap) { set_error("scan %d has %d points, slot capacity is %d", s, upper[s], L->cap); return TC2LI_ERR_CAPACITY; }
         ScanSlot& sl = L->slots[s];
@@ -156,6 +158,16 @@ int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st
 int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_num, double blind, float time_unit_scale, hipStream_t st) {
     PreprocessParams prm{point_filter_num, time_unit_scale, blind * blind};
     const int nb = (int)L->blocks.size();
+    // a batch of scans: one pass over every raw scan (k_pre_stream, a workgroup per scan), which also leaves the voxel filter its bounding
+    // boxes; a few scans: the three-launch form, whose passes are spread over all points.  TC2LI_PRE_STREAM=0 / 1 forces one (tests run both).
+    const char* env = getenv("TC2LI_PRE_STREAM");
+    L->pre_bbox_valid = false;
+    if (env ? atoi(env) != 0 : L->n_scans >= 64) {
+        launch_pre_stream(d_raw, L->d_raw_count.p, L->d_slots.p, L->n_scans, prm, L->d_pre.p, L->d_pre_count.p, L->d_bbox.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        L->pre_bbox_valid = true;
+        return TC2LI_OK;
+    }
     launch_pre_count(d_raw, L->d_raw_count.p, L->d_slots.p, L->d_blocks.p, nb, prm, L->d_block_counts.p, st);
     launch_seg_scan(L->d_slots.p, L->n_scans, L->d_block_counts.p, L->d_block_offsets.p, L->d_pre_count.p, st);
     launch_pre_scatter(d_raw, L->d_raw_count.p, L->d_slots.p, L->d_blocks.p, nb, prm, L->d_block_offsets.p, L->d_pre.p, st);
@@ -169,12 +181,17 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     std::vector<VoxelParams> vp(S);
     for (int s = 0; s < S; ++s) { memset(&vp[s], 0, sizeof(VoxelParams)); vp[s].table_base = s * L->table_size; vp[s].table_mask = L->table_size - 1; }
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_vp.p, vp.data(), S * sizeof(VoxelParams), hipMemcpyHostToDevice, st));
-    std::vector<int> bbox_init(6 * S);
-    for (int s = 0; s < S; ++s) for (int a = 0; a < 3; ++a) { bbox_init[6 * s + a] = 0x7fffffff; bbox_init[6 * s + 3 + a] = (int)0x80000000; }
-    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_bbox.p, bbox_init.data(), bbox_init.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    // the bounding boxes: left by the one-pass preprocess when the filter's input is its output (k_pre_stream), else computed here
+    const bool have_bbox = L->pre_bbox_valid && d_in == L->d_pre.p;
+    L->pre_bbox_valid = false;
+    if (!have_bbox) {
+        std::vector<int> bbox_init(6 * S);
+        for (int s = 0; s < S; ++s) for (int a = 0; a < 3; ++a) { bbox_init[6 * s + a] = 0x7fffffff; bbox_init[6 * s + 3 + a] = (int)0x80000000; }
+        TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_bbox.p, bbox_init.data(), bbox_init.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_n_vox.p, 0, (size_t)S * sizeof(int), st));
     TC2LI_HIP_CHECK(hipMemsetAsync(L->d_down_count.p, 0, (size_t)S * sizeof(int), st));  // an empty scan has no block that would write its count
-    launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
+    if (!have_bbox) launch_voxel_bbox(d_in, d_in_count, L->d_slots.p, L->d_blocks.p, nb, L->d_bbox.p, st);
     launch_voxel_params(L->d_bbox.p, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, st);
     // a batch of scans: one workgroup per scan sorts its (voxel, point) pairs (lidar_kernels.hip, "sorted form"); a few scans: the hash
     // form, whose passes are spread over all points.  TC2LI_VOXEL_SORTED=0 / 1 forces one (the tests run both).

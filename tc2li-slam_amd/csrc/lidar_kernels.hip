@@ -111,6 +111,68 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_scatter(const VelodynePoint* 
 // ---- b3: pcl::VoxelGrid<PointXYZINormal>::filter (LidarFrontEnd.cpp:712-714, 913-915) -------------------------------
 __device__ __forceinline__ bool finite3(const PointXYZINormal& p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
 
+// b1 for a batch of scans in ONE pass over the raw points (round 4; k_pre_count + k_seg_scan + k_pre_scatter read every raw scan twice):
+// one workgroup per scan walks it 1024 points at a time with a running count of the points kept so far -- the output order is the
+// scan's -- and leaves, in the same pass, the bounding box of the kept finite points where the voxel filter's k_voxel_bbox would put it
+// (one more read of the preprocessed cloud saved when the filter follows directly).  Only every point_filter_num-th record can be kept:
+// the others are not even loaded.  The next chunk's records are requested before this chunk's barriers.
+__global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* __restrict__ raw, const int* __restrict__ raw_count,
+                                                          const ScanSlot* __restrict__ slots, PreprocessParams prm, PointXYZINormal* __restrict__ out,
+                                                          int* __restrict__ out_count, int* __restrict__ bbox_enc) {
+    __shared__ int s_wave[kSegBlock / 64];
+    __shared__ int s_min[3], s_max[3];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const ScanSlot sl = slots[s];
+    const int n = raw_count[s];
+    if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; }
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(raw + sl.raw_base);
+    auto wanted = [&](int i) { return i < n && i % prm.point_filter_num == 0; };
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (wanted(tid)) { a = src[2 * (size_t)tid]; b = src[2 * (size_t)tid + 1]; }
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    int kept = 0;
+    for (int c0 = 0; c0 < n; c0 += kSegBlock) {
+        const int i = c0 + tid;
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+        if (wanted(i + kSegBlock)) { na = src[2 * (size_t)(i + kSegBlock)]; nb = src[2 * (size_t)(i + kSegBlock) + 1]; }
+        // VelodynePoint: x y z pad0 | intensity time (ring, pad1) pad2
+        const bool f = wanted(i) && (double)(a.x * a.x + a.y * a.y + a.z * a.z) > prm.blind_sq;
+        int total;
+        const int pos = block_flag_scan(f, s_wave, total);
+        if (f) {
+            PointXYZINormal o;
+            o.x = a.x; o.y = a.y; o.z = a.z; o.pad0 = 1.0f;
+            o.normal_x = 0; o.normal_y = 0; o.normal_z = 0; o.pad1 = 0;
+            o.intensity = b.x;
+            o.curvature = b.y * prm.time_unit_scale;  // milliseconds (preprocess.cpp:157)
+            o.pad2 = 0; o.pad3 = 0;
+            out[sl.base + kept + pos] = o;
+            if (finite3(o)) {
+                mn[0] = min(mn[0], enc_float(o.x)); mx[0] = max(mx[0], enc_float(o.x));
+                mn[1] = min(mn[1], enc_float(o.y)); mx[1] = max(mx[1], enc_float(o.y));
+                mn[2] = min(mn[2], enc_float(o.z)); mx[2] = max(mx[2], enc_float(o.z));
+            }
+        }
+        kept += total;
+        a = na; b = nb;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn[ax] = min(mn[ax], __shfl_xor(mn[ax], o, 64));
+            mx[ax] = max(mx[ax], __shfl_xor(mx[ax], o, 64));
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { atomicMin(&s_min[ax], mn[ax]); atomicMax(&s_max[ax], mx[ax]); }
+    }
+    __syncthreads();
+    if (tid < 3) { bbox_enc[s * 6 + tid] = s_min[tid]; bbox_enc[s * 6 + 3 + tid] = s_max[tid]; }
+    if (tid == 0) out_count[s] = kept;
+}
+
 __global__ __launch_bounds__(kSegBlock) void k_voxel_bbox(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                           const ScanSlot* __restrict__ slots, const SegBlock* __restrict__ blocks,
                                                           int* __restrict__ bbox_enc) {
@@ -1387,6 +1449,10 @@ __global__ __launch_bounds__(kSegBlock) void k_sel_scatter(const uint8_t* __rest
 void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                       PreprocessParams prm, int* block_counts, hipStream_t st) {
     if (nblocks) TC2LI_LAUNCH(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
+}
+void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
+                       int* out_count, int* bbox_enc, hipStream_t st) {
+    if (nscans) TC2LI_LAUNCH(k_pre_stream, dim3(nscans), dim3(kSegBlock), 0, st, raw, raw_count, slots, prm, out, out_count, bbox_enc);
 }
 void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st) {
     if (nscans) TC2LI_LAUNCH(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);

@@ -25,8 +25,10 @@ def scans(synthetic):
     return [synthetic.lidar_scan(sc, f) for f in range(4)]
 
 
-@pytest.mark.parametrize("pfn,blind", [(2, 2.0), (1, 5.0), (3, 8.5), (4, 0.0)])
-def test_preprocess(fe, oracle, scans, pfn, blind):
+@pytest.mark.parametrize("form", ["blocks", "stream"])  # the two device forms (lidar_host.cpp run_preprocess): three launches over 1024-point blocks /
+@pytest.mark.parametrize("pfn,blind", [(2, 2.0), (1, 5.0), (3, 8.5), (4, 0.0)])  # one pass per scan (k_pre_stream, batches of scans)
+def test_preprocess(fe, oracle, scans, pfn, blind, form, monkeypatch):
+    monkeypatch.setenv("TC2LI_PRE_STREAM", "1" if form == "stream" else "0")
     raw = scans[0]
     got = fe.process(raw, pfn, blind, 1e-3)
     want = oracle.lidar_preprocess(raw, pfn, blind, 1e-3)
@@ -63,6 +65,35 @@ def test_voxel_filter(fe, oracle, scans, leaf, form, monkeypatch):
     wide["x"][11::97] = np.float32(np.nan); wide["z"][5::131] = np.float32(np.inf)
     assert same_points(fe.voxel_filter(wide, leaf), oracle.voxel_grid(wide, leaf))
     assert len(fe.voxel_filter(pts[:0], leaf)) == 0
+
+
+def test_frontend_batch_preprocess_and_filter_forms(pkg, oracle, scans, monkeypatch):
+    """tc2li_lidar_frontend_batch with the one-pass preprocess (k_pre_stream, which also hands the voxel filter its bounding boxes) and with
+    the three-launch form: the oracle's numbers of preprocessed and down-sampled points per scan, and the same selected features byte for
+    byte from both forms -- ragged scans, an empty one, NaN / inf coordinates."""
+    import torch
+    batch = [scans[0], scans[1][:50001].copy(), scans[2][:0], scans[3][:777]]
+    batch[1]["x"][10::101] = np.float32(np.nan); batch[1]["z"][6::313] = np.float32(np.inf)
+    f4 = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=4)
+    raw = torch.from_numpy(np.concatenate(batch).view(np.uint8)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(b) for b in batch])]).astype(np.int32)
+    boot = oracle.voxel_grid(oracle.lidar_preprocess(scans[0]))
+    maps = []
+    for _ in batch:
+        m = pkg.LidarMap(); m.Build(boot); maps.append(m)
+    st = np.stack([pkg.pack_lidar_state(np.eye(3), np.zeros(3))] * 4)
+    out = {}
+    for stream in (0, 1):
+        monkeypatch.setenv("TC2LI_PRE_STREAM", str(stream))
+        counts, ori, corr = f4.frontend_batch(raw.data_ptr(), offs, maps, st, want_points=True)
+        for s, b in enumerate(batch):
+            pre = oracle.lidar_preprocess(b)
+            assert int(counts[0][s]) == len(pre) and int(counts[1][s]) == len(oracle.voxel_grid(pre)), (stream, s)
+        out[stream] = (counts.copy(), ori.copy(), corr.copy())
+    assert out[0][0][2][0] > 1000  # the first scan finds its features in the map of its own points
+    for a, b in zip(out[0], out[1]):
+        assert a.tobytes() == b.tobytes()
+    f4.close()
 
 
 def test_feature_extraction(pkg, fe, oracle, synthetic, scans):
