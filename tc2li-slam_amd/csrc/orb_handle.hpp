@@ -68,6 +68,8 @@ struct tc2li_orb {
     tc2li::ScaleTable scale_tab{};
 
     hipStream_t side_stream = nullptr;
+    hipStream_t chunk_stream = nullptr;  // the odd chunks of a chunked batch call (round 4): their kernels overlap the even chunks' bus-bound tails
+    hipEvent_t ev_fork = nullptr;
     // per chunk of a batch call (tc2li_orb_extract_batch pipelines chunks of images): 0/1 pyramid, 8/3 FAST, 3/2 compaction, 4/5 blur, 6/7 descriptors
     // 9/10 keypoint distribution
     static constexpr int kMaxChunks = 4, kEvPerChunk = 11;
@@ -82,6 +84,8 @@ struct tc2li_orb {
     ~tc2li_orb() {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (chunk_stream) (void)hipStreamDestroy(chunk_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
 };
 

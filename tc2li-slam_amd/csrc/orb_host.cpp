@@ -265,6 +265,8 @@ int tc2li_orb_create(const tc2li_orb_params* p, int max_width, int max_height, i
     o->d_levels.resize(L); o->d_blur.resize(L);
     o->d_xofs.resize(L); o->d_yofs.resize(L); o->d_ialpha.resize(L); o->d_ibeta.resize(L);
     TC2LI_HIP_CHECK(hipStreamCreateWithFlags(&o->side_stream, hipStreamNonBlocking));
+    TC2LI_HIP_CHECK(hipStreamCreateWithFlags(&o->chunk_stream, hipStreamNonBlocking));
+    TC2LI_HIP_CHECK(hipEventCreateWithFlags(&o->ev_fork, hipEventDisableTiming));
     for (auto& e : o->ev) TC2LI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventBlockingSync));  // timed, and waited on without spinning
     int rc = setup_geometry(o.get(), max_width, max_height);
     if (rc != TC2LI_OK) return rc;
@@ -351,7 +353,13 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     // 1.21); a stereo pair alone is 16 jobs, each a long chain of rounds, and more lanes shorten a round (0.265 / 0.223 / 0.214 ms)
     static const int kQuadThreadsEnv = getenv("TC2LI_QUADTREE_THREADS") ? atoi(getenv("TC2LI_QUADTREE_THREADS")) : 0;
     const int kQuadThreads = kQuadThreadsEnv > 0 ? kQuadThreadsEnv : 0;  // 0: keys sorted by path in LDS (quadtree_kernels.hip); > 0: the global-memory form with that many lanes
-    const int want_chunks = kChunkEnv > 0 ? kChunkEnv : 1;
+    // Round 4: a large batch goes in TWO chunks on two streams -- the tail of a chunk (k_orient_describe and k_quadtree_gather write the host
+    // mirrors of 92 MB per 1024 images over the bus; the distribution kernel's last workgroups) runs under the other chunk's FAST and blur
+    // instead of holding the extraction stream alone.  (On one stream chunking only added tails: 2.4 / 2.9 / 3.9 ms for 1 / 2 / 4 chunks.)
+    // TC2LI_ORB_CHUNK_STREAMS=0: the chunks one after the other on the caller's stream, as before (A/B measurements).
+    const char* cs_env = getenv("TC2LI_ORB_CHUNK_STREAMS");
+    const bool two_streams = !(cs_env && atoi(cs_env) == 0);
+    const int want_chunks = kChunkEnv > 0 ? kChunkEnv : (M >= 256 && two_streams ? 2 : 1);
     const int n_chunks = o->profiling ? 1 : std::max(1, std::min(std::min(want_chunks, (int)tc2li_orb::kMaxChunks), M));
     o->last_chunks = n_chunks;
     hipStream_t blur_st = o->profiling ? st : o->side_stream;
@@ -360,47 +368,52 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     const int kp_stride = o->kp_cap_per_image;
     TC2LI_HIP_CHECK(hipMemsetAsync(o->d_status.p, 0, sizeof(int), st));
     if (ncells == 0) TC2LI_HIP_CHECK(hipMemsetAsync(o->d_level_counts.p, 0, (size_t)M * L * sizeof(int), st));
+    if (n_chunks > 1 && two_streams && !o->profiling) TC2LI_HIP_CHECK(hipEventRecord(o->ev_fork, st));
     for (int c = 0; c < n_chunks; ++c) {
         const int i0 = chunk_begin(c), m = chunk_begin(c + 1) - i0;
+        hipStream_t cst = ((c & 1) && two_streams && !o->profiling) ? o->chunk_stream : st;  // this chunk's stream
+        if (cst != st) TC2LI_HIP_CHECK(hipStreamWaitEvent(cst, o->ev_fork, 0));  // behind whatever the caller's stream held when the call began
         LevelTable craw = raw, cblur = blur;  // this chunk's images
         for (int l = 0; l < L; ++l) {
             craw.lv[l].img = raw.lv[l].img + (size_t)i0 * raw.lv[l].img_stride;
             cblur.lv[l].img = blur.lv[l].img + (size_t)i0 * blur.lv[l].img_stride;
         }
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 0), st));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 0), cst));
         for (int l = 1; l < L; ++l)
-            launch_resize(craw.lv[l - 1], craw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, m, st);
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 1), st));
+            launch_resize(craw.lv[l - 1], craw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, m, cst);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 1), cst));
         if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, EV(c, 1), 0));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 4), blur_st));
         launch_blur_all(craw, cblur, L, m, o->gauss_rounded_taps, blur_st);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 5), blur_st));
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 8), st));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 8), cst));
         if (ncells > 0) {
             launch_fast(craw, o->d_cells.p, ncells, o->prm.ini_th_fast, o->prm.min_th_fast, o->d_slab.p + (size_t)i0 * o->slab_per_image,
                         (size_t)o->slab_per_image, o->d_cell_counts.p + (size_t)i0 * ncells, m, o->d_cell_ids.p, o->n_small_cells,
-                        o->d_cell_ids.p + o->n_small_cells, o->n_large_cells, st);
-            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
+                        o->d_cell_ids.p + o->n_small_cells, o->n_large_cells, cst);
+            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), cst));
             launch_compact(o->d_cells.p, o->d_level_cell_begin.p, o->d_cell_counts.p + (size_t)i0 * ncells, ncells,
                            o->d_slab.p + (size_t)i0 * o->slab_per_image, (size_t)o->slab_per_image,
-                           o->d_dense.p + (size_t)i0 * o->slab_per_image, o->d_level_dense_off.p, o->d_level_counts.p + (size_t)i0 * L, L, m, st);
+                           o->d_dense.p + (size_t)i0 * o->slab_per_image, o->d_level_dense_off.p, o->d_level_counts.p + (size_t)i0 * L, L, m, cst);
         } else {
-            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), st));
+            TC2LI_HIP_CHECK(hipEventRecord(EV(c, 3), cst));
         }
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 2), st));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 2), cst));
         // ---- stage 2: keypoint distribution per (image, level), and the per-image keypoint lists ----
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 9), st));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 9), cst));
         launch_quadtree(o->d_jobs.p, i0 * L, m * L, o->d_dense.p, o->d_level_counts.p, o->d_qscratch.p, o->d_picked.p, o->d_picked_count.p, o->d_status.p,
-                        kQuadThreads, L, st);
+                        kQuadThreads, L, cst);
         launch_quadtree_gather(o->d_jobs.p, o->d_picked.p, o->d_picked_count.p, o->d_level_counts.p, i0, m, L, kp_stride, o->d_kps.p, o->h_kps.p, o->d_nkp.p,
-                               o->h_nkp.p, o->h_level_counts.p, o->d_status.p, st);
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 10), st));
+                               o->h_nkp.p, o->h_level_counts.p, o->d_status.p, cst);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 10), cst));
         // ---- stage 3: orientation + descriptors of the chunk's keypoints ----
-        TC2LI_HIP_CHECK(hipStreamWaitEvent(st, EV(c, 5), 0));
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 6), st));
-        launch_orient_describe(raw, blur, o->scale_tab, o->d_kps.p, o->d_nkp.p, i0, m, kp_stride, o->h_angles.p, o->d_angles.p, o->h_desc.p, o->d_mkeys.p, o->d_desc.p, st);
-        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 7), st));
+        TC2LI_HIP_CHECK(hipStreamWaitEvent(cst, EV(c, 5), 0));
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 6), cst));
+        launch_orient_describe(raw, blur, o->scale_tab, o->d_kps.p, o->d_nkp.p, i0, m, kp_stride, o->h_angles.p, o->d_angles.p, o->h_desc.p, o->d_mkeys.p, o->d_desc.p, cst);
+        TC2LI_HIP_CHECK(hipEventRecord(EV(c, 7), cst));
     }
+    for (int c = 1; c < n_chunks; c += 2)  // the odd chunks' work joins the caller's stream
+        if (two_streams && !o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(st, EV(c, 7), 0));
     TC2LI_HIP_CHECK(hipMemcpyAsync(o->h_status.p, o->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipGetLastError());
     WorkerPool& pool = global_pool();
