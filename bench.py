@@ -168,6 +168,34 @@ def sweep_children(args):
     return out
 
 
+def thread_cpu_seconds():
+    """{thread name: CPU seconds so far} summed over the threads of this process with that name (/proc/self/task/*/stat)."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open("/proc/self/task/%s/stat" % tid).read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[name] = out.get(name, 0.0) + (int(f[11]) + int(f[12])) / tick
+        except Exception:  # noqa: BLE001
+            pass
+    return out
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use per second (cgroup v2 cpu.max, v1 cfs quota); None: unlimited / unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def apply_host_budget(pkg, local_rank):
     """The host side of a rank: with R ranks on the node every rank keeps to its share of the cores this job may run on --
     a contiguous block of the affinity list (ranks follow the GPUs; on the 8-GPU nodes neighbouring cores and neighbouring GPUs share a socket),
@@ -347,6 +375,11 @@ class StageWorker:
         self.t.start()
 
     def _main(self, local_rank, torch):
+        try:  # the thread's name where top -H and /proc/<pid>/task/*/comm show it
+            import ctypes
+            ctypes.CDLL(None).prctl(15, threading.current_thread().name[:15].encode(), 0, 0, 0)
+        except Exception:  # noqa: BLE001
+            pass
         torch.cuda.set_device(local_rank)  # HIP's current device is per thread; a new thread starts on device 0
         while True:
             item = self.q.get()
@@ -1252,10 +1285,19 @@ def main(argv=None):
     barrier()
     loop.orb_times.clear(); loop.lidar_times.clear()
     ba0 = loop.ba_windows_done
+    tcpu0 = thread_cpu_seconds()
+    cpu0 = os.times()
     t0 = time.perf_counter()
     loop.run(args.steps, stages)
     barrier()
     local_elapsed = time.perf_counter() - t0
+    cpu1 = os.times()
+    host_budget["cpu_s_per_wall_s_timed_region"] = round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(local_elapsed, 1e-9), 2)
+    host_budget["cgroup_cpu_quota"] = cgroup_cpu_quota()
+    tcpu1 = thread_cpu_seconds()
+    host_budget["cpu_s_per_wall_s_by_thread_name"] = {k: round((v - tcpu0.get(k, 0.0)) / max(local_elapsed, 1e-9), 2)
+                                                       for k, v in sorted(tcpu1.items(), key=lambda kv: -(kv[1] - tcpu0.get(kv[0], 0.0)))
+                                                       if v - tcpu0.get(k, 0.0) > 0.02 * local_elapsed}
     elapsed = dist_util.max_elapsed(dist, local_elapsed, device="cuda" if args.backend == "nccl" else "cpu")
     ranks_seen = dist_util.count_ranks(dist, device="cuda" if args.backend == "nccl" else "cpu")
     if set(stages) != {"orb", "track", "lidar", "ba"}:  # diagnostics: which stages slow each other down

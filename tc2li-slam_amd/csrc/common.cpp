@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #if defined(__linux__)
+#include <pthread.h>
 #include <sched.h>
 #endif
 
@@ -127,8 +128,13 @@ bool acquire(const char* name, hipEvent_t* start, hipEvent_t* stop) {
 }
 }  // namespace prof
 
-WorkerPool::WorkerPool(int nthreads) {
-    for (int i = 0; i < nthreads - 1; ++i) workers_.emplace_back([this] { loop(); });
+WorkerPool::WorkerPool(int nthreads, const char* name) {
+    for (int i = 0; i < nthreads - 1; ++i) {
+        workers_.emplace_back([this] { loop(); });
+#if defined(__linux__)
+        if (name) (void)pthread_setname_np(workers_.back().native_handle(), name);  // <= 15 characters: visible in /proc/<pid>/task/*/comm, top -H
+#endif
+    }
 }
 
 WorkerPool::~WorkerPool() {
@@ -254,7 +260,11 @@ int pool_threads(int id) {
 
 WorkerPool& named_pool(int id) {
     std::lock_guard<std::mutex> lk(g_pools_mu);
-    if (!g_pools[id]) g_pools[id] = new WorkerPool(pool_threads(id));
+    if (!g_pools[id]) {
+        const char* name = id == kPoolGlobal ? "tc2li-orb" : id == kPoolTracking ? "tc2li-track" : id == kPoolLidar ? "tc2li-lidar" :
+                           id == kPoolBaTop || id == kPoolLviTop ? "tc2li-ba-top" : "tc2li-ba-group";
+        g_pools[id] = new WorkerPool(pool_threads(id), name);
+    }
     return *g_pools[id];
 }
 

@@ -108,7 +108,7 @@ struct PinnedBuf {
 // Runs fn(i) for i in [0, n) on a fixed set of worker threads (the caller participates).
 class WorkerPool {
 public:
-    explicit WorkerPool(int nthreads);
+    explicit WorkerPool(int nthreads, const char* name = nullptr);
     ~WorkerPool();
     void parallel_for(int n, const std::function<void(int)>& fn);
     int size() const { return (int)workers_.size() + 1; }
