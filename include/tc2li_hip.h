@@ -857,6 +857,14 @@ int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_l
 int tc2li_host_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar_window* lidar, double* clusters, double* coe,
                             int capacity);
 
+/* The same planes from the kernels that extract them for the windows of the batched local BA entry points (round 4: cut_voxel / recut as
+ * three stable sorts of the window's points and a plane test per cell, balm_cut_kernels.hip): same layout, and the same bits as
+ * tc2li_host_lidar_planes.  info (may be NULL) receives [planes, declined, root voxels, planes found].  A window outside the kernels'
+ * range (more than 7 keyframes, 65535 points or 2048 planes, coordinates beyond +-1e6 voxels) is TC2LI_ERR_INVALID here; the BA entry
+ * points take the host extraction for such a window. */
+int tc2li_device_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar_window* lidar, double* clusters, double* coe,
+                              int capacity, int32_t* info);
+
 /* Host-only stage of the extractor, exposed so that it can be checked without a GPU: keypoint distribution of
  * ORBextractor::DistributeOctTree (SF/src/ORBextractor.cc:529-753).  Candidates are (x, y, response) triples with
  * integer-valued x, y in the border-free level frame, in cv::FAST emission order; writes the retained triples in

@@ -127,6 +127,7 @@ def lib():
     L.tc2li_local_inertial_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 5
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.tc2li_device_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     L.tc2li_project_last_frame.argtypes = [C.c_void_p] * 3 + [C.c_float, C.c_float, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_void_p]
     L.tc2li_project_local_map.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
@@ -1474,6 +1475,17 @@ def lidar_planes_host(poses7, win_pose, clouds, Tcl7, capacity=20000):
     n = _check(lib().tc2li_host_lidar_planes(poses.ctypes.data, len(poses), C.addressof(w), out.ctypes.data, coe.ctypes.data, capacity))
     del keep
     return out[:n].copy(), coe[:n].copy()
+
+
+def lidar_planes_device(poses7, win_pose, clouds, Tcl7, capacity=2048):
+    """The same planes from the extraction kernels of the batched local BA (``tc2li_device_lidar_planes``) ->
+    (clusters [n, W, 10], coe [n], info [4] = planes, declined, root voxels, planes found)."""
+    poses = np.ascontiguousarray(poses7, np.float64)
+    w, keep = _pack_lidar_window(win_pose, clouds, Tcl7, 1.0)
+    out, coe, info = np.zeros((capacity, w.n_keyframes, 10)), np.zeros(capacity), np.zeros(4, np.int32)
+    n = _check(lib().tc2li_device_lidar_planes(poses.ctypes.data, len(poses), C.addressof(w), out.ctypes.data, coe.ctypes.data, capacity, info.ctypes.data))
+    del keep
+    return out[:n].copy(), coe[:n].copy(), info
 
 
 def local_lvi_bundle_adjustment(kf33, fixed, has_imu, calib24, points3, edges, link4, preintegrated, cam5, win_kf, clouds, Tcl7, Tbl7, weight,

@@ -1135,11 +1135,57 @@ struct LockstepContext {
     PinnedBuf<uint8_t> h_table;
     PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
     PinnedBuf<CopyTask> h_table_task;  // the steps x_p of a trial phase on their way up: one entry for k_copy_tasks
+    // plane extraction of the batch's LiDAR windows on the device (balm_cut_kernels.hip): a task per window, those with points to cut
+    // compacted into the list the kernels read, and the uploads the LiDAR tasks deferred (the clouds)
+    PinnedBuf<BalmCutTask> h_cut, h_cut_list;
+    DevBuf<BalmCutTask> d_cut_list;
+    PinnedBuf<CopyTask> h_cut_copies;
     hipStream_t st = nullptr;
     ~LockstepContext() { if (st) (void)hipStreamDestroy(st); }
 };
 struct LockstepContexts { LockstepContext c[kMaxLockstepGroups]; };
 LockstepContext& lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 0>().c[group]; }
+
+
+// The LiDAR half of a lock-step batch's setup, after its tasks (the odd entries of `deferred`) have staged the clouds and described the
+// extractions in C.h_cut[0..n): the uploads and the extraction kernels of all windows are queued in one go, so that they run while the
+// host builds the visual structure.  plane_extraction_finish (after that) waits for them and gives every window its planes.
+bool plane_extraction_begin(LockstepContext& C, std::vector<std::vector<CopyTask>>& deferred, int n, hipStream_t st) {
+    int m = 0, max_points = 0, max_table = 0;
+    if (C.h_cut_list.ensure(std::max(n, 1)) != hipSuccess || C.d_cut_list.ensure(std::max(n, 1)) != hipSuccess) return false;
+    for (int i = 0; i < n; ++i) {
+        const BalmCutTask& t = C.h_cut.p[i];
+        if (t.n_points <= 0) continue;
+        C.h_cut_list.p[m++] = t;
+        max_points = std::max(max_points, t.n_points);
+        max_table = std::max(max_table, 1 << t.table_bits);
+    }
+    if (!m) return true;
+    size_t n_copies = 1, max_bytes = (size_t)m * sizeof(BalmCutTask);
+    for (int i = 0; i < n; ++i) n_copies += deferred[2 * (size_t)i + 1].size();
+    if (C.h_cut_copies.ensure(n_copies) != hipSuccess) return false;
+    size_t at = 0;
+    C.h_cut_copies.p[at++] = CopyTask{C.d_cut_list.p, C.h_cut_list.p, (size_t)m * sizeof(BalmCutTask)};
+    for (int i = 0; i < n; ++i) {
+        for (const CopyTask& t : deferred[2 * (size_t)i + 1]) { C.h_cut_copies.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+        deferred[2 * (size_t)i + 1].clear();
+    }
+    launch_copy_tasks(C.h_cut_copies.p, (int)n_copies, max_bytes, st);
+    launch_balm_cut(C.d_cut_list.p, m, max_points, max_table, st);
+    return hipGetLastError() == hipSuccess;
+}
+// rc per window (0, or the error of a window whose planes could not be set up)
+bool plane_extraction_finish(LockstepContext& C, int n, std::vector<int>& rc_lidar, hipStream_t st) {
+    bool any = false;
+    for (int i = 0; i < n; ++i) any |= C.h_cut.p[i].n_points > 0;
+    if (!any) return true;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    for (int i = 0; i < n; ++i) {
+        if (C.h_cut.p[i].n_points <= 0 || rc_lidar[i] < 0) continue;
+        rc_lidar[i] = C.ws[i]->lidar.finish_cut(st);
+    }
+    return true;
+}
 
 // returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
 bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
@@ -1178,10 +1224,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = now();
     const double t_begin = t0;
-    // ---- setup: argument checks, plane extraction (host), uploads ----
+    // ---- setup: argument checks, plane extraction (device, queued first: it runs while the host builds the visual structure), uploads ----
     std::vector<int> rc_lidar(n, 0);
     std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);  // what the tasks would have queued as copies / fills of their own
-    pool.parallel_for(2 * n, [&](int task) {  // two tasks per window: the visual structure + uploads, the LiDAR plane extraction
+    if (C.h_cut.ensure(std::max(n, 1)) != hipSuccess) return false;
+    for (int i = 0; i < n; ++i) C.h_cut.p[i].n_points = 0;
+    auto setup_task = [&](int task) {  // two tasks per window: the visual structure + uploads (even), the LiDAR window (odd)
         CopySink sink(&deferred[task]);
         const int i = task >> 1;
         LockstepWindow& w = W[i];
@@ -1195,7 +1243,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         if (task & 1) {
             if (!args_ok || !lidar_ok || !p.lidar) return;
             const double tb = now();
-            rc_lidar[i] = C.ws[i]->lidar.build(p.poses7, p.n_poses, p.lidar, st);
+            rc_lidar[i] = C.ws[i]->lidar.build(p.poses7, p.n_poses, p.lidar, st, &C.h_cut.p[i]);
             if (kTiming && i == 0) fprintf(stderr, "  window 0: lidar build %.3f ms\n", now() - tb);
             return;
         }
@@ -1228,7 +1276,14 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             w.Hl = ws.h_Hl.p; w.bl_ = ws.h_Hl.p + nn;
             std::fill(w.Hl, w.Hl + nn + n1, 0.0);
         }
-    });
+    };
+    pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
+    if (!plane_extraction_begin(C, deferred, n, st)) { (void)hipStreamSynchronize(st); return false; }
+    if (kTiming) fprintf(stderr, "  lidar tasks + queueing the extraction: %.3f ms\n", now() - t0);
+    pool.parallel_for(n, [&](int i) { setup_task(2 * i); });
+    if (kTiming) fprintf(stderr, "  + visual tasks: %.3f ms\n", now() - t0);
+    if (!plane_extraction_finish(C, n, rc_lidar, st)) return false;
+    if (kTiming) fprintf(stderr, "  + extraction back: %.3f ms\n", now() - t0);
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0 || !problems[i].lidar) continue;
         if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
@@ -1613,10 +1668,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
     double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LviWindow> W(n);
-    // ---- setup: argument checks, inertial links, plane extraction (host), uploads ----
+    // ---- setup: argument checks, inertial links, plane extraction (device, queued first), uploads ----
     std::vector<int> rc_lidar(n, 0);
     std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);
-    pool.parallel_for(2 * n, [&](int task) {  // two tasks per window: structure + uploads, the LiDAR plane extraction
+    if (C.h_cut.ensure(std::max(n, 1)) != hipSuccess) return false;
+    for (int i = 0; i < n; ++i) C.h_cut.p[i].n_points = 0;
+    auto setup_task = [&](int task) {  // two tasks per window: structure + uploads (even), the LiDAR window (odd)
         CopySink sink(&deferred[task]);
         const int i = task >> 1;
         LviWindow& w = W[i];
@@ -1630,7 +1687,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         }
         if (task & 1) {
             if (!args_ok || !lidar_ok || !p.lidar) return;
-            rc_lidar[i] = C.ws[i]->lidar.build_body(p.keyframes, sizeof(tc2li_inertial_keyframe), p.n_keyframes, p.lidar, p.Tbl, sizeof(ImuPose), st);
+            rc_lidar[i] = C.ws[i]->lidar.build_body(p.keyframes, sizeof(tc2li_inertial_keyframe), p.n_keyframes, p.lidar, p.Tbl, sizeof(ImuPose), st, &C.h_cut.p[i]);
             return;
         }
         w.p = &p; w.ws = C.ws[i].get();
@@ -1663,7 +1720,11 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         memcpy(&pb.calib, calib, sizeof(ImuCalib));
         const int nn = w.inertial.n;
         w.M.assign((size_t)std::max(nn * nn, 1), 0.0); w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
-    });
+    };
+    pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
+    if (!plane_extraction_begin(C, deferred, n, st)) { (void)hipStreamSynchronize(st); return false; }
+    pool.parallel_for(n, [&](int i) { setup_task(2 * i); });
+    if (!plane_extraction_finish(C, n, rc_lidar, st)) return false;
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0 || !problems[i].lidar) continue;
         if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;

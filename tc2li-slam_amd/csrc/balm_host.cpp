@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -55,6 +56,15 @@ struct PlaneScratch {
     std::vector<Cell> stack;
 };
 
+// keyframe i's LiDAR frame -> keyframe 0's: x0 = R x + p (cut_voxel works in the frame of the window's first keyframe)
+static void window_relative(const LidarPose* twl, int i, double R[9], double p[3]) {
+    double R0t[9], d[3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R0t[3 * r + c] = twl[0].R[3 * c + r];
+    for (int k = 0; k < 3; ++k) d[k] = twl[i].p[k] - twl[0].p[k];
+    m3_vec(R0t, d, p);
+    m3_mul(R0t, twl[i].R, R);
+}
+
 void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const int32_t* off, std::vector<PlaneCluster>& clusters,
                        std::vector<double>& coe) {
     static thread_local PlaneScratch ws;
@@ -64,8 +74,6 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
     std::vector<WindowPoint>& pts = ws.pts;
     pts.resize(total);
     // ---- points into the frame of the first keyframe's LiDAR, root voxel of every point ----
-    double R0t[9];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R0t[3 * r + c] = twl[0].R[3 * c + r];
     size_t cap = 64;
     int cap_bits = 6;
     while (cap < (size_t)total) { cap <<= 1; ++cap_bits; }  // every point its own voxel still leaves the table half empty
@@ -78,10 +86,8 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
     root_id.resize(total);
     const VoxelKeyHash hasher;
     for (int i = 0; i < W; ++i) {
-        double d[3], p[3], R[9];
-        for (int k = 0; k < 3; ++k) d[k] = twl[i].p[k] - twl[0].p[k];
-        m3_vec(R0t, d, p);
-        m3_mul(R0t, twl[i].R, R);
+        double p[3], R[9];
+        window_relative(twl, i, R, p);
         VoxelKey last_key{0, 0, 0};
         int last_id = -1;  // consecutive returns of a scan mostly fall into the same voxel
         for (int j = off[i]; j < off[i + 1]; ++j) {
@@ -394,16 +400,16 @@ int BalmTerm::window_poses(const double* poses7, int n_poses, const tc2li_lidar_
     return 0;
 }
 
-int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st) {
+int BalmTerm::build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st, BalmCutTask* cut) {
     std::vector<LidarPose> twl;
     const int rcw = window_poses(poses7, n_poses, win, twl);
     if (rcw < 0) return rcw;
     body = false;
-    return upload(twl, win, st);
+    return upload(twl, win, st, cut);
 }
 
 int BalmTerm::build_body(const void* kfs, size_t kf_bytes, int n_kfs, const tc2li_lidar_window* win, const float* Tbl7, size_t imu_pose_bytes,
-                         hipStream_t st) {
+                         hipStream_t st, BalmCutTask* cut) {
     const int rc = check_window(win, n_kfs);
     if (rc < 0) return rc;
     SE3f tcl;
@@ -417,12 +423,29 @@ int BalmTerm::build_body(const void* kfs, size_t kf_bytes, int n_kfs, const tc2l
     body = true;
     memcpy(Tbl.q, Tbl7, 4 * sizeof(float));
     memcpy(Tbl.t, Tbl7 + 4, 3 * sizeof(float));
-    const int r = upload(twl, win, st);
+    const int r = upload(twl, win, st, cut);
     dev.imu_pose_bytes = (int32_t)imu_pose_bytes;
     return r;
 }
 
-int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st) {
+int BalmTerm::set_planes(int n) {
+    n_planes = n;
+    dev.n_planes = n;
+    // a workgroup of the Hessian kernel takes whole batches of planes (8 for windows of <= 7 keyframes, else 4: balm_kernels.hip), at
+    // most 1024 workgroups; a function of the window alone (the partial sums' grouping decides the bits)
+    const int plane_batch = W <= 7 ? 8 : 4;
+    dev.planes_per_chunk = plane_batch * std::max(1, (n_planes + plane_batch * 1024 - 1) / (plane_batch * 1024));
+    dev.n_chunks = n_planes ? (n_planes + dev.planes_per_chunk - 1) / dev.planes_per_chunk : 1;
+    TC2LI_HIP_CHECK(d_plane_res.ensure(std::max(n_planes, 1)));
+    TC2LI_HIP_CHECK(d_eig.ensure((size_t)kBalmEig * std::max(n_planes, 1)));
+    eig_at = nullptr;
+    TC2LI_HIP_CHECK(d_part.ensure((size_t)dev.n_chunks * balm_part_stride(W)));
+    dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
+    dev.plane_res = d_plane_res.p; dev.eig = d_eig.p; dev.part = d_part.p; dev.out = h_out.p;
+    return 0;
+}
+
+int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st, BalmCutTask* cut) {
     W = win->n_keyframes;
     memcpy(Tcl.q, win->Tcl, 4 * sizeof(float));
     memcpy(Tcl.t, win->Tcl + 4, 3 * sizeof(float));
@@ -431,6 +454,63 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     JacT.assign(6 * (size_t)W, 0.0);
     Hessian.assign(36 * (size_t)W * W, 0.0);
     pose_index.assign(win->pose_index, win->pose_index + W);
+    dev = BalmDev{};
+    dev.W = W;
+    dev.Tcl = Tcl;
+    cut_pending = false;
+    TC2LI_HIP_CHECK(d_pose_index.ensure(W));
+    TC2LI_HIP_CHECK(d_twl.ensure(W));
+    TC2LI_HIP_CHECK(h_out.ensure(balm_out_size(W)));
+    TC2LI_HIP_CHECK(h_twl.ensure(W));
+    const int total = win->cloud_offsets[W];
+    if (cut) cut->n_points = 0;
+    static const bool kHostCut = getenv("TC2LI_BALM_HOST_CUT") && atoi(getenv("TC2LI_BALM_HOST_CUT")) != 0;  // measurement: the round-3 path
+    if (cut && !kHostCut && copy_sink_active() && W <= kBalmCutMaxW && total <= kBalmCutMaxPoints) {
+        // ---- the extraction runs on the device: stage the clouds, carve the work space, describe the window ----
+        const size_t cloud_bytes = ((size_t)total * 3 * sizeof(float) + 15) & ~(size_t)15;
+        TC2LI_HIP_CHECK(h_upload.ensure(cloud_bytes + W * sizeof(int32_t) + 16));
+        TC2LI_HIP_CHECK(h_cut_result.ensure(4));
+        uint8_t* h = h_upload.p;
+        memcpy(h, win->cloud_xyz, (size_t)total * 3 * sizeof(float));
+        memcpy(h + cloud_bytes, pose_index.data(), W * sizeof(int32_t));
+        int bits = 7;
+        while (((size_t)1 << bits) < 2 * (size_t)total) ++bits;
+        const size_t cap = (size_t)1 << bits, n = (size_t)total;
+        size_t at = 0;
+        auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 15) & ~(size_t)15; return o; };
+        const size_t o_key = take(cap * 8), o_first = take(cap * 4), o_id = take(cap * 4), o_world = take(n * 24), o_cloud = take(cloud_bytes), o_oct = take(n),
+                     o_slot = take(n * 4), o_ka = take(n * 4), o_kb = take(n * 4), o_va = take(n * 4), o_vb = take(n * 4), o_order = take(3 * n * 4),
+                     o_begin = take(3 * (n + 1) * 4), o_ckey = take(3 * n * 4), o_flag = take(3 * n), o_ncells = take(16), o_plane = take(kBalmCutMaxPlanes * 4),
+                     o_state = take(16);
+        TC2LI_HIP_CHECK(d_cut.ensure(at));
+        TC2LI_HIP_CHECK(d_clusters.ensure((size_t)kBalmCutMaxPlanes * W));
+        TC2LI_HIP_CHECK(d_coe.ensure(kBalmCutMaxPlanes));
+        uint8_t* d = d_cut.p;
+        TC2LI_HIP_CHECK(upload_or_defer(d + o_cloud, h, cloud_bytes, st));
+        TC2LI_HIP_CHECK(upload_or_defer(d_pose_index.p, h + cloud_bytes, W * sizeof(int32_t), st));
+        BalmCutTask& T = *cut;
+        T = BalmCutTask{};
+        T.W = W; T.n_points = total; T.table_bits = bits;
+        for (int i = 0; i <= kBalmCutMaxW; ++i) T.cloud_off[i] = win->cloud_offsets[std::min(i, W)];
+        for (int i = 0; i < W; ++i) window_relative(twl.data(), i, T.rel[i].R, T.rel[i].p);
+        T.cloud = (const float*)(d + o_cloud);
+        T.table_key = (unsigned long long*)(d + o_key); T.table_first = (int32_t*)(d + o_first); T.table_id = (int32_t*)(d + o_id);
+        T.world = (double*)(d + o_world); T.oct = d + o_oct; T.point_slot = (int32_t*)(d + o_slot);
+        T.sort_key_a = (unsigned int*)(d + o_ka); T.sort_key_b = (unsigned int*)(d + o_kb); T.sort_val_a = (int32_t*)(d + o_va); T.sort_val_b = (int32_t*)(d + o_vb);
+        T.order = (int32_t*)(d + o_order); T.cell_begin = (int32_t*)(d + o_begin); T.cell_key = (unsigned int*)(d + o_ckey); T.cell_flag = d + o_flag;
+        T.n_cells = (int32_t*)(d + o_ncells); T.plane_cell = (int32_t*)(d + o_plane); T.state = (int32_t*)(d + o_state);
+        T.result_host = h_cut_result.p;
+        T.clusters = d_clusters.p; T.coe = d_coe.p;
+        h_cut_result.p[0] = 0; h_cut_result.p[1] = 1;  // (a launch that never ran reads as "declined")
+        twl_build = twl;
+        win_build = win;
+        cut_pending = true;
+        // the pose-dependent buffers at their largest, so that finish_cut allocates nothing behind the batch's synchronisation
+        TC2LI_HIP_CHECK(d_plane_res.ensure(kBalmCutMaxPlanes));
+        TC2LI_HIP_CHECK(d_eig.ensure((size_t)kBalmEig * kBalmCutMaxPlanes));
+        TC2LI_HIP_CHECK(d_part.ensure((size_t)(kBalmCutMaxPlanes / 8) * balm_part_stride(W)));
+        return set_planes(0);
+    }
     // members: the asynchronous uploads below read them, and a synchronisation here would make every window of a lock-step group
     // wait for everything the other windows have queued on the shared stream (their operand fills, their uploads)
     std::vector<PlaneCluster>& clusters = h_clusters;
@@ -438,31 +518,15 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
     clusters.clear();
     coe.clear();
     balm_build_planes(twl.data(), W, win->cloud_xyz, win->cloud_offsets, clusters, coe);
-    n_planes = (int)coe.size();
-    dev = BalmDev{};
-    dev.W = W; dev.n_planes = n_planes;
-    // a workgroup of the Hessian kernel takes whole batches of planes (8 for windows of <= 7 keyframes, else 4: balm_kernels.hip), at
-    // most 1024 workgroups; a function of the window alone (the partial sums' grouping decides the bits)
-    const int plane_batch = W <= 7 ? 8 : 4;
-    dev.planes_per_chunk = plane_batch * std::max(1, (n_planes + plane_batch * 1024 - 1) / (plane_batch * 1024));
-    dev.n_chunks = n_planes ? (n_planes + dev.planes_per_chunk - 1) / dev.planes_per_chunk : 1;
-    dev.Tcl = Tcl;
+    const int n = (int)coe.size();
     TC2LI_HIP_CHECK(d_clusters.ensure(std::max(clusters.size(), (size_t)1)));
-    TC2LI_HIP_CHECK(d_coe.ensure(std::max(n_planes, 1)));
-    TC2LI_HIP_CHECK(d_plane_res.ensure(std::max(n_planes, 1)));
-    TC2LI_HIP_CHECK(d_eig.ensure((size_t)kBalmEig * std::max(n_planes, 1)));
-    eig_at = nullptr;
-    TC2LI_HIP_CHECK(d_part.ensure((size_t)dev.n_chunks * balm_part_stride(W)));
-    TC2LI_HIP_CHECK(d_pose_index.ensure(W));
-    TC2LI_HIP_CHECK(d_twl.ensure(W));
-    TC2LI_HIP_CHECK(h_out.ensure(balm_out_size(W)));
-    TC2LI_HIP_CHECK(h_twl.ensure(W));
+    TC2LI_HIP_CHECK(d_coe.ensure(std::max(n, 1)));
     if (copy_sink_active()) {
         // a lock-step group gathers the uploads of all its windows into one launch that reads the sources in place: they must be pinned
         const size_t cb = (clusters.size() * sizeof(PlaneCluster) + 15) & ~(size_t)15, qb = (coe.size() * sizeof(double) + 15) & ~(size_t)15;
         TC2LI_HIP_CHECK(h_upload.ensure(cb + qb + W * sizeof(int32_t) + 16));
         uint8_t* h = h_upload.p;
-        if (n_planes) {
+        if (n) {
             memcpy(h, clusters.data(), clusters.size() * sizeof(PlaneCluster));
             memcpy(h + cb, coe.data(), coe.size() * sizeof(double));
             TC2LI_HIP_CHECK(upload_or_defer(d_clusters.p, h, clusters.size() * sizeof(PlaneCluster), st));
@@ -471,15 +535,32 @@ int BalmTerm::upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window
         memcpy(h + cb + qb, pose_index.data(), W * sizeof(int32_t));
         TC2LI_HIP_CHECK(upload_or_defer(d_pose_index.p, h + cb + qb, W * sizeof(int32_t), st));
     } else {
-        if (n_planes) {
+        if (n) {
             TC2LI_HIP_CHECK(hipMemcpyAsync(d_clusters.p, clusters.data(), clusters.size() * sizeof(PlaneCluster), hipMemcpyHostToDevice, st));
             TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, coe.data(), coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
         }
         TC2LI_HIP_CHECK(hipMemcpyAsync(d_pose_index.p, pose_index.data(), W * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
-    dev.clusters = d_clusters.p; dev.coe = d_coe.p; dev.pose_index = d_pose_index.p; dev.twl = d_twl.p;
-    dev.plane_res = d_plane_res.p; dev.eig = d_eig.p; dev.part = d_part.p; dev.out = h_out.p;
-    return 0;
+    return set_planes(n);
+}
+
+int BalmTerm::finish_cut(hipStream_t st) {
+    if (!cut_pending) return 0;
+    cut_pending = false;
+    const int32_t* r = h_cut_result.p;
+    if (!r[1]) return set_planes(r[0]);
+    // the kernels declined the window: the host extraction, its clusters up by a copy of their own (rare; the vectors are members)
+    h_clusters.clear();
+    h_coe.clear();
+    balm_build_planes(twl_build.data(), W, win_build->cloud_xyz, win_build->cloud_offsets, h_clusters, h_coe);
+    const int n = (int)h_coe.size();
+    TC2LI_HIP_CHECK(d_clusters.ensure(std::max(h_clusters.size(), (size_t)1)));
+    TC2LI_HIP_CHECK(d_coe.ensure(std::max(n, 1)));
+    if (n) {
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_clusters.p, h_clusters.data(), h_clusters.size() * sizeof(PlaneCluster), hipMemcpyHostToDevice, st));
+        TC2LI_HIP_CHECK(hipMemcpyAsync(d_coe.p, h_coe.data(), h_coe.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    return set_planes(n);
 }
 
 void BalmTerm::enqueue_error(const Se3* d_poses, hipStream_t st) {
@@ -583,6 +664,42 @@ extern "C" int tc2li_host_lidar_planes(const double* poses7, int n_poses, const 
     if (m > 0) {
         memcpy(clusters, cl.data(), (size_t)m * win->n_keyframes * sizeof(PlaneCluster));
         memcpy(coe, w.data(), (size_t)m * sizeof(double));
+    }
+    return n;
+}
+
+// The device extraction of one window, for the tests: the clusters balm_cut_kernels.hip forms, read back.
+extern "C" int tc2li_device_lidar_planes(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* clusters, double* coe,
+                                         int capacity, int32_t* info) {
+    using namespace tc2li;
+    if (!poses7 || n_poses <= 0 || !win || capacity < 0 || (capacity > 0 && (!clusters || !coe))) {
+        set_error("tc2li_device_lidar_planes: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    note_hip_touched();
+    BalmTerm term;
+    BalmCutTask task{};
+    std::vector<CopyTask> copies;
+    int rc;
+    {
+        CopySink sink(&copies);
+        rc = term.build(poses7, n_poses, win, nullptr, &task);
+    }
+    if (rc < 0) return rc;
+    if (task.n_points <= 0) { set_error("tc2li_device_lidar_planes: the window is outside the kernels' range (keyframes %d, points %d)", win->n_keyframes, win->cloud_offsets[win->n_keyframes]); return TC2LI_ERR_INVALID; }
+    for (const CopyTask& c : copies) TC2LI_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, nullptr));
+    DevBuf<BalmCutTask> d_task;
+    TC2LI_HIP_CHECK(d_task.ensure(1));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(d_task.p, &task, sizeof(task), hipMemcpyHostToDevice, nullptr));
+    launch_balm_cut(d_task.p, 1, task.n_points, 1 << task.table_bits, nullptr);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (info) memcpy(info, term.h_cut_result.p, 4 * sizeof(int32_t));
+    if (term.h_cut_result.p[1]) { set_error("tc2li_device_lidar_planes: the kernels declined the window (%d planes found)", term.h_cut_result.p[3]); return TC2LI_ERR_INVALID; }
+    const int n = term.h_cut_result.p[0], m = std::min(n, capacity);
+    if (m > 0) {
+        TC2LI_HIP_CHECK(hipMemcpy(clusters, term.d_clusters.p, (size_t)m * win->n_keyframes * sizeof(PlaneCluster), hipMemcpyDeviceToHost));
+        TC2LI_HIP_CHECK(hipMemcpy(coe, term.d_coe.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
     }
     return n;
 }

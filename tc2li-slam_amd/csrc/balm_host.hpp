@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "../../include/tc2li_hip.h"
+#include "balm_cut_device.hpp"
 #include "balm_device.hpp"
 #include "common.hpp"
 
@@ -50,14 +51,24 @@ struct BalmTerm {
     PinnedBuf<double> h_out;
     PinnedBuf<LidarPose> h_twl;
     PinnedBuf<uint8_t> h_upload;  // clusters | coe | pose_index of the last build when the uploads are gathered (CopySink)
+    // Plane extraction on the device (balm_cut_kernels.hip), for the windows of a lock-step batch: build / build_body given a task
+    // stage the clouds, fill the task and leave the planes pending; the batch's owner queues launch_balm_cut over all its tasks and,
+    // after its synchronisation, calls finish_cut -- the number of planes from the device, or the host extraction for a window the
+    // kernels declined (more than kBalmCutMaxPlanes planes, coordinates outside the key range).
+    DevBuf<uint8_t> d_cut;            // the work space of the extraction
+    PinnedBuf<int32_t> h_cut_result;  // [4] planes, declined, roots, planes found
+    std::vector<LidarPose> twl_build;
+    const tc2li_lidar_window* win_build = nullptr;
+    bool cut_pending = false;
+    int finish_cut(hipStream_t st);
 
     // argument checks + LiDAR poses of the window keyframes at `poses7`
     static int window_poses(const double* poses7, int n_poses, const tc2li_lidar_window* win, std::vector<LidarPose>& twl);
     // planes of the window at the poses `poses7` (Tcw per keyframe, rows pose_index of the array)
-    int build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st);
+    int build(const double* poses7, int n_poses, const tc2li_lidar_window* win, hipStream_t st, BalmCutTask* cut = nullptr);
     // the same from keyframe records whose first 12 doubles are Rcw (row-major), tcw (tc2li_inertial_keyframe); body mode
     int build_body(const void* kfs, size_t kf_bytes, int n_kfs, const tc2li_lidar_window* win, const float* Tbl7, size_t imu_pose_bytes,
-                   hipStream_t st);
+                   hipStream_t st, BalmCutTask* cut = nullptr);
     int compute_error(const Se3* d_poses, hipStream_t st);  // EdgeLidarSE3::computeError
     int linearize(const Se3* d_poses, hipStream_t st);      // EdgeLidarSE3::linearizeOplus
     // The same two steps split into "enqueue the kernels" and "use the numbers after the caller's synchronisation", so
@@ -72,7 +83,8 @@ struct BalmTerm {
     void add_quadratic_form(const int* pose_var, int ld, double* Hpp, double* b) const;
 
 private:
-    int upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st);
+    int upload(const std::vector<LidarPose>& twl, const tc2li_lidar_window* win, hipStream_t st, BalmCutTask* cut);
+    int set_planes(int n);  // everything sized by the number of planes
     static int check_window(const tc2li_lidar_window* win, int n_poses);
 };
 

@@ -21,7 +21,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write 
 # matrix-unit occupancy of the dense Schur GEMM: cycles the MFMA pipe is busy next to the cycles its waves exist (own pass; SQ counters).
 # Round 4: the pass profiles `bench.py --mfma-only` -- the 25-keyframe bLarge LocalLVIBA batch, the workload that runs the MFMA kernel
 # (the default loop's Schur product is a vector-unit kernel since round 3 and issues no matrix instruction)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 bench.py --no-build --mfma-only > $OUT/bench_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- python3 bench.py --no-build --no-cpu-baseline --mfma-only > $OUT/bench_mfma.log 2>&1
 # HBM counters of the inertial loop (configs[3]): inertial_config.roofline.traffic
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_fetch_i.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_write_i.log 2>&1
