@@ -62,6 +62,8 @@ def parse_args(argv=None):
                     "JSON line) -- what the world-2 gloo test on CPU drives")
     ap.add_argument("--host-fed", action="store_true", help="the timed loop takes every step's images and raw scans from pinned host memory (uploads inside the "
                     "timed region, overlapped with the previous step): what a drop-in behind the reference's host-buffer entry points delivers")
+    ap.add_argument("--no-lidar-prepare", action="store_true", help="configs[3] loop: preprocess + time sort inside the front-end call instead of a step ahead "
+                    "(tc2li_lidar_inertial_prepare_batch on a second handle): A/B measurements")
     ap.add_argument("--inertial-loop", action="store_true", help="the timed loop is the camera-LiDAR-inertial one (configs[3]) instead of the camera-LiDAR one: "
                     "what the single-sequence child of the inertial line runs")
     ap.add_argument("--mfma-only", action="store_true", help="only the matrix-unit line: a lock-step batch of 25-keyframe bLarge LocalLVIBA windows (the dense "
@@ -426,7 +428,9 @@ class Loop:
         # three feature buffers: extraction of batch k+2, motion-model tracking of batch k+1 and local-map tracking of batch k overlap
         self.exts = [pkg.OrbExtractor(max_width=W, max_height=H, max_images=self.n_img) for _ in range(3)]
         self.track2_stream = torch.cuda.Stream()
-        self.lidar = pkg.LidarFrontEnd(max_points_per_scan=int(max(len(s) for s in wl.scans)), max_scans=F)
+        self.lidar_cap = int(max(len(s) for s in wl.scans))
+        self.lidar_handles = None  # configs[3]: [self.lidar, a second handle] once the scans are prepared a step ahead (InertialLoop.lidar_prepare)
+        self.lidar = pkg.LidarFrontEnd(max_points_per_scan=self.lidar_cap, max_scans=F)
         self.maps = []
         for t in tile:  # every sequence owns its map: map_incremental changes it
             m = pkg.LidarMap()
@@ -454,9 +458,10 @@ class Loop:
         # With 64 sequences or fewer (what strong scaling over 512 leaves a GPU at 8 ranks) even two steps' windows are a latency-bound
         # batch -- a call costs 4.6 ms for 16 windows, 6 ms for 32 -- so there the thread may take up to four steps' keyframes when it lags that far.
         self.ba_batch2 = self.ba_batch4 = None
-        if n_ba >= 2 and F <= 256 and F % args.kf_interval == 0 and not os.environ.get("TC2LI_BENCH_BA_SINGLE_STEP"):
+        multi = int(os.environ.get("TC2LI_BENCH_BA_MULTI_STEP", "0"))  # A/B: 2 / 4 = batches of that many steps' windows whatever F is
+        if n_ba >= 2 and (F <= 256 or multi >= 2) and F % args.kf_interval == 0 and not os.environ.get("TC2LI_BENCH_BA_SINGLE_STEP"):
             self.ba_batch2 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(2 * n_ba)], wl.ba_windows[0]["cam"])
-            if F <= 64:
+            if F <= 64 or multi >= 4:
                 self.ba_batch4 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(4 * n_ba)], wl.ba_windows[0]["cam"])
         self.steps_tracked = 0
         self.ba_due = 0.0
@@ -607,11 +612,33 @@ class Loop:
                 self.steps_tracked += 1
                 free.put(k)
 
+        # configs[3]: the scans of step k + 1 are preprocessed and their time-sort order found (a second front-end handle, an own stream) while
+        # step k's iterated filter runs -- the reference preprocesses in the scan callback, ahead of the thread that consumes lidar_buffer
+        piped = hasattr(self, "lidar_prepare") and not getattr(self.args, "no_lidar_prepare", False)
+        lfree, lready = queue.Queue(), queue.Queue()
+        for h in range(2):
+            lfree.put(h)
+
+        def lidar_prep_thread():
+            for _ in range(n_steps):
+                h = get(lfree)
+                if h is None:
+                    return
+                self.lidar_prepare(h)
+                lready.put(h)
+
         def lidar_thread():
             ev = self._upload(1, 0) if fed else None
             for i in range(n_steps):
                 if failed.is_set():
                     return
+                if piped:
+                    h = get(lready)
+                    if h is None:
+                        return
+                    self.lidar_step(handle=h)
+                    lfree.put(h)
+                    continue
                 raw = None
                 if fed:
                     ev.synchronize()
@@ -638,7 +665,8 @@ class Loop:
         want = set(stages)
         if "track" in want:
             want.add("orb")  # tracking consumes what the extraction produces
-        fns = [f for f in (orb_thread, track_thread, track2_thread, lidar_thread, ba_thread) if f.__name__.split("_")[0].rstrip("2") in want]
+        fns = [f for f in (orb_thread, track_thread, track2_thread, lidar_thread, ba_thread) + ((lidar_prep_thread,) if piped else ())
+               if f.__name__.split("_")[0].rstrip("2") in want]
         if not self.ba_batch:
             fns = [f for f in fns if f is not ba_thread]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
@@ -745,7 +773,14 @@ class InertialLoop(Loop):
         self.pi.preintegrate()
         self.pi.run(stream)
 
-    def lidar_step(self):
+    def lidar_prepare(self, handle):
+        """Preprocess::process + the order of UndistortPcl's time sort of the next step's scans, into front-end handle `handle` (0 / 1)."""
+        if self.lidar_handles is None:
+            self.lidar_handles = [self.lidar, self.pkg.LidarFrontEnd(max_points_per_scan=self.lidar_cap, max_scans=self.F)]
+            self.lidar_prep_stream = self.torch.cuda.Stream()
+        self.li.prepare(self.dev_raw.data_ptr(), stream=self.lidar_prep_stream.cuda_stream, fe=self.lidar_handles[handle])
+
+    def lidar_step(self, handle=None):
         pkg, F = self.pkg, self.F
         todo_maps, todo_boxes = [], []
         for s in range(F):
@@ -754,10 +789,11 @@ class InertialLoop(Loop):
                 todo_maps.append(self.maps[s]); todo_boxes.append(boxes)
         if todo_maps:
             pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
-        self.li.run(self.dev_raw.data_ptr(), stream=self.lidar_stream.cuda_stream)
+        fe = self.lidar if handle is None else self.lidar_handles[handle]
+        self.li.run(None if handle is not None else self.dev_raw.data_ptr(), stream=self.lidar_stream.cuda_stream, fe=fe)
         x = self.li.states36()
         st24 = np.concatenate([x[:, 3:12], x[:, 0:3], x[:, 24:33], x[:, 33:36]], 1)
-        na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, st24, stream=self.lidar_stream.cuda_stream)
+        na, nn, _ = pkg.capi.map_incremental_batch(fe, self.scan_ids, self.maps, st24, stream=self.lidar_stream.cuda_stream)
         self.map_adds = [int(na.sum()), int(nn.sum())]
 
     def inertial_stats(self):
@@ -822,6 +858,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # all edges once: edge 40 B + its place in the landmark-major list 4 B in, chi2 / rho 16 B out; per landmark the point in, Hll / b_l out
             # (round 4: one launch for both roles) + free-pose edges: edge + slot in, W (144 B) out; one 27-vector per (block, pose) out
             "k_ba_linearize_b": (nw * lin * (E * 60 + P * (24 + 80) + Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),
+            "k_ba_linearize_imu_b": (nw * lin * (E * 60 + P * (24 + 80) + Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),  # the same over ImuCamPose vertices (configs[3])
             "k_ba_reduce_all_b": (nw * lin * (blocks * nf * 224 + nf * 216), "B"),
             # S -= W D^-1 W^T: SURVEY 8d prices it per landmark with n (free-pose) observations at n (n + 1) / 2 x (6x3 . 3x3 + 6x3 . 3x6) =
             # n (n + 1) / 2 x 324 FLOP.  (The kernel runs it as a zero-padded dense f64 MFMA product per chunk of landmarks: about nine times

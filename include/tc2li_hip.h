@@ -370,6 +370,14 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* lidar, int n_scans, const t
                                         int point_filter_num, double blind, float time_unit_scale, float leaf, tc2li_lidar_map* const* maps,
                                         tc2li_lidar_inertial_scan* scans, const double cov12[12], double R, int maximum_iter,
                                         const double* limit23, int extrinsic_est_en, void* stream);
+/* The part of LidarInertialProcess that depends on the scans alone, as a call of its own: Preprocess::process of every raw scan (the reference
+ * runs it in the scan callback, LidarFrontEnd.cpp:253, ahead of the thread that consumes lidar_buffer) and the order UndistortPcl's
+ * std::sort(time_list) will leave the points in.  The handle then holds n_scans prepared scans; the next
+ * tc2li_lidar_inertial_frontend_batch on it with dev_raw = NULL (raw_offsets, point_filter_num, blind, time_unit_scale are not read then) and
+ * the same n_scans consumes them and gives exactly the results of the one-call form.  Two handles let a caller prepare the scans of step k + 1
+ * (own stream, own thread) while step k's iterated update runs.  Returns n_scans. */
+int tc2li_lidar_inertial_prepare_batch(tc2li_lidar* lidar, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
+                                       int point_filter_num, double blind, float time_unit_scale, void* stream);
 /* The time sort of UndistortPcl alone (tests / diagnostics): perm[i] = index of the point std::sort(points, time_list) leaves at place i,
  * computed by the device kernel of the batch entry (one scan; depth_limit < 0: std::sort's own 2 floor(log2 n)).  Returns 1 when the
  * recursion reached the depth limit (perm is then unspecified: the batch entry sorts such a scan on the host), else 0. */

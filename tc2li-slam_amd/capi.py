@@ -626,12 +626,22 @@ class LidarFrontEnd:
         fb = _check(lib().tc2li_device_time_sort(self._h, pts.ctypes.data, len(pts), int(depth_limit), perm.ctypes.data))
         return perm[:len(pts)], bool(fb)
 
+    def inertial_prepare_batch(self, dev_raw_ptr, raw_offsets, point_filter_num=2, blind=2.0, time_unit_scale=1e-3, stream=0):
+        """``tc2li_lidar_inertial_prepare_batch``: Preprocess::process + the order of UndistortPcl's time sort for the scans, kept in this handle
+        for the next ``inertial_frontend_batch(None, ...)``."""
+        raw_offsets = np.ascontiguousarray(raw_offsets, np.int32)
+        f = lib().tc2li_lidar_inertial_prepare_batch
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_void_p]
+        return _check(f(self._h, len(raw_offsets) - 1, C.c_void_p(dev_raw_ptr), raw_offsets.ctypes.data, point_filter_num, blind, time_unit_scale,
+                        C.c_void_p(stream)))
+
     def inertial_frontend_batch(self, dev_raw_ptr, raw_offsets, maps, states36, Ps, imus, times, cov12, last6=None, point_filter_num=2, blind=2.0,
                                 time_unit_scale=1e-3, leaf=0.5, R=0.001, max_iter=3, limit=None, extrinsic_est_en=False, stream=0):
         """``LidarInertialProcess`` for a batch of sequences (tc2li_lidar_inertial_frontend_batch).  states36 [S, 36] (pos 3, rot 9, vel 3, bg 3,
         ba 3, grav 3, offset_R_L_I 9, offset_T_L_I 3), Ps [S, 23, 23], imus: list of [K, 7] sample arrays (t, acc, gyr), times [S, 4] =
         pcl_beg_time, pcl_end_time, last_lidar_end_time, acc_scale, last6 [S, 6] = acc_s_last, angvel_last ->
-        (states36, Ps, list of EskfStats, n_preprocessed, n_downsampled, last6)."""
+        (states36, Ps, list of EskfStats, n_preprocessed, n_downsampled, last6).  dev_raw_ptr None: the scans inertial_prepare_batch left in
+        this handle."""
         S = len(raw_offsets) - 1
         raw_offsets = np.ascontiguousarray(raw_offsets, np.int32)
         st = np.ascontiguousarray(states36, np.float64).reshape(S, 36).copy()
@@ -654,7 +664,7 @@ class LidarFrontEnd:
         f = lib().tc2li_lidar_inertial_frontend_batch
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-        _check(f(self._h, S, C.c_void_p(dev_raw_ptr), raw_offsets.ctypes.data, point_filter_num, blind, time_unit_scale, leaf, handles, scans,
+        _check(f(self._h, S, C.c_void_p(dev_raw_ptr or 0), raw_offsets.ctypes.data, point_filter_num, blind, time_unit_scale, leaf, handles, scans,
                  cov.ctypes.data, R, max_iter, lim.ctypes.data, int(extrinsic_est_en), C.c_void_p(stream)))
         stats, n_pre, n_down = [], np.zeros(S, np.int32), np.zeros(S, np.int32)
         for s in range(S):
@@ -1212,7 +1222,13 @@ class LidarInertialBatch:
         self.last_off = LidarInertialScan.acc_s_last.offset
         self.zero6 = np.zeros(6)
 
-    def run(self, dev_raw_ptr, stream=0):
+    def prepare(self, dev_raw_ptr, stream=0, fe=None):
+        """Preprocess + time-sort order of the scans into the handle ``fe`` (default: the batch's own), ahead of ``run(None, ..., fe=fe)``."""
+        point_filter_num, blind, time_unit_scale, _ = self.args
+        return (fe or self.fe).inertial_prepare_batch(dev_raw_ptr, self.raw_offsets, point_filter_num, blind, time_unit_scale, stream)
+
+    def run(self, dev_raw_ptr, stream=0, fe=None):
+        """dev_raw_ptr None: the scans ``prepare`` left in the handle."""
         base = C.addressof(self.scans)
         self.P[...] = self.P0
         for s in range(self.S):
@@ -1222,8 +1238,8 @@ class LidarInertialBatch:
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         R, max_iter, ext = self.tail
-        return _check(f(self.fe._h, self.S, C.c_void_p(dev_raw_ptr), self.raw_offsets.ctypes.data, *self.args, self.handles, self.scans, self.cov.ctypes.data,
-                        R, max_iter, self.lim.ctypes.data, ext, C.c_void_p(stream)))
+        return _check(f((fe or self.fe)._h, self.S, C.c_void_p(dev_raw_ptr or 0), self.raw_offsets.ctypes.data, *self.args, self.handles, self.scans,
+                        self.cov.ctypes.data, R, max_iter, self.lim.ctypes.data, ext, C.c_void_p(stream)))
 
     def states36(self):
         out = np.zeros((self.S, 36))

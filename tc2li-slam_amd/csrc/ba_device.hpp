@@ -126,6 +126,7 @@ struct BaBatchExtent {
     int any_dense, max_sparse_np_pad, max_sparse_slices;
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
+    int inertial;  // the windows' vertices are ImuCamPose records (LocalLVIBA batch): the linearisation kernel of that vertex type
 };
 // n_active <= kBaPhaseMax windows per call (the host cuts a longer list)
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st);

@@ -1732,6 +1732,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     for (int i = 0; i < n; ++i)
         if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) { (void)hipStreamSynchronize(st); return false; }
     BaBatchExtent X{};
+    X.inertial = 1;
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0) continue;
         const BaProblemDev& pb = W[i].vp.pb;

@@ -42,9 +42,10 @@ __device__ __forceinline__ void load_d2(const double* __restrict__ src, double* 
 }
 
 // error of one projection edge at the given estimate: g2o's SE3 vertices (local BA) or ImuCamPose vertices (inertial BA)
-__device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, const BaEdge& e, double p[3], double err[3], int& dim, double& chi2) {
+// (inertial: pb.inertial, as a compile-time value where a kernel exists per vertex type -- the linearisation -- and read from the record elsewhere)
+__device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool inertial, bool trial, const BaEdge& e, double p[3], double err[3], int& dim, double& chi2) {
     const double* X = (trial ? pb.points_trial : pb.points) + 3 * (size_t)e.point;
-    if (pb.inertial) {
+    if (inertial) {
         dim = imu_edge_error((trial ? pb.iposes_trial : pb.iposes)[e.pose], X, e, pb.cam, p, err);
     } else {
         se3_map((trial ? pb.poses_trial : pb.poses)[e.pose], X, p);
@@ -52,6 +53,9 @@ __device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, c
     }
     chi2 = 0;
     for (int d = 0; d < dim; ++d) chi2 += err[d] * e.info * err[d];
+}
+__device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, const BaEdge& e, double p[3], double err[3], int& dim, double& chi2) {
+    edge_state(pb, pb.inertial != 0, trial, e, p, err, dim, chi2);
 }
 
 // sum of v over the workgroup's 256 threads in a fixed order -> out[0]
@@ -71,6 +75,7 @@ __device__ __forceinline__ void block_sum_256(double v, double* s, double* __res
 // bytes) ran with that share of its lanes; its W blocks now leave in slot order.  The error and the weight are simply formed again.
 // LDS of the two roles of the linearisation, declared by the kernel (one launch runs both: the roles share it)
 struct LinearizeLds { double big[256 * 9]; double small[256]; };
+template <bool INERTIAL>
 __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, const int bx, LinearizeLds& lds) {
     double* const s_cp = lds.big;
     uint8_t* const s_rows = reinterpret_cast<uint8_t*>(lds.small);
@@ -81,17 +86,20 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
     s_rows[threadIdx.x] = pb.blk_rows[(size_t)bx * 256 + threadIdx.x];
     int my_r0 = 0, my_r1 = 0;
     if ((int)threadIdx.x < 9 * pb.n_free) { my_r0 = off[threadIdx.x / 9]; my_r1 = off[threadIdx.x / 9 + 1]; }
-    double cp[kContribP];
+    double B[18], wr[3], w = 0;  // what the pose block is formed from, nine values at a time (below): 28 doubles less to hold
+#pragma unroll
+    for (int i = 0; i < 18; ++i) B[i] = 0;
+    wr[0] = wr[1] = wr[2] = 0;
     if (valid) {
         const int e = pb.fl_edge[s];
         const BaEdge ed = pb.edges[e];
         double p[3], err[3], c2, rho0, rho1;
         int dim;
-        edge_state(pb, false, ed, p, err, dim, c2);
+        edge_state(pb, INERTIAL, false, ed, p, err, dim, c2);
         const bool stereo = ed.ur >= 0;
         huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
-        double A[9], B[18];
-        if (pb.inertial) {
+        double A[9];
+        if (INERTIAL) {
             imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
         } else {
             double R[9];
@@ -99,30 +107,10 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
             point_jacobian(p, R, stereo, pb.cam, A);
             pose_jacobian(p, stereo, false, pb.cam, B);
         }
-        const double w = rho1 * ed.info;
-        double wr[3];  // omega_r = -rho' * Omega * e
+        w = rho1 * ed.info;
+        // omega_r = -rho' * Omega * e
 #pragma unroll
         for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
-        // The row sums run over all three rows with compile-time indices (everything stays in registers); the third row of
-        // A and B is zero for a monocular edge, so its terms add exact zeros.
-        cp[27] = 0;
-        int h = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) {
-                double sum = 0;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * B[6 * d + c];
-                cp[h++] = sum;
-            }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double sum = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * wr[d];
-            cp[21 + r] = sum;
-        }
         double W[18];  // Hpl block: B^T W A (6 x 3)
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -137,13 +125,35 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
     }
     // The pose blocks of the workgroup's 256 edges, added per pose in slot order (blk_rows: the block's rows sorted by pose, blk_off
     // the poses' ranges; nine of the 27 values at a time through LDS): what leaves the kernel is one 27-vector per (block, pose)
-    // instead of one per edge (224 B written here and read back by the reduction).
+    // instead of one per edge (224 B written here and read back by the reduction).  Value h < 21 of the 27: entry (r, c >= r) of
+    // B^T W B in row-major order of the upper triangle; 21 + r: (B^T omega_r)_r.  The row sums run over all three rows with compile-time
+    // indices (everything stays in registers); the third row of A and B is zero for a monocular edge, so its terms add exact zeros.
     const int nf = pb.n_free;
 #pragma unroll
     for (int c0 = 0; c0 < 27; c0 += 9) {
         if (valid) {
+            int h = 0;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) s_cp[9 * threadIdx.x + j] = cp[c0 + j];
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) {
+                    if (h >= c0 && h < c0 + 9) {
+                        double sum = 0;
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * B[6 * d + c];
+                        s_cp[9 * threadIdx.x + (h - c0)] = sum;
+                    }
+                    ++h;
+                }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                if (21 + r >= c0 && 21 + r < c0 + 9) {
+                    double sum = 0;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * wr[d];
+                    s_cp[9 * threadIdx.x + (21 + r - c0)] = sum;
+                }
+            }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < 9 * nf; t += 256) {
@@ -156,6 +166,7 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
         __syncthreads();
     }
 }
+template <bool INERTIAL>
 __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int g, LinearizeLds& lds) {
     double* const s_sum = lds.small;
     double* const s_cl = lds.big;
@@ -167,14 +178,14 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
         const BaEdge ed = pb.edges[e];
         double p[3], err[3], c2;
         int dim;
-        edge_state(pb, false, ed, p, err, dim, c2);
+        edge_state(pb, INERTIAL, false, ed, p, err, dim, c2);
         const bool stereo = ed.ur >= 0;
         double rho1;
         huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
         pb.chi2[e] = c2;
         pb.rho0[e] = rho0;
         double A[9];
-        if (pb.inertial) {
+        if (INERTIAL) {
             double B[18];
             imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
         } else {
@@ -224,8 +235,13 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
 // one launch, both roles: workgroups [0, n_groups) the landmark role, the rest the pose role (they do not depend on each other)
 __global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
     __shared__ LinearizeLds lds;
-    if ((int)blockIdx.x < pb.n_groups) d_ba_linearize(pb, blockIdx.x, lds);
-    else d_ba_linearize_pose(pb, (int)blockIdx.x - pb.n_groups, lds);
+    if (pb.inertial) {
+        if ((int)blockIdx.x < pb.n_groups) d_ba_linearize<true>(pb, blockIdx.x, lds);
+        else d_ba_linearize_pose<true>(pb, (int)blockIdx.x - pb.n_groups, lds);
+    } else {
+        if ((int)blockIdx.x < pb.n_groups) d_ba_linearize<false>(pb, blockIdx.x, lds);
+        else d_ba_linearize_pose<false>(pb, (int)blockIdx.x - pb.n_groups, lds);
+    }
 }
 
 // Fixed-order block sum of `width` values per item over the items [begin, end) of an index list.  The tree is the one a 256-entry
@@ -965,18 +981,22 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
 
 // workgroups [0, max_groups) of a window: the landmark role; [max_groups, ...): the pose role -- one launch (two before: the second
 // waited for the first to drain although neither reads what the other writes)
+// A kernel per vertex type (the windows of a batch call share it): the SE3 form does not carry the registers of the ImuCamPose Jacobians
+// (196 VGPRs with both in one body: two wavefronts per SIMD for a kernel that waits on scattered loads; 142 / 148 now, three.  Holding
+// the body to four with amdgpu_waves_per_eu -- 126 registers, 68 bytes of scratch per lane -- measured the same in the loop: 361 against 375 us).
 __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int max_groups) {
     __shared__ LinearizeLds lds;
     TC2LI_SLOT(y);
     const int bx = blockIdx.x;
-    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize(pb, bx, lds); }
-    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose(pb, bx - max_groups, lds);
+    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<false>(pb, bx, lds); }
+    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<false>(pb, bx - max_groups, lds);
 }
-// the pose role as a launch of its own (TC2LI_BA_SPLIT_LINEARIZE=1: A/B measurements against the one-launch form)
-__global__ __launch_bounds__(256) void k_ba_linearize_pose_b(const BaPhase ph) {
+__global__ __launch_bounds__(256) void k_ba_linearize_imu_b(const BaPhase ph, int max_groups) {
     __shared__ LinearizeLds lds;
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x < blocks256(pb.n_free_edges)) d_ba_linearize_pose(pb, blockIdx.x, lds);
+    const int bx = blockIdx.x;
+    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<true>(pb, bx, lds); }
+    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<true>(pb, bx - max_groups, lds);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaPhase ph) {
     TC2LI_SLOT(y);
@@ -1198,13 +1218,8 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    static const bool kSplit = getenv("TC2LI_BA_SPLIT_LINEARIZE") && atoi(getenv("TC2LI_BA_SPLIT_LINEARIZE")) != 0;
-    if (kSplit) {
-        TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups, n_active), dim3(256), 0, st, ph, x.max_groups);
-        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_linearize_pose_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
-    } else {
-        TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
-    }
+    if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }

@@ -118,6 +118,8 @@ struct tc2li_lidar {
     DevBuf<double> d_eskf_partial;  // [(cap + 255) / 256][kEskfOutSize]
     PinnedBuf<double> h_eskf_out;   // [kEskfOutSize], written by k_eskf_reduce
     PinnedBuf<int> h_counts;  // [4 * max_scans + 1]: pre, down, sel counts and the status word
+    PinnedBuf<int> h_sort_flags;  // [max_scans]: scans whose time sort reached std::sort's depth limit
+    int prepared_scans = 0;       // tc2li_lidar_inertial_prepare_batch: d_pre / d_perm / h_counts hold that many scans, ready for the front end
     std::vector<ScanSlot> slots;
     std::vector<SegBlock> blocks;
     int n_scans = 0;
@@ -839,12 +841,76 @@ int tc2li_device_time_sort(tc2li_lidar* L, const tc2li_point* points, int n, int
 // iterated updates in lock step (an iteration's neighbour search for the scans whose last step converged, the re-evaluation of the kept
 // neighbours for the others, the normal equations of all of them; then the 23 x 23 algebra of every scan on the host pool).  Same
 // kernels bodies and host steps as the one-scan entry points: a scan gives the same state alone and in a batch.
+// Preprocess::process of every raw scan and the permutation UndistortPcl's std::sort(time_list) leaves: the part of LidarInertialProcess
+// that depends on the scan alone (the reference runs Preprocess::process in the scan callback, LidarFrontEnd.cpp:253, ahead of the thread
+// that consumes lidar_buffer).  On return d_pre / d_pre_count / d_perm hold the scans and h_counts[0..S) their sizes.
+// (two halves: everything queued; the wait and the scans the host has to sort -- the one-call form propagates the IMU states in between)
+static int inertial_prepare_launch(tc2li_lidar* L, int S, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets, int point_filter_num, double blind,
+                                   float time_unit_scale, hipStream_t st) {
+    const size_t T = L->total;
+    L->prepared_scans = 0;
+    std::vector<int> upper(S);
+    for (int s = 0; s < S; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
+    int rc = setup_segments(L, S, upper.data(), st, raw_offsets);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
+    if (rc != TC2LI_OK) return rc;
+    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(2 * (size_t)L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_ranges.ensure(T));
+    TC2LI_HIP_CHECK(L->h_sort_flags.ensure(L->max_scans));
+    // the time sort: std::sort's permutation, replayed on the device
+    const char* depth_env = getenv("TC2LI_TEST_SORT_DEPTH");  // tests: a small depth limit sends scans through the host fallback
+    launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, S, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_env ? atoi(depth_env) : -1, st);
+    int* hc = L->h_counts.p;
+    int* h_fallback = L->h_sort_flags.p;
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(h_fallback, L->d_sort_fallback.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    return TC2LI_OK;
+}
+static int inertial_prepare_finish(tc2li_lidar* L, int S, hipStream_t st) {
+    const int* hc = L->h_counts.p;
+    const int* h_fallback = L->h_sort_flags.p;
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    for (int s = 0; s < S; ++s) {
+        if (!h_fallback[s]) continue;
+        // the recursion reached std::sort's depth limit (heap sort there): this scan is sorted on the host, like tc2li_lidar_undistort
+        const int n = hc[s];
+        std::vector<PointXYZINormal> pts(n);
+        TC2LI_HIP_CHECK(copy_sync(pts.data(), L->d_pre.p + (size_t)s * L->cap, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
+        struct Rec { float t; int idx; };
+        std::vector<Rec> rec(n);
+        for (int i = 0; i < n; ++i) rec[i] = Rec{pts[i].curvature, i};
+        std::sort(rec.begin(), rec.end(), [](const Rec& a, const Rec& b) { return a.t < b.t; });
+        std::vector<int> perm(n);
+        for (int i = 0; i < n; ++i) perm[i] = rec[i].idx;
+        TC2LI_HIP_CHECK(copy_sync(L->d_perm.p + (size_t)s * L->cap, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    return TC2LI_OK;
+}
+
+int tc2li_lidar_inertial_prepare_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets, int point_filter_num,
+                                       double blind, float time_unit_scale, void* stream_) {
+    if (!L || n_scans < 0 || n_scans > (L ? L->max_scans : 0) || !dev_raw || !raw_offsets || point_filter_num < 1) {
+        set_error("tc2li_lidar_inertial_prepare_batch: invalid argument");
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_scans == 0) { L->prepared_scans = 0; return 0; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    int rc = inertial_prepare_launch(L, n_scans, dev_raw, raw_offsets, point_filter_num, blind, time_unit_scale, (hipStream_t)stream_);
+    if (rc == TC2LI_OK) rc = inertial_prepare_finish(L, n_scans, (hipStream_t)stream_);
+    if (rc != TC2LI_OK) return rc;
+    L->prepared_scans = n_scans;
+    return n_scans;
+}
+
 int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne_point* dev_raw, const int32_t* raw_offsets,
                                         int point_filter_num, double blind, float time_unit_scale, float leaf, tc2li_lidar_map* const* maps,
                                         tc2li_lidar_inertial_scan* scans, const double cov12[12], double R, int maximum_iter, const double* limit23,
                                         int extrinsic_est_en, void* stream_) {
     using namespace eskf;
-    if (!L || n_scans < 0 || n_scans > (L ? L->max_scans : 0) || !dev_raw || !raw_offsets || !maps || !scans || !cov12 || point_filter_num < 1 ||
+    if (!L || n_scans < 0 || n_scans > (L ? L->max_scans : 0) || (dev_raw && !raw_offsets) || !maps || !scans || !cov12 || (dev_raw && point_filter_num < 1) ||
         !(leaf > 0) || !(R > 0) || maximum_iter < 0 || !limit23) {
         set_error("tc2li_lidar_inertial_frontend_batch: invalid argument");
         return TC2LI_ERR_INVALID;
@@ -861,18 +927,20 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     MapLocks locks(maps, n_scans);
     const int S = n_scans;
     const size_t T = L->total;
-    // ---- Preprocess::process of every raw scan (device; the host propagates meanwhile) ----
-    std::vector<int> upper(S);
-    for (int s = 0; s < S; ++s) upper[s] = raw_offsets[s + 1] - raw_offsets[s];
-    int rc = setup_segments(L, S, upper.data(), st, raw_offsets);
-    if (rc != TC2LI_OK) return rc;
-    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
-    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
-    if (rc != TC2LI_OK) return rc;
+    // ---- Preprocess::process of every raw scan and the order of UndistortPcl's time sort: prepared ahead, or now ----
+    int rc = TC2LI_OK;
+    if (dev_raw) {
+        rc = inertial_prepare_launch(L, S, dev_raw, raw_offsets, point_filter_num, blind, time_unit_scale, st);  // (the host propagates meanwhile)
+        if (rc != TC2LI_OK) return rc;
+    } else if (L->prepared_scans != S) {
+        set_error("tc2li_lidar_inertial_frontend_batch: dev_raw is NULL and the handle holds %d prepared scans, not %d", L->prepared_scans, S);
+        return TC2LI_ERR_INVALID;
+    }
+    L->prepared_scans = 0;  // consumed
     // ---- work space of the batch (allocated on first use) ----
     const size_t rows = T / 256;
-    TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_imu_poses.ensure((size_t)L->max_scans * kMaxImuPoses));
-    TC2LI_HIP_CHECK(L->d_n_poses.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(2 * (size_t)L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_ranges.ensure(T)); TC2LI_HIP_CHECK(L->d_scan_list.ensure(L->max_scans));
+    TC2LI_HIP_CHECK(L->d_imu_poses.ensure((size_t)L->max_scans * kMaxImuPoses));
+    TC2LI_HIP_CHECK(L->d_n_poses.ensure(L->max_scans)); TC2LI_HIP_CHECK(L->d_scan_list.ensure(L->max_scans));
     TC2LI_HIP_CHECK(L->d_blocks_a.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_b.ensure(T / kSegBlock)); TC2LI_HIP_CHECK(L->d_blocks_c.ensure(T / kSegBlock));
     TC2LI_HIP_CHECK(L->d_eskf_partial.ensure(rows * kEskfOutSize)); TC2LI_HIP_CHECK(L->h_eskf_out.ensure((size_t)L->max_scans * kEskfOutSize));
     TC2LI_HIP_CHECK(L->h_batch.ensure((size_t)L->max_scans * (kMaxImuPoses * sizeof(Pose6DDev) + sizeof(LidarStateDev) + 4 * sizeof(int)) + 3 * (T / kSegBlock) * sizeof(SegBlock)));
@@ -881,7 +949,7 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     Pose6DDev* h_poses = (Pose6DDev*)hb; hb += (size_t)L->max_scans * kMaxImuPoses * sizeof(Pose6DDev);
     LidarStateDev* h_states = (LidarStateDev*)hb; hb += (size_t)L->max_scans * sizeof(LidarStateDev);
     int* h_n_poses = (int*)hb; hb += (size_t)L->max_scans * sizeof(int);
-    int* h_fallback = (int*)hb; hb += (size_t)L->max_scans * sizeof(int);
+    hb += (size_t)L->max_scans * sizeof(int);
     int* h_scan_list = (int*)hb; hb += (size_t)L->max_scans * 2 * sizeof(int);
     SegBlock* h_blocks_a = (SegBlock*)hb; SegBlock* h_blocks_b = h_blocks_a + T / kSegBlock; SegBlock* h_blocks_c = h_blocks_b + T / kSegBlock;
     // ---- forward propagation of every sequence on the host (IMU_Processing.cpp:176-233; esekf::predict with the covariance) ----
@@ -906,30 +974,13 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_imu_poses.p, h_poses, (size_t)S * kMaxImuPoses * sizeof(Pose6DDev), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_n_poses.p, h_n_poses, S * sizeof(int), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, h_states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
-    // ---- UndistortPcl: the time sort (std::sort's permutation, replayed on the device) and the compensation ----
-    const char* depth_env = getenv("TC2LI_TEST_SORT_DEPTH");  // tests: a small depth limit sends scans through the host fallback
-    launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, S, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
-                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_env ? atoi(depth_env) : -1, st);
-    int* hc = L->h_counts.p;
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(hc, L->d_pre_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(h_fallback, L->d_sort_fallback.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    for (int s = 0; s < S; ++s) {
-        scans[s].n_preprocessed = hc[s];
-        if (!h_fallback[s]) continue;
-        // the recursion reached std::sort's depth limit (heap sort there): this scan is sorted on the host, like tc2li_lidar_undistort
-        const int n = hc[s];
-        std::vector<PointXYZINormal> pts(n);
-        TC2LI_HIP_CHECK(copy_sync(pts.data(), L->d_pre.p + (size_t)s * L->cap, (size_t)n * sizeof(PointXYZINormal), hipMemcpyDeviceToHost, st));
-        struct Rec { float t; int idx; };
-        std::vector<Rec> rec(n);
-        for (int i = 0; i < n; ++i) rec[i] = Rec{pts[i].curvature, i};
-        std::sort(rec.begin(), rec.end(), [](const Rec& a, const Rec& b) { return a.t < b.t; });
-        std::vector<int> perm(n);
-        for (int i = 0; i < n; ++i) perm[i] = rec[i].idx;
-        TC2LI_HIP_CHECK(copy_sync(L->d_perm.p + (size_t)s * L->cap, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, st));
+    // ---- UndistortPcl: the compensation, in the order of the time sort ----
+    if (dev_raw) {
+        rc = inertial_prepare_finish(L, S, st);
+        if (rc != TC2LI_OK) return rc;
     }
+    int* hc = L->h_counts.p;
+    for (int s = 0; s < S; ++s) scans[s].n_preprocessed = hc[s];
     // the compensated scans land in d_cloud_ori (free until a selection is compacted), the voxel filter reads them there
     launch_undistort_batch(L->d_pre.p, L->d_perm.p, L->d_pre_count.p, L->d_slots.p, L->d_blocks.p, (int)L->blocks.size(), L->d_imu_poses.p, L->d_n_poses.p,
                            L->d_states.p, L->d_cloud_ori.p, st);

@@ -195,3 +195,39 @@ def test_batch_argument_checks(pkg, oracle, synthetic):
     q = dict(seqs[0], imu=np.zeros((70, 7)))
     with pytest.raises(pkg.capi.Tc2liError):
         run_batch(pkg, [q])
+
+
+def test_scans_prepared_a_step_ahead_give_the_one_call_results(pkg, oracle, synthetic, monkeypatch):
+    """tc2li_lidar_inertial_prepare_batch on a second handle (own stream) + the front end with dev_raw = NULL: the one-call results bit for bit,
+    map_incremental included; a scan sent through the host sort (depth limit) too; NULL without prepared scans is refused."""
+    import torch
+    seqs = build_batch(pkg, oracle, synthetic, 3, seed0=7)
+    fe0, maps0, (xs0, Ps0, stats0, n_pre0, n_down0, last0) = run_batch(pkg, seqs, max_iter=3)
+    S = len(seqs)
+    raw = np.concatenate([q["raw"] for q in seqs])
+    offs = np.concatenate([[0], np.cumsum([len(q["raw"]) for q in seqs])]).astype(np.int32)
+    dev = torch.from_numpy(raw.view(np.uint8)).cuda()
+    args = (np.stack([q["x"] for q in seqs]), np.stack([q["P"] for q in seqs]), [q["imu"] for q in seqs], np.array([q["times"] for q in seqs]), COV12)
+    for depth in (None, "3"):
+        if depth:
+            monkeypatch.setenv("TC2LI_TEST_SORT_DEPTH", depth)  # every scan reaches the limit: sorted on the host inside prepare
+        fe = pkg.LidarFrontEnd(max_points_per_scan=int(max(len(q["raw"]) for q in seqs)), max_scans=S)
+        maps = []
+        for q in seqs:
+            m = pkg.LidarMap(); m.Build(q["world0"]); maps.append(m)
+        with pytest.raises(pkg.capi.Tc2liError):
+            fe.inertial_frontend_batch(None, offs, maps, *args, max_iter=3)
+        side = torch.cuda.Stream()
+        assert fe.inertial_prepare_batch(dev.data_ptr(), offs, stream=side.cuda_stream) == S
+        xs, Ps, stats, n_pre, n_down, last = fe.inertial_frontend_batch(None, offs, maps, *args, max_iter=3, stream=torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(n_pre, n_pre0) and np.array_equal(n_down, n_down0)
+        assert np.array_equal(xs, xs0) and np.array_equal(Ps, Ps0) and np.array_equal(last, last0)
+        assert all(same_stats(a, b) and a.res_mean_last == b.res_mean_last for a, b in zip(stats, stats0))
+        with pytest.raises(pkg.capi.Tc2liError):  # consumed
+            fe.inertial_frontend_batch(None, offs, maps, *args, max_iter=3)
+        st24 = np.stack([lidar_state24(x) for x in xs])
+        got = pkg.capi.map_incremental_batch(fe, np.arange(S, dtype=np.int32), maps, st24)
+        if depth is None:
+            want = pkg.capi.map_incremental_batch(fe0, np.arange(S, dtype=np.int32), maps0, st24)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert all(np.array_equal(a.points(), b.points()) for a, b in zip(maps, maps0))
