@@ -823,6 +823,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         "k_orient_describe": (n_img * nkp * (709 + 512 + 64 + 16), "B"),                # patch gathers + descriptor / angle / key out
         "k_compact_cells": (n_img * 120e3, "B"),
         "k_stereo_match": (F * nkp * 40 * 64, "B"),                                     # ~40 candidate pairs per left key, 64 B per pair
+        "k_pre_stream": (F * (raw * 32 + pre * 48), "B"),                               # round 4: one pass, the raw scan read once, the kept points written
         "k_pre_count": (F * raw * 32, "B"), "k_pre_scatter": (F * (raw * 32 + pre * 48), "B"),   # SURVEY 8d counts the raw scan once: 7.3 MB per scan in all
         "k_voxel_bbox": (F * pre * 48, "B"), "k_voxel_insert": (F * pre * 48, "B"), "k_voxel_fill": (F * pre * 8, "B"),
         "k_voxel_rank": (F * pre * (48 + 32), "B"), "k_voxel_centroid": (F * (pre * 32 + down * 48), "B"),
@@ -871,6 +872,15 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
             "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
+            # plane extraction on the device (round 4), per window of N cloud points: the point in (12 B), common-frame point + octants + table
+            # slot out; the three orders (a 4 B index per point and layer) from a key per point; the plane test reads every point's common-frame
+            # coordinates once per layer; the walk reads a flag and a key per cell (at most a cell per point and layer); the clusters read the
+            # planes' points once more and write 80 B per (plane, keyframe)
+            "k_balm_cut_points": (nw * ba.get("cloud_points", 0) * (12 + 24 + 1 + 4 + 12), "B"),
+            "k_balm_cut_sort": (nw * ba.get("cloud_points", 0) * (5 + 3 * (4 + 4)), "B"),
+            "k_balm_cut_judge": (nw * ba.get("cloud_points", 0) * 3 * (4 + 24), "B"),
+            "k_balm_cut_walk": (nw * ba.get("cloud_points", 0) * 3 * 5, "B"),
+            "k_balm_cut_clusters": (nw * (ba.get("cloud_points", 0) * (4 + 12) + ba["planes"] * ba["win"] * 80), "B"),
             "k_balm_residual_total_b": (nw * (lin + tr) * ba["planes"] * ba["win"] * 80, "B"),
             # the windows' graphs over the bus and their results back, read + written once each (an estimate from the windows' sizes: edges 40 B,
             # CSR / slot index arrays ~24 B per edge, points 24 B up and 25 B down, chi2 8 B per edge down, plane clusters 80 B per plane and
@@ -896,6 +906,7 @@ def algorithmic_work_inertial(wl, il, nkp, windows_per_step):
         free_edge = fixed[e6[:, 1].astype(int)] == 0
         f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=len(w0["points"]))
         ba = {"edges": len(e6), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(il.ba_batch.lstats[0].n_planes), "win": 6,
+              "cloud_points": int(sum(len(c) for c in w0["clouds"])),
               "free_edges": int(free_edge.sum()), "pose_pairs": int((f_l * (f_l + 1) // 2).sum()), "windows": windows_per_step,
               "linearisations": int(s0.iterations), "trials": int(s0.trials)}
     w = algorithmic_work(wl, il, nkp, (raw, pre, down, 0.0), ba)
@@ -1392,6 +1403,7 @@ def main(argv=None):
             free_edge = np.asarray(w0["fixed"])[np.asarray(w0["edges6"])[:, 1].astype(int)] == 0
             f_l = np.bincount(np.asarray(w0["edges6"])[free_edge, 0].astype(int), minlength=len(w0["points"]))
             ba = {"edges": len(w0["edges"]), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(ls0.n_planes), "win": 6,
+                  "cloud_points": int(sum(len(c) for c in w0["clouds"])),
                   "free_edges": int(free_edge.sum()), "pose_pairs": int((f_l * (f_l + 1) // 2).sum()),
                   "windows": (loop.ba_windows_done - ba1) / n_prof, "linearisations": int(s0.iterations), "trials": int(s0.trials)}
         roofline, kernel_table, kernel_ms_per_step = roofline_from_profile(report, algorithmic_work(wl, loop, nkp, lid_mean, ba), peaks, n_prof)
