@@ -140,4 +140,25 @@ void ba_batch_launch_depth(const BaPhase& ph, int n_active, const BaBatchExtent&
 void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st);
 void balm_batch_launch_hessian(const BaPhase& ph, int n, const BaBatchExtent& x, hipStream_t st);
 
+#if defined(__HIPCC__)
+// *p for an object no kernel of the launch writes, at an address that is the same for the whole wavefront: read through the constant
+// address space, i.e. with scalar loads into SGPRs (the slot table is written by the host's upload only)
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized objects");
+    typedef const unsigned int __attribute__((address_space(4)))* const_dwords;
+    const const_dwords c = (const_dwords)(unsigned long long)p;
+    unsigned int w[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = c[i];
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+// the phase's window number / flags at position `pos` as scalars: sub-dword loads from the argument block at a dynamic index are vector
+// loads, and everything addressed through their result would be fetched per lane (readfirstlane: the value is the same in every lane)
+__device__ __forceinline__ int ba_phase_window(const BaPhase& ph, int pos) { return __builtin_amdgcn_readfirstlane((int)ph.win[pos]); }
+__device__ __forceinline__ unsigned ba_phase_flags(const BaPhase& ph, int pos) { return (unsigned)__builtin_amdgcn_readfirstlane((int)ph.flags[pos]); }
+#endif
+
 }  // namespace tc2li

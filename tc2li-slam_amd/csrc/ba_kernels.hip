@@ -967,8 +967,18 @@ struct BaSlotView {
 };
 __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
     __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = ph.table[ph.win[pos]];
-    BaSlotView v{sl, sl.pb, ph.lambda[pos], ph.flags[pos], sl.xp};
+    // The phase's per-window entries are sub-dword loads from the argument block at a dynamic index: vector loads, so the window number --
+    // and with it the address of everything read from the slot -- would sit in vector registers and the whole record be fetched per lane
+    // (about 40 VGPRs of uniform pointers and sizes in every _b kernel: k_ba_linearize_b 140 -> 100, k_ba_trial_update_b 152 -> 104).
+    // readfirstlane makes them scalar again and load_uniform reads the record through scalar loads into SGPRs.
+    const int win = ba_phase_window(ph, pos);
+    const unsigned flags = ba_phase_flags(ph, pos);
+    union { double d; int i[2]; } lam;
+    lam.d = ph.lambda[pos];
+    lam.i[0] = __builtin_amdgcn_readfirstlane(lam.i[0]);
+    lam.i[1] = __builtin_amdgcn_readfirstlane(lam.i[1]);
+    const BaBatchSlot& sl = ph.table[win];
+    BaSlotView v{sl, load_uniform(&sl.pb), lam.d, flags, load_uniform(&sl.xp)};
     if (v.flags & kBaAcceptedInTrial) {
         Se3* const p = v.pb.poses; v.pb.poses = v.pb.poses_trial; v.pb.poses_trial = p;
         ImuPose* const q = v.pb.iposes; v.pb.iposes = v.pb.iposes_trial; v.pb.iposes_trial = q;

@@ -327,30 +327,30 @@ void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
 // ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
 // the poses of the window at position `pos` of the phase: the accepted estimate or the trial one (the phase's parity bit says which of
 // the slot's two buffers holds the accepted estimate)
-__device__ __forceinline__ const Se3* slot_poses(const BaPhase& ph, int pos, const BaBatchSlot& sl, bool trial) {
-    const bool second = trial != ((ph.flags[pos] & kBaAcceptedInTrial) != 0);
-    if (sl.pb.inertial) return reinterpret_cast<const Se3*>(second ? sl.pb.iposes_trial : sl.pb.iposes);
-    return second ? sl.pb.poses_trial : sl.pb.poses;
+struct BalmSlotView { BalmDev b; const Se3* poses; };
+__device__ __forceinline__ BalmSlotView balm_slot_view(const BaPhase& ph, int pos, bool trial) {
+    __builtin_amdgcn_s_setprio(3);
+    const BaBatchSlot* const sl = ph.table + ba_phase_window(ph, pos);
+    const bool second = trial != ((ba_phase_flags(ph, pos) & kBaAcceptedInTrial) != 0);
+    BalmSlotView v;
+    v.b = load_uniform(&sl->balm);  // (scalar loads: the record lives in SGPRs, not in every lane's registers)
+    if (load_uniform(&sl->pb.inertial)) v.poses = reinterpret_cast<const Se3*>(second ? load_uniform(&sl->pb.iposes_trial) : load_uniform(&sl->pb.iposes));
+    else v.poses = second ? load_uniform(&sl->pb.poses_trial) : load_uniform(&sl->pb.poses);
+    return v;
 }
 __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph, int trial) {
-    __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.x]];
-    const BalmDev b = sl.balm;
-    d_balm_residual_total(b, slot_poses(ph, blockIdx.x, sl, trial != 0));
+    const BalmSlotView v = balm_slot_view(ph, blockIdx.x, trial != 0);
+    d_balm_residual_total(v.b, v.poses);
 }
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPhase ph) {
-    __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.y]];
-    const BalmDev b = sl.balm;
-    if ((int)blockIdx.x >= b.n_chunks) return;
-    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, slot_poses(ph, blockIdx.y, sl, false), blockIdx.x);
+    const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
+    if ((int)blockIdx.x >= v.b.n_chunks) return;
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(v.b, v.poses, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaPhase ph) {
-    __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot& sl = ph.table[ph.win[blockIdx.y]];
-    const BalmDev b = sl.balm;
-    if ((int)blockIdx.x >= (max(balm_part_stride_dev(b.W), 12 * b.W) + 255) / 256) return;
-    d_balm_combine(b, blockIdx.x);
+    const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
+    if ((int)blockIdx.x >= (max(balm_part_stride_dev(v.b.W), 12 * v.b.W) + 255) / 256) return;
+    d_balm_combine(v.b, blockIdx.x);
 }
 void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st) {
     if (n) TC2LI_LAUNCH(k_balm_residual_total_b, dim3(n), dim3(256), 0, st, ph, trial ? 1 : 0);

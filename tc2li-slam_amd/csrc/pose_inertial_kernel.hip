@@ -44,7 +44,9 @@ __device__ __forceinline__ double pi_visual(const ImuPose& T, const ImuCalib& ca
     return c2;
 }
 
-__global__ __launch_bounds__(kPiThreads) void k_pose_inertial(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
+// Two wavefronts per SIMD (amdgpu_waves_per_eu): the body wants 256 + 28 registers, which is one -- one workgroup per CU, i.e. the 512 frames
+// of a batch in two rounds of 2.3 ms; held to 256 (100 B of scratch per lane) two workgroups share a CU and the batch is one round.
+__global__ __launch_bounds__(kPiThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_inertial(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
                                                             const uint8_t* __restrict__ close_flags, ImuCalib cal, CameraD cam, uint8_t* __restrict__ outlier,
                                                             double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
     __shared__ double s_red[4 * kPiRed], s_sum[kPiRed];

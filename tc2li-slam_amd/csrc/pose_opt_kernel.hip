@@ -5,6 +5,9 @@
 // fixed order (deterministic), thread 0 does the 6x6 LDL^T and the accept/reject logic and broadcasts the decision.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
@@ -271,8 +274,11 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization_lds(const Pose
 void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double* Xw, const BaEdge* edges, const CameraD& cam,
                               double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, int max_edges, hipStream_t st) {
     if (nprobs <= 0) return;
-    // the correspondences of a frame in LDS when they fit: up to 1024 leave room for two workgroups per CU, up to 2048 for one
-    const int cap = max_edges <= 1024 ? 1024 : 2048;
+    // the correspondences of a frame in LDS when they fit (2048: 150 KB).  The block is sized from the batch's largest frame, not in two
+    // classes: a workgroup lives for the whole optimisation (milliseconds), and what it does not take of its CU's 160 KB the other stages'
+    // kernels can (1200 correspondences: 88 KB instead of 150; <= 1088: two workgroups per CU).  TC2LI_PO_LDS_CLASSES=1: the two classes (A/B).
+    static const bool kClasses = getenv("TC2LI_PO_LDS_CLASSES") && atoi(getenv("TC2LI_PO_LDS_CLASSES")) != 0;
+    const int cap = kClasses ? (max_edges <= 1024 ? 1024 : 2048) : std::max(64, (max_edges + 63) / 64 * 64);
     if (max_edges <= 2048 && ensure_dynamic_lds((const void*)k_pose_optimization_lds, 2048 * kPoLdsPerEdge + 64)) {
         TC2LI_LAUNCH(k_pose_optimization_lds, dim3(nprobs), dim3(kPoThreads), (size_t)cap * kPoLdsPerEdge + 64, st, probs, Xw, edges, cam, poses7, outlier,
                      inliers, cap);
