@@ -1393,7 +1393,10 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (w.lidar) with_lidar.push_back(i);
         }
         pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, any_maxdiag, st); });
-        // (running the LiDAR kernels on a second stream beside the visual ones was measured: no gain, the chain is not the limit there)
+        // (running the LiDAR kernels on a second stream of the group beside the visual ones -- fork / join by events around the plane
+        // Hessian and around the planes' residual of a trial -- was measured twice: round 3 with the BA stage alone, no gain; round 4 in
+        // the whole loop, three A/B pairs in one call: 30.2-30.5 ms per step against 28.8-29.5 without: the events' cross-stream waits cost
+        // more than the overlap of two short kernels brings)
         // the residual pass at the accepted estimate: only before the first iteration -- later the accepted estimate is the last
         // trial, whose residual and plane decompositions are still in place (same bits)
         bool first_pass = false;
