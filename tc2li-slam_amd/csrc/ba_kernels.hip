@@ -1001,6 +1001,13 @@ __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int ma
     if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<false>(pb, bx, lds); }
     else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<false>(pb, bx - max_groups, lds);
 }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_linearize_w5_b(const BaPhase ph, int max_groups) {  // A/B: TC2LI_BA_LIN_WAVES5=1
+    __shared__ LinearizeLds lds;
+    TC2LI_SLOT(y);
+    const int bx = blockIdx.x;
+    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<false>(pb, bx, lds); }
+    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<false>(pb, bx - max_groups, lds);
+}
 __global__ __launch_bounds__(256) void k_ba_linearize_imu_b(const BaPhase ph, int max_groups) {
     __shared__ LinearizeLds lds;
     TC2LI_SLOT(y);
@@ -1228,7 +1235,9 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
+    static const bool kWaves5 = getenv("TC2LI_BA_LIN_WAVES5") && atoi(getenv("TC2LI_BA_LIN_WAVES5")) != 0;
     if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    else if (kWaves5) TC2LI_LAUNCH(k_ba_linearize_w5_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
     else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
