@@ -859,7 +859,6 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # all edges once: edge 40 B + its place in the landmark-major list 4 B in, chi2 / rho 16 B out; per landmark the point in, Hll / b_l out
             # (round 4: one launch for both roles) + free-pose edges: edge + slot in, W (144 B) out; one 27-vector per (block, pose) out
             "k_ba_linearize_b": (nw * lin * (E * 60 + P * (24 + 80) + Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),
-            "k_ba_linearize_w5_b": (nw * lin * (E * 60 + P * (24 + 80) + Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),
             "k_ba_linearize_imu_b": (nw * lin * (E * 60 + P * (24 + 80) + Ef * (40 + 4 + 144) + blocks * nf * 224), "B"),  # the same over ImuCamPose vertices (configs[3])
             "k_ba_reduce_all_b": (nw * lin * (blocks * nf * 224 + nf * 216), "B"),
             # S -= W D^-1 W^T: SURVEY 8d prices it per landmark with n (free-pose) observations at n (n + 1) / 2 x (6x3 . 3x3 + 6x3 . 3x6) =

@@ -993,15 +993,10 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
 // waited for the first to drain although neither reads what the other writes)
 // A kernel per vertex type (the windows of a batch call share it): the SE3 form does not carry the registers of the ImuCamPose Jacobians
 // (196 VGPRs with both in one body: two wavefronts per SIMD for a kernel that waits on scattered loads; 142 / 148 now, three.  Holding
-// the body to four with amdgpu_waves_per_eu -- 126 registers, 68 bytes of scratch per lane -- measured the same in the loop: 361 against 375 us).
+// the body to four with amdgpu_waves_per_eu -- 126 registers, 68 bytes of scratch per lane -- measured the same in the loop: 361 against 375 us.
+// With the slot read through scalar loads (ba_slot_view) the body needs 100 registers: four wavefronts, 290-300 us in the loop; held to five
+// (96 registers + 12 B of scratch) the kernel runs 254-273 us and the step does not change: 29.5 against 29.7 ms over five A/B pairs).
 __global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int max_groups) {
-    __shared__ LinearizeLds lds;
-    TC2LI_SLOT(y);
-    const int bx = blockIdx.x;
-    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<false>(pb, bx, lds); }
-    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<false>(pb, bx - max_groups, lds);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_linearize_w5_b(const BaPhase ph, int max_groups) {  // A/B: TC2LI_BA_LIN_WAVES5=1
     __shared__ LinearizeLds lds;
     TC2LI_SLOT(y);
     const int bx = blockIdx.x;
@@ -1235,9 +1230,7 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    static const bool kWaves5 = getenv("TC2LI_BA_LIN_WAVES5") && atoi(getenv("TC2LI_BA_LIN_WAVES5")) != 0;
     if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
-    else if (kWaves5) TC2LI_LAUNCH(k_ba_linearize_w5_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
     else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
