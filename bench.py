@@ -118,12 +118,14 @@ def spawn_ranks(args, argv):
 
 
 def single_sequence_child(args, extra=(), what="the same loop with 1 sequence per step (F = 1): one LV-BA window every %d-th frame"):
-    """The F = 1 line measured by a fresh child process with GPU_MAX_HW_QUEUES=8 (see the call site); None when the child fails -- the
+    """The F = 1 line measured by a fresh child process with GPU_MAX_HW_QUEUES=24 (see the call site; 8 until round 4: the two upload streams
+    of the host-fed loop then shared hardware queues with the stage streams -- 557 frames/s host-fed at 8, 810 at 16, 827 at 24, 830 at 32; the
+    resident loop reads 910-920 at any of them); None when the child fails -- the
     caller then measures it in-process.  300 warm-up frames: a cold process (first allocations of every work space, GPU clocks) reads
     627 frames/s after 8 warm-up frames and 780-810 after 300 or 1000."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                                                             "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-    env.update(GPU_MAX_HW_QUEUES=os.environ.get("TC2LI_BENCH_SINGLE_HW_QUEUES", "8"), TC2LI_NO_BUILD="1")
+    env.update(GPU_MAX_HW_QUEUES=os.environ.get("TC2LI_BENCH_SINGLE_HW_QUEUES", "24"), TC2LI_NO_BUILD="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", "1", "--unique", "1", "--steps", "200", "--warmup", "300", "--no-cpu-baseline",
            "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval), "--ba-concurrency", str(args.ba_concurrency)]
     if args.front_end_only:
@@ -1517,7 +1519,7 @@ def main(argv=None):
             dt1 = time.perf_counter() - t1
             single_i = {"value": round(n1 / dt1, 2), "unit": "frames/s", "ms_per_frame": round(1e3 * dt1 / n1, 3), "frames": n1,
                         "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one_i.thread_ms.items()},
-                        "process": "in this process (4 hardware queues; the camera-LiDAR single-sequence line runs in a child with 8)"}
+                        "process": "in this process (4 hardware queues; the camera-LiDAR single-sequence line runs in a child with 24)"}
             one_i.close()
             del one_i
         cpu_i = None

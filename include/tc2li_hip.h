@@ -36,7 +36,8 @@ int tc2li_abi_version(void);
 int tc2li_device_count(void);
 /* Hardware queues the HIP runtime maps this process's streams onto (the runtime's GPU_MAX_HW_QUEUES, 4 by default).  A process that runs
  * ONE sequence -- the reference's own configuration: tracking, LiDAR and local-mapping threads with a stream each, every kernel tiny --
- * should ask for 8 (streams that share a queue wait for each other: 479 against 761 frames/s); batched callers keep
+ * should ask for 8 (streams that share a queue wait for each other: 479 against 761 frames/s) -- 16 to 24 when it also
+ * runs streams of its own, e.g. the uploads of the next frame's images and scan (557 against 810-827 frames/s host-fed); batched callers keep
  * the default.  Returns TC2LI_ERR_INVALID for n < 1 or n > 32.  No reference counterpart.
  * It only takes effect before the process's first HIP call: once this library has called into HIP (any entry that needs the device,
  * tc2li_device_count included) it returns TC2LI_ERR_INVALID instead of silently doing nothing.  It sets an environment variable (setenv):
