@@ -924,6 +924,7 @@ def algorithmic_work_inertial(wl, il, nkp, windows_per_step):
         "k_map_keep_scatter": (F * mp * 96, "B"), "k_map_count": (F * mp * 52, "B"), "k_map_scatter": (F * mp * (48 + 16 + 8), "B"),
         # PoseInertialOptimizationLastFrame: every correspondence read once (edge 40 B + point 24 B + close flag), outlier flag out
         "k_pose_inertial": (F * float(np.mean([len(q["edges"]) for q in il.uniq_pi])) * (40 + 24 + 1 + 1), "B"),
+        "k_pose_inertial_batch": (F * float(np.mean([len(q["edges"]) for q in il.uniq_pi])) * (40 + 24 + 1 + 1), "B"),  # the same body, two workgroups per CU (> 256 frames)
     })
     for k in ("k_sel_scatter", "k_sel_count"):
         w.pop(k, None)

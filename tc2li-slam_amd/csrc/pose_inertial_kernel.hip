@@ -44,11 +44,9 @@ __device__ __forceinline__ double pi_visual(const ImuPose& T, const ImuCalib& ca
     return c2;
 }
 
-// Two wavefronts per SIMD (amdgpu_waves_per_eu): the body wants 256 + 28 registers, which is one -- one workgroup per CU, i.e. the 512 frames
-// of a batch in two rounds of 2.3 ms; held to 256 (100 B of scratch per lane) two workgroups share a CU and the batch is one round.
-__global__ __launch_bounds__(kPiThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_inertial(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
-                                                            const uint8_t* __restrict__ close_flags, ImuCalib cal, CameraD cam, uint8_t* __restrict__ outlier,
-                                                            double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
+__device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
+                                                   const uint8_t* __restrict__ close_flags, const ImuCalib& cal, const CameraD& cam, uint8_t* __restrict__ outlier,
+                                                   double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
     __shared__ double s_red[4 * kPiRed], s_sum[kPiRed];
     __shared__ double s_H[900], s_b[30], s_x[30], s_D[30], s_y[30];
     __shared__ double s_J[216], s_T[216], s_e[9], s_Oe[9];        // inertial edge: J, Omega J, error, Omega error
@@ -325,9 +323,26 @@ __global__ __launch_bounds__(kPiThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     }
 }
 
+// Two kernels of the same body.  k_pose_inertial: the registers the body wants (256 + 28): one wavefront per SIMD, the shortest chain for a
+// frame -- what a single sequence sees.  k_pose_inertial_batch: held to two wavefronts per SIMD (amdgpu_waves_per_eu: 256 registers, 100 B of
+// scratch per lane), so that two workgroups share a CU and the 512 frames of a batch are ONE round of 2.6 ms instead of two of 2.3
+// (4.6 -> 2.7 ms per 512 frames with the tracking stages alone; a lone frame is ~8 % slower in this form).
+__global__ __launch_bounds__(kPiThreads) void k_pose_inertial(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
+                                                            const uint8_t* __restrict__ close_flags, ImuCalib cal, CameraD cam, uint8_t* __restrict__ outlier,
+                                                            double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
+    pose_inertial_body(probs, Xw, edges, close_flags, cal, cam, outlier, chi2_scratch, results);
+}
+__global__ __launch_bounds__(kPiThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pose_inertial_batch(
+    const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges, const uint8_t* __restrict__ close_flags, ImuCalib cal,
+    CameraD cam, uint8_t* __restrict__ outlier, double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
+    pose_inertial_body(probs, Xw, edges, close_flags, cal, cam, outlier, chi2_scratch, results);
+}
+
 void launch_pose_inertial(const PiProblem* probs, int n, const double* Xw, const BaEdge* edges, const uint8_t* close, const ImuCalib& cal,
                           const CameraD& cam, uint8_t* outlier, double* chi2_scratch, PiResult* results, hipStream_t st) {
-    if (n > 0) TC2LI_LAUNCH(k_pose_inertial, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
+    if (n <= 0) return;
+    if (n > 256) TC2LI_LAUNCH(k_pose_inertial_batch, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
+    else TC2LI_LAUNCH(k_pose_inertial, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
 }
 
 }  // namespace tc2li

@@ -75,3 +75,17 @@ def test_pose_inertial_argument_errors(pkg, oracle, synthetic):
     with pytest.raises(pkg.capi.Tc2liError):
         pkg.capi.pose_inertial_optimization_batch([bad], w["calib24"], w["cam"])
     assert pkg.capi.pose_inertial_optimization_batch([], w["calib24"], w["cam"]) == []
+
+
+def test_a_batch_beyond_256_frames_takes_the_two_per_cu_kernel_with_the_same_bits(pkg, oracle, synthetic):
+    """More than 256 frames run k_pose_inertial_batch (the same body held to two wavefronts per SIMD): every frame's result is the one the
+    frame gets in a small batch (k_pose_inertial), bit for bit."""
+    ws = [problem(pkg, oracle, synthetic, 20, True, n_points=400), problem(pkg, oracle, synthetic, 21, False, n_points=250),
+          problem(pkg, oracle, synthetic, 22, True, n_points=60, outlier_frac=0.3)]
+    items = [dict(w, edges=w["packed_edges"]) for w in ws]
+    small = pkg.capi.pose_inertial_optimization_batch(items, ws[0]["calib24"], ws[0]["cam"])
+    big = pkg.capi.pose_inertial_optimization_batch([items[k % 3] for k in range(258)], ws[0]["calib24"], ws[0]["cam"])
+    for k in (0, 1, 2, 128, 255, 256, 257):
+        s, b = small[k % 3], big[k]
+        assert np.array_equal(b[0], s[0]) and np.array_equal(b[1], s[1]) and np.array_equal(b[2], s[2]) and np.array_equal(b[3], s[3])
+        assert b[4] == s[4] and b[5] == s[5] and b[6] == s[6]
