@@ -405,7 +405,9 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
                         kQuadThreads, L, cst);
         // (the results reach the pinned mirrors through the kernels' own stores.  Device copies only + five hipMemcpyAsync per chunk behind the
         // kernels -- the copy engines instead of bus-bound wavefronts -- was measured in round 4: ORB stage alone 9.8 -> 12.3 ms per 1024 images,
-        // the whole loop 29.1 -> 29.9 ms per step over three A/B pairs)
+        // the whole loop 29.1 -> 29.9 ms per step over three A/B pairs; the same with ONE k_copy_tasks launch of 16 / 64 workgroups behind the
+        // chunk's kernels instead of the copy engines: 11.5 ms alone, 29.7-30.2 against 28.6-29.2 in the loop -- the bus time of the results
+        // is hidden best inside the descriptor kernel itself)
         launch_quadtree_gather(o->d_jobs.p, o->d_picked.p, o->d_picked_count.p, o->d_level_counts.p, i0, m, L, kp_stride, o->d_kps.p, o->h_kps.p, o->d_nkp.p,
                                o->h_nkp.p, o->h_level_counts.p, o->d_status.p, cst);
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 10), cst));
