@@ -837,6 +837,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         # keypoint distribution: every candidate once (4 B) + the picks; the rounds of the walk re-read keys that stay in L2
         "k_quadtree": (n_img * (4 * 15000 + 8 * nkp), "B"),
         "k_quadtree_sorted": (n_img * (4 * 15000 + 8 * nkp), "B"),                      # round 3: keys sorted once by their path, everything in LDS
+        "k_quadtree_sorted_list": (n_img * (4 * 15000 + 8 * nkp), "B"),                 # round 4: the same jobs from per-class lists, resident workgroups
         # voxel filter, sorted form: xyz in, (voxel, point) out; the gather reads a point and writes its 32-byte record; the sums read the records
         "k_voxel_sort_points": (F * pre * (16 + 8), "B"), "k_voxel_gather_sorted": (F * pre * (4 + 48 + 32), "B"),
         "k_voxel_centroid_sorted": (F * (pre * 32 + down * 48), "B"),

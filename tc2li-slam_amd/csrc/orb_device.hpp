@@ -42,8 +42,9 @@ struct QuadJob {
     int32_t min_x, max_x, min_y, max_y, n_target, pad_;
 };
 size_t quadtree_scratch_bytes(int max_keys, int max_nodes);
+size_t quadtree_class_work_ints(int n_jobs);  // launch_quadtree's class_work for a batch of that many jobs (per-class job lists + counters)
 void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
-                     int32_t* picked_count, int32_t* status, int threads, int nlevels /* jobs per image, stored (image, level) */, hipStream_t st);
+                     int32_t* picked_count, int32_t* status, int threads, int nlevels /* jobs per image, stored (image, level) */, hipStream_t st, int32_t* class_work = nullptr);
 void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const int32_t* picked_count, const int32_t* level_counts, int first_image, int n_images,
                             int nlevels, int kp_stride, DevKeypoint* kps, DevKeypoint* kps_host, int32_t* n_kp, int32_t* n_kp_host, int32_t* level_counts_host,
                             int32_t* status, hipStream_t st);

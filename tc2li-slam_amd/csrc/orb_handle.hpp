@@ -54,6 +54,7 @@ struct tc2li_orb {
     tc2li::DevBuf<int> d_level_counts, d_picked_count, d_nkp, d_status;
     tc2li::DevBuf<tc2li::QuadJob> d_jobs;
     tc2li::DevBuf<uint8_t> d_qscratch;
+    tc2li::DevBuf<int32_t> d_qclass;  // per chunk: the keypoint distribution's per-class job lists (launch_quadtree)
     tc2li::DevBuf<tc2li::DevKeypoint> d_kps;
     tc2li::PinnedBuf<int> h_level_counts, h_nkp, h_status;
     tc2li::PinnedBuf<tc2li::DevKeypoint> h_kps;

@@ -369,6 +369,8 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
     TC2LI_HIP_CHECK(hipMemsetAsync(o->d_status.p, 0, sizeof(int), st));
     if (ncells == 0) TC2LI_HIP_CHECK(hipMemsetAsync(o->d_level_counts.p, 0, (size_t)M * L * sizeof(int), st));
     if (n_chunks > 1 && two_streams && !o->profiling) TC2LI_HIP_CHECK(hipEventRecord(o->ev_fork, st));
+    const int chunk_jobs_max = ((M + n_chunks - 1) / n_chunks + 1) * L;  // jobs of the largest chunk
+    TC2LI_HIP_CHECK(o->d_qclass.ensure((size_t)n_chunks * quadtree_class_work_ints(chunk_jobs_max)));
     for (int c = 0; c < n_chunks; ++c) {
         const int i0 = chunk_begin(c), m = chunk_begin(c + 1) - i0;
         hipStream_t cst = ((c & 1) && two_streams && !o->profiling) ? o->chunk_stream : st;  // this chunk's stream
@@ -402,7 +404,7 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
         // ---- stage 2: keypoint distribution per (image, level), and the per-image keypoint lists ----
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 9), cst));
         launch_quadtree(o->d_jobs.p, i0 * L, m * L, o->d_dense.p, o->d_level_counts.p, o->d_qscratch.p, o->d_picked.p, o->d_picked_count.p, o->d_status.p,
-                        kQuadThreads, L, cst);
+                        kQuadThreads, L, cst, o->d_qclass.p + (size_t)c * quadtree_class_work_ints(chunk_jobs_max));
         // (the results reach the pinned mirrors through the kernels' own stores.  Device copies only + five hipMemcpyAsync per chunk behind the
         // kernels -- the copy engines instead of bus-bound wavefronts -- was measured in round 4: ORB stage alone 9.8 -> 12.3 ms per 1024 images,
         // the whole loop 29.1 -> 29.9 ms per step over three A/B pairs; the same with ONE k_copy_tasks launch of 16 / 64 workgroups behind the

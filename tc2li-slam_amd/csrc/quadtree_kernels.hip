@@ -17,6 +17,9 @@
 // The candidate with the largest response of every final node is emitted in list order (:731-752).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
@@ -611,13 +614,14 @@ __global__ __launch_bounds__(T) void k_quadtree(const QuadJob* __restrict__ jobs
 // this one reads a candidate twice, replays the sort with the whole workgroup (intro_sort.hpp) and takes 0.26 ms in three launches
 // (LDS classes of 38 / 76 / 156 KB, i.e. 4 / 2 / 1 workgroups per CU: a job runs in the first class it fits; what fits none -- more
 // than ~12 k candidates, or more than ~1000 nodes -- is left to k_quadtree.  Same results: tests/test_quadtree_gpu.py runs both).
+// One job of the sorted form by the calling workgroup (all of its lanes; every return is taken by all of them).  s_quad: the class's
+// dynamic LDS block.  first_class >= 0: the job is checked against the class (one workgroup per job, k_quadtree_sorted); < 0: the caller
+// knows it belongs here (k_quadtree_sorted_list).
 template <int CLASS>
-__global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense,
-                                                                               const int32_t* __restrict__ level_counts, uint32_t* __restrict__ picked,
-                                                                               int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int nlevels, int first_class) {
+__device__ __forceinline__ void quad_sorted_job(const QuadJob& J, const uint32_t* __restrict__ dense, const int32_t* __restrict__ level_counts,
+                                                uint32_t* __restrict__ picked, int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int first_class,
+                                                uint8_t* s_quad) {
     constexpr int T = quad_class_threads(CLASS);
-    extern __shared__ __align__(16) uint8_t s_quad[];
-    const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
     const int tid = threadIdx.x;
     const uint32_t* cand = dense + J.cand_off;
     const int ncand = level_counts[J.count_idx];
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(c
     const int K = J.max_keys, MN = J.max_nodes, N = J.n_target;
     const int W = J.max_x - J.min_x, H = J.max_y - J.min_y;
     const int n_ini = (int)roundf((float)W / (float)H);
-    if (ncand <= 0 || ncand > K || n_ini <= 0 || n_ini > MN) {  // the trivial outcomes belong to the first class
+    if (ncand <= 0 || ncand > K || n_ini <= 0 || n_ini > MN) {  // the trivial outcomes belong to the first class (first_class < 0: to the list's maker)
         if (CLASS == first_class && tid == 0) {
             *out_count = 0;
             if (ncand > K) atomicMax(status, 1);
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(c
         }
         return;
     }
-    if (quad_class_of(ncand, MN, n_ini, first_class) != CLASS) return;  // another launch's job
+    if (first_class >= 0 && quad_class_of(ncand, MN, n_ini, first_class) != CLASS) return;  // another launch's job
     const SortedLayout lay(ncand, MN, T);
     uint32_t* const codes = reinterpret_cast<uint32_t*>(s_quad + lay.codes);
     uint16_t* const idxs = reinterpret_cast<uint16_t*>(s_quad + lay.idx);
@@ -967,6 +971,60 @@ __global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(c
     if (tid == 0) *out_count = size;
 }
 
+
+template <int CLASS>
+__global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted(const QuadJob* __restrict__ jobs, const uint32_t* __restrict__ dense,
+                                                                               const int32_t* __restrict__ level_counts, uint32_t* __restrict__ picked,
+                                                                               int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int nlevels, int first_class) {
+    extern __shared__ __align__(16) uint8_t s_quad[];
+    const QuadJob J = jobs[quad_job_of_block(blockIdx.x, gridDim.x, nlevels)];
+    quad_sorted_job<CLASS>(J, dense, level_counts, picked, picked_count, status, first_class, s_quad);
+}
+
+// ---- batches: the jobs of a class from a list, by as many workgroups as the class's LDS block lets the GPU hold ----
+// One workgroup per job and launch (above) asks the dispatcher for the class's LDS block -- 76 or 156 KB, half or all of a CU's -- for EVERY
+// job of the batch, although a job of another class only looks at its candidate count and leaves: beside the other stages' kernels each of
+// those 4096 workgroups waits for a CU with that much LDS free (k_quadtree_sorted<2>: 0.35 ms alone, 2 ms in the loop).  Here a first
+// kernel sorts the jobs into per-class lists (and settles the trivial outcomes), and every class runs as a resident set of workgroups that
+// take the list's jobs one after the other.
+// lists: [kQuadClasses + 1][n_jobs] job numbers; counters: [0 .. kQuadClasses] list lengths, [kQuadClasses + 1 ..] the classes' next entries
+__global__ __launch_bounds__(256) void k_quadtree_classify(const QuadJob* __restrict__ jobs, int n_jobs, const int32_t* __restrict__ level_counts,
+                                                           int32_t* __restrict__ picked_count, int32_t* __restrict__ status, int32_t* __restrict__ lists,
+                                                           int32_t* __restrict__ counters) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const QuadJob J = jobs[j];
+    const int ncand = level_counts[J.count_idx];
+    const int W = J.max_x - J.min_x, H = J.max_y - J.min_y;
+    const int n_ini = (int)roundf((float)W / (float)H);
+    if (ncand <= 0 || ncand > J.max_keys || n_ini <= 0 || n_ini > J.max_nodes) {
+        picked_count[J.count_idx] = 0;
+        if (ncand > J.max_keys) atomicMax(status, 1);
+        else if (ncand > 0 && n_ini > J.max_nodes) atomicMax(status, 2);
+        return;
+    }
+    const int c = quad_class_of(ncand, J.max_nodes, n_ini, 0);
+    lists[(size_t)c * n_jobs + atomicAdd(&counters[c], 1)] = j;
+}
+template <int CLASS>
+__global__ __launch_bounds__(quad_class_threads(CLASS)) void k_quadtree_sorted_list(const QuadJob* __restrict__ jobs, int n_jobs, const int32_t* __restrict__ lists,
+                                                                                    int32_t* __restrict__ counters, const uint32_t* __restrict__ dense,
+                                                                                    const int32_t* __restrict__ level_counts, uint32_t* __restrict__ picked,
+                                                                                    int32_t* __restrict__ picked_count, int32_t* __restrict__ status) {
+    extern __shared__ __align__(16) uint8_t s_quad[];
+    __shared__ int s_job;
+    const int count = counters[CLASS];
+    for (;;) {
+        __syncthreads();  // the job before has left the LDS block and s_job
+        if (threadIdx.x == 0) s_job = atomicAdd(&counters[kQuadClasses + 1 + CLASS], 1);
+        __syncthreads();
+        const int k = s_job;
+        if (k >= count) break;  // (the same for every lane)
+        const QuadJob J = jobs[lists[(size_t)CLASS * n_jobs + k]];
+        quad_sorted_job<CLASS>(J, dense, level_counts, picked, picked_count, status, -1, s_quad);
+    }
+}
+
 // The keypoints of an image: its per-level lists behind each other (level order, :1093-1137), in level pixel coordinates with the
 // border added (:856-857).  One workgroup per image; the lists go to a device array (the descriptor kernel reads it) and to its pinned
 // host mirror (the assembly on the host reads it), the counts likewise.
@@ -1001,14 +1059,31 @@ __global__ __launch_bounds__(256) void k_quadtree_gather(const QuadJob* __restri
 // global-memory form for what is left; threads = -1 - c: the same starting with class c; threads > 0: the global-memory form alone
 // with that many lanes per job.
 void launch_quadtree(const QuadJob* jobs, int first_job, int n_jobs, const uint32_t* dense, const int32_t* level_counts, uint8_t* scratch, uint32_t* picked,
-                     int32_t* picked_count, int32_t* status, int threads, int nlevels, hipStream_t st) {
+                     int32_t* picked_count, int32_t* status, int threads, int nlevels, hipStream_t st, int32_t* class_work) {
     if (n_jobs <= 0) return;
     const QuadJob* j0 = jobs + first_job;
     int after_sorted = 0;
     // the two wider classes need more dynamic LDS than a kernel gets by default; should the runtime refuse, every job takes the global-memory form
     if (threads <= 0 && !(ensure_dynamic_lds(reinterpret_cast<const void*>(k_quadtree_sorted<1>), (int)quad_class_lds(1)) &&
                           ensure_dynamic_lds(reinterpret_cast<const void*>(k_quadtree_sorted<2>), (int)quad_class_lds(2)))) threads = 256;
-    if (threads <= 0) {
+    const char* lists_env = getenv("TC2LI_QUADTREE_LISTS");  // (read per call: the tests switch it) 0: one workgroup per job and class launch
+    const bool kNoLists = lists_env && atoi(lists_env) == 0;
+    if (threads == 0 && class_work && n_jobs > 256 && !kNoLists) {
+        // a batch: per-class job lists, every class a resident set of workgroups (k_quadtree_sorted_list)
+        int32_t* const lists = class_work + 16;
+        int32_t* const counters = class_work;
+        (void)hipMemsetAsync(counters, 0, 16 * sizeof(int32_t), st);
+        TC2LI_LAUNCH(k_quadtree_classify, dim3((n_jobs + 255) / 256), dim3(256), 0, st, j0, n_jobs, level_counts, picked_count, status, lists, counters);
+        const int cus = 256;
+        TC2LI_LAUNCH(k_quadtree_sorted_list<0>, dim3(std::min(n_jobs, 4 * cus)), dim3(quad_class_threads(0)), quad_class_lds(0), st, j0, n_jobs, lists, counters, dense,
+                     level_counts, picked, picked_count, status);
+        TC2LI_LAUNCH(k_quadtree_sorted_list<1>, dim3(std::min(n_jobs, 2 * cus)), dim3(quad_class_threads(1)), quad_class_lds(1), st, j0, n_jobs, lists, counters, dense,
+                     level_counts, picked, picked_count, status);
+        TC2LI_LAUNCH(k_quadtree_sorted_list<2>, dim3(std::min(n_jobs, cus)), dim3(quad_class_threads(2)), quad_class_lds(2), st, j0, n_jobs, lists, counters, dense,
+                     level_counts, picked, picked_count, status);
+        after_sorted = 1;
+        threads = 256;
+    } else if (threads <= 0) {
         // fewer jobs than CUs (a stereo pair is 16): every job in the widest class, one launch instead of three in a row
         const int first_class = threads < 0 ? min(-threads - 1, kQuadClasses - 1) : (n_jobs <= 256 ? 2 : 0);  // threads < 0: the tests choose
         if (first_class <= 0)
@@ -1033,5 +1108,6 @@ void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const i
 }
 
 size_t quadtree_scratch_bytes(int max_keys, int max_nodes) { return ScratchLayout(max_keys, max_nodes).total; }
+size_t quadtree_class_work_ints(int n_jobs) { return 16 + (size_t)(kQuadClasses + 1) * n_jobs; }
 
 }  // namespace tc2li
