@@ -820,6 +820,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
     w = {
         "k_resize_linear": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # read levels 0..6, write levels 1..7
         "k_resize_strips": (n_img * (sum(px[:-1]) + sum(px[1:])), "B"),                # the same resize as column strips (round 3)
+        "k_resize_tail": (n_img * (sum(px[2:-1]) + sum(px[3:])), "B"),                  # round 4: levels 3..7 in one launch, a workgroup per image
         "k_fast_cells": (n_img * (sum(px) + 4 * 15000), "B"),                          # every level once + the candidate list
         "k_blur7_strips": (n_img * 2 * sum(px), "B"),
         "k_orient_describe": (n_img * nkp * (709 + 512 + 64 + 16), "B"),                # patch gathers + descriptor / angle / key out

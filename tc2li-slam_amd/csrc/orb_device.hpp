@@ -51,6 +51,9 @@ void launch_quadtree_gather(const QuadJob* jobs, const uint32_t* picked, const i
 
 void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, const short* ialpha, const int* yofs,
                    const short* ibeta, int nimg, hipStream_t st);
+// levels l0 .. n_levels - 1 of every image in one launch (one workgroup per image walks them; batches: the chain of dependent launches is the cost)
+void launch_resize_tail(const LevelTable& lv, const int* const* xofs, const short* const* ialpha, const int* const* yofs, const short* const* ibeta, int l0, int n_levels,
+                        int nimg, hipStream_t st);
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
                  size_t slab_img_stride, int* cell_counts, int nimg, const int* small_ids, int n_small, const int* large_ids, int n_large,
                  hipStream_t st);

@@ -381,8 +381,17 @@ int tc2li_orb_extract_batch(tc2li_orb* o, const uint8_t* dev_images, int n_image
             cblur.lv[l].img = blur.lv[l].img + (size_t)i0 * blur.lv[l].img_stride;
         }
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 0), cst));
-        for (int l = 1; l < L; ++l)
+        // the pyramid: the large levels a launch each over the whole GPU, the small ones (from level kTailFrom on) in ONE launch, a workgroup per
+        // image -- seven dependent launches cost the chunk's stream ~0.6 ms each beside the other stages' kernels, whatever their size
+        static const int kTailFromEnv = getenv("TC2LI_RESIZE_TAIL_FROM") ? atoi(getenv("TC2LI_RESIZE_TAIL_FROM")) : 3;
+        const int tail_from = (m >= 32 && kTailFromEnv >= 1) ? std::min(kTailFromEnv, L) : L;
+        for (int l = 1; l < tail_from; ++l)
             launch_resize(craw.lv[l - 1], craw.lv[l], o->d_xofs[l].p, o->d_ialpha[l].p, o->d_yofs[l].p, o->d_ibeta[l].p, m, cst);
+        if (tail_from < L) {
+            const int* xo[kMaxLevels]; const short* ia[kMaxLevels]; const int* yo[kMaxLevels]; const short* ib[kMaxLevels];
+            for (int l = 0; l < L; ++l) { xo[l] = o->d_xofs[l].p; ia[l] = o->d_ialpha[l].p; yo[l] = o->d_yofs[l].p; ib[l] = o->d_ibeta[l].p; }
+            launch_resize_tail(craw, xo, ia, yo, ib, tail_from, L, m, cst);
+        }
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 1), cst));
         if (!o->profiling) TC2LI_HIP_CHECK(hipStreamWaitEvent(blur_st, EV(c, 1), 0));
         TC2LI_HIP_CHECK(hipEventRecord(EV(c, 4), blur_st));

@@ -118,21 +118,11 @@ __device__ __forceinline__ uint32_t load_u16_unaligned(const uint8_t* p) {
     __builtin_memcpy(&w, p, 2);
     return w;
 }
-__global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict__ src, int src_pitch, size_t src_img_stride, int sw, int sh,
-                                                       uint8_t* __restrict__ dst, int dst_pitch, size_t dst_img_stride, int dw, int dh,
-                                                       const int* __restrict__ xofs, const short* __restrict__ ialpha, const int* __restrict__ yofs,
-                                                       const short* __restrict__ ibeta, int gx, int gy, int nimg, int rows_per_wave) {
-    // one wavefront = 256 columns x rows_per_wave rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
-    const int n_units = gx * gy * nimg, per_xcd = (n_units + 7) / 8;
-    const int u = ((int)blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);  // the wavefront's unit inside its XCD's share
-    const int logical = ((int)blockIdx.x & 7) * per_xcd + u;
-    if (u >= per_xcd || logical >= n_units) return;
-    const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
-    const int dx0 = (bx * 64 + (int)(threadIdx.x & 63)) * 4;
-    if (dx0 >= dw) return;
-    const uint8_t* S = src + (size_t)img * src_img_stride;
-    uint8_t* D = dst + (size_t)img * dst_img_stride + dx0;
-    const int dy_begin = by * rows_per_wave, dy_end = min(dy_begin + rows_per_wave, dh);
+// one wavefront's unit of the strip form: destination columns [dx0, dx0 + 4) of this lane, rows [dy_begin, dy_end) of one image
+// (S: the source image, D: the destination image + dx0)
+__device__ __forceinline__ void resize_strip_unit(const uint8_t* __restrict__ S, int src_pitch, int sw, int sh, uint8_t* __restrict__ D, int dst_pitch, int dw,
+                                                  const int* __restrict__ xofs, const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                                                  const short* __restrict__ ibeta, int dx0, int dy_begin, int dy_end) {
     int sx[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -190,6 +180,50 @@ __global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict
         } else {
             for (int k = 0; k < 4 && dx0 + k < dw; ++k) Drow[k] = (uint8_t)(packed >> (8 * k));
         }
+    }
+}
+
+
+__global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict__ src, int src_pitch, size_t src_img_stride, int sw, int sh,
+                                                       uint8_t* __restrict__ dst, int dst_pitch, size_t dst_img_stride, int dw, int dh,
+                                                       const int* __restrict__ xofs, const short* __restrict__ ialpha, const int* __restrict__ yofs,
+                                                       const short* __restrict__ ibeta, int gx, int gy, int nimg, int rows_per_wave) {
+    // one wavefront = 256 columns x rows_per_wave rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
+    const int n_units = gx * gy * nimg, per_xcd = (n_units + 7) / 8;
+    const int u = ((int)blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);  // the wavefront's unit inside its XCD's share
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + u;
+    if (u >= per_xcd || logical >= n_units) return;
+    const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
+    const int dx0 = (bx * 64 + (int)(threadIdx.x & 63)) * 4;
+    if (dx0 >= dw) return;
+    const uint8_t* S = src + (size_t)img * src_img_stride;
+    uint8_t* D = dst + (size_t)img * dst_img_stride + dx0;
+    const int dy_begin = by * rows_per_wave, dy_end = min(dy_begin + rows_per_wave, dh);
+    resize_strip_unit(S, src_pitch, sw, sh, D, dst_pitch, dw, xofs, ialpha, yofs, ibeta, dx0, dy_begin, dy_end);
+}
+
+// The small levels of the pyramid in ONE launch: level l is made from level l - 1 (SF/src/ORBextractor.cc:1159-1186), so the seven resizes of
+// an extraction are a chain of dependent launches, and beside the other stages' kernels every link costs about 0.6 ms whatever its size.
+// From level `l0` on a level is small enough for one workgroup per image to make it whole: the workgroup walks levels l0 .. n_levels - 1,
+// its wavefronts take the strip units of a level in turn, a barrier between two levels (the level just written is read back by the same
+// workgroup: through L2, no other workgroup touches this image).  Same arithmetic as k_resize_strips, unit by unit.
+struct ResizeTables { const int* xofs[kMaxLevels]; const short* ialpha[kMaxLevels]; const int* yofs[kMaxLevels]; const short* ibeta[kMaxLevels]; };
+constexpr int kResizeTailThreads = 1024;
+__global__ __launch_bounds__(kResizeTailThreads) void k_resize_tail(LevelTable lv, ResizeTables tb, int l0, int n_levels) {
+    const int img = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int l = l0; l < n_levels; ++l) {
+        const LevelDesc S = lv.lv[l - 1], D = lv.lv[l];
+        const uint8_t* src = S.img + (size_t)img * S.img_stride;
+        uint8_t* dst = const_cast<uint8_t*>(D.img) + (size_t)img * D.img_stride;
+        const int gx = (D.w + 255) / 256, gy = (D.h + kResizeRows - 1) / kResizeRows;
+        for (int u = wave; u < gx * gy; u += kResizeTailThreads / 64) {
+            const int by = u / gx, bx = u - by * gx;
+            const int dx0 = (bx * 64 + lane) * 4;
+            if (dx0 >= D.w) continue;
+            resize_strip_unit(src, S.pitch, S.w, S.h, dst + dx0, D.pitch, D.w, tb.xofs[l], tb.ialpha[l], tb.yofs[l], tb.ibeta[l], dx0, by * kResizeRows,
+                              min((by + 1) * kResizeRows, D.h));
+        }
+        __syncthreads();  // level l is complete (and visible to this workgroup) before level l + 1 reads it
     }
 }
 
@@ -820,6 +854,14 @@ void launch_resize(const LevelDesc& src, const LevelDesc& dst, const int* xofs, 
     const int per_xcd = (gx * gy * nimg + 7) / 8, wg_per_xcd = (per_xcd + 3) / 4;
     TC2LI_LAUNCH(k_resize_strips, dim3(wg_per_xcd * 8), dim3(256), 0, st, src.img, src.pitch, src.img_stride, src.w, src.h,
                  const_cast<uint8_t*>(dst.img), dst.pitch, dst.img_stride, dst.w, dst.h, xofs, ialpha, yofs, ibeta, gx, gy, nimg, rows);
+}
+
+void launch_resize_tail(const LevelTable& lv, const int* const* xofs, const short* const* ialpha, const int* const* yofs, const short* const* ibeta, int l0, int n_levels,
+                        int nimg, hipStream_t st) {
+    if (nimg <= 0 || l0 >= n_levels) return;
+    ResizeTables tb{};
+    for (int l = l0; l < n_levels; ++l) { tb.xofs[l] = xofs[l]; tb.ialpha[l] = ialpha[l]; tb.yofs[l] = yofs[l]; tb.ibeta[l] = ibeta[l]; }
+    TC2LI_LAUNCH(k_resize_tail, dim3(nimg), dim3(kResizeTailThreads), 0, st, lv, tb, l0, n_levels);
 }
 
 void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, int ini_th, int min_th, uint32_t* slab,
