@@ -335,15 +335,11 @@ int rebuild_grids(tc2li_lidar_map* const* maps, int n_maps, DevBuf<MapGridTask>&
         max_row_entries = std::max(max_row_entries, tasks[i].g.ny * tasks[i].g.nz * tasks[i].g.nsx * kMapSegStride + 1);
     }
     for (int i = 0; i < n_maps; ++i) { maps[i]->counts_dirty = true; maps[i]->grid_valid = false; }
-    static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
-    if (kDebug) fprintf(stderr, "rebuild_grids: %d maps, map 0: n %d n_old %d n_kept %d slots %d cells %d remap %p old %p\n", n_maps, maps[0]->n, tasks[0].n_old, tasks[0].n_kept,
-                        tasks[0].g.n_slots, tasks[0].n_cells, (const void*)tasks[0].remap, (const void*)tasks[0].old_sorted);
     TC2LI_HIP_CHECK(d_tasks.ensure(n_maps));
     TC2LI_HIP_CHECK(hipMemcpyAsync(d_tasks.p, tasks.data(), n_maps * sizeof(MapGridTask), hipMemcpyHostToDevice, st));
     launch_map_grid_build(d_tasks.p, n_maps, max_points, max_cells, max_row_entries, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(stream_wait_blocking(st));
-    if (kDebug) fprintf(stderr, "rebuild_grids: done\n");
     for (int i = 0; i < n_maps; ++i) {
         tc2li_lidar_map* m = maps[i];
         m->grid = tasks[i].g; m->grid_valid = true; m->counts_dirty = false; m->tombstones = 0; ++m->n_grid_builds;
@@ -1249,7 +1245,6 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
-        if (getenv("TC2LI_MAP_DEBUG")) fprintf(stderr, "map_incremental: lists + compaction of %d maps done\n", nt);
         for (int k = 0; k < nt; ++k)
             if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {
                 // the compaction kernels saw the batch word and touched no map; the deletion marks of the lists are taken back
@@ -1271,14 +1266,14 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
             const int* o = L->h_mapinc_out.p + k * kMapIncOut;
             tc2li_lidar_map* m = maps[which[k]];
             const bool fixed = tasks[k].fix_grid != 0;
-            if (o[13]) fprintf(stderr, "tc2li: compaction of map %d found an inconsistent grid (code %d)\n", k, o[13]);
+            const bool grid_bad = o[13] != 0;  // the renumbering met an entry that does not fit its map: the grid is not trusted, rebuilt from the points
+            if (grid_bad) fprintf(stderr, "tc2li: compaction of map %d found an inconsistent grid (code %d): rebuilt from the point list\n", k, o[13]);
             commit_compaction(m, o, true);
             if (n_to_add) n_to_add[which[k]] = o[0];
             if (n_no_need) n_no_need[which[k]] = o[2];
             const int kept = o[4], added = o[5] + o[2];
             if (fixed) { m->have_remap = false; m->rebuild_mode = 2; }  // the old grid's entries carry the new numbering already
-            static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
-            if (kDebug && k == 0) fprintf(stderr, "map_incremental: map 0 fixed %d kept %d appended %d no-need %d tombstones %d of %d points\n", (int)fixed, kept, o[5], o[2], m->tombstones, m->n);
+            if (grid_bad) { m->have_remap = false; m->rebuild_mode = 0; rebuild.push_back(m); continue; }
             if (!fixed || added > kMapInsMax) { rebuild.push_back(m); continue; }
             m->grid.n_points = m->n;
             if (added == 0) {
@@ -1300,15 +1295,13 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
             TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_ins_tasks.p, ins.data(), ni * sizeof(MapInsTask), hipMemcpyHostToDevice, st));
             launch_map_insert(L->d_ins_tasks.p, ni, st);
             TC2LI_HIP_CHECK(hipGetLastError());
-            if (getenv("TC2LI_MAP_DEBUG")) { TC2LI_HIP_CHECK(stream_wait_blocking(st)); fprintf(stderr, "  insertion of %d maps done\n", ni); }
             TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_ins_out.p, L->d_ins_out.p, 4 * (size_t)ni * sizeof(int), hipMemcpyDeviceToHost, st));
             TC2LI_HIP_CHECK(stream_wait_blocking(st));
             for (int k = 0; k < ni; ++k) {
                 tc2li_lidar_map* m = inserted[k];
-                static const bool kDebug = getenv("TC2LI_MAP_DEBUG") != nullptr;
-                if (kDebug && k == 0) fprintf(stderr, "  insertion: rows %d overflow %d tombstones dropped %d\n", L->h_ins_out.p[4 * k], L->h_ins_out.p[4 * k + 1], L->h_ins_out.p[4 * k + 2]);
-                if (L->h_ins_out.p[4 * k + 3]) fprintf(stderr, "tc2li: in-place insertion of map %d found an inconsistent grid (code %d)\n", k, L->h_ins_out.p[4 * k + 3]);
-                if (L->h_ins_out.p[4 * k + 1]) { m->rebuild_mode = 0; rebuild.push_back(m); }  // some rows may hold the new points already: from the point list
+                const bool ins_bad = L->h_ins_out.p[4 * k + 3] != 0;  // an index outside its bounds (the kernel skipped it): rebuilt from the points
+                if (ins_bad) fprintf(stderr, "tc2li: in-place insertion of map %d found an inconsistent grid (code %d): rebuilt from the point list\n", k, L->h_ins_out.p[4 * k + 3]);
+                if (L->h_ins_out.p[4 * k + 1] || ins_bad) { m->have_remap = false; m->rebuild_mode = 0; rebuild.push_back(m); }  // some rows may hold the new points already: from the point list
                 else {
                     // the rewritten segments dropped their tombstones; what is left elsewhere is scanned by every search that passes: beyond an
                     // eighth of the map the grid is rebuilt from its own order (mode 2: it holds every point under its new index)
