@@ -283,7 +283,7 @@ template <int TH, int TW>
 __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, const FastCell* __restrict__ cells, int ini_th,
                                                     int min_th, uint32_t* __restrict__ slab, size_t slab_img_stride,
                                                     int* __restrict__ cell_counts, int ncells, int nimg,
-                                                    const int* __restrict__ cell_ids, int n_ids) {
+                                                    const int* __restrict__ cell_ids, int n_ids, int cells_per_wg) {
     // The window rows are staged as dwords read at the rows' own byte addresses (rows of the caller's image start anywhere): pixel
     // (x, y) of the window is byte y * kTileP + x of the tile.  (Round 1 / 2 staged the ALIGNED dwords and carried a per-row
     // misalignment term through every LDS address; the kernel's time follows its instruction count -- 1.9 G wavefront VALU
@@ -302,10 +302,16 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     // eighth of the (image, cell) list instead of every 8th cell: without this every line was fetched by ~4 XCDs (389 MB of HBM
     // reads per launch for 96 MB of pixels in the first PMC profile).
     // cell_ids: the cells this launch covers (the windows that fit the instantiation's tile), n_ids of the ncells of an image
+    // A workgroup takes cells_per_wg CONSECUTIVE cells of its XCD's share one after the other (batches: a cell is ~5 us of work, and beside the
+    // other stages' kernels the dispatch of 2 x 10^5 workgroups per launch was part of what the launch cost)
     const int total = n_ids * nimg, per_xcd = (total + 7) / 8;
-    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (logical >= total) return;
-    const int tid = threadIdx.x, img = logical / n_ids, cell = cell_ids[logical - img * n_ids];
+    const int tid = threadIdx.x;
+    for (int rep = 0; rep < cells_per_wg; ++rep) {
+    const int in_xcd = ((int)blockIdx.x >> 3) * cells_per_wg + rep;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + in_xcd;
+    if (in_xcd >= per_xcd || logical >= total) break;  // (the same for every lane)
+    if (rep) __syncthreads();  // the cell before has been emitted: its LDS arrays are free
+    const int img = logical / n_ids, cell = cell_ids[logical - img * n_ids];
     const FastCell c = cells[cell];
     const LevelDesc L = levels.lv[c.level];
     const uint8_t* src = L.img + (size_t)img * L.img_stride + (size_t)c.y0 * L.pitch + c.x0;
@@ -462,6 +468,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
         if (rank < c.slab_cap) out[rank] = (py << 20) | (px << 8) | scv;
     }
     if (tid == 0) cell_counts[(size_t)img * ncells + cell] = s_nkept;
+    }
 }
 
 // Ordered concatenation of the per-cell candidate lists of one (image, level) into a dense list: cell-major order,
@@ -869,12 +876,15 @@ void launch_fast(const LevelTable& levels, const FastCell* cells, int ncells, in
                  hipStream_t st) {
     // cell windows are 35-px cells + 6: 48 x 48 holds all but the levels whose height leaves one or two tall rows of cells; those go
     // through the full-size variant (a third of the LDS-limited occupancy), each window class in its own launch
+    static const int kCellsEnv = getenv("TC2LI_FAST_CELLS_PER_WG") ? atoi(getenv("TC2LI_FAST_CELLS_PER_WG")) : 4;
+    const int cpw = nimg >= 32 ? std::max(1, std::min(kCellsEnv, 16)) : 1;  // a few images: every cell its own workgroup (the launch is latency-bound)
+    auto grid = [&](int n_ids) { const int per_xcd = (n_ids * nimg + 7) / 8; return ((per_xcd + cpw - 1) / cpw) * 8; };
     if (n_small > 0)
-        TC2LI_LAUNCH((k_fast_cells<48, 48>), dim3(((n_small * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th, min_th, slab,
-                           slab_img_stride, cell_counts, ncells, nimg, small_ids, n_small);
+        TC2LI_LAUNCH((k_fast_cells<48, 48>), dim3(grid(n_small)), dim3(kFastThreads), 0, st, levels, cells, ini_th, min_th, slab,
+                           slab_img_stride, cell_counts, ncells, nimg, small_ids, n_small, cpw);
     if (n_large > 0)
-        TC2LI_LAUNCH((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(((n_large * nimg + 7) / 8) * 8), dim3(kFastThreads), 0, st, levels, cells, ini_th,
-                           min_th, slab, slab_img_stride, cell_counts, ncells, nimg, large_ids, n_large);
+        TC2LI_LAUNCH((k_fast_cells<kFastTileH, kFastTilePitch>), dim3(grid(n_large)), dim3(kFastThreads), 0, st, levels, cells, ini_th,
+                           min_th, slab, slab_img_stride, cell_counts, ncells, nimg, large_ids, n_large, cpw);
 }
 
 void launch_compact(const FastCell* cells, const int* level_cell_begin, const int* cell_counts, int ncells,
