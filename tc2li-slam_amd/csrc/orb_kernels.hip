@@ -702,15 +702,13 @@ __constant__ int c_umax[16];
 __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTable blurred, ScaleTable sc,
                                                          const DevKeypoint* __restrict__ kps, const int32_t* __restrict__ n_kp, int first_image,
                                                          int n_images, int kp_stride, float* __restrict__ angles, float* __restrict__ angles_dev, uint8_t* __restrict__ desc,
-                                                         MatchKey* __restrict__ mkeys, uint8_t* __restrict__ desc_dev) {
+                                                         MatchKey* __restrict__ mkeys, uint8_t* __restrict__ desc_dev, int reps) {
     // XCD-contiguous block order (as in k_fast_cells): the keypoints come image by image and level by level, and XCD k works on the
     // k-th eighth of the list, so an image's levels are fetched into ONE L2 instead of all eight (307 MB of HBM reads per 64 k keypoints
     // before, against 90 MB of pyramid levels)
     // Keypoint slots: image i owns kp_stride of them and fills the first n_kp[i] (counts known on the device only: k_quadtree_gather)
+    // A workgroup takes `reps` consecutive blocks of eight keypoints of its XCD's share, one after the other (batches: fewer, longer workgroups)
     const int nslot = n_images * kp_stride, nblk = (nslot + 7) / 8, per_xcd = (nblk + 7) / 8;
-    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (logical >= nblk) return;  // whole workgroup
-    const int slot = (logical * 256 + (int)threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31, kpi = threadIdx.x >> 5;
     // The two patches of a keypoint -- 31 x 31 of the level image (orientation), 37 x 37 of the blurred level (the rotated pattern
     // reaches 18 px: its corner points are (+-13, +-13)) -- are staged in LDS, 9 + 12 coalesced dword loads per lane, instead of 31 + 16
@@ -729,6 +727,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         }
         s_icmask[av][j] = m;
     }
+    for (int rep = 0; rep < reps; ++rep) {
+    const int in_xcd = ((int)blockIdx.x >> 3) * reps + rep;
+    const int logical = ((int)blockIdx.x & 7) * per_xcd + in_xcd;
+    if (in_xcd >= per_xcd || logical >= nblk) break;  // whole workgroup
+    if (rep) __syncthreads();                          // the block before has read its patches
+    const int slot = (logical * 256 + (int)threadIdx.x) >> 5;
     bool active = slot < nslot;
     int slot_img = 0;
     if (active) {
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         stage(blurred.lv[level], std::integral_constant<int, kBlurR>{}, std::integral_constant<int, kBlurDw>{}, s_blur[kpi]);
     }
     __syncthreads();
-    if (!active) return;
+    if (!active) continue;
     const uint8_t* pblur = reinterpret_cast<const uint8_t*>(s_blur[kpi]);
     auto blur_at = [&](int u, int v) -> int { return pblur[(v + kBlurR) * 4 * kBlurDw + u + kBlurR]; };
     {
@@ -840,6 +844,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
         }
         desc[(size_t)g * 32 + lane] = (uint8_t)val;
         desc_dev[(size_t)g * 32 + lane] = (uint8_t)val;
+    }
     }
 }
 
@@ -915,8 +920,11 @@ void launch_orient_describe(const LevelTable& raw, const LevelTable& blurred, co
                             hipStream_t st) {
     const long nslot = (long)n_images * kp_stride;
     if (nslot <= 0) return;
-    TC2LI_LAUNCH(k_orient_describe, dim3((unsigned)((((nslot + 7) / 8 + 7) / 8) * 8)), dim3(256), 0, st, raw, blurred, sc, kps, n_kp, first_image, n_images,
-                 kp_stride, angles, angles_dev, desc, mkeys, desc_dev);
+    static const int kRepsEnv = getenv("TC2LI_DESCRIBE_BLOCKS_PER_WG") ? atoi(getenv("TC2LI_DESCRIBE_BLOCKS_PER_WG")) : 4;
+    const int reps = n_images >= 32 ? std::max(1, std::min(kRepsEnv, 16)) : 1;
+    const long per_xcd = ((nslot + 7) / 8 + 7) / 8;
+    TC2LI_LAUNCH(k_orient_describe, dim3((unsigned)(((per_xcd + reps - 1) / reps) * 8)), dim3(256), 0, st, raw, blurred, sc, kps, n_kp, first_image, n_images,
+                 kp_stride, angles, angles_dev, desc, mkeys, desc_dev, reps);
 }
 
 hipError_t upload_umax(const int* umax16) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int)); }
