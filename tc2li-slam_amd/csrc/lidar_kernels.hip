@@ -14,6 +14,9 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "lidar_device.hpp"
 #include "intro_sort.hpp"
 #include "lidar_device_fn.hpp"
@@ -870,7 +873,10 @@ void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSl
     TimeSortArrays A{key, ints5, ints5 + total, ints5 + 2 * total, ints5 + 3 * total, ints5 + 4 * total, ints3, ints3 + total, ints3 + 2 * total, flag};
     TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, ranges, n_ranges, depth_override);
     // ranges per scan: a 65 k scan leaves some tens to a few hundred; the workgroups of a scan take them in turn
-    TC2LI_LAUNCH(k_time_sort_lds, dim3(n_scans >= 64 ? 64 : 256, n_scans), dim3(kSortLdsThreads), 0, st, count, slots, A, perm, fallback, ranges, n_ranges);
+    // (a batch: 8 workgroups per scan, each a dozen ranges one after the other -- a workgroup holds 47 KB of LDS, and beside the other stages'
+    // kernels a launch pays for every workgroup it has placed: 64 per scan read 12-13 ms per 512 scans in the loop against 3.2 alone, 16: 7.3-7.8, 8: 5.8; the LiDAR-inertial stage alone 22.1 / 21.4 / 20.9 ms)
+    static const int kGroups = getenv("TC2LI_TIME_SORT_GROUPS") ? std::max(1, std::min(atoi(getenv("TC2LI_TIME_SORT_GROUPS")), 256)) : 8;
+    TC2LI_LAUNCH(k_time_sort_lds, dim3(n_scans >= 64 ? kGroups : 256, n_scans), dim3(kSortLdsThreads), 0, st, count, slots, A, perm, fallback, ranges, n_ranges);
 }
 void launch_undistort_batch(const PointXYZINormal* in, const int* perm, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                             const Pose6DDev* poses, const int* n_poses, const LidarStateDev* ends, PointXYZINormal* out, hipStream_t st) {
