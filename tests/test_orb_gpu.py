@@ -226,3 +226,43 @@ def test_chunked_batch_equals_single_image_calls(pkg, oracle, synthetic, n_image
         wu, wd, _ = oracle.stereo_match(ol, orr, kl, dl, kr, dr, bf, b)
         assert np.array_equal(u_right[f, :len(kl)], wu) and np.array_equal(depth[f, :len(kl)], wd)
     e.close(); single.close()
+
+
+def test_full_size_batch_forms_equal_single_image_calls(pkg, oracle, synthetic, monkeypatch):
+    """A batch of 34 KITTI-sized images takes the forms only batches use -- the pyramid's small levels in one launch (k_resize_tail), four FAST
+    cells and four descriptor blocks per workgroup, the keypoint distribution from per-class job lists (272 jobs) -- and gives, image by
+    image, what single-image calls give (one workgroup per unit, a launch per level and class); three images also against the oracle.  The
+    same batch with those forms switched off is identical too."""
+    import torch
+    base = synthetic.stereo_batch(4, seed=31)  # [4, 2, H, W]
+    h, w = base.shape[2:]
+    eight = base.reshape(8, h, w)
+    n = 34
+    imgs = np.empty((n, h, w), np.uint8)
+    for i in range(n):  # distinct images: the eight renderings, shifted by a few columns
+        imgs[i] = np.roll(eight[i % 8], 3 * (i // 8), axis=1)
+    dev = torch.from_numpy(imgs).cuda()
+    e = pkg.OrbExtractor(max_width=w, max_height=h, max_images=n)
+    kps, desc, counts, mono = e.extract_batch_dev(dev.data_ptr(), n, w, h, w, w * h)
+    kps, desc, counts, mono = kps.copy(), desc.copy(), counts.copy(), mono.copy()
+    single = pkg.OrbExtractor(max_width=w, max_height=h, max_images=1)
+    for i in range(n):
+        m, k, d = single.extract(imgs[i])
+        c = int(counts[i])
+        assert c == len(k) and int(mono[i]) == m, i
+        for f in FIELDS:
+            assert np.array_equal(kps[i, :c][f], k[f]), (i, f)
+        assert np.array_equal(desc[i, :c], d), i
+    o = oracle.OrbOracle()
+    for i in (0, 17, 33):
+        want = o.extract(imgs[i])
+        assert int(counts[i]) == len(want[1]) and np.array_equal(desc[i, :len(want[1])], want[2])
+        assert np.array_equal(e.candidates(i, 0), o.candidates(0)) and np.array_equal(e.candidates(i, 5), o.candidates(5))
+    e.close()
+    # the same batch in a process state where the batch forms are off (the launch-time switches are read per call or per process:
+    # the per-call one is the job lists; the others are covered by the single-image comparison above)
+    monkeypatch.setenv("TC2LI_QUADTREE_LISTS", "0")
+    e2 = pkg.OrbExtractor(max_width=w, max_height=h, max_images=n)
+    kps2, desc2, counts2, mono2 = e2.extract_batch_dev(dev.data_ptr(), n, w, h, w, w * h)
+    assert np.array_equal(counts2, counts) and np.array_equal(mono2, mono) and np.array_equal(desc2, desc)
+    e2.close()
