@@ -231,3 +231,18 @@ def test_scans_prepared_a_step_ahead_give_the_one_call_results(pkg, oracle, synt
             want = pkg.capi.map_incremental_batch(fe0, np.arange(S, dtype=np.int32), maps0, st24)
         assert all(np.array_equal(a, b) for a, b in zip(got, want))
         assert all(np.array_equal(a.points(), b.points()) for a, b in zip(maps, maps0))
+
+
+def test_a_batch_of_66_scans_takes_the_batch_forms_with_the_one_scan_results(pkg, oracle, synthetic):
+    """64 scans and more switch the front end to its batch forms -- Preprocess::process in one pass per scan (k_pre_stream), the time sort's
+    LDS stage with a few workgroups per scan that take the ranges in turn, the sorted voxel filter -- : every scan still gets the result of the
+    one-scan entry points, bit for bit."""
+    four = build_batch(pkg, oracle, synthetic, 4, seed0=11)
+    seqs = [four[i % 4] for i in range(66)]
+    fe, maps, (xs, Ps, stats, n_pre, n_down, last) = run_batch(pkg, seqs, max_iter=3)
+    ones = [run_one_by_one(pkg, q, max_iter=3)[2] for q in four]
+    for s in range(66):
+        one = ones[s % 4]
+        assert (n_pre[s], n_down[s]) == (one["n_pre"], one["n_down"]), s
+        assert same_stats(stats[s], one["st"]) and stats[s].res_mean_last == one["st"].res_mean_last, s
+        assert np.array_equal(xs[s], one["x"]) and np.array_equal(Ps[s], one["P"]) and np.array_equal(last[s], one["last"]), s
