@@ -12,6 +12,8 @@
 #pragma clang fp contract(off)
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "ba_math.hpp"
 #include "pose_inertial_device.hpp"
 
@@ -44,11 +46,65 @@ __device__ __forceinline__ double pi_visual(const ImuPose& T, const ImuCalib& ca
     return c2;
 }
 
+// LinearSolverDense's LDL^T and its two substitutions for the N x N system in LDS, by ONE wavefront with the matrix in registers: lane r
+// holds row r of the lower triangle, an entry of another row comes through v_readlane at compile-time (row, column) -- no LDS round trip and
+// no barrier per dependent step (the LDS form, one lane for the pivots and the substitutions, was 125 k + 115 k of an iteration's 290 k cycles
+// at N = 30: every step of its 4 x 435-step chains waited for an LDS read).  The operations and their order are those of the LDS form --
+// d_j = H_jj - sum_k (L_jk L_jk) D_k, L_ij = (H_ij - sum_k (L_ik L_jk) D_k) / D_j, k ascending; forward, division, backward substitution with
+// k ascending -- so the bits are the same.  Returns whether every pivot was positive (then x holds the solution), the same in every lane.
+__device__ __forceinline__ double pi_readlane(double v, int lane /* compile-time constant after unrolling */) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+template <int N>
+__device__ __forceinline__ bool pi_ldlt_solve_wave(const double* __restrict__ s_H, const double* __restrict__ s_b, double* __restrict__ s_x) {
+    const int lane = threadIdx.x & 63;
+    double row[N], D[N], y[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) row[k] = lane < N ? s_H[lane * N + k] : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= row[k] * pi_readlane(row[k], j) * D[k];
+        const double dj = pi_readlane(s, j);
+        D[j] = dj;
+        if (!(dj > 0.0) || !(dj - dj == 0.0)) ok = false;
+        row[j] = s / dj;  // lanes below j: L_ij (lane j and the lanes above it hold values nothing reads)
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = s_b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= pi_readlane(row[k], i) * y[k];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] /= D[i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= pi_readlane(row[i], k) * y[k];
+        y[i] = s;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s_x[i] = y[i];
+    }
+    return true;
+}
+
 __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__ probs, const double* __restrict__ Xw, const BaEdge* __restrict__ edges,
                                                    const uint8_t* __restrict__ close_flags, const ImuCalib& cal, const CameraD& cam, uint8_t* __restrict__ outlier,
                                                    double* __restrict__ chi2_scratch, PiResult* __restrict__ results) {
     __shared__ double s_red[4 * kPiRed], s_sum[kPiRed];
-    __shared__ double s_H[900], s_b[30], s_x[30], s_D[30], s_y[30];
+    __shared__ double s_H[900], s_b[30], s_x[30];
     __shared__ double s_J[216], s_T[216], s_e[9], s_Oe[9];        // inertial edge: J, Omega J, error, Omega error
     __shared__ double s_pJ[225], s_pT[225], s_pe[15], s_pOe[15];  // prior edge
     __shared__ double s_r1;                                        // Huber weight of the prior edge
@@ -209,33 +265,16 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
                 }
                 __syncthreads();
             }
-            // ---- LinearSolverDense: LDL^T, usable only when every pivot is positive ----
-            if (tid == 0) s_flag[0] = 1;
-            __syncthreads();
-            for (int j = 0; j < n; ++j) {
+            // ---- LinearSolverDense: LDL^T, usable only when every pivot is positive (pi_ldlt_solve_wave: wavefront 0, matrix in registers) ----
+            if (tid < 64) {
+                const bool pivots_ok = last ? pi_ldlt_solve_wave<30>(s_H, s_b, s_x) : pi_ldlt_solve_wave<15>(s_H, s_b, s_x);
                 if (tid == 0) {
-                    double d = s_H[j * n + j];
-                    for (int k = 0; k < j; ++k) d -= s_H[j * n + k] * s_H[j * n + k] * s_D[k];
-                    s_D[j] = d;
-                    if (!(d > 0.0) || !(d - d == 0.0)) s_flag[0] = 0;
+                    s_flag[0] = pivots_ok ? 1 : 0;
+                    if (!pivots_ok) s_flag[1] = 1;  // the increment of the previous iteration is applied once more and the round ends (GaussNewton::solve)
                 }
-                __syncthreads();
-                if (tid > j && tid < n) {
-                    double s = s_H[tid * n + j];
-                    for (int k = 0; k < j; ++k) s -= s_H[tid * n + k] * s_H[j * n + k] * s_D[k];
-                    s_H[tid * n + j] = s / s_D[j];
-                }
-                __syncthreads();
             }
+            __syncthreads();
             if (tid == 0) {
-                if (s_flag[0]) {
-                    for (int i = 0; i < n; ++i) { double s = s_b[i]; for (int k = 0; k < i; ++k) s -= s_H[i * n + k] * s_y[k]; s_y[i] = s; }
-                    for (int i = 0; i < n; ++i) s_y[i] /= s_D[i];
-                    for (int i = n - 1; i >= 0; --i) { double s = s_y[i]; for (int k = i + 1; k < n; ++k) s -= s_H[k * n + i] * s_y[k]; s_y[i] = s; }
-                    for (int i = 0; i < n; ++i) s_x[i] = s_y[i];
-                } else {
-                    s_flag[1] = 1;  // the increment of the previous iteration is applied once more and the round ends (GaussNewton::solve)
-                }
                 imu_pose_update(s_cur.P, cal, &s_x[0]);
                 for (int k = 0; k < 3; ++k) { s_cur.v[k] += s_x[6 + k]; s_cur.bg[k] += s_x[9 + k]; s_cur.ba[k] += s_x[12 + k]; }
                 if (last) {
@@ -341,7 +380,8 @@ __global__ __launch_bounds__(kPiThreads) __attribute__((amdgpu_waves_per_eu(2, 2
 void launch_pose_inertial(const PiProblem* probs, int n, const double* Xw, const BaEdge* edges, const uint8_t* close, const ImuCalib& cal,
                           const CameraD& cam, uint8_t* outlier, double* chi2_scratch, PiResult* results, hipStream_t st) {
     if (n <= 0) return;
-    if (n > 256) TC2LI_LAUNCH(k_pose_inertial_batch, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
+    static const bool kNoBatchForm = getenv("TC2LI_PI_BATCH_KERNEL") && atoi(getenv("TC2LI_PI_BATCH_KERNEL")) == 0;  // A/B
+    if (n > 256 && !kNoBatchForm) TC2LI_LAUNCH(k_pose_inertial_batch, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
     else TC2LI_LAUNCH(k_pose_inertial, dim3(n), dim3(kPiThreads), 0, st, probs, Xw, edges, close, cal, cam, outlier, chi2_scratch, results);
 }
 
