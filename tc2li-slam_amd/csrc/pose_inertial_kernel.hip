@@ -16,6 +16,7 @@
 
 #include "ba_math.hpp"
 #include "pose_inertial_device.hpp"
+#include "wave_reduce.hpp"
 
 namespace tc2li {
 
@@ -24,12 +25,10 @@ constexpr int kPiRed = 28;  // 21 upper-triangular H entries + 6 b entries + one
 
 __device__ __forceinline__ void pi_block_reduce(double (&v)[kPiRed], double* s_red /*[4][kPiRed]*/, double* s_out /*[kPiRed]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kPiRed; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-        if (lane == 0) s_red[wave * kPiRed + k] = x;
+    {   // (wave_reduce.hpp: the xor butterfly's sums with a sixth of its shuffles)
+        const double x = wave_reduce_32(v);
+        const int k = wave_reduce_index(lane);
+        if ((lane & 1) == 0 && k < kPiRed) s_red[wave * kPiRed + k] = x;
     }
     __syncthreads();
     if (threadIdx.x < kPiRed) s_out[threadIdx.x] = (s_red[threadIdx.x] + s_red[kPiRed + threadIdx.x]) + (s_red[2 * kPiRed + threadIdx.x] + s_red[3 * kPiRed + threadIdx.x]);

@@ -14,6 +14,7 @@
 
 #include "ba_math.hpp"
 #include "pose_opt_device.hpp"
+#include "wave_reduce.hpp"
 
 namespace tc2li {
 
@@ -22,12 +23,10 @@ constexpr int kRed = 28;  // 21 upper-triangular H entries + 6 b entries + chi
 
 __device__ __forceinline__ void block_reduce(double (&v)[kRed], double* s_red /*[4][kRed]*/, double* s_out /*[kRed]*/) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kRed; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-        if (lane == 0) s_red[wave * kRed + k] = x;
+    {   // the wavefront's sums: the xor butterfly's, a lane keeping only the values it answers for (wave_reduce.hpp: same bits, a sixth of the shuffles)
+        const double x = wave_reduce_32(v);
+        const int k = wave_reduce_index(lane);
+        if ((lane & 1) == 0 && k < kRed) s_red[wave * kRed + k] = x;
     }
     __syncthreads();
     if (threadIdx.x < kRed) s_out[threadIdx.x] = (s_red[threadIdx.x] + s_red[kRed + threadIdx.x]) + (s_red[2 * kRed + threadIdx.x] + s_red[3 * kRed + threadIdx.x]);
