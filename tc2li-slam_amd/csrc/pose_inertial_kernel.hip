@@ -61,36 +61,45 @@ __device__ __forceinline__ double pi_readlane(double v, int lane /* compile-time
 template <int N>
 __device__ __forceinline__ bool pi_ldlt_solve_wave(const double* __restrict__ s_H, const double* __restrict__ s_b, double* __restrict__ s_x) {
     const int lane = threadIdx.x & 63;
-    double row[N], D[N], y[N];
+    double row[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) row[k] = lane < N ? s_H[lane * N + k] : 0.0;
+    // Factorisation, right-looking: after column k has its pivot and its entries L_ik = a_ik / D_k, every remaining entry (i, j), j > k, takes
+    // its term of column k -- a_ij -= (L_ik L_jk) D_k -- so an entry collects its terms for k = 0, 1, ... in the order the row-by-row sums of
+    // the LDS form took them (same operands, same order: same bits), but the (N - 1 - k) updates of a step are independent instructions.
     bool ok = true;
+    double my_d = 1.0;  // lane i: D_i
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double s = row[j];
+    for (int k = 0; k < N; ++k) {
+        const double dk = pi_readlane(row[k], k);
+        if (!(dk > 0.0) || !(dk - dk == 0.0)) ok = false;
+        if (lane == k) my_d = dk;
+        row[k] = row[k] / dk;  // lanes above k: L_ik
 #pragma unroll
-        for (int k = 0; k < j; ++k) s -= row[k] * pi_readlane(row[k], j) * D[k];
-        const double dj = pi_readlane(s, j);
-        D[j] = dj;
-        if (!(dj > 0.0) || !(dj - dj == 0.0)) ok = false;
-        row[j] = s / dj;  // lanes below j: L_ij (lane j and the lanes above it hold values nothing reads)
+        for (int j = k + 1; j < N; ++j) row[j] -= row[k] * pi_readlane(row[k], j) * dk;  // (lanes below j update entries nothing reads)
     }
     if (!ok) return false;
+    // Forward substitution, column by column over all rows at once: z_k is final when the columns before k have been applied; row i then
+    // takes its term L_ik z_k -- k ascending, as the row-by-row sum did.  Then the division by D.
+    double z = lane < N ? s_b[lane] : 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        double s = s_b[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) s -= pi_readlane(row[k], i) * y[k];
-        y[i] = s;
+    for (int k = 0; k < N; ++k) {
+        const double zk = pi_readlane(z, k);
+        if (lane > k) z -= row[k] * zk;
     }
+    const double y_mine = z / my_d;
+    // Backward substitution: x_i = y_i - sum_{k > i} L_ki x_k with k ASCENDING (the order of the LDS form): the first term of row i needs
+    // x_{i + 1}, the last one to become known, so the rows cannot run side by side -- a chain of N (N - 1) / 2 steps, here on values every
+    // lane computes alike (L_ki through v_readlane at compile-time indices).
+    double y[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) y[i] /= D[i];
+    for (int i = 0; i < N; ++i) y[i] = pi_readlane(y_mine, i);
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        double s = y[i];
+        double sx = y[i];
 #pragma unroll
-        for (int k = i + 1; k < N; ++k) s -= pi_readlane(row[i], k) * y[k];
-        y[i] = s;
+        for (int k = i + 1; k < N; ++k) sx -= pi_readlane(row[i], k) * y[k];
+        y[i] = sx;
     }
     if (lane == 0) {
 #pragma unroll
@@ -273,13 +282,14 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                imu_pose_update(s_cur.P, cal, &s_x[0]);
-                for (int k = 0; k < 3; ++k) { s_cur.v[k] += s_x[6 + k]; s_cur.bg[k] += s_x[9 + k]; s_cur.ba[k] += s_x[12 + k]; }
-                if (last) {
-                    imu_pose_update(s_oth.P, cal, &s_x[15]);
-                    for (int k = 0; k < 3; ++k) { s_oth.v[k] += s_x[21 + k]; s_oth.bg[k] += s_x[24 + k]; s_oth.ba[k] += s_x[27 + k]; }
-                }
+            if (tid == 0 || (last && tid == 64)) {  // the two states by two wavefronts at the same time, each on a private copy (not through LDS references)
+                const int o = tid == 0 ? 0 : 15;
+                PiState st = tid == 0 ? s_cur : s_oth;
+                double x15[15];
+                for (int k = 0; k < 15; ++k) x15[k] = s_x[o + k];
+                imu_pose_update(st.P, cal, x15);
+                for (int k = 0; k < 3; ++k) { st.v[k] += x15[6 + k]; st.bg[k] += x15[9 + k]; st.ba[k] += x15[12 + k]; }
+                if (tid == 0) s_cur = st; else s_oth = st;
             }
             __syncthreads();
             ok = s_flag[0] != 0;
