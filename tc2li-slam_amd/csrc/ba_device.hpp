@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "ba_math.hpp"
+#include "global_ptr.hpp"
 #include "balm_device.hpp"
 #include "inertial_math.hpp"
 
@@ -154,6 +155,17 @@ __device__ __forceinline__ T load_uniform(const T* p) {
     T out;
     __builtin_memcpy(&out, w, sizeof(T));
     return out;
+}
+// the slot record's pointers as global pointers (global_ptr.hpp)
+__device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb) {
+#define TC2LI_G(f) pb.f = global_ptr(pb.f)
+    TC2LI_G(poses); TC2LI_G(poses_trial); TC2LI_G(iposes); TC2LI_G(iposes_trial); TC2LI_G(points); TC2LI_G(points_trial); TC2LI_G(edges);
+    TC2LI_G(pose_var); TC2LI_G(pt_off); TC2LI_G(pt_edges); TC2LI_G(pv_off); TC2LI_G(pv_edges); TC2LI_G(grp_k0); TC2LI_G(grp_l0);
+    TC2LI_G(fl_off); TC2LI_G(fl_pose); TC2LI_G(w_slot); TC2LI_G(fl_lm); TC2LI_G(fl_place); TC2LI_G(slice_off); TC2LI_G(fl_edge);
+    TC2LI_G(chi2); TC2LI_G(rho0); TC2LI_G(cp_part); TC2LI_G(W); TC2LI_G(blk_off); TC2LI_G(blk_rows);
+    TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(AT); TC2LI_G(BT);
+    TC2LI_G(S_part); TC2LI_G(scale_part); TC2LI_G(chi_part);
+#undef TC2LI_G
 }
 // the phase's window number / flags at position `pos` as scalars: sub-dword loads from the argument block at a dynamic index are vector
 // loads, and everything addressed through their result would be fetched per lane (readfirstlane: the value is the same in every lane)

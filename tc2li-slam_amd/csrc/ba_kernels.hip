@@ -978,13 +978,14 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
     lam.i[0] = __builtin_amdgcn_readfirstlane(lam.i[0]);
     lam.i[1] = __builtin_amdgcn_readfirstlane(lam.i[1]);
     const BaBatchSlot& sl = ph.table[win];
-    BaSlotView v{sl, load_uniform(&sl.pb), lam.d, flags, load_uniform(&sl.xp)};
+    BaSlotView v{sl, load_uniform(&sl.pb), lam.d, flags, global_ptr(load_uniform(&sl.xp))};
+    ba_problem_pointers_are_global(v.pb);
     if (v.flags & kBaAcceptedInTrial) {
         Se3* const p = v.pb.poses; v.pb.poses = v.pb.poses_trial; v.pb.poses_trial = p;
         ImuPose* const q = v.pb.iposes; v.pb.iposes = v.pb.iposes_trial; v.pb.iposes_trial = q;
         double* const x = v.pb.points; v.pb.points = v.pb.points_trial; v.pb.points_trial = x;
     }
-    if (ph.xp_area && 6 * v.pb.n_free <= kBaXpStride) v.xp = ph.xp_area + (size_t)(ph.first + pos) * kBaXpStride;
+    if (ph.xp_area && 6 * v.pb.n_free <= kBaXpStride) v.xp = global_ptr(ph.xp_area) + (size_t)(ph.first + pos) * kBaXpStride;
     return v;
 }
 #define TC2LI_SLOT(axis) const BaSlotView view_ = ba_slot_view(ph, blockIdx.axis); const BaBatchSlot& sl = view_.sl; (void)sl; const BaProblemDev& pb = view_.pb

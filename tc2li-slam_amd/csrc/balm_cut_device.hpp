@@ -5,6 +5,8 @@
 
 #include "balm_math.hpp"
 
+#include "global_ptr.hpp"
+
 namespace tc2li {
 
 constexpr int kBalmCutMaxW = 7;           // keyframes of a window the batched LiDAR kernels take (ba_host.cpp); 8 lanes work on a cell
@@ -38,6 +40,19 @@ struct BalmCutTask {
     PlaneCluster* clusters;          // [n_planes][W]
     double* coe;                     // [n_planes]
 };
+
+#if defined(__HIPCC__)
+// a kernel's private copy of the record with its pointers marked global (global_ptr.hpp); only the fields a kernel uses are loaded
+__device__ __forceinline__ BalmCutTask global_record(BalmCutTask t) {
+    TC2LI_GLOBAL_FIELD(t, cloud); TC2LI_GLOBAL_FIELD(t, table_key); TC2LI_GLOBAL_FIELD(t, table_first); TC2LI_GLOBAL_FIELD(t, table_id);
+    TC2LI_GLOBAL_FIELD(t, world); TC2LI_GLOBAL_FIELD(t, oct); TC2LI_GLOBAL_FIELD(t, point_slot); TC2LI_GLOBAL_FIELD(t, sort_key_a);
+    TC2LI_GLOBAL_FIELD(t, sort_key_b); TC2LI_GLOBAL_FIELD(t, sort_val_a); TC2LI_GLOBAL_FIELD(t, sort_val_b); TC2LI_GLOBAL_FIELD(t, order);
+    TC2LI_GLOBAL_FIELD(t, cell_begin); TC2LI_GLOBAL_FIELD(t, cell_key); TC2LI_GLOBAL_FIELD(t, cell_flag); TC2LI_GLOBAL_FIELD(t, n_cells);
+    TC2LI_GLOBAL_FIELD(t, plane_cell); TC2LI_GLOBAL_FIELD(t, state); TC2LI_GLOBAL_FIELD(t, result_host); TC2LI_GLOBAL_FIELD(t, clusters);
+    TC2LI_GLOBAL_FIELD(t, coe);
+    return t;
+}
+#endif
 
 // queues the extraction of `n_tasks` windows (tasks in device memory; max_points / max_table over them)
 void launch_balm_cut(const BalmCutTask* tasks, int n_tasks, int max_points, int max_table, hipStream_t st);

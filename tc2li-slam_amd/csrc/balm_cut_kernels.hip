@@ -46,7 +46,7 @@ __device__ __forceinline__ void cut_slot_run(const int* __restrict__ order, int 
 
 // ---- pass 0: empty tables ----
 __global__ __launch_bounds__(256) void k_balm_cut_init(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.y];
+    const BalmCutTask T = global_record(tasks[blockIdx.y]);
     const int cap = 1 << T.table_bits;
     for (int h = blockIdx.x * 256 + threadIdx.x; h < cap; h += gridDim.x * 256) { T.table_key[h] = 0ull; T.table_first[h] = INT_MAX; }
     if (blockIdx.x == 0 && threadIdx.x < 4) T.state[threadIdx.x] = 0;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_balm_cut_init(const BalmCutTask* __rest
 
 // ---- pass 1: every point into the common frame; its root key into the window's hash table (smallest point index per key) ----
 __global__ __launch_bounds__(256) void k_balm_cut_points(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.y];
+    const BalmCutTask T = global_record(tasks[blockIdx.y]);
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= T.n_points) return;
     int slot = 0;
@@ -62,13 +62,13 @@ __global__ __launch_bounds__(256) void k_balm_cut_points(const BalmCutTask* __re
     for (int i = 1; i < kBalmCutMaxW; ++i) slot += (i < T.W && j >= T.cloud_off[i]) ? 1 : 0;
     const double local[3] = {(double)T.cloud[3 * (size_t)j], (double)T.cloud[3 * (size_t)j + 1], (double)T.cloud[3 * (size_t)j + 2]};
     double Rx[3], w[3];
-    m3_vec(T.rel[slot].R, local, Rx);
+    m3_vec(tasks[blockIdx.y].rel[slot].R, local, Rx);  // (indexed per lane: from the record in memory, not from the private copy)
     long long kk[3];
     bool in_range = true;
     int o1 = 0, o2 = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        w[k] = Rx[k] + T.rel[slot].p[k];
+        w[k] = Rx[k] + tasks[blockIdx.y].rel[slot].p[k];
         float loc = (float)(w[k] / 1.0);  // voxel_size 1 (bavoxel.cc:50-55)
         if (loc < 0) loc -= 1.0f;
         const bool ok = loc > -1.0e6f && loc < 1.0e6f;  // (false for a NaN too)
@@ -149,7 +149,7 @@ __device__ void cut_radix_sort(unsigned int*& key_a, int*& val_a, unsigned int*&
 }
 
 __global__ __launch_bounds__(kCutThreads) void k_balm_cut_sort(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.x];
+    const BalmCutTask T = global_record(tasks[blockIdx.x]);
     __shared__ unsigned short s_cnt[16 * kCutThreads];
     __shared__ int s_wave[kCutThreads / 64];
     __shared__ int s_n;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kCutThreads) void k_balm_cut_sort(const BalmCutTask
 // Eight lanes per cell, lane i the statistics of keyframe i in the common frame (a sequential sum over the keyframe's run inside the
 // cell); the first lane adds them in keyframe order, forms the covariance and its eigenvalues.
 __global__ __launch_bounds__(256) void k_balm_cut_judge(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.y];
+    const BalmCutTask T = global_record(tasks[blockIdx.y]);
     if (T.state[1]) return;
     const int layer = blockIdx.z, n = T.n_points, W = T.W, n_cells = T.n_cells[layer];
     const int slot = threadIdx.x & 7, first = (threadIdx.x & 63) & ~7;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_balm_cut_judge(const BalmCutTask* __res
         double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (slot < W) {
             int lo, hi;
-            cut_slot_run(order, b, e, T.cloud_off[slot], T.cloud_off[slot + 1], lo, hi);
+            cut_slot_run(order, b, e, tasks[blockIdx.y].cloud_off[slot], tasks[blockIdx.y].cloud_off[slot + 1], lo, hi);  // (indexed per lane: from the record in memory)
             for (int a = lo; a < hi; ++a) {
                 const double* x = T.world + 3 * (size_t)order[a];
                 const double x0 = x[0], x1 = x[1], x2 = x[2];
@@ -298,7 +298,7 @@ __device__ __forceinline__ int cut_walk_root(const BalmCutTask& T, int r, Emit&&
     return count;
 }
 __global__ __launch_bounds__(kCutThreads) void k_balm_cut_walk(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.x];
+    const BalmCutTask T = global_record(tasks[blockIdx.x]);
     __shared__ int s_wave[kCutThreads / 64];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kCutThreads) void k_balm_cut_walk(const BalmCutTask
 
 // ---- pass 5: the planes' clusters: per (plane, keyframe) the points of the cell's run of that keyframe in the keyframe's OWN frame ----
 __global__ __launch_bounds__(256) void k_balm_cut_clusters(const BalmCutTask* __restrict__ tasks) {
-    const BalmCutTask& T = tasks[blockIdx.y];
+    const BalmCutTask T = global_record(tasks[blockIdx.y]);
     if (T.state[1]) return;
     const int t = blockIdx.x * 256 + threadIdx.x, W = T.W, n = T.n_points;
     const int p = t / W, slot = t - p * W;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_balm_cut_clusters(const BalmCutTask* __
     const int* order = T.order + (size_t)layer * n;
     const int b = cell_begin[c], e = cell_begin[c + 1];
     int lo, hi;
-    cut_slot_run(order, b, e, T.cloud_off[slot], T.cloud_off[slot + 1], lo, hi);
+    cut_slot_run(order, b, e, tasks[blockIdx.y].cloud_off[slot], tasks[blockIdx.y].cloud_off[slot + 1], lo, hi);  // (indexed per lane: from the record in memory)
     PlaneCluster pcl;
 #pragma unroll
     for (int k = 0; k < 6; ++k) pcl.P[k] = 0;

@@ -336,6 +336,10 @@ __device__ __forceinline__ BalmSlotView balm_slot_view(const BaPhase& ph, int po
     v.b = load_uniform(&sl->balm);  // (scalar loads: the record lives in SGPRs, not in every lane's registers)
     if (load_uniform(&sl->pb.inertial)) v.poses = reinterpret_cast<const Se3*>(second ? load_uniform(&sl->pb.iposes_trial) : load_uniform(&sl->pb.iposes));
     else v.poses = second ? load_uniform(&sl->pb.poses_trial) : load_uniform(&sl->pb.poses);
+    // pointers out of a record are built from integers: global, not flat, accesses through them (ba_device.hpp: global_ptr)
+    v.poses = global_ptr(v.poses);
+    v.b.clusters = global_ptr(v.b.clusters); v.b.coe = global_ptr(v.b.coe); v.b.pose_index = global_ptr(v.b.pose_index); v.b.twl = global_ptr(v.b.twl);
+    v.b.plane_res = global_ptr(v.b.plane_res); v.b.eig = global_ptr(v.b.eig); v.b.part = global_ptr(v.b.part); v.b.out = global_ptr(v.b.out);
     return v;
 }
 __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph, int trial) {

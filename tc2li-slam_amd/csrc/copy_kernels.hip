@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "global_ptr.hpp"
 #include "launch.hpp"
 
 namespace tc2li {
@@ -26,8 +27,8 @@ __global__ __launch_bounds__(256) void k_copy_tasks(const CopyTask* __restrict__
         __syncthreads();
         for (int t = 0; t < m; ++t) {
             const CopyTask T = s_tasks[t];
-            uint8_t* dst = static_cast<uint8_t*>(T.dst);
-            const uint8_t* src = static_cast<const uint8_t*>(T.src);
+            uint8_t* dst = global_ptr(static_cast<uint8_t*>(T.dst));  // device or pinned host memory: global, not flat, accesses
+            const uint8_t* src = global_ptr(static_cast<const uint8_t*>(T.src));
             const bool wide = ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
             if (wide) {
                 const size_t n16 = T.bytes / 16, per = (n16 + G - 1) / G, lo = (size_t)b * per, hi = min(n16, lo + per);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "global_ptr.hpp"
+
 namespace tc2li {
 
 struct VelodynePoint {  // velodyne_ros::Point (SF/include/lidar_front_end/preprocess.h:62-70), 32 bytes
@@ -152,6 +154,31 @@ struct MapInsTask {
     int* out;                      // [4]: [0] rows that receive points [1] 1: the grid could not take the points (outside the box, a row without room, ...) [2] tombstones the rewritten rows dropped
     int first, count;
 };
+#if defined(__HIPCC__)
+// a kernel's private copy of a record with its pointers marked global (global_ptr.hpp); only the fields a kernel uses are loaded
+__device__ __forceinline__ MapGrid global_record(MapGrid g) {
+    TC2LI_GLOBAL_FIELD(g, points); TC2LI_GLOBAL_FIELD(g, pts); TC2LI_GLOBAL_FIELD(g, bucket_start);
+    return g;
+}
+__device__ __forceinline__ MapIncTask global_record(MapIncTask t) {
+    TC2LI_GLOBAL_FIELD(t, body); TC2LI_GLOBAL_FIELD(t, nearest_idx); TC2LI_GLOBAL_FIELD(t, nfound); TC2LI_GLOBAL_FIELD(t, world); TC2LI_GLOBAL_FIELD(t, cls);
+    TC2LI_GLOBAL_FIELD(t, recs); TC2LI_GLOBAL_FIELD(t, group_start); TC2LI_GLOBAL_FIELD(t, noneed); TC2LI_GLOBAL_FIELD(t, appended);
+    TC2LI_GLOBAL_FIELD(t, has_append); TC2LI_GLOBAL_FIELD(t, out); t.grid = global_record(t.grid); TC2LI_GLOBAL_FIELD(t, deleted);
+    TC2LI_GLOBAL_FIELD(t, keep_counts); TC2LI_GLOBAL_FIELD(t, dst); TC2LI_GLOBAL_FIELD(t, holes); TC2LI_GLOBAL_FIELD(t, batch_overflow);
+    TC2LI_GLOBAL_FIELD(t, remap); TC2LI_GLOBAL_FIELD(t, boxes);
+    return t;
+}
+__device__ __forceinline__ MapGridTask global_record(MapGridTask t) {
+    t.g = global_record(t.g); TC2LI_GLOBAL_FIELD(t, counts); TC2LI_GLOBAL_FIELD(t, start); TC2LI_GLOBAL_FIELD(t, row_start); TC2LI_GLOBAL_FIELD(t, sorted);
+    TC2LI_GLOBAL_FIELD(t, tile_sums); TC2LI_GLOBAL_FIELD(t, old_sorted); TC2LI_GLOBAL_FIELD(t, remap);
+    return t;
+}
+__device__ __forceinline__ MapInsTask global_record(MapInsTask t) {
+    t.g = global_record(t.g); TC2LI_GLOBAL_FIELD(t, pts); TC2LI_GLOBAL_FIELD(t, row_start); TC2LI_GLOBAL_FIELD(t, keys); TC2LI_GLOBAL_FIELD(t, row_list);
+    TC2LI_GLOBAL_FIELD(t, out);
+    return t;
+}
+#endif
 void launch_map_insert(const MapInsTask* tasks, int n_tasks, hipStream_t st);
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);

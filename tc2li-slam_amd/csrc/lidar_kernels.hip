@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_knn_plane(const MapGrid* __restrict__ g
     const int n = count[b.scan];
     const int i = b.start + blockIdx.y * 64 + (threadIdx.x >> 2), l = threadIdx.x & 3;
     if (i >= n) return;  // whole quads leave together
-    const MapGrid grid = grids[b.scan];
+    const MapGrid grid = global_record(grids[b.scan]);
     const PointXYZINormal pb = body[sl.base + i];
     const PointXYZINormal pw = body_to_world(pb, states[b.scan]);
     if (l == 0) world[sl.base + i] = pw;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void k_knn_hard(const MapGrid* __restrict__ gr
     for (int h = wave; h < total; h += n_waves) {
         const int2 q = hard_list[h];
         const ScanSlot sl = slots[q.x];
-        const MapGrid grid = grids[q.x];
+        const MapGrid grid = global_record(grids[q.x]);
         const PointXYZINormal pb = body[sl.base + q.y];
         const PointXYZINormal pw = body_to_world(pb, states[q.x]);
         const int cx = (int)floorf(pw.x * grid.inv_cell), cy = (int)floorf(pw.y * grid.inv_cell), cz = (int)floorf(pw.z * grid.inv_cell);

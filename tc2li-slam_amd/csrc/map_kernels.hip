@@ -18,7 +18,7 @@ namespace tc2li {
 // ---- map_incremental: insertion class of every down-sampled scan point -----------------------------------------------------------
 // 0 = not added, 1 = PointToAdd (down-sampled insertion), 2 = PointNoNeedDownsample; world coordinates at the (possibly updated) state.
 __global__ __launch_bounds__(256) void k_mapinc_classify(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= T.n) return;
     const double fs = T.fs;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_mapinc_classify(const MapIncTask* __res
 // are consecutive and keep their order; group starts are flagged.  The PointNoNeedDownsample list is compacted in order.
 // counts: [0] n_add [1] n_groups [2] n_noneed [3] overflow
 __global__ __launch_bounds__(1024) void k_mapinc_group(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.x];
+    const MapIncTask T = global_record(tasks[blockIdx.x]);
     extern __shared__ unsigned long long s_key[];  // kMapIncMax keys, then kMapIncMax indices
     int* s_idx = reinterpret_cast<int*>(s_key + kMapIncMax);
     __shared__ int s_wave[16], s_base[3];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_mapinc_group(const MapIncTask* __restr
 // the content by the point closest to the voxel centre among content + p whenever the content has more than one point or
 // p itself is that closest point.
 __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     const int g = blockIdx.x * 128 + threadIdx.x;
     if (g >= T.out[1]) return;
     if (*T.batch_overflow) return;  // a failing batch marks nothing (k_mapinc_group has raised the word: no map is touched)
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
 
 // deleted[i] = 1 for every map point inside one of the boxes [min, max) (KD_TREE::Delete_Point_Boxes)
 __global__ __launch_bounds__(256) void k_map_mark_boxes(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= T.n_map) return;
     const PointXYZINormal p = T.grid.points[i];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_map_mark_boxes(const MapIncTask* __rest
 // workgroup per map), the hole / filler lists + the old -> new index map, the moves; then the appended voxel representatives (group
 // order) and the PointNoNeedDownsample points (scan order) follow from K on -------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     if ((int)blockIdx.x >= T.keep_blocks) return;
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const int c = __syncthreads_count(i < T.n_map && !T.deleted[i]);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __res
 }
 // out: [4] kept [5] appended [6..11] bounding box of what is added (encoded floats), initialised here
 __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.x];
+    const MapIncTask T = global_record(tasks[blockIdx.x]);
     __shared__ int s_part[1024];
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, nblocks = T.keep_blocks;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __rest
     if (tid == 0) T.out[12] = (bK < nblocks ? T.keep_counts[bK] : K) + c;
 }
 __global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     if ((int)blockIdx.x >= T.keep_blocks) return;
     if (*T.batch_overflow) return;  // nothing is touched when the batch fails (the flags are reset by the host's next call)
     __shared__ int s_wave[16];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict
     if (keep && i >= K) T.holes[T.n_map + (kp - kpK)] = i;
 }
 __global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.y];
+    const MapIncTask T = global_record(tasks[blockIdx.y]);
     if (*T.batch_overflow) return;
     const int H = T.out[4] - T.out[12];
     PointXYZINormal* pts = T.dst;
@@ -330,7 +330,7 @@ __device__ __forceinline__ void wave_bbox(int* bbox_enc, const PointXYZINormal& 
 }
 
 __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
-    const MapIncTask& T = tasks[blockIdx.x];
+    const MapIncTask T = global_record(tasks[blockIdx.x]);
     if (!T.has_inc || *T.batch_overflow) return;
     __shared__ int s_wave[4];
     __shared__ int s_base;
@@ -394,7 +394,7 @@ __device__ __forceinline__ int map_build_item(const MapGridTask& T, int u, float
     return map_cell(T.g, p.x, p.y, p.z);
 }
 __global__ __launch_bounds__(256) void k_map_count(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
+    const MapGridTask T = global_record(tasks[blockIdx.y]);
     const int u = blockIdx.x * 256 + threadIdx.x;
     if ((int)(blockIdx.x * 256) >= T.n_old + (T.g.n_points - T.n_kept)) return;  // whole workgroup
     float4 q;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_map_count(const MapGridTask* __restrict
 }
 // level 1: sums of tiles of 4096 consecutive cells (coalesced int4 loads)
 __global__ __launch_bounds__(1024) void k_map_scan_tiles(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
+    const MapGridTask T = global_record(tasks[blockIdx.y]);
     const int tile = blockIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
     if (tile >= n_tiles) return;
     __shared__ int s_wave[16];
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_map_scan_tiles(const MapGridTask* __re
 }
 // level 2: exclusive scan of the tile sums (<= 1024 tiles = 4 M cells), one workgroup per map
 __global__ __launch_bounds__(1024) void k_map_scan_tops(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.x];
+    const MapGridTask T = global_record(tasks[blockIdx.x]);
     __shared__ int s_part[1024];
     const int tid = threadIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
     const int v = tid < n_tiles ? T.tile_sums[tid] : 0;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void k_map_scan_tops(const MapGridTask* __res
 }
 // level 3: exclusive scan inside every tile + the tile's offset
 __global__ __launch_bounds__(1024) void k_map_scan_cells(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
+    const MapGridTask T = global_record(tasks[blockIdx.y]);
     const int tile = blockIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
     if (tile >= n_tiles) return;
     __shared__ int s_wave[16];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(1024) void k_map_scan_cells(const MapGridTask* __re
     }
 }
 __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
+    const MapGridTask T = global_record(tasks[blockIdx.y]);
     const int u = blockIdx.x * 256 + threadIdx.x;
     if ((int)(blockIdx.x * 256) >= T.n_old + (T.g.n_points - T.n_kept)) return;  // whole workgroup
     float4 q;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_map_scatter(const MapGridTask* __restri
 // (cells beyond the row's last: the end of the segment's entries); entry 16 of a segment = the end of its entries, the last entry of
 // the array (segment = number of segments, j = 0) = n_slots.
 __global__ __launch_bounds__(256) void k_map_row_starts(const MapGridTask* __restrict__ tasks) {
-    const MapGridTask& T = tasks[blockIdx.y];
+    const MapGridTask T = global_record(tasks[blockIdx.y]);
     const int nseg = T.g.ny * T.g.nz * T.g.nsx;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx > nseg * kMapSegStride) return;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void k_map_row_starts(const MapGridTask* __res
 // 13 GB of traffic per step of 512 maps to add 40 MB of points.)
 // One workgroup per map: (cell, point) keys of the added points, sorted; the rows that receive points.
 __global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restrict__ tasks) {
-    const MapInsTask& T = tasks[blockIdx.x];
+    const MapInsTask T = global_record(tasks[blockIdx.x]);
     extern __shared__ unsigned long long s_keys[];  // kMapInsMax
     __shared__ int s_wave[16], s_base, s_bad;
     const int tid = threadIdx.x, n = T.count;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(1024) void k_map_ins_sort(const MapInsTask* __restr
 // that map's grid (segments written before stay valid or not -- the rebuild starts from the points).  A segment is some tens of entries:
 // a 256-thread workgroup per segment spent its time in barriers (1.6 ms per 512 maps; this form: see DESIGN.md).
 __global__ __launch_bounds__(64) void k_map_ins_rows(const MapInsTask* __restrict__ tasks) {
-    const MapInsTask& T = tasks[blockIdx.y];
+    const MapInsTask T = global_record(tasks[blockIdx.y]);
     __shared__ float4 s_ent[kMapRowMax];
     __shared__ int s_rank[kMapRowMax + 1];
     __shared__ int s_cs[kMapSegStride + 1];

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "global_ptr.hpp"
 #include "orb_device.hpp"  // MatchKey
 
 namespace tc2li {
@@ -27,6 +28,13 @@ struct MatchFrameDev {
     int32_t n_keys, n_queries, query_off, pad_;
     float min_x, max_x, min_y, max_y;
 };
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ MatchFrameDev global_record(MatchFrameDev f) {  // global_ptr.hpp
+    TC2LI_GLOBAL_FIELD(f, keys); TC2LI_GLOBAL_FIELD(f, desc); TC2LI_GLOBAL_FIELD(f, u_right); TC2LI_GLOBAL_FIELD(f, occupied); TC2LI_GLOBAL_FIELD(f, queries);
+    return f;
+}
+#endif
 
 // the three-launch form (grid, candidate lists, rounds over the lists); the tables live in the caller's workspace.  When
 // pool_top[1] comes back non-zero the candidate pool was too small and launch_match_by_projection has to be used instead.

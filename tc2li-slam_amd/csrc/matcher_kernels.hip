@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kThreads) void k_match_by_projection(const MatchFra
     __shared__ uint8_t s_oct[kMaxMatchKeys], s_occ[kMaxMatchKeys];
     __shared__ int s_claim[2][kMaxMatchKeys];
     __shared__ int s_tmp[64];
-    const MatchFrameDev fr = frames[blockIdx.x];
+    const MatchFrameDev fr = global_record(frames[blockIdx.x]);
     const int tid = threadIdx.x, N = fr.n_keys, M = fr.n_queries;
     const float invW = (float)kGridCols / (fr.max_x - fr.min_x), invH = (float)kGridRows / (fr.max_y - fr.min_y);
     int32_t* out = match_of_query + fr.query_off;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_match_grid(const MatchFrameDev* __
     __shared__ int s_cursor[kCells];
     __shared__ int s_cell_of[kMaxMatchKeys];
     __shared__ uint16_t s_items[kMaxMatchKeys];
-    const MatchFrameDev fr = frames[blockIdx.x];
+    const MatchFrameDev fr = global_record(frames[blockIdx.x]);
     const int tid = threadIdx.x, N = fr.n_keys;
     const float invW = (float)kGridCols / (fr.max_x - fr.min_x), invH = (float)kGridRows / (fr.max_y - fr.min_y);
     for (int c = tid; c <= kCells; c += kThreads) s_cell_start[c] = 0;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_match_candidates(const MatchFrameDev* _
     if (g >= total_q) return;
     const int f = query_frame[g];
     if (f < 0) { L.cand_cnt[g] = 0; L.cand_off[g] = 0; return; }
-    const MatchFrameDev fr = frames[f];
+    const MatchFrameDev fr = global_record(frames[f]);
     const MatchQuery Q = fr.queries[g - fr.query_off];
     const int flags = Q.has_observations ? (1 << 30) : 0;
     if (!Q.valid || fr.n_keys == 0) { L.cand_cnt[g] = flags; L.cand_off[g] = 0; return; }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void k_match_resolve(const MatchFrameDev*
                                                            int32_t* __restrict__ match_of_query, int32_t* __restrict__ prev_claim,
                                                            int32_t* __restrict__ rounds_out) {
     __shared__ int s_claim[2][kMaxMatchKeys];
-    const MatchFrameDev fr = frames[blockIdx.x];
+    const MatchFrameDev fr = global_record(frames[blockIdx.x]);
     const int tid = threadIdx.x, N = fr.n_keys, M = fr.n_queries;
     int32_t* out = match_of_query + fr.query_off;
     int32_t* prev = prev_claim + fr.query_off;
