@@ -1363,12 +1363,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     }
     // the steps of a trial phase: window k of `step` at h_xp_area + k * kXpStride, up through a one-entry k_copy_tasks launch on the group's
     // own stream (not hipMemcpyAsync: the runtime's copy path is where the other groups' 1.4 MB window blocks are queued)
+    // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
+    // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
+    // 28.6-29.1 ms per step; TC2LI_BA_XP_PINNED=0: the one-entry k_copy_tasks launch of rounds 3-4)
+    static const bool xp_pinned = !(getenv("TC2LI_BA_XP_PINNED") && atoi(getenv("TC2LI_BA_XP_PINNED")) == 0);
     auto stage_steps = [&](const std::vector<int>& step) {
         for (size_t k = 0; k < step.size(); ++k) {
             const LockstepWindow& w = W[step[k]];
             if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
             memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
         }
+        if (xp_pinned) return;  // the trial kernels read the steps where they are
         if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
         C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
         launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
@@ -1512,7 +1517,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
                 stage_steps(step);
-                pieces(step, d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
+                pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
                 pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
                 sync();
                 if (failed) break;
@@ -1779,12 +1784,17 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
         launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
     }
+    // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
+    // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
+    // 28.6-29.1 ms per step; TC2LI_BA_XP_PINNED=0: the one-entry k_copy_tasks launch of rounds 3-4)
+    static const bool xp_pinned = !(getenv("TC2LI_BA_XP_PINNED") && atoi(getenv("TC2LI_BA_XP_PINNED")) == 0);
     auto stage_steps = [&](const std::vector<int>& step) {
         for (size_t k = 0; k < step.size(); ++k) {
             const LviWindow& w = W[step[k]];
             if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
             memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
         }
+        if (xp_pinned) return;  // the trial kernels read the steps where they are
         if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
         C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
         launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
@@ -1879,7 +1889,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             if (!step.empty()) {
                 stage_steps(step);
                 // (the trial ImuCamPose states come back through slot.iposes_host, written by the trial kernel: a copy launch per trial before)
-                pieces(step, d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
+                pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
                 pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
                 pool.parallel_for((int)step.size(), [&](int k) {  // velocity / bias part of the step, on the host
                     LviWindow& w = W[step[k]];
