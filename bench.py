@@ -842,7 +842,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         "k_quadtree_sorted_list": (n_img * (4 * 15000 + 8 * nkp), "B"),                 # round 4: the same jobs from per-class lists, resident workgroups
         # voxel filter, sorted form: xyz in, (voxel, point) out; the gather reads a point and writes its 32-byte record; the sums read the records
         "k_voxel_sort_points": (F * pre * (16 + 8), "B"), "k_voxel_gather_sorted": (F * pre * (4 + 48 + 32), "B"),
-        "k_voxel_centroid_sorted": (F * (pre * 32 + down * 48), "B"),
+        "k_voxel_centroid_sorted": (F * (pre * 32 + down * 48), "B"), "k_voxel_centroid_fused": (F * (pre * (4 + 48) + down * 48), "B"),
         "k_stereo_rows": (F * nkp * (12 + 2 * 7), "B"),                                 # right keys in, ~7 row entries of 2 B each out
         # tracking: TrackWithMotionModel + TrackLocalMap per frame -- queries (64 B out, source point in), candidate windows, edges
         "k_track_queries_last": (F * nkp * (53 + 64), "B"), "k_track_queries_local": (F * nloc * (68 + 64), "B"),

@@ -703,6 +703,54 @@ __global__ __launch_bounds__(256) void k_voxel_centroid_sorted(const PointXYZINo
     out[sl.base + r] = o;
 }
 
+// gather + centroid in one pass (round 4): a thread per voxel takes its members' indices four at a time, then their points, and adds them
+// in the members' order -- the sums k_voxel_centroid_sorted forms, without the 32-byte records' trip through memory (64 B per point).
+__global__ __launch_bounds__(256) void k_voxel_centroid_fused(const PointXYZINormal* __restrict__ pts, const ScanSlot* __restrict__ slots,
+                                                              const SegBlock* __restrict__ blocks, const VoxelParams* __restrict__ vp,
+                                                              const int* __restrict__ n_vox, const int* __restrict__ vox_start,
+                                                              const int* __restrict__ vox_info, const int* __restrict__ idx_a, const int* __restrict__ idx_b,
+                                                              PointXYZINormal* __restrict__ out, int* __restrict__ out_count, int nblocks) {
+    const int bi = xcd_contiguous((int)blockIdx.x, nblocks);
+    if (bi < 0) return;
+    const SegBlock b = blocks[bi];
+    const ScanSlot sl = slots[b.scan];
+    const int nv = n_vox[b.scan];
+    if (b.start == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_count[b.scan] = nv;
+    const int r = b.start + (int)blockIdx.y * 256 + threadIdx.x;
+    if (r >= nv) return;
+    if (vp[b.scan].passthrough != 0) { out[sl.base + r] = pts[sl.base + r]; return; }
+    const int first = vox_start[sl.base + r], last = r + 1 < nv ? vox_start[sl.base + r + 1] : vox_info[sl.base];
+    const int* __restrict__ idx = (vox_info[sl.base + 1] ? idx_b : idx_a) + sl.base;
+    const float4* __restrict__ q = reinterpret_cast<const float4*>(pts + sl.base);  // three float4 per point
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    int k = first;
+    for (; k + 4 <= last; k += 4) {  // the four indices, then the twelve loads, issued together; additions strictly in order
+        const int i0 = idx[k], i1 = idx[k + 1], i2 = idx[k + 2], i3 = idx[k + 3];
+        const float4 x0 = q[3 * i0], n0 = q[3 * i0 + 1], c0 = q[3 * i0 + 2];
+        const float4 x1 = q[3 * i1], n1 = q[3 * i1 + 1], c1 = q[3 * i1 + 2];
+        const float4 x2 = q[3 * i2], n2 = q[3 * i2 + 1], c2 = q[3 * i2 + 2];
+        const float4 x3 = q[3 * i3], n3 = q[3 * i3 + 1], c3 = q[3 * i3 + 2];
+        a0 += x0.x; a1 += x0.y; a2 += x0.z; a3 += n0.x; a4 += n0.y; a5 += n0.z; a6 += c0.x; a7 += c0.y;
+        a0 += x1.x; a1 += x1.y; a2 += x1.z; a3 += n1.x; a4 += n1.y; a5 += n1.z; a6 += c1.x; a7 += c1.y;
+        a0 += x2.x; a1 += x2.y; a2 += x2.z; a3 += n2.x; a4 += n2.y; a5 += n2.z; a6 += c2.x; a7 += c2.y;
+        a0 += x3.x; a1 += x3.y; a2 += x3.z; a3 += n3.x; a4 += n3.y; a5 += n3.z; a6 += c3.x; a7 += c3.y;
+    }
+    for (; k < last; ++k) {
+        const int i0 = idx[k];
+        const float4 x0 = q[3 * i0], n0 = q[3 * i0 + 1], c0 = q[3 * i0 + 2];
+        a0 += x0.x; a1 += x0.y; a2 += x0.z; a3 += n0.x; a4 += n0.y; a5 += n0.z; a6 += c0.x; a7 += c0.y;
+    }
+    const float fn = (float)(last - first);
+    PointXYZINormal o;
+    o.x = a0 / fn; o.y = a1 / fn; o.z = a2 / fn; o.pad0 = 1.0f;
+    float snx = a3, sny = a4, snz = a5;
+    const float nn = snx * snx + sny * sny + snz * snz;
+    if (nn > 0) { const float rt = sqrtf(nn); snx /= rt; sny /= rt; snz /= rt; }
+    o.normal_x = snx; o.normal_y = sny; o.normal_z = snz; o.pad1 = 0;
+    o.intensity = a6 / fn; o.curvature = a7 / fn; o.pad2 = 0; o.pad3 = 0;
+    out[sl.base + r] = o;
+}
+
 // ---- b2: ImuProcess::UndistortPcl, backward propagation (IMU_Processing.cpp:236-276) --------------------------------
 // Points are in time order.  A point with time t belongs to the interval whose head pose is the last one earlier than t;
 // it is rotated / translated with the constant-rate model of that interval into the scan-end frame, all in double like the
@@ -1508,6 +1556,13 @@ void launch_voxel_sorted(const PointXYZINormal* pts, const int* count, const Sca
     if (!nscans || !nblocks) return;
     TC2LI_LAUNCH(k_voxel_sort_points, dim3(nscans), dim3(kVsThreads), 0, st, pts, count, slots, vp, leaf, reinterpret_cast<uint32_t*>(key_a), idx_a,
                  reinterpret_cast<uint32_t*>(key_b), idx_b, vox_start, vox_info, n_vox);
+    // TC2LI_VOXEL_FUSED=0: the two-pass form (the points' fields written in sorted order, then summed)
+    static const bool fused = !(getenv("TC2LI_VOXEL_FUSED") && atoi(getenv("TC2LI_VOXEL_FUSED")) == 0);
+    if (fused) {
+        TC2LI_LAUNCH(k_voxel_centroid_fused, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, n_vox, vox_start, vox_info,
+                     idx_a, idx_b, out, out_count, nblocks);
+        return;
+    }
     TC2LI_LAUNCH(k_voxel_gather_sorted, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, vox_info, idx_a, idx_b,
                  (CentroidRec*)recs, nblocks);
     TC2LI_LAUNCH(k_voxel_centroid_sorted, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, n_vox, vox_start, vox_info,
