@@ -1557,7 +1557,8 @@ void launch_voxel_sorted(const PointXYZINormal* pts, const int* count, const Sca
     TC2LI_LAUNCH(k_voxel_sort_points, dim3(nscans), dim3(kVsThreads), 0, st, pts, count, slots, vp, leaf, reinterpret_cast<uint32_t*>(key_a), idx_a,
                  reinterpret_cast<uint32_t*>(key_b), idx_b, vox_start, vox_info, n_vox);
     // TC2LI_VOXEL_FUSED=0: the two-pass form (the points' fields written in sorted order, then summed)
-    static const bool fused = !(getenv("TC2LI_VOXEL_FUSED") && atoi(getenv("TC2LI_VOXEL_FUSED")) == 0);
+    const char* fused_env = getenv("TC2LI_VOXEL_FUSED");  // (read per call: the tests switch it)
+    const bool fused = !(fused_env && atoi(fused_env) == 0);
     if (fused) {
         TC2LI_LAUNCH(k_voxel_centroid_fused, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, n_vox, vox_start, vox_info,
                      idx_a, idx_b, out, out_count, nblocks);

@@ -38,10 +38,12 @@ def test_preprocess(fe, oracle, scans, pfn, blind, form, monkeypatch):
     assert same_points(fe.process(raw[:1025], 2, 2.0), oracle.lidar_preprocess(raw[:1025], 2, 2.0))
 
 
-@pytest.mark.parametrize("form", ["hash", "sorted"])  # the two device forms of the filter (lidar_host.cpp run_voxel): few scans / batches
+# the device forms of the filter (lidar_host.cpp run_voxel): few scans / batches; the batches' sums in one kernel or in two passes
+@pytest.mark.parametrize("form", ["hash", "sorted", "sorted-two-pass"])
 @pytest.mark.parametrize("leaf", [0.5, 0.2, 1.5])
 def test_voxel_filter(fe, oracle, scans, leaf, form, monkeypatch):
-    monkeypatch.setenv("TC2LI_VOXEL_SORTED", "1" if form == "sorted" else "0")
+    monkeypatch.setenv("TC2LI_VOXEL_SORTED", "0" if form == "hash" else "1")
+    monkeypatch.setenv("TC2LI_VOXEL_FUSED", "0" if form == "sorted-two-pass" else "1")
     pts = oracle.lidar_preprocess(scans[1])
     got = fe.voxel_filter(pts, leaf)
     want = oracle.voxel_grid(pts, leaf)
