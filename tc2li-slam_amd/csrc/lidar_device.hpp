@@ -85,9 +85,11 @@ void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* 
                        const int* table_rank, const int* vox_member_off, int* vox_fill /* runs per voxel */,
                        int* members /* one word per run: first index | (length - 1) << 24 */, hipStream_t st);
 // the sorted form of the voxel filter (after launch_voxel_bbox / launch_voxel_params): one workgroup per scan sorts (voxel, point), then the centroids
-void launch_voxel_sorted(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, const SegBlock* blocks, int nblocks, float leaf,
-                         const VoxelParams* vp, int* key_a, int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, void* recs,
-                         PointXYZINormal* out, int* out_count, hipStream_t st);
+void launch_voxel_sort_points(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, float leaf, const VoxelParams* vp, int* key_a,
+                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, hipStream_t st);
+void launch_voxel_sums(const PointXYZINormal* pts, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const ScanSlot* vslots, const SegBlock* vblocks,
+                       int nvblocks, const VoxelParams* vp, const int* idx_a, const int* idx_b, const int* vox_start, const int* vox_info, const int* n_vox,
+                       void* recs, PointXYZINormal* out, int* out_count, hipStream_t st);
 void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                            float leaf, const VoxelParams* vp, const int* pt_slot, const int* table_rank, const int* n_vox,
                            const int* vox_member_off, const int* vox_fill, const int* vox_count, const int* members, void* recs /* 32 B per point */,

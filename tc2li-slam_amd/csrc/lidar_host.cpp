@@ -122,6 +122,15 @@ struct tc2li_lidar {
     int prepared_scans = 0;       // tc2li_lidar_inertial_prepare_batch: d_pre / d_perm / h_counts hold that many scans, ready for the front end
     std::vector<ScanSlot> slots;
     std::vector<SegBlock> blocks;
+    // The same tables cut for the DOWN-SAMPLED clouds of a batch (compact_segments): the block list above covers the raw scans' sizes
+    // (128 blocks per KITTI scan), the 4 000 points a scan keeps after the voxel filter fill 4 of them -- a pass over the down-sampled
+    // clouds launched on that list started 97 % of its workgroups (10^6 per k_knn_plane launch of 512 scans) only to let them leave.
+    DevBuf<ScanSlot> d_slots_down;
+    DevBuf<SegBlock> d_blocks_down;
+    PinnedBuf<int> h_down;  // [max_scans]
+    std::vector<ScanSlot> slots_down;
+    std::vector<SegBlock> blocks_down;
+    int nb_down = -1;       // blocks of the compact list, -1: none (the passes use d_slots / d_blocks)
     int n_scans = 0;
     // stage boundaries of the last tc2li_lidar_frontend_batch call: start, after preprocess, before / after the centroid
     // kernel, after the kNN + plane kernel, end
@@ -140,6 +149,7 @@ int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st
     L->slots.resize(n_scans);
     L->blocks.clear();
     L->pre_bbox_valid = false;  // new scans in the slots: d_bbox describes nothing yet
+    L->nb_down = -1;
     for (int s = 0; s < n_scans; ++s) {
         if (upper[s] > L->cap) { set_error("scan %d has %d points, slot capacity is %d", s, upper[s], L->cap); return TC2LI_ERR_CAPACITY; }
         ScanSlot& sl = L->slots[s];
@@ -153,6 +163,30 @@ int setup_segments(tc2li_lidar* L, int n_scans, const int* upper, hipStream_t st
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_slots.p, L->slots.data(), n_scans * sizeof(ScanSlot), hipMemcpyHostToDevice, st));
     if (!L->blocks.empty())
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks.p, L->blocks.data(), L->blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+    return TC2LI_OK;
+}
+
+// The slot / block tables for the down-sampled clouds of the scans in the slots: their sizes (`d_counts`, one per scan, final on the
+// stream) come to the host -- one wait in the middle of the call -- and the passes over those clouds are launched with the blocks they need.
+int compact_segments(tc2li_lidar* L, const int* d_counts, hipStream_t st) {
+    const int S = L->n_scans;
+    L->nb_down = -1;
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_down.p, d_counts, S * sizeof(int), hipMemcpyDeviceToHost, st));
+    TC2LI_HIP_CHECK(stream_wait_blocking(st));
+    std::vector<ScanSlot>& slots = L->slots_down;
+    std::vector<SegBlock>& blocks = L->blocks_down;
+    slots.assign(L->slots.begin(), L->slots.begin() + S);
+    blocks.clear();
+    for (int s = 0; s < S; ++s) {
+        const int n = L->h_down.p[s];
+        if (n < 0 || n > L->cap) { set_error("scan %d: %d down-sampled points in a slot of %d", s, n, L->cap); return TC2LI_ERR_CAPACITY; }
+        slots[s].first_block = (int)blocks.size();
+        slots[s].n_blocks = (n + kSegBlock - 1) / kSegBlock;
+        for (int b = 0; b < slots[s].n_blocks; ++b) blocks.push_back(SegBlock{s, b * kSegBlock});
+    }
+    TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_slots_down.p, slots.data(), S * sizeof(ScanSlot), hipMemcpyHostToDevice, st));
+    if (!blocks.empty()) TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_blocks_down.p, blocks.data(), blocks.size() * sizeof(SegBlock), hipMemcpyHostToDevice, st));
+    L->nb_down = (int)blocks.size();
     return TC2LI_OK;
 }
 
@@ -178,8 +212,9 @@ int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_
 }
 
 // b3: in = (pts, count) per slot -> d_down / d_down_count
-int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count, float leaf, hipStream_t st) {
+int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count, float leaf, hipStream_t st, bool compact = false) {
     const int S = L->n_scans, nb = (int)L->blocks.size();
+    L->nb_down = -1;
     std::vector<VoxelParams> vp(S);
     for (int s = 0; s < S; ++s) { memset(&vp[s], 0, sizeof(VoxelParams)); vp[s].table_base = s * L->table_size; vp[s].table_mask = L->table_size - 1; }
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_vp.p, vp.data(), S * sizeof(VoxelParams), hipMemcpyHostToDevice, st));
@@ -201,8 +236,15 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     const bool sorted = env ? atoi(env) != 0 : S >= 32;
     if (sorted) {
         L->record(2, st);
-        launch_voxel_sorted(d_in, d_in_count, L->d_slots.p, S, L->d_blocks.p, nb, leaf, L->d_vp.p, L->d_pt_slot.p, L->d_vox_keys.p, L->d_members.p,
-                            L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, L->d_recs.p, L->d_down.p, L->d_down_count.p, st);
+        launch_voxel_sort_points(d_in, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, L->d_pt_slot.p, L->d_vox_keys.p, L->d_members.p, L->d_member_off.p,
+                                 L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, st);
+        TC2LI_HIP_CHECK(hipGetLastError());
+        // a batch: the passes over the voxels (and, in run_features, over the down-sampled points) get block tables cut for n_vox
+        if (compact) { const int rc = compact_segments(L, L->d_n_vox.p, st); if (rc != TC2LI_OK) return rc; }
+        const bool c = L->nb_down >= 0;
+        launch_voxel_sums(d_in, L->d_slots.p, L->d_blocks.p, nb, c ? L->d_slots_down.p : L->d_slots.p, c ? L->d_blocks_down.p : L->d_blocks.p, c ? L->nb_down : nb,
+                          L->d_vp.p, L->d_vox_keys.p, L->d_member_off.p, L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, L->d_recs.p, L->d_down.p,
+                          L->d_down_count.p, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         return TC2LI_OK;
     }
@@ -223,18 +265,22 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
 // b4-b6
 int run_features(tc2li_lidar* L, const PointXYZINormal* d_body, const int* d_body_count, tc2li_lidar_map* const* maps,
                  const tc2li_lidar_state* states, hipStream_t st) {
-    const int S = L->n_scans, nb = (int)L->blocks.size();
+    // (the tables cut for the down-sampled clouds when the voxel filter of this call left them: compact_segments)
+    const bool c = L->nb_down >= 0 && d_body == L->d_down.p;
+    const int S = L->n_scans, nb = c ? L->nb_down : (int)L->blocks.size();
+    const ScanSlot* const d_slots = c ? L->d_slots_down.p : L->d_slots.p;
+    const SegBlock* const d_blocks = c ? L->d_blocks_down.p : L->d_blocks.p;
     std::vector<MapGrid> grids(S);
     for (int s = 0; s < S; ++s) grids[s] = maps[s]->grid;
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_grids.p, grids.data(), S * sizeof(MapGrid), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_states.p, states, S * sizeof(LidarStateDev), hipMemcpyHostToDevice, st));
-    launch_knn_plane(L->d_grids.p, d_body, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
+    launch_knn_plane(L->d_grids.p, d_body, d_body_count, d_slots, d_blocks, nb, L->d_states.p, L->d_world.p, L->d_selected.p,
                      L->d_normvec.p, L->d_nearest_idx.p, L->d_nearest_d.p, L->d_nfound.p, L->d_hard_count.p, L->d_hard_list.p, st,
                      (L->ev[6] || hipEventCreate(&L->ev[6]) == hipSuccess) ? L->ev[6] : nullptr);
     L->record(4, st);
-    launch_sel_count(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_counts.p, st);
-    launch_seg_scan(L->d_slots.p, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
-    launch_sel_scatter(L->d_selected.p, d_body_count, L->d_slots.p, L->d_blocks.p, nb, L->d_block_offsets.p, d_body, L->d_normvec.p,
+    launch_sel_count(L->d_selected.p, d_body_count, d_slots, d_blocks, nb, L->d_block_counts.p, st);
+    launch_seg_scan(d_slots, S, L->d_block_counts.p, L->d_block_offsets.p, L->d_sel_count.p, st);
+    launch_sel_scatter(L->d_selected.p, d_body_count, d_slots, d_blocks, nb, L->d_block_offsets.p, d_body, L->d_normvec.p,
                        L->d_cloud_ori.p, L->d_corr.p, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     return TC2LI_OK;
@@ -412,6 +458,7 @@ int tc2li_lidar_create(int max_points_per_scan, int max_scans, tc2li_lidar** out
     TC2LI_HIP_CHECK(L->d_raw_count.alloc(S)); TC2LI_HIP_CHECK(L->d_pre_count.alloc(S)); TC2LI_HIP_CHECK(L->d_down_count.alloc(S));
     TC2LI_HIP_CHECK(L->d_sel_count.alloc(S)); TC2LI_HIP_CHECK(L->d_block_counts.alloc(NB)); TC2LI_HIP_CHECK(L->d_block_offsets.alloc(NB));
     TC2LI_HIP_CHECK(L->d_slots.alloc(S)); TC2LI_HIP_CHECK(L->d_blocks.alloc(NB));
+    TC2LI_HIP_CHECK(L->d_slots_down.alloc(S)); TC2LI_HIP_CHECK(L->d_blocks_down.alloc(NB)); TC2LI_HIP_CHECK(L->h_down.alloc(S));
     TC2LI_HIP_CHECK(L->d_bbox.alloc(6 * S)); TC2LI_HIP_CHECK(L->d_vp.alloc(S));
     TC2LI_HIP_CHECK(L->d_table_keys.alloc(S * L->table_size)); TC2LI_HIP_CHECK(L->d_table_counts.alloc(S * L->table_size));
     TC2LI_HIP_CHECK(L->d_table_rank.alloc(S * L->table_size));
@@ -980,7 +1027,7 @@ int tc2li_lidar_inertial_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li
     // the compensated scans land in d_cloud_ori (free until a selection is compacted), the voxel filter reads them there
     launch_undistort_batch(L->d_pre.p, L->d_perm.p, L->d_pre_count.p, L->d_slots.p, L->d_blocks.p, (int)L->blocks.size(), L->d_imu_poses.p, L->d_n_poses.p,
                            L->d_states.p, L->d_cloud_ori.p, st);
-    rc = run_voxel(L, L->d_cloud_ori.p, L->d_pre_count.p, leaf, st);
+    rc = run_voxel(L, L->d_cloud_ori.p, L->d_pre_count.p, leaf, st, S >= 32);
     if (rc != TC2LI_OK) return rc;
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + S, L->d_down_count.p, S * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(hc + 3 * S, L->d_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1576,7 +1623,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
     if (rc != TC2LI_OK) return rc;
     L->record(1, st);
-    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, st);
+    rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, st, /* compact tables for the down-sampled clouds of a batch */ n_scans >= 32);
     if (rc != TC2LI_OK) return rc;
     L->record(3, st);
     rc = run_features(L, L->d_down.p, L->d_down_count.p, maps, states, st);

@@ -1550,24 +1550,30 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
     TC2LI_LAUNCH(k_voxel_centroid, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, count, slots, blocks, vp, n_vox, vox_member_off,
                        vox_count, (const CentroidRec*)recs, out, out_count, nblocks);
 }
-void launch_voxel_sorted(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, const SegBlock* blocks, int nblocks, float leaf,
-                         const VoxelParams* vp, int* key_a, int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, void* recs,
-                         PointXYZINormal* out, int* out_count, hipStream_t st) {
-    if (!nscans || !nblocks) return;
+void launch_voxel_sort_points(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, float leaf, const VoxelParams* vp, int* key_a,
+                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, hipStream_t st) {
+    if (!nscans) return;
     TC2LI_LAUNCH(k_voxel_sort_points, dim3(nscans), dim3(kVsThreads), 0, st, pts, count, slots, vp, leaf, reinterpret_cast<uint32_t*>(key_a), idx_a,
                  reinterpret_cast<uint32_t*>(key_b), idx_b, vox_start, vox_info, n_vox);
+}
+// (slots, blocks, nblocks): a block list that covers the input points; (vslots, vblocks, nvblocks): one that covers the voxels (n_vox per scan)
+void launch_voxel_sums(const PointXYZINormal* pts, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const ScanSlot* vslots, const SegBlock* vblocks,
+                       int nvblocks, const VoxelParams* vp, const int* idx_a, const int* idx_b, const int* vox_start, const int* vox_info, const int* n_vox,
+                       void* recs, PointXYZINormal* out, int* out_count, hipStream_t st) {
+    if (!nvblocks) return;
     // TC2LI_VOXEL_FUSED=0: the two-pass form (the points' fields written in sorted order, then summed)
     const char* fused_env = getenv("TC2LI_VOXEL_FUSED");  // (read per call: the tests switch it)
     const bool fused = !(fused_env && atoi(fused_env) == 0);
     if (fused) {
-        TC2LI_LAUNCH(k_voxel_centroid_fused, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, n_vox, vox_start, vox_info,
-                     idx_a, idx_b, out, out_count, nblocks);
+        TC2LI_LAUNCH(k_voxel_centroid_fused, dim3((nvblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, vslots, vblocks, vp, n_vox, vox_start, vox_info,
+                     idx_a, idx_b, out, out_count, nvblocks);
         return;
     }
-    TC2LI_LAUNCH(k_voxel_gather_sorted, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, vox_info, idx_a, idx_b,
-                 (CentroidRec*)recs, nblocks);
-    TC2LI_LAUNCH(k_voxel_centroid_sorted, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, n_vox, vox_start, vox_info,
-                 (const CentroidRec*)recs, out, out_count, nblocks);
+    if (nblocks)
+        TC2LI_LAUNCH(k_voxel_gather_sorted, dim3((nblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, slots, blocks, vp, vox_info, idx_a, idx_b,
+                     (CentroidRec*)recs, nblocks);
+    TC2LI_LAUNCH(k_voxel_centroid_sorted, dim3((nvblocks + 7) / 8 * 8, kSegBlock / 256), dim3(256), 0, st, pts, vslots, vblocks, vp, n_vox, vox_start, vox_info,
+                 (const CentroidRec*)recs, out, out_count, nvblocks);
 }
 void launch_knn_plane(const MapGrid* grids, const PointXYZINormal* body, const int* count,
                       const ScanSlot* slots, const SegBlock* blocks, int nblocks, const LidarStateDev* states, PointXYZINormal* world,
