@@ -72,6 +72,8 @@ struct BaProblemDev {
     double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands (dense path only)
     double *S_part;                      // [n_slices][np_pad * np_pad]; sparse path: row 6 n_free holds W D^-1 b_l
     double *scale_part;                  // per 256 landmarks: partial sums of the gain-ratio scale
+    int32_t* ticket;                     // [4] zero between launches: how many workgroups of a window have delivered their partial sums (lock-step batch:
+                                         // the last one adds them up -- [1] trial errors)
     double *chi_part;                    // partial sums of the robust cost: per linearisation group / per 256 edges of a trial
 };
 
@@ -127,6 +129,7 @@ struct BaBatchExtent {
     int any_dense, max_sparse_np_pad, max_sparse_slices;
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
+    int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int inertial;  // the windows' vertices are ImuCamPose records (LocalLVIBA batch): the linearisation kernel of that vertex type
 };
 // n_active <= kBaPhaseMax windows per call (the host cuts a longer list)
@@ -164,7 +167,7 @@ __device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb)
     TC2LI_G(fl_off); TC2LI_G(fl_pose); TC2LI_G(w_slot); TC2LI_G(fl_lm); TC2LI_G(fl_place); TC2LI_G(slice_off); TC2LI_G(fl_edge);
     TC2LI_G(chi2); TC2LI_G(rho0); TC2LI_G(cp_part); TC2LI_G(W); TC2LI_G(blk_off); TC2LI_G(blk_rows);
     TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(AT); TC2LI_G(BT);
-    TC2LI_G(S_part); TC2LI_G(scale_part); TC2LI_G(chi_part);
+    TC2LI_G(S_part); TC2LI_G(scale_part); TC2LI_G(chi_part); TC2LI_G(ticket);
 #undef TC2LI_G
 }
 // the phase's window number / flags at position `pos` as scalars: sub-dword loads from the argument block at a dynamic index are vector

@@ -188,7 +188,7 @@ struct VisualProblem {
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
     memset(h_S.p, 0, (size_t)std::max(np * np, 1) * sizeof(double));  // the finish kernel writes the lower triangle only; the rest stays defined
-    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows], every
+    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows | ticket words], every
     // part 16-byte aligned ----
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
@@ -200,7 +200,7 @@ struct VisualProblem {
                  o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
                  o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
                  o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
-                 in_bytes = align16(o_blk_rows + blk_rows.size());
+                 o_ticket = align16(o_blk_rows + blk_rows.size()), in_bytes = align16(o_ticket + 4 * sizeof(int32_t));
     TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
     uint8_t* const h = ws.h_in.p;
     if (poses7) {
@@ -226,6 +226,7 @@ struct VisualProblem {
     memcpy(h + o_grp_l0, grp_l0.data(), grp_l0.size() * sizeof(int));
     memcpy(h + o_blk_off, blk_off.data(), blk_off.size() * sizeof(int));
     memcpy(h + o_blk_rows, blk_rows.data(), blk_rows.size());
+    memset(h + o_ticket, 0, 4 * sizeof(int32_t));  // (the kernels that use them leave them at zero again)
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
     TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
@@ -245,6 +246,7 @@ struct VisualProblem {
     pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off); pb.fl_edge = (const int*)(d + o_fl_edge);
     pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
     pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
+    pb.ticket = (int32_t*)(d + o_ticket);
     pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? 1 : 0; pb.n_schur_slices = sparse ? n_schur_slices : 0;
     pb.schur_rd = pb.schur_ro = 1;
     if (blocks_form) {
@@ -1295,11 +1297,13 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         }
     tm[0] = now() - t0;
     BaBatchExtent X{};
+    bool all_block_parts = true;
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0) continue;
         const BaProblemDev& pb = W[i].vp.pb;
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
+        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
@@ -1314,6 +1318,15 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
             X.max_W = std::max(X.max_W, W[i].lidar->W);
         }
+    }
+    // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
+    // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
+    // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
+    // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
+    // are a launch; removed.)  TC2LI_BA_FUSE=0 (read per call): the separate launch.
+    {
+        const char* fuse_env = getenv("TC2LI_BA_FUSE");
+        X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
     }
     // TC2LI_BA_DEVICE_SOLVE=1 (read per call): the reduced systems of the batch are solved on the device (k_ba_solve_b; every window on the
     // sparse Schur path, i.e. at most 21 free keyframes) -- Schur product, solve and trial estimate are then one queue of launches with one
@@ -1741,11 +1754,13 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) { (void)hipStreamSynchronize(st); return false; }
     BaBatchExtent X{};
     X.inertial = 1;
+    bool all_block_parts = true;
     for (int i = 0; i < n; ++i) {
         if (W[i].rc < 0) continue;
         const BaProblemDev& pb = W[i].vp.pb;
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
+        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
@@ -1760,6 +1775,15 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
             X.max_W = std::max(X.max_W, W[i].lidar->W);
         }
+    }
+    // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
+    // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
+    // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
+    // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
+    // are a launch; removed.)  TC2LI_BA_FUSE=0 (read per call): the separate launch.
+    {
+        const char* fuse_env = getenv("TC2LI_BA_FUSE");
+        X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
     }
     auto fill_slot = [&](int i) {
         LviWindow& w = W[i];

@@ -59,6 +59,7 @@ __device__ __forceinline__ void edge_state(const BaProblemDev& pb, bool trial, c
 }
 
 // sum of v over the workgroup's 256 threads in a fixed order -> out[0]
+template <bool DEVICE_SCOPE = false>
 __device__ __forceinline__ void block_sum_256(double v, double* s, double* __restrict__ out) {
     s[threadIdx.x] = v;
     __syncthreads();
@@ -66,7 +67,19 @@ __device__ __forceinline__ void block_sum_256(double v, double* s, double* __res
         if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = s[0];
+    if (threadIdx.x == 0) {
+        if (DEVICE_SCOPE) __hip_atomic_store(out, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[0] = s[0];
+    }
+}
+
+// Partial sums that another workgroup of the SAME launch adds up (ba_last_of below) are written and read at device scope -- the store goes
+// through the XCD's L2 to memory (block_sum_256<true>), the load does not take what that L2 holds -- so that no cache-wide write-back /
+// invalidate (__threadfence: buffer_wbl2 + buffer_inv by every wavefront of the launch, on everybody's lines) is needed to see them:
+// measured, with the fences the BA stage took twice as long (35 against 17 ms per 128 windows).
+template <bool DEVICE_SCOPE>
+__device__ __forceinline__ double load_partial(const double* p) {
+    return DEVICE_SCOPE ? __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
 // Workgroups [0, nbe): every edge -- error, Huber weight, robust cost and the landmark block A^T W A, A^T omega_r.  Workgroups from
@@ -325,10 +338,10 @@ __device__ __forceinline__ void reduce_poses_body(const BaProblemDev& pb, int i 
 }
 
 // out[0] = in[0] + in[1] + ... (or the maximum) by one 256-thread workgroup, fixed order
-template <bool MAX>
+template <bool MAX, bool DEVICE_SCOPE = false>
 __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, int n, double* s, double* out) {
     double a = 0;
-    for (int k = threadIdx.x; k < n; k += 256) a = MAX ? fmax(a, in[k]) : a + in[k];
+    for (int k = threadIdx.x; k < n; k += 256) { const double v = load_partial<DEVICE_SCOPE>(in + k); a = MAX ? fmax(a, v) : a + v; }
     s[threadIdx.x] = a;
     __syncthreads();
     for (int st = 128; st >= 1; st >>= 1) {
@@ -908,13 +921,15 @@ __device__ __forceinline__ void d_ba_trial_update(const BaProblemDev& pb, const 
 __global__ __launch_bounds__(256) void k_ba_trial_update(BaProblemDev pb, int nbp, const double* __restrict__ xp, double lambda) { d_ba_trial_update(pb, blockIdx.x, nbp, xp, lambda); }
 
 // [0] landmark part of the gain-ratio scale, [1] robust cost of the trial estimate
+template <bool DEVICE_SCOPE = false>  // chi_part comes from other workgroups of this launch
 __device__ __forceinline__ void d_ba_trial_reduce(const BaProblemDev& pb, const int bx, double* __restrict__ scale_out, double* __restrict__ chi_out) {
     __shared__ double s[256];
     if (bx == 0) block_reduce_256<false>(pb.scale_part, (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock, s, scale_out);
-    else block_reduce_256<false>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
+    else block_reduce_256<false, DEVICE_SCOPE>(pb.chi_part, (pb.n_edges + 255) / 256, s, chi_out);
 }
 __global__ __launch_bounds__(256) void k_ba_trial_reduce(BaProblemDev pb, double* __restrict__ scale_out, double* __restrict__ chi_out) { d_ba_trial_reduce(pb, blockIdx.x, scale_out, chi_out); }
 
+template <bool DEVICE_SCOPE = false>
 __device__ __forceinline__ void d_ba_errors(const BaProblemDev& pb, const int bx) {
     __shared__ double s_sum[256];
     const int e = bx * 256 + threadIdx.x;
@@ -930,7 +945,7 @@ __device__ __forceinline__ void d_ba_errors(const BaProblemDev& pb, const int bx
         pb.chi2[e] = c2;
         pb.rho0[e] = rho0;
     }
-    block_sum_256(rho0, s_sum, pb.chi_part + bx);
+    block_sum_256<DEVICE_SCOPE>(rho0, s_sum, pb.chi_part + bx);
 }
 __global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) { d_ba_errors(pb, blockIdx.x); }
 
@@ -1053,6 +1068,23 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaPhase ph, int st
     if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
+// The last workgroup of a window to deliver (a ticket counter per window, zero between launches).  The partial sums are stored and read at
+// device scope (block_sum_256<true> / load_partial), so what is needed here is only that a wavefront's stores have been performed before its
+// workgroup takes the ticket (the workgroup-scope release: s_waitcnt, no cache operation), that the workgroup meets, and that one
+// thread takes the ticket with a device-scope atomic.  The workgroup that took the last one leaves the counter at zero for the next
+// launch and does the closing sums -- in the fixed order of the separate kernel, whoever comes last.
+__device__ __forceinline__ bool ba_last_of(int32_t* ticket, int n_workgroups) {
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == n_workgroups - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
 __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
@@ -1162,6 +1194,17 @@ __global__ __launch_bounds__(256) void k_ba_errors_b(const BaPhase ph) {
     if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
     d_ba_errors(pb, blockIdx.x);
 }
+// the same, and the last workgroup of a window does k_ba_trial_reduce_b's work for it: the gain-ratio scale's landmark part (partials of
+// k_ba_trial_update_b, an earlier launch) and the trial's cost
+__global__ __launch_bounds__(256) void k_ba_errors_reduce_b(const BaPhase ph) {
+    TC2LI_SLOT(y);
+    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    d_ba_errors<true>(pb, blockIdx.x);
+    if (!ba_last_of(pb.ticket + 1, blocks256(pb.n_edges))) return;
+    d_ba_trial_reduce<true>(pb, 0, sl.scale_out, sl.chi_trial_out);
+    __syncthreads();
+    d_ba_trial_reduce<true>(pb, 1, sl.scale_out, sl.chi_trial_out);
+}
 __global__ __launch_bounds__(256) void k_ba_trial_reduce_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     d_ba_trial_reduce(pb, blockIdx.x, sl.scale_out, sl.chi_trial_out);
@@ -1268,6 +1311,10 @@ void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent&
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
     TC2LI_LAUNCH(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, ph);
+    if (x.fuse_trial) {
+        TC2LI_LAUNCH(k_ba_errors_reduce_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
+        return;
+    }
     TC2LI_LAUNCH(k_ba_errors_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
     TC2LI_LAUNCH(k_ba_trial_reduce_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }

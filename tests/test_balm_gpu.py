@@ -162,11 +162,13 @@ def test_batch_with_a_large_window(pkg, synthetic):
         assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2])
 
 
-def test_mixed_batch_falls_back_per_group(pkg, synthetic):
+@pytest.mark.parametrize("fuse", ["1", "0"])  # a trial's closing sums by the last workgroup of its error pass / by a launch of their own
+def test_mixed_batch_falls_back_per_group(pkg, synthetic, fuse, monkeypatch):
     """A batch of several lock-step groups in which ONE window lies outside the batched LiDAR kernels' range (8 keyframes in its LiDAR
     window, more than the 7 the lock-step kernels take): only that window's group goes through the one-window path -- every window of
     the batch, in the declined group and in the others, equals its one-window call bit for bit (the groups that had
     succeeded were optimised a second time, from their optimised state)."""
+    monkeypatch.setenv("TC2LI_BA_FUSE", fuse)
     windows, singles = [], []
     for seed in range(9):
         w = synthetic.ba_window(50 + seed, n_opt=8, n_fix=6, n_points=500, pose_noise=(0.1, 0.01))
