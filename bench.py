@@ -876,6 +876,10 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
             "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
+            "k_ba_errors_reduce_b": (nw * tr * E * 112, "B"),  # the same pass; a window's last workgroup adds the window's ~110 partial sums
+            # the LiDAR term's Hessian / gradient from the chunks' partial sums: (21 pair blocks x 36 + 36 + 1) doubles per chunk of 8 planes in, the
+            # (6W)^2 + 6W + 1 doubles and the W poses out
+            "k_balm_combine_b": (nw * lin * (((ba["planes"] + 7) // 8) * (ba["win"] * (ba["win"] + 1) // 2 * 36 + 6 * ba["win"] + 1) + 36 * ba["win"] ** 2 + 18 * ba["win"]) * 8, "B"),
             "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
             # plane extraction on the device (round 4), per window of N cloud points: the point in (12 B), common-frame point + octants + table
             # slot out; the three orders (a 4 B index per point and layer) from a key per point; the plane test reads every point's common-frame
