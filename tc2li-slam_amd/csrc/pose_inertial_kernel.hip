@@ -126,6 +126,14 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
     uint8_t* out = outlier + pr.edge_off;
     double* chi2 = chi2_scratch + pr.edge_off;
 
+    // The pre-integration record and the prior are read in every one of the 40 iterations -- by the one lane that forms the inertial edge,
+    // by the lanes that multiply with the information matrices -- and came from global memory each time (a chain of L2 round trips on
+    // single lanes): staged once, 3 KB.  Same values, same operations.
+    __shared__ PiPreint s_pre;
+    __shared__ PiPrior s_prior;
+    static_assert(sizeof(PiPreint) % 4 == 0 && sizeof(PiPrior) % 4 == 0, "copied as dwords");
+    for (int k = tid; k < (int)(sizeof(PiPreint) / 4); k += kPiThreads) reinterpret_cast<uint32_t*>(&s_pre)[k] = reinterpret_cast<const uint32_t*>(&pr.pre)[k];
+    if (last) for (int k = tid; k < (int)(sizeof(PiPrior) / 4); k += kPiThreads) reinterpret_cast<uint32_t*>(&s_prior)[k] = reinterpret_cast<const uint32_t*>(&pr.prior)[k];
     for (int i = tid; i < N; i += kPiThreads) out[i] = 0;
     if (tid == 0) { s_cur = pr.cur; s_oth = pr.other; s_flag[1] = 0; }
     if (tid < 30) s_x[tid] = 0;
@@ -184,10 +192,10 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
             }
             if (tid < 6) s_b[tid] = s_sum[21 + tid];
             // ---- the inertial edge (lane 0) and the prior edge (lane 64: another wavefront) ----
-            if (tid == 0) pi_inertial_edge(pr.pre, s_oth, s_cur, s_e, s_J);
+            if (tid == 0) pi_inertial_edge(s_pre, s_oth, s_cur, s_e, s_J);
             if (tid == 64 && last) {
                 double Jr[9], Jt[9];
-                pi_prior_edge(pr.prior, s_oth, s_pe, Jr, Jt);
+                pi_prior_edge(s_prior, s_oth, s_pe, Jr, Jt);
                 for (int k = 0; k < 225; ++k) s_pJ[k] = 0;
                 for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { s_pJ[15 * r + c] = Jr[3 * r + c]; s_pJ[15 * (3 + r) + 3 + c] = Jt[3 * r + c]; }
                 for (int k = 6; k < 15; ++k) s_pJ[15 * k + k] = 1.0;
@@ -196,24 +204,24 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
             if (tid < 216) {  // T = Omega J
                 const int r = tid / 24, c = tid % 24;
                 double s = 0;
-                for (int k = 0; k < 9; ++k) s += pr.pre.info[9 * r + k] * s_J[24 * k + c];
+                for (int k = 0; k < 9; ++k) s += s_pre.info[9 * r + k] * s_J[24 * k + c];
                 s_T[tid] = s;
             } else if (tid < 225) {
                 const int r = tid - 216;
                 double s = 0;
-                for (int k = 0; k < 9; ++k) s += pr.pre.info[9 * r + k] * s_e[k];
+                for (int k = 0; k < 9; ++k) s += s_pre.info[9 * r + k] * s_e[k];
                 s_Oe[r] = s;
             }
             if (last && tid < 225) {  // prior: T2 = H_prior J
                 const int r = tid / 15, c = tid % 15;
                 double s = 0;
-                for (int k = 0; k < 15; ++k) s += pr.prior.H[15 * r + k] * s_pJ[15 * k + c];
+                for (int k = 0; k < 15; ++k) s += s_prior.H[15 * r + k] * s_pJ[15 * k + c];
                 s_pT[tid] = s;
             }
             if (last && tid >= 225 && tid < 240) {
                 const int r = tid - 225;
                 double s = 0;
-                for (int k = 0; k < 15; ++k) s += pr.prior.H[15 * r + k] * s_pe[k];
+                for (int k = 0; k < 15; ++k) s += s_prior.H[15 * r + k] * s_pe[k];
                 s_pOe[r] = s;
             }
             __syncthreads();
@@ -245,7 +253,7 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
             // EdgeGyroRW / EdgeAccRW: error = frame - other, Jacobians -I / +I
             if (tid < 18) {
                 const int which = tid / 9, r = (tid % 9) / 3, c = tid % 3;
-                const double* info = which ? pr.pre.infoA : pr.pre.infoG;
+                const double* info = which ? s_pre.infoA : s_pre.infoG;
                 const int ic = which ? 12 : 9, io = last ? 15 + ic : -1;
                 const double v = info[3 * r + c];
                 s_H[(ic + r) * n + ic + c] += v;
