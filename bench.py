@@ -881,6 +881,8 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # (6W)^2 + 6W + 1 doubles and the W poses out
             "k_balm_combine_b": (nw * lin * (((ba["planes"] + 7) // 8) * (ba["win"] * (ba["win"] + 1) // 2 * 36 + 6 * ba["win"] + 1) + 36 * ba["win"] ** 2 + 18 * ba["win"]) * 8, "B"),
             "k_balm_hessian_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
+            "k_balm_hessian_lean3_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),  # the same body held to three / four wavefronts per SIMD
+            "k_balm_hessian_lean4_b": (nw * lin * ba["planes"] * ba["win"] * 80, "B"),
             # plane extraction on the device (round 4), per window of N cloud points: the point in (12 B), common-frame point + octants + table
             # slot out; the three orders (a 4 B index per point and layer) from a key per point; the plane test reads every point's common-frame
             # coordinates once per layer; the walk reads a flag and a key per cell (at most a cell per point and layer); the clusters read the

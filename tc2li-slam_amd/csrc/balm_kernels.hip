@@ -11,6 +11,7 @@
 #include "launch.hpp"
 #pragma clang fp contract(off)
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -108,17 +109,25 @@ __global__ __launch_bounds__(256) void k_balm_sum(BalmDev b) {
 // PB planes at a time: lane (p, i) = (tid / SL, tid % SL) does the per-slot algebra of plane p, slot i -- the long dependent chain of
 // the kernel, which one plane alone runs on W of the workgroup's lanes -- then every lane adds the PB planes' terms to the Hessian
 // entries it owns, in plane order (the sums are those of a plane-after-plane loop, bit for bit).  WC: slots the LDS tables hold.
-template <int kItemsPerThread, int NT, int PB, int SL, int WC>
-__device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx) {
-    static_assert(PB * SL <= NT && WC <= SL, "lane layout");
-    __shared__ LidarPose s_twl[kMaxLidarWindow];
-    __shared__ double s_A[PB][WC][18], s_MB[PB][WC][18];  // Auk (3 x 6) and umumT * Auk
-    __shared__ double s_w[PB][WC][3], s_E[PB][WC][9], s_k1[PB][WC], s_k2[PB][WC], s_n[PB][WC], s_cj[PB][WC][6];
-    __shared__ double s_uk[PB][3], s_ukuk[PB][9], s_umum[PB][9], s_vbar[PB][3], s_NN[PB], s_l0[PB], s_coe[PB];
+// the workgroup's LDS tables as one record: the callers place it (statically, or in dynamic LDS -- k_balm_hessian_lean3_b / lean4_b)
+template <int PB, int WC>
+struct HessLds {
+    LidarPose s_twl[kMaxLidarWindow];
+    double s_A[PB][WC][18], s_MB[PB][WC][18];  // Auk (3 x 6) and umumT * Auk
+    double s_w[PB][WC][3], s_E[PB][WC][9], s_k1[PB][WC], s_k2[PB][WC], s_n[PB][WC], s_cj[PB][WC][6];
+    double s_uk[PB][3], s_ukuk[PB][9], s_umum[PB][9], s_vbar[PB][3], s_NN[PB], s_l0[PB], s_coe[PB];
     // the off-diagonal blocks' factors -2 / NN / NN, -2 n_j / NN / NN and -2 n_i n_j / NN / NN: formed once per plane, slot and slot pair
     // (two f64 divisions each) instead of once per Hessian entry
-    __shared__ double s_f0[PB], s_fn[PB][WC], s_fnn[PB][WC * (WC + 1) / 2];
-    __shared__ uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
+    double s_f0[PB], s_fn[PB][WC], s_fnn[PB][WC * (WC + 1) / 2];
+    uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
+};
+template <int kItemsPerThread, int NT, int PB, int SL, int WC, bool kLean = false>
+__device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx, HessLds<PB, WC>& L) {
+    static_assert(PB * SL <= NT && WC <= SL, "lane layout");
+    auto& s_twl = L.s_twl; auto& s_A = L.s_A; auto& s_MB = L.s_MB; auto& s_w = L.s_w; auto& s_E = L.s_E; auto& s_k1 = L.s_k1; auto& s_k2 = L.s_k2;
+    auto& s_n = L.s_n; auto& s_cj = L.s_cj; auto& s_uk = L.s_uk; auto& s_ukuk = L.s_ukuk; auto& s_umum = L.s_umum; auto& s_vbar = L.s_vbar;
+    auto& s_NN = L.s_NN; auto& s_l0 = L.s_l0; auto& s_coe = L.s_coe; auto& s_f0 = L.s_f0; auto& s_fn = L.s_fn; auto& s_fnn = L.s_fnn;
+    auto& s_pi = L.s_pi; auto& s_pj = L.s_pj;
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
     window_poses(b, poses, s_twl);
     if (bx == 0 && tid < W) b.twl[tid] = s_twl[tid];  // for the change of variables on the host
@@ -236,7 +245,10 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
                     for (int c = 0; c < 6; ++c) jac[c] += s_cj[p][tid][c];
 #pragma unroll
         for (int k = 0; k < kItemsPerThread; ++k) {
-            const int item = k * NT + tid;
+            int item = k * NT + tid;
+            // (lean form: the item number is made opaque once per pass, so that the sixteen items' indices and LDS addresses are formed here,
+            // where they are used, instead of being carried in registers across the plane loop -- they were what the kernel's registers went to)
+            if (kLean) asm volatile("" : "+v"(item));
             if (item >= n_items) continue;
             const int pair = item / 36, rc = item % 36, r = rc / 6, c = rc % 6;
             const int i = s_pi[pair], j = s_pj[pair];
@@ -273,10 +285,12 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
 // small windows: one wavefront, 8 planes x 8 slots; large ones: 256 threads, 4 planes x 32 slots
 constexpr int kHessPlanesSmall = 8, kHessPlanesLarge = 4;
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_small(BalmDev b, const Se3* __restrict__ poses) {
-    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, poses, blockIdx.x);
+    __shared__ HessLds<kHessPlanesSmall, 8> lds;
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(b, poses, blockIdx.x, lds);
 }
 __global__ __launch_bounds__(kHessThreads) void k_balm_hessian_large(BalmDev b, const Se3* __restrict__ poses) {
-    d_balm_hessian<kItemsLarge, kHessThreads, kHessPlanesLarge, 32, kMaxLidarWindow>(b, poses, blockIdx.x);
+    __shared__ HessLds<kHessPlanesLarge, kMaxLidarWindow> lds;
+    d_balm_hessian<kItemsLarge, kHessThreads, kHessPlanesLarge, 32, kMaxLidarWindow>(b, poses, blockIdx.x, lds);
 }
 
 // chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one thread per
@@ -349,8 +363,24 @@ __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph,
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPhase ph) {
     const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
     if ((int)blockIdx.x >= v.b.n_chunks) return;
-    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(v.b, v.poses, blockIdx.x);
+    __shared__ HessLds<kHessPlanesSmall, 8> lds;
+    d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(v.b, v.poses, blockIdx.x, lds);
 }
+// The same body with its tables in DYNAMIC LDS and the wavefront held to TC2LI_HESS_WAVES per SIMD.  With the 36 KB declared statically the
+// compiler counts four workgroups per CU -- one wavefront per SIMD -- and lets the body take 325 registers (256 + 69 accumulation
+// registers): alone that costs nothing, but beside the other stages' kernels such a wavefront starts only on a SIMD that has two thirds of
+// its register file free.
+#define TC2LI_HESS_LEAN_KERNEL(name, waves)                                                                                                  \
+    __global__ __launch_bounds__(kHessThreadsSmall) __attribute__((amdgpu_waves_per_eu(waves, waves))) void name(const BaPhase ph) {          \
+        extern __shared__ double s_hess_dyn[];                                                                                               \
+        const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);                                                                        \
+        if ((int)blockIdx.x >= v.b.n_chunks) return;                                                                                         \
+        d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8, true>(v.b, v.poses, blockIdx.x,                               \
+                                                                                     *reinterpret_cast<HessLds<kHessPlanesSmall, 8>*>(s_hess_dyn)); \
+    }
+TC2LI_HESS_LEAN_KERNEL(k_balm_hessian_lean3_b, 3)  // 168 registers, 13 values in scratch
+TC2LI_HESS_LEAN_KERNEL(k_balm_hessian_lean4_b, 4)  // 128 registers, 84 values in scratch
+#undef TC2LI_HESS_LEAN_KERNEL
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaPhase ph) {
     const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
     if ((int)blockIdx.x >= (max(balm_part_stride_dev(v.b.W), 12 * v.b.W) + 255) / 256) return;
@@ -361,7 +391,13 @@ void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_
 }
 void balm_batch_launch_hessian(const BaPhase& ph, int n, const BaBatchExtent& x, hipStream_t st) {
     if (!n) return;
-    TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, ph);
+    // TC2LI_BALM_HESS_LEAN = 0: the 325-register form; 3 (default) / 4: the lean forms (read per call: A/B switch of the measurements)
+    const char* lean_env = getenv("TC2LI_BALM_HESS_LEAN");
+    const int lean = lean_env ? atoi(lean_env) : 3;
+    const size_t lds = sizeof(HessLds<kHessPlanesSmall, 8>);
+    if (lean == 4) TC2LI_LAUNCH(k_balm_hessian_lean4_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph);
+    else if (lean == 3) TC2LI_LAUNCH(k_balm_hessian_lean3_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph);
+    else TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, ph);
     TC2LI_LAUNCH(k_balm_combine_b, dim3((std::max(balm_part_stride(x.max_W), 12 * x.max_W) + 255) / 256, n), dim3(256), 0, st, ph);
 }
 
