@@ -17,6 +17,10 @@ namespace tc2li {
 // pose i gets a product from every slot of pose i, a pair block only from the landmarks both poses see; (Rd, Ro) is the finest cut
 // whose tasks fit the workgroup.
 constexpr int kSchurGroup = 4;
+// The LEAN form of the same product (k_ba_schur_lean, pb.schur_blocks == 2): slices of at most kSchurLeanSlots slots, kSchurGroupLean of
+// them per part -- half the LDS and two thirds of the registers per workgroup, so that beside the other stages' kernels a workgroup
+// finds its place sooner (ba_kernels.hip)
+constexpr int kSchurLeanSlots = 128, kSchurGroupLean = 8;
 constexpr int kSchurBlocksMaxFree = 21;  // every window of the sparse path (np_pad / 16 <= 8): 21 * 20 / 2 + 21 + 21 = 252 tasks
 __host__ __device__ inline int schur_tasks_for(int nf, int rd, int ro) { return rd * nf + ro * (nf * (nf - 1) / 2) + nf; }
 __host__ __device__ inline void schur_ranges(int nf, int& rd, int& ro) {
@@ -46,7 +50,7 @@ struct BaProblemDev {
     float dsqr_mono, dsqr_stereo;
     Se3 *poses, *poses_trial;
     // visual-inertial mode (Optimizer::LocalInertialBA): keyframe poses as ImuCamPose instead of SE3Quat
-    int32_t inertial, pad_;
+    int32_t inertial, schur_group;  // schur_group: slices per part of the block-by-block product (kSchurGroup; the lean form: kSchurGroupLean unless set)
     ImuPose *iposes, *iposes_trial;
     ImuCalib calib;
     double *points, *points_trial;
@@ -60,7 +64,7 @@ struct BaProblemDev {
     // one partial sum per slice; otherwise through the dense k-major operands AT / BT
     // schur_blocks: the sparse product block by block on the f64 vector unit (k_ba_schur_blocks, one partial per kSchurGroup slices)
     // instead of the zero-padded MFMA form (k_ba_schur_sparse4/9, one partial per slice; TC2LI_BA_SCHUR_MFMA=1)
-    int32_t sparse_schur, schur_blocks;
+    int32_t sparse_schur, schur_blocks;  // schur_blocks: 0 MFMA form of the sparse product, 1 block by block, 2 block by block, lean form
     int32_t schur_rd, schur_ro;  // landmark ranges per diagonal / off-diagonal block task (schur_ranges)
     double *chi2, *rho0;
     double *cp_part, *W;                 // per (block of 256 free-pose edges, free pose): 27 (+1) doubles; per free-pose edge (at w_slot): 18
@@ -81,7 +85,7 @@ struct BaProblemDev {
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st);
 // number of partial sums the sparse Schur product of a window with `n_slices` slices leaves in S_part (what `n_slices` means to
 // ba_launch_schur / BaBatchSlot for such a window)
-int ba_schur_parts(int n_slices, bool blocks);
+int ba_schur_parts(int n_slices, int group);  // group: slices per partial sum (pb.schur_group; 1: the MFMA form)
 // S_out [np*np], bs_out [2*np]: b_s followed by b_p
 // lambda_pose: what the finish kernel adds to the diagonal of S (lambda; 0 on the ranks > 0 of a sharded window, whose parts are summed)
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st);
@@ -129,6 +133,7 @@ struct BaBatchExtent {
     int any_dense, max_sparse_np_pad, max_sparse_slices;
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
+    int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int inertial;  // the windows' vertices are ImuCamPose records (LocalLVIBA batch): the linearisation kernel of that vertex type
 };

@@ -102,12 +102,19 @@ struct VisualProblem {
     // fl_off: per landmark [begin, end) of its slots, the landmarks in index order.  (Tried: slots in the order of the poses a landmark
     // is seen from, so that a chunk of the Schur kernel spans a narrow band of poses and the product's empty tiles can be skipped -- the
     // windows' covisibility is not banded enough for that, and the linearisation lost its locality: 64 -> 98 us.)
+    // TC2LI_BA_SCHUR_LEAN (read per window; default 1): the lean form of the block-by-block Schur product (ba_device.hpp); 0: the 256-slot form
+    const char* lean_env = getenv("TC2LI_BA_SCHUR_LEAN");
+    const char* mfma_env0 = getenv("TC2LI_BA_SCHUR_MFMA");
+    const bool schur_lean = (lean_env ? atoi(lean_env) != 0 : true) && (6 * n_free + 1 + 15) / 16 <= 8 && n_free <= kSchurBlocksMaxFree &&
+                            !(mfma_env0 && atoi(mfma_env0) != 0);  // only where the block-by-block form runs (blocks_form below)
     std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
         fl_edge(std::max(n_free_edges, 1)), w_slot(n_edges, -1), slice_off(1, 0);
     {
         // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
         // the window alone, so that a window gives the same bits alone and in a batch
-        constexpr int kSliceEdges = 256, kSliceLandmarks = 64;
+        // (the lean form of the block-by-block product stages half as many slots at a time: kSchurLeanSlots)
+        const int kSliceEdges = schur_lean ? kSchurLeanSlots : 256;
+        constexpr int kSliceLandmarks = 64;
         std::vector<int> seen(std::max(n_free, 1), -1);
         int at = 0, slice_lms = 0;
         for (int l = 0; l < n_points; ++l) {
@@ -157,8 +164,12 @@ struct VisualProblem {
     const char* mfma_env = getenv("TC2LI_BA_SCHUR_MFMA");
     const bool blocks_form = sparse && n_free <= kSchurBlocksMaxFree && !(mfma_env && atoi(mfma_env) != 0);
     const int n_schur_slices = (int)slice_off.size() - 1;
+    int schur_group = 1;
     if (sparse) {
-        n_slices = ba_schur_parts(n_schur_slices, blocks_form);  // partial sums in S_part
+        // TC2LI_BA_SCHUR_GROUP (measurements): slices per part of the lean form
+        const char* grp_env = getenv("TC2LI_BA_SCHUR_GROUP");
+        schur_group = !blocks_form ? 1 : !schur_lean ? kSchurGroup : grp_env ? std::max(1, std::min(64, atoi(grp_env))) : kSchurGroupLean;
+        n_slices = ba_schur_parts(n_schur_slices, schur_group);  // partial sums in S_part
         k_per_slice = 0;
     } else {
         n_slices = std::max(1, std::min(64, k_total / 64));
@@ -247,7 +258,7 @@ struct VisualProblem {
     pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
     pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
     pb.ticket = (int32_t*)(d + o_ticket);
-    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? 1 : 0; pb.n_schur_slices = sparse ? n_schur_slices : 0;
+    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = sparse ? n_schur_slices : 0;
     pb.schur_rd = pb.schur_ro = 1;
     if (blocks_form) {
         schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
@@ -1308,6 +1319,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
                 X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
+                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
             }
         } else if (pb.sparse_schur) {
             X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
@@ -1765,6 +1777,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
                 X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
+                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
             }
         } else if (pb.sparse_schur) {
             X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);

@@ -14,6 +14,7 @@
 // Launches that only depend on the same earlier results share one grid (a dependent launch costs ~10 us on its own).
 // All arithmetic is double precision; reductions run in a fixed order, so results are reproducible run to run.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <cstdlib>
 
 #include "launch.hpp"
@@ -810,6 +811,177 @@ __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks(BaProblemDev pb, dou
     d_ba_schur_blocks(pb, blockIdx.x, lambda, s_schur);
 }
 
+// ---- the same product, LEAN (pb.schur_blocks == 2; round 4, last session) ----
+// k_ba_schur_blocks asks for 80 KB of LDS and 256 registers per lane: alone that is two workgroups per CU and costs nothing, but beside the
+// other stages' kernels such a workgroup starts only on a CU that has half its LDS and half of every SIMD's register file free at the
+// same moment -- the launch took 340-430 us in the loop against 62 us alone (the plane Hessian showed the same and lost a fifth of its
+// in-loop time with its registers cut, balm_kernels.hip).  Here: slices of at most 128 slots (cut by the host, ba_host.cpp), eight per
+// part; threads 0..127 stage a slot each, all 256 are tasks as before; no block is held in registers across the task loop (the other
+// workgroups of the CU cover a workgroup's loads: three fit); the closing sums go through LDS in range order -- the range tasks of a
+// block add themselves one after the other, ((a0 + a1) + a2) + ..., the last one writes the block -- so the operand area (39 KB) is
+// all the LDS the kernel needs.  Same arithmetic per product and the same order rules as above (a function of the window alone); the
+// bits differ from the 256-slot form's because the slices do.
+__host__ __device__ inline size_t schur_lean_lds_bytes(int nf) {
+    return (size_t)kSchurLeanSlots * kSchurOps * sizeof(double) + 64 * 3 * sizeof(double) + 2 * (size_t)nf * 8 + 64 * (size_t)nf;
+}
+__device__ __forceinline__ void d_ba_schur_lean(const BaProblemDev& pb, const int part, const double lambda, double* __restrict__ lds) {
+    const int tid = threadIdx.x, NF = pb.n_free, np = 6 * NF, ld = pb.np_pad;
+    const int Rd = pb.schur_rd, Ro = pb.schur_ro;
+    const int nD = Rd * NF, nO = Ro * (NF * (NF - 1) / 2), nT = nD + nO + NF;
+    double* const ops = lds;
+    double* const dbl = lds + kSchurLeanSlots * kSchurOps;                                   // [64][3]: D^-1 b_l by landmark rank
+    unsigned long long* const masks = reinterpret_cast<unsigned long long*>(dbl + 64 * 3);   // [2][NF]: landmarks of the slice a pose sees
+    unsigned char* const slot_of = reinterpret_cast<unsigned char*>(masks + 2 * NF);         // [64][NF]: the slot of (landmark rank, pose)
+    // ---- this thread's task (the numbering of d_ba_schur_blocks) ----
+    int t_i = 0, t_j = 0, t_kind = -1, t_q = 0, t_R = 1, t_close = -1;  // t_close: the block's place in the closing area (blocks of more than one range)
+    unsigned long long t_sel = 0;
+    if (tid < nD) {
+        t_i = t_j = tid / Rd; t_q = tid - t_i * Rd; t_R = Rd; t_sel = schur_range_mask(Rd, t_q); t_kind = 0;
+        t_close = t_i;
+    } else if (tid < nD + nO) {
+        const int n = (tid - nD) / Ro;  // pair number i (i - 1) / 2 + j, i > j
+        int i = 1;
+        while (i * (i + 1) / 2 <= n) ++i;
+        t_i = i; t_j = n - i * (i - 1) / 2; t_q = (tid - nD) - n * Ro; t_R = Ro; t_sel = schur_range_mask(Ro, t_q); t_kind = 0;
+        t_close = (Rd > 1 ? NF : 0) + n;
+    } else if (tid < nT) { t_i = t_j = tid - nD - nO; t_sel = ~0ull; t_kind = 1; }
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+    const int sl0 = part * pb.schur_group, sl1 = min(sl0 + pb.schur_group, pb.n_schur_slices);
+#pragma unroll 1
+    for (int slice = sl0; slice < sl1; ++slice) {
+        // two mask buffers in turn: this slice's is cleared while the tasks of the previous slice may still read theirs
+        unsigned long long* const mask = masks + ((slice - sl0) & 1) * NF;
+        if (tid < NF) mask[tid] = 0ull;
+        const int s = pb.slice_off[slice] + tid;
+        const bool have = tid < kSchurLeanSlots && s < pb.slice_off[slice + 1];
+        int l = 0, key = 0;
+        if (have) {  // the indices are asked for before the barrier, the blocks after it: nothing large is held while the workgroup waits
+            l = pb.fl_lm[s];
+            // a slice starts with a landmark's first slot (slices are whole landmarks)
+            key = pb.fl_place[s] | pb.fl_pose[s] << 8 | (tid == 0 || pb.fl_lm[s - 1] != l ? 1 << 16 : 0);
+        }
+        __syncthreads();  // the masks are clear; the previous slice's tasks have read the operands and the slot table
+        if (have) {
+            const int place = key & 255, pose = (key >> 8) & 255;
+            double h[6];
+            load_d2<6>(pb.Hll + 6 * (size_t)l, h);
+            const double* b = pb.bl + 3 * (size_t)l;
+            const double b0 = b[0], b1 = b[1], b2 = b[2];
+            const double* const Wg = pb.W + 18 * (size_t)s;
+            double W01[6], W23[6], W45[6];  // the block two rows at a time: requested together, used one pair after the other
+            load_d2<6>(Wg, W01); load_d2<6>(Wg + 6, W23); load_d2<6>(Wg + 12, W45);
+            slot_of[place * NF + pose] = (unsigned char)tid;
+            atomicOr(&mask[pose], 1ull << place);
+            // (Hll + lambda I)^-1 and its product with b_l: the arithmetic of point_dinv (the back substitution forms the same inverse)
+            const double d00 = h[0] + lambda, d01 = h[1], d02 = h[2], d11 = h[3] + lambda, d12 = h[4], d22 = h[5] + lambda;
+            const double c00 = d11 * d22 - d12 * d12, c01 = d12 * d02 - d01 * d22, c02 = d01 * d12 - d11 * d02;
+            const double det = d00 * c00 + d01 * c01 + d02 * c02, id = 1.0 / det;
+            double Di[9];
+            Di[0] = c00 * id; Di[1] = (d02 * d12 - d01 * d22) * id; Di[2] = (d01 * d12 - d02 * d11) * id;
+            Di[3] = c01 * id; Di[4] = (d00 * d22 - d02 * d02) * id; Di[5] = (d02 * d01 - d00 * d12) * id;
+            Di[6] = c02 * id; Di[7] = (d01 * d02 - d00 * d12) * id; Di[8] = (d00 * d11 - d01 * d01) * id;
+            if (key >> 16) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dbl[3 * place + r] = Di[3 * r] * b0 + Di[3 * r + 1] * b1 + Di[3 * r + 2] * b2;
+            }
+            double* const o = ops + tid * kSchurOps;
+            // Y = W D^-1, two rows (three 16-byte pieces) at a time, W beside it
+            auto rows = [&](const double (&w)[6], int r) {
+                double y[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const int rr = e / 3, c = e % 3;
+                    y[e] = w[3 * rr] * Di[c] + w[3 * rr + 1] * Di[3 + c] + w[3 * rr + 2] * Di[6 + c];
+                }
+                store_d2<6>(o + 3 * r, y);
+                store_d2<6>(o + 18 + 3 * r, w);
+            };
+            rows(W01, 0); rows(W23, 2); rows(W45, 4);
+        }
+        __syncthreads();
+        if (t_kind == 0) {
+            unsigned long long m = mask[t_i] & mask[t_j] & t_sel;
+            while (m) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                // W_j whole, Y_i two rows at a time (the same three-term chains per entry as the 256-slot form: fewer values held at once)
+                const double* const yp = ops + (int)slot_of[p * NF + t_i] * kSchurOps;
+                double w[18];
+                load_d2<18>(ops + (int)slot_of[p * NF + t_j] * kSchurOps + 18, w);
+#pragma unroll
+                for (int r = 0; r < 6; r += 2) {
+                    double y[6];
+                    load_d2<6>(yp + 3 * r, y);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int c = 0; c < 6; ++c)
+                            acc[6 * (r + e) + c] = __builtin_fma(y[3 * e + 2], w[3 * c + 2], __builtin_fma(y[3 * e + 1], w[3 * c + 1], __builtin_fma(y[3 * e], w[3 * c], acc[6 * (r + e) + c])));
+                }
+            }
+        } else if (t_kind == 1) {
+            unsigned long long m = mask[t_i];
+            while (m) {
+                const int p = __builtin_ctzll(m);
+                m &= m - 1;
+                const double* Wa = ops + (int)slot_of[p * NF + t_i] * kSchurOps + 18;
+                const double d0 = dbl[3 * p], d1 = dbl[3 * p + 1], d2 = dbl[3 * p + 2];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[r] = __builtin_fma(Wa[3 * r + 2], d2, __builtin_fma(Wa[3 * r + 1], d1, __builtin_fma(Wa[3 * r], d0, acc[r])));
+            }
+        }
+    }
+    // ---- the part's sums: the ranges of a block one after the other through its place in LDS, the last one keeps the sum ----
+    const int Rmax = max(Rd, Ro);
+    double* const cl = ops + 36 * max(t_close, 0);
+    const bool ranged = t_kind == 0 && t_R > 1;
+    for (int q = 0; q + 1 < Rmax; ++q) {
+        __syncthreads();  // q == 0: the last slice's tasks have read the operands; later: range q - 1 is in place
+        if (ranged && t_q == q && q + 1 < t_R) {
+            if (q == 0) {
+                store_d2<36>(cl, acc);
+            } else {
+#pragma unroll
+                for (int hk = 0; hk < 36; hk += 12) {  // a third at a time: few values held beside the 36 sums
+                    double v[12];
+                    load_d2<12>(cl + hk, v);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) v[k] = v[k] + acc[hk + k];
+                    store_d2<12>(cl + hk, v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* const out = pb.S_part + (size_t)part * ld * ld;
+    if (t_kind == 0 && t_q == t_R - 1) {
+        if (t_R > 1) {
+#pragma unroll
+            for (int hk = 0; hk < 36; hk += 12) {
+                double v[12];
+                load_d2<12>(cl + hk, v);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) acc[hk + k] = v[k] + acc[hk + k];
+            }
+        }
+        double* const o = out + (size_t)(6 * t_i) * ld + 6 * t_j;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (t_i != t_j || c <= r) o[(size_t)r * ld + c] = acc[6 * r + c];  // the lower triangle, like the 256-slot form
+    } else if (t_kind == 1) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) out[(size_t)np * ld + 6 * t_i + r] = acc[r];  // row np: sum_l W D^-1 b_l
+    }
+}
+__global__ __launch_bounds__(256, 3) void k_ba_schur_lean(BaProblemDev pb, double lambda) {
+    extern __shared__ double s_schur[];
+    d_ba_schur_lean(pb, blockIdx.x, lambda, s_schur);
+}
+
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out, double* __restrict__ bp_host = nullptr) {
     const int np = 6 * pb.n_free, idx = bx * 256 + threadIdx.x;
@@ -1088,8 +1260,14 @@ __device__ __forceinline__ bool ba_last_of(int32_t* ticket, int n_workgroups) {
 __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || !pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    if (!pb.sparse_schur || pb.schur_blocks != 1 || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
     d_ba_schur_blocks(pb, blockIdx.x, view_.lambda, s_schur);
+}
+__global__ __launch_bounds__(256, 3) void k_ba_schur_lean_b(const BaPhase ph) {
+    extern __shared__ double s_schur[];
+    TC2LI_SLOT(y);
+    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_lean(pb, blockIdx.x, view_.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
@@ -1229,7 +1407,7 @@ static inline size_t schur_lds_bytes(int np_pad) {
     return 2 * 3 * (size_t)(np_pad / 16 <= 5 ? kSchurChunkSmall : kSchurChunkLarge) * schur_ldw(np_pad) * sizeof(double);
 }
 
-int ba_schur_parts(int n_slices, bool blocks_form) { return blocks_form ? (n_slices + kSchurGroup - 1) / kSchurGroup : n_slices; }
+int ba_schur_parts(int n_slices, int group) { return (n_slices + group - 1) / group; }
 
 // the block-by-block kernels need more than the 64 KB of dynamic LDS a kernel gets by default
 static void schur_blocks_attr() {  // a refusal shows as the launch's own error (the callers check hipGetLastError)
@@ -1240,7 +1418,9 @@ static void schur_blocks_attr() {  // a refusal shows as the launch's own error 
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
     const int np = 6 * pb.n_free;
-    if (pb.sparse_schur && pb.schur_blocks) {
+    if (pb.sparse_schur && pb.schur_blocks == 2) {
+        if (n_slices) TC2LI_LAUNCH(k_ba_schur_lean, dim3(n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
+    } else if (pb.sparse_schur && pb.schur_blocks) {
         if (n_slices) {
             schur_blocks_attr();
             TC2LI_LAUNCH(k_ba_schur_blocks, dim3(n_slices), dim3(256), schur_blocks_lds_bytes(pb.n_free), st, pb, lambda);
@@ -1281,10 +1461,14 @@ void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExt
 }
 void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
-    if (x.max_block_parts) {
+    if (x.max_block_parts && x.any_block_fat) {
         schur_blocks_attr();
         TC2LI_LAUNCH(k_ba_schur_blocks_b, dim3(x.max_block_parts, n_active), dim3(256), schur_blocks_lds_bytes(x.max_block_free), st, ph);
     }
+    // (the lean form held to four wavefronts per SIMD -- 128 registers, 116 B of scratch -- measured 87 against 69 us alone and 294-317 against
+    // 290-294 us in the loop: not kept)
+    if (x.max_block_parts && x.any_block_lean)
+        TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts, n_active), dim3(256), schur_lean_lds_bytes(x.max_block_free), st, ph);
     if (x.max_sparse_slices) {
         const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
         if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);

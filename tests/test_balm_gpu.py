@@ -191,9 +191,11 @@ def test_mixed_batch_falls_back_per_group(pkg, synthetic, fuse, monkeypatch):
             assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual, i
 
 
-def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic):
+@pytest.mark.parametrize("schur", ["lean", "256-slot"])  # k_ba_schur_lean_b (default) / k_ba_schur_blocks_b
+def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic, monkeypatch, schur):
     """The windows bench.py times (12 free + 20 fixed keyframes, 3000 points, LiDAR edge over 6 keyframes x 3000 points), through the
     lock-step batch entry, against the oracle directly: same iterations and LM trials, same planes, poses <= 1e-4 relative."""
+    monkeypatch.setenv("TC2LI_BA_SCHUR_LEAN", "1" if schur == "lean" else "0")
     windows, wants = [], []
     for seed in (40, 41, 42, 43):
         w = synthetic.ba_window(seed, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
