@@ -871,8 +871,7 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # these FLOPs at this covisibility, 55 % of the measured matrix peak when it has the GPU to itself -- DESIGN.md section 4.)
             # (since round 3 the default is k_ba_schur_blocks_b: exactly these products, on the f64 vector unit; the MFMA form is TC2LI_BA_SCHUR_MFMA=1)
             "k_ba_schur_blocks_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),
-            "k_ba_schur_lean_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),
-            "k_ba_schur_lean4_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),  # the same products in 128-slot slices (TC2LI_BA_SCHUR_LEAN)
+            "k_ba_schur_lean_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),  # the same products in 128-slot slices (the default since round 4)
             "k_ba_schur_sparse4_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_sparse9_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
