@@ -48,18 +48,25 @@ __host__ __device__ inline void matrix_to_quat(const double R[9], double q[4]) {
         t = 0.5 / t;
         q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
     } else {
+        // the largest diagonal element decides the case; each case with constant indices (the same operations in the same order as the
+        // indexed form -- which kept R and q in scratch memory on the device: every access a trip to memory beside the other stages' kernels)
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t;
-        t = 0.5 / t;
-        qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+#define TC2LI_QUAT_CASE(I, J, K)                                          \
+    {                                                                     \
+        t = sqrt(R[4 * I] - R[4 * J] - R[4 * K] + 1.0);                     \
+        const double qi = 0.5 * t;                                        \
+        t = 0.5 / t;                                                     \
+        q[3] = (R[3 * K + J] - R[3 * J + K]) * t;                         \
+        q[J] = (R[3 * J + I] + R[3 * I + J]) * t;                         \
+        q[K] = (R[3 * K + I] + R[3 * I + K]) * t;                         \
+        q[I] = qi;                                                        \
+    }
+        if (i == 0) TC2LI_QUAT_CASE(0, 1, 2)
+        else if (i == 1) TC2LI_QUAT_CASE(1, 2, 0)
+        else TC2LI_QUAT_CASE(2, 0, 1)
+#undef TC2LI_QUAT_CASE
     }
 }
 // SE3Quat::exp(update) * T  (VertexSE3Expmap::oplusImpl, types_six_dof_expmap.h:73-76)

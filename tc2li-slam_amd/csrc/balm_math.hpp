@@ -32,18 +32,25 @@ __host__ __device__ inline void matrix_to_quat_f(const float R[9], float q[4]) {
         t = 0.5f / t;
         q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
     } else {
+        // the largest diagonal element decides the case; each case with constant indices (the same operations in the same order as the
+        // indexed form -- which kept R and q in scratch memory on the device: every access a trip to memory beside the other stages' kernels)
         int i = 0;
         if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrtf(R[4 * i] - R[4 * j] - R[4 * k] + 1.0f);
-        float qq[4];
-        qq[i] = 0.5f * t;
-        t = 0.5f / t;
-        qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        if (R[8] > (i == 1 ? R[4] : R[0])) i = 2;
+#define TC2LI_QUAT_CASE(I, J, K)                                          \
+    {                                                                     \
+        t = sqrtf(R[4 * I] - R[4 * J] - R[4 * K] + 1.0f);                     \
+        const float qi = 0.5f * t;                                        \
+        t = 0.5f / t;                                                     \
+        q[3] = (R[3 * K + J] - R[3 * J + K]) * t;                         \
+        q[J] = (R[3 * J + I] + R[3 * I + J]) * t;                         \
+        q[K] = (R[3 * K + I] + R[3 * I + K]) * t;                         \
+        q[I] = qi;                                                        \
+    }
+        if (i == 0) TC2LI_QUAT_CASE(0, 1, 2)
+        else if (i == 1) TC2LI_QUAT_CASE(1, 2, 0)
+        else TC2LI_QUAT_CASE(2, 0, 1)
+#undef TC2LI_QUAT_CASE
     }
     const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
@@ -151,13 +158,17 @@ __host__ __device__ inline void eig_sym3(const double* Ain, double lambda[3], do
             }
     }
     int o0 = 0, o1 = 1, o2 = 2;
-    if (A[4 * o1] < A[4 * o0]) { const int t = o0; o0 = o1; o1 = t; }
-    if (A[4 * o2] < A[4 * o0]) { const int t = o0; o0 = o2; o2 = t; }
-    if (A[4 * o2] < A[4 * o1]) { const int t = o1; o1 = o2; o2 = t; }
+    const double dgn[3] = {A[0], A[4], A[8]};
+    auto diag = [&](int o) { return o == 0 ? dgn[0] : o == 1 ? dgn[1] : dgn[2]; };
+    if (diag(o1) < diag(o0)) { const int t = o0; o0 = o1; o1 = t; }
+    if (diag(o2) < diag(o0)) { const int t = o0; o0 = o2; o2 = t; }
+    if (diag(o2) < diag(o1)) { const int t = o1; o1 = o2; o2 = t; }
+    // (selected with comparisons, not indexed: an index known only at run time would put A and V into scratch memory on the device)
     const int ord[3] = {o0, o1, o2};
     for (int k = 0; k < 3; ++k) {
-        lambda[k] = A[4 * ord[k]];
-        for (int r = 0; r < 3; ++r) U[3 * r + k] = V[3 * r + ord[k]];
+        const int o = ord[k];
+        lambda[k] = o == 0 ? A[0] : o == 1 ? A[4] : A[8];
+        for (int r = 0; r < 3; ++r) U[3 * r + k] = o == 0 ? V[3 * r] : o == 1 ? V[3 * r + 1] : V[3 * r + 2];
     }
 }
 
