@@ -21,9 +21,10 @@ constexpr int kSchurGroup = 4;
 // them per part -- half the LDS and two thirds of the registers per workgroup, so that beside the other stages' kernels a workgroup
 // finds its place sooner (ba_kernels.hip)
 constexpr int kSchurLeanSlots = 128, kSchurGroupLean = 8;
+constexpr int kSchurOps = 38;  // doubles per slot in LDS: Y row-major [6][3] | W row-major [6][3] | 2 of padding (16-byte aligned blocks that spread over all banks)
 constexpr int kSchurBlocksMaxFree = 21;  // every window of the sparse path (np_pad / 16 <= 8): 21 * 20 / 2 + 21 + 21 = 252 tasks
-__host__ __device__ inline int schur_tasks_for(int nf, int rd, int ro) { return rd * nf + ro * (nf * (nf - 1) / 2) + nf; }
-__host__ __device__ inline void schur_ranges(int nf, int& rd, int& ro) {
+__host__ __device__ constexpr int schur_tasks_for(int nf, int rd, int ro) { return rd * nf + ro * (nf * (nf - 1) / 2) + nf; }
+__host__ __device__ constexpr void schur_ranges(int nf, int& rd, int& ro) {
     // measured at 12 free keyframes (43 windows, us per launch): (5,2) 65, (4,2) 71, (3,2) 70, (3,3) 76, (2,1) 78, (1,1) 84
     const int pref[7][2] = {{5, 2}, {4, 2}, {3, 2}, {2, 2}, {3, 1}, {2, 1}, {1, 1}};
     for (int k = 0; k < 7; ++k) { rd = pref[k][0]; ro = pref[k][1]; if (schur_tasks_for(nf, rd, ro) <= 256) return; }
@@ -35,6 +36,23 @@ __host__ __device__ inline unsigned long long schur_range_mask(int R, int q) {
     const unsigned long long upto_hi = hi >= 64 ? ~0ull : (1ull << hi) - 1, upto_lo = (1ull << lo) - 1;
     return upto_hi & ~upto_lo;
 }
+
+// The lean form adds a block's range tasks up through the operand area of its LDS (36 doubles per block of more than one range): every
+// window of the block-by-block path must fit (a change of the preference table above that breaks this fails the build)
+__host__ __device__ constexpr int schur_lean_closing_blocks(int nf) {
+    int rd = 1, ro = 1;
+    schur_ranges(nf, rd, ro);
+    return (rd > 1 ? nf : 0) + (ro > 1 ? nf * (nf - 1) / 2 : 0);
+}
+constexpr bool schur_lean_fits_all() {
+    for (int nf = 1; nf <= kSchurBlocksMaxFree; ++nf) {
+        int rd = 1, ro = 1;
+        schur_ranges(nf, rd, ro);
+        if (schur_tasks_for(nf, rd, ro) > 256 || 36 * schur_lean_closing_blocks(nf) > kSchurLeanSlots * kSchurOps) return false;
+    }
+    return true;
+}
+static_assert(schur_lean_fits_all(), "k_ba_schur_lean: tasks or closing sums of some window size do not fit the workgroup");
 
 // One local-BA problem resident on the device.  Free (non-fixed) poses are numbered 0..n_free-1 through pose_var;
 // pt_* is a CSR of the edges of each landmark, pv_* a CSR of the edges of each free pose (n_free_edges in total).

@@ -667,7 +667,6 @@ __global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, doubl
 // MFMA form's: the lower triangle of [np_pad][np_pad] per part and the coefficient row np, so k_ba_schur_finish adds the parts as before.
 // Slot stride in LDS 38 doubles: 16-byte aligned blocks that spread over all banks (at 36 doubles every read of a wavefront met
 // 16-way conflicts).
-constexpr int kSchurOps = 38;  // doubles per slot in LDS: Y row-major [6][3] | W row-major [6][3] | 2 of padding
 __host__ __device__ inline size_t schur_blocks_lds_bytes(int nf) {
     const size_t ops = 256 * kSchurOps * sizeof(double), outs = (size_t)256 * 36 * sizeof(double);
     return (ops > outs ? ops : outs) + 64 * 3 * sizeof(double) + 2 * (size_t)nf * 8 + 64 * (size_t)nf;
