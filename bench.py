@@ -466,6 +466,18 @@ class Loop:
             self.ba_batch2 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(2 * n_ba)], wl.ba_windows[0]["cam"])
             if F <= 64 or multi >= 4:
                 self.ba_batch4 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(4 * n_ba)], wl.ba_windows[0]["cam"])
+        # Beyond 256 sequences the mapping stage runs free, and its windows go to a POOL of mapping workers, each a lock-step group of its
+        # own (tc2li_local_bundle_adjustment_batch_group): a step's windows are dealt into as many chunks as there are workers, a worker takes
+        # the next chunk when it is free.  (The one call per step made its three groups meet at its end: a step's groups take 20-30 ms
+        # beside the other stages, and the call took the slowest.  The reference has a LocalMapping thread per sequence.)
+        # TC2LI_BENCH_BA_WORKERS=0: the one call per step.
+        self.ba_workers = []
+        n_workers = int(os.environ.get("TC2LI_BENCH_BA_WORKERS", "3"))
+        if type(self) is Loop and self.ba_batch is not None and self.ba_batch2 is None and n_workers >= 2 and n_ba >= 8 * n_workers and self.ba_rate == n_ba:
+            self.ba_chunk_sizes = [n_ba * (c + 1) // n_workers - n_ba * c // n_workers for c in range(n_workers)]
+            cam = wl.ba_windows[0]["cam"]
+            for w in range(n_workers):  # a worker's own batches, one per chunk size (the windows are the same four, tiled)
+                self.ba_workers.append({n: pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n)], cam) for n in set(self.ba_chunk_sizes)})
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
@@ -665,6 +677,26 @@ class Loop:
                 self.ba_step(m)
                 done += m
 
+        ba_jobs = {"next": 0}
+        ba_lock = threading.Lock()
+
+        def make_ba_worker(w):
+            def fn():
+                n_chunks = len(self.ba_chunk_sizes)
+                while not failed.is_set():
+                    with ba_lock:
+                        j = ba_jobs["next"]
+                        ba_jobs["next"] += 1
+                    if j >= n_steps * n_chunks:
+                        return
+                    b = self.ba_workers[w][self.ba_chunk_sizes[j % n_chunks]]
+                    if b.run_group(w) != b.n:
+                        raise RuntimeError("a local BA window failed")
+                    with ba_lock:
+                        self.ba_windows_done += b.n
+            fn.__name__ = "ba_worker%d_thread" % w
+            return fn
+
         want = set(stages)
         if "track" in want:
             want.add("orb")  # tracking consumes what the extraction produces
@@ -672,6 +704,8 @@ class Loop:
                if f.__name__.split("_")[0].rstrip("2") in want]
         if not self.ba_batch:
             fns = [f for f in fns if f is not ba_thread]
+        elif self.ba_workers and ba_thread in fns:
+            fns = [f for f in fns if f is not ba_thread] + [make_ba_worker(w) for w in range(len(self.ba_workers))]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
             for _ in range(n_steps):
                 free.put(0)
@@ -696,6 +730,8 @@ class Loop:
             d.wait()
         if errors:
             raise errors[0]
+        if self.ba_workers and any(k.startswith("ba_worker") for k in self.thread_ms):
+            self.thread_ms["ba_thread"] = max(v for k, v in self.thread_ms.items() if k.startswith("ba_worker"))  # local mapping is done when its last worker is
 
     def close(self):
         for w in self.workers.values():
@@ -1609,7 +1645,9 @@ def main(argv=None):
                                  "mapping, each on its own host thread and HIP stream (the reference's tracking / LiDAR / local-mapping threads; with batched "
                                  "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
                                  "processed one batch" + ("; local mapping follows the tracking thread and takes the keyframes of the steps tracked since its last call, at most %d "
-                                                          "steps' per call" % (4 if loop.ba_batch4 is not None else 2) if loop.ba_batch2 is not None else "; the LiDAR stream has high priority"),
+                                                          "steps' per call" % (4 if loop.ba_batch4 is not None else 2) if loop.ba_batch2 is not None else "; the LiDAR stream has high priority") +
+                                 ("; local mapping = %d mapping workers, each a lock-step group of its own (tc2li_local_bundle_adjustment_batch_group), taking the steps' "
+                                  "windows chunk by chunk (%s windows)" % (len(loop.ba_workers), "/".join(str(n) for n in loop.ba_chunk_sizes)) if loop.ba_workers else ""),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": host_budget,
                 "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),

@@ -639,6 +639,13 @@ typedef struct tc2li_ba_problem {
 } tc2li_ba_problem;
 int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam,
                                         int max_concurrency, int32_t* results);
+/* The same for callers that run several local-mapping workers of their own (one LocalMapping thread per sequence in the reference,
+ * SF/src/LocalMapping.cc:66-160; a multi-sequence system has a pool of them): the windows of this call form ONE lock-step group on the
+ * context `group` (0 .. 7: its stream, device work spaces and host pool).  Calls on different groups run side by side and return
+ * independently -- no worker waits for the slowest group of a common call --, calls on the same group serialise.  Every window's result is
+ * the one tc2li_local_bundle_adjustment_batch / tc2li_local_lv_bundle_adjustment give for it. */
+int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int group,
+                                              int32_t* results);
 
 /* One window split over the GPUs of a node (BASELINE configs[4]): the landmarks -- and with them the stereo / mono
  * edges, W, Hll and the back-substitution -- are partitioned over the ranks (landmark l belongs to rank l % world); every rank

@@ -110,6 +110,7 @@ def lib():
     L.tc2li_track_motion_model_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
     L.tc2li_local_bundle_adjustment_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_local_bundle_adjustment_batch_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_lidar_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.tc2li_imu_preintegrated_init.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
     L.tc2li_imu_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
@@ -1477,6 +1478,15 @@ class BaBatch:
             k[1][...] = x0
         return _check(lib().tc2li_local_bundle_adjustment_batch(C.addressof(self.arr), self.n, self.cam5.ctypes.data, max_concurrency,
                                                                 self.results.ctypes.data))
+
+    def run_group(self, group):
+        """The same as ONE lock-step group on the library's context `group` (tc2li_local_bundle_adjustment_batch_group): for callers with
+        several mapping workers, each on a group of its own."""
+        for (p0, x0), k in zip(self.init, self.keep):
+            k[0][...] = p0
+            k[1][...] = x0
+        return _check(lib().tc2li_local_bundle_adjustment_batch_group(C.addressof(self.arr), self.n, self.cam5.ctypes.data, int(group),
+                                                                      self.results.ctypes.data))
 
     def result(self, i):
         k = self.keep[i]

@@ -2099,6 +2099,31 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     return ok;
 }
 
+int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int group, int32_t* results) {
+    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam || group < 0 || group >= kMaxLockstepGroups) {
+        set_error("tc2li_local_bundle_adjustment_batch_group: invalid argument (group 0 .. %d)", kMaxLockstepGroups - 1);
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_problems == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
+    // ONE lock-step group on the caller's thread: the context `group` (stream, work spaces, host pool) is the caller's choice, so that the
+    // mapping workers of a multi-sequence system run their windows side by side without meeting at the end of a common call
+    bool done = false;
+    if (n_problems > 1 && !kNoLockstep) done = ba_batch_lockstep(problems, n_problems, cam, named_pool(kPoolBaGroup0 + group), results, group);
+    if (!done) {  // a window outside the batched kernels' range (the group has written nothing but zeroed stats), or a batch of one
+        for (int i = 0; i < n_problems; ++i) {
+            const tc2li_ba_problem& p = problems[i];
+            results[i] = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam, p.iterations,
+                                                          p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats, p.lidar,
+                                                          p.lidar_stats, private_stream());
+        }
+    }
+    int ok = 0;
+    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
+    return ok;
+}
+
 int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
                                             int max_concurrency, int32_t* results) {
     if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam) { set_error("tc2li_local_lvi_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }

@@ -217,3 +217,39 @@ def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, sy
         for k in range(len(poses)):
             assert rel_pose_err(poses[k], want[0][k]) < POSE_RTOL, (i, k)
         assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6) and np.array_equal(dpos, want[3])
+
+
+def test_group_call_equals_the_batch_call(pkg, synthetic):
+    """tc2li_local_bundle_adjustment_batch_group (one lock-step group on a context of the caller's choice: the mapping workers of a
+    multi-sequence system) gives every window the result of the common batch call, bit for bit; two groups side by side do not disturb
+    each other; a group number outside 0 .. 7 is refused."""
+    import threading
+    windows = []
+    for seed in range(6):
+        w = synthetic.ba_window(30 + seed, n_opt=8, n_fix=8, n_points=700, pose_noise=(0.1, 0.01))
+        d = dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]))
+        if seed % 2 == 0:
+            last = len(w["poses"]) - 1
+            win = list(range(last, last - 4, -1))
+            d.update(win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=2000), Tcl7=synthetic.TCL7, weight=1.0)
+        windows.append(d)
+        cam = w["cam"]
+    ref = pkg.capi.BaBatch(windows, cam)
+    assert ref.run(max_concurrency=8) == len(windows)
+    want = [tuple(np.array(a, copy=True) for a in ref.result(i)[:4]) + (ref.result(i)[4].iterations, ref.result(i)[4].trials, ref.result(i)[4].final_chi2)
+            for i in range(len(windows))]
+    a, b = pkg.capi.BaBatch(windows, cam), pkg.capi.BaBatch(windows, cam)
+    got = {}
+    ts = [threading.Thread(target=lambda bb=bb, g=g: got.__setitem__(g, bb.run_group(g))) for bb, g in ((a, 1), (b, 5))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == {1: len(windows), 5: len(windows)}
+    for batch in (a, b):
+        for i, wnt in enumerate(want):
+            r = batch.result(i)
+            assert all(np.array_equal(r[k], wnt[k]) for k in range(4)), i
+            assert (r[4].iterations, r[4].trials, r[4].final_chi2) == wnt[4:], i
+    with pytest.raises(pkg.Tc2liError):
+        a.run_group(8)
