@@ -560,6 +560,13 @@ class Loop:
         na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, self.states, stream=self.lidar_stream.cuda_stream)
         self.map_adds = [int(na.sum()), int(nn.sum())]
 
+    def ba_stats_batch(self):
+        """The batch whose statistics describe the windows the loop has optimised."""
+        if not self.ba_workers:
+            return self.ba_batch
+        ran = [b for w in self.ba_workers for b in w.values() if b.stats[0].iterations > 0]  # (a worker may not have met every chunk size)
+        return ran[0] if ran else next(iter(self.ba_workers[0].values()))
+
     def ba_step(self, m=1):
         """The local-mapping work of m (1, 2 or 4) steps."""
         self.ba_due += m * self.ba_rate
@@ -1447,7 +1454,8 @@ def main(argv=None):
         report = pkg.capi.profile_report()
         ba = None
         if loop.ba_batch:
-            s0, ls0 = loop.ba_batch.stats[0], loop.ba_batch.lstats[0]
+            sb = loop.ba_stats_batch()  # (with mapping workers the step's windows run in the workers' batches, not in loop.ba_batch)
+            s0, ls0 = sb.stats[0], sb.lstats[0]
             w0 = wl.ba_windows[0]
             free_edge = np.asarray(w0["fixed"])[np.asarray(w0["edges6"])[:, 1].astype(int)] == 0
             f_l = np.bincount(np.asarray(w0["edges6"])[free_edge, 0].astype(int), minlength=len(w0["points"]))
@@ -1656,8 +1664,8 @@ def main(argv=None):
                                                                round(float(np.mean(tlm_out[4])), 1)],
                 "scan_points_raw/preprocessed/downsampled/selected": lid_mean,
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
-                "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_batch.stats[0].iterations), "trials": int(loop.ba_batch.stats[0].trials),
-                                                      "planes": int(loop.ba_batch.lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
+                "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_stats_batch().stats[0].iterations), "trials": int(loop.ba_stats_batch().stats[0].trials),
+                                                      "planes": int(loop.ba_stats_batch().lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
             "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "host_fed": host_fed, "inertial_config": inertial, "mfma_config": mfma, "sequences_per_gpu_sweep": sweep, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
             "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
