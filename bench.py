@@ -1398,6 +1398,9 @@ def main(argv=None):
     cpu1 = os.times()
     host_budget["cpu_s_per_wall_s_timed_region"] = round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(local_elapsed, 1e-9), 2)
     host_budget["cgroup_cpu_quota"] = cgroup_cpu_quota()
+    if loop.ba_workers:  # local mapping as a pool of mapping workers: that many stage threads instead of one, each driving its lock-step group itself
+        host_budget["mapping_workers"] = len(loop.ba_workers)
+        host_budget["stage_threads"] = 4 + len(loop.ba_workers)
     tcpu1 = thread_cpu_seconds()
     host_budget["cpu_s_per_wall_s_by_thread_name"] = {k: round((v - tcpu0.get(k, 0.0)) / max(local_elapsed, 1e-9), 2)
                                                        for k, v in sorted(tcpu1.items(), key=lambda kv: -(kv[1] - tcpu0.get(kv[0], 0.0)))
