@@ -1240,13 +1240,17 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaPhase ph, int st
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
 }
 // The last workgroup of a window to deliver (a ticket counter per window, zero between launches).  The partial sums are stored and read at
-// device scope (block_sum_256<true> / load_partial), so what is needed here is only that a wavefront's stores have been performed before its
-// workgroup takes the ticket (the workgroup-scope release: s_waitcnt, no cache operation), that the workgroup meets, and that one
-// thread takes the ticket with a device-scope atomic.  The workgroup that took the last one leaves the counter at zero for the next
-// launch and does the closing sums -- in the fixed order of the separate kernel, whoever comes last.
+// device scope (block_sum_256<true> / load_partial: `global_store ... sc1` writes through the XCD's L2, `global_load ... sc1` does not take
+// what that L2 holds), so no cache-wide write-back / invalidate is needed -- but the stores must have been PERFORMED before the ticket is
+// taken: every wavefront waits for its own outstanding memory operations (`s_waitcnt vmcnt(0)`: a device-scope store is acknowledged once
+// it is visible at that scope), the workgroup meets, and only then one thread takes the ticket with a device-scope atomic.  (Round 4 had a
+// workgroup-scope release fence in place of the wait; hipcc emits no `s_waitcnt vmcnt` for that on gfx950, so the store and the ticket --
+// different addresses, different L2 channels -- were unordered and the last workgroup could add a stale partial: ADVICE r4, high.)  The
+// workgroup that took the last ticket leaves the counter at zero for the next launch and does the closing sums -- in the fixed order of
+// the separate kernel, whoever comes last.
 __device__ __forceinline__ bool ba_last_of(int32_t* ticket, int n_workgroups) {
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -97,7 +97,13 @@ bool ensure_dynamic_lds(const void* fn, int bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     std::lock_guard<std::mutex> lk(mu);
-    for (const Entry& e : *done) if (e.fn == fn && e.dev == dev && e.bytes >= bytes) return e.ok;
+    // only a GRANTED size answers for the smaller ones; a refusal is remembered for requests at least as large (a refused 156 KB must not
+    // turn a later 38 KB request for the same kernel into a silent "no": ADVICE r4)
+    for (const Entry& e : *done) {
+        if (e.fn != fn || e.dev != dev) continue;
+        if (e.ok && e.bytes >= bytes) return true;
+        if (!e.ok && e.bytes <= bytes) return false;
+    }
     const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (err != hipSuccess) { (void)hipGetLastError(); set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed on device %d: %s", bytes, dev, hipGetErrorString(err)); }
     done->push_back(Entry{fn, dev, bytes, err == hipSuccess});
@@ -236,12 +242,16 @@ int host_thread_budget() {
     return cores_of_this_process();
 }
 
-// Threads of pool `id` under the budget B of this process: the stage threads of a caller like the reference (tracking, LiDAR, local
+// Threads of pool `id` under the budget B of this process.  B counts the CPUs the process may really use (bench.py / a caller passes
+// min(affinity, cgroup quota) / ranks on the node); a pool thread spends part of its time waiting for its stream, so the pools may hold
+// TC2LI_HOST_THREADS_PER_CPU (default 2) threads per CPU in all.  The stage threads of a caller like the reference (tracking, LiDAR, local
 // mapping: counted as 5) come off first; of the rest the extractor pool may take a quarter, the tracking pool, the LiDAR pool and each
-// lock-step BA group an eighth -- with B >= 133 every pool has the size it was tuned at on a one-GPU box (32 / 16 / 16 / 16 per group),
-// with 8 ranks on 256 cores (B = 32) they add up to 6 + 3 + 3 + 3 x 3 + 5 = 26 threads per rank.
+// lock-step BA group an eighth -- with B >= 69 every pool has the size it was tuned at (32 / 16 / 16 / 16 per group), with 16 CPUs (the
+// one-GPU box's cgroup quota) 6 + 3 + 3 + 3 x 3, with 8 ranks on 256 cores (B = 32) 14 + 7 + 7 + 3 x 7.
 int pool_threads(int id) {
-    const int B = std::max(1, host_thread_budget() - 5);
+    int per_cpu = 2;
+    if (const char* s = getenv("TC2LI_HOST_THREADS_PER_CPU")) per_cpu = std::max(1, std::min(16, atoi(s)));
+    const int B = std::max(1, per_cpu * host_thread_budget() - 5);
     auto share = [&](int cap, int den) { return std::max(1, std::min(cap, B / den)); };
     if (id == kPoolGlobal) {
         if (const char* s = getenv("TC2LI_HOST_THREADS")) return std::max(1, std::min(32, atoi(s)));

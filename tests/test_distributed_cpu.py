@@ -117,19 +117,62 @@ def test_bench_spawns_its_ranks_world_2_gloo():
     hb = line["config"]["host_threads_gpu_path"]
     cores = len(os.sched_getaffinity(0))
     assert hb["ranks_on_node"] == 2 and hb["pinned"] and hb["cores_of_this_rank"] == max(1, cores // 2)
-    assert len(line["config"]["affinity_of_rank0"]) == hb["cores_of_this_rank"]
-    assert all(1 <= v <= max(1, hb["cores_of_this_rank"]) for v in hb["library_pools"].values())
+    assert line["config"]["affinity_of_rank0"] == hb["cores_of_this_rank"]
+    # the thread budget is the rank's share of what the cgroup really grants (min(affinity, quota) / ranks), the pools at most two threads per CPU
+    assert 1 <= hb["thread_budget"] <= hb["cores_of_this_rank"] and hb["thread_budget"] <= max(1, hb["cpus_effective"] // 2)
+    assert all(1 <= v <= 2 * hb["thread_budget"] for v in hb["library_pools"].values())
+    assert len(r.stdout.strip().splitlines()[-1]) <= 4096  # the line the driver parses stays small
 
 
 def test_host_thread_budget_of_eight_ranks_fits_the_node():
     """What apply_host_budget gives the library on the driver's 8-GPU node (256 cores): 32 cores per rank, pools that add up -- with the
-    five stage threads and three lock-step BA groups -- to at most those 32 (rounds 1-3: ~130 threads per rank whatever the rank count)."""
+    five stage threads and three lock-step BA groups -- to at most two threads per core (a pool thread waits for its stream about half of
+    its time; rounds 1-3: ~130 threads per rank whatever the rank count); on a node whose cgroup grants 16 CPUs to 8 ranks (2 each) every
+    pool is one thread."""
     import subprocess
     code = ("import sys; sys.path.insert(0, %r)\nimport tc2li_loader\npkg = tc2li_loader.load()\npkg.capi.set_host_thread_budget(256 // 8)\n"
             "h = pkg.capi.host_threads()\nprint(5 + h['extractor_pool'] + h['tracking_pool'] + h['lidar_pool'] + 3 * h['ba_group_pool'])" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert int(r.stdout.split()[-1]) <= 32
+    assert int(r.stdout.split()[-1]) <= 64
+    r = subprocess.run([sys.executable, "-c", code.replace("256 // 8", "16 // 8")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert int(r.stdout.split()[-1]) == 5 + 1 + 1 + 1 + 3
+
+
+def test_the_printed_line_keeps_to_its_byte_budget():
+    """the driver parses ONE line and round 4's 20 KB line was not parsed.  compact_line() cuts any report -- here one fatter
+    than round 4's -- to the contract's keys + one-object summaries within LINE_BUDGET, the roofline's `traffic` as a number."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    table = {"k_kernel_%02d" % i: {"launches_per_step": 1.5, "ms_per_step": 0.123, "avg_launch_us": 12.3, "share_of_kernel_time": 0.04, "achieved_GBps": 123.4,
+                                    "frac_hbm": 0.0123} for i in range(40)}
+    rf = {"kernel": "k_ba_linearize_b", "bound": "hbm", "achieved": 459.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.057, "avg_launch_ms": 0.352,
+          "algorithmic_bytes_per_launch": 161600000, "traffic": {"bytes_per_launch": 177700000, "source": "profiles/r05_pmc_traffic.json", "note": "x" * 300},
+          "all_kernels": table, "measured_in": "y" * 900, "peaks_measured": {"note": "z" * 500}}
+    cpu = {"value": 60.0, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "s" * 700, "single_sequence": {"value": 24.5, "cores": 4, "sample": "t" * 200}}
+    full = {"metric": bench.METRIC, "value": 19900.0, "unit": "frames/s", "n_gpus": 1, "steps": 20, "warmup": 3, "ms_per_step": 25.7, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8, f32, f64", "data": "synthetic",
+            "config": {"workload": "w" * 900, "stage_threads": "v" * 900, "sequences_total": 512, "host_threads_gpu_path": {"cpus_effective": 16, "cgroup_cpu_quota": 16.0,
+                       "cpu_s_per_wall_s_by_thread_name": {"t%d" % i: 0.5 for i in range(60)}}},
+            "roofline": rf, "cpu_baseline": cpu, "single_sequence": {"value": 846.0, "unit": "frames/s", "ms_per_frame": 1.18, "workload": "u" * 500},
+            "host_fed": {"value": 8914.0, "ms_per_step": 57.4, "GB_per_step": 2.61, "link_GBps": 45.5, "workload": "q" * 600},
+            "inertial_config": {"value": 12000.0, "unit": "frames/s", "ms_per_step": 42.0, "workload": "r" * 800, "roofline": dict(rf), "cpu_baseline": dict(cpu),
+                                "single_sequence": {"value": 460.5, "ms_per_frame": 2.17}},
+            "mfma_config": {"workload": "m" * 400, "windows_per_s": 2000.0, "roofline": dict(rf, bound="mfma", unit="TFLOP/s")},
+            "sequences_per_gpu_sweep": {"512": 19576.0, "256": 17800.0, "128": 16300.0, "64": 14521.0, "unit": "n" * 400}}
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    txt = json.dumps(line)
+    assert len(txt) <= bench.LINE_BUDGET, len(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"]) and line["roofline"]["traffic"] == 177700000
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and line["cpu_baseline"]["cores"] == 16
+    assert len(line["config"]["workload"]) <= 200 and "all_kernels" not in txt
+    assert line["inertial_config"]["roofline"]["kernel"] and line["mfma_config"]["roofline"]["bound"] == "mfma"
 
 
 def test_bench_weak_scaling_line_under_torchrun_env():

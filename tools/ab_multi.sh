@@ -4,7 +4,7 @@
 REPS=$1; KERNELS=$2; shift 2
 for k in $(seq 1 $REPS); do
   for setting in "$@"; do
-    env $setting timeout -k 10 300 python bench.py --no-build --no-cpu-baseline --no-extra-lines --with-roofline --steps 24 --warmup 4 2>/dev/null | KERNELS="$KERNELS" SETTING="$setting" python -c "
+    env $setting timeout -k 10 300 python bench.py --no-build --no-cpu-baseline --no-extra-lines --with-roofline --full-line --steps 24 --warmup 4 2>/dev/null | KERNELS="$KERNELS" SETTING="$setting" python -c "
 import json,sys,os
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); ak=d['roofline']['all_kernels']
 t=d['stage_thread_ms_per_step_concurrent']
