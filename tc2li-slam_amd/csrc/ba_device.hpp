@@ -59,6 +59,8 @@ static_assert(schur_lean_fits_all(), "k_ba_schur_lean: tasks or closing sums of 
 // Per-edge records of the linearisation are padded to whole 16-byte pieces (9 -> 10 and 27 -> 28 doubles) so that they are written
 // and read as double2: the kernels' many pointers may alias as far as the compiler knows, and scalar stores stay scalar.
 constexpr int kContribP = 28;
+constexpr int kBacksubMaxNp = 512;     // doubles of a step x_p the trial kernels stage in LDS
+constexpr int kTrialPoseBytes = 12288; // LDS of the fused trial launch for the window's trial poses (219 SE3 vertices / 61 ImuCamPose records)
 struct BaProblemDev {
     int32_t n_edges, n_points, n_poses, n_free, n_free_edges, np_pad;
     int32_t n_groups;         // workgroups of the linearisation: whole landmarks, at most 256 edges each (grp_k0 into pt_edges, grp_l0)
@@ -84,6 +86,10 @@ struct BaProblemDev {
     // instead of the zero-padded MFMA form (k_ba_schur_sparse4/9, one partial per slice; TC2LI_BA_SCHUR_MFMA=1)
     int32_t sparse_schur, schur_blocks;  // schur_blocks: 0 MFMA form of the sparse product, 1 block by block, 2 block by block, lean form
     int32_t schur_rd, schur_ro;  // landmark ranges per diagonal / off-diagonal block task (schur_ranges)
+    // trial_fused: the trial estimate, its cost and the closing sums run as ONE launch over the linearisation's landmark groups (round 5:
+    // k_ba_trial_fused*; a property of the window -- it decides the order of two sums -- set by the setup when the window's step, poses and
+    // groups fit the kernel's LDS: kBacksubMaxNp, kTrialPoseBytes, 256 landmarks per group)
+    int32_t trial_fused, pad_tf_;
     double *chi2, *rho0;
     double *cp_part, *W;                 // per (block of 256 free-pose edges, free pose): 27 (+1) doubles; per free-pose edge (at w_slot): 18
     const int32_t* blk_off;              // per block: n_free + 1 offsets into its rows sorted by pose
@@ -153,6 +159,8 @@ struct BaBatchExtent {
     int max_block_parts, max_block_free, min_block_free;
     int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
+    int fuse_linearize;  // the linearisation's last workgroup of a window does k_ba_reduce_all_b's / k_ba_maxdiag_b's sums (round 5)
+    int any_trial_fused, any_trial_unfused;  // windows with / without pb.trial_fused in the call (each kind has its launches; a kernel skips the other kind)
     int inertial;  // the windows' vertices are ImuCamPose records (LocalLVIBA batch): the linearisation kernel of that vertex type
 };
 // n_active <= kBaPhaseMax windows per call (the host cuts a longer list)
@@ -197,6 +205,30 @@ __device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb)
 // loads, and everything addressed through their result would be fetched per lane (readfirstlane: the value is the same in every lane)
 __device__ __forceinline__ int ba_phase_window(const BaPhase& ph, int pos) { return __builtin_amdgcn_readfirstlane((int)ph.win[pos]); }
 __device__ __forceinline__ unsigned ba_phase_flags(const BaPhase& ph, int pos) { return (unsigned)__builtin_amdgcn_readfirstlane((int)ph.flags[pos]); }
+#endif
+
+#if defined(__HIPCC__)
+// The last workgroup of a window to deliver (a ticket counter per window, zero between launches).  The partial sums are stored and read at
+// device scope (block_sum_256<true> / load_partial: `global_store ... sc1` writes through the XCD's L2, `global_load ... sc1` does not take
+// what that L2 holds), so no cache-wide write-back / invalidate is needed -- but the stores must have been PERFORMED before the ticket is
+// taken: every wavefront waits for its own outstanding memory operations (`s_waitcnt vmcnt(0)`: a device-scope store is acknowledged once
+// it is visible at that scope), the workgroup meets, and only then one thread takes the ticket with a device-scope atomic.  (Round 4 had a
+// workgroup-scope release fence in place of the wait; hipcc emits no `s_waitcnt vmcnt` for that on gfx950, so the store and the ticket --
+// different addresses, different L2 channels -- were unordered and the last workgroup could add a stale partial: ADVICE r4, high.)  The
+// workgroup that took the last ticket leaves the counter at zero for the next launch and does the closing sums -- in the fixed order of
+// the separate kernel, whoever comes last.
+__device__ __forceinline__ bool ba_last_of(int32_t* ticket, int n_workgroups) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == n_workgroups - 1 ? 1 : 0;
+        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
 #endif
 
 }  // namespace tc2li

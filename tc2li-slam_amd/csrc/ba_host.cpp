@@ -64,6 +64,21 @@ struct VisualProblem {
     std::vector<int> pose_var;
     std::vector<Se3> poses;
     int n_free = 0, np = 0, n_slices = 1, k_per_slice = 4;
+    int max_group_landmarks = 0;
+    // pb.trial_fused (ba_device.hpp): whether the window's trials run as the one fused launch -- a property of the window (it fixes the order
+    // of two sums), decided here and again by a caller that switches the vertices to ImuCamPose records.  OFF unless TC2LI_BA_FUSE_TRIAL=1:
+    // built for VERDICT r4 item 2 ("a trial <= 3 launches"), parity-green in both forms (tests/test_ba_gpu.py, test_balm_gpu.py,
+    // test_inertial_ba_gpu.py run whichever the environment selects) and measured SLOWER in the whole loop -- 27.1 / 27.3 ms per step against
+    // 26.1 / 25.8 in two A/B pairs of one call, the camera threads 26.6-27.3 against 25.4-26.1; local BA alone 13.0-13.7 against 12.1-13.9 ms
+    // per 128 windows.  A workgroup of the fused launch runs six dependent trips to memory (step, poses, slots, W blocks, edge list, edges)
+    // while it holds 28 KB of LDS; the three launches it replaces are thin kernels of two or three trips each that start and finish quickly
+    // beside the other stages' wavefronts.  In a loop bound by the kernels' combined occupancy, fewer launches is not the lever; shorter
+    // residency is.
+    void decide_trial_fused() {
+        const char* env = getenv("TC2LI_BA_FUSE_TRIAL");
+        const size_t pose_bytes = (size_t)pb.n_poses * (pb.inertial ? sizeof(ImuPose) : sizeof(Se3));
+        pb.trial_fused = env && atoi(env) != 0 && np <= kBacksubMaxNp && pose_bytes <= (size_t)kTrialPoseBytes && max_group_landmarks <= 256 ? 1 : 0;
+    }
 
     int setup(BaWorkspace& ws, const double* poses7, const uint8_t* fixed, int n_poses, const double* points3, int n_points,
               const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, const uint8_t* extra_used, hipStream_t st) {
@@ -155,6 +170,9 @@ struct VisualProblem {
     }
     grp_k0.push_back(n_edges); grp_l0.push_back(n_points);
     const int n_groups = (int)grp_k0.size() - 1;
+    max_group_landmarks = 0;
+    for (int g = 0; g < n_groups; ++g) max_group_landmarks = std::max(max_group_landmarks, grp_l0[g + 1] - grp_l0[g]);
+    if (max_group_landmarks > 256) { set_error("more than 256 landmarks without edges in a row"); return TC2LI_ERR_INVALID; }  // (a landmark-role workgroup has a thread per landmark)
     np = 6 * n_free;
     // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
     const bool sparse = (np + 1 + 15) / 16 <= 8;
@@ -260,6 +278,7 @@ struct VisualProblem {
     pb.ticket = (int32_t*)(d + o_ticket);
     pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = sparse ? n_schur_slices : 0;
     pb.schur_rd = pb.schur_ro = 1;
+    decide_trial_fused();
     if (blocks_form) {
         schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
     }
@@ -962,6 +981,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
     TC2LI_HIP_CHECK(ws.d_iposes.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.d_iposes_trial.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.h_iposes.ensure(n_kfs));
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_iposes.p, hp.data(), n_kfs * sizeof(ImuPose), hipMemcpyHostToDevice, st));
     pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
+    vp.decide_trial_fused();
     memcpy(&pb.calib, calib, sizeof(ImuCalib));
     auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
     const size_t E = n_edges, P = n_points;
@@ -1315,6 +1335,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
         if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
+        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
@@ -1339,6 +1360,14 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     {
         const char* fuse_env = getenv("TC2LI_BA_FUSE");
         X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
+        // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
+        // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
+        // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
+        // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
+        // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
+        // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
+        const char* fuse_lin_env = getenv("TC2LI_BA_FUSE_LIN");
+        X.fuse_linearize = fuse_lin_env && atoi(fuse_lin_env) != 0 ? 1 : 0;
     }
     // TC2LI_BA_DEVICE_SOLVE=1 (read per call): the reduced systems of the batch are solved on the device (k_ba_solve_b; every window on the
     // sparse Schur path, i.e. at most 21 free keyframes) -- Schur product, solve and trial estimate are then one queue of launches with one
@@ -1497,7 +1526,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                     ba_batch_launch_solve(ph, cnt, X, st);
                     ba_batch_launch_trial(ph, cnt, X, st);
                 });
-                pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+                if (X.any_trial_unfused) pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
                 sync();
                 if (failed) break;
                 tm[3] += now() - t0; t0 = now();
@@ -1543,7 +1572,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (!step.empty()) {
                 stage_steps(step);
                 pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
-                pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+                if (X.any_trial_unfused) pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
                 sync();
                 if (failed) break;
             }
@@ -1750,6 +1779,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         if (upload_or_defer(ws.d_iposes.p, ws.h_iposes_up.p, n_kfs * sizeof(ImuPose), st) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
         BaProblemDev& pb = w.vp.pb;
         pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
+        w.vp.decide_trial_fused();
         memcpy(&pb.calib, calib, sizeof(ImuCalib));
         const int nn = w.inertial.n;
         w.M.assign((size_t)std::max(nn * nn, 1), 0.0); w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
@@ -1773,6 +1803,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
         if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
+        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
@@ -1797,6 +1828,14 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     {
         const char* fuse_env = getenv("TC2LI_BA_FUSE");
         X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
+        // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
+        // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
+        // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
+        // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
+        // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
+        // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
+        const char* fuse_lin_env = getenv("TC2LI_BA_FUSE_LIN");
+        X.fuse_linearize = fuse_lin_env && atoi(fuse_lin_env) != 0 ? 1 : 0;
     }
     auto fill_slot = [&](int i) {
         LviWindow& w = W[i];
@@ -1927,7 +1966,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 stage_steps(step);
                 // (the trial ImuCamPose states come back through slot.iposes_host, written by the trial kernel: a copy launch per trial before)
                 pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
-                pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+                if (X.any_trial_unfused) pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
                 pool.parallel_for((int)step.size(), [&](int k) {  // velocity / bias part of the step, on the host
                     LviWindow& w = W[step[k]];
                     const int np = w.vp.np;

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "ba_device.hpp"
+#include "balm_residual_device.hpp"
 
 namespace tc2li {
 
@@ -89,7 +90,13 @@ __device__ __forceinline__ double load_partial(const double* p) {
 // bytes) ran with that share of its lanes; its W blocks now leave in slot order.  The error and the weight are simply formed again.
 // LDS of the two roles of the linearisation, declared by the kernel (one launch runs both: the roles share it)
 struct LinearizeLds { double big[256 * 9]; double small[256]; };
-template <bool INERTIAL>
+// a partial sum for another workgroup of the same launch (ba_last_of) leaves at device scope; for the next launch a plain store will do
+template <bool DEVICE_SCOPE>
+__device__ __forceinline__ void store_partial(double* p, double v) {
+    if (DEVICE_SCOPE) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool INERTIAL, bool FUSED = false>
 __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, const int bx, LinearizeLds& lds) {
     double* const s_cp = lds.big;
     uint8_t* const s_rows = reinterpret_cast<uint8_t*>(lds.small);
@@ -175,12 +182,12 @@ __device__ __forceinline__ void d_ba_linearize_pose(const BaProblemDev& pb, cons
             const int r0 = t < 256 ? my_r0 : off[i], r1 = t < 256 ? my_r1 : off[i + 1];
             double acc = 0;
             for (int r = r0; r < r1; ++r) acc += s_cp[9 * s_rows[r] + c];
-            pb.cp_part[((size_t)bx * nf + i) * kContribP + c0 + c] = acc;
+            store_partial<FUSED>(pb.cp_part + ((size_t)bx * nf + i) * kContribP + c0 + c, acc);
         }
         __syncthreads();
     }
 }
-template <bool INERTIAL>
+template <bool INERTIAL, bool FUSED = false>
 __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int g, LinearizeLds& lds) {
     double* const s_sum = lds.small;
     double* const s_cl = lds.big;
@@ -242,9 +249,9 @@ __device__ __forceinline__ void d_ba_linearize(const BaProblemDev& pb, const int
         }
         for (int i = 0; i < 6; ++i) pb.Hll[6 * (size_t)l + i] = acc[i];
         for (int i = 0; i < 3; ++i) pb.bl[3 * (size_t)l + i] = acc[6 + i];
-        pb.diag_l[l] = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+        store_partial<FUSED>(pb.diag_l + l, fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))));
     }
-    block_sum_256(rho0, s_sum, pb.chi_part + g);  // the robust cost is summed per workgroup here, finished in the next launch
+    block_sum_256<FUSED>(rho0, s_sum, pb.chi_part + g);  // the robust cost is summed per workgroup here, finished by the closing sums
 }
 // one launch, both roles: workgroups [0, n_groups) the landmark role, the rest the pose role (they do not depend on each other)
 __global__ __launch_bounds__(256) void k_ba_linearize(BaProblemDev pb) {
@@ -351,6 +358,50 @@ __device__ __forceinline__ void block_reduce_256(const double* __restrict__ in, 
     }
     if (threadIdx.x == 0) out[0] = s[0];
     __syncthreads();
+}
+
+// The closing sums of a linearisation by ONE workgroup -- the window's last to deliver (k_ba_linearize*_b, ba_last_of): Hpp / b_p of every free
+// pose as reduce_poses_body adds them (eight interleaved series of blocks, the series in order: the same bits), four poses at a time so that
+// a lane has up to twenty independent loads in flight instead of one dependent chain per pose; then the robust cost over the groups'
+// partials and, when the phase asks for them, the largest diagonal entries.  All partials come from other workgroups of the same launch: read
+// at device scope.  s_part: 4 x 256 doubles.
+__device__ __forceinline__ void d_ba_linearize_close(const BaProblemDev& pb, double* s_part, double* __restrict__ chi_out, double* __restrict__ hpp_out,
+                                                     double* __restrict__ maxdiag_out) {
+    const int q = threadIdx.x >> 5, c = threadIdx.x & 31, nb = (pb.n_free_edges + 255) / 256, nf = pb.n_free;
+    for (int i0 = 0; i0 < nf; i0 += 4) {
+        double a[4] = {0, 0, 0, 0};
+        if (c < 27)
+            for (int b = q; b < nb; b += 8) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < nf) a[u] += load_partial<true>(pb.cp_part + ((size_t)b * nf + i0 + u) * kContribP + c);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_part[256 * u + threadIdx.x] = a[u];
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int u = threadIdx.x >> 5, v = threadIdx.x & 31, i = i0 + u;
+            if (v < 27 && i < nf) {
+                double sum = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum += s_part[256 * u + 32 * w + v];
+                pb.Hpp[27 * (size_t)i + v] = sum;
+                if (hpp_out) hpp_out[27 * (size_t)i + v] = sum;
+                s_part[256 * u + v] = sum;  // (own column of series 0: read above by this lane only)
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 && i0 + (int)threadIdx.x < nf) {
+            const double* h = s_part + 256 * threadIdx.x;
+            pb.diag_p[i0 + threadIdx.x] = fmax(fmax(fabs(h[0]), fabs(h[6])), fmax(fmax(fabs(h[11]), fabs(h[15])), fmax(fabs(h[18]), fabs(h[20]))));
+        }
+        __syncthreads();
+    }
+    block_reduce_256<false, true>(pb.chi_part, pb.n_groups, s_part, chi_out);
+    if (maxdiag_out) {
+        block_reduce_256<true, true>(pb.diag_l, pb.n_points, s_part, maxdiag_out);
+        block_reduce_256<true, true>(pb.diag_p, pb.n_free, s_part, maxdiag_out + 1);  // written by this workgroup above (behind barriers)
+    }
 }
 
 // One launch after the linearisation: workgroups [0, n_free) sum the pose blocks, the last one the robust cost
@@ -1029,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish(BaProblemDev pb, double
 
 // x_l = D^-1 (b_l - W^T x_p), one thread per landmark over its W blocks (landmark-major: a thread reads one contiguous run, the
 // workgroup one contiguous range); x_p comes from the host's pinned memory once per workgroup, not once per use.
-constexpr int kBacksubPerBlock = 256, kBacksubMaxNp = 512;
+constexpr int kBacksubPerBlock = 256;
 __device__ __forceinline__ void backsub_body(const BaProblemDev& pb, int block, const double* __restrict__ xp, double lambda, double* s_sum, double* s_x) {
     const int l = block * kBacksubPerBlock + threadIdx.x;
     const int np = 6 * pb.n_free;
@@ -1120,6 +1171,120 @@ __device__ __forceinline__ void d_ba_errors(const BaProblemDev& pb, const int bx
 }
 __global__ __launch_bounds__(256) void k_ba_errors(BaProblemDev pb) { d_ba_errors(pb, blockIdx.x); }
 
+// ---- the trial estimate, its cost and the closing sums in ONE launch (round 5; windows with pb.trial_fused) -------------------------------
+// A workgroup per landmark GROUP of the linearisation (whole landmarks, <= 256 edges): it stages the step, moves every vertex of the
+// window into LDS (exp(x_p) T: a few dozen poses, formed by every workgroup rather than fetched from a launch before), back-substitutes
+// its landmarks (backsub_body's arithmetic), keeps their trial points in LDS and evaluates its edges against them -- three launches
+// (k_ba_trial_update_b, k_ba_errors_reduce_b, k_balm_residual_total_b) and a round trip of the trial points through memory before.  The
+// partial sums of the gain-ratio scale and of the robust cost are per GROUP (per 256 landmarks / 256 edges in the separate kernels): the
+// one-window entry points run the same kernel, so a window gives the same bits alone and in a batch.  Workgroup 0 of a window writes the
+// trial poses for the launches that follow; the window's last workgroup adds the partials (ba_last_of, ticket word 1).
+struct TrialLds {
+    double x[kBacksubMaxNp];
+    double pts[3 * 256];
+    double sum[256];
+    alignas(16) unsigned char poses[kTrialPoseBytes];
+};
+template <bool INERTIAL>
+__device__ __forceinline__ void trial_poses_lds(const BaProblemDev& pb, const double* s_x, unsigned char* s_poses, bool write_global, ImuPose* __restrict__ iposes_host) {
+    for (int k = threadIdx.x; k < pb.n_poses; k += 256) {
+        const int i = pb.pose_var[k];
+        if (INERTIAL) {
+            ImuPose T = pb.iposes[k];
+            if (i >= 0) {
+                double u[6];
+                for (int r = 0; r < 6; ++r) u[r] = s_x[6 * i + r];
+                imu_pose_update(T, pb.calib, u);
+            }
+            reinterpret_cast<ImuPose*>(s_poses)[k] = T;
+            if (write_global) { pb.iposes_trial[k] = T; if (iposes_host) iposes_host[k] = T; }
+        } else {
+            Se3 T = pb.poses[k];
+            if (i >= 0) {
+                double u[6];
+                for (int r = 0; r < 6; ++r) u[r] = s_x[6 * i + r];
+                T = se3_exp_mul(u, T);
+            }
+            reinterpret_cast<Se3*>(s_poses)[k] = T;
+            if (write_global) pb.poses_trial[k] = T;
+        }
+    }
+}
+template <bool INERTIAL>
+__device__ __forceinline__ void d_ba_trial_group(const BaProblemDev& pb, const int g, const double* __restrict__ xp, double lambda, TrialLds& L,
+                                                 ImuPose* __restrict__ iposes_host) {
+    const int np = 6 * pb.n_free;
+    for (int j = threadIdx.x; j < np; j += 256) L.x[j] = xp[j];
+    __syncthreads();
+    trial_poses_lds<INERTIAL>(pb, L.x, L.poses, g == 0, iposes_host);
+    const int k0 = pb.grp_k0[g], k1 = pb.grp_k0[g + 1], l0 = pb.grp_l0[g], l1 = pb.grp_l0[g + 1];
+    double sc = 0;
+    const int l = l0 + (int)threadIdx.x;
+    if (l < l1) {  // x_l = D^-1 (b_l - W^T x_p): backsub_body's operations in its order
+        double d0 = 0, d1 = 0, d2 = 0;
+        for (int k = pb.fl_off[2 * l]; k < pb.fl_off[2 * l + 1]; ++k) {
+            double W[18];
+            load_d2<18>(pb.W + 18 * (size_t)k, W);
+            const double* x = L.x + 6 * pb.fl_pose[k];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double xr = x[r];
+                d0 += W[3 * r] * xr;
+                d1 += W[3 * r + 1] * xr;
+                d2 += W[3 * r + 2] * xr;
+            }
+        }
+        const double cl[3] = {pb.bl[3 * (size_t)l] - d0, pb.bl[3 * (size_t)l + 1] - d1, pb.bl[3 * (size_t)l + 2] - d2};
+        double Di[9], db_[3];
+        point_dinv(pb, l, lambda, Di, db_);
+        for (int r = 0; r < 3; ++r) {
+            const double x = Di[3 * r] * cl[0] + Di[3 * r + 1] * cl[1] + Di[3 * r + 2] * cl[2];
+            const double X = pb.points[3 * (size_t)l + r] + x;
+            pb.points_trial[3 * (size_t)l + r] = X;
+            L.pts[3 * threadIdx.x + r] = X;
+            sc += x * (lambda * x + pb.bl[3 * (size_t)l + r]);
+        }
+    }
+    __syncthreads();
+    double rho0 = 0;
+    const int k = k0 + (int)threadIdx.x;
+    if (k < k1) {
+        const int e = pb.pt_edges[k];
+        const BaEdge ed = pb.edges[e];
+        const double* X = L.pts + 3 * (ed.point - l0);
+        double p[3], err[3], c2 = 0;
+        int dim;
+        if (INERTIAL) {
+            dim = imu_edge_error(reinterpret_cast<const ImuPose*>(L.poses)[ed.pose], X, ed, pb.cam, p, err);
+        } else {
+            se3_map(reinterpret_cast<const Se3*>(L.poses)[ed.pose], X, p);
+            dim = edge_error(p, ed, pb.cam, err);
+        }
+        for (int d = 0; d < dim; ++d) c2 += err[d] * ed.info * err[d];
+        const bool stereo = ed.ur >= 0;
+        double rho1;
+        huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
+        pb.chi2[e] = c2;
+        pb.rho0[e] = rho0;
+    }
+    block_sum_256<true>(sc, L.sum, pb.scale_part + g);
+    __syncthreads();
+    block_sum_256<true>(rho0, L.sum, pb.chi_part + g);
+}
+// [0] landmark part of the gain-ratio scale, [1] robust cost of the trial estimate: the groups' partials in group order (one workgroup)
+__device__ __forceinline__ void d_ba_trial_close(const BaProblemDev& pb, double* s, double* __restrict__ scale_out, double* __restrict__ chi_out) {
+    block_reduce_256<false, true>(pb.scale_part, pb.n_groups, s, scale_out);
+    block_reduce_256<false, true>(pb.chi_part, pb.n_groups, s, chi_out);
+}
+__global__ __launch_bounds__(256) void k_ba_trial_fused(BaProblemDev pb, const double* __restrict__ xp, double lambda, double* __restrict__ scale_out,
+                                                        double* __restrict__ chi_out) {
+    __shared__ TrialLds L;
+    if (pb.inertial) d_ba_trial_group<true>(pb, blockIdx.x, xp, lambda, L, nullptr);
+    else d_ba_trial_group<false>(pb, blockIdx.x, xp, lambda, L, nullptr);
+    if (!ba_last_of(pb.ticket + 1, pb.n_groups)) return;
+    d_ba_trial_close(pb, L.sum, scale_out, chi_out);
+}
+
 __device__ __forceinline__ void d_ba_depth(const BaProblemDev& pb, const int bx, uint8_t* __restrict__ depth_pos) {
     const int e = bx * 256 + threadIdx.x;
     if (e >= pb.n_edges) return;
@@ -1183,19 +1348,29 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
 // the body to four with amdgpu_waves_per_eu -- 126 registers, 68 bytes of scratch per lane -- measured the same in the loop: 361 against 375 us.
 // With the slot read through scalar loads (ba_slot_view) the body needs 100 registers: four wavefronts, 290-300 us in the loop; held to five
 // (96 registers + 12 B of scratch) the kernel runs 254-273 us and the step does not change: 29.5 against 29.7 ms over five A/B pairs).
-__global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int max_groups) {
-    __shared__ LinearizeLds lds;
+// fuse != 0: the closing sums (k_ba_reduce_all_b, k_ba_maxdiag_b) by the window's last workgroup instead of two more launches (round 5)
+template <bool INERTIAL>
+__device__ __forceinline__ void linearize_b_body(const BaPhase& ph, int max_groups, int fuse, LinearizeLds& lds) {
     TC2LI_SLOT(y);
     const int bx = blockIdx.x;
-    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<false>(pb, bx, lds); }
-    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<false>(pb, bx - max_groups, lds);
+    const int nbe = blocks256(pb.n_free_edges);
+    if (!fuse) {
+        if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<INERTIAL>(pb, bx, lds); }
+        else if (bx - max_groups < nbe) d_ba_linearize_pose<INERTIAL>(pb, bx - max_groups, lds);
+        return;
+    }
+    if (bx < max_groups) { if (bx >= pb.n_groups) return; d_ba_linearize<INERTIAL, true>(pb, bx, lds); }
+    else { if (bx - max_groups >= nbe) return; d_ba_linearize_pose<INERTIAL, true>(pb, bx - max_groups, lds); }
+    if (!ba_last_of(pb.ticket + 0, pb.n_groups + nbe)) return;
+    d_ba_linearize_close(pb, lds.big, sl.chi_out, view_.hpp_out(), (view_.flags & kBaWantMaxdiag) ? sl.maxdiag_out : nullptr);
 }
-__global__ __launch_bounds__(256) void k_ba_linearize_imu_b(const BaPhase ph, int max_groups) {
+__global__ __launch_bounds__(256) void k_ba_linearize_b(const BaPhase ph, int max_groups, int fuse) {
     __shared__ LinearizeLds lds;
-    TC2LI_SLOT(y);
-    const int bx = blockIdx.x;
-    if (bx < max_groups) { if (bx < pb.n_groups) d_ba_linearize<true>(pb, bx, lds); }
-    else if (bx - max_groups < blocks256(pb.n_free_edges)) d_ba_linearize_pose<true>(pb, bx - max_groups, lds);
+    linearize_b_body<false>(ph, max_groups, fuse, lds);
+}
+__global__ __launch_bounds__(256) void k_ba_linearize_imu_b(const BaPhase ph, int max_groups, int fuse) {
+    __shared__ LinearizeLds lds;
+    linearize_b_body<true>(ph, max_groups, fuse, lds);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaPhase ph) {
     TC2LI_SLOT(y);
@@ -1238,27 +1413,6 @@ __global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaPhase ph, int st
     const int tiles = pb.np_pad / 16;
     if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
     d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
-}
-// The last workgroup of a window to deliver (a ticket counter per window, zero between launches).  The partial sums are stored and read at
-// device scope (block_sum_256<true> / load_partial: `global_store ... sc1` writes through the XCD's L2, `global_load ... sc1` does not take
-// what that L2 holds), so no cache-wide write-back / invalidate is needed -- but the stores must have been PERFORMED before the ticket is
-// taken: every wavefront waits for its own outstanding memory operations (`s_waitcnt vmcnt(0)`: a device-scope store is acknowledged once
-// it is visible at that scope), the workgroup meets, and only then one thread takes the ticket with a device-scope atomic.  (Round 4 had a
-// workgroup-scope release fence in place of the wait; hipcc emits no `s_waitcnt vmcnt` for that on gfx950, so the store and the ticket --
-// different addresses, different L2 channels -- were unordered and the last workgroup could add a stale partial: ADVICE r4, high.)  The
-// workgroup that took the last ticket leaves the counter at zero for the next launch and does the closing sums -- in the fixed order of
-// the separate kernel, whoever comes last.
-__device__ __forceinline__ bool ba_last_of(int32_t* ticket, int n_workgroups) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == n_workgroups - 1 ? 1 : 0;
-        if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    return s_last != 0;
 }
 __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
@@ -1364,22 +1518,53 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) 
     }
     if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
 }
+// The fused trial launch of the lock-step batch: workgroups [0, max_groups) the window's landmark groups, workgroup max_groups its LiDAR
+// plane residual at the trial poses (formed in LDS as the groups form them: the launch that wrote them to memory is this one).
+template <bool INERTIAL>
+__device__ __forceinline__ void trial_fused_b_body(const BaPhase& ph, int max_groups, TrialLds& L) {
+    TC2LI_SLOT(y);
+    if (!pb.trial_fused) return;
+    const int bx = blockIdx.x;
+    if (bx < max_groups) {
+        if (bx >= pb.n_groups) return;
+        d_ba_trial_group<INERTIAL>(pb, bx, view_.xp, view_.lambda, L, sl.iposes_host);
+        if (!ba_last_of(pb.ticket + 1, pb.n_groups)) return;
+        d_ba_trial_close(pb, L.sum, sl.scale_out, sl.chi_trial_out);
+        return;
+    }
+    if (!load_uniform(&sl.has_lidar)) return;
+    const int np = 6 * pb.n_free;
+    for (int j = threadIdx.x; j < np; j += 256) L.x[j] = view_.xp[j];
+    __syncthreads();
+    trial_poses_lds<INERTIAL>(pb, L.x, L.poses, false, nullptr);
+    __syncthreads();
+    BalmSlotView v = balm_slot_view(ph, blockIdx.y, true);
+    d_balm_residual_total(v.b, reinterpret_cast<const Se3*>(L.poses));
+}
+__global__ __launch_bounds__(256) void k_ba_trial_fused_b(const BaPhase ph, int max_groups) {
+    __shared__ TrialLds L;
+    trial_fused_b_body<false>(ph, max_groups, L);
+}
+__global__ __launch_bounds__(256) void k_ba_trial_fused_imu_b(const BaPhase ph, int max_groups) {
+    __shared__ TrialLds L;
+    trial_fused_b_body<true>(ph, max_groups, L);
+}
 __global__ __launch_bounds__(256) void k_ba_trial_update_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
-    if ((int)blockIdx.x >= nbp + blocks256(pb.n_poses)) return;
+    if (pb.trial_fused || (int)blockIdx.x >= nbp + blocks256(pb.n_poses)) return;
     d_ba_trial_update(pb, blockIdx.x, nbp, view_.xp, view_.lambda, sl.iposes_host);
 }
 __global__ __launch_bounds__(256) void k_ba_errors_b(const BaPhase ph) {
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    if (pb.trial_fused || (int)blockIdx.x >= blocks256(pb.n_edges)) return;
     d_ba_errors(pb, blockIdx.x);
 }
 // the same, and the last workgroup of a window does k_ba_trial_reduce_b's work for it: the gain-ratio scale's landmark part (partials of
 // k_ba_trial_update_b, an earlier launch) and the trial's cost
 __global__ __launch_bounds__(256) void k_ba_errors_reduce_b(const BaPhase ph) {
     TC2LI_SLOT(y);
-    if ((int)blockIdx.x >= blocks256(pb.n_edges)) return;
+    if (pb.trial_fused || (int)blockIdx.x >= blocks256(pb.n_edges)) return;
     d_ba_errors<true>(pb, blockIdx.x);
     if (!ba_last_of(pb.ticket + 1, blocks256(pb.n_edges))) return;
     d_ba_trial_reduce<true>(pb, 0, sl.scale_out, sl.chi_trial_out);
@@ -1388,6 +1573,7 @@ __global__ __launch_bounds__(256) void k_ba_errors_reduce_b(const BaPhase ph) {
 }
 __global__ __launch_bounds__(256) void k_ba_trial_reduce_b(const BaPhase ph) {
     TC2LI_SLOT(y);
+    if (pb.trial_fused) return;
     d_ba_trial_reduce(pb, blockIdx.x, sl.scale_out, sl.chi_trial_out);
 }
 __global__ __launch_bounds__(256) void k_ba_depth_b(const BaPhase ph) {
@@ -1445,6 +1631,10 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
 }
 
 void ba_launch_trial(const BaProblemDev& pb, const double* xp, double lambda, double* scale_out, double* chi_out, hipStream_t st) {
+    if (pb.trial_fused) {  // one launch: landmark groups with the closing sums by the last of them (the batch's kernel body: same bits)
+        TC2LI_LAUNCH(k_ba_trial_fused, dim3(pb.n_groups), dim3(256), 0, st, pb, xp, lambda, scale_out, chi_out);
+        return;
+    }
     const int nbp = (pb.n_points + kBacksubPerBlock - 1) / kBacksubPerBlock;
     TC2LI_LAUNCH(k_ba_trial_update, dim3(nbp + blocks(pb.n_poses)), dim3(256), 0, st, pb, nbp, xp, lambda);
     TC2LI_LAUNCH(k_ba_errors, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb);
@@ -1457,8 +1647,10 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
-    else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups);
+    const int fuse = x.fuse_linearize;
+    if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups, fuse);
+    else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups, fuse);
+    if (fuse) return;  // the closing sums ran in the windows' last workgroups
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }
@@ -1497,6 +1689,11 @@ void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent&
 }
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;
+    if (x.any_trial_fused) {  // + 1: the windows' LiDAR residual at the trial poses rides in the same launch
+        if (x.inertial) TC2LI_LAUNCH(k_ba_trial_fused_imu_b, dim3(x.max_groups + 1, n_active), dim3(256), 0, st, ph, x.max_groups);
+        else TC2LI_LAUNCH(k_ba_trial_fused_b, dim3(x.max_groups + 1, n_active), dim3(256), 0, st, ph, x.max_groups);
+    }
+    if (!x.any_trial_unfused) return;
     TC2LI_LAUNCH(k_ba_trial_update_b, dim3((x.max_points + kBacksubPerBlock - 1) / kBacksubPerBlock + blocks(x.max_poses), n_active), dim3(256), 0, st, ph);
     if (x.fuse_trial) {
         TC2LI_LAUNCH(k_ba_errors_reduce_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);

@@ -17,6 +17,7 @@
 
 #include "ba_device.hpp"
 #include "balm_device.hpp"
+#include "balm_residual_device.hpp"
 
 namespace tc2li {
 
@@ -31,68 +32,6 @@ constexpr int kItemsSmall = 16, kItemsLarge = 30;
 static_assert(7 * 8 / 2 * 36 <= kHessThreadsSmall * kItemsSmall, "small window does not fit");
 static_assert(kMaxLidarWindow * (kMaxLidarWindow + 1) / 2 * 36 <= kHessThreads * kItemsLarge, "window too large for the item ownership");
 
-// LiDAR poses of the window slots from the vertex estimates (LidarCovisRes::UpdatePose), into LDS of the calling workgroup
-__device__ __forceinline__ void window_poses(const BalmDev& b, const Se3* __restrict__ poses, LidarPose* s_twl) {
-    if ((int)threadIdx.x < b.W) {
-        const int k = b.pose_index[threadIdx.x];
-        if (b.imu_pose_bytes) {  // EdgeLidar on VertexPose (LocalLVIBA): Rcw / tcw of the ImuCamPose
-            const double* rt = reinterpret_cast<const double*>(reinterpret_cast<const char*>(poses) + (size_t)k * b.imu_pose_bytes);
-            s_twl[threadIdx.x] = lidar_pose_from(se3f_from_rt(rt, rt + 9), b.Tcl);
-        } else {
-            s_twl[threadIdx.x] = lidar_pose_from(se3f_from_vertex(poses[k]), b.Tcl);
-        }
-    }
-    __syncthreads();
-}
-
-// merged window cluster of one plane -> covariance -> eigen decomposition -> its term of the residual
-__device__ __forceinline__ double plane_residual(const BalmDev& b, const LidarPose* twl, int a) {
-    double P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[3] = {0, 0, 0}, n = 0;
-    for (int i = 0; i < b.W; ++i) {
-        const PlaneCluster s = b.clusters[(size_t)a * b.W + i];
-        if (s.n == 0) continue;
-        ClusterW t;
-        cluster_transform(s, twl[i], t);
-        for (int k = 0; k < 9; ++k) P[k] += t.P[k];
-        for (int k = 0; k < 3; ++k) v[k] += t.v[k];
-        n += t.n;
-    }
-    const double inv = 1.0 / n;
-    double vb[3], C[9], lambda[3], U[9];
-    for (int k = 0; k < 3; ++k) vb[k] = inv * v[k];
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C[3 * r + c] = inv * P[3 * r + c] - vb[r] * vb[c];
-    eig_sym3(C, lambda, U);
-    // the Hessian pass that follows at the same poses starts from this decomposition instead of repeating it in one lane
-    double* eo = b.eig + (size_t)kBalmEig * a;
-    eo[0] = n;
-    for (int k = 0; k < 3; ++k) { eo[1 + k] = vb[k]; eo[4 + k] = lambda[k]; }
-    for (int k = 0; k < 9; ++k) eo[7 + k] = U[k];
-    return b.coe[a] * lambda[0];
-}
-
-// out[0] = in[0] + in[1] + ... in a fixed order (256 threads: strided partial sums, then a tree)
-__device__ __forceinline__ void sum_fixed_256(const double* __restrict__ in, int n, double* s, double* __restrict__ out) {
-    double a = 0;
-    for (int k = threadIdx.x; k < n; k += 256) a += in[k];
-    s[threadIdx.x] = a;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = s[0];
-}
-
-// VOX_HESS::evaluate_only_residual in one launch when the planes fit one workgroup's loop: poses, per-plane terms, sum
-__device__ __forceinline__ void d_balm_residual_total(const BalmDev& b, const Se3* __restrict__ poses) {
-    __shared__ LidarPose s_twl[kMaxLidarWindow];
-    __shared__ double s[256];
-    window_poses(b, poses, s_twl);
-    for (int a = threadIdx.x; a < b.n_planes; a += 256) b.plane_res[a] = plane_residual(b, s_twl, a);
-    __syncthreads();
-    sum_fixed_256(b.plane_res, b.n_planes, s, b.out);
-}
 __global__ __launch_bounds__(256) void k_balm_residual_total(BalmDev b, const Se3* __restrict__ poses) { d_balm_residual_total(b, poses); }
 // many planes: one thread per plane over the whole grid, then the same fixed-order sum
 __global__ __launch_bounds__(256) void k_balm_residual_planes(BalmDev b, const Se3* __restrict__ poses) {
@@ -121,7 +60,7 @@ struct HessLds {
     double s_f0[PB], s_fn[PB][WC], s_fnn[PB][WC * (WC + 1) / 2];
     uint8_t s_pi[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2], s_pj[kMaxLidarWindow * (kMaxLidarWindow + 1) / 2];
 };
-template <int kItemsPerThread, int NT, int PB, int SL, int WC, bool kLean = false>
+template <int kItemsPerThread, int NT, int PB, int SL, int WC, bool kLean = false, bool kFused = false>
 __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __restrict__ poses, const int bx, HessLds<PB, WC>& L) {
     static_assert(PB * SL <= NT && WC <= SL, "lane layout");
     auto& s_twl = L.s_twl; auto& s_A = L.s_A; auto& s_MB = L.s_MB; auto& s_w = L.s_w; auto& s_E = L.s_E; auto& s_k1 = L.s_k1; auto& s_k2 = L.s_k2;
@@ -130,7 +69,15 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
     auto& s_pi = L.s_pi; auto& s_pj = L.s_pj;
     const int tid = threadIdx.x, W = b.W, n_items = W * (W + 1) / 2 * 36;
     window_poses(b, poses, s_twl);
-    if (bx == 0 && tid < W) b.twl[tid] = s_twl[tid];  // for the change of variables on the host
+    if (bx == 0 && tid < W) {  // for the change of variables on the host
+        if (kFused) {
+            const double* src = reinterpret_cast<const double*>(&s_twl[tid]);
+            double* dst = reinterpret_cast<double*>(&b.twl[tid]);
+            for (int q = 0; q < (int)(sizeof(LidarPose) / sizeof(double)); ++q) __hip_atomic_store(dst + q, src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            b.twl[tid] = s_twl[tid];
+        }
+    }
     if (tid == 0) {
         int p = 0;
         for (int i = 0; i < W; ++i)
@@ -272,15 +219,17 @@ __device__ __forceinline__ void d_balm_hessian(const BalmDev& b, const Se3* __re
         }
         __syncthreads();
     }
+    // (kFused: the window's last chunk adds the partials in this launch -- they leave at device scope, through the XCD's L2)
     double* part = b.part + (size_t)bx * (n_items + 6 * W + 1);
+    auto put = [](double* p, double v) { if (kFused) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; };
 #pragma unroll
     for (int k = 0; k < kItemsPerThread; ++k) {
         const int item = k * NT + tid;
-        if (item < n_items) part[item] = acc[k];
+        if (item < n_items) put(part + item, acc[k]);
     }
     if (tid < W)
-        for (int c = 0; c < 6; ++c) part[n_items + 6 * tid + c] = jac[c];
-    if (tid == 0) part[n_items + 6 * W] = res;
+        for (int c = 0; c < 6; ++c) put(part + n_items + 6 * tid + c, jac[c]);
+    if (tid == 0) put(part + n_items + 6 * W, res);
 }
 // small windows: one wavefront, 8 planes x 8 slots; large ones: 256 threads, 4 planes x 32 slots
 constexpr int kHessPlanesSmall = 8, kHessPlanesLarge = 4;
@@ -295,10 +244,12 @@ __global__ __launch_bounds__(kHessThreads) void k_balm_hessian_large(BalmDev b, 
 
 // chunk partials -> out (JacT, full Hessian with the lower block triangle mirrored, the Hessian pass's residual): one thread per
 // output value adds the chunks in chunk order, eight loads in flight (neighbouring threads read neighbouring values of a chunk).
-__device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) {
+// (kFused: called by the last chunk of the Hessian launch itself -- the other chunks' partials and chunk 0's poses are read at device scope)
+template <bool kFused = false>
+__device__ __forceinline__ void d_balm_combine_value(const BalmDev& b, const int idx) {
     const int W = b.W, n = 6 * W, n_items = W * (W + 1) / 2 * 36, stride = n_items + n + 1;
-    const int idx = bx * 256 + threadIdx.x;
-    if (idx < 12 * W) b.out[2 + n + n * n + idx] = reinterpret_cast<const double*>(b.twl)[idx];  // the poses the derivatives refer to
+    auto get = [](const double* p) { return kFused ? __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
+    if (idx < 12 * W) b.out[2 + n + n * n + idx] = get(reinterpret_cast<const double*>(b.twl) + idx);  // the poses the derivatives refer to
     if (idx >= stride) return;
     double s = 0;
     const double* p = b.part + idx;
@@ -306,11 +257,11 @@ __device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) {
     for (; k + 8 <= b.n_chunks; k += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+        for (int u = 0; u < 8; ++u) v[u] = get(p + (size_t)(k + u) * stride);
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < b.n_chunks; ++k) s += p[(size_t)k * stride];
+    for (; k < b.n_chunks; ++k) s += get(p + (size_t)k * stride);
     if (idx == n_items + n) { b.out[1 + n + n * n] = s; return; }  // out[0] belongs to the residual-only kernels
     if (idx >= n_items) { b.out[1 + (idx - n_items)] = s; return; }
     const int pair = idx / 36, rc = idx % 36, r = rc / 6, c = rc % 6;
@@ -321,6 +272,7 @@ __device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) {
     H[(size_t)(6 * i + r) * n + 6 * j + c] = s;
     if (i != j) H[(size_t)(6 * j + c) * n + 6 * i + r] = s;
 }
+__device__ __forceinline__ void d_balm_combine(const BalmDev& b, const int bx) { d_balm_combine_value(b, bx * 256 + (int)threadIdx.x); }
 __global__ __launch_bounds__(256) void k_balm_combine(BalmDev b) { d_balm_combine(b, blockIdx.x); }
 
 void balm_launch_residual(const BalmDev& b, const Se3* poses, hipStream_t st) {
@@ -339,24 +291,9 @@ void balm_launch_hessian(const BalmDev& b, const Se3* poses, hipStream_t st) {
 }
 
 // ---- lock-step batch (ba_device.hpp): the window's BalmDev and pose arrays come from its slot ----
-// the poses of the window at position `pos` of the phase: the accepted estimate or the trial one (the phase's parity bit says which of
-// the slot's two buffers holds the accepted estimate)
-struct BalmSlotView { BalmDev b; const Se3* poses; };
-__device__ __forceinline__ BalmSlotView balm_slot_view(const BaPhase& ph, int pos, bool trial) {
-    __builtin_amdgcn_s_setprio(3);
-    const BaBatchSlot* const sl = ph.table + ba_phase_window(ph, pos);
-    const bool second = trial != ((ba_phase_flags(ph, pos) & kBaAcceptedInTrial) != 0);
-    BalmSlotView v;
-    v.b = load_uniform(&sl->balm);  // (scalar loads: the record lives in SGPRs, not in every lane's registers)
-    if (load_uniform(&sl->pb.inertial)) v.poses = reinterpret_cast<const Se3*>(second ? load_uniform(&sl->pb.iposes_trial) : load_uniform(&sl->pb.iposes));
-    else v.poses = second ? load_uniform(&sl->pb.poses_trial) : load_uniform(&sl->pb.poses);
-    // pointers out of a record are built from integers: global, not flat, accesses through them (ba_device.hpp: global_ptr)
-    v.poses = global_ptr(v.poses);
-    v.b.clusters = global_ptr(v.b.clusters); v.b.coe = global_ptr(v.b.coe); v.b.pose_index = global_ptr(v.b.pose_index); v.b.twl = global_ptr(v.b.twl);
-    v.b.plane_res = global_ptr(v.b.plane_res); v.b.eig = global_ptr(v.b.eig); v.b.part = global_ptr(v.b.part); v.b.out = global_ptr(v.b.out);
-    return v;
-}
 __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph, int trial) {
+    // (a trial phase's residual of a window with pb.trial_fused ran inside k_ba_trial_fused*_b)
+    if (trial && load_uniform(&(ph.table + ba_phase_window(ph, blockIdx.x))->pb.trial_fused)) return;
     const BalmSlotView v = balm_slot_view(ph, blockIdx.x, trial != 0);
     d_balm_residual_total(v.b, v.poses);
 }
@@ -371,12 +308,18 @@ __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPh
 // registers): alone that costs nothing, but beside the other stages' kernels such a wavefront starts only on a SIMD that has two thirds of
 // its register file free.
 #define TC2LI_HESS_LEAN_KERNEL(name, waves)                                                                                                  \
-    __global__ __launch_bounds__(kHessThreadsSmall) __attribute__((amdgpu_waves_per_eu(waves, waves))) void name(const BaPhase ph) {          \
+    __global__ __launch_bounds__(kHessThreadsSmall) __attribute__((amdgpu_waves_per_eu(waves, waves))) void name(const BaPhase ph, int fuse) { \
         extern __shared__ double s_hess_dyn[];                                                                                               \
         const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);                                                                        \
         if ((int)blockIdx.x >= v.b.n_chunks) return;                                                                                         \
-        d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8, true>(v.b, v.poses, blockIdx.x,                               \
-                                                                                     *reinterpret_cast<HessLds<kHessPlanesSmall, 8>*>(s_hess_dyn)); \
+        auto& L = *reinterpret_cast<HessLds<kHessPlanesSmall, 8>*>(s_hess_dyn);                                                              \
+        /* one instantiation of the body: the partials always leave at device scope (harmless before the separate combine launch) */         \
+        d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8, true, true>(v.b, v.poses, blockIdx.x, L);                      \
+        if (!fuse) return;                                                                                                                   \
+        /* round 5: the window's last chunk adds the chunks' partials (k_balm_combine_b's sums, value by value in chunk order: same bits) */  \
+        if (!ba_last_of(global_ptr(load_uniform(&(ph.table + ba_phase_window(ph, blockIdx.y))->pb.ticket)) + 2, v.b.n_chunks)) return;        \
+        const int n_values = max(balm_part_stride_dev(v.b.W), 12 * v.b.W);                                                                   \
+        for (int idx = threadIdx.x; idx < n_values; idx += kHessThreadsSmall) d_balm_combine_value<true>(v.b, idx);                          \
     }
 TC2LI_HESS_LEAN_KERNEL(k_balm_hessian_lean3_b, 3)  // 168 registers, 13 values in scratch
 TC2LI_HESS_LEAN_KERNEL(k_balm_hessian_lean4_b, 4)  // 128 registers, 84 values in scratch
@@ -395,9 +338,11 @@ void balm_batch_launch_hessian(const BaPhase& ph, int n, const BaBatchExtent& x,
     const char* lean_env = getenv("TC2LI_BALM_HESS_LEAN");
     const int lean = lean_env ? atoi(lean_env) : 3;
     const size_t lds = sizeof(HessLds<kHessPlanesSmall, 8>);
-    if (lean == 4) TC2LI_LAUNCH(k_balm_hessian_lean4_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph);
-    else if (lean == 3) TC2LI_LAUNCH(k_balm_hessian_lean3_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph);
+    const int fuse = x.fuse_linearize && lean != 0;  // the chunks' sums by the window's last chunk (round 5; ba_last_of, ticket word 2)
+    if (lean == 4) TC2LI_LAUNCH(k_balm_hessian_lean4_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph, fuse);
+    else if (lean == 3) TC2LI_LAUNCH(k_balm_hessian_lean3_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), lds, st, ph, fuse);
     else TC2LI_LAUNCH(k_balm_hessian_b, dim3(x.max_chunks, n), dim3(kHessThreadsSmall), 0, st, ph);
+    if (fuse) return;
     TC2LI_LAUNCH(k_balm_combine_b, dim3((std::max(balm_part_stride(x.max_W), 12 * x.max_W) + 255) / 256, n), dim3(256), 0, st, ph);
 }
 

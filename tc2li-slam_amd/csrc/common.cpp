@@ -244,12 +244,14 @@ int host_thread_budget() {
 
 // Threads of pool `id` under the budget B of this process.  B counts the CPUs the process may really use (bench.py / a caller passes
 // min(affinity, cgroup quota) / ranks on the node); a pool thread spends part of its time waiting for its stream, so the pools may hold
-// TC2LI_HOST_THREADS_PER_CPU (default 2) threads per CPU in all.  The stage threads of a caller like the reference (tracking, LiDAR, local
+// TC2LI_HOST_THREADS_PER_CPU (default 8) threads per CPU in all (measured on the one-GPU box, 16 CPUs by cgroup quota, A/B pairs in one call:
+// 2 per CPU -- 3 threads per lock-step group -- 27.3 / 28.7 ms per step of the whole loop, 16 per CPU -- the pool sizes of rounds 2-4 -- 26.1 /
+// 26.0: the per-window host steps of a group's 43 windows want more threads than CPUs, they wait on each other's launches).  The stage threads of a caller like the reference (tracking, LiDAR, local
 // mapping: counted as 5) come off first; of the rest the extractor pool may take a quarter, the tracking pool, the LiDAR pool and each
-// lock-step BA group an eighth -- with B >= 69 every pool has the size it was tuned at (32 / 16 / 16 / 16 per group), with 16 CPUs (the
-// one-GPU box's cgroup quota) 6 + 3 + 3 + 3 x 3, with 8 ranks on 256 cores (B = 32) 14 + 7 + 7 + 3 x 7.
+// lock-step BA group an eighth -- with B >= 18 every pool has the size it was tuned at (32 / 16 / 16 / 16 per group: the one-GPU box's 16 CPUs
+// give 30 / 15 / 15 / 15), with 8 ranks on a node whose cgroup grants 16 CPUs in all (B = 2) 2 + 1 + 1 + 3 x 1.
 int pool_threads(int id) {
-    int per_cpu = 2;
+    int per_cpu = 8;
     if (const char* s = getenv("TC2LI_HOST_THREADS_PER_CPU")) per_cpu = std::max(1, std::min(16, atoi(s)));
     const int B = std::max(1, per_cpu * host_thread_budget() - 5);
     auto share = [&](int cap, int den) { return std::max(1, std::min(cap, B / den)); };
