@@ -1103,9 +1103,10 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
     """the path that DOES use the matrix unit, benched.  The 25-keyframe `bLarge` LocalLVIBA window (Optimizer.cc:1516-1523,
     OptimizerWithLidar.cc:493-500: opt_it 4, lambda 1e-2): 25 free keyframes put the reduced system beyond the block-by-block Schur kernel, so
     S -= (W D^-1) W^T runs as the dense k-major f64 MFMA product (k_ba_schur_gemm*).  A lock-step batch of such windows, timed, then once more
-    with every launch timed (tc2li_profile_*): the GEMM's average launch against the measured f64 MFMA peak.  FLOPs = what the kernel executes
-    (tiles (tiles + 1) / 2 lower-triangle tiles x 16 x 16 x 2 per k step; round 4 counted all tiles^2 and overstated the rate 1.82x); the
-    block-sparse product g2o forms needs a part of them (`useful_frac`)."""
+    with every launch timed (tc2li_profile_*): the product's average launch against the measured f64 MFMA peak.  FLOPs = what the kernel executes:
+    round 5's k_ba_schur_units_b multiplies only the (chunk of 16 landmarks, 16 x 16 tile) pairs the window's observations touch, counted here
+    from the window exactly as the host's chunk masks count them (round 4's line counted all tiles^2 of a dense product whose kernel formed
+    the lower triangle: 1.82x too many); `useful_frac` = the FLOPs of the 6x3 . 3x3 . 3x6 products g2o forms / the executed ones."""
     uniq = []
     for k in range(4):
         w = synthetic.inertial_window(100 + k, n_opt=25, n_points=1500)
@@ -1133,32 +1134,49 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
     s0 = batch.stats[0]
     nf, P = int(s0.n_free_poses), len(uniq[0]["points"])
     np_pad = max(16, (6 * nf + 15) // 16 * 16)
-    tiles, k_total = np_pad // 16, 3 * P
-    n_slices = max(1, min(64, k_total // 64))
-    k_per_slice = ((k_total + n_slices - 1) // n_slices + 3) // 4 * 4
+    tiles = np_pad // 16
     e6, fixed = uniq[0]["edges6"], np.asarray(uniq[0]["fixed"])
     free_edge = fixed[e6[:, 1].astype(int)] == 0
     f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=P)
     useful = float((f_l * (f_l + 1) // 2).sum()) * 324.0
-    gemm = {k: v for k, v in report.items() if base_name(k).startswith("k_ba_schur_gemm")}
+    # what k_ba_schur_units_b EXECUTES for one window and trial: per chunk of 16 landmarks and 16 x 16 tile on or below the diagonal whose rows
+    # and whose columns the chunk touches (the host's chunk_mask, rebuilt here from the window), 12 MFMAs of 16 x 16 x 4 x 2 = 2048 FLOP
+    pose_var = np.cumsum(fixed == 0) - 1
+    fi, fl = pose_var[e6[free_edge, 1].astype(int)], e6[free_edge, 0].astype(int)
+    first, last = np.full(P, 1 << 30), np.full(P, -1)
+    np.minimum.at(first, fl, fi); np.maximum.at(last, fl, fi)
+    seen = np.nonzero(last >= 0)[0]                                  # the host's order: landmarks by (first, last) free pose, stable
+    order = seen[np.lexsort((last[seen], first[seen]))]
+    rank = np.full(P, -1); rank[order] = np.arange(len(order))
+    masks = np.zeros((len(order) + 15) // 16, np.int64)
+    c0 = 6 * fi
+    np.bitwise_or.at(masks, rank[fl] // 16, (1 << (c0 // 16)) | (1 << ((c0 + 5) // 16)))
+    n_mfma = 0
+    for ti in range(tiles):
+        for tj in range(ti + 1):
+            n_mfma += 12 * int((((masks >> ti) & 1) & ((masks >> tj) & 1)).sum())
+    flop_window = n_mfma * 2048.0
+    dense_tiles = tiles * (tiles + 1) // 2 * 12 * len(masks)
+    gemm = {k: v for k, v in report.items() if base_name(k).startswith("k_ba_schur_units")}
     out = {"workload": "%d bLarge LocalLVIBA windows in lock step (25 free keyframes + the fixed one, %d points, %d stereo edges, LiDAR edge over 6 keyframes x 2400 "
-                       "points, 4 iterations at lambda 1e-2): the dense Schur path" % (n_windows, P, len(e6)),
+                       "points, 4 iterations at lambda 1e-2): the MFMA Schur path" % (n_windows, P, len(e6)),
            "windows_per_s": round(n_windows / dt, 1), "ms_per_batch": round(1e3 * dt, 3), "iterations/trials": [int(s0.iterations), int(s0.trials)],
            "free_keyframes": nf, "reduced_system": "(6 + 9) x %d" % nf}
     if gemm:
         name = max(gemm, key=lambda k: gemm[k][1])
         calls, ms = gemm[name]
         third = n_windows // 3 if n_windows >= 6 else n_windows  # three lock-step groups: a launch covers a third of the windows
-        flop_window = (tiles * (tiles + 1) // 2) * 512.0 * k_per_slice * n_slices  # tiles with ti >= tj only (ba_kernels.hip: `if (ti < tj) return`)
         per_launch = flop_window * n_windows * int(s0.trials) / max(calls, 1)
         rate = per_launch / (ms / max(calls, 1) * 1e-3)
         out["roofline"] = {"kernel": base_name(name), "bound": "mfma", "achieved": round(rate / 1e12, 3), "peak": round(peaks["mfma_f64_tflops"], 2), "unit": "TFLOP/s",
                            "frac": round(rate / 1e12 / max(peaks["mfma_f64_tflops"], 1e-9), 5), "frac_of_spec": round(rate / 1e12 / 78.6, 5),
                            "launches": int(calls), "avg_launch_ms": round(ms / max(calls, 1), 6), "executed_flops_per_launch": int(per_launch),
-                           "useful_frac": round(useful / flop_window, 4), "windows_per_launch": third,
-                           "tiles": "%d lower-triangle tiles of 16 x 16 (of %d x %d), k = %d in %d slices" % (tiles * (tiles + 1) // 2, tiles, tiles, k_total, n_slices),
+                           "useful_frac": round(useful / max(flop_window, 1.0), 4), "windows_per_launch": third,
+                           "mfma_per_window_and_trial": n_mfma, "skipped_frac_of_dense_lower_triangle": round(1.0 - n_mfma / max(dense_tiles, 1), 4),
+                           "tiles": "%d lower-triangle tiles of 16 x 16, %d chunks of 16 landmarks (48 operand rows)" % (tiles * (tiles + 1) // 2, len(masks)),
                            "peak_source": "measured: back-to-back v_mfma_f64_16x16x4_f64 (tc2li_diag_peaks); data sheet 78.6 TFLOP/s (frac_of_spec)",
-                           "counters": "profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of this kernel (tools/profile_round.sh, its own --pmc pass of `bench.py --mfma-only`)"}
+                           "counters": "profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES of this kernel / 64 x 2048 FLOP / its launch duration reproduces `achieved` "
+                                       "(tools/profile_round.sh, own --pmc pass of `bench.py --mfma-only`)"}
     return out
 
 

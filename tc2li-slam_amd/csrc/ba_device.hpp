@@ -59,6 +59,7 @@ static_assert(schur_lean_fits_all(), "k_ba_schur_lean: tasks or closing sums of 
 // Per-edge records of the linearisation are padded to whole 16-byte pieces (9 -> 10 and 27 -> 28 doubles) so that they are written
 // and read as double2: the kernels' many pointers may alias as far as the compiler knows, and scalar stores stay scalar.
 constexpr int kContribP = 28;
+constexpr int kUnitChunkHost = 16;     // landmarks per chunk of the dense windows' block-sparse MFMA product (ba_kernels.hip: kUnitChunk)
 constexpr int kBacksubMaxNp = 512;     // doubles of a step x_p the trial kernels stage in LDS
 constexpr int kTrialPoseBytes = 12288; // LDS of the fused trial launch for the window's trial poses (219 SE3 vertices / 61 ImuCamPose records)
 struct BaProblemDev {
@@ -77,9 +78,10 @@ struct BaProblemDev {
     const BaEdge* edges;
     const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges, *grp_k0, *grp_l0;
     // the edges with a free pose, landmark-major ("slots"; the landmarks in the order of the poses they are seen from, ba_host.cpp):
-    // fl_off[2 l], fl_off[2 l + 1] = begin / end of landmark l's slots, fl_pose the free pose of each slot, w_slot[e] the slot of edge e
+    // fl_off[2 l], fl_off[2 l + 1] = begin / end of landmark l's slots, fl_pose the free pose of each slot
     // (-1: fixed pose; dense path only).  A landmark has at most one edge per pose.
-    const int32_t *fl_off, *fl_pose, *w_slot, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each
+    const int32_t *fl_off, *fl_pose, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each
+    const uint32_t* chunk_mask;  // dense path: per chunk of 16 landmarks, the 16-column tiles of the reduced system its landmarks touch
     // sparse_schur: the Schur complement is formed from the landmark-major W blocks (k_ba_schur_sparse; np_pad / 16 <= 8 tile rows),
     // one partial sum per slice; otherwise through the dense k-major operands AT / BT
     // schur_blocks: the sparse product block by block on the f64 vector unit (k_ba_schur_blocks, one partial per kSchurGroup slices)
@@ -97,7 +99,7 @@ struct BaProblemDev {
     double *Hll, *bl, *diag_l;           // per landmark: 6, 3, 1
     double *Hpp, *diag_p;                // per free pose: 27 (21 packed upper + 6 b), 1
     double *coef_e, *coef;               // per edge 6, per free pose 6
-    double *AT, *BT;                     // [3 * n_points][np_pad] k-major GEMM operands (dense path only)
+    double *Y;                           // dense windows: W D^-1 per slot (18), written by k_ba_schur_coef for the trial's lambda
     double *S_part;                      // [n_slices][np_pad * np_pad]; sparse path: row 6 n_free holds W D^-1 b_l
     double *scale_part;                  // per 256 landmarks: partial sums of the gain-ratio scale
     int32_t* ticket;                     // [4] zero between launches: how many workgroups of a window have delivered their partial sums (lock-step batch:
@@ -195,9 +197,9 @@ __device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb)
 #define TC2LI_G(f) pb.f = global_ptr(pb.f)
     TC2LI_G(poses); TC2LI_G(poses_trial); TC2LI_G(iposes); TC2LI_G(iposes_trial); TC2LI_G(points); TC2LI_G(points_trial); TC2LI_G(edges);
     TC2LI_G(pose_var); TC2LI_G(pt_off); TC2LI_G(pt_edges); TC2LI_G(pv_off); TC2LI_G(pv_edges); TC2LI_G(grp_k0); TC2LI_G(grp_l0);
-    TC2LI_G(fl_off); TC2LI_G(fl_pose); TC2LI_G(w_slot); TC2LI_G(fl_lm); TC2LI_G(fl_place); TC2LI_G(slice_off); TC2LI_G(fl_edge);
+    TC2LI_G(fl_off); TC2LI_G(fl_pose); TC2LI_G(chunk_mask); TC2LI_G(fl_lm); TC2LI_G(fl_place); TC2LI_G(slice_off); TC2LI_G(fl_edge);
     TC2LI_G(chi2); TC2LI_G(rho0); TC2LI_G(cp_part); TC2LI_G(W); TC2LI_G(blk_off); TC2LI_G(blk_rows);
-    TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(AT); TC2LI_G(BT);
+    TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(Y);
     TC2LI_G(S_part); TC2LI_G(scale_part); TC2LI_G(chi_part); TC2LI_G(ticket);
 #undef TC2LI_G
 }

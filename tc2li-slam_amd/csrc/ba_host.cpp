@@ -35,7 +35,7 @@ PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
 struct BaWorkspace {
     DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
     DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
-        d_coef_e, d_coef, d_AT, d_Spart, d_scale_part, d_chi_part, d_red;
+        d_coef_e, d_coef, d_Y, d_Spart, d_scale_part, d_chi_part, d_red;
     // the window as the caller hands it over -- poses, points, edges and the index arrays -- goes up in ONE copy: a stream operation
     // costs about as much as one of the loop's kernels, and a batch has one such set per window
     DevBuf<uint8_t> d_in;
@@ -128,11 +128,27 @@ struct VisualProblem {
         // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
         // the window alone, so that a window gives the same bits alone and in a batch
         // (the lean form of the block-by-block product stages half as many slots at a time: kSchurLeanSlots)
-        const int kSliceEdges = schur_lean ? kSchurLeanSlots : 256;
-        constexpr int kSliceLandmarks = 64;
+        // Dense windows (more than 21 free keyframes -- the temporal window of LocalInertialBA's bLarge case; round 5, d_ba_schur_units): the
+        // slots follow the landmarks sorted by the first and the last free pose that sees them, and a slice is a CHUNK of 16 landmarks -- a
+        // landmark of a temporal window is seen from a run of consecutive keyframes, so a chunk touches a band of the reduced system and the
+        // product skips the rest.  (The covisibility windows of the sparse path are not banded: see above.)
+        const bool dense_window = (6 * n_free + 1 + 15) / 16 > 8;
+        const int kSliceEdges = dense_window ? std::numeric_limits<int>::max() : schur_lean ? kSchurLeanSlots : 256;
+        const int kSliceLandmarks = dense_window ? kUnitChunkHost : 64;
+        std::vector<int> order(n_points);
+        for (int l = 0; l < n_points; ++l) order[l] = l;
+        if (dense_window) {
+            std::vector<int> first(n_points, std::numeric_limits<int>::max()), last(n_points, -1);
+            for (int e = 0; e < n_edges; ++e) {
+                const int i = pose_var[edges[e].pose], l = edges[e].point;
+                if (i >= 0) { first[l] = std::min(first[l], i); last[l] = std::max(last[l], i); }
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : last[a] < last[b]; });
+        }
         std::vector<int> seen(std::max(n_free, 1), -1);
         int at = 0, slice_lms = 0;
-        for (int l = 0; l < n_points; ++l) {
+        for (int lo = 0; lo < n_points; ++lo) {
+            const int l = order[lo];
             const int begin = at;
             for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
                 const int e = pt_edges[k], i = pose_var[edges[e].pose];
@@ -177,7 +193,6 @@ struct VisualProblem {
     // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
     const bool sparse = (np + 1 + 15) / 16 <= 8;
     const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
-    const int k_total = 3 * n_points;
     // TC2LI_BA_SCHUR_MFMA=1 (read per window): the zero-padded MFMA form of the sparse product instead of the block-by-block one (A/B measurements)
     const char* mfma_env = getenv("TC2LI_BA_SCHUR_MFMA");
     const bool blocks_form = sparse && n_free <= kSchurBlocksMaxFree && !(mfma_env && atoi(mfma_env) != 0);
@@ -190,34 +205,46 @@ struct VisualProblem {
         n_slices = ba_schur_parts(n_schur_slices, schur_group);  // partial sums in S_part
         k_per_slice = 0;
     } else {
-        n_slices = std::max(1, std::min(64, k_total / 64));
-        k_per_slice = ((k_total + n_slices - 1) / n_slices + 3) / 4 * 4;
+        // dense windows (round 5: d_ba_schur_units): the chunks (slices of slice_off: 16 landmarks each) in at most 8 ranges = partial sums
+        const char* ds_env = getenv("TC2LI_BA_DENSE_SLICES");  // (measurements; read per window)
+        const int want_slices = ds_env ? std::max(1, std::min(64, atoi(ds_env))) : 4;
+        k_per_slice = std::min(64, std::max(1, (n_schur_slices + want_slices - 1) / want_slices));   // chunks per partial sum (at most kUnitMaxChunks: ba_kernels.hip)
+        n_slices = std::max(1, (n_schur_slices + k_per_slice - 1) / k_per_slice);
+    }
+    // which 16-column tiles of the reduced system a chunk of landmarks touches (bit t: a pose with columns in tile t sees one of them)
+    std::vector<uint32_t> chunk_mask;
+    if (!sparse) {
+        if (np_pad / 16 > 32) { set_error("more than 85 free keyframes"); return TC2LI_ERR_INVALID; }
+        chunk_mask.assign((size_t)std::max(n_schur_slices, 1), 0u);
+        for (int c = 0; c < n_schur_slices; ++c)
+            for (int sl = slice_off[c]; sl < slice_off[c + 1]; ++sl) {
+                const int c0 = 6 * fl_pose[sl];
+                chunk_mask[c] |= (1u << (c0 / 16)) | (1u << ((c0 + 5) / 16));
+            }
     }
 
     // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
     auto& d_poses_trial = ws.d_poses_trial;
     auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0,
          &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
-         &d_diag_p = ws.d_diag_p, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef, &d_AT = ws.d_AT,
+         &d_diag_p = ws.d_diag_p, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef,
          &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
     auto& d_depth = ws.d_depth;
     auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
     const size_t E = n_edges, P = n_points;
-    const size_t at_elems = sparse ? 0 : (size_t)(k_per_slice * n_slices + 4) * np_pad;
     TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
     TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
     TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * (size_t)std::max(n_blocks * n_free, 1)));
     TC2LI_HIP_CHECK(d_W.ensure(18 * (size_t)std::max(n_free_edges, 1))); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
     TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
-    if (!sparse) TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E));
+    if (!sparse) { TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E)); TC2LI_HIP_CHECK(ws.d_Y.ensure(18 * (size_t)std::max(n_free_edges, 1))); }
     TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
-    if (!sparse) TC2LI_HIP_CHECK(d_AT.ensure(2 * at_elems));  // A^T and B^T operands back to back: one fill
     TC2LI_HIP_CHECK(d_Spart.ensure((size_t)std::max(n_slices, 1) * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 256 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(std::max(E / 256 + 1, (size_t)n_groups)));
     TC2LI_HIP_CHECK(d_depth.ensure(E));
     TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
     TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
     memset(h_S.p, 0, (size_t)std::max(np * np, 1) * sizeof(double));  // the finish kernel writes the lower triangle only; the rest stays defined
-    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | w_slot | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows | ticket words], every
+    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | chunk_mask | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows | ticket words], every
     // part 16-byte aligned ----
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
@@ -225,7 +252,7 @@ struct VisualProblem {
                  o_pt_edges = align16(o_pt_off + (P + 1) * sizeof(int)), o_pv_off = align16(o_pt_edges + E * sizeof(int)),
                  o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + (sparse ? 0 : pv_edges.size()) * sizeof(int)),
                  o_fl_pose = align16(o_fl_off + 2 * P * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
-                 o_fl_lm = align16(o_w_slot + (sparse ? 0 : E) * sizeof(int)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
+                 o_fl_lm = align16(o_w_slot + chunk_mask.size() * sizeof(uint32_t)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
                  o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
                  o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
                  o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
@@ -246,7 +273,7 @@ struct VisualProblem {
     if (!sparse) memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));  // pv_edges, w_slot: the dense Schur path's
     memcpy(h + o_fl_off, fl_off.data(), 2 * P * sizeof(int));
     memcpy(h + o_fl_pose, fl_pose.data(), fl_pose.size() * sizeof(int));
-    if (!sparse) memcpy(h + o_w_slot, w_slot.data(), E * sizeof(int));
+    if (!sparse) memcpy(h + o_w_slot, chunk_mask.data(), chunk_mask.size() * sizeof(uint32_t));  // (the region held w_slot for the dense form's prepare kernel)
     memcpy(h + o_fl_lm, fl_lm.data(), fl_lm.size() * sizeof(int));
     memcpy(h + o_fl_place, fl_place.data(), fl_place.size() * sizeof(int));
     memcpy(h + o_slice_off, slice_off.data(), slice_off.size() * sizeof(int));
@@ -259,7 +286,6 @@ struct VisualProblem {
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
     TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
-    if (!sparse) TC2LI_HIP_CHECK(zero_or_defer(d_AT.p, 2 * at_elems * sizeof(double), st));
     uint8_t* const d = ws.d_in.p;
 
     pb = BaProblemDev{};
@@ -271,20 +297,20 @@ struct VisualProblem {
     pb.poses = (Se3*)(d + o_poses); pb.poses_trial = d_poses_trial.p; pb.points = (double*)(d + o_points); pb.points_trial = d_points_trial.p;
     pb.edges = (const BaEdge*)(d + o_edges); pb.pose_var = (const int*)(d + o_pose_var); pb.pt_off = (const int*)(d + o_pt_off);
     pb.pt_edges = (const int*)(d + o_pt_edges); pb.pv_off = (const int*)(d + o_pv_off); pb.pv_edges = (const int*)(d + o_pv_edges);
-    pb.fl_off = (const int*)(d + o_fl_off); pb.fl_pose = (const int*)(d + o_fl_pose); pb.w_slot = (const int*)(d + o_w_slot);
+    pb.fl_off = (const int*)(d + o_fl_off); pb.fl_pose = (const int*)(d + o_fl_pose); pb.chunk_mask = (const uint32_t*)(d + o_w_slot);
     pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off); pb.fl_edge = (const int*)(d + o_fl_edge);
     pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
     pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
     pb.ticket = (int32_t*)(d + o_ticket);
-    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = sparse ? n_schur_slices : 0;
+    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = n_schur_slices;  // (dense windows: the chunks of d_ba_schur_units)
     pb.schur_rd = pb.schur_ro = 1;
     decide_trial_fused();
     if (blocks_form) {
         schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
     }
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
-    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p;
-    pb.AT = d_AT.p; pb.BT = d_AT.p + at_elems; pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
+    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p; pb.Y = sparse ? nullptr : ws.d_Y.p;
+    pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
 
         return TC2LI_OK;
     }

@@ -4,9 +4,9 @@
 //   k_ba_linearize      one thread per edge: error, Huber weight, Jacobians, the edge's blocks of J^T W J and J^T W r
 //   k_ba_reduce_all     by workgroup role: Hll, b_l per landmark (CSR, fixed order) | Hpp, b_p per free pose (LDS tree) | robust cost
 //   k_ba_maxdiag        largest diagonal entries for computeLambdaInit (first iteration only)
-//   k_ba_schur_prepare  by role: (Hll + lambda I)^-1, D^-1 b_l per landmark | per edge W D^-1 and W into the k-major GEMM operands
-//   k_ba_reduce_coef    W D^-1 b_l summed per free pose
-//   k_ba_schur_gemm     S_part = sum_k (W D^-1)[:,k] W[:,k]^T with v_mfma_f64_16x16x4_f64, split over k
+//   k_ba_schur_lean     windows of <= 21 free keyframes: S_part = (W D^-1) W^T block by block on the f64 vector unit
+//   k_ba_schur_coef     larger windows, per edge with a free pose: W D^-1 b_l; k_ba_reduce_coef sums them per free pose
+//   k_ba_schur_units    larger windows: S_part = (W D^-1) W^T as a block-sparse product with v_mfma_f64_16x16x4_f64, operand panels in LDS
 //   k_ba_schur_finish   S = Hpp + lambda I - sum S_part, b_s = b_p - coefficients
 //   k_ba_trial_update   by role: x_l = D^-1 (b_l - W^T x_p), trial points, landmark part of the gain-ratio scale | trial poses exp(x_p) * T
 //   k_ba_errors         robust chi2 at the trial estimate
@@ -436,49 +436,29 @@ __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double
 
 // Dense path, per edge with a free pose: W D^-1 and W (6x3) scattered into the two k-major GEMM operands, W D^-1 b_l.  An edge
 // recomputes its landmark's 3x3 inverse (same arithmetic, same value as the back substitution's).
-__device__ __forceinline__ void d_ba_schur_prepare(const BaProblemDev& pb, const int bx, double lambda) {
-    // edges in landmark-major order (the CSR by landmark): neighbouring threads write neighbouring segments of the same three
-    // rows of the GEMM operands; edges of fixed poses drop out
-    const int k = bx * 256 + threadIdx.x;
-    if (k >= pb.n_edges) return;
-    const int e = pb.pt_edges[k];
-    const BaEdge ed = pb.edges[e];
-    const int i = pb.pose_var[ed.pose], l = ed.point;
-    if (i < 0) return;
-    // everything is read first and written last, in 16-byte pieces: the arrays may alias as far as the compiler knows, and
-    // interleaved scalar stores keep it from merging anything (36 eight-byte stores per edge otherwise)
-    typedef double d2 __attribute__((ext_vector_type(2)));
+// Dense-window Schur path (windows of more than 21 free keyframes: LocalInertialBA's bLarge window, Optimizer.cc:1516-1523), per slot =
+// edge with a free pose: the edge's part of sum_l W D^-1 b_l (k_ba_reduce_coef adds a pose's edges in its edge order).  Rounds 1-4 also
+// scattered W D^-1 and W into two dense k-major operands [3 P][np_pad] here (11.5 MB per 25-keyframe window, 29 % non-zero, written
+// every trial and read back by the GEMM); round 5 builds the operand panels in LDS instead (d_ba_schur_units).
+__device__ __forceinline__ void d_ba_schur_coef(const BaProblemDev& pb, const int bx, double lambda) {
+    const int s = bx * 256 + threadIdx.x;
+    if (s >= pb.n_free_edges) return;
+    const int e = pb.fl_edge[s], l = pb.fl_lm[s];
     double W[18];
-    {
-        const d2* w2 = reinterpret_cast<const d2*>(pb.W + 18 * (size_t)pb.w_slot[e]);  // 144 bytes per edge: 16-byte aligned
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { const d2 v = w2[q]; W[2 * q] = v.x; W[2 * q + 1] = v.y; }
-    }
+    load_d2<18>(pb.W + 18 * (size_t)s, W);
     double Di[9], db[3];
     point_dinv(pb, l, lambda, Di, db);
-    double ce[6], y[3][6];
+    double ce[6], Y[18];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         ce[r] = W[3 * r] * db[0] + W[3 * r + 1] * db[1] + W[3 * r + 2] * db[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) y[c][r] = W[3 * r] * Di[c] + W[3 * r + 1] * Di[3 + c] + W[3 * r + 2] * Di[6 + c];
+        for (int k = 0; k < 3; ++k) Y[3 * r + k] = W[3 * r] * Di[k] + W[3 * r + 1] * Di[3 + k] + W[3 * r + 2] * Di[6 + k];  // (W D^-1)[r][k]: the expression of rounds 1-4's prepare kernel
     }
-    d2* co = reinterpret_cast<d2*>(pb.coef_e + 6 * (size_t)e);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) co[q] = d2{ce[2 * q], ce[2 * q + 1]};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const size_t at = (size_t)(3 * l + c) * pb.np_pad + 6 * i;  // np_pad is a multiple of 16, 6 i even: 16-byte aligned
-        d2* a = reinterpret_cast<d2*>(pb.AT + at);  // (W D^-1)^T, k-major
-        d2* b = reinterpret_cast<d2*>(pb.BT + at);  // W^T, k-major
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            a[q] = d2{y[c][2 * q], y[c][2 * q + 1]};
-            b[q] = d2{W[3 * (2 * q) + c], W[3 * (2 * q + 1) + c]};
-        }
-    }
+    store_d2<6>(pb.coef_e + 6 * (size_t)e, ce);
+    store_d2<18>(pb.Y + 18 * (size_t)s, Y);  // the product's first operand, slot by slot (144 B per slot: the units that need it load it instead of inverting again)
 }
-__global__ __launch_bounds__(256) void k_ba_schur_prepare(BaProblemDev pb, double lambda) { d_ba_schur_prepare(pb, blockIdx.x, lambda); }
+__global__ __launch_bounds__(256) void k_ba_schur_coef(BaProblemDev pb, double lambda) { d_ba_schur_coef(pb, blockIdx.x, lambda); }
 
 __device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const int bx) {
     __shared__ double s_part[128 * 6];
@@ -487,111 +467,177 @@ __device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const i
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_coef(BaProblemDev pb) { d_ba_reduce_coef(pb, blockIdx.x); }
 
-// S_part[slice] (np_pad x np_pad, row-major) = sum over the slice's k of AT[k][:]^T BT[k][:]; one wavefront per
-// 16x16 tile and k-slice.  Fragment layout of v_mfma_f64_16x16x4_f64 (checked on gfx950, tools/dbg/mfma_f64_test.hip):
-// A: lane -> A[i = lane % 16][k = lane / 16]; B: lane -> B[k = lane / 16][j = lane % 16];
-// D: lane, r -> D[i = lane / 16 + 4 r][j = lane % 16].
-__device__ __forceinline__ void d_ba_schur_gemm(const int bx, const int by, const double* __restrict__ AT, const double* __restrict__ BT, int np_pad,
-                                                int k_total, int k_per_slice, double* __restrict__ S_part) {
-    const int lane = threadIdx.x, tiles = np_pad / 16;
-    const int ti = bx / tiles, tj = bx % tiles, slice = by;
-    if (ti < tj) return;  // the LDL^T reads the lower triangle only (ldlt_solve_small)
-    const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
-    v4d acc = {0, 0, 0, 0};
-    const int i = lane % 16, kk = lane / 16;
-    const double* pa = AT + 16 * ti + i;
-    const double* pb_ = BT + 16 * tj + i;
-    int k = k0;
-    for (; k + 16 <= k1; k += 16) {  // four k-steps of operands in flight before the first MFMA: the loop is bound by load latency
-        double a[4], b[4];
+// S_part[slice] (np_pad x np_pad, row-major, lower tiles) = sum over the slice's landmarks of (W D^-1) W^T as a block-sparse f64 MFMA
+// product (v_mfma_f64_16x16x4_f64).  Fragment layout (checked on gfx950, tools/dbg/mfma_f64_test.hip): A: lane -> A[i = lane % 16][k = lane / 16];
+// B: lane -> B[k = lane / 16][j = lane % 16]; D: lane, r -> D[i = lane / 16 + 4 r][j = lane % 16].
+//
+// Round 5.  One workgroup of four wavefronts per UNIT = 32 x 32 block of S on or below the diagonal (2 x 2 tiles) and
+// per slice of landmark CHUNKS (16 landmarks = 48 operand rows).  Per chunk the workgroup builds the two operand panels in LDS straight
+// from the landmark-major W blocks -- (W D^-1)^T for the unit's 32 rows, W^T for its 32 columns, [48][32] doubles each, stored as two
+// [48][16] halves so that a fragment read (16 consecutive doubles of four consecutive rows) touches every LDS bank once -- and multiplies
+// them: the chunk's twelve k-steps are dealt to the four wavefronts (w, w + 4, w + 8), each holding the unit's 2 x 2 accumulator tiles,
+// i.e. four independent MFMA chains per wavefront and two operand reads per MFMA pair.  A chunk in which no landmark is seen from the
+// unit's rows or from its columns is skipped (chunk_mask, one bit per 16 columns, built by the host), tile by tile inside a unit: the
+// product is block-sparse -- a landmark touches the poses that see it -- and the dense form multiplied the zeros (29 % useful).  The
+// wavefronts' tiles meet in LDS and are added in wavefront order; k_ba_schur_finish adds the slices in slice order: the bits are a
+// function of the window alone.  No dense operands in HBM (11.5 MB per window and trial before), no prepare scatter, 8 partial
+// sums per window instead of 64.
+constexpr int kUnitChunk = kUnitChunkHost;      // landmarks per chunk (= per slice of slice_off on this path)
+constexpr int kUnitRows = 3 * kUnitChunk;       // operand rows per chunk
+struct UnitPanels { double A[2][kUnitRows][16], B[2][kUnitRows][16]; };
+constexpr int kUnitIdx = 2048;                  // slots of a slice whose (pose, rank in chunk) the workgroup keeps in LDS (beyond: read where they are)
+constexpr int kUnitMaxChunks = 64;              // chunks per slice (the host cuts more slices for larger windows)
+struct UnitsLds {
+    union {
+        UnitPanels buf[2];                      // two chunks' panels: one is multiplied while the other is cleared for the next chunk
+        double red[4][4][256];                  // [wavefront][tile][lane + 64 r]: the wavefronts' accumulators on their way to the sum
+    };
+    unsigned short idx[kUnitIdx];
+    int off[kUnitMaxChunks + 1];
+};
+// What a lane holds of ONE slot of the next chunk while the current one is multiplied (round 5: the loads of chunk c + 1 are in flight
+// under the product of chunk c; before, every chunk was three dependent trips to memory -- offsets, indices, blocks -- with the matrix
+// pipe idle: 31 us per workgroup for 0.5 us of MFMAs per chunk).
+struct UnitSlot { int p, ca, cb; bool inA, inB; double Y[18], W[18]; };
+__device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const int unit, const int slice, const int chunks_per_slice, const double lambda,
+                                                 UnitsLds& L) {
+    (void)lambda;  // (the operands W D^-1 come from k_ba_schur_coef of the same trial)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = pb.np_pad / 16, n_chunks = pb.n_schur_slices;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= unit) ++bi;
+    const int bj = unit - bi * (bi + 1) / 2;
+    const int ti0 = 2 * bi, tj0 = 2 * bj;
+    v4d acc[2][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t kr = (size_t)(k + 4 * u + kk) * np_pad;
-            a[u] = pa[kr];
-            b[u] = pb_[kr];
-        }
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        for (int y = 0; y < 2; ++y) acc[x][y] = v4d{0, 0, 0, 0};
+    // which of the unit's four tiles exist and lie on or below the diagonal
+    bool want[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) want[x][y] = ti0 + x < tiles && tj0 + y <= ti0 + x;
+    const int c_begin = slice * chunks_per_slice, c_end = min(min(c_begin + chunks_per_slice, c_begin + kUnitMaxChunks), n_chunks);
+    const int nc = max(c_end - c_begin, 0);
+    // ---- once per workgroup: the slice's chunk masks (a lane each), its chunks' slot ranges, the slots' (pose, rank) pairs; both buffers clear ----
+    const unsigned my_mask = lane < nc ? pb.chunk_mask[c_begin + lane] : 0u;
+    for (int k = tid; k <= nc; k += 256) L.off[k] = pb.slice_off[c_begin + k];
+    {
+        v2d* z = reinterpret_cast<v2d*>(&L.buf[0]);
+        for (int k = tid; k < (int)(2 * sizeof(UnitPanels) / sizeof(v2d)); k += 256) z[k] = v2d{0, 0};
     }
-    for (; k < k1; k += 4) {
-        const int kr = k + kk;
-        double a = 0, b = 0;
-        if (kr < k1) {
-            a = pa[(size_t)kr * np_pad];
-            b = pb_[(size_t)kr * np_pad];
+    __syncthreads();
+    const int S0 = L.off[0], S1 = L.off[nc];
+    for (int s = S0 + tid; s < min(S1, S0 + kUnitIdx); s += 256) L.idx[s - S0] = (unsigned short)(pb.fl_pose[s] | pb.fl_place[s] << 8);
+    __syncthreads();
+    auto slot_index = [&](int s) -> unsigned { return s - S0 < kUnitIdx ? (unsigned)L.idx[s - S0] : (unsigned)(pb.fl_pose[s] | pb.fl_place[s] << 8); };
+    auto next_chunk = [&](int c) {  // the next chunk from c on that reaches the unit (uniform)
+        for (; c < c_end; ++c) {
+            const unsigned m = __builtin_amdgcn_readlane(my_mask, c - c_begin);
+            if (((m >> ti0) & 3u) && ((m >> tj0) & 3u)) break;
         }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    double* out = S_part + (size_t)slice * np_pad * np_pad;
-    for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + kk + 4 * r) * np_pad + 16 * tj + i] = acc[r];
-}
-__global__ __launch_bounds__(64) void k_ba_schur_gemm(const double* __restrict__ AT, const double* __restrict__ BT, int np_pad,
-                                                      int k_total, int k_per_slice, double* __restrict__ S_part) {
-    d_ba_schur_gemm(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
-}
-
-// The same product with one wavefront per (strip of 32 rows, k-slice): two row tiles times all column tiles (at most CT) in
-// registers, so a k-slice of W D^-1 is read once and the slice of W once per strip instead of once per 16x16 tile.  Every tile
-// still accumulates its k-steps in ascending order: the partial sums are bit-identical to k_ba_schur_gemm's.  Only the tiles on
-// and below the diagonal are formed (column tile <= row tile): the solver reads nothing else, and it is 15 of 25 tiles at 12 poses.
-template <int CT>
-__device__ __forceinline__ void d_ba_schur_gemm_strip(const int strip, const int slice, const double* __restrict__ AT, const double* __restrict__ BT,
-                                                      int np_pad, int k_total, int k_per_slice, double* __restrict__ S_part) {
-    const int lane = threadIdx.x, tiles = np_pad / 16;
-    const int k0 = slice * k_per_slice, k1 = min(k0 + k_per_slice, k_total);
-    const int i = lane % 16, kk = lane / 16;
-    const int t0 = 2 * strip;
-    const bool row1 = t0 + 1 < tiles;
-    v4d acc[2][CT];
+        return c;
+    };
+    auto load_slot = [&](int s, UnitSlot& u) {  // requests the slot's blocks; nothing waits for them here
+        const unsigned ix = slot_index(s);
+        u.p = (int)(ix >> 8);
+        const int col0 = 6 * (int)(ix & 255u);
+        u.ca = col0 - 32 * bi; u.cb = col0 - 32 * bj;  // first column of the pose inside the unit's row / column range
+        u.inA = u.ca > -6 && u.ca < 32; u.inB = u.cb > -6 && u.cb < 32;
+        if (u.inA) load_d2<18>(pb.Y + 18 * (size_t)s, u.Y);  // W D^-1 of the slot (k_ba_schur_coef)
+        if (u.inB) load_d2<18>(pb.W + 18 * (size_t)s, u.W);
+    };
+    auto put_slot = [&](UnitPanels& P, const UnitSlot& u) {
+        if (u.inA) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int r = 0; r < 6; ++r) {
+                const int col = u.ca + r;
+                if (col < 0 || col >= 32) continue;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) acc[a][t] = v4d{0, 0, 0, 0};
-    const double* pa0 = AT + 16 * t0 + i;
-    const double* pa1 = AT + 16 * (row1 ? t0 + 1 : t0) + i;
-    const double* pbase = BT + i;
-    // kU k-steps of operands are requested before the first MFMA of the group consumes them: the loop is bound by load latency,
-    // not by the matrix unit.  The MFMAs of a tile still run in ascending k.
-    constexpr int kU = CT <= 5 ? 8 : 4;
-    for (int k = k0; k < k1; k += 4 * kU) {
-        double a0[kU], a1[kU], b[kU][CT];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int kr = k + 4 * u + kk;
-            const bool in = kr < k1;
-            const size_t ro = (size_t)kr * np_pad;
-            a0[u] = in ? pa0[ro] : 0.0;
-            a1[u] = (in && row1) ? pa1[ro] : 0.0;
-#pragma unroll
-            for (int t = 0; t < CT; ++t) b[u][t] = (in && t < tiles && t <= t0 + 1) ? pbase[ro + 16 * t] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            if (k + 4 * u >= k1) break;  // uniform: steps past the slice would only add zeros
-#pragma unroll
-            for (int t = 0; t < CT; ++t) {
-                if (t > t0 + 1) break;  // uniform over the wavefront
-                if (t <= t0) acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u][t], acc[1][t], 0, 0, 0);
+                for (int k = 0; k < 3; ++k) P.A[col >> 4][3 * u.p + k][col & 15] = u.Y[3 * r + k];
             }
         }
-    }
-    double* out = S_part + (size_t)slice * np_pad * np_pad;
+        if (u.inB) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        if (a == 1 && !row1) break;
+            for (int r = 0; r < 6; ++r) {
+                const int col = u.cb + r;
+                if (col < 0 || col >= 32) continue;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) {
-            if (t >= tiles || t > t0 + a) break;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(size_t)(16 * (t0 + a) + kk + 4 * r) * np_pad + 16 * t + i] = acc[a][t][r];
+                for (int k = 0; k < 3; ++k) P.B[col >> 4][3 * u.p + k][col & 15] = u.W[3 * r + k];
+            }
         }
+    };
+    UnitSlot pre;
+    pre.inA = pre.inB = false;
+    auto preload = [&](int c) {  // this lane's slot of chunk c (the first 256 slots of a chunk are prefetched: 16 landmarks x 16 poses)
+        const int s = L.off[c - c_begin] + tid;
+        pre.inA = pre.inB = false;
+        if (s < L.off[c - c_begin + 1]) load_slot(s, pre);
+    };
+    int cur = 0;
+    int c = next_chunk(c_begin);
+    if (c < c_end) preload(c);
+    while (c < c_end) {
+        const unsigned m = __builtin_amdgcn_readlane(my_mask, c - c_begin);
+        const unsigned rb = (m >> ti0) & 3u, cb = (m >> tj0) & 3u;
+        UnitPanels& P = L.buf[cur];
+        // ---- the panels (clear on entry): every slot of the chunk whose pose has columns in the unit's row / column range writes its part ----
+        put_slot(P, pre);
+        for (int s = L.off[c - c_begin] + 256 + tid; s < L.off[c - c_begin + 1]; s += 256) {  // (a chunk of more than 256 slots: the rest, not prefetched)
+            load_slot(s, pre);  // (the lane's registers of the prefetched slot are free again)
+            put_slot(P, pre);
+        }
+        const int cn = next_chunk(c + 1);
+        if (cn < c_end) preload(cn);  // in flight under the product below
+        __syncthreads();
+        // ---- the product: k-steps wave, wave + 4, wave + 8 of the chunk's twelve ----
+#pragma unroll
+        for (int q = 0; q < kUnitRows / 16; ++q) {
+            const int krow = 4 * (wave + 4 * q) + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x] = P.A[x][krow][lane & 15];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) b[y] = P.B[y][krow][lane & 15];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    if (want[x][y] && ((rb >> x) & 1u) && ((cb >> y) & 1u))  // uniform over the workgroup
+                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        // the other buffer (multiplied one chunk ago: every wavefront is past that) is cleared for the next chunk while the matrix pipe works
+        {
+            v2d* z = reinterpret_cast<v2d*>(&L.buf[cur ^ 1]);
+            for (int k = tid; k < (int)(sizeof(UnitPanels) / sizeof(v2d)); k += 256) z[k] = v2d{0, 0};
+        }
+        __syncthreads();
+        cur ^= 1;  // (the buffer just multiplied is cleared during the next chunk's product and filled again the chunk after)
+        c = cn;
+    }
+    __syncthreads();
+    // ---- the wavefronts' tiles, added in wavefront order; wavefront t writes tile t ----
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) L.red[wave][2 * x + y][lane + 64 * r] = acc[x][y][r];
+    __syncthreads();
+    const int x = wave >> 1, y = wave & 1;
+    if (!(ti0 + x < tiles && tj0 + y <= ti0 + x)) return;
+    double* out = pb.S_part + (size_t)slice * pb.np_pad * pb.np_pad;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = ((L.red[0][wave][lane + 64 * r] + L.red[1][wave][lane + 64 * r]) + L.red[2][wave][lane + 64 * r]) + L.red[3][wave][lane + 64 * r];
+        out[(size_t)(16 * (ti0 + x) + (lane >> 4) + 4 * r) * pb.np_pad + 16 * (tj0 + y) + (lane & 15)] = v;
     }
 }
-template <int CT>
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_strip(const double* __restrict__ AT, const double* __restrict__ BT, int np_pad, int k_total,
-                                                            int k_per_slice, double* __restrict__ S_part) {
-    d_ba_schur_gemm_strip<CT>(blockIdx.x, blockIdx.y, AT, BT, np_pad, k_total, k_per_slice, S_part);
+__global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chunks_per_slice, double lambda) {
+    __shared__ UnitsLds L;
+    d_ba_schur_units(pb, blockIdx.x, blockIdx.y, chunks_per_slice, lambda, L);
 }
 
 // ---- the Schur product from the landmark-major W blocks ----
@@ -1382,37 +1428,23 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaPhase ph) {
     if (!(view_.flags & kBaWantMaxdiag)) return;
     d_ba_maxdiag(pb, blockIdx.x, sl.maxdiag_out);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_prepare_b(const BaPhase ph) {
+__global__ __launch_bounds__(256) void k_ba_schur_coef_b(const BaPhase ph) {
     TC2LI_SLOT(y);
-    if (pb.sparse_schur || !pb.n_free_edges || (int)blockIdx.x >= blocks256(pb.n_edges)) return;
-    d_ba_schur_prepare(pb, blockIdx.x, view_.lambda);
+    if (pb.sparse_schur || (int)blockIdx.x >= blocks256(pb.n_free_edges)) return;
+    d_ba_schur_coef(pb, blockIdx.x, view_.lambda);
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if (pb.sparse_schur || (int)blockIdx.x >= pb.n_free) return;
     d_ba_reduce_coef(pb, blockIdx.x);
 }
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_tiles_b(const BaPhase ph) {
+// the dense windows' Schur product: (unit, slice, window) = blockIdx.(x, y, z)
+__global__ __launch_bounds__(256) void k_ba_schur_units_b(const BaPhase ph) {
+    __shared__ UnitsLds L;
     TC2LI_SLOT(z);
-    const int tiles = pb.np_pad / 16;
-    if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= tiles * tiles || (int)blockIdx.y >= sl.n_slices) return;
-    d_ba_schur_gemm(blockIdx.x, blockIdx.y, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
-}
-// One-dimensional launch in XCD-contiguous order (workgroups reach the 8 XCDs round-robin by linear index, each with its own L2): the
-// strips of one k-slice read the same rows of W^T, so consecutive entries of the (window, slice, strip) list stay on one XCD.
-template <int CT>
-__global__ __launch_bounds__(64) void k_ba_schur_gemm_b(const BaPhase ph, int strips, int max_slices,
-                                                        int n_active) {
-    const int total = strips * max_slices * n_active, per_xcd = (total + 7) / 8;
-    const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (logical >= total) return;
-    const int window = logical / (strips * max_slices), rem = logical - window * (strips * max_slices), slice = rem / strips, strip = rem - slice * strips;
-    const BaSlotView view_ = ba_slot_view(ph, window);
-    const BaBatchSlot& sl = view_.sl;
-    const BaProblemDev& pb = view_.pb;
-    const int tiles = pb.np_pad / 16;
-    if (pb.sparse_schur || !pb.n_free || 2 * strip >= tiles || slice >= sl.n_slices) return;
-    d_ba_schur_gemm_strip<CT>(strip, slice, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, sl.k_per_slice, pb.S_part);
+    const int ub = (pb.np_pad / 16 + 1) / 2;
+    if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= ub * (ub + 1) / 2 || (int)blockIdx.y >= sl.n_slices) return;
+    d_ba_schur_units(pb, blockIdx.x, blockIdx.y, sl.k_per_slice, view_.lambda, L);
 }
 __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
@@ -1620,12 +1652,12 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
             else TC2LI_LAUNCH(k_ba_schur_sparse9, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
         }
     } else {
-        if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare, dim3(blocks(pb.n_edges)), dim3(256), 0, st, pb, lambda);
+        // the dense windows (> 21 free keyframes): edge coefficients, their per-pose sums, the block-sparse MFMA product by units
+        // (k_per_slice = landmark chunks per slice on this path)
+        if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda);
         TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
-        const int tiles = pb.np_pad / 16, strips = (tiles + 1) / 2;
-        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_strip<5>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
-        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_strip<8>, dim3(strips, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
-        else TC2LI_LAUNCH(k_ba_schur_gemm, dim3(tiles * tiles, n_slices), dim3(64), 0, st, pb.AT, pb.BT, pb.np_pad, 3 * pb.n_points, k_per_slice, pb.S_part);
+        const int ub = (pb.np_pad / 16 + 1) / 2;
+        TC2LI_LAUNCH(k_ba_schur_units, dim3(ub * (ub + 1) / 2, n_slices), dim3(256), 0, st, pb, k_per_slice, lambda);
     }
     TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
 }
@@ -1670,13 +1702,10 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
         else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
     }
     if (x.any_dense) {
-        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_prepare_b, dim3(blocks(x.max_edges), n_active), dim3(256), 0, st, ph);
+        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
         TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);
-        const int tiles = x.max_np_pad / 16, strips = (tiles + 1) / 2;
-        const int gemm_blocks = (strips * x.max_slices * n_active + 7) / 8 * 8;
-        if (tiles <= 5) TC2LI_LAUNCH(k_ba_schur_gemm_b<5>, dim3(gemm_blocks), dim3(64), 0, st, ph, strips, x.max_slices, n_active);
-        else if (tiles <= 8) TC2LI_LAUNCH(k_ba_schur_gemm_b<8>, dim3(gemm_blocks), dim3(64), 0, st, ph, strips, x.max_slices, n_active);
-        else TC2LI_LAUNCH(k_ba_schur_gemm_tiles_b, dim3(tiles * tiles, x.max_slices, n_active), dim3(64), 0, st, ph);
+        const int ub = (x.max_np_pad / 16 + 1) / 2;
+        TC2LI_LAUNCH(k_ba_schur_units_b, dim3(ub * (ub + 1) / 2, x.max_slices, n_active), dim3(256), 0, st, ph);
     }
     TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, ph);
 }
