@@ -88,23 +88,27 @@ __device__ __forceinline__ bool pi_ldlt_solve_wave(const double* __restrict__ s_
         if (lane > k) z -= row[k] * zk;
     }
     const double y_mine = z / my_d;
-    // Backward substitution: x_i = y_i - sum_{k > i} L_ki x_k with k ASCENDING (the order of the LDS form): the first term of row i needs
-    // x_{i + 1}, the last one to become known, so the rows cannot run side by side -- a chain of N (N - 1) / 2 steps, here on values every
-    // lane computes alike (L_ki through v_readlane at compile-time indices).
-    double y[N];
+    // Backward substitution x_i = y_i - sum_{k > i} L_ki x_k.  Rounds 3-4 kept the LDS form's order of the terms (k ascending), which makes
+    // row i wait for x_{i + 1} first: a chain of N (N - 1) / 2 dependent steps, 25 k of an iteration's 105 k cycles at N = 30.  Round 5: the
+    // column sweep -- once x_k is final every row above takes its term L_ki x_k (k DESCENDING per row: the sums' order changes, the results
+    // agree with the oracle at its tolerance as before) -- N steps.  Lane i needs column i of L below the diagonal, which lives in the lanes
+    // below as row entries: transposed once through the matrix's LDS block (this wavefront owns it until the workgroup's next barrier).
+    double* s_Lt = const_cast<double*>(s_H);
 #pragma unroll
-    for (int i = 0; i < N; ++i) y[i] = pi_readlane(y_mine, i);
+    for (int i = 0; i < N; ++i) if (lane < N) s_Lt[i * N + lane] = row[i];  // lane k, entry (k, i): read by lane i as its coefficient of x_k
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double col[N];
 #pragma unroll
-    for (int i = N - 1; i >= 0; --i) {
-        double sx = y[i];
+    for (int k = 0; k < N; ++k) col[k] = lane < N ? s_Lt[lane * N + k] : 0.0;
+    double x = lane < N ? y_mine : 0.0;
 #pragma unroll
-        for (int k = i + 1; k < N; ++k) sx -= pi_readlane(row[i], k) * y[k];
-        y[i] = sx;
+    for (int k = N - 1; k >= 1; --k) {
+        const double xk = pi_readlane(x, k);
+        if (lane < k) x -= col[k] * xk;
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) s_x[i] = y[i];
-    }
+    if (lane < N) s_x[lane] = x;
     return true;
 }
 
@@ -153,7 +157,18 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
             double acc[kPiRed];
 #pragma unroll
             for (int k = 0; k < kPiRed; ++k) acc[k] = 0;
-            for (int i = tid; i < N; i += kPiThreads) {
+            // Round 5: the inertial edge (one lane, ~21 k cycles: pre-integration update, two SO3 logarithms / Jacobians) and the prior edge do
+            // not depend on the visual edges -- wavefront 3 and wavefront 2 form them WHILE wavefronts 0 and 1 walk the correspondences (about
+            // the same time at ~1200 correspondences), instead of after them.
+            if (tid == 192) pi_inertial_edge(s_pre, s_oth, s_cur, s_e, s_J);
+            if (tid == 128 && last) {
+                double Jr[9], Jt[9];
+                pi_prior_edge(s_prior, s_oth, s_pe, Jr, Jt);
+                for (int k = 0; k < 225; ++k) s_pJ[k] = 0;
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { s_pJ[15 * r + c] = Jr[3 * r + c]; s_pJ[15 * (3 + r) + 3 + c] = Jt[3 * r + c]; }
+                for (int k = 6; k < 15; ++k) s_pJ[15 * k + k] = 1.0;
+            }
+            for (int i = tid; i < N && tid < 128; i += 128) {
                 if (out[i]) continue;  // level 1
                 const BaEdge e = E[i];
                 double err[3], B[18];
@@ -191,15 +206,7 @@ __device__ __forceinline__ void pose_inertial_body(const PiProblem* __restrict__
                 s_H[r * n + c] = s_sum[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
             }
             if (tid < 6) s_b[tid] = s_sum[21 + tid];
-            // ---- the inertial edge (lane 0) and the prior edge (lane 64: another wavefront) ----
-            if (tid == 0) pi_inertial_edge(s_pre, s_oth, s_cur, s_e, s_J);
-            if (tid == 64 && last) {
-                double Jr[9], Jt[9];
-                pi_prior_edge(s_prior, s_oth, s_pe, Jr, Jt);
-                for (int k = 0; k < 225; ++k) s_pJ[k] = 0;
-                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { s_pJ[15 * r + c] = Jr[3 * r + c]; s_pJ[15 * (3 + r) + 3 + c] = Jt[3 * r + c]; }
-                for (int k = 6; k < 15; ++k) s_pJ[15 * k + k] = 1.0;
-            }
+            // (the inertial and the prior edge were formed beside the visual edges above)
             __syncthreads();
             if (tid < 216) {  // T = Omega J
                 const int r = tid / 24, c = tid % 24;
