@@ -836,28 +836,147 @@ constexpr int kSortThreads = 1024, kSortLdsThreads = 512, kSortLds = 2048;
 struct TimeSortArrays { float* key; int *idx, *sf, *sl, *cl, *cr, *lp, *rp, *cut; uint8_t* flag; };
 
 // ranges[scan slot base ..]: first index of every range the first kernel left for the second; n_ranges[scan]
+//
+// Round 5: the levels in global memory no longer run over per-element bookkeeping arrays.  Rounds 3-4 replayed a level
+// with nine per-element arrays (range first / last, two prefix counts, two rank tables, cut, flags) passed over four times: ~110 B per point and
+// level, 14.2 GB per launch of 512 scans for 0.24 GB of keys (r04_pmc_traffic_inertial.json).  Now the ranges longer than kSortLds are a short
+// LIST in LDS and the workgroup takes them one after the other; a range's partition is two passes over its keys:
+//   (1) per 64-element block the numbers of left candidates (not smaller than the pivot) and right candidates (not larger), block prefix sums
+//       in LDS;
+//   (2) every candidate finds out ALONE whether Hoare's loop swaps it: the k-th left candidate L_k is exchanged with the k-th right candidate
+//       from the right R_k while L_k < R_k, i.e. a left candidate at p with A(p) left candidates up to it and Bc(p) right candidates behind it
+//       takes part iff Bc(p) >= A(p) (as swap number A(p) - 1), a right candidate at q, the j-th from the right, iff at least j left candidates
+//       lie before it.  Only those are written to the rank tables; the cut is min(first left candidate that takes no part, last right
+//       candidate that does) -- __unguarded_partition's return value.  (tools: the rule checked against a literal Hoare loop on 20 000 random
+//       ranges with ties.)
+// A scan that arrives nearly in time order -- the usual case -- swaps a handful of elements per partition: the traffic is the two reads of
+// the keys, 8 B per point and level.
+constexpr int kTsMaxActive = 128, kTsMaxBlocks = 4096;   // ranges longer than kSortLds at one level (n / kSortLds); 64-element blocks of a range (n <= 262144)
+struct TsRange { int f, l, d; };
 __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                             const ScanSlot* __restrict__ slots, TimeSortArrays A, int* __restrict__ perm,
                                                             int* __restrict__ fallback, int* __restrict__ ranges, int* __restrict__ n_ranges, int depth_override) {
-    __shared__ int s_tot[2][kSortThreads / 64], s_base[2][kSortThreads / 64 + 1], s_any, s_count;
-    const int scan = blockIdx.x, tid = threadIdx.x;
+    __shared__ TsRange s_act[2][kTsMaxActive];
+    __shared__ int s_nact[2], s_nfin, s_k, s_minL, s_minR, s_fail, s_cut;
+    __shared__ int s_prefL[kTsMaxBlocks + 1], s_prefR[kTsMaxBlocks + 1];
+    __shared__ int s_wave[kSortThreads / 64];
+    static_assert(kSortThreads == kVsThreads, "vs_block_scan is written for this workgroup size");
+    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ScanSlot sl_ = slots[scan];
     const int n = count[scan], B = sl_.base;
-    if (tid == 0) { fallback[scan] = 0; n_ranges[scan] = 0; s_count = 0; }
+    if (tid == 0) { fallback[scan] = 0; n_ranges[scan] = 0; }
     if (n <= 0) return;
+    if (n > 64 * kTsMaxBlocks) { if (tid == 0) fallback[scan] = 1; return; }  // (the host sorts such a scan)
     float* const key = A.key + B;
-    int *const idx = A.idx + B, *const sf = A.sf + B, *const sl = A.sl + B, *const dep = A.rp + B;  // rp[first of a range] is no candidate slot: free
-    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; sf[x] = 0; sl[x] = n; }
-    const int depth = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
-    if (tid == 0) dep[0] = depth;
-    const bool ok = sort_levels<kSortThreads, int, float>(key, idx, sf, sl, A.cl + B, A.cr + B, A.lp + B, A.rp + B, A.cut + B, A.flag + B, dep, n, depth, kSortLds,
-                                                   s_tot, s_base, &s_any);
-    if (!ok) { if (tid == 0) fallback[scan] = 1; return; }  // uniform
+    int *const idx = A.idx + B, *const lp = A.lp + B, *const rp = A.rp + B, *const last_of = A.sl + B;
+    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; }
+    const int depth0 = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
+    if (tid == 0) {
+        s_nact[0] = s_nact[1] = 0; s_nfin = 0; s_fail = 0; s_k = 0; s_minL = s_minR = 0x7fffffff;
+        if (n > kSortLds) { s_act[0][0] = TsRange{0, n, depth0}; s_nact[0] = 1; }
+        else { ranges[B] = 0; last_of[0] = n; rp[0] = depth0; s_nfin = 1; }
+    }
     __syncthreads();
-    for (int x = tid; x < n; x += kSortThreads)
-        if (sf[x] == x) ranges[B + atomicAdd(&s_count, 1)] = x;
-    __syncthreads();
-    if (tid == 0) n_ranges[scan] = s_count;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);  // lanes up to and including this one
+    int cur = 0;
+    while (s_nact[cur] > 0) {
+        const int na = s_nact[cur];
+        for (int r = 0; r < na; ++r) {
+            const TsRange R = s_act[cur][r];
+            const int f = R.f, l = R.l;
+            if (R.d == 0) { if (tid == 0) s_fail = 1; continue; }  // std::sort would heap-sort this range: the host sorts the scan
+            // ---- __move_median_to_first(first, first + 1, mid, last - 1) ----
+            if (tid == 0) {
+                const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+                const float ka = key[a], kb = key[b], kc = key[c];
+                int m;
+                if (ka < kb) m = kb < kc ? b : (ka < kc ? c : a);
+                else m = ka < kc ? a : (kb < kc ? c : b);
+                const float kf = key[f], km = key[m];
+                const int jf = idx[f], jm = idx[m];
+                key[f] = km; idx[f] = jm; key[m] = kf; idx[m] = jf;
+            }
+            __syncthreads();
+            const float pv = key[f];
+            const int nb = (l - (f + 1) + 63) / 64;
+            // ---- pass 1: candidates per block ----
+            for (int b = wave; b < nb; b += kSortThreads / 64) {
+                const int x = f + 1 + 64 * b + lane;
+                bool fl = false, fr = false;
+                if (x < l) { const float k = key[x]; fl = !(k < pv); fr = !(pv < k); }
+                const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+                if (lane == 0) { s_prefL[b] = __popcll(bl); s_prefR[b] = __popcll(br); }
+            }
+            __syncthreads();
+            // exclusive prefix sums over the blocks: a thread owns q consecutive blocks
+            int totL, totR;
+            {
+                const int q = (nb + kSortThreads - 1) / kSortThreads, b0 = tid * q, b1 = min(b0 + q, nb);
+                int sL = 0, sR = 0;
+                for (int b = b0; b < b1; ++b) { sL += s_prefL[b]; sR += s_prefR[b]; }
+                int eL = vs_block_scan(sL, s_wave, totL);
+                int eR = vs_block_scan(sR, s_wave, totR);
+                for (int b = b0; b < b1; ++b) { const int cL = s_prefL[b], cR = s_prefR[b]; s_prefL[b] = eL; s_prefR[b] = eR; eL += cL; eR += cR; }
+            }
+            __syncthreads();
+            // ---- pass 2: who is swapped, with whom; the first left candidate that is not, the last right candidate that is ----
+            for (int b = wave; b < nb; b += kSortThreads / 64) {
+                const int x = f + 1 + 64 * b + lane;
+                bool fl = false, fr = false;
+                if (x < l) { const float k = key[x]; fl = !(k < pv); fr = !(pv < k); }
+                const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+                const int incL = s_prefL[b] + __popcll(bl & le), incR = s_prefR[b] + __popcll(br & le);
+                bool partL = false, partR = false;
+                if (fl) {
+                    partL = totR - incR >= incL;            // right candidates behind x >= left candidates up to x
+                    if (partL) lp[f + 1 + (incL - 1)] = x;
+                }
+                if (fr) {
+                    const int j = totR - (incR - 1);        // x is the j-th right candidate from the right
+                    partR = incL - (fl ? 1 : 0) >= j;       // at least j left candidates before x
+                    if (partR) rp[f + 1 + (j - 1)] = x;
+                }
+                const unsigned long long bpl = __ballot(partL), bnl = __ballot(fl && !partL), bpr = __ballot(partR);
+                if (lane == 0) {
+                    if (bpl) atomicAdd(&s_k, __popcll(bpl));
+                    if (bnl) atomicMin(&s_minL, f + 1 + 64 * b + __builtin_ctzll(bnl));
+                    if (bpr) atomicMin(&s_minR, f + 1 + 64 * b + __builtin_ctzll(bpr));
+                }
+            }
+            __syncthreads();
+            // ---- the swaps; the two ranges of the partition ----
+            const int ks = s_k;
+            for (int k = tid; k < ks; k += kSortThreads) {
+                const int Lx = lp[f + 1 + k], Rx = rp[f + 1 + k];
+                const float k1 = key[Lx], k2 = key[Rx];
+                const int j1 = idx[Lx], j2 = idx[Rx];
+                key[Lx] = k2; idx[Lx] = j2; key[Rx] = k1; idx[Rx] = j1;
+            }
+            if (tid == 0) s_cut = min(s_minL, ks >= 1 ? s_minR : 0x7fffffff);
+            __syncthreads();
+            if (tid == 0) {
+                const int c = s_cut, d = R.d - 1;
+                const int lo[2] = {f, c}, hi[2] = {c, l};
+                for (int h = 0; h < 2; ++h) {
+                    if (hi[h] <= lo[h]) continue;
+                    if (hi[h] - lo[h] > kSortLds) {
+                        const int at = s_nact[cur ^ 1];
+                        if (at < kTsMaxActive) { s_act[cur ^ 1][at] = TsRange{lo[h], hi[h], d}; s_nact[cur ^ 1] = at + 1; } else s_fail = 1;
+                    } else {
+                        ranges[B + s_nfin] = lo[h]; last_of[lo[h]] = hi[h]; rp[lo[h]] = d; ++s_nfin;  // rp[first of a range]: no rank-table slot (they start at first + 1)
+                    }
+                }
+                s_k = 0; s_minL = s_minR = 0x7fffffff;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) s_nact[cur] = 0;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (s_fail) fallback[scan] = 1; else n_ranges[scan] = s_nfin;
+    }
 }
 
 __global__ __launch_bounds__(kSortLdsThreads) void k_time_sort_lds(const int* __restrict__ count, const ScanSlot* __restrict__ slots, TimeSortArrays A,
