@@ -1482,71 +1482,78 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaPhase ph) {
 // backward substitution is the host's row loop, one lane at a time -- so a window gives the same step here and in the one-window path.
 // The lower triangle lives packed in LDS (row i at i (i + 1) / 2).  A pivot that is zero or not finite: ok = 0 and a zero step (the
 // host treats the trial as failed).
-constexpr int kSolveThreads = 128;
+// The reduced system of a window solved on the device (TC2LI_BA_DEVICE_SOLVE=1): ldlt_solve_small's factorisation and substitutions, the same
+// operations on the same operands in the same order per entry -- so the step is the host's bit for bit -- carried out by a workgroup:
+//   * factorisation RIGHT-LOOKING (round 5): after column k has its pivot and L_ik = a_ik / D_k, every remaining entry (i, j), j > k, takes its
+//     term (L_ik L_jk) D_k -- k = 0, 1, ... in the order the host's row-by-row sums take them -- all entries of a step side by side over the
+//     256 threads (rounds 2-4: one thread per row walked its row's sums, and the closing substitution was ONE thread's chain of n (n - 1) / 2
+//     LDS round trips: 80-100 us per window, slower than the host's 60);
+//   * substitutions as column sweeps by wavefront 0 (x_k is final, every other row takes its term): n steps each.  The backward sweep adds a
+//     row's terms with k DESCENDING; ldlt_solve_small (ba_math.hpp) does the same since round 5.
+constexpr int kSolveThreads = 256;
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) {
     extern __shared__ double s_solve[];
     __shared__ int s_bad;
     TC2LI_SLOT(x);
     const int n = 6 * pb.n_free, tid = threadIdx.x;
     if (n == 0 || !sl.x_dev) return;
-    double* L = s_solve;                    // packed lower triangle
-    double* dg = L + (size_t)n * (n + 1) / 2;  // pivots
-    double* xs = dg + n;                    // solution vector
+    double* L = s_solve;                    // full n x n, lower triangle used: L[i * n + j], j <= i
+    double* dg = L + (size_t)n * n;         // pivots
+    double* xs = dg + n;                    // right-hand side / solution
     if (tid == 0) s_bad = 0;
-    double* Li = L + (size_t)tid * (tid + 1) / 2;
-    double xi = 0;
-    if (tid < n) {
-        const double* Srow = sl.S_out + (size_t)tid * n;
-        if (sl.Hl) {
-            const double* Hrow = sl.Hl + (size_t)tid * n;
-            for (int k = 0; k <= tid; ++k) Li[k] = Srow[k] + Hrow[k];
-            xi = sl.bs_out[tid] + sl.bl_lidar[tid];
-        } else {
-            for (int k = 0; k <= tid; ++k) Li[k] = Srow[k];
-            xi = sl.bs_out[tid];
-        }
+    for (int e = tid; e < n * n; e += kSolveThreads) {
+        const int i = e / n, j = e - i * n;
+        if (j > i) continue;
+        L[e] = sl.Hl ? sl.S_out[e] + sl.Hl[e] : sl.S_out[e];
     }
+    for (int i = tid; i < n; i += kSolveThreads) xs[i] = sl.Hl ? sl.bs_out[i] + sl.bl_lidar[i] : sl.bs_out[i];
     __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        const double* Lj = L + (size_t)j * (j + 1) / 2;
-        double s = 0;
-        if (tid == j) {
-            double d = Lj[j];
-            for (int k = 0; k < j; ++k) d -= Lj[k] * Lj[k] * dg[k];
-            if (!(d == d) || d == 0.0 || d - d != 0.0) s_bad = 1;
-            dg[j] = d;
-            Li[j] = d;
-        } else if (tid > j && tid < n) {
-            s = Li[j];
-            for (int k = 0; k < j; ++k) s -= Li[k] * Lj[k] * dg[k];
-        }
-        __syncthreads();
-        if (tid > j && tid < n) Li[j] = s / dg[j];
-        __syncthreads();
-    }
-    // forward substitution, column by column
     for (int k = 0; k < n; ++k) {
-        if (tid == k) xs[k] = xi;
-        __syncthreads();
-        if (tid > k && tid < n) xi -= Li[k] * xs[k];
-    }
-    __syncthreads();
-    if (tid < n) xs[tid] = xi / dg[tid];
-    __syncthreads();
-    // backward substitution: row i needs every later entry first, and adds them in ascending order like the host
-    for (int i = n - 1; i >= 0; --i) {
-        if (tid == i) {
-            double s = xs[i];
-            for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * (k + 1) / 2 + i] * xs[k];
-            xs[i] = s;
+        const double d = L[k * n + k];
+        if (tid == 0) { if (!(d == d) || d == 0.0 || d - d != 0.0) s_bad = 1; dg[k] = d; }
+        // column k below the pivot still holds a_ik (its terms of the columns before are in): the trailing entries take (a_ik / d)(a_jk / d) d
+        const int m = n - 1 - k;            // rows below
+        for (int e = tid; e < m * (m + 1) / 2; e += kSolveThreads) {
+            // e -> (r, c), c <= r < m: entry (k + 1 + r, k + 1 + c)
+            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while (r * (r + 1) / 2 > e) --r;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            const int c = e - r * (r + 1) / 2, i = k + 1 + r, j = k + 1 + c;
+            const double lik = L[i * n + k] / d, ljk = L[j * n + k] / d;
+            L[i * n + j] -= lik * ljk * d;
         }
         __syncthreads();
+        for (int i = k + 1 + tid; i < n; i += kSolveThreads) L[i * n + k] = L[i * n + k] / d;
+        __syncthreads();
     }
+    if (tid < 64) {
+        // forward substitution z_i = b_i - sum_{k < i} L_ik z_k (k ascending), division by D, backward x_i = y_i - sum_{k > i} L_ki x_k (k descending)
+        const int lane = tid;
+        for (int k = 0; k < n; ++k) {
+            const double zk = xs[k];
+            for (int i = k + 1 + lane; i < n; i += 64) xs[i] -= L[i * n + k] * zk;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        for (int i = lane; i < n; i += 64) xs[i] = xs[i] / dg[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int k = n - 1; k >= 1; --k) {
+            const double xk = xs[k];
+            for (int i = lane; i < k; i += 64) xs[i] -= L[k * n + i] * xk;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    __syncthreads();
     const bool bad = s_bad != 0;
-    if (tid < n) {
-        const double v = bad ? 0.0 : xs[tid];
-        sl.x_dev[tid] = v;
-        sl.x_host[tid] = v;
+    for (int i = tid; i < n; i += kSolveThreads) {
+        const double v = bad ? 0.0 : xs[i];
+        sl.x_dev[i] = v;
+        sl.x_host[i] = v;
     }
     if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
 }
@@ -1712,8 +1719,8 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
     const int n = 6 * x.max_free;
-    const size_t lds = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);
-    (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 72 * 1024);  // 21 free keyframes: 66 KB
+    const size_t lds = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);  // 12 free keyframes: 42 KB; 21: 129 KB
+    (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 132 * 1024);
     TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
 }
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {

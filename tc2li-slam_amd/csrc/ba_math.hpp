@@ -192,9 +192,11 @@ __host__ __device__ inline bool ldlt_solve_small(double* H, int n, const double*
         x[i] = s;
     }
     for (int i = 0; i < n; ++i) x[i] /= H[i * n + i];
+    // (a row's terms with k DESCENDING since round 5: the order in which a column sweep on the device -- x_k final, every row above takes its
+    // term -- adds them, k_ba_solve_b / pi_ldlt_solve_wave; rounds 1-4 added them ascending, which chains the rows on the device)
     for (int i = n - 1; i >= 0; --i) {
         double s = x[i];
-        for (int k = i + 1; k < n; ++k) s -= H[k * n + i] * x[k];
+        for (int k = n - 1; k > i; --k) s -= H[k * n + i] * x[k];
         x[i] = s;
     }
     return true;
