@@ -66,6 +66,19 @@ for k, v in top:
 mf = counter_per_kernel("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
 busy = counter_per_kernel("pmc_mfma", "SQ_BUSY_CYCLES")
 wave = counter_per_kernel("pmc_mfma", "SQ_WAVE_CYCLES")
+def kernel_durations(sub):
+    """{kernel: [launches, total ns]} from the kernel trace of a --pmc pass (the same dispatches the counters belong to)"""
+    acc = {}
+    for f in glob.glob(os.path.join(out, sub, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            a = acc.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return acc
+
+
+mdur = kernel_durations("pmc_mfma")
 mres = {}
 for k, (n, v) in mf.items():
     if v <= 0:
@@ -73,6 +86,13 @@ for k, (n, v) in mf.items():
     b, w = busy.get(k, [0, 0.0]), wave.get(k, [0, 0.0])
     mres[k] = {"launches": n, "mfma_busy_cycles_per_launch": v / n, "sq_busy_cycles_per_launch": b[1] / b[0] if b[0] else None,
                "sq_wave_cycles_per_launch": w[1] / w[0] if w[0] else None}
+    if k in mdur and mdur[k][0]:
+        # the pass's own launch duration next to the counters -- one v_mfma_f64_16x16x4_f64 (2048 FLOP) keeps the pipe busy for 64
+        # counted cycles (k_diag_mfma_f64: 2^27 instructions per launch, 2^33 busy cycles), so busy / 64 x 2048 / duration is the executed rate
+        dur_ns = mdur[k][1] / mdur[k][0]
+        mres[k]["avg_duration_ns_this_pass"] = dur_ns
+        mres[k]["mfma_instructions_per_launch"] = v / n / 64.0
+        mres[k]["executed_tflops_from_counters"] = v / n / 64.0 * 2048.0 / dur_ns / 1e3
 if mres:
     json.dump(mres, open("profiles/%s_pmc_mfma.json" % tag, "w"), indent=1, sort_keys=True)
     for k, v in mres.items():
