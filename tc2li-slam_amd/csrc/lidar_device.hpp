@@ -98,7 +98,7 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
 // ---- map maintenance (map_incremental / Add_Points with down-sampling / Delete_Point_Boxes), batched over maps ----
 struct MapIncRec { unsigned long long key; int idx; int pad; };
 constexpr int kMapIncMax = 8192;
-constexpr int kMapIncOut = 16;  // per task: [0] n_add [1] n_groups [2] n_noneed [3] overflow [4] kept K [5] appended [6..11] bbox of the added points [12] kept among the first K
+constexpr int kMapIncOut = 16;  // per task: [0] n_add [1] n_groups [2] n_noneed [3] overflow [4] kept K [5] appended [6..11] bbox of the added points [12] kept among the first K [13] grid inconsistency found by the compaction [14] listed deletions (lean tasks) [15] more than kMapDelMax of them
 // One (scan, map) pair of a batched map_incremental / compaction (map_kernels.hip).  has_inc = 0: compaction only (box deletion).
 struct MapIncTask {
     // scan side: slots of the tc2li_lidar workspace
@@ -128,7 +128,11 @@ struct MapIncTask {
     const float* boxes;            // [n_boxes][6] (min, max) of KD_TREE::Delete_Point_Boxes; has_inc = 0 tasks only
     int n_boxes;
     int fix_grid;                  // the grid is maintained in place: deleted points' entries become tombstones (k_mapinc_apply), moved points' entries get the new index (k_map_fill)
+    int lean;                      // round 5: the deletions are LISTED (k_mapinc_apply appends to `holes`, count in out[14]) and the compaction works from
+                                   // that list (k_map_compact_list: O(deletions)) instead of passing over the map's flags three times (O(map));
+                                   // tasks with fix_grid and without boxes
 };
+constexpr int kMapDelMax = 8192;   // listed deletions per map and step (more: out[15], and the host repeats the map's compaction through the flag passes)
 // Counting sort of one map's points into its dense grid.
 struct MapGridTask {
     MapGrid g;         // geometry + points of the map (g.pts / g.bucket_start = what the build writes)
@@ -184,7 +188,7 @@ __device__ __forceinline__ MapInsTask global_record(MapInsTask t) {
 void launch_map_insert(const MapInsTask* tasks, int n_tasks, hipStream_t st);
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
-void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, hipStream_t st);
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work /* max over tasks of n_old + added */, int max_cells,
                            int max_row_entries /* max over tasks of segments * kMapSegStride + 1 */, hipStream_t st);
 

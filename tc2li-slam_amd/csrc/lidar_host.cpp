@@ -1254,6 +1254,9 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
     std::vector<int> which;  // task -> index in the caller's arrays
     tasks.reserve(n_tasks);
     int max_points = 0, max_map = 0;
+    bool any_lean = false;
+    const char* lean_env = getenv("TC2LI_MAP_COMPACT_LIST");
+    const bool no_lean = lean_env && atoi(lean_env) == 0;
     const float ds = (float)fs;  // ikdtree.set_downsample_param(filter_size_map_min): float downsample_size
     for (int i = 0; i < n_tasks; ++i) {
         tc2li_lidar_map* m = maps[i];
@@ -1278,20 +1281,41 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         memcpy(&t.st, &states[i], sizeof(LidarStateDev));
         t.fs = fs; t.ds = ds; t.n = n; t.n_map = m->n; t.keep_blocks = kb; t.ekf_inited = ekf_inited; t.has_inc = 1;
         t.fix_grid = m->grid_valid && m->grid.n_slots > 0 && !always_rebuild;
+        // round 5: a map whose grid is maintained in place compacts from the LIST of its deletions (k_map_compact_list) instead of three passes
+        // over all its points; TC2LI_MAP_COMPACT_LIST=0 (read per call): the flag passes for every map
+        t.lean = t.fix_grid && !no_lean ? 1 : 0;
         tasks.push_back(t);
         which.push_back(i);
         max_points = std::max(max_points, n);
-        max_map = std::max(max_map, m->n);
+        if (!t.lean) max_map = std::max(max_map, m->n);
+        any_lean |= t.lean != 0;
     }
     const int nt = (int)tasks.size();
     if (nt) {
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
         TC2LI_HIP_CHECK(hipMemsetAsync(L->d_batch_overflow.p, 0, sizeof(int), st));
         launch_mapinc_lists(L->d_inc_tasks.p, nt, max_points, st);
-        launch_map_compact(L->d_inc_tasks.p, nt, max_map, st);
+        launch_map_compact(L->d_inc_tasks.p, nt, max_map, any_lean, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        {   // a lean map with more deletions than its list holds (out[15]) has not been compacted: once more, through the flag passes
+            std::vector<int> again;
+            for (int k = 0; k < nt; ++k)
+                if (tasks[k].lean && L->h_mapinc_out.p[k * kMapIncOut + 15] && !L->h_mapinc_out.p[k * kMapIncOut + 3]) again.push_back(k);
+            if (!again.empty()) {
+                std::vector<MapIncTask> redo;
+                int redo_max = 0;
+                for (int k : again) { tasks[k].lean = 0; redo.push_back(tasks[k]); redo_max = std::max(redo_max, tasks[k].n_map); }
+                // (the batch's own tasks are done with -- the stream has been waited for -- so the repeated ones take their place; their `out`
+                // pointers are those of the first pass)
+                TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, redo.data(), redo.size() * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
+                launch_map_compact(L->d_inc_tasks.p, (int)redo.size(), redo_max, false, st);
+                TC2LI_HIP_CHECK(hipGetLastError());
+                TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
+                TC2LI_HIP_CHECK(stream_wait_blocking(st));
+            }
+        }
         for (int k = 0; k < nt; ++k)
             if (L->h_mapinc_out.p[k * kMapIncOut + 3]) {
                 // the compaction kernels saw the batch word and touched no map; the deletion marks of the lists are taken back
@@ -1453,7 +1477,7 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_boxes.p, boxes6, 6 * (size_t)total_boxes * sizeof(float), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
     launch_map_mark_boxes(ws.d_tasks.p, nt, max_map, st);
-    launch_map_compact(ws.d_tasks.p, nt, max_map, st);
+    launch_map_compact(ws.d_tasks.p, nt, max_map, false, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_out.p, ws.d_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(stream_wait_blocking(st));  // the uploads above read the caller's and this function's host memory: done here too

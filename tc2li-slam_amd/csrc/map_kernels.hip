@@ -54,6 +54,7 @@ __global__ __launch_bounds__(1024) void k_mapinc_group(const MapIncTask* __restr
     const int tid = threadIdx.x, n = T.n;
     const float ds = T.ds;
     if (tid < 3) s_base[tid] = 0;
+    if (tid == 0) { T.out[14] = 0; T.out[15] = 0; }  // the deletion list of a lean task (k_mapinc_apply, the next launch, appends to it)
     __syncthreads();
     // ordered compaction of both lists, 1024 points at a time
     for (int b0 = 0; b0 < n; b0 += 1024) {
@@ -189,7 +190,17 @@ __global__ __launch_bounds__(128) void k_mapinc_apply(const MapIncTask* __restri
         // here (voxels are disjoint boxes: no other thread looks at these entries)
         float4* const entries = const_cast<float4*>(grid.pts);
         const int fix = T.fix_grid;
-        for_each_stored([&](int idx, int k) { T.deleted[idx] = 1; if (fix) entries[k].w = __int_as_float(-1); });
+        if (T.lean) {  // listed, not flagged: voxels are disjoint boxes, so every point is listed once; the list is sorted before it is used
+            // (the flag is set as well: a map with more than kMapDelMax deletions in one step goes through the flag passes after all)
+            for_each_stored([&](int idx, int k) {
+                const int at = atomicAdd(&T.out[14], 1);
+                if (at < kMapDelMax) T.holes[at] = idx; else T.out[15] = 1;
+                T.deleted[idx] = 1;
+                if (fix) entries[k].w = __int_as_float(-1);
+            });
+        } else {
+            for_each_stored([&](int idx, int k) { T.deleted[idx] = 1; if (fix) entries[k].w = __int_as_float(-1); });
+        }
         T.appended[g] = cur;
         T.has_append[g] = 1;
     } else {
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256) void k_map_mark_boxes(const MapIncTask* __rest
 // order) and the PointNoNeedDownsample points (scan order) follow from K on -------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __restrict__ tasks) {
     const MapIncTask T = global_record(tasks[blockIdx.y]);
-    if ((int)blockIdx.x >= T.keep_blocks) return;
+    if (T.lean || (int)blockIdx.x >= T.keep_blocks) return;
     const int i = blockIdx.x * 1024 + threadIdx.x;
     const int c = __syncthreads_count(i < T.n_map && !T.deleted[i]);
     if (threadIdx.x == 0) T.keep_counts[blockIdx.x] = c;
@@ -226,6 +237,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_count(const MapIncTask* __res
 // out: [4] kept [5] appended [6..11] bounding box of what is added (encoded floats), initialised here
 __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __restrict__ tasks) {
     const MapIncTask T = global_record(tasks[blockIdx.x]);
+    if (T.lean) return;
     __shared__ int s_part[1024];
     __shared__ int s_wave[16];
     const int tid = threadIdx.x, nblocks = T.keep_blocks;
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_map_keep_scan(const MapIncTask* __rest
 }
 __global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict__ tasks) {
     const MapIncTask T = global_record(tasks[blockIdx.y]);
-    if ((int)blockIdx.x >= T.keep_blocks) return;
+    if (T.lean || (int)blockIdx.x >= T.keep_blocks) return;
     if (*T.batch_overflow) return;  // nothing is touched when the batch fails (the flags are reset by the host's next call)
     __shared__ int s_wave[16];
     const int i = blockIdx.x * 1024 + threadIdx.x;
@@ -286,9 +298,104 @@ __global__ __launch_bounds__(1024) void k_map_holes(const MapIncTask* __restrict
     if (!keep && i < K) T.holes[i - kp] = i;
     if (keep && i >= K) T.holes[T.n_map + (kp - kpK)] = i;
 }
+// Round 5: the compaction of a lean task from its deletion LIST -- one workgroup per map.  The three kernels above pass over every point of
+// every map (190 k points x 512 maps: 97 M flags read twice, 390 MB of index map written, 3 M wavefronts launched per step) to find the
+// ~1 600 points per map a step deletes; k_mapinc_apply knows them.  The list is sorted (bitonic, LDS); with d deletions and K = n - d kept,
+// the holes are the listed places below K and the fillers the places from K on that are NOT listed -- both in index order, h-th hole <-
+// h-th filler: the assignment of k_map_holes / k_map_fill, so the map's point array is the same bit for bit.  The index map (remap) is
+// not written: a lean task maintains its grid in place (fix_grid) and nothing reads it.  Also k_map_keep_scan's outputs: out[4] kept,
+// out[5] appended representatives, out[6..11] bounding box words, out[12] kept among the first K, out[13] = 0.
+__global__ __launch_bounds__(1024) void k_map_compact_list(const MapIncTask* __restrict__ tasks) {
+    const MapIncTask T = global_record(tasks[blockIdx.x]);
+    if (!T.lean) return;
+    __shared__ int s_del[kMapDelMax], s_mov[kMapDelMax];
+    __shared__ int s_wave[16], s_tot;
+    const int tid = threadIdx.x;
+    if (*T.batch_overflow != 0) return;  // a failing batch touches no map (the host reports it and takes the deletion marks back)
+    if (T.out[15] != 0) return;          // more deletions than the list holds: the host sends this map through the flag passes (lean = 0)
+    const int d = min(T.out[14], kMapDelMax), n = T.n_map, K = n - d;
+    // appended representatives: has_append over the groups (k_map_keep_scan's sum)
+    int a = 0;
+    const int ng = T.has_inc ? T.out[1] : 0;
+    for (int g = tid; g < ng; g += 1024) a += T.has_append[g];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = a;
+    // the list, padded to a power of two with the largest int, sorted ascending
+    int m = 1;
+    while (m < d) m <<= 1;
+    for (int k = tid; k < m; k += 1024) s_del[k] = k < d ? T.holes[k] : 0x7fffffff;
+    for (int k = tid; k < d; k += 1024) T.deleted[T.holes[k]] = 0;  // the flags are all zero again when the call ends
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) tot += s_wave[k];
+        T.out[4] = K;
+        T.out[5] = tot;
+        T.out[13] = 0;
+        for (int k = 0; k < 3; ++k) { T.out[6 + k] = 0x7fffffff; T.out[9 + k] = (int)0x80000000; }
+    }
+    for (int size = 2; size <= m; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int k = tid; k < m / 2; k += 1024) {
+                const int lo = 2 * k - (k & (stride - 1)), hi = lo + stride;  // the pair (lo, lo + stride) of the bitonic network
+                const bool up = (lo & size) == 0;
+                const int x = s_del[lo], y = s_del[hi];
+                if ((x > y) == up) { s_del[lo] = y; s_del[hi] = x; }
+            }
+            __syncthreads();
+        }
+    // holes: the listed places below K = the first h entries of the sorted list
+    int h = 0;
+    {   // h = number of entries < K (binary search, every thread alike)
+        int lo = 0, hi = d;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_del[mid] < K) lo = mid + 1; else hi = mid; }
+        h = lo;
+    }
+    if (tid == 0) { T.out[12] = K - h; s_tot = 0; }
+    __syncthreads();
+    // fillers: the places K .. n - 1 that are not listed, in index order (there are d candidates, d - h of them listed: h fillers)
+    for (int j0 = 0; j0 < d; j0 += 1024) {
+        const int j = j0 + tid, i = K + j;
+        bool keep = false;
+        if (j < d) {
+            int lo = h, hi = d;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_del[mid] < i) lo = mid + 1; else hi = mid; }
+            keep = !(lo < d && s_del[lo] == i);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const int c = s_wave[k]; off += k < wave ? c : 0; tot += c; }
+        const int base = s_tot;
+        if (keep) s_mov[base + off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) s_tot = base + tot;
+        __syncthreads();
+    }
+    // the moves (k_map_fill's body)
+    PointXYZINormal* pts = T.dst;
+    const MapGrid& g = T.grid;
+    float4* const entries = const_cast<float4*>(g.pts);
+    for (int t = tid; t < h; t += 1024) {
+        const int dst = s_del[t], src = s_mov[t];
+        const PointXYZINormal p = pts[src];
+        pts[dst] = p;
+        if (T.fix_grid) {  // the moved point's grid entry carries its index: renumber it where it stands (its cell is a few entries)
+            const int c = map_cell(g, p.x, p.y, p.z), row = c / g.nx, ix = c - row * g.nx;
+            if (c < 0 || row >= g.ny * g.nz) { atomicOr(&T.out[13], 1); continue; }
+            const int si = map_start_index(g, row, ix);
+            const int k0 = g.bucket_start[si], k1 = g.bucket_start[si + 1];
+            if (k0 < 0 || k1 < k0 || k1 > g.n_slots) { atomicOr(&T.out[13], 2); continue; }
+            for (int k = k0; k < k1; ++k)
+                if (__float_as_int(entries[k].w) == src) { entries[k].w = __int_as_float(dst); break; }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_map_fill(const MapIncTask* __restrict__ tasks) {
     const MapIncTask T = global_record(tasks[blockIdx.y]);
-    if (*T.batch_overflow) return;
+    if (T.lean || *T.batch_overflow) return;
     const int H = T.out[4] - T.out[12];
     PointXYZINormal* pts = T.dst;
     const MapGrid& g = T.grid;
@@ -332,6 +439,7 @@ __device__ __forceinline__ void wave_bbox(int* bbox_enc, const PointXYZINormal& 
 __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict__ tasks) {
     const MapIncTask T = global_record(tasks[blockIdx.x]);
     if (!T.has_inc || *T.batch_overflow) return;
+    if (T.lean && T.out[15]) return;  // its compaction has not run: the host repeats the task through the flag passes
     __shared__ int s_wave[4];
     __shared__ int s_base;
     const int tid = threadIdx.x, ng = T.out[1], nn = T.out[2], kept = T.out[4];
@@ -640,11 +748,13 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
     if (n_tasks && max_map_points) TC2LI_LAUNCH(k_map_mark_boxes, dim3((max_map_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
 }
-void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
+// max_map_points: the largest map among the tasks that are NOT lean (0: every task works from its deletion list); any_lean: some task does
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, hipStream_t st) {
     if (!n_tasks) return;
+    if (any_lean) TC2LI_LAUNCH(k_map_compact_list, dim3(n_tasks), dim3(1024), 0, st, tasks);
     const int nb = (max_map_points + 1023) / 1024;
     if (nb) TC2LI_LAUNCH(k_map_keep_count, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
-    TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
+    if (nb) TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
     if (nb) TC2LI_LAUNCH(k_map_holes, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
     if (nb) TC2LI_LAUNCH(k_map_fill, dim3(std::min(nb * 4, 64), n_tasks), dim3(256), 0, st, tasks);
     TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);
