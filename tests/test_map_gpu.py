@@ -88,6 +88,39 @@ def test_in_place_grid_update_equals_rebuild(pkg, oracle, setup, monkeypatch):
     assert sa["grid_updates"] >= 6 and sa["grid_builds"] + sa["grid_updates"] >= builds0 + 12, sa
 
 
+def test_compaction_from_the_deletion_list_and_its_fallback(pkg, oracle, setup, monkeypatch):
+    """Round 5: a map whose grid is maintained in place compacts from the LIST of the points a step deletes (k_map_compact_list, one workgroup
+    per map) instead of three passes over all of its points; a step with more deletions than the list holds (8192) goes through the flag
+    passes after all.  Both against the flag passes alone (TC2LI_MAP_COMPACT_LIST=0: the same point array element for element -- the holes
+    take the same fillers) and against the oracle, on an ordinary map and on one with twelve points per voxel, of which a scan replaces more
+    than the list holds."""
+    fe, downs, states, world0 = setup
+    rng = np.random.default_rng(11)
+    dense = np.repeat(world0, 12)
+    for k in ("x", "y", "z"):
+        dense[k] = dense[k] + rng.uniform(-0.04, 0.04, len(dense)).astype(np.float32)
+    for base, min_deleted in ((world0, 1), (dense, 8193)):
+        a, b = pkg.LidarMap(), pkg.LidarMap()
+        a.Build(base); b.Build(base)
+        ref = base.copy()
+        for f in (1, 2):
+            upd = states[f].copy(); upd[9:12] += [0.03, -0.02, 0.01]
+            monkeypatch.delenv("TC2LI_MAP_COMPACT_LIST", raising=False)
+            fe.feature_extraction(a, downs[f], states[f])
+            n0 = a.size()
+            na = a.map_incremental(fe, 0, upd, ekf_inited=True, filter_size_map_min=0.5)
+            monkeypatch.setenv("TC2LI_MAP_COMPACT_LIST", "0")
+            fe.feature_extraction(b, downs[f], states[f])
+            nb = b.map_incremental(fe, 0, upd, ekf_inited=True, filter_size_map_min=0.5)
+            ref, wa, wn = oracle.map_incremental(ref, downs[f], states[f], upd, ekf_inited=True, filter_size_map_min=0.5)
+            assert na == nb and (na[1], na[2]) == (wa, wn)
+            pa, pb = a.points(), b.points()
+            assert np.array_equal(pa, pb) and np.array_equal(canon(pa), canon(ref)), f
+            _grid_is_sound(a); _grid_is_sound(b)
+            if f == 1:
+                assert n0 + na[1] + na[2] - a.size() >= min_deleted  # what the step deleted (the dense map: more than the list holds)
+
+
 def test_in_place_grid_update_falls_back_to_a_rebuild(pkg, oracle, setup):
     """What the in-place insertion cannot take ends in a rebuild, with the oracle's map either way: a point outside the grid's box (beyond its
     margin of 8 cells), a segment (16 cells of a row) that receives more points than it has room for, a segment with more entries than the
