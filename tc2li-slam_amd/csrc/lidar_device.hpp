@@ -67,7 +67,7 @@ void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts,
 // the three launches above as one pass per scan (a workgroup per scan: batches of many scans); bbox_enc [6 per scan] = the bounding box of
 // the kept finite points as k_voxel_bbox leaves it
 void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
-                       int* out_count, int* bbox_enc, hipStream_t st);
+                       int* out_count, int* bbox_enc, float* time_out /* NULL, or where the kept points' time stamps go too */, hipStream_t st);
 void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
                         int nblocks, PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st);
 
@@ -208,7 +208,8 @@ void launch_undistort(const PointXYZINormal* in, const int* perm, int n, const P
 // key [total] floats, ints5 [5 total] / ints3 [3 total] ints, flag [total] bytes of work space in the scans' slots; fallback [n_scans] = 1
 // where the recursion reached std::sort's depth limit (the host sorts such a scan); depth_override >= 0 replaces that limit (tests)
 void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int n_scans, float* key, int* ints5, int* ints3, uint8_t* flag,
-                      size_t total, int* perm, int* fallback, int* ranges /* [total] */, int* n_ranges /* [n_scans] */, int depth_override, hipStream_t st);
+                      size_t total, int* perm, int* fallback, int* ranges /* [total] */, int* n_ranges /* [n_scans] */, int depth_override, bool keys_ready /* key[] holds the time stamps */,
+                      hipStream_t st);
 void launch_undistort_batch(const PointXYZINormal* in, const int* perm, const int* count, const ScanSlot* slots, const SegBlock* blocks, int nblocks,
                             const Pose6DDev* poses /* [n_scans][kMaxImuPoses] */, const int* n_poses, const LidarStateDev* ends, PointXYZINormal* out,
                             hipStream_t st);

@@ -191,7 +191,9 @@ int compact_segments(tc2li_lidar* L, const int* d_counts, hipStream_t st) {
 }
 
 // b1
-int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_num, double blind, float time_unit_scale, hipStream_t st) {
+int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_num, double blind, float time_unit_scale, hipStream_t st,
+                   float* time_out = nullptr, bool* times_written = nullptr) {
+    if (times_written) *times_written = false;
     PreprocessParams prm{point_filter_num, time_unit_scale, blind * blind};
     const int nb = (int)L->blocks.size();
     // a batch of scans: one pass over every raw scan (k_pre_stream, a workgroup per scan), which also leaves the voxel filter its bounding
@@ -199,9 +201,10 @@ int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_
     const char* env = getenv("TC2LI_PRE_STREAM");
     L->pre_bbox_valid = false;
     if (env ? atoi(env) != 0 : L->n_scans >= 64) {
-        launch_pre_stream(d_raw, L->d_raw_count.p, L->d_slots.p, L->n_scans, prm, L->d_pre.p, L->d_pre_count.p, L->d_bbox.p, st);
+        launch_pre_stream(d_raw, L->d_raw_count.p, L->d_slots.p, L->n_scans, prm, L->d_pre.p, L->d_pre_count.p, L->d_bbox.p, time_out, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         L->pre_bbox_valid = true;
+        if (times_written) *times_written = time_out != nullptr;
         return TC2LI_OK;
     }
     launch_pre_count(d_raw, L->d_raw_count.p, L->d_slots.p, L->d_blocks.p, nb, prm, L->d_block_counts.p, st);
@@ -871,7 +874,7 @@ int tc2li_device_time_sort(tc2li_lidar* L, const tc2li_point* points, int n, int
     TC2LI_HIP_CHECK(copy_sync(L->d_pre.p, points, (size_t)n * sizeof(PointXYZINormal), hipMemcpyHostToDevice, ps));
     TC2LI_HIP_CHECK(copy_sync(L->d_pre_count.p, &n, sizeof(int), hipMemcpyHostToDevice, ps));
     launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, 1, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
-                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_limit, ps);
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_limit, false, ps);
     TC2LI_HIP_CHECK(hipGetLastError());
     int fb = 0;
     TC2LI_HIP_CHECK(copy_sync(&fb, L->d_sort_fallback.p, sizeof(int), hipMemcpyDeviceToHost, ps));
@@ -897,14 +900,15 @@ static int inertial_prepare_launch(tc2li_lidar* L, int S, const tc2li_velodyne_p
     int rc = setup_segments(L, S, upper.data(), st, raw_offsets);
     if (rc != TC2LI_OK) return rc;
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), S * sizeof(int), hipMemcpyHostToDevice, st));
-    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
+    bool keys_ready = false;  // the time sort's key array filled by the preprocess pass itself (the batch form)
+    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st, L->d_nearest_d.p, &keys_ready);
     if (rc != TC2LI_OK) return rc;
     TC2LI_HIP_CHECK(L->d_perm.ensure(T)); TC2LI_HIP_CHECK(L->d_sort_fallback.ensure(2 * (size_t)L->max_scans)); TC2LI_HIP_CHECK(L->d_sort_ranges.ensure(T));
     TC2LI_HIP_CHECK(L->h_sort_flags.ensure(L->max_scans));
     // the time sort: std::sort's permutation, replayed on the device
     const char* depth_env = getenv("TC2LI_TEST_SORT_DEPTH");  // tests: a small depth limit sends scans through the host fallback
     launch_time_sort(L->d_pre.p, L->d_pre_count.p, L->d_slots.p, S, L->d_nearest_d.p, L->d_nearest_idx.p, reinterpret_cast<int*>(L->d_nearest_d.p + T),
-                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_env ? atoi(depth_env) : -1, st);
+                     L->d_selected.p, T, L->d_perm.p, L->d_sort_fallback.p, L->d_sort_ranges.p, L->d_sort_fallback.p + L->max_scans, depth_env ? atoi(depth_env) : -1, keys_ready, st);
     int* hc = L->h_counts.p;
     int* h_fallback = L->h_sort_flags.p;
     TC2LI_HIP_CHECK(hipGetLastError());

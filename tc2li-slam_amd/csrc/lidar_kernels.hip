@@ -121,7 +121,9 @@ __device__ __forceinline__ bool finite3(const PointXYZINormal& p) { return isfin
 // the others are not even loaded.  The next chunk's records are requested before this chunk's barriers.
 __global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* __restrict__ raw, const int* __restrict__ raw_count,
                                                           const ScanSlot* __restrict__ slots, PreprocessParams prm, PointXYZINormal* __restrict__ out,
-                                                          int* __restrict__ out_count, int* __restrict__ bbox_enc) {
+                                                          int* __restrict__ out_count, int* __restrict__ bbox_enc, float* __restrict__ time_out) {
+    // time_out (may be NULL): the kept points' time stamps (curvature) as an array of their own, for UndistortPcl's time sort -- which
+    // otherwise opens every 48-byte record again for 4 bytes of it (1.44 GB of its 2.4 GB per 512 scans, r05_pmc_traffic_inertial.json)
     __shared__ int s_wave[kSegBlock / 64];
     __shared__ int s_min[3], s_max[3];
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* _
             o.curvature = b.y * prm.time_unit_scale;  // milliseconds (preprocess.cpp:157)
             o.pad2 = 0; o.pad3 = 0;
             out[sl.base + kept + pos] = o;
+            if (time_out) time_out[sl.base + kept + pos] = o.curvature;
             if (finite3(o)) {
                 mn[0] = min(mn[0], enc_float(o.x)); mx[0] = max(mx[0], enc_float(o.x));
                 mn[1] = min(mn[1], enc_float(o.y)); mx[1] = max(mx[1], enc_float(o.y));
@@ -855,7 +858,8 @@ constexpr int kTsMaxActive = 128, kTsMaxBlocks = 4096;   // ranges longer than k
 struct TsRange { int f, l, d; };
 __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
                                                             const ScanSlot* __restrict__ slots, TimeSortArrays A, int* __restrict__ perm,
-                                                            int* __restrict__ fallback, int* __restrict__ ranges, int* __restrict__ n_ranges, int depth_override) {
+                                                            int* __restrict__ fallback, int* __restrict__ ranges, int* __restrict__ n_ranges, int depth_override,
+                                                            int keys_ready) {
     __shared__ TsRange s_act[2][kTsMaxActive];
     __shared__ int s_nact[2], s_nfin, s_k, s_minL, s_minR, s_fail, s_cut;
     __shared__ int s_prefL[kTsMaxBlocks + 1], s_prefR[kTsMaxBlocks + 1];
@@ -869,7 +873,8 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
     if (n > 64 * kTsMaxBlocks) { if (tid == 0) fallback[scan] = 1; return; }  // (the host sorts such a scan)
     float* const key = A.key + B;
     int *const idx = A.idx + B, *const lp = A.lp + B, *const rp = A.rp + B, *const last_of = A.sl + B;
-    for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; }
+    if (keys_ready) { for (int x = tid; x < n; x += kSortThreads) idx[x] = x; }  // A.key holds the time stamps already (k_pre_stream's time_out)
+    else for (int x = tid; x < n; x += kSortThreads) { key[x] = pts[B + x].curvature; idx[x] = x; }
     const int depth0 = depth_override >= 0 ? depth_override : 2 * (31 - __clz(n));
     if (tid == 0) {
         s_nact[0] = s_nact[1] = 0; s_nfin = 0; s_fail = 0; s_k = 0; s_minL = s_minR = 0x7fffffff;
@@ -1035,10 +1040,10 @@ __global__ __launch_bounds__(256) void k_undistort_batch(const PointXYZINormal* 
 }
 
 void launch_time_sort(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int n_scans, float* key, int* ints5, int* ints3, uint8_t* flag,
-                      size_t total, int* perm, int* fallback, int* ranges, int* n_ranges, int depth_override, hipStream_t st) {
+                      size_t total, int* perm, int* fallback, int* ranges, int* n_ranges, int depth_override, bool keys_ready, hipStream_t st) {
     if (!n_scans) return;
     TimeSortArrays A{key, ints5, ints5 + total, ints5 + 2 * total, ints5 + 3 * total, ints5 + 4 * total, ints3, ints3 + total, ints3 + 2 * total, flag};
-    TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, ranges, n_ranges, depth_override);
+    TC2LI_LAUNCH(k_time_sort, dim3(n_scans), dim3(kSortThreads), 0, st, pts, count, slots, A, perm, fallback, ranges, n_ranges, depth_override, keys_ready ? 1 : 0);
     // ranges per scan: a 65 k scan leaves some tens to a few hundred; the workgroups of a scan take them in turn
     // (a batch: 8 workgroups per scan, each a dozen ranges one after the other -- a workgroup holds 47 KB of LDS, and beside the other stages'
     // kernels a launch pays for every workgroup it has placed: 64 per scan read 12-13 ms per 512 scans in the loop against 3.2 alone, 16: 7.3-7.8, 8: 5.8; the LiDAR-inertial stage alone 22.1 / 21.4 / 20.9 ms)
@@ -1624,8 +1629,8 @@ void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const Scan
     if (nblocks) TC2LI_LAUNCH(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
 }
 void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
-                       int* out_count, int* bbox_enc, hipStream_t st) {
-    if (nscans) TC2LI_LAUNCH(k_pre_stream, dim3(nscans), dim3(kSegBlock), 0, st, raw, raw_count, slots, prm, out, out_count, bbox_enc);
+                       int* out_count, int* bbox_enc, float* time_out, hipStream_t st) {
+    if (nscans) TC2LI_LAUNCH(k_pre_stream, dim3(nscans), dim3(kSegBlock), 0, st, raw, raw_count, slots, prm, out, out_count, bbox_enc, time_out);
 }
 void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st) {
     if (nscans) TC2LI_LAUNCH(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);
