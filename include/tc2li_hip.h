@@ -483,9 +483,9 @@ typedef struct tc2li_ba_stats {
  * the inertial-map branch passes 100 (OptimizerWithLidar.cc:141-142).  stop_flag is *pbStopFlag, polled between
  * Levenberg trials like g2o's forceStopFlag.  Outputs: poses and points updated in place (double; the shim casts to
  * float, :468-484), per-edge chi2 as the optimiser left it and isDepthPositive() for the outlier rules (:402-449).
- * Returns the number of iterations performed.  Limits of the graph: every point has an edge; a point has at most one edge to a
- * given optimisable keyframe (two observations of a point from one non-fixed vertex would share a Hessian block: TC2LI_ERR_INVALID)
- * and at most 256 edges in all. */
+ * Returns the number of iterations performed.  Limits of the graph: every point has an edge and at most 256 edges in all.  Several edges
+ * between a point and the same optimisable keyframe are added into the same Hessian blocks, as g2o does
+ * (Thirdparty/g2o/g2o/core/base_binary_edge.hpp:55-137; since round 5 -- rounds 2-4 returned TC2LI_ERR_INVALID for such a pair). */
 int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_poses, double* points3, int n_points,
                                   const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, int iterations,
                                   double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,

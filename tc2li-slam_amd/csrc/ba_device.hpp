@@ -91,7 +91,11 @@ struct BaProblemDev {
     // trial_fused: the trial estimate, its cost and the closing sums run as ONE launch over the linearisation's landmark groups (round 5:
     // k_ba_trial_fused*; a property of the window -- it decides the order of two sums -- set by the setup when the window's step, poses and
     // groups fit the kernel's LDS: kBacksubMaxNp, kTrialPoseBytes, 256 landmarks per group)
-    int32_t trial_fused, pad_tf_;
+    int32_t trial_fused, n_dups;
+    // duplicates: edges between a (point, free pose) pair that has an edge already.  They own no slot; k_ba_dups, after the linearisation's
+    // sums, adds a duplicate's W block to the slot of the pair's first edge (dup_slot) and its pose block to the pose's Hpp / b_p -- per free
+    // pose its duplicates in edge order (dup_off [n_free + 1] into dup_edge / dup_slot)
+    const int32_t *dup_off, *dup_edge, *dup_slot;
     double *chi2, *rho0;
     double *cp_part, *W;                 // per (block of 256 free-pose edges, free pose): 27 (+1) doubles; per free-pose edge (at w_slot): 18
     const int32_t* blk_off;              // per block: n_free + 1 offsets into its rows sorted by pose
@@ -162,6 +166,7 @@ struct BaBatchExtent {
     int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int fuse_linearize;  // the linearisation's last workgroup of a window does k_ba_reduce_all_b's / k_ba_maxdiag_b's sums (round 5)
+    int any_dups;  // some window has duplicate (point, free pose) edges: k_ba_dups_b after the linearisation's sums
     int any_trial_fused, any_trial_unfused;  // windows with / without pb.trial_fused in the call (each kind has its launches; a kernel skips the other kind)
     int inertial;  // the windows' vertices are ImuCamPose records (LocalLVIBA batch): the linearisation kernel of that vertex type
 };
@@ -199,7 +204,7 @@ __device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb)
     TC2LI_G(pose_var); TC2LI_G(pt_off); TC2LI_G(pt_edges); TC2LI_G(pv_off); TC2LI_G(pv_edges); TC2LI_G(grp_k0); TC2LI_G(grp_l0);
     TC2LI_G(fl_off); TC2LI_G(fl_pose); TC2LI_G(chunk_mask); TC2LI_G(fl_lm); TC2LI_G(fl_place); TC2LI_G(slice_off); TC2LI_G(fl_edge);
     TC2LI_G(chi2); TC2LI_G(rho0); TC2LI_G(cp_part); TC2LI_G(W); TC2LI_G(blk_off); TC2LI_G(blk_rows);
-    TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(Y);
+    TC2LI_G(Hll); TC2LI_G(bl); TC2LI_G(diag_l); TC2LI_G(Hpp); TC2LI_G(diag_p); TC2LI_G(coef_e); TC2LI_G(coef); TC2LI_G(Y); TC2LI_G(dup_off); TC2LI_G(dup_edge); TC2LI_G(dup_slot);
     TC2LI_G(S_part); TC2LI_G(scale_part); TC2LI_G(chi_part); TC2LI_G(ticket);
 #undef TC2LI_G
 }

@@ -102,7 +102,7 @@ struct VisualProblem {
         pt_off[l + 1] += pt_off[l];
     }
     for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
-    const int n_free_edges = pv_off[n_free];
+    int n_free_edges = pv_off[n_free];  // edges with a free pose; after the slots are made: the SLOTS (duplicates of a (point, pose) pair have none)
     std::vector<int> pv_edges(std::max(n_free_edges, 1));
     {
         std::vector<int> fl(pt_off.begin(), pt_off.end() - 1), fp(pv_off.begin(), pv_off.end() - 1);
@@ -122,6 +122,8 @@ struct VisualProblem {
     const char* mfma_env0 = getenv("TC2LI_BA_SCHUR_MFMA");
     const bool schur_lean = (lean_env ? atoi(lean_env) != 0 : true) && (6 * n_free + 1 + 15) / 16 <= 8 && n_free <= kSchurBlocksMaxFree &&
                             !(mfma_env0 && atoi(mfma_env0) != 0);  // only where the block-by-block form runs (blocks_form below)
+    struct DupEdge { int pose, edge, slot; };
+    std::vector<DupEdge> dups;
     std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
         fl_edge(std::max(n_free_edges, 1)), w_slot(n_edges, -1), slice_off(1, 0);
     {
@@ -145,7 +147,7 @@ struct VisualProblem {
             }
             std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : last[a] < last[b]; });
         }
-        std::vector<int> seen(std::max(n_free, 1), -1);
+        std::vector<int> seen(std::max(n_free, 1), -1), seen_slot(std::max(n_free, 1), -1);
         int at = 0, slice_lms = 0;
         for (int lo = 0; lo < n_points; ++lo) {
             const int l = order[lo];
@@ -153,9 +155,13 @@ struct VisualProblem {
             for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
                 const int e = pt_edges[k], i = pose_var[edges[e].pose];
                 if (i < 0) continue;
-                // g2o would add the two edges' Hpl blocks; the operands here hold one block per (landmark, pose)
-                if (seen[i] == l) { set_error("point %d has two edges to pose %d", l, edges[e].pose); return TC2LI_ERR_INVALID; }
-                seen[i] = l;
+                // A second edge between the same point and the same free pose: g2o adds the two edges' blocks (BaseBinaryEdge::
+                // constructQuadraticForm on the same Hpl / Hpp blocks, base_binary_edge.hpp:55-137).  The slot arrays hold one W block per
+                // (landmark, pose): the later edge gets no slot -- k_ba_dups adds its W block to the first edge's slot and its pose block to
+                // the pose's sums after the linearisation (round 5; rounds 2-4 refused such a window).  The reference's gather cannot produce
+                // one for a pinhole rig, a two-camera shim can.
+                if (seen[i] == l) { dups.push_back(DupEdge{i, e, seen_slot[i]}); continue; }
+                seen[i] = l; seen_slot[i] = at;
                 w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; fl_edge[at] = e; ++at;
             }
             fl_off[2 * (size_t)l] = begin; fl_off[2 * (size_t)l + 1] = at;
@@ -165,6 +171,19 @@ struct VisualProblem {
             ++slice_lms;
         }
         if (at > slice_off.back()) slice_off.push_back(at);
+        n_free_edges = at;
+    }
+    // duplicates (k_ba_dups): by pose, in edge order; the per-pose edge lists of the dense windows' coefficient sums hold the slots' edges only
+    std::vector<int> dup_off(n_free + 1, 0), dup_edge(std::max(dups.size(), (size_t)1)), dup_slot(std::max(dups.size(), (size_t)1));
+    if (!dups.empty()) {
+        std::stable_sort(dups.begin(), dups.end(), [](const DupEdge& a, const DupEdge& b) { return a.pose != b.pose ? a.pose < b.pose : a.edge < b.edge; });
+        for (size_t k = 0; k < dups.size(); ++k) { dup_off[dups[k].pose + 1]++; dup_edge[k] = dups[k].edge; dup_slot[k] = dups[k].slot; }
+        for (int i = 0; i < n_free; ++i) dup_off[i + 1] += dup_off[i];
+        std::fill(pv_off.begin(), pv_off.end(), 0);
+        for (int e = 0; e < n_edges; ++e) if (w_slot[e] >= 0) pv_off[pose_var[edges[e].pose] + 1]++;
+        for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
+        std::vector<int> fp(pv_off.begin(), pv_off.end() - 1);
+        for (int e = 0; e < n_edges; ++e) if (w_slot[e] >= 0) pv_edges[fp[pose_var[edges[e].pose]]++] = e;
     }
     // blocks of 256 free-pose edges (the pose role of the linearisation): the block's rows sorted by pose, for the per-pose sums
     const int n_blocks = (n_free_edges + 255) / 256;
@@ -256,7 +275,10 @@ struct VisualProblem {
                  o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
                  o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
                  o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
-                 o_ticket = align16(o_blk_rows + blk_rows.size()), in_bytes = align16(o_ticket + 4 * sizeof(int32_t));
+                 o_ticket = align16(o_blk_rows + blk_rows.size()), o_dup_off = align16(o_ticket + 4 * sizeof(int32_t)),
+                 o_dup_edge = align16(o_dup_off + (dups.empty() ? 0 : dup_off.size()) * sizeof(int)),
+                 o_dup_slot = align16(o_dup_edge + (dups.empty() ? 0 : dups.size()) * sizeof(int)),
+                 in_bytes = align16(o_dup_slot + (dups.empty() ? 0 : dups.size()) * sizeof(int));
     TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
     uint8_t* const h = ws.h_in.p;
     if (poses7) {
@@ -283,6 +305,11 @@ struct VisualProblem {
     memcpy(h + o_blk_off, blk_off.data(), blk_off.size() * sizeof(int));
     memcpy(h + o_blk_rows, blk_rows.data(), blk_rows.size());
     memset(h + o_ticket, 0, 4 * sizeof(int32_t));  // (the kernels that use them leave them at zero again)
+    if (!dups.empty()) {
+        memcpy(h + o_dup_off, dup_off.data(), dup_off.size() * sizeof(int));
+        memcpy(h + o_dup_edge, dup_edge.data(), dups.size() * sizeof(int));
+        memcpy(h + o_dup_slot, dup_slot.data(), dups.size() * sizeof(int));
+    }
     // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
     const size_t first = poses7 ? 0 : o_points;
     TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
@@ -302,6 +329,10 @@ struct VisualProblem {
     pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
     pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
     pb.ticket = (int32_t*)(d + o_ticket);
+    pb.n_dups = (int32_t)dups.size();
+    pb.dup_off = dups.empty() ? nullptr : (const int*)(d + o_dup_off);
+    pb.dup_edge = dups.empty() ? nullptr : (const int*)(d + o_dup_edge);
+    pb.dup_slot = dups.empty() ? nullptr : (const int*)(d + o_dup_slot);
     pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = n_schur_slices;  // (dense windows: the chunks of d_ba_schur_units)
     pb.schur_rd = pb.schur_ro = 1;
     decide_trial_fused();
@@ -1362,6 +1393,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
         if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
         if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
+        if (pb.n_dups) X.any_dups = 1;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
@@ -1830,6 +1862,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
         if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
         if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
+        if (pb.n_dups) X.any_dups = 1;
         if (pb.sparse_schur && pb.schur_blocks) {
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;

@@ -420,6 +420,62 @@ __device__ __forceinline__ void d_ba_maxdiag(const BaProblemDev& pb, const int b
 }
 __global__ __launch_bounds__(256) void k_ba_maxdiag(BaProblemDev pb, double* __restrict__ out) { d_ba_maxdiag(pb, blockIdx.x, out); }
 
+// Duplicate edges of a (point, free pose) pair (BaProblemDev::dup_*): one thread per free pose adds its duplicates' blocks, in edge order, to
+// what the linearisation and its sums left -- W of the pair's slot += B^T W A, Hpp / b_p of the pose += B^T W B / B^T omega_r (the pose role's
+// expressions) -- and renews the pose's largest diagonal entry.  g2o adds the edges' blocks to the same Hpl / Hpp entries
+// (base_binary_edge.hpp:55-137); a window without duplicates never launches this.
+template <bool INERTIAL>
+__device__ __forceinline__ void d_ba_dups(const BaProblemDev& pb, double* __restrict__ hpp_out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= pb.n_free || !pb.n_dups) return;
+    const int k0 = pb.dup_off[i], k1 = pb.dup_off[i + 1];
+    if (k0 == k1) return;
+    double* h = pb.Hpp + 27 * (size_t)i;
+    for (int k = k0; k < k1; ++k) {
+        const BaEdge ed = pb.edges[pb.dup_edge[k]];
+        double p[3], err[3], c2, rho0, rho1, A[9], B[18];
+        int dim;
+        edge_state(pb, INERTIAL, false, ed, p, err, dim, c2);
+        const bool stereo = ed.ur >= 0;
+        huber(c2, stereo ? pb.delta_stereo : pb.delta_mono, stereo ? pb.dsqr_stereo : pb.dsqr_mono, rho0, rho1);
+        if (INERTIAL) {
+            imu_edge_jacobians(pb.iposes[ed.pose], pb.calib, p, stereo, pb.cam, A, B);
+        } else {
+            double R[9];
+            quat_to_matrix(pb.poses[ed.pose].q, R);
+            point_jacobian(p, R, stereo, pb.cam, A);
+            pose_jacobian(p, stereo, false, pb.cam, B);
+        }
+        const double w = rho1 * ed.info;
+        double wr[3];
+        for (int d = 0; d < 3; ++d) wr[d] = d < dim ? -(ed.info * err[d]) * rho1 : 0.0;
+        double* Ws = pb.W + 18 * (size_t)pb.dup_slot[k];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 3; ++c) {
+                double sum = 0;
+                for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * A[3 * d + c];
+                Ws[3 * r + c] += sum;
+            }
+        int hh = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) {
+                double sum = 0;
+                for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * w * B[6 * d + c];
+                h[hh++] += sum;
+            }
+        for (int r = 0; r < 6; ++r) {
+            double sum = 0;
+            for (int d = 0; d < 3; ++d) sum += B[6 * d + r] * wr[d];
+            h[21 + r] += sum;
+        }
+    }
+    if (hpp_out) for (int v = 0; v < 27; ++v) hpp_out[27 * (size_t)i + v] = h[v];
+    pb.diag_p[i] = fmax(fmax(fabs(h[0]), fabs(h[6])), fmax(fmax(fabs(h[11]), fabs(h[15])), fmax(fabs(h[18]), fabs(h[20]))));
+}
+__global__ __launch_bounds__(64) void k_ba_dups(BaProblemDev pb) {
+    if (pb.inertial) d_ba_dups<true>(pb, nullptr); else d_ba_dups<false>(pb, nullptr);
+}
+
 // (Hll + lambda I)^-1 and its product with b_l for landmark l
 __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double lambda, double Di[9], double db[3]) {
     const double* h = pb.Hll + 6 * (size_t)l;
@@ -1423,6 +1479,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce_all_b(const BaPhase ph) {
     if ((int)blockIdx.x >= pb.n_free + 1) return;
     d_ba_reduce_all(pb, blockIdx.x, sl.chi_out, view_.hpp_out());
 }
+__global__ __launch_bounds__(64) void k_ba_dups_b(const BaPhase ph) {
+    TC2LI_SLOT(y);
+    if (pb.inertial) d_ba_dups<true>(pb, view_.hpp_out()); else d_ba_dups<false>(pb, view_.hpp_out());
+}
 __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaPhase ph) {
     TC2LI_SLOT(y);
     if (!(view_.flags & kBaWantMaxdiag)) return;
@@ -1628,6 +1688,7 @@ static inline int blocks(int n) { return (n + 255) / 256; }
 void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdiag_out, bool want_maxdiag, hipStream_t st) {
     TC2LI_LAUNCH(k_ba_linearize, dim3(pb.n_groups + blocks(pb.n_free_edges)), dim3(256), 0, st, pb);
     TC2LI_LAUNCH(k_ba_reduce_all, dim3(pb.n_free + 1), dim3(256), 0, st, pb, chi_out);
+    if (pb.n_dups) TC2LI_LAUNCH(k_ba_dups, dim3((pb.n_free + 63) / 64), dim3(64), 0, st, pb);  // duplicate (point, free pose) edges: their blocks on top
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
@@ -1686,11 +1747,12 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 
 void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExtent& x, bool any_maxdiag, hipStream_t st) {
     if (!n_active) return;
-    const int fuse = x.fuse_linearize;
+    const int fuse = x.fuse_linearize && !x.any_dups;  // (a window with duplicate edges takes the separate sums: k_ba_dups_b stands between them and the maxima)
     if (x.inertial) TC2LI_LAUNCH(k_ba_linearize_imu_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups, fuse);
     else TC2LI_LAUNCH(k_ba_linearize_b, dim3(x.max_groups + blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, x.max_groups, fuse);
     if (fuse) return;  // the closing sums ran in the windows' last workgroups
     TC2LI_LAUNCH(k_ba_reduce_all_b, dim3(x.max_free + 1, n_active), dim3(256), 0, st, ph);
+    if (x.any_dups) TC2LI_LAUNCH(k_ba_dups_b, dim3((x.max_free + 63) / 64, n_active), dim3(64), 0, st, ph);
     if (any_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag_b, dim3(2, n_active), dim3(256), 0, st, ph);
 }
 void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {

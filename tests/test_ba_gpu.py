@@ -106,13 +106,30 @@ def test_local_ba_stop_flag_and_structure(pkg, oracle, synthetic):
     bad = e.copy(); bad["pose"][0] = 10 ** 6
     with pytest.raises(pkg.Tc2liError):
         pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], bad, w["cam"])
-    # two edges between the same point and the same free keyframe: g2o would add their Hpl blocks, the W-block layout holds one per
-    # (landmark, pose) -- refused instead of silently dropping one
-    free_pose = int(np.flatnonzero(w["fixed"] == 0)[0])
-    k = int(np.flatnonzero(e["pose"] == free_pose)[0])
-    dup = np.concatenate([e, e[k:k + 1]])
-    with pytest.raises(pkg.Tc2liError):
-        pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], dup, w["cam"])
+    # two (and three) edges between the same point and the same free keyframe: g2o adds their blocks to the same Hpl / Hpp entries
+    # (base_binary_edge.hpp:55-137) -- so does the library since round 5 (k_ba_dups: the later edges' blocks on top of the first one's slot;
+    # rounds 2-4 refused such a window): the oracle's result, alone and in a lock-step batch beside a window without duplicates
+    free = np.flatnonzero(w["fixed"] == 0)
+    ks = [int(np.flatnonzero(e["pose"] == int(free[0]))[0]), int(np.flatnonzero(e["pose"] == int(free[0]))[0]),
+          int(np.flatnonzero(e["pose"] == int(free[1]))[3]), int(np.flatnonzero(e["pose"] == int(free[-1]))[7])]
+    w6 = np.concatenate([w["edges"]] + [w["edges"][k:k + 1] for k in ks])
+    w6[-1, 2] += 0.75   # the repeated observations need not agree with the first ones
+    w6[-2, 3] -= 0.5
+    dup = pkg.pack_ba_edges(w6)
+    want = oracle.local_ba(w["poses"], w["fixed"], w["points"], w6, w["cam"], iterations=6)
+    poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], dup, w["cam"], iterations=6)
+    assert stats.iterations == want[4] and stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.final_chi2 - want[5]["chi2"][-1]) <= 1e-6 * want[5]["chi2"][-1]
+    assert np.allclose(poses, want[0], rtol=POSE_RTOL, atol=1e-7) and np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6)
+    assert np.allclose(chi2, want[2], rtol=1e-5, atol=1e-7)
+    batch = pkg.capi.BaBatch([dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=dup, iterations=6),
+                              dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=e, iterations=6),
+                              dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=dup, iterations=6)], w["cam"])
+    assert batch.run(8) == 3
+    for i in (0, 2):
+        assert np.array_equal(batch.result(i)[0], poses) and np.array_equal(batch.result(i)[1], pts)
+    plain = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], e, w["cam"], iterations=6)
+    assert np.array_equal(batch.result(1)[0], plain[0]) and np.array_equal(batch.result(1)[1], plain[1])
     # the same pair on a FIXED keyframe only adds to the landmark's block: accepted
     fixed_pose = int(np.flatnonzero(w["fixed"] > 0)[0])
     k = int(np.flatnonzero(e["pose"] == fixed_pose)[0])
