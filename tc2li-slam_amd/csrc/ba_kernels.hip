@@ -540,21 +540,22 @@ __global__ __launch_bounds__(256) void k_ba_reduce_coef(BaProblemDev pb) { d_ba_
 // sums per window instead of 64.
 constexpr int kUnitChunk = kUnitChunkHost;      // landmarks per chunk (= per slice of slice_off on this path)
 constexpr int kUnitRows = 3 * kUnitChunk;       // operand rows per chunk
-struct UnitPanels { double A[2][kUnitRows][16], B[2][kUnitRows][16]; };
+constexpr int kUnitW = 64;                      // rows = columns of a unit (4 x 4 tiles)
+struct UnitPanels { double A[4][kUnitRows][16], B[4][kUnitRows][16]; };   // [16-column quarter][operand row][column]: 48 KB
 constexpr int kUnitIdx = 2048;                  // slots of a slice whose (pose, rank in chunk) the workgroup keeps in LDS (beyond: read where they are)
 constexpr int kUnitMaxChunks = 64;              // chunks per slice (the host cuts more slices for larger windows)
 struct UnitsLds {
-    union {
-        UnitPanels buf[2];                      // two chunks' panels: one is multiplied while the other is cleared for the next chunk
-        double red[4][4][256];                  // [wavefront][tile][lane + 64 r]: the wavefronts' accumulators on their way to the sum
-    };
+    UnitPanels P;
     unsigned short idx[kUnitIdx];
     int off[kUnitMaxChunks + 1];
 };
-// What a lane holds of ONE slot of the next chunk while the current one is multiplied (round 5: the loads of chunk c + 1 are in flight
-// under the product of chunk c; before, every chunk was three dependent trips to memory -- offsets, indices, blocks -- with the matrix
-// pipe idle: 31 us per workgroup for 0.5 us of MFMAs per chunk).
+// What a lane holds of ONE slot of the next chunk while the current one is multiplied: the loads of chunk c + 1 are in flight under the
+// product of chunk c (without it every chunk was three dependent trips to memory -- offsets, indices, blocks -- with the matrix pipe idle).
 struct UnitSlot { int p, ca, cb; bool inA, inB; double Y[18], W[18]; };
+// Unit = 64 x 64 block of S (second form of the round: 32 x 32 units re-read a chunk's blocks once per unit that touches it and gave the matrix
+// pipe twelve MFMAs per wavefront and chunk between two trips to memory -- 0.20 of the MFMA peak alone; a 64 x 64 unit multiplies four times
+// the tiles per block loaded).  Wavefront w owns tile ROW w of the unit -- its four accumulator tiles, all twelve k-steps of a chunk: one A
+// fragment and four B fragments per four MFMAs, and no sum across wavefronts at the end.
 __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const int unit, const int slice, const int chunks_per_slice, const double lambda,
                                                  UnitsLds& L) {
     (void)lambda;  // (the operands W D^-1 come from k_ba_schur_coef of the same trial)
@@ -563,36 +564,33 @@ __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const i
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= unit) ++bi;
     const int bj = unit - bi * (bi + 1) / 2;
-    const int ti0 = 2 * bi, tj0 = 2 * bj;
-    v4d acc[2][2];
+    const int ti = 4 * bi + wave, tj0 = 4 * bj;   // this wavefront's tile row; the unit's first tile column
+    v4d acc[4];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int y = 0; y < 4; ++y) acc[y] = v4d{0, 0, 0, 0};
+    bool want[4];                                  // which of the row's four tiles exist and lie on or below the diagonal
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = v4d{0, 0, 0, 0};
-    // which of the unit's four tiles exist and lie on or below the diagonal
-    bool want[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) want[x][y] = ti0 + x < tiles && tj0 + y <= ti0 + x;
+    for (int y = 0; y < 4; ++y) want[y] = ti < tiles && tj0 + y <= ti;
     const int c_begin = slice * chunks_per_slice, c_end = min(min(c_begin + chunks_per_slice, c_begin + kUnitMaxChunks), n_chunks);
     const int nc = max(c_end - c_begin, 0);
-    // ---- once per workgroup: the slice's chunk masks (a lane each), its chunks' slot ranges, the slots' (pose, rank) pairs; both buffers clear ----
+    // ---- once per workgroup: the slice's chunk masks (a lane each), its chunks' slot ranges, the slots' (pose, rank) pairs; the panels clear ----
     const unsigned my_mask = lane < nc ? pb.chunk_mask[c_begin + lane] : 0u;
     for (int k = tid; k <= nc; k += 256) L.off[k] = pb.slice_off[c_begin + k];
-    {
-        v2d* z = reinterpret_cast<v2d*>(&L.buf[0]);
-        for (int k = tid; k < (int)(2 * sizeof(UnitPanels) / sizeof(v2d)); k += 256) z[k] = v2d{0, 0};
-    }
+    auto clear_panels = [&] {
+        v2d* z = reinterpret_cast<v2d*>(&L.P);
+        for (int k = tid; k < (int)(sizeof(UnitPanels) / sizeof(v2d)); k += 256) z[k] = v2d{0, 0};
+    };
+    clear_panels();
     __syncthreads();
     const int S0 = L.off[0], S1 = L.off[nc];
     for (int s = S0 + tid; s < min(S1, S0 + kUnitIdx); s += 256) L.idx[s - S0] = (unsigned short)(pb.fl_pose[s] | pb.fl_place[s] << 8);
     __syncthreads();
+    const unsigned rmask = 15u << (4 * bi), cmask = 15u << (4 * bj);
     auto slot_index = [&](int s) -> unsigned { return s - S0 < kUnitIdx ? (unsigned)L.idx[s - S0] : (unsigned)(pb.fl_pose[s] | pb.fl_place[s] << 8); };
     auto next_chunk = [&](int c) {  // the next chunk from c on that reaches the unit (uniform)
         for (; c < c_end; ++c) {
             const unsigned m = __builtin_amdgcn_readlane(my_mask, c - c_begin);
-            if (((m >> ti0) & 3u) && ((m >> tj0) & 3u)) break;
+            if ((m & rmask) && (m & cmask)) break;
         }
         return c;
     };
@@ -600,28 +598,28 @@ __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const i
         const unsigned ix = slot_index(s);
         u.p = (int)(ix >> 8);
         const int col0 = 6 * (int)(ix & 255u);
-        u.ca = col0 - 32 * bi; u.cb = col0 - 32 * bj;  // first column of the pose inside the unit's row / column range
-        u.inA = u.ca > -6 && u.ca < 32; u.inB = u.cb > -6 && u.cb < 32;
+        u.ca = col0 - kUnitW * bi; u.cb = col0 - kUnitW * bj;  // first column of the pose inside the unit's row / column range
+        u.inA = u.ca > -6 && u.ca < kUnitW; u.inB = u.cb > -6 && u.cb < kUnitW;
         if (u.inA) load_d2<18>(pb.Y + 18 * (size_t)s, u.Y);  // W D^-1 of the slot (k_ba_schur_coef)
         if (u.inB) load_d2<18>(pb.W + 18 * (size_t)s, u.W);
     };
-    auto put_slot = [&](UnitPanels& P, const UnitSlot& u) {
+    auto put_slot = [&](const UnitSlot& u) {
         if (u.inA) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const int col = u.ca + r;
-                if (col < 0 || col >= 32) continue;
+                if (col < 0 || col >= kUnitW) continue;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) P.A[col >> 4][3 * u.p + k][col & 15] = u.Y[3 * r + k];
+                for (int k = 0; k < 3; ++k) L.P.A[col >> 4][3 * u.p + k][col & 15] = u.Y[3 * r + k];
             }
         }
         if (u.inB) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 const int col = u.cb + r;
-                if (col < 0 || col >= 32) continue;
+                if (col < 0 || col >= kUnitW) continue;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) P.B[col >> 4][3 * u.p + k][col & 15] = u.W[3 * r + k];
+                for (int k = 0; k < 3; ++k) L.P.B[col >> 4][3 * u.p + k][col & 15] = u.W[3 * r + k];
             }
         }
     };
@@ -632,63 +630,45 @@ __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const i
         pre.inA = pre.inB = false;
         if (s < L.off[c - c_begin + 1]) load_slot(s, pre);
     };
-    int cur = 0;
     int c = next_chunk(c_begin);
     if (c < c_end) preload(c);
     while (c < c_end) {
         const unsigned m = __builtin_amdgcn_readlane(my_mask, c - c_begin);
-        const unsigned rb = (m >> ti0) & 3u, cb = (m >> tj0) & 3u;
-        UnitPanels& P = L.buf[cur];
+        const bool row_on = ((m >> ti) & 1u) != 0;
+        const unsigned cb = (m >> tj0) & 15u;
         // ---- the panels (clear on entry): every slot of the chunk whose pose has columns in the unit's row / column range writes its part ----
-        put_slot(P, pre);
+        put_slot(pre);
         for (int s = L.off[c - c_begin] + 256 + tid; s < L.off[c - c_begin + 1]; s += 256) {  // (a chunk of more than 256 slots: the rest, not prefetched)
-            load_slot(s, pre);  // (the lane's registers of the prefetched slot are free again)
-            put_slot(P, pre);
+            load_slot(s, pre);
+            put_slot(pre);
         }
         const int cn = next_chunk(c + 1);
         if (cn < c_end) preload(cn);  // in flight under the product below
         __syncthreads();
-        // ---- the product: k-steps wave, wave + 4, wave + 8 of the chunk's twelve ----
+        // ---- the product: this wavefront's tile row over the chunk's twelve k-steps ----
+        if (row_on && ti < tiles) {   // uniform over the wavefront
+#pragma unroll 4
+            for (int q = 0; q < kUnitRows / 4; ++q) {
+                const int krow = 4 * q + (lane >> 4);
+                const double a = L.P.A[wave][krow][lane & 15];
 #pragma unroll
-        for (int q = 0; q < kUnitRows / 16; ++q) {
-            const int krow = 4 * (wave + 4 * q) + (lane >> 4);
-            double a[2], b[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) a[x] = P.A[x][krow][lane & 15];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) b[y] = P.B[y][krow][lane & 15];
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y)
-                    if (want[x][y] && ((rb >> x) & 1u) && ((cb >> y) & 1u))  // uniform over the workgroup
-                        acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < 4; ++y)
+                    if (want[y] && ((cb >> y) & 1u))
+                        acc[y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, L.P.B[y][krow][lane & 15], acc[y], 0, 0, 0);
+            }
         }
-        // the other buffer (multiplied one chunk ago: every wavefront is past that) is cleared for the next chunk while the matrix pipe works
-        {
-            v2d* z = reinterpret_cast<v2d*>(&L.buf[cur ^ 1]);
-            for (int k = tid; k < (int)(sizeof(UnitPanels) / sizeof(v2d)); k += 256) z[k] = v2d{0, 0};
-        }
+        __syncthreads();  // every wavefront has read the panels
+        clear_panels();
         __syncthreads();
-        cur ^= 1;  // (the buffer just multiplied is cleared during the next chunk's product and filled again the chunk after)
         c = cn;
     }
-    __syncthreads();
-    // ---- the wavefronts' tiles, added in wavefront order; wavefront t writes tile t ----
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) L.red[wave][2 * x + y][lane + 64 * r] = acc[x][y][r];
-    __syncthreads();
-    const int x = wave >> 1, y = wave & 1;
-    if (!(ti0 + x < tiles && tj0 + y <= ti0 + x)) return;
+    if (ti >= tiles) return;
     double* out = pb.S_part + (size_t)slice * pb.np_pad * pb.np_pad;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double v = ((L.red[0][wave][lane + 64 * r] + L.red[1][wave][lane + 64 * r]) + L.red[2][wave][lane + 64 * r]) + L.red[3][wave][lane + 64 * r];
-        out[(size_t)(16 * (ti0 + x) + (lane >> 4) + 4 * r) * pb.np_pad + 16 * (tj0 + y) + (lane & 15)] = v;
+    for (int y = 0; y < 4; ++y) {
+        if (!want[y]) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + (lane >> 4) + 4 * r) * pb.np_pad + 16 * (tj0 + y) + (lane & 15)] = acc[y][r];
     }
 }
 __global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chunks_per_slice, double lambda) {
@@ -1502,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaPhase ph) {
 __global__ __launch_bounds__(256) void k_ba_schur_units_b(const BaPhase ph) {
     __shared__ UnitsLds L;
     TC2LI_SLOT(z);
-    const int ub = (pb.np_pad / 16 + 1) / 2;
+    const int ub = (pb.np_pad / 16 + 3) / 4;
     if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= ub * (ub + 1) / 2 || (int)blockIdx.y >= sl.n_slices) return;
     d_ba_schur_units(pb, blockIdx.x, blockIdx.y, sl.k_per_slice, view_.lambda, L);
 }
@@ -1724,7 +1704,7 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
         // (k_per_slice = landmark chunks per slice on this path)
         if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda);
         TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
-        const int ub = (pb.np_pad / 16 + 1) / 2;
+        const int ub = (pb.np_pad / 16 + 3) / 4;
         TC2LI_LAUNCH(k_ba_schur_units, dim3(ub * (ub + 1) / 2, n_slices), dim3(256), 0, st, pb, k_per_slice, lambda);
     }
     TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
@@ -1773,7 +1753,7 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
     if (x.any_dense) {
         if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
         TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);
-        const int ub = (x.max_np_pad / 16 + 1) / 2;
+        const int ub = (x.max_np_pad / 16 + 3) / 4;
         TC2LI_LAUNCH(k_ba_schur_units_b, dim3(ub * (ub + 1) / 2, x.max_slices, n_active), dim3(256), 0, st, ph);
     }
     TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, ph);
