@@ -1104,7 +1104,7 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
     OptimizerWithLidar.cc:493-500: opt_it 4, lambda 1e-2): 25 free keyframes put the reduced system beyond the block-by-block Schur kernel, so
     S -= (W D^-1) W^T runs as the dense k-major f64 MFMA product (k_ba_schur_gemm*).  A lock-step batch of such windows, timed, then once more
     with every launch timed (tc2li_profile_*): the product's average launch against the measured f64 MFMA peak.  FLOPs = what the kernel executes:
-    round 5's k_ba_schur_units_b multiplies only the (chunk of 16 landmarks, 16 x 16 tile) pairs the window's observations touch, counted here
+    round 5's k_ba_schur_full_b (k_ba_schur_units_b for wider windows) multiplies only the (chunk of 16 landmarks, 16 x 16 tile) pairs the window's observations touch, counted here
     from the window exactly as the host's chunk masks count them (round 4's line counted all tiles^2 of a dense product whose kernel formed
     the lower triangle: 1.82x too many); `useful_frac` = the FLOPs of the 6x3 . 3x3 . 3x6 products g2o forms / the executed ones."""
     uniq = []
@@ -1139,7 +1139,7 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
     free_edge = fixed[e6[:, 1].astype(int)] == 0
     f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=P)
     useful = float((f_l * (f_l + 1) // 2).sum()) * 324.0
-    # what k_ba_schur_units_b EXECUTES for one window and trial: per chunk of 16 landmarks and 16 x 16 tile on or below the diagonal whose rows
+    # what k_ba_schur_full_b / k_ba_schur_units_b EXECUTE for one window and trial: per chunk of 16 landmarks and 16 x 16 tile on or below the diagonal whose rows
     # and whose columns the chunk touches (the host's chunk_mask, rebuilt here from the window), 12 MFMAs of 16 x 16 x 4 x 2 = 2048 FLOP
     pose_var = np.cumsum(fixed == 0) - 1
     fi, fl = pose_var[e6[free_edge, 1].astype(int)], e6[free_edge, 0].astype(int)
@@ -1157,7 +1157,7 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
             n_mfma += 12 * int((((masks >> ti) & 1) & ((masks >> tj) & 1)).sum())
     flop_window = n_mfma * 2048.0
     dense_tiles = tiles * (tiles + 1) // 2 * 12 * len(masks)
-    gemm = {k: v for k, v in report.items() if base_name(k).startswith("k_ba_schur_units")}
+    gemm = {k: v for k, v in report.items() if base_name(k).startswith(("k_ba_schur_full", "k_ba_schur_units"))}
     out = {"workload": "%d bLarge LocalLVIBA windows in lock step (25 free keyframes + the fixed one, %d points, %d stereo edges, LiDAR edge over 6 keyframes x 2400 "
                        "points, 4 iterations at lambda 1e-2): the MFMA Schur path" % (n_windows, P, len(e6)),
            "windows_per_s": round(n_windows / dt, 1), "ms_per_batch": round(1e3 * dt, 3), "iterations/trials": [int(s0.iterations), int(s0.trials)],

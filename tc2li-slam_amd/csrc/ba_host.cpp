@@ -226,7 +226,7 @@ struct VisualProblem {
     } else {
         // dense windows (round 5: d_ba_schur_units): the chunks (slices of slice_off: 16 landmarks each) in at most 8 ranges = partial sums
         const char* ds_env = getenv("TC2LI_BA_DENSE_SLICES");  // (measurements; read per window)
-        const int want_slices = ds_env ? std::max(1, std::min(64, atoi(ds_env))) : 4;
+        const int want_slices = ds_env ? std::max(1, std::min(64, atoi(ds_env))) : 8;  // (full-width form, 32 windows per launch beside two other groups: 2 / 4 / 8 slices 0.263 / 0.154 / 0.099 ms)
         k_per_slice = std::min(64, std::max(1, (n_schur_slices + want_slices - 1) / want_slices));   // chunks per partial sum (at most kUnitMaxChunks: ba_kernels.hip)
         n_slices = std::max(1, (n_schur_slices + k_per_slice - 1) / k_per_slice);
     }

@@ -671,6 +671,109 @@ __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const i
         for (int r = 0; r < 4; ++r) out[(size_t)(16 * ti + (lane >> 4) + 4 * r) * pb.np_pad + 16 * (tj0 + y) + (lane & 15)] = acc[y][r];
     }
 }
+// The same product for reduced systems of at most 176 columns (29 free keyframes: LocalInertialBA's 25-keyframe bLarge window) with the chunk's
+// panels at FULL width in LDS -- [tile][48][16] for (W D^-1)^T and W^T, 135 KB -- and ONE workgroup of eight wavefronts per (window, slice):
+// every slot of a chunk is loaded once per window (a 64 x 64 unit re-reads it for each of up to six units), all lower tiles the chunk's band
+// touches are multiplied from the one pair of panels (tile n of the lower triangle belongs to wavefront n % 8: up to nine accumulator tiles
+// each, independent MFMA chains), two wavefronts per SIMD.  Same skipping, same chunk order per
+// tile: the bits are those of the unit form.
+constexpr int kFullTilesMax = 11, kFullThreads = 512, kFullTilesPerWave = 9;   // 11 x 12 / 2 = 66 lower tiles over 8 wavefronts (1024 lanes would cap a lane at 128 registers: 146 spilled)
+struct FullLds {
+    double A[kFullTilesMax][kUnitRows][16], B[kFullTilesMax][kUnitRows][16];
+    unsigned short idx[kUnitIdx];
+    int off[kUnitMaxChunks + 1];
+};
+__device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const int slice, const int chunks_per_slice, FullLds& L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = pb.np_pad / 16, n_lower = tiles * (tiles + 1) / 2, n_chunks = pb.n_schur_slices;
+    int my_ti[kFullTilesPerWave], my_tj[kFullTilesPerWave];
+    v4d acc[kFullTilesPerWave];
+#pragma unroll
+    for (int q = 0; q < kFullTilesPerWave; ++q) {
+        const int n = wave + (kFullThreads / 64) * q;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= n) ++ti;
+        my_ti[q] = n < n_lower ? ti : -1;
+        my_tj[q] = n - ti * (ti + 1) / 2;
+        acc[q] = v4d{0, 0, 0, 0};
+    }
+    const int c_begin = slice * chunks_per_slice, c_end = min(min(c_begin + chunks_per_slice, c_begin + kUnitMaxChunks), n_chunks);
+    const int nc = max(c_end - c_begin, 0);
+    const unsigned my_mask = lane < nc ? pb.chunk_mask[c_begin + lane] : 0u;
+    for (int k = tid; k <= nc; k += kFullThreads) L.off[k] = pb.slice_off[c_begin + k];
+    const int panel_v2 = tiles * kUnitRows * 16 / 2;  // v2d per panel actually used
+    auto clear_panels = [&] {
+        v2d* za = reinterpret_cast<v2d*>(&L.A[0][0][0]);
+        v2d* zb = reinterpret_cast<v2d*>(&L.B[0][0][0]);
+        for (int k = tid; k < panel_v2; k += kFullThreads) { za[k] = v2d{0, 0}; zb[k] = v2d{0, 0}; }
+    };
+    clear_panels();
+    __syncthreads();
+    const int S0 = L.off[0], S1 = L.off[nc];
+    for (int s = S0 + tid; s < min(S1, S0 + kUnitIdx); s += kFullThreads) L.idx[s - S0] = (unsigned short)(pb.fl_pose[s] | pb.fl_place[s] << 8);
+    __syncthreads();
+    auto slot_index = [&](int s) -> unsigned { return s - S0 < kUnitIdx ? (unsigned)L.idx[s - S0] : (unsigned)(pb.fl_pose[s] | pb.fl_place[s] << 8); };
+    // one slot per lane and chunk, prefetched a chunk ahead (16 landmarks x 32 poses fit the workgroup's lanes)
+    int pre_p = 0, pre_col = 0;
+    bool pre_on = false;
+    double preY[18], preW[18];
+    auto load_slot = [&](int s) {
+        const unsigned ix = slot_index(s);
+        pre_p = (int)(ix >> 8);
+        pre_col = 6 * (int)(ix & 255u);
+        load_d2<18>(pb.Y + 18 * (size_t)s, preY);
+        load_d2<18>(pb.W + 18 * (size_t)s, preW);
+    };
+    auto put_slot = [&] {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int col = pre_col + r;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                L.A[col >> 4][3 * pre_p + k][col & 15] = preY[3 * r + k];
+                L.B[col >> 4][3 * pre_p + k][col & 15] = preW[3 * r + k];
+            }
+        }
+    };
+    auto preload = [&](int c) {
+        const int s = L.off[c - c_begin] + tid;
+        pre_on = s < L.off[c - c_begin + 1];
+        if (pre_on) load_slot(s);
+    };
+    int c = c_begin;
+    if (c < c_end) preload(c);
+    while (c < c_end) {
+        const unsigned m = __builtin_amdgcn_readlane(my_mask, c - c_begin);
+        if (pre_on) put_slot();
+        for (int s = L.off[c - c_begin] + kFullThreads + tid; s < L.off[c - c_begin + 1]; s += kFullThreads) { load_slot(s); put_slot(); }
+        if (c + 1 < c_end) preload(c + 1); else pre_on = false;  // in flight under the product below
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kFullTilesPerWave; ++q) {
+            if (my_ti[q] < 0 || !((m >> my_ti[q]) & 1u) || !((m >> my_tj[q]) & 1u)) continue;  // uniform over the wavefront
+#pragma unroll 4
+            for (int ks = 0; ks < kUnitRows / 4; ++ks) {
+                const int krow = 4 * ks + (lane >> 4);
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(L.A[my_ti[q]][krow][lane & 15], L.B[my_tj[q]][krow][lane & 15], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wavefront has read the panels
+        clear_panels();
+        __syncthreads();
+        ++c;
+    }
+    double* out = pb.S_part + (size_t)slice * pb.np_pad * pb.np_pad;
+#pragma unroll
+    for (int q = 0; q < kFullTilesPerWave; ++q) {
+        if (my_ti[q] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * my_ti[q] + (lane >> 4) + 4 * r) * pb.np_pad + 16 * my_tj[q] + (lane & 15)] = acc[q][r];
+    }
+}
+__global__ __launch_bounds__(kFullThreads) void k_ba_schur_full(BaProblemDev pb, int chunks_per_slice) {
+    extern __shared__ double s_full_dyn[];
+    d_ba_schur_full(pb, blockIdx.x, chunks_per_slice, *reinterpret_cast<FullLds*>(s_full_dyn));
+}
 __global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chunks_per_slice, double lambda) {
     __shared__ UnitsLds L;
     d_ba_schur_units(pb, blockIdx.x, blockIdx.y, chunks_per_slice, lambda, L);
@@ -1478,12 +1581,20 @@ __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaPhase ph) {
     if (pb.sparse_schur || (int)blockIdx.x >= pb.n_free) return;
     d_ba_reduce_coef(pb, blockIdx.x);
 }
+// the dense windows of at most 176 columns: (slice, window) = blockIdx.(x, y)
+__global__ __launch_bounds__(kFullThreads) void k_ba_schur_full_b(const BaPhase ph) {
+    extern __shared__ double s_full_dyn[];
+    TC2LI_SLOT(y);
+    if (pb.sparse_schur || !pb.n_free || pb.np_pad > 16 * kFullTilesMax || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_full(pb, blockIdx.x, sl.k_per_slice, *reinterpret_cast<FullLds*>(s_full_dyn));
+}
 // the dense windows' Schur product: (unit, slice, window) = blockIdx.(x, y, z)
 __global__ __launch_bounds__(256) void k_ba_schur_units_b(const BaPhase ph) {
     __shared__ UnitsLds L;
     TC2LI_SLOT(z);
     const int ub = (pb.np_pad / 16 + 3) / 4;
     if (pb.sparse_schur || !pb.n_free || (int)blockIdx.x >= ub * (ub + 1) / 2 || (int)blockIdx.y >= sl.n_slices) return;
+    if (pb.np_pad <= 16 * kFullTilesMax && !ph.pad_) return;  // such a window runs in k_ba_schur_full_b (ph.pad_: TC2LI_BA_DENSE_FULL=0, measurements)
     d_ba_schur_units(pb, blockIdx.x, blockIdx.y, sl.k_per_slice, view_.lambda, L);
 }
 __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
@@ -1677,6 +1788,9 @@ static inline size_t schur_lds_bytes(int np_pad) {
 }
 
 int ba_schur_parts(int n_slices, int group) { return (n_slices + group - 1) / group; }
+// TC2LI_BA_DENSE_FULL=0 (read per call; measurements): the dense windows' product by 64 x 64 units whatever their width
+static bool dense_full_form() { const char* e = getenv("TC2LI_BA_DENSE_FULL"); return !(e && atoi(e) == 0); }
+
 
 // the block-by-block kernels need more than the 64 KB of dynamic LDS a kernel gets by default
 static void schur_blocks_attr() {  // a refusal shows as the launch's own error (the callers check hipGetLastError)
@@ -1704,8 +1818,13 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
         // (k_per_slice = landmark chunks per slice on this path)
         if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda);
         TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
-        const int ub = (pb.np_pad / 16 + 3) / 4;
-        TC2LI_LAUNCH(k_ba_schur_units, dim3(ub * (ub + 1) / 2, n_slices), dim3(256), 0, st, pb, k_per_slice, lambda);
+        if (pb.np_pad <= 16 * kFullTilesMax && dense_full_form()) {
+            (void)ensure_dynamic_lds((const void*)k_ba_schur_full, (int)sizeof(FullLds));
+            TC2LI_LAUNCH(k_ba_schur_full, dim3(n_slices), dim3(kFullThreads), sizeof(FullLds), st, pb, k_per_slice);
+        } else {
+            const int ub = (pb.np_pad / 16 + 3) / 4;
+            TC2LI_LAUNCH(k_ba_schur_units, dim3(ub * (ub + 1) / 2, n_slices), dim3(256), 0, st, pb, k_per_slice, lambda);
+        }
     }
     TC2LI_LAUNCH(k_ba_schur_finish, dim3(blocks(np * np)), dim3(256), 0, st, pb, lambda_pose, n_slices, S_out, bs_out);
 }
@@ -1753,8 +1872,19 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
     if (x.any_dense) {
         if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
         TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);
-        const int ub = (x.max_np_pad / 16 + 3) / 4;
-        TC2LI_LAUNCH(k_ba_schur_units_b, dim3(ub * (ub + 1) / 2, x.max_slices, n_active), dim3(256), 0, st, ph);
+        // windows of at most 176 columns: the full-width form; wider ones (or TC2LI_BA_DENSE_FULL=0): 64 x 64 units.  Both kernels skip the
+        // windows of the other kind.
+        const bool full = dense_full_form();
+        if (full) {
+            (void)ensure_dynamic_lds((const void*)k_ba_schur_full_b, (int)sizeof(FullLds));
+            TC2LI_LAUNCH(k_ba_schur_full_b, dim3(x.max_slices, n_active), dim3(kFullThreads), sizeof(FullLds), st, ph);
+        }
+        if (!full || x.max_np_pad > 16 * kFullTilesMax) {
+            BaPhase ph2 = ph;
+            ph2.pad_ = full ? 0 : 1;
+            const int ub = (x.max_np_pad / 16 + 3) / 4;
+            TC2LI_LAUNCH(k_ba_schur_units_b, dim3(ub * (ub + 1) / 2, x.max_slices, n_active), dim3(256), 0, st, ph2);
+        }
     }
     TC2LI_LAUNCH(k_ba_schur_finish_b, dim3(blocks(36 * x.max_free * x.max_free), n_active), dim3(256), 0, st, ph);
 }
