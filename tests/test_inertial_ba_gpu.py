@@ -154,10 +154,12 @@ def test_lviba_batch_equals_the_one_window_calls(pkg, oracle, synthetic):
             assert st.final_chi2 < st.initial_chi2
 
 
-def test_lviba_large_window_and_benched_cloud(pkg, oracle, synthetic):
+@pytest.mark.parametrize("form", ["full-width", "64x64-units"])  # the two block-sparse MFMA kernels of the dense windows' Schur product (round 5)
+def test_lviba_large_window_and_benched_cloud(pkg, oracle, synthetic, monkeypatch, form):
     """The 25-keyframe `bLarge` window of LocalInertialBA / LocalLVIBA (opt_it 4, lambda 1e-2: Optimizer.cc:1516-1523, OptimizerWithLidar.cc:493-500,
-    :618) against the oracle -- the reduced system has (6 + 9) * 25 unknowns and the dense Schur path is taken -- and an LVIBA window with the
-    LiDAR edge at the benched cloud size."""
+    :618) against the oracle -- the reduced system has (6 + 9) * 25 unknowns and the MFMA Schur path is taken (k_ba_schur_full; k_ba_schur_units with
+    TC2LI_BA_DENSE_FULL=0, the form of windows beyond 176 columns) -- and an LVIBA window with the LiDAR edge at the benched cloud size."""
+    monkeypatch.setenv("TC2LI_BA_DENSE_FULL", "1" if form == "full-width" else "0")
     w = problem(pkg, oracle, synthetic, 11, n_opt=25, n_points=1500)
     K = len(w["kf33"])
     win = list(range(K - 1, K - 7, -1))
