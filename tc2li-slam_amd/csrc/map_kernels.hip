@@ -743,7 +743,8 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
     const size_t lds = (size_t)kMapIncMax * (sizeof(unsigned long long) + sizeof(int));
     (void)ensure_dynamic_lds(reinterpret_cast<const void*>(k_mapinc_group), (int)lds);  // 96 KB of dynamic LDS: above the default limit of a kernel
     TC2LI_LAUNCH(k_mapinc_group, dim3(n_tasks), dim3(1024), lds, st, tasks);
-    TC2LI_LAUNCH(k_mapinc_apply, dim3(kMapIncMax / 128, n_tasks), dim3(128), 0, st, tasks);
+    // a task has at most as many voxel groups as its scan has points (and at most kMapIncMax): no workgroups beyond that
+    TC2LI_LAUNCH(k_mapinc_apply, dim3((std::min(max_points, kMapIncMax) + 127) / 128, n_tasks), dim3(128), 0, st, tasks);
 }
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
     if (n_tasks && max_map_points) TC2LI_LAUNCH(k_map_mark_boxes, dim3((max_map_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
