@@ -43,10 +43,11 @@ int tc2li_device_count(void);
  * tc2li_device_count included) it returns TC2LI_ERR_INVALID instead of silently doing nothing.  It sets an environment variable (setenv):
  * call it before the process starts other threads. */
 int tc2li_set_hardware_queues(int n);
-/* Host threads this process may keep busy: the library sizes its worker pools from it (extractor pool a quarter, tracking pool, LiDAR pool
- * and every lock-step BA group an eighth of what is left after the caller's own stage threads; caps 32 / 16 / 16 / 16 -- the sizes the pools
- * were tuned at on a one-GPU box).  Default: the environment variable TC2LI_HOST_THREAD_BUDGET, else the cores the process may run on
- * (sched_getaffinity).  A launcher with R ranks on a node passes cores / R so that the ranks' pools add up to the node.  Returns
+/* CPUs this process may really keep busy (a launcher passes min(affinity, cgroup quota) / ranks on the node): the library sizes its worker
+ * pools from it -- TC2LI_HOST_THREADS_PER_CPU (default 8: measured on a 16-CPU grant) threads per CPU in all, of
+ * which the extractor pool takes a quarter, the tracking pool, the LiDAR pool and every lock-step BA group an eighth after the caller's own
+ * stage threads; caps 32 / 16 / 16 / 16, the sizes the pools were tuned at on a one-GPU box.  Default: the environment variable
+ * TC2LI_HOST_THREAD_BUDGET, else the cores the process may run on (sched_getaffinity).  Returns
  * TC2LI_ERR_INVALID for threads < 1 or when a pool exists already (call it first, or after tc2li_shutdown).  No reference counterpart (the
  * reference's four threads are fixed, SF/src/System.cc:184-224). */
 int tc2li_set_host_thread_budget(int threads);
