@@ -67,7 +67,8 @@ void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts,
 // the three launches above as one pass per scan (a workgroup per scan: batches of many scans); bbox_enc [6 per scan] = the bounding box of
 // the kept finite points as k_voxel_bbox leaves it
 void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
-                       int* out_count, int* bbox_enc, float* time_out /* NULL, or where the kept points' time stamps go too */, hipStream_t st);
+                       int* out_count, int* bbox_enc, float* time_out /* NULL, or where the kept points' time stamps go too */,
+                       int* vkey_out /* NULL, or the packed voxel coordinates at `leaf` */, float leaf, int* vk_ok /* [nscans] */, hipStream_t st);
 void launch_pre_scatter(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, const SegBlock* blocks,
                         int nblocks, PreprocessParams prm, const int* block_offsets, PointXYZINormal* out, hipStream_t st);
 
@@ -86,7 +87,7 @@ void launch_voxel_fill(const int* count, const ScanSlot* slots, const SegBlock* 
                        int* members /* one word per run: first index | (length - 1) << 24 */, hipStream_t st);
 // the sorted form of the voxel filter (after launch_voxel_bbox / launch_voxel_params): one workgroup per scan sorts (voxel, point), then the centroids
 void launch_voxel_sort_points(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, float leaf, const VoxelParams* vp, int* key_a,
-                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, hipStream_t st);
+                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, const int* vk_ok /* NULL, or per scan: key_b holds k_pre_stream's packed voxel coordinates */, hipStream_t st);
 void launch_voxel_sums(const PointXYZINormal* pts, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const ScanSlot* vslots, const SegBlock* vblocks,
                        int nvblocks, const VoxelParams* vp, const int* idx_a, const int* idx_b, const int* vox_start, const int* vox_info, const int* n_vox,
                        void* recs, PointXYZINormal* out, int* out_count, hipStream_t st);

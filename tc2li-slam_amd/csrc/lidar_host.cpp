@@ -81,6 +81,8 @@ struct tc2li_lidar {
     DevBuf<uint8_t> d_selected;
     DevBuf<int> d_nearest_idx, d_nfound;
     DevBuf<float> d_nearest_d;
+    DevBuf<int> d_vk_ok;           // per scan: k_pre_stream's packed voxel coordinates are usable (every kept point fits)
+    float pre_vkey_leaf = 0.f;     // > 0: d_members holds them for this leaf (between run_preprocess and the run_voxel that follows)
     DevBuf<int> d_raw_count, d_pre_count, d_down_count, d_sel_count, d_block_counts, d_block_offsets;
     DevBuf<ScanSlot> d_slots;
     DevBuf<SegBlock> d_blocks;
@@ -192,8 +194,9 @@ int compact_segments(tc2li_lidar* L, const int* d_counts, hipStream_t st) {
 
 // b1
 int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_num, double blind, float time_unit_scale, hipStream_t st,
-                   float* time_out = nullptr, bool* times_written = nullptr) {
+                   float* time_out = nullptr, bool* times_written = nullptr, float voxel_leaf = 0.f /* > 0: the voxel filter follows at this leaf */) {
     if (times_written) *times_written = false;
+    L->pre_vkey_leaf = 0.f;
     PreprocessParams prm{point_filter_num, time_unit_scale, blind * blind};
     const int nb = (int)L->blocks.size();
     // a batch of scans: one pass over every raw scan (k_pre_stream, a workgroup per scan), which also leaves the voxel filter its bounding
@@ -201,7 +204,13 @@ int run_preprocess(tc2li_lidar* L, const VelodynePoint* d_raw, int point_filter_
     const char* env = getenv("TC2LI_PRE_STREAM");
     L->pre_bbox_valid = false;
     if (env ? atoi(env) != 0 : L->n_scans >= 64) {
-        launch_pre_stream(d_raw, L->d_raw_count.p, L->d_slots.p, L->n_scans, prm, L->d_pre.p, L->d_pre_count.p, L->d_bbox.p, time_out, st);
+        // (the voxel filter's sorted form follows at voxel_leaf: the pass leaves it the points' voxel coordinates in the sort's second key buffer)
+        const char* vk_env = getenv("TC2LI_VOXEL_PRE_KEYS");  // =0: the filter reads the points' positions itself (A/B, tests)
+        const bool vkeys = voxel_leaf > 0.f && !(vk_env && atoi(vk_env) == 0);
+        if (vkeys) TC2LI_HIP_CHECK(L->d_vk_ok.ensure(L->max_scans));
+        launch_pre_stream(d_raw, L->d_raw_count.p, L->d_slots.p, L->n_scans, prm, L->d_pre.p, L->d_pre_count.p, L->d_bbox.p, time_out,
+                          vkeys ? L->d_members.p : nullptr, voxel_leaf, vkeys ? L->d_vk_ok.p : nullptr, st);
+        if (vkeys) L->pre_vkey_leaf = voxel_leaf;
         TC2LI_HIP_CHECK(hipGetLastError());
         L->pre_bbox_valid = true;
         if (times_written) *times_written = time_out != nullptr;
@@ -223,7 +232,9 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_vp.p, vp.data(), S * sizeof(VoxelParams), hipMemcpyHostToDevice, st));
     // the bounding boxes: left by the one-pass preprocess when the filter's input is its output (k_pre_stream), else computed here
     const bool have_bbox = L->pre_bbox_valid && d_in == L->d_pre.p;
+    const bool have_vkeys = have_bbox && L->pre_vkey_leaf == leaf && leaf > 0.f;  // k_pre_stream packed the points' voxel coordinates for this leaf
     L->pre_bbox_valid = false;
+    L->pre_vkey_leaf = 0.f;
     if (!have_bbox) {
         std::vector<int> bbox_init(6 * S);
         for (int s = 0; s < S; ++s) for (int a = 0; a < 3; ++a) { bbox_init[6 * s + a] = 0x7fffffff; bbox_init[6 * s + 3 + a] = (int)0x80000000; }
@@ -240,7 +251,7 @@ int run_voxel(tc2li_lidar* L, const PointXYZINormal* d_in, const int* d_in_count
     if (sorted) {
         L->record(2, st);
         launch_voxel_sort_points(d_in, d_in_count, L->d_slots.p, S, leaf, L->d_vp.p, L->d_pt_slot.p, L->d_vox_keys.p, L->d_members.p, L->d_member_off.p,
-                                 L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, st);
+                                 L->d_vox_fill.p, L->d_vox_count.p, L->d_n_vox.p, have_vkeys ? L->d_vk_ok.p : nullptr, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         // a batch: the passes over the voxels (and, in run_features, over the down-sampled points) get block tables cut for n_vox
         if (compact) { const int rc = compact_segments(L, L->d_n_vox.p, st); if (rc != TC2LI_OK) return rc; }
@@ -1648,7 +1659,7 @@ int tc2li_lidar_frontend_batch(tc2li_lidar* L, int n_scans, const tc2li_velodyne
     if (rc != TC2LI_OK) return rc;
     L->record(0, st);
     TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_raw_count.p, upper.data(), n_scans * sizeof(int), hipMemcpyHostToDevice, st));
-    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st);
+    rc = run_preprocess(L, (const VelodynePoint*)dev_raw, point_filter_num, blind, time_unit_scale, st, nullptr, nullptr, n_scans >= 32 ? leaf : 0.f);
     if (rc != TC2LI_OK) return rc;
     L->record(1, st);
     rc = run_voxel(L, L->d_pre.p, L->d_pre_count.p, leaf, st, /* compact tables for the down-sampled clouds of a batch */ n_scans >= 32);

@@ -121,15 +121,22 @@ __device__ __forceinline__ bool finite3(const PointXYZINormal& p) { return isfin
 // the others are not even loaded.  The next chunk's records are requested before this chunk's barriers.
 __global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* __restrict__ raw, const int* __restrict__ raw_count,
                                                           const ScanSlot* __restrict__ slots, PreprocessParams prm, PointXYZINormal* __restrict__ out,
-                                                          int* __restrict__ out_count, int* __restrict__ bbox_enc, float* __restrict__ time_out) {
+                                                          int* __restrict__ out_count, int* __restrict__ bbox_enc, float* __restrict__ time_out,
+                                                          uint32_t* __restrict__ vkey_out, float inv_leaf, int* __restrict__ vk_ok) {
+    // vkey_out (may be NULL): the kept points' voxel coordinates floor(p / leaf), packed 11 | 11 | 10 bits (x | y | z, two's complement), for the
+    // voxel filter that follows at that leaf -- its sort otherwise opens every 48-byte record again for the 12 bytes of the position
+    // (1.44 GB of the 3.4 GB k_voxel_sort_points moved per 512 scans).  vk_ok[scan] = 0 when a point does not fit (not finite, or beyond
+    // +-1024 / +-512 leaves): the filter then reads the points as before.
     // time_out (may be NULL): the kept points' time stamps (curvature) as an array of their own, for UndistortPcl's time sort -- which
     // otherwise opens every 48-byte record again for 4 bytes of it (1.44 GB of its 2.4 GB per 512 scans, r05_pmc_traffic_inertial.json)
     __shared__ int s_wave[kSegBlock / 64];
-    __shared__ int s_min[3], s_max[3];
+    __shared__ int s_min[3], s_max[3], s_bad;
     const int s = blockIdx.x, tid = threadIdx.x;
     const ScanSlot sl = slots[s];
     const int n = raw_count[s];
     if (tid < 3) { s_min[tid] = 0x7fffffff; s_max[tid] = (int)0x80000000; }
+    if (tid == 0) s_bad = 0;
+    bool bad = false;
     const float4* __restrict__ src = reinterpret_cast<const float4*>(raw + sl.raw_base);
     auto wanted = [&](int i) { return i < n && i % prm.point_filter_num == 0; };
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -153,6 +160,13 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* _
             o.pad2 = 0; o.pad3 = 0;
             out[sl.base + kept + pos] = o;
             if (time_out) time_out[sl.base + kept + pos] = o.curvature;
+            if (vkey_out) {
+                const float fx = floorf(o.x * inv_leaf), fy = floorf(o.y * inv_leaf), fz = floorf(o.z * inv_leaf);  // voxel_index's own terms
+                const bool fits = finite3(o) && fx >= -1024.f && fx <= 1023.f && fy >= -1024.f && fy <= 1023.f && fz >= -512.f && fz <= 511.f;
+                bad |= !fits;
+                const int ix = fits ? (int)fx : 0, iy = fits ? (int)fy : 0, iz = fits ? (int)fz : 0;
+                vkey_out[sl.base + kept + pos] = ((uint32_t)(iz & 0x3ff) << 22) | ((uint32_t)(iy & 0x7ff) << 11) | (uint32_t)(ix & 0x7ff);
+            }
             if (finite3(o)) {
                 mn[0] = min(mn[0], enc_float(o.x)); mx[0] = max(mx[0], enc_float(o.x));
                 mn[1] = min(mn[1], enc_float(o.y)); mx[1] = max(mx[1], enc_float(o.y));
@@ -177,6 +191,11 @@ __global__ __launch_bounds__(kSegBlock) void k_pre_stream(const VelodynePoint* _
     __syncthreads();
     if (tid < 3) { bbox_enc[s * 6 + tid] = s_min[tid]; bbox_enc[s * 6 + 3 + tid] = s_max[tid]; }
     if (tid == 0) out_count[s] = kept;
+    if (vk_ok) {
+        if (bad) atomicOr(&s_bad, 1);
+        __syncthreads();
+        if (tid == 0) vk_ok[s] = s_bad ? 0 : 1;
+    }
 }
 
 __global__ __launch_bounds__(kSegBlock) void k_voxel_bbox(const PointXYZINormal* __restrict__ pts, const int* __restrict__ count,
@@ -535,7 +554,8 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_sort_points(const PointXYZ
                                                                   const ScanSlot* __restrict__ slots, const VoxelParams* __restrict__ vp, float leaf,
                                                                   uint32_t* __restrict__ key_a, int* __restrict__ idx_a, uint32_t* __restrict__ key_b,
                                                                   int* __restrict__ idx_b, int* __restrict__ vox_start, int* __restrict__ vox_info,
-                                                                  int* __restrict__ n_vox) {
+                                                                  int* __restrict__ n_vox, const int* __restrict__ vk_ok) {
+    // vk_ok (may be NULL): vk_ok[scan] != 0 -- key_b holds the points' packed voxel coordinates, left by k_pre_stream for this leaf
     __shared__ int s_hist[4][256], s_place[256], s_cstart[256], s_wave[kVsThreads / 64];
     __shared__ unsigned short s_wcnt[32][256], s_woff[32][256];
     __shared__ unsigned int s_max;
@@ -548,6 +568,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_sort_points(const PointXYZ
     __syncthreads();
     // ---- first sweep: keys of the finite points in point order, digit histograms ----
     const float inv = 1.0f / leaf;
+    const bool use_keys = vk_ok != nullptr && vk_ok[s] != 0;  // uniform
     const unsigned long long lt = (1ull << lane) - 1ull;
     int n_pts = 0;
     unsigned int my_max = 0;
@@ -555,7 +576,13 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_sort_points(const PointXYZ
         const int i = c0 + tid;
         bool valid = false;
         uint32_t key = 0;
-        if (i < n) {
+        if (i < n && use_keys) {  // floor(p / leaf) per axis as k_pre_stream packed it: voxel_index's arithmetic on the same float values
+            const uint32_t pk = key_b[base + i];
+            const int ix = (int)(pk << 21) >> 21, iy = (int)(pk << 10) >> 21, iz = (int)pk >> 22;
+            const int i0 = (int)((float)ix - (float)v.min_b[0]), i1 = (int)((float)iy - (float)v.min_b[1]), i2 = (int)((float)iz - (float)v.min_b[2]);
+            valid = true;
+            key = (uint32_t)(i0 * v.mul[0] + i1 * v.mul[1] + i2 * v.mul[2]);
+        } else if (i < n) {
             const float4 xyz = *reinterpret_cast<const float4*>(&pts[base + i]);
             PointXYZINormal p;
             p.x = xyz.x; p.y = xyz.y; p.z = xyz.z;
@@ -1629,8 +1656,9 @@ void launch_pre_count(const VelodynePoint* raw, const int* raw_count, const Scan
     if (nblocks) TC2LI_LAUNCH(k_pre_count, dim3(nblocks), dim3(kSegBlock), 0, st, raw, raw_count, slots, blocks, prm, block_counts);
 }
 void launch_pre_stream(const VelodynePoint* raw, const int* raw_count, const ScanSlot* slots, int nscans, PreprocessParams prm, PointXYZINormal* out,
-                       int* out_count, int* bbox_enc, float* time_out, hipStream_t st) {
-    if (nscans) TC2LI_LAUNCH(k_pre_stream, dim3(nscans), dim3(kSegBlock), 0, st, raw, raw_count, slots, prm, out, out_count, bbox_enc, time_out);
+                       int* out_count, int* bbox_enc, float* time_out, int* vkey_out, float leaf, int* vk_ok, hipStream_t st) {
+    if (nscans) TC2LI_LAUNCH(k_pre_stream, dim3(nscans), dim3(kSegBlock), 0, st, raw, raw_count, slots, prm, out, out_count, bbox_enc, time_out,
+                             reinterpret_cast<uint32_t*>(vkey_out), vkey_out ? 1.0f / leaf : 0.f, vkey_out ? vk_ok : nullptr);
 }
 void launch_seg_scan(const ScanSlot* slots, int nscans, const int* block_counts, int* block_offsets, int* totals, hipStream_t st) {
     if (nscans) TC2LI_LAUNCH(k_seg_scan, dim3(nscans), dim3(256), 0, st, slots, block_counts, block_offsets, totals);
@@ -1675,10 +1703,10 @@ void launch_voxel_centroid(const PointXYZINormal* pts, const int* count, const S
                        vox_count, (const CentroidRec*)recs, out, out_count, nblocks);
 }
 void launch_voxel_sort_points(const PointXYZINormal* pts, const int* count, const ScanSlot* slots, int nscans, float leaf, const VoxelParams* vp, int* key_a,
-                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, hipStream_t st) {
+                              int* idx_a, int* key_b, int* idx_b, int* vox_start, int* vox_info, int* n_vox, const int* vk_ok, hipStream_t st) {
     if (!nscans) return;
     TC2LI_LAUNCH(k_voxel_sort_points, dim3(nscans), dim3(kVsThreads), 0, st, pts, count, slots, vp, leaf, reinterpret_cast<uint32_t*>(key_a), idx_a,
-                 reinterpret_cast<uint32_t*>(key_b), idx_b, vox_start, vox_info, n_vox);
+                 reinterpret_cast<uint32_t*>(key_b), idx_b, vox_start, vox_info, n_vox, vk_ok);
 }
 // (slots, blocks, nblocks): a block list that covers the input points; (vslots, vblocks, nvblocks): one that covers the voxels (n_vox per scan)
 void launch_voxel_sums(const PointXYZINormal* pts, const ScanSlot* slots, const SegBlock* blocks, int nblocks, const ScanSlot* vslots, const SegBlock* vblocks,

@@ -98,6 +98,38 @@ def test_frontend_batch_preprocess_and_filter_forms(pkg, oracle, scans, monkeypa
     f4.close()
 
 
+def test_frontend_batch_voxel_coordinates_from_the_preprocess_pass(pkg, oracle, scans, monkeypatch):
+    """Round 5: in a batch of >= 32 scans k_pre_stream leaves the voxel filter the kept points' packed voxel coordinates (the filter's sort then
+    does not open the 48-byte records again).  40 ragged scans -- one with NaN / inf coordinates and one reaching beyond +-1024 leaves, for
+    which the filter reads the points itself -- give the oracle's counts and the same features byte for byte with and without the packed
+    coordinates (TC2LI_VOXEL_PRE_KEYS=0)."""
+    import torch
+    batch = [scans[k % 4][:(30000 + 2500 * k)].copy() for k in range(40)]
+    batch[3]["x"][10::101] = np.float32(np.nan); batch[3]["z"][6::313] = np.float32(np.inf)
+    batch[7]["x"][5::997] += np.float32(600.0)   # floor(x / 0.5) beyond 1023: this scan's coordinates do not fit the packing
+    batch[11] = batch[11][:0]
+    f = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=40)
+    raw = torch.from_numpy(np.concatenate(batch).view(np.uint8)).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(b) for b in batch])]).astype(np.int32)
+    boot = oracle.voxel_grid(oracle.lidar_preprocess(scans[0]))
+    maps = []
+    for _ in batch:
+        m = pkg.LidarMap(); m.Build(boot); maps.append(m)
+    st = np.stack([pkg.pack_lidar_state(np.eye(3), np.zeros(3))] * len(batch))
+    monkeypatch.setenv("TC2LI_PRE_STREAM", "1")
+    out = {}
+    for keys in (1, 0):
+        monkeypatch.setenv("TC2LI_VOXEL_PRE_KEYS", str(keys))
+        counts, ori, corr = f.frontend_batch(raw.data_ptr(), offs, maps, st, want_points=True)
+        out[keys] = (counts.copy(), ori.copy(), corr.copy())
+    for s in (0, 3, 7, 11, 39):
+        pre = oracle.lidar_preprocess(batch[s])
+        assert int(out[1][0][0][s]) == len(pre) and int(out[1][0][1][s]) == len(oracle.voxel_grid(pre)), s
+    for a, b in zip(out[0], out[1]):
+        assert a.tobytes() == b.tobytes()
+    f.close()
+
+
 def test_feature_extraction(pkg, fe, oracle, synthetic, scans):
     down = [oracle.voxel_grid(oracle.lidar_preprocess(s)) for s in scans[:3]]
     st = [oracle.pack_state(*synthetic.lidar_state(f)) for f in range(3)]
