@@ -1012,6 +1012,9 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
         "k_pose_optimization": (2 * F * nkp * 0.5 * (40 + 24 + 1 + 8), "B"),
         "k_pose_optimization_lds": (2 * F * nkp * 0.5 * (40 + 24 + 1 + 8), "B"),       # the same with the correspondences staged in LDS (round 3)
         "k_map_holes": (F * mp * (1 + 4), "B"),                                          # compaction in place: every point's deleted flag in, its hole / mover rank out
+        # round 5: the compaction from the step's deletion list (~1 600 per map): the list in, a flag back per entry, the moved points (48 B in and out)
+        "k_map_compact_list": (F * 1600 * (4 + 1 + 0.5 * 96), "B"),
+        "k_mapinc_apply": (F * sel * (48 + 16 + 48), "B"),
     }
     if ba:
         E, P, lin, tr, nw = ba["edges"], ba["points"], ba["linearisations"], ba["trials"], ba["windows"]
@@ -1036,6 +1039,12 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
             "k_ba_errors_reduce_b": (nw * tr * E * 112, "B"),  # the same pass; a window's last workgroup adds the window's ~110 partial sums
+            # round 5 (off by default): the whole trial as one launch over the landmark groups
+            "k_ba_trial_fused_b": (nw * tr * (E * 112 + Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
+            "k_ba_trial_fused_imu_b": (nw * tr * (E * 112 + Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
+            # dense windows (> 21 free keyframes): W D^-1 per slot, then the block-sparse MFMA product (priced in mfma_line by its executed FLOPs)
+            "k_ba_schur_coef_b": (nw * tr * Ef * (144 + 144 + 48 + 72), "B"),
+            "k_ba_schur_full_b": (nw * tr * pairs * 324.0, "FLOP"), "k_ba_schur_units_b": (nw * tr * pairs * 324.0, "FLOP"),
             # the LiDAR term's Hessian / gradient from the chunks' partial sums: (21 pair blocks x 36 + 36 + 1) doubles per chunk of 8 planes in, the
             # (6W)^2 + 6W + 1 doubles and the W poses out
             "k_balm_combine_b": (nw * lin * (((ba["planes"] + 7) // 8) * (ba["win"] * (ba["win"] + 1) // 2 * 36 + 6 * ba["win"] + 1) + 36 * ba["win"] ** 2 + 18 * ba["win"]) * 8, "B"),
