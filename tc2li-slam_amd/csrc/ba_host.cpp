@@ -13,6 +13,7 @@
 #include "ba_device.hpp"
 #include "balm_host.hpp"
 #include "inertial_host.hpp"
+#include "reduced_solve.hpp"
 #include "pose_opt_device.hpp"
 
 using namespace tc2li;
@@ -1050,7 +1051,8 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
     double lambda = lambda_init, ni = 2, last_chi = 0;
     int n_bad = 0, done = 0, trials_total = 0;
     bool ok = true;
-    std::vector<double> M((size_t)std::max(n * n, 1)), rhs(std::max(n, 1)), bfull(std::max(n, 1)), x(std::max(n, 1), 0.0);
+    std::vector<double> rhs(std::max(n, 1)), bfull(std::max(n, 1)), x(std::max(n, 1), 0.0);
+    ReducedSolver solver;
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
         TC2LI_HIP_CHECK(hipGetLastError());
@@ -1068,6 +1070,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             lidar->finish_linearization();  // constructQuadraticForm uses the stored Jacobian / Hessian when the cost grew
             lidar->add_quadratic_form(pose_var.data(), n, Hi.data(), bi.data());
         }
+        solver.set_pattern(Hi.data(), n, np);
         double currentChi = chi_imu + h_scal.p[0], tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
@@ -1088,18 +1091,13 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             TC2LI_HIP_CHECK(hipGetLastError());
             TC2LI_HIP_CHECK(hipStreamSynchronize(st));
             // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]
-            for (int r = 0; r < n; ++r)
-                for (int c = 0; c < n; ++c) {
-                    double v = Hi[(size_t)r * n + c];
-                    if (r < np && c < np) v += h_S.p[(size_t)r * np + c];
-                    else if (r == c) v += lambda;
-                    M[(size_t)r * n + c] = v;
-                }
+            // (the envelope LDL^T of reduced_solve.hpp: velocity / bias unknowns first, the pose rows after them)
             for (int j = 0; j < n; ++j) {
                 bfull[j] = bi[j] + (j < np ? h_bs.p[np + j] : 0.0);
                 rhs[j] = bi[j] + (j < np ? h_bs.p[j] : 0.0);
             }
-            const bool ok2 = n == 0 ? true : ldlt_solve_small(M.data(), n, rhs.data(), x.data(), false);
+            const bool ok2 = n == 0 ? true : solver.factorise(Hi.data(), h_S.p, lambda);
+            if (ok2 && n) solver.solve(rhs.data(), x.data());
             double scale = 0;
             for (int j = 0; j < n; ++j) scale += x[j] * (lambda * x[j] + bfull[j]);
             if (ok2) {
@@ -1753,7 +1751,8 @@ struct LviWindow {
     std::vector<uint8_t> extra_used, imu_used;
     std::vector<ImuPose> hp, hp_trial;
     std::vector<ImuVertexState> sv, sv_trial;
-    std::vector<double> M, rhs, bfull, x;
+    std::vector<double> rhs, bfull, x;
+    ReducedSolver solver;
     double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, chi_imu = 0, last_chi = 0;
     int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
     int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot
@@ -1788,6 +1787,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
     double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LviWindow> W(n);
+    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup, linearise (device + host edges), host after linearise, schur, solve, trial, trial cost, results
+    const double t_begin = kTiming ? now() : 0;
+    double t_mark = t_begin;
+    auto lap = [&](int k) { if (kTiming) { const double t = now(); tm[k] += t - t_mark; t_mark = t; } };
     // ---- setup: argument checks, inertial links, plane extraction (device, queued first), uploads ----
     std::vector<int> rc_lidar(n, 0);
     std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);
@@ -1840,7 +1845,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         w.vp.decide_trial_fused();
         memcpy(&pb.calib, calib, sizeof(ImuCalib));
         const int nn = w.inertial.n;
-        w.M.assign((size_t)std::max(nn * nn, 1), 0.0); w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
+        w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
     };
     pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
     if (!plane_extraction_begin(C, deferred, n, st)) { (void)hipStreamSynchronize(st); return false; }
@@ -1939,10 +1944,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
+    lap(0);
     for (;;) {
         std::vector<int> active, with_lidar;
         for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
         if (active.empty() || failed) break;
+        lap(7);
         // ---- phase A: linearisation at the accepted estimate; the inertial edges on the host meanwhile ----
         bool any_maxdiag = false;
         for (int i : active) {
@@ -1961,6 +1968,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
         sync();
         if (failed) break;
+        lap(1);
         pool.parallel_for((int)active.size(), [&](int k) {
             LviWindow& w = W[active[k]];
             const double* sc = w.ws->h_scal.p;
@@ -1973,6 +1981,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 w.lidar->finish_linearization();
                 w.lidar->add_quadratic_form(w.vp.pose_var.data(), nn, w.inertial.Hi.data(), w.inertial.bi.data());
             }
+            w.solver.set_pattern(w.inertial.Hi.data(), nn, np);
             w.currentChi = chi_imu + sc[0];
             w.tempChi = w.currentChi;
             w.iniChi = w.currentChi;
@@ -1992,33 +2001,30 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             w.qmax = 0;
         });
         // ---- trials ----
+        lap(2);
         std::vector<int> trial = active;
         while (!trial.empty() && !failed) {
             pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
             sync();
             if (failed) break;
+            lap(3);
             pool.parallel_for((int)trial.size(), [&](int k) {
                 LviWindow& w = W[trial[k]];
                 BaWorkspace& ws = *w.ws;
                 const int np = w.vp.np, nn = w.inertial.n;
                 const std::vector<double>&Hi = w.inertial.Hi, &bi = w.inertial.bi;
-                // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]
-                for (int r = 0; r < nn; ++r)
-                    for (int c = 0; c < nn; ++c) {
-                        double v = Hi[(size_t)r * nn + c];
-                        if (r < np && c < np) v += ws.h_S.p[(size_t)r * np + c];
-                        else if (r == c) v += w.lambda;
-                        w.M[(size_t)r * nn + c] = v;
-                    }
+                // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I] (reduced_solve.hpp)
                 for (int j = 0; j < nn; ++j) {
                     w.bfull[j] = bi[j] + (j < np ? ws.h_bs.p[np + j] : 0.0);
                     w.rhs[j] = bi[j] + (j < np ? ws.h_bs.p[j] : 0.0);
                 }
-                w.ok2 = nn == 0 ? true : ldlt_solve_small(w.M.data(), nn, w.rhs.data(), w.x.data(), false);
+                w.ok2 = nn == 0 ? true : w.solver.factorise(Hi.data(), ws.h_S.p, w.lambda);
+                if (w.ok2 && nn) w.solver.solve(w.rhs.data(), w.x.data());
                 w.scale = 0;
                 for (int j = 0; j < nn; ++j) w.scale += w.x[j] * (w.lambda * w.x[j] + w.bfull[j]);
                 if (w.ok2 && np) memcpy(ws.h_xp.p, w.x.data(), np * sizeof(double));
             });
+            lap(4);
             std::vector<int> step, step_lidar;
             for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
             if (!step.empty()) {
@@ -2038,6 +2044,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 });
                 sync();
                 if (failed) break;
+                lap(5);
                 pool.parallel_for((int)step.size(), [&](int k) {
                     LviWindow& w = W[step[k]];
                     memcpy(w.hp_trial.data(), w.ws->h_iposes.p, w.p->n_keyframes * sizeof(ImuPose));
@@ -2047,6 +2054,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                     w.last_chi = w.tempChi;
                 });
             }
+            lap(6);
             std::vector<int> again;
             for (int i : trial) {
                 LviWindow& w = W[i];
@@ -2123,6 +2131,9 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 }
             });
     }
+    lap(7);
+    if (kTiming) fprintf(stderr, "LVI lock-step timing ms (%d windows): setup %.3f linearize %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f trial-cost %.3f results+rest %.3f total %.3f\n",
+                         n, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], now() - t_begin);
     for (int i = 0; i < n; ++i) {
         LviWindow& w = W[i];
         if (w.rc < 0) { results[i] = w.rc; continue; }
