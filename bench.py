@@ -66,6 +66,8 @@ def parse_args(argv=None):
                     "(tc2li_lidar_inertial_prepare_batch on a second handle): A/B measurements")
     ap.add_argument("--inertial-loop", action="store_true", help="the timed loop is the camera-LiDAR-inertial one (configs[3]) instead of the camera-LiDAR one: "
                     "what the single-sequence child of the inertial line runs")
+    ap.add_argument("--lviba-small", action="store_true", help="configs[3] loop: LocalLVIBA windows of 10 keyframes / 10 iterations (bLarge false: a frame tracking "
+                    "<= 100 inliers) instead of the bLarge windows the loop's frames call for")
     ap.add_argument("--mfma-only", action="store_true", help="only the matrix-unit line: a lock-step batch of 25-keyframe bLarge LocalLVIBA windows (the dense "
                     "f64 MFMA Schur product); what the --pmc pass of the MFMA counters profiles")
     ap.add_argument("--full-line", action="store_true", help="print the whole report on the line (tables of all kernels, per-thread CPU, prose) as rounds 1-4 did: "
@@ -907,10 +909,15 @@ class InertialLoop(Loop):
         li = [self.uniq_li[t] for t in self.tile]
         self.li = pkg.capi.LidarInertialBatch(self.lidar, self.raw_offs, self.maps, np.stack([q["x"] for q in li]), np.stack([q["P"] for q in li]),
                                               [q["imu"] for q in li], np.array([q["times"] for q in li]), self.cov12, max_iter=3)
-        # local mapping: LVIBA windows
+        # local mapping: LVIBA windows.  LocalMapping.cc:156-161: bLarge = GetMatchesInliers() > 100 for a stereo rig -- the loop's frames track ~1000
+        # inliers, so the reference calls LocalLVIBA with bLarge: 25 optimisable keyframes, 4 iterations from lambda 1e-2
+        # (OptimizerWithLidar.cc:493-500, 618-623).  --lviba-small: the 10-keyframe / 10-iteration / lambda 1 window of a weakly tracked frame
+        # (what rounds 3-4 benched here).
+        self.lvi_large = not getattr(args, "lviba_small", False)
+        self.lvi_iterations, self.lvi_lambda = (4, 1e-2) if self.lvi_large else (10, 1.0)
         self.uniq_lvi = []
         for k in range(4):
-            w = synthetic.inertial_window(k, n_opt=10, n_points=900)
+            w = synthetic.inertial_window(100 + k, n_opt=25, n_points=1500) if self.lvi_large else synthetic.inertial_window(k, n_opt=10, n_points=900)
             pre = []
             for smp, t1, t2 in w["samples"]:
                 q = pkg.capi.Preintegrated(w["bias6"], *synthetic.IMU_NOISE)
@@ -925,7 +932,8 @@ class InertialLoop(Loop):
         if self.n_ba:
             wins = [self.uniq_lvi[k % 4] for k in range(self.n_ba)]
             self.ba_batch = pkg.capi.LviBatch([dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=w["packed"], link4=w["link4"],
-                                                    pre=w["pre"], win_kf=w["win_kf"], clouds=w["clouds"], Tcl7=w["Tcl7"], Tbl7=w["Tbl7"], weight=1.0) for w in wins],
+                                                    pre=w["pre"], win_kf=w["win_kf"], clouds=w["clouds"], Tcl7=w["Tcl7"], Tbl7=w["Tbl7"], weight=1.0,
+                                                    iterations=self.lvi_iterations, lambda_init=self.lvi_lambda) for w in wins],
                                               self.uniq_lvi[0]["calib24"], self.uniq_lvi[0]["cam"])
         self.ba_batch2 = None
 
@@ -1239,7 +1247,7 @@ def cpu_baseline_inertial(wl, il, args, n_seq_gpu):
     def cpu_lviba(k):
         w = il.uniq_lvi[k % len(il.uniq_lvi)]
         return pyoracle.local_lviba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], w["link4"], lvi_pre[k % len(lvi_pre)], w["cam"],
-                                    w["win_kf"], w["clouds"], synthetic.TCL7, tbl, 1.0)[4]
+                                    w["win_kf"], w["clouds"], synthetic.TCL7, tbl, 1.0, iterations=il.lvi_iterations, lambda_init=il.lvi_lambda)[4]
 
     def run_sequences(n_seq, n_workers, budget):
         seqs = [make_seq(s % wl.U) for s in range(n_seq)]
@@ -1491,7 +1499,7 @@ def main(argv=None):
         # the same with every frame's images and scan taken from pinned host memory (what a drop-in delivers), and the inertial configuration
         single_fed_child = single_sequence_child(args, ("--host-fed",))
         if not args.front_end_only:
-            single_inertial_child = single_sequence_child(args, ("--inertial-loop",), "configs[3] with 1 sequence per step: one LocalLVIBA window every %d-th frame")
+            single_inertial_child = single_sequence_child(args, ("--inertial-loop",) + (("--lviba-small",) if args.lviba_small else ()), "configs[3] with 1 sequence per step: one LocalLVIBA window every %d-th frame")
     sweep_child = None
     if (rank == 0 and world == 1 and not args.no_extra_lines and not args.rehearse and not args.front_end_only and not under_profiler()
             and args.scaling == "strong" and set(args.stages.split(",")) == {"orb", "track", "lidar", "ba"}):
@@ -1690,6 +1698,7 @@ def main(argv=None):
     inertial = None
     if rank == 0 and not args.no_extra_lines and not args.front_end_only:
         il = InertialLoop(wl, seq_ids, args, local_rank)
+        lvi_large = il.lvi_large
         il.run(2, stages)
         torch.cuda.synchronize()
         n_i = max(4, min(args.steps, 10))
@@ -1735,8 +1744,9 @@ def main(argv=None):
                     "workload": "configs[3], camera-LiDAR-inertial, %d batched sequences, one frame of every sequence per step: the camera stages of the main "
                                 "loop + IMU pre-integration + PoseInertialOptimizationLastFrame (batched); LidarInertialProcess for all scans in one call "
                                 "(preprocess, forward propagation on the host, UndistortPcl with its time sort on the device, voxel filter, iterated ESKF "
-                                "in lock step, max 3 iterations) + map_incremental; LocalLVIBA in lock step (10 + 1 keyframes, ~900 points, LiDAR edge over "
-                                "6 keyframes x 2400 points) every %d-th frame" % (F, args.kf_interval),
+                                "in lock step, max 3 iterations) + map_incremental; LocalLVIBA in lock step (%s, LiDAR edge over "
+                                "6 keyframes x 2400 points) every %d-th frame" % (F, "bLarge as LocalMapping.cc:156 decides at > 100 tracked inliers: 25 + 1 keyframes, "
+                                "~1240 points, 4 iterations from lambda 1e-2" if lvi_large else "10 + 1 keyframes, ~900 points, 10 iterations", args.kf_interval),
                     "roofline": rf_i, "cpu_baseline": cpu_i,
                     "single_sequence": single_i,
                     **stats_i}

@@ -126,6 +126,21 @@ void ba_launch_depth(const BaProblemDev& pb, uint8_t* depth_pos, hipStream_t st)
 // A slot describes one window for the batched kernels.  Since round 4 the table goes up ONCE per call, with the windows' input blocks
 // (rounds 2-3 rewrote it before every phase: 30 one-entry copy launches per call, in configs[3] the largest line of the kernel table);
 // what changes from phase to phase travels in the kernels' arguments (BaPhase).
+// The reduced system of an inertial window (LocalInertialBA / LocalLVIBA) for the solve on the device (k_lvi_solve*): reduced_solve.hpp's order --
+// the 9 velocity / bias unknowns per keyframe first (a band: an inertial edge joins consecutive keyframes), the pose rows after them -- and its
+// envelope.  The host leaves the inertial + LiDAR part of the matrix row by row inside the envelope once per linearisation; the kernel adds the
+// visual Schur complement S (pose block) and lambda (velocity / bias diagonal) per trial.  n == 0: the window's system is solved on the host.
+constexpr int kLviBand = 28;          // widest velocity / bias row (i - first[i]) the kernel's rings of 32 columns hold with four columns eliminated per step (17 for consecutive keyframes, 26 with one keyframe between)
+constexpr int kLviMaxPoseRows = 150;  // 25 free keyframes (LocalInertialBA's maxOpt with bLarge): what the packed pose block + rings take of a CU's LDS
+struct LviSolveDev {
+    int32_t n, np, ni, pad_;          // unknowns; pose unknowns (the caller's first np); velocity / bias unknowns
+    const int32_t* first;             // [n] solver order: column of row i's first entry
+    const int32_t* rowoff;            // [n + 1] row i's entries first[i] .. i at henv + rowoff[i]
+    const double* henv;               // the inertial + LiDAR part inside the envelope
+    const double* hband;              // [ni][32] the velocity / bias rows once more at a fixed width: entry (i, c) at 32 i + (c - (i - 31)), zero outside the envelope
+    const double* bi;                 // [n] its right-hand side, the caller's numbering
+    double *LB, *Lband;               // scratch: L of the pose rows per velocity / bias column [ni][np]; L of the band [ni][32] (entry (i, c) at [c][i - c - 1])
+};
 struct BaBatchSlot {
     BaProblemDev pb;       // poses / points = the buffers the call starts from (BaPhase's parity bit swaps them with the trial buffers)
     int32_t n_slices, k_per_slice, has_lidar, pad_;
@@ -139,6 +154,7 @@ struct BaBatchSlot {
     const double *Hl, *bl_lidar;
     double *x_dev, *x_host;
     int32_t* ok_host;
+    LviSolveDev lvi;       // inertial windows solved on the device (k_lvi_solve_b): S_out / bs_out are device buffers, x_dev / x_host take all n unknowns
     const double* xp;      // the step when the phase's staging area does not hold it (a window of more than kBaXpStride / 6 free poses; device solve)
     uint8_t* depth_out;
     BalmDev balm;
@@ -175,6 +191,10 @@ void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExt
 void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 // x = (S + Hl)^-1 (b_s + bl) per window by dense LDL^T, one workgroup per window (windows of at most 21 free keyframes)
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
+// the reduced systems of inertial windows (slot.lvi.n > 0) on the device; max_np / max_ni over the windows of the launch
+void lvi_batch_launch_solve(const BaPhase& ph, int n_active, int max_np, int max_ni, hipStream_t st);
+// one window: S / bs as k_ba_schur_finish left them in device memory, x (n unknowns, the caller's numbering) to x_dev and x_host, ok_host[0] = the pivots were usable
+void lvi_launch_solve(const LviSolveDev& q, const double* S, const double* bs, double lambda, double* x_dev, double* x_host, int32_t* ok_host, hipStream_t st);
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 void ba_batch_launch_depth(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 // the LiDAR term of the listed windows (all with W <= 7 and at most 2048 planes): residual at the accepted or the trial poses,

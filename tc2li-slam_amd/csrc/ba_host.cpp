@@ -33,7 +33,50 @@ struct PoseOptWorkspace {
 };
 PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
 
+// The inertial reduced system on its way to the device solve (k_lvi_solve*, ba_kernels.hip): one blob per window and linearisation --
+// [first n | rowoff n + 1] ints, then [bi n | the envelope's entries] doubles -- and the kernel's scratch.
+struct LviSolveBuffers {
+    DevBuf<uint8_t> d_blob;
+    PinnedBuf<uint8_t> h_blob;
+    DevBuf<double> d_LB, d_Lband;
+    size_t ints_bytes = 0;
+    LviSolveDev dev{};
+    hipError_t ensure(int np, int ni) {
+        const size_t n = (size_t)np + ni;
+        ints_bytes = ((2 * n + 1) * sizeof(int32_t) + 15) / 16 * 16;
+        const size_t max_env = (size_t)ni * 32 + (size_t)np * ni + (size_t)np * (np + 1) / 2;  // band rows, pose rows against the band, pose block
+        const size_t bytes = ints_bytes + (n + (size_t)ni * 32 + max_env) * sizeof(double);
+        hipError_t e;
+        if ((e = d_blob.ensure(bytes)) != hipSuccess || (e = h_blob.ensure(bytes)) != hipSuccess || (e = d_LB.ensure(std::max<size_t>((size_t)ni * np, 1))) != hipSuccess ||
+            (e = d_Lband.ensure(std::max<size_t>((size_t)ni * 32, 1))) != hipSuccess) return e;
+        dev.n = (int32_t)n; dev.np = np; dev.ni = ni; dev.pad_ = 0;
+        dev.first = reinterpret_cast<const int32_t*>(d_blob.p);
+        dev.rowoff = dev.first + n;
+        dev.bi = reinterpret_cast<const double*>(d_blob.p + ints_bytes);
+        dev.hband = dev.bi + n;
+        dev.henv = dev.hband + (size_t)ni * 32;
+        dev.LB = d_LB.p; dev.Lband = d_Lband.p;
+        return hipSuccess;
+    }
+    // after ReducedSolver::set_pattern: the blob of this linearisation; returns the bytes to copy (h_blob -> d_blob)
+    size_t pack(const ReducedSolver& rs, const double* Hi, const double* bi) {
+        const size_t n = (size_t)rs.n;
+        int32_t* ints = reinterpret_cast<int32_t*>(h_blob.p);
+        double* dbl = reinterpret_cast<double*>(h_blob.p + ints_bytes);
+        memcpy(dbl, bi, n * sizeof(double));
+        double* hband = dbl + n;
+        double* henv = hband + (size_t)rs.ni * 32;
+        rs.pack_envelope(Hi, ints, ints + n, henv);
+        for (int i = 0; i < rs.ni; ++i)   // the band rows at a fixed width for the kernel's ring loads
+            for (int t = 0; t < 32; ++t) {
+                const int c = i - 31 + t;
+                hband[(size_t)32 * i + t] = c >= ints[i] && c >= 0 ? henv[ints[n + i] + (c - ints[i])] : 0.0;
+            }
+        return ints_bytes + (n + (size_t)rs.ni * 32 + (size_t)ints[2 * n]) * sizeof(double);
+    }
+};
 struct BaWorkspace {
+    LviSolveBuffers lvi;
     DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
     DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
         d_coef_e, d_coef, d_Y, d_Spart, d_scale_part, d_chi_part, d_red;
@@ -907,6 +950,19 @@ struct InertialTerm {
         n = np + 9 * n_imu;
         Hi.assign((size_t)n * n, 0.0); bi.assign(n, 0.0);
     }
+    // whether k_lvi_solve* takes this window's reduced system: velocity / bias unknowns present, the pose block and the rings fit a CU's LDS
+    // (25 free keyframes: the reference's largest window), every inertial edge joins keyframes at most two places apart in the numbering
+    // (band <= kLviBand).  The decision depends on the window alone: the same alone and in a batch.  TC2LI_LVI_DEVICE_SOLVE=0: the host's
+    // envelope LDL^T (reduced_solve.hpp) for every window.
+    bool device_solve_ok() const {
+        static const bool kEnabled = !(getenv("TC2LI_LVI_DEVICE_SOLVE") && atoi(getenv("TC2LI_LVI_DEVICE_SOLVE")) == 0);
+        if (!kEnabled || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows) return false;
+        for (const InertialLinkHost& lk_ : L) {
+            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2];
+            if (i1 >= 0 && i2 >= 0 && std::abs(i1 - i2) > 2) return false;
+        }
+        return true;
+    }
     double cost(const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
         const std::vector<int>& pv = *pose_var;
         double chi = 0;
@@ -1053,6 +1109,12 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
     bool ok = true;
     std::vector<double> rhs(std::max(n, 1)), bfull(std::max(n, 1)), x(std::max(n, 1), 0.0);
     ReducedSolver solver;
+    // the reduced system on the device (k_lvi_solve: the kernel body of the lock-step batch, so a window gives the same bits here and there)
+    const bool dev_solve = inertial.device_solve_ok();
+    if (dev_solve) {
+        TC2LI_HIP_CHECK(ws.lvi.ensure(np, n - np)); TC2LI_HIP_CHECK(ws.d_S.ensure((size_t)np * np)); TC2LI_HIP_CHECK(ws.d_bs.ensure(2 * (size_t)np));
+        TC2LI_HIP_CHECK(ws.d_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_ok.ensure(1));
+    }
     for (int it = 0; it < iterations && !stopped() && ok; ++it) {
         ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
         TC2LI_HIP_CHECK(hipGetLastError());
@@ -1071,6 +1133,11 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             lidar->add_quadratic_form(pose_var.data(), n, Hi.data(), bi.data());
         }
         solver.set_pattern(Hi.data(), n, np);
+        if (dev_solve) {
+            if (solver.band() > kLviBand) { set_error("tc2li_local_lvi_bundle_adjustment: inertial band wider than the device solve holds"); return TC2LI_ERR_INVALID; }
+            const size_t bytes = ws.lvi.pack(solver, Hi.data(), bi.data());
+            TC2LI_HIP_CHECK(hipMemcpyAsync(ws.lvi.d_blob.p, ws.lvi.h_blob.p, bytes, hipMemcpyHostToDevice, st));
+        }
         double currentChi = chi_imu + h_scal.p[0], tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) {
@@ -1087,6 +1154,58 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
         double rho = 0;
         int qmax = 0;
         do {
+            if (dev_solve) {  // Schur product, solve, trial estimate and its cost in one queue, one synchronisation
+                ba_launch_schur(pb, lambda, lambda, vp.n_slices, vp.k_per_slice, ws.d_S.p, ws.d_bs.p, st);
+                lvi_launch_solve(ws.lvi.dev, ws.d_S.p, ws.d_bs.p, lambda, ws.d_xp.p, h_xp.p, ws.h_ok.p, st);
+                TC2LI_HIP_CHECK(hipMemcpyAsync(h_bs.p + np, ws.d_bs.p + np, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
+                ba_launch_trial(pb, ws.d_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
+                TC2LI_HIP_CHECK(hipGetLastError());
+                TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_iposes.p, pb.iposes_trial, n_kfs * sizeof(ImuPose), hipMemcpyDeviceToHost, st));
+                if (lidar) lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes_trial), st);
+                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+                const bool ok2 = ws.h_ok.p[0] != 0;
+                memcpy(x.data(), h_xp.p, (size_t)n * sizeof(double));
+                double scale = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double bf = bi[j] + (j < np ? h_bs.p[np + j] : 0.0);
+                    scale += x[j] * (lambda * x[j] + bf);
+                }
+                if (ok2) {
+                    sv_trial = sv;
+                    for (int k = 0; k < n_kfs; ++k)
+                        if (imu_var[k] >= 0) {
+                            const double* u = &x[np + 9 * imu_var[k]];
+                            for (int c = 0; c < 3; ++c) { sv_trial[k].v[c] += u[c]; sv_trial[k].bg[c] += u[3 + c]; sv_trial[k].ba[c] += u[6 + c]; }
+                        }
+                    memcpy(hp_trial.data(), ws.h_iposes.p, n_kfs * sizeof(ImuPose));
+                    tempChi = inertial_cost(hp_trial, sv_trial, false) + h_scal.p[4];
+                    if (lidar) { lidar->finish_error(); tempChi += lidar->chi2(); }
+                    scale += h_scal.p[3];
+                    last_chi = tempChi;
+                } else {
+                    tempChi = std::numeric_limits<double>::max();
+                }
+                rho = currentChi - tempChi;
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                    std::swap(pb.iposes, pb.iposes_trial);
+                    std::swap(pb.points, pb.points_trial);
+                    hp.swap(hp_trial);
+                    sv.swap(sv_trial);
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                }
+                qmax++;
+                trials_total++;
+                continue;
+            }
             ba_launch_schur(pb, lambda, lambda, vp.n_slices, vp.k_per_slice, h_S.p, h_bs.p, st);
             TC2LI_HIP_CHECK(hipGetLastError());
             TC2LI_HIP_CHECK(hipStreamSynchronize(st));
@@ -1753,6 +1872,8 @@ struct LviWindow {
     std::vector<ImuVertexState> sv, sv_trial;
     std::vector<double> rhs, bfull, x;
     ReducedSolver solver;
+    bool dev_solve = false;    // the reduced system on the device (k_lvi_solve_b)
+    size_t blob_bytes = 0;
     double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, chi_imu = 0, last_chi = 0;
     int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
     int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot
@@ -1789,7 +1910,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     std::vector<LviWindow> W(n);
     static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // setup, linearise (device + host edges), host after linearise, schur, solve, trial, trial cost, results
+    double tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // setup, linearise (device + host edges), host after linearise, schur, solve, trial, trial cost, results
     const double t_begin = kTiming ? now() : 0;
     double t_mark = t_begin;
     auto lap = [&](int k) { if (kTiming) { const double t = now(); tm[k] += t - t_mark; t_mark = t; } };
@@ -1845,6 +1966,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         w.vp.decide_trial_fused();
         memcpy(&pb.calib, calib, sizeof(ImuCalib));
         const int nn = w.inertial.n;
+        w.dev_solve = w.inertial.device_solve_ok();
+        if (w.dev_solve) {
+            const int np1 = w.vp.np;
+            if (ws.lvi.ensure(np1, nn - np1) != hipSuccess || ws.d_S.ensure((size_t)np1 * np1) != hipSuccess || ws.d_bs.ensure(2 * (size_t)np1) != hipSuccess ||
+                ws.d_xp.ensure(nn) != hipSuccess || ws.h_xp.ensure(nn) != hipSuccess || ws.h_ok.ensure(1) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
+        }
         w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
     };
     pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
@@ -1857,6 +1984,16 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     }
     for (int i = 0; i < n; ++i)
         if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) { (void)hipStreamSynchronize(st); return false; }
+    // the reduced systems on the device or on the host, the whole call one way: a window decides for itself (InertialTerm::device_solve_ok), and a call
+    // whose windows disagree is handed back to the one-window entry points -- every window then runs exactly as it would alone
+    bool dev_solve = false;
+    int max_lvi_np = 0, max_lvi_ni = 0;
+    {
+        int n_dev = 0, n_ok = 0;
+        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { ++n_ok; if (W[i].dev_solve) { ++n_dev; max_lvi_np = std::max(max_lvi_np, W[i].vp.np); max_lvi_ni = std::max(max_lvi_ni, W[i].inertial.n - W[i].vp.np); } }
+        if (n_dev && n_dev != n_ok) { (void)hipStreamSynchronize(st); return false; }
+        dev_solve = n_dev > 0;
+    }
     BaBatchExtent X{};
     X.inertial = 1;
     bool all_block_parts = true;
@@ -1911,6 +2048,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
         s.hpp_out = nullptr; s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
         s.iposes_host = w.ws->h_iposes.p;  // the trial kernel leaves the trial ImuCamPose states there for the host's inertial cost
+        s.lvi = LviSolveDev{};
+        if (w.dev_solve) {  // Schur product, solve and trial in one queue: S and b_s stay on the device, b_p and the step (all n unknowns) come back
+            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = w.ws->h_bs.p + w.vp.np;
+            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = w.ws->h_xp.p; s.ok_host = w.ws->h_ok.p;
+            s.lvi = w.ws->lvi.dev;
+        }
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
     };
     bool failed = false;
@@ -1944,6 +2087,36 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
     auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
 
+    // OptimizationAlgorithmLevenberg::solve's gain ratio and damping update for the windows of a trial; returns those that try again
+    auto lm_decisions = [&](const std::vector<int>& trial) {
+        std::vector<int> again;
+        for (int i : trial) {
+            LviWindow& w = W[i];
+            if (!w.ok2) w.tempChi = std::numeric_limits<double>::max();
+            w.rho = w.currentChi - w.tempChi;
+            w.scale += 1e-3;
+            w.rho /= w.scale;
+            if (w.rho > 0 && std::isfinite(w.tempChi)) {
+                double alpha = 1. - std::pow((2 * w.rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                w.lambda *= std::max(1. / 3., alpha);
+                w.ni = 2;
+                w.currentChi = w.tempChi;
+                std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);
+                std::swap(w.vp.pb.points, w.vp.pb.points_trial);
+                w.parity ^= 1;
+                w.hp.swap(w.hp_trial);
+                w.sv.swap(w.sv_trial);
+            } else {
+                w.lambda *= w.ni;
+                w.ni *= 2;
+            }
+            w.qmax++;
+            w.trials_total++;
+            if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
+        }
+        return again;
+    };
     lap(0);
     for (;;) {
         std::vector<int> active, with_lidar;
@@ -1966,6 +2139,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             balm_batch_launch_hessian(ph, cnt, X, st);
         });
         pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
+        lap(8);
         sync();
         if (failed) break;
         lap(1);
@@ -1982,6 +2156,10 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 w.lidar->add_quadratic_form(w.vp.pose_var.data(), nn, w.inertial.Hi.data(), w.inertial.bi.data());
             }
             w.solver.set_pattern(w.inertial.Hi.data(), nn, np);
+            if (w.dev_solve) {
+                if (w.solver.band() > kLviBand) w.rc = TC2LI_ERR_INVALID;  // (device_solve_ok bounds the band by the links: not reached)
+                else w.blob_bytes = w.ws->lvi.pack(w.solver, w.inertial.Hi.data(), w.inertial.bi.data());
+            }
             w.currentChi = chi_imu + sc[0];
             w.tempChi = w.currentChi;
             w.iniChi = w.currentChi;
@@ -2000,10 +2178,64 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             w.rho = 0;
             w.qmax = 0;
         });
+        if (dev_solve) {  // this linearisation's inertial / LiDAR part of the reduced systems goes up: one launch
+            if (C.h_tasks.ensure(active.size()) != hipSuccess) { failed = true; break; }
+            size_t max_bytes = 0;
+            for (size_t k = 0; k < active.size(); ++k) {
+                LviWindow& w = W[active[k]];
+                if (w.rc < 0) { failed = true; break; }
+                C.h_tasks.p[k] = CopyTask{w.ws->lvi.d_blob.p, w.ws->lvi.h_blob.p, w.blob_bytes};
+                max_bytes = std::max(max_bytes, w.blob_bytes);
+            }
+            if (failed) break;
+            launch_copy_tasks(C.h_tasks.p, (int)active.size(), max_bytes, st);
+        }
         // ---- trials ----
         lap(2);
         std::vector<int> trial = active;
-        while (!trial.empty() && !failed) {
+        while (!trial.empty() && !failed && dev_solve) {
+            // Schur product, solve, trial estimate and its cost in one queue; the host sees the step, whether the factorisation went through, and
+            // the sums at the one synchronisation
+            std::vector<int> trial_lidar;
+            for (int i : trial) if (W[i].lidar) trial_lidar.push_back(i);
+            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) {
+                ba_batch_launch_schur(ph, cnt, X, st);
+                lvi_batch_launch_solve(ph, cnt, max_lvi_np, max_lvi_ni, st);
+                ba_batch_launch_trial(ph, cnt, X, st);
+            });
+            if (X.any_trial_unfused) pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+            sync();
+            if (failed) break;
+            lap(3);
+            pool.parallel_for((int)trial.size(), [&](int k) {
+                LviWindow& w = W[trial[k]];
+                BaWorkspace& ws = *w.ws;
+                const int np = w.vp.np, nn = w.inertial.n;
+                const std::vector<double>& bi = w.inertial.bi;
+                w.ok2 = ws.h_ok.p[0] != 0;
+                memcpy(w.x.data(), ws.h_xp.p, (size_t)nn * sizeof(double));
+                w.scale = 0;
+                for (int j = 0; j < nn; ++j) {
+                    const double bfull = bi[j] + (j < np ? ws.h_bs.p[np + j] : 0.0);
+                    w.scale += w.x[j] * (w.lambda * w.x[j] + bfull);
+                }
+                if (!w.ok2) return;
+                w.sv_trial = w.sv;
+                for (int q = 0; q < w.p->n_keyframes; ++q)
+                    if (w.inertial.imu_var[q] >= 0) {
+                        const double* u = &w.x[np + 9 * w.inertial.imu_var[q]];
+                        for (int c = 0; c < 3; ++c) { w.sv_trial[q].v[c] += u[c]; w.sv_trial[q].bg[c] += u[3 + c]; w.sv_trial[q].ba[c] += u[6 + c]; }
+                    }
+                memcpy(w.hp_trial.data(), ws.h_iposes.p, w.p->n_keyframes * sizeof(ImuPose));
+                w.tempChi = w.inertial.cost(w.hp_trial, w.sv_trial, false) + ws.h_scal.p[4];
+                if (w.lidar) { w.lidar->finish_error(); w.tempChi += w.lidar->chi2(); }
+                w.scale += ws.h_scal.p[3];
+                w.last_chi = w.tempChi;
+            });
+            lap(6);
+            trial = lm_decisions(trial);
+        }
+        while (!trial.empty() && !failed && !dev_solve) {
             pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
             sync();
             if (failed) break;
@@ -2055,33 +2287,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 });
             }
             lap(6);
-            std::vector<int> again;
-            for (int i : trial) {
-                LviWindow& w = W[i];
-                if (!w.ok2) w.tempChi = std::numeric_limits<double>::max();
-                w.rho = w.currentChi - w.tempChi;
-                w.scale += 1e-3;
-                w.rho /= w.scale;
-                if (w.rho > 0 && std::isfinite(w.tempChi)) {
-                    double alpha = 1. - std::pow((2 * w.rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    w.lambda *= std::max(1. / 3., alpha);
-                    w.ni = 2;
-                    w.currentChi = w.tempChi;
-                    std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);
-                    std::swap(w.vp.pb.points, w.vp.pb.points_trial);
-                    w.parity ^= 1;
-                    w.hp.swap(w.hp_trial);
-                    w.sv.swap(w.sv_trial);
-                } else {
-                    w.lambda *= w.ni;
-                    w.ni *= 2;
-                }
-                w.qmax++;
-                w.trials_total++;
-                if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
-            }
-            trial.swap(again);
+            trial = lm_decisions(trial);
         }
         for (int i : active) {
             LviWindow& w = W[i];
@@ -2132,8 +2338,8 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             });
     }
     lap(7);
-    if (kTiming) fprintf(stderr, "LVI lock-step timing ms (%d windows): setup %.3f linearize %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f trial-cost %.3f results+rest %.3f total %.3f\n",
-                         n, tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], now() - t_begin);
+    if (kTiming) fprintf(stderr, "LVI lock-step timing ms (%d windows): setup %.3f inertial edges (host, kernels queued) %.3f + wait %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f trial-cost %.3f results+rest %.3f total %.3f\n",
+                         n, tm[0], tm[8], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], now() - t_begin);
     for (int i = 0; i < n; ++i) {
         LviWindow& w = W[i];
         if (w.rc < 0) { results[i] = w.rc; continue; }

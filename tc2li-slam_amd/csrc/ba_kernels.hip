@@ -1708,6 +1708,399 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) 
     }
     if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
 }
+// ---- The reduced system of an INERTIAL window on the device (LocalInertialBA / LocalLVIBA: 6 unknowns per free keyframe pose + 9 per keyframe with
+// velocity / bias vertices, 375 for the 25-keyframe bLarge window; Optimizer.cc:1635-1638 solves it with g2o's sparse LinearSolverEigen).  Rounds
+// 1-4 and the first half of round 5 solved it on the host (reduced_solve.hpp: 0.55 ms of a host core per window and trial after the envelope
+// form, 6.4 ms before) -- in configs[3] that was most of the sixteen CPUs of a one-GPU box.  Here a workgroup per window does the same elimination:
+//   * order and envelope of reduced_solve.hpp: velocity / bias unknowns first (a band: row i starts at most kLviBand columns before its diagonal),
+//     the pose rows after them; the pose block C (visual Schur complement + inertial + LiDAR part) stays in LDS for the whole solve, packed;
+//   * the band is eliminated column by column (right-looking): the column's entries below the pivot -- the band rows in the ring `Aring`, the
+//     pose rows in the ring `Bring` of the 32 columns ahead -- are divided by the pivot, then every entry (i, j) of the rings and of C whose row and
+//     column have an entry in this column takes its term l_i a_j, side by side over the workgroup; the right-hand side rides along (forward
+//     substitution).  Column k + 32 enters the rings when column k leaves (its rows' envelopes start after k: nothing was due to it yet);
+//   * then the dense LDL^T of C in LDS, the division by the pivots, and the backward substitution: pose rows (a wavefront sweeping columns), the
+//     pose rows' terms of the velocity / bias unknowns (a thread each, rows descending), the band's rows (a wavefront, L from LDS).
+// Every entry's terms come in a fixed order (columns ascending in the elimination, rows descending in the backward sweep): a window gives the same
+// bits alone (k_lvi_solve) and in a lock-step batch (k_lvi_solve_b).  A zero or non-finite pivot: ok = 0 and a zero step, as on the host.
+constexpr int kLviThreads = 512;  // eight wavefronts (four measured slower: 1.27 M against 0.98 M cycles per solve -- a step is a chain of LDS round trips per wavefront, and two wavefronts per SIMD take turns on them)
+constexpr int kLviTilesPerWave = 7;  // 10 x 11 / 2 = 55 lower tiles of 16 x 16 over eight wavefronts (150 pose rows)
+constexpr int kLviCol = 192;        // entries of a column vector: pose rows [0, 160), band rows below the panel at 160 + j
+inline size_t lvi_solve_lds_bytes(int np, int ni) {
+    const size_t n = (size_t)np + ni;
+    const size_t region0 = std::max((size_t)np * (np + 1) / 2 + 33 * (size_t)np, (size_t)32 * ni);
+    return (region0 + 32 * 33 + 8 * (size_t)kLviCol + 2 * n) * sizeof(double) + (n + (size_t)ni + 2) * sizeof(int);
+}
+// a workgroup barrier that waits for this wavefront's LDS traffic only: loads and stores to memory stay in flight across it
+__device__ __forceinline__ void lvi_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// 1 / x by the hardware's estimate and two Newton steps (every thread of a workgroup repeats a panel's four reciprocals: the IEEE division's
+// scaling and fix-up sequence was a third of a step's chain).  Deterministic; within an ulp or two of the quotient, which is all an LDL^T's
+// L = (L D) / D needs -- the pivots D themselves are stored exactly.
+__device__ __forceinline__ double lvi_reciprocal(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ void lvi_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void d_lvi_solve(const LviSolveDev& q_, const double* S, const double* bs, const double lambda,
+                                            double* x_dev, double* x_host, int32_t* ok_host, double* lds) {
+    constexpr int T = kLviThreads, P = 4, kWaves = T / 64;
+    // (the record's pointers are device or pinned host addresses: global accesses, not flat ones -- a flat load counts on the LDS counter too, and
+    // the loop's barriers wait for that counter)
+    LviSolveDev q = q_;
+    q.first = global_ptr(q.first); q.rowoff = global_ptr(q.rowoff); q.henv = global_ptr(q.henv); q.bi = global_ptr(q.bi); q.LB = global_ptr(q.LB); q.Lband = global_ptr(q.Lband); q.hband = global_ptr(q.hband);
+    S = global_ptr(S); bs = global_ptr(bs); x_dev = global_ptr(x_dev); x_host = global_ptr(x_host); ok_host = global_ptr(ok_host);
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lj = lane & 15;
+    const int n = q.n, np = q.np, ni = q.ni;
+    const int tri = np * (np + 1) / 2;
+    const int region0 = max(tri + 33 * np, 32 * ni);
+    double* const C = lds;                    // pose block, packed lower: (r, s) at r (r + 1) / 2 + s (the band phase keeps it in registers, see acc)
+    double* const Bring = C + tri;            // pose rows x the 32 columns ahead: (r, c) at 33 r + (c & 31)
+    double* const Aring = lds + region0;      // band rows: (i, c) at 33 (i & 31) + (c & 31)
+    double* const colL = Aring + 32 * 33;     // [4][kLviCol] the panel's columns divided by their pivots (L): pose rows, then the band rows below the panel
+    double* const colA = colL + 4 * kLviCol;  // [4][kLviCol] the same entries before the division (L D)
+    double* const z = colA + 4 * kLviCol;     // right-hand side -> solution, solver order
+    double* const D = z + n;
+    int* const first = reinterpret_cast<int*>(D + n);
+    int* const rhi = first + n;               // pose rows [0, rhi[k]) can have an entry in column k
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < n; i += T) first[i] = q.first[i];
+    __syncthreads();
+    for (int k = tid; k < ni; k += T) {
+        int h = 0;
+        for (int r = 0; r < np; ++r) if (first[ni + r] <= k) h = r + 1;
+        rhi[k] = h;
+    }
+    // The pose block as 16 x 16 tiles of the lower triangle, tile n with wavefront n % 8, IN REGISTERS through the whole elimination of the band: a
+    // panel's update of a tile is one v_mfma_f64_16x16x4_f64 (K = 4 = the panel's columns) on two operands out of LDS, the block itself never
+    // travels.  Tile layout as in the Schur product: acc[r] of lane -> row 16 ti + lane / 16 + 4 r, column 16 tj + lane % 16.
+    const int tiles = (np + 15) / 16, n_tiles = tiles * (tiles + 1) / 2;
+    int my_ti[kLviTilesPerWave], my_tj[kLviTilesPerWave];
+    v4d acc[kLviTilesPerWave];
+#pragma unroll
+    for (int t = 0; t < kLviTilesPerWave; ++t) {
+        const int tn = wave + kWaves * t;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tn) ++ti;
+        my_ti[t] = tn < n_tiles ? ti : -1;
+        my_tj[t] = tn - ti * (ti + 1) / 2;
+        acc[t] = v4d{0, 0, 0, 0};
+        if (my_ti[t] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * my_ti[t] + kq + 4 * r, col = 16 * my_tj[t] + lj;
+            if (row < np && col <= row) acc[t][r] = S[(size_t)row * np + col] + q.henv[q.rowoff[ni + row] + (ni - first[ni + row]) + col];
+        }
+    }
+    for (int j = tid; j < n; j += T) z[j] = j < ni ? q.bi[np + j] : q.bi[j - ni] + bs[j - ni];
+    for (int e = tid; e < ni * 32; e += T) q.Lband[e] = 0.0;   // (entries of rows further than the rings reach below a column: structurally zero)
+    // The rings are fed from global memory: the entry of (pose row tid, column c) and of (band row c, column c - 31 + tid).  Four columns enter when a
+    // panel's four leave; their entries are requested a whole step earlier and the loop's barriers wait for LDS only (lvi_lds_barrier), so neither
+    // these loads nor the stores of L stand in a step's way.
+    const int my_f = tid < np ? first[ni + tid] : 0, my_off = tid < np ? q.rowoff[ni + tid] : 0;
+    auto fetch_pose = [&](int c) -> double { return tid < np && c < ni && c >= my_f ? q.henv[my_off + (c - my_f)] : 0.0; };
+    auto fetch_band = [&](int c) -> double { return tid < 32 && c < ni ? q.hband[32 * c + tid] : 0.0; };   // (the host left the band rows 32 wide)
+    auto put_column = [&](int c, double vp, double vb) {
+        if (tid < np) Bring[33 * tid + (c & 31)] = vp;
+        if (tid < 32) {
+            const int cc = c - 31 + tid;
+            if (cc >= 0) Aring[(c & 31) * 33 + (cc & 31)] = cc == c ? vb + lambda : vb;
+        }
+    };
+    for (int c0 = 0; c0 < min(32, ni); c0 += 8) {   // (eight columns' entries requested together: one trip to memory per batch)
+        double vp[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { vp[u] = fetch_pose(c0 + u); vb[u] = fetch_band(c0 + u); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (c0 + u < ni) put_column(c0 + u, vp[u], vb[u]);
+    }
+    double pre_p[P], pre_b[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) { pre_p[u] = fetch_pose(32 + u); pre_b[u] = fetch_band(32 + u); }
+    __syncthreads();
+    // FOUR columns per pair of barriers.  A step's cost is not its arithmetic but its chain of LDS round trips (the column-at-a-time build: 4 k
+    // cycles per column with nothing to do, 1.3 ms per solve), so a panel of four columns is eliminated per step: every thread factorises the
+    // panel's 4 x 4 pivot block for itself (reciprocals: lvi_reciprocal), solves its own row against it (y_j = a_j - sum_{m<j} y_m L_jm,
+    // l_j = y_j / D_j: what four single steps would have left in the row), and after ONE barrier every trailing block takes its rank-4 update on
+    // the matrix unit: the pose block's tiles in registers, the rings' tiles read from LDS and written back.  Within a phase every LDS operand is
+    // requested before the first result is used, with clamped addresses instead of branches (a predicated read is a block of its own with its own
+    // wait: 60 waits per step in the first panel build).
+    // pv: the pivot block's lower triangle, zr: the panel rows' right-hand side, a: this thread's row in the panel's columns
+#define TC2LI_LVI_PANEL(pv, zr, a, y, l)                                                                           \
+        _Pragma("unroll") for (int i = 0; i < P; ++i) {                                                           \
+            double yy[P];                                                                                         \
+            _Pragma("unroll") for (int j = 0; j <= i; ++j) {                                                      \
+                double v = i < pw ? pv[i][j] : (i == j ? 1.0 : 0.0);                                              \
+                _Pragma("unroll") for (int m = 0; m < j; ++m) v -= yy[m] * Lp[j][m];                              \
+                yy[j] = v;                                                                                        \
+                if (j < i) Lp[i][j] = v * iD[j];                                                                  \
+            }                                                                                                     \
+            Dp[i] = yy[i]; iD[i] = lvi_reciprocal(yy[i]);                                                         \
+            double zz = i < pw ? zr[i] : 0.0;                                                                     \
+            _Pragma("unroll") for (int m = 0; m < i; ++m) zz -= Lp[i][m] * zk[m];                                 \
+            zk[i] = zz;                                                                                           \
+        }                                                                                                         \
+        if (tid == 0) {                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < P; ++i)                                                         \
+                if (i < pw && (!(Dp[i] == Dp[i]) || Dp[i] == 0.0 || Dp[i] - Dp[i] != 0.0)) s_bad = 1;             \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < P; ++j) {                                                           \
+            double v = a[j];                                                                                      \
+            _Pragma("unroll") for (int m = 0; m < j; ++m) v -= y[m] * Lp[j][m];                                   \
+            y[j] = v; l[j] = v * iD[j];                                                                           \
+        }
+    for (int k = 0; k < ni; k += P) {
+        const int pw = min(P, ni - k), kp = k + pw;
+        const int hi = rhi[kp - 1];
+        const int nb = max(0, min(31, ni - 1 - k) - pw + 1);   // band rows (= ring columns) below the panel: kp .. kp + nb - 1
+        // ---- phase 1: the panel (the wavefronts that own rows: pose rows on the first three, band rows on the last; the others wait) ----
+        const int jb = tid - (T - 32);             // the last half wavefront: band row kp + jb
+        const bool pose_row = tid < hi, band_row = jb >= 0 && jb < nb;
+        double Lp[P][P], Dp[P], iD[P], zk[P], y[P], l[P] = {0, 0, 0, 0};
+        if (wave < 3 || wave == kWaves - 1) {
+        double pv[P][P], zr[P], a[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int ii = min(i, pw - 1);
+            zr[i] = z[k + ii];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) pv[i][j] = Aring[((k + ii) & 31) * 33 + ((k + min(j, pw - 1)) & 31)];
+        }
+        if (wave == kWaves - 1) {
+            const int srow = ((kp + max(jb, 0)) & 31) * 33;
+#pragma unroll
+            for (int j = 0; j < P; ++j) { const double v = Aring[srow + ((k + min(j, pw - 1)) & 31)]; a[j] = band_row && j < pw ? v : 0.0; }
+        } else {
+            const int prow = 33 * min(tid, np - 1);
+#pragma unroll
+            for (int j = 0; j < P; ++j) { const double v = Bring[prow + ((k + min(j, pw - 1)) & 31)]; a[j] = pose_row && j < pw ? v : 0.0; }
+        }
+        TC2LI_LVI_PANEL(pv, zr, a, y, l)
+        if (tid < 160) {   // (rows without an entry in the panel and the tiles' padding: zero operands for the matrix unit; a = 0 gave y = l = 0)
+#pragma unroll
+            for (int j = 0; j < P; ++j) { colA[j * kLviCol + tid] = y[j]; colL[j * kLviCol + tid] = l[j]; }
+        }
+        if (tid < np) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) if (j < pw) q.LB[(size_t)(k + j) * np + tid] = l[j];
+        }
+        if (jb >= 0) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                colA[j * kLviCol + 160 + jb] = y[j]; colL[j * kLviCol + 160 + jb] = l[j];
+                if (j < pw && band_row) q.Lband[(size_t)(k + j) * 32 + (pw - j - 1 + jb)] = l[j];
+            }
+        }
+        if (tid == 64) {   // (the panel's own sub-diagonal entries of L)
+#pragma unroll
+            for (int i = 1; i < P; ++i)
+#pragma unroll
+                for (int j = 0; j < i; ++j) if (i < pw) q.Lband[(size_t)(k + j) * 32 + (i - j - 1)] = Lp[i][j];
+        }
+        }
+        lvi_lds_barrier();
+        // ---- phase 2: the trailing blocks ----
+        // operands of the pose block's tiles (registers)
+        double ma[kLviTilesPerWave], mb[kLviTilesPerWave];
+#pragma unroll
+        for (int t = 0; t < kLviTilesPerWave; ++t) {
+            if (my_ti[t] < 0 || 16 * my_ti[t] >= hi) continue;   // (no row of the tile has an entry in the panel; uniform)
+            ma[t] = colL[kq * kLviCol + 16 * my_ti[t] + lj];
+            mb[t] = colA[kq * kLviCol + 16 * my_tj[t] + lj];
+        }
+        // the ring of band rows: four tiles of 16 row slots x 16 column slots, on wavefronts 4 .. 7
+        const int ta = wave & 3, srl = 16 * (ta >> 1) + lj, scl = 16 * (ta & 1) + lj;     // this lane's row slot (A operand) and column slot (B operand, results)
+        const int jia = (srl - kp) & 31, jcb = (scl - kp) & 31;
+        double aa = 0.0, ab = 0.0;
+        v4d ac = v4d{0, 0, 0, 0};
+        int aat[4] = {-1, -1, -1, -1};
+        if (wave >= 4) {
+            aa = colL[kq * kLviCol + 160 + jia]; ab = colA[kq * kLviCol + 160 + jcb];
+            aa = jia < nb ? aa : 0.0; ab = jcb < nb ? ab : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sr = 16 * (ta >> 1) + kq + 4 * r, ji = (sr - kp) & 31;
+                aat[r] = jcb <= ji && ji < nb ? 33 * sr + scl : -1;
+                ac[r] = Aring[max(aat[r], 0)];
+            }
+        }
+        const double zp = z[ni + min(tid, np - 1)], zb = z[min(kp + max(jb, 0), n - 1)];
+        // the products
+#pragma unroll
+        for (int t = 0; t < kLviTilesPerWave; ++t) {
+            if (my_ti[t] < 0 || 16 * my_ti[t] >= hi) continue;   // (no row of the tile has an entry in the panel; uniform)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma[t], mb[t], acc[t], 0, 0, 0);
+        }
+        // the ring of pose rows x columns ahead: tiles of 16 rows x 16 ring SLOTS, tile (ti, tc) = 2 ti + tc with wavefront % 8, one after the other
+        // (all three in flight at once spilled registers: 60 scratch loads per step)
+#pragma unroll 1
+        for (int tb = wave; 16 * (tb >> 1) < hi; tb += kWaves) {
+            const int ti = tb >> 1, slot = 16 * (tb & 1) + lj;
+            const int jjl = (slot - kp) & 31;                       // the slot holds column kp + jjl
+            const double av = colL[kq * kLviCol + 16 * ti + lj], bv0 = colA[kq * kLviCol + 160 + jjl];
+            v4d bc;
+            int bat[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + kq + 4 * r;
+                bat[r] = row < hi && jjl < nb ? 33 * row + slot : -1;
+                bc[r] = Bring[max(bat[r], 0)];
+            }
+            bc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, jjl < nb ? bv0 : 0.0, bc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (bat[r] >= 0) Bring[bat[r]] = bc[r];
+        }
+        if (wave >= 4) {
+            ac = __builtin_amdgcn_mfma_f64_16x16x4f64(-aa, ab, ac, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (aat[r] >= 0) Aring[aat[r]] = ac[r];
+        }
+        if (pose_row) z[ni + tid] = (((zp - l[0] * zk[0]) - l[1] * zk[1]) - l[2] * zk[2]) - l[3] * zk[3];
+        if (band_row) z[kp + jb] = (((zb - l[0] * zk[0]) - l[1] * zk[1]) - l[2] * zk[2]) - l[3] * zk[3];
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if (i >= pw) continue;
+                D[k + i] = Dp[i]; z[k + i] = zk[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) if (u < pw && k + 32 + u < ni) put_column(k + 32 + u, pre_p[u], pre_b[u]);   // into the slots of the panel's columns
+#pragma unroll
+        for (int u = 0; u < P; ++u) { pre_p[u] = fetch_pose(k + 32 + P + u); pre_b[u] = fetch_band(k + 32 + P + u); }
+        lvi_lds_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < kLviTilesPerWave; ++t) {   // the pose block -- now the Schur complement of the band -- into LDS for its own factorisation
+        if (my_ti[t] < 0) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * my_ti[t] + kq + 4 * r, col = 16 * my_tj[t] + lj;
+            if (row < np && col <= row) C[((row * (row + 1)) >> 1) + col] = acc[t][r];
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < np; k += P) {
+        const int pw = min(P, np - k), kp = k + pw;
+        const bool mine = tid >= kp && tid < np;   // this thread's pose row lies below the panel
+        const int base = ((min(max(tid, kp), np - 1) * (min(max(tid, kp), np - 1) + 1)) >> 1) + k;
+        double Lp[P][P], Dp[P], iD[P], zk[P], y[P], l[P] = {0, 0, 0, 0};
+        if (wave < 3) {
+        double pv[P][P], zr[P], a[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int ri = k + min(i, pw - 1);
+            zr[i] = z[ni + ri];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) pv[i][j] = C[((ri * (ri + 1)) >> 1) + k + min(j, pw - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) { const double v = C[base + min(j, pw - 1)]; a[j] = mine && j < pw ? v : 0.0; }
+        TC2LI_LVI_PANEL(pv, zr, a, y, l)
+        if (tid < 160) {   // (zeros for the rows above the panel's end and the padding)
+#pragma unroll
+            for (int j = 0; j < P; ++j) { colA[j * kLviCol + tid] = y[j]; colL[j * kLviCol + tid] = l[j]; }
+        }
+        }
+        lvi_lds_barrier();
+        double ma[kLviTilesPerWave], mb[kLviTilesPerWave];
+        v4d cc[kLviTilesPerWave];
+        int cat[kLviTilesPerWave][4];
+#pragma unroll
+        for (int t = 0; t < kLviTilesPerWave; ++t) {   // the tiles with rows and columns beyond the panel: out of LDS, one MFMA, back
+            const bool on = my_ti[t] >= 0 && 16 * my_ti[t] + 15 >= kp && 16 * my_tj[t] + 15 >= kp;   // (uniform)
+            if (!on) continue;
+            ma[t] = colL[kq * kLviCol + 16 * my_ti[t] + lj];
+            mb[t] = colA[kq * kLviCol + 16 * my_tj[t] + lj];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * my_ti[t] + kq + 4 * r, col = 16 * my_tj[t] + lj;
+                cat[t][r] = row < np && col >= kp && col <= row ? ((row * (row + 1)) >> 1) + col : -1;
+                cc[t][r] = C[max(cat[t][r], 0)];
+            }
+        }
+        const double zp = z[ni + min(tid, np - 1)];
+#pragma unroll
+        for (int t = 0; t < kLviTilesPerWave; ++t) {
+            if (my_ti[t] < 0 || 16 * my_ti[t] + 15 < kp || 16 * my_tj[t] + 15 < kp) continue;
+            cc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ma[t], mb[t], cc[t], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (cat[t][r] >= 0) C[cat[t][r]] = cc[t][r];
+        }
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < P; ++j) if (j < pw) C[base + j] = l[j];   // L where the backward sweep reads it
+            z[ni + tid] = (((zp - l[0] * zk[0]) - l[1] * zk[1]) - l[2] * zk[2]) - l[3] * zk[3];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                if (i >= pw) continue;
+                D[ni + k + i] = Dp[i]; z[ni + k + i] = zk[i];
+#pragma unroll
+                for (int j = 0; j < i; ++j) C[(((k + i) * (k + i + 1)) >> 1) + k + j] = Lp[i][j];
+            }
+        }
+        lvi_lds_barrier();
+    }
+#undef TC2LI_LVI_PANEL
+    for (int j = tid; j < n; j += T) z[j] = z[j] / D[j];
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = np - 1; k >= 1; --k) {
+            const double xk = z[ni + k];
+            const double* row = C + ((k * (k + 1)) >> 1);
+            for (int s2 = lane; s2 < k; s2 += 64) z[ni + s2] -= row[s2] * xk;
+            lvi_wave_sync();
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < ni; c += T) {
+        double acc1 = z[c];
+        const double* lb = q.LB + (size_t)c * np;
+#pragma unroll 8
+        for (int r = np - 1; r >= 0; --r) acc1 -= lb[r] * z[ni + r];
+        z[c] = acc1;
+    }
+    double* const Lb = lds;   // the band's L, [ni][32] (the pose block is done)
+    __syncthreads();
+    for (int e = tid; e < ni * 32; e += T) Lb[e] = q.Lband[e];
+    __syncthreads();
+    if (wave == 0) {
+        for (int k = ni - 1; k >= 1; --k) {
+            const double xk = z[k];
+            const int i = k - 1 - lane;       // row i takes L_ki x_k: entry (k, i) at [i][k - i - 1]
+            if (lane < 31 && i >= 0) z[i] -= Lb[i * 32 + lane] * xk;
+            lvi_wave_sync();
+        }
+    }
+    __syncthreads();
+    const bool bad = s_bad != 0;
+    for (int j = tid; j < n; j += T) {
+        const double v = bad ? 0.0 : (j < np ? z[ni + j] : z[j - np]);
+        x_dev[j] = v;
+        x_host[j] = v;
+    }
+    if (tid == 0) ok_host[0] = bad ? 0 : 1;
+}
+struct LviSolveArgs { LviSolveDev q; const double *S, *bs; double lambda; double *x_dev, *x_host; int32_t* ok_host; };
+__global__ __launch_bounds__(kLviThreads) void k_lvi_solve(const LviSolveArgs a) {
+    extern __shared__ double s_lvi[];
+    d_lvi_solve(a.q, a.S, a.bs, a.lambda, a.x_dev, a.x_host, a.ok_host, s_lvi);
+}
+__global__ __launch_bounds__(kLviThreads) void k_lvi_solve_b(const BaPhase ph) {
+    extern __shared__ double s_lvi[];
+    TC2LI_SLOT(x);
+    (void)pb;
+    const LviSolveDev q = load_uniform(&sl.lvi);
+    if (q.n == 0) return;
+    d_lvi_solve(q, load_uniform(&sl.S_out), load_uniform(&sl.bs_out), view_.lambda, load_uniform(&sl.x_dev), load_uniform(&sl.x_host), load_uniform(&sl.ok_host), s_lvi);
+}
 // The fused trial launch of the lock-step batch: workgroups [0, max_groups) the window's landmark groups, workgroup max_groups its LiDAR
 // plane residual at the trial poses (formed in LDS as the groups form them: the launch that wrote them to memory is this one).
 template <bool INERTIAL>
@@ -1894,6 +2287,18 @@ void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent&
     const size_t lds = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);  // 12 free keyframes: 42 KB; 21: 129 KB
     (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 132 * 1024);
     TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
+}
+void lvi_batch_launch_solve(const BaPhase& ph, int n_active, int max_np, int max_ni, hipStream_t st) {
+    if (!n_active || max_ni <= 0) return;
+    const size_t lds = lvi_solve_lds_bytes(max_np, max_ni);
+    (void)ensure_dynamic_lds((const void*)k_lvi_solve_b, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6)));
+    TC2LI_LAUNCH(k_lvi_solve_b, dim3(n_active), dim3(kLviThreads), lds, st, ph);
+}
+void lvi_launch_solve(const LviSolveDev& q, const double* S, const double* bs, double lambda, double* x_dev, double* x_host, int32_t* ok_host, hipStream_t st) {
+    if (q.n <= 0) return;
+    (void)ensure_dynamic_lds((const void*)k_lvi_solve, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6)));
+    const LviSolveArgs a{q, S, bs, lambda, x_dev, x_host, ok_host};
+    TC2LI_LAUNCH(k_lvi_solve, dim3(1), dim3(kLviThreads), lvi_solve_lds_bytes(q.np, q.ni), st, a);
 }
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active) return;

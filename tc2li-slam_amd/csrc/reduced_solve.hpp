@@ -7,10 +7,12 @@
 // the dense factorisation's work at 150 unknowns and a ninth at 375; the dense, scalar ldlt_solve_small of rounds 1-4 took 6.4 ms per bLarge
 // window and trial on a host core -- two thirds of such a batch's wall time, and most of the sixteen CPUs of a one-GPU box in configs[3].
 // The arithmetic is plain IEEE double in a fixed order (inner products as eight interleaved partial sums, closed in a fixed tree): a window
-// gives the same bits alone and in a lock-step batch, on every x86-64 host (no FMA contraction: the library is built with -ffp-contract=off).
+// gives the same bits alone and in a lock-step batch, on every x86-64 host (no FMA contraction: the library is built with -ffp-contract=off; the
+// AVX2 build of the inner products -- reduced_solve.cc, chosen at run time -- multiplies and adds the same eight lanes in the same order).
 #pragma once
 #include <algorithm>
 #include <cstddef>
+#include <cstdint>
 #include <vector>
 
 namespace tc2li {
@@ -21,17 +23,6 @@ struct ReducedSolver {
     std::vector<int> first;            // the envelope: first[i] = column of row i's first entry
     std::vector<double> D, z;
 
-    static inline double dot8(const double* a, const double* b, int len) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
-        int k = 0;
-        for (; k + 8 <= len; k += 8) {
-            s0 += a[k] * b[k]; s1 += a[k + 1] * b[k + 1]; s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3];
-            s4 += a[k + 4] * b[k + 4]; s5 += a[k + 5] * b[k + 5]; s6 += a[k + 6] * b[k + 6]; s7 += a[k + 7] * b[k + 7];
-        }
-        double t = 0;
-        for (; k < len; ++k) t += a[k] * b[k];
-        return (((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7))) + t;
-    }
     inline int to_solver(int j) const { return j < np ? ni + j : j - np; }   // the caller's index -> the solver's
 
     // Once per linearisation: the envelope from the entries of Hi (the inertial / LiDAR part, [n][n] in the caller's numbering, lower triangle
@@ -51,56 +42,30 @@ struct ReducedSolver {
             first[ni + r] = f;
         }
     }
-    // Per trial: M = [S + Hi(poses) | Hi(poses, imu); . | Hi(imu) + lambda I] in the solver's order, factorised; false as ldlt_solve_small (a zero or
-    // non-finite pivot).  S: [np][np] with the damping already on its diagonal (k_ba_schur_finish).
-    bool factorise(const double* Hi, const double* S, double lambda) {
+    // For the solve on the device (k_lvi_solve*, ba_kernels.hip): the envelope and the inertial / LiDAR part inside it, row by row in the solver's
+    // order -- first_out [n], rowoff_out [n + 1], henv_out [envelope_entries()].  band(): the widest velocity / bias row (i - first[i]).
+    size_t envelope_entries() const { size_t e = 0; for (int i = 0; i < n; ++i) e += (size_t)(i - first[i] + 1); return e; }
+    int band() const { int b = 0; for (int i = 0; i < ni; ++i) b = std::max(b, i - first[i]); return b; }
+    void pack_envelope(const double* Hi, int32_t* first_out, int32_t* rowoff_out, double* henv_out) const {
+        size_t at = 0;
         for (int r = 0; r < ni; ++r) {
+            first_out[r] = first[r]; rowoff_out[r] = (int32_t)at;
             const double* src = Hi + (size_t)(np + r) * n + np;
-            double* dst = M.data() + (size_t)r * n;
-            for (int c = first[r]; c <= r; ++c) dst[c] = src[c];
-            dst[r] += lambda;
+            for (int c = first[r]; c <= r; ++c) henv_out[at++] = src[c];
         }
         for (int r = 0; r < np; ++r) {
-            double* dst = M.data() + (size_t)(ni + r) * n;
-            for (int c = first[ni + r]; c < ni; ++c) dst[c] = Hi[(size_t)(np + c) * n + r];
+            first_out[ni + r] = first[ni + r]; rowoff_out[ni + r] = (int32_t)at;
+            for (int c = first[ni + r]; c < ni; ++c) henv_out[at++] = Hi[(size_t)(np + c) * n + r];
             const double* hp = Hi + (size_t)r * n;
-            const double* sp = S + (size_t)r * np;
-            for (int c = 0; c <= r; ++c) dst[ni + c] = hp[c] + sp[c];
+            for (int c = 0; c <= r; ++c) henv_out[at++] = hp[c];
         }
-        for (int i = 0; i < n; ++i) {
-            double* ri = M.data() + (size_t)i * n;
-            const int fi = first[i];
-            // y_j = M_ij - sum_k y_k L_jk  (y = L_i D): row i against every row before it, inside both envelopes
-            for (int j = fi; j < i; ++j) {
-                const int k0 = std::max(fi, first[j]);
-                if (k0 < j) ri[j] -= dot8(ri + k0, M.data() + (size_t)j * n + k0, j - k0);
-            }
-            double d = ri[i];
-            for (int j = fi; j < i; ++j) {
-                const double y = ri[j], l = y / D[j];
-                d -= y * l;
-                ri[j] = l;
-            }
-            if (!(d == d) || d == 0.0 || d - d != 0.0) return false;
-            D[i] = d;
-        }
-        return true;
+        rowoff_out[n] = (int32_t)at;
     }
+    // Per trial: M = [S + Hi(poses) | Hi(poses, imu); . | Hi(imu) + lambda I] in the solver's order, factorised; false as ldlt_solve_small (a zero or
+    // non-finite pivot).  S: [np][np] with the damping already on its diagonal (k_ba_schur_finish).
+    bool factorise(const double* Hi, const double* S, double lambda);
     // x (the caller's numbering) from rhs (the caller's numbering)
-    void solve(const double* rhs, double* x) {
-        for (int j = 0; j < n; ++j) z[to_solver(j)] = rhs[j];
-        for (int i = 0; i < n; ++i) {
-            const int fi = first[i];
-            if (fi < i) z[i] -= dot8(M.data() + (size_t)i * n + fi, z.data() + fi, i - fi);
-        }
-        for (int i = 0; i < n; ++i) z[i] /= D[i];
-        for (int i = n - 1; i >= 0; --i) {       // column sweep: x_i is final, every row of its envelope takes its term
-            const double xi = z[i];
-            const double* ri = M.data() + (size_t)i * n;
-            for (int k = first[i]; k < i; ++k) z[k] -= ri[k] * xi;
-        }
-        for (int j = 0; j < n; ++j) x[j] = z[to_solver(j)];
-    }
+    void solve(const double* rhs, double* x);
 };
 
 }  // namespace tc2li
