@@ -1053,6 +1053,11 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # dense windows (> 21 free keyframes): W D^-1 per slot, then the block-sparse MFMA product (priced in mfma_line by its executed FLOPs)
             "k_ba_schur_coef_b": (nw * tr * Ef * (144 + 144 + 48 + 72), "B"),
             "k_ba_schur_full_b": (nw * tr * pairs * 324.0, "FLOP"), "k_ba_schur_units_b": (nw * tr * pairs * 324.0, "FLOP"),
+            # the reduced system of an inertial window on the device (round 5): the multiply-adds of the LDL^T inside its envelope -- per velocity / bias
+            # column (9 per free keyframe, band 18) the band below it, the pose rows that reach it (6 per keyframe up to the next one) and their
+            # pairs; then the dense pose block -- x 2 FLOP
+            "k_lvi_solve_b": (nw * tr * 2.0 * (sum(18 * 9 + 18 * min(6 * nf, 6 * (c // 9 + 2)) + min(6 * nf, 6 * (c // 9 + 2)) ** 2 / 2.0 for c in range(9 * nf)) + (6 * nf) ** 3 / 6.0), "FLOP"),
+            "k_lvi_solve": (nw * tr * 2.0 * (sum(18 * 9 + 18 * min(6 * nf, 6 * (c // 9 + 2)) + min(6 * nf, 6 * (c // 9 + 2)) ** 2 / 2.0 for c in range(9 * nf)) + (6 * nf) ** 3 / 6.0), "FLOP"),
             # the LiDAR term's Hessian / gradient from the chunks' partial sums: (21 pair blocks x 36 + 36 + 1) doubles per chunk of 8 planes in, the
             # (6W)^2 + 6W + 1 doubles and the W poses out
             "k_balm_combine_b": (nw * lin * (((ba["planes"] + 7) // 8) * (ba["win"] * (ba["win"] + 1) // 2 * 36 + 6 * ba["win"] + 1) + 36 * ba["win"] ** 2 + 18 * ba["win"]) * 8, "B"),

@@ -134,11 +134,12 @@ constexpr int kLviBand = 28;          // widest velocity / bias row (i - first[i
 constexpr int kLviMaxPoseRows = 150;  // 25 free keyframes (LocalInertialBA's maxOpt with bLarge): what the packed pose block + rings take of a CU's LDS
 struct LviSolveDev {
     int32_t n, np, ni, pad_;          // unknowns; pose unknowns (the caller's first np); velocity / bias unknowns
-    const int32_t* first;             // [n] solver order: column of row i's first entry
-    const int32_t* rowoff;            // [n + 1] row i's entries first[i] .. i at henv + rowoff[i]
-    const double* henv;               // the inertial + LiDAR part inside the envelope
-    const double* hband;              // [ni][32] the velocity / bias rows once more at a fixed width: entry (i, c) at 32 i + (c - (i - 31)), zero outside the envelope
-    const double* bi;                 // [n] its right-hand side, the caller's numbering
+    const int32_t* first;             // [n] solver order: column of row i's first entry (the envelope)
+    const int32_t* span_end;          // [np] pose row r has its entries against the velocity / bias unknowns in columns first[ni + r] .. span_end[r] - 1
+    const int32_t* rowoff;            // [np + 1] pose row r: the span's entries, then its r + 1 entries of the pose block, at hpose + rowoff[r]
+    const double* hpose;
+    const double* hband;              // [ni][32] the velocity / bias rows at a fixed width: entry (i, c) at 32 i + (c - (i - 31)), zero outside the envelope
+    const double* bi;                 // [n] the right-hand side of the inertial + LiDAR part, the caller's numbering
     double *LB, *Lband;               // scratch: L of the pose rows per velocity / bias column [ni][np]; L of the band [ni][32] (entry (i, c) at [c][i - c - 1])
 };
 struct BaBatchSlot {

@@ -43,18 +43,19 @@ struct LviSolveBuffers {
     LviSolveDev dev{};
     hipError_t ensure(int np, int ni) {
         const size_t n = (size_t)np + ni;
-        ints_bytes = ((2 * n + 1) * sizeof(int32_t) + 15) / 16 * 16;
-        const size_t max_env = (size_t)ni * 32 + (size_t)np * ni + (size_t)np * (np + 1) / 2;  // band rows, pose rows against the band, pose block
-        const size_t bytes = ints_bytes + (n + (size_t)ni * 32 + max_env) * sizeof(double);
+        ints_bytes = ((n + 2 * (size_t)np + 1) * sizeof(int32_t) + 15) / 16 * 16;
+        const size_t max_pose = (size_t)np * ni + (size_t)np * (np + 1) / 2;  // pose rows against the band (worst case: every column), pose block
+        const size_t bytes = ints_bytes + (n + (size_t)ni * 32 + max_pose) * sizeof(double);
         hipError_t e;
         if ((e = d_blob.ensure(bytes)) != hipSuccess || (e = h_blob.ensure(bytes)) != hipSuccess || (e = d_LB.ensure(std::max<size_t>((size_t)ni * np, 1))) != hipSuccess ||
             (e = d_Lband.ensure(std::max<size_t>((size_t)ni * 32, 1))) != hipSuccess) return e;
         dev.n = (int32_t)n; dev.np = np; dev.ni = ni; dev.pad_ = 0;
         dev.first = reinterpret_cast<const int32_t*>(d_blob.p);
-        dev.rowoff = dev.first + n;
+        dev.span_end = dev.first + n;
+        dev.rowoff = dev.span_end + np;
         dev.bi = reinterpret_cast<const double*>(d_blob.p + ints_bytes);
         dev.hband = dev.bi + n;
-        dev.henv = dev.hband + (size_t)ni * 32;
+        dev.hpose = dev.hband + (size_t)ni * 32;
         dev.LB = d_LB.p; dev.Lband = d_Lband.p;
         return hipSuccess;
     }
@@ -63,16 +64,11 @@ struct LviSolveBuffers {
         const size_t n = (size_t)rs.n;
         int32_t* ints = reinterpret_cast<int32_t*>(h_blob.p);
         double* dbl = reinterpret_cast<double*>(h_blob.p + ints_bytes);
+        memcpy(ints, rs.first.data(), n * sizeof(int32_t));
         memcpy(dbl, bi, n * sizeof(double));
-        double* hband = dbl + n;
-        double* henv = hband + (size_t)rs.ni * 32;
-        rs.pack_envelope(Hi, ints, ints + n, henv);
-        for (int i = 0; i < rs.ni; ++i)   // the band rows at a fixed width for the kernel's ring loads
-            for (int t = 0; t < 32; ++t) {
-                const int c = i - 31 + t;
-                hband[(size_t)32 * i + t] = c >= ints[i] && c >= 0 ? henv[ints[n + i] + (c - ints[i])] : 0.0;
-            }
-        return ints_bytes + (n + (size_t)rs.ni * 32 + (size_t)ints[2 * n]) * sizeof(double);
+        std::vector<int32_t> span_first(std::max(rs.np, 1));  // (= first[ni + r]: already in the blob)
+        const size_t entries = rs.pack_for_device(Hi, span_first.data(), ints + n, ints + n + rs.np, dbl + n, dbl + n + (size_t)rs.ni * 32);
+        return ints_bytes + (n + (size_t)rs.ni * 32 + entries) * sizeof(double);
     }
 };
 struct BaWorkspace {

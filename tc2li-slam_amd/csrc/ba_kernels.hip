@@ -1752,7 +1752,7 @@ __device__ __forceinline__ void d_lvi_solve(const LviSolveDev& q_, const double*
     // (the record's pointers are device or pinned host addresses: global accesses, not flat ones -- a flat load counts on the LDS counter too, and
     // the loop's barriers wait for that counter)
     LviSolveDev q = q_;
-    q.first = global_ptr(q.first); q.rowoff = global_ptr(q.rowoff); q.henv = global_ptr(q.henv); q.bi = global_ptr(q.bi); q.LB = global_ptr(q.LB); q.Lband = global_ptr(q.Lband); q.hband = global_ptr(q.hband);
+    q.first = global_ptr(q.first); q.span_end = global_ptr(q.span_end); q.rowoff = global_ptr(q.rowoff); q.hpose = global_ptr(q.hpose); q.bi = global_ptr(q.bi); q.LB = global_ptr(q.LB); q.Lband = global_ptr(q.Lband); q.hband = global_ptr(q.hband);
     S = global_ptr(S); bs = global_ptr(bs); x_dev = global_ptr(x_dev); x_host = global_ptr(x_host); ok_host = global_ptr(ok_host);
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lj = lane & 15;
@@ -1794,7 +1794,7 @@ __device__ __forceinline__ void d_lvi_solve(const LviSolveDev& q_, const double*
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * my_ti[t] + kq + 4 * r, col = 16 * my_tj[t] + lj;
-            if (row < np && col <= row) acc[t][r] = S[(size_t)row * np + col] + q.henv[q.rowoff[ni + row] + (ni - first[ni + row]) + col];
+            if (row < np && col <= row) acc[t][r] = S[(size_t)row * np + col] + q.hpose[q.rowoff[row] + (q.span_end[row] - first[ni + row]) + col];
         }
     }
     for (int j = tid; j < n; j += T) z[j] = j < ni ? q.bi[np + j] : q.bi[j - ni] + bs[j - ni];
@@ -1802,8 +1802,8 @@ __device__ __forceinline__ void d_lvi_solve(const LviSolveDev& q_, const double*
     // The rings are fed from global memory: the entry of (pose row tid, column c) and of (band row c, column c - 31 + tid).  Four columns enter when a
     // panel's four leave; their entries are requested a whole step earlier and the loop's barriers wait for LDS only (lvi_lds_barrier), so neither
     // these loads nor the stores of L stand in a step's way.
-    const int my_f = tid < np ? first[ni + tid] : 0, my_off = tid < np ? q.rowoff[ni + tid] : 0;
-    auto fetch_pose = [&](int c) -> double { return tid < np && c < ni && c >= my_f ? q.henv[my_off + (c - my_f)] : 0.0; };
+    const int my_f = tid < np ? first[ni + tid] : 0, my_e = tid < np ? q.span_end[tid] : 0, my_off = tid < np ? q.rowoff[tid] : 0;
+    auto fetch_pose = [&](int c) -> double { return c >= my_f && c < my_e ? q.hpose[my_off + (c - my_f)] : 0.0; };
     auto fetch_band = [&](int c) -> double { return tid < 32 && c < ni ? q.hband[32 * c + tid] : 0.0; };   // (the host left the band rows 32 wide)
     auto put_column = [&](int c, double vp, double vb) {
         if (tid < np) Bring[33 * tid + (c & 31)] = vp;

@@ -42,24 +42,33 @@ struct ReducedSolver {
             first[ni + r] = f;
         }
     }
-    // For the solve on the device (k_lvi_solve*, ba_kernels.hip): the envelope and the inertial / LiDAR part inside it, row by row in the solver's
-    // order -- first_out [n], rowoff_out [n + 1], henv_out [envelope_entries()].  band(): the widest velocity / bias row (i - first[i]).
-    size_t envelope_entries() const { size_t e = 0; for (int i = 0; i < n; ++i) e += (size_t)(i - first[i] + 1); return e; }
+    // For the solve on the device (k_lvi_solve*, ba_kernels.hip): the inertial / LiDAR part of the matrix as the kernel reads it --
+    //   hband [ni][32]: the velocity / bias rows at a fixed width, entry (i, c) at 32 i + (c - (i - 31)), zero outside the envelope;
+    //   per pose row r: span_first / span_end [np] = the columns of its entries against the velocity / bias unknowns (what lies between the span's end
+    //   and the pose block is fill: zero in this part), rowoff [np + 1], and at hpose + rowoff[r] the span's entries followed by the row's r + 1
+    //   entries of the pose block.
+    // band(): the widest velocity / bias row (i - first[i]).  Returns the number of doubles written to hpose.
     int band() const { int b = 0; for (int i = 0; i < ni; ++i) b = std::max(b, i - first[i]); return b; }
-    void pack_envelope(const double* Hi, int32_t* first_out, int32_t* rowoff_out, double* henv_out) const {
+    size_t pack_for_device(const double* Hi, int32_t* span_first, int32_t* span_end, int32_t* rowoff, double* hband, double* hpose) const {
+        for (int i = 0; i < ni; ++i) {
+            const double* src = Hi + (size_t)(np + i) * n + np;
+            for (int t = 0; t < 32; ++t) {
+                const int c = i - 31 + t;
+                hband[(size_t)32 * i + t] = c >= first[i] && c >= 0 ? src[c] : 0.0;
+            }
+        }
         size_t at = 0;
-        for (int r = 0; r < ni; ++r) {
-            first_out[r] = first[r]; rowoff_out[r] = (int32_t)at;
-            const double* src = Hi + (size_t)(np + r) * n + np;
-            for (int c = first[r]; c <= r; ++c) henv_out[at++] = src[c];
-        }
         for (int r = 0; r < np; ++r) {
-            first_out[ni + r] = first[ni + r]; rowoff_out[ni + r] = (int32_t)at;
-            for (int c = first[ni + r]; c < ni; ++c) henv_out[at++] = Hi[(size_t)(np + c) * n + r];
+            const int f = first[ni + r];
+            int e = f;
+            for (int c = ni - 1; c >= f; --c) if (Hi[(size_t)(np + c) * n + r] != 0.0) { e = c + 1; break; }
+            span_first[r] = f; span_end[r] = e; rowoff[r] = (int32_t)at;
+            for (int c = f; c < e; ++c) hpose[at++] = Hi[(size_t)(np + c) * n + r];
             const double* hp = Hi + (size_t)r * n;
-            for (int c = 0; c <= r; ++c) henv_out[at++] = hp[c];
+            for (int c = 0; c <= r; ++c) hpose[at++] = hp[c];
         }
-        rowoff_out[n] = (int32_t)at;
+        rowoff[np] = (int32_t)at;
+        return at;
     }
     // Per trial: M = [S + Hi(poses) | Hi(poses, imu); . | Hi(imu) + lambda I] in the solver's order, factorised; false as ldlt_solve_small (a zero or
     // non-finite pivot).  S: [np][np] with the damping already on its diagonal (k_ba_schur_finish).
