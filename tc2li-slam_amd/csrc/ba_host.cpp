@@ -917,6 +917,14 @@ struct InertialTerm {
     const std::vector<int>* pose_var = nullptr;
     int np = 0, n = 0, n_imu = 0;
     std::vector<double> Hi, bi;
+    // The row segments of Hi a linearisation writes (the blocks of the inertial edges; the caller adds those of the LiDAR term): from the second
+    // linearisation on only they are cleared -- Hi is n x n (1.1 MB at 375 unknowns) and almost empty, and clearing it whole was half of what
+    // the inertial edges of a window cost the host.
+    std::vector<uint32_t> seg_at;
+    std::vector<uint8_t> seg_len;
+    bool segs_ready = false;
+    void note_segment(size_t at, int len) { if (!segs_ready) { seg_at.push_back((uint32_t)at); seg_len.push_back((uint8_t)len); } }
+    void note_block(int row0, int col0, int rows, int cols) { for (int r = 0; r < rows; ++r) note_segment((size_t)(row0 + r) * n + col0, cols); }
     double d_imu = 0;
     float dsqr_imu = 0;
 
@@ -945,6 +953,7 @@ struct InertialTerm {
         for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && imu_used[k]) imu_var[k] = n_imu++;
         n = np + 9 * n_imu;
         Hi.assign((size_t)n * n, 0.0); bi.assign(n, 0.0);
+        seg_at.clear(); seg_len.clear(); segs_ready = false;
     }
     // whether k_lvi_solve* takes this window's reduced system: velocity / bias unknowns present, the pose block and the rings fit a CU's LDS
     // (25 free keyframes: the reference's largest window), every inertial edge joins keyframes at most two places apart in the numbering
@@ -962,7 +971,11 @@ struct InertialTerm {
     double cost(const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
         const std::vector<int>& pv = *pose_var;
         double chi = 0;
-        if (linearize) { std::fill(Hi.begin(), Hi.end(), 0.0); std::fill(bi.begin(), bi.end(), 0.0); }
+        if (linearize) {
+            if (segs_ready) { for (size_t k = 0; k < seg_at.size(); ++k) std::fill_n(Hi.data() + seg_at[k], seg_len[k], 0.0); }
+            else std::fill(Hi.begin(), Hi.end(), 0.0);
+            std::fill(bi.begin(), bi.end(), 0.0);
+        }
         for (const InertialLinkHost& lk_ : L) {
             double er[9], J[9 * 24];
             lk_.evaluate(Pz[lk_.kf1], Sz[lk_.kf1], Pz[lk_.kf2], Sz[lk_.kf2], er, linearize ? J : nullptr);
@@ -994,6 +1007,7 @@ struct InertialTerm {
                     bi[off[a] + r] -= s;
                     for (int b2 = 0; b2 < 6; ++b2) {
                         if (off[b2] < 0) continue;
+                        note_segment((size_t)(off[a] + r) * n + off[b2], sz[b2]);
                         for (int c = 0; c < sz[b2]; ++c) {
                             double h = 0;
                             for (int k = 0; k < 9; ++k) h += J[24 * k + col[a] + r] * OJ[24 * k + col[b2] + c];
@@ -1007,6 +1021,8 @@ struct InertialTerm {
                 const double* Oe3 = which == 0 ? Og : Oa;
                 const int o1 = i1 >= 0 ? np + 9 * i1 + 3 + 3 * which : -1, o2 = i2 >= 0 ? np + 9 * i2 + 3 + 3 * which : -1;
                 for (int r = 0; r < 3; ++r) {
+                    if (o1 >= 0) { note_segment((size_t)(o1 + r) * n + o1, 3); if (o2 >= 0) note_segment((size_t)(o1 + r) * n + o2, 3); }
+                    if (o2 >= 0) { note_segment((size_t)(o2 + r) * n + o2, 3); if (o1 >= 0) note_segment((size_t)(o2 + r) * n + o1, 3); }
                     if (o1 >= 0) bi[o1 + r] += Oe3[r];
                     if (o2 >= 0) bi[o2 + r] -= Oe3[r];
                     for (int c = 0; c < 3; ++c) {
@@ -1017,6 +1033,7 @@ struct InertialTerm {
                 }
             }
         }
+        if (linearize) segs_ready = true;
         return chi;
     }
 };
@@ -1078,6 +1095,12 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
     const std::vector<int>& pose_var = vp.pose_var;
     const int n_free = vp.n_free, np = vp.np;
     inertial.number(fixed, has_imu, imu_used, n_kfs, pose_var, np);
+    if (lidar_window)   // the LiDAR term's blocks of the reduced system (BalmTerm::add_quadratic_form)
+        for (int i = 0; i < lidar_window->n_keyframes; ++i)
+            for (int j = 0; j < lidar_window->n_keyframes; ++j) {
+                const int vi = pose_var[lidar_window->pose_index[i]], vj = pose_var[lidar_window->pose_index[j]];
+                if (vi >= 0 && vj >= 0) inertial.note_block(6 * vi, 6 * vj, 6, 6);
+            }
     const std::vector<int>& imu_var = inertial.imu_var;
     const int n = inertial.n;
     // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
@@ -1128,7 +1151,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             lidar->finish_linearization();  // constructQuadraticForm uses the stored Jacobian / Hessian when the cost grew
             lidar->add_quadratic_form(pose_var.data(), n, Hi.data(), bi.data());
         }
-        solver.set_pattern(Hi.data(), n, np);
+        solver.set_pattern(Hi.data(), n, np, !dev_solve);
         if (dev_solve) {
             if (solver.band() > kLviBand) { set_error("tc2li_local_lvi_bundle_adjustment: inertial band wider than the device solve holds"); return TC2LI_ERR_INVALID; }
             const size_t bytes = ws.lvi.pack(solver, Hi.data(), bi.data());
@@ -1945,6 +1968,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         w.rc = w.vp.setup(*w.ws, nullptr, p.fixed, n_kfs, p.points3, p.n_points, p.edges, p.n_edges, cam, w.extra_used.data(), st);
         if (w.rc < 0) return;
         w.inertial.number(p.fixed, p.has_imu, w.imu_used, n_kfs, w.vp.pose_var, w.vp.np);
+        if (p.lidar)   // the LiDAR term's blocks of the reduced system (BalmTerm::add_quadratic_form)
+            for (int a = 0; a < p.lidar->n_keyframes; ++a)
+                for (int b = 0; b < p.lidar->n_keyframes; ++b) {
+                    const int vi = w.vp.pose_var[p.lidar->pose_index[a]], vj = w.vp.pose_var[p.lidar->pose_index[b]];
+                    if (vi >= 0 && vj >= 0) w.inertial.note_block(6 * vi, 6 * vj, 6, 6);
+                }
         BaWorkspace& ws = *w.ws;
         w.hp.resize(n_kfs); w.hp_trial.resize(n_kfs); w.sv.resize(n_kfs); w.sv_trial.resize(n_kfs);
         if (ws.d_iposes.ensure(n_kfs) != hipSuccess || ws.d_iposes_trial.ensure(n_kfs) != hipSuccess || ws.h_iposes.ensure(n_kfs) != hipSuccess ||
@@ -2151,7 +2180,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                 w.lidar->finish_linearization();
                 w.lidar->add_quadratic_form(w.vp.pose_var.data(), nn, w.inertial.Hi.data(), w.inertial.bi.data());
             }
-            w.solver.set_pattern(w.inertial.Hi.data(), nn, np);
+            w.solver.set_pattern(w.inertial.Hi.data(), nn, np, !w.dev_solve);
             if (w.dev_solve) {
                 if (w.solver.band() > kLviBand) w.rc = TC2LI_ERR_INVALID;  // (device_solve_ok bounds the band by the links: not reached)
                 else w.blob_bytes = w.ws->lvi.pack(w.solver, w.inertial.Hi.data(), w.inertial.bi.data());
