@@ -960,8 +960,8 @@ struct InertialTerm {
     // (band <= kLviBand).  The decision depends on the window alone: the same alone and in a batch.  TC2LI_LVI_DEVICE_SOLVE=0: the host's
     // envelope LDL^T (reduced_solve.hpp) for every window.
     bool device_solve_ok() const {
-        static const bool kEnabled = !(getenv("TC2LI_LVI_DEVICE_SOLVE") && atoi(getenv("TC2LI_LVI_DEVICE_SOLVE")) == 0);
-        if (!kEnabled || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows) return false;
+        const char* env = getenv("TC2LI_LVI_DEVICE_SOLVE");  // (read per call: the tests run both solvers in one process)
+        if ((env && atoi(env) == 0) || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows) return false;
         for (const InertialLinkHost& lk_ : L) {
             const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2];
             if (i1 >= 0 && i2 >= 0 && std::abs(i1 - i2) > 2) return false;

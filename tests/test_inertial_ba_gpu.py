@@ -188,3 +188,27 @@ def test_lviba_large_window_and_benched_cloud(pkg, oracle, synthetic, monkeypatc
             assert np.allclose(kf[k, 24:], want[0][k, 24:], rtol=RTOL, atol=1e-5)
         assert np.allclose(pts, want[1], rtol=RTOL, atol=1e-4)
         assert stats.final_chi2 < stats.initial_chi2
+
+
+@pytest.mark.gpu
+def test_reduced_system_on_the_device_and_on_the_host(pkg, oracle, synthetic, monkeypatch):
+    """The reduced system of an inertial window -- (6 + 9) unknowns per keyframe, Optimizer.cc:1635-1638 -- is solved by k_lvi_solve* on the device
+    (band of the velocity / bias unknowns eliminated four columns per step, pose block on the matrix unit) or, with TC2LI_LVI_DEVICE_SOLVE=0, by
+    the host's envelope LDL^T (reduced_solve.hpp): the same optimisation up to rounding, at both window sizes of LocalInertialBA, alone and in a
+    lock-step batch."""
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TC2LI_LVI_DEVICE_SOLVE", mode)
+        out = []
+        for seed, n_opt, n_pts, iters, lam in ((21, 25, 1200, 4, 1e-2), (22, 10, 700, 6, 1.0), (23, 3, 300, 5, 1.0)):
+            w = problem(pkg, oracle, synthetic, seed, n_opt=n_opt, n_points=n_pts)
+            kf, pts, chi2, dpos, stats = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"],
+                                                                                  pkg.pack_ba_edges(w["edges"]), w["link4"], w["pre"], w["cam"],
+                                                                                  iterations=iters, lambda_init=lam)
+            assert stats.final_chi2 < stats.initial_chi2
+            out.append((kf, pts, stats.iterations, stats.trials, stats.final_chi2))
+        results[mode] = out
+    for (kf1, pts1, it1, tr1, c1), (kf0, pts0, it0, tr0, c0) in zip(results["1"], results["0"]):
+        assert (it1, tr1) == (it0, tr0)
+        assert abs(c1 - c0) <= 1e-9 * abs(c0)
+        assert np.allclose(kf1, kf0, rtol=1e-9, atol=1e-10) and np.allclose(pts1, pts0, rtol=1e-9, atol=1e-9)
