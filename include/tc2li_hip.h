@@ -695,8 +695,10 @@ int tc2li_rccl_allreduce(void* comm, double* device_buf, size_t count, int op, v
  * VertexAccBias per keyframe and marginalised points; edges EdgeMono / EdgeStereo (Huber), EdgeInertial (+ Huber
  * sqrt(16.92) where `robust`), EdgeGyroRW, EdgeAccRW (SF/include/G2oTypes.h, SF/src/G2oTypes.cc).  The host shim gathers
  * the temporal window, the fixed keyframes and the points exactly as :1520-1640 does and passes them flattened, keyframes in
- * vertex-id order.  Projection edges run on the GPU, the few inertial edges on the host (row c6), the reduced system
- * (6 + 9 unknowns per optimisable keyframe) is solved on the host like g2o's LinearSolverEigen.
+ * vertex-id order.  Projection edges run on the GPU, the few inertial edges on the host (row c6); the reduced system
+ * (6 + 9 unknowns per optimisable keyframe; g2o's sparse LinearSolverEigen, :1635-1638) is solved on the GPU inside the envelope of
+ * the velocity / bias band (windows of at most 25 optimisable keyframes whose inertial edges join keyframes at most two places apart
+ * in the numbering; other windows, and every window with TC2LI_LVI_DEVICE_SOLVE=0, on the host by the same elimination).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct tc2li_inertial_keyframe {  /* ImuCamPose(KeyFrame*) + velocity + biases, widened from the map's floats */
     double Rcw[9], tcw[3];                /* GetRotation(), GetTranslation() */
@@ -739,8 +741,9 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const 
 /* Many independent LocalLVIBA windows (the local-mapping threads of many sequences in the camera-LiDAR-inertial configuration): every
  * problem is what one tc2li_local_lvi_bundle_adjustment call takes (same IMU calibration and camera for all).  With max_concurrency > 1
  * the windows advance through the Levenberg-Marquardt phases in lock step like tc2li_local_bundle_adjustment_batch's -- one launch per
- * kernel and one synchronisation per phase for all windows, the inertial edges and the dense reduced systems on host threads between
- * the phases -- and every window's result is the one of the one-window call.  results[i] = iterations of window i or its error code;
+ * kernel and one synchronisation per phase for all windows (Schur product, solve of the reduced system and trial estimate are one
+ * queue with one synchronisation per Levenberg trial), the inertial edges on host threads between the phases -- and every window's
+ * result is the one of the one-window call.  results[i] = iterations of window i or its error code;
  * returns the number of windows that succeeded. */
 typedef struct tc2li_lvi_problem {
     tc2li_inertial_keyframe* keyframes; const uint8_t* fixed; const uint8_t* has_imu;
