@@ -212,3 +212,35 @@ def test_reduced_system_on_the_device_and_on_the_host(pkg, oracle, synthetic, mo
         assert (it1, tr1) == (it0, tr0)
         assert abs(c1 - c0) <= 1e-9 * abs(c0)
         assert np.allclose(kf1, kf0, rtol=1e-9, atol=1e-10) and np.allclose(pts1, pts0, rtol=1e-9, atol=1e-9)
+
+
+def test_a_window_the_device_solve_does_not_take(pkg, oracle, synthetic):
+    """k_lvi_solve* eliminates the velocity / bias unknowns as a band: a window with an inertial edge between keyframes more than two places apart
+    (here keyframes 1 and 6; nothing the reference's temporal window produces) is solved by the host's envelope LDL^T by itself, and a batch that
+    holds such a window beside ordinary ones hands every window to the one-window path: each result is the one-window call's, bit for bit."""
+    w = problem(pkg, oracle, synthetic, 31, n_opt=6, n_points=400)
+    link4 = np.vstack([w["link4"], [1.0, 6.0, 0.0, 1.0]])
+    pre = list(w["pre"]) + [w["pre"][2]]
+    pre298 = np.vstack([w["pre298"], w["pre298"][2:3]])
+    want = oracle.local_inertial_ba(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], w["edges"], link4, pre298, w["cam"], iterations=6, lambda_init=1.0)
+    edges = pkg.pack_ba_edges(w["edges"])
+    kf, pts, chi2, dpos, stats = pkg.capi.local_inertial_bundle_adjustment(w["kf33"], w["fixed"], w["has_imu"], w["calib24"], w["points"], edges, link4, pre, w["cam"],
+                                                                          iterations=6, lambda_init=1.0)
+    assert stats.iterations == want[4] and stats.trials == int(want[5]["trials"].sum())
+    assert abs(stats.final_chi2 - want[6][1]) <= 1e-5 * want[6][1]
+    for k in range(len(kf)):
+        assert rel(kf[k, :24], want[0][k, :24]) < RTOL
+        assert np.allclose(kf[k, 24:], want[0][k, 24:], rtol=RTOL, atol=1e-5)
+    w2 = problem(pkg, oracle, synthetic, 32, n_opt=5, n_points=300)
+    batch = pkg.capi.LviBatch([dict(kf33=w2["kf33"], fixed=w2["fixed"], has_imu=w2["has_imu"], points=w2["points"], edges=pkg.pack_ba_edges(w2["edges"]), link4=w2["link4"],
+                                    pre=w2["pre"], iterations=6),
+                               dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=edges, link4=link4, pre=pre, iterations=6)],
+                              w["calib24"], w["cam"])
+    assert batch.run(max_concurrency=8) == 2
+    bkf, bpts, bchi2, bdpos, bst, _ = batch.result(1)
+    assert bst.iterations == stats.iterations and bst.trials == stats.trials and bst.final_chi2 == stats.final_chi2
+    assert np.array_equal(bkf, kf) and np.array_equal(bpts, pts)
+    kf2, pts2, _, _, st2 = pkg.capi.local_inertial_bundle_adjustment(w2["kf33"], w2["fixed"], w2["has_imu"], w2["calib24"], w2["points"], pkg.pack_ba_edges(w2["edges"]),
+                                                                    w2["link4"], w2["pre"], w2["cam"], iterations=6, lambda_init=1.0)
+    bkf2, bpts2, _, _, bst2, _ = batch.result(0)
+    assert bst2.trials == st2.trials and np.array_equal(bkf2, kf2) and np.array_equal(bpts2, pts2)
