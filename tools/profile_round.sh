@@ -25,6 +25,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-
 # HBM counters of the inertial loop (configs[3]): inertial_config.roofline.traffic
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_fetch_i.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_write_i.log 2>&1
+# kernel trace + stats of the inertial loop (configs[3] with the bLarge LocalLVIBA windows: k_lvi_solve_b, k_ba_schur_full_b, the time sort ...)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_i -o bench -- python3 $ARGS --no-extra-lines --inertial-loop > $OUT/bench_trace_i.log 2>&1
 # instruction mix and LDS behaviour of every kernel (the bound of k_fast_cells is stated from these): own passes, SQ counters only
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_insts -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_insts.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_lds.log 2>&1
@@ -34,4 +36,4 @@ python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds $OUT/pmc_fetch_i $OUT/pmc_write_i
+rm -rf $OUT/trace $OUT/trace_i $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds $OUT/pmc_fetch_i $OUT/pmc_write_i

@@ -13,6 +13,9 @@ os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], "profiles/%s_bench_kernel_stats.csv" % tag)
+stats_i = glob.glob(os.path.join(out, "trace_i", "**", "*kernel_stats.csv"), recursive=True)
+if stats_i:
+    shutil.copy(stats_i[0], "profiles/%s_inertial_kernel_stats.csv" % tag)
 line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")]
 if line:
     open("profiles/%s_bench_line_under_rocprof.json" % tag, "w").write(line[-1])
