@@ -192,6 +192,7 @@ void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExt
 void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 // x = (S + Hl)^-1 (b_s + bl) per window by dense LDL^T, one workgroup per window (windows of at most 21 free keyframes)
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
+bool lvi_device_solve_available();  // the kernels below get the LDS of their largest window on this device
 // the reduced systems of inertial windows (slot.lvi.n > 0) on the device; max_np / max_ni over the windows of the launch
 void lvi_batch_launch_solve(const BaPhase& ph, int n_active, int max_np, int max_ni, hipStream_t st);
 // one window: S / bs as k_ba_schur_finish left them in device memory, x (n unknowns, the caller's numbering) to x_dev and x_host, ok_host[0] = the pivots were usable

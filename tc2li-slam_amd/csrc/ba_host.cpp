@@ -961,7 +961,7 @@ struct InertialTerm {
     // envelope LDL^T (reduced_solve.hpp) for every window.
     bool device_solve_ok() const {
         const char* env = getenv("TC2LI_LVI_DEVICE_SOLVE");  // (read per call: the tests run both solvers in one process)
-        if ((env && atoi(env) == 0) || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows) return false;
+        if ((env && atoi(env) == 0) || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows || !lvi_device_solve_available()) return false;
         for (const InertialLinkHost& lk_ : L) {
             const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2];
             if (i1 >= 0 && i2 >= 0 && std::abs(i1 - i2) > 2) return false;

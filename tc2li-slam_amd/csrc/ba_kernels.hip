@@ -2288,15 +2288,20 @@ void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent&
     (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 132 * 1024);
     TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
 }
+// whether the two kernels get the LDS of their largest window (25 free keyframes: 160 KB, all a CU has); asked once, before a window is promised
+// to them -- a refusal leaves every window to the host's solver instead of surfacing as a launch error later
+bool lvi_device_solve_available() {
+    static const bool ok = ensure_dynamic_lds((const void*)k_lvi_solve_b, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6))) &&
+                           ensure_dynamic_lds((const void*)k_lvi_solve, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6)));
+    return ok;
+}
 void lvi_batch_launch_solve(const BaPhase& ph, int n_active, int max_np, int max_ni, hipStream_t st) {
     if (!n_active || max_ni <= 0) return;
     const size_t lds = lvi_solve_lds_bytes(max_np, max_ni);
-    (void)ensure_dynamic_lds((const void*)k_lvi_solve_b, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6)));
     TC2LI_LAUNCH(k_lvi_solve_b, dim3(n_active), dim3(kLviThreads), lds, st, ph);
 }
 void lvi_launch_solve(const LviSolveDev& q, const double* S, const double* bs, double lambda, double* x_dev, double* x_host, int32_t* ok_host, hipStream_t st) {
     if (q.n <= 0) return;
-    (void)ensure_dynamic_lds((const void*)k_lvi_solve, (int)lvi_solve_lds_bytes(kLviMaxPoseRows, 9 * (kLviMaxPoseRows / 6)));
     const LviSolveArgs a{q, S, bs, lambda, x_dev, x_host, ok_host};
     TC2LI_LAUNCH(k_lvi_solve, dim3(1), dim3(kLviThreads), lvi_solve_lds_bytes(q.np, q.ni), st, a);
 }
