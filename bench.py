@@ -557,7 +557,7 @@ class Loop:
             m.Build(wl.maps[t])
             self.maps.append(m)
         self.map_points0 = int(np.mean([m.size() for m in self.maps]))
-        self.boxes = [pkg.capi.LocalMapBox() for _ in range(F)]
+        self.boxes = (pkg.capi.LocalMapBox * F)()   # one local-map cube per sequence (lasermap_fov_segment's state), contiguous for the batched call
         self.scan_ids = np.arange(F, dtype=np.int32)
         # tracking inputs
         self.last_frames = pkg.capi.pack_last_frames([wl.last[t] for t in tile])
@@ -659,15 +659,19 @@ class Loop:
         self.tlm_out = self.tlm_outs[k]
         self.track_ms[2] = 1e3 * (time.perf_counter() - t0)
 
+    def fov_positions(self):
+        """the LiDAR positions lasermap_fov_segment looks at, [F, 3]"""
+        return np.ascontiguousarray(self.states[:, 9:12])
+
     def lidar_step(self, raw=None):
         pkg, F = self.pkg, self.F
         raw = self.dev_raw if raw is None else raw
         # lasermap_fov_segment (host logic) + the box deletions it asks for, per sequence
-        todo_maps, todo_boxes = [], []
-        for s in range(F):
-            boxes = pkg.capi.lidar_fov_segment(self.boxes[s], self.states[s][9:12], cube_len=1000.0, det_range=100.0)
-            if len(boxes):
-                todo_maps.append(self.maps[s]); todo_boxes.append(boxes)
+        # (one call for all sequences: 512 calls through ctypes were 2.5 ms of interpreter time per step on the stage thread, more under the
+        # other stage threads' contention for the interpreter lock)
+        boxes_all, n_boxes = pkg.capi.lidar_fov_segment_batch(self.boxes, self.fov_positions(), cube_len=1000.0, det_range=100.0)
+        todo = np.nonzero(n_boxes)[0]
+        todo_maps, todo_boxes = [self.maps[s] for s in todo], [boxes_all[s, :n_boxes[s]].copy() for s in todo]
         if todo_maps:
             pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
         self.lidar_counts = self.lidar.frontend_batch(raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
@@ -951,11 +955,11 @@ class InertialLoop(Loop):
 
     def lidar_step(self, handle=None):
         pkg, F = self.pkg, self.F
-        todo_maps, todo_boxes = [], []
-        for s in range(F):
-            boxes = pkg.capi.lidar_fov_segment(self.boxes[s], self.states[s][9:12], cube_len=1000.0, det_range=100.0)
-            if len(boxes):
-                todo_maps.append(self.maps[s]); todo_boxes.append(boxes)
+        # (one call for all sequences: 512 calls through ctypes were 2.5 ms of interpreter time per step on the stage thread, more under the
+        # other stage threads' contention for the interpreter lock)
+        boxes_all, n_boxes = pkg.capi.lidar_fov_segment_batch(self.boxes, self.fov_positions(), cube_len=1000.0, det_range=100.0)
+        todo = np.nonzero(n_boxes)[0]
+        todo_maps, todo_boxes = [self.maps[s] for s in todo], [boxes_all[s, :n_boxes[s]].copy() for s in todo]
         if todo_maps:
             pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
         fe = self.lidar if handle is None else self.lidar_handles[handle]

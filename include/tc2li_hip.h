@@ -293,6 +293,10 @@ int tc2li_lidar_map_download(const tc2li_lidar_map* map, tc2li_point* out, int c
  * the number of boxes (<= 3, written to boxes6) whose points must be deleted. */
 typedef struct tc2li_local_map_box { float vertex_min[3], vertex_max[3]; int32_t initialized; } tc2li_local_map_box;
 int tc2li_lidar_fov_segment(tc2li_local_map_box* local_map, const double pos_lid[3], double cube_len, double det_range, float boxes6[18]);
+/* The same for n sensors in one call (the per-sequence calls of a batch driver): local_maps [n], pos_lid3 [n][3]; boxes6 [n][18] and n_boxes [n]
+ * receive every sequence's boxes and their number; returns the total. */
+int tc2li_lidar_fov_segment_batch(tc2li_local_map_box* local_maps, const double* pos_lid3, int n, double cube_len, double det_range, float* boxes6,
+                                  int32_t* n_boxes);
 
 /* ---- camera-LiDAR-inertial branch: motion compensation of the scan (ImuProcess::UndistortPcl,
  * SF/include/lidar_front_end/IMU_Processing.cpp:160-277) ---- */

@@ -125,6 +125,7 @@ def lib():
     L.tc2li_lidar_map_delete_boxes_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tc2li_lidar_map_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.tc2li_lidar_fov_segment.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+    L.tc2li_lidar_fov_segment_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.tc2li_local_inertial_bundle_adjustment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double] + [C.c_void_p] * 5
     L.tc2li_host_lidar_planes.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -559,6 +560,17 @@ def lidar_fov_segment(local_map, pos_lid, cube_len=200.0, det_range=100.0):
     boxes = np.zeros((3, 6), np.float32)
     k = _check(lib().tc2li_lidar_fov_segment(C.addressof(local_map), pos.ctypes.data, cube_len, det_range, boxes.ctypes.data))
     return boxes[:k].copy()
+
+
+def lidar_fov_segment_batch(local_maps, pos_lid3, cube_len=200.0, det_range=100.0):
+    """``lasermap_fov_segment`` for n sensors in one call: ``local_maps`` a ctypes array ``(LocalMapBox * n)()``, ``pos_lid3`` [n, 3]
+    -> (boxes [n, 3, 6] float32, counts [n] int32)."""
+    n = len(local_maps)
+    pos = np.ascontiguousarray(pos_lid3, np.float64).reshape(n, 3)
+    boxes = np.zeros((n, 3, 6), np.float32)
+    counts = np.zeros(n, np.int32)
+    _check(lib().tc2li_lidar_fov_segment_batch(C.addressof(local_maps), pos.ctypes.data, n, cube_len, det_range, boxes.ctypes.data, counts.ctypes.data))
+    return boxes, counts
 
 
 class LidarFrontEnd:
@@ -1184,8 +1196,8 @@ class PoseInertialBatch:
         """Resets every frame to its initial state and optimises all of them -> results [n] (initial correspondences - bad)."""
         frame_off, stride = PoseInertialProblem.frame.offset, C.sizeof(PoseInertialProblem)
         base = C.addressof(self.arr)
-        for f in range(self.n):
-            C.memmove(base + f * stride + frame_off, self.init33[f].ctypes.data, 66 * 8)  # frame | other are adjacent
+        # frame | other are adjacent: every record's 66 doubles in one strided assignment (a loop of memmoves was interpreter time on the stage thread)
+        np.frombuffer(self.arr, np.uint8).reshape(self.n, stride)[:, frame_off:frame_off + 66 * 8] = np.ascontiguousarray(self.init33).view(np.uint8).reshape(self.n, 66 * 8)
         f_ = lib().tc2li_pose_inertial_optimization_batch
         f_.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _check(f_(base, self.n, self.calib24.ctypes.data, self.cam5.ctypes.data, self.results.ctypes.data, C.c_void_p(stream)))
@@ -1230,11 +1242,10 @@ class LidarInertialBatch:
 
     def run(self, dev_raw_ptr, stream=0, fe=None):
         """dev_raw_ptr None: the scans ``prepare`` left in the handle."""
-        base = C.addressof(self.scans)
         self.P[...] = self.P0
-        for s in range(self.S):
-            C.memmove(base + s * self.stride + self.state_off, self.st0[s].ctypes.data, 36 * 8)
-            C.memmove(base + s * self.stride + self.last_off, self.zero6.ctypes.data, 48)
+        raw = np.frombuffer(self.scans, np.uint8).reshape(self.S, self.stride)   # the records' bytes: states and last accelerations in two strided assignments
+        raw[:, self.state_off:self.state_off + 36 * 8] = self.st0.view(np.uint8).reshape(self.S, 36 * 8)
+        raw[:, self.last_off:self.last_off + 48] = 0
         f = lib().tc2li_lidar_inertial_frontend_batch
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -1243,11 +1254,8 @@ class LidarInertialBatch:
                         self.cov.ctypes.data, R, max_iter, self.lim.ctypes.data, ext, C.c_void_p(stream)))
 
     def states36(self):
-        out = np.zeros((self.S, 36))
-        base = C.addressof(self.scans)
-        for s in range(self.S):
-            C.memmove(out[s].ctypes.data, base + s * self.stride + self.state_off, 36 * 8)
-        return out
+        raw = np.frombuffer(self.scans, np.uint8).reshape(self.S, self.stride)
+        return np.ascontiguousarray(raw[:, self.state_off:self.state_off + 36 * 8]).view(np.float64).reshape(self.S, 36)
 
     def stats(self):
         return [(sc.stats.calls, sc.stats.searches, sc.stats.effct_feat_num, sc.n_preprocessed, sc.n_downsampled) for sc in self.scans]

@@ -1600,6 +1600,20 @@ int tc2li_lidar_fov_segment(tc2li_local_map_box* lm, const double pos_lid[3], do
     return nb;
 }
 
+// the same for the sensors of n sequences in one call (a batch driver: one lasermap_fov_segment per sequence and scan)
+int tc2li_lidar_fov_segment_batch(tc2li_local_map_box* local_maps, const double* pos_lid3, int n, double cube_len, double det_range, float* boxes6,
+                                  int32_t* n_boxes) {
+    if (n < 0 || (n > 0 && (!local_maps || !pos_lid3 || !boxes6 || !n_boxes))) { set_error("tc2li_lidar_fov_segment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int k = tc2li_lidar_fov_segment(local_maps + i, pos_lid3 + 3 * (size_t)i, cube_len, det_range, boxes6 + 18 * (size_t)i);
+        if (k < 0) return k;
+        n_boxes[i] = k;
+        total += k;
+    }
+    return total;
+}
+
 int tc2li_lidar_feature_extraction(tc2li_lidar* L, tc2li_lidar_map* map, const tc2li_point* feats_down_body, int n,
                                    const tc2li_lidar_state* state, tc2li_point* feats_down_world, uint8_t* point_selected,
                                    tc2li_point* normvec, tc2li_point* nearest_points, float* nearest_sqdist, int32_t* n_nearest,

@@ -18,6 +18,28 @@ def test_fov_segment_matches_the_oracle(pkg, oracle):
     assert moved >= 3  # the cube was shifted several times along the way
 
 
+def test_fov_segment_batch_equals_the_per_sequence_calls(pkg, oracle):
+    """tc2li_lidar_fov_segment_batch: the cubes of n sequences in one call -- every sequence's boxes and cube are those of its own
+    tc2li_lidar_fov_segment calls (and so the oracle's)."""
+    F = 17
+    rng = np.random.default_rng(3)
+    cubes = (pkg.capi.LocalMapBox * F)()
+    singles = [pkg.capi.LocalMapBox() for _ in range(F)]
+    pos = np.zeros((F, 3))
+    total = 0
+    for _ in range(60):
+        pos = pos + rng.normal([6.0, 1.0, 0.0], [3.0, 3.0, 0.3], (F, 3))
+        boxes, counts = pkg.capi.lidar_fov_segment_batch(cubes, pos, cube_len=200.0, det_range=100.0 / 3)
+        for s in range(F):
+            want = pkg.capi.lidar_fov_segment(singles[s], pos[s], cube_len=200.0, det_range=100.0 / 3)
+            assert counts[s] == len(want) and np.array_equal(boxes[s, :counts[s]], want)
+            assert np.array_equal(np.array(cubes[s].vertex_min), np.array(singles[s].vertex_min))
+            assert np.array_equal(np.array(cubes[s].vertex_max), np.array(singles[s].vertex_max))
+        total += int(counts.sum())
+    assert total >= F  # every cube was shifted along the way
+    assert pkg.capi.lidar_fov_segment_batch((pkg.capi.LocalMapBox * 0)(), np.zeros((0, 3)))[1].shape == (0,)
+
+
 def test_imu_forward_propagation_matches_the_oracle(pkg, oracle):
     from scipy.spatial.transform import Rotation
     rng = np.random.default_rng(1)
