@@ -1658,6 +1658,16 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (first_pass) balm_batch_launch_residual(ph, cnt, false, st);
             balm_batch_launch_hessian(ph, cnt, X, st);
         });
+        // Round 5: the first trial's Schur product does not wait for the host -- its operands are the linearisation's, its damping the window's
+        // current lambda (known unless this is the first iteration of a window whose lambda comes from computeLambdaInit) -- so it is queued
+        // behind the linearisation and the phase's one synchronisation covers both: a host round trip fewer per iteration, and the host's part
+        // of the linearisation (the LiDAR term's change of variables) runs beside the product.  TC2LI_BA_PRE_SCHUR=0: queued after the host's part.
+        static const bool kPreSchur = !(getenv("TC2LI_BA_PRE_SCHUR") && atoi(getenv("TC2LI_BA_PRE_SCHUR")) == 0);
+        bool pre_schur = kPreSchur && !dev_solve && !any_maxdiag;
+        if (pre_schur) {
+            for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
+            pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
+        }
         tm[6] += now() - t0;  // of the phase: the time to queue it
         sync();
         if (failed) break;
@@ -1738,9 +1748,12 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                 }
                 tm[4] += now() - t0; t0 = now();
             } else {
-            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-            sync();
-            if (failed) break;
+            if (pre_schur) pre_schur = false;  // (the product of this trial came with the linearisation)
+            else {
+                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
+                sync();
+                if (failed) break;
+            }
             tm[3] += now() - t0; t0 = now();
             phase_for((int)trial.size(), [&](int k) {
                 LockstepWindow& w = W[trial[k]];
@@ -2163,6 +2176,14 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             balm_batch_launch_residual(ph, cnt, false, st);
             balm_batch_launch_hessian(ph, cnt, X, st);
         });
+        // (the first trial's Schur product behind the linearisation, as in ba_batch_lockstep: the host's inertial edges, the LiDAR term's change of
+        // variables and the upload of the reduced system's inertial part run beside it)
+        static const bool kPreSchur = !(getenv("TC2LI_BA_PRE_SCHUR") && atoi(getenv("TC2LI_BA_PRE_SCHUR")) == 0);
+        bool pre_schur = kPreSchur && !any_maxdiag;
+        if (pre_schur) {
+            for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
+            pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
+        }
         pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
         lap(8);
         sync();
@@ -2223,8 +2244,10 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             // the sums at the one synchronisation
             std::vector<int> trial_lidar;
             for (int i : trial) if (W[i].lidar) trial_lidar.push_back(i);
+            const bool have_schur = pre_schur;  // (this trial's product came with the linearisation)
+            pre_schur = false;
             pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, X, st);
+                if (!have_schur) ba_batch_launch_schur(ph, cnt, X, st);
                 lvi_batch_launch_solve(ph, cnt, max_lvi_np, max_lvi_ni, st);
                 ba_batch_launch_trial(ph, cnt, X, st);
             });
@@ -2261,9 +2284,12 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             trial = lm_decisions(trial);
         }
         while (!trial.empty() && !failed && !dev_solve) {
-            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-            sync();
-            if (failed) break;
+            if (pre_schur) pre_schur = false;  // (this trial's product came with the linearisation)
+            else {
+                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
+                sync();
+                if (failed) break;
+            }
             lap(3);
             pool.parallel_for((int)trial.size(), [&](int k) {
                 LviWindow& w = W[trial[k]];
