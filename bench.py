@@ -875,10 +875,10 @@ class Loop:
 # compensation + iterated ESKF in the LiDAR thread, LocalLVIBA in local mapping
 # ---------------------------------------------------------------------------------------------------------------------------------
 class InertialLoop(Loop):
-    """F sequences of the inertial configuration (BASELINE configs[3]) on the stage threads of Loop.  Camera / tracking thread: the batched calls of
-    the main loop, then IMU pre-integration between the frames (tc2li_imu_preintegrate_frames, host) and PoseInertialOptimizationLastFrame for
-    all frames (tc2li_pose_inertial_optimization_batch) -- TrackLocalMap's visual PoseOptimization runs as well, extra work inside the timed
-    region.  LiDAR thread: lasermap_fov_segment + box deletions, then LidarInertialProcess for all scans in one call
+    """F sequences of the inertial configuration (BASELINE configs[3]) on the stage threads of Loop.  Camera / tracking thread: ORB extraction and stereo
+    matching as in the main loop; with the IMU initialised TrackWithMotionModel is the IMU prediction alone and TrackLocalMap is SearchLocalPoints
+    (tc2li_search_local_points_batch), the IMU pre-integration between the frames (tc2li_imu_preintegrate_frames, host) and
+    PoseInertialOptimizationLastFrame for all frames (tc2li_pose_inertial_optimization_batch) -- Tracking.cc:2746-2752, 2857-2878.  LiDAR thread: lasermap_fov_segment + box deletions, then LidarInertialProcess for all scans in one call
     (tc2li_lidar_inertial_frontend_batch: preprocess, forward propagation, UndistortPcl with its time sort, voxel filter, iterated ESKF in lock
     step) and map_incremental for all maps.  Local mapping: F / kf_interval LocalLVIBA windows per step in lock step
     (tc2li_local_lvi_bundle_adjustment_batch: 10 optimisable keyframes + the fixed one, LiDAR edge over 6 keyframes x 2400 points)."""
@@ -940,11 +940,29 @@ class InertialLoop(Loop):
                                                     iterations=self.lvi_iterations, lambda_init=self.lvi_lambda) for w in wins],
                                               self.uniq_lvi[0]["calib24"], self.uniq_lvi[0]["cam"])
         self.ba_batch2 = None
+        self.slp_outs = [None, None, None]
+
+    # The camera path with the IMU initialised (the steady state of configs[3]): TrackWithMotionModel is PredictStateIMU() and nothing else
+    # (Tracking.cc:2746-2752: no search against the last frame, no PoseOptimization), and TrackLocalMap optimises with
+    # PoseInertialOptimizationLastFrame / LastKeyFrame INSTEAD of PoseOptimization (Tracking.cc:2857-2878).  Rounds 3-4 and the first part of
+    # round 5 ran the main loop's TrackWithMotionModel and TrackLocalMap (both with their visual PoseOptimization) and the pose-inertial
+    # optimisation on top: more than the reference does per frame.
+    def track(self, k, stream):
+        """Stereo matching of feature buffer k; the motion-model step is the IMU prediction (host, from the pre-integration since the last frame)."""
+        wl, pkg, F = self.wl, self.pkg, self.F
+        t0 = time.perf_counter()
+        self.st_outs[k] = pkg.stereo_match_batch(self.exts[k], F, float(wl.bf), float(wl.b), stream=stream, out=self.st_outs[k])
+        self.track_ms[0], self.track_ms[1] = 1e3 * (time.perf_counter() - t0), 0.0
 
     def track_local(self, k, stream):
-        super().track_local(k, stream)
+        """TrackLocalMap: SearchLocalPoints from the predicted pose, IMU pre-integration between the frames, PoseInertialOptimizationLastFrame."""
+        wl, pkg, F = self.wl, self.pkg, self.F
+        t0 = time.perf_counter()
+        self.slp_outs[k] = pkg.capi.search_local_points_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.pose_pred, self.held, self.held_Xw,
+                                                              self.local_pts, self.local_off, wl.cam5, th=1.0, stream=stream, out=self.slp_outs[k])
         self.pi.preintegrate()
         self.pi.run(stream)
+        self.track_ms[2] = 1e3 * (time.perf_counter() - t0)
 
     def lidar_prepare(self, handle):
         """Preprocess::process + the order of UndistortPcl's time sort of the next step's scans, into front-end handle `handle` (0 / 1)."""
@@ -1208,7 +1226,8 @@ def mfma_line(pkg, synthetic, peaks, n_windows=96, repeats=3):
 
 def cpu_baseline_inertial(wl, il, args, n_seq_gpu):
     """configs[3] on the CPU oracle with the reference's threads: per frame the tracking thread (left / right ORB on two threads, stereo matching,
-    TrackWithMotionModel, TrackLocalMap, IMU pre-integration, PoseInertialOptimizationLastFrame) beside the LiDAR thread (preprocess, forward
+    the IMU prediction in place of TrackWithMotionModel, SearchLocalPoints, IMU pre-integration, PoseInertialOptimizationLastFrame -- the camera path with
+    the IMU initialised, Tracking.cc:2746-2752, 2857-2878) beside the LiDAR thread (preprocess, forward
     propagation, UndistortPcl, voxel filter, iterated ESKF against the sequence's ikd-Tree, Add_Points), LocalLVIBA of every kf_interval-th
     frame on a local-mapping thread."""
     from oracle import pyoracle
@@ -1247,7 +1266,7 @@ def cpu_baseline_inertial(wl, il, args, n_seq_gpu):
         lid = pool.submit(lidar_thread, seq, t)
         held, held_Xw, pts = wl.local[t]
         seq["cam"].frame(wl.images[t, 0], wl.images[t, 1], float(wl.bf), float(wl.b), no_scan, wl.states[t], wl.pose_pred, lasts[t], wl.cam5, 7.0,
-                         held, held_Xw, pts, th_local=1.0)
+                         held, held_Xw, pts, th_local=1.0, imu_mode=True)
         q = il.uniq_pi[t]
         pre298 = pyoracle.pack_preintegrated(pyoracle.imu_preintegrate(q["samples"], q["t1"], q["t2"], q["bias6"], *noise)[1], q["bias6"])
         pyoracle.pose_inertial(q["cur33"], q["other33"], True, q["prior246"], q["calib24"], pre298, pre298, q["Xw"], q["edges"], q["close"], q["cam"])
@@ -1750,8 +1769,9 @@ def main(argv=None):
             cpu_i = cpu_baseline_inertial(wl, il, args, F)
         inertial = {"value": round(F * n_i / dti, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dti / n_i, 3), "sequences": F, "steps": n_i,
                     "lviba_windows_per_step": round(ba_windows_i / n_i, 2), "stage_thread_ms_per_step_concurrent": thread_ms_i,
-                    "workload": "configs[3], camera-LiDAR-inertial, %d batched sequences, one frame of every sequence per step: the camera stages of the main "
-                                "loop + IMU pre-integration + PoseInertialOptimizationLastFrame (batched); LidarInertialProcess for all scans in one call "
+                    "workload": "configs[3], camera-LiDAR-inertial, %d batched sequences, one frame of every sequence per step: ORB + stereo matching, "
+                                "the IMU prediction in place of TrackWithMotionModel, SearchLocalPoints + IMU pre-integration + PoseInertialOptimizationLastFrame (batched; the "
+                                "camera path with the IMU initialised, Tracking.cc:2746, 2857); LidarInertialProcess for all scans in one call "
                                 "(preprocess, forward propagation on the host, UndistortPcl with its time sort on the device, voxel filter, iterated ESKF "
                                 "in lock step, max 3 iterations) + map_incremental; LocalLVIBA in lock step (%s, LiDAR edge over "
                                 "6 keyframes x 2400 points) every %d-th frame" % (F, "bLarge as LocalMapping.cc:156 decides at > 100 tracked inliers: 25 + 1 keyframes, "
@@ -1828,9 +1848,10 @@ def main(argv=None):
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": host_budget,
                 "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),
-                "motion_model_matches/inliers_per_frame": [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
-                "local_map_points/matches/inliers_per_frame": [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1),
-                                                               round(float(np.mean(tlm_out[4])), 1)],
+                # (the inertial loop's camera path: the IMU prediction in place of TrackWithMotionModel, SearchLocalPoints in place of TrackLocalMap's visual half)
+                "motion_model_matches/inliers_per_frame": None if trk_out is None else [round(float(np.mean(trk_out[2])), 1), round(float(np.mean(trk_out[3])), 1)],
+                "local_map_points/matches/inliers_per_frame": [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(loop.slp_outs[0][1])), 1), None]
+                if tlm_out is None else [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1), round(float(np.mean(tlm_out[4])), 1)],
                 "scan_points_raw/preprocessed/downsampled/selected": lid_mean,
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
                 "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_stats_batch().stats[0].iterations), "trials": int(loop.ba_stats_batch().stats[0].trials),

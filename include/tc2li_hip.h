@@ -598,6 +598,14 @@ int tc2li_track_local_map_batch(tc2li_orb* orb, int n_frames, const tc2li_keypoi
                                 const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
                                 double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
                                 int32_t* n_inliers, void* stream);
+/* Tracking::SearchLocalPoints alone (SF/src/Tracking.cc:3232-3294), same arguments: with the IMU initialised TrackLocalMap does not call
+ * PoseOptimization but PoseInertialOptimizationLastFrame / LastKeyFrame on the frame's map points (Tracking.cc:2857-2878;
+ * tc2li_pose_inertial_optimization_batch), and TrackWithMotionModel is PredictStateIMU alone (:2746-2752).  local_of_keypoint and
+ * n_matches as above. */
+int tc2li_search_local_points_batch(tc2li_orb* orb, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                    const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                    const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                    int32_t* local_of_keypoint, int32_t* n_matches, void* stream);
 
 /* The LiDAR co-visibility window of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): the first
  * min(6, .) local keyframes with a non-empty surface cloud, in list order.  Replaces LidarCovisRes::AddFromKeyFrame /

@@ -662,7 +662,7 @@ void oracle_project_local_map(const float* pose7, const float* cam4, float mbf, 
 }  // extern "C"
 static int track_local_core(FrameView& F, const float* scales, const float* inv_sigma2, int nlevels, float log_scale, const float* pose7,
                             const double* cam5, const uint8_t* held, const float* held_Xw, const MapPointPOD* pts, int m, float th, int far_points,
-                            float th_far, double* pose_out7, int* local_of_keypoint, uint8_t* outlier, int* n_matches) {
+                            float th_far, double* pose_out7, int* local_of_keypoint, uint8_t* outlier, int* n_matches, bool optimise = true) {
     const int n = (int)F.keys.size(), cols = F.cols, rows = F.rows;
     F.occupied.resize(n);
     for (int i = 0; i < n; ++i) F.occupied[i] = held[i] == 1;
@@ -685,6 +685,10 @@ static int track_local_core(FrameView& F, const float* scales, const float* inv_
     *n_matches = nm;
     for (int i = 0; i < n; ++i) { local_of_keypoint[i] = -1; outlier[i] = 0; }
     for (int q = 0; q < m; ++q) if (match[q] >= 0) local_of_keypoint[match[q]] = q;
+    for (int c = 0; c < 7; ++c) pose_out7[c] = (double)pose7[c];
+    // SearchLocalPoints only (Tracking.cc:3232-3294): with the IMU initialised TrackLocalMap hands the correspondences to
+    // PoseInertialOptimizationLastFrame / LastKeyFrame instead of PoseOptimization (Tracking.cc:2857-2878)
+    if (!optimise) return nm;
     std::vector<double> Xd;
     std::vector<BAEdge> edges;
     std::vector<int> kp_of_edge;
@@ -754,7 +758,7 @@ int oracle_sequence_frame(void* h, const uint8_t* il, const uint8_t* ir, int w, 
                           const double* state24, const float* pose_pred7, const float* pose_last7, const double* cam5, float th, int n_last,
                           const uint8_t* has_point, const uint8_t* outlier_last, const float* Xw, const float* last_keys6, const uint8_t* mp_desc,
                           int n_held, const uint8_t* held, const float* held_Xw, const MapPointPOD* local, int n_local, float th_local,
-                          double cube_len, double det_range, double* pose_out7, int* out4) {
+                          double cube_len, double det_range, double* pose_out7, int* out4, int imu_mode) {
     OracleSequence* S = (OracleSequence*)h;
     LidarState st;
     std::memcpy(st.rot, state24, 9 * sizeof(double)); std::memcpy(st.pos, state24 + 9, 3 * sizeof(double));
@@ -784,6 +788,10 @@ int oracle_sequence_frame(void* h, const uint8_t* il, const uint8_t* ir, int w, 
     std::vector<int> mp(n + 1), lk(n + 1);
     int nm = 0, nm2 = 0;
     double pose_mm[7];
+    // imu_mode: the IMU is initialised -- TrackWithMotionModel is PredictStateIMU() and nothing else (Tracking.cc:2746-2752: no search against the last
+    // frame, no PoseOptimization), and TrackLocalMap's optimiser is the pose-inertial one, which the caller runs on the correspondences
+    if (imu_mode) { out4[0] = 0; for (int c = 0; c < 7; ++c) pose_mm[c] = (double)pose_pred7[c]; }
+    else
     out4[0] = track_core(F, S->el.mvScaleFactor.data(), S->el.mvInvLevelSigma2.data(), (int)S->el.mvScaleFactor.size(), pose_pred7, pose_last7, cam5, mb,
                          th, n_last, has_point, outlier_last, Xw, kps_from(last_keys6, n_last), mp_desc, pose_mm, mp.data(), &nm);
     // TrackLocalMap starts from the pose TrackWithMotionModel left (float on the Frame)
@@ -796,7 +804,7 @@ int oracle_sequence_frame(void* h, const uint8_t* il, const uint8_t* ir, int w, 
     std::memcpy(heldX.data(), held_Xw, 3 * (size_t)nh * sizeof(float));
     const float log_scale = std::log(S->el.mvScaleFactor[1]);
     out4[1] = track_local_core(F, S->el.mvScaleFactor.data(), S->el.mvInvLevelSigma2.data(), (int)S->el.mvScaleFactor.size(), log_scale, pose_f, cam5,
-                               held_n.data(), heldX.data(), local, n_local, th_local, 0, 0.f, pose_out7, lk.data(), outl.data(), &nm2);
+                               held_n.data(), heldX.data(), local, n_local, th_local, 0, 0.f, pose_out7, lk.data(), outl.data(), &nm2, imu_mode == 0);
     lidar.join();
     out4[2] = fe.effct_feat_num;
     // UpdateMap (LidarFrontEnd.cpp:1075-1079) -> map_incremental (:387-435)

@@ -315,7 +315,7 @@ class Sequence:
         self._h = C.c_void_p(f(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast, mp.ctypes.data, len(mp)))
         self._frame = lib().oracle_sequence_frame
         self._frame.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int] +
-                                [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p])
+                                [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int])
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -328,9 +328,11 @@ class Sequence:
         return lib().oracle_sequence_map_size(self._h)
 
     def frame(self, left, right, bf, b, scan, state24, pose_pred7, last, cam5, th, held, held_Xw, local_points, th_local=1.0, cube_len=1000.0,
-              det_range=100.0):
+              det_range=100.0, imu_mode=False):
         """last: dict with pose7, has_point, outlier, Xw, keys6 (floats), descriptors.  -> (pose7 double, [inliers of the motion-model step,
-        mnMatchesInliers, selected LiDAR features, map size])."""
+        mnMatchesInliers, selected LiDAR features, map size]).  imu_mode: the camera path with the IMU initialised -- TrackWithMotionModel is
+        PredictStateIMU alone (Tracking.cc:2746-2752), TrackLocalMap searches the local points and leaves the optimisation to the caller's
+        PoseInertialOptimization (Tracking.cc:2857-2878); out4[1] is then SearchLocalPoints' number of matches."""
         h, w = left.shape
         st = _f64(state24)
         pp = np.ascontiguousarray(pose_pred7, np.float32); pl = np.ascontiguousarray(last["pose7"], np.float32)
@@ -341,7 +343,7 @@ class Sequence:
         self._frame(self._h, left.ctypes.data, right.ctypes.data, w, h, bf, b, scan.ctypes.data, len(scan), st.ctypes.data, pp.ctypes.data, pl.ctypes.data,
                     cam.ctypes.data, th, len(last["keys6"]), last["has_point"].ctypes.data, last["outlier"].ctypes.data, last["Xw"].ctypes.data,
                     last["keys6"].ctypes.data, last["descriptors"].ctypes.data, len(held), held.ctypes.data, hx.ctypes.data,
-                    lp.ctypes.data if len(lp) else None, len(lp), th_local, cube_len, det_range, pose.ctypes.data, out4.ctypes.data)
+                    lp.ctypes.data if len(lp) else None, len(lp), th_local, cube_len, det_range, pose.ctypes.data, out4.ctypes.data, int(bool(imu_mode)))
         return pose, out4
 
 

@@ -992,6 +992,30 @@ def track_local_map_batch(ext, n_frames, keypoints, u_right, poses7, held, held_
     return out_p, lk, ol, nm, inl
 
 
+def search_local_points_batch(ext, n_frames, keypoints, u_right, poses7, held, held_Xw, local_points, local_offsets, cam5, th=1.0, far_points=False,
+                              th_far=0.0, stream=0, out=None):
+    """``tc2li_search_local_points_batch`` (Tracking::SearchLocalPoints alone: the camera-LiDAR-inertial configuration's TrackLocalMap optimises with
+    PoseInertialOptimization) on the features of the last ``extract_batch_dev`` call -> (local_of_keypoint [F, cap], n_matches [F])."""
+    kps = np.ascontiguousarray(keypoints, KEYPOINT_DTYPE)
+    cap = kps.shape[1]
+    ur = np.ascontiguousarray(u_right, np.float32)
+    p7 = np.ascontiguousarray(poses7, np.float32).reshape(n_frames, 7)
+    h = np.ascontiguousarray(held, np.uint8).reshape(n_frames, cap)
+    hx = np.ascontiguousarray(held_Xw, np.float32).reshape(n_frames, cap, 3)
+    pts = np.ascontiguousarray(local_points, MAP_POINT_DTYPE)
+    off = np.ascontiguousarray(local_offsets, np.int32)
+    cam5 = np.ascontiguousarray(cam5, np.float64)
+    if out is None:
+        out = (np.full((n_frames, cap), -1, np.int32), np.zeros(n_frames, np.int32))
+    lk, nm = out
+    f = lib().tc2li_search_local_points_batch
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                  C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(f(ext._h, n_frames, kps.ctypes.data, ur.ctypes.data, cap, p7.ctypes.data, h.ctypes.data, hx.ctypes.data, pts.ctypes.data if len(pts) else None,
+             off.ctypes.data, cam5.ctypes.data, th, int(far_points), th_far, lk.ctypes.data, nm.ctypes.data, C.c_void_p(stream)))
+    return lk, nm
+
+
 def fuse_search(keys, desc, u_right, cols, rows, pose7, cam4, bf, scale_factors, inv_level_sigma2, log_scale_factor, points, valid, th=3.0, stream=0):
     """``ORBmatcher::Fuse``, the search part -> (n_fused, best_idx [m], best_dist [m]); points: MAP_POINT_DTYPE."""
     k = np.ascontiguousarray(keys, KEYPOINT_DTYPE)

@@ -294,13 +294,15 @@ extern "C" int tc2li_track_motion_model_batch(tc2li_orb* o, int n_frames, const 
 // The data path of Tracking::TrackLocalMap (SF/src/Tracking.cc:3119-3230) for a batch of independent frames: SearchLocalPoints
 // (:3232-3294: isInFrustum + SearchByProjection(F, mvpLocalMapPoints, th, far points) with ORBmatcher(0.8)) on the device-resident
 // features, then Optimizer::PoseOptimization over every map point the frame holds, and mnMatchesInliers.
-extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
-                                           const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
-                                           const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
-                                           double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
-                                           int32_t* n_inliers, void* stream_) {
-    if (!o || n_frames < 0 || capacity < 0 || !keypoints || !u_right || !poses7 || !held || !held_Xw || !local_offsets || !cam || !poses7_out ||
-        !local_of_keypoint || !outlier || !n_matches || !n_inliers) {
+// optimise = false: SearchLocalPoints alone (tc2li_search_local_points_batch) -- with the IMU initialised TrackLocalMap hands the correspondences to
+// PoseInertialOptimizationLastFrame / LastKeyFrame (Tracking.cc:2857-2878; tc2li_pose_inertial_optimization_batch) instead of PoseOptimization
+static int track_local_map_impl(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
+                                int32_t* n_inliers, void* stream_, const bool optimise) {
+    if (!o || n_frames < 0 || capacity < 0 || !keypoints || !u_right || !poses7 || !held || !held_Xw || !local_offsets || !cam || !local_of_keypoint || !n_matches ||
+        (optimise && (!poses7_out || !outlier || !n_inliers))) {
         set_error("tc2li_track_local_map_batch: invalid argument");
         return TC2LI_ERR_INVALID;
     }
@@ -421,6 +423,14 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     TC2LI_HIP_CHECK(w.d_outlier_key.ensure(ne));
     launch_track_edges_local(w.d_frames.p, n_frames, C, o->d_mkeys.p, d_ur, w.d_match.p, d_held, d_hx, d_pts, w.d_of_key.p, w.d_probs.p, w.d_edges.p, w.d_Xw.p,
                              w.d_edge_kp.p, w.d_poses.p, st);
+    if (!optimise) {  // the keypoints' new map points are what the caller wants; the optimisation is the pose-inertial one, elsewhere
+        TC2LI_HIP_CHECK(hipGetLastError());
+        TC2LI_HIP_CHECK(hipMemcpyAsync(local_of_keypoint, w.d_of_key.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TC2LI_HIP_CHECK(stream_wait_blocking(st));
+        tm[3] = now() - t0;
+        if (kTiming) fprintf(stderr, "search-local-points timing ms: stage %.3f queries %.3f search %.3f results %.3f\n", tm[0], tm[1], tm[2], tm[3]);
+        return n_frames;
+    }
     CameraD cd;
     memcpy(&cd, cam, sizeof(cd));
     launch_pose_optimization(w.d_probs.p, n_frames, w.d_Xw.p, w.d_edges.p, cd, w.d_poses.p, w.d_outlier.p, w.d_chi2.p, w.d_inliers.p, capacity, st);
@@ -434,4 +444,23 @@ extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2
     tm[3] = now() - t0;
     if (kTiming) fprintf(stderr, "track-local-map timing ms: stage %.3f queries %.3f search %.3f edges+pose-opt+results %.3f\n", tm[0], tm[1], tm[2], tm[3]);
     return n_frames;
+}
+
+extern "C" int tc2li_track_local_map_batch(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                           const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                           const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                           double* poses7_out, int32_t* local_of_keypoint, uint8_t* outlier, int32_t* n_matches,
+                                           int32_t* n_inliers, void* stream_) {
+    return track_local_map_impl(o, n_frames, keypoints, u_right, capacity, poses7, held, held_Xw, local_points, local_offsets, cam, th, far_points,
+                                th_far_points, poses7_out, local_of_keypoint, outlier, n_matches, n_inliers, stream_, true);
+}
+
+// Tracking::SearchLocalPoints (SF/src/Tracking.cc:3232-3294) for a batch of frames: the first half of tc2li_track_local_map_batch, for the
+// camera-LiDAR-inertial configuration's TrackLocalMap (the optimiser there is PoseInertialOptimization*)
+extern "C" int tc2li_search_local_points_batch(tc2li_orb* o, int n_frames, const tc2li_keypoint* keypoints, const float* u_right, int capacity,
+                                               const float* poses7, const uint8_t* held, const float* held_Xw, const tc2li_map_point* local_points,
+                                               const int32_t* local_offsets, const tc2li_camera* cam, float th, int far_points, float th_far_points,
+                                               int32_t* local_of_keypoint, int32_t* n_matches, void* stream_) {
+    return track_local_map_impl(o, n_frames, keypoints, u_right, capacity, poses7, held, held_Xw, local_points, local_offsets, cam, th, far_points,
+                                th_far_points, nullptr, local_of_keypoint, nullptr, n_matches, nullptr, stream_, false);
 }

@@ -155,6 +155,29 @@ def test_track_local_map_batch(pkg, oracle, synthetic, th, far):
         assert np.all(got[1][f, :n][sc["held"][f, :n] == 1] == -1)
 
 
+@pytest.mark.parametrize("th,far", [(1.0, False), (2.0, True)])
+def test_search_local_points_batch(pkg, oracle, synthetic, th, far):
+    """tc2li_search_local_points_batch = Tracking::SearchLocalPoints alone (the inertial configuration's TrackLocalMap optimises with
+    PoseInertialOptimization, Tracking.cc:2857-2878): the keypoints' new map points and the match counts of the oracle's TrackLocalMap."""
+    sc = local_map_scenario(pkg, oracle, synthetic, [10, 11, 12, 13])
+    F = len(sc["poses"])
+    cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, sc["bf"]]).astype(np.float64)
+    lk, nm = pkg.capi.search_local_points_batch(sc["ext"], F, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"], sc["local_off"], cam5,
+                                                th=th, far_points=far, th_far=30.0)
+    scales, inv_sigma2 = sc["ext"].GetScaleFactors(), sc["ext"].GetInverseScaleSigmaSquares()
+    log_scale = float(np.log(np.float32(1.2)))
+    for f in range(F):
+        n = int(sc["counts"][2 * f])
+        pts = sc["local"][sc["local_off"][f]:sc["local_off"][f + 1]]
+        want = oracle.track_local_map(sc["kps"][2 * f, :n], sc["desc"][2 * f, :n], sc["u_right"][f, :n], sc["w"], sc["h"], scales, inv_sigma2, log_scale,
+                                      sc["poses"][f], cam5, sc["held"][f, :n], sc["held_Xw"][f, :n], pts, th=th, far_points=far, th_far=30.0)
+        assert nm[f] == want[3] and want[3] > 100
+        assert np.array_equal(lk[f, :n], want[1]) and np.all(lk[f, n:] == -1)
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.search_local_points_batch(sc["ext"], F, sc["kps"], sc["u_right"], sc["poses"], sc["held"], sc["held_Xw"], sc["local"],
+                                           np.array([1, 5, 9, 12, 20], np.int32), cam5)
+
+
 def test_track_local_map_edge_cases(pkg, oracle, synthetic):
     sc = local_map_scenario(pkg, oracle, synthetic, [14, 15])
     cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, sc["bf"]]).astype(np.float64)
