@@ -941,6 +941,18 @@ class InertialLoop(Loop):
                                               self.uniq_lvi[0]["calib24"], self.uniq_lvi[0]["cam"])
         self.ba_batch2 = None
         self.slp_outs = [None, None, None]
+        # mapping workers as in the main loop (TC2LI_BENCH_BA_WORKERS): each a lock-step group of its own on tc2li_local_lvi_bundle_adjustment_batch_group
+        n_workers = int(os.environ.get("TC2LI_BENCH_BA_WORKERS", "3"))
+        if self.n_ba and F > 256 and n_workers >= 2 and self.n_ba >= 8 * n_workers and self.ba_rate == self.n_ba:
+            self.ba_chunk_sizes = [self.n_ba * (c + 1) // n_workers - self.n_ba * c // n_workers for c in range(n_workers)]
+
+            def lvi_batch(n):
+                return pkg.capi.LviBatch([dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=w["packed"], link4=w["link4"],
+                                               pre=w["pre"], win_kf=w["win_kf"], clouds=w["clouds"], Tcl7=w["Tcl7"], Tbl7=w["Tbl7"], weight=1.0,
+                                               iterations=self.lvi_iterations, lambda_init=self.lvi_lambda) for w in [self.uniq_lvi[k % 4] for k in range(n)]],
+                                         self.uniq_lvi[0]["calib24"], self.uniq_lvi[0]["cam"])
+            for w_ in range(n_workers):
+                self.ba_workers.append({n: lvi_batch(n) for n in set(self.ba_chunk_sizes)})
 
     # The camera path with the IMU initialised (the steady state of configs[3]): TrackWithMotionModel is PredictStateIMU() and nothing else
     # (Tracking.cc:2746-2752: no search against the last frame, no PoseOptimization), and TrackLocalMap optimises with
@@ -991,7 +1003,7 @@ class InertialLoop(Loop):
         ls = np.array(self.li.stats())
         return {"scan_points_preprocessed/downsampled/eskf_features/h_share_model_calls": [int(ls[:, 3].mean()), int(ls[:, 4].mean()), int(ls[:, 2].mean()), int(ls[:, 0].mean())],
                 "pose_inertial_edges/inliers": [int(np.mean([len(q["edges"]) for q in self.uniq_pi])), int(self.pi.inliers().mean())],
-                "lviba_iterations/planes": [int(self.ba_batch.stats[0].iterations), int(self.ba_batch.lstats[0].n_planes)] if self.n_ba else None,
+                "lviba_iterations/planes": [int(self.ba_stats_batch().stats[0].iterations), int(self.ba_stats_batch().lstats[0].n_planes)] if self.n_ba else None,
                 "map_points_added_per_step": self.map_adds}
 
 
@@ -1114,12 +1126,12 @@ def algorithmic_work_inertial(wl, il, nkp, windows_per_step):
     ba = None
     if il.n_ba:
         w0 = il.uniq_lvi[0]
-        s0 = il.ba_batch.stats[0]
+        s0 = il.ba_stats_batch().stats[0]
         fixed = np.asarray(w0["fixed"])
         e6 = np.asarray(w0["edges"])
         free_edge = fixed[e6[:, 1].astype(int)] == 0
         f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=len(w0["points"]))
-        ba = {"edges": len(e6), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(il.ba_batch.lstats[0].n_planes), "win": 6,
+        ba = {"edges": len(e6), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(il.ba_stats_batch().lstats[0].n_planes), "win": 6,
               "cloud_points": int(sum(len(c) for c in w0["clouds"])),
               "free_edges": int(free_edge.sum()), "pose_pairs": int((f_l * (f_l + 1) // 2).sum()), "windows": windows_per_step,
               "linearisations": int(s0.iterations), "trials": int(s0.trials)}

@@ -769,6 +769,10 @@ typedef struct tc2li_lvi_problem {
 } tc2li_lvi_problem;
 int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib,
                                             const tc2li_camera* cam, int max_concurrency, int32_t* results);
+/* The same as ONE lock-step group on the context `group` (0 .. 7), for callers with several local-mapping workers: as
+ * tc2li_local_bundle_adjustment_batch_group.  Every window's result is the one tc2li_local_lvi_bundle_adjustment gives for it. */
+int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib,
+                                                  const tc2li_camera* cam, int group, int32_t* results);
 
 /* ---- local mapping: new map points ----
  * What ORBmatcher::SearchForTriangulation (SF/src/ORBmatcher.cc:916) and the pair loop of LocalMapping::CreateNewMapPoints

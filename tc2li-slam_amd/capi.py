@@ -1627,6 +1627,16 @@ class LviBatch:
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         return _check(f(C.addressof(self.arr), self.n, self.calib24.ctypes.data, self.cam5.ctypes.data, max_concurrency, self.results.ctypes.data))
 
+    def run_group(self, group):
+        """The same as ONE lock-step group on the library's context `group` (tc2li_local_lvi_bundle_adjustment_batch_group): for callers with several
+        mapping workers, each on a group of its own."""
+        for (k0, x0), k in zip(self.init, self.keep):
+            k[0][...] = k0
+            k[1][...] = x0
+        f = lib().tc2li_local_lvi_bundle_adjustment_batch_group
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        return _check(f(C.addressof(self.arr), self.n, self.calib24.ctypes.data, self.cam5.ctypes.data, int(group), self.results.ctypes.data))
+
     def result(self, i):
         k = self.keep[i]
         return k[0], k[1], k[6][:len(k[4])], k[7][:len(k[4])], self.stats[i], self.lstats[i]

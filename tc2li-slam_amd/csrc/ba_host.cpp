@@ -2522,6 +2522,32 @@ int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, i
     return ok;
 }
 
+// The same as ONE lock-step group on the context `group` (as tc2li_local_bundle_adjustment_batch_group): for the mapping workers of a multi-sequence
+// camera-LiDAR-inertial system
+int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
+                                                  int group, int32_t* results) {
+    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam || group < 0 || group >= kMaxLockstepGroups) {
+        set_error("tc2li_local_lvi_bundle_adjustment_batch_group: invalid argument (group 0 .. %d)", kMaxLockstepGroups - 1);
+        return TC2LI_ERR_INVALID;
+    }
+    if (n_problems == 0) return 0;
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
+    bool done = false;
+    if (n_problems > 1 && !kNoLockstep) done = lvi_batch_lockstep(problems, n_problems, calib, cam, named_pool(kPoolLviGroup0 + group), results, group);
+    if (!done) {  // a window outside the batched kernels' range, windows that disagree about the reduced system's solver, or a batch of one
+        for (int i = 0; i < n_problems; ++i) {
+            const tc2li_lvi_problem& p = problems[i];
+            results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
+                                                           p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,
+                                                           p.lidar, p.Tbl, p.lidar_stats, private_stream());
+        }
+    }
+    int ok = 0;
+    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
+    return ok;
+}
+
 int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* residual, double* JacT,
                                 double* Hessian, void* stream_) {
     if (!poses7 || n_poses <= 0 || !win) { set_error("tc2li_lidar_window_evaluate: invalid argument"); return TC2LI_ERR_INVALID; }

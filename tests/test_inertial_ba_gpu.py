@@ -154,6 +154,22 @@ def test_lviba_batch_equals_the_one_window_calls(pkg, oracle, synthetic):
             assert st.final_chi2 < st.initial_chi2
 
 
+def test_lviba_batch_group_equals_the_batch_call(pkg, oracle, synthetic):
+    """tc2li_local_lvi_bundle_adjustment_batch_group (one lock-step group on a context of the caller's choice, for several mapping workers):
+    the windows' results are those of tc2li_local_lvi_bundle_adjustment_batch."""
+    specs = [(6, 5, 300, True), (7, 8, 500, False), (8, 6, 400, True)]
+    wins = [_lvi_window(pkg, oracle, synthetic, s, n, p, lidar=l) for s, n, p, l in specs]
+    w0 = wins[0][0]
+    batch = pkg.capi.LviBatch([d for _, d in wins], w0["calib24"], w0["cam"])
+    assert batch.run(max_concurrency=8) == len(wins)
+    ref = [tuple(np.copy(a) for a in batch.result(i)[:4]) + (batch.result(i)[4].trials, batch.result(i)[4].final_chi2) for i in range(len(wins))]
+    for group in (0, 2):
+        assert batch.run_group(group) == len(wins)
+        for i in range(len(wins)):
+            r = batch.result(i)
+            assert all(np.array_equal(a, b) for a, b in zip(r[:4], ref[i][:4])) and (r[4].trials, r[4].final_chi2) == ref[i][4:], (group, i)
+
+
 @pytest.mark.parametrize("form", ["full-width", "64x64-units"])  # the two block-sparse MFMA kernels of the dense windows' Schur product (round 5)
 def test_lviba_large_window_and_benched_cloud(pkg, oracle, synthetic, monkeypatch, form):
     """The 25-keyframe `bLarge` window of LocalInertialBA / LocalLVIBA (opt_it 4, lambda 1e-2: Optimizer.cc:1516-1523, OptimizerWithLidar.cc:493-500,
