@@ -47,6 +47,27 @@ __host__ __device__ inline void pi_mul3f(const float* a, const float* b, float* 
 }
 // IMU::NormalizeRotation (float JacobiSVD in the reference): one-sided Jacobi rotations, as csrc/imu_host.cpp
 __host__ __device__ inline void pi_normalize_rotation_f(const float* R, float* out) {
+    // (round 5: dR exp(JRg dbg) is orthogonal to float precision already -- its polar factor by two Newton steps X <- (X + X^-T) / 2 instead of
+    // Jacobi sweeps on one lane; the sweeps remain for anything further from a rotation)
+    {
+        float e = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = a; b < 3; ++b)
+                e = fmaxf(e, fabsf(R[a] * R[b] + R[3 + a] * R[3 + b] + R[6 + a] * R[6 + b] - (a == b ? 1.0f : 0.0f)));
+        if (e < 1e-3f) {
+            float X[9];
+            for (int k = 0; k < 9; ++k) X[k] = R[k];
+            for (int it = 0; it < 2; ++it) {
+                const float c[9] = {X[4] * X[8] - X[5] * X[7], X[5] * X[6] - X[3] * X[8], X[3] * X[7] - X[4] * X[6],
+                                    X[2] * X[7] - X[1] * X[8], X[0] * X[8] - X[2] * X[6], X[1] * X[6] - X[0] * X[7],
+                                    X[1] * X[5] - X[2] * X[4], X[2] * X[3] - X[0] * X[5], X[0] * X[4] - X[1] * X[3]};
+                const float inv = 1.0f / (X[0] * c[0] + X[1] * c[1] + X[2] * c[2]);
+                for (int k = 0; k < 9; ++k) X[k] = 0.5f * (X[k] + c[k] * inv);
+            }
+            for (int k = 0; k < 9; ++k) out[k] = X[k];
+            return;
+        }
+    }
     float A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int k = 0; k < 9; ++k) A[k] = R[k];
     for (int sweep = 0; sweep < 30; ++sweep) {
