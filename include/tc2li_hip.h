@@ -886,6 +886,17 @@ const int32_t* tc2li_local_map_device_points(const tc2li_local_map* map);
 int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* lidar, double* residual,
                                 double* JacT, double* Hessian, void* stream);
 
+/* Host-only: the envelope LDL^T of the inertial windows' reduced system (csrc/reduced_solve.hpp -- what tc2li_local_lvi_bundle_adjustment uses
+ * with TC2LI_LVI_DEVICE_SOLVE=0 and for windows the device solve does not take), exposed so that it can be checked without a GPU.
+ * Hi [n][n]: the inertial + LiDAR part in the caller's numbering (np pose unknowns first, lower triangle read); S [np][np]: the visual Schur
+ * complement with its damping (lower triangle read); lambda is added to the diagonal of the other n - np unknowns.  Solves for x [n] from rhs [n];
+ * returns 1, or 0 when a pivot is zero or not finite. */
+int tc2li_host_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x);
+/* The same system through the device solve (k_lvi_solve: what the inertial windows use by default), for tests of the kernel alone: returns 1,
+ * 0 for a failed pivot, TC2LI_ERR_INVALID when the kernel does not take the system (more than 150 pose unknowns, no velocity / bias
+ * unknowns, a velocity / bias row wider than 28). */
+int tc2li_device_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x, void* stream);
+
 /* Host-only stage of the LiDAR term, exposed so that it can be checked without a GPU: the planes of the window
  * (cut_voxel + recut + tras_opt, SF/src/bavoxel.cc:42-91, SF/include/bavoxel.h:492-602,723-740).  clusters receives, per
  * plane and window keyframe, 10 doubles: P00 P01 P02 P11 P12 P22 (sum x x^T), v (sum x), N in the keyframe's LiDAR

@@ -562,6 +562,32 @@ def lidar_fov_segment(local_map, pos_lid, cube_len=200.0, det_range=100.0):
     return boxes[:k].copy()
 
 
+def host_reduced_solve(Hi, S, lam, rhs):
+    """``tc2li_host_reduced_solve``: the host's envelope LDL^T of an inertial window's reduced system (no GPU) -> x, or None when a pivot fails."""
+    Hi = np.ascontiguousarray(Hi, np.float64)
+    S = np.ascontiguousarray(S, np.float64)
+    rhs = np.ascontiguousarray(rhs, np.float64)
+    n, npose = len(Hi), len(S)
+    x = np.zeros(n)
+    f = lib().tc2li_host_reduced_solve
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    ok = _check(f(Hi.ctypes.data, S.ctypes.data if npose else None, n, npose, float(lam), rhs.ctypes.data, x.ctypes.data))
+    return x if ok else None
+
+
+def device_reduced_solve(Hi, S, lam, rhs, stream=0):
+    """``tc2li_device_reduced_solve``: the same system through k_lvi_solve -> x, or None when a pivot fails."""
+    Hi = np.ascontiguousarray(Hi, np.float64)
+    S = np.ascontiguousarray(S, np.float64)
+    rhs = np.ascontiguousarray(rhs, np.float64)
+    n, npose = len(Hi), len(S)
+    x = np.zeros(n)
+    f = lib().tc2li_device_reduced_solve
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    ok = _check(f(Hi.ctypes.data, S.ctypes.data, n, npose, float(lam), rhs.ctypes.data, x.ctypes.data, C.c_void_p(stream)))
+    return x if ok else None
+
+
 def lidar_fov_segment_batch(local_maps, pos_lid3, cube_len=200.0, det_range=100.0):
     """``lasermap_fov_segment`` for n sensors in one call: ``local_maps`` a ctypes array ``(LocalMapBox * n)()``, ``pos_lid3`` [n, 3]
     -> (boxes [n, 3, 6] float32, counts [n] int32)."""

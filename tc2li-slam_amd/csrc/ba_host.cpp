@@ -2522,6 +2522,40 @@ int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, i
     return ok;
 }
 
+int tc2li_host_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x) {
+    if (!Hi || n <= 0 || np < 0 || np > n || (np > 0 && !S) || !rhs || !x) { set_error("tc2li_host_reduced_solve: invalid argument"); return TC2LI_ERR_INVALID; }
+    ReducedSolver solver;
+    solver.set_pattern(Hi, n, np);
+    if (!solver.factorise(Hi, S, lambda)) return 0;
+    solver.solve(rhs, x);
+    return 1;
+}
+
+int tc2li_device_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x, void* stream_) {
+    if (!Hi || n <= 0 || np <= 0 || np >= n || !S || !rhs || !x) { set_error("tc2li_device_reduced_solve: invalid argument"); return TC2LI_ERR_INVALID; }
+    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
+    ReducedSolver solver;
+    solver.set_pattern(Hi, n, np, false);
+    if (np > kLviMaxPoseRows || solver.band() > kLviBand || !lvi_device_solve_available()) {
+        set_error("tc2li_device_reduced_solve: %d pose unknowns / band %d: outside the kernel's range (%d / %d)", np, solver.band(), kLviMaxPoseRows, kLviBand);
+        return TC2LI_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    BaWorkspace& ws = ba_ws();
+    std::lock_guard<std::mutex> lk(ws.mu);
+    TC2LI_HIP_CHECK(ws.lvi.ensure(np, n - np)); TC2LI_HIP_CHECK(ws.d_S.ensure((size_t)np * np)); TC2LI_HIP_CHECK(ws.d_bs.ensure(2 * (size_t)np));
+    TC2LI_HIP_CHECK(ws.d_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_ok.ensure(1));
+    const size_t bytes = ws.lvi.pack(solver, Hi, rhs);   // (the whole right-hand side as the inertial part's; the visual part b_s is zero)
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.lvi.d_blob.p, ws.lvi.h_blob.p, bytes, hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_S.p, S, (size_t)np * np * sizeof(double), hipMemcpyHostToDevice, st));
+    TC2LI_HIP_CHECK(hipMemsetAsync(ws.d_bs.p, 0, 2 * (size_t)np * sizeof(double), st));
+    lvi_launch_solve(ws.lvi.dev, ws.d_S.p, ws.d_bs.p, lambda, ws.d_xp.p, ws.h_xp.p, ws.h_ok.p, st);
+    TC2LI_HIP_CHECK(hipGetLastError());
+    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(x, ws.h_xp.p, (size_t)n * sizeof(double));
+    return ws.h_ok.p[0] != 0 ? 1 : 0;
+}
+
 // The same as ONE lock-step group on the context `group` (as tc2li_local_bundle_adjustment_batch_group): for the mapping workers of a multi-sequence
 // camera-LiDAR-inertial system
 int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
