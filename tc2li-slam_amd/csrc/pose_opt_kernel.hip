@@ -47,7 +47,10 @@ __device__ __forceinline__ double block_sum(double x, double* s_red, double* s_o
 
 // E, X, chi2, out: the frame's N correspondences, their map points, one chi2 and one outlier flag per edge -- in global memory, or staged in
 // LDS by the caller (k_pose_optimization_lds)
-__device__ __forceinline__ void pose_optimization_body(const int N, const BaEdge* __restrict__ E, const double* __restrict__ X, double* __restrict__ chi2,
+// (edge_at(i): the i-th correspondence as a BaEdge -- out of global memory, or rebuilt from the four doubles the LDS form keeps of it; Chi2T: double
+// in global memory, float in LDS -- the only reader of the stored chi2 is the classification, which compares it as a float: Optimizer.cc:1018-1102)
+template <typename EdgeAt, typename Chi2T>
+__device__ __forceinline__ void pose_optimization_body(const int N, const EdgeAt edge_at, const double* __restrict__ X, Chi2T* __restrict__ chi2,
                                                        uint8_t* __restrict__ out, const CameraD& cam, double* __restrict__ pose_io, int* __restrict__ inliers) {
     __shared__ double s_red[4 * kRed], s_sum[kRed];
     __shared__ Se3 s_pose, s_trial;
@@ -82,14 +85,14 @@ __device__ __forceinline__ void pose_optimization_body(const int N, const BaEdge
             for (int k = 0; k < kRed; ++k) acc[k] = 0;
             for (int i = tid; i < N; i += kPoThreads) {
                 if (out[i]) continue;  // level 1
-                const BaEdge e = E[i];
+                const BaEdge e = edge_at(i);
                 double p[3], err[3], B[18];
                 se3_map(T, X + 3 * i, p);
                 const bool stereo = e.ur >= 0;
                 const int dim = edge_error(p, e, cam, err);
                 double c2 = 0;
                 for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
-                chi2[i] = c2;
+                chi2[i] = (Chi2T)c2;
                 double rho0 = c2, rho1 = 1.0;
                 if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
                 pose_jacobian(p, stereo, true, cam, B);
@@ -147,14 +150,14 @@ __device__ __forceinline__ void pose_optimization_body(const int N, const BaEdge
                 double chi_trial = 0;
                 for (int i = tid; i < N; i += kPoThreads) {
                     if (out[i]) continue;
-                    const BaEdge e = E[i];
+                    const BaEdge e = edge_at(i);
                     double p[3], err[3];
                     se3_map(Tt, X + 3 * i, p);
                     const bool stereo = e.ur >= 0;
                     const int dim = edge_error(p, e, cam, err);
                     double c2 = 0;
                     for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
-                    chi2[i] = c2;
+                    chi2[i] = (Chi2T)c2;
                     double rho0 = c2, rho1 = 1.0;
                     if (robust) huber(c2, stereo ? d_stereo : d_mono, stereo ? dsqr_stereo : dsqr_mono, rho0, rho1);
                     chi_trial += rho0;
@@ -204,14 +207,14 @@ __device__ __forceinline__ void pose_optimization_body(const int N, const BaEdge
         const Se3 T = s_pose;
         int bad = 0;
         for (int i = tid; i < N; i += kPoThreads) {
-            const BaEdge e = E[i];
+            const BaEdge e = edge_at(i);
             if (out[i]) {
                 double p[3], err[3];
                 se3_map(T, X + 3 * i, p);
                 const int dim = edge_error(p, e, cam, err);
                 double c2 = 0;
                 for (int d = 0; d < dim; ++d) c2 += err[d] * e.info * err[d];
-                chi2[i] = c2;
+                chi2[i] = (Chi2T)c2;
             }
             const float c = (float)chi2[i];
             const float th = e.ur >= 0 ? 7.815f : 5.991f;
@@ -237,14 +240,18 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization(const PoseProb
                                                                  double* __restrict__ poses7, uint8_t* __restrict__ outlier,
                                                                  double* __restrict__ chi2_scratch, int* __restrict__ inliers) {
     const PoseProblem pr = probs[blockIdx.x];
-    pose_optimization_body(pr.n, edges + pr.edge_off, Xw + 3 * (size_t)pr.edge_off, chi2_scratch + pr.edge_off, outlier + pr.edge_off, cam,
+    const BaEdge* E = edges + pr.edge_off;
+    pose_optimization_body(pr.n, [E](int i) { return E[i]; }, Xw + 3 * (size_t)pr.edge_off, chi2_scratch + pr.edge_off, outlier + pr.edge_off, cam,
                            poses7 + 7 * (size_t)blockIdx.x, inliers + blockIdx.x);
 }
 
 // The same with the frame's correspondences staged in LDS for the whole optimisation: HBM sees each edge and map point once and one outlier
 // flag per edge, instead of a re-read of edge, point and chi2 on each of the ~40 linearisations and trial evaluations (26 x the algorithmic
 // bytes in round 2's counters).  Same loops, same order of the sums: the same bits.  cap = edges the dynamic LDS block holds (>= every n).
-constexpr int kPoLdsPerEdge = sizeof(BaEdge) + 3 * sizeof(double) + sizeof(double) + 1;  // 73 B
+// Round 5: 61 bytes per correspondence instead of 73 -- observation and information as four doubles (the edge's two indices are not used here),
+// the chi2 as the float the classification compares -- so that a frame of up to 1 311 correspondences leaves room for a second workgroup on its CU
+// (the batched frames hold ~1 200: one workgroup per CU at 73 bytes, i.e. two rounds of 256 for 512 frames).
+constexpr int kPoLdsPerEdge = 4 * sizeof(double) + 3 * sizeof(double) + sizeof(float) + 1;  // 61 B
 __global__ __launch_bounds__(kPoThreads) void k_pose_optimization_lds(const PoseProblem* __restrict__ probs, const double* __restrict__ Xw,
                                                                      const BaEdge* __restrict__ edges, CameraD cam,
                                                                      double* __restrict__ poses7, uint8_t* __restrict__ outlier,
@@ -253,18 +260,18 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization_lds(const Pose
     const PoseProblem pr = probs[blockIdx.x];
     const int N = pr.n, tid = threadIdx.x;
     double* const s_X = s_po;                                  // [cap][3]
-    double* const s_chi2 = s_X + 3 * (size_t)cap;              // [cap]
-    BaEdge* const s_E = reinterpret_cast<BaEdge*>(s_chi2 + cap);  // [cap] (40 B each: 8-byte aligned)
-    uint8_t* const s_out = reinterpret_cast<uint8_t*>(s_E + cap);
+    double* const s_E = s_X + 3 * (size_t)cap;                 // [cap][4]: u, v, ur, info
+    float* const s_chi2 = reinterpret_cast<float*>(s_E + 4 * (size_t)cap);  // [cap]
+    uint8_t* const s_out = reinterpret_cast<uint8_t*>(s_chi2 + cap);
     {
         const double* gx = Xw + 3 * (size_t)pr.edge_off;
         for (int k = tid; k < 3 * N; k += kPoThreads) s_X[k] = gx[k];
-        const double* ge = reinterpret_cast<const double*>(edges + pr.edge_off);
-        double* se = reinterpret_cast<double*>(s_E);
-        for (int k = tid; k < 5 * N; k += kPoThreads) se[k] = ge[k];
+        const double* ge = reinterpret_cast<const double*>(edges + pr.edge_off);   // 5 doubles per edge: (point, pose), u, v, ur, info
+        for (int k = tid; k < 4 * N; k += kPoThreads) s_E[k] = ge[5 * (k >> 2) + 1 + (k & 3)];
     }
     __syncthreads();
-    pose_optimization_body(N, s_E, s_X, s_chi2, s_out, cam, poses7 + 7 * (size_t)blockIdx.x, inliers + blockIdx.x);
+    pose_optimization_body(N, [s_E](int i) { return BaEdge{0, 0, s_E[4 * i], s_E[4 * i + 1], s_E[4 * i + 2], s_E[4 * i + 3]}; }, s_X, s_chi2, s_out, cam,
+                           poses7 + 7 * (size_t)blockIdx.x, inliers + blockIdx.x);
     __syncthreads();
     uint8_t* out = outlier + pr.edge_off;
     for (int i = tid; i < N; i += kPoThreads) out[i] = s_out[i];
@@ -273,9 +280,9 @@ __global__ __launch_bounds__(kPoThreads) void k_pose_optimization_lds(const Pose
 void launch_pose_optimization(const PoseProblem* probs, int nprobs, const double* Xw, const BaEdge* edges, const CameraD& cam,
                               double* poses7, uint8_t* outlier, double* chi2_scratch, int* inliers, int max_edges, hipStream_t st) {
     if (nprobs <= 0) return;
-    // the correspondences of a frame in LDS when they fit (2048: 150 KB).  The block is sized from the batch's largest frame, not in two
+    // the correspondences of a frame in LDS when they fit (2048: 125 KB).  The block is sized from the batch's largest frame, not in two
     // classes: a workgroup lives for the whole optimisation (milliseconds), and what it does not take of its CU's 160 KB the other stages'
-    // kernels can (1200 correspondences: 88 KB instead of 150; <= 1088: two workgroups per CU).  TC2LI_PO_LDS_CLASSES=1: the two classes (A/B).
+    // kernels can (1200 correspondences: 73 KB; <= 1311: two workgroups per CU).  TC2LI_PO_LDS_CLASSES=1: the two classes (A/B).
     static const bool kClasses = getenv("TC2LI_PO_LDS_CLASSES") && atoi(getenv("TC2LI_PO_LDS_CLASSES")) != 0;
     const int cap = kClasses ? (max_edges <= 1024 ? 1024 : 2048) : std::max(64, (max_edges + 63) / 64 * 64);
     if (max_edges <= 2048 && ensure_dynamic_lds((const void*)k_pose_optimization_lds, 2048 * kPoLdsPerEdge + 64)) {
