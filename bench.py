@@ -323,7 +323,7 @@ def compact_line(full, detail_path=None):
         line["host_fed"] = _pick(full["host_fed"], ("value", "ms_per_step", "GB_per_step", "link_GBps"))
     ic = full.get("inertial_config")
     if isinstance(ic, dict):
-        line["inertial_config"] = {**_pick(ic, ("value", "unit", "ms_per_step", "sequences", "steps", "lviba_windows_per_step")),
+        line["inertial_config"] = {**_pick(ic, ("value", "unit", "ms_per_step", "sequences", "steps", "lviba_windows_per_step", "lviba_window")),
                                    "roofline": compact_roofline(ic.get("roofline")), "cpu_baseline": compact_cpu(ic.get("cpu_baseline")),
                                    "single_sequence": _pick(ic.get("single_sequence") or {}, ("value", "ms_per_frame"))}
     mf = full.get("mfma_config")
@@ -1781,6 +1781,7 @@ def main(argv=None):
             cpu_i = cpu_baseline_inertial(wl, il, args, F)
         inertial = {"value": round(F * n_i / dti, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dti / n_i, 3), "sequences": F, "steps": n_i,
                     "lviba_windows_per_step": round(ba_windows_i / n_i, 2), "stage_thread_ms_per_step_concurrent": thread_ms_i,
+                    "lviba_window": "bLarge: 25 keyframes x 4 iterations (LocalMapping.cc:156); IMU-initialised camera path" if lvi_large else "10 keyframes x 10 iterations",
                     "workload": "configs[3], camera-LiDAR-inertial, %d batched sequences, one frame of every sequence per step: ORB + stereo matching, "
                                 "the IMU prediction in place of TrackWithMotionModel, SearchLocalPoints + IMU pre-integration + PoseInertialOptimizationLastFrame (batched; the "
                                 "camera path with the IMU initialised, Tracking.cc:2746, 2857); LidarInertialProcess for all scans in one call "
