@@ -496,7 +496,7 @@ __device__ __forceinline__ void point_dinv(const BaProblemDev& pb, int l, double
 // edge with a free pose: the edge's part of sum_l W D^-1 b_l (k_ba_reduce_coef adds a pose's edges in its edge order).  Rounds 1-4 also
 // scattered W D^-1 and W into two dense k-major operands [3 P][np_pad] here (11.5 MB per 25-keyframe window, 29 % non-zero, written
 // every trial and read back by the GEMM); round 5 builds the operand panels in LDS instead (d_ba_schur_units).
-__device__ __forceinline__ void d_ba_schur_coef(const BaProblemDev& pb, const int bx, double lambda) {
+__device__ __forceinline__ void d_ba_schur_coef(const BaProblemDev& pb, const int bx, double lambda, const bool write_Y) {
     const int s = bx * 256 + threadIdx.x;
     if (s >= pb.n_free_edges) return;
     const int e = pb.fl_edge[s], l = pb.fl_lm[s];
@@ -512,9 +512,11 @@ __device__ __forceinline__ void d_ba_schur_coef(const BaProblemDev& pb, const in
         for (int k = 0; k < 3; ++k) Y[3 * r + k] = W[3 * r] * Di[k] + W[3 * r + 1] * Di[3 + k] + W[3 * r + 2] * Di[6 + k];  // (W D^-1)[r][k]: the expression of rounds 1-4's prepare kernel
     }
     store_d2<6>(pb.coef_e + 6 * (size_t)e, ce);
-    store_d2<18>(pb.Y + 18 * (size_t)s, Y);  // the product's first operand, slot by slot (144 B per slot: the units that need it load it instead of inverting again)
+    // the product's first operand, slot by slot, for the 64 x 64 units (144 B per slot: they load it instead of inverting again); the full-width form
+    // rebuilds it from W and the landmark's block while it stages the slot (d_ba_schur_full): a third of that kernel's bytes less, and none here
+    if (write_Y) store_d2<18>(pb.Y + 18 * (size_t)s, Y);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_coef(BaProblemDev pb, double lambda) { d_ba_schur_coef(pb, blockIdx.x, lambda); }
+__global__ __launch_bounds__(256) void k_ba_schur_coef(BaProblemDev pb, double lambda, int write_Y) { d_ba_schur_coef(pb, blockIdx.x, lambda, write_Y != 0); }
 
 __device__ __forceinline__ void d_ba_reduce_coef(const BaProblemDev& pb, const int bx) {
     __shared__ double s_part[128 * 6];
@@ -681,9 +683,10 @@ constexpr int kFullTilesMax = 11, kFullThreads = 512, kFullTilesPerWave = 9;   /
 struct FullLds {
     double A[kFullTilesMax][kUnitRows][16], B[kFullTilesMax][kUnitRows][16];
     unsigned short idx[kUnitIdx];
+    int lm[kUnitIdx];            // the slots' landmarks
     int off[kUnitMaxChunks + 1];
 };
-__device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const int slice, const int chunks_per_slice, FullLds& L) {
+__device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const int slice, const int chunks_per_slice, const double lambda, FullLds& L) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = pb.np_pad / 16, n_lower = tiles * (tiles + 1) / 2, n_chunks = pb.n_schur_slices;
     int my_ti[kFullTilesPerWave], my_tj[kFullTilesPerWave];
@@ -710,21 +713,38 @@ __device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const in
     clear_panels();
     __syncthreads();
     const int S0 = L.off[0], S1 = L.off[nc];
-    for (int s = S0 + tid; s < min(S1, S0 + kUnitIdx); s += kFullThreads) L.idx[s - S0] = (unsigned short)(pb.fl_pose[s] | pb.fl_place[s] << 8);
+    for (int s = S0 + tid; s < min(S1, S0 + kUnitIdx); s += kFullThreads) { L.idx[s - S0] = (unsigned short)(pb.fl_pose[s] | pb.fl_place[s] << 8); L.lm[s - S0] = pb.fl_lm[s]; }
     __syncthreads();
     auto slot_index = [&](int s) -> unsigned { return s - S0 < kUnitIdx ? (unsigned)L.idx[s - S0] : (unsigned)(pb.fl_pose[s] | pb.fl_place[s] << 8); };
     // one slot per lane and chunk, prefetched a chunk ahead (16 landmarks x 32 poses fit the workgroup's lanes)
     int pre_p = 0, pre_col = 0;
     bool pre_on = false;
-    double preY[18], preW[18];
+    // The first operand W D^-1 is formed HERE from the slot's W block and its landmark's 3 x 3 block (point_dinv's arithmetic and
+    // d_ba_schur_coef's expression: the same bits as the Y array the 64 x 64 units read) -- 24 doubles per slot from memory instead of 36: with a
+    // batch's 256 workgroups loading at once the kernel is bound by those bytes (127 MB per 32-window launch), not by the 9 us of matrix work.
+    double preW[18], preH[6];
     auto load_slot = [&](int s) {
         const unsigned ix = slot_index(s);
         pre_p = (int)(ix >> 8);
         pre_col = 6 * (int)(ix & 255u);
-        load_d2<18>(pb.Y + 18 * (size_t)s, preY);
+        const int l = s - S0 < kUnitIdx ? L.lm[s - S0] : pb.fl_lm[s];
         load_d2<18>(pb.W + 18 * (size_t)s, preW);
+        load_d2<6>(pb.Hll + 6 * (size_t)l, preH);
     };
     auto put_slot = [&] {
+        double preY[18];
+        {
+            const double d00 = preH[0] + lambda, d01 = preH[1], d02 = preH[2], d11 = preH[3] + lambda, d12 = preH[4], d22 = preH[5] + lambda;
+            const double c00 = d11 * d22 - d12 * d12, c01 = d12 * d02 - d01 * d22, c02 = d01 * d12 - d11 * d02;
+            const double det = d00 * c00 + d01 * c01 + d02 * c02, id = 1.0 / det;
+            const double Di[9] = {c00 * id, (d02 * d12 - d01 * d22) * id, (d01 * d12 - d02 * d11) * id,
+                                  c01 * id, (d00 * d22 - d02 * d02) * id, (d02 * d01 - d00 * d12) * id,
+                                  c02 * id, (d01 * d02 - d00 * d12) * id, (d00 * d11 - d01 * d01) * id};
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) preY[3 * r + k] = preW[3 * r] * Di[k] + preW[3 * r + 1] * Di[3 + k] + preW[3 * r + 2] * Di[6 + k];
+        }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int col = pre_col + r;
@@ -770,9 +790,9 @@ __device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const in
         for (int r = 0; r < 4; ++r) out[(size_t)(16 * my_ti[q] + (lane >> 4) + 4 * r) * pb.np_pad + 16 * my_tj[q] + (lane & 15)] = acc[q][r];
     }
 }
-__global__ __launch_bounds__(kFullThreads) void k_ba_schur_full(BaProblemDev pb, int chunks_per_slice) {
+__global__ __launch_bounds__(kFullThreads) void k_ba_schur_full(BaProblemDev pb, int chunks_per_slice, double lambda) {
     extern __shared__ double s_full_dyn[];
-    d_ba_schur_full(pb, blockIdx.x, chunks_per_slice, *reinterpret_cast<FullLds*>(s_full_dyn));
+    d_ba_schur_full(pb, blockIdx.x, chunks_per_slice, lambda, *reinterpret_cast<FullLds*>(s_full_dyn));
 }
 __global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chunks_per_slice, double lambda) {
     __shared__ UnitsLds L;
@@ -1571,10 +1591,10 @@ __global__ __launch_bounds__(256) void k_ba_maxdiag_b(const BaPhase ph) {
     if (!(view_.flags & kBaWantMaxdiag)) return;
     d_ba_maxdiag(pb, blockIdx.x, sl.maxdiag_out);
 }
-__global__ __launch_bounds__(256) void k_ba_schur_coef_b(const BaPhase ph) {
+__global__ __launch_bounds__(256) void k_ba_schur_coef_b(const BaPhase ph, int full_form) {
     TC2LI_SLOT(y);
     if (pb.sparse_schur || (int)blockIdx.x >= blocks256(pb.n_free_edges)) return;
-    d_ba_schur_coef(pb, blockIdx.x, view_.lambda);
+    d_ba_schur_coef(pb, blockIdx.x, view_.lambda, !(full_form && pb.np_pad <= 16 * kFullTilesMax));
 }
 __global__ __launch_bounds__(256) void k_ba_reduce_coef_b(const BaPhase ph) {
     TC2LI_SLOT(y);
@@ -1586,7 +1606,7 @@ __global__ __launch_bounds__(kFullThreads) void k_ba_schur_full_b(const BaPhase 
     extern __shared__ double s_full_dyn[];
     TC2LI_SLOT(y);
     if (pb.sparse_schur || !pb.n_free || pb.np_pad > 16 * kFullTilesMax || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_full(pb, blockIdx.x, sl.k_per_slice, *reinterpret_cast<FullLds*>(s_full_dyn));
+    d_ba_schur_full(pb, blockIdx.x, sl.k_per_slice, view_.lambda, *reinterpret_cast<FullLds*>(s_full_dyn));
 }
 // the dense windows' Schur product: (unit, slice, window) = blockIdx.(x, y, z)
 __global__ __launch_bounds__(256) void k_ba_schur_units_b(const BaPhase ph) {
@@ -2209,11 +2229,12 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
     } else {
         // the dense windows (> 21 free keyframes): edge coefficients, their per-pose sums, the block-sparse MFMA product by units
         // (k_per_slice = landmark chunks per slice on this path)
-        if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda);
+        const bool full_form = pb.np_pad <= 16 * kFullTilesMax && dense_full_form();
+        if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda, full_form ? 0 : 1);
         TC2LI_LAUNCH(k_ba_reduce_coef, dim3(pb.n_free), dim3(256), 0, st, pb);
-        if (pb.np_pad <= 16 * kFullTilesMax && dense_full_form()) {
+        if (full_form) {
             (void)ensure_dynamic_lds((const void*)k_ba_schur_full, (int)sizeof(FullLds));
-            TC2LI_LAUNCH(k_ba_schur_full, dim3(n_slices), dim3(kFullThreads), sizeof(FullLds), st, pb, k_per_slice);
+            TC2LI_LAUNCH(k_ba_schur_full, dim3(n_slices), dim3(kFullThreads), sizeof(FullLds), st, pb, k_per_slice, lambda);
         } else {
             const int ub = (pb.np_pad / 16 + 3) / 4;
             TC2LI_LAUNCH(k_ba_schur_units, dim3(ub * (ub + 1) / 2, n_slices), dim3(256), 0, st, pb, k_per_slice, lambda);
@@ -2263,7 +2284,7 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
         else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
     }
     if (x.any_dense) {
-        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph);
+        if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, dense_full_form() ? 1 : 0);
         TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);
         // windows of at most 176 columns: the full-width form; wider ones (or TC2LI_BA_DENSE_FULL=0): 64 x 64 units.  Both kernels skip the
         // windows of the other kind.
