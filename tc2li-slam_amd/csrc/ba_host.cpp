@@ -751,9 +751,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
+                lambda = lm_lambda_accepted(lambda, rho);
                 ni = 2;
                 currentChi = tempChi;
                 std::swap(pb.poses, pb.poses_trial);
@@ -1208,9 +1206,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
                 scale += 1e-3;
                 rho /= scale;
                 if (rho > 0 && std::isfinite(tempChi)) {
-                    double alpha = 1. - std::pow((2 * rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    lambda *= std::max(1. / 3., alpha);
+                    lambda = lm_lambda_accepted(lambda, rho);
                     ni = 2;
                     currentChi = tempChi;
                     std::swap(pb.iposes, pb.iposes_trial);
@@ -1263,9 +1259,7 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow((2 * rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
+                lambda = lm_lambda_accepted(lambda, rho);
                 ni = 2;
                 currentChi = tempChi;
                 std::swap(pb.iposes, pb.iposes_trial);
@@ -1800,9 +1794,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
                 w.scale += 1e-3;
                 w.rho /= w.scale;
                 if (w.rho > 0 && std::isfinite(w.tempChi)) {
-                    double alpha = 1. - std::pow((2 * w.rho - 1), 3);
-                    alpha = std::min(alpha, 2. / 3.);
-                    w.lambda *= std::max(1. / 3., alpha);
+                    w.lambda = lm_lambda_accepted(w.lambda, w.rho);
                     w.ni = 2;
                     w.currentChi = w.tempChi;
                     std::swap(w.vp.pb.poses, w.vp.pb.poses_trial);  // the host's record (the results are read through it); the device's view: parity
@@ -2135,9 +2127,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
             w.scale += 1e-3;
             w.rho /= w.scale;
             if (w.rho > 0 && std::isfinite(w.tempChi)) {
-                double alpha = 1. - std::pow((2 * w.rho - 1), 3);
-                alpha = std::min(alpha, 2. / 3.);
-                w.lambda *= std::max(1. / 3., alpha);
+                w.lambda = lm_lambda_accepted(w.lambda, w.rho);
                 w.ni = 2;
                 w.currentChi = w.tempChi;
                 std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);

@@ -172,6 +172,26 @@ __host__ __device__ inline void huber(double e, double delta, float dsqr, double
     }
 }
 
+// (2 rho - 1)^3 of the Levenberg-Marquardt damping update (optimization_algorithm_levenberg.cpp:133: pow((2 * rho - 1), 3)) as one
+// correctly rounded cube: the square and the product carried in double-double (two error-free fma steps), rounded once.  The LM decision
+// runs on the host (one-window entry points) and on the device (k_ba_lm_decide_b, round 6); libm's pow and the device library's differ in the
+// last bit now and then, this form is the same IEEE operations on both sides -- a window gives the same lambda wherever its loop runs.
+__host__ __device__ inline double lm_cube(double x) {
+    if (!(x > -1e100 && x < 1e100)) return x * x * x;  // (overflow, infinities, NaN: no error terms to carry)
+    const double p = x * x;
+    const double pe = __builtin_fma(x, x, -p);   // p + pe = x^2 exactly
+    const double h = p * x;
+    const double he = __builtin_fma(p, x, -h);   // h + he = p x exactly
+    return h + (he + pe * x);
+}
+// lambda after an accepted step with gain ratio rho (:133-137)
+__host__ __device__ inline double lm_lambda_accepted(double lambda, double rho) {
+    double alpha = 1. - lm_cube(2 * rho - 1);
+    alpha = alpha < 2. / 3. ? alpha : 2. / 3.;
+    const double scale = 1. / 3. > alpha ? 1. / 3. : alpha;
+    return lambda * scale;
+}
+
 // dense LDL^T without pivoting on an n x n row-major matrix (lower triangle used, overwritten); returns false on a
 // zero / non-finite pivot, or a negative one when need_positive (Eigen::LDLT::isPositive of LinearSolverDense)
 __host__ __device__ inline bool ldlt_solve_small(double* H, int n, const double* b, double* x, bool need_positive) {

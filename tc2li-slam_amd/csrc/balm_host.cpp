@@ -223,101 +223,13 @@ void balm_build_planes(const LidarPose* twl, int W, const float* cloud, const in
     }
 }
 
-static void so3_log_f(const double* Rd, double out[3]) {  // Sophus::SO3f(R.cast<float>()).log()
-    float R[9], q[4];
-    for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
-    matrix_to_quat_f(R, q);
-    const float sq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], w = q[3];
-    float two_atan;
-    const float eps = 1e-10f;
-    if (sq < eps * eps) {
-        two_atan = 2.0f / w - (2.0f / 3.0f) * sq / (w * w * w);
-    } else {
-        const float n = sqrtf(sq);
-        if (fabsf(w) < eps) two_atan = (w > 0 ? 3.14159265358979323846f : -3.14159265358979323846f) / n;
-        else two_atan = 2.0f * atanf(n / w) / n;
-    }
-    for (int k = 0; k < 3; ++k) out[k] = (double)(two_atan * q[k]);
-}
-
-static void inverse_right_jacobian_so3(const double v[3], double J[9]) {  // SF/src/G2oTypes.cc:823-839
-    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
-    for (int k = 0; k < 9; ++k) J[k] = k % 4 == 0 ? 1.0 : 0.0;
-    if (d < 1e-5) return;
-    double Wm[9], W2[9];
-    m3_hat(v, Wm);
-    m3_mul(Wm, Wm, W2);
-    const double k2 = 1.0 / d2 - (1.0 + cos(d)) / (2.0 * d * sin(d));
-    for (int k = 0; k < 9; ++k) J[k] = J[k] + 0.5 * Wm[k] + k2 * W2[k];
-}
-
 void balm_to_camera_se3(const LidarPose* twl, int W, const SE3f& Tcl, double* JacT, double* H) {
     const int n = 6 * W;
-    // Tlc = Tcl^-1 in float, widened
-    const float qi[4] = {-Tcl.q[0], -Tcl.q[1], -Tcl.q[2], Tcl.q[3]};
-    const float nt[3] = {Tcl.t[0] * -1.f, Tcl.t[1] * -1.f, Tcl.t[2] * -1.f};
-    float tlc_f[3];
-    quat_rotate_f(qi, nt, tlc_f);
-    double Rlc[9];
-    quat_to_matrix_f(qi, Rlc);
-    const double tlc[3] = {(double)tlc_f[0], (double)tlc_f[1], (double)tlc_f[2]};
-    const double tcl[3] = {(double)Tcl.t[0], (double)Tcl.t[1], (double)Tcl.t[2]};
-    for (int i = 0; i < W; ++i) {
-        const double* Rwl = twl[i].R;
-        double Rwc[9], Rcw[9], twc[3], tcw[3], tmp[3];
-        m3_mul(Rwl, Rlc, Rwc);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rcw[3 * r + c] = Rwc[3 * c + r];
-        m3_vec(Rwl, tlc, tmp);
-        for (int k = 0; k < 3; ++k) twc[k] = tmp[k] + twl[i].p[k];
-        m3_vec(Rcw, twc, tmp);
-        for (int k = 0; k < 3; ++k) tcw[k] = -1.0 * tmp[k];
-        const double* Jw = JacT + 6 * i;
-        const double* Jt = JacT + 6 * i + 3;
-        double rwl[3], Jr[9], JrRlc[9], A[9] /* (Jr^-1 Rlc)^T */, dt[3], dth[9], RwcH[9], B[9] /* (Rwc [tcl - tcw]x)^T */;
-        so3_log_f(Rwl, rwl);
-        inverse_right_jacobian_so3(rwl, Jr);
-        m3_mul(Jr, Rlc, JrRlc);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlc[3 * c + r];
-        for (int k = 0; k < 3; ++k) dt[k] = tcl[k] - tcw[k];
-        m3_hat(dt, dth);
-        m3_mul(Rwc, dth, RwcH);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwcH[3 * c + r];
-        double AJw[3], BJt[3], Jw2[3], Jt2[3], tcwh[9], tcwhT[9], t1[3], t2[3];
-        m3_vec(A, Jw, AJw);
-        m3_vec(B, Jt, BJt);
-        for (int k = 0; k < 3; ++k) Jw2[k] = -1.0 * AJw[k] + BJt[k];
-        m3_vec(Rcw, Jt, tmp);
-        for (int k = 0; k < 3; ++k) Jt2[k] = -1.0 * tmp[k];
-        m3_hat(tcw, tcwh);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tcwhT[3 * r + c] = tcwh[3 * c + r];
-        m3_vec(Rcw, Jw2, t1);
-        m3_vec(tcwhT, Jt2, t2);
-        // D_i^T (6 x 6): rows = camera increment (rotation, translation), columns = LiDAR-pose increment
-        double DT[36] = {0}, D[36], m1[9], m2[9], m3[9];
-        m3_mul(Rcw, A, m1);
-        m3_mul(Rcw, B, m2);
-        m3_mul(tcwhT, Rcw, m3);
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                DT[6 * r + c] = -1.0 * m1[3 * r + c];
-                DT[6 * r + 3 + c] = m2[3 * r + c] + m3[3 * r + c];
-                DT[6 * (3 + r) + 3 + c] = -1.0 * Rcw[3 * r + c];
-            }
-        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[6 * r + c] = DT[6 * c + r];
-        for (int k = 0; k < 3; ++k) { JacT[6 * i + k] = t1[k] - t2[k]; JacT[6 * i + 3 + k] = Jt2[k]; }
-        // row block i <- D_i^T * row block i, then column block i <- column block i * D_i, block by block
-        for (int j = 0; j < W; ++j) {
-            double blk[36], o[36];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * i + r) * n + 6 * j + c];
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DT[6 * r + k] * blk[6 * k + c]; o[6 * r + c] = s; }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * i + r) * n + 6 * j + c] = o[6 * r + c];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * j + r) * n + 6 * i + c];
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += blk[6 * r + k] * D[6 * k + c]; o[6 * r + c] = s; }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * j + r) * n + 6 * i + c] = o[6 * r + c];
-        }
-    }
+    const BalmCameraFrame F = balm_camera_frame(Tcl);
+    std::vector<double> DT(36 * (size_t)W);
+    for (int i = 0; i < W; ++i) balm_camera_se3_D(twl[i], F, JacT + 6 * i, DT.data() + 36 * (size_t)i);
+    for (int a = 0; a < W; ++a)
+        for (int b = 0; b < W; ++b) balm_change_block(H, n, a, b, DT.data() + 36 * (size_t)a, DT.data() + 36 * (size_t)b);
 }
 
 void balm_to_body(const LidarPose* twl, int W, const SE3f& Tbl, double* JacT, double* H) {
@@ -326,44 +238,10 @@ void balm_to_body(const LidarPose* twl, int W, const SE3f& Tbl, double* JacT, do
     double Rlb[9];
     quat_to_matrix_f(qi, Rlb);
     const double tbl[3] = {(double)Tbl.t[0], (double)Tbl.t[1], (double)Tbl.t[2]};
-    for (int i = 0; i < W; ++i) {
-        const double* Rwl = twl[i].R;
-        double Rwb[9], RwbT[9], rwl[3], Jr[9], JrRlb[9], A[9] /* (Jr^-1 Rlb)^T */, th[9], RwbH[9], B[9] /* (Rwb [tbl]x)^T */;
-        m3_mul(Rwl, Rlb, Rwb);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RwbT[3 * r + c] = Rwb[3 * c + r];
-        so3_log_f(Rwl, rwl);
-        inverse_right_jacobian_so3(rwl, Jr);
-        m3_mul(Jr, Rlb, JrRlb);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlb[3 * c + r];
-        m3_hat(tbl, th);
-        m3_mul(Rwb, th, RwbH);
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwbH[3 * c + r];
-        const double Jw[3] = {JacT[6 * i], JacT[6 * i + 1], JacT[6 * i + 2]}, Jt[3] = {JacT[6 * i + 3], JacT[6 * i + 4], JacT[6 * i + 5]};
-        double AJw[3], BJt[3], RJt[3];
-        m3_vec(A, Jw, AJw);
-        m3_vec(B, Jt, BJt);
-        m3_vec(RwbT, Jt, RJt);
-        for (int k = 0; k < 3; ++k) { JacT[6 * i + k] = AJw[k] - BJt[k]; JacT[6 * i + 3 + k] = RJt[k]; }
-        double DT[36] = {0}, D[36];
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                DT[6 * r + c] = A[3 * r + c];
-                DT[6 * r + 3 + c] = -1.0 * B[3 * r + c];
-                DT[6 * (3 + r) + 3 + c] = RwbT[3 * r + c];
-            }
-        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) D[6 * r + c] = DT[6 * c + r];
-        for (int j = 0; j < W; ++j) {
-            double blk[36], o[36];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * i + r) * n + 6 * j + c];
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DT[6 * r + k] * blk[6 * k + c]; o[6 * r + c] = s; }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * i + r) * n + 6 * j + c] = o[6 * r + c];
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * j + r) * n + 6 * i + c];
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += blk[6 * r + k] * D[6 * k + c]; o[6 * r + c] = s; }
-            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * j + r) * n + 6 * i + c] = o[6 * r + c];
-        }
-    }
+    std::vector<double> DT(36 * (size_t)W);
+    for (int i = 0; i < W; ++i) balm_body_D(twl[i], Rlb, tbl, JacT + 6 * i, DT.data() + 36 * (size_t)i);
+    for (int a = 0; a < W; ++a)
+        for (int b = 0; b < W; ++b) balm_change_block(H, n, a, b, DT.data() + 36 * (size_t)a, DT.data() + 36 * (size_t)b);
 }
 
 // ---- the edge ---------------------------------------------------------------------------------------------------------

@@ -100,6 +100,66 @@ __host__ __device__ inline SE3f se3f_from_rt(const double* Rcw, const double* tc
     return o;
 }
 
+// ---- sin / cos / atanf as fixed sequences of IEEE operations --------------------------------------------------------------------------
+// The change of variables of the plane term (LidarCovisRes::ComputeJandHSE3: Sophus::SO3f::log -> atan, InverseRightJacobianSO3 -> sin, cos)
+// runs on the host for the one-window entry points and on the device for a lock-step batch whose Levenberg-Marquardt loop stays on the GPU
+// (k_ba_lm_begin_b, round 6).  libm's and the device library's functions differ in the last bit now and then; these do not: the classic
+// argument reduction + minimax polynomials (the published fdlibm kernels), every step a plain multiply / add / divide (the build has
+// -ffp-contract=off on both sides).  Accuracy below 1 ulp over the ranges used: the rotation angle in [0, 3.3] for sin / cos, any float for atanf.
+__host__ __device__ inline double det_kernel_sin(double x, double y) {  // |x| <= pi / 4, y: tail of x
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+__host__ __device__ inline double det_kernel_cos(double x, double y) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+// x in [0, ~3.4]: n = nearest multiple of pi / 2 (0, 1 or 2), remainder in two pieces
+__host__ __device__ inline void det_sincos(double x, double* s, double* c) {
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;  // pi / 2 = pio2_1 + pio2_1t (33 + 53 bits)
+    const int n = x < 0.78539816339744830962 ? 0 : x < 2.35619449019234492885 ? 1 : 2;
+    const double r = x - n * pio2_1, w = n * pio2_1t;
+    const double y0 = r - w, y1 = (r - y0) - w;
+    const double ks = det_kernel_sin(y0, y1), kc = det_kernel_cos(y0, y1);
+    if (n == 0) { *s = ks; *c = kc; }
+    else if (n == 1) { *s = kc; *c = -ks; }
+    else { *s = -ks; *c = -kc; }
+}
+__host__ __device__ inline float det_atanf(float x) {
+    const float hi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float lo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                          6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const bool neg = x < 0;
+    float a = neg ? -x : x;
+    if (!(a == a)) return x;
+    if (a >= 1.7179869184e10f) { const float z = hi[3] + lo[3]; return neg ? -z : z; }  // 2^34
+    int id = -1;
+    if (a < 0.4375f) {
+        if (a < 1.862645149e-09f) return x;  // 2^-29
+    } else if (a < 1.1875f) {
+        if (a < 0.6875f) { id = 0; a = (2.0f * a - 1.0f) / (2.0f + a); }
+        else { id = 1; a = (a - 1.0f) / (a + 1.0f); }
+    } else {
+        if (a < 2.4375f) { id = 2; a = (a - 1.5f) / (1.0f + 1.5f * a); }
+        else { id = 3; a = -1.0f / a; }
+    }
+    const float z = a * a, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) { const float r = a - a * (s1 + s2); return neg ? -r : r; }
+    const float r = (id == 0 ? hi[0] : id == 1 ? hi[1] : id == 2 ? hi[2] : hi[3]) -
+                    ((a * (s1 + s2) - (id == 0 ? lo[0] : id == 1 ? lo[1] : id == 2 ? lo[2] : lo[3])) - a);
+    return neg ? -r : r;
+}
+
 // ---- 3x3 helpers (row-major) ------------------------------------------------------------------------------------------
 __host__ __device__ inline void m3_mul(const double* a, const double* b, double* o) {
     for (int r = 0; r < 3; ++r)
@@ -120,6 +180,137 @@ __host__ __device__ inline void m3_hat(const double* v, double* o) {
 }
 __host__ __device__ inline void sym_unpack(const double* s, double* m) {
     m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[3] = s[1]; m[4] = s[3]; m[5] = s[4]; m[6] = s[2]; m[7] = s[4]; m[8] = s[5];
+}
+
+// ---- change of variables of the plane term's Jacobian / Hessian: LiDAR-pose increments -> the optimiser's vertex increments ----------------
+// (host: balm_to_camera_se3 / balm_to_body, balm_host.cpp; device: k_ba_lm_begin_b -- the same functions, the same bits)
+__host__ __device__ inline void so3_log_f(const double* Rd, double out[3]) {  // Sophus::SO3f(R.cast<float>()).log()
+    float R[9], q[4];
+    for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
+    matrix_to_quat_f(R, q);
+    const float sq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], w = q[3];
+    float two_atan;
+    const float eps = 1e-10f;
+    if (sq < eps * eps) {
+        two_atan = 2.0f / w - (2.0f / 3.0f) * sq / (w * w * w);
+    } else {
+        const float n = sqrtf(sq);
+        if (fabsf(w) < eps) two_atan = (w > 0 ? 3.14159265358979323846f : -3.14159265358979323846f) / n;
+        else two_atan = 2.0f * det_atanf(n / w) / n;
+    }
+    for (int k = 0; k < 3; ++k) out[k] = (double)(two_atan * q[k]);
+}
+__host__ __device__ inline void inverse_right_jacobian_so3(const double v[3], double J[9]) {  // SF/src/G2oTypes.cc:823-839
+    const double d2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], d = sqrt(d2);
+    for (int k = 0; k < 9; ++k) J[k] = k % 4 == 0 ? 1.0 : 0.0;
+    if (d < 1e-5) return;
+    double Wm[9], W2[9], sd, cd;
+    m3_hat(v, Wm);
+    m3_mul(Wm, Wm, W2);
+    det_sincos(d, &sd, &cd);  // (d = |log R| <= pi)
+    const double k2 = 1.0 / d2 - (1.0 + cd) / (2.0 * d * sd);
+    for (int k = 0; k < 9; ++k) J[k] = J[k] + 0.5 * Wm[k] + k2 * W2[k];
+}
+// Tlc = Tcl^-1 in float, widened (LidarCovisRes::ComputeJandHSE3, SF/src/LidarRes.cc:136-186)
+struct BalmCameraFrame { double Rlc[9], tlc[3], tcl[3]; };
+__host__ __device__ inline BalmCameraFrame balm_camera_frame(const SE3f& Tcl) {
+    BalmCameraFrame F;
+    const float qi[4] = {-Tcl.q[0], -Tcl.q[1], -Tcl.q[2], Tcl.q[3]};
+    const float nt[3] = {Tcl.t[0] * -1.f, Tcl.t[1] * -1.f, Tcl.t[2] * -1.f};
+    float tlc_f[3];
+    quat_rotate_f(qi, nt, tlc_f);
+    quat_to_matrix_f(qi, F.Rlc);
+    for (int k = 0; k < 3; ++k) { F.tlc[k] = (double)tlc_f[k]; F.tcl[k] = (double)Tcl.t[k]; }
+    return F;
+}
+// keyframe i of the window: its six entries of JacT (in place) and D_i^T (6 x 6: rows = camera increment (rotation, translation), columns =
+// LiDAR-pose increment)
+__host__ __device__ inline void balm_camera_se3_D(const LidarPose& T, const BalmCameraFrame& F, double* J6, double* DT) {
+    const double* Rwl = T.R;
+    double Rwc[9], Rcw[9], twc[3], tcw[3], tmp[3];
+    m3_mul(Rwl, F.Rlc, Rwc);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rcw[3 * r + c] = Rwc[3 * c + r];
+    m3_vec(Rwl, F.tlc, tmp);
+    for (int k = 0; k < 3; ++k) twc[k] = tmp[k] + T.p[k];
+    m3_vec(Rcw, twc, tmp);
+    for (int k = 0; k < 3; ++k) tcw[k] = -1.0 * tmp[k];
+    const double Jw[3] = {J6[0], J6[1], J6[2]}, Jt[3] = {J6[3], J6[4], J6[5]};
+    double rwl[3], Jr[9], JrRlc[9], A[9] /* (Jr^-1 Rlc)^T */, dt[3], dth[9], RwcH[9], B[9] /* (Rwc [tcl - tcw]x)^T */;
+    so3_log_f(Rwl, rwl);
+    inverse_right_jacobian_so3(rwl, Jr);
+    m3_mul(Jr, F.Rlc, JrRlc);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlc[3 * c + r];
+    for (int k = 0; k < 3; ++k) dt[k] = F.tcl[k] - tcw[k];
+    m3_hat(dt, dth);
+    m3_mul(Rwc, dth, RwcH);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwcH[3 * c + r];
+    double AJw[3], BJt[3], Jw2[3], Jt2[3], tcwh[9], tcwhT[9], t1[3], t2[3];
+    m3_vec(A, Jw, AJw);
+    m3_vec(B, Jt, BJt);
+    for (int k = 0; k < 3; ++k) Jw2[k] = -1.0 * AJw[k] + BJt[k];
+    m3_vec(Rcw, Jt, tmp);
+    for (int k = 0; k < 3; ++k) Jt2[k] = -1.0 * tmp[k];
+    m3_hat(tcw, tcwh);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) tcwhT[3 * r + c] = tcwh[3 * c + r];
+    m3_vec(Rcw, Jw2, t1);
+    m3_vec(tcwhT, Jt2, t2);
+    double m1[9], m2[9], m3[9];
+    m3_mul(Rcw, A, m1);
+    m3_mul(Rcw, B, m2);
+    m3_mul(tcwhT, Rcw, m3);
+    for (int k = 0; k < 36; ++k) DT[k] = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            DT[6 * r + c] = -1.0 * m1[3 * r + c];
+            DT[6 * r + 3 + c] = m2[3 * r + c] + m3[3 * r + c];
+            DT[6 * (3 + r) + 3 + c] = -1.0 * Rcw[3 * r + c];
+        }
+    for (int k = 0; k < 3; ++k) { J6[k] = t1[k] - t2[k]; J6[3 + k] = Jt2[k]; }
+}
+// the same for the body-frame increment of VertexPose (LidarCovisRes::ComputeJandH, SF/src/LidarRes.cc:89-128); Rlb of mTlb = mTbl.inverse()
+__host__ __device__ inline void balm_body_D(const LidarPose& T, const double Rlb[9], const double tbl[3], double* J6, double* DT) {
+    const double* Rwl = T.R;
+    double Rwb[9], RwbT[9], rwl[3], Jr[9], JrRlb[9], A[9] /* (Jr^-1 Rlb)^T */, th[9], RwbH[9], B[9] /* (Rwb [tbl]x)^T */;
+    m3_mul(Rwl, Rlb, Rwb);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RwbT[3 * r + c] = Rwb[3 * c + r];
+    so3_log_f(Rwl, rwl);
+    inverse_right_jacobian_so3(rwl, Jr);
+    m3_mul(Jr, Rlb, JrRlb);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = JrRlb[3 * c + r];
+    m3_hat(tbl, th);
+    m3_mul(Rwb, th, RwbH);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) B[3 * r + c] = RwbH[3 * c + r];
+    const double Jw[3] = {J6[0], J6[1], J6[2]}, Jt[3] = {J6[3], J6[4], J6[5]};
+    double AJw[3], BJt[3], RJt[3];
+    m3_vec(A, Jw, AJw);
+    m3_vec(B, Jt, BJt);
+    m3_vec(RwbT, Jt, RJt);
+    for (int k = 0; k < 3; ++k) { J6[k] = AJw[k] - BJt[k]; J6[3 + k] = RJt[k]; }
+    for (int k = 0; k < 36; ++k) DT[k] = 0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            DT[6 * r + c] = A[3 * r + c];
+            DT[6 * r + 3 + c] = -1.0 * B[3 * r + c];
+            DT[6 * (3 + r) + 3 + c] = RwbT[3 * r + c];
+        }
+}
+// Block (a, b) of the (6W)^2 Hessian: D_a^T H_ab D_b.  The reference walks i = 0 .. W - 1 and, for every j, replaces row block (i, j) by
+// D_i^T (i, j) and then column block (j, i) by (j, i) D_i, in place: block (a, b) is multiplied from the left first when a <= b and from
+// the right first when a > b -- the order the two roundings happen in, kept here so that the blocks can be formed independently.
+__host__ __device__ inline void balm_change_block(double* H, int n, int a, int b, const double* DTa, const double* DTb) {
+    double blk[36], o[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) blk[6 * r + c] = H[(size_t)(6 * a + r) * n + 6 * b + c];
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((pass == 0) == (a <= b)) {  // D_a^T blk
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += DTa[6 * r + k] * blk[6 * k + c]; o[6 * r + c] = s; }
+        } else {                        // blk D_b (D_b[k][c] = DTb[c][k])
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) { double s = 0; for (int k = 0; k < 6; ++k) s += blk[6 * r + k] * DTb[6 * c + k]; o[6 * r + c] = s; }
+        }
+        for (int k = 0; k < 36; ++k) blk[k] = o[k];
+    }
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) H[(size_t)(6 * a + r) * n + 6 * b + c] = blk[6 * r + c];
 }
 
 // PointCluster::transform: statistics of the same points after x -> R x + p (full 3x3 P, v, n)

@@ -189,7 +189,7 @@ __device__ __forceinline__ MapInsTask global_record(MapInsTask t) {
 void launch_map_insert(const MapInsTask* tasks, int n_tasks, hipStream_t st);
 void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, hipStream_t st);  // classify, group, apply
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st);
-void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, hipStream_t st);
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, bool any_flagged, hipStream_t st);
 void launch_map_grid_build(const MapGridTask* tasks, int n_tasks, int max_work /* max over tasks of n_old + added */, int max_cells,
                            int max_row_entries /* max over tasks of segments * kMapSegStride + 1 */, hipStream_t st);
 

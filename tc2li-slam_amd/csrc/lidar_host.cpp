@@ -1269,7 +1269,7 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
     std::vector<int> which;  // task -> index in the caller's arrays
     tasks.reserve(n_tasks);
     int max_points = 0, max_map = 0;
-    bool any_lean = false;
+    bool any_lean = false, any_flagged = false;
     const char* lean_env = getenv("TC2LI_MAP_COMPACT_LIST");
     const bool no_lean = lean_env && atoi(lean_env) == 0;
     const float ds = (float)fs;  // ikdtree.set_downsample_param(filter_size_map_min): float downsample_size
@@ -1304,13 +1304,14 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
         max_points = std::max(max_points, n);
         if (!t.lean) max_map = std::max(max_map, m->n);
         any_lean |= t.lean != 0;
+        any_flagged |= t.lean == 0;
     }
     const int nt = (int)tasks.size();
     if (nt) {
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
         TC2LI_HIP_CHECK(hipMemsetAsync(L->d_batch_overflow.p, 0, sizeof(int), st));
         launch_mapinc_lists(L->d_inc_tasks.p, nt, max_points, st);
-        launch_map_compact(L->d_inc_tasks.p, nt, max_map, any_lean, st);
+        launch_map_compact(L->d_inc_tasks.p, nt, max_map, any_lean, any_flagged, st);
         TC2LI_HIP_CHECK(hipGetLastError());
         TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
         TC2LI_HIP_CHECK(stream_wait_blocking(st));
@@ -1325,7 +1326,7 @@ int map_incremental_impl(tc2li_lidar* L, int n_tasks, const int32_t* scans, tc2l
                 // (the batch's own tasks are done with -- the stream has been waited for -- so the repeated ones take their place; their `out`
                 // pointers are those of the first pass)
                 TC2LI_HIP_CHECK(hipMemcpyAsync(L->d_inc_tasks.p, redo.data(), redo.size() * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
-                launch_map_compact(L->d_inc_tasks.p, (int)redo.size(), redo_max, false, st);
+                launch_map_compact(L->d_inc_tasks.p, (int)redo.size(), redo_max, false, true, st);
                 TC2LI_HIP_CHECK(hipGetLastError());
                 TC2LI_HIP_CHECK(hipMemcpyAsync(L->h_mapinc_out.p, L->d_mapinc_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
                 TC2LI_HIP_CHECK(stream_wait_blocking(st));
@@ -1492,7 +1493,7 @@ int tc2li_lidar_map_delete_boxes_batch(int n_maps, tc2li_lidar_map* const* maps,
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_boxes.p, boxes6, 6 * (size_t)total_boxes * sizeof(float), hipMemcpyHostToDevice, st));
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_tasks.p, tasks.data(), nt * sizeof(MapIncTask), hipMemcpyHostToDevice, st));
     launch_map_mark_boxes(ws.d_tasks.p, nt, max_map, st);
-    launch_map_compact(ws.d_tasks.p, nt, max_map, false, st);
+    launch_map_compact(ws.d_tasks.p, nt, max_map, false, true, st);
     TC2LI_HIP_CHECK(hipGetLastError());
     TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_out.p, ws.d_out.p, (size_t)nt * kMapIncOut * sizeof(int), hipMemcpyDeviceToHost, st));
     TC2LI_HIP_CHECK(stream_wait_blocking(st));  // the uploads above read the caller's and this function's host memory: done here too

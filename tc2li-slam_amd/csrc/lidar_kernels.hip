@@ -1002,6 +1002,9 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
             }
             __syncthreads();
         }
+        // every wavefront has read this level's count and ranges before they are cleared (a level whose depth budget is spent passes no
+        // other barrier: all its ranges share d and take the `continue` above)
+        __syncthreads();
         if (tid == 0) s_nact[cur] = 0;
         cur ^= 1;
         __syncthreads();

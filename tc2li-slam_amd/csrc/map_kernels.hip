@@ -749,13 +749,16 @@ void launch_mapinc_lists(const MapIncTask* tasks, int n_tasks, int max_points, h
 void launch_map_mark_boxes(const MapIncTask* tasks, int n_tasks, int max_map_points, hipStream_t st) {
     if (n_tasks && max_map_points) TC2LI_LAUNCH(k_map_mark_boxes, dim3((max_map_points + 255) / 256, n_tasks), dim3(256), 0, st, tasks);
 }
-// max_map_points: the largest map among the tasks that are NOT lean (0: every task works from its deletion list); any_lean: some task does
-void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, hipStream_t st) {
+// max_map_points: the largest map among the tasks that are NOT lean; any_lean: some task works from its deletion list; any_flagged: some
+// task does not.  k_map_keep_scan initialises out[4..13] of a task that is not lean -- also of one whose map is still EMPTY (no block to
+// count: max_map_points == 0), so it is launched for any_flagged, not for nb != 0 (such a task read the kept count and the
+// bounding box an earlier call had left in its slot).
+void launch_map_compact(const MapIncTask* tasks, int n_tasks, int max_map_points, bool any_lean, bool any_flagged, hipStream_t st) {
     if (!n_tasks) return;
     if (any_lean) TC2LI_LAUNCH(k_map_compact_list, dim3(n_tasks), dim3(1024), 0, st, tasks);
     const int nb = (max_map_points + 1023) / 1024;
     if (nb) TC2LI_LAUNCH(k_map_keep_count, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
-    if (nb) TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
+    if (any_flagged) TC2LI_LAUNCH(k_map_keep_scan, dim3(n_tasks), dim3(1024), 0, st, tasks);
     if (nb) TC2LI_LAUNCH(k_map_holes, dim3(nb, n_tasks), dim3(1024), 0, st, tasks);
     if (nb) TC2LI_LAUNCH(k_map_fill, dim3(std::min(nb * 4, 64), n_tasks), dim3(256), 0, st, tasks);
     TC2LI_LAUNCH(k_map_append, dim3(n_tasks), dim3(256), 0, st, tasks);

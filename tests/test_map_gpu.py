@@ -298,6 +298,41 @@ def test_map_incremental_batch_equals_one_map_at_a_time(pkg, oracle, synthetic):
         pkg.capi.map_incremental_batch(fe, [0, 1], [maps[0], maps[0]], upd[:2])  # a map twice in one batch
 
 
+def test_an_empty_map_beside_maps_on_the_list_path(pkg, oracle, synthetic):
+    """a map that was never built (no points, no grid: not lean) in a batch whose other maps all compact from their deletion
+    lists.  No block of the flag passes is launched for it (its map has no points), yet k_map_keep_scan must still initialise its kept count
+    and bounding box: the slot of the task list carries the words a previous call left there (here: a 10^5-point map's).  The empty map
+    ends as the oracle's map_incremental on an empty map, the others as before."""
+    import torch
+    S = 3
+    fe = pkg.LidarFrontEnd(max_points_per_scan=140000, max_scans=S)
+    scene = synthetic.Scene(2)
+    raws = [synthetic.lidar_scan(scene, f) for f in range(1, S + 1)]
+    states = np.stack([pkg.pack_lidar_state(*synthetic.lidar_state(f)[:2]) for f in range(1, S + 1)])
+    street = synthetic.lidar_map(scene, x_from=-60.0, x_to=90.0)
+    raw = np.concatenate(raws)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in raws])]).astype(np.int32)
+    dev = torch.from_numpy(raw.view(np.uint8)).cuda()
+    # first call: three built maps, so that task slot 2 is left holding a large map's kept count
+    maps = [pkg.LidarMap() for _ in range(S)]
+    for m in maps:
+        m.Build(street)
+    fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    pkg.capi.map_incremental_batch(fe, [0, 1, 2], maps, states)
+    # second call: slots 0 and 1 take the list path (their grids are maintained in place), slot 2 is a map without points
+    inits = [maps[0].points(), maps[1].points(), np.zeros(0, pkg.capi.POINT_DTYPE)]
+    maps[2] = pkg.LidarMap()
+    counts, _, _ = fe.frontend_batch(dev.data_ptr(), offs, maps, states, want_points=False)
+    na, nn, sz = pkg.capi.map_incremental_batch(fe, [0, 1, 2], maps, states)
+    for s in range(S):
+        down = oracle.voxel_grid(oracle.lidar_preprocess(raws[s]))
+        want, wa, wn = oracle.map_incremental(inits[s], down, states[s], states[s])
+        assert (na[s], nn[s], sz[s]) == (wa, wn, len(want)), s
+        assert np.array_equal(canon(maps[s].points()), canon(want)), s
+    assert 1000 < sz[2] <= counts[1][2]            # the scan's own points (one per map voxel: the insertion rule down-samples among them)
+    assert maps[0].stats()["grid_updates"] >= 1    # ... and the other two did take the list path
+
+
 def test_reference_sized_map(pkg, oracle, synthetic):
     """the reference's map holds 10^5 - 10^6 points.  Feature extraction and map_incremental against the
     ~1.9 * 10^5-point street map bench.py uses: identical neighbours, selection and inserted points as the oracle's k-d tree."""
