@@ -142,6 +142,29 @@ struct LviSolveDev {
     const double* bi;                 // [n] the right-hand side of the inertial + LiDAR part, the caller's numbering
     double *LB, *Lband;               // scratch: L of the pose rows per velocity / bias column [ni][np]; L of the band [ni][32] (entry (i, c) at [c][i - c - 1])
 };
+// ---- The Levenberg-Marquardt loop of a lock-step window ON THE DEVICE (round 6) ----
+// g2o runs solve() as one sequential loop per window (optimization_algorithm_levenberg.cpp:61-169); rounds 2-5 ran its control flow on the host,
+// one round trip per phase.  With a BaLmState per window in device memory the decisions are taken by two one-wavefront kernels:
+//   k_ba_lm_begin_b   after a linearisation: the robust cost, the LiDAR edge's state machine (EdgeLidarSE3: r1 / r2 / is_calc_hess) and the change
+//                     of variables of its Jacobian / Hessian (LidarCovisRes::ComputeJandHSE3) into the window's (6K)^2 block, computeLambdaInit;
+//   k_ba_lm_decide_b  after a trial: computeScale's pose part, the gain ratio, accept / reject, the damping update, the stop rules of
+//                     OptimizableGraph / the reference's `_nBad >= 3`, and what the window needs next (status).
+// Every batched kernel reads lambda and the parity of the window's two estimate buffers from the state and runs only for a window whose status
+// is the one its phase expects (BaPhase::expect), so the host can queue rounds AHEAD of the device -- a round = [linearisation set (windows in
+// kLmIterate) | trial set (windows in kLmTrial)] -- and reads one status word per window and round from a pinned mirror, where it also polls
+// the caller's stop flag (g2o's terminate()).  The arithmetic is the host loop's, operation for operation (lm_lambda_accepted, the sums' order):
+// a window gives the same bits here, in the host-driven lock-step loop and in the one-window entry points.
+constexpr int32_t kLmDone = 0, kLmIterate = 1, kLmTrial = 2;
+struct BaLmState {
+    double lambda, ni, currentChi, tempChi, iniChi, rho, initial_chi2;
+    double lidar_error, r1, r2;        // EdgeLidarSE3: error, the last two residuals (SF/include/G2oTypesWithLidar.h:130-139)
+    int32_t status, parity;            // parity 1: the accepted estimate lives in the slot's trial buffers
+    int32_t qmax, trials_total, n_bad, it, done, ok;
+    int32_t is_calc_hess, hessian_evaluations;
+    int32_t solve_ok, rounds;          // solve_ok: k_ba_solve_b's pivots were usable; rounds: decide kernels that ran for this window
+};
+static_assert(sizeof(BaLmState) == 128, "BaLmState is mirrored to the host as sixteen 8-byte words");
+
 struct BaBatchSlot {
     BaProblemDev pb;       // poses / points = the buffers the call starts from (BaPhase's parity bit swaps them with the trial buffers)
     int32_t n_slices, k_per_slice, has_lidar, pad_;
@@ -159,6 +182,13 @@ struct BaBatchSlot {
     const double* xp;      // the step when the phase's staging area does not hold it (a window of more than kBaXpStride / 6 free poses; device solve)
     uint8_t* depth_out;
     BalmDev balm;
+    // device-side LM (NULL: lambda / parity come with the phase, the host decides)
+    BaLmState* lm;            // device
+    BaLmState* lm_host;       // pinned mirror, written by k_ba_lm_decide_b
+    const int32_t* stop_host; // pinned: nonzero once the host has seen the caller's stop flag
+    double* lidar_JH;         // [6W | (6W)^2]: the LiDAR edge's Jacobian / Hessian in the vertices' increments, kept while is_calc_hess is false
+    double lambda_init, lidar_information;
+    int32_t iterations, lm_pad_;
 };
 // The windows of one launch and their state in this phase, passed BY VALUE in the kernel arguments (HIP gives a kernel 4 KB of them):
 // workgroups of window position y = blockIdx.y (z for the tiled GEMM) work on table[win[y]].
@@ -168,6 +198,7 @@ struct BaPhase {
     const BaBatchSlot* table;      // the call's table in device memory
     const double* xp_area;         // steps of a trial phase, window position y at (first + y) * kBaXpStride; NULL: slot.xp
     int32_t first, pad_;           // position of win[0] in the phase's list
+    int32_t expect, pad2_;         // device-side LM: the kernels of this launch run for windows whose BaLmState::status equals `expect` (0: for all)
     uint16_t win[kBaPhaseMax];
     uint8_t flags[kBaPhaseMax];    // kBaAcceptedInTrial: the accepted estimate lives in the trial buffers (an odd number of accepted steps);
                                    // kBaWantMaxdiag: computeLambdaInit's diagonal maxima; kBaWantHpp: Hpp / b_p to slot.hpp_out
@@ -199,6 +230,9 @@ void lvi_batch_launch_solve(const BaPhase& ph, int n_active, int max_np, int max
 void lvi_launch_solve(const LviSolveDev& q, const double* S, const double* bs, double lambda, double* x_dev, double* x_host, int32_t* ok_host, hipStream_t st);
 void ba_batch_launch_trial(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
 void ba_batch_launch_depth(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st);
+// device-side LM (ba_lm_kernels.hip): one wavefront per window of the phase
+void ba_batch_launch_lm_begin(const BaPhase& ph, int n_active, hipStream_t st);
+void ba_batch_launch_lm_decide(const BaPhase& ph, int n_active, hipStream_t st);
 // the LiDAR term of the listed windows (all with W <= 7 and at most 2048 planes): residual at the accepted or the trial poses,
 // Jacobian / Hessian at the accepted poses
 void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st);
@@ -234,6 +268,21 @@ __device__ __forceinline__ void ba_problem_pointers_are_global(BaProblemDev& pb)
 // loads, and everything addressed through their result would be fetched per lane (readfirstlane: the value is the same in every lane)
 __device__ __forceinline__ int ba_phase_window(const BaPhase& ph, int pos) { return __builtin_amdgcn_readfirstlane((int)ph.win[pos]); }
 __device__ __forceinline__ unsigned ba_phase_flags(const BaPhase& ph, int pos) { return (unsigned)__builtin_amdgcn_readfirstlane((int)ph.flags[pos]); }
+// What a batched kernel needs of the window's LM state (device-side LM): whether the launch is meant for the window now, the parity / request
+// bits in BaPhase::flags' encoding, lambda.  Scalar loads: the state was written by an earlier launch of the stream (k_ba_lm_begin_b /
+// k_ba_lm_decide_b / the call's upload), never by this one.
+struct BaLmView { bool active; unsigned flags; double lambda; };
+__device__ __forceinline__ BaLmView ba_lm_view(const BaPhase& ph, const BaBatchSlot* sl, unsigned phase_flags, double phase_lambda) {
+    const BaLmState* lm = load_uniform(&sl->lm);
+    if (!lm) return BaLmView{true, phase_flags, phase_lambda};
+    const int32_t status = load_uniform(&lm->status), parity = load_uniform(&lm->parity), it = load_uniform(&lm->it);
+    const double lambda_init = load_uniform(&sl->lambda_init);
+    BaLmView v;
+    v.active = ph.expect == 0 || status == ph.expect;
+    v.flags = (parity ? kBaAcceptedInTrial : 0u) | (it == 0 && !(lambda_init > 0) ? kBaWantMaxdiag : 0u);
+    v.lambda = load_uniform(&lm->lambda);
+    return v;
+}
 #endif
 
 #if defined(__HIPCC__)

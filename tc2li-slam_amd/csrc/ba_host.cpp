@@ -87,6 +87,8 @@ struct BaWorkspace {
     PinnedBuf<uint8_t> h_result;  // lock-step batch: poses, points, per-edge chi2 and depth flags on their way to the caller
     // lock-step batch with the reduced system solved on the device: S, [b_s | b_p], the step; the LiDAR term's Hessian | gradient on both sides
     DevBuf<double> d_S, d_bs, d_xp, d_Hl;
+    // device-side LM (round 6): the kernels' scalar sums, the LiDAR term's output record and its camera-se3 Jacobian / Hessian stay in device memory
+    DevBuf<double> d_scal, d_balm_out, d_lidar_JH;
     PinnedBuf<double> h_Hl;
     PinnedBuf<int32_t> h_ok;
     BalmTerm lidar;
@@ -1326,9 +1328,9 @@ struct LockstepWindow {
 
 // The windows `list[c0 .. c1)` of a phase as kernel arguments (ba_device.hpp BaPhase): table index, parity / request bits, lambda.
 template <typename Win>
-BaPhase make_phase(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, size_t c0, size_t c1) {
+BaPhase make_phase(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, size_t c0, size_t c1, int expect = 0) {
     BaPhase ph;
-    ph.table = d_table; ph.xp_area = d_xp_area; ph.first = (int32_t)c0; ph.pad_ = 0;
+    ph.table = d_table; ph.xp_area = d_xp_area; ph.first = (int32_t)c0; ph.pad_ = 0; ph.expect = expect; ph.pad2_ = 0;
     for (size_t k = c0; k < c1; ++k) {
         const Win& w = W[list[k]];
         ph.win[k - c0] = (uint16_t)list[k];
@@ -1339,10 +1341,10 @@ BaPhase make_phase(const BaBatchSlot* d_table, const double* d_xp_area, const st
 }
 // fn(phase, windows in it) for every piece of at most kBaPhaseMax windows of `list`
 template <typename Win, typename Fn>
-void for_phase_pieces(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, Fn&& fn) {
+void for_phase_pieces(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, Fn&& fn, int expect = 0) {
     for (size_t c0 = 0; c0 < list.size(); c0 += kBaPhaseMax) {
         const size_t c1 = std::min(list.size(), c0 + (size_t)kBaPhaseMax);
-        const BaPhase ph = make_phase(d_table, d_xp_area, W, list, c0, c1);
+        const BaPhase ph = make_phase(d_table, d_xp_area, W, list, c0, c1, expect);
         fn(ph, (int)(c1 - c0));
     }
 }
@@ -1360,8 +1362,16 @@ struct LockstepContext {
     PinnedBuf<BalmCutTask> h_cut, h_cut_list;
     DevBuf<BalmCutTask> d_cut_list;
     PinnedBuf<CopyTask> h_cut_copies;
+    // device-side LM: the windows' states (device), their initial values and the mirror the decide kernel writes (pinned), the stop words
+    DevBuf<BaLmState> d_lm;
+    PinnedBuf<BaLmState> h_lm_init, h_lm;
+    PinnedBuf<int32_t> h_stop;
+    hipEvent_t round_done[2] = {nullptr, nullptr};
     hipStream_t st = nullptr;
-    ~LockstepContext() { if (st) (void)hipStreamDestroy(st); }
+    ~LockstepContext() {
+        for (hipEvent_t e : round_done) if (e) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+    }
 };
 struct LockstepContexts { LockstepContext c[kMaxLockstepGroups]; };
 LockstepContext& lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 0>().c[group]; }
@@ -1399,7 +1409,7 @@ bool plane_extraction_finish(LockstepContext& C, int n, std::vector<int>& rc_lid
     bool any = false;
     for (int i = 0; i < n; ++i) any |= C.h_cut.p[i].n_points > 0;
     if (!any) return true;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    if (stream_wait_blocking(st) != hipSuccess) return false;
     for (int i = 0; i < n; ++i) {
         if (C.h_cut.p[i].n_points <= 0 || rc_lidar[i] < 0) continue;
         rc_lidar[i] = C.ws[i]->lidar.finish_cut(st);
@@ -1486,10 +1496,13 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         w.x.assign(std::max(np, 1), 0.0);
         BaWorkspace& ws = *w.ws;
         const size_t nn = (size_t)std::max(np * np, 1), n1 = (size_t)std::max(np, 1);
-        if (ws.d_S.ensure(nn) != hipSuccess || ws.d_bs.ensure(2 * n1) != hipSuccess || ws.d_xp.ensure(n1) != hipSuccess || ws.h_ok.ensure(1) != hipSuccess) {
+        if (ws.d_S.ensure(nn) != hipSuccess || ws.d_bs.ensure(2 * n1) != hipSuccess || ws.d_xp.ensure(n1) != hipSuccess || ws.h_ok.ensure(1) != hipSuccess ||
+            ws.d_scal.ensure(8) != hipSuccess) {
             w.rc = TC2LI_ERR_HIP; return;
         }
         if (p.lidar) {
+            const size_t nl = 6 * (size_t)p.lidar->n_keyframes;
+            if (ws.d_balm_out.ensure((size_t)balm_out_size(p.lidar->n_keyframes)) != hipSuccess || ws.d_lidar_JH.ensure(nl + nl * nl) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
             // computeLambdaInit with a LiDAR term reads the diagonal of Hpp on the host (first iteration, no lambda given): where the reduction writes it
             if (ws.h_Hpp.ensure(27 * (size_t)std::max(w.vp.n_free, 1)) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
             if (ws.d_Hl.ensure(nn + n1) != hipSuccess || ws.h_Hl.ensure(nn + n1) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
@@ -1565,10 +1578,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // solve stays the default.
     const char* dev_solve_env = getenv("TC2LI_BA_DEVICE_SOLVE");
     const bool dev_solve = dev_solve_env && atoi(dev_solve_env) != 0 && !X.any_dense && X.max_free > 0;
+    // TC2LI_BA_DEVICE_LM=0: the Levenberg-Marquardt decisions of rounds 2-5, on the host between the phases.  Default (round 6): on
+    // the device (ba_device.hpp: BaLmState) for every batch whose reduced systems the solve kernel takes -- all windows on the sparse Schur path.
+    const char* device_lm_env = getenv("TC2LI_BA_DEVICE_LM");  // (read per call: the tests run both forms in one process)
+    const bool device_lm = !(device_lm_env && atoi(device_lm_env) == 0) && !X.any_dense && !X.any_trial_fused;
+    if (device_lm && (C.d_lm.ensure(n) != hipSuccess || C.h_lm_init.ensure(n) != hipSuccess || C.h_lm.ensure(n) != hipSuccess || C.h_stop.ensure(n) != hipSuccess)) return false;
     auto fill_slot = [&](int i) {
         LockstepWindow& w = W[i];
         BaBatchSlot& s = h_slots[i];
         s.pb = w.vp.pb;
+        s.lm = nullptr; s.lm_host = nullptr; s.stop_host = nullptr; s.lidar_JH = nullptr; s.lambda_init = w.p->lambda_init; s.lidar_information = 0;
+        s.iterations = w.p->iterations; s.lm_pad_ = 0;
         s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
         double* sc = w.ws->h_scal.p;
         s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
@@ -1583,6 +1603,28 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (w.lidar) { s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn; }
         }
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
+        if (device_lm) {
+            // everything a phase leaves for the next one stays in device memory; the decide kernel mirrors the window's state to the host
+            const size_t nn = (size_t)w.vp.np * w.vp.np;
+            double* sc = w.ws->d_scal.p;
+            s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
+            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = nullptr; s.hpp_out = nullptr;
+            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = nullptr;
+            s.lm = C.d_lm.p + i; s.lm_host = C.h_lm.p + i; s.stop_host = C.h_stop.p + i;
+            s.ok_host = &s.lm->solve_ok;
+            if (w.lidar) {
+                s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn;
+                s.balm.out = w.ws->d_balm_out.p;
+                s.lidar_JH = w.ws->d_lidar_JH.p;
+                s.lidar_information = w.lidar->information;
+            }
+            BaLmState& m = C.h_lm_init.p[i];
+            m = BaLmState{};
+            m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
+            m.status = w.wants_iteration() ? kLmIterate : kLmDone;
+            C.h_lm.p[i] = m;
+            C.h_stop.p[i] = 0;
+        }
     };
     // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
     // (a pool dispatch costs more than it saves, and far more on a busy host)
@@ -1594,12 +1636,15 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     bool failed = false;
     // the table and everything the setup deferred (uploads, operand fills): one launch; the windows' megabyte input blocks go through the copy engines (launch_copy_tasks)
     {
-        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) fill_slot(i); else h_slots[i] = BaBatchSlot{};
-        size_t n_tasks = 1, max_bytes = table_bytes;
+        for (int i = 0; i < n; ++i)
+            if (W[i].rc >= 0) fill_slot(i);
+            else { h_slots[i] = BaBatchSlot{}; if (device_lm) { C.h_lm_init.p[i] = BaLmState{}; C.h_lm.p[i] = BaLmState{}; C.h_stop.p[i] = 0; } }
+        size_t n_tasks = device_lm ? 2 : 1, max_bytes = std::max(table_bytes, device_lm ? (size_t)n * sizeof(BaLmState) : (size_t)0);
         for (const auto& d : deferred) n_tasks += d.size();
         if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
         size_t at = 0;
         C.h_tasks.p[at++] = CopyTask{C.d_table.p, C.h_table.p, table_bytes};
+        if (device_lm) C.h_tasks.p[at++] = CopyTask{C.d_lm.p, C.h_lm_init.p, (size_t)n * sizeof(BaLmState)};
         for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
         launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
     }
@@ -1621,11 +1666,76 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
     };
     auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
+    auto pieces_for = [&](const std::vector<int>& list, int expect, auto&& fn) { for_phase_pieces(d_table, (const double*)nullptr, W, list, fn, expect); };
     // (the group's thread spins on its stream between the phases: sleeping on a blocking event instead was measured in round 4 -- the same host
     // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
-    auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
+    auto sync = [&] { if (hipGetLastError() != hipSuccess || (device_lm ? stream_wait_blocking(st) : hipStreamSynchronize(st)) != hipSuccess) failed = true; };
 
-    for (;;) {
+    // ---- device-side LM: rounds queued ahead of the device, one status read per window and round ----
+    // A round = [linearisation set: the windows in kLmIterate | trial set: the windows in kLmTrial]; a window that accepted its step takes both
+    // halves of the next round, one that rejected it only the second, each at its own pace.  The host's lists are what it last SAW alive -- a
+    // superset: the kernels themselves skip a window whose status is not the launch's -- so round r + 1 is queued before round r has been
+    // waited for and the device never idles on the host; the wait is a sleeping one (no spinning thread per group: 2.8 of the 13 CPUs the
+    // loop kept busy in round 5), and the reduced solves, the LiDAR term's change of variables and the LM bookkeeping (5.3 more) are gone
+    // from the pool threads.  The caller's stop flag is polled at every round and handed to the decide kernel through a pinned word.
+    if (device_lm) {
+        for (hipEvent_t& e : C.round_done)
+            if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = true; }
+        std::vector<int> live, live_lidar;
+        bool first_maxdiag = false;
+        auto refresh = [&] {
+            live.clear(); live_lidar.clear();
+            for (int i = 0; i < n; ++i)
+                if (W[i].rc >= 0 && C.h_lm.p[i].status != kLmDone) { live.push_back(i); if (W[i].lidar) live_lidar.push_back(i); }
+        };
+        refresh();
+        for (int i : live) first_maxdiag |= !(W[i].p->lambda_init > 0);
+        int queued = 0, seen = 0;
+        auto queue_round = [&] {
+            const bool first = queued == 0;
+            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, first && first_maxdiag, st); });
+            pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) {
+                if (first) balm_batch_launch_residual(ph, cnt, false, st);  // later the accepted estimate is the last trial: its residual and decompositions are in place
+                balm_batch_launch_hessian(ph, cnt, X, st);
+            });
+            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
+            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
+                ba_batch_launch_schur(ph, cnt, X, st);
+                ba_batch_launch_solve(ph, cnt, X, st);
+                ba_batch_launch_trial(ph, cnt, X, st);
+            });
+            pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
+            if (hipGetLastError() != hipSuccess || hipEventRecord(C.round_done[queued & 1], st) != hipSuccess) failed = true;
+            ++queued;
+        };
+        t0 = now();
+        while (!live.empty() && !failed) {
+            if (queued == seen) queue_round();
+            // one round ahead while some window cannot be finished by what is queued (it has iterations left even if every queued trial is accepted)
+            if (!failed && queued - seen < 2) {
+                bool more = false;
+                for (int i : live) more |= C.h_lm.p[i].it + (queued - seen) < W[i].p->iterations;
+                if (more) queue_round();
+            }
+            if (failed || event_wait_sleeping(C.round_done[seen & 1]) != hipSuccess) { failed = true; break; }
+            ++seen;
+            for (int i : live) if (W[i].stopped()) C.h_stop.p[i] = 1;
+            refresh();
+        }
+        if (!failed && queued > seen && event_wait_sleeping(C.round_done[(queued - 1) & 1]) != hipSuccess) failed = true;  // (a round queued ahead that found nothing to do)
+        tm[1] += now() - t0;
+        for (int i = 0; i < n && !failed; ++i) {
+            LockstepWindow& w = W[i];
+            if (w.rc < 0) continue;
+            const BaLmState& m = C.h_lm.p[i];
+            w.lambda = m.lambda; w.currentChi = m.currentChi; w.done = m.done; w.it = m.it; w.trials_total = m.trials_total; w.parity = m.parity;
+            if (m.parity) { std::swap(w.vp.pb.poses, w.vp.pb.poses_trial); std::swap(w.vp.pb.points, w.vp.pb.points_trial); }
+            if (w.p->stats && m.done > 0) { w.p->stats->initial_chi2 = m.initial_chi2; w.p->stats->final_chi2 = m.currentChi; w.p->stats->final_lambda = m.lambda; }
+            if (w.lidar) { w.lidar->error = m.lidar_error; w.lidar->hessian_evaluations = m.hessian_evaluations; }
+        }
+    }
+    for (; !device_lm;) {
         std::vector<int> active, with_lidar;
         for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
         if (active.empty() || failed) break;

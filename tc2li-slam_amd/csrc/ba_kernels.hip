@@ -1519,6 +1519,7 @@ struct BaSlotView {
     double lambda;
     unsigned flags;
     const double* xp;
+    bool active;  // device-side LM: the window's status is the one this launch is for (BaPhase::expect)
     __device__ __forceinline__ double* hpp_out() const { return (flags & kBaWantHpp) ? sl.hpp_out : nullptr; }
 };
 __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
@@ -1534,7 +1535,8 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
     lam.i[0] = __builtin_amdgcn_readfirstlane(lam.i[0]);
     lam.i[1] = __builtin_amdgcn_readfirstlane(lam.i[1]);
     const BaBatchSlot& sl = ph.table[win];
-    BaSlotView v{sl, load_uniform(&sl.pb), lam.d, flags, global_ptr(load_uniform(&sl.xp))};
+    const BaLmView lmv = ba_lm_view(ph, &sl, flags, lam.d);  // device-side LM: lambda, parity and the request bits from the window's state
+    BaSlotView v{sl, load_uniform(&sl.pb), lmv.lambda, lmv.flags, global_ptr(load_uniform(&sl.xp)), lmv.active};
     ba_problem_pointers_are_global(v.pb);
     if (v.flags & kBaAcceptedInTrial) {
         Se3* const p = v.pb.poses; v.pb.poses = v.pb.poses_trial; v.pb.poses_trial = p;
@@ -1544,7 +1546,7 @@ __device__ __forceinline__ BaSlotView ba_slot_view(const BaPhase& ph, int pos) {
     if (ph.xp_area && 6 * v.pb.n_free <= kBaXpStride) v.xp = global_ptr(ph.xp_area) + (size_t)(ph.first + pos) * kBaXpStride;
     return v;
 }
-#define TC2LI_SLOT(axis) const BaSlotView view_ = ba_slot_view(ph, blockIdx.axis); const BaBatchSlot& sl = view_.sl; (void)sl; const BaProblemDev& pb = view_.pb
+#define TC2LI_SLOT(axis) const BaSlotView view_ = ba_slot_view(ph, blockIdx.axis); if (!view_.active) return; const BaBatchSlot& sl = view_.sl; (void)sl; const BaProblemDev& pb = view_.pb
 
 // workgroups [0, max_groups) of a window: the landmark role; [max_groups, ...): the pose role -- one launch (two before: the second
 // waited for the first to drain although neither reads what the other writes)
@@ -1724,9 +1726,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) 
     for (int i = tid; i < n; i += kSolveThreads) {
         const double v = bad ? 0.0 : xs[i];
         sl.x_dev[i] = v;
-        sl.x_host[i] = v;
+        if (sl.x_host) sl.x_host[i] = v;
     }
-    if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;
+    if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;  // (device-side LM: BaLmState::solve_ok)
 }
 // ---- The reduced system of an INERTIAL window on the device (LocalInertialBA / LocalLVIBA: 6 unknowns per free keyframe pose + 9 per keyframe with
 // velocity / bias vertices, 375 for the 25-keyframe bLarge window; Optimizer.cc:1635-1638 solves it with g2o's sparse LinearSolverEigen).  Rounds

@@ -295,11 +295,12 @@ __global__ __launch_bounds__(256) void k_balm_residual_total_b(const BaPhase ph,
     // (a trial phase's residual of a window with pb.trial_fused ran inside k_ba_trial_fused*_b)
     if (trial && load_uniform(&(ph.table + ba_phase_window(ph, blockIdx.x))->pb.trial_fused)) return;
     const BalmSlotView v = balm_slot_view(ph, blockIdx.x, trial != 0);
+    if (!v.active) return;
     d_balm_residual_total(v.b, v.poses);
 }
 __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPhase ph) {
     const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
-    if ((int)blockIdx.x >= v.b.n_chunks) return;
+    if (!v.active || (int)blockIdx.x >= v.b.n_chunks) return;
     __shared__ HessLds<kHessPlanesSmall, 8> lds;
     d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8>(v.b, v.poses, blockIdx.x, lds);
 }
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(kHessThreadsSmall) void k_balm_hessian_b(const BaPh
     __global__ __launch_bounds__(kHessThreadsSmall) __attribute__((amdgpu_waves_per_eu(waves, waves))) void name(const BaPhase ph, int fuse) { \
         extern __shared__ double s_hess_dyn[];                                                                                               \
         const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);                                                                        \
-        if ((int)blockIdx.x >= v.b.n_chunks) return;                                                                                         \
+        if (!v.active || (int)blockIdx.x >= v.b.n_chunks) return;                                                                            \
         auto& L = *reinterpret_cast<HessLds<kHessPlanesSmall, 8>*>(s_hess_dyn);                                                              \
         /* one instantiation of the body: the partials always leave at device scope (harmless before the separate combine launch) */         \
         d_balm_hessian<kItemsSmall, kHessThreadsSmall, kHessPlanesSmall, 8, 8, true, true>(v.b, v.poses, blockIdx.x, L);                      \
@@ -326,7 +327,7 @@ TC2LI_HESS_LEAN_KERNEL(k_balm_hessian_lean4_b, 4)  // 128 registers, 84 values i
 #undef TC2LI_HESS_LEAN_KERNEL
 __global__ __launch_bounds__(256) void k_balm_combine_b(const BaPhase ph) {
     const BalmSlotView v = balm_slot_view(ph, blockIdx.y, false);
-    if ((int)blockIdx.x >= (max(balm_part_stride_dev(v.b.W), 12 * v.b.W) + 255) / 256) return;
+    if (!v.active || (int)blockIdx.x >= (max(balm_part_stride_dev(v.b.W), 12 * v.b.W) + 255) / 256) return;
     d_balm_combine(v.b, blockIdx.x);
 }
 void balm_batch_launch_residual(const BaPhase& ph, int n, bool trial, hipStream_t st) {

@@ -73,12 +73,14 @@ __device__ __forceinline__ void d_balm_residual_total(const BalmDev& b, const Se
 }
 // the poses of the window at position `pos` of the phase: the accepted estimate or the trial one (the phase's parity bit says which of
 // the slot's two buffers holds the accepted estimate)
-struct BalmSlotView { BalmDev b; const Se3* poses; };
+struct BalmSlotView { BalmDev b; const Se3* poses; bool active; };
 __device__ __forceinline__ BalmSlotView balm_slot_view(const BaPhase& ph, int pos, bool trial) {
     __builtin_amdgcn_s_setprio(3);
     const BaBatchSlot* const sl = ph.table + ba_phase_window(ph, pos);
-    const bool second = trial != ((ba_phase_flags(ph, pos) & kBaAcceptedInTrial) != 0);
+    const BaLmView lmv = ba_lm_view(ph, sl, ba_phase_flags(ph, pos), 0.0);  // device-side LM: the parity from the window's state
+    const bool second = trial != ((lmv.flags & kBaAcceptedInTrial) != 0);
     BalmSlotView v;
+    v.active = lmv.active;
     v.b = load_uniform(&sl->balm);  // (scalar loads: the record lives in SGPRs, not in every lane's registers)
     if (load_uniform(&sl->pb.inertial)) v.poses = reinterpret_cast<const Se3*>(second ? load_uniform(&sl->pb.iposes_trial) : load_uniform(&sl->pb.iposes));
     else v.poses = second ? load_uniform(&sl->pb.poses_trial) : load_uniform(&sl->pb.poses);

@@ -3,9 +3,12 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <ctime>
 #if defined(__linux__)
 #include <pthread.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #endif
 
 namespace tc2li {
@@ -34,6 +37,34 @@ bool device_ready() {
     return true;
 }
 
+// Waiting for the GPU without holding a core (round 6).  hipEventSynchronize on a hipEventBlockingSync event -- what this function did in
+// rounds 2-5 -- does not sleep on this runtime: every waiting thread showed 0.6-1.0 CPU-seconds per second in /proc (the five stage threads
+// and the three lock-step groups of the bench: 6 of the 13 CPUs the loop kept busy).  Now: record an event, look at it (hipEventQuery) for
+// the first 250 us -- the waits of a one-sequence call end there: with 40 us one host-fed sequence read 547 frames/s against 826 spinning -- and then between real sleeps that grow from 30 to
+// 200 us (the thread's timer slack set to 1 us once, so that a 30 us sleep is not rounded up to 80).  TC2LI_SPIN_WAIT=1: hipStreamSynchronize.
+hipError_t event_wait_sleeping(hipEvent_t ev) {
+#if defined(__linux__)
+    static thread_local bool slack_set = false;
+    if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL); slack_set = true; }
+#endif
+    static const int spin_us = getenv("TC2LI_WAIT_SPIN_US") ? std::max(0, atoi(getenv("TC2LI_WAIT_SPIN_US"))) : 250;
+    const auto t0 = std::chrono::steady_clock::now();
+    long nap_ns = 30000;
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();  // (hipErrorNotReady is sticky in hipGetLastError otherwise)
+        if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < spin_us) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            continue;
+        }
+        struct timespec ts = {0, nap_ns};
+        (void)nanosleep(&ts, nullptr);
+        nap_ns = std::min(200000L, nap_ns + nap_ns / 2);
+    }
+}
 hipError_t stream_wait_blocking(hipStream_t st) {
     struct Ev {
         hipEvent_t e = nullptr;
@@ -43,12 +74,12 @@ hipError_t stream_wait_blocking(hipStream_t st) {
     static const bool spin = getenv("TC2LI_SPIN_WAIT") != nullptr;  // A/B switch for measurements
     if (spin) return hipStreamSynchronize(st);
     if (!ev.e) {
-        hipError_t e = hipEventCreateWithFlags(&ev.e, hipEventBlockingSync | hipEventDisableTiming);
+        hipError_t e = hipEventCreateWithFlags(&ev.e, hipEventDisableTiming);
         if (e != hipSuccess) { ev.e = nullptr; return hipStreamSynchronize(st); }
     }
     hipError_t e = hipEventRecord(ev.e, st);
     if (e != hipSuccess) return e;
-    return hipEventSynchronize(ev.e);
+    return event_wait_sleeping(ev.e);
 }
 
 hipStream_t private_stream() {
@@ -244,14 +275,16 @@ int host_thread_budget() {
 
 // Threads of pool `id` under the budget B of this process.  B counts the CPUs the process may really use (bench.py / a caller passes
 // min(affinity, cgroup quota) / ranks on the node); a pool thread spends part of its time waiting for its stream, so the pools may hold
-// TC2LI_HOST_THREADS_PER_CPU (default 8) threads per CPU in all (measured on the one-GPU box, 16 CPUs by cgroup quota, A/B pairs in one call:
-// 2 per CPU -- 3 threads per lock-step group -- 27.3 / 28.7 ms per step of the whole loop, 16 per CPU -- the pool sizes of rounds 2-4 -- 26.1 /
-// 26.0: the per-window host steps of a group's 43 windows want more threads than CPUs, they wait on each other's launches).  The stage threads of a caller like the reference (tracking, LiDAR, local
+// TC2LI_HOST_THREADS_PER_CPU (default 3 since round 6; 8 in round 5) threads per CPU in all.  Round 5 measured 2 per CPU -- 3 threads per
+// lock-step group -- at 27.3 / 28.7 ms per step of the whole loop against 26.1 / 26.0 with 16: the per-window host steps between the phases of
+// a group's 43 windows wanted more threads than CPUs.  Those steps are gone (the LM loop runs on the device, ba_device.hpp: BaLmState): on the
+// 16-CPU box 8 / 3 / 2 per CPU now read 19.97-20.40 / 19.96-20.06 / 19.74-19.97 k frames/s with 110 / 40 / 26 threads and 6.0 / 4.8-5.1 / 4.0
+// CPU-seconds per second, confined to 8 CPUs 18.8-19.0 k either way (15.4 k with the host-driven loop).  The stage threads of a caller like the reference (tracking, LiDAR, local
 // mapping: counted as 5) come off first; of the rest the extractor pool may take a quarter, the tracking pool, the LiDAR pool and each
-// lock-step BA group an eighth -- with B >= 18 every pool has the size it was tuned at (32 / 16 / 16 / 16 per group: the one-GPU box's 16 CPUs
-// give 30 / 15 / 15 / 15), with 8 ranks on a node whose cgroup grants 16 CPUs in all (B = 2) 2 + 1 + 1 + 3 x 1.
+// lock-step BA group an eighth -- the one-GPU box's 16 CPUs give 10 / 5 / 5 / 5 per group (round 5: 30 / 15 / 15 / 15), 8 ranks on a node whose
+// cgroup grants 16 CPUs in all (B = 2) 1 + 1 + 1 + 3 x 1.
 int pool_threads(int id) {
-    int per_cpu = 8;
+    int per_cpu = 3;
     if (const char* s = getenv("TC2LI_HOST_THREADS_PER_CPU")) per_cpu = std::max(1, std::min(16, atoi(s)));
     const int B = std::max(1, per_cpu * host_thread_budget() - 5);
     auto share = [&](int cap, int den) { return std::max(1, std::min(cap, B / den)); };

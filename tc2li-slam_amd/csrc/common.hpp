@@ -22,10 +22,12 @@ namespace tc2li {
 void set_error(const char* fmt, ...);
 bool device_ready();
 // hipStreamSynchronize for waits that last milliseconds (the front-end stages): the calling thread sleeps on an event made with
-// hipEventBlockingSync instead of spinning on the queue -- several host threads wait on the GPU at once and a spinning thread costs
-// a whole core (the GPU boxes give a process 16).  The short waits of the bundle-adjustment loop keep spinning: a wake-up costs
-// more than one of its kernels.
+// sleeping between looks at an event instead of spinning on the queue -- several host threads wait on the GPU at once and a spinning
+// thread costs a whole core (the GPU boxes give a process 16); see common.cpp.  The host-driven lock-step BA loop (TC2LI_BA_DEVICE_LM=0)
+// keeps spinning on its short phases: a wake-up costs more than one of its kernels.
 hipError_t stream_wait_blocking(hipStream_t st);
+// the wait itself, on an event the caller has recorded: a short look, then sleeps between looks (common.cpp)
+hipError_t event_wait_sleeping(hipEvent_t ev);
 // The stream of the entry points that take none (single-scan / single-frame calls): one non-blocking stream per host thread and
 // device, so such a call never touches the NULL stream -- work on the NULL stream serialises against every blocking stream of the
 // process (the other stage threads of the caller).  nullptr (= the NULL stream) only when the stream cannot be created.

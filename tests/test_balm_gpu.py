@@ -129,19 +129,28 @@ def test_local_bundle_adjustment_batch(pkg, synthetic):
             if s[4].iterations > 0:  # the per-edge chi2 is whatever the last error evaluation left; none ran with iterations = 0
                 assert np.array_equal(r[2], s[2]), (conc, i)
             if len(s) > 5:
-                assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual
-    # the same batch with the reduced systems solved on the device (k_ba_solve_b, opt-in): the workgroup-per-window LDL^T repeats the host's
-    # operations in the host's order, so nothing changes -- trials, poses, points, per-edge chi2 bit for bit
+                assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual and r[5].hessian_evaluations == s[5].hessian_evaluations
+            assert r[4].final_chi2 == s[4].final_chi2 and r[4].final_lambda == s[4].final_lambda and r[4].initial_chi2 == s[4].initial_chi2, (conc, i)
+    # Round 6: the runs above took the Levenberg-Marquardt decisions ON THE DEVICE (k_ba_lm_begin_b / k_ba_lm_decide_b, rounds queued ahead
+    # of the device; the singles run g2o's loop on the host).  The same batch with the decisions on the host between the phases
+    # (TC2LI_BA_DEVICE_LM=0: rounds 2-5), with the host's LDL^T and with the device's (k_ba_solve_b repeats the host's operations in the host's
+    # order): nothing changes -- trials, poses, points, per-edge chi2, the LiDAR edge's residual, bit for bit.
     import os
-    os.environ["TC2LI_BA_DEVICE_SOLVE"] = "1"
-    try:
-        assert batch.run(max_concurrency=8) == len(windows)
-    finally:
-        del os.environ["TC2LI_BA_DEVICE_SOLVE"]
-    for i, s in enumerate(singles):
-        r = batch.result(i)
-        assert batch.results[i] == s[4].iterations and r[4].trials == s[4].trials, i
-        assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[3], s[3]), i
+    for env in ({"TC2LI_BA_DEVICE_LM": "0"}, {"TC2LI_BA_DEVICE_LM": "0", "TC2LI_BA_DEVICE_SOLVE": "1"}):
+        os.environ.update(env)
+        try:
+            assert batch.run(max_concurrency=8) == len(windows)
+        finally:
+            for k in env:
+                del os.environ[k]
+        for i, s in enumerate(singles):
+            r = batch.result(i)
+            assert batch.results[i] == s[4].iterations and r[4].trials == s[4].trials, (env, i)
+            assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[3], s[3]), (env, i)
+            if s[4].iterations > 0:
+                assert np.array_equal(r[2], s[2]), (env, i)
+            if len(s) > 5:
+                assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual and r[5].hessian_evaluations == s[5].hessian_evaluations, (env, i)
 
 
 def test_batch_with_a_large_window(pkg, synthetic):
