@@ -1664,72 +1664,143 @@ __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaPhase ph) {
 //   * substitutions as column sweeps by wavefront 0 (x_k is final, every other row takes its term): n steps each.  The backward sweep adds a
 //     row's terms with k DESCENDING; ldlt_solve_small (ba_math.hpp) does the same since round 5.
 constexpr int kSolveThreads = 256;
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) {
-    extern __shared__ double s_solve[];
+// Round 6: the matrix lives in REGISTERS.  Rounds 2-5 kept it in LDS and found every trailing entry's place with a double-precision square root
+// and two divisions per update: 128 us per launch whatever the batch -- a third of a lock-step round at 64 sequences per GPU, where the round IS
+// the step.  Now thread (ty, tx) = (tid / 16, tid % 16) owns entry (16 ti + ty, 16 tj + tx) of every 16 x 16 tile (ti >= tj) of the lower
+// triangle -- NT (NT + 1) / 2 doubles, NT = 5 for up to 13 free keyframes, 8 for the sparse path's limit of 21 -- and the right-hand side rides
+// along (thread (ty, 0): entry 16 ti + ty).  Column k of the right-looking elimination: its owners (the 16 threads with tx = k % 16) put their
+// entries into LDS, one thread per row divides by the pivot, and every thread takes its entries' terms (l_i l_j) d from
+// the two short LDS vectors -- two barriers per column, no index arithmetic (the tile loops are unrolled, a tile left of the column is a
+// scalar branch).  The operations per entry are the old kernel's and ldlt_solve_small's, in their order: the step is the same bit for bit.
+// Then L goes to LDS once and wavefront 0 runs the backward sweep with the solution in its registers (x_k by v_readlane).
+template <int NT>
+__device__ __forceinline__ void d_ba_solve_tiles(const BaBatchSlot& sl, const int n, double* s_L) {
+    constexpr int kTiles = NT * (NT + 1) / 2;
+    __shared__ double s_colA[16 * 8], s_colL[16 * 8], s_dg[16 * 8], s_xs[16 * 8], s_y;
     __shared__ int s_bad;
-    TC2LI_SLOT(x);
-    const int n = 6 * pb.n_free, tid = threadIdx.x;
-    if (n == 0 || !sl.x_dev) return;
-    double* L = s_solve;                    // full n x n, lower triangle used: L[i * n + j], j <= i
-    double* dg = L + (size_t)n * n;         // pivots
-    double* xs = dg + n;                    // right-hand side / solution
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // (neighbouring lanes: neighbouring columns of a row -- the loads below run along rows)
+    const double* __restrict__ S = global_ptr(load_uniform(&sl.S_out));
+    const double* __restrict__ Hl = global_ptr(load_uniform(&sl.Hl));
+    const double* __restrict__ bs = global_ptr(load_uniform(&sl.bs_out));
+    const double* __restrict__ bl = global_ptr(load_uniform(&sl.bl_lidar));
+    double a[kTiles], rhs[NT];
     if (tid == 0) s_bad = 0;
-    for (int e = tid; e < n * n; e += kSolveThreads) {
-        const int i = e / n, j = e - i * n;
-        if (j > i) continue;
-        L[e] = sl.Hl ? sl.S_out[e] + sl.Hl[e] : sl.S_out[e];
-    }
-    for (int i = tid; i < n; i += kSolveThreads) xs[i] = sl.Hl ? sl.bs_out[i] + sl.bl_lidar[i] : sl.bs_out[i];
-    __syncthreads();
-    for (int k = 0; k < n; ++k) {
-        const double d = L[k * n + k];
-        if (tid == 0) { if (!(d == d) || d == 0.0 || d - d != 0.0) s_bad = 1; dg[k] = d; }
-        // column k below the pivot still holds a_ik (its terms of the columns before are in): the trailing entries take (a_ik / d)(a_jk / d) d
-        const int m = n - 1 - k;            // rows below
-        for (int e = tid; e < m * (m + 1) / 2; e += kSolveThreads) {
-            // e -> (r, c), c <= r < m: entry (k + 1 + r, k + 1 + c)
-            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (r * (r + 1) / 2 > e) --r;
-            while ((r + 1) * (r + 2) / 2 <= e) ++r;
-            const int c = e - r * (r + 1) / 2, i = k + 1 + r, j = k + 1 + c;
-            const double lik = L[i * n + k] / d, ljk = L[j * n + k] / d;
-            L[i * n + j] -= lik * ljk * d;
+    if (tid < 16 * 8) s_colL[tid] = 0.0;   // (never written at or beyond row n: the unpredicated products there stay zero)
+    // every load at a clamped (always valid) address and without a branch around it: they are all in flight together; what lies outside
+    // the window's lower triangle is zeroed afterwards
+    {
+        double hs[kTiles], hl[kTiles], rb[NT], rl[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int i = min(16 * ti + ty, n - 1);
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int e = i * n + min(16 * tj + tx, n - 1), q = ti * (ti + 1) / 2 + tj;
+                hs[q] = S[e];
+                hl[q] = Hl ? Hl[e] : 0.0;
+            }
+            rb[ti] = bs[i];
+            rl[ti] = Hl ? bl[i] : 0.0;
         }
-        __syncthreads();
-        for (int i = k + 1 + tid; i < n; i += kSolveThreads) L[i * n + k] = L[i * n + k] / d;
-        __syncthreads();
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int i = 16 * ti + ty;
+#pragma unroll
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int j = 16 * tj + tx, q = ti * (ti + 1) / 2 + tj;
+                const double v = Hl ? hs[q] + hl[q] : hs[q];
+                a[q] = i < n && j <= i ? v : 0.0;
+            }
+            const double v = Hl ? rb[ti] + rl[ti] : rb[ti];
+            rhs[ti] = tx == 0 && i < n ? v : 0.0;
+        }
     }
+    // The columns tile column by tile column: inside a segment the tile numbers are compile-time constants -- which tiles lie right of the
+    // column, which register holds the column's entry of a tile row -- so a step is the products and little else (a wavefront alone on its
+    // SIMD issues an instruction every four to five cycles: with the tile tests made per step the kernel spent 600 instructions on a
+    // column's 45 multiply-subtracts, 92 us per solve).  What lies above the diagonal inside a diagonal tile, and beyond row n, is carried
+    // along unpredicated: those registers are never read into a result (s_colL stays zero beyond n).
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k_end = min(16 * (kt + 1), n);
+        for (int k = 16 * kt; k < k_end; ++k) {
+            const int kr = k - 16 * kt;
+            // the column's entries from the pivot down, and the right-hand side's entry k (final: it is y_k)
+            if (tx == kr) {
+                if (ty >= kr) s_colA[16 * kt + ty] = a[kt * (kt + 1) / 2 + kt];
+#pragma unroll
+                for (int ti = kt + 1; ti < NT; ++ti) s_colA[16 * ti + ty] = a[ti * (ti + 1) / 2 + kt];
+            }
+            if (tx == 0 && ty == kr) s_y = rhs[kt];
+            __syncthreads();
+            const double d = s_colA[k], y = s_y;
+            if (tid == 0) { if (!(d == d) || d == 0.0 || d - d != 0.0) s_bad = 1; s_dg[k] = d; }
+            if (tid > k && tid < n) s_colL[tid] = s_colA[tid] / d;
+            __syncthreads();
+            double li[NT], lj[NT];
+#pragma unroll
+            for (int t = kt; t < NT; ++t) { li[t] = s_colL[16 * t + ty]; lj[t] = s_colL[16 * t + tx]; }
+            const bool pi = ty > kr, pj = tx > kr, pk = tx == kr;   // row below the pivot / column right of it / the column itself (tile column kt only)
+            {   // the diagonal tile of the segment
+                const int q = kt * (kt + 1) / 2 + kt;
+                const double upd = a[q] - li[kt] * lj[kt] * d;
+                a[q] = pi && pj ? upd : (pi && pk ? li[kt] : a[q]);
+                const double r = rhs[kt] - li[kt] * y;
+                rhs[kt] = pi ? r : rhs[kt];
+            }
+#pragma unroll
+            for (int ti = kt + 1; ti < NT; ++ti) {
+                {   // the tile in the column's own tile column: its entries right of the column take their term, the column's become L
+                    const int q = ti * (ti + 1) / 2 + kt;
+                    const double upd = a[q] - li[ti] * lj[kt] * d;
+                    a[q] = pj ? upd : (pk ? li[ti] : a[q]);
+                }
+#pragma unroll
+                for (int tj = kt + 1; tj <= ti; ++tj) { const int q = ti * (ti + 1) / 2 + tj; a[q] -= li[ti] * lj[tj] * d; }
+                rhs[ti] -= li[ti] * y;
+            }
+        }
+    }
+    // L (strictly lower) and y to LDS; z = y / D; backward sweep x_i = z_i - sum_{k > i} L_ki x_k, k descending, by wavefront 0
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const int i = 16 * ti + ty;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) { const int j = 16 * tj + tx; if (i < n && j < i) s_L[i * n + j] = a[ti * (ti + 1) / 2 + tj]; }
+        if (tx == 0 && i < n) s_xs[i] = rhs[ti];
+    }
+    __syncthreads();
     if (tid < 64) {
-        // forward substitution z_i = b_i - sum_{k < i} L_ik z_k (k ascending), division by D, backward x_i = y_i - sum_{k > i} L_ki x_k (k descending)
         const int lane = tid;
-        for (int k = 0; k < n; ++k) {
-            const double zk = xs[k];
-            for (int i = k + 1 + lane; i < n; i += 64) xs[i] -= L[i * n + k] * zk;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        for (int i = lane; i < n; i += 64) xs[i] = xs[i] / dg[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double x0 = lane < n ? s_xs[lane] / s_dg[lane] : 0.0, x1 = lane + 64 < n ? s_xs[lane + 64] / s_dg[lane + 64] : 0.0;
         for (int k = n - 1; k >= 1; --k) {
-            const double xk = xs[k];
-            for (int i = lane; i < k; i += 64) xs[i] -= L[k * n + i] * xk;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            union { double d; int w[2]; } xk;
+            xk.d = k >= 64 ? x1 : x0;
+            xk.w[0] = __builtin_amdgcn_readlane(xk.w[0], k & 63);
+            xk.w[1] = __builtin_amdgcn_readlane(xk.w[1], k & 63);
+            const double l0 = s_L[k * n + min(lane, k - 1)], l1 = s_L[k * n + min(max(lane + 64, 0), k - 1)];
+            x0 = lane < k ? x0 - l0 * xk.d : x0;
+            x1 = lane + 64 < k ? x1 - l1 * xk.d : x1;
         }
+        const bool bad = s_bad != 0;
+        double* x_dev = global_ptr(load_uniform(&sl.x_dev));
+        double* x_host = global_ptr(load_uniform(&sl.x_host));
+        if (lane < n) { const double v = bad ? 0.0 : x0; x_dev[lane] = v; if (x_host) x_host[lane] = v; }
+        if (lane + 64 < n) { const double v = bad ? 0.0 : x1; x_dev[lane + 64] = v; if (x_host) x_host[lane + 64] = v; }
+        if (lane == 0) global_ptr(load_uniform(&sl.ok_host))[0] = bad ? 0 : 1;  // (device-side LM: BaLmState::solve_ok)
     }
-    __syncthreads();
-    const bool bad = s_bad != 0;
-    for (int i = tid; i < n; i += kSolveThreads) {
-        const double v = bad ? 0.0 : xs[i];
-        sl.x_dev[i] = v;
-        if (sl.x_host) sl.x_host[i] = v;
-    }
-    if (tid == 0) sl.ok_host[0] = bad ? 0 : 1;  // (device-side LM: BaLmState::solve_ok)
 }
+template <int NT>
+__device__ __forceinline__ void solve_b_body(const BaPhase& ph) {
+    extern __shared__ double s_solve[];
+    const BaSlotView view_ = ba_slot_view(ph, blockIdx.x);
+    if (!view_.active) return;
+    const int n = 6 * view_.pb.n_free;
+    if (n == 0 || !view_.sl.x_dev || n > 16 * NT) return;  // (the launcher picks NT for the call's widest window)
+    d_ba_solve_tiles<NT>(view_.sl, n, s_solve);
+}
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) { solve_b_body<8>(ph); }
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve5_b(const BaPhase ph) { solve_b_body<5>(ph); }
 // ---- The reduced system of an INERTIAL window on the device (LocalInertialBA / LocalLVIBA: 6 unknowns per free keyframe pose + 9 per keyframe with
 // velocity / bias vertices, 375 for the 25-keyframe bLarge window; Optimizer.cc:1635-1638 solves it with g2o's sparse LinearSolverEigen).  Rounds
 // 1-4 and the first half of round 5 solved it on the host (reduced_solve.hpp: 0.55 ms of a host core per window and trial after the envelope
@@ -2307,9 +2378,13 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
     const int n = 6 * x.max_free;
-    const size_t lds = ((size_t)n * n + 2 * (size_t)n) * sizeof(double);  // 12 free keyframes: 42 KB; 21: 129 KB
-    (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 132 * 1024);
-    TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
+    const size_t lds = (size_t)n * n * sizeof(double);  // L for the backward sweep: 12 free keyframes 41 KB, 21: 127 KB
+    if (n <= 80) {
+        TC2LI_LAUNCH(k_ba_solve5_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
+    } else {
+        (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 128 * 1024);
+        TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
+    }
 }
 // whether the two kernels get the LDS of their largest window (25 free keyframes: 160 KB, all a CU has); asked once, before a window is promised
 // to them -- a refusal leaves every window to the host's solver instead of surfacing as a launch error later

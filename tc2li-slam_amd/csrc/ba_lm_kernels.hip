@@ -23,7 +23,8 @@ namespace tc2li {
 
 namespace {
 
-constexpr int kLmThreads = 64;
+constexpr int kLmThreads = 64;      // k_ba_lm_decide_b: one wavefront
+constexpr int kLmBeginThreads = 256; // k_ba_lm_begin_b: the (6W)^2 change of variables one output entry per thread
 constexpr int kLmMaxW = 7;          // windows of the batched LiDAR kernels (ba_batch_lockstep sends wider ones through the per-window path)
 constexpr int kLmMaxNp = 6 * kSchurBlocksMaxFree;
 
@@ -42,6 +43,19 @@ __device__ __forceinline__ LmWindow lm_window(const BaPhase& ph, int pos) {
     w.has_lidar = load_uniform(&w.sl->has_lidar);
     return w;
 }
+// Block (a, b) of D^T H D entry by entry (balm_change_block's two products, balm_math.hpp: from the left first when a <= b, from the right
+// first otherwise; every entry the same six-term sum in the same order): pass 0 writes the first product of H into T, pass 1 the second of T into H
+__device__ __forceinline__ void lm_change_pass(const double* in, double* out, const double* DT, int W, int pass, int tid, int nthreads) {
+    const int n = 6 * W;
+    for (int e = tid; e < n * n; e += nthreads) {
+        const int row = e / n, col = e - row * n, a = row / 6, r = row - 6 * a, b = col / 6, c = col - 6 * b;
+        const double* blk = in + (size_t)(6 * a) * n + 6 * b;
+        double sum = 0;
+        if ((pass == 0) == (a <= b)) { const double* D = DT + 36 * a; for (int k = 0; k < 6; ++k) sum += D[6 * r + k] * blk[(size_t)k * n + c]; }
+        else { const double* D = DT + 36 * b; for (int k = 0; k < 6; ++k) sum += blk[(size_t)r * n + k] * D[6 * c + k]; }
+        out[e] = sum;
+    }
+}
 // the state as sixteen 8-byte words: one lane each
 __device__ __forceinline__ void lm_store(const BaLmState& s, BaLmState* dst, BaLmState* mirror, int lane, unsigned long long* stage) {
     if (lane == 0) *reinterpret_cast<BaLmState*>(stage) = s;
@@ -57,10 +71,11 @@ __device__ __forceinline__ void lm_store(const BaLmState& s, BaLmState* dst, BaL
 
 // After the linearisation of a window in kLmIterate: g2o's computeActiveErrors + the edges' constructQuadraticForm as far as the host did them
 // (ba_batch_lockstep's step between phases A and B), then status = kLmTrial.
-__global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin_b(const BaPhase ph) {
+__global__ __launch_bounds__(kLmBeginThreads) void k_ba_lm_begin_b(const BaPhase ph) {
+    constexpr int kLmThreads = kLmBeginThreads;
     const LmWindow w = lm_window(ph, blockIdx.x);
     if (!w.lm || load_uniform(&w.lm->status) != kLmIterate) return;
-    __shared__ double s_H[36 * kLmMaxW * kLmMaxW], s_J[6 * kLmMaxW], s_DT[36 * kLmMaxW];
+    __shared__ double s_H[36 * kLmMaxW * kLmMaxW], s_T[36 * kLmMaxW * kLmMaxW], s_J[6 * kLmMaxW], s_DT[36 * kLmMaxW], s_max[kLmBeginThreads / 64];
     __shared__ LidarPose s_twl[kLmMaxW];
     __shared__ int s_var[kLmMaxW];
     __shared__ unsigned long long s_stage[sizeof(BaLmState) / 8];
@@ -103,7 +118,9 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin_b(const BaPhase ph) 
                     balm_camera_se3_D(s_twl[lane], F, s_J + 6 * lane, s_DT + 36 * lane);
                 }
                 __syncthreads();
-                if (lane < W * W) balm_change_block(s_H, n, lane / W, lane % W, s_DT + 36 * (lane / W), s_DT + 36 * (lane % W));
+                lm_change_pass(s_H, s_T, s_DT, W, 0, lane, kLmThreads);
+                __syncthreads();
+                lm_change_pass(s_T, s_H, s_DT, W, 1, lane, kLmThreads);
             }
             __syncthreads();
             for (int k = lane; k < n; k += kLmThreads) JH[k] = s_J[k];
@@ -113,9 +130,12 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin_b(const BaPhase ph) 
             for (int k = lane; k < n * n; k += kLmThreads) s_H[k] = JH[n + k];
         }
         if (lane < W) s_var[lane] = pose_var[b.pose_index[lane]];
-        // BalmTerm::add_quadratic_form into the zeroed (6K)^2 block and gradient: every entry is written by one term (0 + h: the host's sum)
-        for (int k = lane; k < np * np; k += kLmThreads) Hl[k] = 0.0;
-        for (int k = lane; k < np; k += kLmThreads) bl[k] = 0.0;
+        // BalmTerm::add_quadratic_form into the zeroed (6K)^2 block and gradient: every entry is written by one term (0 + h: the host's sum).
+        // The entries written are the same in every iteration (the window's keyframes do not move in the numbering): zeroed once per call.
+        if (st.it == 0) {
+            for (int k = lane; k < np * np; k += kLmThreads) Hl[k] = 0.0;
+            for (int k = lane; k < np; k += kLmThreads) bl[k] = 0.0;
+        }
         __syncthreads();
         // The reference reads the 6x6 blocks at ELEMENT offsets (i, i) / (i, j) of the 6W x 6W Hessian (G2oTypesWithLidar.h:168-236); kept as is.
         for (int t = lane; t < 42 * W; t += kLmThreads) {
@@ -144,6 +164,10 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin_b(const BaPhase ph) 
                 m = fmax(m, fabs(Hpp[27 * (size_t)(j / 6) + dpos] + Hl[(size_t)j * np + j]));
             }
             for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            if ((lane & 63) == 0) s_max[lane >> 6] = m;
+            __syncthreads();
+            m = s_max[0];
+            for (int q = 1; q < kLmThreads / 64; ++q) m = fmax(m, s_max[q]);
             max_pose_diag = m;
         }
     }
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_decide_b(const BaPhase ph)
 }
 
 void ba_batch_launch_lm_begin(const BaPhase& ph, int n_active, hipStream_t st) {
-    if (n_active) TC2LI_LAUNCH(k_ba_lm_begin_b, dim3(n_active), dim3(kLmThreads), 0, st, ph);
+    if (n_active) TC2LI_LAUNCH(k_ba_lm_begin_b, dim3(n_active), dim3(kLmBeginThreads), 0, st, ph);
 }
 void ba_batch_launch_lm_decide(const BaPhase& ph, int n_active, hipStream_t st) {
     if (n_active) TC2LI_LAUNCH(k_ba_lm_decide_b, dim3(n_active), dim3(kLmThreads), 0, st, ph);
