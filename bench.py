@@ -47,6 +47,9 @@ def parse_args(argv=None):
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames rendered (tiled over the sequences)")
     ap.add_argument("--kf-interval", type=int, default=4, help="a keyframe (one local BA window) every k-th frame")
     ap.add_argument("--ba-concurrency", type=int, default=8, help="local-BA windows in flight (streams) per GPU")
+    ap.add_argument("--ba-mix", choices=("varied", "uniform"), default="varied", help="the local-BA windows of the timed loop: 64 distinct windows "
+                    "drawn by synthetic.ba_window_varied (4-24 free / 2-40 fixed keyframes, 500-6000 points, 0-15 %% outliers, LiDAR windows of 0 / 3-6 clouds, heavy "
+                    "LiDAR edges, interrupted windows) or the four 12 + 20-keyframe / 3000-point windows of rounds 1-5, tiled")
     ap.add_argument("--map-length", type=float, default=1000.0, help="metres of street in every sequence's LiDAR map (~190 points per metre)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -176,6 +179,45 @@ def sweep_children(args):
                    "process initialised the GPU (8 warm-up steps, then 10-40 timed steps); the entry above the default batch is informational (the line's "
                    "`value` stays at the default of the earlier rounds)")
     return out
+
+
+def host_budget_children(args):
+    """The default loop with the process confined to 4 / 8 / 16 CPUs (taskset before the child's first GPU call, like the sweep's children):
+    what `value` a rank keeps on a tighter host (eight ranks of this on a node).  {cpus: {value, cpu_s_per_wall_s, threads}}"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+                                                            "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env.update(TC2LI_NO_BUILD="1")
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    out = {}
+    for n in (4, 8):
+        if n >= effective_cpus() or n > len(cpus):
+            continue
+        cmd = ["taskset", "-c", ",".join(str(c) for c in cpus[:n]), sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", str(args.sequences),
+               "--unique", str(args.unique), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval),
+               "--ba-concurrency", str(args.ba_concurrency), "--map-length", str(args.map_length)]
+        try:
+            txt = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
+            line = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+            h = (line.get("config") or {}).get("host") or {}
+            out[str(n)] = {"value": line["value"], "cpu_s_per_wall_s": h.get("cpu_s_per_wall_s_timed_region"), "threads": h.get("threads_of_this_rank")}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench.py: the %d-CPU child failed (%s)\n" % (n, e))
+            return None
+    return out
+
+
+def ba_batch_of(pkg, wl, first, n):
+    """BaBatch of the n windows first, first + 1, ... of the workload's list (tiled): the LiDAR keys only for a window that has the edge."""
+    ws = []
+    for k in range(first, first + n):
+        w = wl.ba_windows[k % len(wl.ba_windows)]
+        d = dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=w["edges"], iterations=w.get("iterations", 10))
+        if len(w["win_pose"]):
+            d.update(win_pose=w["win_pose"], clouds=w["clouds"], Tcl7=w["Tcl7"], weight=w["weight"])
+        ws.append(d)
+    b = pkg.capi.BaBatch(ws, wl.ba_windows[0]["cam"])
+    b.window_ids = [k % len(wl.ba_windows) for k in range(first, first + n)]
+    return b
 
 
 def thread_cpu_seconds():
@@ -333,6 +375,11 @@ def compact_line(full, detail_path=None):
     if isinstance(sw, dict):
         line["sequences_per_gpu_sweep"] = {k: v for k, v in sw.items() if k != "unit"}
         line["sequences_per_gpu_sweep"]["note"] = "frames/s at that many sequences per step on this ONE GPU; N > 1 over RCCL is unmeasured on hardware"
+    if isinstance(full.get("value_uniform"), dict):
+        line["value_uniform"] = _pick(full["value_uniform"], ("value", "ms_per_step", "ba"))
+    hbs = full.get("host_budget_sweep")
+    if isinstance(hbs, dict):
+        line["host_budget_sweep"] = {k: (v if not isinstance(v, dict) else _pick(v, ("value", "cpu_s_per_wall_s", "threads"))) for k, v in hbs.items() if k != "note"}
     if isinstance(full.get("sharded_window"), dict):
         line["sharded_window"] = _pick(full["sharded_window"], ("ranks", "ms_per_window", "single_gpu_ms_per_window", "max_pose_difference_vs_single_gpu"))
     if isinstance(full.get("stage_thread_ms_per_step_concurrent"), dict):
@@ -340,7 +387,7 @@ def compact_line(full, detail_path=None):
     if detail_path:
         line["detail"] = detail_path
     # the budget is a contract: shed the optional legs, least important first, rather than print a line the driver cannot parse
-    for k in ("stage_thread_ms_per_step_concurrent", "sharded_window", "sequences_per_gpu_sweep", "mfma_config", "host_fed", "single_sequence", "inertial_config"):
+    for k in ("stage_thread_ms_per_step_concurrent", "sharded_window", "value_uniform", "host_budget_sweep", "sequences_per_gpu_sweep", "mfma_config", "host_fed", "single_sequence", "inertial_config"):
         if len(json.dumps(line)) <= LINE_BUDGET:
             break
         line.pop(k, None)
@@ -373,6 +420,19 @@ def level_dims(w, h, nlevels=8, scale=1.2):
     return dims
 
 
+def uniform_ba_windows(pkg, synthetic):
+    """The four windows rounds 1-5 tiled over a step's batch: 12 free + 20 fixed keyframes, 3000 points, a LiDAR edge over 6 keyframes x 3000 points."""
+    out = []
+    for k in range(4):
+        w = synthetic.ba_window(k, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
+        last = len(w["poses"]) - 1
+        win = list(range(last, last - 6, -1))
+        out.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=w["edges"],
+                        win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=3000), Tcl7=synthetic.TCL7, weight=1.0,
+                        cam=w["cam"], iterations=10, params=dict(n_opt=12, n_fix=20, kind="ordinary")))
+    return out
+
+
 class Workload:
     """The synthetic inputs of `unique` distinct sequences: stereo pair, 64-beam scan, the street's accumulated
     LiDAR map, the last frame TrackWithMotionModel projects from and the local map TrackLocalMap searches; sequence s uses set s % unique."""
@@ -394,14 +454,19 @@ class Workload:
             self.states.append(pkg.pack_lidar_state(*synthetic.lidar_state(u + 1)[:2]))
             self.maps.append(synthetic.lidar_map(sc, x_from=-0.7 * map_length, x_to=0.3 * map_length))
         self.ba_windows = []
-        if with_ba:
-            for k in range(4):
-                w = synthetic.ba_window(k, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
-                last = len(w["poses"]) - 1
-                win = list(range(last, last - 6, -1))
-                self.ba_windows.append(dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=w["edges"],
-                                            win_pose=win, clouds=synthetic.ba_window_clouds(w, win, n_points=3000), Tcl7=synthetic.TCL7, weight=1.0,
-                                            cam=w["cam"]))
+        self.ba_mix = "none"
+        if with_ba and with_ba != "uniform":
+            self.ba_mix = "varied"
+            for k in range(64):
+                w = synthetic.ba_window_varied(k)
+                d = dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), edges6=w["edges"], cam=w["cam"],
+                         iterations=w["iterations"], params=w["params"], win_pose=[], clouds=[], Tcl7=synthetic.TCL7, weight=w["weight"])
+                if w["win_pose"]:
+                    d.update(win_pose=w["win_pose"], clouds=w["clouds"])
+                self.ba_windows.append(d)
+        elif with_ba:
+            self.ba_mix = "uniform"
+            self.ba_windows = uniform_ba_windows(pkg, synthetic)
         ang = 0.002
         self.pose_pred = np.array([0, np.sin(ang / 2), 0, np.cos(ang / 2), 0.02, -0.01, -0.08], np.float32)
         self.last = None   # per unique: the last frame of TrackWithMotionModel
@@ -570,7 +635,7 @@ class Loop:
         self.ba_rate = 0.0 if (args.front_end_only or not wl.ba_windows) else F / args.kf_interval
         n_ba = int(np.ceil(self.ba_rate)) if self.ba_rate else 0
         self.n_ba = n_ba
-        self.ba_batch = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n_ba)], wl.ba_windows[0]["cam"]) if n_ba else None
+        self.ba_batch = ba_batch_of(pkg, wl, 0, n_ba) if n_ba else None
         # Local mapping is asynchronous in the reference: it optimises whatever keyframes have arrived when it becomes free.  With few
         # sequences per GPU a step's windows are a short, latency-bound batch (16 windows: 8.6 ms against 6.4 ms for the other stages), so
         # the mapping thread takes the windows of two steps in one call, as soon as the tracking thread has finished both (a second,
@@ -580,9 +645,9 @@ class Loop:
         self.ba_batch2 = self.ba_batch4 = None
         multi = int(os.environ.get("TC2LI_BENCH_BA_MULTI_STEP", "0"))  # A/B: 2 / 4 = batches of that many steps' windows whatever F is
         if n_ba >= 2 and (F <= 256 or multi >= 2) and F % args.kf_interval == 0 and not os.environ.get("TC2LI_BENCH_BA_SINGLE_STEP"):
-            self.ba_batch2 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(2 * n_ba)], wl.ba_windows[0]["cam"])
+            self.ba_batch2 = ba_batch_of(pkg, wl, 0, 2 * n_ba)
             if F <= 64 or multi >= 4:
-                self.ba_batch4 = pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(4 * n_ba)], wl.ba_windows[0]["cam"])
+                self.ba_batch4 = ba_batch_of(pkg, wl, 0, 4 * n_ba)
         # Beyond 256 sequences the mapping stage runs free, and its windows go to a POOL of mapping workers, each a lock-step group of its
         # own (tc2li_local_bundle_adjustment_batch_group): a step's windows are dealt into as many chunks as there are workers, a worker takes
         # the next chunk when it is free.  (The one call per step made its three groups meet at its end: a step's groups take 20-30 ms
@@ -592,9 +657,12 @@ class Loop:
         n_workers = int(os.environ.get("TC2LI_BENCH_BA_WORKERS", "3"))
         if type(self) is Loop and self.ba_batch is not None and self.ba_batch2 is None and n_workers >= 2 and n_ba >= 8 * n_workers and self.ba_rate == n_ba:
             self.ba_chunk_sizes = [n_ba * (c + 1) // n_workers - n_ba * c // n_workers for c in range(n_workers)]
-            cam = wl.ba_windows[0]["cam"]
-            for w in range(n_workers):  # a worker's own batches, one per chunk size (the windows are the same four, tiled)
-                self.ba_workers.append({n: pkg.capi.BaBatch([wl.ba_windows[k % len(wl.ba_windows)] for k in range(n)], cam) for n in set(self.ba_chunk_sizes)})
+            # a worker's own batches, one per chunk size; worker w's windows start where worker w - 1's end, so that the workers' batches of a
+            # chunk size hold different stretches of the workload's window list (with the varied mix: different windows)
+            first = 0
+            for w in range(n_workers):
+                self.ba_workers.append({n: ba_batch_of(pkg, wl, first, n) for n in set(self.ba_chunk_sizes)})
+                first += self.ba_chunk_sizes[w]
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
@@ -687,6 +755,48 @@ class Loop:
             return self.ba_batch
         ran = [b for w in self.ba_workers for b in w.values() if b.stats[0].iterations > 0]  # (a worker may not have met every chunk size)
         return ran[0] if ran else next(iter(self.ba_workers[0].values()))
+
+    def ba_run_batches(self):
+        """Every BaBatch of the loop that has run at least once."""
+        all_b = [self.ba_batch, self.ba_batch2, self.ba_batch4] + [b for w in self.ba_workers for b in w.values()]
+        return [b for b in all_b if b is not None and any(b.stats[i].iterations > 0 or b.results[i] > 0 for i in range(b.n))]
+
+    def ba_mix_summary(self, wl):
+        """What the optimised windows were and did: per distinct window of the workload's list (as last run) its sizes, iterations and trials;
+        the sums the roofline's byte / FLOP counts are made of (weighted by the linearisations a window ran)."""
+        seen = {}
+        for b in self.ba_run_batches():
+            for i, wid in enumerate(b.window_ids):
+                st, ls = b.stats[i], b.lstats[i]
+                seen[wid] = (int(st.iterations), int(st.trials), int(st.n_free_poses), int(ls.n_planes))
+        if not seen:
+            return None
+        rows = []
+        for wid, (it, tr, nf, planes) in sorted(seen.items()):
+            w = wl.ba_windows[wid]
+            e6 = np.asarray(w["edges6"])
+            free_edge = np.asarray(w["fixed"])[e6[:, 1].astype(int)] == 0
+            f_l = np.bincount(e6[free_edge, 0].astype(int), minlength=len(w["points"]))
+            rows.append(dict(edges=len(e6), points=len(w["points"]), free=nf, planes=planes, win=len(w["win_pose"]), cloud_points=int(sum(len(c) for c in w["clouds"])),
+                             free_edges=int(free_edge.sum()), pose_pairs=int((f_l * (f_l + 1) // 2).sum()), it=it, tr=tr))
+        it = np.array([r["it"] for r in rows], float)
+        tr = np.array([r["tr"] for r in rows], float)
+        wgt = np.maximum(it, 1e-9) / max(it.sum(), 1e-9)
+
+        def mean_w(key):
+            return float(np.sum(wgt * np.array([r[key] for r in rows], float)))
+        agg = {k: mean_w(k) for k in ("edges", "points", "free", "planes", "win", "cloud_points", "free_edges", "pose_pairs")}
+        for k in ("edges", "points", "free_edges", "pose_pairs", "planes", "cloud_points"):
+            agg[k] = int(round(agg[k]))
+        agg["free"] = max(1, int(round(agg["free"]))); agg["win"] = max(1, int(round(agg["win"])))
+        agg.update(linearisations=float(it.mean()), trials=float(tr.mean()), distinct_windows=len(rows),
+                   iterations_min_mean_max=[int(it.min()), round(float(it.mean()), 2), int(it.max())], trials_min_mean_max=[int(tr.min()), round(float(tr.mean()), 2), int(tr.max())],
+                   free_keyframes_min_max=[int(min(r["free"] for r in rows)), int(max(r["free"] for r in rows))],
+                   points_min_max=[int(min(r["points"] for r in rows)), int(max(r["points"] for r in rows))],
+                   edges_min_max=[int(min(r["edges"] for r in rows)), int(max(r["edges"] for r in rows))],
+                   windows_without_lidar_edge=int(sum(r["win"] == 0 for r in rows)), windows_with_rejected_steps=int(sum(r["tr"] > r["it"] for r in rows)),
+                   windows_interrupted=int(sum(r["it"] < 10 for r in rows)))
+        return agg
 
     def ba_step(self, m=1):
         """The local-mapping work of m (1, 2 or 4) steps."""
@@ -1442,7 +1552,10 @@ def cpu_baseline(wl, args, n_seq_gpu, with_ba):
 
     def cpu_ba(k):
         w = wl.ba_windows[k % len(wl.ba_windows)]
-        return pyoracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges6"], w["cam"], w["win_pose"], w["clouds"], w["Tcl7"], 1.0)[4]
+        if not len(w["win_pose"]):
+            return pyoracle.local_ba(w["poses"], w["fixed"], w["points"], w["edges6"], w["cam"], iterations=w.get("iterations", 10))[4]
+        return pyoracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges6"], w["cam"], w["win_pose"], w["clouds"], w["Tcl7"], w["weight"],
+                                       iterations=w.get("iterations", 10))[4]
 
     def run_sequences(n_seq, n_workers, budget):
         """n_seq sequences advanced frame by frame by n_workers concurrent tracking threads (each frame call spawns the reference's ORB and LiDAR
@@ -1540,10 +1653,11 @@ def main(argv=None):
         single_fed_child = single_sequence_child(args, ("--host-fed",))
         if not args.front_end_only:
             single_inertial_child = single_sequence_child(args, ("--inertial-loop",) + (("--lviba-small",) if args.lviba_small else ()), "configs[3] with 1 sequence per step: one LocalLVIBA window every %d-th frame")
-    sweep_child = None
+    sweep_child = budget_child = None
     if (rank == 0 and world == 1 and not args.no_extra_lines and not args.rehearse and not args.front_end_only and not under_profiler()
             and args.scaling == "strong" and set(args.stages.split(",")) == {"orb", "track", "lidar", "ba"}):
         sweep_child = sweep_children(args)
+        budget_child = host_budget_children(args)
     if not torch.cuda.is_available() or pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -1565,7 +1679,7 @@ def main(argv=None):
     if not seq_ids:
         raise SystemExit("bench.py: rank %d owns no sequence (%d sequences over %d ranks)" % (rank, args.sequences, world))
     U = min(args.unique, max(len(seq_ids), 1) if args.scaling == "weak" else args.unique)
-    wl = Workload(pkg, synthetic, U, args.map_length, with_ba=not args.front_end_only)
+    wl = Workload(pkg, synthetic, U, args.map_length, with_ba=False if args.front_end_only else args.ba_mix)
     stream = torch.cuda.current_stream().cuda_stream
     ext0 = pkg.OrbExtractor(max_width=wl.W, max_height=wl.H, max_images=2 * U)
     wl.build_tracking_inputs(ext0, stream)
@@ -1652,15 +1766,9 @@ def main(argv=None):
         report = pkg.capi.profile_report()
         ba = None
         if loop.ba_batch:
-            sb = loop.ba_stats_batch()  # (with mapping workers the step's windows run in the workers' batches, not in loop.ba_batch)
-            s0, ls0 = sb.stats[0], sb.lstats[0]
-            w0 = wl.ba_windows[0]
-            free_edge = np.asarray(w0["fixed"])[np.asarray(w0["edges6"])[:, 1].astype(int)] == 0
-            f_l = np.bincount(np.asarray(w0["edges6"])[free_edge, 0].astype(int), minlength=len(w0["points"]))
-            ba = {"edges": len(w0["edges"]), "points": len(w0["points"]), "free": int(s0.n_free_poses), "planes": int(ls0.n_planes), "win": 6,
-                  "cloud_points": int(sum(len(c) for c in w0["clouds"])),
-                  "free_edges": int(free_edge.sum()), "pose_pairs": int((f_l * (f_l + 1) // 2).sum()),
-                  "windows": (loop.ba_windows_done - ba1) / n_prof, "linearisations": int(s0.iterations), "trials": int(s0.trials)}
+            # the windows' sizes as means over the mix the loop ran, weighted by the linearisations a window took (the products windows x
+            # linearisations x size of the table below are then the sums over the windows; with the uniform mix: the one window's own numbers)
+            ba = dict(loop.ba_mix_summary(wl), windows=(loop.ba_windows_done - ba1) / n_prof)
         roofline, kernel_table, kernel_ms_per_step = roofline_from_profile(report, algorithmic_work(wl, loop, nkp, lid_mean, ba), peaks, n_prof)
         roofline["traffic"] = pmc_traffic(roofline["kernel"])
         roofline["measured_in"] = ("a second pass of %d steps of the same concurrent loop in which every kernel is launched with a start and a stop "
@@ -1692,6 +1800,30 @@ def main(argv=None):
                                 "data sheet)" % (loop.n_img, F, gb)}
         loop.host_fed = False
 
+    # ---- the same loop with the windows rounds 1-5 timed: four 12 + 20-keyframe windows tiled over the step's batch ----
+    value_uniform = None
+    if rank == 0 and world == 1 and not args.no_extra_lines and wl.ba_mix == "varied" and loop.ba_batch and set(stages) == {"orb", "track", "lidar", "ba"} \
+            and not args.inertial_loop:
+        import copy
+        wl_u = copy.copy(wl)
+        wl_u.ba_windows, wl_u.ba_mix = uniform_ba_windows(pkg, synthetic), "uniform"
+        lu = Loop(wl_u, seq_ids, args, local_rank)
+        lu.run(max(args.warmup, 3), stages)
+        torch.cuda.synchronize()
+        n_u = max(6, min(args.steps, 16))
+        t1 = time.perf_counter()
+        lu.run(n_u, stages)
+        torch.cuda.synchronize()
+        dt_u = time.perf_counter() - t1
+        su = lu.ba_mix_summary(wl_u) or {}
+        value_uniform = {"value": round(F * n_u / dt_u, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_u / n_u, 3), "steps": n_u,
+                         "ba": {k: su.get(k) for k in ("iterations_min_mean_max", "trials_min_mean_max", "distinct_windows")},
+                         "workload": "the loop of `value` with local mapping's windows as rounds 1-5 timed them: four windows of 12 free + 20 fixed keyframes, "
+                                     "3000 points and a LiDAR edge over 6 keyframes, tiled over the step's batch -- every window of a lock-step group takes the same "
+                                     "Levenberg-Marquardt path"}
+        lu.close()
+        del lu
+
     # ---- the same loop for ONE sequence (F = 1): what a single KITTI-00 run sees ----
     single = single_child
     if single is not None and single_fed_child is not None:
@@ -1712,6 +1844,15 @@ def main(argv=None):
                   "stage_thread_ms_per_frame": {k: round(v, 3) for k, v in one.thread_ms.items()}}
         one.close()
 
+    # ---- the same loop on a tighter host: 4 / 8 CPUs (children) beside this process's own figure at the full grant ----
+    host_budget_sweep = None
+    if budget_child is not None:
+        host_budget_sweep = dict(budget_child)
+        host_budget_sweep[str(host_budget.get("cpus_effective"))] = {"value": round(total_sequences * args.steps / elapsed, 1),
+                                                                      "cpu_s_per_wall_s": host_budget.get("cpu_s_per_wall_s_timed_region"),
+                                                                      "threads": host_budget.get("threads_of_this_rank")}
+        host_budget_sweep["note"] = ("frames/s of the default loop with the process confined to that many CPUs (taskset before the first GPU call); CPU-seconds "
+                                     "per wall second and library + stage threads of the rank beside it")
     # ---- sequences per GPU: what strong scaling over the fixed list turns into at 8 / 4 / 2 ranks, timed here on one GPU ----
     sweep = None
     if sweep_child is not None:
@@ -1849,8 +1990,11 @@ def main(argv=None):
                             "optimisation, twice), LiDAR fov_segment / preprocess / voxel 0.5 m / 5-NN plane features against the sequence's own "
                             "map / map_incremental (64-beam scan, ~130k returns)" % (
                                 total_sequences, args.scaling, "the list is dealt over the ranks" if args.scaling == "strong" else "%d per rank" % args.frames) +
-                            ("" if args.front_end_only else ", LocalLVBundleAdjustment (12 free + 20 fixed keyframes, ~2500 points, ~26k stereo "
-                                                            "edges, LiDAR plane edge over 6 keyframes x 3000 points)"),
+                            ("" if args.front_end_only else
+                             ", LocalLVBundleAdjustment over 64 distinct windows (4-24 free / 2-40 fixed keyframes, 500-6000 points, 0-15 % outliers, LiDAR edge over "
+                             "0 / 3-6 keyframes, heavy LiDAR edges with rejected steps, interrupted windows: config.ba)" if wl.ba_mix == "varied" else
+                             ", LocalLVBundleAdjustment (12 free + 20 fixed keyframes, ~2500 points, ~26k stereo "
+                             "edges, LiDAR plane edge over 6 keyframes x 3000 points)"),
                 "stage_threads": "ORB extraction | stereo matching + TrackWithMotionModel | TrackLocalMap | LiDAR front end + map maintenance | local "
                                  "mapping, each on its own host thread and HIP stream (the reference's tracking / LiDAR / local-mapping threads; with batched "
                                  "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
@@ -1867,9 +2011,10 @@ def main(argv=None):
                 if tlm_out is None else [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1), round(float(np.mean(tlm_out[4])), 1)],
                 "scan_points_raw/preprocessed/downsampled/selected": lid_mean,
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
-                "ba": None if not loop.ba_batch else {"iterations": int(loop.ba_stats_batch().stats[0].iterations), "trials": int(loop.ba_stats_batch().stats[0].trials),
-                                                      "planes": int(loop.ba_stats_batch().lstats[0].n_planes), "edges": int(len(wl.ba_windows[0]["edges"]))}},
-            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "host_fed": host_fed, "inertial_config": inertial, "mfma_config": mfma, "sequences_per_gpu_sweep": sweep, **({"sharded_window": sharded_window} if sharded_window else {}),
+                "ba": None if not loop.ba_batch else dict(mix=wl.ba_mix, **{k: v for k, v in (loop.ba_mix_summary(wl) or {}).items()
+                                                                             if k.endswith("min_max") or k.endswith("mean_max") or k.startswith("windows_") or k == "distinct_windows"})},
+            "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "host_fed": host_fed, "inertial_config": inertial, "mfma_config": mfma, "sequences_per_gpu_sweep": sweep,
+            "host_budget_sweep": host_budget_sweep, "value_uniform": value_uniform, **({"sharded_window": sharded_window} if sharded_window else {}),
             "stage_thread_ms_per_step_concurrent": {k: round(v, 3) for k, v in thread_ms.items()},
             "stage_wall_ms_alone": {k: round(1e3 * v, 3) for k, v in wall.items()},
             "track_calls_ms_last_step": dict(zip(("stereo_match_batch", "track_motion_model_batch", "track_local_map_batch"), [round(v, 3) for v in loop.track_ms])),

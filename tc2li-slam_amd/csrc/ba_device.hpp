@@ -22,6 +22,7 @@ constexpr int kSchurGroup = 4;
 // finds its place sooner (ba_kernels.hip)
 constexpr int kSchurLeanSlots = 128, kSchurGroupLean = 8;
 constexpr int kSchurOps = 38;  // doubles per slot in LDS: Y row-major [6][3] | W row-major [6][3] | 2 of padding (16-byte aligned blocks that spread over all banks)
+constexpr int kSolveMaxFree = 24;        // widest reduced system k_ba_solve_b factorises (144 unknowns: nine 16 x 16 tile rows in a workgroup's registers)
 constexpr int kSchurBlocksMaxFree = 21;  // every window of the sparse path (np_pad / 16 <= 8): 21 * 20 / 2 + 21 + 21 = 252 tasks
 __host__ __device__ constexpr int schur_tasks_for(int nf, int rd, int ro) { return rd * nf + ro * (nf * (nf - 1) / 2) + nf; }
 __host__ __device__ constexpr void schur_ranges(int nf, int& rd, int& ro) {

@@ -1417,6 +1417,42 @@ bool plane_extraction_finish(LockstepContext& C, int n, std::vector<int>& rc_lid
     return true;
 }
 
+// What the launches of a phase have to cover: the largest sizes among the listed windows and which kernel families they need.  Taken over
+// the whole batch once (the fusion switches follow from it) and, with the device-side LM loop, again over the windows still alive whenever that
+// list shrinks: the rounds a few stragglers need after the bulk has finished are launched for THEIR sizes and families only (no dense-path
+// kernels once the last window of more than 21 free keyframes is done, the narrow solve kernel for narrow systems).
+template <typename Win>
+BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& list, bool* all_block_parts_out = nullptr) {
+    BaBatchExtent X{};
+    bool all_block_parts = true;
+    for (int i : list) {
+        if (W[i].rc < 0) continue;
+        const BaProblemDev& pb = W[i].vp.pb;
+        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
+        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
+        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
+        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
+        if (pb.n_dups) X.any_dups = 1;
+        if (pb.sparse_schur && pb.schur_blocks) {
+            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
+                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
+                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
+                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
+            }
+        } else if (pb.sparse_schur) {
+            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
+        } else {
+            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
+        }
+        if (W[i].lidar) {
+            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
+            X.max_W = std::max(X.max_W, W[i].lidar->W);
+        }
+    }
+    if (all_block_parts_out) *all_block_parts_out = all_block_parts;
+    return X;
+}
+
 // returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
 bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
     LockstepContext& C = lockstep_ctx(group);
@@ -1424,16 +1460,14 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     for (int i = 0; i < n; ++i)
         if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
     if (!C.st) {
-        // the loop is a chain of ~140 short dependent launches: on a GPU shared with the front-end kernels they go first
+        // the loop is a chain of ~140 short dependent launches: on a GPU shared with the front-end kernels they go first.  (Round 6 also tried
+        // compute units of their own -- hipExtStreamCreateWithCUMask: the lock-step groups on 32 / 64 / 96 of the 256, every other stream of the
+        // loop on the rest.  A chain of tiny kernels beside GEMMs gains 25x from that; this one does not: its large kernels want the whole chip --
+        // 512 sequences 9.6 / 14.7 / 16.8 k frames/s against 20.2 k unpartitioned, 64 sequences 8.3 / 12.0 k against 15.1 k.  Removed.)
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
             hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
-        if (getenv("TC2LI_BA_TIMING")) {
-            int pr = 0;
-            (void)hipStreamGetPriority(C.st, &pr);
-            fprintf(stderr, "BA lock-step stream: priority %d (device range least %d .. greatest %d)\n", pr, lo, hi);
-        }
     }
     hipStream_t st = C.st;
     while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
@@ -1527,32 +1561,10 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             return false;
         }
     tm[0] = now() - t0;
-    BaBatchExtent X{};
+    std::vector<int> all_windows(n);
+    for (int i = 0; i < n; ++i) all_windows[i] = i;
     bool all_block_parts = true;
-    for (int i = 0; i < n; ++i) {
-        if (W[i].rc < 0) continue;
-        const BaProblemDev& pb = W[i].vp.pb;
-        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
-        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
-        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
-        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
-        if (pb.n_dups) X.any_dups = 1;
-        if (pb.sparse_schur && pb.schur_blocks) {
-            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
-                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
-                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
-                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
-            }
-        } else if (pb.sparse_schur) {
-            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
-        } else {
-            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
-        }
-        if (W[i].lidar) {
-            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
-            X.max_W = std::max(X.max_W, W[i].lidar->W);
-        }
-    }
+    BaBatchExtent X = batch_extent(W, all_windows, &all_block_parts);
     // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
     // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
     // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
@@ -1577,11 +1589,11 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // the pool threads plus the extra synchronisation -- 8.8 against 10.2 k frames/s at 64 sequences, no difference at 512 -- so the host
     // solve stays the default.
     const char* dev_solve_env = getenv("TC2LI_BA_DEVICE_SOLVE");
-    const bool dev_solve = dev_solve_env && atoi(dev_solve_env) != 0 && !X.any_dense && X.max_free > 0;
+    const bool dev_solve = dev_solve_env && atoi(dev_solve_env) != 0 && X.max_free <= kSolveMaxFree && X.max_free > 0;
     // TC2LI_BA_DEVICE_LM=0: the Levenberg-Marquardt decisions of rounds 2-5, on the host between the phases.  Default (round 6): on
-    // the device (ba_device.hpp: BaLmState) for every batch whose reduced systems the solve kernel takes -- all windows on the sparse Schur path.
+    // the device (ba_device.hpp: BaLmState) for every batch whose reduced systems the solve kernel takes: at most kSolveMaxFree free keyframes.
     const char* device_lm_env = getenv("TC2LI_BA_DEVICE_LM");  // (read per call: the tests run both forms in one process)
-    const bool device_lm = !(device_lm_env && atoi(device_lm_env) == 0) && !X.any_dense && !X.any_trial_fused;
+    const bool device_lm = !(device_lm_env && atoi(device_lm_env) == 0) && X.max_free <= kSolveMaxFree;
     if (device_lm && (C.d_lm.ensure(n) != hipSuccess || C.h_lm_init.ensure(n) != hipSuccess || C.h_lm.ensure(n) != hipSuccess || C.h_stop.ensure(n) != hipSuccess)) return false;
     auto fill_slot = [&](int i) {
         LockstepWindow& w = W[i];
@@ -1683,31 +1695,39 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = true; }
         std::vector<int> live, live_lidar;
         bool first_maxdiag = false;
+        BaBatchExtent XL = X;   // the extent of the windows still alive (the batch's fusion switches stay: a window's sums keep their order)
         auto refresh = [&] {
+            const size_t before = live.size();
             live.clear(); live_lidar.clear();
             for (int i = 0; i < n; ++i)
                 if (W[i].rc >= 0 && C.h_lm.p[i].status != kLmDone) { live.push_back(i); if (W[i].lidar) live_lidar.push_back(i); }
+            if (live.size() != before && !live.empty()) {
+                XL = batch_extent(W, live);
+                XL.fuse_trial = X.fuse_trial; XL.fuse_linearize = X.fuse_linearize; XL.inertial = X.inertial;
+            }
         };
         refresh();
         for (int i : live) first_maxdiag |= !(W[i].p->lambda_init > 0);
         int queued = 0, seen = 0;
         auto queue_round = [&] {
+            const double tq = now();
             const bool first = queued == 0;
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, first && first_maxdiag, st); });
+            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, first && first_maxdiag, st); });
             pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) {
                 if (first) balm_batch_launch_residual(ph, cnt, false, st);  // later the accepted estimate is the last trial: its residual and decompositions are in place
-                balm_batch_launch_hessian(ph, cnt, X, st);
+                balm_batch_launch_hessian(ph, cnt, XL, st);
             });
             pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
             pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, X, st);
-                ba_batch_launch_solve(ph, cnt, X, st);
-                ba_batch_launch_trial(ph, cnt, X, st);
+                ba_batch_launch_schur(ph, cnt, XL, st);
+                ba_batch_launch_solve(ph, cnt, XL, st);
+                ba_batch_launch_trial(ph, cnt, XL, st);
             });
-            pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
+            if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
             pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
             if (hipGetLastError() != hipSuccess || hipEventRecord(C.round_done[queued & 1], st) != hipSuccess) failed = true;
             ++queued;
+            tm[6] += now() - tq;  // the host's time to queue the rounds
         };
         t0 = now();
         while (!live.empty() && !failed) {
@@ -2134,33 +2154,11 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         if (n_dev && n_dev != n_ok) { (void)hipStreamSynchronize(st); return false; }
         dev_solve = n_dev > 0;
     }
-    BaBatchExtent X{};
-    X.inertial = 1;
+    std::vector<int> all_windows(n);
+    for (int i = 0; i < n; ++i) all_windows[i] = i;
     bool all_block_parts = true;
-    for (int i = 0; i < n; ++i) {
-        if (W[i].rc < 0) continue;
-        const BaProblemDev& pb = W[i].vp.pb;
-        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
-        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
-        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
-        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
-        if (pb.n_dups) X.any_dups = 1;
-        if (pb.sparse_schur && pb.schur_blocks) {
-            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
-                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
-                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
-                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
-            }
-        } else if (pb.sparse_schur) {
-            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
-        } else {
-            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
-        }
-        if (W[i].lidar) {
-            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
-            X.max_W = std::max(X.max_W, W[i].lidar->W);
-        }
-    }
+    BaBatchExtent X = batch_extent(W, all_windows, &all_block_parts);
+    X.inertial = 1;
     // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
     // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
     // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8

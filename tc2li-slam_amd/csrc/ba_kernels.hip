@@ -1676,7 +1676,8 @@ constexpr int kSolveThreads = 256;
 template <int NT>
 __device__ __forceinline__ void d_ba_solve_tiles(const BaBatchSlot& sl, const int n, double* s_L) {
     constexpr int kTiles = NT * (NT + 1) / 2;
-    __shared__ double s_colA[16 * 8], s_colL[16 * 8], s_dg[16 * 8], s_xs[16 * 8], s_y;
+    constexpr int kRows = 16 * 9;   // the widest variant: 24 free keyframes
+    __shared__ double s_colA[kRows], s_colL[kRows], s_dg[kRows], s_xs[kRows], s_y;
     __shared__ int s_bad;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;   // (neighbouring lanes: neighbouring columns of a row -- the loads below run along rows)
     const double* __restrict__ S = global_ptr(load_uniform(&sl.S_out));
@@ -1685,7 +1686,7 @@ __device__ __forceinline__ void d_ba_solve_tiles(const BaBatchSlot& sl, const in
     const double* __restrict__ bl = global_ptr(load_uniform(&sl.bl_lidar));
     double a[kTiles], rhs[NT];
     if (tid == 0) s_bad = 0;
-    if (tid < 16 * 8) s_colL[tid] = 0.0;   // (never written at or beyond row n: the unpredicated products there stay zero)
+    if (tid < kRows) s_colL[tid] = 0.0;   // (never written at or beyond row n: the unpredicated products there stay zero)
     // every load at a clamped (always valid) address and without a branch around it: they are all in flight together; what lies outside
     // the window's lower triangle is zeroed afterwards
     {
@@ -1766,27 +1767,31 @@ __device__ __forceinline__ void d_ba_solve_tiles(const BaBatchSlot& sl, const in
     for (int ti = 0; ti < NT; ++ti) {
         const int i = 16 * ti + ty;
 #pragma unroll
-        for (int tj = 0; tj <= ti; ++tj) { const int j = 16 * tj + tx; if (i < n && j < i) s_L[i * n + j] = a[ti * (ti + 1) / 2 + tj]; }
+        for (int tj = 0; tj <= ti; ++tj) { const int j = 16 * tj + tx; if (i < n && j < i) s_L[i * (i + 1) / 2 + j] = a[ti * (ti + 1) / 2 + tj]; }  // (packed: 24 free keyframes are 83 KB)
         if (tx == 0 && i < n) s_xs[i] = rhs[ti];
     }
     __syncthreads();
     if (tid < 64) {
         const int lane = tid;
-        double x0 = lane < n ? s_xs[lane] / s_dg[lane] : 0.0, x1 = lane + 64 < n ? s_xs[lane + 64] / s_dg[lane + 64] : 0.0;
+        double x0 = lane < n ? s_xs[lane] / s_dg[lane] : 0.0, x1 = lane + 64 < n ? s_xs[lane + 64] / s_dg[lane + 64] : 0.0,
+               x2 = lane + 128 < n ? s_xs[lane + 128] / s_dg[lane + 128] : 0.0;
         for (int k = n - 1; k >= 1; --k) {
             union { double d; int w[2]; } xk;
-            xk.d = k >= 64 ? x1 : x0;
+            xk.d = k >= 128 ? x2 : k >= 64 ? x1 : x0;
             xk.w[0] = __builtin_amdgcn_readlane(xk.w[0], k & 63);
             xk.w[1] = __builtin_amdgcn_readlane(xk.w[1], k & 63);
-            const double l0 = s_L[k * n + min(lane, k - 1)], l1 = s_L[k * n + min(max(lane + 64, 0), k - 1)];
+            const double* row = s_L + k * (k + 1) / 2;
+            const double l0 = row[min(lane, k - 1)], l1 = row[min(lane + 64, k - 1)], l2 = row[min(lane + 128, k - 1)];
             x0 = lane < k ? x0 - l0 * xk.d : x0;
             x1 = lane + 64 < k ? x1 - l1 * xk.d : x1;
+            x2 = lane + 128 < k ? x2 - l2 * xk.d : x2;
         }
         const bool bad = s_bad != 0;
         double* x_dev = global_ptr(load_uniform(&sl.x_dev));
         double* x_host = global_ptr(load_uniform(&sl.x_host));
         if (lane < n) { const double v = bad ? 0.0 : x0; x_dev[lane] = v; if (x_host) x_host[lane] = v; }
         if (lane + 64 < n) { const double v = bad ? 0.0 : x1; x_dev[lane + 64] = v; if (x_host) x_host[lane + 64] = v; }
+        if (lane + 128 < n) { const double v = bad ? 0.0 : x2; x_dev[lane + 128] = v; if (x_host) x_host[lane + 128] = v; }
         if (lane == 0) global_ptr(load_uniform(&sl.ok_host))[0] = bad ? 0 : 1;  // (device-side LM: BaLmState::solve_ok)
     }
 }
@@ -1801,6 +1806,7 @@ __device__ __forceinline__ void solve_b_body(const BaPhase& ph) {
 }
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) { solve_b_body<8>(ph); }
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve5_b(const BaPhase ph) { solve_b_body<5>(ph); }
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve9_b(const BaPhase ph) { solve_b_body<9>(ph); }  // 22-24 free keyframes (the dense Schur path's smallest windows)
 // ---- The reduced system of an INERTIAL window on the device (LocalInertialBA / LocalLVIBA: 6 unknowns per free keyframe pose + 9 per keyframe with
 // velocity / bias vertices, 375 for the 25-keyframe bLarge window; Optimizer.cc:1635-1638 solves it with g2o's sparse LinearSolverEigen).  Rounds
 // 1-4 and the first half of round 5 solved it on the host (reduced_solve.hpp: 0.55 ms of a host core per window and trial after the envelope
@@ -2378,12 +2384,15 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
     const int n = 6 * x.max_free;
-    const size_t lds = (size_t)n * n * sizeof(double);  // L for the backward sweep: 12 free keyframes 41 KB, 21: 127 KB
+    const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);  // L, packed, for the backward sweep: 12 free keyframes 21 KB, 24: 83 KB
     if (n <= 80) {
         TC2LI_LAUNCH(k_ba_solve5_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
-    } else {
-        (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 128 * 1024);
+    } else if (n <= 128) {
+        (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 96 * 1024);
         TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
+    } else {   // (the callers send no window beyond kSolveMaxFree free keyframes here)
+        (void)ensure_dynamic_lds((const void*)k_ba_solve9_b, 96 * 1024);
+        TC2LI_LAUNCH(k_ba_solve9_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
     }
 }
 // whether the two kernels get the LDS of their largest window (25 free keyframes: 160 KB, all a CU has); asked once, before a window is promised

@@ -26,7 +26,7 @@ namespace {
 constexpr int kLmThreads = 64;      // k_ba_lm_decide_b: one wavefront
 constexpr int kLmBeginThreads = 256; // k_ba_lm_begin_b: the (6W)^2 change of variables one output entry per thread
 constexpr int kLmMaxW = 7;          // windows of the batched LiDAR kernels (ba_batch_lockstep sends wider ones through the per-window path)
-constexpr int kLmMaxNp = 6 * kSchurBlocksMaxFree;
+constexpr int kLmMaxNp = 6 * kSolveMaxFree;
 
 struct LmWindow {
     const BaBatchSlot* sl;

@@ -308,6 +308,76 @@ def ba_window(seed=0, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.5, 0.05),
     return dict(poses=poses, fixed=fixed, points=pts_noisy, edges=edges, cam=cam, poses_true=poses_true, points_true=pts_true)
 
 
+def ba_window_varied(seed=0):
+    """A local-BA window drawn from the spread the reference's windows have (round 6): the keyframe that triggers local
+    mapping takes ALL its covisible keyframes (OptimizerWithLidar.cc:63-76), fixes whoever else sees their points (:106-123), and gets the
+    LiDAR edge only if more than two of them carry a surface cloud, over at most six (:226-241).  Drawn per window: 4-24 free and 2-40 fixed
+    keyframes, 500-6000 points (log-uniform), 0-15 % gross outliers, pose noise 0.2-2 x the benched window's (0.1 deg, 1 cm), a LiDAR window of
+    0 (no edge) or 3-6 clouds of 1500-3000 points, its weight 1 -- or, one window in sixteen, 1000: the optimiser then rejects steps (the edge's
+    gradient lacks the residual) -- and one in sixteen is INTERRUPTED after 2-7 iterations: the reference's tracking thread raises
+    mbAbortBA when the next keyframe waits (LocalMapping.cc:302, 908) and g2o's terminate() ends the loop; the count stands in for the moment the
+    flag arrives, so that the run stays deterministic.  (Windows that end by the `_nBad >= 3` rule do not occur at these sizes: from
+    tau = 1e-5 the damping starts at ~500 and the robust cost still falls by 0.3 % in the tenth iteration -- measured with the oracle.)
+    The same layout as ba_window() plus win_pose / clouds / weight; vectorised, its own random stream (ba_window's stays as the fixtures know it)."""
+    rng = np.random.default_rng([SEED0, 0xBA5, seed])
+    n_opt, n_fix = int(rng.integers(4, 25)), int(rng.integers(2, 41))
+    n_points = int(np.exp(rng.uniform(np.log(500.0), np.log(6000.0))))
+    outlier_frac = float(rng.uniform(0.0, 0.15))
+    kind = min(int(rng.integers(0, 16)), 2)   # 0: heavy LiDAR edge (one window in 16), 1: interrupted (one in 16), 2: ordinary
+    noise_scale = float(rng.uniform(0.2, 2.0))
+    iterations = int(rng.integers(2, 8)) if kind == 1 else 10
+    pose_noise = (0.1 * noise_scale, 0.01 * noise_scale)
+    W = int(rng.choice([0, 3, 4, 5, 6], p=[0.15, 0.15, 0.2, 0.2, 0.3]))
+    W = W if W <= n_opt else (n_opt if n_opt >= 3 else 0)
+    if kind == 0 and W == 0:
+        W = min(n_opt, 5)
+    cloud_points = int(rng.integers(1500, 3001))
+    K = n_opt + n_fix
+    k = np.arange(K)
+    yaw = 0.03 * np.sin(0.4 * k)
+    Rcw = np.stack([_rot_from_rvec(np.array([0.0, y, 0.0])).T for y in yaw])
+    twc = np.stack([0.3 * np.sin(0.2 * k), 0.02 * np.cos(0.3 * k), 1.0 * k], 1)
+    tcw = -np.einsum("kij,kj->ki", Rcw, twc)
+    pts = np.stack([rng.uniform(-12, 12, n_points), rng.uniform(-3, 1.65, n_points), rng.uniform(2.0, K + 40.0, n_points)], 1)
+    pc = np.einsum("kij,pj->pki", Rcw, pts) + tcw[None]                      # [P, K, 3]
+    z = pc[..., 2]
+    zs = np.where(z > 0.5, z, 1.0)
+    u, v = FX * pc[..., 0] / zs + CX, FY * pc[..., 1] / zs + CY
+    seen = (z >= 1.0) & (z <= 45.0) & (u > 20) & (u < WIDTH - 20) & (v > 20) & (v < HEIGHT - 20) & (rng.random((n_points, K)) <= 0.55)
+    lvl = np.clip(np.floor(np.log(np.maximum(zs, 1.0) / 6.0) / np.log(1.2) + 3), 0, 7).astype(int)
+    sig = (1.2 ** np.arange(8))[lvl]
+    uo, vo = u + rng.normal(0, 1, u.shape) * sig, v + rng.normal(0, 1, u.shape) * sig
+    ur = uo - BF / zs + rng.normal(0, 1, u.shape) * sig
+    out = rng.random(u.shape) < outlier_frac
+    uo = uo + out * rng.choice([-1.0, 1.0], u.shape) * rng.uniform(8, 20, u.shape)
+    vo = vo + out * rng.choice([-1.0, 1.0], u.shape) * rng.uniform(8, 20, u.shape)
+    ur = np.where(rng.random(u.shape) < 0.1, -1.0, ur)
+    keep = seen.sum(1) >= 2                                                  # points with at least two observations, as local mapping keeps them
+    seen &= keep[:, None]
+    remap = -np.ones(n_points, int); remap[keep] = np.arange(keep.sum())
+    pi, ki = np.nonzero(seen)                                                # point-major, keyframes ascending: ba_window's edge order
+    edges = np.stack([remap[pi], ki, np.float32(uo[pi, ki]), np.float32(vo[pi, ki]), np.float32(ur[pi, ki]),
+                      np.float32(1.0) / np.float32(sig[pi, ki] ** 2)], 1).astype(np.float64)
+    pts_true = pts[keep]
+    poses_true = np.array([np.concatenate([_quat_from_rot(Rcw[j]), tcw[j]]) for j in range(K)])
+    fixed = np.zeros(K, np.uint8); fixed[:n_fix] = 1
+    poses = poses_true.copy()
+    for j in range(n_fix, K):
+        dR = _rot_from_rvec(rng.normal(0, np.deg2rad(pose_noise[0]), 3))
+        poses[j] = np.concatenate([_quat_from_rot(dR @ Rcw[j]), tcw[j] + rng.normal(0, pose_noise[1], 3)])
+    poses = poses.astype(np.float32).astype(np.float64)
+    pts_noisy = (pts_true * (1 + rng.normal(0, 0.01 * min(noise_scale, 1.0), (len(pts_true), 1)))).astype(np.float32).astype(np.float64)
+    cam = np.array([np.float32(FX), np.float32(FY), np.float32(CX), np.float32(CY), np.float32(BF)], np.float64)
+    w = dict(poses=poses, fixed=fixed, points=pts_noisy, edges=edges, cam=cam, poses_true=poses_true, points_true=pts_true,
+             params=dict(n_opt=n_opt, n_fix=n_fix, n_points=int(keep.sum()), outlier_frac=outlier_frac, noise_scale=noise_scale, lidar_keyframes=W,
+                         iterations=iterations, kind=("heavy LiDAR edge", "interrupted")[kind] if kind < 2 else "ordinary"))
+    w["win_pose"] = list(range(K - 1, K - 1 - W, -1))
+    w["clouds"] = ba_window_clouds(w, w["win_pose"], n_points=cloud_points, seed=seed) if W else []
+    w["weight"] = 1000.0 if kind == 0 else 1.0
+    w["iterations"] = iterations
+    return w
+
+
 # ---- LiDAR clouds for the BALM term of the local BA -----------------------------------------------------------------
 # KITTI-00 camera <- LiDAR extrinsic used by the synthetic windows: LiDAR axes x forward / y left / z up, camera axes
 # x right / y down / z forward, LiDAR 0.27 m behind and 0.08 m above the camera.

@@ -228,6 +228,46 @@ def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, sy
         assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6) and np.array_equal(dpos, want[3])
 
 
+def varied_window_dict(pkg, synthetic, w):
+    d = dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), iterations=w["iterations"])
+    if w["win_pose"]:
+        d.update(win_pose=w["win_pose"], clouds=w["clouds"], Tcl7=synthetic.TCL7, weight=w["weight"])
+    return d
+
+
+def test_mixed_lock_step_batch_against_the_oracle_window_by_window(pkg, oracle, synthetic):
+    """a 16-window batch from the generator bench.py's headline uses (synthetic.ba_window_varied: 4-24 free and 2-40 fixed
+    keyframes, 500-6000 points, 0-15 % outliers, LiDAR windows of 0 / 3-6 clouds, heavy LiDAR edges whose steps are rejected, windows
+    interrupted after 2-7 iterations), through ONE lock-step group -- the Levenberg-Marquardt loop on the device, every window at its
+    own pace -- against the oracle window by window: the same iterations and trials, the same planes, poses <= 1e-4 relative.  The batch holds
+    windows of the sparse and of the dense Schur path (more than 21 free keyframes), windows that end early and windows that retry."""
+    seeds = list(range(14)) + [17, 39]   # (the two heavy LiDAR edges of the benched 64 among them)
+    ws = [synthetic.ba_window_varied(s) for s in seeds]
+    assert any(w["params"]["n_opt"] > 21 for w in ws) and any(not w["win_pose"] for w in ws) and any(w["weight"] > 1 for w in ws)
+    batch = pkg.capi.BaBatch([varied_window_dict(pkg, synthetic, w) for w in ws], ws[0]["cam"])
+    assert batch.run_group(0) == len(ws)
+    its, extra_trials = [], 0
+    for i, w in enumerate(ws):
+        if w["win_pose"]:
+            want = oracle.local_ba_lidar(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], w["win_pose"], w["clouds"], synthetic.TCL7, w["weight"],
+                                         iterations=w["iterations"])
+        else:
+            want = oracle.local_ba(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], iterations=w["iterations"])
+        r = batch.result(i)
+        poses, pts, chi2, dpos, stats = r[:5]
+        assert batch.results[i] == want[4] and stats.trials == int(want[5]["trials"].sum()), (i, w["params"], batch.results[i], want[4], stats.trials, want[5]["trials"])
+        if w["win_pose"]:
+            assert r[5].n_planes == want[6] and abs(r[5].residual - want[7]["residual"]) <= 1e-6 * max(abs(want[7]["residual"]), 1e-9), i
+        if want[4] > 0:
+            assert abs(stats.final_chi2 - want[5]["chi2"][-1]) <= 1e-6 * want[5]["chi2"][-1], i
+        for k in range(len(poses)):
+            assert rel_pose_err(poses[k], want[0][k]) < POSE_RTOL, (i, k)
+        assert np.allclose(pts, want[1], rtol=POSE_RTOL, atol=1e-6) and np.array_equal(dpos, want[3]), i
+        its.append(want[4])
+        extra_trials += int(want[5]["trials"].sum()) - want[4]
+    assert min(its) < 10 and max(its) == 10 and extra_trials > 0, (its, extra_trials)  # windows that stop early, windows with rejected steps
+
+
 def test_group_call_equals_the_batch_call(pkg, synthetic):
     """tc2li_local_bundle_adjustment_batch_group (one lock-step group on a context of the caller's choice: the mapping workers of a
     multi-sequence system) gives every window the result of the common batch call, bit for bit; two groups side by side do not disturb
