@@ -30,6 +30,25 @@ __host__ __device__ constexpr void schur_ranges(int nf, int& rd, int& ro) {
     const int pref[7][2] = {{5, 2}, {4, 2}, {3, 2}, {2, 2}, {3, 1}, {2, 1}, {1, 1}};
     for (int k = 0; k < 7; ++k) { rd = pref[k][0]; ro = pref[k][1]; if (schur_tasks_for(nf, rd, ro) <= 256) return; }
 }
+// The WIDE lean form (round 6): windows of 22 .. kSchurLeanMaxFree free keyframes -- one side of the old sparse / dense boundary, where the
+// dense path's full-width MFMA kernel (139 KB of LDS per workgroup: it waits for whole CUs beside the other stages) cost 15 of the mixed loop's
+// 108 ms of kernel time per step for an eighth of the windows -- run the same lean product on a workgroup of 512 threads: 24 free keyframes
+// are 24 diagonal + 276 pair + 24 coefficient tasks.  The finest cut of the landmark ranges whose tasks fit 512 threads and whose closing
+// sums fit the operand area.
+constexpr int kSchurLeanMaxFree = 24;
+__host__ __device__ constexpr void schur_ranges_wide(int nf, int& rd, int& ro) {
+    const int pref[4][2] = {{4, 1}, {3, 1}, {2, 1}, {1, 1}};
+    for (int k = 0; k < 4; ++k) { rd = pref[k][0]; ro = pref[k][1]; if (schur_tasks_for(nf, rd, ro) <= 512) return; }
+}
+constexpr bool schur_lean_wide_fits() {
+    for (int nf = kSchurBlocksMaxFree + 1; nf <= kSchurLeanMaxFree; ++nf) {
+        int rd = 1, ro = 1;
+        schur_ranges_wide(nf, rd, ro);
+        if (schur_tasks_for(nf, rd, ro) > 512 || 36 * ((rd > 1 ? nf : 0) + (ro > 1 ? nf * (nf - 1) / 2 : 0)) > kSchurLeanSlots * kSchurOps || nf > 255) return false;
+    }
+    return true;
+}
+static_assert(schur_lean_wide_fits(), "k_ba_schur_lean_wide: tasks or closing sums of some window size do not fit the workgroup");
 __host__ __device__ inline int schur_task_count(int nf) { int rd = 1, ro = 1; schur_ranges(nf, rd, ro); return schur_tasks_for(nf, rd, ro); }
 // landmark ranks [64 q / R, 64 (q + 1) / R) as a bit mask
 __host__ __device__ inline unsigned long long schur_range_mask(int R, int q) {
@@ -213,6 +232,7 @@ struct BaBatchExtent {
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
     int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
+    int any_block_wide;                 // some window runs the lean form on 512 threads (more than kSchurBlocksMaxFree free keyframes)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int fuse_linearize;  // the linearisation's last workgroup of a window does k_ba_reduce_all_b's / k_ba_maxdiag_b's sums (round 5)
     int any_dups;  // some window has duplicate (point, free pose) edges: k_ba_dups_b after the linearisation's sums

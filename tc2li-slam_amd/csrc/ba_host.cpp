@@ -162,8 +162,10 @@ struct VisualProblem {
     // TC2LI_BA_SCHUR_LEAN (read per window; default 1): the lean form of the block-by-block Schur product (ba_device.hpp); 0: the 256-slot form
     const char* lean_env = getenv("TC2LI_BA_SCHUR_LEAN");
     const char* mfma_env0 = getenv("TC2LI_BA_SCHUR_MFMA");
-    const bool schur_lean = (lean_env ? atoi(lean_env) != 0 : true) && (6 * n_free + 1 + 15) / 16 <= 8 && n_free <= kSchurBlocksMaxFree &&
-                            !(mfma_env0 && atoi(mfma_env0) != 0);  // only where the block-by-block form runs (blocks_form below)
+    // (round 6: the lean form also takes the windows of 22 .. kSchurLeanMaxFree free keyframes, on 512 threads -- schur_ranges_wide)
+    const bool lean_on = (lean_env ? atoi(lean_env) != 0 : true) && !(mfma_env0 && atoi(mfma_env0) != 0);
+    const bool lean_wide = lean_on && n_free > kSchurBlocksMaxFree && n_free <= kSchurLeanMaxFree;
+    const bool schur_lean = lean_on && (((6 * n_free + 1 + 15) / 16 <= 8 && n_free <= kSchurBlocksMaxFree) || lean_wide);  // only where the block-by-block form runs (blocks_form below)
     struct DupEdge { int pose, edge, slot; };
     std::vector<DupEdge> dups;
     std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
@@ -176,7 +178,7 @@ struct VisualProblem {
         // slots follow the landmarks sorted by the first and the last free pose that sees them, and a slice is a CHUNK of 16 landmarks -- a
         // landmark of a temporal window is seen from a run of consecutive keyframes, so a chunk touches a band of the reduced system and the
         // product skips the rest.  (The covisibility windows of the sparse path are not banded: see above.)
-        const bool dense_window = (6 * n_free + 1 + 15) / 16 > 8;
+        const bool dense_window = (6 * n_free + 1 + 15) / 16 > 8 && !lean_wide;
         const int kSliceEdges = dense_window ? std::numeric_limits<int>::max() : schur_lean ? kSchurLeanSlots : 256;
         const int kSliceLandmarks = dense_window ? kUnitChunkHost : 64;
         std::vector<int> order(n_points);
@@ -252,11 +254,11 @@ struct VisualProblem {
     if (max_group_landmarks > 256) { set_error("more than 256 landmarks without edges in a row"); return TC2LI_ERR_INVALID; }  // (a landmark-role workgroup has a thread per landmark)
     np = 6 * n_free;
     // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
-    const bool sparse = (np + 1 + 15) / 16 <= 8;
+    const bool sparse = (np + 1 + 15) / 16 <= 8 || lean_wide;
     const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
     // TC2LI_BA_SCHUR_MFMA=1 (read per window): the zero-padded MFMA form of the sparse product instead of the block-by-block one (A/B measurements)
     const char* mfma_env = getenv("TC2LI_BA_SCHUR_MFMA");
-    const bool blocks_form = sparse && n_free <= kSchurBlocksMaxFree && !(mfma_env && atoi(mfma_env) != 0);
+    const bool blocks_form = sparse && (n_free <= kSchurBlocksMaxFree || lean_wide) && !(mfma_env && atoi(mfma_env) != 0);
     const int n_schur_slices = (int)slice_off.size() - 1;
     int schur_group = 1;
     if (sparse) {
@@ -379,7 +381,7 @@ struct VisualProblem {
     pb.schur_rd = pb.schur_ro = 1;
     decide_trial_fused();
     if (blocks_form) {
-        schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
+        if (lean_wide) schur_ranges_wide(n_free, pb.schur_rd, pb.schur_ro); else schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
     }
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
     pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p; pb.Y = sparse ? nullptr : ws.d_Y.p;
@@ -1438,6 +1440,7 @@ BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& li
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
                 X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
                 if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
+                if (pb.n_free > kSchurBlocksMaxFree) X.any_block_wide = 1;
             }
         } else if (pb.sparse_schur) {
             X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);

@@ -1236,6 +1236,11 @@ __global__ __launch_bounds__(256, 3) void k_ba_schur_lean(BaProblemDev pb, doubl
     extern __shared__ double s_schur[];
     d_ba_schur_lean(pb, blockIdx.x, lambda, s_schur);
 }
+// the same body on 512 threads: windows of 22 .. kSchurLeanMaxFree free keyframes (ba_device.hpp: schur_ranges_wide)
+__global__ __launch_bounds__(512) void k_ba_schur_lean_wide(BaProblemDev pb, double lambda) {
+    extern __shared__ double s_schur[];
+    d_ba_schur_lean(pb, blockIdx.x, lambda, s_schur);
+}
 
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
                                                          double* __restrict__ bs_out, double* __restrict__ bp_host = nullptr) {
@@ -1628,7 +1633,13 @@ __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) 
 __global__ __launch_bounds__(256, 3) void k_ba_schur_lean_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
+    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free || pb.n_free > kSchurBlocksMaxFree || (int)blockIdx.x >= sl.n_slices) return;
+    d_ba_schur_lean(pb, blockIdx.x, view_.lambda, s_schur);
+}
+__global__ __launch_bounds__(512) void k_ba_schur_lean_wide_b(const BaPhase ph) {
+    extern __shared__ double s_schur[];
+    TC2LI_SLOT(y);
+    if (!pb.sparse_schur || pb.schur_blocks != 2 || pb.n_free <= kSchurBlocksMaxFree || (int)blockIdx.x >= sl.n_slices) return;
     d_ba_schur_lean(pb, blockIdx.x, view_.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaPhase ph) {
@@ -2294,7 +2305,8 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
     const int np = 6 * pb.n_free;
     if (pb.sparse_schur && pb.schur_blocks == 2) {
-        if (n_slices) TC2LI_LAUNCH(k_ba_schur_lean, dim3(n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
+        if (n_slices && pb.n_free > kSchurBlocksMaxFree) TC2LI_LAUNCH(k_ba_schur_lean_wide, dim3(n_slices), dim3(512), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
+        else if (n_slices) TC2LI_LAUNCH(k_ba_schur_lean, dim3(n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
     } else if (pb.sparse_schur && pb.schur_blocks) {
         if (n_slices) {
             schur_blocks_attr();
@@ -2355,8 +2367,10 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
     }
     // (the lean form held to four wavefronts per SIMD -- 128 registers, 116 B of scratch -- measured 87 against 69 us alone and 294-317 against
     // 290-294 us in the loop: not kept)
-    if (x.max_block_parts && x.any_block_lean)
-        TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts, n_active), dim3(256), schur_lean_lds_bytes(x.max_block_free), st, ph);
+    if (x.max_block_parts && x.any_block_lean && x.min_block_free <= kSchurBlocksMaxFree)
+        TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts, n_active), dim3(256), schur_lean_lds_bytes(std::min(x.max_block_free, kSchurBlocksMaxFree)), st, ph);
+    if (x.max_block_parts && x.any_block_wide)  // the windows of 22 .. 24 free keyframes: the same product on 512 threads (each kernel skips the other's windows)
+        TC2LI_LAUNCH(k_ba_schur_lean_wide_b, dim3(x.max_block_parts, n_active), dim3(512), schur_lean_lds_bytes(x.max_block_free), st, ph);
     if (x.max_sparse_slices) {
         const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
         if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
