@@ -32,9 +32,10 @@ __host__ __device__ constexpr void schur_ranges(int nf, int& rd, int& ro) {
 }
 // The WIDE lean form (round 6): windows of 22 .. kSchurLeanMaxFree free keyframes -- one side of the old sparse / dense boundary, where the
 // dense path's full-width MFMA kernel (139 KB of LDS per workgroup: it waits for whole CUs beside the other stages) cost 15 of the mixed loop's
-// 108 ms of kernel time per step for an eighth of the windows -- run the same lean product on a workgroup of 512 threads: 24 free keyframes
-// are 24 diagonal + 276 pair + 24 coefficient tasks.  The finest cut of the landmark ranges whose tasks fit 512 threads and whose closing
-// sums fit the operand area.
+// 108 ms of kernel time per step for an eighth of the windows -- run the same lean product with TWO workgroups per part, each half of the up
+// to 512 tasks (24 free keyframes are 24 diagonal + 276 pair + 24 coefficient tasks), in the launch of the narrower windows.  The finest cut
+// of the landmark ranges whose tasks fit 512 threads, whose diagonal blocks' range tasks stay in the first half and whose closing sums fit
+// the operand area.
 constexpr int kSchurLeanMaxFree = 24;
 __host__ __device__ constexpr void schur_ranges_wide(int nf, int& rd, int& ro) {
     const int pref[4][2] = {{4, 1}, {3, 1}, {2, 1}, {1, 1}};
@@ -44,7 +45,8 @@ constexpr bool schur_lean_wide_fits() {
     for (int nf = kSchurBlocksMaxFree + 1; nf <= kSchurLeanMaxFree; ++nf) {
         int rd = 1, ro = 1;
         schur_ranges_wide(nf, rd, ro);
-        if (schur_tasks_for(nf, rd, ro) > 512 || 36 * ((rd > 1 ? nf : 0) + (ro > 1 ? nf * (nf - 1) / 2 : 0)) > kSchurLeanSlots * kSchurOps || nf > 255) return false;
+        if (schur_tasks_for(nf, rd, ro) > 512 || 36 * ((rd > 1 ? nf : 0) + (ro > 1 ? nf * (nf - 1) / 2 : 0)) > kSchurLeanSlots * kSchurOps || nf > 255 ||
+            rd * nf > 256 || ro != 1) return false;  // (a block's range tasks meet in their workgroup's LDS: the diagonal ones in the first half, pairs uncut)
     }
     return true;
 }

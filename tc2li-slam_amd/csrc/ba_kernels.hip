@@ -1079,8 +1079,10 @@ __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks(BaProblemDev pb, dou
 __host__ __device__ inline size_t schur_lean_lds_bytes(int nf) {
     return (size_t)kSchurLeanSlots * kSchurOps * sizeof(double) + 64 * 3 * sizeof(double) + 2 * (size_t)nf * 8 + 64 * (size_t)nf;
 }
-__device__ __forceinline__ void d_ba_schur_lean(const BaProblemDev& pb, const int part, const double lambda, double* __restrict__ lds) {
-    const int tid = threadIdx.x, NF = pb.n_free, np = 6 * NF, ld = pb.np_pad;
+// task_base: 0, or 256 for the second workgroup of a part of a WIDE window (22 .. kSchurLeanMaxFree free keyframes: up to 512 tasks; both
+// workgroups stage the part's slots, each takes its half of the tasks -- schur_ranges_wide keeps every block's range tasks in one half)
+__device__ __forceinline__ void d_ba_schur_lean(const BaProblemDev& pb, const int part, const double lambda, double* __restrict__ lds, const int task_base = 0) {
+    const int tid = threadIdx.x, task = tid + task_base, NF = pb.n_free, np = 6 * NF, ld = pb.np_pad;
     const int Rd = pb.schur_rd, Ro = pb.schur_ro;
     const int nD = Rd * NF, nO = Ro * (NF * (NF - 1) / 2), nT = nD + nO + NF;
     double* const ops = lds;
@@ -1090,16 +1092,16 @@ __device__ __forceinline__ void d_ba_schur_lean(const BaProblemDev& pb, const in
     // ---- this thread's task (the numbering of d_ba_schur_blocks) ----
     int t_i = 0, t_j = 0, t_kind = -1, t_q = 0, t_R = 1, t_close = -1;  // t_close: the block's place in the closing area (blocks of more than one range)
     unsigned long long t_sel = 0;
-    if (tid < nD) {
-        t_i = t_j = tid / Rd; t_q = tid - t_i * Rd; t_R = Rd; t_sel = schur_range_mask(Rd, t_q); t_kind = 0;
+    if (task < nD) {
+        t_i = t_j = task / Rd; t_q = task - t_i * Rd; t_R = Rd; t_sel = schur_range_mask(Rd, t_q); t_kind = 0;
         t_close = t_i;
-    } else if (tid < nD + nO) {
-        const int n = (tid - nD) / Ro;  // pair number i (i - 1) / 2 + j, i > j
+    } else if (task < nD + nO) {
+        const int n = (task - nD) / Ro;  // pair number i (i - 1) / 2 + j, i > j
         int i = 1;
         while (i * (i + 1) / 2 <= n) ++i;
-        t_i = i; t_j = n - i * (i - 1) / 2; t_q = (tid - nD) - n * Ro; t_R = Ro; t_sel = schur_range_mask(Ro, t_q); t_kind = 0;
+        t_i = i; t_j = n - i * (i - 1) / 2; t_q = (task - nD) - n * Ro; t_R = Ro; t_sel = schur_range_mask(Ro, t_q); t_kind = 0;
         t_close = (Rd > 1 ? NF : 0) + n;
-    } else if (tid < nT) { t_i = t_j = tid - nD - nO; t_sel = ~0ull; t_kind = 1; }
+    } else if (task < nT) { t_i = t_j = task - nD - nO; t_sel = ~0ull; t_kind = 1; }
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; ++k) acc[k] = 0.0;
@@ -1236,10 +1238,10 @@ __global__ __launch_bounds__(256, 3) void k_ba_schur_lean(BaProblemDev pb, doubl
     extern __shared__ double s_schur[];
     d_ba_schur_lean(pb, blockIdx.x, lambda, s_schur);
 }
-// the same body on 512 threads: windows of 22 .. kSchurLeanMaxFree free keyframes (ba_device.hpp: schur_ranges_wide)
-__global__ __launch_bounds__(512) void k_ba_schur_lean_wide(BaProblemDev pb, double lambda) {
+// windows of 22 .. kSchurLeanMaxFree free keyframes (ba_device.hpp: schur_ranges_wide): two workgroups per part, each half of the tasks
+__global__ __launch_bounds__(256, 3) void k_ba_schur_lean_wide(BaProblemDev pb, double lambda) {
     extern __shared__ double s_schur[];
-    d_ba_schur_lean(pb, blockIdx.x, lambda, s_schur);
+    d_ba_schur_lean(pb, blockIdx.x >> 1, lambda, s_schur, 256 * (blockIdx.x & 1));
 }
 
 __device__ __forceinline__ void d_ba_schur_finish(const BaProblemDev& pb, const int bx, double lambda, int n_slices, double* __restrict__ S_out,
@@ -1633,14 +1635,11 @@ __global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) 
 __global__ __launch_bounds__(256, 3) void k_ba_schur_lean_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free || pb.n_free > kSchurBlocksMaxFree || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_lean(pb, blockIdx.x, view_.lambda, s_schur);
-}
-__global__ __launch_bounds__(512) void k_ba_schur_lean_wide_b(const BaPhase ph) {
-    extern __shared__ double s_schur[];
-    TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks != 2 || pb.n_free <= kSchurBlocksMaxFree || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_lean(pb, blockIdx.x, view_.lambda, s_schur);
+    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free) return;
+    // a wide window (more than kSchurBlocksMaxFree free keyframes): two workgroups per part, the same launch as everybody else's
+    const int halves = pb.n_free > kSchurBlocksMaxFree ? 2 : 1, part = (int)blockIdx.x / halves;
+    if (part >= sl.n_slices) return;
+    d_ba_schur_lean(pb, part, view_.lambda, s_schur, 256 * ((int)blockIdx.x - part * halves));
 }
 __global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
@@ -2305,7 +2304,7 @@ void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, 
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
     const int np = 6 * pb.n_free;
     if (pb.sparse_schur && pb.schur_blocks == 2) {
-        if (n_slices && pb.n_free > kSchurBlocksMaxFree) TC2LI_LAUNCH(k_ba_schur_lean_wide, dim3(n_slices), dim3(512), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
+        if (n_slices && pb.n_free > kSchurBlocksMaxFree) TC2LI_LAUNCH(k_ba_schur_lean_wide, dim3(2 * n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
         else if (n_slices) TC2LI_LAUNCH(k_ba_schur_lean, dim3(n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
     } else if (pb.sparse_schur && pb.schur_blocks) {
         if (n_slices) {
@@ -2367,10 +2366,8 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
     }
     // (the lean form held to four wavefronts per SIMD -- 128 registers, 116 B of scratch -- measured 87 against 69 us alone and 294-317 against
     // 290-294 us in the loop: not kept)
-    if (x.max_block_parts && x.any_block_lean && x.min_block_free <= kSchurBlocksMaxFree)
-        TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts, n_active), dim3(256), schur_lean_lds_bytes(std::min(x.max_block_free, kSchurBlocksMaxFree)), st, ph);
-    if (x.max_block_parts && x.any_block_wide)  // the windows of 22 .. 24 free keyframes: the same product on 512 threads (each kernel skips the other's windows)
-        TC2LI_LAUNCH(k_ba_schur_lean_wide_b, dim3(x.max_block_parts, n_active), dim3(512), schur_lean_lds_bytes(x.max_block_free), st, ph);
+    if (x.max_block_parts && x.any_block_lean)  // (a wide window -- 22 .. 24 free keyframes -- takes two workgroups per part)
+        TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts * (x.any_block_wide ? 2 : 1), n_active), dim3(256), schur_lean_lds_bytes(x.max_block_free), st, ph);
     if (x.max_sparse_slices) {
         const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
         if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
