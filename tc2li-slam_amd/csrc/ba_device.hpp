@@ -234,7 +234,7 @@ struct BaBatchExtent {
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
     int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
-    int any_block_wide;                 // some window runs the lean form on 512 threads (more than kSchurBlocksMaxFree free keyframes)
+    int any_block_wide;                 // some window runs the lean form with two workgroups per part (more than kSchurBlocksMaxFree free keyframes)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int fuse_linearize;  // the linearisation's last workgroup of a window does k_ba_reduce_all_b's / k_ba_maxdiag_b's sums (round 5)
     int any_dups;  // some window has duplicate (point, free pose) edges: k_ba_dups_b after the linearisation's sums

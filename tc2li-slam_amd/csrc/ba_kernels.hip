@@ -1805,18 +1805,24 @@ __device__ __forceinline__ void d_ba_solve_tiles(const BaBatchSlot& sl, const in
         if (lane == 0) global_ptr(load_uniform(&sl.ok_host))[0] = bad ? 0 : 1;  // (device-side LM: BaLmState::solve_ok)
     }
 }
+// Three variants -- 5 tile rows up to 13 free keyframes, 8 up to 21, 9 up to kSolveMaxFree -- and ONE launch per phase: the launcher picks the
+// variant of the widest window among those still alive, narrower windows ride along in it.  Measured in the mixed loop of bench.py (64
+// distinct windows, an eighth of them with 22-24 free keyframes), frames/s at 512 sequences: one variant per launch 17.9-18.2 k; a launch per
+// width class, each skipping the others' windows, 16.8-17.0 k (a launch more per round and class costs more beside the other stages than
+// the narrow windows save); one kernel dispatching on the window's width 17.6 k, and 19.6 against 20.2 k on the uniform batch (256 registers
+// for everybody: the workgroup waits for half of a CU's register file on all four SIMDs).
 template <int NT>
 __device__ __forceinline__ void solve_b_body(const BaPhase& ph) {
     extern __shared__ double s_solve[];
     const BaSlotView view_ = ba_slot_view(ph, blockIdx.x);
     if (!view_.active) return;
     const int n = 6 * view_.pb.n_free;
-    if (n == 0 || !view_.sl.x_dev || n > 16 * NT) return;  // (the launcher picks NT for the call's widest window)
+    if (n == 0 || !view_.sl.x_dev || n > 16 * NT) return;  // (the launcher picks NT for the widest window of the launch)
     d_ba_solve_tiles<NT>(view_.sl, n, s_solve);
 }
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) { solve_b_body<8>(ph); }
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve5_b(const BaPhase ph) { solve_b_body<5>(ph); }
-__global__ __launch_bounds__(kSolveThreads) void k_ba_solve9_b(const BaPhase ph) { solve_b_body<9>(ph); }  // 22-24 free keyframes (the dense Schur path's smallest windows)
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_b(const BaPhase ph) { solve_b_body<8>(ph); }
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve9_b(const BaPhase ph) { solve_b_body<9>(ph); }  // 22-24 free keyframes
 // ---- The reduced system of an INERTIAL window on the device (LocalInertialBA / LocalLVIBA: 6 unknowns per free keyframe pose + 9 per keyframe with
 // velocity / bias vertices, 375 for the 25-keyframe bLarge window; Optimizer.cc:1635-1638 solves it with g2o's sparse LinearSolverEigen).  Rounds
 // 1-4 and the first half of round 5 solved it on the host (reduced_solve.hpp: 0.55 ms of a host core per window and trial after the envelope
@@ -2394,14 +2400,14 @@ void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent&
 }
 void ba_batch_launch_solve(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
-    const int n = 6 * x.max_free;
+    const int n = 6 * x.max_free;   // (the callers send no window beyond kSolveMaxFree free keyframes here)
     const size_t lds = (size_t)n * (n + 1) / 2 * sizeof(double);  // L, packed, for the backward sweep: 12 free keyframes 21 KB, 24: 83 KB
     if (n <= 80) {
         TC2LI_LAUNCH(k_ba_solve5_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
     } else if (n <= 128) {
         (void)ensure_dynamic_lds((const void*)k_ba_solve_b, 96 * 1024);
         TC2LI_LAUNCH(k_ba_solve_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
-    } else {   // (the callers send no window beyond kSolveMaxFree free keyframes here)
+    } else {
         (void)ensure_dynamic_lds((const void*)k_ba_solve9_b, 96 * 1024);
         TC2LI_LAUNCH(k_ba_solve9_b, dim3(n_active), dim3(kSolveThreads), lds, st, ph);
     }
