@@ -366,17 +366,19 @@ def compact_line(full, detail_path=None):
     ic = full.get("inertial_config")
     if isinstance(ic, dict):
         line["inertial_config"] = {**_pick(ic, ("value", "unit", "ms_per_step", "sequences", "steps", "lviba_windows_per_step", "lviba_window")),
-                                   "roofline": compact_roofline(ic.get("roofline")), "cpu_baseline": compact_cpu(ic.get("cpu_baseline")),
+                                   "roofline": _pick(compact_roofline(ic.get("roofline")), ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step", "traffic")),
+                                   "cpu_baseline": _pick(compact_cpu(ic.get("cpu_baseline")), ("value", "unit", "cores", "kind", "single_sequence")),
                                    "single_sequence": _pick(ic.get("single_sequence") or {}, ("value", "ms_per_frame"))}
     mf = full.get("mfma_config")
     if isinstance(mf, dict):
-        line["mfma_config"] = {**_pick(mf, ("windows_per_s", "ms_per_batch", "free_keyframes")), "roofline": compact_roofline(mf.get("roofline"))}
+        line["mfma_config"] = {**_pick(mf, ("windows_per_s", "ms_per_batch", "free_keyframes")),
+                               "roofline": _pick(compact_roofline(mf.get("roofline")), ("kernel", "bound", "achieved", "peak", "unit", "frac", "useful_frac", "avg_launch_ms", "traffic"))}
     sw = full.get("sequences_per_gpu_sweep")
     if isinstance(sw, dict):
         line["sequences_per_gpu_sweep"] = {k: v for k, v in sw.items() if k != "unit"}
         line["sequences_per_gpu_sweep"]["note"] = "frames/s at that many sequences per step on this ONE GPU; N > 1 over RCCL is unmeasured on hardware"
-    if isinstance(full.get("value_uniform"), dict):
-        line["value_uniform"] = _pick(full["value_uniform"], ("value", "ms_per_step", "ba"))
+    if isinstance(full.get("value_uniform"), dict):   # (a number: the leg must not be shed with the optional objects below)
+        line["value_uniform"] = full["value_uniform"].get("value")
     hbs = full.get("host_budget_sweep")
     if isinstance(hbs, dict):
         line["host_budget_sweep"] = {k: (v if not isinstance(v, dict) else _pick(v, ("value", "cpu_s_per_wall_s", "threads"))) for k, v in hbs.items() if k != "note"}
@@ -387,7 +389,7 @@ def compact_line(full, detail_path=None):
     if detail_path:
         line["detail"] = detail_path
     # the budget is a contract: shed the optional legs, least important first, rather than print a line the driver cannot parse
-    for k in ("stage_thread_ms_per_step_concurrent", "sharded_window", "value_uniform", "host_budget_sweep", "sequences_per_gpu_sweep", "mfma_config", "host_fed", "single_sequence", "inertial_config"):
+    for k in ("stage_thread_ms_per_step_concurrent", "sharded_window", "host_budget_sweep", "sequences_per_gpu_sweep", "mfma_config", "host_fed", "single_sequence", "inertial_config"):
         if len(json.dumps(line)) <= LINE_BUDGET:
             break
         line.pop(k, None)
@@ -1184,7 +1186,10 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # these FLOPs at this covisibility, 55 % of the measured matrix peak when it has the GPU to itself -- DESIGN.md section 4.)
             # (since round 3 the default is k_ba_schur_blocks_b: exactly these products, on the f64 vector unit; the MFMA form is TC2LI_BA_SCHUR_MFMA=1)
             "k_ba_schur_blocks_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),
-            "k_ba_schur_lean_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),  # the same products in 128-slot slices (the default since round 4)
+            # the same products in 128-slot slices (the default since round 4).  Priced in BYTES since round 6: per slot the W block (144 B) and its
+            # three indices, per landmark Hll + b_l (72 B), per part of 8 slices the lower triangle of S and the coefficient row out -- at ~5 FLOP
+            # per byte the kernel sits below the f64 vector unit's ridge (66 TFLOP/s over 6.3 TB/s = 10.5): HBM is the roof that bounds it
+            "k_ba_schur_lean_b": (nw * tr * (Ef * (144 + 12) + P * 72 + max(1, -(-slices // 8)) * (lower + 6 * nf) * 8), "B"),
             "k_ba_schur_sparse4_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_sparse9_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
