@@ -1184,15 +1184,19 @@ def algorithmic_work(wl, loop, nkp, lid, ba):
             # S -= W D^-1 W^T: SURVEY 8d prices it per landmark with n (free-pose) observations at n (n + 1) / 2 x (6x3 . 3x3 + 6x3 . 3x6) =
             # n (n + 1) / 2 x 324 FLOP.  (The kernel runs it as a zero-padded dense f64 MFMA product per chunk of landmarks: about nine times
             # these FLOPs at this covisibility, 55 % of the measured matrix peak when it has the GPU to itself -- DESIGN.md section 4.)
-            # (since round 3 the default is k_ba_schur_blocks_b: exactly these products, on the f64 vector unit; the MFMA form is TC2LI_BA_SCHUR_MFMA=1)
-            "k_ba_schur_blocks_b": (nw * tr * pairs * 324.0, "FLOP_VALU"),
             # the same products in 128-slot slices (the default since round 4).  Priced in BYTES since round 6: per slot the W block (144 B) and its
             # three indices, per landmark Hll + b_l (72 B), per part of 8 slices the lower triangle of S and the coefficient row out -- at ~5 FLOP
             # per byte the kernel sits below the f64 vector unit's ridge (66 TFLOP/s over 6.3 TB/s = 10.5): HBM is the roof that bounds it
             "k_ba_schur_lean_b": (nw * tr * (Ef * (144 + 12) + P * 72 + max(1, -(-slices // 8)) * (lower + 6 * nf) * 8), "B"),
-            "k_ba_schur_sparse4_b": (nw * tr * pairs * 324.0, "FLOP"),
-            "k_ba_schur_sparse9_b": (nw * tr * pairs * 324.0, "FLOP"),
             "k_ba_schur_finish_b": (nw * tr * (slices + 1) * lower * 8, "B"),
+            # round 6, the reduced system's LDL^T on the device (one workgroup per window and trial): the lower triangles of S and of the LiDAR
+            # block and the two right-hand sides in, the step out -- the three variants (5 / 8 / 9 tile rows) read the same bytes
+            "k_ba_solve5_b": (nw * tr * (2 * lower + 3 * 6 * nf) * 8, "B"), "k_ba_solve_b": (nw * tr * (2 * lower + 3 * 6 * nf) * 8, "B"),
+            "k_ba_solve9_b": (nw * tr * (2 * lower + 3 * 6 * nf) * 8, "B"),
+            # the LM bookkeeping on the device: per linearisation the plane term's (6W)^2 Hessian + gradient in and its camera-se3 form out (twice:
+            # the kept copy and the window's (6K)^2 block entries), per trial the step and b_p in, the 128-byte state in and out (+ its host mirror)
+            "k_ba_lm_begin_b": (nw * lin * ((36 * ba["win"] ** 2 + 18 * ba["win"]) * 8 * 3 + 256), "B"),
+            "k_ba_lm_decide_b": (nw * tr * (3 * 6 * nf * 8 + 3 * 128), "B"),
             "k_ba_trial_update_b": (nw * tr * (Ef * (144 + 4) + P * (48 + 24 + 24 + 24)), "B"),
             "k_ba_errors_b": (nw * tr * E * 112, "B"),
             "k_ba_errors_reduce_b": (nw * tr * E * 112, "B"),  # the same pass; a window's last workgroup adds the window's ~110 partial sums
@@ -2016,6 +2020,7 @@ def main(argv=None):
                 if tlm_out is None else [int(np.mean(np.diff(loop.local_off))), round(float(np.mean(tlm_out[3])), 1), round(float(np.mean(tlm_out[4])), 1)],
                 "scan_points_raw/preprocessed/downsampled/selected": lid_mean,
                 "map_points_per_sequence_start/end": [loop.map_points0, map_points_end], "map_incremental_to_add/no_need_last_step": loop.map_adds,
+                "ba_options": pkg.capi.ba_options(),
                 "ba": None if not loop.ba_batch else dict(mix=wl.ba_mix, **{k: v for k, v in (loop.ba_mix_summary(wl) or {}).items()
                                                                              if k.endswith("min_max") or k.endswith("mean_max") or k.startswith("windows_") or k == "distinct_windows"})},
             "roofline": roofline, "cpu_baseline": cpu, "single_sequence": single, "host_fed": host_fed, "inertial_config": inertial, "mfma_config": mfma, "sequences_per_gpu_sweep": sweep,

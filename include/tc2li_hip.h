@@ -971,6 +971,10 @@ int tc2li_pose_inertial_optimization_batch(tc2li_pose_inertial_problem* problems
  * ---------------------------------------------------------------------------------------------- */
 int tc2li_profile_enable(int on);
 int tc2li_profile_report(char* text, int capacity);
+/* The environment switches the bundle-adjustment entry points would run under if called now, as one line of JSON (what a benchmark logs beside
+ * its numbers): {"device_lm": 1, "device_solve": 0, "fuse_linearize": 0, "fuse_trial": 0, "lvi_device_solve": 1, "lockstep": 1, "groups": 3}.
+ * Returns the number of bytes the text needs (including the terminator); writes at most `capacity`.  No reference counterpart. */
+int tc2li_ba_options(char* text, int capacity);
 int tc2li_diag_peaks(double* mfma_f64_tflops, double* fma_f64_tflops, double* hbm_copy_gbps);
 /* The shader clock (GHz) the chip holds inside the two arithmetic loops of tc2li_diag_peaks, from s_memtime against the constant 100 MHz
  * counter: the data sheet's 78.6 TFLOP/s of f64 matrix / vector arithmetic assume 2.4 GHz. */

@@ -198,6 +198,16 @@ def profile_enable(on=True):
     _check(lib().tc2li_profile_enable(int(bool(on))))
 
 
+def ba_options():
+    """tc2li_ba_options -> dict of the bundle-adjustment switches in effect."""
+    import json
+    f = lib().tc2li_ba_options
+    f.argtypes = [C.c_char_p, C.c_int]
+    buf = C.create_string_buffer(512)
+    f(buf, len(buf))
+    return json.loads(buf.value.decode())
+
+
 def profile_report():
     """{kernel name: (launches, total ms)} of the launches since the last report (call with idle streams)."""
     f = lib().tc2li_profile_report

@@ -230,10 +230,10 @@ constexpr unsigned kBaAcceptedInTrial = 1, kBaWantMaxdiag = 2, kBaWantHpp = 4;
 struct BaBatchExtent {
     int max_edges, max_points, max_poses, max_free, max_free_edges, max_groups, max_np_pad, max_slices, max_planes, max_chunks, max_W;
     // max_np_pad / max_slices: over the windows on the dense Schur path; the sparse ones:
-    int any_dense, max_sparse_np_pad, max_sparse_slices;
+    int any_dense;
     // the windows on the block-by-block sparse path (pb.schur_blocks): partial sums per window, free keyframes
     int max_block_parts, max_block_free, min_block_free;
-    int any_block_fat, any_block_lean;  // which of the two block-by-block kernels the call's windows need (pb.schur_blocks 1 / 2)
+    int any_block_lean;                 // some window runs the lean block-by-block product
     int any_block_wide;                 // some window runs the lean form with two workgroups per part (more than kSchurBlocksMaxFree free keyframes)
     int fuse_trial;   // the trial errors' last workgroup of a window does k_ba_trial_reduce_b's sums
     int fuse_linearize;  // the linearisation's last workgroup of a window does k_ba_reduce_all_b's / k_ba_maxdiag_b's sums (round 5)

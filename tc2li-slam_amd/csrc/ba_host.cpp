@@ -23,6 +23,35 @@ static_assert(sizeof(tc2li_camera) == sizeof(CameraD), "ABI layout");
 
 namespace {
 
+// The environment switches of the bundle-adjustment entry points, parsed in ONE place at the start of every call (the tests flip some of
+// them between two calls of one process) and reported by tc2li_ba_options (bench.py logs it in its detail file).  Round 6 retired the
+// switches whose A/B measurements are in DESIGN.md and whose losing form was only kept as a fall-back: TC2LI_BA_SCHUR_LEAN / _MFMA / _GROUP
+// (the lean Schur product is the only block-by-block form), TC2LI_BA_FUSE, TC2LI_BA_XP_PINNED, TC2LI_BA_PRE_SCHUR, TC2LI_BA_PHASE_SERIAL,
+// TC2LI_BA_DENSE_SLICES.
+struct BaOptions {
+    bool device_lm = true;        // TC2LI_BA_DEVICE_LM=0: the LM decisions on the host between the phases (rounds 2-5)
+    bool device_solve = false;    // TC2LI_BA_DEVICE_SOLVE=1: host-driven loop with the reduced systems solved by k_ba_solve_b
+    bool fuse_linearize = false;  // TC2LI_BA_FUSE_LIN=1: the linearisation's closing sums by the window's last workgroup
+    bool fuse_trial = false;      // TC2LI_BA_FUSE_TRIAL=1: a trial as one launch over the landmark groups (pb.trial_fused)
+    bool lvi_device_solve = true; // TC2LI_LVI_DEVICE_SOLVE=0: the inertial windows' reduced systems on the host's envelope solver
+    bool lockstep = true;         // TC2LI_BA_NO_LOCKSTEP: every window through the one-window path
+    bool timing = false;          // TC2LI_BA_TIMING: per-call laps on stderr
+    int groups = 3;               // TC2LI_BA_LOCKSTEP_GROUPS: lock-step groups of the batch entry points
+    std::string shard_fail;       // TC2LI_TEST_SHARD_FAIL: "<rank>:setup" / "<rank>:trial" (tests of the sharded window's failure protocol)
+    static BaOptions read() {
+        auto flag = [](const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; };
+        BaOptions o;
+        o.device_lm = flag("TC2LI_BA_DEVICE_LM", true); o.device_solve = flag("TC2LI_BA_DEVICE_SOLVE", false);
+        o.fuse_linearize = flag("TC2LI_BA_FUSE_LIN", false); o.fuse_trial = flag("TC2LI_BA_FUSE_TRIAL", false);
+        o.lvi_device_solve = flag("TC2LI_LVI_DEVICE_SOLVE", true);
+        o.lockstep = getenv("TC2LI_BA_NO_LOCKSTEP") == nullptr; o.timing = getenv("TC2LI_BA_TIMING") != nullptr;
+        if (const char* e = getenv("TC2LI_BA_LOCKSTEP_GROUPS")) o.groups = atoi(e);
+        o.groups = std::max(1, std::min(kMaxLockstepGroups, o.groups));
+        if (const char* e = getenv("TC2LI_TEST_SHARD_FAIL")) o.shard_fail = e;
+        return o;
+    }
+};
+
 struct PoseOptWorkspace {
     DevBuf<PoseProblem> d_probs;
     DevBuf<double> d_Xw, d_poses, d_chi2;
@@ -117,9 +146,8 @@ struct VisualProblem {
     // beside the other stages' wavefronts.  In a loop bound by the kernels' combined occupancy, fewer launches is not the lever; shorter
     // residency is.
     void decide_trial_fused() {
-        const char* env = getenv("TC2LI_BA_FUSE_TRIAL");
         const size_t pose_bytes = (size_t)pb.n_poses * (pb.inertial ? sizeof(ImuPose) : sizeof(Se3));
-        pb.trial_fused = env && atoi(env) != 0 && np <= kBacksubMaxNp && pose_bytes <= (size_t)kTrialPoseBytes && max_group_landmarks <= 256 ? 1 : 0;
+        pb.trial_fused = BaOptions::read().fuse_trial && np <= kBacksubMaxNp && pose_bytes <= (size_t)kTrialPoseBytes && max_group_landmarks <= 256 ? 1 : 0;
     }
 
     int setup(BaWorkspace& ws, const double* poses7, const uint8_t* fixed, int n_poses, const double* points3, int n_points,
@@ -159,13 +187,10 @@ struct VisualProblem {
     // fl_off: per landmark [begin, end) of its slots, the landmarks in index order.  (Tried: slots in the order of the poses a landmark
     // is seen from, so that a chunk of the Schur kernel spans a narrow band of poses and the product's empty tiles can be skipped -- the
     // windows' covisibility is not banded enough for that, and the linearisation lost its locality: 64 -> 98 us.)
-    // TC2LI_BA_SCHUR_LEAN (read per window; default 1): the lean form of the block-by-block Schur product (ba_device.hpp); 0: the 256-slot form
-    const char* lean_env = getenv("TC2LI_BA_SCHUR_LEAN");
-    const char* mfma_env0 = getenv("TC2LI_BA_SCHUR_MFMA");
-    // (round 6: the lean form also takes the windows of 22 .. kSchurLeanMaxFree free keyframes, on 512 threads -- schur_ranges_wide)
-    const bool lean_on = (lean_env ? atoi(lean_env) != 0 : true) && !(mfma_env0 && atoi(mfma_env0) != 0);
-    const bool lean_wide = lean_on && n_free > kSchurBlocksMaxFree && n_free <= kSchurLeanMaxFree;
-    const bool schur_lean = lean_on && (((6 * n_free + 1 + 15) / 16 <= 8 && n_free <= kSchurBlocksMaxFree) || lean_wide);  // only where the block-by-block form runs (blocks_form below)
+    // Every window of at most kSchurLeanMaxFree (24) free keyframes runs the lean block-by-block Schur product (ba_device.hpp) -- up to
+    // kSchurBlocksMaxFree (21) with one workgroup per part, above with two (schur_ranges_wide); wider windows the block-sparse MFMA kernels.
+    const bool lean_wide = n_free > kSchurBlocksMaxFree && n_free <= kSchurLeanMaxFree;
+    const bool schur_lean = (6 * n_free + 1 + 15) / 16 <= 8 || lean_wide;
     struct DupEdge { int pose, edge, slot; };
     std::vector<DupEdge> dups;
     std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
@@ -179,7 +204,7 @@ struct VisualProblem {
         // landmark of a temporal window is seen from a run of consecutive keyframes, so a chunk touches a band of the reduced system and the
         // product skips the rest.  (The covisibility windows of the sparse path are not banded: see above.)
         const bool dense_window = (6 * n_free + 1 + 15) / 16 > 8 && !lean_wide;
-        const int kSliceEdges = dense_window ? std::numeric_limits<int>::max() : schur_lean ? kSchurLeanSlots : 256;
+        const int kSliceEdges = dense_window ? std::numeric_limits<int>::max() : kSchurLeanSlots;
         const int kSliceLandmarks = dense_window ? kUnitChunkHost : 64;
         std::vector<int> order(n_points);
         for (int l = 0; l < n_points; ++l) order[l] = l;
@@ -254,23 +279,17 @@ struct VisualProblem {
     if (max_group_landmarks > 256) { set_error("more than 256 landmarks without edges in a row"); return TC2LI_ERR_INVALID; }  // (a landmark-role workgroup has a thread per landmark)
     np = 6 * n_free;
     // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
-    const bool sparse = (np + 1 + 15) / 16 <= 8 || lean_wide;
+    const bool sparse = schur_lean;
     const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
-    // TC2LI_BA_SCHUR_MFMA=1 (read per window): the zero-padded MFMA form of the sparse product instead of the block-by-block one (A/B measurements)
-    const char* mfma_env = getenv("TC2LI_BA_SCHUR_MFMA");
-    const bool blocks_form = sparse && (n_free <= kSchurBlocksMaxFree || lean_wide) && !(mfma_env && atoi(mfma_env) != 0);
     const int n_schur_slices = (int)slice_off.size() - 1;
     int schur_group = 1;
     if (sparse) {
-        // TC2LI_BA_SCHUR_GROUP (measurements): slices per part of the lean form
-        const char* grp_env = getenv("TC2LI_BA_SCHUR_GROUP");
-        schur_group = !blocks_form ? 1 : !schur_lean ? kSchurGroup : grp_env ? std::max(1, std::min(64, atoi(grp_env))) : kSchurGroupLean;
+        schur_group = kSchurGroupLean;  // slices per part
         n_slices = ba_schur_parts(n_schur_slices, schur_group);  // partial sums in S_part
         k_per_slice = 0;
     } else {
         // dense windows (round 5: d_ba_schur_units): the chunks (slices of slice_off: 16 landmarks each) in at most 8 ranges = partial sums
-        const char* ds_env = getenv("TC2LI_BA_DENSE_SLICES");  // (measurements; read per window)
-        const int want_slices = ds_env ? std::max(1, std::min(64, atoi(ds_env))) : 8;  // (full-width form, 32 windows per launch beside two other groups: 2 / 4 / 8 slices 0.263 / 0.154 / 0.099 ms)
+        const int want_slices = 8;  // (full-width form, 32 windows per launch beside two other groups: 2 / 4 / 8 slices 0.263 / 0.154 / 0.099 ms)
         k_per_slice = std::min(64, std::max(1, (n_schur_slices + want_slices - 1) / want_slices));   // chunks per partial sum (at most kUnitMaxChunks: ba_kernels.hip)
         n_slices = std::max(1, (n_schur_slices + k_per_slice - 1) / k_per_slice);
     }
@@ -377,10 +396,10 @@ struct VisualProblem {
     pb.dup_off = dups.empty() ? nullptr : (const int*)(d + o_dup_off);
     pb.dup_edge = dups.empty() ? nullptr : (const int*)(d + o_dup_edge);
     pb.dup_slot = dups.empty() ? nullptr : (const int*)(d + o_dup_slot);
-    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = blocks_form ? (schur_lean ? 2 : 1) : 0; pb.schur_group = schur_group; pb.n_schur_slices = n_schur_slices;  // (dense windows: the chunks of d_ba_schur_units)
+    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = sparse ? 2 : 0; pb.schur_group = schur_group; pb.n_schur_slices = n_schur_slices;  // (dense windows: the chunks of d_ba_schur_units)
     pb.schur_rd = pb.schur_ro = 1;
     decide_trial_fused();
-    if (blocks_form) {
+    if (sparse) {
         if (lean_wide) schur_ranges_wide(n_free, pb.schur_rd, pb.schur_ro); else schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
     }
     pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
@@ -469,6 +488,8 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     }
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     hipStream_t st = (hipStream_t)stream_;
+    const BaOptions opt = BaOptions::read();
+    const std::string& inj_s = opt.shard_fail;
     // ---- sharded window: a failure is agreed on, no rank leaves alone -------------------------------------------------------
     // Every all-reduce carries one more element, the status word (0 = fine, 1 = this rank failed), and every rank reads it at
     // the synchronisation that follows: a peer's failure makes all ranks return TC2LI_ERR_COMM from the same collective.  A rank
@@ -547,7 +568,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
         h_stat[6] = 0.0; h_stat[7] = 1.0;
         if (iterations > 0) next = Collective{d_red, 1, TC2LI_REDUCE_SUM};
         else result_sum_next = true;  // the wrapper's result sum comes first
-        if (const char* inj = getenv("TC2LI_TEST_SHARD_FAIL")) {  // tests: "<rank>:setup" makes that rank fail before its first collective
+        if (const char* inj = inj_s.empty() ? nullptr : inj_s.c_str()) {  // tests: "<rank>:setup" makes that rank fail before its first collective
             int r = -1; char where[16] = {0};
             if (sscanf(inj, "%d:%15s", &r, where) == 2 && r == shard->rank && !strcmp(where, "setup")) {
                 set_error("injected failure (TC2LI_TEST_SHARD_FAIL=%s)", inj);
@@ -590,7 +611,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
     auto& d_depth = ws.d_depth;
     const size_t E = n_edges, P = n_points;
 
-    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    const bool kTiming = opt.timing;
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -731,7 +752,7 @@ static int lv_ba_impl(double* poses7, const uint8_t* fixed, int n_poses, double*
                 TC2LI_SH_CHECK(hipStreamSynchronize(st));
                 if (sharded && peer_failed()) return (int)TC2LI_ERR_COMM;
                 if (sharded)
-                    if (const char* inj = getenv("TC2LI_TEST_SHARD_FAIL")) {  // tests: "<rank>:trial" fails here, where the next collective is not known yet
+                    if (const char* inj = inj_s.empty() ? nullptr : inj_s.c_str()) {  // tests: "<rank>:trial" fails here, where the next collective is not known yet
                         int r = -1; char where[16] = {0};
                         if (sscanf(inj, "%d:%15s", &r, where) == 2 && r == shard->rank && !strcmp(where, "trial")) {
                             set_error("injected failure (TC2LI_TEST_SHARD_FAIL=%s)", inj);
@@ -962,8 +983,7 @@ struct InertialTerm {
     // (band <= kLviBand).  The decision depends on the window alone: the same alone and in a batch.  TC2LI_LVI_DEVICE_SOLVE=0: the host's
     // envelope LDL^T (reduced_solve.hpp) for every window.
     bool device_solve_ok() const {
-        const char* env = getenv("TC2LI_LVI_DEVICE_SOLVE");  // (read per call: the tests run both solvers in one process)
-        if ((env && atoi(env) == 0) || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows || !lvi_device_solve_available()) return false;
+        if (!BaOptions::read().lvi_device_solve || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows || !lvi_device_solve_available()) return false;
         for (const InertialLinkHost& lk_ : L) {
             const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2];
             if (i1 >= 0 && i2 >= 0 && std::abs(i1 - i2) > 2) return false;
@@ -1439,12 +1459,10 @@ BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& li
             if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
                 X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
                 X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
-                if (pb.schur_blocks == 2) X.any_block_lean = 1; else X.any_block_fat = 1;
+                X.any_block_lean = 1;
                 if (pb.n_free > kSchurBlocksMaxFree) X.any_block_wide = 1;
             }
-        } else if (pb.sparse_schur) {
-            X.max_sparse_np_pad = std::max(X.max_sparse_np_pad, pb.np_pad); X.max_sparse_slices = std::max(X.max_sparse_slices, W[i].vp.n_slices);
-        } else {
+        } else if (!pb.sparse_schur) {
             X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
         }
         if (W[i].lidar) {
@@ -1460,6 +1478,7 @@ BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& li
 bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
     LockstepContext& C = lockstep_ctx(group);
     std::lock_guard<std::mutex> lk(C.mu);
+    const BaOptions opt = BaOptions::read();
     for (int i = 0; i < n; ++i)
         if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
     if (!C.st) {
@@ -1487,7 +1506,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
     double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LockstepWindow> W(n);
-    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    const bool kTiming = opt.timing;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = now();
     const double t_begin = t0;
@@ -1572,18 +1591,16 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
     // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
     // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
-    // are a launch; removed.)  TC2LI_BA_FUSE=0 (read per call): the separate launch.
+    // are a launch; removed.)
     {
-        const char* fuse_env = getenv("TC2LI_BA_FUSE");
-        X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
+        X.fuse_trial = all_block_parts ? 1 : 0;
         // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
         // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
         // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
         // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
         // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
         // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
-        const char* fuse_lin_env = getenv("TC2LI_BA_FUSE_LIN");
-        X.fuse_linearize = fuse_lin_env && atoi(fuse_lin_env) != 0 ? 1 : 0;
+        X.fuse_linearize = opt.fuse_linearize ? 1 : 0;
     }
     // TC2LI_BA_DEVICE_SOLVE=1 (read per call): the reduced systems of the batch are solved on the device (k_ba_solve_b; every window on the
     // sparse Schur path, i.e. at most 21 free keyframes) -- Schur product, solve and trial estimate are then one queue of launches with one
@@ -1591,12 +1608,10 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // workgroup-per-window LDL^T (its substitutions are serial chains through LDS) takes longer on the stream than the host's solves on
     // the pool threads plus the extra synchronisation -- 8.8 against 10.2 k frames/s at 64 sequences, no difference at 512 -- so the host
     // solve stays the default.
-    const char* dev_solve_env = getenv("TC2LI_BA_DEVICE_SOLVE");
-    const bool dev_solve = dev_solve_env && atoi(dev_solve_env) != 0 && X.max_free <= kSolveMaxFree && X.max_free > 0;
+    const bool dev_solve = opt.device_solve && X.max_free <= kSolveMaxFree && X.max_free > 0;
     // TC2LI_BA_DEVICE_LM=0: the Levenberg-Marquardt decisions of rounds 2-5, on the host between the phases.  Default (round 6): on
     // the device (ba_device.hpp: BaLmState) for every batch whose reduced systems the solve kernel takes: at most kSolveMaxFree free keyframes.
-    const char* device_lm_env = getenv("TC2LI_BA_DEVICE_LM");  // (read per call: the tests run both forms in one process)
-    const bool device_lm = !(device_lm_env && atoi(device_lm_env) == 0) && X.max_free <= kSolveMaxFree;
+    const bool device_lm = opt.device_lm && X.max_free <= kSolveMaxFree;
     if (device_lm && (C.d_lm.ensure(n) != hipSuccess || C.h_lm_init.ensure(n) != hipSuccess || C.h_lm.ensure(n) != hipSuccess || C.h_stop.ensure(n) != hipSuccess)) return false;
     auto fill_slot = [&](int i) {
         LockstepWindow& w = W[i];
@@ -1643,11 +1658,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     };
     // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
     // (a pool dispatch costs more than it saves, and far more on a busy host)
-    static const int kSerialBelow = getenv("TC2LI_BA_PHASE_SERIAL") ? atoi(getenv("TC2LI_BA_PHASE_SERIAL")) : 0;
-    auto phase_for = [&](int cnt, const std::function<void(int)>& fn) {
-        if (cnt <= kSerialBelow) { for (int k = 0; k < cnt; ++k) fn(k); }
-        else pool.parallel_for(cnt, fn);
-    };
+    auto phase_for = [&](int cnt, const std::function<void(int)>& fn) { pool.parallel_for(cnt, fn); };
     bool failed = false;
     // the table and everything the setup deferred (uploads, operand fills): one launch; the windows' megabyte input blocks go through the copy engines (launch_copy_tasks)
     {
@@ -1667,8 +1678,8 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
     // own stream (not hipMemcpyAsync: the runtime's copy path is where the other groups' 1.4 MB window blocks are queued)
     // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
     // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
-    // 28.6-29.1 ms per step; TC2LI_BA_XP_PINNED=0: the one-entry k_copy_tasks launch of rounds 3-4)
-    static const bool xp_pinned = !(getenv("TC2LI_BA_XP_PINNED") && atoi(getenv("TC2LI_BA_XP_PINNED")) == 0);
+    // 28.6-29.1 ms per step against the one-entry k_copy_tasks launch of rounds 3-4)
+    constexpr bool xp_pinned = true;
     auto stage_steps = [&](const std::vector<int>& step) {
         for (size_t k = 0; k < step.size(); ++k) {
             const LockstepWindow& w = W[step[k]];
@@ -1789,7 +1800,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         // current lambda (known unless this is the first iteration of a window whose lambda comes from computeLambdaInit) -- so it is queued
         // behind the linearisation and the phase's one synchronisation covers both: a host round trip fewer per iteration, and the host's part
         // of the linearisation (the LiDAR term's change of variables) runs beside the product.  TC2LI_BA_PRE_SCHUR=0: queued after the host's part.
-        static const bool kPreSchur = !(getenv("TC2LI_BA_PRE_SCHUR") && atoi(getenv("TC2LI_BA_PRE_SCHUR")) == 0);
+        constexpr bool kPreSchur = true;
         bool pre_schur = kPreSchur && !dev_solve && !any_maxdiag;
         if (pre_schur) {
             for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
@@ -2045,6 +2056,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
                         int group = 0) {
     LockstepContext& C = lvi_lockstep_ctx(group);
     std::lock_guard<std::mutex> lk(C.mu);
+    const BaOptions opt = BaOptions::read();
     for (int i = 0; i < n; ++i)
         if (problems[i].lidar && problems[i].lidar->n_keyframes > 7) return false;
     if (!C.st) {
@@ -2065,7 +2077,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
     double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
     std::vector<LviWindow> W(n);
-    static const bool kTiming = getenv("TC2LI_BA_TIMING") != nullptr;
+    const bool kTiming = opt.timing;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // setup, linearise (device + host edges), host after linearise, schur, solve, trial, trial cost, results
     const double t_begin = kTiming ? now() : 0;
@@ -2166,18 +2178,16 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
     // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
     // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
-    // are a launch; removed.)  TC2LI_BA_FUSE=0 (read per call): the separate launch.
+    // are a launch; removed.)
     {
-        const char* fuse_env = getenv("TC2LI_BA_FUSE");
-        X.fuse_trial = all_block_parts && !(fuse_env && atoi(fuse_env) == 0) ? 1 : 0;
+        X.fuse_trial = all_block_parts ? 1 : 0;
         // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
         // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
         // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
         // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
         // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
         // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
-        const char* fuse_lin_env = getenv("TC2LI_BA_FUSE_LIN");
-        X.fuse_linearize = fuse_lin_env && atoi(fuse_lin_env) != 0 ? 1 : 0;
+        X.fuse_linearize = opt.fuse_linearize ? 1 : 0;
     }
     auto fill_slot = [&](int i) {
         LviWindow& w = W[i];
@@ -2210,8 +2220,8 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     }
     // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
     // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
-    // 28.6-29.1 ms per step; TC2LI_BA_XP_PINNED=0: the one-entry k_copy_tasks launch of rounds 3-4)
-    static const bool xp_pinned = !(getenv("TC2LI_BA_XP_PINNED") && atoi(getenv("TC2LI_BA_XP_PINNED")) == 0);
+    // 28.6-29.1 ms per step against the one-entry k_copy_tasks launch of rounds 3-4)
+    constexpr bool xp_pinned = true;
     auto stage_steps = [&](const std::vector<int>& step) {
         for (size_t k = 0; k < step.size(); ++k) {
             const LviWindow& w = W[step[k]];
@@ -2279,7 +2289,7 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         });
         // (the first trial's Schur product behind the linearisation, as in ba_batch_lockstep: the host's inertial edges, the LiDAR term's change of
         // variables and the upload of the reduced system's inertial part run beside it)
-        static const bool kPreSchur = !(getenv("TC2LI_BA_PRE_SCHUR") && atoi(getenv("TC2LI_BA_PRE_SCHUR")) == 0);
+        constexpr bool kPreSchur = true;
         bool pre_schur = kPreSchur && !any_maxdiag;
         if (pre_schur) {
             for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
@@ -2518,10 +2528,11 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
     const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
     WorkerPool* pool = &named_pool(kPoolBaGroup0);  // persistent: its threads keep their streams and workspaces
-    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;  // A/B switch for measurements
+    const BaOptions opt = BaOptions::read();
+    const bool kNoLockstep = !opt.lockstep;
     // The lock-step loop is a chain of dependent launches with a host step after every phase: while the host works the stream is
     // empty.  Several groups of windows, each a lock-step batch of its own on its own stream and host thread, fill each other's gaps.
-    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
+    const int kGroups = opt.groups;
     // windows the lock-step groups could not take (a LiDAR window outside the batched kernels' range: a group that declines has written
     // nothing but zeroed stats) go through the one-window path below -- those windows only, every other window keeps its lock-step result
     std::vector<uint8_t> todo(n_problems, 1);
@@ -2566,6 +2577,16 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
     return ok;
 }
 
+int tc2li_ba_options(char* text, int capacity) {
+    const BaOptions o = BaOptions::read();
+    char buf[256];
+    const int n = snprintf(buf, sizeof(buf), "{\"device_lm\": %d, \"device_solve\": %d, \"fuse_linearize\": %d, \"fuse_trial\": %d, \"lvi_device_solve\": %d, "
+                           "\"lockstep\": %d, \"groups\": %d}", (int)o.device_lm, (int)o.device_solve, (int)o.fuse_linearize, (int)o.fuse_trial, (int)o.lvi_device_solve,
+                           (int)o.lockstep, o.groups);
+    if (text && capacity > 0) { const int m = std::min(capacity - 1, n); memcpy(text, buf, m); text[m] = 0; }
+    return n + 1;
+}
+
 int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int group, int32_t* results) {
     if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam || group < 0 || group >= kMaxLockstepGroups) {
         set_error("tc2li_local_bundle_adjustment_batch_group: invalid argument (group 0 .. %d)", kMaxLockstepGroups - 1);
@@ -2573,7 +2594,8 @@ int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, 
     }
     if (n_problems == 0) return 0;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
+    const BaOptions opt = BaOptions::read();
+    const bool kNoLockstep = !opt.lockstep;
     // ONE lock-step group on the caller's thread: the context `group` (stream, work spaces, host pool) is the caller's choice, so that the
     // mapping workers of a multi-sequence system run their windows side by side without meeting at the end of a common call
     bool done = false;
@@ -2596,8 +2618,9 @@ int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, i
     if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam) { set_error("tc2li_local_lvi_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
     if (n_problems == 0) return 0;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
-    static const int kGroups = std::max(1, std::min(kMaxLockstepGroups, getenv("TC2LI_BA_LOCKSTEP_GROUPS") ? atoi(getenv("TC2LI_BA_LOCKSTEP_GROUPS")) : 3));
+    const BaOptions opt = BaOptions::read();
+    const bool kNoLockstep = !opt.lockstep;
+    const int kGroups = opt.groups;
     // as in tc2li_local_bundle_adjustment_batch: only the windows of a group that declined go through the one-window path
     std::vector<uint8_t> todo(n_problems, 1);
     if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
@@ -2667,7 +2690,8 @@ int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* probl
     }
     if (n_problems == 0) return 0;
     if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    static const bool kNoLockstep = getenv("TC2LI_BA_NO_LOCKSTEP") != nullptr;
+    const BaOptions opt = BaOptions::read();
+    const bool kNoLockstep = !opt.lockstep;
     bool done = false;
     if (n_problems > 1 && !kNoLockstep) done = lvi_batch_lockstep(problems, n_problems, calib, cam, named_pool(kPoolLviGroup0 + group), results, group);
     if (!done) {  // a window outside the batched kernels' range, windows that disagree about the reduced system's solver, or a batch of one

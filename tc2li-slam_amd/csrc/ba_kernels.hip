@@ -799,115 +799,6 @@ __global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chu
     d_ba_schur_units(pb, blockIdx.x, blockIdx.y, chunks_per_slice, lambda, L);
 }
 
-// ---- the Schur product from the landmark-major W blocks ----
-// One workgroup per slice of landmarks: at most 256 edges with a free pose (one per thread) of at most 64 landmarks, cut by the host
-// (slice_off; fl_place = the landmark's rank within its slice).  Every thread loads its 6x3 block W up front -- the only round trip to
-// memory -- and forms W D^-1; then, a chunk of 16 (8) landmarks = 48 (24) operand rows at a time, the threads of the chunk put their
-// blocks into two LDS operands [rows][np_pad] that are zero elsewhere (and clear them again after the chunk's MFMAs).  Column 6 n_free
-// of the first operand takes D^-1 b_l, so that row 6 n_free of the product is sum_l W D^-1 b_l.  The dense operands of
-// k_ba_schur_prepare (2 x 3 n_points x np_pad doubles per window, written and read every iteration) never exist; HBM sees the W blocks
-// once.  The tiles on and below the diagonal are dealt to the four wavefronts round-robin; a tile accumulates its k-steps in ascending order, chunk after chunk, so the result does not depend on the launch.
-constexpr int kSchurChunkSmall = 16, kSchurChunkLarge = 8;  // landmarks per chunk at 4 / 9 tiles per wavefront (LDS: 2 x 3 x chunk x ldw doubles)
-__host__ __device__ inline int schur_ldw(int np_pad) { return np_pad % 32 == 16 ? np_pad : np_pad + 16; }  // rows r, r+1 on disjoint banks
-
-template <int TPW, int kSchurChunk>  // TPW tiles per wavefront: the tiles(tiles + 1) / 2 tiles on and below the diagonal are dealt round-robin
-__device__ __forceinline__ void d_ba_schur_sparse(const BaProblemDev& pb, const int slice, const double lambda, double* __restrict__ lds) {
-    constexpr int kSchurRows = 3 * kSchurChunk;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int np = 6 * pb.n_free, ld = pb.np_pad, tiles = ld / 16, ldw = schur_ldw(ld);
-    double* Yt = lds;                     // [rows][ldw]: (W D^-1)^T, column np: D^-1 b_l
-    double* Wt = lds + kSchurRows * ldw;  // [rows][ldw]: W^T
-    const int s0 = pb.slice_off[slice], s1 = pb.slice_off[slice + 1];
-    const int n_chunks = pb.fl_place[s1 - 1] / kSchurChunk + 1;  // the last edge belongs to the last landmark of the slice
-    const int s = s0 + tid;
-    double W[18], y[3][6], db[3];
-    int my_chunk = -1, at = 0;
-    bool first = false;
-    if (s < s1) {
-        const int l = pb.fl_lm[s], place = pb.fl_place[s];
-        load_d2<18>(pb.W + 18 * (size_t)s, W);
-        first = s == pb.fl_off[2 * l];  // the landmark's first edge also carries D^-1 b_l
-        double Di[9];
-        point_dinv(pb, l, lambda, Di, db);
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) y[c][r] = W[3 * r] * Di[c] + W[3 * r + 1] * Di[3 + c] + W[3 * r + 2] * Di[6 + c];
-        my_chunk = place / kSchurChunk;
-        at = 3 * (place % kSchurChunk) * ldw + 6 * pb.fl_pose[s];
-    }
-    for (int k = tid; k < 2 * kSchurRows * ldw; k += 256) lds[k] = 0.0;
-    int tile_a[TPW], tile_b[TPW];  // operand column offsets of this wavefront's tiles (-1: none), wavefront-uniform
-    {
-        const int n_tiles = tiles * (tiles + 1) / 2;
-#pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int n = wave + 4 * q;
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= n) ++ti;
-            tile_a[q] = n < n_tiles ? 16 * ti : -1;
-            tile_b[q] = 16 * (n - ti * (ti + 1) / 2);
-        }
-    }
-    v4d acc[TPW];
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) acc[q] = v4d{0, 0, 0, 0};
-    const int i16 = lane & 15, kk = lane >> 4;
-    for (int q = 0; q < n_chunks; ++q) {
-        __syncthreads();  // the previous chunk's MFMAs have read the operands
-        if (q > 0 && my_chunk == q - 1) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    *reinterpret_cast<v2d*>(Yt + at + c * ldw + 2 * h) = v2d{0, 0};
-                    *reinterpret_cast<v2d*>(Wt + at + c * ldw + 2 * h) = v2d{0, 0};
-                }
-                if (first) Yt[at - at % ldw + c * ldw + np] = 0.0;
-            }
-        }
-        __syncthreads();
-        if (my_chunk == q) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-#pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    *reinterpret_cast<v2d*>(Yt + at + c * ldw + 2 * h) = v2d{y[c][2 * h], y[c][2 * h + 1]};
-                    *reinterpret_cast<v2d*>(Wt + at + c * ldw + 2 * h) = v2d{W[3 * (2 * h) + c], W[3 * (2 * h + 1) + c]};
-                }
-                if (first) Yt[at - at % ldw + c * ldw + np] = db[c];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int st = 0; st < kSchurRows / 4; ++st) {
-            const int ro = (4 * st + kk) * ldw + i16;
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                if (tile_a[u] < 0) break;  // uniform over the wavefront
-                acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(Yt[ro + tile_a[u]], Wt[ro + tile_b[u]], acc[u], 0, 0, 0);
-            }
-        }
-    }
-    double* out = pb.S_part + (size_t)slice * ld * ld;
-#pragma unroll
-    for (int q = 0; q < TPW; ++q) {
-        if (tile_a[q] < 0) break;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(tile_a[q] + kk + 4 * r) * ld + tile_b[q] + i16] = acc[q][r];
-    }
-}
-// 4 tiles per wavefront (np_pad <= 80): held to 168 registers, three wavefronts per SIMD (a dozen spilled values of the prologue) --
-// the other workgroups' MFMAs cover a workgroup's loads and barriers
-__global__ __launch_bounds__(256) void k_ba_schur_sparse4(BaProblemDev pb, double lambda) {
-    extern __shared__ double s_schur[];
-    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, lambda, s_schur);
-}
-__global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, double lambda) {
-    extern __shared__ double s_schur[];
-    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, lambda, s_schur);
-}
-
 // ---- the Schur product block by block on the f64 vector unit (default since round 3) ----
 // S_part = sum over landmarks l and pairs (i >= j) of free poses that see l of (W_il D_l^-1) W_jl^T, plus the row sum_l W_il D_l^-1 b_l:
 // exactly the 6x3 . 3x3 . 3x6 products g2o's BlockSolver forms (block_solver.hpp:381-432), and nothing else -- the MFMA form above
@@ -923,148 +814,10 @@ __global__ __launch_bounds__(256) void k_ba_schur_sparse9(BaProblemDev pb, doubl
 // MFMA form's: the lower triangle of [np_pad][np_pad] per part and the coefficient row np, so k_ba_schur_finish adds the parts as before.
 // Slot stride in LDS 38 doubles: 16-byte aligned blocks that spread over all banks (at 36 doubles every read of a wavefront met
 // 16-way conflicts).
-__host__ __device__ inline size_t schur_blocks_lds_bytes(int nf) {
-    const size_t ops = 256 * kSchurOps * sizeof(double), outs = (size_t)256 * 36 * sizeof(double);
-    return (ops > outs ? ops : outs) + 64 * 3 * sizeof(double) + 2 * (size_t)nf * 8 + 64 * (size_t)nf;
-}
-
-struct SchurSlotA { int l, key; };                                 // landmark (-1: no slot) | place | pose << 8 | first-of-landmark << 16
-struct SchurSlotB { double W[18], H[6], b[3]; };                   // the slot's W block and its landmark's Hll, b_l
-__device__ __forceinline__ SchurSlotA schur_load_a(const BaProblemDev& pb, int slice, int s1_all) {
-    SchurSlotA a{-1, 0};
-    if (slice >= s1_all) return a;
-    const int s0 = pb.slice_off[slice], s = s0 + (int)threadIdx.x;
-    if (s >= pb.slice_off[slice + 1]) return a;
-    a.l = pb.fl_lm[s];
-    // a slice starts with a landmark's first slot (slices are whole landmarks)
-    const int first = threadIdx.x == 0 || pb.fl_lm[s - 1] != a.l;
-    a.key = pb.fl_place[s] | pb.fl_pose[s] << 8 | first << 16;
-    return a;
-}
-__device__ __forceinline__ void schur_load_b(const BaProblemDev& pb, int slice, const SchurSlotA& a, SchurSlotB& o) {
-    if (a.l < 0) return;
-    const int s = pb.slice_off[slice] + (int)threadIdx.x;
-    load_d2<18>(pb.W + 18 * (size_t)s, o.W);
-    load_d2<6>(pb.Hll + 6 * (size_t)a.l, o.H);
-    const double* b = pb.bl + 3 * (size_t)a.l;
-    o.b[0] = b[0]; o.b[1] = b[1]; o.b[2] = b[2];
-}
-
-__device__ __forceinline__ void d_ba_schur_blocks(const BaProblemDev& pb, const int part, const double lambda, double* __restrict__ lds) {
-    const int tid = threadIdx.x, NF = pb.n_free, np = 6 * NF, ld = pb.np_pad;
-    const int Rd = pb.schur_rd, Ro = pb.schur_ro;
-    const int nD = Rd * NF, nO = Ro * (NF * (NF - 1) / 2), nT = nD + nO + NF;
-    const size_t ops_doubles = max((size_t)256 * kSchurOps, (size_t)nT * 36);
-    double* const ops = lds;
-    double* const dbl = lds + ops_doubles;                                                   // [64][3]: D^-1 b_l by landmark rank
-    unsigned long long* const masks = reinterpret_cast<unsigned long long*>(dbl + 64 * 3);   // [2][NF]: landmarks of the slice a pose sees
-    unsigned char* const slot_of = reinterpret_cast<unsigned char*>(masks + 2 * NF);         // [64][NF]: the slot of (landmark rank, pose)
-    // ---- this thread's task ----
-    int t_i = 0, t_j = 0, t_kind = -1;  // 0: block, 1: coefficient row
-    unsigned long long t_sel = 0;
-    if (tid < nD) { t_i = t_j = tid / Rd; t_sel = schur_range_mask(Rd, tid - t_i * Rd); t_kind = 0; }
-    else if (tid < nD + nO) {
-        const int n = (tid - nD) / Ro;  // pair number i (i - 1) / 2 + j, i > j
-        int i = 1;
-        while (i * (i + 1) / 2 <= n) ++i;
-        t_i = i; t_j = n - i * (i - 1) / 2; t_sel = schur_range_mask(Ro, (tid - nD) - n * Ro); t_kind = 0;
-    } else if (tid < nT) { t_i = t_j = tid - nD - nO; t_sel = ~0ull; t_kind = 1; }
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-    const int sl0 = part * kSchurGroup, sl1 = min(sl0 + kSchurGroup, pb.n_schur_slices);
-    // the index arrays of all the part's slices first (one round trip), then slice by slice the blocks
-    SchurSlotA a[kSchurGroup];
-#pragma unroll
-    for (int k = 0; k < kSchurGroup; ++k) a[k] = schur_load_a(pb, sl0 + k, sl1);
-    SchurSlotB b_cur, b_nxt;
-    schur_load_b(pb, sl0, a[0], b_cur);
-#pragma unroll
-    for (int k = 0; k < kSchurGroup; ++k) {
-        if (sl0 + k >= sl1) break;  // uniform
-        if (k + 1 < kSchurGroup) schur_load_b(pb, sl0 + k + 1, a[k + 1], b_nxt);  // in flight while this slice is multiplied
-        // two mask buffers in turn: this slice's is cleared while the tasks of the previous slice may still read theirs
-        unsigned long long* const mask = masks + (k & 1) * NF;
-        if (tid < NF) mask[tid] = 0ull;
-        double Y[18], db[3];
-        const bool have = a[k].l >= 0;
-        if (have) {
-            // (Hll + lambda I)^-1 and its product with b_l: the arithmetic of point_dinv (the back substitution forms the same inverse)
-            const double* h = b_cur.H;
-            const double d00 = h[0] + lambda, d01 = h[1], d02 = h[2], d11 = h[3] + lambda, d12 = h[4], d22 = h[5] + lambda;
-            const double c00 = d11 * d22 - d12 * d12, c01 = d12 * d02 - d01 * d22, c02 = d01 * d12 - d11 * d02;
-            const double det = d00 * c00 + d01 * c01 + d02 * c02, id = 1.0 / det;
-            double Di[9];
-            Di[0] = c00 * id; Di[1] = (d02 * d12 - d01 * d22) * id; Di[2] = (d01 * d12 - d02 * d11) * id;
-            Di[3] = c01 * id; Di[4] = (d00 * d22 - d02 * d02) * id; Di[5] = (d02 * d01 - d00 * d12) * id;
-            Di[6] = c02 * id; Di[7] = (d01 * d02 - d00 * d12) * id; Di[8] = (d00 * d11 - d01 * d01) * id;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) db[r] = Di[3 * r] * b_cur.b[0] + Di[3 * r + 1] * b_cur.b[1] + Di[3 * r + 2] * b_cur.b[2];
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Y[3 * r + c] = b_cur.W[3 * r] * Di[c] + b_cur.W[3 * r + 1] * Di[3 + c] + b_cur.W[3 * r + 2] * Di[6 + c];
-        }
-        __syncthreads();  // the masks are clear; the previous slice's tasks have read the operands and the slot table
-        if (have) {
-            const int place = a[k].key & 255, pose = (a[k].key >> 8) & 255;
-            store_d2<18>(ops + tid * kSchurOps, Y);
-            store_d2<18>(ops + tid * kSchurOps + 18, b_cur.W);
-            slot_of[place * NF + pose] = (unsigned char)tid;
-            atomicOr(&mask[pose], 1ull << place);
-            if (a[k].key >> 16) { dbl[3 * place] = db[0]; dbl[3 * place + 1] = db[1]; dbl[3 * place + 2] = db[2]; }
-        }
-        __syncthreads();
-        if (t_kind == 0) {
-            unsigned long long m = mask[t_i] & mask[t_j] & t_sel;
-            while (m) {
-                const int p = __builtin_ctzll(m);
-                m &= m - 1;
-                double y[18], w[18];
-                load_d2<18>(ops + (int)slot_of[p * NF + t_i] * kSchurOps, y);
-                load_d2<18>(ops + (int)slot_of[p * NF + t_j] * kSchurOps + 18, w);
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c)
-                        acc[6 * r + c] = __builtin_fma(y[3 * r + 2], w[3 * c + 2], __builtin_fma(y[3 * r + 1], w[3 * c + 1], __builtin_fma(y[3 * r], w[3 * c], acc[6 * r + c])));
-            }
-        } else if (t_kind == 1) {
-            unsigned long long m = mask[t_i];
-            while (m) {
-                const int p = __builtin_ctzll(m);
-                m &= m - 1;
-                const double* Wa = ops + (int)slot_of[p * NF + t_i] * kSchurOps + 18;
-                const double d0 = dbl[3 * p], d1 = dbl[3 * p + 1], d2 = dbl[3 * p + 2];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[r] = __builtin_fma(Wa[3 * r + 2], d2, __builtin_fma(Wa[3 * r + 1], d1, __builtin_fma(Wa[3 * r], d0, acc[r])));
-            }
-        }
-        if (k + 1 < kSchurGroup) b_cur = b_nxt;
-    }
-    // ---- the part's sums: tasks -> LDS (by task number), then one thread per entry of the lower triangle / of the coefficient row adds
-    // the landmark ranges in order ----
-    __syncthreads();
-    if (t_kind >= 0) store_d2<36>(ops + (size_t)tid * 36, acc);
-    __syncthreads();
-    double* const out = pb.S_part + (size_t)part * ld * ld;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int r = wave; r < np; r += 4) {  // wavefront: row of the lower triangle, lane: column
-        const int bi = r / 6, e0 = 6 * (r - 6 * bi);
-        for (int c = lane; c <= r; c += 64) {
-            const int bj = c / 6, e = e0 + (c - 6 * bj);
-            const int t0 = bi == bj ? Rd * bi : nD + Ro * (bi * (bi - 1) / 2 + bj), R = bi == bj ? Rd : Ro;
-            double sum = ops[(size_t)t0 * 36 + e];
-            for (int q = 1; q < R; ++q) sum += ops[(size_t)(t0 + q) * 36 + e];
-            out[(size_t)r * ld + c] = sum;
-        }
-    }
-    if (tid < np) out[(size_t)np * ld + tid] = ops[(size_t)(nD + nO + tid / 6) * 36 + tid % 6];  // row np: sum_l W D^-1 b_l
-}
-__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks(BaProblemDev pb, double lambda) {  // two wavefronts per SIMD: 80 KB of LDS allow two workgroups per CU
-    extern __shared__ double s_schur[];
-    d_ba_schur_blocks(pb, blockIdx.x, lambda, s_schur);
-}
+// (Round 6: the 256-slot form of this product -- k_ba_schur_blocks, 80 KB of LDS and 256 registers per lane -- and the zero-padded MFMA form
+// of rounds 1-2 -- k_ba_schur_sparse4 / 9 -- are gone: since round 4 the loop runs the LEAN form below, which is this product in 128-slot
+// slices; the two were kept as switches with tests of their own.  Windows of more than kSchurLeanMaxFree free keyframes take the
+// block-sparse MFMA kernels above.)
 
 // ---- the same product, LEAN (pb.schur_blocks == 2; round 4, last session) ----
 // k_ba_schur_blocks asks for 80 KB of LDS and 256 registers per lane: alone that is two workgroups per CU and costs nothing, but beside the
@@ -1626,32 +1379,14 @@ __global__ __launch_bounds__(256) void k_ba_schur_units_b(const BaPhase ph) {
     if (pb.np_pad <= 16 * kFullTilesMax && !ph.pad_) return;  // such a window runs in k_ba_schur_full_b (ph.pad_: TC2LI_BA_DENSE_FULL=0, measurements)
     d_ba_schur_units(pb, blockIdx.x, blockIdx.y, sl.k_per_slice, view_.lambda, L);
 }
-__global__ __launch_bounds__(256, 2) void k_ba_schur_blocks_b(const BaPhase ph) {
-    extern __shared__ double s_schur[];
-    TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks != 1 || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_blocks(pb, blockIdx.x, view_.lambda, s_schur);
-}
 __global__ __launch_bounds__(256, 3) void k_ba_schur_lean_b(const BaPhase ph) {
     extern __shared__ double s_schur[];
     TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks != 2 || !pb.n_free) return;
+    if (!pb.sparse_schur || !pb.n_free) return;
     // a wide window (more than kSchurBlocksMaxFree free keyframes): two workgroups per part, the same launch as everybody else's
     const int halves = pb.n_free > kSchurBlocksMaxFree ? 2 : 1, part = (int)blockIdx.x / halves;
     if (part >= sl.n_slices) return;
     d_ba_schur_lean(pb, part, view_.lambda, s_schur, 256 * ((int)blockIdx.x - part * halves));
-}
-__global__ __launch_bounds__(256) void k_ba_schur_sparse4_b(const BaPhase ph) {
-    extern __shared__ double s_schur[];
-    TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<4, kSchurChunkSmall>(pb, blockIdx.x, view_.lambda, s_schur);
-}
-__global__ __launch_bounds__(256) void k_ba_schur_sparse9_b(const BaPhase ph) {
-    extern __shared__ double s_schur[];
-    TC2LI_SLOT(y);
-    if (!pb.sparse_schur || pb.schur_blocks || !pb.n_free || (int)blockIdx.x >= sl.n_slices) return;
-    d_ba_schur_sparse<9, kSchurChunkLarge>(pb, blockIdx.x, view_.lambda, s_schur);
 }
 __global__ __launch_bounds__(256) void k_ba_schur_finish_b(const BaPhase ph) {
     TC2LI_SLOT(y);
@@ -2291,39 +2026,19 @@ void ba_launch_linearize(const BaProblemDev& pb, double* chi_out, double* maxdia
     if (want_maxdiag) TC2LI_LAUNCH(k_ba_maxdiag, dim3(2), dim3(256), 0, st, pb, maxdiag_out);
 }
 
-static inline size_t schur_lds_bytes(int np_pad) {
-    return 2 * 3 * (size_t)(np_pad / 16 <= 5 ? kSchurChunkSmall : kSchurChunkLarge) * schur_ldw(np_pad) * sizeof(double);
-}
-
 int ba_schur_parts(int n_slices, int group) { return (n_slices + group - 1) / group; }
 // TC2LI_BA_DENSE_FULL=0 (read per call; measurements): the dense windows' product by 64 x 64 units whatever their width
 static bool dense_full_form() { const char* e = getenv("TC2LI_BA_DENSE_FULL"); return !(e && atoi(e) == 0); }
 
 
-// the block-by-block kernels need more than the 64 KB of dynamic LDS a kernel gets by default
-static void schur_blocks_attr() {  // a refusal shows as the launch's own error (the callers check hipGetLastError)
-    (void)ensure_dynamic_lds((const void*)k_ba_schur_blocks, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
-    (void)ensure_dynamic_lds((const void*)k_ba_schur_blocks_b, (int)schur_blocks_lds_bytes(kSchurBlocksMaxFree));
-}
-
 void ba_launch_schur(const BaProblemDev& pb, double lambda, double lambda_pose, int n_slices, int k_per_slice, double* S_out, double* bs_out, hipStream_t st) {
     if (!pb.n_free) return;  // a free pose may carry no visual edge when the LiDAR window brings it in; no free pose: nothing to form
     const int np = 6 * pb.n_free;
-    if (pb.sparse_schur && pb.schur_blocks == 2) {
+    if (pb.sparse_schur) {  // the lean block-by-block product (every window of at most kSchurLeanMaxFree free keyframes)
         if (n_slices && pb.n_free > kSchurBlocksMaxFree) TC2LI_LAUNCH(k_ba_schur_lean_wide, dim3(2 * n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
         else if (n_slices) TC2LI_LAUNCH(k_ba_schur_lean, dim3(n_slices), dim3(256), schur_lean_lds_bytes(pb.n_free), st, pb, lambda);
-    } else if (pb.sparse_schur && pb.schur_blocks) {
-        if (n_slices) {
-            schur_blocks_attr();
-            TC2LI_LAUNCH(k_ba_schur_blocks, dim3(n_slices), dim3(256), schur_blocks_lds_bytes(pb.n_free), st, pb, lambda);
-        }
-    } else if (pb.sparse_schur) {
-        if (n_slices) {
-            if (pb.np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
-            else TC2LI_LAUNCH(k_ba_schur_sparse9, dim3(n_slices), dim3(256), schur_lds_bytes(pb.np_pad), st, pb, lambda);
-        }
     } else {
-        // the dense windows (> 21 free keyframes): edge coefficients, their per-pose sums, the block-sparse MFMA product by units
+        // the dense windows (> 24 free keyframes): edge coefficients, their per-pose sums, the block-sparse MFMA product by units
         // (k_per_slice = landmark chunks per slice on this path)
         const bool full_form = pb.np_pad <= 16 * kFullTilesMax && dense_full_form();
         if (pb.n_free_edges) TC2LI_LAUNCH(k_ba_schur_coef, dim3(blocks(pb.n_free_edges)), dim3(256), 0, st, pb, lambda, full_form ? 0 : 1);
@@ -2366,19 +2081,8 @@ void ba_batch_launch_linearize(const BaPhase& ph, int n_active, const BaBatchExt
 }
 void ba_batch_launch_schur(const BaPhase& ph, int n_active, const BaBatchExtent& x, hipStream_t st) {
     if (!n_active || !x.max_free) return;
-    if (x.max_block_parts && x.any_block_fat) {
-        schur_blocks_attr();
-        TC2LI_LAUNCH(k_ba_schur_blocks_b, dim3(x.max_block_parts, n_active), dim3(256), schur_blocks_lds_bytes(x.max_block_free), st, ph);
-    }
-    // (the lean form held to four wavefronts per SIMD -- 128 registers, 116 B of scratch -- measured 87 against 69 us alone and 294-317 against
-    // 290-294 us in the loop: not kept)
     if (x.max_block_parts && x.any_block_lean)  // (a wide window -- 22 .. 24 free keyframes -- takes two workgroups per part)
         TC2LI_LAUNCH(k_ba_schur_lean_b, dim3(x.max_block_parts * (x.any_block_wide ? 2 : 1), n_active), dim3(256), schur_lean_lds_bytes(x.max_block_free), st, ph);
-    if (x.max_sparse_slices) {
-        const size_t lds = schur_lds_bytes(x.max_sparse_np_pad);
-        if (x.max_sparse_np_pad / 16 <= 5) TC2LI_LAUNCH(k_ba_schur_sparse4_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
-        else TC2LI_LAUNCH(k_ba_schur_sparse9_b, dim3(x.max_sparse_slices, n_active), dim3(256), lds, st, ph);
-    }
     if (x.any_dense) {
         if (x.max_free_edges) TC2LI_LAUNCH(k_ba_schur_coef_b, dim3(blocks(x.max_free_edges), n_active), dim3(256), 0, st, ph, dense_full_form() ? 1 : 0);
         TC2LI_LAUNCH(k_ba_reduce_coef_b, dim3(x.max_free, n_active), dim3(256), 0, st, ph);

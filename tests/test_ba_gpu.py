@@ -65,11 +65,10 @@ def rel_pose_err(a, b):
 
 
 @pytest.mark.parametrize("seed,n_opt,n_fix,n_pts,lam", [(0, 12, 20, 3000, 0.0), (1, 4, 2, 120, 0.0), (2, 8, 10, 800, 100.0),
-                                                          (6, 20, 12, 2000, 0.0), (7, 24, 6, 1500, 0.0),
+                                                          (6, 20, 12, 2000, 0.0), (7, 24, 6, 1500, 0.0),   # 24: the lean form with two workgroups per part
+                                                          (9, 27, 5, 1500, 0.0),                          # 27: the block-sparse MFMA kernels
                                                           (8, 15, 6, 1200, 0.0)])  # 15 free keyframes: (2, 2) ranges, the lean form's largest closing area
-@pytest.mark.parametrize("schur", ["lean", "256-slot"])  # the two block-by-block Schur kernels (TC2LI_BA_SCHUR_LEAN, read per window)
-def test_local_bundle_adjustment(pkg, oracle, synthetic, monkeypatch, seed, n_opt, n_fix, n_pts, lam, schur):
-    monkeypatch.setenv("TC2LI_BA_SCHUR_LEAN", "1" if schur == "lean" else "0")
+def test_local_bundle_adjustment(pkg, oracle, synthetic, seed, n_opt, n_fix, n_pts, lam):
     w = synthetic.ba_window(seed, n_opt=n_opt, n_fix=n_fix, n_points=n_pts)
     want = oracle.local_ba(w["poses"], w["fixed"], w["points"], w["edges"], w["cam"], iterations=10, lambda_init=lam)
     poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], pkg.pack_ba_edges(w["edges"]),

@@ -171,13 +171,13 @@ def test_batch_with_a_large_window(pkg, synthetic):
         assert np.array_equal(r[0], s[0]) and np.array_equal(r[1], s[1]) and np.array_equal(r[2], s[2])
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])  # a trial's closing sums by the last workgroup of its error pass / by a launch of their own
-def test_mixed_batch_falls_back_per_group(pkg, synthetic, fuse, monkeypatch):
+@pytest.mark.parametrize("device_lm", ["1", "0"])  # the LM decisions on the device (rounds queued ahead) / on the host between the phases
+def test_mixed_batch_falls_back_per_group(pkg, synthetic, device_lm, monkeypatch):
     """A batch of several lock-step groups in which ONE window lies outside the batched LiDAR kernels' range (8 keyframes in its LiDAR
     window, more than the 7 the lock-step kernels take): only that window's group goes through the one-window path -- every window of
     the batch, in the declined group and in the others, equals its one-window call bit for bit (the groups that had
     succeeded were optimised a second time, from their optimised state)."""
-    monkeypatch.setenv("TC2LI_BA_FUSE", fuse)
+    monkeypatch.setenv("TC2LI_BA_DEVICE_LM", device_lm)
     windows, singles = [], []
     for seed in range(9):
         w = synthetic.ba_window(50 + seed, n_opt=8, n_fix=6, n_points=500, pose_noise=(0.1, 0.01))
@@ -200,11 +200,9 @@ def test_mixed_batch_falls_back_per_group(pkg, synthetic, fuse, monkeypatch):
             assert r[5].n_planes == s[5].n_planes and r[5].residual == s[5].residual, i
 
 
-@pytest.mark.parametrize("schur", ["lean", "256-slot"])  # k_ba_schur_lean_b (default) / k_ba_schur_blocks_b
-def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic, monkeypatch, schur):
+def test_lock_step_batch_against_the_oracle_at_the_benched_shape(pkg, oracle, synthetic):
     """The windows bench.py times (12 free + 20 fixed keyframes, 3000 points, LiDAR edge over 6 keyframes x 3000 points), through the
     lock-step batch entry, against the oracle directly: same iterations and LM trials, same planes, poses <= 1e-4 relative."""
-    monkeypatch.setenv("TC2LI_BA_SCHUR_LEAN", "1" if schur == "lean" else "0")
     windows, wants = [], []
     for seed in (40, 41, 42, 43):
         w = synthetic.ba_window(seed, n_opt=12, n_fix=20, n_points=3000, pose_noise=(0.1, 0.01))
