@@ -768,6 +768,8 @@ class Loop:
         the sums the roofline's byte / FLOP counts are made of (weighted by the linearisations a window ran)."""
         seen = {}
         for b in self.ba_run_batches():
+            if not hasattr(b, "window_ids"):   # (the inertial loop's LocalLVIBA batches: its windows are described by algorithmic_work_inertial)
+                continue
             for i, wid in enumerate(b.window_ids):
                 st, ls = b.stats[i], b.lstats[i]
                 seen[wid] = (int(st.iterations), int(st.trials), int(st.n_free_poses), int(ls.n_planes))
