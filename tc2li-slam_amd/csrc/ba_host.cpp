@@ -2193,6 +2193,8 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
         LviWindow& w = W[i];
         BaBatchSlot& s = h_slots[i];
         s.pb = w.vp.pb;
+        // (the LM decisions of the inertial windows stay on the host: no device-side state -- the table's memory is reused from call to call)
+        s.lm = nullptr; s.lm_host = nullptr; s.stop_host = nullptr; s.lidar_JH = nullptr; s.lambda_init = 0; s.lidar_information = 0; s.iterations = 0; s.lm_pad_ = 0;
         s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
         double* sc = w.ws->h_scal.p;
         s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
