@@ -665,6 +665,29 @@ class Loop:
             for w in range(n_workers):
                 self.ba_workers.append({n: ba_batch_of(pkg, wl, first, n) for n in set(self.ba_chunk_sizes)})
                 first += self.ba_chunk_sizes[w]
+        # From 128 sequences per GPU on the windows go through tc2li_ba_engine instead (TC2LI_BENCH_BA_ENGINE = number of engines, 0 = the batch
+        # calls above; default 3): running lock-step queues that windows join and leave one by one.  Every sequence is a mapping thread of its
+        # own there: its window is a ticket, submitted when the tracking thread has finished the keyframe's step AND the sequence's previous
+        # window has come back (a LocalMapping thread runs one optimisation at a time, LocalMapping.cc:66-160); nobody waits for another
+        # sequence's window.  A ring of kf_interval prebuilt batches holds the arrays (a sequence's next keyframe comes kf_interval frames
+        # later), each a different stretch of the workload's window list.  Measured (round 6, varied mix, frames/s, batch calls -> 3 engines):
+        # 64 sequences 12.5k -> 11.7k (a round of few windows is a chain of ten launches whatever their number: the batch calls' 64 windows per
+        # call win), 128: 13.4k -> 15.0k, 256: 15.8k -> 17.0k, 512: 17.9k -> 19.5k (16 CPUs; 17.0k -> 18.9k on 8).
+        self.ba_engine, self.ba_engines, self.ba_ring = None, [], []
+        n_engines = int(os.environ.get("TC2LI_BENCH_BA_ENGINE", "3" if F >= 128 else "0"))
+        if type(self) is Loop and self.ba_batch is not None and self.ba_rate == n_ba and n_engines > 0:
+            self.ba_engines = [pkg.capi.BaEngine(wl.ba_windows[0]["cam"], max_windows=int(os.environ.get("TC2LI_BENCH_BA_ENGINE_SLOTS", "192")))
+                               for _ in range(n_engines)]
+            self.ba_engine = self.ba_engines[0]
+            self.ba_ring = [ba_batch_of(pkg, wl, r * n_ba, n_ba) for r in range(int(os.environ.get("TC2LI_BENCH_BA_ENGINE_RING", "0")) or max(1, args.kf_interval))]
+            self.ba_workers, self.ba_batch2, self.ba_batch4 = [], None, None
+            # the engines' work spaces take their sizes from the windows they meet (a batch call's do so in its first call): every ticket of the
+            # ring once through its engines before anything is timed
+            for _ in range(2):
+                K = len(self.ba_engines)
+                tickets = [(self.ba_engines[i % K], self.ba_engines[i % K].submit(b, i, 1)) for b in self.ba_ring for i in range(b.n)]  # (window i: engine i % K, as in the loop)
+                for e, t in tickets:
+                    e.wait(t)
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
@@ -753,6 +776,8 @@ class Loop:
 
     def ba_stats_batch(self):
         """The batch whose statistics describe the windows the loop has optimised."""
+        if self.ba_ring:
+            return self.ba_ring[0]
         if not self.ba_workers:
             return self.ba_batch
         ran = [b for w in self.ba_workers for b in w.values() if b.stats[0].iterations > 0]  # (a worker may not have met every chunk size)
@@ -760,7 +785,7 @@ class Loop:
 
     def ba_run_batches(self):
         """Every BaBatch of the loop that has run at least once."""
-        all_b = [self.ba_batch, self.ba_batch2, self.ba_batch4] + [b for w in self.ba_workers for b in w.values()]
+        all_b = [self.ba_batch, self.ba_batch2, self.ba_batch4] + [b for w in self.ba_workers for b in w.values()] + list(self.ba_ring)
         return [b for b in all_b if b is not None and any(b.stats[i].iterations > 0 or b.results[i] > 0 for i in range(b.n))]
 
     def ba_mix_summary(self, wl):
@@ -919,6 +944,50 @@ class Loop:
                 self.ba_step(m)
                 done += m
 
+        def ba_engine_thread():
+            """Every window (r, i) of the ring is a sequence's mapping thread: its window of step j = r, r + R, ... is submitted (a ticket of its own)
+            when the tracking thread has finished step j AND the sequence's previous window has come back -- a LocalMapping thread runs one
+            optimisation at a time; nobody waits for another sequence's window."""
+            follows_tracking = "track" in set(stages) and F_follow
+            R, K, SENT = len(self.ba_ring), len(self.ba_engines), -(1 << 30)
+            nxt = [np.full(b.n, r, np.int64) for r, b in enumerate(self.ba_ring)]      # the step of the window's next submission
+            ticket = [np.zeros(b.n, np.int64) for b in self.ba_ring]                   # > 0: in flight
+            left = sum(len(range(r, n_steps, R)) * b.n for r, b in enumerate(self.ba_ring))
+            dbg = [] if os.environ.get("TC2LI_BENCH_BA_ENGINE_DEBUG") else None
+            t_sub = [np.zeros(b.n) for b in self.ba_ring]
+            t_tracked = {}
+            while left > 0 and not failed.is_set():
+                tracked = min(n_steps, self.steps_tracked if follows_tracking else n_steps)
+                if dbg is not None and tracked not in t_tracked:
+                    t_tracked[tracked] = time.perf_counter()
+                progressed = False
+                for r, b in enumerate(self.ba_ring):
+                    back = np.nonzero((ticket[r] > 0) & (b.results != SENT))[0]
+                    for i in back:
+                        if self.ba_engines[i % K].wait(int(ticket[r][i])) != 1:
+                            raise RuntimeError("a local BA window failed")
+                        ticket[r][i] = 0
+                        self.ba_windows_done += 1
+                        left -= 1
+                        if dbg is not None:
+                            dbg.append((time.perf_counter() - t_sub[r][i], int(b.stats[i].trials), int(nxt[r][i] - R)))
+                    for i in np.nonzero((ticket[r] == 0) & (nxt[r] < tracked))[0]:
+                        b.results[i] = SENT
+                        ticket[r][i] = self.ba_engines[i % K].submit(b, int(i), 1)
+                        t_sub[r][i] = time.perf_counter()
+                        nxt[r][i] += R
+                    progressed |= len(back) > 0
+                if not progressed:
+                    time.sleep(0.0002)
+            if dbg:
+                lat = np.array([d[0] for d in dbg]) * 1e3
+                tr = np.array([d[1] for d in dbg])
+                last = max(t_tracked.values())
+                print("engine debug: %d windows, latency ms mean %.2f p50 %.2f p90 %.2f max %.2f; per trial %.3f; end lag after last tracked step %.2f ms" % (
+                    len(lat), lat.mean(), np.median(lat), np.percentile(lat, 90), lat.max(), (lat / np.maximum(tr, 1)).mean(), 1e3 * (time.perf_counter() - last)), file=sys.stderr)
+        ba_engine_thread.__name__ = "ba_thread"
+        F_follow = self.F <= 256
+
         ba_jobs = {"next": 0}
         ba_lock = threading.Lock()
 
@@ -946,6 +1015,8 @@ class Loop:
                if f.__name__.split("_")[0].rstrip("2") in want]
         if not self.ba_batch:
             fns = [f for f in fns if f is not ba_thread]
+        elif self.ba_engine is not None and ba_thread in fns:
+            fns = [f for f in fns if f is not ba_thread] + [ba_engine_thread]
         elif self.ba_workers and ba_thread in fns:
             fns = [f for f in fns if f is not ba_thread] + [make_ba_worker(w) for w in range(len(self.ba_workers))]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
@@ -981,6 +1052,10 @@ class Loop:
         for w in self.workers.values():
             w.t.join()
         self.workers = {}
+        if self.ba_engine is not None:
+            for e in self.ba_engines:
+                e.close()
+            self.ba_engine, self.ba_engines = None, []
         _OPEN_LOOPS.discard(self)
 
 
@@ -1718,6 +1793,8 @@ def main(argv=None):
     cpu1 = os.times()
     host_budget["cpu_s_per_wall_s_timed_region"] = round(((cpu1.user - cpu0.user) + (cpu1.system - cpu0.system)) / max(local_elapsed, 1e-9), 2)
     host_budget["cgroup_cpu_quota"] = cgroup_cpu_quota()
+    if loop.ba_engine is not None:
+        host_budget["ba_engines"] = len(loop.ba_engines)
     if loop.ba_workers:  # local mapping as a pool of mapping workers: that many stage threads instead of one, each driving its lock-step group itself
         host_budget["mapping_workers"] = len(loop.ba_workers)
         host_budget["stage_threads"] = 4 + len(loop.ba_workers)
@@ -2011,6 +2088,9 @@ def main(argv=None):
                                  "sequences the tracking thread's two halves are pipeline stages over three feature buffers); a step = every stage has "
                                  "processed one batch" + ("; local mapping follows the tracking thread and takes the keyframes of the steps tracked since its last call, at most %d "
                                                           "steps' per call" % (4 if loop.ba_batch4 is not None else 2) if loop.ba_batch2 is not None else "; the LiDAR stream has high priority") +
+                                 ("; local mapping = %d bundle-adjustment engines (tc2li_ba_engine: running lock-step queues), every sequence a ticket stream of its "
+                                  "own: a window is submitted when its keyframe's step has been tracked and the sequence's previous window has come back" % len(loop.ba_engines)
+                                  if loop.ba_engine is not None else "") +
                                  ("; local mapping = %d mapping workers, each a lock-step group of its own (tc2li_local_bundle_adjustment_batch_group), taking the steps' "
                                   "windows chunk by chunk (%s windows)" % (len(loop.ba_workers), "/".join(str(n) for n in loop.ba_chunk_sizes)) if loop.ba_workers else ""),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,

@@ -660,6 +660,26 @@ int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_
 int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int group,
                                               int32_t* results);
 
+/* The same windows through a running ENGINE instead of a call per batch: the local-mapping threads of many sequences (one
+ * LocalMapping::Run loop per sequence, SF/src/LocalMapping.cc:66-160, each reaching Optimizer::LocalBundleAdjustment /
+ * OptimizerWithLidar::LocalLVBundleAdjustment at its own time) submit their windows as they come and collect them one ticket at a time.
+ * The engine keeps up to max_windows windows in flight in ONE lock-step Levenberg-Marquardt queue on a stream of its own: a window joins
+ * the queue at the next round after its setup, leaves it at the round its optimisation ends, and its slot is handed to the next waiting
+ * window -- no window waits for the slowest one of a batch, and the host work of setting a window up and of writing its results back
+ * runs beside the rounds of the others.  Every window's result is bit for bit the one tc2li_local_bundle_adjustment_batch /
+ * tc2li_local_lv_bundle_adjustment give for it (a window's arithmetic never depends on its neighbours in the queue).
+ *   submit: the windows of `problems` (arrays that stay valid and untouched until the ticket has been waited for) -> ticket > 0, or an
+ *           error code < 0; results[i] receives window i's return value.  May be called from any thread, also while tickets are open.
+ *   poll:   1 when every window of the ticket has finished (wait will not block), 0 while one is still in the queue.
+ *   wait:   blocks until every window of the ticket has finished -> number of windows that succeeded; a ticket is collected once.
+ *   destroy: finishes the windows already submitted, then stops the engine's thread. */
+typedef struct tc2li_ba_engine tc2li_ba_engine;
+int tc2li_ba_engine_create(const tc2li_camera* cam, int max_windows, tc2li_ba_engine** out);
+void tc2li_ba_engine_destroy(tc2li_ba_engine* engine);
+int64_t tc2li_ba_engine_submit(tc2li_ba_engine* engine, const tc2li_ba_problem* problems, int n_problems, int32_t* results);
+int tc2li_ba_engine_poll(tc2li_ba_engine* engine, int64_t ticket);
+int tc2li_ba_engine_wait(tc2li_ba_engine* engine, int64_t ticket);
+
 /* One window split over the GPUs of a node (BASELINE configs[4]): the landmarks -- and with them the stereo / mono
  * edges, W, Hll and the back-substitution -- are partitioned over the ranks (landmark l belongs to rank l % world); every rank
  * keeps all keyframe poses.  What the ranks exchange are the shared-pose blocks only: per LM trial ONE sum of

@@ -111,6 +111,13 @@ def lib():
                                                  C.c_float, C.c_float] + [C.c_void_p] * 5
     L.tc2li_local_bundle_adjustment_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.tc2li_local_bundle_adjustment_batch_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_ba_engine_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.tc2li_ba_engine_destroy.argtypes = [C.c_void_p]
+    L.tc2li_ba_engine_destroy.restype = None
+    L.tc2li_ba_engine_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.tc2li_ba_engine_submit.restype = C.c_int64
+    L.tc2li_ba_engine_wait.argtypes = [C.c_void_p, C.c_int64]
+    L.tc2li_ba_engine_poll.argtypes = [C.c_void_p, C.c_int64]
     L.tc2li_lidar_last_timings.argtypes = [C.c_void_p, C.c_void_p]
     L.tc2li_imu_preintegrated_init.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
     L.tc2li_imu_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
@@ -1532,10 +1539,12 @@ class BaBatch:
             lw = None
             if w.get("win_pose") is not None:
                 lw = _pack_lidar_window(w["win_pose"], w["clouds"], w["Tcl7"], w.get("weight", 1.0))
+            stop = w.get("stop_flag")   # (a uint8 array of one element the caller may set while the window is optimised: *pbStopFlag)
             self.init.append((poses0, pts0))
-            self.keep.append((poses, pts, fixed, edges, chi2, dpos, lw))
+            self.keep.append((poses, pts, fixed, edges, chi2, dpos, lw, stop))
             self.arr[i] = BaProblem(poses.ctypes.data, fixed.ctypes.data, pts.ctypes.data, edges.ctypes.data, len(poses), len(pts), len(edges),
-                                    int(w.get("iterations", 10)), float(w.get("lambda_init", 0.0)), None, chi2.ctypes.data, dpos.ctypes.data,
+                                    int(w.get("iterations", 10)), float(w.get("lambda_init", 0.0)), stop.ctypes.data if stop is not None else None,
+                                    chi2.ctypes.data, dpos.ctypes.data,
                                     C.addressof(self.stats) + i * C.sizeof(BaStats), C.addressof(lw[0]) if lw else None,
                                     C.addressof(self.lstats) + i * C.sizeof(LidarBaStats))
 
@@ -1556,9 +1565,54 @@ class BaBatch:
         return _check(lib().tc2li_local_bundle_adjustment_batch_group(C.addressof(self.arr), self.n, self.cam5.ctypes.data, int(group),
                                                                       self.results.ctypes.data))
 
+    def reset(self):
+        for (p0, x0), k in zip(self.init, self.keep):
+            k[0][...] = p0
+            k[1][...] = x0
+
     def result(self, i):
         k = self.keep[i]
         return k[0], k[1], k[4][:len(k[3])], k[5][:len(k[3])], self.stats[i], self.lstats[i]
+
+
+class BaEngine:
+    """``tc2li_ba_engine``: a running lock-step queue with up to ``max_windows`` local-BA windows in flight; windows join and leave it
+    one by one.  submit(batch) -> ticket (the BaBatch's arrays must stay alive until wait(ticket))."""
+
+    def __init__(self, cam5, max_windows=192):
+        self.cam5 = np.ascontiguousarray(cam5, np.float64)
+        self.h = C.c_void_p()
+        _check(lib().tc2li_ba_engine_create(self.cam5.ctypes.data, int(max_windows), C.byref(self.h)))
+
+    def submit(self, batch, first=0, count=None):
+        """Resets the windows [first, first + count) of the BaBatch to their initial estimates and hands them to the engine."""
+        count = batch.n - first if count is None else count
+        for (p0, x0), k in zip(batch.init[first:first + count], batch.keep[first:first + count]):
+            k[0][...] = p0
+            k[1][...] = x0
+        t = lib().tc2li_ba_engine_submit(self.h, C.addressof(batch.arr) + first * C.sizeof(BaProblem), count,
+                                         batch.results.ctypes.data + 4 * first)
+        if t < 0:
+            _check(int(t))
+        return t
+
+    def wait(self, ticket):
+        return _check(lib().tc2li_ba_engine_wait(self.h, ticket))
+
+    def done(self, ticket):
+        """True when wait(ticket) will not block."""
+        return _check(lib().tc2li_ba_engine_poll(self.h, ticket)) == 1
+
+    def close(self):
+        if self.h:
+            lib().tc2li_ba_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def lidar_planes_host(poses7, win_pose, clouds, Tcl7, capacity=20000):

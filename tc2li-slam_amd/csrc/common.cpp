@@ -283,6 +283,27 @@ int host_thread_budget() {
 // mapping: counted as 5) come off first; of the rest the extractor pool may take a quarter, the tracking pool, the LiDAR pool and each
 // lock-step BA group an eighth -- the one-GPU box's 16 CPUs give 10 / 5 / 5 / 5 per group (round 5: 30 / 15 / 15 / 15), 8 ranks on a node whose
 // cgroup grants 16 CPUs in all (B = 2) 1 + 1 + 1 + 3 x 1.
+std::atomic<long> g_buffer_allocs{0};
+thread_local BufferCache* tl_buffer_cache = nullptr;
+BufferCache::~BufferCache() {
+    for (auto& kv : device) (void)hipFree(kv.second);
+    for (auto& kv : pinned) (void)hipHostFree(kv.second);
+}
+void* BufferCache::take(bool is_pinned, size_t bytes, size_t* real_bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto& m = is_pinned ? pinned : device;
+    auto it = m.lower_bound(bytes);
+    if (it == m.end() || it->first > 2 * bytes + 4096) return nullptr;
+    void* p = it->second;
+    *real_bytes = it->first;
+    m.erase(it);
+    return p;
+}
+void BufferCache::give(bool is_pinned, void* p, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    (is_pinned ? pinned : device).emplace(bytes, p);
+}
+
 int pool_threads(int id) {
     int per_cpu = 3;
     if (const char* s = getenv("TC2LI_HOST_THREADS_PER_CPU")) per_cpu = std::max(1, std::min(16, atoi(s)));

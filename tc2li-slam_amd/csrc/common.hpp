@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/tc2li_hip.h"
@@ -62,6 +63,29 @@ hipError_t zero_or_defer(void* dst, size_t bytes, hipStream_t st);
         }                                                                                           \
     } while (0)
 
+extern std::atomic<long> g_buffer_allocs;  // hipMalloc / hipHostMalloc calls of DevBuf / PinnedBuf so far (TC2LI_BA_TIMING reports them)
+
+// Growing a DevBuf / PinnedBuf is hipFree + hipMalloc, and hipFree waits for the whole device.  A one-off for the batch calls (a window
+// always meets the same work space); in the bundle-adjustment engine windows of every size pass through every work space, and a
+// synchronisation per growth stalls every stream of the process.  While a BufferCacheScope is alive on a thread, buffers released there go
+// to the cache instead of back to the runtime, and allocations are served from it when a block of at least (and at most twice) the size is
+// there.  The owner guarantees what hipFree's wait did: a buffer is released only when no queued work uses it.
+struct BufferCache {
+    std::mutex mu;
+    std::multimap<size_t, void*> device, pinned;   // bytes -> block
+    ~BufferCache();
+    void* take(bool is_pinned, size_t bytes, size_t* real_bytes);
+    void give(bool is_pinned, void* p, size_t bytes);
+};
+extern thread_local BufferCache* tl_buffer_cache;
+struct BufferCacheScope {
+    BufferCache* prev_;
+    explicit BufferCacheScope(BufferCache* c) : prev_(tl_buffer_cache) { tl_buffer_cache = c; }
+    ~BufferCacheScope() { tl_buffer_cache = prev_; }
+    BufferCacheScope(const BufferCacheScope&) = delete;
+    BufferCacheScope& operator=(const BufferCacheScope&) = delete;
+};
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -71,10 +95,18 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     ~DevBuf() { release(); }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() {
+        if (p) { if (tl_buffer_cache) tl_buffer_cache->give(false, p, n * sizeof(T)); else (void)hipFree(p); }
+        p = nullptr; n = 0;
+    }
     hipError_t alloc(size_t count) {
         release();
         if (count == 0) return hipSuccess;
+        if (tl_buffer_cache) {
+            size_t real = 0;
+            if (void* q = tl_buffer_cache->take(false, count * sizeof(T), &real)) { p = (T*)q; n = real / sizeof(T); return hipSuccess; }
+        }
+        g_buffer_allocs.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e == hipSuccess) n = count;
         return e;
@@ -96,10 +128,18 @@ struct PinnedBuf {
     PinnedBuf& operator=(const PinnedBuf&) = delete;
     PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     ~PinnedBuf() { release(); }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+    void release() {
+        if (p) { if (tl_buffer_cache) tl_buffer_cache->give(true, p, n * sizeof(T)); else (void)hipHostFree(p); }
+        p = nullptr; n = 0;
+    }
     hipError_t alloc(size_t count) {
         release();
         if (count == 0) return hipSuccess;
+        if (tl_buffer_cache) {
+            size_t real = 0;
+            if (void* q = tl_buffer_cache->take(true, count * sizeof(T), &real)) { p = (T*)q; n = real / sizeof(T); return hipSuccess; }
+        }
+        g_buffer_allocs.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
         if (e == hipSuccess) n = count;
         return e;

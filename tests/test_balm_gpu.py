@@ -266,6 +266,99 @@ def test_mixed_lock_step_batch_against_the_oracle_window_by_window(pkg, oracle, 
     assert min(its) < 10 and max(its) == 10 and extra_trials > 0, (its, extra_trials)  # windows that stop early, windows with rejected steps
 
 
+def _window_results(batch, i):
+    r = batch.result(i)
+    return tuple(np.array(a, copy=True) for a in r[:4]) + (int(batch.results[i]), r[4].iterations, r[4].trials, r[4].initial_chi2, r[4].final_chi2,
+                                                           r[5].n_planes, r[5].residual, r[5].chi2)
+
+
+def test_engine_gives_every_window_the_bits_of_the_batch_call(pkg, synthetic):
+    """tc2li_ba_engine (windows join and leave one running lock-step queue): the varied mix -- camera-only and LiDAR windows, sparse and dense
+    Schur forms, windows that end early -- through an engine with FEWER slots than windows, as two tickets of which the second is
+    submitted while the first runs; every window's poses, points, per-edge chi2, depth flags and statistics are bit for bit the ones of
+    tc2li_local_bundle_adjustment_batch_group.  An empty ticket returns at once; a ticket is collected once."""
+    seeds = list(range(14)) + [17, 39]
+    ws = [synthetic.ba_window_varied(s) for s in seeds]
+    dicts = [varied_window_dict(pkg, synthetic, w) for w in ws]
+    ref = pkg.capi.BaBatch(dicts, ws[0]["cam"])
+    assert ref.run_group(0) == len(ws)
+    want = [_window_results(ref, i) for i in range(len(ws))]
+    for cap in (5, 64):
+        eng = pkg.capi.BaEngine(ws[0]["cam"], max_windows=cap)
+        b = pkg.capi.BaBatch(dicts, ws[0]["cam"])
+        t0 = eng.submit(b, 0, 9)
+        t1 = eng.submit(b, 9, len(ws) - 9)
+        te = eng.submit(b, 0, 0)
+        assert eng.wait(te) == 0
+        assert eng.wait(t1) == len(ws) - 9 and eng.wait(t0) == 9
+        with pytest.raises(pkg.capi.Tc2liError):
+            eng.wait(t0)
+        for i in range(len(ws)):
+            got = _window_results(b, i)
+            for a, c in zip(got, want[i]):
+                assert np.array_equal(a, c), (cap, i, ws[i]["params"])
+        # the engine is reusable: the same windows again
+        t2 = eng.submit(b)
+        assert eng.wait(t2) == len(ws)
+        for i in range(len(ws)):
+            for a, c in zip(_window_results(b, i), want[i]):
+                assert np.array_equal(a, c), (cap, i)
+        eng.close()
+
+
+def test_engine_edge_cases(pkg, synthetic):
+    """The engine beside the one-window call on the windows the batched kernels do not take and on the calls' error behaviour: a window of 27
+    free keyframes (outside the device-side LM: the one-window path inside the engine), a window whose stop flag is set (nothing moves, 0
+    iterations: OptimizerWithLidar.cc:387-391), a window with every pose fixed, a malformed window (its result is the error code, its
+    neighbours are optimised), tickets from several threads at once."""
+    import threading
+    cam = synthetic.ba_window(0, n_opt=4, n_fix=2, n_points=100)["cam"]
+
+    def as_dict(w, **kw):
+        return dict(poses=w["poses"], fixed=w["fixed"], points=w["points"], edges=pkg.pack_ba_edges(w["edges"]), **kw)
+    wide = synthetic.ba_window(9, n_opt=27, n_fix=5, n_points=1500)
+    small = synthetic.ba_window(3, n_opt=5, n_fix=4, n_points=300)
+    allfix = dict(small, fixed=np.ones_like(small["fixed"]))
+    bad = as_dict(small)
+    bad["edges"] = bad["edges"].copy(); bad["edges"]["pose"][0] = 10 ** 6
+    dicts = [as_dict(wide), as_dict(small, stop_flag=np.ones(1, np.uint8)), as_dict(allfix, iterations=5), bad, as_dict(small)]
+    eng = pkg.capi.BaEngine(cam, max_windows=3)
+    b = pkg.capi.BaBatch(dicts, cam)
+    assert eng.wait(eng.submit(b)) == 4
+    assert b.results[3] < 0 and b.results[1] == 0 and b.result(1)[4].iterations == 0
+    assert np.array_equal(b.result(1)[0], small["poses"]) and np.array_equal(b.result(1)[1], small["points"])
+    for i, w, kw in [(0, wide, {}), (2, allfix, dict(iterations=5)), (4, small, {})]:
+        poses, pts, chi2, dpos, stats = pkg.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], pkg.pack_ba_edges(w["edges"]), cam, **kw)
+        got = b.result(i)
+        assert b.results[i] == stats.iterations and got[4].trials == stats.trials and got[4].n_free_poses == stats.n_free_poses, i
+        if i == 0:   # (the one-window path's host-side LM and the device-side LM agree to the tolerance, not bit for bit)
+            assert np.array_equal(got[0], poses) and np.array_equal(got[1], pts) and np.array_equal(got[2], chi2) and np.array_equal(got[3], dpos)
+        else:
+            assert np.allclose(got[0], poses, rtol=1e-9, atol=1e-12) and np.allclose(got[1], pts, rtol=1e-9, atol=1e-12) and np.array_equal(got[3], dpos), i
+    # several submitters: every thread's windows come back with the bits of the first run
+    want = [np.array(b.result(4)[0], copy=True), np.array(b.result(4)[1], copy=True)]
+    batches = [pkg.capi.BaBatch([as_dict(small)] * 4, cam) for _ in range(4)]
+    out = {}
+
+    def submitter(k):
+        out[k] = [eng.wait(eng.submit(batches[k])) for _ in range(3)]
+    ts = [threading.Thread(target=submitter, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out == {k: [4, 4, 4] for k in range(4)}
+    for bb in batches:
+        for i in range(4):
+            assert np.array_equal(bb.result(i)[0], want[0]) and np.array_equal(bb.result(i)[1], want[1])
+    # destroying an engine with work in its queue finishes that work first
+    t = eng.submit(batches[0])
+    eng.close()
+    assert all(batches[0].results[i] == b.results[4] for i in range(4)) and t > 0
+    with pytest.raises(pkg.capi.Tc2liError):
+        pkg.capi.BaEngine(cam, max_windows=0)
+
+
 def test_group_call_equals_the_batch_call(pkg, synthetic):
     """tc2li_local_bundle_adjustment_batch_group (one lock-step group on a context of the caller's choice: the mapping workers of a
     multi-sequence system) gives every window the result of the common batch call, bit for bit; two groups side by side do not disturb
