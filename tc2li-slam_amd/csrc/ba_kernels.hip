@@ -561,7 +561,7 @@ struct UnitSlot { int p, ca, cb; bool inA, inB; double Y[18], W[18]; };
 __device__ __forceinline__ void d_ba_schur_units(const BaProblemDev& pb, const int unit, const int slice, const int chunks_per_slice, const double lambda,
                                                  UnitsLds& L) {
     (void)lambda;  // (the operands W D^-1 come from k_ba_schur_coef of the same trial)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const int tiles = pb.np_pad / 16, n_chunks = pb.n_schur_slices;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= unit) ++bi;
@@ -687,7 +687,7 @@ struct FullLds {
     int off[kUnitMaxChunks + 1];
 };
 __device__ __forceinline__ void d_ba_schur_full(const BaProblemDev& pb, const int slice, const int chunks_per_slice, const double lambda, FullLds& L) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const int tiles = pb.np_pad / 16, n_lower = tiles * (tiles + 1) / 2, n_chunks = pb.n_schur_slices;
     int my_ti[kFullTilesPerWave], my_tj[kFullTilesPerWave];
     v4d acc[kFullTilesPerWave];
@@ -1605,7 +1605,7 @@ __device__ __forceinline__ void d_lvi_solve(const LviSolveDev& q_, const double*
     q.first = global_ptr(q.first); q.span_end = global_ptr(q.span_end); q.rowoff = global_ptr(q.rowoff); q.hpose = global_ptr(q.hpose); q.bi = global_ptr(q.bi); q.LB = global_ptr(q.LB); q.Lband = global_ptr(q.Lband); q.hband = global_ptr(q.hband);
     S = global_ptr(S); bs = global_ptr(bs); x_dev = global_ptr(x_dev); x_host = global_ptr(x_host); ok_host = global_ptr(ok_host);
     __shared__ int s_bad;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lj = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block(), kq = lane >> 4, lj = lane & 15;
     const int n = q.n, np = q.np, ni = q.ni;
     const int tri = np * (np + 1) / 2;
     const int region0 = max(tri + 33 * np, 32 * ni);

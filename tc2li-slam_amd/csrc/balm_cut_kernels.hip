@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_balm_cut_points(const BalmCutTask* __re
 // [t per, (t + 1) per) of the list and ranks its elements in order.  The sorted list is in (key_a, val_a) on return.
 __device__ void cut_radix_sort(unsigned int*& key_a, int*& val_a, unsigned int*& key_b, int*& val_b, int n, int bits, unsigned short* s_cnt /* [16][kCutThreads] */,
                                int* s_wave) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = (n + kCutThreads - 1) / kCutThreads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block(), per = (n + kCutThreads - 1) / kCutThreads;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     for (int sh = 0; sh < bits; sh += 4) {
         int cnt[16];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kCutThreads) void k_balm_cut_sort(const BalmCutTask
     __shared__ int s_wave[kCutThreads / 64];
     __shared__ int s_n;
     if (T.state[1]) return;  // (set by an earlier launch: the same for every thread)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = T.n_points, cap = 1 << T.table_bits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block(), n = T.n_points, cap = 1 << T.table_bits;
     // ---- the roots: the occupied table slots (in any order), sorted by the smallest point index = first appearance ----
     if (tid == 0) s_n = 0;
     __syncthreads();
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kCutThreads) void k_balm_cut_walk(const BalmCutTask
     const BalmCutTask T = global_record(tasks[blockIdx.x]);
     __shared__ int s_wave[kCutThreads / 64];
     __shared__ int s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     if (T.state[1]) { if (tid == 0) { T.result_host[0] = 0; T.result_host[1] = 1; } return; }
     const int n_roots = T.state[2];
     if (tid == 0) s_base = 0;

@@ -15,7 +15,7 @@ __device__ __forceinline__ bool sort_levels(K* __restrict__ key, int* __restrict
                                             T* __restrict__ cr, T* __restrict__ lp, T* __restrict__ rp, T* __restrict__ cut, uint8_t* __restrict__ flag,
                                             int* __restrict__ dep, int n, int depth, int stop, int (*s_tot)[NT / 64], int (*s_base)[NT / 64 + 1], int* s_any) {
     constexpr int NW = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     // contiguous ranges of the wavefronts for the prefix counts: C elements each, a multiple of 64
     const int C = ((n + NW - 1) / NW + 63) / 64 * 64;
     bool any = n > stop;

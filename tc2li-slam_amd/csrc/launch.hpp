@@ -7,6 +7,11 @@
 #include <atomic>
 
 namespace tc2li {
+// The wavefront's number inside its workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes, but the compiler cannot know, and
+// everything derived from it (the row / keypoint / problem a wavefront owns, its addresses) then lives in vector registers and is computed
+// 64 times over; through readfirstlane it is a scalar register, the addresses are scalar arithmetic and the loads take a lane offset
+// (round 6, k_blur7_strips: 78 -> 52 VGPRs from this line alone).
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // ---- per-launch timing (measurement only; include/tc2li_hip.h "tc2li_profile_*") ------------------------------------------------
 // While enabled, every kernel launch of the library carries two HIP events that the runtime stamps when the dispatch starts and when
 // it completes (hipExtLaunchKernel's startEvent / stopEvent): their distance is the kernel's own execution time -- what rocprofv3's

@@ -9,7 +9,7 @@ namespace tc2li {
 
 // Exclusive prefix of a per-thread flag over a 1024-thread block (16 wavefronts); returns the block total in `total`.
 __device__ __forceinline__ int block_flag_scan(bool f, int* s_wave, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     const unsigned long long bal = __ballot(f);
     if (lane == 0) s_wave[wave] = __popcll(bal);
     __syncthreads();

@@ -535,7 +535,7 @@ __device__ __forceinline__ unsigned long long match8(uint32_t d, unsigned long l
     return m;
 }
 __device__ __forceinline__ int vs_block_scan(int v, int* s_wave, int& total) {  // exclusive prefix over the 1024 threads; two barriers
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kVsThreads) void k_voxel_sort_points(const PointXYZ
     __shared__ int s_hist[4][256], s_place[256], s_cstart[256], s_wave[kVsThreads / 64];
     __shared__ unsigned short s_wcnt[32][256], s_woff[32][256];
     __shared__ unsigned int s_max;
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const int n = count[s], base = slots[s].base;
     const VoxelParams v = vp[s];
     if (v.passthrough) { if (tid == 0) n_vox[s] = n; return; }
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kSortThreads) void k_time_sort(const PointXYZINorma
     __shared__ int s_prefL[kTsMaxBlocks + 1], s_prefR[kTsMaxBlocks + 1];
     __shared__ int s_wave[kSortThreads / 64];
     static_assert(kSortThreads == kVsThreads, "vs_block_scan is written for this workgroup size");
-    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int scan = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const ScanSlot sl_ = slots[scan];
     const int n = count[scan], B = sl_.base;
     if (tid == 0) { fallback[scan] = 0; n_ranges[scan] = 0; }
@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(256) void k_knn_hard(const MapGrid* __restrict__ gr
                                                   uint8_t* __restrict__ selected, PointXYZINormal* __restrict__ normvec,
                                                   int* __restrict__ nearest_idx, float* __restrict__ nearest_d, int* __restrict__ nfound,
                                                   const int* __restrict__ hard_count, const int2* __restrict__ hard_list) {
-    const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+    const int lane = threadIdx.x & 63, wave = (int)blockIdx.x * 4 + wave_in_block(), n_waves = gridDim.x * 4;
     const int total = *hard_count;
     for (int h = wave; h < total; h += n_waves) {
         const int2 q = hard_list[h];

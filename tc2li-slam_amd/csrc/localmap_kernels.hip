@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_lm_votes(LocalMapDev m, const int32_t* 
 
 // inclusive scan of one int per thread over a 1024-thread workgroup; returns the exclusive prefix, *total = the block's sum
 __device__ __forceinline__ int block_scan_1024(int v, int* s_wave, int* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     int incl = v;
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(incl, o, 64);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_lm_scatter(LocalMapDev m, int n_local, 
         keep = p >= 0 && m.first_pos[p] == pos;
     }
     const unsigned long long bal = __ballot(keep);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     if (lane == 0) s_cnt[wave] = __popcll(bal);
     __syncthreads();
     int off = base;

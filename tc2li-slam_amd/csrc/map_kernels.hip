@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_map_compact_list(const MapIncTask* __r
             keep = !(lo < d && s_del[lo] == i);
         }
         const unsigned long long bal = __ballot(keep);
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = wave_in_block();
         if (lane == 0) s_wave[wave] = __popcll(bal);
         __syncthreads();
         int off = 0, tot = 0;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_map_append(const MapIncTask* __restrict
         const int g = b0 + tid;
         const bool f = g < ng && T.has_append[g];
         const unsigned long long bal = __ballot(f);
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = wave_in_block();
         if (lane == 0) s_wave[wave] = __popcll(bal);
         __syncthreads();
         int off = 0, tot = 0;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(1024) void k_map_scan_cells(const MapGridTask* __re
     const int tile = blockIdx.x, n_tiles = (T.n_cells + kScanTile - 1) / kScanTile;
     if (tile >= n_tiles) return;
     __shared__ int s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = tile * kScanTile + 4 * tid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block(), base = tile * kScanTile + 4 * tid;
     int c[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c[k] = base + k < T.n_cells ? T.counts[base + k] : 0; sum += c[k]; }

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_resize_linear(const uint8_t* __restrict
     const int logical = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (logical >= gx * gy * nimg) return;
     const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
-    const int dy = by * 4 + (threadIdx.x >> 6);
+    const int dy = by * 4 + wave_in_block();
     const int dx0 = (bx * 64 + (threadIdx.x & 63)) * 4;
     if (dy >= dh || dx0 >= dw) return;
     const uint8_t* S = src + (size_t)img * src_img_stride;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict
                                                        const short* __restrict__ ibeta, int gx, int gy, int nimg, int rows_per_wave) {
     // one wavefront = 256 columns x rows_per_wave rows; XCD k takes the k-th contiguous eighth of the (image, row strip, column block) list
     const int n_units = gx * gy * nimg, per_xcd = (n_units + 7) / 8;
-    const int u = ((int)blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6);  // the wavefront's unit inside its XCD's share
+    const int u = ((int)blockIdx.x >> 3) * 4 + wave_in_block();  // the wavefront's unit inside its XCD's share
     const int logical = ((int)blockIdx.x & 7) * per_xcd + u;
     if (u >= per_xcd || logical >= n_units) return;
     const int img = logical / (gx * gy), rem = logical - img * (gx * gy), by = rem / gx, bx = rem - by * gx;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_resize_strips(const uint8_t* __restrict
 struct ResizeTables { const int* xofs[kMaxLevels]; const short* ialpha[kMaxLevels]; const int* yofs[kMaxLevels]; const short* ibeta[kMaxLevels]; };
 constexpr int kResizeTailThreads = 1024;
 __global__ __launch_bounds__(kResizeTailThreads) void k_resize_tail(LevelTable lv, ResizeTables tb, int l0, int n_levels) {
-    const int img = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, wave = wave_in_block(), lane = threadIdx.x & 63;
     for (int l = l0; l < n_levels; ++l) {
         const LevelDesc S = lv.lv[l - 1], D = lv.lv[l];
         const uint8_t* src = S.img + (size_t)img * S.img_stride;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restric
             run += idx < n ? cnt[idx] : 0;
         }
         int incl = run;
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = wave_in_block();
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o, 64);
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restric
     __syncthreads();
     const uint32_t* in = slab + (size_t)img * slab_img_stride;
     uint32_t* out = dense + (size_t)img * slab_img_stride + level_dense_off[level];
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = wave_in_block();
     for (int k = wave; k < n; k += 4) {
         const int m = s_off[k + 1] - s_off[k];
         const uint32_t* ci = in + cells[cb + k].slab_off;
@@ -528,10 +528,20 @@ __global__ __launch_bounds__(256) void k_compact_cells(const FastCell* __restric
 // round to nearest.
 // ------------------------------------------------------------------------------------------------------
 // Every level in one launch, streaming: a wavefront owns a strip of 256 columns x 32 rows; a lane loads the dword of its four
-// pixels per row at its byte address (rows of a caller image may start at any byte; rounds 1-2 cut the pixels out of two aligned
-// dwords with v_alignbit -- the kernel is bound by VALU issue, so that went), takes its neighbours' pixels by wave shuffle, filters horizontally into four 8.8 values and keeps the last
-// seven rows of them in registers for the vertical pass: every pixel is read once from HBM (plus a 6-row halo per 32 rows)
-// and no LDS is used.  The few lanes at the left / right image border gather their pixels one by one with REFLECT_101.
+// pixels per row at its byte address (rows of a caller image may start at any byte), takes its neighbours' pixels from the lanes
+// beside it (one DPP move each way: wave_shr:1 / wave_shl:1 -- a vector instruction, no trip through the LDS as a shuffle is), filters
+// horizontally into four 8.8 values and keeps the last six rows of them in registers for the vertical pass: every pixel is read
+// once from HBM (plus a 6-row halo per 32 rows) and no LDS is used.
+// Round 6: the kernel took the same time with every store suppressed (a probe, removed again): it is bound by instruction issue, like the
+// whole extraction (3.2 G wavefront vector instructions per 1024 images at ~2 ns each per SIMD -- tools/probes/valu_rate.hip: v_dot4 /
+// v_dot2 / v_perm / v_alignbyte 2.0 ns, v_add / v_fma 1.2 ns, a DPP move 2.7 ns, a shuffle through the LDS 10 ns -- are 6 of its 9.7 ms).
+// It had 116 VGPRs (4 waves per SIMD), 89 branches (a byte-wise path per row for the two rows whose dword loads could leave the buffer,
+// divergent border fix-ups), two LDS shuffles per row, three loads per row of which two served one lane each, and every row address as
+// 64-bit vector arithmetic (the wavefront's number was not known to be uniform).  Now: 52 VGPRs, 47 vector instructions per row (58): the last
+// lane of a row loads the row's LAST dword and shifts (no load leaves the buffer: no guarded rows), ONE edge load per row serves lane 0
+// (left neighbour dword) and lane 63 (right neighbour dword), the border fix-ups are selects, and the vertical pass keeps ONE set of row
+// pairs (rows in pairs: the even row of a pair takes three v_dot2 on the pairs (r-6, r-5), (r-4, r-3), (r-2, r-1) plus its own tap, the
+// odd row four v_dot2 on the same pairs with the taps shifted by one row plus the pair it completes) instead of both parities.
 constexpr int kStripW = 256, kStripRows = 32, kStripWaves = 4;
 struct BlurWork { int32_t first_block[kMaxLevels + 1]; int32_t nsx[kMaxLevels], ncy[kMaxLevels]; int32_t nlevels, nimg; };
 
@@ -539,16 +549,9 @@ __device__ __forceinline__ int reflect101(int v, int n) {
     v = v < 0 ? -v : (v >= n ? 2 * n - 2 - v : v);
     return min(max(v, 0), n - 1);
 }
-// the dword of pixels [x, x + 4) of a row with REFLECT_101 applied per pixel (border lanes only)
-__device__ __forceinline__ uint32_t gather4(const uint8_t* __restrict__ row, int x, int w) {
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v |= (uint32_t)row[reflect101(x + k, w)] << (8 * k);
-    return v;
-}
-__device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t mid, uint32_t hi, int k /* -4 .. 7, compile time */) {
-    return k < 0 ? (lo >> (8 * (k + 4))) & 0xffu : (k < 4 ? (mid >> (8 * k)) & 0xffu : (hi >> (8 * (k - 4))) & 0xffu);
-}
+// lane i receives lane i - 1's value (lane 0: `edge`) / lane i + 1's value (lane 63: `edge`): gfx9 DPP wave shifts (tools/probes/dpp_probe.hip)
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v, uint32_t edge) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v, uint32_t edge) { return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }
 
 // ROUNDED selects the fixed-point taps of cv::GaussianBlur(7 x 7, sigma 2) on CV_8U (what getFixedpointGaussianKernel hands to the 8.8 path):
 //   false: {18, 34, 48, 56, 48, 34, 18}, sum 256 -- the error-diffused quantiser (getGaussianKernelFixedPoint_ED of the later 3.4 / 4.x releases);
@@ -566,7 +569,9 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
     const int img = b / per_img;
     b -= img * per_img;
     const int cy = b / wk.nsx[level], sx = b - cy * wk.nsx[level];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (the wavefront's number through readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all 64 lanes, and without
+    // that every row's address was 64-bit vector arithmetic in every lane -- with it the rows are scalar registers and the loads take a 32-bit lane offset)
+    const int wave = wave_in_block(), lane = threadIdx.x & 63;
     const int y0 = (cy * kStripWaves + wave) * kStripRows;
     if (y0 >= S.h) return;
     const int w = S.w, h = S.h;
@@ -575,115 +580,121 @@ __global__ __launch_bounds__(64 * kStripWaves) void k_blur7_strips(LevelTable sr
     uint8_t* out = const_cast<uint8_t*>(D.img) + (size_t)img * D.img_stride;
     const bool inside = x < w;                        // the lane owns at least one pixel
     const int y1 = min(y0 + kStripRows, h);
+    constexpr uint32_t T2 = ROUNDED ? 49u : 48u, T3 = ROUNDED ? 55u : 56u;
+    if (w < 16) {
+        // an image narrower than four dwords (no pyramid level of a camera image is): pixel by pixel with REFLECT_101, the same arithmetic
+        const uint32_t taps[7] = {18u, 34u, T2, T3, T2, 34u, 18u};
+        for (int oy = y0; oy < y1; ++oy)
+            for (int k = 0; k < 4 && x + k < w; ++k) {
+                uint32_t acc = 32768u;
+                for (int dy = -3; dy <= 3; ++dy) {
+                    const uint8_t* row = base + (size_t)reflect101(oy + dy, h) * S.pitch;
+                    uint32_t hz = 0;
+                    for (int dx = -3; dx <= 3; ++dx) hz += taps[dx + 3] * row[reflect101(x + k + dx, w)];
+                    acc += taps[dy + 3] * hz;
+                }
+                out[(size_t)oy * D.pitch + x + k] = (uint8_t)(ROUNDED ? min(acc >> 16, 255u) : (acc >> 16));
+            }
+        return;
+    }
     // Border lanes: the lane at x = 0 mirrors its left neighbour dword out of its own pixels, the last lane of the row mirrors
-    // the bytes past the row end out of its own and its left neighbour's pixels (REFLECT_101), both with one v_perm_b32 whose
+    // the bytes past the row end out of its own and its left neighbour's pixels (REFLECT_101), each with one v_perm_b32 whose
     // selector is fixed for the whole strip.  Byte numbering of v_perm(S0, S1): S1 = bytes 0..3, S0 = bytes 4..7.
     const int nvalid = w - x;                          // pixels the lane owns when it is the last one: 1..4
     const bool is_first = x == 0, is_last = inside && nvalid <= 4;
-    uint32_t sel_cur = 0x07060504u, sel_hi = 0;        // over (S0 = cur, S1 = lo)
+    uint32_t sel_cur = 0x07060504u, sel_hi_last = 0;   // over (S0 = cur, S1 = lo)
+    uint32_t shift_last = 0;                           // the last lane loads the row's last dword: its pixels are that dword's top bytes
     if (is_last) {
-        sel_cur = 0; sel_hi = 0;
+        sel_cur = 0;
         for (int i = 0; i < 4; ++i) {
             const int sc = i < nvalid ? 4 + i : 4 + 2 * nvalid - 2 - i;  // cur byte i
             const int sh_ = 4 + 2 * nvalid - 6 - i;                        // hi byte i (only needed while it maps into lo / cur)
             sel_cur |= (uint32_t)max(sc, 0) << (8 * i);
-            sel_hi |= (uint32_t)max(sh_, 0) << (8 * i);
+            sel_hi_last |= (uint32_t)max(sh_, 0) << (8 * i);
+        }
+        shift_last = 8u * (uint32_t)(4 - nvalid);
+    }
+    // lane 63 of a strip whose right neighbour dword [x + 4, x + 8) crosses the row end (the last lane sits in the next strip): it loads
+    // the row's last dword instead, in which pixel x + 4 + i is byte i + (x + 8 - w); a pixel beyond the row is mirrored to
+    // 2 (w - 1) - (x + 4 + i), which lies 2 (w - x) - 6 - i pixels right of x -- in that dword again or in the lane's own.  Over (S0 = the loaded dword, S1 = cur):
+    uint32_t sel_hi63 = 0x07060504u;
+    const bool hi_crosses = lane == 63 && x + 4 < w && x + 8 > w;
+    if (hi_crosses) {
+        sel_hi63 = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int p = x + 4 + i < w ? 4 + i : 2 * (w - x) - 6 - i;           // the pixel's place relative to x (mirrored when beyond the row)
+            sel_hi63 |= (uint32_t)(p >= 4 ? p + (x + 8 - w) : p) << (8 * i);       // in the loaded dword (shifted by x + 8 - w) or in cur
         }
     }
-    // lane 63 of a strip whose right neighbour dword [x + 4, x + 8) crosses the row end (the last lane sits in the next strip):
-    // byte i of that dword is pixel x + 4 + i, mirrored to 2 (w - 1) - (x + 4 + i) when it lies beyond the row; over
-    // (S0 = the loaded dword, S1 = cur) the source index is 4 + i for a real pixel and 2 (w - x) - 6 - i for a mirrored one
-    uint32_t sel_hi63 = 0x07060504u;
-    if (lane == 63 && x + 4 < w && x + 8 > w) {
-        sel_hi63 = 0;
-        for (int i = 0; i < 4; ++i) sel_hi63 |= (uint32_t)(x + 4 + i < w ? 4 + i : 2 * (w - x) - 6 - i) << (8 * i);
-    }
-    // rows whose dword loads could leave the buffer (they read up to 3 bytes before and 7 bytes after the row): the first row
-    // of the first image and the last row of the last image take the byte-wise path
-    const bool tiny = w < 16;
-    // V[j][k] = (hz of row j-1, hz of row j) of pixel k as two u16: the vertical pass is three v_dot2_u32_u16 on the pairs
-    // (r-6, r-5), (r-4, r-3), (r-2, r-1) plus the tap of row r.  Six rows of pairs live in registers; the loop is unrolled by
-    // six so that their roles rotate at compile time instead of moving registers.
-    uint32_t V[6][4], prev[4] = {0, 0, 0, 0};
+    // byte offsets of the lane's two loads inside a row: its own dword (the row's first dword for a lane beyond the row: loaded, not used)
+    // and the edge dword -- lane 0: the dword left of the strip, lane 63: the one right of it (none of the two: the row's first dword)
+    const uint32_t off_m = inside ? (uint32_t)(is_last ? w - 4 : x) : 0u;
+    const uint32_t off_e = lane == 0 && x > 0 ? (uint32_t)(x - 4) : (lane == 63 && x + 4 < w ? (uint32_t)min(x + 4, w - 4) : 0u);
+    const uint32_t keep = inside ? 0xffffffffu : 0u;
+    // P[j][k]: a pair of rows' horizontal sums (8.8) of pixel k as two u16, older row low; E[k]: the even row of the pair being formed
+    uint32_t P[3][4], E[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) V[j][k] = 0;
+        for (int k = 0; k < 4; ++k) P[j][k] = 0;
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     auto dot2 = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
         return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
     };
-    constexpr uint32_t T2 = ROUNDED ? 49u : 48u, T3 = ROUNDED ? 55u : 56u;
     constexpr uint32_t TA = 18u | (34u << 8) | (T2 << 16) | (T3 << 24), TB = T2 | (34u << 8) | (18u << 16);
-    constexpr uint32_t C01 = 18u | (34u << 16), C23 = T2 | (T3 << 16), C45 = T2 | (34u << 16);
+    // even row r of a pair: rows (r-6, r-5) (r-4, r-3) (r-2, r-1) + 18 hz(r); odd row r + 1: the same pairs one tap on, + the pair (r, r + 1)
+    constexpr uint32_t A0 = 18u | (34u << 16), A1 = T2 | (T3 << 16), A2 = T2 | (34u << 16);
+    constexpr uint32_t B0 = 18u << 16, B1 = 34u | (T2 << 16), B2 = T3 | (T2 << 16), B3 = 34u | (18u << 16);
     const int r_end = y1 + 3;
     for (int r0 = y0 - 3; r0 < r_end; r0 += 6) {
         // The six rows of a round are REQUESTED first and used afterwards: with the load next to its use every row cost the wavefront a
-        // full trip to memory (one dword per lane in flight: 38 trips per strip, 0.31 ms per 128 images at 1.3 TB/s, 4 % VALU issue).
-        uint32_t ld_m[6], ld_l[6], ld_n1[6];  // raw dwords only (own, left of lane 0, right of lane 63), read at their byte addresses: nothing here waits for a load
-        const uint8_t* ld_row[6];
-        bool ld_guarded[6];
-        // every load below is unconditional -- a lane that has nothing to fetch reads the image's first dword instead (an address
-        // select, not a value select: nothing depends on a loaded register until the second loop)
+        // full trip to memory.
+        uint32_t ld_m[6], ld_e[6];
         auto load4 = [](const uint8_t* p) -> uint32_t { uint32_t t; __builtin_memcpy(&t, p, 4); return t; };
 #pragma unroll
         for (int ph = 0; ph < 6; ++ph) {
-            const int r = r0 + ph;
-            const int ry = reflect101(min(r, r_end - 1), h);
+            const int ry = reflect101(min(r0 + ph, r_end - 1), h);
             const uint8_t* row = base + (size_t)ry * S.pitch;
-            ld_row[ph] = row;
-            ld_guarded[ph] = tiny || (img == 0 && ry == 0) || (img == wk.nimg - 1 && ry == h - 1);
-            const bool live = r < r_end && !ld_guarded[ph];
-            // the four bytes left of lane 0 and right of lane 63 are not a neighbour's: those lanes fetch them
-            const bool want_l = live && lane == 0 && x > 0, want_hi = live && lane == 63 && x + 4 < w;
-            ld_m[ph] = load4(live && inside ? row + x : base);
-            ld_l[ph] = load4(want_l ? row + x - 4 : base);
-            ld_n1[ph] = load4(want_hi ? row + x + 4 : base);
+            ld_m[ph] = load4(row + off_m);
+            ld_e[ph] = load4(row + off_e);
         }
 #pragma unroll
         for (int ph = 0; ph < 6; ++ph) {
             const int r = r0 + ph;
             if (r < r_end) {
-                const uint8_t* row = ld_row[ph];
-                uint32_t cur = 0, lo, hi;
-                if (!ld_guarded[ph]) {
-                    cur = inside ? ld_m[ph] : 0u;
-                    lo = __shfl_up(cur, 1, 64);
-                    if (lane == 0 && x > 0) lo = ld_l[ph];
-                    cur = __builtin_amdgcn_perm(cur, lo, sel_cur);           // identity except in the last lane
-                    hi = __shfl_down(cur, 1, 64);
-                    if (lane == 63 && x + 4 < w) {
-                        hi = ld_n1[ph];
-                        if (x + 8 > w) hi = __builtin_amdgcn_perm(hi, cur, sel_hi63);  // the row ends inside that dword: mirror the rest
-                    }
-                    if (is_last) hi = __builtin_amdgcn_perm(cur, lo, sel_hi);
-                    if (is_first) lo = __builtin_amdgcn_perm(hi, cur, 0x01020304u);  // pixels -4..-1 = pixels 4, 3, 2, 1
-                } else {
-                    if (inside) { cur = gather4(row, x, w); lo = gather4(row, x - 4, w); hi = gather4(row, x + 4, w); }
-                    else { lo = 0; hi = 0; }
-                }
+                uint32_t cur = (ld_m[ph] >> shift_last) & keep;
+                uint32_t lo = from_lane_below(cur, ld_e[ph]);
+                cur = __builtin_amdgcn_perm(cur, lo, sel_cur);                  // identity except in the last lane
+                uint32_t hi = from_lane_above(cur, ld_e[ph]);
+                hi = __builtin_amdgcn_perm(hi, cur, sel_hi63);                  // identity except where the row ends inside lane 63's right dword
+                const uint32_t hi_last = __builtin_amdgcn_perm(cur, lo, sel_hi_last);
+                hi = is_last ? hi_last : hi;
+                const uint32_t lo_first = __builtin_amdgcn_perm(hi, cur, 0x01020304u);  // pixels -4..-1 = pixels 4, 3, 2, 1
+                lo = is_first ? lo_first : lo;
                 // horizontal: pixel k needs bytes k-3 .. k+3 around its own: two 4-byte windows, two v_dot4_u32_u8
                 uint32_t hz[4];
                 hz[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 1), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 1), TB, 0u, false), false);
                 hz[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 2), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 2), TB, 0u, false), false);
                 hz[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(cur, lo, 3), TA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(hi, cur, 3), TB, 0u, false), false);
                 hz[3] = __builtin_amdgcn_udot4(cur, TA, __builtin_amdgcn_udot4(hi, TB, 0u, false), false);
-                // slot (ph) receives the pair (row r-1, row r); the pairs of rows (r-6, r-5), (r-4, r-3), (r-2, r-1) are in the
-                // slots written 5, 3 and 1 rows ago
+                const int j0 = (ph / 2) % 3, j1 = (ph / 2 + 1) % 3, j2 = (ph / 2 + 2) % 3;   // the pairs (r-6, r-5), (r-4, r-3), (r-2, r-1) of an even row
                 uint32_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t acc = dot2(V[(ph + 1) % 6][k], C01, dot2(V[(ph + 3) % 6][k], C23, dot2(V[(ph + 5) % 6][k], C45, 18u * hz[k] + 32768u)));
+                    uint32_t acc;
+                    if (ph % 2 == 0) {
+                        acc = dot2(P[j0][k], A0, dot2(P[j1][k], A1, dot2(P[j2][k], A2, 18u * hz[k] + 32768u)));
+                        E[k] = hz[k];
+                    } else {
+                        const uint32_t n = E[k] | (hz[k] << 16);
+                        acc = dot2(P[j0][k], B0, dot2(P[j1][k], B1, dot2(P[j2][k], B2, dot2(n, B3, 32768u))));
+                        P[j0][k] = n;                                            // the oldest pair's place: (r-6, r-5) is not needed again
+                    }
                     packed |= (ROUNDED ? min(acc >> 16, 255u) : (acc >> 16)) << (8 * k);  // taps summing to 257 can reach 256: saturate_cast
-                    V[ph][k] = prev[k] | (hz[k] << 16);
-                    prev[k] = hz[k];
                 }
                 const int oy = r - 3;
-                if (oy >= y0 && inside) {
-                    uint8_t* o = out + (size_t)oy * D.pitch + x;
-                    if (x + 4 <= w) *reinterpret_cast<uint32_t*>(o) = packed;
-                    else for (int k = 0; k < 4 && x + k < w; ++k) o[k] = (uint8_t)(packed >> (8 * k));
-                }
+                // (the last lane's dword may end up to three bytes beyond the row: inside the level's pitch, which launch_blur_all checks)
+                if (oy >= y0 && inside) *reinterpret_cast<uint32_t*>(out + (size_t)oy * D.pitch + x) = packed;
             }
         }
     }
@@ -911,6 +922,8 @@ void launch_blur_all(const LevelTable& src, const LevelTable& dst, int nlevels, 
         total += wk.nsx[l] * wk.ncy[l] * nimg;
     }
     for (int l = nlevels; l <= kMaxLevels; ++l) wk.first_block[l] = total;
+    for (int l = 0; l < nlevels; ++l)   // the kernel stores whole dwords: a destination row holds its width rounded up to four bytes (the extractor's levels: to 64)
+        if (dst.lv[l].pitch < ((dst.lv[l].w + 3) & ~3)) { fprintf(stderr, "tc2li: blur destination pitch %d below the dwords of a row of %d pixels\n", dst.lv[l].pitch, dst.lv[l].w); abort(); }
     if (total && rounded_taps) TC2LI_LAUNCH(k_blur7_strips<true>, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
     else if (total) TC2LI_LAUNCH(k_blur7_strips<false>, dim3(total), dim3(64 * kStripWaves), 0, st, src, dst, wk);
 }

@@ -24,7 +24,7 @@ constexpr int kPiThreads = 256;
 constexpr int kPiRed = 28;  // 21 upper-triangular H entries + 6 b entries + one counter
 
 __device__ __forceinline__ void pi_block_reduce(double (&v)[kPiRed], double* s_red /*[4][kPiRed]*/, double* s_out /*[kPiRed]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     {   // (wave_reduce.hpp: the xor butterfly's sums with a sixth of its shuffles)
         const double x = wave_reduce_32(v);
         const int k = wave_reduce_index(lane);

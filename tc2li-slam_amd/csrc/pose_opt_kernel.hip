@@ -22,7 +22,7 @@ constexpr int kPoThreads = 256;
 constexpr int kRed = 28;  // 21 upper-triangular H entries + 6 b entries + chi
 
 __device__ __forceinline__ void block_reduce(double (&v)[kRed], double* s_red /*[4][kRed]*/, double* s_out /*[kRed]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     {   // the wavefront's sums: the xor butterfly's, a lane keeping only the values it answers for (wave_reduce.hpp: same bits, a sixth of the shuffles)
         const double x = wave_reduce_32(v);
         const int k = wave_reduce_index(lane);
@@ -35,7 +35,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[kRed], double* s_red /*
 
 // sum of ONE value over the block (the trial pass and the outlier count need nothing else: a 28-value reduction there is wasted latency)
 __device__ __forceinline__ double block_sum(double x, double* s_red, double* s_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
     if (lane == 0) s_red[wave] = x;

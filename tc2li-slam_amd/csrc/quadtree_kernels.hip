@@ -184,7 +184,7 @@ template <class A> __device__ void std_sort(const A& v, int n, int* stack) {
 // Exclusive prefix sums over the block; every thread of the block calls them the same number of times.
 template <int T, typename V>
 __device__ __forceinline__ V block_excl_scan(V v, V* s_wave, V& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     V incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

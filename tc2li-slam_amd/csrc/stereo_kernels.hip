@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(ScaleTable sc, const Stereo
     __shared__ int s_cnt[kStereoMaxRows];
     __shared__ int s_wave[4];
     const StereoFrame fr = frames[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const MatchKey* kr = keys + fr.right_off;
     int32_t* rs = row_start + (size_t)blockIdx.x * (rows + 1);
     uint16_t* out = entries + (size_t)blockIdx.x * entry_cap;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
     if (logical >= total) return;
     const int frame = logical / gx, bx = logical - frame * gx;
     const StereoFrame fr = frames[frame];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_in_block();
     const int first = bx * kLeftPerBlock;
     if (first >= fr.n_left) return;
     const MatchKey* kr = keys + fr.right_off;

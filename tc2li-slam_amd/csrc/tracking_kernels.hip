@@ -42,7 +42,7 @@ __device__ __forceinline__ void store_query(MatchQuery* dst, const MatchQuery& q
 }
 
 __device__ __forceinline__ int block_excl_scan_256(int v, int* s_wave, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_in_block();
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
