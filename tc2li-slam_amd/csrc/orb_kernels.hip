@@ -340,8 +340,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     if (tid == 0) { s_cnt_ini = 0; s_nlist = 0; s_nkept = 0; }
     __syncthreads();
 
-    const int ew = w - 6, eh = h - 6, npix = ew > 0 && eh > 0 ? ew * eh : 0;
-    const float inv_ew = 1.0f / (float)(ew > 0 ? ew : 1);  // i / ew for i < 6000 through a float multiply (exact: see row_of)
+    const int ew = w - 6, eh = h - 6;
     // the 16 circle pixels and the centre of window position (cx, cy)
     auto circle = [&](int cx, int cy, int (&p)[16]) -> int {
         const uint8_t* r3 = tile + cy * kTileP + cx;
@@ -365,21 +364,36 @@ __global__ __launch_bounds__(kFastThreads) void k_fast_cells(LevelTable levels, 
     }
     // Pass 0, every pixel: a necessary condition of the segment test on the four compass pixels -- nine contiguous circle pixels
     // always contain pixel 0 or 8 and pixel 4 or 12, so a brighter (darker) arc needs (p0 | p8) & (p4 | p12) brighter (darker).
-    // Most pixels of an image stop here after five LDS bytes; the others are appended to a list (any order).
-    // (row, column) of pixel tid + 128 k stepped, not divided: 128 = q_step * ew + r_step
-    const int q_step = ew > 0 ? kFastThreads / ew : 0, r_step = kFastThreads - q_step * ew;
-    int ey = row_of(tid, ew > 0 ? ew : 1, inv_ew), ex = tid - ey * ew;
-    for (int i = tid; i < npix; i += kFastThreads) {
-        const int cx = ex + 3, cy = ey + 3;
-        ex += r_step; ey += q_step;
-        if (ex >= ew) { ex -= ew; ++ey; }
-        const uint8_t* r3 = tile + cy * kTileP + cx;
-        const uint8_t *r0 = r3 - 3 * kTileP, *r6 = r3 + 3 * kTileP;
-        const int v = r3[0], hi_t = v + th, lo_t = v - th;
-        const int p0 = r6[0], p8 = r0[0], p4 = r3[3], p12 = r3[-3];
-        const bool bright = (p0 > hi_t || p8 > hi_t) && (p4 > hi_t || p12 > hi_t);
-        const bool dark = (p0 < lo_t || p8 < lo_t) && (p4 < lo_t || p12 < lo_t);
-        if (bright || dark) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(cy * TW + cx);
+    // Most pixels of an image stop here; the others are appended to a list (any order).
+    // FOUR pixels per lane (round 6; the pass was a byte load per compass pixel, an address and a loop step per pixel: 22 vector and 5 LDS
+    // instructions each, and the kernel -- like the whole extraction -- is bound by instruction issue): the lane reads the ALIGNED dwords
+    // around its four centres (three of the centre row, two of the rows three above and below: four LDS instructions), cuts the five
+    // 4-pixel words out of them with v_alignbyte -- window pixel cx = 3 + 4 g + k sits in byte 3 of dword g or bytes 0..2 of dword
+    // g + 1, the pixel three to its left in byte k of dword g, the one three to its right in dwords g + 1 / g + 2 -- and tests pixel k on
+    // byte k of those words (the byte selects are operand modifiers, not instructions).
+    {
+        constexpr int kDw = kTileP / 4;
+        const int ngx = (ew + 3) >> 2, ngroups = ew > 0 && eh > 0 ? ngx * eh : 0;
+        const float inv_ngx = 1.0f / (float)(ngx > 0 ? ngx : 1);
+        const int q_step = ngx > 0 ? kFastThreads / ngx : 0, r_step = kFastThreads - q_step * ngx;   // (row, group) of item tid + 128 k stepped, not divided
+        int gy = row_of(tid, ngx > 0 ? ngx : 1, inv_ngx), g = tid - gy * ngx;
+        for (int i = tid; i < ngroups; i += kFastThreads) {
+            const int cy = gy + 3, g0 = g;
+            g += r_step; gy += q_step;
+            if (g >= ngx) { g -= ngx; ++gy; }
+            const uint32_t* rc = tile32 + cy * kDw + g0;
+            const uint32_t a0 = rc[0], a1 = rc[1], a2 = rc[2];
+            const uint32_t u0 = rc[-3 * kDw], u1 = rc[-3 * kDw + 1], d0 = rc[3 * kDw], d1 = rc[3 * kDw + 1];
+            const uint32_t V = __builtin_amdgcn_alignbyte(a1, a0, 3), P4 = __builtin_amdgcn_alignbyte(a2, a1, 2), P12 = a0;
+            const uint32_t P8 = __builtin_amdgcn_alignbyte(u1, u0, 3), P0 = __builtin_amdgcn_alignbyte(d1, d0, 3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = (int)((V >> (8 * k)) & 0xffu);
+                const int p0 = (int)((P0 >> (8 * k)) & 0xffu), p8 = (int)((P8 >> (8 * k)) & 0xffu), p4 = (int)((P4 >> (8 * k)) & 0xffu), p12 = (int)((P12 >> (8 * k)) & 0xffu);
+                const int most = min(max(p0, p8), max(p4, p12)), least = max(min(p0, p8), min(p4, p12));
+                if ((most > v + th || least < v - th) && 4 * g0 + k < ew) s_list[atomicAdd(&s_nlist, 1)] = (uint16_t)(cy * TW + 3 + 4 * g0 + k);
+            }
+        }
     }
     __syncthreads();
     // Pass 1, the pixels that passed, packed densely over the lanes: the segment test proper (two 16-bit masks, "9 contiguous"

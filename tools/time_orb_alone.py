@@ -22,6 +22,8 @@ t = time.perf_counter()
 for _ in range(reps): out = ext.extract_batch_dev(dev.data_ptr(), N, W, H, W, W * H, stream=st.cuda_stream, out=out)
 torch.cuda.synchronize()
 print("%d images: %.3f ms per call, %.1f keypoints per image" % (N, (time.perf_counter() - t) * 1e3 / reps, float(np.mean(out[2]))))
+if os.environ.get("TC2LI_ORB_SERIAL"):   # every kernel on one stream, one after the other: its duration is its own
+    ext.set_profiling(True)
 pkg.capi.profile_enable(True)
 for _ in range(3): out = ext.extract_batch_dev(dev.data_ptr(), N, W, H, W, W * H, stream=st.cuda_stream, out=out)
 torch.cuda.synchronize()
