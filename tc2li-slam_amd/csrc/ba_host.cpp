@@ -2055,6 +2055,7 @@ struct EngineTicket {
 struct EngineSlot {
     int state = kSlotFree, index = 0, rc_lidar = 0;
     std::atomic<int> setup_left{0};   // the window's setup tasks (structure + staging; LiDAR window) still running on the setup threads
+    long side_tick = 0;               // > 0: the tick whose plane-extraction launch (on the engine's side stream) the window waits for
     long seq = 0;               // the event (tick) whose completion means the work queued for this state has run
     int cap[6] = {0, 0, 0, 0, 0, 0};  // the largest window its work space has held: poses, points, edges, LiDAR keyframes, cloud points, free poses
     EngineTicket* ticket = nullptr;
@@ -2089,6 +2090,21 @@ struct tc2li_ba_engine {
     std::unique_ptr<WorkerPool> pool;
     long tick = 0;
     int busy = 0;                                             // slots not free
+    // The plane extraction of newly admitted windows (their clouds up, six kernels of 0.3-0.5 ms together) sits between two rounds of
+    // everything alive when it is queued in the main stream.  TC2LI_BA_ENGINE_SIDE=1 queues it on a SIDE stream of the engine instead (one event
+    // per tick parity; a parity's staging buffers and event are reused only when its last launch has completed).  Measured, three engines,
+    // frames/s main -> side: 512 sequences 20.3-20.6 k -> 19.7-20.3 k, 256: 16.8-17.2 k -> 17.8-18.5 k, 128: 14.8-15.2 k -> 14.4-14.6 k -- with
+    // the side streams the LiDAR thread's step grows from 16-18 to 25 ms at 512 (the process's streams share four hardware queues, and the
+    // long single-workgroup sort of the extraction then sits in front of another stage's kernels): off by default.
+    hipStream_t side = nullptr;
+    bool use_side = false;
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    long side_last[2] = {0, 0};                               // the tick of the last launch recorded on side_ev[parity] (0: none)
+    bool side_done(int par) { return side_last[par] == 0 || hipEventQuery(side_ev[par]) == hipSuccess; }
+    ~tc2li_ba_engine() {
+        for (hipEvent_t e : side_ev) if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+    }
     // ---- the setup threads: a window's host-side setup runs beside the rounds of the others ----
     std::mutex smu;
     std::condition_variable scv;
@@ -2181,6 +2197,9 @@ void tc2li_ba_engine::run() {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; failed = 1; }
         for (hipEvent_t& e : C.round_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
+        use_side = getenv("TC2LI_BA_ENGINE_SIDE") && atoi(getenv("TC2LI_BA_ENGINE_SIDE")) != 0;
+        if (use_side && hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; failed = 1; }
+        for (hipEvent_t& e : side_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
     }
     hipStream_t st = C.st;
     const int cap = capacity;
@@ -2211,7 +2230,7 @@ void tc2li_ba_engine::run() {
         if (kTiming) { t_lap = now(); ++n_ticks; }
         EngineStaging& G = S[tick & 1];
         bool queued_any = false;
-        int n_in_setup = 0;
+        int n_in_setup = 0, n_waiting_side = 0;
         // ---- 1. windows whose result copies have landed (queued two ticks ago, that tick's round has been waited for) ----
         {
             std::vector<int> done;
@@ -2266,7 +2285,9 @@ void tc2li_ba_engine::run() {
             size_t max_bytes = 0;
             for (int s = 0; s < cap; ++s) {
                 EngineSlot& sl = slots[s];
-                if (sl.state != kSlotStaged || sl.seq > waited) continue;
+                if (sl.state != kSlotStaged) continue;
+                // (a window without planes to extract has nothing in flight: alive at the tick after its setup)
+                if (sl.side_tick && side_last[sl.side_tick & 1] == sl.side_tick && hipEventQuery(side_ev[sl.side_tick & 1]) != hipSuccess) { ++n_waiting_side; continue; }
                 LockstepWindow& w = W[s];
                 if (w.rc >= 0 && w.p->lidar) {
                     if (sl.rc_lidar >= 0 && C.h_cut.p[s].n_points > 0) sl.rc_lidar = C.ws[s]->lidar.finish_cut(st);
@@ -2357,13 +2378,16 @@ void tc2li_ba_engine::run() {
                 { std::lock_guard<std::mutex> lk(smu); for (int s : admitted) { setup_queue.push_back(2 * s); setup_queue.push_back(2 * s + 1); } }
                 scv.notify_all();
             }
-            // windows whose setup has finished: staged from this tick on
-            for (int s = 0; s < cap; ++s)
-                if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) { slots[s].state = kSlotStaged; slots[s].seq = tick; fresh.push_back(s); }
+            // windows whose setup has finished: staged from this tick on -- unless this parity's staging buffers still serve a plane extraction
+            // that has not run (then at the next tick)
+            const int par = (int)(tick & 1);
+            if (side_done(par))
+                for (int s = 0; s < cap; ++s)
+                    if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; fresh.push_back(s); }
             n_in_setup = 0;
             for (int s = 0; s < cap; ++s) n_in_setup += slots[s].state == kSlotSetup;
             if (!fresh.empty()) {
-                // the extraction of the staged windows' planes: their clouds up, the cut kernels (as plane_extraction_begin)
+                // the extraction of the staged windows' planes: their clouds up, the cut kernels (as plane_extraction_begin), on the side stream
                 int m = 0, max_points = 0, max_table = 0;
                 size_t n_copies = 1;
                 for (int s : fresh) n_copies += slots[s].deferred_lidar.size();
@@ -2377,9 +2401,18 @@ void tc2li_ba_engine::run() {
                     }
                     size_t at = 0, max_bytes = (size_t)std::max(m, 1) * sizeof(BalmCutTask);
                     if (m) G.h_copies_a.p[at++] = CopyTask{G.d_cut_list.p, G.h_cut_list.p, (size_t)m * sizeof(BalmCutTask)};
-                    for (int s : fresh) { for (const CopyTask& t : slots[s].deferred_lidar) { G.h_copies_a.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); } slots[s].deferred_lidar.clear(); }
-                    if (at) { launch_copy_tasks(G.h_copies_a.p, (int)at, max_bytes, st); queued_any = true; }
-                    if (m) launch_balm_cut(G.d_cut_list.p, m, max_points, max_table, st);
+                    for (int s : fresh) {
+                        if (!slots[s].deferred_lidar.empty() || (C.h_cut.p[s].n_points > 0 && slots[s].rc_lidar >= 0)) slots[s].side_tick = tick;
+                        for (const CopyTask& t : slots[s].deferred_lidar) { G.h_copies_a.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
+                        slots[s].deferred_lidar.clear();
+                    }
+                    hipStream_t cut_st = use_side ? side : st;
+                    if (at) launch_copy_tasks(G.h_copies_a.p, (int)at, max_bytes, cut_st);
+                    if (m) launch_balm_cut(G.d_cut_list.p, m, max_points, max_table, cut_st);
+                    if (at || m) {
+                        if (hipGetLastError() != hipSuccess || hipEventRecord(side_ev[par], cut_st) != hipSuccess) failed = 1;
+                        side_last[par] = tick;
+                    }
                 }
             }
         }
@@ -2449,7 +2482,7 @@ void tc2li_ba_engine::run() {
             // nothing alive: what is in flight (plane extractions, result copies) is all there is to wait for -- without this the loop would
             // run through empty ticks
             while (!failed && live.empty() && waited < recorded) wait_one();
-            if (!failed && live.empty() && n_in_setup > 0 && !queued_any) std::this_thread::sleep_for(std::chrono::microseconds(50));  // only setups are running
+            if (!failed && live.empty() && (n_in_setup > 0 || n_waiting_side > 0) && !queued_any) std::this_thread::sleep_for(std::chrono::microseconds(50));  // only setups / plane extractions are running
         }
         lap(5);
         if (failed) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); if (error.empty()) error = "HIP error in the engine thread"; }
@@ -2457,6 +2490,7 @@ void tc2li_ba_engine::run() {
     if (kTiming && n_ticks) fprintf(stderr, "BA engine timing: %ld windows in %ld ticks (%.1f alive per tick); ms per tick: finish %.3f go-live %.3f admit+setup %.3f retire %.3f queue round %.3f wait %.3f; %ld buffer (re)allocations in the process meanwhile\n",
                                     n_windows, n_ticks, (double)n_live_sum / n_ticks, tm[0] / n_ticks, tm[1] / n_ticks, tm[2] / n_ticks, tm[3] / n_ticks, tm[4] / n_ticks, tm[5] / n_ticks, g_buffer_allocs.load() - allocs0);
     if (C.st) (void)hipStreamSynchronize(C.st);
+    if (side) (void)hipStreamSynchronize(side);
 }
 
 namespace {
