@@ -2055,6 +2055,7 @@ struct EngineTicket {
 struct EngineSlot {
     int state = kSlotFree, index = 0, rc_lidar = 0;
     std::atomic<int> setup_left{0};   // the window's setup tasks (structure + staging; LiDAR window) still running on the setup threads
+    long ready_tick = 0;              // > 0: the tick its setup was first seen finished (it waits to be staged with others)
     long side_tick = 0;               // > 0: the tick whose plane-extraction launch (on the engine's side stream) the window waits for
     long seq = 0;               // the event (tick) whose completion means the work queued for this state has run
     int cap[6] = {0, 0, 0, 0, 0, 0};  // the largest window its work space has held: poses, points, edges, LiDAR keyframes, cloud points, free poses
@@ -2098,6 +2099,9 @@ struct tc2li_ba_engine {
     // long single-workgroup sort of the extraction then sits in front of another stage's kernels): off by default.
     hipStream_t side = nullptr;
     bool use_side = false;
+    // TC2LI_BA_ENGINE_STAGE="min,wait": windows staged together / ticks one waits at most.  Measured, three engines, frames/s at "1,0" / "4,2" /
+    // "8,3": 512 sequences 20.4-20.6 k / 20.5-20.7 k / 20.7-20.9 k; 256: 17.4-17.7 / 17.7-17.8 / 17.7-18.0; 128: 14.7-15.3 / 15.3-15.7 / 15.2-15.5
+    int stage_min = 8, stage_wait = 3;
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     long side_last[2] = {0, 0};                               // the tick of the last launch recorded on side_ev[parity] (0: none)
     bool side_done(int par) { return side_last[par] == 0 || hipEventQuery(side_ev[par]) == hipSuccess; }
@@ -2198,6 +2202,7 @@ void tc2li_ba_engine::run() {
         if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; failed = 1; }
         for (hipEvent_t& e : C.round_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
         use_side = getenv("TC2LI_BA_ENGINE_SIDE") && atoi(getenv("TC2LI_BA_ENGINE_SIDE")) != 0;
+        if (const char* e = getenv("TC2LI_BA_ENGINE_STAGE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 0) { stage_min = a; stage_wait = b; } }
         if (use_side && hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; failed = 1; }
         for (hipEvent_t& e : side_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
     }
@@ -2367,7 +2372,7 @@ void tc2li_ba_engine::run() {
                     }
                     const int s = best >= 0 ? best : largest;
                     for (int k = 0; k < 6; ++k) slots[s].cap[k] = std::max(slots[s].cap[k], dims[k]);
-                    slots[s].ticket = t; slots[s].index = t->next++; slots[s].state = kSlotSetup; slots[s].rc_lidar = 0;
+                    slots[s].ticket = t; slots[s].index = t->next++; slots[s].state = kSlotSetup; slots[s].rc_lidar = 0; slots[s].ready_tick = 0;
                     if (t->next == t->n) queue.pop_front();
                     admitted.push_back(s);
                     ++busy; --n_free_slots;
@@ -2380,10 +2385,21 @@ void tc2li_ba_engine::run() {
             }
             // windows whose setup has finished: staged from this tick on -- unless this parity's staging buffers still serve a plane extraction
             // that has not run (then at the next tick)
+            // (and, with LiDAR windows among them, only when a few have gathered or one has waited: the extraction is six launches of 0.3-0.5 ms
+            // together in front of the next round whether it serves one window or ten)
             const int par = (int)(tick & 1);
-            if (side_done(par))
+            if (side_done(par)) {
+                int n_ready = 0, n_ready_lidar = 0;
+                long oldest = tick;
                 for (int s = 0; s < cap; ++s)
-                    if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; fresh.push_back(s); }
+                    if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) {
+                        if (!slots[s].ready_tick) slots[s].ready_tick = tick;
+                        ++n_ready; n_ready_lidar += C.h_cut.p[s].n_points > 0; oldest = std::min(oldest, slots[s].ready_tick);
+                    }
+                if (n_ready && (n_ready_lidar == 0 || n_ready >= stage_min || tick - oldest >= stage_wait))
+                    for (int s = 0; s < cap; ++s)
+                        if (slots[s].state == kSlotSetup && slots[s].ready_tick) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; slots[s].ready_tick = 0; fresh.push_back(s); }
+            }
             n_in_setup = 0;
             for (int s = 0; s < cap; ++s) n_in_setup += slots[s].state == kSlotSetup;
             if (!fresh.empty()) {
