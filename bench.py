@@ -681,13 +681,16 @@ class Loop:
             self.ba_engine = self.ba_engines[0]
             self.ba_ring = [ba_batch_of(pkg, wl, r * n_ba, n_ba) for r in range(int(os.environ.get("TC2LI_BENCH_BA_ENGINE_RING", "0")) or max(1, args.kf_interval))]
             self.ba_workers, self.ba_batch2, self.ba_batch4 = [], None, None
-            # the engines' work spaces take their sizes from the windows they meet (a batch call's do so in its first call): every ticket of the
-            # ring once through its engines before anything is timed
-            for _ in range(2):
-                K = len(self.ba_engines)
-                tickets = [(self.ba_engines[i % K], self.ba_engines[i % K].submit(b, i, 1)) for b in self.ba_ring for i in range(b.n)]  # (window i: engine i % K, as in the loop)
-                for e, t in tickets:
+            # the engines' work spaces take their sizes from the windows they meet (a batch call's do so in its first call): before anything is
+            # timed every engine is handed ALL the ring's windows at once (every slot's work space is touched: its ~40 buffers are allocated on
+            # first use), then once more in the loop's own assignment (window i: engine i % K)
+            K = len(self.ba_engines)
+            for e in self.ba_engines:
+                for t in [e.submit(b) for b in self.ba_ring]:
                     e.wait(t)
+            tickets = [(self.ba_engines[i % K], self.ba_engines[i % K].submit(b, i, 1)) for b in self.ba_ring for i in range(b.n)]
+            for e, t in tickets:
+                e.wait(t)
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]

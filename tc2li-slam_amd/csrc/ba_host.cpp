@@ -2047,6 +2047,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
 // rounds later, and nobody waits for a straggler.  Same kernels, same per-window arithmetic: a window's bits are those of the batch calls.
 enum { kSlotFree = 0, kSlotStaged = 1, kSlotLive = 2, kSlotRetiring = 3, kSlotSetup = 4 };
 struct EngineTicket {
+    double t_submit = 0;
     const tc2li_ba_problem* problems = nullptr;
     int32_t* results = nullptr;
     int n = 0, next = 0, remaining = 0, n_ok = 0;
@@ -2055,6 +2056,7 @@ struct EngineTicket {
 struct EngineSlot {
     int state = kSlotFree, index = 0, rc_lidar = 0;
     std::atomic<int> setup_left{0};   // the window's setup tasks (structure + staging; LiDAR window) still running on the setup threads
+    double t_submit = 0, t_admit = 0, t_ready = 0, t_staged = 0, t_live = 0, t_retire = 0;   // TC2LI_BA_TIMING: where a window's time goes
     long ready_tick = 0;              // > 0: the tick its setup was first seen finished (it waits to be staged with others)
     long side_tick = 0;               // > 0: the tick whose plane-extraction launch (on the engine's side stream) the window waits for
     long seq = 0;               // the event (tick) whose completion means the work queued for this state has run
@@ -2115,6 +2117,7 @@ struct tc2li_ba_engine {
     std::deque<int> setup_queue;                              // 2 * slot + (0: structure and staging, 1: LiDAR window)
     bool setup_quit = false;
     std::vector<std::thread> setup_threads;
+    std::atomic<long> setup_us[2] = {{0}, {0}}, setup_n[2] = {{0}, {0}};   // (TC2LI_BA_TIMING) time inside the two kinds of setup task
     void run();
     void finish_window(int s, int rc);
     void setup_task(int task);
@@ -2187,7 +2190,10 @@ void tc2li_ba_engine::setup_loop() {
             if (setup_queue.empty()) return;
             task = setup_queue.front(); setup_queue.pop_front();
         }
+        const auto t0 = std::chrono::steady_clock::now();
         setup_task(task);
+        setup_us[task & 1].fetch_add((long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+        setup_n[task & 1].fetch_add(1, std::memory_order_relaxed);
         slots[task >> 1].setup_left.fetch_sub(1, std::memory_order_release);
     }
 }
@@ -2219,6 +2225,7 @@ void tc2li_ba_engine::run() {
     }
     while ((int)C.ws.size() < cap) C.ws.emplace_back(new BaWorkspace());
     const bool kTiming = BaOptions::read().timing;
+    double lat[6] = {0}; long n_lat = 0;
     double tm[8] = {0}; long n_live_sum = 0, n_windows = 0, n_ticks = 0; const long allocs0 = g_buffer_allocs.load();
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_lap = 0;
@@ -2264,6 +2271,11 @@ void tc2li_ba_engine::run() {
                     if (w.lidar && p.lidar_stats) {
                         p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = m.hessian_evaluations;
                         p.lidar_stats->residual = m.lidar_error; p.lidar_stats->chi2 = m.lidar_error * w.lidar->information * m.lidar_error;
+                    }
+                    if (kTiming) {
+                        const EngineSlot& sl = slots[s]; const double t = now();
+                        lat[0] += sl.t_admit - sl.t_submit; lat[1] += sl.t_ready - sl.t_admit; lat[2] += sl.t_staged - sl.t_ready; lat[3] += sl.t_live - sl.t_staged;
+                        lat[4] += sl.t_retire - sl.t_live; lat[5] += t - sl.t_retire; ++n_lat;
                     }
                     finish_window(s, failed ? (int)TC2LI_ERR_HIP : m.done);
                 }
@@ -2335,7 +2347,7 @@ void tc2li_ba_engine::run() {
                 copies.push_back(CopyTask{C.d_lm.p + s, &m, sizeof(BaLmState)});
                 for (const CopyTask& t : sl.deferred_vis) copies.push_back(t);
                 sl.deferred_vis.clear();
-                sl.state = kSlotLive; sl.seq = tick;
+                sl.state = kSlotLive; sl.seq = tick; if (kTiming) sl.t_live = now();
             }
             if (!failed && !copies.empty()) {
                 if (G.h_copies_b.ensure(copies.size()) != hipSuccess) failed = 1;
@@ -2373,6 +2385,7 @@ void tc2li_ba_engine::run() {
                     const int s = best >= 0 ? best : largest;
                     for (int k = 0; k < 6; ++k) slots[s].cap[k] = std::max(slots[s].cap[k], dims[k]);
                     slots[s].ticket = t; slots[s].index = t->next++; slots[s].state = kSlotSetup; slots[s].rc_lidar = 0; slots[s].ready_tick = 0;
+                    if (kTiming) { slots[s].t_submit = t->t_submit; slots[s].t_admit = now(); slots[s].t_ready = 0; }
                     if (t->next == t->n) queue.pop_front();
                     admitted.push_back(s);
                     ++busy; --n_free_slots;
@@ -2393,12 +2406,12 @@ void tc2li_ba_engine::run() {
                 long oldest = tick;
                 for (int s = 0; s < cap; ++s)
                     if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) {
-                        if (!slots[s].ready_tick) slots[s].ready_tick = tick;
+                        if (!slots[s].ready_tick) { slots[s].ready_tick = tick; if (kTiming) slots[s].t_ready = now(); }
                         ++n_ready; n_ready_lidar += C.h_cut.p[s].n_points > 0; oldest = std::min(oldest, slots[s].ready_tick);
                     }
                 if (n_ready && (n_ready_lidar == 0 || n_ready >= stage_min || tick - oldest >= stage_wait))
                     for (int s = 0; s < cap; ++s)
-                        if (slots[s].state == kSlotSetup && slots[s].ready_tick) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; slots[s].ready_tick = 0; fresh.push_back(s); }
+                        if (slots[s].state == kSlotSetup && slots[s].ready_tick) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; slots[s].ready_tick = 0; if (kTiming) slots[s].t_staged = now(); fresh.push_back(s); }
             }
             n_in_setup = 0;
             for (int s = 0; s < cap; ++s) n_in_setup += slots[s].state == kSlotSetup;
@@ -2465,7 +2478,7 @@ void tc2li_ba_engine::run() {
                 add(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double));
                 if (p.edge_chi2) add(hc, w.ws->d_chi2.p, E * sizeof(double));
                 if (p.edge_depth_positive) add(hc + E * sizeof(double), w.ws->d_depth.p, E);
-                slots[s].state = kSlotRetiring; slots[s].seq = tick;
+                slots[s].state = kSlotRetiring; slots[s].seq = tick; if (kTiming) slots[s].t_retire = now();
             }
             if (!failed && n_tasks) { launch_copy_tasks(G.h_copies_r.p, (int)n_tasks, max_bytes, st); queued_any = true; }
         }
@@ -2503,6 +2516,10 @@ void tc2li_ba_engine::run() {
         lap(5);
         if (failed) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); if (error.empty()) error = "HIP error in the engine thread"; }
     }
+    if (kTiming && n_lat) fprintf(stderr, "BA engine window latency ms (%ld windows): queue %.3f setup %.3f wait-to-stage %.3f extraction %.3f rounds %.3f results %.3f\n",
+                                  n_lat, lat[0] / n_lat, lat[1] / n_lat, lat[2] / n_lat, lat[3] / n_lat, lat[4] / n_lat, lat[5] / n_lat);
+    if (kTiming && setup_n[0].load()) fprintf(stderr, "BA engine setup tasks: structure + staging %.3f ms each (%ld), LiDAR window %.3f ms each (%ld)\n",
+                                               1e-3 * setup_us[0].load() / setup_n[0].load(), setup_n[0].load(), 1e-3 * setup_us[1].load() / std::max(setup_n[1].load(), 1L), setup_n[1].load());
     if (kTiming && n_ticks) fprintf(stderr, "BA engine timing: %ld windows in %ld ticks (%.1f alive per tick); ms per tick: finish %.3f go-live %.3f admit+setup %.3f retire %.3f queue round %.3f wait %.3f; %ld buffer (re)allocations in the process meanwhile\n",
                                     n_windows, n_ticks, (double)n_live_sum / n_ticks, tm[0] / n_ticks, tm[1] / n_ticks, tm[2] / n_ticks, tm[3] / n_ticks, tm[4] / n_ticks, tm[5] / n_ticks, g_buffer_allocs.load() - allocs0);
     if (C.st) (void)hipStreamSynchronize(C.st);
@@ -3256,6 +3273,7 @@ int64_t tc2li_ba_engine_submit(tc2li_ba_engine* e, const tc2li_ba_problem* probl
     if (!e || n < 0 || (n > 0 && (!problems || !results))) { set_error("tc2li_ba_engine_submit: invalid argument"); return TC2LI_ERR_INVALID; }
     std::unique_ptr<EngineTicket> t(new EngineTicket());
     t->problems = problems; t->results = results; t->n = n; t->remaining = n;
+    t->t_submit = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     int64_t id;
     {
         std::lock_guard<std::mutex> lk(e->mu);
