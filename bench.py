@@ -665,16 +665,18 @@ class Loop:
             for w in range(n_workers):
                 self.ba_workers.append({n: ba_batch_of(pkg, wl, first, n) for n in set(self.ba_chunk_sizes)})
                 first += self.ba_chunk_sizes[w]
-        # From 128 sequences per GPU on the windows go through tc2li_ba_engine instead (TC2LI_BENCH_BA_ENGINE = number of engines, 0 = the batch
+        # From 512 sequences per GPU on the windows go through tc2li_ba_engine instead (TC2LI_BENCH_BA_ENGINE = number of engines, 0 = the batch
         # calls above; default 3): running lock-step queues that windows join and leave one by one.  Every sequence is a mapping thread of its
         # own there: its window is a ticket, submitted when the tracking thread has finished the keyframe's step AND the sequence's previous
         # window has come back (a LocalMapping thread runs one optimisation at a time, LocalMapping.cc:66-160); nobody waits for another
         # sequence's window.  A ring of kf_interval prebuilt batches holds the arrays (a sequence's next keyframe comes kf_interval frames
         # later), each a different stretch of the workload's window list.  Measured (round 6, varied mix, frames/s, batch calls -> 3 engines):
         # 64 sequences 12.5k -> 11.7k (a round of few windows is a chain of ten launches whatever their number: the batch calls' 64 windows per
-        # call win), 128: 13.4k -> 15.0k, 256: 15.8k -> 17.0k, 512: 17.9k -> 19.5k (16 CPUs; 17.0k -> 18.9k on 8).
+        # call win), 128: 13.4k -> 15.0k, 256: 15.8k -> 17.0k, 512: 17.9k -> 19.5k (16 CPUs; 17.0k -> 18.9k on 8).  Against the step workers
+        # below (four steps in flight, a step = one lock-step group): 128: 15.4k / 17.5k, 256: 17.8k / 19.2k, 512: 21.0k / 20.9k, 1024: 21.6k / 20.0k
+        # -- the engines from 512 sequences on, the step workers below.
         self.ba_engine, self.ba_engines, self.ba_ring = None, [], []
-        n_engines = int(os.environ.get("TC2LI_BENCH_BA_ENGINE", "3" if F >= 128 else "0"))
+        n_engines = int(os.environ.get("TC2LI_BENCH_BA_ENGINE", "3" if F >= 512 else "0"))
         if type(self) is Loop and self.ba_batch is not None and self.ba_rate == n_ba and n_engines > 0:
             self.ba_engines = [pkg.capi.BaEngine(wl.ba_windows[0]["cam"], max_windows=int(os.environ.get("TC2LI_BENCH_BA_ENGINE_SLOTS", "192")))
                                for _ in range(n_engines)]
@@ -691,6 +693,19 @@ class Loop:
             tickets = [(self.ba_engines[i % K], self.ba_engines[i % K].submit(b, i, 1)) for b in self.ba_ring for i in range(b.n)]
             for e, t in tickets:
                 e.wait(t)
+        # Below 512 sequences per GPU (TC2LI_BENCH_BA_STEP_WORKERS, default kf_interval = 4; 0: the calls of one / two / four steps' windows
+        # above): a step's windows (16 at 64 sequences) are ONE lock-step group, and up to that many steps are in flight side by side, each on
+        # a mapping worker with a group context of its own -- a sequence's next keyframe comes kf_interval frames later, so no sequence has two
+        # windows in flight.  Alone on the GPU four such groups side by side take 2.7 ms per step's windows against 6.4 for one call per step
+        # and 2.9 for one call per four steps (tools/time_ba_batch.py), and a window waits for its own group only.  In the loop (frames/s,
+        # calls of 1-4 steps' windows -> four step workers): 32 sequences 9.7k -> 11.0k, 64: 12.9k -> 14.7-15.3k.
+        self.ba_step_workers = []
+        n_step_workers = int(os.environ.get("TC2LI_BENCH_BA_STEP_WORKERS", str(args.kf_interval) if F < 512 else "0"))
+        if (type(self) is Loop and self.ba_batch is not None and self.ba_engine is None and self.ba_rate == n_ba and n_ba >= 2
+                and 2 <= n_step_workers <= 8 and F % args.kf_interval == 0):
+            self.ba_step_workers = [ba_batch_of(pkg, wl, w * n_ba, n_ba) for w in range(min(n_step_workers, args.kf_interval))]
+            self.ba_batch2 = self.ba_batch4 = None
+            self.ba_workers = []
         self.steps_tracked = 0
         self.ba_due = 0.0
         self.orb_outs = [None, None, None]
@@ -781,6 +796,8 @@ class Loop:
         """The batch whose statistics describe the windows the loop has optimised."""
         if self.ba_ring:
             return self.ba_ring[0]
+        if self.ba_step_workers:
+            return self.ba_step_workers[0]
         if not self.ba_workers:
             return self.ba_batch
         ran = [b for w in self.ba_workers for b in w.values() if b.stats[0].iterations > 0]  # (a worker may not have met every chunk size)
@@ -788,7 +805,7 @@ class Loop:
 
     def ba_run_batches(self):
         """Every BaBatch of the loop that has run at least once."""
-        all_b = [self.ba_batch, self.ba_batch2, self.ba_batch4] + [b for w in self.ba_workers for b in w.values()] + list(self.ba_ring)
+        all_b = [self.ba_batch, self.ba_batch2, self.ba_batch4] + [b for w in self.ba_workers for b in w.values()] + list(self.ba_ring) + list(self.ba_step_workers)
         return [b for b in all_b if b is not None and any(b.stats[i].iterations > 0 or b.results[i] > 0 for i in range(b.n))]
 
     def ba_mix_summary(self, wl):
@@ -1011,6 +1028,25 @@ class Loop:
             fn.__name__ = "ba_worker%d_thread" % w
             return fn
 
+        def make_ba_step_worker(w):
+            def fn():
+                follows_tracking = "track" in set(stages)
+                while not failed.is_set():
+                    with ba_lock:
+                        j = ba_jobs["next"]
+                        ba_jobs["next"] += 1
+                    if j >= n_steps:
+                        return
+                    while follows_tracking and self.steps_tracked <= j and not failed.is_set():
+                        time.sleep(0.0002)
+                    b = self.ba_step_workers[w]
+                    if b.run_group(w) != b.n:
+                        raise RuntimeError("a local BA window failed")
+                    with ba_lock:
+                        self.ba_windows_done += b.n
+            fn.__name__ = "ba_worker%d_thread" % w
+            return fn
+
         want = set(stages)
         if "track" in want:
             want.add("orb")  # tracking consumes what the extraction produces
@@ -1020,6 +1056,8 @@ class Loop:
             fns = [f for f in fns if f is not ba_thread]
         elif self.ba_engine is not None and ba_thread in fns:
             fns = [f for f in fns if f is not ba_thread] + [ba_engine_thread]
+        elif self.ba_step_workers and ba_thread in fns:
+            fns = [f for f in fns if f is not ba_thread] + [make_ba_step_worker(w) for w in range(len(self.ba_step_workers))]
         elif self.ba_workers and ba_thread in fns:
             fns = [f for f in fns if f is not ba_thread] + [make_ba_worker(w) for w in range(len(self.ba_workers))]
         if "track" not in want and "orb" in want:  # nobody returns the feature buffers: the extraction thread recycles them itself
@@ -1046,7 +1084,7 @@ class Loop:
             d.wait()
         if errors:
             raise errors[0]
-        if self.ba_workers and any(k.startswith("ba_worker") for k in self.thread_ms):
+        if (self.ba_workers or self.ba_step_workers) and any(k.startswith("ba_worker") for k in self.thread_ms):
             self.thread_ms["ba_thread"] = max(v for k, v in self.thread_ms.items() if k.startswith("ba_worker"))  # local mapping is done when its last worker is
 
     def close(self):
@@ -1798,6 +1836,9 @@ def main(argv=None):
     host_budget["cgroup_cpu_quota"] = cgroup_cpu_quota()
     if loop.ba_engine is not None:
         host_budget["ba_engines"] = len(loop.ba_engines)
+    if loop.ba_step_workers:
+        host_budget["mapping_workers"] = len(loop.ba_step_workers)
+        host_budget["stage_threads"] = 4 + len(loop.ba_step_workers)
     if loop.ba_workers:  # local mapping as a pool of mapping workers: that many stage threads instead of one, each driving its lock-step group itself
         host_budget["mapping_workers"] = len(loop.ba_workers)
         host_budget["stage_threads"] = 4 + len(loop.ba_workers)
@@ -2094,6 +2135,9 @@ def main(argv=None):
                                  ("; local mapping = %d bundle-adjustment engines (tc2li_ba_engine: running lock-step queues), every sequence a ticket stream of its "
                                   "own: a window is submitted when its keyframe's step has been tracked and the sequence's previous window has come back" % len(loop.ba_engines)
                                   if loop.ba_engine is not None else "") +
+                                 ("; local mapping = %d mapping workers, each taking the next tracked step's windows as ONE lock-step group "
+                                  "(tc2li_local_bundle_adjustment_batch_group): up to that many steps in flight, no sequence with two windows in flight" % len(loop.ba_step_workers)
+                                  if loop.ba_step_workers else "") +
                                  ("; local mapping = %d mapping workers, each a lock-step group of its own (tc2li_local_bundle_adjustment_batch_group), taking the steps' "
                                   "windows chunk by chunk (%s windows)" % (len(loop.ba_workers), "/".join(str(n) for n in loop.ba_chunk_sizes)) if loop.ba_workers else ""),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
