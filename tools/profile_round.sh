@@ -30,10 +30,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_i -o bench --
 # instruction mix and LDS behaviour of every kernel (the bound of k_fast_cells is stated from these): own passes, SQ counters only
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/pmc_insts -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_insts.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- python3 $ARGS --no-extra-lines > $OUT/bench_lds.log 2>&1
+# round 6: the small-batch regime and the extraction alone, kernel trace + stats each
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_64 -o bench -- python3 bench.py --no-build --no-cpu-baseline --no-extra-lines --sequences 64 --steps 40 --warmup 8 > $OUT/bench_trace_64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_orb -o bench -- python3 bench.py --no-build --no-cpu-baseline --no-extra-lines --front-end-only --stages orb --steps 12 --warmup 3 > $OUT/bench_trace_orb.log 2>&1
 # every pass must have left through a normal exit: no abort hidden behind the profiler's signal handler
 if grep -l "signal 6\|terminate called\|Memory access fault" $OUT/*.log; then echo "profile_round: a profiled process died (see the logs above)"; exit 1; fi
 python tools/summarize_profile.py $OUT $TAG
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 # keep the merge small: the raw traces stay on the box
-rm -rf $OUT/trace $OUT/trace_i $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds $OUT/pmc_fetch_i $OUT/pmc_write_i
+rm -rf $OUT/trace $OUT/trace_i $OUT/trace_64 $OUT/trace_orb $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/pmc_insts $OUT/pmc_lds $OUT/pmc_fetch_i $OUT/pmc_write_i

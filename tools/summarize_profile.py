@@ -16,6 +16,10 @@ if stats:
 stats_i = glob.glob(os.path.join(out, "trace_i", "**", "*kernel_stats.csv"), recursive=True)
 if stats_i:
     shutil.copy(stats_i[0], "profiles/%s_inertial_kernel_stats.csv" % tag)
+for sub, name in (("trace_64", "seq64_kernel_stats.csv"), ("trace_orb", "alone_orb_kernel_stats.csv")):
+    st = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], "profiles/%s_%s" % (tag, name))
 line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")]
 if line:
     open("profiles/%s_bench_line_under_rocprof.json" % tag, "w").write(line[-1])
