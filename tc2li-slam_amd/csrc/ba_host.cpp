@@ -951,7 +951,10 @@ struct InertialTerm {
     std::vector<uint32_t> seg_at;
     std::vector<uint8_t> seg_len;
     bool segs_ready = false;
-    void note_segment(size_t at, int len) { if (!segs_ready) { seg_at.push_back((uint32_t)at); seg_len.push_back((uint8_t)len); } }
+    void note_segment(size_t at, int len) {  // (a length is a byte: longer runs are recorded in pieces)
+        if (segs_ready) return;
+        for (; len > 0; at += 255, len -= 255) { seg_at.push_back((uint32_t)at); seg_len.push_back((uint8_t)std::min(len, 255)); }
+    }
     void note_block(int row0, int col0, int rows, int cols) { for (int r = 0; r < rows; ++r) note_segment((size_t)(row0 + r) * n + col0, cols); }
     double d_imu = 0;
     float dsqr_imu = 0;
@@ -999,8 +1002,13 @@ struct InertialTerm {
         const std::vector<int>& pv = *pose_var;
         double chi = 0;
         if (linearize) {
-            if (segs_ready) { for (size_t k = 0; k < seg_at.size(); ++k) std::fill_n(Hi.data() + seg_at[k], seg_len[k], 0.0); }
-            else std::fill(Hi.begin(), Hi.end(), 0.0);
+            if (segs_ready) {
+                for (size_t k = 0; k < seg_at.size(); ++k) std::fill_n(Hi.data() + seg_at[k], seg_len[k], 0.0);
+                // TC2LI_TEST_HI_CLEAR (tests): every writer of Hi must have registered its blocks during the first linearisation -- after the
+                // segment-wise clear the matrix has to be zero everywhere, or a term added later is accumulating stale entries
+                static const bool kCheck = getenv("TC2LI_TEST_HI_CLEAR") != nullptr;
+                if (kCheck) for (double v : Hi) if (v != 0.0) { fprintf(stderr, "tc2li: InertialTerm: Hi holds an entry outside the registered segments\n"); abort(); }
+            } else std::fill(Hi.begin(), Hi.end(), 0.0);
             std::fill(bi.begin(), bi.end(), 0.0);
         }
         for (const InertialLinkHost& lk_ : L) {
@@ -2036,15 +2044,17 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
 // which call a window came with or how far it has got: every batched kernel runs for the windows whose status asks for it.  The engine keeps
 // ONE stream of rounds going and lets windows in and out at the round boundaries:
 //   submit    hands over windows (a ticket); they wait in a queue
-//   tick      (engine thread) windows whose result copies have landed are finished and their slots freed; windows staged two ticks ago
-//             (their plane extraction has run) get their table entry and state and become LIVE; new windows from the queue are set up on
-//             the pool (graph structure, staging, plane extraction queued); windows the last mirror shows as done are RETIRED (depth flags,
-//             result copies queued); then the next round is queued for everything alive, and the tick waits for the round BEFORE it --
-//             one round is always in flight while the host works
-//   wait      blocks until a ticket's windows have all been finished
-// At 64 sequences per GPU (what 8-way strong scaling leaves a rank) a step brings 16 windows; a call's three groups of 5-6 took 4-5 ms
-// beside the front end's 3.7 ms -- the step waited for local mapping.  In the engine those windows join the ~20 that are alive, leave ten
-// rounds later, and nobody waits for a straggler.  Same kernels, same per-window arithmetic: a window's bits are those of the batch calls.
+//   tick      (engine thread) windows whose result copies have landed are finished and their slots freed; windows whose plane extraction
+//             has run get their table entry and state and are LIVE from this round on; new windows from the queue go to free slots (best
+//             fit: the work space that has held the smallest window at least as large) and are set up on the SETUP THREADS beside the rounds;
+//             windows whose setup is done are staged a few at a time (clouds up, plane extraction queued); windows the last mirror shows
+//             as done are RETIRED (depth flags, result copies queued); then the next round is queued for everything alive, and the tick
+//             waits for the round BEFORE it -- one round is always in flight while the host works
+//   wait      blocks until a ticket's windows have all been finished (poll: without blocking)
+// Same kernels, same per-window arithmetic: a window's bits are those of the batch calls (tests/test_balm_gpu.py).  Work spaces grow
+// through a per-engine BufferCache (common.hpp): hipFree would wait for the whole device every time a slot meets a larger window.
+// Measured against the alternatives in DESIGN.md section 4, round 6 item 5: the engines are the best form of local mapping from 512 sequences
+// per GPU on; below that four mapping workers that each take a whole step's windows as one group call are ahead.
 enum { kSlotFree = 0, kSlotStaged = 1, kSlotLive = 2, kSlotRetiring = 3, kSlotSetup = 4 };
 struct EngineTicket {
     double t_submit = 0;
@@ -2243,7 +2253,7 @@ void tc2li_ba_engine::run() {
         EngineStaging& G = S[tick & 1];
         bool queued_any = false;
         int n_in_setup = 0, n_waiting_side = 0;
-        // ---- 1. windows whose result copies have landed (queued two ticks ago, that tick's round has been waited for) ----
+        // ---- 1. windows whose result copies have landed (the event of the tick that queued them has been waited for) ----
         {
             std::vector<int> done;
             for (int s = 0; s < cap; ++s) if (slots[s].state == kSlotRetiring && slots[s].seq <= waited) done.push_back(s);
@@ -2296,7 +2306,7 @@ void tc2li_ba_engine::run() {
             }
             continue;
         }
-        // ---- 2. windows staged two ticks ago: their planes are back; table entry, state, uploads; alive from this tick's round on ----
+        // ---- 2. staged windows whose plane extraction has run: table entry, state, uploads; alive from this tick's round on ----
         {
             std::vector<CopyTask> copies;
             size_t max_bytes = 0;

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # Build BEFORE any rocprofv3 line: under the profiler's preload a child process (make -> sh -> hipcc) would be an exec from a process
 # that has initialised the GPU.  bench.py --no-build then fails instead of building, and the command after `--` stays one interpreter.
 python __graft_entry__.py
-ARGS="bench.py --no-build --no-cpu-baseline --steps 8 --warmup 2 $*"
+ARGS="bench.py --no-build --no-cpu-baseline --steps 24 --warmup 4 $*"
 # --no-extra-lines: the process then runs the default workload only (warm-up, timed steps, the instrumented pass), so the CSV's per-kernel
 # averages are averages over the same loop the line's roofline is measured in
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $ARGS --no-extra-lines --with-roofline > $OUT/bench_trace.log 2>&1
