@@ -665,8 +665,9 @@ class Loop:
             for w in range(n_workers):
                 self.ba_workers.append({n: ba_batch_of(pkg, wl, first, n) for n in set(self.ba_chunk_sizes)})
                 first += self.ba_chunk_sizes[w]
-        # From 512 sequences per GPU on the windows go through tc2li_ba_engine instead (TC2LI_BENCH_BA_ENGINE = number of engines, 0 = the batch
-        # calls above; default 3): running lock-step queues that windows join and leave one by one.  Every sequence is a mapping thread of its
+        # Beyond 512 sequences per GPU the windows go through tc2li_ba_engine instead (TC2LI_BENCH_BA_ENGINE = number of engines, 0 = the batch
+        # calls above; default 3 there, 0 up to 512 -- at 512 the two forms measure the same and the step workers' launches are the same from
+        # run to run, which the roofline check against the profiler's averages needs): running lock-step queues that windows join and leave one by one.  Every sequence is a mapping thread of its
         # own there: its window is a ticket, submitted when the tracking thread has finished the keyframe's step AND the sequence's previous
         # window has come back (a LocalMapping thread runs one optimisation at a time, LocalMapping.cc:66-160); nobody waits for another
         # sequence's window.  A ring of kf_interval prebuilt batches holds the arrays (a sequence's next keyframe comes kf_interval frames
@@ -674,9 +675,9 @@ class Loop:
         # 64 sequences 12.5k -> 11.7k (a round of few windows is a chain of ten launches whatever their number: the batch calls' 64 windows per
         # call win), 128: 13.4k -> 15.0k, 256: 15.8k -> 17.0k, 512: 17.9k -> 19.5k (16 CPUs; 17.0k -> 18.9k on 8).  Against the step workers
         # below (four steps in flight, a step = one lock-step group): 128: 15.4k / 17.5k, 256: 17.8k / 19.2k, 512: 21.0k / 20.9k, 1024: 21.6k / 20.0k
-        # -- the engines from 512 sequences on, the step workers below.
+        # -- the engines beyond 512 sequences, the step workers up to there.
         self.ba_engine, self.ba_engines, self.ba_ring = None, [], []
-        n_engines = int(os.environ.get("TC2LI_BENCH_BA_ENGINE", "3" if F >= 512 else "0"))
+        n_engines = int(os.environ.get("TC2LI_BENCH_BA_ENGINE", "3" if F > 512 else "0"))
         if type(self) is Loop and self.ba_batch is not None and self.ba_rate == n_ba and n_engines > 0:
             self.ba_engines = [pkg.capi.BaEngine(wl.ba_windows[0]["cam"], max_windows=int(os.environ.get("TC2LI_BENCH_BA_ENGINE_SLOTS", "192")))
                                for _ in range(n_engines)]
@@ -693,14 +694,14 @@ class Loop:
             tickets = [(self.ba_engines[i % K], self.ba_engines[i % K].submit(b, i, 1)) for b in self.ba_ring for i in range(b.n)]
             for e, t in tickets:
                 e.wait(t)
-        # Below 512 sequences per GPU (TC2LI_BENCH_BA_STEP_WORKERS, default kf_interval = 4; 0: the calls of one / two / four steps' windows
+        # Up to 512 sequences per GPU (TC2LI_BENCH_BA_STEP_WORKERS, default kf_interval = 4; 0: the calls of one / two / four steps' windows
         # above): a step's windows (16 at 64 sequences) are ONE lock-step group, and up to that many steps are in flight side by side, each on
         # a mapping worker with a group context of its own -- a sequence's next keyframe comes kf_interval frames later, so no sequence has two
         # windows in flight.  Alone on the GPU four such groups side by side take 2.7 ms per step's windows against 6.4 for one call per step
         # and 2.9 for one call per four steps (tools/time_ba_batch.py), and a window waits for its own group only.  In the loop (frames/s,
         # calls of 1-4 steps' windows -> four step workers): 32 sequences 9.7k -> 11.0k, 64: 12.9k -> 14.7-15.3k.
         self.ba_step_workers = []
-        n_step_workers = int(os.environ.get("TC2LI_BENCH_BA_STEP_WORKERS", str(args.kf_interval) if F < 512 else "0"))
+        n_step_workers = int(os.environ.get("TC2LI_BENCH_BA_STEP_WORKERS", str(args.kf_interval) if F <= 512 else "0"))
         if (type(self) is Loop and self.ba_batch is not None and self.ba_engine is None and self.ba_rate == n_ba and n_ba >= 2
                 and 2 <= n_step_workers <= 8 and F % args.kf_interval == 0):
             self.ba_step_workers = [ba_batch_of(pkg, wl, w * n_ba, n_ba) for w in range(min(n_step_workers, args.kf_interval))]
