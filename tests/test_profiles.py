@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = "r05"
+ROUND = "r06"
 
 
 def test_round_profiles_are_committed_and_stamped():
