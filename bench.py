@@ -44,7 +44,10 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--sequences", type=int, default=512, help="strong scaling: sequences of the whole job, dealt over the ranks")
     ap.add_argument("--frames", type=int, default=64, help="weak scaling: sequences (one frame each per step) per GPU")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames rendered (tiled over the sequences)")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic scenes rendered (tiled over the sequences)")
+    ap.add_argument("--cycle-frames", type=int, default=4, help="frames rendered along every scene's drive (1 m apart, camera and LiDAR); step j of the timed loop "
+                    "processes frame j %% this many of every sequence, so that images, scans, tracking inputs and map insertions differ from step to step (1: the same "
+                    "frame every step, rounds 1-5)")
     ap.add_argument("--kf-interval", type=int, default=4, help="a keyframe (one local BA window) every k-th frame")
     ap.add_argument("--ba-concurrency", type=int, default=8, help="local-BA windows in flight (streams) per GPU")
     ap.add_argument("--ba-mix", choices=("varied", "uniform"), default="varied", help="the local-BA windows of the timed loop: 64 distinct windows "
@@ -134,7 +137,7 @@ def single_sequence_child(args, extra=(), what="the same loop with 1 sequence pe
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                                                             "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
     env.update(GPU_MAX_HW_QUEUES=os.environ.get("TC2LI_BENCH_SINGLE_HW_QUEUES", "24"), TC2LI_NO_BUILD="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", "1", "--unique", "1", "--steps", "200", "--warmup", "300", "--no-cpu-baseline",
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", "1", "--unique", "1", "--cycle-frames", str(args.cycle_frames), "--steps", "200", "--warmup", "300", "--no-cpu-baseline",
            "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval), "--ba-concurrency", str(args.ba_concurrency)]
     if args.front_end_only:
         cmd.append("--front-end-only")
@@ -164,7 +167,7 @@ def sweep_children(args):
         if n_seq == args.sequences or (n_seq > args.sequences and n_seq != 2 * args.sequences) or n_seq > 1024:
             continue
         steps = max(10, min(40, 5120 // n_seq))
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", str(n_seq), "--unique", str(args.unique), "--steps", str(steps), "--warmup", "8",
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", str(n_seq), "--unique", str(args.unique), "--cycle-frames", str(args.cycle_frames), "--steps", str(steps), "--warmup", "8",
                "--no-cpu-baseline", "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval), "--ba-concurrency", str(args.ba_concurrency),
                "--map-length", str(args.map_length)]
         if args.front_end_only:
@@ -193,7 +196,7 @@ def host_budget_children(args):
         if n >= effective_cpus() or n > len(cpus):
             continue
         cmd = ["taskset", "-c", ",".join(str(c) for c in cpus[:n]), sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sequences", str(args.sequences),
-               "--unique", str(args.unique), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval),
+               "--unique", str(args.unique), "--cycle-frames", str(args.cycle_frames), "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-extra-lines", "--no-build", "--kf-interval", str(args.kf_interval),
                "--ba-concurrency", str(args.ba_concurrency), "--map-length", str(args.map_length)]
         try:
             txt = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True).stdout.decode()
@@ -435,26 +438,35 @@ def uniform_ba_windows(pkg, synthetic):
     return out
 
 
+class FrameInputs:
+    """What one frame index holds for all the unique scenes: stereo images [U, 2, H, W], raw scans, LiDAR states, and (after
+    Workload.build_tracking_inputs) the last frame and local map of every scene."""
+    def __init__(self, index):
+        self.index, self.images, self.scans, self.states, self.last, self.local = index, None, [], [], None, None
+
+
 class Workload:
     """The synthetic inputs of `unique` distinct sequences: stereo pair, 64-beam scan, the street's accumulated
     LiDAR map, the last frame TrackWithMotionModel projects from and the local map TrackLocalMap searches; sequence s uses set s % unique."""
 
-    def __init__(self, pkg, synthetic, unique, map_length, with_ba):
+    def __init__(self, pkg, synthetic, unique, map_length, with_ba, cycle=1):
         self.pkg, self.synthetic, self.U = pkg, synthetic, unique
+        self.K = max(1, int(cycle))
         W, H = synthetic.WIDTH, synthetic.HEIGHT
         self.W, self.H = W, H
         self.bf = np.float32(synthetic.BF)
         self.b = np.float32(self.bf / np.float32(synthetic.FX))
         self.cam5 = np.float32([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY, self.bf]).astype(np.float64)
-        self.images = np.empty((unique, 2, H, W), np.uint8)
-        self.scans, self.states, self.maps = [], [], []
+        # frame f of scene u: the camera f metres down the street (Scene.render's cam_z), the LiDAR at sensor_pose(u + 1 + f) (1 m per frame);
+        # frames[0] is what rounds 1-5 processed every step.  The rendered frames are kept in /tmp for the child processes of one bench run.
+        self.frames = self._render_frames(synthetic, unique, self.K, W, H)
+        self.images, self.scans = self.frames[0].images, self.frames[0].scans
+        self.maps = []
+        for fr in self.frames:
+            fr.states = [pkg.pack_lidar_state(*synthetic.lidar_state(u + 1 + fr.index)[:2]) for u in range(unique)]
+        self.states = self.frames[0].states
         for u in range(unique):
-            sc = synthetic.Scene(u)
-            self.images[u, 0], _ = sc.render(0.0, W, H, noise_seed=1)
-            self.images[u, 1], _ = sc.render(synthetic.BASELINE, W, H, noise_seed=2)
-            self.scans.append(synthetic.lidar_scan(sc, u + 1))
-            self.states.append(pkg.pack_lidar_state(*synthetic.lidar_state(u + 1)[:2]))
-            self.maps.append(synthetic.lidar_map(sc, x_from=-0.7 * map_length, x_to=0.3 * map_length))
+            self.maps.append(synthetic.lidar_map(synthetic.Scene(u), x_from=-0.7 * map_length, x_to=0.3 * map_length))
         self.ba_windows = []
         self.ba_mix = "none"
         if with_ba and with_ba != "uniform":
@@ -474,21 +486,65 @@ class Workload:
         self.last = None   # per unique: the last frame of TrackWithMotionModel
         self.local = None  # per unique: (held, held_Xw, local map points)
 
+    @staticmethod
+    def _render_frames(synthetic, unique, K, W, H):
+        import hashlib
+        import tempfile
+        gen = hashlib.sha256(open(synthetic.__file__, "rb").read()).hexdigest()[:12]   # (the cache belongs to this generator)
+        cache = os.path.join(tempfile.gettempdir(), "tc2li_bench_frames_%s_U%d_K%d_%dx%d.npz" % (gen, unique, K, W, H))
+        frames = [FrameInputs(f) for f in range(K)]
+        try:
+            z = np.load(cache)
+            images, scan_offs = z["images"], z["scan_offs"]
+            for fr in frames:
+                fr.images = images[fr.index]
+                offs, pts = scan_offs[fr.index], z["scans_%d" % fr.index]
+                fr.scans = [pts[offs[u]:offs[u + 1]] for u in range(unique)]
+            return frames
+        except Exception:  # noqa: BLE001  (no cache yet, or one of another shape: render)
+            pass
+        for fr in frames:
+            f = fr.index
+            fr.images = np.empty((unique, 2, H, W), np.uint8)
+            for u in range(unique):
+                sc = synthetic.Scene(u)
+                fr.images[u, 0], _ = sc.render(0.0, W, H, noise_seed=1 + 2 * f, cam_z=float(f))
+                fr.images[u, 1], _ = sc.render(synthetic.BASELINE, W, H, noise_seed=2 + 2 * f, cam_z=float(f))
+                fr.scans.append(synthetic.lidar_scan(sc, u + 1 + f))
+        try:
+            tmp = cache + ".%d.tmp.npz" % os.getpid()
+            np.savez(tmp, images=np.stack([fr.images for fr in frames]),
+                     scan_offs=np.stack([np.concatenate([[0], np.cumsum([len(x) for x in fr.scans])]) for fr in frames]),
+                     **{"scans_%d" % fr.index: np.concatenate(fr.scans) for fr in frames})
+            os.replace(tmp, cache)
+        except Exception:  # noqa: BLE001
+            pass
+        return frames
+
     def build_tracking_inputs(self, ext, stream):
-        """One extraction + stereo matching of the unique frames gives the 3-D points the tracking inputs are made of: the 'last frame' of
+        """The tracking inputs of every frame index (frames[f].last / .local); .last / .local of the workload are frame 0's."""
+        orb0 = None
+        for fr in self.frames:
+            orb = self._tracking_inputs_of(fr, ext, stream)
+            orb0 = orb if orb0 is None else orb0
+        self.last, self.local = self.frames[0].last, self.frames[0].local
+        return orb0
+
+    def _tracking_inputs_of(self, fr, ext, stream):
+        """One extraction + stereo matching of the unique scenes' frame `fr` gives the 3-D points the tracking inputs are made of: the 'last frame' of
         every sequence = the frame's own stereo points seen from the previous pose (descriptors drifted, 3 % outliers); the local map =
         the frame's stereo points that the motion-model step does not hold, plus as many again that project outside the image or carry
         foreign descriptors (what UpdateLocalMap hands to SearchLocalPoints: a few thousand points, about half of them in the frustum)."""
         pkg, U, W, H = self.pkg, self.U, self.W, self.H
         import torch
-        dev = torch.from_numpy(self.images.reshape(2 * U, H, W)).cuda()
+        dev = torch.from_numpy(np.ascontiguousarray(fr.images).reshape(2 * U, H, W)).cuda()
         orb = ext.extract_batch_dev(dev.data_ptr(), 2 * U, W, H, W, W * H, stream=stream)
         st = pkg.stereo_match_batch(ext, U, float(self.bf), float(self.b), stream=stream)
         fx, fy, cx, cy = [np.float32(v) for v in self.cam5[:4]]
         sf = ext.GetScaleFactors()
-        self.last, lasts = [], []
+        last, lasts = [], []
         for u in range(U):
-            rng = np.random.default_rng(7000 + u)
+            rng = np.random.default_rng(7000 + u + 100 * fr.index)
             n = int(orb[2][2 * u])
             kl, dl, z = orb[0][2 * u, :n].copy(), orb[1][2 * u, :n].copy(), st[1][u, :n].copy()
             order = rng.permutation(n)
@@ -501,16 +557,16 @@ class Workload:
             for k in range(12):  # descriptor drift between consecutive frames
                 rows = rng.random(n) < 0.7
                 md[rows, flips[rows, k] // 8] ^= (np.uint8(1) << (flips[rows, k] % 8).astype(np.uint8))
-            self.last.append(dict(has_point=(z[order] > 0).astype(np.uint8), outlier=(rng.random(n) < 0.03).astype(np.uint8), Xw=Xw, keys=lk,
+            last.append(dict(has_point=(z[order] > 0).astype(np.uint8), outlier=(rng.random(n) < 0.03).astype(np.uint8), Xw=Xw, keys=lk,
                                   descriptors=md, pose7=np.array([0, 0, 0, 1, 0, 0, 0], np.float32)))
         # what the motion-model step leaves on the frame decides which keypoints hold a point when TrackLocalMap starts
-        packed = pkg.capi.pack_last_frames(self.last)
+        packed = pkg.capi.pack_last_frames(last)
         trk = pkg.capi.track_motion_model_batch(ext, U, orb[0], st[0], packed, np.tile(self.pose_pred, (U, 1)), self.cam5, float(self.b), 7.0,
                                                 stream=stream)
-        self.local = []
+        local = []
         cap = orb[0].shape[1]
         for u in range(U):
-            rng = np.random.default_rng(9000 + u)
+            rng = np.random.default_rng(9000 + u + 100 * fr.index)
             n = int(orb[2][2 * u])
             k, d, z = orb[0][2 * u, :n], orb[1][2 * u, :n], st[1][u, :n]
             ok = z > 0
@@ -519,7 +575,7 @@ class Workload:
             mp = trk[1][u, :n]
             held = np.where(mp >= 0, 1, 0).astype(np.uint8)
             held_Xw = np.zeros((cap, 3), np.float32)
-            held_Xw[:n][mp >= 0] = self.last[u]["Xw"][mp[mp >= 0]]
+            held_Xw[:n][mp >= 0] = last[u]["Xw"][mp[mp >= 0]]
             loc = np.nonzero(ok & (held == 0))[0]
             loc = loc[rng.permutation(len(loc))]
             n_extra = len(loc) + 1500
@@ -542,9 +598,11 @@ class Workload:
             pts = pts[rng.permutation(len(pts))]
             hfull = np.zeros(cap, np.uint8)
             hfull[:n] = held
-            self.local.append((hfull, held_Xw, pts))
-        self.keypoints_per_image = float(np.mean(orb[2]))
-        self.stereo_matches = float(np.mean((st[1] > 0).sum(1)))
+            local.append((hfull, held_Xw, pts))
+        fr.last, fr.local = last, local
+        if fr.index == 0:
+            self.keypoints_per_image = float(np.mean(orb[2]))
+            self.stereo_matches = float(np.mean((st[1] > 0).sum(1)))
         return orb
 
 
@@ -615,7 +673,7 @@ class Loop:
         # three feature buffers: extraction of batch k+2, motion-model tracking of batch k+1 and local-map tracking of batch k overlap
         self.exts = [pkg.OrbExtractor(max_width=W, max_height=H, max_images=self.n_img) for _ in range(3)]
         self.track2_stream = torch.cuda.Stream()
-        self.lidar_cap = int(max(len(s) for s in wl.scans))
+        self.lidar_cap = int(max(len(x) for fr in wl.frames for x in fr.scans))
         self.lidar_handles = None  # configs[3]: [self.lidar, a second handle] once the scans are prepared a step ahead (InertialLoop.lidar_prepare)
         self.lidar = pkg.LidarFrontEnd(max_points_per_scan=self.lidar_cap, max_scans=F)
         self.maps = []
@@ -633,6 +691,24 @@ class Loop:
         self.held_Xw = np.stack([wl.local[t][1] for t in tile])
         self.local_pts = np.concatenate([wl.local[t][2] for t in tile])
         self.local_off = np.concatenate([[0], np.cumsum([len(wl.local[t][2]) for t in tile])]).astype(np.int32)
+        # The frames the timed loop cycles through (--cycle-frames): step j processes frame j % K of every sequence -- other
+        # images, another scan from a metre further on, that frame's own last frame and local map.  frame_sets[0] is None: frame 0 lives in the
+        # attributes above, which everything that does not cycle (the inertial loop, the host-fed leg, the roofline's counts) keeps reading.
+        from types import SimpleNamespace
+        self.frame_sets = [None]
+        self.step_base = 0
+        self.buf_frame = [0, 0, 0]   # the frame index a feature buffer was extracted from
+        for fr in (wl.frames[1:] if type(self) is Loop else []):
+            raw_f = np.concatenate([fr.scans[t] for t in tile])
+            self.frame_sets.append(SimpleNamespace(
+                dev_img=torch.from_numpy(np.ascontiguousarray(fr.images[tile]).reshape(2 * F, H, W)).cuda(),
+                dev_raw=torch.from_numpy(raw_f.view(np.uint8)).cuda(),
+                raw_offs=np.concatenate([[0], np.cumsum([len(fr.scans[t]) for t in tile])]).astype(np.int32),
+                states=np.stack([fr.states[t] for t in tile]),
+                last_frames=pkg.capi.pack_last_frames([fr.last[t] for t in tile]),
+                held=np.stack([fr.local[t][0] for t in tile]), held_Xw=np.stack([fr.local[t][1] for t in tile]),
+                local_pts=np.concatenate([fr.local[t][2] for t in tile]),
+                local_off=np.concatenate([[0], np.cumsum([len(fr.local[t][2]) for t in tile])]).astype(np.int32)))
         # local mapping: F / kf_interval windows per step (a fraction of a window per step when F < kf_interval)
         self.ba_rate = 0.0 if (args.front_end_only or not wl.ba_windows) else F / args.kf_interval
         n_ba = int(np.ceil(self.ba_rate)) if self.ba_rate else 0
@@ -752,9 +828,14 @@ class Loop:
         return ev
 
     # -- stages ------------------------------------------------------------------------------------------------------------
-    def extract(self, k, stream, img=None):
+    def frame_set(self, f):
+        """The inputs of frame index f: the attributes of the loop itself for frame 0, a namespace with the same names otherwise."""
+        return self if not f else self.frame_sets[f]
+
+    def extract(self, k, stream, img=None, f=0):
         W, H = self.wl.W, self.wl.H
-        img = self.dev_img if img is None else img
+        img = self.frame_set(f).dev_img if img is None else img
+        self.buf_frame[k] = f
         self.orb_outs[k] = self.exts[k].extract_batch_dev(img.data_ptr(), self.n_img, W, H, W, W * H, stream=stream, out=self.orb_outs[k])
 
     def track(self, k, stream):
@@ -763,7 +844,7 @@ class Loop:
         t0 = time.perf_counter()
         self.st_outs[k] = pkg.stereo_match_batch(self.exts[k], F, float(wl.bf), float(wl.b), stream=stream, out=self.st_outs[k])
         t1 = time.perf_counter()
-        self.trk_outs[k] = pkg.capi.track_motion_model_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.last_frames, self.pose_pred, wl.cam5,
+        self.trk_outs[k] = pkg.capi.track_motion_model_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.frame_set(self.buf_frame[k]).last_frames, self.pose_pred, wl.cam5,
                                                              float(wl.b), 7.0, stream=stream, out=self.trk_outs[k])
         self.track_ms[0], self.track_ms[1] = 1e3 * (t1 - t0), 1e3 * (time.perf_counter() - t1)
 
@@ -771,32 +852,34 @@ class Loop:
         """TrackLocalMap of feature buffer k, from the pose the motion-model step left on the frame (Tracking.cc:2038 -> :2218)."""
         wl, pkg, F = self.wl, self.pkg, self.F
         t0 = time.perf_counter()
+        fs = self.frame_set(self.buf_frame[k])
         self.tlm_outs[k] = pkg.capi.track_local_map_batch(self.exts[k], F, self.orb_outs[k][0], self.st_outs[k][0], self.trk_outs[k][0].astype(np.float32),
-                                                          self.held, self.held_Xw, self.local_pts, self.local_off, wl.cam5, th=1.0, stream=stream,
+                                                          fs.held, fs.held_Xw, fs.local_pts, fs.local_off, wl.cam5, th=1.0, stream=stream,
                                                           out=self.tlm_outs[k])
         self.tlm_out = self.tlm_outs[k]
         self.track_ms[2] = 1e3 * (time.perf_counter() - t0)
 
-    def fov_positions(self):
+    def fov_positions(self, f=0):
         """the LiDAR positions lasermap_fov_segment looks at, [F, 3]"""
-        return np.ascontiguousarray(self.states[:, 9:12])
+        return np.ascontiguousarray(self.frame_set(f).states[:, 9:12])
 
-    def lidar_step(self, raw=None):
+    def lidar_step(self, raw=None, f=0):
         pkg, F = self.pkg, self.F
-        raw = self.dev_raw if raw is None else raw
+        fs = self.frame_set(f)
+        raw = fs.dev_raw if raw is None else raw
         # lasermap_fov_segment (host logic) + the box deletions it asks for, per sequence
         # (one call for all sequences: 512 calls through ctypes were 2.5 ms of interpreter time per step on the stage thread, more under the
         # other stage threads' contention for the interpreter lock)
-        boxes_all, n_boxes = pkg.capi.lidar_fov_segment_batch(self.boxes, self.fov_positions(), cube_len=1000.0, det_range=100.0)
+        boxes_all, n_boxes = pkg.capi.lidar_fov_segment_batch(self.boxes, self.fov_positions(f), cube_len=1000.0, det_range=100.0)
         todo = np.nonzero(n_boxes)[0]
         todo_maps, todo_boxes = [self.maps[s] for s in todo], [boxes_all[s, :n_boxes[s]].copy() for s in todo]
         if todo_maps:
             pkg.capi.delete_point_boxes_batch(todo_maps, todo_boxes, stream=self.lidar_stream.cuda_stream)
-        self.lidar_counts = self.lidar.frontend_batch(raw.data_ptr(), self.raw_offs, self.maps, self.states, stream=self.lidar_stream.cuda_stream,
+        self.lidar_counts = self.lidar.frontend_batch(raw.data_ptr(), fs.raw_offs, self.maps, fs.states, stream=self.lidar_stream.cuda_stream,
                                                       want_points=False)[0]
         self.lidar_times.append(self.lidar.last_timings().astype(float))
         # UpdateMap -> map_incremental (Tracking.cc:1602-1603) for every sequence's map: one batched call
-        na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, self.states, stream=self.lidar_stream.cuda_stream)
+        na, nn, _ = pkg.capi.map_incremental_batch(self.lidar, self.scan_ids, self.maps, fs.states, stream=self.lidar_stream.cuda_stream)
         self.map_adds = [int(na.sum()), int(nn.sum())]
 
     def ba_stats_batch(self):
@@ -887,6 +970,8 @@ class Loop:
             return None
 
         fed = getattr(self, "host_fed", False)
+        K_frames, base = (1 if fed else len(self.frame_sets)), self.step_base   # (the host-fed leg feeds frame 0: its pinned copies are of that frame)
+        self.step_base += n_steps
 
         def orb_thread():
             ev = self._upload(0, 0) if fed else None
@@ -900,7 +985,7 @@ class Loop:
                     img = self.img_bufs[i % 2]
                     if i + 1 < n_steps:
                         ev = self._upload(0, (i + 1) % 2)
-                self.extract(k, self.stream, img)
+                self.extract(k, self.stream, img, (base + i) % K_frames)
                 self.orb_times.append(self.exts[k].last_timings().astype(float))
                 ready.put(k)
 
@@ -954,7 +1039,12 @@ class Loop:
                     raw = self.raw_bufs[i % 2]
                     if i + 1 < n_steps:
                         ev = self._upload(1, (i + 1) % 2)
-                self.lidar_step(raw) if raw is not None else self.lidar_step()
+                if raw is not None:
+                    self.lidar_step(raw)
+                elif K_frames > 1:
+                    self.lidar_step(f=(base + i) % K_frames)
+                else:
+                    self.lidar_step()
 
         def ba_thread():
             done = 0  # steps whose windows have been optimised; a step's keyframes exist once the tracking thread has finished it
@@ -1819,7 +1909,8 @@ def main(argv=None):
     if not seq_ids:
         raise SystemExit("bench.py: rank %d owns no sequence (%d sequences over %d ranks)" % (rank, args.sequences, world))
     U = min(args.unique, max(len(seq_ids), 1) if args.scaling == "weak" else args.unique)
-    wl = Workload(pkg, synthetic, U, args.map_length, with_ba=False if args.front_end_only else args.ba_mix)
+    wl = Workload(pkg, synthetic, U, args.map_length, with_ba=False if args.front_end_only else args.ba_mix,
+                  cycle=1 if (args.inertial_loop or args.mfma_only) else args.cycle_frames)
     stream = torch.cuda.current_stream().cuda_stream
     ext0 = pkg.OrbExtractor(max_width=wl.W, max_height=wl.H, max_images=2 * U)
     wl.build_tracking_inputs(ext0, stream)
@@ -2130,11 +2221,11 @@ def main(argv=None):
             "config": {
                 "workload": ("configs[1]: KITTI-00 camera-LiDAR front end" if args.front_end_only else
                              "configs[1]+[2]: KITTI camera-LiDAR loop, front end + HIP local LV-BA every %d-th frame" % args.kf_interval) +
-                            ", %d batched sequences in all (%s scaling: %s), one frame of every sequence per step -- stereo ORB (2 x 1242x375, 2000 "
+                            ", %d batched sequences in all (%s scaling: %s), one frame of every sequence per step (step j: frame j %% %d of the sequence's drive) -- stereo ORB (2 x 1242x375, 2000 "
                             "features, 8 levels, FAST 20/7), stereo matching, TrackWithMotionModel + TrackLocalMap (projection matching + pose "
                             "optimisation, twice), LiDAR fov_segment / preprocess / voxel 0.5 m / 5-NN plane features against the sequence's own "
                             "map / map_incremental (64-beam scan, ~130k returns)" % (
-                                total_sequences, args.scaling, "the list is dealt over the ranks" if args.scaling == "strong" else "%d per rank" % args.frames) +
+                                total_sequences, args.scaling, "the list is dealt over the ranks" if args.scaling == "strong" else "%d per rank" % args.frames, len(loop.frame_sets)) +
                             ("" if args.front_end_only else
                              ", LocalLVBundleAdjustment over 64 distinct windows (4-24 free / 2-40 fixed keyframes, 500-6000 points, 0-15 % outliers, LiDAR edge over "
                              "0 / 3-6 keyframes, heavy LiDAR edges with rejected steps, interrupted windows: config.ba)" if wl.ba_mix == "varied" else
@@ -2154,6 +2245,7 @@ def main(argv=None):
                                  ("; local mapping = %d mapping workers, each a lock-step group of its own (tc2li_local_bundle_adjustment_batch_group), taking the steps' "
                                   "windows chunk by chunk (%s windows)" % (len(loop.ba_workers), "/".join(str(n) for n in loop.ba_chunk_sizes)) if loop.ba_workers else ""),
                 "sequences_total": total_sequences, "frames_per_step_per_gpu": F, "images_per_step_per_gpu": loop.n_img,
+                "frames_cycled_per_sequence": len(loop.frame_sets),
                 "ba_windows_per_step_per_gpu": round(ba_windows_timed / args.steps, 3), "host_threads_gpu_path": host_budget,
                 "keypoints_per_image": round(nkp, 1), "stereo_matches_per_frame": round(float(np.mean((st_out[1] > 0).sum(1))), 1),
                 # (the inertial loop's camera path: the IMU prediction in place of TrackWithMotionModel, SearchLocalPoints in place of TrackLocalMap's visual half)
