@@ -272,11 +272,14 @@ def _window_results(batch, i):
                                                            r[5].n_planes, r[5].residual, r[5].chi2)
 
 
-def test_engine_gives_every_window_the_bits_of_the_batch_call(pkg, synthetic):
+@pytest.mark.parametrize("knobs", [{}, {"TC2LI_BA_ENGINE_SIDE": "1", "TC2LI_BA_ENGINE_STAGE": "1,0"}, {"TC2LI_BA_ENGINE_STAGE": "3,5"}])
+def test_engine_gives_every_window_the_bits_of_the_batch_call(pkg, synthetic, monkeypatch, knobs):
     """tc2li_ba_engine (windows join and leave one running lock-step queue): the varied mix -- camera-only and LiDAR windows, sparse and dense
     Schur forms, windows that end early -- through an engine with FEWER slots than windows, as two tickets of which the second is
     submitted while the first runs; every window's poses, points, per-edge chi2, depth flags and statistics are bit for bit the ones of
     tc2li_local_bundle_adjustment_batch_group.  An empty ticket returns at once; a ticket is collected once."""
+    for k, v in knobs.items():   # (an engine reads its switches when it is created: the plane extraction on a side stream, how windows are staged)
+        monkeypatch.setenv(k, v)
     seeds = list(range(14)) + [17, 39]
     ws = [synthetic.ba_window_varied(s) for s in seeds]
     dicts = [varied_window_dict(pkg, synthetic, w) for w in ws]
