@@ -775,7 +775,10 @@ int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* keyframes, const 
  * the windows advance through the Levenberg-Marquardt phases in lock step like tc2li_local_bundle_adjustment_batch's -- one launch per
  * kernel and one synchronisation per phase for all windows (Schur product, solve of the reduced system and trial estimate are one
  * queue with one synchronisation per Levenberg trial), the inertial edges on host threads between the phases -- and every window's
- * result is the one of the one-window call.  results[i] = iterations of window i or its error code;
+ * result is the one of the one-window call.  (A window's reduced system is solved on the device or by the host's envelope LDL^T according
+ * to the window's own shape -- at most 25 optimisable keyframes with IMU state, inertial edges at most two keyframes apart --; the two
+ * solvers agree to 1e-9 relative, not bit for bit.  A lock-step group runs one of them: windows that differ from their group's majority
+ * go through the one-window call inside the batch call.)  results[i] = iterations of window i or its error code;
  * returns the number of windows that succeeded. */
 typedef struct tc2li_lvi_problem {
     tc2li_inertial_keyframe* keyframes; const uint8_t* fixed; const uint8_t* has_imu;

@@ -57,6 +57,9 @@ struct BaOptions {
     }
 };
 
+// result of a window a lock-step group hands back to the one-window path (never seen by a caller: the batch entry points run that path at once)
+constexpr int kLockstepDeclined = -1000000;
+
 struct PoseOptWorkspace {
     DevBuf<PoseProblem> d_probs;
     DevBuf<double> d_Xw, d_poses, d_chi2;
@@ -2681,7 +2684,18 @@ bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_im
     {
         int n_dev = 0, n_ok = 0;
         for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { ++n_ok; if (W[i].dev_solve) { ++n_dev; max_lvi_np = std::max(max_lvi_np, W[i].vp.np); max_lvi_ni = std::max(max_lvi_ni, W[i].inertial.n - W[i].vp.np); } }
-        if (n_dev && n_dev != n_ok) { (void)hipStreamSynchronize(st); return false; }
+        if (n_dev && n_dev != n_ok) {
+            // the windows disagree: the majority stays in lock step, the others are handed back one by one (the whole group used to
+            // go back -- one window without a velocity vertex sent 43 through the serial path)
+            const bool keep_dev = 2 * n_dev >= n_ok;
+            max_lvi_np = max_lvi_ni = 0;
+            for (int i = 0; i < n; ++i) {
+                if (W[i].rc < 0) continue;
+                if (W[i].dev_solve != keep_dev) { W[i].rc = kLockstepDeclined; continue; }
+                if (keep_dev) { max_lvi_np = std::max(max_lvi_np, W[i].vp.np); max_lvi_ni = std::max(max_lvi_ni, W[i].inertial.n - W[i].vp.np); }
+            }
+            n_dev = keep_dev ? n_dev : 0;
+        }
         dev_solve = n_dev > 0;
     }
     std::vector<int> all_windows(n);
@@ -3145,7 +3159,7 @@ int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, i
         auto run_group = [&](int g) {
             const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
             if (lvi_batch_lockstep(problems + b, e - b, calib, cam, named_pool(kPoolLviGroup0 + g), results + b, g))
-                std::fill(todo.begin() + b, todo.begin() + e, (uint8_t)0);
+                for (int i = b; i < e; ++i) todo[i] = results[i] == kLockstepDeclined;
         };
         if (groups == 1) run_group(0);
         else named_pool(kPoolLviTop).parallel_for(groups, run_group);
@@ -3211,8 +3225,9 @@ int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* probl
     const bool kNoLockstep = !opt.lockstep;
     bool done = false;
     if (n_problems > 1 && !kNoLockstep) done = lvi_batch_lockstep(problems, n_problems, calib, cam, named_pool(kPoolLviGroup0 + group), results, group);
-    if (!done) {  // a window outside the batched kernels' range, windows that disagree about the reduced system's solver, or a batch of one
+    {   // a window outside the batched kernels' range or a batch of one: all of them; windows the group handed back: those
         for (int i = 0; i < n_problems; ++i) {
+            if (done && results[i] != kLockstepDeclined) continue;
             const tc2li_lvi_problem& p = problems[i];
             results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
                                                            p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,

@@ -233,7 +233,8 @@ def test_reduced_system_on_the_device_and_on_the_host(pkg, oracle, synthetic, mo
 def test_a_window_the_device_solve_does_not_take(pkg, oracle, synthetic):
     """k_lvi_solve* eliminates the velocity / bias unknowns as a band: a window with an inertial edge between keyframes more than two places apart
     (here keyframes 1 and 6; nothing the reference's temporal window produces) is solved by the host's envelope LDL^T by itself, and a batch that
-    holds such a window beside ordinary ones hands every window to the one-window path: each result is the one-window call's, bit for bit."""
+    holds such a window beside ordinary ones keeps the ordinary ones in lock step and hands THAT window to the one-window path (round 6; the whole
+    group went back before): each result is the one-window call's, bit for bit."""
     w = problem(pkg, oracle, synthetic, 31, n_opt=6, n_points=400)
     link4 = np.vstack([w["link4"], [1.0, 6.0, 0.0, 1.0]])
     pre = list(w["pre"]) + [w["pre"][2]]
@@ -253,6 +254,20 @@ def test_a_window_the_device_solve_does_not_take(pkg, oracle, synthetic):
                                dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=edges, link4=link4, pre=pre, iterations=6)],
                               w["calib24"], w["cam"])
     assert batch.run(max_concurrency=8) == 2
+    # the same with the odd window in the minority of ONE group of three (two ordinary windows stay in lock step)
+    w3 = problem(pkg, oracle, synthetic, 33, n_opt=5, n_points=300)
+    three = pkg.capi.LviBatch([dict(kf33=w2["kf33"], fixed=w2["fixed"], has_imu=w2["has_imu"], points=w2["points"], edges=pkg.pack_ba_edges(w2["edges"]), link4=w2["link4"],
+                                    pre=w2["pre"], iterations=6),
+                               dict(kf33=w["kf33"], fixed=w["fixed"], has_imu=w["has_imu"], points=w["points"], edges=edges, link4=link4, pre=pre, iterations=6),
+                               dict(kf33=w3["kf33"], fixed=w3["fixed"], has_imu=w3["has_imu"], points=w3["points"], edges=pkg.pack_ba_edges(w3["edges"]), link4=w3["link4"],
+                                    pre=w3["pre"], iterations=6)], w["calib24"], w["cam"])
+    assert three.run_group(2) == 3
+    for i in (0, 1):
+        a, b = three.result(i), batch.result(i)
+        assert a[4].trials == b[4].trials and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    kf3, pts3, _, _, st3 = pkg.capi.local_inertial_bundle_adjustment(w3["kf33"], w3["fixed"], w3["has_imu"], w3["calib24"], w3["points"], pkg.pack_ba_edges(w3["edges"]),
+                                                                    w3["link4"], w3["pre"], w3["cam"], iterations=6, lambda_init=1.0)
+    assert three.result(2)[4].trials == st3.trials and np.array_equal(three.result(2)[0], kf3) and np.array_equal(three.result(2)[1], pts3)
     bkf, bpts, bchi2, bdpos, bst, _ = batch.result(1)
     assert bst.iterations == stats.iterations and bst.trials == stats.trials and bst.final_chi2 == stats.final_chi2
     assert np.array_equal(bkf, kf) and np.array_equal(bpts, pts)
