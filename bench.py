@@ -775,7 +775,9 @@ class Loop:
         # a mapping worker with a group context of its own -- a sequence's next keyframe comes kf_interval frames later, so no sequence has two
         # windows in flight.  Alone on the GPU four such groups side by side take 2.7 ms per step's windows against 6.4 for one call per step
         # and 2.9 for one call per four steps (tools/time_ba_batch.py), and a window waits for its own group only.  In the loop (frames/s,
-        # calls of 1-4 steps' windows -> four step workers): 32 sequences 9.7k -> 11.0k, 64: 12.9k -> 14.7-15.3k.
+        # calls of 1-4 steps' windows -> four step workers): 32 sequences 9.7k -> 11.0k, 64: 12.9k -> 14.7-15.3k.  (A step's windows as TWO groups on
+        # eight workers measured worse -- 512 sequences 21.1-21.6k against 21.3-21.6k, 256: 19.4k against 19.8k, 64: 12.0-12.5k against 15.4-15.6k: with
+        # eight BA streams the LiDAR stream shares a hardware queue with one of them and its thread's step doubles.)
         self.ba_step_workers = []
         n_step_workers = int(os.environ.get("TC2LI_BENCH_BA_STEP_WORKERS", str(args.kf_interval) if F <= 512 else "0"))
         if (type(self) is Loop and self.ba_batch is not None and self.ba_engine is None and self.ba_rate == n_ba and n_ba >= 2
