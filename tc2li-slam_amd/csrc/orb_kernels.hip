@@ -838,11 +838,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(LevelTable raw, LevelTa
             m10 = (int)wsum - kRawR * (int)sum;
             m01 = v * (int)sum;
         }
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) {
-            m10 += __shfl_xor(m10, o, 32);
-            m01 += __shfl_xor(m01, o, 32);
-        }
+        m10 = half_wave_sum_i32(m10);
+        m01 = half_wave_sum_i32(m01);
         const float angle = fast_atan2_deg((float)m01, (float)m10);
         if (lane == 0) {
             angles[g] = angle;

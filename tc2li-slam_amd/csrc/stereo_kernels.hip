@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+        best = wave_min_u32(best);
         const int bestDist = (int)(best >> 16), bestIdx = (int)(best & 0xffff);
         float out_u = -1.0f, out_d = -1.0f;
         int out_sad = -1;
@@ -199,8 +198,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(LevelTable left, LevelTabl
                 for (int inc = -5; inc <= 5; ++inc) {
                     int s = abs(a0 - rv0[inc + 5]);
                     if (has1) s += abs(a1 - rv1[inc + 5]);
-#pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+                    s = wave_sum_i32(s);   // (a scalar: the comparisons below are scalar arithmetic)
                     sads[inc + 5] = s;
                     if (s < bestS) { bestS = s; bestInc = inc; }
                 }
