@@ -324,6 +324,8 @@ def compact_roofline(rf):
     out = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_spec", "useful_frac", "avg_launch_ms", "launches_per_step", "launches",
                      "share_of_kernel_time", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "executed_flops_per_launch",
                      "kernel_ms_per_step_all_streams"))
+    if isinstance(rf.get("alone"), dict):
+        out["alone"] = _pick(rf["alone"], ("stages", "avg_launch_ms", "frac"))
     t = rf.get("traffic")
     out["traffic"] = t.get("bytes_per_launch") if isinstance(t, dict) else t
     if isinstance(t, dict) and t.get("source"):
@@ -387,8 +389,8 @@ def compact_line(full, detail_path=None):
         line["host_budget_sweep"] = {k: (v if not isinstance(v, dict) else _pick(v, ("value", "cpu_s_per_wall_s", "threads"))) for k, v in hbs.items() if k != "note"}
     if isinstance(full.get("sharded_window"), dict):
         line["sharded_window"] = _pick(full["sharded_window"], ("ranks", "ms_per_window", "single_gpu_ms_per_window", "max_pose_difference_vs_single_gpu"))
-    if isinstance(full.get("stage_thread_ms_per_step_concurrent"), dict):
-        line["stage_thread_ms_per_step_concurrent"] = full["stage_thread_ms_per_step_concurrent"]
+    if isinstance(full.get("stage_thread_ms_per_step_concurrent"), dict):   # (the mapping workers' own entries stay in the detail file: ba_thread is their maximum)
+        line["stage_thread_ms_per_step_concurrent"] = {k: v for k, v in full["stage_thread_ms_per_step_concurrent"].items() if not k.startswith("ba_worker")}
     if detail_path:
         line["detail"] = detail_path
     # the budget is a contract: shed the optional legs, least important first, rather than print a line the driver cannot parse
@@ -2016,6 +2018,27 @@ def main(argv=None):
         roofline["all_kernels"] = kernel_table
         roofline["kernel_ms_per_step_all_streams"] = round(kernel_ms_per_step, 3)
         roofline["peaks_measured"] = peaks
+        # The same kernel with its STAGE alone on the GPU (the other stage threads idle): in the loop a launch shares the vector units with
+        # three other stages' kernels and takes two to four times as long, which says how full the GPU is, not how good the kernel is.
+        # Same recipe: the stage's loop for a few steps with per-dispatch events, the step's algorithmic amount over the kernel's launches.
+        dom = roofline.get("kernel") or ""
+        alone_stages = (("ba",) if dom.startswith(("k_ba_", "k_balm_", "k_copy_")) else ("lidar",) if dom.startswith(("k_knn", "k_voxel", "k_pre_", "k_map", "k_sel_", "k_seg_")) else
+                        ("orb", "track") if dom.startswith(("k_stereo", "k_match", "k_pose_opt", "k_track", "k_project")) else ("orb",))
+        if set(alone_stages) <= set(stages) and not under_profiler():
+            n_alone = 4 if "ba" not in alone_stages else max(4, args.kf_interval)
+            loop.run(2, alone_stages)
+            torch.cuda.synchronize()
+            pkg.capi.profile_enable(True)
+            loop.run(n_alone, alone_stages)
+            torch.cuda.synchronize()
+            pkg.capi.profile_enable(False)
+            rep_a = {k: v for k, v in pkg.capi.profile_report().items() if base_name(k) == dom}
+            calls_a, ms_a = sum(v[0] for v in rep_a.values()), sum(v[1] for v in rep_a.values())
+            amount = roofline.get("algorithmic_bytes_per_launch") or roofline.get("algorithmic_flops_per_launch")
+            if calls_a and ms_a > 0 and amount and roofline.get("launches_per_step") and roofline.get("peak"):
+                per_launch = amount * roofline["launches_per_step"] * n_alone / calls_a   # the same work per step over this pass's launches
+                rate = per_launch / (ms_a / calls_a * 1e-3) / (1e9 if roofline.get("unit") == "GB/s" else 1e12)
+                roofline["alone"] = {"stages": list(alone_stages), "avg_launch_ms": round(ms_a / calls_a, 6), "achieved": round(rate, 2), "frac": round(rate / roofline["peak"], 5)}
 
     # ---- host-fed inputs: the same loop with every step's images and raw scans taken from pinned host memory (what a drop-in delivers) ----
     host_fed = None
