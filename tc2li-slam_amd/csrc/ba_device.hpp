@@ -99,7 +99,7 @@ struct BaProblemDev {
     double *points, *points_trial;
     const BaEdge* edges;
     const int32_t *pose_var, *pt_off, *pt_edges, *pv_off, *pv_edges, *grp_k0, *grp_l0;
-    // the edges with a free pose, landmark-major ("slots"; the landmarks in the order of the poses they are seen from, ba_host.cpp):
+    // the edges with a free pose, landmark-major ("slots"; the landmarks in the order of the poses they are seen from, VisualProblem::setup in ba_internal.hpp):
     // fl_off[2 l], fl_off[2 l + 1] = begin / end of landmark l's slots, fl_pose the free pose of each slot
     // (-1: fixed pose; dense path only).  A landmark has at most one edge per pose.
     const int32_t *fl_off, *fl_pose, *fl_lm, *fl_place, *slice_off, *fl_edge;  // fl_edge: the edge of each

@@ -1,424 +1,12 @@
 // Host side of the optimisation entry points (include/tc2li_hip.h): tc2li_pose_optimization[_batch] replaces
 // Optimizer::PoseOptimization (SF/src/Optimizer.cc:816-1116).
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstddef>
-#include <cstring>
-#include <condition_variable>
-#include <deque>
-#include <limits>
-#include <map>
-#include <mutex>
-#include <thread>
-#include <pthread.h>
-
-#include "common.hpp"
-#include "ba_device.hpp"
-#include "balm_host.hpp"
-#include "inertial_host.hpp"
-#include "reduced_solve.hpp"
-#include "pose_opt_device.hpp"
+#include "ba_internal.hpp"
 
 using namespace tc2li;
+using namespace tc2li::ba_detail;
 
 static_assert(sizeof(tc2li_ba_edge) == sizeof(BaEdge), "ABI layout");
 static_assert(sizeof(tc2li_camera) == sizeof(CameraD), "ABI layout");
-
-namespace {
-
-// The environment switches of the bundle-adjustment entry points, parsed in ONE place at the start of every call (the tests flip some of
-// them between two calls of one process) and reported by tc2li_ba_options (bench.py logs it in its detail file).  Round 6 retired the
-// switches whose A/B measurements are in DESIGN.md and whose losing form was only kept as a fall-back: TC2LI_BA_SCHUR_LEAN / _MFMA / _GROUP
-// (the lean Schur product is the only block-by-block form), TC2LI_BA_FUSE, TC2LI_BA_XP_PINNED, TC2LI_BA_PRE_SCHUR, TC2LI_BA_PHASE_SERIAL,
-// TC2LI_BA_DENSE_SLICES.
-struct BaOptions {
-    bool device_lm = true;        // TC2LI_BA_DEVICE_LM=0: the LM decisions on the host between the phases (rounds 2-5)
-    bool device_solve = false;    // TC2LI_BA_DEVICE_SOLVE=1: host-driven loop with the reduced systems solved by k_ba_solve_b
-    bool fuse_linearize = false;  // TC2LI_BA_FUSE_LIN=1: the linearisation's closing sums by the window's last workgroup
-    bool fuse_trial = false;      // TC2LI_BA_FUSE_TRIAL=1: a trial as one launch over the landmark groups (pb.trial_fused)
-    bool lvi_device_solve = true; // TC2LI_LVI_DEVICE_SOLVE=0: the inertial windows' reduced systems on the host's envelope solver
-    bool lockstep = true;         // TC2LI_BA_NO_LOCKSTEP: every window through the one-window path
-    bool timing = false;          // TC2LI_BA_TIMING: per-call laps on stderr
-    int groups = 3;               // TC2LI_BA_LOCKSTEP_GROUPS: lock-step groups of the batch entry points
-    std::string shard_fail;       // TC2LI_TEST_SHARD_FAIL: "<rank>:setup" / "<rank>:trial" (tests of the sharded window's failure protocol)
-    static BaOptions read() {
-        auto flag = [](const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; };
-        BaOptions o;
-        o.device_lm = flag("TC2LI_BA_DEVICE_LM", true); o.device_solve = flag("TC2LI_BA_DEVICE_SOLVE", false);
-        o.fuse_linearize = flag("TC2LI_BA_FUSE_LIN", false); o.fuse_trial = flag("TC2LI_BA_FUSE_TRIAL", false);
-        o.lvi_device_solve = flag("TC2LI_LVI_DEVICE_SOLVE", true);
-        o.lockstep = getenv("TC2LI_BA_NO_LOCKSTEP") == nullptr; o.timing = getenv("TC2LI_BA_TIMING") != nullptr;
-        if (const char* e = getenv("TC2LI_BA_LOCKSTEP_GROUPS")) o.groups = atoi(e);
-        o.groups = std::max(1, std::min(kMaxLockstepGroups, o.groups));
-        if (const char* e = getenv("TC2LI_TEST_SHARD_FAIL")) o.shard_fail = e;
-        return o;
-    }
-};
-
-// result of a window a lock-step group hands back to the one-window path (never seen by a caller: the batch entry points run that path at once)
-constexpr int kLockstepDeclined = -1000000;
-
-struct PoseOptWorkspace {
-    DevBuf<PoseProblem> d_probs;
-    DevBuf<double> d_Xw, d_poses, d_chi2;
-    DevBuf<BaEdge> d_edges;
-    DevBuf<uint8_t> d_outlier;
-    DevBuf<int> d_inliers;
-    std::mutex mu;
-};
-PoseOptWorkspace& po_ws() { static thread_local PoseOptWorkspace w; return w; }
-
-// The inertial reduced system on its way to the device solve (k_lvi_solve*, ba_kernels.hip): one blob per window and linearisation --
-// [first n | rowoff n + 1] ints, then [bi n | the envelope's entries] doubles -- and the kernel's scratch.
-struct LviSolveBuffers {
-    DevBuf<uint8_t> d_blob;
-    PinnedBuf<uint8_t> h_blob;
-    DevBuf<double> d_LB, d_Lband;
-    size_t ints_bytes = 0;
-    LviSolveDev dev{};
-    hipError_t ensure(int np, int ni) {
-        const size_t n = (size_t)np + ni;
-        ints_bytes = ((n + 2 * (size_t)np + 1) * sizeof(int32_t) + 15) / 16 * 16;
-        const size_t max_pose = (size_t)np * ni + (size_t)np * (np + 1) / 2;  // pose rows against the band (worst case: every column), pose block
-        const size_t bytes = ints_bytes + (n + (size_t)ni * 32 + max_pose) * sizeof(double);
-        hipError_t e;
-        if ((e = d_blob.ensure(bytes)) != hipSuccess || (e = h_blob.ensure(bytes)) != hipSuccess || (e = d_LB.ensure(std::max<size_t>((size_t)ni * np, 1))) != hipSuccess ||
-            (e = d_Lband.ensure(std::max<size_t>((size_t)ni * 32, 1))) != hipSuccess) return e;
-        dev.n = (int32_t)n; dev.np = np; dev.ni = ni; dev.pad_ = 0;
-        dev.first = reinterpret_cast<const int32_t*>(d_blob.p);
-        dev.span_end = dev.first + n;
-        dev.rowoff = dev.span_end + np;
-        dev.bi = reinterpret_cast<const double*>(d_blob.p + ints_bytes);
-        dev.hband = dev.bi + n;
-        dev.hpose = dev.hband + (size_t)ni * 32;
-        dev.LB = d_LB.p; dev.Lband = d_Lband.p;
-        return hipSuccess;
-    }
-    // after ReducedSolver::set_pattern: the blob of this linearisation; returns the bytes to copy (h_blob -> d_blob)
-    size_t pack(const ReducedSolver& rs, const double* Hi, const double* bi) {
-        const size_t n = (size_t)rs.n;
-        int32_t* ints = reinterpret_cast<int32_t*>(h_blob.p);
-        double* dbl = reinterpret_cast<double*>(h_blob.p + ints_bytes);
-        memcpy(ints, rs.first.data(), n * sizeof(int32_t));
-        memcpy(dbl, bi, n * sizeof(double));
-        std::vector<int32_t> span_first(std::max(rs.np, 1));  // (= first[ni + r]: already in the blob)
-        const size_t entries = rs.pack_for_device(Hi, span_first.data(), ints + n, ints + n + rs.np, dbl + n, dbl + n + (size_t)rs.ni * 32);
-        return ints_bytes + (n + (size_t)rs.ni * 32 + entries) * sizeof(double);
-    }
-};
-struct BaWorkspace {
-    LviSolveBuffers lvi;
-    DevBuf<Se3> d_poses, d_poses_trial;  // d_poses: tc2li_lidar_window_evaluate only; a window's poses live in d_in
-    DevBuf<double> d_points_trial, d_chi2, d_rho0, d_cp, d_W, d_Hll, d_bl, d_diag_l, d_Hpp, d_diag_p,
-        d_coef_e, d_coef, d_Y, d_Spart, d_scale_part, d_chi_part, d_red;
-    // the window as the caller hands it over -- poses, points, edges and the index arrays -- goes up in ONE copy: a stream operation
-    // costs about as much as one of the loop's kernels, and a batch has one such set per window
-    DevBuf<uint8_t> d_in;
-    PinnedBuf<uint8_t> h_in;
-    DevBuf<uint8_t> d_depth;
-    PinnedBuf<double> h_S, h_bs, h_xp, h_scal, h_Hpp, h_stat;
-    DevBuf<ImuPose> d_iposes, d_iposes_trial;
-    PinnedBuf<ImuPose> h_iposes, h_iposes_up;  // trial states on their way back; the initial states on their way up (lock-step batch)
-    PinnedBuf<uint8_t> h_result;  // lock-step batch: poses, points, per-edge chi2 and depth flags on their way to the caller
-    // lock-step batch with the reduced system solved on the device: S, [b_s | b_p], the step; the LiDAR term's Hessian | gradient on both sides
-    DevBuf<double> d_S, d_bs, d_xp, d_Hl;
-    // device-side LM (round 6): the kernels' scalar sums, the LiDAR term's output record and its camera-se3 Jacobian / Hessian stay in device memory
-    DevBuf<double> d_scal, d_balm_out, d_lidar_JH;
-    PinnedBuf<double> h_Hl;
-    PinnedBuf<int32_t> h_ok;
-    BalmTerm lidar;
-    std::mutex mu;
-};
-// one workspace per host thread: windows optimised from different threads (tc2li_local_bundle_adjustment_batch) do not
-// share device buffers
-BaWorkspace& ba_ws() { static thread_local BaWorkspace w; return w; }
-
-// Structure and device state of the projection-edge part of a local BA (shared by the visual / LiDAR and the inertial
-// entry points): free-pose numbering, CSR of the edges by landmark and by free pose, workspace sizing, uploads, and the
-// BaProblemDev handed to the kernels.  poses7 == NULL: the caller uploads ImuPose states itself (inertial mode).
-struct VisualProblem {
-    BaProblemDev pb{};
-    std::vector<int> pose_var;
-    std::vector<Se3> poses;
-    int n_free = 0, np = 0, n_slices = 1, k_per_slice = 4;
-    int max_group_landmarks = 0;
-    // pb.trial_fused (ba_device.hpp): whether the window's trials run as the one fused launch -- a property of the window (it fixes the order
-    // of two sums), decided here and again by a caller that switches the vertices to ImuCamPose records.  OFF unless TC2LI_BA_FUSE_TRIAL=1:
-    // built for VERDICT r4 item 2 ("a trial <= 3 launches"), parity-green in both forms (tests/test_ba_gpu.py, test_balm_gpu.py,
-    // test_inertial_ba_gpu.py run whichever the environment selects) and measured SLOWER in the whole loop -- 27.1 / 27.3 ms per step against
-    // 26.1 / 25.8 in two A/B pairs of one call, the camera threads 26.6-27.3 against 25.4-26.1; local BA alone 13.0-13.7 against 12.1-13.9 ms
-    // per 128 windows.  A workgroup of the fused launch runs six dependent trips to memory (step, poses, slots, W blocks, edge list, edges)
-    // while it holds 28 KB of LDS; the three launches it replaces are thin kernels of two or three trips each that start and finish quickly
-    // beside the other stages' wavefronts.  In a loop bound by the kernels' combined occupancy, fewer launches is not the lever; shorter
-    // residency is.
-    void decide_trial_fused() {
-        const size_t pose_bytes = (size_t)pb.n_poses * (pb.inertial ? sizeof(ImuPose) : sizeof(Se3));
-        pb.trial_fused = BaOptions::read().fuse_trial && np <= kBacksubMaxNp && pose_bytes <= (size_t)kTrialPoseBytes && max_group_landmarks <= 256 ? 1 : 0;
-    }
-
-    int setup(BaWorkspace& ws, const double* poses7, const uint8_t* fixed, int n_poses, const double* points3, int n_points,
-              const tc2li_ba_edge* edges, int n_edges, const tc2li_camera* cam, const uint8_t* extra_used, hipStream_t st) {
-    // ---- structure: free-pose numbering, CSR by landmark and by free pose ----
-    pose_var.assign(n_poses, -1);
-    n_free = 0;
-    std::vector<uint8_t> used(n_poses, 0);
-    for (int e = 0; e < n_edges; ++e) {
-        if (edges[e].pose < 0 || edges[e].pose >= n_poses || edges[e].point < 0 || edges[e].point >= n_points) {
-            set_error("edge %d references pose %d / point %d out of range", e, edges[e].pose, edges[e].point);
-            return TC2LI_ERR_INVALID;
-        }
-        used[edges[e].pose] = 1;
-    }
-    for (int k = 0; k < n_poses; ++k) if (extra_used && extra_used[k]) used[k] = 1;
-    for (int k = 0; k < n_poses; ++k) if (!fixed[k] && used[k]) pose_var[k] = n_free++;
-    std::vector<int> pt_off(n_points + 1, 0), pt_edges(n_edges), pv_off(n_free + 1, 0);
-    for (int e = 0; e < n_edges; ++e) { pt_off[edges[e].point + 1]++; if (pose_var[edges[e].pose] >= 0) pv_off[pose_var[edges[e].pose] + 1]++; }
-    for (int l = 0; l < n_points; ++l) {
-        if (pt_off[l + 1] == 0) { set_error("point %d has no edge", l); return TC2LI_ERR_INVALID; }
-        pt_off[l + 1] += pt_off[l];
-    }
-    for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
-    int n_free_edges = pv_off[n_free];  // edges with a free pose; after the slots are made: the SLOTS (duplicates of a (point, pose) pair have none)
-    std::vector<int> pv_edges(std::max(n_free_edges, 1));
-    {
-        std::vector<int> fl(pt_off.begin(), pt_off.end() - 1), fp(pv_off.begin(), pv_off.end() - 1);
-        for (int e = 0; e < n_edges; ++e) {
-            pt_edges[fl[edges[e].point]++] = e;
-            const int i = pose_var[edges[e].pose];
-            if (i >= 0) pv_edges[fp[i]++] = e;
-        }
-    }
-    // the edges with a free pose in landmark-major order: where the W blocks live (the Schur product and the back substitution walk
-    // them by landmark)
-    // fl_off: per landmark [begin, end) of its slots, the landmarks in index order.  (Tried: slots in the order of the poses a landmark
-    // is seen from, so that a chunk of the Schur kernel spans a narrow band of poses and the product's empty tiles can be skipped -- the
-    // windows' covisibility is not banded enough for that, and the linearisation lost its locality: 64 -> 98 us.)
-    // Every window of at most kSchurLeanMaxFree (24) free keyframes runs the lean block-by-block Schur product (ba_device.hpp) -- up to
-    // kSchurBlocksMaxFree (21) with one workgroup per part, above with two (schur_ranges_wide); wider windows the block-sparse MFMA kernels.
-    const bool lean_wide = n_free > kSchurBlocksMaxFree && n_free <= kSchurLeanMaxFree;
-    const bool schur_lean = (6 * n_free + 1 + 15) / 16 <= 8 || lean_wide;
-    struct DupEdge { int pose, edge, slot; };
-    std::vector<DupEdge> dups;
-    std::vector<int> fl_off(2 * (size_t)n_points, 0), fl_pose(std::max(n_free_edges, 1)), fl_lm(std::max(n_free_edges, 1)), fl_place(std::max(n_free_edges, 1)),
-        fl_edge(std::max(n_free_edges, 1)), w_slot(n_edges, -1), slice_off(1, 0);
-    {
-        // slices of the sparse Schur kernel: whole landmarks, at most 256 edges (one per thread) of at most 64 landmarks; a function of
-        // the window alone, so that a window gives the same bits alone and in a batch
-        // (the lean form of the block-by-block product stages half as many slots at a time: kSchurLeanSlots)
-        // Dense windows (more than 21 free keyframes -- the temporal window of LocalInertialBA's bLarge case; round 5, d_ba_schur_units): the
-        // slots follow the landmarks sorted by the first and the last free pose that sees them, and a slice is a CHUNK of 16 landmarks -- a
-        // landmark of a temporal window is seen from a run of consecutive keyframes, so a chunk touches a band of the reduced system and the
-        // product skips the rest.  (The covisibility windows of the sparse path are not banded: see above.)
-        const bool dense_window = (6 * n_free + 1 + 15) / 16 > 8 && !lean_wide;
-        const int kSliceEdges = dense_window ? std::numeric_limits<int>::max() : kSchurLeanSlots;
-        const int kSliceLandmarks = dense_window ? kUnitChunkHost : 64;
-        std::vector<int> order(n_points);
-        for (int l = 0; l < n_points; ++l) order[l] = l;
-        if (dense_window) {
-            std::vector<int> first(n_points, std::numeric_limits<int>::max()), last(n_points, -1);
-            for (int e = 0; e < n_edges; ++e) {
-                const int i = pose_var[edges[e].pose], l = edges[e].point;
-                if (i >= 0) { first[l] = std::min(first[l], i); last[l] = std::max(last[l], i); }
-            }
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : last[a] < last[b]; });
-        }
-        std::vector<int> seen(std::max(n_free, 1), -1), seen_slot(std::max(n_free, 1), -1);
-        int at = 0, slice_lms = 0;
-        for (int lo = 0; lo < n_points; ++lo) {
-            const int l = order[lo];
-            const int begin = at;
-            for (int k = pt_off[l]; k < pt_off[l + 1]; ++k) {
-                const int e = pt_edges[k], i = pose_var[edges[e].pose];
-                if (i < 0) continue;
-                // A second edge between the same point and the same free pose: g2o adds the two edges' blocks (BaseBinaryEdge::
-                // constructQuadraticForm on the same Hpl / Hpp blocks, base_binary_edge.hpp:55-137).  The slot arrays hold one W block per
-                // (landmark, pose): the later edge gets no slot -- k_ba_dups adds its W block to the first edge's slot and its pose block to
-                // the pose's sums after the linearisation (round 5; rounds 2-4 refused such a window).  The reference's gather cannot produce
-                // one for a pinhole rig, a two-camera shim can.
-                if (seen[i] == l) { dups.push_back(DupEdge{i, e, seen_slot[i]}); continue; }
-                seen[i] = l; seen_slot[i] = at;
-                w_slot[e] = at; fl_pose[at] = i; fl_lm[at] = l; fl_edge[at] = e; ++at;
-            }
-            fl_off[2 * (size_t)l] = begin; fl_off[2 * (size_t)l + 1] = at;
-            if (at == begin) continue;
-            if (slice_lms == kSliceLandmarks || at - slice_off.back() > kSliceEdges) { slice_off.push_back(begin); slice_lms = 0; }
-            for (int k = begin; k < at; ++k) fl_place[k] = slice_lms;
-            ++slice_lms;
-        }
-        if (at > slice_off.back()) slice_off.push_back(at);
-        n_free_edges = at;
-    }
-    // duplicates (k_ba_dups): by pose, in edge order; the per-pose edge lists of the dense windows' coefficient sums hold the slots' edges only
-    std::vector<int> dup_off(n_free + 1, 0), dup_edge(std::max(dups.size(), (size_t)1)), dup_slot(std::max(dups.size(), (size_t)1));
-    if (!dups.empty()) {
-        std::stable_sort(dups.begin(), dups.end(), [](const DupEdge& a, const DupEdge& b) { return a.pose != b.pose ? a.pose < b.pose : a.edge < b.edge; });
-        for (size_t k = 0; k < dups.size(); ++k) { dup_off[dups[k].pose + 1]++; dup_edge[k] = dups[k].edge; dup_slot[k] = dups[k].slot; }
-        for (int i = 0; i < n_free; ++i) dup_off[i + 1] += dup_off[i];
-        std::fill(pv_off.begin(), pv_off.end(), 0);
-        for (int e = 0; e < n_edges; ++e) if (w_slot[e] >= 0) pv_off[pose_var[edges[e].pose] + 1]++;
-        for (int i = 0; i < n_free; ++i) pv_off[i + 1] += pv_off[i];
-        std::vector<int> fp(pv_off.begin(), pv_off.end() - 1);
-        for (int e = 0; e < n_edges; ++e) if (w_slot[e] >= 0) pv_edges[fp[pose_var[edges[e].pose]]++] = e;
-    }
-    // blocks of 256 free-pose edges (the pose role of the linearisation): the block's rows sorted by pose, for the per-pose sums
-    const int n_blocks = (n_free_edges + 255) / 256;
-    std::vector<int> blk_off((size_t)std::max(n_blocks, 1) * (n_free + 1), 0);
-    std::vector<uint8_t> blk_rows((size_t)std::max(n_blocks, 1) * 256, 0);
-    for (int b = 0; b < n_blocks; ++b) {
-        int* off = blk_off.data() + (size_t)b * (n_free + 1);
-        const int s0 = 256 * b, s1 = std::min(n_free_edges, s0 + 256);
-        for (int s = s0; s < s1; ++s) off[fl_pose[s] + 1]++;
-        for (int i = 0; i < n_free; ++i) off[i + 1] += off[i];
-        std::vector<int> fill(off, off + n_free);
-        for (int s = s0; s < s1; ++s) blk_rows[(size_t)b * 256 + fill[fl_pose[s]]++] = (uint8_t)(s - s0);
-    }
-    // groups of the linearisation: whole landmarks, at most 256 edges (one per thread)
-    std::vector<int> grp_k0(1, 0), grp_l0(1, 0);
-    for (int l = 0; l < n_points; ++l) {
-        if (pt_off[l + 1] - pt_off[l] > 256) { set_error("point %d has more than 256 edges", l); return TC2LI_ERR_INVALID; }
-        if (pt_off[l + 1] - grp_k0.back() > 256) { grp_k0.push_back(pt_off[l]); grp_l0.push_back(l); }
-    }
-    grp_k0.push_back(n_edges); grp_l0.push_back(n_points);
-    const int n_groups = (int)grp_k0.size() - 1;
-    max_group_landmarks = 0;
-    for (int g = 0; g < n_groups; ++g) max_group_landmarks = std::max(max_group_landmarks, grp_l0[g + 1] - grp_l0[g]);
-    if (max_group_landmarks > 256) { set_error("more than 256 landmarks without edges in a row"); return TC2LI_ERR_INVALID; }  // (a landmark-role workgroup has a thread per landmark)
-    np = 6 * n_free;
-    // sparse path: one spare row for W D^-1 b_l (row np of the product); dense path: the operands' width
-    const bool sparse = schur_lean;
-    const int np_pad = sparse ? (np + 1 + 15) / 16 * 16 : std::max(16, (np + 15) / 16 * 16);
-    const int n_schur_slices = (int)slice_off.size() - 1;
-    int schur_group = 1;
-    if (sparse) {
-        schur_group = kSchurGroupLean;  // slices per part
-        n_slices = ba_schur_parts(n_schur_slices, schur_group);  // partial sums in S_part
-        k_per_slice = 0;
-    } else {
-        // dense windows (round 5: d_ba_schur_units): the chunks (slices of slice_off: 16 landmarks each) in at most 8 ranges = partial sums
-        const int want_slices = 8;  // (full-width form, 32 windows per launch beside two other groups: 2 / 4 / 8 slices 0.263 / 0.154 / 0.099 ms)
-        k_per_slice = std::min(64, std::max(1, (n_schur_slices + want_slices - 1) / want_slices));   // chunks per partial sum (at most kUnitMaxChunks: ba_kernels.hip)
-        n_slices = std::max(1, (n_schur_slices + k_per_slice - 1) / k_per_slice);
-    }
-    // which 16-column tiles of the reduced system a chunk of landmarks touches (bit t: a pose with columns in tile t sees one of them)
-    std::vector<uint32_t> chunk_mask;
-    if (!sparse) {
-        if (np_pad / 16 > 32) { set_error("more than 85 free keyframes"); return TC2LI_ERR_INVALID; }
-        chunk_mask.assign((size_t)std::max(n_schur_slices, 1), 0u);
-        for (int c = 0; c < n_schur_slices; ++c)
-            for (int sl = slice_off[c]; sl < slice_off[c + 1]; ++sl) {
-                const int c0 = 6 * fl_pose[sl];
-                chunk_mask[c] |= (1u << (c0 / 16)) | (1u << ((c0 + 5) / 16));
-            }
-    }
-
-    // ---- device memory: a per-thread workspace that only grows (hipMalloc per call would dominate the run time) ----
-    auto& d_poses_trial = ws.d_poses_trial;
-    auto &d_points_trial = ws.d_points_trial, &d_chi2 = ws.d_chi2, &d_rho0 = ws.d_rho0,
-         &d_cp = ws.d_cp, &d_W = ws.d_W, &d_Hll = ws.d_Hll, &d_bl = ws.d_bl, &d_diag_l = ws.d_diag_l, &d_Hpp = ws.d_Hpp,
-         &d_diag_p = ws.d_diag_p, &d_coef_e = ws.d_coef_e, &d_coef = ws.d_coef,
-         &d_Spart = ws.d_Spart, &d_scale_part = ws.d_scale_part, &d_chi_part = ws.d_chi_part;
-    auto& d_depth = ws.d_depth;
-    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
-    const size_t E = n_edges, P = n_points;
-    TC2LI_HIP_CHECK(d_poses_trial.ensure(n_poses));
-    TC2LI_HIP_CHECK(d_points_trial.ensure(3 * P));
-    TC2LI_HIP_CHECK(d_chi2.ensure(E)); TC2LI_HIP_CHECK(d_rho0.ensure(E)); TC2LI_HIP_CHECK(d_cp.ensure(kContribP * (size_t)std::max(n_blocks * n_free, 1)));
-    TC2LI_HIP_CHECK(d_W.ensure(18 * (size_t)std::max(n_free_edges, 1))); TC2LI_HIP_CHECK(d_Hll.ensure(6 * P)); TC2LI_HIP_CHECK(d_bl.ensure(3 * P)); TC2LI_HIP_CHECK(d_diag_l.ensure(P));
-    TC2LI_HIP_CHECK(d_Hpp.ensure(27 * (size_t)std::max(n_free, 1))); TC2LI_HIP_CHECK(d_diag_p.ensure(std::max(n_free, 1)));
-    if (!sparse) { TC2LI_HIP_CHECK(d_coef_e.ensure(6 * E)); TC2LI_HIP_CHECK(ws.d_Y.ensure(18 * (size_t)std::max(n_free_edges, 1))); }
-    TC2LI_HIP_CHECK(d_coef.ensure(6 * (size_t)std::max(n_free, 1)));
-    TC2LI_HIP_CHECK(d_Spart.ensure((size_t)std::max(n_slices, 1) * np_pad * np_pad)); TC2LI_HIP_CHECK(d_scale_part.ensure(P / 256 + 1)); TC2LI_HIP_CHECK(d_chi_part.ensure(std::max(E / 256 + 1, (size_t)n_groups)));
-    TC2LI_HIP_CHECK(d_depth.ensure(E));
-    TC2LI_HIP_CHECK(h_S.ensure((size_t)std::max(np * np, 1))); TC2LI_HIP_CHECK(h_bs.ensure(2 * (size_t)std::max(np, 1)));
-    TC2LI_HIP_CHECK(h_xp.ensure(std::max(np, 1))); TC2LI_HIP_CHECK(h_scal.ensure(8));
-    memset(h_S.p, 0, (size_t)std::max(np * np, 1) * sizeof(double));  // the finish kernel writes the lower triangle only; the rest stays defined
-    // ---- the input block: [poses | points | edges | pose_var | pt_off | pt_edges | pv_off | pv_edges | fl_off | fl_pose | chunk_mask | fl_lm | fl_place | slice_off | fl_edge | grp_k0 | grp_l0 | blk_off | blk_rows | ticket words], every
-    // part 16-byte aligned ----
-    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t o_poses = 0, o_points = align16(o_poses + n_poses * sizeof(Se3)), o_edges = align16(o_points + 3 * P * sizeof(double)),
-                 o_pose_var = align16(o_edges + E * sizeof(BaEdge)), o_pt_off = align16(o_pose_var + n_poses * sizeof(int)),
-                 o_pt_edges = align16(o_pt_off + (P + 1) * sizeof(int)), o_pv_off = align16(o_pt_edges + E * sizeof(int)),
-                 o_pv_edges = align16(o_pv_off + (n_free + 1) * sizeof(int)), o_fl_off = align16(o_pv_edges + (sparse ? 0 : pv_edges.size()) * sizeof(int)),
-                 o_fl_pose = align16(o_fl_off + 2 * P * sizeof(int)), o_w_slot = align16(o_fl_pose + fl_pose.size() * sizeof(int)),
-                 o_fl_lm = align16(o_w_slot + chunk_mask.size() * sizeof(uint32_t)), o_fl_place = align16(o_fl_lm + fl_lm.size() * sizeof(int)),
-                 o_slice_off = align16(o_fl_place + fl_place.size() * sizeof(int)), o_fl_edge = align16(o_slice_off + slice_off.size() * sizeof(int)),
-                 o_grp_k0 = align16(o_fl_edge + fl_edge.size() * sizeof(int)), o_grp_l0 = align16(o_grp_k0 + grp_k0.size() * sizeof(int)),
-                 o_blk_off = align16(o_grp_l0 + grp_l0.size() * sizeof(int)), o_blk_rows = align16(o_blk_off + blk_off.size() * sizeof(int)),
-                 o_ticket = align16(o_blk_rows + blk_rows.size()), o_dup_off = align16(o_ticket + 4 * sizeof(int32_t)),
-                 o_dup_edge = align16(o_dup_off + (dups.empty() ? 0 : dup_off.size()) * sizeof(int)),
-                 o_dup_slot = align16(o_dup_edge + (dups.empty() ? 0 : dups.size()) * sizeof(int)),
-                 in_bytes = align16(o_dup_slot + (dups.empty() ? 0 : dups.size()) * sizeof(int));
-    TC2LI_HIP_CHECK(ws.d_in.ensure(in_bytes)); TC2LI_HIP_CHECK(ws.h_in.ensure(in_bytes));
-    uint8_t* const h = ws.h_in.p;
-    if (poses7) {
-        poses.resize(n_poses);
-        for (int k = 0; k < n_poses; ++k) { memcpy(poses[k].q, poses7 + 7 * k, 4 * sizeof(double)); memcpy(poses[k].t, poses7 + 7 * k + 4, 3 * sizeof(double)); }
-        memcpy(h + o_poses, poses.data(), n_poses * sizeof(Se3));
-    }
-    memcpy(h + o_points, points3, 3 * P * sizeof(double));
-    memcpy(h + o_edges, edges, E * sizeof(BaEdge));
-    memcpy(h + o_pose_var, pose_var.data(), n_poses * sizeof(int));
-    memcpy(h + o_pt_off, pt_off.data(), (P + 1) * sizeof(int));
-    memcpy(h + o_pt_edges, pt_edges.data(), E * sizeof(int));
-    memcpy(h + o_pv_off, pv_off.data(), (n_free + 1) * sizeof(int));
-    if (!sparse) memcpy(h + o_pv_edges, pv_edges.data(), pv_edges.size() * sizeof(int));  // pv_edges, w_slot: the dense Schur path's
-    memcpy(h + o_fl_off, fl_off.data(), 2 * P * sizeof(int));
-    memcpy(h + o_fl_pose, fl_pose.data(), fl_pose.size() * sizeof(int));
-    if (!sparse) memcpy(h + o_w_slot, chunk_mask.data(), chunk_mask.size() * sizeof(uint32_t));  // (the region held w_slot for the dense form's prepare kernel)
-    memcpy(h + o_fl_lm, fl_lm.data(), fl_lm.size() * sizeof(int));
-    memcpy(h + o_fl_place, fl_place.data(), fl_place.size() * sizeof(int));
-    memcpy(h + o_slice_off, slice_off.data(), slice_off.size() * sizeof(int));
-    memcpy(h + o_fl_edge, fl_edge.data(), fl_edge.size() * sizeof(int));
-    memcpy(h + o_grp_k0, grp_k0.data(), grp_k0.size() * sizeof(int));
-    memcpy(h + o_grp_l0, grp_l0.data(), grp_l0.size() * sizeof(int));
-    memcpy(h + o_blk_off, blk_off.data(), blk_off.size() * sizeof(int));
-    memcpy(h + o_blk_rows, blk_rows.data(), blk_rows.size());
-    memset(h + o_ticket, 0, 4 * sizeof(int32_t));  // (the kernels that use them leave them at zero again)
-    if (!dups.empty()) {
-        memcpy(h + o_dup_off, dup_off.data(), dup_off.size() * sizeof(int));
-        memcpy(h + o_dup_edge, dup_edge.data(), dups.size() * sizeof(int));
-        memcpy(h + o_dup_slot, dup_slot.data(), dups.size() * sizeof(int));
-    }
-    // inertial mode (poses7 == NULL) uploads ImuPose states itself and does not read the Se3 block
-    const size_t first = poses7 ? 0 : o_points;
-    TC2LI_HIP_CHECK(upload_or_defer(ws.d_in.p + first, h + first, in_bytes - first, st));  // h is pinned
-    uint8_t* const d = ws.d_in.p;
-
-    pb = BaProblemDev{};
-    pb.n_edges = n_edges; pb.n_points = n_points; pb.n_poses = n_poses; pb.n_free = n_free; pb.n_free_edges = n_free_edges; pb.np_pad = np_pad;
-    memcpy(&pb.cam, cam, sizeof(CameraD));
-    const float dm = sqrtf(5.991f), ds = sqrtf(7.815f);  // thHuberMono / thHuberStereo are floats (OptimizerWithLidar.cc:219-220)
-    pb.delta_mono = dm; pb.delta_stereo = ds;
-    pb.dsqr_mono = (float)((double)dm * (double)dm); pb.dsqr_stereo = (float)((double)ds * (double)ds);
-    pb.poses = (Se3*)(d + o_poses); pb.poses_trial = d_poses_trial.p; pb.points = (double*)(d + o_points); pb.points_trial = d_points_trial.p;
-    pb.edges = (const BaEdge*)(d + o_edges); pb.pose_var = (const int*)(d + o_pose_var); pb.pt_off = (const int*)(d + o_pt_off);
-    pb.pt_edges = (const int*)(d + o_pt_edges); pb.pv_off = (const int*)(d + o_pv_off); pb.pv_edges = (const int*)(d + o_pv_edges);
-    pb.fl_off = (const int*)(d + o_fl_off); pb.fl_pose = (const int*)(d + o_fl_pose); pb.chunk_mask = (const uint32_t*)(d + o_w_slot);
-    pb.fl_lm = (const int*)(d + o_fl_lm); pb.fl_place = (const int*)(d + o_fl_place); pb.slice_off = (const int*)(d + o_slice_off); pb.fl_edge = (const int*)(d + o_fl_edge);
-    pb.grp_k0 = (const int*)(d + o_grp_k0); pb.grp_l0 = (const int*)(d + o_grp_l0); pb.n_groups = n_groups;
-    pb.blk_off = (const int*)(d + o_blk_off); pb.blk_rows = (const uint8_t*)(d + o_blk_rows);
-    pb.ticket = (int32_t*)(d + o_ticket);
-    pb.n_dups = (int32_t)dups.size();
-    pb.dup_off = dups.empty() ? nullptr : (const int*)(d + o_dup_off);
-    pb.dup_edge = dups.empty() ? nullptr : (const int*)(d + o_dup_edge);
-    pb.dup_slot = dups.empty() ? nullptr : (const int*)(d + o_dup_slot);
-    pb.sparse_schur = sparse ? 1 : 0; pb.schur_blocks = sparse ? 2 : 0; pb.schur_group = schur_group; pb.n_schur_slices = n_schur_slices;  // (dense windows: the chunks of d_ba_schur_units)
-    pb.schur_rd = pb.schur_ro = 1;
-    decide_trial_fused();
-    if (sparse) {
-        if (lean_wide) schur_ranges_wide(n_free, pb.schur_rd, pb.schur_ro); else schur_ranges(n_free, pb.schur_rd, pb.schur_ro);
-    }
-    pb.chi2 = d_chi2.p; pb.rho0 = d_rho0.p; pb.cp_part = d_cp.p; pb.W = d_W.p; pb.Hll = d_Hll.p; pb.bl = d_bl.p;
-    pb.diag_l = d_diag_l.p; pb.Hpp = d_Hpp.p; pb.diag_p = d_diag_p.p; pb.coef_e = d_coef_e.p; pb.coef = d_coef.p; pb.Y = sparse ? nullptr : ws.d_Y.p;
-    pb.S_part = d_Spart.p; pb.scale_part = d_scale_part.p; pb.chi_part = d_chi_part.p;
-
-        return TC2LI_OK;
-    }
-};
-
-}  // namespace
 
 extern "C" {
 
@@ -936,2177 +524,6 @@ int tc2li_local_bundle_adjustment(double* poses7, const uint8_t* fixed, int n_po
                                             stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, stream);
 }
 
-}  // extern "C"
-
-namespace {
-// The inertial edges of a window (EdgeInertial + EdgeGyroRW + EdgeAccRW per link, SF/src/OptimizerWithLidar.cc:729-800) on the host:
-// their robust cost at a state and, when asked, their dense normal equations in the numbering [6 per free pose | 9 per free
-// keyframe with IMU state].  Shared by the one-window entry point and the lock-step batch.
-struct InertialTerm {
-    std::vector<InertialLinkHost> L;
-    std::vector<int> imu_var;
-    const std::vector<int>* pose_var = nullptr;
-    int np = 0, n = 0, n_imu = 0;
-    std::vector<double> Hi, bi;
-    // The row segments of Hi a linearisation writes (the blocks of the inertial edges; the caller adds those of the LiDAR term): from the second
-    // linearisation on only they are cleared -- Hi is n x n (1.1 MB at 375 unknowns) and almost empty, and clearing it whole was half of what
-    // the inertial edges of a window cost the host.
-    std::vector<uint32_t> seg_at;
-    std::vector<uint8_t> seg_len;
-    bool segs_ready = false;
-    void note_segment(size_t at, int len) {  // (a length is a byte: longer runs are recorded in pieces)
-        if (segs_ready) return;
-        for (; len > 0; at += 255, len -= 255) { seg_at.push_back((uint32_t)at); seg_len.push_back((uint8_t)std::min(len, 255)); }
-    }
-    void note_block(int row0, int col0, int rows, int cols) { for (int r = 0; r < rows; ++r) note_segment((size_t)(row0 + r) * n + col0, cols); }
-    double d_imu = 0;
-    float dsqr_imu = 0;
-
-    // links -> L; extra_used / imu_used [n_kfs]: keyframes an inertial edge touches
-    int prepare(const tc2li_inertial_link* links, int n_links, const uint8_t* has_imu, int n_kfs, std::vector<uint8_t>& extra_used) {
-        L.resize(n_links);
-        extra_used.assign(n_kfs, 0);
-        for (int l = 0; l < n_links; ++l) {
-            const tc2li_inertial_link& in = links[l];
-            if (in.kf1 < 0 || in.kf1 >= n_kfs || in.kf2 < 0 || in.kf2 >= n_kfs || !in.preintegrated) { set_error("inertial link %d: invalid keyframe index or null pre-integration", l); return TC2LI_ERR_INVALID; }
-            if (!has_imu[in.kf1] || !has_imu[in.kf2]) { set_error("inertial link %d joins a keyframe without IMU state", l); return TC2LI_ERR_INVALID; }
-            L[l].kf1 = in.kf1; L[l].kf2 = in.kf2; L[l].robust = in.robust != 0; L[l].pre = in.preintegrated;
-            if (!L[l].prepare(in.info_scale)) { set_error("inertial link %d: the pre-integration covariance is not positive definite", l); return TC2LI_ERR_INVALID; }
-            extra_used[in.kf1] = extra_used[in.kf2] = 1;
-        }
-        const float d_imu_f = sqrtf(16.92f);
-        d_imu = d_imu_f;
-        dsqr_imu = (float)((double)d_imu_f * (double)d_imu_f);
-        return TC2LI_OK;
-    }
-    // imu_used: keyframes whose velocity / bias vertices an inertial edge touches (extra_used before the LiDAR window was added)
-    void number(const uint8_t* fixed, const uint8_t* has_imu, const std::vector<uint8_t>& imu_used, int n_kfs, const std::vector<int>& pose_var_, int np_) {
-        pose_var = &pose_var_; np = np_;
-        imu_var.assign(n_kfs, -1);
-        n_imu = 0;
-        for (int k = 0; k < n_kfs; ++k) if (!fixed[k] && has_imu[k] && imu_used[k]) imu_var[k] = n_imu++;
-        n = np + 9 * n_imu;
-        Hi.assign((size_t)n * n, 0.0); bi.assign(n, 0.0);
-        seg_at.clear(); seg_len.clear(); segs_ready = false;
-    }
-    // whether k_lvi_solve* takes this window's reduced system: velocity / bias unknowns present, the pose block and the rings fit a CU's LDS
-    // (25 free keyframes: the reference's largest window), every inertial edge joins keyframes at most two places apart in the numbering
-    // (band <= kLviBand).  The decision depends on the window alone: the same alone and in a batch.  TC2LI_LVI_DEVICE_SOLVE=0: the host's
-    // envelope LDL^T (reduced_solve.hpp) for every window.
-    bool device_solve_ok() const {
-        if (!BaOptions::read().lvi_device_solve || n_imu <= 0 || np <= 0 || np > kLviMaxPoseRows || !lvi_device_solve_available()) return false;
-        for (const InertialLinkHost& lk_ : L) {
-            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2];
-            if (i1 >= 0 && i2 >= 0 && std::abs(i1 - i2) > 2) return false;
-        }
-        return true;
-    }
-    double cost(const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) {
-        const std::vector<int>& pv = *pose_var;
-        double chi = 0;
-        if (linearize) {
-            if (segs_ready) {
-                for (size_t k = 0; k < seg_at.size(); ++k) std::fill_n(Hi.data() + seg_at[k], seg_len[k], 0.0);
-                // TC2LI_TEST_HI_CLEAR (tests): every writer of Hi must have registered its blocks during the first linearisation -- after the
-                // segment-wise clear the matrix has to be zero everywhere, or a term added later is accumulating stale entries
-                static const bool kCheck = getenv("TC2LI_TEST_HI_CLEAR") != nullptr;
-                if (kCheck) for (double v : Hi) if (v != 0.0) { fprintf(stderr, "tc2li: InertialTerm: Hi holds an entry outside the registered segments\n"); abort(); }
-            } else std::fill(Hi.begin(), Hi.end(), 0.0);
-            std::fill(bi.begin(), bi.end(), 0.0);
-        }
-        for (const InertialLinkHost& lk_ : L) {
-            double er[9], J[9 * 24];
-            lk_.evaluate(Pz[lk_.kf1], Sz[lk_.kf1], Pz[lk_.kf2], Sz[lk_.kf2], er, linearize ? J : nullptr);
-            double Oe[9], c2 = 0;
-            for (int r = 0; r < 9; ++r) { double s = 0; for (int k = 0; k < 9; ++k) s += lk_.info[9 * r + k] * er[k]; Oe[r] = s; c2 += er[r] * s; }
-            double rho0 = c2, rho1 = 1.0;
-            if (lk_.robust) huber(c2, d_imu, dsqr_imu, rho0, rho1);
-            chi += rho0;
-            double eg[3], ea[3], Og[3], Oa[3];
-            for (int k = 0; k < 3; ++k) { eg[k] = Sz[lk_.kf2].bg[k] - Sz[lk_.kf1].bg[k]; ea[k] = Sz[lk_.kf2].ba[k] - Sz[lk_.kf1].ba[k]; }
-            for (int r = 0; r < 3; ++r) {
-                Og[r] = lk_.infoG[3 * r] * eg[0] + lk_.infoG[3 * r + 1] * eg[1] + lk_.infoG[3 * r + 2] * eg[2];
-                Oa[r] = lk_.infoA[3 * r] * ea[0] + lk_.infoA[3 * r + 1] * ea[1] + lk_.infoA[3 * r + 2] * ea[2];
-                chi += eg[r] * Og[r] + ea[r] * Oa[r];
-            }
-            if (!linearize) continue;
-            const int i1 = imu_var[lk_.kf1], i2 = imu_var[lk_.kf2], p1 = pv[lk_.kf1], p2 = pv[lk_.kf2];
-            const int off[6] = {p1 >= 0 ? 6 * p1 : -1, i1 >= 0 ? np + 9 * i1 : -1, i1 >= 0 ? np + 9 * i1 + 3 : -1, i1 >= 0 ? np + 9 * i1 + 6 : -1,
-                                p2 >= 0 ? 6 * p2 : -1, i2 >= 0 ? np + 9 * i2 : -1};
-            const int col[6] = {0, 6, 9, 12, 15, 21}, sz[6] = {6, 3, 3, 3, 6, 3};
-            double OJ[9 * 24];  // (rho' Omega) J
-            for (int r = 0; r < 9; ++r)
-                for (int c = 0; c < 24; ++c) { double t = 0; for (int k = 0; k < 9; ++k) t += rho1 * lk_.info[9 * r + k] * J[24 * k + c]; OJ[24 * r + c] = t; }
-            for (int a = 0; a < 6; ++a) {
-                if (off[a] < 0) continue;
-                for (int r = 0; r < sz[a]; ++r) {
-                    double s = 0;
-                    for (int k = 0; k < 9; ++k) s += J[24 * k + col[a] + r] * (rho1 * Oe[k]);
-                    bi[off[a] + r] -= s;
-                    for (int b2 = 0; b2 < 6; ++b2) {
-                        if (off[b2] < 0) continue;
-                        note_segment((size_t)(off[a] + r) * n + off[b2], sz[b2]);
-                        for (int c = 0; c < sz[b2]; ++c) {
-                            double h = 0;
-                            for (int k = 0; k < 9; ++k) h += J[24 * k + col[a] + r] * OJ[24 * k + col[b2] + c];
-                            Hi[(size_t)(off[a] + r) * n + off[b2] + c] += h;
-                        }
-                    }
-                }
-            }
-            for (int which = 0; which < 2; ++which) {  // EdgeGyroRW / EdgeAccRW: J = (-I, I)
-                const double* Om = which == 0 ? lk_.infoG : lk_.infoA;
-                const double* Oe3 = which == 0 ? Og : Oa;
-                const int o1 = i1 >= 0 ? np + 9 * i1 + 3 + 3 * which : -1, o2 = i2 >= 0 ? np + 9 * i2 + 3 + 3 * which : -1;
-                for (int r = 0; r < 3; ++r) {
-                    if (o1 >= 0) { note_segment((size_t)(o1 + r) * n + o1, 3); if (o2 >= 0) note_segment((size_t)(o1 + r) * n + o2, 3); }
-                    if (o2 >= 0) { note_segment((size_t)(o2 + r) * n + o2, 3); if (o1 >= 0) note_segment((size_t)(o2 + r) * n + o1, 3); }
-                    if (o1 >= 0) bi[o1 + r] += Oe3[r];
-                    if (o2 >= 0) bi[o2 + r] -= Oe3[r];
-                    for (int c = 0; c < 3; ++c) {
-                        if (o1 >= 0) Hi[(size_t)(o1 + r) * n + o1 + c] += Om[3 * r + c];
-                        if (o2 >= 0) Hi[(size_t)(o2 + r) * n + o2 + c] += Om[3 * r + c];
-                        if (o1 >= 0 && o2 >= 0) { Hi[(size_t)(o1 + r) * n + o2 + c] -= Om[3 * r + c]; Hi[(size_t)(o2 + r) * n + o1 + c] -= Om[3 * r + c]; }
-                    }
-                }
-            }
-        }
-        if (linearize) segs_ready = true;
-        return chi;
-    }
-};
-}  // namespace
-
-extern "C" {
-
-static_assert(sizeof(tc2li_imu_calib) == sizeof(ImuCalib), "ABI layout");
-
-int tc2li_local_inertial_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
-                                           const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges,
-                                           int n_edges, const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam,
-                                           int iterations, double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2,
-                                           uint8_t* edge_depth_positive, tc2li_ba_stats* stats, void* stream_) {
-    return tc2li_local_lvi_bundle_adjustment(kfs, fixed, has_imu, n_kfs, calib, points3, n_points, edges, n_edges, links, n_links, cam, iterations,
-                                             lambda_init, stop_flag, edge_chi2, edge_depth_positive, stats, nullptr, nullptr, nullptr, stream_);
-}
-
-int tc2li_local_lvi_bundle_adjustment(tc2li_inertial_keyframe* kfs, const uint8_t* fixed, const uint8_t* has_imu, int n_kfs,
-                                      const tc2li_imu_calib* calib, double* points3, int n_points, const tc2li_ba_edge* edges, int n_edges,
-                                      const tc2li_inertial_link* links, int n_links, const tc2li_camera* cam, int iterations,
-                                      double lambda_init, const volatile uint8_t* stop_flag, double* edge_chi2, uint8_t* edge_depth_positive,
-                                      tc2li_ba_stats* stats, const tc2li_lidar_window* lidar_window, const float* Tbl7,
-                                      tc2li_lidar_ba_stats* lidar_stats, void* stream_) {
-    if (!kfs || !fixed || !has_imu || !calib || !points3 || !edges || !cam || n_kfs <= 0 || n_points <= 0 || n_edges <= 0 || n_links < 0 ||
-        (n_links > 0 && !links) || iterations < 0 || (lidar_window && !Tbl7)) {
-        set_error("tc2li_local_inertial_bundle_adjustment: invalid argument");
-        return TC2LI_ERR_INVALID;
-    }
-    if (lidar_stats) memset(lidar_stats, 0, sizeof(*lidar_stats));
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    hipStream_t st = (hipStream_t)stream_;
-    if (stats) memset(stats, 0, sizeof(*stats));
-    // ---- inertial edges ----
-    InertialTerm inertial;
-    std::vector<uint8_t> extra_used;
-    {
-        const int rc = inertial.prepare(links, n_links, has_imu, n_kfs, extra_used);
-        if (rc < 0) return rc;
-    }
-    std::vector<uint8_t> imu_used = extra_used;  // keyframes whose velocity / bias vertices an inertial edge touches
-    BaWorkspace& ws = ba_ws();
-    std::lock_guard<std::mutex> lk(ws.mu);
-    static_assert(offsetof(tc2li_inertial_keyframe, Rcw) == 0 && offsetof(tc2li_inertial_keyframe, tcw) == 72, "Rcw, tcw first");
-    static_assert(offsetof(ImuPose, Rcw) == 0 && offsetof(ImuPose, tcw) == 72, "Rcw, tcw first");
-    BalmTerm* lidar = nullptr;
-    if (lidar_window) {
-        const int rc = ws.lidar.build_body(kfs, sizeof(tc2li_inertial_keyframe), n_kfs, lidar_window, Tbl7, sizeof(ImuPose), st);
-        if (rc < 0) return rc;
-        lidar = &ws.lidar;
-        for (int i = 0; i < lidar_window->n_keyframes; ++i) extra_used[lidar_window->pose_index[i]] = 1;
-    }
-    VisualProblem vp;
-    {
-        const int rc = vp.setup(ws, nullptr, fixed, n_kfs, points3, n_points, edges, n_edges, cam, extra_used.data(), st);
-        if (rc < 0) return rc;
-    }
-    BaProblemDev& pb = vp.pb;
-    const std::vector<int>& pose_var = vp.pose_var;
-    const int n_free = vp.n_free, np = vp.np;
-    inertial.number(fixed, has_imu, imu_used, n_kfs, pose_var, np);
-    if (lidar_window)   // the LiDAR term's blocks of the reduced system (BalmTerm::add_quadratic_form)
-        for (int i = 0; i < lidar_window->n_keyframes; ++i)
-            for (int j = 0; j < lidar_window->n_keyframes; ++j) {
-                const int vi = pose_var[lidar_window->pose_index[i]], vj = pose_var[lidar_window->pose_index[j]];
-                if (vi >= 0 && vj >= 0) inertial.note_block(6 * vi, 6 * vj, 6, 6);
-            }
-    const std::vector<int>& imu_var = inertial.imu_var;
-    const int n = inertial.n;
-    // ---- keyframe states: ImuCamPose on the device (authoritative), a host mirror for the inertial edges ----
-    std::vector<ImuPose> hp(n_kfs), hp_trial(n_kfs);
-    std::vector<ImuVertexState> sv(n_kfs), sv_trial(n_kfs);
-    for (int k = 0; k < n_kfs; ++k) {
-        memcpy(hp[k].Rcw, kfs[k].Rcw, 72); memcpy(hp[k].tcw, kfs[k].tcw, 24); memcpy(hp[k].Rwb, kfs[k].Rwb, 72); memcpy(hp[k].twb, kfs[k].twb, 24);
-        hp[k].its = 0; hp[k].pad_ = 0;
-        memcpy(sv[k].v, kfs[k].velocity, 24); memcpy(sv[k].bg, kfs[k].gyro_bias, 24); memcpy(sv[k].ba, kfs[k].acc_bias, 24);
-    }
-    TC2LI_HIP_CHECK(ws.d_iposes.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.d_iposes_trial.ensure(n_kfs)); TC2LI_HIP_CHECK(ws.h_iposes.ensure(n_kfs));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_iposes.p, hp.data(), n_kfs * sizeof(ImuPose), hipMemcpyHostToDevice, st));
-    pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
-    vp.decide_trial_fused();
-    memcpy(&pb.calib, calib, sizeof(ImuCalib));
-    auto &h_S = ws.h_S, &h_bs = ws.h_bs, &h_xp = ws.h_xp, &h_scal = ws.h_scal;
-    const size_t E = n_edges, P = n_points;
-
-    std::vector<double>&Hi = inertial.Hi, &bi = inertial.bi;
-    auto inertial_cost = [&](const std::vector<ImuPose>& Pz, const std::vector<ImuVertexState>& Sz, bool linearize) { return inertial.cost(Pz, Sz, linearize); };
-
-    auto stopped = [&] { return stop_flag && *stop_flag; };
-    double lambda = lambda_init, ni = 2, last_chi = 0;
-    int n_bad = 0, done = 0, trials_total = 0;
-    bool ok = true;
-    std::vector<double> rhs(std::max(n, 1)), bfull(std::max(n, 1)), x(std::max(n, 1), 0.0);
-    ReducedSolver solver;
-    // the reduced system on the device (k_lvi_solve: the kernel body of the lock-step batch, so a window gives the same bits here and there)
-    const bool dev_solve = inertial.device_solve_ok();
-    if (dev_solve) {
-        TC2LI_HIP_CHECK(ws.lvi.ensure(np, n - np)); TC2LI_HIP_CHECK(ws.d_S.ensure((size_t)np * np)); TC2LI_HIP_CHECK(ws.d_bs.ensure(2 * (size_t)np));
-        TC2LI_HIP_CHECK(ws.d_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_ok.ensure(1));
-    }
-    for (int it = 0; it < iterations && !stopped() && ok; ++it) {
-        ba_launch_linearize(pb, h_scal.p, h_scal.p + 1, it == 0 && !(lambda_init > 0), st);
-        TC2LI_HIP_CHECK(hipGetLastError());
-        if (lidar) {  // computeActiveErrors + linearizeOplus of the LiDAR edge ride on the same synchronisation
-            lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes), st);
-            const int rc = lidar->enqueue_linearization(reinterpret_cast<const Se3*>(pb.iposes), st);
-            if (rc < 0) return rc;
-        }
-        double chi_imu = inertial_cost(hp, sv, true);  // overlaps with the kernels
-        TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-        if (lidar) {
-            if (it == 0) lidar->finish_error();  // the computeActiveErrors() before optimize() (OptimizerWithLidar.cc:978)
-            lidar->finish_error();
-            chi_imu += lidar->chi2();
-            lidar->finish_linearization();  // constructQuadraticForm uses the stored Jacobian / Hessian when the cost grew
-            lidar->add_quadratic_form(pose_var.data(), n, Hi.data(), bi.data());
-        }
-        solver.set_pattern(Hi.data(), n, np, !dev_solve);
-        if (dev_solve) {
-            if (solver.band() > kLviBand) { set_error("tc2li_local_lvi_bundle_adjustment: inertial band wider than the device solve holds"); return TC2LI_ERR_INVALID; }
-            const size_t bytes = ws.lvi.pack(solver, Hi.data(), bi.data());
-            TC2LI_HIP_CHECK(hipMemcpyAsync(ws.lvi.d_blob.p, ws.lvi.h_blob.p, bytes, hipMemcpyHostToDevice, st));
-        }
-        double currentChi = chi_imu + h_scal.p[0], tempChi = currentChi;
-        const double iniChi = currentChi;
-        if (it == 0) {
-            if (stats) stats->initial_chi2 = currentChi;
-            last_chi = currentChi;
-            if (!(lambda_init > 0)) {  // computeLambdaInit over the whole diagonal (not used by the reference's settings)
-                double mx = std::max(h_scal.p[1], h_scal.p[2]);
-                for (int j = np; j < n; ++j) mx = std::max(mx, std::fabs(Hi[(size_t)j * n + j]));
-                lambda = 1e-5 * mx;
-            }
-            ni = 2;
-            n_bad = 0;
-        }
-        double rho = 0;
-        int qmax = 0;
-        do {
-            if (dev_solve) {  // Schur product, solve, trial estimate and its cost in one queue, one synchronisation
-                ba_launch_schur(pb, lambda, lambda, vp.n_slices, vp.k_per_slice, ws.d_S.p, ws.d_bs.p, st);
-                lvi_launch_solve(ws.lvi.dev, ws.d_S.p, ws.d_bs.p, lambda, ws.d_xp.p, h_xp.p, ws.h_ok.p, st);
-                TC2LI_HIP_CHECK(hipMemcpyAsync(h_bs.p + np, ws.d_bs.p + np, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, st));
-                ba_launch_trial(pb, ws.d_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
-                TC2LI_HIP_CHECK(hipGetLastError());
-                TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_iposes.p, pb.iposes_trial, n_kfs * sizeof(ImuPose), hipMemcpyDeviceToHost, st));
-                if (lidar) lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes_trial), st);
-                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-                const bool ok2 = ws.h_ok.p[0] != 0;
-                memcpy(x.data(), h_xp.p, (size_t)n * sizeof(double));
-                double scale = 0;
-                for (int j = 0; j < n; ++j) {
-                    const double bf = bi[j] + (j < np ? h_bs.p[np + j] : 0.0);
-                    scale += x[j] * (lambda * x[j] + bf);
-                }
-                if (ok2) {
-                    sv_trial = sv;
-                    for (int k = 0; k < n_kfs; ++k)
-                        if (imu_var[k] >= 0) {
-                            const double* u = &x[np + 9 * imu_var[k]];
-                            for (int c = 0; c < 3; ++c) { sv_trial[k].v[c] += u[c]; sv_trial[k].bg[c] += u[3 + c]; sv_trial[k].ba[c] += u[6 + c]; }
-                        }
-                    memcpy(hp_trial.data(), ws.h_iposes.p, n_kfs * sizeof(ImuPose));
-                    tempChi = inertial_cost(hp_trial, sv_trial, false) + h_scal.p[4];
-                    if (lidar) { lidar->finish_error(); tempChi += lidar->chi2(); }
-                    scale += h_scal.p[3];
-                    last_chi = tempChi;
-                } else {
-                    tempChi = std::numeric_limits<double>::max();
-                }
-                rho = currentChi - tempChi;
-                scale += 1e-3;
-                rho /= scale;
-                if (rho > 0 && std::isfinite(tempChi)) {
-                    lambda = lm_lambda_accepted(lambda, rho);
-                    ni = 2;
-                    currentChi = tempChi;
-                    std::swap(pb.iposes, pb.iposes_trial);
-                    std::swap(pb.points, pb.points_trial);
-                    hp.swap(hp_trial);
-                    sv.swap(sv_trial);
-                } else {
-                    lambda *= ni;
-                    ni *= 2;
-                }
-                qmax++;
-                trials_total++;
-                continue;
-            }
-            ba_launch_schur(pb, lambda, lambda, vp.n_slices, vp.k_per_slice, h_S.p, h_bs.p, st);
-            TC2LI_HIP_CHECK(hipGetLastError());
-            TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-            // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I]
-            // (the envelope LDL^T of reduced_solve.hpp: velocity / bias unknowns first, the pose rows after them)
-            for (int j = 0; j < n; ++j) {
-                bfull[j] = bi[j] + (j < np ? h_bs.p[np + j] : 0.0);
-                rhs[j] = bi[j] + (j < np ? h_bs.p[j] : 0.0);
-            }
-            const bool ok2 = n == 0 ? true : solver.factorise(Hi.data(), h_S.p, lambda);
-            if (ok2 && n) solver.solve(rhs.data(), x.data());
-            double scale = 0;
-            for (int j = 0; j < n; ++j) scale += x[j] * (lambda * x[j] + bfull[j]);
-            if (ok2) {
-                if (np) memcpy(h_xp.p, x.data(), np * sizeof(double));
-                ba_launch_trial(pb, h_xp.p, lambda, h_scal.p + 3, h_scal.p + 4, st);
-                TC2LI_HIP_CHECK(hipGetLastError());
-                TC2LI_HIP_CHECK(hipMemcpyAsync(ws.h_iposes.p, pb.iposes_trial, n_kfs * sizeof(ImuPose), hipMemcpyDeviceToHost, st));
-                if (lidar) lidar->enqueue_error(reinterpret_cast<const Se3*>(pb.iposes_trial), st);
-                sv_trial = sv;
-                for (int k = 0; k < n_kfs; ++k)
-                    if (imu_var[k] >= 0) {
-                        const double* u = &x[np + 9 * imu_var[k]];
-                        for (int c = 0; c < 3; ++c) { sv_trial[k].v[c] += u[c]; sv_trial[k].bg[c] += u[3 + c]; sv_trial[k].ba[c] += u[6 + c]; }
-                    }
-                TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-                memcpy(hp_trial.data(), ws.h_iposes.p, n_kfs * sizeof(ImuPose));
-                tempChi = inertial_cost(hp_trial, sv_trial, false) + h_scal.p[4];
-                if (lidar) { lidar->finish_error(); tempChi += lidar->chi2(); }
-                scale += h_scal.p[3];
-                last_chi = tempChi;
-            } else {
-                tempChi = std::numeric_limits<double>::max();
-            }
-            rho = currentChi - tempChi;
-            scale += 1e-3;
-            rho /= scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                lambda = lm_lambda_accepted(lambda, rho);
-                ni = 2;
-                currentChi = tempChi;
-                std::swap(pb.iposes, pb.iposes_trial);
-                std::swap(pb.points, pb.points_trial);
-                hp.swap(hp_trial);
-                sv.swap(sv_trial);
-            } else {
-                lambda *= ni;
-                ni *= 2;
-            }
-            qmax++;
-            trials_total++;
-        } while (rho < 0 && qmax < 10 && !stopped());
-        ++done;
-        if (stats) stats->final_lambda = lambda;
-        if (qmax == 10 || rho == 0) { ok = false; continue; }
-        if ((iniChi - currentChi) * 1e3 < iniChi) n_bad++; else n_bad = 0;
-        if (n_bad >= 3) ok = false;
-    }
-    if (stats) { stats->iterations = done; stats->trials = trials_total; stats->n_free_poses = n_free; stats->final_chi2 = last_chi; }
-    if (lidar && lidar_stats) {
-        lidar_stats->n_planes = lidar->n_planes; lidar_stats->hessian_evaluations = lidar->hessian_evaluations;
-        lidar_stats->residual = lidar->error; lidar_stats->chi2 = lidar->chi2();
-    }
-    // ---- results ----
-    ba_launch_depth(pb, ws.d_depth.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipMemcpyAsync(points3, pb.points, 3 * P * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (edge_chi2) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_chi2, ws.d_chi2.p, E * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (edge_depth_positive) TC2LI_HIP_CHECK(hipMemcpyAsync(edge_depth_positive, ws.d_depth.p, E, hipMemcpyDeviceToHost, st));
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-    for (int k = 0; k < n_kfs; ++k) {
-        memcpy(kfs[k].Rcw, hp[k].Rcw, 72); memcpy(kfs[k].tcw, hp[k].tcw, 24); memcpy(kfs[k].Rwb, hp[k].Rwb, 72); memcpy(kfs[k].twb, hp[k].twb, 24);
-        memcpy(kfs[k].velocity, sv[k].v, 24); memcpy(kfs[k].gyro_bias, sv[k].bg, 24); memcpy(kfs[k].acc_bias, sv[k].ba, 24);
-    }
-    return done;
-}
-
-}  // extern "C"
-
-namespace {
-
-// ---- lock-step batch -----------------------------------------------------------------------------------------------------
-// All windows advance through the phases of the Levenberg-Marquardt loop together: one launch per kernel and one stream
-// synchronisation per phase for the whole batch (a window alone is bound by launch and synchronisation latency: its kernels take
-// 5-20 us each).  The arithmetic of a window is the one of tc2li_local_lv_bundle_adjustment (same kernel bodies, same host
-// steps), so the results are identical to optimising the windows one by one.
-struct LockstepWindow {
-    const tc2li_ba_problem* p = nullptr;
-    BaWorkspace* ws = nullptr;
-    VisualProblem vp;
-    BalmTerm* lidar = nullptr;
-    std::vector<uint8_t> extra_used;
-    std::vector<double> Swork, x;
-    double *Hl = nullptr, *bl_ = nullptr;  // the LiDAR term's (6K)^2 Hessian and 6K gradient (pinned: ws->h_Hl)
-    double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, max_pose_diag = 0;
-    int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
-    int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot (an odd number of accepted steps)
-    bool ok = true, ok2 = true, need_diag = false, want_maxdiag = false;
-    bool wants_hpp() const { return need_diag; }
-    bool stopped() const { return p->stop_flag && *p->stop_flag; }
-    bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
-};
-
-// The windows `list[c0 .. c1)` of a phase as kernel arguments (ba_device.hpp BaPhase): table index, parity / request bits, lambda.
-template <typename Win>
-BaPhase make_phase(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, size_t c0, size_t c1, int expect = 0) {
-    BaPhase ph;
-    ph.table = d_table; ph.xp_area = d_xp_area; ph.first = (int32_t)c0; ph.pad_ = 0; ph.expect = expect; ph.pad2_ = 0;
-    for (size_t k = c0; k < c1; ++k) {
-        const Win& w = W[list[k]];
-        ph.win[k - c0] = (uint16_t)list[k];
-        ph.flags[k - c0] = (uint8_t)((w.parity ? kBaAcceptedInTrial : 0u) | (w.want_maxdiag ? kBaWantMaxdiag : 0u) | (w.wants_hpp() ? kBaWantHpp : 0u));
-        ph.lambda[k - c0] = w.lambda;
-    }
-    return ph;
-}
-// fn(phase, windows in it) for every piece of at most kBaPhaseMax windows of `list`
-template <typename Win, typename Fn>
-void for_phase_pieces(const BaBatchSlot* d_table, const double* d_xp_area, const std::vector<Win>& W, const std::vector<int>& list, Fn&& fn, int expect = 0) {
-    for (size_t c0 = 0; c0 < list.size(); c0 += kBaPhaseMax) {
-        const size_t c1 = std::min(list.size(), c0 + (size_t)kBaPhaseMax);
-        const BaPhase ph = make_phase(d_table, d_xp_area, W, list, c0, c1, expect);
-        fn(ph, (int)(c1 - c0));
-    }
-}
-
-struct LockstepContext {
-    std::mutex mu;
-    std::vector<std::unique_ptr<BaWorkspace>> ws;
-    // slot table and, behind it, the two index lists of a phase: one host buffer, one device buffer, one copy per phase
-    DevBuf<uint8_t> d_table;
-    PinnedBuf<uint8_t> h_table;
-    PinnedBuf<CopyTask> h_tasks;  // the uploads / operand fills of a batch's setup, then its result copies: one launch each (copy_kernels.hip)
-    PinnedBuf<CopyTask> h_table_task;  // the steps x_p of a trial phase on their way up: one entry for k_copy_tasks
-    // plane extraction of the batch's LiDAR windows on the device (balm_cut_kernels.hip): a task per window, those with points to cut
-    // compacted into the list the kernels read, and the uploads the LiDAR tasks deferred (the clouds)
-    PinnedBuf<BalmCutTask> h_cut, h_cut_list;
-    DevBuf<BalmCutTask> d_cut_list;
-    PinnedBuf<CopyTask> h_cut_copies;
-    // device-side LM: the windows' states (device), their initial values and the mirror the decide kernel writes (pinned), the stop words
-    DevBuf<BaLmState> d_lm;
-    PinnedBuf<BaLmState> h_lm_init, h_lm;
-    PinnedBuf<int32_t> h_stop;
-    hipEvent_t round_done[2] = {nullptr, nullptr};
-    hipStream_t st = nullptr;
-    ~LockstepContext() {
-        for (hipEvent_t e : round_done) if (e) (void)hipEventDestroy(e);
-        if (st) (void)hipStreamDestroy(st);
-    }
-};
-struct LockstepContexts { LockstepContext c[kMaxLockstepGroups]; };
-LockstepContext& lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 0>().c[group]; }
-
-
-// The LiDAR half of a lock-step batch's setup, after its tasks (the odd entries of `deferred`) have staged the clouds and described the
-// extractions in C.h_cut[0..n): the uploads and the extraction kernels of all windows are queued in one go, so that they run while the
-// host builds the visual structure.  plane_extraction_finish (after that) waits for them and gives every window its planes.
-bool plane_extraction_begin(LockstepContext& C, std::vector<std::vector<CopyTask>>& deferred, int n, hipStream_t st) {
-    int m = 0, max_points = 0, max_table = 0;
-    if (C.h_cut_list.ensure(std::max(n, 1)) != hipSuccess || C.d_cut_list.ensure(std::max(n, 1)) != hipSuccess) return false;
-    for (int i = 0; i < n; ++i) {
-        const BalmCutTask& t = C.h_cut.p[i];
-        if (t.n_points <= 0) continue;
-        C.h_cut_list.p[m++] = t;
-        max_points = std::max(max_points, t.n_points);
-        max_table = std::max(max_table, 1 << t.table_bits);
-    }
-    if (!m) return true;
-    size_t n_copies = 1, max_bytes = (size_t)m * sizeof(BalmCutTask);
-    for (int i = 0; i < n; ++i) n_copies += deferred[2 * (size_t)i + 1].size();
-    if (C.h_cut_copies.ensure(n_copies) != hipSuccess) return false;
-    size_t at = 0;
-    C.h_cut_copies.p[at++] = CopyTask{C.d_cut_list.p, C.h_cut_list.p, (size_t)m * sizeof(BalmCutTask)};
-    for (int i = 0; i < n; ++i) {
-        for (const CopyTask& t : deferred[2 * (size_t)i + 1]) { C.h_cut_copies.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-        deferred[2 * (size_t)i + 1].clear();
-    }
-    launch_copy_tasks(C.h_cut_copies.p, (int)n_copies, max_bytes, st);
-    launch_balm_cut(C.d_cut_list.p, m, max_points, max_table, st);
-    return hipGetLastError() == hipSuccess;
-}
-// rc per window (0, or the error of a window whose planes could not be set up)
-bool plane_extraction_finish(LockstepContext& C, int n, std::vector<int>& rc_lidar, hipStream_t st) {
-    bool any = false;
-    for (int i = 0; i < n; ++i) any |= C.h_cut.p[i].n_points > 0;
-    if (!any) return true;
-    if (stream_wait_blocking(st) != hipSuccess) return false;
-    for (int i = 0; i < n; ++i) {
-        if (C.h_cut.p[i].n_points <= 0 || rc_lidar[i] < 0) continue;
-        rc_lidar[i] = C.ws[i]->lidar.finish_cut(st);
-    }
-    return true;
-}
-
-// What the launches of a phase have to cover: the largest sizes among the listed windows and which kernel families they need.  Taken over
-// the whole batch once (the fusion switches follow from it) and, with the device-side LM loop, again over the windows still alive whenever that
-// list shrinks: the rounds a few stragglers need after the bulk has finished are launched for THEIR sizes and families only (no dense-path
-// kernels once the last window of more than 21 free keyframes is done, the narrow solve kernel for narrow systems).
-template <typename Win>
-BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& list, bool* all_block_parts_out = nullptr) {
-    BaBatchExtent X{};
-    bool all_block_parts = true;
-    for (int i : list) {
-        if (W[i].rc < 0) continue;
-        const BaProblemDev& pb = W[i].vp.pb;
-        X.max_edges = std::max(X.max_edges, pb.n_edges); X.max_points = std::max(X.max_points, pb.n_points); X.max_poses = std::max(X.max_poses, pb.n_poses);
-        X.max_free = std::max(X.max_free, pb.n_free); X.max_free_edges = std::max(X.max_free_edges, pb.n_free_edges); X.max_groups = std::max(X.max_groups, pb.n_groups);
-        if (!(pb.sparse_schur && pb.schur_blocks && pb.n_free > 0 && W[i].vp.n_slices > 0)) all_block_parts = false;
-        if (pb.trial_fused) X.any_trial_fused = 1; else X.any_trial_unfused = 1;
-        if (pb.n_dups) X.any_dups = 1;
-        if (pb.sparse_schur && pb.schur_blocks) {
-            if (pb.n_free > 0 && W[i].vp.n_slices > 0) {
-                X.min_block_free = X.max_block_parts ? std::min(X.min_block_free, pb.n_free) : pb.n_free;
-                X.max_block_parts = std::max(X.max_block_parts, W[i].vp.n_slices); X.max_block_free = std::max(X.max_block_free, pb.n_free);
-                X.any_block_lean = 1;
-                if (pb.n_free > kSchurBlocksMaxFree) X.any_block_wide = 1;
-            }
-        } else if (!pb.sparse_schur) {
-            X.any_dense = 1; X.max_np_pad = std::max(X.max_np_pad, pb.np_pad); X.max_slices = std::max(X.max_slices, W[i].vp.n_slices);
-        }
-        if (W[i].lidar) {
-            X.max_planes = std::max(X.max_planes, W[i].lidar->n_planes); X.max_chunks = std::max(X.max_chunks, W[i].lidar->dev.n_chunks);
-            X.max_W = std::max(X.max_W, W[i].lidar->W);
-        }
-    }
-    if (all_block_parts_out) *all_block_parts_out = all_block_parts;
-    return X;
-}
-
-// returns false when the batch has to go through the one-thread-per-window path (a LiDAR window outside the batched kernels' range)
-bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0) {
-    LockstepContext& C = lockstep_ctx(group);
-    std::lock_guard<std::mutex> lk(C.mu);
-    const BaOptions opt = BaOptions::read();
-    for (int i = 0; i < n; ++i)
-        if (problems[i].lidar && (problems[i].lidar->n_keyframes > 7)) return false;
-    if (!C.st) {
-        // the loop is a chain of ~140 short dependent launches: on a GPU shared with the front-end kernels they go first.  (Round 6 also tried
-        // compute units of their own -- hipExtStreamCreateWithCUMask: the lock-step groups on 32 / 64 / 96 of the 256, every other stream of the
-        // loop on the rest.  A chain of tiny kernels beside GEMMs gains 25x from that; this one does not: its large kernels want the whole chip --
-        // 512 sequences 9.6 / 14.7 / 16.8 k frames/s against 20.2 k unpartitioned, 64 sequences 8.3 / 12.0 k against 15.1 k.  Removed.)
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
-            hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
-    }
-    hipStream_t st = C.st;
-    while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    // the slot table: one slot per window, filled once after the setup and uploaded with the windows' input blocks; what a phase changes
-    // (which windows take part, lambda, which of a slot's two buffers holds the accepted estimate) travels in the kernels' arguments
-    // (BaPhase).  Behind the table: the steps x_p of the windows of a trial phase (kBaXpStride doubles each), so that the trial kernels
-    // read them from device memory (a window with more free keyframes than that keeps reading the solver's pinned buffer).
-    if (n > 65535) return false;  // BaPhase names a window by 16 bits
-    constexpr size_t kXpStride = kBaXpStride;
-    const size_t table_bytes = (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
-    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
-    double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
-    const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
-    double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
-    std::vector<LockstepWindow> W(n);
-    const bool kTiming = opt.timing;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = now();
-    const double t_begin = t0;
-    // ---- setup: argument checks, plane extraction (device, queued first: it runs while the host builds the visual structure), uploads ----
-    std::vector<int> rc_lidar(n, 0);
-    std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);  // what the tasks would have queued as copies / fills of their own
-    if (C.h_cut.ensure(std::max(n, 1)) != hipSuccess) return false;
-    for (int i = 0; i < n; ++i) C.h_cut.p[i].n_points = 0;
-    auto setup_task = [&](int task) {  // two tasks per window: the visual structure + uploads (even), the LiDAR window (odd)
-        CopySink sink(&deferred[task]);
-        const int i = task >> 1;
-        LockstepWindow& w = W[i];
-        const tc2li_ba_problem& p = problems[i];
-        const bool args_ok = p.poses7 && p.fixed && p.points3 && p.edges && p.n_poses > 0 && p.n_points > 0 && p.n_edges > 0 && p.iterations >= 0;
-        bool lidar_ok = true;
-        if (args_ok && p.lidar) {
-            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) lidar_ok = false;
-            else for (int k = 0; k < p.lidar->n_keyframes; ++k) if (p.lidar->pose_index[k] < 0 || p.lidar->pose_index[k] >= p.n_poses) lidar_ok = false;
-        }
-        if (task & 1) {
-            if (!args_ok || !lidar_ok || !p.lidar) return;
-            const double tb = now();
-            rc_lidar[i] = C.ws[i]->lidar.build(p.poses7, p.n_poses, p.lidar, st, &C.h_cut.p[i]);
-            if (kTiming && i == 0) fprintf(stderr, "  window 0: lidar build %.3f ms\n", now() - tb);
-            return;
-        }
-        w.p = &p; w.ws = C.ws[i].get();
-        if (!args_ok) { set_error("tc2li_local_bundle_adjustment: invalid argument"); w.rc = TC2LI_ERR_INVALID; return; }
-        if (!lidar_ok) { set_error("lidar window: invalid argument or pose_index out of range"); w.rc = TC2LI_ERR_INVALID; return; }
-        if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
-        if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
-        if (p.lidar) {
-            w.extra_used.assign(p.n_poses, 0);
-            for (int k = 0; k < p.lidar->n_keyframes; ++k) w.extra_used[p.lidar->pose_index[k]] = 1;
-        }
-        const double ts = now();
-        w.rc = w.vp.setup(*w.ws, p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
-                          w.extra_used.empty() ? nullptr : w.extra_used.data(), st);
-        if (kTiming && i == 0) fprintf(stderr, "  window 0: visual setup %.3f ms\n", now() - ts);
-        if (w.rc < 0) return;
-        const int np = w.vp.np;
-        w.Swork.assign((size_t)std::max(np * np, 1), 0.0);
-        w.x.assign(std::max(np, 1), 0.0);
-        BaWorkspace& ws = *w.ws;
-        const size_t nn = (size_t)std::max(np * np, 1), n1 = (size_t)std::max(np, 1);
-        if (ws.d_S.ensure(nn) != hipSuccess || ws.d_bs.ensure(2 * n1) != hipSuccess || ws.d_xp.ensure(n1) != hipSuccess || ws.h_ok.ensure(1) != hipSuccess ||
-            ws.d_scal.ensure(8) != hipSuccess) {
-            w.rc = TC2LI_ERR_HIP; return;
-        }
-        if (p.lidar) {
-            const size_t nl = 6 * (size_t)p.lidar->n_keyframes;
-            if (ws.d_balm_out.ensure((size_t)balm_out_size(p.lidar->n_keyframes)) != hipSuccess || ws.d_lidar_JH.ensure(nl + nl * nl) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-            // computeLambdaInit with a LiDAR term reads the diagonal of Hpp on the host (first iteration, no lambda given): where the reduction writes it
-            if (ws.h_Hpp.ensure(27 * (size_t)std::max(w.vp.n_free, 1)) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-            if (ws.d_Hl.ensure(nn + n1) != hipSuccess || ws.h_Hl.ensure(nn + n1) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-            w.Hl = ws.h_Hl.p; w.bl_ = ws.h_Hl.p + nn;
-            std::fill(w.Hl, w.Hl + nn + n1, 0.0);
-        }
-    };
-    pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
-    if (!plane_extraction_begin(C, deferred, n, st)) { (void)hipStreamSynchronize(st); return false; }
-    if (kTiming) fprintf(stderr, "  lidar tasks + queueing the extraction: %.3f ms\n", now() - t0);
-    pool.parallel_for(n, [&](int i) { setup_task(2 * i); });
-    if (kTiming) fprintf(stderr, "  + visual tasks: %.3f ms\n", now() - t0);
-    if (!plane_extraction_finish(C, n, rc_lidar, st)) return false;
-    if (kTiming) fprintf(stderr, "  + extraction back: %.3f ms\n", now() - t0);
-    for (int i = 0; i < n; ++i) {
-        if (W[i].rc < 0 || !problems[i].lidar) continue;
-        if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
-    }
-    for (int i = 0; i < n; ++i)
-        if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) {  // outside the batched LiDAR kernels: per-window path for this batch
-            (void)hipStreamSynchronize(st);
-            return false;
-        }
-    tm[0] = now() - t0;
-    std::vector<int> all_windows(n);
-    for (int i = 0; i < n; ++i) all_windows[i] = i;
-    bool all_block_parts = true;
-    BaBatchExtent X = batch_extent(W, all_windows, &all_block_parts);
-    // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
-    // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
-    // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
-    // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
-    // are a launch; removed.)
-    {
-        X.fuse_trial = all_block_parts ? 1 : 0;
-        // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
-        // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
-        // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
-        // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
-        // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
-        // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
-        X.fuse_linearize = opt.fuse_linearize ? 1 : 0;
-    }
-    // TC2LI_BA_DEVICE_SOLVE=1 (read per call): the reduced systems of the batch are solved on the device (k_ba_solve_b; every window on the
-    // sparse Schur path, i.e. at most 21 free keyframes) -- Schur product, solve and trial estimate are then one queue of launches with one
-    // host round trip per LM trial instead of two, and the step is the host's bit for bit.  Built for VERDICT 5 and measured: the
-    // workgroup-per-window LDL^T (its substitutions are serial chains through LDS) takes longer on the stream than the host's solves on
-    // the pool threads plus the extra synchronisation -- 8.8 against 10.2 k frames/s at 64 sequences, no difference at 512 -- so the host
-    // solve stays the default.
-    const bool dev_solve = opt.device_solve && X.max_free <= kSolveMaxFree && X.max_free > 0;
-    // TC2LI_BA_DEVICE_LM=0: the Levenberg-Marquardt decisions of rounds 2-5, on the host between the phases.  Default (round 6): on
-    // the device (ba_device.hpp: BaLmState) for every batch whose reduced systems the solve kernel takes: at most kSolveMaxFree free keyframes.
-    const bool device_lm = opt.device_lm && X.max_free <= kSolveMaxFree;
-    if (device_lm && (C.d_lm.ensure(n) != hipSuccess || C.h_lm_init.ensure(n) != hipSuccess || C.h_lm.ensure(n) != hipSuccess || C.h_stop.ensure(n) != hipSuccess)) return false;
-    auto fill_slot = [&](int i) {
-        LockstepWindow& w = W[i];
-        BaBatchSlot& s = h_slots[i];
-        s.pb = w.vp.pb;
-        s.lm = nullptr; s.lm_host = nullptr; s.stop_host = nullptr; s.lidar_JH = nullptr; s.lambda_init = w.p->lambda_init; s.lidar_information = 0;
-        s.iterations = w.p->iterations; s.lm_pad_ = 0;
-        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
-        double* sc = w.ws->h_scal.p;
-        s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
-        s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
-        s.hpp_out = w.lidar ? w.ws->h_Hpp.p : nullptr;  // written when a phase asks for it (kBaWantHpp)
-        s.iposes_host = nullptr;
-        s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
-        if (dev_solve) {
-            const size_t nn = (size_t)w.vp.np * w.vp.np;
-            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = w.ws->h_bs.p + w.vp.np;
-            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = w.ws->h_xp.p; s.ok_host = w.ws->h_ok.p;
-            if (w.lidar) { s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn; }
-        }
-        if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
-        if (device_lm) {
-            // everything a phase leaves for the next one stays in device memory; the decide kernel mirrors the window's state to the host
-            const size_t nn = (size_t)w.vp.np * w.vp.np;
-            double* sc = w.ws->d_scal.p;
-            s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
-            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = nullptr; s.hpp_out = nullptr;
-            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = nullptr;
-            s.lm = C.d_lm.p + i; s.lm_host = C.h_lm.p + i; s.stop_host = C.h_stop.p + i;
-            s.ok_host = &s.lm->solve_ok;
-            if (w.lidar) {
-                s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn;
-                s.balm.out = w.ws->d_balm_out.p;
-                s.lidar_JH = w.ws->d_lidar_JH.p;
-                s.lidar_information = w.lidar->information;
-            }
-            BaLmState& m = C.h_lm_init.p[i];
-            m = BaLmState{};
-            m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
-            m.status = w.wants_iteration() ? kLmIterate : kLmDone;
-            C.h_lm.p[i] = m;
-            C.h_stop.p[i] = 0;
-        }
-    };
-    // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
-    // (a pool dispatch costs more than it saves, and far more on a busy host)
-    auto phase_for = [&](int cnt, const std::function<void(int)>& fn) { pool.parallel_for(cnt, fn); };
-    bool failed = false;
-    // the table and everything the setup deferred (uploads, operand fills): one launch; the windows' megabyte input blocks go through the copy engines (launch_copy_tasks)
-    {
-        for (int i = 0; i < n; ++i)
-            if (W[i].rc >= 0) fill_slot(i);
-            else { h_slots[i] = BaBatchSlot{}; if (device_lm) { C.h_lm_init.p[i] = BaLmState{}; C.h_lm.p[i] = BaLmState{}; C.h_stop.p[i] = 0; } }
-        size_t n_tasks = device_lm ? 2 : 1, max_bytes = std::max(table_bytes, device_lm ? (size_t)n * sizeof(BaLmState) : (size_t)0);
-        for (const auto& d : deferred) n_tasks += d.size();
-        if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
-        size_t at = 0;
-        C.h_tasks.p[at++] = CopyTask{C.d_table.p, C.h_table.p, table_bytes};
-        if (device_lm) C.h_tasks.p[at++] = CopyTask{C.d_lm.p, C.h_lm_init.p, (size_t)n * sizeof(BaLmState)};
-        for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-        launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-    }
-    // the steps of a trial phase: window k of `step` at h_xp_area + k * kXpStride, up through a one-entry k_copy_tasks launch on the group's
-    // own stream (not hipMemcpyAsync: the runtime's copy path is where the other groups' 1.4 MB window blocks are queued)
-    // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
-    // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
-    // 28.6-29.1 ms per step against the one-entry k_copy_tasks launch of rounds 3-4)
-    constexpr bool xp_pinned = true;
-    auto stage_steps = [&](const std::vector<int>& step) {
-        for (size_t k = 0; k < step.size(); ++k) {
-            const LockstepWindow& w = W[step[k]];
-            if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
-            memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
-        }
-        if (xp_pinned) return;  // the trial kernels read the steps where they are
-        if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
-        C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
-        launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
-    };
-    auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
-    auto pieces_for = [&](const std::vector<int>& list, int expect, auto&& fn) { for_phase_pieces(d_table, (const double*)nullptr, W, list, fn, expect); };
-    // (the group's thread spins on its stream between the phases: sleeping on a blocking event instead was measured in round 4 -- the same host
-    // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
-    auto sync = [&] { if (hipGetLastError() != hipSuccess || (device_lm ? stream_wait_blocking(st) : hipStreamSynchronize(st)) != hipSuccess) failed = true; };
-
-    // ---- device-side LM: rounds queued ahead of the device, one status read per window and round ----
-    // A round = [linearisation set: the windows in kLmIterate | trial set: the windows in kLmTrial]; a window that accepted its step takes both
-    // halves of the next round, one that rejected it only the second, each at its own pace.  The host's lists are what it last SAW alive -- a
-    // superset: the kernels themselves skip a window whose status is not the launch's -- so round r + 1 is queued before round r has been
-    // waited for and the device never idles on the host; the wait is a sleeping one (no spinning thread per group: 2.8 of the 13 CPUs the
-    // loop kept busy in round 5), and the reduced solves, the LiDAR term's change of variables and the LM bookkeeping (5.3 more) are gone
-    // from the pool threads.  The caller's stop flag is polled at every round and handed to the decide kernel through a pinned word.
-    if (device_lm) {
-        for (hipEvent_t& e : C.round_done)
-            if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = true; }
-        std::vector<int> live, live_lidar;
-        bool first_maxdiag = false;
-        BaBatchExtent XL = X;   // the extent of the windows still alive (the batch's fusion switches stay: a window's sums keep their order)
-        auto refresh = [&] {
-            const size_t before = live.size();
-            live.clear(); live_lidar.clear();
-            for (int i = 0; i < n; ++i)
-                if (W[i].rc >= 0 && C.h_lm.p[i].status != kLmDone) { live.push_back(i); if (W[i].lidar) live_lidar.push_back(i); }
-            if (live.size() != before && !live.empty()) {
-                XL = batch_extent(W, live);
-                XL.fuse_trial = X.fuse_trial; XL.fuse_linearize = X.fuse_linearize; XL.inertial = X.inertial;
-            }
-        };
-        refresh();
-        for (int i : live) first_maxdiag |= !(W[i].p->lambda_init > 0);
-        int queued = 0, seen = 0;
-        auto queue_round = [&] {
-            const double tq = now();
-            const bool first = queued == 0;
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, first && first_maxdiag, st); });
-            pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) {
-                if (first) balm_batch_launch_residual(ph, cnt, false, st);  // later the accepted estimate is the last trial: its residual and decompositions are in place
-                balm_batch_launch_hessian(ph, cnt, XL, st);
-            });
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, XL, st);
-                ba_batch_launch_solve(ph, cnt, XL, st);
-                ba_batch_launch_trial(ph, cnt, XL, st);
-            });
-            if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
-            if (hipGetLastError() != hipSuccess || hipEventRecord(C.round_done[queued & 1], st) != hipSuccess) failed = true;
-            ++queued;
-            tm[6] += now() - tq;  // the host's time to queue the rounds
-        };
-        t0 = now();
-        while (!live.empty() && !failed) {
-            if (queued == seen) queue_round();
-            // one round ahead while some window cannot be finished by what is queued (it has iterations left even if every queued trial is accepted)
-            if (!failed && queued - seen < 2) {
-                bool more = false;
-                for (int i : live) more |= C.h_lm.p[i].it + (queued - seen) < W[i].p->iterations;
-                if (more) queue_round();
-            }
-            if (failed || event_wait_sleeping(C.round_done[seen & 1]) != hipSuccess) { failed = true; break; }
-            ++seen;
-            for (int i : live) if (W[i].stopped()) C.h_stop.p[i] = 1;
-            refresh();
-        }
-        if (!failed && queued > seen && event_wait_sleeping(C.round_done[(queued - 1) & 1]) != hipSuccess) failed = true;  // (a round queued ahead that found nothing to do)
-        tm[1] += now() - t0;
-        for (int i = 0; i < n && !failed; ++i) {
-            LockstepWindow& w = W[i];
-            if (w.rc < 0) continue;
-            const BaLmState& m = C.h_lm.p[i];
-            w.lambda = m.lambda; w.currentChi = m.currentChi; w.done = m.done; w.it = m.it; w.trials_total = m.trials_total; w.parity = m.parity;
-            if (m.parity) { std::swap(w.vp.pb.poses, w.vp.pb.poses_trial); std::swap(w.vp.pb.points, w.vp.pb.points_trial); }
-            if (w.p->stats && m.done > 0) { w.p->stats->initial_chi2 = m.initial_chi2; w.p->stats->final_chi2 = m.currentChi; w.p->stats->final_lambda = m.lambda; }
-            if (w.lidar) { w.lidar->error = m.lidar_error; w.lidar->hessian_evaluations = m.hessian_evaluations; }
-        }
-    }
-    for (; !device_lm;) {
-        std::vector<int> active, with_lidar;
-        for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
-        if (active.empty() || failed) break;
-        // ---- phase A: linearisation at the accepted estimate ----
-        t0 = now();
-        bool any_maxdiag = false;
-        for (int i : active) {
-            LockstepWindow& w = W[i];
-            w.want_maxdiag = w.it == 0 && !(w.p->lambda_init > 0);
-            w.need_diag = w.lidar && w.want_maxdiag && w.vp.n_free > 0;
-            any_maxdiag |= w.want_maxdiag;
-            if (w.lidar) with_lidar.push_back(i);
-        }
-        pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, any_maxdiag, st); });
-        // (running the LiDAR kernels on a second stream of the group beside the visual ones -- fork / join by events around the plane
-        // Hessian and around the planes' residual of a trial -- was measured twice: round 3 with the BA stage alone, no gain; round 4 in
-        // the whole loop, three A/B pairs in one call: 30.2-30.5 ms per step against 28.8-29.5 without: the events' cross-stream waits cost
-        // more than the overlap of two short kernels brings)
-        // the residual pass at the accepted estimate: only before the first iteration -- later the accepted estimate is the last
-        // trial, whose residual and plane decompositions are still in place (same bits)
-        bool first_pass = false;
-        for (int i : with_lidar) first_pass |= W[i].it == 0;
-        pieces(with_lidar, nullptr, [&](const BaPhase& ph, int cnt) {
-            if (first_pass) balm_batch_launch_residual(ph, cnt, false, st);
-            balm_batch_launch_hessian(ph, cnt, X, st);
-        });
-        // Round 5: the first trial's Schur product does not wait for the host -- its operands are the linearisation's, its damping the window's
-        // current lambda (known unless this is the first iteration of a window whose lambda comes from computeLambdaInit) -- so it is queued
-        // behind the linearisation and the phase's one synchronisation covers both: a host round trip fewer per iteration, and the host's part
-        // of the linearisation (the LiDAR term's change of variables) runs beside the product.  TC2LI_BA_PRE_SCHUR=0: queued after the host's part.
-        constexpr bool kPreSchur = true;
-        bool pre_schur = kPreSchur && !dev_solve && !any_maxdiag;
-        if (pre_schur) {
-            for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
-            pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-        }
-        tm[6] += now() - t0;  // of the phase: the time to queue it
-        sync();
-        if (failed) break;
-        tm[1] += now() - t0; t0 = now();
-        phase_for((int)active.size(), [&](int k) {
-            LockstepWindow& w = W[active[k]];
-            const int np = w.vp.np;
-            const double* sc = w.ws->h_scal.p;
-            w.currentChi = sc[0];
-            w.max_pose_diag = sc[2];
-            if (w.lidar) {
-                w.lidar->finish_error();
-                w.currentChi = w.lidar->chi2() + w.currentChi;
-                w.lidar->finish_linearization();
-                std::fill(w.Hl, w.Hl + (size_t)np * np, 0.0);
-                std::fill(w.bl_, w.bl_ + np, 0.0);
-                w.lidar->add_quadratic_form(w.vp.pose_var.data(), np, w.Hl, w.bl_);
-                if (w.need_diag) {
-                    static const int dpos[6] = {0, 6, 11, 15, 18, 20};
-                    w.max_pose_diag = 0;
-                    for (int j = 0; j < np; ++j)
-                        w.max_pose_diag = std::max(w.max_pose_diag, std::fabs(w.ws->h_Hpp.p[27 * (size_t)(j / 6) + dpos[j % 6]] + w.Hl[(size_t)j * np + j]));
-                }
-            }
-            w.tempChi = w.currentChi;
-            w.iniChi = w.currentChi;
-            if (w.it == 0) {
-                if (w.p->stats) w.p->stats->initial_chi2 = w.currentChi;
-                w.lambda = w.p->lambda_init > 0 ? w.p->lambda_init : 1e-5 * std::max(sc[1], w.max_pose_diag);
-                w.ni = 2;
-                w.n_bad = 0;
-            }
-            w.rho = 0;
-            w.qmax = 0;
-        });
-        if (dev_solve && !with_lidar.empty()) {  // the LiDAR term of this linearisation goes where the solve kernel adds it (one launch)
-            if (C.h_tasks.ensure(with_lidar.size()) != hipSuccess) { failed = true; break; }
-            size_t max_bytes = 0;
-            for (size_t k = 0; k < with_lidar.size(); ++k) {
-                LockstepWindow& w = W[with_lidar[k]];
-                const size_t bytes = ((size_t)w.vp.np * w.vp.np + w.vp.np) * sizeof(double);
-                C.h_tasks.p[k] = CopyTask{w.ws->d_Hl.p, w.ws->h_Hl.p, bytes};
-                max_bytes = std::max(max_bytes, bytes);
-            }
-            launch_copy_tasks(C.h_tasks.p, (int)with_lidar.size(), max_bytes, st);
-        }
-        // ---- trials ----
-        tm[2] += now() - t0;
-        std::vector<int> trial = active;
-        while (!trial.empty() && !failed) {
-            // phase B: reduced camera system at the window's lambda
-            t0 = now();
-            if (dev_solve) {
-                // phases B + C in one queue: Schur product, solve, trial estimate and its cost; the host sees the step, whether the
-                // factorisation went through, and the sums at the one synchronisation
-                std::vector<int> trial_lidar;
-                for (int i : trial) if (W[i].lidar) trial_lidar.push_back(i);
-                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) {
-                    ba_batch_launch_schur(ph, cnt, X, st);
-                    ba_batch_launch_solve(ph, cnt, X, st);
-                    ba_batch_launch_trial(ph, cnt, X, st);
-                });
-                if (X.any_trial_unfused) pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
-                sync();
-                if (failed) break;
-                tm[3] += now() - t0; t0 = now();
-                for (int i : trial) {
-                    LockstepWindow& w = W[i];
-                    const int np = w.vp.np;
-                    BaWorkspace& ws = *w.ws;
-                    w.ok2 = np == 0 || ws.h_ok.p[0] != 0;
-                    w.scale = 0;
-                    // pose part of computeScale(): b_p (+ the LiDAR gradient) as the host path has it in h_bs[np .. 2 np)
-                    for (int j = 0; j < np; ++j) {
-                        const double bpj = w.lidar ? ws.h_bs.p[np + j] + w.bl_[j] : ws.h_bs.p[np + j];
-                        w.scale += ws.h_xp.p[j] * (w.lambda * ws.h_xp.p[j] + bpj);
-                    }
-                }
-                tm[4] += now() - t0; t0 = now();
-            } else {
-            if (pre_schur) pre_schur = false;  // (the product of this trial came with the linearisation)
-            else {
-                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-                sync();
-                if (failed) break;
-            }
-            tm[3] += now() - t0; t0 = now();
-            phase_for((int)trial.size(), [&](int k) {
-                LockstepWindow& w = W[trial[k]];
-                const int np = w.vp.np;
-                BaWorkspace& ws = *w.ws;
-                w.ok2 = true;
-                if (np > 0) {
-                    memcpy(w.Swork.data(), ws.h_S.p, (size_t)np * np * sizeof(double));
-                    if (w.lidar) {
-                        for (size_t q = 0; q < (size_t)np * np; ++q) w.Swork[q] += w.Hl[q];
-                        for (int j = 0; j < np; ++j) { ws.h_bs.p[j] += w.bl_[j]; ws.h_bs.p[np + j] += w.bl_[j]; }
-                    }
-                    w.ok2 = ldlt_solve_small(w.Swork.data(), np, ws.h_bs.p, w.x.data(), false);
-                    memcpy(ws.h_xp.p, w.x.data(), np * sizeof(double));
-                }
-                w.scale = 0;
-                for (int j = 0; j < np; ++j) w.scale += w.x[j] * (w.lambda * w.x[j] + ws.h_bs.p[np + j]);
-            });
-            // phase C: the trial estimate and its cost
-            tm[4] += now() - t0; t0 = now();
-            std::vector<int> step, step_lidar;
-            for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
-            if (!step.empty()) {
-                stage_steps(step);
-                pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
-                if (X.any_trial_unfused) pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
-                sync();
-                if (failed) break;
-            }
-            }
-            tm[5] += now() - t0; t0 = now();
-            std::vector<int> again;
-            for (int i : trial) {
-                LockstepWindow& w = W[i];
-                if (w.ok2) {
-                    const double* sc = w.ws->h_scal.p;
-                    w.tempChi = sc[4];
-                    w.scale += sc[3];
-                    if (w.lidar) { w.lidar->finish_error(); w.tempChi = w.lidar->chi2() + w.tempChi; }
-                } else {
-                    w.tempChi = std::numeric_limits<double>::max();
-                }
-                w.rho = w.currentChi - w.tempChi;
-                w.scale += 1e-3;
-                w.rho /= w.scale;
-                if (w.rho > 0 && std::isfinite(w.tempChi)) {
-                    w.lambda = lm_lambda_accepted(w.lambda, w.rho);
-                    w.ni = 2;
-                    w.currentChi = w.tempChi;
-                    std::swap(w.vp.pb.poses, w.vp.pb.poses_trial);  // the host's record (the results are read through it); the device's view: parity
-                    std::swap(w.vp.pb.points, w.vp.pb.points_trial);
-                    w.parity ^= 1;
-                } else {
-                    w.lambda *= w.ni;
-                    w.ni *= 2;
-                }
-                w.qmax++;
-                w.trials_total++;
-                if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
-            }
-            trial.swap(again);
-        }
-        for (int i : active) {
-            LockstepWindow& w = W[i];
-            ++w.done;
-            ++w.it;
-            if (w.p->stats) { w.p->stats->final_chi2 = w.currentChi; w.p->stats->final_lambda = w.lambda; }
-            if (w.qmax == 10 || w.rho == 0) { w.ok = false; continue; }
-            if ((w.iniChi - w.currentChi) * 1e3 < w.iniChi) w.n_bad++; else w.n_bad = 0;
-            if (w.n_bad >= 3) w.ok = false;
-        }
-    }
-    // ---- results ----
-    t0 = now();
-    std::vector<int> all;
-    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) all.push_back(i);
-    if (!failed && !all.empty()) {
-        pieces(all, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_depth(ph, cnt, X, st); });
-        // device -> pinned staging: one launch writes every window's results (the setup's copy list is done with: the stream has been
-        // synchronised many times since), then the copies into the caller's arrays run in parallel
-        size_t n_tasks = 0, max_bytes = 0;
-        if (C.h_tasks.ensure(4 * all.size()) != hipSuccess) failed = true;
-        for (int i : all) {
-            if (failed) break;
-            LockstepWindow& w = W[i];
-            const tc2li_ba_problem& p = *w.p;
-            const BaProblemDev& pb = w.vp.pb;
-            const size_t E = p.n_edges, P = p.n_points;
-            const size_t bytes = p.n_poses * sizeof(Se3) + 3 * P * sizeof(double) + E * sizeof(double) + E;
-            if (w.ws->h_result.ensure(bytes) != hipSuccess) { failed = true; break; }
-            uint8_t* h = w.ws->h_result.p;
-            uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
-            auto add = [&](void* dst, const void* src, size_t nbytes) { C.h_tasks.p[n_tasks++] = CopyTask{dst, src, nbytes}; max_bytes = std::max(max_bytes, nbytes); };
-            add(h, pb.poses, p.n_poses * sizeof(Se3));
-            add(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double));
-            if (p.edge_chi2) add(hc, w.ws->d_chi2.p, E * sizeof(double));
-            if (p.edge_depth_positive) add(hc + E * sizeof(double), w.ws->d_depth.p, E);
-        }
-        if (!failed) launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-        sync();
-        if (!failed)
-            pool.parallel_for((int)all.size(), [&](int k) {
-                LockstepWindow& w = W[all[k]];
-                const tc2li_ba_problem& p = *w.p;
-                const size_t E = p.n_edges, P = p.n_points;
-                const uint8_t* h = w.ws->h_result.p;
-                memcpy(w.vp.poses.data(), h, p.n_poses * sizeof(Se3));
-                memcpy(p.points3, h + p.n_poses * sizeof(Se3), 3 * P * sizeof(double));
-                const uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
-                if (p.edge_chi2) memcpy(p.edge_chi2, hc, E * sizeof(double));
-                if (p.edge_depth_positive) memcpy(p.edge_depth_positive, hc + E * sizeof(double), E);
-            });
-    }
-    for (int i = 0; i < n; ++i) {
-        LockstepWindow& w = W[i];
-        if (w.rc < 0) { results[i] = w.rc; continue; }
-        if (failed) { set_error("tc2li_local_bundle_adjustment_batch: HIP error in the lock-step loop: %s", hipGetErrorString(hipGetLastError())); results[i] = TC2LI_ERR_HIP; continue; }
-        const tc2li_ba_problem& p = *w.p;
-        for (int k = 0; k < p.n_poses; ++k) { memcpy(p.poses7 + 7 * k, w.vp.poses[k].q, 4 * sizeof(double)); memcpy(p.poses7 + 7 * k + 4, w.vp.poses[k].t, 3 * sizeof(double)); }
-        if (p.stats) { p.stats->iterations = w.done; p.stats->trials = w.trials_total; p.stats->n_free_poses = w.vp.n_free; }
-        if (w.lidar && p.lidar_stats) {
-            p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = w.lidar->hessian_evaluations;
-            p.lidar_stats->residual = w.lidar->error; p.lidar_stats->chi2 = w.lidar->chi2();
-        }
-        results[i] = w.done;
-    }
-    if (kTiming) fprintf(stderr, "BA lock-step timing ms (%d windows): setup %.3f linearize %.3f (queueing %.3f) host-lin %.3f schur %.3f solve %.3f trial %.3f results %.3f total %.3f\n",
-                         n, tm[0], tm[1], tm[6], tm[2], tm[3], tm[4], tm[5], now() - t0, now() - t_begin);
-    return true;
-}
-
-
-// ---- The bundle-adjustment ENGINE: continuous admission (round 6) -------------------------------------------------------------------------
-// The batch entry points above are calls: a call's windows are set up together, optimised together and handed back together -- a group
-// returns when its SLOWEST window is done (a window whose steps keep being rejected needs up to 26 rounds where the others need 10), and
-// the setup of the next call starts only then.  With the Levenberg-Marquardt decisions on the device (BaLmState) a round no longer cares
-// which call a window came with or how far it has got: every batched kernel runs for the windows whose status asks for it.  The engine keeps
-// ONE stream of rounds going and lets windows in and out at the round boundaries:
-//   submit    hands over windows (a ticket); they wait in a queue
-//   tick      (engine thread) windows whose result copies have landed are finished and their slots freed; windows whose plane extraction
-//             has run get their table entry and state and are LIVE from this round on; new windows from the queue go to free slots (best
-//             fit: the work space that has held the smallest window at least as large) and are set up on the SETUP THREADS beside the rounds;
-//             windows whose setup is done are staged a few at a time (clouds up, plane extraction queued); windows the last mirror shows
-//             as done are RETIRED (depth flags, result copies queued); then the next round is queued for everything alive, and the tick
-//             waits for the round BEFORE it -- one round is always in flight while the host works
-//   wait      blocks until a ticket's windows have all been finished (poll: without blocking)
-// Same kernels, same per-window arithmetic: a window's bits are those of the batch calls (tests/test_balm_gpu.py).  Work spaces grow
-// through a per-engine BufferCache (common.hpp): hipFree would wait for the whole device every time a slot meets a larger window.
-// Measured against the alternatives in DESIGN.md section 4, round 6 item 5: the engines are the best form of local mapping from 512 sequences
-// per GPU on; below that four mapping workers that each take a whole step's windows as one group call are ahead.
-enum { kSlotFree = 0, kSlotStaged = 1, kSlotLive = 2, kSlotRetiring = 3, kSlotSetup = 4 };
-struct EngineTicket {
-    double t_submit = 0;
-    const tc2li_ba_problem* problems = nullptr;
-    int32_t* results = nullptr;
-    int n = 0, next = 0, remaining = 0, n_ok = 0;
-    int64_t id = 0;
-};
-struct EngineSlot {
-    int state = kSlotFree, index = 0, rc_lidar = 0;
-    std::atomic<int> setup_left{0};   // the window's setup tasks (structure + staging; LiDAR window) still running on the setup threads
-    double t_submit = 0, t_admit = 0, t_ready = 0, t_staged = 0, t_live = 0, t_retire = 0;   // TC2LI_BA_TIMING: where a window's time goes
-    long ready_tick = 0;              // > 0: the tick its setup was first seen finished (it waits to be staged with others)
-    long side_tick = 0;               // > 0: the tick whose plane-extraction launch (on the engine's side stream) the window waits for
-    long seq = 0;               // the event (tick) whose completion means the work queued for this state has run
-    int cap[6] = {0, 0, 0, 0, 0, 0};  // the largest window its work space has held: poses, points, edges, LiDAR keyframes, cloud points, free poses
-    EngineTicket* ticket = nullptr;
-    std::vector<CopyTask> deferred_vis, deferred_lidar;
-};
-struct EngineStaging {  // pinned staging of one tick's launches (two sets, by tick parity: a set is rewritten when its tick's round has been waited for)
-    PinnedBuf<BalmCutTask> h_cut_list;
-    DevBuf<BalmCutTask> d_cut_list;
-    PinnedBuf<CopyTask> h_copies_a, h_copies_b, h_copies_r;
-};
-
-}  // namespace
-
-struct tc2li_ba_engine {
-    tc2li_camera cam{};
-    int capacity = 0, device = 0;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<EngineTicket*> queue;                          // tickets with windows still to admit
-    std::map<int64_t, std::unique_ptr<EngineTicket>> open;    // every ticket not yet collected by tc2li_ba_engine_wait
-    int64_t next_id = 1;
-    bool quit = false;
-    int failed = 0;                                           // a HIP error in the engine thread: every window ends with TC2LI_ERR_HIP
-    std::string error;
-    std::thread th;
-    BufferCache cache;                                        // declared before everything that owns buffers: destroyed after them
-    // ---- engine thread only ----
-    LockstepContext C;
-    EngineStaging S[2];
-    std::vector<EngineSlot> slots;
-    std::vector<LockstepWindow> W;
-    std::unique_ptr<WorkerPool> pool;
-    long tick = 0;
-    int busy = 0;                                             // slots not free
-    // The plane extraction of newly admitted windows (their clouds up, six kernels of 0.3-0.5 ms together) sits between two rounds of
-    // everything alive when it is queued in the main stream.  TC2LI_BA_ENGINE_SIDE=1 queues it on a SIDE stream of the engine instead (one event
-    // per tick parity; a parity's staging buffers and event are reused only when its last launch has completed).  Measured, three engines,
-    // frames/s main -> side: 512 sequences 20.3-20.6 k -> 19.7-20.3 k, 256: 16.8-17.2 k -> 17.8-18.5 k, 128: 14.8-15.2 k -> 14.4-14.6 k -- with
-    // the side streams the LiDAR thread's step grows from 16-18 to 25 ms at 512 (the process's streams share four hardware queues, and the
-    // long single-workgroup sort of the extraction then sits in front of another stage's kernels): off by default.
-    hipStream_t side = nullptr;
-    bool use_side = false;
-    // TC2LI_BA_ENGINE_STAGE="min,wait": windows staged together / ticks one waits at most.  Measured, three engines, frames/s at "1,0" / "4,2" /
-    // "8,3": 512 sequences 20.4-20.6 k / 20.5-20.7 k / 20.7-20.9 k; 256: 17.4-17.7 / 17.7-17.8 / 17.7-18.0; 128: 14.7-15.3 / 15.3-15.7 / 15.2-15.5
-    int stage_min = 8, stage_wait = 3;
-    hipEvent_t side_ev[2] = {nullptr, nullptr};
-    long side_last[2] = {0, 0};                               // the tick of the last launch recorded on side_ev[parity] (0: none)
-    bool side_done(int par) { return side_last[par] == 0 || hipEventQuery(side_ev[par]) == hipSuccess; }
-    ~tc2li_ba_engine() {
-        for (hipEvent_t e : side_ev) if (e) (void)hipEventDestroy(e);
-        if (side) (void)hipStreamDestroy(side);
-    }
-    // ---- the setup threads: a window's host-side setup runs beside the rounds of the others ----
-    std::mutex smu;
-    std::condition_variable scv;
-    std::deque<int> setup_queue;                              // 2 * slot + (0: structure and staging, 1: LiDAR window)
-    bool setup_quit = false;
-    std::vector<std::thread> setup_threads;
-    std::atomic<long> setup_us[2] = {{0}, {0}}, setup_n[2] = {{0}, {0}};   // (TC2LI_BA_TIMING) time inside the two kinds of setup task
-    void run();
-    void finish_window(int s, int rc);
-    void setup_task(int task);
-    void setup_loop();
-};
-
-
-void tc2li_ba_engine::finish_window(int s, int rc) {
-    EngineSlot& sl = slots[s];
-    EngineTicket* t = sl.ticket;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        t->results[sl.index] = rc;
-        if (rc >= 0) ++t->n_ok;
-        if (--t->remaining == 0) cv_done.notify_all();
-    }
-    sl.state = kSlotFree; sl.ticket = nullptr; sl.deferred_vis.clear(); sl.deferred_lidar.clear();
-    --busy;
-}
-
-void tc2li_ba_engine::setup_task(int task) {
-    hipStream_t st = C.st;
-    const int s = task >> 1;
-    EngineSlot& sl = slots[s];
-    LockstepWindow& w = W[s];
-    const tc2li_ba_problem& p = sl.ticket->problems[sl.index];
-    const bool args_ok = p.poses7 && p.fixed && p.points3 && p.edges && p.n_poses > 0 && p.n_points > 0 && p.n_edges > 0 && p.iterations >= 0;
-    bool lidar_ok = true;
-    if (args_ok && p.lidar) {
-        if (p.lidar->n_keyframes < 1 || p.lidar->n_keyframes > 7 || !p.lidar->pose_index) lidar_ok = false;
-        else for (int k = 0; k < p.lidar->n_keyframes; ++k) if (p.lidar->pose_index[k] < 0 || p.lidar->pose_index[k] >= p.n_poses) lidar_ok = false;
-    }
-    if (task & 1) {
-        if (!args_ok || !lidar_ok || !p.lidar) return;
-        CopySink sink(&sl.deferred_lidar);
-        sl.rc_lidar = C.ws[s]->lidar.build(p.poses7, p.n_poses, p.lidar, st, &C.h_cut.p[s]);
-        return;
-    }
-    CopySink sink(&sl.deferred_vis);
-    w.p = &p; w.ws = C.ws[s].get();
-    if (!args_ok) { set_error("tc2li_ba_engine: invalid window"); w.rc = TC2LI_ERR_INVALID; return; }
-    if (!lidar_ok) { set_error("tc2li_ba_engine: a LiDAR window of 1 .. 7 keyframes with pose_index in range"); w.rc = TC2LI_ERR_INVALID; return; }
-    if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
-    if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
-    if (p.lidar) {
-        w.extra_used.assign(p.n_poses, 0);
-        for (int k = 0; k < p.lidar->n_keyframes; ++k) w.extra_used[p.lidar->pose_index[k]] = 1;
-    }
-    w.rc = w.vp.setup(*w.ws, p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, &cam, w.extra_used.empty() ? nullptr : w.extra_used.data(), st);
-    if (w.rc < 0) return;
-    BaWorkspace& ws = *w.ws;
-    const size_t nn = (size_t)std::max(w.vp.np * w.vp.np, 1), n1 = (size_t)std::max(w.vp.np, 1), E = p.n_edges, P = p.n_points;
-    bool ok = ws.d_S.ensure(nn) == hipSuccess && ws.d_bs.ensure(2 * n1) == hipSuccess && ws.d_xp.ensure(n1) == hipSuccess && ws.d_scal.ensure(8) == hipSuccess &&
-              ws.h_result.ensure(p.n_poses * sizeof(Se3) + 3 * P * sizeof(double) + E * sizeof(double) + E) == hipSuccess;
-    if (ok && p.lidar) {
-        const size_t nl = 6 * (size_t)p.lidar->n_keyframes;
-        ok = ws.d_Hl.ensure(nn + n1) == hipSuccess && ws.d_balm_out.ensure((size_t)balm_out_size(p.lidar->n_keyframes)) == hipSuccess && ws.d_lidar_JH.ensure(nl + nl * nl) == hipSuccess;
-    }
-    if (!ok) w.rc = TC2LI_ERR_HIP;
-}
-void tc2li_ba_engine::setup_loop() {
-    (void)pthread_setname_np(pthread_self(), "tc2li-ba-setup");
-    (void)hipSetDevice(device);
-    BufferCacheScope cached(&cache);
-    for (;;) {
-        int task;
-        {
-            std::unique_lock<std::mutex> lk(smu);
-            scv.wait(lk, [&] { return setup_quit || !setup_queue.empty(); });
-            if (setup_queue.empty()) return;
-            task = setup_queue.front(); setup_queue.pop_front();
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        setup_task(task);
-        setup_us[task & 1].fetch_add((long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
-        setup_n[task & 1].fetch_add(1, std::memory_order_relaxed);
-        slots[task >> 1].setup_left.fetch_sub(1, std::memory_order_release);
-    }
-}
-
-void tc2li_ba_engine::run() {
-    (void)pthread_setname_np(pthread_self(), "tc2li-ba-engine");
-    (void)hipSetDevice(device);
-    BufferCacheScope cached(&cache);
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; failed = 1; }
-        for (hipEvent_t& e : C.round_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
-        use_side = getenv("TC2LI_BA_ENGINE_SIDE") && atoi(getenv("TC2LI_BA_ENGINE_SIDE")) != 0;
-        if (const char* e = getenv("TC2LI_BA_ENGINE_STAGE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 0) { stage_min = a; stage_wait = b; } }
-        if (use_side && hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi) != hipSuccess && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; failed = 1; }
-        for (hipEvent_t& e : side_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; failed = 1; }
-    }
-    hipStream_t st = C.st;
-    const int cap = capacity;
-    const size_t table_bytes = (size_t)cap * sizeof(BaBatchSlot);
-    if (C.d_table.ensure(table_bytes) != hipSuccess || C.h_table.ensure(table_bytes) != hipSuccess || C.d_lm.ensure(cap) != hipSuccess || C.h_lm_init.ensure(cap) != hipSuccess ||
-        C.h_lm.ensure(cap) != hipSuccess || C.h_stop.ensure(cap) != hipSuccess || C.h_cut.ensure(cap) != hipSuccess) failed = 1;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
-    const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
-    if (!failed) {
-        memset(C.h_table.p, 0, table_bytes);
-        for (int s = 0; s < cap; ++s) { C.h_lm.p[s] = BaLmState{}; C.h_stop.p[s] = 0; C.h_cut.p[s].n_points = 0; }
-    }
-    while ((int)C.ws.size() < cap) C.ws.emplace_back(new BaWorkspace());
-    const bool kTiming = BaOptions::read().timing;
-    double lat[6] = {0}; long n_lat = 0;
-    double tm[8] = {0}; long n_live_sum = 0, n_windows = 0, n_ticks = 0; const long allocs0 = g_buffer_allocs.load();
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_lap = 0;
-    auto lap = [&](int k) { if (kTiming) { const double t = now(); tm[k] += t - t_lap; t_lap = t; } };
-    long recorded = 0, waited = 0;   // one event per tick (tick t records event t); `waited`: every event up to it has completed
-    auto pieces_for = [&](const std::vector<int>& list, int expect, auto&& fn) { for_phase_pieces(d_table, (const double*)nullptr, W, list, fn, expect); };
-    for (;;) {
-        {   // ---- sleep while there is nothing to do ----
-            std::unique_lock<std::mutex> lk(mu);
-            cv_work.wait(lk, [&] { return quit || !queue.empty() || busy > 0; });
-            if (quit && queue.empty() && busy == 0) break;
-        }
-        ++tick;
-        if (kTiming) { t_lap = now(); ++n_ticks; }
-        EngineStaging& G = S[tick & 1];
-        bool queued_any = false;
-        int n_in_setup = 0, n_waiting_side = 0;
-        // ---- 1. windows whose result copies have landed (the event of the tick that queued them has been waited for) ----
-        {
-            std::vector<int> done;
-            for (int s = 0; s < cap; ++s) if (slots[s].state == kSlotRetiring && slots[s].seq <= waited) done.push_back(s);
-            if (!done.empty()) {
-                pool->parallel_for((int)done.size(), [&](int k) {
-                    LockstepWindow& w = W[done[k]];
-                    const tc2li_ba_problem& p = *w.p;
-                    const size_t E = p.n_edges, P = p.n_points;
-                    const uint8_t* h = w.ws->h_result.p;
-                    memcpy(w.vp.poses.data(), h, p.n_poses * sizeof(Se3));
-                    for (int q = 0; q < p.n_poses; ++q) { memcpy(p.poses7 + 7 * q, w.vp.poses[q].q, 4 * sizeof(double)); memcpy(p.poses7 + 7 * q + 4, w.vp.poses[q].t, 3 * sizeof(double)); }
-                    memcpy(p.points3, h + p.n_poses * sizeof(Se3), 3 * P * sizeof(double));
-                    const uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
-                    if (p.edge_chi2) memcpy(p.edge_chi2, hc, E * sizeof(double));
-                    if (p.edge_depth_positive) memcpy(p.edge_depth_positive, hc + E * sizeof(double), E);
-                });
-                for (int s : done) {
-                    LockstepWindow& w = W[s];
-                    const tc2li_ba_problem& p = *w.p;
-                    const BaLmState& m = C.h_lm.p[s];
-                    if (p.stats) {
-                        p.stats->iterations = m.done; p.stats->trials = m.trials_total; p.stats->n_free_poses = w.vp.n_free;
-                        if (m.done > 0) { p.stats->initial_chi2 = m.initial_chi2; p.stats->final_chi2 = m.currentChi; p.stats->final_lambda = m.lambda; }
-                    }
-                    if (w.lidar && p.lidar_stats) {
-                        p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = m.hessian_evaluations;
-                        p.lidar_stats->residual = m.lidar_error; p.lidar_stats->chi2 = m.lidar_error * w.lidar->information * m.lidar_error;
-                    }
-                    if (kTiming) {
-                        const EngineSlot& sl = slots[s]; const double t = now();
-                        lat[0] += sl.t_admit - sl.t_submit; lat[1] += sl.t_ready - sl.t_admit; lat[2] += sl.t_staged - sl.t_ready; lat[3] += sl.t_live - sl.t_staged;
-                        lat[4] += sl.t_retire - sl.t_live; lat[5] += t - sl.t_retire; ++n_lat;
-                    }
-                    finish_window(s, failed ? (int)TC2LI_ERR_HIP : m.done);
-                }
-            }
-        }
-        lap(0);
-        if (failed) {   // nothing more is queued: every window that is still somewhere ends with the error
-            for (int s = 0; s < cap; ++s) {
-                if (slots[s].state == kSlotFree) continue;
-                while (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
-                finish_window(s, (int)TC2LI_ERR_HIP);
-            }
-            std::unique_lock<std::mutex> lk(mu);
-            while (!queue.empty()) {
-                EngineTicket* t = queue.front(); queue.pop_front();
-                for (; t->next < t->n; ++t->next) { t->results[t->next] = (int)TC2LI_ERR_HIP; --t->remaining; }
-                cv_done.notify_all();
-            }
-            continue;
-        }
-        // ---- 2. staged windows whose plane extraction has run: table entry, state, uploads; alive from this tick's round on ----
-        {
-            std::vector<CopyTask> copies;
-            size_t max_bytes = 0;
-            for (int s = 0; s < cap; ++s) {
-                EngineSlot& sl = slots[s];
-                if (sl.state != kSlotStaged) continue;
-                // (a window without planes to extract has nothing in flight: alive at the tick after its setup)
-                if (sl.side_tick && side_last[sl.side_tick & 1] == sl.side_tick && hipEventQuery(side_ev[sl.side_tick & 1]) != hipSuccess) { ++n_waiting_side; continue; }
-                LockstepWindow& w = W[s];
-                if (w.rc >= 0 && w.p->lidar) {
-                    if (sl.rc_lidar >= 0 && C.h_cut.p[s].n_points > 0) sl.rc_lidar = C.ws[s]->lidar.finish_cut(st);
-                    if (sl.rc_lidar < 0) w.rc = sl.rc_lidar; else w.lidar = &C.ws[s]->lidar;
-                }
-                C.h_cut.p[s].n_points = 0;
-                // outside the batched kernels: the one-window path, here (rare: more than kSolveMaxFree free keyframes, more than 2048 planes)
-                if (w.rc >= 0 && (w.vp.n_free > kSolveMaxFree || (w.lidar && w.lidar->n_planes > 2048))) {
-                    if (hipStreamSynchronize(st) != hipSuccess) { failed = 1; break; }
-                    const tc2li_ba_problem& p = *w.p;
-                    const int rc = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, &cam, p.iterations, p.lambda_init,
-                                                                    p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats, p.lidar, p.lidar_stats, st);
-                    finish_window(s, rc);
-                    continue;
-                }
-                if (w.rc < 0) { finish_window(s, w.rc); continue; }
-                // the slot: everything a phase leaves for the next one stays in device memory (ba_batch_lockstep's device-LM form)
-                BaBatchSlot& b = h_slots[s];
-                b = BaBatchSlot{};
-                b.pb = w.vp.pb;
-                b.lambda_init = w.p->lambda_init; b.iterations = w.p->iterations;
-                b.n_slices = w.vp.n_slices; b.k_per_slice = w.vp.k_per_slice; b.has_lidar = w.lidar != nullptr;
-                const size_t nn = (size_t)w.vp.np * w.vp.np;
-                double* sc = w.ws->d_scal.p;
-                b.chi_out = sc; b.maxdiag_out = sc + 1; b.scale_out = sc + 3; b.chi_trial_out = sc + 4;
-                b.S_out = w.ws->d_S.p; b.bs_out = w.ws->d_bs.p; b.xp = b.x_dev = w.ws->d_xp.p; b.depth_out = w.ws->d_depth.p;
-                b.lm = C.d_lm.p + s; b.lm_host = C.h_lm.p + s; b.stop_host = C.h_stop.p + s; b.ok_host = &b.lm->solve_ok;
-                if (w.lidar) {
-                    b.balm = w.lidar->dev;
-                    b.Hl = w.ws->d_Hl.p; b.bl_lidar = w.ws->d_Hl.p + nn; b.balm.out = w.ws->d_balm_out.p; b.lidar_JH = w.ws->d_lidar_JH.p;
-                    b.lidar_information = w.lidar->information;
-                }
-                BaLmState& m = C.h_lm_init.p[s];
-                m = BaLmState{};
-                m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
-                m.status = w.wants_iteration() ? kLmIterate : kLmDone;
-                C.h_lm.p[s] = m;
-                C.h_stop.p[s] = 0;
-                copies.push_back(CopyTask{C.d_table.p + (size_t)s * sizeof(BaBatchSlot), &b, sizeof(BaBatchSlot)});
-                copies.push_back(CopyTask{C.d_lm.p + s, &m, sizeof(BaLmState)});
-                for (const CopyTask& t : sl.deferred_vis) copies.push_back(t);
-                sl.deferred_vis.clear();
-                sl.state = kSlotLive; sl.seq = tick; if (kTiming) sl.t_live = now();
-            }
-            if (!failed && !copies.empty()) {
-                if (G.h_copies_b.ensure(copies.size()) != hipSuccess) failed = 1;
-                else {
-                    for (size_t k = 0; k < copies.size(); ++k) { G.h_copies_b.p[k] = copies[k]; max_bytes = std::max(max_bytes, copies[k].bytes); }
-                    launch_copy_tasks(G.h_copies_b.p, (int)copies.size(), max_bytes, st);
-                    queued_any = true;
-                }
-            }
-        }
-        lap(1);
-        // ---- 3. new windows from the queue into free slots: structure + staging on the pool, the plane extraction queued ----
-        {
-            std::vector<int> fresh, admitted;
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                // A slot's work space keeps its device and pinned buffers from window to window, and growing one is a device-wide synchronisation
-                // (hipFree): a window goes to the free slot whose work space has held the SMALLEST window at least as large in every measure
-                // (best fit); if none has, to the one that has held the largest (it grows, and there is one more large work space).
-                int n_free_slots = 0;
-                for (int s = 0; s < cap; ++s) n_free_slots += slots[s].state == kSlotFree;
-                while (n_free_slots > 0 && !queue.empty()) {
-                    EngineTicket* t = queue.front();
-                    const tc2li_ba_problem& p = t->problems[t->next];
-                    int dims[6] = {p.n_poses, p.n_points, p.n_edges, 0, 0, 0};
-                    if (p.fixed) for (int q = 0; q < p.n_poses; ++q) dims[5] += p.fixed[q] == 0;
-                    if (p.lidar && p.lidar->n_keyframes >= 1 && p.lidar->n_keyframes <= 20 && p.lidar->cloud_offsets) { dims[3] = p.lidar->n_keyframes; dims[4] = p.lidar->cloud_offsets[p.lidar->n_keyframes]; }
-                    int best = -1, largest = -1;
-                    for (int s = 0; s < cap; ++s) {
-                        if (slots[s].state != kSlotFree) continue;
-                        const int* c = slots[s].cap;
-                        if (c[0] >= dims[0] && c[1] >= dims[1] && c[2] >= dims[2] && c[3] >= dims[3] && c[4] >= dims[4] && c[5] >= dims[5] && (best < 0 || c[2] < slots[best].cap[2])) best = s;
-                        if (largest < 0 || c[2] > slots[largest].cap[2]) largest = s;
-                    }
-                    const int s = best >= 0 ? best : largest;
-                    for (int k = 0; k < 6; ++k) slots[s].cap[k] = std::max(slots[s].cap[k], dims[k]);
-                    slots[s].ticket = t; slots[s].index = t->next++; slots[s].state = kSlotSetup; slots[s].rc_lidar = 0; slots[s].ready_tick = 0;
-                    if (kTiming) { slots[s].t_submit = t->t_submit; slots[s].t_admit = now(); slots[s].t_ready = 0; }
-                    if (t->next == t->n) queue.pop_front();
-                    admitted.push_back(s);
-                    ++busy; --n_free_slots;
-                }
-            }
-            if (!admitted.empty()) {   // their setup: on the setup threads, while this thread goes on with the rounds
-                for (int s : admitted) { W[s] = LockstepWindow{}; C.h_cut.p[s].n_points = 0; slots[s].setup_left.store(2, std::memory_order_relaxed); }
-                { std::lock_guard<std::mutex> lk(smu); for (int s : admitted) { setup_queue.push_back(2 * s); setup_queue.push_back(2 * s + 1); } }
-                scv.notify_all();
-            }
-            // windows whose setup has finished: staged from this tick on -- unless this parity's staging buffers still serve a plane extraction
-            // that has not run (then at the next tick)
-            // (and, with LiDAR windows among them, only when a few have gathered or one has waited: the extraction is six launches of 0.3-0.5 ms
-            // together in front of the next round whether it serves one window or ten)
-            const int par = (int)(tick & 1);
-            if (side_done(par)) {
-                int n_ready = 0, n_ready_lidar = 0;
-                long oldest = tick;
-                for (int s = 0; s < cap; ++s)
-                    if (slots[s].state == kSlotSetup && slots[s].setup_left.load(std::memory_order_acquire) == 0) {
-                        if (!slots[s].ready_tick) { slots[s].ready_tick = tick; if (kTiming) slots[s].t_ready = now(); }
-                        ++n_ready; n_ready_lidar += C.h_cut.p[s].n_points > 0; oldest = std::min(oldest, slots[s].ready_tick);
-                    }
-                if (n_ready && (n_ready_lidar == 0 || n_ready >= stage_min || tick - oldest >= stage_wait))
-                    for (int s = 0; s < cap; ++s)
-                        if (slots[s].state == kSlotSetup && slots[s].ready_tick) { slots[s].state = kSlotStaged; slots[s].seq = tick; slots[s].side_tick = 0; slots[s].ready_tick = 0; if (kTiming) slots[s].t_staged = now(); fresh.push_back(s); }
-            }
-            n_in_setup = 0;
-            for (int s = 0; s < cap; ++s) n_in_setup += slots[s].state == kSlotSetup;
-            if (!fresh.empty()) {
-                // the extraction of the staged windows' planes: their clouds up, the cut kernels (as plane_extraction_begin), on the side stream
-                int m = 0, max_points = 0, max_table = 0;
-                size_t n_copies = 1;
-                for (int s : fresh) n_copies += slots[s].deferred_lidar.size();
-                if (G.h_cut_list.ensure(fresh.size()) != hipSuccess || G.d_cut_list.ensure(fresh.size()) != hipSuccess || G.h_copies_a.ensure(n_copies) != hipSuccess) failed = 1;
-                if (!failed) {
-                    for (int s : fresh) {
-                        const BalmCutTask& t = C.h_cut.p[s];
-                        if (t.n_points <= 0 || slots[s].rc_lidar < 0) continue;
-                        G.h_cut_list.p[m++] = t;
-                        max_points = std::max(max_points, t.n_points); max_table = std::max(max_table, 1 << t.table_bits);
-                    }
-                    size_t at = 0, max_bytes = (size_t)std::max(m, 1) * sizeof(BalmCutTask);
-                    if (m) G.h_copies_a.p[at++] = CopyTask{G.d_cut_list.p, G.h_cut_list.p, (size_t)m * sizeof(BalmCutTask)};
-                    for (int s : fresh) {
-                        if (!slots[s].deferred_lidar.empty() || (C.h_cut.p[s].n_points > 0 && slots[s].rc_lidar >= 0)) slots[s].side_tick = tick;
-                        for (const CopyTask& t : slots[s].deferred_lidar) { G.h_copies_a.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-                        slots[s].deferred_lidar.clear();
-                    }
-                    hipStream_t cut_st = use_side ? side : st;
-                    if (at) launch_copy_tasks(G.h_copies_a.p, (int)at, max_bytes, cut_st);
-                    if (m) launch_balm_cut(G.d_cut_list.p, m, max_points, max_table, cut_st);
-                    if (at || m) {
-                        if (hipGetLastError() != hipSuccess || hipEventRecord(side_ev[par], cut_st) != hipSuccess) failed = 1;
-                        side_last[par] = tick;
-                    }
-                }
-            }
-        }
-        lap(2);
-        // ---- 4. retire what the last mirror shows as done; the caller's stop flags; 5. the next round for everything alive ----
-        std::vector<int> live, live_lidar, lidar_first, retire;
-        bool want_maxdiag = false;
-        for (int s = 0; s < cap && !failed; ++s) {
-            if (slots[s].state != kSlotLive) continue;
-            const BaLmState& m = C.h_lm.p[s];
-            if (m.status == kLmDone) { retire.push_back(s); continue; }
-            if (W[s].stopped()) C.h_stop.p[s] = 1;
-            live.push_back(s);
-            if (W[s].lidar) { live_lidar.push_back(s); if (m.it == 0) lidar_first.push_back(s); }
-            want_maxdiag |= m.it == 0 && !(W[s].p->lambda_init > 0);
-        }
-        if (!failed && !retire.empty()) {
-            const BaBatchExtent XR = batch_extent(W, retire);
-            pieces_for(retire, 0, [&](const BaPhase& ph, int cnt) { ba_batch_launch_depth(ph, cnt, XR, st); });
-            if (G.h_copies_r.ensure(4 * retire.size()) != hipSuccess) failed = 1;
-            size_t n_tasks = 0, max_bytes = 0;
-            for (int s : retire) {
-                if (failed) break;
-                LockstepWindow& w = W[s];
-                const tc2li_ba_problem& p = *w.p;
-                const BaLmState& m = C.h_lm.p[s];
-                BaProblemDev pb = w.vp.pb;
-                if (m.parity) { std::swap(pb.poses, pb.poses_trial); std::swap(pb.points, pb.points_trial); }
-                const size_t E = p.n_edges, P = p.n_points;
-                uint8_t* h = w.ws->h_result.p;
-                uint8_t* hc = h + p.n_poses * sizeof(Se3) + 3 * P * sizeof(double);
-                auto add = [&](void* dst, const void* src, size_t nbytes) { G.h_copies_r.p[n_tasks++] = CopyTask{dst, src, nbytes}; max_bytes = std::max(max_bytes, nbytes); };
-                add(h, pb.poses, p.n_poses * sizeof(Se3));
-                add(h + p.n_poses * sizeof(Se3), pb.points, 3 * P * sizeof(double));
-                if (p.edge_chi2) add(hc, w.ws->d_chi2.p, E * sizeof(double));
-                if (p.edge_depth_positive) add(hc + E * sizeof(double), w.ws->d_depth.p, E);
-                slots[s].state = kSlotRetiring; slots[s].seq = tick; if (kTiming) slots[s].t_retire = now();
-            }
-            if (!failed && n_tasks) { launch_copy_tasks(G.h_copies_r.p, (int)n_tasks, max_bytes, st); queued_any = true; }
-        }
-        lap(3);
-        n_live_sum += (long)live.size(); n_windows += (long)retire.size();
-        if (!failed && !live.empty()) {
-            bool all_block = true;
-            BaBatchExtent XL = batch_extent(W, live, &all_block);
-            XL.fuse_trial = all_block ? 1 : 0;
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, want_maxdiag, st); });
-            pieces_for(lidar_first, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, false, st); });
-            pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_hessian(ph, cnt, XL, st); });
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, XL, st);
-                ba_batch_launch_solve(ph, cnt, XL, st);
-                ba_batch_launch_trial(ph, cnt, XL, st);
-            });
-            if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
-            queued_any = true;
-        }
-        lap(4);
-        // ---- 6. this tick's event; wait for the tick BEFORE it (one tick's work stays in flight while the host prepares the next) ----
-        if (!failed) {
-            if (hipGetLastError() != hipSuccess || hipEventRecord(C.round_done[tick & 1], st) != hipSuccess) failed = 1;
-            else recorded = tick;
-            auto wait_one = [&] { if (event_wait_sleeping(C.round_done[(waited + 1) & 1]) != hipSuccess) failed = 1; ++waited; };
-            if (!failed && recorded - waited > 1) wait_one();
-            // nothing alive: what is in flight (plane extractions, result copies) is all there is to wait for -- without this the loop would
-            // run through empty ticks
-            while (!failed && live.empty() && waited < recorded) wait_one();
-            if (!failed && live.empty() && (n_in_setup > 0 || n_waiting_side > 0) && !queued_any) std::this_thread::sleep_for(std::chrono::microseconds(50));  // only setups / plane extractions are running
-        }
-        lap(5);
-        if (failed) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(mu); if (error.empty()) error = "HIP error in the engine thread"; }
-    }
-    if (kTiming && n_lat) fprintf(stderr, "BA engine window latency ms (%ld windows): queue %.3f setup %.3f wait-to-stage %.3f extraction %.3f rounds %.3f results %.3f\n",
-                                  n_lat, lat[0] / n_lat, lat[1] / n_lat, lat[2] / n_lat, lat[3] / n_lat, lat[4] / n_lat, lat[5] / n_lat);
-    if (kTiming && setup_n[0].load()) fprintf(stderr, "BA engine setup tasks: structure + staging %.3f ms each (%ld), LiDAR window %.3f ms each (%ld)\n",
-                                               1e-3 * setup_us[0].load() / setup_n[0].load(), setup_n[0].load(), 1e-3 * setup_us[1].load() / std::max(setup_n[1].load(), 1L), setup_n[1].load());
-    if (kTiming && n_ticks) fprintf(stderr, "BA engine timing: %ld windows in %ld ticks (%.1f alive per tick); ms per tick: finish %.3f go-live %.3f admit+setup %.3f retire %.3f queue round %.3f wait %.3f; %ld buffer (re)allocations in the process meanwhile\n",
-                                    n_windows, n_ticks, (double)n_live_sum / n_ticks, tm[0] / n_ticks, tm[1] / n_ticks, tm[2] / n_ticks, tm[3] / n_ticks, tm[4] / n_ticks, tm[5] / n_ticks, g_buffer_allocs.load() - allocs0);
-    if (C.st) (void)hipStreamSynchronize(C.st);
-    if (side) (void)hipStreamSynchronize(side);
-}
-
-namespace {
-
-// ---- lock-step batch of LocalLVIBA windows (tc2li_local_lvi_bundle_adjustment_batch) -------------------------------------------
-// The phases of ba_batch_lockstep with the host steps of tc2li_local_lvi_bundle_adjustment between them: the inertial edges'
-// normal equations (InertialTerm, overlapping the linearisation kernels), the dense reduced system [6 per free pose | 9 per free
-// keyframe with IMU state] = Schur complement of the landmarks + inertial + LiDAR blocks, its LDL^T, and the inertial cost of every
-// trial state (the trial ImuCamPose states come back through one copy launch per phase).  Same kernel bodies and host arithmetic
-// as the one-window entry point: a window gives the same result alone and in a batch.
-struct LviWindow {
-    const tc2li_lvi_problem* p = nullptr;
-    BaWorkspace* ws = nullptr;
-    VisualProblem vp;
-    BalmTerm* lidar = nullptr;
-    InertialTerm inertial;
-    std::vector<uint8_t> extra_used, imu_used;
-    std::vector<ImuPose> hp, hp_trial;
-    std::vector<ImuVertexState> sv, sv_trial;
-    std::vector<double> rhs, bfull, x;
-    ReducedSolver solver;
-    bool dev_solve = false;    // the reduced system on the device (k_lvi_solve_b)
-    size_t blob_bytes = 0;
-    double lambda = -1, ni = 2, currentChi = 0, tempChi = 0, iniChi = 0, rho = 0, scale = 0, chi_imu = 0, last_chi = 0;
-    int n_bad = 0, done = 0, trials_total = 0, qmax = 0, it = 0, rc = 0;
-    int parity = 0;  // 1: the accepted estimate lives in the trial buffers of the slot
-    bool ok = true, ok2 = true, want_maxdiag = false;
-    bool wants_hpp() const { return false; }
-    bool stopped() const { return p->stop_flag && *p->stop_flag; }
-    bool wants_iteration() const { return rc >= 0 && it < p->iterations && !stopped() && ok; }
-};
-LockstepContext& lvi_lockstep_ctx(int group) { return shutdown_owned<LockstepContexts, 1>().c[group]; }
-
-bool lvi_batch_lockstep(const tc2li_lvi_problem* problems, int n, const tc2li_imu_calib* calib, const tc2li_camera* cam, WorkerPool& pool, int32_t* results,
-                        int group = 0) {
-    LockstepContext& C = lvi_lockstep_ctx(group);
-    std::lock_guard<std::mutex> lk(C.mu);
-    const BaOptions opt = BaOptions::read();
-    for (int i = 0; i < n; ++i)
-        if (problems[i].lidar && problems[i].lidar->n_keyframes > 7) return false;
-    if (!C.st) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&C.st, hipStreamNonBlocking, hi) != hipSuccess &&
-            hipStreamCreateWithFlags(&C.st, hipStreamNonBlocking) != hipSuccess) { C.st = nullptr; return false; }
-    }
-    hipStream_t st = C.st;
-    while ((int)C.ws.size() < n) C.ws.emplace_back(new BaWorkspace());
-    // the slot table and the steps' staging area, as in ba_batch_lockstep: the table goes up once, a phase's state in the kernels' arguments
-    if (n > 65535) return false;
-    constexpr size_t kXpStride = kBaXpStride;
-    const size_t table_bytes = (size_t)n * sizeof(BaBatchSlot), xp_bytes = (size_t)n * kXpStride * sizeof(double);
-    if (C.d_table.ensure(table_bytes + xp_bytes) != hipSuccess || C.h_table.ensure(table_bytes + xp_bytes) != hipSuccess) return false;
-    BaBatchSlot* const h_slots = (BaBatchSlot*)C.h_table.p;
-    double* const h_xp_area = (double*)(C.h_table.p + table_bytes);
-    const BaBatchSlot* const d_table = (const BaBatchSlot*)C.d_table.p;
-    double* const d_xp_area = (double*)(C.d_table.p + table_bytes);
-    std::vector<LviWindow> W(n);
-    const bool kTiming = opt.timing;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // setup, linearise (device + host edges), host after linearise, schur, solve, trial, trial cost, results
-    const double t_begin = kTiming ? now() : 0;
-    double t_mark = t_begin;
-    auto lap = [&](int k) { if (kTiming) { const double t = now(); tm[k] += t - t_mark; t_mark = t; } };
-    // ---- setup: argument checks, inertial links, plane extraction (device, queued first), uploads ----
-    std::vector<int> rc_lidar(n, 0);
-    std::vector<std::vector<CopyTask>> deferred(2 * (size_t)n);
-    if (C.h_cut.ensure(std::max(n, 1)) != hipSuccess) return false;
-    for (int i = 0; i < n; ++i) C.h_cut.p[i].n_points = 0;
-    auto setup_task = [&](int task) {  // two tasks per window: structure + uploads (even), the LiDAR window (odd)
-        CopySink sink(&deferred[task]);
-        const int i = task >> 1;
-        LviWindow& w = W[i];
-        const tc2li_lvi_problem& p = problems[i];
-        const bool args_ok = p.keyframes && p.fixed && p.has_imu && p.points3 && p.edges && p.n_keyframes > 0 && p.n_points > 0 && p.n_edges > 0 &&
-                             p.n_links >= 0 && (p.n_links == 0 || p.links) && p.iterations >= 0 && (!p.lidar || p.Tbl);
-        bool lidar_ok = true;
-        if (args_ok && p.lidar) {
-            if (p.lidar->n_keyframes < 1 || !p.lidar->pose_index) lidar_ok = false;
-            else for (int k = 0; k < p.lidar->n_keyframes; ++k) if (p.lidar->pose_index[k] < 0 || p.lidar->pose_index[k] >= p.n_keyframes) lidar_ok = false;
-        }
-        if (task & 1) {
-            if (!args_ok || !lidar_ok || !p.lidar) return;
-            rc_lidar[i] = C.ws[i]->lidar.build_body(p.keyframes, sizeof(tc2li_inertial_keyframe), p.n_keyframes, p.lidar, p.Tbl, sizeof(ImuPose), st, &C.h_cut.p[i]);
-            return;
-        }
-        w.p = &p; w.ws = C.ws[i].get();
-        if (!args_ok) { set_error("tc2li_local_lvi_bundle_adjustment_batch: problem %d: invalid argument", i); w.rc = TC2LI_ERR_INVALID; return; }
-        if (!lidar_ok) { set_error("lidar window: invalid argument or pose_index out of range"); w.rc = TC2LI_ERR_INVALID; return; }
-        if (p.stats) memset(p.stats, 0, sizeof(*p.stats));
-        if (p.lidar_stats) memset(p.lidar_stats, 0, sizeof(*p.lidar_stats));
-        const int n_kfs = p.n_keyframes;
-        w.rc = w.inertial.prepare(p.links, p.n_links, p.has_imu, n_kfs, w.extra_used);
-        if (w.rc < 0) return;
-        w.imu_used = w.extra_used;
-        if (p.lidar) for (int k = 0; k < p.lidar->n_keyframes; ++k) w.extra_used[p.lidar->pose_index[k]] = 1;
-        w.rc = w.vp.setup(*w.ws, nullptr, p.fixed, n_kfs, p.points3, p.n_points, p.edges, p.n_edges, cam, w.extra_used.data(), st);
-        if (w.rc < 0) return;
-        w.inertial.number(p.fixed, p.has_imu, w.imu_used, n_kfs, w.vp.pose_var, w.vp.np);
-        if (p.lidar)   // the LiDAR term's blocks of the reduced system (BalmTerm::add_quadratic_form)
-            for (int a = 0; a < p.lidar->n_keyframes; ++a)
-                for (int b = 0; b < p.lidar->n_keyframes; ++b) {
-                    const int vi = w.vp.pose_var[p.lidar->pose_index[a]], vj = w.vp.pose_var[p.lidar->pose_index[b]];
-                    if (vi >= 0 && vj >= 0) w.inertial.note_block(6 * vi, 6 * vj, 6, 6);
-                }
-        BaWorkspace& ws = *w.ws;
-        w.hp.resize(n_kfs); w.hp_trial.resize(n_kfs); w.sv.resize(n_kfs); w.sv_trial.resize(n_kfs);
-        if (ws.d_iposes.ensure(n_kfs) != hipSuccess || ws.d_iposes_trial.ensure(n_kfs) != hipSuccess || ws.h_iposes.ensure(n_kfs) != hipSuccess ||
-            ws.h_iposes_up.ensure(n_kfs) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-        for (int k = 0; k < n_kfs; ++k) {
-            const tc2li_inertial_keyframe& kf = p.keyframes[k];
-            memcpy(w.hp[k].Rcw, kf.Rcw, 72); memcpy(w.hp[k].tcw, kf.tcw, 24); memcpy(w.hp[k].Rwb, kf.Rwb, 72); memcpy(w.hp[k].twb, kf.twb, 24);
-            w.hp[k].its = 0; w.hp[k].pad_ = 0;
-            memcpy(w.sv[k].v, kf.velocity, 24); memcpy(w.sv[k].bg, kf.gyro_bias, 24); memcpy(w.sv[k].ba, kf.acc_bias, 24);
-        }
-        memcpy(ws.h_iposes_up.p, w.hp.data(), n_kfs * sizeof(ImuPose));
-        if (upload_or_defer(ws.d_iposes.p, ws.h_iposes_up.p, n_kfs * sizeof(ImuPose), st) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-        BaProblemDev& pb = w.vp.pb;
-        pb.inertial = 1; pb.iposes = ws.d_iposes.p; pb.iposes_trial = ws.d_iposes_trial.p;
-        w.vp.decide_trial_fused();
-        memcpy(&pb.calib, calib, sizeof(ImuCalib));
-        const int nn = w.inertial.n;
-        w.dev_solve = w.inertial.device_solve_ok();
-        if (w.dev_solve) {
-            const int np1 = w.vp.np;
-            if (ws.lvi.ensure(np1, nn - np1) != hipSuccess || ws.d_S.ensure((size_t)np1 * np1) != hipSuccess || ws.d_bs.ensure(2 * (size_t)np1) != hipSuccess ||
-                ws.d_xp.ensure(nn) != hipSuccess || ws.h_xp.ensure(nn) != hipSuccess || ws.h_ok.ensure(1) != hipSuccess) { w.rc = TC2LI_ERR_HIP; return; }
-        }
-        w.rhs.assign(std::max(nn, 1), 0.0); w.bfull.assign(std::max(nn, 1), 0.0); w.x.assign(std::max(nn, 1), 0.0);
-    };
-    pool.parallel_for(n, [&](int i) { setup_task(2 * i + 1); });
-    if (!plane_extraction_begin(C, deferred, n, st)) { (void)hipStreamSynchronize(st); return false; }
-    pool.parallel_for(n, [&](int i) { setup_task(2 * i); });
-    if (!plane_extraction_finish(C, n, rc_lidar, st)) return false;
-    for (int i = 0; i < n; ++i) {
-        if (W[i].rc < 0 || !problems[i].lidar) continue;
-        if (rc_lidar[i] < 0) W[i].rc = rc_lidar[i]; else W[i].lidar = &C.ws[i]->lidar;
-    }
-    for (int i = 0; i < n; ++i)
-        if (W[i].rc >= 0 && W[i].lidar && W[i].lidar->n_planes > 2048) { (void)hipStreamSynchronize(st); return false; }
-    // the reduced systems on the device or on the host, the whole call one way: a window decides for itself (InertialTerm::device_solve_ok), and a call
-    // whose windows disagree is handed back to the one-window entry points -- every window then runs exactly as it would alone
-    bool dev_solve = false;
-    int max_lvi_np = 0, max_lvi_ni = 0;
-    {
-        int n_dev = 0, n_ok = 0;
-        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) { ++n_ok; if (W[i].dev_solve) { ++n_dev; max_lvi_np = std::max(max_lvi_np, W[i].vp.np); max_lvi_ni = std::max(max_lvi_ni, W[i].inertial.n - W[i].vp.np); } }
-        if (n_dev && n_dev != n_ok) {
-            // the windows disagree: the majority stays in lock step, the others are handed back one by one (the whole group used to
-            // go back -- one window without a velocity vertex sent 43 through the serial path)
-            const bool keep_dev = 2 * n_dev >= n_ok;
-            max_lvi_np = max_lvi_ni = 0;
-            for (int i = 0; i < n; ++i) {
-                if (W[i].rc < 0) continue;
-                if (W[i].dev_solve != keep_dev) { W[i].rc = kLockstepDeclined; continue; }
-                if (keep_dev) { max_lvi_np = std::max(max_lvi_np, W[i].vp.np); max_lvi_ni = std::max(max_lvi_ni, W[i].inertial.n - W[i].vp.np); }
-            }
-            n_dev = keep_dev ? n_dev : 0;
-        }
-        dev_solve = n_dev > 0;
-    }
-    std::vector<int> all_windows(n);
-    for (int i = 0; i < n; ++i) all_windows[i] = i;
-    bool all_block_parts = true;
-    BaBatchExtent X = batch_extent(W, all_windows, &all_block_parts);
-    X.inertial = 1;
-    // The sums behind a trial's errors (k_ba_trial_reduce_b: two workgroups per window) are taken by the LAST workgroup of the window's
-    // error pass (a ticket per window, ba_kernels.hip: ba_last_of): one launch fewer per LM trial -- BA stage alone 15.0-15.2 against 15.2-15.6 ms
-    // per 128 windows, the loop 28.3 / 28.7 against 28.4 / 28.9 ms.  (The same for the Schur product's closing sums measured SLOWER, 29.5-29.8
-    // against 28.4-28.6 ms: one workgroup adding ten parts of 2 700 values is a longer tail than the 21 workgroups of k_ba_schur_finish_b
-    // are a launch; removed.)
-    {
-        X.fuse_trial = all_block_parts ? 1 : 0;
-        // round 5: the linearisation's closing sums (pose blocks, robust cost, largest diagonals) and the plane Hessian's
-        // chunk sums the same way -- an iteration's linearisation phase is then two launches instead of four or five.  Built, bit-identical
-        // (the same sums in the same order), and measured in the whole loop, three A/B pairs in one call: 26.24 / 26.26 / 26.27 ms per step fused
-        // against 26.08 / 25.95 / 26.03 separate (mapping workers 25.1-25.7 against 24.5-25.3): the loop is bound by the kernels' combined
-        // throughput, not by the number of launches in a chain, and one workgroup's tail is longer than the small launch it replaces.  Off by
-        // default; TC2LI_BA_FUSE_LIN=1 (read per call) switches it on.
-        X.fuse_linearize = opt.fuse_linearize ? 1 : 0;
-    }
-    auto fill_slot = [&](int i) {
-        LviWindow& w = W[i];
-        BaBatchSlot& s = h_slots[i];
-        s.pb = w.vp.pb;
-        // (the LM decisions of the inertial windows stay on the host: no device-side state -- the table's memory is reused from call to call)
-        s.lm = nullptr; s.lm_host = nullptr; s.stop_host = nullptr; s.lidar_JH = nullptr; s.lambda_init = 0; s.lidar_information = 0; s.iterations = 0; s.lm_pad_ = 0;
-        s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr; s.pad_ = 0;
-        double* sc = w.ws->h_scal.p;
-        s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
-        s.S_out = w.ws->h_S.p; s.bs_out = w.ws->h_bs.p; s.xp = w.ws->h_xp.p; s.depth_out = w.ws->d_depth.p;
-        s.hpp_out = nullptr; s.bp_host = nullptr; s.Hl = s.bl_lidar = nullptr; s.x_dev = s.x_host = nullptr; s.ok_host = nullptr;
-        s.iposes_host = w.ws->h_iposes.p;  // the trial kernel leaves the trial ImuCamPose states there for the host's inertial cost
-        s.lvi = LviSolveDev{};
-        if (w.dev_solve) {  // Schur product, solve and trial in one queue: S and b_s stay on the device, b_p and the step (all n unknowns) come back
-            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = w.ws->h_bs.p + w.vp.np;
-            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = w.ws->h_xp.p; s.ok_host = w.ws->h_ok.p;
-            s.lvi = w.ws->lvi.dev;
-        }
-        if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
-    };
-    bool failed = false;
-    {   // the table and everything the setup deferred: one launch
-        for (int i = 0; i < n; ++i) if (W[i].rc >= 0) fill_slot(i); else h_slots[i] = BaBatchSlot{};
-        size_t n_tasks = 1, max_bytes = table_bytes;
-        for (const auto& d : deferred) n_tasks += d.size();
-        if (C.h_tasks.ensure(n_tasks) != hipSuccess) return false;
-        size_t at = 0;
-        C.h_tasks.p[at++] = CopyTask{C.d_table.p, C.h_table.p, table_bytes};
-        for (const auto& d : deferred) for (const CopyTask& t : d) { C.h_tasks.p[at++] = t; max_bytes = std::max(max_bytes, t.bytes); }
-        launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-    }
-    // No upload launch for the steps: the trial kernels read a window's step (<= 1.5 KB, once per workgroup) from the pinned staging area
-    // over the bus -- ten launches fewer per call at the same speed (BA stage alone 15.3 / 15.4 ms per 128 windows, the loop 28.5-28.7 /
-    // 28.6-29.1 ms per step against the one-entry k_copy_tasks launch of rounds 3-4)
-    constexpr bool xp_pinned = true;
-    auto stage_steps = [&](const std::vector<int>& step) {
-        for (size_t k = 0; k < step.size(); ++k) {
-            const LviWindow& w = W[step[k]];
-            if (w.vp.np <= 0 || w.vp.np > (int)kXpStride) continue;
-            memcpy(h_xp_area + k * kXpStride, w.ws->h_xp.p, (size_t)w.vp.np * sizeof(double));
-        }
-        if (xp_pinned) return;  // the trial kernels read the steps where they are
-        if (C.h_table_task.ensure(1) != hipSuccess) { failed = true; return; }
-        C.h_table_task.p[0] = CopyTask{d_xp_area, h_xp_area, step.size() * kXpStride * sizeof(double)};
-        launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
-    };
-    auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
-    // (the group's thread spins on its stream between the phases: sleeping on a blocking event instead was measured in round 4 -- the same host
-    // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
-    auto sync = [&] { if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) failed = true; };
-
-    // OptimizationAlgorithmLevenberg::solve's gain ratio and damping update for the windows of a trial; returns those that try again
-    auto lm_decisions = [&](const std::vector<int>& trial) {
-        std::vector<int> again;
-        for (int i : trial) {
-            LviWindow& w = W[i];
-            if (!w.ok2) w.tempChi = std::numeric_limits<double>::max();
-            w.rho = w.currentChi - w.tempChi;
-            w.scale += 1e-3;
-            w.rho /= w.scale;
-            if (w.rho > 0 && std::isfinite(w.tempChi)) {
-                w.lambda = lm_lambda_accepted(w.lambda, w.rho);
-                w.ni = 2;
-                w.currentChi = w.tempChi;
-                std::swap(w.vp.pb.iposes, w.vp.pb.iposes_trial);
-                std::swap(w.vp.pb.points, w.vp.pb.points_trial);
-                w.parity ^= 1;
-                w.hp.swap(w.hp_trial);
-                w.sv.swap(w.sv_trial);
-            } else {
-                w.lambda *= w.ni;
-                w.ni *= 2;
-            }
-            w.qmax++;
-            w.trials_total++;
-            if (w.rho < 0 && w.qmax < 10 && !w.stopped()) again.push_back(i);
-        }
-        return again;
-    };
-    lap(0);
-    for (;;) {
-        std::vector<int> active, with_lidar;
-        for (int i = 0; i < n; ++i) if (W[i].wants_iteration()) active.push_back(i);
-        if (active.empty() || failed) break;
-        lap(7);
-        // ---- phase A: linearisation at the accepted estimate; the inertial edges on the host meanwhile ----
-        bool any_maxdiag = false;
-        for (int i : active) {
-            LviWindow& w = W[i];
-            w.want_maxdiag = w.it == 0 && !(w.p->lambda_init > 0);
-            any_maxdiag |= w.want_maxdiag;
-            if (w.lidar) with_lidar.push_back(i);
-        }
-        pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, X, any_maxdiag, st); });
-        // computeActiveErrors + linearizeOplus of the LiDAR edge: the residual at the accepted estimate and the Hessian, every iteration
-        // (the one-window path's enqueue_error + enqueue_linearization)
-        pieces(with_lidar, nullptr, [&](const BaPhase& ph, int cnt) {
-            balm_batch_launch_residual(ph, cnt, false, st);
-            balm_batch_launch_hessian(ph, cnt, X, st);
-        });
-        // (the first trial's Schur product behind the linearisation, as in ba_batch_lockstep: the host's inertial edges, the LiDAR term's change of
-        // variables and the upload of the reduced system's inertial part run beside it)
-        constexpr bool kPreSchur = true;
-        bool pre_schur = kPreSchur && !any_maxdiag;
-        if (pre_schur) {
-            for (int i : active) if (W[i].it == 0) W[i].lambda = W[i].p->lambda_init;  // (what the host's part sets below)
-            pieces(active, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-        }
-        pool.parallel_for((int)active.size(), [&](int k) { LviWindow& w = W[active[k]]; w.chi_imu = w.inertial.cost(w.hp, w.sv, true); });
-        lap(8);
-        sync();
-        if (failed) break;
-        lap(1);
-        pool.parallel_for((int)active.size(), [&](int k) {
-            LviWindow& w = W[active[k]];
-            const double* sc = w.ws->h_scal.p;
-            const int np = w.vp.np, nn = w.inertial.n;
-            double chi_imu = w.chi_imu;
-            if (w.lidar) {
-                if (w.it == 0) w.lidar->finish_error();  // the computeActiveErrors() before optimize() (OptimizerWithLidar.cc:978)
-                w.lidar->finish_error();
-                chi_imu += w.lidar->chi2();
-                w.lidar->finish_linearization();
-                w.lidar->add_quadratic_form(w.vp.pose_var.data(), nn, w.inertial.Hi.data(), w.inertial.bi.data());
-            }
-            w.solver.set_pattern(w.inertial.Hi.data(), nn, np, !w.dev_solve);
-            if (w.dev_solve) {
-                if (w.solver.band() > kLviBand) w.rc = TC2LI_ERR_INVALID;  // (device_solve_ok bounds the band by the links: not reached)
-                else w.blob_bytes = w.ws->lvi.pack(w.solver, w.inertial.Hi.data(), w.inertial.bi.data());
-            }
-            w.currentChi = chi_imu + sc[0];
-            w.tempChi = w.currentChi;
-            w.iniChi = w.currentChi;
-            if (w.it == 0) {
-                if (w.p->stats) w.p->stats->initial_chi2 = w.currentChi;
-                w.last_chi = w.currentChi;
-                w.lambda = w.p->lambda_init;
-                if (!(w.p->lambda_init > 0)) {  // computeLambdaInit over the whole diagonal (not used by the reference's settings)
-                    double mx = std::max(sc[1], sc[2]);
-                    for (int j = np; j < nn; ++j) mx = std::max(mx, std::fabs(w.inertial.Hi[(size_t)j * nn + j]));
-                    w.lambda = 1e-5 * mx;
-                }
-                w.ni = 2;
-                w.n_bad = 0;
-            }
-            w.rho = 0;
-            w.qmax = 0;
-        });
-        if (dev_solve) {  // this linearisation's inertial / LiDAR part of the reduced systems goes up: one launch
-            if (C.h_tasks.ensure(active.size()) != hipSuccess) { failed = true; break; }
-            size_t max_bytes = 0;
-            for (size_t k = 0; k < active.size(); ++k) {
-                LviWindow& w = W[active[k]];
-                if (w.rc < 0) { failed = true; break; }
-                C.h_tasks.p[k] = CopyTask{w.ws->lvi.d_blob.p, w.ws->lvi.h_blob.p, w.blob_bytes};
-                max_bytes = std::max(max_bytes, w.blob_bytes);
-            }
-            if (failed) break;
-            launch_copy_tasks(C.h_tasks.p, (int)active.size(), max_bytes, st);
-        }
-        // ---- trials ----
-        lap(2);
-        std::vector<int> trial = active;
-        while (!trial.empty() && !failed && dev_solve) {
-            // Schur product, solve, trial estimate and its cost in one queue; the host sees the step, whether the factorisation went through, and
-            // the sums at the one synchronisation
-            std::vector<int> trial_lidar;
-            for (int i : trial) if (W[i].lidar) trial_lidar.push_back(i);
-            const bool have_schur = pre_schur;  // (this trial's product came with the linearisation)
-            pre_schur = false;
-            pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) {
-                if (!have_schur) ba_batch_launch_schur(ph, cnt, X, st);
-                lvi_batch_launch_solve(ph, cnt, max_lvi_np, max_lvi_ni, st);
-                ba_batch_launch_trial(ph, cnt, X, st);
-            });
-            if (X.any_trial_unfused) pieces(trial_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
-            sync();
-            if (failed) break;
-            lap(3);
-            pool.parallel_for((int)trial.size(), [&](int k) {
-                LviWindow& w = W[trial[k]];
-                BaWorkspace& ws = *w.ws;
-                const int np = w.vp.np, nn = w.inertial.n;
-                const std::vector<double>& bi = w.inertial.bi;
-                w.ok2 = ws.h_ok.p[0] != 0;
-                memcpy(w.x.data(), ws.h_xp.p, (size_t)nn * sizeof(double));
-                w.scale = 0;
-                for (int j = 0; j < nn; ++j) {
-                    const double bfull = bi[j] + (j < np ? ws.h_bs.p[np + j] : 0.0);
-                    w.scale += w.x[j] * (w.lambda * w.x[j] + bfull);
-                }
-                if (!w.ok2) return;
-                w.sv_trial = w.sv;
-                for (int q = 0; q < w.p->n_keyframes; ++q)
-                    if (w.inertial.imu_var[q] >= 0) {
-                        const double* u = &w.x[np + 9 * w.inertial.imu_var[q]];
-                        for (int c = 0; c < 3; ++c) { w.sv_trial[q].v[c] += u[c]; w.sv_trial[q].bg[c] += u[3 + c]; w.sv_trial[q].ba[c] += u[6 + c]; }
-                    }
-                memcpy(w.hp_trial.data(), ws.h_iposes.p, w.p->n_keyframes * sizeof(ImuPose));
-                w.tempChi = w.inertial.cost(w.hp_trial, w.sv_trial, false) + ws.h_scal.p[4];
-                if (w.lidar) { w.lidar->finish_error(); w.tempChi += w.lidar->chi2(); }
-                w.scale += ws.h_scal.p[3];
-                w.last_chi = w.tempChi;
-            });
-            lap(6);
-            trial = lm_decisions(trial);
-        }
-        while (!trial.empty() && !failed && !dev_solve) {
-            if (pre_schur) pre_schur = false;  // (this trial's product came with the linearisation)
-            else {
-                pieces(trial, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_schur(ph, cnt, X, st); });
-                sync();
-                if (failed) break;
-            }
-            lap(3);
-            pool.parallel_for((int)trial.size(), [&](int k) {
-                LviWindow& w = W[trial[k]];
-                BaWorkspace& ws = *w.ws;
-                const int np = w.vp.np, nn = w.inertial.n;
-                const std::vector<double>&Hi = w.inertial.Hi, &bi = w.inertial.bi;
-                // reduced system: [S_visual + H_inertial(poses)   H_inertial(poses, imu) ; ...   H_inertial(imu) + lambda I] (reduced_solve.hpp)
-                for (int j = 0; j < nn; ++j) {
-                    w.bfull[j] = bi[j] + (j < np ? ws.h_bs.p[np + j] : 0.0);
-                    w.rhs[j] = bi[j] + (j < np ? ws.h_bs.p[j] : 0.0);
-                }
-                w.ok2 = nn == 0 ? true : w.solver.factorise(Hi.data(), ws.h_S.p, w.lambda);
-                if (w.ok2 && nn) w.solver.solve(w.rhs.data(), w.x.data());
-                w.scale = 0;
-                for (int j = 0; j < nn; ++j) w.scale += w.x[j] * (w.lambda * w.x[j] + w.bfull[j]);
-                if (w.ok2 && np) memcpy(ws.h_xp.p, w.x.data(), np * sizeof(double));
-            });
-            lap(4);
-            std::vector<int> step, step_lidar;
-            for (int i : trial) if (W[i].ok2) { step.push_back(i); if (W[i].lidar) step_lidar.push_back(i); }
-            if (!step.empty()) {
-                stage_steps(step);
-                // (the trial ImuCamPose states come back through slot.iposes_host, written by the trial kernel: a copy launch per trial before)
-                pieces(step, xp_pinned ? h_xp_area : d_xp_area, [&](const BaPhase& ph, int cnt) { ba_batch_launch_trial(ph, cnt, X, st); });
-                if (X.any_trial_unfused) pieces(step_lidar, nullptr, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
-                pool.parallel_for((int)step.size(), [&](int k) {  // velocity / bias part of the step, on the host
-                    LviWindow& w = W[step[k]];
-                    const int np = w.vp.np;
-                    w.sv_trial = w.sv;
-                    for (int q = 0; q < w.p->n_keyframes; ++q)
-                        if (w.inertial.imu_var[q] >= 0) {
-                            const double* u = &w.x[np + 9 * w.inertial.imu_var[q]];
-                            for (int c = 0; c < 3; ++c) { w.sv_trial[q].v[c] += u[c]; w.sv_trial[q].bg[c] += u[3 + c]; w.sv_trial[q].ba[c] += u[6 + c]; }
-                        }
-                });
-                sync();
-                if (failed) break;
-                lap(5);
-                pool.parallel_for((int)step.size(), [&](int k) {
-                    LviWindow& w = W[step[k]];
-                    memcpy(w.hp_trial.data(), w.ws->h_iposes.p, w.p->n_keyframes * sizeof(ImuPose));
-                    w.tempChi = w.inertial.cost(w.hp_trial, w.sv_trial, false) + w.ws->h_scal.p[4];
-                    if (w.lidar) { w.lidar->finish_error(); w.tempChi += w.lidar->chi2(); }
-                    w.scale += w.ws->h_scal.p[3];
-                    w.last_chi = w.tempChi;
-                });
-            }
-            lap(6);
-            trial = lm_decisions(trial);
-        }
-        for (int i : active) {
-            LviWindow& w = W[i];
-            ++w.done;
-            ++w.it;
-            if (w.p->stats) w.p->stats->final_lambda = w.lambda;
-            if (w.qmax == 10 || w.rho == 0) { w.ok = false; continue; }
-            if ((w.iniChi - w.currentChi) * 1e3 < w.iniChi) w.n_bad++; else w.n_bad = 0;
-            if (w.n_bad >= 3) w.ok = false;
-        }
-    }
-    // ---- results ----
-    std::vector<int> all;
-    for (int i = 0; i < n; ++i) if (W[i].rc >= 0) all.push_back(i);
-    if (!failed && !all.empty()) {
-        pieces(all, nullptr, [&](const BaPhase& ph, int cnt) { ba_batch_launch_depth(ph, cnt, X, st); });
-        size_t n_tasks = 0, max_bytes = 0;
-        if (C.h_tasks.ensure(3 * all.size()) != hipSuccess) failed = true;
-        for (int i : all) {
-            if (failed) break;
-            LviWindow& w = W[i];
-            const tc2li_lvi_problem& p = *w.p;
-            const size_t E = p.n_edges, P = p.n_points;
-            const size_t bytes = 3 * P * sizeof(double) + E * sizeof(double) + E;
-            if (w.ws->h_result.ensure(bytes) != hipSuccess) { failed = true; break; }
-            uint8_t* h = w.ws->h_result.p;
-            auto add = [&](void* dst, const void* src, size_t nbytes) { C.h_tasks.p[n_tasks++] = CopyTask{dst, src, nbytes}; max_bytes = std::max(max_bytes, nbytes); };
-            add(h, w.vp.pb.points, 3 * P * sizeof(double));
-            if (p.edge_chi2) add(h + 3 * P * sizeof(double), w.ws->d_chi2.p, E * sizeof(double));
-            if (p.edge_depth_positive) add(h + 3 * P * sizeof(double) + E * sizeof(double), w.ws->d_depth.p, E);
-        }
-        if (!failed) launch_copy_tasks(C.h_tasks.p, (int)n_tasks, max_bytes, st);
-        sync();
-        if (!failed)
-            pool.parallel_for((int)all.size(), [&](int k) {
-                LviWindow& w = W[all[k]];
-                const tc2li_lvi_problem& p = *w.p;
-                const size_t E = p.n_edges, P = p.n_points;
-                const uint8_t* h = w.ws->h_result.p;
-                memcpy(p.points3, h, 3 * P * sizeof(double));
-                if (p.edge_chi2) memcpy(p.edge_chi2, h + 3 * P * sizeof(double), E * sizeof(double));
-                if (p.edge_depth_positive) memcpy(p.edge_depth_positive, h + 3 * P * sizeof(double) + E * sizeof(double), E);
-                for (int q = 0; q < p.n_keyframes; ++q) {
-                    tc2li_inertial_keyframe& kf = p.keyframes[q];
-                    memcpy(kf.Rcw, w.hp[q].Rcw, 72); memcpy(kf.tcw, w.hp[q].tcw, 24); memcpy(kf.Rwb, w.hp[q].Rwb, 72); memcpy(kf.twb, w.hp[q].twb, 24);
-                    memcpy(kf.velocity, w.sv[q].v, 24); memcpy(kf.gyro_bias, w.sv[q].bg, 24); memcpy(kf.acc_bias, w.sv[q].ba, 24);
-                }
-            });
-    }
-    lap(7);
-    if (kTiming) fprintf(stderr, "LVI lock-step timing ms (%d windows): setup %.3f inertial edges (host, kernels queued) %.3f + wait %.3f host-lin %.3f schur %.3f solve %.3f trial %.3f trial-cost %.3f results+rest %.3f total %.3f\n",
-                         n, tm[0], tm[8], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7], now() - t_begin);
-    for (int i = 0; i < n; ++i) {
-        LviWindow& w = W[i];
-        if (w.rc < 0) { results[i] = w.rc; continue; }
-        if (failed) { set_error("tc2li_local_lvi_bundle_adjustment_batch: HIP error in the lock-step loop: %s", hipGetErrorString(hipGetLastError())); results[i] = TC2LI_ERR_HIP; continue; }
-        const tc2li_lvi_problem& p = *w.p;
-        if (p.stats) { p.stats->iterations = w.done; p.stats->trials = w.trials_total; p.stats->n_free_poses = w.vp.n_free; p.stats->final_chi2 = w.last_chi; }
-        if (w.lidar && p.lidar_stats) {
-            p.lidar_stats->n_planes = w.lidar->n_planes; p.lidar_stats->hessian_evaluations = w.lidar->hessian_evaluations;
-            p.lidar_stats->residual = w.lidar->error; p.lidar_stats->chi2 = w.lidar->chi2();
-        }
-        results[i] = w.done;
-    }
-    return true;
-}
-
-}  // namespace
-
-extern "C" {
-
-int tc2li_local_bundle_adjustment_batch(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int max_concurrency,
-                                        int32_t* results) {
-    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam) { set_error("tc2li_local_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
-    if (n_problems == 0) return 0;
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    const int workers = std::max(1, std::min(std::min(max_concurrency, n_problems), 16));
-    WorkerPool* pool = &named_pool(kPoolBaGroup0);  // persistent: its threads keep their streams and workspaces
-    const BaOptions opt = BaOptions::read();
-    const bool kNoLockstep = !opt.lockstep;
-    // The lock-step loop is a chain of dependent launches with a host step after every phase: while the host works the stream is
-    // empty.  Several groups of windows, each a lock-step batch of its own on its own stream and host thread, fill each other's gaps.
-    const int kGroups = opt.groups;
-    // windows the lock-step groups could not take (a LiDAR window outside the batched kernels' range: a group that declines has written
-    // nothing but zeroed stats) go through the one-window path below -- those windows only, every other window keeps its lock-step result
-    std::vector<uint8_t> todo(n_problems, 1);
-    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
-        const int groups = std::max(1, std::min(kGroups, n_problems / 2));
-        // the setup of a group (per window: graph structure + staging, plane extraction of the LiDAR window) and the per-window host steps
-        // between the phases (LiDAR quadratic form, 6K LDL^T) are host work on the group's own pool (common.cpp pool_threads: 16 threads per
-        // group on a one-GPU box -- 8 -> 16 took the step from 41.8-42.9 to 40.7-40.8 ms in round 2, 32: 41.0 -- fewer under a smaller budget)
-        auto run_group = [&](int g) {
-            const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
-            if (ba_batch_lockstep(problems + b, e - b, cam, named_pool(kPoolBaGroup0 + g), results + b, g))
-                std::fill(todo.begin() + b, todo.begin() + e, (uint8_t)0);
-        };
-        if (groups == 1) run_group(0);
-        else named_pool(kPoolBaTop).parallel_for(groups, run_group);
-    }
-    std::vector<int> rest;
-    for (int i = 0; i < n_problems; ++i) if (todo[i]) rest.push_back(i);
-    if (rest.empty()) {
-        int ok_ = 0;
-        for (int i = 0; i < n_problems; ++i) ok_ += results[i] >= 0;
-        return ok_;
-    }
-    struct ThreadStream {
-        hipStream_t s = nullptr;
-        ~ThreadStream() { if (s) (void)hipStreamDestroy(s); }
-    };
-    std::atomic<int> next{0};
-    pool->parallel_for(std::min(workers, (int)rest.size()), [&](int) {
-        static thread_local ThreadStream ts;
-        if (!ts.s && hipStreamCreateWithFlags(&ts.s, hipStreamNonBlocking) != hipSuccess) ts.s = nullptr;
-        for (int k; (k = next.fetch_add(1)) < (int)rest.size();) {
-            const int i = rest[k];
-            const tc2li_ba_problem& p = problems[i];
-            results[i] = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam,
-                                                          p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive,
-                                                          p.stats, p.lidar, p.lidar_stats, ts.s);
-        }
-    });
-    int ok = 0;
-    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
-    return ok;
-}
 
 int tc2li_ba_options(char* text, int capacity) {
     const BaOptions o = BaOptions::read();
@@ -3116,127 +533,6 @@ int tc2li_ba_options(char* text, int capacity) {
                            (int)o.lockstep, o.groups);
     if (text && capacity > 0) { const int m = std::min(capacity - 1, n); memcpy(text, buf, m); text[m] = 0; }
     return n + 1;
-}
-
-int tc2li_local_bundle_adjustment_batch_group(const tc2li_ba_problem* problems, int n_problems, const tc2li_camera* cam, int group, int32_t* results) {
-    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !cam || group < 0 || group >= kMaxLockstepGroups) {
-        set_error("tc2li_local_bundle_adjustment_batch_group: invalid argument (group 0 .. %d)", kMaxLockstepGroups - 1);
-        return TC2LI_ERR_INVALID;
-    }
-    if (n_problems == 0) return 0;
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    const BaOptions opt = BaOptions::read();
-    const bool kNoLockstep = !opt.lockstep;
-    // ONE lock-step group on the caller's thread: the context `group` (stream, work spaces, host pool) is the caller's choice, so that the
-    // mapping workers of a multi-sequence system run their windows side by side without meeting at the end of a common call
-    bool done = false;
-    if (n_problems > 1 && !kNoLockstep) done = ba_batch_lockstep(problems, n_problems, cam, named_pool(kPoolBaGroup0 + group), results, group);
-    if (!done) {  // a window outside the batched kernels' range (the group has written nothing but zeroed stats), or a batch of one
-        for (int i = 0; i < n_problems; ++i) {
-            const tc2li_ba_problem& p = problems[i];
-            results[i] = tc2li_local_lv_bundle_adjustment(p.poses7, p.fixed, p.n_poses, p.points3, p.n_points, p.edges, p.n_edges, cam, p.iterations,
-                                                          p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats, p.lidar,
-                                                          p.lidar_stats, private_stream());
-        }
-    }
-    int ok = 0;
-    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
-    return ok;
-}
-
-int tc2li_local_lvi_bundle_adjustment_batch(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
-                                            int max_concurrency, int32_t* results) {
-    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam) { set_error("tc2li_local_lvi_bundle_adjustment_batch: invalid argument"); return TC2LI_ERR_INVALID; }
-    if (n_problems == 0) return 0;
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    const BaOptions opt = BaOptions::read();
-    const bool kNoLockstep = !opt.lockstep;
-    const int kGroups = opt.groups;
-    // as in tc2li_local_bundle_adjustment_batch: only the windows of a group that declined go through the one-window path
-    std::vector<uint8_t> todo(n_problems, 1);
-    if (max_concurrency > 1 && n_problems > 1 && !kNoLockstep) {
-        const int groups = std::max(1, std::min(kGroups, n_problems / 2));
-        auto run_group = [&](int g) {
-            const int b = (int)((long)n_problems * g / groups), e = (int)((long)n_problems * (g + 1) / groups);
-            if (lvi_batch_lockstep(problems + b, e - b, calib, cam, named_pool(kPoolLviGroup0 + g), results + b, g))
-                for (int i = b; i < e; ++i) todo[i] = results[i] == kLockstepDeclined;
-        };
-        if (groups == 1) run_group(0);
-        else named_pool(kPoolLviTop).parallel_for(groups, run_group);
-    }
-    // one window after the other (a LiDAR window outside the batched kernels' range, or a batch of one)
-    for (int i = 0; i < n_problems; ++i) {
-        if (!todo[i]) continue;
-        const tc2li_lvi_problem& p = problems[i];
-        results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
-                                                       p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,
-                                                       p.lidar, p.Tbl, p.lidar_stats, private_stream());
-    }
-    int ok = 0;
-    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
-    return ok;
-}
-
-int tc2li_host_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x) {
-    if (!Hi || n <= 0 || np < 0 || np > n || (np > 0 && !S) || !rhs || !x) { set_error("tc2li_host_reduced_solve: invalid argument"); return TC2LI_ERR_INVALID; }
-    ReducedSolver solver;
-    solver.set_pattern(Hi, n, np);
-    if (!solver.factorise(Hi, S, lambda)) return 0;
-    solver.solve(rhs, x);
-    return 1;
-}
-
-int tc2li_device_reduced_solve(const double* Hi, const double* S, int n, int np, double lambda, const double* rhs, double* x, void* stream_) {
-    if (!Hi || n <= 0 || np <= 0 || np >= n || !S || !rhs || !x) { set_error("tc2li_device_reduced_solve: invalid argument"); return TC2LI_ERR_INVALID; }
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    ReducedSolver solver;
-    solver.set_pattern(Hi, n, np, false);
-    if (np > kLviMaxPoseRows || solver.band() > kLviBand || !lvi_device_solve_available()) {
-        set_error("tc2li_device_reduced_solve: %d pose unknowns / band %d: outside the kernel's range (%d / %d)", np, solver.band(), kLviMaxPoseRows, kLviBand);
-        return TC2LI_ERR_INVALID;
-    }
-    hipStream_t st = (hipStream_t)stream_;
-    BaWorkspace& ws = ba_ws();
-    std::lock_guard<std::mutex> lk(ws.mu);
-    TC2LI_HIP_CHECK(ws.lvi.ensure(np, n - np)); TC2LI_HIP_CHECK(ws.d_S.ensure((size_t)np * np)); TC2LI_HIP_CHECK(ws.d_bs.ensure(2 * (size_t)np));
-    TC2LI_HIP_CHECK(ws.d_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_xp.ensure(n)); TC2LI_HIP_CHECK(ws.h_ok.ensure(1));
-    const size_t bytes = ws.lvi.pack(solver, Hi, rhs);   // (the whole right-hand side as the inertial part's; the visual part b_s is zero)
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.lvi.d_blob.p, ws.lvi.h_blob.p, bytes, hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemcpyAsync(ws.d_S.p, S, (size_t)np * np * sizeof(double), hipMemcpyHostToDevice, st));
-    TC2LI_HIP_CHECK(hipMemsetAsync(ws.d_bs.p, 0, 2 * (size_t)np * sizeof(double), st));
-    lvi_launch_solve(ws.lvi.dev, ws.d_S.p, ws.d_bs.p, lambda, ws.d_xp.p, ws.h_xp.p, ws.h_ok.p, st);
-    TC2LI_HIP_CHECK(hipGetLastError());
-    TC2LI_HIP_CHECK(hipStreamSynchronize(st));
-    memcpy(x, ws.h_xp.p, (size_t)n * sizeof(double));
-    return ws.h_ok.p[0] != 0 ? 1 : 0;
-}
-
-// The same as ONE lock-step group on the context `group` (as tc2li_local_bundle_adjustment_batch_group): for the mapping workers of a multi-sequence
-// camera-LiDAR-inertial system
-int tc2li_local_lvi_bundle_adjustment_batch_group(const tc2li_lvi_problem* problems, int n_problems, const tc2li_imu_calib* calib, const tc2li_camera* cam,
-                                                  int group, int32_t* results) {
-    if (n_problems < 0 || (n_problems > 0 && (!problems || !results)) || !calib || !cam || group < 0 || group >= kMaxLockstepGroups) {
-        set_error("tc2li_local_lvi_bundle_adjustment_batch_group: invalid argument (group 0 .. %d)", kMaxLockstepGroups - 1);
-        return TC2LI_ERR_INVALID;
-    }
-    if (n_problems == 0) return 0;
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    const BaOptions opt = BaOptions::read();
-    const bool kNoLockstep = !opt.lockstep;
-    bool done = false;
-    if (n_problems > 1 && !kNoLockstep) done = lvi_batch_lockstep(problems, n_problems, calib, cam, named_pool(kPoolLviGroup0 + group), results, group);
-    {   // a window outside the batched kernels' range or a batch of one: all of them; windows the group handed back: those
-        for (int i = 0; i < n_problems; ++i) {
-            if (done && results[i] != kLockstepDeclined) continue;
-            const tc2li_lvi_problem& p = problems[i];
-            results[i] = tc2li_local_lvi_bundle_adjustment(p.keyframes, p.fixed, p.has_imu, p.n_keyframes, calib, p.points3, p.n_points, p.edges, p.n_edges, p.links,
-                                                           p.n_links, cam, p.iterations, p.lambda_init, p.stop_flag, p.edge_chi2, p.edge_depth_positive, p.stats,
-                                                           p.lidar, p.Tbl, p.lidar_stats, private_stream());
-        }
-    }
-    int ok = 0;
-    for (int i = 0; i < n_problems; ++i) ok += results[i] >= 0;
-    return ok;
 }
 
 int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_lidar_window* win, double* residual, double* JacT,
@@ -3266,70 +562,4 @@ int tc2li_lidar_window_evaluate(const double* poses7, int n_poses, const tc2li_l
     return ws.lidar.n_planes;
 }
 
-
-// ---- the engine's entry points (include/tc2li_hip.h) ----
-int tc2li_ba_engine_create(const tc2li_camera* cam, int max_windows, tc2li_ba_engine** out) {
-    if (!cam || !out || max_windows < 1 || max_windows > 4096) { set_error("tc2li_ba_engine_create: invalid argument (1 .. 4096 windows in flight)"); return TC2LI_ERR_INVALID; }
-    if (!device_ready()) return TC2LI_ERR_NO_DEVICE;
-    std::unique_ptr<tc2li_ba_engine> e(new tc2li_ba_engine());
-    e->cam = *cam; e->capacity = max_windows;
-    if (hipGetDevice(&e->device) != hipSuccess) { (void)hipGetLastError(); e->device = 0; }
-    e->slots = std::vector<EngineSlot>(max_windows); e->W.resize(max_windows);
-    // host threads: what the three lock-step groups of the batch calls have between them -- two thirds for the setups, a third for the results
-    const int per_group = std::max(1, pool_threads(kPoolBaGroup0));
-    e->pool.reset(new WorkerPool(per_group, "tc2li-ba-result"));
-    tc2li_ba_engine* raw = e.get();
-    for (int k = 0; k < 2 * per_group; ++k) e->setup_threads.emplace_back([raw] { raw->setup_loop(); });
-    e->th = std::thread([raw] { raw->run(); });
-    *out = e.release();
-    return TC2LI_OK;
-}
-void tc2li_ba_engine_destroy(tc2li_ba_engine* e) {
-    if (!e) return;
-    { std::lock_guard<std::mutex> lk(e->mu); e->quit = true; }
-    e->cv_work.notify_all();
-    if (e->th.joinable()) e->th.join();
-    { std::lock_guard<std::mutex> lk(e->smu); e->setup_quit = true; }
-    e->scv.notify_all();
-    for (std::thread& t : e->setup_threads) if (t.joinable()) t.join();
-    delete e;
-}
-int64_t tc2li_ba_engine_submit(tc2li_ba_engine* e, const tc2li_ba_problem* problems, int n, int32_t* results) {
-    if (!e || n < 0 || (n > 0 && (!problems || !results))) { set_error("tc2li_ba_engine_submit: invalid argument"); return TC2LI_ERR_INVALID; }
-    std::unique_ptr<EngineTicket> t(new EngineTicket());
-    t->problems = problems; t->results = results; t->n = n; t->remaining = n;
-    t->t_submit = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    int64_t id;
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        if (e->quit) { set_error("tc2li_ba_engine_submit: the engine is shutting down"); return TC2LI_ERR_INVALID; }
-        id = t->id = e->next_id++;
-        if (n > 0) e->queue.push_back(t.get());
-        e->open[id] = std::move(t);
-    }
-    e->cv_work.notify_all();
-    return id;
-}
-int tc2li_ba_engine_poll(tc2li_ba_engine* e, int64_t ticket) {
-    if (!e) { set_error("tc2li_ba_engine_poll: invalid argument"); return TC2LI_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(e->mu);
-    auto it = e->open.find(ticket);
-    if (it == e->open.end()) { set_error("tc2li_ba_engine_poll: no such ticket (collected already?)"); return TC2LI_ERR_INVALID; }
-    return it->second->remaining == 0 ? 1 : 0;
-}
-int tc2li_ba_engine_wait(tc2li_ba_engine* e, int64_t ticket) {
-    if (!e) { set_error("tc2li_ba_engine_wait: invalid argument"); return TC2LI_ERR_INVALID; }
-    std::unique_lock<std::mutex> lk(e->mu);
-    auto it = e->open.find(ticket);
-    if (it == e->open.end()) { set_error("tc2li_ba_engine_wait: no such ticket (collected already?)"); return TC2LI_ERR_INVALID; }
-    EngineTicket* t = it->second.get();
-    e->cv_done.wait(lk, [&] { return t->remaining == 0; });
-    const int ok = t->n_ok;
-    const bool failed = e->failed != 0;
-    const std::string why = e->error;
-    e->open.erase(it);
-    lk.unlock();
-    if (failed && ok == 0 && !why.empty()) set_error("tc2li_ba_engine: %s", why.c_str());
-    return ok;
-}
 }  // extern "C"

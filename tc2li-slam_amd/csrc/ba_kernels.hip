@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void k_ba_schur_units(BaProblemDev pb, int chu
 // k_ba_schur_blocks asks for 80 KB of LDS and 256 registers per lane: alone that is two workgroups per CU and costs nothing, but beside the
 // other stages' kernels such a workgroup starts only on a CU that has half its LDS and half of every SIMD's register file free at the
 // same moment -- the launch took 340-430 us in the loop against 62 us alone (the plane Hessian showed the same and lost a fifth of its
-// in-loop time with its registers cut, balm_kernels.hip).  Here: slices of at most 128 slots (cut by the host, ba_host.cpp), eight per
+// in-loop time with its registers cut, balm_kernels.hip).  Here: slices of at most 128 slots (cut by the host, VisualProblem::setup in ba_internal.hpp), eight per
 // part; threads 0..127 stage a slot each, all 256 are tasks as before; no block is held in registers across the task loop (the other
 // workgroups of the CU cover a workgroup's loads: three fit); the closing sums go through LDS in range order -- the range tasks of a
 // block add themselves one after the other, ((a0 + a1) + a2) + ..., the last one writes the block -- so the operand area (39 KB) is

@@ -9,7 +9,7 @@
 
 namespace tc2li {
 
-constexpr int kBalmCutMaxW = 7;           // keyframes of a window the batched LiDAR kernels take (ba_host.cpp); 8 lanes work on a cell
+constexpr int kBalmCutMaxW = 7;           // keyframes of a window the batched LiDAR kernels take (ba_lockstep.cpp, ba_engine.cpp); 8 lanes work on a cell
 constexpr int kBalmCutMaxPoints = 65535;  // points of a window: the sort's 16-bit counters
 constexpr int kBalmCutMaxPlanes = 2048;   // planes of a window the batched LiDAR kernels take
 

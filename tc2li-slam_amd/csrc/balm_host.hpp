@@ -1,5 +1,5 @@
 // Host side of the LiDAR plane term of LocalLVBundleAdjustment (SF/src/OptimizerWithLidar.cc:226-260): plane extraction
-// from the window's surface clouds and the EdgeLidarSE3 state that the Levenberg-Marquardt loop of ba_host.cpp drives.
+// from the window's surface clouds and the EdgeLidarSE3 state that the Levenberg-Marquardt loops of ba_host.cpp / ba_lockstep.cpp / lvi_host.cpp drive.
 #pragma once
 #include <vector>
 

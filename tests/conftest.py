@@ -3,7 +3,7 @@ import sys
 
 import pytest
 
-# the library's self-check of the inertial term's segment-wise clearing of its Hessian (ba_host.cpp, InertialTerm::cost): on in every test run
+# the library's self-check of the inertial term's segment-wise clearing of its Hessian (ba_internal.hpp, InertialTerm::cost): on in every test run
 os.environ.setdefault("TC2LI_TEST_HI_CLEAR", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
