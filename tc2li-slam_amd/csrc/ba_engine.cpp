@@ -7,7 +7,7 @@ using namespace tc2li::ba_detail;
 namespace {
 
 // ---- The bundle-adjustment ENGINE: continuous admission (round 6) -------------------------------------------------------------------------
-// The batch entry points above are calls: a call's windows are set up together, optimised together and handed back together -- a group
+// The batch entry points (ba_lockstep.cpp) are calls: a call's windows are set up together, optimised together and handed back together -- a group
 // returns when its SLOWEST window is done (a window whose steps keep being rejected needs up to 26 rounds where the others need 10), and
 // the setup of the next call starts only then.  With the Levenberg-Marquardt decisions on the device (BaLmState) a round no longer cares
 // which call a window came with or how far it has got: every batched kernel runs for the windows whose status asks for it.  The engine keeps
@@ -302,26 +302,8 @@ void tc2li_ba_engine::run() {
                 if (w.rc < 0) { finish_window(s, w.rc); continue; }
                 // the slot: everything a phase leaves for the next one stays in device memory (ba_batch_lockstep's device-LM form)
                 BaBatchSlot& b = h_slots[s];
-                b = BaBatchSlot{};
-                b.pb = w.vp.pb;
-                b.lambda_init = w.p->lambda_init; b.iterations = w.p->iterations;
-                b.n_slices = w.vp.n_slices; b.k_per_slice = w.vp.k_per_slice; b.has_lidar = w.lidar != nullptr;
-                const size_t nn = (size_t)w.vp.np * w.vp.np;
-                double* sc = w.ws->d_scal.p;
-                b.chi_out = sc; b.maxdiag_out = sc + 1; b.scale_out = sc + 3; b.chi_trial_out = sc + 4;
-                b.S_out = w.ws->d_S.p; b.bs_out = w.ws->d_bs.p; b.xp = b.x_dev = w.ws->d_xp.p; b.depth_out = w.ws->d_depth.p;
-                b.lm = C.d_lm.p + s; b.lm_host = C.h_lm.p + s; b.stop_host = C.h_stop.p + s; b.ok_host = &b.lm->solve_ok;
-                if (w.lidar) {
-                    b.balm = w.lidar->dev;
-                    b.Hl = w.ws->d_Hl.p; b.bl_lidar = w.ws->d_Hl.p + nn; b.balm.out = w.ws->d_balm_out.p; b.lidar_JH = w.ws->d_lidar_JH.p;
-                    b.lidar_information = w.lidar->information;
-                }
+                fill_device_lm_slot(b, w, C, s);
                 BaLmState& m = C.h_lm_init.p[s];
-                m = BaLmState{};
-                m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
-                m.status = w.wants_iteration() ? kLmIterate : kLmDone;
-                C.h_lm.p[s] = m;
-                C.h_stop.p[s] = 0;
                 copies.push_back(CopyTask{C.d_table.p + (size_t)s * sizeof(BaBatchSlot), &b, sizeof(BaBatchSlot)});
                 copies.push_back(CopyTask{C.d_lm.p + s, &m, sizeof(BaLmState)});
                 for (const CopyTask& t : sl.deferred_vis) copies.push_back(t);
@@ -467,17 +449,7 @@ void tc2li_ba_engine::run() {
             bool all_block = true;
             BaBatchExtent XL = batch_extent(W, live, &all_block);
             XL.fuse_trial = all_block ? 1 : 0;
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, want_maxdiag, st); });
-            pieces_for(lidar_first, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, false, st); });
-            pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_hessian(ph, cnt, XL, st); });
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, XL, st);
-                ba_batch_launch_solve(ph, cnt, XL, st);
-                ba_batch_launch_trial(ph, cnt, XL, st);
-            });
-            if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
+            queue_lm_round(d_table, W, live, live_lidar, lidar_first, XL, want_maxdiag, st);
             queued_any = true;
         }
         lap(4);

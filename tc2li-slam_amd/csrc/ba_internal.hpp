@@ -703,6 +703,52 @@ BaBatchExtent batch_extent(const std::vector<Win>& W, const std::vector<int>& li
 }
 
 
+// ---- what the device-side Levenberg-Marquardt loop's two drivers share (ba_batch_lockstep's device-LM form, tc2li_ba_engine) ----
+// The table entry and the initial optimiser state of window w in slot i of context C: everything a phase leaves for the next one stays in
+// device memory, the decide kernel mirrors the window's state into C.h_lm[i].  The entry goes up with the caller's next copy launch
+// (C.d_table + i), the state from C.h_lm_init[i] to C.d_lm[i].
+inline void fill_device_lm_slot(BaBatchSlot& s, const LockstepWindow& w, LockstepContext& C, int i) {
+    s = BaBatchSlot{};
+    s.pb = w.vp.pb;
+    s.lambda_init = w.p->lambda_init; s.iterations = w.p->iterations;
+    s.n_slices = w.vp.n_slices; s.k_per_slice = w.vp.k_per_slice; s.has_lidar = w.lidar != nullptr;
+    const size_t nn = (size_t)w.vp.np * w.vp.np;
+    double* sc = w.ws->d_scal.p;
+    s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
+    s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.xp = s.x_dev = w.ws->d_xp.p; s.depth_out = w.ws->d_depth.p;
+    s.lm = C.d_lm.p + i; s.lm_host = C.h_lm.p + i; s.stop_host = C.h_stop.p + i; s.ok_host = &s.lm->solve_ok;
+    if (w.lidar) {
+        s.balm = w.lidar->dev;
+        s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn; s.balm.out = w.ws->d_balm_out.p; s.lidar_JH = w.ws->d_lidar_JH.p;
+        s.lidar_information = w.lidar->information;
+    }
+    BaLmState& m = C.h_lm_init.p[i];
+    m = BaLmState{};
+    m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
+    m.status = w.wants_iteration() ? kLmIterate : kLmDone;
+    C.h_lm.p[i] = m;
+    C.h_stop.p[i] = 0;
+}
+// One round of the windows in `live` queued on st as ONE sequence without a host decision in it: linearise (windows whose status is
+// kLmIterate) + the plane term + begin, then Schur + solve + trial estimate + errors + decide (windows in kLmTrial).  live_lidar: those of
+// `live` with a LiDAR edge; lidar_first: those of them whose plane residual at the current estimate is not in place yet (their first
+// linearisation: later the accepted estimate is the last trial, whose residual and decompositions are).
+inline void queue_lm_round(const BaBatchSlot* d_table, const std::vector<LockstepWindow>& W, const std::vector<int>& live, const std::vector<int>& live_lidar,
+                           const std::vector<int>& lidar_first, const BaBatchExtent& XL, bool want_maxdiag, hipStream_t st) {
+    auto pieces_for = [&](const std::vector<int>& list, int expect, auto&& fn) { for_phase_pieces(d_table, (const double*)nullptr, W, list, fn, expect); };
+    pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, want_maxdiag, st); });
+    pieces_for(lidar_first, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, false, st); });
+    pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) { balm_batch_launch_hessian(ph, cnt, XL, st); });
+    pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
+    pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
+        ba_batch_launch_schur(ph, cnt, XL, st);
+        ba_batch_launch_solve(ph, cnt, XL, st);
+        ba_batch_launch_trial(ph, cnt, XL, st);
+    });
+    if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial kernel)
+    pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
+}
+
 // the lock-step drivers (ba_lockstep.cpp, lvi_host.cpp): false = the batch goes through the one-window path
 bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_camera* cam, WorkerPool& pool, int32_t* results, int group = 0);
 

@@ -166,28 +166,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
             if (w.lidar) { s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn; }
         }
         if (w.lidar) s.balm = w.lidar->dev; else s.balm = BalmDev{};
-        if (device_lm) {
-            // everything a phase leaves for the next one stays in device memory; the decide kernel mirrors the window's state to the host
-            const size_t nn = (size_t)w.vp.np * w.vp.np;
-            double* sc = w.ws->d_scal.p;
-            s.chi_out = sc; s.maxdiag_out = sc + 1; s.scale_out = sc + 3; s.chi_trial_out = sc + 4;
-            s.S_out = w.ws->d_S.p; s.bs_out = w.ws->d_bs.p; s.bp_host = nullptr; s.hpp_out = nullptr;
-            s.xp = s.x_dev = w.ws->d_xp.p; s.x_host = nullptr;
-            s.lm = C.d_lm.p + i; s.lm_host = C.h_lm.p + i; s.stop_host = C.h_stop.p + i;
-            s.ok_host = &s.lm->solve_ok;
-            if (w.lidar) {
-                s.Hl = w.ws->d_Hl.p; s.bl_lidar = w.ws->d_Hl.p + nn;
-                s.balm.out = w.ws->d_balm_out.p;
-                s.lidar_JH = w.ws->d_lidar_JH.p;
-                s.lidar_information = w.lidar->information;
-            }
-            BaLmState& m = C.h_lm_init.p[i];
-            m = BaLmState{};
-            m.lambda = -1; m.ni = 2; m.r1 = 1000; m.r2 = 1000; m.is_calc_hess = 1; m.ok = 1; m.solve_ok = 1;
-            m.status = w.wants_iteration() ? kLmIterate : kLmDone;
-            C.h_lm.p[i] = m;
-            C.h_stop.p[i] = 0;
-        }
+        if (device_lm) fill_device_lm_slot(s, w, C, i);   // (replaces the host-loop entries above: everything stays in device memory)
     };
     // the per-window host steps between two phases are tens of microseconds each: few windows run on the calling thread
     // (a pool dispatch costs more than it saves, and far more on a busy host)
@@ -225,7 +204,6 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         launch_copy_tasks(C.h_table_task.p, 1, 4096, st);
     };
     auto pieces = [&](const std::vector<int>& list, const double* xp_area, auto&& fn) { for_phase_pieces(d_table, xp_area, W, list, fn); };
-    auto pieces_for = [&](const std::vector<int>& list, int expect, auto&& fn) { for_phase_pieces(d_table, (const double*)nullptr, W, list, fn, expect); };
     // (the group's thread spins on its stream between the phases: sleeping on a blocking event instead was measured in round 4 -- the same host
     // CPU time, 13.7 of the 16 CPUs a one-GPU box's cgroup grants, and a step 0.3 ms longer)
     auto sync = [&] { if (hipGetLastError() != hipSuccess || (device_lm ? stream_wait_blocking(st) : hipStreamSynchronize(st)) != hipSuccess) failed = true; };
@@ -259,19 +237,7 @@ bool ba_batch_lockstep(const tc2li_ba_problem* problems, int n, const tc2li_came
         auto queue_round = [&] {
             const double tq = now();
             const bool first = queued == 0;
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_linearize(ph, cnt, XL, first && first_maxdiag, st); });
-            pieces_for(live_lidar, kLmIterate, [&](const BaPhase& ph, int cnt) {
-                if (first) balm_batch_launch_residual(ph, cnt, false, st);  // later the accepted estimate is the last trial: its residual and decompositions are in place
-                balm_batch_launch_hessian(ph, cnt, XL, st);
-            });
-            pieces_for(live, kLmIterate, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_begin(ph, cnt, st); });
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) {
-                ba_batch_launch_schur(ph, cnt, XL, st);
-                ba_batch_launch_solve(ph, cnt, XL, st);
-                ba_batch_launch_trial(ph, cnt, XL, st);
-            });
-            if (XL.any_trial_unfused) pieces_for(live_lidar, kLmTrial, [&](const BaPhase& ph, int cnt) { balm_batch_launch_residual(ph, cnt, true, st); });  // (windows with pb.trial_fused: inside the trial launch)
-            pieces_for(live, kLmTrial, [&](const BaPhase& ph, int cnt) { ba_batch_launch_lm_decide(ph, cnt, st); });
+            queue_lm_round(d_table, W, live, live_lidar, first ? live_lidar : std::vector<int>(), XL, first && first_maxdiag, st);
             if (hipGetLastError() != hipSuccess || hipEventRecord(C.round_done[queued & 1], st) != hipSuccess) failed = true;
             ++queued;
             tm[6] += now() - tq;  // the host's time to queue the rounds
